@@ -1,0 +1,265 @@
+"""Generate golden fixtures by running the REFERENCE (imported in place from /root/reference).
+
+Run in the build container only:  ``python tests/golden/make_golden.py``.
+Outputs small ``.npz`` files next to this script; they are data (inputs + expected outputs),
+committed, and are what pins ``oracle/`` (tests/test_oracle_golden.py) and the HIP path.
+The reference itself never travels: nothing here is imported by the package, the GPU tests,
+``smoke()`` or ``bench.py``.
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from _ref_import import load_reference  # noqa: E402
+from deepof_amd.graph import adjacency_from_graph, bodypart_graph  # noqa: E402
+
+R = load_reference()
+torch.set_num_threads(1)
+
+
+def sd_np(model, prefix="sd::"):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def synth_batch(B, T, N, E, seed):
+    """Smooth, standardised synthetic trajectories; no all-zero frames."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, T + 8, N, 3)).astype(np.float32)
+    a = rng.standard_normal((B, T + 8, E, 1)).astype(np.float32)
+    k = np.ones(9, dtype=np.float32) / 3.0
+    x = np.stack([np.convolve(x[b, :, n, f], k, mode="valid") for b in range(B) for n in range(N) for f in range(3)])
+    a = np.stack([np.convolve(a[b, :, e, 0], k, mode="valid") for b in range(B) for e in range(E)])
+    x = x.reshape(B, N, 3, T).transpose(0, 3, 1, 2).copy()
+    a = a.reshape(B, E, 1, T).transpose(0, 3, 1, 2).copy()
+    return x.astype(np.float32), a.astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------
+def gen_scramble():
+    out = {}
+    for (T, G, F) in [(25, 14, 3), (25, 14, 1), (50, 28, 3), (50, 32, 1), (24, 11, 3), (7, 3, 2)]:
+        src = torch.arange(T * G * F, dtype=torch.float32).reshape(1, T, G, F)
+        y = R.M.RecurrentEncoderPT.tf_style_group_reshape(src, G, F)
+        out[f"idx_{T}_{G}_{F}"] = y[0].numpy().astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "scramble.npz"), **out)
+
+
+def gen_graph_ops():
+    out = {}
+    for tag, ids in [("single", [""]), ("pair", ["B", "W"])]:
+        nodes, edges = bodypart_graph(ids)
+        adj = adjacency_from_graph(nodes, edges)
+        lap, elap, inc = R.C.CensNetConvPT.preprocess(torch.tensor(adj))
+        out[f"{tag}_adj"] = adj
+        out[f"{tag}_lap"] = lap.float().numpy()
+        out[f"{tag}_elap"] = elap.float().numpy()
+        out[f"{tag}_inc"] = inc.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "graph_ops.npz"), **out)
+
+
+def gen_recurrent_block():
+    """RecurrentBlockPT forward + parameter grads, incl. sequences with masked (all-zero conv) rows."""
+    out = {}
+    for tag, F, L in [("node", 3, 8), ("edge", 1, 8), ("node_l6", 3, 6)]:
+        torch.manual_seed(11)
+        blk = R.M.RecurrentBlockPT(input_features=F, latent_dim=L)
+        B, G, T = 3, 5, 25
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal((B, G, T, F)).astype(np.float32)
+        # Q2: zero runs long enough (>= 5+k) that some conv rows vanish -> length < T
+        x[0, 1, 8:16] = 0.0
+        x[1, 3, 0:9] = 0.0
+        x[2, 0, :] = 0.0  # whole sequence masked -> dropped from the packed GRU
+        x[2, 4, 17:] = 0.0
+        xt = torch.from_numpy(x)
+        y = blk(xt)
+        up = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+        (y * up).sum().backward()
+        out.update(sd_np(blk, f"{tag}::sd::"))
+        out[f"{tag}::x"] = x
+        out[f"{tag}::y"] = y.detach().numpy()
+        out[f"{tag}::up"] = up.numpy()
+        for n, p in blk.named_parameters():
+            if p.grad is not None:
+                out[f"{tag}::grad::{n}"] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "recurrent_block.npz"), **out)
+
+
+def _cfgs(K, L, **vade_kw):
+    common = R.U.CommonFitCfg(n_components=K, latent_dim=L, kmeans_loss=0.0)
+    vade = R.U.VaDECfg(**vade_kw)
+    teacher = R.U.TurtleTeacherCfg()
+    return common, vade, teacher
+
+
+def gen_vade(tag, ids, T, L, K, B, seed):
+    nodes, edges = bodypart_graph(ids)
+    adj = adjacency_from_graph(nodes, edges)
+    N, E = len(nodes), len(edges)
+    torch.manual_seed(seed)
+    model = R.M.VaDEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type="recurrent", kmeans_loss=1.0)
+    with torch.no_grad():  # make the GMM heads / prior-free bits non-trivial
+        model.latent_space.gmm_means.mul_(3.0)
+    x, a = synth_batch(B, T, N, E, seed + 1)
+    xt, at = torch.from_numpy(x), torch.from_numpy(a)
+    out = dict(sd_np(model))
+    out.update(x=x, a=a, adj=adj)
+
+    # ---- eval forward (bit-stable): z_mean, q, recon loc
+    model.eval()
+    with torch.no_grad():
+        dist, z, q, km = model(xt, at)
+        enc = model.encoder(xt, at)
+    out.update(eval_z=z.numpy(), eval_q=q.numpy(), eval_loc=dist.base_dist.base_dist.loc.numpy(),
+               eval_kmeans=np.float64(km), eval_enc=enc.numpy())
+
+    # ---- train forward with known noise + every loss term + all grads, both phases
+    eps = torch.randn(B, L, generator=torch.Generator().manual_seed(seed + 2))
+    eps_mc = torch.randn(32, B, L, generator=torch.Generator().manual_seed(seed + 3))
+    out.update(eps=eps.numpy(), eps_mc=eps_mc.numpy())
+    tau = torch.softmax(torch.randn(B, K, generator=torch.Generator().manual_seed(seed + 4)) * 2.0, dim=-1)
+    out["tau"] = tau.numpy()
+
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def patched_randn(*size, **kw):
+        if len(size) == 3 and tuple(size) == (32, B, L):
+            return eps_mc.clone()
+        return real_randn(*size, **kw)
+
+    def patched_randn_like(t, **kw):
+        if tuple(t.shape) == (B, L):
+            return eps.clone()
+        return real_randn_like(t, **kw)
+
+    for phase, klw, with_teacher, extra in [
+        ("pre", 0.13, False, {}),
+        ("main", 0.7, False, {}),
+        ("mainT", 0.7, True, {}),
+        ("mainX", 0.45, True, dict(repel_weight=0.3, reg_scatter_weight=0.2, temporal_cohesion_weight=0.1,
+                                   reg_cat_clusters=0.5, tf_cluster_weight=0.7)),
+    ]:
+        common, vade, teacher = _cfgs(K, L, **extra)
+        if phase == "mainX":
+            common.kmeans_loss = 0.5
+            teacher.distill_conf_weight = True
+        crit = R.L.VadeLoss(common_cfg=common, vade_cfg=vade, teacher_cfg=teacher)
+        crit.set_mode("pretrain" if phase == "pre" else "main")
+        crit.kl_scheduler = SimpleNamespace(get_weight=lambda k=klw: k, max_weight=1.0, current_iteration=0)
+        if with_teacher:
+            crit.set_teacher(tau_star=tau, lambda_distill=1.7)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        torch.randn, torch.randn_like = patched_randn, patched_randn_like
+        try:
+            outputs = model(xt, at, return_gmm_params=True)
+            ld = crit(outputs, xt, batch_indices=torch.arange(B) if with_teacher else None)
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_randn_like
+        ld["total_loss"].backward()
+        for k, v in ld.items():
+            out[f"{phase}::loss::{k}"] = np.float64(float(v))
+        out[f"{phase}::z"] = outputs[1].detach().numpy()
+        out[f"{phase}::q"] = outputs[2].detach().numpy()
+        out[f"{phase}::loc"] = outputs[0].base_dist.base_dist.loc.detach().numpy()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                out[f"{phase}::grad::{n}"] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, f"vade_{tag}.npz"), **out)
+
+
+def gen_train_trace():
+    """3 pretrain + 3 main reference optimisation steps (step_vade + clip + Adam), noise injected."""
+    nodes, edges = bodypart_graph([""])
+    adj = adjacency_from_graph(nodes, edges)
+    N, E, T, L, K, B = len(nodes), len(edges), 25, 8, 10, 16
+    torch.manual_seed(3)
+    model = R.M.VaDEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type="recurrent", kmeans_loss=1.0)
+    out = dict(sd_np(model, "sd0::"))
+    common, vade, teacher = _cfgs(K, L)
+    crit = R.L.VadeLoss(common_cfg=common, vade_cfg=vade, teacher_cfg=teacher)
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+    step_id = 0
+    for phase, nsteps, lr_b, lr_g, klws in [("pre", 3, 1e-3, 0.0, [0.0, 0.05, 0.2]), ("main", 3, 5e-4, 2e-4, [0.1, 0.6, 1.0])]:
+        crit.set_mode("pretrain" if phase == "pre" else "main")
+        model.set_pretrain_mode(phase == "pre")
+        opt = R.L.build_optimizer_vade(model=model, base_lr=lr_b, gmm_lr=lr_g)
+        for i in range(nsteps):
+            x, a = synth_batch(B, T, N, E, 100 + step_id)
+            eps = torch.randn(B, L, generator=torch.Generator().manual_seed(200 + step_id))
+            eps_mc = torch.randn(32, B, L, generator=torch.Generator().manual_seed(300 + step_id))
+            klw = klws[i]
+            crit.kl_scheduler = SimpleNamespace(get_weight=lambda k=klw: k, max_weight=1.0, current_iteration=0)
+            torch.randn = lambda *s, **kw: eps_mc.clone() if tuple(s) == (32, B, L) else real_randn(*s, **kw)
+            torch.randn_like = lambda t, **kw: eps.clone() if tuple(t.shape) == (B, L) else real_randn_like(t, **kw)
+            try:
+                model.train()
+                res = R.T.step_vade(model, (torch.from_numpy(x), torch.from_numpy(a), torch.arange(B)),
+                                    SimpleNamespace(criterion=crit, train=True))
+            finally:
+                torch.randn, torch.randn_like = real_randn, real_randn_like
+            opt.zero_grad(set_to_none=True)
+            res.loss.backward()
+            torch.nn.utils.clip_grad_value_(model.parameters(), 0.75)
+            opt.step()
+            out[f"step{step_id}::x"], out[f"step{step_id}::a"] = x, a
+            out[f"step{step_id}::eps"], out[f"step{step_id}::eps_mc"] = eps.numpy(), eps_mc.numpy()
+            out[f"step{step_id}::klw"] = np.float64(klw)
+            out[f"step{step_id}::lr"] = np.array([lr_b, lr_g])
+            out[f"step{step_id}::phase"] = np.array(phase)
+            for k, v in res.logs.items():
+                out[f"step{step_id}::log::{k}"] = np.float64(v)
+            out[f"step{step_id}::pnorm"] = np.float64(
+                float(torch.sqrt(sum((p.detach() ** 2).sum() for p in model.parameters()))))
+            step_id += 1
+    out.update(sd_np(model, "sd_final::"))
+    np.savez_compressed(os.path.join(HERE, "vade_train_trace.npz"), **out)
+
+
+def gen_schedules_kmeans():
+    out = {}
+    for mode in ["linear", "sigmoid", "tf_sigmoid"]:
+        m = R.L.Dynamic_weight_manager(7, mode=mode, warmup_epochs=3, max_weight=0.8, at_max_epochs=2,
+                                       cooldown_epochs=4, end_weight=0.25)
+        ws = []
+        for _ in range(80):
+            ws.append(m.get_weight())
+            m.step()
+        out[f"sched_{mode}"] = np.array(ws)
+    m = R.L.Dynamic_weight_manager(5, mode="tf_sigmoid", warmup_epochs=0, max_weight=4.0, at_max_epochs=2,
+                                   cooldown_epochs=2, end_weight=0.2)
+    ws = []
+    for _ in range(30):
+        ws.append(m.get_weight())
+        m.step()
+    out["sched_lambda"] = np.array(ws)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(64, 8, generator=g, requires_grad=True)
+    with torch.no_grad():
+        z[:, 3] = z[:, 2] * 0.5  # rank-deficient-ish
+    km = R.L.compute_kmeans_loss_pt(z, 1.3)
+    km.backward()
+    out["km_z"] = z.detach().numpy()
+    out["km_val"] = np.float64(float(km))
+    out["km_grad"] = z.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "schedules_kmeans.npz"), **out)
+
+
+if __name__ == "__main__":
+    gen_scramble()
+    gen_graph_ops()
+    gen_recurrent_block()
+    gen_vade("rec14", [""], 25, 8, 10, 16, 21)
+    gen_vade("rec28", ["B", "W"], 12, 6, 5, 6, 31)
+    gen_train_trace()
+    gen_schedules_kmeans()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
