@@ -1,0 +1,74 @@
+"""ctypes signatures of the libdeepof_hip C ABI (include/deepof_hip.h).
+
+``bind(cdll)`` attaches argtypes/restypes; ``check(lib, rc)`` raises with the library's error text.
+The product loads ``deepof_amd/csrc/libdeepof_hip.so`` through ``deepof_amd._lib`` (and fails
+loudly if it is missing); this module itself has no knowledge of where a library comes from.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+ABI_VERSION = 1
+
+# hyper[] indices (enum in deepof_hip.h)
+H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
+H_NONEMPTY_W, H_NONEMPTY_FLOOR, H_NONEMPTY_P, H_L1_ACT, H_DISTILL_T, H_CONF_W = 6, 7, 8, 9, 10, 11
+H_CONF_THR, H_HAS_TEACHER, H_LOGVAR_LO, H_LOGVAR_HI = 12, 13, 14, 15
+H_CLIP, H_WD, H_LR0, H_BC0, H_ACTIVE0, H_COUNT = 16, 17, 18, 22, 30, 34
+SEG_ENCODER, SEG_DECODER, SEG_GMM, SEG_HEADS, SEG_COUNT = 0, 1, 2, 3, 4
+LOG_KEYS = ("total_loss", "reconstruct_loss", "kl_div", "cat_clust_loss", "kmeans_loss", "activity_l1",
+            "prior_loss", "distill_loss", "tf_clust_loss", "nonempty_loss", "temporal_loss", "scatter_loss",
+            "repel_loss", "kl_weight")
+LOG_COUNT = 16
+
+
+class VadeDims(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("window", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
+                ("latent", C.c_int32), ("n_clusters", C.c_int32), ("mc_samples", C.c_int32)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+
+SIGNATURES = {
+    "dof_last_error_string": (C.c_char_p, []),
+    "dof_abi_version": (C.c_int, []),
+    "dof_window_gather": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "dof_window_gather_range": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "dof_vade_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_vade_plan_destroy": (None, [_P]),
+    "dof_vade_param_count": (_I32, [_P]),
+    "dof_vade_param_name": (C.c_char_p, [_P, _I32]),
+    "dof_vade_param_offset": (_I64, [_P, _I32]),
+    "dof_vade_param_numel": (_I64, [_P, _I32]),
+    "dof_vade_param_total": (_I64, [_P]),
+    "dof_vade_workspace_bytes": (_I64, [_P]),
+    "dof_vade_bind": (C.c_int, [_P, _P, _P]),
+    "dof_vade_forward": (C.c_int, [_P] * 13),
+    "dof_vade_loss_grads": (C.c_int, [_P] * 10 + [_I32, _P, _P, _P]),
+    "dof_optimizer_step": (C.c_int, [_P] * 7),
+}
+
+
+def bind(cdll):
+    missing = [n for n in SIGNATURES if not hasattr(cdll, n)]
+    if missing:
+        raise RuntimeError(f"libdeepof_hip is missing exported symbols: {missing}")
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    if cdll.dof_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libdeepof_hip ABI {cdll.dof_abi_version()} != expected {ABI_VERSION}")
+    return cdll
+
+
+class DofError(RuntimeError):
+    pass
+
+
+def check(lib, rc, what=""):
+    if rc != 0:
+        msg = lib.dof_last_error_string()
+        raise DofError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

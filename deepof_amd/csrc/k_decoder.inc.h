@@ -1,0 +1,172 @@
+// Recurrent decoder tail + reconstruction likelihood.
+//
+// Reference semantics restated here:
+//   * validity mask / lengths from all-zero INPUT frames     /root/reference/deepof/clustering/models_new.py:330-332
+//   * Conv1d(4L->2L, k=5, same, no bias) + ReLU + LayerNorm   models_new.py:365-369
+//   * ProbabilisticDecoderPT: loc = Linear(2L->3N); Independent(Normal(loc,1)) scaled by the
+//     mask: log_prob = -0.5||x-loc||^2 - 3N/2 log(2pi) on valid frames, NaN on masked frames
+//     (scale 0)                                               models_new.py:686-710
+//   * reconstruction loss = -mean_{b,t} log_prob              losses.py:586
+// The bidirectional GRUs / LayerNorms in front of this tail are the shared kernels of k_rnn.hip.
+#include "dof_rt.h"
+#include "launchers.h"
+
+namespace {
+
+#define SOA(t, c, C, Sp, s) (((int64_t)(t) * (C) + (c)) * (Sp) + (s))
+
+__global__ void __launch_bounds__(256) k_dec_valid(const float* __restrict__ x, int T, int C3, int64_t B, int64_t Bp,
+                                                   float* __restrict__ valid, int* __restrict__ len) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0;
+  for (int t = 0; t < T; ++t) {
+    const float* __restrict__ row = x + (b * T + t) * C3;
+    bool any = false;
+    for (int j = 0; j < C3; ++j) any |= (row[j] != 0.0f);
+    valid[(int64_t)t * Bp + b] = any ? 1.0f : 0.0f;
+    n += any ? 1 : 0;
+  }
+  len[b] = n;
+}
+
+struct DecTailArgs {
+  const float* n2;     // [T][4L][Bp]
+  const float *wc, *g3, *b3, *wp, *bp;  // conv (2L,4L,5), norm3, loc_projection (3N,2L),(3N)
+  const float* x;      // (B,T,3N)
+  const float* valid;  // [T][Bp]
+  float* cv;           // [T][2L][Bp] relu(conv)
+  float* n3;           // [T][2L][Bp]
+  float* loc_out;      // (B,T,3N) or null
+  float* recon_partial;  // [nblk]
+  float* dloc;         // [T][3N][Bp]   (train)
+  float* dcv;          // [T][2L][Bp]   (train) grad at conv pre-activation
+  float* ln3_partial;  // [nblk][4L]    (train)
+  int T, C3, train;
+  int64_t B, Bp;
+};
+
+template <int L>
+__global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
+  constexpr int CI = 4 * L, CO = 2 * L;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < (int64_t)A.T * A.B;
+  float vals[2 * CO];
+#pragma unroll
+  for (int c = 0; c < 2 * CO; ++c) vals[c] = 0.0f;
+  float nll[1] = {0.0f};
+  if (live) {
+    const int t = (int)(i / A.B);
+    const int64_t b = i - (int64_t)t * A.B;
+    float cv[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) cv[o] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int ts = t + k - 2;
+      if (ts < 0 || ts >= A.T) continue;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const float v = A.n2[SOA(ts, c, CI, A.Bp, b)];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) cv[o] = fmaf(A.wc[(o * CI + c) * 5 + k], v, cv[o]);
+      }
+    }
+    float mean = 0.0f;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      cv[o] = cv[o] > 0.0f ? cv[o] : 0.0f;
+      A.cv[SOA(t, o, CO, A.Bp, b)] = cv[o];
+      mean += cv[o];
+    }
+    mean *= (1.0f / CO);
+    float var = 0.0f;
+    float xh[CO], n3[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      xh[o] = cv[o] - mean;
+      var = fmaf(xh[o], xh[o], var);
+    }
+    const float rstd = rsqrtf(var * (1.0f / CO) + 1e-3f);
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      xh[o] *= rstd;
+      n3[o] = fmaf(xh[o], A.g3[o], A.b3[o]);
+      A.n3[SOA(t, o, CO, A.Bp, b)] = n3[o];
+    }
+    const bool ok = A.valid[(int64_t)t * A.Bp + b] != 0.0f;
+    const float inv_bt = 1.0f / ((float)A.B * (float)A.T);
+    const float* __restrict__ xr = A.x + (b * A.T + t) * A.C3;
+    float dn3[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) dn3[o] = 0.0f;
+    float sq = 0.0f;
+    for (int j = 0; j < A.C3; ++j) {
+      float loc = A.bp[j];
+#pragma unroll
+      for (int o = 0; o < CO; ++o) loc = fmaf(A.wp[j * CO + o], n3[o], loc);
+      if (loc != loc) loc = 0.0f;  // nan_to_num(nan=0, +-inf -> +-1e6)
+      loc = fminf(fmaxf(loc, -1e6f), 1e6f);
+      if (A.loc_out) A.loc_out[(b * A.T + t) * A.C3 + j] = loc;
+      const float df = xr[j] - loc;
+      sq = fmaf(df, df, sq);
+      if (A.train) {
+        const float dl = ok ? -df * inv_bt : NAN;
+        A.dloc[SOA(t, j, A.C3, A.Bp, b)] = dl;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) dn3[o] = fmaf(A.wp[j * CO + o], dl, dn3[o]);
+      }
+    }
+    const float LOG_2PI = 1.8378770664093453f;
+    nll[0] = ok ? 0.5f * sq + 0.5f * (float)A.C3 * LOG_2PI : NAN;
+    if (A.train) {
+      float mg = 0.0f, mgx = 0.0f;
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        const float g = dn3[o] * A.g3[o];
+        mg += g;
+        mgx = fmaf(g, xh[o], mgx);
+        vals[o] = dn3[o] * xh[o];
+        vals[CO + o] = dn3[o];
+      }
+      mg *= (1.0f / CO);
+      mgx *= (1.0f / CO);
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        const float d = rstd * (dn3[o] * A.g3[o] - mg - xh[o] * mgx);
+        A.dcv[SOA(t, o, CO, A.Bp, b)] = cv[o] > 0.0f ? d : 0.0f;
+      }
+    }
+  }
+  dof_block_colsum<1>(nll, A.recon_partial + blockIdx.x);
+  if (A.train) dof_block_colsum<2 * CO>(vals, A.ln3_partial + (int64_t)blockIdx.x * 2 * CO);
+}
+
+// d n2[t][c] = sum_k sum_o wc[o][c][k] * dcv[t-k+2][o]
+template <int L>
+__global__ void __launch_bounds__(256) k_dec_conv_bwd(const float* __restrict__ dcv, const float* __restrict__ wc,
+                                                      float* __restrict__ dn2, int T, int64_t B, int64_t Bp) {
+  constexpr int CI = 4 * L, CO = 2 * L;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)T * B) return;
+  const int t = (int)(i / B);
+  const int64_t b = i - (int64_t)t * B;
+  float acc[CI];
+#pragma unroll
+  for (int c = 0; c < CI; ++c) acc[c] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int ts = t - k + 2;
+    if (ts < 0 || ts >= T) continue;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const float v = dcv[SOA(ts, o, CO, Bp, b)];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) acc[c] = fmaf(wc[(o * CI + c) * 5 + k], v, acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CI; ++c) dn2[SOA(t, c, CI, Bp, b)] = acc[c];
+}
+
+}  // namespace

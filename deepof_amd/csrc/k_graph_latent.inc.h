@@ -1,0 +1,805 @@
+// CensNet graph layer, GMM latent space, and the batch-level VaDE loss terms
+// (SURVEY.md section 8a rows R4, R5, R6, R8, R9).
+//
+// Reference semantics restated here:
+//   * CensNetConvPT._propagate_nodes/_propagate_edges  /root/reference/deepof/clustering/censNetConv_pt.py:92-136
+//     out_v = relu(((T diag(Xe.pe) T^T) * Lap_v) Xv Kv + bv)  -- evaluated through the sparsity of
+//     the Laplacians: a host-built list of (row r, partner m, other-stream element o, coef=Lap[r][m])
+//     triplets, exact for any adjacency;
+//   * RecurrentEncoderPT tail (flatten+concat -> Linear)    models_new.py:163-181
+//   * GaussianMixtureLatentPT                               models_new.py:1724-1791
+//   * compute_kmeans_loss_pt (fp64 spectrum of the Gram)    losses.py:257-287
+//   * VadeLoss terms                                        losses.py:567-797
+#include "dof_rt.h"
+#include "launchers.h"
+#include "deepof_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// CensNet
+// ---------------------------------------------------------------------------------------------
+struct CensStream {
+  const float* X;      // [D][Sp]  block outputs of this stream, s = b*G + g
+  const float* dots;   // [Sp_other] dot products of the OTHER stream (weights the pairs)
+  DofTriplets tri;     // grouped by output row r
+  const float* kern;   // (D, L)
+  const float* bias;   // (L)
+  float* Y;            // [D][Sp]  propagated features (saved for d kern)
+  float* Z;            // [L][Sp]  relu output (saved for the mask)
+  int G, G_other;
+  int64_t S, Sp;
+  int flat_row0;       // first row of this stream inside flat [(N+E)L][Bp]
+};
+
+template <int D>
+__global__ void __launch_bounds__(256) k_cens_dots(const float* __restrict__ X, const float* __restrict__ p,
+                                                   float* __restrict__ dots, int64_t S, int64_t Sp) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  float acc = 0.0f;
+#pragma unroll
+  for (int c = 0; c < D; ++c) acc = fmaf(X[(int64_t)c * Sp + s], p[c], acc);
+  dots[s] = acc;
+}
+
+template <int L>
+__global__ void __launch_bounds__(256) k_cens_fwd(CensStream A, CensStream Bs, float* __restrict__ flat, int64_t Bp) {
+  constexpr int D = 2 * L;
+  const CensStream& P = blockIdx.y ? Bs : A;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= P.S) return;
+  const int64_t b = s / P.G;
+  const int r = (int)(s - b * P.G);
+  float y[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) y[c] = 0.0f;
+  for (int e = P.tri.ptr[r]; e < P.tri.ptr[r + 1]; ++e) {
+    const float w = P.tri.coef[e] * P.dots[b * P.G_other + P.tri.o[e]];
+    const int64_t sm = b * P.G + P.tri.m[e];
+#pragma unroll
+    for (int c = 0; c < D; ++c) y[c] = fmaf(w, P.X[(int64_t)c * P.Sp + sm], y[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < D; ++c) P.Y[(int64_t)c * P.Sp + s] = y[c];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    float acc = P.bias[l];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc = fmaf(y[c], P.kern[c * L + l], acc);
+    acc = acc > 0.0f ? acc : 0.0f;
+    P.Z[(int64_t)l * P.Sp + s] = acc;
+    flat[(int64_t)(P.flat_row0 + r * L + l) * Bp + b] = acc;
+  }
+}
+
+struct CensBwdStream {
+  const float* X;       // [D][Sp] this stream's inputs
+  const float* dots;    // [Sp_other]
+  const float* Z;       // [L][Sp]
+  const float* kern;    // (D,L)
+  const float* pw;      // (D) this stream's dot-product weights (used by the OTHER stream's update)
+  float* dZ;            // [L][Sp] out: grad at pre-activation
+  float* dY;            // [D][Sp] out
+  DofTriplets by_m;     // this stream's update, grouped by partner m  (fields: r, o, coef)
+  DofTriplets oth_by_o; // the OTHER stream's update, grouped by o = element of THIS stream (fields: r, m, coef)
+  const float* X_oth;   // [D][Sp_other]
+  const float* dY_oth;  // [D][Sp_other]
+  float* dX;            // [D][Sp] out: grad wrt this stream's block output
+  float* dd;            // [Sp]    out: grad wrt this stream's dot products
+  int G, G_other;
+  int64_t S, Sp, Sp_other;
+  int flat_row0;
+};
+
+template <int L>
+__global__ void __launch_bounds__(256) k_cens_bwd1(CensBwdStream A, CensBwdStream Bs, const float* __restrict__ dflat,
+                                                   int64_t Bp) {
+  constexpr int D = 2 * L;
+  const CensBwdStream& P = blockIdx.y ? Bs : A;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= P.S) return;
+  const int64_t b = s / P.G;
+  const int r = (int)(s - b * P.G);
+  float dz[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const float g = dflat[(int64_t)(P.flat_row0 + r * L + l) * Bp + b];
+    dz[l] = P.Z[(int64_t)l * P.Sp + s] > 0.0f ? g : 0.0f;
+    P.dZ[(int64_t)l * P.Sp + s] = dz[l];
+  }
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) acc = fmaf(P.kern[c * L + l], dz[l], acc);
+    P.dY[(int64_t)c * P.Sp + s] = acc;
+  }
+}
+
+template <int L>
+__global__ void __launch_bounds__(256) k_cens_bwd2(CensBwdStream A, CensBwdStream Bs) {
+  constexpr int D = 2 * L;
+  const CensBwdStream& P = blockIdx.y ? Bs : A;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= P.S) return;
+  const int64_t b = s / P.G;
+  const int m = (int)(s - b * P.G);
+  float dx[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) dx[c] = 0.0f;
+  // (a) through the propagated features of THIS stream: Y[r] += coef * dots[o] * X[m]
+  for (int e = P.by_m.ptr[m]; e < P.by_m.ptr[m + 1]; ++e) {
+    const float w = P.by_m.coef[e] * P.dots[b * P.G_other + P.by_m.o[e]];
+    const int64_t sr = b * P.G + P.by_m.r[e];
+#pragma unroll
+    for (int c = 0; c < D; ++c) dx[c] = fmaf(w, P.dY[(int64_t)c * P.Sp + sr], dx[c]);
+  }
+  // (b) through this element's dot product, which weights pairs of the OTHER stream's update
+  float dd = 0.0f;
+  for (int e = P.oth_by_o.ptr[m]; e < P.oth_by_o.ptr[m + 1]; ++e) {
+    const int64_t sr = b * P.G_other + P.oth_by_o.r[e];
+    const int64_t sm = b * P.G_other + P.oth_by_o.m[e];
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc = fmaf(P.X_oth[(int64_t)c * P.Sp_other + sm], P.dY_oth[(int64_t)c * P.Sp_other + sr], acc);
+    dd = fmaf(P.oth_by_o.coef[e], acc, dd);
+  }
+  P.dd[s] = dd;
+#pragma unroll
+  for (int c = 0; c < D; ++c) P.dX[(int64_t)c * P.Sp + s] = fmaf(dd, P.pw[c], dx[c]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Latent forward: final dense, mean / softplus(log-var) heads, reparameterisation, GMM posterior.
+// ---------------------------------------------------------------------------------------------
+struct LatentFwdArgs {
+  const float* flat;  // [J][Bp]
+  int J;
+  const float *wf, *bf, *wm, *bm, *ws, *bs;  // final_dense (L,J); encoder_mean (L,L); encoder_log_var (L,L)
+  const float *gmm_means, *gmm_log_vars, *prior;  // (K,L), (K,L), (K)
+  const float* eps;   // (B,L) row-major or null (eval: z = mean)
+  float *enc, *mu, *pre, *sv, *z;  // [L][Bp]
+  float *q, *qn;      // [K][Bp] posterior, clamp+renormalised posterior
+  float *z_out, *q_out, *mu_out, *sv_out, *enc_out;  // reference-layout exports (B,L)/(B,K) or null
+  int K;
+  int64_t B, Bp;
+};
+
+template <int L>
+__global__ void __launch_bounds__(256) k_latent_fwd(LatentFwdArgs A) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= A.B) return;
+  float enc[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) enc[l] = A.bf[l];
+  for (int j = 0; j < A.J; ++j) {
+    const float f = A.flat[(int64_t)j * A.Bp + b];
+#pragma unroll
+    for (int l = 0; l < L; ++l) enc[l] = fmaf(A.wf[l * A.J + j], f, enc[l]);
+  }
+  float z[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    float m = A.bm[l], p = A.bs[l];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      m = fmaf(A.wm[l * L + k], enc[k], m);
+      p = fmaf(A.ws[l * L + k], enc[k], p);
+    }
+    const float sv = dof_softplus(p);
+    z[l] = A.eps ? fmaf(expf(0.5f * sv), A.eps[b * L + l], m) : m;
+    A.enc[(int64_t)l * A.Bp + b] = enc[l];
+    A.mu[(int64_t)l * A.Bp + b] = m;
+    A.pre[(int64_t)l * A.Bp + b] = p;
+    A.sv[(int64_t)l * A.Bp + b] = sv;
+    A.z[(int64_t)l * A.Bp + b] = z[l];
+    if (A.z_out) A.z_out[b * L + l] = z[l];
+    if (A.mu_out) A.mu_out[b * L + l] = m;
+    if (A.sv_out) A.sv_out[b * L + l] = sv;
+    if (A.enc_out) A.enc_out[b * L + l] = enc[l];
+  }
+  // posterior: softmax_c(log(prior+1e-9) + sum_d log N(z_d; m_cd, max(exp(l_cd/2),1e-3)))
+  const float HALF_LOG_2PI = 0.9189385332046727f;
+  float mx = -INFINITY;
+  for (int c = 0; c < A.K; ++c) {
+    float lg = logf(A.prior[c] + 1e-9f);
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      const float sd = fmaxf(expf(0.5f * A.gmm_log_vars[c * L + d]), 1e-3f);
+      const float u = (z[d] - A.gmm_means[c * L + d]) / sd;
+      lg += -0.5f * u * u - logf(sd) - HALF_LOG_2PI;
+    }
+    A.q[(int64_t)c * A.Bp + b] = lg;
+    mx = fmaxf(mx, lg);
+  }
+  float sum = 0.0f;
+  for (int c = 0; c < A.K; ++c) {
+    const float e = expf(A.q[(int64_t)c * A.Bp + b] - mx);
+    A.q[(int64_t)c * A.Bp + b] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / sum;
+  float csum = 0.0f;
+  for (int c = 0; c < A.K; ++c) {
+    const float qv = A.q[(int64_t)c * A.Bp + b] * inv;
+    A.q[(int64_t)c * A.Bp + b] = qv;
+    if (A.q_out) A.q_out[b * A.K + c] = qv;
+    csum += fmaxf(qv, 1e-8f);
+  }
+  const float cinv = 1.0f / csum;
+  for (int c = 0; c < A.K; ++c) A.qn[(int64_t)c * A.Bp + b] = fmaxf(A.q[(int64_t)c * A.Bp + b], 1e-8f) * cinv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram spectrum ("k-means" loss): value and the matrix Pm with dLoss/dZ = Z * Pm.
+//   loss = w * mean_i sqrt(max(lambda_i(Z^T Z / B), 1e-9)) ;  dLoss/dZ = w/(L*B) * Z * G^{-1/2}
+// One thread, cyclic Jacobi in fp64 on the L x L Gram (formed in fp32 like the reference).
+// ---------------------------------------------------------------------------------------------
+template <int L>
+__global__ void k_kmeans_eig(const float* __restrict__ gram_sum, const float* __restrict__ hyper, int64_t B,
+                             float* __restrict__ km_out /*[0]=weighted loss*/, float* __restrict__ Pm /*[L][L]*/) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float w_lat = hyper[DOF_H_KM_LATENT];
+  const float w_loss = hyper[DOF_H_KM_LOSS];
+  if (!(w_lat > 0.0f)) {
+    km_out[0] = 0.0f;
+    for (int i = 0; i < L * L; ++i) Pm[i] = 0.0f;
+    return;
+  }
+  double a[L][L], v[L][L];
+  for (int i = 0; i < L; ++i)
+    for (int j = 0; j < L; ++j) {
+      a[i][j] = (double)(gram_sum[i * L + j] / (float)B);
+      v[i][j] = i == j ? 1.0 : 0.0;
+    }
+  for (int i = 0; i < L; ++i)
+    for (int j = i + 1; j < L; ++j) a[i][j] = a[j][i] = 0.5 * (a[i][j] + a[j][i]);
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < L; ++i)
+      for (int j = i + 1; j < L; ++j) off += a[i][j] * a[i][j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < L; ++p)
+      for (int q = p + 1; q < L; ++q) {
+        if (fabs(a[p][q]) < 1e-300) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < L; ++k) {
+          const double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - s * akq;
+          a[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < L; ++k) {
+          const double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - s * aqk;
+          a[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < L; ++k) {
+          const double vkp = v[k][p], vkq = v[k][q];
+          v[k][p] = c * vkp - s * vkq;
+          v[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  double val = 0.0, inv[L];
+  for (int i = 0; i < L; ++i) {
+    const double lam = fabs(a[i][i]);  // singular values of a symmetric matrix = |eigenvalues|
+    val += sqrt(lam > 1e-9 ? lam : 1e-9);
+    inv[i] = lam > 1e-9 ? 1.0 / sqrt(lam) : 0.0;
+  }
+  const double w = (double)w_lat;
+  km_out[0] = (float)(w * val / L) * w_loss;
+  const double scale = (double)w_lat * (double)w_loss / ((double)L * (double)B);
+  for (int i = 0; i < L; ++i)
+    for (int j = 0; j < L; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < L; ++k) acc += v[i][k] * inv[k] * v[j][k];
+      Pm[i * L + j] = (float)(scale * acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch statistics.  Block c < K: sum_b qn[b,c] and sum_b qn[b,c] z[b,:].  Block K: activity,
+// pretrain KL and distillation class-weight sums.  One block per quantity => fixed summation order.
+// ---------------------------------------------------------------------------------------------
+struct StatsArgs {
+  const float *qn, *z, *mu, *sv;  // SoA
+  const float* tau;               // (B,K) row-major teacher targets or null
+  const float* class_weight;      // (K)
+  const float* hyper;
+  float* stats;                   // [K][1+L] cluster sums, then [3] scalars at K*(1+L)
+  int K;
+  int64_t B, Bp;
+};
+
+template <int L>
+__global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
+  const int c = blockIdx.x;
+  float vals[L + 1];
+#pragma unroll
+  for (int i = 0; i <= L; ++i) vals[i] = 0.0f;
+  if (c < A.K) {
+    for (int64_t b = threadIdx.x; b < A.B; b += 256) {
+      const float qv = A.qn[(int64_t)c * A.Bp + b];
+      vals[0] += qv;
+#pragma unroll
+      for (int d = 0; d < L; ++d) vals[1 + d] = fmaf(qv, A.z[(int64_t)d * A.Bp + b], vals[1 + d]);
+    }
+  } else {
+    const float Ts = A.hyper[DOF_H_DISTILL_T];
+    for (int64_t b = threadIdx.x; b < A.B; b += 256) {
+      float act = 0.0f, kl = 0.0f;
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float s = A.sv[(int64_t)d * A.Bp + b];
+        const float m = A.mu[(int64_t)d * A.Bp + b];
+        act += fabsf(s);
+        const float sc = fminf(fmaxf(s, -4.0f), 2.0f);
+        kl += m * m + expf(sc) - 1.0f - sc;
+      }
+      vals[0] += act;
+      vals[1] += 0.5f * kl / L;
+      if (A.tau) {  // w_class_b = sum_c sharpen(tau)[c] * class_weight[c]
+        float mx = -INFINITY;
+        for (int k = 0; k < A.K; ++k) mx = fmaxf(mx, logf(fmaxf(A.tau[b * A.K + k], 1e-8f)) / Ts);
+        float se = 0.0f, sw = 0.0f;
+        for (int k = 0; k < A.K; ++k) {
+          const float e = expf(logf(fmaxf(A.tau[b * A.K + k], 1e-8f)) / Ts - mx);
+          se += e;
+          sw = fmaf(e, A.class_weight[k], sw);
+        }
+        vals[2] += sw / se;
+      }
+    }
+  }
+  __shared__ float out[L + 1];
+  dof_block_colsum<L + 1>(vals, out);
+  __syncthreads();
+  if (threadIdx.x <= L) {
+    if (c < A.K) A.stats[c * (L + 1) + threadIdx.x] = out[threadIdx.x];
+    else if (threadIdx.x < 3) A.stats[A.K * (L + 1) + threadIdx.x] = out[threadIdx.x];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Monte-Carlo KL against the GMM prior (main phase), losses.py:525-545.  Thread = (sample, b).
+// ---------------------------------------------------------------------------------------------
+struct McklArgs {
+  const float *mu, *sv;       // [L][Bp]
+  const float* eps_mc;        // (S,B,L) row-major
+  const float *gmm_means, *gmm_log_vars, *prior;
+  const float* hyper;
+  float* term;                // [S][Bp]  log q - log p
+  float* lse;                 // [S][Bp]
+  float* dz;                  // [S][L][Bp]  d log p / d z
+  int K, S;
+  int64_t B, Bp;
+};
+
+template <int L>
+__device__ __forceinline__ float gmm_logp_c(const float* zs, const float* means, const float* log_vars, float lo,
+                                            float hi, int c) {
+  const float LOG_2PI = 1.8378770664093453f;
+  float acc = 0.0f;
+#pragma unroll
+  for (int d = 0; d < L; ++d) {
+    const float lv = fminf(fmaxf(log_vars[c * L + d], lo), hi);
+    const float df = zs[d] - means[c * L + d];
+    acc += LOG_2PI + lv + df * df * expf(-lv);
+  }
+  return -0.5f * acc;
+}
+
+template <int L>
+__global__ void __launch_bounds__(256) k_mckl_fwd(McklArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)A.S * A.B) return;
+  const int smp = (int)(i / A.B);
+  const int64_t b = i - (int64_t)smp * A.B;
+  const float lo = A.hyper[DOF_H_LOGVAR_LO], hi = A.hyper[DOF_H_LOGVAR_HI];
+  const float LOG_2PI = 1.8378770664093453f;
+  float zs[L];
+  float logq = 0.0f;
+#pragma unroll
+  for (int d = 0; d < L; ++d) {
+    const float sc = fminf(fmaxf(A.sv[(int64_t)d * A.Bp + b], -4.0f), 2.0f);
+    const float e = A.eps_mc[((int64_t)smp * A.B + b) * L + d];
+    zs[d] = fmaf(e, expf(0.5f * sc), A.mu[(int64_t)d * A.Bp + b]);
+    logq += LOG_2PI + sc + e * e;
+  }
+  logq *= -0.5f;
+  float mx = -INFINITY;
+  for (int c = 0; c < A.K; ++c)
+    mx = fmaxf(mx, logf(fmaxf(A.prior[c], 1e-8f)) + gmm_logp_c<L>(zs, A.gmm_means, A.gmm_log_vars, lo, hi, c));
+  float se = 0.0f;
+  float g[L];
+#pragma unroll
+  for (int d = 0; d < L; ++d) g[d] = 0.0f;
+  for (int c = 0; c < A.K; ++c) {
+    const float e = expf(logf(fmaxf(A.prior[c], 1e-8f)) + gmm_logp_c<L>(zs, A.gmm_means, A.gmm_log_vars, lo, hi, c) - mx);
+    se += e;
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      const float lv = fminf(fmaxf(A.gmm_log_vars[c * L + d], lo), hi);
+      g[d] = fmaf(e, -(zs[d] - A.gmm_means[c * L + d]) * expf(-lv), g[d]);
+    }
+  }
+  const float lse = mx + logf(se);
+  A.term[(int64_t)smp * A.Bp + b] = logq - lse;
+  A.lse[(int64_t)smp * A.Bp + b] = lse;
+#pragma unroll
+  for (int d = 0; d < L; ++d) A.dz[((int64_t)smp * L + d) * A.Bp + b] = g[d] / se;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss assembly (one thread): every scalar of VadeLoss + the small tensors the backward needs.
+// ---------------------------------------------------------------------------------------------
+struct LossMidArgs {
+  const float* stats;          // from k_batch_stats
+  const float* recon_partial;  // [n_recon] per-block sums of -log_prob
+  int n_recon;
+  const float* mckl_partial;   // [n_mckl] per-block sums of (log q - log p) or null (pretrain)
+  int n_mckl;
+  const float* km;             // [1] weighted k-means term
+  const float* teacher_marginal;  // (K) or null
+  const float* hyper;
+  float* dqbar;                // [K]  d(nonempty)/d mean_b qn[b,c]
+  float* dcen;                 // [K][L] d(repel)/d centroid, pre-divided by pi_b[c]
+  float* scal;                 // [8]: 0 klscale(main: klw*flag/(S*B)), 1 wcls_mean, 2 distill_sum(filled later)
+  float* logs;                 // [DOF_LOG_COUNT]
+  int K, L, S, T, pretrain;
+  int64_t B;
+};
+
+__global__ void k_loss_mid(LossMidArgs A) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int K = A.K, L = A.L;
+  const float* H = A.hyper;
+  const float Bf = (float)A.B;
+  float recon = 0.0f;
+  for (int i = 0; i < A.n_recon; ++i) recon += A.recon_partial[i];
+  recon /= (Bf * (float)A.T);
+  const float* sc = A.stats + K * (L + 1);
+  const float activity = H[DOF_H_L1_ACT] * sc[0] / Bf;
+  const float klw = H[DOF_H_KLW];
+  float kl;
+  if (A.pretrain) {
+    kl = klw * sc[1] / Bf;
+    A.scal[0] = 0.0f;
+  } else {
+    float s = 0.0f;
+    for (int i = 0; i < A.n_mckl; ++i) s += A.mckl_partial[i];
+    const float raw = s / ((float)A.S * Bf);
+    kl = klw * fmaxf(raw, 0.0f);
+    A.scal[0] = raw > 0.0f ? klw / ((float)A.S * Bf) : 0.0f;
+  }
+  A.scal[1] = fmaxf(sc[2] / Bf, 1e-8f);
+  // nonempty floor on the batch marginal
+  float nonempty = 0.0f;
+  const float nw = H[DOF_H_NONEMPTY_W], base_floor = H[DOF_H_NONEMPTY_FLOOR], pw = H[DOF_H_NONEMPTY_P];
+  for (int c = 0; c < K; ++c) {
+    const float qm = A.stats[c * (L + 1)] / Bf;
+    float fl = base_floor;
+    if (A.teacher_marginal && H[DOF_H_HAS_TEACHER] != 0.0f) fl = fmaxf(fl, 0.9f * A.teacher_marginal[c]);
+    const float under = fmaxf(fl - qm, 0.0f);
+    float g = 0.0f;
+    if (nw > 0.0f && under > 0.0f) {
+      nonempty += powf(under, pw);
+      g = -nw * pw * powf(under, pw - 1.0f);
+    }
+    A.dqbar[c] = g;
+  }
+  nonempty *= nw;
+  // repulsion between soft centroids (q detached)
+  float repel = 0.0f;
+  const float rw = H[DOF_H_REPEL_W];
+  for (int i = 0; i < K * L; ++i) A.dcen[i] = 0.0f;
+  if (rw > 0.0f) {
+    const float ls = H[DOF_H_REPEL_LS];
+    const float den = fmaxf(1e-9f, 2.0f * ls * ls);
+    const float norm = (float)(K * K - K > 1 ? K * K - K : 1);
+    float ksum = 0.0f;
+    for (int c = 0; c < K; ++c) {
+      const float pc = fmaxf(A.stats[c * (L + 1)], 1e-8f);
+      for (int e = 0; e < K; ++e) {
+        if (e == c) continue;
+        const float pe = fmaxf(A.stats[e * (L + 1)], 1e-8f);
+        float d2 = 0.0f;
+        for (int d = 0; d < L; ++d) {
+          const float df = A.stats[c * (L + 1) + 1 + d] / pc - A.stats[e * (L + 1) + 1 + d] / pe;
+          d2 += df * df;
+        }
+        const float kv = expf(-d2 / den);
+        ksum += kv;
+        for (int d = 0; d < L; ++d) {
+          const float df = A.stats[c * (L + 1) + 1 + d] / pc - A.stats[e * (L + 1) + 1 + d] / pe;
+          A.dcen[c * L + d] += (rw / norm) * 2.0f * kv * (-2.0f * df / den) / pc;
+        }
+      }
+    }
+    repel = rw * ksum / norm;
+  }
+  float prior_loss = 0.0f;
+  if (!A.pretrain) {  // -(q * log(1/K)).sum(-1).mean(); q rows sum to one after renormalisation
+    float qs = 0.0f;
+    for (int c = 0; c < K; ++c) qs += A.stats[c * (L + 1)];
+    prior_loss = logf((float)(K > 1 ? K : 1)) * qs / Bf;
+  }
+  float* lg = A.logs;
+  lg[DOF_LOG_RECON] = recon;
+  lg[DOF_LOG_KL] = kl;
+  lg[DOF_LOG_KMEANS] = A.km[0];
+  lg[DOF_LOG_ACTIVITY] = activity;
+  lg[DOF_LOG_PRIOR] = prior_loss;
+  lg[DOF_LOG_NONEMPTY] = nonempty;
+  lg[DOF_LOG_REPEL] = repel;
+  lg[DOF_LOG_CAT] = 0.0f;
+  lg[DOF_LOG_TFCLUST] = 0.0f;
+  lg[DOF_LOG_TEMPORAL] = 0.0f;
+  lg[DOF_LOG_SCATTER] = 0.0f;
+  lg[DOF_LOG_KLW] = klw;
+  lg[DOF_LOG_DISTILL] = 0.0f;  // filled by k_loss_total once the per-sample CE sums exist
+  lg[DOF_LOG_TOTAL] = recon + kl + nonempty + prior_loss + A.km[0] + activity + repel;
+}
+
+__global__ void k_loss_total(const float* __restrict__ distill_partial, int n, const float* __restrict__ hyper,
+                             int64_t B, float* __restrict__ logs) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.0f;
+  for (int i = 0; i < n; ++i) s += distill_partial[i];
+  const float d = hyper[DOF_H_LAMBDA_DISTILL] * s / (float)B;
+  logs[DOF_LOG_DISTILL] = d;
+  logs[DOF_LOG_TOTAL] += d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Latent backward, thread = b.
+// ---------------------------------------------------------------------------------------------
+struct LatentBwdArgs {
+  // forward state
+  const float *enc, *mu, *pre, *sv, *z, *q, *qn;
+  const float* eps;        // (B,L)
+  const float* eps_mc;     // (S,B,L) or null
+  const float* mckl_dz;    // [S][L][Bp] or null
+  const float* dz_dec;     // [2][L][Bp] from the decoder
+  const float *wf, *wm, *ws, *gmm_means, *gmm_log_vars;
+  const float *Pm, *dcen, *dqbar, *scal, *hyper;
+  const float* tau;        // (B,K) or null
+  const float* class_weight;
+  // outputs
+  float* dmu_dpre;         // [2L][Bp]
+  float* denc;             // [L][Bp]
+  float* dlogit;           // [K][Bp]
+  float* dflat;            // [J][Bp]
+  float* distill_partial;  // [nblk]
+  int J, K, S, pretrain;
+  int64_t B, Bp;
+};
+
+template <int L>
+__global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b < A.B;
+  float ce_w = 0.0f;
+  if (live) {
+    const float* H = A.hyper;
+    const float Bf = (float)A.B;
+    const int K = A.K;
+    float z[L], dz[L];
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      z[d] = A.z[(int64_t)d * A.Bp + b];
+      dz[d] = A.dz_dec[(int64_t)d * A.Bp + b] + A.dz_dec[(int64_t)(L + d) * A.Bp + b];
+    }
+    // ---- gradient wrt the renormalised posterior qn
+    const float lam = H[DOF_H_LAMBDA_DISTILL];
+    const bool distill = A.tau && lam > 0.0f;
+    float w_total = 1.0f, tmx = 0.0f, tse = 1.0f;
+    const float Ts = H[DOF_H_DISTILL_T];
+    if (distill) {
+      tmx = -INFINITY;
+      for (int c = 0; c < K; ++c) tmx = fmaxf(tmx, logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts);
+      tse = 0.0f;
+      float sw = 0.0f, cmax = 0.0f;
+      for (int c = 0; c < K; ++c) {
+        const float e = expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx);
+        tse += e;
+        sw = fmaf(e, A.class_weight[c], sw);
+        cmax = fmaxf(cmax, e);
+      }
+      w_total = (sw / tse) / A.scal[1];
+      if (H[DOF_H_CONF_W] != 0.0f) {
+        const float thr = H[DOF_H_CONF_THR];
+        w_total *= fminf(fmaxf((cmax / tse - thr) / fmaxf(1e-6f, 1.0f - thr), 0.0f), 1.0f);
+      }
+    }
+    // pass 1: dot = sum_c dqn[c]*qn[c] ; csum = sum_c max(q,1e-8)
+    float dot = 0.0f, csum = 0.0f, ce = 0.0f;
+    for (int c = 0; c < K; ++c) {
+      const float qn = A.qn[(int64_t)c * A.Bp + b];
+      float g = A.dqbar[c] / Bf;
+      if (distill) {
+        const float tb = expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx) / tse;
+        ce -= tb * logf(fmaxf(qn, 1e-8f));
+        if (qn >= 1e-8f) g -= (lam / Bf) * w_total * tb / qn;
+      }
+      dot = fmaf(g, qn, dot);
+      csum += fmaxf(A.q[(int64_t)c * A.Bp + b], 1e-8f);
+    }
+    ce_w = distill ? w_total * ce : 0.0f;
+    // pass 2: dq through clamp+renormalise, accumulate softmax inner product
+    float sdot = 0.0f;
+    for (int c = 0; c < K; ++c) {
+      const float qn = A.qn[(int64_t)c * A.Bp + b];
+      const float q = A.q[(int64_t)c * A.Bp + b];
+      float g = A.dqbar[c] / Bf;
+      if (distill && qn >= 1e-8f) {
+        const float tb = expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx) / tse;
+        g -= (lam / Bf) * w_total * tb / qn;
+      }
+      const float dq = q >= 1e-8f ? (g - dot) / csum : 0.0f;
+      A.dlogit[(int64_t)c * A.Bp + b] = dq;  // temporarily dq
+      sdot = fmaf(dq, q, sdot);
+    }
+    // pass 3: dlogit, posterior path into z, repel path
+    for (int c = 0; c < K; ++c) {
+      const float q = A.q[(int64_t)c * A.Bp + b];
+      const float dl = q * (A.dlogit[(int64_t)c * A.Bp + b] - sdot);
+      A.dlogit[(int64_t)c * A.Bp + b] = dl;
+      const float qn = A.qn[(int64_t)c * A.Bp + b];
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float sd = fmaxf(expf(0.5f * A.gmm_log_vars[c * L + d]), 1e-3f);
+        dz[d] = fmaf(dl, -(z[d] - A.gmm_means[c * L + d]) / (sd * sd), dz[d]);
+        dz[d] = fmaf(qn, A.dcen[c * L + d], dz[d]);
+      }
+    }
+    // k-means (Gram spectrum): dZ = Z * Pm
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < L; ++e) acc = fmaf(z[e], A.Pm[e * L + d], acc);
+      dz[d] += acc;
+    }
+    // ---- through the reparameterisation, activity L1, KL
+    const float klw = H[DOF_H_KLW];
+    const float act = H[DOF_H_L1_ACT] / Bf;
+    float dmu[L], dpre[L];
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      const float s = A.sv[(int64_t)d * A.Bp + b];
+      const float m = A.mu[(int64_t)d * A.Bp + b];
+      float dm = dz[d];
+      float ds = dz[d] * A.eps[b * L + d] * 0.5f * expf(0.5f * s);
+      ds += s > 0.0f ? act : (s < 0.0f ? -act : 0.0f);
+      const float sc = fminf(fmaxf(s, -4.0f), 2.0f);
+      const bool pass = (s >= -4.0f) && (s <= 2.0f);
+      if (A.pretrain) {
+        dm = fmaf(klw / (Bf * L), m, dm);
+        if (pass) ds = fmaf(klw / (Bf * L), 0.5f * (expf(sc) - 1.0f), ds);
+      } else {
+        const float ksc = A.scal[0];
+        if (ksc != 0.0f) {
+          float gz = 0.0f, gze = 0.0f;
+          for (int smp = 0; smp < A.S; ++smp) {
+            const float g = A.mckl_dz[((int64_t)smp * L + d) * A.Bp + b];
+            gz += g;
+            gze = fmaf(g, A.eps_mc[((int64_t)smp * A.B + b) * L + d], gze);
+          }
+          dm = fmaf(-ksc, gz, dm);
+          if (pass) ds += ksc * (-gze * 0.5f * expf(0.5f * sc) - 0.5f * (float)A.S);
+        }
+      }
+      dmu[d] = dm;
+      dpre[d] = ds * dof_sigmoid(A.pre[(int64_t)d * A.Bp + b]);
+      A.dmu_dpre[(int64_t)d * A.Bp + b] = dm;
+      A.dmu_dpre[(int64_t)(L + d) * A.Bp + b] = dpre[d];
+    }
+    float denc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        acc = fmaf(A.wm[l * L + k], dmu[l], acc);
+        acc = fmaf(A.ws[l * L + k], dpre[l], acc);
+      }
+      denc[k] = acc;
+      A.denc[(int64_t)k * A.Bp + b] = acc;
+    }
+    for (int j = 0; j < A.J; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) acc = fmaf(A.wf[l * A.J + j], denc[l], acc);
+      A.dflat[(int64_t)j * A.Bp + b] = acc;
+    }
+  }
+  float v1[1] = {ce_w};
+  dof_block_colsum<1>(v1, A.distill_partial + blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GMM parameter gradients.  Block c: posterior path (sum over b) + MC-KL path (sum over (s,b)).
+// ---------------------------------------------------------------------------------------------
+struct GmmGradArgs {
+  const float *z, *dlogit;           // [L][Bp], [K][Bp]
+  const float *mu, *sv, *eps_mc, *lse;  // MC-KL recompute (main) or null
+  const float *gmm_means, *gmm_log_vars, *prior, *scal, *hyper;
+  float *g_means, *g_log_vars;       // (K,L) destinations inside the grad buffer
+  int K, S, pretrain;
+  int64_t B, Bp;
+};
+
+template <int L>
+__global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A) {
+  const int c = blockIdx.x;
+  float vals[2 * L];
+#pragma unroll
+  for (int i = 0; i < 2 * L; ++i) vals[i] = 0.0f;
+  float m[L], lvraw[L];
+#pragma unroll
+  for (int d = 0; d < L; ++d) {
+    m[d] = A.gmm_means[c * L + d];
+    lvraw[d] = A.gmm_log_vars[c * L + d];
+  }
+  for (int64_t b = threadIdx.x; b < A.B; b += 256) {
+    const float dl = A.dlogit[(int64_t)c * A.Bp + b];
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      const float e = expf(0.5f * lvraw[d]);
+      const float sd = fmaxf(e, 1e-3f);
+      const float u = (A.z[(int64_t)d * A.Bp + b] - m[d]) / sd;
+      vals[d] = fmaf(dl, u / sd, vals[d]);
+      // d/d log_var of [-u^2/2 - log sd] = (u^2 - 1) * 0.5, only while the 1e-3 floor is inactive
+      if (e >= 1e-3f) vals[L + d] = fmaf(dl, 0.5f * (u * u - 1.0f), vals[L + d]);
+    }
+  }
+  const float ksc = A.pretrain ? 0.0f : A.scal[0];
+  if (ksc != 0.0f) {
+    const float lo = A.hyper[DOF_H_LOGVAR_LO], hi = A.hyper[DOF_H_LOGVAR_HI];
+    const float lp = logf(fmaxf(A.prior[c], 1e-8f));
+    const int64_t n = (int64_t)A.S * A.B;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+      const int smp = (int)(i / A.B);
+      const int64_t b = i - (int64_t)smp * A.B;
+      float zs[L];
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float sc = fminf(fmaxf(A.sv[(int64_t)d * A.Bp + b], -4.0f), 2.0f);
+        zs[d] = fmaf(A.eps_mc[((int64_t)smp * A.B + b) * L + d], expf(0.5f * sc), A.mu[(int64_t)d * A.Bp + b]);
+      }
+      const float r = expf(lp + gmm_logp_c<L>(zs, A.gmm_means, A.gmm_log_vars, lo, hi, c) - A.lse[(int64_t)smp * A.Bp + b]);
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float lv = fminf(fmaxf(lvraw[d], lo), hi);
+        const float df = zs[d] - m[d];
+        const float iv = expf(-lv);
+        // loss has -log p: gradient = -ksc * r * d(log N)/d(param)
+        vals[d] = fmaf(-ksc * r, df * iv, vals[d]);
+        if (lvraw[d] >= lo && lvraw[d] <= hi) vals[L + d] = fmaf(-ksc * r, 0.5f * (df * df * iv - 1.0f), vals[L + d]);
+      }
+    }
+  }
+  __shared__ float out[2 * L];
+  dof_block_colsum<2 * L>(vals, out);
+  __syncthreads();
+  if (threadIdx.x < L) A.g_means[c * L + threadIdx.x] = out[threadIdx.x];
+  else if (threadIdx.x < 2 * L) A.g_log_vars[c * L + threadIdx.x - L] = out[threadIdx.x];
+}
+
+// generic per-block sums of a [n][Bp]-strided SoA scalar field (used for the MC-KL term)
+__global__ void __launch_bounds__(256) k_block_sum(const float* __restrict__ x, int rows, int64_t B, int64_t Bp,
+                                                   float* __restrict__ partial) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float v[1] = {0.0f};
+  if (i < (int64_t)rows * B) {
+    const int r = (int)(i / B);
+    v[0] = x[(int64_t)r * Bp + (i - (int64_t)r * B)];
+  }
+  dof_block_colsum<1>(v, partial + blockIdx.x);
+}
+
+}  // namespace

@@ -1,0 +1,187 @@
+// Weight-gradient reductions and the optimiser.
+//
+//  * k_outer: every dense weight gradient of the model is a tall-skinny product
+//        dW[i][j] = sum_{t,s} dG[t][i][s] * X[t+shift][j][s]
+//    over SoA operands.  This is the one GEMM-shaped reduction of the step (K = T*S ~ 7e5), so it
+//    runs on the matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32, same rounding as an fmaf chain).
+//    Operands stream straight from HBM as 16-byte lane loads (4 consecutive sequences per lane
+//    = the 4 k-slices of 4 MFMAs); one launch carries all jobs of the step.  Each workgroup
+//    writes one partial tile; k_outer_finalize adds the partials in a fixed order, so gradients
+//    are bitwise reproducible run to run (no float atomics).
+//  * k_clip_adam: clip_grad_value_(0.75) + torch.optim.Adam on the flat parameter buffer
+//    (/root/reference/deepof/clustering/training.py:162-166, losses.py:817-833).
+#include "dof_rt.h"
+#include "launchers.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ jobs, int njobs,
+                                               float* __restrict__ partials) {
+  __shared__ float red[4][64][65];
+  int jid = 0;
+  for (int j = 0; j < njobs; ++j)
+    if ((int)blockIdx.x >= jobs[j].blk0) jid = j;
+  const DofOuterJob& J = jobs[jid];
+  const int blk = blockIdx.x - J.blk0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int T = J.T;
+  const int64_t Sp = J.Sp;
+  const int64_t chunks = Sp >> 4;
+  const int64_t n_units = (int64_t)T * chunks;
+  const int MT = (J.a_rows + 15) >> 4;
+  const int NT = J.n_tiles;
+
+  dof_f32x4 acc[4][4];
+  float rs[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    rs[a] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+
+  for (int64_t u = (int64_t)blk * 4 + wave; u < n_units; u += (int64_t)J.nblk * 4) {
+    const int t = (int)(u / chunks);
+    const int64_t s0 = ((u - (int64_t)t * chunks) << 4) + 4 * q;
+    float4 av[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      av[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mt < MT) {
+        const int row = mt * 16 + i;
+        if (row < J.a_rows)
+          av[mt] = *reinterpret_cast<const float4*>(J.a_ptr + (int64_t)t * J.a_tstride + (int64_t)row * J.a_cstride + s0);
+        rs[mt] += (av[mt].x + av[mt].y) + (av[mt].z + av[mt].w);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if (nt < NT) {
+        const DofOuterTile& B = J.tile[nt];
+        const int tb = t + B.shift;
+        if (tb >= 0 && tb < T) {
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i < B.nc)
+            bv = *reinterpret_cast<const float4*>(B.ptr + (int64_t)tb * B.t_stride + (int64_t)i * B.c_stride + s0);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            if (mt < MT) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv.x, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv.y, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv.z, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv.w, acc[mt][nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // wave tiles -> LDS.  D layout of mfma_f32_16x16x4: lane holds rows (lane>>4)*4 + r, col lane&15.
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    float r = rs[mt];
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
+    if (q == 0) red[wave][mt * 16 + i][64] = r;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) red[wave][mt * 16 + q * 4 + r4][nt * 16 + i] = acc[mt][nt][r4];
+  }
+  __syncthreads();
+  float* __restrict__ out = partials + J.partial_off + (int64_t)blk * DOF_OUTER_PARTIAL_FLOATS;
+  for (int e = threadIdx.x; e < 64 * 65; e += 256) {
+    const int row = e / 65, col = e - row * 65;
+    if (row < J.a_rows && (col < NT * 16 || col == 64))
+      out[e] = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_outer_finalize(const DofOuterJob* __restrict__ jobs,
+                                                        const DofFinJob* __restrict__ fin, int n_fin, int total,
+                                                        const float* __restrict__ partials, float* __restrict__ grads) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int lo = 0, hi = n_fin - 1;
+  while (lo < hi) {  // last fin-job with elem0 <= e
+    const int mid = (lo + hi + 1) >> 1;
+    if (fin[mid].elem0 <= e) lo = mid; else hi = mid - 1;
+  }
+  const DofFinJob& F = fin[lo];
+  const DofOuterJob& J = jobs[F.job];
+  const int local = e - F.elem0;
+  const int ri = local / F.cols, ci = local - ri * F.cols;
+  const int src_row = ri < F.r1 ? ri : ri + (F.r2 - F.r1);
+  const float* __restrict__ p = partials + J.partial_off + (int64_t)src_row * 65 + F.col0 + ci;
+  float acc = 0.0f;
+  for (int b = 0; b < J.nblk; ++b) acc += p[(int64_t)b * DOF_OUTER_PARTIAL_FLOATS];
+  grads[F.dst_off + (int64_t)ri * F.row_stride + (int64_t)ci * F.col_stride] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ partial, int64_t nblk, int nv,
+                                                      float* __restrict__ out, int accumulate) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  float acc = 0.0f;
+  for (int64_t b = 0; b < nblk; ++b) acc += partial[b * nv + v];
+  out[v] = accumulate ? out[v] + acc : acc;
+}
+
+__global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ params, const float* __restrict__ grads,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ hyper,
+                                                   const DofAdamSeg* __restrict__ segs, int nseg, int64_t total,
+                                                   int clip_index) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int sg = -1;
+  for (int k = 0; k < nseg; ++k)
+    if (i >= segs[k].lo && i < segs[k].hi) sg = k;
+  if (sg < 0) return;
+  const DofAdamSeg S = segs[sg];
+  if (hyper[S.active_index] == 0.0f) return;  // grad is None in the reference -> parameter skipped
+  const float clip = hyper[clip_index];
+  const float wd = hyper[clip_index + 1];
+  float g = grads[i];
+  if (clip > 0.0f) g = fminf(fmaxf(g, -clip), clip);
+  float p = params[i];
+  if (wd != 0.0f) g = fmaf(wd, p, g);
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  const float mi = fmaf(b1, m[i], (1.0f - b1) * g);
+  const float vi = fmaf(b2, v[i], (1.0f - b2) * g * g);
+  m[i] = mi;
+  v[i] = vi;
+  const float lr = hyper[S.lr_index];
+  const float bc1 = hyper[S.bc_index], bc2 = hyper[S.bc_index + 1];
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  params[i] = p - (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+
+int dof_launch_outer(const DofOuterJob* jobs_dev, int njobs, int total_blocks, float* partials, hipStream_t st) {
+  if (total_blocks <= 0) return DOF_OK;
+  DOF_LAUNCH(k_outer, ((unsigned)total_blocks), (256), st, jobs_dev, njobs, partials);
+  return dof_check_launch("k_outer");
+}
+
+int dof_launch_outer_finalize(const DofOuterJob* jobs_dev, const DofFinJob* fin_dev, int n_fin, int total_elems,
+                              const float* partials, float* grads, hipStream_t st) {
+  if (total_elems <= 0) return DOF_OK;
+  DOF_LAUNCH(k_outer_finalize, (dof_cdiv(total_elems, 256)), (256), st, jobs_dev, fin_dev, n_fin, total_elems,
+             partials, grads);
+  return dof_check_launch("k_outer_finalize");
+}
+
+int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* out, int accumulate, hipStream_t st) {
+  DOF_LAUNCH(k_sum_partials, (dof_cdiv(nv, 256)), (256), st, partial, nblk, nv, out, accumulate);
+  return dof_check_launch("k_sum_partials");
+}
+
+int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,
+                         const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, hipStream_t st) {
+  DOF_LAUNCH(k_clip_adam, (dof_cdiv(total, 256)), (256), st, params, grads, m, v, hyper, segs_dev, nseg, total,
+             clip_index);
+  return dof_check_launch("k_clip_adam");
+}

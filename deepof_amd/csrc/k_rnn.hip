@@ -1,0 +1,477 @@
+// Recurrent encoder/decoder kernels.
+//
+// Data layout: every activation is "sequence-minor" SoA  X[t][c][s]  (index (t*C + c)*Sp + s,
+// Sp = sequence count padded to 64).  One HIP thread owns one sequence (and one direction for
+// the GRUs), so all global traffic is coalesced across the 64 lanes of a wavefront, the
+// recurrent state lives in VGPRs, and the (wave-uniform) weights are read through the scalar
+// cache (s_load) -- hidden sizes are 8..32, far too small for MFMA tiles to pay in fp32.
+//
+// Reference semantics restated here:
+//   * tf_style_group_reshape scramble  /root/reference/deepof/clustering/models_new.py:120-138
+//   * RecurrentBlockPT                 models_new.py:217-278  (Conv1d k=5 'same' no-bias + ReLU;
+//     length = number of non-zero conv rows, the FIRST `length` steps are processed (packed
+//     semantics), outputs beyond are 0; LayerNorm eps=1e-3 over ALL steps; final hidden of GRU2)
+//   * GRU cell = torch.nn.GRU (gates r,z,n; h' = (1-z)*n + z*h)
+#include "dof_rt.h"
+#include "launchers.h"
+
+namespace {
+
+#define SOA(t, c, C, Sp, s) (((int64_t)(t) * (C) + (c)) * (Sp) + (s))
+
+// ---------------------------------------------------------------------------------------------
+// Encoder stage 1: scrambled read + Conv1d(F -> C1, k=5, same, no bias) + ReLU + mask/length.
+// ---------------------------------------------------------------------------------------------
+template <int C1, int F>
+__global__ void __launch_bounds__(256) k_enc_conv_fwd(const float* __restrict__ xin,  // (B,T,G,F) reference layout
+                                                      const float* __restrict__ w,    // (C1,F,5)
+                                                      float* __restrict__ xs,         // [T][F][Sp] scrambled copy
+                                                      float* __restrict__ c,          // [T][C1][Sp]
+                                                      int* __restrict__ len, int T, int G, int64_t S, int64_t Sp) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int64_t b = s / G;
+  const int g = (int)(s - b * G);
+  const float* __restrict__ win = xin + b * (int64_t)T * G * F;
+  float rows[5][F];  // rows[k] = input at time (tcur + k - 4)
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int f = 0; f < F; ++f) rows[k][f] = 0.0f;
+  int count = 0;
+  for (int tt = 0; tt < T + 2; ++tt) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int f = 0; f < F; ++f) rows[k][f] = rows[k + 1][f];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      float v = 0.0f;
+      if (tt < T) {
+        // y[b,g,tt,f] = x[b, t, cc] with cc*T + t = (f*T + tt)*G + g   (models_new.py:131-137)
+        const int lin = (f * T + tt) * G + g;
+        const int cc = lin / T;
+        const int t = lin - cc * T;
+        v = win[(int64_t)t * G * F + cc];
+        xs[SOA(tt, f, F, Sp, s)] = v;
+      }
+      rows[4][f] = v;
+    }
+    const int to = tt - 2;  // output time whose 5-tap window [to-2, to+2] is now in rows[0..4]
+    if (to >= 0) {
+      bool nz = false;
+#pragma unroll
+      for (int o = 0; o < C1; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+          for (int k = 0; k < 5; ++k) acc = fmaf(w[(o * F + f) * 5 + k], rows[k][f], acc);
+        acc = acc > 0.0f ? acc : 0.0f;
+        nz |= (acc != 0.0f);
+        c[SOA(to, o, C1, Sp, s)] = acc;
+      }
+      count += nz ? 1 : 0;
+    }
+  }
+  len[s] = count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRU forward.  Thread = (sequence, direction).  Saves gates (r, z, n, W_hn h + b_hn) for bwd.
+// ---------------------------------------------------------------------------------------------
+template <int IN, int HID, bool BCAST>
+__global__ void __launch_bounds__(256) k_gru_fwd(const float* __restrict__ X,  // [T][IN][Sp] (or [IN][Sp] if BCAST)
+                                                 const int* __restrict__ len, DofGruW W,
+                                                 float* __restrict__ O,    // [T][2*HID][Sp]
+                                                 float* __restrict__ GS,   // [2][T][4*HID][Sp] or null (inference)
+                                                 int T, int64_t S, int64_t Sp) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int dir = blockIdx.y;
+  const float* __restrict__ wih = dir ? W.wih1 : W.wih0;
+  const float* __restrict__ whh = dir ? W.whh1 : W.whh0;
+  const float* __restrict__ bih = dir ? W.bih1 : W.bih0;
+  const float* __restrict__ bhh = dir ? W.bhh1 : W.bhh0;
+  float* __restrict__ gs = GS ? GS + (int64_t)dir * T * 4 * HID * Sp : nullptr;
+  const int n = len[s];
+  float h[HID];
+#pragma unroll
+  for (int j = 0; j < HID; ++j) h[j] = 0.0f;
+  float x[IN];
+  float gi[3 * HID];
+  if (BCAST) {
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x[k] = X[(int64_t)k * Sp + s];
+#pragma unroll
+    for (int j = 0; j < 3 * HID; ++j) {
+      float acc = bih[j];
+#pragma unroll
+      for (int k = 0; k < IN; ++k) acc = fmaf(wih[j * IN + k], x[k], acc);
+      gi[j] = acc;
+    }
+  }
+  for (int step = 0; step < n; ++step) {
+    const int t = dir ? (n - 1 - step) : step;
+    if (!BCAST) {
+#pragma unroll
+      for (int k = 0; k < IN; ++k) x[k] = X[SOA(t, k, IN, Sp, s)];
+    }
+    float hn[HID];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+      float ar, az, an, ahn = bhh[2 * HID + j];
+      if (BCAST) {
+        ar = gi[j] + bhh[j];
+        az = gi[HID + j] + bhh[HID + j];
+        an = gi[2 * HID + j];
+      } else {
+        ar = bih[j] + bhh[j];
+        az = bih[HID + j] + bhh[HID + j];
+        an = bih[2 * HID + j];
+#pragma unroll
+        for (int k = 0; k < IN; ++k) {
+          ar = fmaf(wih[j * IN + k], x[k], ar);
+          az = fmaf(wih[(HID + j) * IN + k], x[k], az);
+          an = fmaf(wih[(2 * HID + j) * IN + k], x[k], an);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HID; ++k) {
+        ar = fmaf(whh[j * HID + k], h[k], ar);
+        az = fmaf(whh[(HID + j) * HID + k], h[k], az);
+        ahn = fmaf(whh[(2 * HID + j) * HID + k], h[k], ahn);
+      }
+      const float r = dof_sigmoid(ar);
+      const float z = dof_sigmoid(az);
+      const float nn = dof_tanh(fmaf(r, ahn, an));
+      hn[j] = fmaf(z, h[j] - nn, nn);
+      if (gs) {
+        gs[SOA(t, j, 4 * HID, Sp, s)] = r;
+        gs[SOA(t, HID + j, 4 * HID, Sp, s)] = z;
+        gs[SOA(t, 2 * HID + j, 4 * HID, Sp, s)] = nn;
+        gs[SOA(t, 3 * HID + j, 4 * HID, Sp, s)] = ahn;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+      h[j] = hn[j];
+      O[SOA(t, dir * HID + j, 2 * HID, Sp, s)] = hn[j];
+    }
+  }
+  for (int t = n; t < T; ++t) {
+#pragma unroll
+    for (int j = 0; j < HID; ++j) O[SOA(t, dir * HID + j, 2 * HID, Sp, s)] = 0.0f;
+    if (gs) {
+#pragma unroll
+      for (int j = 0; j < 4 * HID; ++j) gs[SOA(t, j, 4 * HID, Sp, s)] = 0.0f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRU backward.  Consumes the saved gates, overwrites them in place with the pre-activation
+// gate gradients dG = [d r_pre, d z_pre, d n_pre, d(W_hn h + b_hn)] (input of the weight-grad
+// reduction), writes dX per direction.
+// ---------------------------------------------------------------------------------------------
+template <int IN, int HID, bool BCAST>
+__global__ void __launch_bounds__(256) k_gru_bwd(const int* __restrict__ len, DofGruW W,
+                                                 const float* __restrict__ O,      // [T][2*HID][Sp] fwd outputs
+                                                 float* __restrict__ GS,           // [2][T][4*HID][Sp] gates -> dG
+                                                 const float* __restrict__ dO,     // [T][2*HID][Sp] or null
+                                                 const float* __restrict__ dHfin,  // [2*HID][Sp] or null
+                                                 float* __restrict__ dX,  // [2][T][IN][Sp]  (BCAST: [2][IN][Sp])
+                                                 int T, int64_t S, int64_t Sp) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int dir = blockIdx.y;
+  const float* __restrict__ wih = dir ? W.wih1 : W.wih0;
+  const float* __restrict__ whh = dir ? W.whh1 : W.whh0;
+  float* __restrict__ gs = GS + (int64_t)dir * T * 4 * HID * Sp;
+  float* __restrict__ dx_out = dX + (int64_t)dir * (BCAST ? 1 : T) * IN * Sp;
+  const int n = len[s];
+  float dh[HID];
+#pragma unroll
+  for (int j = 0; j < HID; ++j) dh[j] = (dHfin && n > 0) ? dHfin[(int64_t)(dir * HID + j) * Sp + s] : 0.0f;
+  float dxacc[IN];
+  if (BCAST) {
+#pragma unroll
+    for (int k = 0; k < IN; ++k) dxacc[k] = 0.0f;
+  }
+  for (int step = n - 1; step >= 0; --step) {
+    const int t = dir ? (n - 1 - step) : step;
+    const int tp = dir ? t + 1 : t - 1;  // time index holding h_{prev}
+    float dg[4 * HID];
+    float dhn[HID];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+      const float r = gs[SOA(t, j, 4 * HID, Sp, s)];
+      const float z = gs[SOA(t, HID + j, 4 * HID, Sp, s)];
+      const float nn = gs[SOA(t, 2 * HID + j, 4 * HID, Sp, s)];
+      const float ahn = gs[SOA(t, 3 * HID + j, 4 * HID, Sp, s)];
+      const float hp = (step > 0) ? O[SOA(tp, dir * HID + j, 2 * HID, Sp, s)] : 0.0f;
+      float dht = dh[j];
+      if (dO) dht += dO[SOA(t, dir * HID + j, 2 * HID, Sp, s)];
+      const float dn = dht * (1.0f - z);
+      const float dz = dht * (hp - nn);
+      dhn[j] = dht * z;
+      const float dnp = dn * (1.0f - nn * nn);
+      dg[j] = dnp * ahn * r * (1.0f - r);
+      dg[HID + j] = dz * z * (1.0f - z);
+      dg[2 * HID + j] = dnp;
+      dg[3 * HID + j] = dnp * r;
+    }
+#pragma unroll
+    for (int j = 0; j < 4 * HID; ++j) gs[SOA(t, j, 4 * HID, Sp, s)] = dg[j];
+    // dh_prev += W_hh^T [dr, dz, d(ahn)]
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+#pragma unroll
+      for (int k = 0; k < HID; ++k) {
+        dhn[k] = fmaf(whh[j * HID + k], dg[j], dhn[k]);
+        dhn[k] = fmaf(whh[(HID + j) * HID + k], dg[HID + j], dhn[k]);
+        dhn[k] = fmaf(whh[(2 * HID + j) * HID + k], dg[3 * HID + j], dhn[k]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < HID; ++j) dh[j] = dhn[j];
+    // dx = W_ih^T [dr, dz, dn]
+    float dx[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) dx[k] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3 * HID; ++j) {
+#pragma unroll
+      for (int k = 0; k < IN; ++k) dx[k] = fmaf(wih[j * IN + k], dg[j], dx[k]);
+    }
+    if (BCAST) {
+#pragma unroll
+      for (int k = 0; k < IN; ++k) dxacc[k] += dx[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < IN; ++k) dx_out[SOA(t, k, IN, Sp, s)] = dx[k];
+    }
+  }
+  if (BCAST) {
+#pragma unroll
+    for (int k = 0; k < IN; ++k) dx_out[(int64_t)k * Sp + s] = dxacc[k];
+  } else {
+    for (int t = n; t < T; ++t)
+#pragma unroll
+      for (int k = 0; k < IN; ++k) dx_out[SOA(t, k, IN, Sp, s)] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over channels (eps = 1e-3), thread = (t, s).
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float* __restrict__ Y, int T,
+                                                int64_t S, int64_t Sp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)T * S) return;
+  const int t = (int)(i / S);
+  const int64_t s = i - (int64_t)t * S;
+  float x[C];
+  float mean = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    x[c] = X[SOA(t, c, C, Sp, s)];
+    mean += x[c];
+  }
+  mean *= (1.0f / C);
+  float var = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float d = x[c] - mean;
+    var = fmaf(d, d, var);
+  }
+  const float rstd = rsqrtf(var * (1.0f / C) + 1e-3f);
+#pragma unroll
+  for (int c = 0; c < C; ++c) Y[SOA(t, c, C, Sp, s)] = fmaf((x[c] - mean) * rstd, gamma[c], beta[c]);
+}
+
+// dX = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dY*gamma; per-block partial dgamma/dbeta.
+template <int C>
+__global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ X, const float* __restrict__ dY1,
+                                                const float* __restrict__ dY2, const float* __restrict__ gamma,
+                                                float* __restrict__ dX, float* __restrict__ partial,  // [nblk][2C]
+                                                int T, int64_t S, int64_t Sp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < (int64_t)T * S;
+  float vals[2 * C];
+#pragma unroll
+  for (int c = 0; c < 2 * C; ++c) vals[c] = 0.0f;
+  if (live) {
+    const int t = (int)(i / S);
+    const int64_t s = i - (int64_t)t * S;
+    float x[C], dy[C];
+    float mean = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      x[c] = X[SOA(t, c, C, Sp, s)];
+      dy[c] = dY1[SOA(t, c, C, Sp, s)];
+      if (dY2) dy[c] += dY2[SOA(t, c, C, Sp, s)];
+      mean += x[c];
+    }
+    mean *= (1.0f / C);
+    float var = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      x[c] -= mean;
+      var = fmaf(x[c], x[c], var);
+    }
+    const float rstd = rsqrtf(var * (1.0f / C) + 1e-3f);
+    float mg = 0.0f, mgx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      x[c] *= rstd;  // xhat
+      const float g = dy[c] * gamma[c];
+      mg += g;
+      mgx = fmaf(g, x[c], mgx);
+      vals[c] = dy[c] * x[c];
+      vals[C + c] = dy[c];
+    }
+    mg *= (1.0f / C);
+    mgx *= (1.0f / C);
+#pragma unroll
+    for (int c = 0; c < C; ++c) dX[SOA(t, c, C, Sp, s)] = rstd * (dy[c] * gamma[c] - mg - x[c] * mgx);
+  }
+  dof_block_colsum<2 * C>(vals, partial + (int64_t)blockIdx.x * 2 * C);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder block tail: gather the final hidden state of GRU2 ([fwd @ len-1, bwd @ 0]) + LayerNorm.
+// ---------------------------------------------------------------------------------------------
+template <int C>  // C = 2*H
+__global__ void __launch_bounds__(256) k_enc_final_fwd(const float* __restrict__ O2, const int* __restrict__ len,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ HF,
+                                                       float* __restrict__ Y, int T, int64_t S, int64_t Sp) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int n = len[s];
+  float x[C];
+  float mean = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int t = (c < C / 2) ? n - 1 : 0;
+    x[c] = n > 0 ? O2[SOA(t, c, C, Sp, s)] : 0.0f;
+    HF[(int64_t)c * Sp + s] = x[c];
+    mean += x[c];
+  }
+  mean *= (1.0f / C);
+  float var = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float d = x[c] - mean;
+    var = fmaf(d, d, var);
+  }
+  const float rstd = rsqrtf(var * (1.0f / C) + 1e-3f);
+#pragma unroll
+  for (int c = 0; c < C; ++c) Y[(int64_t)c * Sp + s] = fmaf((x[c] - mean) * rstd, gamma[c], beta[c]);
+}
+
+// dc = (dXf + dXb) * (c > 0)   (ReLU mask of the encoder conv; in place into dXf)
+__global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ act, float* __restrict__ d0,
+                                                    const float* __restrict__ d1, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    d0[i] = act[i] > 0.0f ? d0[i] + d1[i] : 0.0f;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+#define DOF_DISPATCH_L(L, CALL)                            \
+  switch (L) {                                             \
+    case 4: { constexpr int LL = 4; CALL; } break;         \
+    case 6: { constexpr int LL = 6; CALL; } break;         \
+    case 8: { constexpr int LL = 8; CALL; } break;         \
+    default:                                               \
+      dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", (int)(L)); \
+      return DOF_ERR_UNSUPPORTED;                          \
+  }
+
+int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, float* xs, float* c, int* len, int T,
+                            int G, int64_t S, int64_t Sp, hipStream_t st) {
+  const unsigned nb = dof_cdiv(S, 256);
+  if (F == 3) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd<2 * LL, 3>), (nb), (256), st, xin, w, xs, c, len, T, G, S, Sp));
+  } else if (F == 1) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd<2 * LL, 1>), (nb), (256), st, xin, w, xs, c, len, T, G, S, Sp));
+  } else {
+    dof_set_error("features per group %d not supported (3 or 1)", F);
+    return DOF_ERR_UNSUPPORTED;
+  }
+  return dof_check_launch("k_enc_conv_fwd");
+}
+
+// kind: 0 = (IN=2L,HID=2L) enc gru1 / dec gru2 ; 1 = (IN=4L,HID=L) enc gru2 ; 2 = (IN=L,HID=L, broadcast input) dec gru1
+int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
+                       int64_t S, int64_t Sp, hipStream_t st) {
+  const unsigned nb = dof_cdiv(S, 256);
+  if (kind == 0) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_fwd<2 * LL, 2 * LL, false>), (nb, 2), (256), st, X, len, W, O, GS, T, S, Sp));
+  } else if (kind == 1) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_fwd<4 * LL, LL, false>), (nb, 2), (256), st, X, len, W, O, GS, T, S, Sp));
+  } else {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_fwd<LL, LL, true>), (nb, 2), (256), st, X, len, W, O, GS, T, S, Sp));
+  }
+  return dof_check_launch("k_gru_fwd");
+}
+
+int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* O, float* GS, const float* dO,
+                       const float* dHfin, float* dX, int T, int64_t S, int64_t Sp, hipStream_t st) {
+  const unsigned nb = dof_cdiv(S, 256);
+  if (kind == 0) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_bwd<2 * LL, 2 * LL, false>), (nb, 2), (256), st, len, W, O, GS, dO, dHfin, dX, T, S, Sp));
+  } else if (kind == 1) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_bwd<4 * LL, LL, false>), (nb, 2), (256), st, len, W, O, GS, dO, dHfin, dX, T, S, Sp));
+  } else {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_bwd<LL, LL, true>), (nb, 2), (256), st, len, W, O, GS, dO, dHfin, dX, T, S, Sp));
+  }
+  return dof_check_launch("k_gru_bwd");
+}
+
+// mult: channels = mult * L  (2 or 4)
+int dof_launch_ln_fwd(int L, int mult, const float* X, const float* gamma, const float* beta, float* Y, int T,
+                      int64_t S, int64_t Sp, hipStream_t st) {
+  const unsigned nb = dof_cdiv((int64_t)T * S, 256);
+  if (mult == 2) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_fwd<2 * LL>), (nb), (256), st, X, gamma, beta, Y, T, S, Sp));
+  } else {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_fwd<4 * LL>), (nb), (256), st, X, gamma, beta, Y, T, S, Sp));
+  }
+  return dof_check_launch("k_ln_fwd");
+}
+
+int64_t dof_ln_bwd_blocks(int T, int64_t S) { return dof_cdiv((int64_t)T * S, 256); }
+
+int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const float* dY2, const float* gamma,
+                      float* dX, float* partial, int T, int64_t S, int64_t Sp, hipStream_t st) {
+  const unsigned nb = (unsigned)dof_ln_bwd_blocks(T, S);
+  if (mult == 2) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_bwd<2 * LL>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp));
+  } else {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_bwd<4 * LL>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp));
+  }
+  return dof_check_launch("k_ln_bwd");
+}
+
+int dof_launch_enc_final_fwd(int L, const float* O2, const int* len, const float* gamma, const float* beta, float* HF,
+                             float* Y, int T, int64_t S, int64_t Sp, hipStream_t st) {
+  const unsigned nb = dof_cdiv(S, 256);
+  DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_final_fwd<2 * LL>), (nb), (256), st, O2, len, gamma, beta, HF, Y, T, S, Sp));
+  return dof_check_launch("k_enc_final_fwd");
+}
+
+int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t n, hipStream_t st) {
+  unsigned nb = dof_cdiv(n, 256);
+  if (nb > 4096) nb = 4096;
+  DOF_LAUNCH(k_relu_merge, (nb), (256), st, act, d0, d1, n);
+  return dof_check_launch("k_relu_merge");
+}

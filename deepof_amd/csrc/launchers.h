@@ -1,0 +1,81 @@
+// Internal host-side launcher declarations shared between the kernel files and the step
+// orchestration (vade.hip).  Not part of the public C ABI (that is include/deepof_hip.h).
+#pragma once
+#include "dof_rt.h"
+
+struct DofGruW {  // both directions of one torch.nn.GRU layer (weight_ih_l0[_reverse], ...)
+  const float *wih0, *whh0, *bih0, *bhh0;
+  const float *wih1, *whh1, *bih1, *bhh1;
+};
+
+// ---- k_rnn.hip ------------------------------------------------------------------------------
+int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, float* xs, float* c, int* len, int T,
+                            int G, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
+                       int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* O, float* GS, const float* dO,
+                       const float* dHfin, float* dX, int T, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_ln_fwd(int L, int mult, const float* X, const float* gamma, const float* beta, float* Y, int T,
+                      int64_t S, int64_t Sp, hipStream_t st);
+int64_t dof_ln_bwd_blocks(int T, int64_t S);
+int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const float* dY2, const float* gamma,
+                      float* dX, float* partial, int T, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_enc_final_fwd(int L, const float* O2, const int* len, const float* gamma, const float* beta, float* HF,
+                             float* Y, int T, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t n, hipStream_t st);
+
+// ---- k_reduce.hip ---------------------------------------------------------------------------
+// Weight-gradient reductions: out[i][j] = sum_{t,s} A[t][i][s] * B[t+shift][j][s] as fp32 MFMA
+// (16x16x4) tiles over SoA operands, many jobs per launch, per-block partials + fixed-order
+// finalize (run-to-run deterministic).
+struct DofOuterTile {  // one 16-column tile of the B operand
+  const float* ptr;
+  int64_t t_stride, c_stride;  // element strides of the time and channel axes (s is contiguous)
+  int nc;                      // valid columns (<=16); rest masked to 0
+  int shift;                   // B is read at time t+shift (skipped when outside [0,T))
+};
+struct DofOuterJob {
+  const float* a_ptr;
+  int64_t a_tstride, a_cstride;
+  int a_rows;     // valid A rows (<= 64)
+  int T;          // time steps
+  int64_t Sp;     // padded sequence count (multiple of 64)
+  int n_tiles;    // 1..4
+  DofOuterTile tile[4];
+  int blk0, nblk;        // block range of this job inside the launch
+  int64_t partial_off;   // float offset of this job's partials: [nblk][64][65]  (col 64 = row sums of A)
+};
+struct DofFinJob {  // scatter-add of one reduced (rows x cols) block into a gradient tensor
+  int job;              // source DofOuterJob index
+  int col0;             // first source column (tile*16 + offset), or 64 for the row-sum column
+  int rows, cols;       // extent
+  int r1, r2;           // source row i maps to dst row i (i < r1) or i - (r2 - r1) (i >= r2); rows in [r1,r2) skipped
+  int64_t dst_off;      // float offset into the grad buffer
+  int64_t row_stride, col_stride;
+  int elem0;            // prefix offset of this fin-job's elements in the finalize launch
+};
+#define DOF_OUTER_PARTIAL_FLOATS (64 * 65)
+
+int dof_launch_outer(const DofOuterJob* jobs_dev, int njobs, int total_blocks, float* partials, hipStream_t st);
+int dof_launch_outer_finalize(const DofOuterJob* jobs_dev, const DofFinJob* fin_dev, int n_fin, int total_elems,
+                              const float* partials, float* grads, hipStream_t st);
+// out[dst_off + v] (+)= sum_b partial[b][v]   (fixed order)
+int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* out, int accumulate, hipStream_t st);
+
+struct DofAdamSeg {  // one contiguous parameter range with its own lr / step count / freeze flag
+  int64_t lo, hi;
+  int lr_index;   // index into hyper[] of the learning rate
+  int bc_index;   // index into hyper[] of (1-b1^t, 1-b2^t) pair
+  int active_index;  // index into hyper[] of the 0/1 "has gradient" flag
+};
+int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,
+                         const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, hipStream_t st);
+
+// ---- k_graph_latent.hip ----------------------------------------------------------------------
+struct DofTriplets {  // CSR of (partner row m, other-stream element o, coefficient) grouped by a key row
+  const int* ptr;     // [G+1]
+  const int* m;       // partner index in the SAME stream
+  const int* o;       // index in the OTHER stream (whose dot-product weights the pair)
+  const int* r;       // output row (used by the by-m / by-o orderings)
+  const float* coef;  // Laplacian entry
+};

@@ -1,0 +1,846 @@
+// VaDE (recurrent encoder / GMM latent / recurrent decoder) step orchestration + C ABI.
+//
+// Host side of libdeepof_hip for the hot path: the plan (parameter layout in the reference's
+// state_dict order, workspace carve-up, CensNet sparsity, weight-gradient job tables) and the
+// launch sequences for inference forward, forward+loss+backward, and the optimiser.  Everything
+// is enqueued on the caller's stream with no allocation and no synchronisation, so the Python
+// host can capture a whole training step into one hipGraph.
+//
+// Reference call path being replaced:  /root/reference/deepof/clustering/training.py:130-166
+// (train_one_epoch_indexed body) -> step_vade :231-309 -> VaDEPT.forward models_new.py:1841-1891
+// -> VadeLoss.forward losses.py:567-797 -> backward -> clip -> Adam.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dof_rt.h"
+#include "launchers.h"
+#include "deepof_hip.h"
+
+#include "k_decoder.inc.h"
+#include "k_graph_latent.inc.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void dof_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int dof_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    dof_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+    return DOF_ERR_LAUNCH;
+  }
+  return DOF_OK;
+}
+
+extern "C" const char* dof_last_error_string(void) { return g_err; }
+extern "C" int dof_abi_version(void) { return DOF_ABI_VERSION; }
+
+#define TRY(x)                 \
+  do {                         \
+    int _rc = (x);             \
+    if (_rc != DOF_OK) return _rc; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct ParamEntry {
+  std::string name;
+  int64_t off, numel;
+};
+
+struct GruOff { int64_t t[8]; };  // wih, whh, bih, bhh, then the _reverse four
+
+struct BlockOff {
+  int64_t conv;
+  GruOff g1;
+  int64_t n1w, n1b;
+  GruOff g2;
+  int64_t n2w, n2b, projw, projb;
+};
+
+struct TripHost {  // CSR triplet lists (see DofTriplets)
+  std::vector<int> ptr, m, o, r;
+  std::vector<float> coef;
+};
+
+struct StreamWs {  // float offsets into the workspace
+  int G, F;
+  int64_t S, Sp;
+  int64_t xs, c, len, o1, g1, n1, o2, g2, hf, n2;
+  int64_t dn2, dhf, dn1x, do1, dc;
+  int64_t dots, Y, Z, dZ, dY, dd;
+  int64_t ln1p, ln2p;
+  int64_t ln1_blocks, ln2_blocks;
+  // device triplet tables (int offsets are in floats too; tables are 4-byte entries)
+  int64_t tri_r[5], tri_m[5], tri_o[5];  // ptr, m, o, r, coef for by-r / by-m / by-o orderings
+};
+
+}  // namespace
+
+struct DofVadePlan {
+  DofVadeDims d;
+  int L, K, T, N, E, S, J, C3;
+  int64_t B, Bp;
+  std::vector<ParamEntry> params;
+  int64_t param_total = 0;
+  BlockOff blk[2];
+  int64_t c_nk, c_ek, c_nw, c_ew, c_nb, c_eb, fd_w, fd_b;
+  GruOff dg1, dg2;
+  int64_t dn1w, dn1b, dn2w, dn2b, dconv, dn3w, dn3b, dpw, dpb;
+  int64_t gmm_m, gmm_lv, mean_w, mean_b, lv_w, lv_b, lens_w, lens_b;
+  int64_t seg_lo[DOF_SEG_COUNT], seg_hi[DOF_SEG_COUNT];
+  // graph
+  TripHost tri[2][3];  // [stream][by r, by m, by o(other stream's update keyed by this stream's element)]
+  // workspace
+  StreamWs sw[2];
+  int64_t flat, enc, mu, pre, sv, z, q, qn, dlogit, dmu_dpre, denc, dflat;
+  int64_t gram, Pm, km, stats, dqbar, dcen, scal;
+  int64_t mterm, mlse, mdz, mckl_partial, distill_partial, recon_partial;
+  int64_t mckl_blocks, lat_blocks, tail_blocks;
+  int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
+  int64_t ln3p, lnd2p, lnd1p, lnd_blocks;
+  int64_t partials, jobs_tab, fin_tab, gram_jobs_tab, gram_fin_tab, segs_tab;
+  int64_t ws_floats = 0;
+  // tables built at bind
+  std::vector<DofOuterJob> jobs, gram_jobs;
+  std::vector<DofFinJob> fins, gram_fins;
+  int total_blocks = 0, fin_elems = 0, gram_blocks = 0, gram_fin_elems = 0;
+  float* ws = nullptr;
+};
+
+namespace {
+
+struct Carver {
+  int64_t cur = 0;
+  int64_t take(int64_t n) {
+    int64_t o = cur;
+    cur += (n + 63) / 64 * 64;
+    return o;
+  }
+};
+
+void add_param(DofVadePlan* p, const std::string& name, int64_t numel, int64_t* off) {
+  p->params.push_back({name, p->param_total, numel});
+  if (off) *off = p->param_total;
+  p->param_total += numel;
+}
+
+void add_gru(DofVadePlan* p, const std::string& prefix, int in, int hid, GruOff* g) {
+  const char* sfx[2] = {"", "_reverse"};
+  for (int d = 0; d < 2; ++d) {
+    add_param(p, prefix + ".weight_ih_l0" + sfx[d], 3LL * hid * in, &g->t[d * 4 + 0]);
+    add_param(p, prefix + ".weight_hh_l0" + sfx[d], 3LL * hid * hid, &g->t[d * 4 + 1]);
+    add_param(p, prefix + ".bias_ih_l0" + sfx[d], 3LL * hid, &g->t[d * 4 + 2]);
+    add_param(p, prefix + ".bias_hh_l0" + sfx[d], 3LL * hid, &g->t[d * 4 + 3]);
+  }
+}
+
+void build_param_layout(DofVadePlan* p) {
+  const int L = p->L, N = p->N, E = p->E, K = p->K;
+  const char* bn[2] = {"encoder.node_recurrent_block", "encoder.edge_recurrent_block"};
+  const int F[2] = {3, 1};
+  p->seg_lo[DOF_SEG_ENCODER] = 0;
+  for (int s = 0; s < 2; ++s) {
+    BlockOff& b = p->blk[s];
+    const std::string pre = bn[s];
+    add_param(p, pre + ".conv1d.weight", 2LL * L * F[s] * 5, &b.conv);
+    add_gru(p, pre + ".gru1", 2 * L, 2 * L, &b.g1);
+    add_param(p, pre + ".norm1.weight", 4 * L, &b.n1w);
+    add_param(p, pre + ".norm1.bias", 4 * L, &b.n1b);
+    add_gru(p, pre + ".gru2", 4 * L, L, &b.g2);
+    add_param(p, pre + ".norm2.weight", 2 * L, &b.n2w);
+    add_param(p, pre + ".norm2.bias", 2 * L, &b.n2b);
+    add_param(p, pre + ".projection.weight", 4LL * L * L, &b.projw);  // unused when internal_dim == latent
+    add_param(p, pre + ".projection.bias", 2 * L, &b.projb);
+  }
+  add_param(p, "encoder.spatial_gnn_block.node_kernel", 2LL * L * L, &p->c_nk);
+  add_param(p, "encoder.spatial_gnn_block.edge_kernel", 2LL * L * L, &p->c_ek);
+  add_param(p, "encoder.spatial_gnn_block.node_weights", 2 * L, &p->c_nw);
+  add_param(p, "encoder.spatial_gnn_block.edge_weights", 2 * L, &p->c_ew);
+  add_param(p, "encoder.spatial_gnn_block.node_bias", L, &p->c_nb);
+  add_param(p, "encoder.spatial_gnn_block.edge_bias", L, &p->c_eb);
+  add_param(p, "encoder.final_dense.weight", (int64_t)L * (N + E) * L, &p->fd_w);
+  add_param(p, "encoder.final_dense.bias", L, &p->fd_b);
+  p->seg_hi[DOF_SEG_ENCODER] = p->param_total;
+  p->seg_lo[DOF_SEG_DECODER] = p->param_total;
+  add_gru(p, "decoder.gru1", L, L, &p->dg1);
+  add_param(p, "decoder.norm1.weight", 2 * L, &p->dn1w);
+  add_param(p, "decoder.norm1.bias", 2 * L, &p->dn1b);
+  add_gru(p, "decoder.gru2", 2 * L, 2 * L, &p->dg2);
+  add_param(p, "decoder.norm2.weight", 4 * L, &p->dn2w);
+  add_param(p, "decoder.norm2.bias", 4 * L, &p->dn2b);
+  add_param(p, "decoder.conv1d.weight", 2LL * L * 4 * L * 5, &p->dconv);
+  add_param(p, "decoder.norm3.weight", 2 * L, &p->dn3w);
+  add_param(p, "decoder.norm3.bias", 2 * L, &p->dn3b);
+  add_param(p, "decoder.prob_decoder.loc_projection.weight", 3LL * N * 2 * L, &p->dpw);
+  add_param(p, "decoder.prob_decoder.loc_projection.bias", 3 * N, &p->dpb);
+  p->seg_hi[DOF_SEG_DECODER] = p->param_total;
+  p->seg_lo[DOF_SEG_GMM] = p->param_total;
+  add_param(p, "latent_space.gmm_means", (int64_t)K * L, &p->gmm_m);
+  add_param(p, "latent_space.gmm_log_vars", (int64_t)K * L, &p->gmm_lv);
+  p->seg_hi[DOF_SEG_GMM] = p->param_total;
+  p->seg_lo[DOF_SEG_HEADS] = p->param_total;
+  add_param(p, "latent_space.encoder_mean.weight", (int64_t)L * L, &p->mean_w);
+  add_param(p, "latent_space.encoder_mean.bias", L, &p->mean_b);
+  add_param(p, "latent_space.encoder_log_var.weight", (int64_t)L * L, &p->lv_w);
+  add_param(p, "latent_space.encoder_log_var.bias", L, &p->lv_b);
+  add_param(p, "latent_space.lens.weight", (int64_t)L * L, &p->lens_w);  // never used (lens_enabled=False)
+  add_param(p, "latent_space.lens.bias", L, &p->lens_b);
+  p->seg_hi[DOF_SEG_HEADS] = p->param_total;
+}
+
+// M[r][m] = Lap[r][m] * sum_o I(r,o) I(m,o) d[o]  ->  triplets (r, m, o, Lap[r][m])
+void build_triplets(DofVadePlan* p, const float* lap, const float* elap, const float* inc) {
+  const int N = p->N, E = p->E;
+  struct Tr { int r, m, o; float c; };
+  for (int s = 0; s < 2; ++s) {
+    const int G = s == 0 ? N : E, Go = s == 0 ? E : N;
+    std::vector<Tr> all;
+    for (int r = 0; r < G; ++r)
+      for (int m = 0; m < G; ++m) {
+        const float lv = s == 0 ? lap[r * N + m] : elap[r * E + m];
+        if (lv == 0.0f) continue;
+        for (int o = 0; o < Go; ++o) {
+          // incidence is (N,E): node update pairs nodes through edges, edge update pairs edges through nodes
+          const float ir = s == 0 ? inc[r * E + o] : inc[o * E + r];
+          const float im = s == 0 ? inc[m * E + o] : inc[o * E + m];
+          if (ir * im != 0.0f) all.push_back({r, m, o, lv * ir * im});
+        }
+      }
+    auto fill = [&](TripHost& th, int nkeys, int key_field) {
+      th.ptr.assign(nkeys + 1, 0);
+      for (const Tr& t : all) th.ptr[(key_field == 0 ? t.r : key_field == 1 ? t.m : t.o) + 1]++;
+      for (int i = 0; i < nkeys; ++i) th.ptr[i + 1] += th.ptr[i];
+      std::vector<int> cur(th.ptr.begin(), th.ptr.end() - 1);
+      th.m.resize(all.size()); th.o.resize(all.size()); th.r.resize(all.size()); th.coef.resize(all.size());
+      for (const Tr& t : all) {
+        const int k = key_field == 0 ? t.r : key_field == 1 ? t.m : t.o;
+        const int at = cur[k]++;
+        th.m[at] = t.m; th.o[at] = t.o; th.r[at] = t.r; th.coef[at] = t.c;
+      }
+    };
+    fill(p->tri[s][0], G, 0);
+    fill(p->tri[s][1], G, 1);
+    // by-o lists of stream s's update are keyed by elements of the OTHER stream: store them there
+    fill(p->tri[1 - s][2], Go, 2);
+  }
+}
+
+void build_workspace_layout(DofVadePlan* p) {
+  const int L = p->L, T = p->T, K = p->K, S = p->S;
+  Carver cv;
+  for (int s = 0; s < 2; ++s) {
+    StreamWs& w = p->sw[s];
+    w.G = s == 0 ? p->N : p->E;
+    w.F = s == 0 ? 3 : 1;
+    w.S = p->B * w.G;
+    w.Sp = dof_pad64(w.S);
+    const int64_t Sp = w.Sp;
+    w.xs = cv.take((int64_t)T * w.F * Sp);
+    w.c = cv.take((int64_t)T * 2 * L * Sp);
+    w.len = cv.take(Sp);
+    w.o1 = cv.take((int64_t)T * 4 * L * Sp);
+    w.g1 = cv.take(2LL * T * 8 * L * Sp);
+    w.n1 = cv.take((int64_t)T * 4 * L * Sp);
+    w.o2 = cv.take((int64_t)T * 2 * L * Sp);
+    w.g2 = cv.take(2LL * T * 4 * L * Sp);
+    w.hf = cv.take(2LL * L * Sp);
+    w.n2 = cv.take(2LL * L * Sp);
+    w.dn2 = cv.take(2LL * L * Sp);
+    w.dhf = cv.take(2LL * L * Sp);
+    w.dn1x = cv.take(2LL * T * 4 * L * Sp);
+    w.do1 = cv.take((int64_t)T * 4 * L * Sp);
+    w.dc = cv.take(2LL * T * 2 * L * Sp);
+    w.dots = cv.take(Sp);
+    w.Y = cv.take(2LL * L * Sp);
+    w.Z = cv.take((int64_t)L * Sp);
+    w.dZ = cv.take((int64_t)L * Sp);
+    w.dY = cv.take(2LL * L * Sp);
+    w.dd = cv.take(Sp);
+    w.ln1_blocks = dof_ln_bwd_blocks(T, w.S);
+    w.ln2_blocks = dof_ln_bwd_blocks(1, w.S);
+    w.ln1p = cv.take(w.ln1_blocks * 8 * L);
+    w.ln2p = cv.take(w.ln2_blocks * 4 * L);
+    for (int k = 0; k < 3; ++k) {
+      const TripHost& th = p->tri[s][k];
+      int64_t* dst = k == 0 ? w.tri_r : k == 1 ? w.tri_m : w.tri_o;
+      dst[0] = cv.take((int64_t)th.ptr.size());
+      dst[1] = cv.take((int64_t)th.m.size() + 1);
+      dst[2] = cv.take((int64_t)th.o.size() + 1);
+      dst[3] = cv.take((int64_t)th.r.size() + 1);
+      dst[4] = cv.take((int64_t)th.coef.size() + 1);
+    }
+  }
+  const int64_t Bp = p->Bp;
+  p->flat = cv.take((int64_t)p->J * Bp);
+  p->enc = cv.take((int64_t)L * Bp);
+  p->mu = cv.take((int64_t)L * Bp);
+  p->pre = cv.take((int64_t)L * Bp);
+  p->sv = cv.take((int64_t)L * Bp);
+  p->z = cv.take((int64_t)L * Bp);
+  p->q = cv.take((int64_t)K * Bp);
+  p->qn = cv.take((int64_t)K * Bp);
+  p->dlogit = cv.take((int64_t)K * Bp);
+  p->dmu_dpre = cv.take(2LL * L * Bp);
+  p->denc = cv.take((int64_t)L * Bp);
+  p->dflat = cv.take((int64_t)p->J * Bp);
+  p->gram = cv.take(L * L);
+  p->Pm = cv.take(L * L);
+  p->km = cv.take(1);
+  p->stats = cv.take((int64_t)K * (L + 1) + 3);
+  p->dqbar = cv.take(K);
+  p->dcen = cv.take((int64_t)K * L);
+  p->scal = cv.take(8);
+  p->mterm = cv.take((int64_t)S * Bp);
+  p->mlse = cv.take((int64_t)S * Bp);
+  p->mdz = cv.take((int64_t)S * L * Bp);
+  p->mckl_blocks = dof_cdiv((int64_t)S * p->B, 256);
+  p->lat_blocks = dof_cdiv(p->B, 256);
+  p->tail_blocks = dof_cdiv((int64_t)T * p->B, 256);
+  p->mckl_partial = cv.take(p->mckl_blocks);
+  p->distill_partial = cv.take(p->lat_blocks);
+  p->recon_partial = cv.take(p->tail_blocks);
+  p->valid = cv.take((int64_t)T * Bp);
+  p->len_d = cv.take(Bp);
+  p->o1d = cv.take((int64_t)T * 2 * L * Bp);
+  p->g1d = cv.take(2LL * T * 4 * L * Bp);
+  p->n1d = cv.take((int64_t)T * 2 * L * Bp);
+  p->o2d = cv.take((int64_t)T * 4 * L * Bp);
+  p->g2d = cv.take(2LL * T * 8 * L * Bp);
+  p->n2d = cv.take((int64_t)T * 4 * L * Bp);
+  p->cv = cv.take((int64_t)T * 2 * L * Bp);
+  p->n3 = cv.take((int64_t)T * 2 * L * Bp);
+  p->dloc = cv.take((int64_t)T * p->C3 * Bp);
+  p->dcv = cv.take((int64_t)T * 2 * L * Bp);
+  p->dn2d = cv.take((int64_t)T * 4 * L * Bp);
+  p->do2d = cv.take((int64_t)T * 4 * L * Bp);
+  p->dn1dx = cv.take(2LL * T * 2 * L * Bp);
+  p->do1d = cv.take((int64_t)T * 2 * L * Bp);
+  p->dzdec = cv.take(2LL * L * Bp);
+  p->lnd_blocks = dof_ln_bwd_blocks(T, p->B);
+  p->ln3p = cv.take(p->tail_blocks * 4 * L);
+  p->lnd2p = cv.take(p->lnd_blocks * 8 * L);
+  p->lnd1p = cv.take(p->lnd_blocks * 4 * L);
+  // tables: sized generously (counts are fixed small numbers)
+  p->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
+  p->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
+  p->gram_jobs_tab = cv.take((int64_t)(sizeof(DofOuterJob) / 4 + 1));
+  p->gram_fin_tab = cv.take((int64_t)(sizeof(DofFinJob) / 4 + 1));
+  p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
+  p->ws_floats = cv.cur;  // the partial-tile region is appended by finish_workspace_layout()
+}
+
+// ---- weight-gradient job tables (need the bound workspace pointer) ----------------------------
+struct JobBuilder {
+  std::vector<DofOuterJob>& jobs;
+  std::vector<DofFinJob>& fins;
+  int64_t partial_cur = 0;
+  int blk_cur = 0, elem_cur = 0;
+  int add_job(const float* a, int64_t ats, int64_t acs, int rows, int T, int64_t Sp) {
+    DofOuterJob j;
+    memset(&j, 0, sizeof(j));
+    j.a_ptr = a; j.a_tstride = ats; j.a_cstride = acs; j.a_rows = rows; j.T = T; j.Sp = Sp; j.n_tiles = 0;
+    const int64_t units = (int64_t)T * (Sp / 16);
+    int64_t nb = (units + 31) / 32;
+    if (nb < 1) nb = 1;
+    if (nb > 256) nb = 256;
+    j.nblk = (int)nb; j.blk0 = blk_cur; j.partial_off = partial_cur;
+    blk_cur += j.nblk;
+    partial_cur += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
+    jobs.push_back(j);
+    return (int)jobs.size() - 1;
+  }
+  int add_tile(int job, const float* ptr, int64_t ts, int64_t cs, int nc, int shift) {
+    DofOuterJob& j = jobs[job];
+    DofOuterTile& t = j.tile[j.n_tiles];
+    t.ptr = ptr; t.t_stride = ts; t.c_stride = cs; t.nc = nc; t.shift = shift;
+    return j.n_tiles++;
+  }
+  void add_fin(int job, int col0, int rows, int cols, int r1, int r2, int64_t dst, int64_t rs, int64_t cs) {
+    DofFinJob f;
+    f.job = job; f.col0 = col0; f.rows = rows; f.cols = cols; f.r1 = r1; f.r2 = r2;
+    f.dst_off = dst; f.row_stride = rs; f.col_stride = cs; f.elem0 = elem_cur;
+    elem_cur += rows * cols;
+    fins.push_back(f);
+  }
+};
+
+// One bidirectional GRU layer: per direction A = dG (4*HID rows), tiles = input channels + h_prev.
+void gru_jobs(JobBuilder& jb, const float* dG, const float* X, int64_t x_ts, int IN, const float* O, int HID, int T,
+              int64_t Sp, const GruOff& g) {
+  for (int d = 0; d < 2; ++d) {
+    const float* a = dG + (int64_t)d * T * 4 * HID * Sp;
+    const int job = jb.add_job(a, 4LL * HID * Sp, Sp, 4 * HID, T, Sp);
+    for (int c0 = 0; c0 < IN; c0 += 16)
+      jb.add_tile(job, X + (int64_t)c0 * Sp, x_ts, Sp, IN - c0 < 16 ? IN - c0 : 16, 0);
+    const int hh = jb.add_tile(job, O + (int64_t)d * HID * Sp, 2LL * HID * Sp, Sp, HID, d == 0 ? -1 : +1);
+    jb.add_fin(job, 0, 3 * HID, IN, 3 * HID, 3 * HID, g.t[d * 4 + 0], IN, 1);            // weight_ih
+    jb.add_fin(job, hh * 16, 3 * HID, HID, 2 * HID, 3 * HID, g.t[d * 4 + 1], HID, 1);    // weight_hh (r,z,hn rows)
+    jb.add_fin(job, 64, 3 * HID, 1, 3 * HID, 3 * HID, g.t[d * 4 + 2], 1, 1);             // bias_ih
+    jb.add_fin(job, 64, 3 * HID, 1, 2 * HID, 3 * HID, g.t[d * 4 + 3], 1, 1);             // bias_hh
+  }
+}
+
+void build_jobs(DofVadePlan* p) {
+  const int L = p->L, T = p->T;
+  float* ws = p->ws;
+  p->jobs.clear(); p->fins.clear(); p->gram_jobs.clear(); p->gram_fins.clear();
+  JobBuilder jb{p->jobs, p->fins};
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const BlockOff& b = p->blk[s];
+    const int64_t Sp = w.Sp;
+    const int C1 = 2 * L;
+    // encoder conv: dW[o][f][k] = sum dc[t][o] * xs[t+k-2][f]
+    for (int k0 = 0; k0 < 5; k0 += 4) {
+      const int job = jb.add_job(ws + w.dc, (int64_t)C1 * Sp, Sp, C1, T, Sp);
+      for (int k = k0; k < 5 && k < k0 + 4; ++k) {
+        const int tl = jb.add_tile(job, ws + w.xs, (int64_t)w.F * Sp, Sp, w.F, k - 2);
+        jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
+      }
+    }
+    gru_jobs(jb, ws + w.g1, ws + w.c, (int64_t)C1 * Sp, C1, ws + w.o1, C1, T, Sp, b.g1);
+    gru_jobs(jb, ws + w.g2, ws + w.n1, 4LL * L * Sp, 4 * L, ws + w.o2, L, T, Sp, b.g2);
+    // CensNet: kernel (D,L) = sum Y ⊗ dZ ; bias = rowsum dZ ; dot weights (D,1) = sum X ⊗ dd
+    const int64_t kern = s == 0 ? p->c_nk : p->c_ek, bias = s == 0 ? p->c_nb : p->c_eb;
+    const int64_t dotw = s == 0 ? p->c_nw : p->c_ew;
+    int job = jb.add_job(ws + w.Y, 0, Sp, 2 * L, 1, Sp);
+    jb.add_tile(job, ws + w.dZ, 0, Sp, L, 0);
+    jb.add_fin(job, 0, 2 * L, L, 2 * L, 2 * L, kern, L, 1);
+    job = jb.add_job(ws + w.dZ, 0, Sp, L, 1, Sp);
+    jb.add_tile(job, ws + w.dZ, 0, Sp, 1, 0);
+    jb.add_fin(job, 64, L, 1, L, L, bias, 1, 1);
+    job = jb.add_job(ws + w.n2, 0, Sp, 2 * L, 1, Sp);
+    jb.add_tile(job, ws + w.dd, 0, Sp, 1, 0);
+    jb.add_fin(job, 0, 2 * L, 1, 2 * L, 2 * L, dotw, 1, 1);
+  }
+  const int64_t Bp = p->Bp;
+  // final dense (L,J): A = flat rows (<=64 per job), B = denc
+  for (int r0 = 0; r0 < p->J; r0 += 64) {
+    const int rows = p->J - r0 < 64 ? p->J - r0 : 64;
+    const int job = jb.add_job(ws + p->flat + (int64_t)r0 * Bp, 0, Bp, rows, 1, Bp);
+    jb.add_tile(job, ws + p->denc, 0, Bp, L, 0);
+    jb.add_fin(job, 0, rows, L, rows, rows, p->fd_w + r0, 1, p->J);
+  }
+  {
+    int job = jb.add_job(ws + p->denc, 0, Bp, L, 1, Bp);
+    jb.add_tile(job, ws + p->denc, 0, Bp, 1, 0);
+    jb.add_fin(job, 64, L, 1, L, L, p->fd_b, 1, 1);
+    job = jb.add_job(ws + p->dmu_dpre, 0, Bp, 2 * L, 1, Bp);
+    jb.add_tile(job, ws + p->enc, 0, Bp, L, 0);
+    jb.add_fin(job, 0, L, L, L, L, p->mean_w, L, 1);
+    jb.add_fin(job, 0, L, L, 0, L, p->lv_w, L, 1);
+    jb.add_fin(job, 64, L, 1, L, L, p->mean_b, 1, 1);
+    jb.add_fin(job, 64, L, 1, 0, L, p->lv_b, 1, 1);
+  }
+  // decoder
+  gru_jobs(jb, ws + p->g1d, ws + p->z, 0, L, ws + p->o1d, L, T, Bp, p->dg1);
+  gru_jobs(jb, ws + p->g2d, ws + p->n1d, 2LL * L * Bp, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2);
+  {
+    const int CI = 4 * L, CO = 2 * L;
+    int job = -1;
+    for (int k = 0; k < 5; ++k)
+      for (int c0 = 0; c0 < CI; c0 += 16) {
+        if (job < 0 || p->jobs[job].n_tiles == 4) job = jb.add_job(ws + p->dcv, (int64_t)CO * Bp, Bp, CO, T, Bp);
+        const int nc = CI - c0 < 16 ? CI - c0 : 16;
+        const int tl = jb.add_tile(job, ws + p->n2d + (int64_t)c0 * Bp, (int64_t)CI * Bp, Bp, nc, k - 2);
+        jb.add_fin(job, tl * 16, CO, nc, CO, CO, p->dconv + (int64_t)c0 * 5 + k, (int64_t)CI * 5, 5);
+      }
+    for (int r0 = 0; r0 < p->C3; r0 += 64) {
+      const int rows = p->C3 - r0 < 64 ? p->C3 - r0 : 64;
+      job = jb.add_job(ws + p->dloc + (int64_t)r0 * Bp, (int64_t)p->C3 * Bp, Bp, rows, T, Bp);
+      jb.add_tile(job, ws + p->n3, (int64_t)CO * Bp, Bp, CO, 0);
+      jb.add_fin(job, 0, rows, CO, rows, rows, p->dpw + (int64_t)r0 * CO, CO, 1);
+      jb.add_fin(job, 64, rows, 1, rows, rows, p->dpb + r0, 1, 1);
+    }
+  }
+  p->total_blocks = jb.blk_cur;
+  p->fin_elems = jb.elem_cur;
+  // Gram of the latent batch (forward-time launch of the same kernel)
+  JobBuilder gb{p->gram_jobs, p->gram_fins};
+  gb.partial_cur = 0;
+  const int gj = gb.add_job(ws + p->z, 0, Bp, L, 1, Bp);
+  gb.add_tile(gj, ws + p->z, 0, Bp, L, 0);
+  gb.add_fin(gj, 0, L, L, L, L, p->gram, L, 1);
+  p->gram_blocks = gb.blk_cur;
+  p->gram_fin_elems = gb.elem_cur;
+}
+
+// partial tiles of the weight-gradient reduction: sized from a dry enumeration of the jobs
+void finish_workspace_layout(DofVadePlan* p) {
+  p->ws = nullptr;
+  build_jobs(p);  // pointers are meaningless here; only block counts matter
+  int64_t need = 0;
+  for (const DofOuterJob& j : p->jobs) need += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
+  for (const DofOuterJob& j : p->gram_jobs) {
+    const int64_t g = (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
+    if (g > need) need = g;
+  }
+  p->partials = p->ws_floats;
+  p->ws_floats += (need + 63) / 64 * 64;
+}
+
+DofGruW gru_w(const float* params, const GruOff& g) {
+  DofGruW w;
+  w.wih0 = params + g.t[0]; w.whh0 = params + g.t[1]; w.bih0 = params + g.t[2]; w.bhh0 = params + g.t[3];
+  w.wih1 = params + g.t[4]; w.whh1 = params + g.t[5]; w.bih1 = params + g.t[6]; w.bhh1 = params + g.t[7];
+  return w;
+}
+
+DofTriplets trip_dev(const float* ws, const int64_t* t) {
+  DofTriplets d;
+  d.ptr = reinterpret_cast<const int*>(ws + t[0]);
+  d.m = reinterpret_cast<const int*>(ws + t[1]);
+  d.o = reinterpret_cast<const int*>(ws + t[2]);
+  d.r = reinterpret_cast<const int*>(ws + t[3]);
+  d.coef = ws + t[4];
+  return d;
+}
+
+#define LDISPATCH(L, CALL)                         \
+  switch (L) {                                     \
+    case 4: { constexpr int LL = 4; CALL; } break; \
+    case 6: { constexpr int LL = 6; CALL; } break; \
+    case 8: { constexpr int LL = 8; CALL; } break; \
+    default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
+  }
+
+// ---- forward pieces -----------------------------------------------------------------------------
+int encoder_forward(DofVadePlan* p, const float* params, const float* x, const float* a, bool train,
+                    hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T;
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const BlockOff& b = p->blk[s];
+    int* len = reinterpret_cast<int*>(ws + w.len);
+    TRY(dof_launch_enc_conv_fwd(L, w.F, s == 0 ? x : a, params + b.conv, ws + w.xs, ws + w.c, len, T, w.G, w.S, w.Sp, st));
+    TRY(dof_launch_gru_fwd(L, 0, ws + w.c, len, gru_w(params, b.g1), ws + w.o1, train ? ws + w.g1 : nullptr, T, w.S, w.Sp, st));
+    TRY(dof_launch_ln_fwd(L, 4, ws + w.o1, params + b.n1w, params + b.n1b, ws + w.n1, T, w.S, w.Sp, st));
+    TRY(dof_launch_gru_fwd(L, 1, ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, train ? ws + w.g2 : nullptr, T, w.S, w.Sp, st));
+    TRY(dof_launch_enc_final_fwd(L, ws + w.o2, len, params + b.n2w, params + b.n2b, ws + w.hf, ws + w.n2, T, w.S, w.Sp, st));
+  }
+  // CensNet: node update is weighted by edge dot products (edge_weights) and vice versa
+  const StreamWs& wn = p->sw[0];
+  const StreamWs& we = p->sw[1];
+  LDISPATCH(L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(wn.S, 256)), (256), st, (const float*)(ws + wn.n2),
+                          params + p->c_nw, ws + wn.dots, wn.S, wn.Sp));
+  LDISPATCH(L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(we.S, 256)), (256), st, (const float*)(ws + we.n2),
+                          params + p->c_ew, ws + we.dots, we.S, we.Sp));
+  CensStream cs[2];
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const StreamWs& o = p->sw[1 - s];
+    cs[s].X = ws + w.n2; cs[s].dots = ws + o.dots; cs[s].tri = trip_dev(ws, w.tri_r);
+    cs[s].kern = params + (s == 0 ? p->c_nk : p->c_ek); cs[s].bias = params + (s == 0 ? p->c_nb : p->c_eb);
+    cs[s].Y = ws + w.Y; cs[s].Z = ws + w.Z; cs[s].G = w.G; cs[s].G_other = o.G; cs[s].S = w.S; cs[s].Sp = w.Sp;
+    cs[s].flat_row0 = s == 0 ? 0 : p->N * L;
+  }
+  const int64_t smax = wn.S > we.S ? wn.S : we.S;
+  LDISPATCH(L, DOF_LAUNCH((k_cens_fwd<LL>), (dof_cdiv(smax, 256), 2), (256), st, cs[0], cs[1], ws + p->flat, p->Bp));
+  return dof_check_launch("censnet forward");
+}
+
+int latent_forward(DofVadePlan* p, const float* params, const float* prior, const float* eps, float* z_out,
+                   float* q_out, float* mu_out, float* sv_out, float* enc_out, hipStream_t st) {
+  float* ws = p->ws;
+  LatentFwdArgs A;
+  A.flat = ws + p->flat; A.J = p->J;
+  A.wf = params + p->fd_w; A.bf = params + p->fd_b; A.wm = params + p->mean_w; A.bm = params + p->mean_b;
+  A.ws = params + p->lv_w; A.bs = params + p->lv_b;
+  A.gmm_means = params + p->gmm_m; A.gmm_log_vars = params + p->gmm_lv; A.prior = prior; A.eps = eps;
+  A.enc = ws + p->enc; A.mu = ws + p->mu; A.pre = ws + p->pre; A.sv = ws + p->sv; A.z = ws + p->z;
+  A.q = ws + p->q; A.qn = ws + p->qn;
+  A.z_out = z_out; A.q_out = q_out; A.mu_out = mu_out; A.sv_out = sv_out; A.enc_out = enc_out;
+  A.K = p->K; A.B = p->B; A.Bp = p->Bp;
+  LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd<LL>), (dof_cdiv(p->B, 256)), (256), st, A));
+  return dof_check_launch("k_latent_fwd");
+}
+
+int decoder_forward(DofVadePlan* p, const float* params, const float* x, bool train, float* loc_out,
+                    hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T;
+  const int64_t B = p->B, Bp = p->Bp;
+  int* len = reinterpret_cast<int*>(ws + p->len_d);
+  DOF_LAUNCH(k_dec_valid, (dof_cdiv(B, 256)), (256), st, x, T, p->C3, B, Bp, ws + p->valid, len);
+  TRY(dof_check_launch("k_dec_valid"));
+  TRY(dof_launch_gru_fwd(L, 2, ws + p->z, len, gru_w(params, p->dg1), ws + p->o1d, train ? ws + p->g1d : nullptr, T, B, Bp, st));
+  TRY(dof_launch_ln_fwd(L, 2, ws + p->o1d, params + p->dn1w, params + p->dn1b, ws + p->n1d, T, B, Bp, st));
+  TRY(dof_launch_gru_fwd(L, 0, ws + p->n1d, len, gru_w(params, p->dg2), ws + p->o2d, train ? ws + p->g2d : nullptr, T, B, Bp, st));
+  TRY(dof_launch_ln_fwd(L, 4, ws + p->o2d, params + p->dn2w, params + p->dn2b, ws + p->n2d, T, B, Bp, st));
+  DecTailArgs A;
+  A.n2 = ws + p->n2d; A.wc = params + p->dconv; A.g3 = params + p->dn3w; A.b3 = params + p->dn3b;
+  A.wp = params + p->dpw; A.bp = params + p->dpb; A.x = x; A.valid = ws + p->valid;
+  A.cv = ws + p->cv; A.n3 = ws + p->n3; A.loc_out = loc_out; A.recon_partial = ws + p->recon_partial;
+  A.dloc = ws + p->dloc; A.dcv = ws + p->dcv; A.ln3_partial = ws + p->ln3p;
+  A.T = T; A.C3 = p->C3; A.train = train ? 1 : 0; A.B = B; A.Bp = Bp;
+  LDISPATCH(L, DOF_LAUNCH((k_dec_tail<LL>), ((unsigned)p->tail_blocks), (256), st, A));
+  return dof_check_launch("k_dec_tail");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int dof_vade_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                    const float* incidence, DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_vade_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  if (dims->batch <= 0 || dims->window < 5 || dims->n_nodes <= 0 || dims->n_edges <= 0 || dims->n_clusters <= 0 ||
+      dims->mc_samples <= 0) {
+    dof_set_error("dof_vade_plan_create: bad dims (batch %d window %d nodes %d edges %d clusters %d)", dims->batch,
+                  dims->window, dims->n_nodes, dims->n_edges, dims->n_clusters);
+    return DOF_ERR_ARG;
+  }
+  if (dims->latent != 4 && dims->latent != 6 && dims->latent != 8) {
+    dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", dims->latent);
+    return DOF_ERR_UNSUPPORTED;
+  }
+  DofVadePlan* p = new DofVadePlan();
+  p->d = *dims;
+  p->L = dims->latent; p->K = dims->n_clusters; p->T = dims->window; p->N = dims->n_nodes; p->E = dims->n_edges;
+  p->S = dims->mc_samples; p->B = dims->batch; p->Bp = dof_pad64(p->B);
+  p->J = (p->N + p->E) * p->L;
+  p->C3 = 3 * p->N;
+  build_param_layout(p);
+  build_triplets(p, laplacian, edge_laplacian, incidence);
+  build_workspace_layout(p);
+  finish_workspace_layout(p);
+  *out = p;
+  return DOF_OK;
+}
+
+extern "C" void dof_vade_plan_destroy(DofVadePlan* plan) { delete plan; }
+extern "C" int32_t dof_vade_param_count(const DofVadePlan* p) { return (int32_t)p->params.size(); }
+extern "C" const char* dof_vade_param_name(const DofVadePlan* p, int32_t i) { return p->params[i].name.c_str(); }
+extern "C" int64_t dof_vade_param_offset(const DofVadePlan* p, int32_t i) { return p->params[i].off; }
+extern "C" int64_t dof_vade_param_numel(const DofVadePlan* p, int32_t i) { return p->params[i].numel; }
+extern "C" int64_t dof_vade_param_total(const DofVadePlan* p) { return p->param_total; }
+extern "C" int64_t dof_vade_workspace_bytes(const DofVadePlan* p) { return p->ws_floats * 4; }
+
+extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
+  if (!p || !workspace) {
+    dof_set_error("dof_vade_bind: null argument");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  p->ws = static_cast<float*>(workspace);
+  if (hipMemsetAsync(workspace, 0, (size_t)p->ws_floats * 4, st) != hipSuccess) {
+    dof_set_error("dof_vade_bind: memset failed");
+    return DOF_ERR_LAUNCH;
+  }
+  build_jobs(p);
+  if (p->jobs.size() > 96 || p->fins.size() > 512) {
+    dof_set_error("dof_vade_bind: job table overflow (%zu jobs, %zu fins)", p->jobs.size(), p->fins.size());
+    return DOF_ERR_STATE;
+  }
+  float* ws = p->ws;
+  auto up = [&](int64_t off, const void* src, size_t bytes) {
+    if (bytes) hipMemcpyAsync(ws + off, src, bytes, hipMemcpyHostToDevice, st);
+  };
+  up(p->jobs_tab, p->jobs.data(), p->jobs.size() * sizeof(DofOuterJob));
+  up(p->fin_tab, p->fins.data(), p->fins.size() * sizeof(DofFinJob));
+  up(p->gram_jobs_tab, p->gram_jobs.data(), p->gram_jobs.size() * sizeof(DofOuterJob));
+  up(p->gram_fin_tab, p->gram_fins.data(), p->gram_fins.size() * sizeof(DofFinJob));
+  for (int s = 0; s < 2; ++s)
+    for (int k = 0; k < 3; ++k) {
+      const TripHost& th = p->tri[s][k];
+      const int64_t* t = k == 0 ? p->sw[s].tri_r : k == 1 ? p->sw[s].tri_m : p->sw[s].tri_o;
+      up(t[0], th.ptr.data(), th.ptr.size() * 4);
+      up(t[1], th.m.data(), th.m.size() * 4);
+      up(t[2], th.o.data(), th.o.size() * 4);
+      up(t[3], th.r.data(), th.r.size() * 4);
+      up(t[4], th.coef.data(), th.coef.size() * 4);
+    }
+  DofAdamSeg segs[DOF_SEG_COUNT];
+  for (int i = 0; i < DOF_SEG_COUNT; ++i) {
+    segs[i].lo = p->seg_lo[i]; segs[i].hi = p->seg_hi[i];
+    segs[i].lr_index = DOF_H_LR0 + i; segs[i].bc_index = DOF_H_BC0 + 2 * i; segs[i].active_index = DOF_H_ACTIVE0 + i;
+  }
+  static thread_local DofAdamSeg seg_keep[DOF_SEG_COUNT];  // source must outlive the async copy
+  memcpy(seg_keep, segs, sizeof(segs));
+  up(p->segs_tab, seg_keep, sizeof(segs));
+  return dof_check_launch("dof_vade_bind");
+}
+
+extern "C" int dof_vade_forward(DofVadePlan* p, const float* params, const float* prior, const float* x,
+                                const float* a, const float* eps, float* z_out, float* q_out, float* zmean_out,
+                                float* zlogvar_out, float* loc_out, float* enc_out, void* stream) {
+  if (!p || !p->ws) {
+    dof_set_error("dof_vade_forward: plan not bound to a workspace");
+    return DOF_ERR_STATE;
+  }
+  if (!params || !prior || !x || !a) {
+    dof_set_error("dof_vade_forward: null argument");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  TRY(encoder_forward(p, params, x, a, false, st));
+  TRY(latent_forward(p, params, prior, eps, z_out, q_out, zmean_out, zlogvar_out, enc_out, st));
+  if (loc_out) TRY(decoder_forward(p, params, x, false, loc_out, st));
+  return DOF_OK;
+}
+
+extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const float* prior, const float* x,
+                                   const float* a, const float* eps, const float* eps_mc, const float* tau,
+                                   const float* teacher, const float* hyper, int32_t pretrain, float* grads,
+                                   float* logs, void* stream) {
+  if (!p || !p->ws) {
+    dof_set_error("dof_vade_loss_grads: plan not bound to a workspace");
+    return DOF_ERR_STATE;
+  }
+  if (!params || !prior || !x || !a || !eps || !hyper || !grads || !logs || (!pretrain && !eps_mc)) {
+    dof_set_error("dof_vade_loss_grads: null argument");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = p->ws;
+  const int L = p->L, T = p->T, K = p->K;
+  const int64_t B = p->B, Bp = p->Bp;
+  if (hipMemsetAsync(grads, 0, (size_t)p->param_total * 4, st) != hipSuccess) return DOF_ERR_LAUNCH;
+
+  // ---------------- forward
+  TRY(encoder_forward(p, params, x, a, true, st));
+  TRY(latent_forward(p, params, prior, eps, nullptr, nullptr, nullptr, nullptr, nullptr, st));
+  const DofOuterJob* gjobs = reinterpret_cast<const DofOuterJob*>(ws + p->gram_jobs_tab);
+  const DofFinJob* gfins = reinterpret_cast<const DofFinJob*>(ws + p->gram_fin_tab);
+  TRY(dof_launch_outer(gjobs, 1, p->gram_blocks, ws + p->partials, st));
+  TRY(dof_launch_outer_finalize(gjobs, gfins, 1, p->gram_fin_elems, ws + p->partials, ws, st));
+  LDISPATCH(L, DOF_LAUNCH((k_kmeans_eig<LL>), (1), (64), st, (const float*)(ws + p->gram), hyper, B, ws + p->km, ws + p->Pm));
+  TRY(dof_check_launch("k_kmeans_eig"));
+  TRY(decoder_forward(p, params, x, true, nullptr, st));
+
+  // ---------------- decoder backward
+  LDISPATCH(L, DOF_LAUNCH((k_dec_conv_bwd<LL>), ((unsigned)p->tail_blocks), (256), st, (const float*)(ws + p->dcv),
+                          params + p->dconv, ws + p->dn2d, T, B, Bp));
+  TRY(dof_check_launch("k_dec_conv_bwd"));
+  const int* len_d = reinterpret_cast<const int*>(ws + p->len_d);
+  TRY(dof_launch_ln_bwd(L, 4, ws + p->o2d, ws + p->dn2d, nullptr, params + p->dn2w, ws + p->do2d, ws + p->lnd2p, T, B, Bp, st));
+  TRY(dof_launch_gru_bwd(L, 0, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d, nullptr, ws + p->dn1dx, T, B, Bp, st));
+  TRY(dof_launch_ln_bwd(L, 2, ws + p->o1d, ws + p->dn1dx, ws + p->dn1dx + (int64_t)T * 2 * L * Bp, params + p->dn1w,
+                        ws + p->do1d, ws + p->lnd1p, T, B, Bp, st));
+  TRY(dof_launch_gru_bwd(L, 2, len_d, gru_w(params, p->dg1), ws + p->o1d, ws + p->g1d, ws + p->do1d, nullptr, ws + p->dzdec, T, B, Bp, st));
+
+  // ---------------- batch-level loss terms
+  StatsArgs SA;
+  SA.qn = ws + p->qn; SA.z = ws + p->z; SA.mu = ws + p->mu; SA.sv = ws + p->sv; SA.tau = tau;
+  SA.class_weight = teacher; SA.hyper = hyper; SA.stats = ws + p->stats; SA.K = K; SA.B = B; SA.Bp = Bp;
+  LDISPATCH(L, DOF_LAUNCH((k_batch_stats<LL>), ((unsigned)(K + 1)), (256), st, SA));
+  TRY(dof_check_launch("k_batch_stats"));
+  if (!pretrain) {
+    McklArgs MA;
+    MA.mu = ws + p->mu; MA.sv = ws + p->sv; MA.eps_mc = eps_mc; MA.gmm_means = params + p->gmm_m;
+    MA.gmm_log_vars = params + p->gmm_lv; MA.prior = prior; MA.hyper = hyper; MA.term = ws + p->mterm;
+    MA.lse = ws + p->mlse; MA.dz = ws + p->mdz; MA.K = K; MA.S = p->S; MA.B = B; MA.Bp = Bp;
+    LDISPATCH(L, DOF_LAUNCH((k_mckl_fwd<LL>), ((unsigned)p->mckl_blocks), (256), st, MA));
+    TRY(dof_check_launch("k_mckl_fwd"));
+    DOF_LAUNCH(k_block_sum, ((unsigned)p->mckl_blocks), (256), st, (const float*)(ws + p->mterm), p->S, B, Bp, ws + p->mckl_partial);
+    TRY(dof_check_launch("k_block_sum"));
+  }
+  LossMidArgs LM;
+  LM.stats = ws + p->stats; LM.recon_partial = ws + p->recon_partial; LM.n_recon = (int)p->tail_blocks;
+  LM.mckl_partial = ws + p->mckl_partial; LM.n_mckl = (int)p->mckl_blocks; LM.km = ws + p->km;
+  LM.teacher_marginal = teacher ? teacher + K : nullptr; LM.hyper = hyper; LM.dqbar = ws + p->dqbar;
+  LM.dcen = ws + p->dcen; LM.scal = ws + p->scal; LM.logs = logs; LM.K = K; LM.L = L; LM.S = p->S; LM.T = T;
+  LM.pretrain = pretrain ? 1 : 0; LM.B = B;
+  DOF_LAUNCH(k_loss_mid, (1), (64), st, LM);
+  TRY(dof_check_launch("k_loss_mid"));
+
+  // ---------------- latent backward
+  LatentBwdArgs LB;
+  LB.enc = ws + p->enc; LB.mu = ws + p->mu; LB.pre = ws + p->pre; LB.sv = ws + p->sv; LB.z = ws + p->z;
+  LB.q = ws + p->q; LB.qn = ws + p->qn; LB.eps = eps; LB.eps_mc = eps_mc; LB.mckl_dz = ws + p->mdz;
+  LB.dz_dec = ws + p->dzdec; LB.wf = params + p->fd_w; LB.wm = params + p->mean_w; LB.ws = params + p->lv_w;
+  LB.gmm_means = params + p->gmm_m; LB.gmm_log_vars = params + p->gmm_lv; LB.Pm = ws + p->Pm; LB.dcen = ws + p->dcen;
+  LB.dqbar = ws + p->dqbar; LB.scal = ws + p->scal; LB.hyper = hyper; LB.tau = tau; LB.class_weight = teacher;
+  LB.dmu_dpre = ws + p->dmu_dpre; LB.denc = ws + p->denc; LB.dlogit = ws + p->dlogit; LB.dflat = ws + p->dflat;
+  LB.distill_partial = ws + p->distill_partial; LB.J = p->J; LB.K = K; LB.S = p->S; LB.pretrain = pretrain ? 1 : 0;
+  LB.B = B; LB.Bp = Bp;
+  LDISPATCH(L, DOF_LAUNCH((k_latent_bwd<LL>), ((unsigned)p->lat_blocks), (256), st, LB));
+  TRY(dof_check_launch("k_latent_bwd"));
+  DOF_LAUNCH(k_loss_total, (1), (64), st, (const float*)(ws + p->distill_partial), (int)p->lat_blocks, hyper, B, logs);
+  TRY(dof_check_launch("k_loss_total"));
+  GmmGradArgs GG;
+  GG.z = ws + p->z; GG.dlogit = ws + p->dlogit; GG.mu = ws + p->mu; GG.sv = ws + p->sv; GG.eps_mc = eps_mc;
+  GG.lse = ws + p->mlse; GG.gmm_means = params + p->gmm_m; GG.gmm_log_vars = params + p->gmm_lv; GG.prior = prior;
+  GG.scal = ws + p->scal; GG.hyper = hyper; GG.g_means = grads + p->gmm_m; GG.g_log_vars = grads + p->gmm_lv;
+  GG.K = K; GG.S = p->S; GG.pretrain = pretrain ? 1 : 0; GG.B = B; GG.Bp = Bp;
+  LDISPATCH(L, DOF_LAUNCH((k_gmm_grads<LL>), ((unsigned)K), (256), st, GG));
+  TRY(dof_check_launch("k_gmm_grads"));
+
+  // ---------------- CensNet backward
+  CensBwdStream cb[2];
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const StreamWs& o = p->sw[1 - s];
+    cb[s].X = ws + w.n2; cb[s].dots = ws + o.dots; cb[s].Z = ws + w.Z;
+    cb[s].kern = params + (s == 0 ? p->c_nk : p->c_ek); cb[s].pw = params + (s == 0 ? p->c_nw : p->c_ew);
+    cb[s].dZ = ws + w.dZ; cb[s].dY = ws + w.dY; cb[s].by_m = trip_dev(ws, w.tri_m); cb[s].oth_by_o = trip_dev(ws, w.tri_o);
+    cb[s].X_oth = ws + o.n2; cb[s].dY_oth = ws + o.dY; cb[s].dX = ws + w.dn2; cb[s].dd = ws + w.dd;
+    cb[s].G = w.G; cb[s].G_other = o.G; cb[s].S = w.S; cb[s].Sp = w.Sp; cb[s].Sp_other = o.Sp;
+    cb[s].flat_row0 = s == 0 ? 0 : p->N * L;
+  }
+  const int64_t smax = p->sw[0].S > p->sw[1].S ? p->sw[0].S : p->sw[1].S;
+  LDISPATCH(L, DOF_LAUNCH((k_cens_bwd1<LL>), (dof_cdiv(smax, 256), 2), (256), st, cb[0], cb[1], (const float*)(ws + p->dflat), Bp));
+  TRY(dof_check_launch("k_cens_bwd1"));
+  LDISPATCH(L, DOF_LAUNCH((k_cens_bwd2<LL>), (dof_cdiv(smax, 256), 2), (256), st, cb[0], cb[1]));
+  TRY(dof_check_launch("k_cens_bwd2"));
+
+  // ---------------- encoder backward
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const BlockOff& b = p->blk[s];
+    const int* len = reinterpret_cast<const int*>(ws + w.len);
+    TRY(dof_launch_ln_bwd(L, 2, ws + w.hf, ws + w.dn2, nullptr, params + b.n2w, ws + w.dhf, ws + w.ln2p, 1, w.S, w.Sp, st));
+    TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
+    TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
+                          ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
+    TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
+    TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
+    TRY(dof_launch_sum_partials(ws + w.ln1p, w.ln1_blocks, 8 * L, grads + b.n1w, 0, st));
+    TRY(dof_launch_sum_partials(ws + w.ln2p, w.ln2_blocks, 4 * L, grads + b.n2w, 0, st));
+  }
+  TRY(dof_launch_sum_partials(ws + p->lnd2p, p->lnd_blocks, 8 * L, grads + p->dn2w, 0, st));
+  TRY(dof_launch_sum_partials(ws + p->lnd1p, p->lnd_blocks, 4 * L, grads + p->dn1w, 0, st));
+  TRY(dof_launch_sum_partials(ws + p->ln3p, p->tail_blocks, 4 * L, grads + p->dn3w, 0, st));
+
+  // ---------------- weight gradients (one MFMA reduction launch + fixed-order finalize)
+  const DofOuterJob* jobs = reinterpret_cast<const DofOuterJob*>(ws + p->jobs_tab);
+  const DofFinJob* fins = reinterpret_cast<const DofFinJob*>(ws + p->fin_tab);
+  TRY(dof_launch_outer(jobs, (int)p->jobs.size(), p->total_blocks, ws + p->partials, st));
+  TRY(dof_launch_outer_finalize(jobs, fins, (int)p->fins.size(), p->fin_elems, ws + p->partials, grads, st));
+  return DOF_OK;
+}
+
+extern "C" int dof_optimizer_step(DofVadePlan* p, float* params, const float* grads, float* adam_m, float* adam_v,
+                                  const float* hyper, void* stream) {
+  if (!p || !p->ws) {
+    dof_set_error("dof_optimizer_step: plan not bound to a workspace");
+    return DOF_ERR_STATE;
+  }
+  if (!params || !grads || !adam_m || !adam_v || !hyper) {
+    dof_set_error("dof_optimizer_step: null argument");
+    return DOF_ERR_ARG;
+  }
+  const DofAdamSeg* segs = reinterpret_cast<const DofAdamSeg*>(p->ws + p->segs_tab);
+  return dof_launch_clip_adam(params, grads, adam_m, adam_v, hyper, segs, DOF_SEG_COUNT, p->param_total, DOF_H_CLIP,
+                              (hipStream_t)stream);
+}

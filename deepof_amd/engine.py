@@ -1,0 +1,244 @@
+"""Host-side driver of the libdeepof_hip VaDE step (device memory + streams are PyTorch plumbing).
+
+``VadeEngine`` owns the flat parameter / gradient / Adam buffers and the workspace as torch
+tensors, exposes them under the reference's ``state_dict`` names, and issues the C-ABI calls on
+the current HIP stream.  Product code obtains it through :func:`create_vade_engine`, which
+requires a ROCm device and the compiled ``libdeepof_hip.so`` and raises otherwise -- there is no
+CPU or PyTorch fallback.  (``tests/`` may construct ``VadeEngine`` directly with the pytest-only
+emulator build of the same kernels to check kernel logic in the GPU-less build container.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _capi
+from .graph import censnet_operators
+
+BUFFER_NAMES = ("encoder.laplacian", "encoder.edge_laplacian", "encoder.incidence",
+                "latent_space.prior", "latent_space.pretrain")
+
+
+def _param_shape(name: str, numel: int, N: int, E: int, L: int, K: int):
+    leaf = name.split(".")[-1]
+    if name.endswith("conv1d.weight"):
+        if name.startswith("decoder"):
+            return (2 * L, 4 * L, 5)
+        return (2 * L, 3 if "node_recurrent" in name else 1, 5)
+    if leaf.startswith("weight_ih") or leaf.startswith("weight_hh"):
+        if name.startswith("decoder.gru1"):
+            return (3 * L, L)
+        if name.startswith("decoder.gru2") or ".gru1." in name:
+            return (6 * L, 2 * L)
+        return (3 * L, 4 * L) if leaf.startswith("weight_ih") else (3 * L, L)  # encoder gru2
+    if name.endswith("projection.weight") and "loc_projection" not in name:
+        return (2 * L, 2 * L)
+    if name.endswith("node_kernel") or name.endswith("edge_kernel"):
+        return (2 * L, L)
+    if name.endswith("node_weights") or name.endswith("edge_weights"):
+        return (2 * L, 1)
+    if name == "encoder.final_dense.weight":
+        return (L, (N + E) * L)
+    if name.endswith("loc_projection.weight"):
+        return (3 * N, 2 * L)
+    if name in ("latent_space.gmm_means", "latent_space.gmm_log_vars"):
+        return (K, L)
+    if name.startswith("latent_space.") and leaf == "weight":
+        return (L, L)
+    return (numel,)
+
+
+class VadeEngine:
+    def __init__(self, lib, device, batch: int, window: int, adjacency: np.ndarray, latent_dim: int,
+                 n_clusters: int, mc_samples: int = 32, graph_ops=None):
+        self.lib = lib
+        self.device = torch.device(device)
+        adjacency = np.asarray(adjacency, dtype=np.float32)
+        lap, elap, inc = graph_ops if graph_ops is not None else censnet_operators(adjacency)
+        self.adjacency = adjacency
+        self.lap, self.elap, self.inc = (np.ascontiguousarray(m, dtype=np.float32) for m in (lap, elap, inc))
+        self.N, self.E = self.inc.shape
+        self.B, self.T, self.L, self.K, self.S = int(batch), int(window), int(latent_dim), int(n_clusters), int(mc_samples)
+        dims = _capi.VadeDims(self.B, self.T, self.N, self.E, self.L, self.K, self.S)
+        plan = C.c_void_p()
+        _capi.check(lib, lib.dof_vade_plan_create(C.byref(dims), self.lap.ctypes.data, self.elap.ctypes.data,
+                                                  self.inc.ctypes.data, C.byref(plan)), "dof_vade_plan_create")
+        self.plan = plan
+        self.names = []
+        self.layout: Dict[str, tuple] = {}
+        for i in range(lib.dof_vade_param_count(plan)):
+            name = lib.dof_vade_param_name(plan, i).decode()
+            off, numel = lib.dof_vade_param_offset(plan, i), lib.dof_vade_param_numel(plan, i)
+            self.names.append(name)
+            self.layout[name] = (off, numel, _param_shape(name, numel, self.N, self.E, self.L, self.K))
+        total = lib.dof_vade_param_total(plan)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(total, **f32)
+        self.grads = torch.zeros(total, **f32)
+        self.adam_m = torch.zeros(total, **f32)
+        self.adam_v = torch.zeros(total, **f32)
+        self.prior = torch.full((self.K,), 1.0 / self.K, **f32)
+        self.hyper_host = torch.zeros(_capi.H_COUNT, dtype=torch.float32)
+        self.hyper = torch.zeros(_capi.H_COUNT, **f32)
+        self.logs = torch.zeros(_capi.LOG_COUNT, **f32)
+        self.teacher = torch.zeros(2 * self.K, **f32)
+        self.adam_t = [0] * _capi.SEG_COUNT
+        ws_bytes = lib.dof_vade_workspace_bytes(plan)
+        self.workspace = torch.empty(ws_bytes // 4, **f32)
+        _capi.check(lib, lib.dof_vade_bind(plan, self.workspace.data_ptr(), self._stream()), "dof_vade_bind")
+        self._sync()
+        self.set_hyper(logvar_lo=-8.0, logvar_hi=8.0, clip=0.75, wd=0.0, l1_act=0.1, distill_T=0.5)
+        for s in range(_capi.SEG_COUNT):
+            self.hyper_host[_capi.H_ACTIVE0 + s] = 1.0
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return 0
+
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.dof_vade_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        off, numel, shape = self.layout[name]
+        return (self.params if buf is None else buf)[off:off + numel].view(shape)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Reference-compatible state_dict (parameter order + buffers; models_new.py VaDEPT)."""
+        sd = {"encoder.laplacian": torch.from_numpy(self.lap.copy()),
+              "encoder.edge_laplacian": torch.from_numpy(self.elap.copy()),
+              "encoder.incidence": torch.from_numpy(self.inc.copy())}
+        for n in self.names:
+            if n == "latent_space.encoder_mean.weight":
+                sd["latent_space.prior"] = self.prior.detach().cpu().clone()
+                sd["latent_space.pretrain"] = torch.tensor(0.0)
+            sd[n] = self.view(n).detach().cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        for n in self.names:
+            if n in sd:
+                self.view(n).copy_(torch.as_tensor(sd[n], dtype=torch.float32).reshape(self.layout[n][2]))
+            elif strict:
+                raise KeyError(f"missing parameter {n}")
+        if "latent_space.prior" in sd:
+            self.prior.copy_(torch.as_tensor(sd["latent_space.prior"], dtype=torch.float32))
+
+    _HYPER_IDX = dict(klw=_capi.H_KLW, lambda_distill=_capi.H_LAMBDA_DISTILL, km_latent=_capi.H_KM_LATENT,
+                      km_loss=_capi.H_KM_LOSS, repel_w=_capi.H_REPEL_W, repel_ls=_capi.H_REPEL_LS,
+                      nonempty_w=_capi.H_NONEMPTY_W, nonempty_floor=_capi.H_NONEMPTY_FLOOR,
+                      nonempty_p=_capi.H_NONEMPTY_P, l1_act=_capi.H_L1_ACT, distill_T=_capi.H_DISTILL_T,
+                      conf_w=_capi.H_CONF_W, conf_thr=_capi.H_CONF_THR, has_teacher=_capi.H_HAS_TEACHER,
+                      logvar_lo=_capi.H_LOGVAR_LO, logvar_hi=_capi.H_LOGVAR_HI, clip=_capi.H_CLIP, wd=_capi.H_WD)
+
+    def set_hyper(self, **kw):
+        for k, v in kw.items():
+            self.hyper_host[self._HYPER_IDX[k]] = float(v)
+
+    def set_lr(self, seg: int, lr: float):
+        self.hyper_host[_capi.H_LR0 + seg] = float(lr)
+
+    def set_active(self, seg: int, active: bool):
+        self.hyper_host[_capi.H_ACTIVE0 + seg] = 1.0 if active else 0.0
+
+    def reset_optimizer(self):
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.adam_t = [0] * _capi.SEG_COUNT
+
+    def push_hyper(self):
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+
+    def set_teacher(self, class_weight: Optional[torch.Tensor], marginal: Optional[torch.Tensor]):
+        if class_weight is None:
+            self.set_hyper(has_teacher=0.0)
+            return
+        self.teacher[: self.K].copy_(class_weight.to(torch.float32))
+        self.teacher[self.K:].copy_(marginal.to(torch.float32))
+        self.set_hyper(has_teacher=1.0)
+
+    # ------------------------------------------------------------------ compute
+    def _chk_batch(self, x, a):
+        assert tuple(x.shape) == (self.B, self.T, self.N, 3), (tuple(x.shape), (self.B, self.T, self.N, 3))
+        assert tuple(a.shape) == (self.B, self.T, self.E, 1), tuple(a.shape)
+        assert x.is_contiguous() and a.is_contiguous() and x.dtype == torch.float32 and a.dtype == torch.float32
+        assert x.device == self.params.device and a.device == self.params.device
+
+    def forward(self, x: torch.Tensor, a: torch.Tensor, eps: Optional[torch.Tensor] = None,
+                want_loc: bool = True, want_enc: bool = False) -> Dict[str, torch.Tensor]:
+        """VaDEPT.forward.  eps=None -> eval mode (z = z_mean)."""
+        self._chk_batch(x, a)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        out = {"z": torch.empty(self.B, self.L, **f32), "q": torch.empty(self.B, self.K, **f32),
+               "z_mean": torch.empty(self.B, self.L, **f32), "z_log_var": torch.empty(self.B, self.L, **f32)}
+        if want_loc:
+            out["loc"] = torch.empty(self.B, self.T, 3 * self.N, **f32)
+        if want_enc:
+            out["enc"] = torch.empty(self.B, self.L, **f32)
+        ptr = lambda k: out[k].data_ptr() if k in out else None
+        rc = self.lib.dof_vade_forward(self.plan, self.params.data_ptr(), self.prior.data_ptr(), x.data_ptr(),
+                                       a.data_ptr(), None if eps is None else eps.data_ptr(), ptr("z"), ptr("q"),
+                                       ptr("z_mean"), ptr("z_log_var"), ptr("loc"), ptr("enc"), self._stream())
+        _capi.check(self.lib, rc, "dof_vade_forward")
+        return out
+
+    def loss_grads(self, x, a, eps, eps_mc=None, tau=None, pretrain: bool = True):
+        """Forward + VadeLoss + backward; fills self.grads and self.logs (device)."""
+        self._chk_batch(x, a)
+        assert tuple(eps.shape) == (self.B, self.L) and eps.is_contiguous()
+        if not pretrain:
+            assert eps_mc is not None and tuple(eps_mc.shape) == (self.S, self.B, self.L) and eps_mc.is_contiguous()
+        if tau is not None:
+            assert tuple(tau.shape) == (self.B, self.K) and tau.is_contiguous()
+        rc = self.lib.dof_vade_loss_grads(
+            self.plan, self.params.data_ptr(), self.prior.data_ptr(), x.data_ptr(), a.data_ptr(), eps.data_ptr(),
+            None if eps_mc is None else eps_mc.data_ptr(), None if tau is None else tau.data_ptr(),
+            self.teacher.data_ptr() if self.hyper_host[_capi.H_HAS_TEACHER] != 0 else None,
+            self.hyper.data_ptr(), 1 if pretrain else 0, self.grads.data_ptr(), self.logs.data_ptr(), self._stream())
+        _capi.check(self.lib, rc, "dof_vade_loss_grads")
+
+    def advance_adam(self):
+        """Bump the per-segment Adam step counters (bias corrections live in hyper[])."""
+        for s in range(_capi.SEG_COUNT):
+            if self.hyper_host[_capi.H_ACTIVE0 + s] != 0:
+                self.adam_t[s] += 1
+            t = max(self.adam_t[s], 1)
+            self.hyper_host[_capi.H_BC0 + 2 * s] = 1.0 - 0.9 ** t
+            self.hyper_host[_capi.H_BC0 + 2 * s + 1] = 1.0 - 0.999 ** t
+
+    def optimizer_step(self):
+        rc = self.lib.dof_optimizer_step(self.plan, self.params.data_ptr(), self.grads.data_ptr(),
+                                         self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.hyper.data_ptr(),
+                                         self._stream())
+        _capi.check(self.lib, rc, "dof_optimizer_step")
+
+    def read_logs(self) -> Dict[str, float]:
+        vals = self.logs.detach().cpu().tolist()
+        return {k: vals[i] for i, k in enumerate(_capi.LOG_KEYS)}
+
+
+def create_vade_engine(batch, window, adjacency, latent_dim, n_clusters, mc_samples=32, device=None, graph_ops=None):
+    """Product entry: requires a ROCm GPU and the compiled HIP library (no fallback)."""
+    from ._lib import load_hip_library
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("deepof_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+    lib = load_hip_library()
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    if dev.type != "cuda":
+        raise RuntimeError(f"deepof_amd runs on ROCm devices only, got {dev}")
+    return VadeEngine(lib, dev, batch, window, adjacency, latent_dim, n_clusters, mc_samples, graph_ops)

@@ -1,0 +1,123 @@
+/* libdeepof_hip -- C ABI of the MI355X-native DeepOF unsupervised-embedding hot path.
+ *
+ * Drop-in boundary for the reference trainer (mlfpm/deepof v0.9.0, deepof/clustering).  The
+ * reference has no native code: the Python functions below are what a maintainer would rebind
+ * (through ctypes).  Every entry point
+ *   - takes plain device pointers / sizes / a hipStream_t (passed as void*), no torch types;
+ *   - never allocates device memory and never synchronises: the caller owns all buffers,
+ *     including the workspace whose size dof_vade_workspace_bytes() reports;
+ *   - returns 0 (DOF_OK) or a negative error code; dof_last_error_string() explains it.
+ *
+ * Reference interface each entry replaces (paths relative to /root/reference):
+ *   dof_window_gather[_range]   deepof/utils.py:3354-3377 rolling_window +
+ *                               deepof/clustering/dataset.py:16-26 reorder_and_reshape, :183-290 _build_hdf5,
+ *                               :561-670 _H5BatchIterableDataset.__iter__ (batch fetch)
+ *   dof_vade_forward            deepof/clustering/models_new.py:1841-1891 VaDEPT.forward (eval / train mode)
+ *   dof_vade_loss_grads         deepof/clustering/training.py:231-309 step_vade + losses.py:567-797
+ *                               VadeLoss.forward + loss.backward() (training.py:163)
+ *   dof_optimizer_step          training.py:164-166 clip_grad_value_ + optimizer.step(), losses.py:805-833
+ */
+#ifndef DEEPOF_HIP_H
+#define DEEPOF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOF_ABI_VERSION 1
+
+/* ---- error reporting ---------------------------------------------------------------------- */
+const char* dof_last_error_string(void);
+int dof_abi_version(void);
+
+/* ---- window tensor build (SURVEY 8a R0+R1) -------------------------------------------------
+ * node_table (rows, 3N) fp32 column blocks [x_1..x_N | y_1..y_N | s_1..s_N]; edge_table (rows, E).
+ * Window b covers table rows row_start[b] .. row_start[b]+window-1.  Outputs in the reference's
+ * batch layout: x_out (n_windows, window, N, 3), a_out (n_windows, window, E, 1).  All pointers
+ * are device pointers.  The _range variant takes row_start[b] = first_row + b*row_step. */
+int dof_window_gather(const float* node_table, const float* edge_table, const int64_t* row_start,
+                      int64_t n_windows, int32_t window, int32_t n_nodes, int32_t n_edges, float* x_out,
+                      float* a_out, void* stream);
+int dof_window_gather_range(const float* node_table, const float* edge_table, int64_t first_row, int64_t row_step,
+                            int64_t n_windows, int32_t window, int32_t n_nodes, int32_t n_edges, float* x_out,
+                            float* a_out, void* stream);
+
+/* ---- VaDE (recurrent encoder/decoder) ------------------------------------------------------ */
+typedef struct DofVadeDims {
+  int32_t batch;      /* windows per step (per rank) */
+  int32_t window;     /* T */
+  int32_t n_nodes;    /* N, 3 features per node */
+  int32_t n_edges;    /* E, 1 feature per edge */
+  int32_t latent;     /* L (internal GRU width = L; L <= 64 in the reference, this build: 4, 6, 8) */
+  int32_t n_clusters; /* K */
+  int32_t mc_samples; /* S of the Monte-Carlo KL (reference: 32) */
+} DofVadeDims;
+
+typedef struct DofVadePlan DofVadePlan;
+
+/* Host-side plan: parameter layout, workspace carve-up, graph sparsity.  laplacian (N,N),
+ * edge_laplacian (E,E), incidence (N,E) are HOST fp32 arrays (the encoder's registered buffers). */
+int dof_vade_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                         const float* incidence, DofVadePlan** out);
+void dof_vade_plan_destroy(DofVadePlan* plan);
+
+/* Flat fp32 parameter buffer, tensors in the reference's state_dict order and shapes. */
+int32_t dof_vade_param_count(const DofVadePlan* plan);
+const char* dof_vade_param_name(const DofVadePlan* plan, int32_t i);
+int64_t dof_vade_param_offset(const DofVadePlan* plan, int32_t i);
+int64_t dof_vade_param_numel(const DofVadePlan* plan, int32_t i);
+int64_t dof_vade_param_total(const DofVadePlan* plan);
+
+int64_t dof_vade_workspace_bytes(const DofVadePlan* plan);
+/* Zero the workspace and upload the plan's tables into it (enqueued on stream).  Call once per
+ * workspace before the first forward / step, outside any graph capture. */
+int dof_vade_bind(DofVadePlan* plan, void* workspace, void* stream);
+
+/* hyper[]: device fp32 array of DOF_H_COUNT scalars read by the kernels (graph-replay safe). */
+enum {
+  DOF_H_KLW = 0, DOF_H_LAMBDA_DISTILL, DOF_H_KM_LATENT, DOF_H_KM_LOSS, DOF_H_REPEL_W, DOF_H_REPEL_LS,
+  DOF_H_NONEMPTY_W, DOF_H_NONEMPTY_FLOOR, DOF_H_NONEMPTY_P, DOF_H_L1_ACT, DOF_H_DISTILL_T, DOF_H_CONF_W,
+  DOF_H_CONF_THR, DOF_H_HAS_TEACHER, DOF_H_LOGVAR_LO, DOF_H_LOGVAR_HI,
+  DOF_H_CLIP = 16, DOF_H_WD = 17,
+  DOF_H_LR0 = 18,      /* 4 learning rates, one per optimiser segment */
+  DOF_H_BC0 = 22,      /* 4 x (1-beta1^t, 1-beta2^t) */
+  DOF_H_ACTIVE0 = 30,  /* 4 x "segment has gradients" (0 = frozen / grad None) */
+  DOF_H_COUNT = 34
+};
+/* optimiser segments of the VaDE parameter buffer */
+enum { DOF_SEG_ENCODER = 0, DOF_SEG_DECODER = 1, DOF_SEG_GMM = 2, DOF_SEG_HEADS = 3, DOF_SEG_COUNT = 4 };
+/* logs[]: device fp32 array of DOF_LOG_COUNT loss terms (keys of step_vade's logs dict). */
+enum {
+  DOF_LOG_TOTAL = 0, DOF_LOG_RECON, DOF_LOG_KL, DOF_LOG_CAT, DOF_LOG_KMEANS, DOF_LOG_ACTIVITY, DOF_LOG_PRIOR,
+  DOF_LOG_DISTILL, DOF_LOG_TFCLUST, DOF_LOG_NONEMPTY, DOF_LOG_TEMPORAL, DOF_LOG_SCATTER, DOF_LOG_REPEL,
+  DOF_LOG_KLW, DOF_LOG_COUNT = 16
+};
+
+/* Forward.  x (B,T,N,3), a (B,T,E,1) device fp32.  prior (K) device.  eps (B,L) device or NULL:
+ * NULL = eval mode (z = z_mean), non-NULL = train mode (z = mean + exp(softplus/2)*eps).
+ * Outputs (any may be NULL): z_out (B,L) latent, q_out (B,K) soft cluster assignments,
+ * zmean_out (B,L), zlogvar_out (B,L) (softplus output), loc_out (B,T,3N) reconstruction mean,
+ * enc_out (B,L) encoder output. */
+int dof_vade_forward(DofVadePlan* plan, const float* params, const float* prior, const float* x, const float* a,
+                     const float* eps, float* z_out, float* q_out, float* zmean_out, float* zlogvar_out,
+                     float* loc_out, float* enc_out, void* stream);
+
+/* Forward + VadeLoss + backward: fills grads (same layout as params) and logs[DOF_LOG_COUNT].
+ * eps (B,L); eps_mc (S,B,L) (main phase only); tau (B,K) teacher targets for this batch or NULL;
+ * teacher (2K): class weights then teacher marginal, or NULL; pretrain != 0 selects the
+ * pre-training objective (KL vs N(0,I)), 0 the main objective (MC-KL vs the GMM). */
+int dof_vade_loss_grads(DofVadePlan* plan, const float* params, const float* prior, const float* x,
+                        const float* a, const float* eps, const float* eps_mc, const float* tau,
+                        const float* teacher, const float* hyper, int32_t pretrain, float* grads, float* logs,
+                        void* stream);
+
+/* clip_grad_value_(hyper[DOF_H_CLIP]) + Adam(betas 0.9/0.999, eps 1e-8, weight decay hyper[DOF_H_WD]). */
+int dof_optimizer_step(DofVadePlan* plan, float* params, const float* grads, float* adam_m, float* adam_v,
+                       const float* hyper, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPOF_HIP_H */

@@ -1,0 +1,145 @@
+// TEST TOOL (not product): fiber-based SIMT emulator runtime.  See emu_rt.h.
+#include "emu_rt.h"
+
+#include <ucontext.h>
+
+#include <vector>
+
+dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace {
+enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
+constexpr size_t kStack = 256 * 1024;
+
+struct Fiber {
+  ucontext_t ctx;
+  State st = DONE;
+  dim3 tid;
+};
+
+ucontext_t g_main;
+std::vector<Fiber> g_fibers;
+std::vector<unsigned char> g_stacks;
+int g_cur = -1;
+const std::function<void()>* g_body = nullptr;
+float g_xchg[1024 * 2];  // per-thread exchange slots (a, b)
+
+void fiber_entry() {
+  (*g_body)();
+  g_fibers[g_cur].st = DONE;
+  swapcontext(&g_fibers[g_cur].ctx, &g_main);
+}
+
+void yield_as(State s) {
+  int me = g_cur;
+  g_fibers[me].st = s;
+  swapcontext(&g_fibers[me].ctx, &g_main);
+  threadIdx = g_fibers[me].tid;
+}
+
+void run_block(int nthreads) {
+  if ((int)g_fibers.size() < nthreads) g_fibers.resize(nthreads);
+  if (g_stacks.size() < kStack * (size_t)nthreads) g_stacks.resize(kStack * (size_t)nthreads);
+  for (int i = 0; i < nthreads; ++i) {
+    Fiber& f = g_fibers[i];
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = g_stacks.data() + kStack * (size_t)i;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = &g_main;
+    f.st = RUNNABLE;
+    f.tid = dim3(i % blockDim.x, (i / blockDim.x) % blockDim.y, i / (blockDim.x * blockDim.y));
+    makecontext(&f.ctx, fiber_entry, 0);
+  }
+  for (;;) {
+    bool ran = false;
+    for (int i = 0; i < nthreads; ++i) {
+      if (g_fibers[i].st != RUNNABLE) continue;
+      g_cur = i;
+      threadIdx = g_fibers[i].tid;
+      swapcontext(&g_main, &g_fibers[i].ctx);
+      ran = true;
+    }
+    // release barriers
+    bool released = false;
+    int nwaves = (nthreads + 63) / 64;
+    for (int w = 0; w < nwaves; ++w) {
+      int lo = w * 64, hi = lo + 64 > nthreads ? nthreads : lo + 64;
+      int waiting = 0, live = 0;
+      for (int i = lo; i < hi; ++i) {
+        if (g_fibers[i].st != DONE) ++live;
+        if (g_fibers[i].st == WAIT_WAVE) ++waiting;
+      }
+      if (live > 0 && waiting == live) {
+        for (int i = lo; i < hi; ++i)
+          if (g_fibers[i].st == WAIT_WAVE) g_fibers[i].st = RUNNABLE;
+        released = true;
+      }
+    }
+    int live = 0, waiting = 0;
+    for (int i = 0; i < nthreads; ++i) {
+      if (g_fibers[i].st != DONE) ++live;
+      if (g_fibers[i].st == WAIT_BLOCK) ++waiting;
+    }
+    if (live == 0) break;
+    if (waiting == live) {
+      for (int i = 0; i < nthreads; ++i)
+        if (g_fibers[i].st == WAIT_BLOCK) g_fibers[i].st = RUNNABLE;
+      released = true;
+    }
+    if (!ran && !released) {
+      fprintf(stderr, "emu: deadlock (divergent barrier) in block (%u,%u)\n", blockIdx.x, blockIdx.y);
+      abort();
+    }
+  }
+}
+}  // namespace
+
+void emu_sync_block() { yield_as(WAIT_BLOCK); }
+
+float emu_shfl(float v, int src_lane, int width) {
+  int me = g_cur;
+  int lane = me & 63;
+  (void)width;
+  g_xchg[me * 2] = v;
+  yield_as(WAIT_WAVE);
+  int src = (me - lane) + (src_lane & 63);
+  float r = g_xchg[src * 2];
+  yield_as(WAIT_WAVE);
+  return r;
+}
+
+emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c) {
+  // A[i][k]: lane k*16+i ; B[k][j]: lane k*16+j ; D[row=(lane>>4)*4+r][col=lane&15]
+  int me = g_cur;
+  int lane = me & 63, base = me - lane;
+  g_xchg[me * 2] = a;
+  g_xchg[me * 2 + 1] = b;
+  yield_as(WAIT_WAVE);
+  int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = (lane >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(g_xchg[(base + k * 16 + row) * 2], g_xchg[(base + k * 16 + col) * 2 + 1], acc);
+    c[r] = acc;
+  }
+  yield_as(WAIT_WAVE);
+  return c;
+}
+
+void emu_run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
+  g_body = &body;
+  gridDim = grid;
+  blockDim = block;
+  int nthreads = (int)(block.x * block.y * block.z);
+  if (nthreads > 1024) {
+    fprintf(stderr, "emu: block too large\n");
+    abort();
+  }
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx = dim3(bx, by, bz);
+        run_block(nthreads);
+      }
+  g_body = nullptr;
+}

@@ -1,0 +1,139 @@
+"""Shared parity checks (used with the emulator on CPU and with the real library on the GPU)."""
+import os
+
+import numpy as np
+import torch
+
+from deepof_amd import _capi
+from deepof_amd.engine import VadeEngine
+from oracle import windows as OW
+
+
+def load_golden(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
+
+
+def params_from(d, prefix="sd::"):
+    return {k[len(prefix):]: torch.from_numpy(v) for k, v in d.items() if k.startswith(prefix)}
+
+
+PHASES = {
+    "pre": dict(klw=0.13, pretrain=True, teacher=False),
+    "main": dict(klw=0.7, pretrain=False, teacher=False),
+    "mainT": dict(klw=0.7, pretrain=False, teacher=True),
+}
+
+
+def configure_phase(eng, K, pretrain, klw, tau=None, lambda_distill=0.0):
+    """Reference defaults of VadeLoss per phase (training.py:640-668, losses.py:426-443)."""
+    eng.set_hyper(klw=klw, km_latent=1.0, km_loss=1.0 if pretrain else 0.0,
+                  repel_w=0.5 if pretrain else 0.0, repel_ls=0.5 if pretrain else 1.0,
+                  nonempty_w=0.02, nonempty_floor=max(1e-4, 0.05 / K), nonempty_p=2.0,
+                  l1_act=0.1, distill_T=0.5, conf_w=0.0, conf_thr=0.3, lambda_distill=lambda_distill)
+    if tau is not None:
+        pi = tau.mean(dim=0).clamp_min(1e-8)
+        w = pi.pow(-1.0)
+        w = (w / w.mean()).clamp_max(3.0)
+        eng.set_teacher(w, pi)
+    else:
+        eng.set_teacher(None, None)
+    eng.push_hyper()
+
+
+def gather_check(lib, device):
+    rng = np.random.default_rng(0)
+    for (N, E, W, Fr, starts) in [(14, 14, 25, 90, [0, 1, 2, 3, 40, 65, 7]), (5, 4, 7, 31, list(range(25))),
+                                  (28, 32, 50, 120, [70, 0, 33])]:
+        nodes = rng.standard_normal((Fr, 3 * N)).astype(np.float32)
+        edges = rng.standard_normal((Fr, E)).astype(np.float32)
+        x_ref, a_ref = OW.gather_windows(nodes, edges, np.array(starts), W)
+        tn, te = torch.from_numpy(nodes).to(device), torch.from_numpy(edges).to(device)
+        st = torch.tensor(starts, dtype=torch.int64, device=device)
+        x = torch.full((len(starts), W, N, 3), float("nan"), device=device)
+        a = torch.full((len(starts), W, E, 1), float("nan"), device=device)
+        stream = torch.cuda.current_stream().cuda_stream if device != "cpu" else 0
+        _capi.check(lib, lib.dof_window_gather(tn.data_ptr(), te.data_ptr(), st.data_ptr(), len(starts), W, N, E,
+                                               x.data_ptr(), a.data_ptr(), stream))
+        np.testing.assert_array_equal(x.cpu().numpy(), x_ref)
+        np.testing.assert_array_equal(a.cpu().numpy(), a_ref)
+        # arithmetic starts (stride-2 windows) through the _range entry point
+        nw = (Fr - W) // 2 + 1
+        x2 = torch.empty((nw, W, N, 3), device=device)
+        a2 = torch.empty((nw, W, E, 1), device=device)
+        _capi.check(lib, lib.dof_window_gather_range(tn.data_ptr(), te.data_ptr(), 0, 2, nw, W, N, E,
+                                                     x2.data_ptr(), a2.data_ptr(), stream))
+        xr, ar = OW.gather_windows(nodes, edges, np.arange(nw) * 2, W)
+        np.testing.assert_array_equal(x2.cpu().numpy(), xr)
+        np.testing.assert_array_equal(a2.cpu().numpy(), ar)
+
+
+def run_phase_check(lib, device, golden_dir, tag, phase, atol_g=5e-5, rtol_g=5e-4):
+    d = load_golden(golden_dir, f"vade_{tag}.npz")
+    spec = PHASES[phase]
+    x, a = torch.from_numpy(d["x"]).to(device), torch.from_numpy(d["a"]).to(device)
+    B, T, N, _ = x.shape
+    K, L = d["sd::latent_space.gmm_means"].shape
+    eng = VadeEngine(lib, device, B, T, d["adj"], L, K)
+    eng.load_state_dict(params_from(d))
+    tau = torch.from_numpy(d["tau"]) if spec["teacher"] else None
+    configure_phase(eng, K, spec["pretrain"], spec["klw"], tau, 1.7 if spec["teacher"] else 0.0)
+    eng.loss_grads(x, a, torch.from_numpy(d["eps"]).to(device), torch.from_numpy(d["eps_mc"]).to(device),
+                   None if tau is None else tau.to(device), pretrain=spec["pretrain"])
+    logs = eng.read_logs()
+    for k, v in logs.items():
+        if k == "kl_weight":
+            continue
+        ref = float(d[f"{phase}::loss::{k}"])
+        np.testing.assert_allclose(v, ref, rtol=1e-4, atol=1e-5, err_msg=f"{tag}/{phase}: {k}")
+    worst = []
+    for k in d:
+        if k.startswith(f"{phase}::grad::"):
+            name = k.split("::grad::")[1]
+            g = eng.view(name, eng.grads).cpu().numpy()
+            ref = d[k].reshape(g.shape)
+            err = np.abs(g - ref).max() / (np.abs(ref).max() + 1e-12)
+            worst.append((err, name))
+            np.testing.assert_allclose(g, ref, atol=atol_g, rtol=rtol_g, err_msg=f"{tag}/{phase}: grad {name}")
+    assert len(worst) >= 80
+    # parameters the reference leaves without gradient stay exactly zero here
+    for name in eng.names:
+        if f"{phase}::grad::{name}" not in d:
+            assert float(eng.view(name, eng.grads).abs().max()) == 0.0, name
+    return sorted(worst)[-3:]
+
+
+def run_trace_check(lib, device, golden_dir):
+    d = load_golden(golden_dir, "vade_train_trace.npz")
+    sd0 = params_from(d, "sd0::")
+    K, L = sd0["latent_space.gmm_means"].shape
+    x0 = d["step0::x"]
+    B, T, N, _ = x0.shape
+    nodes_adj = load_golden(golden_dir, "graph_ops.npz")["single_adj"]
+    eng = VadeEngine(lib, device, B, T, nodes_adj, L, K)
+    eng.load_state_dict(sd0)
+    last = None
+    for s in range(6):
+        phase = str(d[f"step{s}::phase"])
+        if phase != last:
+            eng.reset_optimizer()
+            last = phase
+        lr_b, lr_g = (float(v) for v in d[f"step{s}::lr"])
+        for seg in (_capi.SEG_ENCODER, _capi.SEG_DECODER, _capi.SEG_HEADS):
+            eng.set_lr(seg, lr_b)
+        eng.set_lr(_capi.SEG_GMM, lr_g)
+        eng.advance_adam()
+        configure_phase(eng, K, phase == "pre", float(d[f"step{s}::klw"]))
+        t = lambda k: torch.from_numpy(d[f"step{s}::{k}"]).to(device)
+        eng.loss_grads(t("x"), t("a"), t("eps"), t("eps_mc"), None, pretrain=(phase == "pre"))
+        eng.optimizer_step()
+        logs = eng.read_logs()
+        for k, v in logs.items():
+            if k == "kl_weight":
+                continue
+            np.testing.assert_allclose(v, float(d[f"step{s}::log::{k}"]), rtol=2e-3, atol=2e-4, err_msg=f"step {s}: {k}")
+        pn = float(torch.sqrt((eng.params.double() ** 2).sum()))
+        np.testing.assert_allclose(pn, float(d[f"step{s}::pnorm"]), rtol=2e-5)
+    for k, v in params_from(d, "sd_final::").items():
+        if k in eng.layout:
+            np.testing.assert_allclose(eng.view(k).cpu().numpy(), v.numpy().reshape(eng.layout[k][2]), atol=5e-4,
+                                       rtol=2e-3, err_msg=k)

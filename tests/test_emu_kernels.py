@@ -1,0 +1,38 @@
+"""Kernel-logic checks of the HIP sources under the CPU emulator (no GPU needed) against the oracle
+and the reference golden fixtures.  The same comparisons run on the real MI355X in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from deepof_amd.engine import VadeEngine
+from emu_util import emu_lib
+from parity_common import gather_check, load_golden, params_from, run_phase_check, run_trace_check
+
+
+def test_gather_emu():
+    gather_check(emu_lib(), "cpu")
+
+
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+def test_vade_eval_forward_emu(golden_dir, tag):
+    d = load_golden(golden_dir, f"vade_{tag}.npz")
+    x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
+    B, T, N, _ = x.shape
+    K, L = d["sd::latent_space.gmm_means"].shape
+    eng = VadeEngine(emu_lib(), "cpu", B, T, d["adj"], L, K)
+    eng.load_state_dict(params_from(d))
+    out = eng.forward(x, a, None, want_loc=True, want_enc=True)
+    np.testing.assert_allclose(out["enc"].numpy(), d["eval_enc"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["z"].numpy(), d["eval_z"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["q"].numpy(), d["eval_q"], atol=1e-5, rtol=1e-3)
+    np.testing.assert_allclose(out["loc"].numpy(), d["eval_loc"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag,phase", [("rec14", "pre"), ("rec14", "main"), ("rec14", "mainT"), ("rec28", "pre"),
+                                       ("rec28", "mainT")])
+def test_vade_loss_grads_emu(golden_dir, tag, phase):
+    run_phase_check(emu_lib(), "cpu", golden_dir, tag, phase)
+
+
+def test_vade_train_trace_emu(golden_dir):
+    run_trace_check(emu_lib(), "cpu", golden_dir)
