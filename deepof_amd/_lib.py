@@ -4,6 +4,8 @@ from __future__ import annotations
 import ctypes
 import os
 
+import torch  # noqa: F401  (must load first: the library shares torch's HIP runtime, streams and pointers)
+
 from . import _capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

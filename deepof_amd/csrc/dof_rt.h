@@ -18,6 +18,30 @@ typedef emu_f32x4 dof_f32x4;
 typedef float dof_f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
+#ifdef DOF_EMU
+#define DOF_SCHED_FENCE() ((void)0)
+#else
+#define DOF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// Wave-uniform read-only weights: viewing them through the constant address space makes every
+// uniform load a scalar-cache s_load (no VMEM traffic, weights arrive in SGPRs and feed v_fmac
+// directly).  dof_opaque_zero() is an SGPR the optimiser cannot see through; adding it to the
+// base inside a time loop keeps the loads inside the loop instead of being hoisted and spilled.
+#ifdef DOF_EMU
+typedef const float* dof_cfp;
+static inline dof_cfp dof_cw(const float* p) { return p; }
+static inline int dof_opaque_zero() { return 0; }
+#else
+typedef const float __attribute__((address_space(4)))* dof_cfp;
+__device__ __forceinline__ dof_cfp dof_cw(const float* p) { return (dof_cfp)(uintptr_t)p; }
+__device__ __forceinline__ int dof_opaque_zero() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
+#endif
+
 #define DOF_OK 0
 #define DOF_ERR_ARG (-1)
 #define DOF_ERR_UNSUPPORTED (-2)
@@ -33,10 +57,17 @@ static inline unsigned dof_cdiv(int64_t a, int64_t b) { return (unsigned)((a + b
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dof_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dof_rcp(float x) {
+#ifdef DOF_EMU
+  return 1.0f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);  // v_rcp_f32, 1 ulp
+#endif
+}
+__device__ __forceinline__ float dof_sigmoid(float x) { return dof_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float dof_tanh(float x) {
   // 1 - 2/(1+e^{2x}); saturates cleanly at +-1 for large |x|
-  return 1.0f - 2.0f / (1.0f + __expf(2.0f * x));
+  return 1.0f - 2.0f * dof_rcp(1.0f + __expf(2.0f * x));
 }
 __device__ __forceinline__ float dof_softplus(float x) {
   // torch.nn.functional.softplus, beta=1, threshold=20
@@ -51,6 +82,7 @@ __device__ __forceinline__ void dof_block_colsum(const float* vals, float* out) 
   constexpr int CH = NV < 32 ? NV : 32;
   __shared__ float tile[32][257];
   const int tid = threadIdx.x;
+#pragma unroll
   for (int c0 = 0; c0 < NV; c0 += CH) {
     __syncthreads();
 #pragma unroll

@@ -15,18 +15,25 @@ namespace {
 
 #define SOA(t, c, C, Sp, s) (((int64_t)(t) * (C) + (c)) * (Sp) + (s))
 
+// thread = (b, t): frame validity; k_dec_len then counts per window
 __global__ void __launch_bounds__(256) k_dec_valid(const float* __restrict__ x, int T, int C3, int64_t B, int64_t Bp,
-                                                   float* __restrict__ valid, int* __restrict__ len) {
+                                                   float* __restrict__ valid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  const int64_t b = i / T;
+  const int t = (int)(i - b * T);
+  const float* __restrict__ row = x + i * C3;
+  bool any = false;
+  for (int j = 0; j < C3; ++j) any |= (row[j] != 0.0f);
+  valid[(int64_t)t * Bp + b] = any ? 1.0f : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) k_dec_len(const float* __restrict__ valid, int T, int64_t B, int64_t Bp,
+                                                 int* __restrict__ len) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int n = 0;
-  for (int t = 0; t < T; ++t) {
-    const float* __restrict__ row = x + (b * T + t) * C3;
-    bool any = false;
-    for (int j = 0; j < C3; ++j) any |= (row[j] != 0.0f);
-    valid[(int64_t)t * Bp + b] = any ? 1.0f : 0.0f;
-    n += any ? 1 : 0;
-  }
+  for (int t = 0; t < T; ++t) n += valid[(int64_t)t * Bp + b] != 0.0f ? 1 : 0;
   len[b] = n;
 }
 
@@ -58,6 +65,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
   if (live) {
     const int t = (int)(i / A.B);
     const int64_t b = i - (int64_t)t * A.B;
+    const dof_cfp wc = dof_cw(A.wc), g3 = dof_cw(A.g3), b3 = dof_cw(A.b3), wp = dof_cw(A.wp), bp = dof_cw(A.bp);
     float cv[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) cv[o] = 0.0f;
@@ -69,7 +77,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
       for (int c = 0; c < CI; ++c) {
         const float v = A.n2[SOA(ts, c, CI, A.Bp, b)];
 #pragma unroll
-        for (int o = 0; o < CO; ++o) cv[o] = fmaf(A.wc[(o * CI + c) * 5 + k], v, cv[o]);
+        for (int o = 0; o < CO; ++o) cv[o] = fmaf(wc[(o * CI + c) * 5 + k], v, cv[o]);
       }
     }
     float mean = 0.0f;
@@ -91,7 +99,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
       xh[o] *= rstd;
-      n3[o] = fmaf(xh[o], A.g3[o], A.b3[o]);
+      n3[o] = fmaf(xh[o], g3[o], b3[o]);
       A.n3[SOA(t, o, CO, A.Bp, b)] = n3[o];
     }
     const bool ok = A.valid[(int64_t)t * A.Bp + b] != 0.0f;
@@ -102,9 +110,9 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
     for (int o = 0; o < CO; ++o) dn3[o] = 0.0f;
     float sq = 0.0f;
     for (int j = 0; j < A.C3; ++j) {
-      float loc = A.bp[j];
+      float loc = bp[j];
 #pragma unroll
-      for (int o = 0; o < CO; ++o) loc = fmaf(A.wp[j * CO + o], n3[o], loc);
+      for (int o = 0; o < CO; ++o) loc = fmaf(wp[j * CO + o], n3[o], loc);
       if (loc != loc) loc = 0.0f;  // nan_to_num(nan=0, +-inf -> +-1e6)
       loc = fminf(fmaxf(loc, -1e6f), 1e6f);
       if (A.loc_out) A.loc_out[(b * A.T + t) * A.C3 + j] = loc;
@@ -114,7 +122,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
         const float dl = ok ? -df * inv_bt : NAN;
         A.dloc[SOA(t, j, A.C3, A.Bp, b)] = dl;
 #pragma unroll
-        for (int o = 0; o < CO; ++o) dn3[o] = fmaf(A.wp[j * CO + o], dl, dn3[o]);
+        for (int o = 0; o < CO; ++o) dn3[o] = fmaf(wp[j * CO + o], dl, dn3[o]);
       }
     }
     const float LOG_2PI = 1.8378770664093453f;
@@ -123,7 +131,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
       float mg = 0.0f, mgx = 0.0f;
 #pragma unroll
       for (int o = 0; o < CO; ++o) {
-        const float g = dn3[o] * A.g3[o];
+        const float g = dn3[o] * g3[o];
         mg += g;
         mgx = fmaf(g, xh[o], mgx);
         vals[o] = dn3[o] * xh[o];
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
       mgx *= (1.0f / CO);
 #pragma unroll
       for (int o = 0; o < CO; ++o) {
-        const float d = rstd * (dn3[o] * A.g3[o] - mg - xh[o] * mgx);
+        const float d = rstd * (dn3[o] * g3[o] - mg - xh[o] * mgx);
         A.dcv[SOA(t, o, CO, A.Bp, b)] = cv[o] > 0.0f ? d : 0.0f;
       }
     }
@@ -151,6 +159,7 @@ __global__ void __launch_bounds__(256) k_dec_conv_bwd(const float* __restrict__ 
   if (i >= (int64_t)T * B) return;
   const int t = (int)(i / B);
   const int64_t b = i - (int64_t)t * B;
+  const dof_cfp wcc = dof_cw(wc);
   float acc[CI];
 #pragma unroll
   for (int c = 0; c < CI; ++c) acc[c] = 0.0f;
@@ -162,7 +171,7 @@ __global__ void __launch_bounds__(256) k_dec_conv_bwd(const float* __restrict__ 
     for (int o = 0; o < CO; ++o) {
       const float v = dcv[SOA(ts, o, CO, Bp, b)];
 #pragma unroll
-      for (int c = 0; c < CI; ++c) acc[c] = fmaf(wc[(o * CI + c) * 5 + k], v, acc[c]);
+      for (int c = 0; c < CI; ++c) acc[c] = fmaf(wcc[(o * CI + c) * 5 + k], v, acc[c]);
     }
   }
 #pragma unroll

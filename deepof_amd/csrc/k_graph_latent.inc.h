@@ -170,22 +170,24 @@ template <int L>
 __global__ void __launch_bounds__(256) k_latent_fwd(LatentFwdArgs A) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= A.B) return;
+  const dof_cfp wf = dof_cw(A.wf), bf = dof_cw(A.bf), wm = dof_cw(A.wm), bm = dof_cw(A.bm), wsv = dof_cw(A.ws),
+                bsv = dof_cw(A.bs), gmeans = dof_cw(A.gmm_means), glv = dof_cw(A.gmm_log_vars), prior = dof_cw(A.prior);
   float enc[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) enc[l] = A.bf[l];
+  for (int l = 0; l < L; ++l) enc[l] = bf[l];
   for (int j = 0; j < A.J; ++j) {
     const float f = A.flat[(int64_t)j * A.Bp + b];
 #pragma unroll
-    for (int l = 0; l < L; ++l) enc[l] = fmaf(A.wf[l * A.J + j], f, enc[l]);
+    for (int l = 0; l < L; ++l) enc[l] = fmaf(wf[l * A.J + j], f, enc[l]);
   }
   float z[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    float m = A.bm[l], p = A.bs[l];
+    float m = bm[l], p = bsv[l];
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-      m = fmaf(A.wm[l * L + k], enc[k], m);
-      p = fmaf(A.ws[l * L + k], enc[k], p);
+      m = fmaf(wm[l * L + k], enc[k], m);
+      p = fmaf(wsv[l * L + k], enc[k], p);
     }
     const float sv = dof_softplus(p);
     z[l] = A.eps ? fmaf(expf(0.5f * sv), A.eps[b * L + l], m) : m;
@@ -203,11 +205,11 @@ __global__ void __launch_bounds__(256) k_latent_fwd(LatentFwdArgs A) {
   const float HALF_LOG_2PI = 0.9189385332046727f;
   float mx = -INFINITY;
   for (int c = 0; c < A.K; ++c) {
-    float lg = logf(A.prior[c] + 1e-9f);
+    float lg = logf(prior[c] + 1e-9f);
 #pragma unroll
     for (int d = 0; d < L; ++d) {
-      const float sd = fmaxf(expf(0.5f * A.gmm_log_vars[c * L + d]), 1e-3f);
-      const float u = (z[d] - A.gmm_means[c * L + d]) / sd;
+      const float sd = fmaxf(expf(0.5f * glv[c * L + d]), 1e-3f);
+      const float u = (z[d] - gmeans[c * L + d]) / sd;
       lg += -0.5f * u * u - logf(sd) - HALF_LOG_2PI;
     }
     A.q[(int64_t)c * A.Bp + b] = lg;
@@ -242,7 +244,7 @@ __global__ void k_kmeans_eig(const float* __restrict__ gram_sum, const float* __
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float w_lat = hyper[DOF_H_KM_LATENT];
   const float w_loss = hyper[DOF_H_KM_LOSS];
-  if (!(w_lat > 0.0f)) {
+  if (!(w_lat > 0.0f) || w_loss == 0.0f) {  // value and gradient are multiplied by both weights
     km_out[0] = 0.0f;
     for (int i = 0; i < L * L; ++i) Pm[i] = 0.0f;
     return;
@@ -255,11 +257,13 @@ __global__ void k_kmeans_eig(const float* __restrict__ gram_sum, const float* __
     }
   for (int i = 0; i < L; ++i)
     for (int j = i + 1; j < L; ++j) a[i][j] = a[j][i] = 0.5 * (a[i][j] + a[j][i]);
+  double diag2 = 0.0;
+  for (int i = 0; i < L; ++i) diag2 += a[i][i] * a[i][i];
   for (int sweep = 0; sweep < 30; ++sweep) {
     double off = 0.0;
     for (int i = 0; i < L; ++i)
       for (int j = i + 1; j < L; ++j) off += a[i][j] * a[i][j];
-    if (off < 1e-300) break;
+    if (off <= 1e-30 * diag2 || off < 1e-300) break;
     for (int p = 0; p < L; ++p)
       for (int q = p + 1; q < L; ++q) {
         if (fabs(a[p][q]) < 1e-300) continue;
@@ -584,7 +588,9 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
   const bool live = b < A.B;
   float ce_w = 0.0f;
   if (live) {
-    const float* H = A.hyper;
+    const dof_cfp H = dof_cw(A.hyper);
+    const dof_cfp wf = dof_cw(A.wf), wm = dof_cw(A.wm), wsv = dof_cw(A.ws), gmeans = dof_cw(A.gmm_means),
+                  glv = dof_cw(A.gmm_log_vars);
     const float Bf = (float)A.B;
     const int K = A.K;
     float z[L], dz[L];
@@ -651,8 +657,8 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       const float qn = A.qn[(int64_t)c * A.Bp + b];
 #pragma unroll
       for (int d = 0; d < L; ++d) {
-        const float sd = fmaxf(expf(0.5f * A.gmm_log_vars[c * L + d]), 1e-3f);
-        dz[d] = fmaf(dl, -(z[d] - A.gmm_means[c * L + d]) / (sd * sd), dz[d]);
+        const float sd = fmaxf(expf(0.5f * glv[c * L + d]), 1e-3f);
+        dz[d] = fmaf(dl, -(z[d] - gmeans[c * L + d]) / (sd * sd), dz[d]);
         dz[d] = fmaf(qn, A.dcen[c * L + d], dz[d]);
       }
     }
@@ -704,8 +710,8 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       float acc = 0.0f;
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        acc = fmaf(A.wm[l * L + k], dmu[l], acc);
-        acc = fmaf(A.ws[l * L + k], dpre[l], acc);
+        acc = fmaf(wm[l * L + k], dmu[l], acc);
+        acc = fmaf(wsv[l * L + k], dpre[l], acc);
       }
       denc[k] = acc;
       A.denc[(int64_t)k * A.Bp + b] = acc;
@@ -713,7 +719,7 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
     for (int j = 0; j < A.J; ++j) {
       float acc = 0.0f;
 #pragma unroll
-      for (int l = 0; l < L; ++l) acc = fmaf(A.wf[l * A.J + j], denc[l], acc);
+      for (int l = 0; l < L; ++l) acc = fmaf(wf[l * A.J + j], denc[l], acc);
       A.dflat[(int64_t)j * A.Bp + b] = acc;
     }
   }

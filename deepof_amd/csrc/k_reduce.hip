@@ -119,13 +119,20 @@ __global__ void __launch_bounds__(256) k_outer_finalize(const DofOuterJob* __res
   grads[F.dst_off + (int64_t)ri * F.row_stride + (int64_t)ci * F.col_stride] = acc;
 }
 
+// one workgroup per output value: strided partial sums + fixed-shape LDS tree (deterministic)
 __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ partial, int64_t nblk, int nv,
                                                       float* __restrict__ out, int accumulate) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nv) return;
+  __shared__ float red[256];
+  const int v = blockIdx.x;
   float acc = 0.0f;
-  for (int64_t b = 0; b < nblk; ++b) acc += partial[b * nv + v];
-  out[v] = accumulate ? out[v] + acc : acc;
+  for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += partial[b * nv + v];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[v] = accumulate ? out[v] + red[0] : red[0];
 }
 
 __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ params, const float* __restrict__ grads,
@@ -175,7 +182,7 @@ int dof_launch_outer_finalize(const DofOuterJob* jobs_dev, const DofFinJob* fin_
 }
 
 int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* out, int accumulate, hipStream_t st) {
-  DOF_LAUNCH(k_sum_partials, (dof_cdiv(nv, 256)), (256), st, partial, nblk, nv, out, accumulate);
+  DOF_LAUNCH(k_sum_partials, ((unsigned)nv), (256), st, partial, nblk, nv, out, accumulate);
   return dof_check_launch("k_sum_partials");
 }
 

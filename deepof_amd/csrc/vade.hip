@@ -577,7 +577,8 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, bool tr
   const int L = p->L, T = p->T;
   const int64_t B = p->B, Bp = p->Bp;
   int* len = reinterpret_cast<int*>(ws + p->len_d);
-  DOF_LAUNCH(k_dec_valid, (dof_cdiv(B, 256)), (256), st, x, T, p->C3, B, Bp, ws + p->valid, len);
+  DOF_LAUNCH(k_dec_valid, (dof_cdiv(B * T, 256)), (256), st, x, T, p->C3, B, Bp, ws + p->valid);
+  DOF_LAUNCH(k_dec_len, (dof_cdiv(B, 256)), (256), st, (const float*)(ws + p->valid), T, B, Bp, len);
   TRY(dof_check_launch("k_dec_valid"));
   TRY(dof_launch_gru_fwd(L, 2, ws + p->z, len, gru_w(params, p->dg1), ws + p->o1d, train ? ws + p->g1d : nullptr, T, B, Bp, st));
   TRY(dof_launch_ln_fwd(L, 2, ws + p->o1d, params + p->dn1w, params + p->dn1b, ws + p->n1d, T, B, Bp, st));

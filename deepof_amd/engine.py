@@ -83,6 +83,8 @@ class VadeEngine:
         self.adam_v = torch.zeros(total, **f32)
         self.prior = torch.full((self.K,), 1.0 / self.K, **f32)
         self.hyper_host = torch.zeros(_capi.H_COUNT, dtype=torch.float32)
+        if self.device.type == "cuda":
+            self.hyper_host = self.hyper_host.pin_memory()
         self.hyper = torch.zeros(_capi.H_COUNT, **f32)
         self.logs = torch.zeros(_capi.LOG_COUNT, **f32)
         self.teacher = torch.zeros(2 * self.K, **f32)
@@ -94,6 +96,8 @@ class VadeEngine:
         self.set_hyper(logvar_lo=-8.0, logvar_hi=8.0, clip=0.75, wd=0.0, l1_act=0.1, distill_T=0.5)
         for s in range(_capi.SEG_COUNT):
             self.hyper_host[_capi.H_ACTIVE0 + s] = 1.0
+            self.hyper_host[_capi.H_BC0 + 2 * s] = 1.0 - 0.9      # t = 1 until advance_adam() is called
+            self.hyper_host[_capi.H_BC0 + 2 * s + 1] = 1.0 - 0.999
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
