@@ -42,6 +42,12 @@ __device__ __forceinline__ int dof_opaque_zero() {
 }
 #endif
 
+// Index of element (time t, sequence s, channel c) of a time-major activation: channel-minor
+// [t][s][c] ("AoS").  A thread that owns a sequence reads/writes its C channels as one contiguous
+// 4C-byte run (vectorised), and a 16-lane group that owns the 16 hidden units of one sequence is
+// perfectly coalesced; Sp = sequence count padded to 64.
+#define ACT(t, c, C, Sp, s) ((((int64_t)(t)) * (Sp) + (s)) * (C) + (c))
+
 #define DOF_OK 0
 #define DOF_ERR_ARG (-1)
 #define DOF_ERR_UNSUPPORTED (-2)

@@ -13,7 +13,6 @@
 
 namespace {
 
-#define SOA(t, c, C, Sp, s) (((int64_t)(t) * (C) + (c)) * (Sp) + (s))
 
 // thread = (b, t): frame validity; k_dec_len then counts per window
 __global__ void __launch_bounds__(256) k_dec_valid(const float* __restrict__ x, int T, int C3, int64_t B, int64_t Bp,
@@ -75,7 +74,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
       if (ts < 0 || ts >= A.T) continue;
 #pragma unroll
       for (int c = 0; c < CI; ++c) {
-        const float v = A.n2[SOA(ts, c, CI, A.Bp, b)];
+        const float v = A.n2[ACT(ts, c, CI, A.Bp, b)];
 #pragma unroll
         for (int o = 0; o < CO; ++o) cv[o] = fmaf(wc[(o * CI + c) * 5 + k], v, cv[o]);
       }
@@ -84,7 +83,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
       cv[o] = cv[o] > 0.0f ? cv[o] : 0.0f;
-      A.cv[SOA(t, o, CO, A.Bp, b)] = cv[o];
+      A.cv[ACT(t, o, CO, A.Bp, b)] = cv[o];
       mean += cv[o];
     }
     mean *= (1.0f / CO);
@@ -100,7 +99,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
     for (int o = 0; o < CO; ++o) {
       xh[o] *= rstd;
       n3[o] = fmaf(xh[o], g3[o], b3[o]);
-      A.n3[SOA(t, o, CO, A.Bp, b)] = n3[o];
+      A.n3[ACT(t, o, CO, A.Bp, b)] = n3[o];
     }
     const bool ok = A.valid[(int64_t)t * A.Bp + b] != 0.0f;
     const float inv_bt = 1.0f / ((float)A.B * (float)A.T);
@@ -120,7 +119,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
       sq = fmaf(df, df, sq);
       if (A.train) {
         const float dl = ok ? -df * inv_bt : NAN;
-        A.dloc[SOA(t, j, A.C3, A.Bp, b)] = dl;
+        A.dloc[ACT(t, j, A.C3, A.Bp, b)] = dl;
 #pragma unroll
         for (int o = 0; o < CO; ++o) dn3[o] = fmaf(wp[j * CO + o], dl, dn3[o]);
       }
@@ -142,7 +141,7 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
 #pragma unroll
       for (int o = 0; o < CO; ++o) {
         const float d = rstd * (dn3[o] * g3[o] - mg - xh[o] * mgx);
-        A.dcv[SOA(t, o, CO, A.Bp, b)] = cv[o] > 0.0f ? d : 0.0f;
+        A.dcv[ACT(t, o, CO, A.Bp, b)] = cv[o] > 0.0f ? d : 0.0f;
       }
     }
   }
@@ -169,13 +168,13 @@ __global__ void __launch_bounds__(256) k_dec_conv_bwd(const float* __restrict__ 
     if (ts < 0 || ts >= T) continue;
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
-      const float v = dcv[SOA(ts, o, CO, Bp, b)];
+      const float v = dcv[ACT(ts, o, CO, Bp, b)];
 #pragma unroll
       for (int c = 0; c < CI; ++c) acc[c] = fmaf(wcc[(o * CI + c) * 5 + k], v, acc[c]);
     }
   }
 #pragma unroll
-  for (int c = 0; c < CI; ++c) dn2[SOA(t, c, CI, Bp, b)] = acc[c];
+  for (int c = 0; c < CI; ++c) dn2[ACT(t, c, CI, Bp, b)] = acc[c];
 }
 
 }  // namespace

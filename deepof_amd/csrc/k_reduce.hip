@@ -4,8 +4,9 @@
 //        dW[i][j] = sum_{t,s} dG[t][i][s] * X[t+shift][j][s]
 //    over SoA operands.  This is the one GEMM-shaped reduction of the step (K = T*S ~ 7e5), so it
 //    runs on the matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32, same rounding as an fmaf chain).
-//    Operands stream straight from HBM as 16-byte lane loads (4 consecutive sequences per lane
-//    = the 4 k-slices of 4 MFMAs); one launch carries all jobs of the step.  Each workgroup
+//    Operands stream straight from HBM with arbitrary (time, sequence, channel) strides -- the
+//    big activations are channel-minor [t][s][c], so a k-slice of 4 sequences x 16 channels is
+//    4 contiguous 64-byte segments; one launch carries all jobs of the step.  Each workgroup
 //    writes one partial tile; k_outer_finalize adds the partials in a fixed order, so gradients
 //    are bitwise reproducible run to run (no float atomics).
 //  * k_clip_adam: clip_grad_value_(0.75) + torch.optim.Adam on the flat parameter buffer
@@ -27,7 +28,7 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
   const int i = lane & 15, q = lane >> 4;
   const int T = J.T;
   const int64_t Sp = J.Sp;
-  const int64_t chunks = Sp >> 4;
+  const int64_t chunks = Sp >> 4;  // 16 sequences per unit = 4 MFMA k-slices of 4 sequences
   const int64_t n_units = (int64_t)T * chunks;
   const int MT = (J.a_rows + 15) >> 4;
   const int NT = J.n_tiles;
@@ -43,16 +44,20 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
 
   for (int64_t u = (int64_t)blk * 4 + wave; u < n_units; u += (int64_t)J.nblk * 4) {
     const int t = (int)(u / chunks);
-    const int64_t s0 = ((u - (int64_t)t * chunks) << 4) + 4 * q;
-    float4 av[4];
+    const int64_t s0 = ((u - (int64_t)t * chunks) << 4) + q;  // this lane's sequence in k-slice 0
+    float av[4][4];  // [row tile][k-slice]
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      av[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) av[mt][kk] = 0.0f;
       if (mt < MT) {
         const int row = mt * 16 + i;
-        if (row < J.a_rows)
-          av[mt] = *reinterpret_cast<const float4*>(J.a_ptr + (int64_t)t * J.a_tstride + (int64_t)row * J.a_cstride + s0);
-        rs[mt] += (av[mt].x + av[mt].y) + (av[mt].z + av[mt].w);
+        if (row < J.a_rows) {
+          const float* __restrict__ ap = J.a_ptr + (int64_t)t * J.a_tstride + (int64_t)row * J.a_cstride + s0 * J.a_sstride;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) av[mt][kk] = ap[(int64_t)(4 * kk) * J.a_sstride];
+        }
+        rs[mt] += (av[mt][0] + av[mt][1]) + (av[mt][2] + av[mt][3]);
       }
     }
 #pragma unroll
@@ -61,16 +66,18 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
         const DofOuterTile& B = J.tile[nt];
         const int tb = t + B.shift;
         if (tb >= 0 && tb < T) {
-          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (i < B.nc)
-            bv = *reinterpret_cast<const float4*>(B.ptr + (int64_t)tb * B.t_stride + (int64_t)i * B.c_stride + s0);
+          float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (i < B.nc) {
+            const float* __restrict__ bp = B.ptr + (int64_t)tb * B.t_stride + (int64_t)i * B.c_stride + s0 * B.s_stride;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) bv[kk] = bp[(int64_t)(4 * kk) * B.s_stride];
+          }
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             if (mt < MT) {
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv.x, acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv.y, acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv.z, acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv.w, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][kk], bv[kk], acc[mt][nt], 0, 0, 0);
             }
           }
         }

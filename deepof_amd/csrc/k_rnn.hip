@@ -1,10 +1,8 @@
 // Recurrent encoder/decoder kernels.
 //
-// Data layout: every activation is "sequence-minor" SoA  X[t][c][s]  (index (t*C + c)*Sp + s,
-// Sp = sequence count padded to 64).  One HIP thread owns one sequence (and one direction for
-// the GRUs), so all global traffic is coalesced across the 64 lanes of a wavefront, the
-// recurrent state lives in VGPRs, and the (wave-uniform) weights are read through the scalar
-// cache (s_load) -- hidden sizes are 8..32, far too small for MFMA tiles to pay in fp32.
+// Data layout: time-major activations are channel-minor X[t][s][c] (ACT() in dof_rt.h; Sp =
+// sequence count padded to 64); per-window tensors are [c][s].  Hidden sizes are 8..32 -- far too
+// small for MFMA tiles to pay in fp32 -- so the recurrences run on the VALU with the state in VGPRs.
 //
 // Reference semantics restated here:
 //   * tf_style_group_reshape scramble  /root/reference/deepof/clustering/models_new.py:120-138
@@ -17,7 +15,6 @@
 
 namespace {
 
-#define SOA(t, c, C, Sp, s) (((int64_t)(t) * (C) + (c)) * (Sp) + (s))
 
 // ---------------------------------------------------------------------------------------------
 // Encoder stage 1: scrambled read + Conv1d(F -> C1, k=5, same, no bias) + ReLU + mask/length.
@@ -55,7 +52,7 @@ __global__ void __launch_bounds__(256) k_enc_conv_fwd(const float* __restrict__ 
         const int cc = lin / T;
         const int t = lin - cc * T;
         v = win[(int64_t)t * G * F + cc];
-        xs[SOA(tt, f, F, Sp, s)] = v;
+        xs[ACT(tt, f, F, Sp, s)] = v;
       }
       rows[4][f] = v;
     }
@@ -71,7 +68,7 @@ __global__ void __launch_bounds__(256) k_enc_conv_fwd(const float* __restrict__ 
           for (int k = 0; k < 5; ++k) acc = fmaf(wc[(o * F + f) * 5 + k], rows[k][f], acc);
         acc = acc > 0.0f ? acc : 0.0f;
         nz |= (acc != 0.0f);
-        c[SOA(to, o, C1, Sp, s)] = acc;
+        c[ACT(to, o, C1, Sp, s)] = acc;
       }
       count += nz ? 1 : 0;
     }
@@ -140,7 +137,7 @@ __global__ void __launch_bounds__(256) k_gru_fwd(const float* __restrict__ X,  /
     const int t = dir ? (n - 1 - step) : step;
     if (!BCAST) {
 #pragma unroll
-      for (int k = 0; k < IN; ++k) x[k] = X[SOA(t, k, IN, Sp, s)];
+      for (int k = 0; k < IN; ++k) x[k] = X[ACT(t, k, IN, Sp, s)];
     }
     float hn[HID];
 #pragma unroll
@@ -172,24 +169,24 @@ __global__ void __launch_bounds__(256) k_gru_fwd(const float* __restrict__ X,  /
       const float nn = dof_tanh(fmaf(r, ahn, an));
       hn[j] = fmaf(z, h[j] - nn, nn);
       if (gs) {
-        gs[SOA(t, j, 4 * HID, Sp, s)] = r;
-        gs[SOA(t, HID + j, 4 * HID, Sp, s)] = z;
-        gs[SOA(t, 2 * HID + j, 4 * HID, Sp, s)] = nn;
-        gs[SOA(t, 3 * HID + j, 4 * HID, Sp, s)] = ahn;
+        gs[ACT(t, j, 4 * HID, Sp, s)] = r;
+        gs[ACT(t, HID + j, 4 * HID, Sp, s)] = z;
+        gs[ACT(t, 2 * HID + j, 4 * HID, Sp, s)] = nn;
+        gs[ACT(t, 3 * HID + j, 4 * HID, Sp, s)] = ahn;
       }
     }
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
       h[j] = hn[j];
-      O[SOA(t, dir * HID + j, 2 * HID, Sp, s)] = hn[j];
+      O[ACT(t, dir * HID + j, 2 * HID, Sp, s)] = hn[j];
     }
   }
   for (int t = n; t < T; ++t) {
 #pragma unroll
-    for (int j = 0; j < HID; ++j) O[SOA(t, dir * HID + j, 2 * HID, Sp, s)] = 0.0f;
+    for (int j = 0; j < HID; ++j) O[ACT(t, dir * HID + j, 2 * HID, Sp, s)] = 0.0f;
     if (gs) {
 #pragma unroll
-      for (int j = 0; j < 4 * HID; ++j) gs[SOA(t, j, 4 * HID, Sp, s)] = 0.0f;
+      for (int j = 0; j < 4 * HID; ++j) gs[ACT(t, j, 4 * HID, Sp, s)] = 0.0f;
     }
   }
 }
@@ -239,13 +236,13 @@ __global__ void __launch_bounds__(256) k_gru_bwd(const int* __restrict__ len,
     float dhn[HID];
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
-      const float r = gs[SOA(t, j, 4 * HID, Sp, s)];
-      const float z = gs[SOA(t, HID + j, 4 * HID, Sp, s)];
-      const float nn = gs[SOA(t, 2 * HID + j, 4 * HID, Sp, s)];
-      const float ahn = gs[SOA(t, 3 * HID + j, 4 * HID, Sp, s)];
-      const float hp = (step > 0) ? O[SOA(tp, dir * HID + j, 2 * HID, Sp, s)] : 0.0f;
+      const float r = gs[ACT(t, j, 4 * HID, Sp, s)];
+      const float z = gs[ACT(t, HID + j, 4 * HID, Sp, s)];
+      const float nn = gs[ACT(t, 2 * HID + j, 4 * HID, Sp, s)];
+      const float ahn = gs[ACT(t, 3 * HID + j, 4 * HID, Sp, s)];
+      const float hp = (step > 0) ? O[ACT(tp, dir * HID + j, 2 * HID, Sp, s)] : 0.0f;
       float dht = dh[j];
-      if (dO) dht += dO[SOA(t, dir * HID + j, 2 * HID, Sp, s)];
+      if (dO) dht += dO[ACT(t, dir * HID + j, 2 * HID, Sp, s)];
       const float dn = dht * (1.0f - z);
       const float dz = dht * (hp - nn);
       dhn[j] = dht * z;
@@ -256,7 +253,7 @@ __global__ void __launch_bounds__(256) k_gru_bwd(const int* __restrict__ len,
       dg[3 * HID + j] = dnp * r;
     }
 #pragma unroll
-    for (int j = 0; j < 4 * HID; ++j) gs[SOA(t, j, 4 * HID, Sp, s)] = dg[j];
+    for (int j = 0; j < 4 * HID; ++j) gs[ACT(t, j, 4 * HID, Sp, s)] = dg[j];
     // dh_prev += W_hh^T [dr, dz, d(ahn)]
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
@@ -283,7 +280,7 @@ __global__ void __launch_bounds__(256) k_gru_bwd(const int* __restrict__ len,
       for (int k = 0; k < IN; ++k) dxacc[k] += dx[k];
     } else {
 #pragma unroll
-      for (int k = 0; k < IN; ++k) dx_out[SOA(t, k, IN, Sp, s)] = dx[k];
+      for (int k = 0; k < IN; ++k) dx_out[ACT(t, k, IN, Sp, s)] = dx[k];
     }
   }
   if (BCAST) {
@@ -292,7 +289,7 @@ __global__ void __launch_bounds__(256) k_gru_bwd(const int* __restrict__ len,
   } else {
     for (int t = n; t < T; ++t)
 #pragma unroll
-      for (int k = 0; k < IN; ++k) dx_out[SOA(t, k, IN, Sp, s)] = 0.0f;
+      for (int k = 0; k < IN; ++k) dx_out[ACT(t, k, IN, Sp, s)] = 0.0f;
   }
 }
 
@@ -311,7 +308,7 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ X, con
   float mean = 0.0f;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    x[c] = X[SOA(t, c, C, Sp, s)];
+    x[c] = X[ACT(t, c, C, Sp, s)];
     mean += x[c];
   }
   mean *= (1.0f / C);
@@ -323,17 +320,19 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ X, con
   }
   const float rstd = rsqrtf(var * (1.0f / C) + 1e-3f);
 #pragma unroll
-  for (int c = 0; c < C; ++c) Y[SOA(t, c, C, Sp, s)] = fmaf((x[c] - mean) * rstd, dof_cw(gamma)[c], dof_cw(beta)[c]);
+  for (int c = 0; c < C; ++c) Y[ACT(t, c, C, Sp, s)] = fmaf((x[c] - mean) * rstd, dof_cw(gamma)[c], dof_cw(beta)[c]);
 }
 
 // dX = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dY*gamma; per-block partial dgamma/dbeta.
-template <int C>
+// PW = true: per-window tensors [c][s] (the encoder's final LayerNorm, T = 1).
+template <int C, bool PW>
 __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ X, const float* __restrict__ dY1,
                                                 const float* __restrict__ dY2, const float* __restrict__ gamma,
                                                 float* __restrict__ dX, float* __restrict__ partial,  // [nblk][2C]
                                                 int T, int64_t S, int64_t Sp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < (int64_t)T * S;
+#define LNIDX(t, c, s) (PW ? ((int64_t)(c) * Sp + (s)) : ACT(t, c, C, Sp, s))
   float vals[2 * C];
 #pragma unroll
   for (int c = 0; c < 2 * C; ++c) vals[c] = 0.0f;
@@ -344,9 +343,9 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ X, con
     float mean = 0.0f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      x[c] = X[SOA(t, c, C, Sp, s)];
-      dy[c] = dY1[SOA(t, c, C, Sp, s)];
-      if (dY2) dy[c] += dY2[SOA(t, c, C, Sp, s)];
+      x[c] = X[LNIDX(t, c, s)];
+      dy[c] = dY1[LNIDX(t, c, s)];
+      if (dY2) dy[c] += dY2[LNIDX(t, c, s)];
       mean += x[c];
     }
     mean *= (1.0f / C);
@@ -370,9 +369,10 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ X, con
     mg *= (1.0f / C);
     mgx *= (1.0f / C);
 #pragma unroll
-    for (int c = 0; c < C; ++c) dX[SOA(t, c, C, Sp, s)] = rstd * (dy[c] * dof_cw(gamma)[c] - mg - x[c] * mgx);
+    for (int c = 0; c < C; ++c) dX[LNIDX(t, c, s)] = rstd * (dy[c] * dof_cw(gamma)[c] - mg - x[c] * mgx);
   }
   dof_block_colsum<2 * C>(vals, partial + (int64_t)blockIdx.x * 2 * C);
+#undef LNIDX
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) k_enc_final_fwd(const float* __restrict__
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int t = (c < C / 2) ? n - 1 : 0;
-    x[c] = n > 0 ? O2[SOA(t, c, C, Sp, s)] : 0.0f;
+    x[c] = n > 0 ? O2[ACT(t, c, C, Sp, s)] : 0.0f;
     HF[(int64_t)c * Sp + s] = x[c];
     mean += x[c];
   }
@@ -488,10 +488,12 @@ int64_t dof_ln_bwd_blocks(int T, int64_t S) { return dof_cdiv((int64_t)T * S, 25
 int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const float* dY2, const float* gamma,
                       float* dX, float* partial, int T, int64_t S, int64_t Sp, hipStream_t st) {
   const unsigned nb = (unsigned)dof_ln_bwd_blocks(T, S);
-  if (mult == 2) {
-    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_bwd<2 * LL>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp));
+  if (mult == 2 && T == 1) {  // per-window [c][s] tensors (encoder block output)
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_bwd<2 * LL, true>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp));
+  } else if (mult == 2) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_bwd<2 * LL, false>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp));
   } else {
-    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_bwd<4 * LL>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp));
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_bwd<4 * LL, false>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp));
   }
   return dof_check_launch("k_ln_bwd");
 }

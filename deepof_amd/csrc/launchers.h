@@ -30,13 +30,13 @@ int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t 
 // finalize (run-to-run deterministic).
 struct DofOuterTile {  // one 16-column tile of the B operand
   const float* ptr;
-  int64_t t_stride, c_stride;  // element strides of the time and channel axes (s is contiguous)
+  int64_t t_stride, s_stride, c_stride;  // element strides of the time, sequence and channel axes
   int nc;                      // valid columns (<=16); rest masked to 0
   int shift;                   // B is read at time t+shift (skipped when outside [0,T))
 };
 struct DofOuterJob {
   const float* a_ptr;
-  int64_t a_tstride, a_cstride;
+  int64_t a_tstride, a_sstride, a_cstride;
   int a_rows;     // valid A rows (<= 64)
   int T;          // time steps
   int64_t Sp;     // padded sequence count (multiple of 64)

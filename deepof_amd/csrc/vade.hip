@@ -345,15 +345,25 @@ void build_workspace_layout(DofVadePlan* p) {
 }
 
 // ---- weight-gradient job tables (need the bound workspace pointer) ----------------------------
+struct View {  // strided operand of the reduction: element (t, s, c) at p[t*ts + s*ss + c*cs]
+  const float* p;
+  int64_t ts, ss, cs;
+};
+// channel-minor activation [t][s][C], starting at channel c0
+View aos(const float* p, int C, int64_t Sp, int c0 = 0) { return View{p + c0, Sp * C, C, 1}; }
+// per-window tensor [c][s] (no time axis; also used for inputs broadcast over time), from channel c0
+View soa(const float* p, int64_t Sp, int c0 = 0) { return View{p + (int64_t)c0 * Sp, 0, 1, Sp}; }
+
 struct JobBuilder {
   std::vector<DofOuterJob>& jobs;
   std::vector<DofFinJob>& fins;
   int64_t partial_cur = 0;
   int blk_cur = 0, elem_cur = 0;
-  int add_job(const float* a, int64_t ats, int64_t acs, int rows, int T, int64_t Sp) {
+  int add_job(View a, int rows, int T, int64_t Sp) {
     DofOuterJob j;
     memset(&j, 0, sizeof(j));
-    j.a_ptr = a; j.a_tstride = ats; j.a_cstride = acs; j.a_rows = rows; j.T = T; j.Sp = Sp; j.n_tiles = 0;
+    j.a_ptr = a.p; j.a_tstride = a.ts; j.a_sstride = a.ss; j.a_cstride = a.cs; j.a_rows = rows; j.T = T; j.Sp = Sp;
+    j.n_tiles = 0;
     const int64_t units = (int64_t)T * (Sp / 16);
     int64_t nb = (units + 31) / 32;
     if (nb < 1) nb = 1;
@@ -364,10 +374,10 @@ struct JobBuilder {
     jobs.push_back(j);
     return (int)jobs.size() - 1;
   }
-  int add_tile(int job, const float* ptr, int64_t ts, int64_t cs, int nc, int shift) {
+  int add_tile(int job, View b, int nc, int shift) {
     DofOuterJob& j = jobs[job];
     DofOuterTile& t = j.tile[j.n_tiles];
-    t.ptr = ptr; t.t_stride = ts; t.c_stride = cs; t.nc = nc; t.shift = shift;
+    t.ptr = b.p; t.t_stride = b.ts; t.s_stride = b.ss; t.c_stride = b.cs; t.nc = nc; t.shift = shift;
     return j.n_tiles++;
   }
   void add_fin(int job, int col0, int rows, int cols, int r1, int r2, int64_t dst, int64_t rs, int64_t cs) {
@@ -380,14 +390,15 @@ struct JobBuilder {
 };
 
 // One bidirectional GRU layer: per direction A = dG (4*HID rows), tiles = input channels + h_prev.
-void gru_jobs(JobBuilder& jb, const float* dG, const float* X, int64_t x_ts, int IN, const float* O, int HID, int T,
+// X_bcast: the layer input is a per-window vector [IN][Sp] repeated over time (decoder GRU1).
+void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int IN, const float* O, int HID, int T,
               int64_t Sp, const GruOff& g) {
   for (int d = 0; d < 2; ++d) {
     const float* a = dG + (int64_t)d * T * 4 * HID * Sp;
-    const int job = jb.add_job(a, 4LL * HID * Sp, Sp, 4 * HID, T, Sp);
+    const int job = jb.add_job(aos(a, 4 * HID, Sp), 4 * HID, T, Sp);
     for (int c0 = 0; c0 < IN; c0 += 16)
-      jb.add_tile(job, X + (int64_t)c0 * Sp, x_ts, Sp, IN - c0 < 16 ? IN - c0 : 16, 0);
-    const int hh = jb.add_tile(job, O + (int64_t)d * HID * Sp, 2LL * HID * Sp, Sp, HID, d == 0 ? -1 : +1);
+      jb.add_tile(job, x_bcast ? soa(X, Sp, c0) : aos(X, IN, Sp, c0), IN - c0 < 16 ? IN - c0 : 16, 0);
+    const int hh = jb.add_tile(job, aos(O, 2 * HID, Sp, d * HID), HID, d == 0 ? -1 : +1);
     jb.add_fin(job, 0, 3 * HID, IN, 3 * HID, 3 * HID, g.t[d * 4 + 0], IN, 1);            // weight_ih
     jb.add_fin(job, hh * 16, 3 * HID, HID, 2 * HID, 3 * HID, g.t[d * 4 + 1], HID, 1);    // weight_hh (r,z,hn rows)
     jb.add_fin(job, 64, 3 * HID, 1, 3 * HID, 3 * HID, g.t[d * 4 + 2], 1, 1);             // bias_ih
@@ -407,63 +418,63 @@ void build_jobs(DofVadePlan* p) {
     const int C1 = 2 * L;
     // encoder conv: dW[o][f][k] = sum dc[t][o] * xs[t+k-2][f]
     for (int k0 = 0; k0 < 5; k0 += 4) {
-      const int job = jb.add_job(ws + w.dc, (int64_t)C1 * Sp, Sp, C1, T, Sp);
+      const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
       for (int k = k0; k < 5 && k < k0 + 4; ++k) {
-        const int tl = jb.add_tile(job, ws + w.xs, (int64_t)w.F * Sp, Sp, w.F, k - 2);
+        const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), w.F, k - 2);
         jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
       }
     }
-    gru_jobs(jb, ws + w.g1, ws + w.c, (int64_t)C1 * Sp, C1, ws + w.o1, C1, T, Sp, b.g1);
-    gru_jobs(jb, ws + w.g2, ws + w.n1, 4LL * L * Sp, 4 * L, ws + w.o2, L, T, Sp, b.g2);
+    gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1);
+    gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2);
     // CensNet: kernel (D,L) = sum Y ⊗ dZ ; bias = rowsum dZ ; dot weights (D,1) = sum X ⊗ dd
     const int64_t kern = s == 0 ? p->c_nk : p->c_ek, bias = s == 0 ? p->c_nb : p->c_eb;
     const int64_t dotw = s == 0 ? p->c_nw : p->c_ew;
-    int job = jb.add_job(ws + w.Y, 0, Sp, 2 * L, 1, Sp);
-    jb.add_tile(job, ws + w.dZ, 0, Sp, L, 0);
+    int job = jb.add_job(soa(ws + w.Y, Sp), 2 * L, 1, Sp);
+    jb.add_tile(job, soa(ws + w.dZ, Sp), L, 0);
     jb.add_fin(job, 0, 2 * L, L, 2 * L, 2 * L, kern, L, 1);
-    job = jb.add_job(ws + w.dZ, 0, Sp, L, 1, Sp);
-    jb.add_tile(job, ws + w.dZ, 0, Sp, 1, 0);
+    job = jb.add_job(soa(ws + w.dZ, Sp), L, 1, Sp);
+    jb.add_tile(job, soa(ws + w.dZ, Sp), 1, 0);
     jb.add_fin(job, 64, L, 1, L, L, bias, 1, 1);
-    job = jb.add_job(ws + w.n2, 0, Sp, 2 * L, 1, Sp);
-    jb.add_tile(job, ws + w.dd, 0, Sp, 1, 0);
+    job = jb.add_job(soa(ws + w.n2, Sp), 2 * L, 1, Sp);
+    jb.add_tile(job, soa(ws + w.dd, Sp), 1, 0);
     jb.add_fin(job, 0, 2 * L, 1, 2 * L, 2 * L, dotw, 1, 1);
   }
   const int64_t Bp = p->Bp;
   // final dense (L,J): A = flat rows (<=64 per job), B = denc
   for (int r0 = 0; r0 < p->J; r0 += 64) {
     const int rows = p->J - r0 < 64 ? p->J - r0 : 64;
-    const int job = jb.add_job(ws + p->flat + (int64_t)r0 * Bp, 0, Bp, rows, 1, Bp);
-    jb.add_tile(job, ws + p->denc, 0, Bp, L, 0);
+    const int job = jb.add_job(soa(ws + p->flat, Bp, r0), rows, 1, Bp);
+    jb.add_tile(job, soa(ws + p->denc, Bp), L, 0);
     jb.add_fin(job, 0, rows, L, rows, rows, p->fd_w + r0, 1, p->J);
   }
   {
-    int job = jb.add_job(ws + p->denc, 0, Bp, L, 1, Bp);
-    jb.add_tile(job, ws + p->denc, 0, Bp, 1, 0);
+    int job = jb.add_job(soa(ws + p->denc, Bp), L, 1, Bp);
+    jb.add_tile(job, soa(ws + p->denc, Bp), 1, 0);
     jb.add_fin(job, 64, L, 1, L, L, p->fd_b, 1, 1);
-    job = jb.add_job(ws + p->dmu_dpre, 0, Bp, 2 * L, 1, Bp);
-    jb.add_tile(job, ws + p->enc, 0, Bp, L, 0);
+    job = jb.add_job(soa(ws + p->dmu_dpre, Bp), 2 * L, 1, Bp);
+    jb.add_tile(job, soa(ws + p->enc, Bp), L, 0);
     jb.add_fin(job, 0, L, L, L, L, p->mean_w, L, 1);
     jb.add_fin(job, 0, L, L, 0, L, p->lv_w, L, 1);
     jb.add_fin(job, 64, L, 1, L, L, p->mean_b, 1, 1);
     jb.add_fin(job, 64, L, 1, 0, L, p->lv_b, 1, 1);
   }
   // decoder
-  gru_jobs(jb, ws + p->g1d, ws + p->z, 0, L, ws + p->o1d, L, T, Bp, p->dg1);
-  gru_jobs(jb, ws + p->g2d, ws + p->n1d, 2LL * L * Bp, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2);
+  gru_jobs(jb, ws + p->g1d, ws + p->z, true, L, ws + p->o1d, L, T, Bp, p->dg1);
+  gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2);
   {
     const int CI = 4 * L, CO = 2 * L;
     int job = -1;
     for (int k = 0; k < 5; ++k)
       for (int c0 = 0; c0 < CI; c0 += 16) {
-        if (job < 0 || p->jobs[job].n_tiles == 4) job = jb.add_job(ws + p->dcv, (int64_t)CO * Bp, Bp, CO, T, Bp);
+        if (job < 0 || p->jobs[job].n_tiles == 4) job = jb.add_job(aos(ws + p->dcv, CO, Bp), CO, T, Bp);
         const int nc = CI - c0 < 16 ? CI - c0 : 16;
-        const int tl = jb.add_tile(job, ws + p->n2d + (int64_t)c0 * Bp, (int64_t)CI * Bp, Bp, nc, k - 2);
+        const int tl = jb.add_tile(job, aos(ws + p->n2d, CI, Bp, c0), nc, k - 2);
         jb.add_fin(job, tl * 16, CO, nc, CO, CO, p->dconv + (int64_t)c0 * 5 + k, (int64_t)CI * 5, 5);
       }
     for (int r0 = 0; r0 < p->C3; r0 += 64) {
       const int rows = p->C3 - r0 < 64 ? p->C3 - r0 : 64;
-      job = jb.add_job(ws + p->dloc + (int64_t)r0 * Bp, (int64_t)p->C3 * Bp, Bp, rows, T, Bp);
-      jb.add_tile(job, ws + p->n3, (int64_t)CO * Bp, Bp, CO, 0);
+      job = jb.add_job(aos(ws + p->dloc, p->C3, Bp, r0), rows, T, Bp);
+      jb.add_tile(job, aos(ws + p->n3, CO, Bp), CO, 0);
       jb.add_fin(job, 0, rows, CO, rows, rows, p->dpw + (int64_t)r0 * CO, CO, 1);
       jb.add_fin(job, 64, rows, 1, rows, rows, p->dpb + r0, 1, 1);
     }
@@ -473,8 +484,8 @@ void build_jobs(DofVadePlan* p) {
   // Gram of the latent batch (forward-time launch of the same kernel)
   JobBuilder gb{p->gram_jobs, p->gram_fins};
   gb.partial_cur = 0;
-  const int gj = gb.add_job(ws + p->z, 0, Bp, L, 1, Bp);
-  gb.add_tile(gj, ws + p->z, 0, Bp, L, 0);
+  const int gj = gb.add_job(soa(ws + p->z, Bp), L, 1, Bp);
+  gb.add_tile(gj, soa(ws + p->z, Bp), L, 0);
   gb.add_fin(gj, 0, L, L, L, L, p->gram, L, 1);
   p->gram_blocks = gb.blk_cur;
   p->gram_fin_elems = gb.elem_cur;
