@@ -6,6 +6,8 @@
 // tool: it is not shipped, the deepof_amd package never loads it, and there is no CPU fallback.
 #pragma once
 #include <cstdint>
+#include <type_traits>
+#include <utility>
 
 #ifdef DOF_EMU
 #include "emu_rt.h"
@@ -48,6 +50,55 @@ __device__ __forceinline__ int dof_opaque_zero() {
 // perfectly coalesced; Sp = sequence count padded to 64.
 #define ACT(t, c, C, Sp, s) ((((int64_t)(t)) * (Sp) + (s)) * (C) + (c))
 
+// compile-time unrolled loop: dof_static_for<N>([&](auto kc) { constexpr int k = decltype(kc)::value; ... });
+template <class F, int... I>
+__device__ __forceinline__ void dof_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void dof_static_for(F&& f) {
+  dof_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Value held by lane K of this lane's GROUP-lane group (GROUP = 16 or 8, groups aligned to DPP
+// rows).  gfx950: v_mov_b32_dpp row_newbcast:K -- a full-rate VALU op, no LDS crossbar traffic.
+template <int K, int GROUP>
+__device__ __forceinline__ float dof_gbcast(float v) {
+#ifdef DOF_EMU
+  const int lane = (int)(threadIdx.x & 63);
+  return __shfl(v, (lane & ~(GROUP - 1)) | K);
+#else
+  static_assert(GROUP == 16 || GROUP == 8, "group must be 8 or 16 lanes");
+  const int iv = __builtin_bit_cast(int, v);
+  if constexpr (GROUP == 16) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x150 + K, 0xf, 0xf, true));
+  } else {
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x150 + K, 0xf, 0xf, true));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x150 + K + 8, 0xf, 0xf, true));
+    return (threadIdx.x & 8) ? hi : lo;
+  }
+#endif
+}
+
+// One sequence's C channels at one time step are 4C contiguous, 16-byte aligned bytes: move them
+// as dwordx4 (scalar dword accesses at a 4C-byte lane stride touch 64 cache lines per instruction).
+template <int C>
+__device__ __forceinline__ void dof_ld_row(const float* __restrict__ p, float* v) {
+  static_assert(C % 4 == 0, "row width must be a multiple of 4 floats");
+#pragma unroll
+  for (int i = 0; i < C / 4; ++i) {
+    const float4 q = reinterpret_cast<const float4*>(p)[i];
+    v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+  }
+}
+template <int C>
+__device__ __forceinline__ void dof_st_row(float* __restrict__ p, const float* v) {
+  static_assert(C % 4 == 0, "row width must be a multiple of 4 floats");
+#pragma unroll
+  for (int i = 0; i < C / 4; ++i)
+    reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
 #define DOF_OK 0
 #define DOF_ERR_ARG (-1)
 #define DOF_ERR_UNSUPPORTED (-2)
@@ -87,7 +138,9 @@ template <int NV>
 __device__ __forceinline__ void dof_block_colsum(const float* vals, float* out) {
   constexpr int CH = NV < 32 ? NV : 32;
   __shared__ float tile[32][257];
+  __shared__ float part[32][9];
   const int tid = threadIdx.x;
+  const int col = tid & 31, seg = tid >> 5;  // 8 segments of 32 rows per column
 #pragma unroll
   for (int c0 = 0; c0 < NV; c0 += CH) {
     __syncthreads();
@@ -95,9 +148,17 @@ __device__ __forceinline__ void dof_block_colsum(const float* vals, float* out) 
     for (int v = 0; v < CH; ++v)
       if (c0 + v < NV) tile[v][tid] = vals[c0 + v];
     __syncthreads();
+    if (col < CH) {
+      float acc = 0.0f;
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) acc += tile[col][seg * 32 + i];
+      part[col][seg] = acc;
+    }
+    __syncthreads();
     if (tid < CH && c0 + tid < NV) {
       float acc = 0.0f;
-      for (int i = 0; i < 256; ++i) acc += tile[tid][i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += part[tid][k];
       out[c0 + tid] = acc;
     }
   }

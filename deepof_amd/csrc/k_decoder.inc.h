@@ -72,20 +72,21 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
     for (int k = 0; k < 5; ++k) {
       const int ts = t + k - 2;
       if (ts < 0 || ts >= A.T) continue;
+      float xin[CI];
+      dof_ld_row<CI>(A.n2 + ACT(ts, 0, CI, A.Bp, b), xin);
 #pragma unroll
       for (int c = 0; c < CI; ++c) {
-        const float v = A.n2[ACT(ts, c, CI, A.Bp, b)];
 #pragma unroll
-        for (int o = 0; o < CO; ++o) cv[o] = fmaf(wc[(o * CI + c) * 5 + k], v, cv[o]);
+        for (int o = 0; o < CO; ++o) cv[o] = fmaf(wc[(o * CI + c) * 5 + k], xin[c], cv[o]);
       }
     }
     float mean = 0.0f;
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
       cv[o] = cv[o] > 0.0f ? cv[o] : 0.0f;
-      A.cv[ACT(t, o, CO, A.Bp, b)] = cv[o];
       mean += cv[o];
     }
+    dof_st_row<CO>(A.cv + ACT(t, 0, CO, A.Bp, b), cv);
     mean *= (1.0f / CO);
     float var = 0.0f;
     float xh[CO], n3[CO];
@@ -99,8 +100,8 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
     for (int o = 0; o < CO; ++o) {
       xh[o] *= rstd;
       n3[o] = fmaf(xh[o], g3[o], b3[o]);
-      A.n3[ACT(t, o, CO, A.Bp, b)] = n3[o];
     }
+    dof_st_row<CO>(A.n3 + ACT(t, 0, CO, A.Bp, b), n3);
     const bool ok = A.valid[(int64_t)t * A.Bp + b] != 0.0f;
     const float inv_bt = 1.0f / ((float)A.B * (float)A.T);
     const float* __restrict__ xr = A.x + (b * A.T + t) * A.C3;
@@ -138,11 +139,13 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
       }
       mg *= (1.0f / CO);
       mgx *= (1.0f / CO);
+      float drow[CO];
 #pragma unroll
       for (int o = 0; o < CO; ++o) {
         const float d = rstd * (dn3[o] * g3[o] - mg - xh[o] * mgx);
-        A.dcv[ACT(t, o, CO, A.Bp, b)] = cv[o] > 0.0f ? d : 0.0f;
+        drow[o] = cv[o] > 0.0f ? d : 0.0f;
       }
+      dof_st_row<CO>(A.dcv + ACT(t, 0, CO, A.Bp, b), drow);
     }
   }
   dof_block_colsum<1>(nll, A.recon_partial + blockIdx.x);
@@ -166,15 +169,15 @@ __global__ void __launch_bounds__(256) k_dec_conv_bwd(const float* __restrict__ 
   for (int k = 0; k < 5; ++k) {
     const int ts = t - k + 2;
     if (ts < 0 || ts >= T) continue;
+    float drow[CO];
+    dof_ld_row<CO>(dcv + ACT(ts, 0, CO, Bp, b), drow);
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
-      const float v = dcv[ACT(ts, o, CO, Bp, b)];
 #pragma unroll
-      for (int c = 0; c < CI; ++c) acc[c] = fmaf(wcc[(o * CI + c) * 5 + k], v, acc[c]);
+      for (int c = 0; c < CI; ++c) acc[c] = fmaf(wcc[(o * CI + c) * 5 + k], drow[o], acc[c]);
     }
   }
-#pragma unroll
-  for (int c = 0; c < CI; ++c) dn2[ACT(t, c, CI, Bp, b)] = acc[c];
+  dof_st_row<CI>(dn2 + ACT(t, 0, CI, Bp, b), acc);
 }
 
 }  // namespace

@@ -8,68 +8,108 @@
 // a launch writes the reference-layout batch x (B,W,N,3), a (B,W,E,1) for any list of window
 // start rows.  Algorithmic bytes per window: W*(3N+E)*4 written + (3N+E)*4 newly read.
 //
-// Mapping: one thread = one 16-byte store (4 consecutive output floats, coalesced, streaming /
-// non-temporal so the 5.6 KB-per-window write stream does not evict the small, heavily re-read
-// frame rows from L2); the 4 source words come from the (cached) frame rows.
+// Stores are 16-byte, coalesced, streaming / non-temporal so the 5.6 KB-per-window write stream
+// does not evict the small, heavily re-read frame rows from L2; the 4 source words of a store
+// come from the (cached) frame rows.
+#include <cmath>
+
 #include "dof_rt.h"
 #include "deepof_hip.h"
 
 namespace {
 
+constexpr int WB = 16;  // windows per workgroup: keeps every workgroup's output 16-byte aligned
+
+// exact unsigned division for n < 2^24 by a runtime divisor with a precomputed (rounded-down) reciprocal
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float rcp_lo) {
+  unsigned q = (unsigned)((float)n * rcp_lo);  // never overshoots
+  if (n - q * d >= d) ++q;
+  return q;
+}
+
+// Mapping: one workgroup = WB consecutive windows (a 16-byte aligned, 4*WB*W*(3N+E)-byte output
+// run), one thread = one 16-byte streaming store at a time.  All per-element index arithmetic is
+// 32-bit with reciprocal multiplies (the first version spent its time in 64-bit integer division
+// and reached only 25 % of HBM peak); the 64-bit row offsets of the WB windows sit in LDS.
 template <bool INDEXED>
 __global__ void __launch_bounds__(256) k_window_gather(
     const float* __restrict__ node_table, const float* __restrict__ edge_table,
     const int64_t* __restrict__ row_start, int64_t first_row, int64_t row_step, int64_t n_windows,
-    int W, int N, int E, float* __restrict__ x_out, float* __restrict__ a_out) {
+    int W, int N, int E, float rcp_perwin, float rcp_cols, float* __restrict__ x_out, float* __restrict__ a_out) {
+  __shared__ int64_t row0[WB];
   const int C = 3 * N;
-  const int64_t per_win_x = (int64_t)W * C;
-  const int64_t per_win_a = (int64_t)W * E;
-  const int64_t total_x = n_windows * per_win_x;
-  const int64_t total_a = n_windows * per_win_a;
-  const int64_t quads_x = (total_x + 3) >> 2;
-  const int64_t quads_a = (total_a + 3) >> 2;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads_x + quads_a; q += stride) {
-    const bool is_x = q < quads_x;
-    const int64_t base = (is_x ? q : q - quads_x) << 2;
-    const int64_t total = is_x ? total_x : total_a;
-    const int64_t per_win = is_x ? per_win_x : per_win_a;
-    const int cols = is_x ? C : E;
-    const float* __restrict__ table = is_x ? node_table : edge_table;
-    float v[4];
+  const unsigned per_x = (unsigned)(W * C), per_a = (unsigned)(W * E);
+  const int64_t w0 = (int64_t)blockIdx.x * WB;
+  const int nwin = (int)((n_windows - w0) < WB ? (n_windows - w0) : WB);
+  if ((int)threadIdx.x < nwin)
+    row0[threadIdx.x] = INDEXED ? row_start[w0 + threadIdx.x] : first_row + (w0 + threadIdx.x) * row_step;
+  __syncthreads();
+  // ---- nodes: (rows, [x..|y..|s..]) -> (W, N, 3)
+  {
+    float* __restrict__ out = x_out + w0 * per_x;
+    const unsigned total = (unsigned)nwin * per_x;
+    for (unsigned e0 = 4 * threadIdx.x; e0 < total; e0 += 4 * 256) {
+      float v[4];
+      unsigned w = fast_div(e0, per_x, rcp_perwin);
+      unsigned o = e0 - w * per_x;
+      unsigned t = fast_div(o, (unsigned)C, rcp_cols);
+      unsigned r = o - t * C;
+      unsigned n = (r * 43691u) >> 17;  // r / 3 for r < 2^16
+      unsigned f = r - 3 * n;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t i = base + j;
-      float val = 0.0f;
-      if (i < total) {
-        const int64_t b = i / per_win;
-        const int o = (int)(i - b * per_win);
-        const int t = o / cols;
-        const int r = o - t * cols;
-        int src_col = r;
-        if (is_x) {
-          const int n = r / 3;
-          const int f = r - 3 * n;
-          src_col = f * N + n;
-        }
-        const int64_t row = (INDEXED ? row_start[b] : first_row + b * row_step) + t;
-        val = table[row * cols + src_col];
+      for (int j = 0; j < 4; ++j) {
+        v[j] = (e0 + j < total) ? node_table[(row0[w] + t) * C + f * N + n] : 0.0f;
+        if (++f == 3) { f = 0; ++n; }
+        if (++r == (unsigned)C) { r = 0; n = 0; f = 0; ++t; }
+        if (++o == per_x) { o = 0; t = 0; ++w; if (w >= (unsigned)nwin) w = nwin - 1; }
       }
-      v[j] = val;
-    }
-    float* __restrict__ out = is_x ? x_out : a_out;
-    if (base + 3 < total) {
+      if (e0 + 3 < total) {
 #ifdef DOF_EMU
-      out[base] = v[0]; out[base + 1] = v[1]; out[base + 2] = v[2]; out[base + 3] = v[3];
+        out[e0] = v[0]; out[e0 + 1] = v[1]; out[e0 + 2] = v[2]; out[e0 + 3] = v[3];
 #else
-      dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
-      __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + base));
+        dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + e0));
 #endif
-    } else {
-      for (int j = 0; j < 4; ++j)
-        if (base + j < total) out[base + j] = v[j];
+      } else {
+        for (int j = 0; j < 4; ++j)
+          if (e0 + j < total) out[e0 + j] = v[j];
+      }
     }
   }
+  // ---- edges: a window is W*E contiguous source floats
+  {
+    float* __restrict__ out = a_out + w0 * per_a;
+    const unsigned total = (unsigned)nwin * per_a;
+    const float rcp_pa = rcp_perwin * ((float)C / (float)E) * 0.999999f;
+    for (unsigned e0 = 4 * threadIdx.x; e0 < total; e0 += 4 * 256) {
+      float v[4];
+      unsigned w = fast_div(e0, per_a, rcp_pa);
+      unsigned o = e0 - w * per_a;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = (e0 + j < total) ? edge_table[row0[w] * E + o] : 0.0f;
+        if (++o == per_a) { o = 0; ++w; if (w >= (unsigned)nwin) w = nwin - 1; }
+      }
+      if (e0 + 3 < total) {
+#ifdef DOF_EMU
+        out[e0] = v[0]; out[e0 + 1] = v[1]; out[e0 + 2] = v[2]; out[e0 + 3] = v[3];
+#else
+        dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + e0));
+#endif
+      } else {
+        for (int j = 0; j < 4; ++j)
+          if (e0 + j < total) out[e0 + j] = v[j];
+      }
+    }
+  }
+}
+
+// largest float not above 1/d (so fast_div's first guess never overshoots)
+float rcp_down(unsigned d) {
+  float r = 1.0f / (float)d;
+  while ((double)r * (double)d > 1.0) r = nextafterf(r, 0.0f);
+  return r * 0.9999999f;
 }
 
 int launch_gather(const float* node_table, const float* edge_table, const int64_t* row_start, int64_t first_row,
@@ -79,16 +119,19 @@ int launch_gather(const float* node_table, const float* edge_table, const int64_
     dof_set_error("dof_window_gather: bad argument");
     return DOF_ERR_ARG;
   }
+  if ((int64_t)WB * W * 3 * N >= (1 << 24) || (int64_t)WB * W * E >= (1 << 24)) {
+    dof_set_error("dof_window_gather: window too large (W*3N*16 must stay below 2^24)");
+    return DOF_ERR_UNSUPPORTED;
+  }
   if (n_windows == 0) return DOF_OK;
-  const int64_t quads = (n_windows * (int64_t)W * (3 * N + E) + 3) / 4 + 1;
-  int64_t blocks = (quads + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;  // 16 workgroups per CU, grid-stride the rest
+  const unsigned blocks = (unsigned)((n_windows + WB - 1) / WB);
+  const float rp = rcp_down((unsigned)(W * 3 * N)), rc = rcp_down((unsigned)(3 * N));
   if (row_start)
-    DOF_LAUNCH(k_window_gather<true>, ((unsigned)blocks), (256), stream, node_table, edge_table, row_start, first_row,
-               row_step, n_windows, W, N, E, x_out, a_out);
+    DOF_LAUNCH(k_window_gather<true>, (blocks), (256), stream, node_table, edge_table, row_start, first_row, row_step,
+               n_windows, W, N, E, rp, rc, x_out, a_out);
   else
-    DOF_LAUNCH(k_window_gather<false>, ((unsigned)blocks), (256), stream, node_table, edge_table, row_start, first_row,
-               row_step, n_windows, W, N, E, x_out, a_out);
+    DOF_LAUNCH(k_window_gather<false>, (blocks), (256), stream, node_table, edge_table, row_start, first_row,
+               row_step, n_windows, W, N, E, rp, rc, x_out, a_out);
   return dof_check_launch("k_window_gather");
 }
 

@@ -166,20 +166,49 @@ struct LatentFwdArgs {
   int64_t B, Bp;
 };
 
+// encoder.final_dense: enc[l][b] = bf[l] + sum_j wf[l][j] flat[j][b]; thread = (b, l = blockIdx.y)
+__global__ void __launch_bounds__(256) k_final_dense(const float* __restrict__ flat, const float* __restrict__ wf_,
+                                                     const float* __restrict__ bf_, float* __restrict__ enc, int J,
+                                                     int64_t B, int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int l = blockIdx.y;
+  const dof_cfp wf = dof_cw(wf_) + (int64_t)l * J;
+  float a0 = dof_cw(bf_)[l], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int j = 0;
+  for (; j + 3 < J; j += 4) {
+    a0 = fmaf(wf[j], flat[(int64_t)j * Bp + b], a0);
+    a1 = fmaf(wf[j + 1], flat[(int64_t)(j + 1) * Bp + b], a1);
+    a2 = fmaf(wf[j + 2], flat[(int64_t)(j + 2) * Bp + b], a2);
+    a3 = fmaf(wf[j + 3], flat[(int64_t)(j + 3) * Bp + b], a3);
+  }
+  for (; j < J; ++j) a0 = fmaf(wf[j], flat[(int64_t)j * Bp + b], a0);
+  enc[(int64_t)l * Bp + b] = (a0 + a1) + (a2 + a3);
+}
+
+// d flat[j][b] = sum_l wf[l][j] denc[l][b]; thread = (b, j = blockIdx.y)
+template <int L>
+__global__ void __launch_bounds__(256) k_final_dense_bwd(const float* __restrict__ denc, const float* __restrict__ wf_,
+                                                         float* __restrict__ dflat, int J, int64_t B, int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int j = blockIdx.y;
+  const dof_cfp wf = dof_cw(wf_);
+  float acc = 0.0f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) acc = fmaf(wf[l * J + j], denc[(int64_t)l * Bp + b], acc);
+  dflat[(int64_t)j * Bp + b] = acc;
+}
+
 template <int L>
 __global__ void __launch_bounds__(256) k_latent_fwd(LatentFwdArgs A) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= A.B) return;
-  const dof_cfp wf = dof_cw(A.wf), bf = dof_cw(A.bf), wm = dof_cw(A.wm), bm = dof_cw(A.bm), wsv = dof_cw(A.ws),
+  const dof_cfp wm = dof_cw(A.wm), bm = dof_cw(A.bm), wsv = dof_cw(A.ws),
                 bsv = dof_cw(A.bs), gmeans = dof_cw(A.gmm_means), glv = dof_cw(A.gmm_log_vars), prior = dof_cw(A.prior);
   float enc[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) enc[l] = bf[l];
-  for (int j = 0; j < A.J; ++j) {
-    const float f = A.flat[(int64_t)j * A.Bp + b];
-#pragma unroll
-    for (int l = 0; l < L; ++l) enc[l] = fmaf(wf[l * A.J + j], f, enc[l]);
-  }
+  for (int l = 0; l < L; ++l) enc[l] = A.enc[(int64_t)l * A.Bp + b];
   float z[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
@@ -191,7 +220,6 @@ __global__ void __launch_bounds__(256) k_latent_fwd(LatentFwdArgs A) {
     }
     const float sv = dof_softplus(p);
     z[l] = A.eps ? fmaf(expf(0.5f * sv), A.eps[b * L + l], m) : m;
-    A.enc[(int64_t)l * A.Bp + b] = enc[l];
     A.mu[(int64_t)l * A.Bp + b] = m;
     A.pre[(int64_t)l * A.Bp + b] = p;
     A.sv[(int64_t)l * A.Bp + b] = sv;
@@ -437,6 +465,23 @@ __global__ void __launch_bounds__(256) k_mckl_fwd(McklArgs A) {
   for (int d = 0; d < L; ++d) A.dz[((int64_t)smp * L + d) * A.Bp + b] = g[d] / se;
 }
 
+// sum over the S samples of dlogp/dz and dlogp/dz * eps; thread = (b, d = blockIdx.y)
+__global__ void __launch_bounds__(256) k_mckl_reduce(const float* __restrict__ dz, const float* __restrict__ eps_mc,
+                                                     float* __restrict__ gsum /*[2L][Bp]*/, int S, int L, int64_t B,
+                                                     int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int d = blockIdx.y;
+  float gz = 0.0f, gze = 0.0f;
+  for (int smp = 0; smp < S; ++smp) {
+    const float g = dz[((int64_t)smp * L + d) * Bp + b];
+    gz += g;
+    gze = fmaf(g, eps_mc[((int64_t)smp * B + b) * L + d], gze);
+  }
+  gsum[(int64_t)d * Bp + b] = gz;
+  gsum[(int64_t)(L + d) * Bp + b] = gze;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Loss assembly (one thread): every scalar of VadeLoss + the small tensors the backward needs.
 // ---------------------------------------------------------------------------------------------
@@ -566,7 +611,7 @@ struct LatentBwdArgs {
   const float *enc, *mu, *pre, *sv, *z, *q, *qn;
   const float* eps;        // (B,L)
   const float* eps_mc;     // (S,B,L) or null
-  const float* mckl_dz;    // [S][L][Bp] or null
+  const float* mckl_gsum;  // [2L][Bp] sample sums of dlogp/dz and dlogp/dz*eps, or null
   const float* dz_dec;     // [2][L][Bp] from the decoder
   const float *wf, *wm, *ws, *gmm_means, *gmm_log_vars;
   const float *Pm, *dcen, *dqbar, *scal, *hyper;
@@ -589,7 +634,7 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
   float ce_w = 0.0f;
   if (live) {
     const dof_cfp H = dof_cw(A.hyper);
-    const dof_cfp wf = dof_cw(A.wf), wm = dof_cw(A.wm), wsv = dof_cw(A.ws), gmeans = dof_cw(A.gmm_means),
+    const dof_cfp wm = dof_cw(A.wm), wsv = dof_cw(A.ws), gmeans = dof_cw(A.gmm_means),
                   glv = dof_cw(A.gmm_log_vars);
     const float Bf = (float)A.B;
     const int K = A.K;
@@ -689,12 +734,8 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       } else {
         const float ksc = A.scal[0];
         if (ksc != 0.0f) {
-          float gz = 0.0f, gze = 0.0f;
-          for (int smp = 0; smp < A.S; ++smp) {
-            const float g = A.mckl_dz[((int64_t)smp * L + d) * A.Bp + b];
-            gz += g;
-            gze = fmaf(g, A.eps_mc[((int64_t)smp * A.B + b) * L + d], gze);
-          }
+          const float gz = A.mckl_gsum[(int64_t)d * A.Bp + b];
+          const float gze = A.mckl_gsum[(int64_t)(L + d) * A.Bp + b];
           dm = fmaf(-ksc, gz, dm);
           if (pass) ds += ksc * (-gze * 0.5f * expf(0.5f * sc) - 0.5f * (float)A.S);
         }
@@ -716,12 +757,6 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       denc[k] = acc;
       A.denc[(int64_t)k * A.Bp + b] = acc;
     }
-    for (int j = 0; j < A.J; ++j) {
-      float acc = 0.0f;
-#pragma unroll
-      for (int l = 0; l < L; ++l) acc = fmaf(wf[l * A.J + j], denc[l], acc);
-      A.dflat[(int64_t)j * A.Bp + b] = acc;
-    }
   }
   float v1[1] = {ce_w};
   dof_block_colsum<1>(v1, A.distill_partial + blockIdx.x);
@@ -734,7 +769,7 @@ struct GmmGradArgs {
   const float *z, *dlogit;           // [L][Bp], [K][Bp]
   const float *mu, *sv, *eps_mc, *lse;  // MC-KL recompute (main) or null
   const float *gmm_means, *gmm_log_vars, *prior, *scal, *hyper;
-  float *g_means, *g_log_vars;       // (K,L) destinations inside the grad buffer
+  float* partial;                    // [gridDim.y][2*K*L]: means (K,L) then log-vars (K,L)
   int K, S, pretrain;
   int64_t B, Bp;
 };
@@ -751,7 +786,9 @@ __global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A) {
     m[d] = A.gmm_means[c * L + d];
     lvraw[d] = A.gmm_log_vars[c * L + d];
   }
-  for (int64_t b = threadIdx.x; b < A.B; b += 256) {
+  const int64_t tstride = (int64_t)gridDim.y * 256;
+  const int64_t t0 = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  for (int64_t b = t0; b < A.B; b += tstride) {
     const float dl = A.dlogit[(int64_t)c * A.Bp + b];
 #pragma unroll
     for (int d = 0; d < L; ++d) {
@@ -768,7 +805,7 @@ __global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A) {
     const float lo = A.hyper[DOF_H_LOGVAR_LO], hi = A.hyper[DOF_H_LOGVAR_HI];
     const float lp = logf(fmaxf(A.prior[c], 1e-8f));
     const int64_t n = (int64_t)A.S * A.B;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
+    for (int64_t i = t0; i < n; i += tstride) {
       const int smp = (int)(i / A.B);
       const int64_t b = i - (int64_t)smp * A.B;
       float zs[L];
@@ -792,8 +829,9 @@ __global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A) {
   __shared__ float out[2 * L];
   dof_block_colsum<2 * L>(vals, out);
   __syncthreads();
-  if (threadIdx.x < L) A.g_means[c * L + threadIdx.x] = out[threadIdx.x];
-  else if (threadIdx.x < 2 * L) A.g_log_vars[c * L + threadIdx.x - L] = out[threadIdx.x];
+  float* __restrict__ dst = A.partial + (int64_t)blockIdx.y * 2 * A.K * L;
+  if (threadIdx.x < L) dst[c * L + threadIdx.x] = out[threadIdx.x];
+  else if (threadIdx.x < 2 * L) dst[A.K * L + c * L + threadIdx.x - L] = out[threadIdx.x];
 }
 
 // generic per-block sums of a [n][Bp]-strided SoA scalar field (used for the MC-KL term)

@@ -18,7 +18,7 @@ namespace {
 
 __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ jobs, int njobs,
                                                float* __restrict__ partials) {
-  __shared__ float red[4][64][65];
+  __shared__ float red[64][65];
   int jid = 0;
   for (int j = 0; j < njobs; ++j)
     if ((int)blockIdx.x >= jobs[j].blk0) jid = j;
@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
   const int64_t n_units = (int64_t)T * chunks;
   const int MT = (J.a_rows + 15) >> 4;
   const int NT = J.n_tiles;
+  const int64_t stride = (int64_t)J.nblk * 4;
 
   dof_f32x4 acc[4][4];
   float rs[4];
@@ -42,66 +43,92 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
     for (int b = 0; b < 4; ++b) acc[a][b] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
 
-  for (int64_t u = (int64_t)blk * 4 + wave; u < n_units; u += (int64_t)J.nblk * 4) {
+  float av[4][4], bv[4][4];      // operands of the unit being multiplied   [tile][k-slice]
+  float an[4][4], bn[4][4];      // operands of the next unit, in flight while the MFMAs run
+  auto load_unit = [&](int64_t u, float (&A)[4][4], float (&B)[4][4]) {
     const int t = (int)(u / chunks);
-    const int64_t s0 = ((u - (int64_t)t * chunks) << 4) + q;  // this lane's sequence in k-slice 0
-    float av[4][4];  // [row tile][k-slice]
+    const int64_t s0 = ((u - (int64_t)t * chunks) << 4) + q;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) av[mt][kk] = 0.0f;
-      if (mt < MT) {
-        const int row = mt * 16 + i;
-        if (row < J.a_rows) {
-          const float* __restrict__ ap = J.a_ptr + (int64_t)t * J.a_tstride + (int64_t)row * J.a_cstride + s0 * J.a_sstride;
+      for (int kk = 0; kk < 4; ++kk) A[mt][kk] = 0.0f;
+      const int row = mt * 16 + i;
+      if (mt < MT && row < J.a_rows) {
+        const float* __restrict__ ap = J.a_ptr + (int64_t)t * J.a_tstride + (int64_t)row * J.a_cstride + s0 * J.a_sstride;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) av[mt][kk] = ap[(int64_t)(4 * kk) * J.a_sstride];
-        }
-        rs[mt] += (av[mt][0] + av[mt][1]) + (av[mt][2] + av[mt][3]);
+        for (int kk = 0; kk < 4; ++kk) A[mt][kk] = ap[(int64_t)(4 * kk) * J.a_sstride];
       }
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) B[nt][kk] = 0.0f;
       if (nt < NT) {
-        const DofOuterTile& B = J.tile[nt];
-        const int tb = t + B.shift;
-        if (tb >= 0 && tb < T) {
-          float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (i < B.nc) {
-            const float* __restrict__ bp = B.ptr + (int64_t)tb * B.t_stride + (int64_t)i * B.c_stride + s0 * B.s_stride;
+        const DofOuterTile& Bt = J.tile[nt];
+        const int tb = t + Bt.shift;
+        if (tb >= 0 && tb < T && i < Bt.nc) {
+          const float* __restrict__ bp = Bt.ptr + (int64_t)tb * Bt.t_stride + (int64_t)i * Bt.c_stride + s0 * Bt.s_stride;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) bv[kk] = bp[(int64_t)(4 * kk) * B.s_stride];
-          }
+          for (int kk = 0; kk < 4; ++kk) B[nt][kk] = bp[(int64_t)(4 * kk) * Bt.s_stride];
+        }
+      }
+    }
+  };
+
+  int64_t u = (int64_t)blk * 4 + wave;
+  if (u < n_units) load_unit(u, av, bv);
+  for (; u < n_units; u += stride) {
+    const bool more = u + stride < n_units;
+    if (more) load_unit(u + stride, an, bn);
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            if (mt < MT) {
+    for (int mt = 0; mt < 4; ++mt) {
+      if (mt < MT) {
+        rs[mt] += (av[mt][0] + av[mt][1]) + (av[mt][2] + av[mt][3]);
 #pragma unroll
-              for (int kk = 0; kk < 4; ++kk)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][kk], bv[kk], acc[mt][nt], 0, 0, 0);
-            }
+        for (int nt = 0; nt < 4; ++nt) {
+          if (nt < NT) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][kk], bv[nt][kk], acc[mt][nt], 0, 0, 0);
           }
         }
       }
     }
+    if (more) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          av[a][kk] = an[a][kk];
+          bv[a][kk] = bn[a][kk];
+        }
+    }
   }
-  // wave tiles -> LDS.  D layout of mfma_f32_16x16x4: lane holds rows (lane>>4)*4 + r, col lane&15.
+  // Sum the four waves' tiles through one LDS tile (fixed wave order => deterministic).
+  // D layout of mfma_f32_16x16x4: lane holds rows (lane>>4)*4 + r, col lane&15.
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    float r = rs[mt];
-    r += __shfl_xor(r, 16);
-    r += __shfl_xor(r, 32);
-    if (q == 0) red[wave][mt * 16 + i][64] = r;
+      for (int mt = 0; mt < 4; ++mt) {
+        float r = rs[mt];
+        r += __shfl_xor(r, 16);
+        r += __shfl_xor(r, 32);
+        if (q == 0) red[mt * 16 + i][64] = (w == 0 ? 0.0f : red[mt * 16 + i][64]) + r;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) red[wave][mt * 16 + q * 4 + r4][nt * 16 + i] = acc[mt][nt][r4];
+          for (int r4 = 0; r4 < 4; ++r4) {
+            float* cell = &red[mt * 16 + q * 4 + r4][nt * 16 + i];
+            *cell = (w == 0 ? 0.0f : *cell) + acc[mt][nt][r4];
+          }
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   float* __restrict__ out = partials + J.partial_off + (int64_t)blk * DOF_OUTER_PARTIAL_FLOATS;
   for (int e = threadIdx.x; e < 64 * 65; e += 256) {
     const int row = e / 65, col = e - row * 65;
-    if (row < J.a_rows && (col < NT * 16 || col == 64))
-      out[e] = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+    if (row < J.a_rows && (col < NT * 16 || col == 64)) out[e] = red[row][col];
   }
 }
 

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(256) k_enc_conv_fwd(const float* __restrict__ 
     const int to = tt - 2;  // output time whose 5-tap window [to-2, to+2] is now in rows[0..4]
     if (to >= 0) {
       bool nz = false;
+      float crow[C1];
 #pragma unroll
       for (int o = 0; o < C1; ++o) {
         float acc = 0.0f;
@@ -68,8 +69,9 @@ __global__ void __launch_bounds__(256) k_enc_conv_fwd(const float* __restrict__ 
           for (int k = 0; k < 5; ++k) acc = fmaf(wc[(o * F + f) * 5 + k], rows[k][f], acc);
         acc = acc > 0.0f ? acc : 0.0f;
         nz |= (acc != 0.0f);
-        c[ACT(to, o, C1, Sp, s)] = acc;
+        crow[o] = acc;
       }
+      dof_st_row<C1>(c + ACT(to, 0, C1, Sp, s), crow);
       count += nz ? 1 : 0;
     }
   }
@@ -294,6 +296,207 @@ __global__ void __launch_bounds__(256) k_gru_bwd(const int* __restrict__ len,
 }
 
 // ---------------------------------------------------------------------------------------------
+// GRU, weight-stationary form (latent 8: hidden sizes 16 and 8).  One LANE per hidden unit: the
+// 16 (or 8) lanes of a DPP row own the units of one (sequence, direction), keep their three gate
+// rows of W_ih / W_hh in VGPRs for the whole sequence (no weight traffic inside the time loop) and
+// exchange x_t / h_{t-1} with row_newbcast DPP moves.  16x (8x) more wavefronts than the
+// one-thread-per-sequence form above, which at batch 1024 was pure latency (<= 1 wave per SIMD).
+// Same saved-gate / dG buffers and the same arithmetic; the generic kernels remain the path for
+// other latent sizes.
+// ---------------------------------------------------------------------------------------------
+template <int IN, int HID, bool BCAST>
+__global__ void __launch_bounds__(256) k_gru3_fwd(const float* __restrict__ X, const int* __restrict__ len,
+                                                  const float* __restrict__ wih0, const float* __restrict__ whh0,
+                                                  const float* __restrict__ bih0, const float* __restrict__ bhh0,
+                                                  const float* __restrict__ wih1, const float* __restrict__ whh1,
+                                                  const float* __restrict__ bih1, const float* __restrict__ bhh1,
+                                                  float* __restrict__ O, float* __restrict__ GS, int T, int64_t S,
+                                                  int64_t Sp) {
+  constexpr int G = HID;
+  const int u = threadIdx.x % G;
+  const int64_t s = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const int dir = blockIdx.y;
+  if (s >= S) return;  // whole groups leave together
+  const float* __restrict__ wih = dir ? wih1 : wih0;
+  const float* __restrict__ whh = dir ? whh1 : whh0;
+  const float* __restrict__ bih = dir ? bih1 : bih0;
+  const float* __restrict__ bhh = dir ? bhh1 : bhh0;
+  float wr[IN], wz[IN], wn[IN], hr[HID], hz[HID], hnw[HID];
+#pragma unroll
+  for (int k = 0; k < IN; ++k) {
+    wr[k] = wih[u * IN + k];
+    wz[k] = wih[(HID + u) * IN + k];
+    wn[k] = wih[(2 * HID + u) * IN + k];
+  }
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    hr[k] = whh[u * HID + k];
+    hz[k] = whh[(HID + u) * HID + k];
+    hnw[k] = whh[(2 * HID + u) * HID + k];
+  }
+  float br = bih[u] + bhh[u], bz = bih[HID + u] + bhh[HID + u], bin = bih[2 * HID + u];
+  const float bhn = bhh[2 * HID + u];
+  if (BCAST) {  // input constant over time: fold W_ih x into the biases once
+#pragma unroll
+    for (int k = 0; k < IN; ++k) {
+      const float xk = X[(int64_t)k * Sp + s];
+      br = fmaf(wr[k], xk, br);
+      bz = fmaf(wz[k], xk, bz);
+      bin = fmaf(wn[k], xk, bin);
+    }
+  }
+  float* __restrict__ gs = GS ? GS + (int64_t)dir * T * 4 * HID * Sp : nullptr;
+  const int n = len[s];
+  float h = 0.0f;
+  for (int step = 0; step < n; ++step) {
+    const int t = dir ? (n - 1 - step) : step;
+    float ar = br, az = bz, an = bin, ahn = bhn;
+    if (!BCAST) {
+      if (IN == G) {
+        const float xu = X[ACT(t, u, IN, Sp, s)];
+        dof_static_for<IN>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const float b = dof_gbcast<k, G>(xu);
+          ar = fmaf(wr[k], b, ar);
+          az = fmaf(wz[k], b, az);
+          an = fmaf(wn[k], b, an);
+        });
+      } else {  // wider input than the group: every lane reads the (group-uniform) input row
+        float xrow[IN];
+        dof_ld_row<IN>(X + ACT(t, 0, IN, Sp, s), xrow);
+#pragma unroll
+        for (int k = 0; k < IN; ++k) {
+          ar = fmaf(wr[k], xrow[k], ar);
+          az = fmaf(wz[k], xrow[k], az);
+          an = fmaf(wn[k], xrow[k], an);
+        }
+      }
+    }
+    dof_static_for<HID>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const float b = dof_gbcast<k, G>(h);
+      ar = fmaf(hr[k], b, ar);
+      az = fmaf(hz[k], b, az);
+      ahn = fmaf(hnw[k], b, ahn);
+    });
+    const float r = dof_sigmoid(ar);
+    const float z = dof_sigmoid(az);
+    const float nn = dof_tanh(fmaf(r, ahn, an));
+    h = fmaf(z, h - nn, nn);
+    O[ACT(t, dir * HID + u, 2 * HID, Sp, s)] = h;
+    if (gs) {
+      gs[ACT(t, u, 4 * HID, Sp, s)] = r;
+      gs[ACT(t, HID + u, 4 * HID, Sp, s)] = z;
+      gs[ACT(t, 2 * HID + u, 4 * HID, Sp, s)] = nn;
+      gs[ACT(t, 3 * HID + u, 4 * HID, Sp, s)] = ahn;
+    }
+  }
+  for (int t = n; t < T; ++t) {
+    O[ACT(t, dir * HID + u, 2 * HID, Sp, s)] = 0.0f;
+    if (gs) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gs[ACT(t, g * HID + u, 4 * HID, Sp, s)] = 0.0f;
+    }
+  }
+}
+
+template <int IN, int HID, bool BCAST>
+__global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, const float* __restrict__ wih0,
+                                                  const float* __restrict__ whh0, const float* __restrict__ wih1,
+                                                  const float* __restrict__ whh1, const float* __restrict__ O,
+                                                  float* __restrict__ GS, const float* __restrict__ dO,
+                                                  const float* __restrict__ dHfin, float* __restrict__ dX, int T,
+                                                  int64_t S, int64_t Sp) {
+  constexpr int G = HID;
+  constexpr int M = IN / G;  // input columns handled by this lane: u, u+G, ...
+  static_assert(IN % G == 0, "input width must be a multiple of the group width");
+  const int u = threadIdx.x % G;
+  const int64_t s = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const int dir = blockIdx.y;
+  if (s >= S) return;
+  const float* __restrict__ wih = dir ? wih1 : wih0;
+  const float* __restrict__ whh = dir ? whh1 : whh0;
+  // transposed views: column u of W_hh, columns u + m*G of W_ih
+  float tr[HID], tz[HID], tn[HID];
+  float xr[M][HID], xz[M][HID], xn[M][HID];
+#pragma unroll
+  for (int j = 0; j < HID; ++j) {
+    tr[j] = whh[j * HID + u];
+    tz[j] = whh[(HID + j) * HID + u];
+    tn[j] = whh[(2 * HID + j) * HID + u];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      xr[m][j] = wih[j * IN + u + m * G];
+      xz[m][j] = wih[(HID + j) * IN + u + m * G];
+      xn[m][j] = wih[(2 * HID + j) * IN + u + m * G];
+    }
+  }
+  float* __restrict__ gs = GS + (int64_t)dir * T * 4 * HID * Sp;
+  float* __restrict__ dx_out = dX + (int64_t)dir * (BCAST ? 1 : T) * IN * Sp;
+  const int n = len[s];
+  float dh = (dHfin && n > 0) ? dHfin[(int64_t)(dir * HID + u) * Sp + s] : 0.0f;
+  float dxacc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) dxacc[m] = 0.0f;
+  for (int step = n - 1; step >= 0; --step) {
+    const int t = dir ? (n - 1 - step) : step;
+    const int tp = dir ? t + 1 : t - 1;
+    const float r = gs[ACT(t, u, 4 * HID, Sp, s)];
+    const float z = gs[ACT(t, HID + u, 4 * HID, Sp, s)];
+    const float nn = gs[ACT(t, 2 * HID + u, 4 * HID, Sp, s)];
+    const float ahn = gs[ACT(t, 3 * HID + u, 4 * HID, Sp, s)];
+    const float hp = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
+    float dht = dh;
+    if (dO) dht += dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)];
+    const float dn = dht * (1.0f - z);
+    const float dz = dht * (hp - nn);
+    const float dnp = dn * (1.0f - nn * nn);
+    const float g_r = dnp * ahn * r * (1.0f - r);
+    const float g_z = dz * z * (1.0f - z);
+    const float g_n = dnp;
+    const float g_h = dnp * r;
+    gs[ACT(t, u, 4 * HID, Sp, s)] = g_r;
+    gs[ACT(t, HID + u, 4 * HID, Sp, s)] = g_z;
+    gs[ACT(t, 2 * HID + u, 4 * HID, Sp, s)] = g_n;
+    gs[ACT(t, 3 * HID + u, 4 * HID, Sp, s)] = g_h;
+    float dhp = dht * z;
+    float dx[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) dx[m] = 0.0f;
+    dof_static_for<HID>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const float b_r = dof_gbcast<j, G>(g_r);
+      const float b_z = dof_gbcast<j, G>(g_z);
+      const float b_n = dof_gbcast<j, G>(g_n);
+      const float b_h = dof_gbcast<j, G>(g_h);
+      dhp = fmaf(tr[j], b_r, dhp);
+      dhp = fmaf(tz[j], b_z, dhp);
+      dhp = fmaf(tn[j], b_h, dhp);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        dx[m] = fmaf(xr[m][j], b_r, dx[m]);
+        dx[m] = fmaf(xz[m][j], b_z, dx[m]);
+        dx[m] = fmaf(xn[m][j], b_n, dx[m]);
+      }
+    });
+    dh = dhp;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (BCAST) dxacc[m] += dx[m];
+      else dx_out[ACT(t, u + m * G, IN, Sp, s)] = dx[m];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (BCAST) {
+      dx_out[(int64_t)(u + m * G) * Sp + s] = dxacc[m];
+    } else {
+      for (int t = n; t < T; ++t) dx_out[ACT(t, u + m * G, IN, Sp, s)] = 0.0f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm over channels (eps = 1e-3), thread = (t, s).
 // ---------------------------------------------------------------------------------------------
 template <int C>
@@ -305,12 +508,10 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ X, con
   const int t = (int)(i / S);
   const int64_t s = i - (int64_t)t * S;
   float x[C];
+  dof_ld_row<C>(X + ACT(t, 0, C, Sp, s), x);
   float mean = 0.0f;
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    x[c] = X[ACT(t, c, C, Sp, s)];
-    mean += x[c];
-  }
+  for (int c = 0; c < C; ++c) mean += x[c];
   mean *= (1.0f / C);
   float var = 0.0f;
 #pragma unroll
@@ -320,7 +521,8 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ X, con
   }
   const float rstd = rsqrtf(var * (1.0f / C) + 1e-3f);
 #pragma unroll
-  for (int c = 0; c < C; ++c) Y[ACT(t, c, C, Sp, s)] = fmaf((x[c] - mean) * rstd, dof_cw(gamma)[c], dof_cw(beta)[c]);
+  for (int c = 0; c < C; ++c) x[c] = fmaf((x[c] - mean) * rstd, dof_cw(gamma)[c], dof_cw(beta)[c]);
+  dof_st_row<C>(Y + ACT(t, 0, C, Sp, s), x);
 }
 
 // dX = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dY*gamma; per-block partial dgamma/dbeta.
@@ -340,14 +542,26 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ X, con
     const int t = (int)(i / S);
     const int64_t s = i - (int64_t)t * S;
     float x[C], dy[C];
+    if (PW) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        x[c] = X[LNIDX(t, c, s)];
+        dy[c] = dY1[LNIDX(t, c, s)];
+        if (dY2) dy[c] += dY2[LNIDX(t, c, s)];
+      }
+    } else {
+      dof_ld_row<C>(X + ACT(t, 0, C, Sp, s), x);
+      dof_ld_row<C>(dY1 + ACT(t, 0, C, Sp, s), dy);
+      if (dY2) {
+        float d2[C];
+        dof_ld_row<C>(dY2 + ACT(t, 0, C, Sp, s), d2);
+#pragma unroll
+        for (int c = 0; c < C; ++c) dy[c] += d2[c];
+      }
+    }
     float mean = 0.0f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      x[c] = X[LNIDX(t, c, s)];
-      dy[c] = dY1[LNIDX(t, c, s)];
-      if (dY2) dy[c] += dY2[LNIDX(t, c, s)];
-      mean += x[c];
-    }
+    for (int c = 0; c < C; ++c) mean += x[c];
     mean *= (1.0f / C);
     float var = 0.0f;
 #pragma unroll
@@ -368,8 +582,15 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ X, con
     }
     mg *= (1.0f / C);
     mgx *= (1.0f / C);
+    float dxr[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) dX[LNIDX(t, c, s)] = rstd * (dy[c] * dof_cw(gamma)[c] - mg - x[c] * mgx);
+    for (int c = 0; c < C; ++c) dxr[c] = rstd * (dy[c] * dof_cw(gamma)[c] - mg - x[c] * mgx);
+    if (PW) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) dX[LNIDX(t, c, s)] = dxr[c];
+    } else {
+      dof_st_row<C>(dX + ACT(t, 0, C, Sp, s), dxr);
+    }
   }
   dof_block_colsum<2 * C>(vals, partial + (int64_t)blockIdx.x * 2 * C);
 #undef LNIDX
@@ -445,8 +666,15 @@ int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, floa
 }
 
 // kind: 0 = (IN=2L,HID=2L) enc gru1 / dec gru2 ; 1 = (IN=4L,HID=L) enc gru2 ; 2 = (IN=L,HID=L, broadcast input) dec gru1
+#define GRU3_W W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st) {
+  if (L == 8) {  // weight-stationary lane-per-unit kernels
+    if (kind == 0) DOF_LAUNCH((k_gru3_fwd<16, 16, false>), (dof_cdiv(S, 16), 2), (256), st, X, len, GRU3_W, O, GS, T, S, Sp);
+    else if (kind == 1) DOF_LAUNCH((k_gru3_fwd<32, 8, false>), (dof_cdiv(S, 32), 2), (256), st, X, len, GRU3_W, O, GS, T, S, Sp);
+    else DOF_LAUNCH((k_gru3_fwd<8, 8, true>), (dof_cdiv(S, 32), 2), (256), st, X, len, GRU3_W, O, GS, T, S, Sp);
+    return dof_check_launch("k_gru3_fwd");
+  }
   const unsigned nb = dof_cdiv(S, 256);
   if (kind == 0) {
     DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_fwd<2 * LL, 2 * LL, false>), (nb, 2), (256), st, X, len, W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1, O, GS, T, S, Sp));
@@ -460,6 +688,12 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
 
 int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* O, float* GS, const float* dO,
                        const float* dHfin, float* dX, int T, int64_t S, int64_t Sp, hipStream_t st) {
+  if (L == 8) {
+    if (kind == 0) DOF_LAUNCH((k_gru3_bwd<16, 16, false>), (dof_cdiv(S, 16), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
+    else if (kind == 1) DOF_LAUNCH((k_gru3_bwd<32, 8, false>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
+    else DOF_LAUNCH((k_gru3_bwd<8, 8, true>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
+    return dof_check_launch("k_gru3_bwd");
+  }
   const unsigned nb = dof_cdiv(S, 256);
   if (kind == 0) {
     DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_bwd<2 * LL, 2 * LL, false>), (nb, 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp));

@@ -109,7 +109,7 @@ struct DofVadePlan {
   StreamWs sw[2];
   int64_t flat, enc, mu, pre, sv, z, q, qn, dlogit, dmu_dpre, denc, dflat;
   int64_t gram, Pm, km, stats, dqbar, dcen, scal;
-  int64_t mterm, mlse, mdz, mckl_partial, distill_partial, recon_partial;
+  int64_t mterm, mlse, mdz, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks;
@@ -308,6 +308,8 @@ void build_workspace_layout(DofVadePlan* p) {
   p->mterm = cv.take((int64_t)S * Bp);
   p->mlse = cv.take((int64_t)S * Bp);
   p->mdz = cv.take((int64_t)S * L * Bp);
+  p->mgsum = cv.take(2LL * L * Bp);
+  p->gmmp = cv.take(16LL * 2 * K * L);
   p->mckl_blocks = dof_cdiv((int64_t)S * p->B, 256);
   p->lat_blocks = dof_cdiv(p->B, 256);
   p->tail_blocks = dof_cdiv((int64_t)T * p->B, 256);
@@ -570,6 +572,9 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
                    float* q_out, float* mu_out, float* sv_out, float* enc_out, hipStream_t st) {
   float* ws = p->ws;
   LatentFwdArgs A;
+  DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
+             params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
+  TRY(dof_check_launch("k_final_dense"));
   A.flat = ws + p->flat; A.J = p->J;
   A.wf = params + p->fd_w; A.bf = params + p->fd_b; A.wm = params + p->mean_w; A.bm = params + p->mean_b;
   A.ws = params + p->lv_w; A.bs = params + p->lv_b;
@@ -765,6 +770,8 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
     LDISPATCH(L, DOF_LAUNCH((k_mckl_fwd<LL>), ((unsigned)p->mckl_blocks), (256), st, MA));
     TRY(dof_check_launch("k_mckl_fwd"));
     DOF_LAUNCH(k_block_sum, ((unsigned)p->mckl_blocks), (256), st, (const float*)(ws + p->mterm), p->S, B, Bp, ws + p->mckl_partial);
+    DOF_LAUNCH(k_mckl_reduce, (dof_cdiv(B, 256), (unsigned)L), (256), st, (const float*)(ws + p->mdz), eps_mc,
+               ws + p->mgsum, p->S, L, B, Bp);
     TRY(dof_check_launch("k_block_sum"));
   }
   LossMidArgs LM;
@@ -779,7 +786,7 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   // ---------------- latent backward
   LatentBwdArgs LB;
   LB.enc = ws + p->enc; LB.mu = ws + p->mu; LB.pre = ws + p->pre; LB.sv = ws + p->sv; LB.z = ws + p->z;
-  LB.q = ws + p->q; LB.qn = ws + p->qn; LB.eps = eps; LB.eps_mc = eps_mc; LB.mckl_dz = ws + p->mdz;
+  LB.q = ws + p->q; LB.qn = ws + p->qn; LB.eps = eps; LB.eps_mc = eps_mc; LB.mckl_gsum = ws + p->mgsum;
   LB.dz_dec = ws + p->dzdec; LB.wf = params + p->fd_w; LB.wm = params + p->mean_w; LB.ws = params + p->lv_w;
   LB.gmm_means = params + p->gmm_m; LB.gmm_log_vars = params + p->gmm_lv; LB.Pm = ws + p->Pm; LB.dcen = ws + p->dcen;
   LB.dqbar = ws + p->dqbar; LB.scal = ws + p->scal; LB.hyper = hyper; LB.tau = tau; LB.class_weight = teacher;
@@ -788,15 +795,19 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   LB.B = B; LB.Bp = Bp;
   LDISPATCH(L, DOF_LAUNCH((k_latent_bwd<LL>), ((unsigned)p->lat_blocks), (256), st, LB));
   TRY(dof_check_launch("k_latent_bwd"));
+  LDISPATCH(L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(B, 256), (unsigned)p->J), (256), st,
+                          (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, B, Bp));
+  TRY(dof_check_launch("k_final_dense_bwd"));
   DOF_LAUNCH(k_loss_total, (1), (64), st, (const float*)(ws + p->distill_partial), (int)p->lat_blocks, hyper, B, logs);
   TRY(dof_check_launch("k_loss_total"));
   GmmGradArgs GG;
   GG.z = ws + p->z; GG.dlogit = ws + p->dlogit; GG.mu = ws + p->mu; GG.sv = ws + p->sv; GG.eps_mc = eps_mc;
   GG.lse = ws + p->mlse; GG.gmm_means = params + p->gmm_m; GG.gmm_log_vars = params + p->gmm_lv; GG.prior = prior;
-  GG.scal = ws + p->scal; GG.hyper = hyper; GG.g_means = grads + p->gmm_m; GG.g_log_vars = grads + p->gmm_lv;
+  GG.scal = ws + p->scal; GG.hyper = hyper; GG.partial = ws + p->gmmp;
   GG.K = K; GG.S = p->S; GG.pretrain = pretrain ? 1 : 0; GG.B = B; GG.Bp = Bp;
-  LDISPATCH(L, DOF_LAUNCH((k_gmm_grads<LL>), ((unsigned)K), (256), st, GG));
+  LDISPATCH(L, DOF_LAUNCH((k_gmm_grads<LL>), ((unsigned)K, 16), (256), st, GG));
   TRY(dof_check_launch("k_gmm_grads"));
+  TRY(dof_launch_sum_partials(ws + p->gmmp, 16, 2 * K * L, grads + p->gmm_m, 0, st));  // gmm_means | gmm_log_vars
 
   // ---------------- CensNet backward
   CensBwdStream cb[2];

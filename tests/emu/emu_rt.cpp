@@ -1,7 +1,6 @@
 // TEST TOOL (not product): fiber-based SIMT emulator runtime.  See emu_rt.h.
 #include "emu_rt.h"
 
-#include <ucontext.h>
 
 #include <vector>
 
@@ -11,13 +10,39 @@ namespace {
 enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
 constexpr size_t kStack = 256 * 1024;
 
+// Minimal x86-64 System V context switch (callee-saved registers + stack pointer).  ucontext's
+// swapcontext issues a sigprocmask syscall per switch, which made shuffle-heavy kernels crawl.
+extern "C" void emu_swap(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_swap
+.type emu_swap,@function
+emu_swap:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_swap,.-emu_swap
+)");
+
 struct Fiber {
-  ucontext_t ctx;
+  void* sp = nullptr;
   State st = DONE;
   dim3 tid;
 };
 
-ucontext_t g_main;
+void* g_main_sp = nullptr;
 std::vector<Fiber> g_fibers;
 std::vector<unsigned char> g_stacks;
 int g_cur = -1;
@@ -27,13 +52,14 @@ float g_xchg[1024 * 2];  // per-thread exchange slots (a, b)
 void fiber_entry() {
   (*g_body)();
   g_fibers[g_cur].st = DONE;
-  swapcontext(&g_fibers[g_cur].ctx, &g_main);
+  emu_swap(&g_fibers[g_cur].sp, g_main_sp);
+  abort();  // a finished fiber is never resumed
 }
 
 void yield_as(State s) {
   int me = g_cur;
   g_fibers[me].st = s;
-  swapcontext(&g_fibers[me].ctx, &g_main);
+  emu_swap(&g_fibers[me].sp, g_main_sp);
   threadIdx = g_fibers[me].tid;
 }
 
@@ -42,13 +68,16 @@ void run_block(int nthreads) {
   if (g_stacks.size() < kStack * (size_t)nthreads) g_stacks.resize(kStack * (size_t)nthreads);
   for (int i = 0; i < nthreads; ++i) {
     Fiber& f = g_fibers[i];
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = g_stacks.data() + kStack * (size_t)i;
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = &g_main;
+    // initial frame: six callee-saved slots, then fiber_entry as the return address of emu_swap
+    uintptr_t top = reinterpret_cast<uintptr_t>(g_stacks.data() + kStack * (size_t)(i + 1));
+    top &= ~(uintptr_t)15;
+    void** sp = reinterpret_cast<void**>(top);
+    *--sp = nullptr;                                   // fake return address of fiber_entry (keeps rsp = 16n+8)
+    *--sp = reinterpret_cast<void*>(&fiber_entry);
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;
+    f.sp = sp;
     f.st = RUNNABLE;
     f.tid = dim3(i % blockDim.x, (i / blockDim.x) % blockDim.y, i / (blockDim.x * blockDim.y));
-    makecontext(&f.ctx, fiber_entry, 0);
   }
   for (;;) {
     bool ran = false;
@@ -56,7 +85,7 @@ void run_block(int nthreads) {
       if (g_fibers[i].st != RUNNABLE) continue;
       g_cur = i;
       threadIdx = g_fibers[i].tid;
-      swapcontext(&g_main, &g_fibers[i].ctx);
+      emu_swap(&g_main_sp, g_fibers[i].sp);
       ran = true;
     }
     // release barriers
