@@ -1,0 +1,152 @@
+"""Device-resident window dataset + the reference's batch ordering.
+
+Replaces ``BatchDictDataset`` / ``_H5BatchIterableDataset``
+(/root/reference/deepof/clustering/dataset.py:29-670): instead of materialising every window to
+HDF5 and re-reading it each epoch through h5py + H2D copies, the windows (or, better, the
+un-windowed frame tables) are uploaded to HBM once (288 GB/GPU) and every batch is produced on
+device by ``dof_window_gather``.
+
+The batch order is the reference's arithmetic, reproduced exactly (dataset.py:589-622):
+batch starts ``arange(0, n, bs)``; per-epoch ``numpy.random.default_rng((seed + epoch) % 2**32)``
+shuffle of the starts (block shuffle, windows inside a batch stay contiguous); truncate to a
+multiple of the world size; rank r takes ``starts[r::world]``; the last batch may be ragged
+(``drop_last=False``).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+def reorder_and_reshape(data: np.ndarray) -> np.ndarray:
+    """(n, W, 3N) column blocks [x|y|s] -> (n, W, N, 3)   (dataset.py:16-26)."""
+    assert data.shape[2] % 3 == 0, "Error! Number of columns is not a multiple of 3 (x, y, speed)!"
+    n = data.shape[2] // 3
+    return np.stack([data[:, :, 0:n], data[:, :, n:2 * n], data[:, :, 2 * n:3 * n]], axis=-1)
+
+
+def batch_starts(n_samples: int, batch_size: int, epoch: int, seed: Optional[int], shuffle: bool,
+                 world_size: int = 1, rank: int = 0, drop_last: bool = False) -> np.ndarray:
+    """Start indices of this rank's batches for 1-based ``epoch`` (the reference's ``_epoch`` counter)."""
+    if drop_last:
+        starts = np.arange(0, (n_samples // batch_size) * batch_size, batch_size, dtype=np.int64)
+    else:
+        starts = np.arange(0, n_samples, batch_size, dtype=np.int64)
+    base_seed = seed if seed is not None else 0
+    rng = np.random.default_rng((base_seed + epoch) % (2 ** 32))
+    if shuffle:
+        rng.shuffle(starts)
+    if world_size > 1:
+        starts = starts[: (len(starts) // world_size) * world_size]
+        starts = starts[rank::world_size]
+    return starts
+
+
+def n_batches(n_samples: int, batch_size: int, world_size: int = 1, drop_last: bool = False) -> int:
+    """len(loader) of the reference (dataset.py:469-484)."""
+    total = (n_samples // batch_size) if drop_last else ((n_samples + batch_size - 1) // batch_size)
+    if world_size > 1:
+        total = (total // world_size) * world_size // world_size
+    return total
+
+
+class WindowDataset:
+    """All windows of a ``{video_key: (nodes (n,W,3N), edges (n,W,E), angles)}`` dict, resident on ``device``.
+
+    Stored in the reference's batch layout x (n,W,N,3), a (n,W,E,1) fp32 (what the HDF5 files held).
+    ``from_tables`` keeps only the frame tables and gathers windows on the fly (W-fold less memory).
+    """
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.x: Optional[torch.Tensor] = None
+        self.a: Optional[torch.Tensor] = None
+        self.node_table: Optional[torch.Tensor] = None
+        self.edge_table: Optional[torch.Tensor] = None
+        self.row_start: Optional[torch.Tensor] = None
+        self.video_idx: Optional[np.ndarray] = None
+        self.keys: List[str] = []
+        self.length = 0
+        self.x_shape: Tuple[int, int, int] = (0, 0, 0)
+        self.a_shape: Tuple[int, int, int] = (0, 0, 0)
+        self._epoch = 0
+        self._lib = None
+
+    # ---- construction ----------------------------------------------------------------------
+    @classmethod
+    def from_preprocessed(cls, preprocessed: Dict, device) -> "WindowDataset":
+        ds = cls(device)
+        xs, as_, vid = [], [], []
+        for i, key in enumerate(preprocessed.keys()):
+            nodes, edges = preprocessed[key][0], preprocessed[key][1]
+            nodes, edges = np.asarray(nodes), np.asarray(edges)
+            xs.append(reorder_and_reshape(nodes).astype(np.float32))
+            as_.append(np.expand_dims(edges, -1).astype(np.float32))
+            vid.append(np.full(nodes.shape[0], i, dtype=np.int32))
+            ds.keys.append(key)
+        x, a = np.concatenate(xs), np.concatenate(as_)
+        ds.x = torch.from_numpy(x).to(ds.device)
+        ds.a = torch.from_numpy(a).to(ds.device)
+        ds.video_idx = np.concatenate(vid)
+        ds.length = x.shape[0]
+        ds.x_shape, ds.a_shape = tuple(x.shape[1:]), tuple(a.shape[1:])
+        return ds
+
+    @classmethod
+    def from_tables(cls, tables: Dict, window_size: int, window_step: int, device, lib) -> "WindowDataset":
+        """``tables``: {video_key: (node_table (frames,3N), edge_table (frames,E))}, un-windowed."""
+        ds = cls(device)
+        ds._lib = lib
+        nts, ets, starts, vid, off = [], [], [], [], 0
+        for i, key in enumerate(tables.keys()):
+            nt, et = (np.asarray(t, dtype=np.float32) for t in tables[key][:2])
+            nw = (nt.shape[0] - window_size) // window_step + 1
+            starts.append(off + np.arange(nw, dtype=np.int64) * window_step)
+            vid.append(np.full(nw, i, dtype=np.int32))
+            nts.append(nt)
+            ets.append(et)
+            off += nt.shape[0]
+            ds.keys.append(key)
+        ds.node_table = torch.from_numpy(np.concatenate(nts)).to(ds.device)
+        ds.edge_table = torch.from_numpy(np.concatenate(ets)).to(ds.device)
+        ds.row_start = torch.from_numpy(np.concatenate(starts)).to(ds.device)
+        ds.video_idx = np.concatenate(vid)
+        ds.length = int(ds.row_start.numel())
+        n, e = ds.node_table.shape[1] // 3, ds.edge_table.shape[1]
+        ds.x_shape, ds.a_shape = (window_size, n, 3), (window_size, e, 1)
+        return ds
+
+    def __len__(self):
+        return self.length
+
+    # ---- batches ---------------------------------------------------------------------------
+    def fetch(self, s: int, e: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Windows [s, e) as contiguous device tensors x (b,W,N,3), a (b,W,E,1)."""
+        if self.x is not None:
+            return self.x[s:e], self.a[s:e]
+        W, N, _ = self.x_shape
+        E = self.a_shape[1]
+        b = e - s
+        x = torch.empty(b, W, N, 3, device=self.device)
+        a = torch.empty(b, W, E, 1, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        rows = self.row_start[s:e].contiguous()
+        _capi.check(self._lib, self._lib.dof_window_gather(self.node_table.data_ptr(), self.edge_table.data_ptr(),
+                                                           rows.data_ptr(), b, W, N, E, x.data_ptr(), a.data_ptr(),
+                                                           stream), "dof_window_gather")
+        return x, a
+
+    def iter_batches(self, batch_size: int, shuffle: bool, seed: Optional[int], world_size: int = 1, rank: int = 0,
+                     drop_last: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, np.ndarray]]:
+        """One epoch: yields (x, a, idx[int64 device], video_idx[int32 host]) like the reference loader."""
+        self._epoch += 1
+        for s in batch_starts(self.length, batch_size, self._epoch, seed, shuffle, world_size, rank, drop_last):
+            s = int(s)
+            e = min(s + batch_size, self.length)
+            x, a = self.fetch(s, e)
+            idx = torch.arange(s, e, device=self.device, dtype=torch.int64)
+            yield x, a, idx, self.video_idx[s:e]

@@ -54,7 +54,9 @@ def _param_shape(name: str, numel: int, N: int, E: int, L: int, K: int):
 
 class VadeEngine:
     def __init__(self, lib, device, batch: int, window: int, adjacency: np.ndarray, latent_dim: int,
-                 n_clusters: int, mc_samples: int = 32, graph_ops=None):
+                 n_clusters: int, mc_samples: int = 32, graph_ops=None, shared: "VadeEngine" = None):
+        """``shared``: another engine (different batch size) whose parameter / gradient / Adam / hyper
+        buffers this one borrows -- every batch size needs its own plan and workspace, not its own weights."""
         self.lib = lib
         self.device = torch.device(device)
         adjacency = np.asarray(adjacency, dtype=np.float32)
@@ -77,6 +79,16 @@ class VadeEngine:
             self.layout[name] = (off, numel, _param_shape(name, numel, self.N, self.E, self.L, self.K))
         total = lib.dof_vade_param_total(plan)
         f32 = dict(dtype=torch.float32, device=self.device)
+        ws_bytes = lib.dof_vade_workspace_bytes(plan)
+        self.workspace = torch.empty(ws_bytes // 4, **f32)
+        _capi.check(lib, lib.dof_vade_bind(plan, self.workspace.data_ptr(), self._stream()), "dof_vade_bind")
+        self._sync()
+        if shared is not None:
+            assert shared.params.numel() == total and shared.K == self.K and shared.L == self.L
+            for attr in ("params", "grads", "adam_m", "adam_v", "prior", "hyper_host", "hyper", "logs", "teacher",
+                         "adam_t"):
+                setattr(self, attr, getattr(shared, attr))
+            return
         self.params = torch.zeros(total, **f32)
         self.grads = torch.zeros(total, **f32)
         self.adam_m = torch.zeros(total, **f32)
@@ -89,10 +101,6 @@ class VadeEngine:
         self.logs = torch.zeros(_capi.LOG_COUNT, **f32)
         self.teacher = torch.zeros(2 * self.K, **f32)
         self.adam_t = [0] * _capi.SEG_COUNT
-        ws_bytes = lib.dof_vade_workspace_bytes(plan)
-        self.workspace = torch.empty(ws_bytes // 4, **f32)
-        _capi.check(lib, lib.dof_vade_bind(plan, self.workspace.data_ptr(), self._stream()), "dof_vade_bind")
-        self._sync()
         self.set_hyper(logvar_lo=-8.0, logvar_hi=8.0, clip=0.75, wd=0.0, l1_act=0.1, distill_T=0.5)
         for s in range(_capi.SEG_COUNT):
             self.hyper_host[_capi.H_ACTIVE0 + s] = 1.0
@@ -162,7 +170,8 @@ class VadeEngine:
     def reset_optimizer(self):
         self.adam_m.zero_()
         self.adam_v.zero_()
-        self.adam_t = [0] * _capi.SEG_COUNT
+        for i in range(_capi.SEG_COUNT):
+            self.adam_t[i] = 0
 
     def push_hyper(self):
         self.hyper.copy_(self.hyper_host, non_blocking=True)
@@ -235,7 +244,8 @@ class VadeEngine:
         return {k: vals[i] for i, k in enumerate(_capi.LOG_KEYS)}
 
 
-def create_vade_engine(batch, window, adjacency, latent_dim, n_clusters, mc_samples=32, device=None, graph_ops=None):
+def create_vade_engine(batch, window, adjacency, latent_dim, n_clusters, mc_samples=32, device=None, graph_ops=None,
+                       shared=None):
     """Product entry: requires a ROCm GPU and the compiled HIP library (no fallback)."""
     from ._lib import load_hip_library
 
@@ -245,4 +255,4 @@ def create_vade_engine(batch, window, adjacency, latent_dim, n_clusters, mc_samp
     dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
     if dev.type != "cuda":
         raise RuntimeError(f"deepof_amd runs on ROCm devices only, got {dev}")
-    return VadeEngine(lib, dev, batch, window, adjacency, latent_dim, n_clusters, mc_samples, graph_ops)
+    return VadeEngine(lib, dev, batch, window, adjacency, latent_dim, n_clusters, mc_samples, graph_ops, shared)

@@ -1,0 +1,220 @@
+"""Model objects with the reference's interface, backed by the HIP engine.
+
+``VaDE`` mirrors what downstream DeepOF code touches on ``VaDEPT``
+(/root/reference/deepof/clustering/models_new.py:1794-1975, consumed by ``embedding_per_video``
+model_utils_new.py:542-617): an ``nn.Module`` with ``window_size``, ``encoder.spatial_gnn_block``
+(whose ``str()`` is ``"CensNetConvPT()"``), ``latent_space.*``, the reference ``state_dict`` keys
+and order (checkpoints are cross-loadable), and ``model(x, a, return_gmm_params=False) ->
+(reconstruction_dist, z, q, kmeans_loss)``.  All tensors are views into the engine's flat fp32
+buffer; all arithmetic happens in libdeepof_hip.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _capi
+from .engine import VadeEngine, create_vade_engine
+
+
+class _Box(nn.Module):
+    """Plain container used to rebuild the reference's module tree (names only, no compute)."""
+
+
+class CensNetConvPT(_Box):  # name matters: embedding_per_video checks str(block) == "CensNetConvPT()"
+    pass
+
+
+class ReconDistribution:
+    """Independent Normal(loc, 1) over the 3N node features of each frame, masked by frame validity
+    (models_new.py:686-710): .mean and .log_prob(x) as the reference's AffineTransformedDistribution."""
+
+    def __init__(self, loc: torch.Tensor, valid: torch.Tensor):
+        self.loc, self.valid = loc, valid
+
+    @property
+    def mean(self) -> torch.Tensor:
+        return self.loc * self.valid.unsqueeze(-1).to(self.loc.dtype)
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        d = x.shape[-1]
+        lp = -0.5 * ((x - self.loc) ** 2).sum(dim=-1) - 0.5 * d * math.log(2.0 * math.pi)
+        return torch.where(self.valid, lp, torch.full_like(lp, float("nan")))
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = False):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, CensNetConvPT() if p == "spatial_gnn_block" else _Box())
+        mod = getattr(mod, p)
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class VaDE(nn.Module):
+    def __init__(self, input_shape, edge_feature_shape, adjacency_matrix: np.ndarray, latent_dim: int,
+                 n_components: int, encoder_type: str = "recurrent", use_gnn: bool = True, kmeans_loss: float = 1.0,
+                 interaction_regularization: float = 0.0, lens_enabled: bool = False, batch_size: int = 256,
+                 device=None, _engine_factory: Optional[Callable[..., VadeEngine]] = None):
+        super().__init__()
+        if str(encoder_type).lower() != "recurrent":
+            raise NotImplementedError(
+                f"encoder_type={encoder_type!r}: this build implements the recurrent encoder/decoder "
+                "(TCN / transformer are later rows of SURVEY.md section 8a)")
+        if not use_gnn:
+            raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
+        time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
+        if n_feat != 3 or int(edge_feature_shape[-1]) != 1:
+            raise ValueError("expected 3 features per node and 1 per edge")
+        self.window_size = time_steps
+        self.input_n_nodes = n_nodes
+        self.input_n_features_per_node = n_feat
+        self.latent_dim = int(latent_dim)
+        self.n_components = int(n_components)
+        self.encoder_type = "recurrent"
+        self.kmeans_weight = float(kmeans_loss)
+        self.lens_enabled = False
+        self._adjacency = np.asarray(adjacency_matrix, dtype=np.float32)
+        self._factory = _engine_factory or (lambda **kw: create_vade_engine(device=device, **kw))
+        self._engines: Dict[int, VadeEngine] = {}
+        self._base = self._make_engine(int(batch_size), None)
+        eng = self._base
+        # --- reference module tree / state_dict (order follows registration)
+        self.encoder = _Box()
+        self.encoder.register_buffer("laplacian", torch.from_numpy(eng.lap.copy()))
+        self.encoder.register_buffer("edge_laplacian", torch.from_numpy(eng.elap.copy()))
+        self.encoder.register_buffer("incidence", torch.from_numpy(eng.inc.copy()))
+        self.decoder = _Box()
+        self.latent_space = _Box()
+        for name in eng.names:
+            if name == "latent_space.encoder_mean.weight":
+                self.latent_space.register_buffer("prior", eng.prior)
+                self.latent_space.register_buffer("pretrain", torch.tensor(0.0))
+            _attach(self, name, eng.view(name))
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ engines
+    def _make_engine(self, batch: int, shared):
+        return self._factory(batch=batch, window=self.window_size, adjacency=self._adjacency,
+                             latent_dim=self.latent_dim, n_clusters=self.n_components, shared=shared)
+
+    def engine(self, batch: int) -> VadeEngine:
+        """Plan + workspace for this batch size (parameters are shared across batch sizes)."""
+        batch = int(batch)
+        if batch == self._base.B:
+            return self._base
+        if batch not in self._engines:
+            self._engines[batch] = self._make_engine(batch, self._base)
+        return self._engines[batch]
+
+    @property
+    def device(self) -> torch.device:
+        return self._base.device
+
+    # ------------------------------------------------------------------ init (PyTorch default inits of the reference)
+    @torch.no_grad()
+    def reset_parameters(self):
+        for name, p in self.named_parameters():
+            leaf = name.split(".")[-1]
+            if ".gru" in name:
+                hid = p.shape[0] // 3
+                p.uniform_(-1.0 / math.sqrt(hid), 1.0 / math.sqrt(hid))
+            elif "norm" in name:
+                p.fill_(1.0 if leaf == "weight" else 0.0)
+            elif name in ("latent_space.gmm_means", "latent_space.gmm_log_vars"):
+                nn.init.xavier_normal_(p)
+            elif "spatial_gnn_block" in name:
+                if leaf in ("node_kernel", "edge_kernel", "node_weights", "edge_weights"):
+                    nn.init.xavier_uniform_(p)
+                else:  # bias ~ U(+-1/sqrt(fan_in)), fan_in = channels (censNetConv_pt.py:75-84)
+                    bound = 1.0 / math.sqrt(self.latent_dim)
+                    p.uniform_(-bound, bound)
+            elif leaf == "weight":  # Conv1d / Linear: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+                fan_in = int(np.prod(p.shape[1:]))
+                p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+            elif leaf == "bias":
+                w = dict(self.named_parameters())[name[: -len("bias")] + "weight"]
+                fan_in = int(np.prod(w.shape[1:]))
+                p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+
+    # ------------------------------------------------------------------ reference-facing API
+    def set_pretrain_mode(self, pretrain_on: bool):
+        self.latent_space.pretrain.fill_(1.0 if pretrain_on else 0.0)
+
+    @property
+    def get_gmm_params(self) -> dict:
+        means, log_vars = self.latent_space.gmm_means, self.latent_space.gmm_log_vars
+        return {"means": means, "log_vars": log_vars, "sigmas": torch.exp(0.5 * log_vars),
+                "weights": self.latent_space.prior}
+
+    def _run(self, x: torch.Tensor, a: torch.Tensor, eps=None, want_loc=True):
+        x = x.to(self.device, torch.float32).contiguous()
+        a = a.to(self.device, torch.float32).contiguous()
+        eng = self.engine(x.shape[0])
+        out = eng.forward(x, a, eps, want_loc=want_loc)
+        return x, out
+
+    def forward(self, x: torch.Tensor, a: torch.Tensor, return_gmm_params: bool = False):
+        """(reconstruction_dist, z, q, kmeans_loss[, z_mean, z_log_var, gmm_params]).  Training mode draws the
+        reparameterisation noise on device; eval mode uses z = z_mean (models_new.py:1761-1791)."""
+        eps = None
+        if self.training:
+            eps = torch.randn(x.shape[0], self.latent_dim, device=self.device)
+        x, out = self._run(x, a, eps)
+        B, T = x.shape[:2]
+        x_flat = x.reshape(B, T, -1)
+        valid = ~torch.all(x_flat == 0.0, dim=2)
+        dist = ReconDistribution(out["loc"], valid)
+        kmeans = self._kmeans_value(out["z"])
+        if return_gmm_params:
+            gmm = {"means": self.latent_space.gmm_means, "log_vars": self.latent_space.gmm_log_vars,
+                   "prior": self.latent_space.prior}
+            return dist, out["z"], out["q"], kmeans, out["z_mean"], out["z_log_var"], gmm
+        return dist, out["z"], out["q"], kmeans
+
+    def _kmeans_value(self, z: torch.Tensor) -> torch.Tensor:
+        """Gram-spectrum term of the latent layer (losses.py:257-287); host-side fp64 on an LxL matrix, value only
+        (inside the training step the HIP path computes value and gradient on device)."""
+        if not self.kmeans_weight > 0:
+            return torch.zeros((), device=z.device)
+        gram = (z.T @ z) / float(z.shape[0])
+        sv = torch.linalg.svdvals(gram.double().cpu())
+        return (self.kmeans_weight * torch.sqrt(torch.clamp(sv, min=1e-9)).mean()).to(z.device)
+
+    @torch.no_grad()
+    def embed(self, x, a):
+        """Latent embedding z (eval: z_mean).  (The reference's embed()/group() raise on a tuple-unpack bug, Q8.)"""
+        was = self.training
+        self.eval()
+        _, out = self._run(x, a, None, want_loc=False)
+        self.train(was)
+        return out["z"]
+
+    @torch.no_grad()
+    def group(self, x, a):
+        was = self.training
+        self.eval()
+        _, out = self._run(x, a, None, want_loc=False)
+        self.train(was)
+        return out["q"]
+
+    @torch.no_grad()
+    def encode_windows(self, x: torch.Tensor, a: torch.Tensor, batch: int = 256):
+        """Batched inference over many windows -> (embeddings (n,L), soft_counts (n,K)) like the inner loop of
+        embedding_per_video (model_utils_new.py:604-617).  The last ragged chunk uses its own plan."""
+        n = x.shape[0]
+        zs, qs = [], []
+        for s in range(0, n, batch):
+            xb, ab = x[s:s + batch], a[s:s + batch]
+            _, out = self._run(xb, ab, None, want_loc=False)
+            zs.append(out["z"])
+            qs.append(out["q"])
+        return torch.cat(zs), torch.cat(qs)

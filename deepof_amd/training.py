@@ -1,0 +1,613 @@
+"""Public trainer API of the hot path (mirrors /root/reference/deepof/clustering/training.py).
+
+``train_deepof_model(...)`` keeps the reference's signature, defaults, enum handling, return
+tuple ``(model_val, model_score, model_teacher_init_or_None, log_summary)`` and on-disk artefacts
+(checkpoint bundle + ``_info.txt``), so ``Coordinates.deep_unsupervised_embedding`` can call it
+unchanged.  The epoch loop, the step and the optimiser run in libdeepof_hip on a
+ROCm device; data parallelism = one process per GPU, one RCCL all-reduce of the flat gradient per
+step (torch.distributed "nccl").  Implemented model family in this build: VaDE with the recurrent
+encoder/decoder; others raise NotImplementedError loudly.
+"""
+from __future__ import annotations
+
+import math
+import os
+import warnings
+from copy import deepcopy
+from types import SimpleNamespace
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from .config import (CommonFitCfg, ContrastiveCfg, TurtleTeacherCfg, VaDECfg, cfg_lines, check_model_inputs)
+from .dataset import WindowDataset, n_batches
+from .models import VaDE
+from .schedules import WeightSchedule
+
+LOG_SUMMARY_KEYS = ("total_loss", "reconstruction_loss", "kl_divergence", "cat_cluster_loss", "kmeans_loss",
+                    "distill_loss", "temporal_loss", "scatter_loss", "nonempty_loss", "repel_loss", "tf_cluster_loss",
+                    "prior_loss", "activity_l1", "pos_similarity", "neg_similarity", "conf_norm", "bal_norm",
+                    "alignment_score")
+
+
+# ------------------------------------------------------------------------------------------------
+# distributed plumbing (model_utils_new.py:196-226)
+# ------------------------------------------------------------------------------------------------
+def ddp_init_if_needed(backend: str = "nccl"):
+    import torch.distributed as dist
+
+    if "RANK" not in os.environ and "SLURM_PROCID" in os.environ:
+        os.environ["RANK"] = os.environ["SLURM_PROCID"]
+        os.environ["WORLD_SIZE"] = os.environ["SLURM_NTASKS"]
+        os.environ["LOCAL_RANK"] = os.environ.get("SLURM_LOCALID", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+    if dist.is_available() and dist.is_initialized():
+        return True, dist.get_rank(), dist.get_world_size(), int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ or not torch.cuda.is_available():
+        return False, 0, 1, 0
+    if int(os.environ["WORLD_SIZE"]) <= 1:
+        return False, 0, 1, 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend=backend, init_method="env://")
+    return True, dist.get_rank(), dist.get_world_size(), local_rank
+
+
+def _dist_state():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint bundles (model_utils_new.py:263-329, 368-374, 822-938)
+# ------------------------------------------------------------------------------------------------
+def ckpt_paths(model_name: str, common_cfg: CommonFitCfg):
+    ckpt_dir = os.path.join(common_cfg.output_path, "models", model_name.lower(), f"run_{common_cfg.run}")
+    os.makedirs(ckpt_dir, exist_ok=True)
+    return (ckpt_dir, os.path.join(ckpt_dir, "best_model_val.pth"), os.path.join(ckpt_dir, "best_model_score.pth"),
+            os.path.join(ckpt_dir, "model_teacher_init.pth"))
+
+
+def save_model_info(ckpt_path: str, *, stage: str, epoch=None, train_steps=None, val_total=None, score_value=None,
+                    extra=None, common_cfg=None, teacher_cfg=None, vade_cfg=None, contrastive_cfg=None, model=None,
+                    log_summary=None, rebuild_spec=None, save_weights: bool = True) -> None:
+    info_path = os.path.splitext(ckpt_path)[0] + "_info.txt"
+    lines = [f"stage: {stage}"]
+    for label, v, cast in (("epoch", epoch, int), ("train_steps", train_steps, int), ("val_total", val_total, float),
+                           ("score_value", score_value, float)):
+        if v is not None:
+            lines.append(f"{label}: {cast(v)}")
+    lines.append("")
+    if save_weights and model is not None:
+        keys = ["state_dict"] + (["rebuild_spec"] if rebuild_spec is not None else []) + \
+            (["log_summary"] if log_summary is not None else [])
+        lines += ["[checkpoint_format]", "ckpt_contains: bundle", "bundle_keys: " + ", ".join(keys), ""]
+    for title, cfg in (("common_cfg", common_cfg), ("teacher_cfg", teacher_cfg), ("vade_cfg", vade_cfg),
+                       ("contrastive_cfg", contrastive_cfg)):
+        lines += cfg_lines(title, cfg)
+    if extra:
+        lines += ["[extra]"] + [f"{k}: {extra[k]}" for k in sorted(extra)] + [""]
+    os.makedirs(os.path.dirname(ckpt_path), exist_ok=True)
+    if save_weights and model is not None:
+        payload = {"state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}
+        if rebuild_spec is not None:
+            payload["rebuild_spec"] = rebuild_spec
+        if log_summary is not None:
+            payload["log_summary"] = log_summary
+        torch.save(payload, ckpt_path)
+    with open(info_path, "w", encoding="utf-8") as f:
+        f.write("\n".join(lines))
+
+
+def build_model_from_spec(spec: dict, device=None, batch_size: int = 256, _engine_factory=None) -> VaDE:
+    name = str(spec.get("model_name", "vade")).lower()
+    if name != "vade":
+        raise NotImplementedError(f"checkpoint of model {name!r}: only VaDE bundles are supported in this build")
+    return VaDE(tuple(spec["x_shape"]), tuple(spec["a_shape"]), np.asarray(spec["adjacency_matrix"]),
+                int(spec["latent_dim"]), int(spec["n_components"]), encoder_type=spec.get("encoder_type", "recurrent"),
+                use_gnn=bool(spec.get("use_gnn", True)), kmeans_loss=float(spec.get("kmeans_loss", 0.0)),
+                batch_size=batch_size, device=device, _engine_factory=_engine_factory)
+
+
+def load_model_from_ckpt(path: str, device=None, _engine_factory=None):
+    """-> (model, log_summary, rebuild_spec, load_report); bundle written by save_model_info (reference-compatible)."""
+    bundle = torch.load(path, map_location="cpu", weights_only=False)
+    if not isinstance(bundle, dict) or "state_dict" not in bundle or "rebuild_spec" not in bundle:
+        raise RuntimeError(f"{path} is not a model bundle with state_dict + rebuild_spec")
+    model = build_model_from_spec(bundle["rebuild_spec"], device=device, _engine_factory=_engine_factory)
+    report = model.load_state_dict(bundle["state_dict"], strict=False)
+    model.eval()
+    return model, bundle.get("log_summary"), bundle["rebuild_spec"], report
+
+
+def _clone_model(model: VaDE) -> VaDE:
+    """Independent copy (own parameter buffer) -- deepcopy() of the reference."""
+    twin = VaDE((model.window_size, model.input_n_nodes, 3), (model.window_size, model._base.E, 1), model._adjacency,
+                model.latent_dim, model.n_components, kmeans_loss=model.kmeans_weight, batch_size=model._base.B,
+                _engine_factory=model._factory)
+    twin._base.params.copy_(model._base.params)
+    twin._base.prior.copy_(model._base.prior)
+    twin.train(model.training)
+    return twin
+
+
+def load_best_checkpoints(model: VaDE, best_path_val: str, best_path_score: str, save_weights: bool):
+    """(model_val, model_score): reload the saved bests, else the last weights for both (Q18)."""
+    out = []
+    for path in (best_path_val, best_path_score):
+        if save_weights and os.path.exists(path):
+            m = _clone_model(model)
+            m.load_state_dict(torch.load(path, map_location="cpu", weights_only=False)["state_dict"], strict=False)
+            m.eval()
+            out.append(m)
+        else:
+            out.append(model)
+    return out[0], out[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# logging (logging.py:304-349, 427-433)
+# ------------------------------------------------------------------------------------------------
+def init_log_summary(model_name: str) -> dict:
+    summary = {"model_type": model_name}
+    for split in ("train", "val"):
+        summary[split] = {k: [] for k in LOG_SUMMARY_KEYS}
+    return summary
+
+
+def _update_log_summary(log_summary: dict, train_logs: dict, val_logs: dict) -> dict:
+    for split, logs in (("train", train_logs), ("val", val_logs)):
+        # (the reference also overwrites every other top-level key -- i.e. "model_type" -- with NaN here,
+        #  logging.py:337-342; that side effect is deliberately not reproduced)
+        for key in log_summary[split]:
+            log_summary[split][key].append(logs.get(key, np.nan))
+    return log_summary
+
+
+def average_logs(logs_list) -> Dict[str, float]:
+    acc: Dict[str, Tuple[float, int]] = {}
+    for logs in logs_list:
+        for k, v in logs.items():
+            s, n = acc.get(k, (0.0, 0))
+            acc[k] = (s + float(v), n + 1)
+    return {k: s / max(n, 1) for k, (s, n) in acc.items()}
+
+
+def _clip01(v: float) -> float:
+    return float(min(1.0, max(0.0, v)))
+
+
+@torch.no_grad()
+def compute_diagnostics(model: VaDE, dataset: WindowDataset, batch_size: int, n_components: int, tau_star=None,
+                        distill_sharpen_T: float = 0.5, distill_conf_weight: bool = False,
+                        distill_conf_thresh: float = 0.55, max_batches: int = 4) -> Dict[str, float]:
+    """conf_norm / bal_norm / alignment_score on <= max_batches validation batches (logging.py:148-301)."""
+    total, sum_ent, sum_max, sum_q = 0, 0.0, 0.0, None
+    for bi, s in enumerate(range(0, len(dataset), batch_size)):
+        if bi >= max_batches:
+            break
+        x, a = dataset.fetch(s, min(s + batch_size, len(dataset)))
+        q = model.group(x, a).float().clamp_min(1e-8)
+        q = q / q.sum(dim=-1, keepdim=True).clamp_min(1e-8)
+        sum_ent += float(-(q * q.log()).sum())
+        sum_max += float(q.max(dim=-1).values.sum())
+        total += q.shape[0]
+        sum_q = q.sum(dim=0) if sum_q is None else sum_q + q.sum(dim=0)
+    out = {k: float("nan") for k in ("diag/q_mean_entropy", "diag/q_marginal_entropy", "diag/q_mean_max_prob",
+                                     "diag/teacher_marginal_entropy", "diag/teacher_conf_mean",
+                                     "diag/teacher_weight_mean", "diag/kl_marg_q_to_tau", "conf_norm", "bal_norm",
+                                     "alignment_score")}
+    if total > 0:
+        q_marg = (sum_q / total).clamp_min(1e-9)
+        mean_ent = sum_ent / total
+        q_marg_ent = float(-(q_marg * q_marg.log()).sum())
+        log_k = math.log(float(n_components))
+        conf = _clip01(1.0 - mean_ent / max(1e-9, log_k))
+        out.update({"diag/q_mean_entropy": mean_ent, "diag/q_marginal_entropy": q_marg_ent,
+                    "diag/q_mean_max_prob": sum_max / total})
+        if tau_star is not None:
+            tau = tau_star.detach().to(q_marg.device, q_marg.dtype)
+            tau_marg = tau.mean(dim=0).clamp_min(1e-9)
+            kl = max(0.0, float((q_marg * (q_marg.log() - tau_marg.log())).sum()))
+            bal = _clip01(1.0 - kl / max(1e-9, log_k))
+            sharp = torch.softmax(tau.clamp_min(1e-8).log() / distill_sharpen_T, dim=-1) if distill_sharpen_T > 0 else tau
+            cmax = sharp.max(dim=1).values
+            out.update({"diag/teacher_marginal_entropy": float(-(tau_marg * tau_marg.log()).sum()),
+                        "diag/teacher_conf_mean": float(cmax.mean()), "diag/kl_marg_q_to_tau": kl,
+                        "diag/teacher_weight_mean": float(((cmax - distill_conf_thresh) / max(1e-6, 1 - distill_conf_thresh)
+                                                           ).clamp(0, 1).mean()) if distill_conf_weight else 1.0})
+        else:
+            bal = _clip01(q_marg_ent / max(1e-9, log_k))
+        out.update({"conf_norm": conf, "bal_norm": bal, "alignment_score": conf * bal})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the VaDE step driver
+# ------------------------------------------------------------------------------------------------
+class VadeStepper:
+    """Owns the loss configuration for one phase and issues train / validation steps on the engine."""
+
+    def __init__(self, model: VaDE, common_cfg: CommonFitCfg, vade_cfg: VaDECfg, teacher_cfg: TurtleTeacherCfg):
+        self.model, self.common, self.vade, self.teacher = model, common_cfg, vade_cfg, teacher_cfg
+        unsupported = {"main_clustering_loss (tf_cluster_weight)": vade_cfg.tf_cluster_weight,
+                       "reg_cat_clusters": vade_cfg.reg_cat_clusters,
+                       "temporal_cohesion_weight": vade_cfg.temporal_cohesion_weight,
+                       "reg_scatter_weight": vade_cfg.reg_scatter_weight}
+        bad = [k for k, v in unsupported.items() if float(v) != 0.0]
+        if bad:
+            raise NotImplementedError(f"optional VaDE loss terms not implemented in this build: {bad} (reference default 0)")
+        self.pretrain = True
+        self.kl_scheduler: Optional[WeightSchedule] = None
+        self.lambda_scheduler: Optional[WeightSchedule] = None
+        self.lambda_distill = 0.0
+        self.tau_star: Optional[torch.Tensor] = None
+        self.set_mode("pretrain")
+
+    def set_mode(self, mode: str):
+        self.pretrain = mode == "pretrain"
+        K, v = self.common.n_components, self.vade
+        eng = self.model._base
+        if self.pretrain:
+            eng.set_hyper(km_loss=v.kmeans_loss_pretrain, repel_w=v.repel_weight_pretrain,
+                          repel_ls=v.repel_length_scale_pretrain, nonempty_w=v.nonempty_weight_pretrain,
+                          nonempty_floor=max(1e-4, v.nonempty_floor_percent_pretrain / K),
+                          nonempty_p=int(v.nonempty_p_pretrain))
+        else:
+            eng.set_hyper(km_loss=self.common.kmeans_loss, repel_w=v.repel_weight, repel_ls=v.repel_length_scale,
+                          nonempty_w=v.nonempty_weight, nonempty_floor=max(1e-4, v.nonempty_floor_percent / K),
+                          nonempty_p=int(v.nonempty_p))
+        eng.set_hyper(km_latent=self.model.kmeans_weight, l1_act=0.1, distill_T=self.teacher.distill_sharpen_T,
+                      conf_w=1.0 if self.teacher.distill_conf_weight else 0.0, conf_thr=self.teacher.distill_conf_thresh)
+
+    def set_teacher(self, tau_star: Optional[torch.Tensor], lambda_distill: float, lambda_scheduler=None):
+        eng = self.model._base
+        self.tau_star, self.lambda_distill, self.lambda_scheduler = tau_star, float(lambda_distill), lambda_scheduler
+        if tau_star is None:
+            eng.set_teacher(None, None)
+            return
+        pi = tau_star.mean(dim=0).clamp_min(1e-8)
+        w = pi.pow(-float(self.teacher.distill_class_reweight_beta))
+        w = w / w.mean()
+        if self.teacher.distill_class_reweight_cap is not None:
+            w = w.clamp_max(float(self.teacher.distill_class_reweight_cap))
+        eng.set_teacher(w, pi)
+
+    def _step(self, x, a, idx, train: bool, apply_distill: bool):
+        dist, rank, world = _dist_state()
+        eng = self.model.engine(x.shape[0])
+        B, L, S = x.shape[0], eng.L, eng.S
+        klw = self.kl_scheduler.get_weight() if self.kl_scheduler is not None else 0.0
+        lam = self.lambda_distill
+        if self.lambda_scheduler is not None:
+            lam = float(self.lambda_scheduler.get_weight())
+        use_tau = apply_distill and self.tau_star is not None and lam > 0.0
+        eng.set_hyper(klw=klw, lambda_distill=lam if use_tau else 0.0)
+        if train:
+            eng.advance_adam()
+        eng.push_hyper()
+        # train: z = mean + exp(softplus/2)*eps ; eval (validation): eps = 0 <=> z = mean
+        eps = torch.randn(B, L, device=eng.device) if train else torch.zeros(B, L, device=eng.device)
+        eps_mc = None if self.pretrain else torch.randn(S, B, L, device=eng.device)
+        tau = self.tau_star[idx].contiguous() if use_tau else None
+        eng.loss_grads(x.contiguous(), a.contiguous(), eps, eps_mc, tau, pretrain=self.pretrain)
+        if train:
+            if world > 1:
+                dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+                eng.grads.mul_(1.0 / world)
+            eng.optimizer_step()
+        return eng.logs.clone()
+
+    def train_epoch(self, dataset: WindowDataset, seed, shuffle=True):
+        _, rank, world = _dist_state()
+        self.model.train()
+        logs, mean_klw, mean_lam = [], 0.0, 0.0
+        nb = n_batches(len(dataset), self.common.batch_size, world)
+        for step, (x, a, idx, _vid) in enumerate(dataset.iter_batches(self.common.batch_size, shuffle, seed, world, rank)):
+            logs.append(self._step(x, a, idx, True, True))
+            if self.kl_scheduler is not None:
+                self.kl_scheduler.step()
+                if step == int(nb / 2):
+                    mean_klw = self.kl_scheduler.get_weight()
+            if self.lambda_scheduler is not None:
+                self.lambda_scheduler.step()
+                if step == int(nb / 2):
+                    mean_lam = self.lambda_scheduler.get_weight()
+        return self._avg(logs), mean_klw, mean_lam
+
+    @torch.no_grad()
+    def validate_epoch(self, dataset: WindowDataset):
+        self.model.eval()
+        logs = [self._step(x, a, idx, False, False)
+                for x, a, idx, _ in dataset.iter_batches(self.common.batch_size, False, None, 1, 0)]
+        return self._avg(logs)
+
+    @staticmethod
+    def _avg(device_logs):
+        """One host sync per epoch: the per-step log vectors stay on device until here."""
+        if not device_logs:
+            return {k: float("nan") for k in _capi.LOG_KEYS}
+        m = torch.stack(device_logs).mean(dim=0).cpu().tolist()
+        out = {k: m[i] for i, k in enumerate(_capi.LOG_KEYS)}
+        out.pop("kl_weight", None)
+        return out
+
+
+def _set_lrs(eng, base_lr: float, gmm_lr: float):
+    for seg in (_capi.SEG_ENCODER, _capi.SEG_DECODER, _capi.SEG_HEADS):
+        eng.set_lr(seg, base_lr)
+    eng.set_lr(_capi.SEG_GMM, gmm_lr)
+
+
+@torch.no_grad()
+def initialize_gmm_from_data(model: VaDE, dataset: WindowDataset, batch_size: int, seed, n_samples: int = 10000):
+    """sklearn diag GMM (reg_covar 1e-4) on <= 10k latent means -> gmm_means / gmm_log_vars (models_new.py:1907-1943)."""
+    from sklearn.mixture import GaussianMixture
+
+    _, rank, world = _dist_state()
+    model.eval()
+    chunks, got = [], 0
+    for x, a, _idx, _vid in dataset.iter_batches(batch_size, True, seed, world, rank):
+        _, out = model._run(x, a, None, want_loc=False)
+        chunks.append(out["z_mean"].cpu())
+        got += x.shape[0]
+        if got >= n_samples:
+            break
+    emb = torch.cat(chunks).numpy()[:n_samples]
+    gmm = GaussianMixture(n_components=model.n_components, covariance_type="diag", reg_covar=1e-4).fit(emb)
+    model.latent_space.gmm_means.copy_(torch.from_numpy(gmm.means_).float())
+    model.latent_space.gmm_log_vars.copy_(torch.from_numpy(np.log(gmm.covariances_)).float())
+
+
+def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
+             teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, device=None, _engine_factory=None):
+    """training.py:1522-1918 (pretrain -> GMM init -> main epochs with best-val / best-score selection)."""
+    dist, rank, world = _dist_state()
+    is_main = rank == 0
+    model = VaDE(train_ds.x_shape, train_ds.a_shape, adjacency_matrix, common_cfg.latent_dim, common_cfg.n_components,
+                 encoder_type=common_cfg.encoder_type, use_gnn=True, kmeans_loss=vade_cfg.kmeans_loss_pretrain,
+                 interaction_regularization=common_cfg.interaction_regularization, batch_size=common_cfg.batch_size,
+                 device=device, _engine_factory=_engine_factory)
+    eng = model._base
+    if world > 1:  # DDP constructor semantics: rank 0's initial weights everywhere
+        dist.broadcast(eng.params, src=0)
+    rebuild_spec = {"model_name": "vade", "x_shape": train_ds.x_shape, "a_shape": train_ds.a_shape,
+                    "adjacency_matrix": np.asarray(adjacency_matrix).astype("float32"),
+                    "latent_dim": common_cfg.latent_dim, "n_components": common_cfg.n_components,
+                    "encoder_type": common_cfg.encoder_type, "use_gnn": True, "kmeans_loss": common_cfg.kmeans_loss,
+                    "interaction_regularization": common_cfg.interaction_regularization, "lens_enabled": False}
+    stepper = VadeStepper(model, common_cfg, vade_cfg, teacher_cfg)
+    nb = n_batches(len(train_ds), common_cfg.batch_size, world)
+
+    # ---- pretraining: KL vs N(0, I); GMM learning rate 0
+    if is_main:
+        print("\n--- Pretraining (reconstruction and setting up the latent space) ---")
+    model.set_pretrain_mode(True)
+    eng.reset_optimizer()
+    _set_lrs(eng, vade_cfg.learning_rate_pretrain, 0.0)
+    stepper.kl_scheduler = WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode_pretrain,
+                                          warmup_epochs=vade_cfg.kl_warmup_pretrain,
+                                          max_weight=vade_cfg.kl_max_weight_pretrain,
+                                          cooldown_epochs=vade_cfg.kl_cooldown_pretrain,
+                                          end_weight=vade_cfg.kl_end_weight_pretrain)
+    for _ep in range(vade_cfg.pretrain_epochs):
+        stepper.train_epoch(train_ds, common_cfg.seed)
+
+    # ---- main phase
+    model.set_pretrain_mode(False)
+    stepper.set_mode("main")
+    stepper.kl_scheduler = WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode, warmup_epochs=vade_cfg.kl_warmup,
+                                          max_weight=vade_cfg.kl_max_weight, cooldown_epochs=vade_cfg.kl_cooldown,
+                                          end_weight=vade_cfg.kl_end_weight)
+    eng.reset_optimizer()
+    _set_lrs(eng, common_cfg.learning_rate, vade_cfg.gmm_learning_rate)
+    _, best_path_val, best_path_score, _teacher_path = ckpt_paths("vade", common_cfg)
+    log_summary = init_log_summary("vade")
+    teacher_init_model = None
+    if teacher_cfg.use_turtle_teacher:
+        warnings.warn("TURTLE teacher distillation (SURVEY section 8f row N3) is not implemented in this build; "
+                      "continuing on the reference's use_turtle_teacher=False path (sklearn GMM initialisation, "
+                      "no distillation term).", RuntimeWarning)
+    if is_main:
+        print("\n--- Initializing GMM from embeddings (sklearn) ---")
+    initialize_gmm_from_data(model, train_ds, common_cfg.batch_size, common_cfg.seed)
+    if world > 1:
+        dist.broadcast(eng.params, src=0)
+
+    best_val, best_score, best_score_val = -float("inf"), -float("inf"), float("inf")
+    score_tol, val_tol = 0.01, 0.01
+    score_start_epoch = max(3, math.ceil(0.1 * common_cfg.epochs))
+    val_top_reached = False
+    for epoch in range(common_cfg.epochs):
+        if epoch == 0 and vade_cfg.freeze_gmm_epochs > 0:
+            eng.set_active(_capi.SEG_GMM, False)
+        if epoch == vade_cfg.freeze_gmm_epochs:  # reference hard-codes these learning rates here (Q22)
+            _set_lrs(eng, 5e-4, 2e-4)
+            eng.set_active(_capi.SEG_GMM, True)
+        if epoch == 0 and vade_cfg.freeze_decoder_epochs > 0:
+            eng.set_active(_capi.SEG_DECODER, False)
+        if epoch == vade_cfg.freeze_decoder_epochs:
+            eng.set_active(_capi.SEG_DECODER, True)
+        train_logs, klw, lambda_d = stepper.train_epoch(train_ds, common_cfg.seed)
+        val_logs = stepper.validate_epoch(val_ds)
+        diag = compute_diagnostics(model, val_ds, common_cfg.batch_size, common_cfg.n_components, tau_star=stepper.tau_star,
+                                   distill_sharpen_T=teacher_cfg.distill_sharpen_T,
+                                   distill_conf_weight=teacher_cfg.distill_conf_weight,
+                                   distill_conf_thresh=teacher_cfg.distill_conf_thresh,
+                                   max_batches=common_cfg.diag_max_batches)
+        val_logs.update(diag)
+        val_total = float(val_logs.get("total_loss", float("inf")))
+        score_value = float(val_logs["alignment_score"])
+        log_summary = _update_log_summary(log_summary, train_logs, val_logs)
+        if is_main:
+            print(f"Epoch {epoch + 1}/{common_cfg.epochs} | KLw={klw:.3f} | lambda_distill={lambda_d:.3f} | "
+                  f"train total={train_logs['total_loss']:.4f} recon={train_logs['reconstruct_loss']:.4f} | "
+                  f"val total={val_total:.4f} | align score={score_value:.3f}")
+        improved_val = (val_total + val_tol) < best_val
+        if not improved_val and not val_top_reached:  # track the rising validation loss until it tops out (Q19)
+            best_val = val_total
+        improved_score = math.isfinite(score_value) and (
+            score_value > best_score or (abs(score_value - best_score) <= score_tol and val_total < best_score_val))
+        common_info = dict(common_cfg=common_cfg, teacher_cfg=teacher_cfg, vade_cfg=vade_cfg, model=model,
+                           log_summary=log_summary, rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
+        if improved_val:
+            val_top_reached, best_val, val_tol = True, val_total, 0.0
+            if common_cfg.save_weights and is_main:
+                save_model_info(best_path_val, stage="best_val", epoch=epoch, train_steps=(epoch + 1) * nb,
+                                val_total=val_total, **common_info)
+        if improved_score and epoch > score_start_epoch:
+            best_score, best_score_val = score_value, val_total
+            if common_cfg.save_weights and is_main:
+                save_model_info(best_path_score, stage="best_score", epoch=epoch, train_steps=(epoch + 1) * nb,
+                                val_total=val_total, score_value=score_value, **common_info)
+    model_val, model_score = load_best_checkpoints(model, best_path_val, best_path_score, common_cfg.save_weights)
+    return model_val, model_score, teacher_init_model, log_summary
+
+
+# ------------------------------------------------------------------------------------------------
+# public API
+# ------------------------------------------------------------------------------------------------
+def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, common_cfg: CommonFitCfg,
+                            teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, contrastive_cfg: ContrastiveCfg,
+                            h5_dataset_folder: str = None, shuffle: bool = True, device: str = None,
+                            bootstrap_training: bool = False, bootstrap_block_len: int = 250, _engine_factory=None):
+    if common_cfg.pretrained:
+        model, log_summary, _spec, _rep = load_model_from_ckpt(common_cfg.pretrained, _engine_factory=_engine_factory)
+        return model, None, None, log_summary
+    if device is not None and device not in ("cpu", "gpu"):
+        raise ValueError("If a device is given, it needs to be either cpu or gpu!")
+    if device == "cpu" and _engine_factory is None:
+        raise RuntimeError("deepof_amd has no CPU path: the trainer runs on ROCm GPUs only (device='gpu' or None)")
+    if bootstrap_training:
+        raise NotImplementedError("bootstrap_training (block bootstrap of batch starts) is not implemented in this build")
+    is_ddp, rank, world, local_rank = ddp_init_if_needed()
+    torch.manual_seed(common_cfg.seed if common_cfg.seed is not None else 0)
+    np.random.seed(common_cfg.seed if common_cfg.seed is not None else 0)
+    model_name = common_cfg.model_name
+    if model_name != "vade":
+        if model_name in ("vqvae", "contrastive"):
+            raise NotImplementedError(f"model_name={model_name!r}: not built yet (SURVEY section 8a rows R10-R14); "
+                                      "this build implements VaDE")
+        raise ValueError(f"Unsupported model: {model_name}")
+    dev = None
+    if _engine_factory is None:
+        dev = torch.device(f"cuda:{local_rank}" if is_ddp else "cuda")
+    data_dev = dev if dev is not None else torch.device("cpu")
+    preprocessed_train, preprocessed_val = preprocessed_object
+    train_ds = WindowDataset.from_preprocessed(preprocessed_train, data_dev)
+    val_ds = WindowDataset.from_preprocessed(preprocessed_val, data_dev)
+    return fit_VADE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
+                    _engine_factory=_engine_factory)
+
+
+def train_deepof_model(
+    preprocessed_object: Tuple[dict, dict] = None, adjacency_matrix: np.ndarray = None, meta_info: dict = None,
+    encoder_type: str = None, batch_size: int = None, latent_dim: int = None, epochs: int = None,
+    output_path: str = None,
+    n_clusters: int = 10, learning_rate: float = 1e-3, log_history: bool = True, data_path: str = ".",
+    pretrained: Optional[str] = None, save_weights: bool = True, run: int = 0,
+    reg_cat_clusters: float = 0.0, recluster: bool = False, freeze_gmm_epochs: int = 0, freeze_decoder_epochs: int = 0,
+    prior_loss_weight: float = 0.0, gmm_learning_rate: float = 1e-3, learning_rate_pretrain: float = 1e-3,
+    interaction_regularization: float = 0.0003, kmeans_loss: float = 0.0,
+    num_workers: int = 0, prefetch_factor: int = 0, use_amp: bool = False,
+    use_turtle_teacher: bool = True, teacher_gamma: float = 8.0, teacher_outer_steps: int = 500,
+    teacher_inner_steps: int = 100, teacher_normalize_feats: bool = True, lambda_distill: float = 4.0,
+    lambda_decay_start: int = 10, lambda_end_weight: float = 0.2, lambda_cooldown: int = 10,
+    teacher_refresh_every: Optional[int] = False, teacher_freeze_at: Optional[int] = 10,
+    teacher_head_temp: float = 0.5, teacher_task_temp: float = 0.5, teacher_alpha_sample_entropy: float = 2.0,
+    teacher_batch_size: int = 2048,
+    pretrain_epochs: int = 10, kmeans_loss_pretrain: float = 1.0, repel_weight_pretrain: float = 0.5,
+    repel_length_scale_pretrain: float = 0.5, nonempty_weight_pretrain: float = 2e-2,
+    nonempty_p_pretrain: float = 2.0, nonempty_floor_percent_pretrain: float = 0.05,
+    kl_annealing_mode: str = "tf_sigmoid", kl_max_weight: float = 1, kl_warmup: int = 5, kl_end_weight: float = 0.2,
+    kl_cooldown: int = 5, kl_annealing_mode_pretrain: str = "tf_sigmoid", kl_max_weight_pretrain: float = 0.2,
+    kl_warmup_pretrain: int = 15, kl_end_weight_pretrain: float = 0.2, kl_cooldown_pretrain: int = 10,
+    reg_scatter_weight: float = 0, temporal_cohesion_weight: float = 0, reg_scatter_beta: float = 1.0,
+    repel_weight: float = 0, repel_length_scale: float = 1.0,
+    main_clustering_loss: float = 0.0, nonempty_weight: float = 2e-2, nonempty_floor_percent: float = 0.05,
+    nonempty_p: float = 2.0,
+    distill_conf_weight: bool = False, distill_conf_thresh: float = 0.3, distill_sharpen_T: float = 0.5,
+    include_edges_view: bool = False, include_nodes_view: bool = True, pca_nodes_dim: int = 32,
+    pca_edges_dim: int = 32, include_angles_view: bool = False, pca_angles_dim: int = 32,
+    reinit_gmm_on_refresh: bool = False,
+    diag_max_batches: int = 4,
+    model_name: str = "VaDE",
+    generic_lambda_distill: float = 2.0, generic_distill_sharpen_T: float = 0.5,
+    generic_distill_conf_weight: bool = True, generic_distill_conf_thresh: float = 0.6,
+    generic_distill_warmup_epochs: int = 1, distill_class_reweight_beta: float = 1,
+    distill_class_reweight_cap: float = 3,
+    temperature: float = 0.1, contrastive_similarity_function: str = "cosine",
+    contrastive_loss_function: str = "nce", beta: float = 0.1, tau: float = 0.1,
+    aug_min_shift: int = 1, aug_max_shift: int = 3, aug_p_shift: int = 0.4, aug_max_rot: int = 30, aug_n_rot: int = 3,
+    aug_p_rot: int = 0.8, aug_max_interp: int = 8, aug_min_interp: int = 3, aug_p_interp: float = 0.4,
+    aug_noise_sigma: float = 0.03, aug_p_noise: float = 0.4,
+    device: str = None, h5_dataset_folder: Optional[str] = None, bootstrap_training: Optional[bool] = False,
+    bootstrap_block_len: int = 250,
+    random_seed: int = 0,
+    _engine_factory=None,
+):
+    """Same signature / defaults / return value as the reference ``train_deepof_model`` (training.py:592-881)."""
+    model_name = str(model_name).lower()
+    encoder_type = str(encoder_type).lower()
+    kl_annealing_mode = str(kl_annealing_mode).lower()
+    contrastive_similarity_function = str(contrastive_similarity_function).lower()
+    contrastive_loss_function = str(contrastive_loss_function).lower()
+    check_model_inputs(preprocessed_object, adjacency_matrix, meta_info, encoder_type, batch_size, latent_dim, epochs,
+                       output_path, model_name, kl_annealing_mode, contrastive_similarity_function,
+                       contrastive_loss_function, pretrained)
+    common_cfg = CommonFitCfg(
+        model_name=model_name, encoder_type=encoder_type, batch_size=batch_size, latent_dim=latent_dim, epochs=epochs,
+        n_components=n_clusters, learning_rate=learning_rate, output_path=output_path, data_path=data_path,
+        log_history=log_history, pretrained=pretrained, save_weights=save_weights, run=run, num_workers=num_workers,
+        prefetch_factor=prefetch_factor, use_amp=use_amp, interaction_regularization=interaction_regularization,
+        kmeans_loss=kmeans_loss, diag_max_batches=diag_max_batches, seed=random_seed)
+    teacher_cfg = TurtleTeacherCfg(
+        use_turtle_teacher=use_turtle_teacher, teacher_gamma=teacher_gamma, teacher_outer_steps=teacher_outer_steps,
+        teacher_inner_steps=teacher_inner_steps, teacher_normalize_feats=teacher_normalize_feats,
+        teacher_head_temp=teacher_head_temp, teacher_task_temp=teacher_task_temp,
+        teacher_alpha_sample_entropy=teacher_alpha_sample_entropy, lambda_distill=lambda_distill,
+        lambda_decay_start=lambda_decay_start, lambda_end_weight=lambda_end_weight, lambda_cooldown=lambda_cooldown,
+        distill_sharpen_T=distill_sharpen_T, distill_conf_weight=distill_conf_weight,
+        distill_conf_thresh=distill_conf_thresh, generic_lambda_distill=generic_lambda_distill,
+        generic_distill_sharpen_T=generic_distill_sharpen_T, generic_distill_conf_weight=generic_distill_conf_weight,
+        generic_distill_conf_thresh=generic_distill_conf_thresh,
+        generic_distill_warmup_epochs=generic_distill_warmup_epochs,
+        distill_class_reweight_beta=distill_class_reweight_beta, distill_class_reweight_cap=distill_class_reweight_cap,
+        include_edges_view=include_edges_view, include_nodes_view=include_nodes_view,
+        include_angles_view=include_angles_view, pca_nodes_dim=pca_nodes_dim, pca_edges_dim=pca_edges_dim,
+        pca_angles_dim=pca_angles_dim,
+        teacher_refresh_every=(None if teacher_refresh_every is False else teacher_refresh_every),
+        teacher_freeze_at=teacher_freeze_at, reinit_gmm_on_refresh=reinit_gmm_on_refresh,
+        teacher_batch_size=teacher_batch_size)
+    vade_cfg = VaDECfg(
+        reg_cat_clusters=reg_cat_clusters, recluster=recluster, freeze_gmm_epochs=freeze_gmm_epochs,
+        freeze_decoder_epochs=freeze_decoder_epochs, gmm_learning_rate=gmm_learning_rate,
+        learning_rate_pretrain=learning_rate_pretrain, prior_loss_weight=prior_loss_weight,
+        pretrain_epochs=pretrain_epochs, reg_scatter_weight=reg_scatter_weight,
+        temporal_cohesion_weight=temporal_cohesion_weight, reg_scatter_beta=reg_scatter_beta,
+        repel_weight=repel_weight, repel_length_scale=repel_length_scale, tf_cluster_weight=main_clustering_loss,
+        nonempty_weight=nonempty_weight, nonempty_floor_percent=nonempty_floor_percent, nonempty_p=nonempty_p,
+        kmeans_loss_pretrain=kmeans_loss_pretrain, repel_weight_pretrain=repel_weight_pretrain,
+        repel_length_scale_pretrain=repel_length_scale_pretrain, nonempty_weight_pretrain=nonempty_weight_pretrain,
+        nonempty_p_pretrain=nonempty_p_pretrain, nonempty_floor_percent_pretrain=nonempty_floor_percent_pretrain,
+        kl_annealing_mode=kl_annealing_mode, kl_max_weight=kl_max_weight, kl_warmup=kl_warmup,
+        kl_end_weight=kl_end_weight, kl_cooldown=kl_cooldown, kl_annealing_mode_pretrain=kl_annealing_mode_pretrain,
+        kl_max_weight_pretrain=kl_max_weight_pretrain, kl_warmup_pretrain=kl_warmup_pretrain,
+        kl_end_weight_pretrain=kl_end_weight_pretrain, kl_cooldown_pretrain=kl_cooldown_pretrain)
+    contrastive_cfg = ContrastiveCfg(
+        temperature=temperature, contrastive_similarity_function=contrastive_similarity_function,
+        contrastive_loss_function=contrastive_loss_function, beta=beta, tau=tau, aug_min_shift=aug_min_shift,
+        aug_max_shift=aug_max_shift, aug_p_shift=aug_p_shift, aug_noise_sigma=aug_noise_sigma, aug_p_noise=aug_p_noise,
+        aug_min_interp=aug_min_interp, aug_max_interp=aug_max_interp, aug_p_interp=aug_p_interp,
+        aug_max_rot=aug_max_rot, aug_n_rot=aug_n_rot, aug_p_rot=aug_p_rot)
+    return train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, common_cfg=common_cfg,
+                                   teacher_cfg=teacher_cfg, vade_cfg=vade_cfg, contrastive_cfg=contrastive_cfg,
+                                   h5_dataset_folder=h5_dataset_folder, device=device,
+                                   bootstrap_training=bootstrap_training, bootstrap_block_len=bootstrap_block_len,
+                                   _engine_factory=_engine_factory)

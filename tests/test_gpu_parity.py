@@ -83,3 +83,115 @@ def test_full_size_oracle_parity_c2(hip):
     np.testing.assert_allclose(out["z"].cpu().numpy(), ref["z"].numpy(), atol=3e-5, rtol=1e-3)
     np.testing.assert_allclose(out["q"].cpu().numpy(), ref["q"].numpy(), atol=3e-5, rtol=2e-3)
     np.testing.assert_allclose(out["loc"].cpu().numpy(), ref["loc"].numpy(), atol=1e-4, rtol=1e-3)
+
+
+def _c2_engine(B=1024):
+    from deepof_amd.engine import create_vade_engine
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    nodes, edges = bodypart_graph([""])
+    eng = create_vade_engine(B, 25, adjacency_from_graph(nodes, edges), 8, 10)
+    g = torch.Generator().manual_seed(0)
+    for n in eng.names:
+        shape = eng.layout[n][2]
+        v = torch.randn(shape, generator=g) * (0.3 if len(shape) > 1 else 0.1)
+        if "norm" in n and n.endswith("weight"):
+            v = 1.0 + v
+        eng.view(n).copy_(v)
+    return eng, len(nodes), len(edges), g
+
+
+def test_full_size_step_properties_c2(hip):
+    """BASELINE C2 size (B=1024): logged total == sum of parts, finite gradients, and bitwise run-to-run
+    reproducibility of the whole gradient (fixed-order reductions, no float atomics)."""
+    from parity_common import configure_phase
+    eng, N, E, g = _c2_engine()
+    B, T, L, K = eng.B, eng.T, eng.L, eng.K
+    x = torch.randn(B, T, N, 3, generator=g).cuda()
+    a = torch.randn(B, T, E, 1, generator=g).cuda()
+    eps = torch.randn(B, L, generator=g).cuda()
+    eps_mc = torch.randn(32, B, L, generator=g).cuda()
+    tau = torch.softmax(torch.randn(B, K, generator=g) * 2, dim=-1).cuda()
+    for pretrain in (True, False):
+        configure_phase(eng, K, pretrain, 0.5, tau.cpu() if not pretrain else None, 4.0 if not pretrain else 0.0)
+        eng.loss_grads(x, a, eps, eps_mc, None if pretrain else tau, pretrain=pretrain)
+        g1, logs = eng.grads.clone(), eng.read_logs()
+        eng.loss_grads(x, a, eps, eps_mc, None if pretrain else tau, pretrain=pretrain)
+        assert torch.equal(g1, eng.grads), "gradient is not bitwise reproducible"
+        assert bool(torch.isfinite(g1).all())
+        parts = sum(v for k, v in logs.items() if k not in ("total_loss", "kl_weight"))
+        np.testing.assert_allclose(logs["total_loss"], parts, rtol=1e-5)
+        assert float(g1.abs().max()) > 0
+
+
+def test_full_size_gradient_parity_c2(hip):
+    """B=1024 gradients vs CPU-oracle autograd on the same inputs (pretrain objective)."""
+    from oracle import vade as OV
+    from parity_common import configure_phase
+    eng, N, E, g = _c2_engine(256)
+    B, T, L, K = eng.B, eng.T, eng.L, eng.K
+    x = torch.randn(B, T, N, 3, generator=g)
+    a = torch.randn(B, T, E, 1, generator=g)
+    eps = torch.randn(B, L, generator=g)
+    configure_phase(eng, K, True, 0.2)
+    eng.loss_grads(x.cuda(), a.cuda(), eps.cuda(), None, None, pretrain=True)
+    ref, grads, _ = OV.vade_grads(eng.state_dict(), x, a, OV.VadeLossCfg(K, True), 0.2, eps)
+    logs = eng.read_logs()
+    for k, v in ref.items():
+        np.testing.assert_allclose(logs[k], float(v), rtol=2e-4, atol=2e-5, err_msg=k)
+    for name, gr in grads.items():
+        if gr is None:
+            continue
+        got = eng.view(name, eng.grads).cpu().numpy()
+        scale = float(gr.abs().max()) + 1e-8
+        assert np.abs(got - gr.numpy()).max() / scale < 2e-3, name
+
+
+def test_gather_full_size_checksum(hip):
+    """C2-sized materialisation (600k windows): every output element is checked through a size-independent
+    identity -- sum over windows of x equals sum over frames of (multiplicity * frame), per column."""
+    from deepof_amd import _capi
+    F, N, E, W = 600_000, 14, 14, 25
+    g = torch.Generator(device="cuda").manual_seed(1)
+    tn = torch.randn(F, 3 * N, device="cuda", generator=g)
+    te = torch.randn(F, E, device="cuda", generator=g)
+    nw = F - W + 1
+    x = torch.empty(nw, W, N, 3, device="cuda")
+    a = torch.empty(nw, W, E, 1, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _capi.check(hip, hip.dof_window_gather_range(tn.data_ptr(), te.data_ptr(), 0, 1, nw, W, N, E, x.data_ptr(),
+                                                 a.data_ptr(), st))
+    mult = torch.minimum(torch.minimum(torch.arange(1, F + 1, device="cuda"), torch.arange(F, 0, -1, device="cuda")),
+                         torch.tensor(W, device="cuda")).clamp(max=nw).double()
+    want_n = (tn.double() * mult[:, None]).sum(0)                       # per table column
+    got_n = x.double().sum(dim=(0, 1)).permute(1, 0).reshape(-1)        # (N,3) -> [x.. y.. s..]
+    np.testing.assert_allclose(got_n.cpu().numpy(), want_n.cpu().numpy(), rtol=1e-9, atol=1e-6)
+    want_e = (te.double() * mult[:, None]).sum(0)
+    np.testing.assert_allclose(a.double().sum(dim=(0, 1, 3)).cpu().numpy(), want_e.cpu().numpy(), rtol=1e-9, atol=1e-6)
+    # spot-check exact values of the first, a middle and the last window
+    for w in (0, 123_457, nw - 1):
+        ref = tn[w:w + W].reshape(W, 3, N).permute(0, 2, 1)
+        assert torch.equal(x[w], ref) and torch.equal(a[w, :, :, 0], te[w:w + W])
+
+
+def test_training_api_on_gpu(hip, tmp_path):
+    """deep_unsupervised_embedding-sized smoke through the public API on the device (reference
+    tests/test_data.py:954-1015: 100 frames, W=25 -> 76 windows, latent 8, k=10)."""
+    from deepof_amd.training import train_deepof_model
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    from oracle import windows as OW
+    nodes, edges = bodypart_graph([""])
+    rng = np.random.default_rng(0)
+    def video(frames):
+        return (OW.rolling_window(rng.standard_normal((frames, 42)).cumsum(0) * 0.1, 25),
+                OW.rolling_window(rng.standard_normal((frames, 14)), 25), np.zeros((frames - 24, 25, 0)))
+    train, val = {"a": video(100), "b": video(100)}, {"c": video(100)}
+    mv, ms, mt, logs = train_deepof_model(
+        preprocessed_object=(train, val), adjacency_matrix=adjacency_from_graph(nodes, edges), meta_info={},
+        encoder_type="recurrent", batch_size=16, latent_dim=8, epochs=3, output_path=str(tmp_path), n_clusters=10,
+        pretrain_epochs=2, use_turtle_teacher=False, save_weights=False)
+    assert mt is None and len(logs["train"]["total_loss"]) == 3 and np.isfinite(logs["val"]["total_loss"]).all()
+    x = torch.from_numpy(OW.node_windows_to_x(val["c"][0]))
+    a = torch.from_numpy(OW.edge_windows_to_a(val["c"][1]))
+    emb, soft = mv.encode_windows(x, a, batch=256)
+    assert tuple(emb.shape) == (76, 8) and tuple(soft.shape) == (76, 10)      # reference shape pin
+    np.testing.assert_allclose(soft.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
