@@ -81,32 +81,13 @@ def init_params(eng, seed=0):
         eng.view(n).copy_(v)
 
 
-def cpu_baseline(adj, B, T, L, K, steps=4, warm=1):
-    """Oracle ('port' of the reference PyTorch-CPU path) timed on a bounded sample of the same workload."""
+def cpu_baseline(P, B, T, N, E, L, K, steps=3, warm=1):
+    """Oracle ('port' of the reference PyTorch-CPU path) timed on a bounded sample of the same workload:
+    same architecture and initial weights (state_dict P), same batch size, main phase with distillation."""
     from oracle import vade as OV
-    from deepof_amd.graph import censnet_operators
 
     torch.manual_seed(0)
-    N = adj.shape[0]
-    lap, elap, inc = censnet_operators(adj)
-    E = inc.shape[1]
-
-    names_shapes = cpu_param_table(N, E, L, K)
-    P = {}
     g = torch.Generator().manual_seed(0)
-    for n, shape in names_shapes:
-        if "norm" in n and n.endswith("weight"):
-            P[n] = torch.ones(shape)
-        elif "norm" in n and n.endswith("bias"):
-            P[n] = torch.zeros(shape)
-        else:
-            fan = int(np.prod(shape[1:])) if len(shape) > 1 else 10
-            P[n] = (torch.rand(shape, generator=g) * 2 - 1) / np.sqrt(fan)
-    P["encoder.laplacian"] = torch.from_numpy(lap)
-    P["encoder.edge_laplacian"] = torch.from_numpy(elap)
-    P["encoder.incidence"] = torch.from_numpy(inc)
-    P["latent_space.prior"] = torch.full((K,), 1.0 / K)
-    P["latent_space.pretrain"] = torch.tensor(0.0)
     x = torch.randn(B, T, N, 3, generator=g)
     a = torch.randn(B, T, E, 1, generator=g)
     tau = torch.softmax(torch.randn(B, K, generator=g), dim=-1)
@@ -114,53 +95,29 @@ def cpu_baseline(adj, B, T, L, K, steps=4, warm=1):
     w = pi.pow(-1.0)
     w = (w / w.mean()).clamp_max(3.0)
     cfg = OV.VadeLossCfg(K, False, lambda_distill=4.0, class_weight=w, teacher_marginal=pi)
-    opt = OV.AdamState()
-    times = []
-    for i in range(warm + steps):
-        t0 = time.perf_counter()
-        eps = torch.randn(B, L)
-        eps_mc = torch.randn(32, B, L)
-        OV.vade_train_step(P, opt, x, a, cfg, 1.0, 5e-4, 2e-4, eps, eps_mc, tau)
-        dt = time.perf_counter() - t0
-        if i >= warm:
-            times.append(dt)
-    med = float(np.median(times))
-    return {"value": B / med, "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps of batch {B} after {warm} warm-up (oracle/vade.py, torch CPU fp32), median"}
-
-
-def cpu_param_table(N, E, L, K):
-    """(name, shape) list in the reference state_dict order (no device needed)."""
-    out = []
-    for blk, F in (("encoder.node_recurrent_block", 3), ("encoder.edge_recurrent_block", 1)):
-        out.append((f"{blk}.conv1d.weight", (2 * L, F, 5)))
-        for g, (i, h) in (("gru1", (2 * L, 2 * L)), ("norm1", None), ("gru2", (4 * L, L)), ("norm2", None)):
-            if g.startswith("norm"):
-                c = 4 * L if g == "norm1" else 2 * L
-                out += [(f"{blk}.{g}.weight", (c,)), (f"{blk}.{g}.bias", (c,))]
-            else:
-                for sfx in ("", "_reverse"):
-                    out += [(f"{blk}.{g}.weight_ih_l0{sfx}", (3 * h, i)), (f"{blk}.{g}.weight_hh_l0{sfx}", (3 * h, h)),
-                            (f"{blk}.{g}.bias_ih_l0{sfx}", (3 * h,)), (f"{blk}.{g}.bias_hh_l0{sfx}", (3 * h,))]
-        out += [(f"{blk}.projection.weight", (2 * L, 2 * L)), (f"{blk}.projection.bias", (2 * L,))]
-    sg = "encoder.spatial_gnn_block"
-    out += [(f"{sg}.node_kernel", (2 * L, L)), (f"{sg}.edge_kernel", (2 * L, L)), (f"{sg}.node_weights", (2 * L, 1)),
-            (f"{sg}.edge_weights", (2 * L, 1)), (f"{sg}.node_bias", (L,)), (f"{sg}.edge_bias", (L,)),
-            ("encoder.final_dense.weight", (L, (N + E) * L)), ("encoder.final_dense.bias", (L,))]
-    for g, (i, h) in (("gru1", (L, L)), ("gru2", (2 * L, 2 * L))):
-        for sfx in ("", "_reverse"):
-            out += [(f"decoder.{g}.weight_ih_l0{sfx}", (3 * h, i)), (f"decoder.{g}.weight_hh_l0{sfx}", (3 * h, h)),
-                    (f"decoder.{g}.bias_ih_l0{sfx}", (3 * h,)), (f"decoder.{g}.bias_hh_l0{sfx}", (3 * h,))]
-        c = 2 * L if g == "gru1" else 4 * L
-        nn = "norm1" if g == "gru1" else "norm2"
-        out += [(f"decoder.{nn}.weight", (c,)), (f"decoder.{nn}.bias", (c,))]
-    out += [("decoder.conv1d.weight", (2 * L, 4 * L, 5)), ("decoder.norm3.weight", (2 * L,)), ("decoder.norm3.bias", (2 * L,)),
-            ("decoder.prob_decoder.loc_projection.weight", (3 * N, 2 * L)), ("decoder.prob_decoder.loc_projection.bias", (3 * N,)),
-            ("latent_space.gmm_means", (K, L)), ("latent_space.gmm_log_vars", (K, L)),
-            ("latent_space.encoder_mean.weight", (L, L)), ("latent_space.encoder_mean.bias", (L,)),
-            ("latent_space.encoder_log_var.weight", (L, L)), ("latent_space.encoder_log_var.bias", (L,)),
-            ("latent_space.lens.weight", (L, L)), ("latent_space.lens.bias", (L,))]
-    return out
+    all_cores = torch.get_num_threads()
+    results = {}
+    # tiny-op eager PyTorch does not scale with threads: report the best of a few thread counts
+    for threads in sorted({min(8, all_cores), min(32, all_cores), all_cores}):
+        torch.set_num_threads(threads)
+        P_run = {k: v.clone() for k, v in P.items()}
+        opt = OV.AdamState()
+        times = []
+        for i in range(warm + steps):
+            t0 = time.perf_counter()
+            eps = torch.randn(B, L)
+            eps_mc = torch.randn(32, B, L)
+            OV.vade_train_step(P_run, opt, x, a, cfg, 1.0, 5e-4, 2e-4, eps, eps_mc, tau)
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                times.append(dt)
+        results[threads] = B / float(np.median(times))
+    torch.set_num_threads(all_cores)
+    best = max(results, key=results.get)
+    others = ", ".join(f"{t} threads: {v:.1f}" for t, v in sorted(results.items()))
+    return {"value": results[best], "unit": "windows/s", "cores": best, "kind": "port",
+            "sample": f"{steps} train steps of batch {B} after {warm} warm-up per thread count (oracle/vade.py, "
+                      f"torch CPU fp32, median; host has {all_cores} threads; windows/s by thread count: {others})"}
 
 
 def main():
@@ -200,6 +157,7 @@ def main():
     eng = create_vade_engine(B, T, adj, L, K, S, device=dev)
     lib = eng.lib
     init_params(eng, seed=0)  # identical on every rank (DDP broadcast equivalent)
+    initial_state = eng.state_dict() if rank == 0 else None
 
     # --- device-resident dataset: 2 animals per rank, concatenated frame tables + window start rows
     n_animals, F = 2, args.frames
@@ -348,13 +306,18 @@ def main():
         bytes_per_window = T * (3 * N + E) * 4 + (3 * N + E) * 4
         alg_bytes = win_per_animal * bytes_per_window
         achieved = alg_bytes / sec_per_launch / 1e9
+        traffic = None  # HBM bytes/launch from rocprofv3 PMC passes of this same launch (profiles/r01_gather_pmc.json)
+        pmc_file = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
+        if os.path.exists(pmc_file) and win_per_animal == 599976 and (T, N, E) == (25, 14, 14):
+            traffic = json.load(open(pmc_file))["hbm_bytes_per_launch"]
         out["roofline"] = {"kernel": "k_window_gather", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": alg_bytes,
                            "bytes_per_window": bytes_per_window, "windows_per_launch": win_per_animal,
                            "avg_launch_ms": sec_per_launch * 1e3}
         del xg, ag
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(adj, B, T, L, K)
+            out["cpu_baseline"] = cpu_baseline(initial_state, B, T, N, E, L, K)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
