@@ -132,10 +132,13 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
   }
 }
 
+// One 64-lane wavefront per output element: lanes stride over the job's per-workgroup partial
+// tiles, then a fixed-shape butterfly adds the 64 lane sums (deterministic).
 __global__ void __launch_bounds__(256) k_outer_finalize(const DofOuterJob* __restrict__ jobs,
                                                         const DofFinJob* __restrict__ fin, int n_fin, int total,
                                                         const float* __restrict__ partials, float* __restrict__ grads) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (e >= total) return;
   int lo = 0, hi = n_fin - 1;
   while (lo < hi) {  // last fin-job with elem0 <= e
@@ -149,8 +152,10 @@ __global__ void __launch_bounds__(256) k_outer_finalize(const DofOuterJob* __res
   const int src_row = ri < F.r1 ? ri : ri + (F.r2 - F.r1);
   const float* __restrict__ p = partials + J.partial_off + (int64_t)src_row * 65 + F.col0 + ci;
   float acc = 0.0f;
-  for (int b = 0; b < J.nblk; ++b) acc += p[(int64_t)b * DOF_OUTER_PARTIAL_FLOATS];
-  grads[F.dst_off + (int64_t)ri * F.row_stride + (int64_t)ci * F.col_stride] = acc;
+  for (int b = lane; b < J.nblk; b += 64) acc += p[(int64_t)b * DOF_OUTER_PARTIAL_FLOATS];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (lane == 0) grads[F.dst_off + (int64_t)ri * F.row_stride + (int64_t)ci * F.col_stride] = acc;
 }
 
 // one workgroup per output value: strided partial sums + fixed-shape LDS tree (deterministic)
@@ -210,7 +215,7 @@ int dof_launch_outer(const DofOuterJob* jobs_dev, int njobs, int total_blocks, f
 int dof_launch_outer_finalize(const DofOuterJob* jobs_dev, const DofFinJob* fin_dev, int n_fin, int total_elems,
                               const float* partials, float* grads, hipStream_t st) {
   if (total_elems <= 0) return DOF_OK;
-  DOF_LAUNCH(k_outer_finalize, (dof_cdiv(total_elems, 256)), (256), st, jobs_dev, fin_dev, n_fin, total_elems,
+  DOF_LAUNCH(k_outer_finalize, (dof_cdiv(total_elems, 4)), (256), st, jobs_dev, fin_dev, n_fin, total_elems,
              partials, grads);
   return dof_check_launch("k_outer_finalize");
 }

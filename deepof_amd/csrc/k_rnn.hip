@@ -22,60 +22,53 @@ namespace {
 template <int C1, int F>
 __global__ void __launch_bounds__(256) k_enc_conv_fwd(const float* __restrict__ xin,  // (B,T,G,F) reference layout
                                                       const float* __restrict__ w,    // (C1,F,5)
-                                                      float* __restrict__ xs,         // [T][F][Sp] scrambled copy
-                                                      float* __restrict__ c,          // [T][C1][Sp]
+                                                      float* __restrict__ xs,         // [T][Sp][F] scrambled copy
+                                                      float* __restrict__ c,          // [T][Sp][C1]
                                                       int* __restrict__ len, int T, int G, int64_t S, int64_t Sp) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
+  // thread = (output time, sequence): T x more parallelism than one thread per sequence; the
+  // per-sequence length (number of non-zero conv rows) is an integer atomic count (order-free).
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)T * S) return;
+  const int to = (int)(i / S);
+  const int64_t s = i - (int64_t)to * S;
   const int64_t b = s / G;
   const int g = (int)(s - b * G);
   const float* __restrict__ win = xin + b * (int64_t)T * G * F;
-  float rows[5][F];  // rows[k] = input at time (tcur + k - 4)
+  const dof_cfp wc = dof_cw(w);
+  float rows[5][F];
 #pragma unroll
-  for (int k = 0; k < 5; ++k)
-#pragma unroll
-    for (int f = 0; f < F; ++f) rows[k][f] = 0.0f;
-  int count = 0;
-  const dof_cfp w0 = dof_cw(w);
-  for (int tt = 0; tt < T + 2; ++tt) {
-    const dof_cfp wc = w0 + dof_opaque_zero();
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int f = 0; f < F; ++f) rows[k][f] = rows[k + 1][f];
+  for (int k = 0; k < 5; ++k) {
+    const int tt = to + k - 2;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       float v = 0.0f;
-      if (tt < T) {
+      if (tt >= 0 && tt < T) {
         // y[b,g,tt,f] = x[b, t, cc] with cc*T + t = (f*T + tt)*G + g   (models_new.py:131-137)
         const int lin = (f * T + tt) * G + g;
         const int cc = lin / T;
         const int t = lin - cc * T;
         v = win[(int64_t)t * G * F + cc];
-        xs[ACT(tt, f, F, Sp, s)] = v;
       }
-      rows[4][f] = v;
-    }
-    const int to = tt - 2;  // output time whose 5-tap window [to-2, to+2] is now in rows[0..4]
-    if (to >= 0) {
-      bool nz = false;
-      float crow[C1];
-#pragma unroll
-      for (int o = 0; o < C1; ++o) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int f = 0; f < F; ++f)
-#pragma unroll
-          for (int k = 0; k < 5; ++k) acc = fmaf(wc[(o * F + f) * 5 + k], rows[k][f], acc);
-        acc = acc > 0.0f ? acc : 0.0f;
-        nz |= (acc != 0.0f);
-        crow[o] = acc;
-      }
-      dof_st_row<C1>(c + ACT(to, 0, C1, Sp, s), crow);
-      count += nz ? 1 : 0;
+      rows[k][f] = v;
     }
   }
-  len[s] = count;
+#pragma unroll
+  for (int f = 0; f < F; ++f) xs[ACT(to, f, F, Sp, s)] = rows[2][f];
+  bool nz = false;
+  float crow[C1];
+#pragma unroll
+  for (int o = 0; o < C1; ++o) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) acc = fmaf(wc[(o * F + f) * 5 + k], rows[k][f], acc);
+    acc = acc > 0.0f ? acc : 0.0f;
+    nz |= (acc != 0.0f);
+    crow[o] = acc;
+  }
+  dof_st_row<C1>(c + ACT(to, 0, C1, Sp, s), crow);
+  if (nz) atomicAdd(len + s, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -497,6 +490,162 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// GRU backward (IN = HID = 16) with the weight-gradient reduction fused in.
+// In the lane-per-unit mapping a wavefront holds 4 sequences x 16 units, which IS the operand
+// layout of v_mfma_f32_16x16x4_f32 (lane = (row i = unit, k = sequence)): the outer products
+//   dW_ih[g] += dG_g (16 units x 4 seq) . X^T (4 seq x 16 inputs),  dW_hh[g] += dG_g . Hprev^T
+// are 6 MFMAs per step straight out of the registers that already hold dG, x_t and h_{t-1}; the
+// matrix pipe runs beside the VALU recurrence.  dG is never written to HBM and the separate
+// k_outer pass over it disappears.  The time loop is wave-uniform (MFMA ignores EXEC), finished
+// sequences contribute zeros.  Per-workgroup partial tiles -> k_gru16_wg_finalize (fixed order).
+// ---------------------------------------------------------------------------------------------
+#define GRU16_WG_FLOATS (6 * 256 + 4 * 16)
+__global__ void __launch_bounds__(256) k_gru16_bwd_fused(
+    const float* __restrict__ X, const int* __restrict__ len, const float* __restrict__ wih0,
+    const float* __restrict__ whh0, const float* __restrict__ wih1, const float* __restrict__ whh1,
+    const float* __restrict__ O, const float* __restrict__ GS, const float* __restrict__ dO,
+    float* __restrict__ dX, float* __restrict__ wg_partial, int T, int64_t S, int64_t Sp) {
+  constexpr int HID = 16, IN = 16, G = 16;
+  __shared__ float red[4][6][256];
+  __shared__ float bred[256][5];
+  const int u = threadIdx.x & 15;
+  const int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int dir = blockIdx.y;
+  const bool in_range = s < S;
+  const float* __restrict__ wih = dir ? wih1 : wih0;
+  const float* __restrict__ whh = dir ? whh1 : whh0;
+  float tr[HID], tz[HID], tn[HID], xr[HID], xz[HID], xn[HID];
+#pragma unroll
+  for (int j = 0; j < HID; ++j) {
+    tr[j] = whh[j * HID + u];
+    tz[j] = whh[(HID + j) * HID + u];
+    tn[j] = whh[(2 * HID + j) * HID + u];
+    xr[j] = wih[j * IN + u];
+    xz[j] = wih[(HID + j) * IN + u];
+    xn[j] = wih[(2 * HID + j) * IN + u];
+  }
+  const float* __restrict__ gs = GS + (int64_t)dir * T * 4 * HID * Sp;
+  float* __restrict__ dx_out = dX + (int64_t)dir * T * IN * Sp;
+  const int n = in_range ? len[s] : 0;
+  float dh = 0.0f;
+  dof_f32x4 acc[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) acc[a] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float sb_r = 0.0f, sb_z = 0.0f, sb_n = 0.0f, sb_h = 0.0f;
+  for (int step = T - 1; step >= 0; --step) {
+    const bool act = step < n;
+    const int t = dir ? (n - 1 - step) : step;
+    const int tp = dir ? t + 1 : t - 1;
+    float g_r = 0.0f, g_z = 0.0f, g_n = 0.0f, g_h = 0.0f, hp = 0.0f, xu = 0.0f, dht = 0.0f, z = 0.0f;
+    if (act) {
+      const float r = gs[ACT(t, u, 4 * HID, Sp, s)];
+      z = gs[ACT(t, HID + u, 4 * HID, Sp, s)];
+      const float nn = gs[ACT(t, 2 * HID + u, 4 * HID, Sp, s)];
+      const float ahn = gs[ACT(t, 3 * HID + u, 4 * HID, Sp, s)];
+      hp = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
+      xu = X[ACT(t, u, IN, Sp, s)];
+      dht = dh;
+      if (dO) dht += dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)];
+      const float dn = dht * (1.0f - z);
+      const float dz = dht * (hp - nn);
+      const float dnp = dn * (1.0f - nn * nn);
+      g_r = dnp * ahn * r * (1.0f - r);
+      g_z = dz * z * (1.0f - z);
+      g_n = dnp;
+      g_h = dnp * r;
+    }
+    // weight-gradient tiles: rows = unit (this lane), k = sequence (lane >> 4), cols = input / hidden index
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_r, xu, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_z, xu, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_n, xu, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_r, hp, acc[3], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_z, hp, acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_h, hp, acc[5], 0, 0, 0);
+    sb_r += g_r; sb_z += g_z; sb_n += g_n; sb_h += g_h;
+    float dhp = dht * z;
+    float dx = 0.0f;
+    dof_static_for<HID>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const float b_r = dof_gbcast<j, G>(g_r);
+      const float b_z = dof_gbcast<j, G>(g_z);
+      const float b_n = dof_gbcast<j, G>(g_n);
+      const float b_h = dof_gbcast<j, G>(g_h);
+      dhp = fmaf(tr[j], b_r, dhp);
+      dhp = fmaf(tz[j], b_z, dhp);
+      dhp = fmaf(tn[j], b_h, dhp);
+      dx = fmaf(xr[j], b_r, dx);
+      dx = fmaf(xz[j], b_z, dx);
+      dx = fmaf(xn[j], b_n, dx);
+    });
+    if (act) {
+      dh = dhp;
+      dx_out[ACT(t, u, IN, Sp, s)] = dx;
+    }
+  }
+  if (in_range)
+    for (int t = n; t < T; ++t) dx_out[ACT(t, u, IN, Sp, s)] = 0.0f;
+  // ---- workgroup reduction of the 4 waves' tiles and of the bias sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) red[wave][a][((lane >> 4) * 4 + r4) * 16 + (lane & 15)] = acc[a][r4];
+  bred[threadIdx.x][0] = sb_r; bred[threadIdx.x][1] = sb_z; bred[threadIdx.x][2] = sb_n; bred[threadIdx.x][3] = sb_h;
+  __syncthreads();
+  float* __restrict__ out = wg_partial + ((int64_t)dir * gridDim.x + blockIdx.x) * GRU16_WG_FLOATS;
+  for (int e = threadIdx.x; e < 6 * 256; e += 256) {
+    const int a = e >> 8, c = e & 255;
+    out[e] = (red[0][a][c] + red[1][a][c]) + (red[2][a][c] + red[3][a][c]);
+  }
+  if (threadIdx.x < 64) {  // (gate, unit): sum over the 16 sequences of the workgroup
+    const int gate = threadIdx.x >> 4, unit = threadIdx.x & 15;
+    float acc_b = 0.0f;
+    for (int g = 0; g < 16; ++g) acc_b += bred[g * 16 + unit][gate];
+    out[6 * 256 + threadIdx.x] = acc_b;
+  }
+}
+
+// grads of one direction of a (16,16) GRU layer from the per-workgroup partials; block = one output value
+__global__ void __launch_bounds__(256) k_gru16_wg_finalize(const float* __restrict__ wg_partial, int nblk,
+                                                           float* __restrict__ g_wih0, float* __restrict__ g_whh0,
+                                                           float* __restrict__ g_bih0, float* __restrict__ g_bhh0,
+                                                           float* __restrict__ g_wih1, float* __restrict__ g_whh1,
+                                                           float* __restrict__ g_bih1, float* __restrict__ g_bhh1) {
+  __shared__ float red[256];
+  const int v = blockIdx.x, dir = blockIdx.y;
+  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU16_WG_FLOATS + v;
+  float acc = 0.0f;
+  for (int b = threadIdx.x; b < nblk; b += 256) acc += p[(int64_t)b * GRU16_WG_FLOATS];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const float val = red[0];
+  float* g_wih = dir ? g_wih1 : g_wih0;
+  float* g_whh = dir ? g_whh1 : g_whh0;
+  float* g_bih = dir ? g_bih1 : g_bih0;
+  float* g_bhh = dir ? g_bhh1 : g_bhh0;
+  if (v < 6 * 256) {
+    const int tile = v >> 8, row = (v & 255) >> 4, col = v & 15;
+    if (tile < 3) g_wih[(tile * 16 + row) * 16 + col] = val;
+    else g_whh[((tile - 3) * 16 + row) * 16 + col] = val;
+  } else {
+    const int gate = (v - 6 * 256) >> 4, unit = v & 15;  // gates: r, z, n(input side), hn(hidden side)
+    if (gate < 2) {
+      g_bih[gate * 16 + unit] = val;
+      g_bhh[gate * 16 + unit] = val;
+    } else if (gate == 2) {
+      g_bih[32 + unit] = val;
+    } else {
+      g_bhh[32 + unit] = val;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm over channels (eps = 1e-3), thread = (t, s).
 // ---------------------------------------------------------------------------------------------
 template <int C>
@@ -653,7 +802,8 @@ __global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ ac
 
 int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, float* xs, float* c, int* len, int T,
                             int G, int64_t S, int64_t Sp, hipStream_t st) {
-  const unsigned nb = dof_cdiv(S, 256);
+  const unsigned nb = dof_cdiv((int64_t)T * S, 256);
+  if (hipMemsetAsync(len, 0, (size_t)S * sizeof(int), st) != hipSuccess) return DOF_ERR_LAUNCH;
   if (F == 3) {
     DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd<2 * LL, 3>), (nb), (256), st, xin, w, xs, c, len, T, G, S, Sp));
   } else if (F == 1) {
@@ -715,6 +865,23 @@ int dof_launch_ln_fwd(int L, int mult, const float* X, const float* gamma, const
     DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_fwd<4 * LL>), (nb), (256), st, X, gamma, beta, Y, T, S, Sp));
   }
   return dof_check_launch("k_ln_fwd");
+}
+
+int64_t dof_gru16_wg_floats(int64_t S) { return 2 * (int64_t)dof_cdiv(S, 16) * GRU16_WG_FLOATS; }
+
+int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
+                               const float* dO, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
+                               hipStream_t st) {
+  DOF_LAUNCH(k_gru16_bwd_fused, (dof_cdiv(S, 16), 2), (256), st, X, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dX,
+             wg_partial, T, S, Sp);
+  return dof_check_launch("k_gru16_bwd_fused");
+}
+
+// g: gradient buffer base; off[8]: offsets of (wih, whh, bih, bhh) x (fwd, reverse) as in the parameter layout
+int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, hipStream_t st) {
+  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)GRU16_WG_FLOATS, 2), (256), st, wg_partial, (int)dof_cdiv(S, 16),
+             g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6], g + off[7]);
+  return dof_check_launch("k_gru16_wg_finalize");
 }
 
 int64_t dof_ln_bwd_blocks(int T, int64_t S) { return dof_cdiv((int64_t)T * S, 256); }

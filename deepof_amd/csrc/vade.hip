@@ -83,7 +83,7 @@ struct StreamWs {  // float offsets into the workspace
   int64_t xs, c, len, o1, g1, n1, o2, g2, hf, n2;
   int64_t dn2, dhf, dn1x, do1, dc;
   int64_t dots, Y, Z, dZ, dY, dd;
-  int64_t ln1p, ln2p;
+  int64_t ln1p, ln2p, wg1;
   int64_t ln1_blocks, ln2_blocks;
   // device triplet tables (int offsets are in floats too; tables are 4-byte entries)
   int64_t tri_r[5], tri_m[5], tri_o[5];  // ptr, m, o, r, coef for by-r / by-m / by-o orderings
@@ -112,7 +112,7 @@ struct DofVadePlan {
   int64_t mterm, mlse, mdz, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
-  int64_t ln3p, lnd2p, lnd1p, lnd_blocks;
+  int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
   int64_t partials, jobs_tab, fin_tab, gram_jobs_tab, gram_fin_tab, segs_tab;
   int64_t ws_floats = 0;
   // tables built at bind
@@ -275,6 +275,7 @@ void build_workspace_layout(DofVadePlan* p) {
     w.ln2_blocks = dof_ln_bwd_blocks(1, w.S);
     w.ln1p = cv.take(w.ln1_blocks * 8 * L);
     w.ln2p = cv.take(w.ln2_blocks * 4 * L);
+    w.wg1 = cv.take(L == 8 ? dof_gru16_wg_floats(w.S) : 0);
     for (int k = 0; k < 3; ++k) {
       const TripHost& th = p->tri[s][k];
       int64_t* dst = k == 0 ? w.tri_r : k == 1 ? w.tri_m : w.tri_o;
@@ -337,6 +338,7 @@ void build_workspace_layout(DofVadePlan* p) {
   p->ln3p = cv.take(p->tail_blocks * 4 * L);
   p->lnd2p = cv.take(p->lnd_blocks * 8 * L);
   p->lnd1p = cv.take(p->lnd_blocks * 4 * L);
+  p->wgd2 = cv.take(L == 8 ? dof_gru16_wg_floats(p->B) : 0);
   // tables: sized generously (counts are fixed small numbers)
   p->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
   p->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
@@ -426,7 +428,7 @@ void build_jobs(DofVadePlan* p) {
         jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
       }
     }
-    gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1);
+    if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1);  // L == 8: fused in k_gru16_bwd_fused
     gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2);
     // CensNet: kernel (D,L) = sum Y ⊗ dZ ; bias = rowsum dZ ; dot weights (D,1) = sum X ⊗ dd
     const int64_t kern = s == 0 ? p->c_nk : p->c_ek, bias = s == 0 ? p->c_nb : p->c_eb;
@@ -462,7 +464,7 @@ void build_jobs(DofVadePlan* p) {
   }
   // decoder
   gru_jobs(jb, ws + p->g1d, ws + p->z, true, L, ws + p->o1d, L, T, Bp, p->dg1);
-  gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2);
+  if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2);
   {
     const int CI = 4 * L, CO = 2 * L;
     int job = -1;
@@ -751,7 +753,13 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   TRY(dof_check_launch("k_dec_conv_bwd"));
   const int* len_d = reinterpret_cast<const int*>(ws + p->len_d);
   TRY(dof_launch_ln_bwd(L, 4, ws + p->o2d, ws + p->dn2d, nullptr, params + p->dn2w, ws + p->do2d, ws + p->lnd2p, T, B, Bp, st));
-  TRY(dof_launch_gru_bwd(L, 0, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d, nullptr, ws + p->dn1dx, T, B, Bp, st));
+  if (L == 8) {
+    TRY(dof_launch_gru16_bwd_fused(ws + p->n1d, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d,
+                                   ws + p->dn1dx, ws + p->wgd2, T, B, Bp, st));
+    TRY(dof_launch_gru16_wg_finalize(ws + p->wgd2, B, grads, p->dg2.t, st));
+  } else {
+    TRY(dof_launch_gru_bwd(L, 0, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d, nullptr, ws + p->dn1dx, T, B, Bp, st));
+  }
   TRY(dof_launch_ln_bwd(L, 2, ws + p->o1d, ws + p->dn1dx, ws + p->dn1dx + (int64_t)T * 2 * L * Bp, params + p->dn1w,
                         ws + p->do1d, ws + p->lnd1p, T, B, Bp, st));
   TRY(dof_launch_gru_bwd(L, 2, len_d, gru_w(params, p->dg1), ws + p->o1d, ws + p->g1d, ws + p->do1d, nullptr, ws + p->dzdec, T, B, Bp, st));
@@ -836,7 +844,13 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
     TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
     TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
                           ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
-    TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
+    if (L == 8) {
+      TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
+                                     ws + w.wg1, T, w.S, w.Sp, st));
+      TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, st));
+    } else {
+      TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
+    }
     TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
     TRY(dof_launch_sum_partials(ws + w.ln1p, w.ln1_blocks, 8 * L, grads + b.n1w, 0, st));
     TRY(dof_launch_sum_partials(ws + w.ln2p, w.ln2_blocks, 4 * L, grads + b.n2w, 0, st));
