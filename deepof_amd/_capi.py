@@ -8,18 +8,19 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
 H_NONEMPTY_W, H_NONEMPTY_FLOOR, H_NONEMPTY_P, H_L1_ACT, H_DISTILL_T, H_CONF_W = 6, 7, 8, 9, 10, 11
 H_CONF_THR, H_HAS_TEACHER, H_LOGVAR_LO, H_LOGVAR_HI = 12, 13, 14, 15
-H_CLIP, H_WD, H_LR0, H_BC0, H_ACTIVE0, H_COUNT = 16, 17, 18, 22, 30, 34
+H_CLIP, H_WD, H_LR0, H_BC0, H_ACTIVE0, H_VQ_BETA, H_COUNT = 16, 17, 18, 22, 30, 34, 36
 SEG_ENCODER, SEG_DECODER, SEG_GMM, SEG_HEADS, SEG_COUNT = 0, 1, 2, 3, 4
 LOG_KEYS = ("total_loss", "reconstruct_loss", "kl_div", "cat_clust_loss", "kmeans_loss", "activity_l1",
             "prior_loss", "distill_loss", "tf_clust_loss", "nonempty_loss", "temporal_loss", "scatter_loss",
             "repel_loss", "kl_weight")
-LOG_COUNT = 16
+LOG_ENC_REC, LOG_VQ, LOG_POPULATED = 14, 15, 16
+LOG_COUNT = 20
 
 
 class VadeDims(C.Structure):
@@ -47,6 +48,9 @@ SIGNATURES = {
     "dof_vade_bind": (C.c_int, [_P, _P, _P]),
     "dof_vade_forward": (C.c_int, [_P] * 13),
     "dof_vade_loss_grads": (C.c_int, [_P] * 10 + [_I32, _P, _P, _P]),
+    "dof_vqvae_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_vqvae_forward": (C.c_int, [_P] * 11),
+    "dof_vqvae_loss_grads": (C.c_int, [_P] * 8),
     "dof_optimizer_step": (C.c_int, [_P] * 7),
 }
 

@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
 // tiles, then a fixed-shape butterfly adds the 64 lane sums (deterministic).
 __global__ void __launch_bounds__(256) k_outer_finalize(const DofOuterJob* __restrict__ jobs,
                                                         const DofFinJob* __restrict__ fin, int n_fin, int total,
-                                                        const float* __restrict__ partials, float* __restrict__ grads) {
+                                                        const float* __restrict__ partials, float* __restrict__ grads,
+                                                        int accumulate) {
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (e >= total) return;
@@ -155,7 +156,10 @@ __global__ void __launch_bounds__(256) k_outer_finalize(const DofOuterJob* __res
   for (int b = lane; b < J.nblk; b += 64) acc += p[(int64_t)b * DOF_OUTER_PARTIAL_FLOATS];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-  if (lane == 0) grads[F.dst_off + (int64_t)ri * F.row_stride + (int64_t)ci * F.col_stride] = acc;
+  if (lane == 0) {
+    float* dst = grads + F.dst_off + (int64_t)ri * F.row_stride + (int64_t)ci * F.col_stride;
+    *dst = accumulate ? *dst + acc : acc;
+  }
 }
 
 // one workgroup per output value: strided partial sums + fixed-shape LDS tree (deterministic)
@@ -178,9 +182,10 @@ __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ params, c
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ hyper,
                                                    const DofAdamSeg* __restrict__ segs, int nseg, int64_t total,
-                                                   int clip_index) {
+                                                   int clip_index, const float* __restrict__ mask) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
+  if (mask[i] == 0.0f) return;  // parameter never receives a gradient in the reference (grad None): untouched
   int sg = -1;
   for (int k = 0; k < nseg; ++k)
     if (i >= segs[k].lo && i < segs[k].hi) sg = k;
@@ -213,10 +218,10 @@ int dof_launch_outer(const DofOuterJob* jobs_dev, int njobs, int total_blocks, f
 }
 
 int dof_launch_outer_finalize(const DofOuterJob* jobs_dev, const DofFinJob* fin_dev, int n_fin, int total_elems,
-                              const float* partials, float* grads, hipStream_t st) {
+                              const float* partials, float* grads, int accumulate, hipStream_t st) {
   if (total_elems <= 0) return DOF_OK;
   DOF_LAUNCH(k_outer_finalize, (dof_cdiv(total_elems, 4)), (256), st, jobs_dev, fin_dev, n_fin, total_elems,
-             partials, grads);
+             partials, grads, accumulate);
   return dof_check_launch("k_outer_finalize");
 }
 
@@ -226,8 +231,9 @@ int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* o
 }
 
 int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,
-                         const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, hipStream_t st) {
+                         const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, const float* mask,
+                         hipStream_t st) {
   DOF_LAUNCH(k_clip_adam, (dof_cdiv(total, 256)), (256), st, params, grads, m, v, hyper, segs_dev, nseg, total,
-             clip_index);
+             clip_index, mask);
   return dof_check_launch("k_clip_adam");
 }

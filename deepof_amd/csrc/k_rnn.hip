@@ -610,7 +610,8 @@ __global__ void __launch_bounds__(256) k_gru16_wg_finalize(const float* __restri
                                                            float* __restrict__ g_wih0, float* __restrict__ g_whh0,
                                                            float* __restrict__ g_bih0, float* __restrict__ g_bhh0,
                                                            float* __restrict__ g_wih1, float* __restrict__ g_whh1,
-                                                           float* __restrict__ g_bih1, float* __restrict__ g_bhh1) {
+                                                           float* __restrict__ g_bih1, float* __restrict__ g_bhh1,
+                                                           int accumulate) {
   __shared__ float red[256];
   const int v = blockIdx.x, dir = blockIdx.y;
   const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU16_WG_FLOATS + v;
@@ -630,17 +631,15 @@ __global__ void __launch_bounds__(256) k_gru16_wg_finalize(const float* __restri
   float* g_bhh = dir ? g_bhh1 : g_bhh0;
   if (v < 6 * 256) {
     const int tile = v >> 8, row = (v & 255) >> 4, col = v & 15;
-    if (tile < 3) g_wih[(tile * 16 + row) * 16 + col] = val;
-    else g_whh[((tile - 3) * 16 + row) * 16 + col] = val;
+    float* d = tile < 3 ? &g_wih[(tile * 16 + row) * 16 + col] : &g_whh[((tile - 3) * 16 + row) * 16 + col];
+    *d = accumulate ? *d + val : val;
   } else {
     const int gate = (v - 6 * 256) >> 4, unit = v & 15;  // gates: r, z, n(input side), hn(hidden side)
+    float* d0 = gate < 2 ? &g_bih[gate * 16 + unit] : (gate == 2 ? &g_bih[32 + unit] : &g_bhh[32 + unit]);
+    *d0 = accumulate ? *d0 + val : val;
     if (gate < 2) {
-      g_bih[gate * 16 + unit] = val;
-      g_bhh[gate * 16 + unit] = val;
-    } else if (gate == 2) {
-      g_bih[32 + unit] = val;
-    } else {
-      g_bhh[32 + unit] = val;
+      float* d1 = &g_bhh[gate * 16 + unit];
+      *d1 = accumulate ? *d1 + val : val;
     }
   }
 }
@@ -878,9 +877,10 @@ int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const 
 }
 
 // g: gradient buffer base; off[8]: offsets of (wih, whh, bih, bhh) x (fwd, reverse) as in the parameter layout
-int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, hipStream_t st) {
+int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
+                                 hipStream_t st) {
   DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)GRU16_WG_FLOATS, 2), (256), st, wg_partial, (int)dof_cdiv(S, 16),
-             g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6], g + off[7]);
+             g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6], g + off[7], accumulate);
   return dof_check_launch("k_gru16_wg_finalize");
 }
 

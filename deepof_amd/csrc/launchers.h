@@ -22,7 +22,8 @@ int64_t dof_gru16_wg_floats(int64_t S);
 int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
                                const float* dO, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
                                hipStream_t st);
-int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, hipStream_t st);
+int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
+                                 hipStream_t st);
 int64_t dof_ln_bwd_blocks(int T, int64_t S);
 int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const float* dY2, const float* gamma,
                       float* dX, float* partial, int T, int64_t S, int64_t Sp, hipStream_t st);
@@ -64,7 +65,7 @@ struct DofFinJob {  // scatter-add of one reduced (rows x cols) block into a gra
 
 int dof_launch_outer(const DofOuterJob* jobs_dev, int njobs, int total_blocks, float* partials, hipStream_t st);
 int dof_launch_outer_finalize(const DofOuterJob* jobs_dev, const DofFinJob* fin_dev, int n_fin, int total_elems,
-                              const float* partials, float* grads, hipStream_t st);
+                              const float* partials, float* grads, int accumulate, hipStream_t st);
 // out[dst_off + v] (+)= sum_b partial[b][v]   (fixed order)
 int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* out, int accumulate, hipStream_t st);
 
@@ -75,7 +76,8 @@ struct DofAdamSeg {  // one contiguous parameter range with its own lr / step co
   int active_index;  // index into hyper[] of the 0/1 "has gradient" flag
 };
 int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,
-                         const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, hipStream_t st);
+                         const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, const float* mask,
+                         hipStream_t st);
 
 // ---- k_graph_latent.hip ----------------------------------------------------------------------
 struct DofTriplets {  // CSR of (partner row m, other-stream element o, coefficient) grouped by a key row

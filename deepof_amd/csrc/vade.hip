@@ -21,6 +21,7 @@
 
 #include "k_decoder.inc.h"
 #include "k_graph_latent.inc.h"
+#include "k_vq.inc.h"
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -91,8 +92,16 @@ struct StreamWs {  // float offsets into the workspace
 
 }  // namespace
 
+struct JobSet {  // one launch of the MFMA weight-gradient reduction + its finalize
+  std::vector<DofOuterJob> jobs;
+  std::vector<DofFinJob> fins;
+  int total_blocks = 0, fin_elems = 0;
+  int64_t jobs_tab = 0, fin_tab = 0;  // workspace offsets of the uploaded tables
+};
+
 struct DofVadePlan {
   DofVadeDims d;
+  int kind = 0;  // 0 = VaDE (GMM latent), 1 = VQ-VAE (codebook of K codes)
   int L, K, T, N, E, S, J, C3;
   int64_t B, Bp;
   std::vector<ParamEntry> params;
@@ -102,6 +111,7 @@ struct DofVadePlan {
   GruOff dg1, dg2;
   int64_t dn1w, dn1b, dn2w, dn2b, dconv, dn3w, dn3b, dpw, dpb;
   int64_t gmm_m, gmm_lv, mean_w, mean_b, lv_w, lv_b, lens_w, lens_b;
+  int64_t codebook = 0;  // VQ-VAE: vq_layer.codebook (L,K)
   int64_t seg_lo[DOF_SEG_COUNT], seg_hi[DOF_SEG_COUNT];
   // graph
   TripHost tri[2][3];  // [stream][by r, by m, by o(other stream's update keyed by this stream's element)]
@@ -113,12 +123,11 @@ struct DofVadePlan {
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
-  int64_t partials, jobs_tab, fin_tab, gram_jobs_tab, gram_fin_tab, segs_tab;
+  int64_t partials, segs_tab, mask_tab;
+  int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
   int64_t ws_floats = 0;
-  // tables built at bind
-  std::vector<DofOuterJob> jobs, gram_jobs;
-  std::vector<DofFinJob> fins, gram_fins;
-  int total_blocks = 0, fin_elems = 0, gram_blocks = 0, gram_fin_elems = 0;
+  // tables built at bind: encoder side, decoder fed from ws.z (latent / quantised) or ws.enc (raw z_e), Gram
+  JobSet js_enc, js_dec[2], js_gram;
   float* ws = nullptr;
 };
 
@@ -190,6 +199,12 @@ void build_param_layout(DofVadePlan* p) {
   add_param(p, "decoder.prob_decoder.loc_projection.bias", 3 * N, &p->dpb);
   p->seg_hi[DOF_SEG_DECODER] = p->param_total;
   p->seg_lo[DOF_SEG_GMM] = p->param_total;
+  if (p->kind == 1) {  // VQ-VAE: the codebook takes the "GMM" optimiser segment, no latent heads
+    add_param(p, "vq_layer.codebook", (int64_t)L * K, &p->codebook);
+    p->seg_hi[DOF_SEG_GMM] = p->param_total;
+    p->seg_lo[DOF_SEG_HEADS] = p->seg_hi[DOF_SEG_HEADS] = p->param_total;
+    return;
+  }
   add_param(p, "latent_space.gmm_means", (int64_t)K * L, &p->gmm_m);
   add_param(p, "latent_space.gmm_log_vars", (int64_t)K * L, &p->gmm_lv);
   p->seg_hi[DOF_SEG_GMM] = p->param_total;
@@ -317,6 +332,10 @@ void build_workspace_layout(DofVadePlan* p) {
   p->mckl_partial = cv.take(p->mckl_blocks);
   p->distill_partial = cv.take(p->lat_blocks);
   p->recon_partial = cv.take(p->tail_blocks);
+  p->recon_partial2 = cv.take(p->tail_blocks);
+  p->vq_idx = cv.take(Bp);
+  p->vq_partial = cv.take(p->lat_blocks);
+  p->vq_pop = cv.take(K);
   p->valid = cv.take((int64_t)T * Bp);
   p->len_d = cv.take(Bp);
   p->o1d = cv.take((int64_t)T * 2 * L * Bp);
@@ -340,11 +359,12 @@ void build_workspace_layout(DofVadePlan* p) {
   p->lnd1p = cv.take(p->lnd_blocks * 4 * L);
   p->wgd2 = cv.take(L == 8 ? dof_gru16_wg_floats(p->B) : 0);
   // tables: sized generously (counts are fixed small numbers)
-  p->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
-  p->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
-  p->gram_jobs_tab = cv.take((int64_t)(sizeof(DofOuterJob) / 4 + 1));
-  p->gram_fin_tab = cv.take((int64_t)(sizeof(DofFinJob) / 4 + 1));
+  for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+    js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
+    js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
+  }
   p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
+  p->mask_tab = cv.take(p->param_total);
   p->ws_floats = cv.cur;  // the partial-tile region is appended by finish_workspace_layout()
 }
 
@@ -361,6 +381,14 @@ View soa(const float* p, int64_t Sp, int c0 = 0) { return View{p + (int64_t)c0 *
 struct JobBuilder {
   std::vector<DofOuterJob>& jobs;
   std::vector<DofFinJob>& fins;
+  explicit JobBuilder(JobSet& js) : jobs(js.jobs), fins(js.fins) {
+    jobs.clear();
+    fins.clear();
+  }
+  void close(JobSet& js) const {
+    js.total_blocks = blk_cur;
+    js.fin_elems = elem_cur;
+  }
   int64_t partial_cur = 0;
   int blk_cur = 0, elem_cur = 0;
   int add_job(View a, int rows, int T, int64_t Sp) {
@@ -413,64 +441,69 @@ void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int
 void build_jobs(DofVadePlan* p) {
   const int L = p->L, T = p->T;
   float* ws = p->ws;
-  p->jobs.clear(); p->fins.clear(); p->gram_jobs.clear(); p->gram_fins.clear();
-  JobBuilder jb{p->jobs, p->fins};
-  for (int s = 0; s < 2; ++s) {
-    const StreamWs& w = p->sw[s];
-    const BlockOff& b = p->blk[s];
-    const int64_t Sp = w.Sp;
-    const int C1 = 2 * L;
-    // encoder conv: dW[o][f][k] = sum dc[t][o] * xs[t+k-2][f]
-    for (int k0 = 0; k0 < 5; k0 += 4) {
-      const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
-      for (int k = k0; k < 5 && k < k0 + 4; ++k) {
-        const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), w.F, k - 2);
-        jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
-      }
-    }
-    if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1);  // L == 8: fused in k_gru16_bwd_fused
-    gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2);
-    // CensNet: kernel (D,L) = sum Y ⊗ dZ ; bias = rowsum dZ ; dot weights (D,1) = sum X ⊗ dd
-    const int64_t kern = s == 0 ? p->c_nk : p->c_ek, bias = s == 0 ? p->c_nb : p->c_eb;
-    const int64_t dotw = s == 0 ? p->c_nw : p->c_ew;
-    int job = jb.add_job(soa(ws + w.Y, Sp), 2 * L, 1, Sp);
-    jb.add_tile(job, soa(ws + w.dZ, Sp), L, 0);
-    jb.add_fin(job, 0, 2 * L, L, 2 * L, 2 * L, kern, L, 1);
-    job = jb.add_job(soa(ws + w.dZ, Sp), L, 1, Sp);
-    jb.add_tile(job, soa(ws + w.dZ, Sp), 1, 0);
-    jb.add_fin(job, 64, L, 1, L, L, bias, 1, 1);
-    job = jb.add_job(soa(ws + w.n2, Sp), 2 * L, 1, Sp);
-    jb.add_tile(job, soa(ws + w.dd, Sp), 1, 0);
-    jb.add_fin(job, 0, 2 * L, 1, 2 * L, 2 * L, dotw, 1, 1);
-  }
   const int64_t Bp = p->Bp;
-  // final dense (L,J): A = flat rows (<=64 per job), B = denc
-  for (int r0 = 0; r0 < p->J; r0 += 64) {
-    const int rows = p->J - r0 < 64 ? p->J - r0 : 64;
-    const int job = jb.add_job(soa(ws + p->flat, Bp, r0), rows, 1, Bp);
-    jb.add_tile(job, soa(ws + p->denc, Bp), L, 0);
-    jb.add_fin(job, 0, rows, L, rows, rows, p->fd_w + r0, 1, p->J);
-  }
+  // ---- encoder side (both streams, CensNet, final dense, VaDE heads)
   {
+    JobBuilder jb(p->js_enc);
+    for (int s = 0; s < 2; ++s) {
+      const StreamWs& w = p->sw[s];
+      const BlockOff& b = p->blk[s];
+      const int64_t Sp = w.Sp;
+      const int C1 = 2 * L;
+      // encoder conv: dW[o][f][k] = sum dc[t][o] * xs[t+k-2][f]
+      for (int k0 = 0; k0 < 5; k0 += 4) {
+        const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
+        for (int k = k0; k < 5 && k < k0 + 4; ++k) {
+          const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), w.F, k - 2);
+          jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
+        }
+      }
+      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1);  // L == 8: fused in k_gru16_bwd_fused
+      gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2);
+      // CensNet: kernel (D,L) = sum Y (x) dZ ; bias = rowsum dZ ; dot weights (D,1) = sum X (x) dd
+      const int64_t kern = s == 0 ? p->c_nk : p->c_ek, bias = s == 0 ? p->c_nb : p->c_eb;
+      const int64_t dotw = s == 0 ? p->c_nw : p->c_ew;
+      int job = jb.add_job(soa(ws + w.Y, Sp), 2 * L, 1, Sp);
+      jb.add_tile(job, soa(ws + w.dZ, Sp), L, 0);
+      jb.add_fin(job, 0, 2 * L, L, 2 * L, 2 * L, kern, L, 1);
+      job = jb.add_job(soa(ws + w.dZ, Sp), L, 1, Sp);
+      jb.add_tile(job, soa(ws + w.dZ, Sp), 1, 0);
+      jb.add_fin(job, 64, L, 1, L, L, bias, 1, 1);
+      job = jb.add_job(soa(ws + w.n2, Sp), 2 * L, 1, Sp);
+      jb.add_tile(job, soa(ws + w.dd, Sp), 1, 0);
+      jb.add_fin(job, 0, 2 * L, 1, 2 * L, 2 * L, dotw, 1, 1);
+    }
+    // final dense (L,J): A = flat rows (<=64 per job), B = denc
+    for (int r0 = 0; r0 < p->J; r0 += 64) {
+      const int rows = p->J - r0 < 64 ? p->J - r0 : 64;
+      const int job = jb.add_job(soa(ws + p->flat, Bp, r0), rows, 1, Bp);
+      jb.add_tile(job, soa(ws + p->denc, Bp), L, 0);
+      jb.add_fin(job, 0, rows, L, rows, rows, p->fd_w + r0, 1, p->J);
+    }
     int job = jb.add_job(soa(ws + p->denc, Bp), L, 1, Bp);
     jb.add_tile(job, soa(ws + p->denc, Bp), 1, 0);
     jb.add_fin(job, 64, L, 1, L, L, p->fd_b, 1, 1);
-    job = jb.add_job(soa(ws + p->dmu_dpre, Bp), 2 * L, 1, Bp);
-    jb.add_tile(job, soa(ws + p->enc, Bp), L, 0);
-    jb.add_fin(job, 0, L, L, L, L, p->mean_w, L, 1);
-    jb.add_fin(job, 0, L, L, 0, L, p->lv_w, L, 1);
-    jb.add_fin(job, 64, L, 1, L, L, p->mean_b, 1, 1);
-    jb.add_fin(job, 64, L, 1, 0, L, p->lv_b, 1, 1);
+    if (p->kind == 0) {
+      job = jb.add_job(soa(ws + p->dmu_dpre, Bp), 2 * L, 1, Bp);
+      jb.add_tile(job, soa(ws + p->enc, Bp), L, 0);
+      jb.add_fin(job, 0, L, L, L, L, p->mean_w, L, 1);
+      jb.add_fin(job, 0, L, L, 0, L, p->lv_w, L, 1);
+      jb.add_fin(job, 64, L, 1, L, L, p->mean_b, 1, 1);
+      jb.add_fin(job, 64, L, 1, 0, L, p->lv_b, 1, 1);
+    }
+    jb.close(p->js_enc);
   }
-  // decoder
-  gru_jobs(jb, ws + p->g1d, ws + p->z, true, L, ws + p->o1d, L, T, Bp, p->dg1);
-  if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2);
-  {
+  // ---- decoder, once per possible latent input buffer (ws.z: VaDE latent / VQ quantised; ws.enc: VQ raw z_e)
+  for (int v = 0; v < 2; ++v) {
+    JobBuilder jb(p->js_dec[v]);
+    const float* zin = ws + (v == 0 ? p->z : p->enc);
+    gru_jobs(jb, ws + p->g1d, zin, true, L, ws + p->o1d, L, T, Bp, p->dg1);
+    if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2);
     const int CI = 4 * L, CO = 2 * L;
     int job = -1;
     for (int k = 0; k < 5; ++k)
       for (int c0 = 0; c0 < CI; c0 += 16) {
-        if (job < 0 || p->jobs[job].n_tiles == 4) job = jb.add_job(aos(ws + p->dcv, CO, Bp), CO, T, Bp);
+        if (job < 0 || jb.jobs[job].n_tiles == 4) job = jb.add_job(aos(ws + p->dcv, CO, Bp), CO, T, Bp);
         const int nc = CI - c0 < 16 ? CI - c0 : 16;
         const int tl = jb.add_tile(job, aos(ws + p->n2d, CI, Bp, c0), nc, k - 2);
         jb.add_fin(job, tl * 16, CO, nc, CO, CO, p->dconv + (int64_t)c0 * 5 + k, (int64_t)CI * 5, 5);
@@ -482,17 +515,17 @@ void build_jobs(DofVadePlan* p) {
       jb.add_fin(job, 0, rows, CO, rows, rows, p->dpw + (int64_t)r0 * CO, CO, 1);
       jb.add_fin(job, 64, rows, 1, rows, rows, p->dpb + r0, 1, 1);
     }
+    jb.close(p->js_dec[v]);
   }
-  p->total_blocks = jb.blk_cur;
-  p->fin_elems = jb.elem_cur;
-  // Gram of the latent batch (forward-time launch of the same kernel)
-  JobBuilder gb{p->gram_jobs, p->gram_fins};
-  gb.partial_cur = 0;
-  const int gj = gb.add_job(soa(ws + p->z, Bp), L, 1, Bp);
-  gb.add_tile(gj, soa(ws + p->z, Bp), L, 0);
-  gb.add_fin(gj, 0, L, L, L, L, p->gram, L, 1);
-  p->gram_blocks = gb.blk_cur;
-  p->gram_fin_elems = gb.elem_cur;
+  // ---- Gram of the latent batch (forward-time launch of the same kernel)
+  {
+    JobBuilder gb(p->js_gram);
+    const float* zsrc = ws + (p->kind == 0 ? p->z : p->enc);
+    const int gj = gb.add_job(soa(zsrc, Bp), L, 1, Bp);
+    gb.add_tile(gj, soa(zsrc, Bp), L, 0);
+    gb.add_fin(gj, 0, L, L, L, L, p->gram, L, 1);
+    gb.close(p->js_gram);
+  }
 }
 
 // partial tiles of the weight-gradient reduction: sized from a dry enumeration of the jobs
@@ -500,13 +533,20 @@ void finish_workspace_layout(DofVadePlan* p) {
   p->ws = nullptr;
   build_jobs(p);  // pointers are meaningless here; only block counts matter
   int64_t need = 0;
-  for (const DofOuterJob& j : p->jobs) need += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
-  for (const DofOuterJob& j : p->gram_jobs) {
-    const int64_t g = (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
-    if (g > need) need = g;
+  for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+    int64_t g = 0;
+    for (const DofOuterJob& j : js->jobs) g += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
+    if (g > need) need = g;  // the sets run one after another and share the region
   }
   p->partials = p->ws_floats;
   p->ws_floats += (need + 63) / 64 * 64;
+}
+
+int run_jobset(DofVadePlan* p, const JobSet& js, float* dst, int accumulate, hipStream_t st) {
+  const DofOuterJob* jobs = reinterpret_cast<const DofOuterJob*>(p->ws + js.jobs_tab);
+  const DofFinJob* fins = reinterpret_cast<const DofFinJob*>(p->ws + js.fin_tab);
+  TRY(dof_launch_outer(jobs, (int)js.jobs.size(), js.total_blocks, p->ws + p->partials, st));
+  return dof_launch_outer_finalize(jobs, fins, (int)js.fins.size(), js.fin_elems, p->ws + p->partials, dst, accumulate, st);
 }
 
 DofGruW gru_w(const float* params, const GruOff& g) {
@@ -589,8 +629,8 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
   return dof_check_launch("k_latent_fwd");
 }
 
-int decoder_forward(DofVadePlan* p, const float* params, const float* x, bool train, float* loc_out,
-                    hipStream_t st) {
+int decoder_forward(DofVadePlan* p, const float* params, const float* x, const float* zin, float* recon_partial,
+                    bool train, float* loc_out, hipStream_t st) {
   float* ws = p->ws;
   const int L = p->L, T = p->T;
   const int64_t B = p->B, Bp = p->Bp;
@@ -598,18 +638,89 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, bool tr
   DOF_LAUNCH(k_dec_valid, (dof_cdiv(B * T, 256)), (256), st, x, T, p->C3, B, Bp, ws + p->valid);
   DOF_LAUNCH(k_dec_len, (dof_cdiv(B, 256)), (256), st, (const float*)(ws + p->valid), T, B, Bp, len);
   TRY(dof_check_launch("k_dec_valid"));
-  TRY(dof_launch_gru_fwd(L, 2, ws + p->z, len, gru_w(params, p->dg1), ws + p->o1d, train ? ws + p->g1d : nullptr, T, B, Bp, st));
+  TRY(dof_launch_gru_fwd(L, 2, zin, len, gru_w(params, p->dg1), ws + p->o1d, train ? ws + p->g1d : nullptr, T, B, Bp, st));
   TRY(dof_launch_ln_fwd(L, 2, ws + p->o1d, params + p->dn1w, params + p->dn1b, ws + p->n1d, T, B, Bp, st));
   TRY(dof_launch_gru_fwd(L, 0, ws + p->n1d, len, gru_w(params, p->dg2), ws + p->o2d, train ? ws + p->g2d : nullptr, T, B, Bp, st));
   TRY(dof_launch_ln_fwd(L, 4, ws + p->o2d, params + p->dn2w, params + p->dn2b, ws + p->n2d, T, B, Bp, st));
   DecTailArgs A;
   A.n2 = ws + p->n2d; A.wc = params + p->dconv; A.g3 = params + p->dn3w; A.b3 = params + p->dn3b;
   A.wp = params + p->dpw; A.bp = params + p->dpb; A.x = x; A.valid = ws + p->valid;
-  A.cv = ws + p->cv; A.n3 = ws + p->n3; A.loc_out = loc_out; A.recon_partial = ws + p->recon_partial;
+  A.cv = ws + p->cv; A.n3 = ws + p->n3; A.loc_out = loc_out; A.recon_partial = recon_partial;
   A.dloc = ws + p->dloc; A.dcv = ws + p->dcv; A.ln3_partial = ws + p->ln3p;
   A.T = T; A.C3 = p->C3; A.train = train ? 1 : 0; A.B = B; A.Bp = Bp;
   LDISPATCH(L, DOF_LAUNCH((k_dec_tail<LL>), ((unsigned)p->tail_blocks), (256), st, A));
   return dof_check_launch("k_dec_tail");
+}
+
+// Backward of the decoder (after decoder_forward(train)): parameter gradients into `grads` (set or
+// accumulated), gradient wrt the latent input into ws.dzdec ([2][L][Bp], one slab per GRU direction).
+int decoder_backward(DofVadePlan* p, const float* params, int which_input, float* grads, int accumulate,
+                     hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T;
+  const int64_t B = p->B, Bp = p->Bp;
+  LDISPATCH(L, DOF_LAUNCH((k_dec_conv_bwd<LL>), ((unsigned)p->tail_blocks), (256), st, (const float*)(ws + p->dcv),
+                          params + p->dconv, ws + p->dn2d, T, B, Bp));
+  TRY(dof_check_launch("k_dec_conv_bwd"));
+  const int* len_d = reinterpret_cast<const int*>(ws + p->len_d);
+  TRY(dof_launch_ln_bwd(L, 4, ws + p->o2d, ws + p->dn2d, nullptr, params + p->dn2w, ws + p->do2d, ws + p->lnd2p, T, B, Bp, st));
+  if (L == 8) {
+    TRY(dof_launch_gru16_bwd_fused(ws + p->n1d, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d,
+                                   ws + p->dn1dx, ws + p->wgd2, T, B, Bp, st));
+    TRY(dof_launch_gru16_wg_finalize(ws + p->wgd2, B, grads, p->dg2.t, accumulate, st));
+  } else {
+    TRY(dof_launch_gru_bwd(L, 0, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d, nullptr, ws + p->dn1dx, T, B, Bp, st));
+  }
+  TRY(dof_launch_ln_bwd(L, 2, ws + p->o1d, ws + p->dn1dx, ws + p->dn1dx + (int64_t)T * 2 * L * Bp, params + p->dn1w,
+                        ws + p->do1d, ws + p->lnd1p, T, B, Bp, st));
+  TRY(dof_launch_gru_bwd(L, 2, len_d, gru_w(params, p->dg1), ws + p->o1d, ws + p->g1d, ws + p->do1d, nullptr, ws + p->dzdec, T, B, Bp, st));
+  TRY(dof_launch_sum_partials(ws + p->lnd2p, p->lnd_blocks, 8 * L, grads + p->dn2w, accumulate, st));
+  TRY(dof_launch_sum_partials(ws + p->lnd1p, p->lnd_blocks, 4 * L, grads + p->dn1w, accumulate, st));
+  TRY(dof_launch_sum_partials(ws + p->ln3p, p->tail_blocks, 4 * L, grads + p->dn3w, accumulate, st));
+  return run_jobset(p, p->js_dec[which_input], grads, accumulate, st);
+}
+
+// Backward of CensNet + both recurrent encoder streams from ws.dflat; fills the encoder gradients.
+int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T;
+  const int64_t Bp = p->Bp;
+  CensBwdStream cb[2];
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const StreamWs& o = p->sw[1 - s];
+    cb[s].X = ws + w.n2; cb[s].dots = ws + o.dots; cb[s].Z = ws + w.Z;
+    cb[s].kern = params + (s == 0 ? p->c_nk : p->c_ek); cb[s].pw = params + (s == 0 ? p->c_nw : p->c_ew);
+    cb[s].dZ = ws + w.dZ; cb[s].dY = ws + w.dY; cb[s].by_m = trip_dev(ws, w.tri_m); cb[s].oth_by_o = trip_dev(ws, w.tri_o);
+    cb[s].X_oth = ws + o.n2; cb[s].dY_oth = ws + o.dY; cb[s].dX = ws + w.dn2; cb[s].dd = ws + w.dd;
+    cb[s].G = w.G; cb[s].G_other = o.G; cb[s].S = w.S; cb[s].Sp = w.Sp; cb[s].Sp_other = o.Sp;
+    cb[s].flat_row0 = s == 0 ? 0 : p->N * L;
+  }
+  const int64_t smax = p->sw[0].S > p->sw[1].S ? p->sw[0].S : p->sw[1].S;
+  LDISPATCH(L, DOF_LAUNCH((k_cens_bwd1<LL>), (dof_cdiv(smax, 256), 2), (256), st, cb[0], cb[1], (const float*)(ws + p->dflat), Bp));
+  TRY(dof_check_launch("k_cens_bwd1"));
+  LDISPATCH(L, DOF_LAUNCH((k_cens_bwd2<LL>), (dof_cdiv(smax, 256), 2), (256), st, cb[0], cb[1]));
+  TRY(dof_check_launch("k_cens_bwd2"));
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const BlockOff& b = p->blk[s];
+    const int* len = reinterpret_cast<const int*>(ws + w.len);
+    TRY(dof_launch_ln_bwd(L, 2, ws + w.hf, ws + w.dn2, nullptr, params + b.n2w, ws + w.dhf, ws + w.ln2p, 1, w.S, w.Sp, st));
+    TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
+    TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
+                          ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
+    if (L == 8) {
+      TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
+                                     ws + w.wg1, T, w.S, w.Sp, st));
+      TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, 0, st));
+    } else {
+      TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
+    }
+    TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
+    TRY(dof_launch_sum_partials(ws + w.ln1p, w.ln1_blocks, 8 * L, grads + b.n1w, 0, st));
+    TRY(dof_launch_sum_partials(ws + w.ln2p, w.ln2_blocks, 4 * L, grads + b.n2w, 0, st));
+  }
+  return run_jobset(p, p->js_enc, grads, 0, st);
 }
 
 }  // namespace
@@ -617,15 +728,11 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, bool tr
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-extern "C" int dof_vade_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
-                                    const float* incidence, DofVadePlan** out) {
-  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
-    dof_set_error("dof_vade_plan_create: null argument");
-    return DOF_ERR_ARG;
-  }
+static int plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                       const float* incidence, int kind, DofVadePlan** out) {
   if (dims->batch <= 0 || dims->window < 5 || dims->n_nodes <= 0 || dims->n_edges <= 0 || dims->n_clusters <= 0 ||
       dims->mc_samples <= 0) {
-    dof_set_error("dof_vade_plan_create: bad dims (batch %d window %d nodes %d edges %d clusters %d)", dims->batch,
+    dof_set_error("plan_create: bad dims (batch %d window %d nodes %d edges %d clusters %d)", dims->batch,
                   dims->window, dims->n_nodes, dims->n_edges, dims->n_clusters);
     return DOF_ERR_ARG;
   }
@@ -635,6 +742,7 @@ extern "C" int dof_vade_plan_create(const DofVadeDims* dims, const float* laplac
   }
   DofVadePlan* p = new DofVadePlan();
   p->d = *dims;
+  p->kind = kind;
   p->L = dims->latent; p->K = dims->n_clusters; p->T = dims->window; p->N = dims->n_nodes; p->E = dims->n_edges;
   p->S = dims->mc_samples; p->B = dims->batch; p->Bp = dof_pad64(p->B);
   p->J = (p->N + p->E) * p->L;
@@ -645,6 +753,15 @@ extern "C" int dof_vade_plan_create(const DofVadeDims* dims, const float* laplac
   finish_workspace_layout(p);
   *out = p;
   return DOF_OK;
+}
+
+extern "C" int dof_vade_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                    const float* incidence, DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_vade_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  return plan_create(dims, laplacian, edge_laplacian, incidence, 0, out);
 }
 
 extern "C" void dof_vade_plan_destroy(DofVadePlan* plan) { delete plan; }
@@ -667,18 +784,26 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
     return DOF_ERR_LAUNCH;
   }
   build_jobs(p);
-  if (p->jobs.size() > 96 || p->fins.size() > 512) {
-    dof_set_error("dof_vade_bind: job table overflow (%zu jobs, %zu fins)", p->jobs.size(), p->fins.size());
-    return DOF_ERR_STATE;
-  }
   float* ws = p->ws;
   auto up = [&](int64_t off, const void* src, size_t bytes) {
     if (bytes) hipMemcpyAsync(ws + off, src, bytes, hipMemcpyHostToDevice, st);
   };
-  up(p->jobs_tab, p->jobs.data(), p->jobs.size() * sizeof(DofOuterJob));
-  up(p->fin_tab, p->fins.data(), p->fins.size() * sizeof(DofFinJob));
-  up(p->gram_jobs_tab, p->gram_jobs.data(), p->gram_jobs.size() * sizeof(DofOuterJob));
-  up(p->gram_fin_tab, p->gram_fins.data(), p->gram_fins.size() * sizeof(DofFinJob));
+  for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+    if (js->jobs.size() > 96 || js->fins.size() > 512) {
+      dof_set_error("dof_vade_bind: job table overflow (%zu jobs, %zu fins)", js->jobs.size(), js->fins.size());
+      return DOF_ERR_STATE;
+    }
+    up(js->jobs_tab, js->jobs.data(), js->jobs.size() * sizeof(DofOuterJob));
+    up(js->fin_tab, js->fins.data(), js->fins.size() * sizeof(DofFinJob));
+  }
+  {  // parameters that never receive a gradient in the reference (grad None => skipped by Adam, incl. weight decay)
+    static thread_local std::vector<float> mask;
+    mask.assign((size_t)p->param_total, 1.0f);
+    for (const ParamEntry& e : p->params)
+      if (e.name.find(".projection.") != std::string::npos || e.name.find(".lens.") != std::string::npos)
+        for (int64_t i = 0; i < e.numel; ++i) mask[(size_t)(e.off + i)] = 0.0f;
+    up(p->mask_tab, mask.data(), mask.size() * sizeof(float));
+  }
   for (int s = 0; s < 2; ++s)
     for (int k = 0; k < 3; ++k) {
       const TripHost& th = p->tri[s][k];
@@ -700,11 +825,18 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
   return dof_check_launch("dof_vade_bind");
 }
 
+static int gram_spectrum(DofVadePlan* p, const float* hyper, hipStream_t st) {
+  float* ws = p->ws;
+  TRY(run_jobset(p, p->js_gram, ws, 0, st));  // Gram sums land in ws.gram
+  LDISPATCH(p->L, DOF_LAUNCH((k_kmeans_eig<LL>), (1), (64), st, (const float*)(ws + p->gram), hyper, p->B, ws + p->km, ws + p->Pm));
+  return dof_check_launch("k_kmeans_eig");
+}
+
 extern "C" int dof_vade_forward(DofVadePlan* p, const float* params, const float* prior, const float* x,
                                 const float* a, const float* eps, float* z_out, float* q_out, float* zmean_out,
                                 float* zlogvar_out, float* loc_out, float* enc_out, void* stream) {
-  if (!p || !p->ws) {
-    dof_set_error("dof_vade_forward: plan not bound to a workspace");
+  if (!p || !p->ws || p->kind != 0) {
+    dof_set_error("dof_vade_forward: plan not bound to a workspace (or not a VaDE plan)");
     return DOF_ERR_STATE;
   }
   if (!params || !prior || !x || !a) {
@@ -714,7 +846,7 @@ extern "C" int dof_vade_forward(DofVadePlan* p, const float* params, const float
   hipStream_t st = (hipStream_t)stream;
   TRY(encoder_forward(p, params, x, a, false, st));
   TRY(latent_forward(p, params, prior, eps, z_out, q_out, zmean_out, zlogvar_out, enc_out, st));
-  if (loc_out) TRY(decoder_forward(p, params, x, false, loc_out, st));
+  if (loc_out) TRY(decoder_forward(p, params, x, p->ws + p->z, p->ws + p->recon_partial, false, loc_out, st));
   return DOF_OK;
 }
 
@@ -722,8 +854,8 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
                                    const float* a, const float* eps, const float* eps_mc, const float* tau,
                                    const float* teacher, const float* hyper, int32_t pretrain, float* grads,
                                    float* logs, void* stream) {
-  if (!p || !p->ws) {
-    dof_set_error("dof_vade_loss_grads: plan not bound to a workspace");
+  if (!p || !p->ws || p->kind != 0) {
+    dof_set_error("dof_vade_loss_grads: plan not bound to a workspace (or not a VaDE plan)");
     return DOF_ERR_STATE;
   }
   if (!params || !prior || !x || !a || !eps || !hyper || !grads || !logs || (!pretrain && !eps_mc)) {
@@ -739,30 +871,11 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   // ---------------- forward
   TRY(encoder_forward(p, params, x, a, true, st));
   TRY(latent_forward(p, params, prior, eps, nullptr, nullptr, nullptr, nullptr, nullptr, st));
-  const DofOuterJob* gjobs = reinterpret_cast<const DofOuterJob*>(ws + p->gram_jobs_tab);
-  const DofFinJob* gfins = reinterpret_cast<const DofFinJob*>(ws + p->gram_fin_tab);
-  TRY(dof_launch_outer(gjobs, 1, p->gram_blocks, ws + p->partials, st));
-  TRY(dof_launch_outer_finalize(gjobs, gfins, 1, p->gram_fin_elems, ws + p->partials, ws, st));
-  LDISPATCH(L, DOF_LAUNCH((k_kmeans_eig<LL>), (1), (64), st, (const float*)(ws + p->gram), hyper, B, ws + p->km, ws + p->Pm));
-  TRY(dof_check_launch("k_kmeans_eig"));
-  TRY(decoder_forward(p, params, x, true, nullptr, st));
+  TRY(gram_spectrum(p, hyper, st));
+  TRY(decoder_forward(p, params, x, ws + p->z, ws + p->recon_partial, true, nullptr, st));
 
-  // ---------------- decoder backward
-  LDISPATCH(L, DOF_LAUNCH((k_dec_conv_bwd<LL>), ((unsigned)p->tail_blocks), (256), st, (const float*)(ws + p->dcv),
-                          params + p->dconv, ws + p->dn2d, T, B, Bp));
-  TRY(dof_check_launch("k_dec_conv_bwd"));
-  const int* len_d = reinterpret_cast<const int*>(ws + p->len_d);
-  TRY(dof_launch_ln_bwd(L, 4, ws + p->o2d, ws + p->dn2d, nullptr, params + p->dn2w, ws + p->do2d, ws + p->lnd2p, T, B, Bp, st));
-  if (L == 8) {
-    TRY(dof_launch_gru16_bwd_fused(ws + p->n1d, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d,
-                                   ws + p->dn1dx, ws + p->wgd2, T, B, Bp, st));
-    TRY(dof_launch_gru16_wg_finalize(ws + p->wgd2, B, grads, p->dg2.t, st));
-  } else {
-    TRY(dof_launch_gru_bwd(L, 0, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d, nullptr, ws + p->dn1dx, T, B, Bp, st));
-  }
-  TRY(dof_launch_ln_bwd(L, 2, ws + p->o1d, ws + p->dn1dx, ws + p->dn1dx + (int64_t)T * 2 * L * Bp, params + p->dn1w,
-                        ws + p->do1d, ws + p->lnd1p, T, B, Bp, st));
-  TRY(dof_launch_gru_bwd(L, 2, len_d, gru_w(params, p->dg1), ws + p->o1d, ws + p->g1d, ws + p->do1d, nullptr, ws + p->dzdec, T, B, Bp, st));
+  // ---------------- decoder backward (needed first: it yields d loss / d z)
+  TRY(decoder_backward(p, params, 0, grads, 0, st));
 
   // ---------------- batch-level loss terms
   StatsArgs SA;
@@ -817,54 +930,99 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   TRY(dof_check_launch("k_gmm_grads"));
   TRY(dof_launch_sum_partials(ws + p->gmmp, 16, 2 * K * L, grads + p->gmm_m, 0, st));  // gmm_means | gmm_log_vars
 
-  // ---------------- CensNet backward
-  CensBwdStream cb[2];
-  for (int s = 0; s < 2; ++s) {
-    const StreamWs& w = p->sw[s];
-    const StreamWs& o = p->sw[1 - s];
-    cb[s].X = ws + w.n2; cb[s].dots = ws + o.dots; cb[s].Z = ws + w.Z;
-    cb[s].kern = params + (s == 0 ? p->c_nk : p->c_ek); cb[s].pw = params + (s == 0 ? p->c_nw : p->c_ew);
-    cb[s].dZ = ws + w.dZ; cb[s].dY = ws + w.dY; cb[s].by_m = trip_dev(ws, w.tri_m); cb[s].oth_by_o = trip_dev(ws, w.tri_o);
-    cb[s].X_oth = ws + o.n2; cb[s].dY_oth = ws + o.dY; cb[s].dX = ws + w.dn2; cb[s].dd = ws + w.dd;
-    cb[s].G = w.G; cb[s].G_other = o.G; cb[s].S = w.S; cb[s].Sp = w.Sp; cb[s].Sp_other = o.Sp;
-    cb[s].flat_row0 = s == 0 ? 0 : p->N * L;
-  }
-  const int64_t smax = p->sw[0].S > p->sw[1].S ? p->sw[0].S : p->sw[1].S;
-  LDISPATCH(L, DOF_LAUNCH((k_cens_bwd1<LL>), (dof_cdiv(smax, 256), 2), (256), st, cb[0], cb[1], (const float*)(ws + p->dflat), Bp));
-  TRY(dof_check_launch("k_cens_bwd1"));
-  LDISPATCH(L, DOF_LAUNCH((k_cens_bwd2<LL>), (dof_cdiv(smax, 256), 2), (256), st, cb[0], cb[1]));
-  TRY(dof_check_launch("k_cens_bwd2"));
+  // ---------------- CensNet + recurrent encoder backward, encoder-side weight gradients
+  return encoder_backward(p, params, grads, st);
+}
 
-  // ---------------- encoder backward
-  for (int s = 0; s < 2; ++s) {
-    const StreamWs& w = p->sw[s];
-    const BlockOff& b = p->blk[s];
-    const int* len = reinterpret_cast<const int*>(ws + w.len);
-    TRY(dof_launch_ln_bwd(L, 2, ws + w.hf, ws + w.dn2, nullptr, params + b.n2w, ws + w.dhf, ws + w.ln2p, 1, w.S, w.Sp, st));
-    TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
-    TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
-                          ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
-    if (L == 8) {
-      TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
-                                     ws + w.wg1, T, w.S, w.Sp, st));
-      TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, st));
-    } else {
-      TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
-    }
-    TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
-    TRY(dof_launch_sum_partials(ws + w.ln1p, w.ln1_blocks, 8 * L, grads + b.n1w, 0, st));
-    TRY(dof_launch_sum_partials(ws + w.ln2p, w.ln2_blocks, 4 * L, grads + b.n2w, 0, st));
+// ---------------------------------------------------------------------------------------------
+// VQ-VAE
+// ---------------------------------------------------------------------------------------------
+extern "C" int dof_vqvae_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                     const float* incidence, DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_vqvae_plan_create: null argument");
+    return DOF_ERR_ARG;
   }
-  TRY(dof_launch_sum_partials(ws + p->lnd2p, p->lnd_blocks, 8 * L, grads + p->dn2w, 0, st));
-  TRY(dof_launch_sum_partials(ws + p->lnd1p, p->lnd_blocks, 4 * L, grads + p->dn1w, 0, st));
-  TRY(dof_launch_sum_partials(ws + p->ln3p, p->tail_blocks, 4 * L, grads + p->dn3w, 0, st));
+  return plan_create(dims, laplacian, edge_laplacian, incidence, 1, out);
+}
 
-  // ---------------- weight gradients (one MFMA reduction launch + fixed-order finalize)
-  const DofOuterJob* jobs = reinterpret_cast<const DofOuterJob*>(ws + p->jobs_tab);
-  const DofFinJob* fins = reinterpret_cast<const DofFinJob*>(ws + p->fin_tab);
-  TRY(dof_launch_outer(jobs, (int)p->jobs.size(), p->total_blocks, ws + p->partials, st));
-  TRY(dof_launch_outer_finalize(jobs, fins, (int)p->fins.size(), p->fin_elems, ws + p->partials, grads, st));
+static int vq_quantise(DofVadePlan* p, const float* params, const float* hyper, float* soft_out, float* ze_out,
+                       float* quant_out, int32_t* idx_out, hipStream_t st) {
+  float* ws = p->ws;
+  VqFwdArgs A;
+  A.ze = ws + p->enc; A.codebook = params + p->codebook; A.quant = ws + p->z;
+  A.idx = reinterpret_cast<int*>(ws + p->vq_idx); A.sq_partial = ws + p->vq_partial;
+  A.soft_out = soft_out; A.ze_out = ze_out; A.quant_out = quant_out; A.idx_out = idx_out;
+  A.K = p->K; A.B = p->B; A.Bp = p->Bp;
+  LDISPATCH(p->L, DOF_LAUNCH((k_vq_fwd<LL>), ((unsigned)p->lat_blocks), (256), st, A));
+  (void)hyper;
+  return dof_check_launch("k_vq_fwd");
+}
+
+extern "C" int dof_vqvae_forward(DofVadePlan* p, const float* params, const float* x, const float* a,
+                                 float* ze_out, float* quant_out, float* soft_out, int32_t* idx_out,
+                                 float* loc_q_out, float* loc_e_out, void* stream) {
+  if (!p || !p->ws || p->kind != 1) {
+    dof_set_error("dof_vqvae_forward: plan not bound to a workspace (or not a VQ-VAE plan)");
+    return DOF_ERR_STATE;
+  }
+  if (!params || !x || !a) {
+    dof_set_error("dof_vqvae_forward: null argument");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = p->ws;
+  TRY(encoder_forward(p, params, x, a, false, st));
+  DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
+             params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
+  TRY(dof_check_launch("k_final_dense"));
+  TRY(vq_quantise(p, params, nullptr, soft_out, ze_out, quant_out, idx_out, st));
+  if (loc_q_out) TRY(decoder_forward(p, params, x, ws + p->z, ws + p->recon_partial, false, loc_q_out, st));
+  if (loc_e_out) TRY(decoder_forward(p, params, x, ws + p->enc, ws + p->recon_partial2, false, loc_e_out, st));
   return DOF_OK;
+}
+
+extern "C" int dof_vqvae_loss_grads(DofVadePlan* p, const float* params, const float* x, const float* a,
+                                    const float* hyper, float* grads, float* logs, void* stream) {
+  if (!p || !p->ws || p->kind != 1) {
+    dof_set_error("dof_vqvae_loss_grads: plan not bound to a workspace (or not a VQ-VAE plan)");
+    return DOF_ERR_STATE;
+  }
+  if (!params || !x || !a || !hyper || !grads || !logs) {
+    dof_set_error("dof_vqvae_loss_grads: null argument");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = p->ws;
+  const int L = p->L, K = p->K;
+  const int64_t B = p->B, Bp = p->Bp;
+  if (hipMemsetAsync(grads, 0, (size_t)p->param_total * 4, st) != hipSuccess) return DOF_ERR_LAUNCH;
+  TRY(encoder_forward(p, params, x, a, true, st));
+  DOF_LAUNCH(k_final_dense, (dof_cdiv(B, 256), (unsigned)L), (256), st, (const float*)(ws + p->flat), params + p->fd_w,
+             params + p->fd_b, ws + p->enc, p->J, B, Bp);
+  TRY(dof_check_launch("k_final_dense"));
+  TRY(vq_quantise(p, params, hyper, nullptr, nullptr, nullptr, nullptr, st));
+  TRY(gram_spectrum(p, hyper, st));  // value-only k-means term on z_e (detached in the reference's step)
+  // pass 1: decode the QUANTISED latents -> decoder grads (set) + codebook grads
+  TRY(decoder_forward(p, params, x, ws + p->z, ws + p->recon_partial, true, nullptr, st));
+  TRY(decoder_backward(p, params, 0, grads, 0, st));
+  LDISPATCH(L, DOF_LAUNCH((k_vq_codebook_grad<LL>), ((unsigned)K), (256), st, (const float*)(ws + p->dzdec),
+                          (const int*)(ws + p->vq_idx), grads + p->codebook, ws + p->vq_pop, K, B, Bp));
+  TRY(dof_check_launch("k_vq_codebook_grad"));
+  // pass 2: decode the RAW encoder output -> decoder grads (accumulate) + gradient into the encoder
+  TRY(decoder_forward(p, params, x, ws + p->enc, ws + p->recon_partial2, true, nullptr, st));
+  TRY(decoder_backward(p, params, 1, grads, 1, st));
+  LDISPATCH(L, DOF_LAUNCH((k_vq_denc<LL>), (dof_cdiv(B, 256)), (256), st, (const float*)(ws + p->dzdec), ws + p->denc, B, Bp));
+  LDISPATCH(L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(B, 256), (unsigned)p->J), (256), st,
+                          (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, B, Bp));
+  TRY(dof_check_launch("k_final_dense_bwd"));
+  VqLossArgs VL;
+  VL.recon_q = ws + p->recon_partial; VL.recon_e = ws + p->recon_partial2; VL.n_recon = (int)p->tail_blocks;
+  VL.sq_partial = ws + p->vq_partial; VL.n_sq = (int)p->lat_blocks; VL.pop = ws + p->vq_pop; VL.km = ws + p->km;
+  VL.hyper = hyper; VL.logs = logs; VL.K = K; VL.L = L; VL.T = p->T; VL.B = B;
+  DOF_LAUNCH(k_vq_loss, (1), (64), st, VL);
+  TRY(dof_check_launch("k_vq_loss"));
+  return encoder_backward(p, params, grads, st);
 }
 
 extern "C" int dof_optimizer_step(DofVadePlan* p, float* params, const float* grads, float* adam_m, float* adam_v,
@@ -879,5 +1037,5 @@ extern "C" int dof_optimizer_step(DofVadePlan* p, float* params, const float* gr
   }
   const DofAdamSeg* segs = reinterpret_cast<const DofAdamSeg*>(p->ws + p->segs_tab);
   return dof_launch_clip_adam(params, grads, adam_m, adam_v, hyper, segs, DOF_SEG_COUNT, p->param_total, DOF_H_CLIP,
-                              (hipStream_t)stream);
+                              p->ws + p->mask_tab, (hipStream_t)stream);
 }

@@ -47,6 +47,8 @@ def _param_shape(name: str, numel: int, N: int, E: int, L: int, K: int):
         return (3 * N, 2 * L)
     if name in ("latent_space.gmm_means", "latent_space.gmm_log_vars"):
         return (K, L)
+    if name == "vq_layer.codebook":
+        return (L, K)
     if name.startswith("latent_space.") and leaf == "weight":
         return (L, L)
     return (numel,)
@@ -54,7 +56,8 @@ def _param_shape(name: str, numel: int, N: int, E: int, L: int, K: int):
 
 class VadeEngine:
     def __init__(self, lib, device, batch: int, window: int, adjacency: np.ndarray, latent_dim: int,
-                 n_clusters: int, mc_samples: int = 32, graph_ops=None, shared: "VadeEngine" = None):
+                 n_clusters: int, mc_samples: int = 32, graph_ops=None, shared: "VadeEngine" = None,
+                 kind: str = "vade"):
         """``shared``: another engine (different batch size) whose parameter / gradient / Adam / hyper
         buffers this one borrows -- every batch size needs its own plan and workspace, not its own weights."""
         self.lib = lib
@@ -67,8 +70,11 @@ class VadeEngine:
         self.B, self.T, self.L, self.K, self.S = int(batch), int(window), int(latent_dim), int(n_clusters), int(mc_samples)
         dims = _capi.VadeDims(self.B, self.T, self.N, self.E, self.L, self.K, self.S)
         plan = C.c_void_p()
-        _capi.check(lib, lib.dof_vade_plan_create(C.byref(dims), self.lap.ctypes.data, self.elap.ctypes.data,
-                                                  self.inc.ctypes.data, C.byref(plan)), "dof_vade_plan_create")
+        assert kind in ("vade", "vqvae")
+        self.kind = kind
+        create = lib.dof_vade_plan_create if kind == "vade" else lib.dof_vqvae_plan_create
+        _capi.check(lib, create(C.byref(dims), self.lap.ctypes.data, self.elap.ctypes.data, self.inc.ctypes.data,
+                                C.byref(plan)), "dof_*_plan_create")
         self.plan = plan
         self.names = []
         self.layout: Dict[str, tuple] = {}
@@ -155,7 +161,8 @@ class VadeEngine:
                       nonempty_w=_capi.H_NONEMPTY_W, nonempty_floor=_capi.H_NONEMPTY_FLOOR,
                       nonempty_p=_capi.H_NONEMPTY_P, l1_act=_capi.H_L1_ACT, distill_T=_capi.H_DISTILL_T,
                       conf_w=_capi.H_CONF_W, conf_thr=_capi.H_CONF_THR, has_teacher=_capi.H_HAS_TEACHER,
-                      logvar_lo=_capi.H_LOGVAR_LO, logvar_hi=_capi.H_LOGVAR_HI, clip=_capi.H_CLIP, wd=_capi.H_WD)
+                      logvar_lo=_capi.H_LOGVAR_LO, logvar_hi=_capi.H_LOGVAR_HI, clip=_capi.H_CLIP, wd=_capi.H_WD,
+                      vq_beta=_capi.H_VQ_BETA)
 
     def set_hyper(self, **kw):
         for k, v in kw.items():
@@ -224,6 +231,40 @@ class VadeEngine:
             self.hyper.data_ptr(), 1 if pretrain else 0, self.grads.data_ptr(), self.logs.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_vade_loss_grads")
 
+    # ------------------------------------------------------------------ VQ-VAE
+    def vq_forward(self, x, a, want_loc: bool = True, want_soft: bool = True) -> Dict[str, torch.Tensor]:
+        """VQVAEPT.forward(return_all_outputs=True): encoder output, quantised latents, soft counts, code indices and
+        the reconstruction means from the quantised / raw latents."""
+        self._chk_batch(x, a)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        out = {"ze": torch.empty(self.B, self.L, **f32), "quantized": torch.empty(self.B, self.L, **f32),
+               "idx": torch.empty(self.B, dtype=torch.int32, device=self.device)}
+        if want_soft:
+            out["soft_counts"] = torch.empty(self.B, self.K, **f32)
+        if want_loc:
+            out["loc_q"] = torch.empty(self.B, self.T, 3 * self.N, **f32)
+            out["loc_e"] = torch.empty(self.B, self.T, 3 * self.N, **f32)
+        ptr = lambda k: out[k].data_ptr() if k in out else None
+        rc = self.lib.dof_vqvae_forward(self.plan, self.params.data_ptr(), x.data_ptr(), a.data_ptr(), ptr("ze"),
+                                        ptr("quantized"), ptr("soft_counts"), ptr("idx"), ptr("loc_q"), ptr("loc_e"),
+                                        self._stream())
+        _capi.check(self.lib, rc, "dof_vqvae_forward")
+        return out
+
+    def vq_loss_grads(self, x, a):
+        """step_vqvae_distill (without distillation head) + backward; fills self.grads / self.logs."""
+        self._chk_batch(x, a)
+        rc = self.lib.dof_vqvae_loss_grads(self.plan, self.params.data_ptr(), x.data_ptr(), a.data_ptr(),
+                                           self.hyper.data_ptr(), self.grads.data_ptr(), self.logs.data_ptr(),
+                                           self._stream())
+        _capi.check(self.lib, rc, "dof_vqvae_loss_grads")
+
+    def read_vq_logs(self) -> Dict[str, float]:
+        v = self.logs.detach().cpu().tolist()
+        return {"total_loss": v[0], "enc_rec_loss": v[_capi.LOG_ENC_REC], "reconstruct_loss": v[1],
+                "vq_loss": v[_capi.LOG_VQ], "kmeans_loss": v[4], "number_of_populated_clusters": v[_capi.LOG_POPULATED],
+                "distill_loss": v[7]}
+
     def advance_adam(self):
         """Bump the per-segment Adam step counters (bias corrections live in hyper[])."""
         for s in range(_capi.SEG_COUNT):
@@ -245,7 +286,7 @@ class VadeEngine:
 
 
 def create_vade_engine(batch, window, adjacency, latent_dim, n_clusters, mc_samples=32, device=None, graph_ops=None,
-                       shared=None):
+                       shared=None, kind="vade"):
     """Product entry: requires a ROCm GPU and the compiled HIP library (no fallback)."""
     from ._lib import load_hip_library
 
@@ -255,4 +296,4 @@ def create_vade_engine(batch, window, adjacency, latent_dim, n_clusters, mc_samp
     dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
     if dev.type != "cuda":
         raise RuntimeError(f"deepof_amd runs on ROCm devices only, got {dev}")
-    return VadeEngine(lib, dev, batch, window, adjacency, latent_dim, n_clusters, mc_samples, graph_ops, shared)
+    return VadeEngine(lib, dev, batch, window, adjacency, latent_dim, n_clusters, mc_samples, graph_ops, shared, kind)

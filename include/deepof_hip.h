@@ -15,6 +15,7 @@
  *   dof_vade_forward            deepof/clustering/models_new.py:1841-1891 VaDEPT.forward (eval / train mode)
  *   dof_vade_loss_grads         deepof/clustering/training.py:231-309 step_vade + losses.py:567-797
  *                               VadeLoss.forward + loss.backward() (training.py:163)
+ *   dof_vqvae_forward/_loss_grads  models_new.py:1575-1635 VQVAEPT.forward, training.py:312-389 step_vqvae_distill
  *   dof_optimizer_step          training.py:164-166 clip_grad_value_ + optimizer.step(), losses.py:805-833
  */
 #ifndef DEEPOF_HIP_H
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 1
+#define DOF_ABI_VERSION 2
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -84,7 +85,8 @@ enum {
   DOF_H_LR0 = 18,      /* 4 learning rates, one per optimiser segment */
   DOF_H_BC0 = 22,      /* 4 x (1-beta1^t, 1-beta2^t) */
   DOF_H_ACTIVE0 = 30,  /* 4 x "segment has gradients" (0 = frozen / grad None) */
-  DOF_H_COUNT = 34
+  DOF_H_VQ_BETA = 34,  /* VQ-VAE commitment weight beta */
+  DOF_H_COUNT = 36
 };
 /* optimiser segments of the VaDE parameter buffer */
 enum { DOF_SEG_ENCODER = 0, DOF_SEG_DECODER = 1, DOF_SEG_GMM = 2, DOF_SEG_HEADS = 3, DOF_SEG_COUNT = 4 };
@@ -92,7 +94,9 @@ enum { DOF_SEG_ENCODER = 0, DOF_SEG_DECODER = 1, DOF_SEG_GMM = 2, DOF_SEG_HEADS 
 enum {
   DOF_LOG_TOTAL = 0, DOF_LOG_RECON, DOF_LOG_KL, DOF_LOG_CAT, DOF_LOG_KMEANS, DOF_LOG_ACTIVITY, DOF_LOG_PRIOR,
   DOF_LOG_DISTILL, DOF_LOG_TFCLUST, DOF_LOG_NONEMPTY, DOF_LOG_TEMPORAL, DOF_LOG_SCATTER, DOF_LOG_REPEL,
-  DOF_LOG_KLW, DOF_LOG_COUNT = 16
+  DOF_LOG_KLW,
+  DOF_LOG_ENC_REC = 14, DOF_LOG_VQ = 15, DOF_LOG_POPULATED = 16, /* VQ-VAE: enc_rec_loss, vq_loss, populated codes */
+  DOF_LOG_COUNT = 20
 };
 
 /* Forward.  x (B,T,N,3), a (B,T,E,1) device fp32.  prior (K) device.  eps (B,L) device or NULL:
@@ -112,6 +116,22 @@ int dof_vade_loss_grads(DofVadePlan* plan, const float* params, const float* pri
                         const float* a, const float* eps, const float* eps_mc, const float* tau,
                         const float* teacher, const float* hyper, int32_t pretrain, float* grads, float* logs,
                         void* stream);
+
+/* ---- VQ-VAE (recurrent encoder/decoder + codebook of dims.n_clusters codes) ------------------
+ * Same plan type / parameter-table / workspace / bind functions as VaDE (dof_vade_param_*,
+ * dof_vade_workspace_bytes, dof_vade_bind, dof_vade_plan_destroy); parameters = encoder.*,
+ * decoder.*, vq_layer.codebook (L,K) in the reference VQVAEPT state_dict order.
+ * Replaces models_new.py:1575-1635 VQVAEPT.forward, :1330-1423 VectorQuantizerPT and
+ * training.py:312-389 step_vqvae_distill (+ backward).  Outputs of dof_vqvae_forward (any may be
+ * NULL): ze (B,L) encoder output, quant (B,L), soft (B,K) soft counts, idx (B) int32 code indices,
+ * loc_q / loc_e (B,T,3N) reconstruction means from the quantised / raw latents. */
+int dof_vqvae_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                          const float* incidence, DofVadePlan** out);
+int dof_vqvae_forward(DofVadePlan* plan, const float* params, const float* x, const float* a, float* ze_out,
+                      float* quant_out, float* soft_out, int32_t* idx_out, float* loc_q_out, float* loc_e_out,
+                      void* stream);
+int dof_vqvae_loss_grads(DofVadePlan* plan, const float* params, const float* x, const float* a, const float* hyper,
+                         float* grads, float* logs, void* stream);
 
 /* clip_grad_value_(hyper[DOF_H_CLIP]) + Adam(betas 0.9/0.999, eps 1e-8, weight decay hyper[DOF_H_WD]). */
 int dof_optimizer_step(DofVadePlan* plan, float* params, const float* grads, float* adam_m, float* adam_v,

@@ -1,0 +1,76 @@
+"""Oracle (test infrastructure): VQ-VAE restatement, PyTorch-CPU fp32.
+
+* VectorQuantizerPT            /root/reference/deepof/clustering/models_new.py:1330-1423
+* VQVAEPT.forward              models_new.py:1575-1635  (two decoder passes: quantised + raw z_e)
+* step_vqvae_distill           /root/reference/deepof/clustering/training.py:312-389
+  (vq_loss / kmeans_loss enter the total as detached Python floats; no straight-through)
+* build_optimizer_generic      /root/reference/deepof/clustering/losses.py:805-814 (Adam, weight_decay 1e-4)
+
+Shares the recurrent encoder / decoder restatement with oracle/vade.py.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import vade as OV
+
+Params = Dict[str, torch.Tensor]
+
+
+def vq_layer(ze: torch.Tensor, codebook: torch.Tensor, beta: float = 1.0, kmeans_weight: float = 0.0):
+    """ze (B,L), codebook (L,K) -> dict(quantized, idx, soft_counts, vq_loss, kmeans_loss, distances)."""
+    sim = ze @ codebook
+    dist = (ze**2).sum(dim=1, keepdim=True) + (codebook**2).sum(dim=0) - 2 * sim
+    idx = torch.argmin(dist, dim=1)
+    inv = (1.0 / dist) ** 2
+    soft = inv / inv.sum(dim=1, keepdim=True)
+    onehot = torch.nn.functional.one_hot(idx, codebook.shape[1]).float()
+    quantized = onehot @ codebook.T
+    vq_loss = beta * torch.mean((quantized.detach() - ze) ** 2) + torch.mean((quantized - ze.detach()) ** 2)
+    km = torch.zeros(())
+    if kmeans_weight:
+        km = OV.kmeans_gram_loss(ze, kmeans_weight)
+    return dict(quantized=quantized, idx=idx, soft_counts=soft, vq_loss=vq_loss, kmeans_loss=km, distances=dist)
+
+
+def vqvae_forward(P: Params, x: torch.Tensor, a: torch.Tensor, beta: float = 1.0, kmeans_weight: float = 0.0):
+    B, T = x.shape[:2]
+    ze = OV.encoder(x, a, P)
+    vq = vq_layer(ze, P["vq_layer.codebook"], beta, kmeans_weight)
+    x_flat = x.reshape(B, T, -1)
+    loc_q, valid = OV.decoder(vq["quantized"], x_flat, P)
+    loc_e, _ = OV.decoder(ze, x_flat, P)
+    vq.update(ze=ze, loc_q=loc_q, loc_e=loc_e, valid=valid)
+    return vq
+
+
+def vqvae_loss(out: dict, x: torch.Tensor):
+    B, T = x.shape[:2]
+    x_flat = x.reshape(B, T, -1).float()
+    enc_rec = -(OV.recon_log_prob(out["loc_q"], out["valid"], x_flat)).mean()
+    rec = -(OV.recon_log_prob(out["loc_e"], out["valid"], x_flat)).mean()
+    const = float(out["vq_loss"]) + float(out["kmeans_loss"])
+    total = enc_rec + rec + const
+    populated = float(out["soft_counts"].argmax(dim=-1).unique().numel())
+    return dict(total_loss=total, enc_rec_loss=enc_rec, reconstruct_loss=rec, vq_loss=float(out["vq_loss"]),
+                kmeans_loss=float(out["kmeans_loss"]), number_of_populated_clusters=populated,
+                distill_loss=torch.zeros(()))
+
+
+def vqvae_grads(P: Params, x, a, beta: float = 1.0, kmeans_weight: float = 0.0):
+    keys = OV.trainable_keys(P)
+    leaf = {k: (P[k].detach().clone().requires_grad_(True) if k in keys else P[k]) for k in P}
+    out = vqvae_forward(leaf, x, a, beta, kmeans_weight)
+    losses = vqvae_loss(out, x)
+    gl = torch.autograd.grad(losses["total_loss"], [leaf[k] for k in keys], allow_unused=True)
+    return losses, dict(zip(keys, gl)), out
+
+
+def vqvae_train_step(P: Params, opt: OV.AdamState, x, a, lr: float, weight_decay: float = 1e-4, clip: float = 0.75,
+                     beta: float = 1.0, kmeans_weight: float = 0.0):
+    losses, grads, out = vqvae_grads(P, x, a, beta, kmeans_weight)
+    grads = {k: (None if g is None else g.clamp(-clip, clip)) for k, g in grads.items()}
+    opt.step(P, grads, lr, lr, weight_decay=weight_decay)
+    return {k: float(v) for k, v in losses.items()}, grads, out

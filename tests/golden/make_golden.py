@@ -252,6 +252,48 @@ def gen_schedules_kmeans():
     np.savez_compressed(os.path.join(HERE, "schedules_kmeans.npz"), **out)
 
 
+def gen_vqvae(tag, ids, T, L, K, B, seed, kmeans=0.0):
+    nodes, edges = bodypart_graph(ids)
+    adj = adjacency_from_graph(nodes, edges)
+    N, E = len(nodes), len(edges)
+    torch.manual_seed(seed)
+    model = R.M.VQVAEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type="recurrent", kmeans_loss=kmeans)
+    with torch.no_grad():  # spread the codebook so that several codes are populated
+        model.vq_layer.codebook.copy_(torch.randn(L, K) * 0.6)
+    x, a = synth_batch(B, T, N, E, seed + 1)
+    xt, at = torch.from_numpy(x), torch.from_numpy(a)
+    out = dict(sd_np(model))
+    out.update(x=x, a=a, adj=adj, kmeans=np.float64(kmeans))
+    model.train()
+    model.zero_grad(set_to_none=True)
+    res = R.T.step_vqvae_distill(model, (xt, at, torch.arange(B)), SimpleNamespace(apply_distill=False))
+    res.loss.backward()
+    enc_rec, rec, quant, soft, ze, vql = model(xt, at, return_losses=True, return_all_outputs=True)
+    out.update(quantized=quant.detach().numpy(), soft_counts=soft.detach().numpy(), ze=ze.detach().numpy(),
+               loc_q=enc_rec.base_dist.base_dist.loc.detach().numpy(), loc_e=rec.base_dist.base_dist.loc.detach().numpy(),
+               idx=model.vq_layer.get_code_indices(ze.detach()).numpy())
+    for k, v in res.logs.items():
+        out[f"log::{k}"] = np.float64(v)
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            out[f"grad::{n}"] = p.grad.numpy().copy()
+    # 3 optimisation steps with the generic optimiser (Adam + weight decay 1e-4), clip 0.75
+    opt = R.L.build_optimizer_generic(model, None, base_lr=1e-3, weight_decay=1e-4)
+    for i in range(3):
+        xs, as_ = synth_batch(B, T, N, E, seed + 10 + i)
+        r = R.T.step_vqvae_distill(model, (torch.from_numpy(xs), torch.from_numpy(as_), torch.arange(B)),
+                                   SimpleNamespace(apply_distill=False))
+        opt.zero_grad(set_to_none=True)
+        r.loss.backward()
+        torch.nn.utils.clip_grad_value_(model.parameters(), 0.75)
+        opt.step()
+        out[f"step{i}::x"], out[f"step{i}::a"] = xs, as_
+        for k, v in r.logs.items():
+            out[f"step{i}::log::{k}"] = np.float64(v)
+    out.update(sd_np(model, "sd_final::"))
+    np.savez_compressed(os.path.join(HERE, f"vqvae_{tag}.npz"), **out)
+
+
 if __name__ == "__main__":
     gen_scramble()
     gen_graph_ops()
@@ -260,6 +302,8 @@ if __name__ == "__main__":
     gen_vade("rec28", ["B", "W"], 12, 6, 5, 6, 31)
     gen_train_trace()
     gen_schedules_kmeans()
+    gen_vqvae("rec14", [""], 25, 8, 64, 16, 41)
+    gen_vqvae("rec28", ["B", "W"], 12, 6, 20, 6, 51, kmeans=0.5)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

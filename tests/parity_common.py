@@ -137,3 +137,53 @@ def run_trace_check(lib, device, golden_dir):
         if k in eng.layout:
             np.testing.assert_allclose(eng.view(k).cpu().numpy(), v.numpy().reshape(eng.layout[k][2]), atol=5e-4,
                                        rtol=2e-3, err_msg=k)
+
+
+def run_vqvae_check(lib, device, golden_dir, tag):
+    """VQ-VAE forward outputs, step losses, all gradients and a 3-step Adam(+weight decay) trace vs the reference."""
+    d = load_golden(golden_dir, f"vqvae_{tag}.npz")
+    x, a = torch.from_numpy(d["x"]).to(device), torch.from_numpy(d["a"]).to(device)
+    B, T, N, _ = x.shape
+    L, K = d["sd::vq_layer.codebook"].shape
+    km = float(d["kmeans"])
+    eng = VadeEngine(lib, device, B, T, d["adj"], L, K, kind="vqvae")
+    eng.load_state_dict(params_from(d))
+    out = eng.vq_forward(x, a)
+    np.testing.assert_array_equal(out["idx"].cpu().numpy(), d["idx"])
+    np.testing.assert_allclose(out["ze"].cpu().numpy(), d["ze"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["quantized"].cpu().numpy(), d["quantized"], atol=1e-6)
+    np.testing.assert_allclose(out["soft_counts"].cpu().numpy(), d["soft_counts"], atol=2e-6, rtol=2e-3)
+    np.testing.assert_allclose(out["loc_q"].cpu().numpy(), d["loc_q"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["loc_e"].cpu().numpy(), d["loc_e"], atol=2e-5, rtol=1e-4)
+    eng.set_hyper(vq_beta=1.0, km_latent=km, km_loss=1.0 if km else 0.0, clip=0.75, wd=1e-4)
+    for seg in range(_capi.SEG_COUNT):
+        eng.set_lr(seg, 1e-3)
+    eng.push_hyper()
+    eng.vq_loss_grads(x, a)
+    logs = eng.read_vq_logs()
+    for k, v in logs.items():
+        np.testing.assert_allclose(v, float(d[f"log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=f"{tag}: {k}")
+    n = 0
+    for k in d:
+        if k.startswith("grad::"):
+            name = k[6:]
+            g = eng.view(name, eng.grads).cpu().numpy()
+            np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=5e-5, rtol=5e-4, err_msg=f"{tag}: grad {name}")
+            n += 1
+    assert n >= 70
+    for name in eng.names:
+        if f"grad::{name}" not in d:
+            assert float(eng.view(name, eng.grads).abs().max()) == 0.0, name
+    eng.reset_optimizer()
+    for i in range(3):
+        eng.advance_adam()
+        eng.push_hyper()
+        xs, as_ = torch.from_numpy(d[f"step{i}::x"]).to(device), torch.from_numpy(d[f"step{i}::a"]).to(device)
+        eng.vq_loss_grads(xs, as_)
+        eng.optimizer_step()
+        for k, v in eng.read_vq_logs().items():
+            np.testing.assert_allclose(v, float(d[f"step{i}::log::{k}"]), rtol=2e-3, atol=2e-4, err_msg=f"step {i}: {k}")
+    for k, v in params_from(d, "sd_final::").items():
+        if k in eng.layout:
+            np.testing.assert_allclose(eng.view(k).cpu().numpy(), v.numpy().reshape(eng.layout[k][2]), atol=5e-4,
+                                       rtol=2e-3, err_msg=k)

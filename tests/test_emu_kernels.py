@@ -6,7 +6,7 @@ import torch
 
 from deepof_amd.engine import VadeEngine
 from emu_util import emu_lib
-from parity_common import gather_check, load_golden, params_from, run_phase_check, run_trace_check
+from parity_common import gather_check, load_golden, params_from, run_phase_check, run_trace_check, run_vqvae_check
 
 
 def test_gather_emu():
@@ -36,3 +36,8 @@ def test_vade_loss_grads_emu(golden_dir, tag, phase):
 
 def test_vade_train_trace_emu(golden_dir):
     run_trace_check(emu_lib(), "cpu", golden_dir)
+
+
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+def test_vqvae_emu(golden_dir, tag):
+    run_vqvae_check(emu_lib(), "cpu", golden_dir, tag)

@@ -172,3 +172,39 @@ def test_kmeans_value_and_grad(golden_dir):
     km.backward()
     np.testing.assert_allclose(float(km), float(d["km_val"]), rtol=1e-9)
     np.testing.assert_allclose(z.grad.numpy(), d["km_grad"], atol=1e-7, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+def test_vqvae_forward_loss_grads_trace(golden_dir, tag):
+    from oracle import vqvae as OQ
+    d = _load(golden_dir, f"vqvae_{tag}.npz")
+    P = _params(d)
+    km = float(d["kmeans"])
+    x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
+    losses, grads, out = OQ.vqvae_grads(P, x, a, 1.0, km)
+    np.testing.assert_array_equal(out["idx"].numpy(), d["idx"])
+    np.testing.assert_allclose(out["ze"].detach().numpy(), d["ze"], atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(out["quantized"].detach().numpy(), d["quantized"], atol=1e-6)
+    np.testing.assert_allclose(out["soft_counts"].detach().numpy(), d["soft_counts"], atol=1e-6, rtol=2e-4)
+    np.testing.assert_allclose(out["loc_q"].detach().numpy(), d["loc_q"], atol=5e-6, rtol=1e-5)
+    np.testing.assert_allclose(out["loc_e"].detach().numpy(), d["loc_e"], atol=5e-6, rtol=1e-5)
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), float(d[f"log::{k}"]), rtol=2e-5, atol=2e-6, err_msg=k)
+    n = 0
+    for k in d:
+        if k.startswith("grad::"):
+            name = k[6:]
+            np.testing.assert_allclose(grads[name].numpy(), d[k], atol=2e-5, rtol=2e-4, err_msg=name)
+            n += 1
+    assert n >= 70
+    for name, g in grads.items():
+        if f"grad::{name}" not in d:
+            assert g is None, name
+    opt = OV.AdamState()
+    for i in range(3):
+        logs, _, _ = OQ.vqvae_train_step(P, opt, torch.from_numpy(d[f"step{i}::x"]), torch.from_numpy(d[f"step{i}::a"]),
+                                         1e-3, 1e-4, 0.75, 1.0, km)
+        for k, v in logs.items():
+            np.testing.assert_allclose(v, float(d[f"step{i}::log::{k}"]), rtol=5e-4, atol=5e-5, err_msg=f"{i}:{k}")
+    for k, v in _params(d, "sd_final::").items():
+        np.testing.assert_allclose(P[k].numpy(), v.numpy(), atol=2e-4, rtol=1e-3, err_msg=k)
