@@ -102,9 +102,11 @@ class VaDE(nn.Module):
         self.reset_parameters()
 
     # ------------------------------------------------------------------ engines
+    _KIND = "vade"
+
     def _make_engine(self, batch: int, shared):
         return self._factory(batch=batch, window=self.window_size, adjacency=self._adjacency,
-                             latent_dim=self.latent_dim, n_clusters=self.n_components, shared=shared)
+                             latent_dim=self.latent_dim, n_clusters=self.n_components, shared=shared, kind=self._KIND)
 
     def engine(self, batch: int) -> VadeEngine:
         """Plan + workspace for this batch size (parameters are shared across batch sizes)."""
@@ -217,4 +219,82 @@ class VaDE(nn.Module):
             _, out = self._run(xb, ab, None, want_loc=False)
             zs.append(out["z"])
             qs.append(out["q"])
+        return torch.cat(zs), torch.cat(qs)
+
+
+class VQVAE(VaDE):
+    """VQ-VAE with the reference's interface (models_new.py:1507-1640, VQVAEPT): ``state_dict`` = encoder.*,
+    decoder.*, vq_layer.codebook (L,K); ``model(x, a, return_losses=True, return_all_outputs=False)``."""
+
+    _KIND = "vqvae"
+
+    def __init__(self, input_shape, edge_feature_shape, adjacency_matrix, latent_dim: int, n_components: int,
+                 encoder_type: str = "recurrent", use_gnn: bool = True, kmeans_loss: float = 0.0,
+                 interaction_regularization: float = 0.0, beta: float = 1.0, batch_size: int = 256, device=None,
+                 _engine_factory=None):
+        nn.Module.__init__(self)
+        if str(encoder_type).lower() != "recurrent":
+            raise NotImplementedError(f"encoder_type={encoder_type!r}: this build implements the recurrent encoder/decoder")
+        if not use_gnn:
+            raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
+        time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
+        self.window_size, self.input_n_nodes, self.input_n_features_per_node = time_steps, n_nodes, n_feat
+        self.latent_dim, self.n_components = int(latent_dim), int(n_components)
+        self.encoder_type, self.beta, self.kmeans_weight = "recurrent", float(beta), float(kmeans_loss)
+        self._adjacency = np.asarray(adjacency_matrix, dtype=np.float32)
+        self._factory = _engine_factory or (lambda **kw: create_vade_engine(device=device, **kw))
+        self._engines = {}
+        self._base = self._make_engine(int(batch_size), None)
+        eng = self._base
+        self.encoder = _Box()
+        self.encoder.register_buffer("laplacian", torch.from_numpy(eng.lap.copy()))
+        self.encoder.register_buffer("edge_laplacian", torch.from_numpy(eng.elap.copy()))
+        self.encoder.register_buffer("incidence", torch.from_numpy(eng.inc.copy()))
+        self.decoder = _Box()
+        self.vq_layer = _Box()
+        for name in eng.names:
+            _attach(self, name, eng.view(name))
+        self.reset_parameters()
+        with torch.no_grad():
+            self.vq_layer.codebook.uniform_(0.0, 1.0)  # models_new.py:1348-1350
+
+    def _quantise(self, x, a, want_loc=True):
+        x = x.to(self.device, torch.float32).contiguous()
+        a = a.to(self.device, torch.float32).contiguous()
+        return x, self.engine(x.shape[0]).vq_forward(x, a, want_loc=want_loc)
+
+    def forward(self, x, a, return_losses: bool = True, return_all_outputs: bool = False):
+        x, out = self._quantise(x, a)
+        B, T = x.shape[:2]
+        valid = ~torch.all(x.reshape(B, T, -1) == 0.0, dim=2)
+        enc_dist, rec_dist = ReconDistribution(out["loc_q"], valid), ReconDistribution(out["loc_e"], valid)
+        losses = None
+        if return_losses:
+            sq = torch.mean((out["quantized"] - out["ze"]) ** 2)
+            losses = {"vq_loss": (self.beta + 1.0) * sq}
+            if self.kmeans_weight:
+                losses["kmeans_loss"] = self._kmeans_value(out["ze"])
+        if return_all_outputs:
+            return enc_dist, rec_dist, out["quantized"], out["soft_counts"], out["ze"], losses
+        return (enc_dist, rec_dist, losses) if return_losses else (enc_dist, rec_dist)
+
+    @torch.no_grad()
+    def encode(self, x, a):
+        return self._quantise(x, a, want_loc=False)[1]["ze"]
+
+    embed = encode
+
+    @torch.no_grad()
+    def group(self, x, a):
+        return self._quantise(x, a, want_loc=False)[1]["soft_counts"]
+
+    @torch.no_grad()
+    def encode_windows(self, x, a, batch: int = 256):
+        """(embeddings = encoder outputs (n,L), soft_counts (n,K)) -- outputs [4] and [3] of the 6-tuple that
+        embedding_per_video reads for VQ-VAE (model_utils_new.py:614)."""
+        zs, qs = [], []
+        for s in range(0, x.shape[0], batch):
+            _, out = self._quantise(x[s:s + batch], a[s:s + batch], want_loc=False)
+            zs.append(out["ze"])
+            qs.append(out["soft_counts"])
         return torch.cat(zs), torch.cat(qs)

@@ -23,7 +23,7 @@ import torch
 from . import _capi
 from .config import (CommonFitCfg, ContrastiveCfg, TurtleTeacherCfg, VaDECfg, cfg_lines, check_model_inputs)
 from .dataset import WindowDataset, n_batches
-from .models import VaDE
+from .models import VaDE, VQVAE
 from .schedules import WeightSchedule
 
 LOG_SUMMARY_KEYS = ("total_loss", "reconstruction_loss", "kl_divergence", "cat_cluster_loss", "kmeans_loss",
@@ -107,8 +107,13 @@ def save_model_info(ckpt_path: str, *, stage: str, epoch=None, train_steps=None,
 
 def build_model_from_spec(spec: dict, device=None, batch_size: int = 256, _engine_factory=None) -> VaDE:
     name = str(spec.get("model_name", "vade")).lower()
+    if name == "vqvae":
+        return VQVAE(tuple(spec["x_shape"]), tuple(spec["a_shape"]), np.asarray(spec["adjacency_matrix"]),
+                     int(spec["latent_dim"]), int(spec["n_components"]),
+                     encoder_type=spec.get("encoder_type", "recurrent"), use_gnn=bool(spec.get("use_gnn", True)),
+                     batch_size=batch_size, device=device, _engine_factory=_engine_factory)
     if name != "vade":
-        raise NotImplementedError(f"checkpoint of model {name!r}: only VaDE bundles are supported in this build")
+        raise NotImplementedError(f"checkpoint of model {name!r}: VaDE and VQ-VAE bundles are supported in this build")
     return VaDE(tuple(spec["x_shape"]), tuple(spec["a_shape"]), np.asarray(spec["adjacency_matrix"]),
                 int(spec["latent_dim"]), int(spec["n_components"]), encoder_type=spec.get("encoder_type", "recurrent"),
                 use_gnn=bool(spec.get("use_gnn", True)), kmeans_loss=float(spec.get("kmeans_loss", 0.0)),
@@ -128,9 +133,9 @@ def load_model_from_ckpt(path: str, device=None, _engine_factory=None):
 
 def _clone_model(model: VaDE) -> VaDE:
     """Independent copy (own parameter buffer) -- deepcopy() of the reference."""
-    twin = VaDE((model.window_size, model.input_n_nodes, 3), (model.window_size, model._base.E, 1), model._adjacency,
-                model.latent_dim, model.n_components, kmeans_loss=model.kmeans_weight, batch_size=model._base.B,
-                _engine_factory=model._factory)
+    twin = type(model)((model.window_size, model.input_n_nodes, 3), (model.window_size, model._base.E, 1),
+                       model._adjacency, model.latent_dim, model.n_components, kmeans_loss=model.kmeans_weight,
+                       batch_size=model._base.B, _engine_factory=model._factory)
     twin._base.params.copy_(model._base.params)
     twin._base.prior.copy_(model._base.prior)
     twin.train(model.training)
@@ -470,6 +475,83 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
     return model_val, model_score, teacher_init_model, log_summary
 
 
+def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
+              teacher_cfg: TurtleTeacherCfg, device=None, _engine_factory=None):
+    """training.py:1036-1263: Adam(lr, weight_decay 1e-4) on encoder + decoder + codebook, clip 0.75; best-val
+    checkpointing; the distillation head / alignment score need the TURTLE teacher (not built yet)."""
+    dist, rank, world = _dist_state()
+    is_main = rank == 0
+    model = VQVAE(train_ds.x_shape, train_ds.a_shape, adjacency_matrix, common_cfg.latent_dim, common_cfg.n_components,
+                  encoder_type=common_cfg.encoder_type, use_gnn=True, kmeans_loss=common_cfg.kmeans_loss,
+                  interaction_regularization=common_cfg.interaction_regularization, batch_size=common_cfg.batch_size,
+                  device=device, _engine_factory=_engine_factory)
+    eng = model._base
+    if world > 1:
+        dist.broadcast(eng.params, src=0)
+    rebuild_spec = {"model_name": "vqvae", "x_shape": train_ds.x_shape, "a_shape": train_ds.a_shape,
+                    "adjacency_matrix": np.asarray(adjacency_matrix).astype("float32"),
+                    "latent_dim": common_cfg.latent_dim, "n_components": common_cfg.n_components,
+                    "encoder_type": common_cfg.encoder_type, "use_gnn": True,
+                    "interaction_regularization": common_cfg.interaction_regularization}
+    if teacher_cfg.use_turtle_teacher:
+        warnings.warn("TURTLE teacher distillation is not implemented in this build; training the VQ-VAE without the "
+                      "distillation head (the reference's behaviour when no teacher is available).", RuntimeWarning)
+    eng.reset_optimizer()
+    for seg in range(_capi.SEG_COUNT):
+        eng.set_lr(seg, common_cfg.learning_rate)
+    eng.set_hyper(vq_beta=model.beta, km_latent=common_cfg.kmeans_loss, km_loss=1.0 if common_cfg.kmeans_loss else 0.0,
+                  clip=0.75, wd=1e-4)
+    _, best_path_val, best_path_score, _ = ckpt_paths("vqvae", common_cfg)
+    best_val = float("inf")
+    log_summary = init_log_summary("vqvae")
+    nb = n_batches(len(train_ds), common_cfg.batch_size, world)
+    keys = ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss", "kmeans_loss",
+            "number_of_populated_clusters", "distill_loss")
+
+    def run_epoch(ds, train):
+        model.train(train)
+        acc = []
+        it = ds.iter_batches(common_cfg.batch_size, train, common_cfg.seed if train else None,
+                             world if train else 1, rank if train else 0)
+        for x, a, _idx, _vid in it:
+            e = model.engine(x.shape[0])
+            if train:
+                e.advance_adam()
+            e.push_hyper()
+            e.vq_loss_grads(x.contiguous(), a.contiguous())
+            if train:
+                if world > 1:
+                    dist.all_reduce(e.grads, op=dist.ReduceOp.SUM)
+                    e.grads.mul_(1.0 / world)
+                e.optimizer_step()
+            acc.append(e.logs.clone())
+        if not acc:
+            return {k: float("nan") for k in keys}
+        m = torch.stack(acc).mean(dim=0).cpu().tolist()
+        return {"total_loss": m[0], "enc_rec_loss": m[_capi.LOG_ENC_REC], "reconstruct_loss": m[1],
+                "vq_loss": m[_capi.LOG_VQ], "kmeans_loss": m[4], "number_of_populated_clusters": m[_capi.LOG_POPULATED],
+                "distill_loss": m[7]}
+
+    for epoch in range(common_cfg.epochs):
+        train_logs = run_epoch(train_ds, True)
+        val_logs = run_epoch(val_ds, False)
+        val_logs.update(alignment_score=float("nan"), conf_norm=float("nan"), bal_norm=float("nan"))
+        v_total = float(val_logs["total_loss"])
+        log_summary = _update_log_summary(log_summary, train_logs, val_logs)
+        if is_main:
+            print(f"Epoch {epoch + 1}/{common_cfg.epochs} | train total={train_logs['total_loss']:.4f} "
+                  f"recon={train_logs['reconstruct_loss']:.4f} codes={train_logs['number_of_populated_clusters']:.1f} | "
+                  f"val total={v_total:.4f}")
+        if v_total < best_val:
+            best_val = v_total
+            if common_cfg.save_weights and is_main:
+                save_model_info(best_path_val, stage="best_val", epoch=epoch, train_steps=(epoch + 1) * nb,
+                                val_total=v_total, common_cfg=common_cfg, teacher_cfg=teacher_cfg, model=model,
+                                log_summary=log_summary, rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
+    model_val, model_score = load_best_checkpoints(model, best_path_val, best_path_score, common_cfg.save_weights)
+    return model_val, model_score, None, log_summary
+
+
 # ------------------------------------------------------------------------------------------------
 # public API
 # ------------------------------------------------------------------------------------------------
@@ -490,10 +572,10 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
     torch.manual_seed(common_cfg.seed if common_cfg.seed is not None else 0)
     np.random.seed(common_cfg.seed if common_cfg.seed is not None else 0)
     model_name = common_cfg.model_name
-    if model_name != "vade":
-        if model_name in ("vqvae", "contrastive"):
-            raise NotImplementedError(f"model_name={model_name!r}: not built yet (SURVEY section 8a rows R10-R14); "
-                                      "this build implements VaDE")
+    if model_name == "contrastive":
+        raise NotImplementedError("model_name='contrastive': not built yet (SURVEY section 8a rows R12-R14); "
+                                  "this build implements VaDE and VQ-VAE with the recurrent encoder")
+    if model_name not in ("vade", "vqvae"):
         raise ValueError(f"Unsupported model: {model_name}")
     dev = None
     if _engine_factory is None:
@@ -502,6 +584,9 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
     preprocessed_train, preprocessed_val = preprocessed_object
     train_ds = WindowDataset.from_preprocessed(preprocessed_train, data_dev)
     val_ds = WindowDataset.from_preprocessed(preprocessed_val, data_dev)
+    if model_name == "vqvae":
+        return fit_VQVAE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
+                         _engine_factory=_engine_factory)
     return fit_VADE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
                     _engine_factory=_engine_factory)
 

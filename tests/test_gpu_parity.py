@@ -195,3 +195,52 @@ def test_training_api_on_gpu(hip, tmp_path):
     emb, soft = mv.encode_windows(x, a, batch=256)
     assert tuple(emb.shape) == (76, 8) and tuple(soft.shape) == (76, 10)      # reference shape pin
     np.testing.assert_allclose(soft.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+def test_vqvae_parity_gpu(hip, golden_dir, tag):
+    from parity_common import run_vqvae_check
+    run_vqvae_check(hip, "cuda", golden_dir, tag)
+
+
+def test_vqvae_full_size_c3(hip):
+    """BASELINE config C3 (VQ-VAE, 14 body parts, window 25, codebook 512, batch 4096): step properties at full
+    size + forward parity of code indices / embeddings against the CPU oracle on a slice."""
+    from deepof_amd.engine import create_vade_engine
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    from deepof_amd import _capi
+    from oracle import vqvae as OQ
+    nodes, edges = bodypart_graph([""])
+    B, T, L, K = 4096, 25, 8, 512
+    eng = create_vade_engine(B, T, adjacency_from_graph(nodes, edges), L, K, kind="vqvae")
+    g = torch.Generator().manual_seed(0)
+    for n in eng.names:
+        shape = eng.layout[n][2]
+        v = torch.randn(shape, generator=g) * (0.3 if len(shape) > 1 else 0.1)
+        if "norm" in n and n.endswith("weight"):
+            v = 1.0 + v
+        if n == "vq_layer.codebook":
+            v = torch.randn(shape, generator=g) * 0.7
+        eng.view(n).copy_(v)
+    x = torch.randn(B, T, len(nodes), 3, generator=g)
+    a = torch.randn(B, T, len(edges), 1, generator=g)
+    eng.set_hyper(vq_beta=1.0, km_latent=0.0, km_loss=0.0, clip=0.75, wd=1e-4)
+    for seg in range(_capi.SEG_COUNT):
+        eng.set_lr(seg, 1e-3)
+    eng.advance_adam()
+    eng.push_hyper()
+    eng.vq_loss_grads(x.cuda(), a.cuda())
+    g1, logs = eng.grads.clone(), eng.read_vq_logs()
+    eng.vq_loss_grads(x.cuda(), a.cuda())
+    assert torch.equal(g1, eng.grads) and bool(torch.isfinite(g1).all())
+    np.testing.assert_allclose(logs["total_loss"], logs["enc_rec_loss"] + logs["reconstruct_loss"] + logs["vq_loss"]
+                               + logs["kmeans_loss"], rtol=1e-6)
+    assert 1 <= logs["number_of_populated_clusters"] <= K
+    out = eng.vq_forward(x.cuda(), a.cuda(), want_loc=False)
+    P = eng.state_dict()
+    with torch.no_grad():
+        ref = OQ.vqvae_forward(P, x[:128], a[:128])
+    np.testing.assert_allclose(out["ze"][:128].cpu().numpy(), ref["ze"].numpy(), atol=3e-5, rtol=1e-3)
+    agree = (out["idx"][:128].cpu().long() == ref["idx"]).float().mean()
+    assert float(agree) >= 0.98          # argmin ties / near-ties may flip under fp32 reordering
+    np.testing.assert_allclose(out["soft_counts"][:128].sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)

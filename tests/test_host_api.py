@@ -18,7 +18,7 @@ from parity_common import load_golden
 
 def emu_factory(**kw):
     return VadeEngine(emu_lib(), "cpu", kw["batch"], kw["window"], kw["adjacency"], kw["latent_dim"],
-                      kw["n_clusters"], shared=kw.get("shared"))
+                      kw["n_clusters"], shared=kw.get("shared"), kind=kw.get("kind", "vade"))
 
 
 def chain_adj(n):
@@ -125,7 +125,7 @@ def test_input_validation_errors():
     with pytest.raises(ValueError):
         TR.train_deepof_model(**{**kw, "device": "tpu"})
     with pytest.raises(NotImplementedError):
-        TR.train_deepof_model(**{**kw, "model_name": "VQVAE"})
+        TR.train_deepof_model(**{**kw, "model_name": "Contrastive"})
     with pytest.raises(RuntimeError):   # product path: no CPU fallback
         TR.train_deepof_model(**{**kw, "device": "cpu", "_engine_factory": None})
 
@@ -221,3 +221,35 @@ def test_data_parallel_gradient_allreduce_gloo(tmp_path):
     torch.testing.assert_close(r0["reduced"], r1["reduced"], rtol=0, atol=0)
     torch.testing.assert_close(r0["reduced"], 0.5 * (r0["local"] + r1["local"]), rtol=1e-6, atol=1e-8)
     assert float((r0["local"] - r1["local"]).abs().max()) > 0
+
+
+def test_vqvae_model_and_fit(golden_dir, tmp_path):
+    from deepof_amd.models import VQVAE
+    d = load_golden(golden_dir, "vqvae_rec14.npz")
+    ref_keys = [k[4:] for k in d if k.startswith("sd::")]
+    model = VQVAE((25, 14, 3), (25, 14, 1), d["adj"], 8, 64, batch_size=16, _engine_factory=emu_factory)
+    assert list(model.state_dict().keys()) == ref_keys
+    model.load_state_dict({k: torch.from_numpy(d["sd::" + k]) for k in ref_keys})
+    six = model(torch.from_numpy(d["x"]), torch.from_numpy(d["a"]), return_losses=True, return_all_outputs=True)
+    assert len(six) == 6
+    np.testing.assert_allclose(six[4].numpy(), d["ze"], atol=1e-5, rtol=1e-4)            # encoder_output  -> embeddings
+    np.testing.assert_allclose(six[3].numpy(), d["soft_counts"], atol=2e-6, rtol=2e-3)    # soft counts
+    np.testing.assert_allclose(float(six[5]["vq_loss"]), float(d["log::vq_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(-six[1].log_prob(torch.from_numpy(d["x"]).reshape(16, 25, -1)).mean()),
+                               float(d["log::reconstruct_loss"]), rtol=1e-4)
+    pre_tr, pre_va = tiny_preprocessed(seed=3), tiny_preprocessed(n_videos=1, n_win=16, seed=4)
+    mv, ms, mt, logs = TR.train_deepof_model(
+        preprocessed_object=(pre_tr, pre_va), adjacency_matrix=chain_adj(4), meta_info={}, encoder_type="recurrent",
+        batch_size=8, latent_dim=4, epochs=3, output_path=str(tmp_path), n_clusters=6, model_name="VQVAE",
+        use_turtle_teacher=False, save_weights=True, _engine_factory=emu_factory)
+    assert isinstance(mv, VQVAE) and mt is None and len(logs["train"]["total_loss"]) == 3
+    assert logs["train"]["total_loss"][-1] < logs["train"]["total_loss"][0]
+    ckpt = tmp_path / "models" / "vqvae" / "run_0" / "best_model_val.pth"
+    assert ckpt.exists()
+    loaded, *_ = TR.load_model_from_ckpt(str(ckpt), _engine_factory=emu_factory)
+    assert isinstance(loaded, VQVAE)
+    x = torch.from_numpy(reorder_and_reshape(pre_va["vid0"][0])[:8])
+    a = torch.from_numpy(pre_va["vid0"][1][:8, ..., None])
+    emb, soft = loaded.encode_windows(x, a)
+    assert tuple(emb.shape) == (8, 4) and tuple(soft.shape) == (8, 6)
+    np.testing.assert_allclose(emb.numpy(), mv.encode(x, a).numpy(), atol=1e-5)
