@@ -776,6 +776,16 @@ __global__ void __launch_bounds__(256) k_enc_final_fwd(const float* __restrict__
   for (int c = 0; c < C; ++c) Y[(int64_t)c * Sp + s] = fmaf((x[c] - mean) * rstd, gamma[c], beta[c]);
 }
 
+__global__ void __launch_bounds__(256) k_zero_f32(float* __restrict__ p, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.0f;
+}
+
+__global__ void __launch_bounds__(256) k_zero_int(int* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 // dc = (dXf + dXb) * (c > 0)   (ReLU mask of the encoder conv; in place into dXf)
 __global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ act, float* __restrict__ d0,
                                                     const float* __restrict__ d1, int64_t n) {
@@ -802,7 +812,7 @@ __global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ ac
 int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, float* xs, float* c, int* len, int T,
                             int G, int64_t S, int64_t Sp, hipStream_t st) {
   const unsigned nb = dof_cdiv((int64_t)T * S, 256);
-  if (hipMemsetAsync(len, 0, (size_t)S * sizeof(int), st) != hipSuccess) return DOF_ERR_LAUNCH;
+  DOF_LAUNCH(k_zero_int, (dof_cdiv(S, 256)), (256), st, len, S);  // (a memset node here faulted under hipGraph replay)
   if (F == 3) {
     DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd<2 * LL, 3>), (nb), (256), st, xin, w, xs, c, len, T, G, S, Sp));
   } else if (F == 1) {
@@ -904,6 +914,14 @@ int dof_launch_enc_final_fwd(int L, const float* O2, const int* len, const float
   const unsigned nb = dof_cdiv(S, 256);
   DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_final_fwd<2 * LL>), (nb), (256), st, O2, len, gamma, beta, HF, Y, T, S, Sp));
   return dof_check_launch("k_enc_final_fwd");
+}
+
+// zero-fill as a kernel (graph-replay safe; memset nodes on sub-buffers misbehaved under hipGraph replay)
+int dof_launch_zero(float* p, int64_t n, hipStream_t st) {
+  unsigned nb = dof_cdiv(n, 256);
+  if (nb > 2048) nb = 2048;
+  DOF_LAUNCH(k_zero_f32, (nb), (256), st, p, n);
+  return dof_check_launch("k_zero_f32");
 }
 
 int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t n, hipStream_t st) {

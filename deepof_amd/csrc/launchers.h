@@ -29,6 +29,7 @@ int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const f
                       float* dX, float* partial, int T, int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_enc_final_fwd(int L, const float* O2, const int* len, const float* gamma, const float* beta, float* HF,
                              float* Y, int T, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_zero(float* p, int64_t n, hipStream_t st);
 int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t n, hipStream_t st);
 
 // ---- k_reduce.hip ---------------------------------------------------------------------------

@@ -866,7 +866,7 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   float* ws = p->ws;
   const int L = p->L, T = p->T, K = p->K;
   const int64_t B = p->B, Bp = p->Bp;
-  if (hipMemsetAsync(grads, 0, (size_t)p->param_total * 4, st) != hipSuccess) return DOF_ERR_LAUNCH;
+  TRY(dof_launch_zero(grads, p->param_total, st));
 
   // ---------------- forward
   TRY(encoder_forward(p, params, x, a, true, st));
@@ -996,7 +996,7 @@ extern "C" int dof_vqvae_loss_grads(DofVadePlan* p, const float* params, const f
   float* ws = p->ws;
   const int L = p->L, K = p->K;
   const int64_t B = p->B, Bp = p->Bp;
-  if (hipMemsetAsync(grads, 0, (size_t)p->param_total * 4, st) != hipSuccess) return DOF_ERR_LAUNCH;
+  TRY(dof_launch_zero(grads, p->param_total, st));
   TRY(encoder_forward(p, params, x, a, true, st));
   DOF_LAUNCH(k_final_dense, (dof_cdiv(B, 256), (unsigned)L), (256), st, (const float*)(ws + p->flat), params + p->fd_w,
              params + p->fd_b, ws + p->enc, p->J, B, Bp);

@@ -18,7 +18,7 @@ def hip():
 def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == 1
+    assert hip.dof_abi_version() == 2
 
 
 def test_gather_gpu(hip):
