@@ -14,7 +14,8 @@ ABI_VERSION = 2
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
 H_NONEMPTY_W, H_NONEMPTY_FLOOR, H_NONEMPTY_P, H_L1_ACT, H_DISTILL_T, H_CONF_W = 6, 7, 8, 9, 10, 11
 H_CONF_THR, H_HAS_TEACHER, H_LOGVAR_LO, H_LOGVAR_HI = 12, 13, 14, 15
-H_CLIP, H_WD, H_LR0, H_BC0, H_ACTIVE0, H_VQ_BETA, H_COUNT = 16, 17, 18, 22, 30, 34, 36
+H_CLIP, H_WD, H_LR0, H_BC0, H_ACTIVE0, H_VQ_BETA = 16, 17, 18, 22, 30, 34
+H_TF_W, H_CAT_W, H_TEMPORAL_W, H_SCATTER_W, H_SCATTER_BETA, H_COUNT = 36, 37, 38, 39, 40, 42
 SEG_ENCODER, SEG_DECODER, SEG_GMM, SEG_HEADS, SEG_COUNT = 0, 1, 2, 3, 4
 LOG_KEYS = ("total_loss", "reconstruct_loss", "kl_div", "cat_clust_loss", "kmeans_loss", "activity_l1",
             "prior_loss", "distill_loss", "tf_clust_loss", "nonempty_loss", "temporal_loss", "scatter_loss",

@@ -341,23 +341,29 @@ struct StatsArgs {
   const float* tau;               // (B,K) row-major teacher targets or null
   const float* class_weight;      // (K)
   const float* hyper;
-  float* stats;                   // [K][1+L] cluster sums, then [3] scalars at K*(1+L)
+  float* stats;                   // [K][3L+1]: sum qn | sum qn z | sum qn mu | sum qn mu^2 ; then [4] scalars
   int K;
   int64_t B, Bp;
 };
 
 template <int L>
 __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
+  constexpr int SW = 3 * L + 1;
   const int c = blockIdx.x;
-  float vals[L + 1];
+  float vals[SW];
 #pragma unroll
-  for (int i = 0; i <= L; ++i) vals[i] = 0.0f;
+  for (int i = 0; i < SW; ++i) vals[i] = 0.0f;
   if (c < A.K) {
     for (int64_t b = threadIdx.x; b < A.B; b += 256) {
       const float qv = A.qn[(int64_t)c * A.Bp + b];
       vals[0] += qv;
 #pragma unroll
-      for (int d = 0; d < L; ++d) vals[1 + d] = fmaf(qv, A.z[(int64_t)d * A.Bp + b], vals[1 + d]);
+      for (int d = 0; d < L; ++d) {
+        const float m = A.mu[(int64_t)d * A.Bp + b];
+        vals[1 + d] = fmaf(qv, A.z[(int64_t)d * A.Bp + b], vals[1 + d]);
+        vals[1 + L + d] = fmaf(qv, m, vals[1 + L + d]);
+        vals[1 + 2 * L + d] = fmaf(qv * m, m, vals[1 + 2 * L + d]);
+      }
     }
   } else {
     const float Ts = A.hyper[DOF_H_DISTILL_T];
@@ -384,14 +390,19 @@ __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
         }
         vals[2] += sw / se;
       }
+      if (b + 1 < A.B) {  // temporal cohesion: sum_c |qn[b+1,c] - qn[b,c]|
+        float tv = 0.0f;
+        for (int k = 0; k < A.K; ++k) tv += fabsf(A.qn[(int64_t)k * A.Bp + b + 1] - A.qn[(int64_t)k * A.Bp + b]);
+        vals[3] += tv;
+      }
     }
   }
-  __shared__ float out[L + 1];
-  dof_block_colsum<L + 1>(vals, out);
+  __shared__ float out[SW];
+  dof_block_colsum<SW>(vals, out);
   __syncthreads();
-  if (threadIdx.x <= L) {
-    if (c < A.K) A.stats[c * (L + 1) + threadIdx.x] = out[threadIdx.x];
-    else if (threadIdx.x < 3) A.stats[A.K * (L + 1) + threadIdx.x] = out[threadIdx.x];
+  if (threadIdx.x < SW) {
+    if (c < A.K) A.stats[c * SW + threadIdx.x] = out[threadIdx.x];
+    else if (threadIdx.x < 4) A.stats[A.K * SW + threadIdx.x] = out[threadIdx.x];
   }
 }
 
@@ -494,8 +505,9 @@ struct LossMidArgs {
   const float* km;             // [1] weighted k-means term
   const float* teacher_marginal;  // (K) or null
   const float* hyper;
-  float* dqbar;                // [K]  d(nonempty)/d mean_b qn[b,c]
+  float* dqbar;                // [K]  d(nonempty + cat)/d mean_b qn[b,c]
   float* dcen;                 // [K][L] d(repel)/d centroid, pre-divided by pi_b[c]
+  float* dscat;                // [K][2L+1] scatter term: d/dP_c | d/dM_cd | d/dS2_cd
   float* scal;                 // [8]: 0 klscale(main: klw*flag/(S*B)), 1 wcls_mean, 2 distill_sum(filled later)
   float* logs;                 // [DOF_LOG_COUNT]
   int K, L, S, T, pretrain;
@@ -505,12 +517,13 @@ struct LossMidArgs {
 __global__ void k_loss_mid(LossMidArgs A) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int K = A.K, L = A.L;
+  const int SW = 3 * L + 1;
   const float* H = A.hyper;
   const float Bf = (float)A.B;
   float recon = 0.0f;
   for (int i = 0; i < A.n_recon; ++i) recon += A.recon_partial[i];
   recon /= (Bf * (float)A.T);
-  const float* sc = A.stats + K * (L + 1);
+  const float* sc = A.stats + K * SW;
   const float activity = H[DOF_H_L1_ACT] * sc[0] / Bf;
   const float klw = H[DOF_H_KLW];
   float kl;
@@ -529,7 +542,7 @@ __global__ void k_loss_mid(LossMidArgs A) {
   float nonempty = 0.0f;
   const float nw = H[DOF_H_NONEMPTY_W], base_floor = H[DOF_H_NONEMPTY_FLOOR], pw = H[DOF_H_NONEMPTY_P];
   for (int c = 0; c < K; ++c) {
-    const float qm = A.stats[c * (L + 1)] / Bf;
+    const float qm = A.stats[c * SW] / Bf;
     float fl = base_floor;
     if (A.teacher_marginal && H[DOF_H_HAS_TEACHER] != 0.0f) fl = fmaxf(fl, 0.9f * A.teacher_marginal[c]);
     const float under = fmaxf(fl - qm, 0.0f);
@@ -551,19 +564,19 @@ __global__ void k_loss_mid(LossMidArgs A) {
     const float norm = (float)(K * K - K > 1 ? K * K - K : 1);
     float ksum = 0.0f;
     for (int c = 0; c < K; ++c) {
-      const float pc = fmaxf(A.stats[c * (L + 1)], 1e-8f);
+      const float pc = fmaxf(A.stats[c * SW], 1e-8f);
       for (int e = 0; e < K; ++e) {
         if (e == c) continue;
-        const float pe = fmaxf(A.stats[e * (L + 1)], 1e-8f);
+        const float pe = fmaxf(A.stats[e * SW], 1e-8f);
         float d2 = 0.0f;
         for (int d = 0; d < L; ++d) {
-          const float df = A.stats[c * (L + 1) + 1 + d] / pc - A.stats[e * (L + 1) + 1 + d] / pe;
+          const float df = A.stats[c * SW + 1 + d] / pc - A.stats[e * SW + 1 + d] / pe;
           d2 += df * df;
         }
         const float kv = expf(-d2 / den);
         ksum += kv;
         for (int d = 0; d < L; ++d) {
-          const float df = A.stats[c * (L + 1) + 1 + d] / pc - A.stats[e * (L + 1) + 1 + d] / pe;
+          const float df = A.stats[c * SW + 1 + d] / pc - A.stats[e * SW + 1 + d] / pe;
           A.dcen[c * L + d] += (rw / norm) * 2.0f * kv * (-2.0f * df / den) / pc;
         }
       }
@@ -573,8 +586,61 @@ __global__ void k_loss_mid(LossMidArgs A) {
   float prior_loss = 0.0f;
   if (!A.pretrain) {  // -(q * log(1/K)).sum(-1).mean(); q rows sum to one after renormalisation
     float qs = 0.0f;
-    for (int c = 0; c < K; ++c) qs += A.stats[c * (L + 1)];
+    for (int c = 0; c < K; ++c) qs += A.stats[c * SW];
     prior_loss = logf((float)(K > 1 ? K : 1)) * qs / Bf;
+  }
+  // ---- optional main-phase regularisers (reference default weight 0): cat-KL, temporal, scatter
+  float cat = 0.0f, temporal = 0.0f, scatter = 0.0f;
+  for (int i = 0; i < K * (2 * L + 1); ++i) A.dscat[i] = 0.0f;
+  if (!A.pretrain) {
+    const float wcat = H[DOF_H_CAT_W];
+    if (wcat > 0.0f) {  // KLDivLoss(batchmean) of log(mean q + 1e-9) vs uniform, divided by K (losses.py:354-359)
+      const float u = 1.0f / (float)K;
+      for (int c = 0; c < K; ++c) {
+        const float qm = A.stats[c * SW] / Bf;
+        cat += u * (logf(u) - logf(qm + 1e-9f));
+        A.dqbar[c] += -wcat * (u / (float)K) / (qm + 1e-9f);
+      }
+      cat *= wcat / (float)K;
+    }
+    const float rho = H[DOF_H_TEMPORAL_W];
+    if (rho > 0.0f && A.B > 1) temporal = rho * sc[3] / (Bf - 1.0f);
+    const float eta = H[DOF_H_SCATTER_W];
+    if (eta > 0.0f) {
+      const float beta = H[DOF_H_SCATTER_BETA];
+      float pbar = 0.0f;
+      for (int c = 0; c < K; ++c) pbar += fmaxf(A.stats[c * SW], 1e-8f);
+      pbar /= (float)K;
+      float wa_sum = 0.0f;  // sum_e w_e A_e
+      for (int c = 0; c < K; ++c) {
+        const float pc = fmaxf(A.stats[c * SW], 1e-8f);
+        const float w = powf(pc / pbar, -beta);
+        float a_c = 0.0f;
+        for (int d = 0; d < L; ++d) {
+          const float mu = A.stats[c * SW + 1 + L + d] / pc;
+          a_c += A.stats[c * SW + 1 + 2 * L + d] / pc - mu * mu;
+        }
+        wa_sum += w * a_c;
+      }
+      const float norm = eta / ((float)K * (float)L);
+      scatter = norm * wa_sum;
+      for (int c = 0; c < K; ++c) {
+        const float praw = A.stats[c * SW];
+        const float pc = fmaxf(praw, 1e-8f);
+        const float w = powf(pc / pbar, -beta);
+        float a_c = 0.0f, dp = 0.0f;
+        for (int d = 0; d < L; ++d) {
+          const float m = A.stats[c * SW + 1 + L + d], s2 = A.stats[c * SW + 1 + 2 * L + d];
+          const float mu = m / pc;
+          a_c += s2 / pc - mu * mu;
+          dp += -s2 / (pc * pc) + 2.0f * m * m / (pc * pc * pc);
+          A.dscat[c * (2 * L + 1) + 1 + d] = norm * w * (-2.0f * mu / pc);
+          A.dscat[c * (2 * L + 1) + 1 + L + d] = norm * w / pc;
+        }
+        // through the (clamped) cluster mass: scatter itself, its weight w_c, and the mean mass in every w_e
+        A.dscat[c * (2 * L + 1)] = praw > 1e-8f ? norm * (w * dp - beta * w * a_c / pc + beta * wa_sum / ((float)K * pbar)) : 0.0f;
+      }
+    }
   }
   float* lg = A.logs;
   lg[DOF_LOG_RECON] = recon;
@@ -584,23 +650,28 @@ __global__ void k_loss_mid(LossMidArgs A) {
   lg[DOF_LOG_PRIOR] = prior_loss;
   lg[DOF_LOG_NONEMPTY] = nonempty;
   lg[DOF_LOG_REPEL] = repel;
-  lg[DOF_LOG_CAT] = 0.0f;
-  lg[DOF_LOG_TFCLUST] = 0.0f;
-  lg[DOF_LOG_TEMPORAL] = 0.0f;
-  lg[DOF_LOG_SCATTER] = 0.0f;
+  lg[DOF_LOG_CAT] = cat;
+  lg[DOF_LOG_TFCLUST] = 0.0f;  // filled by k_loss_total from the per-sample sums
+  lg[DOF_LOG_TEMPORAL] = temporal;
+  lg[DOF_LOG_SCATTER] = scatter;
   lg[DOF_LOG_KLW] = klw;
   lg[DOF_LOG_DISTILL] = 0.0f;  // filled by k_loss_total once the per-sample CE sums exist
-  lg[DOF_LOG_TOTAL] = recon + kl + nonempty + prior_loss + A.km[0] + activity + repel;
+  lg[DOF_LOG_TOTAL] = recon + kl + nonempty + prior_loss + A.km[0] + activity + repel + cat + temporal + scatter;
 }
 
-__global__ void k_loss_total(const float* __restrict__ distill_partial, int n, const float* __restrict__ hyper,
-                             int64_t B, float* __restrict__ logs) {
+__global__ void k_loss_total(const float* __restrict__ distill_partial, const float* __restrict__ tf_partial, int n,
+                             const float* __restrict__ hyper, int64_t B, int pretrain, float* __restrict__ logs) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float s = 0.0f;
-  for (int i = 0; i < n; ++i) s += distill_partial[i];
+  float s = 0.0f, t = 0.0f;
+  for (int i = 0; i < n; ++i) {
+    s += distill_partial[i];
+    t += tf_partial[i];
+  }
   const float d = hyper[DOF_H_LAMBDA_DISTILL] * s / (float)B;
+  const float tf = pretrain ? 0.0f : -hyper[DOF_H_TF_W] * t / (float)B;
   logs[DOF_LOG_DISTILL] = d;
-  logs[DOF_LOG_TOTAL] += d;
+  logs[DOF_LOG_TFCLUST] = tf;
+  logs[DOF_LOG_TOTAL] += d + tf;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -614,7 +685,7 @@ struct LatentBwdArgs {
   const float* mckl_gsum;  // [2L][Bp] sample sums of dlogp/dz and dlogp/dz*eps, or null
   const float* dz_dec;     // [2][L][Bp] from the decoder
   const float *wf, *wm, *ws, *gmm_means, *gmm_log_vars;
-  const float *Pm, *dcen, *dqbar, *scal, *hyper;
+  const float *Pm, *dcen, *dqbar, *dscat, *scal, *hyper;
   const float* tau;        // (B,K) or null
   const float* class_weight;
   // outputs
@@ -622,7 +693,9 @@ struct LatentBwdArgs {
   float* denc;             // [L][Bp]
   float* dlogit;           // [K][Bp]
   float* dflat;            // [J][Bp]
+  float* dlogp2;           // [K][Bp] tf_cluster path: grad wrt the clamped-variance component log-likelihoods
   float* distill_partial;  // [nblk]
+  float* tf_partial;       // [nblk] per-block sums of sum_c qn*softmax(logp)
   int J, K, S, pretrain;
   int64_t B, Bp;
 };
@@ -631,7 +704,7 @@ template <int L>
 __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = b < A.B;
-  float ce_w = 0.0f;
+  float ce_w = 0.0f, tf_w = 0.0f;
   if (live) {
     const dof_cfp H = dof_cw(A.hyper);
     const dof_cfp wm = dof_cw(A.wm), wsv = dof_cw(A.ws), gmeans = dof_cw(A.gmm_means),
@@ -666,26 +739,78 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
         w_total *= fminf(fmaxf((cmax / tse - thr) / fmaxf(1e-6f, 1.0f - thr), 0.0f), 1.0f);
       }
     }
+    // ---- optional main-phase terms that touch qn: temporal cohesion, scatter, tf-cluster (default weight 0)
+    const float rho = A.pretrain ? 0.0f : H[DOF_H_TEMPORAL_W];
+    const float eta = A.pretrain ? 0.0f : H[DOF_H_SCATTER_W];
+    const float wtf = A.pretrain ? 0.0f : H[DOF_H_TF_W];
+    const float lo = H[DOF_H_LOGVAR_LO], hi = H[DOF_H_LOGVAR_HI];
+    float mu_b[L];
+#pragma unroll
+    for (int d = 0; d < L; ++d) mu_b[d] = A.mu[(int64_t)d * A.Bp + b];
+    float pl_mx = -INFINITY, pl_se = 1.0f;
+    if (wtf != 0.0f) {  // pl = softmax_c log N(z; m_c, clamp(l_c)) with the 1e-3 std floor (losses.py:547-564)
+      for (int c = 0; c < K; ++c) {
+        float lg = 0.0f;
+#pragma unroll
+        for (int d = 0; d < L; ++d) {
+          const float sd = fmaxf(expf(0.5f * fminf(fmaxf(glv[c * L + d], lo), hi)), 1e-3f);
+          const float u = (z[d] - gmeans[c * L + d]) / sd;
+          lg += -0.5f * u * u - logf(sd);
+        }
+        A.dlogp2[(int64_t)c * A.Bp + b] = lg;
+        pl_mx = fmaxf(pl_mx, lg);
+      }
+      pl_se = 0.0f;
+      for (int c = 0; c < K; ++c) pl_se += expf(A.dlogp2[(int64_t)c * A.Bp + b] - pl_mx);
+    }
+    auto extra_dqn = [&](int c, float qn_c) -> float {
+      float g = 0.0f;
+      if (rho != 0.0f && A.B > 1) {
+        const float sc = rho / ((float)A.B - 1.0f);
+        if (b > 0) {
+          const float df = qn_c - A.qn[(int64_t)c * A.Bp + b - 1];
+          g += sc * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+        }
+        if (b + 1 < A.B) {
+          const float df = A.qn[(int64_t)c * A.Bp + b + 1] - qn_c;
+          g -= sc * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+        }
+      }
+      if (eta != 0.0f) {
+        const float* ds = A.dscat + c * (2 * L + 1);
+        g += ds[0];
+#pragma unroll
+        for (int d = 0; d < L; ++d) g += ds[1 + d] * mu_b[d] + ds[1 + L + d] * mu_b[d] * mu_b[d];
+      }
+      if (wtf != 0.0f) g += -(wtf / Bf) * expf(A.dlogp2[(int64_t)c * A.Bp + b] - pl_mx) / pl_se;
+      return g;
+    };
     // pass 1: dot = sum_c dqn[c]*qn[c] ; csum = sum_c max(q,1e-8)
-    float dot = 0.0f, csum = 0.0f, ce = 0.0f;
+    float dot = 0.0f, csum = 0.0f, ce = 0.0f, tf_sum = 0.0f, pl_dot = 0.0f;
     for (int c = 0; c < K; ++c) {
       const float qn = A.qn[(int64_t)c * A.Bp + b];
-      float g = A.dqbar[c] / Bf;
+      float g = A.dqbar[c] / Bf + extra_dqn(c, qn);
       if (distill) {
         const float tb = expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx) / tse;
         ce -= tb * logf(fmaxf(qn, 1e-8f));
         if (qn >= 1e-8f) g -= (lam / Bf) * w_total * tb / qn;
       }
+      if (wtf != 0.0f) {
+        const float pl = expf(A.dlogp2[(int64_t)c * A.Bp + b] - pl_mx) / pl_se;
+        tf_sum = fmaf(qn, pl, tf_sum);
+        pl_dot = fmaf(-(wtf / Bf) * qn, pl, pl_dot);  // sum_c dpl[c]*pl[c]
+      }
       dot = fmaf(g, qn, dot);
       csum += fmaxf(A.q[(int64_t)c * A.Bp + b], 1e-8f);
     }
     ce_w = distill ? w_total * ce : 0.0f;
+    tf_w = tf_sum;
     // pass 2: dq through clamp+renormalise, accumulate softmax inner product
     float sdot = 0.0f;
     for (int c = 0; c < K; ++c) {
       const float qn = A.qn[(int64_t)c * A.Bp + b];
       const float q = A.q[(int64_t)c * A.Bp + b];
-      float g = A.dqbar[c] / Bf;
+      float g = A.dqbar[c] / Bf + extra_dqn(c, qn);
       if (distill && qn >= 1e-8f) {
         const float tb = expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx) / tse;
         g -= (lam / Bf) * w_total * tb / qn;
@@ -694,18 +819,28 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       A.dlogit[(int64_t)c * A.Bp + b] = dq;  // temporarily dq
       sdot = fmaf(dq, q, sdot);
     }
-    // pass 3: dlogit, posterior path into z, repel path
+    // pass 3: dlogit, posterior path into z, repel path, tf-cluster path
     for (int c = 0; c < K; ++c) {
       const float q = A.q[(int64_t)c * A.Bp + b];
       const float dl = q * (A.dlogit[(int64_t)c * A.Bp + b] - sdot);
       A.dlogit[(int64_t)c * A.Bp + b] = dl;
       const float qn = A.qn[(int64_t)c * A.Bp + b];
+      float dl2 = 0.0f;
+      if (wtf != 0.0f) {  // softmax backward of pl with d loss / d pl[c] = -(w/B) qn[c]
+        const float pl = expf(A.dlogp2[(int64_t)c * A.Bp + b] - pl_mx) / pl_se;
+        dl2 = pl * (-(wtf / Bf) * qn - pl_dot);
+      }
 #pragma unroll
       for (int d = 0; d < L; ++d) {
         const float sd = fmaxf(expf(0.5f * glv[c * L + d]), 1e-3f);
         dz[d] = fmaf(dl, -(z[d] - gmeans[c * L + d]) / (sd * sd), dz[d]);
         dz[d] = fmaf(qn, A.dcen[c * L + d], dz[d]);
+        if (wtf != 0.0f) {
+          const float sd2 = fmaxf(expf(0.5f * fminf(fmaxf(glv[c * L + d], lo), hi)), 1e-3f);
+          dz[d] = fmaf(dl2, -(z[d] - gmeans[c * L + d]) / (sd2 * sd2), dz[d]);
+        }
       }
+      if (wtf != 0.0f) A.dlogp2[(int64_t)c * A.Bp + b] = dl2;  // consumed by k_gmm_grads
     }
     // k-means (Gram spectrum): dZ = Z * Pm
 #pragma unroll
@@ -724,6 +859,12 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       const float s = A.sv[(int64_t)d * A.Bp + b];
       const float m = A.mu[(int64_t)d * A.Bp + b];
       float dm = dz[d];
+      if (eta != 0.0f) {  // scatter term acts on z_mean directly: sum_c qn (dM_cd + 2 dS2_cd mu)
+        for (int c = 0; c < K; ++c) {
+          const float* dsc = A.dscat + c * (2 * L + 1);
+          dm = fmaf(A.qn[(int64_t)c * A.Bp + b], dsc[1 + d] + 2.0f * dsc[1 + L + d] * m, dm);
+        }
+      }
       float ds = dz[d] * A.eps[b * L + d] * 0.5f * expf(0.5f * s);
       ds += s > 0.0f ? act : (s < 0.0f ? -act : 0.0f);
       const float sc = fminf(fmaxf(s, -4.0f), 2.0f);
@@ -758,8 +899,16 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       A.denc[(int64_t)k * A.Bp + b] = acc;
     }
   }
-  float v1[1] = {ce_w};
-  dof_block_colsum<1>(v1, A.distill_partial + blockIdx.x);
+  float v2[2] = {ce_w, tf_w};
+  float out2[2] = {0.0f, 0.0f};
+  __shared__ float o2[2];
+  dof_block_colsum<2>(v2, o2);
+  __syncthreads();
+  (void)out2;
+  if (threadIdx.x == 0) {
+    A.distill_partial[blockIdx.x] = o2[0];
+    A.tf_partial[blockIdx.x] = o2[1];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -767,6 +916,7 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
 // ---------------------------------------------------------------------------------------------
 struct GmmGradArgs {
   const float *z, *dlogit;           // [L][Bp], [K][Bp]
+  const float* dlogp2;               // [K][Bp] tf-cluster path (clamped log-variances) or unused
   const float *mu, *sv, *eps_mc, *lse;  // MC-KL recompute (main) or null
   const float *gmm_means, *gmm_log_vars, *prior, *scal, *hyper;
   float* partial;                    // [gridDim.y][2*K*L]: means (K,L) then log-vars (K,L)
@@ -788,6 +938,8 @@ __global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A) {
   }
   const int64_t tstride = (int64_t)gridDim.y * 256;
   const int64_t t0 = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  const bool use_tf = !A.pretrain && A.hyper[DOF_H_TF_W] != 0.0f;
+  const float tlo = A.hyper[DOF_H_LOGVAR_LO], thi = A.hyper[DOF_H_LOGVAR_HI];
   for (int64_t b = t0; b < A.B; b += tstride) {
     const float dl = A.dlogit[(int64_t)c * A.Bp + b];
 #pragma unroll
@@ -798,6 +950,18 @@ __global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A) {
       vals[d] = fmaf(dl, u / sd, vals[d]);
       // d/d log_var of [-u^2/2 - log sd] = (u^2 - 1) * 0.5, only while the 1e-3 floor is inactive
       if (e >= 1e-3f) vals[L + d] = fmaf(dl, 0.5f * (u * u - 1.0f), vals[L + d]);
+    }
+    if (use_tf) {
+      const float dl2 = A.dlogp2[(int64_t)c * A.Bp + b];
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float lvc = fminf(fmaxf(lvraw[d], tlo), thi);
+        const float e = expf(0.5f * lvc);
+        const float sd = fmaxf(e, 1e-3f);
+        const float u = (A.z[(int64_t)d * A.Bp + b] - m[d]) / sd;
+        vals[d] = fmaf(dl2, u / sd, vals[d]);
+        if (e >= 1e-3f && lvraw[d] >= tlo && lvraw[d] <= thi) vals[L + d] = fmaf(dl2, 0.5f * (u * u - 1.0f), vals[L + d]);
+      }
     }
   }
   const float ksc = A.pretrain ? 0.0f : A.scal[0];

@@ -118,7 +118,7 @@ struct DofVadePlan {
   // workspace
   StreamWs sw[2];
   int64_t flat, enc, mu, pre, sv, z, q, qn, dlogit, dmu_dpre, denc, dflat;
-  int64_t gram, Pm, km, stats, dqbar, dcen, scal;
+  int64_t gram, Pm, km, stats, dqbar, dcen, dscat, dlogp2, tf_partial, scal;
   int64_t mterm, mlse, mdz, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
@@ -317,7 +317,9 @@ void build_workspace_layout(DofVadePlan* p) {
   p->gram = cv.take(L * L);
   p->Pm = cv.take(L * L);
   p->km = cv.take(1);
-  p->stats = cv.take((int64_t)K * (L + 1) + 3);
+  p->stats = cv.take((int64_t)K * (3 * L + 1) + 4);
+  p->dscat = cv.take((int64_t)K * (2 * L + 1));
+  p->dlogp2 = cv.take((int64_t)K * Bp);
   p->dqbar = cv.take(K);
   p->dcen = cv.take((int64_t)K * L);
   p->scal = cv.take(8);
@@ -331,6 +333,7 @@ void build_workspace_layout(DofVadePlan* p) {
   p->tail_blocks = dof_cdiv((int64_t)T * p->B, 256);
   p->mckl_partial = cv.take(p->mckl_blocks);
   p->distill_partial = cv.take(p->lat_blocks);
+  p->tf_partial = cv.take(p->lat_blocks);
   p->recon_partial = cv.take(p->tail_blocks);
   p->recon_partial2 = cv.take(p->tail_blocks);
   p->vq_idx = cv.take(Bp);
@@ -899,7 +902,7 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   LM.stats = ws + p->stats; LM.recon_partial = ws + p->recon_partial; LM.n_recon = (int)p->tail_blocks;
   LM.mckl_partial = ws + p->mckl_partial; LM.n_mckl = (int)p->mckl_blocks; LM.km = ws + p->km;
   LM.teacher_marginal = teacher ? teacher + K : nullptr; LM.hyper = hyper; LM.dqbar = ws + p->dqbar;
-  LM.dcen = ws + p->dcen; LM.scal = ws + p->scal; LM.logs = logs; LM.K = K; LM.L = L; LM.S = p->S; LM.T = T;
+  LM.dcen = ws + p->dcen; LM.dscat = ws + p->dscat; LM.scal = ws + p->scal; LM.logs = logs; LM.K = K; LM.L = L; LM.S = p->S; LM.T = T;
   LM.pretrain = pretrain ? 1 : 0; LM.B = B;
   DOF_LAUNCH(k_loss_mid, (1), (64), st, LM);
   TRY(dof_check_launch("k_loss_mid"));
@@ -910,7 +913,8 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   LB.q = ws + p->q; LB.qn = ws + p->qn; LB.eps = eps; LB.eps_mc = eps_mc; LB.mckl_gsum = ws + p->mgsum;
   LB.dz_dec = ws + p->dzdec; LB.wf = params + p->fd_w; LB.wm = params + p->mean_w; LB.ws = params + p->lv_w;
   LB.gmm_means = params + p->gmm_m; LB.gmm_log_vars = params + p->gmm_lv; LB.Pm = ws + p->Pm; LB.dcen = ws + p->dcen;
-  LB.dqbar = ws + p->dqbar; LB.scal = ws + p->scal; LB.hyper = hyper; LB.tau = tau; LB.class_weight = teacher;
+  LB.dqbar = ws + p->dqbar; LB.dscat = ws + p->dscat; LB.dlogp2 = ws + p->dlogp2; LB.tf_partial = ws + p->tf_partial;
+  LB.scal = ws + p->scal; LB.hyper = hyper; LB.tau = tau; LB.class_weight = teacher;
   LB.dmu_dpre = ws + p->dmu_dpre; LB.denc = ws + p->denc; LB.dlogit = ws + p->dlogit; LB.dflat = ws + p->dflat;
   LB.distill_partial = ws + p->distill_partial; LB.J = p->J; LB.K = K; LB.S = p->S; LB.pretrain = pretrain ? 1 : 0;
   LB.B = B; LB.Bp = Bp;
@@ -919,10 +923,11 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   LDISPATCH(L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(B, 256), (unsigned)p->J), (256), st,
                           (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, B, Bp));
   TRY(dof_check_launch("k_final_dense_bwd"));
-  DOF_LAUNCH(k_loss_total, (1), (64), st, (const float*)(ws + p->distill_partial), (int)p->lat_blocks, hyper, B, logs);
+  DOF_LAUNCH(k_loss_total, (1), (64), st, (const float*)(ws + p->distill_partial), (const float*)(ws + p->tf_partial),
+             (int)p->lat_blocks, hyper, B, pretrain ? 1 : 0, logs);
   TRY(dof_check_launch("k_loss_total"));
   GmmGradArgs GG;
-  GG.z = ws + p->z; GG.dlogit = ws + p->dlogit; GG.mu = ws + p->mu; GG.sv = ws + p->sv; GG.eps_mc = eps_mc;
+  GG.z = ws + p->z; GG.dlogit = ws + p->dlogit; GG.dlogp2 = ws + p->dlogp2; GG.mu = ws + p->mu; GG.sv = ws + p->sv; GG.eps_mc = eps_mc;
   GG.lse = ws + p->mlse; GG.gmm_means = params + p->gmm_m; GG.gmm_log_vars = params + p->gmm_lv; GG.prior = prior;
   GG.scal = ws + p->scal; GG.hyper = hyper; GG.partial = ws + p->gmmp;
   GG.K = K; GG.S = p->S; GG.pretrain = pretrain ? 1 : 0; GG.B = B; GG.Bp = Bp;

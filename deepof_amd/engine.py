@@ -162,7 +162,8 @@ class VadeEngine:
                       nonempty_p=_capi.H_NONEMPTY_P, l1_act=_capi.H_L1_ACT, distill_T=_capi.H_DISTILL_T,
                       conf_w=_capi.H_CONF_W, conf_thr=_capi.H_CONF_THR, has_teacher=_capi.H_HAS_TEACHER,
                       logvar_lo=_capi.H_LOGVAR_LO, logvar_hi=_capi.H_LOGVAR_HI, clip=_capi.H_CLIP, wd=_capi.H_WD,
-                      vq_beta=_capi.H_VQ_BETA)
+                      vq_beta=_capi.H_VQ_BETA, tf_w=_capi.H_TF_W, cat_w=_capi.H_CAT_W, temporal_w=_capi.H_TEMPORAL_W,
+                      scatter_w=_capi.H_SCATTER_W, scatter_beta=_capi.H_SCATTER_BETA)
 
     def set_hyper(self, **kw):
         for k, v in kw.items():

@@ -241,13 +241,6 @@ class VadeStepper:
 
     def __init__(self, model: VaDE, common_cfg: CommonFitCfg, vade_cfg: VaDECfg, teacher_cfg: TurtleTeacherCfg):
         self.model, self.common, self.vade, self.teacher = model, common_cfg, vade_cfg, teacher_cfg
-        unsupported = {"main_clustering_loss (tf_cluster_weight)": vade_cfg.tf_cluster_weight,
-                       "reg_cat_clusters": vade_cfg.reg_cat_clusters,
-                       "temporal_cohesion_weight": vade_cfg.temporal_cohesion_weight,
-                       "reg_scatter_weight": vade_cfg.reg_scatter_weight}
-        bad = [k for k, v in unsupported.items() if float(v) != 0.0]
-        if bad:
-            raise NotImplementedError(f"optional VaDE loss terms not implemented in this build: {bad} (reference default 0)")
         self.pretrain = True
         self.kl_scheduler: Optional[WeightSchedule] = None
         self.lambda_scheduler: Optional[WeightSchedule] = None
@@ -268,6 +261,9 @@ class VadeStepper:
             eng.set_hyper(km_loss=self.common.kmeans_loss, repel_w=v.repel_weight, repel_ls=v.repel_length_scale,
                           nonempty_w=v.nonempty_weight, nonempty_floor=max(1e-4, v.nonempty_floor_percent / K),
                           nonempty_p=int(v.nonempty_p))
+        # main-phase-only regularisers (kernels ignore them while pretraining)
+        eng.set_hyper(tf_w=v.tf_cluster_weight, cat_w=v.reg_cat_clusters, temporal_w=v.temporal_cohesion_weight,
+                      scatter_w=v.reg_scatter_weight, scatter_beta=v.reg_scatter_beta)
         eng.set_hyper(km_latent=self.model.kmeans_weight, l1_act=0.1, distill_T=self.teacher.distill_sharpen_T,
                       conf_w=1.0 if self.teacher.distill_conf_weight else 0.0, conf_thr=self.teacher.distill_conf_thresh)
 

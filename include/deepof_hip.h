@@ -86,7 +86,8 @@ enum {
   DOF_H_BC0 = 22,      /* 4 x (1-beta1^t, 1-beta2^t) */
   DOF_H_ACTIVE0 = 30,  /* 4 x "segment has gradients" (0 = frozen / grad None) */
   DOF_H_VQ_BETA = 34,  /* VQ-VAE commitment weight beta */
-  DOF_H_COUNT = 36
+  DOF_H_TF_W = 36, DOF_H_CAT_W = 37, DOF_H_TEMPORAL_W = 38, DOF_H_SCATTER_W = 39, DOF_H_SCATTER_BETA = 40,
+  DOF_H_COUNT = 42
 };
 /* optimiser segments of the VaDE parameter buffer */
 enum { DOF_SEG_ENCODER = 0, DOF_SEG_DECODER = 1, DOF_SEG_GMM = 2, DOF_SEG_HEADS = 3, DOF_SEG_COUNT = 4 };

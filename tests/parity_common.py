@@ -21,15 +21,22 @@ PHASES = {
     "pre": dict(klw=0.13, pretrain=True, teacher=False),
     "main": dict(klw=0.7, pretrain=False, teacher=False),
     "mainT": dict(klw=0.7, pretrain=False, teacher=True),
+    # every optional regulariser switched on at once (reference defaults are 0 for these)
+    "mainX": dict(klw=0.45, pretrain=False, teacher=True,
+                  extra=dict(repel_w=0.3, repel_ls=1.0, scatter_w=0.2, scatter_beta=1.0, temporal_w=0.1, cat_w=0.5,
+                             tf_w=0.7, km_loss=0.5, conf_w=1.0, conf_thr=0.3)),
 }
 
 
-def configure_phase(eng, K, pretrain, klw, tau=None, lambda_distill=0.0):
+def configure_phase(eng, K, pretrain, klw, tau=None, lambda_distill=0.0, extra=None):
     """Reference defaults of VadeLoss per phase (training.py:640-668, losses.py:426-443)."""
     eng.set_hyper(klw=klw, km_latent=1.0, km_loss=1.0 if pretrain else 0.0,
                   repel_w=0.5 if pretrain else 0.0, repel_ls=0.5 if pretrain else 1.0,
                   nonempty_w=0.02, nonempty_floor=max(1e-4, 0.05 / K), nonempty_p=2.0,
-                  l1_act=0.1, distill_T=0.5, conf_w=0.0, conf_thr=0.3, lambda_distill=lambda_distill)
+                  l1_act=0.1, distill_T=0.5, conf_w=0.0, conf_thr=0.3, lambda_distill=lambda_distill,
+                  tf_w=0.0, cat_w=0.0, temporal_w=0.0, scatter_w=0.0, scatter_beta=1.0)
+    if extra:
+        eng.set_hyper(**extra)
     if tau is not None:
         pi = tau.mean(dim=0).clamp_min(1e-8)
         w = pi.pow(-1.0)
@@ -76,7 +83,7 @@ def run_phase_check(lib, device, golden_dir, tag, phase, atol_g=5e-5, rtol_g=5e-
     eng = VadeEngine(lib, device, B, T, d["adj"], L, K)
     eng.load_state_dict(params_from(d))
     tau = torch.from_numpy(d["tau"]) if spec["teacher"] else None
-    configure_phase(eng, K, spec["pretrain"], spec["klw"], tau, 1.7 if spec["teacher"] else 0.0)
+    configure_phase(eng, K, spec["pretrain"], spec["klw"], tau, 1.7 if spec["teacher"] else 0.0, spec.get("extra"))
     eng.loss_grads(x, a, torch.from_numpy(d["eps"]).to(device), torch.from_numpy(d["eps_mc"]).to(device),
                    None if tau is None else tau.to(device), pretrain=spec["pretrain"])
     logs = eng.read_logs()

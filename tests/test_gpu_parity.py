@@ -43,8 +43,8 @@ def test_vade_eval_forward_gpu(hip, golden_dir, tag):
     np.testing.assert_allclose(out["loc"].cpu().numpy(), d["eval_loc"], atol=2e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("tag,phase", [("rec14", "pre"), ("rec14", "main"), ("rec14", "mainT"), ("rec28", "pre"),
-                                       ("rec28", "main"), ("rec28", "mainT")])
+@pytest.mark.parametrize("tag,phase", [("rec14", "pre"), ("rec14", "main"), ("rec14", "mainT"), ("rec14", "mainX"),
+                                       ("rec28", "pre"), ("rec28", "main"), ("rec28", "mainT"), ("rec28", "mainX")])
 def test_vade_loss_grads_gpu(hip, golden_dir, tag, phase):
     from parity_common import run_phase_check
     worst = run_phase_check(hip, "cuda", golden_dir, tag, phase)
