@@ -109,3 +109,14 @@ def censnet_operators(adjacency: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np
     line = inc.T.astype(np.float64) @ inc.astype(np.float64) - 2.0 * np.eye(inc.shape[1])
     edge_lap = _gcn_filter(line)
     return lap.astype(np.float32), edge_lap.astype(np.float32), inc
+
+
+def edge_index_from_graph(nodes: Sequence[str], edges: Sequence[Tuple[str, str]]):
+    """(global (E,2), within-animal (E_local,2)) int32 node-index pairs in ``edges`` order; an edge is local
+    when both endpoints carry the same animal prefix (text before the first underscore).
+    Mirrors reference training.py:1936-2004 _build_edge_from_metainfo."""
+    idx = {n: i for i, n in enumerate(nodes)}
+    key = [n.split("_", 1)[0] if "_" in n else "" for n in nodes]
+    glob = np.array([(idx[u], idx[v]) for u, v in edges], dtype=np.int32).reshape(-1, 2)
+    local = np.array([e for e in glob.tolist() if key[e[0]] == key[e[1]]], dtype=np.int32).reshape(-1, 2)
+    return glob, local

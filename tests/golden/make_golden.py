@@ -294,6 +294,162 @@ def gen_vqvae(tag, ids, T, L, K, B, seed, kmeans=0.0):
     np.savez_compressed(os.path.join(HERE, f"vqvae_{tag}.npz"), **out)
 
 
+class _Recorder:
+    """Records every torch.rand/randint/randn/randperm result produced inside the reference call."""
+
+    def __init__(self):
+        self.calls = []
+        self._orig = {}
+
+    def __enter__(self):
+        for name in ("rand", "randint", "randn", "randperm"):
+            self._orig[name] = getattr(torch, name)
+
+            def wrap(*a, _n=name, **k):
+                out = self._orig[_n](*a, **k)
+                self.calls.append((_n, out.clone()))
+                return out
+
+            setattr(torch, name, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(torch, name, fn)
+
+
+def _draws_from_calls(calls, ccfg, T_full, N, centers, branches_a, branches_c, n_trip):
+    """Resolve the recorded draws of one _make_augmented_view call (training.py:2373-2403) into the explicit
+    augmentation parameters that the oracle / the HIP kernel take (oracle/contrastive.py AugDraws)."""
+    from oracle.contrastive import choose_rotations
+    it = iter(calls)
+
+    def nxt(kind):
+        k, v = next(it)
+        assert k == kind, (k, kind)
+        return v
+
+    half = T_full // 2
+    base = (T_full - half) // 2
+    ap = nxt("rand") < ccfg.aug_p_shift
+    mag, sgn = nxt("randint"), nxt("randint") * 2 - 1
+    start = (base + mag * sgn * ap.long()).clamp(0, T_full - half)
+    ap = (nxt("rand") < ccfg.aug_p_rot).float()
+    perm = nxt("randperm").tolist()
+    chosen = choose_rotations(perm, centers, N, ccfg.aug_n_rot)
+    piv, nodes, thetas = [], [], []
+    for k in chosen:
+        side_a = bool(nxt("rand") < 0.5)
+        th = (nxt("rand") * 2.0 - 1.0) * (float(ccfg.aug_max_rot) * np.pi / 180.0) * ap
+        piv.append(centers[k]); nodes.append(branches_a[k] if side_a else branches_c[k]); thetas.append(th)
+    ap = nxt("rand") < ccfg.aug_p_interp
+    ln = nxt("randint")
+    t0 = torch.minimum(nxt("randint"), (half - ln - 1).clamp_min(1))
+    ln = ln * ap.long()
+    ap = (nxt("rand") < ccfg.aug_p_noise).float().view(-1, 1)
+    axis = nxt("randint")
+    off = ccfg.aug_noise_sigma * nxt("randn") * ap
+    ds = ccfg.aug_noise_sigma * nxt("randn") * ap
+    noise = torch.stack([off * (axis == 0).float(), off * (axis == 1).float(), ds], -1)
+    assert next(it, None) is None
+    return dict(start=start.numpy().astype(np.int32), rot_pivot=np.array(piv, dtype=np.int32),
+                rot_nodes=[np.array(n, dtype=np.int32) for n in nodes],
+                theta=torch.stack(thetas).numpy().astype(np.float32) if thetas else np.zeros((0, len(start)), np.float32),
+                interp_t0=t0.numpy().astype(np.int32), interp_len=ln.numpy().astype(np.int32),
+                noise=noise.numpy().astype(np.float32))
+
+
+def gen_contrastive(tag, ids, T_full, L, B, seed):
+    """ContrastivePT (recurrent encoder on the half window) + step_contrastive_distill, RNG draws recorded."""
+    from deepof_amd.graph import make_meta_info
+    from oracle.contrastive import rotation_triplets
+    nodes, edges = bodypart_graph(ids)
+    adj = adjacency_from_graph(nodes, edges)
+    N, E = len(nodes), len(edges)
+    meta = make_meta_info(nodes, edges)
+    dev = torch.device("cpu")
+    ei_g, ei_l, _ = R.T._build_edge_from_metainfo(meta, dev, N, return_local=True)
+    pre = R.T.build_rotation_precomp(ei_l, N, dev)
+    trips, ba, bc = rotation_triplets(ei_l.tolist(), N)
+    assert [tuple(t) for t in pre.triplets.tolist()] == trips
+    for k in range(len(trips)):
+        assert sorted(pre.branches_a[k].tolist()) == ba[k] and sorted(pre.branches_c[k].tolist()) == bc[k]
+    centers = [t[1] for t in trips]
+    x_full, _ = synth_batch(B, T_full, N, E, seed + 1)
+    x_full = (x_full * 0.5).astype(np.float32)
+    xt = torch.from_numpy(x_full)
+    out = dict(x_full=x_full, adj=adj, edge_index=ei_g.numpy().astype(np.int32),
+               edge_index_local=ei_l.numpy().astype(np.int32))
+    # fixed-embedding loss table (losses.py:35-249), all similarity x loss combinations
+    g = torch.Generator().manual_seed(seed)
+    zz, zza = torch.randn(B, L, generator=g), torch.randn(B, L, generator=g)
+    zz, zza = torch.nn.functional.normalize(zz, dim=1), torch.nn.functional.normalize(0.6 * zz + 0.8 * zza, dim=1)
+    out.update(loss_z=zz.numpy(), loss_za=zza.numpy())
+    for sim in ("cosine", "dot", "euclidean", "edit"):
+        for lf in ("nce", "dcl", "fc", "hard_dcl"):
+            a_ = zz.clone().requires_grad_(True); b_ = zza.clone().requires_grad_(True)
+            l_, p_, n_ = R.L.select_contrastive_loss_pt(a_, b_, similarity=sim, loss_fn=lf, temperature=0.1, tau=0.1,
+                                                        beta=0.1, elimination_topk=0.1)
+            ga, gb = torch.autograd.grad(l_, [a_, b_])
+            out[f"loss::{sim}::{lf}"] = np.array([float(l_), float(p_), float(n_)])
+            out[f"loss_grad::{sim}::{lf}"] = np.stack([ga.numpy(), gb.numpy()])
+    for ci, (sim, lf) in enumerate([("cosine", "nce"), ("euclidean", "hard_dcl"), ("dot", "dcl")]):
+        torch.manual_seed(seed + ci)
+        model = R.M.ContrastivePT((T_full, N, 3), (T_full, E, 1), adj, latent_dim=L, encoder_type="recurrent",
+                                  similarity_function=sim, loss_function=lf, temperature=0.1, beta=0.1, tau=0.1)
+        ccfg = R.U.ContrastiveCfg(aug_n_rot=3, aug_p_rot=0.7, aug_p_noise=0.9, aug_p_interp=0.6)
+        ctx = SimpleNamespace(apply_distill=False, edge_index=ei_g, edge_index_local=ei_l, contrastive_cfg=ccfg,
+                              rot_precomp=pre)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        a_dummy = torch.zeros(B, T_full, E, 1)
+        with _Recorder() as rec:
+            res = R.T.step_contrastive_distill(model, (xt, a_dummy, torch.arange(B)), ctx)
+        res.loss.backward()
+        calls = rec.calls
+        dr = _draws_from_calls(calls, ccfg, T_full, N, centers, ba, bc, len(trips))
+        pfx = f"c{ci}::"
+        out[pfx + "sim"], out[pfx + "loss_fn"] = np.array(sim), np.array(lf)
+        for k, v in dr.items():
+            if k == "rot_nodes":
+                mask = np.zeros((len(v), N), dtype=np.int32)
+                for r, nn_ in enumerate(v):
+                    mask[r, nn_] = 1
+                out[pfx + "aug::rot_mask"] = mask
+            else:
+                out[pfx + "aug::" + k] = v
+        # replay the same draws through the reference augmentation to store the views themselves
+        seq = [v for _, v in calls]
+        it = iter(seq)
+        orig = {n: getattr(torch, n) for n in ("rand", "randint", "randn", "randperm")}
+        try:
+            for n in orig:
+                setattr(torch, n, lambda *a, **k: next(it).clone())
+            xa, aa = R.T._make_augmented_view(
+                xt, R.U.recompute_edges(xt, ei_g), ei_g, pre, min_shift=ccfg.aug_min_shift, max_shift=ccfg.aug_max_shift,
+                p_shift=ccfg.aug_p_shift, noise_sigma=ccfg.aug_noise_sigma, p_noise=ccfg.aug_p_noise,
+                max_interp=ccfg.aug_max_interp, min_interp=ccfg.aug_min_interp, p_interp=ccfg.aug_p_interp,
+                max_rot=ccfg.aug_max_rot, n_rot=ccfg.aug_n_rot, p_rot=ccfg.aug_p_rot)
+        finally:
+            for n, fn in orig.items():
+                setattr(torch, n, fn)
+        out[pfx + "x_aug"], out[pfx + "a_aug"] = xa.numpy(), aa.numpy()
+        half = T_full // 2
+        st = (torch.ones(B) * half // 2).int()
+        xc = R.U.slice_time_per_sample(xt, st, half)
+        out[pfx + "x"], out[pfx + "a"] = xc.numpy(), R.U.recompute_edges(xc, ei_g).numpy()
+        with torch.no_grad():
+            out[pfx + "z"] = model(xc, R.U.recompute_edges(xc, ei_g)).numpy()
+            out[pfx + "z_aug"] = model(xa, aa).numpy()
+        out.update(sd_np(model, pfx + "sd::"))
+        for k, v in res.logs.items():
+            out[pfx + f"log::{k}"] = np.float64(v)
+        for n, p_ in model.named_parameters():
+            if p_.grad is not None:
+                out[pfx + f"grad::{n}"] = p_.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, f"contrastive_{tag}.npz"), **out)
+
+
 if __name__ == "__main__":
     gen_scramble()
     gen_graph_ops()
@@ -304,6 +460,8 @@ if __name__ == "__main__":
     gen_schedules_kmeans()
     gen_vqvae("rec14", [""], 25, 8, 64, 16, 41)
     gen_vqvae("rec28", ["B", "W"], 12, 6, 20, 6, 51, kmeans=0.5)
+    gen_contrastive("rec14", [""], 24, 8, 16, 61)
+    gen_contrastive("rec28", ["B", "W"], 25, 6, 7, 71)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -208,3 +208,76 @@ def test_vqvae_forward_loss_grads_trace(golden_dir, tag):
             np.testing.assert_allclose(v, float(d[f"step{i}::log::{k}"]), rtol=5e-4, atol=5e-5, err_msg=f"{i}:{k}")
     for k, v in _params(d, "sd_final::").items():
         np.testing.assert_allclose(P[k].numpy(), v.numpy(), atol=2e-4, rtol=1e-3, err_msg=k)
+
+
+# ----------------------------------------------------------------------------- contrastive (R13/R14)
+def _aug_draws(d, pfx):
+    from oracle import contrastive as OC
+    mask = d[pfx + "aug::rot_mask"]
+    return OC.AugDraws(start=torch.from_numpy(d[pfx + "aug::start"]),
+                       rot_pivot=[int(v) for v in d[pfx + "aug::rot_pivot"]],
+                       rot_nodes=[np.nonzero(m)[0].tolist() for m in mask],
+                       theta=torch.from_numpy(d[pfx + "aug::theta"]),
+                       interp_t0=torch.from_numpy(d[pfx + "aug::interp_t0"]),
+                       interp_len=torch.from_numpy(d[pfx + "aug::interp_len"]),
+                       noise=torch.from_numpy(d[pfx + "aug::noise"]))
+
+
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+def test_contrastive_losses_match_reference(golden_dir, tag):
+    from oracle import contrastive as OC
+    d = _load(golden_dir, f"contrastive_{tag}.npz")
+    for sim in ("cosine", "dot", "euclidean", "edit"):
+        for lf in ("nce", "dcl", "fc", "hard_dcl"):
+            z = torch.from_numpy(d["loss_z"]).requires_grad_(True)
+            za = torch.from_numpy(d["loss_za"]).requires_grad_(True)
+            l, p, n = OC.contrastive_loss(z, za, sim, lf, 0.1, 0.1, 0.1)
+            np.testing.assert_allclose([float(l), float(p), float(n)], d[f"loss::{sim}::{lf}"], rtol=1e-5, atol=1e-6,
+                                       err_msg=f"{sim}/{lf}")
+            g = torch.autograd.grad(l, [z, za])
+            np.testing.assert_allclose(np.stack([g[0].numpy(), g[1].numpy()]), d[f"loss_grad::{sim}::{lf}"],
+                                       rtol=1e-4, atol=1e-6, err_msg=f"{sim}/{lf}")
+
+
+@pytest.mark.parametrize("tag,ids", [("rec14", [""]), ("rec28", ["B", "W"])])
+def test_contrastive_views_and_step_match_reference(golden_dir, tag, ids):
+    from oracle import contrastive as OC
+    d = _load(golden_dir, f"contrastive_{tag}.npz")
+    nodes, edges = G.bodypart_graph(ids)
+    ei, ei_local = G.edge_index_from_graph(nodes, edges)
+    np.testing.assert_array_equal(ei, d["edge_index"])
+    np.testing.assert_array_equal(ei_local, d["edge_index_local"])
+    x_full = torch.from_numpy(d["x_full"])
+    eit = torch.from_numpy(d["edge_index"]).long()
+    for ci in range(3):
+        pfx = f"c{ci}::"
+        dr = _aug_draws(d, pfx)
+        assert (d[pfx + "aug::interp_len"] > 0).any() and np.abs(d[pfx + "aug::theta"]).max() > 0
+        xa, aa = OC.augmented_view(x_full, eit, dr)
+        np.testing.assert_allclose(xa.numpy(), d[pfx + "x_aug"], atol=1e-6)
+        np.testing.assert_allclose(aa.numpy(), d[pfx + "a_aug"], atol=2e-6)
+        xc, ac = OC.central_view(x_full, eit)
+        np.testing.assert_array_equal(xc.numpy(), d[pfx + "x"])
+        np.testing.assert_allclose(ac.numpy(), d[pfx + "a"], atol=1e-7)
+        P = _params(d, pfx + "sd::")
+        logs, grads, aux = OC.contrastive_grads(P, x_full, eit, dr, sim_kind=str(d[pfx + "sim"]),
+                                                loss_fn=str(d[pfx + "loss_fn"]), temperature=0.1, tau=0.1, beta=0.1)
+        np.testing.assert_allclose(aux["z"].detach().numpy(), d[pfx + "z"], atol=3e-6, rtol=1e-5)
+        np.testing.assert_allclose(aux["z_aug"].detach().numpy(), d[pfx + "z_aug"], atol=3e-6, rtol=1e-5)
+        for k in ("total_loss", "pos_similarity", "neg_similarity"):
+            np.testing.assert_allclose(logs[k], float(d[pfx + f"log::{k}"]), rtol=2e-5, atol=2e-6, err_msg=k)
+        n = 0
+        for k in d:
+            if k.startswith(pfx + "grad::"):
+                name = k[len(pfx) + 6:]
+                np.testing.assert_allclose(grads[name].numpy(), d[k], atol=2e-5, rtol=3e-4, err_msg=name)
+                n += 1
+        assert n >= 40
+
+
+def test_rotation_triplets_choice():
+    from oracle import contrastive as OC
+    trips, ba, bc = OC.rotation_triplets([(0, 1), (1, 2), (1, 3), (3, 4)], 5)
+    assert trips == [(0, 1, 2), (0, 1, 3), (2, 1, 3), (1, 3, 4)]
+    assert ba[1] == [0] and bc[1] == [3, 4] and ba[3] == [0, 1, 2] and bc[3] == [4]
+    assert OC.choose_rotations([0, 1, 2, 3], [t[1] for t in trips], 5, 3) == [0, 1, 3]
