@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -20,13 +20,22 @@ SEG_ENCODER, SEG_DECODER, SEG_GMM, SEG_HEADS, SEG_COUNT = 0, 1, 2, 3, 4
 LOG_KEYS = ("total_loss", "reconstruct_loss", "kl_div", "cat_clust_loss", "kmeans_loss", "activity_l1",
             "prior_loss", "distill_loss", "tf_clust_loss", "nonempty_loss", "temporal_loss", "scatter_loss",
             "repel_loss", "kl_weight")
-LOG_ENC_REC, LOG_VQ, LOG_POPULATED = 14, 15, 16
+LOG_ENC_REC, LOG_VQ, LOG_POPULATED, LOG_POS_SIM, LOG_NEG_SIM = 14, 15, 16, 17, 18
+MAX_ROT = 8
+SIMILARITIES = {"cosine": 0, "dot": 1, "euclidean": 2, "edit": 2}
+CONTRASTIVE_LOSSES = {"nce": 0, "dcl": 1, "hard_dcl": 2}
 LOG_COUNT = 20
 
 
 class VadeDims(C.Structure):
     _fields_ = [("batch", C.c_int32), ("window", C.c_int32), ("n_nodes", C.c_int32), ("n_edges", C.c_int32),
                 ("latent", C.c_int32), ("n_clusters", C.c_int32), ("mc_samples", C.c_int32)]
+
+
+class Augment(C.Structure):
+    _fields_ = [("start", C.c_void_p), ("n_rot", C.c_int32), ("rot_pivot", C.c_int32 * 8),
+                ("rot_nodes", C.c_uint64 * 8), ("theta", C.c_void_p), ("interp_t0", C.c_void_p),
+                ("interp_len", C.c_void_p), ("noise", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -53,6 +62,11 @@ SIGNATURES = {
     "dof_vqvae_forward": (C.c_int, [_P] * 11),
     "dof_vqvae_loss_grads": (C.c_int, [_P] * 8),
     "dof_optimizer_step": (C.c_int, [_P] * 7),
+    "dof_contrastive_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_contrastive_views": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, C.POINTER(Augment), _P, _P, _P]),
+    "dof_contrastive_encode": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P]),
+    "dof_contrastive_loss": (C.c_int, [_P, _P, _P, _I32, _I32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "dof_contrastive_backward": (C.c_int, [_P, _P, _P, _P, _I32, _P]),
 }
 
 

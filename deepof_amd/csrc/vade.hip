@@ -22,6 +22,7 @@
 #include "k_decoder.inc.h"
 #include "k_graph_latent.inc.h"
 #include "k_vq.inc.h"
+#include "k_contrastive.inc.h"
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -101,7 +102,7 @@ struct JobSet {  // one launch of the MFMA weight-gradient reduction + its final
 
 struct DofVadePlan {
   DofVadeDims d;
-  int kind = 0;  // 0 = VaDE (GMM latent), 1 = VQ-VAE (codebook of K codes)
+  int kind = 0;  // 0 = VaDE (GMM latent), 1 = VQ-VAE (codebook of K codes), 2 = contrastive (encoder only)
   int L, K, T, N, E, S, J, C3;
   int64_t B, Bp;
   std::vector<ParamEntry> params;
@@ -125,6 +126,7 @@ struct DofVadePlan {
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
   int64_t partials, segs_tab, mask_tab;
   int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
+  int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks;  // contrastive loss scratch
   int64_t ws_floats = 0;
   // tables built at bind: encoder side, decoder fed from ws.z (latent / quantised) or ws.enc (raw z_e), Gram
   JobSet js_enc, js_dec[2], js_gram;
@@ -185,6 +187,10 @@ void build_param_layout(DofVadePlan* p) {
   add_param(p, "encoder.final_dense.weight", (int64_t)L * (N + E) * L, &p->fd_w);
   add_param(p, "encoder.final_dense.bias", L, &p->fd_b);
   p->seg_hi[DOF_SEG_ENCODER] = p->param_total;
+  if (p->kind == 2) {  // contrastive: ContrastivePT owns nothing but the encoder
+    for (int sg = DOF_SEG_DECODER; sg < DOF_SEG_COUNT; ++sg) p->seg_lo[sg] = p->seg_hi[sg] = p->param_total;
+    return;
+  }
   p->seg_lo[DOF_SEG_DECODER] = p->param_total;
   add_gru(p, "decoder.gru1", L, L, &p->dg1);
   add_param(p, "decoder.norm1.weight", 2 * L, &p->dn1w);
@@ -304,6 +310,25 @@ void build_workspace_layout(DofVadePlan* p) {
   const int64_t Bp = p->Bp;
   p->flat = cv.take((int64_t)p->J * Bp);
   p->enc = cv.take((int64_t)L * Bp);
+  p->denc = cv.take((int64_t)L * Bp);
+  p->dflat = cv.take((int64_t)p->J * Bp);
+  p->lat_blocks = dof_cdiv(p->B, 256);
+  p->cl_blocks = p->lat_blocks;
+  if (p->kind == 2) {
+    p->cl_zn = cv.take(2 * p->B * L);
+    p->cl_inv = cv.take(2 * p->B);
+    p->cl_rn = cv.take(2 * p->B);
+    p->cl_rowstat = cv.take(4 * p->B);
+    p->cl_partial = cv.take(3 * p->cl_blocks);
+    for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+      js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
+      js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
+    }
+    p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
+    p->mask_tab = cv.take(p->param_total);
+    p->ws_floats = cv.cur;
+    return;
+  }
   p->mu = cv.take((int64_t)L * Bp);
   p->pre = cv.take((int64_t)L * Bp);
   p->sv = cv.take((int64_t)L * Bp);
@@ -312,8 +337,6 @@ void build_workspace_layout(DofVadePlan* p) {
   p->qn = cv.take((int64_t)K * Bp);
   p->dlogit = cv.take((int64_t)K * Bp);
   p->dmu_dpre = cv.take(2LL * L * Bp);
-  p->denc = cv.take((int64_t)L * Bp);
-  p->dflat = cv.take((int64_t)p->J * Bp);
   p->gram = cv.take(L * L);
   p->Pm = cv.take(L * L);
   p->km = cv.take(1);
@@ -329,7 +352,6 @@ void build_workspace_layout(DofVadePlan* p) {
   p->mgsum = cv.take(2LL * L * Bp);
   p->gmmp = cv.take(16LL * 2 * K * L);
   p->mckl_blocks = dof_cdiv((int64_t)S * p->B, 256);
-  p->lat_blocks = dof_cdiv(p->B, 256);
   p->tail_blocks = dof_cdiv((int64_t)T * p->B, 256);
   p->mckl_partial = cv.take(p->mckl_blocks);
   p->distill_partial = cv.take(p->lat_blocks);
@@ -496,6 +518,7 @@ void build_jobs(DofVadePlan* p) {
     }
     jb.close(p->js_enc);
   }
+  if (p->kind == 2) return;
   // ---- decoder, once per possible latent input buffer (ws.z: VaDE latent / VQ quantised; ws.enc: VQ raw z_e)
   for (int v = 0; v < 2; ++v) {
     JobBuilder jb(p->js_dec[v]);
@@ -684,7 +707,7 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
 }
 
 // Backward of CensNet + both recurrent encoder streams from ws.dflat; fills the encoder gradients.
-int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st) {
+int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st, int accumulate = 0) {
   float* ws = p->ws;
   const int L = p->L, T = p->T;
   const int64_t Bp = p->Bp;
@@ -715,15 +738,15 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     if (L == 8) {
       TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
                                      ws + w.wg1, T, w.S, w.Sp, st));
-      TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, 0, st));
+      TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, accumulate, st));
     } else {
       TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
     }
     TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
-    TRY(dof_launch_sum_partials(ws + w.ln1p, w.ln1_blocks, 8 * L, grads + b.n1w, 0, st));
-    TRY(dof_launch_sum_partials(ws + w.ln2p, w.ln2_blocks, 4 * L, grads + b.n2w, 0, st));
+    TRY(dof_launch_sum_partials(ws + w.ln1p, w.ln1_blocks, 8 * L, grads + b.n1w, accumulate, st));
+    TRY(dof_launch_sum_partials(ws + w.ln2p, w.ln2_blocks, 4 * L, grads + b.n2w, accumulate, st));
   }
-  return run_jobset(p, p->js_enc, grads, 0, st);
+  return run_jobset(p, p->js_enc, grads, accumulate, st);
 }
 
 }  // namespace
@@ -741,6 +764,10 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
   }
   if (dims->latent != 4 && dims->latent != 6 && dims->latent != 8) {
     dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", dims->latent);
+    return DOF_ERR_UNSUPPORTED;
+  }
+  if (dims->n_nodes > DOF_CL_MAX_NODES && kind == 2) {
+    dof_set_error("contrastive plan: n_nodes %d > %d", dims->n_nodes, DOF_CL_MAX_NODES);
     return DOF_ERR_UNSUPPORTED;
   }
   DofVadePlan* p = new DofVadePlan();
@@ -1043,4 +1070,144 @@ extern "C" int dof_optimizer_step(DofVadePlan* p, float* params, const float* gr
   const DofAdamSeg* segs = reinterpret_cast<const DofAdamSeg*>(p->ws + p->segs_tab);
   return dof_launch_clip_adam(params, grads, adam_m, adam_v, hyper, segs, DOF_SEG_COUNT, p->param_total, DOF_H_CLIP,
                               p->ws + p->mask_tab, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Contrastive
+// ---------------------------------------------------------------------------------------------
+extern "C" int dof_contrastive_plan_create(const DofVadeDims* dims, const float* laplacian,
+                                           const float* edge_laplacian, const float* incidence, DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_contrastive_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  DofVadeDims d = *dims;
+  if (d.n_clusters <= 0) d.n_clusters = 1;
+  if (d.mc_samples <= 0) d.mc_samples = 1;
+  return plan_create(&d, laplacian, edge_laplacian, incidence, 2, out);
+}
+
+extern "C" int dof_contrastive_views(const float* x_full, const int32_t* edge_index, int32_t batch, int32_t t_full,
+                                     int32_t n_nodes, int32_t n_edges, const DofAugment* aug, float* x_out,
+                                     float* a_out, void* stream) {
+  if (!x_full || !edge_index || !x_out || !a_out) {
+    dof_set_error("dof_contrastive_views: null argument");
+    return DOF_ERR_ARG;
+  }
+  if (batch <= 0 || t_full < 2 || n_nodes <= 0 || n_nodes > DOF_CL_MAX_NODES || n_edges <= 0) {
+    dof_set_error("dof_contrastive_views: bad sizes (batch %d t_full %d nodes %d (max %d) edges %d)", batch, t_full,
+                  n_nodes, DOF_CL_MAX_NODES, n_edges);
+    return DOF_ERR_ARG;
+  }
+  ViewArgs A;
+  memset(&A, 0, sizeof(A));
+  A.x_full = x_full; A.edge_index = edge_index; A.x_out = x_out; A.a_out = a_out;
+  A.B = batch; A.Tf = t_full; A.N = n_nodes; A.E = n_edges; A.half = t_full / 2;
+  if (aug) {
+    if (aug->n_rot < 0 || aug->n_rot > DOF_MAX_ROT || (aug->n_rot > 0 && !aug->theta)) {
+      dof_set_error("dof_contrastive_views: n_rot %d out of range (0..%d) or theta missing", aug->n_rot, DOF_MAX_ROT);
+      return DOF_ERR_ARG;
+    }
+    for (int r = 0; r < aug->n_rot; ++r) {
+      if (aug->rot_pivot[r] < 0 || aug->rot_pivot[r] >= n_nodes) {
+        dof_set_error("dof_contrastive_views: rotation %d pivot %d outside 0..%d", r, aug->rot_pivot[r], n_nodes - 1);
+        return DOF_ERR_ARG;
+      }
+      A.rot_pivot[r] = aug->rot_pivot[r];
+      A.rot_mask[r] = aug->rot_nodes[r];
+    }
+    if ((aug->interp_t0 == nullptr) != (aug->interp_len == nullptr)) {
+      dof_set_error("dof_contrastive_views: interp_t0 and interp_len must be given together");
+      return DOF_ERR_ARG;
+    }
+    A.start = aug->start; A.n_rot = aug->n_rot; A.theta = aug->theta; A.interp_t0 = aug->interp_t0;
+    A.interp_len = aug->interp_len; A.noise = aug->noise;
+  }
+  DOF_LAUNCH(k_cl_view, (dof_cdiv((int64_t)batch * A.half, 64)), (64), (hipStream_t)stream, A);
+  return dof_check_launch("k_cl_view");
+}
+
+extern "C" int dof_contrastive_encode(DofVadePlan* p, const float* params, const float* x, const float* a,
+                                      int32_t train, float* z_out, void* stream) {
+  if (!p || !p->ws || p->kind != 2) {
+    dof_set_error("dof_contrastive_encode: plan not bound to a workspace (or not a contrastive plan)");
+    return DOF_ERR_STATE;
+  }
+  if (!params || !x || !a) {
+    dof_set_error("dof_contrastive_encode: null argument");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = p->ws;
+  TRY(encoder_forward(p, params, x, a, train != 0, st));
+  DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
+             params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
+  TRY(dof_check_launch("k_final_dense"));
+  if (z_out) {
+    LDISPATCH(p->L, DOF_LAUNCH((k_cl_export<LL>), (dof_cdiv(p->B, 256)), (256), st, (const float*)(ws + p->enc), z_out,
+                               p->B, p->Bp));
+    TRY(dof_check_launch("k_cl_export"));
+  }
+  return DOF_OK;
+}
+
+extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float* z_aug, int32_t similarity,
+                                    int32_t loss_fn, float temperature, float tau, float beta, float* dz,
+                                    float* dz_aug, float* logs, void* stream) {
+  if (!p || !p->ws || p->kind != 2) {
+    dof_set_error("dof_contrastive_loss: plan not bound to a workspace (or not a contrastive plan)");
+    return DOF_ERR_STATE;
+  }
+  if (!z || !z_aug || !logs || ((dz == nullptr) != (dz_aug == nullptr))) {
+    dof_set_error("dof_contrastive_loss: null argument (dz and dz_aug go together)");
+    return DOF_ERR_ARG;
+  }
+  if (similarity < DOF_SIM_COSINE || similarity > DOF_SIM_EUCLIDEAN) {
+    dof_set_error("dof_contrastive_loss: unknown similarity %d", similarity);
+    return DOF_ERR_ARG;
+  }
+  if (loss_fn < DOF_CLOSS_NCE || loss_fn > DOF_CLOSS_HARD_DCL) {
+    dof_set_error("dof_contrastive_loss: loss function %d not supported by this build (nce, dcl, hard_dcl)", loss_fn);
+    return DOF_ERR_UNSUPPORTED;
+  }
+  if (!(temperature > 0.0f) || !(tau < 1.0f)) {
+    dof_set_error("dof_contrastive_loss: temperature must be > 0 and tau < 1");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = p->ws;
+  ClArgs A;
+  A.z = z; A.za = z_aug; A.zn = ws + p->cl_zn; A.inv = ws + p->cl_inv; A.rn = ws + p->cl_rn;
+  A.rowstat = ws + p->cl_rowstat; A.partial = ws + p->cl_partial; A.dz = dz; A.dza = dz_aug; A.logs = logs;
+  A.sim = similarity; A.loss_fn = loss_fn; A.inv_T = 1.0f / temperature; A.tau = tau; A.beta = beta;
+  A.B = (int)p->B; A.nblk = (int)p->cl_blocks;
+  LDISPATCH(p->L, DOF_LAUNCH((k_cl_normalize<LL>), (dof_cdiv(2 * p->B, 256)), (256), st, A));
+  LDISPATCH(p->L, DOF_LAUNCH((k_cl_rowstats<LL>), ((unsigned)A.nblk), (256), st, A));
+  TRY(dof_check_launch("k_cl_rowstats"));
+  if (dz) {
+    LDISPATCH(p->L, DOF_LAUNCH((k_cl_grad<LL, false>), ((unsigned)A.nblk), (256), st, A));
+    LDISPATCH(p->L, DOF_LAUNCH((k_cl_grad<LL, true>), ((unsigned)A.nblk), (256), st, A));
+  }
+  DOF_LAUNCH(k_cl_finalize, (1), (64), st, A);
+  return dof_check_launch("k_cl_finalize");
+}
+
+extern "C" int dof_contrastive_backward(DofVadePlan* p, const float* params, const float* dz, float* grads,
+                                        int32_t accumulate, void* stream) {
+  if (!p || !p->ws || p->kind != 2) {
+    dof_set_error("dof_contrastive_backward: plan not bound to a workspace (or not a contrastive plan)");
+    return DOF_ERR_STATE;
+  }
+  if (!params || !dz || !grads) {
+    dof_set_error("dof_contrastive_backward: null argument");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = p->ws;
+  if (!accumulate) TRY(dof_launch_zero(grads, p->param_total, st));
+  LDISPATCH(p->L, DOF_LAUNCH((k_cl_import<LL>), (dof_cdiv(p->B, 256)), (256), st, dz, ws + p->denc, p->B, p->Bp));
+  LDISPATCH(p->L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(p->B, 256), (unsigned)p->J), (256), st,
+                             (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, p->B, p->Bp));
+  TRY(dof_check_launch("k_final_dense_bwd"));
+  return encoder_backward(p, params, grads, st, accumulate ? 1 : 0);
 }

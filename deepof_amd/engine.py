@@ -70,9 +70,10 @@ class VadeEngine:
         self.B, self.T, self.L, self.K, self.S = int(batch), int(window), int(latent_dim), int(n_clusters), int(mc_samples)
         dims = _capi.VadeDims(self.B, self.T, self.N, self.E, self.L, self.K, self.S)
         plan = C.c_void_p()
-        assert kind in ("vade", "vqvae")
+        assert kind in ("vade", "vqvae", "contrastive")
         self.kind = kind
-        create = lib.dof_vade_plan_create if kind == "vade" else lib.dof_vqvae_plan_create
+        create = {"vade": lib.dof_vade_plan_create, "vqvae": lib.dof_vqvae_plan_create,
+                  "contrastive": lib.dof_contrastive_plan_create}[kind]
         _capi.check(lib, create(C.byref(dims), self.lap.ctypes.data, self.elap.ctypes.data, self.inc.ctypes.data,
                                 C.byref(plan)), "dof_*_plan_create")
         self.plan = plan
@@ -266,6 +267,44 @@ class VadeEngine:
                 "vq_loss": v[_capi.LOG_VQ], "kmeans_loss": v[4], "number_of_populated_clusters": v[_capi.LOG_POPULATED],
                 "distill_loss": v[7]}
 
+    # ------------------------------------------------------------------ contrastive
+    def contrastive_encode(self, x, a, train: bool = False) -> torch.Tensor:
+        """ContrastivePT.forward on one view (half windows): (B, L) embeddings."""
+        self._chk_batch(x, a)
+        z = torch.empty(self.B, self.L, dtype=torch.float32, device=self.device)
+        rc = self.lib.dof_contrastive_encode(self.plan, self.params.data_ptr(), x.data_ptr(), a.data_ptr(),
+                                             1 if train else 0, z.data_ptr(), self._stream())
+        _capi.check(self.lib, rc, "dof_contrastive_encode")
+        return z
+
+    def contrastive_loss(self, z, z_aug, similarity="cosine", loss_fn="nce", temperature=0.1, tau=0.1, beta=0.1,
+                         want_grads: bool = True):
+        """Normalise + pairwise loss; fills self.logs, returns (dz, dz_aug) or (None, None)."""
+        if loss_fn not in _capi.CONTRASTIVE_LOSSES:
+            raise NotImplementedError(f"contrastive loss {loss_fn!r} is not built (available: "
+                                      f"{sorted(_capi.CONTRASTIVE_LOSSES)})")
+        assert tuple(z.shape) == (self.B, self.L) and tuple(z_aug.shape) == (self.B, self.L)
+        assert z.is_contiguous() and z_aug.is_contiguous()
+        dz = torch.empty_like(z) if want_grads else None
+        dza = torch.empty_like(z) if want_grads else None
+        rc = self.lib.dof_contrastive_loss(self.plan, z.data_ptr(), z_aug.data_ptr(), _capi.SIMILARITIES[similarity],
+                                           _capi.CONTRASTIVE_LOSSES[loss_fn], float(temperature), float(tau),
+                                           float(beta), dz.data_ptr() if want_grads else None,
+                                           dza.data_ptr() if want_grads else None, self.logs.data_ptr(), self._stream())
+        _capi.check(self.lib, rc, "dof_contrastive_loss")
+        return dz, dza
+
+    def contrastive_backward(self, dz, accumulate: bool):
+        assert tuple(dz.shape) == (self.B, self.L) and dz.is_contiguous()
+        rc = self.lib.dof_contrastive_backward(self.plan, self.params.data_ptr(), dz.data_ptr(), self.grads.data_ptr(),
+                                               1 if accumulate else 0, self._stream())
+        _capi.check(self.lib, rc, "dof_contrastive_backward")
+
+    def read_contrastive_logs(self) -> Dict[str, float]:
+        v = self.logs.detach().cpu().tolist()
+        return {"total_loss": v[0], "pos_similarity": v[_capi.LOG_POS_SIM], "neg_similarity": v[_capi.LOG_NEG_SIM],
+                "distill_loss": 0.0, "seperability": 0.0}
+
     def advance_adam(self):
         """Bump the per-segment Adam step counters (bias corrections live in hyper[])."""
         for s in range(_capi.SEG_COUNT):
@@ -298,3 +337,49 @@ def create_vade_engine(batch, window, adjacency, latent_dim, n_clusters, mc_samp
     if dev.type != "cuda":
         raise RuntimeError(f"deepof_amd runs on ROCm devices only, got {dev}")
     return VadeEngine(lib, dev, batch, window, adjacency, latent_dim, n_clusters, mc_samples, graph_ops, shared, kind)
+
+
+def contrastive_views(lib, x_full: torch.Tensor, edge_index: torch.Tensor, aug: Optional[dict] = None, stream=0):
+    """dof_contrastive_views: one (x, a) view of every full window.  ``aug`` = None gives the central view;
+    otherwise a dict with the resolved draws (start, rot_pivot, rot_nodes, theta, interp_t0, interp_len, noise;
+    tensors on x_full's device, rot_pivot / rot_nodes host lists)."""
+    B, Tf, N, _ = x_full.shape
+    E = edge_index.shape[0]
+    assert x_full.is_contiguous() and x_full.dtype == torch.float32
+    assert edge_index.dtype == torch.int32 and edge_index.is_contiguous() and edge_index.device == x_full.device
+    half = Tf // 2
+    x = torch.empty(B, half, N, 3, dtype=torch.float32, device=x_full.device)
+    a = torch.empty(B, half, E, 1, dtype=torch.float32, device=x_full.device)
+    arg = None
+    keep = []
+    if aug is not None:
+        A = _capi.Augment()
+
+        def dev(key, dtype, shape):
+            t = aug.get(key)
+            if t is None:
+                return None
+            t = t.to(device=x_full.device, dtype=dtype).contiguous()
+            assert tuple(t.shape) == shape, (key, tuple(t.shape), shape)
+            keep.append(t)
+            return t.data_ptr()
+
+        piv = list(aug.get("rot_pivot", []))
+        A.n_rot = len(piv)
+        assert A.n_rot <= _capi.MAX_ROT
+        for r, (pv, nodes) in enumerate(zip(piv, aug.get("rot_nodes", []))):
+            A.rot_pivot[r] = int(pv)
+            m = 0
+            for n in nodes:
+                m |= 1 << int(n)
+            A.rot_nodes[r] = m
+        A.start = dev("start", torch.int32, (B,))
+        A.theta = dev("theta", torch.float32, (A.n_rot, B)) if A.n_rot else None
+        A.interp_t0 = dev("interp_t0", torch.int32, (B,))
+        A.interp_len = dev("interp_len", torch.int32, (B,))
+        A.noise = dev("noise", torch.float32, (B, N, 3))
+        arg = C.byref(A)
+    rc = lib.dof_contrastive_views(x_full.data_ptr(), edge_index.data_ptr(), B, Tf, N, E, arg, x.data_ptr(),
+                                   a.data_ptr(), stream)
+    _capi.check(lib, rc, "dof_contrastive_views")
+    return x, a

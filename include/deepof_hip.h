@@ -16,6 +16,12 @@
  *   dof_vade_loss_grads         deepof/clustering/training.py:231-309 step_vade + losses.py:567-797
  *                               VadeLoss.forward + loss.backward() (training.py:163)
  *   dof_vqvae_forward/_loss_grads  models_new.py:1575-1635 VQVAEPT.forward, training.py:312-389 step_vqvae_distill
+ *   dof_contrastive_views       training.py:2128-2403 _make_augmented_view (+ the four augmentations),
+ *                               model_utils_new.py:332-363 recompute_edges, :751-763 slice_time_per_sample
+ *   dof_contrastive_encode      models_new.py:2069-2075 ContrastivePT.forward (recurrent encoder)
+ *   dof_contrastive_loss        training.py:482-589 step_contrastive_distill (normalise + loss + logs),
+ *                               losses.py:35-249 select_contrastive_loss_pt
+ *   dof_contrastive_backward    loss.backward() through one view's encoder pass (training.py:163)
  *   dof_optimizer_step          training.py:164-166 clip_grad_value_ + optimizer.step(), losses.py:805-833
  */
 #ifndef DEEPOF_HIP_H
@@ -27,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 2
+#define DOF_ABI_VERSION 3
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -97,6 +103,7 @@ enum {
   DOF_LOG_DISTILL, DOF_LOG_TFCLUST, DOF_LOG_NONEMPTY, DOF_LOG_TEMPORAL, DOF_LOG_SCATTER, DOF_LOG_REPEL,
   DOF_LOG_KLW,
   DOF_LOG_ENC_REC = 14, DOF_LOG_VQ = 15, DOF_LOG_POPULATED = 16, /* VQ-VAE: enc_rec_loss, vq_loss, populated codes */
+  DOF_LOG_POS_SIM = 17, DOF_LOG_NEG_SIM = 18,                    /* contrastive: pos_similarity, neg_similarity */
   DOF_LOG_COUNT = 20
 };
 
@@ -133,6 +140,54 @@ int dof_vqvae_forward(DofVadePlan* plan, const float* params, const float* x, co
                       void* stream);
 int dof_vqvae_loss_grads(DofVadePlan* plan, const float* params, const float* x, const float* a, const float* hyper,
                          float* grads, float* logs, void* stream);
+
+/* ---- Contrastive (recurrent encoder on half windows, two views per window) -----------------------
+ * Plan: dims.window = the HALF window the encoder sees (full window // 2); dims.n_clusters /
+ * mc_samples are ignored.  Parameters = encoder.* only (ContrastivePT state_dict order); same
+ * dof_vade_param_* / workspace / bind / destroy / dof_optimizer_step functions as the other plans.
+ * One plan + workspace per view (activations of both views are alive until the backward passes);
+ * the two plans share the caller's parameter, gradient and Adam buffers. */
+int dof_contrastive_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                const float* incidence, DofVadePlan** out);
+
+#define DOF_MAX_ROT 8
+/* Resolved random choices of one augmented view (the reference draws them inside
+ * _make_augmented_view).  Device arrays unless stated; any pointer may be NULL = that step is off. */
+typedef struct DofAugment {
+  const int32_t* start;       /* (B) first frame of the view inside the full window (base + shift, clamped) */
+  int32_t n_rot;              /* rotations applied in order, <= DOF_MAX_ROT (host scalars below) */
+  int32_t rot_pivot[DOF_MAX_ROT];   /* pivot node of each rotation */
+  uint64_t rot_nodes[DOF_MAX_ROT];  /* bit n set = node n is rotated about the pivot (n_nodes <= 64) */
+  const float* theta;         /* (n_rot, B) rotation angles in radians (0 = sample not rotated) */
+  const int32_t* interp_t0;   /* (B) first frame of the linearly interpolated segment */
+  const int32_t* interp_len;  /* (B) its length; 0 = none */
+  const float* noise;         /* (B, N, 3) offsets added to (x, y, speed) of every frame */
+} DofAugment;
+
+/* Builds one view of every full window: x_full (B, t_full, N, 3) -> x_out (B, t_full/2, N, 3) and
+ * a_out (B, t_full/2, E, 1) = node distances over edge_index (E,2 int32, device).  aug == NULL gives
+ * the reference's un-augmented central view (start = (t_full/2)/2). */
+int dof_contrastive_views(const float* x_full, const int32_t* edge_index, int32_t batch, int32_t t_full,
+                          int32_t n_nodes, int32_t n_edges, const DofAugment* aug, float* x_out, float* a_out,
+                          void* stream);
+
+/* Encoder pass of one view: z_out (B, L).  train != 0 keeps the activations for dof_contrastive_backward. */
+int dof_contrastive_encode(DofVadePlan* plan, const float* params, const float* x, const float* a, int32_t train,
+                           float* z_out, void* stream);
+
+enum { DOF_SIM_COSINE = 0, DOF_SIM_DOT = 1, DOF_SIM_EUCLIDEAN = 2 /* also "edit" */ };
+enum { DOF_CLOSS_NCE = 0, DOF_CLOSS_DCL = 1, DOF_CLOSS_HARD_DCL = 2 /* "fc": not in this build */ };
+/* Row-normalises z / z_aug (B, L), evaluates the loss over all B x B pairs, writes d loss / d z and
+ * d loss / d z_aug (B, L; either may be NULL together = value only) and logs[DOF_LOG_TOTAL |
+ * DOF_LOG_POS_SIM | DOF_LOG_NEG_SIM].  Scratch comes from the plan's workspace. */
+int dof_contrastive_loss(DofVadePlan* plan, const float* z, const float* z_aug, int32_t similarity, int32_t loss_fn,
+                         float temperature, float tau, float beta, float* dz, float* dz_aug, float* logs,
+                         void* stream);
+
+/* Backward of the plan's last dof_contrastive_encode(train) from dz (B, L): encoder gradients into
+ * grads (accumulate == 0: overwritten, else added -- the second view accumulates onto the first). */
+int dof_contrastive_backward(DofVadePlan* plan, const float* params, const float* dz, float* grads,
+                             int32_t accumulate, void* stream);
 
 /* clip_grad_value_(hyper[DOF_H_CLIP]) + Adam(betas 0.9/0.999, eps 1e-8, weight decay hyper[DOF_H_WD]). */
 int dof_optimizer_step(DofVadePlan* plan, float* params, const float* grads, float* adam_m, float* adam_v,

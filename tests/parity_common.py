@@ -194,3 +194,85 @@ def run_vqvae_check(lib, device, golden_dir, tag):
         if k in eng.layout:
             np.testing.assert_allclose(eng.view(k).cpu().numpy(), v.numpy().reshape(eng.layout[k][2]), atol=5e-4,
                                        rtol=2e-3, err_msg=k)
+
+
+def aug_from_golden(d, pfx, device):
+    mask = d[pfx + "aug::rot_mask"]
+    return dict(start=torch.from_numpy(d[pfx + "aug::start"]).to(device),
+                rot_pivot=[int(v) for v in d[pfx + "aug::rot_pivot"]],
+                rot_nodes=[np.nonzero(m)[0].tolist() for m in mask],
+                theta=torch.from_numpy(d[pfx + "aug::theta"]).to(device),
+                interp_t0=torch.from_numpy(d[pfx + "aug::interp_t0"]).to(device),
+                interp_len=torch.from_numpy(d[pfx + "aug::interp_len"]).to(device),
+                noise=torch.from_numpy(d[pfx + "aug::noise"]).to(device))
+
+
+def run_contrastive_loss_check(lib, device, golden_dir, tag):
+    """Pairwise losses + gradients wrt both (unnormalised) embeddings vs the reference loss table."""
+    from deepof_amd.engine import VadeEngine
+    d = load_golden(golden_dir, f"contrastive_{tag}.npz")
+    z, za = torch.from_numpy(d["loss_z"]).to(device), torch.from_numpy(d["loss_za"]).to(device)
+    B, L = z.shape
+    eng = VadeEngine(lib, device, B, 12, d["adj"], L, 1, kind="contrastive")
+    for sim in ("cosine", "dot", "euclidean", "edit"):
+        for lf in ("nce", "dcl", "hard_dcl"):
+            dz, dza = eng.contrastive_loss(z, za, sim, lf, 0.1, 0.1, 0.1)
+            logs = eng.read_contrastive_logs()
+            ref = d[f"loss::{sim}::{lf}"]
+            np.testing.assert_allclose([logs["total_loss"], logs["pos_similarity"], logs["neg_similarity"]], ref,
+                                       rtol=2e-5, atol=2e-6, err_msg=f"{sim}/{lf}")
+            # the reference table differentiates wrt unit-norm inputs; the kernel adds the F.normalize
+            # backward (projection off the radial direction, norms are 1): compare against the projected grads
+            for got, g, v in ((dz, d[f"loss_grad::{sim}::{lf}"][0], z), (dza, d[f"loss_grad::{sim}::{lf}"][1], za)):
+                g = torch.from_numpy(g)
+                vc = v.cpu()
+                proj = g - (g * vc).sum(1, keepdim=True) * vc
+                np.testing.assert_allclose(got.cpu().numpy(), proj.numpy(), rtol=2e-4, atol=2e-6,
+                                           err_msg=f"{sim}/{lf}")
+    with np.testing.assert_raises(NotImplementedError):
+        eng.contrastive_loss(z, za, "cosine", "fc")
+
+
+def run_contrastive_check(lib, device, golden_dir, tag):
+    """Views (central + augmented, identical draws), embeddings, step logs and encoder gradients vs the reference."""
+    from deepof_amd.engine import VadeEngine, contrastive_views
+    d = load_golden(golden_dir, f"contrastive_{tag}.npz")
+    x_full = torch.from_numpy(d["x_full"]).to(device)
+    ei = torch.from_numpy(d["edge_index"]).to(device)
+    B, Tf, N, _ = x_full.shape
+    half = Tf // 2
+    for ci in range(3):
+        pfx = f"c{ci}::"
+        sim, lf = str(d[pfx + "sim"]), str(d[pfx + "loss_fn"])
+        L = d[pfx + "sd::encoder.final_dense.bias"].shape[0]
+        xc, ac = contrastive_views(lib, x_full, ei, None)
+        np.testing.assert_array_equal(xc.cpu().numpy(), d[pfx + "x"])
+        np.testing.assert_allclose(ac.cpu().numpy(), d[pfx + "a"], atol=1e-7)
+        xa, aa = contrastive_views(lib, x_full, ei, aug_from_golden(d, pfx, device))
+        np.testing.assert_allclose(xa.cpu().numpy(), d[pfx + "x_aug"], atol=2e-6)
+        np.testing.assert_allclose(aa.cpu().numpy(), d[pfx + "a_aug"], atol=3e-6)
+        e1 = VadeEngine(lib, device, B, half, d["adj"], L, 1, kind="contrastive")
+        e2 = VadeEngine(lib, device, B, half, d["adj"], L, 1, kind="contrastive", shared=e1)
+        e1.load_state_dict(params_from(d, pfx + "sd::"))
+        assert e1.names[0].startswith("encoder.") and all(n.startswith("encoder.") for n in e1.names)
+        z = e1.contrastive_encode(xc, ac, train=True)
+        z_aug = e2.contrastive_encode(xa, aa, train=True)
+        np.testing.assert_allclose(z.cpu().numpy(), d[pfx + "z"], atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(z_aug.cpu().numpy(), d[pfx + "z_aug"], atol=2e-5, rtol=1e-4)
+        dz, dza = e1.contrastive_loss(z, z_aug, sim, lf, 0.1, 0.1, 0.1)
+        logs = e1.read_contrastive_logs()
+        for k in ("total_loss", "pos_similarity", "neg_similarity"):
+            np.testing.assert_allclose(logs[k], float(d[pfx + f"log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=f"{ci}: {k}")
+        e1.contrastive_backward(dz, accumulate=False)
+        e2.contrastive_backward(dza, accumulate=True)
+        n = 0
+        for k in d:
+            if k.startswith(pfx + "grad::"):
+                name = k[len(pfx) + 6:]
+                g = e1.view(name, e1.grads).cpu().numpy()
+                np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=5e-5, rtol=1e-3, err_msg=f"{ci}: grad {name}")
+                n += 1
+        assert n >= 40
+        for name in e1.names:
+            if pfx + f"grad::{name}" not in d:
+                assert float(e1.view(name, e1.grads).abs().max()) == 0.0, name

@@ -41,3 +41,15 @@ def test_vade_train_trace_emu(golden_dir):
 @pytest.mark.parametrize("tag", ["rec14", "rec28"])
 def test_vqvae_emu(golden_dir, tag):
     run_vqvae_check(emu_lib(), "cpu", golden_dir, tag)
+
+
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+def test_contrastive_losses_emu(golden_dir, tag):
+    from parity_common import run_contrastive_loss_check
+    run_contrastive_loss_check(emu_lib(), "cpu", golden_dir, tag)
+
+
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+def test_contrastive_step_emu(golden_dir, tag):
+    from parity_common import run_contrastive_check
+    run_contrastive_check(emu_lib(), "cpu", golden_dir, tag)
