@@ -298,3 +298,77 @@ class VQVAE(VaDE):
             zs.append(out["ze"])
             qs.append(out["soft_counts"])
         return torch.cat(zs), torch.cat(qs)
+
+
+class Contrastive(VaDE):
+    """Contrastive embedding model with the reference's interface (models_new.py:1978-2075, ContrastivePT):
+    the recurrent encoder built for HALF windows (``window_size = T // 2``); ``state_dict`` = encoder.* only;
+    ``model(x_half, a_half)`` -> (B, latent_dim) embeddings.  Every batch size gets a pair of plans (central /
+    augmented view) that share the parameters."""
+
+    _KIND = "contrastive"
+
+    def __init__(self, input_shape, edge_feature_shape, adjacency_matrix, latent_dim: int = 8,
+                 encoder_type: str = "recurrent", use_gnn: bool = True, temperature: float = 0.1,
+                 similarity_function: str = "cosine", loss_function: str = "nce", beta: float = 0.1, tau: float = 0.1,
+                 interaction_regularization: float = 0.0, batch_size: int = 256, device=None, _engine_factory=None):
+        nn.Module.__init__(self)
+        if str(encoder_type).lower() != "recurrent":
+            raise NotImplementedError(f"encoder_type={encoder_type!r}: this build implements the recurrent encoder")
+        if not use_gnn:
+            raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
+        time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
+        if int(edge_feature_shape[0]) != time_steps:
+            raise ValueError(f"Node and edge time dims must match: T={time_steps}, Te={edge_feature_shape[0]}")
+        self.full_time_steps = time_steps
+        self.window_size = time_steps // 2  # the encoder sees half windows (room for the time-shift augmentation)
+        self.input_shape, self.edge_feature_shape = tuple(input_shape), tuple(edge_feature_shape)
+        self.input_n_nodes, self.input_n_features_per_node = n_nodes, n_feat
+        self.latent_dim, self.n_components = int(latent_dim), 1
+        self.encoder_type, self.use_gnn = "recurrent", True
+        self.temperature, self.similarity_function, self.loss_function = float(temperature), similarity_function, loss_function
+        self.beta, self.tau = float(beta), float(tau)
+        self.interaction_regularization = interaction_regularization
+        self.kmeans_weight = 0.0
+        self._adjacency = np.asarray(adjacency_matrix, dtype=np.float32)
+        self.adjacency_matrix = self._adjacency
+        self._factory = _engine_factory or (lambda **kw: create_vade_engine(device=device, **kw))
+        self._engines = {}
+        self._aug_engines = {}
+        self._base = self._make_engine(int(batch_size), None)
+        eng = self._base
+        self.encoder = _Box()
+        self.encoder.register_buffer("laplacian", torch.from_numpy(eng.lap.copy()))
+        self.encoder.register_buffer("edge_laplacian", torch.from_numpy(eng.elap.copy()))
+        self.encoder.register_buffer("incidence", torch.from_numpy(eng.inc.copy()))
+        for name in eng.names:
+            _attach(self, name, eng.view(name))
+        self.reset_parameters()
+
+    def aug_engine(self, batch: int) -> VadeEngine:
+        """Second plan/workspace of this batch size: holds the augmented view's activations until its backward."""
+        batch = int(batch)
+        if batch not in self._aug_engines:
+            self._aug_engines[batch] = self._make_engine(batch, self._base)
+        return self._aug_engines[batch]
+
+    def forward(self, x, a):
+        x = x.to(self.device, torch.float32).contiguous()
+        a = a.to(self.device, torch.float32).contiguous()
+        return self.engine(x.shape[0]).contrastive_encode(x, a, train=False)
+
+    @torch.no_grad()
+    def embed(self, x, a):
+        return self.forward(x, a)
+
+    def group(self, x, a):
+        raise NotImplementedError("the contrastive model has no cluster head (ContrastivePT defines none)")
+
+    set_pretrain_mode = None
+    get_gmm_params = None
+
+    @torch.no_grad()
+    def encode_windows(self, x, a, batch: int = 256):
+        """Embeddings of many HALF windows (model_utils_new.py:604-617 feeds the sliced centre of each window)."""
+        zs = [self.forward(x[s:s + batch], a[s:s + batch]) for s in range(0, x.shape[0], batch)]
+        return torch.cat(zs), None

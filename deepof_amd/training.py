@@ -23,7 +23,7 @@ import torch
 from . import _capi
 from .config import (CommonFitCfg, ContrastiveCfg, TurtleTeacherCfg, VaDECfg, cfg_lines, check_model_inputs)
 from .dataset import WindowDataset, n_batches
-from .models import VaDE, VQVAE
+from .models import Contrastive, VaDE, VQVAE
 from .schedules import WeightSchedule
 
 LOG_SUMMARY_KEYS = ("total_loss", "reconstruction_loss", "kl_divergence", "cat_cluster_loss", "kmeans_loss",
@@ -112,8 +112,13 @@ def build_model_from_spec(spec: dict, device=None, batch_size: int = 256, _engin
                      int(spec["latent_dim"]), int(spec["n_components"]),
                      encoder_type=spec.get("encoder_type", "recurrent"), use_gnn=bool(spec.get("use_gnn", True)),
                      batch_size=batch_size, device=device, _engine_factory=_engine_factory)
+    if name == "contrastive":
+        return Contrastive(tuple(spec["x_shape"]), tuple(spec["a_shape"]), np.asarray(spec["adjacency_matrix"]),
+                           int(spec["latent_dim"]), encoder_type=spec.get("encoder_type", "recurrent"),
+                           use_gnn=bool(spec.get("use_gnn", True)), batch_size=batch_size, device=device,
+                           _engine_factory=_engine_factory)
     if name != "vade":
-        raise NotImplementedError(f"checkpoint of model {name!r}: VaDE and VQ-VAE bundles are supported in this build")
+        raise NotImplementedError(f"checkpoint of model {name!r}: unknown model name")
     return VaDE(tuple(spec["x_shape"]), tuple(spec["a_shape"]), np.asarray(spec["adjacency_matrix"]),
                 int(spec["latent_dim"]), int(spec["n_components"]), encoder_type=spec.get("encoder_type", "recurrent"),
                 use_gnn=bool(spec.get("use_gnn", True)), kmeans_loss=float(spec.get("kmeans_loss", 0.0)),
@@ -133,6 +138,14 @@ def load_model_from_ckpt(path: str, device=None, _engine_factory=None):
 
 def _clone_model(model: VaDE) -> VaDE:
     """Independent copy (own parameter buffer) -- deepcopy() of the reference."""
+    if isinstance(model, Contrastive):
+        twin = Contrastive(model.input_shape, model.edge_feature_shape, model._adjacency, model.latent_dim,
+                           temperature=model.temperature, similarity_function=model.similarity_function,
+                           loss_function=model.loss_function, beta=model.beta, tau=model.tau,
+                           batch_size=model._base.B, _engine_factory=model._factory)
+        twin._base.params.copy_(model._base.params)
+        twin.train(model.training)
+        return twin
     twin = type(model)((model.window_size, model.input_n_nodes, 3), (model.window_size, model._base.E, 1),
                        model._adjacency, model.latent_dim, model.n_components, kmeans_loss=model.kmeans_weight,
                        batch_size=model._base.B, _engine_factory=model._factory)
@@ -548,6 +561,135 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
     return model_val, model_score, None, log_summary
 
 
+class ContrastiveStepper:
+    """One step of step_contrastive_distill (training.py:482-589) on the HIP path: both views of every window are
+    built by dof_contrastive_views, encoded by the two plans of the batch size, scored by the all-pairs loss
+    kernels, and back-propagated view by view into the shared gradient buffer."""
+
+    def __init__(self, model: Contrastive, edge_index: np.ndarray, edge_index_local: np.ndarray,
+                 cfg: ContrastiveCfg, seed: int = 0):
+        from .augment import build_rotation_precomp
+        self.model, self.cfg = model, cfg
+        self.lib = model._base.lib
+        self.edge_index = torch.from_numpy(np.ascontiguousarray(edge_index, dtype=np.int32)).to(model.device)
+        self.precomp = build_rotation_precomp(edge_index_local.tolist(), model.input_n_nodes)
+        self.gen = torch.Generator(device=model.device)
+        self.gen.manual_seed(int(seed))
+        self.host_gen = torch.Generator()
+        self.host_gen.manual_seed(int(seed))
+
+    def views(self, x_full: torch.Tensor, draws: dict = None):
+        from .augment import draw_augmentation
+        from .engine import contrastive_views
+        B, Tf, N, _ = x_full.shape
+        if draws is None:
+            draws = draw_augmentation(B, Tf, N, self.cfg, self.precomp, x_full.device, self.gen, self.host_gen)
+        st = self.model._base._stream()
+        x, a = contrastive_views(self.lib, x_full, self.edge_index, None, st)
+        xa, aa = contrastive_views(self.lib, x_full, self.edge_index, draws, st)
+        return x, a, xa, aa
+
+    def loss_grads(self, x_full: torch.Tensor, draws: dict = None, want_grads: bool = True):
+        """Fills the shared grads (if want_grads) and e.logs; returns the central-view engine."""
+        m = self.model
+        x_full = x_full.to(m.device, torch.float32).contiguous()
+        x, a, xa, aa = self.views(x_full, draws)
+        B = x_full.shape[0]
+        e1, e2 = m.engine(B), m.aug_engine(B)
+        z = e1.contrastive_encode(x, a, train=want_grads)
+        z_aug = e2.contrastive_encode(xa, aa, train=want_grads)
+        dz, dza = e1.contrastive_loss(z, z_aug, m.similarity_function, m.loss_function, m.temperature, m.tau, m.beta,
+                                      want_grads=want_grads)
+        if want_grads:
+            e1.contrastive_backward(dz, accumulate=False)
+            e2.contrastive_backward(dza, accumulate=True)
+        return e1
+
+
+def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, meta_info: dict,
+                    common_cfg: CommonFitCfg, teacher_cfg: TurtleTeacherCfg, contrastive_cfg: ContrastiveCfg,
+                    device=None, _engine_factory=None):
+    """training.py:1266-1520: Adam(lr, weight_decay 1e-4) on the encoder, clip 0.75, best-val checkpointing.  The
+    distillation head / alignment score need the TURTLE teacher (not built): trained without, as the reference does
+    when no teacher is available."""
+    from .augment import edge_index_from_meta
+    dist, rank, world = _dist_state()
+    is_main = rank == 0
+    if meta_info is None:
+        raise RuntimeError("meta_info (node_columns / edge_columns) is required for the contrastive augmentations")
+    model = Contrastive(train_ds.x_shape, train_ds.a_shape, adjacency_matrix, latent_dim=common_cfg.latent_dim,
+                        encoder_type=common_cfg.encoder_type, use_gnn=True,
+                        similarity_function=contrastive_cfg.contrastive_similarity_function,
+                        loss_function=contrastive_cfg.contrastive_loss_function,
+                        temperature=contrastive_cfg.temperature, beta=contrastive_cfg.beta, tau=contrastive_cfg.tau,
+                        batch_size=common_cfg.batch_size, device=device, _engine_factory=_engine_factory)
+    eng = model._base
+    if world > 1:
+        dist.broadcast(eng.params, src=0)
+    rebuild_spec = {"model_name": "contrastive", "x_shape": train_ds.x_shape, "a_shape": train_ds.a_shape,
+                    "adjacency_matrix": np.asarray(adjacency_matrix).astype("float32"),
+                    "latent_dim": common_cfg.latent_dim, "n_components": common_cfg.n_components,
+                    "encoder_type": common_cfg.encoder_type, "use_gnn": True,
+                    "interaction_regularization": common_cfg.interaction_regularization}
+    if teacher_cfg.use_turtle_teacher:
+        warnings.warn("TURTLE teacher distillation is not implemented in this build; training the contrastive model "
+                      "without the distillation head.", RuntimeWarning)
+    ei_g, ei_l = edge_index_from_meta(meta_info, train_ds.x_shape[1])
+    seed = common_cfg.seed if common_cfg.seed is not None else 0
+    stepper = ContrastiveStepper(model, ei_g, ei_l, contrastive_cfg, seed=seed + 7919 * rank)
+    eng.reset_optimizer()
+    for seg in range(_capi.SEG_COUNT):
+        eng.set_lr(seg, common_cfg.learning_rate)
+    eng.set_hyper(clip=0.75, wd=1e-4)
+    _, best_path_val, best_path_score, _ = ckpt_paths("contrastive", common_cfg)
+    best_val = float("inf")
+    log_summary = init_log_summary("contrastive")
+    nb = n_batches(len(train_ds), common_cfg.batch_size, world)
+    keys = ("total_loss", "pos_similarity", "neg_similarity", "distill_loss", "seperability")
+
+    def run_epoch(ds, train):
+        model.train(train)
+        acc = []
+        it = ds.iter_batches(common_cfg.batch_size, train, common_cfg.seed if train else None,
+                             world if train else 1, rank if train else 0)
+        for x, _a, _idx, _vid in it:
+            if train:
+                eng.advance_adam()
+            eng.push_hyper()
+            e = stepper.loss_grads(x, want_grads=train)
+            if train:
+                if world > 1:
+                    dist.all_reduce(e.grads, op=dist.ReduceOp.SUM)
+                    e.grads.mul_(1.0 / world)
+                e.optimizer_step()
+            acc.append(e.logs.clone())
+        if not acc:
+            return {k: float("nan") for k in keys}
+        m = torch.stack(acc).mean(dim=0).cpu().tolist()
+        return {"total_loss": m[0], "pos_similarity": m[_capi.LOG_POS_SIM], "neg_similarity": m[_capi.LOG_NEG_SIM],
+                "distill_loss": 0.0, "seperability": 0.0}
+
+    for epoch in range(common_cfg.epochs):
+        train_logs = run_epoch(train_ds, True)
+        val_logs = run_epoch(val_ds, False)
+        val_logs.update(alignment_score=float("nan"), conf_norm=float("nan"), bal_norm=float("nan"))
+        v_total = float(val_logs["total_loss"])
+        log_summary = _update_log_summary(log_summary, train_logs, val_logs)
+        if is_main:
+            print(f"Epoch {epoch + 1}/{common_cfg.epochs} | train total={train_logs['total_loss']:.4f} "
+                  f"pos={train_logs['pos_similarity']:.3f} neg={train_logs['neg_similarity']:.3f} | "
+                  f"val total={v_total:.4f}")
+        if v_total < best_val:
+            best_val = v_total
+            if common_cfg.save_weights and is_main:
+                save_model_info(best_path_val, stage="best_val", epoch=epoch, train_steps=(epoch + 1) * nb,
+                                val_total=v_total, common_cfg=common_cfg, teacher_cfg=teacher_cfg,
+                                contrastive_cfg=contrastive_cfg, model=model, log_summary=log_summary,
+                                rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
+    model_val, model_score = load_best_checkpoints(model, best_path_val, best_path_score, common_cfg.save_weights)
+    return model_val, model_score, None, log_summary
+
+
 # ------------------------------------------------------------------------------------------------
 # public API
 # ------------------------------------------------------------------------------------------------
@@ -568,10 +710,7 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
     torch.manual_seed(common_cfg.seed if common_cfg.seed is not None else 0)
     np.random.seed(common_cfg.seed if common_cfg.seed is not None else 0)
     model_name = common_cfg.model_name
-    if model_name == "contrastive":
-        raise NotImplementedError("model_name='contrastive': not built yet (SURVEY section 8a rows R12-R14); "
-                                  "this build implements VaDE and VQ-VAE with the recurrent encoder")
-    if model_name not in ("vade", "vqvae"):
+    if model_name not in ("vade", "vqvae", "contrastive"):
         raise ValueError(f"Unsupported model: {model_name}")
     dev = None
     if _engine_factory is None:
@@ -583,6 +722,9 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
     if model_name == "vqvae":
         return fit_VQVAE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
                          _engine_factory=_engine_factory)
+    if model_name == "contrastive":
+        return fit_contrastive(train_ds, val_ds, np.asarray(adjacency_matrix), meta_info, common_cfg, teacher_cfg,
+                               contrastive_cfg, device=dev, _engine_factory=_engine_factory)
     return fit_VADE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
                     _engine_factory=_engine_factory)
 

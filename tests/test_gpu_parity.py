@@ -18,7 +18,7 @@ def hip():
 def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == 2
+    assert hip.dof_abi_version() == 3
 
 
 def test_gather_gpu(hip):
@@ -244,3 +244,96 @@ def test_vqvae_full_size_c3(hip):
     agree = (out["idx"][:128].cpu().long() == ref["idx"]).float().mean()
     assert float(agree) >= 0.98          # argmin ties / near-ties may flip under fp32 reordering
     np.testing.assert_allclose(out["soft_counts"][:128].sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+def test_contrastive_parity_gpu(hip, golden_dir, tag):
+    from parity_common import run_contrastive_check, run_contrastive_loss_check
+    run_contrastive_loss_check(hip, "cuda", golden_dir, tag)
+    run_contrastive_check(hip, "cuda", golden_dir, tag)
+
+
+def test_contrastive_full_size_c4(hip):
+    """BASELINE config C4 shape (window 50 -> half 25, batch 8192 per rank, recurrent encoder): the step at full
+    size -- determinism, finiteness, loss bounds -- and view / loss parity against the CPU oracle on the same
+    draws (views: whole batch; loss: the oracle evaluated on the device embeddings)."""
+    from deepof_amd import graph as G
+    from deepof_amd.augment import build_rotation_precomp, draw_augmentation
+    from deepof_amd.config import ContrastiveCfg
+    from deepof_amd.engine import contrastive_views, create_vade_engine
+    from oracle import contrastive as OC
+    nodes, edges = G.bodypart_graph([""])
+    adj = G.adjacency_from_graph(nodes, edges)
+    ei, eil = G.edge_index_from_graph(nodes, edges)
+    B, Tf, L, N = 8192, 50, 8, len(nodes)
+    g = torch.Generator().manual_seed(0)
+    x_full = (torch.randn(B, Tf, N, 3, generator=g).cumsum(1) * 0.1).contiguous()
+    cfg = ContrastiveCfg(aug_p_rot=0.7, aug_p_noise=0.8, aug_p_interp=0.6)
+    pc = build_rotation_precomp(eil.tolist(), N)
+    draws = draw_augmentation(B, Tf, N, cfg, pc, "cpu", g, g)
+    xd, eid = x_full.cuda(), torch.from_numpy(ei).cuda()
+    x, a = contrastive_views(hip, xd, eid, None)
+    xa, aa = contrastive_views(hip, xd, eid, {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in draws.items()})
+    od = OC.AugDraws(start=draws["start"], rot_pivot=draws["rot_pivot"], rot_nodes=draws["rot_nodes"],
+                     theta=draws["theta"], interp_t0=draws["interp_t0"], interp_len=draws["interp_len"],
+                     noise=draws["noise"])
+    xo, ao = OC.augmented_view(x_full, torch.from_numpy(ei).long(), od)
+    np.testing.assert_allclose(xa.cpu().numpy(), xo.numpy(), atol=5e-6, rtol=1e-5)
+    np.testing.assert_allclose(aa.cpu().numpy(), ao.numpy(), atol=1e-5, rtol=1e-5)
+    xc, ac = OC.central_view(x_full, torch.from_numpy(ei).long())
+    assert torch.equal(x.cpu(), xc)
+    np.testing.assert_allclose(a.cpu().numpy(), ac.numpy(), atol=1e-6)
+    e1 = create_vade_engine(B, Tf // 2, adj, L, 1, kind="contrastive")
+    e2 = create_vade_engine(B, Tf // 2, adj, L, 1, kind="contrastive", shared=e1)
+    for n in e1.names:
+        shape = e1.layout[n][2]
+        v = torch.randn(shape, generator=g) * (0.3 if len(shape) > 1 else 0.1)
+        if "norm" in n and n.endswith("weight"):
+            v = 1.0 + v
+        e1.view(n).copy_(v)
+
+    def step():
+        z, za = e1.contrastive_encode(x, a, train=True), e2.contrastive_encode(xa, aa, train=True)
+        dz, dza = e1.contrastive_loss(z, za, "cosine", "nce", 0.1, 0.1, 0.1)
+        e1.contrastive_backward(dz, accumulate=False)
+        e2.contrastive_backward(dza, accumulate=True)
+        return z, za, e1.grads.clone(), e1.read_contrastive_logs()
+
+    z, za, g1, logs = step()
+    _, _, g2, _ = step()
+    assert torch.equal(g1, g2) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    assert 0.0 < logs["total_loss"] < np.log(B) + 1.0 / 0.1 * 2 and -1.0 <= logs["neg_similarity"] <= logs["pos_similarity"] <= 1.0
+    for sim, lf in (("cosine", "nce"), ("euclidean", "hard_dcl"), ("dot", "dcl")):
+        e1.contrastive_loss(z, za, sim, lf, 0.1, 0.1, 0.1, want_grads=False)
+        got = e1.read_contrastive_logs()
+        zn, zan = (torch.nn.functional.normalize(t.cpu().double(), dim=1) for t in (z, za))
+        lo, po, no = OC.contrastive_loss(zn, zan, sim, lf, 0.1, 0.1, 0.1)
+        np.testing.assert_allclose([got["total_loss"], got["pos_similarity"], got["neg_similarity"]],
+                                   [float(lo), float(po), float(no)], rtol=2e-4, atol=2e-5, err_msg=f"{sim}/{lf}")
+
+
+def test_contrastive_training_api_gpu(tmp_path):
+    """train_deepof_model(model_name='Contrastive') end to end on the device (product path, no emulator)."""
+    from deepof_amd import training as TR
+    from deepof_amd.models import Contrastive
+    rng = np.random.default_rng(0)
+    N, E, W = 5, 4, 16
+    names = [f"n{i}" for i in range(N)]
+    meta = {"node_columns": [(n, "x") for n in names] + [(n, "y") for n in names] + names,
+            "edge_columns": [(names[i], names[i + 1]) for i in range(E)]}
+    adj = np.zeros((N, N), np.float32)
+    for i in range(E):
+        adj[i, i + 1] = adj[i + 1, i] = 1
+    def pre(nv, nw, seed):
+        r = np.random.default_rng(seed)
+        return {f"v{v}": (np.cumsum(r.standard_normal((nw, W, 3 * N)), 1).astype(np.float32) * 0.3,
+                          r.standard_normal((nw, W, E)).astype(np.float32), np.zeros((nw, W, 0), np.float32))
+                for v in range(nv)}
+    mv, ms, mt, logs = TR.train_deepof_model(
+        preprocessed_object=(pre(2, 300, 1), pre(1, 100, 2)), adjacency_matrix=adj, meta_info=meta,
+        encoder_type="recurrent", batch_size=64, latent_dim=8, epochs=4, output_path=str(tmp_path), n_clusters=5,
+        model_name="Contrastive", use_turtle_teacher=False, save_weights=True, aug_p_rot=0.5, aug_p_noise=0.5,
+        aug_max_shift=3, aug_max_interp=4, aug_min_interp=2)
+    assert isinstance(mv, Contrastive) and len(logs["train"]["total_loss"]) == 4
+    assert logs["train"]["total_loss"][-1] < logs["train"]["total_loss"][0]
+    assert (tmp_path / "models" / "contrastive" / "run_0" / "best_model_val.pth").exists()

@@ -125,7 +125,7 @@ def test_input_validation_errors():
     with pytest.raises(ValueError):
         TR.train_deepof_model(**{**kw, "device": "tpu"})
     with pytest.raises(NotImplementedError):
-        TR.train_deepof_model(**{**kw, "model_name": "Contrastive"})
+        TR.train_deepof_model(**{**kw, "model_name": "Contrastive", "encoder_type": "TCN"})
     with pytest.raises(RuntimeError):   # product path: no CPU fallback
         TR.train_deepof_model(**{**kw, "device": "cpu", "_engine_factory": None})
 
@@ -253,3 +253,70 @@ def test_vqvae_model_and_fit(golden_dir, tmp_path):
     emb, soft = loaded.encode_windows(x, a)
     assert tuple(emb.shape) == (8, 4) and tuple(soft.shape) == (8, 6)
     np.testing.assert_allclose(emb.numpy(), mv.encode(x, a).numpy(), atol=1e-5)
+
+
+def test_augmentation_draws_and_rotation_precomp():
+    from deepof_amd import graph as G
+    from deepof_amd.augment import build_rotation_precomp, draw_augmentation, edge_index_from_meta
+    from deepof_amd.config import ContrastiveCfg
+    nodes, edges = G.bodypart_graph(["B", "W"])
+    meta = G.make_meta_info(nodes, edges)
+    ei, eil = edge_index_from_meta(meta, len(nodes))
+    g2, l2 = G.edge_index_from_graph(nodes, edges)
+    np.testing.assert_array_equal(ei, g2)
+    np.testing.assert_array_equal(eil, l2)
+    assert len(eil) == len(ei) - 4  # the four cross-animal edges are not "local"
+    pc = build_rotation_precomp(eil.tolist(), len(nodes))
+    assert len(pc.triplets) == len(pc.branches_a) == len(pc.branches_c) > 0
+    for (a, b, c), ba, bc in zip(pc.triplets, pc.branches_a, pc.branches_c):
+        assert a in ba and c in bc and b not in ba and b not in bc
+    cfg = ContrastiveCfg(aug_p_rot=1.0, aug_p_noise=1.0, aug_p_interp=1.0, aug_p_shift=1.0, aug_n_rot=4)
+    g = torch.Generator().manual_seed(3)
+    B, Tf = 64, 24
+    d = draw_augmentation(B, Tf, len(nodes), cfg, pc, "cpu", g, g)
+    half = Tf // 2
+    assert d["start"].min() >= 0 and d["start"].max() <= Tf - half and (d["start"] != half // 2).all()
+    assert len(d["rot_pivot"]) == 4 and max(np.bincount(d["rot_pivot"])) <= 2
+    assert tuple(d["theta"].shape) == (4, B) and float(d["theta"].abs().max()) <= np.pi / 6 + 1e-6
+    assert (d["interp_t0"] >= 1).all() and (d["interp_t0"] + d["interp_len"] <= half - 1).all()
+    assert (d["interp_len"] >= cfg.aug_min_interp).all()
+    nz = (d["noise"][..., :2] != 0).sum(-1)
+    assert (nz == 1).all() and tuple(d["noise"].shape) == (B, len(nodes), 3)
+    off = draw_augmentation(B, Tf, len(nodes), ContrastiveCfg(aug_p_shift=0.0, aug_p_interp=0.0), pc, "cpu", g, g)
+    assert (off["start"] == half // 2).all() and not off["rot_pivot"] and "noise" not in off
+    assert "interp_len" not in off
+
+
+def test_contrastive_model_and_fit(golden_dir, tmp_path):
+    from deepof_amd.models import Contrastive
+    d = load_golden(golden_dir, "contrastive_rec14.npz")
+    ref_keys = [k[8:] for k in d if k.startswith("c0::sd::")]
+    model = Contrastive((24, 14, 3), (24, 14, 1), d["adj"], latent_dim=8, batch_size=16, _engine_factory=emu_factory)
+    assert list(model.state_dict().keys()) == ref_keys and model.window_size == 12
+    model.load_state_dict({k: torch.from_numpy(d["c0::sd::" + k]) for k in ref_keys})
+    z = model(torch.from_numpy(d["c0::x"]), torch.from_numpy(d["c0::a"]))
+    np.testing.assert_allclose(z.numpy(), d["c0::z"], atol=1e-5, rtol=1e-4)
+    names = [f"n{i}" for i in range(4)]
+    meta = {"node_columns": [(n, "x") for n in names] + [(n, "y") for n in names] + names,
+            "edge_columns": [(names[i], names[i + 1]) for i in range(3)]}
+    pre_tr, pre_va = tiny_preprocessed(W=12, seed=5), tiny_preprocessed(n_videos=1, n_win=16, W=12, seed=6)
+    kw = dict(adjacency_matrix=chain_adj(4), encoder_type="recurrent", batch_size=8, latent_dim=4, epochs=3,
+              output_path=str(tmp_path), n_clusters=6, model_name="Contrastive", use_turtle_teacher=False,
+              save_weights=True, aug_p_rot=0.7, aug_p_noise=0.8, aug_max_interp=3, aug_min_interp=2, aug_max_shift=3,
+              _engine_factory=emu_factory)
+    with pytest.raises(RuntimeError, match="meta_info"):
+        TR.train_deepof_model(preprocessed_object=(pre_tr, pre_va), meta_info=None, **kw)
+    mv, ms, mt, logs = TR.train_deepof_model(preprocessed_object=(pre_tr, pre_va), meta_info=meta, **kw)
+    assert isinstance(mv, Contrastive) and mt is None and len(logs["train"]["total_loss"]) == 3
+    assert logs["train"]["total_loss"][-1] < logs["train"]["total_loss"][0]
+    assert np.isfinite(logs["val"]["total_loss"]).all()
+    ckpt = tmp_path / "models" / "contrastive" / "run_0" / "best_model_val.pth"
+    assert ckpt.exists()
+    loaded, *_ = TR.load_model_from_ckpt(str(ckpt), _engine_factory=emu_factory)
+    assert isinstance(loaded, Contrastive)
+    x = torch.from_numpy(reorder_and_reshape(pre_va["vid0"][0])[:8, 3:9]).contiguous()
+    a = torch.from_numpy(pre_va["vid0"][1][:8, 3:9, :, None]).contiguous()
+    np.testing.assert_allclose(loaded.embed(x, a).numpy(), mv.embed(x, a).numpy(), atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        TR.train_deepof_model(preprocessed_object=(pre_tr, pre_va), meta_info=meta,
+                              **{**kw, "contrastive_loss_function": "fc"})
