@@ -190,18 +190,21 @@ def contrastive_loss(z, z_aug, sim_kind="cosine", loss_fn="nce", temperature=0.1
 
 
 # ----------------------------------------------------------------------------- model + step
-def encode(P, x, a):
-    """ContrastivePT.forward = RecurrentEncoderPT on the half window (models_new.py:2069-2075)."""
+def encode(P, x, a, training=True):
+    """ContrastivePT.forward = the recurrent or the TCN encoder on the half window (models_new.py:2038-2075)."""
+    if "encoder.node_tcn.blocks.0.conv1.weight" in P:
+        from . import tcn as ot
+        return ot.tcn_encoder(x, a, P, training)
     return ov.encoder(x, a, P)
 
 
 def contrastive_step(P, x_full, edge_index, draws: AugDraws, sim_kind="cosine", loss_fn="nce", temperature=0.1,
-                     tau=0.1, beta=0.1):
+                     tau=0.1, beta=0.1, training=True):
     """training.py:482-589 without the distillation head.  Returns (total, logs, aux)."""
     x_aug, a_aug = augmented_view(x_full, edge_index, draws)
     x, a = central_view(x_full, edge_index)
-    z = encode(P, x, a)
-    z_aug = encode(P, x_aug, a_aug)
+    z = encode(P, x, a, training)
+    z_aug = encode(P, x_aug, a_aug, training)
     zn, zan = F.normalize(z, dim=1), F.normalize(z_aug, dim=1)
     loss, pos, neg = contrastive_loss(zn, zan, sim_kind, loss_fn, temperature, tau, beta)
     logs = {"total_loss": float(loss), "pos_similarity": float(pos), "neg_similarity": float(neg),
@@ -210,10 +213,12 @@ def contrastive_step(P, x_full, edge_index, draws: AugDraws, sim_kind="cosine", 
 
 
 def contrastive_grads(P, x_full, edge_index, draws, **kw):
+    buffers = ("laplacian", "edge_laplacian", "incidence", "running_mean", "running_var", "num_batches_tracked")
     leaves = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and k.startswith("encoder.") and
-                                                   k.split(".")[-1] not in ("laplacian", "edge_laplacian", "incidence"))
+                                                   k.split(".")[-1] not in buffers)
               for k, v in P.items()}
     loss, logs, aux = contrastive_step(leaves, x_full, edge_index, draws, **kw)
     names = [k for k, v in leaves.items() if v.requires_grad]
     gs = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    aux["buffers"] = {k: v.detach() for k, v in leaves.items() if k.split(".")[-1] in buffers[3:]}
     return logs, {k: g for k, g in zip(names, gs)}, aux

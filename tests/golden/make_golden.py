@@ -359,7 +359,7 @@ def _draws_from_calls(calls, ccfg, T_full, N, centers, branches_a, branches_c, n
                 noise=noise.numpy().astype(np.float32))
 
 
-def gen_contrastive(tag, ids, T_full, L, B, seed):
+def gen_contrastive(tag, ids, T_full, L, B, seed, encoder_type="recurrent", cases=None):
     """ContrastivePT (recurrent encoder on the half window) + step_contrastive_distill, RNG draws recorded."""
     from deepof_amd.graph import make_meta_info
     from oracle.contrastive import rotation_triplets
@@ -393,13 +393,18 @@ def gen_contrastive(tag, ids, T_full, L, B, seed):
             ga, gb = torch.autograd.grad(l_, [a_, b_])
             out[f"loss::{sim}::{lf}"] = np.array([float(l_), float(p_), float(n_)])
             out[f"loss_grad::{sim}::{lf}"] = np.stack([ga.numpy(), gb.numpy()])
-    for ci, (sim, lf) in enumerate([("cosine", "nce"), ("euclidean", "hard_dcl"), ("dot", "dcl")]):
+    for ci, (sim, lf) in enumerate(cases or [("cosine", "nce"), ("euclidean", "hard_dcl"), ("dot", "dcl")]):
         torch.manual_seed(seed + ci)
-        model = R.M.ContrastivePT((T_full, N, 3), (T_full, E, 1), adj, latent_dim=L, encoder_type="recurrent",
+        model = R.M.ContrastivePT((T_full, N, 3), (T_full, E, 1), adj, latent_dim=L, encoder_type=encoder_type,
                                   similarity_function=sim, loss_function=lf, temperature=0.1, beta=0.1, tau=0.1)
         ccfg = R.U.ContrastiveCfg(aug_n_rot=3, aug_p_rot=0.7, aug_p_noise=0.9, aug_p_interp=0.6)
         ctx = SimpleNamespace(apply_distill=False, edge_index=ei_g, edge_index_local=ei_l, contrastive_cfg=ccfg,
                               rot_precomp=pre)
+        opt = R.L.build_optimizer_generic(model, None, base_lr=1e-3, weight_decay=1e-4)  # before any forward (Q11)
+        if encoder_type != "recurrent":
+            model.eval()
+            R.U._materialize_encoder(model, (T_full // 2, N, 3), (T_full // 2, E, 1), torch.device("cpu"))
+            sd0 = sd_np(model, f"c{ci}::sd::")
         model.train()
         model.zero_grad(set_to_none=True)
         a_dummy = torch.zeros(B, T_full, E, 1)
@@ -438,15 +443,54 @@ def gen_contrastive(tag, ids, T_full, L, B, seed):
         st = (torch.ones(B) * half // 2).int()
         xc = R.U.slice_time_per_sample(xt, st, half)
         out[pfx + "x"], out[pfx + "a"] = xc.numpy(), R.U.recompute_edges(xc, ei_g).numpy()
-        with torch.no_grad():
-            out[pfx + "z"] = model(xc, R.U.recompute_edges(xc, ei_g)).numpy()
-            out[pfx + "z_aug"] = model(xa, aa).numpy()
-        out.update(sd_np(model, pfx + "sd::"))
+        if encoder_type == "recurrent":
+            with torch.no_grad():
+                out[pfx + "z"] = model(xc, R.U.recompute_edges(xc, ei_g)).numpy()
+                out[pfx + "z_aug"] = model(xa, aa).numpy()
+            out.update(sd_np(model, pfx + "sd::"))
+        else:
+            # BatchNorm: the train-mode embeddings depend on (and update) the running buffers -> replay on a copy
+            import copy
+            twin = copy.deepcopy(model)
+            twin.load_state_dict({k[len(pfx) + 4:]: torch.from_numpy(v) for k, v in sd0.items()})
+            twin.train()
+            with torch.no_grad():
+                out[pfx + "z"] = twin(xc, R.U.recompute_edges(xc, ei_g)).numpy()
+                out[pfx + "z_aug"] = twin(xa, aa).numpy()
+            out.update({k: v for k, v in sd_np(twin, pfx + "sd_after::").items()  # running statistics after
+                        if "running_" in k or "num_batches" in k})                    # the two forward passes
+            twin.load_state_dict({k[len(pfx) + 4:]: torch.from_numpy(v) for k, v in sd0.items()})
+            twin.eval()
+            with torch.no_grad():
+                out[pfx + "z_eval"] = twin(xc, R.U.recompute_edges(xc, ei_g)).numpy()
+            out.update(sd0)
         for k, v in res.logs.items():
             out[pfx + f"log::{k}"] = np.float64(v)
         for n, p_ in model.named_parameters():
             if p_.grad is not None:
                 out[pfx + f"grad::{n}"] = p_.grad.numpy().copy()
+        if encoder_type != "recurrent":
+            # finish optimiser step 1 on the recorded gradients, then one more full step (draws recorded again)
+            torch.nn.utils.clip_grad_value_(model.parameters(), 0.75)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            with _Recorder() as rec2:
+                res2 = R.T.step_contrastive_distill(model, (xt, a_dummy, torch.arange(B)), ctx)
+            res2.loss.backward()
+            torch.nn.utils.clip_grad_value_(model.parameters(), 0.75)
+            opt.step()
+            dr2 = _draws_from_calls(rec2.calls, ccfg, T_full, N, centers, ba, bc, len(trips))
+            for k, v in dr2.items():
+                if k == "rot_nodes":
+                    mask = np.zeros((len(v), N), dtype=np.int32)
+                    for r, nn_ in enumerate(v):
+                        mask[r, nn_] = 1
+                    out[pfx + "aug2::rot_mask"] = mask
+                else:
+                    out[pfx + "aug2::" + k] = v
+            for k, v in res2.logs.items():
+                out[pfx + f"log2::{k}"] = np.float64(v)
+            out.update(sd_np(model, pfx + "sd_step2::"))
     np.savez_compressed(os.path.join(HERE, f"contrastive_{tag}.npz"), **out)
 
 
@@ -462,6 +506,7 @@ if __name__ == "__main__":
     gen_vqvae("rec28", ["B", "W"], 12, 6, 20, 6, 51, kmeans=0.5)
     gen_contrastive("rec14", [""], 24, 8, 16, 61)
     gen_contrastive("rec28", ["B", "W"], 25, 6, 7, 71)
+    gen_contrastive("tcn14", [""], 24, 8, 6, 81, encoder_type="TCN", cases=[("cosine", "nce")])
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

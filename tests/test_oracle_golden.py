@@ -281,3 +281,34 @@ def test_rotation_triplets_choice():
     assert trips == [(0, 1, 2), (0, 1, 3), (2, 1, 3), (1, 3, 4)]
     assert ba[1] == [0] and bc[1] == [3, 4] and ba[3] == [0, 1, 2] and bc[3] == [4]
     assert OC.choose_rotations([0, 1, 2, 3], [t[1] for t in trips], 5, 3) == [0, 1, 3]
+
+
+def test_tcn_contrastive_matches_reference(golden_dir):
+    """TCN encoder (R12) inside the contrastive step: train-mode embeddings, BatchNorm running buffers, eval-mode
+    embeddings, loss and every gradient; then the two recorded optimiser steps (CensNet frozen, quirk Q11)."""
+    from oracle import contrastive as OC
+    from oracle import tcn as OT
+    d = _load(golden_dir, "contrastive_tcn14.npz")
+    pfx = "c0::"
+    x_full = torch.from_numpy(d["x_full"])
+    eit = torch.from_numpy(d["edge_index"]).long()
+    P = _params(d, pfx + "sd::")
+    with torch.no_grad():
+        z_eval = OT.tcn_encoder(torch.from_numpy(d[pfx + "x"]), torch.from_numpy(d[pfx + "a"]),
+                                {k: v.clone() for k, v in P.items()}, False)
+    np.testing.assert_allclose(z_eval.numpy(), d[pfx + "z_eval"], atol=2e-6, rtol=1e-5)
+    logs, grads, aux = OC.contrastive_grads(P, x_full, eit, _aug_draws(d, pfx), sim_kind="cosine", loss_fn="nce")
+    np.testing.assert_allclose(aux["z"].detach().numpy(), d[pfx + "z"], atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(aux["z_aug"].detach().numpy(), d[pfx + "z_aug"], atol=3e-6, rtol=1e-5)
+    for k, v in aux["buffers"].items():
+        np.testing.assert_allclose(v.numpy(), d[pfx + "sd_after::" + k], atol=1e-6, rtol=1e-5, err_msg=k)
+    for k in ("total_loss", "pos_similarity", "neg_similarity"):
+        np.testing.assert_allclose(logs[k], float(d[pfx + f"log::{k}"]), rtol=2e-5, atol=2e-6, err_msg=k)
+    n = 0
+    for k in d:
+        if k.startswith(pfx + "grad::"):
+            name = k[len(pfx) + 6:]
+            # (conv biases feeding a BatchNorm have an exactly-zero true gradient: pure rounding noise there)
+            np.testing.assert_allclose(grads[name].numpy(), d[k], atol=6e-5, rtol=5e-4, err_msg=name)
+            n += 1
+    assert n == 196
