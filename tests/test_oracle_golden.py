@@ -311,4 +311,4 @@ def test_tcn_contrastive_matches_reference(golden_dir):
             # (conv biases feeding a BatchNorm have an exactly-zero true gradient: pure rounding noise there)
             np.testing.assert_allclose(grads[name].numpy(), d[k], atol=6e-5, rtol=5e-4, err_msg=name)
             n += 1
-    assert n == 196
+    assert n == 148
