@@ -354,6 +354,11 @@ __global__ void __launch_bounds__(64) k_cl_finalize(ClArgs A) {
   }
 }
 
+__global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ p, float v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 // (B, L) reference layout <-> [L][Bp] workspace layout
 template <int L>
 __global__ void __launch_bounds__(256) k_cl_export(const float* __restrict__ enc, float* __restrict__ z, int64_t B,

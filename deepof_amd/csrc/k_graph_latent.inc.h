@@ -43,9 +43,8 @@ __global__ void __launch_bounds__(256) k_cens_dots(const float* __restrict__ X, 
   dots[s] = acc;
 }
 
-template <int L>
+template <int L, int D>
 __global__ void __launch_bounds__(256) k_cens_fwd(CensStream A, CensStream Bs, float* __restrict__ flat, int64_t Bp) {
-  constexpr int D = 2 * L;
   const CensStream& P = blockIdx.y ? Bs : A;
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= P.S) return;
@@ -92,10 +91,9 @@ struct CensBwdStream {
   int flat_row0;
 };
 
-template <int L>
+template <int L, int D>
 __global__ void __launch_bounds__(256) k_cens_bwd1(CensBwdStream A, CensBwdStream Bs, const float* __restrict__ dflat,
                                                    int64_t Bp) {
-  constexpr int D = 2 * L;
   const CensBwdStream& P = blockIdx.y ? Bs : A;
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= P.S) return;
@@ -117,9 +115,8 @@ __global__ void __launch_bounds__(256) k_cens_bwd1(CensBwdStream A, CensBwdStrea
   }
 }
 
-template <int L>
+template <int L, int D>
 __global__ void __launch_bounds__(256) k_cens_bwd2(CensBwdStream A, CensBwdStream Bs) {
-  constexpr int D = 2 * L;
   const CensBwdStream& P = blockIdx.y ? Bs : A;
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= P.S) return;

@@ -1,0 +1,611 @@
+// Temporal convolutional encoder and the BatchNorm MLP head.
+//
+// Reference semantics restated here (/root/reference/deepof/clustering/models_new.py):
+//   * TemporalBlockPT :376-443  causal pad -> Conv1d(k=4, dilation d, bias) -> BatchNorm1d(eps 1e-3, batch
+//     statistics in train mode, momentum 0.1) -> ReLU, twice; residual (1x1 conv on the first block);
+//     out = ReLU(a2 + res); skip = a2
+//   * TCN1DPT :446-506          8 blocks, dilations 1,2,4,8,1,2,4,8; ReLU(sum of skips) at the last time step
+//   * TCNEncoderPT head :593-657  x / max(rms(x), 1) -> clamp +-1e4 -> Linear -> ReLU -> BN(momentum 0.01) ->
+//     Linear -> ReLU -> BN -> Linear
+//
+// Mapping.  Activations are channel-minor [t][s][32] (s = window*G + group, padded to 64), so one time
+// step of 16 neighbouring sequences is a contiguous 2 KB run.  A 32->32 dilated convolution is a GEMM with
+// K = 4 taps x 32 channels: one wave owns 16 (t, s) rows, keeps the whole 128x32 weight matrix in 64 VGPRs
+// as the B operand of v_mfma_f32_16x16x4_f32 and streams the four tap rows as the A operand (each lane
+// loads 8 consecutive channels = 32 B, four lanes cover a 128-byte row).  BatchNorm needs statistics over
+// every sequence and time step, i.e. a grid-wide reduction between a convolution and its activation: the
+// convolution writes the pre-normalisation tensor plus per-wave channel sums, a tiny kernel turns the sums
+// into per-channel (scale, shift), and the CONSUMER applies scale/shift + ReLU while loading -- the
+// activated tensor makes no extra HBM round trip in the forward pass.  The same kernel with the taps
+// reversed and the weights transposed is the data-gradient; weight gradients go through the strided MFMA
+// reduction in k_reduce.hip.
+#include "dof_rt.h"
+#include "launchers.h"
+
+namespace {
+
+constexpr int TC = 32;  // conv_filters
+constexpr int TK = 4;   // kernel_size
+
+// per-layer BatchNorm record bnp[4][C]: batch (or running) mean, rstd, scale = gamma*rstd, shift = beta - mean*scale
+#define BNP_MEAN(p, C, c) (p)[(c)]
+#define BNP_RSTD(p, C, c) (p)[(C) + (c)]
+#define BNP_SCALE(p, C, c) (p)[2 * (C) + (c)]
+#define BNP_SHIFT(p, C, c) (p)[3 * (C) + (c)]
+
+// ---------------------------------------------------------------------------------------------
+// Block 0, conv1: scrambled read of the window tensor + Conv1d(F -> 32, k=4, dilation d) + bias.
+// ---------------------------------------------------------------------------------------------
+template <int F>
+__global__ void __launch_bounds__(256) k_tcn_in_conv(const float* __restrict__ xin,  // (B,T,G,F) reference layout
+                                                     const float* __restrict__ w,    // (32,F,4)
+                                                     const float* __restrict__ bias, float* __restrict__ xs,  // [T][Sp][F]
+                                                     float* __restrict__ y,          // [T][Sp][32]
+                                                     float* __restrict__ partial,    // [nblk][64]
+                                                     int T, int G, int64_t S, int64_t Sp, int dil) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float st[2 * TC];
+#pragma unroll
+  for (int c = 0; c < 2 * TC; ++c) st[c] = 0.0f;
+  if (i < (int64_t)T * S) {
+    const int to = (int)(i / S);
+    const int64_t s = i - (int64_t)to * S;
+    const int64_t b = s / G;
+    const int g = (int)(s - b * G);
+    const float* __restrict__ win = xin + b * (int64_t)T * G * F;
+    const dof_cfp wc = dof_cw(w);
+    float rows[TK][F];
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      const int tt = to - (TK - 1 - k) * dil;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        float v = 0.0f;
+        if (tt >= 0) {  // y[b,g,tt,f] = x[b, t, cc] with cc*T + t = (f*T + tt)*G + g   (models_new.py:616-619)
+          const int lin = (f * T + tt) * G + g;
+          const int cc = lin / T;
+          v = win[(int64_t)(lin - cc * T) * G * F + cc];
+        }
+        rows[k][f] = v;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) xs[ACT(to, f, F, Sp, s)] = rows[TK - 1][f];
+    float out[TC];
+#pragma unroll
+    for (int o = 0; o < TC; ++o) {
+      float acc = dof_cw(bias)[o];
+#pragma unroll
+      for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int k = 0; k < TK; ++k) acc = fmaf(wc[(o * F + f) * TK + k], rows[k][f], acc);
+      out[o] = acc;
+      st[o] = acc;
+      st[TC + o] = acc * acc;
+    }
+    dof_st_row<TC>(y + ACT(to, 0, TC, Sp, s), out);
+  }
+  dof_block_colsum<2 * TC>(st, partial + (int64_t)blockIdx.x * 2 * TC);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 32 -> 32 dilated convolution on the matrix cores.
+//   REVERSE = false: y[t] = bias + sum_j W[:, :, j] in[t - (3-j) d]           (+ channel sums of y, y^2)
+//   REVERSE = true : out[t] (+)= sum_j W[:, :, j]^T in[t + (3-j) d]           (data gradient)
+//   BN_IN: the loaded rows are pre-normalisation values; scale/shift + ReLU is applied on the fly and the
+//          activated own row (tap offset 0) is stored to a_out for the backward pass.
+// ---------------------------------------------------------------------------------------------
+struct TcnConvArgs {
+  const float* in;      // [T][Sp][32]
+  const float* w;       // (32,32,4)
+  const float* bias;    // (32) or null
+  const float* bnp_in;  // BatchNorm record of the producer (BN_IN)
+  float* a_out;         // [T][Sp][32] activated input (BN_IN, forward only) or null
+  float* out;           // [T][Sp][32]
+  float* partial;       // [n_waves][64] channel sums (forward) or null
+  int T, dil, accumulate;
+  int64_t S, Sp;
+};
+
+template <bool REVERSE, bool BN_IN>
+__global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  // B operand: k-step (tap j, q) covers input channels {kk*8 + q}; lane (kk, col) holds the weight that
+  // multiplies channel kk*8+q of tap j for output column ct*16+col.
+  float wr[TK][8][2];
+#pragma unroll
+  for (int j = 0; j < TK; ++j)
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int cin = kk * 8 + q, col = ct * 16 + i;
+        wr[j][q][ct] = REVERSE ? A.w[(cin * TC + col) * TK + j] : A.w[(col * TC + cin) * TK + j];
+      }
+  float sc[8], sh[8];
+  if (BN_IN) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      sc[q] = BNP_SCALE(A.bnp_in, TC, kk * 8 + q);
+      sh[q] = BNP_SHIFT(A.bnp_in, TC, kk * 8 + q);
+    }
+  }
+  const float b0 = (!REVERSE && A.bias) ? A.bias[i] : 0.0f;
+  const float b1 = (!REVERSE && A.bias) ? A.bias[16 + i] : 0.0f;
+  float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
+  const int64_t tiles_per_t = A.Sp / 16;
+  const int64_t n_tiles = (int64_t)A.T * tiles_per_t;
+  for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+    const int t = (int)(tile / tiles_per_t);
+    const int64_t s0 = (tile - (int64_t)t * tiles_per_t) * 16;
+    dof_f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      const int tt = REVERSE ? t + (TK - 1 - j) * A.dil : t - (TK - 1 - j) * A.dil;
+      float a[8];
+      if (tt >= 0 && tt < A.T) {  // wave-uniform
+        dof_ld_row<8>(A.in + ACT(tt, kk * 8, TC, A.Sp, s0 + i), a);
+        if (BN_IN) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a[q] = fmaxf(fmaf(a[q], sc[q], sh[q]), 0.0f);
+          if (!REVERSE && j == TK - 1 && A.a_out && s0 + i < A.S) dof_st_row<8>(A.a_out + ACT(t, kk * 8, TC, A.Sp, s0 + i), a);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wr[j][q][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wr[j][q][1], acc1, 0, 0, 0);
+        }
+      }
+    }
+    // D layout: lane holds rows kk*4 + r, column i (of column tile 0 / 1)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t s = s0 + kk * 4 + r;
+      if (s < A.S) {
+        float* o = A.out + ACT(t, 0, TC, A.Sp, s);
+        float v0 = acc0[r], v1 = acc1[r];
+        if (REVERSE && A.accumulate) {
+          v0 += o[i];
+          v1 += o[16 + i];
+        }
+        o[i] = v0;
+        o[16 + i] = v1;
+        if (!REVERSE) {
+          s1[0] += v0; s2[0] = fmaf(v0, v0, s2[0]);
+          s1[1] += v1; s2[1] = fmaf(v1, v1, s2[1]);
+        }
+      }
+    }
+  }
+  if (!REVERSE && A.partial) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      s1[ct] += __shfl_xor(s1[ct], 16); s1[ct] += __shfl_xor(s1[ct], 32);
+      s2[ct] += __shfl_xor(s2[ct], 16); s2[ct] += __shfl_xor(s2[ct], 32);
+    }
+    if (kk == 0) {
+      float* p = A.partial + (int64_t)wave * 2 * TC;
+      p[i] = s1[0]; p[16 + i] = s1[1];
+      p[TC + i] = s2[0]; p[TC + 16 + i] = s2[1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping (shared by the TCN layers, C = 32, and the head, C = 2L / L)
+// ---------------------------------------------------------------------------------------------
+// sums[2][C] = (sum x, sum x^2) over `count` samples  ->  bnp; train: running buffers updated in place
+__global__ void __launch_bounds__(64) k_bn_fwd_fin(const float* __restrict__ sums, float count,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                                   int train, float* __restrict__ bnp, int C) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (train) {
+    mean = sums[c] / count;
+    var = fmaxf(sums[C + c] / count - mean * mean, 0.0f);
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * (count / fmaxf(count - 1.0f, 1.0f));
+  } else {
+    mean = rmean[c];
+    var = rvar[c];
+  }
+  const float rstd = 1.0f / sqrtf(var + 1e-3f);
+  const float scale = gamma[c] * rstd;
+  BNP_MEAN(bnp, C, c) = mean;
+  BNP_RSTD(bnp, C, c) = rstd;
+  BNP_SCALE(bnp, C, c) = scale;
+  BNP_SHIFT(bnp, C, c) = beta[c] - mean * scale;
+}
+
+// sums[2][C] = (sum g, sum g*xhat): gamma / beta gradients and the two batch means of the input gradient
+__global__ void __launch_bounds__(64) k_bn_bwd_fin(const float* __restrict__ sums, float count,
+                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                   int accumulate, float* __restrict__ coef, int C) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const float sg = sums[c], sgx = sums[C + c];
+  dbeta[c] = accumulate ? dbeta[c] + sg : sg;
+  dgamma[c] = accumulate ? dgamma[c] + sgx : sgx;
+  coef[c] = sg / count;
+  coef[C + c] = sgx / count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block tail: a2 = ReLU(BN2(y2)); res = previous block output (or the 1x1 conv of the raw input on block 0);
+// out = ReLU(a2 + res); skip-sum += a2; on the last block the last-step features ReLU(skip-sum) leave in
+// the [c][s] layout the CensNet kernels read.
+// ---------------------------------------------------------------------------------------------
+struct TcnCombineArgs {
+  const float* y2;
+  const float* bnp2;
+  const float* res;    // [T][Sp][32] previous block output, or null on block 0
+  const float* xs;     // [T][Sp][F] raw input (block 0)
+  const float *dsw, *dsb;  // (32,F,1), (32)
+  float* out;          // [T][Sp][32] or null (last block: unused by the reference)
+  float* skip;         // [T][Sp][32] running sum
+  float* feat;         // [32][Sp] or null
+  int first, T, F;
+  int64_t S, Sp;
+};
+
+__global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)A.T * A.S) return;
+  const int t = (int)(i / A.S);
+  const int64_t s = i - (int64_t)t * A.S;
+  float y[TC], r[TC], sk[TC];
+  dof_ld_row<TC>(A.y2 + ACT(t, 0, TC, A.Sp, s), y);
+  if (A.res) {
+    dof_ld_row<TC>(A.res + ACT(t, 0, TC, A.Sp, s), r);
+  } else {
+    float xin[3];
+    for (int f = 0; f < A.F; ++f) xin[f] = A.xs[ACT(t, f, A.F, A.Sp, s)];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      float acc = A.dsb[c];
+      for (int f = 0; f < A.F; ++f) acc = fmaf(A.dsw[c * A.F + f], xin[f], acc);
+      r[c] = acc;
+    }
+  }
+  if (!A.first) dof_ld_row<TC>(A.skip + ACT(t, 0, TC, A.Sp, s), sk);
+#pragma unroll
+  for (int c = 0; c < TC; ++c) {
+    const float a2 = fmaxf(fmaf(y[c], BNP_SCALE(A.bnp2, TC, c), BNP_SHIFT(A.bnp2, TC, c)), 0.0f);
+    sk[c] = A.first ? a2 : sk[c] + a2;
+    r[c] = fmaxf(a2 + r[c], 0.0f);
+  }
+  dof_st_row<TC>(A.skip + ACT(t, 0, TC, A.Sp, s), sk);
+  if (A.out) dof_st_row<TC>(A.out + ACT(t, 0, TC, A.Sp, s), r);
+  if (A.feat && t == A.T - 1) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c) A.feat[(int64_t)c * A.Sp + s] = fmaxf(sk[c], 0.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward through ReLU + BatchNorm of one layer, pass 1: g = upstream * [a > 0], channel sums of g, g*xhat.
+//   upstream = din (+ block-level terms when `blk`): din masked by the block output, plus the gradient of
+//   the last-step features at t = T-1; the masked din is also the residual-branch gradient (stored to gres).
+// ---------------------------------------------------------------------------------------------
+struct TcnBnBwd1Args {
+  const float* din;     // [T][Sp][32] or null
+  const float* y;       // pre-normalisation tensor of this layer
+  const float* bnp;
+  float* g;             // [T][Sp][32] out
+  float* partial;       // [nblk][64]
+  // block-level (BN2) extras
+  const float* out_blk; // block output (mask of din) or null
+  const float* dfeat;   // [32][Sp] gradient of the last-step features or null
+  const float* skip;    // final skip-sum (mask of dfeat)
+  float* gres;          // [T][Sp][32] masked din (gradient entering the residual branch) or null
+  int blk, T;
+  int64_t S, Sp;
+};
+
+__global__ void __launch_bounds__(256) k_tcn_bn_bwd1(TcnBnBwd1Args A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float st[2 * TC];
+#pragma unroll
+  for (int c = 0; c < 2 * TC; ++c) st[c] = 0.0f;
+  if (i < (int64_t)A.T * A.S) {
+    const int t = (int)(i / A.S);
+    const int64_t s = i - (int64_t)t * A.S;
+    float d[TC], y[TC];
+    if (A.din) {
+      dof_ld_row<TC>(A.din + ACT(t, 0, TC, A.Sp, s), d);
+    } else {
+#pragma unroll
+      for (int c = 0; c < TC; ++c) d[c] = 0.0f;
+    }
+    if (A.blk) {
+      if (A.out_blk) {
+        float o[TC];
+        dof_ld_row<TC>(A.out_blk + ACT(t, 0, TC, A.Sp, s), o);
+#pragma unroll
+        for (int c = 0; c < TC; ++c) d[c] = o[c] > 0.0f ? d[c] : 0.0f;
+      }
+      if (A.gres) dof_st_row<TC>(A.gres + ACT(t, 0, TC, A.Sp, s), d);
+      if (A.dfeat && t == A.T - 1) {
+        float sk[TC];
+        dof_ld_row<TC>(A.skip + ACT(t, 0, TC, A.Sp, s), sk);
+#pragma unroll
+        for (int c = 0; c < TC; ++c) d[c] += sk[c] > 0.0f ? A.dfeat[(int64_t)c * A.Sp + s] : 0.0f;
+      }
+    }
+    dof_ld_row<TC>(A.y + ACT(t, 0, TC, A.Sp, s), y);
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      const float a = fmaf(y[c], BNP_SCALE(A.bnp, TC, c), BNP_SHIFT(A.bnp, TC, c));
+      const float g = a > 0.0f ? d[c] : 0.0f;
+      const float xh = (y[c] - BNP_MEAN(A.bnp, TC, c)) * BNP_RSTD(A.bnp, TC, c);
+      d[c] = g;
+      st[c] = g;
+      st[TC + c] = g * xh;
+    }
+    dof_st_row<TC>(A.g + ACT(t, 0, TC, A.Sp, s), d);
+  }
+  dof_block_colsum<2 * TC>(st, A.partial + (int64_t)blockIdx.x * 2 * TC);
+}
+
+// pass 2: dy = scale * (g - mean(g) - xhat * mean(g*xhat)), in place
+__global__ void __launch_bounds__(256) k_tcn_bn_bwd2(float* __restrict__ g, const float* __restrict__ y,
+                                                     const float* __restrict__ bnp, const float* __restrict__ coef,
+                                                     int T, int64_t S, int64_t Sp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)T * S) return;
+  const int t = (int)(i / S);
+  const int64_t s = i - (int64_t)t * S;
+  float d[TC], yv[TC];
+  dof_ld_row<TC>(g + ACT(t, 0, TC, Sp, s), d);
+  dof_ld_row<TC>(y + ACT(t, 0, TC, Sp, s), yv);
+#pragma unroll
+  for (int c = 0; c < TC; ++c) {
+    const float xh = (yv[c] - BNP_MEAN(bnp, TC, c)) * BNP_RSTD(bnp, TC, c);
+    d[c] = BNP_SCALE(bnp, TC, c) * (d[c] - coef[c] - xh * coef[TC + c]);
+  }
+  dof_st_row<TC>(g + ACT(t, 0, TC, Sp, s), d);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Head: [c][Bp] tensors, one thread per window
+// ---------------------------------------------------------------------------------------------
+// hn = x / max(rms(x), 1), clamped to +-1e4; rinv[b] = 1 / max(rms, 1); flag[b] = rms > 1
+__global__ void __launch_bounds__(256) k_head_rms(const float* __restrict__ flat, float* __restrict__ hn,
+                                                  float* __restrict__ rinv, int J, int64_t B, int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float ss = 0.0f;
+  for (int j = 0; j < J; ++j) {
+    const float v = flat[(int64_t)j * Bp + b];
+    ss = fmaf(v, v, ss);
+  }
+  const float rms = sqrtf(ss / (float)J);
+  const float r = 1.0f / fmaxf(rms, 1.0f);
+  rinv[b] = rms > 1.0f ? r : -1.0f;  // sign = "the scale is constant" marker for the backward pass
+  for (int j = 0; j < J; ++j) hn[(int64_t)j * Bp + b] = fminf(fmaxf(flat[(int64_t)j * Bp + b] * r, -1e4f), 1e4f);
+}
+
+// out[o][b] = act(bias[o] + sum_i W[o][i] * bn(in[i][b])); thread = (b, o = blockIdx.y); optional channel sums
+__global__ void __launch_bounds__(256) k_head_dense(const float* __restrict__ in, const float* __restrict__ bnp_in,
+                                                    float* __restrict__ in_norm, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                    float* __restrict__ partial, int CI, int relu, int64_t B,
+                                                    int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  float st[2] = {0.0f, 0.0f};
+  if (b < B) {
+    const dof_cfp wr = dof_cw(w) + (int64_t)o * CI;
+    float acc = dof_cw(bias)[o];
+    for (int i = 0; i < CI; ++i) {
+      float v = in[(int64_t)i * Bp + b];
+      if (bnp_in) {
+        v = fmaf(v, BNP_SCALE(bnp_in, CI, i), BNP_SHIFT(bnp_in, CI, i));
+        if (o == 0) in_norm[(int64_t)i * Bp + b] = v;
+      }
+      acc = fmaf(wr[i], v, acc);
+    }
+    if (relu) acc = fmaxf(acc, 0.0f);
+    out[(int64_t)o * Bp + b] = acc;
+    st[0] = acc;
+    st[1] = acc * acc;
+  }
+  if (partial) dof_block_colsum<2>(st, partial + ((int64_t)o * gridDim.x + blockIdx.x) * 2);
+}
+
+// partial[(o*nblk + blk)*2 + k] -> sums[k*C + o]   (fixed order)
+__global__ void __launch_bounds__(64) k_head_sum(const float* __restrict__ partial, int nblk, float* __restrict__ sums,
+                                                 int C) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float a = 0.0f, q = 0.0f;
+  for (int k = 0; k < nblk; ++k) {
+    a += partial[((int64_t)c * nblk + k) * 2];
+    q += partial[((int64_t)c * nblk + k) * 2 + 1];
+  }
+  sums[c] = a;
+  sums[C + c] = q;
+}
+
+// din[i][b] = sum_o W[o][i] dout[o][b]; thread = (b, i = blockIdx.y)
+__global__ void __launch_bounds__(256) k_head_dense_bwd(const float* __restrict__ dout, const float* __restrict__ w,
+                                                        float* __restrict__ din, int CI, int CO, int64_t B,
+                                                        int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int i = blockIdx.y;
+  float acc = 0.0f;
+  for (int o = 0; o < CO; ++o) acc = fmaf(dof_cw(w)[(int64_t)o * CI + i], dout[(int64_t)o * Bp + b], acc);
+  din[(int64_t)i * Bp + b] = acc;
+}
+
+// BatchNorm backward over the batch, pass 1: sums of g and g*xhat (h = BN input = post-ReLU activation)
+__global__ void __launch_bounds__(256) k_head_bn_bwd1(const float* __restrict__ g, const float* __restrict__ h,
+                                                      const float* __restrict__ bnp, float* __restrict__ partial,
+                                                      int C, int64_t B, int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  float st[2] = {0.0f, 0.0f};
+  if (b < B) {
+    const float gv = g[(int64_t)c * Bp + b];
+    st[0] = gv;
+    st[1] = gv * (h[(int64_t)c * Bp + b] - BNP_MEAN(bnp, C, c)) * BNP_RSTD(bnp, C, c);
+  }
+  dof_block_colsum<2>(st, partial + ((int64_t)c * gridDim.x + blockIdx.x) * 2);
+}
+
+// pass 2 + ReLU of the producing Linear: dpre = scale*(g - c1 - xhat*c2) * [h > 0]
+__global__ void __launch_bounds__(256) k_head_bn_bwd2(const float* __restrict__ g, const float* __restrict__ h,
+                                                      const float* __restrict__ bnp, const float* __restrict__ coef,
+                                                      float* __restrict__ dpre, int C, int64_t B, int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int c = blockIdx.y;
+  const float hv = h[(int64_t)c * Bp + b];
+  const float xh = (hv - BNP_MEAN(bnp, C, c)) * BNP_RSTD(bnp, C, c);
+  const float d = BNP_SCALE(bnp, C, c) * (g[(int64_t)c * Bp + b] - coef[c] - xh * coef[C + c]);
+  dpre[(int64_t)c * Bp + b] = hv > 0.0f ? d : 0.0f;
+}
+
+// backward of hn = x * r(x): dflat = r * (dhn - hn * (dhn . hn) / J) when rms > 1, else dhn
+__global__ void __launch_bounds__(256) k_head_rms_bwd(const float* __restrict__ dhn, const float* __restrict__ hn,
+                                                      const float* __restrict__ rinv, float* __restrict__ dflat, int J,
+                                                      int64_t B, int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float r = rinv[b];
+  if (r < 0.0f) {
+    for (int j = 0; j < J; ++j) dflat[(int64_t)j * Bp + b] = dhn[(int64_t)j * Bp + b];
+    return;
+  }
+  float dot = 0.0f;
+  for (int j = 0; j < J; ++j) dot = fmaf(dhn[(int64_t)j * Bp + b], hn[(int64_t)j * Bp + b], dot);
+  dot /= (float)J;
+  for (int j = 0; j < J; ++j)
+    dflat[(int64_t)j * Bp + b] = r * (dhn[(int64_t)j * Bp + b] - hn[(int64_t)j * Bp + b] * dot);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int64_t dof_tcn_row_blocks(int T, int64_t S) { return dof_cdiv((int64_t)T * S, 256); }
+int64_t dof_tcn_conv_waves(int T, int64_t Sp) {
+  const int64_t tiles = (int64_t)T * (Sp / 16);
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return blocks * 4;
+}
+
+int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float* bias, float* xs, float* y,
+                           float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st) {
+  const unsigned nb = (unsigned)dof_tcn_row_blocks(T, S);
+  if (F == 3) {
+    DOF_LAUNCH((k_tcn_in_conv<3>), (nb), (256), st, xin, w, bias, xs, y, partial, T, G, S, Sp, dil);
+  } else if (F == 1) {
+    DOF_LAUNCH((k_tcn_in_conv<1>), (nb), (256), st, xin, w, bias, xs, y, partial, T, G, S, Sp, dil);
+  } else {
+    dof_set_error("features per group %d not supported (3 or 1)", F);
+    return DOF_ERR_UNSUPPORTED;
+  }
+  return dof_check_launch("k_tcn_in_conv");
+}
+
+int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
+                        float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
+                        hipStream_t st) {
+  TcnConvArgs A;
+  A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
+  A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
+  const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
+  if (reverse) {
+    DOF_LAUNCH((k_tcn_conv<true, false>), (nb), (256), st, A);
+  } else if (bnp_in) {
+    DOF_LAUNCH((k_tcn_conv<false, true>), (nb), (256), st, A);
+  } else {
+    DOF_LAUNCH((k_tcn_conv<false, false>), (nb), (256), st, A);
+  }
+  return dof_check_launch("k_tcn_conv");
+}
+
+int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
+                          float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st) {
+  DOF_LAUNCH(k_bn_fwd_fin, (1), (64), st, sums, count, gamma, beta, rmean, rvar, momentum, train, bnp, C);
+  return dof_check_launch("k_bn_fwd_fin");
+}
+
+int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,
+                          int C, hipStream_t st) {
+  DOF_LAUNCH(k_bn_bwd_fin, (1), (64), st, sums, count, dgamma, dbeta, accumulate, coef, C);
+  return dof_check_launch("k_bn_bwd_fin");
+}
+
+int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
+                           const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int64_t S,
+                           int64_t Sp, hipStream_t st) {
+  TcnCombineArgs A;
+  A.y2 = y2; A.bnp2 = bnp2; A.res = res; A.xs = xs; A.dsw = dsw; A.dsb = dsb; A.out = out; A.skip = skip;
+  A.feat = feat; A.first = first; A.T = T; A.F = F; A.S = S; A.Sp = Sp;
+  DOF_LAUNCH(k_tcn_combine, ((unsigned)dof_tcn_row_blocks(T, S)), (256), st, A);
+  return dof_check_launch("k_tcn_combine");
+}
+
+int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, int blk,
+                           const float* out_blk, const float* dfeat, const float* skip, float* gres, int T, int64_t S,
+                           int64_t Sp, hipStream_t st) {
+  TcnBnBwd1Args A;
+  A.din = din; A.y = y; A.bnp = bnp; A.g = g; A.partial = partial; A.blk = blk; A.out_blk = out_blk; A.dfeat = dfeat;
+  A.skip = skip; A.gres = gres; A.T = T; A.S = S; A.Sp = Sp;
+  DOF_LAUNCH(k_tcn_bn_bwd1, ((unsigned)dof_tcn_row_blocks(T, S)), (256), st, A);
+  return dof_check_launch("k_tcn_bn_bwd1");
+}
+
+int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int64_t S, int64_t Sp,
+                           hipStream_t st) {
+  DOF_LAUNCH(k_tcn_bn_bwd2, ((unsigned)dof_tcn_row_blocks(T, S)), (256), st, g, y, bnp, coef, T, S, Sp);
+  return dof_check_launch("k_tcn_bn_bwd2");
+}
+
+int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st) {
+  DOF_LAUNCH(k_head_rms, (dof_cdiv(B, 256)), (256), st, flat, hn, rinv, J, B, Bp);
+  return dof_check_launch("k_head_rms");
+}
+
+int dof_launch_head_dense(const float* in, const float* bnp_in, float* in_norm, const float* w, const float* bias,
+                          float* out, float* partial, float* sums, int CI, int CO, int relu, int64_t B, int64_t Bp,
+                          hipStream_t st) {
+  const unsigned nb = dof_cdiv(B, 256);
+  DOF_LAUNCH(k_head_dense, (nb, (unsigned)CO), (256), st, in, bnp_in, in_norm, w, bias, out, partial, CI, relu, B, Bp);
+  if (partial) DOF_LAUNCH(k_head_sum, (1), (64), st, (const float*)partial, (int)nb, sums, CO);
+  return dof_check_launch("k_head_dense");
+}
+
+int dof_launch_head_dense_bwd(const float* dout, const float* w, float* din, int CI, int CO, int64_t B, int64_t Bp,
+                              hipStream_t st) {
+  DOF_LAUNCH(k_head_dense_bwd, (dof_cdiv(B, 256), (unsigned)CI), (256), st, dout, w, din, CI, CO, B, Bp);
+  return dof_check_launch("k_head_dense_bwd");
+}
+
+int dof_launch_head_bn_bwd(const float* g, const float* h, const float* bnp, float* partial, float* sums, float* coef,
+                           float* dgamma, float* dbeta, int accumulate, float* dpre, int C, int64_t B, int64_t Bp,
+                           hipStream_t st) {
+  const unsigned nb = dof_cdiv(B, 256);
+  DOF_LAUNCH(k_head_bn_bwd1, (nb, (unsigned)C), (256), st, g, h, bnp, partial, C, B, Bp);
+  DOF_LAUNCH(k_head_sum, (1), (64), st, (const float*)partial, (int)nb, sums, C);
+  DOF_LAUNCH(k_bn_bwd_fin, (1), (64), st, (const float*)sums, (float)B, dgamma, dbeta, accumulate, coef, C);
+  DOF_LAUNCH(k_head_bn_bwd2, (nb, (unsigned)C), (256), st, g, h, bnp, (const float*)coef, dpre, C, B, Bp);
+  return dof_check_launch("k_head_bn_bwd");
+}
+
+int dof_launch_head_rms_bwd(const float* dhn, const float* hn, const float* rinv, float* dflat, int J, int64_t B,
+                            int64_t Bp, hipStream_t st) {
+  DOF_LAUNCH(k_head_rms_bwd, (dof_cdiv(B, 256)), (256), st, dhn, hn, rinv, dflat, J, B, Bp);
+  return dof_check_launch("k_head_rms_bwd");
+}

@@ -32,6 +32,38 @@ int dof_launch_enc_final_fwd(int L, const float* O2, const int* len, const float
 int dof_launch_zero(float* p, int64_t n, hipStream_t st);
 int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t n, hipStream_t st);
 
+// ---- k_tcn.hip ---------------------------------------------------------------------------------
+int64_t dof_tcn_row_blocks(int T, int64_t S);   // partial rows written by the row-per-thread kernels
+int64_t dof_tcn_conv_waves(int T, int64_t Sp);  // partial rows written by the MFMA convolution (one per wave)
+int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float* bias, float* xs, float* y,
+                           float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st);
+int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
+                        float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
+                        hipStream_t st);
+int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
+                          float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st);
+int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,
+                          int C, hipStream_t st);
+int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
+                           const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int64_t S,
+                           int64_t Sp, hipStream_t st);
+int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, int blk,
+                           const float* out_blk, const float* dfeat, const float* skip, float* gres, int T, int64_t S,
+                           int64_t Sp, hipStream_t st);
+int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int64_t S, int64_t Sp,
+                           hipStream_t st);
+int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st);
+int dof_launch_head_dense(const float* in, const float* bnp_in, float* in_norm, const float* w, const float* bias,
+                          float* out, float* partial, float* sums, int CI, int CO, int relu, int64_t B, int64_t Bp,
+                          hipStream_t st);
+int dof_launch_head_dense_bwd(const float* dout, const float* w, float* din, int CI, int CO, int64_t B, int64_t Bp,
+                              hipStream_t st);
+int dof_launch_head_bn_bwd(const float* g, const float* h, const float* bnp, float* partial, float* sums, float* coef,
+                           float* dgamma, float* dbeta, int accumulate, float* dpre, int C, int64_t B, int64_t Bp,
+                           hipStream_t st);
+int dof_launch_head_rms_bwd(const float* dhn, const float* hn, const float* rinv, float* dflat, int J, int64_t B,
+                            int64_t Bp, hipStream_t st);
+
 // ---- k_reduce.hip ---------------------------------------------------------------------------
 // Weight-gradient reductions: out[i][j] = sum_{t,s} A[t][i][s] * B[t+shift][j][s] as fp32 MFMA
 // (16x16x4) tiles over SoA operands, many jobs per launch, per-block partials + fixed-order

@@ -62,6 +62,21 @@ namespace {
 struct ParamEntry {
   std::string name;
   int64_t off, numel;
+  std::vector<int64_t> shape;  // filled for the TCN family (the host derives the recurrent shapes from the names)
+};
+
+struct TcnBlockOff {  // one TemporalBlockPT: conv / BatchNorm (weight, bias, running mean / var) twice, 1x1 residual conv
+  int64_t c1w, c1b, g1, b1, rm1, rv1, c2w, c2b, g2, b2, rm2, rv2, dsw, dsb;
+};
+struct TcnWs {  // float offsets of one stream's TCN buffers ([T][Sp][32] unless noted)
+  int64_t xs;                           // [T][Sp][F] scrambled raw input
+  int64_t y1[8], a1[8], y2[8], out[8];  // pre-BN conv outputs, activated conv2 input, block outputs
+  int64_t skip;                         // running / final skip sum
+  int64_t g1[8], g2[8];                 // d loss / d (pre-BN conv output): A operands of the weight-gradient jobs
+  int64_t dout[2], da;                  // ping-pong block-output gradients, conv2 input gradient
+  int64_t bnp[16];                      // per-layer BatchNorm records [4][32]
+  int64_t partial, sums, coef;
+  int64_t partial_rows;
 };
 
 struct GruOff { int64_t t[8]; };  // wih, whh, bih, bhh, then the _reverse four
@@ -102,7 +117,7 @@ struct JobSet {  // one launch of the MFMA weight-gradient reduction + its final
 
 struct DofVadePlan {
   DofVadeDims d;
-  int kind = 0;  // 0 = VaDE (GMM latent), 1 = VQ-VAE (codebook of K codes), 2 = contrastive (encoder only)
+  int kind = 0;  // 0 = VaDE, 1 = VQ-VAE, 2 = contrastive (recurrent encoder only), 3 = contrastive (TCN encoder only)
   int L, K, T, N, E, S, J, C3;
   int64_t B, Bp;
   std::vector<ParamEntry> params;
@@ -127,6 +142,13 @@ struct DofVadePlan {
   int64_t partials, segs_tab, mask_tab;
   int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks;  // contrastive loss scratch
+  // TCN encoder (kind 3)
+  int D = 0;  // CensNet input channels: 2L (recurrent blocks) or 32 (TCN features)
+  TcnBlockOff tblk[2][8];
+  TcnWs tw[2];
+  int64_t h0w, h0b, h2g, h2b, h2rm, h2rv, h3w, h3b, h5g, h5b, h5rm, h5rv, h6w, h6b;
+  int64_t hd_hn, hd_rinv, hd_h1, hd_n1, hd_h2, hd_n2, hd_bnp1, hd_bnp2, hd_partial, hd_sums, hd_coef;
+  int64_t hd_dn2, hd_dpre2, hd_dn1, hd_dpre1, hd_dhn;
   int64_t ws_floats = 0;
   // tables built at bind: encoder side, decoder fed from ws.z (latent / quantised) or ws.enc (raw z_e), Gram
   JobSet js_enc, js_dec[2], js_gram;
@@ -145,9 +167,70 @@ struct Carver {
 };
 
 void add_param(DofVadePlan* p, const std::string& name, int64_t numel, int64_t* off) {
-  p->params.push_back({name, p->param_total, numel});
+  p->params.push_back({name, p->param_total, numel, {}});
   if (off) *off = p->param_total;
   p->param_total += numel;
+}
+
+void add_shaped(DofVadePlan* p, const std::string& name, std::vector<int64_t> shape, int64_t* off) {
+  int64_t n = 1;
+  for (int64_t d : shape) n *= d;
+  add_param(p, name, n, off);
+  p->params.back().shape = std::move(shape);
+}
+
+// ContrastivePT(encoder_type="TCN").state_dict() order (models_new.py:376-601); BatchNorm running buffers sit in
+// the same flat buffer (never touched by the optimiser), num_batches_tracked is kept by the host.
+void build_tcn_param_layout(DofVadePlan* p) {
+  const int L = p->L, C = 32;
+  const char* tn[2] = {"encoder.node_tcn", "encoder.edge_tcn"};
+  const int F[2] = {3, 1};
+  p->seg_lo[DOF_SEG_ENCODER] = 0;
+  for (int s = 0; s < 2; ++s)
+    for (int b = 0; b < 8; ++b) {
+      TcnBlockOff& o = p->tblk[s][b];
+      const std::string pre = std::string(tn[s]) + ".blocks." + std::to_string(b);
+      const int cin = b == 0 ? F[s] : C;
+      add_shaped(p, pre + ".conv1.weight", {C, cin, 4}, &o.c1w);
+      add_shaped(p, pre + ".conv1.bias", {C}, &o.c1b);
+      add_shaped(p, pre + ".bn1.weight", {C}, &o.g1);
+      add_shaped(p, pre + ".bn1.bias", {C}, &o.b1);
+      add_shaped(p, pre + ".bn1.running_mean", {C}, &o.rm1);
+      add_shaped(p, pre + ".bn1.running_var", {C}, &o.rv1);
+      add_shaped(p, pre + ".conv2.weight", {C, C, 4}, &o.c2w);
+      add_shaped(p, pre + ".conv2.bias", {C}, &o.c2b);
+      add_shaped(p, pre + ".bn2.weight", {C}, &o.g2);
+      add_shaped(p, pre + ".bn2.bias", {C}, &o.b2);
+      add_shaped(p, pre + ".bn2.running_mean", {C}, &o.rm2);
+      add_shaped(p, pre + ".bn2.running_var", {C}, &o.rv2);
+      o.dsw = o.dsb = -1;
+      if (b == 0) {
+        add_shaped(p, pre + ".downsample.weight", {C, cin, 1}, &o.dsw);
+        add_shaped(p, pre + ".downsample.bias", {C}, &o.dsb);
+      }
+    }
+  add_shaped(p, "encoder.spatial_gnn_block.node_kernel", {C, L}, &p->c_nk);
+  add_shaped(p, "encoder.spatial_gnn_block.edge_kernel", {C, L}, &p->c_ek);
+  add_shaped(p, "encoder.spatial_gnn_block.node_weights", {C, 1}, &p->c_nw);
+  add_shaped(p, "encoder.spatial_gnn_block.edge_weights", {C, 1}, &p->c_ew);
+  add_shaped(p, "encoder.spatial_gnn_block.node_bias", {L}, &p->c_nb);
+  add_shaped(p, "encoder.spatial_gnn_block.edge_bias", {L}, &p->c_eb);
+  add_shaped(p, "encoder.head.0.weight", {2 * L, p->J}, &p->h0w);
+  add_shaped(p, "encoder.head.0.bias", {2 * L}, &p->h0b);
+  add_shaped(p, "encoder.head.2.weight", {2 * L}, &p->h2g);
+  add_shaped(p, "encoder.head.2.bias", {2 * L}, &p->h2b);
+  add_shaped(p, "encoder.head.2.running_mean", {2 * L}, &p->h2rm);
+  add_shaped(p, "encoder.head.2.running_var", {2 * L}, &p->h2rv);
+  add_shaped(p, "encoder.head.3.weight", {L, 2 * L}, &p->h3w);
+  add_shaped(p, "encoder.head.3.bias", {L}, &p->h3b);
+  add_shaped(p, "encoder.head.5.weight", {L}, &p->h5g);
+  add_shaped(p, "encoder.head.5.bias", {L}, &p->h5b);
+  add_shaped(p, "encoder.head.5.running_mean", {L}, &p->h5rm);
+  add_shaped(p, "encoder.head.5.running_var", {L}, &p->h5rv);
+  add_shaped(p, "encoder.head.6.weight", {L, L}, &p->h6w);
+  add_shaped(p, "encoder.head.6.bias", {L}, &p->h6b);
+  p->seg_hi[DOF_SEG_ENCODER] = p->param_total;
+  for (int sg = DOF_SEG_DECODER; sg < DOF_SEG_COUNT; ++sg) p->seg_lo[sg] = p->seg_hi[sg] = p->param_total;
 }
 
 void add_gru(DofVadePlan* p, const std::string& prefix, int in, int hid, GruOff* g) {
@@ -161,6 +244,7 @@ void add_gru(DofVadePlan* p, const std::string& prefix, int in, int hid, GruOff*
 }
 
 void build_param_layout(DofVadePlan* p) {
+  if (p->kind == 3) return build_tcn_param_layout(p);
   const int L = p->L, N = p->N, E = p->E, K = p->K;
   const char* bn[2] = {"encoder.node_recurrent_block", "encoder.edge_recurrent_block"};
   const int F[2] = {3, 1};
@@ -261,7 +345,94 @@ void build_triplets(DofVadePlan* p, const float* lap, const float* elap, const f
   }
 }
 
+void take_triplets(DofVadePlan* p, Carver& cv, int s) {
+  StreamWs& w = p->sw[s];
+  for (int k = 0; k < 3; ++k) {
+    const TripHost& th = p->tri[s][k];
+    int64_t* dst = k == 0 ? w.tri_r : k == 1 ? w.tri_m : w.tri_o;
+    dst[0] = cv.take((int64_t)th.ptr.size());
+    dst[1] = cv.take((int64_t)th.m.size() + 1);
+    dst[2] = cv.take((int64_t)th.o.size() + 1);
+    dst[3] = cv.take((int64_t)th.r.size() + 1);
+    dst[4] = cv.take((int64_t)th.coef.size() + 1);
+  }
+}
+
+void build_tcn_workspace_layout(DofVadePlan* p) {
+  const int L = p->L, T = p->T, D = p->D;
+  Carver cv;
+  for (int s = 0; s < 2; ++s) {
+    StreamWs& w = p->sw[s];
+    TcnWs& t = p->tw[s];
+    w.G = s == 0 ? p->N : p->E;
+    w.F = s == 0 ? 3 : 1;
+    w.S = p->B * w.G;
+    w.Sp = dof_pad64(w.S);
+    const int64_t Sp = w.Sp, act = (int64_t)T * Sp * 32;
+    t.xs = cv.take((int64_t)T * Sp * w.F);
+    for (int b = 0; b < 8; ++b) {
+      t.y1[b] = cv.take(act); t.a1[b] = cv.take(act); t.y2[b] = cv.take(act);
+      t.out[b] = b < 7 ? cv.take(act) : 0;
+      t.g1[b] = cv.take(act); t.g2[b] = cv.take(act);
+    }
+    t.skip = cv.take(act);
+    t.dout[0] = cv.take(act); t.dout[1] = cv.take(act); t.da = cv.take(act);
+    for (int k = 0; k < 16; ++k) t.bnp[k] = cv.take(4 * 32);
+    const int64_t rows = dof_tcn_row_blocks(T, w.S), waves = dof_tcn_conv_waves(T, Sp);
+    t.partial_rows = rows > waves ? rows : waves;
+    t.partial = cv.take(t.partial_rows * 64);
+    t.sums = cv.take(64);
+    t.coef = cv.take(64);
+    // CensNet operands
+    w.n2 = cv.take((int64_t)D * Sp);
+    w.dn2 = cv.take((int64_t)D * Sp);
+    w.dots = cv.take(Sp);
+    w.Y = cv.take((int64_t)D * Sp);
+    w.Z = cv.take((int64_t)L * Sp);
+    w.dZ = cv.take((int64_t)L * Sp);
+    w.dY = cv.take((int64_t)D * Sp);
+    w.dd = cv.take(Sp);
+    take_triplets(p, cv, s);
+  }
+  const int64_t Bp = p->Bp;
+  p->flat = cv.take((int64_t)p->J * Bp);
+  p->enc = cv.take((int64_t)L * Bp);
+  p->denc = cv.take((int64_t)L * Bp);
+  p->dflat = cv.take((int64_t)p->J * Bp);
+  p->lat_blocks = dof_cdiv(p->B, 256);
+  p->cl_blocks = p->lat_blocks;
+  p->cl_zn = cv.take(2 * p->B * L);
+  p->cl_inv = cv.take(2 * p->B);
+  p->cl_rn = cv.take(2 * p->B);
+  p->cl_rowstat = cv.take(4 * p->B);
+  p->cl_partial = cv.take(3 * p->cl_blocks);
+  p->hd_hn = cv.take((int64_t)p->J * Bp);
+  p->hd_rinv = cv.take(Bp);
+  p->hd_h1 = cv.take(2LL * L * Bp);
+  p->hd_n1 = cv.take(2LL * L * Bp);
+  p->hd_h2 = cv.take((int64_t)L * Bp);
+  p->hd_n2 = cv.take((int64_t)L * Bp);
+  p->hd_bnp1 = cv.take(8 * L);
+  p->hd_bnp2 = cv.take(4 * L);
+  p->hd_partial = cv.take(2LL * L * p->lat_blocks * 2);
+  p->hd_sums = cv.take(4 * L);
+  p->hd_coef = cv.take(4 * L);
+  p->hd_dn2 = cv.take((int64_t)L * Bp);
+  p->hd_dpre2 = cv.take((int64_t)L * Bp);
+  p->hd_dn1 = cv.take(2LL * L * Bp);
+  p->hd_dpre1 = cv.take(2LL * L * Bp);
+  p->hd_dhn = cv.take((int64_t)p->J * Bp);
+  for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+    js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
+    js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
+  }
+  p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
+  p->mask_tab = cv.take(p->param_total);
+  p->ws_floats = cv.cur;
+}
+
 void build_workspace_layout(DofVadePlan* p) {
+  if (p->kind == 3) return build_tcn_workspace_layout(p);
   const int L = p->L, T = p->T, K = p->K, S = p->S;
   Carver cv;
   for (int s = 0; s < 2; ++s) {
@@ -297,15 +468,7 @@ void build_workspace_layout(DofVadePlan* p) {
     w.ln1p = cv.take(w.ln1_blocks * 8 * L);
     w.ln2p = cv.take(w.ln2_blocks * 4 * L);
     w.wg1 = cv.take(L == 8 ? dof_gru16_wg_floats(w.S) : 0);
-    for (int k = 0; k < 3; ++k) {
-      const TripHost& th = p->tri[s][k];
-      int64_t* dst = k == 0 ? w.tri_r : k == 1 ? w.tri_m : w.tri_o;
-      dst[0] = cv.take((int64_t)th.ptr.size());
-      dst[1] = cv.take((int64_t)th.m.size() + 1);
-      dst[2] = cv.take((int64_t)th.o.size() + 1);
-      dst[3] = cv.take((int64_t)th.r.size() + 1);
-      dst[4] = cv.take((int64_t)th.coef.size() + 1);
-    }
+    take_triplets(p, cv, s);
   }
   const int64_t Bp = p->Bp;
   p->flat = cv.take((int64_t)p->J * Bp);
@@ -463,7 +626,90 @@ void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int
   }
 }
 
+// CensNet weight gradients of stream s (shared by both encoder families; D input channels)
+void cens_jobs(DofVadePlan* p, JobBuilder& jb, int s) {
+  const int L = p->L, D = p->D;
+  float* ws = p->ws;
+  const StreamWs& w = p->sw[s];
+  const int64_t Sp = w.Sp;
+  const int64_t kern = s == 0 ? p->c_nk : p->c_ek, bias = s == 0 ? p->c_nb : p->c_eb;
+  const int64_t dotw = s == 0 ? p->c_nw : p->c_ew;
+  // kernel (D,L) = sum Y (x) dZ ; bias = rowsum dZ ; dot weights (D,1) = sum X (x) dd
+  int job = jb.add_job(soa(ws + w.Y, Sp), D, 1, Sp);
+  jb.add_tile(job, soa(ws + w.dZ, Sp), L, 0);
+  jb.add_fin(job, 0, D, L, D, D, kern, L, 1);
+  job = jb.add_job(soa(ws + w.dZ, Sp), L, 1, Sp);
+  jb.add_tile(job, soa(ws + w.dZ, Sp), 1, 0);
+  jb.add_fin(job, 64, L, 1, L, L, bias, 1, 1);
+  job = jb.add_job(soa(ws + w.n2, Sp), D, 1, Sp);
+  jb.add_tile(job, soa(ws + w.dd, Sp), 1, 0);
+  jb.add_fin(job, 0, D, 1, D, D, dotw, 1, 1);
+}
+
+const int kTcnDil[8] = {1, 2, 4, 8, 1, 2, 4, 8};
+
+void build_tcn_jobs(DofVadePlan* p) {
+  const int L = p->L, T = p->T, C = 32;
+  float* ws = p->ws;
+  const int64_t Bp = p->Bp;
+  JobBuilder jb(p->js_enc);
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const TcnWs& t = p->tw[s];
+    const int64_t Sp = w.Sp;
+    for (int b = 0; b < 8; ++b) {
+      const TcnBlockOff& o = p->tblk[s][b];
+      const int d = kTcnDil[b];
+      // one convolution: dW[o][c][j] = sum dy[t][o] * in[t - (3-j) d][c] ; db = sum dy
+      auto conv = [&](const float* dy, const float* in, int cin, int64_t wOff, int64_t bOff) {
+        int job = -1;
+        bool bias_done = false;
+        for (int j = 0; j < 4; ++j)
+          for (int c0 = 0; c0 < cin; c0 += 16) {
+            if (job < 0 || jb.jobs[job].n_tiles == 4) {
+              job = jb.add_job(aos(dy, C, Sp), C, T, Sp);
+              if (!bias_done) jb.add_fin(job, 64, C, 1, C, C, bOff, 1, 1);
+              bias_done = true;
+            }
+            const int nc = cin - c0 < 16 ? cin - c0 : 16;
+            const int tl = jb.add_tile(job, aos(in, cin, Sp, c0), nc, -(3 - j) * d);
+            jb.add_fin(job, tl * 16, C, nc, C, C, wOff + (int64_t)c0 * 4 + j, (int64_t)cin * 4, 4);
+          }
+      };
+      conv(ws + t.g1[b], b == 0 ? ws + t.xs : ws + t.out[b - 1], b == 0 ? w.F : C, o.c1w, o.c1b);
+      conv(ws + t.g2[b], ws + t.a1[b], C, o.c2w, o.c2b);
+      if (b == 0) {  // 1x1 residual conv: A = gradient entering the residual branch of block 0 (left in dout[1])
+        const int job = jb.add_job(aos(ws + t.dout[1], C, Sp), C, T, Sp);
+        const int tl = jb.add_tile(job, aos(ws + t.xs, w.F, Sp), w.F, 0);
+        jb.add_fin(job, tl * 16, C, w.F, C, C, o.dsw, w.F, 1);
+        jb.add_fin(job, 64, C, 1, C, C, o.dsb, 1, 1);
+      }
+    }
+    cens_jobs(p, jb, s);
+  }
+  // head: Linear(J -> 2L), Linear(2L -> L), Linear(L -> L)
+  for (int r0 = 0; r0 < p->J; r0 += 64) {
+    const int rows = p->J - r0 < 64 ? p->J - r0 : 64;
+    const int job = jb.add_job(soa(ws + p->hd_hn, Bp, r0), rows, 1, Bp);
+    jb.add_tile(job, soa(ws + p->hd_dpre1, Bp), 2 * L, 0);
+    jb.add_fin(job, 0, rows, 2 * L, rows, rows, p->h0w + r0, 1, p->J);
+  }
+  int job = jb.add_job(soa(ws + p->hd_dpre1, Bp), 2 * L, 1, Bp);
+  jb.add_tile(job, soa(ws + p->hd_dpre1, Bp), 1, 0);
+  jb.add_fin(job, 64, 2 * L, 1, 2 * L, 2 * L, p->h0b, 1, 1);
+  job = jb.add_job(soa(ws + p->hd_dpre2, Bp), L, 1, Bp);
+  jb.add_tile(job, soa(ws + p->hd_n1, Bp), 2 * L, 0);
+  jb.add_fin(job, 0, L, 2 * L, L, L, p->h3w, 2 * L, 1);
+  jb.add_fin(job, 64, L, 1, L, L, p->h3b, 1, 1);
+  job = jb.add_job(soa(ws + p->denc, Bp), L, 1, Bp);
+  jb.add_tile(job, soa(ws + p->hd_n2, Bp), L, 0);
+  jb.add_fin(job, 0, L, L, L, L, p->h6w, L, 1);
+  jb.add_fin(job, 64, L, 1, L, L, p->h6b, 1, 1);
+  jb.close(p->js_enc);
+}
+
 void build_jobs(DofVadePlan* p) {
+  if (p->kind == 3) return build_tcn_jobs(p);
   const int L = p->L, T = p->T;
   float* ws = p->ws;
   const int64_t Bp = p->Bp;
@@ -485,18 +731,7 @@ void build_jobs(DofVadePlan* p) {
       }
       if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1);  // L == 8: fused in k_gru16_bwd_fused
       gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2);
-      // CensNet: kernel (D,L) = sum Y (x) dZ ; bias = rowsum dZ ; dot weights (D,1) = sum X (x) dd
-      const int64_t kern = s == 0 ? p->c_nk : p->c_ek, bias = s == 0 ? p->c_nb : p->c_eb;
-      const int64_t dotw = s == 0 ? p->c_nw : p->c_ew;
-      int job = jb.add_job(soa(ws + w.Y, Sp), 2 * L, 1, Sp);
-      jb.add_tile(job, soa(ws + w.dZ, Sp), L, 0);
-      jb.add_fin(job, 0, 2 * L, L, 2 * L, 2 * L, kern, L, 1);
-      job = jb.add_job(soa(ws + w.dZ, Sp), L, 1, Sp);
-      jb.add_tile(job, soa(ws + w.dZ, Sp), 1, 0);
-      jb.add_fin(job, 64, L, 1, L, L, bias, 1, 1);
-      job = jb.add_job(soa(ws + w.n2, Sp), 2 * L, 1, Sp);
-      jb.add_tile(job, soa(ws + w.dd, Sp), 1, 0);
-      jb.add_fin(job, 0, 2 * L, 1, 2 * L, 2 * L, dotw, 1, 1);
+      cens_jobs(p, jb, s);
     }
     // final dense (L,J): A = flat rows (<=64 per job), B = denc
     for (int r0 = 0; r0 < p->J; r0 += 64) {
@@ -600,7 +835,48 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
   }
 
+// CensNet kernels are specialised on (latent L, input channels D): D = 2L behind the recurrent blocks, 32 behind the TCNs
+#define CENS_DISPATCH(p, NAME, GRID, ...)                                                              \
+  do {                                                                                                 \
+    const int _l = (p)->L, _d = (p)->D;                                                                \
+    if (_l == 4 && _d == 8) DOF_LAUNCH((NAME<4, 8>), GRID, (256), st, __VA_ARGS__);                    \
+    else if (_l == 6 && _d == 12) DOF_LAUNCH((NAME<6, 12>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 8 && _d == 16) DOF_LAUNCH((NAME<8, 16>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 4 && _d == 32) DOF_LAUNCH((NAME<4, 32>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 6 && _d == 32) DOF_LAUNCH((NAME<6, 32>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 8 && _d == 32) DOF_LAUNCH((NAME<8, 32>), GRID, (256), st, __VA_ARGS__);             \
+    else { dof_set_error("CensNet (latent %d, channels %d) not supported by this build", _l, _d); return DOF_ERR_UNSUPPORTED; } \
+  } while (0)
+
 // ---- forward pieces -----------------------------------------------------------------------------
+int censnet_forward(DofVadePlan* p, const float* params, hipStream_t st) {
+  float* ws = p->ws;
+  // CensNet: node update is weighted by edge dot products (edge_weights) and vice versa
+  const StreamWs& wn = p->sw[0];
+  const StreamWs& we = p->sw[1];
+  if (p->D == 32) {
+    DOF_LAUNCH((k_cens_dots<32>), (dof_cdiv(wn.S, 256)), (256), st, (const float*)(ws + wn.n2), params + p->c_nw, ws + wn.dots, wn.S, wn.Sp);
+    DOF_LAUNCH((k_cens_dots<32>), (dof_cdiv(we.S, 256)), (256), st, (const float*)(ws + we.n2), params + p->c_ew, ws + we.dots, we.S, we.Sp);
+  } else {
+    LDISPATCH(p->L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(wn.S, 256)), (256), st, (const float*)(ws + wn.n2),
+                               params + p->c_nw, ws + wn.dots, wn.S, wn.Sp));
+    LDISPATCH(p->L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(we.S, 256)), (256), st, (const float*)(ws + we.n2),
+                               params + p->c_ew, ws + we.dots, we.S, we.Sp));
+  }
+  CensStream cs[2];
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const StreamWs& o = p->sw[1 - s];
+    cs[s].X = ws + w.n2; cs[s].dots = ws + o.dots; cs[s].tri = trip_dev(ws, w.tri_r);
+    cs[s].kern = params + (s == 0 ? p->c_nk : p->c_ek); cs[s].bias = params + (s == 0 ? p->c_nb : p->c_eb);
+    cs[s].Y = ws + w.Y; cs[s].Z = ws + w.Z; cs[s].G = w.G; cs[s].G_other = o.G; cs[s].S = w.S; cs[s].Sp = w.Sp;
+    cs[s].flat_row0 = s == 0 ? 0 : p->N * p->L;
+  }
+  const int64_t smax = wn.S > we.S ? wn.S : we.S;
+  CENS_DISPATCH(p, k_cens_fwd, (dof_cdiv(smax, 256), 2), cs[0], cs[1], ws + p->flat, p->Bp);
+  return dof_check_launch("censnet forward");
+}
+
 int encoder_forward(DofVadePlan* p, const float* params, const float* x, const float* a, bool train,
                     hipStream_t st) {
   float* ws = p->ws;
@@ -615,25 +891,59 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
     TRY(dof_launch_gru_fwd(L, 1, ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, train ? ws + w.g2 : nullptr, T, w.S, w.Sp, st));
     TRY(dof_launch_enc_final_fwd(L, ws + w.o2, len, params + b.n2w, params + b.n2b, ws + w.hf, ws + w.n2, T, w.S, w.Sp, st));
   }
-  // CensNet: node update is weighted by edge dot products (edge_weights) and vice versa
-  const StreamWs& wn = p->sw[0];
-  const StreamWs& we = p->sw[1];
-  LDISPATCH(L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(wn.S, 256)), (256), st, (const float*)(ws + wn.n2),
-                          params + p->c_nw, ws + wn.dots, wn.S, wn.Sp));
-  LDISPATCH(L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(we.S, 256)), (256), st, (const float*)(ws + we.n2),
-                          params + p->c_ew, ws + we.dots, we.S, we.Sp));
-  CensStream cs[2];
+  return censnet_forward(p, params, st);
+}
+
+// TCN encoder: both streams' temporal blocks, CensNet, RMS-normalised BatchNorm head -> ws.enc [L][Bp].
+// train: batch statistics (and the running buffers inside `params` are updated, as module.train() does);
+// otherwise the running statistics normalise.
+int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const float* a, bool train, hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T;
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
-    const StreamWs& o = p->sw[1 - s];
-    cs[s].X = ws + w.n2; cs[s].dots = ws + o.dots; cs[s].tri = trip_dev(ws, w.tri_r);
-    cs[s].kern = params + (s == 0 ? p->c_nk : p->c_ek); cs[s].bias = params + (s == 0 ? p->c_nb : p->c_eb);
-    cs[s].Y = ws + w.Y; cs[s].Z = ws + w.Z; cs[s].G = w.G; cs[s].G_other = o.G; cs[s].S = w.S; cs[s].Sp = w.Sp;
-    cs[s].flat_row0 = s == 0 ? 0 : p->N * L;
+    const TcnWs& t = p->tw[s];
+    const float count = (float)((int64_t)T * w.S);
+    for (int b = 0; b < 8; ++b) {
+      const TcnBlockOff& o = p->tblk[s][b];
+      const int d = kTcnDil[b];
+      int64_t nrows;
+      if (b == 0) {
+        TRY(dof_launch_tcn_in_conv(w.F, s == 0 ? x : a, params + o.c1w, params + o.c1b, ws + t.xs, ws + t.y1[0],
+                                   ws + t.partial, T, w.G, w.S, w.Sp, d, st));
+        nrows = dof_tcn_row_blocks(T, w.S);
+      } else {
+        TRY(dof_launch_tcn_conv(0, ws + t.out[b - 1], params + o.c1w, params + o.c1b, nullptr, nullptr, ws + t.y1[b],
+                                ws + t.partial, 0, T, d, w.S, w.Sp, st));
+        nrows = dof_tcn_conv_waves(T, w.Sp);
+      }
+      TRY(dof_launch_sum_partials(ws + t.partial, nrows, 64, ws + t.sums, 0, st));
+      TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
+                                train, ws + t.bnp[2 * b], 32, st));
+      TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b], ws + t.a1[b],
+                              ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st));
+      TRY(dof_launch_sum_partials(ws + t.partial, dof_tcn_conv_waves(T, w.Sp), 64, ws + t.sums, 0, st));
+      TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
+                                train, ws + t.bnp[2 * b + 1], 32, st));
+      TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
+                                 b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb,
+                                 b < 7 ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr, b == 0, T, w.F,
+                                 w.S, w.Sp, st));
+    }
   }
-  const int64_t smax = wn.S > we.S ? wn.S : we.S;
-  LDISPATCH(L, DOF_LAUNCH((k_cens_fwd<LL>), (dof_cdiv(smax, 256), 2), (256), st, cs[0], cs[1], ws + p->flat, p->Bp));
-  return dof_check_launch("censnet forward");
+  TRY(censnet_forward(p, params, st));
+  const int64_t B = p->B, Bp = p->Bp;
+  TRY(dof_launch_head_rms(ws + p->flat, ws + p->hd_hn, ws + p->hd_rinv, p->J, B, Bp, st));
+  TRY(dof_launch_head_dense(ws + p->hd_hn, nullptr, nullptr, params + p->h0w, params + p->h0b, ws + p->hd_h1,
+                            ws + p->hd_partial, ws + p->hd_sums, p->J, 2 * L, 1, B, Bp, st));
+  TRY(dof_launch_bn_fwd_fin(ws + p->hd_sums, (float)B, params + p->h2g, params + p->h2b, params + p->h2rm,
+                            params + p->h2rv, 0.01f, train, ws + p->hd_bnp1, 2 * L, st));
+  TRY(dof_launch_head_dense(ws + p->hd_h1, ws + p->hd_bnp1, ws + p->hd_n1, params + p->h3w, params + p->h3b,
+                            ws + p->hd_h2, ws + p->hd_partial, ws + p->hd_sums, 2 * L, L, 1, B, Bp, st));
+  TRY(dof_launch_bn_fwd_fin(ws + p->hd_sums, (float)B, params + p->h5g, params + p->h5b, params + p->h5rm,
+                            params + p->h5rv, 0.01f, train, ws + p->hd_bnp2, L, st));
+  return dof_launch_head_dense(ws + p->hd_h2, ws + p->hd_bnp2, ws + p->hd_n2, params + p->h6w, params + p->h6b,
+                               ws + p->enc, nullptr, nullptr, L, L, 0, B, Bp, st);
 }
 
 int latent_forward(DofVadePlan* p, const float* params, const float* prior, const float* eps, float* z_out,
@@ -706,10 +1016,9 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
   return run_jobset(p, p->js_dec[which_input], grads, accumulate, st);
 }
 
-// Backward of CensNet + both recurrent encoder streams from ws.dflat; fills the encoder gradients.
-int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st, int accumulate = 0) {
+// Backward of CensNet from ws.dflat: d(block outputs) into sw[s].dn2, dZ / dY / dd for the weight-gradient jobs.
+int censnet_backward(DofVadePlan* p, const float* params, hipStream_t st) {
   float* ws = p->ws;
-  const int L = p->L, T = p->T;
   const int64_t Bp = p->Bp;
   CensBwdStream cb[2];
   for (int s = 0; s < 2; ++s) {
@@ -720,13 +1029,67 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     cb[s].dZ = ws + w.dZ; cb[s].dY = ws + w.dY; cb[s].by_m = trip_dev(ws, w.tri_m); cb[s].oth_by_o = trip_dev(ws, w.tri_o);
     cb[s].X_oth = ws + o.n2; cb[s].dY_oth = ws + o.dY; cb[s].dX = ws + w.dn2; cb[s].dd = ws + w.dd;
     cb[s].G = w.G; cb[s].G_other = o.G; cb[s].S = w.S; cb[s].Sp = w.Sp; cb[s].Sp_other = o.Sp;
-    cb[s].flat_row0 = s == 0 ? 0 : p->N * L;
+    cb[s].flat_row0 = s == 0 ? 0 : p->N * p->L;
   }
   const int64_t smax = p->sw[0].S > p->sw[1].S ? p->sw[0].S : p->sw[1].S;
-  LDISPATCH(L, DOF_LAUNCH((k_cens_bwd1<LL>), (dof_cdiv(smax, 256), 2), (256), st, cb[0], cb[1], (const float*)(ws + p->dflat), Bp));
+  CENS_DISPATCH(p, k_cens_bwd1, (dof_cdiv(smax, 256), 2), cb[0], cb[1], (const float*)(ws + p->dflat), Bp);
   TRY(dof_check_launch("k_cens_bwd1"));
-  LDISPATCH(L, DOF_LAUNCH((k_cens_bwd2<LL>), (dof_cdiv(smax, 256), 2), (256), st, cb[0], cb[1]));
-  TRY(dof_check_launch("k_cens_bwd2"));
+  CENS_DISPATCH(p, k_cens_bwd2, (dof_cdiv(smax, 256), 2), cb[0], cb[1]);
+  return dof_check_launch("k_cens_bwd2");
+}
+
+// Backward of the TCN encoder from ws.denc (gradient of the head output); fills / accumulates the gradients.
+int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st, int accumulate) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T;
+  const int64_t B = p->B, Bp = p->Bp;
+  // head: Linear <- BN <- ReLU <- Linear <- BN <- ReLU <- Linear <- RMS scale
+  TRY(dof_launch_head_dense_bwd(ws + p->denc, params + p->h6w, ws + p->hd_dn2, L, L, B, Bp, st));
+  TRY(dof_launch_head_bn_bwd(ws + p->hd_dn2, ws + p->hd_h2, ws + p->hd_bnp2, ws + p->hd_partial, ws + p->hd_sums,
+                             ws + p->hd_coef, grads + p->h5g, grads + p->h5b, accumulate, ws + p->hd_dpre2, L, B, Bp, st));
+  TRY(dof_launch_head_dense_bwd(ws + p->hd_dpre2, params + p->h3w, ws + p->hd_dn1, 2 * L, L, B, Bp, st));
+  TRY(dof_launch_head_bn_bwd(ws + p->hd_dn1, ws + p->hd_h1, ws + p->hd_bnp1, ws + p->hd_partial, ws + p->hd_sums,
+                             ws + p->hd_coef, grads + p->h2g, grads + p->h2b, accumulate, ws + p->hd_dpre1, 2 * L, B, Bp, st));
+  TRY(dof_launch_head_dense_bwd(ws + p->hd_dpre1, params + p->h0w, ws + p->hd_dhn, p->J, 2 * L, B, Bp, st));
+  TRY(dof_launch_head_rms_bwd(ws + p->hd_dhn, ws + p->hd_hn, ws + p->hd_rinv, ws + p->dflat, p->J, B, Bp, st));
+  TRY(censnet_backward(p, params, st));
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    const TcnWs& t = p->tw[s];
+    const float count = (float)((int64_t)T * w.S);
+    const int64_t rows = dof_tcn_row_blocks(T, w.S);
+    for (int b = 7; b >= 0; --b) {
+      const TcnBlockOff& o = p->tblk[s][b];
+      const int d = kTcnDil[b];
+      float* dprev = ws + t.dout[(b + 1) & 1];  // gradient of the previous block's output (this block's input)
+      // BN2 + ReLU + block tail
+      TRY(dof_launch_tcn_bn_bwd1(b == 7 ? nullptr : ws + t.dout[b & 1], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.g2[b],
+                                 ws + t.partial, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip, dprev, T, w.S,
+                                 w.Sp, st));
+      TRY(dof_launch_sum_partials(ws + t.partial, rows, 64, ws + t.sums, 0, st));
+      TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, ws + t.coef, 32, st));
+      TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.coef, T, w.S, w.Sp, st));
+      TRY(dof_launch_tcn_conv(1, ws + t.g2[b], params + o.c2w, nullptr, nullptr, nullptr, ws + t.da, nullptr, 0, T, d,
+                              w.S, w.Sp, st));
+      // BN1 + ReLU
+      TRY(dof_launch_tcn_bn_bwd1(ws + t.da, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b], ws + t.partial, 0, nullptr,
+                                 nullptr, nullptr, nullptr, T, w.S, w.Sp, st));
+      TRY(dof_launch_sum_partials(ws + t.partial, rows, 64, ws + t.sums, 0, st));
+      TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g1, grads + o.b1, accumulate, ws + t.coef, 32, st));
+      TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef, T, w.S, w.Sp, st));
+      if (b > 0)
+        TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
+                                w.Sp, st));
+    }
+  }
+  return run_jobset(p, p->js_enc, grads, accumulate, st);
+}
+
+// Backward of CensNet + both recurrent encoder streams from ws.dflat; fills the encoder gradients.
+int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st, int accumulate = 0) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T;
+  TRY(censnet_backward(p, params, st));
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
     const BlockOff& b = p->blk[s];
@@ -766,7 +1129,7 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
     dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", dims->latent);
     return DOF_ERR_UNSUPPORTED;
   }
-  if (dims->n_nodes > DOF_CL_MAX_NODES && kind == 2) {
+  if (dims->n_nodes > DOF_CL_MAX_NODES && kind >= 2) {
     dof_set_error("contrastive plan: n_nodes %d > %d", dims->n_nodes, DOF_CL_MAX_NODES);
     return DOF_ERR_UNSUPPORTED;
   }
@@ -777,6 +1140,7 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
   p->S = dims->mc_samples; p->B = dims->batch; p->Bp = dof_pad64(p->B);
   p->J = (p->N + p->E) * p->L;
   p->C3 = 3 * p->N;
+  p->D = kind == 3 ? 32 : 2 * p->L;
   build_param_layout(p);
   build_triplets(p, laplacian, edge_laplacian, incidence);
   build_workspace_layout(p);
@@ -800,6 +1164,24 @@ extern "C" const char* dof_vade_param_name(const DofVadePlan* p, int32_t i) { re
 extern "C" int64_t dof_vade_param_offset(const DofVadePlan* p, int32_t i) { return p->params[i].off; }
 extern "C" int64_t dof_vade_param_numel(const DofVadePlan* p, int32_t i) { return p->params[i].numel; }
 extern "C" int64_t dof_vade_param_total(const DofVadePlan* p) { return p->param_total; }
+extern "C" int32_t dof_vade_param_shape(const DofVadePlan* p, int32_t i, int64_t* dims4) {
+  const std::vector<int64_t>& sh = p->params[i].shape;
+  for (size_t k = 0; k < sh.size() && k < 4; ++k) dims4[k] = sh[k];
+  return (int32_t)sh.size();
+}
+extern "C" int dof_vade_set_trainable(DofVadePlan* p, int32_t i, int32_t trainable, void* stream) {
+  if (!p || !p->ws || i < 0 || i >= (int32_t)p->params.size()) {
+    dof_set_error("dof_vade_set_trainable: plan not bound or parameter index out of range");
+    return DOF_ERR_STATE;
+  }
+  const ParamEntry& e = p->params[i];
+  float* m = p->ws + p->mask_tab + e.off;
+  if (trainable) {
+    DOF_LAUNCH(k_fill_f32, (dof_cdiv(e.numel, 256)), (256), (hipStream_t)stream, m, 1.0f, e.numel);
+    return dof_check_launch("k_fill_f32");
+  }
+  return dof_launch_zero(m, e.numel, (hipStream_t)stream);
+}
 extern "C" int64_t dof_vade_workspace_bytes(const DofVadePlan* p) { return p->ws_floats * 4; }
 
 extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
@@ -830,7 +1212,8 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
     static thread_local std::vector<float> mask;
     mask.assign((size_t)p->param_total, 1.0f);
     for (const ParamEntry& e : p->params)
-      if (e.name.find(".projection.") != std::string::npos || e.name.find(".lens.") != std::string::npos)
+      if (e.name.find(".projection.") != std::string::npos || e.name.find(".lens.") != std::string::npos ||
+          e.name.find(".running_") != std::string::npos)  // BatchNorm buffers: not parameters
         for (int64_t i = 0; i < e.numel; ++i) mask[(size_t)(e.off + i)] = 0.0f;
     up(p->mask_tab, mask.data(), mask.size() * sizeof(float));
   }
@@ -1075,6 +1458,19 @@ extern "C" int dof_optimizer_step(DofVadePlan* p, float* params, const float* gr
 // ---------------------------------------------------------------------------------------------
 // Contrastive
 // ---------------------------------------------------------------------------------------------
+extern "C" int dof_contrastive_tcn_plan_create(const DofVadeDims* dims, const float* laplacian,
+                                               const float* edge_laplacian, const float* incidence,
+                                               DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_contrastive_tcn_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  DofVadeDims d = *dims;
+  if (d.n_clusters <= 0) d.n_clusters = 1;
+  if (d.mc_samples <= 0) d.mc_samples = 1;
+  return plan_create(&d, laplacian, edge_laplacian, incidence, 3, out);
+}
+
 extern "C" int dof_contrastive_plan_create(const DofVadeDims* dims, const float* laplacian,
                                            const float* edge_laplacian, const float* incidence, DofVadePlan** out) {
   if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
@@ -1129,7 +1525,7 @@ extern "C" int dof_contrastive_views(const float* x_full, const int32_t* edge_in
 
 extern "C" int dof_contrastive_encode(DofVadePlan* p, const float* params, const float* x, const float* a,
                                       int32_t train, float* z_out, void* stream) {
-  if (!p || !p->ws || p->kind != 2) {
+  if (!p || !p->ws || p->kind < 2) {
     dof_set_error("dof_contrastive_encode: plan not bound to a workspace (or not a contrastive plan)");
     return DOF_ERR_STATE;
   }
@@ -1139,10 +1535,15 @@ extern "C" int dof_contrastive_encode(DofVadePlan* p, const float* params, const
   }
   hipStream_t st = (hipStream_t)stream;
   float* ws = p->ws;
-  TRY(encoder_forward(p, params, x, a, train != 0, st));
-  DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
-             params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
-  TRY(dof_check_launch("k_final_dense"));
+  if (p->kind == 3) {
+    // BatchNorm running buffers live in the parameter buffer and are refreshed by a train-mode pass
+    TRY(tcn_encoder_forward(p, const_cast<float*>(params), x, a, train != 0, st));
+  } else {
+    TRY(encoder_forward(p, params, x, a, train != 0, st));
+    DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
+               params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
+    TRY(dof_check_launch("k_final_dense"));
+  }
   if (z_out) {
     LDISPATCH(p->L, DOF_LAUNCH((k_cl_export<LL>), (dof_cdiv(p->B, 256)), (256), st, (const float*)(ws + p->enc), z_out,
                                p->B, p->Bp));
@@ -1154,7 +1555,7 @@ extern "C" int dof_contrastive_encode(DofVadePlan* p, const float* params, const
 extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float* z_aug, int32_t similarity,
                                     int32_t loss_fn, float temperature, float tau, float beta, float* dz,
                                     float* dz_aug, float* logs, void* stream) {
-  if (!p || !p->ws || p->kind != 2) {
+  if (!p || !p->ws || p->kind < 2) {
     dof_set_error("dof_contrastive_loss: plan not bound to a workspace (or not a contrastive plan)");
     return DOF_ERR_STATE;
   }
@@ -1194,7 +1595,7 @@ extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float*
 
 extern "C" int dof_contrastive_backward(DofVadePlan* p, const float* params, const float* dz, float* grads,
                                         int32_t accumulate, void* stream) {
-  if (!p || !p->ws || p->kind != 2) {
+  if (!p || !p->ws || p->kind < 2) {
     dof_set_error("dof_contrastive_backward: plan not bound to a workspace (or not a contrastive plan)");
     return DOF_ERR_STATE;
   }
@@ -1206,6 +1607,7 @@ extern "C" int dof_contrastive_backward(DofVadePlan* p, const float* params, con
   float* ws = p->ws;
   if (!accumulate) TRY(dof_launch_zero(grads, p->param_total, st));
   LDISPATCH(p->L, DOF_LAUNCH((k_cl_import<LL>), (dof_cdiv(p->B, 256)), (256), st, dz, ws + p->denc, p->B, p->Bp));
+  if (p->kind == 3) return tcn_encoder_backward(p, params, grads, st, accumulate ? 1 : 0);
   LDISPATCH(p->L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(p->B, 256), (unsigned)p->J), (256), st,
                              (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, p->B, p->Bp));
   TRY(dof_check_launch("k_final_dense_bwd"));

@@ -70,10 +70,11 @@ class VadeEngine:
         self.B, self.T, self.L, self.K, self.S = int(batch), int(window), int(latent_dim), int(n_clusters), int(mc_samples)
         dims = _capi.VadeDims(self.B, self.T, self.N, self.E, self.L, self.K, self.S)
         plan = C.c_void_p()
-        assert kind in ("vade", "vqvae", "contrastive")
+        assert kind in ("vade", "vqvae", "contrastive", "contrastive_tcn")
         self.kind = kind
         create = {"vade": lib.dof_vade_plan_create, "vqvae": lib.dof_vqvae_plan_create,
-                  "contrastive": lib.dof_contrastive_plan_create}[kind]
+                  "contrastive": lib.dof_contrastive_plan_create,
+                  "contrastive_tcn": lib.dof_contrastive_tcn_plan_create}[kind]
         _capi.check(lib, create(C.byref(dims), self.lap.ctypes.data, self.elap.ctypes.data, self.inc.ctypes.data,
                                 C.byref(plan)), "dof_*_plan_create")
         self.plan = plan
@@ -83,7 +84,16 @@ class VadeEngine:
             name = lib.dof_vade_param_name(plan, i).decode()
             off, numel = lib.dof_vade_param_offset(plan, i), lib.dof_vade_param_numel(plan, i)
             self.names.append(name)
-            self.layout[name] = (off, numel, _param_shape(name, numel, self.N, self.E, self.L, self.K))
+            dims4 = (C.c_int64 * 4)()
+            rank = lib.dof_vade_param_shape(plan, i, dims4)
+            shape = tuple(int(dims4[k]) for k in range(rank)) if rank else \
+                _param_shape(name, numel, self.N, self.E, self.L, self.K)
+            self.layout[name] = (off, numel, shape)
+        self.index = {n: i for i, n in enumerate(self.names)}
+        # BatchNorm bookkeeping of the TCN family: running buffers are entries of the flat buffer, the step
+        # counters (num_batches_tracked, int64 in the reference state_dict) are host integers
+        self.bn_layers = [n[: -len(".running_mean")] for n in self.names if n.endswith(".running_mean")]
+        self.num_batches_tracked = {n: 0 for n in self.bn_layers}
         total = lib.dof_vade_param_total(plan)
         f32 = dict(dtype=torch.float32, device=self.device)
         ws_bytes = lib.dof_vade_workspace_bytes(plan)
@@ -93,7 +103,7 @@ class VadeEngine:
         if shared is not None:
             assert shared.params.numel() == total and shared.K == self.K and shared.L == self.L
             for attr in ("params", "grads", "adam_m", "adam_v", "prior", "hyper_host", "hyper", "logs", "teacher",
-                         "adam_t"):
+                         "adam_t", "num_batches_tracked"):
                 setattr(self, attr, getattr(shared, attr))
             return
         self.params = torch.zeros(total, **f32)
@@ -146,6 +156,9 @@ class VadeEngine:
                 sd["latent_space.prior"] = self.prior.detach().cpu().clone()
                 sd["latent_space.pretrain"] = torch.tensor(0.0)
             sd[n] = self.view(n).detach().cpu().clone()
+            if n.endswith(".running_var"):
+                layer = n[: -len(".running_var")]
+                sd[layer + ".num_batches_tracked"] = torch.tensor(self.num_batches_tracked[layer], dtype=torch.int64)
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
@@ -156,6 +169,14 @@ class VadeEngine:
                 raise KeyError(f"missing parameter {n}")
         if "latent_space.prior" in sd:
             self.prior.copy_(torch.as_tensor(sd["latent_space.prior"], dtype=torch.float32))
+        for layer in self.bn_layers:
+            if layer + ".num_batches_tracked" in sd:
+                self.num_batches_tracked[layer] = int(sd[layer + ".num_batches_tracked"])
+
+    def set_trainable(self, name: str, trainable: bool):
+        """Take a parameter out of (or back into) the optimiser step (reference quirk Q11)."""
+        rc = self.lib.dof_vade_set_trainable(self.plan, self.index[name], 1 if trainable else 0, self._stream())
+        _capi.check(self.lib, rc, "dof_vade_set_trainable")
 
     _HYPER_IDX = dict(klw=_capi.H_KLW, lambda_distill=_capi.H_LAMBDA_DISTILL, km_latent=_capi.H_KM_LATENT,
                       km_loss=_capi.H_KM_LOSS, repel_w=_capi.H_REPEL_W, repel_ls=_capi.H_REPEL_LS,
@@ -275,6 +296,9 @@ class VadeEngine:
         rc = self.lib.dof_contrastive_encode(self.plan, self.params.data_ptr(), x.data_ptr(), a.data_ptr(),
                                              1 if train else 0, z.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_contrastive_encode")
+        if train:
+            for layer in self.num_batches_tracked:
+                self.num_batches_tracked[layer] += 1
         return z
 
     def contrastive_loss(self, z, z_aug, similarity="cosine", loss_fn="nce", temperature=0.1, tau=0.1, beta=0.1,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 3
+#define DOF_ABI_VERSION 4
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -76,11 +76,18 @@ const char* dof_vade_param_name(const DofVadePlan* plan, int32_t i);
 int64_t dof_vade_param_offset(const DofVadePlan* plan, int32_t i);
 int64_t dof_vade_param_numel(const DofVadePlan* plan, int32_t i);
 int64_t dof_vade_param_total(const DofVadePlan* plan);
+/* Tensor shape of parameter i into dims4 (returns the rank; 0 = derive it from the name as for the
+ * recurrent families, whose shapes follow from (L, N, E, K)). */
+int32_t dof_vade_param_shape(const DofVadePlan* plan, int32_t i, int64_t* dims4);
 
 int64_t dof_vade_workspace_bytes(const DofVadePlan* plan);
 /* Zero the workspace and upload the plan's tables into it (enqueued on stream).  Call once per
  * workspace before the first forward / step, outside any graph capture. */
 int dof_vade_bind(DofVadePlan* plan, void* workspace, void* stream);
+
+/* Exclude (trainable = 0) / include parameter i in dof_optimizer_step -- the reference's "this tensor is
+ * not in the optimiser" cases (quirk Q11: the lazily built CensNet tensors of the TCN encoders). */
+int dof_vade_set_trainable(DofVadePlan* plan, int32_t i, int32_t trainable, void* stream);
 
 /* hyper[]: device fp32 array of DOF_H_COUNT scalars read by the kernels (graph-replay safe). */
 enum {
@@ -149,6 +156,13 @@ int dof_vqvae_loss_grads(DofVadePlan* plan, const float* params, const float* x,
  * the two plans share the caller's parameter, gradient and Adam buffers. */
 int dof_contrastive_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
                                 const float* incidence, DofVadePlan** out);
+
+/* Same, with the TCN encoder (models_new.py:376-657 TemporalBlockPT / TCN1DPT / TCNEncoderPT): parameters =
+ * ContrastivePT(encoder_type="TCN").state_dict() order, BatchNorm running_mean / running_var included as
+ * entries of the flat buffer (never touched by the optimiser; updated in place by a train-mode
+ * dof_contrastive_encode, which is why that call may write to `params` for this plan kind). */
+int dof_contrastive_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                    const float* incidence, DofVadePlan** out);
 
 #define DOF_MAX_ROT 8
 /* Resolved random choices of one augmented view (the reference draws them inside

@@ -276,3 +276,96 @@ def run_contrastive_check(lib, device, golden_dir, tag):
         for name in e1.names:
             if pfx + f"grad::{name}" not in d:
                 assert float(e1.view(name, e1.grads).abs().max()) == 0.0, name
+
+
+def run_contrastive_tcn_check(lib, device, golden_dir):
+    """Contrastive step with the TCN encoder (R12): eval-mode embeddings (running statistics), train-mode embeddings,
+    BatchNorm buffers after the two passes, loss and all gradients, then the reference's two optimiser steps
+    (Adam + weight decay 1e-4, clip 0.75, CensNet tensors outside the optimiser -- quirk Q11)."""
+    from deepof_amd.engine import VadeEngine, contrastive_views
+    d = load_golden(golden_dir, "contrastive_tcn14.npz")
+    pfx = "c0::"
+    x_full = torch.from_numpy(d["x_full"]).to(device)
+    ei = torch.from_numpy(d["edge_index"]).to(device)
+    B, Tf, N, _ = x_full.shape
+    L = d[pfx + "sd::encoder.head.6.bias"].shape[0]
+    e1 = VadeEngine(lib, device, B, Tf // 2, d["adj"], L, 1, kind="contrastive_tcn")
+    e2 = VadeEngine(lib, device, B, Tf // 2, d["adj"], L, 1, kind="contrastive_tcn", shared=e1)
+    sd0 = params_from(d, pfx + "sd::")
+    e1.load_state_dict(sd0)
+    assert list(e1.state_dict().keys()) == list(sd0.keys())
+    xc, ac = contrastive_views(lib, x_full, ei, None)
+    xa, aa = contrastive_views(lib, x_full, ei, aug_from_golden(d, pfx, device))
+    z_eval = e1.contrastive_encode(xc, ac, train=False)
+    np.testing.assert_allclose(z_eval.cpu().numpy(), d[pfx + "z_eval"], atol=2e-5, rtol=1e-4)
+    z = e1.contrastive_encode(xc, ac, train=True)
+    z_aug = e2.contrastive_encode(xa, aa, train=True)
+    np.testing.assert_allclose(z.cpu().numpy(), d[pfx + "z"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(z_aug.cpu().numpy(), d[pfx + "z_aug"], atol=2e-5, rtol=1e-4)
+    sd1 = e1.state_dict()
+    nbuf = 0
+    for k in d:
+        if k.startswith(pfx + "sd_after::"):
+            name = k[len(pfx) + 10:]
+            np.testing.assert_allclose(sd1[name].numpy(), d[k], atol=2e-6, rtol=2e-5, err_msg=name)
+            nbuf += 1
+    assert nbuf == 3 * 34
+    dz, dza = e1.contrastive_loss(z, z_aug, "cosine", "nce", 0.1, 0.1, 0.1)
+    logs = e1.read_contrastive_logs()
+    for k in ("total_loss", "pos_similarity", "neg_similarity"):
+        np.testing.assert_allclose(logs[k], float(d[pfx + f"log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=k)
+    e1.contrastive_backward(dz, accumulate=False)
+    e2.contrastive_backward(dza, accumulate=True)
+    n = 0
+    for k in d:
+        if k.startswith(pfx + "grad::"):
+            name = k[len(pfx) + 6:]
+            g = e1.view(name, e1.grads).cpu().numpy()
+            np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=1e-4, rtol=2e-3, err_msg=f"grad {name}")
+            n += 1
+    assert n == 148
+    # optimiser: step 1 on these gradients, step 2 = a full step with the second set of recorded draws
+    for name in e1.names:
+        if ".spatial_gnn_block." in name:
+            e1.set_trainable(name, False)
+    e1.reset_optimizer()
+    for seg in range(_capi.SEG_COUNT):
+        e1.set_lr(seg, 1e-3)
+    e1.set_hyper(clip=0.75, wd=1e-4)
+    e1.advance_adam()
+    e1.push_hyper()
+    e1.optimizer_step()
+    aug2 = {k.replace("aug2::", "aug::"): v for k, v in d.items() if k.startswith(pfx + "aug2::")}
+    xa2, aa2 = contrastive_views(lib, x_full, ei, aug_from_golden(aug2, pfx, device))
+    z = e1.contrastive_encode(xc, ac, train=True)
+    z_aug = e2.contrastive_encode(xa2, aa2, train=True)
+    dz, dza = e1.contrastive_loss(z, z_aug, "cosine", "nce", 0.1, 0.1, 0.1)
+    for k, v in e1.read_contrastive_logs().items():
+        if f"{pfx}log2::{k}" in d and k != "seperability":
+            np.testing.assert_allclose(v, float(d[f"{pfx}log2::{k}"]), rtol=2e-3, atol=2e-4, err_msg=f"step 2: {k}")
+    e1.contrastive_backward(dz, accumulate=False)
+    e2.contrastive_backward(dza, accumulate=True)
+    e1.advance_adam()
+    e1.push_hyper()
+    e1.optimizer_step()
+    sd2 = e1.state_dict()
+    for k, v in params_from(d, pfx + "sd_step2::").items():
+        if v.dtype == torch.int64:
+            assert int(sd2[k]) == int(v), k
+        elif k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            # a bias in front of a BatchNorm has an exactly-zero gradient; Adam normalises the rounding noise of
+            # either implementation into +-lr steps, so only the bound is comparable
+            assert float(sd2[k].abs().max()) <= 2.1e-3 and float(v.abs().max()) <= 2.1e-3, k
+        elif k in e1.layout:
+            # (the running mean of a conv BatchNorm contains 0.1 x that noise-driven bias)
+            got, ref = sd2[k].numpy(), v.numpy().reshape(sd2[k].shape)
+            atol = 6e-4 if k.endswith("running_mean") else 3e-4
+            bad = np.abs(got - ref) > atol + 2e-3 * np.abs(ref)
+            # Adam turns the rounding noise of a (mathematically) zero gradient into +-lr steps -- e.g. a bias whose
+            # unit is active for the whole batch in front of a BatchNorm: such elements are only bounded, and
+            # isolated near-zero-gradient elements elsewhere are tolerated
+            if pfx + "grad::" + k in d:
+                bad &= np.abs(d[pfx + "grad::" + k].reshape(got.shape)) > 2e-5
+            assert bad.mean() <= 0.005 and np.abs(got - ref).max() <= 2.1e-3, (k, bad.sum(), np.abs(got - ref).max())
+    np.testing.assert_array_equal(sd2["encoder.spatial_gnn_block.node_kernel"].numpy(),
+                                  d[pfx + "sd::encoder.spatial_gnn_block.node_kernel"])

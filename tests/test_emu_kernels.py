@@ -53,3 +53,8 @@ def test_contrastive_losses_emu(golden_dir, tag):
 def test_contrastive_step_emu(golden_dir, tag):
     from parity_common import run_contrastive_check
     run_contrastive_check(emu_lib(), "cpu", golden_dir, tag)
+
+
+def test_contrastive_tcn_emu(golden_dir):
+    from parity_common import run_contrastive_tcn_check
+    run_contrastive_tcn_check(emu_lib(), "cpu", golden_dir)
