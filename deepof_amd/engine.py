@@ -93,7 +93,7 @@ class VadeEngine:
         # BatchNorm bookkeeping of the TCN family: running buffers are entries of the flat buffer, the step
         # counters (num_batches_tracked, int64 in the reference state_dict) are host integers
         self.bn_layers = [n[: -len(".running_mean")] for n in self.names if n.endswith(".running_mean")]
-        self.num_batches_tracked = {n: 0 for n in self.bn_layers}
+        self.num_batches_tracked = {n: torch.zeros((), dtype=torch.int64) for n in self.bn_layers}
         total = lib.dof_vade_param_total(plan)
         f32 = dict(dtype=torch.float32, device=self.device)
         ws_bytes = lib.dof_vade_workspace_bytes(plan)
@@ -158,7 +158,7 @@ class VadeEngine:
             sd[n] = self.view(n).detach().cpu().clone()
             if n.endswith(".running_var"):
                 layer = n[: -len(".running_var")]
-                sd[layer + ".num_batches_tracked"] = torch.tensor(self.num_batches_tracked[layer], dtype=torch.int64)
+                sd[layer + ".num_batches_tracked"] = self.num_batches_tracked[layer].clone()
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
@@ -171,7 +171,7 @@ class VadeEngine:
             self.prior.copy_(torch.as_tensor(sd["latent_space.prior"], dtype=torch.float32))
         for layer in self.bn_layers:
             if layer + ".num_batches_tracked" in sd:
-                self.num_batches_tracked[layer] = int(sd[layer + ".num_batches_tracked"])
+                self.num_batches_tracked[layer].fill_(int(sd[layer + ".num_batches_tracked"]))
 
     def set_trainable(self, name: str, trainable: bool):
         """Take a parameter out of (or back into) the optimiser step (reference quirk Q11)."""
@@ -297,8 +297,8 @@ class VadeEngine:
                                              1 if train else 0, z.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_contrastive_encode")
         if train:
-            for layer in self.num_batches_tracked:
-                self.num_batches_tracked[layer] += 1
+            for t in self.num_batches_tracked.values():
+                t += 1
         return z
 
     def contrastive_loss(self, z, z_aug, similarity="cosine", loss_fn="nce", temperature=0.1, tau=0.1, beta=0.1,

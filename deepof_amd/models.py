@@ -313,8 +313,11 @@ class Contrastive(VaDE):
                  similarity_function: str = "cosine", loss_function: str = "nce", beta: float = 0.1, tau: float = 0.1,
                  interaction_regularization: float = 0.0, batch_size: int = 256, device=None, _engine_factory=None):
         nn.Module.__init__(self)
-        if str(encoder_type).lower() != "recurrent":
-            raise NotImplementedError(f"encoder_type={encoder_type!r}: this build implements the recurrent encoder")
+        enc = str(encoder_type)
+        if enc.lower() not in ("recurrent", "tcn"):
+            raise NotImplementedError(f"encoder_type={encoder_type!r}: this build implements the recurrent and the "
+                                      "TCN encoder for the contrastive model")
+        self._KIND = "contrastive_tcn" if enc.lower() == "tcn" else "contrastive"
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
         time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
@@ -325,7 +328,7 @@ class Contrastive(VaDE):
         self.input_shape, self.edge_feature_shape = tuple(input_shape), tuple(edge_feature_shape)
         self.input_n_nodes, self.input_n_features_per_node = n_nodes, n_feat
         self.latent_dim, self.n_components = int(latent_dim), 1
-        self.encoder_type, self.use_gnn = "recurrent", True
+        self.encoder_type, self.use_gnn = ("TCN" if self._KIND == "contrastive_tcn" else "recurrent"), True
         self.temperature, self.similarity_function, self.loss_function = float(temperature), similarity_function, loss_function
         self.beta, self.tau = float(beta), float(tau)
         self.interaction_regularization = interaction_regularization
@@ -342,8 +345,49 @@ class Contrastive(VaDE):
         self.encoder.register_buffer("edge_laplacian", torch.from_numpy(eng.elap.copy()))
         self.encoder.register_buffer("incidence", torch.from_numpy(eng.inc.copy()))
         for name in eng.names:
-            _attach(self, name, eng.view(name))
+            _attach(self, name, eng.view(name), buffer=".running_" in name)
+            if name.endswith(".running_var"):  # BatchNorm step counter: host int64, shared with the engine
+                layer = name[: -len(".running_var")]
+                _attach(self, layer + ".num_batches_tracked", eng.num_batches_tracked[layer], buffer=True)
         self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        if self._KIND != "contrastive_tcn":
+            return VaDE.reset_parameters(self)
+        for name, p in self.named_parameters():  # models_new.py:420-430 (convs), :596-601 (head), censNetConv_pt.py:75-84
+            leaf = name.split(".")[-1]
+            if ".bn" in name or name.startswith("encoder.head.2") or name.startswith("encoder.head.5"):
+                p.fill_(1.0 if leaf == "weight" else 0.0)
+            elif "spatial_gnn_block" in name:
+                if leaf in ("node_kernel", "edge_kernel", "node_weights", "edge_weights"):
+                    nn.init.xavier_uniform_(p)
+                else:
+                    bound = 1.0 / math.sqrt(self.latent_dim)
+                    p.uniform_(-bound, bound)
+            elif ".head." in name:
+                nn.init.xavier_uniform_(p) if leaf == "weight" else p.zero_()
+            elif leaf == "weight":
+                p.normal_(0.0, 0.05)
+            else:
+                p.zero_()
+        for name, b in self.named_buffers():
+            if name.endswith("running_mean"):
+                b.zero_()
+            elif name.endswith("running_var"):
+                b.fill_(1.0)
+            elif name.endswith("num_batches_tracked"):
+                b.zero_()
+
+    def _make_engine(self, batch: int, shared):
+        eng = VaDE._make_engine(self, batch, shared)
+        if self._KIND == "contrastive_tcn" and not getattr(self, "censnet_in_optimizer", False):
+            # reference quirk Q11: the TCN encoder builds its CensNet tensors lazily, after fit_contrastive has
+            # created the optimiser, so they receive gradients but are never updated
+            for name in eng.names:
+                if ".spatial_gnn_block." in name:
+                    eng.set_trainable(name, False)
+        return eng
 
     def aug_engine(self, batch: int) -> VadeEngine:
         """Second plan/workspace of this batch size: holds the augmented view's activations until its backward."""
@@ -353,13 +397,19 @@ class Contrastive(VaDE):
         return self._aug_engines[batch]
 
     def forward(self, x, a):
+        """Embeddings of half windows.  With the TCN encoder a module in train() mode normalises with batch
+        statistics and refreshes the running buffers, as the reference module does; eval() uses the buffers."""
         x = x.to(self.device, torch.float32).contiguous()
         a = a.to(self.device, torch.float32).contiguous()
-        return self.engine(x.shape[0]).contrastive_encode(x, a, train=False)
+        return self.engine(x.shape[0]).contrastive_encode(x, a, train=self.training and self._KIND == "contrastive_tcn")
 
     @torch.no_grad()
     def embed(self, x, a):
-        return self.forward(x, a)
+        was = self.training
+        self.eval()
+        z = self.forward(x, a)
+        self.train(was)
+        return z
 
     def group(self, x, a):
         raise NotImplementedError("the contrastive model has no cluster head (ContrastivePT defines none)")
@@ -370,5 +420,5 @@ class Contrastive(VaDE):
     @torch.no_grad()
     def encode_windows(self, x, a, batch: int = 256):
         """Embeddings of many HALF windows (model_utils_new.py:604-617 feeds the sliced centre of each window)."""
-        zs = [self.forward(x[s:s + batch], a[s:s + batch]) for s in range(0, x.shape[0], batch)]
+        zs = [self.embed(x[s:s + batch], a[s:s + batch]) for s in range(0, x.shape[0], batch)]
         return torch.cat(zs), None

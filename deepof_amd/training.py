@@ -114,7 +114,7 @@ def build_model_from_spec(spec: dict, device=None, batch_size: int = 256, _engin
                      batch_size=batch_size, device=device, _engine_factory=_engine_factory)
     if name == "contrastive":
         return Contrastive(tuple(spec["x_shape"]), tuple(spec["a_shape"]), np.asarray(spec["adjacency_matrix"]),
-                           int(spec["latent_dim"]), encoder_type=spec.get("encoder_type", "recurrent"),
+                           int(spec["latent_dim"]), encoder_type=spec.get("encoder_type", "TCN"),
                            use_gnn=bool(spec.get("use_gnn", True)), batch_size=batch_size, device=device,
                            _engine_factory=_engine_factory)
     if name != "vade":
@@ -140,10 +140,12 @@ def _clone_model(model: VaDE) -> VaDE:
     """Independent copy (own parameter buffer) -- deepcopy() of the reference."""
     if isinstance(model, Contrastive):
         twin = Contrastive(model.input_shape, model.edge_feature_shape, model._adjacency, model.latent_dim,
-                           temperature=model.temperature, similarity_function=model.similarity_function,
+                           encoder_type=model.encoder_type, temperature=model.temperature, similarity_function=model.similarity_function,
                            loss_function=model.loss_function, beta=model.beta, tau=model.tau,
                            batch_size=model._base.B, _engine_factory=model._factory)
         twin._base.params.copy_(model._base.params)
+        for k, t in model._base.num_batches_tracked.items():
+            twin._base.num_batches_tracked[k].copy_(t)
         twin.train(model.training)
         return twin
     twin = type(model)((model.window_size, model.input_n_nodes, 3), (model.window_size, model._base.E, 1),

@@ -18,7 +18,7 @@ def hip():
 def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == 3
+    assert hip.dof_abi_version() == 4
 
 
 def test_gather_gpu(hip):
@@ -337,3 +337,64 @@ def test_contrastive_training_api_gpu(tmp_path):
     assert isinstance(mv, Contrastive) and len(logs["train"]["total_loss"]) == 4
     assert logs["train"]["total_loss"][-1] < logs["train"]["total_loss"][0]
     assert (tmp_path / "models" / "contrastive" / "run_0" / "best_model_val.pth").exists()
+
+
+def test_contrastive_tcn_parity_gpu(hip, golden_dir):
+    from parity_common import run_contrastive_tcn_check
+    run_contrastive_tcn_check(hip, "cuda", golden_dir)
+
+
+def test_contrastive_tcn_full_size_c4(hip):
+    """BASELINE config C4 as named (contrastive, TCN encoder, window 50 -> half 25, batch 8192 per rank): one full
+    step -- determinism, finite gradients for every tensor, BatchNorm buffers moved -- and train-mode embedding
+    parity against the CPU oracle on a 64-window slice run with the SAME batch statistics (the oracle is fed the
+    device's per-layer statistics through the running buffers in eval mode)."""
+    from deepof_amd import graph as G
+    from deepof_amd.engine import contrastive_views, create_vade_engine
+    nodes, edges = G.bodypart_graph([""])
+    adj = G.adjacency_from_graph(nodes, edges)
+    ei, _ = G.edge_index_from_graph(nodes, edges)
+    B, Tf, L, N = 8192, 50, 8, len(nodes)
+    g = torch.Generator().manual_seed(0)
+    x_full = (torch.randn(B, Tf, N, 3, generator=g).cumsum(1) * 0.1).contiguous().cuda()
+    eid = torch.from_numpy(ei).cuda()
+    e1 = create_vade_engine(B, Tf // 2, adj, L, 1, kind="contrastive_tcn")
+    e2 = create_vade_engine(B, Tf // 2, adj, L, 1, kind="contrastive_tcn", shared=e1)
+    for n in e1.names:
+        shape = e1.layout[n][2]
+        if n.endswith("running_var") or (".bn" in n and n.endswith("weight")) or n in ("encoder.head.2.weight", "encoder.head.5.weight"):
+            v = torch.ones(shape)
+        elif n.endswith("running_mean") or n.endswith("bias"):
+            v = torch.zeros(shape)
+        elif ".head." in n or "spatial_gnn_block" in n:
+            v = torch.randn(shape, generator=g) * 0.3
+        else:
+            v = torch.randn(shape, generator=g) * 0.05
+        e1.view(n).copy_(v)
+    p0 = e1.params.clone()
+    x, a = contrastive_views(hip, x_full, eid, None)
+    xa, aa = contrastive_views(hip, x_full, eid, {"start": torch.randint(8, 18, (B,), generator=g).int().cuda()})
+
+    def step():
+        e1.params.copy_(p0)
+        z, za = e1.contrastive_encode(x, a, train=True), e2.contrastive_encode(xa, aa, train=True)
+        dz, dza = e1.contrastive_loss(z, za, "cosine", "nce", 0.1, 0.1, 0.1)
+        e1.contrastive_backward(dz, accumulate=False)
+        e2.contrastive_backward(dza, accumulate=True)
+        return z, e1.grads.clone(), e1.read_contrastive_logs()
+
+    z, g1, logs = step()
+    _, g2, _ = step()
+    assert torch.equal(g1, g2) and bool(torch.isfinite(g1).all())
+    for n in e1.names:
+        if "running" not in n and not n.endswith("conv1.bias") and not n.endswith("conv2.bias"):
+            assert float(e1.view(n, g1).abs().max()) > 0, n
+    assert float((e1.view("encoder.node_tcn.blocks.5.bn2.running_mean") - 0).abs().max()) > 0
+    assert 0.0 < logs["total_loss"] < 30.0 and np.isfinite(logs["pos_similarity"])
+    # eval-mode parity vs the oracle with the device's refreshed running statistics (any batch size works in eval)
+    from oracle import tcn as OT
+    z_eval = e1.contrastive_encode(x, a, train=False)
+    P = {k: v.clone() for k, v in e1.state_dict().items()}
+    with torch.no_grad():
+        ref = OT.tcn_encoder(x[:64].cpu(), a[:64].cpu(), P, False)
+    np.testing.assert_allclose(z_eval[:64].cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-3)

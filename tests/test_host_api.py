@@ -320,3 +320,43 @@ def test_contrastive_model_and_fit(golden_dir, tmp_path):
     with pytest.raises(NotImplementedError):
         TR.train_deepof_model(preprocessed_object=(pre_tr, pre_va), meta_info=meta,
                               **{**kw, "contrastive_loss_function": "fc"})
+
+
+def test_contrastive_tcn_model_and_fit(golden_dir, tmp_path):
+    from deepof_amd.models import Contrastive
+    d = load_golden(golden_dir, "contrastive_tcn14.npz")
+    ref_keys = [k[8:] for k in d if k.startswith("c0::sd::")]
+    model = Contrastive((24, 14, 3), (24, 14, 1), d["adj"], latent_dim=8, encoder_type="TCN", batch_size=6,
+                        _engine_factory=emu_factory)
+    assert list(model.state_dict().keys()) == ref_keys and len(ref_keys) == 253
+    sd = model.state_dict()
+    assert float(sd["encoder.node_tcn.blocks.3.bn1.running_var"].min()) == 1.0
+    assert sd["encoder.head.5.num_batches_tracked"].dtype == torch.int64
+    assert abs(float(sd["encoder.node_tcn.blocks.2.conv1.weight"].std()) - 0.05) < 0.005
+    model.load_state_dict({k: torch.from_numpy(d["c0::sd::" + k]) for k in ref_keys})
+    model.eval()
+    z = model(torch.from_numpy(d["c0::x"]), torch.from_numpy(d["c0::a"]))
+    np.testing.assert_allclose(z.numpy(), d["c0::z_eval"], atol=2e-5, rtol=1e-4)
+    model.train()
+    z = model(torch.from_numpy(d["c0::x"]), torch.from_numpy(d["c0::a"]))      # batch statistics + buffer update
+    np.testing.assert_allclose(z.numpy(), d["c0::z"], atol=2e-5, rtol=1e-4)
+    assert int(model.state_dict()["encoder.head.2.num_batches_tracked"]) == int(d["c0::sd::encoder.head.2.num_batches_tracked"]) + 1
+    names = [f"n{i}" for i in range(4)]
+    meta = {"node_columns": [(n, "x") for n in names] + [(n, "y") for n in names] + names,
+            "edge_columns": [(names[i], names[i + 1]) for i in range(3)]}
+    pre_tr, pre_va = tiny_preprocessed(n_videos=1, n_win=16, W=12, seed=5), tiny_preprocessed(n_videos=1, n_win=8, W=12, seed=6)
+    mv, ms, mt, logs = TR.train_deepof_model(
+        preprocessed_object=(pre_tr, pre_va), meta_info=meta, adjacency_matrix=chain_adj(4), encoder_type="TCN",
+        batch_size=8, latent_dim=4, epochs=1, output_path=str(tmp_path), n_clusters=6, model_name="Contrastive",
+        use_turtle_teacher=False, save_weights=True, aug_max_interp=3, aug_min_interp=2, aug_max_shift=3,
+        _engine_factory=emu_factory)
+    assert isinstance(mv, Contrastive) and mv.encoder_type == "TCN" and len(logs["train"]["total_loss"]) == 1
+    assert np.isfinite(logs["train"]["total_loss"]).all() and np.isfinite(logs["val"]["total_loss"]).all()
+    loaded, *_ = TR.load_model_from_ckpt(str(tmp_path / "models" / "contrastive" / "run_0" / "best_model_val.pth"),
+                                         _engine_factory=emu_factory)
+    assert isinstance(loaded, Contrastive) and loaded.encoder_type == "TCN"
+    x = torch.from_numpy(reorder_and_reshape(pre_va["vid0"][0])[:8, 3:9]).contiguous()
+    a = torch.from_numpy(pre_va["vid0"][1][:8, 3:9, :, None]).contiguous()
+    np.testing.assert_allclose(loaded.embed(x, a).numpy(), mv.embed(x, a).numpy(), atol=1e-5)
+    sdl = loaded.state_dict()
+    assert int(sdl["encoder.head.2.num_batches_tracked"]) > 0   # BatchNorm counters travel with the bundle
