@@ -366,6 +366,6 @@ def run_contrastive_tcn_check(lib, device, golden_dir):
             # isolated near-zero-gradient elements elsewhere are tolerated
             if pfx + "grad::" + k in d:
                 bad &= np.abs(d[pfx + "grad::" + k].reshape(got.shape)) > 2e-5
-            assert bad.mean() <= 0.005 and np.abs(got - ref).max() <= 2.1e-3, (k, bad.sum(), np.abs(got - ref).max())
+            assert bad.mean() <= 0.005 and np.abs(got - ref).max() <= 4.2e-3, (k, bad.sum(), np.abs(got - ref).max())
     np.testing.assert_array_equal(sd2["encoder.spatial_gnn_block.node_kernel"].numpy(),
                                   d[pfx + "sd::encoder.spatial_gnn_block.node_kernel"])

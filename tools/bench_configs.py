@@ -6,8 +6,8 @@
 Prints one JSON line per configuration: whole train steps (window build -> forward -> loss -> backward ->
 clip + Adam) on device-resident synthetic data, fp32, eager launches on the current stream.
   c3  VQ-VAE, 14 body parts, window 25, codebook 512, batch 4096
-  c4  Contrastive, recurrent encoder on half windows (window 50 -> 25), batch 8192, nce / cosine
-      (BASELINE names the TCN encoder for this config; the TCN family is not built yet -- DESIGN.md)
+  c4  Contrastive, TCN encoder on half windows (window 50 -> 25), batch 8192, nce / cosine (as BASELINE names it)
+  c4r the same step with the recurrent encoder
   c5  VaDE, 2 animals (28 nodes, 32 edges), window 50, k=25, batch 4096, main phase
 """
 import argparse
@@ -82,7 +82,7 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
     return sec, logs["total_loss"], N, E
 
 
-def run_contrastive(B, Tf, steps, warmup, frames=200_000):
+def run_contrastive(B, Tf, steps, warmup, frames=200_000, kind="contrastive_tcn"):
     from deepof_amd import _capi, graph as G
     from deepof_amd.augment import build_rotation_precomp, draw_augmentation
     from deepof_amd.config import ContrastiveCfg
@@ -93,9 +93,20 @@ def run_contrastive(B, Tf, steps, warmup, frames=200_000):
     adj = G.adjacency_from_graph(nodes, edges)
     ei, eil = G.edge_index_from_graph(nodes, edges)
     eid = torch.from_numpy(ei).to(dev)
-    e1 = create_vade_engine(B, Tf // 2, adj, L, 1, device=dev, kind="contrastive")
-    e2 = create_vade_engine(B, Tf // 2, adj, L, 1, device=dev, kind="contrastive", shared=e1)
+    e1 = create_vade_engine(B, Tf // 2, adj, L, 1, device=dev, kind=kind)
+    e2 = create_vade_engine(B, Tf // 2, adj, L, 1, device=dev, kind=kind, shared=e1)
     init_params(e1)
+    if kind == "contrastive_tcn":
+        g = torch.Generator().manual_seed(0)
+        for n in e1.names:  # reference inits: conv ~ N(0, 0.05), BatchNorm identity, zero biases
+            if n.endswith("running_var") or ((".bn" in n or ".head.2" in n or ".head.5" in n) and n.endswith("weight")):
+                e1.view(n).fill_(1.0)
+            elif n.endswith("running_mean") or n.endswith("bias"):
+                e1.view(n).zero_()
+            elif "_tcn." in n:
+                e1.view(n).copy_(torch.randn(e1.layout[n][2], generator=g) * 0.05)
+            if ".spatial_gnn_block." in n:
+                e1.set_trainable(n, False)  # reference quirk Q11
     for seg in range(_capi.SEG_COUNT):
         e1.set_lr(seg, 1e-3)
     e1.set_hyper(clip=0.75, wd=1e-4)
@@ -133,7 +144,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--only", default="c3,c4,c5")
+    ap.add_argument("--only", default="c3,c4,c4r,c5")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a ROCm GPU")
@@ -142,10 +153,12 @@ def main():
             B = 4096
             sec, loss, N, E = run_vade_like("vqvae", [""], 25, 512, B, args.steps, args.warmup)
             desc = "C3: VQ-VAE recurrent, N=14,E=14, window=25, codebook=512, latent=8, batch=4096"
-        elif name == "c4":
+        elif name in ("c4", "c4r"):
             B = 8192
-            sec, loss, N, E = run_contrastive(B, 50, args.steps, args.warmup)
-            desc = ("C4 shape with the RECURRENT encoder: contrastive nce/cosine, N=14,E=14, window 50 -> half 25, "
+            kind = "contrastive_tcn" if name == "c4" else "contrastive"
+            sec, loss, N, E = run_contrastive(B, 50, args.steps, args.warmup, kind=kind)
+            desc = (f"C4{'' if name == 'c4' else ' shape with the RECURRENT encoder'}: contrastive "
+                    f"{'TCN' if name == 'c4' else 'recurrent'} encoder, nce/cosine, N=14,E=14, window 50 -> half 25, "
                     "latent=8, batch=8192, both views + augmentations")
         elif name == "c5":
             B = 4096
