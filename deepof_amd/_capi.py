@@ -23,7 +23,7 @@ LOG_KEYS = ("total_loss", "reconstruct_loss", "kl_div", "cat_clust_loss", "kmean
 LOG_ENC_REC, LOG_VQ, LOG_POPULATED, LOG_POS_SIM, LOG_NEG_SIM = 14, 15, 16, 17, 18
 MAX_ROT = 8
 SIMILARITIES = {"cosine": 0, "dot": 1, "euclidean": 2, "edit": 2}
-CONTRASTIVE_LOSSES = {"nce": 0, "dcl": 1, "hard_dcl": 2}
+CONTRASTIVE_LOSSES = {"nce": 0, "dcl": 1, "dlc": 1, "hard_dcl": 2, "fc": 3}
 LOG_COUNT = 20
 
 

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(64) k_cl_view(ViewArgs A) {
 // pairwise losses
 // ---------------------------------------------------------------------------------------------
 enum { CL_SIM_COSINE = 0, CL_SIM_DOT = 1, CL_SIM_EUCLID = 2 };
-enum { CL_LOSS_NCE = 0, CL_LOSS_DCL = 1, CL_LOSS_HARD = 2 };
+enum { CL_LOSS_NCE = 0, CL_LOSS_DCL = 1, CL_LOSS_HARD = 2, CL_LOSS_FC = 3 };
 
 struct ClArgs {
   const float* z;    // (B, L) encoder outputs of the central view
@@ -128,6 +128,8 @@ struct ClArgs {
   float* inv;        // (2, B)  1 / max(|z|, 1e-12)
   float* rn;         // (2, B)  cosine: 1 / max(|zn|, 1e-8); otherwise 1
   float* rowstat;    // (B, 4)  s_ii, and the row's weights: dL/ds_ij = ca*e + cb*e^2 (j != i), dL/ds_ii = cd
+  float* theta;      // (B) fc: largest similarity kept by the row's top-k elimination (+inf otherwise)
+  int fc_keep;       // fc: negatives kept per row = (B-1) - ceil(min(topk, 0.5) * B)
   float* partial;    // (nblk, 3) block sums of loss_i, s_ii, sum_{j != i} s_ij
   float* dz;         // (B, L) d loss / d z
   float* dza;        // (B, L) d loss / d z_aug
@@ -182,6 +184,61 @@ __device__ __forceinline__ float cl_sim(int sim, const float* x, const float* y,
   return sim == CL_SIM_COSINE ? dot * rx * ry : dot;
 }
 
+// order-preserving map float -> uint32 (and back) for the bisection of the fc loss
+__device__ __forceinline__ unsigned cl_f2o(float f) {
+  const unsigned u = __builtin_bit_cast(unsigned, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float cl_o2f(unsigned o) {
+  const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __builtin_bit_cast(float, u);
+}
+
+// fc loss (losses.py:176-208): each row drops its k LARGEST negatives.  theta_i = the fc_keep-th smallest
+// off-diagonal similarity of row i, found by a 32-step bisection over the ordered bit patterns (every step
+// recounts the row; similarities are recomputed, never stored).  A block handles 256 rows so the tiles of the
+// other side are shared.
+template <int L>
+__global__ void __launch_bounds__(256) k_cl_fc_threshold(ClArgs A) {
+  __shared__ float ty[256][L + 1];
+  __shared__ float tr[256];
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  const bool live = i < A.B;
+  float x[L], rx = 1.0f;
+  if (live) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) x[l] = A.zn[(int64_t)i * L + l];
+    rx = A.rn[i];
+  }
+  const float* yn = A.zn + (int64_t)A.B * L;
+  const float* ryv = A.rn + A.B;
+  unsigned lo = 0u, hi = 0xffffffffu;  // smallest v with count(s <= v) >= fc_keep
+  for (int it = 0; it < 32; ++it) {
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    const float fm = cl_o2f(mid);
+    int cnt = 0;
+    for (int j0 = 0; j0 < A.B; j0 += 256) {
+      __syncthreads();
+      if (j0 + tid < A.B) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) ty[tid][l] = yn[(int64_t)(j0 + tid) * L + l];
+        tr[tid] = ryv[j0 + tid];
+      }
+      __syncthreads();
+      if (!live) continue;
+      const int nj = A.B - j0 < 256 ? A.B - j0 : 256;
+      for (int jj = 0; jj < nj; ++jj) {
+        float aux;
+        const float s = cl_sim<L>(A.sim, x, ty[jj], rx, tr[jj], &aux);
+        cnt += (j0 + jj != i && s <= fm) ? 1 : 0;
+      }
+    }
+    if (cnt >= A.fc_keep) hi = mid; else lo = mid + 1;
+  }
+  if (live) A.theta[i] = A.fc_keep > 0 ? cl_o2f(hi) : -INFINITY;
+}
+
 template <int L>
 __global__ void __launch_bounds__(256) k_cl_rowstats(ClArgs A) {
   __shared__ float ty[256][L + 1];
@@ -198,6 +255,7 @@ __global__ void __launch_bounds__(256) k_cl_rowstats(ClArgs A) {
   const float* yn = A.zn + (int64_t)A.B * L;
   const float* ryv = A.rn + A.B;
   float a1 = 0.0f, a2 = 0.0f, soff = 0.0f, p = 0.0f;
+  const float th = (A.loss_fn == CL_LOSS_FC && live) ? A.theta[i] : INFINITY;
   for (int j0 = 0; j0 < A.B; j0 += 256) {
     __syncthreads();
     if (j0 + tid < A.B) {
@@ -213,7 +271,7 @@ __global__ void __launch_bounds__(256) k_cl_rowstats(ClArgs A) {
       const float s = cl_sim<L>(A.sim, x, ty[jj], rx, tr[jj], &aux);
       if (j0 + jj == i) {
         p = s;
-      } else {
+      } else if (s <= th) {
         const float e = __expf((s - 1.0f) * A.inv_T);
         a1 += e;
         a2 = fmaf(e, e, a2);
@@ -226,7 +284,7 @@ __global__ void __launch_bounds__(256) k_cl_rowstats(ClArgs A) {
     const float ne = (float)(A.B - 1), invB = 1.0f / (float)A.B;
     const float pos = __expf((p - 1.0f) * A.inv_T);
     float den, ca, cb = 0.0f, cd;
-    if (A.loss_fn == CL_LOSS_NCE) {
+    if (A.loss_fn == CL_LOSS_NCE || A.loss_fn == CL_LOSS_FC) {  // fc: the same form over the kept negatives
       den = pos + a1;
       ca = A.inv_T / den;
       cd = A.inv_T * (pos / den - 1.0f);
@@ -261,7 +319,7 @@ template <int L, bool COLS>
 __global__ void __launch_bounds__(256) k_cl_grad(ClArgs A) {
   __shared__ float ty[256][L + 1];
   __shared__ float tr[256];
-  __shared__ float tw[256][3];
+  __shared__ float tw[256][4];
   const int tid = threadIdx.x;
   const int i = blockIdx.x * 256 + tid;
   const bool live = i < A.B;
@@ -269,13 +327,15 @@ __global__ void __launch_bounds__(256) k_cl_grad(ClArgs A) {
   const float* oth = A.zn + (COLS ? 0 : (int64_t)A.B * L);
   const float* rown = A.rn + (COLS ? A.B : 0);
   const float* roth = A.rn + (COLS ? 0 : A.B);
-  float x[L], rx = 1.0f, ca = 0.0f, cb = 0.0f, cd = 0.0f;
+  float x[L], rx = 1.0f, ca = 0.0f, cb = 0.0f, cd = 0.0f, th = INFINITY;
+  const bool fc = A.loss_fn == CL_LOSS_FC;
   if (live) {
 #pragma unroll
     for (int l = 0; l < L; ++l) x[l] = own[(int64_t)i * L + l];
     rx = rown[i];
     if (!COLS) {
       ca = A.rowstat[(int64_t)i * 4 + 1]; cb = A.rowstat[(int64_t)i * 4 + 2]; cd = A.rowstat[(int64_t)i * 4 + 3];
+      if (fc) th = A.theta[i];
     }
   }
   float V[L], sx = 0.0f;
@@ -291,6 +351,7 @@ __global__ void __launch_bounds__(256) k_cl_grad(ClArgs A) {
         tw[tid][0] = A.rowstat[(int64_t)(j0 + tid) * 4 + 1];
         tw[tid][1] = A.rowstat[(int64_t)(j0 + tid) * 4 + 2];
         tw[tid][2] = A.rowstat[(int64_t)(j0 + tid) * 4 + 3];
+        tw[tid][3] = fc ? A.theta[j0 + tid] : INFINITY;
       }
     }
     __syncthreads();
@@ -300,11 +361,13 @@ __global__ void __launch_bounds__(256) k_cl_grad(ClArgs A) {
       float aux;
       const float s = cl_sim<L>(A.sim, x, ty[jj], rx, tr[jj], &aux);
       if (COLS) {
-        ca = tw[jj][0]; cb = tw[jj][1]; cd = tw[jj][2];
+        ca = tw[jj][0]; cb = tw[jj][1]; cd = tw[jj][2]; th = tw[jj][3];
       }
       float w;
       if (j0 + jj == i) {
         w = cd;
+      } else if (s > th) {
+        w = 0.0f;  // negative eliminated by the row's top-k rule
       } else {
         const float e = __expf((s - 1.0f) * A.inv_T);
         w = e * fmaf(cb, e, ca);
@@ -350,7 +413,8 @@ __global__ void __launch_bounds__(64) k_cl_finalize(ClArgs A) {
     for (int k = 0; k < DOF_LOG_COUNT; ++k) A.logs[k] = 0.0f;
     A.logs[DOF_LOG_TOTAL] = acc[0] / B;
     A.logs[DOF_LOG_POS_SIM] = acc[1] / B;
-    A.logs[DOF_LOG_NEG_SIM] = A.B > 1 ? acc[2] / (B * (B - 1.0f)) : 0.0f;
+    const float per_row = A.loss_fn == CL_LOSS_FC ? (float)A.fc_keep : B - 1.0f;
+    A.logs[DOF_LOG_NEG_SIM] = per_row > 0.0f ? acc[2] / (B * per_row) : 0.0f;
   }
 }
 

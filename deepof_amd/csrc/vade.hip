@@ -9,6 +9,7 @@
 // Reference call path being replaced:  /root/reference/deepof/clustering/training.py:130-166
 // (train_one_epoch_indexed body) -> step_vade :231-309 -> VaDEPT.forward models_new.py:1841-1891
 // -> VadeLoss.forward losses.py:567-797 -> backward -> clip -> Adam.
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -141,7 +142,7 @@ struct DofVadePlan {
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
   int64_t partials, segs_tab, mask_tab;
   int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
-  int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks;  // contrastive loss scratch
+  int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
   // TCN encoder (kind 3)
   int D = 0;  // CensNet input channels: 2L (recurrent blocks) or 32 (TCN features)
   TcnBlockOff tblk[2][8];
@@ -405,6 +406,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
   p->cl_inv = cv.take(2 * p->B);
   p->cl_rn = cv.take(2 * p->B);
   p->cl_rowstat = cv.take(4 * p->B);
+  p->cl_theta = cv.take(p->B);
   p->cl_partial = cv.take(3 * p->cl_blocks);
   p->hd_hn = cv.take((int64_t)p->J * Bp);
   p->hd_rinv = cv.take(Bp);
@@ -482,6 +484,7 @@ void build_workspace_layout(DofVadePlan* p) {
     p->cl_inv = cv.take(2 * p->B);
     p->cl_rn = cv.take(2 * p->B);
     p->cl_rowstat = cv.take(4 * p->B);
+    p->cl_theta = cv.take(p->B);
     p->cl_partial = cv.take(3 * p->cl_blocks);
     for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
       js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
@@ -1567,9 +1570,9 @@ extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float*
     dof_set_error("dof_contrastive_loss: unknown similarity %d", similarity);
     return DOF_ERR_ARG;
   }
-  if (loss_fn < DOF_CLOSS_NCE || loss_fn > DOF_CLOSS_HARD_DCL) {
-    dof_set_error("dof_contrastive_loss: loss function %d not supported by this build (nce, dcl, hard_dcl)", loss_fn);
-    return DOF_ERR_UNSUPPORTED;
+  if (loss_fn < DOF_CLOSS_NCE || loss_fn > DOF_CLOSS_FC) {
+    dof_set_error("dof_contrastive_loss: unknown loss function %d", loss_fn);
+    return DOF_ERR_ARG;
   }
   if (!(temperature > 0.0f) || !(tau < 1.0f)) {
     dof_set_error("dof_contrastive_loss: temperature must be > 0 and tau < 1");
@@ -1582,7 +1585,15 @@ extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float*
   A.rowstat = ws + p->cl_rowstat; A.partial = ws + p->cl_partial; A.dz = dz; A.dza = dz_aug; A.logs = logs;
   A.sim = similarity; A.loss_fn = loss_fn; A.inv_T = 1.0f / temperature; A.tau = tau; A.beta = beta;
   A.B = (int)p->B; A.nblk = (int)p->cl_blocks;
+  A.theta = ws + p->cl_theta;
+  {  // fc (losses.py:176-208; the caller hard-wires elimination_topk = 0.1, training.py:545 / Q16)
+    int k = (int)ceil(0.1 * (double)p->B);
+    if (k < 1) k = 1;
+    A.fc_keep = (int)p->B - 1 - k;
+    if (A.fc_keep < 0) A.fc_keep = 0;
+  }
   LDISPATCH(p->L, DOF_LAUNCH((k_cl_normalize<LL>), (dof_cdiv(2 * p->B, 256)), (256), st, A));
+  if (loss_fn == DOF_CLOSS_FC) LDISPATCH(p->L, DOF_LAUNCH((k_cl_fc_threshold<LL>), ((unsigned)A.nblk), (256), st, A));
   LDISPATCH(p->L, DOF_LAUNCH((k_cl_rowstats<LL>), ((unsigned)A.nblk), (256), st, A));
   TRY(dof_check_launch("k_cl_rowstats"));
   if (dz) {

@@ -190,7 +190,7 @@ int dof_contrastive_encode(DofVadePlan* plan, const float* params, const float* 
                            float* z_out, void* stream);
 
 enum { DOF_SIM_COSINE = 0, DOF_SIM_DOT = 1, DOF_SIM_EUCLIDEAN = 2 /* also "edit" */ };
-enum { DOF_CLOSS_NCE = 0, DOF_CLOSS_DCL = 1, DOF_CLOSS_HARD_DCL = 2 /* "fc": not in this build */ };
+enum { DOF_CLOSS_NCE = 0, DOF_CLOSS_DCL = 1, DOF_CLOSS_HARD_DCL = 2, DOF_CLOSS_FC = 3 /* top-10 % negatives dropped per row */ };
 /* Row-normalises z / z_aug (B, L), evaluates the loss over all B x B pairs, writes d loss / d z and
  * d loss / d z_aug (B, L; either may be NULL together = value only) and logs[DOF_LOG_TOTAL |
  * DOF_LOG_POS_SIM | DOF_LOG_NEG_SIM].  Scratch comes from the plan's workspace. */

@@ -215,7 +215,7 @@ def run_contrastive_loss_check(lib, device, golden_dir, tag):
     B, L = z.shape
     eng = VadeEngine(lib, device, B, 12, d["adj"], L, 1, kind="contrastive")
     for sim in ("cosine", "dot", "euclidean", "edit"):
-        for lf in ("nce", "dcl", "hard_dcl"):
+        for lf in ("nce", "dcl", "hard_dcl", "fc"):
             dz, dza = eng.contrastive_loss(z, za, sim, lf, 0.1, 0.1, 0.1)
             logs = eng.read_contrastive_logs()
             ref = d[f"loss::{sim}::{lf}"]
@@ -230,7 +230,7 @@ def run_contrastive_loss_check(lib, device, golden_dir, tag):
                 np.testing.assert_allclose(got.cpu().numpy(), proj.numpy(), rtol=2e-4, atol=2e-6,
                                            err_msg=f"{sim}/{lf}")
     with np.testing.assert_raises(NotImplementedError):
-        eng.contrastive_loss(z, za, "cosine", "fc")
+        eng.contrastive_loss(z, za, "cosine", "triplet")
 
 
 def run_contrastive_check(lib, device, golden_dir, tag):

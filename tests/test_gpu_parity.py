@@ -303,7 +303,7 @@ def test_contrastive_full_size_c4(hip):
     _, _, g2, _ = step()
     assert torch.equal(g1, g2) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
     assert 0.0 < logs["total_loss"] < np.log(B) + 1.0 / 0.1 * 2 and -1.0 <= logs["neg_similarity"] <= logs["pos_similarity"] <= 1.0
-    for sim, lf in (("cosine", "nce"), ("euclidean", "hard_dcl"), ("dot", "dcl")):
+    for sim, lf in (("cosine", "nce"), ("euclidean", "hard_dcl"), ("dot", "dcl"), ("cosine", "fc")):
         e1.contrastive_loss(z, za, sim, lf, 0.1, 0.1, 0.1, want_grads=False)
         got = e1.read_contrastive_logs()
         zn, zan = (torch.nn.functional.normalize(t.cpu().double(), dim=1) for t in (z, za))

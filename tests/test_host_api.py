@@ -317,9 +317,9 @@ def test_contrastive_model_and_fit(golden_dir, tmp_path):
     x = torch.from_numpy(reorder_and_reshape(pre_va["vid0"][0])[:8, 3:9]).contiguous()
     a = torch.from_numpy(pre_va["vid0"][1][:8, 3:9, :, None]).contiguous()
     np.testing.assert_allclose(loaded.embed(x, a).numpy(), mv.embed(x, a).numpy(), atol=1e-5)
-    with pytest.raises(NotImplementedError):
-        TR.train_deepof_model(preprocessed_object=(pre_tr, pre_va), meta_info=meta,
-                              **{**kw, "contrastive_loss_function": "fc"})
+    *_, logs_fc = TR.train_deepof_model(preprocessed_object=(pre_tr, pre_va), meta_info=meta,
+                                        **{**kw, "contrastive_loss_function": "fc", "epochs": 1})
+    assert np.isfinite(logs_fc["train"]["total_loss"]).all()
 
 
 def test_contrastive_tcn_model_and_fit(golden_dir, tmp_path):
