@@ -79,3 +79,20 @@ def tcn_encoder(x, a, P, training, prefix="encoder"):
     h = torch.relu(F.linear(h, P[prefix + ".head.3.weight"], P[prefix + ".head.3.bias"]))
     h = _bn(h, P, prefix + ".head.5", training, 0.01)
     return F.linear(h, P[prefix + ".head.6.weight"], P[prefix + ".head.6.bias"])
+
+
+def tcn_decoder(z, x_flat, P, training, prefix="decoder"):
+    """TCNDecoderPT.forward (models_new.py:713-819): z (B,L), x_flat (B,T,3N) -> (loc (B,T,3N), valid (B,T)).
+    RMS guard -> Linear -> BN -> Linear -> ReLU -> BN -> Linear -> ReLU -> BN -> repeat over T -> TCN(64 filters,
+    dilations 8,4,2,1, return_sequences) -> Linear(64 -> 3N)."""
+    B, T, _ = x_flat.shape
+    valid = ~torch.all(x_flat == 0.0, dim=-1)
+    g = z.float()
+    rms = g.pow(2).mean(dim=1, keepdim=True).sqrt()
+    g = torch.nan_to_num((g / rms.clamp(min=1.0)).clamp(min=-1e4, max=1e4), nan=0.0, posinf=1e4, neginf=-1e4)
+    h = _bn(F.linear(g, P[prefix + ".fc0.weight"], P[prefix + ".fc0.bias"]), P, prefix + ".bn0", training, 0.01)
+    h = _bn(torch.relu(F.linear(h, P[prefix + ".fc1.weight"], P[prefix + ".fc1.bias"])), P, prefix + ".bn1", training, 0.01)
+    h = _bn(torch.relu(F.linear(h, P[prefix + ".fc2.weight"], P[prefix + ".fc2.bias"])), P, prefix + ".bn2", training, 0.01)
+    hidden = tcn(h.unsqueeze(1).repeat(1, T, 1), P, prefix + ".tcn", training, return_sequences=True)
+    loc = F.linear(hidden, P[prefix + ".prob_decoder.loc_projection.weight"], P[prefix + ".prob_decoder.loc_projection.bias"])
+    return torch.nan_to_num(loc, nan=0.0, posinf=1e6, neginf=-1e6), valid

@@ -182,9 +182,15 @@ def vade_forward(P: Params, x: torch.Tensor, a: torch.Tensor, training: bool,
                  eps: Optional[torch.Tensor] = None, kmeans_weight: float = 1.0):
     """VaDEPT.forward, models_new.py:1841-1891.  Returns dict with loc/valid/z/q/z_mean/z_log_var/kmeans."""
     B, T = x.shape[:2]
-    h = encoder(x, a, P)
-    lat = gmm_latent(h, P, training, eps, kmeans_weight)
-    loc, valid = decoder(lat["z"], x.reshape(B, T, -1), P)
+    if "encoder.node_tcn.blocks.0.conv1.weight" in P:  # TCN family (models_new.py:518-819): BatchNorm follows `training`
+        from . import tcn as ot
+        h = ot.tcn_encoder(x, a, P, training)
+        lat = gmm_latent(h, P, training, eps, kmeans_weight)
+        loc, valid = ot.tcn_decoder(lat["z"], x.reshape(B, T, -1), P, training)
+    else:
+        h = encoder(x, a, P)
+        lat = gmm_latent(h, P, training, eps, kmeans_weight)
+        loc, valid = decoder(lat["z"], x.reshape(B, T, -1), P)
     lat.update(loc=loc, valid=valid, enc=h)
     return lat
 
@@ -320,7 +326,8 @@ def vade_loss(out: dict, x: torch.Tensor, P: Params, cfg: VadeLossCfg, klw: floa
 # train step (autograd + clip_grad_value_ + Adam), training.py:159-166, losses.py:817-833
 # --------------------------------------------------------------------------------------
 GMM_KEYS = ("latent_space.gmm_means", "latent_space.gmm_log_vars")
-BUFFER_SUFFIXES = ("laplacian", "edge_laplacian", "incidence", "prior", "pretrain")
+BUFFER_SUFFIXES = ("laplacian", "edge_laplacian", "incidence", "prior", "pretrain", "running_mean", "running_var",
+                   "num_batches_tracked")
 
 
 def trainable_keys(P: Params):

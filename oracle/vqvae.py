@@ -35,11 +35,20 @@ def vq_layer(ze: torch.Tensor, codebook: torch.Tensor, beta: float = 1.0, kmeans
     return dict(quantized=quantized, idx=idx, soft_counts=soft, vq_loss=vq_loss, kmeans_loss=km, distances=dist)
 
 
-def vqvae_forward(P: Params, x: torch.Tensor, a: torch.Tensor, beta: float = 1.0, kmeans_weight: float = 0.0):
+def vqvae_forward(P: Params, x: torch.Tensor, a: torch.Tensor, beta: float = 1.0, kmeans_weight: float = 0.0,
+                  training: bool = True):
     B, T = x.shape[:2]
+    x_flat = x.reshape(B, T, -1)
+    if "encoder.node_tcn.blocks.0.conv1.weight" in P:  # TCN family: encoder, then the decoder on q, then on z_e
+        from . import tcn as ot
+        ze = ot.tcn_encoder(x, a, P, training)
+        vq = vq_layer(ze, P["vq_layer.codebook"], beta, kmeans_weight)
+        loc_q, valid = ot.tcn_decoder(vq["quantized"], x_flat, P, training)
+        loc_e, _ = ot.tcn_decoder(ze, x_flat, P, training)
+        vq.update(ze=ze, loc_q=loc_q, loc_e=loc_e, valid=valid)
+        return vq
     ze = OV.encoder(x, a, P)
     vq = vq_layer(ze, P["vq_layer.codebook"], beta, kmeans_weight)
-    x_flat = x.reshape(B, T, -1)
     loc_q, valid = OV.decoder(vq["quantized"], x_flat, P)
     loc_e, _ = OV.decoder(ze, x_flat, P)
     vq.update(ze=ze, loc_q=loc_q, loc_e=loc_e, valid=valid)

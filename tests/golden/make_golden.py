@@ -494,6 +494,79 @@ def gen_contrastive(tag, ids, T_full, L, B, seed, encoder_type="recurrent", case
     np.savez_compressed(os.path.join(HERE, f"contrastive_{tag}.npz"), **out)
 
 
+def gen_vade_tcn(tag, ids, T, L, K, B, seed):
+    """VaDEPT(encoder_type="TCN") -- TCN encoder + GMM latent + TCN decoder (R12): eval forward, and for two phases
+    (each restarted from the same initial state, BatchNorm buffers included) the train-mode outputs, loss terms,
+    BatchNorm buffers after the pass, and gradients (all of them for "pre"; the latent space only for "mainT")."""
+    nodes, edges = bodypart_graph(ids)
+    adj = adjacency_from_graph(nodes, edges)
+    N, E = len(nodes), len(edges)
+    torch.manual_seed(seed)
+    model = R.M.VaDEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type="TCN", kmeans_loss=1.0)
+    model.eval()
+    R.U._materialize_encoder(model, (T, N, 3), (T, E, 1), torch.device("cpu"))
+    with torch.no_grad():
+        model.latent_space.gmm_means.mul_(3.0)
+        for n, b in model.named_buffers():      # non-trivial running statistics for the eval-mode check
+            if n.endswith("running_mean"):
+                b.normal_(0.0, 0.1)
+            elif n.endswith("running_var"):
+                b.uniform_(0.5, 1.5)
+    x, a = synth_batch(B, T, N, E, seed + 1)
+    xt, at = torch.from_numpy(x), torch.from_numpy(a)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    out = dict(sd_np(model))
+    out.update(x=x, a=a, adj=adj)
+    with torch.no_grad():
+        dist, z, q, km = model(xt, at)
+        enc = model.encoder(xt, at)
+    out.update(eval_z=z.numpy(), eval_q=q.numpy(), eval_loc=dist.base_dist.base_dist.loc.numpy(), eval_enc=enc.numpy())
+    eps = torch.randn(B, L, generator=torch.Generator().manual_seed(seed + 2))
+    eps_mc = torch.randn(32, B, L, generator=torch.Generator().manual_seed(seed + 3))
+    tau = torch.softmax(torch.randn(B, K, generator=torch.Generator().manual_seed(seed + 4)) * 2.0, dim=-1)
+    out.update(eps=eps.numpy(), eps_mc=eps_mc.numpy(), tau=tau.numpy())
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def patched_randn(*size, **kw):
+        if len(size) == 3 and tuple(size) == (32, B, L):
+            return eps_mc.clone()
+        return real_randn(*size, **kw)
+
+    def patched_randn_like(t, **kw):
+        if tuple(t.shape) == (B, L):
+            return eps.clone()
+        return real_randn_like(t, **kw)
+
+    for phase, klw, with_teacher in [("pre", 0.13, False), ("mainT", 0.7, True)]:
+        model.load_state_dict(sd0)
+        common, vade, teacher = _cfgs(K, L)
+        crit = R.L.VadeLoss(common_cfg=common, vade_cfg=vade, teacher_cfg=teacher)
+        crit.set_mode("pretrain" if phase == "pre" else "main")
+        crit.kl_scheduler = SimpleNamespace(get_weight=lambda k=klw: k, max_weight=1.0, current_iteration=0)
+        if with_teacher:
+            crit.set_teacher(tau_star=tau, lambda_distill=1.7)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        torch.randn, torch.randn_like = patched_randn, patched_randn_like
+        try:
+            outputs = model(xt, at, return_gmm_params=True)
+            ld = crit(outputs, xt, batch_indices=torch.arange(B) if with_teacher else None)
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_randn_like
+        ld["total_loss"].backward()
+        for k, v in ld.items():
+            out[f"{phase}::loss::{k}"] = np.float64(float(v))
+        out[f"{phase}::z"] = outputs[1].detach().numpy()
+        out[f"{phase}::q"] = outputs[2].detach().numpy()
+        out[f"{phase}::loc"] = outputs[0].base_dist.base_dist.loc.detach().numpy()
+        for n, p in model.named_parameters():
+            if p.grad is not None and (phase == "pre" or n.startswith("latent_space") or n.startswith("decoder.fc")):
+                out[f"{phase}::grad::{n}"] = p.grad.numpy().copy()
+        if phase == "pre":
+            out.update({k: v for k, v in sd_np(model, "pre::sd_after::").items() if "running_" in k})
+    np.savez_compressed(os.path.join(HERE, f"vade_{tag}.npz"), **out)
+
+
 if __name__ == "__main__":
     gen_scramble()
     gen_graph_ops()
@@ -507,6 +580,7 @@ if __name__ == "__main__":
     gen_contrastive("rec14", [""], 24, 8, 16, 61)
     gen_contrastive("rec28", ["B", "W"], 25, 6, 7, 71)
     gen_contrastive("tcn14", [""], 24, 8, 6, 81, encoder_type="TCN", cases=[("cosine", "nce")])
+    gen_vade_tcn("tcn14", [""], 25, 8, 10, 6, 91)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

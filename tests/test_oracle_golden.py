@@ -312,3 +312,48 @@ def test_tcn_contrastive_matches_reference(golden_dir):
             np.testing.assert_allclose(grads[name].numpy(), d[k], atol=6e-5, rtol=5e-4, err_msg=name)
             n += 1
     assert n == 148
+
+
+def test_vade_tcn_matches_reference(golden_dir):
+    """VaDE with the TCN encoder AND decoder (R12): eval forward on running statistics, then train-mode outputs,
+    loss terms, BatchNorm buffers and gradients for the pre-training and the main (+teacher) objective."""
+    d = _load(golden_dir, "vade_tcn14.npz")
+    x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
+    K, L = d["sd::latent_space.gmm_means"].shape
+    P0 = _params(d)
+    with torch.no_grad():
+        out = OV.vade_forward({k: v.clone() for k, v in P0.items()}, x, a, training=False)
+    np.testing.assert_allclose(out["enc"].numpy(), d["eval_enc"], atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(out["z"].numpy(), d["eval_z"], atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(out["q"].numpy(), d["eval_q"], atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(out["loc"].numpy(), d["eval_loc"], atol=1e-5, rtol=1e-5)
+    eps, eps_mc, tau = (torch.from_numpy(d[k]) for k in ("eps", "eps_mc", "tau"))
+    for phase, klw, teacher in (("pre", 0.13, False), ("mainT", 0.7, True)):
+        P = {k: v.clone() for k, v in P0.items()}
+        kw = {}
+        if teacher:
+            pi = tau.mean(0).clamp_min(1e-8)
+            w = pi.pow(-1.0)
+            kw = dict(lambda_distill=1.7, class_weight=(w / w.mean()).clamp_max(3.0), teacher_marginal=pi)
+        cfg = OV.VadeLossCfg(K, phase == "pre", **kw)
+        losses, grads, out = OV.vade_grads(P, x, a, cfg, klw, eps, None if phase == "pre" else eps_mc,
+                                           tau if teacher else None)
+        np.testing.assert_allclose(out["z"].detach().numpy(), d[f"{phase}::z"], atol=5e-6, rtol=1e-5)
+        np.testing.assert_allclose(out["loc"].detach().numpy(), d[f"{phase}::loc"], atol=2e-5, rtol=1e-5)
+        for k in d:
+            if k.startswith(f"{phase}::loss::"):
+                name = k.split("::")[-1]
+                if name in losses:
+                    np.testing.assert_allclose(float(losses[name]), float(d[k]), rtol=2e-5, atol=2e-6, err_msg=k)
+        n = 0
+        for k in d:
+            if k.startswith(f"{phase}::grad::"):
+                name = k.split("::")[-1]
+                np.testing.assert_allclose(grads[name].numpy(), d[k], atol=1e-4 + 2e-5 * np.abs(d[k]).max(), rtol=1e-3,
+                                           err_msg=f"{phase} {name}")
+                n += 1
+        assert n >= (250 if phase == "pre" else 10)
+        if phase == "pre":
+            for k in d:
+                if k.startswith("pre::sd_after::"):
+                    np.testing.assert_allclose(P[k[len("pre::sd_after::"):]].numpy(), d[k], atol=2e-6, rtol=2e-5, err_msg=k)
