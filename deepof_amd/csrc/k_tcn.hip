@@ -194,6 +194,102 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
   }
 }
 
+// Generic variant for the 64-filter decoder TCN: KC input channels per tap, NC output channels, the whole
+// (4 KC) x NC weight matrix staged ONCE per workgroup in LDS in B-operand order (64 KB for 64 x 64), so an
+// MFMA's B value is one conflict-free ds_read_b32.  cin_real < KC (decoder block 0: 4L inputs) is zero-padded.
+template <bool REVERSE, bool BN_IN, int KC, int NC>
+__global__ void __launch_bounds__(256) k_tcn_convg(TcnConvArgs A, int cin_real, int w_ci) {
+  constexpr int KS = KC / 4, NT = NC / 16;
+  __shared__ float wl[TK * KS * NT * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  for (int e = threadIdx.x; e < TK * KS * NT * 64; e += blockDim.x) {
+    const int ln = e & 63, ct = (e >> 6) % NT, ks = ((e >> 6) / NT) % KS, j = (e >> 6) / (NT * KS);
+    const int ch = (ln >> 4) * KS + ks, n = ct * 16 + (ln & 15);
+    // forward: W[o = n][c = ch][j] (c < cin_real); reverse: W[o = ch][c = n][j] (c = n < cin_real)
+    float v;
+    if (REVERSE) v = n < cin_real ? A.w[((int64_t)ch * w_ci + n) * TK + j] : 0.0f;
+    else v = ch < cin_real ? A.w[((int64_t)n * w_ci + ch) * TK + j] : 0.0f;
+    wl[e] = v;
+  }
+  __syncthreads();
+  float sc[KS], sh[KS];
+  if (BN_IN) {
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      sc[q] = BNP_SCALE(A.bnp_in, KC, kk * KS + q);
+      sh[q] = BNP_SHIFT(A.bnp_in, KC, kk * KS + q);
+    }
+  }
+  float bias[NT], s1[NT], s2[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    bias[ct] = (!REVERSE && A.bias) ? A.bias[ct * 16 + i] : 0.0f;
+    s1[ct] = s2[ct] = 0.0f;
+  }
+  const int64_t tiles_per_t = A.Sp / 16;
+  const int64_t n_tiles = (int64_t)A.T * tiles_per_t;
+  for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+    const int t = (int)(tile / tiles_per_t);
+    const int64_t s0 = (tile - (int64_t)t * tiles_per_t) * 16;
+    dof_f32x4 acc[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      const dof_f32x4 bv = {bias[ct], bias[ct], bias[ct], bias[ct]};
+      acc[ct] = bv;
+    }
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      const int tt = REVERSE ? t + (TK - 1 - j) * A.dil : t - (TK - 1 - j) * A.dil;
+      if (tt >= 0 && tt < A.T) {
+        float a[KS];
+        dof_ld_row<KS>(A.in + ACT(tt, kk * KS, KC, A.Sp, s0 + i), a);
+        if (BN_IN) {
+#pragma unroll
+          for (int q = 0; q < KS; ++q) a[q] = fmaxf(fmaf(a[q], sc[q], sh[q]), 0.0f);
+          if (!REVERSE && j == TK - 1 && A.a_out && s0 + i < A.S) dof_st_row<KS>(A.a_out + ACT(t, kk * KS, KC, A.Sp, s0 + i), a);
+        }
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wl[((j * KS + q) * NT + ct) * 64 + lane], acc[ct], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t s = s0 + kk * 4 + r;
+      if (s < A.S) {
+        float* o = A.out + ACT(t, 0, NC, A.Sp, s);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          float v = acc[ct][r];
+          if (REVERSE && A.accumulate) v += o[ct * 16 + i];
+          o[ct * 16 + i] = v;
+          if (!REVERSE) {
+            s1[ct] += v;
+            s2[ct] = fmaf(v, v, s2[ct]);
+          }
+        }
+      }
+    }
+  }
+  if (!REVERSE && A.partial) {
+    float* p = A.partial + (int64_t)wave * 2 * NC;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      s1[ct] += __shfl_xor(s1[ct], 16); s1[ct] += __shfl_xor(s1[ct], 32);
+      s2[ct] += __shfl_xor(s2[ct], 16); s2[ct] += __shfl_xor(s2[ct], 32);
+      if (kk == 0) {
+        p[ct * 16 + i] = s1[ct];
+        p[NC + ct * 16 + i] = s2[ct];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (shared by the TCN layers, C = 32, and the head, C = 2L / L)
 // ---------------------------------------------------------------------------------------------
@@ -243,44 +339,46 @@ __global__ void __launch_bounds__(64) k_bn_bwd_fin(const float* __restrict__ sum
 struct TcnCombineArgs {
   const float* y2;
   const float* bnp2;
-  const float* res;    // [T][Sp][32] previous block output, or null on block 0
+  const float* res;    // [T][Sp][CT] previous block output, or null on block 0
   const float* xs;     // [T][Sp][F] raw input (block 0)
-  const float *dsw, *dsb;  // (32,F,1), (32)
-  float* out;          // [T][Sp][32] or null (last block: unused by the reference)
-  float* skip;         // [T][Sp][32] running sum
+  const float *dsw, *dsb;  // (CT,F,1), (CT)
+  float* out;          // [T][Sp][CT] or null (encoder's last block: unused by the reference)
+  float* skip;         // [T][Sp][CT] running sum
   float* feat;         // [32][Sp] or null
-  int first, T, F;
+  int first, T, F, CT;
   int64_t S, Sp;
 };
 
+// thread = (row (t,s), 32-channel half blockIdx.y of the CT = 32 | 64 channels)
 __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)A.T * A.S) return;
   const int t = (int)(i / A.S);
   const int64_t s = i - (int64_t)t * A.S;
+  const int c0 = blockIdx.y * TC, CT = A.CT;
   float y[TC], r[TC], sk[TC];
-  dof_ld_row<TC>(A.y2 + ACT(t, 0, TC, A.Sp, s), y);
+  dof_ld_row<TC>(A.y2 + ACT(t, c0, CT, A.Sp, s), y);
   if (A.res) {
-    dof_ld_row<TC>(A.res + ACT(t, 0, TC, A.Sp, s), r);
+    dof_ld_row<TC>(A.res + ACT(t, c0, CT, A.Sp, s), r);
   } else {
-    float xin[3];
+    float xin[32];
     for (int f = 0; f < A.F; ++f) xin[f] = A.xs[ACT(t, f, A.F, A.Sp, s)];
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
-      float acc = A.dsb[c];
-      for (int f = 0; f < A.F; ++f) acc = fmaf(A.dsw[c * A.F + f], xin[f], acc);
+      float acc = A.dsb[c0 + c];
+      for (int f = 0; f < A.F; ++f) acc = fmaf(A.dsw[(c0 + c) * A.F + f], xin[f], acc);
       r[c] = acc;
     }
   }
-  if (!A.first) dof_ld_row<TC>(A.skip + ACT(t, 0, TC, A.Sp, s), sk);
+  if (!A.first) dof_ld_row<TC>(A.skip + ACT(t, c0, CT, A.Sp, s), sk);
 #pragma unroll
   for (int c = 0; c < TC; ++c) {
-    const float a2 = fmaxf(fmaf(y[c], BNP_SCALE(A.bnp2, TC, c), BNP_SHIFT(A.bnp2, TC, c)), 0.0f);
+    const float a2 = fmaxf(fmaf(y[c], BNP_SCALE(A.bnp2, CT, c0 + c), BNP_SHIFT(A.bnp2, CT, c0 + c)), 0.0f);
     sk[c] = A.first ? a2 : sk[c] + a2;
     r[c] = fmaxf(a2 + r[c], 0.0f);
   }
-  dof_st_row<TC>(A.skip + ACT(t, 0, TC, A.Sp, s), sk);
-  if (A.out) dof_st_row<TC>(A.out + ACT(t, 0, TC, A.Sp, s), r);
+  dof_st_row<TC>(A.skip + ACT(t, c0, CT, A.Sp, s), sk);
+  if (A.out) dof_st_row<TC>(A.out + ACT(t, c0, CT, A.Sp, s), r);
   if (A.feat && t == A.T - 1) {
 #pragma unroll
     for (int c = 0; c < TC; ++c) A.feat[(int64_t)c * A.Sp + s] = fmaxf(sk[c], 0.0f);
@@ -293,22 +391,24 @@ __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
 //   the last-step features at t = T-1; the masked din is also the residual-branch gradient (stored to gres).
 // ---------------------------------------------------------------------------------------------
 struct TcnBnBwd1Args {
-  const float* din;     // [T][Sp][32] or null
+  const float* din;     // [T][Sp][CT] or null
   const float* y;       // pre-normalisation tensor of this layer
   const float* bnp;
-  float* g;             // [T][Sp][32] out
-  float* partial;       // [nblk][64]
+  float* g;             // [T][Sp][CT] out
+  float* partial;       // [halves][nblk][64]
   // block-level (BN2) extras
   const float* out_blk; // block output (mask of din) or null
-  const float* dfeat;   // [32][Sp] gradient of the last-step features or null
+  const float* dfeat;   // [32][Sp] gradient of the last-step features (encoder) or null
   const float* skip;    // final skip-sum (mask of dfeat)
-  float* gres;          // [T][Sp][32] masked din (gradient entering the residual branch) or null
-  int blk, T;
+  const float* dskip;   // [T][Sp][CT] gradient of the skip-sum at every step, already masked (decoder) or null
+  float* gres;          // [T][Sp][CT] masked din (gradient entering the residual branch) or null
+  int blk, T, CT;
   int64_t S, Sp;
 };
 
 __global__ void __launch_bounds__(256) k_tcn_bn_bwd1(TcnBnBwd1Args A) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = blockIdx.y * TC, CT = A.CT;
   float st[2 * TC];
 #pragma unroll
   for (int c = 0; c < 2 * TC; ++c) st[c] = 0.0f;
@@ -317,7 +417,7 @@ __global__ void __launch_bounds__(256) k_tcn_bn_bwd1(TcnBnBwd1Args A) {
     const int64_t s = i - (int64_t)t * A.S;
     float d[TC], y[TC];
     if (A.din) {
-      dof_ld_row<TC>(A.din + ACT(t, 0, TC, A.Sp, s), d);
+      dof_ld_row<TC>(A.din + ACT(t, c0, CT, A.Sp, s), d);
     } else {
 #pragma unroll
       for (int c = 0; c < TC; ++c) d[c] = 0.0f;
@@ -325,50 +425,76 @@ __global__ void __launch_bounds__(256) k_tcn_bn_bwd1(TcnBnBwd1Args A) {
     if (A.blk) {
       if (A.out_blk) {
         float o[TC];
-        dof_ld_row<TC>(A.out_blk + ACT(t, 0, TC, A.Sp, s), o);
+        dof_ld_row<TC>(A.out_blk + ACT(t, c0, CT, A.Sp, s), o);
 #pragma unroll
         for (int c = 0; c < TC; ++c) d[c] = o[c] > 0.0f ? d[c] : 0.0f;
       }
-      if (A.gres) dof_st_row<TC>(A.gres + ACT(t, 0, TC, A.Sp, s), d);
+      if (A.gres) dof_st_row<TC>(A.gres + ACT(t, c0, CT, A.Sp, s), d);
       if (A.dfeat && t == A.T - 1) {
         float sk[TC];
-        dof_ld_row<TC>(A.skip + ACT(t, 0, TC, A.Sp, s), sk);
+        dof_ld_row<TC>(A.skip + ACT(t, c0, CT, A.Sp, s), sk);
 #pragma unroll
-        for (int c = 0; c < TC; ++c) d[c] += sk[c] > 0.0f ? A.dfeat[(int64_t)c * A.Sp + s] : 0.0f;
+        for (int c = 0; c < TC; ++c) d[c] += sk[c] > 0.0f ? A.dfeat[(int64_t)(c0 + c) * A.Sp + s] : 0.0f;
+      }
+      if (A.dskip) {
+        float ds[TC];
+        dof_ld_row<TC>(A.dskip + ACT(t, c0, CT, A.Sp, s), ds);
+#pragma unroll
+        for (int c = 0; c < TC; ++c) d[c] += ds[c];
       }
     }
-    dof_ld_row<TC>(A.y + ACT(t, 0, TC, A.Sp, s), y);
+    dof_ld_row<TC>(A.y + ACT(t, c0, CT, A.Sp, s), y);
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
-      const float a = fmaf(y[c], BNP_SCALE(A.bnp, TC, c), BNP_SHIFT(A.bnp, TC, c));
+      const float a = fmaf(y[c], BNP_SCALE(A.bnp, CT, c0 + c), BNP_SHIFT(A.bnp, CT, c0 + c));
       const float g = a > 0.0f ? d[c] : 0.0f;
-      const float xh = (y[c] - BNP_MEAN(A.bnp, TC, c)) * BNP_RSTD(A.bnp, TC, c);
+      const float xh = (y[c] - BNP_MEAN(A.bnp, CT, c0 + c)) * BNP_RSTD(A.bnp, CT, c0 + c);
       d[c] = g;
       st[c] = g;
       st[TC + c] = g * xh;
     }
-    dof_st_row<TC>(A.g + ACT(t, 0, TC, A.Sp, s), d);
+    dof_st_row<TC>(A.g + ACT(t, c0, CT, A.Sp, s), d);
   }
-  dof_block_colsum<2 * TC>(st, A.partial + (int64_t)blockIdx.x * 2 * TC);
+  dof_block_colsum<2 * TC>(st, A.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * TC);
 }
 
 // pass 2: dy = scale * (g - mean(g) - xhat * mean(g*xhat)), in place
 __global__ void __launch_bounds__(256) k_tcn_bn_bwd2(float* __restrict__ g, const float* __restrict__ y,
                                                      const float* __restrict__ bnp, const float* __restrict__ coef,
-                                                     int T, int64_t S, int64_t Sp) {
+                                                     int T, int CT, int64_t S, int64_t Sp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)T * S) return;
   const int t = (int)(i / S);
   const int64_t s = i - (int64_t)t * S;
+  const int c0 = blockIdx.y * TC;
   float d[TC], yv[TC];
-  dof_ld_row<TC>(g + ACT(t, 0, TC, Sp, s), d);
-  dof_ld_row<TC>(y + ACT(t, 0, TC, Sp, s), yv);
+  dof_ld_row<TC>(g + ACT(t, c0, CT, Sp, s), d);
+  dof_ld_row<TC>(y + ACT(t, c0, CT, Sp, s), yv);
 #pragma unroll
   for (int c = 0; c < TC; ++c) {
-    const float xh = (yv[c] - BNP_MEAN(bnp, TC, c)) * BNP_RSTD(bnp, TC, c);
-    d[c] = BNP_SCALE(bnp, TC, c) * (d[c] - coef[c] - xh * coef[TC + c]);
+    const float xh = (yv[c] - BNP_MEAN(bnp, CT, c0 + c)) * BNP_RSTD(bnp, CT, c0 + c);
+    d[c] = BNP_SCALE(bnp, CT, c0 + c) * (d[c] - coef[c0 + c] - xh * coef[CT + c0 + c]);
   }
-  dof_st_row<TC>(g + ACT(t, 0, TC, Sp, s), d);
+  dof_st_row<TC>(g + ACT(t, c0, CT, Sp, s), d);
+}
+
+// channel sums of the row-per-thread kernels: partial[h][nblk][64] -> sums[2][CT] (sum, second moment)
+__global__ void __launch_bounds__(256) k_tcn_sum_halves(const float* __restrict__ partial, int64_t nblk, int CT,
+                                                        float* __restrict__ sums) {
+  __shared__ float red[256];
+  const int v = blockIdx.x;            // 0 .. 2*CT-1 : [sum(CT) | second(CT)]
+  const int which = v / CT, ch = v - which * CT;
+  const int h = ch / TC, c = ch - h * TC;
+  const float* src = partial + (int64_t)h * nblk * 2 * TC + which * TC + c;
+  float acc = 0.0f;
+  for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += src[b * 2 * TC];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[v] = red[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -548,29 +674,56 @@ int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* 
 }
 
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
-                           const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int64_t S,
-                           int64_t Sp, hipStream_t st) {
+                           const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
+                           int64_t S, int64_t Sp, hipStream_t st) {
   TcnCombineArgs A;
   A.y2 = y2; A.bnp2 = bnp2; A.res = res; A.xs = xs; A.dsw = dsw; A.dsb = dsb; A.out = out; A.skip = skip;
-  A.feat = feat; A.first = first; A.T = T; A.F = F; A.S = S; A.Sp = Sp;
-  DOF_LAUNCH(k_tcn_combine, ((unsigned)dof_tcn_row_blocks(T, S)), (256), st, A);
+  A.feat = feat; A.first = first; A.T = T; A.F = F; A.CT = CT; A.S = S; A.Sp = Sp;
+  DOF_LAUNCH(k_tcn_combine, ((unsigned)dof_tcn_row_blocks(T, S), (unsigned)(CT / TC)), (256), st, A);
   return dof_check_launch("k_tcn_combine");
 }
 
-int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, int blk,
-                           const float* out_blk, const float* dfeat, const float* skip, float* gres, int T, int64_t S,
-                           int64_t Sp, hipStream_t st) {
+// pass 1 of a layer's BatchNorm backward + the reduction of its channel sums into sums[2][CT]
+int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, float* sums,
+                           int blk, const float* out_blk, const float* dfeat, const float* skip, const float* dskip,
+                           float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st) {
   TcnBnBwd1Args A;
   A.din = din; A.y = y; A.bnp = bnp; A.g = g; A.partial = partial; A.blk = blk; A.out_blk = out_blk; A.dfeat = dfeat;
-  A.skip = skip; A.gres = gres; A.T = T; A.S = S; A.Sp = Sp;
-  DOF_LAUNCH(k_tcn_bn_bwd1, ((unsigned)dof_tcn_row_blocks(T, S)), (256), st, A);
+  A.skip = skip; A.dskip = dskip; A.gres = gres; A.T = T; A.CT = CT; A.S = S; A.Sp = Sp;
+  const unsigned nb = (unsigned)dof_tcn_row_blocks(T, S);
+  DOF_LAUNCH(k_tcn_bn_bwd1, (nb, (unsigned)(CT / TC)), (256), st, A);
+  DOF_LAUNCH(k_tcn_sum_halves, ((unsigned)(2 * CT)), (256), st, (const float*)partial, (int64_t)nb, CT, sums);
   return dof_check_launch("k_tcn_bn_bwd1");
 }
 
-int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int64_t S, int64_t Sp,
-                           hipStream_t st) {
-  DOF_LAUNCH(k_tcn_bn_bwd2, ((unsigned)dof_tcn_row_blocks(T, S)), (256), st, g, y, bnp, coef, T, S, Sp);
+int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int CT, int64_t S,
+                           int64_t Sp, hipStream_t st) {
+  DOF_LAUNCH(k_tcn_bn_bwd2, ((unsigned)dof_tcn_row_blocks(T, S), (unsigned)(CT / TC)), (256), st, g, y, bnp, coef, T, CT,
+             S, Sp);
   return dof_check_launch("k_tcn_bn_bwd2");
+}
+
+// generic convolution (LDS weights): (KC, NC) in {(32,64), (64,64), (64,32)}; ci = input channels of the FORWARD
+// convolution's weight tensor (its middle dimension), cin_real <= padded KC / NC
+int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const float* w, int w_ci, int cin_real,
+                         const float* bias, const float* bnp_in, float* a_out, float* out, float* partial,
+                         int accumulate, int T, int dil, int64_t S, int64_t Sp, hipStream_t st) {
+  TcnConvArgs A;
+  A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
+  A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
+  const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
+#define CONVG(R, BN, K, N) DOF_LAUNCH((k_tcn_convg<R, BN, K, N>), (nb), (256), st, A, cin_real, w_ci)
+  if (!reverse && !bnp_in && KC == 32 && NC == 64) CONVG(false, false, 32, 64);
+  else if (!reverse && !bnp_in && KC == 64 && NC == 64) CONVG(false, false, 64, 64);
+  else if (!reverse && bnp_in && KC == 64 && NC == 64) CONVG(false, true, 64, 64);
+  else if (reverse && KC == 64 && NC == 64) CONVG(true, false, 64, 64);
+  else if (reverse && KC == 64 && NC == 32) CONVG(true, false, 64, 32);
+  else {
+    dof_set_error("tcn conv variant (reverse %d, bn %d, %d -> %d) not built", reverse, bnp_in != nullptr, KC, NC);
+    return DOF_ERR_UNSUPPORTED;
+  }
+#undef CONVG
+  return dof_check_launch("k_tcn_convg");
 }
 
 int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st) {

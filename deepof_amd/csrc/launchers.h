@@ -45,13 +45,16 @@ int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, co
 int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,
                           int C, hipStream_t st);
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
-                           const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int64_t S,
+                           const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
+                           int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, float* sums,
+                           int blk, const float* out_blk, const float* dfeat, const float* skip, const float* dskip,
+                           float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int CT, int64_t S,
                            int64_t Sp, hipStream_t st);
-int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, int blk,
-                           const float* out_blk, const float* dfeat, const float* skip, float* gres, int T, int64_t S,
-                           int64_t Sp, hipStream_t st);
-int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int64_t S, int64_t Sp,
-                           hipStream_t st);
+int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const float* w, int w_ci, int cin_real,
+                         const float* bias, const float* bnp_in, float* a_out, float* out, float* partial,
+                         int accumulate, int T, int dil, int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st);
 int dof_launch_head_dense(const float* in, const float* bnp_in, float* in_norm, const float* w, const float* bias,
                           float* out, float* partial, float* sums, int CI, int CO, int relu, int64_t B, int64_t Bp,

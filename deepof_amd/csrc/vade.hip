@@ -931,7 +931,7 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
                                  b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb,
                                  b < 7 ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr, b == 0, T, w.F,
-                                 w.S, w.Sp, st));
+                                 32, w.S, w.Sp, st));
     }
   }
   TRY(censnet_forward(p, params, st));
@@ -1060,26 +1060,23 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
     const StreamWs& w = p->sw[s];
     const TcnWs& t = p->tw[s];
     const float count = (float)((int64_t)T * w.S);
-    const int64_t rows = dof_tcn_row_blocks(T, w.S);
     for (int b = 7; b >= 0; --b) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
       float* dprev = ws + t.dout[(b + 1) & 1];  // gradient of the previous block's output (this block's input)
       // BN2 + ReLU + block tail
       TRY(dof_launch_tcn_bn_bwd1(b == 7 ? nullptr : ws + t.dout[b & 1], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.g2[b],
-                                 ws + t.partial, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip, dprev, T, w.S,
-                                 w.Sp, st));
-      TRY(dof_launch_sum_partials(ws + t.partial, rows, 64, ws + t.sums, 0, st));
+                                 ws + t.partial, ws + t.sums, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip,
+                                 nullptr, dprev, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, ws + t.coef, 32, st));
-      TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.coef, T, w.S, w.Sp, st));
+      TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.coef, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_tcn_conv(1, ws + t.g2[b], params + o.c2w, nullptr, nullptr, nullptr, ws + t.da, nullptr, 0, T, d,
                               w.S, w.Sp, st));
       // BN1 + ReLU
-      TRY(dof_launch_tcn_bn_bwd1(ws + t.da, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b], ws + t.partial, 0, nullptr,
-                                 nullptr, nullptr, nullptr, T, w.S, w.Sp, st));
-      TRY(dof_launch_sum_partials(ws + t.partial, rows, 64, ws + t.sums, 0, st));
+      TRY(dof_launch_tcn_bn_bwd1(ws + t.da, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b], ws + t.partial, ws + t.sums, 0,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g1, grads + o.b1, accumulate, ws + t.coef, 32, st));
-      TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef, T, w.S, w.Sp, st));
+      TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef, T, 32, w.S, w.Sp, st));
       if (b > 0)
         TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
                                 w.Sp, st));
