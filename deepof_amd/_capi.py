@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -48,6 +48,8 @@ SIGNATURES = {
     "dof_window_gather": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "dof_window_gather_range": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "dof_vade_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_vade_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_vqvae_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vade_plan_destroy": (None, [_P]),
     "dof_vade_param_count": (_I32, [_P]),
     "dof_vade_param_name": (C.c_char_p, [_P, _I32]),

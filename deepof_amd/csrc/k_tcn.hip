@@ -22,16 +22,22 @@
 #include "dof_rt.h"
 #include "launchers.h"
 
+#define TRY_RC(x) do { int _rc = (x); if (_rc != DOF_OK) return _rc; } while (0)
+
 namespace {
 
 constexpr int TC = 32;  // conv_filters
 constexpr int TK = 4;   // kernel_size
 
-// per-layer BatchNorm record bnp[4][C]: batch (or running) mean, rstd, scale = gamma*rstd, shift = beta - mean*scale
+// per-layer BatchNorm record bnp[4][C]: batch (or running) mean, rstd, scale = gamma*rstd, shift = beta - mean*scale.
+// Applied as y*scale + shift -- the form ATen's CPU batch_norm uses (alpha/beta "linear and constant terms"), so
+// the rounding pattern matches the reference's; measured against an fp64 evaluation both forms sit at the
+// reference's own fp32 noise level.
 #define BNP_MEAN(p, C, c) (p)[(c)]
 #define BNP_RSTD(p, C, c) (p)[(C) + (c)]
 #define BNP_SCALE(p, C, c) (p)[2 * (C) + (c)]
 #define BNP_SHIFT(p, C, c) (p)[3 * (C) + (c)]
+#define BN_APPLY(p, C, c, y) fmaf((y), BNP_SCALE(p, C, c), BNP_SHIFT(p, C, c))
 
 // ---------------------------------------------------------------------------------------------
 // Block 0, conv1: scrambled read of the window tensor + Conv1d(F -> 32, k=4, dilation d) + bias.
@@ -293,7 +299,9 @@ __global__ void __launch_bounds__(256) k_tcn_convg(TcnConvArgs A, int cin_real, 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (shared by the TCN layers, C = 32, and the head, C = 2L / L)
 // ---------------------------------------------------------------------------------------------
-// sums[2][C] = (sum x, sum x^2) over `count` samples  ->  bnp; train: running buffers updated in place
+// sums[2][C] = (sum x, sum (x - mean)^2) over `count` samples  ->  bnp; train: running buffers updated in place.
+// (The second moment is taken about the mean in a second pass over the tensor: E[x^2] - mean^2 in fp32 loses
+//  the variance to cancellation as soon as |mean| >> std, and the reference's two-pass variance does not.)
 __global__ void __launch_bounds__(64) k_bn_fwd_fin(const float* __restrict__ sums, float count,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
@@ -303,7 +311,7 @@ __global__ void __launch_bounds__(64) k_bn_fwd_fin(const float* __restrict__ sum
   float mean, var;
   if (train) {
     mean = sums[c] / count;
-    var = fmaxf(sums[C + c] / count - mean * mean, 0.0f);
+    var = sums[C + c] / count;
     rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
     rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * (count / fmaxf(count - 1.0f, 1.0f));
   } else {
@@ -316,6 +324,67 @@ __global__ void __launch_bounds__(64) k_bn_fwd_fin(const float* __restrict__ sum
   BNP_RSTD(bnp, C, c) = rstd;
   BNP_SCALE(bnp, C, c) = scale;
   BNP_SHIFT(bnp, C, c) = beta[c] - mean * scale;
+}
+
+// second pass of the batch statistics: channel sums of (y - mean)^2, mean = sums[c] / count; row-per-thread,
+// 32-channel half per blockIdx.y; partial[h][nblk][32]
+__global__ void __launch_bounds__(256) k_tcn_var(const float* __restrict__ y, const float* __restrict__ sums, float count,
+                                                 float* __restrict__ partial, int T, int CT, int64_t S, int64_t Sp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = blockIdx.y * TC;
+  float st[TC];
+#pragma unroll
+  for (int c = 0; c < TC; ++c) st[c] = 0.0f;
+  if (i < (int64_t)T * S) {
+    const int t = (int)(i / S);
+    const int64_t s = i - (int64_t)t * S;
+    float v[TC];
+    dof_ld_row<TC>(y + ACT(t, c0, CT, Sp, s), v);
+    const float rc = 1.0f / count;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      const float dv = v[c] - sums[c0 + c] * rc;
+      st[c] = dv * dv;
+    }
+  }
+  dof_block_colsum<TC>(st, partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * TC);
+}
+
+// partial[h][nblk][32] -> sums[CT + h*32 + c]
+__global__ void __launch_bounds__(256) k_tcn_var_sum(const float* __restrict__ partial, int64_t nblk, int CT,
+                                                     float* __restrict__ sums) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x, h = ch / TC, c = ch - h * TC;
+  const float* src = partial + (int64_t)h * nblk * TC + c;
+  float acc = 0.0f;
+  for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += src[b * TC];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[CT + ch] = red[0];
+}
+
+// the same for [c][Bp] head tensors: sums[C + c] = sum_b (h[c][b] - mean_c)^2 ; one workgroup per channel
+__global__ void __launch_bounds__(256) k_head_var(const float* __restrict__ h, float* __restrict__ sums, float count, int C,
+                                                  int64_t B, int64_t Bp) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  const float mean = sums[c] / count;
+  float acc = 0.0f;
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    const float dv = h[(int64_t)c * Bp + b] - mean;
+    acc = fmaf(dv, dv, acc);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[C + c] = red[0];
 }
 
 // sums[2][C] = (sum g, sum g*xhat): gamma / beta gradients and the two batch means of the input gradient
@@ -373,7 +442,7 @@ __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
   if (!A.first) dof_ld_row<TC>(A.skip + ACT(t, c0, CT, A.Sp, s), sk);
 #pragma unroll
   for (int c = 0; c < TC; ++c) {
-    const float a2 = fmaxf(fmaf(y[c], BNP_SCALE(A.bnp2, CT, c0 + c), BNP_SHIFT(A.bnp2, CT, c0 + c)), 0.0f);
+    const float a2 = fmaxf(BN_APPLY(A.bnp2, CT, c0 + c, y[c]), 0.0f);
     sk[c] = A.first ? a2 : sk[c] + a2;
     r[c] = fmaxf(a2 + r[c], 0.0f);
   }
@@ -446,7 +515,7 @@ __global__ void __launch_bounds__(256) k_tcn_bn_bwd1(TcnBnBwd1Args A) {
     dof_ld_row<TC>(A.y + ACT(t, c0, CT, A.Sp, s), y);
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
-      const float a = fmaf(y[c], BNP_SCALE(A.bnp, CT, c0 + c), BNP_SHIFT(A.bnp, CT, c0 + c));
+      const float a = BN_APPLY(A.bnp, CT, c0 + c, y[c]);
       const float g = a > 0.0f ? d[c] : 0.0f;
       const float xh = (y[c] - BNP_MEAN(A.bnp, CT, c0 + c)) * BNP_RSTD(A.bnp, CT, c0 + c);
       d[c] = g;
@@ -531,7 +600,7 @@ __global__ void __launch_bounds__(256) k_head_dense(const float* __restrict__ in
     for (int i = 0; i < CI; ++i) {
       float v = in[(int64_t)i * Bp + b];
       if (bnp_in) {
-        v = fmaf(v, BNP_SCALE(bnp_in, CI, i), BNP_SHIFT(bnp_in, CI, i));
+        v = BN_APPLY(bnp_in, CI, i, v);
         if (o == 0) in_norm[(int64_t)i * Bp + b] = v;
       }
       acc = fmaf(wr[i], v, acc);
@@ -588,14 +657,14 @@ __global__ void __launch_bounds__(256) k_head_bn_bwd1(const float* __restrict__ 
 // pass 2 + ReLU of the producing Linear: dpre = scale*(g - c1 - xhat*c2) * [h > 0]
 __global__ void __launch_bounds__(256) k_head_bn_bwd2(const float* __restrict__ g, const float* __restrict__ h,
                                                       const float* __restrict__ bnp, const float* __restrict__ coef,
-                                                      float* __restrict__ dpre, int C, int64_t B, int64_t Bp) {
+                                                      float* __restrict__ dpre, int C, int relu, int64_t B, int64_t Bp) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int c = blockIdx.y;
   const float hv = h[(int64_t)c * Bp + b];
   const float xh = (hv - BNP_MEAN(bnp, C, c)) * BNP_RSTD(bnp, C, c);
   const float d = BNP_SCALE(bnp, C, c) * (g[(int64_t)c * Bp + b] - coef[c] - xh * coef[C + c]);
-  dpre[(int64_t)c * Bp + b] = hv > 0.0f ? d : 0.0f;
+  dpre[(int64_t)c * Bp + b] = (!relu || hv > 0.0f) ? d : 0.0f;
 }
 
 // backward of hn = x * r(x): dflat = r * (dhn - hn * (dhn . hn) / J) when rms > 1, else dhn
@@ -614,6 +683,103 @@ __global__ void __launch_bounds__(256) k_head_rms_bwd(const float* __restrict__ 
   dot /= (float)J;
   for (int j = 0; j < J; ++j)
     dflat[(int64_t)j * Bp + b] = r * (dhn[(int64_t)j * Bp + b] - hn[(int64_t)j * Bp + b] * dot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TCN decoder ends (models_new.py:713-819): repeat the normalised latent features over time; output head
+// ---------------------------------------------------------------------------------------------
+// zrep[t][b][c] = BN2(d2)[c][b] for every t (channels c >= C4 are zero padding up to 32)
+__global__ void __launch_bounds__(256) k_dec_repeat(const float* __restrict__ d2, const float* __restrict__ bnp,
+                                                    float* __restrict__ zrep, int C4, int T, int64_t B, int64_t Bp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)T * B) return;
+  const int t = (int)(i / B);
+  const int64_t b = i - (int64_t)t * B;
+  float row[TC];
+#pragma unroll
+  for (int c = 0; c < TC; ++c)
+    row[c] = c < C4 ? BN_APPLY(bnp, C4, c, d2[(int64_t)c * Bp + b]) : 0.0f;
+  dof_st_row<TC>(zrep + ACT(t, 0, TC, Bp, b), row);
+}
+
+// dzf[c][b] = sum_t dzrep[t][b][c]
+__global__ void __launch_bounds__(256) k_dec_sum_time(const float* __restrict__ dzrep, float* __restrict__ dzf, int C4,
+                                                      int T, int64_t B, int64_t Bp) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc[TC];
+#pragma unroll
+  for (int c = 0; c < TC; ++c) acc[c] = 0.0f;
+  for (int t = 0; t < T; ++t) {
+    float row[TC];
+    dof_ld_row<TC>(dzrep + ACT(t, 0, TC, Bp, b), row);
+#pragma unroll
+    for (int c = 0; c < TC; ++c) acc[c] += row[c];
+  }
+  for (int c = 0; c < C4; ++c) dzf[(int64_t)c * Bp + b] = acc[c];
+}
+
+// hidden = ReLU(skip-sum) at every step -> loc = Linear(64 -> 3N) -> unit-variance Normal log-prob on valid
+// frames (NaN on masked ones, Q3) and its gradient back to the skip-sum.  Same conventions as k_dec_tail.
+struct TcnDecOutArgs {
+  const float* skip;   // [T][Bp][64]
+  const float *wp, *bp;  // (C3,64), (C3)
+  const float* x;      // (B,T,C3)
+  const float* valid;  // [T][Bp]
+  float* hid;          // [T][Bp][64]
+  float* loc_out;      // (B,T,C3) or null
+  float* recon_partial;
+  float* dloc;         // [T][Bp][C3]
+  float* dskip;        // [T][Bp][64]
+  int T, C3, train;
+  int64_t B, Bp;
+};
+
+__global__ void __launch_bounds__(256) k_tcn_dec_out(TcnDecOutArgs A) {
+  constexpr int CH = 64;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float nll[1] = {0.0f};
+  if (i < (int64_t)A.T * A.B) {
+    const int t = (int)(i / A.B);
+    const int64_t b = i - (int64_t)t * A.B;
+    const dof_cfp wp = dof_cw(A.wp), bp = dof_cw(A.bp);
+    float h[CH], dh[CH];
+    dof_ld_row<CH>(A.skip + ACT(t, 0, CH, A.Bp, b), h);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      h[c] = fmaxf(h[c], 0.0f);
+      dh[c] = 0.0f;
+    }
+    if (A.train) dof_st_row<CH>(A.hid + ACT(t, 0, CH, A.Bp, b), h);
+    const bool ok = A.valid[(int64_t)t * A.Bp + b] != 0.0f;
+    const float inv_bt = 1.0f / ((float)A.B * (float)A.T);
+    const float* __restrict__ xr = A.x + (b * A.T + t) * A.C3;
+    float sq = 0.0f;
+    for (int j = 0; j < A.C3; ++j) {
+      float loc = bp[j];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) loc = fmaf(wp[j * CH + c], h[c], loc);
+      if (loc != loc) loc = 0.0f;
+      loc = fminf(fmaxf(loc, -1e6f), 1e6f);
+      if (A.loc_out) A.loc_out[(b * A.T + t) * A.C3 + j] = loc;
+      const float df = xr[j] - loc;
+      sq = fmaf(df, df, sq);
+      if (A.train) {
+        const float dl = ok ? -df * inv_bt : NAN;
+        A.dloc[ACT(t, j, A.C3, A.Bp, b)] = dl;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) dh[c] = fmaf(wp[j * CH + c], dl, dh[c]);
+      }
+    }
+    const float LOG_2PI = 1.8378770664093453f;
+    nll[0] = ok ? 0.5f * sq + 0.5f * (float)A.C3 * LOG_2PI : NAN;
+    if (A.train) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) dh[c] = h[c] > 0.0f ? dh[c] : 0.0f;
+      dof_st_row<CH>(A.dskip + ACT(t, 0, CH, A.Bp, b), dh);
+    }
+  }
+  dof_block_colsum<1>(nll, A.recon_partial + blockIdx.x);
 }
 
 }  // namespace
@@ -736,7 +902,10 @@ int dof_launch_head_dense(const float* in, const float* bnp_in, float* in_norm, 
                           hipStream_t st) {
   const unsigned nb = dof_cdiv(B, 256);
   DOF_LAUNCH(k_head_dense, (nb, (unsigned)CO), (256), st, in, bnp_in, in_norm, w, bias, out, partial, CI, relu, B, Bp);
-  if (partial) DOF_LAUNCH(k_head_sum, (1), (64), st, (const float*)partial, (int)nb, sums, CO);
+  if (partial) {
+    DOF_LAUNCH(k_head_sum, (1), (64), st, (const float*)partial, (int)nb, sums, CO);
+    DOF_LAUNCH(k_head_var, ((unsigned)CO), (256), st, (const float*)out, sums, (float)B, CO, B, Bp);
+  }
   return dof_check_launch("k_head_dense");
 }
 
@@ -748,12 +917,12 @@ int dof_launch_head_dense_bwd(const float* dout, const float* w, float* din, int
 
 int dof_launch_head_bn_bwd(const float* g, const float* h, const float* bnp, float* partial, float* sums, float* coef,
                            float* dgamma, float* dbeta, int accumulate, float* dpre, int C, int64_t B, int64_t Bp,
-                           hipStream_t st) {
+                           hipStream_t st, int relu) {
   const unsigned nb = dof_cdiv(B, 256);
   DOF_LAUNCH(k_head_bn_bwd1, (nb, (unsigned)C), (256), st, g, h, bnp, partial, C, B, Bp);
   DOF_LAUNCH(k_head_sum, (1), (64), st, (const float*)partial, (int)nb, sums, C);
   DOF_LAUNCH(k_bn_bwd_fin, (1), (64), st, (const float*)sums, (float)B, dgamma, dbeta, accumulate, coef, C);
-  DOF_LAUNCH(k_head_bn_bwd2, (nb, (unsigned)C), (256), st, g, h, bnp, (const float*)coef, dpre, C, B, Bp);
+  DOF_LAUNCH(k_head_bn_bwd2, (nb, (unsigned)C), (256), st, g, h, bnp, (const float*)coef, dpre, C, relu, B, Bp);
   return dof_check_launch("k_head_bn_bwd");
 }
 
@@ -761,4 +930,36 @@ int dof_launch_head_rms_bwd(const float* dhn, const float* hn, const float* rinv
                             int64_t Bp, hipStream_t st) {
   DOF_LAUNCH(k_head_rms_bwd, (dof_cdiv(B, 256)), (256), st, dhn, hn, rinv, dflat, J, B, Bp);
   return dof_check_launch("k_head_rms_bwd");
+}
+
+int dof_launch_dec_repeat(const float* d2, const float* bnp, float* zrep, int C4, int T, int64_t B, int64_t Bp,
+                          hipStream_t st) {
+  DOF_LAUNCH(k_dec_repeat, (dof_cdiv((int64_t)T * B, 256)), (256), st, d2, bnp, zrep, C4, T, B, Bp);
+  return dof_check_launch("k_dec_repeat");
+}
+
+int dof_launch_dec_sum_time(const float* dzrep, float* dzf, int C4, int T, int64_t B, int64_t Bp, hipStream_t st) {
+  DOF_LAUNCH(k_dec_sum_time, (dof_cdiv(B, 256)), (256), st, dzrep, dzf, C4, T, B, Bp);
+  return dof_check_launch("k_dec_sum_time");
+}
+
+int dof_launch_tcn_dec_out(const float* skip, const float* wp, const float* bp, const float* x, const float* valid,
+                           float* hid, float* loc_out, float* recon_partial, float* dloc, float* dskip, int T, int C3,
+                           int train, int64_t B, int64_t Bp, hipStream_t st) {
+  TcnDecOutArgs A;
+  A.skip = skip; A.wp = wp; A.bp = bp; A.x = x; A.valid = valid; A.hid = hid; A.loc_out = loc_out;
+  A.recon_partial = recon_partial; A.dloc = dloc; A.dskip = dskip; A.T = T; A.C3 = C3; A.train = train; A.B = B; A.Bp = Bp;
+  DOF_LAUNCH(k_tcn_dec_out, (dof_cdiv((int64_t)T * B, 256)), (256), st, A);
+  return dof_check_launch("k_tcn_dec_out");
+}
+
+// Batch statistics of one TCN layer from the convolution's channel-sum partials (rows of `stride` floats, the first
+// CT of which are the sums of y) + a centred second pass over y; leaves sums[2][CT] for dof_launch_bn_fwd_fin.
+int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
+                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st) {
+  TRY_RC(dof_launch_sum_partials(partial, n_partial, stride, sums, 0, st));
+  const unsigned nb = (unsigned)dof_tcn_row_blocks(T, S);
+  DOF_LAUNCH(k_tcn_var, (nb, (unsigned)(CT / TC)), (256), st, y, (const float*)sums, count, partial, T, CT, S, Sp);
+  DOF_LAUNCH(k_tcn_var_sum, ((unsigned)CT), (256), st, (const float*)partial, (int64_t)nb, CT, sums);
+  return dof_check_launch("k_tcn_var");
 }

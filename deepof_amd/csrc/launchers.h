@@ -40,6 +40,8 @@ int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float*
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st);
+int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
+                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
                           float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st);
 int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,
@@ -63,7 +65,13 @@ int dof_launch_head_dense_bwd(const float* dout, const float* w, float* din, int
                               hipStream_t st);
 int dof_launch_head_bn_bwd(const float* g, const float* h, const float* bnp, float* partial, float* sums, float* coef,
                            float* dgamma, float* dbeta, int accumulate, float* dpre, int C, int64_t B, int64_t Bp,
-                           hipStream_t st);
+                           hipStream_t st, int relu = 1);
+int dof_launch_dec_repeat(const float* d2, const float* bnp, float* zrep, int C4, int T, int64_t B, int64_t Bp,
+                          hipStream_t st);
+int dof_launch_dec_sum_time(const float* dzrep, float* dzf, int C4, int T, int64_t B, int64_t Bp, hipStream_t st);
+int dof_launch_tcn_dec_out(const float* skip, const float* wp, const float* bp, const float* x, const float* valid,
+                           float* hid, float* loc_out, float* recon_partial, float* dloc, float* dskip, int T, int C3,
+                           int train, int64_t B, int64_t Bp, hipStream_t st);
 int dof_launch_head_rms_bwd(const float* dhn, const float* hn, const float* rinv, float* dflat, int J, int64_t B,
                             int64_t Bp, hipStream_t st);
 

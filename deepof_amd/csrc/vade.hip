@@ -69,6 +69,14 @@ struct ParamEntry {
 struct TcnBlockOff {  // one TemporalBlockPT: conv / BatchNorm (weight, bias, running mean / var) twice, 1x1 residual conv
   int64_t c1w, c1b, g1, b1, rm1, rv1, c2w, c2b, g2, b2, rm2, rv2, dsw, dsb;
 };
+struct TcnDecWs {  // TCN decoder buffers (sequences = windows; [T][Bp][64] unless noted)
+  int64_t hn, rinv, d0, n0, d1, n1, d2, bnp0, bnp1, bnp2;  // front MLP, [c][Bp]
+  int64_t zrep;                                            // [T][Bp][32] BN2 output repeated over time (zero-padded channels)
+  int64_t y1[4], a1[4], y2[4], out[4], skip, g1[4], g2[4], dout[2], da;
+  int64_t bnp[8], partial, partial_rows, sums, coef;
+  int64_t hid, dskip, dzrep, dzf, dpre2, dn1, dpre1, dn0, dpre0, dhn;
+  int64_t hpartial, hsums, hcoef;
+};
 struct TcnWs {  // float offsets of one stream's TCN buffers ([T][Sp][32] unless noted)
   int64_t xs;                           // [T][Sp][F] scrambled raw input
   int64_t y1[8], a1[8], y2[8], out[8];  // pre-BN conv outputs, activated conv2 input, block outputs
@@ -118,7 +126,7 @@ struct JobSet {  // one launch of the MFMA weight-gradient reduction + its final
 
 struct DofVadePlan {
   DofVadeDims d;
-  int kind = 0;  // 0 = VaDE, 1 = VQ-VAE, 2 = contrastive (recurrent encoder only), 3 = contrastive (TCN encoder only)
+  int kind = 0;  // 0 = VaDE, 1 = VQ-VAE, 2 = contrastive (encoder only); `tcn` selects the TCN encoder / decoder family
   int L, K, T, N, E, S, J, C3;
   int64_t B, Bp;
   std::vector<ParamEntry> params;
@@ -143,8 +151,12 @@ struct DofVadePlan {
   int64_t partials, segs_tab, mask_tab;
   int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
-  // TCN encoder (kind 3)
+  // TCN family (encoder: all kinds; decoder: kinds 0 / 1)
+  bool tcn = false;
   int D = 0;  // CensNet input channels: 2L (recurrent blocks) or 32 (TCN features)
+  TcnBlockOff dblk[4];  // decoder TCN blocks (64 filters, dilations 8,4,2,1)
+  int64_t dfc0w, dfc0b, dfc1w, dfc1b, dfc2w, dfc2b, dbn0[4], dbn1[4], dbn2[4];  // decoder MLP; bn: gamma, beta, rm, rv
+  TcnDecWs td;
   TcnBlockOff tblk[2][8];
   TcnWs tw[2];
   int64_t h0w, h0b, h2g, h2b, h2rm, h2rv, h3w, h3b, h5g, h5b, h5rm, h5rv, h6w, h6b;
@@ -172,6 +184,8 @@ void add_param(DofVadePlan* p, const std::string& name, int64_t numel, int64_t* 
   if (off) *off = p->param_total;
   p->param_total += numel;
 }
+
+void add_latent_params(DofVadePlan* p);
 
 void add_shaped(DofVadePlan* p, const std::string& name, std::vector<int64_t> shape, int64_t* off) {
   int64_t n = 1;
@@ -231,7 +245,51 @@ void build_tcn_param_layout(DofVadePlan* p) {
   add_shaped(p, "encoder.head.6.weight", {L, L}, &p->h6w);
   add_shaped(p, "encoder.head.6.bias", {L}, &p->h6b);
   p->seg_hi[DOF_SEG_ENCODER] = p->param_total;
-  for (int sg = DOF_SEG_DECODER; sg < DOF_SEG_COUNT; ++sg) p->seg_lo[sg] = p->seg_hi[sg] = p->param_total;
+  if (p->kind == 2) {
+    for (int sg = DOF_SEG_DECODER; sg < DOF_SEG_COUNT; ++sg) p->seg_lo[sg] = p->seg_hi[sg] = p->param_total;
+    return;
+  }
+  // TCNDecoderPT (models_new.py:713-771): fc0/bn0, fc1/bn1, fc2/bn2, tcn.blocks.0..3 (64 filters), prob_decoder
+  p->seg_lo[DOF_SEG_DECODER] = p->param_total;
+  const int CD = 64;
+  auto bn = [&](const std::string& pre, int c, int64_t* o4) {
+    add_shaped(p, pre + ".weight", {c}, &o4[0]);
+    add_shaped(p, pre + ".bias", {c}, &o4[1]);
+    add_shaped(p, pre + ".running_mean", {c}, &o4[2]);
+    add_shaped(p, pre + ".running_var", {c}, &o4[3]);
+  };
+  add_shaped(p, "decoder.fc0.weight", {L, L}, &p->dfc0w);
+  add_shaped(p, "decoder.fc0.bias", {L}, &p->dfc0b);
+  bn("decoder.bn0", L, p->dbn0);
+  add_shaped(p, "decoder.fc1.weight", {2 * L, L}, &p->dfc1w);
+  add_shaped(p, "decoder.fc1.bias", {2 * L}, &p->dfc1b);
+  bn("decoder.bn1", 2 * L, p->dbn1);
+  add_shaped(p, "decoder.fc2.weight", {4 * L, 2 * L}, &p->dfc2w);
+  add_shaped(p, "decoder.fc2.bias", {4 * L}, &p->dfc2b);
+  bn("decoder.bn2", 4 * L, p->dbn2);
+  for (int b = 0; b < 4; ++b) {
+    TcnBlockOff& o = p->dblk[b];
+    const std::string pre = "decoder.tcn.blocks." + std::to_string(b);
+    const int cin = b == 0 ? 4 * L : CD;
+    int64_t q[4];
+    add_shaped(p, pre + ".conv1.weight", {CD, cin, 4}, &o.c1w);
+    add_shaped(p, pre + ".conv1.bias", {CD}, &o.c1b);
+    bn(pre + ".bn1", CD, q);
+    o.g1 = q[0]; o.b1 = q[1]; o.rm1 = q[2]; o.rv1 = q[3];
+    add_shaped(p, pre + ".conv2.weight", {CD, CD, 4}, &o.c2w);
+    add_shaped(p, pre + ".conv2.bias", {CD}, &o.c2b);
+    bn(pre + ".bn2", CD, q);
+    o.g2 = q[0]; o.b2 = q[1]; o.rm2 = q[2]; o.rv2 = q[3];
+    o.dsw = o.dsb = -1;
+    if (b == 0) {
+      add_shaped(p, pre + ".downsample.weight", {CD, cin, 1}, &o.dsw);
+      add_shaped(p, pre + ".downsample.bias", {CD}, &o.dsb);
+    }
+  }
+  add_shaped(p, "decoder.prob_decoder.loc_projection.weight", {3 * p->N, CD}, &p->dpw);
+  add_shaped(p, "decoder.prob_decoder.loc_projection.bias", {3 * p->N}, &p->dpb);
+  p->seg_hi[DOF_SEG_DECODER] = p->param_total;
+  add_latent_params(p);
 }
 
 void add_gru(DofVadePlan* p, const std::string& prefix, int in, int hid, GruOff* g) {
@@ -245,7 +303,7 @@ void add_gru(DofVadePlan* p, const std::string& prefix, int in, int hid, GruOff*
 }
 
 void build_param_layout(DofVadePlan* p) {
-  if (p->kind == 3) return build_tcn_param_layout(p);
+  if (p->tcn) return build_tcn_param_layout(p);
   const int L = p->L, N = p->N, E = p->E, K = p->K;
   const char* bn[2] = {"encoder.node_recurrent_block", "encoder.edge_recurrent_block"};
   const int F[2] = {3, 1};
@@ -289,6 +347,11 @@ void build_param_layout(DofVadePlan* p) {
   add_param(p, "decoder.prob_decoder.loc_projection.weight", 3LL * N * 2 * L, &p->dpw);
   add_param(p, "decoder.prob_decoder.loc_projection.bias", 3 * N, &p->dpb);
   p->seg_hi[DOF_SEG_DECODER] = p->param_total;
+  add_latent_params(p);
+}
+
+void add_latent_params(DofVadePlan* p) {
+  const int L = p->L, K = p->K;
   p->seg_lo[DOF_SEG_GMM] = p->param_total;
   if (p->kind == 1) {  // VQ-VAE: the codebook takes the "GMM" optimiser segment, no latent heads
     add_param(p, "vq_layer.codebook", (int64_t)L * K, &p->codebook);
@@ -345,6 +408,9 @@ void build_triplets(DofVadePlan* p, const float* lap, const float* elap, const f
     fill(p->tri[1 - s][2], Go, 2);
   }
 }
+
+void take_latent_buffers(DofVadePlan* p, Carver& cv);
+void take_tables(DofVadePlan* p, Carver& cv);
 
 void take_triplets(DofVadePlan* p, Carver& cv, int s) {
   StreamWs& w = p->sw[s];
@@ -424,17 +490,44 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
   p->hd_dn1 = cv.take(2LL * L * Bp);
   p->hd_dpre1 = cv.take(2LL * L * Bp);
   p->hd_dhn = cv.take((int64_t)p->J * Bp);
-  for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
-    js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
-    js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
+  if (p->kind != 2) {
+    take_latent_buffers(p, cv);
+    TcnDecWs& d = p->td;
+    const int64_t B = p->B;
+    const int64_t act = (int64_t)T * Bp * 64;
+    p->valid = cv.take((int64_t)T * Bp);
+    p->len_d = cv.take(Bp);
+    p->dloc = cv.take((int64_t)T * p->C3 * Bp);
+    p->dzdec = cv.take(2LL * L * Bp);
+    d.hn = cv.take((int64_t)L * Bp); d.rinv = cv.take(Bp);
+    d.d0 = cv.take((int64_t)L * Bp); d.n0 = cv.take((int64_t)L * Bp);
+    d.d1 = cv.take(2LL * L * Bp); d.n1 = cv.take(2LL * L * Bp);
+    d.d2 = cv.take(4LL * L * Bp);
+    d.bnp0 = cv.take(4 * L); d.bnp1 = cv.take(8 * L); d.bnp2 = cv.take(16 * L);
+    d.zrep = cv.take((int64_t)T * Bp * 32);
+    for (int b = 0; b < 4; ++b) {
+      d.y1[b] = cv.take(act); d.a1[b] = cv.take(act); d.y2[b] = cv.take(act); d.out[b] = cv.take(act);
+      d.g1[b] = cv.take(act); d.g2[b] = cv.take(act);
+    }
+    d.skip = cv.take(act); d.dout[0] = cv.take(act); d.dout[1] = cv.take(act); d.da = cv.take(act);
+    for (int k = 0; k < 8; ++k) d.bnp[k] = cv.take(4 * 64);
+    const int64_t rows = 2 * dof_tcn_row_blocks(T, B), waves = 2 * dof_tcn_conv_waves(T, Bp);
+    d.partial_rows = rows > waves ? rows : waves;
+    d.partial = cv.take(d.partial_rows * 64);
+    d.sums = cv.take(128); d.coef = cv.take(128);
+    d.hid = cv.take(act); d.dskip = cv.take(act);
+    d.dzrep = cv.take((int64_t)T * Bp * 32);
+    d.dzf = cv.take(4LL * L * Bp); d.dpre2 = cv.take(4LL * L * Bp);
+    d.dn1 = cv.take(2LL * L * Bp); d.dpre1 = cv.take(2LL * L * Bp);
+    d.dn0 = cv.take((int64_t)L * Bp); d.dpre0 = cv.take((int64_t)L * Bp);
+    d.dhn = cv.take((int64_t)L * Bp);
+    d.hpartial = cv.take(4LL * L * p->lat_blocks * 2); d.hsums = cv.take(8 * L); d.hcoef = cv.take(8 * L);
   }
-  p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
-  p->mask_tab = cv.take(p->param_total);
-  p->ws_floats = cv.cur;
+  take_tables(p, cv);
 }
 
 void build_workspace_layout(DofVadePlan* p) {
-  if (p->kind == 3) return build_tcn_workspace_layout(p);
+  if (p->tcn) return build_tcn_workspace_layout(p);
   const int L = p->L, T = p->T, K = p->K, S = p->S;
   Carver cv;
   for (int s = 0; s < 2; ++s) {
@@ -486,15 +579,50 @@ void build_workspace_layout(DofVadePlan* p) {
     p->cl_rowstat = cv.take(4 * p->B);
     p->cl_theta = cv.take(p->B);
     p->cl_partial = cv.take(3 * p->cl_blocks);
-    for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
-      js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
-      js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
-    }
-    p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
-    p->mask_tab = cv.take(p->param_total);
-    p->ws_floats = cv.cur;
+    take_tables(p, cv);
     return;
   }
+  take_latent_buffers(p, cv);
+  p->valid = cv.take((int64_t)T * Bp);
+  p->len_d = cv.take(Bp);
+  p->o1d = cv.take((int64_t)T * 2 * L * Bp);
+  p->g1d = cv.take(2LL * T * 4 * L * Bp);
+  p->n1d = cv.take((int64_t)T * 2 * L * Bp);
+  p->o2d = cv.take((int64_t)T * 4 * L * Bp);
+  p->g2d = cv.take(2LL * T * 8 * L * Bp);
+  p->n2d = cv.take((int64_t)T * 4 * L * Bp);
+  p->cv = cv.take((int64_t)T * 2 * L * Bp);
+  p->n3 = cv.take((int64_t)T * 2 * L * Bp);
+  p->dloc = cv.take((int64_t)T * p->C3 * Bp);
+  p->dcv = cv.take((int64_t)T * 2 * L * Bp);
+  p->dn2d = cv.take((int64_t)T * 4 * L * Bp);
+  p->do2d = cv.take((int64_t)T * 4 * L * Bp);
+  p->dn1dx = cv.take(2LL * T * 2 * L * Bp);
+  p->do1d = cv.take((int64_t)T * 2 * L * Bp);
+  p->dzdec = cv.take(2LL * L * Bp);
+  p->lnd_blocks = dof_ln_bwd_blocks(T, p->B);
+  p->ln3p = cv.take(p->tail_blocks * 4 * L);
+  p->lnd2p = cv.take(p->lnd_blocks * 8 * L);
+  p->lnd1p = cv.take(p->lnd_blocks * 4 * L);
+  p->wgd2 = cv.take(L == 8 ? dof_gru16_wg_floats(p->B) : 0);
+  take_tables(p, cv);
+}
+
+// plan-level tables: weight-gradient jobs, optimiser segments, trainable mask
+void take_tables(DofVadePlan* p, Carver& cv) {
+  for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+    js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
+    js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
+  }
+  p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
+  p->mask_tab = cv.take(p->param_total);
+  p->ws_floats = cv.cur;  // the partial-tile region is appended by finish_workspace_layout()
+}
+
+// latent space / loss scratch shared by the VaDE and VQ-VAE plans of both families ([c][Bp] unless noted)
+void take_latent_buffers(DofVadePlan* p, Carver& cv) {
+  const int L = p->L, T = p->T, K = p->K, S = p->S;
+  const int64_t Bp = p->Bp;
   p->mu = cv.take((int64_t)L * Bp);
   p->pre = cv.take((int64_t)L * Bp);
   p->sv = cv.take((int64_t)L * Bp);
@@ -527,36 +655,6 @@ void build_workspace_layout(DofVadePlan* p) {
   p->vq_idx = cv.take(Bp);
   p->vq_partial = cv.take(p->lat_blocks);
   p->vq_pop = cv.take(K);
-  p->valid = cv.take((int64_t)T * Bp);
-  p->len_d = cv.take(Bp);
-  p->o1d = cv.take((int64_t)T * 2 * L * Bp);
-  p->g1d = cv.take(2LL * T * 4 * L * Bp);
-  p->n1d = cv.take((int64_t)T * 2 * L * Bp);
-  p->o2d = cv.take((int64_t)T * 4 * L * Bp);
-  p->g2d = cv.take(2LL * T * 8 * L * Bp);
-  p->n2d = cv.take((int64_t)T * 4 * L * Bp);
-  p->cv = cv.take((int64_t)T * 2 * L * Bp);
-  p->n3 = cv.take((int64_t)T * 2 * L * Bp);
-  p->dloc = cv.take((int64_t)T * p->C3 * Bp);
-  p->dcv = cv.take((int64_t)T * 2 * L * Bp);
-  p->dn2d = cv.take((int64_t)T * 4 * L * Bp);
-  p->do2d = cv.take((int64_t)T * 4 * L * Bp);
-  p->dn1dx = cv.take(2LL * T * 2 * L * Bp);
-  p->do1d = cv.take((int64_t)T * 2 * L * Bp);
-  p->dzdec = cv.take(2LL * L * Bp);
-  p->lnd_blocks = dof_ln_bwd_blocks(T, p->B);
-  p->ln3p = cv.take(p->tail_blocks * 4 * L);
-  p->lnd2p = cv.take(p->lnd_blocks * 8 * L);
-  p->lnd1p = cv.take(p->lnd_blocks * 4 * L);
-  p->wgd2 = cv.take(L == 8 ? dof_gru16_wg_floats(p->B) : 0);
-  // tables: sized generously (counts are fixed small numbers)
-  for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
-    js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
-    js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
-  }
-  p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
-  p->mask_tab = cv.take(p->param_total);
-  p->ws_floats = cv.cur;  // the partial-tile region is appended by finish_workspace_layout()
 }
 
 // ---- weight-gradient job tables (need the bound workspace pointer) ----------------------------
@@ -708,11 +806,94 @@ void build_tcn_jobs(DofVadePlan* p) {
   jb.add_tile(job, soa(ws + p->hd_n2, Bp), L, 0);
   jb.add_fin(job, 0, L, L, L, L, p->h6w, L, 1);
   jb.add_fin(job, 64, L, 1, L, L, p->h6b, 1, 1);
+  if (p->kind == 0) {  // VaDE latent heads (as in the recurrent family)
+    job = jb.add_job(soa(ws + p->dmu_dpre, Bp), 2 * L, 1, Bp);
+    jb.add_tile(job, soa(ws + p->enc, Bp), L, 0);
+    jb.add_fin(job, 0, L, L, L, L, p->mean_w, L, 1);
+    jb.add_fin(job, 0, L, L, 0, L, p->lv_w, L, 1);
+    jb.add_fin(job, 64, L, 1, L, L, p->mean_b, 1, 1);
+    jb.add_fin(job, 64, L, 1, 0, L, p->lv_b, 1, 1);
+  }
   jb.close(p->js_enc);
+  if (p->kind == 2) return;
+  // ---- TCN decoder (the latent input only enters through hn, so one job set serves both VQ passes)
+  {
+    JobBuilder jd(p->js_dec[0]);
+    const TcnDecWs& d = p->td;
+    const int CD = 64, C4 = 4 * L;
+    const int ddil[4] = {8, 4, 2, 1};
+    for (int b = 0; b < 4; ++b) {
+      const TcnBlockOff& o = p->dblk[b];
+      auto conv = [&](const float* dy, const float* in, int cin_buf, int cin, int64_t wOff, int64_t bOff) {
+        int jobc = -1;
+        bool bias_done = false;
+        for (int j = 0; j < 4; ++j)
+          for (int c0 = 0; c0 < cin; c0 += 16) {
+            if (jobc < 0 || jd.jobs[jobc].n_tiles == 4) {
+              jobc = jd.add_job(aos(dy, CD, Bp), CD, T, Bp);
+              if (!bias_done) jd.add_fin(jobc, 64, CD, 1, CD, CD, bOff, 1, 1);
+              bias_done = true;
+            }
+            const int nc = cin - c0 < 16 ? cin - c0 : 16;
+            const int tl = jd.add_tile(jobc, aos(in, cin_buf, Bp, c0), nc, -(3 - j) * ddil[b]);
+            jd.add_fin(jobc, tl * 16, CD, nc, CD, CD, wOff + (int64_t)c0 * 4 + j, (int64_t)cin * 4, 4);
+          }
+      };
+      if (b == 0) conv(ws + d.g1[0], ws + d.zrep, 32, C4, o.c1w, o.c1b);
+      else conv(ws + d.g1[b], ws + d.out[b - 1], CD, CD, o.c1w, o.c1b);
+      conv(ws + d.g2[b], ws + d.a1[b], CD, CD, o.c2w, o.c2b);
+      if (b == 0) {  // 1x1 residual conv (4L -> 64): A = gradient entering block 0's residual branch (dout[1])
+        int jobd = -1;
+        for (int c0 = 0; c0 < C4; c0 += 16) {
+          if (jobd < 0) {
+            jobd = jd.add_job(aos(ws + d.dout[1], CD, Bp), CD, T, Bp);
+            jd.add_fin(jobd, 64, CD, 1, CD, CD, o.dsb, 1, 1);
+          }
+          const int nc = C4 - c0 < 16 ? C4 - c0 : 16;
+          const int tl = jd.add_tile(jobd, aos(ws + d.zrep, 32, Bp, c0), nc, 0);
+          jd.add_fin(jobd, tl * 16, CD, nc, CD, CD, o.dsw + c0, C4, 1);
+        }
+      }
+    }
+    // loc projection (3N, 64): A = dloc rows (<= 64 per job), B = hidden
+    for (int r0 = 0; r0 < p->C3; r0 += 64) {
+      const int rows = p->C3 - r0 < 64 ? p->C3 - r0 : 64;
+      const int jobp = jd.add_job(aos(ws + p->dloc, p->C3, Bp, r0), rows, T, Bp);
+      for (int c0 = 0; c0 < CD; c0 += 16) {
+        const int tl = jd.add_tile(jobp, aos(ws + d.hid, CD, Bp, c0), 16, 0);
+        jd.add_fin(jobp, tl * 16, rows, 16, rows, rows, p->dpw + (int64_t)r0 * CD + c0, CD, 1);
+      }
+      jd.add_fin(jobp, 64, rows, 1, rows, rows, p->dpb + r0, 1, 1);
+    }
+    // front MLP: fc2 (4L, 2L), fc1 (2L, L), fc0 (L, L)
+    auto dense = [&](const float* dpre, int co, const float* in, int ci, int64_t wOff, int64_t bOff) {
+      for (int c0 = 0; c0 < ci; c0 += 16) {
+        const int jobm = jd.add_job(soa(dpre, Bp), co, 1, Bp);
+        const int nc = ci - c0 < 16 ? ci - c0 : 16;
+        jd.add_tile(jobm, soa(in, Bp, c0), nc, 0);
+        jd.add_fin(jobm, 0, co, nc, co, co, wOff + c0, ci, 1);
+        if (c0 == 0) jd.add_fin(jobm, 64, co, 1, co, co, bOff, 1, 1);
+      }
+    };
+    dense(ws + d.dpre2, 4 * L, ws + d.n1, 2 * L, p->dfc2w, p->dfc2b);
+    dense(ws + d.dpre1, 2 * L, ws + d.n0, L, p->dfc1w, p->dfc1b);
+    dense(ws + d.dpre0, L, ws + d.hn, L, p->dfc0w, p->dfc0b);
+    jd.close(p->js_dec[0]);
+    JobBuilder j1(p->js_dec[1]);
+    j1.close(p->js_dec[1]);
+  }
+  {
+    JobBuilder gb(p->js_gram);
+    const float* zsrc = ws + (p->kind == 0 ? p->z : p->enc);
+    const int gj = gb.add_job(soa(zsrc, Bp), L, 1, Bp);
+    gb.add_tile(gj, soa(zsrc, Bp), L, 0);
+    gb.add_fin(gj, 0, L, L, L, L, p->gram, L, 1);
+    gb.close(p->js_gram);
+  }
 }
 
 void build_jobs(DofVadePlan* p) {
-  if (p->kind == 3) return build_tcn_jobs(p);
+  if (p->tcn) return build_tcn_jobs(p);
   const int L = p->L, T = p->T;
   float* ws = p->ws;
   const int64_t Bp = p->Bp;
@@ -880,8 +1061,14 @@ int censnet_forward(DofVadePlan* p, const float* params, hipStream_t st) {
   return dof_check_launch("censnet forward");
 }
 
+int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const float* a, bool train, hipStream_t st);
+
+// Both encoder families leave the L-dimensional encoder output in ws.enc when `with_output` (the recurrent family's
+// final dense layer is launched by the latent / VQ / contrastive callers otherwise -- kept as is).
 int encoder_forward(DofVadePlan* p, const float* params, const float* x, const float* a, bool train,
                     hipStream_t st) {
+  // the TCN family refreshes its BatchNorm running buffers (stored in the parameter buffer) in train mode
+  if (p->tcn) return tcn_encoder_forward(p, const_cast<float*>(params), x, a, train, st);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
   for (int s = 0; s < 2; ++s) {
@@ -920,12 +1107,12 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
                                 ws + t.partial, 0, T, d, w.S, w.Sp, st));
         nrows = dof_tcn_conv_waves(T, w.Sp);
       }
-      TRY(dof_launch_sum_partials(ws + t.partial, nrows, 64, ws + t.sums, 0, st));
+      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
                                 train, ws + t.bnp[2 * b], 32, st));
       TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b], ws + t.a1[b],
                               ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st));
-      TRY(dof_launch_sum_partials(ws + t.partial, dof_tcn_conv_waves(T, w.Sp), 64, ws + t.sums, 0, st));
+      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv_waves(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
                                 train, ws + t.bnp[2 * b + 1], 32, st));
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
@@ -949,13 +1136,28 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
                                ws + p->enc, nullptr, nullptr, L, L, 0, B, Bp, st);
 }
 
+// encoder.final_dense of the recurrent family (flat -> enc); the TCN head has already produced ws.enc
+int final_dense_fwd(DofVadePlan* p, const float* params, hipStream_t st) {
+  if (p->tcn) return DOF_OK;
+  float* ws = p->ws;
+  DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
+             params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
+  return dof_check_launch("k_final_dense");
+}
+// ... and its data gradient (denc -> dflat); the TCN encoder backward starts from ws.denc itself
+int final_dense_bwd(DofVadePlan* p, const float* params, hipStream_t st) {
+  if (p->tcn) return DOF_OK;
+  float* ws = p->ws;
+  LDISPATCH(p->L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(p->B, 256), (unsigned)p->J), (256), st,
+                             (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, p->B, p->Bp));
+  return dof_check_launch("k_final_dense_bwd");
+}
+
 int latent_forward(DofVadePlan* p, const float* params, const float* prior, const float* eps, float* z_out,
                    float* q_out, float* mu_out, float* sv_out, float* enc_out, hipStream_t st) {
   float* ws = p->ws;
   LatentFwdArgs A;
-  DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
-             params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
-  TRY(dof_check_launch("k_final_dense"));
+  TRY(final_dense_fwd(p, params, st));
   A.flat = ws + p->flat; A.J = p->J;
   A.wf = params + p->fd_w; A.bf = params + p->fd_b; A.wm = params + p->mean_w; A.bm = params + p->mean_b;
   A.ws = params + p->lv_w; A.bs = params + p->lv_b;
@@ -968,8 +1170,115 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
   return dof_check_launch("k_latent_fwd");
 }
 
+const int kTcnDecDil[4] = {8, 4, 2, 1};
+
+// TCNDecoderPT.forward (models_new.py:772-819) from the latent batch zin [L][Bp]
+int tcn_decoder_forward(DofVadePlan* p, float* params, const float* x, const float* zin, float* recon_partial,
+                        bool train, float* loc_out, hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T, CD = 64, C4 = 4 * L;
+  const int64_t B = p->B, Bp = p->Bp;
+  const TcnDecWs& d = p->td;
+  DOF_LAUNCH(k_dec_valid, (dof_cdiv(B * T, 256)), (256), st, x, T, p->C3, B, Bp, ws + p->valid);
+  TRY(dof_check_launch("k_dec_valid"));
+  // front MLP: RMS guard -> fc0 -> BN0 -> fc1 -> ReLU -> BN1 -> fc2 -> ReLU -> BN2
+  TRY(dof_launch_head_rms(zin, ws + d.hn, ws + d.rinv, L, B, Bp, st));
+  TRY(dof_launch_head_dense(ws + d.hn, nullptr, nullptr, params + p->dfc0w, params + p->dfc0b, ws + d.d0, ws + d.hpartial,
+                            ws + d.hsums, L, L, 0, B, Bp, st));
+  TRY(dof_launch_bn_fwd_fin(ws + d.hsums, (float)B, params + p->dbn0[0], params + p->dbn0[1], params + p->dbn0[2],
+                            params + p->dbn0[3], 0.01f, train, ws + d.bnp0, L, st));
+  TRY(dof_launch_head_dense(ws + d.d0, ws + d.bnp0, ws + d.n0, params + p->dfc1w, params + p->dfc1b, ws + d.d1,
+                            ws + d.hpartial, ws + d.hsums, L, 2 * L, 1, B, Bp, st));
+  TRY(dof_launch_bn_fwd_fin(ws + d.hsums, (float)B, params + p->dbn1[0], params + p->dbn1[1], params + p->dbn1[2],
+                            params + p->dbn1[3], 0.01f, train, ws + d.bnp1, 2 * L, st));
+  TRY(dof_launch_head_dense(ws + d.d1, ws + d.bnp1, ws + d.n1, params + p->dfc2w, params + p->dfc2b, ws + d.d2,
+                            ws + d.hpartial, ws + d.hsums, 2 * L, C4, 1, B, Bp, st));
+  TRY(dof_launch_bn_fwd_fin(ws + d.hsums, (float)B, params + p->dbn2[0], params + p->dbn2[1], params + p->dbn2[2],
+                            params + p->dbn2[3], 0.01f, train, ws + d.bnp2, C4, st));
+  TRY(dof_launch_dec_repeat(ws + d.d2, ws + d.bnp2, ws + d.zrep, C4, T, B, Bp, st));
+  // TCN over the repeated features
+  const float count = (float)((int64_t)T * B);
+  const int64_t waves = dof_tcn_conv_waves(T, Bp);
+  for (int b = 0; b < 4; ++b) {
+    const TcnBlockOff& o = p->dblk[b];
+    const int dl = kTcnDecDil[b];
+    if (b == 0) {
+      TRY(dof_launch_tcn_convg(0, 32, CD, ws + d.zrep, params + o.c1w, C4, C4, params + o.c1b, nullptr, nullptr,
+                               ws + d.y1[0], ws + d.partial, 0, T, dl, B, Bp, st));
+    } else {
+      TRY(dof_launch_tcn_convg(0, CD, CD, ws + d.out[b - 1], params + o.c1w, CD, CD, params + o.c1b, nullptr, nullptr,
+                               ws + d.y1[b], ws + d.partial, 0, T, dl, B, Bp, st));
+    }
+    if (train) TRY(dof_launch_tcn_bn_stats(ws + d.y1[b], ws + d.partial, waves, 2 * CD, ws + d.sums, count, T, CD, B, Bp, st));
+    TRY(dof_launch_bn_fwd_fin(ws + d.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
+                              train, ws + d.bnp[2 * b], CD, st));
+    TRY(dof_launch_tcn_convg(0, CD, CD, ws + d.y1[b], params + o.c2w, CD, CD, params + o.c2b, ws + d.bnp[2 * b],
+                             ws + d.a1[b], ws + d.y2[b], ws + d.partial, 0, T, dl, B, Bp, st));
+    if (train) TRY(dof_launch_tcn_bn_stats(ws + d.y2[b], ws + d.partial, waves, 2 * CD, ws + d.sums, count, T, CD, B, Bp, st));
+    TRY(dof_launch_bn_fwd_fin(ws + d.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
+                              train, ws + d.bnp[2 * b + 1], CD, st));
+    TRY(dof_launch_tcn_combine(ws + d.y2[b], ws + d.bnp[2 * b + 1], b ? ws + d.out[b - 1] : nullptr, ws + d.zrep,
+                               b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb, ws + d.out[b], ws + d.skip,
+                               nullptr, b == 0, T, b ? CD : C4, CD, B, Bp, st));
+  }
+  return dof_launch_tcn_dec_out(ws + d.skip, params + p->dpw, params + p->dpb, x, ws + p->valid, ws + d.hid, loc_out,
+                                recon_partial, ws + p->dloc, ws + d.dskip, T, p->C3, train ? 1 : 0, B, Bp, st);
+}
+
+// Backward of tcn_decoder_forward(train): parameter gradients (set / accumulated), d loss / d zin into slab 0 of
+// ws.dzdec (slab 1 stays zero: it is the second GRU direction of the recurrent decoder).
+int tcn_decoder_backward(DofVadePlan* p, const float* params, float* grads, int accumulate, hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T, CD = 64, C4 = 4 * L;
+  const int64_t B = p->B, Bp = p->Bp;
+  const TcnDecWs& d = p->td;
+  const float count = (float)((int64_t)T * B);
+  for (int b = 3; b >= 0; --b) {
+    const TcnBlockOff& o = p->dblk[b];
+    const int dl = kTcnDecDil[b];
+    float* dprev = ws + d.dout[(b + 1) & 1];
+    // the last block's output feeds nothing (only the skip-sum is used): its gradient is zero
+    TRY(dof_launch_tcn_bn_bwd1(b == 3 ? nullptr : ws + d.dout[b & 1], ws + d.y2[b], ws + d.bnp[2 * b + 1], ws + d.g2[b],
+                               ws + d.partial, ws + d.sums, 1, b == 3 ? nullptr : ws + d.out[b], nullptr, nullptr,
+                               ws + d.dskip, dprev, T, CD, B, Bp, st));
+    TRY(dof_launch_bn_bwd_fin(ws + d.sums, count, grads + o.g2, grads + o.b2, accumulate, ws + d.coef, CD, st));
+    TRY(dof_launch_tcn_bn_bwd2(ws + d.g2[b], ws + d.y2[b], ws + d.bnp[2 * b + 1], ws + d.coef, T, CD, B, Bp, st));
+    TRY(dof_launch_tcn_convg(1, CD, CD, ws + d.g2[b], params + o.c2w, CD, CD, nullptr, nullptr, nullptr, ws + d.da,
+                             nullptr, 0, T, dl, B, Bp, st));
+    TRY(dof_launch_tcn_bn_bwd1(ws + d.da, ws + d.y1[b], ws + d.bnp[2 * b], ws + d.g1[b], ws + d.partial, ws + d.sums, 0,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, T, CD, B, Bp, st));
+    TRY(dof_launch_bn_bwd_fin(ws + d.sums, count, grads + o.g1, grads + o.b1, accumulate, ws + d.coef, CD, st));
+    TRY(dof_launch_tcn_bn_bwd2(ws + d.g1[b], ws + d.y1[b], ws + d.bnp[2 * b], ws + d.coef, T, CD, B, Bp, st));
+    if (b > 0) {
+      TRY(dof_launch_tcn_convg(1, CD, CD, ws + d.g1[b], params + o.c1w, CD, CD, nullptr, nullptr, nullptr, dprev,
+                               nullptr, 1, T, dl, B, Bp, st));
+    } else {
+      // gradient of the repeated input: conv1^T(dy1) + downsample^T(residual gradient, left in dout[1])
+      TRY(dof_launch_tcn_convg(1, CD, 32, ws + d.g1[0], params + o.c1w, C4, C4, nullptr, nullptr, nullptr, ws + d.dzrep,
+                               nullptr, 0, T, dl, B, Bp, st));
+      DOF_LAUNCH(k_dec_ds_bwd, (dof_cdiv((int64_t)T * B, 256)), (256), st, (const float*)(ws + d.dout[1]),
+                 params + o.dsw, ws + d.dzrep, C4, T, B, Bp);
+      TRY(dof_check_launch("k_dec_ds_bwd"));
+    }
+  }
+  TRY(dof_launch_dec_sum_time(ws + d.dzrep, ws + d.dzf, C4, T, B, Bp, st));
+  // front MLP backward: BN2 <- ReLU <- fc2 <- BN1 <- ReLU <- fc1 <- BN0 <- fc0 <- RMS guard
+  TRY(dof_launch_head_bn_bwd(ws + d.dzf, ws + d.d2, ws + d.bnp2, ws + d.hpartial, ws + d.hsums, ws + d.hcoef,
+                             grads + p->dbn2[0], grads + p->dbn2[1], accumulate, ws + d.dpre2, C4, B, Bp, st, 1));
+  TRY(dof_launch_head_dense_bwd(ws + d.dpre2, params + p->dfc2w, ws + d.dn1, 2 * L, C4, B, Bp, st));
+  TRY(dof_launch_head_bn_bwd(ws + d.dn1, ws + d.d1, ws + d.bnp1, ws + d.hpartial, ws + d.hsums, ws + d.hcoef,
+                             grads + p->dbn1[0], grads + p->dbn1[1], accumulate, ws + d.dpre1, 2 * L, B, Bp, st, 1));
+  TRY(dof_launch_head_dense_bwd(ws + d.dpre1, params + p->dfc1w, ws + d.dn0, L, 2 * L, B, Bp, st));
+  TRY(dof_launch_head_bn_bwd(ws + d.dn0, ws + d.d0, ws + d.bnp0, ws + d.hpartial, ws + d.hsums, ws + d.hcoef,
+                             grads + p->dbn0[0], grads + p->dbn0[1], accumulate, ws + d.dpre0, L, B, Bp, st, 0));
+  TRY(dof_launch_head_dense_bwd(ws + d.dpre0, params + p->dfc0w, ws + d.dhn, L, L, B, Bp, st));
+  TRY(dof_launch_head_rms_bwd(ws + d.dhn, ws + d.hn, ws + d.rinv, ws + p->dzdec, L, B, Bp, st));
+  return run_jobset(p, p->js_dec[0], grads, accumulate, st);
+}
+
 int decoder_forward(DofVadePlan* p, const float* params, const float* x, const float* zin, float* recon_partial,
                     bool train, float* loc_out, hipStream_t st) {
+  if (p->tcn) return tcn_decoder_forward(p, const_cast<float*>(params), x, zin, recon_partial, train, loc_out, st);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
   const int64_t B = p->B, Bp = p->Bp;
@@ -995,6 +1304,7 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, const f
 // accumulated), gradient wrt the latent input into ws.dzdec ([2][L][Bp], one slab per GRU direction).
 int decoder_backward(DofVadePlan* p, const float* params, int which_input, float* grads, int accumulate,
                      hipStream_t st) {
+  if (p->tcn) return tcn_decoder_backward(p, params, grads, accumulate, st);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
   const int64_t B = p->B, Bp = p->Bp;
@@ -1087,6 +1397,7 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
 
 // Backward of CensNet + both recurrent encoder streams from ws.dflat; fills the encoder gradients.
 int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st, int accumulate = 0) {
+  if (p->tcn) return tcn_encoder_backward(p, params, grads, st, accumulate);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
   TRY(censnet_backward(p, params, st));
@@ -1118,7 +1429,7 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static int plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
-                       const float* incidence, int kind, DofVadePlan** out) {
+                       const float* incidence, int kind, DofVadePlan** out, bool tcn = false) {
   if (dims->batch <= 0 || dims->window < 5 || dims->n_nodes <= 0 || dims->n_edges <= 0 || dims->n_clusters <= 0 ||
       dims->mc_samples <= 0) {
     dof_set_error("plan_create: bad dims (batch %d window %d nodes %d edges %d clusters %d)", dims->batch,
@@ -1129,18 +1440,19 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
     dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", dims->latent);
     return DOF_ERR_UNSUPPORTED;
   }
-  if (dims->n_nodes > DOF_CL_MAX_NODES && kind >= 2) {
+  if (dims->n_nodes > DOF_CL_MAX_NODES && kind == 2) {
     dof_set_error("contrastive plan: n_nodes %d > %d", dims->n_nodes, DOF_CL_MAX_NODES);
     return DOF_ERR_UNSUPPORTED;
   }
   DofVadePlan* p = new DofVadePlan();
   p->d = *dims;
   p->kind = kind;
+  p->tcn = tcn;
   p->L = dims->latent; p->K = dims->n_clusters; p->T = dims->window; p->N = dims->n_nodes; p->E = dims->n_edges;
   p->S = dims->mc_samples; p->B = dims->batch; p->Bp = dof_pad64(p->B);
   p->J = (p->N + p->E) * p->L;
   p->C3 = 3 * p->N;
-  p->D = kind == 3 ? 32 : 2 * p->L;
+  p->D = tcn ? 32 : 2 * p->L;
   build_param_layout(p);
   build_triplets(p, laplacian, edge_laplacian, incidence);
   build_workspace_layout(p);
@@ -1156,6 +1468,24 @@ extern "C" int dof_vade_plan_create(const DofVadeDims* dims, const float* laplac
     return DOF_ERR_ARG;
   }
   return plan_create(dims, laplacian, edge_laplacian, incidence, 0, out);
+}
+
+extern "C" int dof_vade_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                        const float* incidence, DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_vade_tcn_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  return plan_create(dims, laplacian, edge_laplacian, incidence, 0, out, true);
+}
+
+extern "C" int dof_vqvae_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                         const float* incidence, DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_vqvae_tcn_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  return plan_create(dims, laplacian, edge_laplacian, incidence, 1, out, true);
 }
 
 extern "C" void dof_vade_plan_destroy(DofVadePlan* plan) { delete plan; }
@@ -1257,9 +1587,12 @@ extern "C" int dof_vade_forward(DofVadePlan* p, const float* params, const float
     return DOF_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
-  TRY(encoder_forward(p, params, x, a, false, st));
+  // TCN family: a train-mode forward (eps given) normalises with batch statistics and refreshes the running
+  // buffers, as module.train() does in the reference; the recurrent family has no such state
+  const bool bn_train = p->tcn && eps != nullptr;
+  TRY(encoder_forward(p, params, x, a, bn_train, st));
   TRY(latent_forward(p, params, prior, eps, z_out, q_out, zmean_out, zlogvar_out, enc_out, st));
-  if (loc_out) TRY(decoder_forward(p, params, x, p->ws + p->z, p->ws + p->recon_partial, false, loc_out, st));
+  if (loc_out) TRY(decoder_forward(p, params, x, p->ws + p->z, p->ws + p->recon_partial, bn_train, loc_out, st));
   return DOF_OK;
 }
 
@@ -1330,9 +1663,7 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   LB.B = B; LB.Bp = Bp;
   LDISPATCH(L, DOF_LAUNCH((k_latent_bwd<LL>), ((unsigned)p->lat_blocks), (256), st, LB));
   TRY(dof_check_launch("k_latent_bwd"));
-  LDISPATCH(L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(B, 256), (unsigned)p->J), (256), st,
-                          (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, B, Bp));
-  TRY(dof_check_launch("k_final_dense_bwd"));
+  TRY(final_dense_bwd(p, params, st));
   DOF_LAUNCH(k_loss_total, (1), (64), st, (const float*)(ws + p->distill_partial), (const float*)(ws + p->tf_partial),
              (int)p->lat_blocks, hyper, B, pretrain ? 1 : 0, logs);
   TRY(dof_check_launch("k_loss_total"));
@@ -1388,9 +1719,7 @@ extern "C" int dof_vqvae_forward(DofVadePlan* p, const float* params, const floa
   hipStream_t st = (hipStream_t)stream;
   float* ws = p->ws;
   TRY(encoder_forward(p, params, x, a, false, st));
-  DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
-             params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
-  TRY(dof_check_launch("k_final_dense"));
+  TRY(final_dense_fwd(p, params, st));
   TRY(vq_quantise(p, params, nullptr, soft_out, ze_out, quant_out, idx_out, st));
   if (loc_q_out) TRY(decoder_forward(p, params, x, ws + p->z, ws + p->recon_partial, false, loc_q_out, st));
   if (loc_e_out) TRY(decoder_forward(p, params, x, ws + p->enc, ws + p->recon_partial2, false, loc_e_out, st));
@@ -1413,9 +1742,7 @@ extern "C" int dof_vqvae_loss_grads(DofVadePlan* p, const float* params, const f
   const int64_t B = p->B, Bp = p->Bp;
   TRY(dof_launch_zero(grads, p->param_total, st));
   TRY(encoder_forward(p, params, x, a, true, st));
-  DOF_LAUNCH(k_final_dense, (dof_cdiv(B, 256), (unsigned)L), (256), st, (const float*)(ws + p->flat), params + p->fd_w,
-             params + p->fd_b, ws + p->enc, p->J, B, Bp);
-  TRY(dof_check_launch("k_final_dense"));
+  TRY(final_dense_fwd(p, params, st));
   TRY(vq_quantise(p, params, hyper, nullptr, nullptr, nullptr, nullptr, st));
   TRY(gram_spectrum(p, hyper, st));  // value-only k-means term on z_e (detached in the reference's step)
   // pass 1: decode the QUANTISED latents -> decoder grads (set) + codebook grads
@@ -1428,9 +1755,7 @@ extern "C" int dof_vqvae_loss_grads(DofVadePlan* p, const float* params, const f
   TRY(decoder_forward(p, params, x, ws + p->enc, ws + p->recon_partial2, true, nullptr, st));
   TRY(decoder_backward(p, params, 1, grads, 1, st));
   LDISPATCH(L, DOF_LAUNCH((k_vq_denc<LL>), (dof_cdiv(B, 256)), (256), st, (const float*)(ws + p->dzdec), ws + p->denc, B, Bp));
-  LDISPATCH(L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(B, 256), (unsigned)p->J), (256), st,
-                          (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, B, Bp));
-  TRY(dof_check_launch("k_final_dense_bwd"));
+  TRY(final_dense_bwd(p, params, st));
   VqLossArgs VL;
   VL.recon_q = ws + p->recon_partial; VL.recon_e = ws + p->recon_partial2; VL.n_recon = (int)p->tail_blocks;
   VL.sq_partial = ws + p->vq_partial; VL.n_sq = (int)p->lat_blocks; VL.pop = ws + p->vq_pop; VL.km = ws + p->km;
@@ -1468,7 +1793,7 @@ extern "C" int dof_contrastive_tcn_plan_create(const DofVadeDims* dims, const fl
   DofVadeDims d = *dims;
   if (d.n_clusters <= 0) d.n_clusters = 1;
   if (d.mc_samples <= 0) d.mc_samples = 1;
-  return plan_create(&d, laplacian, edge_laplacian, incidence, 3, out);
+  return plan_create(&d, laplacian, edge_laplacian, incidence, 2, out, true);
 }
 
 extern "C" int dof_contrastive_plan_create(const DofVadeDims* dims, const float* laplacian,
@@ -1525,7 +1850,7 @@ extern "C" int dof_contrastive_views(const float* x_full, const int32_t* edge_in
 
 extern "C" int dof_contrastive_encode(DofVadePlan* p, const float* params, const float* x, const float* a,
                                       int32_t train, float* z_out, void* stream) {
-  if (!p || !p->ws || p->kind < 2) {
+  if (!p || !p->ws || p->kind != 2) {
     dof_set_error("dof_contrastive_encode: plan not bound to a workspace (or not a contrastive plan)");
     return DOF_ERR_STATE;
   }
@@ -1535,15 +1860,8 @@ extern "C" int dof_contrastive_encode(DofVadePlan* p, const float* params, const
   }
   hipStream_t st = (hipStream_t)stream;
   float* ws = p->ws;
-  if (p->kind == 3) {
-    // BatchNorm running buffers live in the parameter buffer and are refreshed by a train-mode pass
-    TRY(tcn_encoder_forward(p, const_cast<float*>(params), x, a, train != 0, st));
-  } else {
-    TRY(encoder_forward(p, params, x, a, train != 0, st));
-    DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
-               params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
-    TRY(dof_check_launch("k_final_dense"));
-  }
+  TRY(encoder_forward(p, params, x, a, train != 0, st));
+  TRY(final_dense_fwd(p, params, st));
   if (z_out) {
     LDISPATCH(p->L, DOF_LAUNCH((k_cl_export<LL>), (dof_cdiv(p->B, 256)), (256), st, (const float*)(ws + p->enc), z_out,
                                p->B, p->Bp));
@@ -1555,7 +1873,7 @@ extern "C" int dof_contrastive_encode(DofVadePlan* p, const float* params, const
 extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float* z_aug, int32_t similarity,
                                     int32_t loss_fn, float temperature, float tau, float beta, float* dz,
                                     float* dz_aug, float* logs, void* stream) {
-  if (!p || !p->ws || p->kind < 2) {
+  if (!p || !p->ws || p->kind != 2) {
     dof_set_error("dof_contrastive_loss: plan not bound to a workspace (or not a contrastive plan)");
     return DOF_ERR_STATE;
   }
@@ -1603,7 +1921,7 @@ extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float*
 
 extern "C" int dof_contrastive_backward(DofVadePlan* p, const float* params, const float* dz, float* grads,
                                         int32_t accumulate, void* stream) {
-  if (!p || !p->ws || p->kind < 2) {
+  if (!p || !p->ws || p->kind != 2) {
     dof_set_error("dof_contrastive_backward: plan not bound to a workspace (or not a contrastive plan)");
     return DOF_ERR_STATE;
   }
@@ -1615,9 +1933,6 @@ extern "C" int dof_contrastive_backward(DofVadePlan* p, const float* params, con
   float* ws = p->ws;
   if (!accumulate) TRY(dof_launch_zero(grads, p->param_total, st));
   LDISPATCH(p->L, DOF_LAUNCH((k_cl_import<LL>), (dof_cdiv(p->B, 256)), (256), st, dz, ws + p->denc, p->B, p->Bp));
-  if (p->kind == 3) return tcn_encoder_backward(p, params, grads, st, accumulate ? 1 : 0);
-  LDISPATCH(p->L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(p->B, 256), (unsigned)p->J), (256), st,
-                             (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, p->B, p->Bp));
-  TRY(dof_check_launch("k_final_dense_bwd"));
+  TRY(final_dense_bwd(p, params, st));
   return encoder_backward(p, params, grads, st, accumulate ? 1 : 0);
 }

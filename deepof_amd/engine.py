@@ -70,11 +70,12 @@ class VadeEngine:
         self.B, self.T, self.L, self.K, self.S = int(batch), int(window), int(latent_dim), int(n_clusters), int(mc_samples)
         dims = _capi.VadeDims(self.B, self.T, self.N, self.E, self.L, self.K, self.S)
         plan = C.c_void_p()
-        assert kind in ("vade", "vqvae", "contrastive", "contrastive_tcn")
+        assert kind in ("vade", "vqvae", "contrastive", "contrastive_tcn", "vade_tcn", "vqvae_tcn")
         self.kind = kind
         create = {"vade": lib.dof_vade_plan_create, "vqvae": lib.dof_vqvae_plan_create,
                   "contrastive": lib.dof_contrastive_plan_create,
-                  "contrastive_tcn": lib.dof_contrastive_tcn_plan_create}[kind]
+                  "contrastive_tcn": lib.dof_contrastive_tcn_plan_create,
+                  "vade_tcn": lib.dof_vade_tcn_plan_create, "vqvae_tcn": lib.dof_vqvae_tcn_plan_create}[kind]
         _capi.check(lib, create(C.byref(dims), self.lap.ctypes.data, self.elap.ctypes.data, self.inc.ctypes.data,
                                 C.byref(plan)), "dof_*_plan_create")
         self.plan = plan
@@ -173,6 +174,12 @@ class VadeEngine:
             if layer + ".num_batches_tracked" in sd:
                 self.num_batches_tracked[layer].fill_(int(sd[layer + ".num_batches_tracked"]))
 
+    def _count_bn(self, prefix: str, n: int):
+        """num_batches_tracked of the BatchNorm layers under ``prefix`` after n train-mode passes."""
+        for layer, t in self.num_batches_tracked.items():
+            if layer.startswith(prefix):
+                t += n
+
     def set_trainable(self, name: str, trainable: bool):
         """Take a parameter out of (or back into) the optimiser step (reference quirk Q11)."""
         rc = self.lib.dof_vade_set_trainable(self.plan, self.index[name], 1 if trainable else 0, self._stream())
@@ -237,6 +244,10 @@ class VadeEngine:
                                        a.data_ptr(), None if eps is None else eps.data_ptr(), ptr("z"), ptr("q"),
                                        ptr("z_mean"), ptr("z_log_var"), ptr("loc"), ptr("enc"), self._stream())
         _capi.check(self.lib, rc, "dof_vade_forward")
+        if eps is not None:
+            self._count_bn("encoder.", 1)
+            if want_loc:
+                self._count_bn("decoder.", 1)
         return out
 
     def loss_grads(self, x, a, eps, eps_mc=None, tau=None, pretrain: bool = True):
@@ -253,6 +264,7 @@ class VadeEngine:
             self.teacher.data_ptr() if self.hyper_host[_capi.H_HAS_TEACHER] != 0 else None,
             self.hyper.data_ptr(), 1 if pretrain else 0, self.grads.data_ptr(), self.logs.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_vade_loss_grads")
+        self._count_bn("", 1)
 
     # ------------------------------------------------------------------ VQ-VAE
     def vq_forward(self, x, a, want_loc: bool = True, want_soft: bool = True) -> Dict[str, torch.Tensor]:
@@ -281,6 +293,8 @@ class VadeEngine:
                                            self.hyper.data_ptr(), self.grads.data_ptr(), self.logs.data_ptr(),
                                            self._stream())
         _capi.check(self.lib, rc, "dof_vqvae_loss_grads")
+        self._count_bn("encoder.", 1)
+        self._count_bn("decoder.", 2)   # the decoder runs on the quantised and on the raw latents
 
     def read_vq_logs(self) -> Dict[str, float]:
         v = self.logs.detach().cpu().tolist()
@@ -297,8 +311,7 @@ class VadeEngine:
                                              1 if train else 0, z.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_contrastive_encode")
         if train:
-            for t in self.num_batches_tracked.values():
-                t += 1
+            self._count_bn("", 1)
         return z
 
     def contrastive_loss(self, z, z_aug, similarity="cosine", loss_fn="nce", temperature=0.1, tau=0.1, beta=0.1,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 4
+#define DOF_ABI_VERSION 5
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -84,6 +84,16 @@ int64_t dof_vade_workspace_bytes(const DofVadePlan* plan);
 /* Zero the workspace and upload the plan's tables into it (enqueued on stream).  Call once per
  * workspace before the first forward / step, outside any graph capture. */
 int dof_vade_bind(DofVadePlan* plan, void* workspace, void* stream);
+
+/* TCN family (models_new.py:376-819: TCNEncoderPT + TCNDecoderPT): same entry points as the recurrent plans,
+ * parameters in VaDEPT / VQVAEPT(encoder_type="TCN").state_dict() order with the BatchNorm running_mean /
+ * running_var as entries of the flat buffer (skipped by the optimiser).  dof_vade_loss_grads /
+ * dof_vqvae_loss_grads and a dof_vade_forward with eps != NULL run the BatchNorms in train mode and update
+ * those entries in place (the `const float* params` of these calls is written to for TCN plans). */
+int dof_vade_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                             const float* incidence, DofVadePlan** out);
+int dof_vqvae_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                              const float* incidence, DofVadePlan** out);
 
 /* Exclude (trainable = 0) / include parameter i in dof_optimizer_step -- the reference's "this tensor is
  * not in the optimiser" cases (quirk Q11: the lazily built CensNet tensors of the TCN encoders). */

@@ -369,3 +369,55 @@ def run_contrastive_tcn_check(lib, device, golden_dir):
             assert bad.mean() <= 0.005 and np.abs(got - ref).max() <= 4.2e-3, (k, bad.sum(), np.abs(got - ref).max())
     np.testing.assert_array_equal(sd2["encoder.spatial_gnn_block.node_kernel"].numpy(),
                                   d[pfx + "sd::encoder.spatial_gnn_block.node_kernel"])
+
+
+def run_vade_tcn_check(lib, device, golden_dir):
+    """VaDE with the TCN encoder and decoder (R12) vs the reference golden: eval forward on the running statistics,
+    then (from the same initial state each) train-mode loss terms, all gradients and the refreshed BatchNorm buffers."""
+    d = load_golden(golden_dir, "vade_tcn14.npz")
+    x, a = torch.from_numpy(d["x"]).to(device), torch.from_numpy(d["a"]).to(device)
+    B, T, N, _ = x.shape
+    K, L = d["sd::latent_space.gmm_means"].shape
+    eng = VadeEngine(lib, device, B, T, d["adj"], L, K, kind="vade_tcn")
+    sd0 = params_from(d)
+    eng.load_state_dict(sd0)
+    assert list(eng.state_dict().keys()) == list(sd0.keys())
+    out = eng.forward(x, a, None, want_loc=True, want_enc=True)
+    np.testing.assert_allclose(out["enc"].cpu().numpy(), d["eval_enc"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["z"].cpu().numpy(), d["eval_z"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["q"].cpu().numpy(), d["eval_q"], atol=1e-5, rtol=1e-3)
+    np.testing.assert_allclose(out["loc"].cpu().numpy(), d["eval_loc"], atol=5e-5, rtol=1e-4)
+    eps, eps_mc = torch.from_numpy(d["eps"]).to(device), torch.from_numpy(d["eps_mc"]).to(device)
+    tau = torch.from_numpy(d["tau"]).to(device)
+    for phase, klw, teacher in (("pre", 0.13, False), ("mainT", 0.7, True)):
+        eng.load_state_dict(sd0)
+        configure_phase(eng, K, phase == "pre", klw, tau if teacher else None, 1.7 if teacher else 0.0)
+        eng.loss_grads(x, a, eps, None if phase == "pre" else eps_mc, tau if teacher else None, pretrain=phase == "pre")
+        logs = eng.read_logs()
+        for k, v in logs.items():
+            key = f"{phase}::loss::{k}"
+            if key in d:
+                np.testing.assert_allclose(v, float(d[key]), rtol=2e-4, atol=2e-5, err_msg=key)
+        # gradients: the golden holds the reference evaluated in float64 and, per tensor, the reference's own fp32
+        # deviation from it ("gnoise": ~3e-4 of the tensor scale here -- BatchNorm over 6 windows is ill-conditioned).
+        # Bar: within 8 noise units of the fp64 value (measured: median 1.5, worst 5.5).
+        n, worst = 0, 0.0
+        for k in d:
+            if k.startswith(f"{phase}::grad::"):
+                name = k.split("::")[-1]
+                g = eng.view(name, eng.grads).cpu().numpy()
+                ref = d[k].reshape(g.shape)
+                err, noise = np.abs(g - ref).max(), float(d[f"{phase}::gnoise::{name}"])
+                assert err <= 8.0 * noise + 2e-6 * np.abs(ref).max() + 1e-7, (phase, name, err, noise)
+                worst = max(worst, err / (noise + 2e-6 * np.abs(ref).max() + 1e-7))
+                n += 1
+        assert n >= (200 if phase == "pre" else 10)
+        if phase == "pre":
+            sd1 = eng.state_dict()
+            nb = 0
+            for k in d:
+                if k.startswith("pre::sd_after::"):
+                    name = k[len("pre::sd_after::"):]
+                    np.testing.assert_allclose(sd1[name].numpy(), d[k], atol=5e-6, rtol=5e-5, err_msg=name)
+                    nb += 1
+            assert nb == 2 * (34 + 3 + 8)

@@ -58,3 +58,8 @@ def test_contrastive_step_emu(golden_dir, tag):
 def test_contrastive_tcn_emu(golden_dir):
     from parity_common import run_contrastive_tcn_check
     run_contrastive_tcn_check(emu_lib(), "cpu", golden_dir)
+
+
+def test_vade_tcn_emu(golden_dir):
+    from parity_common import run_vade_tcn_check
+    run_vade_tcn_check(emu_lib(), "cpu", golden_dir)

@@ -315,8 +315,10 @@ def test_tcn_contrastive_matches_reference(golden_dir):
 
 
 def test_vade_tcn_matches_reference(golden_dir):
-    """VaDE with the TCN encoder AND decoder (R12): eval forward on running statistics, then train-mode outputs,
-    loss terms, BatchNorm buffers and gradients for the pre-training and the main (+teacher) objective."""
+    """VaDE with the TCN encoder AND decoder (R12): eval forward on running statistics (bit-stable), then the
+    train-mode step for the pre-training and the main (+teacher) objective.  BatchNorm over 6 windows amplifies
+    fp32 rounding to ~1e-4 relative in the gradients, so the golden holds the reference evaluated in float64 plus
+    the reference's own fp32 deviation from it per tensor ("noise"); the oracle must sit within a few noise units."""
     d = _load(golden_dir, "vade_tcn14.npz")
     x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
     K, L = d["sd::latent_space.gmm_means"].shape
@@ -338,8 +340,9 @@ def test_vade_tcn_matches_reference(golden_dir):
         cfg = OV.VadeLossCfg(K, phase == "pre", **kw)
         losses, grads, out = OV.vade_grads(P, x, a, cfg, klw, eps, None if phase == "pre" else eps_mc,
                                            tau if teacher else None)
-        np.testing.assert_allclose(out["z"].detach().numpy(), d[f"{phase}::z"], atol=5e-6, rtol=1e-5)
-        np.testing.assert_allclose(out["loc"].detach().numpy(), d[f"{phase}::loc"], atol=2e-5, rtol=1e-5)
+        for key in ("z", "loc"):
+            err = np.abs(out[key].detach().numpy() - d[f"{phase}::{key}"]).max()
+            assert err <= 3.0 * float(d[f"{phase}::noise::{key}"]) + 1e-6, (phase, key, err)
         for k in d:
             if k.startswith(f"{phase}::loss::"):
                 name = k.split("::")[-1]
@@ -349,8 +352,8 @@ def test_vade_tcn_matches_reference(golden_dir):
         for k in d:
             if k.startswith(f"{phase}::grad::"):
                 name = k.split("::")[-1]
-                np.testing.assert_allclose(grads[name].numpy(), d[k], atol=1e-4 + 2e-5 * np.abs(d[k]).max(), rtol=1e-3,
-                                           err_msg=f"{phase} {name}")
+                err = np.abs(grads[name].numpy() - d[k]).max()
+                assert err <= 3.0 * float(d[f"{phase}::gnoise::{name}"]) + 1e-6 * np.abs(d[k]).max() + 1e-7, (phase, name, err)
                 n += 1
         assert n >= (200 if phase == "pre" else 10)
         if phase == "pre":
