@@ -421,3 +421,61 @@ def run_vade_tcn_check(lib, device, golden_dir):
                     np.testing.assert_allclose(sd1[name].numpy(), d[k], atol=5e-6, rtol=5e-5, err_msg=name)
                     nb += 1
             assert nb == 2 * (34 + 3 + 8)
+
+
+def _oracle_truth(fn, P, *tensors):
+    """Run an oracle function in fp32 and in fp64 (its .float() casts redirected to double): (out32, out64)."""
+    r32 = fn({k: v.clone() for k, v in P.items()}, *tensors)
+    P64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in P.items()}
+    orig = torch.Tensor.float
+    torch.Tensor.float = lambda self: self.double()
+    try:
+        r64 = fn(P64, *[t.double() if t.dtype == torch.float32 else t for t in tensors])
+    finally:
+        torch.Tensor.float = orig
+    return r32, r64
+
+
+def run_vqvae_tcn_check(lib, device, golden_dir):
+    """VQ-VAE with the TCN encoder/decoder: weights = the VaDE-TCN golden's encoder/decoder + a random codebook.
+    Eval forward vs the oracle directly; the train step (encoder once, decoder on the quantised and on the raw
+    latents, BatchNorm in train mode) vs the oracle evaluated in fp64, in units of the oracle's own fp32 noise."""
+    from oracle import vqvae as OQ
+    d = load_golden(golden_dir, "vade_tcn14.npz")
+    x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
+    B, T, N, _ = x.shape
+    L, K = 8, 12
+    P = {k: v for k, v in params_from(d).items() if not k.startswith("latent_space")}
+    P["vq_layer.codebook"] = torch.randn(L, K, generator=torch.Generator().manual_seed(5)) * 0.5
+    eng = VadeEngine(lib, device, B, T, d["adj"], L, K, kind="vqvae_tcn")
+    assert [n for n in eng.state_dict() if n not in P] == []
+    eng.load_state_dict(P)
+    out = eng.vq_forward(x.to(device), a.to(device))
+    with torch.no_grad():
+        ref = OQ.vqvae_forward({k: v.clone() for k, v in P.items()}, x, a, training=False)
+    np.testing.assert_array_equal(out["idx"].cpu().numpy(), ref["idx"].numpy())
+    np.testing.assert_allclose(out["ze"].cpu().numpy(), ref["ze"].numpy(), atol=5e-6, rtol=1e-5)
+    np.testing.assert_allclose(out["loc_q"].cpu().numpy(), ref["loc_q"].numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["loc_e"].cpu().numpy(), ref["loc_e"].numpy(), atol=2e-5, rtol=1e-4)
+    eng.set_hyper(vq_beta=1.0, km_latent=0.0, km_loss=0.0, clip=0.75, wd=1e-4)
+    eng.push_hyper()
+    eng.vq_loss_grads(x.to(device), a.to(device))
+    logs = eng.read_vq_logs()
+    (l32, g32, _), (l64, g64, _) = _oracle_truth(lambda Pq, xx, aa: OQ.vqvae_grads(Pq, xx, aa, 1.0, 0.0), P, x, a)
+    for k in ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss"):
+        np.testing.assert_allclose(logs[k], float(l64[k]), rtol=2e-4, atol=2e-5, err_msg=k)
+    n = 0
+    for name, t in g64.items():
+        if t is None:
+            assert float(eng.view(name, eng.grads).abs().max()) == 0.0, name
+            continue
+        g = eng.view(name, eng.grads).cpu().numpy().astype(np.float64)
+        t = t.numpy().reshape(g.shape)
+        noise = np.abs(g32[name].numpy().astype(np.float64).reshape(g.shape) - t).max()
+        err = np.abs(g - t).max()
+        assert err <= 8.0 * noise + 2e-6 * np.abs(t).max() + 1e-7, (name, err, noise)
+        n += 1
+    assert n >= 180
+    sd = eng.state_dict()
+    assert int(sd["decoder.bn0.num_batches_tracked"]) == int(P["decoder.bn0.num_batches_tracked"]) + 2
+    assert int(sd["encoder.head.2.num_batches_tracked"]) == int(P["encoder.head.2.num_batches_tracked"]) + 1
