@@ -58,6 +58,7 @@ SIGNATURES = {
     "dof_vade_param_total": (_I64, [_P]),
     "dof_vade_param_shape": (_I32, [_P, _I32, C.POINTER(_I64)]),
     "dof_vade_set_trainable": (C.c_int, [_P, _I32, _I32, _P]),
+    "dof_vade_set_batchnorm_training": (C.c_int, [_P, _I32]),
     "dof_vade_workspace_bytes": (_I64, [_P]),
     "dof_vade_bind": (C.c_int, [_P, _P, _P]),
     "dof_vade_forward": (C.c_int, [_P] * 13),

@@ -153,6 +153,7 @@ struct DofVadePlan {
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
   // TCN family (encoder: all kinds; decoder: kinds 0 / 1)
   bool tcn = false;
+  bool bn_training = true;  // dof_vade_set_batchnorm_training(): false = the loss/grad entries normalise with the running buffers
   int D = 0;  // CensNet input channels: 2L (recurrent blocks) or 32 (TCN features)
   TcnBlockOff dblk[4];  // decoder TCN blocks (64 filters, dilations 8,4,2,1)
   int64_t dfc0w, dfc0b, dfc1w, dfc1b, dfc2w, dfc2b, dbn0[4], dbn1[4], dbn2[4];  // decoder MLP; bn: gamma, beta, rm, rv
@@ -1090,6 +1091,7 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
 int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const float* a, bool train, hipStream_t st) {
   float* ws = p->ws;
   const int L = p->L, T = p->T;
+  train = train && p->bn_training;
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
     const TcnWs& t = p->tw[s];
@@ -1179,6 +1181,8 @@ int tcn_decoder_forward(DofVadePlan* p, float* params, const float* x, const flo
   const int L = p->L, T = p->T, CD = 64, C4 = 4 * L;
   const int64_t B = p->B, Bp = p->Bp;
   const TcnDecWs& d = p->td;
+  const bool keep = train;              // write the tensors the backward pass needs
+  train = train && p->bn_training;      // BatchNorm mode
   DOF_LAUNCH(k_dec_valid, (dof_cdiv(B * T, 256)), (256), st, x, T, p->C3, B, Bp, ws + p->valid);
   TRY(dof_check_launch("k_dec_valid"));
   // front MLP: RMS guard -> fc0 -> BN0 -> fc1 -> ReLU -> BN1 -> fc2 -> ReLU -> BN2
@@ -1222,7 +1226,7 @@ int tcn_decoder_forward(DofVadePlan* p, float* params, const float* x, const flo
                                nullptr, b == 0, T, b ? CD : C4, CD, B, Bp, st));
   }
   return dof_launch_tcn_dec_out(ws + d.skip, params + p->dpw, params + p->dpb, x, ws + p->valid, ws + d.hid, loc_out,
-                                recon_partial, ws + p->dloc, ws + d.dskip, T, p->C3, train ? 1 : 0, B, Bp, st);
+                                recon_partial, ws + p->dloc, ws + d.dskip, T, p->C3, keep ? 1 : 0, B, Bp, st);
 }
 
 // Backward of tcn_decoder_forward(train): parameter gradients (set / accumulated), d loss / d zin into slab 0 of
@@ -1499,6 +1503,15 @@ extern "C" int32_t dof_vade_param_shape(const DofVadePlan* p, int32_t i, int64_t
   for (size_t k = 0; k < sh.size() && k < 4; ++k) dims4[k] = sh[k];
   return (int32_t)sh.size();
 }
+extern "C" int dof_vade_set_batchnorm_training(DofVadePlan* p, int32_t training) {
+  if (!p) {
+    dof_set_error("dof_vade_set_batchnorm_training: null plan");
+    return DOF_ERR_ARG;
+  }
+  p->bn_training = training != 0;
+  return DOF_OK;
+}
+
 extern "C" int dof_vade_set_trainable(DofVadePlan* p, int32_t i, int32_t trainable, void* stream) {
   if (!p || !p->ws || i < 0 || i >= (int32_t)p->params.size()) {
     dof_set_error("dof_vade_set_trainable: plan not bound or parameter index out of range");

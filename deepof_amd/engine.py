@@ -95,6 +95,7 @@ class VadeEngine:
         # counters (num_batches_tracked, int64 in the reference state_dict) are host integers
         self.bn_layers = [n[: -len(".running_mean")] for n in self.names if n.endswith(".running_mean")]
         self.num_batches_tracked = {n: torch.zeros((), dtype=torch.int64) for n in self.bn_layers}
+        self.bn_training = True
         total = lib.dof_vade_param_total(plan)
         f32 = dict(dtype=torch.float32, device=self.device)
         ws_bytes = lib.dof_vade_workspace_bytes(plan)
@@ -174,8 +175,16 @@ class VadeEngine:
             if layer + ".num_batches_tracked" in sd:
                 self.num_batches_tracked[layer].fill_(int(sd[layer + ".num_batches_tracked"]))
 
+    def set_bn_training(self, training: bool):
+        """module.train() / module.eval() for the plan's BatchNorm layers (no-op for the recurrent family)."""
+        self.bn_training = bool(training)
+        _capi.check(self.lib, self.lib.dof_vade_set_batchnorm_training(self.plan, 1 if training else 0),
+                    "dof_vade_set_batchnorm_training")
+
     def _count_bn(self, prefix: str, n: int):
         """num_batches_tracked of the BatchNorm layers under ``prefix`` after n train-mode passes."""
+        if not self.bn_training:
+            return
         for layer, t in self.num_batches_tracked.items():
             if layer.startswith(prefix):
                 t += n

@@ -59,16 +59,74 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = F
         mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
+def _attach_all(model: nn.Module, eng: VadeEngine, extra=None):
+    """Register the engine's tensors on the module tree under the reference names: parameters, BatchNorm running
+    buffers (views of the flat buffer) and their int64 step counters (shared with the engine), in state_dict order."""
+    for name in eng.names:
+        if extra is not None:
+            extra(name)
+        _attach(model, name, eng.view(name), buffer=".running_" in name)
+        if name.endswith(".running_var"):
+            layer = name[: -len(".running_var")]
+            _attach(model, layer + ".num_batches_tracked", eng.num_batches_tracked[layer], buffer=True)
+
+
+@torch.no_grad()
+def _reset_tcn_family(model: nn.Module, latent_dim: int):
+    """Initialisers of the TCN family (models_new.py:420-430 convs ~ N(0, 0.05) / zero bias; :596-601 and :764-766
+    MLPs xavier-uniform / zero bias; BatchNorm identity; CensNet censNetConv_pt.py:62-84; GMM xavier-normal)."""
+    for name, p in model.named_parameters():
+        leaf = name.split(".")[-1]
+        if ".bn" in name or name.startswith("encoder.head.2") or name.startswith("encoder.head.5"):
+            p.fill_(1.0 if leaf == "weight" else 0.0)
+        elif "spatial_gnn_block" in name:
+            if leaf in ("node_kernel", "edge_kernel", "node_weights", "edge_weights"):
+                nn.init.xavier_uniform_(p)
+            else:
+                bound = 1.0 / math.sqrt(latent_dim)
+                p.uniform_(-bound, bound)
+        elif ".head." in name or name.startswith("decoder.fc"):
+            nn.init.xavier_uniform_(p) if leaf == "weight" else p.zero_()
+        elif name in ("latent_space.gmm_means", "latent_space.gmm_log_vars"):
+            nn.init.xavier_normal_(p)
+        elif name == "vq_layer.codebook":
+            p.uniform_(0.0, 1.0)
+        elif "_tcn." in name or ".tcn." in name:
+            p.normal_(0.0, 0.05) if leaf == "weight" else p.zero_()
+        elif leaf == "weight":  # nn.Linear default: U(+-1/sqrt(fan_in))
+            fan_in = int(np.prod(p.shape[1:]))
+            p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+        elif leaf == "bias":
+            w = dict(model.named_parameters())[name[: -len("bias")] + "weight"]
+            fan_in = int(np.prod(w.shape[1:]))
+            p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+    for name, b in model.named_buffers():
+        if name.endswith("running_mean"):
+            b.zero_()
+        elif name.endswith("running_var"):
+            b.fill_(1.0)
+        elif name.endswith("num_batches_tracked"):
+            b.zero_()
+
+
+def _encoder_family(encoder_type) -> bool:
+    """True for the TCN family; raises for encoders this build does not have."""
+    enc = str(encoder_type).lower()
+    if enc not in ("recurrent", "tcn"):
+        raise NotImplementedError(f"encoder_type={encoder_type!r}: this build implements the recurrent and the TCN "
+                                  "encoder/decoder (the transformer variant is SURVEY.md section 8a row R17)")
+    return enc == "tcn"
+
+
 class VaDE(nn.Module):
     def __init__(self, input_shape, edge_feature_shape, adjacency_matrix: np.ndarray, latent_dim: int,
                  n_components: int, encoder_type: str = "recurrent", use_gnn: bool = True, kmeans_loss: float = 1.0,
                  interaction_regularization: float = 0.0, lens_enabled: bool = False, batch_size: int = 256,
                  device=None, _engine_factory: Optional[Callable[..., VadeEngine]] = None):
         super().__init__()
-        if str(encoder_type).lower() != "recurrent":
-            raise NotImplementedError(
-                f"encoder_type={encoder_type!r}: this build implements the recurrent encoder/decoder "
-                "(TCN / transformer are later rows of SURVEY.md section 8a)")
+        self._tcn = _encoder_family(encoder_type)
+        if self._tcn:
+            self._KIND = "vade_tcn"
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
         time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
@@ -79,7 +137,7 @@ class VaDE(nn.Module):
         self.input_n_features_per_node = n_feat
         self.latent_dim = int(latent_dim)
         self.n_components = int(n_components)
-        self.encoder_type = "recurrent"
+        self.encoder_type = "TCN" if self._tcn else "recurrent"
         self.kmeans_weight = float(kmeans_loss)
         self.lens_enabled = False
         self._adjacency = np.asarray(adjacency_matrix, dtype=np.float32)
@@ -94,19 +152,52 @@ class VaDE(nn.Module):
         self.encoder.register_buffer("incidence", torch.from_numpy(eng.inc.copy()))
         self.decoder = _Box()
         self.latent_space = _Box()
-        for name in eng.names:
+
+        def latent_buffers(name):
             if name == "latent_space.encoder_mean.weight":
                 self.latent_space.register_buffer("prior", eng.prior)
                 self.latent_space.register_buffer("pretrain", torch.tensor(0.0))
-            _attach(self, name, eng.view(name))
+
+        _attach_all(self, eng, latent_buffers)
         self.reset_parameters()
 
     # ------------------------------------------------------------------ engines
     _KIND = "vade"
 
     def _make_engine(self, batch: int, shared):
-        return self._factory(batch=batch, window=self.window_size, adjacency=self._adjacency,
-                             latent_dim=self.latent_dim, n_clusters=self.n_components, shared=shared, kind=self._KIND)
+        eng = self._factory(batch=batch, window=self.window_size, adjacency=self._adjacency,
+                            latent_dim=self.latent_dim, n_clusters=self.n_components, shared=shared, kind=self._KIND)
+        if getattr(self, "_tcn", False):
+            eng.set_bn_training(self.training)
+            if not getattr(self, "censnet_in_optimizer", False):
+                # reference quirk Q11: the TCN encoder creates its CensNet tensors lazily at the first forward, i.e.
+                # AFTER fit_VQVAE / fit_contrastive / fit_VADE's pre-training have built their optimiser: they get
+                # gradients but are never updated (fit_VADE's main-phase optimiser does include them)
+                for name in eng.names:
+                    if ".spatial_gnn_block." in name:
+                        eng.set_trainable(name, False)
+        return eng
+
+    def set_censnet_trainable(self, flag: bool):
+        """Put the TCN encoder's CensNet tensors into / out of the optimiser on every plan of this model (Q11)."""
+        self.censnet_in_optimizer = bool(flag)
+        if getattr(self, "_tcn", False):
+            for eng in self._all_engines():
+                for name in eng.names:
+                    if ".spatial_gnn_block." in name:
+                        eng.set_trainable(name, flag)
+
+    def _all_engines(self):
+        out = [self._base] + list(self._engines.values())
+        return out + list(getattr(self, "_aug_engines", {}).values())
+
+    def train(self, mode: bool = True):
+        """module.train()/eval(): the TCN family's BatchNorm layers follow the module mode in the step entries."""
+        super().train(mode)
+        if getattr(self, "_tcn", False) and hasattr(self, "_base"):
+            for eng in self._all_engines():
+                eng.set_bn_training(mode)
+        return self
 
     def engine(self, batch: int) -> VadeEngine:
         """Plan + workspace for this batch size (parameters are shared across batch sizes)."""
@@ -124,6 +215,8 @@ class VaDE(nn.Module):
     # ------------------------------------------------------------------ init (PyTorch default inits of the reference)
     @torch.no_grad()
     def reset_parameters(self):
+        if getattr(self, "_tcn", False):
+            return _reset_tcn_family(self, self.latent_dim)
         for name, p in self.named_parameters():
             leaf = name.split(".")[-1]
             if ".gru" in name:
@@ -233,14 +326,15 @@ class VQVAE(VaDE):
                  interaction_regularization: float = 0.0, beta: float = 1.0, batch_size: int = 256, device=None,
                  _engine_factory=None):
         nn.Module.__init__(self)
-        if str(encoder_type).lower() != "recurrent":
-            raise NotImplementedError(f"encoder_type={encoder_type!r}: this build implements the recurrent encoder/decoder")
+        self._tcn = _encoder_family(encoder_type)
+        if self._tcn:
+            self._KIND = "vqvae_tcn"
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
         time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
         self.window_size, self.input_n_nodes, self.input_n_features_per_node = time_steps, n_nodes, n_feat
         self.latent_dim, self.n_components = int(latent_dim), int(n_components)
-        self.encoder_type, self.beta, self.kmeans_weight = "recurrent", float(beta), float(kmeans_loss)
+        self.encoder_type, self.beta, self.kmeans_weight = ("TCN" if self._tcn else "recurrent"), float(beta), float(kmeans_loss)
         self._adjacency = np.asarray(adjacency_matrix, dtype=np.float32)
         self._factory = _engine_factory or (lambda **kw: create_vade_engine(device=device, **kw))
         self._engines = {}
@@ -252,8 +346,7 @@ class VQVAE(VaDE):
         self.encoder.register_buffer("incidence", torch.from_numpy(eng.inc.copy()))
         self.decoder = _Box()
         self.vq_layer = _Box()
-        for name in eng.names:
-            _attach(self, name, eng.view(name))
+        _attach_all(self, eng)
         self.reset_parameters()
         with torch.no_grad():
             self.vq_layer.codebook.uniform_(0.0, 1.0)  # models_new.py:1348-1350
@@ -313,11 +406,8 @@ class Contrastive(VaDE):
                  similarity_function: str = "cosine", loss_function: str = "nce", beta: float = 0.1, tau: float = 0.1,
                  interaction_regularization: float = 0.0, batch_size: int = 256, device=None, _engine_factory=None):
         nn.Module.__init__(self)
-        enc = str(encoder_type)
-        if enc.lower() not in ("recurrent", "tcn"):
-            raise NotImplementedError(f"encoder_type={encoder_type!r}: this build implements the recurrent and the "
-                                      "TCN encoder for the contrastive model")
-        self._KIND = "contrastive_tcn" if enc.lower() == "tcn" else "contrastive"
+        self._tcn = _encoder_family(encoder_type)
+        self._KIND = "contrastive_tcn" if self._tcn else "contrastive"
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
         time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
@@ -344,50 +434,8 @@ class Contrastive(VaDE):
         self.encoder.register_buffer("laplacian", torch.from_numpy(eng.lap.copy()))
         self.encoder.register_buffer("edge_laplacian", torch.from_numpy(eng.elap.copy()))
         self.encoder.register_buffer("incidence", torch.from_numpy(eng.inc.copy()))
-        for name in eng.names:
-            _attach(self, name, eng.view(name), buffer=".running_" in name)
-            if name.endswith(".running_var"):  # BatchNorm step counter: host int64, shared with the engine
-                layer = name[: -len(".running_var")]
-                _attach(self, layer + ".num_batches_tracked", eng.num_batches_tracked[layer], buffer=True)
+        _attach_all(self, eng)
         self.reset_parameters()
-
-    @torch.no_grad()
-    def reset_parameters(self):
-        if self._KIND != "contrastive_tcn":
-            return VaDE.reset_parameters(self)
-        for name, p in self.named_parameters():  # models_new.py:420-430 (convs), :596-601 (head), censNetConv_pt.py:75-84
-            leaf = name.split(".")[-1]
-            if ".bn" in name or name.startswith("encoder.head.2") or name.startswith("encoder.head.5"):
-                p.fill_(1.0 if leaf == "weight" else 0.0)
-            elif "spatial_gnn_block" in name:
-                if leaf in ("node_kernel", "edge_kernel", "node_weights", "edge_weights"):
-                    nn.init.xavier_uniform_(p)
-                else:
-                    bound = 1.0 / math.sqrt(self.latent_dim)
-                    p.uniform_(-bound, bound)
-            elif ".head." in name:
-                nn.init.xavier_uniform_(p) if leaf == "weight" else p.zero_()
-            elif leaf == "weight":
-                p.normal_(0.0, 0.05)
-            else:
-                p.zero_()
-        for name, b in self.named_buffers():
-            if name.endswith("running_mean"):
-                b.zero_()
-            elif name.endswith("running_var"):
-                b.fill_(1.0)
-            elif name.endswith("num_batches_tracked"):
-                b.zero_()
-
-    def _make_engine(self, batch: int, shared):
-        eng = VaDE._make_engine(self, batch, shared)
-        if self._KIND == "contrastive_tcn" and not getattr(self, "censnet_in_optimizer", False):
-            # reference quirk Q11: the TCN encoder builds its CensNet tensors lazily, after fit_contrastive has
-            # created the optimiser, so they receive gradients but are never updated
-            for name in eng.names:
-                if ".spatial_gnn_block." in name:
-                    eng.set_trainable(name, False)
-        return eng
 
     def aug_engine(self, batch: int) -> VadeEngine:
         """Second plan/workspace of this batch size: holds the augmented view's activations until its backward."""

@@ -149,10 +149,12 @@ def _clone_model(model: VaDE) -> VaDE:
         twin.train(model.training)
         return twin
     twin = type(model)((model.window_size, model.input_n_nodes, 3), (model.window_size, model._base.E, 1),
-                       model._adjacency, model.latent_dim, model.n_components, kmeans_loss=model.kmeans_weight,
-                       batch_size=model._base.B, _engine_factory=model._factory)
+                       model._adjacency, model.latent_dim, model.n_components, encoder_type=model.encoder_type,
+                       kmeans_loss=model.kmeans_weight, batch_size=model._base.B, _engine_factory=model._factory)
     twin._base.params.copy_(model._base.params)
     twin._base.prior.copy_(model._base.prior)
+    for k, t in model._base.num_batches_tracked.items():
+        twin._base.num_batches_tracked[k].copy_(t)
     twin.train(model.training)
     return twin
 
@@ -418,6 +420,7 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
     # ---- main phase
     model.set_pretrain_mode(False)
     stepper.set_mode("main")
+    model.set_censnet_trainable(True)  # the main-phase optimiser is built after the first forward (Q11)
     stepper.kl_scheduler = WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode, warmup_epochs=vade_cfg.kl_warmup,
                                           max_weight=vade_cfg.kl_max_weight, cooldown_epochs=vade_cfg.kl_cooldown,
                                           end_weight=vade_cfg.kl_end_weight)

@@ -95,6 +95,11 @@ int dof_vade_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, co
 int dof_vqvae_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
                               const float* incidence, DofVadePlan** out);
 
+/* module.train() / module.eval() for the BatchNorm layers of a TCN plan (default: training).  With training = 0
+ * the loss/grad and train-flagged encode entries normalise with the running buffers and leave them untouched --
+ * the reference's validation passes (validate_one_epoch_indexed, training.py:190-229, runs under model.eval()). */
+int dof_vade_set_batchnorm_training(DofVadePlan* plan, int32_t training);
+
 /* Exclude (trainable = 0) / include parameter i in dof_optimizer_step -- the reference's "this tensor is
  * not in the optimiser" cases (quirk Q11: the lazily built CensNet tensors of the TCN encoders). */
 int dof_vade_set_trainable(DofVadePlan* plan, int32_t i, int32_t trainable, void* stream);

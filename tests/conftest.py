@@ -1,4 +1,5 @@
 import os
+import subprocess
 import sys
 
 import pytest
@@ -8,6 +9,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _gpu_present() -> bool:
+    return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """GPU-less container: spread the CPU suite (most of it runs HIP kernels under the SIMT emulator, one fiber at a
+    time) over a few worker processes when pytest-xdist is available and the caller did not choose -n / -p no:xdist.
+    On a GPU box nothing changes: the device tests stay in one process."""
+    if _gpu_present() or not config.pluginmanager.hasplugin("xdist") or "PYTEST_XDIST_WORKER" in os.environ:
+        return None
+    if getattr(config.option, "numprocesses", None) in (None, 0) and not getattr(config.option, "collectonly", False):
+        # build the emulator library once, before the workers race to do it
+        subprocess.run(["make", "-C", os.path.join(ROOT, "deepof_amd", "csrc"), "emu", "-j4"], check=False,
+                       stdout=subprocess.DEVNULL)
+        config.option.numprocesses = min(4, os.cpu_count() or 1)
+    return None
 
 
 def pytest_configure(config):

@@ -18,7 +18,7 @@ def hip():
 def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == 4
+    assert hip.dof_abi_version() == 5
 
 
 def test_gather_gpu(hip):
@@ -398,3 +398,38 @@ def test_contrastive_tcn_full_size_c4(hip):
     with torch.no_grad():
         ref = OT.tcn_encoder(x[:64].cpu(), a[:64].cpu(), P, False)
     np.testing.assert_allclose(z_eval[:64].cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-3)
+
+
+def test_vade_tcn_parity_gpu(hip, golden_dir):
+    from parity_common import run_vade_tcn_check
+    run_vade_tcn_check(hip, "cuda", golden_dir)
+
+
+def test_vqvae_tcn_parity_gpu(hip, golden_dir):
+    from parity_common import run_vqvae_tcn_check
+    run_vqvae_tcn_check(hip, "cuda", golden_dir)
+
+
+@pytest.mark.parametrize("name", ["VaDE", "VQVAE"])
+def test_tcn_training_api_gpu(tmp_path, name):
+    """train_deepof_model(encoder_type="TCN") end to end on the device for both reconstruction models."""
+    from deepof_amd import training as TR
+    N, E, W = 5, 4, 25
+    adj = np.zeros((N, N), np.float32)
+    for i in range(E):
+        adj[i, i + 1] = adj[i + 1, i] = 1
+
+    def pre(nv, nw, seed):
+        r = np.random.default_rng(seed)
+        return {f"v{v}": (np.cumsum(r.standard_normal((nw, W, 3 * N)), 1).astype(np.float32) * 0.2,
+                          r.standard_normal((nw, W, E)).astype(np.float32), np.zeros((nw, W, 0), np.float32))
+                for v in range(nv)}
+    mv, ms, mt, logs = TR.train_deepof_model(
+        preprocessed_object=(pre(2, 400, 1), pre(1, 128, 2)), adjacency_matrix=adj, meta_info={}, encoder_type="TCN",
+        batch_size=128, latent_dim=8, epochs=4, output_path=str(tmp_path), n_clusters=5, model_name=name,
+        use_turtle_teacher=False, save_weights=True, pretrain_epochs=2)
+    assert mv.encoder_type == "TCN" and len(logs["train"]["total_loss"]) == 4
+    assert np.isfinite(logs["train"]["total_loss"]).all() and np.isfinite(logs["val"]["total_loss"]).all()
+    assert logs["train"]["reconstruct_loss"][-1] < logs["train"]["reconstruct_loss"][0]
+    sd = mv.state_dict()
+    assert int(sd["decoder.bn0.num_batches_tracked"]) > 0 and float(sd["decoder.bn0.running_var"].min()) > 0

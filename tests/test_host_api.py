@@ -111,7 +111,7 @@ def test_model_object_matches_reference_interface(golden_dir):
     np.testing.assert_allclose(emb.numpy(), d["eval_z"][:11], atol=1e-5, rtol=1e-4)
     assert soft.shape == (11, 10)
     with pytest.raises(NotImplementedError):
-        VaDE((25, 14, 3), (25, 14, 1), d["adj"], 8, 10, encoder_type="TCN", _engine_factory=emu_factory)
+        VaDE((25, 14, 3), (25, 14, 1), d["adj"], 8, 10, encoder_type="transformer", _engine_factory=emu_factory)
 
 
 def test_input_validation_errors():
@@ -125,7 +125,7 @@ def test_input_validation_errors():
     with pytest.raises(ValueError):
         TR.train_deepof_model(**{**kw, "device": "tpu"})
     with pytest.raises(NotImplementedError):
-        TR.train_deepof_model(**{**kw, "model_name": "Contrastive", "encoder_type": "TCN"})
+        TR.train_deepof_model(**{**kw, "model_name": "VQVAE", "encoder_type": "transformer"})
     with pytest.raises(RuntimeError):   # product path: no CPU fallback
         TR.train_deepof_model(**{**kw, "device": "cpu", "_engine_factory": None})
 
@@ -360,3 +360,43 @@ def test_contrastive_tcn_model_and_fit(golden_dir, tmp_path):
     np.testing.assert_allclose(loaded.embed(x, a).numpy(), mv.embed(x, a).numpy(), atol=1e-5)
     sdl = loaded.state_dict()
     assert int(sdl["encoder.head.2.num_batches_tracked"]) > 0   # BatchNorm counters travel with the bundle
+
+
+@pytest.mark.parametrize("name", ["VaDE", "VQVAE"])
+def test_tcn_family_models_and_fit(golden_dir, tmp_path, name):
+    """VaDE / VQ-VAE with encoder_type="TCN" through the public trainer: reference state_dict (344 keys for VaDE),
+    BatchNorm train/eval semantics, optimiser quirk Q11, checkpoint round trip."""
+    from deepof_amd.models import VQVAE
+    if name == "VaDE":
+        d = load_golden(golden_dir, "vade_tcn14.npz")
+        ref_keys = [k[4:] for k in d if k.startswith("sd::")]
+        model = VaDE((25, 14, 3), (25, 14, 1), d["adj"], 8, 10, encoder_type="TCN", batch_size=6, _engine_factory=emu_factory)
+        assert list(model.state_dict().keys()) == ref_keys and len(ref_keys) == 344
+        model.load_state_dict({k: torch.from_numpy(d["sd::" + k]) for k in ref_keys})
+        model.eval()
+        before = model.state_dict()["decoder.bn1.running_mean"].clone()
+        dist, z, q, km = model(torch.from_numpy(d["x"]), torch.from_numpy(d["a"]))   # eval: buffers untouched
+        np.testing.assert_allclose(z.numpy(), d["eval_z"], atol=2e-5, rtol=1e-4)
+        np.testing.assert_allclose(dist.mean.numpy(), d["eval_loc"], atol=5e-5, rtol=1e-4)
+        assert torch.equal(before, model.state_dict()["decoder.bn1.running_mean"])
+        model.train()
+        model(torch.from_numpy(d["x"]), torch.from_numpy(d["a"]))           # train: batch statistics, buffers move
+        assert not torch.equal(before, model.state_dict()["decoder.bn1.running_mean"])
+        assert int(model.state_dict()["decoder.bn1.num_batches_tracked"]) == int(d["sd::decoder.bn1.num_batches_tracked"]) + 1
+    pre_tr, pre_va = tiny_preprocessed(n_videos=1, n_win=8, W=8, seed=7), tiny_preprocessed(n_videos=1, n_win=8, W=8, seed=8)
+    mv, ms, mt, logs = TR.train_deepof_model(
+        preprocessed_object=(pre_tr, pre_va), adjacency_matrix=chain_adj(4), meta_info={}, encoder_type="TCN",
+        batch_size=8, latent_dim=4, epochs=1, output_path=str(tmp_path), n_clusters=3, model_name=name,
+        use_turtle_teacher=False, save_weights=True, pretrain_epochs=1, _engine_factory=emu_factory)
+    cls = VaDE if name == "VaDE" else VQVAE
+    assert isinstance(mv, cls) and mv.encoder_type == "TCN"
+    assert np.isfinite(logs["train"]["total_loss"]).all() and np.isfinite(logs["val"]["total_loss"]).all()
+    ck = tmp_path / "models" / name.lower() / "run_0" / "best_model_val.pth"
+    if ck.exists():
+        loaded, *_ = TR.load_model_from_ckpt(str(ck), _engine_factory=emu_factory)
+        assert isinstance(loaded, cls) and loaded.encoder_type == "TCN"
+        x = torch.from_numpy(reorder_and_reshape(pre_va["vid0"][0])[:8])
+        a = torch.from_numpy(pre_va["vid0"][1][:8, ..., None])
+        e1, _ = loaded.encode_windows(x, a)
+        e2, _ = mv.encode_windows(x, a)
+        np.testing.assert_allclose(e1.numpy(), e2.numpy(), atol=1e-5)
