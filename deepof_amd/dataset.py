@@ -29,9 +29,52 @@ def reorder_and_reshape(data: np.ndarray) -> np.ndarray:
     return np.stack([data[:, :, 0:n], data[:, :, n:2 * n], data[:, :, 2 * n:3 * n]], axis=-1)
 
 
+def video_ranges(video_idx: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(starts, ends) of the contiguous per-video runs of the concatenated window list (dataset.py:486-502)."""
+    vid = np.asarray(video_idx)
+    if vid.shape[0] == 0:
+        return np.array([], dtype=np.int64), np.array([], dtype=np.int64)
+    change = np.flatnonzero(vid[1:] != vid[:-1]) + 1
+    bounds = np.concatenate(([0], change, [vid.shape[0]])).astype(np.int64)
+    return bounds[:-1], bounds[1:]
+
+
+def block_bootstrap_starts(rng: np.random.Generator, video_idx: np.ndarray, batch_size: int, target_batches: int,
+                           block_len: int = 250) -> np.ndarray:
+    """Block bootstrap of batch starts (dataset.py:505-559): draw a video, then a block of ceil(block_len / bs)
+    consecutive full batches inside it, until ``target_batches`` starts are collected (sampling with replacement).
+    Consumes ``rng`` exactly as the reference does, so the same seed yields the same batches."""
+    v_starts, v_ends = video_ranges(video_idx)
+    v_lens = (v_ends - v_starts).astype(np.int64)
+    ok = v_lens >= batch_size
+    v_starts, v_ends, v_lens = v_starts[ok], v_ends[ok], v_lens[ok]
+    if len(v_lens) == 0:
+        raise RuntimeError("No video segment long enough to provide a full batch.")
+    per_block = int(max(1, np.ceil(int(block_len) / batch_size)))
+    out = np.empty((target_batches,), dtype=np.int64)
+    filled = 0
+    while filled < target_batches:
+        v = int(rng.choice(len(v_lens), p=None))
+        vs, ve, m = int(v_starts[v]), int(v_ends[v]), int(v_lens[v])
+        n_take = min(per_block, m // batch_size)
+        last_start = ve - n_take * batch_size
+        if last_start < vs:
+            continue
+        s0 = int(rng.integers(vs, last_start + 1))
+        for j in range(n_take):
+            if filled >= target_batches:
+                break
+            out[filled] = s0 + j * batch_size
+            filled += 1
+    return out
+
+
 def batch_starts(n_samples: int, batch_size: int, epoch: int, seed: Optional[int], shuffle: bool,
-                 world_size: int = 1, rank: int = 0, drop_last: bool = False) -> np.ndarray:
-    """Start indices of this rank's batches for 1-based ``epoch`` (the reference's ``_epoch`` counter)."""
+                 world_size: int = 1, rank: int = 0, drop_last: bool = False, video_idx: Optional[np.ndarray] = None,
+                 bootstrap: bool = False, bootstrap_block_len: int = 250) -> np.ndarray:
+    """Start indices of this rank's batches for 1-based ``epoch`` (the reference's ``_epoch`` counter);
+    dataset.py:585-618: seeded block shuffle, truncation to a multiple of the world size, optional block
+    bootstrap (same generator, after the shuffle), then the rank's strided share."""
     if drop_last:
         starts = np.arange(0, (n_samples // batch_size) * batch_size, batch_size, dtype=np.int64)
     else:
@@ -42,6 +85,11 @@ def batch_starts(n_samples: int, batch_size: int, epoch: int, seed: Optional[int
         rng.shuffle(starts)
     if world_size > 1:
         starts = starts[: (len(starts) // world_size) * world_size]
+    if bootstrap:
+        if video_idx is None:
+            raise ValueError("bootstrap needs the per-window video index")
+        starts = block_bootstrap_starts(rng, video_idx, batch_size, len(starts), bootstrap_block_len)
+    if world_size > 1:
         starts = starts[rank::world_size]
     return starts
 
@@ -144,7 +192,9 @@ class WindowDataset:
                      drop_last: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, np.ndarray]]:
         """One epoch: yields (x, a, idx[int64 device], video_idx[int32 host]) like the reference loader."""
         self._epoch += 1
-        for s in batch_starts(self.length, batch_size, self._epoch, seed, shuffle, world_size, rank, drop_last):
+        boot = bool(getattr(self, "bootstrap_training", False)) and shuffle
+        for s in batch_starts(self.length, batch_size, self._epoch, seed, shuffle, world_size, rank, drop_last,
+                              self.video_idx, boot, getattr(self, "bootstrap_block_len", 250)):
             s = int(s)
             e = min(s + batch_size, self.length)
             x, a = self.fetch(s, e)

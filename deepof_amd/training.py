@@ -709,8 +709,6 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
         raise ValueError("If a device is given, it needs to be either cpu or gpu!")
     if device == "cpu" and _engine_factory is None:
         raise RuntimeError("deepof_amd has no CPU path: the trainer runs on ROCm GPUs only (device='gpu' or None)")
-    if bootstrap_training:
-        raise NotImplementedError("bootstrap_training (block bootstrap of batch starts) is not implemented in this build")
     is_ddp, rank, world, local_rank = ddp_init_if_needed()
     torch.manual_seed(common_cfg.seed if common_cfg.seed is not None else 0)
     np.random.seed(common_cfg.seed if common_cfg.seed is not None else 0)
@@ -724,6 +722,8 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
     preprocessed_train, preprocessed_val = preprocessed_object
     train_ds = WindowDataset.from_preprocessed(preprocessed_train, data_dev)
     val_ds = WindowDataset.from_preprocessed(preprocessed_val, data_dev)
+    # block bootstrap of the training batches (dataset.py:351-352, 604-614); validation is never bootstrapped
+    train_ds.bootstrap_training, train_ds.bootstrap_block_len = bool(bootstrap_training), int(bootstrap_block_len)
     if model_name == "vqvae":
         return fit_VQVAE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
                          _engine_factory=_engine_factory)

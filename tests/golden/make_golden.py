@@ -494,6 +494,28 @@ def gen_contrastive(tag, ids, T_full, L, B, seed, encoder_type="recurrent", case
     np.savez_compressed(os.path.join(HERE, f"contrastive_{tag}.npz"), **out)
 
 
+def gen_bootstrap():
+    """Batch starts of the reference loader's block bootstrap (dataset.py:505-559, 585-618) for a few cases."""
+    out = {}
+    cases = [(3, [700, 130, 420], 64, 250, 1, 0), (2, [300, 90], 100, 250, 2, 1), (4, [64, 200, 63, 500], 32, 100, 3, 2)]
+    for ci, (nv, lens, bs, L, world, seed) in enumerate(cases):
+        vid = np.concatenate([np.full(n, i, dtype=np.int32) for i, n in enumerate(lens)])
+        n = len(vid)
+        fake = SimpleNamespace(bootstrap_block_len=L)
+        fake._compute_video_ranges = lambda v: R.D._H5BatchIterableDataset._compute_video_ranges(fake, v)
+        for epoch in (1, 2):
+            starts = np.arange(0, n, bs, dtype=np.int64)
+            rng = np.random.default_rng((seed + epoch) % (2 ** 32))
+            rng.shuffle(starts)
+            if world > 1:
+                starts = starts[: (len(starts) // world) * world]
+            bs_starts = R.D._H5BatchIterableDataset._block_bootstrap_batch_starts(fake, rng, vid, n, bs, len(starts))
+            out[f"c{ci}::e{epoch}"] = bs_starts
+        out[f"c{ci}::cfg"] = np.array([bs, L, world, seed], dtype=np.int64)
+        out[f"c{ci}::vid"] = vid
+    np.savez_compressed(os.path.join(HERE, "bootstrap.npz"), **out)
+
+
 def gen_vade_tcn(tag, ids, T, L, K, B, seed):
     """VaDEPT(encoder_type="TCN") -- TCN encoder + GMM latent + TCN decoder (R12): eval forward, and for two phases
     (each restarted from the same initial state, BatchNorm buffers included) the train-mode outputs, loss terms,
@@ -609,6 +631,7 @@ if __name__ == "__main__":
     gen_contrastive("rec28", ["B", "W"], 25, 6, 7, 71)
     gen_contrastive("tcn14", [""], 24, 8, 6, 81, encoder_type="TCN", cases=[("cosine", "nce")])
     gen_vade_tcn("tcn14", [""], 25, 8, 10, 6, 91)
+    gen_bootstrap()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

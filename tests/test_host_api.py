@@ -400,3 +400,26 @@ def test_tcn_family_models_and_fit(golden_dir, tmp_path, name):
         e1, _ = loaded.encode_windows(x, a)
         e2, _ = mv.encode_windows(x, a)
         np.testing.assert_allclose(e1.numpy(), e2.numpy(), atol=1e-5)
+
+
+def test_block_bootstrap_matches_reference(golden_dir):
+    """bootstrap_training: the batch starts equal the reference loader's for the same seed / epoch (bit-exact)."""
+    d = load_golden(golden_dir, "bootstrap.npz")
+    for ci in range(3):
+        bs, L, world, seed = (int(v) for v in d[f"c{ci}::cfg"])
+        vid = d[f"c{ci}::vid"]
+        for epoch in (1, 2):
+            ref = d[f"c{ci}::e{epoch}"]
+            for rank in range(world):
+                got = batch_starts(len(vid), bs, epoch, seed, True, world, rank, False, vid, True, L)
+                np.testing.assert_array_equal(got, ref[rank::world])
+            v_s, v_e = __import__("deepof_amd.dataset", fromlist=["video_ranges"]).video_ranges(vid)
+            for s in ref:   # every bootstrapped batch is a full batch inside one video
+                k = np.searchsorted(v_e, s, side="right")
+                assert v_s[k] <= s and s + bs <= v_e[k]
+    pre = tiny_preprocessed(n_videos=2, n_win=40, W=8)
+    ds = WindowDataset.from_preprocessed(pre, "cpu")
+    ds.bootstrap_training, ds.bootstrap_block_len = True, 16
+    seen = [int(i[0]) for _, _, i, _ in ds.iter_batches(8, True, 0)]
+    assert len(seen) == 10 and all(s % 1 == 0 for s in seen)
+    assert [int(i[0]) for _, _, i, _ in ds.iter_batches(8, False, None)] == list(range(0, 80, 8))  # validation: plain order
