@@ -9,6 +9,7 @@ clip + Adam) on device-resident synthetic data, fp32, eager launches on the curr
   c4  Contrastive, TCN encoder on half windows (window 50 -> 25), batch 8192, nce / cosine (as BASELINE names it)
   c4r the same step with the recurrent encoder
   c5  VaDE, 2 animals (28 nodes, 32 edges), window 50, k=25, batch 4096, main phase
+  c2tcn  the headline C2 workload (VaDE, 14 body parts, window 25, k=10, batch 1024) with the TCN encoder/decoder
 """
 import argparse
 import json
@@ -37,6 +38,18 @@ def timed(step, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def init_tcn_params(eng, seed=0):
+    """Reference initialisers of the TCN family (conv ~ N(0, 0.05), BatchNorm identity, zero biases)."""
+    g = torch.Generator().manual_seed(seed)
+    for n in eng.names:
+        if n.endswith("running_var") or ((".bn" in n or ".head.2" in n or ".head.5" in n) and n.endswith("weight")):
+            eng.view(n).fill_(1.0)
+        elif n.endswith("running_mean") or (n.endswith("bias") and ("tcn." in n or ".bn" in n or ".head." in n or "decoder.fc" in n)):
+            eng.view(n).zero_()
+        elif "_tcn." in n or ".tcn." in n:
+            eng.view(n).copy_(torch.randn(eng.layout[n][2], generator=g) * 0.05)
+
+
 def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
     from deepof_amd import _capi
     from deepof_amd.engine import create_vade_engine
@@ -47,7 +60,9 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
     N, E, L, S = len(nodes), len(edges), 8, 32
     eng = create_vade_engine(B, T, adjacency_from_graph(nodes, edges), L, K, S, device=dev, kind=kind)
     init_params(eng)
-    if kind == "vqvae":
+    if kind.endswith("_tcn"):
+        init_tcn_params(eng)
+    if kind.startswith("vqvae"):
         eng.view("vq_layer.codebook").uniform_(0.0, 1.0)
     tn, te = synth_tables_fast(frames, N, E, 0, dev)
     n_batches = (frames - T + 1) // B
@@ -56,7 +71,7 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
     tau = torch.softmax(torch.randn(B, K, device=dev) * 2, dim=-1)
     for seg in range(_capi.SEG_COUNT):
         eng.set_lr(seg, 5e-4)
-    if kind == "vade":
+    if kind.startswith("vade"):
         configure_phase(eng, K, False, 1.0, tau, 4.0)
     else:
         eng.set_hyper(vq_beta=1.0, km_latent=0.0, km_loss=0.0, clip=0.75, wd=1e-4)
@@ -68,7 +83,7 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
                                                      a.data_ptr(), torch.cuda.current_stream().cuda_stream))
         eng.advance_adam()
         eng.push_hyper()
-        if kind == "vade":
+        if kind.startswith("vade"):
             eps.normal_()
             eps_mc.normal_()
             eng.loss_grads(x, a, eps, eps_mc, tau, pretrain=False)
@@ -77,7 +92,7 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
         eng.optimizer_step()
 
     sec = timed(step, steps, warmup)
-    logs = eng.read_logs() if kind == "vade" else eng.read_vq_logs()
+    logs = eng.read_logs() if kind.startswith("vade") else eng.read_vq_logs()
     assert np.isfinite(logs["total_loss"]), logs
     return sec, logs["total_loss"], N, E
 
@@ -144,7 +159,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--only", default="c3,c4,c4r,c5")
+    ap.add_argument("--only", default="c3,c4,c4r,c5,c2tcn")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a ROCm GPU")
@@ -160,6 +175,10 @@ def main():
             desc = (f"C4{'' if name == 'c4' else ' shape with the RECURRENT encoder'}: contrastive "
                     f"{'TCN' if name == 'c4' else 'recurrent'} encoder, nce/cosine, N=14,E=14, window 50 -> half 25, "
                     "latent=8, batch=8192, both views + augmentations")
+        elif name == "c2tcn":
+            B = 1024
+            sec, loss, N, E = run_vade_like("vade_tcn", [""], 25, 10, B, args.steps, args.warmup)
+            desc = "C2 with the TCN family: VaDE TCN encoder/decoder, N=14,E=14, window=25, k=10, latent=8, batch=1024, main phase"
         elif name == "c5":
             B = 4096
             sec, loss, N, E = run_vade_like("vade", ["B", "W"], 50, 25, B, args.steps, args.warmup)
