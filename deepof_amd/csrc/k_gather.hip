@@ -31,12 +31,23 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float rcp_l
 // run), one thread = one 16-byte streaming store at a time.  All per-element index arithmetic is
 // 32-bit with reciprocal multiplies (the first version spent its time in 64-bit integer division
 // and reached only 25 % of HBM peak); the 64-bit row offsets of the WB windows sit in LDS.
-template <bool INDEXED>
+//
+// STAGE > 0 (the normal case): the frame rows the workgroup's windows cover -- (WB-1)*step + W rows for
+// regularly spaced windows, 40 rows = 9 KB for BASELINE C2 -- are first copied into LDS with coalesced
+// loads, and a W*3N-entry table holds the (frame, column) source offset of every element of a window, so a
+// 16-byte store costs four table lookups + four LDS reads instead of four strided global gathers (the
+// gathers kept the kernel on the texture-address path: 56 % of HBM peak; a pure fill reaches 6.2 TB/s here).
+// Workgroups whose windows are too far apart for the staging buffer take the direct path (STAGE == 0 code).
+template <bool INDEXED, int STAGE, int TAB>
 __global__ void __launch_bounds__(256) k_window_gather(
     const float* __restrict__ node_table, const float* __restrict__ edge_table,
     const int64_t* __restrict__ row_start, int64_t first_row, int64_t row_step, int64_t n_windows,
     int W, int N, int E, float rcp_perwin, float rcp_cols, float* __restrict__ x_out, float* __restrict__ a_out) {
   __shared__ int64_t row0[WB];
+  __shared__ int lrow[WB];
+  __shared__ int64_t span[2];
+  __shared__ float stage[STAGE > 0 ? STAGE : 1];
+  __shared__ int tab[TAB > 0 ? TAB : 1];
   const int C = 3 * N;
   const unsigned per_x = (unsigned)(W * C), per_a = (unsigned)(W * E);
   const int64_t w0 = (int64_t)blockIdx.x * WB;
@@ -44,6 +55,103 @@ __global__ void __launch_bounds__(256) k_window_gather(
   if ((int)threadIdx.x < nwin)
     row0[threadIdx.x] = INDEXED ? row_start[w0 + threadIdx.x] : first_row + (w0 + threadIdx.x) * row_step;
   __syncthreads();
+  bool staged = false;
+  if (STAGE > 0) {
+    if (threadIdx.x == 0) {
+      int64_t lo = row0[0], hi = row0[0];
+      for (int i = 1; i < nwin; ++i) {
+        lo = row0[i] < lo ? row0[i] : lo;
+        hi = row0[i] > hi ? row0[i] : hi;
+      }
+      span[0] = lo;
+      span[1] = hi - lo + W;  // rows covered
+    }
+    __syncthreads();
+    const int64_t rmin = span[0], rows = span[1];
+    staged = rows * (C + E) <= STAGE && (int)per_x <= TAB;
+    if (staged) {
+      const int nnode = (int)rows * C, nedge = (int)rows * E;
+      const float* __restrict__ srcn = node_table + rmin * C;
+      const float* __restrict__ srce = edge_table + rmin * E;
+      for (int i = threadIdx.x; i < nnode; i += 256) stage[i] = srcn[i];
+      for (int i = threadIdx.x; i < nedge; i += 256) stage[nnode + i] = srce[i];
+      // element o = (t, n, f) of a window  <-  frame t, column f*N + n
+      for (unsigned o = threadIdx.x; o < per_x; o += 256) {
+        const unsigned t = fast_div(o, (unsigned)C, rcp_cols);
+        const unsigned r = o - t * C;
+        const unsigned n = (r * 43691u) >> 17;  // r / 3 for r < 2^16
+        tab[o] = (int)(t * C + (r - 3 * n) * N + n);
+      }
+      if ((int)threadIdx.x < nwin) lrow[threadIdx.x] = (int)(row0[threadIdx.x] - rmin);
+      __syncthreads();
+      // ---- nodes
+      {
+        float* __restrict__ out = x_out + w0 * per_x;
+        const unsigned total = (unsigned)nwin * per_x;
+        for (unsigned e0 = 4 * threadIdx.x; e0 < total; e0 += 4 * 256) {
+          float v[4];
+          unsigned w = fast_div(e0, per_x, rcp_perwin);
+          unsigned o = e0 - w * per_x;
+          int base = lrow[w] * C;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = stage[base + tab[o]];
+            if (++o == per_x) {
+              o = 0;
+              w = w + 1 < (unsigned)nwin ? w + 1 : w;
+              base = lrow[w] * C;
+            }
+          }
+          if (e0 + 3 < total) {
+#ifdef DOF_EMU
+            out[e0] = v[0]; out[e0 + 1] = v[1]; out[e0 + 2] = v[2]; out[e0 + 3] = v[3];
+#else
+            dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + e0));
+#endif
+          } else {
+            for (int j = 0; j < 4; ++j)
+              if (e0 + j < total) out[e0 + j] = v[j];
+          }
+        }
+      }
+      // ---- edges: a window is W*E contiguous staged floats
+      {
+        float* __restrict__ out = a_out + w0 * per_a;
+        const float* __restrict__ se = stage + nnode;
+        const unsigned total = (unsigned)nwin * per_a;
+        const float rcp_pa = rcp_perwin * ((float)C / (float)E) * 0.999999f;
+        for (unsigned e0 = 4 * threadIdx.x; e0 < total; e0 += 4 * 256) {
+          float v[4];
+          unsigned w = fast_div(e0, per_a, rcp_pa);
+          unsigned o = e0 - w * per_a;
+          int base = lrow[w] * E;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = se[base + o];
+            if (++o == per_a) {
+              o = 0;
+              w = w + 1 < (unsigned)nwin ? w + 1 : w;
+              base = lrow[w] * E;
+            }
+          }
+          if (e0 + 3 < total) {
+#ifdef DOF_EMU
+            out[e0] = v[0]; out[e0 + 1] = v[1]; out[e0 + 2] = v[2]; out[e0 + 3] = v[3];
+#else
+            dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + e0));
+#endif
+          } else {
+            for (int j = 0; j < 4; ++j)
+              if (e0 + j < total) out[e0 + j] = v[j];
+          }
+        }
+      }
+      return;
+    }
+  }
+  // ---- direct path (windows of this workgroup too far apart to stage)
   // ---- nodes: (rows, [x..|y..|s..]) -> (W, N, 3)
   {
     float* __restrict__ out = x_out + w0 * per_x;
@@ -126,12 +234,19 @@ int launch_gather(const float* node_table, const float* edge_table, const int64_
   if (n_windows == 0) return DOF_OK;
   const unsigned blocks = (unsigned)((n_windows + WB - 1) / WB);
   const float rp = rcp_down((unsigned)(W * 3 * N)), rc = rcp_down((unsigned)(3 * N));
-  if (row_start)
-    DOF_LAUNCH(k_window_gather<true>, (blocks), (256), stream, node_table, edge_table, row_start, first_row, row_step,
-               n_windows, W, N, E, rp, rc, x_out, a_out);
-  else
-    DOF_LAUNCH(k_window_gather<false>, (blocks), (256), stream, node_table, edge_table, row_start, first_row,
-               row_step, n_windows, W, N, E, rp, rc, x_out, a_out);
+  // staging-buffer class by the footprint of WB stride-1 windows (other spacings decide per workgroup)
+  const int64_t need = (int64_t)(WB - 1 + W) * (3 * N + E), tabn = (int64_t)W * 3 * N;
+#define GATHER(IDX, ST, TB)                                                                                      \
+  DOF_LAUNCH((k_window_gather<IDX, ST, TB>), (blocks), (256), stream, node_table, edge_table, row_start, first_row, \
+             row_step, n_windows, W, N, E, rp, rc, x_out, a_out)
+  if (need <= 3072 && tabn <= 1280) {
+    if (row_start) GATHER(true, 3072, 1280); else GATHER(false, 3072, 1280);
+  } else if (need <= 10240 && tabn <= 4608) {
+    if (row_start) GATHER(true, 10240, 4608); else GATHER(false, 10240, 4608);
+  } else {
+    if (row_start) GATHER(true, 0, 0); else GATHER(false, 0, 0);
+  }
+#undef GATHER
   return dof_check_launch("k_window_gather");
 }
 

@@ -49,8 +49,12 @@ def configure_phase(eng, K, pretrain, klw, tau=None, lambda_distill=0.0, extra=N
 
 def gather_check(lib, device):
     rng = np.random.default_rng(0)
+    # (staged-in-LDS path: consecutive / clustered starts incl. a ragged last workgroup and both buffer classes;
+    #  direct path: starts too far apart for the staging buffer)
     for (N, E, W, Fr, starts) in [(14, 14, 25, 90, [0, 1, 2, 3, 40, 65, 7]), (5, 4, 7, 31, list(range(25))),
-                                  (28, 32, 50, 120, [70, 0, 33])]:
+                                  (28, 32, 50, 120, [70, 0, 33]), (14, 14, 25, 120, list(range(3, 3 + 37))),
+                                  (28, 32, 50, 130, list(range(60, 60 + 21))), (14, 14, 25, 90, [9, 4, 11, 4, 30, 12]),
+                                  (42, 47, 50, 140, list(range(0, 70, 3)))]:
         nodes = rng.standard_normal((Fr, 3 * N)).astype(np.float32)
         edges = rng.standard_normal((Fr, E)).astype(np.float32)
         x_ref, a_ref = OW.gather_windows(nodes, edges, np.array(starts), W)
