@@ -84,22 +84,24 @@ __global__ void __launch_bounds__(256) k_window_gather(
       }
       if ((int)threadIdx.x < nwin) lrow[threadIdx.x] = (int)(row0[threadIdx.x] - rmin);
       __syncthreads();
-      // ---- nodes
+      // ---- nodes: (window, element) of a thread's next store advance incrementally (1024 floats per pass)
       {
         float* __restrict__ out = x_out + w0 * per_x;
         const unsigned total = (unsigned)nwin * per_x;
-        for (unsigned e0 = 4 * threadIdx.x; e0 < total; e0 += 4 * 256) {
+        unsigned e0 = 4 * threadIdx.x;
+        unsigned w = fast_div(e0, per_x, rcp_perwin);
+        unsigned o = e0 - w * per_x;
+        for (; e0 < total; e0 += 4 * 256) {
           float v[4];
-          unsigned w = fast_div(e0, per_x, rcp_perwin);
-          unsigned o = e0 - w * per_x;
-          int base = lrow[w] * C;
+          unsigned wj = w < (unsigned)nwin ? w : (unsigned)nwin - 1, oj = o;
+          int base = lrow[wj] * C;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            v[j] = stage[base + tab[o]];
-            if (++o == per_x) {
-              o = 0;
-              w = w + 1 < (unsigned)nwin ? w + 1 : w;
-              base = lrow[w] * C;
+            v[j] = stage[base + tab[oj]];
+            if (++oj == per_x) {
+              oj = 0;
+              wj = wj + 1 < (unsigned)nwin ? wj + 1 : wj;
+              base = lrow[wj] * C;
             }
           }
           if (e0 + 3 < total) {
@@ -112,6 +114,11 @@ __global__ void __launch_bounds__(256) k_window_gather(
           } else {
             for (int j = 0; j < 4; ++j)
               if (e0 + j < total) out[e0 + j] = v[j];
+          }
+          o += 4 * 256;
+          while (o >= per_x) {
+            o -= per_x;
+            ++w;
           }
         }
       }
