@@ -516,6 +516,43 @@ def gen_bootstrap():
     np.savez_compressed(os.path.join(HERE, "bootstrap.npz"), **out)
 
 
+def gen_turtle():
+    """TURTLE teacher (teacher_model.py:43-350): a short fit over a fixed batch list from recorded initial weights,
+    final weights, tau* of a prediction pass, and initialize_gmm_from_teacher on a latent view."""
+    import deepof.clustering.teacher_model as TM
+    torch.manual_seed(7)
+    dims, K, B, nb = [8, 32, 32], 6, 96, 3
+    g = torch.Generator().manual_seed(11)
+    centers = [torch.randn(K, d, generator=g) * 1.5 for d in dims]
+    batches = []
+    for _ in range(nb):
+        lab = torch.randint(0, K, (B,), generator=g)
+        batches.append([c[lab] + 0.7 * torch.randn(B, c.shape[1], generator=g) for c in centers])
+    teacher = TM.TurtleTeacher(feature_dims=dims, n_components=K, gamma=8.0, alpha_sample_entropy=2.0, inner_lr=0.1,
+                               inner_steps=12, head_wd=1e-4, head_temp=0.35, task_temp=0.35, normalize_feats=True,
+                               lr_theta=1e-3, device="cpu")
+    out = {"dims": np.array(dims), "cfg": np.array([K, B, nb, 12, 7])}
+    for k, v in teacher.state_dict().items():
+        out["init::" + k] = v.numpy().copy()
+    for i, bt in enumerate(batches):
+        for v, f in enumerate(bt):
+            out[f"batch{i}::{v}"] = f.numpy()
+    teacher.fit(batches, outer_steps=7, rho=0.04, verbose=False)
+    for k, v in teacher.state_dict().items():
+        out["final::" + k] = v.numpy().copy()
+    tau = teacher.predict([batches[0], batches[1]])
+    out["tau_star"] = tau.numpy()
+    z = torch.cat([batches[0][0], batches[1][0]])
+    fake = SimpleNamespace(latent_space=SimpleNamespace(gmm_means=torch.nn.Parameter(torch.zeros(K, dims[0])),
+                                                        gmm_log_vars=torch.nn.Parameter(torch.zeros(K, dims[0])),
+                                                        prior=torch.zeros(K)),
+                           eval=lambda: None, parameters=lambda: iter([torch.zeros(1)]))
+    TM.initialize_gmm_from_teacher(fake, z, tau, min_var=0.01)
+    out["gmm_means"], out["gmm_log_vars"] = fake.latent_space.gmm_means.detach().numpy(), fake.latent_space.gmm_log_vars.detach().numpy()
+    out["gmm_prior"] = fake.latent_space.prior.numpy()
+    np.savez_compressed(os.path.join(HERE, "turtle.npz"), **out)
+
+
 def gen_vade_tcn(tag, ids, T, L, K, B, seed):
     """VaDEPT(encoder_type="TCN") -- TCN encoder + GMM latent + TCN decoder (R12): eval forward, and for two phases
     (each restarted from the same initial state, BatchNorm buffers included) the train-mode outputs, loss terms,
@@ -632,6 +669,7 @@ if __name__ == "__main__":
     gen_contrastive("tcn14", [""], 24, 8, 6, 81, encoder_type="TCN", cases=[("cosine", "nce")])
     gen_vade_tcn("tcn14", [""], 25, 8, 10, 6, 91)
     gen_bootstrap()
+    gen_turtle()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -360,3 +360,30 @@ def test_vade_tcn_matches_reference(golden_dir):
             for k in d:
                 if k.startswith("pre::sd_after::"):
                     np.testing.assert_allclose(P[k[len("pre::sd_after::"):]].numpy(), d[k], atol=2e-6, rtol=2e-5, err_msg=k)
+
+
+def _turtle_inputs(d):
+    K, B, nb, inner, outer = (int(v) for v in d["cfg"])
+    dims = [int(v) for v in d["dims"]]
+    P = {k[6:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("init::")}
+    batches = [[torch.from_numpy(d[f"batch{i}::{v}"]) for v in range(len(dims))] for i in range(nb)]
+    return K, B, inner, outer, dims, P, batches
+
+
+def test_turtle_teacher_matches_reference(golden_dir):
+    """TURTLE teacher (N3): 7 outer x 12 inner steps from recorded initial weights over a fixed batch list, the
+    prediction pass, and the GMM initialisation from tau*."""
+    from oracle import turtle as OT
+    d = _load(golden_dir, "turtle.npz")
+    K, B, inner, outer, dims, P, batches = _turtle_inputs(d)
+    OT.fit(P, batches, K, outer, inner, gamma=8.0, alpha=2.0, delta=40.0, head_temp=0.35, task_temp=0.35, lr_theta=1e-3)
+    for k, v in d.items():
+        if k.startswith("final::"):
+            np.testing.assert_allclose(P[k[7:]].numpy(), v, atol=2e-6, rtol=2e-5, err_msg=k)
+    tau = torch.cat([OT.predict(P, batches[0], 0.35), OT.predict(P, batches[1], 0.35)])
+    np.testing.assert_allclose(tau.numpy(), d["tau_star"], atol=1e-6, rtol=1e-5)
+    z = torch.cat([batches[0][0], batches[1][0]])
+    m, lv, pr = OT.gmm_from_teacher(z, tau, min_var=0.01)
+    np.testing.assert_allclose(m.numpy(), d["gmm_means"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(lv.numpy(), d["gmm_log_vars"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(pr.numpy(), d["gmm_prior"], atol=1e-6, rtol=1e-5)
