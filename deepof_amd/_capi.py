@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -36,6 +36,16 @@ class Augment(C.Structure):
     _fields_ = [("start", C.c_void_p), ("n_rot", C.c_int32), ("rot_pivot", C.c_int32 * 8),
                 ("rot_nodes", C.c_uint64 * 8), ("theta", C.c_void_p), ("interp_t0", C.c_void_p),
                 ("interp_len", C.c_void_p), ("noise", C.c_void_p)]
+
+
+class TurtleDims(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("n_views", C.c_int32), ("n_clusters", C.c_int32), ("view_dim", C.c_int32 * 8)]
+
+
+class TurtleHyper(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("alpha", C.c_float), ("delta", C.c_float), ("head_temp", C.c_float),
+                ("task_temp", C.c_float), ("inner_lr", C.c_float), ("head_wd", C.c_float), ("lr_theta", C.c_float),
+                ("rho", C.c_float), ("inner_steps", C.c_int32), ("normalize_feats", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -67,6 +77,12 @@ SIGNATURES = {
     "dof_vqvae_forward": (C.c_int, [_P] * 11),
     "dof_vqvae_loss_grads": (C.c_int, [_P] * 8),
     "dof_optimizer_step": (C.c_int, [_P] * 7),
+    "dof_turtle_param_total": (_I64, [C.POINTER(TurtleDims)]),
+    "dof_turtle_param_offset": (_I64, [C.POINTER(TurtleDims), _I32, _I32, _I32]),
+    "dof_turtle_workspace_bytes": (_I64, [C.POINTER(TurtleDims)]),
+    "dof_turtle_fit_step": (C.c_int, [C.POINTER(TurtleDims), C.POINTER(TurtleHyper), C.POINTER(_P), _P, _P, _P, _I32,
+                                      _I32, _P, _P, _P]),
+    "dof_turtle_predict": (C.c_int, [C.POINTER(TurtleDims), C.c_float, C.POINTER(_P), _P, _I64, _P, _P]),
     "dof_contrastive_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_contrastive_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_contrastive_views": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, C.POINTER(Augment), _P, _P, _P]),

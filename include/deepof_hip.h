@@ -22,6 +22,7 @@
  *   dof_contrastive_loss        training.py:482-589 step_contrastive_distill (normalise + loss + logs),
  *                               losses.py:35-249 select_contrastive_loss_pt
  *   dof_contrastive_backward    loss.backward() through one view's encoder pass (training.py:163)
+ *   dof_turtle_fit_step/_predict  teacher_model.py:43-350 TurtleTeacher (heads inner fit, task encoder, fit, predict)
  *   dof_optimizer_step          training.py:164-166 clip_grad_value_ + optimizer.step(), losses.py:805-833
  */
 #ifndef DEEPOF_HIP_H
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 5
+#define DOF_ABI_VERSION 6
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -217,6 +218,36 @@ int dof_contrastive_loss(DofVadePlan* plan, const float* z, const float* z_aug, 
  * grads (accumulate == 0: overwritten, else added -- the second view accumulates onto the first). */
 int dof_contrastive_backward(DofVadePlan* plan, const float* params, const float* dz, float* grads,
                              int32_t accumulate, void* stream);
+
+/* ---- TURTLE teacher (soft cluster targets tau* from linear heads over several views) ------------------
+ * Replaces teacher_model.py:43-350 (TurtleHeads.inner_fit, TaskEncoder.forward, TurtleTeacher.fit / predict).
+ * Parameter buffer = TurtleTeacher.state_dict() order: heads.heads.v.{weight (K,d_v), bias (K)} for every view,
+ * then task_encoder.projs.v.{weight, bias}.  adam_m / adam_v have the same layout (only the task-encoder part
+ * is used).  feats: HOST array of n_views DEVICE pointers, view v = (rows, d_v) fp32 row-major. */
+#define DOF_TURTLE_MAX_VIEWS 8
+typedef struct DofTurtleDims {
+  int32_t batch;       /* rows per outer step */
+  int32_t n_views;
+  int32_t n_clusters;  /* K <= 64 */
+  int32_t view_dim[DOF_TURTLE_MAX_VIEWS];
+} DofTurtleDims;
+typedef struct DofTurtleHyper {
+  float gamma, alpha, delta;        /* marginal-entropy weight, sample-entropy weight, dead-cluster barrier */
+  float head_temp, task_temp;
+  float inner_lr, head_wd, lr_theta, rho;
+  int32_t inner_steps, normalize_feats;
+} DofTurtleHyper;
+int64_t dof_turtle_param_total(const DofTurtleDims* dims);
+int64_t dof_turtle_param_offset(const DofTurtleDims* dims, int32_t task_encoder, int32_t view, int32_t bias);
+int64_t dof_turtle_workspace_bytes(const DofTurtleDims* dims);
+/* One outer step `step` of `outer_steps` on one batch: tau, all inner SGD steps of every head, the loss and the
+ * Adam update of the task encoder.  logs[5] (device) = loss, CE, E[H(tau)], H(marginal), dead-cluster penalty. */
+int dof_turtle_fit_step(const DofTurtleDims* dims, const DofTurtleHyper* hyper, const float* const* feats,
+                        float* params, float* adam_m, float* adam_v, int32_t step, int32_t outer_steps,
+                        void* workspace, float* logs, void* stream);
+/* tau (n_rows, K) of the task encoder for any number of rows (dims.batch is ignored). */
+int dof_turtle_predict(const DofTurtleDims* dims, float task_temp, const float* const* feats, const float* params,
+                       int64_t n_rows, float* tau_out, void* stream);
 
 /* clip_grad_value_(hyper[DOF_H_CLIP]) + Adam(betas 0.9/0.999, eps 1e-8, weight decay hyper[DOF_H_WD]). */
 int dof_optimizer_step(DofVadePlan* plan, float* params, const float* grads, float* adam_m, float* adam_v,

@@ -484,3 +484,31 @@ def run_vqvae_tcn_check(lib, device, golden_dir):
     sd = eng.state_dict()
     assert int(sd["decoder.bn0.num_batches_tracked"]) == int(P["decoder.bn0.num_batches_tracked"]) + 2
     assert int(sd["encoder.head.2.num_batches_tracked"]) == int(P["encoder.head.2.num_batches_tracked"]) + 1
+
+
+def run_turtle_check(lib, device, golden_dir):
+    """TURTLE teacher (N3) vs the reference golden: 7 outer x 12 inner steps from the recorded initial weights over the
+    recorded batch list, tau* of the prediction pass, GMM initialisation from tau*."""
+    from deepof_amd.teacher import TurtleTeacher, gmm_from_teacher
+    d = load_golden(golden_dir, "turtle.npz")
+    K, B, nb, inner, outer = (int(v) for v in d["cfg"])
+    dims = [int(v) for v in d["dims"]]
+    t = TurtleTeacher(dims, K, gamma=8.0, alpha_sample_entropy=2.0, inner_lr=0.1, inner_steps=inner, head_wd=1e-4,
+                      head_temp=0.35, task_temp=0.35, normalize_feats=True, lr_theta=1e-3, device=device, lib=lib)
+    init = {k[6:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("init::")}
+    assert list(t.state_dict().keys()) == list(init.keys())
+    t.load_state_dict(init)
+    batches = [[torch.from_numpy(d[f"batch{i}::{v}"]).to(device) for v in range(len(dims))] for i in range(nb)]
+    t.fit(batches, outer_steps=outer, rho=0.04, verbose=False)
+    sd = t.state_dict()
+    for k, v in d.items():
+        if k.startswith("final::"):
+            np.testing.assert_allclose(sd[k[7:]].numpy(), v, atol=2e-5, rtol=2e-4, err_msg=k)
+    tau = t.predict([batches[0], batches[1]])
+    np.testing.assert_allclose(tau.numpy(), d["tau_star"], atol=2e-5, rtol=2e-4)
+    np.testing.assert_allclose(tau.sum(1).numpy(), 1.0, atol=1e-5)
+    z = torch.cat([batches[0][0], batches[1][0]]).cpu()
+    m, lv, pr = gmm_from_teacher(z, torch.from_numpy(d["tau_star"]), min_var=0.01)
+    np.testing.assert_allclose(m.numpy(), d["gmm_means"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(lv.numpy(), d["gmm_log_vars"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(pr.numpy(), d["gmm_prior"], atol=1e-6, rtol=1e-5)

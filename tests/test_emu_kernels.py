@@ -68,3 +68,8 @@ def test_vade_tcn_emu(golden_dir):
 def test_vqvae_tcn_emu(golden_dir):
     from parity_common import run_vqvae_tcn_check
     run_vqvae_tcn_check(emu_lib(), "cpu", golden_dir)
+
+
+def test_turtle_teacher_emu(golden_dir):
+    from parity_common import run_turtle_check
+    run_turtle_check(emu_lib(), "cpu", golden_dir)
