@@ -429,15 +429,42 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
     _, best_path_val, best_path_score, _teacher_path = ckpt_paths("vade", common_cfg)
     log_summary = init_log_summary("vade")
     teacher_init_model = None
+    teacher_views = {}
+    lambda_scheduler = None
+    lib = eng.lib
     if teacher_cfg.use_turtle_teacher:
-        warnings.warn("TURTLE teacher distillation (SURVEY section 8f row N3) is not implemented in this build; "
-                      "continuing on the reference's use_turtle_teacher=False path (sklearn GMM initialisation, "
-                      "no distillation term).", RuntimeWarning)
-    if is_main:
-        print("\n--- Initializing GMM from embeddings (sklearn) ---")
-    initialize_gmm_from_data(model, train_ds, common_cfg.batch_size, common_cfg.seed)
+        # training.py:1664-1716: latent view of the pre-trained encoder + PCA views -> TURTLE teacher -> tau*;
+        # GMM initialised from tau*-weighted moments; distillation towards tau* during the main phase
+        from . import teacher as TT
+        if is_main:
+            print("\n--- Extracting latents for teacher ---")
+        z_all = TT.extract_latents(model, train_ds, batch_size=2048)
+        lambda_scheduler = WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode, warmup_epochs=0,
+                                          at_max_epochs=teacher_cfg.lambda_decay_start, max_weight=teacher_cfg.lambda_distill,
+                                          cooldown_epochs=teacher_cfg.lambda_cooldown,
+                                          end_weight=teacher_cfg.lambda_end_weight)
+        teacher_cfg.include_latent_view = True  # VaDE has a free and useful latent view thanks to the pre-training
+        _teacher, tau_star, teacher_views = TT.maybe_build_turtle_teacher(
+            teacher_cfg=teacher_cfg, common_cfg=common_cfg, train_dataset=train_ds, device=eng.device,
+            latent_view=z_all, lib=lib)
+        if is_main:
+            print("\n--- Initializing GMM from teacher tau* ---")
+        TT.initialize_gmm_from_teacher(model, z_all, tau_star, min_var=0.01)
+        stepper.set_teacher(tau_star.to(eng.device), teacher_cfg.lambda_distill, lambda_scheduler)
+        teacher_init_model = _clone_model(model)
+        if common_cfg.save_weights and is_main:
+            save_model_info(_teacher_path, stage="teacher_init", epoch=vade_cfg.pretrain_epochs - 1,
+                            train_steps=vade_cfg.pretrain_epochs * nb,
+                            extra={"note": "after pretrain + teacher + GMM init, before main training"},
+                            common_cfg=common_cfg, teacher_cfg=teacher_cfg, vade_cfg=vade_cfg, model=model,
+                            log_summary=log_summary, rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
+    else:
+        if is_main:
+            print("\n--- Initializing GMM from embeddings (sklearn) ---")
+        initialize_gmm_from_data(model, train_ds, common_cfg.batch_size, common_cfg.seed)
     if world > 1:
         dist.broadcast(eng.params, src=0)
+        dist.broadcast(eng.prior, src=0)
 
     best_val, best_score, best_score_val = -float("inf"), -float("inf"), float("inf")
     score_tol, val_tol = 0.01, 0.01
@@ -453,6 +480,29 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
             eng.set_active(_capi.SEG_DECODER, False)
         if epoch == vade_cfg.freeze_decoder_epochs:
             eng.set_active(_capi.SEG_DECODER, True)
+        if (epoch > 0 and teacher_cfg.use_turtle_teacher and teacher_cfg.teacher_refresh_every
+                and teacher_cfg.teacher_refresh_every > 0 and epoch % teacher_cfg.teacher_refresh_every == 0
+                and (teacher_cfg.teacher_freeze_at is None or epoch <= teacher_cfg.teacher_freeze_at)):
+            # training.py:1770-1802: refit the teacher on the CURRENT latents (PCA views are reused)
+            from . import teacher as TT
+            if is_main:
+                print(f"\n--- Refresh TURTLE teacher at epoch {epoch + 1} ---")
+            z_curr = TT.extract_latents(model, train_ds, batch_size=2048)
+            views = {"z": z_curr}
+            for key, flag in (("pca_pos", teacher_cfg.include_nodes_view), ("pca_spd", teacher_cfg.include_nodes_view),
+                              ("pca_edges", teacher_cfg.include_edges_view)):
+                if flag and teacher_views.get(key) is not None:
+                    views[key] = teacher_views[key]
+            _teacher, tau_star = TT.run_turtle_teacher_on_views(
+                views, common_cfg.n_components, gamma=teacher_cfg.teacher_gamma,
+                alpha_sample_entropy=teacher_cfg.teacher_alpha_sample_entropy,
+                outer_steps=max(200, teacher_cfg.teacher_outer_steps), inner_steps=teacher_cfg.teacher_inner_steps,
+                normalize_feats=teacher_cfg.teacher_normalize_feats, verbose=is_main, device=eng.device,
+                head_temp=teacher_cfg.teacher_head_temp, task_temp=teacher_cfg.teacher_task_temp,
+                batch_size=teacher_cfg.teacher_batch_size, seed=(common_cfg.seed or 0) + epoch, lib=lib)
+            stepper.set_teacher(tau_star.to(eng.device), teacher_cfg.lambda_distill, lambda_scheduler)
+            if teacher_cfg.reinit_gmm_on_refresh:
+                TT.initialize_gmm_from_teacher(model, z_curr, tau_star, min_var=1e-4)
         train_logs, klw, lambda_d = stepper.train_epoch(train_ds, common_cfg.seed)
         val_logs = stepper.validate_epoch(val_ds)
         diag = compute_diagnostics(model, val_ds, common_cfg.batch_size, common_cfg.n_components, tau_star=stepper.tau_star,

@@ -423,3 +423,32 @@ def test_block_bootstrap_matches_reference(golden_dir):
     seen = [int(i[0]) for _, _, i, _ in ds.iter_batches(8, True, 0)]
     assert len(seen) == 10 and all(s % 1 == 0 for s in seen)
     assert [int(i[0]) for _, _, i, _ in ds.iter_batches(8, False, None)] == list(range(0, 80, 8))  # validation: plain order
+
+
+def test_fit_vade_with_turtle_teacher(tmp_path):
+    """use_turtle_teacher=True (the reference default): latent + PCA views -> TURTLE tau* -> GMM init from tau* ->
+    distillation during the main phase, teacher-init checkpoint, teacher refresh."""
+    from deepof_amd import teacher as TT
+    pre_tr, pre_va = tiny_preprocessed(n_videos=2, n_win=24, W=8, seed=11), tiny_preprocessed(n_videos=1, n_win=16, W=8, seed=12)
+    mv, ms, mt, logs = TR.train_deepof_model(
+        preprocessed_object=(pre_tr, pre_va), adjacency_matrix=chain_adj(4), meta_info={}, encoder_type="recurrent",
+        batch_size=8, latent_dim=4, epochs=3, output_path=str(tmp_path), n_clusters=3, model_name="VaDE",
+        use_turtle_teacher=True, teacher_outer_steps=6, teacher_inner_steps=5, pca_nodes_dim=4, teacher_batch_size=16,
+        teacher_refresh_every=2, save_weights=True, pretrain_epochs=1, _engine_factory=emu_factory)
+    assert isinstance(mt, VaDE) and mt is not mv            # model after pretrain + teacher + GMM init
+    assert (tmp_path / "models" / "vade" / "run_0" / "model_teacher_init.pth").exists()
+    assert np.isfinite(logs["train"]["total_loss"]).all()
+    assert max(logs["train"]["distill_loss"]) > 0.0          # the distillation term is live
+    assert np.isfinite(logs["val"]["alignment_score"]).all()
+    prior = mt.state_dict()["latent_space.prior"]
+    assert abs(float(prior.sum()) - 1.0) < 1e-5 and float(prior.min()) > 0  # tau*-weighted mixture weights
+    # the PCA views follow the reference's two-pass IncrementalPCA
+    ds = WindowDataset.from_preprocessed(pre_tr, "cpu")
+    pos, spd = TT.fit_nodes_pca(ds, 4, 3, batch_size=16)
+    assert tuple(pos.shape) == (48, 4) and tuple(spd.shape) == (48, 3)
+    from sklearn.decomposition import IncrementalPCA
+    X = ds.fetch(0, 48)[0][..., :2].reshape(48, -1).numpy()
+    ip = IncrementalPCA(n_components=4)
+    for s in range(0, 48, 16):
+        ip.partial_fit(X[s:s + 16])
+    np.testing.assert_allclose(pos.numpy(), ip.transform(X), atol=1e-5)
