@@ -8,9 +8,8 @@
 //                               + gamma_t relu(log K - H(mean_b tau)) + delta_t sum_k relu(floor - mean_b tau_k^2)/(floor K)
 //                               [+ rho mean_b |tau_{b+1} - tau_b|_1 on odd steps];  Adam(lr_theta) on (W, c)
 // The problem is tiny and dense (B ~ 2048 rows, d <= 64 features, K ~ 10 clusters) but the reference spends
-// 100 optimiser steps x views x ~6 torch ops per OUTER step on it.  Here one launch per head runs all M inner
-// steps inside one workgroup (weights in LDS; per step: row pass -> coefficient matrix -> deterministic
-// (cluster, feature)-parallel reduction over the rows), so an outer step is 6 launches.
+// 100 optimiser steps x views x ~6 framework ops per OUTER step on it.  Here an inner step is two short launches
+// over 256-row tiles (all views at once, features resident in L2), an outer step 4 more.
 #include <cmath>
 #include <cstring>
 
@@ -22,7 +21,6 @@ namespace {
 struct TtView {
   const float* f;   // (B, d) features of this view
   float* fn;        // (B, d) row-normalised copy (workspace)
-  float* coef;      // (B, K) inner-step coefficients (workspace)
   int d;
   int64_t task_w, task_b, head_w, head_b;  // float offsets into the parameter buffer
 };
@@ -36,6 +34,8 @@ struct TtArgs {
   float* dtau;      // (B, K)
   float* dlogit;    // (B, K)
   float* partial;   // (nblk, 2K + 4)
+  float* inner_partial;  // (views, nblk, maxel) tile partials of the inner-step gradient
+  int maxel;
   float* scal;      // cm[K], cu[K], misc
   float* logs;
   int nblk;
@@ -99,77 +99,79 @@ __device__ __forceinline__ void tt_head_logp(const float* __restrict__ H, const 
   for (int k = 0; k < K; ++k) lp[k] -= lse;
 }
 
-// All M inner SGD steps of one head (blockIdx.x = view) inside one workgroup.
-constexpr int TT_THREADS = 1024;
+// One inner SGD step of every head = two launches:
+//   k_tt_inner_grad  (grid: views x 256-row tiles)  the tile's normalised features, tau rows and the head's weights
+//                    go to LDS; a thread per row forms the soft-CE coefficients (softmax * sum tau - tau) / (T B),
+//                    then a thread per weight element reduces the tile -> partial[view][tile][element]
+//   k_tt_inner_step  (grid: views)  sums the tile partials in fixed order and applies SGD with weight decay.
+// The views' features (B x d, <= 256 KB) stay in L2 across the M steps; 2 M short launches per outer step replace
+// the reference's M x views x ~6 framework ops, and every sum has a fixed order (run-to-run reproducible).
+constexpr int TT_TILE = 256;
 constexpr int TT_MAXW = 8192;  // K * (d + 1) floats of one head
-__global__ void __launch_bounds__(TT_THREADS) k_tt_inner(TtArgs A) {
+
+__global__ void __launch_bounds__(TT_TILE) k_tt_inner_grad(TtArgs A, float* __restrict__ partial, int ntile, int maxel) {
   __shared__ float Hs[TT_MAXW];
-  __shared__ float red[TT_THREADS];
+  __shared__ float cf[TT_TILE][TT_MAXK + 1];
   const TtView w = A.v[blockIdx.x];
-  const int K = A.K, d = w.d, B = A.B, tid = threadIdx.x;
-  const int nel = K * (d + 1);  // element e: k = e / (d+1), i = e % (d+1) (i == d: bias)
-  for (int e = tid; e < nel; e += TT_THREADS) {
+  const int tile = blockIdx.y, K = A.K, d = w.d, B = A.B, tid = threadIdx.x;
+  const int nel = K * (d + 1);
+  for (int e = tid; e < nel; e += TT_TILE) {
     const int k = e / (d + 1), i = e - k * (d + 1);
     Hs[e] = i < d ? A.params[w.head_w + (int64_t)k * d + i] : A.params[w.head_b + k];
   }
   __syncthreads();
+  const int b = tile * TT_TILE + tid;
   const float inv_temp = 1.0f / A.head_temp;
-  // (element, row-chunk) decomposition of the gradient reduction
-  int nchunk = TT_THREADS / nel;
-  if (nchunk < 1) nchunk = 1;
-  if (nchunk > 16) nchunk = 16;
-  const int rows_per = (B + nchunk - 1) / nchunk;
-  for (int m = 0; m < A.inner_steps; ++m) {
-    // pass 1: coef[b][k] = (softmax_k * sum_j tau_j - tau_k) / (T * B), tau clamped to [1e-8, 1]
-    for (int b = tid; b < B; b += TT_THREADS) {
-      float lp[TT_MAXK];
-      const float* __restrict__ fn = w.fn + (int64_t)b * d;
-      float mx = -INFINITY;
-      for (int k = 0; k < K; ++k) {
-        float acc = Hs[k * (d + 1) + d];
-        const float* wr = Hs + k * (d + 1);
-        for (int i = 0; i < d; ++i) acc = fmaf(wr[i], fn[i], acc);
-        lp[k] = acc * inv_temp;
-        mx = fmaxf(mx, lp[k]);
-      }
-      float se = 0.0f, st = 0.0f;
-      for (int k = 0; k < K; ++k) {
-        lp[k] = expf(lp[k] - mx);
-        se += lp[k];
-        st += fminf(fmaxf(A.tau[(int64_t)b * K + k], 1e-8f), 1.0f);
-      }
-      const float sc = inv_temp / (float)B;
-      for (int k = 0; k < K; ++k) {
-        const float tk = fminf(fmaxf(A.tau[(int64_t)b * K + k], 1e-8f), 1.0f);
-        w.coef[(int64_t)b * K + k] = (lp[k] / se * st - tk) * sc;
-      }
+  if (b < B) {
+    float lp[TT_MAXK];
+    const float* __restrict__ fn = w.fn + (int64_t)b * d;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float acc = Hs[k * (d + 1) + d];
+      const float* wr = Hs + k * (d + 1);
+      for (int i = 0; i < d; ++i) acc = fmaf(wr[i], fn[i], acc);
+      lp[k] = acc * inv_temp;
+      mx = fmaxf(mx, lp[k]);
     }
-    __syncthreads();
-    // pass 2: g[k][i] = sum_b coef[b][k] * fn[b][i] (i == d: 1) in fixed order; SGD with weight decay
-    for (int e0 = 0; e0 < nel; e0 += TT_THREADS / nchunk) {
-      const int slot = tid / nchunk, ch = tid - slot * nchunk;
-      const int e = e0 + slot;
-      float acc = 0.0f;
-      if (slot < TT_THREADS / nchunk && e < nel) {
-        const int k = e / (d + 1), i = e - k * (d + 1);
-        const int b0 = ch * rows_per, b1 = (b0 + rows_per) < B ? (b0 + rows_per) : B;
-        for (int b = b0; b < b1; ++b)
-          acc = fmaf(w.coef[(int64_t)b * K + k], i < d ? w.fn[(int64_t)b * d + i] : 1.0f, acc);
-      }
-      red[tid] = acc;
-      __syncthreads();
-      if (ch == 0 && slot < TT_THREADS / nchunk && e < nel) {
-        float g = 0.0f;
-        for (int c = 0; c < nchunk; ++c) g += red[slot * nchunk + c];
-        Hs[e] -= A.inner_lr * (g + A.head_wd * Hs[e]);
-      }
-      __syncthreads();
+    float se = 0.0f, st = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      lp[k] = expf(lp[k] - mx);
+      se += lp[k];
+      st += fminf(fmaxf(A.tau[(int64_t)b * K + k], 1e-8f), 1.0f);
     }
+    const float sc = inv_temp / (float)B;
+    for (int k = 0; k < K; ++k) {
+      const float tk = fminf(fmaxf(A.tau[(int64_t)b * K + k], 1e-8f), 1.0f);
+      cf[tid][k] = (lp[k] / se * st - tk) * sc;
+    }
+  } else {
+    for (int k = 0; k < K; ++k) cf[tid][k] = 0.0f;
   }
-  for (int e = tid; e < nel; e += TT_THREADS) {
+  __syncthreads();
+  const int r0 = tile * TT_TILE, nr = (B - r0) < TT_TILE ? (B - r0) : TT_TILE;
+  float* __restrict__ pout = partial + ((int64_t)blockIdx.x * ntile + tile) * maxel;
+  for (int e = tid; e < nel; e += TT_TILE) {
     const int k = e / (d + 1), i = e - k * (d + 1);
-    if (i < d) A.params[w.head_w + (int64_t)k * d + i] = Hs[e];
-    else A.params[w.head_b + k] = Hs[e];
+    float acc = 0.0f;
+    if (i < d) {
+      const float* __restrict__ col = w.fn + (int64_t)r0 * d + i;
+      for (int r = 0; r < nr; ++r) acc = fmaf(cf[r][k], col[(int64_t)r * d], acc);
+    } else {
+      for (int r = 0; r < nr; ++r) acc += cf[r][k];
+    }
+    pout[e] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tt_inner_step(TtArgs A, const float* __restrict__ partial, int ntile, int maxel) {
+  const TtView w = A.v[blockIdx.x];
+  const int K = A.K, d = w.d, nel = K * (d + 1);
+  for (int e = threadIdx.x; e < nel; e += 256) {
+    float g = 0.0f;
+    for (int t = 0; t < ntile; ++t) g += partial[((int64_t)blockIdx.x * ntile + t) * maxel + e];
+    const int k = e / (d + 1), i = e - k * (d + 1);
+    float* p = i < d ? A.params + w.head_w + (int64_t)k * d + i : A.params + w.head_b + k;
+    *p -= A.inner_lr * (g + A.head_wd * *p);
   }
 }
 
@@ -302,6 +304,7 @@ __global__ void __launch_bounds__(256) k_tt_dlogit(TtArgs A) {
   for (int k = 0; k < K; ++k) A.dlogit[(int64_t)b * K + k] = tau[k] * (dt[k] - dot) * sc;
 }
 
+constexpr int TT_THREADS = 1024;
 // d W_v = dlogit^T f_v (raw features), d c_v = column sums; Adam on the task encoder of view blockIdx.x
 __global__ void __launch_bounds__(TT_THREADS) k_tt_theta(TtArgs A) {
   __shared__ float red[TT_THREADS];
@@ -359,7 +362,7 @@ int tt_check(const DofTurtleDims* D, const char* who) {
   return DOF_OK;
 }
 
-// workspace carve-up (floats): fn_v, coef_v, tau, dtau, dlogit, partial, scal
+// workspace carve-up (floats): fn_v, inner-step tile partials, tau, dtau, dlogit, partial, scal
 void tt_layout(const DofTurtleDims* D, float* ws, TtArgs* A, int64_t* total) {
   int64_t cur = 0;
   auto take = [&](int64_t n) {
@@ -369,15 +372,16 @@ void tt_layout(const DofTurtleDims* D, float* ws, TtArgs* A, int64_t* total) {
   };
   const int64_t B = D->batch, K = D->n_clusters;
   for (int v = 0; v < D->n_views; ++v) {
-    const int64_t o1 = take(B * D->view_dim[v]), o2 = take(B * K);
-    if (ws) {
-      A->v[v].fn = ws + o1;
-      A->v[v].coef = ws + o2;
-    }
+    const int64_t o1 = take(B * D->view_dim[v]);
+    if (ws) A->v[v].fn = ws + o1;
   }
   const int nblk = (int)((B + 255) / 256);
+  int64_t maxel = 0;
+  for (int v = 0; v < D->n_views; ++v) maxel = maxel > K * (D->view_dim[v] + 1) ? maxel : K * (D->view_dim[v] + 1);
+  const int64_t oi = take((int64_t)D->n_views * nblk * maxel);
   const int64_t ot = take(B * K), od = take(B * K), ol = take(B * K), op = take((int64_t)nblk * (2 * K + 4)), os = take(2 * K + 8);
   if (ws) {
+    A->inner_partial = ws + oi; A->maxel = (int)maxel;
     A->tau = ws + ot; A->dtau = ws + od; A->dlogit = ws + ol; A->partial = ws + op; A->scal = ws + os; A->nblk = nblk;
   }
   if (total) *total = cur;
@@ -440,7 +444,10 @@ extern "C" int dof_turtle_fit_step(const DofTurtleDims* dims, const DofTurtleHyp
   A.bc1 = (float)(1.0 - pow(0.9, step + 1)); A.bc2 = (float)(1.0 - pow(0.999, step + 1));
   hipStream_t st = (hipStream_t)stream;
   DOF_LAUNCH(k_tt_prepare, (dof_cdiv(A.B, 256)), (256), st, A, (int64_t)A.B, A.tau);
-  DOF_LAUNCH(k_tt_inner, ((unsigned)A.V), (TT_THREADS), st, A);
+  for (int m = 0; m < A.inner_steps; ++m) {
+    DOF_LAUNCH(k_tt_inner_grad, ((unsigned)A.V, (unsigned)A.nblk), (TT_TILE), st, A, A.inner_partial, A.nblk, A.maxel);
+    DOF_LAUNCH(k_tt_inner_step, ((unsigned)A.V), (256), st, A, (const float*)A.inner_partial, A.nblk, A.maxel);
+  }
   DOF_LAUNCH(k_tt_rows, ((unsigned)A.nblk), (256), st, A);
   DOF_LAUNCH(k_tt_scalars, (1), (64), st, A);
   DOF_LAUNCH(k_tt_dlogit, ((unsigned)A.nblk), (256), st, A);
