@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -75,7 +75,7 @@ SIGNATURES = {
     "dof_vade_loss_grads": (C.c_int, [_P] * 10 + [_I32, _P, _P, _P]),
     "dof_vqvae_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vqvae_forward": (C.c_int, [_P] * 11),
-    "dof_vqvae_loss_grads": (C.c_int, [_P] * 8),
+    "dof_vqvae_loss_grads": (C.c_int, [_P] * 9),
     "dof_optimizer_step": (C.c_int, [_P] * 7),
     "dof_turtle_param_total": (_I64, [C.POINTER(TurtleDims)]),
     "dof_turtle_param_offset": (_I64, [C.POINTER(TurtleDims), _I32, _I32, _I32]),
@@ -87,7 +87,7 @@ SIGNATURES = {
     "dof_contrastive_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_contrastive_views": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, C.POINTER(Augment), _P, _P, _P]),
     "dof_contrastive_encode": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P]),
-    "dof_contrastive_loss": (C.c_int, [_P, _P, _P, _I32, _I32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "dof_contrastive_loss": (C.c_int, [_P, _P, _P, _I32, _I32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "dof_contrastive_backward": (C.c_int, [_P, _P, _P, _P, _I32, _P]),
 }
 

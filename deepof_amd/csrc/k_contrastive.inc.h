@@ -134,6 +134,8 @@ struct ClArgs {
   float* dz;         // (B, L) d loss / d z
   float* dza;        // (B, L) d loss / d z_aug
   float* logs;       // DOF_LOG_* (total, pos_similarity, neg_similarity)
+  const float* dzh;  // (B, L) d (distillation loss) / d zn of the central view, or null
+  const float* dh_partial;  // per-block sums of the distillation loss
   int sim, loss_fn;
   float inv_T, tau, beta;
   int B, nblk;
@@ -392,6 +394,7 @@ __global__ void __launch_bounds__(256) k_cl_grad(ClArgs A) {
   for (int l = 0; l < L; ++l) {
     if (A.sim == CL_SIM_COSINE) g[l] = rx * (V[l] - sx * rx * x[l]);
     else g[l] = V[l] - sx * x[l];
+    if (!COLS && A.dzh) g[l] += A.dzh[(int64_t)i * L + l];  // distillation head acts on the normalised central view
     gz = fmaf(g[l], x[l], gz);
   }
   // backward of F.normalize: d z = (g - (g . zn) zn) / max(|z|, eps)
@@ -411,11 +414,116 @@ __global__ void __launch_bounds__(64) k_cl_finalize(ClArgs A) {
   if (lane == 0) {
     const float B = (float)A.B;
     for (int k = 0; k < DOF_LOG_COUNT; ++k) A.logs[k] = 0.0f;
-    A.logs[DOF_LOG_TOTAL] = acc[0] / B;
+    float dist = 0.0f;
+    if (A.dh_partial)
+      for (int k = 0; k < A.nblk; ++k) dist += A.dh_partial[k];
+    A.logs[DOF_LOG_DISTILL] = dist;
+    A.logs[DOF_LOG_TOTAL] = acc[0] / B + dist;
     A.logs[DOF_LOG_POS_SIM] = acc[1] / B;
     const float per_row = A.loss_fn == CL_LOSS_FC ? (float)A.fc_keep : B - 1.0f;
     A.logs[DOF_LOG_NEG_SIM] = per_row > 0.0f ? acc[2] / (B * per_row) : 0.0f;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic distillation head of the VQ-VAE / contrastive steps (training.py:344-372, 553-580):
+//   logits = W z + b ; tau_b sharpened (softmax(log tau / T)) ; optional confidence weight
+//   loss = lambda * mean_b w_b * soft-CE(logits_b, tau_b)
+// z is read through (row, column) strides so the [L][Bp] encoder output and the (B, L) normalised embeddings both fit.
+// ---------------------------------------------------------------------------------------------
+struct DistillHeadArgs {
+  const float* z;
+  int64_t zs_b, zs_l;     // element (b, l) at z[b*zs_b + l*zs_l]
+  const float* tau;       // (B, K) teacher targets of this batch
+  const float *w, *bias;  // (K, L), (K)
+  const float* hyper;     // lambda, sharpening T, confidence weighting
+  float* dl;              // (B, K) d loss / d logits
+  float* dz;              // d loss / d z, element (b, l) at dz[b*dzs_b + l*dzs_l]
+  int64_t dzs_b, dzs_l;
+  float* partial;         // per-block sums of lambda * w_b * CE_b / B
+  int K;
+  int64_t B;
+};
+
+template <int L>
+__global__ void __launch_bounds__(256) k_distill_head(DistillHeadArgs A) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float part[1] = {0.0f};
+  if (b < A.B) {
+    const int K = A.K;
+    const float lam = A.hyper[DOF_H_LAMBDA_DISTILL], T = A.hyper[DOF_H_DISTILL_T];
+    float z[L], lp[64], ts[64];
+#pragma unroll
+    for (int l = 0; l < L; ++l) z[l] = A.z[b * A.zs_b + l * A.zs_l];
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float acc = A.bias[k];
+#pragma unroll
+      for (int l = 0; l < L; ++l) acc = fmaf(A.w[k * L + l], z[l], acc);
+      lp[k] = acc;
+      mx = fmaxf(mx, acc);
+    }
+    float se = 0.0f;
+    for (int k = 0; k < K; ++k) se += expf(lp[k] - mx);
+    const float lse = mx + logf(se);
+    // sharpened targets
+    float tmx = -INFINITY, cmax = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      ts[k] = A.tau[b * K + k];
+      if (T > 0.0f) {
+        ts[k] = logf(fmaxf(ts[k], 1e-8f)) / T;
+        tmx = fmaxf(tmx, ts[k]);
+      }
+    }
+    if (T > 0.0f) {
+      float s2 = 0.0f;
+      for (int k = 0; k < K; ++k) {
+        ts[k] = expf(ts[k] - tmx);
+        s2 += ts[k];
+      }
+      for (int k = 0; k < K; ++k) ts[k] /= s2;
+    }
+    for (int k = 0; k < K; ++k) cmax = fmaxf(cmax, ts[k]);
+    float wgt = 1.0f;
+    if (A.hyper[DOF_H_CONF_W] != 0.0f) {
+      const float thr = A.hyper[DOF_H_CONF_THR];
+      wgt = fminf(fmaxf((cmax - thr) / fmaxf(1e-6f, 1.0f - thr), 0.0f), 1.0f);
+    }
+    float ce = 0.0f, st = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      const float tc = fminf(fmaxf(ts[k], 1e-8f), 1.0f);
+      ce -= tc * (lp[k] - lse);
+      st += tc;
+    }
+    const float sc = lam * wgt / (float)A.B;
+    part[0] = sc * ce;
+    float dzv[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) dzv[l] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      const float tc = fminf(fmaxf(ts[k], 1e-8f), 1.0f);
+      const float g = sc * (expf(lp[k] - lse) * st - tc);
+      A.dl[b * K + k] = g;
+#pragma unroll
+      for (int l = 0; l < L; ++l) dzv[l] = fmaf(A.w[k * L + l], g, dzv[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) A.dz[b * A.dzs_b + l * A.dzs_l] = dzv[l];
+  }
+  dof_block_colsum<1>(part, A.partial + blockIdx.x);
+}
+
+// d W[k][l] = sum_b dl[b][k] z[b][l], d bias[k] = sum_b dl[b][k]; block = cluster k, lane l (lane L = bias)
+template <int L>
+__global__ void __launch_bounds__(64) k_distill_wgrad(const float* __restrict__ dl, const float* __restrict__ z,
+                                                      int64_t zs_b, int64_t zs_l, float* __restrict__ gw,
+                                                      float* __restrict__ gb, int K, int64_t B) {
+  const int k = blockIdx.x, l = threadIdx.x;
+  if (l > L) return;
+  float acc = 0.0f;
+  for (int64_t b = 0; b < B; ++b) acc = fmaf(dl[b * K + k], l < L ? z[b * zs_b + l * zs_l] : 1.0f, acc);
+  if (l < L) gw[k * L + l] = acc;
+  else gb[k] = acc;
 }
 
 __global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ p, float v, int64_t n) {

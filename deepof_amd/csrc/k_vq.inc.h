@@ -99,12 +99,16 @@ __global__ void __launch_bounds__(256) k_vq_codebook_grad(const float* __restric
 }
 
 template <int L>
-__global__ void __launch_bounds__(256) k_vq_denc(const float* __restrict__ dzdec, float* __restrict__ denc, int64_t B,
-                                                 int64_t Bp) {
+__global__ void __launch_bounds__(256) k_vq_denc(const float* __restrict__ dzdec, const float* __restrict__ dzh,
+                                                 float* __restrict__ denc, int64_t B, int64_t Bp) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
 #pragma unroll
-  for (int l = 0; l < L; ++l) denc[(int64_t)l * Bp + b] = dzdec[(int64_t)l * Bp + b] + dzdec[(int64_t)(L + l) * Bp + b];
+  for (int l = 0; l < L; ++l) {
+    float v = dzdec[(int64_t)l * Bp + b] + dzdec[(int64_t)(L + l) * Bp + b];
+    if (dzh) v += dzh[(int64_t)l * Bp + b];  // distillation head on z_e
+    denc[(int64_t)l * Bp + b] = v;
+  }
 }
 
 struct VqLossArgs {
@@ -115,6 +119,8 @@ struct VqLossArgs {
   const float* pop;  // [K] windows per code
   const float* km;   // weighted Gram-spectrum value
   const float* hyper;
+  const float* distill_partial;  // per-block sums of the distillation term or null
+  int n_distill;
   float* logs;
   int K, L, T;
   int64_t B;
@@ -139,7 +145,11 @@ __global__ void k_vq_loss(VqLossArgs A) {
   A.logs[DOF_LOG_VQ] = vq;
   A.logs[DOF_LOG_KMEANS] = A.km[0];
   A.logs[DOF_LOG_POPULATED] = (float)populated;
-  A.logs[DOF_LOG_TOTAL] = enc_rec + rec + vq + A.km[0];
+  float dist = 0.0f;
+  if (A.distill_partial)
+    for (int i = 0; i < A.n_distill; ++i) dist += A.distill_partial[i];
+  A.logs[DOF_LOG_DISTILL] = dist;
+  A.logs[DOF_LOG_TOTAL] = enc_rec + rec + vq + A.km[0] + dist;
 }
 
 }  // namespace

@@ -153,6 +153,9 @@ struct DofVadePlan {
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
   // TCN family (encoder: all kinds; decoder: kinds 0 / 1)
   bool tcn = false;
+  int64_t dh_w = -1, dh_b = -1;          // generic distillation head distill_head.fc.{weight (K,L), bias (K)} (VQ-VAE / contrastive)
+  int64_t dh_dl = 0, dh_dz = 0, dh_partial = 0, dh_zsrc = 0;
+  bool dh_pending = false;               // contrastive: head weight gradients still to be written by the backward entry
   bool bn_training = true;  // dof_vade_set_batchnorm_training(): false = the loss/grad entries normalise with the running buffers
   int D = 0;  // CensNet input channels: 2L (recurrent blocks) or 32 (TCN features)
   TcnBlockOff dblk[4];  // decoder TCN blocks (64 filters, dilations 8,4,2,1)
@@ -187,6 +190,7 @@ void add_param(DofVadePlan* p, const std::string& name, int64_t numel, int64_t* 
 }
 
 void add_latent_params(DofVadePlan* p);
+void add_distill_head(DofVadePlan* p);
 
 void add_shaped(DofVadePlan* p, const std::string& name, std::vector<int64_t> shape, int64_t* off) {
   int64_t n = 1;
@@ -248,6 +252,7 @@ void build_tcn_param_layout(DofVadePlan* p) {
   p->seg_hi[DOF_SEG_ENCODER] = p->param_total;
   if (p->kind == 2) {
     for (int sg = DOF_SEG_DECODER; sg < DOF_SEG_COUNT; ++sg) p->seg_lo[sg] = p->seg_hi[sg] = p->param_total;
+    add_distill_head(p);
     return;
   }
   // TCNDecoderPT (models_new.py:713-771): fc0/bn0, fc1/bn1, fc2/bn2, tcn.blocks.0..3 (64 filters), prob_decoder
@@ -333,6 +338,7 @@ void build_param_layout(DofVadePlan* p) {
   p->seg_hi[DOF_SEG_ENCODER] = p->param_total;
   if (p->kind == 2) {  // contrastive: ContrastivePT owns nothing but the encoder
     for (int sg = DOF_SEG_DECODER; sg < DOF_SEG_COUNT; ++sg) p->seg_lo[sg] = p->seg_hi[sg] = p->param_total;
+    add_distill_head(p);
     return;
   }
   p->seg_lo[DOF_SEG_DECODER] = p->param_total;
@@ -351,13 +357,22 @@ void build_param_layout(DofVadePlan* p) {
   add_latent_params(p);
 }
 
+// DiscriminativeHead (teacher_model.py:795-808) of fit_VQVAE / fit_contrastive: a separate module in the reference
+// (not part of the model's state_dict) that shares the model's optimiser; here the tail of the flat buffer.
+void add_distill_head(DofVadePlan* p) {
+  p->seg_lo[DOF_SEG_HEADS] = p->param_total;
+  add_shaped(p, "distill_head.fc.weight", {p->K, p->L}, &p->dh_w);
+  add_shaped(p, "distill_head.fc.bias", {p->K}, &p->dh_b);
+  p->seg_hi[DOF_SEG_HEADS] = p->param_total;
+}
+
 void add_latent_params(DofVadePlan* p) {
   const int L = p->L, K = p->K;
   p->seg_lo[DOF_SEG_GMM] = p->param_total;
   if (p->kind == 1) {  // VQ-VAE: the codebook takes the "GMM" optimiser segment, no latent heads
     add_param(p, "vq_layer.codebook", (int64_t)L * K, &p->codebook);
     p->seg_hi[DOF_SEG_GMM] = p->param_total;
-    p->seg_lo[DOF_SEG_HEADS] = p->seg_hi[DOF_SEG_HEADS] = p->param_total;
+    add_distill_head(p);
     return;
   }
   add_param(p, "latent_space.gmm_means", (int64_t)K * L, &p->gmm_m);
@@ -611,6 +626,11 @@ void build_workspace_layout(DofVadePlan* p) {
 
 // plan-level tables: weight-gradient jobs, optimiser segments, trainable mask
 void take_tables(DofVadePlan* p, Carver& cv) {
+  if (p->dh_w >= 0) {
+    p->dh_dl = cv.take(p->B * p->K);
+    p->dh_dz = cv.take((int64_t)p->L * p->Bp + p->B * p->L);
+    p->dh_partial = cv.take(p->lat_blocks);
+  }
   for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
     js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
     js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
@@ -1740,7 +1760,7 @@ extern "C" int dof_vqvae_forward(DofVadePlan* p, const float* params, const floa
 }
 
 extern "C" int dof_vqvae_loss_grads(DofVadePlan* p, const float* params, const float* x, const float* a,
-                                    const float* hyper, float* grads, float* logs, void* stream) {
+                                    const float* tau, const float* hyper, float* grads, float* logs, void* stream) {
   if (!p || !p->ws || p->kind != 1) {
     dof_set_error("dof_vqvae_loss_grads: plan not bound to a workspace (or not a VQ-VAE plan)");
     return DOF_ERR_STATE;
@@ -1767,12 +1787,25 @@ extern "C" int dof_vqvae_loss_grads(DofVadePlan* p, const float* params, const f
   // pass 2: decode the RAW encoder output -> decoder grads (accumulate) + gradient into the encoder
   TRY(decoder_forward(p, params, x, ws + p->enc, ws + p->recon_partial2, true, nullptr, st));
   TRY(decoder_backward(p, params, 1, grads, 1, st));
-  LDISPATCH(L, DOF_LAUNCH((k_vq_denc<LL>), (dof_cdiv(B, 256)), (256), st, (const float*)(ws + p->dzdec), ws + p->denc, B, Bp));
+  const float* dzh = nullptr;
+  if (tau) {  // generic distillation head on z_e (training.py:344-372)
+    DistillHeadArgs DH;
+    DH.z = ws + p->enc; DH.zs_b = 1; DH.zs_l = Bp; DH.tau = tau; DH.w = params + p->dh_w; DH.bias = params + p->dh_b;
+    DH.hyper = hyper; DH.dl = ws + p->dh_dl; DH.dz = ws + p->dh_dz; DH.dzs_b = 1; DH.dzs_l = Bp;
+    DH.partial = ws + p->dh_partial; DH.K = K; DH.B = B;
+    LDISPATCH(L, DOF_LAUNCH((k_distill_head<LL>), ((unsigned)p->lat_blocks), (256), st, DH));
+    LDISPATCH(L, DOF_LAUNCH((k_distill_wgrad<LL>), ((unsigned)K), (64), st, (const float*)(ws + p->dh_dl),
+                            (const float*)(ws + p->enc), (int64_t)1, Bp, grads + p->dh_w, grads + p->dh_b, K, B));
+    TRY(dof_check_launch("k_distill_head"));
+    dzh = ws + p->dh_dz;
+  }
+  LDISPATCH(L, DOF_LAUNCH((k_vq_denc<LL>), (dof_cdiv(B, 256)), (256), st, (const float*)(ws + p->dzdec), dzh, ws + p->denc, B, Bp));
   TRY(final_dense_bwd(p, params, st));
   VqLossArgs VL;
   VL.recon_q = ws + p->recon_partial; VL.recon_e = ws + p->recon_partial2; VL.n_recon = (int)p->tail_blocks;
   VL.sq_partial = ws + p->vq_partial; VL.n_sq = (int)p->lat_blocks; VL.pop = ws + p->vq_pop; VL.km = ws + p->km;
   VL.hyper = hyper; VL.logs = logs; VL.K = K; VL.L = L; VL.T = p->T; VL.B = B;
+  VL.distill_partial = tau ? ws + p->dh_partial : nullptr; VL.n_distill = (int)p->lat_blocks;
   DOF_LAUNCH(k_vq_loss, (1), (64), st, VL);
   TRY(dof_check_launch("k_vq_loss"));
   return encoder_backward(p, params, grads, st);
@@ -1884,8 +1917,9 @@ extern "C" int dof_contrastive_encode(DofVadePlan* p, const float* params, const
 }
 
 extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float* z_aug, int32_t similarity,
-                                    int32_t loss_fn, float temperature, float tau, float beta, float* dz,
-                                    float* dz_aug, float* logs, void* stream) {
+                                    int32_t loss_fn, float temperature, float tau, float beta, const float* params,
+                                    const float* teacher_tau, const float* hyper, float* dz, float* dz_aug,
+                                    float* logs, void* stream) {
   if (!p || !p->ws || p->kind != 2) {
     dof_set_error("dof_contrastive_loss: plan not bound to a workspace (or not a contrastive plan)");
     return DOF_ERR_STATE;
@@ -1924,6 +1958,24 @@ extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float*
   if (loss_fn == DOF_CLOSS_FC) LDISPATCH(p->L, DOF_LAUNCH((k_cl_fc_threshold<LL>), ((unsigned)A.nblk), (256), st, A));
   LDISPATCH(p->L, DOF_LAUNCH((k_cl_rowstats<LL>), ((unsigned)A.nblk), (256), st, A));
   TRY(dof_check_launch("k_cl_rowstats"));
+  A.dzh = nullptr;
+  A.dh_partial = nullptr;
+  p->dh_pending = false;
+  if (teacher_tau) {  // generic distillation head on the normalised central embeddings (training.py:553-580)
+    if (!params || !hyper) {
+      dof_set_error("dof_contrastive_loss: distillation needs params and hyper");
+      return DOF_ERR_ARG;
+    }
+    DistillHeadArgs DH;
+    DH.z = A.zn; DH.zs_b = p->L; DH.zs_l = 1; DH.tau = teacher_tau; DH.w = params + p->dh_w; DH.bias = params + p->dh_b;
+    DH.hyper = hyper; DH.dl = ws + p->dh_dl; DH.dz = ws + p->dh_dz; DH.dzs_b = p->L; DH.dzs_l = 1;
+    DH.partial = ws + p->dh_partial; DH.K = p->K; DH.B = p->B;
+    LDISPATCH(p->L, DOF_LAUNCH((k_distill_head<LL>), ((unsigned)p->lat_blocks), (256), st, DH));
+    TRY(dof_check_launch("k_distill_head"));
+    A.dzh = ws + p->dh_dz;
+    A.dh_partial = ws + p->dh_partial;
+    p->dh_pending = dz != nullptr;  // the head's weight gradients are written by this plan's backward call
+  }
   if (dz) {
     LDISPATCH(p->L, DOF_LAUNCH((k_cl_grad<LL, false>), ((unsigned)A.nblk), (256), st, A));
     LDISPATCH(p->L, DOF_LAUNCH((k_cl_grad<LL, true>), ((unsigned)A.nblk), (256), st, A));
@@ -1945,6 +1997,13 @@ extern "C" int dof_contrastive_backward(DofVadePlan* p, const float* params, con
   hipStream_t st = (hipStream_t)stream;
   float* ws = p->ws;
   if (!accumulate) TRY(dof_launch_zero(grads, p->param_total, st));
+  if (p->dh_pending) {
+    p->dh_pending = false;
+    LDISPATCH(p->L, DOF_LAUNCH((k_distill_wgrad<LL>), ((unsigned)p->K), (64), st, (const float*)(ws + p->dh_dl),
+                               (const float*)(ws + p->cl_zn), (int64_t)p->L, (int64_t)1, grads + p->dh_w, grads + p->dh_b,
+                               p->K, p->B));
+    TRY(dof_check_launch("k_distill_wgrad"));
+  }
   LDISPATCH(p->L, DOF_LAUNCH((k_cl_import<LL>), (dof_cdiv(p->B, 256)), (256), st, dz, ws + p->denc, p->B, p->Bp));
   TRY(final_dense_bwd(p, params, st));
   return encoder_backward(p, params, grads, st, accumulate ? 1 : 0);

@@ -121,6 +121,12 @@ class VadeEngine:
         self.teacher = torch.zeros(2 * self.K, **f32)
         self.adam_t = [0] * _capi.SEG_COUNT
         self.set_hyper(logvar_lo=-8.0, logvar_hi=8.0, clip=0.75, wd=0.0, l1_act=0.1, distill_T=0.5)
+        if "distill_head.fc.weight" in self.layout:  # DiscriminativeHead = nn.Linear(L, K) default init
+            bound = 1.0 / math.sqrt(self.L)
+            g = torch.Generator().manual_seed(0)  # own stream: the model's initialisation draws stay what they were
+            for nm in ("distill_head.fc.weight", "distill_head.fc.bias"):
+                v = self.view(nm)
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * bound)
         for s in range(_capi.SEG_COUNT):
             self.hyper_host[_capi.H_ACTIVE0 + s] = 1.0
             self.hyper_host[_capi.H_BC0 + 2 * s] = 1.0 - 0.9      # t = 1 until advance_adam() is called
@@ -154,6 +160,8 @@ class VadeEngine:
               "encoder.edge_laplacian": torch.from_numpy(self.elap.copy()),
               "encoder.incidence": torch.from_numpy(self.inc.copy())}
         for n in self.names:
+            if n.startswith("distill_head."):  # a separate module in the reference, not part of the model
+                continue
             if n == "latent_space.encoder_mean.weight":
                 sd["latent_space.prior"] = self.prior.detach().cpu().clone()
                 sd["latent_space.pretrain"] = torch.tensor(0.0)
@@ -167,7 +175,7 @@ class VadeEngine:
         for n in self.names:
             if n in sd:
                 self.view(n).copy_(torch.as_tensor(sd[n], dtype=torch.float32).reshape(self.layout[n][2]))
-            elif strict:
+            elif strict and not n.startswith("distill_head."):
                 raise KeyError(f"missing parameter {n}")
         if "latent_space.prior" in sd:
             self.prior.copy_(torch.as_tensor(sd["latent_space.prior"], dtype=torch.float32))
@@ -295,12 +303,15 @@ class VadeEngine:
         _capi.check(self.lib, rc, "dof_vqvae_forward")
         return out
 
-    def vq_loss_grads(self, x, a):
-        """step_vqvae_distill (without distillation head) + backward; fills self.grads / self.logs."""
+    def vq_loss_grads(self, x, a, tau: Optional[torch.Tensor] = None):
+        """step_vqvae_distill + backward; fills self.grads / self.logs.  tau (B,K): teacher targets of the batch -> the
+        distillation head term with hyper lambda_distill / distill_T / conf_w / conf_thr."""
         self._chk_batch(x, a)
+        if tau is not None:
+            assert tuple(tau.shape) == (self.B, self.K) and tau.is_contiguous()
         rc = self.lib.dof_vqvae_loss_grads(self.plan, self.params.data_ptr(), x.data_ptr(), a.data_ptr(),
-                                           self.hyper.data_ptr(), self.grads.data_ptr(), self.logs.data_ptr(),
-                                           self._stream())
+                                           None if tau is None else tau.data_ptr(), self.hyper.data_ptr(),
+                                           self.grads.data_ptr(), self.logs.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_vqvae_loss_grads")
         self._count_bn("encoder.", 1)
         self._count_bn("decoder.", 2)   # the decoder runs on the quantised and on the raw latents
@@ -324,8 +335,9 @@ class VadeEngine:
         return z
 
     def contrastive_loss(self, z, z_aug, similarity="cosine", loss_fn="nce", temperature=0.1, tau=0.1, beta=0.1,
-                         want_grads: bool = True):
-        """Normalise + pairwise loss; fills self.logs, returns (dz, dz_aug) or (None, None)."""
+                         want_grads: bool = True, teacher_tau: Optional[torch.Tensor] = None):
+        """Normalise + pairwise loss [+ distillation head on the normalised central embeddings when teacher_tau (B,K)
+        is given]; fills self.logs, returns (dz, dz_aug) or (None, None)."""
         if loss_fn not in _capi.CONTRASTIVE_LOSSES:
             raise NotImplementedError(f"contrastive loss {loss_fn!r} is not built (available: "
                                       f"{sorted(_capi.CONTRASTIVE_LOSSES)})")
@@ -335,7 +347,9 @@ class VadeEngine:
         dza = torch.empty_like(z) if want_grads else None
         rc = self.lib.dof_contrastive_loss(self.plan, z.data_ptr(), z_aug.data_ptr(), _capi.SIMILARITIES[similarity],
                                            _capi.CONTRASTIVE_LOSSES[loss_fn], float(temperature), float(tau),
-                                           float(beta), dz.data_ptr() if want_grads else None,
+                                           float(beta), self.params.data_ptr(),
+                                           None if teacher_tau is None else teacher_tau.data_ptr(), self.hyper.data_ptr(),
+                                           dz.data_ptr() if want_grads else None,
                                            dza.data_ptr() if want_grads else None, self.logs.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_contrastive_loss")
         return dz, dza
@@ -349,7 +363,7 @@ class VadeEngine:
     def read_contrastive_logs(self) -> Dict[str, float]:
         v = self.logs.detach().cpu().tolist()
         return {"total_loss": v[0], "pos_similarity": v[_capi.LOG_POS_SIM], "neg_similarity": v[_capi.LOG_NEG_SIM],
-                "distill_loss": 0.0, "seperability": 0.0}
+                "distill_loss": v[7], "seperability": 0.0}
 
     def advance_adam(self):
         """Bump the per-segment Adam step counters (bias corrections live in hyper[])."""

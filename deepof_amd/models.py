@@ -63,6 +63,8 @@ def _attach_all(model: nn.Module, eng: VadeEngine, extra=None):
     """Register the engine's tensors on the module tree under the reference names: parameters, BatchNorm running
     buffers (views of the flat buffer) and their int64 step counters (shared with the engine), in state_dict order."""
     for name in eng.names:
+        if name.startswith("distill_head."):  # the reference's DiscriminativeHead is not part of the model
+            continue
         if extra is not None:
             extra(name)
         _attach(model, name, eng.view(name), buffer=".running_" in name)
@@ -404,7 +406,8 @@ class Contrastive(VaDE):
     def __init__(self, input_shape, edge_feature_shape, adjacency_matrix, latent_dim: int = 8,
                  encoder_type: str = "recurrent", use_gnn: bool = True, temperature: float = 0.1,
                  similarity_function: str = "cosine", loss_function: str = "nce", beta: float = 0.1, tau: float = 0.1,
-                 interaction_regularization: float = 0.0, batch_size: int = 256, device=None, _engine_factory=None):
+                 interaction_regularization: float = 0.0, batch_size: int = 256, device=None, _engine_factory=None,
+                 n_components: int = 1):
         nn.Module.__init__(self)
         self._tcn = _encoder_family(encoder_type)
         self._KIND = "contrastive_tcn" if self._tcn else "contrastive"
@@ -417,7 +420,7 @@ class Contrastive(VaDE):
         self.window_size = time_steps // 2  # the encoder sees half windows (room for the time-shift augmentation)
         self.input_shape, self.edge_feature_shape = tuple(input_shape), tuple(edge_feature_shape)
         self.input_n_nodes, self.input_n_features_per_node = n_nodes, n_feat
-        self.latent_dim, self.n_components = int(latent_dim), 1
+        self.latent_dim, self.n_components = int(latent_dim), max(1, int(n_components))  # K of the distillation head
         self.encoder_type, self.use_gnn = ("TCN" if self._KIND == "contrastive_tcn" else "recurrent"), True
         self.temperature, self.similarity_function, self.loss_function = float(temperature), similarity_function, loss_function
         self.beta, self.tau = float(beta), float(tau)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 6
+#define DOF_ABI_VERSION 7
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -161,8 +161,11 @@ int dof_vqvae_plan_create(const DofVadeDims* dims, const float* laplacian, const
 int dof_vqvae_forward(DofVadePlan* plan, const float* params, const float* x, const float* a, float* ze_out,
                       float* quant_out, float* soft_out, int32_t* idx_out, float* loc_q_out, float* loc_e_out,
                       void* stream);
-int dof_vqvae_loss_grads(DofVadePlan* plan, const float* params, const float* x, const float* a, const float* hyper,
-                         float* grads, float* logs, void* stream);
+/* tau (B,K): teacher targets of this batch or NULL.  With tau the generic distillation head (the last two entries of
+ * the parameter buffer, distill_head.fc.{weight (K,L), bias (K)} = the reference's DiscriminativeHead, which shares
+ * the model's optimiser) adds hyper[DOF_H_LAMBDA_DISTILL] * soft-CE(head(z_e), sharpened tau) (training.py:344-372). */
+int dof_vqvae_loss_grads(DofVadePlan* plan, const float* params, const float* x, const float* a, const float* tau,
+                         const float* hyper, float* grads, float* logs, void* stream);
 
 /* ---- Contrastive (recurrent encoder on half windows, two views per window) -----------------------
  * Plan: dims.window = the HALF window the encoder sees (full window // 2); dims.n_clusters /
@@ -210,9 +213,12 @@ enum { DOF_CLOSS_NCE = 0, DOF_CLOSS_DCL = 1, DOF_CLOSS_HARD_DCL = 2, DOF_CLOSS_F
 /* Row-normalises z / z_aug (B, L), evaluates the loss over all B x B pairs, writes d loss / d z and
  * d loss / d z_aug (B, L; either may be NULL together = value only) and logs[DOF_LOG_TOTAL |
  * DOF_LOG_POS_SIM | DOF_LOG_NEG_SIM].  Scratch comes from the plan's workspace. */
+/* teacher_tau (B,K) or NULL: as for the VQ-VAE, the distillation head acts on the NORMALISED central embeddings
+ * (training.py:553-580); it needs params (head weights) and hyper (lambda, sharpening, confidence weighting), its
+ * weight gradients are written by the following dof_contrastive_backward(plan, ..., accumulate = 0). */
 int dof_contrastive_loss(DofVadePlan* plan, const float* z, const float* z_aug, int32_t similarity, int32_t loss_fn,
-                         float temperature, float tau, float beta, float* dz, float* dz_aug, float* logs,
-                         void* stream);
+                         float temperature, float tau, float beta, const float* params, const float* teacher_tau,
+                         const float* hyper, float* dz, float* dz_aug, float* logs, void* stream);
 
 /* Backward of the plan's last dof_contrastive_encode(train) from dz (B, L): encoder gradients into
  * grads (accumulate == 0: overwritten, else added -- the second view accumulates onto the first). */

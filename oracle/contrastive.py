@@ -199,7 +199,7 @@ def encode(P, x, a, training=True):
 
 
 def contrastive_step(P, x_full, edge_index, draws: AugDraws, sim_kind="cosine", loss_fn="nce", temperature=0.1,
-                     tau=0.1, beta=0.1, training=True):
+                     tau=0.1, beta=0.1, training=True, distill=None):
     """training.py:482-589 without the distillation head.  Returns (total, logs, aux)."""
     x_aug, a_aug = augmented_view(x_full, edge_index, draws)
     x, a = central_view(x_full, edge_index)
@@ -207,14 +207,19 @@ def contrastive_step(P, x_full, edge_index, draws: AugDraws, sim_kind="cosine", 
     z_aug = encode(P, x_aug, a_aug, training)
     zn, zan = F.normalize(z, dim=1), F.normalize(z_aug, dim=1)
     loss, pos, neg = contrastive_loss(zn, zan, sim_kind, loss_fn, temperature, tau, beta)
+    dist = 0.0
+    if distill is not None:  # head on the NORMALISED central embeddings (training.py:553-580)
+        from .vqvae import distill_term
+        dist = distill_term(zn, P["distill_head.fc.weight"], P["distill_head.fc.bias"], **distill)
+        loss = loss + dist
     logs = {"total_loss": float(loss), "pos_similarity": float(pos), "neg_similarity": float(neg),
-            "distill_loss": 0.0}
+            "distill_loss": float(dist)}
     return loss, logs, {"x": x, "a": a, "x_aug": x_aug, "a_aug": a_aug, "z": z, "z_aug": z_aug}
 
 
 def contrastive_grads(P, x_full, edge_index, draws, **kw):
     buffers = ("laplacian", "edge_laplacian", "incidence", "running_mean", "running_var", "num_batches_tracked")
-    leaves = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and k.startswith("encoder.") and
+    leaves = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and (k.startswith("encoder.") or k.startswith("distill_head.")) and
                                                    k.split(".")[-1] not in buffers)
               for k, v in P.items()}
     loss, logs, aux = contrastive_step(leaves, x_full, edge_index, draws, **kw)

@@ -55,24 +55,43 @@ def vqvae_forward(P: Params, x: torch.Tensor, a: torch.Tensor, beta: float = 1.0
     return vq
 
 
-def vqvae_loss(out: dict, x: torch.Tensor):
+def distill_term(z, W, b, tau_b, lam: float, T: float = 0.5, conf_weight: bool = False, thr: float = 0.6):
+    """Generic distillation head term of step_vqvae_distill / step_contrastive_distill (training.py:344-372, 553-580):
+    lam * mean_b w_b * soft-CE(W z_b + b, sharpened tau_b)."""
+    logits = torch.nn.functional.linear(z, W, b)
+    if T > 0.0:
+        tau_b = torch.softmax(tau_b.clamp_min(1e-8).log() / T, dim=-1)
+    per = -(torch.clamp(tau_b, min=1e-8, max=1.0) * torch.nn.functional.log_softmax(logits, dim=-1)).sum(dim=-1)
+    if conf_weight:
+        w = ((tau_b.max(dim=1).values - thr) / max(1e-6, 1.0 - thr)).clamp(0.0, 1.0).detach()
+        return lam * (w * per).mean()
+    return lam * per.mean()
+
+
+def vqvae_loss(out: dict, x: torch.Tensor, distill=None):
     B, T = x.shape[:2]
     x_flat = x.reshape(B, T, -1).float()
     enc_rec = -(OV.recon_log_prob(out["loc_q"], out["valid"], x_flat)).mean()
     rec = -(OV.recon_log_prob(out["loc_e"], out["valid"], x_flat)).mean()
     const = float(out["vq_loss"]) + float(out["kmeans_loss"])
-    total = enc_rec + rec + const
+    dist = torch.zeros(())
+    if distill is not None:
+        dist = distill_term(out["ze"], **distill)
+    total = enc_rec + rec + const + dist
     populated = float(out["soft_counts"].argmax(dim=-1).unique().numel())
     return dict(total_loss=total, enc_rec_loss=enc_rec, reconstruct_loss=rec, vq_loss=float(out["vq_loss"]),
                 kmeans_loss=float(out["kmeans_loss"]), number_of_populated_clusters=populated,
-                distill_loss=torch.zeros(()))
+                distill_loss=dist)
 
 
-def vqvae_grads(P: Params, x, a, beta: float = 1.0, kmeans_weight: float = 0.0):
+def vqvae_grads(P: Params, x, a, beta: float = 1.0, kmeans_weight: float = 0.0, distill=None):
+    """distill: dict(tau_b, lam, T, conf_weight, thr) -- the head weights are P["distill_head.fc.weight" / ".bias"]."""
     keys = OV.trainable_keys(P)
     leaf = {k: (P[k].detach().clone().requires_grad_(True) if k in keys else P[k]) for k in P}
     out = vqvae_forward(leaf, x, a, beta, kmeans_weight)
-    losses = vqvae_loss(out, x)
+    if distill is not None:
+        distill = dict(distill, W=leaf["distill_head.fc.weight"], b=leaf["distill_head.fc.bias"])
+    losses = vqvae_loss(out, x, distill)
     gl = torch.autograd.grad(losses["total_loss"], [leaf[k] for k in keys], allow_unused=True)
     return losses, dict(zip(keys, gl)), out
 

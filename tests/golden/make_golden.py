@@ -291,6 +291,25 @@ def gen_vqvae(tag, ids, T, L, K, B, seed, kmeans=0.0):
         for k, v in r.logs.items():
             out[f"step{i}::log::{k}"] = np.float64(v)
     out.update(sd_np(model, "sd_final::"))
+    if tag == "rec28":
+        # distillation head (teacher_model.py:795-808) inside step_vqvae_distill, on the trained weights above
+        import deepof.clustering.teacher_model as TM
+        torch.manual_seed(seed + 77)
+        head = TM.DiscriminativeHead(L, K)
+        tau = torch.softmax(torch.randn(B, K) * 1.5, dim=-1)
+        ctx = SimpleNamespace(apply_distill=True, distill_head=head, tau_star=tau, distill_sharpen_T=0.5,
+                              distill_conf_weight=True, distill_conf_thresh=0.2,
+                              lambda_scheduler=SimpleNamespace(get_weight=lambda: 1.3))
+        model.zero_grad(set_to_none=True)
+        r = R.T.step_vqvae_distill(model, (xt, at, torch.arange(B)), ctx)
+        r.loss.backward()
+        out["dist::tau"] = tau.numpy()
+        out.update(sd_np(head, "dist::head::"))
+        for k, v in r.logs.items():
+            out[f"dist::log::{k}"] = np.float64(v)
+        for n, p in list(model.named_parameters()) + [("distill_head." + n, p) for n, p in head.named_parameters()]:
+            if p.grad is not None:
+                out[f"dist::grad::{n}"] = p.grad.numpy().copy()
     np.savez_compressed(os.path.join(HERE, f"vqvae_{tag}.npz"), **out)
 
 
@@ -469,6 +488,35 @@ def gen_contrastive(tag, ids, T_full, L, B, seed, encoder_type="recurrent", case
         for n, p_ in model.named_parameters():
             if p_.grad is not None:
                 out[pfx + f"grad::{n}"] = p_.grad.numpy().copy()
+        if encoder_type == "recurrent" and tag == "rec28" and ci == 0:
+            # same step with the distillation head on (replaying the same draws)
+            import deepof.clustering.teacher_model as TM
+            torch.manual_seed(seed + 99)
+            Kd = 5
+            head = TM.DiscriminativeHead(L, Kd)
+            tau = torch.softmax(torch.randn(B, Kd) * 1.5, dim=-1)
+            ctx2 = SimpleNamespace(apply_distill=True, edge_index=ei_g, edge_index_local=ei_l, contrastive_cfg=ccfg,
+                                   rot_precomp=pre, distill_head=head, tau_star=tau, distill_sharpen_T=0.5,
+                                   distill_conf_weight=True, distill_conf_thresh=0.2,
+                                   lambda_scheduler=SimpleNamespace(get_weight=lambda: 0.9))
+            model.zero_grad(set_to_none=True)
+            it2 = iter([v for _, v in calls])
+            orig2 = {n: getattr(torch, n) for n in ("rand", "randint", "randn", "randperm")}
+            try:
+                for n in orig2:
+                    setattr(torch, n, lambda *a, **k: next(it2).clone())
+                r2 = R.T.step_contrastive_distill(model, (xt, a_dummy, torch.arange(B)), ctx2)
+            finally:
+                for n, fn in orig2.items():
+                    setattr(torch, n, fn)
+            r2.loss.backward()
+            out["dist::tau"] = tau.numpy()
+            out.update(sd_np(head, "dist::head::"))
+            for k, v in r2.logs.items():
+                out[f"dist::log::{k}"] = np.float64(v)
+            for n, p_ in list(model.named_parameters()) + [("distill_head." + n, p_) for n, p_ in head.named_parameters()]:
+                if p_.grad is not None:
+                    out[f"dist::grad::{n}"] = p_.grad.numpy().copy()
         if encoder_type != "recurrent":
             # finish optimiser step 1 on the recorded gradients, then one more full step (draws recorded again)
             torch.nn.utils.clip_grad_value_(model.parameters(), 0.75)

@@ -258,7 +258,8 @@ def run_contrastive_check(lib, device, golden_dir, tag):
         e1 = VadeEngine(lib, device, B, half, d["adj"], L, 1, kind="contrastive")
         e2 = VadeEngine(lib, device, B, half, d["adj"], L, 1, kind="contrastive", shared=e1)
         e1.load_state_dict(params_from(d, pfx + "sd::"))
-        assert e1.names[0].startswith("encoder.") and all(n.startswith("encoder.") for n in e1.names)
+        assert all(n.startswith("encoder.") or n.startswith("distill_head.") for n in e1.names)
+        assert all(n.startswith("encoder.") for n in e1.state_dict() if "." in n)
         z = e1.contrastive_encode(xc, ac, train=True)
         z_aug = e2.contrastive_encode(xa, aa, train=True)
         np.testing.assert_allclose(z.cpu().numpy(), d[pfx + "z"], atol=1e-5, rtol=1e-4)
@@ -279,7 +280,7 @@ def run_contrastive_check(lib, device, golden_dir, tag):
         assert n >= 40
         for name in e1.names:
             if pfx + f"grad::{name}" not in d:
-                assert float(e1.view(name, e1.grads).abs().max()) == 0.0, name
+                assert float(e1.view(name, e1.grads).abs().max()) == 0.0, name   # incl. the unused distillation head
 
 
 def run_contrastive_tcn_check(lib, device, golden_dir):
@@ -512,3 +513,61 @@ def run_turtle_check(lib, device, golden_dir):
     np.testing.assert_allclose(m.numpy(), d["gmm_means"], atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(lv.numpy(), d["gmm_log_vars"], atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(pr.numpy(), d["gmm_prior"], atol=1e-6, rtol=1e-5)
+
+
+def run_distill_head_check(lib, device, golden_dir):
+    """Generic distillation head (VQ-VAE on z_e, contrastive on the normalised central embeddings) vs the reference."""
+    from deepof_amd.engine import VadeEngine, contrastive_views
+    # ---- VQ-VAE
+    d = load_golden(golden_dir, "vqvae_rec28.npz")
+    x, a = torch.from_numpy(d["x"]).to(device), torch.from_numpy(d["a"]).to(device)
+    B, T, N, _ = x.shape
+    L, K = d["sd::vq_layer.codebook"].shape
+    eng = VadeEngine(lib, device, B, T, d["adj"], L, K, kind="vqvae")
+    sd = params_from(d, "sd_final::")
+    sd.update({"distill_head." + k: v for k, v in params_from(d, "dist::head::").items()})
+    eng.load_state_dict(sd)
+    km = float(d["kmeans"])
+    eng.set_hyper(vq_beta=1.0, km_latent=km, km_loss=1.0 if km else 0.0, clip=0.75, wd=1e-4, lambda_distill=1.3,
+                  distill_T=0.5, conf_w=1.0, conf_thr=0.2)
+    eng.push_hyper()
+    eng.vq_loss_grads(x, a, torch.from_numpy(d["dist::tau"]).to(device))
+    logs = eng.read_vq_logs()
+    for k in ("total_loss", "distill_loss", "reconstruct_loss", "enc_rec_loss"):
+        np.testing.assert_allclose(logs[k], float(d[f"dist::log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=k)
+    for k in d:
+        if k.startswith("dist::grad::"):
+            g = eng.view(k[12:], eng.grads).cpu().numpy()
+            np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=5e-5, rtol=5e-4, err_msg=k)
+    # ---- contrastive
+    d = load_golden(golden_dir, "contrastive_rec28.npz")
+    pfx = "c0::"
+    x_full = torch.from_numpy(d["x_full"]).to(device)
+    ei = torch.from_numpy(d["edge_index"]).to(device)
+    B, Tf, N, _ = x_full.shape
+    L = d[pfx + "sd::encoder.final_dense.bias"].shape[0]
+    Kd = d["dist::tau"].shape[1]
+    e1 = VadeEngine(lib, device, B, Tf // 2, d["adj"], L, Kd, kind="contrastive")
+    e2 = VadeEngine(lib, device, B, Tf // 2, d["adj"], L, Kd, kind="contrastive", shared=e1)
+    sd = params_from(d, pfx + "sd::")
+    sd.update({"distill_head." + k: v for k, v in params_from(d, "dist::head::").items()})
+    e1.load_state_dict(sd)
+    e1.set_hyper(lambda_distill=0.9, distill_T=0.5, conf_w=1.0, conf_thr=0.2)
+    e1.push_hyper()
+    xc, ac = contrastive_views(lib, x_full, ei, None)
+    xa, aa = contrastive_views(lib, x_full, ei, aug_from_golden(d, pfx, device))
+    z, z_aug = e1.contrastive_encode(xc, ac, train=True), e2.contrastive_encode(xa, aa, train=True)
+    dz, dza = e1.contrastive_loss(z, z_aug, str(d[pfx + "sim"]), str(d[pfx + "loss_fn"]), 0.1, 0.1, 0.1,
+                                  teacher_tau=torch.from_numpy(d["dist::tau"]).to(device))
+    logs = e1.read_contrastive_logs()
+    for k in ("total_loss", "distill_loss", "pos_similarity", "neg_similarity"):
+        np.testing.assert_allclose(logs[k], float(d[f"dist::log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=k)
+    e1.contrastive_backward(dz, accumulate=False)
+    e2.contrastive_backward(dza, accumulate=True)
+    n = 0
+    for k in d:
+        if k.startswith("dist::grad::"):
+            g = e1.view(k[12:], e1.grads).cpu().numpy()
+            np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=5e-5, rtol=1e-3, err_msg=k)
+            n += 1
+    assert n >= 42

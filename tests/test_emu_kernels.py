@@ -73,3 +73,8 @@ def test_vqvae_tcn_emu(golden_dir):
 def test_turtle_teacher_emu(golden_dir):
     from parity_common import run_turtle_check
     run_turtle_check(emu_lib(), "cpu", golden_dir)
+
+
+def test_distillation_head_emu(golden_dir):
+    from parity_common import run_distill_head_check
+    run_distill_head_check(emu_lib(), "cpu", golden_dir)

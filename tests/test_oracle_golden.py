@@ -387,3 +387,34 @@ def test_turtle_teacher_matches_reference(golden_dir):
     np.testing.assert_allclose(m.numpy(), d["gmm_means"], atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(lv.numpy(), d["gmm_log_vars"], atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(pr.numpy(), d["gmm_prior"], atol=1e-6, rtol=1e-5)
+
+
+def test_distillation_head_matches_reference(golden_dir):
+    """Generic distillation head (DiscriminativeHead) inside the VQ-VAE and the contrastive step: logged terms and
+    every gradient incl. the head's own."""
+    from oracle import vqvae as OQ
+    from oracle import contrastive as OC
+    d = _load(golden_dir, "vqvae_rec28.npz")
+    P = _params(d, "sd_final::")
+    P.update({"distill_head." + k: v for k, v in _params(d, "dist::head::").items()})
+    x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
+    dist = dict(tau_b=torch.from_numpy(d["dist::tau"]), lam=1.3, T=0.5, conf_weight=True, thr=0.2)
+    losses, grads, _ = OQ.vqvae_grads(P, x, a, 1.0, float(d["kmeans"]), distill=dist)
+    for k in ("total_loss", "distill_loss", "reconstruct_loss", "enc_rec_loss"):
+        np.testing.assert_allclose(float(losses[k]), float(d[f"dist::log::{k}"]), rtol=2e-5, atol=2e-6, err_msg=k)
+    for k in d:
+        if k.startswith("dist::grad::"):
+            np.testing.assert_allclose(grads[k[12:]].numpy(), d[k], atol=2e-5, rtol=3e-4, err_msg=k)
+    d = _load(golden_dir, "contrastive_rec28.npz")
+    pfx = "c0::"
+    P = _params(d, pfx + "sd::")
+    P.update({"distill_head." + k: v for k, v in _params(d, "dist::head::").items()})
+    dist = dict(tau_b=torch.from_numpy(d["dist::tau"]), lam=0.9, T=0.5, conf_weight=True, thr=0.2)
+    logs, grads, _ = OC.contrastive_grads(P, torch.from_numpy(d["x_full"]), torch.from_numpy(d["edge_index"]).long(),
+                                          _aug_draws(d, pfx), sim_kind=str(d[pfx + "sim"]), loss_fn=str(d[pfx + "loss_fn"]),
+                                          distill=dist)
+    for k in ("total_loss", "distill_loss", "pos_similarity"):
+        np.testing.assert_allclose(logs[k], float(d[f"dist::log::{k}"]), rtol=2e-5, atol=2e-6, err_msg=k)
+    for k in d:
+        if k.startswith("dist::grad::"):
+            np.testing.assert_allclose(grads[k[12:]].numpy(), d[k], atol=2e-5, rtol=3e-4, err_msg=k)
