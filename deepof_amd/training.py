@@ -115,6 +115,7 @@ def build_model_from_spec(spec: dict, device=None, batch_size: int = 256, _engin
     if name == "contrastive":
         return Contrastive(tuple(spec["x_shape"]), tuple(spec["a_shape"]), np.asarray(spec["adjacency_matrix"]),
                            int(spec["latent_dim"]), encoder_type=spec.get("encoder_type", "TCN"),
+                           n_components=int(spec.get("n_components", 1)),
                            use_gnn=bool(spec.get("use_gnn", True)), batch_size=batch_size, device=device,
                            _engine_factory=_engine_factory)
     if name != "vade":
@@ -140,7 +141,8 @@ def _clone_model(model: VaDE) -> VaDE:
     """Independent copy (own parameter buffer) -- deepcopy() of the reference."""
     if isinstance(model, Contrastive):
         twin = Contrastive(model.input_shape, model.edge_feature_shape, model._adjacency, model.latent_dim,
-                           encoder_type=model.encoder_type, temperature=model.temperature, similarity_function=model.similarity_function,
+                           encoder_type=model.encoder_type, n_components=model.n_components, temperature=model.temperature,
+                           similarity_function=model.similarity_function,
                            loss_function=model.loss_function, beta=model.beta, tau=model.tau,
                            batch_size=model._base.B, _engine_factory=model._factory)
         twin._base.params.copy_(model._base.params)
@@ -557,9 +559,8 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
                     "latent_dim": common_cfg.latent_dim, "n_components": common_cfg.n_components,
                     "encoder_type": common_cfg.encoder_type, "use_gnn": True,
                     "interaction_regularization": common_cfg.interaction_regularization}
-    if teacher_cfg.use_turtle_teacher:
-        warnings.warn("TURTLE teacher distillation is not implemented in this build; training the VQ-VAE without the "
-                      "distillation head (the reference's behaviour when no teacher is available).", RuntimeWarning)
+    nb = n_batches(len(train_ds), common_cfg.batch_size, world)
+    tau_star, lambda_scheduler = _generic_teacher(train_ds, common_cfg, teacher_cfg, eng, nb, is_main)
     eng.reset_optimizer()
     for seg in range(_capi.SEG_COUNT):
         eng.set_lr(seg, common_cfg.learning_rate)
@@ -568,7 +569,8 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
     _, best_path_val, best_path_score, _ = ckpt_paths("vqvae", common_cfg)
     best_val = float("inf")
     log_summary = init_log_summary("vqvae")
-    nb = n_batches(len(train_ds), common_cfg.batch_size, world)
+    best_score, best_score_val = -float("inf"), float("inf")
+    score_start_epoch, score_tol = max(3, math.ceil(0.1 * common_cfg.epochs)), 0.01
     keys = ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss", "kmeans_loss",
             "number_of_populated_clusters", "distill_loss")
 
@@ -577,17 +579,25 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
         acc = []
         it = ds.iter_batches(common_cfg.batch_size, train, common_cfg.seed if train else None,
                              world if train else 1, rank if train else 0)
-        for x, a, _idx, _vid in it:
+        lam_mid = 0.0
+        for step, (x, a, idx, _vid) in enumerate(it):
             e = model.engine(x.shape[0])
+            lam = float(lambda_scheduler.get_weight()) if (train and lambda_scheduler is not None) else 0.0
+            use_tau = train and tau_star is not None and lam > 0.0
+            e.set_hyper(lambda_distill=lam if use_tau else 0.0)
             if train:
                 e.advance_adam()
             e.push_hyper()
-            e.vq_loss_grads(x.contiguous(), a.contiguous())
+            e.vq_loss_grads(x.contiguous(), a.contiguous(), tau_star[idx].contiguous() if use_tau else None)
             if train:
                 if world > 1:
                     dist.all_reduce(e.grads, op=dist.ReduceOp.SUM)
                     e.grads.mul_(1.0 / world)
                 e.optimizer_step()
+                if lambda_scheduler is not None:
+                    lambda_scheduler.step()
+                    if step == int(nb / 2):
+                        lam_mid = lam
             acc.append(e.logs.clone())
         if not acc:
             return {k: float("nan") for k in keys}
@@ -599,13 +609,32 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
     for epoch in range(common_cfg.epochs):
         train_logs = run_epoch(train_ds, True)
         val_logs = run_epoch(val_ds, False)
-        val_logs.update(alignment_score=float("nan"), conf_norm=float("nan"), bal_norm=float("nan"))
+        if tau_star is not None:
+            zb = []
+            for bi, s0 in enumerate(range(0, len(val_ds), common_cfg.batch_size)):
+                if bi >= common_cfg.diag_max_batches:
+                    break
+                xv, av = val_ds.fetch(s0, min(s0 + common_cfg.batch_size, len(val_ds)))
+                zb.append(model.encode(xv, av))
+            val_logs.update(_head_diagnostics(eng, zb, common_cfg.n_components, tau_star, teacher_cfg))
+        else:
+            val_logs.update(alignment_score=float("nan"), conf_norm=float("nan"), bal_norm=float("nan"))
         v_total = float(val_logs["total_loss"])
+        score_value = float(val_logs["alignment_score"])
         log_summary = _update_log_summary(log_summary, train_logs, val_logs)
         if is_main:
             print(f"Epoch {epoch + 1}/{common_cfg.epochs} | train total={train_logs['total_loss']:.4f} "
-                  f"recon={train_logs['reconstruct_loss']:.4f} codes={train_logs['number_of_populated_clusters']:.1f} | "
-                  f"val total={v_total:.4f}")
+                  f"recon={train_logs['reconstruct_loss']:.4f} codes={train_logs['number_of_populated_clusters']:.1f} "
+                  f"distill={train_logs['distill_loss']:.4f} | val total={v_total:.4f} | align score={score_value:.3f}")
+        improved_score = tau_star is not None and math.isfinite(score_value) and (
+            score_value > best_score or (abs(score_value - best_score) <= score_tol and v_total < best_score_val))
+        if improved_score and epoch > score_start_epoch:
+            best_score, best_score_val = score_value, v_total
+            if common_cfg.save_weights and is_main:
+                save_model_info(best_path_score, stage="best_score", epoch=epoch, train_steps=(epoch + 1) * nb,
+                                val_total=v_total, score_value=score_value, common_cfg=common_cfg, teacher_cfg=teacher_cfg,
+                                model=model, log_summary=log_summary, rebuild_spec=rebuild_spec,
+                                save_weights=common_cfg.save_weights)
         if v_total < best_val:
             best_val = v_total
             if common_cfg.save_weights and is_main:
@@ -614,6 +643,47 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
                                 log_summary=log_summary, rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
     model_val, model_score = load_best_checkpoints(model, best_path_val, best_path_score, common_cfg.save_weights)
     return model_val, model_score, None, log_summary
+
+
+def _generic_teacher(train_ds, common_cfg, teacher_cfg, eng, nb, is_main):
+    """Teacher + distillation schedule of fit_VQVAE / fit_contrastive (training.py:1098-1123, 1338-1363): PCA views
+    only (no latent view), tf_sigmoid lambda schedule; returns (tau_star on the device or None, lambda schedule)."""
+    if not teacher_cfg.use_turtle_teacher:
+        return None, None
+    from . import teacher as TT
+    teacher_cfg.include_latent_view = False
+    _t, tau_star, _views = TT.maybe_build_turtle_teacher(teacher_cfg=teacher_cfg, common_cfg=common_cfg,
+                                                         train_dataset=train_ds, device=eng.device, latent_view=None,
+                                                         lib=eng.lib)
+    if tau_star is None:
+        return None, None
+    sched = WeightSchedule(nb, mode="tf_sigmoid", warmup_epochs=0, at_max_epochs=teacher_cfg.lambda_decay_start,
+                           max_weight=teacher_cfg.lambda_distill, cooldown_epochs=teacher_cfg.lambda_cooldown,
+                           end_weight=teacher_cfg.lambda_end_weight)
+    eng.set_hyper(distill_T=teacher_cfg.generic_distill_sharpen_T,
+                  conf_w=1.0 if teacher_cfg.generic_distill_conf_weight else 0.0,
+                  conf_thr=teacher_cfg.generic_distill_conf_thresh)
+    return tau_star.to(eng.device), sched
+
+
+def _head_diagnostics(eng, z_batches, n_components, tau_star, teacher_cfg):
+    """conf_norm / bal_norm / alignment_score from q = softmax(distill_head(z)) over a few validation batches
+    (logging.py:62-146 get_q_vqvae / get_q_contrastive + compute_diagnostics :148-301).  Diagnostics only."""
+    W, b = eng.view("distill_head.fc.weight"), eng.view("distill_head.fc.bias")
+    qs = []
+    for z in z_batches:
+        q = torch.softmax(z.float() @ W.T + b, dim=-1).clamp_min(1e-8)
+        qs.append(q / q.sum(dim=-1, keepdim=True).clamp_min(1e-8))
+    if not qs:
+        return {"alignment_score": float("nan"), "conf_norm": float("nan"), "bal_norm": float("nan")}
+    q = torch.cat(qs)
+    log_k = math.log(float(n_components))
+    conf = _clip01(1.0 - float(-(q * q.log()).sum(dim=-1).mean()) / max(1e-9, log_k))
+    q_marg = q.mean(dim=0).clamp_min(1e-9)
+    tau_marg = tau_star.to(q.device, q.dtype).mean(dim=0).clamp_min(1e-9)
+    kl = max(0.0, float((q_marg * (q_marg.log() - tau_marg.log())).sum()))
+    bal = _clip01(1.0 - kl / max(1e-9, log_k))
+    return {"alignment_score": conf * bal, "conf_norm": conf, "bal_norm": bal}
 
 
 class ContrastiveStepper:
@@ -644,8 +714,9 @@ class ContrastiveStepper:
         xa, aa = contrastive_views(self.lib, x_full, self.edge_index, draws, st)
         return x, a, xa, aa
 
-    def loss_grads(self, x_full: torch.Tensor, draws: dict = None, want_grads: bool = True):
-        """Fills the shared grads (if want_grads) and e.logs; returns the central-view engine."""
+    def loss_grads(self, x_full: torch.Tensor, draws: dict = None, want_grads: bool = True, teacher_tau=None):
+        """Fills the shared grads (if want_grads) and e.logs; returns the central-view engine.  teacher_tau (B,K):
+        targets of this batch for the distillation head (None = no distillation term)."""
         m = self.model
         x_full = x_full.to(m.device, torch.float32).contiguous()
         x, a, xa, aa = self.views(x_full, draws)
@@ -654,7 +725,7 @@ class ContrastiveStepper:
         z = e1.contrastive_encode(x, a, train=want_grads)
         z_aug = e2.contrastive_encode(xa, aa, train=want_grads)
         dz, dza = e1.contrastive_loss(z, z_aug, m.similarity_function, m.loss_function, m.temperature, m.tau, m.beta,
-                                      want_grads=want_grads)
+                                      want_grads=want_grads, teacher_tau=teacher_tau)
         if want_grads:
             e1.contrastive_backward(dz, accumulate=False)
             e2.contrastive_backward(dza, accumulate=True)
@@ -677,7 +748,8 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
                         similarity_function=contrastive_cfg.contrastive_similarity_function,
                         loss_function=contrastive_cfg.contrastive_loss_function,
                         temperature=contrastive_cfg.temperature, beta=contrastive_cfg.beta, tau=contrastive_cfg.tau,
-                        batch_size=common_cfg.batch_size, device=device, _engine_factory=_engine_factory)
+                        batch_size=common_cfg.batch_size, device=device, _engine_factory=_engine_factory,
+                        n_components=common_cfg.n_components)
     eng = model._base
     if world > 1:
         dist.broadcast(eng.params, src=0)
@@ -686,9 +758,8 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
                     "latent_dim": common_cfg.latent_dim, "n_components": common_cfg.n_components,
                     "encoder_type": common_cfg.encoder_type, "use_gnn": True,
                     "interaction_regularization": common_cfg.interaction_regularization}
-    if teacher_cfg.use_turtle_teacher:
-        warnings.warn("TURTLE teacher distillation is not implemented in this build; training the contrastive model "
-                      "without the distillation head.", RuntimeWarning)
+    nb = n_batches(len(train_ds), common_cfg.batch_size, world)
+    tau_star, lambda_scheduler = _generic_teacher(train_ds, common_cfg, teacher_cfg, eng, nb, is_main)
     ei_g, ei_l = edge_index_from_meta(meta_info, train_ds.x_shape[1])
     seed = common_cfg.seed if common_cfg.seed is not None else 0
     stepper = ContrastiveStepper(model, ei_g, ei_l, contrastive_cfg, seed=seed + 7919 * rank)
@@ -699,7 +770,8 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
     _, best_path_val, best_path_score, _ = ckpt_paths("contrastive", common_cfg)
     best_val = float("inf")
     log_summary = init_log_summary("contrastive")
-    nb = n_batches(len(train_ds), common_cfg.batch_size, world)
+    best_score, best_score_val = -float("inf"), float("inf")
+    score_start_epoch, score_tol = max(3, math.ceil(0.1 * common_cfg.epochs)), 0.01
     keys = ("total_loss", "pos_similarity", "neg_similarity", "distill_loss", "seperability")
 
     def run_epoch(ds, train):
@@ -707,33 +779,59 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
         acc = []
         it = ds.iter_batches(common_cfg.batch_size, train, common_cfg.seed if train else None,
                              world if train else 1, rank if train else 0)
-        for x, _a, _idx, _vid in it:
+        for x, _a, idx, _vid in it:
+            lam = float(lambda_scheduler.get_weight()) if (train and lambda_scheduler is not None) else 0.0
+            use_tau = train and tau_star is not None and lam > 0.0
+            eng.set_hyper(lambda_distill=lam if use_tau else 0.0)
             if train:
                 eng.advance_adam()
             eng.push_hyper()
-            e = stepper.loss_grads(x, want_grads=train)
+            e = stepper.loss_grads(x, want_grads=train, teacher_tau=tau_star[idx].contiguous() if use_tau else None)
             if train:
                 if world > 1:
                     dist.all_reduce(e.grads, op=dist.ReduceOp.SUM)
                     e.grads.mul_(1.0 / world)
                 e.optimizer_step()
+                if lambda_scheduler is not None:
+                    lambda_scheduler.step()
             acc.append(e.logs.clone())
         if not acc:
             return {k: float("nan") for k in keys}
         m = torch.stack(acc).mean(dim=0).cpu().tolist()
         return {"total_loss": m[0], "pos_similarity": m[_capi.LOG_POS_SIM], "neg_similarity": m[_capi.LOG_NEG_SIM],
-                "distill_loss": 0.0, "seperability": 0.0}
+                "distill_loss": m[7], "seperability": 0.0}
 
     for epoch in range(common_cfg.epochs):
         train_logs = run_epoch(train_ds, True)
         val_logs = run_epoch(val_ds, False)
-        val_logs.update(alignment_score=float("nan"), conf_norm=float("nan"), bal_norm=float("nan"))
+        if tau_star is not None:
+            zb = []
+            model.eval()
+            for bi, s0 in enumerate(range(0, len(val_ds), common_cfg.batch_size)):
+                if bi >= common_cfg.diag_max_batches:
+                    break
+                xv, _av = val_ds.fetch(s0, min(s0 + common_cfg.batch_size, len(val_ds)))
+                xc, ac, _xa, _aa = stepper.views(xv.to(model.device, torch.float32).contiguous())
+                zb.append(torch.nn.functional.normalize(model.embed(xc, ac), dim=1))
+            val_logs.update(_head_diagnostics(eng, zb, common_cfg.n_components, tau_star, teacher_cfg))
+        else:
+            val_logs.update(alignment_score=float("nan"), conf_norm=float("nan"), bal_norm=float("nan"))
         v_total = float(val_logs["total_loss"])
+        score_value = float(val_logs["alignment_score"])
         log_summary = _update_log_summary(log_summary, train_logs, val_logs)
         if is_main:
             print(f"Epoch {epoch + 1}/{common_cfg.epochs} | train total={train_logs['total_loss']:.4f} "
-                  f"pos={train_logs['pos_similarity']:.3f} neg={train_logs['neg_similarity']:.3f} | "
-                  f"val total={v_total:.4f}")
+                  f"pos={train_logs['pos_similarity']:.3f} neg={train_logs['neg_similarity']:.3f} "
+                  f"distill={train_logs['distill_loss']:.4f} | val total={v_total:.4f} | align score={score_value:.3f}")
+        improved_score = tau_star is not None and math.isfinite(score_value) and (
+            score_value > best_score or (abs(score_value - best_score) <= score_tol and v_total < best_score_val))
+        if improved_score and epoch > score_start_epoch:
+            best_score, best_score_val = score_value, v_total
+            if common_cfg.save_weights and is_main:
+                save_model_info(best_path_score, stage="best_score", epoch=epoch, train_steps=(epoch + 1) * nb,
+                                val_total=v_total, score_value=score_value, common_cfg=common_cfg, teacher_cfg=teacher_cfg,
+                                contrastive_cfg=contrastive_cfg, model=model, log_summary=log_summary,
+                                rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
         if v_total < best_val:
             best_val = v_total
             if common_cfg.save_weights and is_main:

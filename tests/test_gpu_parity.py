@@ -18,7 +18,7 @@ def hip():
 def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == 6
+    assert hip.dof_abi_version() == 7
 
 
 def test_gather_gpu(hip):
@@ -489,3 +489,8 @@ def test_vade_teacher_training_api_gpu(tmp_path):
     assert isinstance(mt, VaDE) and (tmp_path / "models" / "vade" / "run_0" / "model_teacher_init.pth").exists()
     assert np.isfinite(logs["train"]["total_loss"]).all() and max(logs["train"]["distill_loss"]) > 0
     assert np.isfinite(logs["val"]["alignment_score"]).all()
+
+
+def test_distillation_head_gpu(hip, golden_dir):
+    from parity_common import run_distill_head_check
+    run_distill_head_check(hip, "cuda", golden_dir)

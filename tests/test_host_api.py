@@ -452,3 +452,24 @@ def test_fit_vade_with_turtle_teacher(tmp_path):
     for s in range(0, 48, 16):
         ip.partial_fit(X[s:s + 16])
     np.testing.assert_allclose(pos.numpy(), ip.transform(X), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["VQVAE", "Contrastive"])
+def test_generic_distillation_through_trainer(tmp_path, name):
+    """use_turtle_teacher=True for VQ-VAE / contrastive: PCA views -> teacher -> tau*, DiscriminativeHead trained with
+    the model, distillation term live, alignment score from the head."""
+    W = 8 if name == "VQVAE" else 12
+    pre_tr, pre_va = tiny_preprocessed(n_videos=2, n_win=24, W=W, seed=21), tiny_preprocessed(n_videos=1, n_win=16, W=W, seed=22)
+    names = [f"n{i}" for i in range(4)]
+    meta = {"node_columns": [(n, "x") for n in names] + [(n, "y") for n in names] + names,
+            "edge_columns": [(names[i], names[i + 1]) for i in range(3)]}
+    mv, ms, mt, logs = TR.train_deepof_model(
+        preprocessed_object=(pre_tr, pre_va), adjacency_matrix=chain_adj(4), meta_info=meta, encoder_type="recurrent",
+        batch_size=8, latent_dim=4, epochs=2, output_path=str(tmp_path), n_clusters=3, model_name=name,
+        use_turtle_teacher=True, teacher_outer_steps=5, teacher_inner_steps=4, pca_nodes_dim=4, teacher_batch_size=16,
+        aug_max_interp=3, aug_min_interp=2, aug_max_shift=2, _engine_factory=emu_factory)
+    assert max(logs["train"]["distill_loss"]) > 0.0
+    assert np.isfinite(logs["train"]["total_loss"]).all() and np.isfinite(logs["val"]["alignment_score"]).all()
+    assert "distill_head.fc.weight" not in mv.state_dict()            # the head is not part of the model bundle
+    head = mv._base.view("distill_head.fc.weight")
+    assert tuple(head.shape) == (3, 4) and float(head.abs().sum()) > 0
