@@ -409,7 +409,8 @@ struct TcnCombineArgs {
   const float* y2;
   const float* bnp2;
   const float* res;    // [T][Sp][CT] previous block output, or null on block 0
-  const float* xs;     // [T][Sp][F] raw input (block 0)
+  const float* xs;     // [T][Sp][xs_ch] raw input (block 0): F real channels in rows of xs_ch floats
+  int xs_ch;
   const float *dsw, *dsb;  // (CT,F,1), (CT)
   float* out;          // [T][Sp][CT] or null (encoder's last block: unused by the reference)
   float* skip;         // [T][Sp][CT] running sum
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
     dof_ld_row<TC>(A.res + ACT(t, c0, CT, A.Sp, s), r);
   } else {
     float xin[32];
-    for (int f = 0; f < A.F; ++f) xin[f] = A.xs[ACT(t, f, A.F, A.Sp, s)];
+    for (int f = 0; f < A.F; ++f) xin[f] = A.xs[ACT(t, f, A.xs_ch, A.Sp, s)];
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
       float acc = A.dsb[c0 + c];
@@ -841,8 +842,9 @@ int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* 
 
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
                            const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
-                           int64_t S, int64_t Sp, hipStream_t st) {
+                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch) {
   TcnCombineArgs A;
+  A.xs_ch = xs_ch > 0 ? xs_ch : F;
   A.y2 = y2; A.bnp2 = bnp2; A.res = res; A.xs = xs; A.dsw = dsw; A.dsb = dsb; A.out = out; A.skip = skip;
   A.feat = feat; A.first = first; A.T = T; A.F = F; A.CT = CT; A.S = S; A.Sp = Sp;
   DOF_LAUNCH(k_tcn_combine, ((unsigned)dof_tcn_row_blocks(T, S), (unsigned)(CT / TC)), (256), st, A);

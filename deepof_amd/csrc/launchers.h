@@ -48,7 +48,7 @@ int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* 
                           int C, hipStream_t st);
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
                            const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
-                           int64_t S, int64_t Sp, hipStream_t st);
+                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch = 0);
 int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, float* sums,
                            int blk, const float* out_blk, const float* dfeat, const float* skip, const float* dskip,
                            float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st);

@@ -1243,7 +1243,7 @@ int tcn_decoder_forward(DofVadePlan* p, float* params, const float* x, const flo
                               train, ws + d.bnp[2 * b + 1], CD, st));
     TRY(dof_launch_tcn_combine(ws + d.y2[b], ws + d.bnp[2 * b + 1], b ? ws + d.out[b - 1] : nullptr, ws + d.zrep,
                                b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb, ws + d.out[b], ws + d.skip,
-                               nullptr, b == 0, T, b ? CD : C4, CD, B, Bp, st));
+                               nullptr, b == 0, T, b ? CD : C4, CD, B, Bp, st, 32));
   }
   return dof_launch_tcn_dec_out(ws + d.skip, params + p->dpw, params + p->dpb, x, ws + p->valid, ws + d.hid, loc_out,
                                 recon_partial, ws + p->dloc, ws + d.dskip, T, p->C3, keep ? 1 : 0, B, Bp, st);

@@ -571,3 +571,52 @@ def run_distill_head_check(lib, device, golden_dir):
             np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=5e-5, rtol=1e-3, err_msg=k)
             n += 1
     assert n >= 42
+
+
+def run_vade_tcn_vs_oracle(lib, device, L=4, K=3, B=6, T=10, seed=3):
+    """VaDE-TCN at a latent size whose decoder input (4L channels) needs the zero-padded MFMA operand path
+    (4L < 32): eval forward and train-step gradients vs the CPU oracle, fp64-anchored as in run_vade_tcn_check."""
+    from oracle import vade as OV
+    adj = np.zeros((4, 4), np.float32)
+    for i in range(3):
+        adj[i, i + 1] = adj[i + 1, i] = 1.0
+    eng = VadeEngine(lib, device, B, T, adj, L, K, kind="vade_tcn")
+    g = torch.Generator().manual_seed(seed)
+    P = eng.state_dict()
+    for n, v in P.items():
+        if not v.dtype.is_floating_point or n.split(".")[-1] in ("laplacian", "edge_laplacian", "incidence", "prior", "pretrain"):
+            continue
+        if n.endswith("running_var"):
+            P[n] = torch.rand(v.shape, generator=g) + 0.5
+        elif n.endswith("running_mean"):
+            P[n] = torch.randn(v.shape, generator=g) * 0.1
+        elif (".bn" in n or "head.2" in n or "head.5" in n) and n.endswith("weight"):
+            P[n] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            P[n] = torch.randn(v.shape, generator=g) * (0.3 if v.dim() > 1 else 0.05)
+    eng.load_state_dict(P)
+    x = torch.randn(B, T, 4, 3, generator=g).cumsum(1) * 0.3
+    a = torch.randn(B, T, 3, 1, generator=g)
+    out = eng.forward(x.to(device), a.to(device), None, want_loc=True, want_enc=True)
+    with torch.no_grad():
+        ref = OV.vade_forward({k: v.clone() for k, v in P.items()}, x, a, training=False)
+    np.testing.assert_allclose(out["enc"].cpu().numpy(), ref["enc"].numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["loc"].cpu().numpy(), ref["loc"].numpy(), atol=5e-5, rtol=2e-4)
+    eps = torch.randn(B, L, generator=g)
+    configure_phase(eng, K, True, 0.2, None, 0.0)
+    eng.loss_grads(x.to(device), a.to(device), eps.to(device), None, None, pretrain=True)
+    cfg = OV.VadeLossCfg(K, True)
+    (l32, g32, _), (l64, g64, _) = _oracle_truth(lambda Pq, xx, aa, ee: OV.vade_grads(Pq, xx, aa, cfg, 0.2, ee, None, None),
+                                                 P, x, a, eps)
+    np.testing.assert_allclose(eng.read_logs()["total_loss"], float(l64["total_loss"]), rtol=2e-4)
+    n = 0
+    for name, t in g64.items():
+        if t is None or name not in eng.layout:
+            continue
+        got = eng.view(name, eng.grads).cpu().numpy().astype(np.float64)
+        t = t.numpy().reshape(got.shape)
+        noise = np.abs(g32[name].numpy().astype(np.float64).reshape(got.shape) - t).max()
+        err = np.abs(got - t).max()
+        assert err <= 10.0 * noise + 5e-6 * np.abs(t).max() + 1e-6, (name, err, noise)
+        n += 1
+    assert n >= 200

@@ -78,3 +78,9 @@ def test_turtle_teacher_emu(golden_dir):
 def test_distillation_head_emu(golden_dir):
     from parity_common import run_distill_head_check
     run_distill_head_check(emu_lib(), "cpu", golden_dir)
+
+
+@pytest.mark.parametrize("L", [4, 6])
+def test_vade_tcn_padded_decoder_input_emu(L):
+    from parity_common import run_vade_tcn_vs_oracle
+    run_vade_tcn_vs_oracle(emu_lib(), "cpu", L=L)

@@ -494,3 +494,9 @@ def test_vade_teacher_training_api_gpu(tmp_path):
 def test_distillation_head_gpu(hip, golden_dir):
     from parity_common import run_distill_head_check
     run_distill_head_check(hip, "cuda", golden_dir)
+
+
+@pytest.mark.parametrize("L", [4, 6])
+def test_vade_tcn_padded_decoder_input_gpu(hip, L):
+    from parity_common import run_vade_tcn_vs_oracle
+    run_vade_tcn_vs_oracle(hip, "cuda", L=L)
