@@ -128,14 +128,18 @@ class WindowDataset:
     @classmethod
     def from_preprocessed(cls, preprocessed: Dict, device) -> "WindowDataset":
         ds = cls(device)
-        xs, as_, vid = [], [], []
+        xs, as_, vid, angs = [], [], [], []
         for i, key in enumerate(preprocessed.keys()):
             nodes, edges = preprocessed[key][0], preprocessed[key][1]
             nodes, edges = np.asarray(nodes), np.asarray(edges)
             xs.append(reorder_and_reshape(nodes).astype(np.float32))
             as_.append(np.expand_dims(edges, -1).astype(np.float32))
             vid.append(np.full(nodes.shape[0], i, dtype=np.int32))
+            if len(preprocessed[key]) > 2 and preprocessed[key][2] is not None:
+                angs.append(np.asarray(preprocessed[key][2], dtype=np.float32))
             ds.keys.append(key)
+        # angle windows (n, W, A): host-resident, only the teacher's optional angle view reads them (dataset.py:81-92)
+        ds.angles = np.concatenate(angs) if len(angs) == len(xs) and angs and angs[0].shape[-1] > 0 else None
         x, a = np.concatenate(xs), np.concatenate(as_)
         ds.x = torch.from_numpy(x).to(ds.device)
         ds.a = torch.from_numpy(a).to(ds.device)

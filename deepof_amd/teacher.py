@@ -210,6 +210,18 @@ def extract_pca_edges_view(dataset, n_components: int = 16, batch_size: int = 81
     return _pca_two_pass(gen, n_components)
 
 
+def fit_angles_pca(dataset, n_components: int = 32, batch_size: int = 8192) -> torch.Tensor:
+    """teacher_model.py:576-635: two-pass IncrementalPCA of the flattened angle windows (n, W*A)."""
+    ang = getattr(dataset, "angles", None)
+    if ang is None:
+        raise RuntimeError("include_angles_view=True but the preprocessed data carries no angle tables")
+
+    def gen():
+        for s in range(0, ang.shape[0], batch_size):
+            yield ang[s:s + batch_size].reshape(min(batch_size, ang.shape[0] - s), -1)
+    return _pca_two_pass(gen, n_components)
+
+
 @torch.no_grad()
 def extract_latents(model, dataset, batch_size: int = 2048) -> torch.Tensor:
     """z_mean of every window of the dataset, in order, on the host (teacher_model.py:354-391)."""
@@ -253,8 +265,7 @@ def initialize_gmm_from_teacher(model, z_all: torch.Tensor, tau_star: torch.Tens
 
 def maybe_build_turtle_teacher(*, teacher_cfg, common_cfg, train_dataset, device=None,
                                latent_view: Optional[torch.Tensor] = None, lib=None):
-    """teacher_model.py:811-905 -> (teacher, tau_star (N,K) host, views).  The angle view needs the angle tables of the
-    preprocessing stage, which this build does not carry (out of the hot path): requesting it raises."""
+    """teacher_model.py:811-905 -> (teacher, tau_star (N,K) host, views)."""
     if not teacher_cfg.use_turtle_teacher:
         return None, None, {}
     views = {"z": None, "pca_pos": None, "pca_spd": None, "pca_edges": None, "pca_angles": None}
@@ -270,7 +281,8 @@ def maybe_build_turtle_teacher(*, teacher_cfg, common_cfg, train_dataset, device
         print("\n--- Building PCA views for teacher (edges) ---")
         views["pca_edges"] = extract_pca_edges_view(train_dataset, teacher_cfg.pca_edges_dim, teacher_cfg.batch_size_edges)
     if teacher_cfg.include_angles_view:
-        raise NotImplementedError("include_angles_view: the angle tables are not part of this build's dataset")
+        print("\n--- Building PCA views for teacher (angles) ---")
+        views["pca_angles"] = fit_angles_pca(train_dataset, teacher_cfg.pca_angles_dim, teacher_cfg.batch_size_angles)
     print("\n--- Running TURTLE teacher on views ---")
     teacher, tau_star = run_turtle_teacher_on_views(
         views, common_cfg.n_components, gamma=teacher_cfg.teacher_gamma,

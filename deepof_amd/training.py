@@ -492,7 +492,7 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
             z_curr = TT.extract_latents(model, train_ds, batch_size=2048)
             views = {"z": z_curr}
             for key, flag in (("pca_pos", teacher_cfg.include_nodes_view), ("pca_spd", teacher_cfg.include_nodes_view),
-                              ("pca_edges", teacher_cfg.include_edges_view)):
+                              ("pca_edges", teacher_cfg.include_edges_view), ("pca_angles", teacher_cfg.include_angles_view)):
                 if flag and teacher_views.get(key) is not None:
                     views[key] = teacher_views[key]
             _teacher, tau_star = TT.run_turtle_teacher_on_views(

@@ -452,6 +452,14 @@ def test_fit_vade_with_turtle_teacher(tmp_path):
     for s in range(0, 48, 16):
         ip.partial_fit(X[s:s + 16])
     np.testing.assert_allclose(pos.numpy(), ip.transform(X), atol=1e-5)
+    # the optional edge / angle views (angle windows ride along on the host)
+    rng = np.random.default_rng(5)
+    pre_ang = {k: (v[0], v[1], rng.standard_normal((v[0].shape[0], 8, 5)).astype(np.float32)) for k, v in pre_tr.items()}
+    ds2 = WindowDataset.from_preprocessed(pre_ang, "cpu")
+    assert tuple(TT.fit_angles_pca(ds2, 3, batch_size=20).shape) == (48, 3)
+    assert tuple(TT.extract_pca_edges_view(ds2, 2, batch_size=20).shape) == (48, 2)
+    with pytest.raises(RuntimeError, match="angle"):
+        TT.fit_angles_pca(ds, 3)
 
 
 @pytest.mark.parametrize("name", ["VQVAE", "Contrastive"])
