@@ -500,3 +500,54 @@ def test_distillation_head_gpu(hip, golden_dir):
 def test_vade_tcn_padded_decoder_input_gpu(hip, L):
     from parity_common import run_vade_tcn_vs_oracle
     run_vade_tcn_vs_oracle(hip, "cuda", L=L)
+
+
+def test_full_size_c5(hip):
+    """BASELINE config C5 (VaDE, 2 animals: 28 nodes / 32 edges, window 50, k=25, batch 4096): main-phase step at
+    full size -- run-to-run identical gradients, finite, logged total = sum of its parts -- and forward parity
+    (embeddings, soft assignments, reconstruction) against the CPU oracle on a 48-window slice; C5-sized window
+    gather (second staging-buffer class) against the oracle."""
+    from deepof_amd import _capi
+    from deepof_amd.engine import create_vade_engine
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    from oracle import vade as OV, windows as OW
+    from parity_common import configure_phase
+    nodes, edges = bodypart_graph(["B", "W"])
+    N, E = len(nodes), len(edges)
+    assert (N, E) == (28, 32)
+    B, T, L, K, S = 4096, 50, 8, 25, 32
+    eng = create_vade_engine(B, T, adjacency_from_graph(nodes, edges), L, K, S)
+    g = torch.Generator().manual_seed(0)
+    for n in eng.names:
+        shape = eng.layout[n][2]
+        v = torch.randn(shape, generator=g) * (0.3 if len(shape) > 1 else 0.1)
+        if "norm" in n and n.endswith("weight"):
+            v = 1.0 + v
+        eng.view(n).copy_(v)
+    # windows straight from frame tables (C5 rows are 116 floats: the larger staging class of the gather kernel)
+    F = B + T - 1 + 17
+    tn, te = torch.randn(F, 3 * N, generator=g), torch.randn(F, E, generator=g)
+    x = torch.empty(B, T, N, 3, device="cuda")
+    a = torch.empty(B, T, E, 1, device="cuda")
+    _capi.check(hip, hip.dof_window_gather_range(tn.cuda().data_ptr(), te.cuda().data_ptr(), 5, 1, B, T, N, E,
+                                                 x.data_ptr(), a.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    xr, ar = OW.gather_windows(tn.numpy(), te.numpy(), np.arange(B) + 5, T)
+    assert np.array_equal(x.cpu().numpy(), xr) and np.array_equal(a.cpu().numpy(), ar)
+    tau = torch.softmax(torch.randn(B, K, generator=g) * 2, dim=-1).cuda()
+    eps, eps_mc = torch.randn(B, L, generator=g).cuda(), torch.randn(S, B, L, generator=g).cuda()
+    configure_phase(eng, K, False, 0.7, tau.cpu(), 1.7)
+    eng.loss_grads(x, a, eps, eps_mc, tau, pretrain=False)
+    g1, logs = eng.grads.clone(), eng.read_logs()
+    eng.loss_grads(x, a, eps, eps_mc, tau, pretrain=False)
+    assert torch.equal(g1, eng.grads) and bool(torch.isfinite(g1).all())
+    parts = sum(logs[k] for k in ("reconstruct_loss", "cat_clust_loss", "kmeans_loss", "activity_l1", "prior_loss",
+                                  "distill_loss", "tf_clust_loss", "nonempty_loss", "temporal_loss", "scatter_loss",
+                                  "repel_loss")) + logs["kl_weight"] * logs["kl_div"]
+    np.testing.assert_allclose(logs["total_loss"], parts, rtol=2e-5)
+    out = eng.forward(x, a, None, want_loc=True)
+    P = eng.state_dict()
+    with torch.no_grad():
+        ref = OV.vade_forward(P, x[:48].cpu(), a[:48].cpu(), training=False)
+    np.testing.assert_allclose(out["z"][:48].cpu().numpy(), ref["z"].numpy(), atol=5e-5, rtol=1e-3)
+    np.testing.assert_allclose(out["q"][:48].cpu().numpy(), ref["q"].numpy(), atol=5e-5, rtol=5e-3)
+    np.testing.assert_allclose(out["loc"][:48].cpu().numpy(), ref["loc"].numpy(), atol=2e-4, rtol=1e-3)
