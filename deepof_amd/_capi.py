@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -47,6 +47,18 @@ class TurtleHyper(C.Structure):
                 ("task_temp", C.c_float), ("inner_lr", C.c_float), ("head_wd", C.c_float), ("lr_theta", C.c_float),
                 ("rho", C.c_float), ("inner_steps", C.c_int32), ("normalize_feats", C.c_int32)]
 
+
+class PreprocDims(C.Structure):
+    _fields_ = [("n_frames", C.c_int64), ("n_videos", C.c_int32), ("n_cols", C.c_int32), ("n_animals", C.c_int32),
+                ("n_node_cols", C.c_int32), ("n_edge_cols", C.c_int32), ("n_angle_cols", C.c_int32),
+                ("speed_mode", C.c_int32), ("dist_mode", C.c_int32), ("coord_mode", C.c_int32),
+                ("log_distances", C.c_int32), ("inter_scale", C.c_int32), ("fit_global", C.c_int32), ("clip", C.c_double)]
+
+
+PP_KINDS = {"other": 0, "coord": 1, "speed": 2, "dist_inner": 3, "dist_intra": 4, "angle": 5}
+PP_MODES = {None: 0, "per_column": 1, "groupwise": 2}
+PP_INTER_SCALE = {"mean": 0, "geom": 1, "global": 2}
+PP_MAX_COLS, PP_MAX_ANIMALS, PP_MAX_OUT = 512, 8, 256
 
 _P = C.c_void_p
 _I64 = C.c_int64
@@ -89,6 +101,8 @@ SIGNATURES = {
     "dof_contrastive_encode": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P]),
     "dof_contrastive_loss": (C.c_int, [_P, _P, _P, _I32, _I32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "dof_contrastive_backward": (C.c_int, [_P, _P, _P, _P, _I32, _P]),
+    "dof_preprocess_workspace_bytes": (_I64, [C.POINTER(PreprocDims)]),
+    "dof_preprocess_tables": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 16),
 }
 
 

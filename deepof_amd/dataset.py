@@ -172,6 +172,35 @@ class WindowDataset:
         ds.x_shape, ds.a_shape = (window_size, n, 3), (window_size, e, 1)
         return ds
 
+    @classmethod
+    def from_device_tables(cls, pre, window_size: int, window_step: int, lib, keys: Optional[List[str]] = None) -> "WindowDataset":
+        """Windows over the frame tables ``deepof_amd.preprocess.preprocess_tables`` left on the device (nothing is
+        copied): stride-``window_step`` windows inside every video, never across two (extract_windows,
+        /root/reference/deepof/utils.py:3380-3474).  ``keys`` selects videos (e.g. the training or the test ones)."""
+        ds = cls(pre.node_table.device)
+        ds._lib = lib
+        starts, vid = [], []
+        for i, key in enumerate(pre.keys):
+            if keys is not None and key not in keys:
+                continue
+            lo, hi = int(pre.video_off[i]), int(pre.video_off[i + 1])
+            nw = (hi - lo - window_size) // window_step + 1
+            if nw <= 0:
+                continue
+            starts.append(lo + np.arange(nw, dtype=np.int64) * window_step)
+            vid.append(np.full(nw, len(ds.keys), dtype=np.int32))
+            ds.keys.append(key)
+        if not starts:
+            raise ValueError("no video is long enough for one window")
+        ds.node_table, ds.edge_table = pre.node_table, pre.edge_table
+        ds.row_start = torch.from_numpy(np.concatenate(starts)).to(ds.device)
+        ds.video_idx = np.concatenate(vid)
+        ds.length = int(ds.row_start.numel())
+        ds.x_shape = (window_size, pre.node_table.shape[1] // 3, 3)
+        ds.a_shape = (window_size, pre.edge_table.shape[1], 1)
+        ds.angles = None
+        return ds
+
     def __len__(self):
         return self.length
 

@@ -24,6 +24,11 @@
  *   dof_contrastive_backward    loss.backward() through one view's encoder pass (training.py:163)
  *   dof_turtle_fit_step/_predict  teacher_model.py:43-350 TurtleTeacher (heads inner fit, task encoder, fit, predict)
  *   dof_optimizer_step          training.py:164-166 clip_grad_value_ + optimizer.step(), losses.py:805-833
+ *   dof_preprocess_tables       deepof/data.py:3773-3916 TableDict.preprocess (scale="standard") up to window
+ *                               extraction: utils.py:2425-2566 scale_table, :2665-2792 _pp_pass1_collect_samples,
+ *                               :2795-2863 _pp_fit_global_scaler, :2866-2921 _pp_apply_global,
+ *                               :2924-3027 _pp_pass2_scale_and_save, :2577-2583 _pp_sanitize_numeric; output in the
+ *                               frame-table layout of data.py:2797-2880 get_graph_dataset (node / edge / angle columns)
  */
 #ifndef DEEPOF_HIP_H
 #define DEEPOF_HIP_H
@@ -34,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 7
+#define DOF_ABI_VERSION 8
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -258,6 +263,53 @@ int dof_turtle_predict(const DofTurtleDims* dims, float task_temp, const float* 
 /* clip_grad_value_(hyper[DOF_H_CLIP]) + Adam(betas 0.9/0.999, eps 1e-8, weight decay hyper[DOF_H_WD]). */
 int dof_optimizer_step(DofVadePlan* plan, float* params, const float* grads, float* adam_m, float* adam_v,
                        const float* hyper, void* stream);
+
+/* ---- pose-table preprocessing -----------------------------------------------
+ * Raw merged tables of all videos, concatenated: raw (n_frames, n_cols) float64 row-major (NaN = missing), video v =
+ * rows video_off[v] .. video_off[v+1]-1.  One call = TableDict.preprocess(scale="standard") without the windows:
+ * size factors (nan-median nose--tail-base length per animal and video), size normalisation, log1p of distances,
+ * per-video standardisation, global standardisation fitted on the sampled rows (or taken from `scaler`), clipping
+ * of |z| > clip to missing, linear interpolation in time within each video (flat at the ends, 0 for a column with
+ * no valid row), fp32 cast, column selection into the resident frame tables dof_window_gather reads:
+ * node_out (n_frames, n_node_cols) = [x.. | y.. | speed..], edge_out (n_frames, n_edge_cols), angle_out.
+ * All arithmetic is float64 like the reference's pandas / sklearn path.  Column metadata (device int32 arrays):
+ *   col_kind[n_cols]        DOF_PP_OTHER .. DOF_PP_ANGLE
+ *   size_ref[n_animals][4]  columns of (nose x, nose y, tail-base x, tail-base y) of each animal, -1 when absent
+ *   chain_off[n_cols+1], chain[3*k]  size-divisor chain of a column: entries (animal a1, animal a2, same) with -1 =
+ *                           "not one of the animals" -> default factor; divisor = prod over entries of
+ *                           (same ? s[a1] : combine(s[a1], s[a2])); a column with an empty chain is not divided
+ *   out_cols[n_node_cols + n_edge_cols + n_angle_cols]   source column of every output column
+ * sample_mask (n_frames) uint8 or NULL: rows entering the global fit (NULL = all rows).
+ * scaler (n_cols, 2) float64 = (mean, scale) of the global scaler per column (a group's columns hold the same pair):
+ * written when dims.fit_global, read otherwise.  size_out (n_videos, n_animals + 1) float64 or NULL: the size
+ * factors and the default factor.  video_scaler (n_videos, n_cols, 2) float64 or NULL: per-video (mean, scale). */
+#define DOF_PP_OTHER 0
+#define DOF_PP_COORD 1
+#define DOF_PP_SPEED 2
+#define DOF_PP_DIST_INNER 3
+#define DOF_PP_DIST_INTRA 4
+#define DOF_PP_ANGLE 5
+#define DOF_PP_MODE_NONE 0
+#define DOF_PP_MODE_PER_COLUMN 1
+#define DOF_PP_MODE_GROUPWISE 2
+#define DOF_PP_MAX_COLS 512
+#define DOF_PP_MAX_ANIMALS 8
+typedef struct DofPreprocDims {
+  int64_t n_frames;          /* rows of raw */
+  int32_t n_videos, n_cols, n_animals;
+  int32_t n_node_cols, n_edge_cols, n_angle_cols;
+  int32_t speed_mode, dist_mode, coord_mode; /* DOF_PP_MODE_* */
+  int32_t log_distances;
+  int32_t inter_scale;       /* 0 mean, 1 geometric mean, 2 default factor (scale_table's inter_scale) */
+  int32_t fit_global;        /* 1: fit the global scalers; 0: apply the ones passed in `scaler` */
+  double clip;               /* interpolate_normalized; 0 disables clipping */
+} DofPreprocDims;
+int64_t dof_preprocess_workspace_bytes(const DofPreprocDims* dims);
+int dof_preprocess_tables(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
+                          const int32_t* col_kind, const int32_t* size_ref, const int32_t* chain_off,
+                          const int32_t* chain, const int32_t* out_cols, const uint8_t* sample_mask, double* scaler,
+                          double* size_out, double* video_scaler, float* node_out, float* edge_out, float* angle_out,
+                          void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

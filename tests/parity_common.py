@@ -620,3 +620,117 @@ def run_vade_tcn_vs_oracle(lib, device, L=4, K=3, B=6, T=10, seed=3):
         assert err <= 10.0 * noise + 5e-6 * np.abs(t).max() + 1e-6, (name, err, noise)
         n += 1
     assert n >= 200
+
+
+# ---- pose-table preprocessing ---------------------------------------------------------
+def load_preprocess_golden(golden_dir):
+    import json
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    cases = json.loads(str(g["cases"]))
+    data = {}
+    for tag in ("pair", "single"):
+        cols = [tuple(c) if isinstance(c, list) else c for c in json.loads(str(g[f"{tag}::columns"]))]
+        tabs = {k.split("::")[-1]: g[k] for k in g.files if k.startswith(f"{tag}::raw::")}
+        data[tag] = (cols, json.loads(str(g[f"{tag}::animal_ids"])), tabs)
+    return g, cases, data
+
+
+def preprocess_output_columns(cols):
+    """Frame-table columns the way get_graph_dataset orders them: sorted nodes [x | y | speed], a subset of the
+    distance columns as 'edges', all angles."""
+    nodes = sorted({c[0] for c in cols if isinstance(c, tuple) and len(c) == 2 and c[1] in ("x", "y")})
+    node_cols = [(n, "x") for n in nodes] + [(n, "y") for n in nodes] + nodes
+    dist = [c for c in cols if isinstance(c, tuple) and len(c) == 2 and c[1] not in ("x", "y")]
+    edge_cols = sorted(dist[::3])
+    angle_cols = [c for c in cols if isinstance(c, tuple) and len(c) == 3]
+    return node_cols, edge_cols, angle_cols
+
+
+def _check_tables(res, exp, cols, node_cols, edge_cols, angle_cols, what):
+    pos = {c: i for i, c in enumerate(cols)}
+    assert res.keys == sorted(exp), what
+    for i, k in enumerate(res.keys):
+        lo, hi = int(res.video_off[i]), int(res.video_off[i + 1])
+        for name, tab, sel in (("node", res.node_table, node_cols), ("edge", res.edge_table, edge_cols),
+                               ("angle", res.angle_table, angle_cols)):
+            if not sel:
+                continue
+            got = tab[lo:hi].cpu().numpy()
+            want = exp[k][:, [pos[c] for c in sel]].astype(np.float32)
+            assert got.dtype == np.float32 and np.isfinite(got).all()
+            # float64 pipeline on both sides, compared after the fp32 cast: 1 fp32 ulp of slack
+            np.testing.assert_allclose(got, want, rtol=2.5e-7, atol=1e-7, err_msg=f"{what} {k} {name}")
+
+
+def run_preprocess_check(lib, device, golden_dir):
+    from deepof_amd.preprocess import preprocess_tables
+    g, cases, data = load_preprocess_golden(golden_dir)
+    first_scaler = None
+    for c in cases:
+        cols, aids, tabs = data[c["data"]]
+        node_cols, edge_cols, angle_cols = preprocess_output_columns(cols)
+        res = preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, samples_max=c["samples_max"],
+                                dist_standardize=c["dist"], speed_standardize=c["speed"], coord_standardize=c["coord"],
+                                log_distances=c["log"], interpolate_normalized=c["clip"], device=device, lib=lib)
+        exp = {k.split("::")[-1]: g[k] for k in g.files if k.startswith(c["case"] + "::out::")}
+        _check_tables(res, exp, cols, node_cols, edge_cols, angle_cols, c["case"])
+        for part in ("speed", "dist", "dist_inner", "dist_intra", "coord"):
+            key = f"{c['case']}::scaler::{part}::mean"
+            have = res.global_scaler is not None and res.global_scaler.get(part) is not None
+            assert have == (key in g.files), (c["case"], part)
+            if have:
+                np.testing.assert_allclose(res.global_scaler[part][0], g[key], rtol=1e-9, atol=1e-12, err_msg=key)
+                np.testing.assert_allclose(res.global_scaler[part][1], g[key.replace("mean", "scale")], rtol=1e-9, atol=1e-12)
+        if first_scaler is None:
+            first_scaler = (c, res.global_scaler)
+    # the fitted scalers re-applied to other videos (pretrained_scaler path)
+    c, gs = first_scaler
+    cols, aids, _ = data["pair"]
+    node_cols, edge_cols, angle_cols = preprocess_output_columns(cols)
+    new = {k.split("::")[-1]: g[k] for k in g.files if k.startswith("pair::pre::raw::")}
+    res = preprocess_tables(new, cols, aids, node_cols, edge_cols, angle_cols, dist_standardize=c["dist"],
+                            speed_standardize=c["speed"], coord_standardize=c["coord"], pretrained_scaler=gs, device=device, lib=lib)
+    _check_tables(res, {k: g[f"pair::pre::out::{k}"] for k in new}, cols, node_cols, edge_cols, angle_cols, "pretrained")
+
+
+def synth_raw_tables(n_videos, frames, bodyparts, seed, nan_rate=0.002):
+    """Random-walk pose tables (coords, speeds, all pairwise distances) with sparse gaps; float64 (frames, C) per video."""
+    from itertools import combinations
+    rng = np.random.default_rng(seed)
+    cols = [(bp, ax) for bp in bodyparts for ax in ("x", "y")] + list(bodyparts) + [tuple(p) for p in combinations(bodyparts, 2)]
+    pairs = [c for c in cols if isinstance(c, tuple) and c[1] not in ("x", "y")]
+    ia = np.array([bodyparts.index(p[0]) for p in pairs])
+    ib = np.array([bodyparts.index(p[1]) for p in pairs])
+    tabs = {}
+    for v in range(n_videos):
+        n = frames if np.isscalar(frames) else frames[v]
+        pos = np.cumsum(rng.standard_normal((n, len(bodyparts), 2)), axis=0) + rng.uniform(-30, 30, (len(bodyparts), 2)) * (1 + 0.3 * v)
+        speed = np.concatenate([np.zeros((1, len(bodyparts))), np.linalg.norm(np.diff(pos, axis=0), axis=2)])
+        dist = np.linalg.norm(pos[:, ia] - pos[:, ib], axis=2)
+        t = np.concatenate([pos.reshape(n, -1), speed, dist], axis=1)
+        t[rng.random(t.shape) < nan_rate] = np.nan
+        tabs[f"v{v:03d}"] = t
+    return tabs, cols
+
+
+def run_preprocess_vs_oracle(lib, device, n_videos=3, frames=(300, 97, 161), seed=5, samples_max=227272, **modes):
+    """Device path against the (reference-pinned) oracle on larger random tables; tiles, strips and videos ragged."""
+    from deepof_amd.preprocess import preprocess_tables
+    from oracle import preprocess as op
+    bps = [f"{a}_{p}" for a in ("B", "W") for p in ("Nose", "Center", "Tail_base", "Left_ear", "Right_ear")]
+    tabs, cols = synth_raw_tables(n_videos, frames, bps, seed, nan_rate=0.02)
+    k0 = sorted(tabs)[0]
+    tabs[k0][:40, 3] = np.nan                          # a leading gap longer than a tile
+    tabs[k0][100:230, 7] = np.nan                      # an interior gap spanning several tiles
+    tabs[k0][-50:, len(bps) * 2 + 1] = np.nan          # a trailing gap
+    node_cols, edge_cols, angle_cols = preprocess_output_columns(cols)
+    kw = dict(dist_standardize=modes.get("dist", "groupwise"), speed_standardize=modes.get("speed", "groupwise"),
+              coord_standardize=modes.get("coord", "groupwise"))
+    want, gs = op.preprocess(tabs, cols, ["B", "W"], samples_max=samples_max, **kw)
+    res = preprocess_tables(tabs, cols, ["B", "W"], node_cols, edge_cols, angle_cols, samples_max=samples_max, device=device, lib=lib, **kw)
+    _check_tables(res, want, cols, node_cols, edge_cols, angle_cols, f"oracle {modes}")
+    sf = res.size_factors.cpu().numpy()
+    for i, k in enumerate(res.keys):
+        s_by, dflt = op.size_factors(tabs[k], cols, ["B", "W"])
+        np.testing.assert_allclose(sf[i], [s_by["B"], s_by["W"], dflt], rtol=1e-15, atol=0)   # exact selection
+    return res

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from deepof_amd.engine import VadeEngine
+import parity_common as PC
 from emu_util import emu_lib
 from parity_common import gather_check, load_golden, params_from, run_phase_check, run_trace_check, run_vqvae_check
 
@@ -84,3 +85,18 @@ def test_distillation_head_emu(golden_dir):
 def test_vade_tcn_padded_decoder_input_emu(L):
     from parity_common import run_vade_tcn_vs_oracle
     run_vade_tcn_vs_oracle(emu_lib(), "cpu", L=L)
+
+
+def test_preprocess_tables_emu(golden_dir):
+    """N2: device preprocessing (emulated kernels) against the outputs of the reference's scale_table / _pp_* run."""
+    PC.run_preprocess_check(emu_lib(), "cpu", golden_dir)
+
+
+@pytest.mark.parametrize("modes", [dict(), dict(dist="per_column", speed="per_column", coord="per_column"),
+                                   dict(dist=None, speed="groupwise", coord="per_column")])
+def test_preprocess_tables_vs_oracle_emu(modes):
+    PC.run_preprocess_vs_oracle(emu_lib(), "cpu", **modes)
+
+
+def test_preprocess_tables_sampled_rows_emu():
+    PC.run_preprocess_vs_oracle(emu_lib(), "cpu", samples_max=120, seed=9)

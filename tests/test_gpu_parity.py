@@ -18,7 +18,7 @@ def hip():
 def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == 7
+    assert hip.dof_abi_version() == 8
 
 
 def test_gather_gpu(hip):
@@ -549,3 +549,63 @@ def test_full_size_c5(hip):
     np.testing.assert_allclose(out["z"][:48].cpu().numpy(), ref["z"].numpy(), atol=5e-5, rtol=1e-3)
     np.testing.assert_allclose(out["q"][:48].cpu().numpy(), ref["q"].numpy(), atol=5e-5, rtol=5e-3)
     np.testing.assert_allclose(out["loc"][:48].cpu().numpy(), ref["loc"].numpy(), atol=2e-4, rtol=1e-3)
+
+
+# ---- pose-table preprocessing ---------------------------------------------------------
+def test_preprocess_tables_gpu(hip, golden_dir):
+    """Device preprocessing against the outputs of the reference's own scale_table / _pp_* functions (7 configurations
+    + the pretrained-scaler path): every frame-table element within 1 fp32 ulp, scalers to 1e-9."""
+    import parity_common as PC
+    PC.run_preprocess_check(hip, "cuda", golden_dir)
+
+
+@pytest.mark.parametrize("modes", [dict(), dict(dist="per_column", speed="per_column", coord="per_column"),
+                                   dict(dist=None, speed="groupwise", coord="per_column")])
+def test_preprocess_tables_vs_oracle_gpu(hip, modes):
+    import parity_common as PC
+    PC.run_preprocess_vs_oracle(hip, "cuda", **modes)
+    PC.run_preprocess_vs_oracle(hip, "cuda", samples_max=120, seed=9, **modes)
+    PC.run_preprocess_vs_oracle(hip, "cuda", n_videos=5, frames=(2000, 33, 4097, 31, 640), seed=11, **modes)
+
+
+def test_preprocess_full_size_c2(hip):
+    """BASELINE C2's data set (600k frames, 14 body parts -> 133 raw columns, 40 videos) through the device pipeline:
+    size-independent properties + the oracle on two whole videos under the device-fitted scalers + windows."""
+    import parity_common as PC
+    from deepof_amd.dataset import WindowDataset
+    from deepof_amd.preprocess import preprocess_tables
+    from oracle import preprocess as op
+    bps = ["Nose", "Left_ear", "Right_ear", "Spine_1", "Center", "Spine_2", "Left_fhip", "Right_fhip", "Left_bhip", "Right_bhip",
+           "Tail_base", "Tail_1", "Tail_2", "Tail_tip"]
+    tabs, cols = PC.synth_raw_tables(40, 15_000, bps, seed=3, nan_rate=0.001)
+    node_cols, edge_cols, _ = PC.preprocess_output_columns(cols)
+    edge_cols = edge_cols[:14]
+    kw = dict(dist_standardize="groupwise", speed_standardize="groupwise", coord_standardize="groupwise")
+    res = preprocess_tables(tabs, cols, [""], node_cols, edge_cols, (), device="cuda", lib=hip, **kw)
+    assert res.node_table.shape == (600_000, 42) and res.edge_table.shape == (600_000, 14)
+    assert bool(torch.isfinite(res.node_table).all()) and bool(torch.isfinite(res.edge_table).all())
+    # (1) moments: a groupwise-standardised section has mean 0 / variance 1 over all frames (gaps are rare, clipped
+    #     values rarer), and each video's speeds alone do too (per-video standardisation)
+    nt = res.node_table.double()
+    xy, sp = nt[:, :28], nt[:, 28:]
+    assert abs(float(xy.mean())) < 2e-3 and abs(float(xy.var(unbiased=False)) - 1) < 5e-3
+    assert abs(float(sp.mean())) < 5e-3 and abs(float(sp.var(unbiased=False)) - 1) < 3e-2
+    v7 = sp[int(res.video_off[7]):int(res.video_off[8])]
+    assert abs(float(v7.mean())) < 1e-2 and abs(float(v7.var(unbiased=False)) - 1) < 5e-2
+    # (2) parts vs whole: with the fitted scalers passed back in, any subset of videos reproduces its rows bit for bit
+    some = {k: tabs[k] for k in ("v003", "v021")}
+    part = preprocess_tables(some, cols, [""], node_cols, edge_cols, (), pretrained_scaler=res.global_scaler, device="cuda", lib=hip, **kw)
+    for i, k in enumerate(part.keys):
+        j = res.keys.index(k)
+        lo, hi = int(res.video_off[j]), int(res.video_off[j + 1])
+        assert torch.equal(part.node_table[int(part.video_off[i]):int(part.video_off[i + 1])], res.node_table[lo:hi])
+        assert torch.equal(part.edge_table[int(part.video_off[i]):int(part.video_off[i + 1])], res.edge_table[lo:hi])
+    # (3) the oracle on those two whole videos under the same scalers
+    want, _ = op.preprocess(some, cols, [""], pretrained_scaler=res.global_scaler, **kw)
+    PC._check_tables(part, want, cols, node_cols, edge_cols, [], "c2 subset vs oracle")
+    # (4) straight into the window builder: windows never cross videos, values are the table rows
+    ds = WindowDataset.from_device_tables(res, 25, 1, hip)
+    assert len(ds) == 40 * (15_000 - 24)
+    x, a = ds.fetch(14_975, 14_978)         # last window of video 0 and the first two of video 1
+    assert torch.equal(x[0, :, :, 0], res.node_table[14_975:15_000, :14]) and torch.equal(x[1, :, :, 0], res.node_table[15_000:15_025, :14])
+    assert torch.equal(a[2, :, :, 0], res.edge_table[15_001:15_026])

@@ -418,3 +418,62 @@ def test_distillation_head_matches_reference(golden_dir):
     for k in d:
         if k.startswith("dist::grad::"):
             np.testing.assert_allclose(grads[k[12:]].numpy(), d[k], atol=2e-5, rtol=3e-4, err_msg=k)
+
+
+# ---- pose-table preprocessing ---------------------------------------------------------
+def load_preprocess_golden():
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess.npz"))
+    cases = json.loads(str(g["cases"]))
+    data = {}
+    for tag in ("pair", "single"):
+        cols = [tuple(c) if isinstance(c, list) else c for c in json.loads(str(g[f"{tag}::columns"]))]
+        tabs = {k.split("::")[-1]: g[k] for k in g.files if k.startswith(f"{tag}::raw::")}
+        data[tag] = (cols, json.loads(str(g[f"{tag}::animal_ids"])), tabs)
+    return g, cases, data
+
+
+def test_preprocess_oracle_matches_reference():
+    from oracle import preprocess as op
+    g, cases, data = load_preprocess_golden()
+    for c in cases:
+        cols, aids, tabs = data[c["data"]]
+        out, gs = op.preprocess(tabs, cols, aids, samples_max=c["samples_max"], dist_standardize=c["dist"],
+                                speed_standardize=c["speed"], coord_standardize=c["coord"], log_distances=c["log"],
+                                interpolate_normalized=c["clip"])
+        exp = {k.split("::")[-1]: g[k] for k in g.files if k.startswith(c["case"] + "::out::")}
+        assert sorted(out) == sorted(exp), c["case"]
+        for k in exp:
+            assert np.isfinite(out[k]).all()
+            np.testing.assert_allclose(out[k], exp[k], rtol=1e-11, atol=1e-11, err_msg=f"{c['case']} {k}")
+        for part in ("speed", "dist", "dist_inner", "dist_intra", "coord"):
+            key = f"{c['case']}::scaler::{part}::mean"
+            assert (key in g.files) == (part in gs), (c["case"], part)
+            if part in gs:
+                np.testing.assert_allclose(np.atleast_1d(gs[part][0]), g[key], rtol=1e-11, atol=1e-12)
+                np.testing.assert_allclose(np.atleast_1d(gs[part][1]), g[key.replace("mean", "scale")], rtol=1e-11, atol=1e-12)
+    # pretrained scaler re-applied to new videos
+    cols, aids, _ = data["pair"]
+    c = cases[0]
+    _, gs = op.preprocess(data["pair"][2], cols, aids, dist_standardize=c["dist"], speed_standardize=c["speed"],
+                          coord_standardize=c["coord"])
+    new = {k.split("::")[-1]: g[k] for k in g.files if k.startswith("pair::pre::raw::")}
+    out, _ = op.preprocess(new, cols, aids, dist_standardize=c["dist"], speed_standardize=c["speed"], coord_standardize=c["coord"],
+                           pretrained_scaler=gs)
+    for k in new:
+        np.testing.assert_allclose(out[k], g[f"pair::pre::out::{k}"], rtol=1e-11, atol=1e-11)
+
+
+def test_scale_table_oracle_matches_reference():
+    from oracle import preprocess as op
+    g, _, data = load_preprocess_golden()
+    cols, aids, tabs = data["pair"]
+    t = tabs["vid0"]
+    runs = {"size_only": dict(standardize=False), "geom": dict(inter_scale="geom", standardize=False), "full_pc": dict(),
+            "full_gw": dict(dist_standardize="groupwise", speed_standardize="groupwise", coord_standardize="groupwise"),
+            "infer_ids": dict(animal_ids=None)}
+    for nm, kw in runs.items():
+        kw = dict(kw)
+        aid = kw.pop("animal_ids", aids)
+        np.testing.assert_allclose(op.scale_table(t, cols, aid, **kw), g[f"scale_table::{nm}"], rtol=1e-12, atol=1e-12,
+                                   equal_nan=True, err_msg=nm)
