@@ -13,8 +13,8 @@
 // Passes over the raw table (8 B/element each; everything else is O(videos x columns)):
 //   k_pp_size     4 columns per animal: hypot(nose - tail base) -> exact nan-median by bitwise bisection
 //   k_pp_stats    one pass: shifted sums per (video, strip, column) -> (n, mean, M2), all rows and sampled rows
-//   k_pp_edges    first / last valid row per (32-row tile, output column) under the final transform
-//   k_pp_finish   transform, clip, interpolate across the tile (neighbours from k_pp_carry), cast, write fp32
+//   k_pp_finish   output columns only: transform, clip, interpolate inside a 32-row tile, cast, write fp32
+//   k_pp_fill     closes the (rare) gaps that reach a tile edge from the tiles' first / last valid-row notes
 // The per-video and the global StandardScaler statistics come from the ONE statistics pass: the per-video
 // transform is affine per column, so the statistics of the per-video-standardised samples follow from
 // (n, mean, M2) of the sampled rows, merged over videos with Chan's pairwise update in a fixed order
@@ -29,7 +29,7 @@
 namespace {
 
 constexpr int PP_RS = 256;  // rows per statistics strip
-constexpr int PP_TR = 32;   // rows per interpolation tile
+constexpr int PP_TR = 8;    // rows per output tile (one thread owns a column of it)
 constexpr double PP_EPS = 2.220446049250313e-16;
 
 struct PpStat {
@@ -106,12 +106,18 @@ __device__ __forceinline__ int pp_mode(int kind, int speed_mode, int dist_mode, 
 
 // ---------------------------------------------------------------------------------------------------------
 // size factor of animal a in video v: nan-median over the video's rows of hypot(nose - tail base).
-// Exact selection without a sort: the order statistics (n-1)/2 and n/2 are built bit by bit from the top
-// (non-negative doubles order like their bit patterns), one counting sweep of the L2-resident lengths per bit.
+// Exact selection without a sort: non-negative doubles order like their bit patterns, so the order statistics
+// (n-1)/2 and n/2 are found digit by digit from the top -- 8 sweeps of the (L2-resident) lengths, each building a
+// 256-bin histogram of the next 8 bits among the values that share the prefix found so far (integer LDS atomics:
+// order-independent, so the result is deterministic).
 __global__ void __launch_bounds__(256) k_pp_size(const double* __restrict__ raw, const int64_t* __restrict__ video_off,
                                                  const int* __restrict__ size_ref, int C, int A, int64_t F,
                                                  double* __restrict__ hyp, double* __restrict__ s_out) {
-  __shared__ long long red[2][256];
+  __shared__ int hist[2][4][256];
+  __shared__ int red[256];
+  __shared__ unsigned long long mm[2][256];
+  __shared__ unsigned long long sel[2];
+  __shared__ int krem[2];
   const int a = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
   const int c0 = size_ref[4 * a], c1 = size_ref[4 * a + 1], c2 = size_ref[4 * a + 2], c3 = size_ref[4 * a + 3];
   double* out = s_out + (int64_t)v * (A + 1) + a;
@@ -121,53 +127,106 @@ __global__ void __launch_bounds__(256) k_pp_size(const double* __restrict__ raw,
   }
   const int64_t r0 = video_off[v], r1 = video_off[v + 1];
   double* h = hyp + (int64_t)a * F;
-  long long nv = 0;
-  for (int64_t r = r0 + tid; r < r1; r += 256) {
-    const double* row = raw + r * C;
-    const double len = hypot(row[c0] - row[c2], row[c1] - row[c3]);
-    h[r] = len;
-    nv += !pp_isnan(len);
+  int nv = 0;
+  for (int64_t rb = r0 + tid; rb < r1; rb += 256 * 4) {
+    double len[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = rb + 256 * i;
+      if (r < r1) {
+        const double* row = raw + r * C;
+        len[i] = hypot(row[c0] - row[c2], row[c1] - row[c3]);
+      } else {
+        len[i] = pp_nanv();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = rb + 256 * i;
+      if (r < r1) h[r] = len[i];
+      nv += !pp_isnan(len[i]);
+    }
   }
-  red[0][tid] = nv;
+  red[tid] = nv;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[0][tid] += red[0][tid + s];
+    if (tid < s) red[tid] += red[tid + s];
     __syncthreads();
   }
-  const long long n = red[0][0];
-  __syncthreads();
+  const int n = red[0];
   if (n == 0) {
     if (tid == 0) *out = pp_nanv();
     return;
   }
-  const long long k1 = (n - 1) / 2, k2 = n / 2;
-  uint64_t res1 = 0, res2 = 0;
-  for (int bit = 62; bit >= 0; --bit) {
-    const uint64_t t1 = res1 | (1ull << bit), t2 = res2 | (1ull << bit);
-    long long q1 = 0, q2 = 0;
-    for (int64_t r = r0 + tid; r < r1; r += 256) {
-      const double len = h[r];
-      if (!pp_isnan(len)) {
-        const uint64_t key = pp_bits(len);
-        q1 += key < t1;
-        q2 += key < t2;
-      }
+  // every key shares the bits above the highest bit in which the smallest and the largest key differ: start the
+  // digit walk there (the top bytes -- sign, exponent -- would otherwise put all values into one or two bins and
+  // serialise the LDS atomics)
+  unsigned long long kmin = ~0ull, kmax = 0ull;
+  for (int64_t r = r0 + tid; r < r1; r += 256) {
+    const double len = h[r];
+    if (!pp_isnan(len)) {
+      const unsigned long long key = pp_bits(len);
+      kmin = key < kmin ? key : kmin;
+      kmax = key > kmax ? key : kmax;
     }
-    red[0][tid] = q1;
-    red[1][tid] = q2;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) {
-        red[0][tid] += red[0][tid + s];
-        red[1][tid] += red[1][tid + s];
-      }
-      __syncthreads();
+  }
+  mm[0][tid] = kmin;
+  mm[1][tid] = kmax;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      mm[0][tid] = mm[0][tid + s] < mm[0][tid] ? mm[0][tid + s] : mm[0][tid];
+      mm[1][tid] = mm[1][tid + s] > mm[1][tid] ? mm[1][tid + s] : mm[1][tid];
     }
-    if (red[0][0] <= k1) res1 = t1;
-    if (red[1][0] <= k2) res2 = t2;
     __syncthreads();
   }
-  if (tid == 0) *out = (pp_from_bits(res1) + pp_from_bits(res2)) / 2.0;
+  const unsigned long long diff = mm[0][0] ^ mm[1][0];
+  int top = 0;  // shift of the highest byte that differs
+  while (top < 56 && (diff >> (top + 8)) != 0ull) top += 8;
+  if (tid == 0) {
+    sel[0] = sel[1] = top == 56 ? 0ull : mm[0][0] & (~0ull << (top + 8));
+    krem[0] = (n - 1) / 2;
+    krem[1] = n / 2;
+  }
+  const int wv = tid >> 6;
+  for (int shift = top; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 2 * 4 * 256; i += 256) (&hist[0][0][0])[i] = 0;
+    __syncthreads();
+    const unsigned long long p0 = sel[0], p1 = sel[1];
+    const unsigned long long himask = shift == 56 ? 0ull : ~0ull << (shift + 8);
+    for (int64_t rb = r0 + tid; rb < r1; rb += 256 * 8) {
+      double len[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t r = rb + 256 * i;
+        len[i] = r < r1 ? h[r] : pp_nanv();
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (!pp_isnan(len[i])) {
+          const unsigned long long key = pp_bits(len[i]);
+          const int digit = (int)((key >> shift) & 255);
+          if ((key & himask) == p0) atomicAdd(&hist[0][wv][digit], 1);
+          if ((key & himask) == p1) atomicAdd(&hist[1][wv][digit], 1);
+        }
+      }
+    }
+    __syncthreads();
+    hist[0][0][tid] += hist[0][1][tid] + hist[0][2][tid] + hist[0][3][tid];
+    hist[1][0][tid] += hist[1][1][tid] + hist[1][2][tid] + hist[1][3][tid];
+    __syncthreads();
+    if (tid < 2) {
+      int k = krem[tid], d = 0;
+      while (d < 255 && k >= hist[tid][0][d]) {
+        k -= hist[tid][0][d];
+        ++d;
+      }
+      krem[tid] = k;
+      sel[tid] |= (unsigned long long)d << shift;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *out = (pp_from_bits(sel[0]) + pp_from_bits(sel[1])) / 2.0;
 }
 
 // default factor (median of the usable factors, else 1), substitution of unusable factors, and the reciprocal
@@ -213,101 +272,282 @@ __global__ void __launch_bounds__(256) k_pp_divisors(const int* __restrict__ cha
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The statistics pass.  A workgroup = one strip of PP_RS rows of one video; lanes run along the columns
-// (a row is one contiguous 8C-byte run, so a wavefront reads 512 contiguous bytes), 4 wavefronts interleave
-// the rows.  Per-thread sums are taken about the first value seen (no cancellation), turned into
-// (n, mean, M2) and merged 4 -> 1 in LDS; the strip's result is a partial for the fixed-order finalize.
-__global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw, const int64_t* __restrict__ video_off,
-                                                  const int* __restrict__ col_kind, const double* __restrict__ rdiv,
-                                                  const uint8_t* __restrict__ mask, int V, int C, int log_dist,
-                                                  int speed_mode, int dist_mode, int coord_mode,
-                                                  PpStat* __restrict__ part_all, PpStat* __restrict__ part_smp) {
-  __shared__ PpStat sh[2][4][64];
+// slot -> video table (one binary search per slot here instead of one per workgroup in every pass); the tile
+// table also carries the tile's first row and row count: (video or -1, global row, row within the video, rows)
+__global__ void __launch_bounds__(256) k_pp_slot_table(const int64_t* __restrict__ video_off, int V, int R, int64_t n_slots,
+                                                       int* __restrict__ slot_v, int* __restrict__ slot_rec) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_slots) return;
   int v;
-  int64_t strip;
-  const bool live = pp_locate(video_off, V, PP_RS, blockIdx.x, &v, &strip);
-  if (!live) return;
-  const int64_t r0 = video_off[v] + strip * PP_RS;
-  const int64_t vend = video_off[v + 1];
+  int64_t k;
+  const bool live = pp_locate(video_off, V, R, b, &v, &k);
+  if (slot_v) slot_v[b] = live ? v : -1;
+  if (slot_rec) {
+    const int64_t voff = video_off[v], left = video_off[v + 1] - voff - k * R;
+    slot_rec[4 * b] = live ? v : -1;
+    slot_rec[4 * b + 1] = (int)(voff + k * R);
+    slot_rec[4 * b + 2] = (int)(k * R);
+    slot_rec[4 * b + 3] = live ? (int)(left < R ? left : R) : 0;
+  }
+}
+
+// Column chunks: runs of <= 64 consecutive columns (of the raw table, or of the output column list `index`) that
+// agree on "takes log1p", so a wavefront never pays for the logarithm on behalf of a few lanes.
+// chunks[0] = count, then (start, n, log) triples.  One thread per column, two Hillis-Steele scans in LDS
+// (run start = prefix max of the flip positions, chunk number = prefix sum of the chunk starts).
+__global__ void __launch_bounds__(DOF_PP_MAX_COLS) k_pp_chunks(const int* __restrict__ col_kind, const int* __restrict__ index,
+                                                               int n_cols, int log_dist, int* __restrict__ chunks) {
+  __shared__ int lg[DOF_PP_MAX_COLS], a[DOF_PP_MAX_COLS], b[DOF_PP_MAX_COLS];
+  const int c = threadIdx.x;
+  int mine = 0;
+  if (c < n_cols) {
+    const int k = col_kind[index ? index[c] : c];
+    mine = log_dist && (k == DOF_PP_DIST_INNER || k == DOF_PP_DIST_INTRA);
+  }
+  lg[c] = mine;
+  __syncthreads();
+  a[c] = (c < n_cols && (c == 0 || lg[c - 1] != mine)) ? c : -1;  // run starts
+  __syncthreads();
+  for (int off = 1; off < DOF_PP_MAX_COLS; off <<= 1) {
+    const int o = c >= off ? a[c - off] : -1;
+    __syncthreads();
+    if (o > a[c]) a[c] = o;
+    __syncthreads();
+  }
+  const int run0 = a[c];
+  const int start = c < n_cols && ((c - run0) & 63) == 0;  // a chunk starts every 64 columns of a run
+  b[c] = start;
+  __syncthreads();
+  for (int off = 1; off < DOF_PP_MAX_COLS; off <<= 1) {
+    const int o = c >= off ? b[c - off] : 0;
+    __syncthreads();
+    b[c] += o;
+    __syncthreads();
+  }
+  if (c < n_cols) {
+    // chunk length: up to the next chunk start or the end of the run
+    if (start) {
+      int e = c + 1;
+      while (e < n_cols && e - c < 64 && lg[e] == mine) ++e;
+      const int n = b[c] - 1;
+      chunks[1 + 3 * n] = c;
+      chunks[2 + 3 * n] = e - c;
+      chunks[3 + 3 * n] = mine;
+    }
+    if (c == n_cols - 1) chunks[0] = b[c];
+  }
+}
+
+// Reference-accuracy logarithm of c in [1, 2] (argument reduction s = f / (2 + f), fdlibm's e_log minimax
+// coefficients, < 1 ulp); only used to fill the 128-entry table below.
+__device__ __forceinline__ double pp_log_1to2(double c) {
+  double m = c;
+  double dk = 0.0;
+  if (m > 1.4142135623730951) {
+    m *= 0.5;
+    dk = 1.0;
+  }
+  const double f = m - 1.0, s = f / (2.0 + f), z = s * s, w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 +
+                         w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const double r = t1 + t2, hfsq = 0.5 * f * f;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + r) + dk * 1.90821492927058770002e-10)) - f);
+}
+// tab[i] = (1 / c_i, log c_i), c_i = 1 + (i + 1/2) / 128: call with all threads of the block, then __syncthreads()
+__device__ __forceinline__ void pp_log_table_init(double (*tab)[2]) {
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+    const double c = 1.0 + ((double)i + 0.5) / 128.0;
+    tab[i][0] = 1.0 / c;
+    tab[i][1] = pp_log_1to2(c);
+  }
+}
+// log1p for x >= 0 (negative distances were clamped): log(u) + (x - (u - 1)) / u with u = fl(1 + x) = 2^k m, m in
+// [1, 2): the top 7 mantissa bits pick c_i from the table, r = m / c_i - 1 (|r| <= 2^-8, one fma), log(1 + r) is a
+// degree-7 Taylor polynomial (remainder < 2^-67), log u = k ln2 + log c_i + log(1 + r).  Absolute error ~1e-16, a
+// third of the instructions of the general-purpose library routine, which made the statistics pass compute-bound.
+__device__ __forceinline__ double pp_log1p(double x, const double (*tab)[2]) {
+  if (!(x < INFINITY)) return x;  // +inf or NaN
+  const double u = 1.0 + x;
+  const double c = x - (u - 1.0);
+  const uint64_t bits = pp_bits(u);
+  const unsigned hi = (unsigned)(bits >> 32);
+  const double dk = (double)((int)(hi >> 20) - 1023);
+  const int i = (int)((hi >> 13) & 127u);
+  const double m = pp_from_bits((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+  const double r = fma(m, tab[i][0], -1.0);
+  double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+  p = fma(r, p, 1.0 / 5.0);
+  p = fma(r, p, -1.0 / 4.0);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  const double lg = fma(dk, 6.93147180369123816490e-01, tab[i][1] + fma(r, p, dk * 1.90821492927058770002e-10));
+  const double res = lg + c * (double)(1.0f / (float)u);
+  return x == 0.0 ? 0.0 : res;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The statistics pass.  A workgroup = one strip of PP_RS rows of one video; lanes run along the columns of a chunk
+// (a row is one contiguous 8C-byte run, so a wavefront reads up to 512 contiguous bytes).  A chunk narrower than
+// 32 columns is packed 2x / 4x ... along the rows so that no wavefront idles most of its lanes; the 4 wavefronts
+// interleave the remaining rows, 8 independent loads in flight per lane.  Per-thread sums are taken about the
+// first value seen (no cancellation), turned into (n, mean, M2) and merged in LDS in a fixed order; the strip's
+// result is a partial for the fixed-order finalize.
+template <bool MASKED>
+__global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw, const int64_t* __restrict__ video_off,
+                                                  const int* __restrict__ slot_v, const int* __restrict__ chunks,
+                                                  const int* __restrict__ col_kind, const double* __restrict__ rdiv,
+                                                  const uint8_t* __restrict__ mask, int C, int speed_mode, int dist_mode,
+                                                  int coord_mode, PpStat* __restrict__ part_all,
+                                                  PpStat* __restrict__ part_smp) {
+  __shared__ PpStat sh[2][4][64];
+  __shared__ double logtab[128][2];
+  const int v = slot_v[blockIdx.x];
+  if (v < 0) return;
+  pp_log_table_init(logtab);
+  __syncthreads();
+  const int64_t voff = video_off[v], vend = video_off[v + 1];
+  const int64_t r0 = voff + ((int64_t)blockIdx.x - (voff / PP_RS + v)) * PP_RS;
   const int64_t r1 = r0 + PP_RS < vend ? r0 + PP_RS : vend;
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  for (int cbase = 0; cbase < C; cbase += 64) {
-    const int c = cbase + lane;
+  const int nchunk = chunks[0];
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int cbase = chunks[1 + 3 * ch], ccount = chunks[2 + 3 * ch], lg = chunks[3 + 3 * ch];
+    int width = 64;  // lanes per row: smallest power of two >= ccount
+    while (width / 2 >= ccount && width > 1) width >>= 1;
+    const int pack = 64 / width, sub = lane / width, cl = lane - sub * width;
+    const int c = cbase + cl;
     double n = 0.0, shift = 0.0, s1 = 0.0, s2 = 0.0, nb = 0.0, s1b = 0.0, s2b = 0.0;
-    bool need = false;
-    if (c < C) {
-      const int kind = col_kind[c];
-      need = pp_mode(kind, speed_mode, dist_mode, coord_mode) != DOF_PP_MODE_NONE;
-      if (need) {
-        const double rd = rdiv[(int64_t)v * C + c];
-        const bool lg = log_dist && (kind == DOF_PP_DIST_INNER || kind == DOF_PP_DIST_INTRA);
-        for (int64_t r = r0 + rg; r < r1; r += 4) {
-          double u = raw[r * C + c] * rd;
+    const bool mine = cl < ccount && pp_mode(col_kind[c], speed_mode, dist_mode, coord_mode) != DOF_PP_MODE_NONE;
+    if (mine) {
+      const double rd = rdiv[(int64_t)v * C + c];
+      const int rstep = 4 * pack;
+      for (int64_t rb = r0 + rg * pack + sub; rb < r1; rb += 8 * rstep) {
+        double x[8];
+        bool in[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int64_t r = rb + rstep * i;
+          in[i] = MASKED && r < r1 && mask[r];
+          x[i] = r < r1 ? raw[r * C + c] : pp_nanv();
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          double u = x[i] * rd;
           if (lg) {
             if (u < 0.0) u = 0.0;
-            u = log1p(u);
+            u = pp_log1p(u, logtab);
           }
-          if (!pp_isnan(u)) {
-            if (n == 0.0) shift = u;
-            const double d = u - shift;
-            n += 1.0;
-            s1 += d;
-            s2 += d * d;
-            if (mask && mask[r]) {
-              nb += 1.0;
-              s1b += d;
-              s2b += d * d;
-            }
+          const bool ok = !pp_isnan(u);
+          if (ok && n == 0.0) shift = u;
+          const double d = ok ? u - shift : 0.0;
+          n += ok ? 1.0 : 0.0;
+          s1 += d;
+          s2 += d * d;
+          if (MASKED) {
+            const bool smp = ok && in[i];
+            nb += smp ? 1.0 : 0.0;
+            s1b += smp ? d : 0.0;
+            s2b += smp ? d * d : 0.0;
           }
         }
       }
     }
     sh[0][rg][lane] = pp_from_sums(n, shift, s1, s2);
-    sh[1][rg][lane] = mask ? pp_from_sums(nb, shift, s1b, s2b) : sh[0][rg][lane];
+    sh[1][rg][lane] = MASKED ? pp_from_sums(nb, shift, s1b, s2b) : sh[0][rg][lane];
     __syncthreads();
-    if (rg < 2 && c < C) {
-      PpStat t = sh[rg][0][lane];
-      for (int g = 1; g < 4; ++g) t = pp_merge(t, sh[rg][g][lane]);
+    if (rg < 2 && lane < ccount) {
+      PpStat t = {0.0, 0.0, 0.0};
+      for (int g = 0; g < 4; ++g)
+        for (int k = 0; k < pack; ++k) t = pp_merge(t, sh[rg][g][k * width + lane]);
       (rg == 0 ? part_all : part_smp)[(int64_t)blockIdx.x * C + c] = t;
     }
     __syncthreads();
   }
 }
 
-// per video: strips -> columns -> groups; per-video (mean, scale); statistics of the per-video-standardised
-// sampled rows (what the global scalers are fitted on)
-__global__ void __launch_bounds__(256) k_pp_video_fin(const int64_t* __restrict__ video_off,
-                                                      const int* __restrict__ col_kind,
-                                                      const PpStat* __restrict__ part_all,
-                                                      const PpStat* __restrict__ part_smp, int C, int speed_mode,
+// one of 4 interleaved sub-sequences (rg) of `count` partials (stride in PpStat units), merged in a fixed order,
+// 8 loads in flight
+__device__ __forceinline__ PpStat pp_merge_run(const PpStat* __restrict__ base, int64_t count, int64_t stride, int rg) {
+  PpStat acc = {0.0, 0.0, 0.0};
+  for (int64_t k = rg; k < count; k += 32) {
+    PpStat t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t kk = k + 4 * i;
+      if (kk < count) t[i] = base[kk * stride]; else t[i].n = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = pp_merge(acc, t[i]);
+  }
+  return acc;
+}
+
+// strips -> (video, column) statistics, all rows and sampled rows: one workgroup per (64-column chunk, video)
+__global__ void __launch_bounds__(256) k_pp_video_cols(const int64_t* __restrict__ video_off,
+                                                       const PpStat* __restrict__ part_all,
+                                                       const PpStat* __restrict__ part_smp, int C,
+                                                       PpStat* __restrict__ vcol_all, PpStat* __restrict__ vcol_smp) {
+  __shared__ PpStat sh[2][4][64];
+  const int v = blockIdx.y, lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t slot0 = video_off[v] / PP_RS + v;
+  const int64_t nstrip = (video_off[v + 1] - video_off[v] + PP_RS - 1) / PP_RS;
+  PpStat a = {0.0, 0.0, 0.0}, s = {0.0, 0.0, 0.0};
+  if (c < C) {
+    a = pp_merge_run(part_all + slot0 * C + c, nstrip, C, rg);
+    s = pp_merge_run(part_smp + slot0 * C + c, nstrip, C, rg);
+  }
+  sh[0][rg][lane] = a;
+  sh[1][rg][lane] = s;
+  __syncthreads();
+  if (rg < 2 && c < C) {
+    PpStat t = sh[rg][0][lane];
+    for (int g = 1; g < 4; ++g) t = pp_merge(t, sh[rg][g][lane]);
+    (rg == 0 ? vcol_all : vcol_smp)[(int64_t)v * C + c] = t;
+  }
+}
+
+// statistics of column groups: wavefront w merges the columns of kind kind0 + w (its 64 lanes stride over the
+// columns, then a 6-step tree in LDS); fixed order, run-to-run deterministic.  tree: [4][64] scratch.
+__device__ __forceinline__ void pp_group_stats(const PpStat* __restrict__ col, const int* __restrict__ kinds, int C,
+                                               int kind0, int n_groups, PpStat (*tree)[64], PpStat* __restrict__ grp) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  PpStat acc = {0.0, 0.0, 0.0};
+  if (w < n_groups)
+    for (int c = lane; c < C; c += 64)
+      if (kinds[c] == kind0 + w) acc = pp_merge(acc, col[c]);
+  tree[w][lane] = acc;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (lane < s) tree[w][lane] = pp_merge(tree[w][lane], tree[w][lane + s]);
+    __syncthreads();
+  }
+  if (lane == 0 && w < n_groups) grp[w] = tree[w][0];
+  __syncthreads();
+}
+
+// per video: columns -> groups; per-video (mean, scale); statistics of the per-video-standardised sampled rows
+// (what the global scalers are fitted on)
+__global__ void __launch_bounds__(256) k_pp_video_fin(const int* __restrict__ col_kind,
+                                                      const PpStat* __restrict__ vcol_all,
+                                                      const PpStat* __restrict__ vcol_smp, int C, int speed_mode,
                                                       int dist_mode, double* __restrict__ vscale,
                                                       PpStat* __restrict__ ystat) {
   __shared__ PpStat col_all[DOF_PP_MAX_COLS];
-  __shared__ PpStat col_smp[DOF_PP_MAX_COLS];
-  __shared__ PpStat grp[3];
+  __shared__ int kinds[DOF_PP_MAX_COLS];
+  __shared__ PpStat tree[4][64];
+  __shared__ PpStat grp[4];
   const int v = blockIdx.x;
-  const int64_t slot0 = video_off[v] / PP_RS + v;
-  const int64_t nstrip = (video_off[v + 1] - video_off[v] + PP_RS - 1) / PP_RS;
   for (int c = threadIdx.x; c < C; c += 256) {
-    PpStat a = {0.0, 0.0, 0.0}, s = {0.0, 0.0, 0.0};
-    for (int64_t k = 0; k < nstrip; ++k) {
-      a = pp_merge(a, part_all[(slot0 + k) * C + c]);
-      s = pp_merge(s, part_smp[(slot0 + k) * C + c]);
-    }
-    col_all[c] = a;
-    col_smp[c] = s;
+    col_all[c] = vcol_all[(int64_t)v * C + c];
+    kinds[c] = col_kind[c];
   }
   __syncthreads();
-  if (threadIdx.x < 3) {
-    const int kind = DOF_PP_SPEED + threadIdx.x;  // speed, inner, intra
-    PpStat g = {0.0, 0.0, 0.0};
-    for (int c = 0; c < C; ++c)
-      if (col_kind[c] == kind) g = pp_merge(g, col_all[c]);
-    grp[threadIdx.x] = g;
-  }
-  __syncthreads();
+  pp_group_stats(col_all, kinds, C, DOF_PP_SPEED, 3, tree, grp);  // speed, inner, intra
   for (int c = threadIdx.x; c < C; c += 256) {
-    const int kind = col_kind[c];
+    const int kind = kinds[c];
     const int mode = kind == DOF_PP_SPEED ? speed_mode
                      : (kind == DOF_PP_DIST_INNER || kind == DOF_PP_DIST_INTRA) ? dist_mode : DOF_PP_MODE_NONE;
     double m = 0.0, s = 1.0;
@@ -315,7 +555,7 @@ __global__ void __launch_bounds__(256) k_pp_video_fin(const int64_t* __restrict_
     if (mode == DOF_PP_MODE_GROUPWISE) pp_fit(grp[kind - DOF_PP_SPEED], &m, &s);
     vscale[((int64_t)v * C + c) * 2] = m;
     vscale[((int64_t)v * C + c) * 2 + 1] = s;
-    PpStat y = col_smp[c];
+    PpStat y = vcol_smp[(int64_t)v * C + c];
     y.mean = (y.mean - m) / s;
     y.m2 = y.m2 / (s * s);
     if (pp_isnan(y.mean) || pp_isnan(y.m2)) y.n = 0.0;
@@ -323,47 +563,63 @@ __global__ void __launch_bounds__(256) k_pp_video_fin(const int64_t* __restrict_
   }
 }
 
-// global scalers: videos -> columns -> groups (speed, inner, intra, coord)
-__global__ void __launch_bounds__(256) k_pp_global_fin(const int* __restrict__ col_kind,
-                                                       const PpStat* __restrict__ ystat, int V, int C, int speed_mode,
-                                                       int dist_mode, int coord_mode, double* __restrict__ scaler) {
-  __shared__ PpStat col[DOF_PP_MAX_COLS];
-  __shared__ PpStat grp[4];
-  for (int c = threadIdx.x; c < C; c += 256) {
-    PpStat g = {0.0, 0.0, 0.0};
-    for (int v = 0; v < V; ++v) g = pp_merge(g, ystat[(int64_t)v * C + c]);
-    col[c] = g;
-  }
+// videos -> per-column statistics of the sampled, per-video-standardised rows: one workgroup per 64 columns
+__global__ void __launch_bounds__(256) k_pp_global_cols(const PpStat* __restrict__ ystat, int V, int C,
+                                                        PpStat* __restrict__ gcol) {
+  __shared__ PpStat sh[4][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  PpStat a = {0.0, 0.0, 0.0};
+  if (c < C) a = pp_merge_run(ystat + c, V, C, rg);
+  sh[rg][lane] = a;
   __syncthreads();
-  if (threadIdx.x < 4) {
-    const int kind = DOF_PP_COORD + threadIdx.x;  // coord, speed, inner, intra
-    PpStat g = {0.0, 0.0, 0.0};
-    for (int c = 0; c < C; ++c)
-      if (col_kind[c] == kind) g = pp_merge(g, col[c]);
-    grp[threadIdx.x] = g;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int kind = col_kind[c];
-    const int mode = pp_mode(kind, speed_mode, dist_mode, coord_mode);
-    double m = 0.0, s = 1.0;
-    if (mode != DOF_PP_MODE_NONE) {
-      const PpStat st = mode == DOF_PP_MODE_PER_COLUMN ? col[c] : grp[kind - DOF_PP_COORD];
-      pp_fit(st, &m, &s);  // nothing sampled -> NaN like the reference's 0/0 (such columns hold no value anyway)
-    }
-    scaler[2 * c] = m;
-    scaler[2 * c + 1] = s;
+  if (rg == 0 && c < C) {
+    PpStat t = sh[0][lane];
+    for (int g = 1; g < 4; ++g) t = pp_merge(t, sh[g][lane]);
+    gcol[c] = t;
   }
 }
 
-// coefficients of the complete element transform: u = x * cf[0] [log1p(max(u, 0))]; z = u * cf[1] + cf[2]
-__global__ void __launch_bounds__(256) k_pp_coef(const double* __restrict__ rdiv, const double* __restrict__ vscale,
-                                                 const double* __restrict__ scaler, int C, double* __restrict__ coef,
+// per video: the global scalers (columns -> groups coord / speed / inner / intra; every workgroup derives the same
+// values, workgroup 0 publishes them) and the coefficients of the complete element transform
+//   u = x * cf[0] [log1p(max(u, 0))];  z = u * cf[1] + cf[2]
+__global__ void __launch_bounds__(256) k_pp_coef(const int* __restrict__ col_kind, const PpStat* __restrict__ gcol,
+                                                 const double* __restrict__ rdiv, const double* __restrict__ vscale,
+                                                 double* __restrict__ scaler, int fit_global, int C, int speed_mode,
+                                                 int dist_mode, int coord_mode, double* __restrict__ coef,
                                                  double* __restrict__ video_scaler) {
+  __shared__ PpStat col[DOF_PP_MAX_COLS];
+  __shared__ int kinds[DOF_PP_MAX_COLS];
+  __shared__ PpStat tree[4][64];
+  __shared__ PpStat grp[4];
   const int v = blockIdx.x;
+  if (fit_global) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      col[c] = gcol[c];
+      kinds[c] = col_kind[c];
+    }
+    __syncthreads();
+    pp_group_stats(col, kinds, C, DOF_PP_COORD, 4, tree, grp);  // coord, speed, inner, intra
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
+    double gm, gs;
+    if (fit_global) {
+      const int kind = kinds[c];
+      const int mode = pp_mode(kind, speed_mode, dist_mode, coord_mode);
+      gm = 0.0;
+      gs = 1.0;
+      // nothing sampled -> NaN like the reference's 0/0 (such columns hold no value anyway)
+      if (mode != DOF_PP_MODE_NONE) pp_fit(mode == DOF_PP_MODE_PER_COLUMN ? col[c] : grp[kind - DOF_PP_COORD], &gm, &gs);
+      if (v == 0) {
+        scaler[2 * c] = gm;
+        scaler[2 * c + 1] = gs;
+      }
+    } else {
+      gm = scaler[2 * c];
+      gs = scaler[2 * c + 1];
+    }
     const int64_t i = (int64_t)v * C + c;
-    const double m = vscale[2 * i], s = vscale[2 * i + 1], gm = scaler[2 * c], gs = scaler[2 * c + 1];
+    const double m = vscale[2 * i], s = vscale[2 * i + 1];
     const double p = 1.0 / s, q = 1.0 / gs;
     coef[3 * i] = rdiv[i];
     coef[3 * i + 1] = p * q;
@@ -378,103 +634,26 @@ __global__ void __launch_bounds__(256) k_pp_coef(const double* __restrict__ rdiv
 struct PpOutArgs {
   const double* raw;
   const int64_t* video_off;
+  const int* slot_rec;  // (video or -1, global row, row within the video, rows) per PP_TR-row tile slot
   const int* col_kind;
   const int* out_cols;
   const double* coef;
-  int V, C, n_out, log_dist;
+  int64_t n_slots;
+  int C, n_out, n_node, n_edge, log_dist;
   double clip;
+  float *node_out, *edge_out, *angle_out;
 };
 
 // final value of raw element x of column c (coefficients cf); NaN when missing or clipped
-__device__ __forceinline__ double pp_value(double x, const double* __restrict__ cf, int kind, int log_dist, double clip) {
-  double u = x * cf[0];
-  if (log_dist && (kind == DOF_PP_DIST_INNER || kind == DOF_PP_DIST_INTRA)) {
+__device__ __forceinline__ double pp_value(double x, double cf0, double cf1, double cf2, bool lg, bool clipk, double clip,
+                                           const double (*tab)[2]) {
+  double u = x * cf0;
+  if (lg) {
     if (u < 0.0) u = 0.0;
-    u = log1p(u);
+    u = pp_log1p(u, tab);
   }
-  const double z = u * cf[1] + cf[2];
-  const bool clipped = clip > 0.0 && kind >= DOF_PP_COORD && kind <= DOF_PP_DIST_INTRA && fabs(z) > clip;
-  return clipped ? pp_nanv() : z;
-}
-
-// first / last valid row (relative to the video start, -1 = none) of every output column in every PP_TR-row tile
-__global__ void __launch_bounds__(256) k_pp_edges(PpOutArgs A, int* __restrict__ first_v, int* __restrict__ last_v) {
-  __shared__ int shf[4][64], shl[4][64];
-  int v;
-  int64_t tile;
-  if (!pp_locate(A.video_off, A.V, PP_TR, blockIdx.x, &v, &tile)) return;
-  const int64_t voff = A.video_off[v], vlen = A.video_off[v + 1] - voff;
-  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int64_t t0 = tile * PP_TR;
-  for (int jb = 0; jb < A.n_out; jb += 64) {
-    const int j = jb + lane;
-    int f = -1, l = -1;
-    if (j < A.n_out) {
-      const int c = A.out_cols[j], kind = A.col_kind[c];
-      const double* cf = A.coef + ((int64_t)v * A.C + c) * 3;
-      for (int k = 0; k < PP_TR / 4; ++k) {
-        const int64_t row = t0 + rg * (PP_TR / 4) + k;
-        if (row < vlen) {
-          const double z = pp_value(A.raw[(voff + row) * A.C + c], cf, kind, A.log_dist, A.clip);
-          if (!pp_isnan(z)) {
-            if (f < 0) f = (int)row;
-            l = (int)row;
-          }
-        }
-      }
-    }
-    shf[rg][lane] = f;
-    shl[rg][lane] = l;
-    __syncthreads();
-    if (rg == 0 && j < A.n_out) {
-      int ff = -1, ll = -1;
-      for (int g = 0; g < 4; ++g) {
-        if (ff < 0) ff = shf[g][lane];
-        if (shl[g][lane] >= 0) ll = shl[g][lane];
-      }
-      first_v[(int64_t)blockIdx.x * A.n_out + j] = ff;
-      last_v[(int64_t)blockIdx.x * A.n_out + j] = ll;
-    }
-    __syncthreads();
-  }
-}
-
-// nearest valid row before / after every tile, per (video, output column): prefix max of the tiles' last valid
-// row and suffix min of their first valid row (chunked per thread + a 256-entry scan in LDS)
-__global__ void __launch_bounds__(256) k_pp_carry(const int64_t* __restrict__ video_off, int n_out,
-                                                  const int* __restrict__ first_v, const int* __restrict__ last_v,
-                                                  int* __restrict__ prev_v, int* __restrict__ next_v) {
-  __shared__ int sh_max[256], sh_min[256];
-  const int j = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
-  const int64_t slot0 = video_off[v] / PP_TR + v;
-  const int64_t nt = (video_off[v + 1] - video_off[v] + PP_TR - 1) / PP_TR;
-  const int64_t chunk = (nt + 255) / 256;
-  const int64_t a = tid * chunk, b = a + chunk < nt ? a + chunk : nt;
-  const int none = 0x7fffffff;
-  int mx = -1, mn = none;
-  for (int64_t t = a; t < b; ++t) {
-    const int l = last_v[(slot0 + t) * n_out + j], f = first_v[(slot0 + t) * n_out + j];
-    if (l > mx) mx = l;
-    if (f >= 0 && f < mn) mn = f;
-  }
-  sh_max[tid] = mx;
-  sh_min[tid] = mn;
-  __syncthreads();
-  int carry = -1, back = none;
-  for (int i = 0; i < tid; ++i)
-    if (sh_max[i] > carry) carry = sh_max[i];
-  for (int i = 255; i > tid; --i)
-    if (sh_min[i] < back) back = sh_min[i];
-  for (int64_t t = a; t < b; ++t) {
-    prev_v[(slot0 + t) * n_out + j] = carry;
-    const int l = last_v[(slot0 + t) * n_out + j];
-    if (l > carry) carry = l;
-  }
-  for (int64_t t = b - 1; t >= a; --t) {
-    next_v[(slot0 + t) * n_out + j] = back == none ? -1 : back;
-    const int f = first_v[(slot0 + t) * n_out + j];
-    if (f >= 0 && f < back) back = f;
-  }
+  const double z = u * cf1 + cf2;
+  return (clipk && fabs(z) > clip) ? pp_nanv() : z;
 }
 
 #ifdef DOF_EMU
@@ -484,111 +663,219 @@ __global__ void __launch_bounds__(256) k_pp_carry(const int64_t* __restrict__ vi
 #define PP_MUL_RN(a, b) __dmul_rn((a), (b))
 #define PP_ADD_RN(a, b) __dadd_rn((a), (b))
 #endif
+// numpy.interp between valid rows p < q (values pv, qv): slope * (x - x0) + y0, multiply and add rounded separately;
+// flat beyond the first / last valid row of the video, 0 for a column without any valid row
+__device__ __forceinline__ double pp_interp(int64_t row, int64_t p, double pv, int64_t q, double qv) {
+  if (p >= 0 && q >= 0) {
+    const double slope = (qv - pv) / (double)(q - p);
+    return PP_ADD_RN(PP_MUL_RN(slope, (double)(row - p)), pv);
+  }
+  return p >= 0 ? pv : q >= 0 ? qv : 0.0;
+}
+// column j of the concatenated output -> (table, width, column inside the table)
+__device__ __forceinline__ float* pp_out_column(const PpOutArgs& A, int j, int* width) {
+  if (j < A.n_node) {
+    *width = A.n_node;
+    return A.node_out + j;
+  }
+  if (j < A.n_node + A.n_edge) {
+    *width = A.n_edge;
+    return A.edge_out + (j - A.n_node);
+  }
+  *width = A.n_out - A.n_node - A.n_edge;
+  return A.angle_out + (j - A.n_node - A.n_edge);
+}
 
-// One PP_TR-row tile of one video: transform + clip into LDS, fill the gaps per column (numpy.interp's
-// slope * (x - x0) + y0 with separately rounded multiply and add, flat beyond the first / last valid row of the
-// video, 0 for a column without any), then one coalesced fp32 store of whole frame-table rows.
-template <int NO, int TR>
-__global__ void __launch_bounds__(256) k_pp_finish(PpOutArgs A, const int* __restrict__ prev_v,
-                                                   const int* __restrict__ next_v, int n_node, int n_edge,
-                                                   float* __restrict__ node_out, float* __restrict__ edge_out,
-                                                   float* __restrict__ angle_out) {
-  static_assert(PP_TR % TR == 0, "sub-tile must divide the tile");
-  __shared__ double zt[TR][NO + 1];
-  int v;
-  int64_t tile;
-  if (!pp_locate(A.video_off, A.V, PP_TR, blockIdx.x, &v, &tile)) return;
-  const int64_t voff = A.video_off[v], vlen = A.video_off[v + 1] - voff;
-  const int n_out = A.n_out;
-  for (int sub = 0; sub < PP_TR / TR; ++sub) {
-    const int64_t t0 = tile * PP_TR + sub * TR;
-    if (t0 >= vlen) break;
-    const int nrows = (int)(vlen - t0 < TR ? vlen - t0 : TR);
-    for (int idx = threadIdx.x; idx < nrows * n_out; idx += 256) {
-      const int r = idx / n_out, j = idx - r * n_out;
-      const int c = A.out_cols[j];
-      zt[r][j] = pp_value(A.raw[(voff + t0 + r) * A.C + c], A.coef + ((int64_t)v * A.C + c) * 3, A.col_kind[c],
-                          A.log_dist, A.clip);
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < n_out; j += 256) {
-      const int c = A.out_cols[j], kind = A.col_kind[c];
-      const double* cf = A.coef + ((int64_t)v * A.C + c) * 3;
-      // nearest valid rows outside this sub-tile: inside the tile they are found by walking, outside from the carry
-      int64_t p = -1, q_after = -2;
-      double pv = 0.0, qv_after = 0.0;
-      {
-        // rows of earlier sub-tiles of the same tile are not in LDS any more: look them up through the raw table
-        int64_t cand = prev_v[(int64_t)blockIdx.x * n_out + j];
-        for (int64_t row = t0 - 1; row >= tile * PP_TR; --row) {
-          const double z = pp_value(A.raw[(voff + row) * A.C + c], cf, kind, A.log_dist, A.clip);
-          if (!pp_isnan(z)) { cand = row; break; }
-        }
-        p = cand;
-        if (p >= 0) pv = pp_value(A.raw[(voff + p) * A.C + c], cf, kind, A.log_dist, A.clip);
-      }
-      int r = 0;
-      while (r < nrows) {
-        const double z = zt[r][j];
-        if (!pp_isnan(z)) {
-          p = t0 + r;
-          pv = z;
-          ++r;
-          continue;
-        }
-        int e = r;
-        while (e < nrows && pp_isnan(zt[e][j])) ++e;
-        int64_t q = -1;
-        double qv = 0.0;
-        if (e < nrows) {
-          q = t0 + e;
-          qv = zt[e][j];
-        } else {
-          if (q_after == -2) {
-            int64_t cand = next_v[(int64_t)blockIdx.x * n_out + j];
-            const int64_t tile_end = (tile + 1) * PP_TR < vlen ? (tile + 1) * PP_TR : vlen;
-            for (int64_t row = t0 + nrows; row < tile_end; ++row) {
-              const double zz = pp_value(A.raw[(voff + row) * A.C + c], cf, kind, A.log_dist, A.clip);
-              if (!pp_isnan(zz)) { cand = row; break; }
-            }
-            q_after = cand;
-            if (cand >= 0) qv_after = pp_value(A.raw[(voff + cand) * A.C + c], cf, kind, A.log_dist, A.clip);
-          }
-          q = q_after;
-          qv = qv_after;
-        }
-        for (int k = r; k < e; ++k) {
-          double val = 0.0;
-          if (p >= 0 && q >= 0) {
-            const double slope = (qv - pv) / (double)(q - p);
-            val = PP_ADD_RN(PP_MUL_RN(slope, (double)(t0 + k - p)), pv);
-          } else if (p >= 0) {
-            val = pv;
-          } else if (q >= 0) {
-            val = qv;
-          }
-          zt[k][j] = val;
-        }
-        r = e;
-      }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < nrows * n_out; idx += 256) {
-      const int r = idx / n_out, j = idx - r * n_out;
-      const int64_t row = voff + t0 + r;
-      const float val = (float)zt[r][j];
-      if (j < n_node) node_out[row * n_node + j] = val;
-      else if (j < n_node + n_edge) edge_out[row * n_edge + (j - n_node)] = val;
-      else angle_out[row * (n_out - n_node - n_edge) + (j - n_node - n_edge)] = val;
-    }
+// The output pass: pure streaming, no LDS staging, no barrier after the table set-up.  A thread owns one output
+// column of one PP_TR(=8)-row tile: 8 independent loads down the column, transform + clip, fp32 stores -- lanes run
+// along the output columns, so both the loads (inside one 8C-byte raw row) and the stores (inside one frame-table
+// row) of a wavefront touch one contiguous region per row.  A wavefront walks 8 consecutive tiles (64 rows); chunks
+// narrower than 32 columns (typically the log1p'd edge columns) take 2 / 4 / 8 tiles at a time.  A tile column with
+// missing values closes the gaps that have both neighbours inside the tile from its registers and leaves a validity
+// byte (bit r = row r valid) for k_pp_fill, which closes the gaps that reach a tile edge; the memset value 0xFF
+// means "all rows valid", so the common case writes no note at all.
+__global__ void __launch_bounds__(256) k_pp_finish(PpOutArgs A, const int* __restrict__ ochunks,
+                                                   uint8_t* __restrict__ notes) {
+  __shared__ double logtab[128][2];
+  if (A.log_dist) {
+    pp_log_table_init(logtab);
     __syncthreads();
   }
+  const int lane = threadIdx.x & 63;
+  const int64_t group0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;  // first of this wavefront's 8 slots
+  if (group0 >= A.n_slots) return;
+  const int nchunk = ochunks[0];
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int jbase = ochunks[1 + 3 * ch], count = ochunks[2 + 3 * ch];
+    const bool lg = ochunks[3 + 3 * ch] != 0;
+    int width = 64;
+    while (width / 2 >= count && width > 8) width >>= 1;
+    const int pack = 64 / width, sub = lane / width, cl = lane - sub * width;
+    if (cl >= count) continue;
+    const int j = jbase + cl, c = A.out_cols[j], kind = A.col_kind[c];
+    const bool clipk = A.clip > 0.0 && kind >= DOF_PP_COORD && kind <= DOF_PP_DIST_INTRA;
+    int wdt;
+    float* const out_col = pp_out_column(A, j, &wdt);
+    int v_have = -1;
+    double cf0 = 0.0, cf1 = 0.0, cf2 = 0.0;
+    for (int it = 0; it < 8; it += pack) {
+      const int64_t slot = group0 + it + sub;
+      if (slot >= A.n_slots) break;
+      const int v = A.slot_rec[4 * slot], nrows = A.slot_rec[4 * slot + 3];
+      if (v < 0) continue;
+      const int64_t grow = A.slot_rec[4 * slot + 1], t0 = A.slot_rec[4 * slot + 2];
+      if (v != v_have) {
+        const double* cf = A.coef + ((int64_t)v * A.C + c) * 3;
+        cf0 = cf[0];
+        cf1 = cf[1];
+        cf2 = cf[2];
+        v_have = v;
+      }
+      const double* src = A.raw + grow * A.C + c;
+      double z[PP_TR];
+#pragma unroll
+      for (int r = 0; r < PP_TR; ++r) z[r] = r < nrows ? src[(int64_t)r * A.C] : 0.0;
+      unsigned valid = 0;
+#pragma unroll
+      for (int r = 0; r < PP_TR; ++r) {
+        z[r] = pp_value(z[r], cf0, cf1, cf2, lg, clipk, A.clip, logtab);
+        valid |= (r >= nrows || !pp_isnan(z[r])) ? 1u << r : 0u;
+      }
+      if (valid != 0xffu) {
+        // gaps with both neighbours inside the tile: forward pass = nearest valid row before, backward pass = after
+        int before[PP_TR];
+        double before_v[PP_TR];
+        int p = -1;
+        double pv = 0.0;
+#pragma unroll
+        for (int r = 0; r < PP_TR; ++r) {
+          before[r] = p;
+          before_v[r] = pv;
+          if ((valid >> r) & 1u) {
+            p = r;
+            pv = z[r];
+          }
+        }
+        int q = -1;
+        double qv = 0.0;
+#pragma unroll
+        for (int r = PP_TR - 1; r >= 0; --r) {
+          if ((valid >> r) & 1u) {
+            if (r < nrows) {
+              q = r;
+              qv = z[r];
+            }
+          } else if (before[r] >= 0 && q >= 0) {
+            z[r] = pp_interp(t0 + r, t0 + before[r], before_v[r], t0 + q, qv);
+          }
+        }
+        notes[(int64_t)j * A.n_slots + slot] = (uint8_t)valid;
+      }
+      float* dst = out_col + grow * wdt;
+#pragma unroll
+      for (int r = 0; r < PP_TR; ++r)
+        if (r < nrows) dst[(int64_t)r * wdt] = (float)z[r];
+    }
+  }
+}
+
+// Gaps that touch a tile edge, per (output column, video): the nearest valid row before / after a tile comes from
+// the tiles' validity bytes (prefix max of the last valid row / suffix min of the first: a 256-wide scan in LDS over
+// per-thread chunks of tiles, then short walks inside the chunk); every tile closes its own part of a gap with the
+// same (p, q) pair, so a gap spanning many tiles is filled in parallel and with the arithmetic of one numpy.interp
+// call.
+__global__ void __launch_bounds__(256) k_pp_fill(PpOutArgs A, const uint8_t* __restrict__ notes) {
+  __shared__ int sh_max[256], sh_min[256];
+  __shared__ double logtab[128][2];
+  if (A.log_dist) pp_log_table_init(logtab);
+  const int j = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+  const int64_t voff = A.video_off[v], vlen = A.video_off[v + 1] - voff;
+  const int64_t nt = (vlen + PP_TR - 1) / PP_TR;
+  const uint8_t* N = notes + (int64_t)j * A.n_slots + (voff / PP_TR + v);
+  const int64_t chunk = (nt + 255) / 256;
+  const int64_t a = tid * chunk < nt ? tid * chunk : nt, b = a + chunk < nt ? a + chunk : nt;
+  const int none = 0x7fffffff;
+  // validity bits of tile t without the padding bits of the video's last tile
+  auto bits_of = [&](int64_t t) -> unsigned {
+    const int64_t left = vlen - t * PP_TR;
+    return left >= PP_TR ? (unsigned)N[t] : (unsigned)N[t] & ((1u << left) - 1u);
+  };
+  int mx = -1, mn = none;
+  bool work = false;
+  for (int64_t t = a; t < b; ++t) {
+    if (N[t] != 0xffu) work = true;
+    const unsigned m = bits_of(t);
+    if (m != 0u) {
+      const int l = (int)(t * PP_TR) + (31 - __builtin_clz(m)), f = (int)(t * PP_TR) + __builtin_ctz(m);
+      if (l > mx) mx = l;
+      if (f < mn) mn = f;
+    }
+  }
+  sh_max[tid] = mx;
+  sh_min[tid] = mn;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int m = tid >= off ? sh_max[tid - off] : -1;
+    const int n = tid + off < 256 ? sh_min[tid + off] : none;
+    __syncthreads();
+    if (m > sh_max[tid]) sh_max[tid] = m;
+    if (n < sh_min[tid]) sh_min[tid] = n;
+    __syncthreads();
+  }
+  if (!work) return;
+  const int carry = tid > 0 ? sh_max[tid - 1] : -1;
+  const int back = tid < 255 ? sh_min[tid + 1] : none;
+  const int c = A.out_cols[j], kind = A.col_kind[c];
+  const double* cf = A.coef + ((int64_t)v * A.C + c) * 3;
+  const double cf0 = cf[0], cf1 = cf[1], cf2 = cf[2];
+  const bool lg = A.log_dist && (kind == DOF_PP_DIST_INNER || kind == DOF_PP_DIST_INTRA);
+  const bool clipk = A.clip > 0.0 && kind >= DOF_PP_COORD && kind <= DOF_PP_DIST_INTRA;
+  int wdt;
+  float* const out_col = pp_out_column(A, j, &wdt);
+#define PP_AT(row) pp_value(A.raw[(voff + (row)) * A.C + c], cf0, cf1, cf2, lg, clipk, A.clip, logtab)
+  for (int64_t t = a; t < b; ++t) {
+    if (N[t] == 0xffu) continue;
+    const int64_t t0 = t * PP_TR, tend = t0 + PP_TR < vlen ? t0 + PP_TR : vlen;
+    const unsigned me = bits_of(t);
+    const int64_t f = me ? t0 + __builtin_ctz(me) : -1, l = me ? t0 + (31 - __builtin_clz(me)) : -1;
+    const bool need_p = f != t0, need_q = l != tend - 1;
+    if (!need_p && !need_q) continue;  // only interior gaps, already closed
+    int64_t p = -1, q = -1;            // nearest valid rows outside the tile
+    if (need_p) {
+      p = carry;
+      for (int64_t u = t - 1; u >= a; --u)
+        if (N[u] != 0u) { p = u * PP_TR + (31 - __builtin_clz((unsigned)N[u])); break; }  // u is never the last tile
+    }
+    if (need_q) {
+      q = back == none ? -1 : back;
+      for (int64_t u = t + 1; u < b; ++u) {
+        const unsigned mu = bits_of(u);
+        if (mu != 0u) { q = u * PP_TR + __builtin_ctz(mu); break; }
+      }
+    }
+    const double pv = p >= 0 ? PP_AT(p) : 0.0, qv = q >= 0 ? PP_AT(q) : 0.0;
+    if (f < 0) {  // no valid row in the tile: one gap
+      for (int64_t row = t0; row < tend; ++row) out_col[(voff + row) * wdt] = (float)pp_interp(row, p, pv, q, qv);
+      continue;
+    }
+    if (need_p) {
+      const double fv = PP_AT(f);
+      for (int64_t row = t0; row < f; ++row) out_col[(voff + row) * wdt] = (float)pp_interp(row, p, pv, f, fv);
+    }
+    if (need_q) {
+      const double lv = PP_AT(l);
+      for (int64_t row = l + 1; row < tend; ++row) out_col[(voff + row) * wdt] = (float)pp_interp(row, l, lv, q, qv);
+    }
+  }
+#undef PP_AT
 }
 
 struct PpWorkspace {
   double *hyp, *sfac, *rdiv, *vscale, *coef;
-  PpStat *part_all, *part_smp, *ystat;
-  int *first_v, *last_v, *prev_v, *next_v;
+  PpStat *part_all, *part_smp, *vcol_all, *vcol_smp, *ystat, *gcol;
+  int *strip_v, *tile_rec, *chunks, *ochunks;
+  uint8_t* notes;
+  int64_t note_bytes;
   int64_t bytes;
 };
 
@@ -611,11 +898,16 @@ PpWorkspace pp_layout(const DofPreprocDims& d, void* base) {
   w.coef = (double*)take(vc * 24);
   w.part_all = (PpStat*)take(strips * d.n_cols * (int64_t)sizeof(PpStat));
   w.part_smp = (PpStat*)take(strips * d.n_cols * (int64_t)sizeof(PpStat));
+  w.vcol_all = (PpStat*)take(vc * (int64_t)sizeof(PpStat));
+  w.vcol_smp = (PpStat*)take(vc * (int64_t)sizeof(PpStat));
   w.ystat = (PpStat*)take(vc * (int64_t)sizeof(PpStat));
-  w.first_v = (int*)take(tiles * n_out * 4);
-  w.last_v = (int*)take(tiles * n_out * 4);
-  w.prev_v = (int*)take(tiles * n_out * 4);
-  w.next_v = (int*)take(tiles * n_out * 4);
+  w.gcol = (PpStat*)take((int64_t)d.n_cols * (int64_t)sizeof(PpStat));
+  w.note_bytes = tiles * n_out;
+  w.notes = (uint8_t*)take(w.note_bytes);
+  w.strip_v = (int*)take(strips * 4);
+  w.tile_rec = (int*)take(tiles * 16);
+  w.chunks = (int*)take((1 + 3 * (int64_t)(2 * d.n_cols + 2)) * 4);
+  w.ochunks = (int*)take((1 + 3 * (int64_t)(2 * n_out + 2)) * 4);
   w.bytes = off;
   return w;
 }
@@ -631,8 +923,8 @@ int pp_check(const DofPreprocDims* d) {
     dof_set_error("dof_preprocess: bad dims");
     return DOF_ERR_ARG;
   }
-  if (d->n_cols > DOF_PP_MAX_COLS || d->n_animals > DOF_PP_MAX_ANIMALS || n_out > 256 || d->n_frames >= (1ll << 31)) {
-    dof_set_error("dof_preprocess: unsupported size (columns <= %d, animals <= %d, output columns <= 256, frames < 2^31)",
+  if (d->n_cols > DOF_PP_MAX_COLS || d->n_animals > DOF_PP_MAX_ANIMALS || n_out > DOF_PP_MAX_COLS || d->n_frames >= (1ll << 31)) {
+    dof_set_error("dof_preprocess: unsupported size (columns <= %d, animals <= %d, output columns <= columns, frames < 2^31)",
                   DOF_PP_MAX_COLS, DOF_PP_MAX_ANIMALS);
     return DOF_ERR_UNSUPPORTED;
   }
@@ -672,40 +964,47 @@ extern "C" int dof_preprocess_tables(const DofPreprocDims* dims, const double* r
   const PpWorkspace w = pp_layout(d, workspace);
   const int V = d.n_videos, C = d.n_cols, A = d.n_animals;
   const int n_out = d.n_node_cols + d.n_edge_cols + d.n_angle_cols;
-  const unsigned strips = (unsigned)pp_slots(d.n_frames, V, PP_RS), tiles = (unsigned)pp_slots(d.n_frames, V, PP_TR);
+  const int64_t strips = pp_slots(d.n_frames, V, PP_RS), tiles = pp_slots(d.n_frames, V, PP_TR);
+  DOF_LAUNCH(k_pp_slot_table, (dof_cdiv(strips, 256)), (256), st, video_off, V, PP_RS, strips, w.strip_v, (int*)nullptr);
+  DOF_LAUNCH(k_pp_slot_table, (dof_cdiv(tiles, 256)), (256), st, video_off, V, PP_TR, tiles, (int*)nullptr, w.tile_rec);
+  DOF_LAUNCH(k_pp_chunks, (1), (DOF_PP_MAX_COLS), st, col_kind, (const int*)nullptr, C, d.log_distances, w.chunks);
+  DOF_LAUNCH(k_pp_chunks, (1), (DOF_PP_MAX_COLS), st, col_kind, out_cols, n_out, d.log_distances, w.ochunks);
+  (void)hipMemsetAsync(w.notes, 0xFF, (size_t)w.note_bytes, st);
   if (A > 0) DOF_LAUNCH(k_pp_size, (A, V), (256), st, raw, video_off, size_ref, C, A, d.n_frames, w.hyp, w.sfac);
   DOF_LAUNCH(k_pp_divisors, (V), (256), st, chain_off, chain, C, A, d.inter_scale, w.sfac, w.rdiv);
-  DOF_LAUNCH(k_pp_stats, (strips), (256), st, raw, video_off, col_kind, (const double*)w.rdiv, sample_mask, V, C,
-             d.log_distances, d.speed_mode, d.dist_mode, d.fit_global ? d.coord_mode : DOF_PP_MODE_NONE, w.part_all,
-             w.part_smp);
-  DOF_LAUNCH(k_pp_video_fin, (V), (256), st, video_off, col_kind, (const PpStat*)w.part_all, (const PpStat*)w.part_smp, C,
-             d.speed_mode, d.dist_mode, w.vscale, w.ystat);
-  if (d.fit_global)
-    DOF_LAUNCH(k_pp_global_fin, (1), (256), st, col_kind, (const PpStat*)w.ystat, V, C, d.speed_mode, d.dist_mode,
-               d.coord_mode, scaler);
-  DOF_LAUNCH(k_pp_coef, (V), (256), st, (const double*)w.rdiv, (const double*)w.vscale, (const double*)scaler, C, w.coef,
-             video_scaler);
+#define PP_STATS(M)                                                                                                  \
+  DOF_LAUNCH((k_pp_stats<M>), ((unsigned)strips), (256), st, raw, video_off, (const int*)w.strip_v, (const int*)w.chunks, \
+             col_kind, (const double*)w.rdiv, sample_mask, C, d.speed_mode, d.dist_mode,                             \
+             d.fit_global ? d.coord_mode : DOF_PP_MODE_NONE, w.part_all, w.part_smp)
+  if (sample_mask) PP_STATS(true); else PP_STATS(false);
+#undef PP_STATS
+  const unsigned col_chunks = dof_cdiv(C, 64);
+  DOF_LAUNCH(k_pp_video_cols, (col_chunks, V), (256), st, video_off, (const PpStat*)w.part_all, (const PpStat*)w.part_smp, C,
+             w.vcol_all, w.vcol_smp);
+  DOF_LAUNCH(k_pp_video_fin, (V), (256), st, col_kind, (const PpStat*)w.vcol_all, (const PpStat*)w.vcol_smp, C, d.speed_mode,
+             d.dist_mode, w.vscale, w.ystat);
+  if (d.fit_global) DOF_LAUNCH(k_pp_global_cols, (col_chunks), (256), st, (const PpStat*)w.ystat, V, C, w.gcol);
+  DOF_LAUNCH(k_pp_coef, (V), (256), st, col_kind, (const PpStat*)w.gcol, (const double*)w.rdiv, (const double*)w.vscale,
+             scaler, d.fit_global, C, d.speed_mode, d.dist_mode, d.coord_mode, w.coef, video_scaler);
   PpOutArgs oa;
   oa.raw = raw;
   oa.video_off = video_off;
+  oa.slot_rec = w.tile_rec;
   oa.col_kind = col_kind;
   oa.out_cols = out_cols;
   oa.coef = w.coef;
-  oa.V = V;
+  oa.n_slots = tiles;
   oa.C = C;
   oa.n_out = n_out;
+  oa.n_node = d.n_node_cols;
+  oa.n_edge = d.n_edge_cols;
   oa.log_dist = d.log_distances;
   oa.clip = d.clip;
-  DOF_LAUNCH(k_pp_edges, (tiles), (256), st, oa, w.first_v, w.last_v);
-  DOF_LAUNCH(k_pp_carry, (n_out, V), (256), st, video_off, n_out, (const int*)w.first_v, (const int*)w.last_v, w.prev_v,
-             w.next_v);
-#define PP_FINISH(NO, TR)                                                                                          \
-  DOF_LAUNCH((k_pp_finish<NO, TR>), (tiles), (256), st, oa, (const int*)w.prev_v, (const int*)w.next_v, d.n_node_cols, \
-             d.n_edge_cols, node_out, edge_out, angle_out)
-  if (n_out <= 64) PP_FINISH(64, 32);
-  else if (n_out <= 128) PP_FINISH(128, 32);
-  else PP_FINISH(256, 16);
-#undef PP_FINISH
+  oa.node_out = node_out;
+  oa.edge_out = edge_out;
+  oa.angle_out = angle_out;
+  DOF_LAUNCH(k_pp_finish, (dof_cdiv(tiles, 32)), (256), st, oa, (const int*)w.ochunks, w.notes);
+  DOF_LAUNCH(k_pp_fill, (n_out, V), (256), st, oa, (const uint8_t*)w.notes);
   if (size_out)
     (void)hipMemcpyAsync(size_out, w.sfac, (size_t)V * (A + 1) * 8, hipMemcpyDeviceToDevice, st);
   return dof_check_launch("dof_preprocess_tables");

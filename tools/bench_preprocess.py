@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--animals", type=int, default=1)
     ap.add_argument("--mode", default="groupwise")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-log", action="store_true", help="log_distances=False")
     args = ap.parse_args()
     import parity_common as PC
     from deepof_amd._lib import load_hip_library
@@ -42,7 +43,7 @@ def main():
     node_cols, edge_cols, _ = PC.preprocess_output_columns(cols)
     edge_cols = edge_cols[:14 * args.animals + (4 if args.animals == 2 else 0)]
     mode = None if args.mode == "none" else args.mode
-    kw = dict(dist_standardize=mode, speed_standardize=mode, coord_standardize=mode)
+    kw = dict(dist_standardize=mode, speed_standardize=mode, coord_standardize=mode, log_distances=not args.no_log)
     keys = sorted(tabs)
     t0 = time.perf_counter()
     raw = torch.from_numpy(np.concatenate([tabs[k] for k in keys])).cuda()
@@ -103,7 +104,7 @@ def device_time(lib, res, raw, tabs, cols, aids, node_cols, edge_cols, kw, iters
     dims = _capi.PreprocDims(n_frames=raw.shape[0], n_videos=len(res.keys), n_cols=len(cols), n_animals=len(plan.animal_ids),
                              n_node_cols=len(node_cols), n_edge_cols=len(edge_cols), n_angle_cols=0,
                              speed_mode=_capi.PP_MODES[kw["speed_standardize"]], dist_mode=_capi.PP_MODES[kw["dist_standardize"]],
-                             coord_mode=_capi.PP_MODES[kw["coord_standardize"]], log_distances=1, inter_scale=0, fit_global=1, clip=10.0)
+                             coord_mode=_capi.PP_MODES[kw["coord_standardize"]], log_distances=int(kw["log_distances"]), inter_scale=0, fit_global=1, clip=10.0)
     ws = torch.empty(lib.dof_preprocess_workspace_bytes(ctypes.byref(dims)), dtype=torch.uint8, device="cuda")
     node, edge = torch.empty_like(res.node_table), torch.empty_like(res.edge_table)
     st = torch.cuda.current_stream().cuda_stream
