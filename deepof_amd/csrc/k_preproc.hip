@@ -107,13 +107,34 @@ __device__ __forceinline__ int pp_mode(int kind, int speed_mode, int dist_mode, 
 // ---------------------------------------------------------------------------------------------------------
 // size factor of animal a in video v: nan-median over the video's rows of hypot(nose - tail base).
 // Exact selection without a sort: non-negative doubles order like their bit patterns, so the order statistics
-// (n-1)/2 and n/2 are found digit by digit from the top -- 8 sweeps of the (L2-resident) lengths, each building a
-// 256-bin histogram of the next 8 bits among the values that share the prefix found so far (integer LDS atomics:
-// order-independent, so the result is deterministic).
-__global__ void __launch_bounds__(256) k_pp_size(const double* __restrict__ raw, const int64_t* __restrict__ video_off,
-                                                 const int* __restrict__ size_ref, int C, int A, int64_t F,
-                                                 double* __restrict__ hyp, double* __restrict__ s_out) {
-  __shared__ int hist[2][4][256];
+// (n-1)/2 and n/2 are found digit by digit, 8 bits per sweep, from the highest byte in which the smallest and the
+// largest length differ: each sweep builds a 256-bin histogram of the next byte among the values that share the
+// prefix found so far (integer LDS atomics on 8 private copies: order-independent, so deterministic).  A video of
+// up to 256 x 64 rows keeps its keys in registers (one workgroup per (animal, video) is latency-bound otherwise);
+// longer ones sweep the L2-resident keys.
+constexpr int PP_KPT = 64;
+constexpr unsigned long long PP_NOKEY = ~0ull;  // a NaN bit pattern no hypot() returns: "no value"
+
+// keys of all rows, all animals: one thread per row (the 4 reference coordinates of an animal are 4 scattered
+// 8-byte reads of the row -- done once here, by as many workgroups as it takes, not by the one workgroup per
+// (animal, video) of the selection below)
+__global__ void __launch_bounds__(256) k_pp_hyp(const double* __restrict__ raw, const int* __restrict__ size_ref, int C, int A,
+                                                int64_t F, unsigned long long* __restrict__ keys) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= F) return;
+  const double* row = raw + r * C;
+  for (int a = 0; a < A; ++a) {
+    const int c0 = size_ref[4 * a], c1 = size_ref[4 * a + 1], c2 = size_ref[4 * a + 2], c3 = size_ref[4 * a + 3];
+    if (c0 < 0 || c1 < 0 || c2 < 0 || c3 < 0) continue;
+    const double len = hypot(row[c0] - row[c2], row[c1] - row[c3]);
+    keys[(int64_t)a * F + r] = pp_isnan(len) ? PP_NOKEY : pp_bits(len);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pp_size(const int64_t* __restrict__ video_off, const int* __restrict__ size_ref,
+                                                 int A, int64_t F, const unsigned long long* __restrict__ keys,
+                                                 double* __restrict__ s_out) {
+  __shared__ int hist[2][8][256];
   __shared__ int red[256];
   __shared__ unsigned long long mm[2][256];
   __shared__ unsigned long long sel[2];
@@ -126,31 +147,50 @@ __global__ void __launch_bounds__(256) k_pp_size(const double* __restrict__ raw,
     return;
   }
   const int64_t r0 = video_off[v], r1 = video_off[v + 1];
-  double* h = hyp + (int64_t)a * F;
-  int nv = 0;
-  for (int64_t rb = r0 + tid; rb < r1; rb += 256 * 4) {
-    double len[4];
+  const bool in_regs = r1 - r0 <= 256 * PP_KPT;
+  const unsigned long long* h = keys + (int64_t)a * F;
+  unsigned long long key[PP_KPT];
+  if (in_regs) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t r = rb + 256 * i;
-      if (r < r1) {
-        const double* row = raw + r * C;
-        len[i] = hypot(row[c0] - row[c2], row[c1] - row[c3]);
-      } else {
-        len[i] = pp_nanv();
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t r = rb + 256 * i;
-      if (r < r1) h[r] = len[i];
-      nv += !pp_isnan(len[i]);
+    for (int i = 0; i < PP_KPT; ++i) {
+      const int64_t r = r0 + tid + 256 * i;
+      key[i] = r < r1 ? h[r] : PP_NOKEY;
     }
   }
+  // f(key) for every key of this thread
+  auto sweep = [&](auto f) {
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < PP_KPT; ++i)
+        if (key[i] != PP_NOKEY) f(key[i]);
+    } else {
+      for (int64_t rb = r0 + tid; rb < r1; rb += 256 * 8) {
+        unsigned long long k8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k8[i] = rb + 256 * i < r1 ? h[rb + 256 * i] : PP_NOKEY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (k8[i] != PP_NOKEY) f(k8[i]);
+      }
+    }
+  };
+  int nv = 0;
+  unsigned long long kmin = PP_NOKEY, kmax = 0ull;
+  sweep([&](unsigned long long k) {
+    ++nv;
+    kmin = k < kmin ? k : kmin;
+    kmax = k > kmax ? k : kmax;
+  });
   red[tid] = nv;
+  mm[0][tid] = kmin;
+  mm[1][tid] = kmax;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
+    if (tid < s) {
+      red[tid] += red[tid + s];
+      mm[0][tid] = mm[0][tid + s] < mm[0][tid] ? mm[0][tid + s] : mm[0][tid];
+      mm[1][tid] = mm[1][tid + s] > mm[1][tid] ? mm[1][tid + s] : mm[1][tid];
+    }
     __syncthreads();
   }
   const int n = red[0];
@@ -158,28 +198,7 @@ __global__ void __launch_bounds__(256) k_pp_size(const double* __restrict__ raw,
     if (tid == 0) *out = pp_nanv();
     return;
   }
-  // every key shares the bits above the highest bit in which the smallest and the largest key differ: start the
-  // digit walk there (the top bytes -- sign, exponent -- would otherwise put all values into one or two bins and
-  // serialise the LDS atomics)
-  unsigned long long kmin = ~0ull, kmax = 0ull;
-  for (int64_t r = r0 + tid; r < r1; r += 256) {
-    const double len = h[r];
-    if (!pp_isnan(len)) {
-      const unsigned long long key = pp_bits(len);
-      kmin = key < kmin ? key : kmin;
-      kmax = key > kmax ? key : kmax;
-    }
-  }
-  mm[0][tid] = kmin;
-  mm[1][tid] = kmax;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) {
-      mm[0][tid] = mm[0][tid + s] < mm[0][tid] ? mm[0][tid + s] : mm[0][tid];
-      mm[1][tid] = mm[1][tid + s] > mm[1][tid] ? mm[1][tid + s] : mm[1][tid];
-    }
-    __syncthreads();
-  }
+  // every key shares the bits above the highest bit in which the smallest and the largest key differ
   const unsigned long long diff = mm[0][0] ^ mm[1][0];
   int top = 0;  // shift of the highest byte that differs
   while (top < 56 && (diff >> (top + 8)) != 0ull) top += 8;
@@ -188,41 +207,48 @@ __global__ void __launch_bounds__(256) k_pp_size(const double* __restrict__ raw,
     krem[0] = (n - 1) / 2;
     krem[1] = n / 2;
   }
-  const int wv = tid >> 6;
+  const int copy = (tid >> 3) & 7;  // 8 private copies of each histogram spread the hot bins
   for (int shift = top; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 2 * 4 * 256; i += 256) (&hist[0][0][0])[i] = 0;
+    for (int i = tid; i < 2 * 8 * 256; i += 256) (&hist[0][0][0])[i] = 0;
     __syncthreads();
     const unsigned long long p0 = sel[0], p1 = sel[1];
+    const bool twin = p0 != p1;  // the two order statistics parted ways: they need their own histograms
     const unsigned long long himask = shift == 56 ? 0ull : ~0ull << (shift + 8);
-    for (int64_t rb = r0 + tid; rb < r1; rb += 256 * 8) {
-      double len[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int64_t r = rb + 256 * i;
-        len[i] = r < r1 ? h[r] : pp_nanv();
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (!pp_isnan(len[i])) {
-          const unsigned long long key = pp_bits(len[i]);
-          const int digit = (int)((key >> shift) & 255);
-          if ((key & himask) == p0) atomicAdd(&hist[0][wv][digit], 1);
-          if ((key & himask) == p1) atomicAdd(&hist[1][wv][digit], 1);
-        }
-      }
+    sweep([&](unsigned long long k) {
+      const int digit = (int)((k >> shift) & 255);
+      if ((k & himask) == p0) atomicAdd(&hist[0][copy][digit], 1);
+      if (twin && (k & himask) == p1) atomicAdd(&hist[1][copy][digit], 1);
+    });
+    __syncthreads();
+    int t0 = 0, t1 = 0;
+    for (int k = 0; k < 8; ++k) {
+      t0 += hist[0][k][tid];
+      t1 += hist[1][k][tid];
     }
+    if (!twin) t1 = t0;
     __syncthreads();
-    hist[0][0][tid] += hist[0][1][tid] + hist[0][2][tid] + hist[0][3][tid];
-    hist[1][0][tid] += hist[1][1][tid] + hist[1][2][tid] + hist[1][3][tid];
+    // inclusive prefix sums over the 256 digits (both statistics at once); the digit whose running count first
+    // exceeds the remaining rank is the next byte
+    hist[0][0][tid] = t0;
+    hist[1][0][tid] = t1;
     __syncthreads();
-    if (tid < 2) {
-      int k = krem[tid], d = 0;
-      while (d < 255 && k >= hist[tid][0][d]) {
-        k -= hist[tid][0][d];
-        ++d;
-      }
-      krem[tid] = k;
-      sel[tid] |= (unsigned long long)d << shift;
+    for (int off = 1; off < 256; off <<= 1) {
+      const int u0 = tid >= off ? hist[0][0][tid - off] : 0, u1 = tid >= off ? hist[1][0][tid - off] : 0;
+      __syncthreads();
+      hist[0][0][tid] += u0;
+      hist[1][0][tid] += u1;
+      __syncthreads();
+    }
+    const int k0 = krem[0], k1 = krem[1];
+    const int inc0 = hist[0][0][tid], inc1 = hist[1][0][tid];
+    __syncthreads();
+    if (inc0 - t0 <= k0 && k0 < inc0) {
+      krem[0] = k0 - (inc0 - t0);
+      sel[0] |= (unsigned long long)tid << shift;
+    }
+    if (inc1 - t1 <= k1 && k1 < inc1) {
+      krem[1] = k1 - (inc1 - t1);
+      sel[1] |= (unsigned long long)tid << shift;
     }
     __syncthreads();
   }
@@ -274,9 +300,8 @@ __global__ void __launch_bounds__(256) k_pp_divisors(const int* __restrict__ cha
 // ---------------------------------------------------------------------------------------------------------
 // slot -> video table (one binary search per slot here instead of one per workgroup in every pass); the tile
 // table also carries the tile's first row and row count: (video or -1, global row, row within the video, rows)
-__global__ void __launch_bounds__(256) k_pp_slot_table(const int64_t* __restrict__ video_off, int V, int R, int64_t n_slots,
-                                                       int* __restrict__ slot_v, int* __restrict__ slot_rec) {
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pp_slot_table(int64_t b, const int64_t* __restrict__ video_off, int V, int R, int64_t n_slots,
+                                              int* __restrict__ slot_v, int* __restrict__ slot_rec) {
   if (b >= n_slots) return;
   int v;
   int64_t k;
@@ -295,8 +320,8 @@ __global__ void __launch_bounds__(256) k_pp_slot_table(const int64_t* __restrict
 // agree on "takes log1p", so a wavefront never pays for the logarithm on behalf of a few lanes.
 // chunks[0] = count, then (start, n, log) triples.  One thread per column, two Hillis-Steele scans in LDS
 // (run start = prefix max of the flip positions, chunk number = prefix sum of the chunk starts).
-__global__ void __launch_bounds__(DOF_PP_MAX_COLS) k_pp_chunks(const int* __restrict__ col_kind, const int* __restrict__ index,
-                                                               int n_cols, int log_dist, int* __restrict__ chunks) {
+__device__ __forceinline__ void pp_chunks(const int* __restrict__ col_kind, const int* __restrict__ index, int n_cols,
+                                          int log_dist, int* __restrict__ chunks) {
   __shared__ int lg[DOF_PP_MAX_COLS], a[DOF_PP_MAX_COLS], b[DOF_PP_MAX_COLS];
   const int c = threadIdx.x;
   int mine = 0;
@@ -338,6 +363,22 @@ __global__ void __launch_bounds__(DOF_PP_MAX_COLS) k_pp_chunks(const int* __rest
   }
 }
 
+// all index tables of a call in one launch: strip slots, tile slots, raw-column chunks, output-column chunks
+__global__ void __launch_bounds__(DOF_PP_MAX_COLS) k_pp_setup(const int64_t* __restrict__ video_off, int V, int64_t strips,
+                                                              int64_t tiles, const int* __restrict__ col_kind,
+                                                              const int* __restrict__ out_cols, int C, int n_out,
+                                                              int log_dist, int* __restrict__ strip_v,
+                                                              int* __restrict__ tile_rec, int* __restrict__ chunks,
+                                                              int* __restrict__ ochunks) {
+  const int64_t nb_s = (strips + DOF_PP_MAX_COLS - 1) / DOF_PP_MAX_COLS, nb_t = (tiles + DOF_PP_MAX_COLS - 1) / DOF_PP_MAX_COLS;
+  const int64_t blk = blockIdx.x;
+  if (blk < nb_s) pp_slot_table(blk * DOF_PP_MAX_COLS + threadIdx.x, video_off, V, PP_RS, strips, strip_v, nullptr);
+  else if (blk < nb_s + nb_t)
+    pp_slot_table((blk - nb_s) * DOF_PP_MAX_COLS + threadIdx.x, video_off, V, PP_TR, tiles, nullptr, tile_rec);
+  else if (blk == nb_s + nb_t) pp_chunks(col_kind, nullptr, C, log_dist, chunks);
+  else pp_chunks(col_kind, out_cols, n_out, log_dist, ochunks);
+}
+
 // Reference-accuracy logarithm of c in [1, 2] (argument reduction s = f / (2 + f), fdlibm's e_log minimax
 // coefficients, < 1 ulp); only used to fill the 128-entry table below.
 __device__ __forceinline__ double pp_log_1to2(double c) {
@@ -376,12 +417,10 @@ __device__ __forceinline__ double pp_log1p(double x, const double (*tab)[2]) {
   const int i = (int)((hi >> 13) & 127u);
   const double m = pp_from_bits((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
   const double r = fma(m, tab[i][0], -1.0);
-  double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
-  p = fma(r, p, 1.0 / 5.0);
-  p = fma(r, p, -1.0 / 4.0);
-  p = fma(r, p, 1.0 / 3.0);
-  p = fma(r, p, -0.5);
-  p = fma(r, p, 1.0);
+  // log(1 + r) = r (1 - r/2 + r^2/3 - ... + r^6/7), Estrin's scheme (three short dependent steps instead of seven)
+  const double r2 = r * r, r4 = r2 * r2;
+  const double p01 = fma(r, -0.5, 1.0), p23 = fma(r, -1.0 / 4.0, 1.0 / 3.0), p45 = fma(r, -1.0 / 6.0, 1.0 / 5.0);
+  const double p = fma(r4, fma(r2, 1.0 / 7.0, p45), fma(r2, p23, p01));
   const double lg = fma(dk, 6.93147180369123816490e-01, tab[i][1] + fma(r, p, dk * 1.90821492927058770002e-10));
   const double res = lg + c * (double)(1.0f / (float)u);
   return x == 0.0 ? 0.0 : res;
@@ -418,7 +457,12 @@ __global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw
     while (width / 2 >= ccount && width > 1) width >>= 1;
     const int pack = 64 / width, sub = lane / width, cl = lane - sub * width;
     const int c = cbase + cl;
-    double n = 0.0, shift = 0.0, s1 = 0.0, s2 = 0.0, nb = 0.0, s1b = 0.0, s2b = 0.0;
+    // two interleaved accumulator sets (shorter dependency chains); sums are taken about `shift`, the first value
+    // this thread sees (fixed from then on, so no element waits for the previous one)
+    double n[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0}, nb[2] = {0.0, 0.0}, s1b[2] = {0.0, 0.0},
+           s2b[2] = {0.0, 0.0};
+    double shift = 0.0;
+    bool have_shift = false;
     const bool mine = cl < ccount && pp_mode(col_kind[c], speed_mode, dist_mode, coord_mode) != DOF_PP_MODE_NONE;
     if (mine) {
       const double rd = rdiv[(int64_t)v * C + c];
@@ -439,23 +483,34 @@ __global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw
             if (u < 0.0) u = 0.0;
             u = pp_log1p(u, logtab);
           }
-          const bool ok = !pp_isnan(u);
-          if (ok && n == 0.0) shift = u;
-          const double d = ok ? u - shift : 0.0;
-          n += ok ? 1.0 : 0.0;
-          s1 += d;
-          s2 += d * d;
+          x[i] = u;
+        }
+        if (!have_shift) {
+#pragma unroll
+          for (int i = 7; i >= 0; --i)
+            if (!pp_isnan(x[i])) {
+              shift = x[i];
+              have_shift = true;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool ok = !pp_isnan(x[i]);
+          const double d = ok ? x[i] - shift : 0.0;
+          n[i & 1] += ok ? 1.0 : 0.0;
+          s1[i & 1] += d;
+          s2[i & 1] = fma(d, d, s2[i & 1]);
           if (MASKED) {
             const bool smp = ok && in[i];
-            nb += smp ? 1.0 : 0.0;
-            s1b += smp ? d : 0.0;
-            s2b += smp ? d * d : 0.0;
+            nb[i & 1] += smp ? 1.0 : 0.0;
+            s1b[i & 1] += smp ? d : 0.0;
+            s2b[i & 1] += smp ? d * d : 0.0;
           }
         }
       }
     }
-    sh[0][rg][lane] = pp_from_sums(n, shift, s1, s2);
-    sh[1][rg][lane] = MASKED ? pp_from_sums(nb, shift, s1b, s2b) : sh[0][rg][lane];
+    sh[0][rg][lane] = pp_from_sums(n[0] + n[1], shift, s1[0] + s1[1], s2[0] + s2[1]);
+    sh[1][rg][lane] = MASKED ? pp_from_sums(nb[0] + nb[1], shift, s1b[0] + s1b[1], s2b[0] + s2b[1]) : sh[0][rg][lane];
     __syncthreads();
     if (rg < 2 && lane < ccount) {
       PpStat t = {0.0, 0.0, 0.0};
@@ -965,12 +1020,15 @@ extern "C" int dof_preprocess_tables(const DofPreprocDims* dims, const double* r
   const int V = d.n_videos, C = d.n_cols, A = d.n_animals;
   const int n_out = d.n_node_cols + d.n_edge_cols + d.n_angle_cols;
   const int64_t strips = pp_slots(d.n_frames, V, PP_RS), tiles = pp_slots(d.n_frames, V, PP_TR);
-  DOF_LAUNCH(k_pp_slot_table, (dof_cdiv(strips, 256)), (256), st, video_off, V, PP_RS, strips, w.strip_v, (int*)nullptr);
-  DOF_LAUNCH(k_pp_slot_table, (dof_cdiv(tiles, 256)), (256), st, video_off, V, PP_TR, tiles, (int*)nullptr, w.tile_rec);
-  DOF_LAUNCH(k_pp_chunks, (1), (DOF_PP_MAX_COLS), st, col_kind, (const int*)nullptr, C, d.log_distances, w.chunks);
-  DOF_LAUNCH(k_pp_chunks, (1), (DOF_PP_MAX_COLS), st, col_kind, out_cols, n_out, d.log_distances, w.ochunks);
+  DOF_LAUNCH(k_pp_setup, (dof_cdiv(strips, DOF_PP_MAX_COLS) + dof_cdiv(tiles, DOF_PP_MAX_COLS) + 2), (DOF_PP_MAX_COLS), st,
+             video_off, V, strips, tiles, col_kind, out_cols, C, n_out, d.log_distances, w.strip_v, w.tile_rec, w.chunks,
+             w.ochunks);
   (void)hipMemsetAsync(w.notes, 0xFF, (size_t)w.note_bytes, st);
-  if (A > 0) DOF_LAUNCH(k_pp_size, (A, V), (256), st, raw, video_off, size_ref, C, A, d.n_frames, w.hyp, w.sfac);
+  if (A > 0) {
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(w.hyp);
+    DOF_LAUNCH(k_pp_hyp, (dof_cdiv(d.n_frames, 256)), (256), st, raw, size_ref, C, A, d.n_frames, keys);
+    DOF_LAUNCH(k_pp_size, (A, V), (256), st, video_off, size_ref, A, d.n_frames, (const unsigned long long*)keys, w.sfac);
+  }
   DOF_LAUNCH(k_pp_divisors, (V), (256), st, chain_off, chain, C, A, d.inter_scale, w.sfac, w.rdiv);
 #define PP_STATS(M)                                                                                                  \
   DOF_LAUNCH((k_pp_stats<M>), ((unsigned)strips), (256), st, raw, video_off, (const int*)w.strip_v, (const int*)w.chunks, \

@@ -100,3 +100,8 @@ def test_preprocess_tables_vs_oracle_emu(modes):
 
 def test_preprocess_tables_sampled_rows_emu():
     PC.run_preprocess_vs_oracle(emu_lib(), "cpu", samples_max=120, seed=9)
+
+
+def test_preprocess_tables_long_video_emu():
+    """> 16384 rows in one video: the size-factor selection leaves the register-resident path."""
+    PC.run_preprocess_vs_oracle(emu_lib(), "cpu", n_videos=2, frames=(16_700, 40), seed=13)

@@ -566,6 +566,8 @@ def test_preprocess_tables_vs_oracle_gpu(hip, modes):
     PC.run_preprocess_vs_oracle(hip, "cuda", **modes)
     PC.run_preprocess_vs_oracle(hip, "cuda", samples_max=120, seed=9, **modes)
     PC.run_preprocess_vs_oracle(hip, "cuda", n_videos=5, frames=(2000, 33, 4097, 31, 640), seed=11, **modes)
+    # a video longer than 16384 rows: the size-factor selection sweeps global memory instead of registers
+    PC.run_preprocess_vs_oracle(hip, "cuda", n_videos=2, frames=(20_011, 300), seed=13, **modes)
 
 
 def test_preprocess_full_size_c2(hip):

@@ -516,3 +516,68 @@ def test_trainer_data_parallel_gloo(tmp_path, name):
     if name == "Contrastive":   # augmentation draws are rank-local (as in the reference): logs differ, weights must not
         assert r0["total"] != r1["total"]
     torch.testing.assert_close(r0["params"], r1["params"], rtol=0, atol=0)
+
+
+# ---- pose-table preprocessing host logic -----------------------------------------------
+def test_preprocess_column_plan_and_sampling():
+    from deepof_amd import _capi
+    from deepof_amd import preprocess as PP
+    from oracle import preprocess as op
+    cols = [("B_Nose", "x"), ("B_Nose", "y"), ("B_Tail_base", "x"), ("B_Tail_base", "y"), ("W_Nose", "x"), ("W_Nose", "y"),
+            "B_Nose", "B_Tail_base", "W_Nose", ("B_Nose", "B_Tail_base"), ("B_Nose", "W_Nose"), ("B_Nose", "B_Tail_base", "W_Nose"), "pheno"]
+    kinds = PP.classify_columns(cols)
+    ct = op.column_types(cols)                          # same classification as the (reference-pinned) oracle
+    K = _capi.PP_KINDS
+    assert [i for i, k in enumerate(kinds) if k == K["coord"]] == ct["coords"]
+    assert [i for i, k in enumerate(kinds) if k == K["speed"]] == ct["speeds"]
+    assert [i for i, k in enumerate(kinds) if k == K["dist_inner"]] == ct["inner"]
+    assert [i for i, k in enumerate(kinds) if k == K["dist_intra"]] == ct["intra"]
+    assert [i for i, k in enumerate(kinds) if k == K["angle"]] == ct["angles"] and kinds[-1] == K["other"]
+    plan = PP.column_plan(cols, ["B", "W"])
+    assert plan.size_ref[0].tolist() == [0, 1, 2, 3] and plan.size_ref[1].tolist() == [-1, -1, -1, -1]   # W has no tail base
+    chain = lambda c: plan.chain[plan.chain_off[c]:plan.chain_off[c + 1]].tolist()   # noqa: E731
+    assert chain(0) == [[0, 0, 1]] and chain(4) == [[1, 1, 1]]          # coordinates: own animal once
+    # speed of B_Nose: own factor, then once per distance column it appears in (reference .loc quirk)
+    assert chain(6) == [[0, 0, 1], [0, 0, 1], [0, 1, 0]]
+    assert chain(9) == [] and chain(10) == []                           # distances themselves are never divided
+    with pytest.raises(KeyError):
+        PP.column_plan([("A_x", "x"), ("A_x", "y"), ("A_y", "x"), ("A_y", "y"), "A_x", ("A_x", "A_y")], ["A"])  # no speed A_y
+    # single-animal default ids [""]: no reference columns -> no size factor at all
+    single = PP.column_plan([("Nose", "x"), ("Nose", "y"), "Nose"], [""])
+    assert single.size_ref.tolist() == [[-1, -1, -1, -1]] and single.chain.size == 0
+    # row sampling: one RandomState(2) through the videos, mask only when some video is longer than samples_max
+    assert PP.sample_mask([50, 70], 100) is None
+    m = PP.sample_mask([50, 70, 20], 30)
+    want = op.sample_rows([50, 70, 20], 30)
+    assert m.sum() == 30 + 30 + 20 and sorted(np.flatnonzero(m[50:120]).tolist()) == sorted(want[1].tolist())
+
+
+def test_preprocess_host_api_emu(golden_dir):
+    import parity_common as PC
+    from deepof_amd.dataset import WindowDataset
+    from deepof_amd.preprocess import preprocess_tables
+    lib = emu_lib()
+    g, cases, data = PC.load_preprocess_golden(golden_dir)
+    cols, aids, tabs = data["pair"]
+    node_cols, edge_cols, angle_cols = PC.preprocess_output_columns(cols)
+    import pandas as pd
+    frames = {k: pd.DataFrame(v, columns=pd.Index(cols, tupleize_cols=False)) for k, v in tabs.items()}   # DataFrames work too
+    res = preprocess_tables(frames, cols, aids, node_cols, edge_cols, angle_cols, device="cpu", lib=lib)
+    assert res.keys == ["vid0", "vid1", "vid2"]                          # the all-NaN table is dropped
+    assert res.global_scaler["kind"] == "standard" and res.global_scaler["dist"] is None
+    assert res.global_scaler["coord"][0].shape == (1,) and res.global_scaler["dist_inner"] is not None
+    sf = res.size_factors.numpy()
+    assert sf.shape == (3, 3) and (sf > 0).all()
+    ds = WindowDataset.from_device_tables(res, 12, 3, lib)
+    lens = np.diff(res.video_off)
+    assert len(ds) == sum((n - 12) // 3 + 1 for n in lens) and ds.x_shape == (12, 8, 3) and ds.a_shape == (12, len(edge_cols), 1)
+    x, a = ds.fetch(0, 4)
+    assert torch.equal(x[1, :, :, 1], res.node_table[3:15, 8:16]) and torch.equal(a[3, :, :, 0], res.edge_table[9:21])
+    only = WindowDataset.from_device_tables(res, 12, 3, lib, keys=["vid2"])
+    assert only.keys == ["vid2"] and len(only) == (lens[2] - 12) // 3 + 1
+    with pytest.raises(NotImplementedError):
+        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, scale="minmax", device="cpu", lib=lib)
+    with pytest.raises(ValueError):
+        preprocess_tables({"a": np.full((5, len(cols)), np.nan)}, cols, aids, node_cols, edge_cols, device="cpu", lib=lib)
+    with pytest.raises(ValueError):
+        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, dist_standardize="columnwise", device="cpu", lib=lib)
