@@ -103,6 +103,8 @@ SIGNATURES = {
     "dof_contrastive_backward": (C.c_int, [_P, _P, _P, _P, _I32, _P]),
     "dof_preprocess_workspace_bytes": (_I64, [C.POINTER(PreprocDims)]),
     "dof_preprocess_tables": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 16),
+    "dof_preprocess_video_stats": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 10),
+    "dof_preprocess_fit_global": (C.c_int, [C.POINTER(PreprocDims), _I32, _P, _P, _P, _P]),
 }
 
 

@@ -635,6 +635,41 @@ __global__ void __launch_bounds__(256) k_pp_global_cols(const PpStat* __restrict
   }
 }
 
+// the global scalers alone, from the (n, mean, M2) rows of ALL videos (one workgroup; the multi-GPU path gathers
+// every rank's rows and runs this on each rank): same merge order as k_pp_global_cols + k_pp_coef, so the scalers
+// are bit-identical to those of a single-GPU call over the same videos
+__global__ void __launch_bounds__(256) k_pp_fit_global(const int* __restrict__ col_kind, const PpStat* __restrict__ ystat, int V,
+                                                       int C, int speed_mode, int dist_mode, int coord_mode,
+                                                       double* __restrict__ scaler) {
+  __shared__ PpStat col[DOF_PP_MAX_COLS];
+  __shared__ int kinds[DOF_PP_MAX_COLS];
+  __shared__ PpStat tree[4][64];
+  __shared__ PpStat grp[4];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  for (int cbase = 0; cbase < C; cbase += 64) {
+    const int c = cbase + lane;
+    PpStat a = {0.0, 0.0, 0.0};
+    if (c < C) a = pp_merge_run(ystat + c, V, C, rg);
+    tree[rg][lane] = a;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+      PpStat t = tree[0][lane];
+      for (int g = 1; g < 4; ++g) t = pp_merge(t, tree[g][lane]);
+      col[c] = t;
+      kinds[c] = col_kind[c];
+    }
+    __syncthreads();
+  }
+  pp_group_stats(col, kinds, C, DOF_PP_COORD, 4, tree, grp);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int mode = pp_mode(kinds[c], speed_mode, dist_mode, coord_mode);
+    double gm = 0.0, gs = 1.0;
+    if (mode != DOF_PP_MODE_NONE) pp_fit(mode == DOF_PP_MODE_PER_COLUMN ? col[c] : grp[kinds[c] - DOF_PP_COORD], &gm, &gs);
+    scaler[2 * c] = gm;
+    scaler[2 * c + 1] = gs;
+  }
+}
+
 // per video: the global scalers (columns -> groups coord / speed / inner / intra; every workgroup derives the same
 // values, workgroup 0 publishes them) and the coefficients of the complete element transform
 //   u = x * cf[0] [log1p(max(u, 0))];  z = u * cf[1] + cf[2]
@@ -967,13 +1002,13 @@ PpWorkspace pp_layout(const DofPreprocDims& d, void* base) {
   return w;
 }
 
-int pp_check(const DofPreprocDims* d) {
+int pp_check(const DofPreprocDims* d, bool stats_only = false) {
   if (!d) {
     dof_set_error("dof_preprocess: dims is null");
     return DOF_ERR_ARG;
   }
   const int n_out = d->n_node_cols + d->n_edge_cols + d->n_angle_cols;
-  if (d->n_frames <= 0 || d->n_videos <= 0 || d->n_cols <= 0 || d->n_animals < 0 || n_out <= 0 || d->n_node_cols < 0 ||
+  if (d->n_frames <= 0 || d->n_videos <= 0 || d->n_cols <= 0 || d->n_animals < 0 || (n_out <= 0 && !stats_only) || d->n_node_cols < 0 ||
       d->n_edge_cols < 0 || d->n_angle_cols < 0 || d->clip < 0.0) {
     dof_set_error("dof_preprocess: bad dims");
     return DOF_ERR_ARG;
@@ -1002,28 +1037,33 @@ extern "C" int64_t dof_preprocess_workspace_bytes(const DofPreprocDims* dims) {
   return pp_layout(*dims, nullptr).bytes;
 }
 
-extern "C" int dof_preprocess_tables(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
-                                     const int32_t* col_kind, const int32_t* size_ref, const int32_t* chain_off,
-                                     const int32_t* chain, const int32_t* out_cols, const uint8_t* sample_mask,
-                                     double* scaler, double* size_out, double* video_scaler, float* node_out,
-                                     float* edge_out, float* angle_out, void* workspace, void* stream) {
-  const int rc = pp_check(dims);
+namespace {
+// stats_only: stop after the per-video statistics and hand out the (n, mean, M2) rows of the sampled,
+// per-video-standardised values (what the global scalers are fitted on)
+int pp_run(const DofPreprocDims* dims, bool stats_only, const double* raw, const int64_t* video_off, const int32_t* col_kind,
+           const int32_t* size_ref, const int32_t* chain_off, const int32_t* chain, const int32_t* out_cols,
+           const uint8_t* sample_mask, double* scaler, double* size_out, double* video_scaler, double* ystat_out,
+           float* node_out, float* edge_out, float* angle_out, void* workspace, void* stream) {
+  const int rc = pp_check(dims, stats_only);
   if (rc != DOF_OK) return rc;
   const DofPreprocDims& d = *dims;
-  if (!raw || !video_off || !col_kind || !chain_off || !out_cols || !scaler || !workspace || (d.n_animals > 0 && !size_ref) ||
-      (d.n_node_cols > 0 && !node_out) || (d.n_edge_cols > 0 && !edge_out) || (d.n_angle_cols > 0 && !angle_out)) {
-    dof_set_error("dof_preprocess_tables: null pointer argument");
+  const bool bad_out = !stats_only && (!out_cols || !scaler || (d.n_node_cols > 0 && !node_out) ||
+                                       (d.n_edge_cols > 0 && !edge_out) || (d.n_angle_cols > 0 && !angle_out));
+  if (!raw || !video_off || !col_kind || !chain_off || !workspace || (d.n_animals > 0 && !size_ref) || bad_out ||
+      (stats_only && !ystat_out)) {
+    dof_set_error("dof_preprocess: null pointer argument");
     return DOF_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
   const PpWorkspace w = pp_layout(d, workspace);
   const int V = d.n_videos, C = d.n_cols, A = d.n_animals;
-  const int n_out = d.n_node_cols + d.n_edge_cols + d.n_angle_cols;
+  const int n_out = stats_only ? 0 : d.n_node_cols + d.n_edge_cols + d.n_angle_cols;
   const int64_t strips = pp_slots(d.n_frames, V, PP_RS), tiles = pp_slots(d.n_frames, V, PP_TR);
+  const bool coord_stats = stats_only || d.fit_global;
   DOF_LAUNCH(k_pp_setup, (dof_cdiv(strips, DOF_PP_MAX_COLS) + dof_cdiv(tiles, DOF_PP_MAX_COLS) + 2), (DOF_PP_MAX_COLS), st,
              video_off, V, strips, tiles, col_kind, out_cols, C, n_out, d.log_distances, w.strip_v, w.tile_rec, w.chunks,
              w.ochunks);
-  (void)hipMemsetAsync(w.notes, 0xFF, (size_t)w.note_bytes, st);
+  if (!stats_only) (void)hipMemsetAsync(w.notes, 0xFF, (size_t)w.note_bytes, st);
   if (A > 0) {
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(w.hyp);
     DOF_LAUNCH(k_pp_hyp, (dof_cdiv(d.n_frames, 256)), (256), st, raw, size_ref, C, A, d.n_frames, keys);
@@ -1033,7 +1073,7 @@ extern "C" int dof_preprocess_tables(const DofPreprocDims* dims, const double* r
 #define PP_STATS(M)                                                                                                  \
   DOF_LAUNCH((k_pp_stats<M>), ((unsigned)strips), (256), st, raw, video_off, (const int*)w.strip_v, (const int*)w.chunks, \
              col_kind, (const double*)w.rdiv, sample_mask, C, d.speed_mode, d.dist_mode,                             \
-             d.fit_global ? d.coord_mode : DOF_PP_MODE_NONE, w.part_all, w.part_smp)
+             coord_stats ? d.coord_mode : DOF_PP_MODE_NONE, w.part_all, w.part_smp)
   if (sample_mask) PP_STATS(true); else PP_STATS(false);
 #undef PP_STATS
   const unsigned col_chunks = dof_cdiv(C, 64);
@@ -1041,6 +1081,11 @@ extern "C" int dof_preprocess_tables(const DofPreprocDims* dims, const double* r
              w.vcol_all, w.vcol_smp);
   DOF_LAUNCH(k_pp_video_fin, (V), (256), st, col_kind, (const PpStat*)w.vcol_all, (const PpStat*)w.vcol_smp, C, d.speed_mode,
              d.dist_mode, w.vscale, w.ystat);
+  if (size_out) (void)hipMemcpyAsync(size_out, w.sfac, (size_t)V * (A + 1) * 8, hipMemcpyDeviceToDevice, st);
+  if (stats_only) {
+    (void)hipMemcpyAsync(ystat_out, w.ystat, (size_t)V * C * sizeof(PpStat), hipMemcpyDeviceToDevice, st);
+    return dof_check_launch("dof_preprocess_video_stats");
+  }
   if (d.fit_global) DOF_LAUNCH(k_pp_global_cols, (col_chunks), (256), st, (const PpStat*)w.ystat, V, C, w.gcol);
   DOF_LAUNCH(k_pp_coef, (V), (256), st, col_kind, (const PpStat*)w.gcol, (const double*)w.rdiv, (const double*)w.vscale,
              scaler, d.fit_global, C, d.speed_mode, d.dist_mode, d.coord_mode, w.coef, video_scaler);
@@ -1063,7 +1108,34 @@ extern "C" int dof_preprocess_tables(const DofPreprocDims* dims, const double* r
   oa.angle_out = angle_out;
   DOF_LAUNCH(k_pp_finish, (dof_cdiv(tiles, 32)), (256), st, oa, (const int*)w.ochunks, w.notes);
   DOF_LAUNCH(k_pp_fill, (n_out, V), (256), st, oa, (const uint8_t*)w.notes);
-  if (size_out)
-    (void)hipMemcpyAsync(size_out, w.sfac, (size_t)V * (A + 1) * 8, hipMemcpyDeviceToDevice, st);
   return dof_check_launch("dof_preprocess_tables");
+}
+}  // namespace
+
+extern "C" int dof_preprocess_tables(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
+                                     const int32_t* col_kind, const int32_t* size_ref, const int32_t* chain_off,
+                                     const int32_t* chain, const int32_t* out_cols, const uint8_t* sample_mask,
+                                     double* scaler, double* size_out, double* video_scaler, float* node_out,
+                                     float* edge_out, float* angle_out, void* workspace, void* stream) {
+  return pp_run(dims, false, raw, video_off, col_kind, size_ref, chain_off, chain, out_cols, sample_mask, scaler, size_out,
+                video_scaler, nullptr, node_out, edge_out, angle_out, workspace, stream);
+}
+
+extern "C" int dof_preprocess_video_stats(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
+                                          const int32_t* col_kind, const int32_t* size_ref, const int32_t* chain_off,
+                                          const int32_t* chain, const uint8_t* sample_mask, double* ystat_out,
+                                          void* workspace, void* stream) {
+  return pp_run(dims, true, raw, video_off, col_kind, size_ref, chain_off, chain, nullptr, sample_mask, nullptr, nullptr, nullptr,
+                ystat_out, nullptr, nullptr, nullptr, workspace, stream);
+}
+
+extern "C" int dof_preprocess_fit_global(const DofPreprocDims* dims, int32_t n_videos_total, const int32_t* col_kind,
+                                         const double* ystat_all, double* scaler, void* stream) {
+  if (!dims || !col_kind || !ystat_all || !scaler || n_videos_total <= 0 || dims->n_cols <= 0 || dims->n_cols > DOF_PP_MAX_COLS) {
+    dof_set_error("dof_preprocess_fit_global: bad argument");
+    return DOF_ERR_ARG;
+  }
+  DOF_LAUNCH(k_pp_fit_global, (1), (256), (hipStream_t)stream, col_kind, reinterpret_cast<const PpStat*>(ystat_all),
+             n_videos_total, dims->n_cols, dims->speed_mode, dims->dist_mode, dims->coord_mode, scaler);
+  return dof_check_launch("dof_preprocess_fit_global");
 }

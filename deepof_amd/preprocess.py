@@ -189,16 +189,98 @@ def _scaler_from_dict(gs: dict, kinds: np.ndarray, modes: Dict[str, Optional[str
     return per_col
 
 
+class _Call:
+    """Descriptor tensors + one invocation of the C ABI for a set of (local) videos."""
+
+    def __init__(self, lib, device, arrays, plan, out_cols, n_node, n_edge, n_ang, modes, log_distances, inter_scale, clip,
+                 raw_device=None):
+        self.lib, self.device, self.plan = lib, torch.device(device), plan
+        self.lengths = [a.shape[0] for a in arrays]
+        self.video_off = np.zeros(len(arrays) + 1, dtype=np.int64)
+        self.video_off[1:] = np.cumsum(self.lengths)
+        self.n_frames, self.n_cols = int(self.video_off[-1]), len(plan.kinds)
+        if raw_device is None:
+            raw_device = torch.from_numpy(np.concatenate(arrays) if len(arrays) > 1 else np.ascontiguousarray(arrays[0])).to(self.device)
+        if raw_device.dtype != torch.float64 or tuple(raw_device.shape) != (self.n_frames, self.n_cols):
+            raise ValueError("raw_device must be the concatenated float64 tables")
+        self.raw = raw_device
+        dev = self._dev
+        self.d_off, self.d_kind = dev(self.video_off), dev(plan.kinds)
+        self.d_ref = dev(plan.size_ref.reshape(-1) if plan.size_ref.size else np.zeros(4, np.int32))
+        self.d_coff = dev(plan.chain_off)
+        self.d_chain = dev(plan.chain.reshape(-1) if plan.chain.size else np.zeros(3, np.int32))
+        self.d_out = dev(out_cols)
+        self.counts = (n_node, n_edge, n_ang)
+        self.dims = _capi.PreprocDims(n_frames=self.n_frames, n_videos=len(arrays), n_cols=self.n_cols, n_animals=len(plan.animal_ids),
+                                      n_node_cols=n_node, n_edge_cols=n_edge, n_angle_cols=n_ang,
+                                      speed_mode=_capi.PP_MODES[modes["speed"]], dist_mode=_capi.PP_MODES[modes["dist"]],
+                                      coord_mode=_capi.PP_MODES[modes["coord"]], log_distances=int(bool(log_distances)),
+                                      inter_scale=_capi.PP_INTER_SCALE[inter_scale], fit_global=1, clip=float(clip or 0))
+        ws_bytes = lib.dof_preprocess_workspace_bytes(ctypes.byref(self.dims))
+        if ws_bytes < 0:
+            _capi.check(lib, -1, "dof_preprocess_workspace_bytes")
+        self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+
+    def _dev(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    @staticmethod
+    def _ptr(t):
+        return t.data_ptr() if t is not None else None
+
+    def video_stats(self, mask) -> torch.Tensor:
+        """(videos, C, 3) float64 (n, mean, M2) of the sampled, per-video-standardised rows."""
+        d_mask = self._dev(mask) if mask is not None else None
+        ystat = torch.empty(len(self.lengths), self.n_cols, 3, dtype=torch.float64, device=self.device)
+        p = self._ptr
+        _capi.check(self.lib, self.lib.dof_preprocess_video_stats(ctypes.byref(self.dims), p(self.raw), p(self.d_off), p(self.d_kind),
+                                                                  p(self.d_ref), p(self.d_coff), p(self.d_chain), p(d_mask), p(ystat),
+                                                                  p(self.ws), self.stream), "dof_preprocess_video_stats")
+        return ystat
+
+    def fit_global(self, ystat_all: torch.Tensor) -> torch.Tensor:
+        scaler = torch.empty(self.n_cols, 2, dtype=torch.float64, device=self.device)
+        p = self._ptr
+        _capi.check(self.lib, self.lib.dof_preprocess_fit_global(ctypes.byref(self.dims), int(ystat_all.shape[0]), p(self.d_kind),
+                                                                 p(ystat_all.contiguous()), p(scaler), self.stream),
+                    "dof_preprocess_fit_global")
+        return scaler
+
+    def tables(self, mask, scaler: Optional[torch.Tensor]):
+        """Run the whole pipeline on these videos; ``scaler`` given = apply it instead of fitting."""
+        n_node, n_edge, n_ang = self.counts
+        self.dims.fit_global = int(scaler is None)
+        d_scaler = scaler if scaler is not None else torch.empty(self.n_cols, 2, dtype=torch.float64, device=self.device)
+        d_mask = self._dev(mask) if (mask is not None and scaler is None) else None
+        node = torch.empty(self.n_frames, n_node, dtype=torch.float32, device=self.device)
+        edge = torch.empty(self.n_frames, n_edge, dtype=torch.float32, device=self.device)
+        ang = torch.empty(self.n_frames, n_ang, dtype=torch.float32, device=self.device) if n_ang else None
+        sizes = torch.empty(len(self.lengths), len(self.plan.animal_ids) + 1, dtype=torch.float64, device=self.device)
+        vsc = torch.empty(len(self.lengths), self.n_cols, 2, dtype=torch.float64, device=self.device)
+        p = self._ptr
+        _capi.check(self.lib, self.lib.dof_preprocess_tables(ctypes.byref(self.dims), p(self.raw), p(self.d_off), p(self.d_kind),
+                                                             p(self.d_ref), p(self.d_coff), p(self.d_chain), p(self.d_out), p(d_mask),
+                                                             p(d_scaler), p(sizes), p(vsc), p(node), p(edge), p(ang), p(self.ws),
+                                                             self.stream), "dof_preprocess_tables")
+        return node, edge, ang, sizes, vsc, d_scaler
+
+
 def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids, node_columns: Sequence,
                       edge_columns: Sequence, angle_columns: Sequence = (), *, scale: str = "standard",
                       samples_max: int = 227272, dist_standardize: Optional[str] = "groupwise",
                       speed_standardize: Optional[str] = "groupwise", coord_standardize: Optional[str] = "groupwise",
                       log_distances: bool = True, interpolate_normalized: float = 10, pretrained_scaler: Optional[dict] = None,
                       filter_low_variance=False, inter_scale: str = "mean", device="cuda", lib=None,
-                      raw_device: Optional[torch.Tensor] = None) -> PreprocessedTables:
+                      raw_device: Optional[torch.Tensor] = None, shard_videos: bool = False) -> PreprocessedTables:
     """``TableDict.preprocess`` for ``scale="standard"`` on the device.  ``tables``: {video key: (frames, C) float64
     array or DataFrame}; ``columns``: the C labels; ``node_columns`` / ``edge_columns`` / ``angle_columns``: the labels
-    the frame tables keep, in output order (get_graph_dataset's node_sorting / edge_sorting / angle_sorting indices)."""
+    the frame tables keep, in output order (get_graph_dataset's node_sorting / edge_sorting / angle_sorting indices).
+
+    ``shard_videos=True`` under an initialised ``torch.distributed`` group: rank r preprocesses videos r, r+world, ...
+    (sorted key order); the ranks exchange the per-video statistics the global scalers are fitted on (one all-gather
+    of (videos, C, 3) float64), fit identical scalers, finish their own videos and all-gather the frame tables, so
+    every rank ends up with the tables of ALL videos -- bit-identical to the single-process result."""
     if scale != "standard":
         raise NotImplementedError("only scale='standard' (the reference default) runs on the device")
     if filter_low_variance:
@@ -216,8 +298,6 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
     plan = column_plan(columns, animal_ids)
     where = {c: i for i, c in enumerate(columns)}
     out_cols = np.array([where[c] for c in list(node_columns) + list(edge_columns) + list(angle_columns)], dtype=np.int32)
-    if len(out_cols) > _capi.PP_MAX_OUT:
-        raise ValueError(f"at most {_capi.PP_MAX_OUT} output columns")
     arrays, keys = [], []
     for k in sorted(tables.keys()):
         t = tables[k]
@@ -233,45 +313,75 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
     lengths = [a.shape[0] for a in arrays]
     video_off = np.zeros(len(arrays) + 1, dtype=np.int64)
     video_off[1:] = np.cumsum(lengths)
-    n_frames = int(video_off[-1])
     modes = {"speed": speed_standardize, "dist": dist_standardize, "coord": coord_standardize}
+    n_node, n_edge, n_ang = len(node_columns), len(edge_columns), len(angle_columns)
     fit_global = pretrained_scaler is None
     mask = sample_mask(lengths, samples_max) if fit_global else None
-    if raw_device is None:
-        raw_device = torch.from_numpy(np.concatenate(arrays) if len(arrays) > 1 else arrays[0]).to(device)
-    if raw_device.dtype != torch.float64 or tuple(raw_device.shape) != (n_frames, len(columns)):
-        raise ValueError("raw_device must be the concatenated float64 tables")
-
-    def dev(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
-
-    scaler_host = np.tile(np.array([0.0, 1.0]), (len(columns), 1)) if fit_global else _scaler_from_dict(pretrained_scaler, plan.kinds, modes)
-    d_off, d_kind, d_ref = dev(video_off), dev(plan.kinds), dev(plan.size_ref.reshape(-1) if plan.size_ref.size else np.zeros(4, np.int32))
-    d_coff = dev(plan.chain_off)
-    d_chain = dev(plan.chain.reshape(-1) if plan.chain.size else np.zeros(3, np.int32))
-    d_out, d_scaler = dev(out_cols), dev(scaler_host)
-    d_mask = dev(mask) if mask is not None else None
-    n_node, n_edge, n_ang = len(node_columns), len(edge_columns), len(angle_columns)
-    dims = _capi.PreprocDims(n_frames=n_frames, n_videos=len(arrays), n_cols=len(columns), n_animals=len(plan.animal_ids),
-                             n_node_cols=n_node, n_edge_cols=n_edge, n_angle_cols=n_ang,
-                             speed_mode=_capi.PP_MODES[speed_standardize], dist_mode=_capi.PP_MODES[dist_standardize],
-                             coord_mode=_capi.PP_MODES[coord_standardize], log_distances=int(bool(log_distances)),
-                             inter_scale=_capi.PP_INTER_SCALE[inter_scale], fit_global=int(fit_global),
-                             clip=float(interpolate_normalized or 0))
-    ws_bytes = lib.dof_preprocess_workspace_bytes(ctypes.byref(dims))
-    if ws_bytes < 0:
-        _capi.check(lib, -1, "dof_preprocess_workspace_bytes")
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-    node = torch.empty(n_frames, n_node, dtype=torch.float32, device=device)
-    edge = torch.empty(n_frames, n_edge, dtype=torch.float32, device=device)
-    ang = torch.empty(n_frames, n_ang, dtype=torch.float32, device=device) if n_ang else None
-    sizes = torch.empty(len(arrays), len(plan.animal_ids) + 1, dtype=torch.float64, device=device)
-    vsc = torch.empty(len(arrays), len(columns), 2, dtype=torch.float64, device=device)
-    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
-    ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-    _capi.check(lib, lib.dof_preprocess_tables(ctypes.byref(dims), ptr(raw_device), ptr(d_off), ptr(d_kind), ptr(d_ref),
-                                               ptr(d_coff), ptr(d_chain), ptr(d_out), ptr(d_mask), ptr(d_scaler), ptr(sizes),
-                                               ptr(vsc), ptr(node), ptr(edge), ptr(ang), ptr(ws), stream),
-                "dof_preprocess_tables")
+    scaler_in = None if fit_global else torch.from_numpy(_scaler_from_dict(pretrained_scaler, plan.kinds, modes)).to(device)
+    common = dict(plan=plan, out_cols=out_cols, n_node=n_node, n_edge=n_edge, n_ang=n_ang, modes=modes, log_distances=log_distances,
+                  inter_scale=inter_scale, clip=interpolate_normalized)
+    import torch.distributed as dist
+    world = dist.get_world_size() if (shard_videos and dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        call = _Call(lib, device, arrays, raw_device=raw_device, **common)
+        node, edge, ang, sizes, vsc, d_scaler = call.tables(mask, scaler_in)
+    else:
+        node, edge, ang, sizes, vsc, d_scaler = _sharded(lib, device, arrays, video_off, mask, scaler_in, world, dist.get_rank(),
+                                                         len(plan.animal_ids), common)
     scaler = pretrained_scaler if not fit_global else _scaler_to_dict(d_scaler.cpu().numpy(), plan.kinds, modes, bool(log_distances))
     return PreprocessedTables(node, edge, ang, video_off, keys, scaler, sizes, vsc, columns)
+
+
+def _all_gather_rows(local: torch.Tensor, rows_per_rank: List[int]) -> List[torch.Tensor]:
+    """all_gather of tensors whose first dimension differs per rank (padded to the longest)."""
+    import torch.distributed as dist
+    longest = max(rows_per_rank)
+    pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in rows_per_rank]
+    dist.all_gather(parts, pad)
+    return [p[:n] for p, n in zip(parts, rows_per_rank)]
+
+
+def _sharded(lib, device, arrays, video_off, mask, scaler_in, world, rank, n_animals, common):
+    """Videos i = rank, rank + world, ... on this rank; two collectives (statistics rows, finished tables)."""
+    n_videos, n_cols = len(arrays), len(common["plan"].kinds)
+    owner = [list(range(r, n_videos, world)) for r in range(world)]
+    mine = owner[rank]
+    lengths = np.diff(video_off)
+    call = _Call(lib, device, [arrays[i] for i in mine], **common) if mine else None
+    local_mask = None
+    if mask is not None and mine:
+        local_mask = np.concatenate([mask[video_off[i]:video_off[i + 1]] for i in mine])
+    order = [i for r in range(world) for i in owner[r]]          # global index of the rows as gathered
+    back = torch.from_numpy(np.argsort(np.array(order))).to(device)
+    if scaler_in is None:
+        ystat = call.video_stats(local_mask) if mine else torch.zeros(0, n_cols, 3, dtype=torch.float64, device=device)
+        ystat_all = torch.cat(_all_gather_rows(ystat, [len(o) for o in owner]))[back]      # global video order
+        helper = call if call is not None else _Call(lib, device, [arrays[0][:1]], **common)
+        scaler_in = helper.fit_global(ystat_all)
+    n_node, n_edge, n_ang = common["n_node"], common["n_edge"], common["n_ang"]
+    if mine:
+        node, edge, ang, sizes, vsc, _ = call.tables(None, scaler_in)
+    else:
+        node = torch.zeros(0, n_node, device=device)
+        edge = torch.zeros(0, n_edge, device=device)
+        ang = torch.zeros(0, n_ang, device=device) if n_ang else None
+        sizes = torch.zeros(0, n_animals + 1, dtype=torch.float64, device=device)
+        vsc = torch.zeros(0, n_cols, 2, dtype=torch.float64, device=device)
+    rows = [int(sum(lengths[i] for i in o)) for o in owner]
+
+    def assemble(local, per_video: bool):
+        parts = _all_gather_rows(local, [len(o) for o in owner] if per_video else rows)
+        if per_video:
+            return torch.cat(parts)[back]
+        pieces = {}
+        for r, o in enumerate(owner):
+            off = 0
+            for i in o:
+                pieces[i] = parts[r][off:off + int(lengths[i])]
+                off += int(lengths[i])
+        return torch.cat([pieces[i] for i in range(n_videos)])
+
+    return (assemble(node, False), assemble(edge, False), assemble(ang, False) if n_ang else None, assemble(sizes, True),
+            assemble(vsc, True), scaler_in)

@@ -24,7 +24,8 @@
  *   dof_contrastive_backward    loss.backward() through one view's encoder pass (training.py:163)
  *   dof_turtle_fit_step/_predict  teacher_model.py:43-350 TurtleTeacher (heads inner fit, task encoder, fit, predict)
  *   dof_optimizer_step          training.py:164-166 clip_grad_value_ + optimizer.step(), losses.py:805-833
- *   dof_preprocess_tables       deepof/data.py:3773-3916 TableDict.preprocess (scale="standard") up to window
+ *   dof_preprocess_tables, dof_preprocess_video_stats, dof_preprocess_fit_global
+ *                               deepof/data.py:3773-3916 TableDict.preprocess (scale="standard") up to window
  *                               extraction: utils.py:2425-2566 scale_table, :2665-2792 _pp_pass1_collect_samples,
  *                               :2795-2863 _pp_fit_global_scaler, :2866-2921 _pp_apply_global,
  *                               :2924-3027 _pp_pass2_scale_and_save, :2577-2583 _pp_sanitize_numeric; output in the
@@ -310,6 +311,18 @@ int dof_preprocess_tables(const DofPreprocDims* dims, const double* raw, const i
                           const int32_t* chain, const int32_t* out_cols, const uint8_t* sample_mask, double* scaler,
                           double* size_out, double* video_scaler, float* node_out, float* edge_out, float* angle_out,
                           void* workspace, void* stream);
+/* Videos sharded over ranks (one process per GPU): the only quantity that couples the videos is the global scaler.
+ * dof_preprocess_video_stats runs the statistics pass on the local videos and writes ystat_out (n_videos, n_cols, 3)
+ * float64 = (n, mean, M2) of the sampled, per-video-standardised values; after an all-gather of these rows (in global
+ * video order) dof_preprocess_fit_global fits the scalers exactly as a single call over all videos would (same merge
+ * order, bit-identical), and dof_preprocess_tables(fit_global = 0, scaler) finishes the local videos.  The output
+ * column counts of dims are ignored by these two. */
+int dof_preprocess_video_stats(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
+                               const int32_t* col_kind, const int32_t* size_ref, const int32_t* chain_off,
+                               const int32_t* chain, const uint8_t* sample_mask, double* ystat_out, void* workspace,
+                               void* stream);
+int dof_preprocess_fit_global(const DofPreprocDims* dims, int32_t n_videos_total, const int32_t* col_kind,
+                              const double* ystat_all, double* scaler, void* stream);
 
 #ifdef __cplusplus
 }

@@ -581,3 +581,47 @@ def test_preprocess_host_api_emu(golden_dir):
         preprocess_tables({"a": np.full((5, len(cols)), np.nan)}, cols, aids, node_cols, edge_cols, device="cpu", lib=lib)
     with pytest.raises(ValueError):
         preprocess_tables(tabs, cols, aids, node_cols, edge_cols, dist_standardize="columnwise", device="cpu", lib=lib)
+
+
+def _pp_shard_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    import parity_common as PC
+    from deepof_amd.preprocess import preprocess_tables
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = emu_lib()
+    bps = [f"{a}_{p}" for a in ("B", "W") for p in ("Nose", "Center", "Tail_base", "Left_ear")]
+    tabs, cols = PC.synth_raw_tables(5, (90, 41, 130, 64, 77), bps, seed=21, nan_rate=0.03)
+    tabs["v001"][:20, 2] = np.nan
+    node_cols, edge_cols, _ = PC.preprocess_output_columns(cols)
+    out = {}
+    for name, kw in (("gw", dict(samples_max=50)), ("pc", dict(dist_standardize="per_column", speed_standardize="per_column",
+                                                              coord_standardize="per_column"))):
+        res = preprocess_tables(tabs, cols, ["B", "W"], node_cols, edge_cols, (), device="cpu", lib=lib, shard_videos=True, **kw)
+        out[name] = (res.node_table, res.edge_table, res.size_factors, res.video_scaler, res.global_scaler)
+        if rank == 0:
+            dist.barrier()
+            one = preprocess_tables(tabs, cols, ["B", "W"], node_cols, edge_cols, (), device="cpu", lib=lib, **kw)
+            out[name + "_single"] = (one.node_table, one.edge_table, one.size_factors, one.video_scaler, one.global_scaler)
+        else:
+            dist.barrier()
+    torch.save(out, os.path.join(tmp, f"pp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_preprocess_sharded_over_videos_gloo(tmp_path):
+    """N2 on 2 ranks (gloo, CPU, emulated kernels): videos sharded round-robin, statistics rows and finished tables
+    all-gathered -> every rank holds the tables of all videos, bit-identical to the single-process result."""
+    import torch.multiprocessing as mp
+    port = 33000 + (os.getpid() % 2000)
+    mp.spawn(_pp_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"pp{r}.pt", weights_only=False) for r in (0, 1))
+    for name in ("gw", "pc"):
+        for a, b, c in zip(r0[name][:4], r1[name][:4], r0[name + "_single"][:4]):
+            assert torch.equal(a, b) and torch.equal(a, c), name
+        for part in ("speed", "dist", "dist_inner", "dist_intra", "coord"):
+            g0, g1, gs = r0[name][4][part], r1[name][4][part], r0[name + "_single"][4][part]
+            assert (g0 is None) == (gs is None)
+            if g0 is not None:
+                assert all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(g0, g1, gs))
