@@ -713,17 +713,32 @@ def synth_raw_tables(n_videos, frames, bodyparts, seed, nan_rate=0.002):
     return tabs, cols
 
 
-def run_preprocess_vs_oracle(lib, device, n_videos=3, frames=(300, 97, 161), seed=5, samples_max=227272, **modes):
-    """Device path against the (reference-pinned) oracle on larger random tables; tiles, strips and videos ragged."""
+def run_preprocess_vs_oracle(lib, device, n_videos=3, frames=(300, 97, 161), seed=5, samples_max=227272, parts=5, edge_stride=3,
+                             n_angles=0, nan_rate=0.02, **modes):
+    """Device path against the (reference-pinned) oracle on larger random tables; tiles, strips and videos ragged.
+    ``parts`` body parts per animal (2 animals), every ``edge_stride``-th distance column is an output edge,
+    ``n_angles`` angle columns (interpolated only)."""
     from deepof_amd.preprocess import preprocess_tables
     from oracle import preprocess as op
-    bps = [f"{a}_{p}" for a in ("B", "W") for p in ("Nose", "Center", "Tail_base", "Left_ear", "Right_ear")]
-    tabs, cols = synth_raw_tables(n_videos, frames, bps, seed, nan_rate=0.02)
+    names = ["Nose", "Center", "Tail_base", "Left_ear", "Right_ear"] + [f"Spine_{i}" for i in range(40)]
+    bps = [f"{a}_{p}" for a in ("B", "W") for p in names[:parts]]
+    tabs, cols = synth_raw_tables(n_videos, frames, bps, seed, nan_rate=nan_rate)
+    rng = np.random.default_rng(seed + 1)
+    if n_angles:
+        cols = cols + [(bps[i], bps[i + 1], bps[i + 2]) for i in range(n_angles)]
+        for k in tabs:
+            ang = rng.uniform(0, np.pi, (tabs[k].shape[0], n_angles))
+            ang[rng.random(ang.shape) < 0.05] = np.nan
+            tabs[k] = np.concatenate([tabs[k], ang], axis=1)
     k0 = sorted(tabs)[0]
-    tabs[k0][:40, 3] = np.nan                          # a leading gap longer than a tile
-    tabs[k0][100:230, 7] = np.nan                      # an interior gap spanning several tiles
-    tabs[k0][-50:, len(bps) * 2 + 1] = np.nan          # a trailing gap
-    node_cols, edge_cols, angle_cols = preprocess_output_columns(cols)
+    n0 = tabs[k0].shape[0]
+    if n0 > 60:
+        tabs[k0][:40, 3] = np.nan                          # a leading gap longer than a tile
+        tabs[k0][n0 // 3: n0 // 3 + min(130, n0 // 3), 7] = np.nan   # an interior gap spanning several tiles
+        tabs[k0][-50:, len(bps) * 2 + 1] = np.nan          # a trailing gap
+    node_cols, _, angle_cols = preprocess_output_columns(cols)
+    dist = [c for c in cols if isinstance(c, tuple) and len(c) == 2 and c[1] not in ("x", "y")]
+    edge_cols = sorted(dist[::edge_stride])
     kw = dict(dist_standardize=modes.get("dist", "groupwise"), speed_standardize=modes.get("speed", "groupwise"),
               coord_standardize=modes.get("coord", "groupwise"))
     want, gs = op.preprocess(tabs, cols, ["B", "W"], samples_max=samples_max, **kw)

@@ -105,3 +105,14 @@ def test_preprocess_tables_sampled_rows_emu():
 def test_preprocess_tables_long_video_emu():
     """> 16384 rows in one video: the size-factor selection leaves the register-resident path."""
     PC.run_preprocess_vs_oracle(emu_lib(), "cpu", n_videos=2, frames=(16_700, 40), seed=13)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(n_videos=4, frames=(1, 7, 8, 9), parts=3, edge_stride=1, nan_rate=0.0),            # one-frame video, no gap at all
+    dict(n_videos=2, frames=(70, 33), parts=3, edge_stride=15),                             # a single edge column (packed 8x)
+    dict(n_videos=2, frames=(70, 33), parts=4, edge_stride=3, n_angles=3),                  # angle columns
+    dict(n_videos=2, frames=(40, 25), parts=9, edge_stride=2),                              # 153 distances, > 64 output columns
+    dict(n_videos=2, frames=(30, 17), parts=14, edge_stride=2, dist="per_column"),          # 462 raw columns, > 128 output columns
+])
+def test_preprocess_tables_shapes_emu(shape):
+    PC.run_preprocess_vs_oracle(emu_lib(), "cpu", seed=17, **shape)

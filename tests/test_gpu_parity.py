@@ -611,3 +611,17 @@ def test_preprocess_full_size_c2(hip):
     x, a = ds.fetch(14_975, 14_978)         # last window of video 0 and the first two of video 1
     assert torch.equal(x[0, :, :, 0], res.node_table[14_975:15_000, :14]) and torch.equal(x[1, :, :, 0], res.node_table[15_000:15_025, :14])
     assert torch.equal(a[2, :, :, 0], res.edge_table[15_001:15_026])
+
+
+@pytest.mark.parametrize("shape", [
+    dict(n_videos=4, frames=(1, 7, 8, 9), parts=3, edge_stride=1, nan_rate=0.0),
+    dict(n_videos=2, frames=(700, 333), parts=3, edge_stride=15),
+    dict(n_videos=2, frames=(700, 333), parts=4, edge_stride=3, n_angles=3),
+    dict(n_videos=3, frames=(400, 255, 1031), parts=9, edge_stride=2),
+    dict(n_videos=2, frames=(300, 170), parts=14, edge_stride=2, dist="per_column"),
+])
+def test_preprocess_tables_shapes_gpu(hip, shape):
+    """Ragged / extreme shapes: one-frame videos, a single packed edge column, angle columns, > 64 and > 128 output
+    columns, 462 raw columns."""
+    import parity_common as PC
+    PC.run_preprocess_vs_oracle(hip, "cuda", seed=17, **shape)
