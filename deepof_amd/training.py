@@ -868,8 +868,12 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
         dev = torch.device(f"cuda:{local_rank}" if is_ddp else "cuda")
     data_dev = dev if dev is not None else torch.device("cpu")
     preprocessed_train, preprocessed_val = preprocessed_object
-    train_ds = WindowDataset.from_preprocessed(preprocessed_train, data_dev)
-    val_ds = WindowDataset.from_preprocessed(preprocessed_val, data_dev)
+    # either the reference's {video: (node windows, edge windows, angles)} dicts, or window datasets over frame
+    # tables that deepof_amd.preprocess.preprocess_tables left on the device (nothing is materialised on the host)
+    train_ds = preprocessed_train if isinstance(preprocessed_train, WindowDataset) else \
+        WindowDataset.from_preprocessed(preprocessed_train, data_dev)
+    val_ds = preprocessed_val if isinstance(preprocessed_val, WindowDataset) else \
+        WindowDataset.from_preprocessed(preprocessed_val, data_dev)
     # block bootstrap of the training batches (dataset.py:351-352, 604-614); validation is never bootstrapped
     train_ds.bootstrap_training, train_ds.bootstrap_block_len = bool(bootstrap_training), int(bootstrap_block_len)
     if model_name == "vqvae":

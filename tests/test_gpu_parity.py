@@ -625,3 +625,31 @@ def test_preprocess_tables_shapes_gpu(hip, shape):
     columns, 462 raw columns."""
     import parity_common as PC
     PC.run_preprocess_vs_oracle(hip, "cuda", seed=17, **shape)
+
+
+def test_raw_tables_to_training_gpu(hip, tmp_path):
+    """Raw pose tables -> dof_preprocess_tables -> window datasets over the resident frame tables -> train_deepof_model
+    on the MI355X: the scaled tables and the windows never exist on the host."""
+    import parity_common as PC
+    from deepof_amd import training as TR
+    from deepof_amd.dataset import WindowDataset
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    from deepof_amd.preprocess import preprocess_tables
+    nodes, edges = bodypart_graph([""])
+    tabs, cols = PC.synth_raw_tables(4, (900, 700, 800, 600), list(nodes), seed=4, nan_rate=0.005)
+    have = {frozenset(c): c for c in cols if isinstance(c, tuple) and len(c) == 2 and c[1] not in ("x", "y")}
+    edge_cols = [have[frozenset(e)] for e in sorted(tuple(sorted(e)) for e in edges)]
+    node_cols = [(n, "x") for n in nodes] + [(n, "y") for n in nodes] + list(nodes)
+    pre = preprocess_tables(tabs, cols, [""], node_cols, edge_cols, (), dist_standardize="per_column", speed_standardize="per_column",
+                            coord_standardize="per_column", device="cuda", lib=hip)
+    train = WindowDataset.from_device_tables(pre, 25, 1, hip, keys=["v000", "v001", "v002"])
+    val = WindowDataset.from_device_tables(pre, 25, 1, hip, keys=["v003"])
+    model, _, _, logs = TR.train_deepof_model(
+        preprocessed_object=(train, val), adjacency_matrix=adjacency_from_graph(nodes, edges),
+        meta_info={"node_columns": node_cols, "edge_columns": edge_cols}, encoder_type="recurrent", batch_size=256, latent_dim=8,
+        epochs=2, output_path=str(tmp_path), n_clusters=5, model_name="VaDE", use_turtle_teacher=False, save_weights=False,
+        pretrain_epochs=1)
+    tl = logs["train"]["total_loss"]
+    assert np.isfinite(tl).all() and np.isfinite(logs["val"]["total_loss"]).all()
+    emb = model.encode_windows(*val.fetch(0, 64))
+    assert all(bool(torch.isfinite(t).all()) for t in (emb if isinstance(emb, tuple) else (emb,)))

@@ -625,3 +625,31 @@ def test_preprocess_sharded_over_videos_gloo(tmp_path):
             assert (g0 is None) == (gs is None)
             if g0 is not None:
                 assert all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(g0, g1, gs))
+
+
+def test_raw_tables_to_training_emu(tmp_path):
+    """Raw pose tables -> device preprocessing -> window datasets over the resident frame tables -> trainer, without
+    a host copy of the scaled tables or of the windows (emulated kernels)."""
+    import parity_common as PC
+    from deepof_amd.graph import adjacency_from_graph
+    from deepof_amd.preprocess import preprocess_tables
+    lib = emu_lib()
+    bps = ["Nose", "Left_ear", "Right_ear", "Center"]
+    tabs, cols = PC.synth_raw_tables(3, (40, 31, 36), bps, seed=2, nan_rate=0.02)
+    nodes = sorted(bps)
+    edges = [c for c in cols if isinstance(c, tuple) and c[1] == "Center"]      # the 3 distances to the centre
+    node_cols = [(n, "x") for n in nodes] + [(n, "y") for n in nodes] + nodes
+    pre = preprocess_tables(tabs, cols, [""], node_cols, edges, (), dist_standardize="per_column", speed_standardize="per_column",
+                            coord_standardize="per_column", device="cpu", lib=lib)
+    train = WindowDataset.from_device_tables(pre, 8, 1, lib, keys=["v000", "v001"])
+    val = WindowDataset.from_device_tables(pre, 8, 1, lib, keys=["v002"])
+    assert len(train) == 33 + 24 and len(val) == 29 and train.x_shape == (8, 4, 3) and train.a_shape == (8, 3, 1)
+    adj = adjacency_from_graph(nodes, edges)
+    meta = {"node_columns": node_cols, "edge_columns": edges}
+    model, _, _, logs = TR.train_deepof_model(
+        preprocessed_object=(train, val), adjacency_matrix=adj, meta_info=meta, encoder_type="recurrent", batch_size=8, latent_dim=4,
+        epochs=1, output_path=str(tmp_path), n_clusters=3, model_name="VaDE", use_turtle_teacher=False, save_weights=False,
+        pretrain_epochs=1, _engine_factory=emu_factory)
+    assert np.isfinite(logs["train"]["total_loss"]).all() and np.isfinite(logs["val"]["total_loss"]).all()
+    emb = model.encode_windows(*val.fetch(0, 5))
+    assert all(torch.isfinite(t).all() for t in (emb if isinstance(emb, tuple) else (emb,)))
