@@ -894,6 +894,89 @@ int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const flo
   return dof_check_launch("k_tcn_convg");
 }
 
+namespace {
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of a 32 -> 32 dilated convolution: dW[o][c][j] = sum_{t,s} dy[t][s][o] * in[t - (3-j) d][s][c],
+// db[o] = sum dy.  The generic k_outer streams every MFMA operand from global memory with scalar dword loads and
+// reads the input once per tap (4x) and dy once per 4-tile job (2x): 770 us per convolution at B = 8192 (24 % MFMA
+// utilisation, issue-stalled on the loads).  Here a workgroup stages all T time steps of a few (4) sequences of both
+// tensors in LDS with coalesced 16-byte loads (each tensor is read from HBM exactly once), wavefront j owns tap j:
+// per time step 4 MFMAs (2 x 2 tiles, one k-slice of 4 sequences) against 4 conflict-free ds_reads; 26 KB of LDS
+// per workgroup, so six workgroups per CU overlap each other's load and MFMA phases.
+template <int NSEQ>  // sequences per staged chunk: 4 (one MFMA k-slice) or 8
+__global__ void __launch_bounds__(256) k_tcn_wgrad(const DofTcnWgrad* __restrict__ descs, float* __restrict__ partials) {
+  __shared__ float sx[DOF_TCN_WGRAD_MAX_T][NSEQ][33];
+  __shared__ float sd[DOF_TCN_WGRAD_MAX_T][NSEQ][33];
+  const DofTcnWgrad D = descs[blockIdx.y];
+  if ((int)blockIdx.x >= D.nblk) return;
+  const int T = D.T;
+  const int64_t Sp = D.Sp;
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int shift = -(3 - j) * D.dil;
+  dof_f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float rs0 = 0.0f, rs1 = 0.0f;
+  const int64_t chunks = Sp / NSEQ;
+  constexpr int F4 = NSEQ * 8;  // float4 per time step of one tensor
+  for (int64_t ch = blockIdx.x; ch < chunks; ch += D.nblk) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * F4; idx += 256) {
+      const int t = idx / F4, r = idx - t * F4, s = r >> 3, c = (r & 7) * 4;
+      const int64_t off = ((int64_t)t * Sp + ch * NSEQ + s) * 32 + c;
+      const float4 vx = *reinterpret_cast<const float4*>(D.in + off);
+      const float4 vd = *reinterpret_cast<const float4*>(D.dy + off);
+      sx[t][s][c] = vx.x; sx[t][s][c + 1] = vx.y; sx[t][s][c + 2] = vx.z; sx[t][s][c + 3] = vx.w;
+      sd[t][s][c] = vd.x; sd[t][s][c + 1] = vd.y; sd[t][s][c + 2] = vd.z; sd[t][s][c + 3] = vd.w;
+    }
+    __syncthreads();
+    for (int t = shift < 0 ? -shift : 0; t < T; ++t) {
+      const int tb = t + shift;
+#pragma unroll
+      for (int kk = 0; kk < NSEQ / 4; ++kk) {
+        const float a0 = sd[t][q + 4 * kk][i], a1 = sd[t][q + 4 * kk][16 + i];
+        const float b0 = sx[tb][q + 4 * kk][i], b1 = sx[tb][q + 4 * kk][16 + i];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        rs0 += a0;  // tap 3 has shift 0, i.e. sees every time step exactly once: its row sums are the bias gradient
+        rs1 += a1;
+      }
+    }
+  }
+  // D layout of mfma_f32_16x16x4: lane holds rows (lane>>4)*4 + r, column lane&15
+  float* out = partials + (j < 2 ? D.part0 : D.part1) + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) out[(mt * 16 + q * 4 + r4) * 65 + (j & 1) * 32 + nt * 16 + i] = acc[mt][nt][r4];
+  if (j == 3) {
+    rs0 += __shfl_xor(rs0, 16);
+    rs0 += __shfl_xor(rs0, 32);
+    rs1 += __shfl_xor(rs1, 16);
+    rs1 += __shfl_xor(rs1, 32);
+    if (q == 0) {
+      float* b = partials + D.part0 + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+      b[i * 65 + 64] = rs0;
+      b[(16 + i) * 65 + 64] = rs1;
+    }
+  }
+}
+
+}  // namespace
+
+int dof_launch_tcn_wgrad(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st) {
+  if (n <= 0) return DOF_OK;
+  DOF_LAUNCH((k_tcn_wgrad<4>), ((unsigned)max_nblk, (unsigned)n), (256), st, descs_dev, partials);
+  return dof_check_launch("k_tcn_wgrad");
+}
+
 int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st) {
   DOF_LAUNCH(k_head_rms, (dof_cdiv(B, 256)), (256), st, flat, hn, rinv, J, B, Bp);
   return dof_check_launch("k_head_rms");

@@ -57,6 +57,18 @@ int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const flo
 int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const float* w, int w_ci, int cin_real,
                          const float* bias, const float* bnp_in, float* a_out, float* out, float* partial,
                          int accumulate, int T, int dil, int64_t S, int64_t Sp, hipStream_t st);
+// weight gradient of one 32 -> 32 dilated convolution (k = 4) with both operands staged through LDS; writes its
+// partial tiles in the DofOuterJob layout of two 4-tile jobs (taps 0,1 -> part0, taps 2,3 -> part1; bias sums in
+// column 64 of part0), so k_outer_finalize consumes them unchanged
+struct DofTcnWgrad {
+  const float* dy;  // [T][Sp][32] gradient w.r.t. the pre-BatchNorm conv output
+  const float* in;  // [T][Sp][32] convolution input
+  int dil, nblk, T;
+  int64_t Sp;
+  int64_t part0, part1;  // float offsets of the two jobs' partial regions ([nblk][64][65] each)
+};
+#define DOF_TCN_WGRAD_MAX_T 25
+int dof_launch_tcn_wgrad(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st);
 int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st);
 int dof_launch_head_dense(const float* in, const float* bnp_in, float* in_norm, const float* w, const float* bias,
                           float* out, float* partial, float* sums, int CI, int CO, int relu, int64_t B, int64_t Bp,

@@ -120,8 +120,9 @@ struct StreamWs {  // float offsets into the workspace
 struct JobSet {  // one launch of the MFMA weight-gradient reduction + its finalize
   std::vector<DofOuterJob> jobs;
   std::vector<DofFinJob> fins;
-  int total_blocks = 0, fin_elems = 0;
-  int64_t jobs_tab = 0, fin_tab = 0;  // workspace offsets of the uploaded tables
+  std::vector<DofTcnWgrad> wgrads;  // TCN convolutions whose partial tiles come from k_tcn_wgrad instead of k_outer
+  int total_blocks = 0, fin_elems = 0, wg_blocks = 0;
+  int64_t jobs_tab = 0, fin_tab = 0, wg_tab = 0;  // workspace offsets of the uploaded tables
 };
 
 struct DofVadePlan {
@@ -634,6 +635,7 @@ void take_tables(DofVadePlan* p, Carver& cv) {
   for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
     js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
     js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
+    js->wg_tab = cv.take(48 * (int64_t)(sizeof(DofTcnWgrad) / 4 + 1));
   }
   p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
   p->mask_tab = cv.take(p->param_total);
@@ -701,7 +703,9 @@ struct JobBuilder {
   }
   int64_t partial_cur = 0;
   int blk_cur = 0, elem_cur = 0;
-  int add_job(View a, int rows, int T, int64_t Sp) {
+  // external_blocks > 0: the job's partial tiles ([external_blocks][64][65]) are produced by another kernel;
+  // k_outer never picks it up (its first block is out of range), k_outer_finalize reduces it like any other job
+  int add_job(View a, int rows, int T, int64_t Sp, int external_blocks = 0) {
     DofOuterJob j;
     memset(&j, 0, sizeof(j));
     j.a_ptr = a.p; j.a_tstride = a.ts; j.a_sstride = a.ss; j.a_cstride = a.cs; j.a_rows = rows; j.T = T; j.Sp = Sp;
@@ -710,8 +714,9 @@ struct JobBuilder {
     int64_t nb = (units + 31) / 32;
     if (nb < 1) nb = 1;
     if (nb > 256) nb = 256;
-    j.nblk = (int)nb; j.blk0 = blk_cur; j.partial_off = partial_cur;
-    blk_cur += j.nblk;
+    if (external_blocks > 0) nb = external_blocks;
+    j.nblk = (int)nb; j.blk0 = external_blocks > 0 ? 0x7fffffff : blk_cur; j.partial_off = partial_cur;
+    if (external_blocks == 0) blk_cur += j.nblk;
     partial_cur += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
     jobs.push_back(j);
     return (int)jobs.size() - 1;
@@ -775,6 +780,8 @@ void build_tcn_jobs(DofVadePlan* p) {
   float* ws = p->ws;
   const int64_t Bp = p->Bp;
   JobBuilder jb(p->js_enc);
+  p->js_enc.wgrads.clear();
+  p->js_enc.wg_blocks = 0;
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
     const TcnWs& t = p->tw[s];
@@ -786,10 +793,21 @@ void build_tcn_jobs(DofVadePlan* p) {
       auto conv = [&](const float* dy, const float* in, int cin, int64_t wOff, int64_t bOff) {
         int job = -1;
         bool bias_done = false;
+        // 32 -> 32 convolutions: the partial tiles of the two jobs come from k_tcn_wgrad (LDS-staged operands)
+        const bool staged = cin == C && T <= DOF_TCN_WGRAD_MAX_T;
+        const int ext = staged ? (int)(Sp / 8 < 448 ? Sp / 8 : 448) : 0;
+        if (staged) {
+          DofTcnWgrad g;
+          memset(&g, 0, sizeof(g));
+          g.dy = dy; g.in = in; g.dil = d; g.nblk = ext; g.T = T; g.Sp = Sp;
+          p->js_enc.wgrads.push_back(g);
+          if (ext > p->js_enc.wg_blocks) p->js_enc.wg_blocks = ext;
+        }
         for (int j = 0; j < 4; ++j)
           for (int c0 = 0; c0 < cin; c0 += 16) {
             if (job < 0 || jb.jobs[job].n_tiles == 4) {
-              job = jb.add_job(aos(dy, C, Sp), C, T, Sp);
+              job = jb.add_job(aos(dy, C, Sp), C, T, Sp, ext);
+              if (staged) (j < 2 ? p->js_enc.wgrads.back().part0 : p->js_enc.wgrads.back().part1) = jb.jobs[job].partial_off;
               if (!bias_done) jb.add_fin(job, 64, C, 1, C, C, bOff, 1, 1);
               bias_done = true;
             }
@@ -1012,6 +1030,8 @@ int run_jobset(DofVadePlan* p, const JobSet& js, float* dst, int accumulate, hip
   const DofOuterJob* jobs = reinterpret_cast<const DofOuterJob*>(p->ws + js.jobs_tab);
   const DofFinJob* fins = reinterpret_cast<const DofFinJob*>(p->ws + js.fin_tab);
   TRY(dof_launch_outer(jobs, (int)js.jobs.size(), js.total_blocks, p->ws + p->partials, st));
+  TRY(dof_launch_tcn_wgrad(reinterpret_cast<const DofTcnWgrad*>(p->ws + js.wg_tab), (int)js.wgrads.size(), js.wg_blocks,
+                           p->ws + p->partials, st));
   return dof_launch_outer_finalize(jobs, fins, (int)js.fins.size(), js.fin_elems, p->ws + p->partials, dst, accumulate, st);
 }
 
@@ -1570,6 +1590,11 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
     }
     up(js->jobs_tab, js->jobs.data(), js->jobs.size() * sizeof(DofOuterJob));
     up(js->fin_tab, js->fins.data(), js->fins.size() * sizeof(DofFinJob));
+    if (js->wgrads.size() > 48) {
+      dof_set_error("dof_vade_bind: staged weight-gradient table overflow (%zu)", js->wgrads.size());
+      return DOF_ERR_STATE;
+    }
+    up(js->wg_tab, js->wgrads.data(), js->wgrads.size() * sizeof(DofTcnWgrad));
   }
   {  // parameters that never receive a gradient in the reference (grad None => skipped by Adam, incl. weight decay)
     static thread_local std::vector<float> mask;
