@@ -83,21 +83,20 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
       if (mt < MT) rs[mt] += (av[mt][0] + av[mt][1]) + (av[mt][2] + av[mt][3]);
-    // k-slice outermost: consecutive MFMAs write different accumulators, so none waits for the result of the one
-    // before it (with the k-slices innermost every MFMA depended on its predecessor: 63 busy cycles per
-    // 16x16x4 instead of 32, SQ_VALU_MFMA_BUSY_CYCLES on the C4 step); per accumulator the order of the
-    // additions is unchanged, so results are bit-identical
+    // k-slices innermost.  (Making the k-slice the outer loop, so that consecutive MFMAs hit different accumulators,
+    // was measured: k_outer -2 % on the TCN jobs, but the C2 step +0.55 % -- three runs each on one box -- so the
+    // order stayed.)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int mt = 0; mt < 4; ++mt)
+      if (mt < MT) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        if (mt < MT) {
+        for (int nt = 0; nt < 4; ++nt)
+          if (nt < NT) {
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            if (nt < NT) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][kk], bv[nt][kk], acc[mt][nt], 0, 0, 0);
-        }
+            for (int kk = 0; kk < 4; ++kk)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][kk], bv[nt][kk], acc[mt][nt], 0, 0, 0);
+          }
       }
-    }
     if (more) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
