@@ -199,8 +199,10 @@ class _Call:
         self.video_off = np.zeros(len(arrays) + 1, dtype=np.int64)
         self.video_off[1:] = np.cumsum(self.lengths)
         self.n_frames, self.n_cols = int(self.video_off[-1]), len(plan.kinds)
-        if raw_device is None:
-            raw_device = torch.from_numpy(np.concatenate(arrays) if len(arrays) > 1 else np.ascontiguousarray(arrays[0])).to(self.device)
+        if raw_device is None:   # one host-to-device copy per table, straight into its rows (no host-side concatenation)
+            raw_device = torch.empty(self.n_frames, self.n_cols, dtype=torch.float64, device=self.device)
+            for a, lo, hi in zip(arrays, self.video_off[:-1], self.video_off[1:]):
+                raw_device[int(lo):int(hi)].copy_(torch.from_numpy(np.ascontiguousarray(a)), non_blocking=True)
         if raw_device.dtype != torch.float64 or tuple(raw_device.shape) != (self.n_frames, self.n_cols):
             raise ValueError("raw_device must be the concatenated float64 tables")
         self.raw = raw_device
