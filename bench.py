@@ -138,12 +138,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    # DOF_BENCH_SHARE_GPU=1 (debug only): all ranks on cuda:0 over gloo, to exercise the N > 1 control flow (all-reduce,
+    # barriers, max-over-ranks, rank-0 JSON) on a 1-GPU box; RCCL refuses two ranks on one device.  Never a result.
+    share = os.environ.get("DOF_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from deepof_amd import _capi
     from deepof_amd.engine import create_vade_engine
