@@ -58,7 +58,7 @@ class PreprocDims(C.Structure):
 PP_KINDS = {"other": 0, "coord": 1, "speed": 2, "dist_inner": 3, "dist_intra": 4, "angle": 5}
 PP_MODES = {None: 0, "per_column": 1, "groupwise": 2}
 PP_INTER_SCALE = {"mean": 0, "geom": 1, "global": 2}
-PP_MAX_COLS, PP_MAX_ANIMALS, PP_MAX_OUT = 512, 8, 256
+PP_MAX_COLS, PP_MAX_ANIMALS = 512, 8
 
 _P = C.c_void_p
 _I64 = C.c_int64

@@ -11,10 +11,11 @@
 // W-fold window blow-up ever exist on the host.
 //
 // Passes over the raw table (8 B/element each; everything else is O(videos x columns)):
-//   k_pp_size     4 columns per animal: hypot(nose - tail base) -> exact nan-median by bitwise bisection
+//   k_pp_hyp      4 columns per animal: hypot(nose - tail base) as an order-preserving key per row
+//                 (k_pp_size then selects the exact nan-median per (animal, video) by 8-bit radix selection)
 //   k_pp_stats    one pass: shifted sums per (video, strip, column) -> (n, mean, M2), all rows and sampled rows
-//   k_pp_finish   output columns only: transform, clip, interpolate inside a 32-row tile, cast, write fp32
-//   k_pp_fill     closes the (rare) gaps that reach a tile edge from the tiles' first / last valid-row notes
+//   k_pp_finish   output columns only: transform, clip, interpolate inside an 8-row tile, cast, write fp32
+//   k_pp_fill     closes the (rare) gaps that reach a tile edge, from the tiles' validity bytes
 // The per-video and the global StandardScaler statistics come from the ONE statistics pass: the per-video
 // transform is affine per column, so the statistics of the per-video-standardised samples follow from
 // (n, mean, M2) of the sampled rows, merged over videos with Chan's pairwise update in a fixed order
