@@ -387,3 +387,47 @@ def _sharded(lib, device, arrays, video_off, mask, scaler_in, world, rank, n_ani
 
     return (assemble(node, False), assemble(edge, False), assemble(ang, False) if n_ang else None, assemble(sizes, True),
             assemble(vsc, True), scaler_in)
+
+
+def graph_dataset_from_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids=("",), *, graph_preset: str = "deepof_14",
+                              window_size: int = 25, window_step: int = 1, test_keys: Sequence[str] = (), device="cuda", lib=None,
+                              dist_standardize: Optional[str] = "per_column", speed_standardize: Optional[str] = "per_column",
+                              coord_standardize: Optional[str] = "per_column", **preprocess_kw):
+    """``Coordinates.get_graph_dataset(preprocess=True)`` (/root/reference/deepof/data.py:2644-2906) from merged raw
+    tables: body-part graph -> sorted node / edge feature columns (:2797-2835; nodes absent from the tables are
+    dropped from the graph, :2776-2781) -> device preprocessing -> window datasets over the resident frame tables.
+
+    Returns ``((train, val), meta_info, adjacency, pre)``: ``train`` / ``val`` go to ``train_deepof_model`` as
+    ``preprocessed_object``; ``pre.global_scaler`` is the fitted scaler.  ``test_keys`` are the held-out videos (the
+    reference picks them at random in ``get_training_set``; that choice is control plane and stays with the caller)."""
+    from .dataset import WindowDataset
+    from .graph import adjacency_from_graph, bodypart_graph
+    if lib is None:
+        from ._lib import load_hip_library
+        lib = load_hip_library()
+    columns = list(columns)
+    have = set(columns)
+    nodes, edges = bodypart_graph(list(animal_ids), graph_preset)
+    nodes = [n for n in nodes if (n, "x") in have and (n, "y") in have]
+    keep = set(nodes)
+    edges = [e for e in edges if e[0] in keep and e[1] in keep]
+    missing = [n for n in nodes if n not in have]
+    if missing:
+        raise KeyError(f"speed columns missing for {missing}")
+    by_pair = {frozenset(c): c for c in columns if _is_pair(c) and c[1] not in ("x", "y")}
+    edge_cols = []
+    for e in edges:
+        if frozenset(e) not in by_pair:
+            raise KeyError(f"distance column for edge {e} missing")
+        edge_cols.append(by_pair[frozenset(e)])
+    node_cols = [(n, "x") for n in nodes] + [(n, "y") for n in nodes] + nodes
+    pre = preprocess_tables(tables, columns, animal_ids, node_cols, edge_cols, (), dist_standardize=dist_standardize,
+                            speed_standardize=speed_standardize, coord_standardize=coord_standardize, device=device, lib=lib,
+                            **preprocess_kw)
+    test = [k for k in pre.keys if k in set(test_keys)]
+    train = WindowDataset.from_device_tables(pre, window_size, window_step, lib, keys=[k for k in pre.keys if k not in set(test)])
+    val = WindowDataset.from_device_tables(pre, window_size, window_step, lib, keys=test) if test else train
+    meta = {"node_columns": node_cols, "edge_columns": edge_cols, "angle_columns": [],
+            "shape_train": [(len(train),) + train.x_shape[:1] + (len(node_cols),), (len(train),) + train.a_shape[:1] + (len(edge_cols),)],
+            "dist_standardize": dist_standardize, "speed_standardize": speed_standardize, "coord_standardize": coord_standardize}
+    return (train, val), meta, adjacency_from_graph(nodes, edges), pre

@@ -653,3 +653,26 @@ def test_raw_tables_to_training_emu(tmp_path):
     assert np.isfinite(logs["train"]["total_loss"]).all() and np.isfinite(logs["val"]["total_loss"]).all()
     emb = model.encode_windows(*val.fetch(0, 5))
     assert all(torch.isfinite(t).all() for t in (emb if isinstance(emb, tuple) else (emb,)))
+
+
+def test_graph_dataset_from_tables_emu(tmp_path):
+    """The get_graph_dataset(preprocess=True) mirror: body-part graph -> column order -> device preprocessing -> datasets."""
+    import parity_common as PC
+    from deepof_amd.graph import bodypart_graph
+    from deepof_amd.preprocess import graph_dataset_from_tables
+    nodes, edges = bodypart_graph([""])
+    tabs, cols = PC.synth_raw_tables(3, (40, 33, 37), list(reversed(nodes)), seed=8, nan_rate=0.01)   # table order != graph order
+    (train, val), meta, adj, pre = graph_dataset_from_tables(tabs, cols, [""], window_size=10, test_keys=["v001"], device="cpu",
+                                                            lib=emu_lib())
+    assert meta["node_columns"][:14] == [(n, "x") for n in nodes] and len(meta["edge_columns"]) == len(edges) == int(adj.sum()) // 2
+    assert train.keys == ["v000", "v002"] and val.keys == ["v001"] and len(train) == 31 + 28 and train.x_shape == (10, 14, 3)
+    where = {c: i for i, c in enumerate(cols)}
+    assert pre.global_scaler["coord_mode"] == "per_column" and pre.global_scaler["coord"][0].shape == (28,)
+    # edge e of the dataset is the distance between the graph's edge endpoints, whatever the label order in the table
+    for e, lab in zip(edges, meta["edge_columns"]):
+        assert set(e) == set(lab) and lab in where
+    model, _, _, logs = TR.train_deepof_model(preprocessed_object=(train, val), adjacency_matrix=adj, meta_info=meta,
+                                              encoder_type="recurrent", batch_size=16, latent_dim=4, epochs=1, output_path=str(tmp_path),
+                                              n_clusters=3, model_name="VQVAE", use_turtle_teacher=False, save_weights=False,
+                                              _engine_factory=emu_factory)
+    assert np.isfinite(logs["train"]["total_loss"]).all()
