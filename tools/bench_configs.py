@@ -9,6 +9,7 @@ clip + Adam) on device-resident synthetic data, fp32, eager launches on the curr
   c4  Contrastive, TCN encoder on half windows (window 50 -> 25), batch 8192, nce / cosine (as BASELINE names it)
   c4r the same step with the recurrent encoder
   c5  VaDE, 2 animals (28 nodes, 32 edges), window 50, k=25, batch 4096, main phase
+  infer  N1: gather + eval-mode encoder forward (embeddings + soft counts) of the C2 model, batch 4096
   c2tcn  the headline C2 workload (VaDE, 14 body parts, window 25, k=10, batch 1024) with the TCN encoder/decoder
 """
 import argparse
@@ -155,6 +156,34 @@ def run_contrastive(B, Tf, steps, warmup, frames=200_000, kind="contrastive_tcn"
     return sec, logs["total_loss"], N, E
 
 
+def run_inference(B, steps, warmup, frames=200_000):
+    """N1: embedding_per_video's inner loop -- gather a batch of windows, eval-mode VaDE forward without the decoder,
+    embeddings z (B,L) + soft counts q (B,K) -- for C2's model."""
+    from deepof_amd import _capi
+    from deepof_amd.engine import create_vade_engine
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    dev = torch.device("cuda")
+    nodes, edges = bodypart_graph([""])
+    N, E, T, L, K = len(nodes), len(edges), 25, 8, 10
+    eng = create_vade_engine(B, T, adjacency_from_graph(nodes, edges), L, K, 32, device=dev)
+    init_params(eng, seed=0)
+    tn, te = synth_tables_fast(frames, N, E, 0, dev)
+    x = torch.empty(B, T, N, 3, device=dev)
+    a = torch.empty(B, T, E, 1, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = (frames - T + 1) // B
+    acc = torch.zeros((), device=dev)
+
+    def step(i):
+        _capi.check(eng.lib, eng.lib.dof_window_gather_range(tn.data_ptr(), te.data_ptr(), (i % nb) * B, 1, B, T, N, E,
+                                                             x.data_ptr(), a.data_ptr(), st), "gather")
+        out = eng.forward(x, a, None, want_loc=False)
+        acc.add_(out["q"][0, 0])
+
+    sec = timed(step, steps, warmup)
+    return sec, float(acc), N, E
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
@@ -179,6 +208,14 @@ def main():
             B = 1024
             sec, loss, N, E = run_vade_like("vade_tcn", [""], 25, 10, B, args.steps, args.warmup)
             desc = "C2 with the TCN family: VaDE TCN encoder/decoder, N=14,E=14, window=25, k=10, latent=8, batch=1024, main phase"
+        elif name == "infer":
+            B = 4096
+            sec, loss, N, E = run_inference(B, args.steps, args.warmup)
+            desc = "N1 inference (embedding_per_video inner loop): C2 model, eval forward without decoder, batch=4096"
+            print(json.dumps({"metric": "pose-windows/sec (embedding + soft counts)", "value": B / sec, "unit": "windows/s",
+                              "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3, "dtype": "f32",
+                              "data": "synthetic", "config": {"workload": desc}}), flush=True)
+            continue
         elif name == "c5":
             B = 4096
             sec, loss, N, E = run_vade_like("vade", ["B", "W"], 50, 25, B, args.steps, args.warmup)
