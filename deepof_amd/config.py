@@ -86,6 +86,7 @@ TurtleTeacherCfg = _record("TurtleTeacherCfg", """
     teacher_freeze_at              Optional[int]    10
     reinit_gmm_on_refresh          bool             False
     teacher_batch_size             int              2048
+    pca_backend                    str              'device'
 """)
 
 VaDECfg = _record("VaDECfg", """

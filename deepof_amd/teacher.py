@@ -6,7 +6,8 @@ reference's interface around it:
 
   TurtleTeacher                  teacher_model.py:152-350  (state_dict names, fit(loader), predict)
   run_turtle_teacher_on_views    :710-792   shuffled drop-last batches of the active views, then tau* in dataset order
-  fit_nodes_pca / extract_pca_edges_view  :464-707  PCA views -- sklearn IncrementalPCA on the host, as in the
+  fit_nodes_pca / extract_pca_edges_view  :464-707  PCA views -- IncrementalPCA on the device (DeviceIncrementalPCA;
+                                                    pca_backend="sklearn" = the host implementation), as in the
                                  reference (third-party arithmetic; fitted once per run)
   extract_latents                :354-391   z_mean of every training window
   initialize_gmm_from_teacher    :394-460   tau*-weighted moments -> GMM means / log-variances / prior
@@ -181,36 +182,100 @@ def run_turtle_teacher_on_views(views_dict: dict, n_components: int, gamma: floa
 
 
 # ---------------------------------------------------------------------------------------- views
-def _pca_two_pass(chunks_fn, n_components: int) -> torch.Tensor:
-    from sklearn.decomposition import IncrementalPCA
-    ipca = IncrementalPCA(n_components=n_components)
+class DeviceIncrementalPCA:
+    """``sklearn.decomposition.IncrementalPCA`` (partial_fit / transform, whiten=False) on torch tensors, wherever they
+    live.  Same algorithm, same truncation to ``n_components`` after every batch: sklearn takes the SVD of the stacked
+    matrix ``[S * Vt ; X - batch_mean ; mean_correction]`` ((k + b + 1) x d, LAPACK gesdd in float32 on the host); here
+    its d x d Gram matrix ``(S Vt)^T (S Vt) + Xc^T Xc + c c^T`` is accumulated with one GEMM per batch and decomposed
+    with one symmetric eigen-solve, all in float64 on the device -- no window ever leaves HBM.  At BASELINE C2's size
+    (600k windows, 700 / 350 / 350 features) the host path needs 226 s for the three teacher views; see DESIGN.md.
+    Signs follow ``svd_flip(u_based_decision=False)``: the largest-magnitude entry of every component is positive."""
+
+    def __init__(self, n_components: int):
+        self.n_components = int(n_components)
+        self.n_seen = 0
+        self.mean = None
+        self.components = None        # (k, d)
+        self.singular_values = None   # (k,)
+
+    @torch.no_grad()
+    def partial_fit(self, X: torch.Tensor) -> "DeviceIncrementalPCA":
+        X = X.to(torch.float64)
+        b, d = X.shape
+        k = self.n_components
+        if k > min(b, d):
+            raise ValueError(f"n_components={k} must be less or equal to the batch number of samples {b} and features {d}")
+        batch_sum = X.sum(dim=0)
+        n_total = self.n_seen + b
+        if self.n_seen == 0:
+            col_mean = batch_sum / n_total
+            Xc = X - col_mean
+            G = Xc.T @ Xc
+        else:
+            col_mean = (self.mean * self.n_seen + batch_sum) / n_total
+            batch_mean = batch_sum / b
+            Xc = X - batch_mean
+            corr = math.sqrt((self.n_seen / n_total) * b) * (self.mean - batch_mean)
+            SV = self.singular_values[:, None] * self.components
+            G = SV.T @ SV + Xc.T @ Xc + torch.outer(corr, corr)
+        lam, vec = torch.linalg.eigh(G)                     # ascending eigenvalues, eigenvectors in columns
+        Vt = vec[:, -k:].T.flip(0).contiguous()             # (k, d), descending
+        lam_k = lam[-k:].flip(0).clamp_min(0.0)
+        lead = Vt.abs().argmax(dim=1)
+        signs = torch.sign(Vt[torch.arange(k, device=Vt.device), lead])
+        signs = torch.where(signs == 0, torch.ones_like(signs), signs)
+        self.components = Vt * signs[:, None]
+        self.singular_values = lam_k.sqrt()
+        self.mean, self.n_seen = col_mean, n_total
+        return self
+
+    @torch.no_grad()
+    def transform(self, X: torch.Tensor) -> torch.Tensor:
+        return ((X.to(torch.float64) - self.mean) @ self.components.T).float()
+
+
+def _pca_two_pass(chunks_fn, n_components: int, backend: str = "device") -> torch.Tensor:
+    """Two passes over the chunks (fit, then transform) like teacher_model.py:508-571.  ``backend="sklearn"`` is the
+    reference's own host IncrementalPCA (chunks are copied to the host); ``"device"`` keeps everything where the
+    chunks live (same algorithm, see DeviceIncrementalPCA).  Features are returned on the host, float32."""
+    if backend == "sklearn":
+        from sklearn.decomposition import IncrementalPCA
+        ipca = IncrementalPCA(n_components=n_components)
+        for X in chunks_fn():
+            ipca.partial_fit(X.float().cpu().numpy())
+        return torch.cat([torch.from_numpy(ipca.transform(X.float().cpu().numpy())).float() for X in chunks_fn()], dim=0)
+    if backend != "device":
+        raise ValueError("pca backend must be 'device' or 'sklearn'")
+    ipca = DeviceIncrementalPCA(n_components)
     for X in chunks_fn():
         ipca.partial_fit(X)
-    return torch.cat([torch.from_numpy(ipca.transform(X)).float() for X in chunks_fn()], dim=0)
+    return torch.cat([ipca.transform(X).cpu() for X in chunks_fn()], dim=0)
 
 
-def fit_nodes_pca(dataset, n_components_pos: int = 32, n_components_spd: int = 32, batch_size: int = 4096):
+def fit_nodes_pca(dataset, n_components_pos: int = 32, n_components_spd: int = 32, batch_size: int = 4096,
+                  backend: str = "device"):
     """teacher_model.py:464-573: IncrementalPCA of the flattened (x, y) positions and of the flattened speeds of every
     window (two passes: partial_fit, transform).  Returns (feats_pos (N, n_pos), feats_spd (N, n_spd)) on the host."""
     def chunks(sl):
         def gen():
             for s in range(0, len(dataset), batch_size):
                 x, _a = dataset.fetch(s, min(s + batch_size, len(dataset)))
-                yield x[..., sl].reshape(x.shape[0], -1).float().cpu().numpy()
+                yield x[..., sl].reshape(x.shape[0], -1).float()
         return gen
-    return _pca_two_pass(chunks(slice(0, 2)), n_components_pos), _pca_two_pass(chunks(slice(2, 3)), n_components_spd)
+    return (_pca_two_pass(chunks(slice(0, 2)), n_components_pos, backend),
+            _pca_two_pass(chunks(slice(2, 3)), n_components_spd, backend))
 
 
-def extract_pca_edges_view(dataset, n_components: int = 16, batch_size: int = 8192) -> torch.Tensor:
+def extract_pca_edges_view(dataset, n_components: int = 16, batch_size: int = 8192, backend: str = "device") -> torch.Tensor:
     """teacher_model.py:638-707."""
     def gen():
         for s in range(0, len(dataset), batch_size):
             _x, a = dataset.fetch(s, min(s + batch_size, len(dataset)))
-            yield a.reshape(a.shape[0], -1).float().cpu().numpy()
-    return _pca_two_pass(gen, n_components)
+            yield a.reshape(a.shape[0], -1).float()
+    return _pca_two_pass(gen, n_components, backend)
 
 
-def fit_angles_pca(dataset, n_components: int = 32, batch_size: int = 8192) -> torch.Tensor:
+def fit_angles_pca(dataset, n_components: int = 32, batch_size: int = 8192, backend: str = "device") -> torch.Tensor:
     """teacher_model.py:576-635: two-pass IncrementalPCA of the flattened angle windows (n, W*A)."""
     ang = getattr(dataset, "angles", None)
     if ang is None:
@@ -218,8 +283,8 @@ def fit_angles_pca(dataset, n_components: int = 32, batch_size: int = 8192) -> t
 
     def gen():
         for s in range(0, ang.shape[0], batch_size):
-            yield ang[s:s + batch_size].reshape(min(batch_size, ang.shape[0] - s), -1)
-    return _pca_two_pass(gen, n_components)
+            yield torch.as_tensor(ang[s:s + batch_size].reshape(min(batch_size, ang.shape[0] - s), -1)).float()
+    return _pca_two_pass(gen, n_components, backend)
 
 
 @torch.no_grad()
@@ -273,16 +338,19 @@ def maybe_build_turtle_teacher(*, teacher_cfg, common_cfg, train_dataset, device
         if latent_view is None:
             raise ValueError("include_latent_view=True but latent_view=None")
         views["z"] = latent_view
+    backend = getattr(teacher_cfg, "pca_backend", "device")   # "sklearn" = the reference's host IncrementalPCA
     if teacher_cfg.include_nodes_view:
         print("\n--- Building PCA views for teacher (nodes) ---")
         views["pca_pos"], views["pca_spd"] = fit_nodes_pca(train_dataset, teacher_cfg.pca_nodes_dim, teacher_cfg.pca_nodes_dim,
-                                                           teacher_cfg.batch_size_nodes)
+                                                           teacher_cfg.batch_size_nodes, backend=backend)
     if teacher_cfg.include_edges_view:
         print("\n--- Building PCA views for teacher (edges) ---")
-        views["pca_edges"] = extract_pca_edges_view(train_dataset, teacher_cfg.pca_edges_dim, teacher_cfg.batch_size_edges)
+        views["pca_edges"] = extract_pca_edges_view(train_dataset, teacher_cfg.pca_edges_dim, teacher_cfg.batch_size_edges,
+                                                    backend=backend)
     if teacher_cfg.include_angles_view:
         print("\n--- Building PCA views for teacher (angles) ---")
-        views["pca_angles"] = fit_angles_pca(train_dataset, teacher_cfg.pca_angles_dim, teacher_cfg.batch_size_angles)
+        views["pca_angles"] = fit_angles_pca(train_dataset, teacher_cfg.pca_angles_dim, teacher_cfg.batch_size_angles,
+                                             backend=backend)
     print("\n--- Running TURTLE teacher on views ---")
     teacher, tau_star = run_turtle_teacher_on_views(
         views, common_cfg.n_components, gamma=teacher_cfg.teacher_gamma,

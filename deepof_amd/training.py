@@ -914,7 +914,7 @@ def train_deepof_model(
     nonempty_p: float = 2.0,
     distill_conf_weight: bool = False, distill_conf_thresh: float = 0.3, distill_sharpen_T: float = 0.5,
     include_edges_view: bool = False, include_nodes_view: bool = True, pca_nodes_dim: int = 32,
-    pca_edges_dim: int = 32, include_angles_view: bool = False, pca_angles_dim: int = 32,
+    pca_edges_dim: int = 32, include_angles_view: bool = False, pca_angles_dim: int = 32, pca_backend: str = "device",
     reinit_gmm_on_refresh: bool = False,
     diag_max_batches: int = 4,
     model_name: str = "VaDE",
@@ -961,7 +961,7 @@ def train_deepof_model(
         distill_class_reweight_beta=distill_class_reweight_beta, distill_class_reweight_cap=distill_class_reweight_cap,
         include_edges_view=include_edges_view, include_nodes_view=include_nodes_view,
         include_angles_view=include_angles_view, pca_nodes_dim=pca_nodes_dim, pca_edges_dim=pca_edges_dim,
-        pca_angles_dim=pca_angles_dim,
+        pca_angles_dim=pca_angles_dim, pca_backend=pca_backend,
         teacher_refresh_every=(None if teacher_refresh_every is False else teacher_refresh_every),
         teacher_freeze_at=teacher_freeze_at, reinit_gmm_on_refresh=reinit_gmm_on_refresh,
         teacher_batch_size=teacher_batch_size)

@@ -653,3 +653,26 @@ def test_raw_tables_to_training_gpu(hip, tmp_path):
     assert np.isfinite(tl).all() and np.isfinite(logs["val"]["total_loss"]).all()
     emb = model.encode_windows(*val.fetch(0, 64))
     assert all(bool(torch.isfinite(t).all()) for t in (emb if isinstance(emb, tuple) else (emb,)))
+
+
+def test_teacher_pca_views_device_vs_sklearn_gpu(hip):
+    """N3: the teacher's PCA views computed on the device (windows gathered from the resident frame tables, Gram GEMM +
+    eigen-solve per batch) against the reference's host sklearn IncrementalPCA on the same windows."""
+    from deepof_amd import teacher as TT
+    from deepof_amd.dataset import WindowDataset
+    g = torch.Generator(device="cuda").manual_seed(5)
+    F = 20_000
+    walk = torch.cumsum(torch.randn(F, 42 + 14, device="cuda", generator=g) * 0.1, dim=0)
+    tabs = (walk - walk.mean(0)) / walk.std(0)
+
+    class Pre:
+        node_table, edge_table, video_off, keys = tabs[:, :42].contiguous(), tabs[:, 42:].contiguous(), np.array([0, F]), ["v"]
+
+    ds = WindowDataset.from_device_tables(Pre, 25, 1, hip)
+    dp, dsd = TT.fit_nodes_pca(ds, 16, 16, 4096, backend="device")
+    sp, ssd = TT.fit_nodes_pca(ds, 16, 16, 4096, backend="sklearn")
+    de, se = TT.extract_pca_edges_view(ds, 8, 8192, backend="device"), TT.extract_pca_edges_view(ds, 8, 8192, backend="sklearn")
+    for ours, ref in ((dp, sp), (dsd, ssd), (de, se)):
+        assert ours.shape == ref.shape and bool(torch.isfinite(ours).all())
+        scale = float(ref.abs().max())
+        assert float((ours - ref).abs().max()) < 2e-3 * scale, float((ours - ref).abs().max()) / scale

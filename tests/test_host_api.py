@@ -676,3 +676,29 @@ def test_graph_dataset_from_tables_emu(tmp_path):
                                               n_clusters=3, model_name="VQVAE", use_turtle_teacher=False, save_weights=False,
                                               _engine_factory=emu_factory)
     assert np.isfinite(logs["train"]["total_loss"]).all()
+
+
+def test_device_incremental_pca_matches_sklearn():
+    """DeviceIncrementalPCA = sklearn's IncrementalPCA algorithm (partial_fit per batch incl. a ragged last one,
+    truncation after every batch, svd_flip signs) through the Gram matrix instead of an SVD of the stacked batch."""
+    from sklearn.decomposition import IncrementalPCA
+    from deepof_amd.teacher import DeviceIncrementalPCA, _pca_two_pass
+    rng = np.random.default_rng(0)
+    d, k = 60, 8
+    basis = rng.standard_normal((12, d))
+    X = (rng.standard_normal((1000, 12)) * np.linspace(6, 0.5, 12)) @ basis + 0.05 * rng.standard_normal((1000, d)) + rng.standard_normal(d)
+    X = X.astype(np.float32)
+    chunks = [X[s:s + 300] for s in range(0, 1000, 300)]            # 300, 300, 300, 100
+    ref = IncrementalPCA(n_components=k)
+    ours = DeviceIncrementalPCA(k)
+    for c in chunks:
+        ref.partial_fit(c)
+        ours.partial_fit(torch.from_numpy(c))
+        np.testing.assert_allclose(ours.mean.numpy(), ref.mean_, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(ours.singular_values.numpy(), ref.singular_values_, rtol=2e-5)
+        np.testing.assert_allclose(ours.components.numpy(), ref.components_, atol=2e-4)
+    np.testing.assert_allclose(ours.transform(torch.from_numpy(X)).numpy(), ref.transform(X), rtol=1e-4, atol=2e-3)
+    gen = lambda: (torch.from_numpy(c) for c in chunks)   # noqa: E731
+    np.testing.assert_allclose(_pca_two_pass(gen, k, "device").numpy(), _pca_two_pass(gen, k, "sklearn").numpy(), rtol=1e-4, atol=2e-3)
+    with pytest.raises(ValueError):
+        DeviceIncrementalPCA(8).partial_fit(torch.zeros(5, 60))
