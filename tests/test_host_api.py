@@ -451,7 +451,9 @@ def test_fit_vade_with_turtle_teacher(tmp_path):
     ip = IncrementalPCA(n_components=4)
     for s in range(0, 48, 16):
         ip.partial_fit(X[s:s + 16])
-    np.testing.assert_allclose(pos.numpy(), ip.transform(X), atol=1e-5)
+    ref = ip.transform(X)
+    np.testing.assert_allclose(pos.numpy(), ref, atol=2e-3 * np.abs(ref).max())               # device backend: same algorithm
+    np.testing.assert_allclose(TT.fit_nodes_pca(ds, 4, 3, batch_size=16, backend="sklearn")[0].numpy(), ref, atol=1e-5)
     # the optional edge / angle views (angle windows ride along on the host)
     rng = np.random.default_rng(5)
     pre_ang = {k: (v[0], v[1], rng.standard_normal((v[0].shape[0], 8, 5)).astype(np.float32)) for k, v in pre_tr.items()}
