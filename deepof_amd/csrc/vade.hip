@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -713,7 +714,7 @@ struct JobBuilder {
     const int64_t units = (int64_t)T * (Sp / 16);
     int64_t nb = (units + 31) / 32;
     if (nb < 1) nb = 1;
-    if (nb > 256) nb = 256;
+    if (nb > 256) nb = 256;  // measured on MI355X: 32..1024 workgroups per job, 256 is the best for the C2 step
     if (external_blocks > 0) nb = external_blocks;
     j.nblk = (int)nb; j.blk0 = external_blocks > 0 ? 0x7fffffff : blk_cur; j.partial_off = partial_cur;
     if (external_blocks == 0) blk_cur += j.nblk;
