@@ -65,9 +65,11 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
       for (int kk = 0; kk < 4; ++kk) B[nt][kk] = 0.0f;
       if (nt < NT) {
         const DofOuterTile& Bt = J.tile[nt];
-        const int tb = t + Bt.shift;
+        const int tap = Bt.pack > 0 ? i / Bt.pack : 0;
+        const int ch = Bt.pack > 0 ? i - tap * Bt.pack : i;
+        const int tb = t + Bt.shift + tap;
         if (tb >= 0 && tb < T && i < Bt.nc) {
-          const float* __restrict__ bp = Bt.ptr + (int64_t)tb * Bt.t_stride + (int64_t)i * Bt.c_stride + s0 * Bt.s_stride;
+          const float* __restrict__ bp = Bt.ptr + (int64_t)tb * Bt.t_stride + (int64_t)ch * Bt.c_stride + s0 * Bt.s_stride;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) B[nt][kk] = bp[(int64_t)(4 * kk) * Bt.s_stride];
         }

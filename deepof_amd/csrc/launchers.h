@@ -96,6 +96,9 @@ struct DofOuterTile {  // one 16-column tile of the B operand
   int64_t t_stride, s_stride, c_stride;  // element strides of the time, sequence and channel axes
   int nc;                      // valid columns (<=16); rest masked to 0
   int shift;                   // B is read at time t+shift (skipped when outside [0,T))
+  int pack;                    // 0: column i = channel i.  > 0: several convolution taps share the tile -- column i
+                               // = channel i % pack read at time t + shift + i / pack (a k=5 conv over 3 input
+                               // channels is one 15-column tile instead of five 3-column ones)
 };
 struct DofOuterJob {
   const float* a_ptr;

@@ -722,10 +722,10 @@ struct JobBuilder {
     jobs.push_back(j);
     return (int)jobs.size() - 1;
   }
-  int add_tile(int job, View b, int nc, int shift) {
+  int add_tile(int job, View b, int nc, int shift, int pack = 0) {
     DofOuterJob& j = jobs[job];
     DofOuterTile& t = j.tile[j.n_tiles];
-    t.ptr = b.p; t.t_stride = b.ts; t.s_stride = b.ss; t.c_stride = b.cs; t.nc = nc; t.shift = shift;
+    t.ptr = b.p; t.t_stride = b.ts; t.s_stride = b.ss; t.c_stride = b.cs; t.nc = nc; t.shift = shift; t.pack = pack;
     return j.n_tiles++;
   }
   void add_fin(int job, int col0, int rows, int cols, int r1, int r2, int64_t dst, int64_t rs, int64_t cs) {
@@ -946,11 +946,18 @@ void build_jobs(DofVadePlan* p) {
       const int64_t Sp = w.Sp;
       const int C1 = 2 * L;
       // encoder conv: dW[o][f][k] = sum dc[t][o] * xs[t+k-2][f]
-      for (int k0 = 0; k0 < 5; k0 += 4) {
+      if (5 * w.F <= 16) {  // all five taps in one packed tile (F = 3: 15 columns, F = 1: 5)
         const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
-        for (int k = k0; k < 5 && k < k0 + 4; ++k) {
-          const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), w.F, k - 2);
-          jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
+        const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), 5 * w.F, -2, w.F);
+        for (int k = 0; k < 5; ++k)
+          jb.add_fin(job, tl * 16 + k * w.F, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
+      } else {
+        for (int k0 = 0; k0 < 5; k0 += 4) {
+          const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
+          for (int k = k0; k < 5 && k < k0 + 4; ++k) {
+            const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), w.F, k - 2);
+            jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
+          }
         }
       }
       if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1);  // L == 8: fused in k_gru16_bwd_fused
