@@ -183,6 +183,27 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ 
   if (threadIdx.x == 0) out[v] = accumulate ? out[v] + red[0] : red[0];
 }
 
+__global__ void __launch_bounds__(256) k_sum_partials_multi(DofSumJobs J, int accumulate) {
+  __shared__ float red[256];
+  int v = blockIdx.x, j = 0;
+  while (j + 1 < J.n && v >= J.nv[j]) {
+    v -= J.nv[j];
+    ++j;
+  }
+  const float* __restrict__ partial = J.partial[j];
+  const int64_t nblk = J.nblk[j];
+  const int nv = J.nv[j];
+  float acc = 0.0f;
+  for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += partial[b * nv + v];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) J.out[j][v] = accumulate ? J.out[j][v] + red[0] : red[0];
+}
+
 __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ params, const float* __restrict__ grads,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ hyper,
@@ -233,6 +254,14 @@ int dof_launch_outer_finalize(const DofOuterJob* jobs_dev, const DofFinJob* fin_
 int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* out, int accumulate, hipStream_t st) {
   DOF_LAUNCH(k_sum_partials, ((unsigned)nv), (256), st, partial, nblk, nv, out, accumulate);
   return dof_check_launch("k_sum_partials");
+}
+
+int dof_launch_sum_partials_multi(const DofSumJobs& jobs, int accumulate, hipStream_t st) {
+  int total = 0;
+  for (int j = 0; j < jobs.n; ++j) total += jobs.nv[j];
+  if (total == 0) return DOF_OK;
+  DOF_LAUNCH(k_sum_partials_multi, ((unsigned)total), (256), st, jobs, accumulate);
+  return dof_check_launch("k_sum_partials_multi");
 }
 
 int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,

@@ -127,6 +127,15 @@ int dof_launch_outer_finalize(const DofOuterJob* jobs_dev, const DofFinJob* fin_
                               const float* partials, float* grads, int accumulate, hipStream_t st);
 // out[dst_off + v] (+)= sum_b partial[b][v]   (fixed order)
 int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* out, int accumulate, hipStream_t st);
+// up to 4 such reductions in one launch (the step has eight of them, each a launch-latency-bound 5 us kernel)
+struct DofSumJobs {
+  int n;
+  const float* partial[4];
+  int64_t nblk[4];
+  int nv[4];
+  float* out[4];
+};
+int dof_launch_sum_partials_multi(const DofSumJobs& jobs, int accumulate, hipStream_t st);
 
 struct DofAdamSeg {  // one contiguous parameter range with its own lr / step count / freeze flag
   int64_t lo, hi;

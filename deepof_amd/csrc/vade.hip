@@ -1375,9 +1375,14 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
   TRY(dof_launch_ln_bwd(L, 2, ws + p->o1d, ws + p->dn1dx, ws + p->dn1dx + (int64_t)T * 2 * L * Bp, params + p->dn1w,
                         ws + p->do1d, ws + p->lnd1p, T, B, Bp, st));
   TRY(dof_launch_gru_bwd(L, 2, len_d, gru_w(params, p->dg1), ws + p->o1d, ws + p->g1d, ws + p->do1d, nullptr, ws + p->dzdec, T, B, Bp, st));
-  TRY(dof_launch_sum_partials(ws + p->lnd2p, p->lnd_blocks, 8 * L, grads + p->dn2w, accumulate, st));
-  TRY(dof_launch_sum_partials(ws + p->lnd1p, p->lnd_blocks, 4 * L, grads + p->dn1w, accumulate, st));
-  TRY(dof_launch_sum_partials(ws + p->ln3p, p->tail_blocks, 4 * L, grads + p->dn3w, accumulate, st));
+  {  // LayerNorm weight / bias gradients of the three decoder norms: one launch
+    DofSumJobs sj;
+    sj.n = 3;
+    sj.partial[0] = ws + p->lnd2p; sj.nblk[0] = p->lnd_blocks; sj.nv[0] = 8 * L; sj.out[0] = grads + p->dn2w;
+    sj.partial[1] = ws + p->lnd1p; sj.nblk[1] = p->lnd_blocks; sj.nv[1] = 4 * L; sj.out[1] = grads + p->dn1w;
+    sj.partial[2] = ws + p->ln3p; sj.nblk[2] = p->tail_blocks; sj.nv[2] = 4 * L; sj.out[2] = grads + p->dn3w;
+    TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
+  }
   return run_jobset(p, p->js_dec[which_input], grads, accumulate, st);
 }
 
@@ -1469,8 +1474,18 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
       TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
     }
     TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
-    TRY(dof_launch_sum_partials(ws + w.ln1p, w.ln1_blocks, 8 * L, grads + b.n1w, accumulate, st));
-    TRY(dof_launch_sum_partials(ws + w.ln2p, w.ln2_blocks, 4 * L, grads + b.n2w, accumulate, st));
+  }
+  {  // LayerNorm weight / bias gradients of both streams: one launch
+    DofSumJobs sj;
+    sj.n = 4;
+    for (int s = 0; s < 2; ++s) {
+      const StreamWs& w = p->sw[s];
+      const BlockOff& b = p->blk[s];
+      sj.partial[2 * s] = ws + w.ln1p; sj.nblk[2 * s] = w.ln1_blocks; sj.nv[2 * s] = 8 * L; sj.out[2 * s] = grads + b.n1w;
+      sj.partial[2 * s + 1] = ws + w.ln2p; sj.nblk[2 * s + 1] = w.ln2_blocks; sj.nv[2 * s + 1] = 4 * L;
+      sj.out[2 * s + 1] = grads + b.n2w;
+    }
+    TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
   }
   return run_jobset(p, p->js_enc, grads, accumulate, st);
 }
