@@ -676,3 +676,35 @@ def test_teacher_pca_views_device_vs_sklearn_gpu(hip):
         assert ours.shape == ref.shape and bool(torch.isfinite(ours).all())
         scale = float(ref.abs().max())
         assert float((ours - ref).abs().max()) < 2e-3 * scale, float((ours - ref).abs().max()) / scale
+
+
+def test_preprocess_full_size_two_animals(hip):
+    """C5's data shape through the device preprocessing (two animals: 28 body parts -> 462 raw columns, 116 output
+    columns, size factors active; 20 videos x 15,000 frames): the exact nan-median size factors of every video, and
+    the oracle on one whole video under the device-fitted scalers."""
+    import parity_common as PC
+    from deepof_amd.preprocess import preprocess_tables
+    from oracle import preprocess as op
+    one = ["Nose", "Left_ear", "Right_ear", "Spine_1", "Center", "Spine_2", "Left_fhip", "Right_fhip", "Left_bhip", "Right_bhip",
+           "Tail_base", "Tail_1", "Tail_2", "Tail_tip"]
+    bps = [f"{a}_{b}" for a in ("B", "W") for b in one]
+    tabs, cols = PC.synth_raw_tables(20, 15_000, bps, seed=6, nan_rate=0.001)
+    node_cols, edge_cols, _ = PC.preprocess_output_columns(cols)
+    edge_cols = edge_cols[:32]
+    kw = dict(dist_standardize="per_column", speed_standardize="per_column", coord_standardize="per_column")
+    res = preprocess_tables(tabs, cols, ["B", "W"], node_cols, edge_cols, (), device="cuda", lib=hip, **kw)
+    assert res.node_table.shape == (300_000, 84) and res.edge_table.shape == (300_000, 32)
+    assert bool(torch.isfinite(res.node_table).all()) and bool(torch.isfinite(res.edge_table).all())
+    sf = res.size_factors.cpu().numpy()
+    for i, k in enumerate(res.keys):
+        s_by, dflt = op.size_factors(tabs[k], cols, ["B", "W"])
+        np.testing.assert_allclose(sf[i], [s_by["B"], s_by["W"], dflt], rtol=1e-15, atol=0)
+    # per-column global scalers leave every standardised column with mean 0 / variance 1 over all frames (rare gaps aside)
+    nt = res.node_table.double()
+    assert float(nt.mean(0).abs().max()) < 5e-3 and float((nt.var(0, unbiased=False) - 1).abs().max()) < 3e-2
+    some = {"v007": tabs["v007"]}
+    want, _ = op.preprocess(some, cols, ["B", "W"], pretrained_scaler=res.global_scaler, **kw)
+    part = preprocess_tables(some, cols, ["B", "W"], node_cols, edge_cols, (), pretrained_scaler=res.global_scaler, device="cuda", lib=hip, **kw)
+    PC._check_tables(part, want, cols, node_cols, edge_cols, [], "two animals, one video vs oracle")
+    j = res.keys.index("v007")
+    assert torch.equal(part.node_table, res.node_table[int(res.video_off[j]):int(res.video_off[j + 1])])
