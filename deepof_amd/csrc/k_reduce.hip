@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(256) k_outer_finalize(const DofOuterJob* __res
   const DofOuterJob& J = jobs[F.job];
   const int local = e - F.elem0;
   const int ri = local / F.cols, ci = local - ri * F.cols;
-  const int src_row = ri < F.r1 ? ri : ri + (F.r2 - F.r1);
+  int src_row = ri < F.r1 ? ri : ri + (F.r2 - F.r1);
+  if (F.gate_minor > 0) src_row = (src_row % F.gate_minor) * 4 + src_row / F.gate_minor;
   const float* __restrict__ p = partials + J.partial_off + (int64_t)src_row * 65 + F.col0 + ci;
   float acc = 0.0f;
   for (int b = lane; b < J.nblk; b += 64) acc += p[(int64_t)b * DOF_OUTER_PARTIAL_FLOATS];

@@ -432,18 +432,16 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(const float* __restrict__ X, c
     const float nn = dof_tanh(fmaf(r, ahn, an));
     h = fmaf(z, h - nn, nn);
     O[ACT(t, dir * HID + u, 2 * HID, Sp, s)] = h;
-    if (gs) {
-      gs[ACT(t, u, 4 * HID, Sp, s)] = r;
-      gs[ACT(t, HID + u, 4 * HID, Sp, s)] = z;
-      gs[ACT(t, 2 * HID + u, 4 * HID, Sp, s)] = nn;
-      gs[ACT(t, 3 * HID + u, 4 * HID, Sp, s)] = ahn;
+    if (gs) {  // unit-major gate buffer: (r, z, n, W_hn h + b_hn) of unit u are one 16-byte word
+      const float gate4[4] = {r, z, nn, ahn};
+      dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), gate4);
     }
   }
   for (int t = n; t < T; ++t) {
     O[ACT(t, dir * HID + u, 2 * HID, Sp, s)] = 0.0f;
     if (gs) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gs[ACT(t, g * HID + u, 4 * HID, Sp, s)] = 0.0f;
+      const float zero4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), zero4);
     }
   }
 }
@@ -474,9 +472,9 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
     tn[j] = whh[(2 * HID + j) * HID + u];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      xr[m][j] = wih[j * IN + u + m * G];
-      xz[m][j] = wih[(HID + j) * IN + u + m * G];
-      xn[m][j] = wih[(2 * HID + j) * IN + u + m * G];
+      xr[m][j] = wih[j * IN + M * u + m];
+      xz[m][j] = wih[(HID + j) * IN + M * u + m];
+      xn[m][j] = wih[(2 * HID + j) * IN + M * u + m];
     }
   }
   float* __restrict__ gs = GS + (int64_t)dir * T * 4 * HID * Sp;
@@ -489,10 +487,9 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
   for (int step = n - 1; step >= 0; --step) {
     const int t = dir ? (n - 1 - step) : step;
     const int tp = dir ? t + 1 : t - 1;
-    const float r = gs[ACT(t, u, 4 * HID, Sp, s)];
-    const float z = gs[ACT(t, HID + u, 4 * HID, Sp, s)];
-    const float nn = gs[ACT(t, 2 * HID + u, 4 * HID, Sp, s)];
-    const float ahn = gs[ACT(t, 3 * HID + u, 4 * HID, Sp, s)];
+    float gate4[4];
+    dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), gate4);
+    const float r = gate4[0], z = gate4[1], nn = gate4[2], ahn = gate4[3];
     const float hp = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
     float dht = dh;
     if (dO) dht += dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)];
@@ -503,10 +500,8 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
     const float g_z = dz * z * (1.0f - z);
     const float g_n = dnp;
     const float g_h = dnp * r;
-    gs[ACT(t, u, 4 * HID, Sp, s)] = g_r;
-    gs[ACT(t, HID + u, 4 * HID, Sp, s)] = g_z;
-    gs[ACT(t, 2 * HID + u, 4 * HID, Sp, s)] = g_n;
-    gs[ACT(t, 3 * HID + u, 4 * HID, Sp, s)] = g_h;
+    const float dg4[4] = {g_r, g_z, g_n, g_h};
+    dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), dg4);
     float dhp = dht * z;
     float dx[M];
 #pragma unroll
@@ -528,18 +523,22 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
       }
     });
     dh = dhp;
+    if (BCAST) {
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      if (BCAST) dxacc[m] += dx[m];
-      else dx_out[ACT(t, u + m * G, IN, Sp, s)] = dx[m];
+      for (int m = 0; m < M; ++m) dxacc[m] += dx[m];
+    } else if (M == 4) {  // lane u owns input columns 4u .. 4u+3: one 16-byte store
+      dof_st_row<4>(dx_out + ACT(t, 4 * u, IN, Sp, s), dx);
+    } else {
+#pragma unroll
+      for (int m = 0; m < M; ++m) dx_out[ACT(t, M * u + m, IN, Sp, s)] = dx[m];
     }
   }
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     if (BCAST) {
-      dx_out[(int64_t)(u + m * G) * Sp + s] = dxacc[m];
+      dx_out[(int64_t)(M * u + m) * Sp + s] = dxacc[m];
     } else {
-      for (int t = n; t < T; ++t) dx_out[ACT(t, u + m * G, IN, Sp, s)] = 0.0f;
+      for (int t = n; t < T; ++t) dx_out[ACT(t, M * u + m, IN, Sp, s)] = 0.0f;
     }
   }
 }
@@ -593,10 +592,10 @@ __global__ void __launch_bounds__(256) k_gru16_bwd_fused(
     const int tp = dir ? t + 1 : t - 1;
     float g_r = 0.0f, g_z = 0.0f, g_n = 0.0f, g_h = 0.0f, hp = 0.0f, xu = 0.0f, dht = 0.0f, z = 0.0f;
     if (act) {
-      const float r = gs[ACT(t, u, 4 * HID, Sp, s)];
-      z = gs[ACT(t, HID + u, 4 * HID, Sp, s)];
-      const float nn = gs[ACT(t, 2 * HID + u, 4 * HID, Sp, s)];
-      const float ahn = gs[ACT(t, 3 * HID + u, 4 * HID, Sp, s)];
+      float gate4[4];
+      dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), gate4);
+      const float r = gate4[0], nn = gate4[2], ahn = gate4[3];
+      z = gate4[1];
       hp = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
       xu = X[ACT(t, u, IN, Sp, s)];
       dht = dh;

@@ -119,6 +119,8 @@ struct DofFinJob {  // scatter-add of one reduced (rows x cols) block into a gra
   int64_t dst_off;      // float offset into the grad buffer
   int64_t row_stride, col_stride;
   int elem0;            // prefix offset of this fin-job's elements in the finalize launch
+  int gate_minor;       // HID > 0: the job's A rows are unit-major (row = unit * 4 + gate; the lane-per-unit GRU kernels
+                        // keep a unit's four gate values in one 16-byte word), 0: gate-major (row = gate * HID + unit)
 };
 #define DOF_OUTER_PARTIAL_FLOATS (64 * 65)
 

@@ -728,8 +728,10 @@ struct JobBuilder {
     t.ptr = b.p; t.t_stride = b.ts; t.s_stride = b.ss; t.c_stride = b.cs; t.nc = nc; t.shift = shift; t.pack = pack;
     return j.n_tiles++;
   }
-  void add_fin(int job, int col0, int rows, int cols, int r1, int r2, int64_t dst, int64_t rs, int64_t cs) {
+  void add_fin(int job, int col0, int rows, int cols, int r1, int r2, int64_t dst, int64_t rs, int64_t cs,
+               int gate_minor = 0) {
     DofFinJob f;
+    f.gate_minor = gate_minor;
     f.job = job; f.col0 = col0; f.rows = rows; f.cols = cols; f.r1 = r1; f.r2 = r2;
     f.dst_off = dst; f.row_stride = rs; f.col_stride = cs; f.elem0 = elem_cur;
     elem_cur += rows * cols;
@@ -739,18 +741,20 @@ struct JobBuilder {
 
 // One bidirectional GRU layer: per direction A = dG (4*HID rows), tiles = input channels + h_prev.
 // X_bcast: the layer input is a per-window vector [IN][Sp] repeated over time (decoder GRU1).
+// gate_minor: dG rows are unit-major (the lane-per-unit kernels of latent 8), see DofFinJob
 void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int IN, const float* O, int HID, int T,
-              int64_t Sp, const GruOff& g) {
+              int64_t Sp, const GruOff& g, bool gate_minor) {
+  const int gm = gate_minor ? HID : 0;
   for (int d = 0; d < 2; ++d) {
     const float* a = dG + (int64_t)d * T * 4 * HID * Sp;
     const int job = jb.add_job(aos(a, 4 * HID, Sp), 4 * HID, T, Sp);
     for (int c0 = 0; c0 < IN; c0 += 16)
       jb.add_tile(job, x_bcast ? soa(X, Sp, c0) : aos(X, IN, Sp, c0), IN - c0 < 16 ? IN - c0 : 16, 0);
     const int hh = jb.add_tile(job, aos(O, 2 * HID, Sp, d * HID), HID, d == 0 ? -1 : +1);
-    jb.add_fin(job, 0, 3 * HID, IN, 3 * HID, 3 * HID, g.t[d * 4 + 0], IN, 1);            // weight_ih
-    jb.add_fin(job, hh * 16, 3 * HID, HID, 2 * HID, 3 * HID, g.t[d * 4 + 1], HID, 1);    // weight_hh (r,z,hn rows)
-    jb.add_fin(job, 64, 3 * HID, 1, 3 * HID, 3 * HID, g.t[d * 4 + 2], 1, 1);             // bias_ih
-    jb.add_fin(job, 64, 3 * HID, 1, 2 * HID, 3 * HID, g.t[d * 4 + 3], 1, 1);             // bias_hh
+    jb.add_fin(job, 0, 3 * HID, IN, 3 * HID, 3 * HID, g.t[d * 4 + 0], IN, 1, gm);            // weight_ih
+    jb.add_fin(job, hh * 16, 3 * HID, HID, 2 * HID, 3 * HID, g.t[d * 4 + 1], HID, 1, gm);    // weight_hh (r,z,hn rows)
+    jb.add_fin(job, 64, 3 * HID, 1, 3 * HID, 3 * HID, g.t[d * 4 + 2], 1, 1, gm);             // bias_ih
+    jb.add_fin(job, 64, 3 * HID, 1, 2 * HID, 3 * HID, g.t[d * 4 + 3], 1, 1, gm);             // bias_hh
   }
 }
 
@@ -960,8 +964,8 @@ void build_jobs(DofVadePlan* p) {
           }
         }
       }
-      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1);  // L == 8: fused in k_gru16_bwd_fused
-      gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2);
+      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1, L == 8);  // L == 8: fused in k_gru16_bwd_fused
+      gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8);
       cens_jobs(p, jb, s);
     }
     // final dense (L,J): A = flat rows (<=64 per job), B = denc
@@ -989,8 +993,8 @@ void build_jobs(DofVadePlan* p) {
   for (int v = 0; v < 2; ++v) {
     JobBuilder jb(p->js_dec[v]);
     const float* zin = ws + (v == 0 ? p->z : p->enc);
-    gru_jobs(jb, ws + p->g1d, zin, true, L, ws + p->o1d, L, T, Bp, p->dg1);
-    if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2);
+    gru_jobs(jb, ws + p->g1d, zin, true, L, ws + p->o1d, L, T, Bp, p->dg1, L == 8);
+    if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2, L == 8);
     const int CI = 4 * L, CO = 2 * L;
     int job = -1;
     for (int k = 0; k < 5; ++k)
