@@ -108,12 +108,17 @@ struct TcnConvArgs {
   const float* bnp_in;  // BatchNorm record of the producer (BN_IN)
   float* a_out;         // [T][Sp][32] activated input (BN_IN, forward only) or null
   float* out;           // [T][Sp][32]
-  float* partial;       // [n_waves][64] channel sums (forward) or null
+  float* partial;       // [n_waves][64] channel sums (forward / fused backward) or null
+  const float* fuse_y;    // FUSE_BN: pre-normalisation output of the BatchNorm+ReLU in front of this (reverse) conv's result
+  const float* fuse_bnp;  // FUSE_BN: its record
   int T, dil, accumulate;
   int64_t S, Sp;
 };
 
-template <bool REVERSE, bool BN_IN>
+// FUSE_BN (reverse only): the result is the gradient entering a ReLU(BatchNorm(y)) -- the first pass of that
+// BatchNorm's backward (mask by the activation, channel sums of g and g * xhat) runs in the epilogue, so the
+// gradient is written once, already masked, instead of written, re-read and rewritten by k_tcn_bn_bwd1.
+template <bool REVERSE, bool BN_IN, bool FUSE_BN = false>
 __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -177,6 +182,15 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
           v0 += o[i];
           v1 += o[16 + i];
         }
+        if (FUSE_BN) {
+          const float* yr = A.fuse_y + ACT(t, 0, TC, A.Sp, s);
+          const float y0 = yr[i], y1 = yr[16 + i];
+          v0 = BN_APPLY(A.fuse_bnp, TC, i, y0) > 0.0f ? v0 : 0.0f;
+          v1 = BN_APPLY(A.fuse_bnp, TC, 16 + i, y1) > 0.0f ? v1 : 0.0f;
+          s1[0] += v0; s2[0] = fmaf(v0, (y0 - BNP_MEAN(A.fuse_bnp, TC, i)) * BNP_RSTD(A.fuse_bnp, TC, i), s2[0]);
+          s1[1] += v1;
+          s2[1] = fmaf(v1, (y1 - BNP_MEAN(A.fuse_bnp, TC, 16 + i)) * BNP_RSTD(A.fuse_bnp, TC, 16 + i), s2[1]);
+        }
         o[i] = v0;
         o[16 + i] = v1;
         if (!REVERSE) {
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
       }
     }
   }
-  if (!REVERSE && A.partial) {
+  if ((!REVERSE || FUSE_BN) && A.partial) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       s1[ct] += __shfl_xor(s1[ct], 16); s1[ct] += __shfl_xor(s1[ct], 32);
@@ -816,6 +830,7 @@ int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const floa
                         hipStream_t st) {
   TcnConvArgs A;
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
+  A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
   const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
   if (reverse) {
@@ -826,6 +841,20 @@ int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const floa
     DOF_LAUNCH((k_tcn_conv<false, false>), (nb), (256), st, A);
   }
   return dof_check_launch("k_tcn_conv");
+}
+
+// data gradient of a 32 -> 32 convolution fused with the first backward pass of the BatchNorm + ReLU that produced
+// the convolution's input: g = conv^T(dy) * [BN(y) > 0] into g_out, channel sums (sum g | sum g * xhat) into sums
+int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
+                               float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st) {
+  TcnConvArgs A;
+  A.in = dy; A.w = w; A.bias = nullptr; A.bnp_in = nullptr; A.a_out = nullptr; A.out = g_out; A.partial = partial;
+  A.fuse_y = y; A.fuse_bnp = bnp;
+  A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
+  const int64_t waves = dof_tcn_conv_waves(T, Sp);
+  DOF_LAUNCH((k_tcn_conv<true, false, true>), ((unsigned)(waves / 4)), (256), st, A);
+  if (int rc = dof_check_launch("k_tcn_conv_bwd_bn")) return rc;
+  return dof_launch_sum_partials(partial, waves, 2 * TC, sums, 0, st);
 }
 
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
@@ -878,6 +907,7 @@ int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const flo
                          int accumulate, int T, int dil, int64_t S, int64_t Sp, hipStream_t st) {
   TcnConvArgs A;
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
+  A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
   const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
 #define CONVG(R, BN, K, N) DOF_LAUNCH((k_tcn_convg<R, BN, K, N>), (nb), (256), st, A, cin_real, w_ci)

@@ -37,6 +37,8 @@ int64_t dof_tcn_row_blocks(int T, int64_t S);   // partial rows written by the r
 int64_t dof_tcn_conv_waves(int T, int64_t Sp);  // partial rows written by the MFMA convolution (one per wave)
 int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float* bias, float* xs, float* y,
                            float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st);
+int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
+                               float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st);

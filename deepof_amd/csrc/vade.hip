@@ -1441,11 +1441,9 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
                                  nullptr, dprev, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, ws + t.coef, 32, st));
       TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.coef, T, 32, w.S, w.Sp, st));
-      TRY(dof_launch_tcn_conv(1, ws + t.g2[b], params + o.c2w, nullptr, nullptr, nullptr, ws + t.da, nullptr, 0, T, d,
-                              w.S, w.Sp, st));
-      // BN1 + ReLU
-      TRY(dof_launch_tcn_bn_bwd1(ws + t.da, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b], ws + t.partial, ws + t.sums, 0,
-                                 nullptr, nullptr, nullptr, nullptr, nullptr, T, 32, w.S, w.Sp, st));
+      // conv2's data gradient with BN1 + ReLU's first backward pass in its epilogue
+      TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
+                                     ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st));
       TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g1, grads + o.b1, accumulate, ws + t.coef, 32, st));
       TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef, T, 32, w.S, w.Sp, st));
       if (b > 0)
