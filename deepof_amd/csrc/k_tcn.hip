@@ -543,23 +543,27 @@ __global__ void __launch_bounds__(256) k_tcn_bn_bwd1(TcnBnBwd1Args A) {
 }
 
 // pass 2: dy = scale * (g - mean(g) - xhat * mean(g*xhat)), in place
+// One 16-byte word per lane, lanes along the channels of a row and on to the next rows: a wavefront's load covers
+// 1 KB of contiguous memory (the row-per-thread form touched 64 different 128-byte lines per instruction).
 __global__ void __launch_bounds__(256) k_tcn_bn_bwd2(float* __restrict__ g, const float* __restrict__ y,
                                                      const float* __restrict__ bnp, const float* __restrict__ coef,
                                                      int T, int CT, int64_t S, int64_t Sp) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)T * S) return;
-  const int t = (int)(i / S);
-  const int64_t s = i - (int64_t)t * S;
-  const int c0 = blockIdx.y * TC;
-  float d[TC], yv[TC];
-  dof_ld_row<TC>(g + ACT(t, c0, CT, Sp, s), d);
-  dof_ld_row<TC>(y + ACT(t, c0, CT, Sp, s), yv);
+  const int q = CT >> 2;  // 16-byte words per row (8 or 16: divides the block size, so a lane's channels are fixed)
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S * q) return;
+  const int t = blockIdx.y;
+  const int64_t s = e / q;
+  const int c0 = (int)(e - s * q) * 4;
+  float d[4], yv[4];
+  float* gp = g + ACT(t, c0, CT, Sp, s);
+  dof_ld_row<4>(gp, d);
+  dof_ld_row<4>(y + ACT(t, c0, CT, Sp, s), yv);
 #pragma unroll
-  for (int c = 0; c < TC; ++c) {
+  for (int c = 0; c < 4; ++c) {
     const float xh = (yv[c] - BNP_MEAN(bnp, CT, c0 + c)) * BNP_RSTD(bnp, CT, c0 + c);
     d[c] = BNP_SCALE(bnp, CT, c0 + c) * (d[c] - coef[c0 + c] - xh * coef[CT + c0 + c]);
   }
-  dof_st_row<TC>(g + ACT(t, c0, CT, Sp, s), d);
+  dof_st_row<4>(gp, d);
 }
 
 // channel sums of the row-per-thread kernels: partial[h][nblk][64] -> sums[2][CT] (sum, second moment)
@@ -895,8 +899,7 @@ int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, f
 
 int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int CT, int64_t S,
                            int64_t Sp, hipStream_t st) {
-  DOF_LAUNCH(k_tcn_bn_bwd2, ((unsigned)dof_tcn_row_blocks(T, S), (unsigned)(CT / TC)), (256), st, g, y, bnp, coef, T, CT,
-             S, Sp);
+  DOF_LAUNCH(k_tcn_bn_bwd2, (dof_cdiv(S * (CT / 4), 256), (unsigned)T), (256), st, g, y, bnp, coef, T, CT, S, Sp);
   return dof_check_launch("k_tcn_bn_bwd2");
 }
 
