@@ -727,6 +727,40 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ X, con
   dof_st_row<C>(Y + ACT(t, 0, C, Sp, s), x);
 }
 
+// The same LayerNorm with one 16-byte word per lane: the C / 4 lanes of a row are neighbours (a wavefront's load
+// covers 1 KB of contiguous memory instead of 64 separate 128-byte lines), row sums by xor-shuffles.  C / 4 must be
+// a power of two (latent 8: 4 or 8 lanes per row).
+template <int C>
+__global__ void __launch_bounds__(256) k_ln_fwd_w(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ Y, int64_t S,
+                                                  int64_t Sp) {
+  constexpr int Q = C / 4;
+  static_assert((Q & (Q - 1)) == 0 && Q <= 64, "lanes per row must be a power of two");
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S * Q) return;  // whole rows leave together (Q divides the wavefront)
+  const int t = blockIdx.y;
+  const int64_t s = e / Q;
+  const int c0 = (int)(e - s * Q) * 4;
+  float x[4];
+  dof_ld_row<4>(X + ACT(t, c0, C, Sp, s), x);
+  float sum = (x[0] + x[1]) + (x[2] + x[3]);
+#pragma unroll
+  for (int m = 1; m < Q; m <<= 1) sum += __shfl_xor(sum, m);
+  const float mean = sum * (1.0f / C);
+  float var = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    x[c] -= mean;
+    var = fmaf(x[c], x[c], var);
+  }
+#pragma unroll
+  for (int m = 1; m < Q; m <<= 1) var += __shfl_xor(var, m);
+  const float rstd = rsqrtf(var * (1.0f / C) + 1e-3f);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) x[c] = fmaf(x[c] * rstd, dof_cw(gamma)[c0 + c], dof_cw(beta)[c0 + c]);
+  dof_st_row<4>(Y + ACT(t, c0, C, Sp, s), x);
+}
+
 // dX = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dY*gamma; per-block partial dgamma/dbeta.
 // PW = true: per-window tensors [c][s] (the encoder's final LayerNorm, T = 1).
 template <int C, bool PW>
@@ -934,6 +968,11 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
 int dof_launch_ln_fwd(int L, int mult, const float* X, const float* gamma, const float* beta, float* Y, int T,
                       int64_t S, int64_t Sp, hipStream_t st) {
   const unsigned nb = dof_cdiv((int64_t)T * S, 256);
+  if (L == 8) {  // word-per-lane form (lanes per row a power of two)
+    if (mult == 2) DOF_LAUNCH((k_ln_fwd_w<16>), (dof_cdiv(S * 4, 256), (unsigned)T), (256), st, X, gamma, beta, Y, S, Sp);
+    else DOF_LAUNCH((k_ln_fwd_w<32>), (dof_cdiv(S * 8, 256), (unsigned)T), (256), st, X, gamma, beta, Y, S, Sp);
+    return dof_check_launch("k_ln_fwd_w");
+  }
   if (mult == 2) {
     DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_fwd<2 * LL>), (nb), (256), st, X, gamma, beta, Y, T, S, Sp));
   } else {
