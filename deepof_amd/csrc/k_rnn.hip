@@ -832,6 +832,87 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ X, con
 #undef LNIDX
 }
 
+// LayerNorm backward, one 16-byte word per lane (see k_ln_fwd_w): a workgroup still owns 256 consecutive (t, s) rows
+// -- Q passes of 256 / Q rows -- so the [nblk][2C] partial layout of the dgamma / dbeta reduction is unchanged.
+template <int C>
+__global__ void __launch_bounds__(256) k_ln_bwd_w(const float* __restrict__ X, const float* __restrict__ dY1,
+                                                  const float* __restrict__ dY2, const float* __restrict__ gamma,
+                                                  float* __restrict__ dX, float* __restrict__ partial,  // [nblk][2C]
+                                                  int T, int64_t S, int64_t Sp) {
+  constexpr int Q = C / 4, RPP = 256 / Q;  // lanes per row, rows per pass
+  static_assert((Q & (Q - 1)) == 0, "lanes per row must be a power of two");
+  __shared__ float red[256][8];
+  const int sub = threadIdx.x / Q, c0 = (threadIdx.x % Q) * 4;
+  float gam[4], acc[8];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) gam[c] = dof_cw(gamma)[c0 + c];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+  const int64_t n_rows = (int64_t)T * S;
+  for (int pass = 0; pass < Q; ++pass) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + pass * RPP + sub;
+    const bool live = i < n_rows;
+    const int t = live ? (int)(i / S) : 0;
+    const int64_t s = live ? i - (int64_t)t * S : 0;
+    float x[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dy[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) {
+      dof_ld_row<4>(X + ACT(t, c0, C, Sp, s), x);
+      dof_ld_row<4>(dY1 + ACT(t, c0, C, Sp, s), dy);
+      if (dY2) {
+        float d2[4];
+        dof_ld_row<4>(dY2 + ACT(t, c0, C, Sp, s), d2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dy[c] += d2[c];
+      }
+    }
+    float sum = (x[0] + x[1]) + (x[2] + x[3]);
+#pragma unroll
+    for (int m = 1; m < Q; m <<= 1) sum += __shfl_xor(sum, m);
+    const float mean = sum * (1.0f / C);
+    float var = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      x[c] -= mean;
+      var = fmaf(x[c], x[c], var);
+    }
+#pragma unroll
+    for (int m = 1; m < Q; m <<= 1) var += __shfl_xor(var, m);
+    const float rstd = rsqrtf(var * (1.0f / C) + 1e-3f);
+    float mg = 0.0f, mgx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      x[c] *= rstd;  // xhat
+      const float g = dy[c] * gam[c];
+      mg += g;
+      mgx = fmaf(g, x[c], mgx);
+      acc[c] = fmaf(dy[c], x[c], acc[c]);
+      acc[4 + c] += dy[c];
+    }
+#pragma unroll
+    for (int m = 1; m < Q; m <<= 1) {
+      mg += __shfl_xor(mg, m);
+      mgx += __shfl_xor(mgx, m);
+    }
+    mg *= (1.0f / C);
+    mgx *= (1.0f / C);
+    if (live) {
+      float dxr[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dxr[c] = rstd * (dy[c] * gam[c] - mg - x[c] * mgx);
+      dof_st_row<4>(dX + ACT(t, c0, C, Sp, s), dxr);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) red[threadIdx.x][c] = acc[c];
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * C) {  // value v: [dgamma (C) | dbeta (C)]; channel ch is held by the lanes tid % Q == ch / 4
+    const int which = threadIdx.x / C, ch = threadIdx.x - which * C;
+    float sum = 0.0f;
+    for (int k = ch >> 2; k < 256; k += Q) sum += red[k][which * 4 + (ch & 3)];
+    partial[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = sum;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Encoder block tail: gather the final hidden state of GRU2 ([fwd @ len-1, bwd @ 0]) + LayerNorm.
 // ---------------------------------------------------------------------------------------------
@@ -1004,6 +1085,11 @@ int64_t dof_ln_bwd_blocks(int T, int64_t S) { return dof_cdiv((int64_t)T * S, 25
 int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const float* dY2, const float* gamma,
                       float* dX, float* partial, int T, int64_t S, int64_t Sp, hipStream_t st) {
   const unsigned nb = (unsigned)dof_ln_bwd_blocks(T, S);
+  if (L == 8 && T > 1) {  // word-per-lane form
+    if (mult == 2) DOF_LAUNCH((k_ln_bwd_w<16>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp);
+    else DOF_LAUNCH((k_ln_bwd_w<32>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp);
+    return dof_check_launch("k_ln_bwd_w");
+  }
   if (mult == 2 && T == 1) {  // per-window [c][s] tensors (encoder block output)
     DOF_DISPATCH_L(L, DOF_LAUNCH((k_ln_bwd<2 * LL, true>), (nb), (256), st, X, dY1, dY2, gamma, dX, partial, T, S, Sp));
   } else if (mult == 2) {
