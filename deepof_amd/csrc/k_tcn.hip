@@ -433,39 +433,41 @@ struct TcnCombineArgs {
   int64_t S, Sp;
 };
 
-// thread = (row (t,s), 32-channel half blockIdx.y of the CT = 32 | 64 channels)
+// one 16-byte word per lane: lanes along the channels of a row and on to the next rows (grid.y = time step)
 __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)A.T * A.S) return;
-  const int t = (int)(i / A.S);
-  const int64_t s = i - (int64_t)t * A.S;
-  const int c0 = blockIdx.y * TC, CT = A.CT;
-  float y[TC], r[TC], sk[TC];
-  dof_ld_row<TC>(A.y2 + ACT(t, c0, CT, A.Sp, s), y);
+  const int CT = A.CT, q = CT >> 2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= A.S * q) return;
+  const int t = blockIdx.y;
+  const int64_t s = e / q;
+  const int c0 = (int)(e - s * q) * 4;
+  const int64_t off = ACT(t, c0, CT, A.Sp, s);
+  float y[4], r[4], sk[4];
+  dof_ld_row<4>(A.y2 + off, y);
   if (A.res) {
-    dof_ld_row<TC>(A.res + ACT(t, c0, CT, A.Sp, s), r);
+    dof_ld_row<4>(A.res + off, r);
   } else {
     float xin[32];
     for (int f = 0; f < A.F; ++f) xin[f] = A.xs[ACT(t, f, A.xs_ch, A.Sp, s)];
 #pragma unroll
-    for (int c = 0; c < TC; ++c) {
+    for (int c = 0; c < 4; ++c) {
       float acc = A.dsb[c0 + c];
       for (int f = 0; f < A.F; ++f) acc = fmaf(A.dsw[(c0 + c) * A.F + f], xin[f], acc);
       r[c] = acc;
     }
   }
-  if (!A.first) dof_ld_row<TC>(A.skip + ACT(t, c0, CT, A.Sp, s), sk);
+  if (!A.first) dof_ld_row<4>(A.skip + off, sk);
 #pragma unroll
-  for (int c = 0; c < TC; ++c) {
+  for (int c = 0; c < 4; ++c) {
     const float a2 = fmaxf(BN_APPLY(A.bnp2, CT, c0 + c, y[c]), 0.0f);
     sk[c] = A.first ? a2 : sk[c] + a2;
     r[c] = fmaxf(a2 + r[c], 0.0f);
   }
-  dof_st_row<TC>(A.skip + ACT(t, c0, CT, A.Sp, s), sk);
-  if (A.out) dof_st_row<TC>(A.out + ACT(t, c0, CT, A.Sp, s), r);
+  dof_st_row<4>(A.skip + off, sk);
+  if (A.out) dof_st_row<4>(A.out + off, r);
   if (A.feat && t == A.T - 1) {
 #pragma unroll
-    for (int c = 0; c < TC; ++c) A.feat[(int64_t)c * A.Sp + s] = fmaxf(sk[c], 0.0f);
+    for (int c = 0; c < 4; ++c) A.feat[(int64_t)(c0 + c) * A.Sp + s] = fmaxf(sk[c], 0.0f);
   }
 }
 
@@ -490,56 +492,70 @@ struct TcnBnBwd1Args {
   int64_t S, Sp;
 };
 
-__global__ void __launch_bounds__(256) k_tcn_bn_bwd1(TcnBnBwd1Args A) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c0 = blockIdx.y * TC, CT = A.CT;
-  float st[2 * TC];
+// One 16-byte word per lane (lanes along the channels of a row and on to the next rows, see k_tcn_bn_bwd2; the
+// row-per-thread form it replaces ran at 4.2 TB/s): a workgroup owns 256 rows of one time step in CT / 4 passes; partial[nblk][2 CT] = (sum g | sum g xhat).
+__global__ void __launch_bounds__(256) k_tcn_bn_bwd1_w(TcnBnBwd1Args A) {
+  __shared__ float red[256][8];
+  const int CT = A.CT, q = CT >> 2, rpp = 256 / q;
+  const int sub = threadIdx.x / q, c0 = (threadIdx.x % q) * 4;
+  const int t = blockIdx.y;
+  float acc[8];
 #pragma unroll
-  for (int c = 0; c < 2 * TC; ++c) st[c] = 0.0f;
-  if (i < (int64_t)A.T * A.S) {
-    const int t = (int)(i / A.S);
-    const int64_t s = i - (int64_t)t * A.S;
-    float d[TC], y[TC];
-    if (A.din) {
-      dof_ld_row<TC>(A.din + ACT(t, c0, CT, A.Sp, s), d);
-    } else {
+  for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+  float mean[4], rstd[4], sc[4], sh[4];
 #pragma unroll
-      for (int c = 0; c < TC; ++c) d[c] = 0.0f;
-    }
+  for (int c = 0; c < 4; ++c) {
+    mean[c] = BNP_MEAN(A.bnp, CT, c0 + c);
+    rstd[c] = BNP_RSTD(A.bnp, CT, c0 + c);
+    sc[c] = BNP_SCALE(A.bnp, CT, c0 + c);
+    sh[c] = BNP_SHIFT(A.bnp, CT, c0 + c);
+  }
+  for (int pass = 0; pass < q; ++pass) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + pass * rpp + sub;
+    if (s >= A.S) continue;
+    const int64_t off = ACT(t, c0, CT, A.Sp, s);
+    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f}, y[4];
+    if (A.din) dof_ld_row<4>(A.din + off, d);
     if (A.blk) {
       if (A.out_blk) {
-        float o[TC];
-        dof_ld_row<TC>(A.out_blk + ACT(t, c0, CT, A.Sp, s), o);
+        float o[4];
+        dof_ld_row<4>(A.out_blk + off, o);
 #pragma unroll
-        for (int c = 0; c < TC; ++c) d[c] = o[c] > 0.0f ? d[c] : 0.0f;
+        for (int c = 0; c < 4; ++c) d[c] = o[c] > 0.0f ? d[c] : 0.0f;
       }
-      if (A.gres) dof_st_row<TC>(A.gres + ACT(t, c0, CT, A.Sp, s), d);
+      if (A.gres) dof_st_row<4>(A.gres + off, d);
       if (A.dfeat && t == A.T - 1) {
-        float sk[TC];
-        dof_ld_row<TC>(A.skip + ACT(t, c0, CT, A.Sp, s), sk);
+        float sk[4];
+        dof_ld_row<4>(A.skip + off, sk);
 #pragma unroll
-        for (int c = 0; c < TC; ++c) d[c] += sk[c] > 0.0f ? A.dfeat[(int64_t)(c0 + c) * A.Sp + s] : 0.0f;
+        for (int c = 0; c < 4; ++c) d[c] += sk[c] > 0.0f ? A.dfeat[(int64_t)(c0 + c) * A.Sp + s] : 0.0f;
       }
       if (A.dskip) {
-        float ds[TC];
-        dof_ld_row<TC>(A.dskip + ACT(t, c0, CT, A.Sp, s), ds);
+        float ds[4];
+        dof_ld_row<4>(A.dskip + off, ds);
 #pragma unroll
-        for (int c = 0; c < TC; ++c) d[c] += ds[c];
+        for (int c = 0; c < 4; ++c) d[c] += ds[c];
       }
     }
-    dof_ld_row<TC>(A.y + ACT(t, c0, CT, A.Sp, s), y);
+    dof_ld_row<4>(A.y + off, y);
 #pragma unroll
-    for (int c = 0; c < TC; ++c) {
-      const float a = BN_APPLY(A.bnp, CT, c0 + c, y[c]);
-      const float g = a > 0.0f ? d[c] : 0.0f;
-      const float xh = (y[c] - BNP_MEAN(A.bnp, CT, c0 + c)) * BNP_RSTD(A.bnp, CT, c0 + c);
+    for (int c = 0; c < 4; ++c) {
+      const float g = fmaf(y[c], sc[c], sh[c]) > 0.0f ? d[c] : 0.0f;
       d[c] = g;
-      st[c] = g;
-      st[TC + c] = g * xh;
+      acc[c] += g;
+      acc[4 + c] = fmaf(g, (y[c] - mean[c]) * rstd[c], acc[4 + c]);
     }
-    dof_st_row<TC>(A.g + ACT(t, c0, CT, A.Sp, s), d);
+    dof_st_row<4>(A.g + off, d);
   }
-  dof_block_colsum<2 * TC>(st, A.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * TC);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) red[threadIdx.x][c] = acc[c];
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * CT) {
+    const int which = threadIdx.x / CT, ch = threadIdx.x - which * CT;
+    float sum = 0.0f;
+    for (int k = ch >> 2; k < 256; k += q) sum += red[k][which * 4 + (ch & 3)];
+    A.partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * CT + threadIdx.x] = sum;
+  }
 }
 
 // pass 2: dy = scale * (g - mean(g) - xhat * mean(g*xhat)), in place
@@ -564,25 +580,6 @@ __global__ void __launch_bounds__(256) k_tcn_bn_bwd2(float* __restrict__ g, cons
     d[c] = BNP_SCALE(bnp, CT, c0 + c) * (d[c] - coef[c0 + c] - xh * coef[CT + c0 + c]);
   }
   dof_st_row<4>(gp, d);
-}
-
-// channel sums of the row-per-thread kernels: partial[h][nblk][64] -> sums[2][CT] (sum, second moment)
-__global__ void __launch_bounds__(256) k_tcn_sum_halves(const float* __restrict__ partial, int64_t nblk, int CT,
-                                                        float* __restrict__ sums) {
-  __shared__ float red[256];
-  const int v = blockIdx.x;            // 0 .. 2*CT-1 : [sum(CT) | second(CT)]
-  const int which = v / CT, ch = v - which * CT;
-  const int h = ch / TC, c = ch - h * TC;
-  const float* src = partial + (int64_t)h * nblk * 2 * TC + which * TC + c;
-  float acc = 0.0f;
-  for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += src[b * 2 * TC];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) sums[v] = red[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -880,7 +877,7 @@ int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res,
   A.xs_ch = xs_ch > 0 ? xs_ch : F;
   A.y2 = y2; A.bnp2 = bnp2; A.res = res; A.xs = xs; A.dsw = dsw; A.dsb = dsb; A.out = out; A.skip = skip;
   A.feat = feat; A.first = first; A.T = T; A.F = F; A.CT = CT; A.S = S; A.Sp = Sp;
-  DOF_LAUNCH(k_tcn_combine, ((unsigned)dof_tcn_row_blocks(T, S), (unsigned)(CT / TC)), (256), st, A);
+  DOF_LAUNCH(k_tcn_combine, (dof_cdiv(S * (CT / 4), 256), (unsigned)T), (256), st, A);
   return dof_check_launch("k_tcn_combine");
 }
 
@@ -891,10 +888,10 @@ int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, f
   TcnBnBwd1Args A;
   A.din = din; A.y = y; A.bnp = bnp; A.g = g; A.partial = partial; A.blk = blk; A.out_blk = out_blk; A.dfeat = dfeat;
   A.skip = skip; A.dskip = dskip; A.gres = gres; A.T = T; A.CT = CT; A.S = S; A.Sp = Sp;
-  const unsigned nb = (unsigned)dof_tcn_row_blocks(T, S);
-  DOF_LAUNCH(k_tcn_bn_bwd1, (nb, (unsigned)(CT / TC)), (256), st, A);
-  DOF_LAUNCH(k_tcn_sum_halves, ((unsigned)(2 * CT)), (256), st, (const float*)partial, (int64_t)nb, CT, sums);
-  return dof_check_launch("k_tcn_bn_bwd1");
+  const unsigned nbx = dof_cdiv(S, 256);
+  DOF_LAUNCH(k_tcn_bn_bwd1_w, (nbx, (unsigned)T), (256), st, A);
+  if (int rc = dof_check_launch("k_tcn_bn_bwd1_w")) return rc;
+  return dof_launch_sum_partials(partial, (int64_t)nbx * T, 2 * CT, sums, 0, st);
 }
 
 int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int CT, int64_t S,
