@@ -5,8 +5,9 @@
 
 One "step" = one pass of the hot path over one batch of synthetic windows, inputs resident in
 HBM: window gather from the frame table -> VaDE forward -> VadeLoss -> backward -> [RCCL
-all-reduce of the flat gradient] -> clip + Adam.  Workload = BASELINE config C2 (VaDE recurrent,
-14 body parts, window 25, k=10, latent 8, batch 1024 per GPU, main phase with distillation).
+all-reduce of the flat gradient] -> clip + Adam -- issued through the SAME stepper the product's
+fit loop uses (deepof_amd.training.VadeStepper.step: hipGraph replay per step).  Workload = BASELINE config C2
+(VaDE recurrent, 14 body parts, window 25, k=10, latent 8, batch 1024 per GPU, main phase with distillation).
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : the HBM-bound window-gather kernel measured live with HIP events on a full
                  materialisation of the C2 dataset (5,824 algorithmic bytes/window)
@@ -23,9 +24,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+FP32_PEAK_FLOPS = 157.3e12  # fp32 vector peak (= the f32-input MFMA rate; MI355X_MICROARCH.md)
 
 
 def synth_tables(n_frames, n_nodes, n_edges, seed):
@@ -58,32 +59,11 @@ def synth_tables_fast(n_frames, n_nodes, n_edges, seed, device):
     return tn.clamp_(-10, 10), te.clamp_(-10, 10)
 
 
-def init_params(eng, seed=0):
-    """Random-init weights of the reference architecture (PyTorch default inits; models_new.py)."""
-    g = torch.Generator().manual_seed(seed)
-    L = eng.L
-    for n in eng.names:
-        shape = eng.layout[n][2]
-        if "norm" in n and n.endswith("weight"):
-            v = torch.ones(shape)
-        elif "norm" in n and n.endswith("bias"):
-            v = torch.zeros(shape)
-        elif ".gru" in n:
-            hid = shape[0] // 3
-            v = (torch.rand(shape, generator=g) * 2 - 1) / np.sqrt(hid)
-        elif n.startswith("latent_space.gmm"):
-            v = torch.randn(shape, generator=g) * np.sqrt(2.0 / (shape[0] + shape[1]))
-        elif len(shape) >= 2:
-            fan_in = int(np.prod(shape[1:]))
-            v = (torch.rand(shape, generator=g) * 2 - 1) / np.sqrt(fan_in)
-        else:
-            v = (torch.rand(shape, generator=g) * 2 - 1) * 0.1
-        eng.view(n).copy_(v)
-
-
-def cpu_baseline(P, B, T, N, E, L, K, steps=3, warm=1):
+def cpu_baseline(P, B, T, N, E, L, K, steps=10, warm=3):
     """Oracle ('port' of the reference PyTorch-CPU path) timed on a bounded sample of the same workload:
-    same architecture and initial weights (state_dict P), same batch size, main phase with distillation."""
+    same architecture and initial weights (state_dict P), same batch size, main phase with distillation.
+    SURVEY 8(d): median of >= 10 steps after 3 warm-ups on the host's threads, plus a 1-thread figure (fewer steps:
+    one step takes several seconds there)."""
     from oracle import vade as OV
 
     torch.manual_seed(0)
@@ -96,28 +76,34 @@ def cpu_baseline(P, B, T, N, E, L, K, steps=3, warm=1):
     w = (w / w.mean()).clamp_max(3.0)
     cfg = OV.VadeLossCfg(K, False, lambda_distill=4.0, class_weight=w, teacher_marginal=pi)
     all_cores = torch.get_num_threads()
-    results = {}
-    # tiny-op eager PyTorch does not scale with threads: report the best of a few thread counts
-    for threads in sorted({min(8, all_cores), min(32, all_cores), all_cores}):
+
+    def timed(threads, n_warm, n_steps):
         torch.set_num_threads(threads)
         P_run = {k: v.clone() for k, v in P.items()}
         opt = OV.AdamState()
         times = []
-        for i in range(warm + steps):
+        for i in range(n_warm + n_steps):
             t0 = time.perf_counter()
             eps = torch.randn(B, L)
             eps_mc = torch.randn(32, B, L)
             OV.vade_train_step(P_run, opt, x, a, cfg, 1.0, 5e-4, 2e-4, eps, eps_mc, tau)
             dt = time.perf_counter() - t0
-            if i >= warm:
+            if i >= n_warm:
                 times.append(dt)
-        results[threads] = B / float(np.median(times))
+        return B / float(np.median(times))
+
+    # tiny-op eager PyTorch does not scale with threads (round 1 on this host class: 8 threads 351, 32 threads 247,
+    # all 128 threads 63 windows/s), so the multi-thread figure is taken at 8 threads
+    many = min(8, all_cores)
+    v_many = timed(many, warm, steps)
+    v_one = timed(1, 1, 3)
     torch.set_num_threads(all_cores)
-    best = max(results, key=results.get)
-    others = ", ".join(f"{t} threads: {v:.1f}" for t, v in sorted(results.items()))
-    return {"value": results[best], "unit": "windows/s", "cores": best, "kind": "port",
-            "sample": f"{steps} train steps of batch {B} after {warm} warm-up per thread count (oracle/vade.py, "
-                      f"torch CPU fp32, median; host has {all_cores} threads; windows/s by thread count: {others})"}
+    best, cores = (v_many, many) if v_many >= v_one else (v_one, 1)
+    return {"value": best, "unit": "windows/s", "cores": cores, "kind": "port",
+            "one_thread": v_one, "threads_8": v_many,
+            "sample": f"median of {steps} train steps of batch {B} after {warm} warm-ups on {many} threads "
+                      f"({v_many:.1f} windows/s) and of 3 steps after 1 warm-up on 1 thread ({v_one:.1f} windows/s); "
+                      f"oracle/vade.py, torch CPU fp32; the host has {all_cores} hardware threads"}
 
 
 def main():
@@ -127,9 +113,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--frames", type=int, default=600_000, help="frames per synthetic animal (2 animals per rank)")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-iters", type=int, default=20)
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the timed steps keep stepping for about this long (second, longer measurement)")
     ap.add_argument("--log-every", type=int, default=0, help="debug: print the loss terms every N steps (adds syncs)")
     args = ap.parse_args()
 
@@ -145,109 +133,77 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    if world > 1 or os.environ.get("DOF_BENCH_FORCE_PG") == "1":  # FORCE_PG: a 1-rank RCCL group (exercises the DP path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    from types import SimpleNamespace
+
     from deepof_amd import _capi
-    from deepof_amd.engine import create_vade_engine
+    from deepof_amd.config import CommonFitCfg, TurtleTeacherCfg, VaDECfg
+    from deepof_amd.dataset import WindowDataset, batch_starts
     from deepof_amd.graph import adjacency_from_graph, bodypart_graph
-    from parity_common import configure_phase
+    from deepof_amd.models import VaDE
+    from deepof_amd.schedules import WeightSchedule
+    from deepof_amd.stepping import DeviceSchedule
+    from deepof_amd.training import VadeStepper, _set_lrs
 
     nodes, edges = bodypart_graph([""])
     adj = adjacency_from_graph(nodes, edges)
     N, E = len(nodes), len(edges)
     B, T, L, K, S = args.batch, 25, 8, 10, 32
-    eng = create_vade_engine(B, T, adj, L, K, S, device=dev)
+    # ---- the product objects: model (reference initialisers, identical on every rank = DDP's broadcast), stepper
+    torch.manual_seed(0)
+    model = VaDE((T, N, 3), (T, E, 1), adj, L, K, encoder_type="recurrent", kmeans_loss=1.0, batch_size=B, device=dev)
+    eng = model._base
     lib = eng.lib
-    init_params(eng, seed=0)  # identical on every rank (DDP broadcast equivalent)
     initial_state = eng.state_dict() if rank == 0 else None
+    common = CommonFitCfg(model_name="vade", encoder_type="recurrent", batch_size=B, latent_dim=L, epochs=1,
+                          n_components=K, output_path=".")
+    stepper = VadeStepper(model, common, VaDECfg(), TurtleTeacherCfg(), use_graphs=False if args.no_graph else None)
 
-    # --- device-resident dataset: 2 animals per rank, concatenated frame tables + window start rows
+    # ---- device-resident dataset: 2 animals per rank, concatenated frame tables, stride-1 windows inside each
     n_animals, F = 2, args.frames
     tn, te = synth_tables_fast(n_animals * F, N, E, seed=rank, device=dev)
+    pre = SimpleNamespace(node_table=tn, edge_table=te, keys=[f"animal{i}" for i in range(n_animals)],
+                          video_off=np.arange(n_animals + 1, dtype=np.int64) * F)
+    ds = WindowDataset.from_device_tables(pre, T, 1, lib)
+    n_windows = len(ds)
     win_per_animal = F - T + 1
-    starts = torch.cat([torch.arange(win_per_animal, device=dev, dtype=torch.int64) + i * F for i in range(n_animals)])
-    n_windows = int(starts.numel())
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     tau_star = torch.softmax(torch.randn(n_windows, K, device=dev, generator=g) * 2.0, dim=-1)
-    pi = tau_star.mean(0).clamp_min(1e-8)
-    cw = pi.pow(-1.0)
-    cw = (cw / cw.mean()).clamp_max(3.0)
 
-    # main phase with distillation (reference defaults, training.py:592-719; lr after epoch 0: 5e-4 / 2e-4)
-    for seg in (_capi.SEG_ENCODER, _capi.SEG_DECODER, _capi.SEG_HEADS):
-        eng.set_lr(seg, 5e-4)
-    eng.set_lr(_capi.SEG_GMM, 2e-4)
-    configure_phase(eng, K, False, 1.0, None, 4.0)
-    eng.set_teacher(cw, pi)
+    # ---- main phase with distillation, as fit_VADE configures it (training.py:1643-1755 of the reference): lr after
+    # epoch 0 = 5e-4 / 2e-4, KL weight tf_sigmoid warm-up 5 epochs -> 1, lambda 4 held 10 epochs (defaults)
+    model.set_pretrain_mode(False)
+    model.train()
+    stepper.set_mode("main")
+    nb = n_windows // B
+    vcfg, tcfg = stepper.vade, stepper.teacher
+    stepper.kl_scheduler = DeviceSchedule(WeightSchedule(nb, mode=vcfg.kl_annealing_mode, warmup_epochs=vcfg.kl_warmup,
+                                                         max_weight=vcfg.kl_max_weight, cooldown_epochs=vcfg.kl_cooldown,
+                                                         end_weight=vcfg.kl_end_weight), dev)
+    stepper.set_teacher(tau_star, tcfg.lambda_distill, DeviceSchedule(
+        WeightSchedule(nb, mode=vcfg.kl_annealing_mode, warmup_epochs=0, at_max_epochs=tcfg.lambda_decay_start,
+                       max_weight=tcfg.lambda_distill, cooldown_epochs=tcfg.lambda_cooldown,
+                       end_weight=tcfg.lambda_end_weight), dev))
+    eng.reset_optimizer()
+    _set_lrs(eng, 5e-4, 2e-4)
     eng.push_hyper()
-
-    x = torch.empty(B, T, N, 3, device=dev)
-    a = torch.empty(B, T, E, 1, device=dev)
-    eps = torch.empty(B, L, device=dev)
-    eps_mc = torch.empty(S, B, L, device=dev)
-    tau = torch.empty(B, K, device=dev)
-    batch_rows = torch.empty(B, dtype=torch.int64, device=dev)
-    n_batches = n_windows // B
-    perm = torch.randperm(n_batches, generator=torch.Generator().manual_seed(0)).tolist()
-
-    def stream():
-        return torch.cuda.current_stream().cuda_stream
-
-    def step_body():
-        # batch = contiguous block of windows (reference loader: block shuffle of batch starts, dataset.py:589-634)
-        _capi.check(lib, lib.dof_window_gather(tn.data_ptr(), te.data_ptr(), batch_rows.data_ptr(), B, T, N, E,
-                                               x.data_ptr(), a.data_ptr(), stream()))
-        eps.normal_()
-        eps_mc.normal_()
-        eng.loss_grads(x, a, eps, eps_mc, tau, pretrain=False)
-
-    def opt_body():
-        eng.optimizer_step()
-
-    graph_a = graph_b = None
-    if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        eng.advance_adam()
-        eng.push_hyper()
-        with torch.cuda.stream(side):
-            batch_rows.copy_(starts[:B])
-            tau.copy_(tau_star[:B])
-            step_body()
-            opt_body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        eng.reset_optimizer()
-        graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_a):
-            step_body()
-        with torch.cuda.graph(graph_b):
-            opt_body()
+    stepper.begin_logs()
+    # batches in the reference loader's order: seeded block shuffle of the batch starts (dataset.py:589-597), full batches
+    starts = [int(v) for v in batch_starts(n_windows, B, 1, 0, True) if v + B <= n_windows]
 
     def one_step(i):
-        b0 = perm[i % n_batches] * B
-        batch_rows.copy_(starts[b0:b0 + B])
-        tau.copy_(tau_star[b0:b0 + B])
-        eng.advance_adam()
-        eng.push_hyper()
-        if graph_a is not None:
-            graph_a.replay()
-        else:
-            step_body()
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
-            eng.grads.mul_(1.0 / world)
-        if graph_b is not None:
-            graph_b.replay()
-        else:
-            opt_body()
+        s0 = starts[i % len(starts)]
+        stepper.step(ds, s0, s0 + B, True, True)   # gather + forward + loss + backward [+ all-reduce] + clip/Adam
 
     def barrier():
         if world > 1:
@@ -255,16 +211,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def show(tag, i):
+        if args.log_every and rank == 0 and i % args.log_every == 0:
+            print(tag, i, {k: round(v, 4) for k, v in eng.read_logs().items()}, file=sys.stderr, flush=True)
+
     for i in range(args.warmup):
         one_step(i)
-        if args.log_every and rank == 0 and i % args.log_every == 0:
-            print("warmup", i, {k: round(v, 4) for k, v in eng.read_logs().items()}, file=sys.stderr, flush=True)
+        show("warmup", i)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
-        if args.log_every and rank == 0 and i % args.log_every == 0:
-            print("step", i, {k: round(v, 4) for k, v in eng.read_logs().items()}, file=sys.stderr, flush=True)
+        show("step", i)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -278,6 +236,30 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
 
+    # ---- a second, longer measurement of the same loop (the contract's K steps last only tens of milliseconds)
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_more = max(args.steps, int(args.sustain_seconds / max(ms_per_step * 1e-3, 1e-6)))
+        if world > 1:
+            import torch.distributed as dist
+            nm = torch.tensor([n_more], device=dev)
+            dist.broadcast(nm, src=0)
+            n_more = int(nm.item())
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n_more):
+            one_step(args.warmup + args.steps + i)
+        barrier()
+        el2 = time.perf_counter() - t1
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([el2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        sustained = {"steps": n_more, "ms_per_step": 1e3 * el2 / n_more, "value": world * B * n_more / el2}
+
+    # algorithmic work of one step (7.6 MFLOP forward per window, training = 3 x) against the fp32 vector peak
+    flops_per_step = 3.0 * 7.6e6 * B
     out = {
         "metric": "pose-windows/sec (train step) VaDE 14-bp win=25", "value": value, "unit": "windows/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -285,14 +267,27 @@ def main():
         "config": {"workload": "C2: VaDE GM-VAE recurrent, 14 body parts (N=14,E=14), window=25, k=10, latent=8, "
                                f"batch={B}/GPU, main phase (MC-KL S=32 + distillation), fp32",
                    "global_batch": world * B, "window": T, "parallelism": f"dp{world}",
-                   "hip_graph": graph_a is not None, "final_total_loss": logs["total_loss"]},
+                   "hip_graph": stepper.graphs.enabled, "graph_replays": stepper.graphs.replays,
+                   "path": "deepof_amd.training.VadeStepper.step (the fit loop's step)",
+                   "final_total_loss": logs["total_loss"]},
+        "sustained": sustained,
+        "roofline_step": {"flop_frac": flops_per_step / (ms_per_step * 1e-3) / FP32_PEAK_FLOPS,
+                          "achieved_tflops": flops_per_step / (ms_per_step * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_FLOPS / 1e12,
+                          "algorithmic_flops_per_step": flops_per_step, "hbm_frac": None, "hbm_bytes_per_step": None},
     }
+    step_pmc = os.path.join(ROOT, "profiles", "r02_step_pmc.json")
+    if os.path.exists(step_pmc) and B == 1024:
+        hb = json.load(open(step_pmc))["hbm_bytes_per_step"]
+        out["roofline_step"].update(hbm_bytes_per_step=hb, hbm_frac=hb / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9))
 
     if rank == 0:
         # ---- roofline of the HBM-bound window-gather kernel: full materialisation of this rank's dataset
         nw = n_windows
         xg = torch.empty(nw, T, N, 3, device=dev)
         ag = torch.empty(nw, T, E, 1, device=dev)
+
+        def stream():
+            return torch.cuda.current_stream().cuda_stream
 
         def gather_all():
             for i in range(n_animals):

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -36,6 +36,14 @@ class Augment(C.Structure):
     _fields_ = [("start", C.c_void_p), ("n_rot", C.c_int32), ("rot_pivot", C.c_int32 * 8),
                 ("rot_nodes", C.c_uint64 * 8), ("theta", C.c_void_p), ("interp_t0", C.c_void_p),
                 ("interp_len", C.c_void_p), ("noise", C.c_void_p)]
+
+
+class SchedItem(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("cursor", C.c_void_p), ("len", C.c_int32), ("hyper_index", C.c_int32),
+                ("advance", C.c_int32), ("scale", C.c_float)]
+
+
+SCHED_MAX_ITEMS = 4
 
 
 class TurtleDims(C.Structure):
@@ -88,7 +96,8 @@ SIGNATURES = {
     "dof_vqvae_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vqvae_forward": (C.c_int, [_P] * 11),
     "dof_vqvae_loss_grads": (C.c_int, [_P] * 9),
-    "dof_optimizer_step": (C.c_int, [_P] * 7),
+    "dof_optimizer_step": (C.c_int, [_P] * 7 + [C.c_float, _P]),
+    "dof_schedule_apply": (C.c_int, [_P, C.POINTER(SchedItem), _I32, _P]),
     "dof_turtle_param_total": (_I64, [C.POINTER(TurtleDims)]),
     "dof_turtle_param_offset": (_I64, [C.POINTER(TurtleDims), _I32, _I32, _I32]),
     "dof_turtle_workspace_bytes": (_I64, [C.POINTER(TurtleDims)]),

@@ -158,6 +158,10 @@ _SIMS = ("cosine", "dot", "euclidean", "edit")
 _LOSSES = ("nce", "dcl", "dlc", "fc", "hard_dcl")  # the reference accepts the "dlc" typo; both spellings work here (Q13)
 
 
+SUPPORTED_LATENT_DIMS = (4, 6, 8)
+MAX_CONTRASTIVE_NODES = 64
+
+
 def check_model_inputs(preprocessed_object, adjacency_matrix, meta_info, encoder_type, batch_size, latent_dim, epochs,
                        output_path, model_name, kl_annealing_mode, contrastive_similarity_function,
                        contrastive_loss_function, pretrained):
@@ -175,3 +179,11 @@ def check_model_inputs(preprocessed_object, adjacency_matrix, meta_info, encoder
     for name, v in (("batch_size", batch_size), ("latent_dim", latent_dim), ("epochs", epochs)):
         assert pretrained or (isinstance(v, (int,)) and v > 0), f"{name} must be a positive integer"
     assert pretrained or isinstance(output_path, str), "output_path must be a string"
+    if not pretrained:
+        # limits of this build's kernels, reported before any data is uploaded (the reference accepts any value)
+        if int(latent_dim) not in SUPPORTED_LATENT_DIMS:
+            raise NotImplementedError(f"latent_dim={latent_dim}: libdeepof_hip has plans for latent_dim in "
+                                      f"{SUPPORTED_LATENT_DIMS}")
+        if str(model_name).lower() == "contrastive" and adjacency_matrix.shape[0] > MAX_CONTRASTIVE_NODES:
+            raise NotImplementedError(f"contrastive model: {adjacency_matrix.shape[0]} nodes, the view kernel "
+                                      f"handles at most {MAX_CONTRASTIVE_NODES}")

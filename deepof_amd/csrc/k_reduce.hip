@@ -205,11 +205,27 @@ __global__ void __launch_bounds__(256) k_sum_partials_multi(DofSumJobs J, int ac
   if (threadIdx.x == 0) J.out[j][v] = accumulate ? J.out[j][v] + red[0] : red[0];
 }
 
+// One thread per optimiser segment: a segment that receives gradients this step (hyper[active] != 0) advances its
+// device-side step counter; the Adam bias corrections 1 - beta^t of every segment (t >= 1) go to bc[2 * seg + {0, 1}]
+// for the k_clip_adam launch that follows on the same stream.  Keeping t on the device makes a captured step
+// replayable without any host-written per-step value (torch.optim.Adam keeps `step` per parameter the same way).
+__global__ void k_adam_tick(int* __restrict__ opt_state, const float* __restrict__ hyper,
+                            const DofAdamSeg* __restrict__ segs, int nseg, float* __restrict__ bc) {
+  const int k = threadIdx.x;
+  if (k >= nseg) return;
+  int t = opt_state[k];
+  if (hyper[segs[k].active_index] != 0.0f) opt_state[k] = ++t;
+  if (t < 1) t = 1;
+  bc[2 * k] = (float)(1.0 - pow(0.9, (double)t));
+  bc[2 * k + 1] = (float)(1.0 - pow(0.999, (double)t));
+}
+
 __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ params, const float* __restrict__ grads,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ hyper,
                                                    const DofAdamSeg* __restrict__ segs, int nseg, int64_t total,
-                                                   int clip_index, const float* __restrict__ mask) {
+                                                   int clip_index, const float* __restrict__ mask,
+                                                   const float* __restrict__ bc, float grad_scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   if (mask[i] == 0.0f) return;  // parameter never receives a gradient in the reference (grad None): untouched
@@ -221,7 +237,7 @@ __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ params, c
   if (hyper[S.active_index] == 0.0f) return;  // grad is None in the reference -> parameter skipped
   const float clip = hyper[clip_index];
   const float wd = hyper[clip_index + 1];
-  float g = grads[i];
+  float g = grads[i] * grad_scale;  // data parallel: the all-reduced SUM times 1 / world = DDP's averaged gradient
   if (clip > 0.0f) g = fminf(fmaxf(g, -clip), clip);
   float p = params[i];
   if (wd != 0.0f) g = fmaf(wd, p, g);
@@ -231,9 +247,21 @@ __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ params, c
   m[i] = mi;
   v[i] = vi;
   const float lr = hyper[S.lr_index];
-  const float bc1 = hyper[S.bc_index], bc2 = hyper[S.bc_index + 1];
+  const float bc1 = bc[2 * sg], bc2 = bc[2 * sg + 1];
   const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
   params[i] = p - (lr / bc1) * (mi / denom);
+}
+
+// hyper[item.hyper_index] = scale * table[min(cursor, len - 1)]; cursor advances when item.advance (one thread per
+// item, every item owns its cursor).  See dof_schedule_apply in deepof_hip.h.
+__global__ void k_schedule_apply(float* __restrict__ hyper, DofSchedItems items) {
+  const int k = threadIdx.x;
+  if (k >= items.n) return;
+  const DofSchedItem it = items.item[k];
+  int c = *it.cursor;
+  const int at = c < it.len - 1 ? c : it.len - 1;
+  hyper[it.hyper_index] = it.scale * it.table[at < 0 ? 0 : at];
+  if (it.advance) *it.cursor = c + 1;
 }
 
 }  // namespace
@@ -267,8 +295,14 @@ int dof_launch_sum_partials_multi(const DofSumJobs& jobs, int accumulate, hipStr
 
 int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,
                          const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, const float* mask,
-                         hipStream_t st) {
+                         int* opt_state, float* bc_scratch, float grad_scale, hipStream_t st) {
+  DOF_LAUNCH(k_adam_tick, (1), (64), st, opt_state, hyper, segs_dev, nseg, bc_scratch);
   DOF_LAUNCH(k_clip_adam, (dof_cdiv(total, 256)), (256), st, params, grads, m, v, hyper, segs_dev, nseg, total,
-             clip_index, mask);
+             clip_index, mask, (const float*)bc_scratch, grad_scale);
   return dof_check_launch("k_clip_adam");
+}
+
+int dof_launch_schedule_apply(float* hyper, const DofSchedItems& items, hipStream_t st) {
+  DOF_LAUNCH(k_schedule_apply, (1), (64), st, hyper, items);
+  return dof_check_launch("k_schedule_apply");
 }

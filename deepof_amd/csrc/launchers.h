@@ -2,6 +2,7 @@
 // orchestration (vade.hip).  Not part of the public C ABI (that is include/deepof_hip.h).
 #pragma once
 #include "dof_rt.h"
+#include "deepof_hip.h"
 
 struct DofGruW {  // both directions of one torch.nn.GRU layer (weight_ih_l0[_reverse], ...)
   const float *wih0, *whh0, *bih0, *bhh0;
@@ -144,12 +145,17 @@ int dof_launch_sum_partials_multi(const DofSumJobs& jobs, int accumulate, hipStr
 struct DofAdamSeg {  // one contiguous parameter range with its own lr / step count / freeze flag
   int64_t lo, hi;
   int lr_index;   // index into hyper[] of the learning rate
-  int bc_index;   // index into hyper[] of (1-b1^t, 1-b2^t) pair
+  int bc_index;   // (unused since ABI 9: the bias corrections come from the device-side step counters)
   int active_index;  // index into hyper[] of the 0/1 "has gradient" flag
 };
 int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,
                          const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, const float* mask,
-                         hipStream_t st);
+                         int* opt_state, float* bc_scratch, float grad_scale, hipStream_t st);
+struct DofSchedItems {  // by-value kernel argument of k_schedule_apply
+  int n;
+  DofSchedItem item[DOF_SCHED_MAX_ITEMS];
+};
+int dof_launch_schedule_apply(float* hyper, const DofSchedItems& items, hipStream_t st);
 
 // ---- k_graph_latent.hip ----------------------------------------------------------------------
 struct DofTriplets {  // CSR of (partner row m, other-stream element o, coefficient) grouped by a key row

@@ -150,7 +150,7 @@ struct DofVadePlan {
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
-  int64_t partials, segs_tab, mask_tab;
+  int64_t partials, segs_tab, mask_tab, bc_tab;
   int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
   // TCN family (encoder: all kinds; decoder: kinds 0 / 1)
@@ -640,6 +640,7 @@ void take_tables(DofVadePlan* p, Carver& cv) {
   }
   p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
   p->mask_tab = cv.take(p->param_total);
+  p->bc_tab = cv.take(2 * DOF_SEG_COUNT);
   p->ws_floats = cv.cur;  // the partial-tile region is appended by finish_workspace_layout()
 }
 
@@ -1862,18 +1863,38 @@ extern "C" int dof_vqvae_loss_grads(DofVadePlan* p, const float* params, const f
 }
 
 extern "C" int dof_optimizer_step(DofVadePlan* p, float* params, const float* grads, float* adam_m, float* adam_v,
-                                  const float* hyper, void* stream) {
+                                  const float* hyper, int32_t* opt_state, float grad_scale, void* stream) {
   if (!p || !p->ws) {
     dof_set_error("dof_optimizer_step: plan not bound to a workspace");
     return DOF_ERR_STATE;
   }
-  if (!params || !grads || !adam_m || !adam_v || !hyper) {
+  if (!params || !grads || !adam_m || !adam_v || !hyper || !opt_state) {
     dof_set_error("dof_optimizer_step: null argument");
     return DOF_ERR_ARG;
   }
   const DofAdamSeg* segs = reinterpret_cast<const DofAdamSeg*>(p->ws + p->segs_tab);
   return dof_launch_clip_adam(params, grads, adam_m, adam_v, hyper, segs, DOF_SEG_COUNT, p->param_total, DOF_H_CLIP,
-                              p->ws + p->mask_tab, (hipStream_t)stream);
+                              p->ws + p->mask_tab, opt_state, p->ws + p->bc_tab, grad_scale, (hipStream_t)stream);
+}
+
+extern "C" int dof_schedule_apply(float* hyper, const DofSchedItem* items, int32_t n_items, void* stream) {
+  if (!hyper || (n_items > 0 && !items) || n_items < 0 || n_items > DOF_SCHED_MAX_ITEMS) {
+    dof_set_error("dof_schedule_apply: bad arguments (n_items %d, at most %d)", n_items, DOF_SCHED_MAX_ITEMS);
+    return DOF_ERR_ARG;
+  }
+  DofSchedItems its;
+  memset(&its, 0, sizeof(its));
+  its.n = n_items;
+  for (int i = 0; i < n_items; ++i) {
+    if (!items[i].table || !items[i].cursor || items[i].len <= 0 || items[i].hyper_index < 0 ||
+        items[i].hyper_index >= DOF_H_COUNT) {
+      dof_set_error("dof_schedule_apply: item %d has a null table / cursor, no entries or a bad hyper index", i);
+      return DOF_ERR_ARG;
+    }
+    its.item[i] = items[i];
+  }
+  if (n_items == 0) return DOF_OK;
+  return dof_launch_schedule_apply(hyper, its, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -205,31 +205,45 @@ class WindowDataset:
         return self.length
 
     # ---- batches ---------------------------------------------------------------------------
-    def fetch(self, s: int, e: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Windows [s, e) as contiguous device tensors x (b,W,N,3), a (b,W,E,1)."""
+    def fetch(self, s: int, e: int, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+              ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Windows [s, e) as contiguous device tensors x (b,W,N,3), a (b,W,E,1).  ``out`` = (x, a) buffers of that
+        shape to fill in place (the static batch buffers of a captured step)."""
         if self.x is not None:
-            return self.x[s:e], self.a[s:e]
+            if out is None:
+                return self.x[s:e], self.a[s:e]
+            out[0].copy_(self.x[s:e])
+            out[1].copy_(self.a[s:e])
+            return out
         W, N, _ = self.x_shape
         E = self.a_shape[1]
         b = e - s
-        x = torch.empty(b, W, N, 3, device=self.device)
-        a = torch.empty(b, W, E, 1, device=self.device)
+        if out is None:
+            out = (torch.empty(b, W, N, 3, device=self.device), torch.empty(b, W, E, 1, device=self.device))
+        x, a = out
+        assert tuple(x.shape) == (b, W, N, 3) and tuple(a.shape) == (b, W, E, 1) and x.is_contiguous() and a.is_contiguous()
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-        rows = self.row_start[s:e].contiguous()
+        rows = self.row_start[s:e]  # a slice of the contiguous start-row list: no copy
         _capi.check(self._lib, self._lib.dof_window_gather(self.node_table.data_ptr(), self.edge_table.data_ptr(),
                                                            rows.data_ptr(), b, W, N, E, x.data_ptr(), a.data_ptr(),
                                                            stream), "dof_window_gather")
         return x, a
 
-    def iter_batches(self, batch_size: int, shuffle: bool, seed: Optional[int], world_size: int = 1, rank: int = 0,
-                     drop_last: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, np.ndarray]]:
-        """One epoch: yields (x, a, idx[int64 device], video_idx[int32 host]) like the reference loader."""
+    def iter_ranges(self, batch_size: int, shuffle: bool, seed: Optional[int], world_size: int = 1, rank: int = 0,
+                    drop_last: bool = False) -> Iterator[Tuple[int, int]]:
+        """One epoch of this rank's batches as window ranges [s, e) in the reference loader's order (every batch is a
+        contiguous run of windows: the loader shuffles batch STARTS only, dataset.py:589-634)."""
         self._epoch += 1
         boot = bool(getattr(self, "bootstrap_training", False)) and shuffle
         for s in batch_starts(self.length, batch_size, self._epoch, seed, shuffle, world_size, rank, drop_last,
                               self.video_idx, boot, getattr(self, "bootstrap_block_len", 250)):
             s = int(s)
-            e = min(s + batch_size, self.length)
+            yield s, min(s + batch_size, self.length)
+
+    def iter_batches(self, batch_size: int, shuffle: bool, seed: Optional[int], world_size: int = 1, rank: int = 0,
+                     drop_last: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, np.ndarray]]:
+        """One epoch: yields (x, a, idx[int64 device], video_idx[int32 host]) like the reference loader."""
+        for s, e in self.iter_ranges(batch_size, shuffle, seed, world_size, rank, drop_last):
             x, a = self.fetch(s, e)
             idx = torch.arange(s, e, device=self.device, dtype=torch.int64)
             yield x, a, idx, self.video_idx[s:e]

@@ -105,7 +105,7 @@ class VadeEngine:
         if shared is not None:
             assert shared.params.numel() == total and shared.K == self.K and shared.L == self.L
             for attr in ("params", "grads", "adam_m", "adam_v", "prior", "hyper_host", "hyper", "logs", "teacher",
-                         "adam_t", "num_batches_tracked"):
+                         "opt_state", "num_batches_tracked"):
                 setattr(self, attr, getattr(shared, attr))
             return
         self.params = torch.zeros(total, **f32)
@@ -113,13 +113,13 @@ class VadeEngine:
         self.adam_m = torch.zeros(total, **f32)
         self.adam_v = torch.zeros(total, **f32)
         self.prior = torch.full((self.K,), 1.0 / self.K, **f32)
-        self.hyper_host = torch.zeros(_capi.H_COUNT, dtype=torch.float32)
-        if self.device.type == "cuda":
-            self.hyper_host = self.hyper_host.pin_memory()
+        self.hyper_host = torch.zeros(_capi.H_COUNT, dtype=torch.float32)  # host mirror; push_hyper() snapshots it
         self.hyper = torch.zeros(_capi.H_COUNT, **f32)
         self.logs = torch.zeros(_capi.LOG_COUNT, **f32)
         self.teacher = torch.zeros(2 * self.K, **f32)
-        self.adam_t = [0] * _capi.SEG_COUNT
+        # Adam step count per optimiser segment, on the device: dof_optimizer_step advances it and derives the bias
+        # corrections from it, so a captured step needs no host-written per-step value
+        self.opt_state = torch.zeros(_capi.SEG_COUNT, dtype=torch.int32, device=self.device)
         self.set_hyper(logvar_lo=-8.0, logvar_hi=8.0, clip=0.75, wd=0.0, l1_act=0.1, distill_T=0.5)
         if "distill_head.fc.weight" in self.layout:  # DiscriminativeHead = nn.Linear(L, K) default init
             bound = 1.0 / math.sqrt(self.L)
@@ -129,8 +129,6 @@ class VadeEngine:
                 v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * bound)
         for s in range(_capi.SEG_COUNT):
             self.hyper_host[_capi.H_ACTIVE0 + s] = 1.0
-            self.hyper_host[_capi.H_BC0 + 2 * s] = 1.0 - 0.9      # t = 1 until advance_adam() is called
-            self.hyper_host[_capi.H_BC0 + 2 * s + 1] = 1.0 - 0.999
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -224,11 +222,49 @@ class VadeEngine:
     def reset_optimizer(self):
         self.adam_m.zero_()
         self.adam_v.zero_()
-        for i in range(_capi.SEG_COUNT):
-            self.adam_t[i] = 0
+        self.opt_state.zero_()
 
     def push_hyper(self):
-        self.hyper.copy_(self.hyper_host, non_blocking=True)
+        """Enqueue hyper_host -> hyper.  The copy reads an immutable pinned snapshot taken NOW (the caching host
+        allocator keeps it alive until the copy has run), so later set_hyper() calls cannot leak into steps that
+        are already enqueued.  Per-step values (KL weight, distillation lambda, Adam bias corrections) do not go
+        through here at all in the fit loops: schedule_apply() / dof_optimizer_step produce them on the device."""
+        if self.device.type == "cuda":
+            self.hyper.copy_(self.hyper_host.pin_memory(), non_blocking=True)
+        else:
+            self.hyper.copy_(self.hyper_host)
+
+    def schedule_apply(self, items):
+        """dof_schedule_apply: items = [(DeviceSchedule, hyper index, advance, scale), ...] evaluated on the device at
+        this point of the stream (graph-capturable)."""
+        arr = (_capi.SchedItem * max(1, len(items)))()
+        for i, (sched, index, advance, scale) in enumerate(items):
+            arr[i] = _capi.SchedItem(sched.table.data_ptr(), sched.cursor.data_ptr(), int(sched.table.numel()), int(index),
+                                     1 if advance else 0, float(scale))
+        _capi.check(self.lib, self.lib.dof_schedule_apply(self.hyper.data_ptr(), arr, len(items), self._stream()),
+                    "dof_schedule_apply")
+
+    def configure_vade_phase(self, pretrain: bool, klw: float, tau: Optional[torch.Tensor] = None,
+                             lambda_distill: float = 0.0, extra: Optional[dict] = None):
+        """The reference's default VadeLoss configuration of one phase (training.py:640-668 signature defaults,
+        losses.py:426-443 set_mode) with a fixed KL weight; ``tau`` (n, K) switches the distillation term on with the
+        inverse-marginal class weights of losses.py:460-491 (beta 1, cap 3).  Pushes the values to the device."""
+        K = self.K
+        self.set_hyper(klw=klw, km_latent=1.0, km_loss=1.0 if pretrain else 0.0,
+                       repel_w=0.5 if pretrain else 0.0, repel_ls=0.5 if pretrain else 1.0,
+                       nonempty_w=0.02, nonempty_floor=max(1e-4, 0.05 / K), nonempty_p=2.0,
+                       l1_act=0.1, distill_T=0.5, conf_w=0.0, conf_thr=0.3, lambda_distill=lambda_distill,
+                       tf_w=0.0, cat_w=0.0, temporal_w=0.0, scatter_w=0.0, scatter_beta=1.0)
+        if extra:
+            self.set_hyper(**extra)
+        if tau is not None:
+            pi = tau.mean(dim=0).clamp_min(1e-8)
+            w = pi.pow(-1.0)
+            w = (w / w.mean()).clamp_max(3.0)
+            self.set_teacher(w, pi)
+        else:
+            self.set_teacher(None, None)
+        self.push_hyper()
 
     def set_teacher(self, class_weight: Optional[torch.Tensor], marginal: Optional[torch.Tensor]):
         if class_weight is None:
@@ -267,8 +303,9 @@ class VadeEngine:
                 self._count_bn("decoder.", 1)
         return out
 
-    def loss_grads(self, x, a, eps, eps_mc=None, tau=None, pretrain: bool = True):
-        """Forward + VadeLoss + backward; fills self.grads and self.logs (device)."""
+    def loss_grads(self, x, a, eps, eps_mc=None, tau=None, pretrain: bool = True, count: bool = True):
+        """Forward + VadeLoss + backward; fills self.grads and self.logs (device).  count=False leaves the host-side
+        BatchNorm step counters alone (a graph replay does not run this Python, its caller counts instead)."""
         self._chk_batch(x, a)
         assert tuple(eps.shape) == (self.B, self.L) and eps.is_contiguous()
         if not pretrain:
@@ -281,7 +318,8 @@ class VadeEngine:
             self.teacher.data_ptr() if self.hyper_host[_capi.H_HAS_TEACHER] != 0 else None,
             self.hyper.data_ptr(), 1 if pretrain else 0, self.grads.data_ptr(), self.logs.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_vade_loss_grads")
-        self._count_bn("", 1)
+        if count:
+            self._count_bn("", 1)
 
     # ------------------------------------------------------------------ VQ-VAE
     def vq_forward(self, x, a, want_loc: bool = True, want_soft: bool = True) -> Dict[str, torch.Tensor]:
@@ -303,7 +341,7 @@ class VadeEngine:
         _capi.check(self.lib, rc, "dof_vqvae_forward")
         return out
 
-    def vq_loss_grads(self, x, a, tau: Optional[torch.Tensor] = None):
+    def vq_loss_grads(self, x, a, tau: Optional[torch.Tensor] = None, count: bool = True):
         """step_vqvae_distill + backward; fills self.grads / self.logs.  tau (B,K): teacher targets of the batch -> the
         distillation head term with hyper lambda_distill / distill_T / conf_w / conf_thr."""
         self._chk_batch(x, a)
@@ -313,6 +351,10 @@ class VadeEngine:
                                            None if tau is None else tau.data_ptr(), self.hyper.data_ptr(),
                                            self.grads.data_ptr(), self.logs.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_vqvae_loss_grads")
+        if count:
+            self.count_vq_step()
+
+    def count_vq_step(self):
         self._count_bn("encoder.", 1)
         self._count_bn("decoder.", 2)   # the decoder runs on the quantised and on the raw latents
 
@@ -323,28 +365,30 @@ class VadeEngine:
                 "distill_loss": v[7]}
 
     # ------------------------------------------------------------------ contrastive
-    def contrastive_encode(self, x, a, train: bool = False) -> torch.Tensor:
-        """ContrastivePT.forward on one view (half windows): (B, L) embeddings."""
+    def contrastive_encode(self, x, a, train: bool = False, out: Optional[torch.Tensor] = None,
+                           count: bool = True) -> torch.Tensor:
+        """ContrastivePT.forward on one view (half windows): (B, L) embeddings (into ``out`` when given)."""
         self._chk_batch(x, a)
-        z = torch.empty(self.B, self.L, dtype=torch.float32, device=self.device)
+        z = out if out is not None else torch.empty(self.B, self.L, dtype=torch.float32, device=self.device)
         rc = self.lib.dof_contrastive_encode(self.plan, self.params.data_ptr(), x.data_ptr(), a.data_ptr(),
                                              1 if train else 0, z.data_ptr(), self._stream())
         _capi.check(self.lib, rc, "dof_contrastive_encode")
-        if train:
+        if train and count:
             self._count_bn("", 1)
         return z
 
     def contrastive_loss(self, z, z_aug, similarity="cosine", loss_fn="nce", temperature=0.1, tau=0.1, beta=0.1,
-                         want_grads: bool = True, teacher_tau: Optional[torch.Tensor] = None):
+                         want_grads: bool = True, teacher_tau: Optional[torch.Tensor] = None, out=None):
         """Normalise + pairwise loss [+ distillation head on the normalised central embeddings when teacher_tau (B,K)
-        is given]; fills self.logs, returns (dz, dz_aug) or (None, None)."""
+        is given]; fills self.logs, returns (dz, dz_aug) (the pair ``out`` when given) or (None, None)."""
         if loss_fn not in _capi.CONTRASTIVE_LOSSES:
             raise NotImplementedError(f"contrastive loss {loss_fn!r} is not built (available: "
                                       f"{sorted(_capi.CONTRASTIVE_LOSSES)})")
         assert tuple(z.shape) == (self.B, self.L) and tuple(z_aug.shape) == (self.B, self.L)
         assert z.is_contiguous() and z_aug.is_contiguous()
-        dz = torch.empty_like(z) if want_grads else None
-        dza = torch.empty_like(z) if want_grads else None
+        dz, dza = out if (want_grads and out is not None) else (None, None)
+        if want_grads and dz is None:
+            dz, dza = torch.empty_like(z), torch.empty_like(z)
         rc = self.lib.dof_contrastive_loss(self.plan, z.data_ptr(), z_aug.data_ptr(), _capi.SIMILARITIES[similarity],
                                            _capi.CONTRASTIVE_LOSSES[loss_fn], float(temperature), float(tau),
                                            float(beta), self.params.data_ptr(),
@@ -365,19 +409,12 @@ class VadeEngine:
         return {"total_loss": v[0], "pos_similarity": v[_capi.LOG_POS_SIM], "neg_similarity": v[_capi.LOG_NEG_SIM],
                 "distill_loss": v[7], "seperability": 0.0}
 
-    def advance_adam(self):
-        """Bump the per-segment Adam step counters (bias corrections live in hyper[])."""
-        for s in range(_capi.SEG_COUNT):
-            if self.hyper_host[_capi.H_ACTIVE0 + s] != 0:
-                self.adam_t[s] += 1
-            t = max(self.adam_t[s], 1)
-            self.hyper_host[_capi.H_BC0 + 2 * s] = 1.0 - 0.9 ** t
-            self.hyper_host[_capi.H_BC0 + 2 * s + 1] = 1.0 - 0.999 ** t
-
-    def optimizer_step(self):
+    def optimizer_step(self, grad_scale: float = 1.0):
+        """clip + Adam on the flat buffer; advances the device-side step counters.  grad_scale = 1 / world after an
+        all-reduce SUM (the averaging DDP does)."""
         rc = self.lib.dof_optimizer_step(self.plan, self.params.data_ptr(), self.grads.data_ptr(),
                                          self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.hyper.data_ptr(),
-                                         self._stream())
+                                         self.opt_state.data_ptr(), float(grad_scale), self._stream())
         _capi.check(self.lib, rc, "dof_optimizer_step")
 
     def read_logs(self) -> Dict[str, float]:
@@ -399,17 +436,22 @@ def create_vade_engine(batch, window, adjacency, latent_dim, n_clusters, mc_samp
     return VadeEngine(lib, dev, batch, window, adjacency, latent_dim, n_clusters, mc_samples, graph_ops, shared, kind)
 
 
-def contrastive_views(lib, x_full: torch.Tensor, edge_index: torch.Tensor, aug: Optional[dict] = None, stream=0):
+def contrastive_views(lib, x_full: torch.Tensor, edge_index: torch.Tensor, aug: Optional[dict] = None, stream=0,
+                      out=None):
     """dof_contrastive_views: one (x, a) view of every full window.  ``aug`` = None gives the central view;
     otherwise a dict with the resolved draws (start, rot_pivot, rot_nodes, theta, interp_t0, interp_len, noise;
-    tensors on x_full's device, rot_pivot / rot_nodes host lists)."""
+    tensors on x_full's device, rot_pivot / rot_nodes host lists).  ``out`` = (x, a) buffers to fill."""
     B, Tf, N, _ = x_full.shape
     E = edge_index.shape[0]
     assert x_full.is_contiguous() and x_full.dtype == torch.float32
     assert edge_index.dtype == torch.int32 and edge_index.is_contiguous() and edge_index.device == x_full.device
     half = Tf // 2
-    x = torch.empty(B, half, N, 3, dtype=torch.float32, device=x_full.device)
-    a = torch.empty(B, half, E, 1, dtype=torch.float32, device=x_full.device)
+    if out is not None:
+        x, a = out
+        assert tuple(x.shape) == (B, half, N, 3) and tuple(a.shape) == (B, half, E, 1) and x.is_contiguous() and a.is_contiguous()
+    else:
+        x = torch.empty(B, half, N, 3, dtype=torch.float32, device=x_full.device)
+        a = torch.empty(B, half, E, 1, dtype=torch.float32, device=x_full.device)
     arg = None
     keep = []
     if aug is not None:

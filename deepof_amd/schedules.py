@@ -1,49 +1,71 @@
-"""Iteration-based loss-weight schedules (KL weight, distillation lambda).
+"""Per-iteration loss-weight curves (KL weight, distillation lambda) as precomputed tables.
 
-Same curve as the reference's Dynamic_weight_manager
-(/root/reference/deepof/clustering/losses.py:290-351): warm-up 0 -> max with a shape function,
-optional hold at max, linear cool-down max -> end, then `end` forever.  Shapes: linear,
-logistic 1/(1+e^{-12(p-1/2)}), and "tf_sigmoid" sigma((2p-1)/max(0.01, p-p^2)).
+The curve is the reference's (``Dynamic_weight_manager``, /root/reference/deepof/clustering/losses.py:290-351):
+iterations ``0..w`` ramp ``0 -> top`` through a shape function of ``t/w``, an optional plateau of ``h``
+iterations stays at ``top``, ``c`` iterations blend linearly ``top -> tail``, afterwards ``tail`` for good
+(w, h, c = warm-up / plateau / cool-down epochs x batches per epoch; w is at least one iteration).
+
+Here the whole curve is evaluated once, vectorised, into a float64 table: a step is then a table lookup, and the
+table can be handed to the device in one piece when a captured training step wants to index it with its own
+iteration counter.
 """
 from __future__ import annotations
 
-import math
+import numpy as np
 
 
-def _shape(mode: str, p: float) -> float:
-    p = min(1.0, max(0.0, float(p)))
+def ramp_shape(mode: str, p: np.ndarray) -> np.ndarray:
+    """Shape functions on p in [0, 1]: identity, logistic 1/(1+e^{-12(p-1/2)}), and the "tf_sigmoid"
+    sigma((2p-1)/max(0.01, p-p^2)) (losses.py:311-324); unknown modes fall back to the identity like the reference."""
+    p = np.clip(np.asarray(p, dtype=np.float64), 0.0, 1.0)
     if mode == "sigmoid":
-        return 1.0 / (1.0 + math.exp(-12.0 * (p - 0.5)))
-    if mode == "tf_sigmoid":
-        return 1.0 / (1.0 + math.exp(-(2.0 * p - 1.0) / max(1e-2, p - p * p)))
-    return p
+        arg = 12.0 * (p - 0.5)
+    elif mode == "tf_sigmoid":
+        arg = (2.0 * p - 1.0) / np.maximum(1e-2, p - p * p)
+    else:
+        return p
+    with np.errstate(over="ignore"):
+        return 1.0 / (1.0 + np.exp(-arg))
+
+
+def weight_table(n_batches_per_epoch: int, mode: str, warmup_epochs: float, max_weight: float, at_max_epochs: float,
+                 cooldown_epochs: float, end_weight: float) -> np.ndarray:
+    """table[t] for t = 0 .. total (table[total] = the value held forever after)."""
+    warm = max(1, int(warmup_epochs * n_batches_per_epoch))
+    hold = max(0, int(at_max_epochs * n_batches_per_epoch))
+    cool = max(0, int(cooldown_epochs * n_batches_per_epoch))
+    top, tail = float(max_weight), float(end_weight)
+    t = np.arange(warm + hold + cool + 1, dtype=np.float64)
+    out = np.empty_like(t)
+    ramp = t <= warm
+    out[ramp] = top * ramp_shape(mode, t[ramp] / warm)
+    if hold > 0:  # the plateau claims iteration `warm` itself (the ramp reaches top there only for monotone shapes)
+        out[(t >= warm) & (t < warm + hold)] = top
+    late = t > warm if hold == 0 else t >= warm + hold
+    if cool > 0:
+        frac = (t[late] - (warm + hold)) / cool
+        out[late] = (1.0 - frac) * top + frac * tail
+    else:
+        out[late] = top
+    out[-1] = tail
+    return out
 
 
 class WeightSchedule:
+    """Cursor over a weight table; ``get_weight()`` / ``step()`` are what the fit loops call once per batch."""
+
     def __init__(self, n_batches_per_epoch: int, mode: str = "sigmoid", warmup_epochs: int = 15,
                  max_weight: float = 1.0, at_max_epochs: int = 0, cooldown_epochs: int = 15, end_weight: float = 1.0):
-        self.mode = mode
-        self.warmup_iters = max(1, warmup_epochs * n_batches_per_epoch)
-        self.at_max_iters = max(0, at_max_epochs * n_batches_per_epoch)
-        self.cooldown_iters = max(0, cooldown_epochs * n_batches_per_epoch)
-        self.total_iters = self.warmup_iters + self.at_max_iters + self.cooldown_iters
-        self.current_iteration = 0
+        self.table = weight_table(n_batches_per_epoch, mode, warmup_epochs, max_weight, at_max_epochs, cooldown_epochs,
+                                  end_weight)
         self.max_weight = float(max_weight)
-        self.end_weight = float(end_weight)
+        self.position = 0
+
+    def at(self, iteration: int) -> float:
+        return float(self.table[min(int(iteration), len(self.table) - 1)])
 
     def get_weight(self) -> float:
-        t = self.current_iteration
-        if t >= self.total_iters:
-            return self.end_weight
-        hold_end = self.warmup_iters + self.at_max_iters
-        if self.at_max_iters > 0 and self.warmup_iters <= t < hold_end:
-            return self.max_weight
-        if t <= self.warmup_iters:
-            return self.max_weight * _shape(self.mode, t / self.warmup_iters)
-        if self.cooldown_iters <= 0:
-            return self.max_weight
-        pc = (t - hold_end) / self.cooldown_iters
-        return (1.0 - pc) * self.max_weight + pc * self.end_weight
+        return self.at(self.position)
 
-    def step(self):
-        self.current_iteration += 1
+    def step(self) -> None:
+        self.position += 1

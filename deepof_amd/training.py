@@ -5,8 +5,8 @@ tuple ``(model_val, model_score, model_teacher_init_or_None, log_summary)`` and 
 (checkpoint bundle + ``_info.txt``), so ``Coordinates.deep_unsupervised_embedding`` can call it
 unchanged.  The epoch loop, the step and the optimiser run in libdeepof_hip on a
 ROCm device; data parallelism = one process per GPU, one RCCL all-reduce of the flat gradient per
-step (torch.distributed "nccl").  Implemented model family in this build: VaDE with the recurrent
-encoder/decoder; others raise NotImplementedError loudly.
+step (torch.distributed "nccl").  Model families: VaDE, VQ-VAE and contrastive, each with the recurrent, TCN or
+transformer encoder (``encoder_type``); latent_dim in {4, 6, 8} (check_model_inputs rejects other values up front).
 """
 from __future__ import annotations
 
@@ -25,6 +25,7 @@ from .config import (CommonFitCfg, ContrastiveCfg, TurtleTeacherCfg, VaDECfg, cf
 from .dataset import WindowDataset, n_batches
 from .models import Contrastive, VaDE, VQVAE
 from .schedules import WeightSchedule
+from .stepping import DeviceSchedule, StepGraphs, constant_schedule
 
 LOG_SUMMARY_KEYS = ("total_loss", "reconstruction_loss", "kl_divergence", "cat_cluster_loss", "kmeans_loss",
                     "distill_loss", "temporal_loss", "scatter_loss", "nonempty_loss", "repel_loss", "tf_cluster_loss",
@@ -62,6 +63,12 @@ def _dist_state():
     if dist.is_available() and dist.is_initialized():
         return dist, dist.get_rank(), dist.get_world_size()
     return None, 0, 1
+
+
+def _dp_active(dist, world: int) -> bool:
+    """True when steps take the data-parallel route (gradient all-reduce between the two step graphs).
+    DOF_FORCE_DP=1 takes it with a 1-rank group too: exercises RCCL + graph replay on a single-GPU box."""
+    return world > 1 or (dist is not None and os.environ.get("DOF_FORCE_DP") == "1")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -137,14 +144,18 @@ def load_model_from_ckpt(path: str, device=None, _engine_factory=None):
     return model, bundle.get("log_summary"), bundle["rebuild_spec"], report
 
 
+INFERENCE_BATCH = 256  # plan/workspace size of returned models (embedding_per_video encodes 256 windows at a time)
+
+
 def _clone_model(model: VaDE) -> VaDE:
-    """Independent copy (own parameter buffer) -- deepcopy() of the reference."""
+    """Independent copy (own parameter buffer) -- deepcopy() of the reference.  The copy starts with an
+    inference-sized plan (other batch sizes are created on demand), not with a training-sized workspace."""
     if isinstance(model, Contrastive):
         twin = Contrastive(model.input_shape, model.edge_feature_shape, model._adjacency, model.latent_dim,
                            encoder_type=model.encoder_type, n_components=model.n_components, temperature=model.temperature,
                            similarity_function=model.similarity_function,
                            loss_function=model.loss_function, beta=model.beta, tau=model.tau,
-                           batch_size=model._base.B, _engine_factory=model._factory)
+                           batch_size=min(model._base.B, INFERENCE_BATCH), _engine_factory=model._factory)
         twin._base.params.copy_(model._base.params)
         for k, t in model._base.num_batches_tracked.items():
             twin._base.num_batches_tracked[k].copy_(t)
@@ -152,7 +163,8 @@ def _clone_model(model: VaDE) -> VaDE:
         return twin
     twin = type(model)((model.window_size, model.input_n_nodes, 3), (model.window_size, model._base.E, 1),
                        model._adjacency, model.latent_dim, model.n_components, encoder_type=model.encoder_type,
-                       kmeans_loss=model.kmeans_weight, batch_size=model._base.B, _engine_factory=model._factory)
+                       kmeans_loss=model.kmeans_weight, batch_size=min(model._base.B, INFERENCE_BATCH),
+                       _engine_factory=model._factory)
     twin._base.params.copy_(model._base.params)
     twin._base.prior.copy_(model._base.prior)
     for k, t in model._base.num_batches_tracked.items():
@@ -256,15 +268,26 @@ def compute_diagnostics(model: VaDE, dataset: WindowDataset, batch_size: int, n_
 # the VaDE step driver
 # ------------------------------------------------------------------------------------------------
 class VadeStepper:
-    """Owns the loss configuration for one phase and issues train / validation steps on the engine."""
+    """Owns the loss configuration for one phase and issues train / validation steps on the engine.
 
-    def __init__(self, model: VaDE, common_cfg: CommonFitCfg, vade_cfg: VaDECfg, teacher_cfg: TurtleTeacherCfg):
+    A step = [dof_schedule_apply -> noise -> dof_vade_loss_grads -> log accumulation -> dof_optimizer_step] on static
+    buffers, replayed as one hipGraph per (batch size, phase, teacher on/off, train/validation) -- see
+    ``deepof_amd.stepping``.  Under data parallelism the RCCL all-reduce of the flat gradient runs between two
+    graphs (loss/gradients, optimiser); 1 / world is applied inside the optimiser kernel."""
+
+    def __init__(self, model: VaDE, common_cfg: CommonFitCfg, vade_cfg: VaDECfg, teacher_cfg: TurtleTeacherCfg,
+                 use_graphs: Optional[bool] = None):
         self.model, self.common, self.vade, self.teacher = model, common_cfg, vade_cfg, teacher_cfg
         self.pretrain = True
-        self.kl_scheduler: Optional[WeightSchedule] = None
-        self.lambda_scheduler: Optional[WeightSchedule] = None
-        self.lambda_distill = 0.0
+        self.kl_scheduler: Optional[DeviceSchedule] = None
+        self.lambda_scheduler: Optional[DeviceSchedule] = None
         self.tau_star: Optional[torch.Tensor] = None
+        self.graphs = StepGraphs(model.device, use_graphs)
+        self._zero_kl = constant_schedule(0.0, model.device)
+        self._buffers: Dict[int, SimpleNamespace] = {}
+        self.log_sum = torch.zeros(_capi.LOG_COUNT, dtype=torch.float64, device=model.device)
+        self.log_steps = 0
+        self._teacher_version = 0
         self.set_mode("pretrain")
 
     def set_mode(self, mode: str):
@@ -285,78 +308,129 @@ class VadeStepper:
                       scatter_w=v.reg_scatter_weight, scatter_beta=v.reg_scatter_beta)
         eng.set_hyper(km_latent=self.model.kmeans_weight, l1_act=0.1, distill_T=self.teacher.distill_sharpen_T,
                       conf_w=1.0 if self.teacher.distill_conf_weight else 0.0, conf_thr=self.teacher.distill_conf_thresh)
+        eng.push_hyper()
 
     def set_teacher(self, tau_star: Optional[torch.Tensor], lambda_distill: float, lambda_scheduler=None):
+        """tau* of every training window + the distillation weight: a schedule (WeightSchedule / DeviceSchedule) or,
+        without one, the constant ``lambda_distill``."""
         eng = self.model._base
-        self.tau_star, self.lambda_distill, self.lambda_scheduler = tau_star, float(lambda_distill), lambda_scheduler
+        self.tau_star = tau_star
+        self._teacher_version += 1
         if tau_star is None:
+            self.lambda_scheduler = None
             eng.set_teacher(None, None)
+            eng.set_hyper(lambda_distill=0.0)
+            eng.push_hyper()
             return
+        if lambda_scheduler is None:
+            lambda_scheduler = constant_schedule(float(lambda_distill), eng.device)
+        elif not isinstance(lambda_scheduler, DeviceSchedule):
+            lambda_scheduler = DeviceSchedule(lambda_scheduler, eng.device)
+        self.lambda_scheduler = lambda_scheduler
         pi = tau_star.mean(dim=0).clamp_min(1e-8)
         w = pi.pow(-float(self.teacher.distill_class_reweight_beta))
         w = w / w.mean()
         if self.teacher.distill_class_reweight_cap is not None:
             w = w.clamp_max(float(self.teacher.distill_class_reweight_cap))
         eng.set_teacher(w, pi)
-
-    def _step(self, x, a, idx, train: bool, apply_distill: bool):
-        dist, rank, world = _dist_state()
-        eng = self.model.engine(x.shape[0])
-        B, L, S = x.shape[0], eng.L, eng.S
-        klw = self.kl_scheduler.get_weight() if self.kl_scheduler is not None else 0.0
-        lam = self.lambda_distill
-        if self.lambda_scheduler is not None:
-            lam = float(self.lambda_scheduler.get_weight())
-        use_tau = apply_distill and self.tau_star is not None and lam > 0.0
-        eng.set_hyper(klw=klw, lambda_distill=lam if use_tau else 0.0)
-        if train:
-            eng.advance_adam()
         eng.push_hyper()
-        # train: z = mean + exp(softplus/2)*eps ; eval (validation): eps = 0 <=> z = mean
-        eps = torch.randn(B, L, device=eng.device) if train else torch.zeros(B, L, device=eng.device)
-        eps_mc = None if self.pretrain else torch.randn(S, B, L, device=eng.device)
-        tau = self.tau_star[idx].contiguous() if use_tau else None
-        eng.loss_grads(x.contiguous(), a.contiguous(), eps, eps_mc, tau, pretrain=self.pretrain)
+
+    def _static(self, eng) -> SimpleNamespace:
+        b = self._buffers.get(eng.B)
+        if b is None:
+            f32 = dict(dtype=torch.float32, device=eng.device)
+            b = SimpleNamespace(x=torch.empty(eng.B, eng.T, eng.N, 3, **f32), a=torch.empty(eng.B, eng.T, eng.E, 1, **f32),
+                                eps=torch.empty(eng.B, eng.L, **f32), eps_zero=torch.zeros(eng.B, eng.L, **f32),
+                                eps_mc=torch.empty(eng.S, eng.B, eng.L, **f32), tau=torch.empty(eng.B, eng.K, **f32))
+            self._buffers[eng.B] = b
+        return b
+
+    def step(self, dataset: WindowDataset, s: int, e: int, train: bool, apply_distill: bool):
+        """One step on windows [s, e) of ``dataset``; the loss terms are added to ``self.log_sum``."""
+        dist, rank, world = _dist_state()
+        eng = self.model.engine(e - s)
+        st = self._static(eng)
+        dataset.fetch(s, e, out=(st.x, st.a))
+        lam_now = self.lambda_scheduler.get_weight() if self.lambda_scheduler is not None else 0.0
+        use_tau = bool(apply_distill and self.tau_star is not None and lam_now > 0.0)
+        if use_tau:
+            st.tau.copy_(self.tau_star[s:e])
+        kl = self.kl_scheduler if self.kl_scheduler is not None else self._zero_kl
+        items = [(kl, _capi.H_KLW, train and self.kl_scheduler is not None, 1.0)]
+        if self.lambda_scheduler is not None:
+            items.append((self.lambda_scheduler, _capi.H_LAMBDA_DISTILL, train, 1.0 if use_tau else 0.0))
+        pretrain = self.pretrain
+
+        def forward_backward():
+            eng.schedule_apply(items)  # (no lambda schedule: hyper[lambda_distill] stays at the 0 set_teacher pushed)
+            eps = st.eps.normal_() if train else st.eps_zero  # eval: z = mean
+            eps_mc = None if pretrain else st.eps_mc.normal_()
+            eng.loss_grads(st.x, st.a, eps, eps_mc, st.tau if use_tau else None, pretrain=pretrain, count=False)
+            self.log_sum.add_(eng.logs)
+
+        key = (eng.B, pretrain, train, use_tau, kl.uid, getattr(self.lambda_scheduler, "uid", 0), self._teacher_version,
+               self.model.training)
+        if not train:
+            self.graphs.run(key + ("val",), forward_backward)
+        elif _dp_active(dist, world):
+            self.graphs.run(key + ("grads",), forward_backward)
+            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+            self.graphs.run((eng.B, world, "adam"), lambda: eng.optimizer_step(1.0 / world))
+        else:
+            def whole():
+                forward_backward()
+                eng.optimizer_step()
+            self.graphs.run(key + ("train",), whole)
+        eng._count_bn("", 1)
+        self.log_steps += 1
         if train:
-            if world > 1:
-                dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
-                eng.grads.mul_(1.0 / world)
-            eng.optimizer_step()
-        return eng.logs.clone()
+            if self.kl_scheduler is not None:
+                self.kl_scheduler.step()
+            if self.lambda_scheduler is not None:
+                self.lambda_scheduler.step()
+
+    def begin_logs(self):
+        self.log_sum.zero_()
+        self.log_steps = 0
+
+    def mean_logs(self) -> Dict[str, float]:
+        """One host sync per epoch: the per-step loss terms are summed on the device (float64) until here (Q23)."""
+        if self.log_steps == 0:
+            return {k: float("nan") for k in _capi.LOG_KEYS if k != "kl_weight"}
+        m = (self.log_sum / self.log_steps).cpu().tolist()
+        out = {k: m[i] for i, k in enumerate(_capi.LOG_KEYS)}
+        out.pop("kl_weight", None)
+        return out
 
     def train_epoch(self, dataset: WindowDataset, seed, shuffle=True):
         _, rank, world = _dist_state()
         self.model.train()
-        logs, mean_klw, mean_lam = [], 0.0, 0.0
+        self.begin_logs()
+        mean_klw, mean_lam = 0.0, 0.0
         nb = n_batches(len(dataset), self.common.batch_size, world)
-        for step, (x, a, idx, _vid) in enumerate(dataset.iter_batches(self.common.batch_size, shuffle, seed, world, rank)):
-            logs.append(self._step(x, a, idx, True, True))
-            if self.kl_scheduler is not None:
-                self.kl_scheduler.step()
-                if step == int(nb / 2):
-                    mean_klw = self.kl_scheduler.get_weight()
-            if self.lambda_scheduler is not None:
-                self.lambda_scheduler.step()
-                if step == int(nb / 2):
-                    mean_lam = self.lambda_scheduler.get_weight()
-        return self._avg(logs), mean_klw, mean_lam
+        for step, (s, e) in enumerate(dataset.iter_ranges(self.common.batch_size, shuffle, seed, world, rank)):
+            self.step(dataset, s, e, True, True)
+            if step == int(nb / 2):  # the schedulers have just been stepped, as in training.py:167-181
+                mean_klw = self.kl_scheduler.get_weight() if self.kl_scheduler is not None else 0.0
+                mean_lam = self.lambda_scheduler.get_weight() if self.lambda_scheduler is not None else 0.0
+        return self.mean_logs(), mean_klw, mean_lam
 
     @torch.no_grad()
     def validate_epoch(self, dataset: WindowDataset):
         self.model.eval()
-        logs = [self._step(x, a, idx, False, False)
-                for x, a, idx, _ in dataset.iter_batches(self.common.batch_size, False, None, 1, 0)]
-        return self._avg(logs)
+        self.begin_logs()
+        for s, e in dataset.iter_ranges(self.common.batch_size, False, None, 1, 0):
+            self.step(dataset, s, e, False, False)
+        return self.mean_logs()
 
-    @staticmethod
-    def _avg(device_logs):
-        """One host sync per epoch: the per-step log vectors stay on device until here."""
-        if not device_logs:
-            return {k: float("nan") for k in _capi.LOG_KEYS}
-        m = torch.stack(device_logs).mean(dim=0).cpu().tolist()
-        out = {k: m[i] for i, k in enumerate(_capi.LOG_KEYS)}
-        out.pop("kl_weight", None)
-        return out
+
+def _sync_from_rank0(t: torch.Tensor) -> torch.Tensor:
+    """Data parallel: replace a replicated-by-construction tensor by rank 0's copy (no-op on one rank)."""
+    dist, _rank, world = _dist_state()
+    if world > 1:
+        t = t.contiguous()
+        dist.broadcast(t, src=0)
+    return t
 
 
 def _set_lrs(eng, base_lr: float, gmm_lr: float):
@@ -366,14 +440,15 @@ def _set_lrs(eng, base_lr: float, gmm_lr: float):
 
 
 @torch.no_grad()
-def initialize_gmm_from_data(model: VaDE, dataset: WindowDataset, batch_size: int, seed, n_samples: int = 10000):
+def initialize_gmm_from_data(model: VaDE, dataset: WindowDataset, batch_size: int, seed, n_samples: int = 10000,
+                             shuffle: bool = True):
     """sklearn diag GMM (reg_covar 1e-4) on <= 10k latent means -> gmm_means / gmm_log_vars (models_new.py:1907-1943)."""
     from sklearn.mixture import GaussianMixture
 
     _, rank, world = _dist_state()
     model.eval()
     chunks, got = [], 0
-    for x, a, _idx, _vid in dataset.iter_batches(batch_size, True, seed, world, rank):
+    for x, a, _idx, _vid in dataset.iter_batches(batch_size, shuffle, seed, world, rank):
         _, out = model._run(x, a, None, want_loc=False)
         chunks.append(out["z_mean"].cpu())
         got += x.shape[0]
@@ -386,7 +461,7 @@ def initialize_gmm_from_data(model: VaDE, dataset: WindowDataset, batch_size: in
 
 
 def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
-             teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, device=None, _engine_factory=None):
+             teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, device=None, _engine_factory=None, shuffle: bool = True):
     """training.py:1522-1918 (pretrain -> GMM init -> main epochs with best-val / best-score selection)."""
     dist, rank, world = _dist_state()
     is_main = rank == 0
@@ -411,23 +486,27 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
     model.set_pretrain_mode(True)
     eng.reset_optimizer()
     _set_lrs(eng, vade_cfg.learning_rate_pretrain, 0.0)
-    stepper.kl_scheduler = WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode_pretrain,
-                                          warmup_epochs=vade_cfg.kl_warmup_pretrain,
-                                          max_weight=vade_cfg.kl_max_weight_pretrain,
-                                          cooldown_epochs=vade_cfg.kl_cooldown_pretrain,
-                                          end_weight=vade_cfg.kl_end_weight_pretrain)
+    stepper.kl_scheduler = DeviceSchedule(WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode_pretrain,
+                                                         warmup_epochs=vade_cfg.kl_warmup_pretrain,
+                                                         max_weight=vade_cfg.kl_max_weight_pretrain,
+                                                         cooldown_epochs=vade_cfg.kl_cooldown_pretrain,
+                                                         end_weight=vade_cfg.kl_end_weight_pretrain), eng.device)
+    eng.push_hyper()
     for _ep in range(vade_cfg.pretrain_epochs):
-        stepper.train_epoch(train_ds, common_cfg.seed)
+        stepper.train_epoch(train_ds, common_cfg.seed, shuffle)
 
     # ---- main phase
     model.set_pretrain_mode(False)
     stepper.set_mode("main")
     model.set_censnet_trainable(True)  # the main-phase optimiser is built after the first forward (Q11)
-    stepper.kl_scheduler = WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode, warmup_epochs=vade_cfg.kl_warmup,
-                                          max_weight=vade_cfg.kl_max_weight, cooldown_epochs=vade_cfg.kl_cooldown,
-                                          end_weight=vade_cfg.kl_end_weight)
+    stepper.kl_scheduler = DeviceSchedule(WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode,
+                                                         warmup_epochs=vade_cfg.kl_warmup,
+                                                         max_weight=vade_cfg.kl_max_weight,
+                                                         cooldown_epochs=vade_cfg.kl_cooldown,
+                                                         end_weight=vade_cfg.kl_end_weight), eng.device)
     eng.reset_optimizer()
     _set_lrs(eng, common_cfg.learning_rate, vade_cfg.gmm_learning_rate)
+    eng.push_hyper()
     _, best_path_val, best_path_score, _teacher_path = ckpt_paths("vade", common_cfg)
     log_summary = init_log_summary("vade")
     teacher_init_model = None
@@ -441,18 +520,20 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
         if is_main:
             print("\n--- Extracting latents for teacher ---")
         z_all = TT.extract_latents(model, train_ds, batch_size=2048)
-        lambda_scheduler = WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode, warmup_epochs=0,
-                                          at_max_epochs=teacher_cfg.lambda_decay_start, max_weight=teacher_cfg.lambda_distill,
-                                          cooldown_epochs=teacher_cfg.lambda_cooldown,
-                                          end_weight=teacher_cfg.lambda_end_weight)
+        lambda_scheduler = DeviceSchedule(
+            WeightSchedule(nb, mode=vade_cfg.kl_annealing_mode, warmup_epochs=0,
+                           at_max_epochs=teacher_cfg.lambda_decay_start, max_weight=teacher_cfg.lambda_distill,
+                           cooldown_epochs=teacher_cfg.lambda_cooldown, end_weight=teacher_cfg.lambda_end_weight),
+            eng.device)
         teacher_cfg.include_latent_view = True  # VaDE has a free and useful latent view thanks to the pre-training
         _teacher, tau_star, teacher_views = TT.maybe_build_turtle_teacher(
             teacher_cfg=teacher_cfg, common_cfg=common_cfg, train_dataset=train_ds, device=eng.device,
             latent_view=z_all, lib=lib)
         if is_main:
             print("\n--- Initializing GMM from teacher tau* ---")
+        tau_star = _sync_from_rank0(tau_star.to(eng.device))  # every rank fits its own teacher: keep rank 0's
         TT.initialize_gmm_from_teacher(model, z_all, tau_star, min_var=0.01)
-        stepper.set_teacher(tau_star.to(eng.device), teacher_cfg.lambda_distill, lambda_scheduler)
+        stepper.set_teacher(tau_star, teacher_cfg.lambda_distill, lambda_scheduler)
         teacher_init_model = _clone_model(model)
         if common_cfg.save_weights and is_main:
             save_model_info(_teacher_path, stage="teacher_init", epoch=vade_cfg.pretrain_epochs - 1,
@@ -463,7 +544,7 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
     else:
         if is_main:
             print("\n--- Initializing GMM from embeddings (sklearn) ---")
-        initialize_gmm_from_data(model, train_ds, common_cfg.batch_size, common_cfg.seed)
+        initialize_gmm_from_data(model, train_ds, common_cfg.batch_size, common_cfg.seed, shuffle=shuffle)
     if world > 1:
         dist.broadcast(eng.params, src=0)
         dist.broadcast(eng.prior, src=0)
@@ -502,10 +583,15 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
                 normalize_feats=teacher_cfg.teacher_normalize_feats, verbose=is_main, device=eng.device,
                 head_temp=teacher_cfg.teacher_head_temp, task_temp=teacher_cfg.teacher_task_temp,
                 batch_size=teacher_cfg.teacher_batch_size, seed=(common_cfg.seed or 0) + epoch, lib=lib)
-            stepper.set_teacher(tau_star.to(eng.device), teacher_cfg.lambda_distill, lambda_scheduler)
+            tau_star = _sync_from_rank0(tau_star.to(eng.device))
+            stepper.set_teacher(tau_star, teacher_cfg.lambda_distill, lambda_scheduler)
             if teacher_cfg.reinit_gmm_on_refresh:
                 TT.initialize_gmm_from_teacher(model, z_curr, tau_star, min_var=1e-4)
-        train_logs, klw, lambda_d = stepper.train_epoch(train_ds, common_cfg.seed)
+                if world > 1:  # replicas must not drift apart: rank 0's re-initialised mixture everywhere
+                    dist.broadcast(eng.params, src=0)
+                    dist.broadcast(eng.prior, src=0)
+        eng.push_hyper()  # learning rates / freeze flags of this epoch
+        train_logs, klw, lambda_d = stepper.train_epoch(train_ds, common_cfg.seed, shuffle)
         val_logs = stepper.validate_epoch(val_ds)
         diag = compute_diagnostics(model, val_ds, common_cfg.batch_size, common_cfg.n_components, tau_star=stepper.tau_star,
                                    distill_sharpen_T=teacher_cfg.distill_sharpen_T,
@@ -542,9 +628,9 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
 
 
 def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
-              teacher_cfg: TurtleTeacherCfg, device=None, _engine_factory=None):
-    """training.py:1036-1263: Adam(lr, weight_decay 1e-4) on encoder + decoder + codebook, clip 0.75; best-val
-    checkpointing; the distillation head / alignment score need the TURTLE teacher (not built yet)."""
+              teacher_cfg: TurtleTeacherCfg, device=None, _engine_factory=None, shuffle: bool = True):
+    """training.py:1036-1263: Adam(lr, weight_decay 1e-4) on encoder + decoder + codebook (+ the distillation head
+    when the TURTLE teacher is on), clip 0.75; best-val / best-score (alignment of the head with tau*) checkpoints."""
     dist, rank, world = _dist_state()
     is_main = rank == 0
     model = VQVAE(train_ds.x_shape, train_ds.a_shape, adjacency_matrix, common_cfg.latent_dim, common_cfg.n_components,
@@ -566,6 +652,7 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
         eng.set_lr(seg, common_cfg.learning_rate)
     eng.set_hyper(vq_beta=model.beta, km_latent=common_cfg.kmeans_loss, km_loss=1.0 if common_cfg.kmeans_loss else 0.0,
                   clip=0.75, wd=1e-4)
+    eng.push_hyper()
     _, best_path_val, best_path_score, _ = ckpt_paths("vqvae", common_cfg)
     best_val = float("inf")
     log_summary = init_log_summary("vqvae")
@@ -574,34 +661,60 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
     keys = ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss", "kmeans_loss",
             "number_of_populated_clusters", "distill_loss")
 
+    graphs = StepGraphs(eng.device)
+    log_sum = torch.zeros(_capi.LOG_COUNT, dtype=torch.float64, device=eng.device)
+    buffers: Dict[int, SimpleNamespace] = {}
+
+    def static(e):
+        b = buffers.get(e.B)
+        if b is None:
+            f32 = dict(dtype=torch.float32, device=e.device)
+            b = buffers[e.B] = SimpleNamespace(x=torch.empty(e.B, e.T, e.N, 3, **f32), a=torch.empty(e.B, e.T, e.E, 1, **f32),
+                                               tau=torch.empty(e.B, e.K, **f32))
+        return b
+
     def run_epoch(ds, train):
+        """One pass; every step = [schedule -> dof_vqvae_loss_grads -> log sum -> optimiser] replayed as a hipGraph."""
         model.train(train)
-        acc = []
-        it = ds.iter_batches(common_cfg.batch_size, train, common_cfg.seed if train else None,
-                             world if train else 1, rank if train else 0)
-        lam_mid = 0.0
-        for step, (x, a, idx, _vid) in enumerate(it):
-            e = model.engine(x.shape[0])
+        log_sum.zero_()
+        n_steps = 0
+        ranges = ds.iter_ranges(common_cfg.batch_size, train and shuffle, common_cfg.seed if train else None,
+                                world if train else 1, rank if train else 0)
+        for s0, e0 in ranges:
+            e = model.engine(e0 - s0)
+            st = static(e)
+            ds.fetch(s0, e0, out=(st.x, st.a))
             lam = float(lambda_scheduler.get_weight()) if (train and lambda_scheduler is not None) else 0.0
             use_tau = train and tau_star is not None and lam > 0.0
-            e.set_hyper(lambda_distill=lam if use_tau else 0.0)
-            if train:
-                e.advance_adam()
-            e.push_hyper()
-            e.vq_loss_grads(x.contiguous(), a.contiguous(), tau_star[idx].contiguous() if use_tau else None)
-            if train:
-                if world > 1:
-                    dist.all_reduce(e.grads, op=dist.ReduceOp.SUM)
-                    e.grads.mul_(1.0 / world)
-                e.optimizer_step()
-                if lambda_scheduler is not None:
-                    lambda_scheduler.step()
-                    if step == int(nb / 2):
-                        lam_mid = lam
-            acc.append(e.logs.clone())
-        if not acc:
+            if use_tau:
+                st.tau.copy_(tau_star[s0:e0])
+            items = [] if lambda_scheduler is None else \
+                [(lambda_scheduler, _capi.H_LAMBDA_DISTILL, train, 1.0 if use_tau else 0.0)]
+
+            def forward_backward():
+                e.schedule_apply(items)
+                e.vq_loss_grads(st.x, st.a, st.tau if use_tau else None, count=False)
+                log_sum.add_(e.logs)
+
+            key = (e.B, train, use_tau)
+            if not train:
+                graphs.run(key + ("val",), forward_backward)
+            elif _dp_active(dist, world):
+                graphs.run(key + ("grads",), forward_backward)
+                dist.all_reduce(e.grads, op=dist.ReduceOp.SUM)
+                graphs.run((e.B, "adam"), lambda: e.optimizer_step(1.0 / world))
+            else:
+                def whole():
+                    forward_backward()
+                    e.optimizer_step()
+                graphs.run(key + ("train",), whole)
+            e.count_vq_step()
+            n_steps += 1
+            if train and lambda_scheduler is not None:
+                lambda_scheduler.step()
+        if n_steps == 0:
             return {k: float("nan") for k in keys}
-        m = torch.stack(acc).mean(dim=0).cpu().tolist()
+        m = (log_sum / n_steps).cpu().tolist()
         return {"total_loss": m[0], "enc_rec_loss": m[_capi.LOG_ENC_REC], "reconstruct_loss": m[1],
                 "vq_loss": m[_capi.LOG_VQ], "kmeans_loss": m[4], "number_of_populated_clusters": m[_capi.LOG_POPULATED],
                 "distill_loss": m[7]}
@@ -657,13 +770,14 @@ def _generic_teacher(train_ds, common_cfg, teacher_cfg, eng, nb, is_main):
                                                          lib=eng.lib)
     if tau_star is None:
         return None, None
-    sched = WeightSchedule(nb, mode="tf_sigmoid", warmup_epochs=0, at_max_epochs=teacher_cfg.lambda_decay_start,
-                           max_weight=teacher_cfg.lambda_distill, cooldown_epochs=teacher_cfg.lambda_cooldown,
-                           end_weight=teacher_cfg.lambda_end_weight)
+    sched = DeviceSchedule(
+        WeightSchedule(nb, mode="tf_sigmoid", warmup_epochs=0, at_max_epochs=teacher_cfg.lambda_decay_start,
+                       max_weight=teacher_cfg.lambda_distill, cooldown_epochs=teacher_cfg.lambda_cooldown,
+                       end_weight=teacher_cfg.lambda_end_weight), eng.device)
     eng.set_hyper(distill_T=teacher_cfg.generic_distill_sharpen_T,
                   conf_w=1.0 if teacher_cfg.generic_distill_conf_weight else 0.0,
                   conf_thr=teacher_cfg.generic_distill_conf_thresh)
-    return tau_star.to(eng.device), sched
+    return _sync_from_rank0(tau_star.to(eng.device)), sched
 
 
 def _head_diagnostics(eng, z_batches, n_components, tau_star, teacher_cfg):
@@ -702,16 +816,19 @@ class ContrastiveStepper:
         self.gen.manual_seed(int(seed))
         self.host_gen = torch.Generator()
         self.host_gen.manual_seed(int(seed))
+        self.graphs = StepGraphs(model.device)
+        self._buffers: Dict[int, SimpleNamespace] = {}
 
-    def views(self, x_full: torch.Tensor, draws: dict = None):
+    def views(self, x_full: torch.Tensor, draws: dict = None, out=None):
+        """(x, a, x_aug, a_aug) of the full windows; ``out`` = the four buffers to fill."""
         from .augment import draw_augmentation
         from .engine import contrastive_views
         B, Tf, N, _ = x_full.shape
         if draws is None:
             draws = draw_augmentation(B, Tf, N, self.cfg, self.precomp, x_full.device, self.gen, self.host_gen)
         st = self.model._base._stream()
-        x, a = contrastive_views(self.lib, x_full, self.edge_index, None, st)
-        xa, aa = contrastive_views(self.lib, x_full, self.edge_index, draws, st)
+        x, a = contrastive_views(self.lib, x_full, self.edge_index, None, st, out=None if out is None else out[:2])
+        xa, aa = contrastive_views(self.lib, x_full, self.edge_index, draws, st, out=None if out is None else out[2:])
         return x, a, xa, aa
 
     def loss_grads(self, x_full: torch.Tensor, draws: dict = None, want_grads: bool = True, teacher_tau=None):
@@ -731,13 +848,74 @@ class ContrastiveStepper:
             e2.contrastive_backward(dza, accumulate=True)
         return e1
 
+    # ---- the fit loop's step: views eagerly (their rotation choices are host draws baked into the launch), the
+    # rest -- both encoder passes, the all-pairs loss, both backward passes, the optimiser -- as one hipGraph
+    def _static(self, B: int) -> SimpleNamespace:
+        b = self._buffers.get(B)
+        if b is None:
+            m = self.model
+            f32 = dict(dtype=torch.float32, device=m.device)
+            Tf, N, E, h = m.full_time_steps, m.input_n_nodes, m._base.E, m.window_size
+            b = self._buffers[B] = SimpleNamespace(
+                x_full=torch.empty(B, Tf, N, 3, **f32), a_full=torch.empty(B, Tf, E, 1, **f32),
+                x=torch.empty(B, h, N, 3, **f32), a=torch.empty(B, h, E, 1, **f32),
+                xa=torch.empty(B, h, N, 3, **f32), aa=torch.empty(B, h, E, 1, **f32),
+                z=torch.empty(B, m.latent_dim, **f32), z_aug=torch.empty(B, m.latent_dim, **f32),
+                dz=torch.empty(B, m.latent_dim, **f32), dza=torch.empty(B, m.latent_dim, **f32),
+                tau=torch.empty(B, m.n_components, **f32))
+        return b
+
+    def step(self, dataset: WindowDataset, s: int, e: int, train: bool, tau_star, lambda_scheduler, log_sum):
+        """One step of the fit loop on windows [s, e): adds the loss terms to ``log_sum``, updates the weights when
+        ``train``.  The dataset's own edge tensor is discarded, as in the reference (Q14)."""
+        dist, rank, world = _dist_state()
+        m = self.model
+        B = e - s
+        st = self._static(B)
+        dataset.fetch(s, e, out=(st.x_full, st.a_full))
+        self.views(st.x_full, None, out=(st.x, st.a, st.xa, st.aa))
+        e1, e2 = m.engine(B), m.aug_engine(B)
+        lam = float(lambda_scheduler.get_weight()) if (train and lambda_scheduler is not None) else 0.0
+        use_tau = train and tau_star is not None and lam > 0.0
+        if use_tau:
+            st.tau.copy_(tau_star[s:e])
+        items = [] if lambda_scheduler is None else \
+            [(lambda_scheduler, _capi.H_LAMBDA_DISTILL, train, 1.0 if use_tau else 0.0)]
+
+        def forward_backward():
+            e1.schedule_apply(items)
+            e1.contrastive_encode(st.x, st.a, train=train, out=st.z, count=False)
+            e2.contrastive_encode(st.xa, st.aa, train=train, out=st.z_aug, count=False)
+            e1.contrastive_loss(st.z, st.z_aug, m.similarity_function, m.loss_function, m.temperature, m.tau, m.beta,
+                                want_grads=train, teacher_tau=st.tau if use_tau else None, out=(st.dz, st.dza))
+            if train:
+                e1.contrastive_backward(st.dz, accumulate=False)
+                e2.contrastive_backward(st.dza, accumulate=True)
+            log_sum.add_(e1.logs)
+
+        key = (B, train, use_tau)
+        if not train:
+            self.graphs.run(key + ("val",), forward_backward)
+        elif _dp_active(dist, world):
+            self.graphs.run(key + ("grads",), forward_backward)
+            dist.all_reduce(e1.grads, op=dist.ReduceOp.SUM)
+            self.graphs.run((B, "adam"), lambda: e1.optimizer_step(1.0 / world))
+        else:
+            def whole():
+                forward_backward()
+                e1.optimizer_step()
+            self.graphs.run(key + ("train",), whole)
+        if train:
+            e1._count_bn("", 2)  # two train-mode encoder passes (BatchNorm step counters of the TCN family)
+            if lambda_scheduler is not None:
+                lambda_scheduler.step()
+
 
 def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, meta_info: dict,
                     common_cfg: CommonFitCfg, teacher_cfg: TurtleTeacherCfg, contrastive_cfg: ContrastiveCfg,
-                    device=None, _engine_factory=None):
-    """training.py:1266-1520: Adam(lr, weight_decay 1e-4) on the encoder, clip 0.75, best-val checkpointing.  The
-    distillation head / alignment score need the TURTLE teacher (not built): trained without, as the reference does
-    when no teacher is available."""
+                    device=None, _engine_factory=None, shuffle: bool = True):
+    """training.py:1266-1520: Adam(lr, weight_decay 1e-4) on the encoder (+ the distillation head when the TURTLE
+    teacher is on), clip 0.75, best-val / best-score checkpointing."""
     from .augment import edge_index_from_meta
     dist, rank, world = _dist_state()
     is_main = rank == 0
@@ -767,6 +945,7 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
     for seg in range(_capi.SEG_COUNT):
         eng.set_lr(seg, common_cfg.learning_rate)
     eng.set_hyper(clip=0.75, wd=1e-4)
+    eng.push_hyper()
     _, best_path_val, best_path_score, _ = ckpt_paths("contrastive", common_cfg)
     best_val = float("inf")
     log_summary = init_log_summary("contrastive")
@@ -774,30 +953,19 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
     score_start_epoch, score_tol = max(3, math.ceil(0.1 * common_cfg.epochs)), 0.01
     keys = ("total_loss", "pos_similarity", "neg_similarity", "distill_loss", "seperability")
 
+    log_sum = torch.zeros(_capi.LOG_COUNT, dtype=torch.float64, device=eng.device)
+
     def run_epoch(ds, train):
         model.train(train)
-        acc = []
-        it = ds.iter_batches(common_cfg.batch_size, train, common_cfg.seed if train else None,
-                             world if train else 1, rank if train else 0)
-        for x, _a, idx, _vid in it:
-            lam = float(lambda_scheduler.get_weight()) if (train and lambda_scheduler is not None) else 0.0
-            use_tau = train and tau_star is not None and lam > 0.0
-            eng.set_hyper(lambda_distill=lam if use_tau else 0.0)
-            if train:
-                eng.advance_adam()
-            eng.push_hyper()
-            e = stepper.loss_grads(x, want_grads=train, teacher_tau=tau_star[idx].contiguous() if use_tau else None)
-            if train:
-                if world > 1:
-                    dist.all_reduce(e.grads, op=dist.ReduceOp.SUM)
-                    e.grads.mul_(1.0 / world)
-                e.optimizer_step()
-                if lambda_scheduler is not None:
-                    lambda_scheduler.step()
-            acc.append(e.logs.clone())
-        if not acc:
+        log_sum.zero_()
+        n_steps = 0
+        for s0, e0 in ds.iter_ranges(common_cfg.batch_size, train and shuffle, common_cfg.seed if train else None,
+                                     world if train else 1, rank if train else 0):
+            stepper.step(ds, s0, e0, train, tau_star, lambda_scheduler, log_sum)
+            n_steps += 1
+        if n_steps == 0:
             return {k: float("nan") for k in keys}
-        m = torch.stack(acc).mean(dim=0).cpu().tolist()
+        m = (log_sum / n_steps).cpu().tolist()
         return {"total_loss": m[0], "pos_similarity": m[_capi.LOG_POS_SIM], "neg_similarity": m[_capi.LOG_NEG_SIM],
                 "distill_loss": m[7], "seperability": 0.0}
 
@@ -878,12 +1046,12 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
     train_ds.bootstrap_training, train_ds.bootstrap_block_len = bool(bootstrap_training), int(bootstrap_block_len)
     if model_name == "vqvae":
         return fit_VQVAE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
-                         _engine_factory=_engine_factory)
+                         _engine_factory=_engine_factory, shuffle=shuffle)
     if model_name == "contrastive":
         return fit_contrastive(train_ds, val_ds, np.asarray(adjacency_matrix), meta_info, common_cfg, teacher_cfg,
-                               contrastive_cfg, device=dev, _engine_factory=_engine_factory)
+                               contrastive_cfg, device=dev, _engine_factory=_engine_factory, shuffle=shuffle)
     return fit_VADE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
-                    _engine_factory=_engine_factory)
+                    _engine_factory=_engine_factory, shuffle=shuffle)
 
 
 def train_deepof_model(
@@ -914,7 +1082,7 @@ def train_deepof_model(
     nonempty_p: float = 2.0,
     distill_conf_weight: bool = False, distill_conf_thresh: float = 0.3, distill_sharpen_T: float = 0.5,
     include_edges_view: bool = False, include_nodes_view: bool = True, pca_nodes_dim: int = 32,
-    pca_edges_dim: int = 32, include_angles_view: bool = False, pca_angles_dim: int = 32, pca_backend: str = "device",
+    pca_edges_dim: int = 32, include_angles_view: bool = False, pca_angles_dim: int = 32,
     reinit_gmm_on_refresh: bool = False,
     diag_max_batches: int = 4,
     model_name: str = "VaDE",
@@ -930,9 +1098,12 @@ def train_deepof_model(
     device: str = None, h5_dataset_folder: Optional[str] = None, bootstrap_training: Optional[bool] = False,
     bootstrap_block_len: int = 250,
     random_seed: int = 0,
+    pca_backend: str = "device",
     _engine_factory=None,
 ):
-    """Same signature / defaults / return value as the reference ``train_deepof_model`` (training.py:592-881)."""
+    """Same signature / defaults / return value as the reference ``train_deepof_model`` (training.py:592-881); the
+    two extra keyword arguments come after every reference argument, so positional calls bind as in the reference.
+    ``pca_backend``: "device" (teacher PCA views on the GPU) or "sklearn" (the reference's host IncrementalPCA)."""
     model_name = str(model_name).lower()
     encoder_type = str(encoder_type).lower()
     kl_annealing_mode = str(kl_annealing_mode).lower()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 8
+#define DOF_ABI_VERSION 9
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -261,9 +261,32 @@ int dof_turtle_fit_step(const DofTurtleDims* dims, const DofTurtleHyper* hyper, 
 int dof_turtle_predict(const DofTurtleDims* dims, float task_temp, const float* const* feats, const float* params,
                        int64_t n_rows, float* tau_out, void* stream);
 
-/* clip_grad_value_(hyper[DOF_H_CLIP]) + Adam(betas 0.9/0.999, eps 1e-8, weight decay hyper[DOF_H_WD]). */
+/* clip_grad_value_(hyper[DOF_H_CLIP]) + Adam(betas 0.9/0.999, eps 1e-8, weight decay hyper[DOF_H_WD]).
+ * opt_state: device int32[DOF_SEG_COUNT], the Adam step count t of every optimiser segment (torch.optim.Adam's
+ * per-parameter `step`); this call advances the counter of every segment whose hyper[DOF_H_ACTIVE0 + seg] != 0 and
+ * derives the bias corrections 1 - beta^t from it on the device, so that a captured step replays without any
+ * host-written per-step value (zero the array to restart the optimiser; hyper[DOF_H_BC0 ..] is no longer read).
+ * grad_scale multiplies every gradient before clipping: 1 / world after an all-reduce SUM over data-parallel
+ * ranks (DDP's gradient averaging, training.py:1567-1576), 1 otherwise. */
 int dof_optimizer_step(DofVadePlan* plan, float* params, const float* grads, float* adam_m, float* adam_v,
-                       const float* hyper, void* stream);
+                       const float* hyper, int32_t* opt_state, float grad_scale, void* stream);
+
+/* Per-step schedule values without the host: hyper[item.hyper_index] = item.scale * item.table[min(*item.cursor,
+ * item.len - 1)], then *item.cursor += 1 when item.advance.  table (device fp32, item.len entries) is the whole
+ * weight curve of a Dynamic_weight_manager (losses.py:290-351: KL weight, distillation lambda) evaluated per
+ * iteration; cursor is a device int32 owned by the caller (its get_weight() / step() pair).  Enqueued at the head of
+ * a training step (advance = 1) or of a validation step (advance = 0; scale = 0 switches a term off), it makes the
+ * step a pure function of device memory: capturable into a hipGraph and free of host/device races on hyper[]. */
+#define DOF_SCHED_MAX_ITEMS 4
+typedef struct DofSchedItem {
+  const float* table;
+  int32_t* cursor;
+  int32_t len;
+  int32_t hyper_index;
+  int32_t advance;
+  float scale;
+} DofSchedItem;
+int dof_schedule_apply(float* hyper, const DofSchedItem* items, int32_t n_items, void* stream);
 
 /* ---- pose-table preprocessing -----------------------------------------------
  * Raw merged tables of all videos, concatenated: raw (n_frames, n_cols) float64 row-major (NaN = missing), video v =

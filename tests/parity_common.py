@@ -29,22 +29,9 @@ PHASES = {
 
 
 def configure_phase(eng, K, pretrain, klw, tau=None, lambda_distill=0.0, extra=None):
-    """Reference defaults of VadeLoss per phase (training.py:640-668, losses.py:426-443)."""
-    eng.set_hyper(klw=klw, km_latent=1.0, km_loss=1.0 if pretrain else 0.0,
-                  repel_w=0.5 if pretrain else 0.0, repel_ls=0.5 if pretrain else 1.0,
-                  nonempty_w=0.02, nonempty_floor=max(1e-4, 0.05 / K), nonempty_p=2.0,
-                  l1_act=0.1, distill_T=0.5, conf_w=0.0, conf_thr=0.3, lambda_distill=lambda_distill,
-                  tf_w=0.0, cat_w=0.0, temporal_w=0.0, scatter_w=0.0, scatter_beta=1.0)
-    if extra:
-        eng.set_hyper(**extra)
-    if tau is not None:
-        pi = tau.mean(dim=0).clamp_min(1e-8)
-        w = pi.pow(-1.0)
-        w = (w / w.mean()).clamp_max(3.0)
-        eng.set_teacher(w, pi)
-    else:
-        eng.set_teacher(None, None)
-    eng.push_hyper()
+    """Reference defaults of VadeLoss per phase (VadeEngine.configure_vade_phase)."""
+    assert K == eng.K
+    eng.configure_vade_phase(pretrain, klw, tau, lambda_distill, extra)
 
 
 def gather_check(lib, device):
@@ -132,7 +119,6 @@ def run_trace_check(lib, device, golden_dir):
         for seg in (_capi.SEG_ENCODER, _capi.SEG_DECODER, _capi.SEG_HEADS):
             eng.set_lr(seg, lr_b)
         eng.set_lr(_capi.SEG_GMM, lr_g)
-        eng.advance_adam()
         configure_phase(eng, K, phase == "pre", float(d[f"step{s}::klw"]))
         t = lambda k: torch.from_numpy(d[f"step{s}::{k}"]).to(device)
         eng.loss_grads(t("x"), t("a"), t("eps"), t("eps_mc"), None, pretrain=(phase == "pre"))
@@ -187,7 +173,6 @@ def run_vqvae_check(lib, device, golden_dir, tag):
             assert float(eng.view(name, eng.grads).abs().max()) == 0.0, name
     eng.reset_optimizer()
     for i in range(3):
-        eng.advance_adam()
         eng.push_hyper()
         xs, as_ = torch.from_numpy(d[f"step{i}::x"]).to(device), torch.from_numpy(d[f"step{i}::a"]).to(device)
         eng.vq_loss_grads(xs, as_)
@@ -337,7 +322,6 @@ def run_contrastive_tcn_check(lib, device, golden_dir):
     for seg in range(_capi.SEG_COUNT):
         e1.set_lr(seg, 1e-3)
     e1.set_hyper(clip=0.75, wd=1e-4)
-    e1.advance_adam()
     e1.push_hyper()
     e1.optimizer_step()
     aug2 = {k.replace("aug2::", "aug::"): v for k, v in d.items() if k.startswith(pfx + "aug2::")}
@@ -351,7 +335,6 @@ def run_contrastive_tcn_check(lib, device, golden_dir):
             np.testing.assert_allclose(v, float(d[f"{pfx}log2::{k}"]), rtol=1e-2, atol=1e-3, err_msg=f"step 2: {k}")
     e1.contrastive_backward(dz, accumulate=False)
     e2.contrastive_backward(dza, accumulate=True)
-    e1.advance_adam()
     e1.push_hyper()
     e1.optimizer_step()
     sd2 = e1.state_dict()

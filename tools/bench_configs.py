@@ -55,7 +55,6 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
     from deepof_amd import _capi
     from deepof_amd.engine import create_vade_engine
     from deepof_amd.graph import adjacency_from_graph, bodypart_graph
-    from parity_common import configure_phase
     dev = torch.device("cuda")
     nodes, edges = bodypart_graph(ids)
     N, E, L, S = len(nodes), len(edges), 8, 32
@@ -73,7 +72,7 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
     for seg in range(_capi.SEG_COUNT):
         eng.set_lr(seg, 5e-4)
     if kind.startswith("vade"):
-        configure_phase(eng, K, False, 1.0, tau, 4.0)
+        eng.configure_vade_phase(False, 1.0, tau, 4.0)
     else:
         eng.set_hyper(vq_beta=1.0, km_latent=0.0, km_loss=0.0, clip=0.75, wd=1e-4)
     lib = eng.lib
@@ -82,7 +81,6 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
         b0 = (i * 7919 % n_batches) * B
         _capi.check(lib, lib.dof_window_gather_range(tn.data_ptr(), te.data_ptr(), b0, 1, B, T, N, E, x.data_ptr(),
                                                      a.data_ptr(), torch.cuda.current_stream().cuda_stream))
-        eng.advance_adam()
         eng.push_hyper()
         if kind.startswith("vade"):
             eps.normal_()
@@ -142,7 +140,6 @@ def run_contrastive(B, Tf, steps, warmup, frames=200_000, kind="contrastive_tcn"
         draws = draw_augmentation(B, Tf, N, cfg, pc, dev, gen, hgen)
         x, a = contrastive_views(lib, x_full, eid, None, st)
         xa, aa = contrastive_views(lib, x_full, eid, draws, st)
-        e1.advance_adam()
         e1.push_hyper()
         z, za = e1.contrastive_encode(x, a, True), e2.contrastive_encode(xa, aa, True)
         dz, dza = e1.contrastive_loss(z, za, "cosine", "nce", 0.1, 0.1, 0.1)

@@ -41,6 +41,22 @@ def main():
     train = WindowDataset.from_device_tables(Pre, 25, 1, lib, keys=["train"])
     val = WindowDataset.from_device_tables(Pre, 25, 1, lib, keys=["val"])
     out = tempfile.mkdtemp()
+    # time the training epochs of the fit from the outside (synchronised before and after each)
+    acc = {"steps": 0, "seconds": 0.0, "epochs": []}
+    orig_epoch = TR.VadeStepper.train_epoch
+
+    def timed_epoch(self, dataset, seed, shuffle=True):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        res = orig_epoch(self, dataset, seed, shuffle)
+        torch.cuda.synchronize()
+        dt_e = time.perf_counter() - t
+        acc["steps"] += self.log_steps
+        acc["seconds"] += dt_e
+        acc["epochs"].append(round(1e3 * dt_e / max(1, self.log_steps), 4))
+        return res
+
+    TR.VadeStepper.train_epoch = timed_epoch
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     _, _, _, logs = TR.train_deepof_model(
@@ -50,7 +66,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"model": args.model, "train_windows": len(train), "val_windows": len(val), "epochs": args.epochs,
-                      "teacher": not args.no_teacher, "wall_s": dt, "final_train_loss": float(logs["train"]["total_loss"][-1])}))
+                      "teacher": not args.no_teacher, "wall_s": dt, "final_train_loss": float(logs["train"]["total_loss"][-1]),
+                      "train_steps": acc["steps"], "train_ms_per_step": 1e3 * acc["seconds"] / max(1, acc["steps"]),
+                      "train_ms_per_step_by_epoch": acc["epochs"]}))
 
 
 if __name__ == "__main__":
