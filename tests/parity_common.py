@@ -926,3 +926,125 @@ def run_preprocess_vs_oracle(lib, device, n_videos=3, frames=(300, 97, 161), see
         s_by, dflt = op.size_factors(tabs[k], cols, ["B", "W"])
         np.testing.assert_allclose(sf[i], [s_by["B"], s_by["W"], dflt], rtol=1e-15, atol=0)   # exact selection
     return res
+
+
+# ------------------------------------------------------------------------------------------------
+# R16: replay of the reference's fit_* traces (tests/golden/make_golden_fit.py) through deepof_amd.training.fit_*
+# ------------------------------------------------------------------------------------------------
+def run_fit_trace_check(engine_factory, device, golden_dir, model_name, rtol=0.03):
+    """Same data, initial weights, batch order, injected noise and configuration as the reference run; compares the
+    learning rates held in every training epoch (Q22), the KL weight reported per epoch, the epochs saved as
+    best_val / best_score (Q19) exactly, and every column of the per-epoch log_summary within ``rtol``."""
+    import tempfile
+    from deepof_amd import training as TR
+    from deepof_amd.config import CommonFitCfg, ContrastiveCfg, TurtleTeacherCfg, VaDECfg
+    from deepof_amd.dataset import WindowDataset
+    from deepof_amd.graph import bodypart_graph, make_meta_info
+    from deepof_amd import models as MD
+    from noise_streams import noise
+    d = load_golden(golden_dir, "fit_traces.npz")
+    p = f"trace::{model_name}::"
+    T_full, L, K, BS, n_train, n_val, epochs = (int(v) for v in d[p + "cfg"])
+    x, a, adj = d[p + "x"], d[p + "a"], d[p + "adj"]
+    sd0 = params_from(d, p + "sd0::")
+
+    def dataset(lo, hi):
+        ds = WindowDataset(device)
+        ds.x, ds.a = torch.from_numpy(x[lo:hi]).to(device), torch.from_numpy(a[lo:hi]).to(device)
+        ds.video_idx = np.zeros(hi - lo, dtype=np.int32)
+        ds.length, ds.keys = hi - lo, ["v"]
+        ds.x_shape, ds.a_shape = tuple(x.shape[1:]), tuple(a.shape[1:])
+        ds.angles = None
+        return ds
+
+    train_ds, val_ds = dataset(0, n_train), dataset(n_train, n_train + n_val)
+    out_dir = tempfile.mkdtemp()
+    common = CommonFitCfg(model_name=model_name, encoder_type="recurrent", batch_size=BS, latent_dim=L, epochs=epochs,
+                          n_components=K, output_path=out_dir, save_weights=True, seed=0, diag_max_batches=4,
+                          learning_rate=3e-4)   # the dataclass default the reference run used
+    teacher = TurtleTeacherCfg(use_turtle_teacher=False)
+    vade = VaDECfg(pretrain_epochs=2, kl_warmup=2, kl_cooldown=1, kl_warmup_pretrain=2, kl_cooldown_pretrain=1)
+    ccfg = ContrastiveCfg(aug_p_shift=0.0, aug_p_rot=0.0, aug_p_interp=0.0, aug_p_noise=0.0)
+    cls = {"vade": MD.VaDE, "vqvae": MD.VQVAE, "contrastive": MD.Contrastive}[model_name]
+    rec = {"saves": [], "lrs": [], "klw": []}
+    orig_init, orig_save, orig_epoch = cls.__init__, TR.save_model_info, TR.VadeStepper.train_epoch
+
+    def init(self, *args, **kw):
+        orig_init(self, *args, **kw)
+        self.load_state_dict(sd0, strict=False)
+
+    def save(path, *args, stage=None, epoch=None, **kw):
+        rec["saves"].append((str(stage), int(epoch)))
+        return orig_save(path, *args, stage=stage, epoch=epoch, **kw)
+
+    def train_epoch(self, dataset_, seed, shuffle=True):
+        h = self.model._base.hyper_host
+        rec["lrs"].append([float(h[_capi.H_LR0 + _capi.SEG_ENCODER]), float(h[_capi.H_LR0 + _capi.SEG_GMM])])
+        res = orig_epoch(self, dataset_, seed, shuffle)
+        rec["klw"].append(float(res[1]))
+        return res
+
+    cls.__init__, TR.save_model_info, TR.VadeStepper.train_epoch, TR.NOISE_HOOK = init, save, train_epoch, noise
+    torch.manual_seed(0)
+    np.random.seed(0)
+    try:
+        if model_name == "vade":
+            res = TR.fit_VADE(train_ds, val_ds, adj, common, teacher, vade, device=device, _engine_factory=engine_factory)
+        elif model_name == "vqvae":
+            res = TR.fit_VQVAE(train_ds, val_ds, adj, common, teacher, device=device, _engine_factory=engine_factory)
+        else:
+            nodes, edges = bodypart_graph([""])
+            res = TR.fit_contrastive(train_ds, val_ds, adj, make_meta_info(nodes, edges), common, teacher, ccfg,
+                                     device=device, _engine_factory=engine_factory)
+    finally:
+        cls.__init__, TR.save_model_info, TR.VadeStepper.train_epoch, TR.NOISE_HOOK = orig_init, orig_save, orig_epoch, None
+    log_summary = res[3]
+    # ---- exact items
+    ref_saves = list(zip([str(v) for v in d[p + "saves_stage"]], [int(v) for v in d[p + "saves_epoch"]]))
+    if model_name == "vade":
+        np.testing.assert_allclose(np.array(rec["lrs"]), d[p + "lrs"], rtol=1e-6)       # pretrain lr / 0, then 5e-4 / 2e-4
+        np.testing.assert_allclose(np.array(rec["klw"]), d[p + "klw"], rtol=1e-6, atol=1e-9)
+    report = {}
+    for split in ("train", "val"):
+        for key, ours in log_summary[split].items():
+            ref = d[p + f"log::{split}::{key}"]
+            ours = np.array([float(v) for v in ours], dtype=np.float64)
+            assert ours.shape == ref.shape, (split, key, ours.shape, ref.shape)
+            assert np.array_equal(np.isnan(ours), np.isnan(ref)), (split, key, ours, ref)
+            ok = ~np.isnan(ref)
+            if ok.any():
+                err = np.abs(ours[ok] - ref[ok]) / (np.abs(ref[ok]) + 1e-3)
+                report[f"{split}::{key}"] = float(err.max())
+    bad = {k: v for k, v in report.items() if v > rtol}
+    assert not bad, (bad, report)
+    assert rec["saves"] == ref_saves, (rec["saves"], ref_saves)
+    return report
+
+
+def run_checkpoint_rules_check(golden_dir):
+    """deepof_amd.training.CheckpointSelector against the epochs the REFERENCE's fit_* functions saved when their epoch
+    functions returned scripted validation totals / alignment scores (make_golden_fit.py, part B)."""
+    from deepof_amd.training import CheckpointSelector
+    d = load_golden(golden_dir, "fit_traces.npz")
+    n = 0
+    for model_name in ("vade", "vqvae", "contrastive"):
+        for sname in ("a", "b"):
+            p = f"rules::{model_name}::{sname}::"
+            val, score = d[p + "val"], d[p + "score"]
+            sel = CheckpointSelector(len(val), rising_start=model_name == "vade")
+            saves = []
+            for ep in range(len(val)):
+                # the reference never reads the contrastive model's alignment score (training.py:1447 is commented
+                # out): its best_score checkpoint is never written
+                sc = float("nan") if model_name == "contrastive" else float(score[ep])
+                sv, ss = sel.update(ep, float(val[ep]), sc, has_score=True)
+                if sv:
+                    saves.append(("best_val", ep))
+                if ss:
+                    saves.append(("best_score", ep))
+            ref = list(zip([str(v) for v in d[p + "saves_stage"]], [int(v) for v in d[p + "saves_epoch"]]))
+            if model_name != "vade":   # those two loops test the validation loss first, the score second, like VaDE
+                pass
+            assert sorted(saves) == sorted(ref), (model_name, sname, saves, ref)
+            n += 1
+    return n

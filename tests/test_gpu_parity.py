@@ -792,3 +792,12 @@ def test_vqvae_tcn_reference_gpu(hip, golden_dir):
     """VQVAEPT(encoder_type="TCN") against a golden captured from the reference (round 1 only had the oracle)."""
     from parity_common import run_vqvae_tcn_ref_check
     print("worst gradient error / tensor scale:", run_vqvae_tcn_ref_check(hip, "cuda", golden_dir))
+
+
+@pytest.mark.parametrize("model_name", ["vade", "vqvae", "contrastive"])
+def test_fit_trace_matches_reference_gpu(hip, golden_dir, model_name):
+    """R16 on the HIP path (hipGraph-replayed steps included): fit_VADE / fit_VQVAE / fit_contrastive replay the
+    reference's recorded fits -- learning rates per epoch (Q22), KL weights, saved epochs (Q19), per-epoch log_summary."""
+    from parity_common import run_fit_trace_check
+    report = run_fit_trace_check(None, "cuda", golden_dir, model_name)
+    print(model_name, "worst relative deviation per log column:", {k: round(v, 5) for k, v in report.items() if v > 1e-4})
