@@ -720,3 +720,90 @@ def test_fit_trace_matches_reference_emu(golden_dir, model_name):
     from parity_common import run_fit_trace_check
     report = run_fit_trace_check(emu_factory, "cpu", golden_dir, model_name)
     print(model_name, "worst relative deviation per log column:", {k: round(v, 5) for k, v in report.items() if v > 1e-4})
+
+
+def test_posthoc_soft_counts_match_reference(golden_dir):
+    """N4: the gated GMM soft-count decoder and the reservoir sampler vs the reference's own functions
+    (post_hoc.py:1028-1172, 757-781) executed on synthetic embeddings (tests/golden/make_golden_posthoc.py)."""
+    from deepof_amd import soft_counts as SC
+    d = load_golden(golden_dir, "posthoc.npz")
+    lens = [int(v) for v in d["reservoir::lens"]]
+    segs, at = [], 0
+    for n in lens:
+        segs.append(d["reservoir::segs"][at:at + n])
+        at += n
+    np.testing.assert_array_equal(SC.reservoir_rows(segs, 50, seed=11), d["reservoir::out"])
+    for tag in ("single", "dist", "behav"):
+        p = f"{tag}::"
+        L, C, M, categorical, sample_size, smooth = (int(v) for v in d[p + "cfg"])
+        keys = [str(k) for k in d[p + "keys"]]
+        ng = int(d[p + "n_gates"])
+        emb = {k: d[p + f"emb::{k}"] for k in keys}
+        series = {k: {gi: d[p + f"series::{gi}::{k}"] for gi in range(ng)} for k in keys}
+        edges = {gi: d[p + f"edges::{gi}"] for gi in range(ng)} if (p + "edges::0") in d else None
+        if edges is not None:  # the quantile edges themselves (compute_gate_edges)
+            mine = SC.gate_edges_from_series(keys, series, list(range(ng)), M)
+            for gi in range(ng):
+                np.testing.assert_array_equal(mine[gi], edges[gi])
+        res = SC.contrastive_soft_counts_gmm(emb, gating_series=series, categorical_gates=bool(categorical),
+                                             n_clusters_per_gate=C, M_gates=M, gate_edges=edges, sample_size=sample_size,
+                                             random_state=0, temporal_smooth_win=smooth)
+        for gi in range(ng):
+            for k in keys:
+                ref = d[p + f"soft::{gi}::{k}"]
+                assert res[gi][k].shape == ref.shape == (emb[k].shape[0], M * C)
+                np.testing.assert_allclose(res[gi][k], ref, atol=2e-6, rtol=1e-5, err_msg=f"{tag} gate {gi} {k}")
+    with pytest.raises(NotImplementedError, match="deeptime"):
+        SC.contrastive_soft_counts({"v": np.zeros((20, 4), np.float32)}, method="msm")
+
+
+@pytest.mark.parametrize("kind", ["vade", "vqvae", "contrastive"])
+def test_embedding_per_video_emu(kind):
+    """N1: embedding_per_video over resident frame tables -- output shapes (frames - W + 1, L) / (.., K) per video
+    (reference tests/test_data.py:1014-1015), values against the CPU oracle on windows built by the oracle, ragged
+    chunks, a video shorter than one window."""
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    from deepof_amd.inference import embedding_per_video
+    from deepof_amd.models import Contrastive, VaDE, VQVAE
+    from deepof_amd.preprocess import PreprocessedTables
+    from oracle import vade as OV, vqvae as OQ, windows as OW
+    nodes, edges = bodypart_graph([""])
+    adj = adjacency_from_graph(nodes, edges)
+    N, E, W, L, K = len(nodes), len(edges), 12, 6, 5
+    rng = np.random.default_rng(4)
+    frames = {"a": 40, "b": 9, "c": 33}     # "b" is shorter than one window
+    off = np.concatenate([[0], np.cumsum(list(frames.values()))]).astype(np.int64)
+    nt = rng.standard_normal((int(off[-1]), 3 * N)).astype(np.float32)
+    et = rng.standard_normal((int(off[-1]), E)).astype(np.float32)
+    pre = PreprocessedTables(torch.from_numpy(nt), torch.from_numpy(et), None, off, list(frames), None,
+                             torch.zeros(3, 2, dtype=torch.float64), torch.zeros(3, 1, 2, dtype=torch.float64))
+    torch.manual_seed(5)
+    if kind == "vade":
+        model = VaDE((W, N, 3), (W, E, 1), adj, L, K, batch_size=16, _engine_factory=emu_factory)
+    elif kind == "vqvae":
+        model = VQVAE((W, N, 3), (W, E, 1), adj, L, K, batch_size=16, _engine_factory=emu_factory)
+    else:
+        model = Contrastive((2 * W, N, 3), (2 * W, E, 1), adj, latent_dim=L, batch_size=16, _engine_factory=emu_factory)
+    emb, soft = embedding_per_video(pre, model, chunk=16, states_per_gate=3, shard_videos=False, lib=emu_lib())
+    assert list(emb) == ["a", "c"] and list(soft) == ["a", "c"]
+    P = model._base.state_dict()
+    for key, i in (("a", 0), ("c", 2)):
+        lo, hi = int(off[i]), int(off[i + 1])
+        nw = hi - lo - W + 1
+        x, a = OW.gather_windows(nt[lo:hi], et[lo:hi], np.arange(nw), W)
+        x, a = torch.from_numpy(x), torch.from_numpy(a)
+        assert emb[key].shape == (nw, L)
+        with torch.no_grad():
+            if kind == "vade":
+                ref = OV.vade_forward(P, x, a, training=False)
+                np.testing.assert_allclose(emb[key], ref["z"].numpy(), atol=2e-5, rtol=1e-4)
+                np.testing.assert_allclose(soft[key], ref["q"].numpy(), atol=2e-5, rtol=1e-3)
+                assert soft[key].shape == (nw, K)
+            elif kind == "vqvae":
+                ref = OQ.vqvae_forward(P, x, a)
+                np.testing.assert_allclose(emb[key], ref["ze"].numpy(), atol=2e-5, rtol=1e-4)
+                np.testing.assert_allclose(soft[key], ref["soft_counts"].numpy(), atol=1e-5, rtol=2e-3)
+            else:
+                np.testing.assert_allclose(emb[key], OV.encoder(x, a, P).numpy(), atol=2e-5, rtol=1e-4)
+                assert soft[key].shape == (nw, 3)      # single animal: one gate, one bin, 3 states
+                np.testing.assert_allclose(soft[key].sum(axis=1), 1.0, atol=1e-5)
