@@ -801,3 +801,78 @@ def test_fit_trace_matches_reference_gpu(hip, golden_dir, model_name):
     from parity_common import run_fit_trace_check
     report = run_fit_trace_check(None, "cuda", golden_dir, model_name)
     print(model_name, "worst relative deviation per log column:", {k: round(v, 5) for k, v in report.items() if v > 1e-4})
+
+
+def test_cli_end_to_end_gpu(hip, tmp_path):
+    """J1 + N1 on the device: `python -m deepof_amd.cli` flags -> merged raw tables -> device preprocessing -> windows ->
+    deep_unsupervised_embedding (VaDE, 2 epochs) -> embedding_per_video: shapes (frames - W + 1, L) / (.., K) per video
+    (reference tests/test_data.py:1014-1015), soft counts normalised, and the embeddings equal to a direct eval forward."""
+    import pickle
+    from deepof_amd import cli
+    from deepof_amd.graph import bodypart_graph
+    from parity_common import synth_raw_tables
+    nodes, _ = bodypart_graph([""])
+    frames = (140, 101, 90, 77)
+    tabs, cols = synth_raw_tables(4, frames, list(nodes), seed=3)
+    path = tmp_path / "tables.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({"tables": tabs, "columns": cols}, f)
+    out = tmp_path / "out"
+    trained, emb, soft = cli.main(["-tp", str(path), "-embedding", "VaDE", "-encoder", "recurrent", "-k", "6", "-es", "8", "-bs", "64",
+                                   "-ws", "25", "-vn", "1", "-epochs", "2", "-o", str(out)])
+    model = trained[0]
+    assert sorted(emb) == sorted(tabs)
+    for key, n in zip(sorted(tabs), frames):
+        assert emb[key].shape == (n - 25 + 1, 8) and soft[key].shape == (n - 25 + 1, 6)
+        np.testing.assert_allclose(soft[key].sum(axis=1), 1.0, atol=1e-5)
+        assert np.isfinite(emb[key]).all()
+    assert any(f.endswith("_embeddings.pkl") for f in __import__("os").listdir(out / "Trained_models"))
+    assert model.window_size == 25 and str(model.encoder.spatial_gnn_block) == "CensNetConvPT()"
+
+
+@pytest.mark.parametrize("kind", ["vade", "vqvae", "contrastive"])
+def test_embedding_per_video_gpu(hip, kind):
+    """N1 on the device (graph-replayed chunks, ragged tails) vs the CPU oracle per video."""
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    from deepof_amd.inference import embedding_per_video
+    from deepof_amd.models import Contrastive, VaDE, VQVAE
+    from deepof_amd.preprocess import PreprocessedTables
+    from oracle import vade as OV, vqvae as OQ, windows as OW
+    nodes, edges = bodypart_graph([""])
+    adj = adjacency_from_graph(nodes, edges)
+    N, E, W, L, K = len(nodes), len(edges), 25, 8, 10
+    rng = np.random.default_rng(4)
+    frames = {"a": 700, "b": 20, "c": 333, "d": 410}     # "b" is shorter than one window
+    off = np.concatenate([[0], np.cumsum(list(frames.values()))]).astype(np.int64)
+    nt = rng.standard_normal((int(off[-1]), 3 * N)).astype(np.float32)
+    et = rng.standard_normal((int(off[-1]), E)).astype(np.float32)
+    pre = PreprocessedTables(torch.from_numpy(nt).cuda(), torch.from_numpy(et).cuda(), None, off, list(frames), None,
+                             torch.zeros(4, 2, dtype=torch.float64), torch.zeros(4, 1, 2, dtype=torch.float64))
+    torch.manual_seed(5)
+    if kind == "vade":
+        model = VaDE((W, N, 3), (W, E, 1), adj, L, K, batch_size=256)
+    elif kind == "vqvae":
+        model = VQVAE((W, N, 3), (W, E, 1), adj, L, K, batch_size=256)
+    else:
+        model = Contrastive((2 * W, N, 3), (2 * W, E, 1), adj, latent_dim=L, batch_size=256)
+    emb, soft = embedding_per_video(pre, model, chunk=256, states_per_gate=4)
+    assert list(emb) == ["a", "c", "d"]
+    P = model._base.state_dict()
+    for key, i in (("a", 0), ("c", 2), ("d", 3)):
+        lo, hi = int(off[i]), int(off[i + 1])
+        nw = hi - lo - W + 1
+        x, a = OW.gather_windows(nt[lo:hi], et[lo:hi], np.arange(nw), W)
+        x, a = torch.from_numpy(x), torch.from_numpy(a)
+        assert emb[key].shape == (nw, L)
+        with torch.no_grad():
+            if kind == "vade":
+                ref = OV.vade_forward(P, x, a, training=False)
+                np.testing.assert_allclose(emb[key], ref["z"].numpy(), atol=3e-5, rtol=1e-3)
+                np.testing.assert_allclose(soft[key], ref["q"].numpy(), atol=3e-5, rtol=2e-3)
+            elif kind == "vqvae":
+                ref = OQ.vqvae_forward(P, x, a)
+                np.testing.assert_allclose(emb[key], ref["ze"].numpy(), atol=3e-5, rtol=1e-3)
+                assert soft[key].shape == (nw, K)
+            else:
+                np.testing.assert_allclose(emb[key], OV.encoder(x, a, P).numpy(), atol=3e-5, rtol=1e-3)
+                assert soft[key].shape == (nw, 4)

@@ -807,3 +807,47 @@ def test_embedding_per_video_emu(kind):
                 np.testing.assert_allclose(emb[key], OV.encoder(x, a, P).numpy(), atol=2e-5, rtol=1e-4)
                 assert soft[key].shape == (nw, 3)      # single animal: one gate, one bin, 3 states
                 np.testing.assert_allclose(soft[key].sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_cli_flags_match_reference():
+    """J1: the 26 flags of deepof_train_embeddings.py:30-223 with their short forms and defaults."""
+    from deepof_amd.cli import build_parser
+    p = build_parser()
+    expected = {
+        ("--animal-ids", "-ids"): "", ("--animal-to-preprocess", "-idprep"): None, ("--arena-dims", "-adim"): 380,
+        ("--automatic-changepoints", "-ruptures"): "False", ("--batch-size", "-bs"): 128, ("--n-components", "-k"): 15,
+        ("--encoding-size", "-es"): 8, ("--embedding-model", "-embedding"): "VQVAE", ("--encoder-type", "-encoder"): "recurrent",
+        ("--exclude-bodyparts", "-exc"): "", ("--hpt-trials", "-n"): 25, ("--hyperparameter-tuning", "-tune"): False,
+        ("--hyperparameters", "-hp"): None, ("--input-type", "-d"): "graph", ("--output-path", "-o"): ".",
+        ("--kmeans-loss", "-kmeans"): 0.0, ("--cat-kl-loss", "-catkl"): 0.0, ("--smooth-alpha", "-sa"): 2,
+        ("--train-path", "-tp"): None, ("--val-num", "-vn"): 5, ("--window-size", "-ws"): 25, ("--window-step", "-wt"): 1,
+        ("--max-epochs", "-epochs"): 150, ("--load-project", "-load"): None, ("--run", "-rid"): 0,
+        ("--exp-condition-path", "-ec"): None}
+    got = {tuple(a.option_strings): a.default for a in p._actions if a.option_strings and a.option_strings[0] != "-h"}
+    assert got == expected
+    ns = p.parse_args(["-tp", "x.pkl", "-embedding", "VaDE", "-encoder", "TCN", "-k", "7"])
+    assert (ns.embedding_model, ns.encoder_type, ns.n_components) == ("VaDE", "TCN", 7)
+
+
+def test_deep_unsupervised_embedding_kwarg_mapping(monkeypatch, tmp_path):
+    """J1 / Q18: Coordinates.deep_unsupervised_embedding's mapping onto train_deepof_model (data.py:3362-3397):
+    save_weights <- save_checkpoints, output_path -> <project>/<output_path>/Trained_models, embedding_model ->
+    model_name, pretrained resolved under Trained_models/models, extra kwargs passed through."""
+    import deepof_amd.api as API
+    seen = {}
+    monkeypatch.setattr(API, "train_deepof_model", lambda **kw: seen.update(kw) or ("mv", "ms", None, {}))
+    out = API.deep_unsupervised_embedding(("tr", "va"), adjacency_matrix="adj", embedding_model="VQVAE", encoder_type="TCN",
+                                          batch_size=32, latent_dim=6, epochs=3, n_clusters=9, output_path="out",
+                                          save_checkpoints=False, save_weights=True, pretrained="vade/run_0/best_model_val.pth",
+                                          project_dir=str(tmp_path), meta_info={"m": 1}, use_turtle_teacher=False)
+    assert out == ("mv", "ms", None, {})
+    assert seen["save_weights"] is False                      # <- save_checkpoints, NOT the caller's save_weights
+    assert seen["model_name"] == "VQVAE" and seen["n_clusters"] == 9 and seen["latent_dim"] == 6
+    assert seen["output_path"] == str(tmp_path / "out" / "Trained_models")
+    assert seen["data_path"] == str(tmp_path / "Tables")
+    assert seen["pretrained"] == str(tmp_path / "Trained_models" / "models" / "vade/run_0/best_model_val.pth")
+    assert seen["meta_info"] == {"m": 1} and seen["use_turtle_teacher"] is False
+    assert "bin_size" not in seen and "input_type" not in seen
+    seen.clear()
+    API.deep_unsupervised_embedding(("tr", "va"), save_checkpoints=True, project_dir=str(tmp_path))
+    assert seen["save_weights"] is True and seen["pretrained"] is None and seen["kl_annealing_mode"] == "linear"
