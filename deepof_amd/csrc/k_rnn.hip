@@ -396,30 +396,47 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(const float* __restrict__ X, c
   float* __restrict__ gs = GS ? GS + (int64_t)dir * T * 4 * HID * Sp : nullptr;
   const int n = len[s];
   float h = 0.0f;
+  // The input half of the gates (W_ih x_t + b) does not depend on the recurrence: it is computed one step ahead, in the
+  // shadow of the dependent W_hh h_{t-1} chain and of the sigmoid / tanh latencies of the current step, and x of the
+  // step after that is already in flight (rocprof: 39 % issue stalls + 33 % memory waits in the one-step-at-a-time
+  // form, profiles/r02_gru_pmc.md).  Same operations in the same order per gate: bitwise the same result.
+  float in_r = br, in_z = bz, in_n = bin;
+  float xu_next = 0.0f;
+  constexpr bool WIDE = !BCAST && IN != G;
+  float xrow_next[WIDE ? IN : 4];
+  auto load_x = [&](int step) {
+    if (!BCAST && step < n) {
+      const int t = dir ? (n - 1 - step) : step;
+      if constexpr (WIDE) dof_ld_row<IN>(X + ACT(t, 0, IN, Sp, s), xrow_next);
+      else xu_next = X[ACT(t, u, IN, Sp, s)];
+    }
+  };
+  auto input_half = [&]() {  // gates' input half from the x held in xu_next / xrow_next
+    in_r = br; in_z = bz; in_n = bin;
+    if constexpr (WIDE) {  // wider input than the group: every lane holds the (group-uniform) input row
+#pragma unroll
+      for (int k = 0; k < IN; ++k) {
+        in_r = fmaf(wr[k], xrow_next[k], in_r);
+        in_z = fmaf(wz[k], xrow_next[k], in_z);
+        in_n = fmaf(wn[k], xrow_next[k], in_n);
+      }
+    } else if constexpr (!BCAST) {
+      const float xu = xu_next;
+      dof_static_for<IN>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const float b = dof_gbcast<k, G>(xu);
+        in_r = fmaf(wr[k], b, in_r);
+        in_z = fmaf(wz[k], b, in_z);
+        in_n = fmaf(wn[k], b, in_n);
+      });
+    }
+  };
+  load_x(0);
+  input_half();
+  load_x(1);
   for (int step = 0; step < n; ++step) {
     const int t = dir ? (n - 1 - step) : step;
-    float ar = br, az = bz, an = bin, ahn = bhn;
-    if (!BCAST) {
-      if (IN == G) {
-        const float xu = X[ACT(t, u, IN, Sp, s)];
-        dof_static_for<IN>([&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-          const float b = dof_gbcast<k, G>(xu);
-          ar = fmaf(wr[k], b, ar);
-          az = fmaf(wz[k], b, az);
-          an = fmaf(wn[k], b, an);
-        });
-      } else {  // wider input than the group: every lane reads the (group-uniform) input row
-        float xrow[IN];
-        dof_ld_row<IN>(X + ACT(t, 0, IN, Sp, s), xrow);
-#pragma unroll
-        for (int k = 0; k < IN; ++k) {
-          ar = fmaf(wr[k], xrow[k], ar);
-          az = fmaf(wz[k], xrow[k], az);
-          an = fmaf(wn[k], xrow[k], an);
-        }
-      }
-    }
+    float ar = in_r, az = in_z, an = in_n, ahn = bhn;
     dof_static_for<HID>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       const float b = dof_gbcast<k, G>(h);
@@ -427,6 +444,8 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(const float* __restrict__ X, c
       az = fmaf(hz[k], b, az);
       ahn = fmaf(hnw[k], b, ahn);
     });
+    if (step + 1 < n) input_half();   // next step's input half (x already loaded)
+    load_x(step + 2);
     const float r = dof_sigmoid(ar);
     const float z = dof_sigmoid(az);
     const float nn = dof_tanh(fmaf(r, ahn, an));
@@ -484,15 +503,31 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
   float dxacc[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) dxacc[m] = 0.0f;
-  for (int step = n - 1; step >= 0; --step) {
+  // loads of step - PF are issued before the arithmetic of step (see k_gru16_bwd_fused)
+  constexpr int PF = 3;
+  float nx_gate[PF][4], nx_hp[PF], nx_do[PF];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    nx_gate[d][0] = nx_gate[d][1] = nx_gate[d][2] = nx_gate[d][3] = 0.0f;
+    nx_hp[d] = nx_do[d] = 0.0f;
+  }
+  auto issue_loads = [&](auto slot_c, int step) {
+    constexpr int slot = decltype(slot_c)::value;
+    if (step >= 0) {
+      const int t = dir ? (n - 1 - step) : step;
+      const int tp = dir ? t + 1 : t - 1;
+      dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), nx_gate[slot]);
+      nx_hp[slot] = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
+      nx_do[slot] = dO ? dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
+    }
+  };
+  auto do_step = [&](auto slot_c, int step) {
+    constexpr int slot = decltype(slot_c)::value;
     const int t = dir ? (n - 1 - step) : step;
-    const int tp = dir ? t + 1 : t - 1;
-    float gate4[4];
-    dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), gate4);
-    const float r = gate4[0], z = gate4[1], nn = gate4[2], ahn = gate4[3];
-    const float hp = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
-    float dht = dh;
-    if (dO) dht += dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)];
+    const float r = nx_gate[slot][0], z = nx_gate[slot][1], nn = nx_gate[slot][2], ahn = nx_gate[slot][3];
+    const float hp = nx_hp[slot];
+    const float dht = dh + nx_do[slot];
+    issue_loads(slot_c, step - PF);
     const float dn = dht * (1.0f - z);
     const float dz = dht * (hp - nn);
     const float dnp = dn * (1.0f - nn * nn);
@@ -532,6 +567,13 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
 #pragma unroll
       for (int m = 0; m < M; ++m) dx_out[ACT(t, M * u + m, IN, Sp, s)] = dx[m];
     }
+  };
+  dof_static_for<PF>([&](auto d) { issue_loads(d, n - 1 - decltype(d)::value); });
+  for (int step = n - 1; step >= 0; step -= PF) {
+    dof_static_for<PF>([&](auto d) {
+      const int st = step - decltype(d)::value;
+      if (st >= 0) do_step(d, st);
+    });
   }
 #pragma unroll
   for (int m = 0; m < M; ++m) {
@@ -586,20 +628,42 @@ __global__ void __launch_bounds__(256) k_gru16_bwd_fused(
 #pragma unroll
   for (int a = 0; a < 6; ++a) acc[a] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float sb_r = 0.0f, sb_z = 0.0f, sb_n = 0.0f, sb_h = 0.0f;
-  for (int step = T - 1; step >= 0; --step) {
+  // Software pipeline, PF steps deep: the loads of step - PF (saved gates, h_{t-1}, x_t, dO_t: none of them depends
+  // on the recurrence) are issued before the arithmetic of step.  One step is ~230 VALU instructions (~0.3 us); a
+  // load from these 100 MB-class buffers, whose time steps lie megabytes apart, takes ~0.5 us -- measured: 0.85 us
+  // per step on the decoder's lightly loaded launch without prefetch distance (profiles/r02_gru_pmc.md: 52 % of
+  // the wave-cycles parked on memory at 2 waves per SIMD).  Register slots are static: the loop is unrolled by PF.
+  constexpr int PF = 3;
+  float nx_gate[PF][4], nx_hp[PF], nx_xu[PF], nx_do[PF];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    nx_gate[d][0] = nx_gate[d][1] = nx_gate[d][2] = nx_gate[d][3] = 0.0f;
+    nx_hp[d] = nx_xu[d] = nx_do[d] = 0.0f;
+  }
+  auto issue_loads = [&](auto slot_c, int step) {
+    constexpr int slot = decltype(slot_c)::value;
+    if (step >= 0 && step < n) {
+      const int t = dir ? (n - 1 - step) : step;
+      const int tp = dir ? t + 1 : t - 1;
+      dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), nx_gate[slot]);
+      nx_hp[slot] = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
+      nx_xu[slot] = X[ACT(t, u, IN, Sp, s)];
+      nx_do[slot] = dO ? dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
+    }
+  };
+  auto do_step = [&](auto slot_c, int step) {
+    constexpr int slot = decltype(slot_c)::value;
     const bool act = step < n;
     const int t = dir ? (n - 1 - step) : step;
-    const int tp = dir ? t + 1 : t - 1;
     float g_r = 0.0f, g_z = 0.0f, g_n = 0.0f, g_h = 0.0f, hp = 0.0f, xu = 0.0f, dht = 0.0f, z = 0.0f;
+    const float r = nx_gate[slot][0], zc = nx_gate[slot][1], nn = nx_gate[slot][2], ahn = nx_gate[slot][3];
+    const float hp_c = nx_hp[slot], xu_c = nx_xu[slot], do_c = nx_do[slot];
+    issue_loads(slot_c, step - PF);
     if (act) {
-      float gate4[4];
-      dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), gate4);
-      const float r = gate4[0], nn = gate4[2], ahn = gate4[3];
-      z = gate4[1];
-      hp = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
-      xu = X[ACT(t, u, IN, Sp, s)];
-      dht = dh;
-      if (dO) dht += dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)];
+      z = zc;
+      hp = hp_c;
+      xu = xu_c;
+      dht = dh + do_c;
       const float dn = dht * (1.0f - z);
       const float dz = dht * (hp - nn);
       const float dnp = dn * (1.0f - nn * nn);
@@ -635,6 +699,13 @@ __global__ void __launch_bounds__(256) k_gru16_bwd_fused(
       dh = dhp;
       dx_out[ACT(t, u, IN, Sp, s)] = dx;
     }
+  };
+  dof_static_for<PF>([&](auto d) { issue_loads(d, T - 1 - decltype(d)::value); });
+  for (int step = T - 1; step >= 0; step -= PF) {   // wave-uniform trip count (MFMA ignores EXEC)
+    dof_static_for<PF>([&](auto d) {
+      const int st = step - decltype(d)::value;
+      if (st >= 0) do_step(d, st);
+    });
   }
   if (in_range)
     for (int t = n; t < T; ++t) dx_out[ACT(t, u, IN, Sp, s)] = 0.0f;
