@@ -190,8 +190,11 @@ def contrastive_loss(z, z_aug, sim_kind="cosine", loss_fn="nce", temperature=0.1
 
 
 # ----------------------------------------------------------------------------- model + step
-def encode(P, x, a, training=True):
-    """ContrastivePT.forward = the recurrent or the TCN encoder on the half window (models_new.py:2038-2075)."""
+def encode(P, x, a, training=True, drop=None):
+    """ContrastivePT.forward = the recurrent, TCN or transformer encoder on the half window (models_new.py:2038-2075)."""
+    if "encoder.node_tf.embed.weight" in P:
+        from . import tfm as otf
+        return otf.tfm_encoder(x, a, P, training, drop)
     if "encoder.node_tcn.blocks.0.conv1.weight" in P:
         from . import tcn as ot
         return ot.tcn_encoder(x, a, P, training)
@@ -199,12 +202,12 @@ def encode(P, x, a, training=True):
 
 
 def contrastive_step(P, x_full, edge_index, draws: AugDraws, sim_kind="cosine", loss_fn="nce", temperature=0.1,
-                     tau=0.1, beta=0.1, training=True, distill=None):
+                     tau=0.1, beta=0.1, training=True, distill=None, drop=None):
     """training.py:482-589 without the distillation head.  Returns (total, logs, aux)."""
     x_aug, a_aug = augmented_view(x_full, edge_index, draws)
     x, a = central_view(x_full, edge_index)
-    z = encode(P, x, a, training)
-    z_aug = encode(P, x_aug, a_aug, training)
+    z = encode(P, x, a, training, drop)
+    z_aug = encode(P, x_aug, a_aug, training, drop)
     zn, zan = F.normalize(z, dim=1), F.normalize(z_aug, dim=1)
     loss, pos, neg = contrastive_loss(zn, zan, sim_kind, loss_fn, temperature, tau, beta)
     dist = 0.0

@@ -179,10 +179,16 @@ def recon_log_prob(loc: torch.Tensor, valid: torch.Tensor, x_flat: torch.Tensor)
 # full model + loss
 # --------------------------------------------------------------------------------------
 def vade_forward(P: Params, x: torch.Tensor, a: torch.Tensor, training: bool,
-                 eps: Optional[torch.Tensor] = None, kmeans_weight: float = 1.0):
-    """VaDEPT.forward, models_new.py:1841-1891.  Returns dict with loc/valid/z/q/z_mean/z_log_var/kmeans."""
+                 eps: Optional[torch.Tensor] = None, kmeans_weight: float = 1.0, drop=None):
+    """VaDEPT.forward, models_new.py:1841-1891.  Returns dict with loc/valid/z/q/z_mean/z_log_var/kmeans.
+    drop: oracle.tfm.DropoutTape (transformer family, train mode) or None."""
     B, T = x.shape[:2]
-    if "encoder.node_tcn.blocks.0.conv1.weight" in P:  # TCN family (models_new.py:518-819): BatchNorm follows `training`
+    if "encoder.node_tf.embed.weight" in P:  # transformer family (models_new.py:832-1327)
+        from . import tfm as otf
+        h = otf.tfm_encoder(x, a, P, training, drop)
+        lat = gmm_latent(h, P, training, eps, kmeans_weight)
+        loc, valid = otf.tfm_decoder(lat["z"], x.reshape(B, T, -1), P, training, drop)
+    elif "encoder.node_tcn.blocks.0.conv1.weight" in P:  # TCN family (models_new.py:518-819): BatchNorm follows `training`
         from . import tcn as ot
         h = ot.tcn_encoder(x, a, P, training)
         lat = gmm_latent(h, P, training, eps, kmeans_weight)
@@ -362,11 +368,11 @@ class AdamState:
 
 
 def vade_grads(P: Params, x, a, cfg: VadeLossCfg, klw: float, eps, eps_mc=None, tau_batch=None,
-               kmeans_weight: float = 1.0):
+               kmeans_weight: float = 1.0, drop=None):
     """Forward + loss + autograd.  Returns (loss dict, grads dict (None for unused params), out)."""
     keys = trainable_keys(P)
     leaf = {k: (P[k].detach().clone().requires_grad_(True) if k in keys else P[k]) for k in P}
-    out = vade_forward(leaf, x, a, training=True, eps=eps, kmeans_weight=kmeans_weight)
+    out = vade_forward(leaf, x, a, training=True, eps=eps, kmeans_weight=kmeans_weight, drop=drop)
     losses = vade_loss(out, x, leaf, cfg, klw, eps_mc, tau_batch)
     gl = torch.autograd.grad(losses["total_loss"], [leaf[k] for k in keys], allow_unused=True)
     return losses, dict(zip(keys, gl)), out

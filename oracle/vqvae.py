@@ -36,9 +36,17 @@ def vq_layer(ze: torch.Tensor, codebook: torch.Tensor, beta: float = 1.0, kmeans
 
 
 def vqvae_forward(P: Params, x: torch.Tensor, a: torch.Tensor, beta: float = 1.0, kmeans_weight: float = 0.0,
-                  training: bool = True):
+                  training: bool = True, drop=None):
     B, T = x.shape[:2]
     x_flat = x.reshape(B, T, -1)
+    if "encoder.node_tf.embed.weight" in P:  # transformer family: the two decoder passes draw their own dropout masks
+        from . import tfm as otf
+        ze = otf.tfm_encoder(x, a, P, training, drop)
+        vq = vq_layer(ze, P["vq_layer.codebook"], beta, kmeans_weight)
+        loc_q, valid = otf.tfm_decoder(vq["quantized"], x_flat, P, training, drop, site="dec")
+        loc_e, _ = otf.tfm_decoder(ze, x_flat, P, training, drop, site="dec2")
+        vq.update(ze=ze, loc_q=loc_q, loc_e=loc_e, valid=valid)
+        return vq
     if "encoder.node_tcn.blocks.0.conv1.weight" in P:  # TCN family: encoder, then the decoder on q, then on z_e
         from . import tcn as ot
         ze = ot.tcn_encoder(x, a, P, training)
@@ -84,11 +92,11 @@ def vqvae_loss(out: dict, x: torch.Tensor, distill=None):
                 distill_loss=dist)
 
 
-def vqvae_grads(P: Params, x, a, beta: float = 1.0, kmeans_weight: float = 0.0, distill=None):
+def vqvae_grads(P: Params, x, a, beta: float = 1.0, kmeans_weight: float = 0.0, distill=None, drop=None):
     """distill: dict(tau_b, lam, T, conf_weight, thr) -- the head weights are P["distill_head.fc.weight" / ".bias"]."""
     keys = OV.trainable_keys(P)
     leaf = {k: (P[k].detach().clone().requires_grad_(True) if k in keys else P[k]) for k in P}
-    out = vqvae_forward(leaf, x, a, beta, kmeans_weight)
+    out = vqvae_forward(leaf, x, a, beta, kmeans_weight, drop=drop)
     if distill is not None:
         distill = dict(distill, W=leaf["distill_head.fc.weight"], b=leaf["distill_head.fc.bias"])
     losses = vqvae_loss(out, x, distill)

@@ -583,3 +583,118 @@ def test_vqvae_tcn_matches_reference(golden_dir):
     for k in d:  # BatchNorm buffers after the train-mode step (encoder once, decoder twice)
         if k.startswith("sd_after::") and "running_" in k:
             np.testing.assert_allclose(P[k[len("sd_after::"):]].numpy(), d[k], atol=2e-6, rtol=2e-5, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer family (R17): oracle/tfm.py against the reference goldens of tests/golden/make_golden_tfm.py
+# ------------------------------------------------------------------------------------------------
+def _tape(d, prefix=""):
+    from oracle.tfm import DropoutTape
+    keys = sorted(k for k in d if k.startswith(prefix + "drop::"))
+    return DropoutTape([torch.from_numpy(d[k]) for k in keys])
+
+
+def _check_grads(d, grads, prefix, min_count, zero_names=("encoder.head.6.bias",)):
+    n = 0
+    for k in d:
+        if k.startswith(prefix + "grad::"):
+            name, ref = k.split("::")[-1], d[k]
+            scale = np.abs(ref).max()
+            got = grads[name].numpy()
+            if name in zero_names:  # a constant in front of the batch standardisation: rounding noise on both sides
+                assert scale < 1e-4 and np.abs(got).max() < 1e-4, name
+            else:
+                noise = float(d[prefix + "gnoise::" + name])
+                assert np.abs(got - ref).max() <= 2e-5 + 3e-4 * scale + 4 * noise, (prefix, name)
+            n += 1
+    assert n >= min_count, n
+
+
+def test_vade_tfm_matches_reference(golden_dir):
+    """VaDEPT(encoder_type="transformer"): eval forward (with padded keys / masked frames), two train steps on the
+    recorded dropout masks: every loss term, all gradients, BatchNorm buffers."""
+    d = _load(golden_dir, "vade_tfm14.npz")
+    x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
+    K, L = d["sd::latent_space.gmm_means"].shape
+    P0 = _params(d)
+    with torch.no_grad():
+        out = OV.vade_forward({k: v.clone() for k, v in P0.items()}, x, a, training=False)
+        outm = OV.vade_forward({k: v.clone() for k, v in P0.items()}, torch.from_numpy(d["xm"]), torch.from_numpy(d["am"]),
+                               training=False)
+    for o, pfx in ((out, "eval_"), (outm, "evalm_")):
+        np.testing.assert_allclose(o["z"].numpy(), d[pfx + "z"], atol=5e-6, rtol=1e-5)
+        np.testing.assert_allclose(o["q"].numpy(), d[pfx + "q"], atol=2e-6, rtol=2e-4)
+        np.testing.assert_allclose(o["loc"].numpy(), d[pfx + "loc"], atol=2e-5, rtol=1e-5)
+    assert np.abs(d["evalm_z"] - d["eval_z"]).max() > 1e-3  # the zeroed frames matter
+    eps, eps_mc, tau = (torch.from_numpy(d[k]) for k in ("eps", "eps_mc", "tau"))
+    for phase, klw, teacher in (("pre", 0.13, False), ("mainT", 0.7, True)):
+        P = {k: v.clone() for k, v in P0.items()}
+        kw = {}
+        if teacher:
+            pi = tau.mean(0).clamp_min(1e-8)
+            w = pi.pow(-1.0)
+            kw = dict(lambda_distill=1.7, class_weight=(w / w.mean()).clamp_max(3.0), teacher_marginal=pi)
+        tape = _tape(d, phase + "::")
+        losses, grads, out = OV.vade_grads(P, x, a, OV.VadeLossCfg(K, phase == "pre", **kw), klw, eps,
+                                           None if phase == "pre" else eps_mc, tau if teacher else None, drop=tape)
+        assert tape.pos == len(tape.masks) == 2 * 7 + 2 * 4
+        for k in d:
+            if k.startswith(f"{phase}::loss::") and k.split("::")[-1] in losses:
+                np.testing.assert_allclose(float(losses[k.split("::")[-1]]), float(d[k]), rtol=3e-5, atol=3e-6, err_msg=k)
+        np.testing.assert_allclose(out["z"].detach().numpy(), d[f"{phase}::z"], atol=2e-5, rtol=1e-4)
+        np.testing.assert_allclose(out["loc"].detach().numpy(), d[f"{phase}::loc"], atol=5e-5, rtol=1e-4)
+        _check_grads(d, grads, phase + "::", 100)
+        if phase == "pre":
+            for k in d:
+                if k.startswith("pre::sd_after::") and "running_" in k:
+                    np.testing.assert_allclose(P[k[len("pre::sd_after::"):]].numpy(), d[k], atol=2e-6, rtol=2e-5, err_msg=k)
+
+
+def test_vqvae_tfm_matches_reference(golden_dir):
+    from oracle import vqvae as OQ
+    d = _load(golden_dir, "vqvae_tfm14.npz")
+    x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
+    P0 = _params(d)
+    with torch.no_grad():
+        ev = OQ.vqvae_forward({k: v.clone() for k, v in P0.items()}, x, a, training=False)
+    np.testing.assert_array_equal(ev["idx"].numpy(), d["eval_idx"])
+    np.testing.assert_allclose(ev["ze"].numpy(), d["eval_ze"], atol=5e-6, rtol=1e-5)
+    np.testing.assert_allclose(ev["loc_q"].numpy(), d["eval_loc_q"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(ev["loc_e"].numpy(), d["eval_loc_e"], atol=2e-5, rtol=1e-5)
+    P = {k: v.clone() for k, v in P0.items()}
+    tape = _tape(d)
+    losses, grads, _ = OQ.vqvae_grads(P, x, a, 1.0, 0.0, drop=tape)
+    assert tape.pos == len(tape.masks) == 2 * 7 + 2 * 2 * 4
+    for k in ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss"):
+        np.testing.assert_allclose(float(losses[k]), float(d[f"log::{k}"]), rtol=3e-5, atol=3e-6, err_msg=k)
+    _check_grads(d, grads, "", 100)
+    for k in d:
+        if k.startswith("sd_after::") and "running_" in k:
+            np.testing.assert_allclose(P[k[len("sd_after::"):]].numpy(), d[k], atol=2e-6, rtol=2e-5, err_msg=k)
+
+
+def test_contrastive_tfm_matches_reference(golden_dir):
+    from oracle import contrastive as OC
+    d = _load(golden_dir, "contrastive_tfm14.npz")
+    P0 = _params(d)
+    x, a, xa, aa = (torch.from_numpy(d[k]) for k in ("x", "a", "x_aug", "a_aug"))
+    with torch.no_grad():
+        z = OC.encode({k: v.clone() for k, v in P0.items()}, x, a, training=False)
+    np.testing.assert_allclose(z.numpy(), d["eval_z"], atol=5e-6, rtol=1e-5)
+    buffers = ("laplacian", "edge_laplacian", "incidence", "running_mean", "running_var", "num_batches_tracked")
+    P = {k: (v.clone().requires_grad_(True) if k.split(".")[-1] not in buffers else v.clone()) for k, v in P0.items()}
+    tape = _tape(d)
+    z = OC.encode(P, x, a, True, tape)
+    za = OC.encode(P, xa, aa, True, tape)
+    assert tape.pos == len(tape.masks) == 2 * 2 * 7
+    np.testing.assert_allclose(z.detach().numpy(), d["z"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(za.detach().numpy(), d["z_aug"], atol=2e-5, rtol=1e-4)
+    loss, pos, neg = OC.contrastive_loss(torch.nn.functional.normalize(z, dim=1), torch.nn.functional.normalize(za, dim=1),
+                                         "cosine", "nce", 0.1, 0.1, 0.1)
+    np.testing.assert_allclose([float(loss), float(pos), float(neg)], d["loss"], rtol=3e-5, atol=3e-6)
+    names = [k for k, v in P.items() if v.requires_grad]
+    gs = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
+    _check_grads(d, dict(zip(names, gs)), "", 60)
+    for k in d:
+        if k.startswith("sd_after::") and "running_" in k:
+            np.testing.assert_allclose(P[k[len("sd_after::"):]].detach().numpy(), d[k], atol=2e-6, rtol=2e-5, err_msg=k)
