@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -80,6 +80,15 @@ SIGNATURES = {
     "dof_vade_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vade_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vqvae_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_vade_tfm_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_vqvae_tfm_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_contrastive_tfm_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
+    "dof_tfm_dropout_site_count": (_I32, [_P]),
+    "dof_tfm_dropout_site_name": (C.c_char_p, [_P, _I32]),
+    "dof_tfm_dropout_site_offset": (_I64, [_P, _I32]),
+    "dof_tfm_dropout_site_numel": (_I64, [_P, _I32]),
+    "dof_tfm_dropout_site_p": (C.c_float, [_P, _I32]),
+    "dof_tfm_set_dropout": (C.c_int, [_P, _P, C.c_uint32]),
     "dof_vade_plan_destroy": (None, [_P]),
     "dof_vade_param_count": (_I32, [_P]),
     "dof_vade_param_name": (C.c_char_p, [_P, _I32]),

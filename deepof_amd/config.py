@@ -160,6 +160,7 @@ _LOSSES = ("nce", "dcl", "dlc", "fc", "hard_dcl")  # the reference accepts the "
 
 SUPPORTED_LATENT_DIMS = (4, 6, 8)
 MAX_CONTRASTIVE_NODES = 64
+TRANSFORMER_KEY_DIMS = (24, 32, 40, 48, 64)
 
 
 def check_model_inputs(preprocessed_object, adjacency_matrix, meta_info, encoder_type, batch_size, latent_dim, epochs,
@@ -184,6 +185,12 @@ def check_model_inputs(preprocessed_object, adjacency_matrix, meta_info, encoder
         if int(latent_dim) not in SUPPORTED_LATENT_DIMS:
             raise NotImplementedError(f"latent_dim={latent_dim}: libdeepof_hip has plans for latent_dim in "
                                       f"{SUPPORTED_LATENT_DIMS}")
+        if str(encoder_type).lower() == "transformer":
+            # TFMEncoderPT's key_dim = min(64, 3 N) rounded down to a multiple of its 4 heads (models_new.py:1013-1019)
+            kd = max(4, min(64, 3 * int(adjacency_matrix.shape[0])) // 4 * 4)
+            if kd not in TRANSFORMER_KEY_DIMS:
+                raise NotImplementedError(f"transformer encoder: {adjacency_matrix.shape[0]} nodes give key_dim {kd}; "
+                                          f"libdeepof_hip has kernels for key_dim in {TRANSFORMER_KEY_DIMS}")
         if str(model_name).lower() == "contrastive" and adjacency_matrix.shape[0] > MAX_CONTRASTIVE_NODES:
             raise NotImplementedError(f"contrastive model: {adjacency_matrix.shape[0]} nodes, the view kernel "
                                       f"handles at most {MAX_CONTRASTIVE_NODES}")

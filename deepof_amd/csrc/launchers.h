@@ -90,6 +90,77 @@ int dof_launch_tcn_dec_out(const float* skip, const float* wp, const float* bp, 
 int dof_launch_head_rms_bwd(const float* dhn, const float* hn, const float* rinv, float* dflat, int J, int64_t B,
                             int64_t Bp, hipStream_t st);
 
+// ---- k_tfm.hip (transformer family, models_new.py:832-1327) -----------------------------------
+struct DofDrop {           // one dropout site
+  const uint8_t* inject;   // keep-mask bytes in the reference's tensor order (parity tests) or null
+  const uint32_t* ctr;     // device step counter mixed into the hash (fresh masks on every graph replay)
+  uint32_t seed;           // site seed
+  uint32_t thresh;         // keep iff hash >= thresh (= p * 2^32)
+  float scale;             // 1 / (1 - p); 0 = site disabled (eval mode)
+};
+enum { DOF_EPI_NONE = 0, DOF_EPI_RELU, DOF_EPI_GELU, DOF_EPI_MUL_RELU, DOF_EPI_MUL_DGELU };
+struct DofGemm {           // Y[r][n] (+)= epi(sum_k X[r][k] W[n][k] + bias[n]) over rows r = t*Sp + s, s < S
+  const float* X; int ldx;
+  const float* W; int ldw; // trans = 0: W[n*ldw + k]; trans = 1: W[k*ldw + n] (data gradients)
+  const float* bias;
+  float* Y; int ldy;
+  const float* aux; int ldaux;  // DOF_EPI_MUL_RELU: saved activation; DOF_EPI_MUL_DGELU: saved pre-activation
+  float* aux_out;               // DOF_EPI_GELU: pre-activation out (ld = ldy)
+  DofDrop drop; int drop_ld;    // GELU epilogues: dropout over (row, col), reference index (s*T + t)*drop_ld + col
+  int K, N, trans, epi, accumulate;
+  int T; int64_t S, Sp;
+};
+struct DofAttn {
+  const float* qkv;   // [r][3D]: q | k | v, head h at columns h*dh
+  float* ao;          // forward out [r][D]
+  const float* dao;   // backward in [r][D]
+  float* dqkv;        // backward out [r][3D]
+  const float* pad;   // [T][Sp] 1 = padded key, or null
+  DofDrop drop;
+  int T, D, H, causal, nseq;
+  float scale;
+  int64_t S, Sp;
+};
+struct DofLn {         // u = x + drop(h) (h may be null), y = LayerNorm(u) (gamma null: residual add only)
+  const float* x; const float* h; float* u; float* y; const float* gamma; const float* beta;
+  DofDrop drop; int T; int64_t S, Sp; float eps;
+};
+struct DofLnBwd {
+  const float* dy1; const float* dy2; const float* dres; const float* u; const float* gamma;
+  float* du; float* dh; float* partial; DofDrop drop; int T; int64_t S, Sp; float eps;
+};
+struct DofDecExp {     // TFMDecoderPT.latent_expand; per-window tensors [c][Bp]
+  const float* z; const float *w0, *b0, *w1, *b1, *w2, *b2;
+  float *a1, *g1, *a2, *g2, *a3, *g3;
+  int keep; int64_t B, Bp;
+};
+int dof_launch_tfm_tick(uint32_t* ctr, hipStream_t st);
+int dof_launch_tfm_embed(int F, const float* xin, const float* w, const float* bias, const float* pe, float* xs,
+                         float* pad, float* y, const DofDrop& drop, int T, int G, int D, int64_t S, int64_t Sp,
+                         hipStream_t st);
+int dof_launch_tfm_embed_bwd(int F, const float* xs, const float* w, const float* bias, const float* dy, float* dpre,
+                             const DofDrop& drop, int T, int D, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_tfm_gemm(const DofGemm& g, hipStream_t st);
+int dof_launch_tfm_attn(DofAttn a, int backward, hipStream_t st);
+int64_t dof_tfm_ln_blocks(int C, int T, int64_t Sp);
+int dof_launch_tfm_add_ln(const DofLn& a, int C, hipStream_t st);
+int dof_launch_tfm_ln_bwd(const DofLnBwd& a, int C, hipStream_t st);
+int dof_launch_tfm_last(const float* x, float* n2, int T, int D, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_tfm_last_bwd(const float* dn2, float* dx, int T, int D, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_tfm_bstd(const float* in, float* out, float* stat, int L, int standardize, int64_t B, int64_t Bp,
+                        hipStream_t st);
+int dof_launch_tfm_bstd_bwd(const float* dy, const float* y, const float* stat, float* dx, int L, int standardize,
+                            int64_t B, int64_t Bp, hipStream_t st);
+int dof_launch_tfm_dec_expand(int L, const DofDecExp& a, hipStream_t st);
+int dof_launch_tfm_dec_expand_bwd(int L, const DofDecExp& a, const float* dg3, float* da3, float* da2, float* da1,
+                                  float* dz, hipStream_t st);
+int dof_launch_tfm_dec_h0(const float* g3, const float* pe, float* h0, int T, int D, int64_t B, int64_t Bp,
+                          hipStream_t st);
+int dof_launch_tfm_dec_sum_time(const float* dh0, float* dg3, int T, int D, int64_t B, int64_t Bp, hipStream_t st);
+int dof_launch_tfm_dec_logp(const float* loc, int ld, const float* x, const float* valid, float* loc_out,
+                            float* recon_partial, float* dloc, int T, int C3, int train, int64_t B, int64_t Bp,
+                            hipStream_t st);
+
 // ---- k_reduce.hip ---------------------------------------------------------------------------
 // Weight-gradient reductions: out[i][j] = sum_{t,s} A[t][i][s] * B[t+shift][j][s] as fp32 MFMA
 // (16x16x4) tiles over SoA operands, many jobs per launch, per-block partials + fixed-order

@@ -116,6 +116,38 @@ struct StreamWs {  // float offsets into the workspace
   int64_t tri_r[5], tri_m[5], tri_o[5];  // ptr, m, o, r, coef for by-r / by-m / by-o orderings
 };
 
+struct TfmEncLayerOff { int64_t wqkv, wo, n1w, n1b, f0w, f0b, f2w, f2b, n2w, n2b; };
+struct TfmDecLayerOff { int64_t wqkv, wo, n1w, n1b, n2w, n2b, f0w, f0b, f3w, f3b; };
+struct TfmEncWs {  // one encoder stream; per-time-step tensors [t][s][C]
+  int64_t xs, pad, y0, qkv[2], ao[2], u1[2], x1[2], f1[2], u2[2], x2[2], tmp;
+  int64_t dA, dB, dAO, dH1[2], dH2[2], dF[2], dQKV[2], dE, lnp[4], ln_blocks;
+};
+struct TfmDecWs {
+  int64_t a1, g1, a2, g2, a3, g3, h0, xn1[2], qkv[2], ao[2], hmid[2], xn2[2], fpre[2], f[2], hout[2], tmp, o, loc, dloc;
+  int64_t dR[2], dB, dM, dAO, dH1[2], dH2[2], dF[2], dQKV[2], dO, dg3, da3, da2, da1, lnp[4], ln_blocks;
+};
+struct TfmSite {  // one dropout site of the transformer family
+  std::string name;
+  int64_t numel, offset;
+  float p;
+};
+struct TfmPlan {
+  int D = 0, H = 4, DFF = 128;  // encoder width (key_dim), heads, feed-forward width
+  int D4 = 0, HD = 8, C3p = 0;  // decoder width (4 L), heads, 3N padded to a multiple of 4
+  int64_t emb_w[2], emb_b[2];
+  TfmEncLayerOff el[2][2];      // [stream][layer]
+  int64_t le_w[3], le_b[3];     // decoder.latent_expand.{0,2,4}
+  TfmDecLayerOff dl[2];
+  int64_t out_w, out_b;         // decoder.output_proj
+  TfmEncWs ew[2];
+  TfmDecWs dw;
+  int64_t pe_enc = 0, pe_dec = 0, ctr = 0, enc_pre = 0, denc_pre = 0, bstat = 0;
+  const uint8_t* inject = nullptr;  // injected keep-masks (device), sites in dof_tfm_dropout_site_* order
+  uint32_t seed = 0x2545F491u;
+  std::vector<TfmSite> sites;
+  bool dec_second = false;      // the last decoder forward was the VQ-VAE's pass on the raw encoder output
+};
+
 }  // namespace
 
 struct JobSet {  // one launch of the MFMA weight-gradient reduction + its finalize
@@ -155,6 +187,8 @@ struct DofVadePlan {
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
   // TCN family (encoder: all kinds; decoder: kinds 0 / 1)
   bool tcn = false;
+  bool tfm = false;  // transformer family (TFMEncoderPT / TFMDecoderPT)
+  TfmPlan tf;
   int64_t dh_w = -1, dh_b = -1;          // generic distillation head distill_head.fc.{weight (K,L), bias (K)} (VQ-VAE / contrastive)
   int64_t dh_dl = 0, dh_dz = 0, dh_partial = 0, dh_zsrc = 0;
   bool dh_pending = false;               // contrastive: head weight gradients still to be written by the backward entry
@@ -193,12 +227,35 @@ void add_param(DofVadePlan* p, const std::string& name, int64_t numel, int64_t* 
 
 void add_latent_params(DofVadePlan* p);
 void add_distill_head(DofVadePlan* p);
+void build_tfm_param_layout(DofVadePlan* p);
+void build_tfm_workspace_layout(DofVadePlan* p);
+void build_tfm_jobs(DofVadePlan* p);
 
 void add_shaped(DofVadePlan* p, const std::string& name, std::vector<int64_t> shape, int64_t* off) {
   int64_t n = 1;
   for (int64_t d : shape) n *= d;
   add_param(p, name, n, off);
   p->params.back().shape = std::move(shape);
+}
+
+// encoder.head of the TCN and transformer encoders (models_new.py:593-601, 1074-1082): Linear -> ReLU -> BatchNorm ->
+// Linear -> ReLU -> BatchNorm -> Linear
+void add_head_params(DofVadePlan* p) {
+  const int L = p->L;
+  add_shaped(p, "encoder.head.0.weight", {2 * L, p->J}, &p->h0w);
+  add_shaped(p, "encoder.head.0.bias", {2 * L}, &p->h0b);
+  add_shaped(p, "encoder.head.2.weight", {2 * L}, &p->h2g);
+  add_shaped(p, "encoder.head.2.bias", {2 * L}, &p->h2b);
+  add_shaped(p, "encoder.head.2.running_mean", {2 * L}, &p->h2rm);
+  add_shaped(p, "encoder.head.2.running_var", {2 * L}, &p->h2rv);
+  add_shaped(p, "encoder.head.3.weight", {L, 2 * L}, &p->h3w);
+  add_shaped(p, "encoder.head.3.bias", {L}, &p->h3b);
+  add_shaped(p, "encoder.head.5.weight", {L}, &p->h5g);
+  add_shaped(p, "encoder.head.5.bias", {L}, &p->h5b);
+  add_shaped(p, "encoder.head.5.running_mean", {L}, &p->h5rm);
+  add_shaped(p, "encoder.head.5.running_var", {L}, &p->h5rv);
+  add_shaped(p, "encoder.head.6.weight", {L, L}, &p->h6w);
+  add_shaped(p, "encoder.head.6.bias", {L}, &p->h6b);
 }
 
 // ContrastivePT(encoder_type="TCN").state_dict() order (models_new.py:376-601); BatchNorm running buffers sit in
@@ -237,20 +294,7 @@ void build_tcn_param_layout(DofVadePlan* p) {
   add_shaped(p, "encoder.spatial_gnn_block.edge_weights", {C, 1}, &p->c_ew);
   add_shaped(p, "encoder.spatial_gnn_block.node_bias", {L}, &p->c_nb);
   add_shaped(p, "encoder.spatial_gnn_block.edge_bias", {L}, &p->c_eb);
-  add_shaped(p, "encoder.head.0.weight", {2 * L, p->J}, &p->h0w);
-  add_shaped(p, "encoder.head.0.bias", {2 * L}, &p->h0b);
-  add_shaped(p, "encoder.head.2.weight", {2 * L}, &p->h2g);
-  add_shaped(p, "encoder.head.2.bias", {2 * L}, &p->h2b);
-  add_shaped(p, "encoder.head.2.running_mean", {2 * L}, &p->h2rm);
-  add_shaped(p, "encoder.head.2.running_var", {2 * L}, &p->h2rv);
-  add_shaped(p, "encoder.head.3.weight", {L, 2 * L}, &p->h3w);
-  add_shaped(p, "encoder.head.3.bias", {L}, &p->h3b);
-  add_shaped(p, "encoder.head.5.weight", {L}, &p->h5g);
-  add_shaped(p, "encoder.head.5.bias", {L}, &p->h5b);
-  add_shaped(p, "encoder.head.5.running_mean", {L}, &p->h5rm);
-  add_shaped(p, "encoder.head.5.running_var", {L}, &p->h5rv);
-  add_shaped(p, "encoder.head.6.weight", {L, L}, &p->h6w);
-  add_shaped(p, "encoder.head.6.bias", {L}, &p->h6b);
+  add_head_params(p);
   p->seg_hi[DOF_SEG_ENCODER] = p->param_total;
   if (p->kind == 2) {
     for (int sg = DOF_SEG_DECODER; sg < DOF_SEG_COUNT; ++sg) p->seg_lo[sg] = p->seg_hi[sg] = p->param_total;
@@ -311,6 +355,7 @@ void add_gru(DofVadePlan* p, const std::string& prefix, int in, int hid, GruOff*
 }
 
 void build_param_layout(DofVadePlan* p) {
+  if (p->tfm) return build_tfm_param_layout(p);
   if (p->tcn) return build_tcn_param_layout(p);
   const int L = p->L, N = p->N, E = p->E, K = p->K;
   const char* bn[2] = {"encoder.node_recurrent_block", "encoder.edge_recurrent_block"};
@@ -443,6 +488,27 @@ void take_triplets(DofVadePlan* p, Carver& cv, int s) {
   }
 }
 
+void take_head_buffers(DofVadePlan* p, Carver& cv) {
+  const int L = p->L;
+  const int64_t Bp = p->Bp;
+  p->hd_hn = cv.take((int64_t)p->J * Bp);
+  p->hd_rinv = cv.take(Bp);
+  p->hd_h1 = cv.take(2LL * L * Bp);
+  p->hd_n1 = cv.take(2LL * L * Bp);
+  p->hd_h2 = cv.take((int64_t)L * Bp);
+  p->hd_n2 = cv.take((int64_t)L * Bp);
+  p->hd_bnp1 = cv.take(8 * L);
+  p->hd_bnp2 = cv.take(4 * L);
+  p->hd_partial = cv.take(2LL * L * p->lat_blocks * 2);
+  p->hd_sums = cv.take(4 * L);
+  p->hd_coef = cv.take(4 * L);
+  p->hd_dn2 = cv.take((int64_t)L * Bp);
+  p->hd_dpre2 = cv.take((int64_t)L * Bp);
+  p->hd_dn1 = cv.take(2LL * L * Bp);
+  p->hd_dpre1 = cv.take(2LL * L * Bp);
+  p->hd_dhn = cv.take((int64_t)p->J * Bp);
+}
+
 void build_tcn_workspace_layout(DofVadePlan* p) {
   const int L = p->L, T = p->T, D = p->D;
   Carver cv;
@@ -492,22 +558,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
   p->cl_rowstat = cv.take(4 * p->B);
   p->cl_theta = cv.take(p->B);
   p->cl_partial = cv.take(3 * p->cl_blocks);
-  p->hd_hn = cv.take((int64_t)p->J * Bp);
-  p->hd_rinv = cv.take(Bp);
-  p->hd_h1 = cv.take(2LL * L * Bp);
-  p->hd_n1 = cv.take(2LL * L * Bp);
-  p->hd_h2 = cv.take((int64_t)L * Bp);
-  p->hd_n2 = cv.take((int64_t)L * Bp);
-  p->hd_bnp1 = cv.take(8 * L);
-  p->hd_bnp2 = cv.take(4 * L);
-  p->hd_partial = cv.take(2LL * L * p->lat_blocks * 2);
-  p->hd_sums = cv.take(4 * L);
-  p->hd_coef = cv.take(4 * L);
-  p->hd_dn2 = cv.take((int64_t)L * Bp);
-  p->hd_dpre2 = cv.take((int64_t)L * Bp);
-  p->hd_dn1 = cv.take(2LL * L * Bp);
-  p->hd_dpre1 = cv.take(2LL * L * Bp);
-  p->hd_dhn = cv.take((int64_t)p->J * Bp);
+  take_head_buffers(p, cv);
   if (p->kind != 2) {
     take_latent_buffers(p, cv);
     TcnDecWs& d = p->td;
@@ -545,6 +596,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
 }
 
 void build_workspace_layout(DofVadePlan* p) {
+  if (p->tfm) return build_tfm_workspace_layout(p);
   if (p->tcn) return build_tcn_workspace_layout(p);
   const int L = p->L, T = p->T, K = p->K, S = p->S;
   Carver cv;
@@ -779,6 +831,40 @@ void cens_jobs(DofVadePlan* p, JobBuilder& jb, int s) {
   jb.add_fin(job, 0, D, 1, D, D, dotw, 1, 1);
 }
 
+// encoder head of the TCN / transformer families: Linear(J -> 2L), Linear(2L -> L), Linear(L -> L) (+ the VaDE
+// latent heads); the gradient of the head output is ws.denc (TCN) or the buffer in front of the batch standardisation
+void head_jobs(DofVadePlan* p, JobBuilder& jb) {
+  const int L = p->L;
+  float* ws = p->ws;
+  const int64_t Bp = p->Bp;
+  const float* dout = ws + (p->tfm ? p->tf.denc_pre : p->denc);
+  for (int r0 = 0; r0 < p->J; r0 += 64) {
+    const int rows = p->J - r0 < 64 ? p->J - r0 : 64;
+    const int job = jb.add_job(soa(ws + p->hd_hn, Bp, r0), rows, 1, Bp);
+    jb.add_tile(job, soa(ws + p->hd_dpre1, Bp), 2 * L, 0);
+    jb.add_fin(job, 0, rows, 2 * L, rows, rows, p->h0w + r0, 1, p->J);
+  }
+  int job = jb.add_job(soa(ws + p->hd_dpre1, Bp), 2 * L, 1, Bp);
+  jb.add_tile(job, soa(ws + p->hd_dpre1, Bp), 1, 0);
+  jb.add_fin(job, 64, 2 * L, 1, 2 * L, 2 * L, p->h0b, 1, 1);
+  job = jb.add_job(soa(ws + p->hd_dpre2, Bp), L, 1, Bp);
+  jb.add_tile(job, soa(ws + p->hd_n1, Bp), 2 * L, 0);
+  jb.add_fin(job, 0, L, 2 * L, L, L, p->h3w, 2 * L, 1);
+  jb.add_fin(job, 64, L, 1, L, L, p->h3b, 1, 1);
+  job = jb.add_job(soa(dout, Bp), L, 1, Bp);
+  jb.add_tile(job, soa(ws + p->hd_n2, Bp), L, 0);
+  jb.add_fin(job, 0, L, L, L, L, p->h6w, L, 1);
+  jb.add_fin(job, 64, L, 1, L, L, p->h6b, 1, 1);
+  if (p->kind == 0) {  // VaDE latent heads (as in the recurrent family)
+    job = jb.add_job(soa(ws + p->dmu_dpre, Bp), 2 * L, 1, Bp);
+    jb.add_tile(job, soa(ws + p->enc, Bp), L, 0);
+    jb.add_fin(job, 0, L, L, L, L, p->mean_w, L, 1);
+    jb.add_fin(job, 0, L, L, 0, L, p->lv_w, L, 1);
+    jb.add_fin(job, 64, L, 1, L, L, p->mean_b, 1, 1);
+    jb.add_fin(job, 64, L, 1, 0, L, p->lv_b, 1, 1);
+  }
+}
+
 const int kTcnDil[8] = {1, 2, 4, 8, 1, 2, 4, 8};
 
 void build_tcn_jobs(DofVadePlan* p) {
@@ -833,32 +919,7 @@ void build_tcn_jobs(DofVadePlan* p) {
     }
     cens_jobs(p, jb, s);
   }
-  // head: Linear(J -> 2L), Linear(2L -> L), Linear(L -> L)
-  for (int r0 = 0; r0 < p->J; r0 += 64) {
-    const int rows = p->J - r0 < 64 ? p->J - r0 : 64;
-    const int job = jb.add_job(soa(ws + p->hd_hn, Bp, r0), rows, 1, Bp);
-    jb.add_tile(job, soa(ws + p->hd_dpre1, Bp), 2 * L, 0);
-    jb.add_fin(job, 0, rows, 2 * L, rows, rows, p->h0w + r0, 1, p->J);
-  }
-  int job = jb.add_job(soa(ws + p->hd_dpre1, Bp), 2 * L, 1, Bp);
-  jb.add_tile(job, soa(ws + p->hd_dpre1, Bp), 1, 0);
-  jb.add_fin(job, 64, 2 * L, 1, 2 * L, 2 * L, p->h0b, 1, 1);
-  job = jb.add_job(soa(ws + p->hd_dpre2, Bp), L, 1, Bp);
-  jb.add_tile(job, soa(ws + p->hd_n1, Bp), 2 * L, 0);
-  jb.add_fin(job, 0, L, 2 * L, L, L, p->h3w, 2 * L, 1);
-  jb.add_fin(job, 64, L, 1, L, L, p->h3b, 1, 1);
-  job = jb.add_job(soa(ws + p->denc, Bp), L, 1, Bp);
-  jb.add_tile(job, soa(ws + p->hd_n2, Bp), L, 0);
-  jb.add_fin(job, 0, L, L, L, L, p->h6w, L, 1);
-  jb.add_fin(job, 64, L, 1, L, L, p->h6b, 1, 1);
-  if (p->kind == 0) {  // VaDE latent heads (as in the recurrent family)
-    job = jb.add_job(soa(ws + p->dmu_dpre, Bp), 2 * L, 1, Bp);
-    jb.add_tile(job, soa(ws + p->enc, Bp), L, 0);
-    jb.add_fin(job, 0, L, L, L, L, p->mean_w, L, 1);
-    jb.add_fin(job, 0, L, L, 0, L, p->lv_w, L, 1);
-    jb.add_fin(job, 64, L, 1, L, L, p->mean_b, 1, 1);
-    jb.add_fin(job, 64, L, 1, 0, L, p->lv_b, 1, 1);
-  }
+  head_jobs(p, jb);
   jb.close(p->js_enc);
   if (p->kind == 2) return;
   // ---- TCN decoder (the latent input only enters through hn, so one job set serves both VQ passes)
@@ -938,6 +999,7 @@ void build_tcn_jobs(DofVadePlan* p) {
 }
 
 void build_jobs(DofVadePlan* p) {
+  if (p->tfm) return build_tfm_jobs(p);
   if (p->tcn) return build_tcn_jobs(p);
   const int L = p->L, T = p->T;
   float* ws = p->ws;
@@ -1083,6 +1145,18 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     else if (_l == 4 && _d == 32) DOF_LAUNCH((NAME<4, 32>), GRID, (256), st, __VA_ARGS__);             \
     else if (_l == 6 && _d == 32) DOF_LAUNCH((NAME<6, 32>), GRID, (256), st, __VA_ARGS__);             \
     else if (_l == 8 && _d == 32) DOF_LAUNCH((NAME<8, 32>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 4 && _d == 24) DOF_LAUNCH((NAME<4, 24>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 6 && _d == 24) DOF_LAUNCH((NAME<6, 24>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 8 && _d == 24) DOF_LAUNCH((NAME<8, 24>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 4 && _d == 40) DOF_LAUNCH((NAME<4, 40>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 6 && _d == 40) DOF_LAUNCH((NAME<6, 40>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 8 && _d == 40) DOF_LAUNCH((NAME<8, 40>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 4 && _d == 48) DOF_LAUNCH((NAME<4, 48>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 6 && _d == 48) DOF_LAUNCH((NAME<6, 48>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 8 && _d == 48) DOF_LAUNCH((NAME<8, 48>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 4 && _d == 64) DOF_LAUNCH((NAME<4, 64>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 6 && _d == 64) DOF_LAUNCH((NAME<6, 64>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 8 && _d == 64) DOF_LAUNCH((NAME<8, 64>), GRID, (256), st, __VA_ARGS__);             \
     else { dof_set_error("CensNet (latent %d, channels %d) not supported by this build", _l, _d); return DOF_ERR_UNSUPPORTED; } \
   } while (0)
 
@@ -1092,9 +1166,18 @@ int censnet_forward(DofVadePlan* p, const float* params, hipStream_t st) {
   // CensNet: node update is weighted by edge dot products (edge_weights) and vice versa
   const StreamWs& wn = p->sw[0];
   const StreamWs& we = p->sw[1];
-  if (p->D == 32) {
-    DOF_LAUNCH((k_cens_dots<32>), (dof_cdiv(wn.S, 256)), (256), st, (const float*)(ws + wn.n2), params + p->c_nw, ws + wn.dots, wn.S, wn.Sp);
-    DOF_LAUNCH((k_cens_dots<32>), (dof_cdiv(we.S, 256)), (256), st, (const float*)(ws + we.n2), params + p->c_ew, ws + we.dots, we.S, we.Sp);
+  if (p->D == 32 || p->D == 24 || p->D == 40 || p->D == 48 || p->D == 64) {
+    for (int s = 0; s < 2; ++s) {
+      const StreamWs& w = s ? we : wn;
+      const float* pw = params + (s ? p->c_ew : p->c_nw);
+      switch (p->D) {
+        case 24: DOF_LAUNCH((k_cens_dots<24>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
+        case 32: DOF_LAUNCH((k_cens_dots<32>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
+        case 40: DOF_LAUNCH((k_cens_dots<40>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
+        case 48: DOF_LAUNCH((k_cens_dots<48>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
+        default: DOF_LAUNCH((k_cens_dots<64>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
+      }
+    }
   } else {
     LDISPATCH(p->L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(wn.S, 256)), (256), st, (const float*)(ws + wn.n2),
                                params + p->c_nw, ws + wn.dots, wn.S, wn.Sp));
@@ -1116,12 +1199,48 @@ int censnet_forward(DofVadePlan* p, const float* params, hipStream_t st) {
 }
 
 int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const float* a, bool train, hipStream_t st);
+int tfm_encoder_forward(DofVadePlan* p, float* params, const float* x, const float* a, bool train, hipStream_t st);
+
+// RMS-guarded BatchNorm MLP head of the TCN / transformer encoders: ws.flat -> out [L][Bp].  train: batch statistics,
+// running buffers inside `params` updated.
+int head_forward(DofVadePlan* p, float* params, bool train, float* out, hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L;
+  const int64_t B = p->B, Bp = p->Bp;
+  TRY(dof_launch_head_rms(ws + p->flat, ws + p->hd_hn, ws + p->hd_rinv, p->J, B, Bp, st));
+  TRY(dof_launch_head_dense(ws + p->hd_hn, nullptr, nullptr, params + p->h0w, params + p->h0b, ws + p->hd_h1,
+                            ws + p->hd_partial, ws + p->hd_sums, p->J, 2 * L, 1, B, Bp, st));
+  TRY(dof_launch_bn_fwd_fin(ws + p->hd_sums, (float)B, params + p->h2g, params + p->h2b, params + p->h2rm,
+                            params + p->h2rv, 0.01f, train, ws + p->hd_bnp1, 2 * L, st));
+  TRY(dof_launch_head_dense(ws + p->hd_h1, ws + p->hd_bnp1, ws + p->hd_n1, params + p->h3w, params + p->h3b,
+                            ws + p->hd_h2, ws + p->hd_partial, ws + p->hd_sums, 2 * L, L, 1, B, Bp, st));
+  TRY(dof_launch_bn_fwd_fin(ws + p->hd_sums, (float)B, params + p->h5g, params + p->h5b, params + p->h5rm,
+                            params + p->h5rv, 0.01f, train, ws + p->hd_bnp2, L, st));
+  return dof_launch_head_dense(ws + p->hd_h2, ws + p->hd_bnp2, ws + p->hd_n2, params + p->h6w, params + p->h6b, out,
+                               nullptr, nullptr, L, L, 0, B, Bp, st);
+}
+
+// ... and its backward from dout [L][Bp] (gradient of the head output) down to ws.dflat
+int head_backward(DofVadePlan* p, const float* params, float* grads, int accumulate, const float* dout, hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L;
+  const int64_t B = p->B, Bp = p->Bp;
+  TRY(dof_launch_head_dense_bwd(dout, params + p->h6w, ws + p->hd_dn2, L, L, B, Bp, st));
+  TRY(dof_launch_head_bn_bwd(ws + p->hd_dn2, ws + p->hd_h2, ws + p->hd_bnp2, ws + p->hd_partial, ws + p->hd_sums,
+                             ws + p->hd_coef, grads + p->h5g, grads + p->h5b, accumulate, ws + p->hd_dpre2, L, B, Bp, st));
+  TRY(dof_launch_head_dense_bwd(ws + p->hd_dpre2, params + p->h3w, ws + p->hd_dn1, 2 * L, L, B, Bp, st));
+  TRY(dof_launch_head_bn_bwd(ws + p->hd_dn1, ws + p->hd_h1, ws + p->hd_bnp1, ws + p->hd_partial, ws + p->hd_sums,
+                             ws + p->hd_coef, grads + p->h2g, grads + p->h2b, accumulate, ws + p->hd_dpre1, 2 * L, B, Bp, st));
+  TRY(dof_launch_head_dense_bwd(ws + p->hd_dpre1, params + p->h0w, ws + p->hd_dhn, p->J, 2 * L, B, Bp, st));
+  return dof_launch_head_rms_bwd(ws + p->hd_dhn, ws + p->hd_hn, ws + p->hd_rinv, ws + p->dflat, p->J, B, Bp, st);
+}
 
 // Both encoder families leave the L-dimensional encoder output in ws.enc when `with_output` (the recurrent family's
 // final dense layer is launched by the latent / VQ / contrastive callers otherwise -- kept as is).
 int encoder_forward(DofVadePlan* p, const float* params, const float* x, const float* a, bool train,
                     hipStream_t st) {
   // the TCN family refreshes its BatchNorm running buffers (stored in the parameter buffer) in train mode
+  if (p->tfm) return tfm_encoder_forward(p, const_cast<float*>(params), x, a, train, st);
   if (p->tcn) return tcn_encoder_forward(p, const_cast<float*>(params), x, a, train, st);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
@@ -1177,23 +1296,12 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     }
   }
   TRY(censnet_forward(p, params, st));
-  const int64_t B = p->B, Bp = p->Bp;
-  TRY(dof_launch_head_rms(ws + p->flat, ws + p->hd_hn, ws + p->hd_rinv, p->J, B, Bp, st));
-  TRY(dof_launch_head_dense(ws + p->hd_hn, nullptr, nullptr, params + p->h0w, params + p->h0b, ws + p->hd_h1,
-                            ws + p->hd_partial, ws + p->hd_sums, p->J, 2 * L, 1, B, Bp, st));
-  TRY(dof_launch_bn_fwd_fin(ws + p->hd_sums, (float)B, params + p->h2g, params + p->h2b, params + p->h2rm,
-                            params + p->h2rv, 0.01f, train, ws + p->hd_bnp1, 2 * L, st));
-  TRY(dof_launch_head_dense(ws + p->hd_h1, ws + p->hd_bnp1, ws + p->hd_n1, params + p->h3w, params + p->h3b,
-                            ws + p->hd_h2, ws + p->hd_partial, ws + p->hd_sums, 2 * L, L, 1, B, Bp, st));
-  TRY(dof_launch_bn_fwd_fin(ws + p->hd_sums, (float)B, params + p->h5g, params + p->h5b, params + p->h5rm,
-                            params + p->h5rv, 0.01f, train, ws + p->hd_bnp2, L, st));
-  return dof_launch_head_dense(ws + p->hd_h2, ws + p->hd_bnp2, ws + p->hd_n2, params + p->h6w, params + p->h6b,
-                               ws + p->enc, nullptr, nullptr, L, L, 0, B, Bp, st);
+  return head_forward(p, params, train, ws + p->enc, st);
 }
 
 // encoder.final_dense of the recurrent family (flat -> enc); the TCN head has already produced ws.enc
 int final_dense_fwd(DofVadePlan* p, const float* params, hipStream_t st) {
-  if (p->tcn) return DOF_OK;
+  if (p->tcn || p->tfm) return DOF_OK;
   float* ws = p->ws;
   DOF_LAUNCH(k_final_dense, (dof_cdiv(p->B, 256), (unsigned)p->L), (256), st, (const float*)(ws + p->flat),
              params + p->fd_w, params + p->fd_b, ws + p->enc, p->J, p->B, p->Bp);
@@ -1201,7 +1309,7 @@ int final_dense_fwd(DofVadePlan* p, const float* params, hipStream_t st) {
 }
 // ... and its data gradient (denc -> dflat); the TCN encoder backward starts from ws.denc itself
 int final_dense_bwd(DofVadePlan* p, const float* params, hipStream_t st) {
-  if (p->tcn) return DOF_OK;
+  if (p->tcn || p->tfm) return DOF_OK;
   float* ws = p->ws;
   LDISPATCH(p->L, DOF_LAUNCH((k_final_dense_bwd<LL>), (dof_cdiv(p->B, 256), (unsigned)p->J), (256), st,
                              (const float*)(ws + p->denc), params + p->fd_w, ws + p->dflat, p->J, p->B, p->Bp));
@@ -1333,8 +1441,16 @@ int tcn_decoder_backward(DofVadePlan* p, const float* params, float* grads, int 
   return run_jobset(p, p->js_dec[0], grads, accumulate, st);
 }
 
+int tfm_decoder_forward(DofVadePlan* p, const float* params, const float* x, const float* zin, float* recon_partial,
+                        bool train, float* loc_out, bool second, hipStream_t st);
+int tfm_decoder_backward(DofVadePlan* p, const float* params, int which_input, float* grads, int accumulate,
+                         hipStream_t st);
+int tfm_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st, int accumulate);
+
 int decoder_forward(DofVadePlan* p, const float* params, const float* x, const float* zin, float* recon_partial,
                     bool train, float* loc_out, hipStream_t st) {
+  if (p->tfm)
+    return tfm_decoder_forward(p, params, x, zin, recon_partial, train, loc_out, p->kind == 1 && zin == p->ws + p->enc, st);
   if (p->tcn) return tcn_decoder_forward(p, const_cast<float*>(params), x, zin, recon_partial, train, loc_out, st);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
@@ -1361,6 +1477,7 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, const f
 // accumulated), gradient wrt the latent input into ws.dzdec ([2][L][Bp], one slab per GRU direction).
 int decoder_backward(DofVadePlan* p, const float* params, int which_input, float* grads, int accumulate,
                      hipStream_t st) {
+  if (p->tfm) return tfm_decoder_backward(p, params, which_input, grads, accumulate, st);
   if (p->tcn) return tcn_decoder_backward(p, params, grads, accumulate, st);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
@@ -1419,14 +1536,7 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
   const int L = p->L, T = p->T;
   const int64_t B = p->B, Bp = p->Bp;
   // head: Linear <- BN <- ReLU <- Linear <- BN <- ReLU <- Linear <- RMS scale
-  TRY(dof_launch_head_dense_bwd(ws + p->denc, params + p->h6w, ws + p->hd_dn2, L, L, B, Bp, st));
-  TRY(dof_launch_head_bn_bwd(ws + p->hd_dn2, ws + p->hd_h2, ws + p->hd_bnp2, ws + p->hd_partial, ws + p->hd_sums,
-                             ws + p->hd_coef, grads + p->h5g, grads + p->h5b, accumulate, ws + p->hd_dpre2, L, B, Bp, st));
-  TRY(dof_launch_head_dense_bwd(ws + p->hd_dpre2, params + p->h3w, ws + p->hd_dn1, 2 * L, L, B, Bp, st));
-  TRY(dof_launch_head_bn_bwd(ws + p->hd_dn1, ws + p->hd_h1, ws + p->hd_bnp1, ws + p->hd_partial, ws + p->hd_sums,
-                             ws + p->hd_coef, grads + p->h2g, grads + p->h2b, accumulate, ws + p->hd_dpre1, 2 * L, B, Bp, st));
-  TRY(dof_launch_head_dense_bwd(ws + p->hd_dpre1, params + p->h0w, ws + p->hd_dhn, p->J, 2 * L, B, Bp, st));
-  TRY(dof_launch_head_rms_bwd(ws + p->hd_dhn, ws + p->hd_hn, ws + p->hd_rinv, ws + p->dflat, p->J, B, Bp, st));
+  TRY(head_backward(p, params, grads, accumulate, ws + p->denc, st));
   TRY(censnet_backward(p, params, st));
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
@@ -1457,6 +1567,7 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
 
 // Backward of CensNet + both recurrent encoder streams from ws.dflat; fills the encoder gradients.
 int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st, int accumulate = 0) {
+  if (p->tfm) return tfm_encoder_backward(p, params, grads, st, accumulate);
   if (p->tcn) return tcn_encoder_backward(p, params, grads, st, accumulate);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
@@ -1493,13 +1604,15 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
   return run_jobset(p, p->js_enc, grads, accumulate, st);
 }
 
+#include "tfm_plan.inc.h"
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static int plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
-                       const float* incidence, int kind, DofVadePlan** out, bool tcn = false) {
+                       const float* incidence, int kind, DofVadePlan** out, bool tcn = false, bool tfm = false) {
   if (dims->batch <= 0 || dims->window < 5 || dims->n_nodes <= 0 || dims->n_edges <= 0 || dims->n_clusters <= 0 ||
       dims->mc_samples <= 0) {
     dof_set_error("plan_create: bad dims (batch %d window %d nodes %d edges %d clusters %d)", dims->batch,
@@ -1518,11 +1631,28 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
   p->d = *dims;
   p->kind = kind;
   p->tcn = tcn;
+  p->tfm = tfm;
   p->L = dims->latent; p->K = dims->n_clusters; p->T = dims->window; p->N = dims->n_nodes; p->E = dims->n_edges;
   p->S = dims->mc_samples; p->B = dims->batch; p->Bp = dof_pad64(p->B);
   p->J = (p->N + p->E) * p->L;
   p->C3 = 3 * p->N;
   p->D = tcn ? 32 : 2 * p->L;
+  if (tfm) {  // TFMEncoderPT.__init__ (models_new.py:1013-1019): key_dim from the NODE feature count for both streams
+    TfmPlan& tf = p->tf;
+    int kd = 3 * p->N < 64 ? 3 * p->N : 64;
+    kd = kd / tf.H * tf.H;
+    if (kd < tf.H) kd = tf.H;
+    tf.D = kd;
+    tf.D4 = 4 * p->L;
+    tf.C3p = (p->C3 + 3) / 4 * 4;
+    p->D = kd;
+    if (p->T > 64 || (kd != 24 && kd != 32 && kd != 40 && kd != 48 && kd != 64)) {
+      dof_set_error("transformer plan: window %d (max 64) / key_dim %d (24, 32, 40, 48, 64) not supported by this build", p->T, kd);
+      delete p;
+      return DOF_ERR_UNSUPPORTED;
+    }
+    build_tfm_sites(p);
+  }
   build_param_layout(p);
   build_triplets(p, laplacian, edge_laplacian, incidence);
   build_workspace_layout(p);
@@ -1556,6 +1686,50 @@ extern "C" int dof_vqvae_tcn_plan_create(const DofVadeDims* dims, const float* l
     return DOF_ERR_ARG;
   }
   return plan_create(dims, laplacian, edge_laplacian, incidence, 1, out, true);
+}
+
+// transformer family (models_new.py:832-1327)
+extern "C" int dof_vade_tfm_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                        const float* incidence, DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_vade_tfm_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  return plan_create(dims, laplacian, edge_laplacian, incidence, 0, out, false, true);
+}
+extern "C" int dof_vqvae_tfm_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                         const float* incidence, DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_vqvae_tfm_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  return plan_create(dims, laplacian, edge_laplacian, incidence, 1, out, false, true);
+}
+extern "C" int dof_contrastive_tfm_plan_create(const DofVadeDims* dims, const float* laplacian,
+                                               const float* edge_laplacian, const float* incidence,
+                                               DofVadePlan** out) {
+  if (!dims || !laplacian || !edge_laplacian || !incidence || !out) {
+    dof_set_error("dof_contrastive_tfm_plan_create: null argument");
+    return DOF_ERR_ARG;
+  }
+  DofVadeDims d = *dims;
+  if (d.n_clusters <= 0) d.n_clusters = 1;
+  if (d.mc_samples <= 0) d.mc_samples = 1;
+  return plan_create(&d, laplacian, edge_laplacian, incidence, 2, out, false, true);
+}
+extern "C" int32_t dof_tfm_dropout_site_count(const DofVadePlan* p) { return p ? (int32_t)p->tf.sites.size() : 0; }
+extern "C" const char* dof_tfm_dropout_site_name(const DofVadePlan* p, int32_t i) { return p->tf.sites[i].name.c_str(); }
+extern "C" int64_t dof_tfm_dropout_site_offset(const DofVadePlan* p, int32_t i) { return p->tf.sites[i].offset; }
+extern "C" int64_t dof_tfm_dropout_site_numel(const DofVadePlan* p, int32_t i) { return p->tf.sites[i].numel; }
+extern "C" float dof_tfm_dropout_site_p(const DofVadePlan* p, int32_t i) { return p->tf.sites[i].p; }
+extern "C" int dof_tfm_set_dropout(DofVadePlan* p, const uint8_t* inject_masks, uint32_t seed) {
+  if (!p || !p->tfm) {
+    dof_set_error("dof_tfm_set_dropout: not a transformer plan");
+    return DOF_ERR_ARG;
+  }
+  p->tf.inject = inject_masks;
+  p->tf.seed = seed;
+  return DOF_OK;
 }
 
 extern "C" void dof_vade_plan_destroy(DofVadePlan* plan) { delete plan; }
@@ -1641,6 +1815,24 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
       up(t[3], th.r.data(), th.r.size() * 4);
       up(t[4], th.coef.data(), th.coef.size() * 4);
     }
+  if (p->tfm) {  // sinusoidal positional encodings (models_new.py:832-840), fp32 like the reference's buffer
+    static thread_local std::vector<float> pe;
+    auto table = [&](int d, size_t at) {
+      for (int t = 0; t < p->T; ++t)
+        for (int c = 0; c < d; ++c) {
+          const float div = expf((float)(c & ~1) * (float)(-std::log(10000.0) / (double)d));
+          const float arg = (float)t * div;
+          pe[at + (size_t)t * d + c] = (c & 1) ? cosf(arg) : sinf(arg);
+        }
+    };
+    pe.assign((size_t)p->T * (p->tf.D + p->tf.D4), 0.0f);
+    table(p->tf.D, 0);
+    up(p->tf.pe_enc, pe.data(), (size_t)p->T * p->tf.D * 4);
+    if (p->kind != 2) {
+      table(p->tf.D4, (size_t)p->T * p->tf.D);
+      up(p->tf.pe_dec, pe.data() + (size_t)p->T * p->tf.D, (size_t)p->T * p->tf.D4 * 4);
+    }
+  }
   DofAdamSeg segs[DOF_SEG_COUNT];
   for (int i = 0; i < DOF_SEG_COUNT; ++i) {
     segs[i].lo = p->seg_lo[i]; segs[i].hi = p->seg_hi[i];
@@ -1673,7 +1865,7 @@ extern "C" int dof_vade_forward(DofVadePlan* p, const float* params, const float
   hipStream_t st = (hipStream_t)stream;
   // TCN family: a train-mode forward (eps given) normalises with batch statistics and refreshes the running
   // buffers, as module.train() does in the reference; the recurrent family has no such state
-  const bool bn_train = p->tcn && eps != nullptr;
+  const bool bn_train = (p->tcn || p->tfm) && eps != nullptr;
   TRY(encoder_forward(p, params, x, a, bn_train, st));
   TRY(latent_forward(p, params, prior, eps, z_out, q_out, zmean_out, zlogvar_out, enc_out, st));
   if (loc_out) TRY(decoder_forward(p, params, x, p->ws + p->z, p->ws + p->recon_partial, bn_train, loc_out, st));

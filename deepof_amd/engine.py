@@ -70,12 +70,15 @@ class VadeEngine:
         self.B, self.T, self.L, self.K, self.S = int(batch), int(window), int(latent_dim), int(n_clusters), int(mc_samples)
         dims = _capi.VadeDims(self.B, self.T, self.N, self.E, self.L, self.K, self.S)
         plan = C.c_void_p()
-        assert kind in ("vade", "vqvae", "contrastive", "contrastive_tcn", "vade_tcn", "vqvae_tcn")
+        assert kind in ("vade", "vqvae", "contrastive", "contrastive_tcn", "vade_tcn", "vqvae_tcn", "vade_tfm",
+                        "vqvae_tfm", "contrastive_tfm")
         self.kind = kind
         create = {"vade": lib.dof_vade_plan_create, "vqvae": lib.dof_vqvae_plan_create,
                   "contrastive": lib.dof_contrastive_plan_create,
                   "contrastive_tcn": lib.dof_contrastive_tcn_plan_create,
-                  "vade_tcn": lib.dof_vade_tcn_plan_create, "vqvae_tcn": lib.dof_vqvae_tcn_plan_create}[kind]
+                  "vade_tcn": lib.dof_vade_tcn_plan_create, "vqvae_tcn": lib.dof_vqvae_tcn_plan_create,
+                  "vade_tfm": lib.dof_vade_tfm_plan_create, "vqvae_tfm": lib.dof_vqvae_tfm_plan_create,
+                  "contrastive_tfm": lib.dof_contrastive_tfm_plan_create}[kind]
         _capi.check(lib, create(C.byref(dims), self.lap.ctypes.data, self.elap.ctypes.data, self.inc.ctypes.data,
                                 C.byref(plan)), "dof_*_plan_create")
         self.plan = plan
@@ -186,6 +189,35 @@ class VadeEngine:
         self.bn_training = bool(training)
         _capi.check(self.lib, self.lib.dof_vade_set_batchnorm_training(self.plan, 1 if training else 0),
                     "dof_vade_set_batchnorm_training")
+
+    # ------------------------------------------------------------------ dropout (transformer family)
+    def dropout_sites(self):
+        """[(site name, byte offset, numel, p)] of a transformer plan in the order the reference's forward draws its
+        dropout masks (embedding, then per layer: attention weights, the two residual dropouts; the decoder's four per
+        layer); empty for the other families."""
+        lib, plan = self.lib, self.plan
+        return [(lib.dof_tfm_dropout_site_name(plan, i).decode(), lib.dof_tfm_dropout_site_offset(plan, i),
+                 lib.dof_tfm_dropout_site_numel(plan, i), lib.dof_tfm_dropout_site_p(plan, i))
+                for i in range(lib.dof_tfm_dropout_site_count(plan))]
+
+    def set_dropout(self, masks: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0x2545F491):
+        """Dropout source of a transformer plan.  masks=None: keep-masks come from the on-device counter hash seeded
+        with ``seed`` (a fresh mask set per train-mode step).  masks={site name: 0/1 tensor in the reference's tensor
+        shape}: those masks are used instead (parity tests replay the reference's recorded draws)."""
+        inject = None
+        if masks is not None:
+            sites = self.dropout_sites()
+            total = sum(n for _, _, n, _ in sites)
+            buf = torch.ones(total, dtype=torch.uint8)
+            for name, off, numel, _p in sites:
+                if name in masks:
+                    m = torch.as_tensor(masks[name]).reshape(-1)
+                    assert m.numel() == numel, (name, m.numel(), numel)
+                    buf[off:off + numel] = m.to(torch.uint8)
+            inject = buf.to(self.device)
+        self._drop_inject = inject  # keeps the device buffer alive while the plan points at it
+        _capi.check(self.lib, self.lib.dof_tfm_set_dropout(self.plan, None if inject is None else inject.data_ptr(),
+                                                           int(seed) & 0xFFFFFFFF), "dof_tfm_set_dropout")
 
     def _count_bn(self, prefix: str, n: int):
         """num_batches_tracked of the BatchNorm layers under ``prefix`` after n train-mode passes."""

@@ -111,13 +111,53 @@ def _reset_tcn_family(model: nn.Module, latent_dim: int):
             b.zero_()
 
 
-def _encoder_family(encoder_type) -> bool:
-    """True for the TCN family; raises for encoders this build does not have."""
+@torch.no_grad()
+def _reset_tfm_family(model: nn.Module, latent_dim: int):
+    """Initialisers of the transformer family: every Linear of the encoder cores / head and of the whole decoder is
+    xavier-uniform with zero bias (models_new.py:858-859, 909-912, 941-942, 1085-1088, 1227-1231, 1297-1302), LayerNorm
+    and BatchNorm identity, CensNet as censNetConv_pt.py:62-84, GMM xavier-normal, latent heads nn.Linear default."""
+    params = dict(model.named_parameters())
+    for name, p in params.items():
+        leaf = name.split(".")[-1]
+        if ".norm" in name or name.startswith("encoder.head.2") or name.startswith("encoder.head.5"):
+            p.fill_(1.0 if leaf == "weight" else 0.0)
+        elif "spatial_gnn_block" in name:
+            if leaf in ("node_kernel", "edge_kernel", "node_weights", "edge_weights"):
+                nn.init.xavier_uniform_(p)
+            else:
+                bound = 1.0 / math.sqrt(latent_dim)
+                p.uniform_(-bound, bound)
+        elif name in ("latent_space.gmm_means", "latent_space.gmm_log_vars"):
+            nn.init.xavier_normal_(p)
+        elif name == "vq_layer.codebook":
+            p.uniform_(0.0, 1.0)
+        elif name.startswith("latent_space."):  # nn.Linear default: U(+-1/sqrt(fan_in))
+            w = p if leaf == "weight" else params[name[: -len("bias")] + "weight"]
+            fan_in = int(np.prod(w.shape[1:]))
+            p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+        elif leaf == "weight":
+            nn.init.xavier_uniform_(p)
+        else:
+            p.zero_()
+    for name, b in model.named_buffers():
+        if name.endswith("running_mean"):
+            b.zero_()
+        elif name.endswith("running_var"):
+            b.fill_(1.0)
+        elif name.endswith("num_batches_tracked"):
+            b.zero_()
+
+
+_FAMILY_SUFFIX = {"recurrent": "", "tcn": "_tcn", "transformer": "_tfm"}
+_FAMILY_NAME = {"recurrent": "recurrent", "tcn": "TCN", "transformer": "transformer"}
+
+
+def _encoder_family(encoder_type) -> str:
+    """"recurrent", "tcn" or "transformer" (the reference's three encoder_type values, any case)."""
     enc = str(encoder_type).lower()
-    if enc not in ("recurrent", "tcn"):
-        raise NotImplementedError(f"encoder_type={encoder_type!r}: this build implements the recurrent and the TCN "
-                                  "encoder/decoder (the transformer variant is SURVEY.md section 8a row R17)")
-    return enc == "tcn"
+    if enc not in _FAMILY_SUFFIX:
+        raise NotImplementedError(f'invalid encoder type {encoder_type!r}, try "recurrent", "TCN" or "transformer"')
+    return enc
 
 
 class VaDE(nn.Module):
@@ -126,9 +166,9 @@ class VaDE(nn.Module):
                  interaction_regularization: float = 0.0, lens_enabled: bool = False, batch_size: int = 256,
                  device=None, _engine_factory: Optional[Callable[..., VadeEngine]] = None):
         super().__init__()
-        self._tcn = _encoder_family(encoder_type)
-        if self._tcn:
-            self._KIND = "vade_tcn"
+        self._family = _encoder_family(encoder_type)
+        self._tcn = self._family != "recurrent"  # BatchNorm head + lazily built CensNet (quirk Q11): TCN and transformer
+        self._KIND = "vade" + _FAMILY_SUFFIX[self._family]
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
         time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
@@ -139,7 +179,7 @@ class VaDE(nn.Module):
         self.input_n_features_per_node = n_feat
         self.latent_dim = int(latent_dim)
         self.n_components = int(n_components)
-        self.encoder_type = "TCN" if self._tcn else "recurrent"
+        self.encoder_type = _FAMILY_NAME[self._family]
         self.kmeans_weight = float(kmeans_loss)
         self.lens_enabled = False
         self._adjacency = np.asarray(adjacency_matrix, dtype=np.float32)
@@ -169,6 +209,11 @@ class VaDE(nn.Module):
     def _make_engine(self, batch: int, shared):
         eng = self._factory(batch=batch, window=self.window_size, adjacency=self._adjacency,
                             latent_dim=self.latent_dim, n_clusters=self.n_components, shared=shared, kind=self._KIND)
+        if getattr(self, "_family", "") == "transformer":
+            # dropout masks: counter hash on the device, seeded from torch's generator (torch.manual_seed reproduces a run)
+            if not hasattr(self, "_dropout_seed"):
+                self._dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            eng.set_dropout(None, seed=self._dropout_seed + 7919 * len(getattr(self, "_engines", {})))
         if getattr(self, "_tcn", False):
             eng.set_bn_training(self.training)
             if not getattr(self, "censnet_in_optimizer", False):
@@ -217,6 +262,8 @@ class VaDE(nn.Module):
     # ------------------------------------------------------------------ init (PyTorch default inits of the reference)
     @torch.no_grad()
     def reset_parameters(self):
+        if getattr(self, "_family", "") == "transformer":
+            return _reset_tfm_family(self, self.latent_dim)
         if getattr(self, "_tcn", False):
             return _reset_tcn_family(self, self.latent_dim)
         for name, p in self.named_parameters():
@@ -328,15 +375,15 @@ class VQVAE(VaDE):
                  interaction_regularization: float = 0.0, beta: float = 1.0, batch_size: int = 256, device=None,
                  _engine_factory=None):
         nn.Module.__init__(self)
-        self._tcn = _encoder_family(encoder_type)
-        if self._tcn:
-            self._KIND = "vqvae_tcn"
+        self._family = _encoder_family(encoder_type)
+        self._tcn = self._family != "recurrent"
+        self._KIND = "vqvae" + _FAMILY_SUFFIX[self._family]
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
         time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
         self.window_size, self.input_n_nodes, self.input_n_features_per_node = time_steps, n_nodes, n_feat
         self.latent_dim, self.n_components = int(latent_dim), int(n_components)
-        self.encoder_type, self.beta, self.kmeans_weight = ("TCN" if self._tcn else "recurrent"), float(beta), float(kmeans_loss)
+        self.encoder_type, self.beta, self.kmeans_weight = _FAMILY_NAME[self._family], float(beta), float(kmeans_loss)
         self._adjacency = np.asarray(adjacency_matrix, dtype=np.float32)
         self._factory = _engine_factory or (lambda **kw: create_vade_engine(device=device, **kw))
         self._engines = {}
@@ -409,8 +456,9 @@ class Contrastive(VaDE):
                  interaction_regularization: float = 0.0, batch_size: int = 256, device=None, _engine_factory=None,
                  n_components: int = 1):
         nn.Module.__init__(self)
-        self._tcn = _encoder_family(encoder_type)
-        self._KIND = "contrastive_tcn" if self._tcn else "contrastive"
+        self._family = _encoder_family(encoder_type)
+        self._tcn = self._family != "recurrent"
+        self._KIND = "contrastive" + _FAMILY_SUFFIX[self._family]
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is not implemented (the reference trainer always passes True)")
         time_steps, n_nodes, n_feat = (int(v) for v in input_shape)
@@ -421,7 +469,7 @@ class Contrastive(VaDE):
         self.input_shape, self.edge_feature_shape = tuple(input_shape), tuple(edge_feature_shape)
         self.input_n_nodes, self.input_n_features_per_node = n_nodes, n_feat
         self.latent_dim, self.n_components = int(latent_dim), max(1, int(n_components))  # K of the distillation head
-        self.encoder_type, self.use_gnn = ("TCN" if self._KIND == "contrastive_tcn" else "recurrent"), True
+        self.encoder_type, self.use_gnn = _FAMILY_NAME[self._family], True
         self.temperature, self.similarity_function, self.loss_function = float(temperature), similarity_function, loss_function
         self.beta, self.tau = float(beta), float(tau)
         self.interaction_regularization = interaction_regularization
@@ -452,7 +500,7 @@ class Contrastive(VaDE):
         statistics and refreshes the running buffers, as the reference module does; eval() uses the buffers."""
         x = x.to(self.device, torch.float32).contiguous()
         a = a.to(self.device, torch.float32).contiguous()
-        return self.engine(x.shape[0]).contrastive_encode(x, a, train=self.training and self._KIND == "contrastive_tcn")
+        return self.engine(x.shape[0]).contrastive_encode(x, a, train=self.training and self._tcn)
 
     @torch.no_grad()
     def embed(self, x, a):

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 9
+#define DOF_ABI_VERSION 10
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -101,6 +101,34 @@ int dof_vade_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, co
                              const float* incidence, DofVadePlan** out);
 int dof_vqvae_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
                               const float* incidence, DofVadePlan** out);
+
+/* Transformer family (models_new.py:832-1327: TFMEncoderPT = per-node / per-edge TransformerCorePT (2 post-norm
+ * layers, 4 heads, key_dim = min(64, 3N) rounded down to a multiple of 4, ffn 128, last time step) -> CensNet ->
+ * BatchNorm MLP head -> train-time batch standardisation; TFMDecoderPT = latent-expand MLP -> repeat + positional
+ * encoding -> 2 causal pre-norm layers (8 heads, width 4L, GELU ffn 128) -> Linear(4L -> 3N) -> loc projection):
+ * same entry points as the other plans, parameters in VaDEPT / VQVAEPT / ContrastivePT(encoder_type="transformer")
+ * .state_dict() order.  The BatchNorm running buffers of encoder.head are entries of the flat buffer as for the TCN
+ * family; dof_vade_set_batchnorm_training(0) also switches dropout and the batch standardisation off (module.eval()).
+ * This build: window <= 64, key_dim in {24, 32, 40, 48, 64}. */
+int dof_vade_tfm_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                             const float* incidence, DofVadePlan** out);
+int dof_vqvae_tfm_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                              const float* incidence, DofVadePlan** out);
+int dof_contrastive_tfm_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
+                                    const float* incidence, DofVadePlan** out);
+/* Dropout of a transformer plan (nn.Dropout / the attention-weight dropout of scaled_dot_product_attention,
+ * models_new.py:884, 898, 906, 937, 1290-1294, 1318): the sites in the order the reference's forward draws them,
+ * each a tensor of `numel` elements in the reference's shape ((sequences, T, width) or (sequences, heads, T, T)).
+ * Default source: keep iff hash(seed, site, device step counter, element index) >= p * 2^32, evaluated inside the
+ * kernels in forward and backward (no mask is stored); the counter advances on every train-mode encoder forward, so a
+ * replayed hipGraph draws fresh masks.  inject_masks != NULL (device, one byte per element, sites concatenated at
+ * dof_tfm_dropout_site_offset): those keep-masks are used instead (parity tests replay recorded reference draws). */
+int32_t dof_tfm_dropout_site_count(const DofVadePlan* plan);
+const char* dof_tfm_dropout_site_name(const DofVadePlan* plan, int32_t i);
+int64_t dof_tfm_dropout_site_offset(const DofVadePlan* plan, int32_t i);
+int64_t dof_tfm_dropout_site_numel(const DofVadePlan* plan, int32_t i);
+float dof_tfm_dropout_site_p(const DofVadePlan* plan, int32_t i);
+int dof_tfm_set_dropout(DofVadePlan* plan, const uint8_t* inject_masks, uint32_t seed);
 
 /* module.train() / module.eval() for the BatchNorm layers of a TCN plan (default: training).  With training = 0
  * the loss/grad and train-flagged encode entries normalise with the running buffers and leave them untouched --

@@ -81,6 +81,44 @@ class DropoutRecorder:
         return False
 
 
+class ReluKinkFlipper:
+    """Context manager: every ReLU input element with |x| < delta takes the OTHER branch's derivative (values move by
+    less than delta).  The sign of such an element is decided by fp32 rounding, so two correct fp32 implementations
+    may disagree on it; the gradient change under this flip (``gkink::<name>`` in the fixtures) is the reference's own
+    sensitivity to those undecidable signs and enters the parity bar of the tensors it reaches."""
+
+    def __init__(self, delta=2e-6):
+        self.delta = delta
+        self.flipped = 0
+
+    def relu(self, x, inplace=False):
+        near = (x.detach().abs() < self.delta) & (x.detach() != 0)  # exact zeros: a ReLU applied to a ReLU output
+        self.flipped += int(near.sum())
+        return torch.where(near, torch.where(x > 0, x * 0.0, x), x.clamp_min(0.0))
+
+    def __enter__(self):
+        self._orig = (TF.relu, torch.relu)
+        TF.relu = self.relu
+        torch.relu = lambda x: self.relu(x)
+        return self
+
+    def __exit__(self, *exc):
+        TF.relu, torch.relu = self._orig
+        return False
+
+
+def store_kink(out, prefix, model, rerun):
+    """gkink::<name> = max |gradient with the near-zero ReLU signs flipped - gradient| per parameter."""
+    base = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    with ReluKinkFlipper() as fl:
+        rerun()
+    for n, p in model.named_parameters():
+        if p.grad is not None and n in base:
+            out[f"{prefix}gkink::{n}"] = np.float64((p.grad - base[n]).abs().max())
+    out[f"{prefix}kink_count"] = np.int64(fl.flipped)
+    print(f"{prefix or 'step'}: {fl.flipped} ReLU inputs within 2e-6 of zero")
+
+
 def trained_like_state(model, seed=5):
     """LayerNorm / BatchNorm scales and shifts and all biases away from their initial 1 / 0 / 0 (any trained state)."""
     g = torch.Generator().manual_seed(seed)
@@ -201,6 +239,12 @@ def gen_vade_tfm(seed=301, B=16, T=25, L=8, K=10):
             if p_.grad is not None:
                 out[f"{phase}::grad::{n}"] = p_.grad.numpy().copy()
                 out[f"{phase}::gnoise::{n}"] = np.float64((p_.grad.double() - p64[n].grad).abs().max())
+
+        def rerun():
+            model.load_state_dict(sd0)
+            run(model, torch.float32, phase, klw, with_teacher, DropoutRecorder(replay=rec.masks))
+
+        store_kink(out, f"{phase}::", model, rerun)
     np.savez_compressed(os.path.join(HERE, "vade_tfm14.npz"), **out)
 
 
@@ -252,6 +296,16 @@ def gen_vqvae_tfm(seed=331, B=16, T=25, L=8, K=24):
     for n, p in model.named_parameters():
         if p.grad is not None and p64[n].grad is not None:
             out[f"gnoise::{n}"] = np.float64((p.grad.double() - p64[n].grad).abs().max())
+
+    def rerun():
+        model.load_state_dict(sd0)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        with DropoutRecorder(replay=rec.masks):
+            r = R.T.step_vqvae_distill(model, (xt, at, torch.arange(B)), SimpleNamespace(apply_distill=False))
+        r.loss.backward()
+
+    store_kink(out, "", model, rerun)
     np.savez_compressed(os.path.join(HERE, "vqvae_tfm14.npz"), **out)
 
 
@@ -303,6 +357,12 @@ def gen_contrastive_tfm(seed=361, B=12, T_full=50, L=8):
     for n, p in model.named_parameters():
         if p.grad is not None:
             out[f"gnoise::{n}"] = np.float64((p.grad.double() - p64[n].grad).abs().max())
+
+    def rerun():
+        model.load_state_dict(sd0)
+        step(model, torch.float32, DropoutRecorder(replay=rec.masks))
+
+    store_kink(out, "", model, rerun)
     np.savez_compressed(os.path.join(HERE, "contrastive_tfm14.npz"), **out)
 
 

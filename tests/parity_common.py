@@ -1048,3 +1048,164 @@ def run_checkpoint_rules_check(golden_dir):
             assert sorted(saves) == sorted(ref), (model_name, sname, saves, ref)
             n += 1
     return n
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer family (R17): the HIP path against the REFERENCE goldens of tests/golden/make_golden_tfm.py
+# ------------------------------------------------------------------------------------------------
+def tfm_masks(d, prefix, site_names):
+    """The golden's recorded keep-masks (draw order) keyed by the plan's dropout-site names (same order)."""
+    keys = sorted(k for k in d if k.startswith(prefix + "drop::"))
+    assert len(keys) == len(site_names), (len(keys), site_names)
+    return {name: torch.from_numpy(d[k]) for name, k in zip(site_names, keys)}
+
+
+def _tfm_grad_check(eng, d, prefix, min_count, zero_names=("encoder.head.6.bias", "encoder.head.5.bias")):
+    n, worst = 0, 0.0
+    for k in d:
+        if k.startswith(prefix + "grad::"):
+            name = k.split("::")[-1]
+            g = eng.view(name, eng.grads).cpu().numpy()
+            ref = d[k].reshape(g.shape)
+            scale = float(np.abs(ref).max())
+            if name in zero_names:  # a constant in front of the batch standardisation: rounding noise on both sides
+                assert scale < 1e-4 and float(np.abs(g).max()) < 1e-4, name
+            else:
+                # + the reference's own sensitivity to the ReLU inputs whose sign is decided by fp32 rounding
+                # (|x| < 2e-6, about nine elements per step; tests/golden/make_golden_tfm.py ReluKinkFlipper)
+                kink = float(d[prefix + "gkink::" + name])
+                err = float(np.abs(g - ref).max())
+                assert err <= 5e-5 + 5e-4 * scale + kink, (prefix, name, err, scale, kink)
+                worst = max(worst, err / max(scale, 1e-30))
+            n += 1
+    assert n >= min_count, n
+    return worst
+
+
+def run_vade_tfm_check(lib, device, golden_dir):
+    """VaDEPT(encoder_type="transformer"): eval forward (also with padded keys / masked frames), the pre-training and
+    the main (+ teacher) objective on the reference's recorded dropout masks: every loss term, the train-mode outputs,
+    all 108 gradients, BatchNorm buffers and step counters."""
+    d = load_golden(golden_dir, "vade_tfm14.npz")
+    x, a = torch.from_numpy(d["x"]).to(device), torch.from_numpy(d["a"]).to(device)
+    B, T, N, _ = x.shape
+    K, L = d["sd::latent_space.gmm_means"].shape
+    eng = VadeEngine(lib, device, B, T, d["adj"], L, K, kind="vade_tfm")
+    sd0 = params_from(d)
+    eng.load_state_dict(sd0)
+    assert list(eng.state_dict().keys()) == list(sd0.keys())
+    eng.set_bn_training(False)
+    for pfx, xx, aa in (("eval_", x, a), ("evalm_", torch.from_numpy(d["xm"]).to(device), torch.from_numpy(d["am"]).to(device))):
+        out = eng.forward(xx, aa, None, want_loc=True, want_enc=True)
+        if pfx == "eval_":
+            np.testing.assert_allclose(out["enc"].cpu().numpy(), d["eval_enc"], atol=2e-5, rtol=1e-4)
+        np.testing.assert_allclose(out["z"].cpu().numpy(), d[pfx + "z"], atol=2e-5, rtol=1e-4)
+        np.testing.assert_allclose(out["q"].cpu().numpy(), d[pfx + "q"], atol=1e-5, rtol=1e-3)
+        np.testing.assert_allclose(out["loc"].cpu().numpy(), d[pfx + "loc"], atol=5e-5, rtol=1e-4)
+    eng.set_bn_training(True)
+    eps, eps_mc = torch.from_numpy(d["eps"]).to(device), torch.from_numpy(d["eps_mc"]).to(device)
+    tau = torch.from_numpy(d["tau"]).to(device)
+    sites = [s[0] for s in eng.dropout_sites()]
+    assert len(sites) == 22
+    worst = {}
+    for phase, klw, teacher in (("pre", 0.13, False), ("mainT", 0.7, True)):
+        eng.load_state_dict(sd0)
+        eng.set_dropout(tfm_masks(d, phase + "::", sites))
+        configure_phase(eng, K, phase == "pre", klw, tau if teacher else None, 1.7 if teacher else 0.0)
+        eng.loss_grads(x, a, eps, None if phase == "pre" else eps_mc, tau if teacher else None, pretrain=phase == "pre")
+        logs = eng.read_logs()
+        n_terms = 0
+        for k, v in logs.items():
+            key = f"{phase}::loss::{k}"
+            if key in d:
+                np.testing.assert_allclose(v, float(d[key]), rtol=1e-4, atol=1e-5, err_msg=key)
+                n_terms += 1
+        assert n_terms >= 12
+        worst[phase] = _tfm_grad_check(eng, d, phase + "::", 108)
+        if phase == "pre":
+            sd1 = eng.state_dict()
+            nb = 0
+            for k in d:
+                if k.startswith("pre::sd_after::"):
+                    name = k[len("pre::sd_after::"):]
+                    if name.endswith("num_batches_tracked"):
+                        assert int(sd1[name]) == int(d[k]), name
+                    else:
+                        np.testing.assert_allclose(sd1[name].numpy(), d[k], atol=5e-6, rtol=5e-5, err_msg=name)
+                    nb += 1
+            assert nb == 6
+    eng.set_dropout(None)
+    return worst
+
+
+def run_vqvae_tfm_check(lib, device, golden_dir):
+    """VQVAEPT(encoder_type="transformer"): eval forward (code indices exact), one step_vqvae_distill step: logs and
+    all gradients; the two decoder passes run on their own recorded masks."""
+    d = load_golden(golden_dir, "vqvae_tfm14.npz")
+    x, a = torch.from_numpy(d["x"]).to(device), torch.from_numpy(d["a"]).to(device)
+    B, T, N, _ = x.shape
+    L, K = d["sd::vq_layer.codebook"].shape
+    eng = VadeEngine(lib, device, B, T, d["adj"], L, K, kind="vqvae_tfm")
+    sd0 = params_from(d)
+    eng.load_state_dict(sd0)
+    assert list(eng.state_dict().keys()) == list(sd0.keys())
+    eng.set_bn_training(False)
+    out = eng.vq_forward(x, a)
+    np.testing.assert_array_equal(out["idx"].cpu().numpy(), d["eval_idx"])
+    np.testing.assert_allclose(out["ze"].cpu().numpy(), d["eval_ze"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["soft_counts"].cpu().numpy(), d["eval_soft_counts"], atol=1e-5, rtol=2e-3)
+    np.testing.assert_allclose(out["loc_q"].cpu().numpy(), d["eval_loc_q"], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["loc_e"].cpu().numpy(), d["eval_loc_e"], atol=5e-5, rtol=1e-4)
+    eng.set_bn_training(True)
+    sites = [s[0] for s in eng.dropout_sites()]
+    assert len(sites) == 30
+    eng.set_dropout(tfm_masks(d, "", sites))
+    eng.set_hyper(vq_beta=1.0, km_latent=0.0, km_loss=0.0, clip=0.75, wd=1e-4)
+    eng.push_hyper()
+    eng.vq_loss_grads(x, a)
+    logs = eng.read_vq_logs()
+    for k in ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss"):
+        np.testing.assert_allclose(logs[k], float(d[f"log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=k)
+    worst = _tfm_grad_check(eng, d, "", 100)
+    sd1 = eng.state_dict()
+    for k in d:
+        if k.startswith("sd_after::") and "running_" in k:
+            np.testing.assert_allclose(sd1[k[len("sd_after::"):]].numpy(), d[k], atol=5e-6, rtol=5e-5, err_msg=k)
+    eng.set_dropout(None)
+    return worst
+
+
+def run_contrastive_tfm_check(lib, device, golden_dir):
+    """ContrastivePT(encoder_type="transformer"): eval embeddings, train-mode embeddings of two views on the recorded
+    masks, NCE / cosine loss and every gradient (both views accumulate)."""
+    d = load_golden(golden_dir, "contrastive_tfm14.npz")
+    x, a, xa, aa = (torch.from_numpy(d[k]).to(device) for k in ("x", "a", "x_aug", "a_aug"))
+    B, T, N, _ = x.shape
+    L = d["sd::encoder.head.6.bias"].shape[0]
+    e1 = VadeEngine(lib, device, B, T, d["adj"], L, 1, kind="contrastive_tfm")
+    e2 = VadeEngine(lib, device, B, T, d["adj"], L, 1, kind="contrastive_tfm", shared=e1)
+    sd0 = params_from(d)
+    e1.load_state_dict(sd0)
+    assert list(e1.state_dict().keys()) == list(sd0.keys())
+    np.testing.assert_allclose(e1.contrastive_encode(x, a, train=False).cpu().numpy(), d["eval_z"], atol=2e-5, rtol=1e-4)
+    sites = [s[0] for s in e1.dropout_sites()]
+    assert len(sites) == 14
+    keys = sorted(k for k in d if k.startswith("drop::"))
+    assert len(keys) == 28
+    e1.set_dropout({n: torch.from_numpy(d[k]) for n, k in zip(sites, keys[:14])})
+    e2.set_dropout({n: torch.from_numpy(d[k]) for n, k in zip(sites, keys[14:])})
+    z = e1.contrastive_encode(x, a, train=True)
+    z_aug = e2.contrastive_encode(xa, aa, train=True)
+    np.testing.assert_allclose(z.cpu().numpy(), d["z"], atol=5e-5, rtol=2e-4)
+    np.testing.assert_allclose(z_aug.cpu().numpy(), d["z_aug"], atol=5e-5, rtol=2e-4)
+    dz, dza = e1.contrastive_loss(z, z_aug, "cosine", "nce", 0.1, 0.1, 0.1)
+    logs = e1.read_contrastive_logs()
+    np.testing.assert_allclose([logs["total_loss"], logs["pos_similarity"], logs["neg_similarity"]], d["loss"], rtol=1e-4, atol=1e-5)
+    e1.contrastive_backward(dz, accumulate=False)
+    e2.contrastive_backward(dza, accumulate=True)
+    worst = _tfm_grad_check(e1, d, "", 68)
+    sd1 = e1.state_dict()
+    for k in d:
+        if k.startswith("sd_after::") and "running_" in k:
+            np.testing.assert_allclose(sd1[k[len("sd_after::"):]].numpy(), d[k], atol=5e-6, rtol=5e-5, err_msg=k)
+    return worst

@@ -61,6 +61,16 @@ def test_plan_layout_without_gpu(lib):
     assert lib.dof_vade_param_name(plan, 0) == b"encoder.node_recurrent_block.conv1d.weight"
     assert lib.dof_vade_workspace_bytes(plan) > 0
     lib.dof_vade_plan_destroy(plan)
+    # transformer family: VaDEPT(encoder_type="transformer") has 102,184 parameters + 4 BatchNorm
+    # running buffers (16 + 16 + 8 + 8 floats) in the flat buffer
+    assert lib.dof_vade_tfm_plan_create(ctypes.byref(dims), lap.ctypes.data, elap.ctypes.data, inc.ctypes.data,
+                                        ctypes.byref(plan)) == 0
+    assert lib.dof_vade_param_total(plan) == 102184 + 48
+    assert lib.dof_vade_param_name(plan, 0) == b"encoder.node_tf.embed.weight"
+    assert lib.dof_tfm_dropout_site_count(plan) == 22
+    assert lib.dof_tfm_dropout_site_name(plan, 1) == b"enc.node.l0.attn"
+    assert lib.dof_tfm_dropout_site_numel(plan, 1) == 1024 * 14 * 4 * 25 * 25
+    lib.dof_vade_plan_destroy(plan)
     bad = _capi.VadeDims(8, 25, 14, 14, 7, 10, 32)
     assert lib.dof_vade_plan_create(ctypes.byref(bad), lap.ctypes.data, elap.ctypes.data, inc.ctypes.data,
                                     ctypes.byref(plan)) == -2

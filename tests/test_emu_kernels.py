@@ -151,3 +151,16 @@ def test_preprocess_constant_columns_emu():
     sub = copy.copy(res)
     sub.node_table, sub.edge_table = res.node_table[:, sel_n], res.edge_table[:, sel_e]
     PC._check_tables(sub, want, cols, keep_n, keep_e, [], "columns next to constant ones")
+
+
+def test_vade_tfm_emu(golden_dir):
+    """Transformer family (R17) under the emulator against the reference golden."""
+    print(PC.run_vade_tfm_check(emu_lib(), "cpu", golden_dir))
+
+
+def test_vqvae_tfm_emu(golden_dir):
+    print(PC.run_vqvae_tfm_check(emu_lib(), "cpu", golden_dir))
+
+
+def test_contrastive_tfm_emu(golden_dir):
+    print(PC.run_contrastive_tfm_check(emu_lib(), "cpu", golden_dir))

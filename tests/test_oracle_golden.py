@@ -594,7 +594,7 @@ def _tape(d, prefix=""):
     return DropoutTape([torch.from_numpy(d[k]) for k in keys])
 
 
-def _check_grads(d, grads, prefix, min_count, zero_names=("encoder.head.6.bias",)):
+def _check_grads(d, grads, prefix, min_count, zero_names=("encoder.head.6.bias", "encoder.head.5.bias")):
     n = 0
     for k in d:
         if k.startswith(prefix + "grad::"):
@@ -605,7 +605,8 @@ def _check_grads(d, grads, prefix, min_count, zero_names=("encoder.head.6.bias",
                 assert scale < 1e-4 and np.abs(got).max() < 1e-4, name
             else:
                 noise = float(d[prefix + "gnoise::" + name])
-                assert np.abs(got - ref).max() <= 2e-5 + 3e-4 * scale + 4 * noise, (prefix, name)
+                kink = float(d[prefix + "gkink::" + name])  # ReLU inputs within 2e-6 of zero: undecidable signs
+                assert np.abs(got - ref).max() <= 2e-5 + 3e-4 * scale + 4 * noise + kink, (prefix, name)
             n += 1
     assert n >= min_count, n
 
