@@ -1013,14 +1013,19 @@ void build_jobs(DofVadePlan* p) {
       const int64_t Sp = w.Sp;
       const int C1 = 2 * L;
       // encoder conv: dW[o][f][k] = sum dc[t][o] * xs[t+k-2][f]
+      // A = d conv output = (dX of the forward direction + dX of the reverse direction) * [conv output > 0]: the merge
+      // is done by the reduction's operand load (DofOuterJob::a_add / a_relu)
+      const float* dc_rev = ws + w.dc + (int64_t)T * C1 * Sp;
       if (5 * w.F <= 16) {  // all five taps in one packed tile (F = 3: 15 columns, F = 1: 5)
         const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
+        jb.jobs[job].a_add = dc_rev; jb.jobs[job].a_relu = ws + w.c;
         const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), 5 * w.F, -2, w.F);
         for (int k = 0; k < 5; ++k)
           jb.add_fin(job, tl * 16 + k * w.F, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
       } else {
         for (int k0 = 0; k0 < 5; k0 += 4) {
           const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
+          jb.jobs[job].a_add = dc_rev; jb.jobs[job].a_relu = ws + w.c;
           for (int k = k0; k < 5 && k < k0 + 4; ++k) {
             const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), w.F, k - 2);
             jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
@@ -1587,7 +1592,6 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     } else {
       TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
     }
-    TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
   }
   {  // LayerNorm weight / bias gradients of both streams: one launch
     DofSumJobs sj;

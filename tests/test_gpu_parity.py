@@ -1008,3 +1008,64 @@ def test_vade_tfm_full_size_c2(hip):
         ref = OV.vade_forward(P, x[:32].cpu(), a[:32].cpu(), training=False)
     np.testing.assert_allclose(z.cpu().numpy(), ref["z"].numpy(), atol=3e-5, rtol=1e-4)
     np.testing.assert_allclose(q.cpu().numpy(), ref["q"].numpy(), atol=2e-5, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# RCCL ("nccl" backend): the data-parallel step on real devices
+# ------------------------------------------------------------------------------------------------
+def _rccl_worker(rank, world, port, tmp):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from deepof_amd.engine import create_vade_engine
+    from parity_common import configure_phase
+    adj = np.zeros((4, 4), np.float32)
+    for i in range(3):
+        adj[i, i + 1] = adj[i + 1, i] = 1
+    eng = create_vade_engine(4, 8, adj, 4, 3, device=f"cuda:{rank}")
+    g = torch.Generator().manual_seed(0)
+    eng.params.copy_(torch.randn(eng.params.shape, generator=g) * 0.2)
+    if rank != 0:
+        eng.params.mul_(0.0)
+    dist.broadcast(eng.params, src=0)
+    xs, as_ = torch.randn(4 * world, 8, 4, 3, generator=g), torch.randn(4 * world, 8, 3, 1, generator=g)
+    eps = torch.randn(4 * world, 4, generator=g)
+    configure_phase(eng, 3, True, 0.2)
+    lo = rank * 4
+    dev = eng.device
+    eng.loss_grads(xs[lo:lo + 4].contiguous().to(dev), as_[lo:lo + 4].contiguous().to(dev), eps[lo:lo + 4].contiguous().to(dev),
+                   None, None, True)
+    local = eng.grads.clone()
+    dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+    for seg in range(4):
+        eng.set_lr(seg, 1e-3)
+    eng.push_hyper()
+    eng.optimizer_step(1.0 / world)
+    torch.cuda.synchronize()
+    torch.save({"local": local.cpu(), "sum": eng.grads.cpu(), "params": eng.params.cpu()}, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_data_parallel_step_rccl(tmp_path, world):
+    """The DP contract on the real "nccl" (= RCCL) backend: rank-0 weights broadcast, ONE all-reduce (SUM) of the flat
+    gradient, dof_optimizer_step(grad_scale = 1 / world) -> identical parameters on every rank, sum == sum of the
+    shards' gradients.  world = 2 runs whenever two devices are visible (skipped on a 1-GPU box); world = 1 runs the
+    same code path through an RCCL process group of one rank."""
+    import os
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"{world} devices needed, {torch.cuda.device_count()} visible")
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_rccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    total = sum(r["local"] for r in res)
+    for r in res:
+        torch.testing.assert_close(r["params"], res[0]["params"], rtol=0, atol=0)
+        torch.testing.assert_close(r["sum"], total, rtol=1e-6, atol=1e-8)
+    if world > 1:
+        assert float((res[0]["local"] - res[1]["local"]).abs().max()) > 0
