@@ -511,14 +511,24 @@ struct LossMidArgs {
   int64_t B;
 };
 
+// 64-lane sum of a partial array (lanes stride over it, fixed-shape butterfly: deterministic)
+__device__ __forceinline__ float dof_wave_sum_array(const float* __restrict__ p, int n) {
+  float acc = 0.0f;
+  for (int i = (int)(threadIdx.x & 63); i < n; i += 64) acc += p[i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  return acc;
+}
+
 __global__ void k_loss_mid(LossMidArgs A) {
+  // launched as one wavefront: the per-workgroup partials are summed by all 64 lanes, the scalar part runs on lane 0
+  float recon = dof_wave_sum_array(A.recon_partial, A.n_recon);
+  const float mckl_sum = (!A.pretrain && A.mckl_partial) ? dof_wave_sum_array(A.mckl_partial, A.n_mckl) : 0.0f;
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int K = A.K, L = A.L;
   const int SW = 3 * L + 1;
   const float* H = A.hyper;
   const float Bf = (float)A.B;
-  float recon = 0.0f;
-  for (int i = 0; i < A.n_recon; ++i) recon += A.recon_partial[i];
   recon /= (Bf * (float)A.T);
   const float* sc = A.stats + K * SW;
   const float activity = H[DOF_H_L1_ACT] * sc[0] / Bf;
@@ -528,9 +538,7 @@ __global__ void k_loss_mid(LossMidArgs A) {
     kl = klw * sc[1] / Bf;
     A.scal[0] = 0.0f;
   } else {
-    float s = 0.0f;
-    for (int i = 0; i < A.n_mckl; ++i) s += A.mckl_partial[i];
-    const float raw = s / ((float)A.S * Bf);
+    const float raw = mckl_sum / ((float)A.S * Bf);
     kl = klw * fmaxf(raw, 0.0f);
     A.scal[0] = raw > 0.0f ? klw / ((float)A.S * Bf) : 0.0f;
   }

@@ -127,13 +127,10 @@ struct VqLossArgs {
 };
 
 __global__ void k_vq_loss(VqLossArgs A) {
+  // one wavefront: partial sums by all 64 lanes, the rest on lane 0
+  const float rq = dof_wave_sum_array(A.recon_q, A.n_recon), re = dof_wave_sum_array(A.recon_e, A.n_recon);
+  const float sq = dof_wave_sum_array(A.sq_partial, A.n_sq);
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float rq = 0.0f, re = 0.0f, sq = 0.0f;
-  for (int i = 0; i < A.n_recon; ++i) {
-    rq += A.recon_q[i];
-    re += A.recon_e[i];
-  }
-  for (int i = 0; i < A.n_sq; ++i) sq += A.sq_partial[i];
   const float bt = (float)A.B * (float)A.T;
   const float enc_rec = rq / bt, rec = re / bt;
   const float vq = (A.hyper[DOF_H_VQ_BETA] + 1.0f) * sq / ((float)A.B * (float)A.L);

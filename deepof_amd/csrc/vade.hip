@@ -180,6 +180,7 @@ struct DofVadePlan {
   int64_t gram, Pm, km, stats, dqbar, dcen, dscat, dlogp2, tf_partial, scal;
   int64_t mterm, mlse, mdz, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
   int64_t mckl_blocks, lat_blocks, tail_blocks;
+  bool tail_wide = false;
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
   int64_t partials, segs_tab, mask_tab, bc_tab;
@@ -723,7 +724,9 @@ void take_latent_buffers(DofVadePlan* p, Carver& cv) {
   p->mgsum = cv.take(2LL * L * Bp);
   p->gmmp = cv.take(16LL * 2 * K * L);
   p->mckl_blocks = dof_cdiv((int64_t)S * p->B, 256);
-  p->tail_blocks = dof_cdiv((int64_t)T * p->B, 256);
+  // recurrent family, latent 8: the lane-per-channel decoder tail (16 rows per workgroup); else one row per thread
+  p->tail_wide = !p->tcn && !p->tfm && L == 8 && p->C3 <= 96;
+  p->tail_blocks = dof_cdiv((int64_t)T * p->B, p->tail_wide ? 16 : 256);
   p->mckl_partial = cv.take(p->mckl_blocks);
   p->distill_partial = cv.take(p->lat_blocks);
   p->tf_partial = cv.take(p->lat_blocks);
@@ -1474,7 +1477,11 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, const f
   A.cv = ws + p->cv; A.n3 = ws + p->n3; A.loc_out = loc_out; A.recon_partial = recon_partial;
   A.dloc = ws + p->dloc; A.dcv = ws + p->dcv; A.ln3_partial = ws + p->ln3p;
   A.T = T; A.C3 = p->C3; A.train = train ? 1 : 0; A.B = B; A.Bp = Bp;
-  LDISPATCH(L, DOF_LAUNCH((k_dec_tail<LL>), ((unsigned)p->tail_blocks), (256), st, A));
+  if (p->tail_wide) {
+    DOF_LAUNCH(k_dec_tail_w, ((unsigned)p->tail_blocks), (256), st, A);
+  } else {
+    LDISPATCH(L, DOF_LAUNCH((k_dec_tail<LL>), ((unsigned)p->tail_blocks), (256), st, A));
+  }
   return dof_check_launch("k_dec_tail");
 }
 
@@ -1487,8 +1494,13 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
   float* ws = p->ws;
   const int L = p->L, T = p->T;
   const int64_t B = p->B, Bp = p->Bp;
-  LDISPATCH(L, DOF_LAUNCH((k_dec_conv_bwd<LL>), ((unsigned)p->tail_blocks), (256), st, (const float*)(ws + p->dcv),
-                          params + p->dconv, ws + p->dn2d, T, B, Bp));
+  if (p->tail_wide) {
+    DOF_LAUNCH(k_dec_conv_bwd_w, (dof_cdiv((int64_t)T * B, 8)), (256), st, (const float*)(ws + p->dcv), params + p->dconv,
+               ws + p->dn2d, T, B, Bp);
+  } else {
+    LDISPATCH(L, DOF_LAUNCH((k_dec_conv_bwd<LL>), ((unsigned)p->tail_blocks), (256), st, (const float*)(ws + p->dcv),
+                            params + p->dconv, ws + p->dn2d, T, B, Bp));
+  }
   TRY(dof_check_launch("k_dec_conv_bwd"));
   const int* len_d = reinterpret_cast<const int*>(ws + p->len_d);
   TRY(dof_launch_ln_bwd(L, 4, ws + p->o2d, ws + p->dn2d, nullptr, params + p->dn2w, ws + p->do2d, ws + p->lnd2p, T, B, Bp, st));
