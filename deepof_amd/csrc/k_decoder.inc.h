@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256) k_dec_conv_bwd(const float* __restrict__ 
 // different order than in the row-per-thread form (fp32 rounding only).
 // ---------------------------------------------------------------------------------------------
 constexpr int kTailMaxC3 = 96;
+constexpr int kTailIters = 4;  // row groups of 16 per workgroup of k_dec_tail_w (vade.hip sizes tail_blocks by 16 * kTailIters)
 
 __global__ void __launch_bounds__(256) k_dec_tail_w(DecTailArgs A) {
   constexpr int L = 8, CI = 4 * L, CO = 2 * L, RB = 16, PS = 20;  // PS: padded row stride of the projection weights
@@ -206,94 +207,97 @@ __global__ void __launch_bounds__(256) k_dec_tail_w(DecTailArgs A) {
   }
   for (int e = tid; e < C3 * CO; e += 256) wps[(e / CO) * PS + (e % CO)] = A.wp[e];
   const int64_t rows = (int64_t)A.T * A.B;
-  const int64_t r0 = (int64_t)blockIdx.x * RB;
-  for (int e = tid; e < RB * 5 * (CI / 4); e += 256) {  // float4 units of the staged input rows
-    const int c4 = e % (CI / 4), k = (e / (CI / 4)) % 5, rr = e / (5 * (CI / 4));
-    const int64_t r = r0 + rr;
-    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (r < rows) {
-      const int t = (int)(r / A.B);
-      const int64_t b = r - (int64_t)t * A.B;
-      const int ts = t + k - 2;
-      if (ts >= 0 && ts < A.T) v = *reinterpret_cast<const float4*>(A.n2 + ACT(ts, 4 * c4, CI, A.Bp, b));
-    }
-    *reinterpret_cast<float4*>(xs + (rr * 5 + k) * CI + 4 * c4) = v;
-  }
-  __syncthreads();
-  const int64_t r = r0 + g;
-  const bool live = r < rows;
-  const int t = live ? (int)(r / A.B) : 0;
-  const int64_t b = live ? r - (int64_t)t * A.B : 0;
   auto gsum = [&](float v) {
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
     return v;
   };
-  // conv + ReLU
-  float cvo = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 5; ++k)
-#pragma unroll
-    for (int c4 = 0; c4 < CI / 4; ++c4) {
-      const float4 xv = *reinterpret_cast<const float4*>(xs + (g * 5 + k) * CI + 4 * c4);
-      const float4 wv = *reinterpret_cast<const float4*>(wcs + ((k * (CI / 4) + c4) * CO + o) * 4);
-      cvo = fmaf(wv.x, xv.x, cvo); cvo = fmaf(wv.y, xv.y, cvo); cvo = fmaf(wv.z, xv.z, cvo); cvo = fmaf(wv.w, xv.w, cvo);
-    }
-  cvo = cvo > 0.0f ? cvo : 0.0f;
-  if (live) A.cv[ACT(t, o, CO, A.Bp, b)] = cvo;
-  // LayerNorm(eps 1e-3)
-  const float mean = gsum(cvo) * (1.0f / CO);
-  float xh = cvo - mean;
-  const float rstd = rsqrtf(gsum(xh * xh) * (1.0f / CO) + 1e-3f);
-  xh *= rstd;
-  const float g3o = A.g3[o];
-  const float n3o = fmaf(xh, g3o, A.b3[o]);
-  if (live) A.n3[ACT(t, o, CO, A.Bp, b)] = n3o;
-  float n3all[CO];
-  dof_static_for<CO>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    n3all[k] = dof_gbcast<k, 16>(n3o);
-  });
-  // projection + Normal(loc, 1) log-prob; lane o owns outputs j = o + 16 m
-  const bool ok = live && A.valid[(int64_t)t * A.Bp + b] != 0.0f;
+  const float g3o = A.g3[o], b3o = A.b3[o];
   const float inv_bt = 1.0f / ((float)A.B * (float)A.T);
-  const float* __restrict__ xr = A.x + (b * A.T + t) * C3;
-  float sq = 0.0f;
-  for (int j = o; j < C3; j += 16) {
-    float loc = A.bp[j];
-#pragma unroll
-    for (int q4 = 0; q4 < CO / 4; ++q4) {
-      const float4 wv = *reinterpret_cast<const float4*>(wps + j * PS + 4 * q4);
-      loc = fmaf(wv.x, n3all[4 * q4], loc); loc = fmaf(wv.y, n3all[4 * q4 + 1], loc);
-      loc = fmaf(wv.z, n3all[4 * q4 + 2], loc); loc = fmaf(wv.w, n3all[4 * q4 + 3], loc);
-    }
-    if (loc != loc) loc = 0.0f;
-    loc = fminf(fmaxf(loc, -1e6f), 1e6f);
-    float dl = 0.0f;
-    if (live) {
-      if (A.loc_out) A.loc_out[(b * A.T + t) * C3 + j] = loc;
-      const float df = xr[j] - loc;
-      sq = fmaf(df, df, sq);
-      dl = ok ? -df * inv_bt : NAN;
-      if (A.train) A.dloc[ACT(t, j, C3, A.Bp, b)] = dl;
-    }
-    dls[g * kTailMaxC3 + j] = dl;
-  }
-  sq = gsum(sq);
-  const float LOG_2PI = 1.8378770664093453f;
   float nll[1] = {0.0f};
-  if (live && o == 0) nll[0] = ok ? 0.5f * sq + 0.5f * (float)C3 * LOG_2PI : NAN;
-  __syncthreads();
   float vals0 = 0.0f, vals1 = 0.0f;
-  if (A.train) {
-    float dn3 = 0.0f;
-    for (int j = 0; j < C3; ++j) dn3 = fmaf(wps[j * PS + o], dls[g * kTailMaxC3 + j], dn3);
-    const float gg = dn3 * g3o;
-    const float mg = gsum(gg) * (1.0f / CO), mgx = gsum(gg * xh) * (1.0f / CO);
-    const float d = rstd * (gg - mg - xh * mgx);
-    if (live) {
-      A.dcv[ACT(t, o, CO, A.Bp, b)] = cvo > 0.0f ? d : 0.0f;
-      vals0 = dn3 * xh;
-      vals1 = dn3;
+  for (int it = 0; it < kTailIters; ++it) {  // the staged weights serve kTailIters x 16 rows
+    const int64_t r0 = ((int64_t)blockIdx.x * kTailIters + it) * RB;
+    __syncthreads();  // weights staged / previous iteration done with xs and dls
+    for (int e = tid; e < RB * 5 * (CI / 4); e += 256) {  // float4 units of the staged input rows
+      const int c4 = e % (CI / 4), k = (e / (CI / 4)) % 5, rr = e / (5 * (CI / 4));
+      const int64_t r = r0 + rr;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (r < rows) {
+        const int t = (int)(r / A.B);
+        const int64_t b = r - (int64_t)t * A.B;
+        const int ts = t + k - 2;
+        if (ts >= 0 && ts < A.T) v = *reinterpret_cast<const float4*>(A.n2 + ACT(ts, 4 * c4, CI, A.Bp, b));
+      }
+      *reinterpret_cast<float4*>(xs + (rr * 5 + k) * CI + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int64_t r = r0 + g;
+    const bool live = r < rows;
+    const int t = live ? (int)(r / A.B) : 0;
+    const int64_t b = live ? r - (int64_t)t * A.B : 0;
+    // conv + ReLU
+    float cvo = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int c4 = 0; c4 < CI / 4; ++c4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xs + (g * 5 + k) * CI + 4 * c4);
+        const float4 wv = *reinterpret_cast<const float4*>(wcs + ((k * (CI / 4) + c4) * CO + o) * 4);
+        cvo = fmaf(wv.x, xv.x, cvo); cvo = fmaf(wv.y, xv.y, cvo); cvo = fmaf(wv.z, xv.z, cvo); cvo = fmaf(wv.w, xv.w, cvo);
+      }
+    cvo = cvo > 0.0f ? cvo : 0.0f;
+    if (live) A.cv[ACT(t, o, CO, A.Bp, b)] = cvo;
+    // LayerNorm(eps 1e-3)
+    const float mean = gsum(cvo) * (1.0f / CO);
+    float xh = cvo - mean;
+    const float rstd = rsqrtf(gsum(xh * xh) * (1.0f / CO) + 1e-3f);
+    xh *= rstd;
+    const float n3o = fmaf(xh, g3o, b3o);
+    if (live) A.n3[ACT(t, o, CO, A.Bp, b)] = n3o;
+    float n3all[CO];
+    dof_static_for<CO>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      n3all[k] = dof_gbcast<k, 16>(n3o);
+    });
+    // projection + Normal(loc, 1) log-prob; lane o owns outputs j = o + 16 m
+    const bool ok = live && A.valid[(int64_t)t * A.Bp + b] != 0.0f;
+    const float* __restrict__ xr = A.x + (b * A.T + t) * C3;
+    float sq = 0.0f;
+    for (int j = o; j < C3; j += 16) {
+      float loc = A.bp[j];
+#pragma unroll
+      for (int q4 = 0; q4 < CO / 4; ++q4) {
+        const float4 wv = *reinterpret_cast<const float4*>(wps + j * PS + 4 * q4);
+        loc = fmaf(wv.x, n3all[4 * q4], loc); loc = fmaf(wv.y, n3all[4 * q4 + 1], loc);
+        loc = fmaf(wv.z, n3all[4 * q4 + 2], loc); loc = fmaf(wv.w, n3all[4 * q4 + 3], loc);
+      }
+      if (loc != loc) loc = 0.0f;
+      loc = fminf(fmaxf(loc, -1e6f), 1e6f);
+      float dl = 0.0f;
+      if (live) {
+        if (A.loc_out) A.loc_out[(b * A.T + t) * C3 + j] = loc;
+        const float df = xr[j] - loc;
+        sq = fmaf(df, df, sq);
+        dl = ok ? -df * inv_bt : NAN;
+        if (A.train) A.dloc[ACT(t, j, C3, A.Bp, b)] = dl;
+      }
+      dls[g * kTailMaxC3 + j] = dl;
+    }
+    sq = gsum(sq);
+    const float LOG_2PI = 1.8378770664093453f;
+    if (live && o == 0) nll[0] += ok ? 0.5f * sq + 0.5f * (float)C3 * LOG_2PI : NAN;
+    __syncthreads();
+    if (A.train) {
+      float dn3 = 0.0f;
+      for (int j = 0; j < C3; ++j) dn3 = fmaf(wps[j * PS + o], dls[g * kTailMaxC3 + j], dn3);
+      const float gg = dn3 * g3o;
+      const float mg = gsum(gg) * (1.0f / CO), mgx = gsum(gg * xh) * (1.0f / CO);
+      const float d = rstd * (gg - mg - xh * mgx);
+      if (live) {
+        A.dcv[ACT(t, o, CO, A.Bp, b)] = cvo > 0.0f ? d : 0.0f;
+        vals0 += dn3 * xh;
+        vals1 += dn3;
+      }
     }
   }
   dof_block_colsum<1>(nll, A.recon_partial + blockIdx.x);

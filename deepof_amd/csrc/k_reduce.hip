@@ -54,19 +54,9 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
       for (int kk = 0; kk < 4; ++kk) A[mt][kk] = 0.0f;
       const int row = mt * 16 + i;
       if (mt < MT && row < J.a_rows) {
-        const int64_t aoff = (int64_t)t * J.a_tstride + (int64_t)row * J.a_cstride + s0 * J.a_sstride;
-        const float* __restrict__ ap = J.a_ptr + aoff;
+        const float* __restrict__ ap = J.a_ptr + (int64_t)t * J.a_tstride + (int64_t)row * J.a_cstride + s0 * J.a_sstride;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) A[mt][kk] = ap[(int64_t)(4 * kk) * J.a_sstride];
-        if (J.a_add) {  // (job-uniform)
-          const float* __restrict__ ap2 = J.a_add + aoff;
-          const float* __restrict__ am = J.a_relu + aoff;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const float v = A[mt][kk] + ap2[(int64_t)(4 * kk) * J.a_sstride];
-            A[mt][kk] = am[(int64_t)(4 * kk) * J.a_sstride] > 0.0f ? v : 0.0f;
-          }
-        }
       }
     }
 #pragma unroll

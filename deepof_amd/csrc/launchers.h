@@ -184,10 +184,6 @@ struct DofOuterJob {
   DofOuterTile tile[4];
   int blk0, nblk;        // block range of this job inside the launch
   int64_t partial_off;   // float offset of this job's partials: [nblk][64][65]  (col 64 = row sums of A)
-  // optional fused producer of A (same strides as a_ptr): A = (a + a_add) * [a_relu > 0] -- the sum of the two GRU
-  // directions' input gradients masked by the encoder convolution's ReLU, which used to be a pass of its own
-  const float* a_add;
-  const float* a_relu;
 };
 struct DofFinJob {  // scatter-add of one reduced (rows x cols) block into a gradient tensor
   int job;              // source DofOuterJob index

@@ -726,7 +726,7 @@ void take_latent_buffers(DofVadePlan* p, Carver& cv) {
   p->mckl_blocks = dof_cdiv((int64_t)S * p->B, 256);
   // recurrent family, latent 8: the lane-per-channel decoder tail (16 rows per workgroup); else one row per thread
   p->tail_wide = !p->tcn && !p->tfm && L == 8 && p->C3 <= 96;
-  p->tail_blocks = dof_cdiv((int64_t)T * p->B, p->tail_wide ? 16 : 256);
+  p->tail_blocks = dof_cdiv((int64_t)T * p->B, p->tail_wide ? 64 : 256);
   p->mckl_partial = cv.take(p->mckl_blocks);
   p->distill_partial = cv.take(p->lat_blocks);
   p->tf_partial = cv.take(p->lat_blocks);
@@ -1016,19 +1016,14 @@ void build_jobs(DofVadePlan* p) {
       const int64_t Sp = w.Sp;
       const int C1 = 2 * L;
       // encoder conv: dW[o][f][k] = sum dc[t][o] * xs[t+k-2][f]
-      // A = d conv output = (dX of the forward direction + dX of the reverse direction) * [conv output > 0]: the merge
-      // is done by the reduction's operand load (DofOuterJob::a_add / a_relu)
-      const float* dc_rev = ws + w.dc + (int64_t)T * C1 * Sp;
       if (5 * w.F <= 16) {  // all five taps in one packed tile (F = 3: 15 columns, F = 1: 5)
         const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
-        jb.jobs[job].a_add = dc_rev; jb.jobs[job].a_relu = ws + w.c;
         const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), 5 * w.F, -2, w.F);
         for (int k = 0; k < 5; ++k)
           jb.add_fin(job, tl * 16 + k * w.F, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
       } else {
         for (int k0 = 0; k0 < 5; k0 += 4) {
           const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
-          jb.jobs[job].a_add = dc_rev; jb.jobs[job].a_relu = ws + w.c;
           for (int k = k0; k < 5 && k < k0 + 4; ++k) {
             const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), w.F, k - 2);
             jb.add_fin(job, tl * 16, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
@@ -1604,6 +1599,9 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     } else {
       TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
     }
+    // (fusing this merge into the weight-gradient reduction's operand load was measured: the conv job's loads triple
+    // and k_outer, which is latency-bound per wave, loses 19 us per launch against the 19 us this pass costs per stream)
+    TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
   }
   {  // LayerNorm weight / bias gradients of both streams: one launch
     DofSumJobs sj;
