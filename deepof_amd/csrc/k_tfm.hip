@@ -125,11 +125,14 @@ __global__ void __launch_bounds__(256) k_tfm_embed_bwd(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // rows x K  @  K x N  on the matrix cores
 // ---------------------------------------------------------------------------------------------
-template <int NTMAX>
+template <int NTMAX, int EPI>
 __global__ void __launch_bounds__(256) k_tfm_gemm(DofGemm A) {
   __shared__ float wl[kGemmLds];
+  // NT = the template's tile count: tiles beyond N hold zeros and are multiplied unconditionally (a per-tile branch
+  // inside the MFMA loop made the compiler shuffle the accumulators through thousands of register copies)
+  constexpr int NT = NTMAX;
   const int K = A.K, N = A.N;
-  const int KC = (K + 15) / 16, NT = (N + 15) / 16;
+  const int KC = (K + 15) / 16;
   const int tid = threadIdx.x;
   for (int e = tid; e < KC * 4 * NT * 64; e += 256) {
     const int lane = e & 63;
@@ -145,56 +148,59 @@ __global__ void __launch_bounds__(256) k_tfm_gemm(DofGemm A) {
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int64_t tiles = (int64_t)A.T * (A.Sp / 16);
-  const uint32_t ctr = drop_ctr(A.drop);
+  [[maybe_unused]] const uint32_t ctr = drop_ctr(A.drop);
+#pragma unroll 1
   for (int it = 0; it < 4; ++it) {
     const int64_t tile = (int64_t)blockIdx.x * 16 + wave + 4 * it;
     if (tile >= tiles) break;
     const int64_t row0 = tile * 16;
     const int64_t s0 = row0 % A.Sp;
     if (s0 >= A.S) continue;  // a tile of pad rows (wave-uniform)
-    const int t = (int)(row0 / A.Sp);
     dof_f32x4 acc[NTMAX];
 #pragma unroll
     for (int n = 0; n < NTMAX; ++n) acc[n] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const float* __restrict__ xr = A.X + (row0 + li) * A.ldx;
+    const float* __restrict__ xr = A.X + (row0 + li) * A.ldx + 4 * lg;
+#pragma unroll 1
     for (int jc = 0; jc < KC; ++jc) {
-      const int k = jc * 16 + 4 * lg;
       float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (k < K) a4 = *reinterpret_cast<const float4*>(xr + k);
+      if (jc * 16 + 4 * lg < K) a4 = *reinterpret_cast<const float4*>(xr + jc * 16);
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+      const float* __restrict__ wrow = wl + (jc * 4 * NT) * 64 + lane;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const float* __restrict__ wrow = wl + ((jc * 4 + m) * NT) * 64 + lane;
 #pragma unroll
         for (int n = 0; n < NTMAX; ++n)
-          if (n < NT) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], wrow[n * 64], acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], wrow[(m * NT + n) * 64], acc[n], 0, 0, 0);
       }
     }
+    // epilogue: lane (li, lg) holds rows row0 + 4 lg + r (r < 4), column n * 16 + li of tile n
+    const int64_t rbase = row0 + 4 * lg;
+    float* __restrict__ ybase = A.Y + rbase * A.ldy + li;
+    const int nrow = (int)(A.S - (s0 + 4 * lg));  // valid rows of this lane's four (<= 0: none)
+    [[maybe_unused]] const float* __restrict__ xbase = nullptr;
+    if constexpr (EPI == DOF_EPI_MUL_RELU || EPI == DOF_EPI_MUL_DGELU) xbase = A.aux + rbase * A.ldaux + li;
+    [[maybe_unused]] float* __restrict__ pbase = nullptr;
+    if constexpr (EPI == DOF_EPI_GELU) pbase = A.aux_out + rbase * A.ldy + li;
+    [[maybe_unused]] const int t = (int)(row0 / A.Sp);
 #pragma unroll
     for (int n = 0; n < NTMAX; ++n) {
-      if (n >= NT) continue;
       const int col = n * 16 + li;
       if (col >= N) continue;
       const float bv = A.bias ? A.bias[col] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t s = s0 + 4 * lg + r;
-        if (s >= A.S) continue;
-        const int64_t row = row0 + 4 * lg + r;
+        if (r >= nrow) continue;
         float v = acc[n][r] + bv;
-        switch (A.epi) {
-          case DOF_EPI_RELU: v = fmaxf(v, 0.0f); break;
-          case DOF_EPI_GELU:
-            A.aux_out[row * A.ldy + col] = v;
-            v = gelu_f(v) * drop_scale(A.drop, ctr, (s * A.T + t) * (int64_t)A.drop_ld + col);
-            break;
-          case DOF_EPI_MUL_RELU: v = A.aux[row * A.ldaux + col] > 0.0f ? v : 0.0f; break;
-          case DOF_EPI_MUL_DGELU:
-            v *= dgelu_f(A.aux[row * A.ldaux + col]) * drop_scale(A.drop, ctr, (s * A.T + t) * (int64_t)A.drop_ld + col);
-            break;
-          default: break;
+        if constexpr (EPI == DOF_EPI_RELU) v = fmaxf(v, 0.0f);
+        if constexpr (EPI == DOF_EPI_GELU) {
+          pbase[r * A.ldy + n * 16] = v;
+          v = gelu_f(v) * drop_scale(A.drop, ctr, ((s0 + 4 * lg + r) * A.T + t) * (int64_t)A.drop_ld + col);
         }
-        float* __restrict__ dst = A.Y + row * A.ldy + col;
+        if constexpr (EPI == DOF_EPI_MUL_RELU) v = xbase[r * A.ldaux + n * 16] > 0.0f ? v : 0.0f;
+        if constexpr (EPI == DOF_EPI_MUL_DGELU)
+          v *= dgelu_f(xbase[r * A.ldaux + n * 16]) *
+               drop_scale(A.drop, ctr, ((s0 + 4 * lg + r) * A.T + t) * (int64_t)A.drop_ld + col);
+        float* __restrict__ dst = ybase + r * A.ldy + n * 16;
         *dst = A.accumulate ? *dst + v : v;
       }
     }
@@ -810,19 +816,31 @@ int dof_launch_tfm_embed_bwd(int F, const float* xs, const float* w, const float
 
 int dof_launch_tfm_gemm(const DofGemm& g, hipStream_t st) {
   const int KC = (g.K + 15) / 16, NT = (g.N + 15) / 16;
-  if (KC * NT * 256 > kGemmLds || NT > 12 || (g.ldx & 3)) {
+  const int NTM = NT <= 2 ? 2 : NT <= 3 ? 3 : NT <= 4 ? 4 : NT <= 6 ? 6 : NT <= 8 ? 8 : 12;
+  if (KC * NTM * 256 > kGemmLds || NT > 12 || (g.ldx & 3)) {
     dof_set_error("tfm gemm: K %d x N %d (ldx %d) not supported", g.K, g.N, g.ldx);
     return DOF_ERR_UNSUPPORTED;
   }
   const int64_t tiles = (int64_t)g.T * (g.Sp / 16);
   const unsigned nb = dof_cdiv(tiles, 16);
-  if (NT <= 4) {
-    DOF_LAUNCH((k_tfm_gemm<4>), (nb), (256), st, g);
-  } else if (NT <= 8) {
-    DOF_LAUNCH((k_tfm_gemm<8>), (nb), (256), st, g);
-  } else {
-    DOF_LAUNCH((k_tfm_gemm<12>), (nb), (256), st, g);
+#define GEMM_EPI(NTV)                                                                                          \
+  switch (g.epi) {                                                                                             \
+    case DOF_EPI_NONE: DOF_LAUNCH((k_tfm_gemm<NTV, DOF_EPI_NONE>), (nb), (256), st, g); break;                 \
+    case DOF_EPI_RELU: DOF_LAUNCH((k_tfm_gemm<NTV, DOF_EPI_RELU>), (nb), (256), st, g); break;                 \
+    case DOF_EPI_GELU: DOF_LAUNCH((k_tfm_gemm<NTV, DOF_EPI_GELU>), (nb), (256), st, g); break;                 \
+    case DOF_EPI_MUL_RELU: DOF_LAUNCH((k_tfm_gemm<NTV, DOF_EPI_MUL_RELU>), (nb), (256), st, g); break;         \
+    case DOF_EPI_MUL_DGELU: DOF_LAUNCH((k_tfm_gemm<NTV, DOF_EPI_MUL_DGELU>), (nb), (256), st, g); break;       \
+    default: dof_set_error("tfm gemm: unknown epilogue %d", g.epi); return DOF_ERR_ARG;                        \
   }
+  switch (NTM) {
+    case 2: GEMM_EPI(2) break;
+    case 3: GEMM_EPI(3) break;
+    case 4: GEMM_EPI(4) break;
+    case 6: GEMM_EPI(6) break;
+    case 8: GEMM_EPI(8) break;
+    default: GEMM_EPI(12) break;
+  }
+#undef GEMM_EPI
   return dof_check_launch("k_tfm_gemm");
 }
 

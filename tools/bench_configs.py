@@ -11,6 +11,7 @@ clip + Adam) on device-resident synthetic data, fp32, eager launches on the curr
   c5  VaDE, 2 animals (28 nodes, 32 edges), window 50, k=25, batch 4096, main phase
   infer  N1: gather + eval-mode encoder forward (embeddings + soft counts) of the C2 model, batch 4096
   c2tcn  the headline C2 workload (VaDE, 14 body parts, window 25, k=10, batch 1024) with the TCN encoder/decoder
+  c2tfm  the same workload with the transformer encoder/decoder (dropout from the on-device counter hash)
 """
 import argparse
 import json
@@ -25,7 +26,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from bench import init_params, synth_tables_fast  # noqa: E402
+from bench import synth_tables_fast  # noqa: E402
+
+
+def init_params(eng, seed=0):
+    """Random weights of a trained-like scale for every tensor of the plan (norm scales around 1)."""
+    g = torch.Generator().manual_seed(seed)
+    for n in eng.names:
+        shape = eng.layout[n][2]
+        v = torch.randn(shape, generator=g) * (0.3 if len(shape) > 1 else 0.1)
+        if "norm" in n and n.endswith("weight"):
+            v = 1.0 + v
+        eng.view(n).copy_(v)
 
 
 def timed(step, steps, warmup):
@@ -62,6 +74,13 @@ def run_vade_like(kind, ids, T, K, B, steps, warmup, frames=200_000):
     init_params(eng)
     if kind.endswith("_tcn"):
         init_tcn_params(eng)
+    if kind.endswith("_tfm"):  # LayerNorm / BatchNorm identity, zero biases (the family's initial state)
+        for n in eng.names:
+            if n.endswith("running_var") or ((".norm" in n or ".head.2" in n or ".head.5" in n) and n.endswith("weight")):
+                eng.view(n).fill_(1.0)
+            elif n.endswith("running_mean") or n.endswith("bias"):
+                eng.view(n).zero_()
+        eng.set_dropout(None, seed=1234)
     if kind.startswith("vqvae"):
         eng.view("vq_layer.codebook").uniform_(0.0, 1.0)
     tn, te = synth_tables_fast(frames, N, E, 0, dev)
@@ -185,7 +204,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--only", default="c3,c4,c4r,c5,c2tcn")
+    ap.add_argument("--only", default="c3,c4,c4r,c5,c2tcn,c2tfm")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a ROCm GPU")
@@ -205,6 +224,10 @@ def main():
             B = 1024
             sec, loss, N, E = run_vade_like("vade_tcn", [""], 25, 10, B, args.steps, args.warmup)
             desc = "C2 with the TCN family: VaDE TCN encoder/decoder, N=14,E=14, window=25, k=10, latent=8, batch=1024, main phase"
+        elif name == "c2tfm":
+            B = 1024
+            sec, loss, N, E = run_vade_like("vade_tfm", [""], 25, 10, B, args.steps, args.warmup)
+            desc = "C2 with the transformer family: VaDE transformer encoder/decoder, N=14,E=14, window=25, k=10, latent=8, batch=1024, main phase, dropout on"
         elif name == "infer":
             B = 4096
             sec, loss, N, E = run_inference(B, args.steps, args.warmup)
