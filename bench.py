@@ -106,6 +106,29 @@ def cpu_baseline(P, B, T, N, E, L, K, steps=10, warm=3):
                       f"oracle/vade.py, torch CPU fp32; the host has {all_cores} hardware threads"}
 
 
+def secondary_configs(steps=12, warmup=4):
+    """The other BASELINE configurations (and the two other encoder families at the C2 shape) timed in this same run,
+    so that their rates are driver-visible too: whole train steps on device-resident synthetic data, eager launches,
+    via tools/bench_configs.py.  Never part of `value`; a failing configuration reports its error string."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as BC
+    rows = []
+    plan = [("C3 VQ-VAE recurrent, codebook 512, batch 4096", lambda: BC.run_vade_like("vqvae", [""], 25, 512, 4096, steps, warmup), 4096),
+            ("C5 VaDE recurrent, 2 animals (N=28,E=32), window 50, k=25, batch 4096", lambda: BC.run_vade_like("vade", ["B", "W"], 50, 25, 4096, steps, warmup), 4096),
+            ("C4 contrastive TCN encoder, window 50 -> 25, batch 8192", lambda: BC.run_contrastive(8192, 50, max(4, steps // 3), 2), 8192),
+            ("C2 shape, VaDE TCN encoder/decoder, batch 1024", lambda: BC.run_vade_like("vade_tcn", [""], 25, 10, 1024, steps, warmup), 1024),
+            ("C2 shape, VaDE transformer encoder/decoder (dropout on), batch 1024", lambda: BC.run_vade_like("vade_tfm", [""], 25, 10, 1024, steps, warmup), 1024)]
+    for name, fn, B in plan:
+        try:
+            sec, loss, _n, _e = fn()
+            rows.append({"workload": name, "value": B / sec, "unit": "windows/s", "ms_per_step": sec * 1e3, "dtype": "f32",
+                         "final_total_loss": loss})
+        except Exception as exc:  # noqa: BLE001  (a secondary line must never take the headline down)
+            rows.append({"workload": name, "error": f"{type(exc).__name__}: {exc}"[:300]})
+        torch.cuda.empty_cache()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +138,7 @@ def main():
     ap.add_argument("--frames", type=int, default=600_000, help="frames per synthetic animal (2 animals per rank)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (C3, C4, C5, TCN / transformer)")
     ap.add_argument("--gather-iters", type=int, default=20)
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the timed steps keep stepping for about this long (second, longer measurement)")
@@ -322,6 +346,10 @@ def main():
         del xg, ag
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(initial_state, B, T, N, E, L, K)
+        if not args.no_secondary and world == 1:
+            del stepper, ds, tau_star
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_configs()
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 10 --gather-iters 3 $*"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-secondary --steps 40 --warmup 10 --gather-iters 3 $*"
 cd /tmp
 
 run_pass() {  # name, rocprof flags..., then the command
