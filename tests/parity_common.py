@@ -1209,3 +1209,92 @@ def run_contrastive_tfm_check(lib, device, golden_dir):
         if k.startswith("sd_after::") and "running_" in k:
             np.testing.assert_allclose(sd1[k[len("sd_after::"):]].numpy(), d[k], atol=5e-6, rtol=5e-5, err_msg=k)
     return worst
+
+
+def run_tfm_widths_vs_oracle(lib, device, n_nodes, latent, B=6, T=10, K=5, seed=0, kind="vade"):
+    """Transformer family at other widths than the goldens' (key_dim 24 / 32 / 48 / 64, latent 4 / 6, decoder widths
+    16 / 24): eval forward and one train step (all gradients) against the oracle (pinned to the reference at key_dim
+    40, latent 8) on random keep-masks injected into both.  Chain graph of n_nodes body parts."""
+    from oracle import tfm as OT
+    from oracle import vade as OV
+    from oracle import vqvae as OQ
+    N = n_nodes
+    adj = np.zeros((N, N), np.float32)
+    for i in range(N - 1):
+        adj[i, i + 1] = adj[i + 1, i] = 1
+    E = N - 1
+    eng = VadeEngine(lib, device, B, T, adj, latent, K, kind=f"{kind}_tfm")
+    g = torch.Generator().manual_seed(seed)
+    for n in eng.names:
+        shape = eng.layout[n][2]
+        v = torch.randn(shape, generator=g) * (0.25 if len(shape) > 1 else 0.1)
+        if (".norm" in n or ".head.2" in n or ".head.5" in n) and n.endswith("weight"):
+            v = 1.0 + v
+        if n.endswith("running_var"):
+            v = 0.5 + torch.rand(shape, generator=g)
+        eng.view(n).copy_(v)
+    P = {k: v.clone() for k, v in eng.state_dict().items()}
+    x = torch.randn(B, T, N, 3, generator=g)
+    a = torch.randn(B, T, E, 1, generator=g)
+    x[1, 2] = 0.0
+    a[1, 2] = 0.0                       # one padded / masked frame
+    eng.set_bn_training(False)
+    if kind == "vade":
+        out = eng.forward(x.to(device), a.to(device), None, want_loc=True)
+        with torch.no_grad():
+            ref = OV.vade_forward({k: v.clone() for k, v in P.items()}, x, a, training=False)
+        np.testing.assert_allclose(out["z"].cpu().numpy(), ref["z"].numpy(), atol=3e-5, rtol=2e-4)
+        np.testing.assert_allclose(out["loc"].cpu().numpy(), ref["loc"].numpy(), atol=1e-4, rtol=2e-4)
+    else:
+        out = eng.vq_forward(x.to(device), a.to(device))
+        with torch.no_grad():
+            ref = OQ.vqvae_forward({k: v.clone() for k, v in P.items()}, x, a, training=False)
+        np.testing.assert_allclose(out["ze"].cpu().numpy(), ref["ze"].numpy(), atol=3e-5, rtol=2e-4)
+        np.testing.assert_allclose(out["loc_e"].cpu().numpy(), ref["loc_e"].numpy(), atol=1e-4, rtol=2e-4)
+    # train step on random masks (no masked frames: a masked frame makes the reconstruction loss NaN, SURVEY Q3)
+    x[1, 2] = torch.randn(N, 3, generator=g)
+    a[1, 2] = torch.randn(E, 1, generator=g)
+    eng.set_bn_training(True)
+    sites = eng.dropout_sites()
+    shapes = {}
+    for name, _off, numel, p in sites:
+        shapes[name] = (torch.rand(numel, generator=g) >= p).to(torch.uint8)
+    eng.set_dropout(shapes)
+
+    class Tape(OT.DropoutTape):  # hands out the named masks in the oracle's own draw order
+        def __init__(self):
+            super().__init__([])
+
+        def take(self, site, shape, p):
+            m = shapes[site].reshape(tuple(shape))
+            self.named.append((site, m, p))
+            return m.to(torch.float32) / (1.0 - p)
+
+    eps = torch.randn(B, latent, generator=g)
+    if kind == "vade":
+        configure_phase(eng, K, True, 0.2, None, 0.0)
+        eng.loss_grads(x.to(device), a.to(device), eps.to(device), None, None, pretrain=True)
+        losses, grads, _ = OV.vade_grads({k: v.clone() for k, v in P.items()}, x, a, OV.VadeLossCfg(K, True), 0.2, eps,
+                                         drop=Tape())
+        np.testing.assert_allclose(eng.read_logs()["total_loss"], float(losses["total_loss"]), rtol=2e-4)
+    else:
+        eng.set_hyper(vq_beta=1.0, km_latent=0.0, km_loss=0.0, clip=0.75, wd=1e-4)
+        eng.push_hyper()
+        eng.vq_loss_grads(x.to(device), a.to(device))
+        losses, grads, _ = OQ.vqvae_grads({k: v.clone() for k, v in P.items()}, x, a, 1.0, 0.0, drop=Tape())
+        np.testing.assert_allclose(eng.read_vq_logs()["total_loss"], float(losses["total_loss"]), rtol=2e-4)
+    worst, n = 0.0, 0
+    for name, ref_g in grads.items():
+        if ref_g is None or name in ("encoder.head.6.bias", "encoder.head.5.bias"):
+            continue
+        got = eng.view(name, eng.grads).cpu().numpy()
+        r = ref_g.numpy().reshape(got.shape)
+        scale = float(np.abs(r).max())
+        err = float(np.abs(got - r).max())
+        # small batches: a ReLU input within rounding of zero may flip (see ReluKinkFlipper); bound, do not equate
+        assert err <= 1e-4 + 3e-3 * scale, (name, err, scale)
+        worst = max(worst, err / max(scale, 1e-30))
+        n += 1
+    assert n >= 60
+    eng.set_dropout(None)
+    return worst

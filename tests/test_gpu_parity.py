@@ -1069,3 +1069,12 @@ def test_data_parallel_step_rccl(tmp_path, world):
         torch.testing.assert_close(r["sum"], total, rtol=1e-6, atol=1e-8)
     if world > 1:
         assert float((res[0]["local"] - res[1]["local"]).abs().max()) > 0
+
+
+@pytest.mark.parametrize("n_nodes,latent,kind", [(8, 4, "vade"), (11, 6, "vqvae"), (16, 8, "vade"), (22, 8, "vqvae"),
+                                                  (28, 8, "vade")])
+def test_tfm_other_widths_gpu(hip, n_nodes, latent, kind):
+    """key_dim 24 / 32 / 48 / 64, latent 4 / 6 / 8 (decoder widths 16 / 24 / 32) of the transformer family against the
+    oracle on injected random keep-masks: eval forward with a masked frame, total loss and every gradient."""
+    from parity_common import run_tfm_widths_vs_oracle
+    print("worst gradient error / tensor scale:", run_tfm_widths_vs_oracle(hip, "cuda", n_nodes, latent, B=24, T=25, kind=kind))
