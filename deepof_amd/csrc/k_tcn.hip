@@ -147,11 +147,6 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
   const float b0 = (!REVERSE && A.bias) ? A.bias[i] : 0.0f;
   const float b1 = (!REVERSE && A.bias) ? A.bias[16 + i] : 0.0f;
   float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
-  // forward statistics: sums of (y - c) and (y - c)^2 about a per-wave, per-channel shift c = the channel means of the
-  // wave's first tile (see k_tcn_stats_merge): E[y^2] - mean^2 without the cancellation, without a second pass over y
-  float shift[2] = {0.0f, 0.0f};
-  float n_rows = 0.0f;
-  bool have_shift = false;
   const int64_t tiles_per_t = A.Sp / 16;
   const int64_t n_tiles = (int64_t)A.T * tiles_per_t;
   for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
@@ -177,25 +172,6 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
       }
     }
     // D layout: lane holds rows kk*4 + r, column i (of column tile 0 / 1)
-    if (!REVERSE && A.partial) {
-      const int64_t left = A.S - s0;                   // valid rows of this tile (wave-uniform)
-      const float nv = left >= 16 ? 16.0f : (left > 0 ? (float)left : 0.0f);
-      if (!have_shift && nv > 0.0f) {
-        float m0 = 0.0f, m1 = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (s0 + kk * 4 + r < A.S) {
-            m0 += acc0[r];
-            m1 += acc1[r];
-          }
-        m0 += __shfl_xor(m0, 16); m0 += __shfl_xor(m0, 32);
-        m1 += __shfl_xor(m1, 16); m1 += __shfl_xor(m1, 32);
-        shift[0] = m0 / nv;
-        shift[1] = m1 / nv;
-        have_shift = true;
-      }
-      n_rows += nv;
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t s = s0 + kk * 4 + r;
@@ -218,9 +194,8 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
         o[i] = v0;
         o[16 + i] = v1;
         if (!REVERSE) {
-          const float d0 = v0 - shift[0], d1 = v1 - shift[1];
-          s1[0] += d0; s2[0] = fmaf(d0, d0, s2[0]);
-          s1[1] += d1; s2[1] = fmaf(d1, d1, s2[1]);
+          s1[0] += v0; s2[0] = fmaf(v0, v0, s2[0]);
+          s1[1] += v1; s2[1] = fmaf(v1, v1, s2[1]);
         }
       }
     }
@@ -231,15 +206,7 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
       s1[ct] += __shfl_xor(s1[ct], 16); s1[ct] += __shfl_xor(s1[ct], 32);
       s2[ct] += __shfl_xor(s2[ct], 16); s2[ct] += __shfl_xor(s2[ct], 32);
     }
-    if (!REVERSE) {  // record of k_tcn_stats_merge: [sum (y-c) | sum (y-c)^2 | c | rows]
-      if (kk == 0) {
-        float* p = A.partial + (int64_t)wave * DOF_TCN_STAT_STRIDE(TC);
-        p[i] = s1[0]; p[16 + i] = s1[1];
-        p[TC + i] = s2[0]; p[TC + 16 + i] = s2[1];
-        p[2 * TC + i] = shift[0]; p[2 * TC + 16 + i] = shift[1];
-        if (i == 0) p[3 * TC] = n_rows;
-      }
-    } else if (kk == 0) {
+    if (kk == 0) {
       float* p = A.partial + (int64_t)wave * 2 * TC;
       p[i] = s1[0]; p[16 + i] = s1[1];
       p[TC + i] = s2[0]; p[TC + 16 + i] = s2[1];
@@ -276,14 +243,12 @@ __global__ void __launch_bounds__(256) k_tcn_convg(TcnConvArgs A, int cin_real, 
       sh[q] = BNP_SHIFT(A.bnp_in, KC, kk * KS + q);
     }
   }
-  float bias[NT], s1[NT], s2[NT], shift[NT];
+  float bias[NT], s1[NT], s2[NT];
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
     bias[ct] = (!REVERSE && A.bias) ? A.bias[ct * 16 + i] : 0.0f;
-    s1[ct] = s2[ct] = shift[ct] = 0.0f;
+    s1[ct] = s2[ct] = 0.0f;
   }
-  float n_rows = 0.0f;
-  bool have_shift = false;
   const int64_t tiles_per_t = A.Sp / 16;
   const int64_t n_tiles = (int64_t)A.T * tiles_per_t;
   for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
@@ -313,23 +278,6 @@ __global__ void __launch_bounds__(256) k_tcn_convg(TcnConvArgs A, int cin_real, 
             acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wl[((j * KS + q) * NT + ct) * 64 + lane], acc[ct], 0, 0, 0);
       }
     }
-    if (!REVERSE && A.partial) {  // shifted statistics, see k_tcn_conv
-      const int64_t left = A.S - s0;
-      const float nv = left >= 16 ? 16.0f : (left > 0 ? (float)left : 0.0f);
-      if (!have_shift && nv > 0.0f) {
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-          float m = 0.0f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (s0 + kk * 4 + r < A.S) m += acc[ct][r];
-          m += __shfl_xor(m, 16); m += __shfl_xor(m, 32);
-          shift[ct] = m / nv;
-        }
-        have_shift = true;
-      }
-      n_rows += nv;
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t s = s0 + kk * 4 + r;
@@ -341,16 +289,15 @@ __global__ void __launch_bounds__(256) k_tcn_convg(TcnConvArgs A, int cin_real, 
           if (REVERSE && A.accumulate) v += o[ct * 16 + i];
           o[ct * 16 + i] = v;
           if (!REVERSE) {
-            const float d = v - shift[ct];
-            s1[ct] += d;
-            s2[ct] = fmaf(d, d, s2[ct]);
+            s1[ct] += v;
+            s2[ct] = fmaf(v, v, s2[ct]);
           }
         }
       }
     }
   }
   if (!REVERSE && A.partial) {
-    float* p = A.partial + (int64_t)wave * DOF_TCN_STAT_STRIDE(NC);
+    float* p = A.partial + (int64_t)wave * 2 * NC;
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
       s1[ct] += __shfl_xor(s1[ct], 16); s1[ct] += __shfl_xor(s1[ct], 32);
@@ -358,10 +305,8 @@ __global__ void __launch_bounds__(256) k_tcn_convg(TcnConvArgs A, int cin_real, 
       if (kk == 0) {
         p[ct * 16 + i] = s1[ct];
         p[NC + ct * 16 + i] = s2[ct];
-        p[2 * NC + ct * 16 + i] = shift[ct];
       }
     }
-    if (lane == 0) p[3 * NC] = n_rows;
   }
 }
 
@@ -434,56 +379,6 @@ __global__ void __launch_bounds__(256) k_tcn_var_sum(const float* __restrict__ p
     __syncthreads();
   }
   if (threadIdx.x == 0) sums[CT + ch] = red[0];
-}
-
-// Batch statistics of a convolution output from the per-wave records its epilogue wrote
-// ([sum (y-c) | sum (y-c)^2 | c | rows] with c = the channel means of the wave's first tile, so |mean_w - c| is a
-// fraction of the standard deviation and s2 - s1^2 / n loses nothing): Chan's pairwise update in a fixed order,
-//   mean = sum_w n_w mean_w / N,   M2 = sum_w [M2_w + n_w (mean_w - mean)^2],
-// one workgroup per channel -> sums[ch] = N * mean, sums[NC + ch] = M2 (what k_bn_fwd_fin reads).  This replaces the
-// centred second pass over the whole tensor (k_tcn_var: 367 MB per layer at C4).
-__global__ void __launch_bounds__(256) k_tcn_stats_merge(const float* __restrict__ rec, int64_t n_rec, int NC,
-                                                         float* __restrict__ sums) {
-  __shared__ float red[256];
-  const int ch = blockIdx.x;
-  const int stride = DOF_TCN_STAT_STRIDE(NC);
-  auto block_sum = [&](float v) {
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-      __syncthreads();
-    }
-    const float r = red[0];
-    __syncthreads();
-    return r;
-  };
-  float n_acc = 0.0f, m_acc = 0.0f;
-  for (int64_t w = threadIdx.x; w < n_rec; w += 256) {
-    const float* __restrict__ p = rec + w * stride;
-    const float n = p[3 * NC];
-    if (n > 0.0f) {
-      n_acc += n;
-      m_acc += n * p[2 * NC + ch] + p[ch];   // n * mean_w = n * c + s1
-    }
-  }
-  const float N = block_sum(n_acc);
-  const float mean = block_sum(m_acc) / fmaxf(N, 1.0f);
-  float q_acc = 0.0f;
-  for (int64_t w = threadIdx.x; w < n_rec; w += 256) {
-    const float* __restrict__ p = rec + w * stride;
-    const float n = p[3 * NC];
-    if (n > 0.0f) {
-      const float s1 = p[ch];
-      const float dm = p[2 * NC + ch] + s1 / n - mean;
-      q_acc += (p[NC + ch] - s1 * s1 / n) + n * dm * dm;
-    }
-  }
-  const float M2 = block_sum(q_acc);
-  if (threadIdx.x == 0) {
-    sums[ch] = N * mean;
-    sums[NC + ch] = fmaxf(M2, 0.0f);
-  }
 }
 
 // the same for [c][Bp] head tensors: sums[C + c] = sum_b (h[c][b] - mean_c)^2 ; one workgroup per channel
@@ -1176,11 +1071,7 @@ int dof_launch_tcn_dec_out(const float* skip, const float* wp, const float* bp, 
 // Batch statistics of one TCN layer from the convolution's channel-sum partials (rows of `stride` floats, the first
 // CT of which are the sums of y) + a centred second pass over y; leaves sums[2][CT] for dof_launch_bn_fwd_fin.
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
-                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st, int records) {
-  if (records) {  // per-wave shifted records of the MFMA convolutions: no pass over y
-    DOF_LAUNCH(k_tcn_stats_merge, ((unsigned)CT), (256), st, (const float*)partial, n_partial, CT, sums);
-    return dof_check_launch("k_tcn_stats_merge");
-  }
+                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st) {
   TRY_RC(dof_launch_sum_partials(partial, n_partial, stride, sums, 0, st));
   const unsigned nb = (unsigned)dof_tcn_row_blocks(T, S);
   DOF_LAUNCH(k_tcn_var, (nb, (unsigned)(CT / TC)), (256), st, y, (const float*)sums, count, partial, T, CT, S, Sp);

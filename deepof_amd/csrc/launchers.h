@@ -43,12 +43,8 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st);
-// floats per wave of the forward convolutions' statistics records: sum (y-c) | sum (y-c)^2 | c (NC each) | rows
-#define DOF_TCN_STAT_STRIDE(NC) (3 * (NC) + 4)
-// records = 1: `partial` holds those records (k_tcn_conv / k_tcn_convg forward) and is merged without touching y;
-// records = 0: `partial` holds per-block channel sums (k_tcn_in_conv) and the variance takes a centred pass over y
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
-                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st, int records = 0);
+                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
                           float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st);
 int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,

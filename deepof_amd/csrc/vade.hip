@@ -532,7 +532,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     for (int k = 0; k < 16; ++k) t.bnp[k] = cv.take(4 * 32);
     const int64_t rows = dof_tcn_row_blocks(T, w.S), waves = dof_tcn_conv_waves(T, Sp);
     t.partial_rows = rows > waves ? rows : waves;
-    t.partial = cv.take(t.partial_rows * DOF_TCN_STAT_STRIDE(32));
+    t.partial = cv.take(t.partial_rows * 64);
     t.sums = cv.take(64);
     t.coef = cv.take(64);
     // CensNet operands
@@ -583,7 +583,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     for (int k = 0; k < 8; ++k) d.bnp[k] = cv.take(4 * 64);
     const int64_t rows = 2 * dof_tcn_row_blocks(T, B), waves = 2 * dof_tcn_conv_waves(T, Bp);
     d.partial_rows = rows > waves ? rows : waves;
-    d.partial = cv.take(d.partial_rows * (DOF_TCN_STAT_STRIDE(64) / 2 + 2));
+    d.partial = cv.take(d.partial_rows * 64);
     d.sums = cv.take(128); d.coef = cv.take(128);
     d.hid = cv.take(act); d.dskip = cv.take(act);
     d.dzrep = cv.take((int64_t)T * Bp * 32);
@@ -1284,12 +1284,12 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
                                 ws + t.partial, 0, T, d, w.S, w.Sp, st));
         nrows = dof_tcn_conv_waves(T, w.Sp);
       }
-      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, b > 0));
+      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
                                 train, ws + t.bnp[2 * b], 32, st));
       TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b], ws + t.a1[b],
                               ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st));
-      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv_waves(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, 1));
+      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv_waves(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
                                 train, ws + t.bnp[2 * b + 1], 32, st));
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
@@ -1377,12 +1377,12 @@ int tcn_decoder_forward(DofVadePlan* p, float* params, const float* x, const flo
       TRY(dof_launch_tcn_convg(0, CD, CD, ws + d.out[b - 1], params + o.c1w, CD, CD, params + o.c1b, nullptr, nullptr,
                                ws + d.y1[b], ws + d.partial, 0, T, dl, B, Bp, st));
     }
-    if (train) TRY(dof_launch_tcn_bn_stats(ws + d.y1[b], ws + d.partial, waves, 2 * CD, ws + d.sums, count, T, CD, B, Bp, st, 1));
+    if (train) TRY(dof_launch_tcn_bn_stats(ws + d.y1[b], ws + d.partial, waves, 2 * CD, ws + d.sums, count, T, CD, B, Bp, st));
     TRY(dof_launch_bn_fwd_fin(ws + d.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
                               train, ws + d.bnp[2 * b], CD, st));
     TRY(dof_launch_tcn_convg(0, CD, CD, ws + d.y1[b], params + o.c2w, CD, CD, params + o.c2b, ws + d.bnp[2 * b],
                              ws + d.a1[b], ws + d.y2[b], ws + d.partial, 0, T, dl, B, Bp, st));
-    if (train) TRY(dof_launch_tcn_bn_stats(ws + d.y2[b], ws + d.partial, waves, 2 * CD, ws + d.sums, count, T, CD, B, Bp, st, 1));
+    if (train) TRY(dof_launch_tcn_bn_stats(ws + d.y2[b], ws + d.partial, waves, 2 * CD, ws + d.sums, count, T, CD, B, Bp, st));
     TRY(dof_launch_bn_fwd_fin(ws + d.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
                               train, ws + d.bnp[2 * b + 1], CD, st));
     TRY(dof_launch_tcn_combine(ws + d.y2[b], ws + d.bnp[2 * b + 1], b ? ws + d.out[b - 1] : nullptr, ws + d.zrep,
