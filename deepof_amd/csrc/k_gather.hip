@@ -18,7 +18,8 @@
 
 namespace {
 
-constexpr int WB = 16;  // windows per workgroup: keeps every workgroup's output 16-byte aligned
+constexpr int WB = 16;  // windows per workgroup (a multiple of 4 keeps every workgroup's output 16-byte aligned)
+constexpr int WB_SMALL = 4;  // ... for launches of a few thousand windows (a training batch): 4x the workgroups
 
 // exact unsigned division for n < 2^24 by a runtime divisor with a precomputed (rounded-down) reciprocal
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float rcp_lo) {
@@ -38,7 +39,7 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float rcp_l
 // 16-byte store costs four table lookups + four LDS reads instead of four strided global gathers (the
 // gathers kept the kernel on the texture-address path: 56 % of HBM peak; a pure fill reaches 6.2 TB/s here).
 // Workgroups whose windows are too far apart for the staging buffer take the direct path (STAGE == 0 code).
-template <bool INDEXED, int STAGE, int TAB>
+template <bool INDEXED, int STAGE, int TAB, int WB>
 __global__ void __launch_bounds__(256) k_window_gather(
     const float* __restrict__ node_table, const float* __restrict__ edge_table,
     const int64_t* __restrict__ row_start, int64_t first_row, int64_t row_step, int64_t n_windows,
@@ -239,13 +240,20 @@ int launch_gather(const float* node_table, const float* edge_table, const int64_
     return DOF_ERR_UNSUPPORTED;
   }
   if (n_windows == 0) return DOF_OK;
-  const unsigned blocks = (unsigned)((n_windows + WB - 1) / WB);
+  // a training batch (1024 windows) is 64 workgroups of 16 windows on a 256-CU chip: use 4 windows per workgroup there
+  const bool small = n_windows <= 8192;
+  const int wb = small ? WB_SMALL : WB;
+  const unsigned blocks = (unsigned)((n_windows + wb - 1) / wb);
   const float rp = rcp_down((unsigned)(W * 3 * N)), rc = rcp_down((unsigned)(3 * N));
-  // staging-buffer class by the footprint of WB stride-1 windows (other spacings decide per workgroup)
-  const int64_t need = (int64_t)(WB - 1 + W) * (3 * N + E), tabn = (int64_t)W * 3 * N;
-#define GATHER(IDX, ST, TB)                                                                                      \
-  DOF_LAUNCH((k_window_gather<IDX, ST, TB>), (blocks), (256), stream, node_table, edge_table, row_start, first_row, \
+  // staging-buffer class by the footprint of wb stride-1 windows (other spacings decide per workgroup)
+  const int64_t need = (int64_t)(wb - 1 + W) * (3 * N + E), tabn = (int64_t)W * 3 * N;
+#define GATHER1(IDX, ST, TB, WBV)                                                                                     \
+  DOF_LAUNCH((k_window_gather<IDX, ST, TB, WBV>), (blocks), (256), stream, node_table, edge_table, row_start, first_row, \
              row_step, n_windows, W, N, E, rp, rc, x_out, a_out)
+#define GATHER(IDX, ST, TB)                                            \
+  do {                                                                 \
+    if (small) GATHER1(IDX, ST, TB, WB_SMALL); else GATHER1(IDX, ST, TB, WB); \
+  } while (0)
   if (need <= 3072 && tabn <= 1280) {
     if (row_start) GATHER(true, 3072, 1280); else GATHER(false, 3072, 1280);
   } else if (need <= 10240 && tabn <= 4608) {
@@ -253,6 +261,7 @@ int launch_gather(const float* node_table, const float* edge_table, const int64_
   } else {
     if (row_start) GATHER(true, 0, 0); else GATHER(false, 0, 0);
   }
+#undef GATHER1
 #undef GATHER
   return dof_check_launch("k_window_gather");
 }

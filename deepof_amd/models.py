@@ -329,9 +329,14 @@ class VaDE(nn.Module):
         (inside the training step the HIP path computes value and gradient on device)."""
         if not self.kmeans_weight > 0:
             return torch.zeros((), device=z.device)
-        gram = (z.T @ z) / float(z.shape[0])
-        sv = torch.linalg.svdvals(gram.double().cpu())
-        return (self.kmeans_weight * torch.sqrt(torch.clamp(sv, min=1e-9)).mean()).to(z.device)
+        gram = ((z.T @ z) / float(z.shape[0])).double()
+        if gram.device.type == "cuda":
+            # on the device, no host round trip: the Gram matrix is symmetric positive semi-definite, so its singular
+            # values are its eigenvalues (the reference's svdvals, losses.py:279)
+            sv = torch.linalg.eigvalsh(gram).clamp_min(0.0)
+        else:
+            sv = torch.linalg.svdvals(gram)
+        return (self.kmeans_weight * torch.sqrt(torch.clamp(sv, min=1e-9)).mean()).to(torch.float32)
 
     @torch.no_grad()
     def embed(self, x, a):

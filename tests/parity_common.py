@@ -41,7 +41,9 @@ def gather_check(lib, device):
     for (N, E, W, Fr, starts) in [(14, 14, 25, 90, [0, 1, 2, 3, 40, 65, 7]), (5, 4, 7, 31, list(range(25))),
                                   (28, 32, 50, 120, [70, 0, 33]), (14, 14, 25, 120, list(range(3, 3 + 37))),
                                   (28, 32, 50, 130, list(range(60, 60 + 21))), (14, 14, 25, 90, [9, 4, 11, 4, 30, 12]),
-                                  (42, 47, 50, 140, list(range(0, 70, 3)))]:
+                                  (42, 47, 50, 140, list(range(0, 70, 3))),
+                                  # > 8192 windows: the 16-windows-per-workgroup variant (smaller launches use 4)
+                                  (5, 4, 7, 8400, list(range(1, 1 + 8213)))]:
         nodes = rng.standard_normal((Fr, 3 * N)).astype(np.float32)
         edges = rng.standard_normal((Fr, E)).astype(np.float32)
         x_ref, a_ref = OW.gather_windows(nodes, edges, np.array(starts), W)
