@@ -149,30 +149,57 @@ __global__ void __launch_bounds__(256) k_tfm_gemm(DofGemm A) {
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int64_t tiles = (int64_t)A.T * (A.Sp / 16);
   [[maybe_unused]] const uint32_t ctr = drop_ctr(A.drop);
-#pragma unroll 1
-  for (int it = 0; it < 4; ++it) {
-    const int64_t tile = (int64_t)blockIdx.x * 16 + wave + 4 * it;
-    if (tile >= tiles) break;
-    const int64_t row0 = tile * 16;
+  // A operands: four 16-column chunks (one float4 per lane each) are in flight together, and the next group -- or the
+  // first group of the wave's next tile -- is requested before the current group's MFMAs issue (PMC of the
+  // load-then-multiply form: 58 % of the wave-cycles parked on vmcnt, MFMA pipe 25 % busy)
+  const int G = (KC + 3) / 4;
+  auto load_group = [&](const float* __restrict__ xr, int g, float4 (&buf)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int jc = g * 4 + j;
+      buf[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (jc < KC && jc * 16 + 4 * lg < K) buf[j] = *reinterpret_cast<const float4*>(xr + jc * 16);
+    }
+  };
+  auto tile_of = [&](int it) { return (int64_t)blockIdx.x * 16 + wave + 4 * it; };
+  auto tile_live = [&](int it) {
+    const int64_t tl = tile_of(it);
+    return it < 4 && tl < tiles && (tl * 16) % A.Sp < A.S;
+  };
+  float4 cur[4], nxt[4];
+  int it = 0;
+  while (it < 4 && !tile_live(it)) ++it;
+  if (it < 4) load_group(A.X + (tile_of(it) * 16 + li) * A.ldx + 4 * lg, 0, cur);
+  while (it < 4) {
+    const int64_t row0 = tile_of(it) * 16;
     const int64_t s0 = row0 % A.Sp;
-    if (s0 >= A.S) continue;  // a tile of pad rows (wave-uniform)
+    int it_next = it + 1;
+    while (it_next < 4 && !tile_live(it_next)) ++it_next;
     dof_f32x4 acc[NTMAX];
 #pragma unroll
     for (int n = 0; n < NTMAX; ++n) acc[n] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const float* __restrict__ xr = A.X + (row0 + li) * A.ldx + 4 * lg;
 #pragma unroll 1
-    for (int jc = 0; jc < KC; ++jc) {
-      float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (jc * 16 + 4 * lg < K) a4 = *reinterpret_cast<const float4*>(xr + jc * 16);
-      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-      const float* __restrict__ wrow = wl + (jc * 4 * NT) * 64 + lane;
+    for (int g = 0; g < G; ++g) {
+      if (g + 1 < G) load_group(xr, g + 1, nxt);
+      else if (it_next < 4) load_group(A.X + (tile_of(it_next) * 16 + li) * A.ldx + 4 * lg, 0, nxt);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int j = 0; j < 4; ++j) {
+        if (g * 4 + j < KC) {  // (wave-uniform)
+          const float av[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+          const float* __restrict__ wrow = wl + ((g * 4 + j) * 4 * NT) * 64 + lane;
 #pragma unroll
-        for (int n = 0; n < NTMAX; ++n)
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], wrow[(m * NT + n) * 64], acc[n], 0, 0, 0);
+          for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int n = 0; n < NTMAX; ++n)
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], wrow[(m * NT + n) * 64], acc[n], 0, 0, 0);
+          }
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
     }
+    it = it_next;
     // epilogue: lane (li, lg) holds rows row0 + 4 lg + r (r < 4), column n * 16 + li of tile n
     const int64_t rbase = row0 + 4 * lg;
     float* __restrict__ ybase = A.Y + rbase * A.ldy + li;
