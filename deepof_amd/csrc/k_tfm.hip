@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(512) k_tfm_attn_fwd(DofAttn A) {
   __syncthreads();
   const int tq = tid % T, h = (tid / T) % H, seq = tid / (T * H);
   if (seq >= nseq || s0 + seq >= A.S) return;
+  if (A.q_last && tq != T - 1) return;
   const float scale = A.scale;
   float q[DH];
 #pragma unroll
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(512) k_tfm_attn_bwd(DofAttn A) {
   const bool live = seq < nseq && s0 + seq < A.S;
   const float scale = A.scale;
   const uint32_t ctr = drop_ctr(A.drop);
-  if (live) {  // ---- phase A: thread = query row tx
+  if (live && (!A.q_last || tx == T - 1)) {  // ---- phase A: thread = query row tx
     float q[DH], go[DH];
 #pragma unroll
     for (int d = 0; d < DH; ++d) {
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(512) k_tfm_attn_bwd(DofAttn A) {
       dv[d] = 0.0f;
     }
     const bool key_masked = spad[seq * T + tx] != 0.0f;
-    for (int tq = (A.causal ? tx : 0); tq < T; ++tq) {
+    for (int tq = (A.q_last ? T - 1 : (A.causal ? tx : 0)); tq < T; ++tq) {
       const float* __restrict__ st = sst + ((seq * H + h) * T + tq) * 3;
       const float* __restrict__ qr = sq + (tq * nseq + seq) * W + h * DH;
       const float* __restrict__ gr = sdo + (tq * nseq + seq) * D + h * DH;
@@ -472,8 +473,8 @@ __global__ void __launch_bounds__(256) k_tfm_add_ln_fwd(DofLn A) {
       if (A.h) {
         const float4 h4 = *reinterpret_cast<const float4*>(A.h + row * C + 4 * j);
         const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
-        const int t = (int)(row / A.Sp);
-        const int64_t base = (s * A.T + t) * (int64_t)C + 4 * j;
+        const int t = (int)(row / A.Sp) + A.t_off;
+        const int64_t base = (s * (A.T_idx ? A.T_idx : A.T) + t) * (int64_t)C + 4 * j;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = fmaf(hv[c], drop_scale(A.drop, ctr, base + c), v[c]);
       }
@@ -560,8 +561,8 @@ __global__ void __launch_bounds__(256) k_tfm_ln_bwd(DofLnBwd A) {
       }
       if (A.du) *reinterpret_cast<float4*>(A.du + row * C + 4 * j) = make_float4(du[0], du[1], du[2], du[3]);
       if (A.dh) {
-        const int t = (int)(row / A.Sp);
-        const int64_t base = (s * A.T + t) * (int64_t)C + 4 * j;
+        const int t = (int)(row / A.Sp) + A.t_off;
+        const int64_t base = (s * (A.T_idx ? A.T_idx : A.T) + t) * (int64_t)C + 4 * j;
         float o[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = du[c] * drop_scale(A.drop, ctr, base + c);

@@ -120,14 +120,18 @@ struct DofAttn {
   int T, D, H, causal, nseq;
   float scale;
   int64_t S, Sp;
+  int q_last;         // only the last query row (t = T - 1) is evaluated / differentiated (final encoder layer)
 };
 struct DofLn {         // u = x + drop(h) (h may be null), y = LayerNorm(u) (gamma null: residual add only)
   const float* x; const float* h; float* u; float* y; const float* gamma; const float* beta;
   DofDrop drop; int T; int64_t S, Sp; float eps;
+  int t_off, T_idx;  // dropout index of row (t, s): (s * T_idx + t + t_off) -- a launch over the LAST time step of a
+                     // longer tensor (T = 1, pointers offset) passes t_off = T_full - 1, T_idx = T_full; 0, 0 = (0, T)
 };
 struct DofLnBwd {
   const float* dy1; const float* dy2; const float* dres; const float* u; const float* gamma;
   float* du; float* dh; float* partial; DofDrop drop; int T; int64_t S, Sp; float eps;
+  int t_off, T_idx;
 };
 struct DofDecExp {     // TFMDecoderPT.latent_expand; per-window tensors [c][Bp]
   const float* z; const float *w0, *b0, *w1, *b1, *w2, *b2;

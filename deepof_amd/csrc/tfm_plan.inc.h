@@ -264,10 +264,21 @@ void build_tfm_jobs(DofVadePlan* p) {
     for (int l = 0; l < 2; ++l) {
       const TfmEncLayerOff& o = tf.el[s][l];
       const float* xin = ws + (l == 0 ? e.y0 : e.x2[l - 1]);
-      tfm_dense_jobs(jb, ws + e.dQKV[l], 3 * D, 3 * D, xin, D, D, o.wqkv, -1, T, Sp);
-      tfm_dense_jobs(jb, ws + e.dH1[l], D, D, ws + e.ao[l], D, D, o.wo, -1, T, Sp);
-      tfm_dense_jobs(jb, ws + e.dF[l], DFF, DFF, ws + e.x1[l], D, D, o.f0w, o.f0b, T, Sp);
-      tfm_dense_jobs(jb, ws + e.dH2[l], D, D, ws + e.f1[l], DFF, DFF, o.f2w, o.f2b, T, Sp);
+      if (l == 0) {
+        tfm_dense_jobs(jb, ws + e.dQKV[l], 3 * D, 3 * D, xin, D, D, o.wqkv, -1, T, Sp);
+        tfm_dense_jobs(jb, ws + e.dH1[l], D, D, ws + e.ao[l], D, D, o.wo, -1, T, Sp);
+        tfm_dense_jobs(jb, ws + e.dF[l], DFF, DFF, ws + e.x1[l], D, D, o.f0w, o.f0b, T, Sp);
+        tfm_dense_jobs(jb, ws + e.dH2[l], D, D, ws + e.f1[l], DFF, DFF, o.f2w, o.f2b, T, Sp);
+      } else {
+        // final layer: only its LAST query row feeds the model output, so everything behind the attention lives in
+        // the last time step (rows [(T-1) Sp, T Sp), contiguous); keys / values still come from every step
+        const int64_t ro = (int64_t)(T - 1) * Sp;
+        tfm_dense_jobs(jb, ws + e.dQKV[l] + ro * 3 * D, 3 * D, D, xin + ro * D, D, D, o.wqkv, -1, 1, Sp);            // W_q
+        tfm_dense_jobs(jb, ws + e.dQKV[l] + D, 3 * D, 2 * D, xin, D, D, o.wqkv + (int64_t)D * D, -1, T, Sp);          // W_k | W_v
+        tfm_dense_jobs(jb, ws + e.dH1[l] + ro * D, D, D, ws + e.ao[l] + ro * D, D, D, o.wo, -1, 1, Sp);
+        tfm_dense_jobs(jb, ws + e.dF[l] + ro * DFF, DFF, DFF, ws + e.x1[l] + ro * D, D, D, o.f0w, o.f0b, 1, Sp);
+        tfm_dense_jobs(jb, ws + e.dH2[l] + ro * D, D, D, ws + e.f1[l] + ro * DFF, DFF, DFF, o.f2w, o.f2b, 1, Sp);
+      }
     }
     cens_jobs(p, jb, s);
   }
@@ -338,24 +349,40 @@ int tfm_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
       const TfmEncLayerOff& o = tf.el[s][l];
       const float* xin = ws + (l == 0 ? e.y0 : e.x2[l - 1]);
       const int sl = site0 + 1 + 3 * l;
-      TRY(dof_launch_tfm_gemm(tfm_gemm(xin, D, params + o.wqkv, D, nullptr, ws + e.qkv[l], 3 * D, D, 3 * D, T, S, Sp), st));
+      // final layer: only the LAST query row reaches the output (TransformerCorePT returns y[:, -1]): keys and
+      // values for every step, everything else on the last time step's rows [ro, ro + Sp) with a one-step launch
+      const bool last = l == 1;
+      const int Tl = last ? 1 : T;
+      const int64_t ro = last ? (int64_t)(T - 1) * Sp : 0;
+      if (last) {
+        TRY(dof_launch_tfm_gemm(tfm_gemm(xin, D, params + o.wqkv + (int64_t)D * D, D, nullptr, ws + e.qkv[l] + D, 3 * D, D,
+                                         2 * D, T, S, Sp), st));
+        TRY(dof_launch_tfm_gemm(tfm_gemm(xin + ro * D, D, params + o.wqkv, D, nullptr, ws + e.qkv[l] + ro * 3 * D, 3 * D, D, D,
+                                         1, S, Sp), st));
+      } else {
+        TRY(dof_launch_tfm_gemm(tfm_gemm(xin, D, params + o.wqkv, D, nullptr, ws + e.qkv[l], 3 * D, D, 3 * D, T, S, Sp), st));
+      }
       DofAttn at;
       memset(&at, 0, sizeof(at));
       at.qkv = ws + e.qkv[l]; at.ao = ws + e.ao[l]; at.pad = ws + e.pad; at.drop = tfm_drop(p, sl, train);
-      at.T = T; at.D = D; at.H = tf.H; at.causal = 0; at.S = S; at.Sp = Sp;
+      at.T = T; at.D = D; at.H = tf.H; at.causal = 0; at.S = S; at.Sp = Sp; at.q_last = last ? 1 : 0;
       TRY(dof_launch_tfm_attn(at, 0, st));
-      TRY(dof_launch_tfm_gemm(tfm_gemm(ws + e.ao[l], D, params + o.wo, D, nullptr, ws + e.tmp, D, D, D, T, S, Sp), st));
+      TRY(dof_launch_tfm_gemm(tfm_gemm(ws + e.ao[l] + ro * D, D, params + o.wo, D, nullptr, ws + e.tmp + ro * D, D, D, D, Tl, S,
+                                       Sp), st));
       DofLn ln;
       memset(&ln, 0, sizeof(ln));
-      ln.x = xin; ln.h = ws + e.tmp; ln.u = ws + e.u1[l]; ln.y = ws + e.x1[l]; ln.gamma = params + o.n1w;
-      ln.beta = params + o.n1b; ln.drop = tfm_drop(p, sl + 1, train); ln.T = T; ln.S = S; ln.Sp = Sp; ln.eps = 1e-6f;
+      ln.x = xin + ro * D; ln.h = ws + e.tmp + ro * D; ln.u = ws + e.u1[l] + ro * D; ln.y = ws + e.x1[l] + ro * D;
+      ln.gamma = params + o.n1w; ln.beta = params + o.n1b; ln.drop = tfm_drop(p, sl + 1, train); ln.T = Tl; ln.S = S;
+      ln.Sp = Sp; ln.eps = 1e-6f; ln.t_off = last ? T - 1 : 0; ln.T_idx = T;
       TRY(dof_launch_tfm_add_ln(ln, D, st));
-      DofGemm g1 = tfm_gemm(ws + e.x1[l], D, params + o.f0w, D, params + o.f0b, ws + e.f1[l], DFF, D, DFF, T, S, Sp);
+      DofGemm g1 = tfm_gemm(ws + e.x1[l] + ro * D, D, params + o.f0w, D, params + o.f0b, ws + e.f1[l] + ro * DFF, DFF, D, DFF,
+                            Tl, S, Sp);
       g1.epi = DOF_EPI_RELU;
       TRY(dof_launch_tfm_gemm(g1, st));
-      TRY(dof_launch_tfm_gemm(tfm_gemm(ws + e.f1[l], DFF, params + o.f2w, DFF, params + o.f2b, ws + e.tmp, D, DFF, D, T, S, Sp), st));
-      ln.x = ws + e.x1[l]; ln.u = ws + e.u2[l]; ln.y = ws + e.x2[l]; ln.gamma = params + o.n2w; ln.beta = params + o.n2b;
-      ln.drop = tfm_drop(p, sl + 2, train);
+      TRY(dof_launch_tfm_gemm(tfm_gemm(ws + e.f1[l] + ro * DFF, DFF, params + o.f2w, DFF, params + o.f2b, ws + e.tmp + ro * D, D,
+                                       DFF, D, Tl, S, Sp), st));
+      ln.x = ws + e.x1[l] + ro * D; ln.u = ws + e.u2[l] + ro * D; ln.y = ws + e.x2[l] + ro * D; ln.gamma = params + o.n2w;
+      ln.beta = params + o.n2b; ln.drop = tfm_drop(p, sl + 2, train);
       TRY(dof_launch_tfm_add_ln(ln, D, st));
     }
     TRY(dof_launch_tfm_last(ws + e.x2[1], ws + w.n2, T, D, S, Sp, st));
@@ -379,43 +406,64 @@ int tfm_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
     const TfmEncWs& e = tf.ew[s];
     const int64_t S = w.S, Sp = w.Sp;
     const int site0 = 7 * s;
-    TRY(dof_launch_tfm_last_bwd(ws + w.dn2, ws + e.dA, T, D, S, Sp, st));  // d x2[1]
     for (int l = 1; l >= 0; --l) {
       const TfmEncLayerOff& o = tf.el[s][l];
       const int sl = site0 + 1 + 3 * l;
+      const bool last = l == 1;  // see tfm_encoder_forward: the final layer lives in the last time step
+      const int Tl = last ? 1 : T;
+      const int64_t ro = last ? (int64_t)(T - 1) * Sp : 0;
+      const int t_off = last ? T - 1 : 0;
+      // d x2[l]: the CensNet gradient of the last step (final layer) or the layer above's d xin (in dA)
+      if (last) TRY(dof_launch_tfm_last_bwd(ws + w.dn2, ws + e.dA + ro * D, 1, D, S, Sp, st));
       // LayerNorm2(u2 = x1 + drop2(ffn)): dA = d x2[l]  ->  dB = d u2 (residual part of d x1), dH2 = d ffn output
       DofLnBwd lb;
       memset(&lb, 0, sizeof(lb));
-      lb.dy1 = ws + e.dA; lb.u = ws + e.u2[l]; lb.gamma = params + o.n2w; lb.du = ws + e.dB; lb.dh = ws + e.dH2[l];
-      lb.partial = ws + e.lnp[2 * l + 1]; lb.drop = tfm_drop(p, sl + 2, train); lb.T = T; lb.S = S; lb.Sp = Sp; lb.eps = 1e-6f;
+      lb.dy1 = ws + e.dA + ro * D; lb.u = ws + e.u2[l] + ro * D; lb.gamma = params + o.n2w; lb.du = ws + e.dB + ro * D;
+      lb.dh = ws + e.dH2[l] + ro * D; lb.partial = ws + e.lnp[2 * l + 1]; lb.drop = tfm_drop(p, sl + 2, train); lb.T = Tl;
+      lb.S = S; lb.Sp = Sp; lb.eps = 1e-6f; lb.t_off = t_off; lb.T_idx = T;
       TRY(dof_launch_tfm_ln_bwd(lb, D, st));
-      DofGemm g2 = tfm_gemm(ws + e.dH2[l], D, params + o.f2w, DFF, nullptr, ws + e.dF[l], DFF, D, DFF, T, S, Sp);
-      g2.trans = 1; g2.epi = DOF_EPI_MUL_RELU; g2.aux = ws + e.f1[l]; g2.ldaux = DFF;
+      DofGemm g2 = tfm_gemm(ws + e.dH2[l] + ro * D, D, params + o.f2w, DFF, nullptr, ws + e.dF[l] + ro * DFF, DFF, D, DFF, Tl, S, Sp);
+      g2.trans = 1; g2.epi = DOF_EPI_MUL_RELU; g2.aux = ws + e.f1[l] + ro * DFF; g2.ldaux = DFF;
       TRY(dof_launch_tfm_gemm(g2, st));
-      DofGemm g1 = tfm_gemm(ws + e.dF[l], DFF, params + o.f0w, D, nullptr, ws + e.dA, D, DFF, D, T, S, Sp);
+      DofGemm g1 = tfm_gemm(ws + e.dF[l] + ro * DFF, DFF, params + o.f0w, D, nullptr, ws + e.dA + ro * D, D, DFF, D, Tl, S, Sp);
       g1.trans = 1;
       TRY(dof_launch_tfm_gemm(g1, st));  // dA = d x1 through the ffn
-      // LayerNorm1(u1 = xin + drop1(attn out)): dy = dA + dB  ->  dB' = d u1 (residual part of d xin), dH1
-      lb.dy1 = ws + e.dA; lb.dy2 = ws + e.dB; lb.u = ws + e.u1[l]; lb.gamma = params + o.n1w; lb.du = ws + e.dE;
-      lb.dh = ws + e.dH1[l]; lb.partial = ws + e.lnp[2 * l]; lb.drop = tfm_drop(p, sl + 1, train);
+      // LayerNorm1(u1 = xin + drop1(attn out)): dy = dA + dB  ->  d u1 (residual part of d xin), dH1
+      float* du1 = last ? ws + e.tmp + ro * D : ws + e.dE;
+      lb.dy1 = ws + e.dA + ro * D; lb.dy2 = ws + e.dB + ro * D; lb.u = ws + e.u1[l] + ro * D; lb.gamma = params + o.n1w;
+      lb.du = du1; lb.dh = ws + e.dH1[l] + ro * D; lb.partial = ws + e.lnp[2 * l]; lb.drop = tfm_drop(p, sl + 1, train);
       TRY(dof_launch_tfm_ln_bwd(lb, D, st));
-      DofGemm go = tfm_gemm(ws + e.dH1[l], D, params + o.wo, D, nullptr, ws + e.dAO, D, D, D, T, S, Sp);
+      DofGemm go = tfm_gemm(ws + e.dH1[l] + ro * D, D, params + o.wo, D, nullptr, ws + e.dAO + ro * D, D, D, D, Tl, S, Sp);
       go.trans = 1;
       TRY(dof_launch_tfm_gemm(go, st));
       DofAttn at;
       memset(&at, 0, sizeof(at));
       at.qkv = ws + e.qkv[l]; at.dao = ws + e.dAO; at.dqkv = ws + e.dQKV[l]; at.pad = ws + e.pad;
       at.drop = tfm_drop(p, sl, train); at.T = T; at.D = D; at.H = tf.H; at.causal = 0; at.S = S; at.Sp = Sp;
+      at.q_last = last ? 1 : 0;
       TRY(dof_launch_tfm_attn(at, 1, st));
-      // d xin = dE (residual) + dQKV Wqkv  -> accumulated into dE, which becomes the next (lower) layer's d x2
-      DofGemm gq = tfm_gemm(ws + e.dQKV[l], 3 * D, params + o.wqkv, D, nullptr, ws + e.dE, D, 3 * D, D, T, S, Sp);
-      gq.trans = 1; gq.accumulate = 1;
-      TRY(dof_launch_tfm_gemm(gq, st));
-      if (l == 1) {  // hand over: next iteration reads its incoming gradient from dA
+      if (last) {
+        // d xin = (dK | dV) (W_k | W_v) on every row, + dQ W_q + d u1 on the last step's rows
+        DofGemm gk = tfm_gemm(ws + e.dQKV[l] + D, 3 * D, params + o.wqkv + (int64_t)D * D, D, nullptr, ws + e.dE, D, 2 * D, D, T, S, Sp);
+        gk.trans = 1;
+        TRY(dof_launch_tfm_gemm(gk, st));
+        DofGemm gq = tfm_gemm(ws + e.dQKV[l] + ro * 3 * D, 3 * D, params + o.wqkv, D, nullptr, ws + e.dE + ro * D, D, D, D, 1, S, Sp);
+        gq.trans = 1; gq.accumulate = 1;
+        TRY(dof_launch_tfm_gemm(gq, st));
+        DofLn ad;
+        memset(&ad, 0, sizeof(ad));
+        ad.x = ws + e.dE + ro * D; ad.h = du1; ad.u = ws + e.dE + ro * D; ad.T = 1; ad.S = S; ad.Sp = Sp;
+        TRY(dof_launch_tfm_add_ln(ad, D, st));
+        // hand over: the layer below reads its incoming gradient from dA
         DofLn cp;
         memset(&cp, 0, sizeof(cp));
         cp.x = ws + e.dE; cp.u = ws + e.dA; cp.T = T; cp.S = S; cp.Sp = Sp;
         TRY(dof_launch_tfm_add_ln(cp, D, st));
+      } else {
+        // d xin = dE (residual) + dQKV Wqkv  -> accumulated into dE = d y0
+        DofGemm gq = tfm_gemm(ws + e.dQKV[l], 3 * D, params + o.wqkv, D, nullptr, ws + e.dE, D, 3 * D, D, T, S, Sp);
+        gq.trans = 1; gq.accumulate = 1;
+        TRY(dof_launch_tfm_gemm(gq, st));
       }
     }
     // embedding: dE = d y0 -> gradient of the pre-activation (in place)
@@ -427,8 +475,9 @@ int tfm_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
     DofSumJobs sj;
     sj.n = 4;
     for (int l = 0; l < 2; ++l) {
-      sj.partial[2 * l] = ws + e.lnp[2 * l]; sj.nblk[2 * l] = e.ln_blocks; sj.nv[2 * l] = 2 * D; sj.out[2 * l] = grads + tf.el[s][l].n1w;
-      sj.partial[2 * l + 1] = ws + e.lnp[2 * l + 1]; sj.nblk[2 * l + 1] = e.ln_blocks; sj.nv[2 * l + 1] = 2 * D;
+      const int64_t nb = l == 1 ? dof_tfm_ln_blocks(D, 1, p->sw[s].Sp) : e.ln_blocks;  // final layer: one time step
+      sj.partial[2 * l] = ws + e.lnp[2 * l]; sj.nblk[2 * l] = nb; sj.nv[2 * l] = 2 * D; sj.out[2 * l] = grads + tf.el[s][l].n1w;
+      sj.partial[2 * l + 1] = ws + e.lnp[2 * l + 1]; sj.nblk[2 * l + 1] = nb; sj.nv[2 * l + 1] = 2 * D;
       sj.out[2 * l + 1] = grads + tf.el[s][l].n2w;
     }
     TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
