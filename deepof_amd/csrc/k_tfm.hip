@@ -161,20 +161,21 @@ __global__ void __launch_bounds__(256) k_tfm_gemm(DofGemm A) {
       if (jc < KC && jc * 16 + 4 * lg < K) buf[j] = *reinterpret_cast<const float4*>(xr + jc * 16);
     }
   };
-  auto tile_of = [&](int it) { return (int64_t)blockIdx.x * 16 + wave + 4 * it; };
+  const int ITS = A.its;  // row tiles per wave (1..4): small problems spread over more workgroups
+  auto tile_of = [&](int it) { return (int64_t)blockIdx.x * (4 * ITS) + wave + 4 * it; };
   auto tile_live = [&](int it) {
     const int64_t tl = tile_of(it);
-    return it < 4 && tl < tiles && (tl * 16) % A.Sp < A.S;
+    return it < ITS && tl < tiles && (tl * 16) % A.Sp < A.S;
   };
   float4 cur[4], nxt[4];
   int it = 0;
-  while (it < 4 && !tile_live(it)) ++it;
-  if (it < 4) load_group(A.X + (tile_of(it) * 16 + li) * A.ldx + 4 * lg, 0, cur);
-  while (it < 4) {
+  while (it < ITS && !tile_live(it)) ++it;
+  if (it < ITS) load_group(A.X + (tile_of(it) * 16 + li) * A.ldx + 4 * lg, 0, cur);
+  while (it < ITS) {
     const int64_t row0 = tile_of(it) * 16;
     const int64_t s0 = row0 % A.Sp;
     int it_next = it + 1;
-    while (it_next < 4 && !tile_live(it_next)) ++it_next;
+    while (it_next < ITS && !tile_live(it_next)) ++it_next;
     dof_f32x4 acc[NTMAX];
 #pragma unroll
     for (int n = 0; n < NTMAX; ++n) acc[n] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(256) k_tfm_gemm(DofGemm A) {
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
       if (g + 1 < G) load_group(xr, g + 1, nxt);
-      else if (it_next < 4) load_group(A.X + (tile_of(it_next) * 16 + li) * A.ldx + 4 * lg, 0, nxt);
+      else if (it_next < ITS) load_group(A.X + (tile_of(it_next) * 16 + li) * A.ldx + 4 * lg, 0, nxt);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (g * 4 + j < KC) {  // (wave-uniform)
@@ -241,12 +242,26 @@ __global__ void __launch_bounds__(256) k_tfm_gemm(DofGemm A) {
 __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int W, int T, int nseq,
                                            int64_t s0, int64_t S, int64_t Sp, int tid, int nthr) {
   const int n4 = nseq * W / 4;
-  for (int e = tid; e < T * n4; e += nthr) {
-    const int t = e / n4, j = e - t * n4;
-    const int seq = (j * 4) / W;
-    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (s0 + seq < S) v = *reinterpret_cast<const float4*>(src + ((int64_t)t * Sp + s0) * W + j * 4);
-    *reinterpret_cast<float4*>(dst + (int64_t)t * nseq * W + j * 4) = v;
+  // four loads in flight per thread before the first LDS store (the one-at-a-time form paid a memory latency per 16 bytes)
+  for (int e0 = tid; e0 < T * n4; e0 += 4 * nthr) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * nthr;
+      v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (e < T * n4) {
+        const int t = e / n4, j = e - t * n4;
+        if (s0 + (j * 4) / W < S) v[u] = *reinterpret_cast<const float4*>(src + ((int64_t)t * Sp + s0) * W + j * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * nthr;
+      if (e < T * n4) {
+        const int t = e / n4, j = e - t * n4;
+        *reinterpret_cast<float4*>(dst + (int64_t)t * nseq * W + j * 4) = v[u];
+      }
+    }
   }
 }
 
@@ -842,15 +857,17 @@ int dof_launch_tfm_embed_bwd(int F, const float* xs, const float* w, const float
   return dof_check_launch("k_tfm_embed_bwd");
 }
 
-int dof_launch_tfm_gemm(const DofGemm& g, hipStream_t st) {
-  const int KC = (g.K + 15) / 16, NT = (g.N + 15) / 16;
+int dof_launch_tfm_gemm(const DofGemm& gin, hipStream_t st) {
+  const int KC = (gin.K + 15) / 16, NT = (gin.N + 15) / 16;
   const int NTM = NT <= 2 ? 2 : NT <= 3 ? 3 : NT <= 4 ? 4 : NT <= 6 ? 6 : NT <= 8 ? 8 : 12;
-  if (KC * NTM * 256 > kGemmLds || NT > 12 || (g.ldx & 3)) {
-    dof_set_error("tfm gemm: K %d x N %d (ldx %d) not supported", g.K, g.N, g.ldx);
+  if (KC * NTM * 256 > kGemmLds || NT > 12 || (gin.ldx & 3)) {
+    dof_set_error("tfm gemm: K %d x N %d (ldx %d) not supported", gin.K, gin.N, gin.ldx);
     return DOF_ERR_UNSUPPORTED;
   }
-  const int64_t tiles = (int64_t)g.T * (g.Sp / 16);
-  const unsigned nb = dof_cdiv(tiles, 16);
+  const int64_t tiles = (int64_t)gin.T * (gin.Sp / 16);
+  DofGemm g = gin;
+  g.its = tiles >= 4 * 4 * 1024 ? 4 : tiles >= 2 * 4 * 1024 ? 2 : 1;  // >= ~1024 workgroups when the problem allows
+  const unsigned nb = dof_cdiv(tiles, 4 * g.its);
 #define GEMM_EPI(NTV)                                                                                          \
   switch (g.epi) {                                                                                             \
     case DOF_EPI_NONE: DOF_LAUNCH((k_tfm_gemm<NTV, DOF_EPI_NONE>), (nb), (256), st, g); break;                 \

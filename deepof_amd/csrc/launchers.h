@@ -109,6 +109,7 @@ struct DofGemm {           // Y[r][n] (+)= epi(sum_k X[r][k] W[n][k] + bias[n]) 
   DofDrop drop; int drop_ld;    // GELU epilogues: dropout over (row, col), reference index (s*T + t)*drop_ld + col
   int K, N, trans, epi, accumulate;
   int T; int64_t S, Sp;
+  int its;                      // (set by the launcher) row tiles per wave
 };
 struct DofAttn {
   const float* qkv;   // [r][3D]: q | k | v, head h at columns h*dh
