@@ -173,6 +173,20 @@ __global__ void __launch_bounds__(256) k_final_dense(const float* __restrict__ f
   const dof_cfp wf = dof_cw(wf_) + (int64_t)l * J;
   float a0 = dof_cw(bf_)[l], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
   int j = 0;
+  // 16 activations in flight per thread (the kernel is 32 workgroups of pure load latency at batch 1024); the four
+  // partial sums and their order are those of the 4-wide loop
+  for (; j + 15 < J; j += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = flat[(int64_t)(j + u) * Bp + b];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      a0 = fmaf(wf[j + u], v[u], a0);
+      a1 = fmaf(wf[j + u + 1], v[u + 1], a1);
+      a2 = fmaf(wf[j + u + 2], v[u + 2], a2);
+      a3 = fmaf(wf[j + u + 3], v[u + 3], a3);
+    }
+  }
   for (; j + 3 < J; j += 4) {
     a0 = fmaf(wf[j], flat[(int64_t)j * Bp + b], a0);
     a1 = fmaf(wf[j + 1], flat[(int64_t)(j + 1) * Bp + b], a1);
@@ -197,8 +211,25 @@ __global__ void __launch_bounds__(256) k_final_dense_bwd(const float* __restrict
   dflat[(int64_t)j * Bp + b] = acc;
 }
 
+constexpr int kLatentMaxKL = 1024;  // K * L entries of the per-component constants staged in LDS (K <= 128 at L = 8)
+
 template <int L>
 __global__ void __launch_bounds__(256) k_latent_fwd(LatentFwdArgs A) {
+  // per (component, dimension) constants of the posterior: 1 / sd and the component's additive term
+  // log(prior + 1e-9) - sum_d (log sd + log(2 pi) / 2), once per workgroup instead of an expf, a logf and a division
+  // per (window, component, dimension)
+  __shared__ float s_inv[kLatentMaxKL];
+  __shared__ float s_const[kLatentMaxKL / 4];
+  const bool staged = A.K * L <= kLatentMaxKL;
+  if (staged) {
+    for (int e = threadIdx.x; e < A.K * L; e += 256) s_inv[e] = 1.0f / fmaxf(expf(0.5f * A.gmm_log_vars[e]), 1e-3f);
+    for (int c = threadIdx.x; c < A.K; c += 256) {
+      float acc = logf(A.prior[c] + 1e-9f);
+      for (int d = 0; d < L; ++d) acc += -logf(fmaxf(expf(0.5f * A.gmm_log_vars[c * L + d]), 1e-3f)) - 0.9189385332046727f;
+      s_const[c] = acc;
+    }
+    __syncthreads();
+  }
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= A.B) return;
   const dof_cfp wm = dof_cw(A.wm), bm = dof_cw(A.bm), wsv = dof_cw(A.ws),
@@ -230,12 +261,22 @@ __global__ void __launch_bounds__(256) k_latent_fwd(LatentFwdArgs A) {
   const float HALF_LOG_2PI = 0.9189385332046727f;
   float mx = -INFINITY;
   for (int c = 0; c < A.K; ++c) {
-    float lg = logf(prior[c] + 1e-9f);
+    float lg;
+    if (staged) {
+      lg = s_const[c];
 #pragma unroll
-    for (int d = 0; d < L; ++d) {
-      const float sd = fmaxf(expf(0.5f * glv[c * L + d]), 1e-3f);
-      const float u = (z[d] - gmeans[c * L + d]) / sd;
-      lg += -0.5f * u * u - logf(sd) - HALF_LOG_2PI;
+      for (int d = 0; d < L; ++d) {
+        const float u = (z[d] - gmeans[c * L + d]) * s_inv[c * L + d];
+        lg = fmaf(-0.5f * u, u, lg);
+      }
+    } else {
+      lg = logf(prior[c] + 1e-9f);
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float sd = fmaxf(expf(0.5f * glv[c * L + d]), 1e-3f);
+        const float u = (z[d] - gmeans[c * L + d]) / sd;
+        lg += -0.5f * u * u - logf(sd) - HALF_LOG_2PI;
+      }
     }
     A.q[(int64_t)c * A.Bp + b] = lg;
     mx = fmaxf(mx, lg);
