@@ -387,6 +387,7 @@ struct StatsArgs {
 template <int L>
 __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
   constexpr int SW = 3 * L + 1;
+  __shared__ float s_lt[32][256];
   const int c = blockIdx.x;
   float vals[SW];
 #pragma unroll
@@ -419,10 +420,16 @@ __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
       vals[1] += 0.5f * kl / L;
       if (A.tau) {  // w_class_b = sum_c sharpen(tau)[c] * class_weight[c]
         float mx = -INFINITY;
-        for (int k = 0; k < A.K; ++k) mx = fmaxf(mx, logf(fmaxf(A.tau[b * A.K + k], 1e-8f)) / Ts);
+        const bool cache = A.K <= 32;  // the scaled logs of this window through LDS: one logf per entry instead of two
+        for (int k = 0; k < A.K; ++k) {
+          const float lt = logf(fmaxf(A.tau[b * A.K + k], 1e-8f)) / Ts;
+          if (cache) s_lt[k][threadIdx.x] = lt;
+          mx = fmaxf(mx, lt);
+        }
         float se = 0.0f, sw = 0.0f;
         for (int k = 0; k < A.K; ++k) {
-          const float e = expf(logf(fmaxf(A.tau[b * A.K + k], 1e-8f)) / Ts - mx);
+          const float lt = cache ? s_lt[k][threadIdx.x] : logf(fmaxf(A.tau[b * A.K + k], 1e-8f)) / Ts;
+          const float e = expf(lt - mx);
           se += e;
           sw = fmaf(e, A.class_weight[k], sw);
         }
@@ -748,6 +755,18 @@ struct LatentBwdArgs {
 
 template <int L>
 __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
+  // 1 / sd^2 of every (component, dimension), once per workgroup (was an expf + a division per window and entry)
+  __shared__ float s_isd2[kLatentMaxKL];
+  constexpr int kTbMax = 32;
+  __shared__ float s_tb[kTbMax][256];
+  const bool staged = A.K * L <= kLatentMaxKL;
+  if (staged) {
+    for (int e = threadIdx.x; e < A.K * L; e += 256) {
+      const float sd = fmaxf(expf(0.5f * A.gmm_log_vars[e]), 1e-3f);
+      s_isd2[e] = 1.0f / (sd * sd);
+    }
+    __syncthreads();
+  }
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = b < A.B;
   float ce_w = 0.0f, tf_w = 0.0f;
@@ -831,13 +850,21 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       if (wtf != 0.0f) g += -(wtf / Bf) * expf(A.dlogp2[(int64_t)c * A.Bp + b] - pl_mx) / pl_se;
       return g;
     };
+    // sharpened teacher probabilities of this window: computed once (three transcendentals each), kept in LDS for the
+    // two passes when K <= 32
+    const bool tb_cached = distill && K <= kTbMax;
+    if (tb_cached)
+      for (int c = 0; c < K; ++c) s_tb[c][threadIdx.x] = expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx) / tse;
+    auto teacher_prob = [&](int c) -> float {
+      return tb_cached ? s_tb[c][threadIdx.x] : expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx) / tse;
+    };
     // pass 1: dot = sum_c dqn[c]*qn[c] ; csum = sum_c max(q,1e-8)
     float dot = 0.0f, csum = 0.0f, ce = 0.0f, tf_sum = 0.0f, pl_dot = 0.0f;
     for (int c = 0; c < K; ++c) {
       const float qn = A.qn[(int64_t)c * A.Bp + b];
       float g = A.dqbar[c] / Bf + extra_dqn(c, qn);
       if (distill) {
-        const float tb = expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx) / tse;
+        const float tb = teacher_prob(c);
         ce -= tb * logf(fmaxf(qn, 1e-8f));
         if (qn >= 1e-8f) g -= (lam / Bf) * w_total * tb / qn;
       }
@@ -858,7 +885,7 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       const float q = A.q[(int64_t)c * A.Bp + b];
       float g = A.dqbar[c] / Bf + extra_dqn(c, qn);
       if (distill && qn >= 1e-8f) {
-        const float tb = expf(logf(fmaxf(A.tau[b * K + c], 1e-8f)) / Ts - tmx) / tse;
+        const float tb = teacher_prob(c);
         g -= (lam / Bf) * w_total * tb / qn;
       }
       const float dq = q >= 1e-8f ? (g - dot) / csum : 0.0f;
@@ -878,8 +905,14 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
       }
 #pragma unroll
       for (int d = 0; d < L; ++d) {
-        const float sd = fmaxf(expf(0.5f * glv[c * L + d]), 1e-3f);
-        dz[d] = fmaf(dl, -(z[d] - gmeans[c * L + d]) / (sd * sd), dz[d]);
+        float isd2;
+        if (staged) {
+          isd2 = s_isd2[c * L + d];
+        } else {
+          const float sd = fmaxf(expf(0.5f * glv[c * L + d]), 1e-3f);
+          isd2 = 1.0f / (sd * sd);
+        }
+        dz[d] = fmaf(dl, -(z[d] - gmeans[c * L + d]) * isd2, dz[d]);
         dz[d] = fmaf(qn, A.dcen[c * L + d], dz[d]);
         if (wtf != 0.0f) {
           const float sd2 = fmaxf(expf(0.5f * fminf(fmaxf(glv[c * L + d], lo), hi)), 1e-3f);
