@@ -136,6 +136,7 @@ struct ClArgs {
   float* logs;       // DOF_LOG_* (total, pos_similarity, neg_similarity)
   const float* dzh;  // (B, L) d (distillation loss) / d zn of the central view, or null
   const float* dh_partial;  // per-block sums of the distillation loss
+  int n_dh;                 // ... their count (workgroups of k_distill_head)
   int sim, loss_fn;
   float inv_T, tau, beta;
   int B, nblk;
@@ -196,6 +197,18 @@ __device__ __forceinline__ float cl_o2f(unsigned o) {
   return __builtin_bit_cast(float, u);
 }
 
+// The all-pairs kernels below give every row of the B x B similarity matrix to a GROUP of CLG neighbouring lanes
+// (lane `sub` of the group takes the columns sub, sub + CLG, ... of each staged 256-column tile) and add the lanes'
+// partial sums with a fixed xor butterfly.  One thread per row meant 32 workgroups walking 8192 columns each at batch
+// 8192 (1.4 - 2.4 ms per kernel on a 256-CU chip); a group of 8 gives 256 workgroups and an 8x shorter walk.
+constexpr int CLG = 8;
+constexpr int CL_ROWS = 256 / CLG;  // rows per workgroup
+__device__ __forceinline__ float cl_group_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < CLG; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
 // fc loss (losses.py:176-208): each row drops its k LARGEST negatives.  theta_i = the fc_keep-th smallest
 // off-diagonal similarity of row i, found by a 32-step bisection over the ordered bit patterns (every step
 // recounts the row; similarities are recomputed, never stored).  A block handles 256 rows so the tiles of the
@@ -204,8 +217,8 @@ template <int L>
 __global__ void __launch_bounds__(256) k_cl_fc_threshold(ClArgs A) {
   __shared__ float ty[256][L + 1];
   __shared__ float tr[256];
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * 256 + tid;
+  const int tid = threadIdx.x, sub = tid % CLG;
+  const int i = blockIdx.x * CL_ROWS + tid / CLG;
   const bool live = i < A.B;
   float x[L], rx = 1.0f;
   if (live) {
@@ -219,7 +232,7 @@ __global__ void __launch_bounds__(256) k_cl_fc_threshold(ClArgs A) {
   for (int it = 0; it < 32; ++it) {
     const unsigned mid = lo + ((hi - lo) >> 1);
     const float fm = cl_o2f(mid);
-    int cnt = 0;
+    float cnt = 0.0f;  // (a float count is exact up to 2^24 columns)
     for (int j0 = 0; j0 < A.B; j0 += 256) {
       __syncthreads();
       if (j0 + tid < A.B) {
@@ -230,23 +243,24 @@ __global__ void __launch_bounds__(256) k_cl_fc_threshold(ClArgs A) {
       __syncthreads();
       if (!live) continue;
       const int nj = A.B - j0 < 256 ? A.B - j0 : 256;
-      for (int jj = 0; jj < nj; ++jj) {
+      for (int jj = sub; jj < nj; jj += CLG) {
         float aux;
         const float s = cl_sim<L>(A.sim, x, ty[jj], rx, tr[jj], &aux);
-        cnt += (j0 + jj != i && s <= fm) ? 1 : 0;
+        cnt += (j0 + jj != i && s <= fm) ? 1.0f : 0.0f;
       }
     }
-    if (cnt >= A.fc_keep) hi = mid; else lo = mid + 1;
+    cnt = cl_group_sum(cnt);
+    if (cnt >= (float)A.fc_keep) hi = mid; else lo = mid + 1;
   }
-  if (live) A.theta[i] = A.fc_keep > 0 ? cl_o2f(hi) : -INFINITY;
+  if (live && sub == 0) A.theta[i] = A.fc_keep > 0 ? cl_o2f(hi) : -INFINITY;
 }
 
 template <int L>
 __global__ void __launch_bounds__(256) k_cl_rowstats(ClArgs A) {
   __shared__ float ty[256][L + 1];
   __shared__ float tr[256];
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * 256 + tid;
+  const int tid = threadIdx.x, sub = tid % CLG;
+  const int i = blockIdx.x * CL_ROWS + tid / CLG;
   const bool live = i < A.B;
   float x[L], rx = 1.0f;
   if (live) {
@@ -268,7 +282,7 @@ __global__ void __launch_bounds__(256) k_cl_rowstats(ClArgs A) {
     __syncthreads();
     if (!live) continue;
     const int nj = A.B - j0 < 256 ? A.B - j0 : 256;
-    for (int jj = 0; jj < nj; ++jj) {
+    for (int jj = sub; jj < nj; jj += CLG) {
       float aux;
       const float s = cl_sim<L>(A.sim, x, ty[jj], rx, tr[jj], &aux);
       if (j0 + jj == i) {
@@ -281,8 +295,10 @@ __global__ void __launch_bounds__(256) k_cl_rowstats(ClArgs A) {
       }
     }
   }
+  a1 = cl_group_sum(a1); a2 = cl_group_sum(a2); soff = cl_group_sum(soff);
+  p = cl_group_sum(p);  // exactly one lane of the group met the diagonal
   float out[3] = {0.0f, 0.0f, 0.0f};
-  if (live) {
+  if (live && sub == 0) {
     const float ne = (float)(A.B - 1), invB = 1.0f / (float)A.B;
     const float pos = __expf((p - 1.0f) * A.inv_T);
     float den, ca, cb = 0.0f, cd;
@@ -322,8 +338,8 @@ __global__ void __launch_bounds__(256) k_cl_grad(ClArgs A) {
   __shared__ float ty[256][L + 1];
   __shared__ float tr[256];
   __shared__ float tw[256][4];
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * 256 + tid;
+  const int tid = threadIdx.x, sub = tid % CLG;
+  const int i = blockIdx.x * CL_ROWS + tid / CLG;
   const bool live = i < A.B;
   const float* own = A.zn + (COLS ? (int64_t)A.B * L : 0);
   const float* oth = A.zn + (COLS ? 0 : (int64_t)A.B * L);
@@ -359,7 +375,7 @@ __global__ void __launch_bounds__(256) k_cl_grad(ClArgs A) {
     __syncthreads();
     if (!live) continue;
     const int nj = A.B - j0 < 256 ? A.B - j0 : 256;
-    for (int jj = 0; jj < nj; ++jj) {
+    for (int jj = sub; jj < nj; jj += CLG) {
       float aux;
       const float s = cl_sim<L>(A.sim, x, ty[jj], rx, tr[jj], &aux);
       if (COLS) {
@@ -388,7 +404,10 @@ __global__ void __launch_bounds__(256) k_cl_grad(ClArgs A) {
       sx += sc;
     }
   }
-  if (!live) return;
+#pragma unroll
+  for (int l = 0; l < L; ++l) V[l] = cl_group_sum(V[l]);
+  sx = cl_group_sum(sx);
+  if (!live || sub != 0) return;
   float g[L], gz = 0.0f;
 #pragma unroll
   for (int l = 0; l < L; ++l) {
@@ -416,7 +435,7 @@ __global__ void __launch_bounds__(64) k_cl_finalize(ClArgs A) {
     for (int k = 0; k < DOF_LOG_COUNT; ++k) A.logs[k] = 0.0f;
     float dist = 0.0f;
     if (A.dh_partial)
-      for (int k = 0; k < A.nblk; ++k) dist += A.dh_partial[k];
+      for (int k = 0; k < A.n_dh; ++k) dist += A.dh_partial[k];
     A.logs[DOF_LOG_DISTILL] = dist;
     A.logs[DOF_LOG_TOTAL] = acc[0] / B + dist;
     A.logs[DOF_LOG_POS_SIM] = acc[1] / B;

@@ -175,7 +175,7 @@ void build_tfm_workspace_layout(DofVadePlan* p) {
   tf.ctr = cv.take(1);
   tf.pe_enc = cv.take((int64_t)T * D);
   p->lat_blocks = dof_cdiv(p->B, 256);
-  p->cl_blocks = p->lat_blocks;
+  p->cl_blocks = dof_cdiv(p->B, CL_ROWS);
   p->cl_zn = cv.take(2 * p->B * L);
   p->cl_inv = cv.take(2 * p->B);
   p->cl_rn = cv.take(2 * p->B);

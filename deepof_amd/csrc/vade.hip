@@ -552,7 +552,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
   p->denc = cv.take((int64_t)L * Bp);
   p->dflat = cv.take((int64_t)p->J * Bp);
   p->lat_blocks = dof_cdiv(p->B, 256);
-  p->cl_blocks = p->lat_blocks;
+  p->cl_blocks = dof_cdiv(p->B, CL_ROWS);  // rows per workgroup of the all-pairs contrastive kernels
   p->cl_zn = cv.take(2 * p->B * L);
   p->cl_inv = cv.take(2 * p->B);
   p->cl_rn = cv.take(2 * p->B);
@@ -642,7 +642,7 @@ void build_workspace_layout(DofVadePlan* p) {
   p->denc = cv.take((int64_t)L * Bp);
   p->dflat = cv.take((int64_t)p->J * Bp);
   p->lat_blocks = dof_cdiv(p->B, 256);
-  p->cl_blocks = p->lat_blocks;
+  p->cl_blocks = dof_cdiv(p->B, CL_ROWS);  // rows per workgroup of the all-pairs contrastive kernels
   if (p->kind == 2) {
     p->cl_zn = cv.take(2 * p->B * L);
     p->cl_inv = cv.take(2 * p->B);
@@ -2223,7 +2223,7 @@ extern "C" int dof_contrastive_loss(DofVadePlan* p, const float* z, const float*
   A.z = z; A.za = z_aug; A.zn = ws + p->cl_zn; A.inv = ws + p->cl_inv; A.rn = ws + p->cl_rn;
   A.rowstat = ws + p->cl_rowstat; A.partial = ws + p->cl_partial; A.dz = dz; A.dza = dz_aug; A.logs = logs;
   A.sim = similarity; A.loss_fn = loss_fn; A.inv_T = 1.0f / temperature; A.tau = tau; A.beta = beta;
-  A.B = (int)p->B; A.nblk = (int)p->cl_blocks;
+  A.B = (int)p->B; A.nblk = (int)p->cl_blocks; A.n_dh = (int)p->lat_blocks;
   A.theta = ws + p->cl_theta;
   {  // fc (losses.py:176-208; the caller hard-wires elimination_topk = 0.1, training.py:545 / Q16)
     int k = (int)ceil(0.1 * (double)p->B);
