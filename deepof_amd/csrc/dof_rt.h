@@ -80,6 +80,37 @@ __device__ __forceinline__ float dof_gbcast(float v) {
 #endif
 }
 
+// Lane permutations inside a 16-lane DPP row (full-rate VALU modifiers, no LDS crossbar): CTRL = 0xB1 swaps
+// neighbours (lane ^ 1), 0x4E swaps pairs (lane ^ 2), 0x141 mirrors each half row (i <-> 7 - i), 0x140 mirrors the
+// row (i <-> 15 - i).  Applied in that order, "v op= perm(v)" leaves every lane with the reduction over its row, and
+// all 16 lanes hold bitwise the same value (each step combines the same two operands in both partners).
+template <int CTRL>
+__device__ __forceinline__ float dof_dpp_perm(float v) {
+#ifdef DOF_EMU
+  const int lane = (int)(threadIdx.x & 63);
+  const int src = CTRL == 0xB1 ? (lane ^ 1) : CTRL == 0x4E ? (lane ^ 2)
+                : CTRL == 0x141 ? ((lane & ~7) | (7 - (lane & 7))) : ((lane & ~15) | (15 - (lane & 15)));
+  return __shfl(v, src);
+#else
+  static_assert(CTRL == 0xB1 || CTRL == 0x4E || CTRL == 0x141 || CTRL == 0x140, "row permutation");
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+#endif
+}
+__device__ __forceinline__ float dof_row16_sum(float v) {
+  v += dof_dpp_perm<0xB1>(v);
+  v += dof_dpp_perm<0x4E>(v);
+  v += dof_dpp_perm<0x141>(v);
+  v += dof_dpp_perm<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float dof_row16_max(float v) {
+  v = fmaxf(v, dof_dpp_perm<0xB1>(v));
+  v = fmaxf(v, dof_dpp_perm<0x4E>(v));
+  v = fmaxf(v, dof_dpp_perm<0x141>(v));
+  v = fmaxf(v, dof_dpp_perm<0x140>(v));
+  return v;
+}
+
 // One sequence's C channels at one time step are 4C contiguous, 16-byte aligned bytes: move them
 // as dwordx4 (scalar dword accesses at a 4C-byte lane stride touch 64 cache lines per instruction).
 template <int C>

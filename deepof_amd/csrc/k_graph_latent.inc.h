@@ -299,6 +299,136 @@ __global__ void __launch_bounds__(256) k_latent_fwd(LatentFwdArgs A) {
   for (int c = 0; c < A.K; ++c) A.qn[(int64_t)c * A.Bp + b] = fmaxf(A.q[(int64_t)c * A.Bp + b], 1e-8f) * cinv;
 }
 
+constexpr int kLatRows = 16;  // windows per workgroup of the row kernels
+
+// k_latent_fwd with the work of a window spread over a 16-lane DPP row.  These kernels run one wavefront per SIMD
+// (1,024 windows), so their duration is the instruction count of a lane times four cycles: nothing is replicated.
+// Lane j of a row owns components j, j + 16, ... (NC per lane, K <= 16 NC), latent dimension j mod L, and every
+// 16th input of encoder.final_dense (evaluated here when A.flat is set -- one launch instead of two); row sums and
+// maxima are four DPP steps, single values travel by row broadcast.
+constexpr int kWfMax = 4096;  // J * L entries of the final_dense weight staged in LDS (else read from memory)
+
+template <int L, int NC>
+__global__ void __launch_bounds__(256) k_latent_fwd_w(LatentFwdArgs A) {
+  constexpr int KMAX = 16 * NC;
+  __shared__ float s_inv[KMAX * L], s_gm[KMAX * L], s_const[KMAX];
+  __shared__ float s_wm[L * L], s_ws[L * L], s_bm[L], s_bs[L];
+  __shared__ float s_wf[kWfMax];  // [input][l]
+  const int K = A.K;
+  const bool wf_lds = A.flat && A.J * L <= kWfMax;
+  for (int e = threadIdx.x; e < K * L; e += 256) {
+    s_inv[e] = 1.0f / fmaxf(expf(0.5f * A.gmm_log_vars[e]), 1e-3f);
+    s_gm[e] = A.gmm_means[e];
+  }
+  for (int c = threadIdx.x; c < K; c += 256) {
+    float acc = logf(A.prior[c] + 1e-9f);
+    for (int d = 0; d < L; ++d) acc += -logf(fmaxf(expf(0.5f * A.gmm_log_vars[c * L + d]), 1e-3f)) - 0.9189385332046727f;
+    s_const[c] = acc;
+  }
+  if (threadIdx.x < L * L) {
+    s_wm[threadIdx.x] = A.wm[threadIdx.x];
+    s_ws[threadIdx.x] = A.ws[threadIdx.x];
+  }
+  if (threadIdx.x < L) {
+    s_bm[threadIdx.x] = A.bm[threadIdx.x];
+    s_bs[threadIdx.x] = A.bs[threadIdx.x];
+  }
+  if (wf_lds)
+    for (int e = threadIdx.x; e < A.J * L; e += 256) {
+      const int l = e / A.J;
+      s_wf[(e - l * A.J) * L + l] = A.wf[e];
+    }
+  __syncthreads();
+  const int j = (int)threadIdx.x & 15, row = (int)threadIdx.x >> 4;
+  const int l = j % L;
+  const int64_t b_raw = (int64_t)blockIdx.x * kLatRows + row;
+  const bool live = b_raw < A.B;
+  const int64_t b = live ? b_raw : A.B - 1;  // idle rows shadow the last window (DPP reads every lane)
+  float enc[L];
+  if (A.flat) {
+    float part[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) part[k] = 0.0f;
+    for (int jj = j; jj < A.J; jj += 16) {
+      const float f = A.flat[(int64_t)jj * A.Bp + b];
+#pragma unroll
+      for (int k = 0; k < L; ++k) part[k] = fmaf(wf_lds ? s_wf[jj * L + k] : A.wf[k * A.J + jj], f, part[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k) enc[k] = dof_row16_sum(part[k]) + A.bf[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < L; ++k) enc[k] = A.enc[(int64_t)k * A.Bp + b];
+  }
+  float m = s_bm[l], p = s_bs[l], enc_l = 0.0f;
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    m = fmaf(s_wm[l * L + k], enc[k], m);
+    p = fmaf(s_ws[l * L + k], enc[k], p);
+    if (k == l) enc_l = enc[k];
+  }
+  const float sv = dof_softplus(p);
+  const float zl = A.eps ? fmaf(expf(0.5f * sv), A.eps[b * L + l], m) : m;
+  if (live && j < L) {
+    if (A.flat) A.enc[(int64_t)l * A.Bp + b] = enc_l;
+    A.mu[(int64_t)l * A.Bp + b] = m;
+    A.pre[(int64_t)l * A.Bp + b] = p;
+    A.sv[(int64_t)l * A.Bp + b] = sv;
+    A.z[(int64_t)l * A.Bp + b] = zl;
+    if (A.z_out) A.z_out[b * L + l] = zl;
+    if (A.mu_out) A.mu_out[b * L + l] = m;
+    if (A.sv_out) A.sv_out[b * L + l] = sv;
+    if (A.enc_out) A.enc_out[b * L + l] = enc_l;
+  }
+  float z[L];
+  dof_static_for<L>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    z[d] = dof_gbcast<d, 16>(zl);
+  });
+  // posterior: softmax_c(log(prior+1e-9) + sum_d log N(z_d; m_cd, max(exp(l_cd/2),1e-3)))
+  float lg[NC], mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = j + 16 * i;
+    if (c < K) {
+      float acc = s_const[c];
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float u = (z[d] - s_gm[c * L + d]) * s_inv[c * L + d];
+        acc = fmaf(-0.5f * u, u, acc);
+      }
+      lg[i] = acc;
+    } else {
+      lg[i] = -INFINITY;
+    }
+    mx = fmaxf(mx, lg[i]);
+  }
+  mx = dof_row16_max(mx);
+  float e[NC], sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    e[i] = j + 16 * i < K ? expf(lg[i] - mx) : 0.0f;
+    sum += e[i];
+  }
+  const float inv = 1.0f / dof_row16_sum(sum);
+  float csum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    e[i] *= inv;
+    if (j + 16 * i < K) csum += fmaxf(e[i], 1e-8f);
+  }
+  const float cinv = 1.0f / dof_row16_sum(csum);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = j + 16 * i;
+    if (c < K && live) {
+      A.q[(int64_t)c * A.Bp + b] = e[i];
+      if (A.q_out) A.q_out[b * K + c] = e[i];
+      A.qn[(int64_t)c * A.Bp + b] = fmaxf(e[i], 1e-8f) * cinv;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Gram spectrum ("k-means" loss): value and the matrix Pm with dLoss/dZ = Z * Pm.
 //   loss = w * mean_i sqrt(max(lambda_i(Z^T Z / B), 1e-9)) ;  dLoss/dZ = w/(L*B) * Z * G^{-1/2}
@@ -386,6 +516,8 @@ struct StatsArgs {
 
 template <int L>
 __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
+  // workgroups 0..K-1: one component each; K: activity + pretrain KL; K+1: distillation class weights;
+  // K+2: temporal cohesion (three short dependent chains side by side instead of one long one)
   constexpr int SW = 3 * L + 1;
   __shared__ float s_lt[32][256];
   const int c = blockIdx.x;
@@ -393,6 +525,7 @@ __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
 #pragma unroll
   for (int i = 0; i < SW; ++i) vals[i] = 0.0f;
   if (c < A.K) {
+#pragma unroll 4
     for (int64_t b = threadIdx.x; b < A.B; b += 256) {
       const float qv = A.qn[(int64_t)c * A.Bp + b];
       vals[0] += qv;
@@ -404,8 +537,8 @@ __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
         vals[1 + 2 * L + d] = fmaf(qv * m, m, vals[1 + 2 * L + d]);
       }
     }
-  } else {
-    const float Ts = A.hyper[DOF_H_DISTILL_T];
+  } else if (c == A.K) {
+#pragma unroll 4
     for (int64_t b = threadIdx.x; b < A.B; b += 256) {
       float act = 0.0f, kl = 0.0f;
 #pragma unroll
@@ -418,9 +551,13 @@ __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
       }
       vals[0] += act;
       vals[1] += 0.5f * kl / L;
-      if (A.tau) {  // w_class_b = sum_c sharpen(tau)[c] * class_weight[c]
+    }
+  } else if (c == A.K + 1) {
+    if (A.tau) {  // w_class_b = sum_c sharpen(tau)[c] * class_weight[c]
+      const float Ts = A.hyper[DOF_H_DISTILL_T];
+      const bool cache = A.K <= 32;  // the scaled logs of this window through LDS: one logf per entry instead of two
+      for (int64_t b = threadIdx.x; b < A.B; b += 256) {
         float mx = -INFINITY;
-        const bool cache = A.K <= 32;  // the scaled logs of this window through LDS: one logf per entry instead of two
         for (int k = 0; k < A.K; ++k) {
           const float lt = logf(fmaxf(A.tau[b * A.K + k], 1e-8f)) / Ts;
           if (cache) s_lt[k][threadIdx.x] = lt;
@@ -435,11 +572,12 @@ __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
         }
         vals[2] += sw / se;
       }
-      if (b + 1 < A.B) {  // temporal cohesion: sum_c |qn[b+1,c] - qn[b,c]|
-        float tv = 0.0f;
-        for (int k = 0; k < A.K; ++k) tv += fabsf(A.qn[(int64_t)k * A.Bp + b + 1] - A.qn[(int64_t)k * A.Bp + b]);
-        vals[3] += tv;
-      }
+    }
+  } else {
+    for (int64_t b = threadIdx.x; b + 1 < A.B; b += 256) {  // temporal cohesion: sum_c |qn[b+1,c] - qn[b,c]|
+      float tv = 0.0f;
+      for (int k = 0; k < A.K; ++k) tv += fabsf(A.qn[(int64_t)k * A.Bp + b + 1] - A.qn[(int64_t)k * A.Bp + b]);
+      vals[3] += tv;
     }
   }
   __shared__ float out[SW];
@@ -447,24 +585,36 @@ __global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
   __syncthreads();
   if (threadIdx.x < SW) {
     if (c < A.K) A.stats[c * SW + threadIdx.x] = out[threadIdx.x];
-    else if (threadIdx.x < 4) A.stats[A.K * SW + threadIdx.x] = out[threadIdx.x];
+    else if (c == A.K && threadIdx.x < 2) A.stats[A.K * SW + threadIdx.x] = out[threadIdx.x];
+    else if (c > A.K && (int)threadIdx.x == c - A.K + 1) A.stats[A.K * SW + threadIdx.x] = out[threadIdx.x];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Monte-Carlo KL against the GMM prior (main phase), losses.py:525-545.  Thread = (sample, b).
+// Monte-Carlo KL against the GMM prior (main phase), losses.py:525-545.  One launch: a workgroup owns 8 windows,
+// the 32 lanes of a half-wave stride over the S samples of one window.  Per (sample, window): z_s = mu + eps * sd,
+// log q(z_s), the K component logits (constants of the mixture staged in LDS once per workgroup: mean, 1 / var
+// with the clamped log-variance, log prior - sum_d (log 2 pi + lv) / 2), their log-sum-exp and
+// d log p / d z_s.  The sample sums the backward pass needs (sum_s dlogp/dz and sum_s dlogp/dz * eps per window
+// and dimension; sum of log q - log p per workgroup) are reduced over the half-wave by a fixed butterfly and
+// written directly -- the per-sample gradient tensor never exists.  z_s and the log-sum-exp are kept for
+// k_gmm_grads.  (Round 1: k_mckl_fwd + k_block_sum + k_mckl_reduce, 30 us at B = 1024, S = 32, with the
+// component constants re-derived through three expf per (sample, window, component, dimension).)
 // ---------------------------------------------------------------------------------------------
 struct McklArgs {
   const float *mu, *sv;       // [L][Bp]
   const float* eps_mc;        // (S,B,L) row-major
   const float *gmm_means, *gmm_log_vars, *prior;
   const float* hyper;
-  float* term;                // [S][Bp]  log q - log p
+  float* partial;             // [gridDim.x] per-workgroup sums of log q - log p
   float* lse;                 // [S][Bp]
-  float* dz;                  // [S][L][Bp]  d log p / d z
+  float* zs;                  // (S,B,L) row-major, like eps_mc
+  float* gsum;                // [2L][Bp]: sum_s dlogp/dz | sum_s dlogp/dz * eps
   int K, S;
   int64_t B, Bp;
 };
+
+constexpr int kMcklWindows = 8;  // windows per workgroup
 
 template <int L>
 __device__ __forceinline__ float gmm_logp_c(const float* zs, const float* means, const float* log_vars, float lo,
@@ -481,61 +631,118 @@ __device__ __forceinline__ float gmm_logp_c(const float* zs, const float* means,
 }
 
 template <int L>
-__global__ void __launch_bounds__(256) k_mckl_fwd(McklArgs A) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)A.S * A.B) return;
-  const int smp = (int)(i / A.B);
-  const int64_t b = i - (int64_t)smp * A.B;
-  const float lo = A.hyper[DOF_H_LOGVAR_LO], hi = A.hyper[DOF_H_LOGVAR_HI];
+__global__ void __launch_bounds__(256) k_mckl(McklArgs A) {
+  __shared__ float s_m[kLatentMaxKL], s_iv[kLatentMaxKL], s_c[kLatentMaxKL / 4];
+  __shared__ float s_term[kMcklWindows];
   const float LOG_2PI = 1.8378770664093453f;
-  float zs[L];
-  float logq = 0.0f;
-#pragma unroll
-  for (int d = 0; d < L; ++d) {
-    const float sc = fminf(fmaxf(A.sv[(int64_t)d * A.Bp + b], -4.0f), 2.0f);
-    const float e = A.eps_mc[((int64_t)smp * A.B + b) * L + d];
-    zs[d] = fmaf(e, expf(0.5f * sc), A.mu[(int64_t)d * A.Bp + b]);
-    logq += LOG_2PI + sc + e * e;
+  const float lo = A.hyper[DOF_H_LOGVAR_LO], hi = A.hyper[DOF_H_LOGVAR_HI];
+  const int K = A.K;
+  const bool staged = K * L <= kLatentMaxKL;
+  if (staged) {
+    for (int e = threadIdx.x; e < K * L; e += 256) {
+      s_m[e] = A.gmm_means[e];
+      s_iv[e] = expf(-fminf(fmaxf(A.gmm_log_vars[e], lo), hi));
+    }
+    for (int c = threadIdx.x; c < K; c += 256) {
+      float acc = 0.0f;
+      for (int d = 0; d < L; ++d) acc += LOG_2PI + fminf(fmaxf(A.gmm_log_vars[c * L + d], lo), hi);
+      s_c[c] = logf(fmaxf(A.prior[c], 1e-8f)) - 0.5f * acc;
+    }
+    __syncthreads();
   }
-  logq *= -0.5f;
-  float mx = -INFINITY;
-  for (int c = 0; c < A.K; ++c)
-    mx = fmaxf(mx, logf(fmaxf(A.prior[c], 1e-8f)) + gmm_logp_c<L>(zs, A.gmm_means, A.gmm_log_vars, lo, hi, c));
-  float se = 0.0f;
-  float g[L];
+  const int bl = (int)threadIdx.x >> 5, sl = (int)threadIdx.x & 31;
+  const int64_t b = (int64_t)blockIdx.x * kMcklWindows + bl;
+  const bool live = b < A.B;
+  float acc[2 * L + 1];
 #pragma unroll
-  for (int d = 0; d < L; ++d) g[d] = 0.0f;
-  for (int c = 0; c < A.K; ++c) {
-    const float e = expf(logf(fmaxf(A.prior[c], 1e-8f)) + gmm_logp_c<L>(zs, A.gmm_means, A.gmm_log_vars, lo, hi, c) - mx);
-    se += e;
+  for (int i = 0; i < 2 * L + 1; ++i) acc[i] = 0.0f;
+  if (live) {
+    float mu[L], sd[L], sc[L];
 #pragma unroll
     for (int d = 0; d < L; ++d) {
-      const float lv = fminf(fmaxf(A.gmm_log_vars[c * L + d], lo), hi);
-      g[d] = fmaf(e, -(zs[d] - A.gmm_means[c * L + d]) * expf(-lv), g[d]);
+      sc[d] = fminf(fmaxf(A.sv[(int64_t)d * A.Bp + b], -4.0f), 2.0f);
+      sd[d] = expf(0.5f * sc[d]);
+      mu[d] = A.mu[(int64_t)d * A.Bp + b];
+    }
+    for (int smp = sl; smp < A.S; smp += 32) {
+      const int64_t item = (int64_t)smp * A.B + b;
+      float e[L], zs[L];
+      if constexpr (L % 4 == 0) {
+        dof_ld_row<L>(A.eps_mc + item * L, e);
+      } else {
+#pragma unroll
+        for (int d = 0; d < L; ++d) e[d] = A.eps_mc[item * L + d];
+      }
+      float logq = 0.0f;
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        zs[d] = fmaf(e[d], sd[d], mu[d]);
+        logq += LOG_2PI + sc[d] + e[d] * e[d];
+      }
+      logq *= -0.5f;
+      if constexpr (L % 4 == 0) {
+        dof_st_row<L>(A.zs + item * L, zs);
+      } else {
+#pragma unroll
+        for (int d = 0; d < L; ++d) A.zs[item * L + d] = zs[d];
+      }
+      auto logit = [&](int c) -> float {
+        if (!staged) return logf(fmaxf(A.prior[c], 1e-8f)) + gmm_logp_c<L>(zs, A.gmm_means, A.gmm_log_vars, lo, hi, c);
+        float q = 0.0f;
+#pragma unroll
+        for (int d = 0; d < L; ++d) {
+          const float df = zs[d] - s_m[c * L + d];
+          q = fmaf(df * df, s_iv[c * L + d], q);
+        }
+        return fmaf(-0.5f, q, s_c[c]);
+      };
+      float mx = -INFINITY;
+      for (int c = 0; c < K; ++c) mx = fmaxf(mx, logit(c));
+      float se = 0.0f;
+      float g[L];
+#pragma unroll
+      for (int d = 0; d < L; ++d) g[d] = 0.0f;
+      for (int c = 0; c < K; ++c) {
+        const float w = expf(logit(c) - mx);
+        se += w;
+#pragma unroll
+        for (int d = 0; d < L; ++d) {
+          const float m = staged ? s_m[c * L + d] : A.gmm_means[c * L + d];
+          const float iv = staged ? s_iv[c * L + d] : expf(-fminf(fmaxf(A.gmm_log_vars[c * L + d], lo), hi));
+          g[d] = fmaf(w, -(zs[d] - m) * iv, g[d]);
+        }
+      }
+      const float lse = mx + logf(se);
+      A.lse[(int64_t)smp * A.Bp + b] = lse;
+      acc[0] += logq - lse;
+      const float inv = 1.0f / se;
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float gd = g[d] * inv;
+        acc[1 + d] += gd;
+        acc[1 + L + d] = fmaf(gd, e[d], acc[1 + L + d]);
+      }
     }
   }
-  const float lse = mx + logf(se);
-  A.term[(int64_t)smp * A.Bp + b] = logq - lse;
-  A.lse[(int64_t)smp * A.Bp + b] = lse;
 #pragma unroll
-  for (int d = 0; d < L; ++d) A.dz[((int64_t)smp * L + d) * A.Bp + b] = g[d] / se;
-}
-
-// sum over the S samples of dlogp/dz and dlogp/dz * eps; thread = (b, d = blockIdx.y)
-__global__ void __launch_bounds__(256) k_mckl_reduce(const float* __restrict__ dz, const float* __restrict__ eps_mc,
-                                                     float* __restrict__ gsum /*[2L][Bp]*/, int S, int L, int64_t B,
-                                                     int64_t Bp) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const int d = blockIdx.y;
-  float gz = 0.0f, gze = 0.0f;
-  for (int smp = 0; smp < S; ++smp) {
-    const float g = dz[((int64_t)smp * L + d) * Bp + b];
-    gz += g;
-    gze = fmaf(g, eps_mc[((int64_t)smp * B + b) * L + d], gze);
+  for (int i = 0; i < 2 * L + 1; ++i) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m);
   }
-  gsum[(int64_t)d * Bp + b] = gz;
-  gsum[(int64_t)(L + d) * Bp + b] = gze;
+  if (sl == 0) {
+    s_term[bl] = acc[0];
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < 2 * L; ++d) A.gsum[(int64_t)d * A.Bp + b] = acc[1 + d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kMcklWindows; ++i) t += s_term[i];
+    A.partial[blockIdx.x] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -568,11 +775,21 @@ __device__ __forceinline__ float dof_wave_sum_array(const float* __restrict__ p,
   return acc;
 }
 
+__device__ __forceinline__ float dof_wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
 __global__ void k_loss_mid(LossMidArgs A) {
-  // launched as one wavefront: the per-workgroup partials are summed by all 64 lanes, the scalar part runs on lane 0
+  // launched as ONE wavefront.  Lane c owns mixture component c (c, c + 64, ...): the per-component terms and the
+  // K x K repulsion run side by side, scalars come from 64-lane butterflies (fixed shape: deterministic).  The form
+  // with all of it on lane 0 took 17 us at K = 10 -- as long as the whole posterior backward.
+  __shared__ float s_cen[kLatentMaxKL];  // soft centroids [K][L]
+  __shared__ float s_mass[kLatentMaxKL / 4];
+  const int lane = (int)threadIdx.x;
   float recon = dof_wave_sum_array(A.recon_partial, A.n_recon);
   const float mckl_sum = (!A.pretrain && A.mckl_partial) ? dof_wave_sum_array(A.mckl_partial, A.n_mckl) : 0.0f;
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int K = A.K, L = A.L;
   const int SW = 3 * L + 1;
   const float* H = A.hyper;
@@ -581,120 +798,136 @@ __global__ void k_loss_mid(LossMidArgs A) {
   const float* sc = A.stats + K * SW;
   const float activity = H[DOF_H_L1_ACT] * sc[0] / Bf;
   const float klw = H[DOF_H_KLW];
-  float kl;
+  float kl, scal0;
   if (A.pretrain) {
     kl = klw * sc[1] / Bf;
-    A.scal[0] = 0.0f;
+    scal0 = 0.0f;
   } else {
     const float raw = mckl_sum / ((float)A.S * Bf);
     kl = klw * fmaxf(raw, 0.0f);
-    A.scal[0] = raw > 0.0f ? klw / ((float)A.S * Bf) : 0.0f;
+    scal0 = raw > 0.0f ? klw / ((float)A.S * Bf) : 0.0f;
   }
-  A.scal[1] = fmaxf(sc[2] / Bf, 1e-8f);
+  const bool staged = K * L <= kLatentMaxKL;
+  if (staged) {
+    for (int c = lane; c < K; c += 64) {
+      const float pc = fmaxf(A.stats[c * SW], 1e-8f);
+      s_mass[c] = pc;
+      for (int d = 0; d < L; ++d) s_cen[c * L + d] = A.stats[c * SW + 1 + d] / pc;
+    }
+    __syncthreads();
+  }
+  auto mass = [&](int c) { return staged ? s_mass[c] : fmaxf(A.stats[c * SW], 1e-8f); };
+  auto cen = [&](int c, int d) { return staged ? s_cen[c * L + d] : A.stats[c * SW + 1 + d] / fmaxf(A.stats[c * SW], 1e-8f); };
   // nonempty floor on the batch marginal
   float nonempty = 0.0f;
   const float nw = H[DOF_H_NONEMPTY_W], base_floor = H[DOF_H_NONEMPTY_FLOOR], pw = H[DOF_H_NONEMPTY_P];
-  for (int c = 0; c < K; ++c) {
+  const bool has_teacher = A.teacher_marginal && H[DOF_H_HAS_TEACHER] != 0.0f;
+  const float wcat = A.pretrain ? 0.0f : H[DOF_H_CAT_W];
+  float cat = 0.0f, qs = 0.0f, pbar = 0.0f;
+  for (int c = lane; c < K; c += 64) {
     const float qm = A.stats[c * SW] / Bf;
     float fl = base_floor;
-    if (A.teacher_marginal && H[DOF_H_HAS_TEACHER] != 0.0f) fl = fmaxf(fl, 0.9f * A.teacher_marginal[c]);
+    if (has_teacher) fl = fmaxf(fl, 0.9f * A.teacher_marginal[c]);
     const float under = fmaxf(fl - qm, 0.0f);
     float g = 0.0f;
     if (nw > 0.0f && under > 0.0f) {
       nonempty += powf(under, pw);
       g = -nw * pw * powf(under, pw - 1.0f);
     }
+    if (wcat > 0.0f) {  // KLDivLoss(batchmean) of log(mean q + 1e-9) vs uniform, divided by K (losses.py:354-359)
+      const float u = 1.0f / (float)K;
+      cat += u * (logf(u) - logf(qm + 1e-9f));
+      g += -wcat * (u / (float)K) / (qm + 1e-9f);
+    }
     A.dqbar[c] = g;
+    qs += A.stats[c * SW];
+    pbar += fmaxf(A.stats[c * SW], 1e-8f);
   }
-  nonempty *= nw;
-  // repulsion between soft centroids (q detached)
+  nonempty = nw * dof_wave_sum(nonempty);
+  cat = dof_wave_sum(cat) * (wcat / (float)K);
+  qs = dof_wave_sum(qs);
+  pbar = dof_wave_sum(pbar) / (float)K;
+  // repulsion between soft centroids (q detached): lane c against every other component, in component order
   float repel = 0.0f;
   const float rw = H[DOF_H_REPEL_W];
-  for (int i = 0; i < K * L; ++i) A.dcen[i] = 0.0f;
   if (rw > 0.0f) {
     const float ls = H[DOF_H_REPEL_LS];
     const float den = fmaxf(1e-9f, 2.0f * ls * ls);
     const float norm = (float)(K * K - K > 1 ? K * K - K : 1);
     float ksum = 0.0f;
-    for (int c = 0; c < K; ++c) {
-      const float pc = fmaxf(A.stats[c * SW], 1e-8f);
+    for (int c = lane; c < K; c += 64) {
+      const float pc = mass(c);
+      float acc[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc[d] = 0.0f;
       for (int e = 0; e < K; ++e) {
         if (e == c) continue;
-        const float pe = fmaxf(A.stats[e * SW], 1e-8f);
-        float d2 = 0.0f;
-        for (int d = 0; d < L; ++d) {
-          const float df = A.stats[c * SW + 1 + d] / pc - A.stats[e * SW + 1 + d] / pe;
-          d2 += df * df;
+        float d2 = 0.0f, df[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          df[d] = d < L ? cen(c, d) - cen(e, d) : 0.0f;
+          d2 += df[d] * df[d];
         }
         const float kv = expf(-d2 / den);
         ksum += kv;
-        for (int d = 0; d < L; ++d) {
-          const float df = A.stats[c * SW + 1 + d] / pc - A.stats[e * SW + 1 + d] / pe;
-          A.dcen[c * L + d] += (rw / norm) * 2.0f * kv * (-2.0f * df / den) / pc;
-        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc[d] += (rw / norm) * 2.0f * kv * (-2.0f * df[d] / den) / pc;
       }
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        if (d < L) A.dcen[c * L + d] = acc[d];
     }
-    repel = rw * ksum / norm;
+    repel = rw * dof_wave_sum(ksum) / norm;
+  } else {
+    for (int i = lane; i < K * L; i += 64) A.dcen[i] = 0.0f;
   }
-  float prior_loss = 0.0f;
-  if (!A.pretrain) {  // -(q * log(1/K)).sum(-1).mean(); q rows sum to one after renormalisation
-    float qs = 0.0f;
-    for (int c = 0; c < K; ++c) qs += A.stats[c * SW];
-    prior_loss = logf((float)(K > 1 ? K : 1)) * qs / Bf;
-  }
-  // ---- optional main-phase regularisers (reference default weight 0): cat-KL, temporal, scatter
-  float cat = 0.0f, temporal = 0.0f, scatter = 0.0f;
-  for (int i = 0; i < K * (2 * L + 1); ++i) A.dscat[i] = 0.0f;
+  // -(q * log(1/K)).sum(-1).mean(); q rows sum to one after renormalisation
+  const float prior_loss = A.pretrain ? 0.0f : logf((float)(K > 1 ? K : 1)) * qs / Bf;
+  // ---- optional main-phase regularisers (reference default weight 0): temporal, scatter
+  float temporal = 0.0f, scatter = 0.0f;
+  const float eta = A.pretrain ? 0.0f : H[DOF_H_SCATTER_W];
   if (!A.pretrain) {
-    const float wcat = H[DOF_H_CAT_W];
-    if (wcat > 0.0f) {  // KLDivLoss(batchmean) of log(mean q + 1e-9) vs uniform, divided by K (losses.py:354-359)
-      const float u = 1.0f / (float)K;
-      for (int c = 0; c < K; ++c) {
-        const float qm = A.stats[c * SW] / Bf;
-        cat += u * (logf(u) - logf(qm + 1e-9f));
-        A.dqbar[c] += -wcat * (u / (float)K) / (qm + 1e-9f);
-      }
-      cat *= wcat / (float)K;
-    }
     const float rho = H[DOF_H_TEMPORAL_W];
     if (rho > 0.0f && A.B > 1) temporal = rho * sc[3] / (Bf - 1.0f);
-    const float eta = H[DOF_H_SCATTER_W];
-    if (eta > 0.0f) {
-      const float beta = H[DOF_H_SCATTER_BETA];
-      float pbar = 0.0f;
-      for (int c = 0; c < K; ++c) pbar += fmaxf(A.stats[c * SW], 1e-8f);
-      pbar /= (float)K;
-      float wa_sum = 0.0f;  // sum_e w_e A_e
-      for (int c = 0; c < K; ++c) {
-        const float pc = fmaxf(A.stats[c * SW], 1e-8f);
-        const float w = powf(pc / pbar, -beta);
-        float a_c = 0.0f;
-        for (int d = 0; d < L; ++d) {
-          const float mu = A.stats[c * SW + 1 + L + d] / pc;
-          a_c += A.stats[c * SW + 1 + 2 * L + d] / pc - mu * mu;
-        }
-        wa_sum += w * a_c;
-      }
-      const float norm = eta / ((float)K * (float)L);
-      scatter = norm * wa_sum;
-      for (int c = 0; c < K; ++c) {
-        const float praw = A.stats[c * SW];
-        const float pc = fmaxf(praw, 1e-8f);
-        const float w = powf(pc / pbar, -beta);
-        float a_c = 0.0f, dp = 0.0f;
-        for (int d = 0; d < L; ++d) {
-          const float m = A.stats[c * SW + 1 + L + d], s2 = A.stats[c * SW + 1 + 2 * L + d];
-          const float mu = m / pc;
-          a_c += s2 / pc - mu * mu;
-          dp += -s2 / (pc * pc) + 2.0f * m * m / (pc * pc * pc);
-          A.dscat[c * (2 * L + 1) + 1 + d] = norm * w * (-2.0f * mu / pc);
-          A.dscat[c * (2 * L + 1) + 1 + L + d] = norm * w / pc;
-        }
-        // through the (clamped) cluster mass: scatter itself, its weight w_c, and the mean mass in every w_e
-        A.dscat[c * (2 * L + 1)] = praw > 1e-8f ? norm * (w * dp - beta * w * a_c / pc + beta * wa_sum / ((float)K * pbar)) : 0.0f;
-      }
-    }
   }
+  if (eta > 0.0f) {
+    const float beta = H[DOF_H_SCATTER_BETA];
+    float wa = 0.0f;  // sum_e w_e A_e
+    for (int c = lane; c < K; c += 64) {
+      const float pc = fmaxf(A.stats[c * SW], 1e-8f);
+      const float w = powf(pc / pbar, -beta);
+      float a_c = 0.0f;
+      for (int d = 0; d < L; ++d) {
+        const float mu = A.stats[c * SW + 1 + L + d] / pc;
+        a_c += A.stats[c * SW + 1 + 2 * L + d] / pc - mu * mu;
+      }
+      wa += w * a_c;
+    }
+    const float wa_sum = dof_wave_sum(wa);
+    const float norm = eta / ((float)K * (float)L);
+    scatter = norm * wa_sum;
+    for (int c = lane; c < K; c += 64) {
+      const float praw = A.stats[c * SW];
+      const float pc = fmaxf(praw, 1e-8f);
+      const float w = powf(pc / pbar, -beta);
+      float a_c = 0.0f, dp = 0.0f;
+      for (int d = 0; d < L; ++d) {
+        const float m = A.stats[c * SW + 1 + L + d], s2 = A.stats[c * SW + 1 + 2 * L + d];
+        const float mu = m / pc;
+        a_c += s2 / pc - mu * mu;
+        dp += -s2 / (pc * pc) + 2.0f * m * m / (pc * pc * pc);
+        A.dscat[c * (2 * L + 1) + 1 + d] = norm * w * (-2.0f * mu / pc);
+        A.dscat[c * (2 * L + 1) + 1 + L + d] = norm * w / pc;
+      }
+      // through the (clamped) cluster mass: scatter itself, its weight w_c, and the mean mass in every w_e
+      A.dscat[c * (2 * L + 1)] = praw > 1e-8f ? norm * (w * dp - beta * w * a_c / pc + beta * wa_sum / ((float)K * pbar)) : 0.0f;
+    }
+  } else {
+    for (int i = lane; i < K * (2 * L + 1); i += 64) A.dscat[i] = 0.0f;
+  }
+  if (lane != 0) return;
+  A.scal[0] = scal0;
+  A.scal[1] = fmaxf(sc[2] / Bf, 1e-8f);
   float* lg = A.logs;
   lg[DOF_LOG_RECON] = recon;
   lg[DOF_LOG_KL] = kl;
@@ -714,12 +947,10 @@ __global__ void k_loss_mid(LossMidArgs A) {
 
 __global__ void k_loss_total(const float* __restrict__ distill_partial, const float* __restrict__ tf_partial, int n,
                              const float* __restrict__ hyper, int64_t B, int pretrain, float* __restrict__ logs) {
+  // launched as one wavefront
+  const float s = dof_wave_sum_array(distill_partial, n);
+  const float t = dof_wave_sum_array(tf_partial, n);
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float s = 0.0f, t = 0.0f;
-  for (int i = 0; i < n; ++i) {
-    s += distill_partial[i];
-    t += tf_partial[i];
-  }
   const float d = hyper[DOF_H_LAMBDA_DISTILL] * s / (float)B;
   const float tf = pretrain ? 0.0f : -hyper[DOF_H_TF_W] * t / (float)B;
   logs[DOF_LOG_DISTILL] = d;
@@ -991,12 +1222,303 @@ __global__ void __launch_bounds__(256) k_latent_bwd(LatentBwdArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// GMM parameter gradients.  Block c: posterior path (sum over b) + MC-KL path (sum over (s,b)).
+// Latent backward with the components across lanes: 16 lanes per window, lane j owns components j, j + 16, ...
+// (NC per lane, K <= 16 NC), sums over the components are 4-step butterflies inside the 16-lane row, the
+// per-window tail (Gram spectrum, reparameterisation, the two dense layers) runs replicated in the row.  Same
+// arithmetic as k_latent_bwd (which stays for K > 32); at K = 10 the dependent chain per thread shrinks from ~3 K
+// component visits to 3.  Also emits the data gradient of encoder.final_dense (dflat) when asked to.
+// ---------------------------------------------------------------------------------------------
+
+template <int L, int NC>
+__global__ void __launch_bounds__(256) k_latent_bwd_w(LatentBwdArgs A) {
+  constexpr int KMAX = 16 * NC;
+  __shared__ float s_isd2[KMAX * L], s_gm[KMAX * L], s_dcen[KMAX * L];
+  __shared__ float s_wm[L * L], s_ws[L * L], s_pm[L * L];
+  __shared__ float s_wf[kWfMax];  // [input][l]
+  const int K = A.K;
+  const bool wf_lds = A.dflat && A.J * L <= kWfMax;
+  for (int e = threadIdx.x; e < K * L; e += 256) {
+    const float sd = fmaxf(expf(0.5f * A.gmm_log_vars[e]), 1e-3f);
+    s_isd2[e] = 1.0f / (sd * sd);
+    s_gm[e] = A.gmm_means[e];
+    s_dcen[e] = A.dcen[e];
+  }
+  if (threadIdx.x < L * L) {
+    s_wm[threadIdx.x] = A.wm[threadIdx.x];
+    s_ws[threadIdx.x] = A.ws[threadIdx.x];
+    s_pm[threadIdx.x] = A.Pm[threadIdx.x];
+  }
+  if (wf_lds)
+    for (int e = threadIdx.x; e < A.J * L; e += 256) {
+      const int l = e / A.J;
+      s_wf[(e - l * A.J) * L + l] = A.wf[e];
+    }
+  __syncthreads();
+  const int j = (int)threadIdx.x & 15, row = (int)threadIdx.x >> 4;
+  const int l = j % L;  // the latent dimension this lane owns in the per-window tail
+  const int64_t b_raw = (int64_t)blockIdx.x * kLatRows + row;
+  const bool live = b_raw < A.B;
+  const int64_t b = live ? b_raw : A.B - 1;  // idle rows shadow the last window (DPP reads every lane)
+  const float* H = A.hyper;
+  const float Bf = (float)A.B;
+  const float rho = A.pretrain ? 0.0f : H[DOF_H_TEMPORAL_W];
+  const float eta = A.pretrain ? 0.0f : H[DOF_H_SCATTER_W];
+  const float wtf = A.pretrain ? 0.0f : H[DOF_H_TF_W];
+  const float lo = H[DOF_H_LOGVAR_LO], hi = H[DOF_H_LOGVAR_HI];
+  const float z_l = A.z[(int64_t)l * A.Bp + b];
+  const float mu_l = A.mu[(int64_t)l * A.Bp + b];
+  float z[L], mu_b[L];
+  dof_static_for<L>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    z[d] = dof_gbcast<d, 16>(z_l);
+    mu_b[d] = eta != 0.0f ? dof_gbcast<d, 16>(mu_l) : 0.0f;  // only the scatter term needs every dimension's mean
+  });
+  int cc[NC];
+  bool valid[NC];
+  float q[NC], qn[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    valid[i] = j + 16 * i < K;
+    cc[i] = valid[i] ? j + 16 * i : 0;
+    q[i] = A.q[(int64_t)cc[i] * A.Bp + b];
+    qn[i] = A.qn[(int64_t)cc[i] * A.Bp + b];
+  }
+  // ---- sharpened teacher probabilities and the window's distillation weight
+  const float lam = H[DOF_H_LAMBDA_DISTILL];
+  const bool distill = A.tau && lam > 0.0f;
+  float w_total = 1.0f;
+  float tb[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) tb[i] = 0.0f;
+  if (distill) {
+    const float Ts = H[DOF_H_DISTILL_T];
+    float lt[NC], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      lt[i] = valid[i] ? logf(fmaxf(A.tau[b * K + cc[i]], 1e-8f)) / Ts : -INFINITY;
+      mx = fmaxf(mx, lt[i]);
+    }
+    mx = dof_row16_max(mx);
+    float se = 0.0f, sw = 0.0f, cmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      tb[i] = valid[i] ? expf(lt[i] - mx) : 0.0f;
+      se += tb[i];
+      sw = fmaf(tb[i], valid[i] ? A.class_weight[cc[i]] : 0.0f, sw);
+      cmax = fmaxf(cmax, tb[i]);
+    }
+    se = dof_row16_sum(se);
+    sw = dof_row16_sum(sw);
+    cmax = dof_row16_max(cmax);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) tb[i] /= se;
+    w_total = (sw / se) / A.scal[1];
+    if (H[DOF_H_CONF_W] != 0.0f) {
+      const float thr = H[DOF_H_CONF_THR];
+      w_total *= fminf(fmaxf((cmax / se - thr) / fmaxf(1e-6f, 1.0f - thr), 0.0f), 1.0f);
+    }
+  }
+  // ---- optional main-phase terms that touch qn: temporal cohesion, scatter, tf-cluster (default weight 0)
+  float pl[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) pl[i] = 0.0f;
+  if (wtf != 0.0f) {  // pl = softmax_c log N(z; m_c, clamp(l_c)) with the 1e-3 std floor (losses.py:547-564)
+    float lg[NC], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      lg[i] = 0.0f;
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float sd = fmaxf(expf(0.5f * fminf(fmaxf(A.gmm_log_vars[cc[i] * L + d], lo), hi)), 1e-3f);
+        const float u = (z[d] - s_gm[cc[i] * L + d]) / sd;
+        lg[i] += -0.5f * u * u - logf(sd);
+      }
+      if (!valid[i]) lg[i] = -INFINITY;
+      mx = fmaxf(mx, lg[i]);
+    }
+    mx = dof_row16_max(mx);
+    float se = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      pl[i] = valid[i] ? expf(lg[i] - mx) : 0.0f;
+      se += pl[i];
+    }
+    se = dof_row16_sum(se);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) pl[i] /= se;
+  }
+  // ---- d loss / d qn per component, then through clamp + renormalise and the softmax
+  float g[NC];
+  float dot = 0.0f, csum = 0.0f, ce = 0.0f, tf_sum = 0.0f, pl_dot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = cc[i];
+    float gi = A.dqbar[c] / Bf;
+    if (rho != 0.0f && A.B > 1) {
+      const float sc = rho / ((float)A.B - 1.0f);
+      if (b > 0) {
+        const float df = qn[i] - A.qn[(int64_t)c * A.Bp + b - 1];
+        gi += sc * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+      }
+      if (b + 1 < A.B) {
+        const float df = A.qn[(int64_t)c * A.Bp + b + 1] - qn[i];
+        gi -= sc * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+      }
+    }
+    if (eta != 0.0f) {
+      const float* ds = A.dscat + c * (2 * L + 1);
+      gi += ds[0];
+#pragma unroll
+      for (int d = 0; d < L; ++d) gi += ds[1 + d] * mu_b[d] + ds[1 + L + d] * mu_b[d] * mu_b[d];
+    }
+    if (wtf != 0.0f) gi += -(wtf / Bf) * pl[i];
+    if (distill) {
+      if (valid[i]) ce -= tb[i] * logf(fmaxf(qn[i], 1e-8f));
+      if (qn[i] >= 1e-8f) gi -= (lam / Bf) * w_total * tb[i] / qn[i];
+    }
+    if (!valid[i]) gi = 0.0f;
+    g[i] = gi;
+    if (valid[i]) {
+      tf_sum = fmaf(qn[i], pl[i], tf_sum);
+      pl_dot = fmaf(-(wtf / Bf) * qn[i], pl[i], pl_dot);  // sum_c dpl[c]*pl[c]
+      dot = fmaf(gi, qn[i], dot);
+      csum += fmaxf(q[i], 1e-8f);
+    }
+  }
+  dot = dof_row16_sum(dot);
+  csum = dof_row16_sum(csum);
+  if (distill) ce = dof_row16_sum(ce);
+  if (wtf != 0.0f) {
+    tf_sum = dof_row16_sum(tf_sum);
+    pl_dot = dof_row16_sum(pl_dot);
+  }
+  float dq[NC], sdot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    dq[i] = (valid[i] && q[i] >= 1e-8f) ? (g[i] - dot) / csum : 0.0f;
+    sdot = fmaf(dq[i], valid[i] ? q[i] : 0.0f, sdot);
+  }
+  sdot = dof_row16_sum(sdot);
+  float part[L];
+#pragma unroll
+  for (int d = 0; d < L; ++d) part[d] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = cc[i];
+    const float dl = valid[i] ? q[i] * (dq[i] - sdot) : 0.0f;
+    const float qv = valid[i] ? qn[i] : 0.0f;
+    float dl2 = 0.0f;
+    if (wtf != 0.0f && valid[i]) dl2 = pl[i] * (-(wtf / Bf) * qn[i] - pl_dot);  // softmax backward of pl
+    if (valid[i] && live) {
+      A.dlogit[(int64_t)c * A.Bp + b] = dl;
+      if (wtf != 0.0f) A.dlogp2[(int64_t)c * A.Bp + b] = dl2;  // consumed by k_gmm_grads
+    }
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      const float df = z[d] - s_gm[c * L + d];
+      part[d] = fmaf(dl, -df * s_isd2[c * L + d], part[d]);
+      part[d] = fmaf(qv, s_dcen[c * L + d], part[d]);
+      if (wtf != 0.0f) {
+        const float sd2 = fmaxf(expf(0.5f * fminf(fmaxf(A.gmm_log_vars[c * L + d], lo), hi)), 1e-3f);
+        part[d] = fmaf(dl2, -df / (sd2 * sd2), part[d]);
+      }
+    }
+  }
+  // the lane's own dimension from here on: decoder gradient + the row sums of the component paths
+  float dz_l = A.dz_dec[(int64_t)l * A.Bp + b] + A.dz_dec[(int64_t)(L + l) * A.Bp + b];
+#pragma unroll
+  for (int d = 0; d < L; ++d) {
+    const float t = dof_row16_sum(part[d]);
+    if (d == l) dz_l += t;
+  }
+  // k-means (Gram spectrum): dZ = Z * Pm
+  {
+    float acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < L; ++e) acc = fmaf(z[e], s_pm[e * L + l], acc);
+    dz_l += acc;
+  }
+  // ---- through the reparameterisation, activity L1, KL
+  const float klw = H[DOF_H_KLW];
+  const float act = H[DOF_H_L1_ACT] / Bf;
+  const float s = A.sv[(int64_t)l * A.Bp + b];
+  float dm = dz_l;
+  if (eta != 0.0f) {  // scatter term acts on z_mean directly: sum_c qn (dM_cd + 2 dS2_cd mu)
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      float sc_part = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const float* dsc = A.dscat + cc[i] * (2 * L + 1);
+        if (valid[i]) sc_part = fmaf(qn[i], dsc[1 + d] + 2.0f * dsc[1 + L + d] * mu_b[d], sc_part);
+      }
+      const float t = dof_row16_sum(sc_part);
+      if (d == l) dm += t;
+    }
+  }
+  float ds = dz_l * A.eps[b * L + l] * 0.5f * expf(0.5f * s);
+  ds += s > 0.0f ? act : (s < 0.0f ? -act : 0.0f);
+  const float sc = fminf(fmaxf(s, -4.0f), 2.0f);
+  const bool pass = (s >= -4.0f) && (s <= 2.0f);
+  if (A.pretrain) {
+    dm = fmaf(klw / (Bf * L), mu_l, dm);
+    if (pass) ds = fmaf(klw / (Bf * L), 0.5f * (expf(sc) - 1.0f), ds);
+  } else {
+    const float ksc = A.scal[0];
+    if (ksc != 0.0f) {
+      const float gz = A.mckl_gsum[(int64_t)l * A.Bp + b];
+      const float gze = A.mckl_gsum[(int64_t)(L + l) * A.Bp + b];
+      dm = fmaf(-ksc, gz, dm);
+      if (pass) ds += ksc * (-gze * 0.5f * expf(0.5f * sc) - 0.5f * (float)A.S);
+    }
+  }
+  const float dpre_l = ds * dof_sigmoid(A.pre[(int64_t)l * A.Bp + b]);
+  if (live && j < L) {
+    A.dmu_dpre[(int64_t)l * A.Bp + b] = dm;
+    A.dmu_dpre[(int64_t)(L + l) * A.Bp + b] = dpre_l;
+  }
+  // encoder_mean / encoder_log_var data gradient: denc[k] = sum_l' wm[l', k] dmu[l'] + ws[l', k] dpre[l'], lane owns k = l
+  float denc_l = 0.0f;
+  dof_static_for<L>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    denc_l = fmaf(s_wm[d * L + l], dof_gbcast<d, 16>(dm), denc_l);
+    denc_l = fmaf(s_ws[d * L + l], dof_gbcast<d, 16>(dpre_l), denc_l);
+  });
+  if (live && j < L) A.denc[(int64_t)l * A.Bp + b] = denc_l;
+  if (A.dflat) {  // encoder.final_dense data gradient: dflat[jj] = sum_l wf[l, jj] denc[l]; lane owns every 16th input
+    float denc[L];
+    dof_static_for<L>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      denc[d] = dof_gbcast<d, 16>(denc_l);
+    });
+    if (live)
+      for (int jj = j; jj < A.J; jj += 16) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < L; ++k) acc = fmaf(wf_lds ? s_wf[jj * L + k] : A.wf[k * A.J + jj], denc[k], acc);
+        A.dflat[(int64_t)jj * A.Bp + b] = acc;
+      }
+  }
+  float v2[2] = {(live && j == 0 && distill) ? w_total * ce : 0.0f, (live && j == 0) ? tf_sum : 0.0f};
+  __shared__ float o2[2];
+  dof_block_colsum<2>(v2, o2);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    A.distill_partial[blockIdx.x] = o2[0];
+    A.tf_partial[blockIdx.x] = o2[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GMM parameter gradients.  Workgroup (c, y): posterior path (sum over b) + MC-KL path (sum over (s,b)) of component c
+// over its share of the windows / samples; everything that depends on the component only (1 / sd, 1 / var with the
+// clamped log-variance, the additive constant of its logit) is derived once per thread.  The MC path reads the z_s
+// and log-sum-exp that k_mckl kept.  Per-workgroup partial sums -> k_sum_partials.
 // ---------------------------------------------------------------------------------------------
 struct GmmGradArgs {
   const float *z, *dlogit;           // [L][Bp], [K][Bp]
   const float* dlogp2;               // [K][Bp] tf-cluster path (clamped log-variances) or unused
-  const float *mu, *sv, *eps_mc, *lse;  // MC-KL recompute (main) or null
+  const float *zs, *lse;             // (S,B,L), [S][Bp] from k_mckl (main phase) or null
   const float *gmm_means, *gmm_log_vars, *prior, *scal, *hyper;
   float* partial;                    // [gridDim.y][2*K*L]: means (K,L) then log-vars (K,L)
   int K, S, pretrain;
@@ -1019,74 +1541,90 @@ __global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A) {
   const int64_t t0 = (int64_t)blockIdx.y * 256 + threadIdx.x;
   const bool use_tf = !A.pretrain && A.hyper[DOF_H_TF_W] != 0.0f;
   const float tlo = A.hyper[DOF_H_LOGVAR_LO], thi = A.hyper[DOF_H_LOGVAR_HI];
-  for (int64_t b = t0; b < A.B; b += tstride) {
-    const float dl = A.dlogit[(int64_t)c * A.Bp + b];
+  if (t0 < A.B) {
+    float isd[L];
+    bool free_sd[L];  // the 1e-3 floor on the standard deviation is inactive
 #pragma unroll
     for (int d = 0; d < L; ++d) {
       const float e = expf(0.5f * lvraw[d]);
-      const float sd = fmaxf(e, 1e-3f);
-      const float u = (A.z[(int64_t)d * A.Bp + b] - m[d]) / sd;
-      vals[d] = fmaf(dl, u / sd, vals[d]);
-      // d/d log_var of [-u^2/2 - log sd] = (u^2 - 1) * 0.5, only while the 1e-3 floor is inactive
-      if (e >= 1e-3f) vals[L + d] = fmaf(dl, 0.5f * (u * u - 1.0f), vals[L + d]);
+      isd[d] = 1.0f / fmaxf(e, 1e-3f);
+      free_sd[d] = e >= 1e-3f;
     }
-    if (use_tf) {
-      const float dl2 = A.dlogp2[(int64_t)c * A.Bp + b];
+    for (int64_t b = t0; b < A.B; b += tstride) {
+      const float dl = A.dlogit[(int64_t)c * A.Bp + b];
 #pragma unroll
       for (int d = 0; d < L; ++d) {
-        const float lvc = fminf(fmaxf(lvraw[d], tlo), thi);
-        const float e = expf(0.5f * lvc);
-        const float sd = fmaxf(e, 1e-3f);
-        const float u = (A.z[(int64_t)d * A.Bp + b] - m[d]) / sd;
-        vals[d] = fmaf(dl2, u / sd, vals[d]);
-        if (e >= 1e-3f && lvraw[d] >= tlo && lvraw[d] <= thi) vals[L + d] = fmaf(dl2, 0.5f * (u * u - 1.0f), vals[L + d]);
+        const float u = (A.z[(int64_t)d * A.Bp + b] - m[d]) * isd[d];
+        vals[d] = fmaf(dl, u * isd[d], vals[d]);
+        // d/d log_var of [-u^2/2 - log sd] = (u^2 - 1) * 0.5, only while the 1e-3 floor is inactive
+        if (free_sd[d]) vals[L + d] = fmaf(dl, 0.5f * (u * u - 1.0f), vals[L + d]);
+      }
+    }
+    if (use_tf) {
+      bool free_lv[L];
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        const float e = expf(0.5f * fminf(fmaxf(lvraw[d], tlo), thi));
+        isd[d] = 1.0f / fmaxf(e, 1e-3f);
+        free_lv[d] = e >= 1e-3f && lvraw[d] >= tlo && lvraw[d] <= thi;
+      }
+      for (int64_t b = t0; b < A.B; b += tstride) {
+        const float dl2 = A.dlogp2[(int64_t)c * A.Bp + b];
+#pragma unroll
+        for (int d = 0; d < L; ++d) {
+          const float u = (A.z[(int64_t)d * A.Bp + b] - m[d]) * isd[d];
+          vals[d] = fmaf(dl2, u * isd[d], vals[d]);
+          if (free_lv[d]) vals[L + d] = fmaf(dl2, 0.5f * (u * u - 1.0f), vals[L + d]);
+        }
       }
     }
   }
   const float ksc = A.pretrain ? 0.0f : A.scal[0];
   if (ksc != 0.0f) {
-    const float lo = A.hyper[DOF_H_LOGVAR_LO], hi = A.hyper[DOF_H_LOGVAR_HI];
-    const float lp = logf(fmaxf(A.prior[c], 1e-8f));
+    const float LOG_2PI = 1.8378770664093453f;
+    float iv[L];
+    bool free_lv[L];
+    float cst = 0.0f;
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+      const float lv = fminf(fmaxf(lvraw[d], tlo), thi);
+      iv[d] = expf(-lv);
+      free_lv[d] = lvraw[d] >= tlo && lvraw[d] <= thi;
+      cst += LOG_2PI + lv;
+    }
+    cst = logf(fmaxf(A.prior[c], 1e-8f)) - 0.5f * cst;
     const int64_t n = (int64_t)A.S * A.B;
     for (int64_t i = t0; i < n; i += tstride) {
       const int smp = (int)(i / A.B);
       const int64_t b = i - (int64_t)smp * A.B;
       float zs[L];
+      if constexpr (L % 4 == 0) {
+        dof_ld_row<L>(A.zs + i * L, zs);
+      } else {
 #pragma unroll
-      for (int d = 0; d < L; ++d) {
-        const float sc = fminf(fmaxf(A.sv[(int64_t)d * A.Bp + b], -4.0f), 2.0f);
-        zs[d] = fmaf(A.eps_mc[((int64_t)smp * A.B + b) * L + d], expf(0.5f * sc), A.mu[(int64_t)d * A.Bp + b]);
+        for (int d = 0; d < L; ++d) zs[d] = A.zs[i * L + d];
       }
-      const float r = expf(lp + gmm_logp_c<L>(zs, A.gmm_means, A.gmm_log_vars, lo, hi, c) - A.lse[(int64_t)smp * A.Bp + b]);
+      float q = 0.0f, df[L];
 #pragma unroll
       for (int d = 0; d < L; ++d) {
-        const float lv = fminf(fmaxf(lvraw[d], lo), hi);
-        const float df = zs[d] - m[d];
-        const float iv = expf(-lv);
-        // loss has -log p: gradient = -ksc * r * d(log N)/d(param)
-        vals[d] = fmaf(-ksc * r, df * iv, vals[d]);
-        if (lvraw[d] >= lo && lvraw[d] <= hi) vals[L + d] = fmaf(-ksc * r, 0.5f * (df * df * iv - 1.0f), vals[L + d]);
+        df[d] = zs[d] - m[d];
+        q = fmaf(df[d] * df[d], iv[d], q);
+      }
+      // responsibility of component c for this sample; the loss has -log p: gradient = -ksc * r * d(log N)/d(param)
+      const float w = -ksc * expf(fmaf(-0.5f, q, cst) - A.lse[(int64_t)smp * A.Bp + b]);
+#pragma unroll
+      for (int d = 0; d < L; ++d) {
+        vals[d] = fmaf(w, df[d] * iv[d], vals[d]);
+        if (free_lv[d]) vals[L + d] = fmaf(w, 0.5f * (df[d] * df[d] * iv[d] - 1.0f), vals[L + d]);
       }
     }
   }
   __shared__ float out[2 * L];
   dof_block_colsum<2 * L>(vals, out);
   __syncthreads();
-  float* __restrict__ dst = A.partial + (int64_t)blockIdx.y * 2 * A.K * L;
+  float* dst = A.partial + (int64_t)blockIdx.y * 2 * A.K * L;
   if (threadIdx.x < L) dst[c * L + threadIdx.x] = out[threadIdx.x];
   else if (threadIdx.x < 2 * L) dst[A.K * L + c * L + threadIdx.x - L] = out[threadIdx.x];
-}
-
-// generic per-block sums of a [n][Bp]-strided SoA scalar field (used for the MC-KL term)
-__global__ void __launch_bounds__(256) k_block_sum(const float* __restrict__ x, int rows, int64_t B, int64_t Bp,
-                                                   float* __restrict__ partial) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float v[1] = {0.0f};
-  if (i < (int64_t)rows * B) {
-    const int r = (int)(i / B);
-    v[0] = x[(int64_t)r * Bp + (i - (int64_t)r * B)];
-  }
-  dof_block_colsum<1>(v, partial + blockIdx.x);
 }
 
 }  // namespace

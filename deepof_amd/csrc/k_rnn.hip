@@ -730,26 +730,40 @@ __global__ void __launch_bounds__(256) k_gru16_bwd_fused(
   }
 }
 
-// grads of one direction of a (16,16) GRU layer from the per-workgroup partials; block = one output value
+// grads of a (16,16) GRU layer from the per-workgroup partials [dir][nblk][GRU16_WG_FLOATS].  Workgroup = 8
+// neighbouring values x 32 row slices: lane (slice, value) adds rows slice, slice + 32, ... (four running sums), so a
+// wave-wide load touches 8 rows x 32 contiguous bytes; the 32 slice sums of a value are added in slice order through
+// LDS.  (First form: one workgroup per value with lanes striding over the rows -- 2.9 M scattered dword loads, 64
+// cache lines per load instruction, 18 us at 14,336 sequences.  A two-stage form with a last-workgroup ticket was
+// measured at 55 us: the device-scope fences write back an L2 full of the backward kernel's output.)
+constexpr int kWgVals = 8;
+static_assert(GRU16_WG_FLOATS % kWgVals == 0, "value groups");
 __global__ void __launch_bounds__(256) k_gru16_wg_finalize(const float* __restrict__ wg_partial, int nblk,
                                                            float* __restrict__ g_wih0, float* __restrict__ g_whh0,
                                                            float* __restrict__ g_bih0, float* __restrict__ g_bhh0,
                                                            float* __restrict__ g_wih1, float* __restrict__ g_whh1,
                                                            float* __restrict__ g_bih1, float* __restrict__ g_bhh1,
                                                            int accumulate) {
-  __shared__ float red[256];
-  const int v = blockIdx.x, dir = blockIdx.y;
-  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU16_WG_FLOATS + v;
-  float acc = 0.0f;
-  for (int b = threadIdx.x; b < nblk; b += 256) acc += p[(int64_t)b * GRU16_WG_FLOATS];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-    __syncthreads();
+  __shared__ float red[32][kWgVals + 1];
+  const int dir = blockIdx.y;
+  const int vi = (int)threadIdx.x & (kWgVals - 1), slice = (int)threadIdx.x / kWgVals;
+  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU16_WG_FLOATS + blockIdx.x * kWgVals + vi;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int r = slice;
+  for (; r + 96 < nblk; r += 128) {
+    a0 += p[(int64_t)r * GRU16_WG_FLOATS];
+    a1 += p[(int64_t)(r + 32) * GRU16_WG_FLOATS];
+    a2 += p[(int64_t)(r + 64) * GRU16_WG_FLOATS];
+    a3 += p[(int64_t)(r + 96) * GRU16_WG_FLOATS];
   }
-  if (threadIdx.x != 0) return;
-  const float val = red[0];
+  for (; r < nblk; r += 32) a0 += p[(int64_t)r * GRU16_WG_FLOATS];
+  red[slice][vi] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x >= kWgVals) return;
+  float val = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) val += red[k][vi];
+  const int v = blockIdx.x * kWgVals + vi;
   float* g_wih = dir ? g_wih1 : g_wih0;
   float* g_whh = dir ? g_whh1 : g_whh0;
   float* g_bih = dir ? g_bih1 : g_bih0;
@@ -1146,8 +1160,9 @@ int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const 
 // g: gradient buffer base; off[8]: offsets of (wih, whh, bih, bhh) x (fwd, reverse) as in the parameter layout
 int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
                                  hipStream_t st) {
-  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)GRU16_WG_FLOATS, 2), (256), st, wg_partial, (int)dof_cdiv(S, 16),
-             g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6], g + off[7], accumulate);
+  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)(GRU16_WG_FLOATS / kWgVals), 2), (256), st, wg_partial,
+             (int)dof_cdiv(S, 16), g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6],
+             g + off[7], accumulate);
   return dof_check_launch("k_gru16_wg_finalize");
 }
 

@@ -178,7 +178,7 @@ struct DofVadePlan {
   StreamWs sw[2];
   int64_t flat, enc, mu, pre, sv, z, q, qn, dlogit, dmu_dpre, denc, dflat;
   int64_t gram, Pm, km, stats, dqbar, dcen, dscat, dlogp2, tf_partial, scal;
-  int64_t mterm, mlse, mdz, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
+  int64_t mlse, mzs, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   bool tail_wide = false;
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
@@ -718,18 +718,17 @@ void take_latent_buffers(DofVadePlan* p, Carver& cv) {
   p->dqbar = cv.take(K);
   p->dcen = cv.take((int64_t)K * L);
   p->scal = cv.take(8);
-  p->mterm = cv.take((int64_t)S * Bp);
   p->mlse = cv.take((int64_t)S * Bp);
-  p->mdz = cv.take((int64_t)S * L * Bp);
+  p->mzs = cv.take((int64_t)S * L * Bp);
   p->mgsum = cv.take(2LL * L * Bp);
   p->gmmp = cv.take(16LL * 2 * K * L);
-  p->mckl_blocks = dof_cdiv((int64_t)S * p->B, 256);
+  p->mckl_blocks = dof_cdiv(p->B, kMcklWindows);
   // recurrent family, latent 8: the lane-per-channel decoder tail (16 rows per workgroup); else one row per thread
   p->tail_wide = !p->tcn && !p->tfm && L == 8 && p->C3 <= 96;
   p->tail_blocks = dof_cdiv((int64_t)T * p->B, p->tail_wide ? 64 : 256);
   p->mckl_partial = cv.take(p->mckl_blocks);
-  p->distill_partial = cv.take(p->lat_blocks);
-  p->tf_partial = cv.take(p->lat_blocks);
+  p->distill_partial = cv.take(dof_cdiv(p->B, kLatRows));  // k_latent_bwd_w: 16 windows per workgroup
+  p->tf_partial = cv.take(dof_cdiv(p->B, kLatRows));
   p->recon_partial = cv.take(p->tail_blocks);
   p->recon_partial2 = cv.take(p->tail_blocks);
   p->vq_idx = cv.take(Bp);
@@ -1323,8 +1322,9 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
                    float* q_out, float* mu_out, float* sv_out, float* enc_out, hipStream_t st) {
   float* ws = p->ws;
   LatentFwdArgs A;
-  TRY(final_dense_fwd(p, params, st));
-  A.flat = ws + p->flat; A.J = p->J;
+  const bool rows = p->K <= 32;  // components across lanes; encoder.final_dense evaluated in the same launch
+  if (!rows) TRY(final_dense_fwd(p, params, st));
+  A.flat = (rows && !p->tcn && !p->tfm) ? ws + p->flat : nullptr; A.J = p->J;
   A.wf = params + p->fd_w; A.bf = params + p->fd_b; A.wm = params + p->mean_w; A.bm = params + p->mean_b;
   A.ws = params + p->lv_w; A.bs = params + p->lv_b;
   A.gmm_means = params + p->gmm_m; A.gmm_log_vars = params + p->gmm_lv; A.prior = prior; A.eps = eps;
@@ -1332,7 +1332,13 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
   A.q = ws + p->q; A.qn = ws + p->qn;
   A.z_out = z_out; A.q_out = q_out; A.mu_out = mu_out; A.sv_out = sv_out; A.enc_out = enc_out;
   A.K = p->K; A.B = p->B; A.Bp = p->Bp;
-  LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd<LL>), (dof_cdiv(p->B, 256)), (256), st, A));
+  if (!rows) {
+    LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd<LL>), (dof_cdiv(p->B, 256)), (256), st, A));
+  } else if (p->K <= 16) {
+    LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd_w<LL, 1>), (dof_cdiv(p->B, kLatRows)), (256), st, A));
+  } else {
+    LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd_w<LL, 2>), (dof_cdiv(p->B, kLatRows)), (256), st, A));
+  }
   return dof_check_launch("k_latent_fwd");
 }
 
@@ -1917,19 +1923,15 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   StatsArgs SA;
   SA.qn = ws + p->qn; SA.z = ws + p->z; SA.mu = ws + p->mu; SA.sv = ws + p->sv; SA.tau = tau;
   SA.class_weight = teacher; SA.hyper = hyper; SA.stats = ws + p->stats; SA.K = K; SA.B = B; SA.Bp = Bp;
-  LDISPATCH(L, DOF_LAUNCH((k_batch_stats<LL>), ((unsigned)(K + 1)), (256), st, SA));
+  LDISPATCH(L, DOF_LAUNCH((k_batch_stats<LL>), ((unsigned)(K + 3)), (256), st, SA));
   TRY(dof_check_launch("k_batch_stats"));
   if (!pretrain) {
     McklArgs MA;
     MA.mu = ws + p->mu; MA.sv = ws + p->sv; MA.eps_mc = eps_mc; MA.gmm_means = params + p->gmm_m;
-    MA.gmm_log_vars = params + p->gmm_lv; MA.prior = prior; MA.hyper = hyper; MA.term = ws + p->mterm;
-    MA.lse = ws + p->mlse; MA.dz = ws + p->mdz; MA.K = K; MA.S = p->S; MA.B = B; MA.Bp = Bp;
-    LDISPATCH(L, DOF_LAUNCH((k_mckl_fwd<LL>), ((unsigned)p->mckl_blocks), (256), st, MA));
-    TRY(dof_check_launch("k_mckl_fwd"));
-    DOF_LAUNCH(k_block_sum, ((unsigned)p->mckl_blocks), (256), st, (const float*)(ws + p->mterm), p->S, B, Bp, ws + p->mckl_partial);
-    DOF_LAUNCH(k_mckl_reduce, (dof_cdiv(B, 256), (unsigned)L), (256), st, (const float*)(ws + p->mdz), eps_mc,
-               ws + p->mgsum, p->S, L, B, Bp);
-    TRY(dof_check_launch("k_block_sum"));
+    MA.gmm_log_vars = params + p->gmm_lv; MA.prior = prior; MA.hyper = hyper; MA.partial = ws + p->mckl_partial;
+    MA.lse = ws + p->mlse; MA.zs = ws + p->mzs; MA.gsum = ws + p->mgsum; MA.K = K; MA.S = p->S; MA.B = B; MA.Bp = Bp;
+    LDISPATCH(L, DOF_LAUNCH((k_mckl<LL>), ((unsigned)p->mckl_blocks), (256), st, MA));
+    TRY(dof_check_launch("k_mckl"));
   }
   LossMidArgs LM;
   LM.stats = ws + p->stats; LM.recon_partial = ws + p->recon_partial; LM.n_recon = (int)p->tail_blocks;
@@ -1951,14 +1953,27 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   LB.dmu_dpre = ws + p->dmu_dpre; LB.denc = ws + p->denc; LB.dlogit = ws + p->dlogit; LB.dflat = ws + p->dflat;
   LB.distill_partial = ws + p->distill_partial; LB.J = p->J; LB.K = K; LB.S = p->S; LB.pretrain = pretrain ? 1 : 0;
   LB.B = B; LB.Bp = Bp;
-  LDISPATCH(L, DOF_LAUNCH((k_latent_bwd<LL>), ((unsigned)p->lat_blocks), (256), st, LB));
-  TRY(dof_check_launch("k_latent_bwd"));
-  TRY(final_dense_bwd(p, params, st));
+  int n_lat_partial;
+  if (K <= 32) {  // components across lanes (16 windows per workgroup), final_dense's data gradient included
+    if (p->tcn || p->tfm) LB.dflat = nullptr;
+    n_lat_partial = (int)dof_cdiv(B, kLatRows);
+    if (K <= 16) {
+      LDISPATCH(L, DOF_LAUNCH((k_latent_bwd_w<LL, 1>), ((unsigned)n_lat_partial), (256), st, LB));
+    } else {
+      LDISPATCH(L, DOF_LAUNCH((k_latent_bwd_w<LL, 2>), ((unsigned)n_lat_partial), (256), st, LB));
+    }
+    TRY(dof_check_launch("k_latent_bwd_w"));
+  } else {
+    n_lat_partial = (int)p->lat_blocks;
+    LDISPATCH(L, DOF_LAUNCH((k_latent_bwd<LL>), ((unsigned)p->lat_blocks), (256), st, LB));
+    TRY(dof_check_launch("k_latent_bwd"));
+    TRY(final_dense_bwd(p, params, st));
+  }
   DOF_LAUNCH(k_loss_total, (1), (64), st, (const float*)(ws + p->distill_partial), (const float*)(ws + p->tf_partial),
-             (int)p->lat_blocks, hyper, B, pretrain ? 1 : 0, logs);
+             n_lat_partial, hyper, B, pretrain ? 1 : 0, logs);
   TRY(dof_check_launch("k_loss_total"));
   GmmGradArgs GG;
-  GG.z = ws + p->z; GG.dlogit = ws + p->dlogit; GG.dlogp2 = ws + p->dlogp2; GG.mu = ws + p->mu; GG.sv = ws + p->sv; GG.eps_mc = eps_mc;
+  GG.z = ws + p->z; GG.dlogit = ws + p->dlogit; GG.dlogp2 = ws + p->dlogp2; GG.zs = ws + p->mzs;
   GG.lse = ws + p->mlse; GG.gmm_means = params + p->gmm_m; GG.gmm_log_vars = params + p->gmm_lv; GG.prior = prior;
   GG.scal = ws + p->scal; GG.hyper = hyper; GG.partial = ws + p->gmmp;
   GG.K = K; GG.S = p->S; GG.pretrain = pretrain ? 1 : 0; GG.B = B; GG.Bp = Bp;

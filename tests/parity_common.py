@@ -752,6 +752,58 @@ def run_distill_head_check(lib, device, golden_dir):
     assert n >= 42
 
 
+def run_vade_rec_vs_oracle(lib, device, K, L=8, B=21, T=9, S=5, seed=11):
+    """Recurrent VaDE, main phase with the teacher and every optional regulariser switched on, at component counts the
+    goldens do not have (K = 25: two components per lane of the row kernels; K = 40: the one-thread-per-window
+    kernels) and a batch that is not a multiple of 16: logged loss terms and all gradients vs autograd of the oracle."""
+    from oracle import vade as OV
+    adj = np.zeros((5, 5), np.float32)
+    for i, j in ((0, 1), (1, 2), (2, 3), (3, 4), (1, 3)):
+        adj[i, j] = adj[j, i] = 1.0
+    E = 5
+    eng = VadeEngine(lib, device, B, T, adj, L, K, mc_samples=S)
+    g = torch.Generator().manual_seed(seed)
+    P = eng.state_dict()
+    for n, v in P.items():
+        if v.dtype.is_floating_point and n.split(".")[-1] not in ("laplacian", "edge_laplacian", "incidence", "prior", "pretrain"):
+            P[n] = torch.randn(v.shape, generator=g) * (0.3 if v.dim() > 1 else 0.05)
+    P["latent_space.gmm_means"] = torch.randn(K, L, generator=g) * 0.7
+    P["latent_space.gmm_log_vars"] = torch.randn(K, L, generator=g) * 0.5
+    P["latent_space.prior"] = torch.softmax(torch.randn(K, generator=g), 0)
+    eng.load_state_dict(P)
+    P = eng.state_dict()
+    x = torch.randn(B, T, 5, 3, generator=g).cumsum(1) * 0.3
+    a = torch.randn(B, T, E, 1, generator=g)
+    eps = torch.randn(B, L, generator=g)
+    eps_mc = torch.randn(S, B, L, generator=g)
+    tau = torch.softmax(torch.randn(B, K, generator=g) * 2, dim=-1)
+    extra = PHASES["mainX"]["extra"]
+    klw, lam = 0.45, 1.7
+    configure_phase(eng, K, False, klw, tau, lam, extra)
+    dev = lambda t: t.to(device)
+    eng.loss_grads(dev(x), dev(a), dev(eps), dev(eps_mc), dev(tau), pretrain=False)
+    pi = tau.mean(dim=0).clamp_min(1e-8)
+    w = pi.pow(-1.0)
+    cfg = OV.VadeLossCfg(K, False, lambda_distill=lam, class_weight=(w / w.mean()).clamp_max(3.0), teacher_marginal=pi,
+                         repel_weight=extra["repel_w"], repel_length_scale=extra["repel_ls"],
+                         reg_scatter_weight=extra["scatter_w"], reg_scatter_beta=extra["scatter_beta"],
+                         temporal_cohesion_weight=extra["temporal_w"], reg_cat_clusters=extra["cat_w"],
+                         tf_cluster_weight=extra["tf_w"], kmeans_loss_weight=extra["km_loss"],
+                         distill_conf_weight=True, distill_conf_thresh=extra["conf_thr"])
+    ref, grads, _ = OV.vade_grads(P, x, a, cfg, klw, eps, eps_mc, tau)
+    logs = eng.read_logs()
+    for k, v in ref.items():
+        np.testing.assert_allclose(logs[k], float(v.detach()), rtol=2e-4, atol=2e-5, err_msg=k)
+    checked = 0
+    for name, gr in grads.items():
+        if gr is None:
+            continue
+        got = eng.view(name, eng.grads).cpu().numpy()
+        np.testing.assert_allclose(got, gr.numpy().reshape(got.shape), atol=5e-5, rtol=5e-4, err_msg=name)
+        checked += 1
+    assert checked >= 75, checked
+
+
 def run_vade_tcn_vs_oracle(lib, device, L=4, K=3, B=6, T=10, seed=3):
     """VaDE-TCN at a latent size whose decoder input (4L channels) needs the zero-padded MFMA operand path
     (4L < 32): eval forward and train-step gradients vs the CPU oracle, fp64-anchored as in run_vade_tcn_check."""

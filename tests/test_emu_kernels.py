@@ -35,6 +35,12 @@ def test_vade_loss_grads_emu(golden_dir, tag, phase):
     run_phase_check(emu_lib(), "cpu", golden_dir, tag, phase)
 
 
+@pytest.mark.parametrize("K", [25, 40])
+def test_vade_many_components_emu(K):
+    from parity_common import run_vade_rec_vs_oracle
+    run_vade_rec_vs_oracle(emu_lib(), "cpu", K)
+
+
 def test_vade_train_trace_emu(golden_dir):
     run_trace_check(emu_lib(), "cpu", golden_dir)
 
