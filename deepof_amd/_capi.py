@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -44,6 +44,13 @@ class SchedItem(C.Structure):
 
 
 SCHED_MAX_ITEMS = 4
+
+
+class NoiseBuf(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("n", C.c_int64)]
+
+
+NOISE_MAX_BUFS = 2
 
 
 class TurtleDims(C.Structure):
@@ -107,6 +114,8 @@ SIGNATURES = {
     "dof_vqvae_loss_grads": (C.c_int, [_P] * 9),
     "dof_optimizer_step": (C.c_int, [_P] * 7 + [C.c_float, _P]),
     "dof_schedule_apply": (C.c_int, [_P, C.POINTER(SchedItem), _I32, _P]),
+    "dof_step_begin": (C.c_int, [_P, C.POINTER(SchedItem), _I32, C.c_uint64, _P, C.POINTER(NoiseBuf), _I32, _P]),
+    "dof_vade_set_log_accumulator": (C.c_int, [_P, _P]),
     "dof_turtle_param_total": (_I64, [C.POINTER(TurtleDims)]),
     "dof_turtle_param_offset": (_I64, [C.POINTER(TurtleDims), _I32, _I32, _I32]),
     "dof_turtle_workspace_bytes": (_I64, [C.POINTER(TurtleDims)]),

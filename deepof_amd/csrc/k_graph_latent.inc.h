@@ -946,16 +946,21 @@ __global__ void k_loss_mid(LossMidArgs A) {
 }
 
 __global__ void k_loss_total(const float* __restrict__ distill_partial, const float* __restrict__ tf_partial, int n,
-                             const float* __restrict__ hyper, int64_t B, int pretrain, float* __restrict__ logs) {
-  // launched as one wavefront
+                             const float* __restrict__ hyper, int64_t B, int pretrain, float* __restrict__ logs,
+                             double* __restrict__ accum) {
+  // launched as one wavefront; lane i owns logs[i] (and its running fp64 sum when the caller keeps one)
   const float s = dof_wave_sum_array(distill_partial, n);
   const float t = dof_wave_sum_array(tf_partial, n);
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int i = (int)threadIdx.x;
+  if (i >= DOF_LOG_COUNT || blockIdx.x != 0) return;
   const float d = hyper[DOF_H_LAMBDA_DISTILL] * s / (float)B;
   const float tf = pretrain ? 0.0f : -hyper[DOF_H_TF_W] * t / (float)B;
-  logs[DOF_LOG_DISTILL] = d;
-  logs[DOF_LOG_TFCLUST] = tf;
-  logs[DOF_LOG_TOTAL] += d + tf;
+  float v = logs[i];
+  if (i == DOF_LOG_DISTILL) v = d;
+  if (i == DOF_LOG_TFCLUST) v = tf;
+  if (i == DOF_LOG_TOTAL) v += d + tf;
+  if (i == DOF_LOG_DISTILL || i == DOF_LOG_TFCLUST || i == DOF_LOG_TOTAL) logs[i] = v;
+  if (accum) accum[i] += (double)v;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -205,51 +205,139 @@ __global__ void __launch_bounds__(256) k_sum_partials_multi(DofSumJobs J, int ac
   if (threadIdx.x == 0) J.out[j][v] = accumulate ? J.out[j][v] + red[0] : red[0];
 }
 
-// One thread per optimiser segment: a segment that receives gradients this step (hyper[active] != 0) advances its
-// device-side step counter; the Adam bias corrections 1 - beta^t of every segment (t >= 1) go to bc[2 * seg + {0, 1}]
-// for the k_clip_adam launch that follows on the same stream.  Keeping t on the device makes a captured step
-// replayable without any host-written per-step value (torch.optim.Adam keeps `step` per parameter the same way).
-__global__ void k_adam_tick(int* __restrict__ opt_state, const float* __restrict__ hyper,
-                            const DofAdamSeg* __restrict__ segs, int nseg, float* __restrict__ bc) {
-  const int k = threadIdx.x;
-  if (k >= nseg) return;
-  int t = opt_state[k];
-  if (hyper[segs[k].active_index] != 0.0f) opt_state[k] = ++t;
-  if (t < 1) t = 1;
-  bc[2 * k] = (float)(1.0 - pow(0.9, (double)t));
-  bc[2 * k + 1] = (float)(1.0 - pow(0.999, (double)t));
-}
-
+// clip_grad_value_ + Adam on the flat buffer.  The Adam step count t of every optimiser segment lives on the device
+// (opt_state, torch.optim.Adam keeps `step` per parameter the same way), which makes a captured step replayable
+// without any host-written per-step value: a segment that receives gradients this step (hyper[active] != 0)
+// updates with t + 1; every workgroup derives the bias corrections 1 - beta^(t+1) of the <= 8 segments itself
+// (double pow on one lane per segment, through LDS), and the LAST workgroup to finish -- elected by an integer
+// ticket, after every workgroup has read the counters -- stores the advanced counters.  (Was a separate one-wave
+// k_adam_tick launch in front of this kernel.)
+constexpr int kMaxAdamSegs = 8;
 __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ params, const float* __restrict__ grads,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ hyper,
                                                    const DofAdamSeg* __restrict__ segs, int nseg, int64_t total,
                                                    int clip_index, const float* __restrict__ mask,
-                                                   const float* __restrict__ bc, float grad_scale) {
+                                                   int* opt_state, int* ticket, float grad_scale) {
+  __shared__ float s_bc[2 * kMaxAdamSegs];
+  __shared__ int s_t[kMaxAdamSegs];
+  __shared__ int s_last;
+  if ((int)threadIdx.x < nseg) {
+    const int k = threadIdx.x;
+    int t = opt_state[k];
+    if (hyper[segs[k].active_index] != 0.0f) ++t;
+    s_t[k] = t;
+    if (t < 1) t = 1;
+    s_bc[2 * k] = (float)(1.0 - pow(0.9, (double)t));
+    s_bc[2 * k + 1] = (float)(1.0 - pow(0.999, (double)t));
+  }
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  if (mask[i] == 0.0f) return;  // parameter never receives a gradient in the reference (grad None): untouched
   int sg = -1;
-  for (int k = 0; k < nseg; ++k)
-    if (i >= segs[k].lo && i < segs[k].hi) sg = k;
-  if (sg < 0) return;
-  const DofAdamSeg S = segs[sg];
-  if (hyper[S.active_index] == 0.0f) return;  // grad is None in the reference -> parameter skipped
-  const float clip = hyper[clip_index];
-  const float wd = hyper[clip_index + 1];
-  float g = grads[i] * grad_scale;  // data parallel: the all-reduced SUM times 1 / world = DDP's averaged gradient
-  if (clip > 0.0f) g = fminf(fmaxf(g, -clip), clip);
-  float p = params[i];
-  if (wd != 0.0f) g = fmaf(wd, p, g);
-  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-  const float mi = fmaf(b1, m[i], (1.0f - b1) * g);
-  const float vi = fmaf(b2, v[i], (1.0f - b2) * g * g);
-  m[i] = mi;
-  v[i] = vi;
-  const float lr = hyper[S.lr_index];
-  const float bc1 = bc[2 * sg], bc2 = bc[2 * sg + 1];
-  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-  params[i] = p - (lr / bc1) * (mi / denom);
+  if (i < total && mask[i] != 0.0f) {  // mask 0: the parameter never receives a gradient in the reference (grad None)
+    for (int k = 0; k < nseg; ++k)
+      if (i >= segs[k].lo && i < segs[k].hi) sg = k;
+  }
+  if (sg >= 0) {
+    const DofAdamSeg S = segs[sg];
+    if (hyper[S.active_index] != 0.0f) {  // (0: grad is None in the reference -> parameter skipped)
+      const float clip = hyper[clip_index];
+      const float wd = hyper[clip_index + 1];
+      float g = grads[i] * grad_scale;  // data parallel: the all-reduced SUM times 1 / world = DDP's averaged gradient
+      if (clip > 0.0f) g = fminf(fmaxf(g, -clip), clip);
+      float p = params[i];
+      if (wd != 0.0f) g = fmaf(wd, p, g);
+      const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+      const float mi = fmaf(b1, m[i], (1.0f - b1) * g);
+      const float vi = fmaf(b2, v[i], (1.0f - b2) * g * g);
+      m[i] = mi;
+      v[i] = vi;
+      const float lr = hyper[S.lr_index];
+      const float bc1 = s_bc[2 * sg], bc2 = s_bc[2 * sg + 1];
+      const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+      params[i] = p - (lr / bc1) * (mi / denom);
+    }
+  }
+  // every workgroup has consumed opt_state by now (s_t went through the barrier above); the last ticket holder
+  // publishes the new counters.  No data travels between workgroups, so the ticket needs no fence.
+  if (threadIdx.x == 0) {
+    const int tk = atomicAdd(ticket, 1);
+    s_last = tk == (int)gridDim.x - 1;
+    if (s_last) *ticket = 0;
+  }
+  __syncthreads();
+  if (s_last && (int)threadIdx.x < nseg) opt_state[threadIdx.x] = s_t[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Head of a captured step: schedule items + the step's Gaussian noise in one launch.
+// Philox-4x32-10 (Salmon, Moraes, Dror, Shaw 2011): counter (quad index, buffer, step, 0), key = seed; the four
+// 32-bit outputs become four N(0,1) values by Box-Muller on 24-bit uniforms in (0, 1).  The step index is a
+// device counter read by every workgroup and advanced by the last one to finish (same ticket as k_clip_adam).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dof_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                  uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void __launch_bounds__(256) k_step_begin(float* __restrict__ hyper, DofSchedItems items, DofNoiseArgs N) {
+  __shared__ int s_last;
+  const uint32_t step = N.state ? (uint32_t)N.state[0] : 0u;
+  if (blockIdx.x == 0 && (int)threadIdx.x < items.n) {
+    const DofSchedItem it = items.item[threadIdx.x];
+    int c = *it.cursor;
+    const int at = c < it.len - 1 ? c : it.len - 1;
+    hyper[it.hyper_index] = it.scale * it.table[at < 0 ? 0 : at];
+    if (it.advance) *it.cursor = c + 1;
+  }
+  if (!N.state) return;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int buf = gid >= N.quads0 ? 1 : 0;
+  const int64_t q = buf ? gid - N.quads0 : gid;
+  if (4 * q < N.n[buf]) {
+    uint32_t r[4];
+    dof_philox4x32_10((uint32_t)q, (uint32_t)buf, step, 0u, N.key0, N.key1, r);
+    float g[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * 5.9604644775390625e-8f;      // 2^-24
+      const float u2 = ((float)(r[2 * h + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+      const float rad = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      g[2 * h] = rad * cs;
+      g[2 * h + 1] = rad * sn;
+    }
+    float* __restrict__ o = N.out[buf] + 4 * q;
+    const int64_t left = N.n[buf] - 4 * q;
+    if (left >= 4 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+      *reinterpret_cast<float4*>(o) = make_float4(g[0], g[1], g[2], g[3]);
+    } else {
+      for (int k = 0; k < 4 && k < left; ++k) o[k] = g[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tk = atomicAdd(N.state + 1, 1);
+    s_last = tk == (int)gridDim.x - 1;
+    if (s_last) {
+      N.state[1] = 0;
+      N.state[0] = (int)(step + 1u);
+    }
+  }
 }
 
 // hyper[item.hyper_index] = scale * table[min(cursor, len - 1)]; cursor advances when item.advance (one thread per
@@ -295,11 +383,22 @@ int dof_launch_sum_partials_multi(const DofSumJobs& jobs, int accumulate, hipStr
 
 int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,
                          const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, const float* mask,
-                         int* opt_state, float* bc_scratch, float grad_scale, hipStream_t st) {
-  DOF_LAUNCH(k_adam_tick, (1), (64), st, opt_state, hyper, segs_dev, nseg, bc_scratch);
+                         int* opt_state, int* ticket, float grad_scale, hipStream_t st) {
+  if (nseg > kMaxAdamSegs) {
+    dof_set_error("k_clip_adam: %d optimiser segments, at most %d", nseg, kMaxAdamSegs);
+    return DOF_ERR_ARG;
+  }
   DOF_LAUNCH(k_clip_adam, (dof_cdiv(total, 256)), (256), st, params, grads, m, v, hyper, segs_dev, nseg, total,
-             clip_index, mask, (const float*)bc_scratch, grad_scale);
+             clip_index, mask, opt_state, ticket, grad_scale);
   return dof_check_launch("k_clip_adam");
+}
+
+int dof_launch_step_begin(float* hyper, const DofSchedItems& items, const DofNoiseArgs& noise, hipStream_t st) {
+  int64_t quads = 0;
+  if (noise.state) quads = (noise.n[0] + 3) / 4 + (noise.n[1] + 3) / 4;
+  const unsigned nb = quads > 0 ? dof_cdiv(quads, 256) : 1u;
+  DOF_LAUNCH(k_step_begin, (nb), (256), st, hyper, items, noise);
+  return dof_check_launch("k_step_begin");
 }
 
 int dof_launch_schedule_apply(float* hyper, const DofSchedItems& items, hipStream_t st) {

@@ -226,11 +226,19 @@ struct DofAdamSeg {  // one contiguous parameter range with its own lr / step co
 };
 int dof_launch_clip_adam(float* params, const float* grads, float* m, float* v, const float* hyper,
                          const DofAdamSeg* segs_dev, int nseg, int64_t total, int clip_index, const float* mask,
-                         int* opt_state, float* bc_scratch, float grad_scale, hipStream_t st);
+                         int* opt_state, int* ticket, float grad_scale, hipStream_t st);
 struct DofSchedItems {  // by-value kernel argument of k_schedule_apply
   int n;
   DofSchedItem item[DOF_SCHED_MAX_ITEMS];
 };
+struct DofNoiseArgs {  // by-value kernel argument of k_step_begin
+  float* out[2];
+  int64_t n[2];
+  int64_t quads0;  // ceil(n[0] / 4): Philox calls of buffer 0
+  uint32_t key0, key1;
+  int* state;      // device int32[2]: step counter, ticket; null = no noise
+};
+int dof_launch_step_begin(float* hyper, const DofSchedItems& items, const DofNoiseArgs& noise, hipStream_t st);
 int dof_launch_schedule_apply(float* hyper, const DofSchedItems& items, hipStream_t st);
 
 // ---- k_graph_latent.hip ----------------------------------------------------------------------

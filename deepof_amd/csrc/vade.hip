@@ -184,6 +184,7 @@ struct DofVadePlan {
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
   int64_t partials, segs_tab, mask_tab, bc_tab;
+  double* log_accum = nullptr;  // dof_vade_set_log_accumulator
   int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
   // TCN family (encoder: all kinds; decoder: kinds 0 / 1)
@@ -1970,7 +1971,7 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
     TRY(final_dense_bwd(p, params, st));
   }
   DOF_LAUNCH(k_loss_total, (1), (64), st, (const float*)(ws + p->distill_partial), (const float*)(ws + p->tf_partial),
-             n_lat_partial, hyper, B, pretrain ? 1 : 0, logs);
+             n_lat_partial, hyper, B, pretrain ? 1 : 0, logs, p->log_accum);
   TRY(dof_check_launch("k_loss_total"));
   GmmGradArgs GG;
   GG.z = ws + p->z; GG.dlogit = ws + p->dlogit; GG.dlogp2 = ws + p->dlogp2; GG.zs = ws + p->mzs;
@@ -2095,7 +2096,8 @@ extern "C" int dof_optimizer_step(DofVadePlan* p, float* params, const float* gr
   }
   const DofAdamSeg* segs = reinterpret_cast<const DofAdamSeg*>(p->ws + p->segs_tab);
   return dof_launch_clip_adam(params, grads, adam_m, adam_v, hyper, segs, DOF_SEG_COUNT, p->param_total, DOF_H_CLIP,
-                              p->ws + p->mask_tab, opt_state, p->ws + p->bc_tab, grad_scale, (hipStream_t)stream);
+                              p->ws + p->mask_tab, opt_state, reinterpret_cast<int*>(p->ws + p->bc_tab), grad_scale,
+                              (hipStream_t)stream);
 }
 
 extern "C" int dof_schedule_apply(float* hyper, const DofSchedItem* items, int32_t n_items, void* stream) {
@@ -2116,6 +2118,52 @@ extern "C" int dof_schedule_apply(float* hyper, const DofSchedItem* items, int32
   }
   if (n_items == 0) return DOF_OK;
   return dof_launch_schedule_apply(hyper, its, (hipStream_t)stream);
+}
+
+extern "C" int dof_step_begin(float* hyper, const DofSchedItem* items, int32_t n_items, uint64_t seed,
+                              int32_t* rng_state, const DofNoiseBuf* bufs, int32_t n_bufs, void* stream) {
+  if (!hyper || (n_items > 0 && !items) || n_items < 0 || n_items > DOF_SCHED_MAX_ITEMS || n_bufs < 0 ||
+      n_bufs > DOF_NOISE_MAX_BUFS || (n_bufs > 0 && (!bufs || !rng_state))) {
+    dof_set_error("dof_step_begin: bad arguments (n_items %d of at most %d, n_bufs %d of at most %d)", n_items,
+                  DOF_SCHED_MAX_ITEMS, n_bufs, DOF_NOISE_MAX_BUFS);
+    return DOF_ERR_ARG;
+  }
+  DofSchedItems its;
+  memset(&its, 0, sizeof(its));
+  its.n = n_items;
+  for (int i = 0; i < n_items; ++i) {
+    if (!items[i].table || !items[i].cursor || items[i].len <= 0 || items[i].hyper_index < 0 ||
+        items[i].hyper_index >= DOF_H_COUNT) {
+      dof_set_error("dof_step_begin: item %d has a null table / cursor, no entries or a bad hyper index", i);
+      return DOF_ERR_ARG;
+    }
+    its.item[i] = items[i];
+  }
+  DofNoiseArgs N;
+  memset(&N, 0, sizeof(N));
+  for (int i = 0; i < n_bufs; ++i) {
+    if (!bufs[i].out || bufs[i].n <= 0 || bufs[i].n > (1LL << 33)) {
+      dof_set_error("dof_step_begin: noise buffer %d is null or has a bad length", i);
+      return DOF_ERR_ARG;
+    }
+    N.out[i] = bufs[i].out;
+    N.n[i] = bufs[i].n;
+  }
+  N.quads0 = (N.n[0] + 3) / 4;
+  N.key0 = (uint32_t)seed;
+  N.key1 = (uint32_t)(seed >> 32);
+  N.state = n_bufs > 0 ? rng_state : nullptr;
+  if (n_items == 0 && n_bufs == 0) return DOF_OK;
+  return dof_launch_step_begin(hyper, its, N, (hipStream_t)stream);
+}
+
+extern "C" int dof_vade_set_log_accumulator(DofVadePlan* p, double* accum) {
+  if (!p) {
+    dof_set_error("dof_vade_set_log_accumulator: null plan");
+    return DOF_ERR_ARG;
+  }
+  p->log_accum = accum;
+  return DOF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -276,6 +276,30 @@ class VadeEngine:
         _capi.check(self.lib, self.lib.dof_schedule_apply(self.hyper.data_ptr(), arr, len(items), self._stream()),
                     "dof_schedule_apply")
 
+    def step_begin(self, items, noise, seed: int, rng_state: torch.Tensor):
+        """dof_step_begin: the schedule items of ``schedule_apply`` plus N(0,1) fills of the tensors in ``noise`` (at
+        most two, contiguous fp32) in one launch; ``rng_state`` = device int32[2] call counter of this noise stream."""
+        arr = (_capi.SchedItem * max(1, len(items)))()
+        for i, (sched, index, advance, scale) in enumerate(items):
+            arr[i] = _capi.SchedItem(sched.table.data_ptr(), sched.cursor.data_ptr(), int(sched.table.numel()), int(index),
+                                     1 if advance else 0, float(scale))
+        bufs = (_capi.NoiseBuf * max(1, len(noise)))()
+        for i, t in enumerate(noise):
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.device == self.params.device
+            bufs[i] = _capi.NoiseBuf(t.data_ptr(), int(t.numel()))
+        assert rng_state.dtype == torch.int32 and rng_state.numel() == 2
+        _capi.check(self.lib, self.lib.dof_step_begin(self.hyper.data_ptr(), arr, len(items), int(seed) & (2 ** 64 - 1),
+                                                      rng_state.data_ptr(), bufs, len(noise), self._stream()),
+                    "dof_step_begin")
+
+    def set_log_accumulator(self, accum: Optional[torch.Tensor]):
+        """dof_vade_set_log_accumulator: every loss_grads() also adds its logs to ``accum`` (device float64[LOG_COUNT])."""
+        if accum is not None:
+            assert accum.dtype == torch.float64 and accum.numel() == _capi.LOG_COUNT and accum.device == self.params.device
+        self._log_accum = accum  # keeps the tensor alive while the plan points at it
+        _capi.check(self.lib, self.lib.dof_vade_set_log_accumulator(self.plan, None if accum is None else accum.data_ptr()),
+                    "dof_vade_set_log_accumulator")
+
     def configure_vade_phase(self, pretrain: bool, klw: float, tau: Optional[torch.Tensor] = None,
                              lambda_distill: float = 0.0, extra: Optional[dict] = None):
         """The reference's default VadeLoss configuration of one phase (training.py:640-668 signature defaults,

@@ -296,6 +296,11 @@ class VadeStepper:
         # device generator (such steps are launched eagerly)
         self.noise_fn = NOISE_HOOK
         self._noise_count = {"eps_train": 0, "mc_train": 0, "mc_val": 0}
+        # the device noise stream of this stepper (dof_step_begin): seeded from torch's generator, so torch.manual_seed
+        # fixes it; every data-parallel rank draws its own
+        _, rank, _world = _dist_state()
+        self._noise_seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) + 0x9E3779B97F4A7C15 * rank) & (2 ** 64 - 1)
+        self._rng_state = torch.zeros(2, dtype=torch.int32, device=model.device)
         self.set_mode("pretrain")
 
     def set_mode(self, mode: str):
@@ -379,15 +384,18 @@ class VadeStepper:
             if not pretrain:
                 st.eps_mc.copy_(take("mc_train" if train else "mc_val", (eng.S, eng.B, eng.L)))
 
+        if getattr(eng, "_log_accum", None) is not self.log_sum:
+            eng.set_log_accumulator(self.log_sum)  # the loss kernels add every step's terms to log_sum themselves
+
         def forward_backward():
-            eng.schedule_apply(items)  # (no lambda schedule: hyper[lambda_distill] stays at the 0 set_teacher pushed)
+            # (no lambda schedule: hyper[lambda_distill] stays at the 0 set_teacher pushed)
+            eps, eps_mc = (st.eps if train else st.eps_zero), (None if pretrain else st.eps_mc)  # eval: z = mean
             if inject:
-                eps, eps_mc = (st.eps if train else st.eps_zero), (None if pretrain else st.eps_mc)
-            else:
-                eps = st.eps.normal_() if train else st.eps_zero  # eval: z = mean
-                eps_mc = None if pretrain else st.eps_mc.normal_()
+                eng.schedule_apply(items)
+            else:  # schedules + this step's noise in one launch
+                eng.step_begin(items, ([st.eps] if train else []) + ([] if pretrain else [st.eps_mc]),
+                               self._noise_seed, self._rng_state)
             eng.loss_grads(st.x, st.a, eps, eps_mc, st.tau if use_tau else None, pretrain=pretrain, count=False)
-            self.log_sum.add_(eng.logs)
 
         key = (eng.B, pretrain, train, use_tau, kl.uid, getattr(self.lambda_scheduler, "uid", 0), self._teacher_version,
                self.model.training, inject)

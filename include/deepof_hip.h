@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 10
+#define DOF_ABI_VERSION 11
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -315,6 +315,27 @@ typedef struct DofSchedItem {
   float scale;
 } DofSchedItem;
 int dof_schedule_apply(float* hyper, const DofSchedItem* items, int32_t n_items, void* stream);
+
+/* Head of a captured training step in ONE launch: the schedule items of dof_schedule_apply plus the step's Gaussian
+ * noise.  bufs[i].out[0 .. n) receives independent N(0,1) draws -- the reparameterisation noise of
+ * models_new.py:1741 (torch.randn_like) and the Monte-Carlo samples of losses.py:536 (torch.randn(S, B, D)), which
+ * the reference takes from torch's generator one ATen launch each.  Generator: Philox-4x32-10 with key = seed and
+ * counter (element / 4, buffer index i, call index, 0); the four 32-bit outputs of a call become four normals by
+ * Box-Muller on 24-bit uniforms ((x >> 8) + 0.5) * 2^-24.  rng_state: device int32[2] owned by the caller, zeroed once:
+ * [0] = number of calls made with it (read by the launch and advanced on the device when it ends, so a replayed
+ * hipGraph draws fresh noise), [1] = scratch.  Same stream of draws for the same (seed, rng_state[0]) on every run. */
+#define DOF_NOISE_MAX_BUFS 2
+typedef struct DofNoiseBuf {
+  float* out;
+  int64_t n;
+} DofNoiseBuf;
+int dof_step_begin(float* hyper, const DofSchedItem* items, int32_t n_items, uint64_t seed, int32_t* rng_state,
+                   const DofNoiseBuf* bufs, int32_t n_bufs, void* stream);
+
+/* Running sums of the logged loss terms (step_vade's logs dict averaged over an epoch, training.py:167-181): with
+ * accum != NULL (device float64[DOF_LOG_COUNT]) every dof_vade_loss_grads on this plan also adds its logs[] to
+ * accum[] inside its last loss kernel; NULL switches that off.  The caller zeroes / reads accum. */
+int dof_vade_set_log_accumulator(DofVadePlan* plan, double* accum);
 
 /* ---- pose-table preprocessing -----------------------------------------------
  * Raw merged tables of all videos, concatenated: raw (n_frames, n_cols) float64 row-major (NaN = missing), video v =

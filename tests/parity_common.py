@@ -752,6 +752,32 @@ def run_distill_head_check(lib, device, golden_dir):
     assert n >= 42
 
 
+def run_step_begin_check(lib, device, sizes=(1029, 37), seed=0x1234_5678_9ABC_DEF1, calls=3):
+    """dof_step_begin: noise fills vs the numpy Philox / Box-Muller restatement (oracle.noise) call after call, the
+    device-side call counter, and the schedule items it applies in the same launch."""
+    import ctypes as C
+    from oracle import noise as ON
+    hyper = torch.zeros(_capi.H_COUNT, dtype=torch.float32, device=device)
+    table = torch.tensor([0.25, 0.5, 0.75], dtype=torch.float32, device=device)
+    cursor = torch.zeros(1, dtype=torch.int32, device=device)
+    state = torch.zeros(2, dtype=torch.int32, device=device)
+    outs = [torch.full((n,), float("nan"), dtype=torch.float32, device=device) for n in sizes]
+    stream = torch.cuda.current_stream().cuda_stream if device != "cpu" else 0
+    items = (_capi.SchedItem * 1)(_capi.SchedItem(table.data_ptr(), cursor.data_ptr(), 3, _capi.H_KLW, 1, 2.0))
+    bufs = (_capi.NoiseBuf * len(sizes))(*[_capi.NoiseBuf(o.data_ptr(), o.numel()) for o in outs])
+    for call in range(calls):
+        _capi.check(lib, lib.dof_step_begin(hyper.data_ptr(), items, 1, seed, state.data_ptr(), bufs, len(sizes), stream))
+        for i, o in enumerate(outs):
+            ref = ON.normal_fill(o.numel(), seed, i, call)
+            np.testing.assert_allclose(o.cpu().numpy(), ref, atol=2e-5, rtol=1e-5)
+        assert state.cpu().tolist() == [call + 1, 0]
+        assert float(hyper[_capi.H_KLW]) == 2.0 * [0.25, 0.5, 0.75][min(call, 2)]
+    assert int(cursor.item()) == calls
+    # items only (validation step without noise): nothing but the schedule moves
+    _capi.check(lib, lib.dof_step_begin(hyper.data_ptr(), items, 1, seed, None, None, 0, stream))
+    assert state.cpu().tolist() == [calls, 0] and int(cursor.item()) == calls + 1
+
+
 def run_vade_rec_vs_oracle(lib, device, K, L=8, B=21, T=9, S=5, seed=11):
     """Recurrent VaDE, main phase with the teacher and every optional regulariser switched on, at component counts the
     goldens do not have (K = 25: two components per lane of the row kernels; K = 40: the one-thread-per-window

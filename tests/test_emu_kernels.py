@@ -35,6 +35,11 @@ def test_vade_loss_grads_emu(golden_dir, tag, phase):
     run_phase_check(emu_lib(), "cpu", golden_dir, tag, phase)
 
 
+def test_step_begin_noise_emu():
+    from parity_common import run_step_begin_check
+    run_step_begin_check(emu_lib(), "cpu")
+
+
 @pytest.mark.parametrize("K", [25, 40])
 def test_vade_many_components_emu(K):
     from parity_common import run_vade_rec_vs_oracle

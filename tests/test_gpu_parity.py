@@ -19,7 +19,7 @@ def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     from deepof_amd import _capi
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == _capi.ABI_VERSION == 10
+    assert hip.dof_abi_version() == _capi.ABI_VERSION == 11
 
 
 def test_gather_gpu(hip):
@@ -1078,3 +1078,36 @@ def test_tfm_other_widths_gpu(hip, n_nodes, latent, kind):
     oracle on injected random keep-masks: eval forward with a masked frame, total loss and every gradient."""
     from parity_common import run_tfm_widths_vs_oracle
     print("worst gradient error / tensor scale:", run_tfm_widths_vs_oracle(hip, "cuda", n_nodes, latent, B=24, T=25, kind=kind))
+
+
+def test_step_begin_noise_gpu(hip):
+    """dof_step_begin on the device: fills vs the Philox / Box-Muller oracle (ragged and 16-byte-unaligned cases
+    included), call counter, schedule item; moments of a C2-sized fill; a replayed hipGraph draws fresh noise."""
+    from parity_common import run_step_begin_check
+    run_step_begin_check(hip, "cuda")
+    run_step_begin_check(hip, "cuda", sizes=(1024 * 8, 32 * 1024 * 8), calls=2)
+    from deepof_amd import _capi
+    hyper = torch.zeros(_capi.H_COUNT, device="cuda")
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    base = torch.empty(32 * 1024 * 8 + 1, device="cuda")
+    out = base[1:]  # 4-byte aligned only
+    bufs = (_capi.NoiseBuf * 1)(_capi.NoiseBuf(out.data_ptr(), out.numel()))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        _capi.check(hip, hip.dof_step_begin(hyper.data_ptr(), None, 0, 99, state.data_ptr(), bufs, 1, s.cuda_stream))
+        first = out.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            _capi.check(hip, hip.dof_step_begin(hyper.data_ptr(), None, 0, 99, state.data_ptr(), bufs, 1, s.cuda_stream))
+        g.replay()
+        second = out.clone()
+        g.replay()
+        third = out.clone()
+    torch.cuda.synchronize()
+    from oracle import noise as ON
+    np.testing.assert_allclose(first.cpu().numpy(), ON.normal_fill(out.numel(), 99, 0, 0), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(third.cpu().numpy(), ON.normal_fill(out.numel(), 99, 0, int(state[0].item()) - 1),
+                               atol=2e-5, rtol=1e-5)
+    assert not torch.equal(second, third) and not torch.equal(first, second)
+    x = third.double()
+    assert abs(float(x.mean())) < 0.01 and abs(float(x.var()) - 1.0) < 0.01

@@ -699,3 +699,20 @@ def test_contrastive_tfm_matches_reference(golden_dir):
     for k in d:
         if k.startswith("sd_after::") and "running_" in k:
             np.testing.assert_allclose(P[k[len("sd_after::"):]].detach().numpy(), d[k], atol=2e-6, rtol=2e-5, err_msg=k)
+
+
+def test_philox_known_answers():
+    """oracle.noise's Philox-4x32-10 against the Random123 known-answer vectors (kat_vectors: zero, all ones, digits of
+    pi) -- the generator dof_step_begin's noise is compared with."""
+    from oracle.noise import philox4x32_10, normal_fill
+    kat = [([0, 0, 0, 0], (0, 0), [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, (0xffffffff, 0xffffffff), [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0),
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        got = philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
+        assert [int(v) for v in got] == want
+    x = normal_fill(200_000, 7, 0, 3).astype(np.float64)
+    assert abs(x.mean()) < 0.01 and abs(x.var() - 1.0) < 0.01 and abs((x ** 4).mean() - 3.0) < 0.1
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 0.01
+    assert not np.array_equal(x[:100], normal_fill(100, 7, 0, 4)) and not np.array_equal(x[:100], normal_fill(100, 7, 1, 3))
