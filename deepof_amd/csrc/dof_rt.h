@@ -25,6 +25,8 @@ typedef float dof_f32x4 __attribute__((ext_vector_type(4)));
 #else
 #define DOF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// compiler-only memory fence: loads after it are not merged with / hoisted above earlier ones
+#define DOF_MEM_FENCE() asm volatile("" ::: "memory")
 
 // Wave-uniform read-only weights: viewing them through the constant address space makes every
 // uniform load a scalar-cache s_load (no VMEM traffic, weights arrive in SGPRs and feed v_fmac

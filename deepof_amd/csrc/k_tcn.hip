@@ -111,6 +111,9 @@ struct TcnConvArgs {
   float* partial;       // [n_waves][64] channel sums (forward / fused backward) or null
   const float* fuse_y;    // FUSE_BN: pre-normalisation output of the BatchNorm+ReLU in front of this (reverse) conv's result
   const float* fuse_bnp;  // FUSE_BN: its record
+  const float* bwd_y;     // BWD2 (k_tcn_conv_t): pre-normalisation tensor of the BatchNorm whose pass-1 gradient `in` holds
+  const float* bwd_bnp;   // BWD2: its record
+  const float* bwd_coef;  // BWD2: (mean g | mean g * xhat) of that BatchNorm
   int T, dil, accumulate;
   int64_t S, Sp;
 };
@@ -210,6 +213,207 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
       float* p = A.partial + (int64_t)wave * 2 * TC;
       p[i] = s1[0]; p[16 + i] = s1[1];
       p[TC + i] = s2[0]; p[TC + 16 + i] = s2[1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time-resident form of the same convolution for windows of up to TCT_T steps (the layout is [t][s][32], so the
+// four taps of an output row lie T-strided apart and k_tcn_conv fetches every input row four times -- 1.5 GB per
+// layer at batch 8192, from the Infinity Cache at best).  Here a workgroup owns 16 sequences for ALL time steps:
+// the (T x 16 x 32) input tile is staged in LDS once with coalesced 16-byte loads (50 KB at T = 25, three
+// workgroups per CU overlap their load and MFMA phases), the producer's BatchNorm + ReLU (BN_IN) or the second
+// pass of a BatchNorm backward (BWD2: dy = scale (g - mean g - xhat mean(g xhat)), written back in place for the
+// weight-gradient kernel) is applied once per element while staging instead of once per tap, and wavefront w
+// computes the output rows t = w, w + 4, ...  The 16-byte chunks of a row are XOR-swizzled by the sequence index
+// so that the ds_read_b128 lane groups hit 16 distinct slots.  The MFMA operands are swapped against k_tcn_conv
+// (A = weights, B = input rows): D[channel][sequence] leaves every lane with four consecutive channels of ONE
+// sequence, i.e. a 16-byte store (and 16-byte loads of the epilogue operands) instead of four scattered dwords.
+// ---------------------------------------------------------------------------------------------
+constexpr int TCT_T = 25;
+
+__device__ __forceinline__ int tct_slot(int t, int sq, int chunk) { return (t * 16 + sq) * 8 + (chunk ^ ((sq >> 1) & 7)); }
+
+template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2>
+__global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
+  __shared__ float4 tile[(TCT_T + 1) * 16 * 8];  // + one row for the unconditional staging of an odd T
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  // wavefront -> (output-channel half ct, time parity): 32 of the 128 x 32 weights per lane.
+  // A operand: k-step (tap j, q) multiplies input channel (q < 4 ? 0 : 16) + kk*4 + (q & 3) -- the 16-byte chunks
+  // kk and kk + 4 of a staged row; lane (kk, i) holds the weight of that channel for output channel ct*16 + i.
+  const int ct = wv & 1, tpar = wv >> 1;
+  float wr[TK][8];
+#pragma unroll
+  for (int j = 0; j < TK; ++j)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cin = (q < 4 ? 0 : 16) + kk * 4 + (q & 3), col = ct * 16 + i;
+      wr[j][q] = REVERSE ? A.w[(cin * TC + col) * TK + j] : A.w[(col * TC + cin) * TK + j];
+    }
+  // staging: thread -> (time parity, sequence, 16-byte chunk); its four channels are fixed
+  const int half = threadIdx.x >> 7, sq = (threadIdx.x & 127) >> 3, ch = threadIdx.x & 7;
+  // epilogue constants: output channels ct*16 + kk*4 + r (FUSE_BN: the BatchNorm record waits in LDS)
+  __shared__ float4 frec[FUSE_BN ? 4 * TC / 4 : 1];
+  if (FUSE_BN) {
+    if (threadIdx.x < 4 * TC / 4) frec[threadIdx.x] = reinterpret_cast<const float4*>(A.fuse_bnp)[threadIdx.x];
+  }
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = (!REVERSE && A.bias) ? A.bias[ct * 16 + kk * 4 + r] : 0.0f;
+  float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int T = A.T;
+  const int64_t n_groups = A.Sp / 16;
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t s0 = grp * 16;
+    // per-thread BatchNorm constants of the staging phase, (re)loaded per group: they are dead during the MFMA phase
+    // (the fence keeps the compiler from hoisting them out of the loop into registers that phase needs)
+    DOF_MEM_FENCE();
+    float k0[4], k1[4];                        // BN_IN: scale, shift of the producer's BatchNorm
+    float bm[4], br[4], bs[4], c1[4], c2[4];  // BWD2: mean, rstd, scale, mean g, mean g xhat
+    if (BN_IN) {
+      dof_ld_row<4>(A.bnp_in + 2 * TC + ch * 4, k0);
+      dof_ld_row<4>(A.bnp_in + 3 * TC + ch * 4, k1);
+    }
+    if (BWD2) {
+      dof_ld_row<4>(A.bwd_bnp + ch * 4, bm);
+      dof_ld_row<4>(A.bwd_bnp + TC + ch * 4, br);
+      dof_ld_row<4>(A.bwd_bnp + 2 * TC + ch * 4, bs);
+      dof_ld_row<4>(A.bwd_coef + ch * 4, c1);
+      dof_ld_row<4>(A.bwd_coef + TC + ch * 4, c2);
+    }
+    // ---- stage the group's rows: two time steps per pass over the 256 threads, a batch of loads in flight.  The
+    // loads are unconditional (steps past T re-read step T - 1 and land in LDS rows nobody reads): a predicate
+    // around them would serialise the batch on vmcnt(0).
+    constexpr int NP = (TCT_T + 1) / 2, NBATCH = BWD2 ? 3 : 7;
+    const bool srow = s0 + sq < A.S;
+    // 32-bit element offsets (the launcher checks T * Sp * 32 < 2^31): SGPR base + one VGPR per address
+    const uint32_t row_stride = (uint32_t)A.Sp * TC;
+    const uint32_t st_base = (uint32_t)(s0 + sq) * TC + ch * 4;
+#pragma unroll
+    for (int n0 = 0; n0 < NP; n0 += NBATCH) {
+      float4 v[NBATCH], yv[NBATCH];
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+        if (n0 + u < NP) {
+          const int t = 2 * (n0 + u) + half;
+          const uint32_t off = st_base + (uint32_t)(t < T ? t : T - 1) * row_stride;
+          v[u] = *reinterpret_cast<const float4*>(A.in + off);
+          if (BWD2) yv[u] = *reinterpret_cast<const float4*>(A.bwd_y + off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+        if (n0 + u < NP) {
+          const int t = 2 * (n0 + u) + half;
+          float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          if (BN_IN) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[c] = fmaxf(fmaf(e[c], k0[c], k1[c]), 0.0f);
+          }
+          if (BWD2) {
+            const float y4[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float xh = (y4[c] - bm[c]) * br[c];
+              e[c] = bs[c] * (e[c] - c1[c] - xh * c2[c]);
+            }
+          }
+          const float4 w4 = make_float4(e[0], e[1], e[2], e[3]);
+          tile[tct_slot(t, sq, ch)] = w4;
+          if (srow && t < T) {
+            const uint32_t off = st_base + (uint32_t)t * row_stride;
+            if (BN_IN && !REVERSE && A.a_out) *reinterpret_cast<float4*>(A.a_out + off) = w4;
+            if (BWD2) *reinterpret_cast<float4*>(const_cast<float*>(A.in) + off) = w4;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- output rows t = tpar, tpar + 2, ... of channel half ct; the epilogue's global operand (the accumulation
+    // target or the BatchNorm input of FUSE_BN) is requested two rows ahead
+    const int64_t s = s0 + i;
+    const bool ok = s < A.S;
+    constexpr bool PRE = REVERSE;  // the reverse variants read one epilogue operand (accumulate XOR FUSE_BN)
+    const float* pre_src = FUSE_BN ? A.fuse_y : (const float*)A.out;
+    const bool pre_on = PRE && ok && (FUSE_BN || A.accumulate);
+    const uint32_t ep_base = (uint32_t)s * TC + ct * 16 + kk * 4;
+    const uint32_t pre_base = (uint32_t)(pre_on ? s : s0) * TC + ct * 16 + kk * 4;  // padded lanes read a valid row and ignore it
+    float4 p0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), p1 = p0;
+    if (PRE && (FUSE_BN || A.accumulate)) {
+      p0 = *reinterpret_cast<const float4*>(pre_src + (pre_base + (uint32_t)(tpar < T ? tpar : T - 1) * row_stride));
+      p1 = *reinterpret_cast<const float4*>(pre_src + (pre_base + (uint32_t)(tpar + 2 < T ? tpar + 2 : T - 1) * row_stride));
+    }
+    for (int t = tpar; t < T; t += 2) {
+      const uint32_t off = ep_base + (uint32_t)t * row_stride;
+      const float4 pc = p0;
+      if (PRE && (FUSE_BN || A.accumulate)) {
+        p0 = p1;
+        p1 = *reinterpret_cast<const float4*>(pre_src + (pre_base + (uint32_t)(t + 4 < T ? t + 4 : T - 1) * row_stride));
+      }
+      dof_f32x4 acc = {bias[0], bias[1], bias[2], bias[3]};
+      // all valid taps' rows are requested from LDS before the first MFMA (validity is wave-uniform)
+      float4 lo[TK], hi[TK];
+      bool tap[TK];
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        const int tt = REVERSE ? t + (TK - 1 - j) * A.dil : t - (TK - 1 - j) * A.dil;
+        tap[j] = tt >= 0 && tt < T;
+        if (tap[j]) {
+          lo[j] = tile[tct_slot(tt, i, kk)];
+          hi[j] = tile[tct_slot(tt, i, kk + 4)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        if (tap[j]) {
+          const float a[8] = {lo[j].x, lo[j].y, lo[j].z, lo[j].w, hi[j].x, hi[j].y, hi[j].z, hi[j].w};
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][q], a[q], acc, 0, 0, 0);
+        }
+      }
+      if (ok) {
+        float v0[4] = {acc[0], acc[1], acc[2], acc[3]};
+        if (REVERSE && !FUSE_BN && A.accumulate) {
+          v0[0] += pc.x; v0[1] += pc.y; v0[2] += pc.z; v0[3] += pc.w;
+        }
+        if (FUSE_BN) {
+          const float ya[4] = {pc.x, pc.y, pc.z, pc.w};
+          const int cw = ct * 4 + kk;
+          const float4 m4 = frec[cw], r4 = frec[TC / 4 + cw], sc4 = frec[2 * TC / 4 + cw], sh4 = frec[3 * TC / 4 + cw];
+          const float fm[4] = {m4.x, m4.y, m4.z, m4.w}, fr[4] = {r4.x, r4.y, r4.z, r4.w};
+          const float fsc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, fsh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v0[r] = fmaf(ya[r], fsc[r], fsh[r]) > 0.0f ? v0[r] : 0.0f;
+            s1[r] += v0[r];
+            s2[r] = fmaf(v0[r], (ya[r] - fm[r]) * fr[r], s2[r]);
+          }
+        }
+        *reinterpret_cast<float4*>(A.out + off) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+        if (!REVERSE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1[r] += v0[r];
+            s2[r] = fmaf(v0[r], v0[r], s2[r]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // per-wavefront channel sums: partial[wave][64] = (sum | second sum); a wavefront covers one channel half only
+  if ((!REVERSE || FUSE_BN) && A.partial) {
+    float* p = A.partial + (int64_t)(blockIdx.x * 4 + wv) * 2 * TC;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a1 = dof_row16_sum(s1[r]), a2 = dof_row16_sum(s2[r]);
+      if (i == 0) {
+        p[ct * 16 + kk * 4 + r] = a1;
+        p[TC + ct * 16 + kk * 4 + r] = a2;
+        p[(ct ^ 1) * 16 + kk * 4 + r] = 0.0f;
+        p[TC + (ct ^ 1) * 16 + kk * 4 + r] = 0.0f;
+      }
     }
   }
 }
@@ -826,13 +1030,42 @@ int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float*
   return dof_check_launch("k_tcn_in_conv");
 }
 
+// Workgroups of the time-resident convolution: one per 16 sequences, at most three resident per CU (50 KB of LDS each)
+static bool tct_fits(int T, int64_t Sp) { return T <= TCT_T && (int64_t)T * Sp * TC < ((int64_t)1 << 31); }
+static unsigned tct_blocks(int64_t Sp) {
+  const int64_t groups = Sp / 16;
+  return (unsigned)(groups < 768 ? groups : 768);
+}
+int dof_tcn_conv32_resident(int T, int64_t Sp) { return tct_fits(T, Sp) ? 1 : 0; }
+int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
+  return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(Sp) * 4 : dof_tcn_conv_waves(T, Sp);
+}
+
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
-                        hipStream_t st) {
+                        hipStream_t st, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef) {
   TcnConvArgs A;
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
+  A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
   A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
+  if (dof_tcn_conv32_resident(T, Sp)) {
+    const unsigned nbt = tct_blocks(Sp);
+    if (reverse && bwd_y) {
+      DOF_LAUNCH((k_tcn_conv_t<true, false, false, true>), (nbt), (256), st, A);
+    } else if (reverse) {
+      DOF_LAUNCH((k_tcn_conv_t<true, false, false, false>), (nbt), (256), st, A);
+    } else if (bnp_in) {
+      DOF_LAUNCH((k_tcn_conv_t<false, true, false, false>), (nbt), (256), st, A);
+    } else {
+      DOF_LAUNCH((k_tcn_conv_t<false, false, false, false>), (nbt), (256), st, A);
+    }
+    return dof_check_launch("k_tcn_conv_t");
+  }
+  if (bwd_y) {
+    dof_set_error("k_tcn_conv: the fused BatchNorm-backward pass needs the time-resident kernel (T <= %d)", TCT_T);
+    return DOF_ERR_UNSUPPORTED;
+  }
   const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
   if (reverse) {
     DOF_LAUNCH((k_tcn_conv<true, false>), (nb), (256), st, A);
@@ -846,12 +1079,30 @@ int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const floa
 
 // data gradient of a 32 -> 32 convolution fused with the first backward pass of the BatchNorm + ReLU that produced
 // the convolution's input: g = conv^T(dy) * [BN(y) > 0] into g_out, channel sums (sum g | sum g * xhat) into sums
+// bwd_y != null (time-resident kernel only): dy still holds the pass-1 gradient of ITS BatchNorm; pass 2 is applied
+// while staging and written back in place.
 int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
-                               float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st) {
+                               float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st,
+                               const float* bwd_y, const float* bwd_bnp, const float* bwd_coef) {
   TcnConvArgs A;
   A.in = dy; A.w = w; A.bias = nullptr; A.bnp_in = nullptr; A.a_out = nullptr; A.out = g_out; A.partial = partial;
   A.fuse_y = y; A.fuse_bnp = bnp;
+  A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
+  if (dof_tcn_conv32_resident(T, Sp)) {
+    const unsigned nbt = tct_blocks(Sp);
+    if (bwd_y) {
+      DOF_LAUNCH((k_tcn_conv_t<true, false, true, true>), (nbt), (256), st, A);
+    } else {
+      DOF_LAUNCH((k_tcn_conv_t<true, false, true, false>), (nbt), (256), st, A);
+    }
+    if (int rc = dof_check_launch("k_tcn_conv_t_bwd_bn")) return rc;
+    return dof_launch_sum_partials(partial, (int64_t)nbt * 4, 2 * TC, sums, 0, st);
+  }
+  if (bwd_y) {
+    dof_set_error("k_tcn_conv_bwd_bn: the fused BatchNorm-backward pass needs the time-resident kernel (T <= %d)", TCT_T);
+    return DOF_ERR_UNSUPPORTED;
+  }
   const int64_t waves = dof_tcn_conv_waves(T, Sp);
   DOF_LAUNCH((k_tcn_conv<true, false, true>), ((unsigned)(waves / 4)), (256), st, A);
   if (int rc = dof_check_launch("k_tcn_conv_bwd_bn")) return rc;
@@ -908,6 +1159,7 @@ int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const flo
   TcnConvArgs A;
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
+  A.bwd_y = nullptr; A.bwd_bnp = nullptr; A.bwd_coef = nullptr;
   A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
   const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
 #define CONVG(R, BN, K, N) DOF_LAUNCH((k_tcn_convg<R, BN, K, N>), (nb), (256), st, A, cin_real, w_ci)

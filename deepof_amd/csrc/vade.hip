@@ -1282,14 +1282,14 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
       } else {
         TRY(dof_launch_tcn_conv(0, ws + t.out[b - 1], params + o.c1w, params + o.c1b, nullptr, nullptr, ws + t.y1[b],
                                 ws + t.partial, 0, T, d, w.S, w.Sp, st));
-        nrows = dof_tcn_conv_waves(T, w.Sp);
+        nrows = dof_tcn_conv32_partials(T, w.Sp);
       }
       if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
                                 train, ws + t.bnp[2 * b], 32, st));
       TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b], ws + t.a1[b],
                               ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st));
-      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv_waves(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
+      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
                                 train, ws + t.bnp[2 * b + 1], 32, st));
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
@@ -1561,6 +1561,7 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
     const StreamWs& w = p->sw[s];
     const TcnWs& t = p->tw[s];
     const float count = (float)((int64_t)T * w.S);
+    const bool fuse2 = dof_tcn_conv32_resident(T, w.Sp) != 0;
     for (int b = 7; b >= 0; --b) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
@@ -1570,15 +1571,27 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
                                  ws + t.partial, ws + t.sums, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip,
                                  nullptr, dprev, T, 32, w.S, w.Sp, st));
       TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, ws + t.coef, 32, st));
-      TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.coef, T, 32, w.S, w.Sp, st));
-      // conv2's data gradient with BN1 + ReLU's first backward pass in its epilogue
-      TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
-                                     ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st));
+      // conv2's data gradient with BN1 + ReLU's first backward pass in its epilogue; the time-resident kernel also
+      // applies pass 2 of BN2's backward while it stages g2 (written back in place for the weight-gradient kernel)
+      if (fuse2) {
+        TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
+                                       ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st, ws + t.y2[b],
+                                       ws + t.bnp[2 * b + 1], ws + t.coef));
+      } else {
+        TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.coef, T, 32, w.S, w.Sp, st));
+        TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
+                                       ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st));
+      }
       TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g1, grads + o.b1, accumulate, ws + t.coef, 32, st));
-      TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef, T, 32, w.S, w.Sp, st));
-      if (b > 0)
+      if (fuse2 && b > 0) {  // pass 2 of BN1's backward inside conv1's data gradient
         TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
-                                w.Sp, st));
+                                w.Sp, st, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef));
+      } else {
+        TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef, T, 32, w.S, w.Sp, st));
+        if (b > 0)
+          TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
+                                  w.Sp, st));
+      }
     }
   }
   return run_jobset(p, p->js_enc, grads, accumulate, st);
