@@ -19,6 +19,7 @@
 // activated tensor makes no extra HBM round trip in the forward pass.  The same kernel with the taps
 // reversed and the weights transposed is the data-gradient; weight gradients go through the strided MFMA
 // reduction in k_reduce.hip.
+#include <cstdlib>
 #include "dof_rt.h"
 #include "launchers.h"
 
@@ -114,6 +115,7 @@ struct TcnConvArgs {
   const float* bwd_y;     // BWD2 (k_tcn_conv_t): pre-normalisation tensor of the BatchNorm whose pass-1 gradient `in` holds
   const float* bwd_bnp;   // BWD2: its record
   const float* bwd_coef;  // BWD2: (mean g | mean g * xhat) of that BatchNorm
+  const float* stat_shift;  // forward k_tcn_conv_t: per-channel shift K of the channel sums (sum (y - K) | sum (y - K)^2), or null
   int T, dil, accumulate;
   int64_t S, Sp;
 };
@@ -258,9 +260,12 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
   if (FUSE_BN) {
     if (threadIdx.x < 4 * TC / 4) frec[threadIdx.x] = reinterpret_cast<const float4*>(A.fuse_bnp)[threadIdx.x];
   }
-  float bias[4];
+  float bias[4], kshift[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bias[r] = (!REVERSE && A.bias) ? A.bias[ct * 16 + kk * 4 + r] : 0.0f;
+  for (int r = 0; r < 4; ++r) {
+    bias[r] = (!REVERSE && A.bias) ? A.bias[ct * 16 + kk * 4 + r] : 0.0f;
+    kshift[r] = (!REVERSE && A.stat_shift) ? A.stat_shift[ct * 16 + kk * 4 + r] : 0.0f;
+  }
   float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   const int T = A.T;
   const int64_t n_groups = A.Sp / 16;
@@ -394,8 +399,9 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
         if (!REVERSE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            s1[r] += v0[r];
-            s2[r] = fmaf(v0[r], v0[r], s2[r]);
+            const float dv = v0[r] - kshift[r];
+            s1[r] += dv;
+            s2[r] = fmaf(dv, dv, s2[r]);
           }
         }
       }
@@ -520,14 +526,28 @@ __global__ void __launch_bounds__(256) k_tcn_convg(TcnConvArgs A, int cin_real, 
 // sums[2][C] = (sum x, sum (x - mean)^2) over `count` samples  ->  bnp; train: running buffers updated in place.
 // (The second moment is taken about the mean in a second pass over the tensor: E[x^2] - mean^2 in fp32 loses
 //  the variance to cancellation as soon as |mean| >> std, and the reference's two-pass variance does not.)
+// Shifted single-pass statistics (shifted = 1, the time-resident convolution with stat_shift = the layer's running
+// mean K, read here before it is updated): sums = (S1 = sum (y - K) | S2 = sum (y - K)^2 | M2 of the centred second
+// pass).  mean = K + S1 / n and n var = S2 - S1^2 / n lose log2(S2 / (n var)) bits to cancellation, so the one-pass
+// value is used while S1^2 / n <= S2 / 2 (|mean - K| <= one standard deviation: the steady state of training, where K
+// tracks the batch mean); otherwise k_tcn_var / k_tcn_var_sum -- which evaluate the same predicate and return at
+// once when it holds for all their channels -- have left the two-pass M2 in sums[2C + c].
+__device__ __forceinline__ bool bn_shift_ok(float s1, float s2, float count) { return s1 * (s1 / count) <= 0.5f * s2; }
+
 __global__ void __launch_bounds__(64) k_bn_fwd_fin(const float* __restrict__ sums, float count,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
-                                                   int train, float* __restrict__ bnp, int C) {
+                                                   int train, float* __restrict__ bnp, int C, int shifted) {
   const int c = threadIdx.x;
   if (c >= C) return;
   float mean, var;
-  if (train) {
+  if (train && shifted) {
+    const float s1 = sums[c], s2 = sums[C + c], d = s1 / count;
+    mean = rmean[c] + d;
+    var = bn_shift_ok(s1, s2, count) ? fmaxf(s2 - s1 * d, 0.0f) / count : sums[2 * C + c] / count;
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * var * (count / fmaxf(count - 1.0f, 1.0f));
+  } else if (train) {
     mean = sums[c] / count;
     var = sums[C + c] / count;
     rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
@@ -546,10 +566,21 @@ __global__ void __launch_bounds__(64) k_bn_fwd_fin(const float* __restrict__ sum
 
 // second pass of the batch statistics: channel sums of (y - mean)^2, mean = sums[c] / count; row-per-thread,
 // 32-channel half per blockIdx.y; partial[h][nblk][32]
+// shift != null (shifted statistics, see bn_shift_ok): the pass is only needed for channels whose one-pass variance is
+// ill-conditioned -- the workgroup returns at once when none of its 32 channels is; mean = shift + S1 / count
 __global__ void __launch_bounds__(256) k_tcn_var(const float* __restrict__ y, const float* __restrict__ sums, float count,
-                                                 float* __restrict__ partial, int T, int CT, int64_t S, int64_t Sp) {
+                                                 float* __restrict__ partial, int T, int CT, int64_t S, int64_t Sp,
+                                                 const float* __restrict__ shift) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int c0 = blockIdx.y * TC;
+  if (shift) {
+    __shared__ int need;
+    if (threadIdx.x == 0) need = 0;
+    __syncthreads();
+    if (threadIdx.x < TC && !bn_shift_ok(sums[c0 + threadIdx.x], sums[CT + c0 + threadIdx.x], count)) need = 1;
+    __syncthreads();
+    if (!need) return;
+  }
   float st[TC];
 #pragma unroll
   for (int c = 0; c < TC; ++c) st[c] = 0.0f;
@@ -561,7 +592,7 @@ __global__ void __launch_bounds__(256) k_tcn_var(const float* __restrict__ y, co
     const float rc = 1.0f / count;
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
-      const float dv = v[c] - sums[c0 + c] * rc;
+      const float dv = v[c] - (shift ? shift[c0 + c] + sums[c0 + c] * rc : sums[c0 + c] * rc);
       st[c] = dv * dv;
     }
   }
@@ -569,10 +600,12 @@ __global__ void __launch_bounds__(256) k_tcn_var(const float* __restrict__ y, co
 }
 
 // partial[h][nblk][32] -> sums[CT + h*32 + c]
+// shifted (count > 0): channels with a well-conditioned one-pass variance are skipped, the result goes to sums[2 CT + ch]
 __global__ void __launch_bounds__(256) k_tcn_var_sum(const float* __restrict__ partial, int64_t nblk, int CT,
-                                                     float* __restrict__ sums) {
+                                                     float* __restrict__ sums, float shifted_count) {
   __shared__ float red[256];
   const int ch = blockIdx.x, h = ch / TC, c = ch - h * TC;
+  if (shifted_count > 0.0f && bn_shift_ok(sums[ch], sums[CT + ch], shifted_count)) return;
   const float* src = partial + (int64_t)h * nblk * TC + c;
   float acc = 0.0f;
   for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += src[b * TC];
@@ -582,7 +615,7 @@ __global__ void __launch_bounds__(256) k_tcn_var_sum(const float* __restrict__ p
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) sums[CT + ch] = red[0];
+  if (threadIdx.x == 0) sums[(shifted_count > 0.0f ? 2 * CT : CT) + ch] = red[0];
 }
 
 // the same for [c][Bp] head tensors: sums[C + c] = sum_b (h[c][b] - mean_c)^2 ; one workgroup per channel
@@ -634,6 +667,8 @@ struct TcnCombineArgs {
   float* skip;         // [T][Sp][CT] running sum
   float* feat;         // [32][Sp] or null
   int first, T, F, CT;
+  int skip_last;       // 1: only the last time step of the skip-sum is kept (the encoder reads nothing else of it)
+  int t0;              // first time step of the launch (the encoder's last block has no `out`: t0 = T - 1)
   int64_t S, Sp;
 };
 
@@ -642,11 +677,12 @@ __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
   const int CT = A.CT, q = CT >> 2;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= A.S * q) return;
-  const int t = blockIdx.y;
+  const int t = blockIdx.y + A.t0;
+  const bool do_skip = !A.skip_last || t == A.T - 1;
   const int64_t s = e / q;
   const int c0 = (int)(e - s * q) * 4;
   const int64_t off = ACT(t, c0, CT, A.Sp, s);
-  float y[4], r[4], sk[4];
+  float y[4], r[4], sk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   dof_ld_row<4>(A.y2 + off, y);
   if (A.res) {
     dof_ld_row<4>(A.res + off, r);
@@ -660,14 +696,14 @@ __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
       r[c] = acc;
     }
   }
-  if (!A.first) dof_ld_row<4>(A.skip + off, sk);
+  if (!A.first && do_skip) dof_ld_row<4>(A.skip + off, sk);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float a2 = fmaxf(BN_APPLY(A.bnp2, CT, c0 + c, y[c]), 0.0f);
     sk[c] = A.first ? a2 : sk[c] + a2;
     r[c] = fmaxf(a2 + r[c], 0.0f);
   }
-  dof_st_row<4>(A.skip + off, sk);
+  if (do_skip) dof_st_row<4>(A.skip + off, sk);
   if (A.out) dof_st_row<4>(A.out + off, r);
   if (A.feat && t == A.T - 1) {
 #pragma unroll
@@ -1036,6 +1072,17 @@ static unsigned tct_blocks(int64_t Sp) {
   const int64_t groups = Sp / 16;
   return (unsigned)(groups < 768 ? groups : 768);
 }
+// One-pass (shifted) BatchNorm statistics are opt-in: DOF_TCN_ONEPASS=1.  They are as accurate as the two-pass form
+// in training's steady state (bn_shift_ok) and take 8 % off the C4 step, but ANY change of rounding in the
+// statistics moves a few pre-activations of the small (6-window) reference fixtures across their ReLU ties, and
+// those fixtures pin the default path ("ReLU-mask ties").
+int dof_tcn_onepass_stats() {
+  static const int on = [] {
+    const char* e = getenv("DOF_TCN_ONEPASS");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return on;
+}
 int dof_tcn_conv32_resident(int T, int64_t Sp) { return tct_fits(T, Sp) ? 1 : 0; }
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
   return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(Sp) * 4 : dof_tcn_conv_waves(T, Sp);
@@ -1043,11 +1090,17 @@ int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
 
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
-                        hipStream_t st, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef) {
+                        hipStream_t st, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
+                        const float* stat_shift) {
   TcnConvArgs A;
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
+  A.stat_shift = stat_shift;
+  if (stat_shift && (reverse || !dof_tcn_conv32_resident(T, Sp))) {
+    dof_set_error("k_tcn_conv: shifted channel sums need the forward time-resident kernel");
+    return DOF_ERR_UNSUPPORTED;
+  }
   A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
   if (dof_tcn_conv32_resident(T, Sp)) {
     const unsigned nbt = tct_blocks(Sp);
@@ -1088,6 +1141,7 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
   A.in = dy; A.w = w; A.bias = nullptr; A.bnp_in = nullptr; A.a_out = nullptr; A.out = g_out; A.partial = partial;
   A.fuse_y = y; A.fuse_bnp = bnp;
   A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
+  A.stat_shift = nullptr;
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
   if (dof_tcn_conv32_resident(T, Sp)) {
     const unsigned nbt = tct_blocks(Sp);
@@ -1110,8 +1164,8 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
 }
 
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
-                          float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st) {
-  DOF_LAUNCH(k_bn_fwd_fin, (1), (64), st, sums, count, gamma, beta, rmean, rvar, momentum, train, bnp, C);
+                          float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st, int shifted) {
+  DOF_LAUNCH(k_bn_fwd_fin, (1), (64), st, sums, count, gamma, beta, rmean, rvar, momentum, train, bnp, C, shifted);
   return dof_check_launch("k_bn_fwd_fin");
 }
 
@@ -1123,12 +1177,14 @@ int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* 
 
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
                            const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
-                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch) {
+                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch, int skip_last) {
   TcnCombineArgs A;
+  A.skip_last = skip_last;
+  A.t0 = (skip_last && !out) ? T - 1 : 0;
   A.xs_ch = xs_ch > 0 ? xs_ch : F;
   A.y2 = y2; A.bnp2 = bnp2; A.res = res; A.xs = xs; A.dsw = dsw; A.dsb = dsb; A.out = out; A.skip = skip;
   A.feat = feat; A.first = first; A.T = T; A.F = F; A.CT = CT; A.S = S; A.Sp = Sp;
-  DOF_LAUNCH(k_tcn_combine, (dof_cdiv(S * (CT / 4), 256), (unsigned)T), (256), st, A);
+  DOF_LAUNCH(k_tcn_combine, (dof_cdiv(S * (CT / 4), 256), (unsigned)(T - A.t0)), (256), st, A);
   return dof_check_launch("k_tcn_combine");
 }
 
@@ -1160,6 +1216,7 @@ int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const flo
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.bwd_y = nullptr; A.bwd_bnp = nullptr; A.bwd_coef = nullptr;
+  A.stat_shift = nullptr;
   A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
   const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
 #define CONVG(R, BN, K, N) DOF_LAUNCH((k_tcn_convg<R, BN, K, N>), (nb), (256), st, A, cin_real, w_ci)
@@ -1322,11 +1379,14 @@ int dof_launch_tcn_dec_out(const float* skip, const float* wp, const float* bp, 
 
 // Batch statistics of one TCN layer from the convolution's channel-sum partials (rows of `stride` floats, the first
 // CT of which are the sums of y) + a centred second pass over y; leaves sums[2][CT] for dof_launch_bn_fwd_fin.
+// shift != null: the partials are shifted sums (k_tcn_conv_t with stat_shift = shift); the second pass only runs for
+// ill-conditioned channels and sums needs 3 CT floats (dof_launch_bn_fwd_fin with shifted = 1).
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
-                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st) {
+                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st, const float* shift) {
   TRY_RC(dof_launch_sum_partials(partial, n_partial, stride, sums, 0, st));
   const unsigned nb = (unsigned)dof_tcn_row_blocks(T, S);
-  DOF_LAUNCH(k_tcn_var, (nb, (unsigned)(CT / TC)), (256), st, y, (const float*)sums, count, partial, T, CT, S, Sp);
-  DOF_LAUNCH(k_tcn_var_sum, ((unsigned)CT), (256), st, (const float*)partial, (int64_t)nb, CT, sums);
+  DOF_LAUNCH(k_tcn_var, (nb, (unsigned)(CT / TC)), (256), st, y, (const float*)sums, count, partial, T, CT, S, Sp, shift);
+  DOF_LAUNCH(k_tcn_var_sum, ((unsigned)CT), (256), st, (const float*)partial, (int64_t)nb, CT, sums,
+             shift ? count : 0.0f);
   return dof_check_launch("k_tcn_var");
 }

@@ -38,6 +38,7 @@ int64_t dof_tcn_row_blocks(int T, int64_t S);   // partial rows written by the r
 int64_t dof_tcn_conv_waves(int T, int64_t Sp);  // partial rows written by the MFMA convolution (one per wave)
 int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float* bias, float* xs, float* y,
                            float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st);
+int dof_tcn_onepass_stats();                         // 1 when DOF_TCN_ONEPASS=1 (one-pass shifted BatchNorm statistics, opt-in)
 int dof_tcn_conv32_resident(int T, int64_t Sp);               // 1: the 32 -> 32 convolutions run the time-resident kernel (it can fuse pass 2 of a BatchNorm backward)
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp);   // partial rows written by the 32 -> 32 convolution
 int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
@@ -47,16 +48,16 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st, const float* bwd_y = nullptr, const float* bwd_bnp = nullptr,
-                        const float* bwd_coef = nullptr);
+                        const float* bwd_coef = nullptr, const float* stat_shift = nullptr);
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
-                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st);
+                            int T, int CT, int64_t S, int64_t Sp, hipStream_t st, const float* shift = nullptr);
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
-                          float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st);
+                          float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st, int shifted = 0);
 int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,
                           int C, hipStream_t st);
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
                            const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
-                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch = 0);
+                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch = 0, int skip_last = 0);
 int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, float* sums,
                            int blk, const float* out_blk, const float* dfeat, const float* skip, const float* dskip,
                            float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st);

@@ -534,7 +534,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     const int64_t rows = dof_tcn_row_blocks(T, w.S), waves = dof_tcn_conv_waves(T, Sp);
     t.partial_rows = rows > waves ? rows : waves;
     t.partial = cv.take(t.partial_rows * 64);
-    t.sums = cv.take(64);
+    t.sums = cv.take(128);  // (S1 | S2 | M2 of the fallback pass)
     t.coef = cv.take(64);
     // CensNet operands
     w.n2 = cv.take((int64_t)D * Sp);
@@ -1271,6 +1271,8 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     const StreamWs& w = p->sw[s];
     const TcnWs& t = p->tw[s];
     const float count = (float)((int64_t)T * w.S);
+    // batch statistics in one pass: the time-resident convolutions sum (y - K), (y - K)^2 with K = the running mean
+    const bool sh = train && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_onepass_stats();
     for (int b = 0; b < 8; ++b) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
@@ -1281,21 +1283,23 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
         nrows = dof_tcn_row_blocks(T, w.S);
       } else {
         TRY(dof_launch_tcn_conv(0, ws + t.out[b - 1], params + o.c1w, params + o.c1b, nullptr, nullptr, ws + t.y1[b],
-                                ws + t.partial, 0, T, d, w.S, w.Sp, st));
+                                ws + t.partial, 0, T, d, w.S, w.Sp, st, nullptr, nullptr, nullptr, sh ? params + o.rm1 : nullptr));
         nrows = dof_tcn_conv32_partials(T, w.Sp);
       }
-      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
+      const float* sh1 = (sh && b > 0) ? params + o.rm1 : nullptr;
+      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh1));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
-                                train, ws + t.bnp[2 * b], 32, st));
+                                train, ws + t.bnp[2 * b], 32, st, sh1 != nullptr));
+      const float* sh2 = sh ? params + o.rm2 : nullptr;
       TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b], ws + t.a1[b],
-                              ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st));
-      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st));
+                              ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st, nullptr, nullptr, nullptr, sh2));
+      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh2));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
-                                train, ws + t.bnp[2 * b + 1], 32, st));
+                                train, ws + t.bnp[2 * b + 1], 32, st, sh2 != nullptr));
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
                                  b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb,
                                  b < 7 ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr, b == 0, T, w.F,
-                                 32, w.S, w.Sp, st));
+                                 32, w.S, w.Sp, st, 0, /*skip_last=*/1));
     }
   }
   TRY(censnet_forward(p, params, st));
