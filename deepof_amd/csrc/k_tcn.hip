@@ -115,6 +115,7 @@ struct TcnConvArgs {
   const float* bwd_y;     // BWD2 (k_tcn_conv_t): pre-normalisation tensor of the BatchNorm whose pass-1 gradient `in` holds
   const float* bwd_bnp;   // BWD2: its record
   const float* bwd_coef;  // BWD2: (mean g | mean g * xhat) of that BatchNorm
+  int bwd_store;          // BWD2: 1 = write dy back over `in` (0: the weight-gradient kernel applies pass 2 itself)
   const float* stat_shift;  // forward k_tcn_conv_t: per-channel shift K of the channel sums (sum (y - K) | sum (y - K)^2), or null
   int T, dil, accumulate;
   int64_t S, Sp;
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
           if (srow && t < T) {
             const uint32_t off = st_base + (uint32_t)t * row_stride;
             if (BN_IN && !REVERSE && A.a_out) *reinterpret_cast<float4*>(A.a_out + off) = w4;
-            if (BWD2) *reinterpret_cast<float4*>(const_cast<float*>(A.in) + off) = w4;
+            if (BWD2 && A.bwd_store) *reinterpret_cast<float4*>(const_cast<float*>(A.in) + off) = w4;
           }
         }
       }
@@ -1091,8 +1092,9 @@ int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
-                        const float* stat_shift) {
+                        const float* stat_shift, int bwd_store) {
   TcnConvArgs A;
+  A.bwd_store = bwd_store;
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
@@ -1136,8 +1138,9 @@ int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const floa
 // while staging and written back in place.
 int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
                                float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st,
-                               const float* bwd_y, const float* bwd_bnp, const float* bwd_coef) {
+                               const float* bwd_y, const float* bwd_bnp, const float* bwd_coef, int bwd_store) {
   TcnConvArgs A;
+  A.bwd_store = bwd_store;
   A.in = dy; A.w = w; A.bias = nullptr; A.bnp_in = nullptr; A.a_out = nullptr; A.out = g_out; A.partial = partial;
   A.fuse_y = y; A.fuse_bnp = bnp;
   A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
@@ -1216,7 +1219,7 @@ int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const flo
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.bwd_y = nullptr; A.bwd_bnp = nullptr; A.bwd_coef = nullptr;
-  A.stat_shift = nullptr;
+  A.stat_shift = nullptr; A.bwd_store = 1;
   A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
   const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
 #define CONVG(R, BN, K, N) DOF_LAUNCH((k_tcn_convg<R, BN, K, N>), (nb), (256), st, A, cin_real, w_ci)
@@ -1243,7 +1246,7 @@ namespace {
 // per time step 4 MFMAs (2 x 2 tiles, one k-slice of 4 sequences) against 4 conflict-free ds_reads; 26 KB of LDS
 // per workgroup, so six workgroups per CU overlap each other's load and MFMA phases.
 template <int NSEQ>  // sequences per staged chunk: 4 (one MFMA k-slice) or 8
-__global__ void __launch_bounds__(256) k_tcn_wgrad(const DofTcnWgrad* __restrict__ descs, float* __restrict__ partials) {
+__global__ void __launch_bounds__(256, 6) k_tcn_wgrad(const DofTcnWgrad* __restrict__ descs, float* __restrict__ partials) {
   __shared__ float sx[DOF_TCN_WGRAD_MAX_T][NSEQ][33];
   __shared__ float sd[DOF_TCN_WGRAD_MAX_T][NSEQ][33];
   const DofTcnWgrad D = descs[blockIdx.y];
@@ -1261,15 +1264,52 @@ __global__ void __launch_bounds__(256) k_tcn_wgrad(const DofTcnWgrad* __restrict
   float rs0 = 0.0f, rs1 = 0.0f;
   const int64_t chunks = Sp / NSEQ;
   constexpr int F4 = NSEQ * 8;  // float4 per time step of one tensor
+  const int cth = (threadIdx.x & 7) * 4;  // a thread stages the same four channels in every pass (256 % 8 == 0)
   for (int64_t ch = blockIdx.x; ch < chunks; ch += D.nblk) {
     __syncthreads();
+    // lazy operands: the per-channel constants are (re)read per chunk so that they do not occupy registers during the
+    // MFMA phase (six workgroups per CU leave 80 VGPRs per lane)
+    DOF_MEM_FENCE();
+    float xs[4], xh[4], ka[4], kb[4], kc[4], bm[4];
+    if (D.in_bnp) {
+      dof_ld_row<4>(D.in_bnp + 2 * 32 + cth, xs);
+      dof_ld_row<4>(D.in_bnp + 3 * 32 + cth, xh);
+    }
+    if (D.dy_y) {  // dy = scale (g - c1 - (y - mean) rstd c2) = ka g + kb (y - mean) + kc
+      float br[4], c1[4], c2[4];
+      dof_ld_row<4>(D.dy_bnp + cth, bm);
+      dof_ld_row<4>(D.dy_bnp + 32 + cth, br);
+      dof_ld_row<4>(D.dy_bnp + 2 * 32 + cth, ka);
+      dof_ld_row<4>(D.dy_coef + cth, c1);
+      dof_ld_row<4>(D.dy_coef + 32 + cth, c2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        kb[k] = -ka[k] * br[k] * c2[k];
+        kc[k] = -ka[k] * c1[k];
+      }
+    }
     for (int idx = threadIdx.x; idx < T * F4; idx += 256) {
       const int t = idx / F4, r = idx - t * F4, s = r >> 3, c = (r & 7) * 4;
       const int64_t off = ((int64_t)t * Sp + ch * NSEQ + s) * 32 + c;
       const float4 vx = *reinterpret_cast<const float4*>(D.in + off);
       const float4 vd = *reinterpret_cast<const float4*>(D.dy + off);
-      sx[t][s][c] = vx.x; sx[t][s][c + 1] = vx.y; sx[t][s][c + 2] = vx.z; sx[t][s][c + 3] = vx.w;
-      sd[t][s][c] = vd.x; sd[t][s][c + 1] = vd.y; sd[t][s][c + 2] = vd.z; sd[t][s][c + 3] = vd.w;
+      float ex[4] = {vx.x, vx.y, vx.z, vx.w}, ed[4] = {vd.x, vd.y, vd.z, vd.w};
+      if (D.in_bnp) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ex[k] = fmaxf(fmaf(ex[k], xs[k], xh[k]), 0.0f);
+      }
+      if (D.dy_y) {
+        const float4 vy = *reinterpret_cast<const float4*>(D.dy_y + off);
+        const float ey[4] = {vy.x, vy.y, vy.z, vy.w};
+        const bool valid = ch * NSEQ + s < D.S;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ed[k] = valid ? fmaf(ka[k], ed[k], fmaf(kb[k], ey[k] - bm[k], kc[k])) : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sx[t][s][c + k] = ex[k];
+        sd[t][s][c + k] = ed[k];
+      }
     }
     __syncthreads();
     for (int t = shift < 0 ? -shift : 0; t < T; ++t) {

@@ -44,11 +44,11 @@ int64_t dof_tcn_conv32_partials(int T, int64_t Sp);   // partial rows written by
 int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
                                float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st,
                                const float* bwd_y = nullptr, const float* bwd_bnp = nullptr,
-                               const float* bwd_coef = nullptr);
+                               const float* bwd_coef = nullptr, int bwd_store = 1);
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st, const float* bwd_y = nullptr, const float* bwd_bnp = nullptr,
-                        const float* bwd_coef = nullptr, const float* stat_shift = nullptr);
+                        const float* bwd_coef = nullptr, const float* stat_shift = nullptr, int bwd_store = 1);
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
                             int T, int CT, int64_t S, int64_t Sp, hipStream_t st, const float* shift = nullptr);
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
@@ -72,8 +72,14 @@ int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const flo
 struct DofTcnWgrad {
   const float* dy;  // [T][Sp][32] gradient w.r.t. the pre-BatchNorm conv output
   const float* in;  // [T][Sp][32] convolution input
+  // lazy operands (all null: dy / in are used as they are).  dy_y: `dy` still holds the FIRST-pass gradient g of the
+  // layer's BatchNorm backward; the staging applies pass 2, dy = scale (g - c1 - xhat c2), from the layer's
+  // pre-normalisation tensor dy_y, its record dy_bnp and (mean g | mean g xhat) = dy_coef.  in_bnp: `in` is the
+  // pre-normalisation tensor of the BatchNorm + ReLU in front of this convolution; the staging applies them.
+  const float *dy_y, *dy_bnp, *dy_coef, *in_bnp;
   int dil, nblk, T;
   int64_t Sp;
+  int64_t S;  // valid sequences (lazy dy: rows of padded sequences are zero gradients, not pass 2 of a zero)
   int64_t part0, part1;  // float offsets of the two jobs' partial regions ([nblk][64][65] each)
 };
 #define DOF_TCN_WGRAD_MAX_T 25

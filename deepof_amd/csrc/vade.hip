@@ -86,6 +86,8 @@ struct TcnWs {  // float offsets of one stream's TCN buffers ([T][Sp][32] unless
   int64_t dout[2], da;                  // ping-pong block-output gradients, conv2 input gradient
   int64_t bnp[16];                      // per-layer BatchNorm records [4][32]
   int64_t partial, sums, coef;
+  int64_t coefs[16];                    // per-layer (mean g | mean g xhat): read again by the lazy weight-gradient operands
+  int lazy;                             // 1: BatchNorm-backward pass 2 and the conv2 input activation are applied on load
   int64_t partial_rows;
 };
 
@@ -522,9 +524,13 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     w.S = p->B * w.G;
     w.Sp = dof_pad64(w.S);
     const int64_t Sp = w.Sp, act = (int64_t)T * Sp * 32;
+    // lazy weight-gradient operands (time-resident convolutions + the LDS-staged weight-gradient kernel): pass 2 of the
+    // BatchNorm backward and conv2's input activation are recomputed where they are read, so neither the normalised
+    // gradients nor the activated tensors a1 are ever written (8 x [T][Sp][32] per stream less)
+    t.lazy = (dof_tcn_conv32_resident(T, Sp) && T <= DOF_TCN_WGRAD_MAX_T) ? 1 : 0;
     t.xs = cv.take((int64_t)T * Sp * w.F);
     for (int b = 0; b < 8; ++b) {
-      t.y1[b] = cv.take(act); t.a1[b] = cv.take(act); t.y2[b] = cv.take(act);
+      t.y1[b] = cv.take(act); t.a1[b] = t.lazy ? 0 : cv.take(act); t.y2[b] = cv.take(act);
       t.out[b] = b < 7 ? cv.take(act) : 0;
       t.g1[b] = cv.take(act); t.g2[b] = cv.take(act);
     }
@@ -536,6 +542,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     t.partial = cv.take(t.partial_rows * 64);
     t.sums = cv.take(128);  // (S1 | S2 | M2 of the fallback pass)
     t.coef = cv.take(64);
+    for (int k = 0; k < 16; ++k) t.coefs[k] = cv.take(64);
     // CensNet operands
     w.n2 = cv.take((int64_t)D * Sp);
     w.dn2 = cv.take((int64_t)D * Sp);
@@ -885,7 +892,9 @@ void build_tcn_jobs(DofVadePlan* p) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
       // one convolution: dW[o][c][j] = sum dy[t][o] * in[t - (3-j) d][c] ; db = sum dy
-      auto conv = [&](const float* dy, const float* in, int cin, int64_t wOff, int64_t bOff) {
+      // layer = index of the BatchNorm behind this convolution (lazy dy); in_layer = index of the BatchNorm + ReLU in
+      // front of it (lazy input) or -1
+      auto conv = [&](const float* dy, const float* in, int cin, int64_t wOff, int64_t bOff, int layer, int in_layer) {
         int job = -1;
         bool bias_done = false;
         // 32 -> 32 convolutions: the partial tiles of the two jobs come from k_tcn_wgrad (LDS-staged operands)
@@ -894,7 +903,13 @@ void build_tcn_jobs(DofVadePlan* p) {
         if (staged) {
           DofTcnWgrad g;
           memset(&g, 0, sizeof(g));
-          g.dy = dy; g.in = in; g.dil = d; g.nblk = ext; g.T = T; g.Sp = Sp;
+          g.dy = dy; g.in = in; g.dil = d; g.nblk = ext; g.T = T; g.Sp = Sp; g.S = w.S;
+          if (t.lazy) {
+            g.dy_y = ws + (layer & 1 ? t.y2[layer >> 1] : t.y1[layer >> 1]);
+            g.dy_bnp = ws + t.bnp[layer];
+            g.dy_coef = ws + t.coefs[layer];
+            if (in_layer >= 0) g.in_bnp = ws + t.bnp[in_layer];
+          }
           p->js_enc.wgrads.push_back(g);
           if (ext > p->js_enc.wg_blocks) p->js_enc.wg_blocks = ext;
         }
@@ -911,8 +926,8 @@ void build_tcn_jobs(DofVadePlan* p) {
             jb.add_fin(job, tl * 16, C, nc, C, C, wOff + (int64_t)c0 * 4 + j, (int64_t)cin * 4, 4);
           }
       };
-      conv(ws + t.g1[b], b == 0 ? ws + t.xs : ws + t.out[b - 1], b == 0 ? w.F : C, o.c1w, o.c1b);
-      conv(ws + t.g2[b], ws + t.a1[b], C, o.c2w, o.c2b);
+      conv(ws + t.g1[b], b == 0 ? ws + t.xs : ws + t.out[b - 1], b == 0 ? w.F : C, o.c1w, o.c1b, 2 * b, -1);
+      conv(ws + t.g2[b], t.lazy ? ws + t.y1[b] : ws + t.a1[b], C, o.c2w, o.c2b, 2 * b + 1, 2 * b);
       if (b == 0) {  // 1x1 residual conv: A = gradient entering the residual branch of block 0 (left in dout[1])
         const int job = jb.add_job(aos(ws + t.dout[1], C, Sp), C, T, Sp);
         const int tl = jb.add_tile(job, aos(ws + t.xs, w.F, Sp), w.F, 0);
@@ -1291,8 +1306,9 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
                                 train, ws + t.bnp[2 * b], 32, st, sh1 != nullptr));
       const float* sh2 = sh ? params + o.rm2 : nullptr;
-      TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b], ws + t.a1[b],
-                              ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st, nullptr, nullptr, nullptr, sh2));
+      TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b],
+                              t.lazy ? nullptr : ws + t.a1[b], ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st,
+                              nullptr, nullptr, nullptr, sh2));
       if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh2));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
                                 train, ws + t.bnp[2 * b + 1], 32, st, sh2 != nullptr));
@@ -1574,24 +1590,27 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
       TRY(dof_launch_tcn_bn_bwd1(b == 7 ? nullptr : ws + t.dout[b & 1], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.g2[b],
                                  ws + t.partial, ws + t.sums, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip,
                                  nullptr, dprev, T, 32, w.S, w.Sp, st));
-      TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, ws + t.coef, 32, st));
+      float* coef2 = ws + (t.lazy ? t.coefs[2 * b + 1] : t.coef);
+      float* coef1 = ws + (t.lazy ? t.coefs[2 * b] : t.coef);
+      TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, coef2, 32, st));
       // conv2's data gradient with BN1 + ReLU's first backward pass in its epilogue; the time-resident kernel also
-      // applies pass 2 of BN2's backward while it stages g2 (written back in place for the weight-gradient kernel)
+      // applies pass 2 of BN2's backward while it stages g2 (lazy: the weight-gradient kernel does the same on load;
+      // otherwise written back in place for it)
       if (fuse2) {
         TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
                                        ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st, ws + t.y2[b],
-                                       ws + t.bnp[2 * b + 1], ws + t.coef));
+                                       ws + t.bnp[2 * b + 1], coef2, t.lazy ? 0 : 1));
       } else {
-        TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.coef, T, 32, w.S, w.Sp, st));
+        TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], coef2, T, 32, w.S, w.Sp, st));
         TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
                                        ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st));
       }
-      TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g1, grads + o.b1, accumulate, ws + t.coef, 32, st));
+      TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g1, grads + o.b1, accumulate, coef1, 32, st));
       if (fuse2 && b > 0) {  // pass 2 of BN1's backward inside conv1's data gradient
         TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
-                                w.Sp, st, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef));
-      } else {
-        TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], ws + t.coef, T, 32, w.S, w.Sp, st));
+                                w.Sp, st, ws + t.y1[b], ws + t.bnp[2 * b], coef1, nullptr, t.lazy ? 0 : 1));
+      } else {  // block 0's conv1 gradient goes through the generic reduction: normalised gradient in place
+        TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], coef1, T, 32, w.S, w.Sp, st));
         if (b > 0)
           TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
                                   w.Sp, st));
