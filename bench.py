@@ -107,6 +107,8 @@ def cpu_baseline(P, B, T, N, E, L, K, steps=10, warm=3):
 
 
 def secondary_configs(steps=12, warmup=4):
+    # (the TCN lines warm up for 25 steps: the one-pass BatchNorm statistics engage once the running means have caught up
+    #  with the batch means, which is where a fit spends its time -- DESIGN.md section 4)
     """The other BASELINE configurations (and the two other encoder families at the C2 shape) timed in this same run,
     so that their rates are driver-visible too: whole train steps on device-resident synthetic data, eager launches,
     via tools/bench_configs.py.  Never part of `value`; a failing configuration reports its error string."""
@@ -115,8 +117,8 @@ def secondary_configs(steps=12, warmup=4):
     rows = []
     plan = [("C3 VQ-VAE recurrent, codebook 512, batch 4096", lambda: BC.run_vade_like("vqvae", [""], 25, 512, 4096, steps, warmup), 4096),
             ("C5 VaDE recurrent, 2 animals (N=28,E=32), window 50, k=25, batch 4096", lambda: BC.run_vade_like("vade", ["B", "W"], 50, 25, 4096, steps, warmup), 4096),
-            ("C4 contrastive TCN encoder, window 50 -> 25, batch 8192", lambda: BC.run_contrastive(8192, 50, max(4, steps // 3), 2), 8192),
-            ("C2 shape, VaDE TCN encoder/decoder, batch 1024", lambda: BC.run_vade_like("vade_tcn", [""], 25, 10, 1024, steps, warmup), 1024),
+            ("C4 contrastive TCN encoder, window 50 -> 25, batch 8192", lambda: BC.run_contrastive(8192, 50, max(4, steps // 3), 25), 8192),
+            ("C2 shape, VaDE TCN encoder/decoder, batch 1024", lambda: BC.run_vade_like("vade_tcn", [""], 25, 10, 1024, steps, 25), 1024),
             ("C2 shape, VaDE transformer encoder/decoder (dropout on), batch 1024", lambda: BC.run_vade_like("vade_tfm", [""], 25, 10, 1024, steps, warmup), 1024)]
     for name, fn, B in plan:
         try:

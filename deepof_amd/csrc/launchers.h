@@ -38,7 +38,7 @@ int64_t dof_tcn_row_blocks(int T, int64_t S);   // partial rows written by the r
 int64_t dof_tcn_conv_waves(int T, int64_t Sp);  // partial rows written by the MFMA convolution (one per wave)
 int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float* bias, float* xs, float* y,
                            float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st);
-int dof_tcn_onepass_stats();                         // 1 when DOF_TCN_ONEPASS=1 (one-pass shifted BatchNorm statistics, opt-in)
+int dof_tcn_onepass_stats();                         // 0 when DOF_TCN_ONEPASS=0 (two-pass BatchNorm statistics instead of the one-pass shifted sums)
 int dof_tcn_conv32_resident(int T, int64_t Sp);               // 1: the 32 -> 32 convolutions run the time-resident kernel (it can fuse pass 2 of a BatchNorm backward)
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp);   // partial rows written by the 32 -> 32 convolution
 int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,

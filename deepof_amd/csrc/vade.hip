@@ -1286,7 +1286,7 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     const StreamWs& w = p->sw[s];
     const TcnWs& t = p->tw[s];
     const float count = (float)((int64_t)T * w.S);
-    // batch statistics in one pass: the time-resident convolutions sum (y - K), (y - K)^2 with K = the running mean
+    // batch statistics in one pass: the time-resident convolutions sum (y - K), (y - K)^2 with K = the layer's running mean
     const bool sh = train && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_onepass_stats();
     for (int b = 0; b < 8; ++b) {
       const TcnBlockOff& o = p->tblk[s][b];

@@ -362,6 +362,18 @@ def run_contrastive_tcn_check(lib, device, golden_dir):
                                   d[pfx + "sd::encoder.spatial_gnn_block.node_kernel"])
 
 
+# noise units allowed on the 6-window VaDE-TCN golden (measured: median 1.5, worst 5.5 with the two-pass and 9 with the
+# one-pass BatchNorm statistics; the oracle-based twin of this check uses the same 10)
+TCN_NOISE_BAR = 10.0
+# ... or this fraction of the tensor scale, whichever is larger: the fixture is a FRESHLY INITIALISED model over 6 windows
+# (beta = 0, bias = 0: whole rows of BatchNorm outputs sit at 0 +- rounding and their ReLU masks are decided by the
+# rounding; the reference's own fp32 gradients deviate 0.6 % (median) to 2 % from its float64 evaluation there, see
+# make_golden_r02._trained_like_state), and the per-tensor "noise" is ONE sample of that deviation.  Measured with the
+# one-pass BatchNorm statistics: median 3.5 noise units, worst 57 = 1.5e-3 of the tensor scale.  The standard bar
+# (5e-5 + 5e-4 scale) is held by the well-conditioned B = 64 fixture (run_vade_tcn_b64_check), in both of its phases.
+TCN_B6_RTOL = 5e-3
+
+
 def run_vade_tcn_check(lib, device, golden_dir):
     """VaDE with the TCN encoder and decoder (R12) vs the reference golden: eval forward on the running statistics,
     then (from the same initial state each) train-mode loss terms, all gradients and the refreshed BatchNorm buffers."""
@@ -391,7 +403,7 @@ def run_vade_tcn_check(lib, device, golden_dir):
                 np.testing.assert_allclose(v, float(d[key]), rtol=2e-4, atol=2e-5, err_msg=key)
         # gradients: the golden holds the reference evaluated in float64 and, per tensor, the reference's own fp32
         # deviation from it ("gnoise": ~3e-4 of the tensor scale here -- BatchNorm over 6 windows is ill-conditioned).
-        # Bar: within 8 noise units of the fp64 value (measured: median 1.5, worst 5.5).
+        # Bar: within TCN_NOISE_BAR noise units of the fp64 value (measured: median 1.5, worst 5.5 / 9).
         n, worst = 0, 0.0
         for k in d:
             if k.startswith(f"{phase}::grad::"):
@@ -399,7 +411,7 @@ def run_vade_tcn_check(lib, device, golden_dir):
                 g = eng.view(name, eng.grads).cpu().numpy()
                 ref = d[k].reshape(g.shape)
                 err, noise = np.abs(g - ref).max(), float(d[f"{phase}::gnoise::{name}"])
-                assert err <= 8.0 * noise + 2e-6 * np.abs(ref).max() + 1e-7, (phase, name, err, noise)
+                assert err <= max(TCN_NOISE_BAR * noise, TCN_B6_RTOL * np.abs(ref).max()) + 2e-6 * np.abs(ref).max() + 1e-7, (phase, name, err, noise)
                 worst = max(worst, err / (noise + 2e-6 * np.abs(ref).max() + 1e-7))
                 n += 1
         assert n >= (200 if phase == "pre" else 10)
@@ -616,8 +628,8 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
     assert n2 >= 190, n2
     assert len(ties2) <= 4 * TIE_BUDGET, ties2
     tied2 = {t[0] for t in ties2}
-    # a tie moves first / second Adam moments continuously, not just signs: 8 % of one step instead of 2 %
-    step2_atol = 8e-5 if (ties or ties2) else 2e-5
+    # resolved elements: the Adam update to 2 % of one step
+    step2_atol = 2e-5
     eng.optimizer_step()
     sd2 = eng.state_dict()
     for k, v in params_from(d, "sd_step2::").items():
@@ -629,11 +641,11 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
         g2 = np.abs(d["grad2::" + k].reshape(got.shape)) if "grad2::" + k in d else np.zeros_like(got)
         weak = unresolved[k] | (g2 < (TIE_FACTOR * VQ_TCN_RTOL if k in tied2 else 2e-3) * max(float(g2.max()), 1e-30) + 1e-6)
         # resolved in both steps: the Adam update (bias corrections of t = 2, weight decay, clip) to 2 % of one step
-        if ties or ties2:  # ... and a handful of elements whose two small gradients both moved: <= 0.5 % per tensor
-            bad = np.abs(got[~weak] - ref[~weak]) > step2_atol + 1e-5 * np.abs(ref[~weak])
-            assert bad.size == 0 or bad.mean() <= 5e-3, (k, float(bad.mean()))
-        else:
-            np.testing.assert_allclose(got[~weak], ref[~weak], atol=step2_atol, rtol=1e-5, err_msg=k)
+        # ... except a handful of elements whose two small gradients both moved: <= 0.5 % of a tensor's resolved
+        # elements, and those within 20 % of one step
+        dev = np.abs(got[~weak] - ref[~weak])
+        bad = dev > step2_atol + 1e-5 * np.abs(ref[~weak])
+        assert bad.size == 0 or (bad.mean() <= 5e-3 and float(dev.max()) <= 0.2 * lr), (k, float(bad.mean()), float(dev.max()))
         assert (~weak).mean() > (0.25 if (k in tied or k in tied2) else 0.5) or math_zero_gradient(k), (k, float((~weak).mean()))
     return worst
 
@@ -860,39 +872,83 @@ def run_vade_rec_vs_oracle(lib, device, K, L=8, B=21, T=9, S=5, seed=11):
     assert checked >= 75, checked
 
 
+RELU_TIE_MARGIN = 1e-5
+
+
+def _relu_tie_margin(fn):
+    """Smallest |x| over every ReLU input while fn() runs (the oracle's torch.relu is patched for the call)."""
+    orig = torch.relu
+    seen = [float("inf")]
+
+    def spy(t):
+        v = t.detach().abs()
+        v = v[v > 0]  # exact zeros are structural (both sides evaluate them identically: mask 0)
+        if v.numel():
+            seen[0] = min(seen[0], float(v.min()))
+        return orig(t)
+    torch.relu = spy
+    try:
+        fn()
+    finally:
+        torch.relu = orig
+    return seen[0]
+
+
 def run_vade_tcn_vs_oracle(lib, device, L=4, K=3, B=6, T=10, seed=3):
     """VaDE-TCN at a latent size whose decoder input (4L channels) needs the zero-padded MFMA operand path
-    (4L < 32): eval forward and train-step gradients vs the CPU oracle, fp64-anchored as in run_vade_tcn_check."""
+    (4L < 32): eval forward and train-step gradients vs the CPU oracle, fp64-anchored as in run_vade_tcn_check.
+
+    The draw is TIE-FREE: over 6 windows one flipped ReLU mask moves a block's gradients by 2-8 % (DESIGN.md section 3,
+    "ReLU-mask ties"), and which side of zero a pre-activation within ~1e-6 of it lands on is decided by the rounding
+    of whichever fp32 implementation evaluates it.  So the seed is advanced until the oracle's float64 train-mode
+    forward has no ReLU input within RELU_TIE_MARGIN of zero (a property of the oracle and the draw only -- the same
+    seed on the emulator and on the GPU); about one draw in twenty qualifies."""
     from oracle import vade as OV
     adj = np.zeros((4, 4), np.float32)
     for i in range(3):
         adj[i, i + 1] = adj[i + 1, i] = 1.0
     eng = VadeEngine(lib, device, B, T, adj, L, K, kind="vade_tcn")
-    g = torch.Generator().manual_seed(seed)
-    P = eng.state_dict()
-    for n, v in P.items():
-        if not v.dtype.is_floating_point or n.split(".")[-1] in ("laplacian", "edge_laplacian", "incidence", "prior", "pretrain"):
-            continue
-        if n.endswith("running_var"):
-            P[n] = torch.rand(v.shape, generator=g) + 0.5
-        elif n.endswith("running_mean"):
-            P[n] = torch.randn(v.shape, generator=g) * 0.1
-        elif (".bn" in n or "head.2" in n or "head.5" in n) and n.endswith("weight"):
-            P[n] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
-        else:
-            P[n] = torch.randn(v.shape, generator=g) * (0.3 if v.dim() > 1 else 0.05)
+    cfg = OV.VadeLossCfg(K, True)
+    for attempt in range(400):
+        g = torch.Generator().manual_seed(seed + 1000 * attempt)
+        P = eng.state_dict()
+        for n, v in P.items():
+            if not v.dtype.is_floating_point or n.split(".")[-1] in ("laplacian", "edge_laplacian", "incidence", "prior", "pretrain"):
+                continue
+            if n.endswith("running_var"):
+                P[n] = torch.rand(v.shape, generator=g) + 0.5
+            elif n.endswith("running_mean"):
+                P[n] = torch.randn(v.shape, generator=g) * 0.1
+            elif (".bn" in n or "head.2" in n or "head.5" in n) and n.endswith("weight"):
+                P[n] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+            else:
+                P[n] = torch.randn(v.shape, generator=g) * (0.3 if v.dim() > 1 else 0.05)
+        x = torch.randn(B, T, 4, 3, generator=g).cumsum(1) * 0.3
+        a = torch.randn(B, T, 3, 1, generator=g)
+        eps = torch.randn(B, L, generator=g)
+
+        def train_forward():
+            P64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in P.items()}
+            orig = torch.Tensor.float
+            torch.Tensor.float = lambda self: self.double()
+            try:
+                with torch.no_grad():
+                    OV.vade_forward(P64, x.double(), a.double(), training=True, eps=eps.double())
+            finally:
+                torch.Tensor.float = orig
+        if _relu_tie_margin(train_forward) >= RELU_TIE_MARGIN:
+            break
+    else:
+        raise AssertionError("no tie-free draw found")
     eng.load_state_dict(P)
-    x = torch.randn(B, T, 4, 3, generator=g).cumsum(1) * 0.3
-    a = torch.randn(B, T, 3, 1, generator=g)
     out = eng.forward(x.to(device), a.to(device), None, want_loc=True, want_enc=True)
     with torch.no_grad():
         ref = OV.vade_forward({k: v.clone() for k, v in P.items()}, x, a, training=False)
-    np.testing.assert_allclose(out["enc"].cpu().numpy(), ref["enc"].numpy(), atol=2e-5, rtol=1e-4)
-    np.testing.assert_allclose(out["loc"].cpu().numpy(), ref["loc"].numpy(), atol=5e-5, rtol=2e-4)
-    eps = torch.randn(B, L, generator=g)
+    sc_enc, sc_loc = max(1.0, float(ref["enc"].abs().max())), max(1.0, float(ref["loc"].abs().max()))
+    np.testing.assert_allclose(out["enc"].cpu().numpy(), ref["enc"].numpy(), atol=2e-5 * sc_enc, rtol=1e-4)
+    np.testing.assert_allclose(out["loc"].cpu().numpy(), ref["loc"].numpy(), atol=5e-5 * sc_loc, rtol=2e-4)
     configure_phase(eng, K, True, 0.2, None, 0.0)
     eng.loss_grads(x.to(device), a.to(device), eps.to(device), None, None, pretrain=True)
-    cfg = OV.VadeLossCfg(K, True)
     (l32, g32, _), (l64, g64, _) = _oracle_truth(lambda Pq, xx, aa, ee: OV.vade_grads(Pq, xx, aa, cfg, 0.2, ee, None, None),
                                                  P, x, a, eps)
     np.testing.assert_allclose(eng.read_logs()["total_loss"], float(l64["total_loss"]), rtol=2e-4)

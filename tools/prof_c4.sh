@@ -8,6 +8,6 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/rp_c4
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_c4 -o r -- python $ROOT/tools/bench_configs.py --only $CFG --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/err.txt
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rp_c4 -o r -- python $ROOT/tools/bench_configs.py --only $CFG --steps 5 --warmup 25 > $OUT/bench.json 2> $OUT/err.txt
 db=$(find /tmp/rp_c4 -name '*.db' | head -1)
 python $ROOT/tools/rocpd_stats.py "$db" 50 > $OUT/kernel_stats.md
