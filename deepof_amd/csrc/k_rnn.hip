@@ -784,6 +784,232 @@ __global__ void __launch_bounds__(256) k_gru16_wg_finalize(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// GRU backward (IN = 32, HID = 8: the second encoder layer of latent 8) with the weight-gradient reduction fused in,
+// the twin of k_gru16_bwd_fused.  Eight lanes own one (sequence, direction), so a wavefront holds 8 sequences x 8
+// units: lane = seq * 8 + u, i.e. MFMA row index lane & 15 = (p, u) with p = the parity of the sequence, k index
+// lane >> 4 = the sequence pair.  With A = a gate gradient of the lane's own (u, sequence) and B = an input value of
+// the lane's own sequence (column (p', u') <-> input channel 4 u' + m of tile m, or hidden unit u'), the product
+//   D[(p, u)][(p', u')] = sum_pairs g[u, 2k + p] x[4u' + m, 2k + p']
+// carries the wanted outer products in its two diagonal 8 x 8 blocks (p = p'); the off-diagonal blocks are wasted
+// matrix-pipe work that nobody waits for (15 MFMAs per step beside ~150 VALU instructions).  dG is never written
+// (92 MB per stream at batch 1024) and the generic reduction's pass over dG, the layer input and the hidden states
+// (the largest part of the step's last k_outer launch) disappears.  Per-workgroup partials [dir][nblk][GRU8_WG_FLOATS]:
+// 15 tiles of 8 x 8 (W_ih: gates r, z, n x input tiles m = 0..3; W_hh: r, z, hn) + 4 x 8 bias sums.
+// ---------------------------------------------------------------------------------------------
+#define GRU8_WG_FLOATS (15 * 64 + 4 * 8)
+__global__ void __launch_bounds__(256, 2) k_gru8_bwd_fused(
+    const float* __restrict__ X, const int* __restrict__ len, const float* __restrict__ wih0,
+    const float* __restrict__ whh0, const float* __restrict__ wih1, const float* __restrict__ whh1,
+    const float* __restrict__ O, const float* __restrict__ GS, const float* __restrict__ dHfin,
+    float* __restrict__ dX, float* __restrict__ wg_partial, int T, int64_t S, int64_t Sp) {
+  constexpr int HID = 8, IN = 32, G = 8, M = 4;
+  __shared__ float red[4][15][128];
+  __shared__ float bred[256][5];
+  // W_ih^T for the input gradient: 96 values per unit column would not fit beside the 60 accumulator registers at two
+  // waves per SIMD, so they wait in LDS ([u][j][gate][m], rows padded to 100 floats: the eight rows a ds_read_b128
+  // touches start in distinct bank groups) and are read inside the step (24 reads per step beside ~150 VALU ops)
+  __shared__ float wx[HID][100];
+  const int u = threadIdx.x & 7;
+  const int64_t s = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int dir = blockIdx.y;
+  const bool in_range = s < S;
+  const int64_t sr = in_range ? s : S - 1;  // lanes of sequences past the end read a valid row and contribute zeros
+  const float* __restrict__ wih = dir ? wih1 : wih0;
+  const float* __restrict__ whh = dir ? whh1 : whh0;
+  float tr[HID], tz[HID], tn[HID];
+#pragma unroll
+  for (int j = 0; j < HID; ++j) {
+    tr[j] = whh[j * HID + u];
+    tz[j] = whh[(HID + j) * HID + u];
+    tn[j] = whh[(2 * HID + j) * HID + u];
+  }
+  for (int e = threadIdx.x; e < HID * 96; e += 256) {
+    const int uu = e / 96, rem = e - uu * 96, j = rem / 12, gm = rem - j * 12, g = gm >> 2, m = gm & 3;
+    wx[uu][rem] = wih[(g * HID + j) * IN + M * uu + m];
+  }
+  __syncthreads();
+  const float* __restrict__ gs = GS + (int64_t)dir * T * 4 * HID * Sp;
+  float* __restrict__ dx_out = dX + (int64_t)dir * T * IN * Sp;
+  const int n = in_range ? len[s] : 0;
+  float dh = (dHfin && n > 0) ? dHfin[(int64_t)(dir * HID + u) * Sp + s] : 0.0f;
+  dof_f32x4 acc[15];
+#pragma unroll
+  for (int a = 0; a < 15; ++a) acc[a] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float sb_r = 0.0f, sb_z = 0.0f, sb_n = 0.0f, sb_h = 0.0f;
+  constexpr int PF = 3;  // loads of step - PF are issued before the arithmetic of step (see k_gru16_bwd_fused)
+  float nx_gate[PF][4], nx_hp[PF], nx_x[PF][M];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    nx_gate[d][0] = nx_gate[d][1] = nx_gate[d][2] = nx_gate[d][3] = 0.0f;
+    nx_hp[d] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) nx_x[d][m] = 0.0f;
+  }
+  auto issue_loads = [&](auto slot_c, int step) {
+    constexpr int slot = decltype(slot_c)::value;
+    if (step >= 0 && step < n) {
+      const int t = dir ? (n - 1 - step) : step;
+      const int tp = dir ? t + 1 : t - 1;
+      dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, sr), nx_gate[slot]);
+      nx_hp[slot] = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, sr)] : 0.0f;
+      dof_ld_row<4>(X + ACT(t, M * u, IN, Sp, sr), nx_x[slot]);
+    }
+  };
+  auto do_step = [&](auto slot_c, int step) {
+    constexpr int slot = decltype(slot_c)::value;
+    DOF_MEM_FENCE();  // keeps the LDS weight reads inside the step (hoisted, they would take the registers back)
+    const bool act = step < n;
+    const int t = dir ? (n - 1 - step) : step;
+    float g_r = 0.0f, g_z = 0.0f, g_n = 0.0f, g_h = 0.0f, hp = 0.0f, dht = 0.0f, z = 0.0f;
+    float xv[M] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float r = nx_gate[slot][0], zc = nx_gate[slot][1], nn = nx_gate[slot][2], ahn = nx_gate[slot][3];
+    const float hp_c = nx_hp[slot];
+    const float x_c[M] = {nx_x[slot][0], nx_x[slot][1], nx_x[slot][2], nx_x[slot][3]};
+    issue_loads(slot_c, step - PF);
+    if (act) {
+      z = zc;
+      hp = hp_c;
+#pragma unroll
+      for (int m = 0; m < M; ++m) xv[m] = x_c[m];
+      dht = dh;
+      const float dn = dht * (1.0f - z);
+      const float dz = dht * (hp - nn);
+      const float dnp = dn * (1.0f - nn * nn);
+      g_r = dnp * ahn * r * (1.0f - r);
+      g_z = dz * z * (1.0f - z);
+      g_n = dnp;
+      g_h = dnp * r;
+    }
+    // weight-gradient tiles (the time loop is wave-uniform: MFMA ignores EXEC, inactive lanes multiply zeros)
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_r, xv[m], acc[m], 0, 0, 0);
+      acc[4 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_z, xv[m], acc[4 + m], 0, 0, 0);
+      acc[8 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_n, xv[m], acc[8 + m], 0, 0, 0);
+    }
+    acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_r, hp, acc[12], 0, 0, 0);
+    acc[13] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_z, hp, acc[13], 0, 0, 0);
+    acc[14] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_h, hp, acc[14], 0, 0, 0);
+    sb_r += g_r; sb_z += g_z; sb_n += g_n; sb_h += g_h;
+    float dhp = dht * z;
+    float dx[M] = {0.0f, 0.0f, 0.0f, 0.0f};
+    dof_static_for<HID>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const float b_r = dof_gbcast<j, G>(g_r);
+      const float b_z = dof_gbcast<j, G>(g_z);
+      const float b_n = dof_gbcast<j, G>(g_n);
+      const float b_h = dof_gbcast<j, G>(g_h);
+      dhp = fmaf(tr[j], b_r, dhp);
+      dhp = fmaf(tz[j], b_z, dhp);
+      dhp = fmaf(tn[j], b_h, dhp);
+      float wr4[4], wz4[4], wn4[4];
+      dof_ld_row<4>(&wx[u][j * 12], wr4);
+      dof_ld_row<4>(&wx[u][j * 12 + 4], wz4);
+      dof_ld_row<4>(&wx[u][j * 12 + 8], wn4);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        dx[m] = fmaf(wr4[m], b_r, dx[m]);
+        dx[m] = fmaf(wz4[m], b_z, dx[m]);
+        dx[m] = fmaf(wn4[m], b_n, dx[m]);
+      }
+    });
+    if (act) {
+      dh = dhp;
+      dof_st_row<4>(dx_out + ACT(t, M * u, IN, Sp, s), dx);
+    }
+  };
+  dof_static_for<PF>([&](auto d) { issue_loads(d, T - 1 - decltype(d)::value); });
+  for (int step = T - 1; step >= 0; step -= PF) {  // wave-uniform trip count
+    dof_static_for<PF>([&](auto d) {
+      const int st = step - decltype(d)::value;
+      if (st >= 0) do_step(d, st);
+    });
+  }
+  if (in_range) {
+    const float zero4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = n; t < T; ++t) dof_st_row<4>(dx_out + ACT(t, M * u, IN, Sp, s), zero4);
+  }
+  // ---- workgroup reduction: the diagonal blocks of the 4 waves' tiles, and the bias sums
+  // D layout: lane holds rows (lane >> 4) * 4 + r4 = (p, u), column lane & 15 = (p', u')
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, pcol = col >> 3, ucol = col & 7;
+#pragma unroll
+  for (int a = 0; a < 15; ++a)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int row = (lane >> 4) * 4 + r4;
+      if ((row >> 3) == pcol) red[wave][a][(pcol * 8 + (row & 7)) * 8 + ucol] = acc[a][r4];
+    }
+  bred[threadIdx.x][0] = sb_r; bred[threadIdx.x][1] = sb_z; bred[threadIdx.x][2] = sb_n; bred[threadIdx.x][3] = sb_h;
+  __syncthreads();
+  float* __restrict__ out = wg_partial + ((int64_t)dir * gridDim.x + blockIdx.x) * GRU8_WG_FLOATS;
+  for (int e = threadIdx.x; e < 15 * 64; e += 256) {
+    const int a = e >> 6, c = e & 63;
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[w][a][c] + red[w][a][64 + c];
+    out[e] = v;
+  }
+  if (threadIdx.x < 32) {  // (gate, unit): sum over the 32 sequences of the workgroup
+    const int gate = threadIdx.x >> 3, unit = threadIdx.x & 7;
+    float acc_b = 0.0f;
+    for (int g = 0; g < 32; ++g) acc_b += bred[g * 8 + unit][gate];
+    out[15 * 64 + threadIdx.x] = acc_b;
+  }
+}
+
+// grads of the (32 -> 8) GRU layer from the per-workgroup partials [dir][nblk][GRU8_WG_FLOATS] (same slicing as
+// k_gru16_wg_finalize).  Value v < 960: tile = v / 64 (0-3: r x m, 4-7: z x m, 8-11: n x m, 12-14: hidden r, z, hn),
+// row u = (v % 64) / 8, column u' = v % 8: W_ih[gate * 8 + u][4 u' + m] or W_hh[gate * 8 + u][u'].
+static_assert(GRU8_WG_FLOATS % 8 == 0, "value groups");
+__global__ void __launch_bounds__(256) k_gru8_wg_finalize(const float* __restrict__ wg_partial, int nblk,
+                                                          float* __restrict__ g_wih0, float* __restrict__ g_whh0,
+                                                          float* __restrict__ g_bih0, float* __restrict__ g_bhh0,
+                                                          float* __restrict__ g_wih1, float* __restrict__ g_whh1,
+                                                          float* __restrict__ g_bih1, float* __restrict__ g_bhh1,
+                                                          int accumulate) {
+  constexpr int NV = 8;
+  __shared__ float red[32][NV + 1];
+  const int dir = blockIdx.y;
+  const int vi = (int)threadIdx.x & (NV - 1), slice = (int)threadIdx.x / NV;
+  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU8_WG_FLOATS + blockIdx.x * NV + vi;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int r = slice;
+  for (; r + 96 < nblk; r += 128) {
+    a0 += p[(int64_t)r * GRU8_WG_FLOATS];
+    a1 += p[(int64_t)(r + 32) * GRU8_WG_FLOATS];
+    a2 += p[(int64_t)(r + 64) * GRU8_WG_FLOATS];
+    a3 += p[(int64_t)(r + 96) * GRU8_WG_FLOATS];
+  }
+  for (; r < nblk; r += 32) a0 += p[(int64_t)r * GRU8_WG_FLOATS];
+  red[slice][vi] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x >= NV) return;
+  float val = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) val += red[k][vi];
+  const int v = blockIdx.x * NV + vi;
+  float* g_wih = dir ? g_wih1 : g_wih0;
+  float* g_whh = dir ? g_whh1 : g_whh0;
+  float* g_bih = dir ? g_bih1 : g_bih0;
+  float* g_bhh = dir ? g_bhh1 : g_bhh0;
+  if (v < 15 * 64) {
+    const int tile = v >> 6, uu = (v & 63) >> 3, uc = v & 7;
+    float* d = tile < 12 ? &g_wih[((tile >> 2) * 8 + uu) * 32 + 4 * uc + (tile & 3)]
+                         : &g_whh[((tile - 12) * 8 + uu) * 8 + uc];
+    *d = accumulate ? *d + val : val;
+  } else {
+    const int gate = (v - 15 * 64) >> 3, unit = v & 7;  // gates: r, z, n (input side), hn (hidden side)
+    float* d0 = gate < 2 ? &g_bih[gate * 8 + unit] : (gate == 2 ? &g_bih[16 + unit] : &g_bhh[16 + unit]);
+    *d0 = accumulate ? *d0 + val : val;
+    if (gate < 2) {
+      float* d1 = &g_bhh[gate * 8 + unit];
+      *d1 = accumulate ? *d1 + val : val;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm over channels (eps = 1e-3), thread = (t, s).
 // ---------------------------------------------------------------------------------------------
 template <int C>
@@ -1164,6 +1390,23 @@ int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, c
              (int)dof_cdiv(S, 16), g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6],
              g + off[7], accumulate);
   return dof_check_launch("k_gru16_wg_finalize");
+}
+
+int64_t dof_gru8_wg_floats(int64_t S) { return 2 * (int64_t)dof_cdiv(S, 32) * GRU8_WG_FLOATS; }
+
+int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
+                              const float* dHfin, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
+                              hipStream_t st) {
+  DOF_LAUNCH(k_gru8_bwd_fused, (dof_cdiv(S, 32), 2), (256), st, X, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dHfin, dX,
+             wg_partial, T, S, Sp);
+  return dof_check_launch("k_gru8_bwd_fused");
+}
+
+int dof_launch_gru8_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
+                                hipStream_t st) {
+  DOF_LAUNCH(k_gru8_wg_finalize, ((unsigned)(GRU8_WG_FLOATS / 8), 2), (256), st, wg_partial, (int)dof_cdiv(S, 32),
+             g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6], g + off[7], accumulate);
+  return dof_check_launch("k_gru8_wg_finalize");
 }
 
 int64_t dof_ln_bwd_blocks(int T, int64_t S) { return dof_cdiv((int64_t)T * S, 256); }

@@ -20,6 +20,12 @@ int dof_launch_ln_fwd(int L, int mult, const float* X, const float* gamma, const
                       int64_t S, int64_t Sp, hipStream_t st);
 // fused GRU(16,16) backward + MFMA weight-gradient accumulation (latent 8)
 int64_t dof_gru16_wg_floats(int64_t S);
+int64_t dof_gru8_wg_floats(int64_t S);
+int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
+                              const float* dHfin, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
+                              hipStream_t st);
+int dof_launch_gru8_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
+                                hipStream_t st);
 int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
                                const float* dO, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
                                hipStream_t st);

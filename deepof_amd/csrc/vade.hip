@@ -112,7 +112,7 @@ struct StreamWs {  // float offsets into the workspace
   int64_t xs, c, len, o1, g1, n1, o2, g2, hf, n2;
   int64_t dn2, dhf, dn1x, do1, dc;
   int64_t dots, Y, Z, dZ, dY, dd;
-  int64_t ln1p, ln2p, wg1;
+  int64_t ln1p, ln2p, wg1, wg2;
   int64_t ln1_blocks, ln2_blocks;
   // device triplet tables (int offsets are in floats too; tables are 4-byte entries)
   int64_t tri_r[5], tri_m[5], tri_o[5];  // ptr, m, o, r, coef for by-r / by-m / by-o orderings
@@ -642,6 +642,7 @@ void build_workspace_layout(DofVadePlan* p) {
     w.ln1p = cv.take(w.ln1_blocks * 8 * L);
     w.ln2p = cv.take(w.ln2_blocks * 4 * L);
     w.wg1 = cv.take(L == 8 ? dof_gru16_wg_floats(w.S) : 0);
+    w.wg2 = cv.take(L == 8 ? dof_gru8_wg_floats(w.S) : 0);
     take_triplets(p, cv, s);
   }
   const int64_t Bp = p->Bp;
@@ -877,6 +878,16 @@ void head_jobs(DofVadePlan* p, JobBuilder& jb) {
 
 const int kTcnDil[8] = {1, 2, 4, 8, 1, 2, 4, 8};
 
+// DOF_GRU8_FUSED=0 in the environment keeps the second encoder GRU's weight gradients in the generic reduction
+// (A/B measurements of k_gru8_bwd_fused)
+bool gru8_fused() {
+  static const bool on = [] {
+    const char* e = getenv("DOF_GRU8_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 void build_tcn_jobs(DofVadePlan* p) {
   const int L = p->L, T = p->T, C = 32;
   float* ws = p->ws;
@@ -1046,7 +1057,7 @@ void build_jobs(DofVadePlan* p) {
         }
       }
       if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1, L == 8);  // L == 8: fused in k_gru16_bwd_fused
-      gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8);
+      if (L != 8 || !gru8_fused()) gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8);  // else: fused in k_gru8_bwd_fused
       cens_jobs(p, jb, s);
     }
     // final dense (L,J): A = flat rows (<=64 per job), B = denc
@@ -1632,7 +1643,13 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     const BlockOff& b = p->blk[s];
     const int* len = reinterpret_cast<const int*>(ws + w.len);
     TRY(dof_launch_ln_bwd(L, 2, ws + w.hf, ws + w.dn2, nullptr, params + b.n2w, ws + w.dhf, ws + w.ln2p, 1, w.S, w.Sp, st));
-    TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
+    if (L == 8 && gru8_fused()) {
+      TRY(dof_launch_gru8_bwd_fused(ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, ws + w.dhf, ws + w.dn1x,
+                                    ws + w.wg2, T, w.S, w.Sp, st));
+      TRY(dof_launch_gru8_wg_finalize(ws + w.wg2, w.S, grads, b.g2.t, accumulate, st));
+    } else {
+      TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
+    }
     TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
                           ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
     if (L == 8) {
