@@ -1,6 +1,8 @@
 """Parity of the HIP path on a real MI355X (through the C ABI) against the reference golden fixtures
 and the CPU oracle.  Tolerances: fp32 everywhere; 1e-5 abs / 1e-4 rel on activations, 5e-5 / 5e-4 on
 gradients (fp32 reduction-order differences between oneDNN/ATen and the SoA kernels)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1111,3 +1113,39 @@ def test_step_begin_noise_gpu(hip):
     assert not torch.equal(second, third) and not torch.equal(first, second)
     x = third.double()
     assert abs(float(x.mean())) < 0.01 and abs(float(x.var()) - 1.0) < 0.01
+
+
+def test_tcn_onepass_statistics_gpu():
+    """The one-pass (shifted) BatchNorm statistics of the time-resident TCN convolutions against the centred second pass:
+    the same train step (running means set to the batch means, so the one-pass form is taken for every channel) in two
+    processes, DOF_TCN_ONEPASS unset / = 0 (the switch is read once per process)."""
+    import json
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tcn_onepass_probe.py")
+
+    def run(env_extra):
+        env = dict(os.environ)
+        env.pop("DOF_TCN_ONEPASS", None)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("PROBE ")][-1]
+        return json.loads(line[len("PROBE "):])
+
+    one, two = run({}), run({"DOF_TCN_ONEPASS": "0"})
+    for k, v in two["logs"].items():
+        np.testing.assert_allclose(one["logs"][k], v, rtol=2e-5, atol=1e-6, err_msg=k)
+    for n, v in two["rvar"].items():
+        np.testing.assert_allclose(one["rvar"][n], v, rtol=2e-6, atol=1e-7, err_msg=n)
+    assert len(two["grads"]) > 150
+    worst = 0.0
+    for n, (amax, ssum, ssq) in two["grads"].items():
+        a1, s1, q1 = one["grads"][n]
+        if n.endswith(("conv1.bias", "conv2.bias", "fc0.bias")):   # mathematically zero: rounding noise on both sides
+            continue
+        np.testing.assert_allclose(a1, amax, rtol=5e-4, atol=5e-6, err_msg=n)
+        np.testing.assert_allclose(q1, ssq, rtol=1e-3, atol=1e-10, err_msg=n)
+        worst = max(worst, abs(q1 - ssq) / max(ssq, 1e-30))
+    print("worst relative change of a gradient's squared norm:", worst)
+
