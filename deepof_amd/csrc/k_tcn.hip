@@ -409,18 +409,22 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     }
     __syncthreads();
   }
-  // per-wavefront channel sums: partial[wave][64] = (sum | second sum); a wavefront covers one channel half only
+  // channel sums of the workgroup: partial[workgroup][64] = (sum | second sum).  A wavefront covers one channel half
+  // (ct) and one time parity; the two wavefronts of a half are added through LDS in a fixed order.
   if ((!REVERSE || FUSE_BN) && A.partial) {
-    float* p = A.partial + (int64_t)(blockIdx.x * 4 + wv) * 2 * TC;
+    float* wsum = reinterpret_cast<float*>(tile);  // [wavefront][32]: (sum 16 | second sum 16) of its channel half
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float a1 = dof_row16_sum(s1[r]), a2 = dof_row16_sum(s2[r]);
       if (i == 0) {
-        p[ct * 16 + kk * 4 + r] = a1;
-        p[TC + ct * 16 + kk * 4 + r] = a2;
-        p[(ct ^ 1) * 16 + kk * 4 + r] = 0.0f;
-        p[TC + (ct ^ 1) * 16 + kk * 4 + r] = 0.0f;
+        wsum[wv * 32 + kk * 4 + r] = a1;
+        wsum[wv * 32 + 16 + kk * 4 + r] = a2;
       }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * TC) {  // value v = which * 32 + channel; channel half ct = wavefronts ct and ct + 2
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31, h = c >> 4, cl = c & 15;
+      A.partial[(int64_t)blockIdx.x * 2 * TC + threadIdx.x] = wsum[h * 32 + which * 16 + cl] + wsum[(h + 2) * 32 + which * 16 + cl];
     }
   }
 }
@@ -1087,7 +1091,7 @@ int dof_tcn_onepass_stats() {
 }
 int dof_tcn_conv32_resident(int T, int64_t Sp) { return tct_fits(T, Sp) ? 1 : 0; }
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
-  return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(Sp) * 4 : dof_tcn_conv_waves(T, Sp);
+  return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(Sp) : dof_tcn_conv_waves(T, Sp);
 }
 
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
@@ -1155,7 +1159,7 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
       DOF_LAUNCH((k_tcn_conv_t<true, false, true, false>), (nbt), (256), st, A);
     }
     if (int rc = dof_check_launch("k_tcn_conv_t_bwd_bn")) return rc;
-    return dof_launch_sum_partials(partial, (int64_t)nbt * 4, 2 * TC, sums, 0, st);
+    return dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st);
   }
   if (bwd_y) {
     dof_set_error("k_tcn_conv_bwd_bn: the fused BatchNorm-backward pass needs the time-resident kernel (T <= %d)", TCT_T);
