@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -96,6 +96,7 @@ SIGNATURES = {
     "dof_tfm_dropout_site_numel": (_I64, [_P, _I32]),
     "dof_tfm_dropout_site_p": (C.c_float, [_P, _I32]),
     "dof_tfm_set_dropout": (C.c_int, [_P, _P, C.c_uint32]),
+    "dof_tfm_set_dropout_counter": (C.c_int, [_P, _P]),
     "dof_vade_plan_destroy": (None, [_P]),
     "dof_vade_param_count": (_I32, [_P]),
     "dof_vade_param_name": (C.c_char_p, [_P, _I32]),

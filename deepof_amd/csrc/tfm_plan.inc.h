@@ -118,7 +118,7 @@ DofDrop tfm_drop(const DofVadePlan* p, int site, bool active) {
   if (!active) return d;
   const TfmSite& s = tf.sites[site];
   d.inject = tf.inject ? tf.inject + s.offset : nullptr;
-  d.ctr = reinterpret_cast<const uint32_t*>(p->ws + tf.ctr);
+  d.ctr = tf.ext_ctr ? tf.ext_ctr : reinterpret_cast<const uint32_t*>(p->ws + tf.ctr);
   d.seed = (tf.seed ^ 0x9E3779B9u) * (2654435761u + 2u * (uint32_t)site);
   d.thresh = (uint32_t)((double)s.p * 4294967296.0);
   d.scale = 1.0f / (1.0f - s.p);
@@ -336,7 +336,7 @@ int tfm_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
   const int T = p->T, D = tf.D, DFF = tf.DFF;
   const bool keep = train;
   train = train && p->bn_training;
-  if (train) TRY(dof_launch_tfm_tick(reinterpret_cast<uint32_t*>(ws + tf.ctr), st));
+  if (train) TRY(dof_launch_tfm_tick(tf.ext_ctr ? tf.ext_ctr : reinterpret_cast<uint32_t*>(ws + tf.ctr), st));
   (void)keep;
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];

@@ -145,6 +145,7 @@ struct TfmPlan {
   TfmDecWs dw;
   int64_t pe_enc = 0, pe_dec = 0, ctr = 0, enc_pre = 0, denc_pre = 0, bstat = 0;
   const uint8_t* inject = nullptr;  // injected keep-masks (device), sites in dof_tfm_dropout_site_* order
+  uint32_t* ext_ctr = nullptr;      // caller-owned step counter shared by the plans of one model (else ws + ctr)
   uint32_t seed = 0x2545F491u;
   std::vector<TfmSite> sites;
   bool dec_second = false;      // the last decoder forward was the VQ-VAE's pass on the raw encoder output
@@ -1807,6 +1808,15 @@ extern "C" int dof_tfm_set_dropout(DofVadePlan* p, const uint8_t* inject_masks, 
   }
   p->tf.inject = inject_masks;
   p->tf.seed = seed;
+  return DOF_OK;
+}
+
+extern "C" int dof_tfm_set_dropout_counter(DofVadePlan* p, uint32_t* device_counter) {
+  if (!p || !p->tfm) {
+    dof_set_error("dof_tfm_set_dropout_counter: not a transformer plan");
+    return DOF_ERR_ARG;
+  }
+  p->tf.ext_ctr = device_counter;
   return DOF_OK;
 }
 

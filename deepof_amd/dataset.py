@@ -102,6 +102,32 @@ def n_batches(n_samples: int, batch_size: int, world_size: int = 1, drop_last: b
     return total
 
 
+def _frame_table_of(windows: np.ndarray, stride: Optional[int] = None, chunk: int = 8192):
+    """(table, stride) if ``windows`` (n, W, C) are the stride-s sliding windows of one (frames, C) table -- every element
+    of every window is compared with the window before it (NaN == NaN), no sampling -- else None.  ``stride``: the step
+    to test (default: the smallest s in 1 .. W for which windows 0 and 1 overlap)."""
+    n, W = windows.shape[0], windows.shape[1]
+    if n == 0 or windows.ndim != 3:
+        return None
+    if n == 1:
+        return windows[0], (stride or 1)
+
+    def same(p, q):
+        return bool(np.array_equal(p, q, equal_nan=True)) if p.dtype.kind == "f" else bool(np.array_equal(p, q))
+
+    if stride is None:
+        stride = next((s for s in range(1, W + 1) if s == W or same(windows[1, : W - s], windows[0, s:])), None)
+    if stride is None or stride > W:
+        return None
+    if stride < W:
+        for lo in range(1, n, chunk):
+            hi = min(n, lo + chunk)
+            if not same(windows[lo:hi, : W - stride], windows[lo - 1:hi - 1, stride:]):
+                return None
+    tail = windows[1:, W - min(stride, W):, :].reshape(-1, windows.shape[2])
+    return np.concatenate([windows[0], tail], axis=0), stride
+
+
 class WindowDataset:
     """All windows of a ``{video_key: (nodes (n,W,3N), edges (n,W,E), angles)}`` dict, resident on ``device``.
 
@@ -126,20 +152,59 @@ class WindowDataset:
 
     # ---- construction ----------------------------------------------------------------------
     @classmethod
-    def from_preprocessed(cls, preprocessed: Dict, device) -> "WindowDataset":
+    def from_preprocessed(cls, preprocessed: Dict, device, lib=None) -> "WindowDataset":
+        """The reference's input format: ``{video: (node windows (n,W,3N), edge windows (n,W,E)[, angle windows])}``.
+
+        With ``lib`` (the HIP library) the W-fold redundant windows are NOT uploaded: they are stride-s sliding windows
+        over a frame table (``rolling_window``, /root/reference/deepof/utils.py:3354-3377), so the table is rebuilt
+        from them on the host -- window 0 plus the last s rows of every later window -- after checking, exactly and
+        over every element, that the windows really overlap that way (``_frame_table_of``), and batches come from
+        ``dof_window_gather`` like those of ``from_tables`` (bit-identical to the materialised form; 1/W of the bytes
+        cross PCIe and stay in HBM).  If any video is not a regular sliding-window set (shuffled windows, a hand-made
+        array) the materialised form below is used."""
         ds = cls(device)
-        xs, as_, vid, angs = [], [], [], []
-        for i, key in enumerate(preprocessed.keys()):
+        keys = list(preprocessed.keys())
+        angs = []
+        for key in keys:
+            if len(preprocessed[key]) > 2 and preprocessed[key][2] is not None:
+                angs.append(np.asarray(preprocessed[key][2], dtype=np.float32))
+        # angle windows (n, W, A): host-resident, only the teacher's optional angle view reads them (dataset.py:81-92)
+        ds.angles = np.concatenate(angs) if len(angs) == len(keys) and angs and angs[0].shape[-1] > 0 else None
+        if lib is not None:
+            rebuilt = []
+            for key in keys:
+                nodes, edges = np.asarray(preprocessed[key][0]), np.asarray(preprocessed[key][1])
+                nt = _frame_table_of(nodes)
+                et = _frame_table_of(edges, stride=None if nt is None else nt[1]) if nt is not None else None
+                if nt is None or et is None or nt[1] != et[1]:
+                    rebuilt = None
+                    break
+                rebuilt.append((nt[0], et[0], nt[1], nodes.shape[0], nodes.shape[1]))
+            if rebuilt is not None and len({r[4] for r in rebuilt}) == 1:
+                ds._lib = lib
+                starts, vid, off = [], [], 0
+                for i, (nt, et, stride, n, _w) in enumerate(rebuilt):
+                    starts.append(off + np.arange(n, dtype=np.int64) * stride)
+                    vid.append(np.full(n, i, dtype=np.int32))
+                    off += nt.shape[0]
+                W = rebuilt[0][4]
+                ds.node_table = torch.from_numpy(np.concatenate([r[0] for r in rebuilt]).astype(np.float32)).to(ds.device)
+                ds.edge_table = torch.from_numpy(np.concatenate([r[1] for r in rebuilt]).astype(np.float32)).to(ds.device)
+                ds.row_start = torch.from_numpy(np.concatenate(starts)).to(ds.device)
+                ds.video_idx = np.concatenate(vid)
+                ds.keys = keys
+                ds.length = int(ds.row_start.numel())
+                ds.x_shape = (W, ds.node_table.shape[1] // 3, 3)
+                ds.a_shape = (W, ds.edge_table.shape[1], 1)
+                return ds
+        xs, as_, vid = [], [], []
+        for i, key in enumerate(keys):
             nodes, edges = preprocessed[key][0], preprocessed[key][1]
             nodes, edges = np.asarray(nodes), np.asarray(edges)
             xs.append(reorder_and_reshape(nodes).astype(np.float32))
             as_.append(np.expand_dims(edges, -1).astype(np.float32))
             vid.append(np.full(nodes.shape[0], i, dtype=np.int32))
-            if len(preprocessed[key]) > 2 and preprocessed[key][2] is not None:
-                angs.append(np.asarray(preprocessed[key][2], dtype=np.float32))
             ds.keys.append(key)
-        # angle windows (n, W, A): host-resident, only the teacher's optional angle view reads them (dataset.py:81-92)
-        ds.angles = np.concatenate(angs) if len(angs) == len(xs) and angs and angs[0].shape[-1] > 0 else None
         x, a = np.concatenate(xs), np.concatenate(as_)
         ds.x = torch.from_numpy(x).to(ds.device)
         ds.a = torch.from_numpy(a).to(ds.device)

@@ -219,6 +219,15 @@ class VadeEngine:
         _capi.check(self.lib, self.lib.dof_tfm_set_dropout(self.plan, None if inject is None else inject.data_ptr(),
                                                            int(seed) & 0xFFFFFFFF), "dof_tfm_set_dropout")
 
+    def set_dropout_counter(self, counter: Optional[torch.Tensor]):
+        """Point a transformer plan at a caller-owned device step counter (int32 tensor of one element) shared by all
+        plans of a model; None returns to the plan's own workspace slot."""
+        if counter is not None:
+            assert counter.dtype == torch.int32 and counter.numel() == 1 and counter.device.type == self.device.type
+        self._drop_counter = counter
+        _capi.check(self.lib, self.lib.dof_tfm_set_dropout_counter(self.plan, None if counter is None else counter.data_ptr()),
+                    "dof_tfm_set_dropout_counter")
+
     def _count_bn(self, prefix: str, n: int):
         """num_batches_tracked of the BatchNorm layers under ``prefix`` after n train-mode passes."""
         if not self.bn_training:

@@ -211,9 +211,16 @@ class VaDE(nn.Module):
                             latent_dim=self.latent_dim, n_clusters=self.n_components, shared=shared, kind=self._KIND)
         if getattr(self, "_family", "") == "transformer":
             # dropout masks: counter hash on the device, seeded from torch's generator (torch.manual_seed reproduces a run)
+            # Every plan of the model (base, other batch sizes, the augmented-view plans) gets its own seed AND all of
+            # them read ONE device step counter that each train-mode forward advances: the two contrastive views and the
+            # ragged last batch draw masks no other forward of the run has used, as the reference's F.dropout calls do.
             if not hasattr(self, "_dropout_seed"):
                 self._dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-            eng.set_dropout(None, seed=self._dropout_seed + 7919 * len(getattr(self, "_engines", {})))
+                self._dropout_plans = 0
+                self._dropout_counter = torch.zeros(1, dtype=torch.int32, device=eng.device)
+            eng.set_dropout(None, seed=self._dropout_seed + 7919 * self._dropout_plans)
+            eng.set_dropout_counter(self._dropout_counter)
+            self._dropout_plans += 1
         if getattr(self, "_tcn", False):
             eng.set_bn_training(self.training)
             if not getattr(self, "censnet_in_optimizer", False):

@@ -61,6 +61,15 @@ class WeightSchedule:
         self.max_weight = float(max_weight)
         self.position = 0
 
+    @classmethod
+    def constant(cls, value: float) -> "WeightSchedule":
+        """One-entry table: ``value`` from iteration 0 on (no ramp; ``weight_table`` clamps a warm-up to >= 1 step)."""
+        self = cls.__new__(cls)
+        self.table = np.array([float(value)], dtype=np.float64)
+        self.max_weight = float(value)
+        self.position = 0
+        return self
+
     def at(self, iteration: int) -> float:
         return float(self.table[min(int(iteration), len(self.table) - 1)])
 

@@ -55,9 +55,8 @@ class DeviceSchedule:
 
 
 def constant_schedule(value: float, device) -> DeviceSchedule:
-    """A one-entry table: a fixed weight that still goes through dof_schedule_apply."""
-    return DeviceSchedule(WeightSchedule(1, mode="linear", warmup_epochs=0, max_weight=value, at_max_epochs=0,
-                                         cooldown_epochs=0, end_weight=value), device)
+    """A one-entry table: a fixed weight, in force from the first step, that still goes through dof_schedule_apply."""
+    return DeviceSchedule(WeightSchedule.constant(value), device)
 
 
 class StepGraphs:
@@ -70,13 +69,24 @@ class StepGraphs:
         self.enabled = bool(enabled)
         self._seen = set()
         self._graphs: Dict[Hashable, "torch.cuda.CUDAGraph"] = {}
+        self._slot_key: Dict[Hashable, Hashable] = {}
         self._pool = None
         self.replays = 0
 
-    def run(self, key: Hashable, body: Callable[[], None]) -> None:
+    def run(self, key: Hashable, body: Callable[[], None], slot: Hashable = None) -> None:
+        """``slot``: the part of ``key`` that names the step variant (batch size, phase, train / val ...); the rest of
+        the key names the objects the captured body points at (schedule tables ...).  When a slot is run under a new
+        key -- a schedule was replaced, the teacher refreshed -- the graph captured under its previous key can never
+        be replayed again and is dropped with its pool memory: one live graph per slot."""
         if not self.enabled:
             body()
             return
+        if slot is not None:
+            old = self._slot_key.get(slot)
+            if old is not None and old != key:
+                self._graphs.pop(old, None)
+                self._seen.discard(old)
+            self._slot_key[slot] = key
         g = self._graphs.get(key)
         if g is None:
             if key not in self._seen:  # first occurrence: eager (loads code objects, builds lazily created plans)
@@ -96,3 +106,4 @@ class StepGraphs:
     def clear(self) -> None:
         self._graphs.clear()
         self._seen.clear()
+        self._slot_key.clear()

@@ -26,6 +26,7 @@ from .dataset import WindowDataset, n_batches
 from .models import Contrastive, VaDE, VQVAE
 from .schedules import WeightSchedule
 from .stepping import DeviceSchedule, StepGraphs, constant_schedule
+from .tb_log import log_epoch_to_tensorboard, open_writer
 
 LOG_SUMMARY_KEYS = ("total_loss", "reconstruction_loss", "kl_divergence", "cat_cluster_loss", "kmeans_loss",
                     "distill_loss", "temporal_loss", "scatter_loss", "nonempty_loss", "repel_loss", "tf_cluster_loss",
@@ -57,12 +58,34 @@ def ddp_init_if_needed(backend: str = "nccl"):
     return True, dist.get_rank(), dist.get_world_size(), local_rank
 
 
+TB_WRITER = None  # the running fit's event-file writer (deepof_amd.tb_log), set by train_deepof_model_base
+
+
 def _dist_state():
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized():
         return dist, dist.get_rank(), dist.get_world_size()
     return None, 0, 1
+
+
+def _dp_step(graphs, key, slot, forward_backward, eng, dist, world: int):
+    """The data-parallel step: [gather + loss + gradients] -> ONE all-reduce (SUM) of the flat gradient over RCCL ->
+    [clip + Adam with grad_scale 1 / world].  The collective is enqueued by torch.distributed on RCCL's own stream and
+    the step's stream waits for it on the device (an event, not the host): the host never blocks inside a step.
+    Default: two captured graphs around the eagerly enqueued collective.  DOF_DP_ONE_GRAPH=1 captures the collective
+    too -- the whole step is one hipGraph replay (RCCL kernels are capturable)."""
+    scale = 1.0 / world
+    if os.environ.get("DOF_DP_ONE_GRAPH", "0") == "1":
+        def whole():
+            forward_backward()
+            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+            eng.optimizer_step(scale)
+        graphs.run(key + ("dp",), whole, None if slot is None else slot + ("dp",))
+        return
+    graphs.run(key + ("grads",), forward_backward, None if slot is None else slot + ("grads",))
+    dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+    graphs.run((eng.B, world, "adam"), lambda: eng.optimizer_step(scale))
 
 
 def _dp_active(dist, world: int) -> bool:
@@ -139,8 +162,9 @@ def load_model_from_ckpt(path: str, device=None, _engine_factory=None):
     if not isinstance(bundle, dict) or "state_dict" not in bundle or "rebuild_spec" not in bundle:
         raise RuntimeError(f"{path} is not a model bundle with state_dict + rebuild_spec")
     model = build_model_from_spec(bundle["rebuild_spec"], device=device, _engine_factory=_engine_factory)
-    report = model.load_state_dict(bundle["state_dict"], strict=False)
+    rep = model.load_state_dict(bundle["state_dict"], strict=False)
     model.eval()
+    report = {"missing": list(rep.missing_keys), "unexpected": list(rep.unexpected_keys)}   # as the reference reports
     return model, bundle.get("log_summary"), bundle["rebuild_spec"], report
 
 
@@ -290,7 +314,6 @@ class VadeStepper:
         self._buffers: Dict[int, SimpleNamespace] = {}
         self.log_sum = torch.zeros(_capi.LOG_COUNT, dtype=torch.float64, device=model.device)
         self.log_steps = 0
-        self._teacher_version = 0
         # Parity tests replay reference runs with recorded noise: noise_fn(kind, index, shape) -> tensor supplies the
         # reparameterisation noise ("eps_train") and the Monte-Carlo KL samples ("mc_train" / "mc_val") instead of the
         # device generator (such steps are launched eagerly)
@@ -328,7 +351,6 @@ class VadeStepper:
         without one, the constant ``lambda_distill``."""
         eng = self.model._base
         self.tau_star = tau_star
-        self._teacher_version += 1
         if tau_star is None:
             self.lambda_scheduler = None
             eng.set_teacher(None, None)
@@ -397,19 +419,20 @@ class VadeStepper:
                                self._noise_seed, self._rng_state)
             eng.loss_grads(st.x, st.a, eps, eps_mc, st.tau if use_tau else None, pretrain=pretrain, count=False)
 
-        key = (eng.B, pretrain, train, use_tau, kl.uid, getattr(self.lambda_scheduler, "uid", 0), self._teacher_version,
-               self.model.training, inject)
+        # slot = which step variant; key = slot + the schedule objects whose tables / cursors the captured body points
+        # at.  tau*, the class weights and the teacher marginal are written in place into static buffers, so a teacher
+        # refresh needs no new graph; a replaced schedule does, and StepGraphs drops the slot's previous graph then.
+        slot = (eng.B, pretrain, train, use_tau, self.model.training, inject)
+        key = slot + (kl.uid, getattr(self.lambda_scheduler, "uid", 0))
         if not train:
-            self.graphs.run(key + ("val",), forward_backward)
+            self.graphs.run(key + ("val",), forward_backward, slot + ("val",))
         elif _dp_active(dist, world):
-            self.graphs.run(key + ("grads",), forward_backward)
-            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
-            self.graphs.run((eng.B, world, "adam"), lambda: eng.optimizer_step(1.0 / world))
+            _dp_step(self.graphs, key, slot, forward_backward, eng, dist, world)
         else:
             def whole():
                 forward_backward()
                 eng.optimizer_step()
-            self.graphs.run(key + ("train",), whole)
+            self.graphs.run(key + ("train",), whole, slot + ("train",))
         eng._count_bn("", 1)
         self.log_steps += 1
         if train:
@@ -562,7 +585,9 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
                                                          end_weight=vade_cfg.kl_end_weight_pretrain), eng.device)
     eng.push_hyper()
     for _ep in range(vade_cfg.pretrain_epochs):
-        stepper.train_epoch(train_ds, common_cfg.seed, shuffle)
+        pre_logs, _klw, _lam = stepper.train_epoch(train_ds, common_cfg.seed, shuffle)
+        if TB_WRITER is not None:   # (training.py:1635-1636)
+            TB_WRITER.add_scalar("Pretrain/total_loss", pre_logs["total_loss"], _ep)
 
     # ---- main phase
     model.set_pretrain_mode(False)
@@ -668,6 +693,7 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
         val_total = float(val_logs.get("total_loss", float("inf")))
         score_value = float(val_logs["alignment_score"])
         log_summary = _update_log_summary(log_summary, train_logs, val_logs)
+        log_epoch_to_tensorboard(TB_WRITER, train_logs, val_logs, epoch, score_value)   # (training.py:1838)
         if is_main:
             print(f"Epoch {epoch + 1}/{common_cfg.epochs} | KLw={klw:.3f} | lambda_distill={lambda_d:.3f} | "
                   f"train total={train_logs['total_loss']:.4f} recon={train_logs['reconstruct_loss']:.4f} | "
@@ -685,6 +711,55 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
                                 val_total=val_total, score_value=score_value, **common_info)
     model_val, model_score = load_best_checkpoints(model, best_path_val, best_path_score, common_cfg.save_weights)
     return model_val, model_score, teacher_init_model, log_summary
+
+
+class VQVAEStepper:
+    """One step of the VQ-VAE fit loop (step_vqvae_distill, training.py:312-389 of the reference, + clip + Adam) on
+    windows [s, e) of a device-resident dataset: fetch into static buffers, then [distillation-weight schedule ->
+    dof_vqvae_loss_grads -> log sum -> optimiser] replayed as one hipGraph per (batch size, train / val, teacher)."""
+
+    def __init__(self, model, use_graphs: Optional[bool] = None):
+        self.model = model
+        self.graphs = StepGraphs(model._base.device, use_graphs)
+        self._buffers: Dict[int, SimpleNamespace] = {}
+
+    def _static(self, e) -> SimpleNamespace:
+        b = self._buffers.get(e.B)
+        if b is None:
+            f32 = dict(dtype=torch.float32, device=e.device)
+            b = self._buffers[e.B] = SimpleNamespace(x=torch.empty(e.B, e.T, e.N, 3, **f32),
+                                                     a=torch.empty(e.B, e.T, e.E, 1, **f32),
+                                                     tau=torch.empty(e.B, e.K, **f32))
+        return b
+
+    def step(self, ds: WindowDataset, s0: int, e0: int, train: bool, tau_star, lambda_scheduler, log_sum):
+        dist, rank, world = _dist_state()
+        e = self.model.engine(e0 - s0)
+        st = self._static(e)
+        ds.fetch(s0, e0, out=(st.x, st.a))
+        lam = float(lambda_scheduler.get_weight()) if (train and lambda_scheduler is not None) else 0.0
+        use_tau = train and tau_star is not None and lam > 0.0
+        if use_tau:
+            st.tau.copy_(tau_star[s0:e0])
+        items = [] if lambda_scheduler is None else \
+            [(lambda_scheduler, _capi.H_LAMBDA_DISTILL, train, 1.0 if use_tau else 0.0)]
+
+        def forward_backward():
+            e.schedule_apply(items)
+            e.vq_loss_grads(st.x, st.a, st.tau if use_tau else None, count=False)
+            log_sum.add_(e.logs)
+
+        key = (e.B, train, use_tau)
+        if not train:
+            self.graphs.run(key + ("val",), forward_backward)
+        elif _dp_active(dist, world):
+            _dp_step(self.graphs, key, None, forward_backward, e, dist, world)
+        else:
+            def whole():
+                forward_backward()
+                e.optimizer_step()
+            self.graphs.run(key + ("train",), whole)
+        e.count_vq_step()
 
 
 def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
@@ -719,17 +794,8 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
     keys = ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss", "kmeans_loss",
             "number_of_populated_clusters", "distill_loss")
 
-    graphs = StepGraphs(eng.device)
+    stepper = VQVAEStepper(model)
     log_sum = torch.zeros(_capi.LOG_COUNT, dtype=torch.float64, device=eng.device)
-    buffers: Dict[int, SimpleNamespace] = {}
-
-    def static(e):
-        b = buffers.get(e.B)
-        if b is None:
-            f32 = dict(dtype=torch.float32, device=e.device)
-            b = buffers[e.B] = SimpleNamespace(x=torch.empty(e.B, e.T, e.N, 3, **f32), a=torch.empty(e.B, e.T, e.E, 1, **f32),
-                                               tau=torch.empty(e.B, e.K, **f32))
-        return b
 
     def run_epoch(ds, train):
         """One pass; every step = [schedule -> dof_vqvae_loss_grads -> log sum -> optimiser] replayed as a hipGraph."""
@@ -739,34 +805,7 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
         ranges = ds.iter_ranges(common_cfg.batch_size, train and shuffle, common_cfg.seed if train else None,
                                 world if train else 1, rank if train else 0)
         for s0, e0 in ranges:
-            e = model.engine(e0 - s0)
-            st = static(e)
-            ds.fetch(s0, e0, out=(st.x, st.a))
-            lam = float(lambda_scheduler.get_weight()) if (train and lambda_scheduler is not None) else 0.0
-            use_tau = train and tau_star is not None and lam > 0.0
-            if use_tau:
-                st.tau.copy_(tau_star[s0:e0])
-            items = [] if lambda_scheduler is None else \
-                [(lambda_scheduler, _capi.H_LAMBDA_DISTILL, train, 1.0 if use_tau else 0.0)]
-
-            def forward_backward():
-                e.schedule_apply(items)
-                e.vq_loss_grads(st.x, st.a, st.tau if use_tau else None, count=False)
-                log_sum.add_(e.logs)
-
-            key = (e.B, train, use_tau)
-            if not train:
-                graphs.run(key + ("val",), forward_backward)
-            elif _dp_active(dist, world):
-                graphs.run(key + ("grads",), forward_backward)
-                dist.all_reduce(e.grads, op=dist.ReduceOp.SUM)
-                graphs.run((e.B, "adam"), lambda: e.optimizer_step(1.0 / world))
-            else:
-                def whole():
-                    forward_backward()
-                    e.optimizer_step()
-                graphs.run(key + ("train",), whole)
-            e.count_vq_step()
+            stepper.step(ds, s0, e0, train, tau_star, lambda_scheduler, log_sum)
             n_steps += 1
             if train and lambda_scheduler is not None:
                 lambda_scheduler.step()
@@ -793,6 +832,8 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
         v_total = float(val_logs["total_loss"])
         score_value = float(val_logs["alignment_score"])
         log_summary = _update_log_summary(log_summary, train_logs, val_logs)
+        log_epoch_to_tensorboard(TB_WRITER, train_logs, val_logs, epoch, score_value,
+                                 float(lambda_scheduler.get_weight()) if lambda_scheduler is not None else 0.0)
         if is_main:
             print(f"Epoch {epoch + 1}/{common_cfg.epochs} | train total={train_logs['total_loss']:.4f} "
                   f"recon={train_logs['reconstruct_loss']:.4f} codes={train_logs['number_of_populated_clusters']:.1f} "
@@ -952,9 +993,7 @@ class ContrastiveStepper:
         if not train:
             self.graphs.run(key + ("val",), forward_backward)
         elif _dp_active(dist, world):
-            self.graphs.run(key + ("grads",), forward_backward)
-            dist.all_reduce(e1.grads, op=dist.ReduceOp.SUM)
-            self.graphs.run((B, "adam"), lambda: e1.optimizer_step(1.0 / world))
+            _dp_step(self.graphs, key, None, forward_backward, e1, dist, world)
         else:
             def whole():
                 forward_backward()
@@ -1043,6 +1082,8 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
         # checkpoint is ever written for this model; the score is still logged.
         score_value = float("nan")
         log_summary = _update_log_summary(log_summary, train_logs, val_logs)
+        log_epoch_to_tensorboard(TB_WRITER, train_logs, val_logs, epoch, score_value,
+                                 float(lambda_scheduler.get_weight()) if lambda_scheduler is not None else 0.0)
         if is_main:
             print(f"Epoch {epoch + 1}/{common_cfg.epochs} | train total={train_logs['total_loss']:.4f} "
                   f"pos={train_logs['pos_similarity']:.3f} neg={train_logs['neg_similarity']:.3f} "
@@ -1092,20 +1133,34 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
     preprocessed_train, preprocessed_val = preprocessed_object
     # either the reference's {video: (node windows, edge windows, angles)} dicts, or window datasets over frame
     # tables that deepof_amd.preprocess.preprocess_tables left on the device (nothing is materialised on the host)
+    # (the dicts' W-fold redundant windows are folded back into frame tables on the host and windows are gathered on the
+    #  device, see WindowDataset.from_preprocessed; the emulator-backed test path keeps the materialised form)
+    ingest_lib = None
+    if dev is not None:
+        from ._lib import load_hip_library
+        ingest_lib = load_hip_library()
     train_ds = preprocessed_train if isinstance(preprocessed_train, WindowDataset) else \
-        WindowDataset.from_preprocessed(preprocessed_train, data_dev)
+        WindowDataset.from_preprocessed(preprocessed_train, data_dev, ingest_lib)
     val_ds = preprocessed_val if isinstance(preprocessed_val, WindowDataset) else \
-        WindowDataset.from_preprocessed(preprocessed_val, data_dev)
+        WindowDataset.from_preprocessed(preprocessed_val, data_dev, ingest_lib)
     # block bootstrap of the training batches (dataset.py:351-352, 604-614); validation is never bootstrapped
     train_ds.bootstrap_training, train_ds.bootstrap_block_len = bool(bootstrap_training), int(bootstrap_block_len)
-    if model_name == "vqvae":
-        return fit_VQVAE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
-                         _engine_factory=_engine_factory, shuffle=shuffle)
-    if model_name == "contrastive":
-        return fit_contrastive(train_ds, val_ds, np.asarray(adjacency_matrix), meta_info, common_cfg, teacher_cfg,
-                               contrastive_cfg, device=dev, _engine_factory=_engine_factory, shuffle=shuffle)
-    return fit_VADE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
-                    _engine_factory=_engine_factory, shuffle=shuffle)
+    # TensorBoard event files under <output_path>/logs/<model>_run_<n> (training.py:977-982; rank 0, log_history only)
+    global TB_WRITER
+    TB_WRITER = open_writer(common_cfg, model_name, rank == 0)
+    try:
+        if model_name == "vqvae":
+            return fit_VQVAE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
+                             _engine_factory=_engine_factory, shuffle=shuffle)
+        if model_name == "contrastive":
+            return fit_contrastive(train_ds, val_ds, np.asarray(adjacency_matrix), meta_info, common_cfg, teacher_cfg,
+                                   contrastive_cfg, device=dev, _engine_factory=_engine_factory, shuffle=shuffle)
+        return fit_VADE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
+                        _engine_factory=_engine_factory, shuffle=shuffle)
+    finally:
+        if TB_WRITER is not None:
+            TB_WRITER.close()
+            TB_WRITER = None
 
 
 def train_deepof_model(

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 11
+#define DOF_ABI_VERSION 12
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -129,6 +129,12 @@ int64_t dof_tfm_dropout_site_offset(const DofVadePlan* plan, int32_t i);
 int64_t dof_tfm_dropout_site_numel(const DofVadePlan* plan, int32_t i);
 float dof_tfm_dropout_site_p(const DofVadePlan* plan, int32_t i);
 int dof_tfm_set_dropout(DofVadePlan* plan, const uint8_t* inject_masks, uint32_t seed);
+/* The device step counter the mask hash reads.  Default (NULL): a slot of the plan's own workspace, zeroed by
+ * dof_vade_bind.  A model that owns several plans (batch sizes, the ragged last batch, the two contrastive views)
+ * points all of them at ONE caller-owned device counter, so every train-mode encoder forward of the model consumes a
+ * distinct counter value -- the reference draws independent masks for every forward pass (F.dropout on the global
+ * generator).  The counter is advanced by the train-mode encoder forward of whichever plan runs. */
+int dof_tfm_set_dropout_counter(DofVadePlan* plan, uint32_t* device_counter);
 
 /* module.train() / module.eval() for the BatchNorm layers of a TCN plan (default: training).  With training = 0
  * the loss/grad and train-flagged encode entries normalise with the running buffers and leave them untouched --

@@ -291,7 +291,7 @@ def gen_vqvae(tag, ids, T, L, K, B, seed, kmeans=0.0):
         for k, v in r.logs.items():
             out[f"step{i}::log::{k}"] = np.float64(v)
     out.update(sd_np(model, "sd_final::"))
-    if tag == "rec28":
+    if tag in ("rec28", "c5l8"):
         # distillation head (teacher_model.py:795-808) inside step_vqvae_distill, on the trained weights above
         import deepof.clustering.teacher_model as TM
         torch.manual_seed(seed + 77)
@@ -488,7 +488,7 @@ def gen_contrastive(tag, ids, T_full, L, B, seed, encoder_type="recurrent", case
         for n, p_ in model.named_parameters():
             if p_.grad is not None:
                 out[pfx + f"grad::{n}"] = p_.grad.numpy().copy()
-        if encoder_type == "recurrent" and tag == "rec28" and ci == 0:
+        if encoder_type == "recurrent" and tag in ("rec28", "c5l8") and ci == 0:
             # same step with the distillation head on (replaying the same draws)
             import deepof.clustering.teacher_model as TM
             torch.manual_seed(seed + 99)

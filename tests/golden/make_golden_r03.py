@@ -1,0 +1,351 @@
+"""Round-3 golden fixtures, produced by running the REFERENCE in place (build container only; see make_golden.py):
+
+* vade_c5l8.npz / vqvae_c5l8.npz / contrastive_c5l8.npz
+      the C5 graph (2 animals: 28 nodes, 32 edges), window 50 (contrastive: 50 -> 25), latent 8, k = 25 -- the shapes
+      whose recurrent kernels are the lane-per-unit / MFMA-fused ones (latent 8) with K > 16 mixture components; the
+      round-1 "rec28" fixtures are latent 6 and exercise the generic kernels.
+* vqvae_c3k512.npz
+      C3: single animal, window 25, codebook 512, B = 64 (codebook + encoder gradients at the full codebook size).
+* vade_tcn14_onepass.npz
+      VaDEPT(encoder_type="TCN") at B = 64 whose BatchNorm running means equal the batch means of the very step that
+      is recorded: every channel of every BatchNorm layer then takes the one-pass (shifted-sum) statistics form of the
+      HIP path, and the comparison is elementwise against the reference.
+* tcn_kinks.npz
+      explicit ReLU-kink attribution for vade_tcn14_b64 / vqvae_tcn14 / vade_tcn14_onepass.  One train step of those
+      fixtures evaluates ~23 M BatchNorm+ReLU pre-activations; the ones with 0 < |x| < 5e-6 ("candidates", ~150 per step)
+      are the elements whose ReLU branch fp32 rounding decides, so two correct fp32 implementations may disagree on a
+      few of them, and ONE flipped branch moves the gradients of its block by up to 5 x the standard bar.  For every
+      candidate i the reference step is re-run with exactly that element on the other branch, giving its gradient change
+      D_i.  Stored: candidates whose change stays below a quarter of the standard bar everywhere are summed into
+      ``harmless``; for each of the others ("significant") its 32 most affected gradient elements ("probes":
+      ``probe_tensor`` / ``probe_index``, ``own`` = each candidate's probe rows), the matrix ``A[j, i]`` = D_i at probe j
+      in bar units, and ``maxd[i, tensor]`` = max |D_i| per tensor.  The parity test NAMES the flipped elements by
+      matching pursuit on the gradient error at the probes: a candidate is accepted when the residual, projected on the
+      candidate's own probes, carries its change with coefficient 1 (0.6 .. 1.4) -- a flip happened or it did not --
+      and its change is then subtracted.  A tensor's bar is  standard bar + harmless + changes of the named flips.
+      No tie budget: a deviation that is not the measured consequence of an identified flip fails.
+"""
+import copy
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import make_golden as MG  # noqa: E402
+import make_golden_r02 as MG2  # noqa: E402
+from deepof_amd.graph import adjacency_from_graph, bodypart_graph  # noqa: E402
+
+R = MG.R
+torch.set_num_threads(1)
+KINK_DELTA = 5e-6
+
+
+class KinkFlipper:
+    """ReLU inputs with 0 < |x| < delta take the other branch's derivative (values move by < delta).  ``only`` = the
+    ordinals (call order x flat index) to flip, None = all.  After a run: ``count`` such elements, ``ident`` = their
+    (flat index, value) pairs."""
+
+    def __init__(self, delta=KINK_DELTA, only=None, dry=False):
+        self.delta, self.dry, self.count, self.ident = delta, dry, 0, []
+        self.only = None if only is None else set(int(o) for o in (only if hasattr(only, "__iter__") else [only]))
+
+    def relu(self, x, inplace=False):
+        xd = x.detach()
+        near = (xd.abs() < self.delta) & (xd != 0)
+        n = int(near.sum())
+        first = self.count
+        self.count += n
+        if n == 0:
+            return x.clamp_min(0.0)
+        flat = near.reshape(-1).nonzero().reshape(-1)
+        if self.dry:
+            self.ident += [(int(j), float(xd.reshape(-1)[j])) for j in flat.tolist()]
+            return x.clamp_min(0.0)
+        if self.only is not None:
+            pick = [k for k in range(n) if first + k in self.only]
+            if not pick:
+                return x.clamp_min(0.0)
+            near = torch.zeros_like(near.reshape(-1))
+            near[flat[pick]] = True
+            near = near.reshape(x.shape)
+        return torch.where(near, torch.where(x > 0, x * 0.0, x), x.clamp_min(0.0))
+
+    def __enter__(self):
+        self._orig = (TF.relu, torch.relu)
+        TF.relu = self.relu
+        torch.relu = lambda x: self.relu(x)
+        return self
+
+    def __exit__(self, *exc):
+        TF.relu, torch.relu = self._orig
+        return False
+
+
+def _math_zero(n):
+    """a bias right in front of a BatchNorm: mathematically zero gradient, rounding noise in any implementation"""
+    return (("_tcn.blocks." in n or ".tcn.blocks." in n) and n.endswith(("conv1.bias", "conv2.bias"))) or n == "decoder.fc0.bias"
+
+
+def kink_attribution(out, prefix, model, rerun, base, stored, rtol=5e-4, atol=5e-5):
+    """Writes the attribution data described in the module docstring under ``prefix``.  ``stored`` = names of the
+    gradient tensors the fixture holds (probes are chosen among those)."""
+    with KinkFlipper(dry=True) as fl:
+        rerun()
+    for n, p in model.named_parameters():
+        if n in base:
+            assert torch.equal(p.grad, base[n]), ("patched ReLU changes the step", n)
+    count = fl.count
+    # the same quantity passing two ReLU calls (identical flat index and value) takes both branches together
+    groups = {}
+    for o, key in enumerate(fl.ident):
+        groups.setdefault(key, []).append(o)
+    cands = list(groups.values())
+    names = [n for n in base if n in stored]
+    probe_names = [n for n in names if not _math_zero(n)]
+    bar = {n: atol + rtol * float(base[n].abs().max()) for n in names}
+    harmless = {n: 0.0 for n in names}
+    sig = []   # (ordinals, {name: delta tensor})
+    for ords in cands:
+        with KinkFlipper(only=ords):
+            rerun()
+        delta = {n: (p.grad - base[n]).detach().clone() for n, p in model.named_parameters() if n in bar}
+        rel = max(float(delta[n].abs().max()) / bar[n] for n in names)
+        if rel < 0.25:
+            for n in names:
+                harmless[n] += float(delta[n].abs().max())
+        else:
+            sig.append((ords, delta))
+    # probes: the PROBES_PER most affected gradient elements (in bar units) of every significant candidate
+    PROBES_PER = 32
+    probes, index = [], {}
+    own = []
+    for _o, delta in sig:
+        flat = torch.cat([delta[n].reshape(-1).abs() / bar[n] for n in probe_names])
+        top = torch.topk(flat, min(PROBES_PER, flat.numel())).indices.tolist()
+        mine = []
+        for g in top:
+            if g not in index:
+                index[g] = len(probes)
+                probes.append(g)
+            mine.append(index[g])
+        own.append(mine)
+    sizes = np.cumsum([0] + [base[n].numel() for n in probe_names])
+    p_tensor = [int(np.searchsorted(sizes, g, side="right") - 1) for g in probes]
+    p_index = [int(g - sizes[t]) for g, t in zip(probes, p_tensor)]
+    A = np.zeros((len(probes), len(sig)), dtype=np.float32)
+    maxd = np.zeros((len(sig), len(names)))
+    for i, (_o, delta) in enumerate(sig):
+        for j, (t, k) in enumerate(zip(p_tensor, p_index)):
+            n = probe_names[t]
+            A[j, i] = float(delta[n].reshape(-1)[k]) / bar[n]
+        for k, n in enumerate(names):
+            maxd[i, k] = float(delta[n].abs().max())
+    out[prefix + "count"] = np.int64(count)
+    out[prefix + "tensors"] = np.array(names)
+    out[prefix + "harmless"] = np.array([harmless[n] for n in names])
+    out[prefix + "first_ordinal"] = np.array([o[0] for o, _ in sig], dtype=np.int64)
+    out[prefix + "probe_tensor"] = np.array([probe_names[t] for t in p_tensor]) if probes else np.array([], dtype="U1")
+    out[prefix + "probe_index"] = np.array(p_index, dtype=np.int64)
+    out[prefix + "own"] = np.array([m + [-1] * (PROBES_PER - len(m)) for m in own], dtype=np.int64).reshape(len(sig), PROBES_PER)
+    out[prefix + "A"] = A
+    out[prefix + "maxd"] = maxd
+    out[prefix + "rtol"], out[prefix + "atol"] = np.float64(rtol), np.float64(atol)
+    print(f"{prefix} {count} candidates within {KINK_DELTA} ({len(cands)} distinct), {len(sig)} significant, {len(probes)} probes")
+
+
+# ------------------------------------------------------------------------------------------------
+def _vade_run(model, xt, at, eps, eps_mc, tau, phase, klw, with_teacher, K, L):
+    B = xt.shape[0]
+    common, vade, teacher = MG._cfgs(K, L)
+    crit = R.L.VadeLoss(common_cfg=common, vade_cfg=vade, teacher_cfg=teacher)
+    crit.set_mode("pretrain" if phase == "pre" else "main")
+    crit.kl_scheduler = SimpleNamespace(get_weight=lambda k=klw: k, max_weight=1.0, current_iteration=0)
+    if with_teacher:
+        crit.set_teacher(tau_star=tau, lambda_distill=1.7)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+    torch.randn = lambda *s, **kw: eps_mc.clone() if tuple(s) == (32, B, L) else real_randn(*s, **kw)
+    torch.randn_like = lambda t, **kw: eps.clone() if tuple(t.shape) == (B, L) else real_randn_like(t, **kw)
+    try:
+        o = model(xt, at, return_gmm_params=True)
+        ld = crit(o, xt, batch_indices=torch.arange(B) if with_teacher else None)
+        ld["total_loss"].backward()
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    return o, ld
+
+
+def _tcn_vade_model(d, T, N, E, L, K):
+    model = R.M.VaDEPT((T, N, 3), (T, E, 1), d["adj"], L, K, encoder_type="TCN", kmeans_loss=1.0)
+    model.eval()
+    R.U._materialize_encoder(model, (T, N, 3), (T, E, 1), torch.device("cpu"))
+    sd0 = {k[4:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd::")}
+    model.load_state_dict(sd0)
+    return model, sd0
+
+
+def vade_tcn_kinks(out, fname, tagp):
+    d = dict(np.load(os.path.join(HERE, fname)))
+    x, a = d["x"], d["a"]
+    B, T, N, _ = x.shape
+    E = a.shape[2]
+    K, L = d["sd::latent_space.gmm_means"].shape
+    model, sd0 = _tcn_vade_model(d, T, N, E, L, K)
+    xt, at = torch.from_numpy(x), torch.from_numpy(a)
+    eps, eps_mc, tau = (torch.from_numpy(d[k]) for k in ("eps", "eps_mc", "tau"))
+    for phase, klw, teacher in (("pre", 0.13, False), ("mainT", 0.7, True)):
+        def rerun():
+            model.load_state_dict(sd0)
+            _vade_run(model, xt, at, eps, eps_mc, tau, phase, klw, teacher, K, L)
+        rerun()
+        base = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        n_checked = 0
+        for n, g in base.items():
+            key = f"{phase}::grad::{n}"
+            if key in d:
+                assert np.array_equal(g.numpy(), d[key]), ("regenerated step differs from the committed golden", key)
+                n_checked += 1
+        assert n_checked >= 20
+        stored = {k.split("::grad::")[1] for k in d if k.startswith(f"{phase}::grad::")}
+        kink_attribution(out, f"{tagp}::{phase}::", model, rerun, base, stored)
+
+
+def vqvae_tcn_kinks(out):
+    d = dict(np.load(os.path.join(HERE, "vqvae_tcn14.npz")))
+    x, a = d["x"], d["a"]
+    B, T, N, _ = x.shape
+    E = a.shape[2]
+    L, K = d["sd::vq_layer.codebook"].shape
+    model = R.M.VQVAEPT((T, N, 3), (T, E, 1), d["adj"], L, K, encoder_type="TCN", kmeans_loss=0.0)
+    model.eval()
+    R.U._materialize_encoder(model, (T, N, 3), (T, E, 1), torch.device("cpu"))
+    sd0 = {k[4:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd::")}
+    sd1 = dict(sd0)
+    sd1.update({k[len("sd_step1::"):]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd_step1::")})
+    for step, sd, xx, aa, gkey in (("step1", sd0, x, a, "grad::"), ("step2", sd1, d["step2::x"], d["step2::a"], "grad2::")):
+        xt, at = torch.from_numpy(xx), torch.from_numpy(aa)
+
+        def rerun():
+            model.load_state_dict(sd)
+            model.train()
+            model.zero_grad(set_to_none=True)
+            r = R.T.step_vqvae_distill(model, (xt, at, torch.arange(B)), SimpleNamespace(apply_distill=False))
+            r.loss.backward()
+        rerun()
+        base = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        for n, g in base.items():
+            assert np.array_equal(g.numpy(), d[gkey + n]), ("regenerated step differs from the committed golden", gkey + n)
+        # (the VQ-VAE TCN check runs at VQ_TCN_RTOL = 3e-3, tests/parity_common.py)
+        kink_attribution(out, f"vqvae_tcn14::{step}::", model, rerun, base, set(base), rtol=3e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_vade_tcn_onepass(seed=231, B=64, T=25, L=8, K=10):
+    nodes, edges = bodypart_graph([""])
+    adj = adjacency_from_graph(nodes, edges)
+    N, E = len(nodes), len(edges)
+    torch.manual_seed(seed)
+    model = R.M.VaDEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type="TCN", kmeans_loss=1.0)
+    model.eval()
+    R.U._materialize_encoder(model, (T, N, 3), (T, E, 1), torch.device("cpu"))
+    with torch.no_grad():
+        model.latent_space.gmm_means.mul_(3.0)
+    MG2._trained_like_state(model, seed=7)
+    MG2._randomise_bn_buffers(model)
+    x, a = MG.synth_batch(B, T, N, E, seed + 1)
+    xt, at = torch.from_numpy(x), torch.from_numpy(a)
+    eps = torch.randn(B, L, generator=torch.Generator().manual_seed(seed + 2))
+    eps_mc = torch.randn(32, B, L, generator=torch.Generator().manual_seed(seed + 3))
+    tau = torch.softmax(torch.randn(B, K, generator=torch.Generator().manual_seed(seed + 4)) * 2.0, dim=-1)
+    # batch mean of every BatchNorm layer's input in a train-mode forward (train-mode outputs do not depend on the
+    # running buffers, so these are the batch means of the recorded step itself) -> running_mean
+    means = {}
+    hooks = []
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            def hook(mod, inp, _name=name):
+                v = inp[0].detach().float()
+                means[_name] = v.mean(dim=(0, 2)) if v.dim() == 3 else v.mean(dim=0)
+            hooks.append(m.register_forward_pre_hook(hook))
+    sd_tmp = {k: v.clone() for k, v in model.state_dict().items()}
+    _vade_run(model, xt, at, eps, eps_mc, tau, "pre", 0.13, False, K, L)
+    for h in hooks:
+        h.remove()
+    model.load_state_dict(sd_tmp)
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(means[name])
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    out = dict(MG.sd_np(model))
+    out.update(x=x, a=a, adj=adj, eps=eps.numpy(), eps_mc=eps_mc.numpy(), tau=tau.numpy())
+    model.eval()
+    with torch.no_grad():
+        dist, z, q, _km = model(xt, at)
+        enc = model.encoder(xt, at)
+    out.update(eval_z=z.numpy(), eval_q=q.numpy(), eval_loc=dist.base_dist.base_dist.loc.numpy(), eval_enc=enc.numpy())
+    for phase, klw, teacher in (("pre", 0.13, False), ("mainT", 0.7, True)):
+        def rerun():
+            model.load_state_dict(sd0)
+            return _vade_run(model, xt, at, eps, eps_mc, tau, phase, klw, teacher, K, L)
+        o32, l32 = rerun()
+        for k, v in l32.items():
+            out[f"{phase}::loss::{k}"] = np.float64(float(v))
+        if phase == "pre":
+            out.update({k: v for k, v in MG.sd_np(model, "pre::sd_after::").items() if "running_" in k or "num_batches" in k})
+        out[f"{phase}::z"] = o32[1].detach().numpy()
+        out[f"{phase}::q"] = o32[2].detach().numpy()
+        out[f"{phase}::loc"] = o32[0].base_dist.base_dist.loc.detach().numpy()
+        base = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        for n, g in base.items():
+            out[f"{phase}::grad::{n}"] = g.numpy().copy()
+        # the reference's own fp32-vs-fp64 deviation per tensor (information only)
+        m64 = copy.deepcopy(model)
+        m64.load_state_dict(sd0)
+        m64 = m64.double()
+        orig_float = torch.Tensor.float
+        torch.Tensor.float = lambda self: self.double()
+        try:
+            _vade_run(m64, xt.double(), at.double(), eps.double(), eps_mc.double(), tau.double(), phase, klw, teacher, K, L)
+        finally:
+            torch.Tensor.float = orig_float
+        p64 = dict(m64.named_parameters())
+        for n, g in base.items():
+            out[f"{phase}::gnoise::{n}"] = np.float64((g.double() - p64[n].grad).abs().max())
+    np.savez_compressed(os.path.join(HERE, "vade_tcn14_onepass.npz"), **out)
+
+
+def gen_tcn_kinks():
+    out = {"delta": np.float64(KINK_DELTA)}
+    vade_tcn_kinks(out, "vade_tcn14_b64.npz", "vade_tcn14_b64")
+    vade_tcn_kinks(out, "vade_tcn14_onepass.npz", "vade_tcn14_onepass")
+    vqvae_tcn_kinks(out)
+    np.savez_compressed(os.path.join(HERE, "tcn_kinks.npz"), **out)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["shapes", "tcn"]
+    if "shapes" in what:
+        MG.gen_vade("c5l8", ["B", "W"], 50, 8, 25, 8, 331)
+        MG.gen_vqvae("c5l8", ["B", "W"], 50, 8, 40, 8, 341, kmeans=0.5)
+        MG.gen_vqvae("c3k512", [""], 25, 8, 512, 64, 351)
+        MG.gen_contrastive("c5l8", ["B", "W"], 50, 8, 8, 361)
+    if "tcn" in what:
+        torch.set_num_threads(1)
+        if not os.path.exists(os.path.join(HERE, "vade_tcn14_onepass.npz")) or "onepass" in what:
+            gen_vade_tcn_onepass()
+        gen_tcn_kinks()
+    for f in ("vade_c5l8.npz", "vqvae_c5l8.npz", "vqvae_c3k512.npz", "contrastive_c5l8.npz", "vade_tcn14_onepass.npz",
+              "tcn_kinks.npz"):
+        p = os.path.join(HERE, f)
+        if os.path.exists(p):
+            print(f, os.path.getsize(p))

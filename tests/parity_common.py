@@ -434,41 +434,97 @@ def math_zero_gradient(name) -> bool:
     return (("_tcn.blocks." in n or ".tcn.blocks." in n) and n.endswith(("conv1.bias", "conv2.bias"))) or n == "decoder.fc0.bias"
 
 
-def _grad_bar(got, ref, name, atol=5e-5, rtol=5e-4, ties=None):
-    """Standard fp32 gradient bar: |got - ref| <= atol + rtol * max|ref| per tensor; mathematically-zero gradients
-    (math_zero_gradient) are only bounded.  `ties` (a list) collects tensors between 1x and TIE_FACTOR x the bar
-    instead of failing them -- see TIE_BUDGET."""
+def _grad_bar(got, ref, name, atol=5e-5, rtol=5e-4, extra=0.0):
+    """Standard fp32 gradient bar: |got - ref| <= atol + rtol * max|ref| (+ ``extra``: the measured consequence of
+    identified ReLU-branch flips, see KinkAttribution) per tensor; mathematically-zero gradients (math_zero_gradient)
+    are only bounded."""
     scale = float(np.abs(ref).max())
     if math_zero_gradient(name):
         assert scale < 3e-4 and float(np.abs(got).max()) < 3e-4, (name, scale, float(np.abs(got).max()))
         return 0.0
     err = float(np.abs(got - ref).max())
-    if ties is not None and atol + rtol * scale < err <= TIE_FACTOR * (atol + rtol * scale):
-        ties.append((name, err, scale))
-        return err / max(scale, 1e-30)
-    assert err <= atol + rtol * scale, (name, err, scale)
+    assert err <= atol + rtol * scale + extra, (name, err, scale, extra)
     return err / max(scale, 1e-30)
 
 
-# ReLU-mask ties.  The B = 64 fixture evaluates 2 streams x 16 BatchNorm+ReLU layers x 22,400 rows x 32 channels =
-# 23 M pre-activations of O(1) spread; two fp32 evaluations of the same network differ by ~1e-7 in each of them, so
-# about 23e6 x 0.4 (density at 0) x 2.4e-7 ~ 1-2 elements per evaluation sit on the other side of zero in ANY pair of
-# fp32 implementations (measured: moving from the four-pass to the time-resident convolution kernel flipped one
-# element of channel 15 of node block 1's BatchNorm1 -- the only channel of that layer's gradients that moved).  One
-# flipped element moves the gradients of its own layer (one channel) and of the blocks below it by a few 1e-3 of
-# their scale (measured worst 3.6 x the bar).  A flip is not an arithmetic error, so the check allows at most
-# TIE_BUDGET tensors (one flip reaches the ~12 tensors of two blocks) between 1 x and TIE_FACTOR x the bar and holds
-# every other tensor (~170) to the standard bar.
-TIE_FACTOR = 5.0
-TIE_BUDGET = 14
+class KinkAttribution:
+    """Explicit attribution of ReLU-branch flips in the TCN family (tests/golden/make_golden_r03.py, tcn_kinks.npz).
+
+    A train step of the B = 64 fixtures evaluates ~23 M BatchNorm+ReLU pre-activations of O(1) spread; ~150 of them lie
+    within 5e-6 of zero, where fp32 rounding decides the ReLU branch, so two correct fp32 implementations disagree on a
+    few, and one flipped branch moves the gradients of its block by up to 5 x the standard bar.  The fixture holds, for
+    every such candidate, the REFERENCE's own gradient change when exactly that element takes the other branch.  Here
+    the flipped elements are NAMED: the gradient error at each significant candidate's most affected element ("probe")
+    is explained as A c with c_i in {0, 1}; a coefficient that is neither fails the test.  A tensor's bar is then
+    standard bar + (sum of the harmless candidates' changes) + (changes of the identified flips) -- nothing else."""
+
+    def __init__(self, golden_dir, prefix):
+        k = load_golden(golden_dir, "tcn_kinks.npz")
+        self.prefix = prefix
+        self.tensors = [str(t) for t in k[prefix + "tensors"]]
+        self.col = {t: i for i, t in enumerate(self.tensors)}
+        self.harmless = k[prefix + "harmless"]
+        self.first_ordinal = k[prefix + "first_ordinal"]
+        self.probe_tensor = [str(t) for t in k[prefix + "probe_tensor"]]
+        self.probe_index = k[prefix + "probe_index"]
+        self.own = k[prefix + "own"]
+        self.A, self.maxd = k[prefix + "A"].astype(np.float64), k[prefix + "maxd"]
+        self.rtol, self.atol = float(k[prefix + "rtol"]), float(k[prefix + "atol"])
+        self.flipped = np.zeros(len(self.first_ordinal), dtype=bool)
+
+    def identify(self, got_of, ref_of):
+        """got_of / ref_of: name -> gradient array.  Matching pursuit over the significant candidates: the one whose
+        own probes best carry its change with coefficient 1 is named and subtracted, until none qualifies.  Returns the
+        first ordinals (ReLU call order x flat index in the reference run) of the named flips."""
+        n = len(self.first_ordinal)
+        if n == 0:
+            return []
+        bars = {}
+        R = np.zeros(len(self.probe_tensor))
+        for j, (t, idx) in enumerate(zip(self.probe_tensor, self.probe_index)):
+            ref = ref_of(t).reshape(-1)
+            if t not in bars:
+                bars[t] = self.atol + self.rtol * float(np.abs(ref).max())
+            R[j] = (float(got_of(t).reshape(-1)[idx]) - float(ref[idx])) / bars[t]
+        for _ in range(n):
+            best, best_gain = -1, 0.0
+            for i in range(n):
+                if self.flipped[i]:
+                    continue
+                rows = self.own[i][self.own[i] >= 0]
+                v = self.A[rows, i]
+                vv = float(v @ v)
+                if vv < 0.25:          # (a change below half a bar on its best probes cannot be told from rounding)
+                    continue
+                coef = float(R[rows] @ v) / vv
+                gain = float(R[rows] @ R[rows]) - float((R[rows] - v) @ (R[rows] - v))
+                if 0.6 <= coef <= 1.4 and gain > best_gain:
+                    best, best_gain = i, gain
+            if best < 0:
+                break
+            self.flipped[best] = True
+            R = R - self.A[:, best]
+        return self.first_ordinal[self.flipped].tolist()
+
+    def extra(self, name):
+        """Additional bar of tensor ``name``: harmless candidates + 1.25 x the identified flips' measured changes."""
+        if name not in self.col:
+            return 0.0
+        i = self.col[name]
+        return float(self.harmless[i]) + 1.25 * float(self.maxd[self.flipped, i].sum())
 
 
-def run_vade_tcn_b64_check(lib, device, golden_dir):
+def run_vade_tcn_b64_check(lib, device, golden_dir, fixture="vade_tcn14_b64.npz", min_main=20):
     """VaDE with the TCN encoder and decoder at B = 64 in a trained-like state (tests/golden/make_golden_r02.py)
     against the REFERENCE's fp32 values at the standard bars: eval forward, then for the pre-training and the main
     (+ teacher) objective every loss term, the train-mode outputs, every stored gradient (all 200 parameter tensors
-    for "pre") and the refreshed BatchNorm buffers / step counters."""
-    d = load_golden(golden_dir, "vade_tcn14_b64.npz")
+    for "pre") and the refreshed BatchNorm buffers / step counters.  Gradients: standard bar + the measured consequence
+    of the ReLU-branch flips KinkAttribution identifies (usually none or one).
+
+    fixture="vade_tcn14_onepass.npz" (make_golden_r03.py): the same model with every BatchNorm running mean equal to
+    the batch mean of the recorded step, so every channel of every layer takes the ONE-PASS (shifted-sum) statistics
+    form of the convolution epilogues -- the steady-state path of a fit -- and is compared elementwise."""
+    d = load_golden(golden_dir, fixture)
     x, a = torch.from_numpy(d["x"]).to(device), torch.from_numpy(d["a"]).to(device)
     B, T, N, _ = x.shape
     K, L = d["sd::latent_space.gmm_means"].shape
@@ -497,16 +553,17 @@ def run_vade_tcn_b64_check(lib, device, golden_dir):
                 np.testing.assert_allclose(v, float(d[key]), rtol=1e-4, atol=1e-5, err_msg=key)
                 n_terms += 1
         assert n_terms >= 12
-        n, w, ties = 0, 0.0, []
+        kinks = KinkAttribution(golden_dir, f"{fixture[:-4]}::{phase}::")
+        flips = kinks.identify(lambda t: eng.view(t, eng.grads).cpu().numpy(), lambda t: d[f"{phase}::grad::{t}"])
+        n, w = 0, 0.0
         for k in d:
             if k.startswith(f"{phase}::grad::"):
                 name = k.split("::")[-1]
                 g = eng.view(name, eng.grads).cpu().numpy()
-                w = max(w, _grad_bar(g, d[k].reshape(g.shape), (phase, name), ties=ties))
+                w = max(w, _grad_bar(g, d[k].reshape(g.shape), (phase, name), extra=kinks.extra(name)))
                 n += 1
-        assert len(ties) <= TIE_BUDGET, ties
-        worst[phase] = w
-        assert n >= (200 if phase == "pre" else 20), n
+        worst[phase] = (w, flips)
+        assert n >= (200 if phase == "pre" else min_main), n
         if phase == "pre":
             sd1 = eng.state_dict()
             nb = 0
@@ -565,18 +622,16 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
     logs = eng.read_vq_logs()
     for k in ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss", "number_of_populated_clusters"):
         np.testing.assert_allclose(logs[k], float(d[f"log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=k)
-    n, worst, ties = 0, 0.0, []
+    kinks1 = KinkAttribution(golden_dir, "vqvae_tcn14::step1::")
+    flips1 = kinks1.identify(lambda t: eng.view(t, eng.grads).cpu().numpy(), lambda t: d["grad::" + t])
+    n, worst = 0, 0.0
     for k in d:
         if k.startswith("grad::"):
             name = k[len("grad::"):]
             g = eng.view(name, eng.grads).cpu().numpy()
-            worst = max(worst, _grad_bar(g, d[k].reshape(g.shape), name, rtol=VQ_TCN_RTOL, ties=ties))
+            worst = max(worst, _grad_bar(g, d[k].reshape(g.shape), name, rtol=VQ_TCN_RTOL, extra=kinks1.extra(name)))
             n += 1
     assert n >= 190, n
-    # a ReLU-mask tie (TIE_BUDGET) in the top block reaches every block below it in its stream: 8 blocks x 6-7 tensors
-    assert len(ties) <= 4 * TIE_BUDGET, ties
-    # gradients a tie may have moved by up to TIE_FACTOR x the bar do not resolve the sign of a smaller element
-    tied = {t[0] for t in ties}
     sd1 = eng.state_dict()
     nb = 0
     for k in d:
@@ -605,7 +660,9 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
             continue
         assert float(np.abs(got - start).max()) <= lr * 1.001, k
         g1 = np.abs(d["grad::" + k].reshape(got.shape))
-        weak = g1 < (TIE_FACTOR * VQ_TCN_RTOL if k in tied else 2e-3) * max(float(g1.max()), 1e-30) + 1e-6
+        # (an identified ReLU-branch flip moved this tensor's gradient by up to kinks1.extra(k): smaller elements
+        # have no resolved sign either)
+        weak = g1 < 2e-3 * max(float(g1.max()), 1e-30) + 1e-6 + kinks1.extra(k)
         if math_zero_gradient(k):
             weak[:] = True
         unresolved[k] = weak
@@ -618,16 +675,16 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
     logs2 = eng.read_vq_logs()
     for k in ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss"):
         np.testing.assert_allclose(logs2[k], float(d[f"step2::log::{k}"]), rtol=1e-4, atol=1e-5, err_msg="step 2: " + k)
-    n2, ties2 = 0, []
+    kinks2 = KinkAttribution(golden_dir, "vqvae_tcn14::step2::")
+    flips2 = kinks2.identify(lambda t: eng.view(t, eng.grads).cpu().numpy(), lambda t: d["grad2::" + t])
+    n2 = 0
     for k in d:
         if k.startswith("grad2::"):
             name = k[len("grad2::"):]
             g = eng.view(name, eng.grads).cpu().numpy()
-            worst = max(worst, _grad_bar(g, d[k].reshape(g.shape), name, rtol=VQ_TCN_RTOL, ties=ties2))
+            worst = max(worst, _grad_bar(g, d[k].reshape(g.shape), name, rtol=VQ_TCN_RTOL, extra=kinks2.extra(name)))
             n2 += 1
     assert n2 >= 190, n2
-    assert len(ties2) <= 4 * TIE_BUDGET, ties2
-    tied2 = {t[0] for t in ties2}
     # resolved elements: the Adam update to 2 % of one step
     step2_atol = 2e-5
     eng.optimizer_step()
@@ -639,16 +696,17 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
         start = ref1[k].numpy().reshape(got.shape)
         assert float(np.abs(got - start).max()) <= lr * 1.05, k   # |m_hat| / sqrt(v_hat) peaks just above 1 at t = 2
         g2 = np.abs(d["grad2::" + k].reshape(got.shape)) if "grad2::" + k in d else np.zeros_like(got)
-        weak = unresolved[k] | (g2 < (TIE_FACTOR * VQ_TCN_RTOL if k in tied2 else 2e-3) * max(float(g2.max()), 1e-30) + 1e-6)
+        weak = unresolved[k] | (g2 < 2e-3 * max(float(g2.max()), 1e-30) + 1e-6 + kinks2.extra(k))
         # resolved in both steps: the Adam update (bias corrections of t = 2, weight decay, clip) to 2 % of one step
-        # ... except a handful of elements whose two small gradients both moved: at most two, or 0.5 % of a tensor's
-        # resolved elements, and those within 20 % of one step
+        # ... except elements whose two small gradients both moved: at most 0.5 % of a tensor's resolved elements, and
+        # those within 20 % of one step
         dev = np.abs(got[~weak] - ref[~weak])
         bad = dev > step2_atol + 1e-5 * np.abs(ref[~weak])
-        assert bad.size == 0 or (int(bad.sum()) <= max(2, int(5e-3 * bad.size)) and float(dev.max()) <= 0.2 * lr), \
+        assert bad.size == 0 or (int(bad.sum()) <= int(5e-3 * bad.size) and float(dev.max()) <= 0.2 * lr), \
             (k, int(bad.sum()), bad.size, float(dev.max()))
-        assert (~weak).mean() > (0.25 if (k in tied or k in tied2) else 0.5) or math_zero_gradient(k), (k, float((~weak).mean()))
-    return worst
+        flipped = kinks1.extra(k) > 0 or kinks2.extra(k) > 0
+        assert (~weak).mean() > (0.25 if flipped else 0.5) or math_zero_gradient(k), (k, float((~weak).mean()))
+    return worst, flips1, flips2
 
 
 def _oracle_truth(fn, P, *tensors):

@@ -14,7 +14,7 @@ def test_gather_emu():
     gather_check(emu_lib(), "cpu")
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8"])
 def test_vade_eval_forward_emu(golden_dir, tag):
     d = load_golden(golden_dir, f"vade_{tag}.npz")
     x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
@@ -30,7 +30,8 @@ def test_vade_eval_forward_emu(golden_dir, tag):
 
 
 @pytest.mark.parametrize("tag,phase", [("rec14", "pre"), ("rec14", "main"), ("rec14", "mainT"), ("rec14", "mainX"),
-                                       ("rec28", "pre"), ("rec28", "mainT"), ("rec28", "mainX")])
+                                       ("rec28", "pre"), ("rec28", "mainT"), ("rec28", "mainX"),
+                                       ("c5l8", "pre"), ("c5l8", "mainX")])
 def test_vade_loss_grads_emu(golden_dir, tag, phase):
     run_phase_check(emu_lib(), "cpu", golden_dir, tag, phase)
 
@@ -50,7 +51,7 @@ def test_vade_train_trace_emu(golden_dir):
     run_trace_check(emu_lib(), "cpu", golden_dir)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28"])   # (c5l8 / c3k512: GPU only, 1-2 minutes each under the emulator)
 def test_vqvae_emu(golden_dir, tag):
     run_vqvae_check(emu_lib(), "cpu", golden_dir, tag)
 
@@ -61,7 +62,7 @@ def test_contrastive_losses_emu(golden_dir, tag):
     run_contrastive_loss_check(emu_lib(), "cpu", golden_dir, tag)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8"])
 def test_contrastive_step_emu(golden_dir, tag):
     from parity_common import run_contrastive_check
     run_contrastive_check(emu_lib(), "cpu", golden_dir, tag)
@@ -181,3 +182,16 @@ def test_contrastive_tfm_emu(golden_dir):
 def test_tfm_other_widths_emu(n_nodes, latent, kind):
     """key_dim 24 / 32 / 48 / 64 and decoder widths 16 / 24 / 32 of the transformer family against the oracle."""
     print(PC.run_tfm_widths_vs_oracle(emu_lib(), "cpu", n_nodes, latent, B=4, T=6, kind=kind))
+
+
+def test_gru16_matrix_pipe_kernels_emu():
+    """k_gru16m_fwd / k_gru16m_bwd (the encoder streams' (16, 16) GRU on the matrix pipe, gates recomputed in the
+    backward pass) against the reference goldens: a child process with DOF_GRU_MFMA_MIN_S=0, because at the goldens'
+    batch sizes the product dispatch picks the lane-per-unit kernels (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DOF_GRU_MFMA_MIN_S="0")
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gru_mfma_probe.py")
+    r = subprocess.run([sys.executable, probe, "emu"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -56,7 +56,7 @@ def test_gather_matches_reference_windows(hip, golden_dir):
             np.testing.assert_array_equal(a.cpu().numpy(), d[f"w{ci}::a"])
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8"])
 def test_vade_eval_forward_gpu(hip, golden_dir, tag):
     from deepof_amd.engine import create_vade_engine
     from parity_common import load_golden, params_from
@@ -74,7 +74,9 @@ def test_vade_eval_forward_gpu(hip, golden_dir, tag):
 
 
 @pytest.mark.parametrize("tag,phase", [("rec14", "pre"), ("rec14", "main"), ("rec14", "mainT"), ("rec14", "mainX"),
-                                       ("rec28", "pre"), ("rec28", "main"), ("rec28", "mainT"), ("rec28", "mainX")])
+                                       ("rec28", "pre"), ("rec28", "main"), ("rec28", "mainT"), ("rec28", "mainX"),
+                                       # C5 graph at latent 8, window 50, k = 25: the lane-per-unit / MFMA-fused kernels
+                                       ("c5l8", "pre"), ("c5l8", "main"), ("c5l8", "mainT"), ("c5l8", "mainX")])
 def test_vade_loss_grads_gpu(hip, golden_dir, tag, phase):
     from parity_common import run_phase_check
     worst = run_phase_check(hip, "cuda", golden_dir, tag, phase)
@@ -247,7 +249,7 @@ def test_training_api_on_gpu(hip, tmp_path):
     np.testing.assert_allclose(soft.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512"])
 def test_vqvae_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_vqvae_check
     run_vqvae_check(hip, "cuda", golden_dir, tag)
@@ -319,7 +321,7 @@ def test_vqvae_full_size_c3(hip):
     np.testing.assert_allclose(out["soft_counts"].cpu().numpy(), soft.numpy(), rtol=2e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8"])
 def test_contrastive_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_contrastive_check, run_contrastive_loss_check
     run_contrastive_loss_check(hip, "cuda", golden_dir, tag)
@@ -994,22 +996,27 @@ def test_vade_tfm_full_size_c2(hip):
     for _ in range(2):
         eng.load_state_dict(sd0)
         eng.set_dropout(None, seed=99)
-        # same seed, but the device counter has advanced: force equal masks through a fresh plan instead
+        model._dropout_counter.zero_()      # masks = hash(seed, site, step counter, element): same counter, same masks
         configure_phase(eng, K, False, 0.7, None, 0.0)
         eng.loss_grads(x, a, eps, eps_mc, None, pretrain=False)
         outs.append((eng.grads.clone(), eng.read_logs()["total_loss"]))
     assert all(torch.isfinite(o[0]).all() and np.isfinite(o[1]) for o in outs)
     assert float(outs[0][0].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1], "transformer step is not bitwise reproducible"
+    eng.loss_grads(x, a, eps, eps_mc, None, pretrain=False)   # the counter has advanced: other masks, other gradient
+    assert not torch.equal(outs[0][0], eng.grads)
+    eng.load_state_dict(sd0)
     model.eval()
     m32 = VaDE((T, 14, 3), (T, 14, 1), adj, L, K, encoder_type="transformer", batch_size=32, device="cuda")
     m32.load_state_dict(model.state_dict())
     m32.eval()
-    _d, z, q, _k = m32(x[:32], a[:32])
+    dist, z, q, _k = m32(x[:32], a[:32])
     P = {k: v.cpu() for k, v in model.state_dict().items()}
     with torch.no_grad():
         ref = OV.vade_forward(P, x[:32].cpu(), a[:32].cpu(), training=False)
     np.testing.assert_allclose(z.cpu().numpy(), ref["z"].numpy(), atol=3e-5, rtol=1e-4)
     np.testing.assert_allclose(q.cpu().numpy(), ref["q"].numpy(), atol=2e-5, rtol=1e-3)
+    np.testing.assert_allclose(dist.mean.cpu().numpy(), ref["loc"].numpy(), atol=1e-4, rtol=2e-4)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -89,6 +89,73 @@ def test_window_dataset_layout_and_ragged_last_batch():
     np.testing.assert_array_equal(a.numpy(), ar)
 
 
+def test_window_dict_ingestion_rebuilds_frame_tables(golden_dir):
+    """The reference's {video: (node windows, edge windows)} dict is folded back into frame tables (exact check of the
+    overlap of every window with its predecessor) and served by dof_window_gather: every batch equals the materialised
+    form bit for bit, for stride 1 and stride 3, ragged videos, a one-window video and NaN-free float64 input; a
+    shuffled or irregular window set falls back to the materialised form."""
+    from deepof_amd.dataset import _frame_table_of
+    lib = emu_lib()
+    rng = np.random.default_rng(3)
+    W, N, E = 8, 4, 3
+
+    def windows(table, stride):
+        n = (table.shape[0] - W) // stride + 1
+        return np.stack([table[i * stride: i * stride + W] for i in range(n)])
+
+    for stride in (1, 3):
+        pre, tabs = {}, {}
+        for k, frames in (("a", 40), ("b", W), ("c", 23)):
+            tn = rng.standard_normal((frames, 3 * N))                     # float64, as the reference hands it over
+            te = rng.standard_normal((frames, E)).astype(np.float32)
+            pre[k] = (windows(tn, stride), windows(te, stride), np.zeros((windows(tn, stride).shape[0], W, 0)))
+            tabs[k] = tn
+        full = WindowDataset.from_preprocessed(pre, "cpu")
+        fold = WindowDataset.from_preprocessed(pre, "cpu", lib)
+        assert fold.x is None and fold.node_table is not None and len(fold) == len(full)
+        used = sum((t.shape[0] - W) // stride * stride + W for t in tabs.values())
+        assert fold.node_table.shape[0] == used                            # 1/W of the rows (not the windows) are resident
+        assert fold.x_shape == full.x_shape and fold.a_shape == full.a_shape and fold.keys == full.keys
+        np.testing.assert_array_equal(fold.video_idx, full.video_idx)
+        for s0, e0 in ((0, 7), (5, len(full)), (len(full) - 3, len(full))):
+            xf, af = fold.fetch(s0, e0)
+            xm, am = full.fetch(s0, e0)
+            assert torch.equal(xf, xm) and torch.equal(af, am)
+    # the reference's own rolling_window output (tests/golden/make_golden_windows.py)
+    d = load_golden(golden_dir, "windows_graph.npz")
+    n_ref = 0
+    for k in d:
+        if k.endswith("::node_windows"):
+            pfx = k[: -len("node_windows")]
+            got = _frame_table_of(d[k])
+            stride = int(got[1])
+            table = d[pfx + "node_table"]
+            used = (table.shape[0] - d[k].shape[1]) // stride * stride + d[k].shape[1]
+            np.testing.assert_array_equal(got[0], table[:used])            # the table the reference windowed
+            ds = WindowDataset.from_preprocessed({"v": (d[k], d[pfx + "edge_windows"])}, "cpu", lib)
+            x, a = ds.fetch(0, len(ds))
+            np.testing.assert_array_equal(x.numpy(), d[pfx + "x"])         # = the reference's reorder_and_reshape
+            np.testing.assert_array_equal(a.numpy(), d[pfx + "a"])
+            n_ref += 1
+    assert n_ref >= 2
+    # irregular sets: shuffled windows / one corrupted element -> None (materialised fallback)
+    t = rng.standard_normal((30, 6))
+    w = windows(t, 1)
+    assert _frame_table_of(w)[1] == 1 and np.array_equal(_frame_table_of(w)[0], t)
+    assert _frame_table_of(w[rng.permutation(len(w))]) is None
+    bad = w.copy()
+    bad[11, 2, 3] += 1e-9
+    assert _frame_table_of(bad) is None
+    # a set without any overlap structure is still served exactly: stride W = every window is its own table block
+    rev = {"a": (w[::-1].copy(), windows(rng.standard_normal((30, 2)), 1)[::-1].copy())}
+    ds, ref = WindowDataset.from_preprocessed(rev, "cpu", lib), WindowDataset.from_preprocessed(rev, "cpu")
+    assert ds.node_table is not None and ds.node_table.shape[0] == len(w) * W
+    assert torch.equal(ds.fetch(3, 17)[0], ref.fetch(3, 17)[0]) and torch.equal(ds.fetch(3, 17)[1], ref.fetch(3, 17)[1])
+    # node and edge windows cut with different strides: materialised fallback
+    mixed = {"a": (windows(t, 1)[:8], windows(rng.standard_normal((30, 2)), 2)[:8])}
+    assert WindowDataset.from_preprocessed(mixed, "cpu", lib).x is not None
+
+
 def test_model_object_matches_reference_interface(golden_dir):
     d = load_golden(golden_dir, "vade_rec14.npz")
     ref_keys = [k[4:] for k in d if k.startswith("sd::")]
@@ -460,6 +527,123 @@ def test_transformer_family_models_and_fit(golden_dir, tmp_path, name):
         np.testing.assert_allclose(e1.numpy(), e2.numpy(), atol=1e-5)
 
 
+def test_transformer_dropout_masks_differ_between_plans():
+    """Every plan of a transformer model reads one device step counter and has its own seed: the central and the
+    augmented view of a contrastive step (base plan / aug plan of the same batch size), the ragged-batch plan and
+    consecutive steps all draw different keep-masks; resetting the counter reproduces a forward bit for bit."""
+    from deepof_amd.models import Contrastive
+    torch.manual_seed(0)
+    N, W, B = 8, 16, 6
+    model = Contrastive((W, N, 3), (W, N - 1, 1), chain_adj(N), 4, encoder_type="transformer", batch_size=B,
+                        _engine_factory=emu_factory)
+    model.train()
+    e1, e2, e3 = model.engine(B), model.aug_engine(B), model.engine(4)
+    assert e1._drop_counter is e2._drop_counter is e3._drop_counter is model._dropout_counter
+    g = torch.Generator().manual_seed(1)
+    x, a = torch.randn(B, W // 2, N, 3, generator=g), torch.randn(B, W // 2, N - 1, 1, generator=g)
+    z1 = e1.contrastive_encode(x, a, train=True).clone()
+    z2 = e2.contrastive_encode(x, a, train=True).clone()     # same input, the other view's plan
+    z1b = e1.contrastive_encode(x, a, train=True).clone()    # same plan, next step
+    assert int(model._dropout_counter) == 3
+    assert not torch.equal(z1, z2) and not torch.equal(z1, z1b) and not torch.equal(z2, z1b)
+    # equal counters AND equal seeds would give equal masks: the seeds differ ...
+    model._dropout_counter.fill_(0)
+    z2r = e2.contrastive_encode(x, a, train=True).clone()
+    assert not torch.equal(z2r, z1)
+    # ... and the stream is a function of (seed, counter) only
+    model._dropout_counter.fill_(0)
+    assert torch.equal(e1.contrastive_encode(x, a, train=True), z1)
+
+
+def _check_bundle_outputs(model, name, io, atol=2e-5):
+    x, a = torch.from_numpy(io["x"]), torch.from_numpy(io["a"])
+    model.eval()
+    if name == "vade":
+        dist, z, q, _km = model(x, a)
+        np.testing.assert_allclose(z.cpu().numpy(), io["z"], atol=atol, rtol=1e-4)
+        np.testing.assert_allclose(q.cpu().numpy(), io["q"], atol=atol, rtol=1e-3)
+        np.testing.assert_allclose(dist.mean.cpu().numpy(), io["loc"], atol=5e-5, rtol=1e-4)
+    elif name == "vqvae":
+        out = model(x, a, return_all_outputs=True)
+        ze, soft, quant = out[4], out[3], out[2]
+        np.testing.assert_allclose(ze.cpu().numpy(), io["ze"], atol=atol, rtol=1e-4)
+        np.testing.assert_allclose(quant.cpu().numpy(), io["quantized"], atol=1e-6)
+        np.testing.assert_allclose(soft.cpu().numpy(), io["soft"], atol=2e-6, rtol=2e-3)
+    else:
+        np.testing.assert_allclose(model(x, a).cpu().numpy(), io["z"], atol=atol, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["vade", "vqvae", "contrastive"])
+def test_reference_checkpoint_loads_here(golden_dir, name):
+    """A bundle written by the REFERENCE's save_model_info (tests/golden/make_golden_ckpt.py, committed under
+    tests/golden/ckpt/) loads with deepof_amd.training.load_model_from_ckpt -- every state_dict entry consumed -- and the
+    rebuilt model reproduces the reference's eval outputs."""
+    import os
+    path = os.path.join(golden_dir, "ckpt", f"ref_{name}.pth")
+    model, logs, spec, report = TR.load_model_from_ckpt(path, _engine_factory=emu_factory)
+    assert report["missing"] == [] and report["unexpected"] == [], report
+    assert spec["model_name"] == name and logs["train"]["total_loss"] == [2.0, 1.5]
+    _check_bundle_outputs(model, name, dict(np.load(os.path.join(golden_dir, "ckpt", f"ref_{name}_io.npz"))))
+
+
+@pytest.mark.parametrize("name", ["vade", "vqvae", "contrastive"])
+def test_checkpoint_loads_in_the_reference(golden_dir, tmp_path, name):
+    """The other direction, wherever the reference is mounted (the build container; skipped on the GPU box): a bundle
+    written by deepof_amd's save_model_info loads with the REFERENCE's load_model_from_ckpt (model_utils_new.py:822-904)
+    without missing / unexpected keys, and the reference model computes the same eval outputs as ours."""
+    import os
+    import sys
+    if not os.path.isdir("/root/reference/deepof"):
+        pytest.skip("the reference is not mounted here")
+    from deepof_amd.models import VQVAE, Contrastive
+    d = dict(np.load(os.path.join(golden_dir, "ckpt", f"ref_{name}_io.npz")))
+    adj = load_golden(golden_dir, "graph_ops.npz")["single_adj"]
+    T, N, E, L, K = 25, 14, 14, 8, 10
+    torch.manual_seed(5)
+    if name == "vade":
+        model = VaDE((T, N, 3), (T, E, 1), adj, L, K, batch_size=6, _engine_factory=emu_factory)
+    elif name == "vqvae":
+        model = VQVAE((T, N, 3), (T, E, 1), adj, L, K, batch_size=6, _engine_factory=emu_factory)
+    else:
+        model = Contrastive((2 * T, N, 3), (2 * T, E, 1), adj, L, batch_size=6, _engine_factory=emu_factory)
+    Tm = 2 * T if name == "contrastive" else T
+    spec = {"model_name": name, "x_shape": (Tm, N, 3), "a_shape": (Tm, E, 1), "adjacency_matrix": adj.astype("float32"),
+            "latent_dim": L, "n_components": K, "encoder_type": "recurrent", "use_gnn": True,
+            "interaction_regularization": 0.0}
+    path = str(tmp_path / "models" / f"{name}.pth")
+    TR.save_model_info(path, stage="best_val", epoch=1, model=model, log_summary={"train": {}, "val": {}},
+                       rebuild_spec=spec, save_weights=True)
+    sys.path.insert(0, os.path.join(golden_dir))
+    import make_golden_ckpt as MC
+    ref_out, report = MC.cross_load_into_reference(path, d["x"], d["a"])
+    assert list(report["missing"]) == [] and list(report["unexpected"]) == [], report
+    _check_bundle_outputs(model, name, {"x": d["x"], "a": d["a"], **ref_out})
+
+
+def test_tensorboard_event_files(tmp_path):
+    """log_history=True leaves <output>/logs/<model>_run_<n>/events.out.tfevents.* (training.py:977-982) holding the
+    reference's scalar tags (logging.py:436-467) in valid TFRecord framing (both CRC-32C checks); log_history=False
+    writes no logs directory."""
+    from deepof_amd.tb_log import _crc32c, read_scalars
+    assert _crc32c(b"123456789") == 0xE3069283          # the CRC-32C check value
+    pre_tr, pre_va = tiny_preprocessed(n_videos=1, n_win=16, seed=1), tiny_preprocessed(n_videos=1, n_win=8, seed=2)
+    kw = dict(preprocessed_object=(pre_tr, pre_va), adjacency_matrix=chain_adj(4), encoder_type="recurrent", batch_size=8,
+              latent_dim=4, epochs=2, n_clusters=3, model_name="VaDE", use_turtle_teacher=False, pretrain_epochs=1,
+              save_weights=False, run=3, _engine_factory=emu_factory)
+    TR.train_deepof_model(output_path=str(tmp_path / "a"), log_history=True, **kw)
+    log_dir = tmp_path / "a" / "logs" / "vade_run_3"
+    files = list(log_dir.glob("events.out.tfevents.*"))
+    assert len(files) == 1
+    rows = read_scalars(str(files[0]))
+    tags = {t for _s, t, _v in rows}
+    assert {"Pretrain/total_loss", "Train/total_loss", "Train/reconstruct_loss", "Val/total_loss", "Distill/lambda",
+            "Val/alignment_score", "Val/conf_norm", "Val/bal_norm"} <= tags, tags
+    assert sorted({s_ for s_, t, _v in rows if t == "Train/total_loss"}) == [0, 1]      # one point per epoch
+    assert all(np.isfinite(v) for _s, t, v in rows if t == "Train/total_loss")
+    TR.train_deepof_model(output_path=str(tmp_path / "b"), log_history=False, **kw)
+    assert not (tmp_path / "b" / "logs").exists()
+
+
 def test_block_bootstrap_matches_reference(golden_dir):
     """bootstrap_training: the batch starts equal the reference loader's for the same seed / epoch (bit-exact)."""
     d = load_golden(golden_dir, "bootstrap.npz")
@@ -811,8 +995,86 @@ def test_posthoc_soft_counts_match_reference(golden_dir):
                 ref = d[p + f"soft::{gi}::{k}"]
                 assert res[gi][k].shape == ref.shape == (emb[k].shape[0], M * C)
                 np.testing.assert_allclose(res[gi][k], ref, atol=2e-6, rtol=1e-5, err_msg=f"{tag} gate {gi} {k}")
-    with pytest.raises(NotImplementedError, match="deeptime"):
-        SC.contrastive_soft_counts({"v": np.zeros((20, 4), np.float32)}, method="msm")
+    with pytest.raises(ValueError, match="only"):
+        SC.contrastive_soft_counts({"v": np.zeros((20, 4), np.float32)}, method="spectral")
+
+
+def test_posthoc_msm_pcca_soft_counts(golden_dir):
+    """N4, MSM-PCCA decoder + chaos gates.  (a) The orchestration -- runs, seeded MiniBatchKMeans microstates, active
+    set mapping, padding, decode, smoothing -- against the REFERENCE's own functions executed with the deeptime calls
+    served by deepof_amd.msm_pcca (tests/golden/make_golden_posthoc_msm.py).  (b) The restated deeptime core by its
+    defining properties, since deeptime itself is absent (parity unpinned there): row-stochastic T, detailed balance,
+    the maximum-likelihood fixed point, memberships in the simplex, planted metastable blocks recovered.
+    (c) get_supervised_chaos / add_chaos_gates against the reference's outputs."""
+    from deepof_amd import msm_pcca as MP
+    from deepof_amd import soft_counts as SC
+    d = load_golden(golden_dir, "posthoc_msm.npz")
+    for tag, gates in (("single", [0]), ("dist", [0])):
+        p = f"{tag}::"
+        L, C, M, smooth, n_micro, lag = (int(v) for v in d[p + "cfg"])
+        keys = [str(k) for k in d[p + "keys"]]
+        emb = {k: d[p + f"emb::{k}"] for k in keys}
+        series = {k: {gi: d[p + f"series::{gi}::{k}"] for gi in gates} for k in keys}
+        edges = {gi: d[p + f"edges::{gi}"] for gi in gates}
+        res = SC.contrastive_soft_counts_msm_pcca(emb, gating_series=series, n_clusters_per_gate=C, M_gates=M, gate_edges=edges,
+                                                  random_state=0, temporal_smooth_win=smooth, n_micro=n_micro, lagtime=lag)
+        for gi in gates:
+            for k in keys:
+                ref = d[p + f"soft::{gi}::{k}"]
+                assert res[gi][k].shape == ref.shape == (emb[k].shape[0], M * C)
+                np.testing.assert_allclose(res[gi][k], ref, atol=2e-6, rtol=1e-5, err_msg=f"{tag} {k}")
+                np.testing.assert_allclose(res[gi][k].sum(1), 1.0, atol=1e-5)
+    # the public selector: single animal, the reference's call (temporal_smooth_win=1, n_micro=400, lagtime=3)
+    one = SC.contrastive_soft_counts({k: d[f"single::emb::{k}"] for k in ("v0", "v1", "v2")}, method="msm", n_clusters_per_gate=3)
+    assert one["v0"].shape == (700, 3) and np.all(one["v0"] >= 0)
+    # (b) properties of the restated estimators
+    rng = np.random.default_rng(0)
+    n = 12
+    T0 = np.zeros((n, n))
+    for b in range(3):
+        T0[4 * b:4 * b + 4, 4 * b:4 * b + 4] = rng.uniform(0.5, 1.5, (4, 4))
+    T0 += 0.01 * rng.uniform(size=(n, n))
+    T0 /= T0.sum(1, keepdims=True)
+    x = [0]
+    for _ in range(40000):
+        x.append(int(rng.choice(n, p=T0[x[-1]])))
+    dtrajs = [np.array(x[:25000]), np.array(x[25000:])]
+    Cm = MP.sliding_count_matrix(dtrajs, 2)
+    assert Cm.sum() == (25000 - 2) + (len(x) - 25000 - 2)
+    np.testing.assert_array_equal(MP.largest_connected_set(Cm), np.arange(n))
+    T, pi = MP.reversible_mle(Cm)
+    np.testing.assert_allclose(T.sum(1), 1.0, atol=1e-12)
+    flux = pi[:, None] * T
+    np.testing.assert_allclose(flux, flux.T, atol=1e-12)                                   # detailed balance
+    c_i, xs = Cm.sum(1), flux.sum(1)
+    fixed = (Cm + Cm.T) / ((c_i / xs)[:, None] + (c_i / xs)[None, :])
+    np.testing.assert_allclose(fixed / fixed.sum(), flux / flux.sum(), rtol=1e-6, atol=1e-12)  # MLE fixed point
+    chi = MP.pcca_memberships(T, pi, 3)
+    np.testing.assert_allclose(chi.sum(1), 1.0, atol=1e-12)
+    assert chi.min() >= 0 and np.all(chi.max(1) > 0.95)
+    lab = chi.argmax(1)
+    assert len(set(lab[:4])) == len(set(lab[4:8])) == len(set(lab[8:])) == 1 and len(set(lab)) == 3
+    sparse = [np.array([0, 1, 0, 1, 0, 1]), np.array([5, 5, 5])]                            # states 2-4 never seen, 5 absorbing
+    assert MP.largest_connected_set(MP.sliding_count_matrix(sparse, 1)).tolist() == [0, 1]
+    act, chi2 = MP.fit_pcca_memberships([np.array([0, 1] * 50), np.array([1, 0] * 50)], 1, 4)  # 2 states, 4 requested: padded
+    assert act.tolist() == [0, 1] and chi2.shape == (2, 4) and np.allclose(chi2.sum(1), 1.0) and np.all(chi2[:, 2:] == 0)
+    # (c) chaos labels and gates
+    cols, W = [str(c) for c in d["chaos::cols"]], int(d["chaos::W"])
+    quality = {k: d[f"chaos::quality::{k}"] for k in ("v0", "v1")}
+    chaos = SC.supervised_chaos(quality, cols, ["B", "W"], 0.75, 0.5)
+    for k in quality:
+        for name in ("B_chaos", "W_chaos", "anychaos"):
+            np.testing.assert_array_equal(chaos[k][name], d[f"chaos::label::{name}::{k}"])
+    comb = SC.add_chaos_gates({("B", "W"): {k: d[f"chaos::sc::{k}"] for k in quality}},
+                              {k: d[f"chaos::sc_chaos::{k}"] for k in quality}, chaos, W)
+    for k in quality:
+        np.testing.assert_array_equal(comb[("B", "W")][k], d[f"chaos::combined::{k}"])
+    # method="combined" end to end: chaotic windows carry only chaos states, the others only regular ones
+    emb = {k: d[f"single::emb::{k}"][: quality[k].shape[0] - W + 1] for k in ("v0", "v1")}
+    out = SC.contrastive_soft_counts(emb, method="combined", n_clusters_per_gate=3, quality=quality, quality_columns=cols,
+                                     animal_ids=["B", "W"], window_size=W)
+    win = np.convolve(chaos["v0"]["anychaos"], np.ones(W), mode="valid") > 0
+    assert out["v0"].shape == (emb["v0"].shape[0], 6) and np.all(out["v0"][win, :3] == 0) and np.all(out["v0"][~win, 3:] == 0)
 
 
 @pytest.mark.parametrize("kind", ["vade", "vqvae", "contrastive"])

@@ -45,7 +45,17 @@ def main():
             wr += b
             kernels.setdefault(k[:60], {})["write"] = b
     top = sorted(kernels.items(), key=lambda kv: -(kv[1].get("read", 0) + kv[1].get("write", 0)))[:12]
-    print(json.dumps({"hbm_bytes_per_step": rd + wr, "read_bytes_x2": rd, "write_bytes": wr, "steps_profiled": steps,
+    extra = {}
+    if len(sys.argv) > 4:  # repo root: stamp the kernel sources the passes ran on (bench.py quotes the file only while
+        import hashlib    # they are unchanged)
+        import os
+        sys.path.insert(0, sys.argv[4])
+        from bench import STEP_SOURCES
+        h = hashlib.sha256()
+        for f in STEP_SOURCES:
+            h.update(open(os.path.join(sys.argv[4], "deepof_amd", "csrc", f), "rb").read())
+        extra = {"source_sha": h.hexdigest()[:16], "sources": STEP_SOURCES}
+    print(json.dumps({**extra, "hbm_bytes_per_step": rd + wr, "read_bytes_x2": rd, "write_bytes": wr, "steps_profiled": steps,
                       "note": "FETCH_SIZE doubled (gfx950 correction, upper bound); per-step kernels only; eager launches",
                       "top_kernels": dict(top)}, indent=1))
 
