@@ -1080,12 +1080,16 @@ static unsigned tct_blocks(int64_t Sp) {
   const int64_t groups = Sp / 16;
   return (unsigned)(groups < 768 ? groups : 768);
 }
-// One-pass (shifted) BatchNorm statistics (bn_shift_ok) are the default of the time-resident convolutions;
-// DOF_TCN_ONEPASS=0 in the environment keeps the centred second pass (A/B measurements).
+// One-pass (shifted) BatchNorm statistics (bn_shift_ok) of the time-resident convolutions are OPT-IN since round 3
+// (DOF_TCN_ONEPASS=1): measured elementwise against a reference golden whose running means equal the batch means
+// (tests/golden/vade_tcn14_onepass.npz, every channel on the one-pass form) the gradients of 107 of 200 tensors leave the
+// standard bar, by up to 4.1 x (2e-3 of the tensor scale), while the centred second pass stays within 0.1 x of it on the
+// same fixture -- the refreshed running variances agree with the reference to 1e-7 either way, the loss terms to 1.5e-7.
+// The default path must meet the parity bar; the 4 % of the C4 step the second pass costs is the price.
 int dof_tcn_onepass_stats() {
   static const int on = [] {
     const char* e = getenv("DOF_TCN_ONEPASS");
-    return (e && e[0] == '0') ? 0 : 1;
+    return (e && e[0] == '1') ? 1 : 0;
   }();
   return on;
 }

@@ -216,15 +216,14 @@ def test_contrastive_tcn_gradient_parity_c4_slice(hip):
 
 
 def test_vade_tcn_onepass_reference_gpu(hip, golden_dir):
-    """The steady-state TCN path -- BatchNorm batch statistics from the shifted sums of the convolution epilogues, no
-    centred second pass -- ELEMENTWISE against the reference: the fixture's running means equal the batch means of the
-    recorded step, so |mean - K| <= 0.1 sigma holds for every channel of every time-resident convolution layer (the
-    predicate of DESIGN.md section 4) and all of them take the one-pass form.  Same bars as the B = 64 fixture: eval
-    forward, both objectives' loss terms, all 200 gradients (standard bar + identified ReLU-branch flips), refreshed
-    BatchNorm buffers."""
+    """A reference golden whose BatchNorm running means equal the batch means of the recorded step (make_golden_r03.py):
+    |mean - K| <= 0.1 sigma then holds for every channel of every time-resident convolution layer, i.e. every channel
+    WOULD take the one-pass (shifted-sum) statistics if they are enabled.  The product default (centred second pass)
+    meets the same bars as the B = 64 fixture here: eval forward, both objectives' loss terms, all 200 gradients
+    (standard bar + identified ReLU-branch flips), refreshed BatchNorm buffers."""
     import os
     from parity_common import load_golden, run_vade_tcn_b64_check
-    assert os.environ.get("DOF_TCN_ONEPASS", "1") != "0"
+    assert os.environ.get("DOF_TCN_ONEPASS", "0") != "1"
     d = load_golden(golden_dir, "vade_tcn14_onepass.npz")
     # the fixture's premise, checked on the fixture itself: refreshed running mean = 0.9 K + 0.1 batch mean = K
     n = 0
@@ -237,6 +236,25 @@ def test_vade_tcn_onepass_reference_gpu(hip, golden_dir):
     assert n == 32
     print("worst gradient error / tensor scale, identified flips:",
           run_vade_tcn_b64_check(hip, "cuda", golden_dir, fixture="vade_tcn14_onepass.npz", min_main=200))
+
+
+def test_tcn_onepass_opt_in_deviation_gpu(golden_dir):
+    """DOF_TCN_ONEPASS=1 on the same fixture, in a child process: every channel takes the one-pass statistics.  Loss terms
+    and refreshed buffers still meet the standard bars; the gradients do NOT (measured: 107 of 200 tensors beyond it, worst
+    4.1 x) -- which is why the switch is off by default -- and are held to 1e-2 of the tensor scale here so that the
+    opt-in path cannot rot unnoticed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tcn_onepass_fixture_probe.py")
+    env = dict(os.environ, DOF_TCN_ONEPASS="1")
+    r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("PROBE ")][-1][6:])
+    assert res["worst_loss_rel"] <= 1e-5 and res["worst_buffer_rel"] <= 5e-5, res
+    assert res["n_grads"] >= 160 and res["worst_grad_over_scale"] <= 1e-2, res
+    print("one-pass opt-in: tensors beyond the standard bar", res["beyond_standard_bar"], "worst / scale", res["worst_grad_over_scale"])
 
 
 def test_gru16_matrix_pipe_kernels_gpu():
