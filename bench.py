@@ -51,7 +51,7 @@ def synth_tables_fast(n_frames, n_nodes, n_edges, seed, device):
     return torch.from_numpy(tn).to(device), torch.from_numpy(te).to(device)
 
 
-def cpu_baseline(P, x, a, L, K, budget_s=75.0):
+def cpu_baseline(P, x, a, L, K, budget_s=100.0):
     """Oracle ('port' of the reference PyTorch-CPU path) timed on a bounded sample of the same workload: same
     architecture and initial weights (state_dict P), one batch of the SAME synthetic windows the device path trains on,
     main phase with distillation.  SURVEY 8(d) asks for the host's cores with the count printed: eager PyTorch on these
@@ -87,7 +87,7 @@ def cpu_baseline(P, x, a, L, K, budget_s=75.0):
         return B / float(np.median(times)), len(times)
 
     sweep = {}
-    for threads, n_warm, n_steps in ((8, 2, 6), (32, 1, 2), (all_threads, 1, 1), (1, 1, 1)):
+    for threads, n_warm, n_steps in ((8, 2, 6), (1, 1, 2), (32, 1, 2), (all_threads, 1, 1)):
         threads = min(threads, all_threads)
         if threads in sweep:
             continue

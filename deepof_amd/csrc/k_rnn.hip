@@ -481,23 +481,35 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(const float* __restrict__ X, c
 // by the summation order over k.  Same saved-gate / output layouts as k_gru3_fwd<16,16>: 16-byte output stores, the
 // four units' (r, z, n, W_hn h + b_hn) words are 64 contiguous bytes.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_gru16m_fwd(const float* __restrict__ X, const int* __restrict__ len,
-                                                   const float* __restrict__ wih0, const float* __restrict__ whh0,
-                                                   const float* __restrict__ bih0, const float* __restrict__ bhh0,
-                                                   const float* __restrict__ wih1, const float* __restrict__ whh1,
-                                                   const float* __restrict__ bih1, const float* __restrict__ bhh1,
-                                                   float* __restrict__ O, float* __restrict__ GS, int T, int64_t S,
-                                                   int64_t Sp) {
+// One launch serves up to two independent layers of this shape (blockIdx.z: the node and the edge stream of the encoder):
+// a stream of 14,336 sequences is only 1.75 wavefronts per SIMD, and a wavefront's MFMA and VALU phases do not overlap,
+// so two streams side by side finish in little more than the time of one (measured at 4 x the sequences: 3.4 x the time).
+struct Gru16mStream {
+  const float* X; const int* len;
+  const float *wih0, *whh0, *bih0, *bhh0, *wih1, *whh1, *bih1, *bhh1;
+  float* O; float* GS;          // forward: outputs, saved gates (or null)
+  const float* dO; float* dX; float* wg_partial;   // backward only
+  int64_t S, Sp;
+};
+
+__global__ void __launch_bounds__(64) k_gru16m_fwd(Gru16mStream sa, Gru16mStream sb, int T) {
   constexpr int HID = 16, IN = 16;
+  const Gru16mStream& A = blockIdx.z ? sb : sa;
+  const float* __restrict__ X = A.X;
+  const int* __restrict__ len = A.len;
+  float* __restrict__ O = A.O;
+  float* __restrict__ GS = A.GS;
+  const int64_t S = A.S, Sp = A.Sp;
+  if ((int64_t)blockIdx.x * 16 >= S) return;   // (the grid covers the longer stream)
   const int lane = threadIdx.x & 63;
   const int j = lane & 15, b = lane >> 4;
   const int64_t s = (int64_t)blockIdx.x * 16 + j;
   const int dir = blockIdx.y;
   const bool in_range = s < S;
-  const float* __restrict__ wih = dir ? wih1 : wih0;
-  const float* __restrict__ whh = dir ? whh1 : whh0;
-  const float* __restrict__ bih = dir ? bih1 : bih0;
-  const float* __restrict__ bhh = dir ? bhh1 : bhh0;
+  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
+  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
+  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
+  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
   // A tiles: row i = lane & 15 (a unit), k index = lane >> 4; K-block q covers input / hidden indices 4 (lane >> 4) + q
   float aix[3][4], ahh[3][4];
 #pragma unroll
@@ -873,23 +885,28 @@ __global__ void __launch_bounds__(256) k_gru16_bwd_fused(
 // 72 MFMAs per step and wavefront = 144 matrix-pipe cycles per (sequence, direction) and step (the VALU form: ~230
 // VALU instructions per four pairs).  Per-wavefront partials in k_gru16_bwd_fused's layout -> k_gru16_wg_finalize.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_gru16m_bwd(
-    const float* __restrict__ X, const int* __restrict__ len, const float* __restrict__ wih0,
-    const float* __restrict__ whh0, const float* __restrict__ bih0, const float* __restrict__ bhh0,
-    const float* __restrict__ wih1, const float* __restrict__ whh1, const float* __restrict__ bih1,
-    const float* __restrict__ bhh1, const float* __restrict__ O, const float* __restrict__ dO,
-    float* __restrict__ dX, float* __restrict__ wg_partial, int T, int64_t S, int64_t Sp) {
+__global__ void __launch_bounds__(64) k_gru16m_bwd(Gru16mStream st_a, Gru16mStream st_b, int T) {
   constexpr int HID = 16, IN = 16;
   __shared__ __attribute__((aligned(16))) float tile[6][16][16];  // [g_r, g_z, g_n, g_h, x, h_prev][sequence][unit]
+  const Gru16mStream& A = blockIdx.z ? st_b : st_a;
+  const float* __restrict__ X = A.X;
+  const int* __restrict__ len = A.len;
+  const float* __restrict__ O = A.O;
+  const float* __restrict__ dO = A.dO;
+  float* __restrict__ dX = A.dX;
+  float* __restrict__ wg_partial = A.wg_partial;
+  const int64_t S = A.S, Sp = A.Sp;
+  if ((int64_t)blockIdx.x * 16 >= S) return;   // (the grid covers the longer stream; whole workgroups leave)
+  const unsigned nblk_own = (unsigned)((S + 15) / 16);   // partial rows of THIS stream (gridDim.x may be the other stream's)
   const int lane = threadIdx.x & 63;
   const int j = lane & 15, b = lane >> 4;
   const int64_t s = (int64_t)blockIdx.x * 16 + j;
   const int dir = blockIdx.y;
   const bool in_range = s < S;
-  const float* __restrict__ wih = dir ? wih1 : wih0;
-  const float* __restrict__ whh = dir ? whh1 : whh0;
-  const float* __restrict__ bih = dir ? bih1 : bih0;
-  const float* __restrict__ bhh = dir ? bhh1 : bhh0;
+  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
+  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
+  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
+  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
   // forward tiles (row = unit lane & 15, K-block q = indices 4 (lane >> 4) + q) and transposed tiles (row = input /
   // hidden index lane & 15, K-block q = gate units 4 (lane >> 4) + q)
   float aix[3][4], ahh[3][4], tix[3][4], thh[3][4];
@@ -1031,7 +1048,7 @@ __global__ void __launch_bounds__(64) k_gru16m_bwd(
     for (int t = n; t < T; ++t) dof_st_row<4>(dx_out + ACT(t, 4 * b, IN, Sp, s), zero4);
   }
   // ---- partials of this wavefront's 16 sequences: tiles [a][row = unit][col], then the bias sums [gate][unit]
-  float* __restrict__ out = wg_partial + ((int64_t)dir * gridDim.x + blockIdx.x) * GRU16_WG_FLOATS;
+  float* __restrict__ out = wg_partial + ((int64_t)dir * nblk_own + blockIdx.x) * GRU16_WG_FLOATS;
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -1655,13 +1672,47 @@ bool dof_gru16_mfma(int64_t S) {
   return dof_gru_mfma() && S >= min_s;
 }
 
+static Gru16mStream gru16m_stream(const float* X, const int* len, DofGruW W, float* O, float* GS, const float* dO, float* dX,
+                                  float* wg_partial, int64_t S, int64_t Sp) {
+  Gru16mStream a;
+  a.X = X; a.len = len;
+  a.wih0 = W.wih0; a.whh0 = W.whh0; a.bih0 = W.bih0; a.bhh0 = W.bhh0;
+  a.wih1 = W.wih1; a.whh1 = W.whh1; a.bih1 = W.bih1; a.bhh1 = W.bhh1;
+  a.O = O; a.GS = GS; a.dO = dO; a.dX = dX; a.wg_partial = wg_partial; a.S = S; a.Sp = Sp;
+  return a;
+}
+
+// The encoder's two streams in one launch (see Gru16mStream).  Returns 1 when the pair was launched, 0 when the caller
+// has to launch the layers one by one (the matrix-pipe kernels are not selected for these sizes), < 0 on error.
+int dof_launch_gru16_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2], int T,
+                              const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
+  if (!(dof_gru16_mfma(S[0]) && dof_gru16_mfma(S[1]))) return 0;
+  const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], O[0], nullptr, nullptr, nullptr, nullptr, S[0], Sp[0]);
+  const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], O[1], nullptr, nullptr, nullptr, nullptr, S[1], Sp[1]);
+  const int64_t smax = S[0] > S[1] ? S[0] : S[1];
+  DOF_LAUNCH(k_gru16m_fwd, (dof_cdiv(smax, 16), 2, 2), (64), st, a, b, T);
+  return dof_check_launch("k_gru16m_fwd (pair)") == DOF_OK ? 1 : DOF_ERR_LAUNCH;
+}
+
+int dof_launch_gru16_bwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], const float* const O[2],
+                              const float* const dO[2], float* const dX[2], float* const wg_partial[2], int T,
+                              const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
+  if (!(dof_gru16_mfma(S[0]) && dof_gru16_mfma(S[1]))) return 0;
+  const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], const_cast<float*>(O[0]), nullptr, dO[0], dX[0], wg_partial[0], S[0], Sp[0]);
+  const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], const_cast<float*>(O[1]), nullptr, dO[1], dX[1], wg_partial[1], S[1], Sp[1]);
+  const int64_t smax = S[0] > S[1] ? S[0] : S[1];
+  DOF_LAUNCH(k_gru16m_bwd, (dof_cdiv(smax, 16), 2, 2), (64), st, a, b, T);
+  return dof_check_launch("k_gru16m_bwd (pair)") == DOF_OK ? 1 : DOF_ERR_LAUNCH;
+}
+
 // kind: 0 = (IN=2L,HID=2L) enc gru1 / dec gru2 ; 1 = (IN=4L,HID=L) enc gru2 ; 2 = (IN=L,HID=L, broadcast input) dec gru1
 #define GRU3_W W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st) {
   if (L == 8) {  // weight-stationary kernels: matrix-pipe recurrence (kind 0) / lane per unit
     if (kind == 0 && dof_gru16_mfma(S)) {  // (no gates saved: k_gru16m_bwd recomputes them)
-      DOF_LAUNCH(k_gru16m_fwd, (dof_cdiv(S, 16), 2), (64), st, X, len, GRU3_W, O, (float*)nullptr, T, S, Sp);
+      const Gru16mStream a = gru16m_stream(X, len, W, O, nullptr, nullptr, nullptr, nullptr, S, Sp);
+      DOF_LAUNCH(k_gru16m_fwd, (dof_cdiv(S, 16), 2, 1), (64), st, a, a, T);
     }
     else if (kind == 0) DOF_LAUNCH((k_gru3_fwd<16, 16, false>), (dof_cdiv(S, 16), 2), (256), st, X, len, GRU3_W, O, GS, T, S, Sp);
     else if (kind == 1) DOF_LAUNCH((k_gru3_fwd<32, 8, false>), (dof_cdiv(S, 32), 2), (256), st, X, len, GRU3_W, O, GS, T, S, Sp);
@@ -1721,8 +1772,8 @@ int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const 
                                const float* dO, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
                                hipStream_t st) {
   if (dof_gru16_mfma(S)) {  // matrix-pipe recurrence, gates recomputed (GS is not read: k_gru16m_fwd saved none)
-    DOF_LAUNCH(k_gru16m_bwd, (dof_cdiv(S, 16), 2), (64), st, X, len, W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1,
-               W.bhh1, O, dO, dX, wg_partial, T, S, Sp);
+    const Gru16mStream a = gru16m_stream(X, len, W, const_cast<float*>(O), nullptr, dO, dX, wg_partial, S, Sp);
+    DOF_LAUNCH(k_gru16m_bwd, (dof_cdiv(S, 16), 2, 1), (64), st, a, a, T);
     return dof_check_launch("k_gru16m_bwd");
   }
   DOF_LAUNCH(k_gru16_bwd_fused, (dof_cdiv(S, 16), 2), (256), st, X, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dX,

@@ -12,6 +12,11 @@ struct DofGruW {  // both directions of one torch.nn.GRU layer (weight_ih_l0[_re
 // ---- k_rnn.hip ------------------------------------------------------------------------------
 int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, float* xs, float* c, int* len, int T,
                             int G, int64_t S, int64_t Sp, hipStream_t st);
+int dof_launch_gru16_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2], int T,
+                              const int64_t S[2], const int64_t Sp[2], hipStream_t st);   // 1 = launched, 0 = not selected
+int dof_launch_gru16_bwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], const float* const O[2],
+                              const float* const dO[2], float* const dX[2], float* const wg_partial[2], int T,
+                              const int64_t S[2], const int64_t Sp[2], hipStream_t st);
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* O, float* GS, const float* dO,

@@ -1274,12 +1274,28 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
   if (p->tcn) return tcn_encoder_forward(p, const_cast<float*>(params), x, a, train, st);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
+  // stage by stage over both streams (they are independent): the first GRU layer of the two streams shares one launch
+  // when the matrix-pipe kernels serve it (dof_launch_gru16_fwd_pair)
+  for (int s = 0; s < 2; ++s) {
+    const StreamWs& w = p->sw[s];
+    TRY(dof_launch_enc_conv_fwd(L, w.F, s == 0 ? x : a, params + p->blk[s].conv, ws + w.xs, ws + w.c,
+                                reinterpret_cast<int*>(ws + w.len), T, w.G, w.S, w.Sp, st));
+  }
+  int paired = 0;
+  if (L == 8) {
+    const float* X[2] = {ws + p->sw[0].c, ws + p->sw[1].c};
+    const int* ln[2] = {reinterpret_cast<const int*>(ws + p->sw[0].len), reinterpret_cast<const int*>(ws + p->sw[1].len)};
+    const DofGruW W[2] = {gru_w(params, p->blk[0].g1), gru_w(params, p->blk[1].g1)};
+    float* O[2] = {ws + p->sw[0].o1, ws + p->sw[1].o1};
+    const int64_t S[2] = {p->sw[0].S, p->sw[1].S}, Sp[2] = {p->sw[0].Sp, p->sw[1].Sp};
+    paired = dof_launch_gru16_fwd_pair(X, ln, W, O, T, S, Sp, st);
+    if (paired < 0) return paired;
+  }
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
     const BlockOff& b = p->blk[s];
     int* len = reinterpret_cast<int*>(ws + w.len);
-    TRY(dof_launch_enc_conv_fwd(L, w.F, s == 0 ? x : a, params + b.conv, ws + w.xs, ws + w.c, len, T, w.G, w.S, w.Sp, st));
-    TRY(dof_launch_gru_fwd(L, 0, ws + w.c, len, gru_w(params, b.g1), ws + w.o1, train ? ws + w.g1 : nullptr, T, w.S, w.Sp, st));
+    if (!paired) TRY(dof_launch_gru_fwd(L, 0, ws + w.c, len, gru_w(params, b.g1), ws + w.o1, train ? ws + w.g1 : nullptr, T, w.S, w.Sp, st));
     TRY(dof_launch_ln_fwd(L, 4, ws + w.o1, params + b.n1w, params + b.n1b, ws + w.n1, T, w.S, w.Sp, st));
     TRY(dof_launch_gru_fwd(L, 1, ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, train ? ws + w.g2 : nullptr, T, w.S, w.Sp, st));
     TRY(dof_launch_enc_final_fwd(L, ws + w.o2, len, params + b.n2w, params + b.n2b, ws + w.hf, ws + w.n2, T, w.S, w.Sp, st));
@@ -1642,7 +1658,7 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
   // edge stream first: the forward pass ran node then edge, so the edge stream's saved gates are the more recent
   // residents of the Infinity Cache (measured: the first stream's GRU backward kernels run 15-20 % slower than the
   // second's whichever stream it is; C2 step -0.5 %)
-  for (int si = 0; si < 2; ++si) {
+  for (int si = 0; si < 2; ++si) {   // second layer + the LayerNorm between the layers, stream by stream
     const int s = 1 - si;
     const StreamWs& w = p->sw[s];
     const BlockOff& b = p->blk[s];
@@ -1657,9 +1673,28 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     }
     TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
                           ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
+  }
+  int paired = 0;
+  if (L == 8) {   // first layer: both streams in one launch when the matrix-pipe kernels serve it
+    const float* X[2] = {ws + p->sw[0].c, ws + p->sw[1].c};
+    const int* ln[2] = {reinterpret_cast<const int*>(ws + p->sw[0].len), reinterpret_cast<const int*>(ws + p->sw[1].len)};
+    const DofGruW W[2] = {gru_w(params, p->blk[0].g1), gru_w(params, p->blk[1].g1)};
+    const float* O[2] = {ws + p->sw[0].o1, ws + p->sw[1].o1};
+    const float* dO[2] = {ws + p->sw[0].do1, ws + p->sw[1].do1};
+    float* dX[2] = {ws + p->sw[0].dc, ws + p->sw[1].dc};
+    float* wg[2] = {ws + p->sw[0].wg1, ws + p->sw[1].wg1};
+    const int64_t S[2] = {p->sw[0].S, p->sw[1].S}, Sp[2] = {p->sw[0].Sp, p->sw[1].Sp};
+    paired = dof_launch_gru16_bwd_pair(X, ln, W, O, dO, dX, wg, T, S, Sp, st);
+    if (paired < 0) return paired;
+  }
+  for (int si = 0; si < 2; ++si) {
+    const int s = 1 - si;
+    const StreamWs& w = p->sw[s];
+    const BlockOff& b = p->blk[s];
+    const int* len = reinterpret_cast<const int*>(ws + w.len);
     if (L == 8) {
-      TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
-                                     ws + w.wg1, T, w.S, w.Sp, st));
+      if (!paired) TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
+                                                  ws + w.wg1, T, w.S, w.Sp, st));
       TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, accumulate, st));
     } else {
       TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));

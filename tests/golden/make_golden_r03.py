@@ -53,8 +53,8 @@ class KinkFlipper:
     ordinals (call order x flat index) to flip, None = all.  After a run: ``count`` such elements, ``ident`` = their
     (flat index, value) pairs."""
 
-    def __init__(self, delta=KINK_DELTA, only=None, dry=False):
-        self.delta, self.dry, self.count, self.ident = delta, dry, 0, []
+    def __init__(self, delta=None, only=None, dry=False):
+        self.delta, self.dry, self.count, self.ident = (KINK_DELTA if delta is None else delta), dry, 0, []
         self.only = None if only is None else set(int(o) for o in (only if hasattr(only, "__iter__") else [only]))
 
     def relu(self, x, inplace=False):
@@ -219,7 +219,20 @@ def vade_tcn_kinks(out, fname, tagp):
         kink_attribution(out, f"{tagp}::{phase}::", model, rerun, base, stored)
 
 
-def vqvae_tcn_kinks(out):
+def vqvae_tcn_kinks(out, delta=3e-5):
+    """(delta: the VQ-VAE step differentiates the decoder twice into 2 x 17 encoder BatchNorm layers; its HIP
+    pre-activations sit up to ~1e-5 from the reference's at the top of the streams -- the fixture runs at the looser
+    VQ_TCN_RTOL for the same reason -- so the candidate window is wider here.)"""
+    global KINK_DELTA
+    saved, KINK_DELTA = KINK_DELTA, delta
+    try:
+        _vqvae_tcn_kinks(out)
+    finally:
+        KINK_DELTA = saved
+    out["vqvae_tcn14::delta"] = np.float64(delta)
+
+
+def _vqvae_tcn_kinks(out):
     d = dict(np.load(os.path.join(HERE, "vqvae_tcn14.npz")))
     x, a = d["x"], d["a"]
     B, T, N, _ = x.shape
@@ -339,6 +352,10 @@ if __name__ == "__main__":
         MG.gen_vqvae("c5l8", ["B", "W"], 50, 8, 40, 8, 341, kmeans=0.5)
         MG.gen_vqvae("c3k512", [""], 25, 8, 512, 64, 351)
         MG.gen_contrastive("c5l8", ["B", "W"], 50, 8, 8, 361)
+    if "vqkinks" in what:   # refresh only the VQ-VAE part of tcn_kinks.npz
+        keep = {k: v for k, v in np.load(os.path.join(HERE, "tcn_kinks.npz")).items() if not k.startswith("vqvae_tcn14::")}
+        vqvae_tcn_kinks(keep)
+        np.savez_compressed(os.path.join(HERE, "tcn_kinks.npz"), **keep)
     if "tcn" in what:
         torch.set_num_threads(1)
         if not os.path.exists(os.path.join(HERE, "vade_tcn14_onepass.npz")) or "onepass" in what:
