@@ -18,11 +18,10 @@
       candidate i the reference step is re-run with exactly that element on the other branch, giving its gradient change
       D_i.  Stored: candidates whose change stays below a quarter of the standard bar everywhere are summed into
       ``harmless``; for each of the others ("significant") its 32 most affected gradient elements ("probes":
-      ``probe_tensor`` / ``probe_index``, ``own`` = each candidate's probe rows), the matrix ``A[j, i]`` = D_i at probe j
-      in bar units, and ``maxd[i, tensor]`` = max |D_i| per tensor.  The parity test NAMES the flipped elements by
-      matching pursuit on the gradient error at the probes: a candidate is accepted when the residual, projected on the
-      candidate's own probes, carries its change with coefficient 1 (0.6 .. 1.4) -- a flip happened or it did not --
-      and its change is then subtracted.  A tensor's bar is  standard bar + harmless + changes of the named flips.
+      ``probe_tensor`` / ``probe_index``) with its change there in bar units (``probe_value``), and ``maxd[i, tensor]`` =
+      max |D_i| per tensor.  The parity test NAMES the flipped elements by matching pursuit on the gradient error at the
+      probes: a candidate is accepted when the residual at its own probes carries its change with coefficient 1
+      (0.6 .. 1.4) -- a flip happened or it did not -- and its change is then subtracted there.  A tensor's bar is  standard bar + harmless + changes of the named flips.
       No tie budget: a deviation that is not the measured consequence of an identified flip fails.
 """
 import copy
@@ -125,40 +124,32 @@ def kink_attribution(out, prefix, model, rerun, base, stored, rtol=5e-4, atol=5e
             sig.append((ords, delta))
     # probes: the PROBES_PER most affected gradient elements (in bar units) of every significant candidate
     PROBES_PER = 32
-    probes, index = [], {}
-    own = []
-    for _o, delta in sig:
-        flat = torch.cat([delta[n].reshape(-1).abs() / bar[n] for n in probe_names])
-        top = torch.topk(flat, min(PROBES_PER, flat.numel())).indices.tolist()
-        mine = []
-        for g in top:
-            if g not in index:
-                index[g] = len(probes)
-                probes.append(g)
-            mine.append(index[g])
-        own.append(mine)
     sizes = np.cumsum([0] + [base[n].numel() for n in probe_names])
-    p_tensor = [int(np.searchsorted(sizes, g, side="right") - 1) for g in probes]
-    p_index = [int(g - sizes[t]) for g, t in zip(probes, p_tensor)]
-    A = np.zeros((len(probes), len(sig)), dtype=np.float32)
-    maxd = np.zeros((len(sig), len(names)))
+    p_tensor = np.zeros((len(sig), PROBES_PER), dtype=np.int16)     # index into ``tensors``
+    p_index = np.zeros((len(sig), PROBES_PER), dtype=np.int64)      # flat element index
+    p_value = np.zeros((len(sig), PROBES_PER), dtype=np.float32)    # the candidate's change there, in bar units
+    maxd = np.zeros((len(sig), len(names)), dtype=np.float32)
+    name_col = {n: i for i, n in enumerate(names)}
     for i, (_o, delta) in enumerate(sig):
-        for j, (t, k) in enumerate(zip(p_tensor, p_index)):
-            n = probe_names[t]
-            A[j, i] = float(delta[n].reshape(-1)[k]) / bar[n]
+        flat = torch.cat([delta[n].reshape(-1) / bar[n] for n in probe_names])
+        top = torch.topk(flat.abs(), min(PROBES_PER, flat.numel())).indices
+        for j, g in enumerate(top.tolist()):
+            t = int(np.searchsorted(sizes, g, side="right") - 1)
+            p_tensor[i, j] = name_col[probe_names[t]]
+            p_index[i, j] = g - sizes[t]
+            p_value[i, j] = float(flat[g])
         for k, n in enumerate(names):
             maxd[i, k] = float(delta[n].abs().max())
     out[prefix + "count"] = np.int64(count)
     out[prefix + "tensors"] = np.array(names)
     out[prefix + "harmless"] = np.array([harmless[n] for n in names])
     out[prefix + "first_ordinal"] = np.array([o[0] for o, _ in sig], dtype=np.int64)
-    out[prefix + "probe_tensor"] = np.array([probe_names[t] for t in p_tensor]) if probes else np.array([], dtype="U1")
-    out[prefix + "probe_index"] = np.array(p_index, dtype=np.int64)
-    out[prefix + "own"] = np.array([m + [-1] * (PROBES_PER - len(m)) for m in own], dtype=np.int64).reshape(len(sig), PROBES_PER)
-    out[prefix + "A"] = A
+    out[prefix + "probe_tensor"] = p_tensor
+    out[prefix + "probe_index"] = p_index
+    out[prefix + "probe_value"] = p_value
     out[prefix + "maxd"] = maxd
     out[prefix + "rtol"], out[prefix + "atol"] = np.float64(rtol), np.float64(atol)
-    print(f"{prefix} {count} candidates within {KINK_DELTA} ({len(cands)} distinct), {len(sig)} significant, {len(probes)} probes")
+    print(f"{prefix} {count} candidates within {KINK_DELTA} ({len(cands)} distinct), {len(sig)} significant")
 
 
 # ------------------------------------------------------------------------------------------------

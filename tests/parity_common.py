@@ -465,45 +465,47 @@ class KinkAttribution:
         self.col = {t: i for i, t in enumerate(self.tensors)}
         self.harmless = k[prefix + "harmless"]
         self.first_ordinal = k[prefix + "first_ordinal"]
-        self.probe_tensor = [str(t) for t in k[prefix + "probe_tensor"]]
+        self.probe_tensor = k[prefix + "probe_tensor"]       # (candidates, probes) index into self.tensors
         self.probe_index = k[prefix + "probe_index"]
-        self.own = k[prefix + "own"]
-        self.A, self.maxd = k[prefix + "A"].astype(np.float64), k[prefix + "maxd"]
+        self.probe_value = k[prefix + "probe_value"].astype(np.float64)
+        self.maxd = k[prefix + "maxd"]
         self.rtol, self.atol = float(k[prefix + "rtol"]), float(k[prefix + "atol"])
         self.flipped = np.zeros(len(self.first_ordinal), dtype=bool)
 
     def identify(self, got_of, ref_of):
         """got_of / ref_of: name -> gradient array.  Matching pursuit over the significant candidates: the one whose
-        own probes best carry its change with coefficient 1 is named and subtracted, until none qualifies.  Returns the
-        first ordinals (ReLU call order x flat index in the reference run) of the named flips."""
+        own probes best carry its change with coefficient 1 is named and its change subtracted from the residual at
+        those elements, until none qualifies.  Returns the first ordinals (ReLU call order x flat index in the
+        reference run) of the named flips."""
         n = len(self.first_ordinal)
         if n == 0:
             return []
-        bars = {}
-        R = np.zeros(len(self.probe_tensor))
-        for j, (t, idx) in enumerate(zip(self.probe_tensor, self.probe_index)):
-            ref = ref_of(t).reshape(-1)
-            if t not in bars:
-                bars[t] = self.atol + self.rtol * float(np.abs(ref).max())
-            R[j] = (float(got_of(t).reshape(-1)[idx]) - float(ref[idx])) / bars[t]
+        err, bars = {}, {}
+
+        def residual(t, idx):
+            key = (int(t), int(idx))
+            if key not in err:
+                name = self.tensors[key[0]]
+                ref = ref_of(name).reshape(-1)
+                if key[0] not in bars:
+                    bars[key[0]] = self.atol + self.rtol * float(np.abs(ref).max())
+                err[key] = (float(got_of(name).reshape(-1)[key[1]]) - float(ref[key[1]])) / bars[key[0]]
+            return err[key]
+
+        R = np.array([[residual(t, i) for t, i in zip(self.probe_tensor[c], self.probe_index[c])] for c in range(n)])
+        V = self.probe_value
+        vv = (V * V).sum(1)
         for _ in range(n):
-            best, best_gain = -1, 0.0
-            for i in range(n):
-                if self.flipped[i]:
-                    continue
-                rows = self.own[i][self.own[i] >= 0]
-                v = self.A[rows, i]
-                vv = float(v @ v)
-                if vv < 0.25:          # (a change below half a bar on its best probes cannot be told from rounding)
-                    continue
-                coef = float(R[rows] @ v) / vv
-                gain = float(R[rows] @ R[rows]) - float((R[rows] - v) @ (R[rows] - v))
-                if 0.6 <= coef <= 1.4 and gain > best_gain:
-                    best, best_gain = i, gain
-            if best < 0:
+            coef = np.where(vv >= 0.25, (R * V).sum(1) / np.maximum(vv, 1e-30), 0.0)   # (below half a bar: rounding)
+            gain = (R * R).sum(1) - ((R - V) ** 2).sum(1)
+            ok = (~self.flipped) & (coef >= 0.6) & (coef <= 1.4) & (gain > 0)
+            if not ok.any():
                 break
+            best = int(np.argmax(np.where(ok, gain, -np.inf)))
             self.flipped[best] = True
-            R = R - self.A[:, best]
+            for t, i, v in zip(self.probe_tensor[best], self.probe_index[best], V[best]):
+                err[(int(t), int(i))] -= v
+            R = np.array([[err[(int(t), int(i))] for t, i in zip(self.probe_tensor[c], self.probe_index[c])] for c in range(n)])
         return self.first_ordinal[self.flipped].tolist()
 
     def extra(self, name):
