@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -67,12 +67,15 @@ class PreprocDims(C.Structure):
     _fields_ = [("n_frames", C.c_int64), ("n_videos", C.c_int32), ("n_cols", C.c_int32), ("n_animals", C.c_int32),
                 ("n_node_cols", C.c_int32), ("n_edge_cols", C.c_int32), ("n_angle_cols", C.c_int32),
                 ("speed_mode", C.c_int32), ("dist_mode", C.c_int32), ("coord_mode", C.c_int32),
-                ("log_distances", C.c_int32), ("inter_scale", C.c_int32), ("fit_global", C.c_int32), ("clip", C.c_double)]
+                ("log_distances", C.c_int32), ("inter_scale", C.c_int32), ("fit_global", C.c_int32), ("clip", C.c_double),
+                ("scale_kind", C.c_int32), ("reserved", C.c_int32), ("col_keep", C.c_void_p)]
 
 
 PP_KINDS = {"other": 0, "coord": 1, "speed": 2, "dist_inner": 3, "dist_intra": 4, "angle": 5}
 PP_MODES = {None: 0, "per_column": 1, "groupwise": 2}
 PP_INTER_SCALE = {"mean": 0, "geom": 1, "global": 2}
+PP_SCALE_KINDS = {"standard": 0, "minmax": 1}
+PP_STAT_DOUBLES = 5   # (n, mean, M2, min, max)
 PP_MAX_COLS, PP_MAX_ANIMALS = 512, 8
 
 _P = C.c_void_p
@@ -133,6 +136,7 @@ SIGNATURES = {
     "dof_preprocess_tables": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 16),
     "dof_preprocess_video_stats": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 10),
     "dof_preprocess_fit_global": (C.c_int, [C.POINTER(PreprocDims), _I32, _P, _P, _P, _P]),
+    "dof_preprocess_raw_moments": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 6),
 }
 
 

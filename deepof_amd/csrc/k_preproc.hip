@@ -34,8 +34,10 @@ constexpr int PP_TR = 8;    // rows per output tile (one thread owns a column of
 constexpr double PP_EPS = 2.220446049250313e-16;
 
 struct PpStat {
-  double n, mean, m2;
+  double n, mean, m2, mn, mx;  // DOF_PP_STAT_DOUBLES; mn / mx = +inf / -inf while n == 0
 };
+static_assert(sizeof(PpStat) == DOF_PP_STAT_DOUBLES * sizeof(double), "PpStat is the (videos, columns, 5) exchange row");
+__device__ __forceinline__ PpStat pp_empty() { return PpStat{0.0, 0.0, 0.0, INFINITY, -INFINITY}; }
 
 __device__ __forceinline__ bool pp_isnan(double x) { return x != x; }
 __device__ __forceinline__ uint64_t pp_bits(double x) {
@@ -59,21 +61,33 @@ __device__ __forceinline__ PpStat pp_merge(const PpStat a, const PpStat b) {
   const double d = b.mean - a.mean;
   r.mean = a.mean + d * (b.n / r.n);
   r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+  r.mn = b.mn < a.mn ? b.mn : a.mn;
+  r.mx = b.mx > a.mx ? b.mx : a.mx;
   return r;
 }
-__device__ __forceinline__ PpStat pp_from_sums(double n, double shift, double s1, double s2) {
+__device__ __forceinline__ PpStat pp_from_sums(double n, double shift, double s1, double s2, double mn, double mx) {
   PpStat r;
   r.n = n;
   r.mean = n > 0.0 ? shift + s1 / n : 0.0;
   r.m2 = n > 0.0 ? s2 - s1 * s1 / n : 0.0;
+  r.mn = n > 0.0 ? mn : INFINITY;
+  r.mx = n > 0.0 ? mx : -INFINITY;
   return r;
 }
 // StandardScaler's (mean_, scale_) from (n, mean, M2): population variance, near-constant features get scale 1
 // (sklearn _is_constant_feature / _handle_zeros_in_scale); nothing seen -> NaN like the 0/0 there
-__device__ __forceinline__ void pp_fit(const PpStat s, double* mean, double* scale) {
+// MinMaxScaler (scale_kind 1): X * scale_ + min_ with scale_ = 1 / range, min_ = -data_min * scale_, i.e. the affine map
+// (x - data_min) / range in the same (offset, divisor) form; ranges below 10 eps count as constant (divisor 1)
+__device__ __forceinline__ void pp_fit(const PpStat s, int scale_kind, double* mean, double* scale) {
   if (s.n == 0.0) {
     *mean = pp_nanv();
     *scale = pp_nanv();
+    return;
+  }
+  if (scale_kind == DOF_PP_SCALE_MINMAX) {
+    const double range = s.mx - s.mn;
+    *mean = s.mn;
+    *scale = range < 10.0 * PP_EPS ? 1.0 : range;
     return;
   }
   const double var = s.m2 / s.n;
@@ -119,16 +133,29 @@ constexpr unsigned long long PP_NOKEY = ~0ull;  // a NaN bit pattern no hypot() 
 // keys of all rows, all animals: one thread per row (the 4 reference coordinates of an animal are 4 scattered
 // 8-byte reads of the row -- done once here, by as many workgroups as it takes, not by the one workgroup per
 // (animal, video) of the selection below)
+// keep (videos, C) bytes or null: a reference column the low-variance filter dropped in the row's video is absent there
+// (scale_table then finds no size factor for that animal: "no value" keys)
 __global__ void __launch_bounds__(256) k_pp_hyp(const double* __restrict__ raw, const int* __restrict__ size_ref, int C, int A,
-                                                int64_t F, unsigned long long* __restrict__ keys) {
+                                                int64_t F, const int64_t* __restrict__ video_off, int V,
+                                                const uint8_t* __restrict__ keep, unsigned long long* __restrict__ keys) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= F) return;
   const double* row = raw + r * C;
+  const uint8_t* kv = nullptr;
+  if (keep) {
+    int lo = 0, hi = V - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (video_off[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    kv = keep + (int64_t)lo * C;
+  }
   for (int a = 0; a < A; ++a) {
     const int c0 = size_ref[4 * a], c1 = size_ref[4 * a + 1], c2 = size_ref[4 * a + 2], c3 = size_ref[4 * a + 3];
     if (c0 < 0 || c1 < 0 || c2 < 0 || c3 < 0) continue;
+    const bool present = !kv || (kv[c0] && kv[c1] && kv[c2] && kv[c3]);
     const double len = hypot(row[c0] - row[c2], row[c1] - row[c3]);
-    keys[(int64_t)a * F + r] = pp_isnan(len) ? PP_NOKEY : pp_bits(len);
+    keys[(int64_t)a * F + r] = (!present || pp_isnan(len)) ? PP_NOKEY : pp_bits(len);
   }
 }
 
@@ -259,8 +286,8 @@ __global__ void __launch_bounds__(256) k_pp_size(const int64_t* __restrict__ vid
 // default factor (median of the usable factors, else 1), substitution of unusable factors, and the reciprocal
 // size divisor of every column of every video
 __global__ void __launch_bounds__(256) k_pp_divisors(const int* __restrict__ chain_off, const int* __restrict__ chain,
-                                                     int C, int A, int inter_scale, double* __restrict__ s_out,
-                                                     double* __restrict__ rdiv) {
+                                                     int C, int A, int inter_scale, const uint8_t* __restrict__ keep,
+                                                     double* __restrict__ s_out, double* __restrict__ rdiv) {
   __shared__ double S[DOF_PP_MAX_ANIMALS + 1];
   const int v = blockIdx.x;
   double* sv = s_out + (int64_t)v * (A + 1);
@@ -288,7 +315,8 @@ __global__ void __launch_bounds__(256) k_pp_divisors(const int* __restrict__ cha
   for (int c = threadIdx.x; c < C; c += 256) {
     double d = 1.0;
     for (int e = chain_off[c]; e < chain_off[c + 1]; ++e) {
-      const int a1 = chain[3 * e], a2 = chain[3 * e + 1], same = chain[3 * e + 2];
+      const int a1 = chain[4 * e], a2 = chain[4 * e + 1], same = chain[4 * e + 2], src = chain[4 * e + 3];
+      if (keep && !keep[(int64_t)v * C + src]) continue;  // the column this division comes from is absent in this video
       const double s1 = S[a1 < 0 ? A : a1], s2 = S[a2 < 0 ? A : a2];
       double s = s1;
       if (!same) s = inter_scale == 0 ? 0.5 * (s1 + s2) : inter_scale == 1 ? sqrt(s1 * s2) : S[A];
@@ -439,8 +467,8 @@ __global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw
                                                   const int* __restrict__ slot_v, const int* __restrict__ chunks,
                                                   const int* __restrict__ col_kind, const double* __restrict__ rdiv,
                                                   const uint8_t* __restrict__ mask, int C, int speed_mode, int dist_mode,
-                                                  int coord_mode, PpStat* __restrict__ part_all,
-                                                  PpStat* __restrict__ part_smp) {
+                                                  int coord_mode, int all_cols, const uint8_t* __restrict__ keep,
+                                                  PpStat* __restrict__ part_all, PpStat* __restrict__ part_smp) {
   __shared__ PpStat sh[2][4][64];
   __shared__ double logtab[128][2];
   const int v = slot_v[blockIdx.x];
@@ -462,11 +490,15 @@ __global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw
     // this thread sees (fixed from then on, so no element waits for the previous one)
     double n[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0}, nb[2] = {0.0, 0.0}, s1b[2] = {0.0, 0.0},
            s2b[2] = {0.0, 0.0};
+    double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY}, lob[2] = {INFINITY, INFINITY},
+           hib[2] = {-INFINITY, -INFINITY};
     double shift = 0.0;
     bool have_shift = false;
-    const bool mine = cl < ccount && pp_mode(col_kind[c], speed_mode, dist_mode, coord_mode) != DOF_PP_MODE_NONE;
+    // all_cols: moments of the raw values of every column (the low-variance filter's input)
+    const bool mine = cl < ccount && (all_cols || pp_mode(col_kind[c], speed_mode, dist_mode, coord_mode) != DOF_PP_MODE_NONE) &&
+                      (!keep || keep[(int64_t)v * C + c]);
     if (mine) {
-      const double rd = rdiv[(int64_t)v * C + c];
+      const double rd = all_cols ? 1.0 : rdiv[(int64_t)v * C + c];
       const int rstep = 4 * pack;
       for (int64_t rb = r0 + rg * pack + sub; rb < r1; rb += 8 * rstep) {
         double x[8];
@@ -480,7 +512,7 @@ __global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           double u = x[i] * rd;
-          if (lg) {
+          if (lg && !all_cols) {
             if (u < 0.0) u = 0.0;
             u = pp_log1p(u, logtab);
           }
@@ -501,20 +533,26 @@ __global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw
           n[i & 1] += ok ? 1.0 : 0.0;
           s1[i & 1] += d;
           s2[i & 1] = fma(d, d, s2[i & 1]);
+          lo[i & 1] = ok && x[i] < lo[i & 1] ? x[i] : lo[i & 1];
+          hi[i & 1] = ok && x[i] > hi[i & 1] ? x[i] : hi[i & 1];
           if (MASKED) {
             const bool smp = ok && in[i];
             nb[i & 1] += smp ? 1.0 : 0.0;
             s1b[i & 1] += smp ? d : 0.0;
             s2b[i & 1] += smp ? d * d : 0.0;
+            lob[i & 1] = smp && x[i] < lob[i & 1] ? x[i] : lob[i & 1];
+            hib[i & 1] = smp && x[i] > hib[i & 1] ? x[i] : hib[i & 1];
           }
         }
       }
     }
-    sh[0][rg][lane] = pp_from_sums(n[0] + n[1], shift, s1[0] + s1[1], s2[0] + s2[1]);
-    sh[1][rg][lane] = MASKED ? pp_from_sums(nb[0] + nb[1], shift, s1b[0] + s1b[1], s2b[0] + s2b[1]) : sh[0][rg][lane];
+    sh[0][rg][lane] = pp_from_sums(n[0] + n[1], shift, s1[0] + s1[1], s2[0] + s2[1], fmin(lo[0], lo[1]), fmax(hi[0], hi[1]));
+    sh[1][rg][lane] = MASKED ? pp_from_sums(nb[0] + nb[1], shift, s1b[0] + s1b[1], s2b[0] + s2b[1], fmin(lob[0], lob[1]),
+                                            fmax(hib[0], hib[1]))
+                             : sh[0][rg][lane];
     __syncthreads();
     if (rg < 2 && lane < ccount) {
-      PpStat t = {0.0, 0.0, 0.0};
+      PpStat t = pp_empty();
       for (int g = 0; g < 4; ++g)
         for (int k = 0; k < pack; ++k) t = pp_merge(t, sh[rg][g][k * width + lane]);
       (rg == 0 ? part_all : part_smp)[(int64_t)blockIdx.x * C + c] = t;
@@ -526,7 +564,7 @@ __global__ void __launch_bounds__(256) k_pp_stats(const double* __restrict__ raw
 // one of 4 interleaved sub-sequences (rg) of `count` partials (stride in PpStat units), merged in a fixed order,
 // 8 loads in flight
 __device__ __forceinline__ PpStat pp_merge_run(const PpStat* __restrict__ base, int64_t count, int64_t stride, int rg) {
-  PpStat acc = {0.0, 0.0, 0.0};
+  PpStat acc = pp_empty();
   for (int64_t k = rg; k < count; k += 32) {
     PpStat t[8];
 #pragma unroll
@@ -550,7 +588,7 @@ __global__ void __launch_bounds__(256) k_pp_video_cols(const int64_t* __restrict
   const int c = blockIdx.x * 64 + lane;
   const int64_t slot0 = video_off[v] / PP_RS + v;
   const int64_t nstrip = (video_off[v + 1] - video_off[v] + PP_RS - 1) / PP_RS;
-  PpStat a = {0.0, 0.0, 0.0}, s = {0.0, 0.0, 0.0};
+  PpStat a = pp_empty(), s = pp_empty();
   if (c < C) {
     a = pp_merge_run(part_all + slot0 * C + c, nstrip, C, rg);
     s = pp_merge_run(part_smp + slot0 * C + c, nstrip, C, rg);
@@ -570,7 +608,7 @@ __global__ void __launch_bounds__(256) k_pp_video_cols(const int64_t* __restrict
 __device__ __forceinline__ void pp_group_stats(const PpStat* __restrict__ col, const int* __restrict__ kinds, int C,
                                                int kind0, int n_groups, PpStat (*tree)[64], PpStat* __restrict__ grp) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  PpStat acc = {0.0, 0.0, 0.0};
+  PpStat acc = pp_empty();
   if (w < n_groups)
     for (int c = lane; c < C; c += 64)
       if (kinds[c] == kind0 + w) acc = pp_merge(acc, col[c]);
@@ -589,7 +627,7 @@ __device__ __forceinline__ void pp_group_stats(const PpStat* __restrict__ col, c
 __global__ void __launch_bounds__(256) k_pp_video_fin(const int* __restrict__ col_kind,
                                                       const PpStat* __restrict__ vcol_all,
                                                       const PpStat* __restrict__ vcol_smp, int C, int speed_mode,
-                                                      int dist_mode, double* __restrict__ vscale,
+                                                      int dist_mode, int scale_kind, double* __restrict__ vscale,
                                                       PpStat* __restrict__ ystat) {
   __shared__ PpStat col_all[DOF_PP_MAX_COLS];
   __shared__ int kinds[DOF_PP_MAX_COLS];
@@ -607,14 +645,16 @@ __global__ void __launch_bounds__(256) k_pp_video_fin(const int* __restrict__ co
     const int mode = kind == DOF_PP_SPEED ? speed_mode
                      : (kind == DOF_PP_DIST_INNER || kind == DOF_PP_DIST_INTRA) ? dist_mode : DOF_PP_MODE_NONE;
     double m = 0.0, s = 1.0;
-    if (mode == DOF_PP_MODE_PER_COLUMN) pp_fit(col_all[c], &m, &s);
-    if (mode == DOF_PP_MODE_GROUPWISE) pp_fit(grp[kind - DOF_PP_SPEED], &m, &s);
+    if (mode == DOF_PP_MODE_PER_COLUMN) pp_fit(col_all[c], scale_kind, &m, &s);
+    if (mode == DOF_PP_MODE_GROUPWISE) pp_fit(grp[kind - DOF_PP_SPEED], scale_kind, &m, &s);
     vscale[((int64_t)v * C + c) * 2] = m;
     vscale[((int64_t)v * C + c) * 2 + 1] = s;
     PpStat y = vcol_smp[(int64_t)v * C + c];
     y.mean = (y.mean - m) / s;
     y.m2 = y.m2 / (s * s);
-    if (pp_isnan(y.mean) || pp_isnan(y.m2)) y.n = 0.0;
+    y.mn = (y.mn - m) / s;  // s > 0: the extremes stay the extremes
+    y.mx = (y.mx - m) / s;
+    if (y.n == 0.0 || pp_isnan(y.mean) || pp_isnan(y.m2)) y = pp_empty();
     ystat[(int64_t)v * C + c] = y;
   }
 }
@@ -625,7 +665,7 @@ __global__ void __launch_bounds__(256) k_pp_global_cols(const PpStat* __restrict
   __shared__ PpStat sh[4][64];
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  PpStat a = {0.0, 0.0, 0.0};
+  PpStat a = pp_empty();
   if (c < C) a = pp_merge_run(ystat + c, V, C, rg);
   sh[rg][lane] = a;
   __syncthreads();
@@ -640,7 +680,7 @@ __global__ void __launch_bounds__(256) k_pp_global_cols(const PpStat* __restrict
 // every rank's rows and runs this on each rank): same merge order as k_pp_global_cols + k_pp_coef, so the scalers
 // are bit-identical to those of a single-GPU call over the same videos
 __global__ void __launch_bounds__(256) k_pp_fit_global(const int* __restrict__ col_kind, const PpStat* __restrict__ ystat, int V,
-                                                       int C, int speed_mode, int dist_mode, int coord_mode,
+                                                       int C, int speed_mode, int dist_mode, int coord_mode, int scale_kind,
                                                        double* __restrict__ scaler) {
   __shared__ PpStat col[DOF_PP_MAX_COLS];
   __shared__ int kinds[DOF_PP_MAX_COLS];
@@ -649,7 +689,7 @@ __global__ void __launch_bounds__(256) k_pp_fit_global(const int* __restrict__ c
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   for (int cbase = 0; cbase < C; cbase += 64) {
     const int c = cbase + lane;
-    PpStat a = {0.0, 0.0, 0.0};
+    PpStat a = pp_empty();
     if (c < C) a = pp_merge_run(ystat + c, V, C, rg);
     tree[rg][lane] = a;
     __syncthreads();
@@ -665,7 +705,8 @@ __global__ void __launch_bounds__(256) k_pp_fit_global(const int* __restrict__ c
   for (int c = threadIdx.x; c < C; c += 256) {
     const int mode = pp_mode(kinds[c], speed_mode, dist_mode, coord_mode);
     double gm = 0.0, gs = 1.0;
-    if (mode != DOF_PP_MODE_NONE) pp_fit(mode == DOF_PP_MODE_PER_COLUMN ? col[c] : grp[kinds[c] - DOF_PP_COORD], &gm, &gs);
+    if (mode != DOF_PP_MODE_NONE)
+      pp_fit(mode == DOF_PP_MODE_PER_COLUMN ? col[c] : grp[kinds[c] - DOF_PP_COORD], scale_kind, &gm, &gs);
     scaler[2 * c] = gm;
     scaler[2 * c + 1] = gs;
   }
@@ -677,7 +718,8 @@ __global__ void __launch_bounds__(256) k_pp_fit_global(const int* __restrict__ c
 __global__ void __launch_bounds__(256) k_pp_coef(const int* __restrict__ col_kind, const PpStat* __restrict__ gcol,
                                                  const double* __restrict__ rdiv, const double* __restrict__ vscale,
                                                  double* __restrict__ scaler, int fit_global, int C, int speed_mode,
-                                                 int dist_mode, int coord_mode, double* __restrict__ coef,
+                                                 int dist_mode, int coord_mode, int scale_kind,
+                                                 const uint8_t* __restrict__ keep, double* __restrict__ coef,
                                                  double* __restrict__ video_scaler) {
   __shared__ PpStat col[DOF_PP_MAX_COLS];
   __shared__ int kinds[DOF_PP_MAX_COLS];
@@ -700,7 +742,8 @@ __global__ void __launch_bounds__(256) k_pp_coef(const int* __restrict__ col_kin
       gm = 0.0;
       gs = 1.0;
       // nothing sampled -> NaN like the reference's 0/0 (such columns hold no value anyway)
-      if (mode != DOF_PP_MODE_NONE) pp_fit(mode == DOF_PP_MODE_PER_COLUMN ? col[c] : grp[kind - DOF_PP_COORD], &gm, &gs);
+      if (mode != DOF_PP_MODE_NONE)
+        pp_fit(mode == DOF_PP_MODE_PER_COLUMN ? col[c] : grp[kind - DOF_PP_COORD], scale_kind, &gm, &gs);
       if (v == 0) {
         scaler[2 * c] = gm;
         scaler[2 * c + 1] = gs;
@@ -712,9 +755,12 @@ __global__ void __launch_bounds__(256) k_pp_coef(const int* __restrict__ col_kin
     const int64_t i = (int64_t)v * C + c;
     const double m = vscale[2 * i], s = vscale[2 * i + 1];
     const double p = 1.0 / s, q = 1.0 / gs;
-    coef[3 * i] = rdiv[i];
-    coef[3 * i + 1] = p * q;
-    coef[3 * i + 2] = -(m * p * q + gm * q);
+    // a column the low-variance filter dropped in this video comes back as zeros (the reference re-inserts it as a
+    // missing column, which _pp_sanitize_numeric fills with 0): u = x * 0, z = u * 0 + 0, gaps interpolate between zeros
+    const bool gone = keep && !keep[i];
+    coef[3 * i] = gone ? 0.0 : rdiv[i];
+    coef[3 * i + 1] = gone ? 0.0 : p * q;
+    coef[3 * i + 2] = gone ? 0.0 : -(m * p * q + gm * q);
     if (video_scaler) {
       video_scaler[2 * i] = m;
       video_scaler[2 * i + 1] = s;
@@ -1024,6 +1070,10 @@ int pp_check(const DofPreprocDims* d, bool stats_only = false) {
       dof_set_error("dof_preprocess: bad standardisation mode %d", m);
       return DOF_ERR_ARG;
     }
+  if (d->scale_kind != DOF_PP_SCALE_STANDARD && d->scale_kind != DOF_PP_SCALE_MINMAX) {
+    dof_set_error("dof_preprocess: scale_kind %d not built (standard and minmax are)", d->scale_kind);
+    return DOF_ERR_UNSUPPORTED;
+  }
   if (d->inter_scale < 0 || d->inter_scale > 2) {
     dof_set_error("dof_preprocess: bad inter_scale %d", d->inter_scale);
     return DOF_ERR_ARG;
@@ -1034,7 +1084,7 @@ int pp_check(const DofPreprocDims* d, bool stats_only = false) {
 }  // namespace
 
 extern "C" int64_t dof_preprocess_workspace_bytes(const DofPreprocDims* dims) {
-  if (pp_check(dims) != DOF_OK) return -1;
+  if (pp_check(dims, true) != DOF_OK) return -1;  // no output columns: the statistics-only entry points
   return pp_layout(*dims, nullptr).bytes;
 }
 
@@ -1067,21 +1117,21 @@ int pp_run(const DofPreprocDims* dims, bool stats_only, const double* raw, const
   if (!stats_only) (void)hipMemsetAsync(w.notes, 0xFF, (size_t)w.note_bytes, st);
   if (A > 0) {
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(w.hyp);
-    DOF_LAUNCH(k_pp_hyp, (dof_cdiv(d.n_frames, 256)), (256), st, raw, size_ref, C, A, d.n_frames, keys);
+    DOF_LAUNCH(k_pp_hyp, (dof_cdiv(d.n_frames, 256)), (256), st, raw, size_ref, C, A, d.n_frames, video_off, V, d.col_keep, keys);
     DOF_LAUNCH(k_pp_size, (A, V), (256), st, video_off, size_ref, A, d.n_frames, (const unsigned long long*)keys, w.sfac);
   }
-  DOF_LAUNCH(k_pp_divisors, (V), (256), st, chain_off, chain, C, A, d.inter_scale, w.sfac, w.rdiv);
+  DOF_LAUNCH(k_pp_divisors, (V), (256), st, chain_off, chain, C, A, d.inter_scale, d.col_keep, w.sfac, w.rdiv);
 #define PP_STATS(M)                                                                                                  \
   DOF_LAUNCH((k_pp_stats<M>), ((unsigned)strips), (256), st, raw, video_off, (const int*)w.strip_v, (const int*)w.chunks, \
              col_kind, (const double*)w.rdiv, sample_mask, C, d.speed_mode, d.dist_mode,                             \
-             coord_stats ? d.coord_mode : DOF_PP_MODE_NONE, w.part_all, w.part_smp)
+             coord_stats ? d.coord_mode : DOF_PP_MODE_NONE, 0, d.col_keep, w.part_all, w.part_smp)
   if (sample_mask) PP_STATS(true); else PP_STATS(false);
 #undef PP_STATS
   const unsigned col_chunks = dof_cdiv(C, 64);
   DOF_LAUNCH(k_pp_video_cols, (col_chunks, V), (256), st, video_off, (const PpStat*)w.part_all, (const PpStat*)w.part_smp, C,
              w.vcol_all, w.vcol_smp);
   DOF_LAUNCH(k_pp_video_fin, (V), (256), st, col_kind, (const PpStat*)w.vcol_all, (const PpStat*)w.vcol_smp, C, d.speed_mode,
-             d.dist_mode, w.vscale, w.ystat);
+             d.dist_mode, d.scale_kind, w.vscale, w.ystat);
   if (size_out) (void)hipMemcpyAsync(size_out, w.sfac, (size_t)V * (A + 1) * 8, hipMemcpyDeviceToDevice, st);
   if (stats_only) {
     (void)hipMemcpyAsync(ystat_out, w.ystat, (size_t)V * C * sizeof(PpStat), hipMemcpyDeviceToDevice, st);
@@ -1089,7 +1139,7 @@ int pp_run(const DofPreprocDims* dims, bool stats_only, const double* raw, const
   }
   if (d.fit_global) DOF_LAUNCH(k_pp_global_cols, (col_chunks), (256), st, (const PpStat*)w.ystat, V, C, w.gcol);
   DOF_LAUNCH(k_pp_coef, (V), (256), st, col_kind, (const PpStat*)w.gcol, (const double*)w.rdiv, (const double*)w.vscale,
-             scaler, d.fit_global, C, d.speed_mode, d.dist_mode, d.coord_mode, w.coef, video_scaler);
+             scaler, d.fit_global, C, d.speed_mode, d.dist_mode, d.coord_mode, d.scale_kind, d.col_keep, w.coef, video_scaler);
   PpOutArgs oa;
   oa.raw = raw;
   oa.video_off = video_off;
@@ -1137,6 +1187,29 @@ extern "C" int dof_preprocess_fit_global(const DofPreprocDims* dims, int32_t n_v
     return DOF_ERR_ARG;
   }
   DOF_LAUNCH(k_pp_fit_global, (1), (256), (hipStream_t)stream, col_kind, reinterpret_cast<const PpStat*>(ystat_all),
-             n_videos_total, dims->n_cols, dims->speed_mode, dims->dist_mode, dims->coord_mode, scaler);
+             n_videos_total, dims->n_cols, dims->speed_mode, dims->dist_mode, dims->coord_mode, dims->scale_kind, scaler);
   return dof_check_launch("dof_preprocess_fit_global");
+}
+
+extern "C" int dof_preprocess_raw_moments(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
+                                          const int32_t* col_kind, double* moments_out, void* workspace, void* stream) {
+  const int rc = pp_check(dims, true);
+  if (rc != DOF_OK) return rc;
+  if (!raw || !video_off || !col_kind || !moments_out || !workspace) {
+    dof_set_error("dof_preprocess_raw_moments: null pointer argument");
+    return DOF_ERR_ARG;
+  }
+  const DofPreprocDims& d = *dims;
+  hipStream_t st = (hipStream_t)stream;
+  const PpWorkspace w = pp_layout(d, workspace);
+  const int V = d.n_videos, C = d.n_cols;
+  const int64_t strips = pp_slots(d.n_frames, V, PP_RS), tiles = pp_slots(d.n_frames, V, PP_TR);
+  DOF_LAUNCH(k_pp_setup, (dof_cdiv(strips, DOF_PP_MAX_COLS) + dof_cdiv(tiles, DOF_PP_MAX_COLS) + 2), (DOF_PP_MAX_COLS), st,
+             video_off, V, strips, tiles, col_kind, (const int*)nullptr, C, 0, 0, w.strip_v, w.tile_rec, w.chunks, w.ochunks);
+  DOF_LAUNCH((k_pp_stats<false>), ((unsigned)strips), (256), st, raw, video_off, (const int*)w.strip_v, (const int*)w.chunks,
+             col_kind, (const double*)nullptr, (const uint8_t*)nullptr, C, 0, 0, 0, 1, (const uint8_t*)nullptr, w.part_all, w.part_smp);
+  DOF_LAUNCH(k_pp_video_cols, (dof_cdiv(C, 64), V), (256), st, video_off, (const PpStat*)w.part_all, (const PpStat*)w.part_smp, C,
+             w.vcol_all, w.vcol_smp);
+  (void)hipMemcpyAsync(moments_out, w.vcol_all, (size_t)V * C * sizeof(PpStat), hipMemcpyDeviceToDevice, st);
+  return dof_check_launch("dof_preprocess_raw_moments");
 }

@@ -1,6 +1,7 @@
 """Pose-table preprocessing on the device: the host side of ``dof_preprocess_tables``.
 
-Mirrors ``TableDict.preprocess`` (/root/reference/deepof/data.py:3773-3916, scale="standard") up to window
+Mirrors ``TableDict.preprocess`` (/root/reference/deepof/data.py:3773-3916; scale "standard" or "minmax",
+``filter_low_variance`` where every video drops the same columns) up to window
 extraction, and the column bookkeeping of ``get_graph_dataset`` (data.py:2797-2880): raw merged tables
 (coordinates + speeds + distances [+ angles]) of every video go to the device ONCE as float64; size
 normalisation, log1p, per-video and global standardisation, clipping, interpolation and the fp32 cast run there and
@@ -51,7 +52,7 @@ class ColumnPlan:
     kinds: np.ndarray        # (C,) int32
     size_ref: np.ndarray     # (A, 4) int32
     chain_off: np.ndarray    # (C+1,) int32
-    chain: np.ndarray        # (k, 3) int32
+    chain: np.ndarray        # (k, 4) int32: (animal 1, animal 2, same animal, source column)
     animal_ids: List
 
 
@@ -76,24 +77,24 @@ def column_plan(columns: Sequence, animal_ids) -> ColumnPlan:
         need = [(a, "x"), (a, "y"), (b, "x"), (b, "y")]
         if all(n in where for n in need):
             size_ref[i] = [where[n] for n in need]
-    chains: List[List[Tuple[int, int, int]]] = [[] for _ in columns]
+    chains: List[List[Tuple[int, int, int, int]]] = [[] for _ in columns]
     for aid in animal_ids:
         mine = [bp for bp in bodyparts if owner[bp] == aid]
         for bp in mine:
             for lab in ((bp, "x"), (bp, "y"), bp):
                 if lab in where:
-                    chains[where[lab]].append((code[aid], code[aid], 1))
+                    chains[where[lab]].append((code[aid], code[aid], 1, where[lab]))
     for i, c in enumerate(columns):
         if kinds[i] in (_capi.PP_KINDS["dist_inner"], _capi.PP_KINDS["dist_intra"]):
             o1, o2 = owner.get(c[0]), owner.get(c[1])
-            entry = (code.get(o1, -1), code.get(o2, -1), int(o1 == o2))
+            entry = (code.get(o1, -1), code.get(o2, -1), int(o1 == o2), i)
             for bp in c:   # the reference's .loc[:, (bp1, bp2)] hits the two speed columns (module docstring)
                 if bp not in where:
                     raise KeyError(f"distance column {c} needs the speed column {bp!r} (as in the reference)")
                 chains[where[bp]].append(entry)
     off = np.zeros(len(columns) + 1, dtype=np.int32)
     off[1:] = np.cumsum([len(ch) for ch in chains])
-    flat = np.array([e for ch in chains for e in ch], dtype=np.int32).reshape(-1, 3)
+    flat = np.array([e for ch in chains for e in ch], dtype=np.int32).reshape(-1, 4)
     return ColumnPlan(kinds, size_ref, off, flat, animal_ids)
 
 
@@ -135,13 +136,15 @@ _SECTIONS = (("speed", ("speed",)), ("dist", ("dist_inner", "dist_intra")), ("di
              ("dist_intra", ("dist_intra",)), ("coord", ("coord",)))
 
 
-def _scaler_to_dict(per_col: np.ndarray, kinds: np.ndarray, modes: Dict[str, Optional[str]], log_distances: bool) -> Optional[dict]:
-    """(C,2) -> the legacy dict layout of GlobalScalerSpec.to_legacy_dict (utils.py:2362-2374), (mean, scale) pairs."""
-    out = {"kind": "standard", "speed": None, "dist": None, "dist_inner": None, "dist_intra": None, "coord": None,
+def _scaler_to_dict(per_col: np.ndarray, kinds: np.ndarray, modes: Dict[str, Optional[str]], log_distances: bool,
+                    scale: str = "standard", present: Optional[np.ndarray] = None) -> Optional[dict]:
+    """(C,2) -> the legacy dict layout of GlobalScalerSpec.to_legacy_dict (utils.py:2362-2374): (mean, scale) pairs for
+    "standard", (data_min, data_range with the near-zero ranges already replaced by 1) pairs for "minmax"."""
+    out = {"kind": scale, "speed": None, "dist": None, "dist_inner": None, "dist_intra": None, "coord": None,
            "speed_mode": modes["speed"], "dist_mode": modes["dist"], "coord_mode": modes["coord"], "log_distances": log_distances}
 
-    def cols(names):
-        return [i for i, k in enumerate(kinds) if k in [_capi.PP_KINDS[n] for n in names]]
+    def cols(names):   # columns the low-variance filter removed from every video are not features of the scalers
+        return [i for i, k in enumerate(kinds) if k in [_capi.PP_KINDS[n] for n in names] and (present is None or present[i])]
 
     def put(name, names, mode):
         idx = cols(names)
@@ -161,10 +164,15 @@ def _scaler_to_dict(per_col: np.ndarray, kinds: np.ndarray, modes: Dict[str, Opt
 
 
 def _scaler_from_dict(gs: dict, kinds: np.ndarray, modes: Dict[str, Optional[str]]) -> np.ndarray:
-    """Legacy dict (pairs (mean, scale) or fitted sklearn StandardScalers) -> (C,2), identity where nothing applies."""
+    """Legacy dict (pairs as written by _scaler_to_dict, or fitted sklearn StandardScalers / MinMaxScalers) -> (C,2)
+    (offset, divisor), identity where nothing applies."""
     per_col = np.tile(np.array([0.0, 1.0]), (len(kinds), 1))
 
     def pair(v):
+        if hasattr(v, "data_min_"):     # MinMaxScaler: X * scale_ + min_ == (X - data_min_) / handle_zeros(data_range_)
+            rng = np.atleast_1d(np.asarray(v.data_range_, dtype=np.float64)).copy()
+            rng[rng < 10 * np.finfo(np.float64).eps] = 1.0
+            return np.atleast_1d(np.asarray(v.data_min_, dtype=np.float64)), rng
         if hasattr(v, "mean_"):
             return np.atleast_1d(np.asarray(v.mean_, dtype=np.float64)), np.atleast_1d(np.asarray(v.scale_, dtype=np.float64))
         return np.atleast_1d(np.asarray(v[0], dtype=np.float64)), np.atleast_1d(np.asarray(v[1], dtype=np.float64))
@@ -193,7 +201,7 @@ class _Call:
     """Descriptor tensors + one invocation of the C ABI for a set of (local) videos."""
 
     def __init__(self, lib, device, arrays, plan, out_cols, n_node, n_edge, n_ang, modes, log_distances, inter_scale, clip,
-                 raw_device=None):
+                 raw_device=None, scale="standard", keep=None):
         self.lib, self.device, self.plan = lib, torch.device(device), plan
         self.lengths = [a.shape[0] for a in arrays]
         self.video_off = np.zeros(len(arrays) + 1, dtype=np.int64)
@@ -210,14 +218,17 @@ class _Call:
         self.d_off, self.d_kind = dev(self.video_off), dev(plan.kinds)
         self.d_ref = dev(plan.size_ref.reshape(-1) if plan.size_ref.size else np.zeros(4, np.int32))
         self.d_coff = dev(plan.chain_off)
-        self.d_chain = dev(plan.chain.reshape(-1) if plan.chain.size else np.zeros(3, np.int32))
+        self.d_chain = dev(plan.chain.reshape(-1) if plan.chain.size else np.zeros(4, np.int32))
         self.d_out = dev(out_cols)
         self.counts = (n_node, n_edge, n_ang)
         self.dims = _capi.PreprocDims(n_frames=self.n_frames, n_videos=len(arrays), n_cols=self.n_cols, n_animals=len(plan.animal_ids),
                                       n_node_cols=n_node, n_edge_cols=n_edge, n_angle_cols=n_ang,
                                       speed_mode=_capi.PP_MODES[modes["speed"]], dist_mode=_capi.PP_MODES[modes["dist"]],
                                       coord_mode=_capi.PP_MODES[modes["coord"]], log_distances=int(bool(log_distances)),
-                                      inter_scale=_capi.PP_INTER_SCALE[inter_scale], fit_global=1, clip=float(clip or 0))
+                                      inter_scale=_capi.PP_INTER_SCALE[inter_scale], fit_global=1, clip=float(clip or 0),
+                                      scale_kind=_capi.PP_SCALE_KINDS[scale])
+        self.d_keep = dev(np.asarray(keep, dtype=np.uint8)) if keep is not None else None   # (videos, C), 0 = filtered out
+        self.dims.col_keep = self.d_keep.data_ptr() if self.d_keep is not None else None
         ws_bytes = lib.dof_preprocess_workspace_bytes(ctypes.byref(self.dims))
         if ws_bytes < 0:
             _capi.check(lib, -1, "dof_preprocess_workspace_bytes")
@@ -232,14 +243,22 @@ class _Call:
         return t.data_ptr() if t is not None else None
 
     def video_stats(self, mask) -> torch.Tensor:
-        """(videos, C, 3) float64 (n, mean, M2) of the sampled, per-video-standardised rows."""
+        """(videos, C, 5) float64 (n, mean, M2, min, max) of the sampled, per-video-scaled rows."""
         d_mask = self._dev(mask) if mask is not None else None
-        ystat = torch.empty(len(self.lengths), self.n_cols, 3, dtype=torch.float64, device=self.device)
+        ystat = torch.empty(len(self.lengths), self.n_cols, _capi.PP_STAT_DOUBLES, dtype=torch.float64, device=self.device)
         p = self._ptr
         _capi.check(self.lib, self.lib.dof_preprocess_video_stats(ctypes.byref(self.dims), p(self.raw), p(self.d_off), p(self.d_kind),
                                                                   p(self.d_ref), p(self.d_coff), p(self.d_chain), p(d_mask), p(ystat),
                                                                   p(self.ws), self.stream), "dof_preprocess_video_stats")
         return ystat
+
+    def raw_moments(self) -> torch.Tensor:
+        """(videos, C, 5) float64 (n, mean, M2, min, max) of the raw values of every column."""
+        mom = torch.empty(len(self.lengths), self.n_cols, _capi.PP_STAT_DOUBLES, dtype=torch.float64, device=self.device)
+        p = self._ptr
+        _capi.check(self.lib, self.lib.dof_preprocess_raw_moments(ctypes.byref(self.dims), p(self.raw), p(self.d_off), p(self.d_kind),
+                                                                  p(mom), p(self.ws), self.stream), "dof_preprocess_raw_moments")
+        return mom
 
     def fit_global(self, ystat_all: torch.Tensor) -> torch.Tensor:
         scaler = torch.empty(self.n_cols, 2, dtype=torch.float64, device=self.device)
@@ -275,7 +294,11 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
                       log_distances: bool = True, interpolate_normalized: float = 10, pretrained_scaler: Optional[dict] = None,
                       filter_low_variance=False, inter_scale: str = "mean", device="cuda", lib=None,
                       raw_device: Optional[torch.Tensor] = None, shard_videos: bool = False) -> PreprocessedTables:
-    """``TableDict.preprocess`` for ``scale="standard"`` on the device.  ``tables``: {video key: (frames, C) float64
+    """``TableDict.preprocess`` on the device, ``scale`` "standard" or "minmax" (utils.py:2570 ``_pp_make_scaler``;
+    "robust" needs order statistics of the pooled samples and is not built).  ``filter_low_variance`` (utils.py:2604):
+    a column is dropped where its raw variance (pandas ``var``, ddof 1, NaNs skipped) is not above the threshold;
+    the device path covers the case in which every video drops the SAME columns (the reference otherwise scales
+    tables with differing column sets per video, which its own window extraction cannot stack) and raises otherwise.  ``tables``: {video key: (frames, C) float64
     array or DataFrame}; ``columns``: the C labels; ``node_columns`` / ``edge_columns`` / ``angle_columns``: the labels
     the frame tables keep, in output order (get_graph_dataset's node_sorting / edge_sorting / angle_sorting indices).
 
@@ -283,10 +306,10 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
     (sorted key order); the ranks exchange the per-video statistics the global scalers are fitted on (one all-gather
     of (videos, C, 3) float64), fit identical scalers, finish their own videos and all-gather the frame tables, so
     every rank ends up with the tables of ALL videos -- bit-identical to the single-process result."""
-    if scale != "standard":
-        raise NotImplementedError("only scale='standard' (the reference default) runs on the device")
-    if filter_low_variance:
-        raise NotImplementedError("filter_low_variance is not supported")
+    if scale not in ("standard", "minmax", "robust"):
+        raise ValueError(f"Invalid scaler: {scale}. Choose from {{'standard', 'minmax', 'robust'}}")   # utils.py:2572-2573
+    if scale == "robust":
+        raise NotImplementedError("scale='robust' is not built on the device (standard and minmax are)")
     for m in (dist_standardize, speed_standardize, coord_standardize):
         if m not in _capi.PP_MODES:
             raise ValueError("standardisation modes are 'per_column', 'groupwise' or None")
@@ -297,9 +320,6 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
     columns = list(columns)
     if len(columns) > _capi.PP_MAX_COLS:
         raise ValueError(f"at most {_capi.PP_MAX_COLS} table columns")
-    plan = column_plan(columns, animal_ids)
-    where = {c: i for i, c in enumerate(columns)}
-    out_cols = np.array([where[c] for c in list(node_columns) + list(edge_columns) + list(angle_columns)], dtype=np.int32)
     arrays, keys = [], []
     for k in sorted(tables.keys()):
         t = tables[k]
@@ -312,26 +332,82 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
         keys.append(k)
     if not arrays:
         raise ValueError("no table holds any value")
+    plan = column_plan(columns, animal_ids)
+    where = {c: i for i, c in enumerate(columns)}
+    out_cols = np.array([where[c] for c in list(node_columns) + list(edge_columns) + list(angle_columns)], dtype=np.int32)
     lengths = [a.shape[0] for a in arrays]
     video_off = np.zeros(len(arrays) + 1, dtype=np.int64)
     video_off[1:] = np.cumsum(lengths)
     modes = {"speed": speed_standardize, "dist": dist_standardize, "coord": coord_standardize}
+    keep = None
+    if filter_low_variance:
+        keep, raw_device = _filter_low_variance(lib, device, arrays, columns, plan, modes, filter_low_variance, raw_device)
     n_node, n_edge, n_ang = len(node_columns), len(edge_columns), len(angle_columns)
     fit_global = pretrained_scaler is None
     mask = sample_mask(lengths, samples_max) if fit_global else None
     scaler_in = None if fit_global else torch.from_numpy(_scaler_from_dict(pretrained_scaler, plan.kinds, modes)).to(device)
     common = dict(plan=plan, out_cols=out_cols, n_node=n_node, n_edge=n_edge, n_ang=n_ang, modes=modes, log_distances=log_distances,
-                  inter_scale=inter_scale, clip=interpolate_normalized)
+                  inter_scale=inter_scale, scale=scale,
+                  clip=interpolate_normalized if scale == "standard" else 0)   # utils.py:2993: only "standard" clips
     import torch.distributed as dist
     world = dist.get_world_size() if (shard_videos and dist.is_available() and dist.is_initialized()) else 1
     if world == 1:
-        call = _Call(lib, device, arrays, raw_device=raw_device, **common)
+        call = _Call(lib, device, arrays, raw_device=raw_device, keep=keep, **common)
         node, edge, ang, sizes, vsc, d_scaler = call.tables(mask, scaler_in)
     else:
         node, edge, ang, sizes, vsc, d_scaler = _sharded(lib, device, arrays, video_off, mask, scaler_in, world, dist.get_rank(),
-                                                         len(plan.animal_ids), common)
-    scaler = pretrained_scaler if not fit_global else _scaler_to_dict(d_scaler.cpu().numpy(), plan.kinds, modes, bool(log_distances))
+                                                         len(plan.animal_ids), common, keep)
+    scaler = pretrained_scaler if not fit_global else _scaler_to_dict(d_scaler.cpu().numpy(), plan.kinds, modes, bool(log_distances),
+                                                                               scale, None if keep is None else keep.any(axis=0))
     return PreprocessedTables(node, edge, ang, video_off, keys, scaler, sizes, vsc, columns)
+
+
+def low_variance_keep(moments: np.ndarray, columns: Sequence, threshold) -> np.ndarray:
+    """(videos, C) bool: the columns ``_pp_filter_low_variance`` keeps per video (utils.py:2604-2620): variance with
+    ddof = 1 over the non-missing rows strictly above the threshold (NaN variance = dropped), "pheno" columns always."""
+    n, m2 = moments[..., 0], moments[..., 2]
+    with np.errstate(all="ignore"):
+        var = np.where(n > 1, m2 / (n - 1), np.nan)
+        keep = var > float(threshold)
+    keep[:, [i for i, c in enumerate(columns) if "pheno" in str(c)]] = True
+    return keep
+
+
+def _filter_low_variance(lib, device, arrays, columns, plan, modes, threshold, raw_device):
+    """The low-variance filter: raw moments on the device, the (videos x columns) decisions here.  Returns the keep mask
+    (videos, C) bool and the uploaded raw tables.  A dropped column is absent from that video's scaling and comes back
+    as zeros (utils.py:2966, :3011-3015); angle columns are set aside before the filter runs (:2962-2964)."""
+    n_cols = len(columns)
+    probe = _Call(lib, device, arrays, plan=ColumnPlan(plan.kinds, np.zeros((0, 4), np.int32), np.zeros(n_cols + 1, np.int32),
+                                                       np.zeros((0, 4), np.int32), []),
+                  out_cols=np.zeros(0, np.int32), n_node=0, n_edge=0, n_ang=0, modes={"speed": None, "dist": None, "coord": None},
+                  log_distances=False, inter_scale="mean", clip=0, raw_device=raw_device)
+    keep = low_variance_keep(probe.raw_moments().cpu().numpy(), columns, threshold)
+    K = _capi.PP_KINDS
+    keep[:, plan.kinds == K["angle"]] = True
+    scaled = np.isin(plan.kinds, [K["coord"], K["speed"], K["dist_inner"], K["dist_intra"]])
+    if not (keep[:, plan.kinds != K["angle"]]).any(axis=1).all():
+        raise AssertionError("Error! During preprocessing the entire table was filtered out due to low variance!")   # utils.py:2615
+    where = {c: i for i, c in enumerate(columns)}
+    for v in range(keep.shape[0]):
+        for i in np.flatnonzero(scaled & keep[v]):
+            c = columns[i]
+            if plan.kinds[i] in (K["dist_inner"], K["dist_intra"]):
+                gone = [bp for bp in c if not keep[v, where[bp]]]
+                if gone:   # the reference's .loc[:, (bp1, bp2)] on the filtered table
+                    raise KeyError(f"distance column {c} needs the speed column {gone[0]!r}, which filter_low_variance dropped")
+            bp = c[0] if _is_pair(c) else c
+            if plan.kinds[i] != K["coord"] and not any(keep[v, where[(b, ax)]] for b in ((bp,) if isinstance(c, str) else c)
+                                                       for ax in ("x", "y") if (b, ax) in where):
+                raise NotImplementedError(f"filter_low_variance dropped both coordinates of a body part of column {c}: the "
+                                          "reference then stops treating the column as a speed / distance")
+    for name, kinds_of in (("speed", ("speed",)), ("dist", ("dist_inner", "dist_intra")), ("coord", ("coord",))):
+        if modes[name] == "per_column":   # one scaler feature per column: sklearn refuses tables with other column sets
+            sel = np.isin(plan.kinds, [K[k] for k in kinds_of])
+            if (keep[:, sel] != keep[:1, sel]).any():
+                raise ValueError(f"filter_low_variance keeps different {name} columns in different videos; the per-column "
+                                 "global scaler (fitted on the first video's columns) cannot be applied to them")
+    return keep, probe.raw
 
 
 def _all_gather_rows(local: torch.Tensor, rows_per_rank: List[int]) -> List[torch.Tensor]:
@@ -345,20 +421,21 @@ def _all_gather_rows(local: torch.Tensor, rows_per_rank: List[int]) -> List[torc
     return [p[:n] for p, n in zip(parts, rows_per_rank)]
 
 
-def _sharded(lib, device, arrays, video_off, mask, scaler_in, world, rank, n_animals, common):
+def _sharded(lib, device, arrays, video_off, mask, scaler_in, world, rank, n_animals, common, keep=None):
     """Videos i = rank, rank + world, ... on this rank; two collectives (statistics rows, finished tables)."""
     n_videos, n_cols = len(arrays), len(common["plan"].kinds)
     owner = [list(range(r, n_videos, world)) for r in range(world)]
     mine = owner[rank]
     lengths = np.diff(video_off)
-    call = _Call(lib, device, [arrays[i] for i in mine], **common) if mine else None
+    call = _Call(lib, device, [arrays[i] for i in mine], keep=None if keep is None else keep[mine], **common) if mine else None
     local_mask = None
     if mask is not None and mine:
         local_mask = np.concatenate([mask[video_off[i]:video_off[i + 1]] for i in mine])
     order = [i for r in range(world) for i in owner[r]]          # global index of the rows as gathered
     back = torch.from_numpy(np.argsort(np.array(order))).to(device)
     if scaler_in is None:
-        ystat = call.video_stats(local_mask) if mine else torch.zeros(0, n_cols, 3, dtype=torch.float64, device=device)
+        ystat = call.video_stats(local_mask) if mine else torch.zeros(0, n_cols, _capi.PP_STAT_DOUBLES, dtype=torch.float64,
+                                                                      device=device)
         ystat_all = torch.cat(_all_gather_rows(ystat, [len(o) for o in owner]))[back]      # global video order
         helper = call if call is not None else _Call(lib, device, [arrays[0][:1]], **common)
         scaler_in = helper.fit_global(ystat_all)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 12
+#define DOF_ABI_VERSION 13
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -354,9 +354,10 @@ int dof_vade_set_log_accumulator(DofVadePlan* plan, double* accum);
  * All arithmetic is float64 like the reference's pandas / sklearn path.  Column metadata (device int32 arrays):
  *   col_kind[n_cols]        DOF_PP_OTHER .. DOF_PP_ANGLE
  *   size_ref[n_animals][4]  columns of (nose x, nose y, tail-base x, tail-base y) of each animal, -1 when absent
- *   chain_off[n_cols+1], chain[3*k]  size-divisor chain of a column: entries (animal a1, animal a2, same) with -1 =
- *                           "not one of the animals" -> default factor; divisor = prod over entries of
- *                           (same ? s[a1] : combine(s[a1], s[a2])); a column with an empty chain is not divided
+ *   chain_off[n_cols+1], chain[4*k]  size-divisor chain of a column: entries (animal a1, animal a2, same, source
+ *                           column) with -1 = "not one of the animals" -> default factor; divisor = prod over entries
+ *                           of (same ? s[a1] : combine(s[a1], s[a2])); a column with an empty chain is not divided;
+ *                           an entry whose source column is filtered out of a video (col_keep) is skipped there
  *   out_cols[n_node_cols + n_edge_cols + n_angle_cols]   source column of every output column
  * sample_mask (n_frames) uint8 or NULL: rows entering the global fit (NULL = all rows).
  * scaler (n_cols, 2) float64 = (mean, scale) of the global scaler per column (a group's columns hold the same pair):
@@ -371,6 +372,9 @@ int dof_vade_set_log_accumulator(DofVadePlan* plan, double* accum);
 #define DOF_PP_MODE_NONE 0
 #define DOF_PP_MODE_PER_COLUMN 1
 #define DOF_PP_MODE_GROUPWISE 2
+#define DOF_PP_SCALE_STANDARD 0 /* sklearn StandardScaler: (x - mean) / std */
+#define DOF_PP_SCALE_MINMAX 1   /* sklearn MinMaxScaler: (x - min) / (max - min); `scaler` rows are (min, range) */
+#define DOF_PP_STAT_DOUBLES 5   /* one statistics row: (n, mean, M2, min, max) */
 #define DOF_PP_MAX_COLS 512
 #define DOF_PP_MAX_ANIMALS 8
 typedef struct DofPreprocDims {
@@ -382,6 +386,12 @@ typedef struct DofPreprocDims {
   int32_t inter_scale;       /* 0 mean, 1 geometric mean, 2 default factor (scale_table's inter_scale) */
   int32_t fit_global;        /* 1: fit the global scalers; 0: apply the ones passed in `scaler` */
   double clip;               /* interpolate_normalized; 0 disables clipping */
+  int32_t scale_kind;        /* DOF_PP_SCALE_* (scale_table / _pp_make_scaler's `scale`, utils.py:2425, :2570) */
+  int32_t reserved;
+  /* _pp_filter_low_variance (utils.py:2604): device bytes (n_videos, n_cols), 0 = the column is dropped in that video
+   * (absent from size references, size divisions and every statistic; written back as zeros, utils.py:3011-3015);
+   * NULL = nothing dropped.  The decisions come from dof_preprocess_raw_moments. */
+  const uint8_t* col_keep;
 } DofPreprocDims;
 int64_t dof_preprocess_workspace_bytes(const DofPreprocDims* dims);
 int dof_preprocess_tables(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
@@ -390,8 +400,8 @@ int dof_preprocess_tables(const DofPreprocDims* dims, const double* raw, const i
                           double* size_out, double* video_scaler, float* node_out, float* edge_out, float* angle_out,
                           void* workspace, void* stream);
 /* Videos sharded over ranks (one process per GPU): the only quantity that couples the videos is the global scaler.
- * dof_preprocess_video_stats runs the statistics pass on the local videos and writes ystat_out (n_videos, n_cols, 3)
- * float64 = (n, mean, M2) of the sampled, per-video-standardised values; after an all-gather of these rows (in global
+ * dof_preprocess_video_stats runs the statistics pass on the local videos and writes ystat_out (n_videos, n_cols,
+ * DOF_PP_STAT_DOUBLES) float64 = (n, mean, M2, min, max) of the sampled, per-video-scaled values; after an all-gather of these rows (in global
  * video order) dof_preprocess_fit_global fits the scalers exactly as a single call over all videos would (same merge
  * order, bit-identical), and dof_preprocess_tables(fit_global = 0, scaler) finishes the local videos.  The output
  * column counts of dims are ignored by these two. */
@@ -401,6 +411,12 @@ int dof_preprocess_video_stats(const DofPreprocDims* dims, const double* raw, co
                                void* stream);
 int dof_preprocess_fit_global(const DofPreprocDims* dims, int32_t n_videos_total, const int32_t* col_kind,
                               const double* ystat_all, double* scaler, void* stream);
+/* (n, mean, M2, min, max) of the RAW values of every column of every video: moments_out (n_videos, n_cols,
+ * DOF_PP_STAT_DOUBLES) float64.  The input of _pp_filter_low_variance (utils.py:2604: pandas var, ddof = 1, NaNs
+ * skipped = M2 / (n - 1)); the column decisions themselves are O(videos x columns) host work.  The output column
+ * counts of dims are ignored; workspace as for dof_preprocess_tables. */
+int dof_preprocess_raw_moments(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
+                               const int32_t* col_kind, double* moments_out, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

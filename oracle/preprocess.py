@@ -12,8 +12,10 @@ SURVEY.md section 8(f) row N2.  Follows, under /root/reference/deepof:
                                                  angle interpolation, _pp_sanitize_numeric (:2577-2583)
   TableDict.preprocess      data.py:3773-3916    (time bins and the train/test split are control plane: inputs here)
 sklearn.preprocessing.StandardScaler 1.7 (fit = NaN-ignoring two-pass mean/variance with float64 accumulators,
-near-constant features get scale 1) and pandas ``interpolate(limit_direction="both")`` (= numpy.interp over row
-positions, flat beyond the first/last valid row) are restated with numpy; only ``scale="standard"`` is covered.
+near-constant features get scale 1), MinMaxScaler (``X * scale_ + min_`` with ``scale_ = 1 / handle_zeros(max - min)``,
+``min_ = -data_min * scale_``, NaNs ignored) and pandas ``interpolate(limit_direction="both")`` (= numpy.interp over
+row positions, flat beyond the first/last valid row) are restated with numpy; ``scale`` "standard" and "minmax" are
+covered (``_pp_make_scaler`` utils.py:2570), and ``_pp_filter_low_variance`` (utils.py:2604-2620).
 A table is a float64 array (frames, C) plus the list of column labels: ``(bodypart, "x"|"y")`` coordinates,
 ``bodypart`` speeds, ``(bp1, bp2)`` distances, 3-tuples angles.
 """
@@ -63,15 +65,39 @@ def standard_fit(x: np.ndarray):
     return mean, scale
 
 
-def _standardize(out: np.ndarray, cols: List[int], mode: Optional[str]):
+def minmax_fit(x: np.ndarray):
+    """MinMaxScaler.fit on a 2-D float64 array -> (scale_, min_), NaNs ignored (sklearn _data.py partial_fit:
+    data_range below 10 eps counts as constant -> divisor 1)."""
+    x = np.asarray(x, dtype=np.float64)
+    import warnings
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lo, hi = np.nanmin(x, axis=0), np.nanmax(x, axis=0)
+    rng = hi - lo
+    div = rng.copy()
+    div[div < 10 * np.finfo(np.float64).eps] = 1.0
+    scale = 1.0 / div
+    return scale, 0.0 - lo * scale
+
+
+def fit_scaler(x: np.ndarray, kind: str):
+    return standard_fit(x) if kind == "standard" else minmax_fit(x)
+
+
+def apply_scaler(x: np.ndarray, pair, kind: str) -> np.ndarray:
+    """transform(): StandardScaler (x - mean_) / scale_, MinMaxScaler x * scale_ + min_ (each operation rounded on its own)."""
+    a, b = pair
+    return (x - a) / b if kind == "standard" else x * a + b
+
+
+def _standardize(out: np.ndarray, cols: List[int], mode: Optional[str], kind: str = "standard"):
     if not cols or mode is None:
         return
     if mode == "per_column":
-        m, s = standard_fit(out[:, cols])
-        out[:, cols] = (out[:, cols] - m) / s
+        out[:, cols] = apply_scaler(out[:, cols], fit_scaler(out[:, cols], kind), kind)
     else:
-        m, s = standard_fit(out[:, cols].reshape(-1, 1))
-        out[:, cols] = (out[:, cols] - m[0]) / s[0]
+        a, b = fit_scaler(out[:, cols].reshape(-1, 1), kind)
+        out[:, cols] = apply_scaler(out[:, cols], (a[0], b[0]), kind)
 
 
 def size_factors(tab: np.ndarray, columns: Sequence, animal_ids, size_ref=("Nose", "Tail_base")):
@@ -99,8 +125,8 @@ def size_factors(tab: np.ndarray, columns: Sequence, animal_ids, size_ref=("Nose
 
 def scale_table(tab: np.ndarray, columns: Sequence, animal_ids=None, inter_scale: str = "mean", standardize: bool = True,
                 dist_standardize="per_column", speed_standardize="per_column", coord_standardize="per_column",
-                log_distances: bool = True) -> np.ndarray:
-    """scale_table(scale="standard") (utils.py:2425-2566)."""
+                log_distances: bool = True, scale: str = "standard") -> np.ndarray:
+    """scale_table (utils.py:2425-2566), scale "standard" or "minmax"."""
     out = np.array(tab, dtype=np.float64, copy=True)
     ct = column_types(columns)
     bodyparts = ct["bodyparts"]
@@ -145,14 +171,27 @@ def scale_table(tab: np.ndarray, columns: Sequence, animal_ids=None, inter_scale
         out[:, ct["dists"]] = np.log1p(arr)
     if not standardize:
         return out
-    _standardize(out, ct["speeds"], speed_standardize)
+    _standardize(out, ct["speeds"], speed_standardize, scale)
     if dist_standardize == "per_column":
-        _standardize(out, ct["dists"], "per_column")
+        _standardize(out, ct["dists"], "per_column", scale)
     elif dist_standardize == "groupwise":
-        _standardize(out, ct["inner"], "groupwise")
-        _standardize(out, ct["intra"], "groupwise")
-    _standardize(out, ct["coords"], coord_standardize)
+        _standardize(out, ct["inner"], "groupwise", scale)
+        _standardize(out, ct["intra"], "groupwise", scale)
+    _standardize(out, ct["coords"], coord_standardize, scale)
     return out
+
+
+def low_variance_keep(tab: np.ndarray, columns: Sequence, threshold) -> List[int]:
+    """Column indices _pp_filter_low_variance keeps (utils.py:2604-2620): pandas var (ddof 1, NaNs skipped) > threshold
+    first, then the "pheno" columns (again, if they also passed: the reference concatenates the two index lists)."""
+    import warnings
+    n = (~np.isnan(tab)).sum(axis=0).astype(np.float64)
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mean = np.nansum(tab, axis=0) / n
+        var = np.where(n > 1, np.nansum((tab - mean) ** 2, axis=0) / (n - 1), np.nan)
+        keep = list(np.where(var > threshold)[0])
+    return keep + [i for i, c in enumerate(columns) if "pheno" in str(c)]
 
 
 def interpolate_both(col: np.ndarray) -> np.ndarray:
@@ -178,11 +217,18 @@ def sample_rows(lengths: Sequence[int], samples_max: int) -> List[np.ndarray]:
 
 def preprocess(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids, samples_max: int = 227272,
                dist_standardize="groupwise", speed_standardize="groupwise", coord_standardize="groupwise",
-               log_distances: bool = True, interpolate_normalized: float = 10, pretrained_scaler: Optional[dict] = None):
-    """TableDict.preprocess(scale="standard") up to (not including) window extraction.
-    Returns ({key: (frames, C) float64}, global scaler as {"speed"|"dist"|"dist_inner"|"dist_intra"|"coord": (mean, scale)})."""
-    ct = column_types(columns)
+               log_distances: bool = True, interpolate_normalized: float = 10, pretrained_scaler: Optional[dict] = None,
+               scale: str = "standard", filter_low_variance=False):
+    """TableDict.preprocess up to (not including) window extraction, scale "standard" | "minmax".
+    Returns ({key: (frames, C) float64}, global scaler as {"speed"|"dist"|"dist_inner"|"dist_intra"|"coord": pair}) with
+    pair = (mean_, scale_) for "standard" and (scale_, min_) for "minmax".  ``filter_low_variance``: every video must keep
+    the same columns (the case the product covers); the returned tables then hold the kept columns only, in order."""
     keys = [k for k in sorted(tables) if not np.isnan(tables[k]).all()]
+    if filter_low_variance:
+        return _preprocess_filtered(tables, keys, columns, animal_ids, samples_max, dist_standardize, speed_standardize,
+                                    coord_standardize, log_distances, interpolate_normalized, pretrained_scaler, scale,
+                                    filter_low_variance)
+    ct = column_types(columns)
     local = {}
     for k in keys:
         non_angle = [i for i in range(len(columns)) if i not in ct["angles"]]
@@ -190,7 +236,7 @@ def preprocess(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids, sam
         loc = np.array(tables[k], dtype=np.float64, copy=True)
         loc[:, non_angle] = scale_table(tables[k][:, non_angle], sub_cols, animal_ids, standardize=True,
                                         dist_standardize=dist_standardize, speed_standardize=speed_standardize,
-                                        coord_standardize=None, log_distances=log_distances)
+                                        coord_standardize=None, log_distances=log_distances, scale=scale)
         local[k] = loc
     if pretrained_scaler is not None:
         gs = pretrained_scaler
@@ -205,10 +251,9 @@ def preprocess(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids, sam
             if not parts:
                 return
             if mode == "per_column":
-                gs[name] = standard_fit(np.vstack(parts))
+                gs[name] = fit_scaler(np.vstack(parts), scale)
             else:
-                m, s = standard_fit(np.concatenate([p.reshape(-1) for p in parts]).reshape(-1, 1))
-                gs[name] = (m, s)
+                gs[name] = fit_scaler(np.concatenate([p.reshape(-1) for p in parts]).reshape(-1, 1), scale)
 
         fit("speed", ct["speeds"], speed_standardize)
         if dist_standardize == "per_column":
@@ -223,8 +268,7 @@ def preprocess(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids, sam
 
         def apply(name, cols):
             if cols and gs.get(name) is not None:
-                m, s = gs[name]
-                tab[:, cols] = (tab[:, cols] - m) / s
+                tab[:, cols] = apply_scaler(tab[:, cols], gs[name], scale)
 
         if speed_standardize is not None:
             apply("speed", ct["speeds"])
@@ -236,7 +280,7 @@ def preprocess(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids, sam
         if coord_standardize is not None:
             apply("coord", ct["coords"])
         clip_cols = list(dict.fromkeys(ct["speeds"] + ct["dists"] + ct["coords"]))
-        if interpolate_normalized and clip_cols:
+        if scale == "standard" and interpolate_normalized and clip_cols:   # utils.py:2993
             arr = tab[:, clip_cols]
             with np.errstate(invalid="ignore"):
                 arr[np.abs(arr) > interpolate_normalized] = np.nan
@@ -245,4 +289,85 @@ def preprocess(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids, sam
             tab[:, c] = interpolate_both(tab[:, c])
         tab[np.isnan(tab)] = 0.0
         out[k] = tab
+    return out, gs
+
+
+def _preprocess_filtered(tables, keys, columns, animal_ids, samples_max, dist_standardize, speed_standardize, coord_standardize,
+                         log_distances, interpolate_normalized, pretrained_scaler, scale, threshold):
+    """preprocess() with _pp_filter_low_variance: every video is scaled on its own kept columns (pass 1 filters the whole
+    table, utils.py:2701; pass 2 sets the angles aside first, :2962-2966), the global scalers see the kept columns (per-column
+    sections: the first video's columns, :2651-2656) and a dropped column comes back as zeros (:3011-3015)."""
+    n_cols = len(columns)
+    all_angles = set(column_types(columns)["angles"])
+    kept = {k: sorted(set(low_variance_keep(tables[k], columns, threshold)) - all_angles) for k in keys}
+    local, local_cols = {}, {}
+    for k in keys:
+        idx = kept[k]
+        assert idx, "the entire table was filtered out"
+        sub_cols = [columns[i] for i in idx]
+        local[k] = scale_table(tables[k][:, idx], sub_cols, animal_ids, standardize=True, dist_standardize=dist_standardize,
+                               speed_standardize=speed_standardize, coord_standardize=None, log_distances=log_distances, scale=scale)
+        local_cols[k] = sub_cols
+    if pretrained_scaler is not None:
+        gs = pretrained_scaler
+    else:
+        rows = sample_rows([local[k].shape[0] for k in keys], samples_max)
+        gs = {}
+
+        def fit(name, which, mode):
+            if mode is None:
+                return
+            parts, ref = [], None
+            for k, r in zip(keys, rows):
+                ct = column_types(local_cols[k])
+                cols = [local_cols[k][i] for i in ct[which]]
+                if not cols or not len(r):
+                    continue
+                if mode == "per_column":
+                    ref = ref or cols
+                    assert cols == ref, "per-column sections need the same columns in every video"
+                    parts.append(local[k][r][:, ct[which]])
+                else:
+                    parts.append(local[k][r][:, ct[which]].reshape(-1))
+            if parts:
+                gs[name] = fit_scaler(np.vstack(parts) if mode == "per_column" else np.concatenate(parts).reshape(-1, 1), scale)
+
+        fit("speed", "speeds", speed_standardize)
+        if dist_standardize == "per_column":
+            fit("dist", "dists", "per_column")
+        elif dist_standardize == "groupwise":
+            fit("dist_inner", "inner", "groupwise")
+            fit("dist_intra", "intra", "groupwise")
+        fit("coord", "coords", coord_standardize)
+    out = {}
+    for k in keys:
+        tab, ct = local[k].copy(), column_types(local_cols[k])
+
+        def apply(name, cols):
+            if cols and gs.get(name) is not None:
+                tab[:, cols] = apply_scaler(tab[:, cols], gs[name], scale)
+
+        if speed_standardize is not None:
+            apply("speed", ct["speeds"])
+        if dist_standardize == "per_column":
+            apply("dist", ct["dists"])
+        elif dist_standardize == "groupwise":
+            apply("dist_inner", ct["inner"])
+            apply("dist_intra", ct["intra"])
+        if coord_standardize is not None:
+            apply("coord", ct["coords"])
+        clip_cols = list(dict.fromkeys(ct["speeds"] + ct["dists"] + ct["coords"]))
+        if scale == "standard" and interpolate_normalized and clip_cols:
+            arr = tab[:, clip_cols]
+            with np.errstate(invalid="ignore"):
+                arr[np.abs(arr) > interpolate_normalized] = np.nan
+            tab[:, clip_cols] = arr
+        full = np.full((tab.shape[0], n_cols), np.nan)
+        full[:, kept[k]] = tab
+        for a in all_angles:
+            full[:, a] = tables[k][:, a]
+        for c in range(n_cols):
+            full[:, c] = interpolate_both(full[:, c])
+        full[np.isnan(full)] = 0.0
+        out[k] = full
     return out, gs

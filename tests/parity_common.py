@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from deepof_amd import _capi
@@ -1099,6 +1100,65 @@ def run_preprocess_check(lib, device, golden_dir):
     res = preprocess_tables(new, cols, aids, node_cols, edge_cols, angle_cols, dist_standardize=c["dist"],
                             speed_standardize=c["speed"], coord_standardize=c["coord"], pretrained_scaler=gs, device=device, lib=lib)
     _check_tables(res, {k: g[f"pair::pre::out::{k}"] for k in new}, cols, node_cols, edge_cols, angle_cols, "pretrained")
+
+
+def load_preprocess_r03_golden(golden_dir):
+    import json
+    g = np.load(os.path.join(golden_dir, "preprocess_r03.npz"))
+    cases = json.loads(str(g["cases"]))
+    data = {}
+    for tag in ("pair", "single", "filt", "ragged"):
+        cols = [tuple(c) if isinstance(c, list) else c for c in json.loads(str(g[f"{tag}::columns"]))]
+        tabs = {k.split("::")[-1]: g[k] for k in g.files if k.startswith(f"{tag}::raw::")}
+        data[tag] = (cols, json.loads(str(g[f"{tag}::animal_ids"])), tabs)
+    return g, cases, data
+
+
+def run_preprocess_r03_check(lib, device, golden_dir):
+    """scale="minmax" and filter_low_variance against the reference's own outputs (make_golden_preprocess_r03.py)."""
+    from deepof_amd.preprocess import preprocess_tables
+    g, cases, data = load_preprocess_r03_golden(golden_dir)
+    first_mm = None
+    for c in cases:
+        cols, aids, tabs = data[c["data"]]
+        node_cols, edge_cols, angle_cols = preprocess_output_columns(cols)
+        kw = dict(samples_max=c["samples_max"], dist_standardize=c["dist"], speed_standardize=c["speed"],
+                  coord_standardize=c["coord"], log_distances=c["log"], interpolate_normalized=c["clip"], scale=c["scale"],
+                  filter_low_variance=c["filter"], device=device, lib=lib)
+        res = preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, **kw)
+        exp = {k.split("::")[-1]: g[k] for k in g.files if k.startswith(c["case"] + "::out::")}
+        _check_tables(res, exp, cols, node_cols, edge_cols, angle_cols, c["case"])
+        suffix = ("data_min", "data_range") if c["scale"] == "minmax" else ("mean", "scale")
+        for part in ("speed", "dist", "dist_inner", "dist_intra", "coord"):
+            key = f"{c['case']}::scaler::{part}::{suffix[0]}"
+            have = res.global_scaler is not None and res.global_scaler.get(part) is not None
+            assert have == (key in g.files), (c["case"], part)
+            if have:
+                want1 = g[key.replace(suffix[0], suffix[1])].copy()
+                if c["scale"] == "minmax":
+                    want1[want1 < 10 * np.finfo(np.float64).eps] = 1.0
+                np.testing.assert_allclose(res.global_scaler[part][0], g[key], rtol=1e-9, atol=1e-12, err_msg=key)
+                np.testing.assert_allclose(res.global_scaler[part][1], want1, rtol=1e-9, atol=1e-12, err_msg=key)
+        assert res.global_scaler["kind"] == c["scale"]
+        if first_mm is None and c["scale"] == "minmax":
+            first_mm = (c, res.global_scaler)
+    c, gs = first_mm
+    cols, aids, _ = data["pair"]
+    node_cols, edge_cols, angle_cols = preprocess_output_columns(cols)
+    new = {k.split("::")[-1]: g[k] for k in g.files if k.startswith("pair::pre::raw::")}
+    res = preprocess_tables(new, cols, aids, node_cols, edge_cols, angle_cols, dist_standardize=c["dist"], scale="minmax",
+                            speed_standardize=c["speed"], coord_standardize=c["coord"], pretrained_scaler=gs, device=device, lib=lib)
+    _check_tables(res, {k: g[f"pair::pre::out::{k}"] for k in new}, cols, node_cols, edge_cols, angle_cols, "pretrained minmax")
+    # what the reference refuses, refused the same way
+    cols, aids, tabs = data["ragged"]
+    node_cols, edge_cols, angle_cols = preprocess_output_columns(cols)
+    with pytest.raises(ValueError):      # per-column global scalers over videos that kept different columns
+        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, dist_standardize="per_column",
+                          speed_standardize="per_column", coord_standardize="per_column", filter_low_variance=1.2, device=device, lib=lib)
+    with pytest.raises(ValueError):
+        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, scale="quantile", device=device, lib=lib)
+    with pytest.raises(NotImplementedError):
+        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, scale="robust", device=device, lib=lib)
 
 
 def synth_raw_tables(n_videos, frames, bodyparts, seed, nan_rate=0.002):

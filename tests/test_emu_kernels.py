@@ -104,6 +104,11 @@ def test_preprocess_tables_emu(golden_dir):
     PC.run_preprocess_check(emu_lib(), "cpu", golden_dir)
 
 
+def test_preprocess_minmax_and_filter_emu(golden_dir):
+    """N2 remainder: scale="minmax" and filter_low_variance (emulated kernels) against the reference's own outputs."""
+    PC.run_preprocess_r03_check(emu_lib(), "cpu", golden_dir)
+
+
 @pytest.mark.parametrize("modes", [dict(), dict(dist="per_column", speed="per_column", coord="per_column"),
                                    dict(dist=None, speed="groupwise", coord="per_column")])
 def test_preprocess_tables_vs_oracle_emu(modes):

@@ -634,6 +634,13 @@ def test_preprocess_tables_gpu(hip, golden_dir):
     PC.run_preprocess_check(hip, "cuda", golden_dir)
 
 
+def test_preprocess_minmax_and_filter_gpu(hip, golden_dir):
+    """N2 remainder: scale="minmax" (_pp_make_scaler, utils.py:2570) and filter_low_variance (utils.py:2604) against the
+    outputs of the reference's own functions."""
+    import parity_common as PC
+    PC.run_preprocess_r03_check(hip, "cuda", golden_dir)
+
+
 @pytest.mark.parametrize("modes", [dict(), dict(dist="per_column", speed="per_column", coord="per_column"),
                                    dict(dist=None, speed="groupwise", coord="per_column")])
 def test_preprocess_tables_vs_oracle_gpu(hip, modes):

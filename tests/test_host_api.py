@@ -780,9 +780,9 @@ def test_preprocess_column_plan_and_sampling():
     plan = PP.column_plan(cols, ["B", "W"])
     assert plan.size_ref[0].tolist() == [0, 1, 2, 3] and plan.size_ref[1].tolist() == [-1, -1, -1, -1]   # W has no tail base
     chain = lambda c: plan.chain[plan.chain_off[c]:plan.chain_off[c + 1]].tolist()   # noqa: E731
-    assert chain(0) == [[0, 0, 1]] and chain(4) == [[1, 1, 1]]          # coordinates: own animal once
-    # speed of B_Nose: own factor, then once per distance column it appears in (reference .loc quirk)
-    assert chain(6) == [[0, 0, 1], [0, 0, 1], [0, 1, 0]]
+    assert chain(0) == [[0, 0, 1, 0]] and chain(4) == [[1, 1, 1, 4]]    # coordinates: own animal once (source = itself)
+    # speed of B_Nose: own factor, then once per distance column it appears in (reference .loc quirk; source = that column)
+    assert chain(6) == [[0, 0, 1, 6], [0, 0, 1, 9], [0, 1, 0, 10]]
     assert chain(9) == [] and chain(10) == []                           # distances themselves are never divided
     with pytest.raises(KeyError):
         PP.column_plan([("A_x", "x"), ("A_x", "y"), ("A_y", "x"), ("A_y", "y"), "A_x", ("A_x", "A_y")], ["A"])  # no speed A_y
@@ -820,7 +820,9 @@ def test_preprocess_host_api_emu(golden_dir):
     only = WindowDataset.from_device_tables(res, 12, 3, lib, keys=["vid2"])
     assert only.keys == ["vid2"] and len(only) == (lens[2] - 12) // 3 + 1
     with pytest.raises(NotImplementedError):
-        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, scale="minmax", device="cpu", lib=lib)
+        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, scale="robust", device="cpu", lib=lib)
+    mm = preprocess_tables(tabs, cols, aids, node_cols, edge_cols, scale="minmax", device="cpu", lib=lib)
+    assert mm.global_scaler["kind"] == "minmax" and float(mm.node_table.min()) >= -1e-6   # no clipping, values from 0 up
     with pytest.raises(ValueError):
         preprocess_tables({"a": np.full((5, len(cols)), np.nan)}, cols, aids, node_cols, edge_cols, device="cpu", lib=lib)
     with pytest.raises(ValueError):
@@ -839,8 +841,13 @@ def _pp_shard_worker(rank, world, port, tmp):
     tabs["v001"][:20, 2] = np.nan
     node_cols, edge_cols, _ = PC.preprocess_output_columns(cols)
     out = {}
+    filt = {k: t.copy() for k, t in tabs.items()}     # a distance column below the variance threshold in one video only
+    filt["v002"][:, cols.index(("B_Nose", "B_Tail_base"))] = 9.0
     for name, kw in (("gw", dict(samples_max=50)), ("pc", dict(dist_standardize="per_column", speed_standardize="per_column",
-                                                              coord_standardize="per_column"))):
+                                                              coord_standardize="per_column")),
+                     ("mm", dict(samples_max=60, scale="minmax", speed_standardize="per_column")),
+                     ("flt", dict(samples_max=70, filter_low_variance=0.05))):
+        tabs = filt if name == "flt" else tabs
         res = preprocess_tables(tabs, cols, ["B", "W"], node_cols, edge_cols, (), device="cpu", lib=lib, shard_videos=True, **kw)
         out[name] = (res.node_table, res.edge_table, res.size_factors, res.video_scaler, res.global_scaler)
         if rank == 0:
@@ -861,7 +868,7 @@ def test_preprocess_sharded_over_videos_gloo(tmp_path):
     port = 33000 + (os.getpid() % 2000)
     mp.spawn(_pp_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f"pp{r}.pt", weights_only=False) for r in (0, 1))
-    for name in ("gw", "pc"):
+    for name in ("gw", "pc", "mm", "flt"):
         for a, b, c in zip(r0[name][:4], r1[name][:4], r0[name + "_single"][:4]):
             assert torch.equal(a, b) and torch.equal(a, c), name
         for part in ("speed", "dist", "dist_inner", "dist_intra", "coord"):

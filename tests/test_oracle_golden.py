@@ -512,6 +512,49 @@ def test_scale_table_oracle_matches_reference():
                                    equal_nan=True, err_msg=nm)
 
 
+def test_preprocess_r03_oracle_matches_reference(golden_dir):
+    """scale="minmax" and filter_low_variance (tests/golden/make_golden_preprocess_r03.py: the reference's own functions)."""
+    from oracle import preprocess as op
+    import parity_common as PC
+    g, cases, data = PC.load_preprocess_r03_golden(golden_dir)
+    for c in cases:
+        cols, aids, tabs = data[c["data"]]
+        out, gs = op.preprocess(tabs, cols, aids, samples_max=c["samples_max"], dist_standardize=c["dist"],
+                                speed_standardize=c["speed"], coord_standardize=c["coord"], log_distances=c["log"],
+                                interpolate_normalized=c["clip"], scale=c["scale"], filter_low_variance=c["filter"])
+        exp = {k.split("::")[-1]: g[k] for k in g.files if k.startswith(c["case"] + "::out::")}
+        assert sorted(out) == sorted(exp), c["case"]
+        for k in exp:
+            assert np.isfinite(out[k]).all()
+            np.testing.assert_allclose(out[k], exp[k], rtol=1e-11, atol=1e-11, err_msg=f"{c['case']} {k}")
+        for part in ("speed", "dist", "dist_inner", "dist_intra", "coord"):
+            if c["scale"] == "minmax":
+                key = f"{c['case']}::scaler::{part}::data_min"
+                assert (key in g.files) == (part in gs), (c["case"], part)
+                if part in gs:     # oracle pair = (scale_, min_) of sklearn's MinMaxScaler
+                    rng = g[key.replace("data_min", "data_range")].copy()
+                    rng[rng < 10 * np.finfo(np.float64).eps] = 1.0
+                    np.testing.assert_allclose(np.atleast_1d(gs[part][0]), 1.0 / rng, rtol=1e-12, atol=0)
+                    np.testing.assert_allclose(np.atleast_1d(gs[part][1]), -g[key] / rng, rtol=1e-11, atol=1e-14)
+            else:
+                key = f"{c['case']}::scaler::{part}::mean"
+                assert (key in g.files) == (part in gs), (c["case"], part)
+                if part in gs:
+                    np.testing.assert_allclose(np.atleast_1d(gs[part][0]), g[key], rtol=1e-11, atol=1e-12)
+    cols, aids, tabs = data["pair"]
+    for nm, kw in {"mm_pc": dict(), "mm_gw": dict(dist_standardize="groupwise", speed_standardize="groupwise",
+                                                  coord_standardize="groupwise")}.items():
+        np.testing.assert_allclose(op.scale_table(tabs["vid0"], cols, aids, scale="minmax", **kw), g[f"scale_table::{nm}"],
+                                   rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=nm)
+    c = cases[0]
+    kw = dict(dist_standardize=c["dist"], speed_standardize=c["speed"], coord_standardize=c["coord"], scale="minmax")
+    _, gs = op.preprocess(tabs, cols, aids, **kw)
+    new = {k.split("::")[-1]: g[k] for k in g.files if k.startswith("pair::pre::raw::")}
+    out, _ = op.preprocess(new, cols, aids, pretrained_scaler=gs, **kw)
+    for k in new:
+        np.testing.assert_allclose(out[k], g[f"pair::pre::out::{k}"], rtol=1e-11, atol=1e-11)
+
+
 from parity_common import math_zero_gradient  # noqa: E402
 
 
