@@ -68,13 +68,14 @@ class PreprocDims(C.Structure):
                 ("n_node_cols", C.c_int32), ("n_edge_cols", C.c_int32), ("n_angle_cols", C.c_int32),
                 ("speed_mode", C.c_int32), ("dist_mode", C.c_int32), ("coord_mode", C.c_int32),
                 ("log_distances", C.c_int32), ("inter_scale", C.c_int32), ("fit_global", C.c_int32), ("clip", C.c_double),
-                ("scale_kind", C.c_int32), ("reserved", C.c_int32), ("col_keep", C.c_void_p)]
+                ("scale_kind", C.c_int32), ("reserved", C.c_int32), ("col_keep", C.c_void_p), ("video_scaler_in", C.c_void_p)]
 
 
 PP_KINDS = {"other": 0, "coord": 1, "speed": 2, "dist_inner": 3, "dist_intra": 4, "angle": 5}
 PP_MODES = {None: 0, "per_column": 1, "groupwise": 2}
 PP_INTER_SCALE = {"mean": 0, "geom": 1, "global": 2}
-PP_SCALE_KINDS = {"standard": 0, "minmax": 1}
+PP_SCALE_KINDS = {"standard": 0, "minmax": 1, "robust": 2}
+PP_ORDER_DOUBLES = 7  # n + six order statistics (median pair, 25th-percentile pair, 75th-percentile pair)
 PP_STAT_DOUBLES = 5   # (n, mean, M2, min, max)
 PP_MAX_COLS, PP_MAX_ANIMALS = 512, 8
 
@@ -137,6 +138,7 @@ SIGNATURES = {
     "dof_preprocess_video_stats": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 10),
     "dof_preprocess_fit_global": (C.c_int, [C.POINTER(PreprocDims), _I32, _P, _P, _P, _P]),
     "dof_preprocess_raw_moments": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 6),
+    "dof_preprocess_order_stats": (C.c_int, [C.POINTER(PreprocDims)] + [_P] * 11),
 }
 
 

@@ -1007,12 +1007,228 @@ __global__ void __launch_bounds__(256) k_pp_fill(PpOutArgs A, const uint8_t* __r
 #undef PP_AT
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Exact order statistics for scale = "robust" (sklearn RobustScaler: center = nanmedian, scale = 75th - 25th percentile,
+// numpy's linear interpolation between the two neighbouring order statistics).  Populations: per video the values u of a
+// column (per-column sections) or of all columns of a group (groupwise sections) -- stage A, the per-video scalers -- and,
+// over the sampled rows of all videos, the per-video-scaled values y = (u - center_v) / scale_v -- stage B, the global
+// scalers.  Radix selection as in k_pp_size, but grid-wide: the values become order-preserving 64-bit keys, column-major;
+// per 8-bit digit one pass builds the histograms of the next byte among the keys that share a target's prefix (LDS
+// atomics per workgroup slice, integer atomics into the population's histogram: order-independent, deterministic) and a
+// one-workgroup-per-population kernel advances the (at most) six targets: the two neighbours of the median and of the
+// 25th / 75th percentile positions.
+constexpr int PP_OS_T = 6;  // order statistics per population
+__device__ __forceinline__ unsigned long long pp_order_key(double x) {  // ascending doubles <-> ascending keys; NaN -> PP_NOKEY
+  if (pp_isnan(x)) return PP_NOKEY;
+  const unsigned long long b = pp_bits(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double pp_order_value(unsigned long long k) {
+  return pp_from_bits((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k);
+}
+// representative column of c's population: itself (per-column section), the first column of its group (groupwise), -1
+__device__ __forceinline__ int pp_os_rep(const int* __restrict__ kinds, int C, int c, int speed_mode, int dist_mode, int coord_mode) {
+  const int mode = pp_mode(kinds[c], speed_mode, dist_mode, coord_mode);
+  if (mode == DOF_PP_MODE_NONE) return -1;
+  if (mode == DOF_PP_MODE_PER_COLUMN) return c;
+  for (int k = 0; k < c; ++k)
+    if (kinds[k] == kinds[c]) return k;
+  return c;
+}
+
+// keys[c][r] of every scaled column: a 64 x 64 tile of the row-major table through LDS (coalesced reads along the
+// columns, coalesced writes along the rows).  vscale == null: u; else y = (u - m) / s of the sampled rows (mask null =
+// all rows), each operation rounded on its own like RobustScaler.transform
+__global__ void __launch_bounds__(256) k_pp_os_keys(const double* __restrict__ raw, const int64_t* __restrict__ video_off, int V,
+                                                    const int* __restrict__ col_kind, const double* __restrict__ rdiv,
+                                                    const double* __restrict__ vscale, const uint8_t* __restrict__ mask,
+                                                    const uint8_t* __restrict__ keep, int C, int64_t F, int log_dist,
+                                                    int speed_mode, int dist_mode, int coord_mode,
+                                                    unsigned long long* __restrict__ keys) {
+  __shared__ unsigned long long tile[64][65];
+  __shared__ double logtab[128][2];
+  __shared__ int vrow[64];
+  pp_log_table_init(logtab);
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  if (threadIdx.x < 64) {  // video of each row of the tile
+    const int64_t r = r0 + threadIdx.x;
+    int lo = 0, hi = V - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (video_off[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    vrow[threadIdx.x] = lo;
+  }
+  __syncthreads();
+  const int cl = threadIdx.x & 63, c = c0 + cl;
+  for (int rl = threadIdx.x >> 6; rl < 64; rl += 4) {
+    const int64_t r = r0 + rl;
+    unsigned long long key = PP_NOKEY;
+    if (r < F && c < C) {
+      const int v = vrow[rl], kind = col_kind[c];
+      const int64_t i = (int64_t)v * C + c;
+      const bool on = pp_mode(kind, speed_mode, dist_mode, coord_mode) != DOF_PP_MODE_NONE && (!keep || keep[i]) &&
+                      (!vscale || !mask || mask[r]);
+      if (on) {
+        double u = raw[r * C + c] * rdiv[i];
+        if (log_dist && (kind == DOF_PP_DIST_INNER || kind == DOF_PP_DIST_INTRA)) {
+          if (u < 0.0) u = 0.0;
+          u = pp_log1p(u, logtab);
+        }
+        if (vscale) u = (u - vscale[2 * i]) / vscale[2 * i + 1];
+        key = pp_order_key(u);
+      }
+    }
+    tile[rl][cl] = key;
+  }
+  __syncthreads();
+  const int rl = threadIdx.x & 63;
+  for (int k = threadIdx.x >> 6; k < 64; k += 4)
+    if (c0 + k < C && r0 + rl < F) keys[(int64_t)(c0 + k) * F + r0 + rl] = tile[rl][k];
+}
+
+struct PpOsState {
+  unsigned long long prefix[PP_OS_T];
+  long long krem[PP_OS_T];
+  int rep[PP_OS_T];  // first target with the same prefix: the histogram both read
+  int pad[2];
+  double n;
+};
+
+// one digit pass: workgroup (population, slice).  per_video: population = (video, representative column), its keys are
+// the video's rows of the columns of that population; else population = representative column, all rows
+__global__ void __launch_bounds__(256) k_pp_os_hist(const unsigned long long* __restrict__ keys,
+                                                    const int64_t* __restrict__ video_off, const int* __restrict__ col_kind, int C,
+                                                    int64_t F, int per_video, int speed_mode, int dist_mode, int coord_mode,
+                                                    int shift, const PpOsState* __restrict__ state, int* __restrict__ hist) {
+  __shared__ int h[PP_OS_T][256];
+  const int p = blockIdx.x, c = p % C, v = p / C;
+  if (pp_os_rep(col_kind, C, c, speed_mode, dist_mode, coord_mode) != c) return;
+  const PpOsState st = state[p];
+  if (shift < 56 && st.n == 0.0) return;
+  for (int i = threadIdx.x; i < PP_OS_T * 256; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const unsigned long long himask = shift == 56 ? 0ull : ~0ull << (shift + 8);
+  const int64_t r0 = per_video ? video_off[v] : 0, r1 = per_video ? video_off[v + 1] : F;
+  const bool group = pp_mode(col_kind[c], speed_mode, dist_mode, coord_mode) == DOF_PP_MODE_GROUPWISE;
+  for (int cc = c; cc < (group ? C : c + 1); ++cc) {
+    if (cc != c && col_kind[cc] != col_kind[c]) continue;
+    const unsigned long long* __restrict__ col = keys + (int64_t)cc * F;
+    for (int64_t rb = r0 + (int64_t)blockIdx.y * 256 + threadIdx.x; rb < r1; rb += (int64_t)gridDim.y * 256 * 4) {
+      unsigned long long k4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t r = rb + (int64_t)i * gridDim.y * 256;
+        k4[i] = r < r1 ? col[r] : PP_NOKEY;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (k4[i] == PP_NOKEY) continue;
+        const int digit = (int)((k4[i] >> shift) & 255);
+#pragma unroll
+        for (int j = 0; j < PP_OS_T; ++j)
+          if (st.rep[j] == j && (k4[i] & himask) == st.prefix[j]) atomicAdd(&h[j][digit], 1);
+      }
+    }
+  }
+  __syncthreads();
+  int* __restrict__ out = hist + (int64_t)p * PP_OS_T * 256;
+  for (int i = threadIdx.x; i < PP_OS_T * 256; i += 256)
+    if ((&h[0][0])[i] != 0) atomicAdd(&out[i], (&h[0][0])[i]);
+}
+
+// after a digit pass: next byte of every target (prefix sums over the 256 bins of the histogram it reads), the first
+// pass also counts the population and places the targets: ranks (n-1)/2, n/2 | floor((n-1)/4), +1 | floor(3(n-1)/4), +1
+__global__ void __launch_bounds__(256) k_pp_os_advance(const int* __restrict__ col_kind, int C, int speed_mode, int dist_mode,
+                                                       int coord_mode, int shift, PpOsState* __restrict__ state,
+                                                       int* __restrict__ hist, double* __restrict__ out) {
+  __shared__ long long scan[256];
+  __shared__ PpOsState st;
+  const int p = blockIdx.x, c = p % C, tid = threadIdx.x;
+  if (pp_os_rep(col_kind, C, c, speed_mode, dist_mode, coord_mode) != c) return;
+  int* __restrict__ hp = hist + (int64_t)p * PP_OS_T * 256;
+  if (tid == 0) st = state[p];
+  __syncthreads();
+  if (shift < 56 && st.n == 0.0) return;
+  for (int j = 0; j < PP_OS_T; ++j) {
+    const int src = st.rep[j];
+    const long long mine = hp[src * 256 + tid];
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const long long o = tid >= off ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += o;
+      __syncthreads();
+    }
+    if (shift == 56 && j == 0 && tid == 255) {
+      const long long n = scan[255];
+      st.n = (double)n;
+      const long long m = n > 0 ? n - 1 : 0;
+      st.krem[0] = m / 2;
+      st.krem[1] = n / 2;
+      st.krem[2] = m / 4;
+      st.krem[3] = m / 4 + 1 < n ? m / 4 + 1 : m;
+      st.krem[4] = 3 * m / 4;
+      st.krem[5] = 3 * m / 4 + 1 < n ? 3 * m / 4 + 1 : m;
+    }
+    __syncthreads();
+    const long long k = st.krem[j], inc = scan[tid];
+    const bool live = st.n > 0.0;
+    __syncthreads();  // every thread holds the rank before the owner of the bin rewrites it
+    if (live) {
+      if (inc - mine <= k && k < inc) {  // exactly one bin
+        st.krem[j] = k - (inc - mine);
+        st.prefix[j] |= (unsigned long long)tid << shift;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < PP_OS_T * 256; i += 256) hp[i] = 0;
+  if (tid == 0) {
+    for (int j = 0; j < PP_OS_T; ++j) {
+      int r = j;
+      for (int i = j - 1; i >= 0; --i)
+        if (st.prefix[i] == st.prefix[j]) r = i;
+      st.rep[j] = r;
+    }
+    state[p] = st;
+    if (shift == 0 || st.n == 0.0) {
+      double* o = out + (int64_t)p * (PP_OS_T + 1);
+      o[0] = st.n;
+      for (int j = 0; j < PP_OS_T; ++j) o[1 + j] = st.n > 0.0 ? pp_order_value(st.prefix[j]) : pp_nanv();
+    }
+  }
+}
+
+// a population's result copied to the columns that share it (groupwise sections), NaN rows for unscaled columns
+__global__ void __launch_bounds__(256) k_pp_os_spread(const int* __restrict__ col_kind, int C, int64_t P, int speed_mode,
+                                                      int dist_mode, int coord_mode, double* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int c = (int)(p % C);
+  const int r = pp_os_rep(col_kind, C, c, speed_mode, dist_mode, coord_mode);
+  if (r == c) return;
+  double* o = out + p * (PP_OS_T + 1);
+  if (r < 0) {
+    o[0] = 0.0;
+    for (int j = 0; j < PP_OS_T; ++j) o[1 + j] = pp_nanv();
+  } else {
+    const double* src = out + (p - c + r) * (PP_OS_T + 1);
+    for (int j = 0; j <= PP_OS_T; ++j) o[j] = src[j];
+  }
+}
+
 struct PpWorkspace {
   double *hyp, *sfac, *rdiv, *vscale, *coef;
   PpStat *part_all, *part_smp, *vcol_all, *vcol_smp, *ystat, *gcol;
   int *strip_v, *tile_rec, *chunks, *ochunks;
   uint8_t* notes;
   int64_t note_bytes;
+  unsigned long long* os_keys;  // scale = "robust" only
+  PpOsState* os_state;
+  int* os_hist;
   int64_t bytes;
 };
 
@@ -1045,6 +1261,10 @@ PpWorkspace pp_layout(const DofPreprocDims& d, void* base) {
   w.tile_rec = (int*)take(tiles * 16);
   w.chunks = (int*)take((1 + 3 * (int64_t)(2 * d.n_cols + 2)) * 4);
   w.ochunks = (int*)take((1 + 3 * (int64_t)(2 * n_out + 2)) * 4);
+  const bool robust = d.scale_kind == DOF_PP_SCALE_ROBUST;
+  w.os_keys = (unsigned long long*)take(robust ? d.n_frames * d.n_cols * 8 : 0);
+  w.os_state = (PpOsState*)take(robust ? vc * (int64_t)sizeof(PpOsState) : 0);
+  w.os_hist = (int*)take(robust ? vc * PP_OS_T * 256 * 4 : 0);
   w.bytes = off;
   return w;
 }
@@ -1070,9 +1290,9 @@ int pp_check(const DofPreprocDims* d, bool stats_only = false) {
       dof_set_error("dof_preprocess: bad standardisation mode %d", m);
       return DOF_ERR_ARG;
     }
-  if (d->scale_kind != DOF_PP_SCALE_STANDARD && d->scale_kind != DOF_PP_SCALE_MINMAX) {
-    dof_set_error("dof_preprocess: scale_kind %d not built (standard and minmax are)", d->scale_kind);
-    return DOF_ERR_UNSUPPORTED;
+  if (d->scale_kind < DOF_PP_SCALE_STANDARD || d->scale_kind > DOF_PP_SCALE_ROBUST) {
+    dof_set_error("dof_preprocess: bad scale_kind %d", d->scale_kind);
+    return DOF_ERR_ARG;
   }
   if (d->inter_scale < 0 || d->inter_scale > 2) {
     dof_set_error("dof_preprocess: bad inter_scale %d", d->inter_scale);
@@ -1121,17 +1341,27 @@ int pp_run(const DofPreprocDims* dims, bool stats_only, const double* raw, const
     DOF_LAUNCH(k_pp_size, (A, V), (256), st, video_off, size_ref, A, d.n_frames, (const unsigned long long*)keys, w.sfac);
   }
   DOF_LAUNCH(k_pp_divisors, (V), (256), st, chain_off, chain, C, A, d.inter_scale, d.col_keep, w.sfac, w.rdiv);
+  const bool robust = d.scale_kind == DOF_PP_SCALE_ROBUST;
+  if (robust) {  // order statistics, not moments: both scalers come from dof_preprocess_order_stats through the caller
+    if (stats_only || d.fit_global || !d.video_scaler_in) {
+      dof_set_error("dof_preprocess: scale_kind robust needs video_scaler_in and the fitted `scaler` (fit_global = 0)");
+      return DOF_ERR_ARG;
+    }
+    (void)hipMemcpyAsync(w.vscale, d.video_scaler_in, (size_t)V * C * 16, hipMemcpyDeviceToDevice, st);
+  }
 #define PP_STATS(M)                                                                                                  \
   DOF_LAUNCH((k_pp_stats<M>), ((unsigned)strips), (256), st, raw, video_off, (const int*)w.strip_v, (const int*)w.chunks, \
              col_kind, (const double*)w.rdiv, sample_mask, C, d.speed_mode, d.dist_mode,                             \
              coord_stats ? d.coord_mode : DOF_PP_MODE_NONE, 0, d.col_keep, w.part_all, w.part_smp)
-  if (sample_mask) PP_STATS(true); else PP_STATS(false);
-#undef PP_STATS
   const unsigned col_chunks = dof_cdiv(C, 64);
-  DOF_LAUNCH(k_pp_video_cols, (col_chunks, V), (256), st, video_off, (const PpStat*)w.part_all, (const PpStat*)w.part_smp, C,
-             w.vcol_all, w.vcol_smp);
-  DOF_LAUNCH(k_pp_video_fin, (V), (256), st, col_kind, (const PpStat*)w.vcol_all, (const PpStat*)w.vcol_smp, C, d.speed_mode,
-             d.dist_mode, d.scale_kind, w.vscale, w.ystat);
+  if (!robust) {
+    if (sample_mask) PP_STATS(true); else PP_STATS(false);
+    DOF_LAUNCH(k_pp_video_cols, (col_chunks, V), (256), st, video_off, (const PpStat*)w.part_all, (const PpStat*)w.part_smp, C,
+               w.vcol_all, w.vcol_smp);
+    DOF_LAUNCH(k_pp_video_fin, (V), (256), st, col_kind, (const PpStat*)w.vcol_all, (const PpStat*)w.vcol_smp, C, d.speed_mode,
+               d.dist_mode, d.scale_kind, w.vscale, w.ystat);
+  }
+#undef PP_STATS
   if (size_out) (void)hipMemcpyAsync(size_out, w.sfac, (size_t)V * (A + 1) * 8, hipMemcpyDeviceToDevice, st);
   if (stats_only) {
     (void)hipMemcpyAsync(ystat_out, w.ystat, (size_t)V * C * sizeof(PpStat), hipMemcpyDeviceToDevice, st);
@@ -1189,6 +1419,50 @@ extern "C" int dof_preprocess_fit_global(const DofPreprocDims* dims, int32_t n_v
   DOF_LAUNCH(k_pp_fit_global, (1), (256), (hipStream_t)stream, col_kind, reinterpret_cast<const PpStat*>(ystat_all),
              n_videos_total, dims->n_cols, dims->speed_mode, dims->dist_mode, dims->coord_mode, dims->scale_kind, scaler);
   return dof_check_launch("dof_preprocess_fit_global");
+}
+
+extern "C" int dof_preprocess_order_stats(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
+                                          const int32_t* col_kind, const int32_t* size_ref, const int32_t* chain_off,
+                                          const int32_t* chain, const double* video_scaler, const uint8_t* sample_mask,
+                                          double* out, void* workspace, void* stream) {
+  const int rc = pp_check(dims, true);
+  if (rc != DOF_OK) return rc;
+  const DofPreprocDims& d = *dims;
+  if (!raw || !video_off || !col_kind || !chain_off || !out || !workspace || (d.n_animals > 0 && !size_ref) ||
+      d.scale_kind != DOF_PP_SCALE_ROBUST) {
+    dof_set_error("dof_preprocess_order_stats: null pointer argument or scale_kind is not robust");
+    return DOF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const PpWorkspace w = pp_layout(d, workspace);
+  const int V = d.n_videos, C = d.n_cols, A = d.n_animals;
+  const bool stage_a = video_scaler == nullptr;
+  const int coord_mode = stage_a ? DOF_PP_MODE_NONE : d.coord_mode;  // the per-video scaling leaves the coordinates alone
+  const int64_t P = stage_a ? (int64_t)V * C : C;
+  if (A > 0) {
+    unsigned long long* hk = reinterpret_cast<unsigned long long*>(w.hyp);
+    DOF_LAUNCH(k_pp_hyp, (dof_cdiv(d.n_frames, 256)), (256), st, raw, size_ref, C, A, d.n_frames, video_off, V, d.col_keep, hk);
+    DOF_LAUNCH(k_pp_size, (A, V), (256), st, video_off, size_ref, A, d.n_frames, (const unsigned long long*)hk, w.sfac);
+  }
+  DOF_LAUNCH(k_pp_divisors, (V), (256), st, chain_off, chain, C, A, d.inter_scale, d.col_keep, w.sfac, w.rdiv);
+  DOF_LAUNCH(k_pp_os_keys, (dof_cdiv(d.n_frames, 64), dof_cdiv(C, 64)), (256), st, raw, video_off, V, col_kind,
+             (const double*)w.rdiv, video_scaler, sample_mask, d.col_keep, C, d.n_frames, d.log_distances, d.speed_mode,
+             d.dist_mode, coord_mode, w.os_keys);
+  (void)hipMemsetAsync(w.os_state, 0, (size_t)P * sizeof(PpOsState), st);
+  (void)hipMemsetAsync(w.os_hist, 0, (size_t)P * PP_OS_T * 256 * 4, st);
+  // slices per population: a few thousand keys per workgroup and pass
+  const int64_t rows = stage_a ? d.n_frames / V + 1 : d.n_frames;
+  int64_t slices = rows / 8192 + 1;
+  if (slices > 128) slices = 128;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    DOF_LAUNCH(k_pp_os_hist, ((unsigned)P, (unsigned)slices), (256), st, (const unsigned long long*)w.os_keys, video_off, col_kind,
+               C, d.n_frames, stage_a ? 1 : 0, d.speed_mode, d.dist_mode, coord_mode, shift, (const PpOsState*)w.os_state,
+               w.os_hist);
+    DOF_LAUNCH(k_pp_os_advance, ((unsigned)P), (256), st, col_kind, C, d.speed_mode, d.dist_mode, coord_mode, shift, w.os_state,
+               w.os_hist, out);
+  }
+  DOF_LAUNCH(k_pp_os_spread, (dof_cdiv(P, 256)), (256), st, col_kind, C, P, d.speed_mode, d.dist_mode, coord_mode, out);
+  return dof_check_launch("dof_preprocess_order_stats");
 }
 
 extern "C" int dof_preprocess_raw_moments(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,

@@ -139,7 +139,8 @@ _SECTIONS = (("speed", ("speed",)), ("dist", ("dist_inner", "dist_intra")), ("di
 def _scaler_to_dict(per_col: np.ndarray, kinds: np.ndarray, modes: Dict[str, Optional[str]], log_distances: bool,
                     scale: str = "standard", present: Optional[np.ndarray] = None) -> Optional[dict]:
     """(C,2) -> the legacy dict layout of GlobalScalerSpec.to_legacy_dict (utils.py:2362-2374): (mean, scale) pairs for
-    "standard", (data_min, data_range with the near-zero ranges already replaced by 1) pairs for "minmax"."""
+    "standard", (data_min, data_range with the near-zero ranges already replaced by 1) pairs for "minmax", (center,
+    inter-quartile range) pairs for "robust"."""
     out = {"kind": scale, "speed": None, "dist": None, "dist_inner": None, "dist_intra": None, "coord": None,
            "speed_mode": modes["speed"], "dist_mode": modes["dist"], "coord_mode": modes["coord"], "log_distances": log_distances}
 
@@ -169,6 +170,8 @@ def _scaler_from_dict(gs: dict, kinds: np.ndarray, modes: Dict[str, Optional[str
     per_col = np.tile(np.array([0.0, 1.0]), (len(kinds), 1))
 
     def pair(v):
+        if hasattr(v, "center_"):       # RobustScaler
+            return np.atleast_1d(np.asarray(v.center_, dtype=np.float64)), np.atleast_1d(np.asarray(v.scale_, dtype=np.float64))
         if hasattr(v, "data_min_"):     # MinMaxScaler: X * scale_ + min_ == (X - data_min_) / handle_zeros(data_range_)
             rng = np.atleast_1d(np.asarray(v.data_range_, dtype=np.float64)).copy()
             rng[rng < 10 * np.finfo(np.float64).eps] = 1.0
@@ -260,6 +263,19 @@ class _Call:
                                                                   p(mom), p(self.ws), self.stream), "dof_preprocess_raw_moments")
         return mom
 
+    def order_stats(self, video_scaler: Optional[torch.Tensor], mask) -> torch.Tensor:
+        """scale="robust": (videos, C, 7) per-video rows, or with the per-video scalers given the (C, 7) rows of the pooled
+        sampled values -- n and the six order statistics around the median and the 25th / 75th percentile."""
+        shape = (len(self.lengths), self.n_cols) if video_scaler is None else (self.n_cols,)
+        out = torch.empty(*shape, _capi.PP_ORDER_DOUBLES, dtype=torch.float64, device=self.device)
+        d_mask = self._dev(mask) if (mask is not None and video_scaler is not None) else None
+        p = self._ptr
+        _capi.check(self.lib, self.lib.dof_preprocess_order_stats(ctypes.byref(self.dims), p(self.raw), p(self.d_off), p(self.d_kind),
+                                                                  p(self.d_ref), p(self.d_coff), p(self.d_chain), p(video_scaler),
+                                                                  p(d_mask), p(out), p(self.ws), self.stream),
+                    "dof_preprocess_order_stats")
+        return out
+
     def fit_global(self, ystat_all: torch.Tensor) -> torch.Tensor:
         scaler = torch.empty(self.n_cols, 2, dtype=torch.float64, device=self.device)
         p = self._ptr
@@ -294,8 +310,8 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
                       log_distances: bool = True, interpolate_normalized: float = 10, pretrained_scaler: Optional[dict] = None,
                       filter_low_variance=False, inter_scale: str = "mean", device="cuda", lib=None,
                       raw_device: Optional[torch.Tensor] = None, shard_videos: bool = False) -> PreprocessedTables:
-    """``TableDict.preprocess`` on the device, ``scale`` "standard" or "minmax" (utils.py:2570 ``_pp_make_scaler``;
-    "robust" needs order statistics of the pooled samples and is not built).  ``filter_low_variance`` (utils.py:2604):
+    """``TableDict.preprocess`` on the device, ``scale`` "standard", "minmax" or "robust" (utils.py:2570
+    ``_pp_make_scaler``; "robust" = exact medians / quartiles by radix selection, one process only).  ``filter_low_variance`` (utils.py:2604):
     a column is dropped where its raw variance (pandas ``var``, ddof 1, NaNs skipped) is not above the threshold;
     the device path covers the case in which every video drops the SAME columns (the reference otherwise scales
     tables with differing column sets per video, which its own window extraction cannot stack) and raises otherwise.  ``tables``: {video key: (frames, C) float64
@@ -308,8 +324,6 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
     every rank ends up with the tables of ALL videos -- bit-identical to the single-process result."""
     if scale not in ("standard", "minmax", "robust"):
         raise ValueError(f"Invalid scaler: {scale}. Choose from {{'standard', 'minmax', 'robust'}}")   # utils.py:2572-2573
-    if scale == "robust":
-        raise NotImplementedError("scale='robust' is not built on the device (standard and minmax are)")
     for m in (dist_standardize, speed_standardize, coord_standardize):
         if m not in _capi.PP_MODES:
             raise ValueError("standardisation modes are 'per_column', 'groupwise' or None")
@@ -351,15 +365,58 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
                   clip=interpolate_normalized if scale == "standard" else 0)   # utils.py:2993: only "standard" clips
     import torch.distributed as dist
     world = dist.get_world_size() if (shard_videos and dist.is_available() and dist.is_initialized()) else 1
+    if scale == "robust" and world > 1:
+        raise NotImplementedError("scale='robust' with shard_videos: quantiles of the pooled samples do not merge across ranks")
     if world == 1:
         call = _Call(lib, device, arrays, raw_device=raw_device, keep=keep, **common)
-        node, edge, ang, sizes, vsc, d_scaler = call.tables(mask, scaler_in)
+        if scale == "robust":
+            node, edge, ang, sizes, vsc, d_scaler = _robust_tables(call, plan, modes, mask, scaler_in)
+        else:
+            node, edge, ang, sizes, vsc, d_scaler = call.tables(mask, scaler_in)
     else:
         node, edge, ang, sizes, vsc, d_scaler = _sharded(lib, device, arrays, video_off, mask, scaler_in, world, dist.get_rank(),
                                                          len(plan.animal_ids), common, keep)
     scaler = pretrained_scaler if not fit_global else _scaler_to_dict(d_scaler.cpu().numpy(), plan.kinds, modes, bool(log_distances),
                                                                                scale, None if keep is None else keep.any(axis=0))
     return PreprocessedTables(node, edge, ang, video_off, keys, scaler, sizes, vsc, columns)
+
+
+def robust_center_scale(rows: np.ndarray, scaled: np.ndarray) -> np.ndarray:
+    """(..., C, 7) order-statistics rows -> (..., C, 2) (center_, scale_) of sklearn's RobustScaler: np.nanmedian (mean of the
+    two middle values) and np.nanpercentile(25, 75) with numpy's linear rule (a + (b - a) t below t = 1/2, b - (b - a)(1 - t)
+    from there on), inter-quartile ranges below 10 eps replaced by 1; identity where ``scaled`` (C,) is False."""
+    n = rows[..., 0]
+    with np.errstate(all="ignore"):
+        center = (rows[..., 1] + rows[..., 2]) / 2.0
+        m = np.maximum(n - 1, 0)
+
+        def lerp(a, b, t):
+            d = b - a
+            return np.where(t >= 0.5, b - d * (1 - t), a + d * t)
+
+        q25 = lerp(rows[..., 3], rows[..., 4], (m % 4) / 4.0)
+        q75 = lerp(rows[..., 5], rows[..., 6], ((3 * m) % 4) / 4.0)
+        scale = q75 - q25
+        scale = np.where(scale < 10 * np.finfo(np.float64).eps, 1.0, scale)
+    out = np.stack([center, scale], axis=-1)
+    out[..., ~scaled, 0] = 0.0
+    out[..., ~scaled, 1] = 1.0
+    return out
+
+
+def _robust_tables(call: "_Call", plan, modes, mask, scaler_in):
+    """scale="robust" on one process: per-video order statistics -> per-video (median, IQR); order statistics of the
+    per-video-scaled sampled rows of all videos -> global (median, IQR); then the common output pass."""
+    K = _capi.PP_KINDS
+    on = {K["speed"]: modes["speed"], K["dist_inner"]: modes["dist"], K["dist_intra"]: modes["dist"], K["coord"]: modes["coord"]}
+    per_video = np.array([k != K["coord"] and on.get(int(k)) is not None for k in plan.kinds])
+    globally = np.array([on.get(int(k)) is not None for k in plan.kinds])
+    vs = torch.from_numpy(robust_center_scale(call.order_stats(None, None).cpu().numpy(), per_video)).to(call.device)
+    if scaler_in is None:
+        scaler_in = torch.from_numpy(robust_center_scale(call.order_stats(vs, mask).cpu().numpy(), globally)).to(call.device)
+    call.video_scaler_in = vs          # kept alive for the call
+    call.dims.video_scaler_in = vs.data_ptr()
+    return call.tables(None, scaler_in)
 
 
 def low_variance_keep(moments: np.ndarray, columns: Sequence, threshold) -> np.ndarray:

@@ -374,7 +374,10 @@ int dof_vade_set_log_accumulator(DofVadePlan* plan, double* accum);
 #define DOF_PP_MODE_GROUPWISE 2
 #define DOF_PP_SCALE_STANDARD 0 /* sklearn StandardScaler: (x - mean) / std */
 #define DOF_PP_SCALE_MINMAX 1   /* sklearn MinMaxScaler: (x - min) / (max - min); `scaler` rows are (min, range) */
+#define DOF_PP_SCALE_ROBUST 2   /* sklearn RobustScaler: (x - median) / (q75 - q25); `scaler` rows are (median, IQR) */
 #define DOF_PP_STAT_DOUBLES 5   /* one statistics row: (n, mean, M2, min, max) */
+#define DOF_PP_ORDER_DOUBLES 7  /* one order-statistics row: n, then the order statistics at ranks (n-1)/2, n/2,
+                                 * floor((n-1)/4), that + 1, floor(3(n-1)/4), that + 1 (upper ranks capped at n-1) */
 #define DOF_PP_MAX_COLS 512
 #define DOF_PP_MAX_ANIMALS 8
 typedef struct DofPreprocDims {
@@ -392,6 +395,11 @@ typedef struct DofPreprocDims {
    * (absent from size references, size divisions and every statistic; written back as zeros, utils.py:3011-3015);
    * NULL = nothing dropped.  The decisions come from dof_preprocess_raw_moments. */
   const uint8_t* col_keep;
+  /* scale_kind robust only: per-video (median, IQR) per column, device (n_videos, n_cols, 2) float64, identity (0, 1)
+   * where a column is not scaled per video.  Medians and quantiles are not mergeable statistics, so the robust path is
+   * three calls: dof_preprocess_order_stats (per video) -> these rows; again with them -> `scaler`; then
+   * dof_preprocess_tables(fit_global = 0). */
+  const double* video_scaler_in;
 } DofPreprocDims;
 int64_t dof_preprocess_workspace_bytes(const DofPreprocDims* dims);
 int dof_preprocess_tables(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
@@ -411,6 +419,16 @@ int dof_preprocess_video_stats(const DofPreprocDims* dims, const double* raw, co
                                void* stream);
 int dof_preprocess_fit_global(const DofPreprocDims* dims, int32_t n_videos_total, const int32_t* col_kind,
                               const double* ystat_all, double* scaler, void* stream);
+/* Exact order statistics for scale_kind robust (RobustScaler.fit: np.nanmedian, np.nanpercentile(25, 75), utils.py:2570).
+ * video_scaler == NULL: per video, of the size-normalised / log1p'd values of every per-video-scaled column (groupwise
+ * sections pool the group's columns): out (n_videos, n_cols, DOF_PP_ORDER_DOUBLES).  video_scaler (n_videos, n_cols, 2)
+ * given: over the rows of sample_mask (NULL = all) of ALL videos, of the per-video-scaled values (v - median) / IQR:
+ * out (n_cols, DOF_PP_ORDER_DOUBLES).  Columns outside the scaled sections get n = 0 and NaNs.  The caller turns the
+ * rows into (median, IQR) with numpy's interpolation rule (O(videos x columns) host work). */
+int dof_preprocess_order_stats(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
+                               const int32_t* col_kind, const int32_t* size_ref, const int32_t* chain_off,
+                               const int32_t* chain, const double* video_scaler, const uint8_t* sample_mask, double* out,
+                               void* workspace, void* stream);
 /* (n, mean, M2, min, max) of the RAW values of every column of every video: moments_out (n_videos, n_cols,
  * DOF_PP_STAT_DOUBLES) float64.  The input of _pp_filter_low_variance (utils.py:2604: pandas var, ddof = 1, NaNs
  * skipped = M2 / (n - 1)); the column decisions themselves are O(videos x columns) host work.  The output column

@@ -14,7 +14,7 @@ SURVEY.md section 8(f) row N2.  Follows, under /root/reference/deepof:
 sklearn.preprocessing.StandardScaler 1.7 (fit = NaN-ignoring two-pass mean/variance with float64 accumulators,
 near-constant features get scale 1), MinMaxScaler (``X * scale_ + min_`` with ``scale_ = 1 / handle_zeros(max - min)``,
 ``min_ = -data_min * scale_``, NaNs ignored) and pandas ``interpolate(limit_direction="both")`` (= numpy.interp over
-row positions, flat beyond the first/last valid row) are restated with numpy; ``scale`` "standard" and "minmax" are
+row positions, flat beyond the first/last valid row) are restated with numpy; ``scale`` "standard", "minmax" and "robust" are
 covered (``_pp_make_scaler`` utils.py:2570), and ``_pp_filter_low_variance`` (utils.py:2604-2620).
 A table is a float64 array (frames, C) plus the list of column labels: ``(bodypart, "x"|"y")`` coordinates,
 ``bodypart`` speeds, ``(bp1, bp2)`` distances, 3-tuples angles.
@@ -80,14 +80,29 @@ def minmax_fit(x: np.ndarray):
     return scale, 0.0 - lo * scale
 
 
+def robust_fit(x: np.ndarray):
+    """RobustScaler.fit on a 2-D float64 array -> (center_, scale_): np.nanmedian, np.nanpercentile(25, 75) (linear
+    interpolation), inter-quartile ranges below 10 eps -> 1 (sklearn _data.py RobustScaler.fit)."""
+    import warnings
+    x = np.asarray(x, dtype=np.float64)
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        center = np.nanmedian(x, axis=0)
+        q = np.nanpercentile(x, (25.0, 75.0), axis=0)
+    scale = q[1] - q[0]
+    scale[scale < 10 * np.finfo(np.float64).eps] = 1.0
+    return center, scale
+
+
 def fit_scaler(x: np.ndarray, kind: str):
-    return standard_fit(x) if kind == "standard" else minmax_fit(x)
+    return standard_fit(x) if kind == "standard" else minmax_fit(x) if kind == "minmax" else robust_fit(x)
 
 
 def apply_scaler(x: np.ndarray, pair, kind: str) -> np.ndarray:
-    """transform(): StandardScaler (x - mean_) / scale_, MinMaxScaler x * scale_ + min_ (each operation rounded on its own)."""
+    """transform(): StandardScaler / RobustScaler (x - a) / b, MinMaxScaler x * scale_ + min_ (each operation rounded on
+    its own)."""
     a, b = pair
-    return (x - a) / b if kind == "standard" else x * a + b
+    return x * a + b if kind == "minmax" else (x - a) / b
 
 
 def _standardize(out: np.ndarray, cols: List[int], mode: Optional[str], kind: str = "standard"):
@@ -219,7 +234,7 @@ def preprocess(tables: Dict[str, np.ndarray], columns: Sequence, animal_ids, sam
                dist_standardize="groupwise", speed_standardize="groupwise", coord_standardize="groupwise",
                log_distances: bool = True, interpolate_normalized: float = 10, pretrained_scaler: Optional[dict] = None,
                scale: str = "standard", filter_low_variance=False):
-    """TableDict.preprocess up to (not including) window extraction, scale "standard" | "minmax".
+    """TableDict.preprocess up to (not including) window extraction, scale "standard" | "minmax" | "robust".
     Returns ({key: (frames, C) float64}, global scaler as {"speed"|"dist"|"dist_inner"|"dist_intra"|"coord": pair}) with
     pair = (mean_, scale_) for "standard" and (scale_, min_) for "minmax".  ``filter_low_variance``: every video must keep
     the same columns (the case the product covers); the returned tables then hold the kept columns only, in order."""

@@ -41,6 +41,9 @@ def store_scaler(store, case, gs, scale):
             if scale == "minmax":
                 store[f"{case}::scaler::{part}::data_min"] = np.atleast_1d(sc.data_min_)
                 store[f"{case}::scaler::{part}::data_range"] = np.atleast_1d(sc.data_range_)
+            elif scale == "robust":
+                store[f"{case}::scaler::{part}::center"] = np.atleast_1d(sc.center_)
+                store[f"{case}::scaler::{part}::scale"] = np.atleast_1d(sc.scale_)
             else:
                 store[f"{case}::scaler::{part}::mean"] = np.atleast_1d(sc.mean_)
                 store[f"{case}::scaler::{part}::scale"] = np.atleast_1d(sc.scale_)
@@ -87,6 +90,10 @@ def main():
             ("pair", "mm_pc", "minmax", False, dict(dist="per_column", speed="per_column", coord="per_column", log=True, samples_max=full, clip=10)),
             ("pair", "mm_mixed", "minmax", False, dict(dist="groupwise", speed=None, coord="per_column", log=False, samples_max=25, clip=0.9)),
             ("single", "mm_sub", "minmax", False, dict(dist="per_column", speed="groupwise", coord="groupwise", log=True, samples_max=30, clip=10)),
+            ("pair", "rb_gw", "robust", False, dict(dist="groupwise", speed="groupwise", coord="groupwise", log=True, samples_max=full, clip=10)),
+            ("pair", "rb_pc", "robust", False, dict(dist="per_column", speed="per_column", coord="per_column", log=True, samples_max=35, clip=10)),
+            ("single", "rb_mixed", "robust", False, dict(dist="per_column", speed="groupwise", coord=None, log=False, samples_max=full, clip=10)),
+            ("filt", "rb_filter", "robust", 1.2, dict(dist="groupwise", speed="per_column", coord="groupwise", log=True, samples_max=45, clip=10)),
             ("filt", "std_filter", "standard", 1.2, dict(dist="groupwise", speed="groupwise", coord="groupwise", log=True, samples_max=full, clip=10)),
             ("filt", "mm_filter", "minmax", 1.2, dict(dist="per_column", speed="per_column", coord="per_column", log=True, samples_max=40, clip=10)),
             ("ragged", "std_ragged", "standard", 1.2, dict(dist="groupwise", speed="groupwise", coord="groupwise", log=True, samples_max=50, clip=10))]

@@ -1128,7 +1128,7 @@ def run_preprocess_r03_check(lib, device, golden_dir):
         res = preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, **kw)
         exp = {k.split("::")[-1]: g[k] for k in g.files if k.startswith(c["case"] + "::out::")}
         _check_tables(res, exp, cols, node_cols, edge_cols, angle_cols, c["case"])
-        suffix = ("data_min", "data_range") if c["scale"] == "minmax" else ("mean", "scale")
+        suffix = {"minmax": ("data_min", "data_range"), "robust": ("center", "scale"), "standard": ("mean", "scale")}[c["scale"]]
         for part in ("speed", "dist", "dist_inner", "dist_intra", "coord"):
             key = f"{c['case']}::scaler::{part}::{suffix[0]}"
             have = res.global_scaler is not None and res.global_scaler.get(part) is not None
@@ -1157,8 +1157,6 @@ def run_preprocess_r03_check(lib, device, golden_dir):
                           speed_standardize="per_column", coord_standardize="per_column", filter_low_variance=1.2, device=device, lib=lib)
     with pytest.raises(ValueError):
         preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, scale="quantile", device=device, lib=lib)
-    with pytest.raises(NotImplementedError):
-        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, scale="robust", device=device, lib=lib)
 
 
 def synth_raw_tables(n_videos, frames, bodyparts, seed, nan_rate=0.002):
@@ -1209,6 +1207,7 @@ def run_preprocess_vs_oracle(lib, device, n_videos=3, frames=(300, 97, 161), see
     edge_cols = sorted(dist[::edge_stride])
     kw = dict(dist_standardize=modes.get("dist", "groupwise"), speed_standardize=modes.get("speed", "groupwise"),
               coord_standardize=modes.get("coord", "groupwise"))
+    kw["scale"] = modes.get("scale", "standard")
     want, gs = op.preprocess(tabs, cols, ["B", "W"], samples_max=samples_max, **kw)
     res = preprocess_tables(tabs, cols, ["B", "W"], node_cols, edge_cols, angle_cols, samples_max=samples_max, device=device, lib=lib, **kw)
     _check_tables(res, want, cols, node_cols, edge_cols, angle_cols, f"oracle {modes}")

@@ -115,6 +115,13 @@ def test_preprocess_tables_vs_oracle_emu(modes):
     PC.run_preprocess_vs_oracle(emu_lib(), "cpu", **modes)
 
 
+@pytest.mark.parametrize("modes", [dict(scale="robust"), dict(scale="robust", dist="per_column", speed="per_column", coord="per_column"),
+                                   dict(scale="minmax", dist=None, speed="groupwise", coord="per_column")])
+def test_preprocess_tables_other_scalers_vs_oracle_emu(modes):
+    """scale = "robust" (exact radix selection of medians / quartiles) and "minmax" on ragged random tables, rows sampled."""
+    PC.run_preprocess_vs_oracle(emu_lib(), "cpu", samples_max=110, seed=23, **modes)
+
+
 def test_preprocess_tables_sampled_rows_emu():
     PC.run_preprocess_vs_oracle(emu_lib(), "cpu", samples_max=120, seed=9)
 

@@ -652,6 +652,14 @@ def test_preprocess_tables_vs_oracle_gpu(hip, modes):
     PC.run_preprocess_vs_oracle(hip, "cuda", n_videos=2, frames=(20_011, 300), seed=13, **modes)
 
 
+@pytest.mark.parametrize("modes", [dict(scale="robust"), dict(scale="robust", dist="per_column", speed="per_column", coord="per_column"),
+                                   dict(scale="minmax")])
+def test_preprocess_tables_other_scalers_vs_oracle_gpu(hip, modes):
+    """scale = "robust" / "minmax" against the (reference-pinned) oracle: 4 videos up to 20k frames, rows sampled."""
+    import parity_common as PC
+    PC.run_preprocess_vs_oracle(hip, "cuda", n_videos=4, frames=(20_000, 977, 4_161, 12_345), samples_max=3_000, seed=31, **modes)
+
+
 def test_preprocess_full_size_c2(hip):
     """BASELINE C2's data set (600k frames, 14 body parts -> 133 raw columns, 40 videos) through the device pipeline:
     size-independent properties + the oracle on two whole videos under the device-fitted scalers + windows."""

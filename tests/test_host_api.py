@@ -819,8 +819,8 @@ def test_preprocess_host_api_emu(golden_dir):
     assert torch.equal(x[1, :, :, 1], res.node_table[3:15, 8:16]) and torch.equal(a[3, :, :, 0], res.edge_table[9:21])
     only = WindowDataset.from_device_tables(res, 12, 3, lib, keys=["vid2"])
     assert only.keys == ["vid2"] and len(only) == (lens[2] - 12) // 3 + 1
-    with pytest.raises(NotImplementedError):
-        preprocess_tables(tabs, cols, aids, node_cols, edge_cols, scale="robust", device="cpu", lib=lib)
+    rb = preprocess_tables(tabs, cols, aids, node_cols, edge_cols, scale="robust", device="cpu", lib=lib)
+    assert rb.global_scaler["kind"] == "robust" and rb.global_scaler["coord"][1].shape == (1,)
     mm = preprocess_tables(tabs, cols, aids, node_cols, edge_cols, scale="minmax", device="cpu", lib=lib)
     assert mm.global_scaler["kind"] == "minmax" and float(mm.node_table.min()) >= -1e-6   # no clipping, values from 0 up
     with pytest.raises(ValueError):

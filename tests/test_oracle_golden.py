@@ -537,10 +537,11 @@ def test_preprocess_r03_oracle_matches_reference(golden_dir):
                     np.testing.assert_allclose(np.atleast_1d(gs[part][0]), 1.0 / rng, rtol=1e-12, atol=0)
                     np.testing.assert_allclose(np.atleast_1d(gs[part][1]), -g[key] / rng, rtol=1e-11, atol=1e-14)
             else:
-                key = f"{c['case']}::scaler::{part}::mean"
+                key = f"{c['case']}::scaler::{part}::" + ("center" if c["scale"] == "robust" else "mean")
                 assert (key in g.files) == (part in gs), (c["case"], part)
                 if part in gs:
                     np.testing.assert_allclose(np.atleast_1d(gs[part][0]), g[key], rtol=1e-11, atol=1e-12)
+                    np.testing.assert_allclose(np.atleast_1d(gs[part][1]), g[key.rsplit("::", 1)[0] + "::scale"], rtol=1e-11, atol=1e-12)
     cols, aids, tabs = data["pair"]
     for nm, kw in {"mm_pc": dict(), "mm_gw": dict(dist_standardize="groupwise", speed_standardize="groupwise",
                                                   coord_standardize="groupwise")}.items():
