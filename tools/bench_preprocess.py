@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--animals", type=int, default=1)
     ap.add_argument("--mode", default="groupwise")
+    ap.add_argument("--scale", default="standard", choices=["standard", "minmax", "robust"])
+    ap.add_argument("--filter", type=float, default=0.0, help="filter_low_variance threshold (0 = off)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-log", action="store_true", help="log_distances=False")
     args = ap.parse_args()
@@ -44,6 +46,9 @@ def main():
     edge_cols = edge_cols[:14 * args.animals + (4 if args.animals == 2 else 0)]
     mode = None if args.mode == "none" else args.mode
     kw = dict(dist_standardize=mode, speed_standardize=mode, coord_standardize=mode, log_distances=not args.no_log)
+    plain = args.scale == "standard" and not args.filter
+    if not plain:
+        kw.update(scale=args.scale, filter_low_variance=args.filter or False)
     keys = sorted(tabs)
     torch.zeros(1, device="cuda")                      # context up before anything is timed
     raw = torch.empty(sum(tabs[k].shape[0] for k in keys), len(cols), dtype=torch.float64, device="cuda")
@@ -77,12 +82,15 @@ def main():
         torch.cuda.synchronize()
         wall.append(time.perf_counter() - t0)
     # device-only time: replay the C call alone
-    dev_ms = device_time(lib, res, raw, tabs, cols, aids, node_cols, edge_cols, kw, args.iters)
+    # the other scalers / the filter are several C calls with host decisions in between: the whole host call is their figure
+    dev_ms = device_time(lib, res, raw, tabs, cols, aids, node_cols, edge_cols, kw, args.iters) if plain else float(np.median(wall) * 1e3)
     algo = n_frames * (8 * C + 4 * n_out)
     out = {"metric": "pose-table preprocessing (scale_table + global scaler + clip/interpolate -> fp32 frame tables)",
            "value": n_frames / (dev_ms * 1e-3), "unit": "frames/s", "ms_per_call": dev_ms, "n_frames": int(n_frames),
            "raw_columns": int(C), "output_columns": int(n_out), "videos": args.videos, "dtype": "f64 -> f32",
-           "config": {"workload": f"C2 data set: {args.videos} videos x {args.frames} frames, {len(bps)} body parts, modes={args.mode}"},
+           "config": {"workload": f"C2 data set: {args.videos} videos x {args.frames} frames, {len(bps)} body parts, modes={args.mode}, "
+                                  f"scale={args.scale}, filter_low_variance={args.filter or False}"
+                                  + ("" if plain else " (ms_per_call = median wall time of the whole host call incl. its syncs)")},
            "roofline": {"bound": "hbm", "achieved": algo / (dev_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": algo / (dev_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_call": int(algo),
                         "bytes_per_frame": 8 * C + 4 * n_out},
@@ -110,7 +118,7 @@ def device_time(lib, res, raw, tabs, cols, aids, node_cols, edge_cols, kw, iters
     out_cols = dev(np.array([where[c] for c in node_cols + edge_cols], dtype=np.int32))
     d_off, d_kind = dev(res.video_off), dev(plan.kinds)
     d_ref = dev(plan.size_ref.reshape(-1))
-    d_coff, d_chain = dev(plan.chain_off), dev(plan.chain.reshape(-1) if plan.chain.size else np.zeros(3, np.int32))
+    d_coff, d_chain = dev(plan.chain_off), dev(plan.chain.reshape(-1) if plan.chain.size else np.zeros(4, np.int32))
     d_scaler = torch.zeros(len(cols), 2, dtype=torch.float64, device="cuda")
     dims = _capi.PreprocDims(n_frames=raw.shape[0], n_videos=len(res.keys), n_cols=len(cols), n_animals=len(plan.animal_ids),
                              n_node_cols=len(node_cols), n_edge_cols=len(edge_cols), n_angle_cols=0,
