@@ -20,6 +20,33 @@ typedef emu_f32x4 dof_f32x4;
 typedef float dof_f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
+// v_mfma_f32_32x32x16_bf16 (gfx950): D (32 x 32 fp32) += A (32 x 16 bf16) B (16 x 32 bf16).  Operand of lane l: row (A) /
+// column (B) l & 31, the eight consecutive k values 8 (l >> 5) .. + 7; D register v of lane l: row 8 (v / 4) + 4 (l >> 5) +
+// v % 4, column l & 31.
+#ifdef DOF_EMU
+typedef emu_bf16x8 dof_bf16x8;
+typedef emu_f32x16 dof_f32x16;
+#define DOF_MFMA_32x32x16_BF16(a, b, c) emu_mfma_32x32x16_bf16((a), (b), (c))
+#else
+typedef __bf16 dof_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float dof_f32x16 __attribute__((ext_vector_type(16)));
+#define DOF_MFMA_32x32x16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
+// eight bf16 values (16 bytes, 8-byte aligned) from LDS as an MFMA operand
+__device__ __forceinline__ dof_bf16x8 dof_ld_bf16x8(const uint16_t* p) {
+  union { uint64_t h[2]; dof_bf16x8 v; } u;
+  u.h[0] = reinterpret_cast<const uint64_t*>(p)[0];
+  u.h[1] = reinterpret_cast<const uint64_t*>(p)[1];
+  return u.v;
+}
+// fp32 = hi + mid + lo EXACTLY with three bf16 pieces: each piece is the top 16 bits of what is left (truncation keeps the
+// remainder exactly representable: 8 + 8 + 8 significand bits).  Returns the float with the piece removed.
+__device__ __forceinline__ float dof_bf16_peel(float v, uint32_t& piece) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, v) & 0xFFFF0000u;
+  piece = u >> 16;
+  return v - __builtin_bit_cast(float, u);
+}
+
 #ifdef DOF_EMU
 #define DOF_SCHED_FENCE() ((void)0)
 #else

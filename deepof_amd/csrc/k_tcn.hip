@@ -1357,11 +1357,159 @@ __global__ void __launch_bounds__(256, 6) k_tcn_wgrad(const DofTcnWgrad* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix pipe with fp32-exact products (round 3).  k_tcn_wgrad above runs at 82 % of
+// the fp32 MFMA rate, which is 1/16 of the bf16 rate.  Every staged fp32 operand is split once into three bf16 pieces
+// hi + mid + lo = the value EXACTLY (truncation: 8 + 8 + 8 significand bits), written as three bf16 planes; a product
+// a b is then the six piece products down to 2^-24 relative (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid -- the three
+// dropped terms are below 2^-24 |a b|), each exact in the fp32 accumulator's input, so the result carries the rounding of
+// an fp32 fmaf chain in a different order: six v_mfma_f32_32x32x16_bf16 replace sixteen v_mfma_f32_16x16x4_f32 (2.7 x).
+// GEMM view per tap j: dW_j (32 out x 32 in) = sum over k = (t, s) of dy[k][o] x[k + 4 shift_j][c], k time-major over the 4
+// sequences of a chunk, padded to a multiple of 16; A rows = out channels, B columns = in channels, both K-contiguous in
+// LDS ([plane][channel][k] bf16; x with 16 zero elements in front: a tap's first K-step reaches at most 12 elements before
+// the window, K-steps entirely before it are skipped).  48 KB of LDS: 3 workgroups per CU; the next chunk's global loads
+// are issued before the MFMA phase of the current one.  Same partial-tile layout as k_tcn_wgrad.
+constexpr int WB_DSTR = 120, WB_XSTR = 136, WB_XP = 16;  // row strides (bf16 elements): 240 / 272 bytes, 4 banks apart
+__global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __restrict__ descs, float* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) uint16_t sd16[3][32][WB_DSTR];
+  __shared__ __attribute__((aligned(16))) uint16_t sx16[3][32][WB_XSTR];
+  const DofTcnWgrad D = descs[blockIdx.y];
+  if ((int)blockIdx.x >= D.nblk) return;
+  const int T = D.T;
+  const int64_t Sp = D.Sp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // zero once: the K padding of dy (k >= 4 T) and the borders of x are never written again
+  for (int i = tid; i < 3 * 32 * WB_DSTR / 2; i += 256) reinterpret_cast<uint32_t*>(&sd16[0][0][0])[i] = 0u;
+  for (int i = tid; i < 3 * 32 * WB_XSTR / 2; i += 256) reinterpret_cast<uint32_t*>(&sx16[0][0][0])[i] = 0u;
+  // staging: thread = (time step, 4-channel group); it holds that row piece of the chunk's 4 sequences
+  const int st_t = tid >> 3, cg = (tid & 7) * 4;
+  const bool stager = st_t < T;
+  float xs[4] = {1.0f, 1.0f, 1.0f, 1.0f}, xh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float ka[4], kb[4], kc[4], bm[4];
+  if (D.in_bnp) {
+    dof_ld_row<4>(D.in_bnp + 2 * 32 + cg, xs);
+    dof_ld_row<4>(D.in_bnp + 3 * 32 + cg, xh);
+  }
+  if (D.dy_y) {  // dy = scale (g - c1 - (y - mean) rstd c2) = ka g + kb (y - mean) + kc
+    float br[4], c1[4], c2[4];
+    dof_ld_row<4>(D.dy_bnp + cg, bm);
+    dof_ld_row<4>(D.dy_bnp + 32 + cg, br);
+    dof_ld_row<4>(D.dy_bnp + 2 * 32 + cg, ka);
+    dof_ld_row<4>(D.dy_coef + cg, c1);
+    dof_ld_row<4>(D.dy_coef + 32 + cg, c2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      kb[k] = -ka[k] * br[k] * c2[k];
+      kc[k] = -ka[k] * c1[k];
+    }
+  }
+  const int tap = (wave + (int)blockIdx.x) & 3;  // rotated per workgroup: the taps' K-step counts differ (skipped steps)
+  const int shift = -(3 - tap) * D.dil;
+  const int KS = (4 * T + 15) / 16, ks0 = (-shift) / 4;
+  dof_f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+  float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int64_t chunks = Sp / 4;
+  float4 rx[4], rd[4], ry[4];
+  auto fetch = [&](int64_t ch) {  // unconditional loads (clamped chunk): a predicate around them would serialise the batch
+    const int64_t chc = ch < chunks ? ch : chunks - 1;
+    const int64_t base = ((int64_t)(stager ? st_t : 0) * Sp + chc * 4) * 32 + cg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      rx[q] = *reinterpret_cast<const float4*>(D.in + base + q * 32);
+      rd[q] = *reinterpret_cast<const float4*>(D.dy + base + q * 32);
+      if (D.dy_y) ry[q] = *reinterpret_cast<const float4*>(D.dy_y + base + q * 32);
+    }
+  };
+  fetch(blockIdx.x);
+  const int am = lane & 31, kg = lane >> 5;
+  for (int64_t ch = blockIdx.x; ch < chunks; ch += D.nblk) {
+    __syncthreads();  // the previous chunk's MFMA phase (and the zero fill) is done with the planes
+    if (stager) {
+      float ex[4][4], ed[4][4];  // [sequence][channel]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float vx[4] = {rx[q].x, rx[q].y, rx[q].z, rx[q].w}, vd[4] = {rd[q].x, rd[q].y, rd[q].z, rd[q].w};
+        const float vy[4] = {ry[q].x, ry[q].y, ry[q].z, ry[q].w};
+        const bool valid = ch * 4 + q < D.S;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ex[q][k] = D.in_bnp ? fmaxf(fmaf(vx[k], xs[k], xh[k]), 0.0f) : vx[k];
+          ed[q][k] = D.dy_y ? (valid ? fmaf(ka[k], vd[k], fmaf(kb[k], vy[k] - bm[k], kc[k])) : 0.0f) : vd[k];
+          rs[k] += ed[q][k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t pd[3][4], px[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float r = dof_bf16_peel(ed[q][k], pd[0][q]);
+          r = dof_bf16_peel(r, pd[1][q]);
+          (void)dof_bf16_peel(r, pd[2][q]);
+          float u = dof_bf16_peel(ex[q][k], px[0][q]);
+          u = dof_bf16_peel(u, px[1][q]);
+          (void)dof_bf16_peel(u, px[2][q]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const uint64_t wd = (uint64_t)(pd[p][0] | (pd[p][1] << 16)) | ((uint64_t)(pd[p][2] | (pd[p][3] << 16)) << 32);
+          const uint64_t wx = (uint64_t)(px[p][0] | (px[p][1] << 16)) | ((uint64_t)(px[p][2] | (px[p][3] << 16)) << 32);
+          *reinterpret_cast<uint64_t*>(&sd16[p][cg + k][4 * st_t]) = wd;
+          *reinterpret_cast<uint64_t*>(&sx16[p][cg + k][WB_XP + 4 * st_t]) = wx;
+        }
+      }
+    }
+    fetch(ch + D.nblk);  // lands during the MFMA phase
+    __syncthreads();
+    for (int ks = ks0; ks < KS; ++ks) {
+      const int ka0 = ks * 16 + kg * 8, kb0 = WB_XP + ka0 + 4 * shift;
+      const dof_bf16x8 ah = dof_ld_bf16x8(&sd16[0][am][ka0]), amid = dof_ld_bf16x8(&sd16[1][am][ka0]),
+                       al = dof_ld_bf16x8(&sd16[2][am][ka0]);
+      const dof_bf16x8 bh = dof_ld_bf16x8(&sx16[0][am][kb0]), bmid = dof_ld_bf16x8(&sx16[1][am][kb0]),
+                       bl = dof_ld_bf16x8(&sx16[2][am][kb0]);
+      acc = DOF_MFMA_32x32x16_BF16(ah, bl, acc);
+      acc = DOF_MFMA_32x32x16_BF16(al, bh, acc);
+      acc = DOF_MFMA_32x32x16_BF16(amid, bmid, acc);
+      acc = DOF_MFMA_32x32x16_BF16(ah, bmid, acc);
+      acc = DOF_MFMA_32x32x16_BF16(amid, bh, acc);
+      acc = DOF_MFMA_32x32x16_BF16(ah, bh, acc);
+    }
+  }
+  float* out = partials + (tap < 2 ? D.part0 : D.part1) + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) out[(8 * (v / 4) + 4 * kg + v % 4) * 65 + (tap & 1) * 32 + am] = acc[v];
+  // bias gradient: channel sums of dy over the stagers of a channel group (fixed order)
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(&sd16[0][0][0]);  // [32 time rows][32 channels]
+  if (tid < 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[st_t * 32 + cg + k] = stager ? rs[k] : 0.0f;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float b = 0.0f;
+    for (int t = 0; t < 32; ++t) b += red[t * 32 + tid];
+    partials[D.part0 + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS + tid * 65 + 64] = b;
+  }
+}
+
 }  // namespace
+
+// DOF_TCN_WGRAD_FP32=1: the fp32-MFMA kernel (A/B measurements)
+static int dof_tcn_wgrad_fp32() {
+  static const int v = [] {
+    const char* e = getenv("DOF_TCN_WGRAD_FP32");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return v;
+}
 
 int dof_launch_tcn_wgrad(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st) {
   if (n <= 0) return DOF_OK;
-  DOF_LAUNCH((k_tcn_wgrad<4>), ((unsigned)max_nblk, (unsigned)n), (256), st, descs_dev, partials);
+  if (dof_tcn_wgrad_fp32()) DOF_LAUNCH((k_tcn_wgrad<4>), ((unsigned)max_nblk, (unsigned)n), (256), st, descs_dev, partials);
+  else DOF_LAUNCH(k_tcn_wgrad_b3, ((unsigned)max_nblk, (unsigned)n), (256), st, descs_dev, partials);
   return dof_check_launch("k_tcn_wgrad");
 }
 

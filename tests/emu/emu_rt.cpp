@@ -155,6 +155,37 @@ emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c) {
   return c;
 }
 
+namespace {
+uint16_t g_xchg16[1024][16];  // per-thread bf16 operands (a[8] | b[8])
+float bf16f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+}  // namespace
+
+emu_f32x16 emu_mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
+  // A[m][k]: lane (k / 8) * 32 + m, element k % 8 ; B[k][n]: lane (k / 8) * 32 + n ; D register v: row 8 (v/4) + 4 (lane>>5) + v%4
+  int me = g_cur;
+  int lane = me & 63, base = me - lane;
+  for (int e = 0; e < 8; ++e) {
+    g_xchg16[me][e] = a.v[e];
+    g_xchg16[me][8 + e] = b.v[e];
+  }
+  yield_as(WAIT_WAVE);
+  int col = lane & 31;
+  for (int v = 0; v < 16; ++v) {
+    int row = 8 * (v / 4) + 4 * (lane >> 5) + v % 4;
+    float acc = c[v];
+    for (int k = 0; k < 16; ++k)
+      acc = fmaf(bf16f(g_xchg16[base + (k / 8) * 32 + row][k % 8]), bf16f(g_xchg16[base + (k / 8) * 32 + col][8 + k % 8]), acc);
+    c[v] = acc;
+  }
+  yield_as(WAIT_WAVE);
+  return c;
+}
+
 void emu_run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
   g_body = &body;
   gridDim = grid;

@@ -648,11 +648,11 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
     assert nb == 3 * (34 + 3 + 8)
     # ---- optimiser step 1 on these gradients.  Adam's first step is lr * sign(g): where the gradient is below what
     # fp32 resolves (4 x the gradient bar) the sign is arbitrary in either implementation, elsewhere it must match.
+    g1_hip = {k: eng.view(k, eng.grads).cpu().numpy().copy() for k in eng.names if "grad::" + k in d}
     eng.optimizer_step()
     sd1 = eng.state_dict()
     ref1 = params_from(d, "sd_step1::")
     lr = 1e-3
-    unresolved = {}
     for k in eng.names:
         if k.endswith("running_mean") or k.endswith("running_var") or k.startswith("distill_head."):
             continue
@@ -668,7 +668,6 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
         weak = g1 < 2e-3 * max(float(g1.max()), 1e-30) + 1e-6 + kinks1.extra(k)
         if math_zero_gradient(k):
             weak[:] = True
-        unresolved[k] = weak
         np.testing.assert_allclose(got[~weak], ref[~weak], atol=2e-6, rtol=1e-5, err_msg=k)
     # ---- step 2 from the REFERENCE's post-step-1 weights (teacher forcing: a free-running trace is chaotic, see
     # make_golden_r02.py), our own Adam moments: gradients at the standard bar, then the weights
@@ -688,8 +687,11 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
             worst = max(worst, _grad_bar(g, d[k].reshape(g.shape), name, rtol=VQ_TCN_RTOL, extra=kinks2.extra(name)))
             n2 += 1
     assert n2 >= 190, n2
-    # resolved elements: the Adam update to 2 % of one step
-    step2_atol = 2e-5
+    # The second Adam update of an element is lr * f(g1, g2) with |df| <= (|dg1| + |dg2|) / sqrt(g1^2 + g2^2) (bias
+    # corrections of t = 2; measured constant 0.87): the weights may differ from the reference's by exactly what the two
+    # gradient differences -- each already judged against its bar above -- propagate to, element by element, plus
+    # 0.3 % of a step for the update arithmetic.  No outlier allowance.
+    g2_hip = {k: eng.view(k, eng.grads).cpu().numpy().copy() for k in eng.names if "grad2::" + k in d}
     eng.optimizer_step()
     sd2 = eng.state_dict()
     for k, v in params_from(d, "sd_step2::").items():
@@ -698,15 +700,17 @@ def run_vqvae_tcn_ref_check(lib, device, golden_dir):
         got, ref = sd2[k].numpy(), v.numpy().reshape(sd2[k].shape)
         start = ref1[k].numpy().reshape(got.shape)
         assert float(np.abs(got - start).max()) <= lr * 1.05, k   # |m_hat| / sqrt(v_hat) peaks just above 1 at t = 2
-        g2 = np.abs(d["grad2::" + k].reshape(got.shape)) if "grad2::" + k in d else np.zeros_like(got)
-        weak = unresolved[k] | (g2 < 2e-3 * max(float(g2.max()), 1e-30) + 1e-6 + kinks2.extra(k))
-        # resolved in both steps: the Adam update (bias corrections of t = 2, weight decay, clip) to 2 % of one step
-        # ... except elements whose two small gradients both moved: at most 0.5 % of a tensor's resolved elements, and
-        # those within 20 % of one step
-        dev = np.abs(got[~weak] - ref[~weak])
-        bad = dev > step2_atol + 1e-5 * np.abs(ref[~weak])
-        assert bad.size == 0 or (int(bad.sum()) <= int(5e-3 * bad.size) and float(dev.max()) <= 0.2 * lr), \
-            (k, int(bad.sum()), bad.size, float(dev.max()))
+        if "grad2::" + k not in d or "grad::" + k not in d or math_zero_gradient(k):
+            continue
+        r1, r2 = d["grad::" + k].reshape(got.shape), d["grad2::" + k].reshape(got.shape)
+        e1 = np.abs(g1_hip[k].reshape(got.shape) - r1)
+        e2 = np.abs(g2_hip[k].reshape(got.shape) - r2)
+        rel = (e1 + e2) / np.maximum(np.sqrt(r1.astype(np.float64) ** 2 + r2.astype(np.float64) ** 2), 1e-30)
+        weak = rel > 0.25        # the gradients themselves are not resolved there (within their bars): direction open
+        dev = np.abs(got - ref)
+        tol = 3e-6 + 1e-5 * np.abs(ref) + lr * rel
+        over = (~weak) & (dev > tol)
+        assert not over.any(), (k, int(over.sum()), over.size, float((dev - tol)[over].max()))
         flipped = kinks1.extra(k) > 0 or kinks2.extra(k) > 0
         assert (~weak).mean() > (0.25 if flipped else 0.5) or math_zero_gradient(k), (k, float((~weak).mean()))
     return worst, flips1, flips2
