@@ -40,11 +40,17 @@ __device__ __forceinline__ dof_bf16x8 dof_ld_bf16x8(const uint16_t* p) {
   return u.v;
 }
 // fp32 = hi + mid + lo EXACTLY with three bf16 pieces: each piece is the top 16 bits of what is left (truncation keeps the
-// remainder exactly representable: 8 + 8 + 8 significand bits).  Returns the float with the piece removed.
-__device__ __forceinline__ float dof_bf16_peel(float v, uint32_t& piece) {
-  const uint32_t u = __builtin_bit_cast(uint32_t, v) & 0xFFFF0000u;
-  piece = u >> 16;
-  return v - __builtin_bit_cast(float, u);
+// remainder exactly representable: 8 + 8 + 8 significand bits).  dof_bf16_rest: the value with its top piece removed;
+// dof_pack_hi16: the top pieces of two values as one word (first argument in the low half) -- one v_perm_b32.
+__device__ __forceinline__ float dof_bf16_rest(float v) {
+  return v - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint32_t dof_pack_hi16(float lo_half, float hi_half) {
+#ifdef DOF_EMU
+  return (__builtin_bit_cast(uint32_t, lo_half) >> 16) | (__builtin_bit_cast(uint32_t, hi_half) & 0xFFFF0000u);
+#else
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi_half), __builtin_bit_cast(uint32_t, lo_half), 0x07060302u);
+#endif
 }
 
 #ifdef DOF_EMU

@@ -1369,7 +1369,7 @@ __global__ void __launch_bounds__(256, 6) k_tcn_wgrad(const DofTcnWgrad* __restr
 // LDS ([plane][channel][k] bf16; x with 16 zero elements in front: a tap's first K-step reaches at most 12 elements before
 // the window, K-steps entirely before it are skipped).  48 KB of LDS: 3 workgroups per CU; the next chunk's global loads
 // are issued before the MFMA phase of the current one.  Same partial-tile layout as k_tcn_wgrad.
-constexpr int WB_DSTR = 120, WB_XSTR = 136, WB_XP = 16;  // row strides (bf16 elements): 240 / 272 bytes, 4 banks apart
+constexpr int WB_DSTR = 120, WB_XSTR = 132, WB_XP = 16;  // row strides (bf16 elements): 240 bytes (16-byte reads, 16 lanes a pass) / 264 bytes (8-byte reads, 32 lanes a pass): conflict-free
 __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __restrict__ descs, float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) uint16_t sd16[3][32][WB_DSTR];
   __shared__ __attribute__((aligned(16))) uint16_t sx16[3][32][WB_XSTR];
@@ -1442,22 +1442,20 @@ __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __re
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        uint32_t pd[3][4], px[3][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float r = dof_bf16_peel(ed[q][k], pd[0][q]);
-          r = dof_bf16_peel(r, pd[1][q]);
-          (void)dof_bf16_peel(r, pd[2][q]);
-          float u = dof_bf16_peel(ex[q][k], px[0][q]);
-          u = dof_bf16_peel(u, px[1][q]);
-          (void)dof_bf16_peel(u, px[2][q]);
-        }
+        float vd[4] = {ed[0][k], ed[1][k], ed[2][k], ed[3][k]}, vx[4] = {ex[0][k], ex[1][k], ex[2][k], ex[3][k]};
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          const uint64_t wd = (uint64_t)(pd[p][0] | (pd[p][1] << 16)) | ((uint64_t)(pd[p][2] | (pd[p][3] << 16)) << 32);
-          const uint64_t wx = (uint64_t)(px[p][0] | (px[p][1] << 16)) | ((uint64_t)(px[p][2] | (px[p][3] << 16)) << 32);
+          const uint64_t wd = (uint64_t)dof_pack_hi16(vd[0], vd[1]) | ((uint64_t)dof_pack_hi16(vd[2], vd[3]) << 32);
+          const uint64_t wx = (uint64_t)dof_pack_hi16(vx[0], vx[1]) | ((uint64_t)dof_pack_hi16(vx[2], vx[3]) << 32);
           *reinterpret_cast<uint64_t*>(&sd16[p][cg + k][4 * st_t]) = wd;
           *reinterpret_cast<uint64_t*>(&sx16[p][cg + k][WB_XP + 4 * st_t]) = wx;
+          if (p < 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              vd[q] = dof_bf16_rest(vd[q]);
+              vx[q] = dof_bf16_rest(vx[q]);
+            }
+          }
         }
       }
     }
