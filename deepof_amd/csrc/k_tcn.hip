@@ -117,6 +117,12 @@ struct TcnConvArgs {
   const float* bwd_coef;  // BWD2: (mean g | mean g * xhat) of that BatchNorm
   int bwd_store;          // BWD2: 1 = write dy back over `in` (0: the weight-gradient kernel applies pass 2 itself)
   const float* stat_shift;  // forward k_tcn_conv_t: per-channel shift K of the channel sums (sum (y - K) | sum (y - K)^2), or null (see k_bn_fwd_fin)
+  // TAIL (k_tcn_conv_t, conv1's data gradient of block b + 1): the backward of block b's tail in the epilogue
+  const float* tail_src = nullptr;    // gradient already waiting at block b's output (the residual branch of block b + 1)
+  const float* tail_out = nullptr;    // block b's output (ReLU mask)
+  float* tail_gres = nullptr;         // masked gradient = what enters block b's residual branch
+  const float* tail_skip = nullptr;   // final skip-sum (mask of the last-step feature gradient)
+  const float* tail_dfeat = nullptr;  // [32][Sp] gradient of the last-step features
   int T, dil, accumulate;
   int64_t S, Sp;
 };
@@ -237,8 +243,14 @@ constexpr int TCT_T = 25;
 
 __device__ __forceinline__ int tct_slot(int t, int sq, int chunk) { return (t * 16 + sq) * 8 + (chunk ^ ((sq >> 1) & 7)); }
 
-template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2>
+// TAIL (with REVERSE, FUSE_BN, BWD2; round 3): the convolution is conv1's data gradient of block b + 1, its result plus
+// tail_src is the complete gradient at block b's output, and the epilogue runs the backward of block b's tail on it --
+// mask by the block output, store the residual-branch gradient, add the last-step feature gradient, then (FUSE_BN) the
+// first pass of BatchNorm2's backward of block b.  The gradient at the block output is never written and k_tcn_bn_bwd1_w's
+// pass over it (3 reads, 2 writes per element) shrinks to 2 more reads here.
+template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL = false>
 __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
+  static_assert(!TAIL || (REVERSE && FUSE_BN && BWD2), "the tail epilogue extends the fused data-gradient variant");
   __shared__ float4 tile[(TCT_T + 1) * 16 * 8];  // + one row for the unconditional staging of an odd T
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
@@ -346,16 +358,29 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     const uint32_t ep_base = (uint32_t)s * TC + ct * 16 + kk * 4;
     const uint32_t pre_base = (uint32_t)(pre_on ? s : s0) * TC + ct * 16 + kk * 4;  // padded lanes read a valid row and ignore it
     float4 p0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), p1 = p0;
+    float4 ts0 = p0, to0 = p0;  // TAIL: rows of tail_src / tail_out, requested one output row ahead (register budget)
     if (PRE && (FUSE_BN || A.accumulate)) {
-      p0 = *reinterpret_cast<const float4*>(pre_src + (pre_base + (uint32_t)(tpar < T ? tpar : T - 1) * row_stride));
-      p1 = *reinterpret_cast<const float4*>(pre_src + (pre_base + (uint32_t)(tpar + 2 < T ? tpar + 2 : T - 1) * row_stride));
+      const uint32_t o0 = pre_base + (uint32_t)(tpar < T ? tpar : T - 1) * row_stride;
+      const uint32_t o1 = pre_base + (uint32_t)(tpar + 2 < T ? tpar + 2 : T - 1) * row_stride;
+      p0 = *reinterpret_cast<const float4*>(pre_src + o0);
+      p1 = *reinterpret_cast<const float4*>(pre_src + o1);
+      if (TAIL) {
+        ts0 = *reinterpret_cast<const float4*>(A.tail_src + o0);
+        to0 = *reinterpret_cast<const float4*>(A.tail_out + o0);
+      }
     }
     for (int t = tpar; t < T; t += 2) {
       const uint32_t off = ep_base + (uint32_t)t * row_stride;
-      const float4 pc = p0;
+      const float4 pc = p0, tsc = ts0, toc = to0;
       if (PRE && (FUSE_BN || A.accumulate)) {
+        const uint32_t o2 = pre_base + (uint32_t)(t + 4 < T ? t + 4 : T - 1) * row_stride;
         p0 = p1;
-        p1 = *reinterpret_cast<const float4*>(pre_src + (pre_base + (uint32_t)(t + 4 < T ? t + 4 : T - 1) * row_stride));
+        p1 = *reinterpret_cast<const float4*>(pre_src + o2);
+        if (TAIL) {
+          const uint32_t o1n = pre_base + (uint32_t)(t + 2 < T ? t + 2 : T - 1) * row_stride;
+          ts0 = *reinterpret_cast<const float4*>(A.tail_src + o1n);
+          to0 = *reinterpret_cast<const float4*>(A.tail_out + o1n);
+        }
       }
       dof_f32x4 acc = {bias[0], bias[1], bias[2], bias[3]};
       // all valid taps' rows are requested from LDS before the first MFMA (validity is wave-uniform)
@@ -382,6 +407,19 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
         float v0[4] = {acc[0], acc[1], acc[2], acc[3]};
         if (REVERSE && !FUSE_BN && A.accumulate) {
           v0[0] += pc.x; v0[1] += pc.y; v0[2] += pc.z; v0[3] += pc.w;
+        }
+        if (TAIL) {
+          const float sv[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, ov[4] = {toc.x, toc.y, toc.z, toc.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v0[r] = ov[r] > 0.0f ? v0[r] + sv[r] : 0.0f;
+          *reinterpret_cast<float4*>(A.tail_gres + off) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+          if (A.tail_dfeat && t == T - 1) {
+            const float4 sk = *reinterpret_cast<const float4*>(A.tail_skip + off);
+            const float sk4[4] = {sk.x, sk.y, sk.z, sk.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              v0[r] += sk4[r] > 0.0f ? A.tail_dfeat[(int64_t)(ct * 16 + kk * 4 + r) * A.Sp + s] : 0.0f;
+          }
         }
         if (FUSE_BN) {
           const float ya[4] = {pc.x, pc.y, pc.z, pc.w};
@@ -1173,6 +1211,38 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
   DOF_LAUNCH((k_tcn_conv<true, false, true>), ((unsigned)(waves / 4)), (256), st, A);
   if (int rc = dof_check_launch("k_tcn_conv_bwd_bn")) return rc;
   return dof_launch_sum_partials(partial, waves, 2 * TC, sums, 0, st);
+}
+
+// conv1's data gradient of block b + 1 with the backward of block b's tail and the first pass of block b's BatchNorm2
+// backward in its epilogue (k_tcn_conv_t TAIL): dy = pass-1 gradient of block b + 1's BatchNorm1 (pass 2 applied while
+// staging), tail_src = the gradient waiting at block b's output, g_out = block b's g2, sums = its channel sums
+int dof_tcn_tail_fold() {
+  static const int on = [] {
+    const char* e = getenv("DOF_TCN_TAIL_FOLD");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return on;
+}
+int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
+                             int bwd_store, const float* tail_src, const float* tail_out, float* tail_gres,
+                             const float* tail_skip, const float* tail_dfeat, const float* y2, const float* bnp2, float* g_out,
+                             float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st) {
+  if (!dof_tcn_conv32_resident(T, Sp) || !bwd_y) {
+    dof_set_error("k_tcn_conv_tail: needs the time-resident kernel (T <= %d) and a lazy BatchNorm1 gradient", TCT_T);
+    return DOF_ERR_UNSUPPORTED;
+  }
+  TcnConvArgs A;
+  A.bwd_store = bwd_store;
+  A.in = dy; A.w = w; A.bias = nullptr; A.bnp_in = nullptr; A.a_out = nullptr; A.out = g_out; A.partial = partial;
+  A.fuse_y = y2; A.fuse_bnp = bnp2;
+  A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
+  A.stat_shift = nullptr;
+  A.tail_src = tail_src; A.tail_out = tail_out; A.tail_gres = tail_gres; A.tail_skip = tail_skip; A.tail_dfeat = tail_dfeat;
+  A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
+  const unsigned nbt = tct_blocks(Sp);
+  DOF_LAUNCH((k_tcn_conv_t<true, false, true, true, true>), (nbt), (256), st, A);
+  if (int rc = dof_check_launch("k_tcn_conv_t_tail")) return rc;
+  return dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st);
 }
 
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,

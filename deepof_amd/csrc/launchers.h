@@ -62,6 +62,11 @@ int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const floa
                         const float* bwd_coef = nullptr, const float* stat_shift = nullptr, int bwd_store = 1);
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
                             int T, int CT, int64_t S, int64_t Sp, hipStream_t st, const float* shift = nullptr);
+int dof_tcn_tail_fold();
+int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
+                             int bwd_store, const float* tail_src, const float* tail_out, float* tail_gres,
+                             const float* tail_skip, const float* tail_dfeat, const float* y2, const float* bnp2, float* g_out,
+                             float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
                           float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st, int shifted = 0);
 int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,

@@ -1610,14 +1610,17 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
     const TcnWs& t = p->tw[s];
     const float count = (float)((int64_t)T * w.S);
     const bool fuse2 = dof_tcn_conv32_resident(T, w.Sp) != 0;
+    bool tail_done = false;  // this block's tail backward already ran in the epilogue of the block behind it
     for (int b = 7; b >= 0; --b) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
       float* dprev = ws + t.dout[(b + 1) & 1];  // gradient of the previous block's output (this block's input)
       // BN2 + ReLU + block tail
-      TRY(dof_launch_tcn_bn_bwd1(b == 7 ? nullptr : ws + t.dout[b & 1], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.g2[b],
-                                 ws + t.partial, ws + t.sums, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip,
-                                 nullptr, dprev, T, 32, w.S, w.Sp, st));
+      if (!tail_done)
+        TRY(dof_launch_tcn_bn_bwd1(b == 7 ? nullptr : ws + t.dout[b & 1], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.g2[b],
+                                   ws + t.partial, ws + t.sums, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip,
+                                   nullptr, dprev, T, 32, w.S, w.Sp, st));
+      tail_done = false;
       float* coef2 = ws + (t.lazy ? t.coefs[2 * b + 1] : t.coef);
       float* coef1 = ws + (t.lazy ? t.coefs[2 * b] : t.coef);
       TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, coef2, 32, st));
@@ -1634,7 +1637,15 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
                                        ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st));
       }
       TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g1, grads + o.b1, accumulate, coef1, 32, st));
-      if (fuse2 && b > 0) {  // pass 2 of BN1's backward inside conv1's data gradient
+      if (fuse2 && b > 0 && dof_tcn_tail_fold()) {
+        // ... and the backward of block b - 1's tail + the first pass of its BatchNorm2 in the epilogue: dprev holds
+        // this block's residual-branch gradient, the sum is the gradient at block b - 1's output (never written);
+        // its masked form goes to block b - 1's own dprev (this block's din buffer, free by now)
+        TRY(dof_launch_tcn_conv_tail(ws + t.g1[b], params + o.c1w, ws + t.y1[b], ws + t.bnp[2 * b], coef1, t.lazy ? 0 : 1, dprev,
+                                     ws + t.out[b - 1], ws + t.dout[b & 1], ws + t.skip, ws + w.dn2, ws + t.y2[b - 1],
+                                     ws + t.bnp[2 * b - 1], ws + t.g2[b - 1], ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st));
+        tail_done = true;
+      } else if (fuse2 && b > 0) {  // pass 2 of BN1's backward inside conv1's data gradient
         TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
                                 w.Sp, st, ws + t.y1[b], ws + t.bnp[2 * b], coef1, nullptr, t.lazy ? 0 : 1));
       } else {  // block 0's conv1 gradient goes through the generic reduction: normalised gradient in place
