@@ -1316,6 +1316,11 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     const float count = (float)((int64_t)T * w.S);
     // batch statistics in one pass: the time-resident convolutions sum (y - K), (y - K)^2 with K = the layer's running mean
     const bool sh = train && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_onepass_stats();
+    static const unsigned long long sh_mask = [] {  // development aid: DOF_TCN_ONEPASS_MASK = hex mask over layers (stream * 16 + 2 block + conv)
+      const char* e = getenv("DOF_TCN_ONEPASS_MASK");
+      return e ? strtoull(e, nullptr, 16) : ~0ull;
+    }();
+    auto sh_on = [&](int layer) { return sh && ((sh_mask >> (s * 16 + layer)) & 1ull); };
     for (int b = 0; b < 8; ++b) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
@@ -1326,14 +1331,14 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
         nrows = dof_tcn_row_blocks(T, w.S);
       } else {
         TRY(dof_launch_tcn_conv(0, ws + t.out[b - 1], params + o.c1w, params + o.c1b, nullptr, nullptr, ws + t.y1[b],
-                                ws + t.partial, 0, T, d, w.S, w.Sp, st, nullptr, nullptr, nullptr, sh ? params + o.rm1 : nullptr));
+                                ws + t.partial, 0, T, d, w.S, w.Sp, st, nullptr, nullptr, nullptr, sh_on(2 * b) ? params + o.rm1 : nullptr));
         nrows = dof_tcn_conv32_partials(T, w.Sp);
       }
-      const float* sh1 = (sh && b > 0) ? params + o.rm1 : nullptr;
+      const float* sh1 = (sh_on(2 * b) && b > 0) ? params + o.rm1 : nullptr;
       if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh1));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
                                 train, ws + t.bnp[2 * b], 32, st, sh1 != nullptr));
-      const float* sh2 = sh ? params + o.rm2 : nullptr;
+      const float* sh2 = sh_on(2 * b + 1) ? params + o.rm2 : nullptr;
       TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b],
                               t.lazy ? nullptr : ws + t.a1[b], ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st,
                               nullptr, nullptr, nullptr, sh2));
