@@ -248,9 +248,13 @@ __device__ __forceinline__ int tct_slot(int t, int sq, int chunk) { return (t * 
 // mask by the block output, store the residual-branch gradient, add the last-step feature gradient, then (FUSE_BN) the
 // first pass of BatchNorm2's backward of block b.  The gradient at the block output is never written and k_tcn_bn_bwd1_w's
 // pass over it (3 reads, 2 writes per element) shrinks to 2 more reads here.
-template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL = false>
+// COMB (forward, round 3): the input tile is the previous block's OUTPUT, computed while staging from that block's conv2
+// result and residual input -- out = ReLU(ReLU(BN2(y2)) + res) with `in` = res, bwd_y = y2, bnp_in = BatchNorm2's record --
+// and written to a_out for the backward pass: k_tcn_combine's pass over (y2, res, out) becomes one more read here.
+template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL = false, bool COMB = false>
 __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
   static_assert(!TAIL || (REVERSE && FUSE_BN && BWD2), "the tail epilogue extends the fused data-gradient variant");
+  static_assert(!COMB || (!REVERSE && !BN_IN && !FUSE_BN && !BWD2), "the combine-on-load variant is a plain forward convolution");
   __shared__ float4 tile[(TCT_T + 1) * 16 * 8];  // + one row for the unconditional staging of an odd T
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     DOF_MEM_FENCE();
     float k0[4], k1[4];                        // BN_IN: scale, shift of the producer's BatchNorm
     float bm[4], br[4], bs[4], c1[4], c2[4];  // BWD2: mean, rstd, scale, mean g, mean g xhat
-    if (BN_IN) {
+    if (BN_IN || COMB) {
       dof_ld_row<4>(A.bnp_in + 2 * TC + ch * 4, k0);
       dof_ld_row<4>(A.bnp_in + 3 * TC + ch * 4, k1);
     }
@@ -303,7 +307,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     // ---- stage the group's rows: two time steps per pass over the 256 threads, a batch of loads in flight.  The
     // loads are unconditional (steps past T re-read step T - 1 and land in LDS rows nobody reads): a predicate
     // around them would serialise the batch on vmcnt(0).
-    constexpr int NP = (TCT_T + 1) / 2, NBATCH = BWD2 ? 3 : 7;
+    constexpr int NP = (TCT_T + 1) / 2, NBATCH = (BWD2 || COMB) ? 3 : 7;
     const bool srow = s0 + sq < A.S;
     // 32-bit element offsets (the launcher checks T * Sp * 32 < 2^31): SGPR base + one VGPR per address
     const uint32_t row_stride = (uint32_t)A.Sp * TC;
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
           const int t = 2 * (n0 + u) + half;
           const uint32_t off = st_base + (uint32_t)(t < T ? t : T - 1) * row_stride;
           v[u] = *reinterpret_cast<const float4*>(A.in + off);
-          if (BWD2) yv[u] = *reinterpret_cast<const float4*>(A.bwd_y + off);
+          if (BWD2 || COMB) yv[u] = *reinterpret_cast<const float4*>(A.bwd_y + off);
         }
       }
 #pragma unroll
@@ -328,6 +332,11 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
           if (BN_IN) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) e[c] = fmaxf(fmaf(e[c], k0[c], k1[c]), 0.0f);
+          }
+          if (COMB) {
+            const float y4[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[c] = fmaxf(fmaxf(fmaf(y4[c], k0[c], k1[c]), 0.0f) + e[c], 0.0f);
           }
           if (BWD2) {
             const float y4[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
@@ -341,7 +350,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
           tile[tct_slot(t, sq, ch)] = w4;
           if (srow && t < T) {
             const uint32_t off = st_base + (uint32_t)t * row_stride;
-            if (BN_IN && !REVERSE && A.a_out) *reinterpret_cast<float4*>(A.a_out + off) = w4;
+            if ((BN_IN || COMB) && !REVERSE && A.a_out) *reinterpret_cast<float4*>(A.a_out + off) = w4;
             if (BWD2 && A.bwd_store) *reinterpret_cast<float4*>(const_cast<float*>(A.in) + off) = w4;
           }
         }
@@ -1211,6 +1220,32 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
   DOF_LAUNCH((k_tcn_conv<true, false, true>), ((unsigned)(waves / 4)), (256), st, A);
   if (int rc = dof_check_launch("k_tcn_conv_bwd_bn")) return rc;
   return dof_launch_sum_partials(partial, waves, 2 * TC, sums, 0, st);
+}
+
+// forward conv1 of block b + 1 with block b's tail (out = ReLU(ReLU(BN2(y2)) + res), written to out_blk) computed while staging
+int dof_tcn_combine_fold() {
+  static const int on = [] {
+    const char* e = getenv("DOF_TCN_COMBINE_FOLD");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return on;
+}
+int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp2, float* out_blk, const float* w,
+                             const float* bias, float* out, float* partial, int T, int dil, int64_t S, int64_t Sp,
+                             hipStream_t st, const float* stat_shift) {
+  if (!dof_tcn_conv32_resident(T, Sp)) {
+    dof_set_error("k_tcn_conv_comb: needs the time-resident kernel (T <= %d)", TCT_T);
+    return DOF_ERR_UNSUPPORTED;
+  }
+  TcnConvArgs A;
+  A.bwd_store = 0;
+  A.in = res; A.w = w; A.bias = bias; A.bnp_in = bnp2; A.a_out = out_blk; A.out = out; A.partial = partial;
+  A.fuse_y = nullptr; A.fuse_bnp = nullptr;
+  A.bwd_y = y2; A.bwd_bnp = nullptr; A.bwd_coef = nullptr;
+  A.stat_shift = stat_shift;
+  A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
+  DOF_LAUNCH((k_tcn_conv_t<false, false, false, false, false, true>), (tct_blocks(Sp)), (256), st, A);
+  return dof_check_launch("k_tcn_conv_t_comb");
 }
 
 // conv1's data gradient of block b + 1 with the backward of block b's tail and the first pass of block b's BatchNorm2

@@ -1321,6 +1321,7 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
       return e ? strtoull(e, nullptr, 16) : ~0ull;
     }();
     auto sh_on = [&](int layer) { return sh && ((sh_mask >> (s * 16 + layer)) & 1ull); };
+    const bool comb = dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_combine_fold() != 0;
     for (int b = 0; b < 8; ++b) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
@@ -1329,6 +1330,13 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
         TRY(dof_launch_tcn_in_conv(w.F, s == 0 ? x : a, params + o.c1w, params + o.c1b, ws + t.xs, ws + t.y1[0],
                                    ws + t.partial, T, w.G, w.S, w.Sp, d, st));
         nrows = dof_tcn_row_blocks(T, w.S);
+      } else if (comb && b >= 2) {
+        // the previous block's output is computed here, while the tile is staged (its own combine launch only kept the
+        // last step of the skip-sum): out[b-1] = ReLU(ReLU(BN2(y2[b-1])) + out[b-2])
+        TRY(dof_launch_tcn_conv_comb(ws + t.out[b - 2], ws + t.y2[b - 1], ws + t.bnp[2 * b - 1], ws + t.out[b - 1], params + o.c1w,
+                                     params + o.c1b, ws + t.y1[b], ws + t.partial, T, d, w.S, w.Sp, st,
+                                     sh_on(2 * b) ? params + o.rm1 : nullptr));
+        nrows = dof_tcn_conv32_partials(T, w.Sp);
       } else {
         TRY(dof_launch_tcn_conv(0, ws + t.out[b - 1], params + o.c1w, params + o.c1b, nullptr, nullptr, ws + t.y1[b],
                                 ws + t.partial, 0, T, d, w.S, w.Sp, st, nullptr, nullptr, nullptr, sh_on(2 * b) ? params + o.rm1 : nullptr));
@@ -1347,8 +1355,8 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
                                 train, ws + t.bnp[2 * b + 1], 32, st, sh2 != nullptr));
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
                                  b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb,
-                                 b < 7 ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr, b == 0, T, w.F,
-                                 32, w.S, w.Sp, st, 0, /*skip_last=*/1));
+                                 (b < 7 && !(comb && b >= 1)) ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr,
+                                 b == 0, T, w.F, 32, w.S, w.Sp, st, 0, /*skip_last=*/1));
     }
   }
   TRY(censnet_forward(p, params, st));
