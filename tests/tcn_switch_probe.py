@@ -1,0 +1,14 @@
+"""Child process of test_tcn_kernel_switches_gpu: the B = 64 VaDE-TCN reference check (gradients against the reference golden
+with the explicit ReLU-flip attribution) under whatever DOF_TCN_* switches the parent set; prints one JSON line."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+from deepof_amd._lib import load_hip_library  # noqa: E402
+import parity_common as PC  # noqa: E402
+
+res = PC.run_vade_tcn_b64_check(load_hip_library(), "cuda", os.path.join(HERE, "golden"))
+print("PROBE " + json.dumps({"ok": True, "result": repr(res)[:300]}))

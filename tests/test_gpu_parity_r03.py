@@ -1,6 +1,8 @@
 """Round-3 parity tests on the real MI355X: gradients at the BASELINE shapes the round-2 suite only ran forward
 (C5: 28 nodes / 32 edges / window 50 / k = 25 at latent 8; C3: codebook 512; C4: TCN train mode), the TCN family against
 the reference with explicit ReLU-kink attribution, and the one-pass BatchNorm statistics elementwise."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -272,3 +274,21 @@ def test_gru16_matrix_pipe_kernels_gpu():
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gru_mfma_probe.py")
     r = subprocess.run([sys.executable, probe, "gpu"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("switch", ["DOF_TCN_WGRAD_FP32=1", "DOF_TCN_TAIL_FOLD=0", "DOF_TCN_COMBINE_FOLD=0"])
+def test_tcn_kernel_switches_gpu(switch):
+    """The round-3 TCN kernels (bf16-pipe weight gradients, block-tail backward / forward folded into the neighbouring
+    convolutions) and the kernels they replace meet the SAME reference check: the B = 64 VaDE-TCN golden with the explicit
+    ReLU-flip attribution, run in a child process per switch (the switches are read once per process)."""
+    import json
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tcn_switch_probe.py")
+    env = dict(os.environ)
+    k, v = switch.split("=")
+    env[k] = v
+    out = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("PROBE ")][-1]
+    assert json.loads(line[6:])["ok"]
