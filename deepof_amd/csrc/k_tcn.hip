@@ -123,6 +123,9 @@ struct TcnConvArgs {
   float* tail_gres = nullptr;         // masked gradient = what enters block b's residual branch
   const float* tail_skip = nullptr;   // final skip-sum (mask of the last-step feature gradient)
   const float* tail_dfeat = nullptr;  // [32][Sp] gradient of the last-step features
+  // forward k_tcn_conv_t: 1 = the workgroup's channel statistics leave as mergeable (n | mean | M2) records,
+  // partial[workgroup][3][32] (see k_tcn_stat_merge), instead of plain / shifted sums
+  int stat_records = 0;
   int T, dil, accumulate;
   int64_t S, Sp;
 };
@@ -241,6 +244,45 @@ __global__ void __launch_bounds__(256) k_tcn_conv(TcnConvArgs A) {
 // ---------------------------------------------------------------------------------------------
 constexpr int TCT_T = 25;
 
+// Chan / Golub / LeVeque update of (n, mean, M2) by a second record; an empty record leaves the other unchanged
+__device__ __forceinline__ void dof_stat_merge(float& n, float& mean, float& m2, float nb, float mb, float qb) {
+  if (nb == 0.0f) return;
+  if (n == 0.0f) {
+    n = nb; mean = mb; m2 = qb;
+    return;
+  }
+  const float nt = n + nb, d = mb - mean;
+  mean = fmaf(d, nb / nt, mean);
+  m2 = m2 + qb + d * d * (n * nb / nt);
+  n = nt;
+}
+
+// workgroup records partial[nblk][3][32] -> sums = (n mean | M2) per channel, what k_bn_fwd_fin expects of the two-pass
+// statistics.  One workgroup per channel: 64 strided runs merged sequentially, then a fixed tree.
+__global__ void __launch_bounds__(64) k_tcn_stat_merge(const float* __restrict__ partial, int nblk, float* __restrict__ sums) {
+  __shared__ float rn[64], rm[64], rq[64];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+  for (int b = tid; b < nblk; b += 64) {
+    const float* p = partial + (int64_t)b * 3 * TC;
+    dof_stat_merge(n, mean, m2, p[c], p[TC + c], p[2 * TC + c]);
+  }
+  rn[tid] = n; rm[tid] = mean; rq[tid] = m2;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (tid < w) {
+      float a = rn[tid], b = rm[tid], q = rq[tid];
+      dof_stat_merge(a, b, q, rn[tid + w], rm[tid + w], rq[tid + w]);
+      rn[tid] = a; rm[tid] = b; rq[tid] = q;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    sums[c] = rn[0] * rm[0];
+    sums[TC + c] = rq[0];
+  }
+}
+
 __device__ __forceinline__ int tct_slot(int t, int sq, int chunk) { return (t * 16 + sq) * 8 + (chunk ^ ((sq >> 1) & 7)); }
 
 // TAIL (with REVERSE, FUSE_BN, BWD2; round 3): the convolution is conv1's data gradient of block b + 1, its result plus
@@ -284,6 +326,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     kshift[r] = (!REVERSE && A.stat_shift) ? A.stat_shift[ct * 16 + kk * 4 + r] : 0.0f;
   }
   float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float n_rows = 0.0f;  // stat_records: rows this lane has summed; its sums are taken about the first one
   const int T = A.T;
   const int64_t n_groups = A.Sp / 16;
   for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
@@ -445,6 +488,11 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
         }
         *reinterpret_cast<float4*>(A.out + off) = make_float4(v0[0], v0[1], v0[2], v0[3]);
         if (!REVERSE) {
+          if (A.stat_records && n_rows == 0.0f) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kshift[r] = v0[r];
+          }
+          n_rows += 1.0f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float dv = v0[r] - kshift[r];
@@ -458,7 +506,41 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
   }
   // channel sums of the workgroup: partial[workgroup][64] = (sum | second sum).  A wavefront covers one channel half
   // (ct) and one time parity; the two wavefronts of a half are added through LDS in a fixed order.
-  if ((!REVERSE || FUSE_BN) && A.partial) {
+  if (!REVERSE && A.partial && A.stat_records) {
+    // One-pass statistics without a reference value: every lane's sums are about ITS first output value (no cancellation
+    // beyond the spread of the data), turned into (n, mean, M2) and merged pairwise with Chan's update -- 16 lanes of a
+    // row, the two wavefronts of a channel half, then the workgroups (k_tcn_stat_merge) -- always in the same order.
+    float* rec = reinterpret_cast<float*>(tile);  // [wavefront][3][16]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float n = n_rows, mean = 0.0f, m2 = 0.0f;
+      if (n > 0.0f) {
+        const float d = s1[r] / n;
+        mean = kshift[r] + d;
+        m2 = fmaxf(s2[r] - s1[r] * d, 0.0f);
+      }
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        const float nb = __shfl_xor(n, m), mb = __shfl_xor(mean, m), qb = __shfl_xor(m2, m);
+        dof_stat_merge(n, mean, m2, nb, mb, qb);
+      }
+      if (i == 0) {
+        rec[(wv * 3 + 0) * 16 + kk * 4 + r] = n;
+        rec[(wv * 3 + 1) * 16 + kk * 4 + r] = mean;
+        rec[(wv * 3 + 2) * 16 + kk * 4 + r] = m2;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < TC) {  // channel c: wavefronts h and h + 2 hold its half
+      const int c = threadIdx.x, h = c >> 4, cl = c & 15;
+      float n = rec[(h * 3 + 0) * 16 + cl], mean = rec[(h * 3 + 1) * 16 + cl], m2 = rec[(h * 3 + 2) * 16 + cl];
+      dof_stat_merge(n, mean, m2, rec[((h + 2) * 3 + 0) * 16 + cl], rec[((h + 2) * 3 + 1) * 16 + cl], rec[((h + 2) * 3 + 2) * 16 + cl]);
+      float* out = A.partial + (int64_t)blockIdx.x * 3 * TC;
+      out[c] = n;
+      out[TC + c] = mean;
+      out[2 * TC + c] = m2;
+    }
+  } else if ((!REVERSE || FUSE_BN) && A.partial) {
     float* wsum = reinterpret_cast<float*>(tile);  // [wavefront][32]: (sum 16 | second sum 16) of its channel half
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1141,6 +1223,19 @@ int dof_tcn_onepass_stats() {
   return on;
 }
 int dof_tcn_conv32_resident(int T, int64_t Sp) { return tct_fits(T, Sp) ? 1 : 0; }
+// Mergeable one-pass statistics of the time-resident forward convolutions (default; DOF_TCN_STAT_RECORDS=0: sum pass +
+// centred second pass over the tensor)
+int dof_tcn_stat_records() {
+  static const int on = [] {
+    const char* e = getenv("DOF_TCN_STAT_RECORDS");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return on;
+}
+int dof_launch_tcn_stat_merge(const float* partial, int64_t nblk, float* sums, hipStream_t st) {
+  DOF_LAUNCH(k_tcn_stat_merge, (TC), (64), st, partial, (int)nblk, sums);
+  return dof_check_launch("k_tcn_stat_merge");
+}
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
   return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(Sp) : dof_tcn_conv_waves(T, Sp);
 }
@@ -1148,9 +1243,10 @@ int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
-                        const float* stat_shift, int bwd_store) {
+                        const float* stat_shift, int bwd_store, int stat_records) {
   TcnConvArgs A;
   A.bwd_store = bwd_store;
+  A.stat_records = (stat_records && !reverse && dof_tcn_conv32_resident(T, Sp)) ? 1 : 0;
   A.in = in; A.w = w; A.bias = bias; A.bnp_in = bnp_in; A.a_out = a_out; A.out = out; A.partial = partial;
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
@@ -1232,7 +1328,7 @@ int dof_tcn_combine_fold() {
 }
 int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp2, float* out_blk, const float* w,
                              const float* bias, float* out, float* partial, int T, int dil, int64_t S, int64_t Sp,
-                             hipStream_t st, const float* stat_shift) {
+                             hipStream_t st, const float* stat_shift, int stat_records) {
   if (!dof_tcn_conv32_resident(T, Sp)) {
     dof_set_error("k_tcn_conv_comb: needs the time-resident kernel (T <= %d)", TCT_T);
     return DOF_ERR_UNSUPPORTED;
@@ -1243,6 +1339,7 @@ int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.bwd_y = y2; A.bwd_bnp = nullptr; A.bwd_coef = nullptr;
   A.stat_shift = stat_shift;
+  A.stat_records = stat_records ? 1 : 0;
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
   DOF_LAUNCH((k_tcn_conv_t<false, false, false, false, false, true>), (tct_blocks(Sp)), (256), st, A);
   return dof_check_launch("k_tcn_conv_t_comb");

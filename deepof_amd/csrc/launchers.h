@@ -59,13 +59,16 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st, const float* bwd_y = nullptr, const float* bwd_bnp = nullptr,
-                        const float* bwd_coef = nullptr, const float* stat_shift = nullptr, int bwd_store = 1);
+                        const float* bwd_coef = nullptr, const float* stat_shift = nullptr, int bwd_store = 1,
+                        int stat_records = 0);
+int dof_tcn_stat_records();
+int dof_launch_tcn_stat_merge(const float* partial, int64_t nblk, float* sums, hipStream_t st);
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
                             int T, int CT, int64_t S, int64_t Sp, hipStream_t st, const float* shift = nullptr);
 int dof_tcn_combine_fold();
 int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp2, float* out_blk, const float* w,
                              const float* bias, float* out, float* partial, int T, int dil, int64_t S, int64_t Sp,
-                             hipStream_t st, const float* stat_shift);
+                             hipStream_t st, const float* stat_shift, int stat_records);
 int dof_tcn_tail_fold();
 int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
                              int bwd_store, const float* tail_src, const float* tail_out, float* tail_gres,

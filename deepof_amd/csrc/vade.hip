@@ -1322,6 +1322,8 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     }();
     auto sh_on = [&](int layer) { return sh && ((sh_mask >> (s * 16 + layer)) & 1ull); };
     const bool comb = dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_combine_fold() != 0;
+    // batch statistics of the time-resident convolutions as mergeable (n, mean, M2) records: no pass over the tensor
+    const bool recs = train && !sh && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_stat_records() != 0;
     for (int b = 0; b < 8; ++b) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
@@ -1335,22 +1337,25 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
         // last step of the skip-sum): out[b-1] = ReLU(ReLU(BN2(y2[b-1])) + out[b-2])
         TRY(dof_launch_tcn_conv_comb(ws + t.out[b - 2], ws + t.y2[b - 1], ws + t.bnp[2 * b - 1], ws + t.out[b - 1], params + o.c1w,
                                      params + o.c1b, ws + t.y1[b], ws + t.partial, T, d, w.S, w.Sp, st,
-                                     sh_on(2 * b) ? params + o.rm1 : nullptr));
+                                     sh_on(2 * b) ? params + o.rm1 : nullptr, recs));
         nrows = dof_tcn_conv32_partials(T, w.Sp);
       } else {
         TRY(dof_launch_tcn_conv(0, ws + t.out[b - 1], params + o.c1w, params + o.c1b, nullptr, nullptr, ws + t.y1[b],
-                                ws + t.partial, 0, T, d, w.S, w.Sp, st, nullptr, nullptr, nullptr, sh_on(2 * b) ? params + o.rm1 : nullptr));
+                                ws + t.partial, 0, T, d, w.S, w.Sp, st, nullptr, nullptr, nullptr, sh_on(2 * b) ? params + o.rm1 : nullptr,
+                                1, recs));
         nrows = dof_tcn_conv32_partials(T, w.Sp);
       }
       const float* sh1 = (sh_on(2 * b) && b > 0) ? params + o.rm1 : nullptr;
-      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh1));
+      if (train && recs && b > 0) TRY(dof_launch_tcn_stat_merge(ws + t.partial, nrows, ws + t.sums, st));
+      else if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh1));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
                                 train, ws + t.bnp[2 * b], 32, st, sh1 != nullptr));
       const float* sh2 = sh_on(2 * b + 1) ? params + o.rm2 : nullptr;
       TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b],
                               t.lazy ? nullptr : ws + t.a1[b], ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st,
-                              nullptr, nullptr, nullptr, sh2));
-      if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh2));
+                              nullptr, nullptr, nullptr, sh2, 1, recs));
+      if (train && recs) TRY(dof_launch_tcn_stat_merge(ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), ws + t.sums, st));
+      else if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh2));
       TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
                                 train, ws + t.bnp[2 * b + 1], 32, st, sh2 != nullptr));
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
