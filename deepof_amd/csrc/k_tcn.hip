@@ -258,18 +258,28 @@ __device__ __forceinline__ void dof_stat_merge(float& n, float& mean, float& m2,
 }
 
 // workgroup records partial[nblk][3][32] -> sums = (n mean | M2) per channel, what k_bn_fwd_fin expects of the two-pass
-// statistics.  One workgroup per channel: 64 strided runs merged sequentially, then a fixed tree.
-__global__ void __launch_bounds__(64) k_tcn_stat_merge(const float* __restrict__ partial, int nblk, float* __restrict__ sums) {
-  __shared__ float rn[64], rm[64], rq[64];
+// statistics.  One workgroup per channel: 256 strided runs merged sequentially (3 records each at 768 workgroups, all
+// loaded before the first merge), then a fixed tree.
+__global__ void __launch_bounds__(256) k_tcn_stat_merge(const float* __restrict__ partial, int nblk, float* __restrict__ sums) {
+  __shared__ float rn[256], rm[256], rq[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   float n = 0.0f, mean = 0.0f, m2 = 0.0f;
-  for (int b = tid; b < nblk; b += 64) {
-    const float* p = partial + (int64_t)b * 3 * TC;
-    dof_stat_merge(n, mean, m2, p[c], p[TC + c], p[2 * TC + c]);
+  for (int b0 = tid; b0 < nblk; b0 += 4 * 256) {
+    float pn[4], pm[4], pq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + u * 256;
+      const float* p = partial + (int64_t)(b < nblk ? b : 0) * 3 * TC;
+      pn[u] = b < nblk ? p[c] : 0.0f;
+      pm[u] = p[TC + c];
+      pq[u] = p[2 * TC + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dof_stat_merge(n, mean, m2, pn[u], pm[u], pq[u]);
   }
   rn[tid] = n; rm[tid] = mean; rq[tid] = m2;
   __syncthreads();
-  for (int w = 32; w > 0; w >>= 1) {
+  for (int w = 128; w > 0; w >>= 1) {
     if (tid < w) {
       float a = rn[tid], b = rm[tid], q = rq[tid];
       dof_stat_merge(a, b, q, rn[tid + w], rm[tid + w], rq[tid + w]);
@@ -1233,7 +1243,7 @@ int dof_tcn_stat_records() {
   return on;
 }
 int dof_launch_tcn_stat_merge(const float* partial, int64_t nblk, float* sums, hipStream_t st) {
-  DOF_LAUNCH(k_tcn_stat_merge, (TC), (64), st, partial, (int)nblk, sums);
+  DOF_LAUNCH(k_tcn_stat_merge, (TC), (256), st, partial, (int)nblk, sums);
   return dof_check_launch("k_tcn_stat_merge");
 }
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
