@@ -177,9 +177,10 @@ def vade_stepper_setup(ids, T, K, B, encoder_type, frames, dev, rank=0, use_grap
     return stepper, model, ds, starts, (tn, te), tau_star
 
 
-def run_vade_product(ids, T, K, B, encoder_type, steps, warmup, frames=100_000):
+def run_vade_product(ids, T, K, B, encoder_type, steps, warmup, frames=100_000, window_storage="fp32"):
     dev = torch.device("cuda")
     stepper, model, ds, starts, _tabs, _tau = vade_stepper_setup(ids, T, K, B, encoder_type, frames, dev)
+    ds.window_storage = window_storage   # "bf16": batches gathered as bf16 and widened for the fp32 step kernels
 
     def one_step(i):
         s0 = starts[i % len(starts)]
@@ -280,7 +281,9 @@ def secondary_configs(steps=12, warmup=6):
              lambda: run_contrastive_product(8192, 50, "TCN", max(4, steps // 3), 25), 8192),
             ("C2 shape, VaDE TCN encoder/decoder, batch 1024", lambda: run_vade_product([""], 25, 10, 1024, "TCN", steps, 25), 1024),
             ("C2 shape, VaDE transformer encoder/decoder (dropout on), batch 1024",
-             lambda: run_vade_product([""], 25, 10, 1024, "transformer", steps, warmup), 1024)]
+             lambda: run_vade_product([""], 25, 10, 1024, "transformer", steps, warmup), 1024),
+            ("C2 with bf16 window storage (BASELINE configs[1]: batches gathered as bf16, fp32 arithmetic), batch 1024",
+             lambda: run_vade_product([""], 25, 10, 1024, "recurrent", 4 * steps, warmup, window_storage="bf16"), 1024)]
     for name, fn, B in plan:
         try:
             sec, loss, path = fn()
@@ -486,6 +489,32 @@ def main():
                            "bytes_per_window": bytes_per_window, "windows_per_launch": win_per_animal,
                            "avg_launch_ms": sec_per_launch * 1e3}
         del xg, ag
+        # the same launch writing bf16 (BASELINE configs[1] names bf16; SURVEY 8(d): 3,024 B per C2 window)
+        xg16 = torch.empty(nw, T, N, 3, device=dev, dtype=torch.bfloat16)
+        ag16 = torch.empty(nw, T, E, 1, device=dev, dtype=torch.bfloat16)
+
+        def gather_all16():
+            for i in range(n_animals):
+                lo = i * win_per_animal
+                _capi.check(lib, lib.dof_window_gather_bf16(tn.data_ptr(), te.data_ptr(), None, i * F, 1, win_per_animal, T, N, E,
+                                                            xg16[lo:].data_ptr(), ag16[lo:].data_ptr(), stream()))
+
+        gather_all16()
+        gather_all16()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(args.gather_iters):
+            gather_all16()
+        ev1.record()
+        torch.cuda.synchronize()
+        sec16 = ev0.elapsed_time(ev1) * 1e-3 / launches
+        bpw16 = T * (3 * N + E) * 2 + (3 * N + E) * 4
+        out["roofline_bf16_storage"] = {"kernel": "k_window_gather<.., OUT16>", "bound": "hbm",
+                                        "achieved": win_per_animal * bpw16 / sec16 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": win_per_animal * bpw16 / sec16 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                        "bytes_per_window": bpw16, "windows_per_launch": win_per_animal,
+                                        "avg_launch_ms": sec16 * 1e3, "windows_per_s": win_per_animal / sec16}
+        del xg16, ag16
         if not args.no_cpu_baseline and world == 1:
             xb, ab = ds.fetch(starts[0], starts[0] + B)   # the first batch the device path trained on
             out["cpu_baseline"] = cpu_baseline(initial_state, xb.cpu(), ab.cpu(), L, K)

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -88,6 +88,8 @@ SIGNATURES = {
     "dof_abi_version": (C.c_int, []),
     "dof_window_gather": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "dof_window_gather_range": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "dof_window_gather_bf16": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "dof_widen_bf16": (C.c_int, [_P, _P, _I64, _P]),
     "dof_vade_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vade_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vqvae_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),

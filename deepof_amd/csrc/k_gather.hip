@@ -28,6 +28,45 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float rcp_l
   return q;
 }
 
+// float -> bf16 bits, round to nearest even (finite inputs)
+__device__ __forceinline__ uint32_t bf16_rne(float v) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// One 16-byte streaming store of EPV consecutive output elements starting at element e0 (EPV = 4 fp32 or 8 bf16), or the
+// tail elements one by one
+template <bool OUT16>
+__device__ __forceinline__ void store_run(void* __restrict__ out_base, unsigned e0, unsigned total, const float* v) {
+  constexpr int EPV = OUT16 ? 8 : 4;
+  if (e0 + EPV - 1 < total) {
+    if constexpr (OUT16) {
+      uint16_t* out = reinterpret_cast<uint16_t*>(out_base) + e0;
+#ifdef DOF_EMU
+      for (int j = 0; j < 8; ++j) out[j] = (uint16_t)bf16_rne(v[j]);
+#else
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 pack = {bf16_rne(v[0]) | (bf16_rne(v[1]) << 16), bf16_rne(v[2]) | (bf16_rne(v[3]) << 16),
+                    bf16_rne(v[4]) | (bf16_rne(v[5]) << 16), bf16_rne(v[6]) | (bf16_rne(v[7]) << 16)};
+      __builtin_nontemporal_store(pack, reinterpret_cast<u32x4*>(out));
+#endif
+    } else {
+      float* out = reinterpret_cast<float*>(out_base) + e0;
+#ifdef DOF_EMU
+      out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+#else
+      dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
+      __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out));
+#endif
+    }
+  } else {
+    for (int j = 0; j < EPV; ++j)
+      if (e0 + j < total) {
+        if constexpr (OUT16) reinterpret_cast<uint16_t*>(out_base)[e0 + j] = (uint16_t)bf16_rne(v[j]);
+        else reinterpret_cast<float*>(out_base)[e0 + j] = v[j];
+      }
+  }
+}
+
 // Mapping: one workgroup = WB consecutive windows (a 16-byte aligned, 4*WB*W*(3N+E)-byte output
 // run), one thread = one 16-byte streaming store at a time.  All per-element index arithmetic is
 // 32-bit with reciprocal multiplies (the first version spent its time in 64-bit integer division
@@ -39,11 +78,15 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float rcp_l
 // 16-byte store costs four table lookups + four LDS reads instead of four strided global gathers (the
 // gathers kept the kernel on the texture-address path: 56 % of HBM peak; a pure fill reaches 6.2 TB/s here).
 // Workgroups whose windows are too far apart for the staging buffer take the direct path (STAGE == 0 code).
-template <bool INDEXED, int STAGE, int TAB, int WB>
+// OUT16: the batch leaves as bf16 (the storage format of BASELINE's bf16 configuration: W*(3N+E)*2 bytes written per
+// window), eight elements per 16-byte store.
+template <bool INDEXED, int STAGE, int TAB, int WB, bool OUT16 = false>
 __global__ void __launch_bounds__(256) k_window_gather(
     const float* __restrict__ node_table, const float* __restrict__ edge_table,
     const int64_t* __restrict__ row_start, int64_t first_row, int64_t row_step, int64_t n_windows,
-    int W, int N, int E, float rcp_perwin, float rcp_cols, float* __restrict__ x_out, float* __restrict__ a_out) {
+    int W, int N, int E, float rcp_perwin, float rcp_cols, void* __restrict__ x_out, void* __restrict__ a_out) {
+  constexpr int EPV = OUT16 ? 8 : 4;   // elements per 16-byte store
+  constexpr int OSZ = OUT16 ? 2 : 4;   // bytes per output element
   __shared__ int64_t row0[WB];
   __shared__ int lrow[WB];
   __shared__ int64_t span[2];
@@ -87,17 +130,17 @@ __global__ void __launch_bounds__(256) k_window_gather(
       __syncthreads();
       // ---- nodes: (window, element) of a thread's next store advance incrementally (1024 floats per pass)
       {
-        float* __restrict__ out = x_out + w0 * per_x;
+        char* __restrict__ out = reinterpret_cast<char*>(x_out) + w0 * per_x * OSZ;
         const unsigned total = (unsigned)nwin * per_x;
-        unsigned e0 = 4 * threadIdx.x;
+        unsigned e0 = EPV * threadIdx.x;
         unsigned w = fast_div(e0, per_x, rcp_perwin);
         unsigned o = e0 - w * per_x;
-        for (; e0 < total; e0 += 4 * 256) {
-          float v[4];
+        for (; e0 < total; e0 += EPV * 256) {
+          float v[EPV];
           unsigned wj = w < (unsigned)nwin ? w : (unsigned)nwin - 1, oj = o;
           int base = lrow[wj] * C;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < EPV; ++j) {
             v[j] = stage[base + tab[oj]];
             if (++oj == per_x) {
               oj = 0;
@@ -105,18 +148,8 @@ __global__ void __launch_bounds__(256) k_window_gather(
               base = lrow[wj] * C;
             }
           }
-          if (e0 + 3 < total) {
-#ifdef DOF_EMU
-            out[e0] = v[0]; out[e0 + 1] = v[1]; out[e0 + 2] = v[2]; out[e0 + 3] = v[3];
-#else
-            dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
-            __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + e0));
-#endif
-          } else {
-            for (int j = 0; j < 4; ++j)
-              if (e0 + j < total) out[e0 + j] = v[j];
-          }
-          o += 4 * 256;
+          store_run<OUT16>(out, e0, total, v);
+          o += EPV * 256;
           while (o >= per_x) {
             o -= per_x;
             ++w;
@@ -125,17 +158,17 @@ __global__ void __launch_bounds__(256) k_window_gather(
       }
       // ---- edges: a window is W*E contiguous staged floats
       {
-        float* __restrict__ out = a_out + w0 * per_a;
+        char* __restrict__ out = reinterpret_cast<char*>(a_out) + w0 * per_a * OSZ;
         const float* __restrict__ se = stage + nnode;
         const unsigned total = (unsigned)nwin * per_a;
         const float rcp_pa = rcp_perwin * ((float)C / (float)E) * 0.999999f;
-        for (unsigned e0 = 4 * threadIdx.x; e0 < total; e0 += 4 * 256) {
-          float v[4];
+        for (unsigned e0 = EPV * threadIdx.x; e0 < total; e0 += EPV * 256) {
+          float v[EPV];
           unsigned w = fast_div(e0, per_a, rcp_pa);
           unsigned o = e0 - w * per_a;
           int base = lrow[w] * E;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < EPV; ++j) {
             v[j] = se[base + o];
             if (++o == per_a) {
               o = 0;
@@ -143,17 +176,7 @@ __global__ void __launch_bounds__(256) k_window_gather(
               base = lrow[w] * E;
             }
           }
-          if (e0 + 3 < total) {
-#ifdef DOF_EMU
-            out[e0] = v[0]; out[e0 + 1] = v[1]; out[e0 + 2] = v[2]; out[e0 + 3] = v[3];
-#else
-            dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
-            __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + e0));
-#endif
-          } else {
-            for (int j = 0; j < 4; ++j)
-              if (e0 + j < total) out[e0 + j] = v[j];
-          }
+          store_run<OUT16>(out, e0, total, v);
         }
       }
       return;
@@ -162,10 +185,10 @@ __global__ void __launch_bounds__(256) k_window_gather(
   // ---- direct path (windows of this workgroup too far apart to stage)
   // ---- nodes: (rows, [x..|y..|s..]) -> (W, N, 3)
   {
-    float* __restrict__ out = x_out + w0 * per_x;
+    char* __restrict__ out = reinterpret_cast<char*>(x_out) + w0 * per_x * OSZ;
     const unsigned total = (unsigned)nwin * per_x;
-    for (unsigned e0 = 4 * threadIdx.x; e0 < total; e0 += 4 * 256) {
-      float v[4];
+    for (unsigned e0 = EPV * threadIdx.x; e0 < total; e0 += EPV * 256) {
+      float v[EPV];
       unsigned w = fast_div(e0, per_x, rcp_perwin);
       unsigned o = e0 - w * per_x;
       unsigned t = fast_div(o, (unsigned)C, rcp_cols);
@@ -173,50 +196,30 @@ __global__ void __launch_bounds__(256) k_window_gather(
       unsigned n = (r * 43691u) >> 17;  // r / 3 for r < 2^16
       unsigned f = r - 3 * n;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < EPV; ++j) {
         v[j] = (e0 + j < total) ? node_table[(row0[w] + t) * C + f * N + n] : 0.0f;
         if (++f == 3) { f = 0; ++n; }
         if (++r == (unsigned)C) { r = 0; n = 0; f = 0; ++t; }
         if (++o == per_x) { o = 0; t = 0; ++w; if (w >= (unsigned)nwin) w = nwin - 1; }
       }
-      if (e0 + 3 < total) {
-#ifdef DOF_EMU
-        out[e0] = v[0]; out[e0 + 1] = v[1]; out[e0 + 2] = v[2]; out[e0 + 3] = v[3];
-#else
-        dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
-        __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + e0));
-#endif
-      } else {
-        for (int j = 0; j < 4; ++j)
-          if (e0 + j < total) out[e0 + j] = v[j];
-      }
+      store_run<OUT16>(out, e0, total, v);
     }
   }
   // ---- edges: a window is W*E contiguous source floats
   {
-    float* __restrict__ out = a_out + w0 * per_a;
+    char* __restrict__ out = reinterpret_cast<char*>(a_out) + w0 * per_a * OSZ;
     const unsigned total = (unsigned)nwin * per_a;
     const float rcp_pa = rcp_perwin * ((float)C / (float)E) * 0.999999f;
-    for (unsigned e0 = 4 * threadIdx.x; e0 < total; e0 += 4 * 256) {
-      float v[4];
+    for (unsigned e0 = EPV * threadIdx.x; e0 < total; e0 += EPV * 256) {
+      float v[EPV];
       unsigned w = fast_div(e0, per_a, rcp_pa);
       unsigned o = e0 - w * per_a;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < EPV; ++j) {
         v[j] = (e0 + j < total) ? edge_table[row0[w] * E + o] : 0.0f;
         if (++o == per_a) { o = 0; ++w; if (w >= (unsigned)nwin) w = nwin - 1; }
       }
-      if (e0 + 3 < total) {
-#ifdef DOF_EMU
-        out[e0] = v[0]; out[e0 + 1] = v[1]; out[e0 + 2] = v[2]; out[e0 + 3] = v[3];
-#else
-        dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
-        __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out + e0));
-#endif
-      } else {
-        for (int j = 0; j < 4; ++j)
-          if (e0 + j < total) out[e0 + j] = v[j];
-      }
+      store_run<OUT16>(out, e0, total, v);
     }
   }
 }
@@ -229,14 +232,18 @@ float rcp_down(unsigned d) {
 }
 
 int launch_gather(const float* node_table, const float* edge_table, const int64_t* row_start, int64_t first_row,
-                  int64_t row_step, int64_t n_windows, int W, int N, int E, float* x_out, float* a_out,
-                  hipStream_t stream) {
+                  int64_t row_step, int64_t n_windows, int W, int N, int E, void* x_out, void* a_out,
+                  hipStream_t stream, bool out16 = false) {
   if (!node_table || !edge_table || !x_out || !a_out || n_windows < 0 || W <= 0 || N <= 0 || E <= 0) {
     dof_set_error("dof_window_gather: bad argument");
     return DOF_ERR_ARG;
   }
   if ((int64_t)WB * W * 3 * N >= (1 << 24) || (int64_t)WB * W * E >= (1 << 24)) {
     dof_set_error("dof_window_gather: window too large (W*3N*16 must stay below 2^24)");
+    return DOF_ERR_UNSUPPORTED;
+  }
+  if (out16 && ((W * 3 * N) % 2 != 0 || (W * E) % 2 != 0)) {
+    dof_set_error("dof_window_gather_bf16: W*3N and W*E must be even (16-byte aligned bf16 runs)");
     return DOF_ERR_UNSUPPORTED;
   }
   if (n_windows == 0) return DOF_OK;
@@ -247,9 +254,15 @@ int launch_gather(const float* node_table, const float* edge_table, const int64_
   const float rp = rcp_down((unsigned)(W * 3 * N)), rc = rcp_down((unsigned)(3 * N));
   // staging-buffer class by the footprint of wb stride-1 windows (other spacings decide per workgroup)
   const int64_t need = (int64_t)(wb - 1 + W) * (3 * N + E), tabn = (int64_t)W * 3 * N;
-#define GATHER1(IDX, ST, TB, WBV)                                                                                     \
-  DOF_LAUNCH((k_window_gather<IDX, ST, TB, WBV>), (blocks), (256), stream, node_table, edge_table, row_start, first_row, \
-             row_step, n_windows, W, N, E, rp, rc, x_out, a_out)
+#define GATHER1(IDX, ST, TB, WBV)                                                                                        \
+  do {                                                                                                                   \
+    if (out16)                                                                                                           \
+      DOF_LAUNCH((k_window_gather<IDX, ST, TB, WBV, true>), (blocks), (256), stream, node_table, edge_table, row_start,  \
+                 first_row, row_step, n_windows, W, N, E, rp, rc, x_out, a_out);                                         \
+    else                                                                                                                 \
+      DOF_LAUNCH((k_window_gather<IDX, ST, TB, WBV, false>), (blocks), (256), stream, node_table, edge_table, row_start, \
+                 first_row, row_step, n_windows, W, N, E, rp, rc, x_out, a_out);                                         \
+  } while (0)
 #define GATHER(IDX, ST, TB)                                            \
   do {                                                                 \
     if (small) GATHER1(IDX, ST, TB, WB_SMALL); else GATHER1(IDX, ST, TB, WB); \
@@ -284,4 +297,41 @@ extern "C" int dof_window_gather_range(const float* node_table, const float* edg
                                        int32_t n_edges, float* x_out, float* a_out, void* stream) {
   return launch_gather(node_table, edge_table, nullptr, first_row, row_step, n_windows, window, n_nodes, n_edges, x_out,
                        a_out, (hipStream_t)stream);
+}
+
+extern "C" int dof_window_gather_bf16(const float* node_table, const float* edge_table, const int64_t* row_start,
+                                      int64_t first_row, int64_t row_step, int64_t n_windows, int32_t window, int32_t n_nodes,
+                                      int32_t n_edges, uint16_t* x_out, uint16_t* a_out, void* stream) {
+  return launch_gather(node_table, edge_table, row_start, first_row, row_step, n_windows, window, n_nodes, n_edges, x_out, a_out,
+                       (hipStream_t)stream, true);
+}
+
+namespace {
+// bf16 -> fp32 (exact): the train step's fp32 kernels read a widened copy of a bf16-stored batch (2 + 4 bytes per element,
+// 8.6 MB for a C2 batch: the batches cross HBM between the gather and the step at half the bytes)
+__global__ void __launch_bounds__(256) k_widen_bf16(const uint16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const uint64_t p = *reinterpret_cast<const uint64_t*>(in + i);
+    const uint32_t lo = (uint32_t)p, hi = (uint32_t)(p >> 32);
+    float4 v;
+    v.x = __builtin_bit_cast(float, lo << 16);
+    v.y = __builtin_bit_cast(float, lo & 0xFFFF0000u);
+    v.z = __builtin_bit_cast(float, hi << 16);
+    v.w = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    *reinterpret_cast<float4*>(out + i) = v;
+  } else {
+    for (int64_t k = i; k < n; ++k) out[k] = __builtin_bit_cast(float, (uint32_t)in[k] << 16);
+  }
+}
+}  // namespace
+
+extern "C" int dof_widen_bf16(const uint16_t* in, float* out, int64_t n, void* stream) {
+  if (!in || !out || n < 0) {
+    dof_set_error("dof_widen_bf16: bad argument");
+    return DOF_ERR_ARG;
+  }
+  if (n == 0) return DOF_OK;
+  DOF_LAUNCH(k_widen_bf16, (dof_cdiv(dof_cdiv(n, 4), 256)), (256), (hipStream_t)stream, in, out, n);
+  return dof_check_launch("k_widen_bf16");
 }

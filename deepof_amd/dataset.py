@@ -289,9 +289,47 @@ class WindowDataset:
         assert tuple(x.shape) == (b, W, N, 3) and tuple(a.shape) == (b, W, E, 1) and x.is_contiguous() and a.is_contiguous()
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
         rows = self.row_start[s:e]  # a slice of the contiguous start-row list: no copy
+        if getattr(self, "window_storage", "fp32") == "bf16":
+            # BASELINE's bf16 configuration: the batch is STORED as bf16 (half the bytes written by the gather and read
+            # back by the step); the step's fp32 kernels read an exactly widened copy.  Values = the fp32 batch rounded
+            # to nearest-even bf16.
+            xb, ab = self.fetch_bf16(s, e, self._bf16_scratch(b))
+            _capi.check(self._lib, self._lib.dof_widen_bf16(xb.data_ptr(), x.data_ptr(), xb.numel(), stream), "dof_widen_bf16")
+            _capi.check(self._lib, self._lib.dof_widen_bf16(ab.data_ptr(), a.data_ptr(), ab.numel(), stream), "dof_widen_bf16")
+            return x, a
         _capi.check(self._lib, self._lib.dof_window_gather(self.node_table.data_ptr(), self.edge_table.data_ptr(),
                                                            rows.data_ptr(), b, W, N, E, x.data_ptr(), a.data_ptr(),
                                                            stream), "dof_window_gather")
+        return x, a
+
+    def _bf16_scratch(self, b: int):
+        cache = self.__dict__.setdefault("_bf16_buffers", {})
+        if b not in cache:
+            W, N, _ = self.x_shape
+            E = self.a_shape[1]
+            cache[b] = (torch.empty(b, W, N, 3, dtype=torch.bfloat16, device=self.device),
+                        torch.empty(b, W, E, 1, dtype=torch.bfloat16, device=self.device))
+        return cache[b]
+
+    def fetch_bf16(self, s: int, e: int, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Windows [s, e) as bf16 tensors x (b,W,N,3), a (b,W,E,1) written by the gather itself (``dof_window_gather_bf16``:
+        3,024 instead of 5,824 bytes per C2 window).  Frame-table datasets only."""
+        if self.x is not None:
+            raise ValueError("fetch_bf16 needs a frame-table dataset (from_tables / from_preprocessed / from_device_tables)")
+        W, N, _ = self.x_shape
+        E = self.a_shape[1]
+        b = e - s
+        if out is None:
+            out = (torch.empty(b, W, N, 3, dtype=torch.bfloat16, device=self.device),
+                   torch.empty(b, W, E, 1, dtype=torch.bfloat16, device=self.device))
+        x, a = out
+        assert x.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and tuple(x.shape) == (b, W, N, 3)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        rows = self.row_start[s:e]
+        _capi.check(self._lib, self._lib.dof_window_gather_bf16(self.node_table.data_ptr(), self.edge_table.data_ptr(),
+                                                                rows.data_ptr(), 0, 0, b, W, N, E, x.data_ptr(), a.data_ptr(),
+                                                                stream), "dof_window_gather_bf16")
         return x, a
 
     def iter_ranges(self, batch_size: int, shuffle: bool, seed: Optional[int], world_size: int = 1, rank: int = 0,

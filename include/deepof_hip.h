@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 13
+#define DOF_ABI_VERSION 14
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -57,6 +57,14 @@ int dof_window_gather(const float* node_table, const float* edge_table, const in
 int dof_window_gather_range(const float* node_table, const float* edge_table, int64_t first_row, int64_t row_step,
                             int64_t n_windows, int32_t window, int32_t n_nodes, int32_t n_edges, float* x_out,
                             float* a_out, void* stream);
+/* bf16 storage of the window batches (BASELINE.json configs[1] "bf16"; SURVEY 8(d): W*(3N+E)*2 bytes written per
+ * window): the same gather writing round-to-nearest-even bf16, eight elements per 16-byte store.  row_start != NULL:
+ * the listed start rows (first_row / row_step ignored), NULL: first_row + k * row_step.  W*3N and W*E must be even.
+ * dof_widen_bf16 turns a stored batch back into the fp32 tensors the step kernels read (exact). */
+int dof_window_gather_bf16(const float* node_table, const float* edge_table, const int64_t* row_start, int64_t first_row,
+                           int64_t row_step, int64_t n_windows, int32_t window, int32_t n_nodes, int32_t n_edges,
+                           uint16_t* x_out, uint16_t* a_out, void* stream);
+int dof_widen_bf16(const uint16_t* in, float* out, int64_t n, void* stream);
 
 /* ---- VaDE (recurrent encoder/decoder) ------------------------------------------------------ */
 typedef struct DofVadeDims {

@@ -184,7 +184,7 @@ def _tcn_vade_model(d, T, N, E, L, K):
     return model, sd0
 
 
-def vade_tcn_kinks(out, fname, tagp):
+def vade_tcn_kinks(out, fname, tagp, phases=("pre", "mainT")):
     d = dict(np.load(os.path.join(HERE, fname)))
     x, a = d["x"], d["a"]
     B, T, N, _ = x.shape
@@ -194,6 +194,9 @@ def vade_tcn_kinks(out, fname, tagp):
     xt, at = torch.from_numpy(x), torch.from_numpy(a)
     eps, eps_mc, tau = (torch.from_numpy(d[k]) for k in ("eps", "eps_mc", "tau"))
     for phase, klw, teacher in (("pre", 0.13, False), ("mainT", 0.7, True)):
+        if phase not in phases:
+            continue
+
         def rerun():
             model.load_state_dict(sd0)
             _vade_run(model, xt, at, eps, eps_mc, tau, phase, klw, teacher, K, L)
@@ -352,20 +355,25 @@ if __name__ == "__main__":
     #   python make_golden_r03.py vadekinks:vade_tcn14_b64 & python make_golden_r03.py vadekinks:vade_tcn14_onepass ; ... mergekinks
     for w in what:
         if w.startswith("vadekinks:"):
-            tag = w.split(":", 1)[1]
+            tag, *ph = w.split(":")[1:]      # vadekinks:<fixture>[:<phase>] -- one part file per (fixture, phase)
             KINK_DELTA = 3e-5
-            part = {}
-            vade_tcn_kinks(part, tag + ".npz", tag)
-            part[tag + "::delta"] = np.float64(KINK_DELTA)
-            np.savez_compressed(os.path.join(HERE, f"_kinks_{tag}.npz"), **part)
+            for phase in (ph or ["pre", "mainT"]):
+                f = os.path.join(HERE, f"_kinks_{tag}_{phase}.npz")
+                if os.path.exists(f):
+                    continue
+                part = {}
+                vade_tcn_kinks(part, tag + ".npz", tag, phases=(phase,))
+                part[tag + "::delta"] = np.float64(KINK_DELTA)
+                np.savez_compressed(f, **part)
     if "mergekinks" in what:
         keep = dict(np.load(os.path.join(HERE, "tcn_kinks.npz")).items())
         for tag in ("vade_tcn14_b64", "vade_tcn14_onepass"):
-            f = os.path.join(HERE, f"_kinks_{tag}.npz")
-            if os.path.exists(f):
-                keep = {k: v for k, v in keep.items() if not k.startswith(tag + "::")}
-                keep.update(np.load(f).items())
-                os.remove(f)
+            for phase in ("pre", "mainT"):
+                f = os.path.join(HERE, f"_kinks_{tag}_{phase}.npz")
+                if os.path.exists(f):
+                    keep = {k: v for k, v in keep.items() if not k.startswith(f"{tag}::{phase}::")}
+                    keep.update(np.load(f).items())
+                    os.remove(f)
         np.savez_compressed(os.path.join(HERE, "tcn_kinks.npz"), **keep)
     if "tcn" in what:
         torch.set_num_threads(1)

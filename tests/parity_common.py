@@ -66,6 +66,29 @@ def gather_check(lib, device):
         xr, ar = OW.gather_windows(nodes, edges, np.arange(nw) * 2, W)
         np.testing.assert_array_equal(x2.cpu().numpy(), xr)
         np.testing.assert_array_equal(a2.cpu().numpy(), ar)
+        # bf16 storage (BASELINE configs[1]): the same windows rounded to nearest-even bf16 by the gather itself, bit for bit;
+        # widened back exactly.  (W*3N and W*E must be even: 16-byte aligned runs.)
+        if (W * 3 * N) % 2 == 0 and (W * E) % 2 == 0:
+            xb = torch.zeros((len(starts), W, N, 3), dtype=torch.bfloat16, device=device)
+            ab = torch.zeros((len(starts), W, E, 1), dtype=torch.bfloat16, device=device)
+            _capi.check(lib, lib.dof_window_gather_bf16(tn.data_ptr(), te.data_ptr(), st.data_ptr(), 0, 0, len(starts), W, N, E,
+                                                        xb.data_ptr(), ab.data_ptr(), stream))
+            want_x, want_a = torch.from_numpy(x_ref).to(torch.bfloat16), torch.from_numpy(a_ref).to(torch.bfloat16)
+            assert torch.equal(xb.cpu().view(torch.int16), want_x.view(torch.int16))
+            assert torch.equal(ab.cpu().view(torch.int16), want_a.view(torch.int16))
+            xb2 = torch.zeros((nw, W, N, 3), dtype=torch.bfloat16, device=device)
+            ab2 = torch.zeros((nw, W, E, 1), dtype=torch.bfloat16, device=device)
+            _capi.check(lib, lib.dof_window_gather_bf16(tn.data_ptr(), te.data_ptr(), None, 0, 2, nw, W, N, E,
+                                                        xb2.data_ptr(), ab2.data_ptr(), stream))
+            assert torch.equal(xb2.cpu().view(torch.int16), torch.from_numpy(xr).to(torch.bfloat16).view(torch.int16))
+            assert torch.equal(ab2.cpu().view(torch.int16), torch.from_numpy(ar).to(torch.bfloat16).view(torch.int16))
+            wide = torch.full((len(starts), W, N, 3), float("nan"), device=device)
+            _capi.check(lib, lib.dof_widen_bf16(xb.data_ptr(), wide.data_ptr(), xb.numel(), stream))
+            assert torch.equal(wide.cpu(), want_x.float())
+        else:
+            xb = torch.zeros((len(starts), W, N, 3), dtype=torch.bfloat16, device=device)
+            assert lib.dof_window_gather_bf16(tn.data_ptr(), te.data_ptr(), st.data_ptr(), 0, 0, len(starts), W, N, E,
+                                              xb.data_ptr(), xb.data_ptr(), stream) != 0
 
 
 def run_phase_check(lib, device, golden_dir, tag, phase, atol_g=5e-5, rtol_g=5e-4):

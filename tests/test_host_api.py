@@ -829,6 +829,24 @@ def test_preprocess_host_api_emu(golden_dir):
         preprocess_tables(tabs, cols, aids, node_cols, edge_cols, dist_standardize="columnwise", device="cpu", lib=lib)
 
 
+def test_bf16_window_storage_emu():
+    """BASELINE configs[1] "bf16": a frame-table dataset with window_storage = "bf16" serves batches that were gathered as bf16
+    (dof_window_gather_bf16) and widened back -- the fp32 batch rounded to nearest-even bf16, exactly."""
+    lib = emu_lib()
+    rng = np.random.default_rng(3)
+    nodes, edges = rng.standard_normal((70, 3 * 6)).astype(np.float32), rng.standard_normal((70, 5)).astype(np.float32)
+    ds = WindowDataset.from_tables({"v": (nodes, edges)}, 12, 2, "cpu", lib)
+    x32, a32 = ds.fetch(3, 19)
+    xb, ab = ds.fetch_bf16(3, 19)
+    assert xb.dtype == torch.bfloat16 and torch.equal(xb, x32.to(torch.bfloat16)) and torch.equal(ab, a32.to(torch.bfloat16))
+    ds.window_storage = "bf16"
+    x, a = ds.fetch(3, 19)
+    assert x.dtype == torch.float32 and torch.equal(x, x32.to(torch.bfloat16).float()) and torch.equal(a, a32.to(torch.bfloat16).float())
+    out = (torch.empty_like(x32), torch.empty_like(a32))
+    ds.fetch(3, 19, out)
+    assert torch.equal(out[0], x)
+
+
 def _pp_shard_worker(rank, world, port, tmp):
     import torch.distributed as dist
     import parity_common as PC
