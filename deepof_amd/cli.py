@@ -96,7 +96,10 @@ def main(argv=None):
     if args.input_type != "graph":
         raise NotImplementedError("input_type='coords' (use_gnn=False) is not built: the trainer always runs the graph models")
     if args.hyperparameter_tuning:
-        raise NotImplementedError("hyperparameter tuning (optuna) is outside this build's scope")
+        # the reference's own branch calls deepof.model_utils.tune_search, a module its tree no longer has
+        # (deepof_train_embeddings.py:429); the per-epoch trial hooks it would use are in training.fit_* (trial=...)
+        raise NotImplementedError("the tuning driver is not part of this build (the reference's calls a module it no longer ships); "
+                                  "pass an optuna trial to deepof_amd.training.fit_VADE / fit_VQVAE / fit_contrastive instead")
     unused = {k: getattr(args, k) for k in ("arena_dims", "smooth_alpha", "exclude_bodyparts", "automatic_changepoints",
                                              "load_project", "exp_condition_path", "animal_to_preprocess", "hyperparameters")}
     print("ETL-side options accepted but not used here:", unused)

@@ -552,8 +552,29 @@ def initialize_gmm_from_data(model: VaDE, dataset: WindowDataset, batch_size: in
     model.latent_space.gmm_log_vars.copy_(torch.from_numpy(np.log(gmm.covariances_)).float())
 
 
+class TrialPruned(Exception):
+    """Raised when a tuning trial asks to stop (optuna.TrialPruned when optuna is importable, so that a study catches it)."""
+
+
+try:   # the hooks are duck-typed (trial.report / trial.should_prune); optuna itself is optional
+    import optuna as _optuna
+    TrialPruned = _optuna.TrialPruned   # noqa: F811
+except Exception:   # noqa: BLE001
+    pass
+
+
+def _report_trial(trial, score_value: float, epoch: int) -> float:
+    """The reference's tuning hook at the end of an epoch (training.py:1224-1228, 1420-1424, 1853-1857): report the
+    epoch's alignment score, stop when the pruner says so.  Returns the reported value (the fit's ``max_score``)."""
+    if trial is not None:
+        trial.report(score_value, step=epoch)
+        if trial.should_prune():
+            raise TrialPruned(f"Pruned at epoch={epoch}, best_score={score_value:.4f}")
+    return score_value
+
+
 def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
-             teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, device=None, _engine_factory=None, shuffle: bool = True):
+             teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, device=None, _engine_factory=None, shuffle: bool = True, trial=None):
     """training.py:1522-1918 (pretrain -> GMM init -> main epochs with best-val / best-score selection)."""
     dist, rank, world = _dist_state()
     is_main = rank == 0
@@ -644,6 +665,7 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
         dist.broadcast(eng.prior, src=0)
 
     selector = CheckpointSelector(common_cfg.epochs, rising_start=True)
+    max_score = 0.0
     for epoch in range(common_cfg.epochs):
         if epoch == 0 and vade_cfg.freeze_gmm_epochs > 0:
             eng.set_active(_capi.SEG_GMM, False)
@@ -699,6 +721,7 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
                   f"train total={train_logs['total_loss']:.4f} recon={train_logs['reconstruct_loss']:.4f} | "
                   f"val total={val_total:.4f} | align score={score_value:.3f}")
         improved_val, save_score = selector.update(epoch, val_total, score_value)
+        max_score = _report_trial(trial, score_value, epoch)
         common_info = dict(common_cfg=common_cfg, teacher_cfg=teacher_cfg, vade_cfg=vade_cfg, model=model,
                            log_summary=log_summary, rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
         if improved_val:
@@ -710,6 +733,8 @@ def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: n
                 save_model_info(best_path_score, stage="best_score", epoch=epoch, train_steps=(epoch + 1) * nb,
                                 val_total=val_total, score_value=score_value, **common_info)
     model_val, model_score = load_best_checkpoints(model, best_path_val, best_path_score, common_cfg.save_weights)
+    if trial is not None:   # tuning mode: the last epoch's score rides along (training.py:1914-1915)
+        return model_val, model_score, teacher_init_model, log_summary, max_score
     return model_val, model_score, teacher_init_model, log_summary
 
 
@@ -763,7 +788,7 @@ class VQVAEStepper:
 
 
 def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
-              teacher_cfg: TurtleTeacherCfg, device=None, _engine_factory=None, shuffle: bool = True):
+              teacher_cfg: TurtleTeacherCfg, device=None, _engine_factory=None, shuffle: bool = True, trial=None):
     """training.py:1036-1263: Adam(lr, weight_decay 1e-4) on encoder + decoder + codebook (+ the distillation head
     when the TURTLE teacher is on), clip 0.75; best-val / best-score (alignment of the head with tau*) checkpoints."""
     dist, rank, world = _dist_state()
@@ -791,6 +816,7 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
     _, best_path_val, best_path_score, _ = ckpt_paths("vqvae", common_cfg)
     log_summary = init_log_summary("vqvae")
     selector = CheckpointSelector(common_cfg.epochs, rising_start=False)
+    max_score = 0.0
     keys = ("total_loss", "enc_rec_loss", "reconstruct_loss", "vq_loss", "kmeans_loss",
             "number_of_populated_clusters", "distill_loss")
 
@@ -839,6 +865,7 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
                   f"recon={train_logs['reconstruct_loss']:.4f} codes={train_logs['number_of_populated_clusters']:.1f} "
                   f"distill={train_logs['distill_loss']:.4f} | val total={v_total:.4f} | align score={score_value:.3f}")
         improved_val, save_score = selector.update(epoch, v_total, score_value, has_score=tau_star is not None)
+        max_score = _report_trial(trial, score_value, epoch)
         if save_score:
             if common_cfg.save_weights and is_main:
                 save_model_info(best_path_score, stage="best_score", epoch=epoch, train_steps=(epoch + 1) * nb,
@@ -851,6 +878,8 @@ def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: 
                                 val_total=v_total, common_cfg=common_cfg, teacher_cfg=teacher_cfg, model=model,
                                 log_summary=log_summary, rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
     model_val, model_score = load_best_checkpoints(model, best_path_val, best_path_score, common_cfg.save_weights)
+    if trial is not None:   # (training.py:1260-1261, 1516-1517: four values in tuning mode)
+        return model_val, model_score, log_summary, max_score
     return model_val, model_score, None, log_summary
 
 
@@ -1007,7 +1036,7 @@ class ContrastiveStepper:
 
 def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, meta_info: dict,
                     common_cfg: CommonFitCfg, teacher_cfg: TurtleTeacherCfg, contrastive_cfg: ContrastiveCfg,
-                    device=None, _engine_factory=None, shuffle: bool = True):
+                    device=None, _engine_factory=None, shuffle: bool = True, trial=None):
     """training.py:1266-1520: Adam(lr, weight_decay 1e-4) on the encoder (+ the distillation head when the TURTLE
     teacher is on), clip 0.75, best-val / best-score checkpointing."""
     from .augment import edge_index_from_meta
@@ -1043,6 +1072,7 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
     _, best_path_val, best_path_score, _ = ckpt_paths("contrastive", common_cfg)
     log_summary = init_log_summary("contrastive")
     selector = CheckpointSelector(common_cfg.epochs, rising_start=False)
+    max_score = 0.0
     keys = ("total_loss", "pos_similarity", "neg_similarity", "distill_loss", "seperability")
 
     log_sum = torch.zeros(_capi.LOG_COUNT, dtype=torch.float64, device=eng.device)
@@ -1090,6 +1120,7 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
                   f"distill={train_logs['distill_loss']:.4f} | val total={v_total:.4f} | "
                   f"align score={float(val_logs['alignment_score']):.3f}")
         improved_val, save_score = selector.update(epoch, v_total, score_value, has_score=tau_star is not None)
+        max_score = _report_trial(trial, score_value, epoch)
         if save_score:
             if common_cfg.save_weights and is_main:
                 save_model_info(best_path_score, stage="best_score", epoch=epoch, train_steps=(epoch + 1) * nb,
@@ -1103,6 +1134,8 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
                                 contrastive_cfg=contrastive_cfg, model=model, log_summary=log_summary,
                                 rebuild_spec=rebuild_spec, save_weights=common_cfg.save_weights)
     model_val, model_score = load_best_checkpoints(model, best_path_val, best_path_score, common_cfg.save_weights)
+    if trial is not None:   # (training.py:1260-1261, 1516-1517: four values in tuning mode)
+        return model_val, model_score, log_summary, max_score
     return model_val, model_score, None, log_summary
 
 

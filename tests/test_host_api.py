@@ -829,6 +829,48 @@ def test_preprocess_host_api_emu(golden_dir):
         preprocess_tables(tabs, cols, aids, node_cols, edge_cols, dist_standardize="columnwise", device="cpu", lib=lib)
 
 
+def test_tuning_trial_hooks_emu(tmp_path):
+    """The reference's Optuna hooks (training.py:1045-1049, 1224-1228): fit_* report the epoch's alignment score to a trial
+    object, stop with TrialPruned when it says so, and return max_score in tuning mode.  Duck-typed: no optuna needed."""
+    import parity_common as PC
+    from deepof_amd.config import CommonFitCfg, TurtleTeacherCfg
+    from deepof_amd.graph import adjacency_from_graph
+    lib = emu_lib()
+    bps = ["Nose", "Left_ear", "Right_ear", "Center"]
+    tabs, cols = PC.synth_raw_tables(2, (40, 30), bps, seed=4, nan_rate=0.0)
+    nodes = sorted(bps)
+    edges = [c for c in cols if isinstance(c, tuple) and c[1] == "Center"]
+    node_cols = [(n, "x") for n in nodes] + [(n, "y") for n in nodes] + nodes
+    from deepof_amd.preprocess import preprocess_tables
+    pre = preprocess_tables(tabs, cols, [""], node_cols, edges, (), device="cpu", lib=lib)
+    train = WindowDataset.from_device_tables(pre, 8, 1, lib, keys=["v000"])
+    val = WindowDataset.from_device_tables(pre, 8, 1, lib, keys=["v001"])
+    adj = adjacency_from_graph(nodes, edges)
+    common = CommonFitCfg(model_name="vqvae", encoder_type="recurrent", batch_size=8, latent_dim=4, epochs=3, n_components=3,
+                          output_path=str(tmp_path), save_weights=False, seed=0, diag_max_batches=1)
+    teacher = TurtleTeacherCfg(use_turtle_teacher=False)
+
+    class Trial:
+        def __init__(self, prune_at):
+            self.reports, self.prune_at = [], prune_at
+
+        def report(self, value, step):
+            self.reports.append((float(value), int(step)))
+
+        def should_prune(self):
+            return self.prune_at is not None and len(self.reports) > self.prune_at
+
+    t = Trial(None)
+    res = TR.fit_VQVAE(train, val, adj, common, teacher, device="cpu", _engine_factory=emu_factory, trial=t)
+    assert len(res) == 4 and [s for _, s in t.reports] == [0, 1, 2]
+    assert np.array_equal(res[3], t.reports[-1][0], equal_nan=True)   # (no teacher here: the alignment score is NaN, as in the reference)
+    t2 = Trial(1)
+    with pytest.raises(TR.TrialPruned):
+        TR.fit_VQVAE(train, val, adj, common, teacher, device="cpu", _engine_factory=emu_factory, trial=t2)
+    assert [s for _, s in t2.reports] == [0, 1]
+    assert len(TR.fit_VQVAE(train, val, adj, common, teacher, device="cpu", _engine_factory=emu_factory)) == 4   # (m, m, None, logs)
+
+
 def test_bf16_window_storage_emu():
     """BASELINE configs[1] "bf16": a frame-table dataset with window_storage = "bf16" serves batches that were gathered as bf16
     (dof_window_gather_bf16) and widened back -- the fp32 batch rounded to nearest-even bf16, exactly."""
