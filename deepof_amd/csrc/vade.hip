@@ -159,8 +159,6 @@ struct JobSet {  // one launch of the MFMA weight-gradient reduction + its final
   std::vector<DofTcnWgrad> wgrads;  // TCN convolutions whose partial tiles come from k_tcn_wgrad instead of k_outer
   int total_blocks = 0, fin_elems = 0, wg_blocks = 0;
   int64_t jobs_tab = 0, fin_tab = 0, wg_tab = 0;  // workspace offsets of the uploaded tables
-  int64_t part_base = 0;  // this set's own region of the partial tiles (a finalize may still read it on the side stream
-                          // while the next set's reduction runs)
 };
 
 struct DofVadePlan {
@@ -212,19 +210,6 @@ struct DofVadePlan {
   int64_t ws_floats = 0;
   // tables built at bind: encoder side, decoder fed from ws.z (latent / quantised) or ws.enc (raw z_e), Gram
   JobSet js_enc, js_dec[2], js_gram;
-  // side stream for the off-path finalize kernels (see side_fork)
-  bool side_on = false, side_used = false;
-  int side_k = 0;
-#ifndef DOF_EMU
-  hipStream_t side = nullptr;
-  hipEvent_t side_ev[8] = {}, side_join_ev = nullptr;
-  ~DofVadePlan() {
-    if (side) (void)hipStreamDestroy(side);
-    for (hipEvent_t e : side_ev)
-      if (e) (void)hipEventDestroy(e);
-    if (side_join_ev) (void)hipEventDestroy(side_join_ev);
-  }
-#endif
   float* ws = nullptr;
 };
 
@@ -1137,58 +1122,22 @@ void finish_workspace_layout(DofVadePlan* p) {
   p->ws = nullptr;
   build_jobs(p);  // pointers are meaningless here; only block counts matter
   int64_t need = 0;
-  for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+  for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
     int64_t g = 0;
     for (const DofOuterJob& j : js->jobs) g += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
-    js->part_base = need;  // one region per set
-    need += (g + 63) / 64 * 64;
+    if (g > need) need = g;  // the sets run one after another and share the region
   }
   p->partials = p->ws_floats;
   p->ws_floats += (need + 63) / 64 * 64;
 }
 
-// ---- side stream: reductions nobody waits for until the gradients are complete -------------------------------------
-// The per-tensor finalize kernels (partial tiles -> weight gradients) are 5 us launches whose results are only read by the
-// optimiser.  On the step's stream they sit between the backward kernels (9 of the 62 dispatches of a C2 step); forked
-// onto a second stream (event record / wait: captured into the hipGraph as a parallel branch) they run beside them, and
-// dof_vade_loss_grads joins the branch before it returns.  One side stream, in issue order, so two finalizes that
-// accumulate into the same tensor keep their order.  VaDE plans with the recurrent latent-8 kernels only: the VQ-VAE and
-// contrastive steps run the decoder / encoder twice over the same partial buffers.
-hipStream_t side_fork(DofVadePlan* p, hipStream_t st) {
-#ifndef DOF_EMU
-  if (!p->side_on) return st;
-  hipEvent_t ev = p->side_ev[p->side_k++ & 7];
-  if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(p->side, ev, 0) != hipSuccess) return st;
-  p->side_used = true;
-  return p->side;
-#else
-  (void)p;
-  return st;
-#endif
-}
-int side_join(DofVadePlan* p, hipStream_t st) {
-#ifndef DOF_EMU
-  if (p->side_used) {
-    p->side_used = false;
-    if (hipEventRecord(p->side_join_ev, p->side) != hipSuccess || hipStreamWaitEvent(st, p->side_join_ev, 0) != hipSuccess) {
-      dof_set_error("side stream join failed");
-      return DOF_ERR_LAUNCH;
-    }
-  }
-#else
-  (void)p; (void)st;
-#endif
-  return DOF_OK;
-}
-
-int run_jobset(DofVadePlan* p, const JobSet& js, float* dst, int accumulate, hipStream_t st, bool defer_finalize = false) {
+int run_jobset(DofVadePlan* p, const JobSet& js, float* dst, int accumulate, hipStream_t st) {
   const DofOuterJob* jobs = reinterpret_cast<const DofOuterJob*>(p->ws + js.jobs_tab);
   const DofFinJob* fins = reinterpret_cast<const DofFinJob*>(p->ws + js.fin_tab);
-  float* part = p->ws + p->partials + js.part_base;
-  TRY(dof_launch_outer(jobs, (int)js.jobs.size(), js.total_blocks, part, st));
-  TRY(dof_launch_tcn_wgrad(reinterpret_cast<const DofTcnWgrad*>(p->ws + js.wg_tab), (int)js.wgrads.size(), js.wg_blocks, part, st));
-  return dof_launch_outer_finalize(jobs, fins, (int)js.fins.size(), js.fin_elems, part, dst, accumulate,
-                                   defer_finalize ? side_fork(p, st) : st);
+  TRY(dof_launch_outer(jobs, (int)js.jobs.size(), js.total_blocks, p->ws + p->partials, st));
+  TRY(dof_launch_tcn_wgrad(reinterpret_cast<const DofTcnWgrad*>(p->ws + js.wg_tab), (int)js.wgrads.size(), js.wg_blocks,
+                           p->ws + p->partials, st));
+  return dof_launch_outer_finalize(jobs, fins, (int)js.fins.size(), js.fin_elems, p->ws + p->partials, dst, accumulate, st);
 }
 
 DofGruW gru_w(const float* params, const GruOff& g) {
@@ -1626,7 +1575,7 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
   if (L == 8) {
     TRY(dof_launch_gru16_bwd_fused(ws + p->n1d, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d,
                                    ws + p->dn1dx, ws + p->wgd2, T, B, Bp, st));
-    TRY(dof_launch_gru16_wg_finalize(ws + p->wgd2, B, grads, p->dg2.t, accumulate, side_fork(p, st)));
+    TRY(dof_launch_gru16_wg_finalize(ws + p->wgd2, B, grads, p->dg2.t, accumulate, st));
   } else {
     TRY(dof_launch_gru_bwd(L, 0, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d, nullptr, ws + p->dn1dx, T, B, Bp, st));
   }
@@ -1639,9 +1588,9 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
     sj.partial[0] = ws + p->lnd2p; sj.nblk[0] = p->lnd_blocks; sj.nv[0] = 8 * L; sj.out[0] = grads + p->dn2w;
     sj.partial[1] = ws + p->lnd1p; sj.nblk[1] = p->lnd_blocks; sj.nv[1] = 4 * L; sj.out[1] = grads + p->dn1w;
     sj.partial[2] = ws + p->ln3p; sj.nblk[2] = p->tail_blocks; sj.nv[2] = 4 * L; sj.out[2] = grads + p->dn3w;
-    TRY(dof_launch_sum_partials_multi(sj, accumulate, side_fork(p, st)));
+    TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
   }
-  return run_jobset(p, p->js_dec[which_input], grads, accumulate, st, /*defer_finalize=*/true);
+  return run_jobset(p, p->js_dec[which_input], grads, accumulate, st);
 }
 
 // Backward of CensNet from ws.dflat: d(block outputs) into sw[s].dn2, dZ / dY / dd for the weight-gradient jobs.
@@ -1747,7 +1696,7 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     if (L == 8 && gru8_fused()) {
       TRY(dof_launch_gru8_bwd_fused(ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, ws + w.dhf, ws + w.dn1x,
                                     ws + w.wg2, T, w.S, w.Sp, st));
-      TRY(dof_launch_gru8_wg_finalize(ws + w.wg2, w.S, grads, b.g2.t, accumulate, side_fork(p, st)));
+      TRY(dof_launch_gru8_wg_finalize(ws + w.wg2, w.S, grads, b.g2.t, accumulate, st));
     } else {
       TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
     }
@@ -1775,7 +1724,7 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     if (L == 8) {
       if (!paired) TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
                                                   ws + w.wg1, T, w.S, w.Sp, st));
-      TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, accumulate, side_fork(p, st)));
+      TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, accumulate, st));
     } else {
       TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
     }
@@ -1793,7 +1742,7 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
       sj.partial[2 * s + 1] = ws + w.ln2p; sj.nblk[2 * s + 1] = w.ln2_blocks; sj.nv[2 * s + 1] = 4 * L;
       sj.out[2 * s + 1] = grads + b.n2w;
     }
-    TRY(dof_launch_sum_partials_multi(sj, accumulate, side_fork(p, st)));
+    TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
   }
   return run_jobset(p, p->js_enc, grads, accumulate, st);
 }
@@ -1851,18 +1800,6 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
   build_triplets(p, laplacian, edge_laplacian, incidence);
   build_workspace_layout(p);
   finish_workspace_layout(p);
-#ifndef DOF_EMU
-  {  // side stream of the off-path finalize kernels (DOF_SIDE_STREAM=0: everything on the step's stream)
-    const char* e = getenv("DOF_SIDE_STREAM");
-    if (kind == 0 && !tcn && !tfm && p->L == 8 && !(e && e[0] == '0')) {
-      bool ok = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess;
-      for (int k = 0; k < 8 && ok; ++k) ok = hipEventCreateWithFlags(&p->side_ev[k], hipEventDisableTiming) == hipSuccess;
-      ok = ok && hipEventCreateWithFlags(&p->side_join_ev, hipEventDisableTiming) == hipSuccess;
-      p->side_on = ok;
-      if (!ok) (void)hipGetLastError();
-    }
-  }
-#endif
   *out = p;
   return DOF_OK;
 }
@@ -2177,8 +2114,7 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   TRY(dof_launch_sum_partials(ws + p->gmmp, 16, 2 * K * L, grads + p->gmm_m, 0, st));  // gmm_means | gmm_log_vars
 
   // ---------------- CensNet + recurrent encoder backward, encoder-side weight gradients
-  TRY(encoder_backward(p, params, grads, st));
-  return side_join(p, st);
+  return encoder_backward(p, params, grads, st);
 }
 
 // ---------------------------------------------------------------------------------------------
