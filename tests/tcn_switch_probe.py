@@ -10,5 +10,7 @@ sys.path.insert(0, HERE)
 from deepof_amd._lib import load_hip_library  # noqa: E402
 import parity_common as PC  # noqa: E402
 
-res = PC.run_vade_tcn_b64_check(load_hip_library(), "cuda", os.path.join(HERE, "golden"))
+fixture = os.environ.get("DOF_PROBE_FIXTURE", "vade_tcn14_b64.npz")
+res = PC.run_vade_tcn_b64_check(load_hip_library(), "cuda", os.path.join(HERE, "golden"), fixture=fixture,
+                                min_main=200 if "onepass" in fixture else 20)
 print("PROBE " + json.dumps({"ok": True, "result": repr(res)[:300]}))

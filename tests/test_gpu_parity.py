@@ -1140,9 +1140,8 @@ def test_step_begin_noise_gpu(hip):
 def test_tcn_onepass_statistics_gpu():
     """The one-pass (shifted) BatchNorm statistics of the time-resident TCN convolutions against the centred second pass:
     the same train step (running means set to the batch means, so the one-pass form is taken for every channel) in two
-    processes, DOF_TCN_ONEPASS = 1 / unset (the switch is read once per process).  Summaries only: the elementwise
-    comparison with the REFERENCE is test_vade_tcn_onepass_reference_gpu, where the one-pass form leaves the bar -- it is
-    opt-in for that reason."""
+    processes, DOF_TCN_ONEPASS = 1 / DOF_TCN_STAT_RECORDS = 0 (the switches are read once per process).  Summaries only: the
+    elementwise comparison with the REFERENCE is test_tcn_kernel_switches_gpu (test_gpu_parity_r03.py)."""
     import json
     import subprocess
     import sys
@@ -1157,7 +1156,7 @@ def test_tcn_onepass_statistics_gpu():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("PROBE ")][-1]
         return json.loads(line[len("PROBE "):])
 
-    one, two = run({"DOF_TCN_ONEPASS": "1"}), run({})   # (one-pass statistics are opt-in since round 3)
+    one, two = run({"DOF_TCN_ONEPASS": "1"}), run({"DOF_TCN_STAT_RECORDS": "0"})   # shifted one-pass sums vs centred second pass
     for k, v in two["logs"].items():
         np.testing.assert_allclose(one["logs"][k], v, rtol=2e-5, atol=1e-6, err_msg=k)
     for n, v in two["rvar"].items():
