@@ -36,6 +36,27 @@ __global__ void __launch_bounds__(256) k_dec_len(const float* __restrict__ valid
   len[b] = n;
 }
 
+// both at once (the recurrent decoder needs the lengths too): one 64-lane group per window, lane = time step, the count is
+// a reduction over the group -- one launch instead of two 7 us ones
+__global__ void __launch_bounds__(256) k_dec_valid_len(const float* __restrict__ x, int T, int C3, int64_t B, int64_t Bp,
+                                                       float* __restrict__ valid, int* __restrict__ len) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  float n = 0.0f;
+  if (b < B) {
+    for (int t = lane; t < T; t += 64) {
+      const float* __restrict__ row = x + (b * T + t) * C3;
+      bool any = false;
+      for (int j = 0; j < C3; ++j) any |= (row[j] != 0.0f);
+      valid[(int64_t)t * Bp + b] = any ? 1.0f : 0.0f;
+      n += any ? 1.0f : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
+  if (b < B && lane == 0) len[b] = (int)n;
+}
+
 struct DecTailArgs {
   const float* n2;     // [T][4L][Bp]
   const float *wc, *g3, *b3, *wp, *bp;  // conv (2L,4L,5), norm3, loc_projection (3N,2L),(3N)

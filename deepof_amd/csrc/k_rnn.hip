@@ -1070,12 +1070,18 @@ __global__ void __launch_bounds__(64) k_gru16m_bwd(Gru16mStream st_a, Gru16mStre
 // measured at 55 us: the device-scope fences write back an L2 full of the backward kernel's output.)
 constexpr int kWgVals = 8;
 static_assert(GRU16_WG_FLOATS % kWgVals == 0, "value groups");
-__global__ void __launch_bounds__(256) k_gru16_wg_finalize(const float* __restrict__ wg_partial, int nblk,
-                                                           float* __restrict__ g_wih0, float* __restrict__ g_whh0,
-                                                           float* __restrict__ g_bih0, float* __restrict__ g_bhh0,
-                                                           float* __restrict__ g_wih1, float* __restrict__ g_whh1,
-                                                           float* __restrict__ g_bih1, float* __restrict__ g_bhh1,
-                                                           int accumulate) {
+// (one launch may serve two layers -- the node and the edge stream of an encoder: blockIdx.z picks the argument set)
+struct WgFinArgs {
+  const float* wg_partial;
+  int nblk;
+  float* g[8];  // wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1
+};
+__global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinArgs A1, int accumulate) {
+  const WgFinArgs& A = blockIdx.z ? A1 : A0;
+  const float* __restrict__ wg_partial = A.wg_partial;
+  const int nblk = A.nblk;
+  float *g_wih0 = A.g[0], *g_whh0 = A.g[1], *g_bih0 = A.g[2], *g_bhh0 = A.g[3], *g_wih1 = A.g[4], *g_whh1 = A.g[5],
+        *g_bih1 = A.g[6], *g_bhh1 = A.g[7];
   __shared__ float red[32][kWgVals + 1];
   const int dir = blockIdx.y;
   const int vi = (int)threadIdx.x & (kWgVals - 1), slice = (int)threadIdx.x / kWgVals;
@@ -1294,12 +1300,12 @@ __global__ void __launch_bounds__(256, 2) k_gru8_bwd_fused(
 // k_gru16_wg_finalize).  Value v < 960: tile = v / 64 (0-3: r x m, 4-7: z x m, 8-11: n x m, 12-14: hidden r, z, hn),
 // row u = (v % 64) / 8, column u' = v % 8: W_ih[gate * 8 + u][4 u' + m] or W_hh[gate * 8 + u][u'].
 static_assert(GRU8_WG_FLOATS % 8 == 0, "value groups");
-__global__ void __launch_bounds__(256) k_gru8_wg_finalize(const float* __restrict__ wg_partial, int nblk,
-                                                          float* __restrict__ g_wih0, float* __restrict__ g_whh0,
-                                                          float* __restrict__ g_bih0, float* __restrict__ g_bhh0,
-                                                          float* __restrict__ g_wih1, float* __restrict__ g_whh1,
-                                                          float* __restrict__ g_bih1, float* __restrict__ g_bhh1,
-                                                          int accumulate) {
+__global__ void __launch_bounds__(256) k_gru8_wg_finalize(WgFinArgs A0, WgFinArgs A1, int accumulate) {
+  const WgFinArgs& A = blockIdx.z ? A1 : A0;
+  const float* __restrict__ wg_partial = A.wg_partial;
+  const int nblk = A.nblk;
+  float *g_wih0 = A.g[0], *g_whh0 = A.g[1], *g_bih0 = A.g[2], *g_bhh0 = A.g[3], *g_wih1 = A.g[4], *g_whh1 = A.g[5],
+        *g_bih1 = A.g[6], *g_bhh1 = A.g[7];
   constexpr int NV = 8;
   __shared__ float red[32][NV + 1];
   const int dir = blockIdx.y;
@@ -1782,12 +1788,33 @@ int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const 
 }
 
 // g: gradient buffer base; off[8]: offsets of (wih, whh, bih, bhh) x (fwd, reverse) as in the parameter layout
+static WgFinArgs wg_fin_args(const float* wg_partial, int nblk, float* g, const int64_t* off) {
+  WgFinArgs A;
+  A.wg_partial = wg_partial;
+  A.nblk = nblk;
+  for (int k = 0; k < 8; ++k) A.g[k] = g + off[k];
+  return A;
+}
 int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
                                  hipStream_t st) {
-  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)(GRU16_WG_FLOATS / kWgVals), 2), (256), st, wg_partial,
-             (int)dof_cdiv(S, 16), g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6],
-             g + off[7], accumulate);
+  const WgFinArgs A = wg_fin_args(wg_partial, (int)dof_cdiv(S, 16), g, off);
+  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)(GRU16_WG_FLOATS / kWgVals), 2, 1), (256), st, A, A, accumulate);
   return dof_check_launch("k_gru16_wg_finalize");
+}
+// two layers (the node and the edge stream's) in one launch
+int dof_launch_gru16_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
+                                      int accumulate, hipStream_t st) {
+  const WgFinArgs A0 = wg_fin_args(wg_partial[0], (int)dof_cdiv(S[0], 16), g, off[0]);
+  const WgFinArgs A1 = wg_fin_args(wg_partial[1], (int)dof_cdiv(S[1], 16), g, off[1]);
+  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)(GRU16_WG_FLOATS / kWgVals), 2, 2), (256), st, A0, A1, accumulate);
+  return dof_check_launch("k_gru16_wg_finalize");
+}
+int dof_launch_gru8_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
+                                     int accumulate, hipStream_t st) {
+  const WgFinArgs A0 = wg_fin_args(wg_partial[0], (int)dof_cdiv(S[0], 32), g, off[0]);
+  const WgFinArgs A1 = wg_fin_args(wg_partial[1], (int)dof_cdiv(S[1], 32), g, off[1]);
+  DOF_LAUNCH(k_gru8_wg_finalize, ((unsigned)(GRU8_WG_FLOATS / 8), 2, 2), (256), st, A0, A1, accumulate);
+  return dof_check_launch("k_gru8_wg_finalize");
 }
 
 int64_t dof_gru8_wg_floats(int64_t S) { return 2 * (int64_t)dof_cdiv(S, 32) * GRU8_WG_FLOATS; }
@@ -1802,8 +1829,8 @@ int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const f
 
 int dof_launch_gru8_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
                                 hipStream_t st) {
-  DOF_LAUNCH(k_gru8_wg_finalize, ((unsigned)(GRU8_WG_FLOATS / 8), 2), (256), st, wg_partial, (int)dof_cdiv(S, 32),
-             g + off[0], g + off[1], g + off[2], g + off[3], g + off[4], g + off[5], g + off[6], g + off[7], accumulate);
+  const WgFinArgs A = wg_fin_args(wg_partial, (int)dof_cdiv(S, 32), g, off);
+  DOF_LAUNCH(k_gru8_wg_finalize, ((unsigned)(GRU8_WG_FLOATS / 8), 2, 1), (256), st, A, A, accumulate);
   return dof_check_launch("k_gru8_wg_finalize");
 }
 

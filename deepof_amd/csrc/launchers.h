@@ -31,6 +31,10 @@ int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const f
                               hipStream_t st);
 int dof_launch_gru8_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
                                 hipStream_t st);
+int dof_launch_gru16_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
+                                      int accumulate, hipStream_t st);
+int dof_launch_gru8_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
+                                     int accumulate, hipStream_t st);
 int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
                                const float* dO, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
                                hipStream_t st);

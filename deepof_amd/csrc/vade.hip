@@ -1532,9 +1532,8 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, const f
   const int L = p->L, T = p->T;
   const int64_t B = p->B, Bp = p->Bp;
   int* len = reinterpret_cast<int*>(ws + p->len_d);
-  DOF_LAUNCH(k_dec_valid, (dof_cdiv(B * T, 256)), (256), st, x, T, p->C3, B, Bp, ws + p->valid);
-  DOF_LAUNCH(k_dec_len, (dof_cdiv(B, 256)), (256), st, (const float*)(ws + p->valid), T, B, Bp, len);
-  TRY(dof_check_launch("k_dec_valid"));
+  DOF_LAUNCH(k_dec_valid_len, (dof_cdiv(B, 4)), (256), st, x, T, p->C3, B, Bp, ws + p->valid, len);
+  TRY(dof_check_launch("k_dec_valid_len"));
   TRY(dof_launch_gru_fwd(L, 2, zin, len, gru_w(params, p->dg1), ws + p->o1d, train ? ws + p->g1d : nullptr, T, B, Bp, st));
   TRY(dof_launch_ln_fwd(L, 2, ws + p->o1d, params + p->dn1w, params + p->dn1b, ws + p->n1d, T, B, Bp, st));
   TRY(dof_launch_gru_fwd(L, 0, ws + p->n1d, len, gru_w(params, p->dg2), ws + p->o2d, train ? ws + p->g2d : nullptr, T, B, Bp, st));
@@ -1696,12 +1695,17 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     if (L == 8 && gru8_fused()) {
       TRY(dof_launch_gru8_bwd_fused(ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, ws + w.dhf, ws + w.dn1x,
                                     ws + w.wg2, T, w.S, w.Sp, st));
-      TRY(dof_launch_gru8_wg_finalize(ws + w.wg2, w.S, grads, b.g2.t, accumulate, st));
     } else {
       TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
     }
     TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
                           ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
+  }
+  if (L == 8 && gru8_fused()) {  // the second layer's weight gradients of both streams: one finalize launch
+    const float* wg[2] = {ws + p->sw[0].wg2, ws + p->sw[1].wg2};
+    const int64_t S2[2] = {p->sw[0].S, p->sw[1].S};
+    const int64_t* off[2] = {p->blk[0].g2.t, p->blk[1].g2.t};
+    TRY(dof_launch_gru8_wg_finalize_pair(wg, S2, grads, off, accumulate, st));
   }
   int paired = 0;
   if (L == 8) {   // first layer: both streams in one launch when the matrix-pipe kernels serve it
@@ -1724,13 +1728,18 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     if (L == 8) {
       if (!paired) TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
                                                   ws + w.wg1, T, w.S, w.Sp, st));
-      TRY(dof_launch_gru16_wg_finalize(ws + w.wg1, w.S, grads, b.g1.t, accumulate, st));
     } else {
       TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
     }
     // (fusing this merge into the weight-gradient reduction's operand load was measured: the conv job's loads triple
     // and k_outer, which is latency-bound per wave, loses 19 us per launch against the 19 us this pass costs per stream)
     TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
+  }
+  if (L == 8) {  // the first layer's weight gradients of both streams: one finalize launch
+    const float* wg[2] = {ws + p->sw[0].wg1, ws + p->sw[1].wg1};
+    const int64_t S1[2] = {p->sw[0].S, p->sw[1].S};
+    const int64_t* off[2] = {p->blk[0].g1.t, p->blk[1].g1.t};
+    TRY(dof_launch_gru16_wg_finalize_pair(wg, S1, grads, off, accumulate, st));
   }
   {  // LayerNorm weight / bias gradients of both streams: one launch
     DofSumJobs sj;
