@@ -89,6 +89,11 @@ struct CensBwdStream {
   int G, G_other;
   int64_t S, Sp, Sp_other;
   int flat_row0;
+  // recurrent encoder: the block output is the LayerNorm of the final GRU2 state -- its backward runs right here on the
+  // row the thread holds (k_ln_bwd<D, true>'s arithmetic), dX then is the gradient at the LayerNorm INPUT
+  const float* ln_x = nullptr;      // [D][Sp] LayerNorm input (the final hidden states) or null
+  const float* ln_gamma = nullptr;  // (D)
+  float* ln_partial = nullptr;      // [cdiv(S, 256)][2 D] (sum dy xhat | sum dy) per workgroup
 };
 
 template <int L, int D>
@@ -119,32 +124,76 @@ template <int L, int D>
 __global__ void __launch_bounds__(256) k_cens_bwd2(CensBwdStream A, CensBwdStream Bs) {
   const CensBwdStream& P = blockIdx.y ? Bs : A;
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= P.S) return;
-  const int64_t b = s / P.G;
-  const int m = (int)(s - b * P.G);
+  const bool live = s < P.S;
+  if (!live && !P.ln_x) return;
   float dx[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) dx[c] = 0.0f;
-  // (a) through the propagated features of THIS stream: Y[r] += coef * dots[o] * X[m]
-  for (int e = P.by_m.ptr[m]; e < P.by_m.ptr[m + 1]; ++e) {
-    const float w = P.by_m.coef[e] * P.dots[b * P.G_other + P.by_m.o[e]];
-    const int64_t sr = b * P.G + P.by_m.r[e];
+  if (live) {
+    const int64_t b = s / P.G;
+    const int m = (int)(s - b * P.G);
+    // (a) through the propagated features of THIS stream: Y[r] += coef * dots[o] * X[m]
+    for (int e = P.by_m.ptr[m]; e < P.by_m.ptr[m + 1]; ++e) {
+      const float w = P.by_m.coef[e] * P.dots[b * P.G_other + P.by_m.o[e]];
+      const int64_t sr = b * P.G + P.by_m.r[e];
 #pragma unroll
-    for (int c = 0; c < D; ++c) dx[c] = fmaf(w, P.dY[(int64_t)c * P.Sp + sr], dx[c]);
+      for (int c = 0; c < D; ++c) dx[c] = fmaf(w, P.dY[(int64_t)c * P.Sp + sr], dx[c]);
+    }
+    // (b) through this element's dot product, which weights pairs of the OTHER stream's update
+    float dd = 0.0f;
+    for (int e = P.oth_by_o.ptr[m]; e < P.oth_by_o.ptr[m + 1]; ++e) {
+      const int64_t sr = b * P.G_other + P.oth_by_o.r[e];
+      const int64_t sm = b * P.G_other + P.oth_by_o.m[e];
+      float acc = 0.0f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc = fmaf(P.X_oth[(int64_t)c * P.Sp_other + sm], P.dY_oth[(int64_t)c * P.Sp_other + sr], acc);
+      dd = fmaf(P.oth_by_o.coef[e], acc, dd);
+    }
+    P.dd[s] = dd;
+#pragma unroll
+    for (int c = 0; c < D; ++c) dx[c] = fmaf(dd, P.pw[c], dx[c]);
   }
-  // (b) through this element's dot product, which weights pairs of the OTHER stream's update
-  float dd = 0.0f;
-  for (int e = P.oth_by_o.ptr[m]; e < P.oth_by_o.ptr[m + 1]; ++e) {
-    const int64_t sr = b * P.G_other + P.oth_by_o.r[e];
-    const int64_t sm = b * P.G_other + P.oth_by_o.m[e];
-    float acc = 0.0f;
+  if (!P.ln_x) {
 #pragma unroll
-    for (int c = 0; c < D; ++c) acc = fmaf(P.X_oth[(int64_t)c * P.Sp_other + sm], P.dY_oth[(int64_t)c * P.Sp_other + sr], acc);
-    dd = fmaf(P.oth_by_o.coef[e], acc, dd);
+    for (int c = 0; c < D; ++c) P.dX[(int64_t)c * P.Sp + s] = dx[c];
+    return;
   }
-  P.dd[s] = dd;
+  // ---- LayerNorm backward of the row (dy = dx): dX = rstd (g - mean g - xhat mean(g xhat)), g = dy gamma
+  float vals[2 * D];
 #pragma unroll
-  for (int c = 0; c < D; ++c) P.dX[(int64_t)c * P.Sp + s] = fmaf(dd, P.pw[c], dx[c]);
+  for (int c = 0; c < 2 * D; ++c) vals[c] = 0.0f;
+  if (live) {
+    float x[D];
+    float mean = 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      x[c] = P.ln_x[(int64_t)c * P.Sp + s];
+      mean += x[c];
+    }
+    mean *= (1.0f / D);
+    float var = 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      x[c] -= mean;
+      var = fmaf(x[c], x[c], var);
+    }
+    const float rstd = rsqrtf(var * (1.0f / D) + 1e-3f);
+    float mg = 0.0f, mgx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      x[c] *= rstd;  // xhat
+      const float g = dx[c] * P.ln_gamma[c];
+      mg += g;
+      mgx = fmaf(g, x[c], mgx);
+      vals[c] = dx[c] * x[c];
+      vals[D + c] = dx[c];
+    }
+    mg *= (1.0f / D);
+    mgx *= (1.0f / D);
+#pragma unroll
+    for (int c = 0; c < D; ++c) P.dX[(int64_t)c * P.Sp + s] = rstd * (dx[c] * P.ln_gamma[c] - mg - x[c] * mgx);
+  }
+  if ((int64_t)blockIdx.x * blockDim.x < P.S) dof_block_colsum<2 * D>(vals, P.ln_partial + (int64_t)blockIdx.x * 2 * D);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1565,21 +1565,30 @@ __global__ void __launch_bounds__(256) k_ln_bwd_w(const float* __restrict__ X, c
 // ---------------------------------------------------------------------------------------------
 // Encoder block tail: gather the final hidden state of GRU2 ([fwd @ len-1, bwd @ 0]) + LayerNorm.
 // ---------------------------------------------------------------------------------------------
+// + the CensNet dot product of the row with the stream's weight vector (k_cens_dots' arithmetic, same order), so that the
+// graph layer's first kernel has its operand without a launch of its own.  One launch serves both streams (blockIdx.y).
+struct EncFinalArgs {
+  const float* O2;
+  const int* len;
+  const float *gamma, *beta;
+  float *HF, *Y;
+  const float* cw;  // CensNet weight vector of this stream (2H) or null
+  float* dots;      // [S] or null
+  int64_t S, Sp;
+};
 template <int C>  // C = 2*H
-__global__ void __launch_bounds__(256) k_enc_final_fwd(const float* __restrict__ O2, const int* __restrict__ len,
-                                                       const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ HF,
-                                                       float* __restrict__ Y, int T, int64_t S, int64_t Sp) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  const int n = len[s];
+__global__ void __launch_bounds__(256) k_enc_final_fwd(EncFinalArgs A0, EncFinalArgs A1, int T) {
+  const EncFinalArgs& A = blockIdx.y ? A1 : A0;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, Sp = A.Sp;
+  if (s >= A.S) return;
+  const int n = A.len[s];
   float x[C];
   float mean = 0.0f;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int t = (c < C / 2) ? n - 1 : 0;
-    x[c] = n > 0 ? O2[ACT(t, c, C, Sp, s)] : 0.0f;
-    HF[(int64_t)c * Sp + s] = x[c];
+    x[c] = n > 0 ? A.O2[ACT(t, c, C, Sp, s)] : 0.0f;
+    A.HF[(int64_t)c * Sp + s] = x[c];
     mean += x[c];
   }
   mean *= (1.0f / C);
@@ -1590,8 +1599,15 @@ __global__ void __launch_bounds__(256) k_enc_final_fwd(const float* __restrict__
     var = fmaf(d, d, var);
   }
   const float rstd = rsqrtf(var * (1.0f / C) + 1e-3f);
+  float dot = 0.0f;
 #pragma unroll
-  for (int c = 0; c < C; ++c) Y[(int64_t)c * Sp + s] = fmaf((x[c] - mean) * rstd, gamma[c], beta[c]);
+  for (int c = 0; c < C; ++c) {
+    const float y = fmaf((x[c] - mean) * rstd, A.gamma[c], A.beta[c]);
+    A.Y[(int64_t)c * Sp + s] = y;
+    if (A.cw) dot = fmaf(y, A.cw[c], dot);
+  }
+  if (A.dots) A.dots[s] = dot;
+  (void)T;
 }
 
 __global__ void __launch_bounds__(256) k_zero_f32(float* __restrict__ p, int64_t n) {
@@ -1854,10 +1870,17 @@ int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const f
   return dof_check_launch("k_ln_bwd");
 }
 
-int dof_launch_enc_final_fwd(int L, const float* O2, const int* len, const float* gamma, const float* beta, float* HF,
-                             float* Y, int T, int64_t S, int64_t Sp, hipStream_t st) {
-  const unsigned nb = dof_cdiv(S, 256);
-  DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_final_fwd<2 * LL>), (nb), (256), st, O2, len, gamma, beta, HF, Y, T, S, Sp));
+// both encoder streams' tails (final GRU2 state -> LayerNorm [-> CensNet dot product]) in one launch
+int dof_launch_enc_final_fwd_pair(int L, const float* const O2[2], const int* const len[2], const float* const gamma[2],
+                                  const float* const beta[2], float* const HF[2], float* const Y[2], const float* const cw[2],
+                                  float* const dots[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
+  EncFinalArgs A[2];
+  for (int k = 0; k < 2; ++k) {
+    A[k].O2 = O2[k]; A[k].len = len[k]; A[k].gamma = gamma[k]; A[k].beta = beta[k]; A[k].HF = HF[k]; A[k].Y = Y[k];
+    A[k].cw = cw[k]; A[k].dots = dots[k]; A[k].S = S[k]; A[k].Sp = Sp[k];
+  }
+  const unsigned nb = dof_cdiv(S[0] > S[1] ? S[0] : S[1], 256);
+  DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_final_fwd<2 * LL>), (nb, 2), (256), st, A[0], A[1], T));
   return dof_check_launch("k_enc_final_fwd");
 }
 

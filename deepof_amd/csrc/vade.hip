@@ -1191,7 +1191,7 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
   } while (0)
 
 // ---- forward pieces -----------------------------------------------------------------------------
-int censnet_forward(DofVadePlan* p, const float* params, hipStream_t st) {
+int censnet_forward(DofVadePlan* p, const float* params, hipStream_t st, bool dots_done = false) {
   float* ws = p->ws;
   // CensNet: node update is weighted by edge dot products (edge_weights) and vice versa
   const StreamWs& wn = p->sw[0];
@@ -1208,7 +1208,7 @@ int censnet_forward(DofVadePlan* p, const float* params, hipStream_t st) {
         default: DOF_LAUNCH((k_cens_dots<64>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
       }
     }
-  } else {
+  } else if (!dots_done) {  // (the recurrent encoder's tail kernel has already left them)
     LDISPATCH(p->L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(wn.S, 256)), (256), st, (const float*)(ws + wn.n2),
                                params + p->c_nw, ws + wn.dots, wn.S, wn.Sp));
     LDISPATCH(p->L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(we.S, 256)), (256), st, (const float*)(ws + we.n2),
@@ -1298,9 +1298,22 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
     if (!paired) TRY(dof_launch_gru_fwd(L, 0, ws + w.c, len, gru_w(params, b.g1), ws + w.o1, train ? ws + w.g1 : nullptr, T, w.S, w.Sp, st));
     TRY(dof_launch_ln_fwd(L, 4, ws + w.o1, params + b.n1w, params + b.n1b, ws + w.n1, T, w.S, w.Sp, st));
     TRY(dof_launch_gru_fwd(L, 1, ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, train ? ws + w.g2 : nullptr, T, w.S, w.Sp, st));
-    TRY(dof_launch_enc_final_fwd(L, ws + w.o2, len, params + b.n2w, params + b.n2b, ws + w.hf, ws + w.n2, T, w.S, w.Sp, st));
   }
-  return censnet_forward(p, params, st);
+  {  // both streams' tails in one launch, with the CensNet dot products of the rows they have just normalised
+    const StreamWs& wn = p->sw[0];
+    const StreamWs& we = p->sw[1];
+    const float* O2[2] = {ws + wn.o2, ws + we.o2};
+    const int* ln[2] = {reinterpret_cast<const int*>(ws + wn.len), reinterpret_cast<const int*>(ws + we.len)};
+    const float* gm[2] = {params + p->blk[0].n2w, params + p->blk[1].n2w};
+    const float* bt[2] = {params + p->blk[0].n2b, params + p->blk[1].n2b};
+    float* HF[2] = {ws + wn.hf, ws + we.hf};
+    float* Y[2] = {ws + wn.n2, ws + we.n2};
+    const float* cw[2] = {params + p->c_nw, params + p->c_ew};
+    float* dots[2] = {ws + wn.dots, ws + we.dots};
+    const int64_t S[2] = {wn.S, we.S}, Sp[2] = {wn.Sp, we.Sp};
+    TRY(dof_launch_enc_final_fwd_pair(L, O2, ln, gm, bt, HF, Y, cw, dots, T, S, Sp, st));
+  }
+  return censnet_forward(p, params, st, /*dots_done=*/true);
 }
 
 // TCN encoder: both streams' temporal blocks, CensNet, RMS-normalised BatchNorm head -> ws.enc [L][Bp].
@@ -1593,7 +1606,8 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
 }
 
 // Backward of CensNet from ws.dflat: d(block outputs) into sw[s].dn2, dZ / dY / dd for the weight-gradient jobs.
-int censnet_backward(DofVadePlan* p, const float* params, hipStream_t st) {
+// ln_fold: the recurrent encoder's final LayerNorm backward runs inside k_cens_bwd2 (dX = sw[s].dhf, partials sw[s].ln2p)
+int censnet_backward(DofVadePlan* p, const float* params, hipStream_t st, bool ln_fold = false) {
   float* ws = p->ws;
   const int64_t Bp = p->Bp;
   CensBwdStream cb[2];
@@ -1606,6 +1620,10 @@ int censnet_backward(DofVadePlan* p, const float* params, hipStream_t st) {
     cb[s].X_oth = ws + o.n2; cb[s].dY_oth = ws + o.dY; cb[s].dX = ws + w.dn2; cb[s].dd = ws + w.dd;
     cb[s].G = w.G; cb[s].G_other = o.G; cb[s].S = w.S; cb[s].Sp = w.Sp; cb[s].Sp_other = o.Sp;
     cb[s].flat_row0 = s == 0 ? 0 : p->N * p->L;
+    if (ln_fold) {
+      cb[s].ln_x = ws + w.hf; cb[s].ln_gamma = params + p->blk[s].n2w; cb[s].ln_partial = ws + w.ln2p;
+      cb[s].dX = ws + w.dhf;
+    }
   }
   const int64_t smax = p->sw[0].S > p->sw[1].S ? p->sw[0].S : p->sw[1].S;
   CENS_DISPATCH(p, k_cens_bwd1, (dof_cdiv(smax, 256), 2), cb[0], cb[1], (const float*)(ws + p->dflat), Bp);
@@ -1682,7 +1700,7 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
   if (p->tcn) return tcn_encoder_backward(p, params, grads, st, accumulate);
   float* ws = p->ws;
   const int L = p->L, T = p->T;
-  TRY(censnet_backward(p, params, st));
+  TRY(censnet_backward(p, params, st, /*ln_fold=*/true));
   // edge stream first: the forward pass ran node then edge, so the edge stream's saved gates are the more recent
   // residents of the Infinity Cache (measured: the first stream's GRU backward kernels run 15-20 % slower than the
   // second's whichever stream it is; C2 step -0.5 %)
@@ -1691,7 +1709,6 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     const StreamWs& w = p->sw[s];
     const BlockOff& b = p->blk[s];
     const int* len = reinterpret_cast<const int*>(ws + w.len);
-    TRY(dof_launch_ln_bwd(L, 2, ws + w.hf, ws + w.dn2, nullptr, params + b.n2w, ws + w.dhf, ws + w.ln2p, 1, w.S, w.Sp, st));
     if (L == 8 && gru8_fused()) {
       TRY(dof_launch_gru8_bwd_fused(ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, ws + w.dhf, ws + w.dn1x,
                                     ws + w.wg2, T, w.S, w.Sp, st));
