@@ -483,9 +483,26 @@ __global__ void __launch_bounds__(256) k_latent_fwd_w(LatentFwdArgs A) {
 //   loss = w * mean_i sqrt(max(lambda_i(Z^T Z / B), 1e-9)) ;  dLoss/dZ = w/(L*B) * Z * G^{-1/2}
 // One thread, cyclic Jacobi in fp64 on the L x L Gram (formed in fp32 like the reference).
 // ---------------------------------------------------------------------------------------------
+// partial != null: the Gram's partial tiles ([nblk][64][65] of the weight-gradient reduction, one job) are reduced here
+// first -- k_outer_finalize's arithmetic per element (64 lanes stride over the tiles, fixed butterfly), 16 wavefronts x
+// 4 elements -- and also written to gram_sum: the finalize launch in front of this kernel is gone.
 template <int L>
-__global__ void k_kmeans_eig(const float* __restrict__ gram_sum, const float* __restrict__ hyper, int64_t B,
-                             float* __restrict__ km_out /*[0]=weighted loss*/, float* __restrict__ Pm /*[L][L]*/) {
+__global__ void __launch_bounds__(1024) k_kmeans_eig(float* __restrict__ gram_sum, const float* __restrict__ partial, int nblk,
+                                                    const float* __restrict__ hyper, int64_t B,
+                                                    float* __restrict__ km_out /*[0]=weighted loss*/,
+                                                    float* __restrict__ Pm /*[L][L]*/) {
+  if (partial) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int e = wv; e < L * L; e += nw) {
+      const float* __restrict__ p = partial + (int64_t)(e / L) * 65 + (e % L);
+      float acc = 0.0f;
+      for (int b = lane; b < nblk; b += 64) acc += p[(int64_t)b * DOF_OUTER_PARTIAL_FLOATS];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+      if (lane == 0) gram_sum[e] = acc;
+    }
+    __syncthreads();  // (the same workgroup reads gram_sum below: global writes of a workgroup are visible to it after the barrier)
+  }
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float w_lat = hyper[DOF_H_KM_LATENT];
   const float w_loss = hyper[DOF_H_KM_LOSS];

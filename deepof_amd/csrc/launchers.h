@@ -251,10 +251,10 @@ int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* o
 // up to 4 such reductions in one launch (the step has eight of them, each a launch-latency-bound 5 us kernel)
 struct DofSumJobs {
   int n;
-  const float* partial[4];
-  int64_t nblk[4];
-  int nv[4];
-  float* out[4];
+  const float* partial[6];
+  int64_t nblk[6];
+  int nv[6];
+  float* out[6];
 };
 int dof_launch_sum_partials_multi(const DofSumJobs& jobs, int accumulate, hipStream_t st);
 

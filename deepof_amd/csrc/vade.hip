@@ -210,6 +210,11 @@ struct DofVadePlan {
   int64_t ws_floats = 0;
   // tables built at bind: encoder side, decoder fed from ws.z (latent / quantised) or ws.enc (raw z_e), Gram
   JobSet js_enc, js_dec[2], js_gram;
+  // a partial-sum job the caller of encoder_backward wants reduced with the encoder's own (one launch fewer)
+  const float* pend_partial = nullptr;
+  int64_t pend_nblk = 0;
+  int pend_nv = 0;
+  float* pend_out = nullptr;
   float* ws = nullptr;
 };
 
@@ -1768,6 +1773,11 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
       sj.partial[2 * s + 1] = ws + w.ln2p; sj.nblk[2 * s + 1] = w.ln2_blocks; sj.nv[2 * s + 1] = 4 * L;
       sj.out[2 * s + 1] = grads + b.n2w;
     }
+    if (p->pend_partial) {
+      sj.partial[sj.n] = p->pend_partial; sj.nblk[sj.n] = p->pend_nblk; sj.nv[sj.n] = p->pend_nv; sj.out[sj.n] = p->pend_out;
+      ++sj.n;
+      p->pend_partial = nullptr;
+    }
     TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
   }
   return run_jobset(p, p->js_enc, grads, accumulate, st);
@@ -2024,8 +2034,13 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
 
 static int gram_spectrum(DofVadePlan* p, const float* hyper, hipStream_t st) {
   float* ws = p->ws;
-  TRY(run_jobset(p, p->js_gram, ws, 0, st));  // Gram sums land in ws.gram
-  LDISPATCH(p->L, DOF_LAUNCH((k_kmeans_eig<LL>), (1), (64), st, (const float*)(ws + p->gram), hyper, p->B, ws + p->km, ws + p->Pm));
+  // the Gram's reduction (one job of the weight-gradient kernel); its partial tiles are summed inside the eigen-solver's launch
+  const JobSet& js = p->js_gram;
+  const DofOuterJob* jobs = reinterpret_cast<const DofOuterJob*>(ws + js.jobs_tab);
+  TRY(dof_launch_outer(jobs, (int)js.jobs.size(), js.total_blocks, ws + p->partials, st));
+  const float* part = ws + p->partials + js.jobs[0].partial_off;
+  LDISPATCH(p->L, DOF_LAUNCH((k_kmeans_eig<LL>), (1), (1024), st, ws + p->gram, part, js.jobs[0].nblk, hyper, p->B, ws + p->km,
+                             ws + p->Pm));
   return dof_check_launch("k_kmeans_eig");
 }
 
@@ -2137,7 +2152,11 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   GG.K = K; GG.S = p->S; GG.pretrain = pretrain ? 1 : 0; GG.B = B; GG.Bp = Bp;
   LDISPATCH(L, DOF_LAUNCH((k_gmm_grads<LL>), ((unsigned)K, 16), (256), st, GG));
   TRY(dof_check_launch("k_gmm_grads"));
-  TRY(dof_launch_sum_partials(ws + p->gmmp, 16, 2 * K * L, grads + p->gmm_m, 0, st));  // gmm_means | gmm_log_vars
+  if (p->tcn || p->tfm) {
+    TRY(dof_launch_sum_partials(ws + p->gmmp, 16, 2 * K * L, grads + p->gmm_m, 0, st));  // gmm_means | gmm_log_vars
+  } else {  // reduced with the recurrent encoder's LayerNorm partials at the end of its backward
+    p->pend_partial = ws + p->gmmp; p->pend_nblk = 16; p->pend_nv = 2 * K * L; p->pend_out = grads + p->gmm_m;
+  }
 
   // ---------------- CensNet + recurrent encoder backward, encoder-side weight gradients
   return encoder_backward(p, params, grads, st);
