@@ -1076,8 +1076,8 @@ struct WgFinArgs {
   int nblk;
   float* g[8];  // wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1
 };
-__global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinArgs A1, int accumulate) {
-  const WgFinArgs& A = blockIdx.z ? A1 : A0;
+__global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinArgs A1, WgFinArgs A2, int accumulate) {
+  const WgFinArgs& A = blockIdx.z == 0 ? A0 : blockIdx.z == 1 ? A1 : A2;
   const float* __restrict__ wg_partial = A.wg_partial;
   const int nblk = A.nblk;
   float *g_wih0 = A.g[0], *g_whh0 = A.g[1], *g_bih0 = A.g[2], *g_bhh0 = A.g[3], *g_wih1 = A.g[4], *g_whh1 = A.g[5],
@@ -1814,15 +1814,16 @@ static WgFinArgs wg_fin_args(const float* wg_partial, int nblk, float* g, const 
 int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
                                  hipStream_t st) {
   const WgFinArgs A = wg_fin_args(wg_partial, (int)dof_cdiv(S, 16), g, off);
-  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)(GRU16_WG_FLOATS / kWgVals), 2, 1), (256), st, A, A, accumulate);
+  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)(GRU16_WG_FLOATS / kWgVals), 2, 1), (256), st, A, A, A, accumulate);
   return dof_check_launch("k_gru16_wg_finalize");
 }
-// two layers (the node and the edge stream's) in one launch
-int dof_launch_gru16_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
-                                      int accumulate, hipStream_t st) {
+// two or three layers (the node and the edge stream's [+ the decoder's]) in one launch
+int dof_launch_gru16_wg_finalize_pair(const float* const* wg_partial, const int64_t* S, float* g, const int64_t* const* off,
+                                      int accumulate, hipStream_t st, int n) {
   const WgFinArgs A0 = wg_fin_args(wg_partial[0], (int)dof_cdiv(S[0], 16), g, off[0]);
   const WgFinArgs A1 = wg_fin_args(wg_partial[1], (int)dof_cdiv(S[1], 16), g, off[1]);
-  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)(GRU16_WG_FLOATS / kWgVals), 2, 2), (256), st, A0, A1, accumulate);
+  const WgFinArgs A2 = n > 2 ? wg_fin_args(wg_partial[2], (int)dof_cdiv(S[2], 16), g, off[2]) : A1;
+  DOF_LAUNCH(k_gru16_wg_finalize, ((unsigned)(GRU16_WG_FLOATS / kWgVals), 2, (unsigned)n), (256), st, A0, A1, A2, accumulate);
   return dof_check_launch("k_gru16_wg_finalize");
 }
 int dof_launch_gru8_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],

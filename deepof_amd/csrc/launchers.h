@@ -31,8 +31,8 @@ int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const f
                               hipStream_t st);
 int dof_launch_gru8_wg_finalize(const float* wg_partial, int64_t S, float* g, const int64_t* off, int accumulate,
                                 hipStream_t st);
-int dof_launch_gru16_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
-                                      int accumulate, hipStream_t st);
+int dof_launch_gru16_wg_finalize_pair(const float* const* wg_partial, const int64_t* S, float* g, const int64_t* const* off,
+                                      int accumulate, hipStream_t st, int n = 2);
 int dof_launch_gru8_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
                                      int accumulate, hipStream_t st);
 int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
@@ -251,10 +251,10 @@ int dof_launch_sum_partials(const float* partial, int64_t nblk, int nv, float* o
 // up to 4 such reductions in one launch (the step has eight of them, each a launch-latency-bound 5 us kernel)
 struct DofSumJobs {
   int n;
-  const float* partial[6];
-  int64_t nblk[6];
-  int nv[6];
-  float* out[6];
+  const float* partial[8];
+  int64_t nblk[8];
+  int nv[8];
+  float* out[8];
 };
 int dof_launch_sum_partials_multi(const DofSumJobs& jobs, int accumulate, hipStream_t st);
 

@@ -211,10 +211,12 @@ struct DofVadePlan {
   // tables built at bind: encoder side, decoder fed from ws.z (latent / quantised) or ws.enc (raw z_e), Gram
   JobSet js_enc, js_dec[2], js_gram;
   // a partial-sum job the caller of encoder_backward wants reduced with the encoder's own (one launch fewer)
-  const float* pend_partial = nullptr;
-  int64_t pend_nblk = 0;
-  int pend_nv = 0;
-  float* pend_out = nullptr;
+  DofSumJobs pend = {};  // (pend.n jobs waiting; reduced with accumulate = 0)
+  bool defer_dec_fin = false;  // set by dof_vade_loss_grads around its decoder_backward (recurrent latent-8 plans)
+  // ... and a GRU(16) weight-gradient finalize (the decoder's second layer) that rides with the encoder's pair
+  const float* pend_wg16 = nullptr;
+  int64_t pend_wg16_S = 0;
+  const int64_t* pend_wg16_off = nullptr;
   float* ws = nullptr;
 };
 
@@ -1592,7 +1594,11 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
   if (L == 8) {
     TRY(dof_launch_gru16_bwd_fused(ws + p->n1d, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d,
                                    ws + p->dn1dx, ws + p->wgd2, T, B, Bp, st));
-    TRY(dof_launch_gru16_wg_finalize(ws + p->wgd2, B, grads, p->dg2.t, accumulate, st));
+    if (p->defer_dec_fin) {  // rides with the encoder's finalize launch at the end of the step
+      p->pend_wg16 = ws + p->wgd2; p->pend_wg16_S = B; p->pend_wg16_off = p->dg2.t;
+    } else {
+      TRY(dof_launch_gru16_wg_finalize(ws + p->wgd2, B, grads, p->dg2.t, accumulate, st));
+    }
   } else {
     TRY(dof_launch_gru_bwd(L, 0, len_d, gru_w(params, p->dg2), ws + p->o2d, ws + p->g2d, ws + p->do2d, nullptr, ws + p->dn1dx, T, B, Bp, st));
   }
@@ -1605,7 +1611,15 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
     sj.partial[0] = ws + p->lnd2p; sj.nblk[0] = p->lnd_blocks; sj.nv[0] = 8 * L; sj.out[0] = grads + p->dn2w;
     sj.partial[1] = ws + p->lnd1p; sj.nblk[1] = p->lnd_blocks; sj.nv[1] = 4 * L; sj.out[1] = grads + p->dn1w;
     sj.partial[2] = ws + p->ln3p; sj.nblk[2] = p->tail_blocks; sj.nv[2] = 4 * L; sj.out[2] = grads + p->dn3w;
-    TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
+    if (p->defer_dec_fin) {
+      for (int k = 0; k < 3; ++k) {
+        DofSumJobs& pj = p->pend;
+        pj.partial[pj.n] = sj.partial[k]; pj.nblk[pj.n] = sj.nblk[k]; pj.nv[pj.n] = sj.nv[k]; pj.out[pj.n] = sj.out[k];
+        ++pj.n;
+      }
+    } else {
+      TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
+    }
   }
   return run_jobset(p, p->js_dec[which_input], grads, accumulate, st);
 }
@@ -1758,10 +1772,11 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
   }
   if (L == 8) {  // the first layer's weight gradients of both streams: one finalize launch
-    const float* wg[2] = {ws + p->sw[0].wg1, ws + p->sw[1].wg1};
-    const int64_t S1[2] = {p->sw[0].S, p->sw[1].S};
-    const int64_t* off[2] = {p->blk[0].g1.t, p->blk[1].g1.t};
-    TRY(dof_launch_gru16_wg_finalize_pair(wg, S1, grads, off, accumulate, st));
+    const float* wg[3] = {ws + p->sw[0].wg1, ws + p->sw[1].wg1, p->pend_wg16};
+    const int64_t S1[3] = {p->sw[0].S, p->sw[1].S, p->pend_wg16_S};
+    const int64_t* off[3] = {p->blk[0].g1.t, p->blk[1].g1.t, p->pend_wg16_off};
+    TRY(dof_launch_gru16_wg_finalize_pair(wg, S1, grads, off, accumulate, st, (p->pend_wg16 && !accumulate) ? 3 : 2));
+    p->pend_wg16 = nullptr;
   }
   {  // LayerNorm weight / bias gradients of both streams: one launch
     DofSumJobs sj;
@@ -1773,11 +1788,12 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
       sj.partial[2 * s + 1] = ws + w.ln2p; sj.nblk[2 * s + 1] = w.ln2_blocks; sj.nv[2 * s + 1] = 4 * L;
       sj.out[2 * s + 1] = grads + b.n2w;
     }
-    if (p->pend_partial) {
-      sj.partial[sj.n] = p->pend_partial; sj.nblk[sj.n] = p->pend_nblk; sj.nv[sj.n] = p->pend_nv; sj.out[sj.n] = p->pend_out;
+    for (int k = 0; k < p->pend.n && !accumulate; ++k) {
+      sj.partial[sj.n] = p->pend.partial[k]; sj.nblk[sj.n] = p->pend.nblk[k]; sj.nv[sj.n] = p->pend.nv[k];
+      sj.out[sj.n] = p->pend.out[k];
       ++sj.n;
-      p->pend_partial = nullptr;
     }
+    p->pend.n = 0;
     TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
   }
   return run_jobset(p, p->js_enc, grads, accumulate, st);
@@ -2090,7 +2106,12 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   TRY(decoder_forward(p, params, x, ws + p->z, ws + p->recon_partial, true, nullptr, st));
 
   // ---------------- decoder backward (needed first: it yields d loss / d z)
-  TRY(decoder_backward(p, params, 0, grads, 0, st));
+  p->pend.n = 0;
+  p->pend_wg16 = nullptr;
+  p->defer_dec_fin = !p->tcn && !p->tfm && L == 8;  // its small reductions join the encoder's at the end of the step
+  const int rc_dec = decoder_backward(p, params, 0, grads, 0, st);
+  p->defer_dec_fin = false;
+  TRY(rc_dec);
 
   // ---------------- batch-level loss terms
   StatsArgs SA;
@@ -2155,7 +2176,9 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   if (p->tcn || p->tfm) {
     TRY(dof_launch_sum_partials(ws + p->gmmp, 16, 2 * K * L, grads + p->gmm_m, 0, st));  // gmm_means | gmm_log_vars
   } else {  // reduced with the recurrent encoder's LayerNorm partials at the end of its backward
-    p->pend_partial = ws + p->gmmp; p->pend_nblk = 16; p->pend_nv = 2 * K * L; p->pend_out = grads + p->gmm_m;
+    DofSumJobs& pj = p->pend;
+    pj.partial[pj.n] = ws + p->gmmp; pj.nblk[pj.n] = 16; pj.nv[pj.n] = 2 * K * L; pj.out[pj.n] = grads + p->gmm_m;
+    ++pj.n;
   }
 
   // ---------------- CensNet + recurrent encoder backward, encoder-side weight gradients
