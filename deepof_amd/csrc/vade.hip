@@ -210,6 +210,9 @@ struct DofVadePlan {
   int64_t ws_floats = 0;
   // tables built at bind: encoder side, decoder fed from ws.z (latent / quantised) or ws.enc (raw z_e), Gram
   JobSet js_enc, js_dec[2], js_gram;
+  JobSet js_all;  // recurrent VaDE plans: js_enc + js_dec[0] as ONE reduction at the end of the step (every operand of the
+                  // decoder's jobs has its own workspace region and is still intact there)
+  bool use_js_all = false;
   // a partial-sum job the caller of encoder_backward wants reduced with the encoder's own (one launch fewer)
   DofSumJobs pend = {};  // (pend.n jobs waiting; reduced with accumulate = 0)
   bool defer_dec_fin = false;  // set by dof_vade_loss_grads around its decoder_backward (recurrent latent-8 plans)
@@ -703,7 +706,7 @@ void take_tables(DofVadePlan* p, Carver& cv) {
     p->dh_dz = cv.take((int64_t)p->L * p->Bp + p->B * p->L);
     p->dh_partial = cv.take(p->lat_blocks);
   }
-  for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+  for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram, &p->js_all}) {
     js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
     js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
     js->wg_tab = cv.take(48 * (int64_t)(sizeof(DofTcnWgrad) / 4 + 1));
@@ -1122,6 +1125,32 @@ void build_jobs(DofVadePlan* p) {
     gb.add_fin(gj, 0, L, L, L, L, p->gram, L, 1);
     gb.close(p->js_gram);
   }
+  // ---- VaDE: the encoder's and the decoder's jobs as one set (one k_outer + one finalize at the end of the step)
+  p->js_all.jobs.clear();
+  p->js_all.fins.clear();
+  p->js_all.total_blocks = p->js_all.fin_elems = 0;
+  if (p->kind == 0) {
+    JobSet& all = p->js_all;
+    int64_t part = 0;
+    for (const JobSet* js : {&p->js_enc, &p->js_dec[0]}) {
+      const int job0 = (int)all.jobs.size();
+      int64_t own = 0;
+      for (DofOuterJob j : js->jobs) {
+        own += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
+        j.blk0 += all.total_blocks;
+        j.partial_off += part;
+        all.jobs.push_back(j);
+      }
+      for (DofFinJob f : js->fins) {
+        f.job += job0;
+        f.elem0 += all.fin_elems;
+        all.fins.push_back(f);
+      }
+      all.total_blocks += js->total_blocks;
+      all.fin_elems += js->fin_elems;
+      part += own;
+    }
+  }
 }
 
 // partial tiles of the weight-gradient reduction: sized from a dry enumeration of the jobs
@@ -1129,7 +1158,7 @@ void finish_workspace_layout(DofVadePlan* p) {
   p->ws = nullptr;
   build_jobs(p);  // pointers are meaningless here; only block counts matter
   int64_t need = 0;
-  for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+  for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram, &p->js_all}) {
     int64_t g = 0;
     for (const DofOuterJob& j : js->jobs) g += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
     if (g > need) need = g;  // the sets run one after another and share the region
@@ -1621,6 +1650,7 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
       TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
     }
   }
+  if (p->use_js_all) return DOF_OK;  // its jobs are reduced with the encoder's (js_all)
   return run_jobset(p, p->js_dec[which_input], grads, accumulate, st);
 }
 
@@ -1796,7 +1826,7 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     p->pend.n = 0;
     TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
   }
-  return run_jobset(p, p->js_enc, grads, accumulate, st);
+  return run_jobset(p, p->use_js_all ? p->js_all : p->js_enc, grads, accumulate, st);
 }
 
 #include "tfm_plan.inc.h"
@@ -1987,7 +2017,7 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
   auto up = [&](int64_t off, const void* src, size_t bytes) {
     if (bytes) hipMemcpyAsync(ws + off, src, bytes, hipMemcpyHostToDevice, st);
   };
-  for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram}) {
+  for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram, &p->js_all}) {
     if (js->jobs.size() > 96 || js->fins.size() > 512) {
       dof_set_error("dof_vade_bind: job table overflow (%zu jobs, %zu fins)", js->jobs.size(), js->fins.size());
       return DOF_ERR_STATE;
@@ -2109,6 +2139,7 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   p->pend.n = 0;
   p->pend_wg16 = nullptr;
   p->defer_dec_fin = !p->tcn && !p->tfm && L == 8;  // its small reductions join the encoder's at the end of the step
+  p->use_js_all = !p->tcn && !p->tfm && !p->js_all.jobs.empty();
   const int rc_dec = decoder_backward(p, params, 0, grads, 0, st);
   p->defer_dec_fin = false;
   TRY(rc_dec);
@@ -2182,7 +2213,9 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   }
 
   // ---------------- CensNet + recurrent encoder backward, encoder-side weight gradients
-  return encoder_backward(p, params, grads, st);
+  const int rc_enc = encoder_backward(p, params, grads, st);
+  p->use_js_all = false;
+  return rc_enc;
 }
 
 // ---------------------------------------------------------------------------------------------
