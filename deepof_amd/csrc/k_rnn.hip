@@ -1135,11 +1135,26 @@ __global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinAr
 // 15 tiles of 8 x 8 (W_ih: gates r, z, n x input tiles m = 0..3; W_hh: r, z, hn) + 4 x 8 bias sums.
 // ---------------------------------------------------------------------------------------------
 #define GRU8_WG_FLOATS (15 * 64 + 4 * 8)
-__global__ void __launch_bounds__(256, 2) k_gru8_bwd_fused(
-    const float* __restrict__ X, const int* __restrict__ len, const float* __restrict__ wih0,
-    const float* __restrict__ whh0, const float* __restrict__ wih1, const float* __restrict__ whh1,
-    const float* __restrict__ O, const float* __restrict__ GS, const float* __restrict__ dHfin,
-    float* __restrict__ dX, float* __restrict__ wg_partial, int T, int64_t S, int64_t Sp) {
+// (one launch may serve the node and the edge stream of an encoder: blockIdx.z picks the argument set)
+struct Gru8Args {
+  const float* X;
+  const int* len;
+  const float *wih0, *whh0, *wih1, *whh1, *bih0, *bhh0, *bih1, *bhh1;
+  const float *O, *GS, *dHfin;
+  float *dX, *wg_partial, *Oout, *GSout;
+  int64_t S, Sp;
+  int nblk;  // workgroups per direction of this stream (the partial layout's stride)
+};
+__global__ void __launch_bounds__(256, 2) k_gru8_bwd_fused(Gru8Args A0, Gru8Args A1, int T) {
+  const Gru8Args& AA = blockIdx.z ? A1 : A0;
+  if ((int)blockIdx.x >= AA.nblk) return;
+  const float* __restrict__ X = AA.X;
+  const int* __restrict__ len = AA.len;
+  const float *__restrict__ wih0 = AA.wih0, *__restrict__ whh0 = AA.whh0, *__restrict__ wih1 = AA.wih1,
+              *__restrict__ whh1 = AA.whh1;
+  const float *__restrict__ O = AA.O, *__restrict__ GS = AA.GS, *__restrict__ dHfin = AA.dHfin;
+  float *__restrict__ dX = AA.dX, *__restrict__ wg_partial = AA.wg_partial;
+  const int64_t S = AA.S, Sp = AA.Sp;
   constexpr int HID = 8, IN = 32, G = 8, M = 4;
   __shared__ float red[4][15][128];
   __shared__ float bred[256][5];
@@ -1280,7 +1295,7 @@ __global__ void __launch_bounds__(256, 2) k_gru8_bwd_fused(
     }
   bred[threadIdx.x][0] = sb_r; bred[threadIdx.x][1] = sb_z; bred[threadIdx.x][2] = sb_n; bred[threadIdx.x][3] = sb_h;
   __syncthreads();
-  float* __restrict__ out = wg_partial + ((int64_t)dir * gridDim.x + blockIdx.x) * GRU8_WG_FLOATS;
+  float* __restrict__ out = wg_partial + ((int64_t)dir * AA.nblk + blockIdx.x) * GRU8_WG_FLOATS;
   for (int e = threadIdx.x; e < 15 * 64; e += 256) {
     const int a = e >> 6, c = e & 63;
     float v = 0.0f;
@@ -1839,8 +1854,24 @@ int64_t dof_gru8_wg_floats(int64_t S) { return 2 * (int64_t)dof_cdiv(S, 32) * GR
 int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
                               const float* dHfin, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
                               hipStream_t st) {
-  DOF_LAUNCH(k_gru8_bwd_fused, (dof_cdiv(S, 32), 2), (256), st, X, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dHfin, dX,
-             wg_partial, T, S, Sp);
+  Gru8Args A = {};
+  A.X = X; A.len = len; A.wih0 = W.wih0; A.whh0 = W.whh0; A.wih1 = W.wih1; A.whh1 = W.whh1; A.O = O; A.GS = GS;
+  A.dHfin = dHfin; A.dX = dX; A.wg_partial = wg_partial; A.S = S; A.Sp = Sp; A.nblk = (int)dof_cdiv(S, 32);
+  DOF_LAUNCH(k_gru8_bwd_fused, (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
+  return dof_check_launch("k_gru8_bwd_fused");
+}
+// both encoder streams in one launch
+int dof_launch_gru8_bwd_fused_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], const float* const O[2],
+                                   const float* const GS[2], const float* const dHfin[2], float* const dX[2],
+                                   float* const wg_partial[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
+  Gru8Args A[2] = {};
+  for (int k = 0; k < 2; ++k) {
+    A[k].X = X[k]; A[k].len = len[k]; A[k].wih0 = W[k].wih0; A[k].whh0 = W[k].whh0; A[k].wih1 = W[k].wih1; A[k].whh1 = W[k].whh1;
+    A[k].O = O[k]; A[k].GS = GS[k]; A[k].dHfin = dHfin[k]; A[k].dX = dX[k]; A[k].wg_partial = wg_partial[k];
+    A[k].S = S[k]; A[k].Sp = Sp[k]; A[k].nblk = (int)dof_cdiv(S[k], 32);
+  }
+  const unsigned nb = dof_cdiv(S[0] > S[1] ? S[0] : S[1], 32);
+  DOF_LAUNCH(k_gru8_bwd_fused, (nb, 2, 2), (256), st, A[0], A[1], T);
   return dof_check_launch("k_gru8_bwd_fused");
 }
 

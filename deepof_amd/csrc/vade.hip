@@ -1753,17 +1753,28 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
   // edge stream first: the forward pass ran node then edge, so the edge stream's saved gates are the more recent
   // residents of the Infinity Cache (measured: the first stream's GRU backward kernels run 15-20 % slower than the
   // second's whichever stream it is; C2 step -0.5 %)
-  for (int si = 0; si < 2; ++si) {   // second layer + the LayerNorm between the layers, stream by stream
+  const bool pair8 = L == 8 && gru8_fused();
+  if (pair8) {  // second layer of both streams: one launch
+    const StreamWs& w0 = p->sw[0];
+    const StreamWs& w1 = p->sw[1];
+    const float* X[2] = {ws + w0.n1, ws + w1.n1};
+    const int* ln[2] = {reinterpret_cast<const int*>(ws + w0.len), reinterpret_cast<const int*>(ws + w1.len)};
+    const DofGruW W[2] = {gru_w(params, p->blk[0].g2), gru_w(params, p->blk[1].g2)};
+    const float* O[2] = {ws + w0.o2, ws + w1.o2};
+    const float* GS[2] = {ws + w0.g2, ws + w1.g2};
+    const float* dH[2] = {ws + w0.dhf, ws + w1.dhf};
+    float* dX[2] = {ws + w0.dn1x, ws + w1.dn1x};
+    float* wg[2] = {ws + w0.wg2, ws + w1.wg2};
+    const int64_t S[2] = {w0.S, w1.S}, Sp[2] = {w0.Sp, w1.Sp};
+    TRY(dof_launch_gru8_bwd_fused_pair(X, ln, W, O, GS, dH, dX, wg, T, S, Sp, st));
+  }
+  for (int si = 0; si < 2; ++si) {   // [second layer +] the LayerNorm between the layers, stream by stream
     const int s = 1 - si;
     const StreamWs& w = p->sw[s];
     const BlockOff& b = p->blk[s];
     const int* len = reinterpret_cast<const int*>(ws + w.len);
-    if (L == 8 && gru8_fused()) {
-      TRY(dof_launch_gru8_bwd_fused(ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, ws + w.dhf, ws + w.dn1x,
-                                    ws + w.wg2, T, w.S, w.Sp, st));
-    } else {
+    if (!pair8)
       TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
-    }
     TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
                           ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
   }
