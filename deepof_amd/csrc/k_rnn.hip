@@ -353,14 +353,26 @@ __global__ void __launch_bounds__(256) k_gru_bwd(const int* __restrict__ len,
 // Same saved-gate / dG buffers and the same arithmetic; the generic kernels remain the path for
 // other latent sizes.
 // ---------------------------------------------------------------------------------------------
+// (one launch may serve the node and the edge stream of an encoder: blockIdx.z picks the argument set)
+struct Gru8Args {
+  const float* X;
+  const int* len;
+  const float *wih0, *whh0, *wih1, *whh1, *bih0, *bhh0, *bih1, *bhh1;
+  const float *O, *GS, *dHfin;
+  float *dX, *wg_partial, *Oout, *GSout;
+  int64_t S, Sp;
+  int nblk;  // workgroups per direction of this stream (the partial layout's stride)
+};
 template <int IN, int HID, bool BCAST>
-__global__ void __launch_bounds__(256) k_gru3_fwd(const float* __restrict__ X, const int* __restrict__ len,
-                                                  const float* __restrict__ wih0, const float* __restrict__ whh0,
-                                                  const float* __restrict__ bih0, const float* __restrict__ bhh0,
-                                                  const float* __restrict__ wih1, const float* __restrict__ whh1,
-                                                  const float* __restrict__ bih1, const float* __restrict__ bhh1,
-                                                  float* __restrict__ O, float* __restrict__ GS, int T, int64_t S,
-                                                  int64_t Sp) {
+__global__ void __launch_bounds__(256) k_gru3_fwd(Gru8Args A0, Gru8Args A1, int T) {
+  const Gru8Args& AA = blockIdx.z ? A1 : A0;
+  const float* __restrict__ X = AA.X;
+  const int* __restrict__ len = AA.len;
+  const float *__restrict__ wih0 = AA.wih0, *__restrict__ whh0 = AA.whh0, *__restrict__ bih0 = AA.bih0,
+              *__restrict__ bhh0 = AA.bhh0, *__restrict__ wih1 = AA.wih1, *__restrict__ whh1 = AA.whh1,
+              *__restrict__ bih1 = AA.bih1, *__restrict__ bhh1 = AA.bhh1;
+  float *__restrict__ O = AA.Oout, *__restrict__ GS = AA.GSout;
+  const int64_t S = AA.S, Sp = AA.Sp;
   constexpr int G = HID;
   const int u = threadIdx.x % G;
   const int64_t s = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
@@ -1135,16 +1147,6 @@ __global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinAr
 // 15 tiles of 8 x 8 (W_ih: gates r, z, n x input tiles m = 0..3; W_hh: r, z, hn) + 4 x 8 bias sums.
 // ---------------------------------------------------------------------------------------------
 #define GRU8_WG_FLOATS (15 * 64 + 4 * 8)
-// (one launch may serve the node and the edge stream of an encoder: blockIdx.z picks the argument set)
-struct Gru8Args {
-  const float* X;
-  const int* len;
-  const float *wih0, *whh0, *wih1, *whh1, *bih0, *bhh0, *bih1, *bhh1;
-  const float *O, *GS, *dHfin;
-  float *dX, *wg_partial, *Oout, *GSout;
-  int64_t S, Sp;
-  int nblk;  // workgroups per direction of this stream (the partial layout's stride)
-};
 __global__ void __launch_bounds__(256, 2) k_gru8_bwd_fused(Gru8Args A0, Gru8Args A1, int T) {
   const Gru8Args& AA = blockIdx.z ? A1 : A0;
   if ((int)blockIdx.x >= AA.nblk) return;
@@ -1744,6 +1746,20 @@ int dof_launch_gru16_bwd_pair(const float* const X[2], const int* const len[2], 
 
 // kind: 0 = (IN=2L,HID=2L) enc gru1 / dec gru2 ; 1 = (IN=4L,HID=L) enc gru2 ; 2 = (IN=L,HID=L, broadcast input) dec gru1
 #define GRU3_W W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1
+static Gru8Args gru3_fwd_args(const float* X, const int* len, const DofGruW& W, float* O, float* GS, int64_t S, int64_t Sp) {
+  Gru8Args A = {};
+  A.X = X; A.len = len; A.wih0 = W.wih0; A.whh0 = W.whh0; A.bih0 = W.bih0; A.bhh0 = W.bhh0; A.wih1 = W.wih1; A.whh1 = W.whh1;
+  A.bih1 = W.bih1; A.bhh1 = W.bhh1; A.Oout = O; A.GSout = GS; A.S = S; A.Sp = Sp;
+  return A;
+}
+// the second encoder layer (32 -> 8, latent 8) of both streams in one launch
+int dof_launch_gru8_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2],
+                             float* const GS[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
+  const Gru8Args A0 = gru3_fwd_args(X[0], len[0], W[0], O[0], GS[0], S[0], Sp[0]);
+  const Gru8Args A1 = gru3_fwd_args(X[1], len[1], W[1], O[1], GS[1], S[1], Sp[1]);
+  DOF_LAUNCH((k_gru3_fwd<32, 8, false>), (dof_cdiv(S[0] > S[1] ? S[0] : S[1], 32), 2, 2), (256), st, A0, A1, T);
+  return dof_check_launch("k_gru3_fwd");
+}
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st) {
   if (L == 8) {  // weight-stationary kernels: matrix-pipe recurrence (kind 0) / lane per unit
@@ -1751,9 +1767,11 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
       const Gru16mStream a = gru16m_stream(X, len, W, O, nullptr, nullptr, nullptr, nullptr, S, Sp);
       DOF_LAUNCH(k_gru16m_fwd, (dof_cdiv(S, 16), 2, 1), (64), st, a, a, T);
     }
-    else if (kind == 0) DOF_LAUNCH((k_gru3_fwd<16, 16, false>), (dof_cdiv(S, 16), 2), (256), st, X, len, GRU3_W, O, GS, T, S, Sp);
-    else if (kind == 1) DOF_LAUNCH((k_gru3_fwd<32, 8, false>), (dof_cdiv(S, 32), 2), (256), st, X, len, GRU3_W, O, GS, T, S, Sp);
-    else DOF_LAUNCH((k_gru3_fwd<8, 8, true>), (dof_cdiv(S, 32), 2), (256), st, X, len, GRU3_W, O, GS, T, S, Sp);
+    const Gru8Args A = gru3_fwd_args(X, len, W, O, GS, S, Sp);
+    if (kind == 0 && dof_gru16_mfma(S)) {}
+    else if (kind == 0) DOF_LAUNCH((k_gru3_fwd<16, 16, false>), (dof_cdiv(S, 16), 2, 1), (256), st, A, A, T);
+    else if (kind == 1) DOF_LAUNCH((k_gru3_fwd<32, 8, false>), (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
+    else DOF_LAUNCH((k_gru3_fwd<8, 8, true>), (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
     return dof_check_launch("k_gru3_fwd");
   }
   const unsigned nb = dof_cdiv(S, 256);
