@@ -581,12 +581,12 @@ struct StatsArgs {
 };
 
 template <int L>
-__global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
+__device__ __forceinline__ void batch_stats_body(const StatsArgs& A, const int blk) {
   // workgroups 0..K-1: one component each; K: activity + pretrain KL; K+1: distillation class weights;
   // K+2: temporal cohesion (three short dependent chains side by side instead of one long one)
   constexpr int SW = 3 * L + 1;
   __shared__ float s_lt[32][256];
-  const int c = blockIdx.x;
+  const int c = blk;
   float vals[SW];
 #pragma unroll
   for (int i = 0; i < SW; ++i) vals[i] = 0.0f;
@@ -697,7 +697,7 @@ __device__ __forceinline__ float gmm_logp_c(const float* zs, const float* means,
 }
 
 template <int L>
-__global__ void __launch_bounds__(256) k_mckl(McklArgs A) {
+__device__ __forceinline__ void mckl_body(const McklArgs& A, const int blk) {
   __shared__ float s_m[kLatentMaxKL], s_iv[kLatentMaxKL], s_c[kLatentMaxKL / 4];
   __shared__ float s_term[kMcklWindows];
   const float LOG_2PI = 1.8378770664093453f;
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(256) k_mckl(McklArgs A) {
     __syncthreads();
   }
   const int bl = (int)threadIdx.x >> 5, sl = (int)threadIdx.x & 31;
-  const int64_t b = (int64_t)blockIdx.x * kMcklWindows + bl;
+  const int64_t b = (int64_t)blk * kMcklWindows + bl;
   const bool live = b < A.B;
   float acc[2 * L + 1];
 #pragma unroll
@@ -807,8 +807,23 @@ __global__ void __launch_bounds__(256) k_mckl(McklArgs A) {
     float t = 0.0f;
 #pragma unroll
     for (int i = 0; i < kMcklWindows; ++i) t += s_term[i];
-    A.partial[blockIdx.x] = t;
+    A.partial[blk] = t;
   }
+}
+template <int L>
+__global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
+  batch_stats_body<L>(A, (int)blockIdx.x);
+}
+template <int L>
+__global__ void __launch_bounds__(256) k_mckl(McklArgs A) {
+  mckl_body<L>(A, (int)blockIdx.x);
+}
+// Both in one launch (they are independent and each is a few dozen workgroups of latency): workgroups [0, n_stats) take the
+// batch statistics, the rest the Monte-Carlo KL term.
+template <int L>
+__global__ void __launch_bounds__(256) k_stats_mckl(StatsArgs SA, McklArgs MA, int n_stats) {
+  if ((int)blockIdx.x < n_stats) batch_stats_body<L>(SA, (int)blockIdx.x);
+  else mckl_body<L>(MA, (int)blockIdx.x - n_stats);
 }
 
 // ---------------------------------------------------------------------------------------------

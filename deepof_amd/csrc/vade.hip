@@ -2176,15 +2176,16 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   StatsArgs SA;
   SA.qn = ws + p->qn; SA.z = ws + p->z; SA.mu = ws + p->mu; SA.sv = ws + p->sv; SA.tau = tau;
   SA.class_weight = teacher; SA.hyper = hyper; SA.stats = ws + p->stats; SA.K = K; SA.B = B; SA.Bp = Bp;
-  LDISPATCH(L, DOF_LAUNCH((k_batch_stats<LL>), ((unsigned)(K + 3)), (256), st, SA));
-  TRY(dof_check_launch("k_batch_stats"));
-  if (!pretrain) {
+  if (!pretrain) {  // ... and the Monte-Carlo KL term in the same launch (independent of the statistics)
     McklArgs MA;
     MA.mu = ws + p->mu; MA.sv = ws + p->sv; MA.eps_mc = eps_mc; MA.gmm_means = params + p->gmm_m;
     MA.gmm_log_vars = params + p->gmm_lv; MA.prior = prior; MA.hyper = hyper; MA.partial = ws + p->mckl_partial;
     MA.lse = ws + p->mlse; MA.zs = ws + p->mzs; MA.gsum = ws + p->mgsum; MA.K = K; MA.S = p->S; MA.B = B; MA.Bp = Bp;
-    LDISPATCH(L, DOF_LAUNCH((k_mckl<LL>), ((unsigned)p->mckl_blocks), (256), st, MA));
-    TRY(dof_check_launch("k_mckl"));
+    LDISPATCH(L, DOF_LAUNCH((k_stats_mckl<LL>), ((unsigned)(K + 3 + p->mckl_blocks)), (256), st, SA, MA, K + 3));
+    TRY(dof_check_launch("k_stats_mckl"));
+  } else {
+    LDISPATCH(L, DOF_LAUNCH((k_batch_stats<LL>), ((unsigned)(K + 3)), (256), st, SA));
+    TRY(dof_check_launch("k_batch_stats"));
   }
   LossMidArgs LM;
   LM.stats = ws + p->stats; LM.recon_partial = ws + p->recon_partial; LM.n_recon = (int)p->tail_blocks;
