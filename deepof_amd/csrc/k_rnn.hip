@@ -1593,8 +1593,28 @@ struct EncFinalArgs {
   float* dots;      // [S] or null
   int64_t S, Sp;
 };
+// blockIdx.y == 2: the decoder's frame-validity mask and valid-frame counts of the same batch (they depend on the input
+// windows only): one 64-lane group per window, lane = time step -- a launch of its own otherwise.
 template <int C>  // C = 2*H
-__global__ void __launch_bounds__(256) k_enc_final_fwd(EncFinalArgs A0, EncFinalArgs A1, int T) {
+__global__ void __launch_bounds__(256) k_enc_final_fwd(EncFinalArgs A0, EncFinalArgs A1, int T, DofDecValid V) {
+  if (blockIdx.y == 2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float n = 0.0f;
+    if (b < V.B) {
+      for (int t = lane; t < V.T; t += 64) {
+        const float* __restrict__ row = V.x + (b * V.T + t) * V.C3;
+        bool any = false;
+        for (int j = 0; j < V.C3; ++j) any |= (row[j] != 0.0f);
+        V.valid[(int64_t)t * V.Bp + b] = any ? 1.0f : 0.0f;
+        n += any ? 1.0f : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
+    if (b < V.B && lane == 0) V.len[b] = (int)n;
+    return;
+  }
   const EncFinalArgs& A = blockIdx.y ? A1 : A0;
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, Sp = A.Sp;
   if (s >= A.S) return;
@@ -1923,14 +1943,21 @@ int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const f
 // both encoder streams' tails (final GRU2 state -> LayerNorm [-> CensNet dot product]) in one launch
 int dof_launch_enc_final_fwd_pair(int L, const float* const O2[2], const int* const len[2], const float* const gamma[2],
                                   const float* const beta[2], float* const HF[2], float* const Y[2], const float* const cw[2],
-                                  float* const dots[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
+                                  float* const dots[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st,
+                                  const DofDecValid* dec) {
   EncFinalArgs A[2];
   for (int k = 0; k < 2; ++k) {
     A[k].O2 = O2[k]; A[k].len = len[k]; A[k].gamma = gamma[k]; A[k].beta = beta[k]; A[k].HF = HF[k]; A[k].Y = Y[k];
     A[k].cw = cw[k]; A[k].dots = dots[k]; A[k].S = S[k]; A[k].Sp = Sp[k];
   }
-  const unsigned nb = dof_cdiv(S[0] > S[1] ? S[0] : S[1], 256);
-  DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_final_fwd<2 * LL>), (nb, 2), (256), st, A[0], A[1], T));
+  unsigned nb = dof_cdiv(S[0] > S[1] ? S[0] : S[1], 256);
+  DofDecValid V = {};
+  if (dec && dec->x) {
+    V = *dec;
+    const unsigned nv = dof_cdiv(V.B, 4);
+    if (nv > nb) nb = nv;
+  }
+  DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_final_fwd<2 * LL>), (nb, V.x ? 3 : 2), (256), st, A[0], A[1], T, V));
   return dof_check_launch("k_enc_final_fwd");
 }
 

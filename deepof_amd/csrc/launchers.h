@@ -48,9 +48,18 @@ int dof_launch_gru16_wg_finalize(const float* wg_partial, int64_t S, float* g, c
 int64_t dof_ln_bwd_blocks(int T, int64_t S);
 int dof_launch_ln_bwd(int L, int mult, const float* X, const float* dY1, const float* dY2, const float* gamma,
                       float* dX, float* partial, int T, int64_t S, int64_t Sp, hipStream_t st);
+// frame validity [T][Bp] and valid-frame count per window of the decoder, computed in the same launch (third slice of the grid)
+struct DofDecValid {
+  const float* x;  // (B, T, C3) input windows, or null: no third slice
+  int T, C3;
+  int64_t B, Bp;
+  float* valid;
+  int* len;
+};
 int dof_launch_enc_final_fwd_pair(int L, const float* const O2[2], const int* const len[2], const float* const gamma[2],
                                   const float* const beta[2], float* const HF[2], float* const Y[2], const float* const cw[2],
-                                  float* const dots[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st);
+                                  float* const dots[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st,
+                                  const DofDecValid* dec = nullptr);
 int dof_launch_zero(float* p, int64_t n, hipStream_t st);
 int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t n, hipStream_t st);
 

@@ -1364,7 +1364,13 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
     const float* cw[2] = {params + p->c_nw, params + p->c_ew};
     float* dots[2] = {ws + wn.dots, ws + we.dots};
     const int64_t S[2] = {wn.S, we.S}, Sp[2] = {wn.Sp, we.Sp};
-    TRY(dof_launch_enc_final_fwd_pair(L, O2, ln, gm, bt, HF, Y, cw, dots, T, S, Sp, st));
+    // + the decoder's frame-validity mask / lengths of this batch (VaDE / VQ-VAE plans: a function of x alone)
+    DofDecValid dv = {};
+    if (p->kind != 2) {
+      dv.x = x; dv.T = T; dv.C3 = p->C3; dv.B = p->B; dv.Bp = p->Bp; dv.valid = ws + p->valid;
+      dv.len = reinterpret_cast<int*>(ws + p->len_d);
+    }
+    TRY(dof_launch_enc_final_fwd_pair(L, O2, ln, gm, bt, HF, Y, cw, dots, T, S, Sp, st, &dv));
   }
   return censnet_forward(p, params, st, /*dots_done=*/true);
 }
@@ -1598,8 +1604,8 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, const f
   const int L = p->L, T = p->T;
   const int64_t B = p->B, Bp = p->Bp;
   int* len = reinterpret_cast<int*>(ws + p->len_d);
-  DOF_LAUNCH(k_dec_valid_len, (dof_cdiv(B, 4)), (256), st, x, T, p->C3, B, Bp, ws + p->valid, len);
-  TRY(dof_check_launch("k_dec_valid_len"));
+  // (ws.valid / ws.len_d of this batch were left by the encoder's tail launch: every entry point runs encoder_forward on
+  //  the same x first)
   TRY(dof_launch_gru_fwd(L, 2, zin, len, gru_w(params, p->dg1), ws + p->o1d, train ? ws + p->g1d : nullptr, T, B, Bp, st));
   TRY(dof_launch_ln_fwd(L, 2, ws + p->o1d, params + p->dn1w, params + p->dn1b, ws + p->n1d, T, B, Bp, st));
   TRY(dof_launch_gru_fwd(L, 0, ws + p->n1d, len, gru_w(params, p->dg2), ws + p->o2d, train ? ws + p->g2d : nullptr, T, B, Bp, st));
