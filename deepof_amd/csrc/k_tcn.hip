@@ -260,7 +260,17 @@ __device__ __forceinline__ void dof_stat_merge(float& n, float& mean, float& m2,
 // workgroup records partial[nblk][3][32] -> sums = (n mean | M2) per channel, what k_bn_fwd_fin expects of the two-pass
 // statistics.  One workgroup per channel: 256 strided runs merged sequentially (3 records each at 768 workgroups, all
 // loaded before the first merge), then a fixed tree.
-__global__ void __launch_bounds__(256) k_tcn_stat_merge(const float* __restrict__ partial, int nblk, float* __restrict__ sums) {
+// fin (gamma != null): the channel's BatchNorm record and running buffers straight from the merged record -- k_bn_fwd_fin's
+// train branch on (sums[c], sums[C + c]) = (n mean, M2), one launch instead of two per layer.
+struct StatFinArgs {
+  float count;
+  const float *gamma, *beta;
+  float *rmean, *rvar;
+  float momentum;
+  float* bnp;
+};
+__global__ void __launch_bounds__(256) k_tcn_stat_merge(const float* __restrict__ partial, int nblk, float* __restrict__ sums,
+                                                        StatFinArgs F) {
   __shared__ float rn[256], rm[256], rq[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   float n = 0.0f, mean = 0.0f, m2 = 0.0f;
@@ -288,8 +298,54 @@ __global__ void __launch_bounds__(256) k_tcn_stat_merge(const float* __restrict_
     __syncthreads();
   }
   if (tid == 0) {
-    sums[c] = rn[0] * rm[0];
-    sums[TC + c] = rq[0];
+    const float s1 = rn[0] * rm[0], m2 = rq[0];
+    sums[c] = s1;
+    sums[TC + c] = m2;
+    if (F.gamma) {
+      const float mean = s1 / F.count, var = m2 / F.count;
+      F.rmean[c] = (1.0f - F.momentum) * F.rmean[c] + F.momentum * mean;
+      F.rvar[c] = (1.0f - F.momentum) * F.rvar[c] + F.momentum * var * (F.count / fmaxf(F.count - 1.0f, 1.0f));
+      const float rstd = 1.0f / sqrtf(var + 1e-3f);
+      const float scale = F.gamma[c] * rstd;
+      BNP_MEAN(F.bnp, TC, c) = mean;
+      BNP_RSTD(F.bnp, TC, c) = rstd;
+      BNP_SCALE(F.bnp, TC, c) = scale;
+      BNP_SHIFT(F.bnp, TC, c) = F.beta[c] - mean * scale;
+    }
+  }
+}
+
+// Backward twin: the channel sums (sum g | sum g xhat) of a 32-channel layer from its producer's per-workgroup partials
+// ([nblk][64], k_sum_partials' arithmetic for both values of the channel) AND k_bn_bwd_fin's step on them: gamma / beta
+// gradients and the two batch means pass 2 needs -- one launch instead of two per layer.
+__global__ void __launch_bounds__(256) k_bn_bwd_sum_fin(const float* __restrict__ partial, int64_t nblk, float count,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                        float* __restrict__ coef, float* __restrict__ sums) {
+  __shared__ float red[2][256];
+  const int c = blockIdx.x;
+  float a0 = 0.0f, a1 = 0.0f;
+  for (int64_t b = threadIdx.x; b < nblk; b += 256) {
+    a0 += partial[b * 2 * TC + c];
+    a1 += partial[b * 2 * TC + TC + c];
+  }
+  red[0][threadIdx.x] = a0;
+  red[1][threadIdx.x] = a1;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float sg = red[0][0], sgx = red[1][0];
+    sums[c] = sg;
+    sums[TC + c] = sgx;
+    dbeta[c] = accumulate ? dbeta[c] + sg : sg;
+    dgamma[c] = accumulate ? dgamma[c] + sgx : sgx;
+    coef[c] = sg / count;
+    coef[TC + c] = sgx / count;
   }
 }
 
@@ -1243,9 +1299,24 @@ int dof_tcn_stat_records() {
   return on;
 }
 int dof_launch_tcn_stat_merge(const float* partial, int64_t nblk, float* sums, hipStream_t st) {
-  DOF_LAUNCH(k_tcn_stat_merge, (TC), (256), st, partial, (int)nblk, sums);
+  StatFinArgs F = {};
+  DOF_LAUNCH(k_tcn_stat_merge, (TC), (256), st, partial, (int)nblk, sums, F);
   return dof_check_launch("k_tcn_stat_merge");
 }
+// ... and the layer's BatchNorm record + running buffers (train mode) in the same launch
+int dof_launch_tcn_stat_merge_fin(const float* partial, int64_t nblk, float* sums, float count, const float* gamma,
+                                  const float* beta, float* rmean, float* rvar, float momentum, float* bnp, hipStream_t st) {
+  StatFinArgs F;
+  F.count = count; F.gamma = gamma; F.beta = beta; F.rmean = rmean; F.rvar = rvar; F.momentum = momentum; F.bnp = bnp;
+  DOF_LAUNCH(k_tcn_stat_merge, (TC), (256), st, partial, (int)nblk, sums, F);
+  return dof_check_launch("k_tcn_stat_merge_fin");
+}
+int dof_launch_bn_bwd_sum_fin(const float* partial, int64_t nblk, float* sums, float count, float* dgamma, float* dbeta,
+                              int accumulate, float* coef, hipStream_t st) {
+  DOF_LAUNCH(k_bn_bwd_sum_fin, (TC), (256), st, partial, nblk, count, dgamma, dbeta, accumulate, coef, sums);
+  return dof_check_launch("k_bn_bwd_sum_fin");
+}
+int64_t dof_tcn_bn_bwd1_blocks(int T, int64_t S) { return (int64_t)dof_cdiv(S, 256) * T; }
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
   return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(Sp) : dof_tcn_conv_waves(T, Sp);
 }
@@ -1316,7 +1387,7 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
       DOF_LAUNCH((k_tcn_conv_t<true, false, true, false>), (nbt), (256), st, A);
     }
     if (int rc = dof_check_launch("k_tcn_conv_t_bwd_bn")) return rc;
-    return dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st);
+    return sums ? dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st) : DOF_OK;
   }
   if (bwd_y) {
     dof_set_error("k_tcn_conv_bwd_bn: the fused BatchNorm-backward pass needs the time-resident kernel (T <= %d)", TCT_T);
@@ -1384,7 +1455,7 @@ int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y
   const unsigned nbt = tct_blocks(Sp);
   DOF_LAUNCH((k_tcn_conv_t<true, false, true, true, true>), (nbt), (256), st, A);
   if (int rc = dof_check_launch("k_tcn_conv_t_tail")) return rc;
-  return dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st);
+  return sums ? dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st) : DOF_OK;
 }
 
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
@@ -1422,7 +1493,7 @@ int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, f
   const unsigned nbx = dof_cdiv(S, 256);
   DOF_LAUNCH(k_tcn_bn_bwd1_w, (nbx, (unsigned)T), (256), st, A);
   if (int rc = dof_check_launch("k_tcn_bn_bwd1_w")) return rc;
-  return dof_launch_sum_partials(partial, (int64_t)nbx * T, 2 * CT, sums, 0, st);
+  return sums ? dof_launch_sum_partials(partial, (int64_t)nbx * T, 2 * CT, sums, 0, st) : DOF_OK;
 }
 
 int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int CT, int64_t S,

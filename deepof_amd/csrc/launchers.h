@@ -82,6 +82,11 @@ int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const floa
                         int stat_records = 0);
 int dof_tcn_stat_records();
 int dof_launch_tcn_stat_merge(const float* partial, int64_t nblk, float* sums, hipStream_t st);
+int dof_launch_tcn_stat_merge_fin(const float* partial, int64_t nblk, float* sums, float count, const float* gamma,
+                                  const float* beta, float* rmean, float* rvar, float momentum, float* bnp, hipStream_t st);
+int dof_launch_bn_bwd_sum_fin(const float* partial, int64_t nblk, float* sums, float count, float* dgamma, float* dbeta,
+                              int accumulate, float* coef, hipStream_t st);
+int64_t dof_tcn_bn_bwd1_blocks(int T, int64_t S);
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
                             int T, int CT, int64_t S, int64_t Sp, hipStream_t st, const float* shift = nullptr);
 int dof_tcn_combine_fold();

@@ -1418,18 +1418,26 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
         nrows = dof_tcn_conv32_partials(T, w.Sp);
       }
       const float* sh1 = (sh_on(2 * b) && b > 0) ? params + o.rm1 : nullptr;
-      if (train && recs && b > 0) TRY(dof_launch_tcn_stat_merge(ws + t.partial, nrows, ws + t.sums, st));
-      else if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh1));
-      TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
-                                train, ws + t.bnp[2 * b], 32, st, sh1 != nullptr));
+      if (train && recs && b > 0) {  // records -> statistics -> BatchNorm record + running buffers: one launch
+        TRY(dof_launch_tcn_stat_merge_fin(ws + t.partial, nrows, ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1,
+                                          params + o.rv1, 0.1f, ws + t.bnp[2 * b], st));
+      } else {
+        if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y1[b], ws + t.partial, nrows, 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh1));
+        TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1, params + o.rv1, 0.1f,
+                                  train, ws + t.bnp[2 * b], 32, st, sh1 != nullptr));
+      }
       const float* sh2 = sh_on(2 * b + 1) ? params + o.rm2 : nullptr;
       TRY(dof_launch_tcn_conv(0, ws + t.y1[b], params + o.c2w, params + o.c2b, ws + t.bnp[2 * b],
                               t.lazy ? nullptr : ws + t.a1[b], ws + t.y2[b], ws + t.partial, 0, T, d, w.S, w.Sp, st,
                               nullptr, nullptr, nullptr, sh2, 1, recs));
-      if (train && recs) TRY(dof_launch_tcn_stat_merge(ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), ws + t.sums, st));
-      else if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh2));
-      TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
-                                train, ws + t.bnp[2 * b + 1], 32, st, sh2 != nullptr));
+      if (train && recs) {
+        TRY(dof_launch_tcn_stat_merge_fin(ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), ws + t.sums, count, params + o.g2,
+                                          params + o.b2, params + o.rm2, params + o.rv2, 0.1f, ws + t.bnp[2 * b + 1], st));
+      } else {
+        if (train) TRY(dof_launch_tcn_bn_stats(ws + t.y2[b], ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), 64, ws + t.sums, count, T, 32, w.S, w.Sp, st, sh2));
+        TRY(dof_launch_bn_fwd_fin(ws + t.sums, count, params + o.g2, params + o.b2, params + o.rm2, params + o.rv2, 0.1f,
+                                  train, ws + t.bnp[2 * b + 1], 32, st, sh2 != nullptr));
+      }
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
                                  b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb,
                                  (b < 7 && !(comb && b >= 1)) ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr,
@@ -1723,34 +1731,39 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
       const int d = kTcnDil[b];
       float* dprev = ws + t.dout[(b + 1) & 1];  // gradient of the previous block's output (this block's input)
       // BN2 + ReLU + block tail
-      if (!tail_done)
+      // (the producers leave per-workgroup partials; their reduction and the BatchNorm gradient step share one launch)
+      int64_t nb2 = dof_tcn_conv32_partials(T, w.Sp);  // partial rows of BN2's sums: the previous block's TAIL convolution ...
+      if (!tail_done) {
         TRY(dof_launch_tcn_bn_bwd1(b == 7 ? nullptr : ws + t.dout[b & 1], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.g2[b],
-                                   ws + t.partial, ws + t.sums, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip,
+                                   ws + t.partial, nullptr, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip,
                                    nullptr, dprev, T, 32, w.S, w.Sp, st));
+        nb2 = dof_tcn_bn_bwd1_blocks(T, w.S);  // ... or k_tcn_bn_bwd1_w's
+      }
       tail_done = false;
       float* coef2 = ws + (t.lazy ? t.coefs[2 * b + 1] : t.coef);
       float* coef1 = ws + (t.lazy ? t.coefs[2 * b] : t.coef);
-      TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, coef2, 32, st));
+      TRY(dof_launch_bn_bwd_sum_fin(ws + t.partial, nb2, ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, coef2, st));
       // conv2's data gradient with BN1 + ReLU's first backward pass in its epilogue; the time-resident kernel also
       // applies pass 2 of BN2's backward while it stages g2 (lazy: the weight-gradient kernel does the same on load;
       // otherwise written back in place for it)
       if (fuse2) {
         TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
-                                       ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st, ws + t.y2[b],
+                                       ws + t.partial, nullptr, T, d, w.S, w.Sp, st, ws + t.y2[b],
                                        ws + t.bnp[2 * b + 1], coef2, t.lazy ? 0 : 1));
       } else {
         TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], coef2, T, 32, w.S, w.Sp, st));
         TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
-                                       ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st));
+                                       ws + t.partial, nullptr, T, d, w.S, w.Sp, st));
       }
-      TRY(dof_launch_bn_bwd_fin(ws + t.sums, count, grads + o.g1, grads + o.b1, accumulate, coef1, 32, st));
+      TRY(dof_launch_bn_bwd_sum_fin(ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), ws + t.sums, count, grads + o.g1, grads + o.b1,
+                                    accumulate, coef1, st));
       if (fuse2 && b > 0 && dof_tcn_tail_fold()) {
         // ... and the backward of block b - 1's tail + the first pass of its BatchNorm2 in the epilogue: dprev holds
         // this block's residual-branch gradient, the sum is the gradient at block b - 1's output (never written);
         // its masked form goes to block b - 1's own dprev (this block's din buffer, free by now)
         TRY(dof_launch_tcn_conv_tail(ws + t.g1[b], params + o.c1w, ws + t.y1[b], ws + t.bnp[2 * b], coef1, t.lazy ? 0 : 1, dprev,
                                      ws + t.out[b - 1], ws + t.dout[b & 1], ws + t.skip, ws + w.dn2, ws + t.y2[b - 1],
-                                     ws + t.bnp[2 * b - 1], ws + t.g2[b - 1], ws + t.partial, ws + t.sums, T, d, w.S, w.Sp, st));
+                                     ws + t.bnp[2 * b - 1], ws + t.g2[b - 1], ws + t.partial, nullptr, T, d, w.S, w.Sp, st));
         tail_done = true;
       } else if (fuse2 && b > 0) {  // pass 2 of BN1's backward inside conv1's data gradient
         TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
