@@ -1542,7 +1542,7 @@ __global__ void __launch_bounds__(256, 6) k_tcn_wgrad(const DofTcnWgrad* __restr
   __shared__ float sx[DOF_TCN_WGRAD_MAX_T][NSEQ][33];
   __shared__ float sd[DOF_TCN_WGRAD_MAX_T][NSEQ][33];
   const DofTcnWgrad D = descs[blockIdx.y];
-  if ((int)blockIdx.x >= D.nblk) return;
+  if ((int)blockIdx.x >= D.nblk || D.cin != 0) return;
   const int T = D.T;
   const int64_t Sp = D.Sp;
   const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
@@ -1657,7 +1657,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __re
   __shared__ __attribute__((aligned(16))) uint16_t sd16[3][32][WB_DSTR];
   __shared__ __attribute__((aligned(16))) uint16_t sx16[3][32][WB_XSTR];
   const DofTcnWgrad D = descs[blockIdx.y];
-  if ((int)blockIdx.x >= D.nblk) return;
+  if ((int)blockIdx.x >= D.nblk || D.cin != 0) return;
   const int T = D.T;
   const int64_t Sp = D.Sp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1776,6 +1776,96 @@ __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The first block's weight gradients (round 3): conv1 reads the raw input (3 or 1 channels per sequence, dilation 1) and
+// the block's residual branch is a 1 x 1 convolution of the same input.  Through the generic reduction they cost a pass
+// that normalises conv1's gradient in place (k_tcn_bn_bwd2) plus k_outer's operand stream over two 32-channel gradient
+// tensors.  Here thread (channel o, sequence s) walks the T steps of its sequence: its own element of the two gradient
+// rows straight from HBM (a half-wave reads one 128-byte row; pass 2 of BatchNorm1's backward applied on load, like
+// k_tcn_wgrad), the input row as a half-wave broadcast kept in a four-step register window, and the (4 taps + 1) x cin
+// outer products on the vector pipe (a 32 x 15 result does not need the matrix pipe).  No LDS staging, so occupancy is
+// register-bound and the loads of several steps are in flight; the sixteen sequence groups of a workgroup are added in a
+// fixed order into partial tiles of k_outer's layout.
+template <int F>
+__device__ __forceinline__ void tcn_wgrad_in_body(const DofTcnWgrad& D, float* __restrict__ partials, float* red) {
+  constexpr int NV = 5 * F + 2;  // values per channel: 4 F conv taps, conv bias, F residual weights, its bias
+  constexpr int NG = 16;         // sequence groups (half-waves) per workgroup
+  const int T = D.T, tid = threadIdx.x;
+  const int64_t Sp = D.Sp;
+  const int o = tid & 31, g = tid >> 5;
+  float ka = 1.0f, kb = 0.0f, kc = 0.0f, bm = 0.0f;
+  const bool lazy = D.dy_y != nullptr, two = D.dy2 != nullptr;
+  if (lazy) {  // dy = scale (g - c1 - (y - mean) rstd c2) = ka g + kb (y - mean) + kc
+    bm = D.dy_bnp[o];
+    ka = D.dy_bnp[2 * 32 + o];
+    kb = -ka * D.dy_bnp[32 + o] * D.dy_coef[32 + o];
+    kc = -ka * D.dy_coef[o];
+  }
+  float acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0f;
+  for (int64_t s = (int64_t)blockIdx.x * NG + g; s < Sp; s += (int64_t)D.nblk * NG) {
+    const bool valid = s < D.S;
+    float xw[4][F];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int f = 0; f < F; ++f) xw[j][f] = 0.0f;
+#pragma unroll 5
+    for (int t = 0; t < T; ++t) {
+      const int64_t row = (int64_t)t * Sp + s;
+      float a = D.dy[row * 32 + o];
+      if (lazy) {
+        const float y = D.dy_y[row * 32 + o];
+        a = valid ? fmaf(ka, a, fmaf(kb, y - bm, kc)) : 0.0f;
+      }
+      const float b2 = two ? D.dy2[row * 32 + o] : 0.0f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        xw[0][f] = xw[1][f];
+        xw[1][f] = xw[2][f];
+        xw[2][f] = xw[3][f];
+        xw[3][f] = D.in[row * F + f];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[j * F + f] = fmaf(a, xw[j][f], acc[j * F + f]);
+      acc[4 * F] += a;
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[4 * F + 1 + f] = fmaf(b2, xw[3][f], acc[4 * F + 1 + f]);
+      acc[5 * F + 1] += b2;
+    }
+  }
+  // the sequence groups of the workgroup, added in group order
+#pragma unroll
+  for (int v = 0; v < NV; ++v) red[(g * 32 + o) * NV + v] = acc[v];
+  __syncthreads();
+  float* p0 = partials + D.part0 + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+  float* p1 = partials + D.part1 + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+  for (int e = tid; e < 32 * NV; e += 512) {
+    const int oo = e / NV, v = e - oo * NV;
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) sum += red[(k * 32 + oo) * NV + v];
+    if (v < 4 * F) p0[oo * 65 + (v / F) * 16 + (v % F)] = sum;
+    else if (v == 4 * F) p0[oo * 65 + 64] = sum;
+    else if (two) {
+      if (v < 5 * F + 1) p1[oo * 65 + (v - 4 * F - 1)] = sum;
+      else p1[oo * 65 + 64] = sum;
+    }
+  }
+}
+
+// both streams' descriptors in one launch (node: 3 input channels, edge: 1), so that the two fill the chip together
+__global__ void __launch_bounds__(512) k_tcn_wgrad_in(const DofTcnWgrad* __restrict__ descs, float* __restrict__ partials) {
+  __shared__ float red[16 * 32 * 17];
+  const DofTcnWgrad D = descs[blockIdx.y];
+  if ((int)blockIdx.x >= D.nblk) return;
+  if (D.cin == 3) tcn_wgrad_in_body<3>(D, partials, red);
+  else if (D.cin == 1) tcn_wgrad_in_body<1>(D, partials, red);
+}
+
 }  // namespace
 
 // DOF_TCN_WGRAD_FP32=1: the fp32-MFMA kernel (A/B measurements)
@@ -1792,6 +1882,12 @@ int dof_launch_tcn_wgrad(const DofTcnWgrad* descs_dev, int n, int max_nblk, floa
   if (dof_tcn_wgrad_fp32()) DOF_LAUNCH((k_tcn_wgrad<4>), ((unsigned)max_nblk, (unsigned)n), (256), st, descs_dev, partials);
   else DOF_LAUNCH(k_tcn_wgrad_b3, ((unsigned)max_nblk, (unsigned)n), (256), st, descs_dev, partials);
   return dof_check_launch("k_tcn_wgrad");
+}
+// the descriptors with cin = 3 / 1 (first blocks) among the same table: n_in of them, after the 32-channel ones
+int dof_launch_tcn_wgrad_in(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st) {
+  if (n <= 0) return DOF_OK;
+  DOF_LAUNCH(k_tcn_wgrad_in, ((unsigned)max_nblk, (unsigned)n), (512), st, descs_dev, partials);
+  return dof_check_launch("k_tcn_wgrad_in");
 }
 
 int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st) {

@@ -128,9 +128,15 @@ struct DofTcnWgrad {
   int64_t Sp;
   int64_t S;  // valid sequences (lazy dy: rows of padded sequences are zero gradients, not pass 2 of a zero)
   int64_t part0, part1;  // float offsets of the two jobs' partial regions ([nblk][64][65] each)
+  // cin > 0 (k_tcn_wgrad_in, the first block): `in` is the raw input [T][Sp][cin] (cin = 3 or 1), part0 = the conv1 job's
+  // region (tap j in columns 16 j .. 16 j + cin - 1, bias sums in column 64); dy2 != null: the gradient entering the
+  // block's 1x1 residual convolution, whose weight / bias gradient goes to part1 (columns 0 .. cin - 1, 64)
+  int cin;
+  const float* dy2;
 };
 #define DOF_TCN_WGRAD_MAX_T 25
 int dof_launch_tcn_wgrad(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st);
+int dof_launch_tcn_wgrad_in(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st);
 int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st);
 int dof_launch_head_dense(const float* in, const float* bnp_in, float* in_norm, const float* w, const float* bias,
                           float* out, float* partial, float* sums, int CI, int CO, int relu, int64_t B, int64_t Bp,

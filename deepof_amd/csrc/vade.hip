@@ -88,6 +88,7 @@ struct TcnWs {  // float offsets of one stream's TCN buffers ([T][Sp][32] unless
   int64_t partial, sums, coef;
   int64_t coefs[16];                    // per-layer (mean g | mean g xhat): read again by the lazy weight-gradient operands
   int lazy;                             // 1: BatchNorm-backward pass 2 and the conv2 input activation are applied on load
+  int first_staged;                     // 1: block 0's weight gradients come from k_tcn_wgrad_in (lazy conv1 gradient)
   int64_t partial_rows;
 };
 
@@ -158,6 +159,7 @@ struct JobSet {  // one launch of the MFMA weight-gradient reduction + its final
   std::vector<DofFinJob> fins;
   std::vector<DofTcnWgrad> wgrads;  // TCN convolutions whose partial tiles come from k_tcn_wgrad instead of k_outer
   int total_blocks = 0, fin_elems = 0, wg_blocks = 0;
+  bool wg_first = false;  // some descriptors are first-block ones (k_tcn_wgrad_in)
   int64_t jobs_tab = 0, fin_tab = 0, wg_tab = 0;  // workspace offsets of the uploaded tables
 };
 
@@ -539,6 +541,10 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     // BatchNorm backward and conv2's input activation are recomputed where they are read, so neither the normalised
     // gradients nor the activated tensors a1 are ever written (8 x [T][Sp][32] per stream less)
     t.lazy = (dof_tcn_conv32_resident(T, Sp) && T <= DOF_TCN_WGRAD_MAX_T) ? 1 : 0;
+    {  // DOF_TCN_WGRAD_IN=0: block 0 through the generic reduction (A/B measurements)
+      const char* e = getenv("DOF_TCN_WGRAD_IN");
+      t.first_staged = (t.lazy && (p->sw[s].F == 3 || p->sw[s].F == 1) && !(e && e[0] == '0')) ? 1 : 0;
+    }
     t.xs = cv.take((int64_t)T * Sp * w.F);
     for (int b = 0; b < 8; ++b) {
       t.y1[b] = cv.take(act); t.a1[b] = t.lazy ? 0 : cv.take(act); t.y2[b] = cv.take(act);
@@ -906,6 +912,7 @@ void build_tcn_jobs(DofVadePlan* p) {
   JobBuilder jb(p->js_enc);
   p->js_enc.wgrads.clear();
   p->js_enc.wg_blocks = 0;
+  p->js_enc.wg_first = p->tw[0].first_staged || p->tw[1].first_staged;
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
     const TcnWs& t = p->tw[s];
@@ -920,12 +927,15 @@ void build_tcn_jobs(DofVadePlan* p) {
         int job = -1;
         bool bias_done = false;
         // 32 -> 32 convolutions: the partial tiles of the two jobs come from k_tcn_wgrad (LDS-staged operands)
-        const bool staged = cin == C && T <= DOF_TCN_WGRAD_MAX_T;
-        const int ext = staged ? (int)(Sp / 8 < 448 ? Sp / 8 : 448) : 0;
+        const bool first = cin < C && d == 1 && t.first_staged;  // block 0: one job of four tap tiles, from k_tcn_wgrad_in
+        const bool staged = (cin == C && T <= DOF_TCN_WGRAD_MAX_T) || first;
+        // (first: 256 workgroups of 8 waves per stream = the 4 waves per SIMD its registers allow, both streams resident)
+        const int ext = first ? (int)(Sp / 16 < 1 ? 1 : Sp / 16 < 256 ? Sp / 16 : 256) : staged ? (int)(Sp / 8 < 448 ? Sp / 8 : 448) : 0;
         if (staged) {
           DofTcnWgrad g;
           memset(&g, 0, sizeof(g));
           g.dy = dy; g.in = in; g.dil = d; g.nblk = ext; g.T = T; g.Sp = Sp; g.S = w.S;
+          g.cin = first ? cin : 0;
           if (t.lazy) {
             g.dy_y = ws + (layer & 1 ? t.y2[layer >> 1] : t.y1[layer >> 1]);
             g.dy_bnp = ws + t.bnp[layer];
@@ -951,7 +961,13 @@ void build_tcn_jobs(DofVadePlan* p) {
       conv(ws + t.g1[b], b == 0 ? ws + t.xs : ws + t.out[b - 1], b == 0 ? w.F : C, o.c1w, o.c1b, 2 * b, -1);
       conv(ws + t.g2[b], t.lazy ? ws + t.y1[b] : ws + t.a1[b], C, o.c2w, o.c2b, 2 * b + 1, 2 * b);
       if (b == 0) {  // 1x1 residual conv: A = gradient entering the residual branch of block 0 (left in dout[1])
-        const int job = jb.add_job(aos(ws + t.dout[1], C, Sp), C, T, Sp);
+        // (first_staged: block 0's conv1 descriptor is the one before conv2's)
+        DofTcnWgrad* g0 = t.first_staged ? &p->js_enc.wgrads[p->js_enc.wgrads.size() - 2] : nullptr;
+        const int job = jb.add_job(aos(ws + t.dout[1], C, Sp), C, T, Sp, g0 ? g0->nblk : 0);
+        if (g0) {
+          g0->dy2 = ws + t.dout[1];
+          g0->part1 = jb.jobs[job].partial_off;
+        }
         const int tl = jb.add_tile(job, aos(ws + t.xs, w.F, Sp), w.F, 0);
         jb.add_fin(job, tl * 16, C, w.F, C, C, o.dsw, w.F, 1);
         jb.add_fin(job, 64, C, 1, C, C, o.dsb, 1, 1);
@@ -1173,6 +1189,9 @@ int run_jobset(DofVadePlan* p, const JobSet& js, float* dst, int accumulate, hip
   TRY(dof_launch_outer(jobs, (int)js.jobs.size(), js.total_blocks, p->ws + p->partials, st));
   TRY(dof_launch_tcn_wgrad(reinterpret_cast<const DofTcnWgrad*>(p->ws + js.wg_tab), (int)js.wgrads.size(), js.wg_blocks,
                            p->ws + p->partials, st));
+  if (js.wg_first)
+    TRY(dof_launch_tcn_wgrad_in(reinterpret_cast<const DofTcnWgrad*>(p->ws + js.wg_tab), (int)js.wgrads.size(), js.wg_blocks,
+                                p->ws + p->partials, st));
   return dof_launch_outer_finalize(jobs, fins, (int)js.fins.size(), js.fin_elems, p->ws + p->partials, dst, accumulate, st);
 }
 
@@ -1768,6 +1787,7 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
       } else if (fuse2 && b > 0) {  // pass 2 of BN1's backward inside conv1's data gradient
         TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,
                                 w.Sp, st, ws + t.y1[b], ws + t.bnp[2 * b], coef1, nullptr, t.lazy ? 0 : 1));
+      } else if (b == 0 && t.first_staged) {  // k_tcn_wgrad_in normalises block 0's conv1 gradient on load
       } else {  // block 0's conv1 gradient goes through the generic reduction: normalised gradient in place
         TRY(dof_launch_tcn_bn_bwd2(ws + t.g1[b], ws + t.y1[b], ws + t.bnp[2 * b], coef1, T, 32, w.S, w.Sp, st));
         if (b > 0)
