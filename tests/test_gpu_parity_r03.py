@@ -259,10 +259,10 @@ def test_gru16_matrix_pipe_kernels_gpu():
 
 
 @pytest.mark.parametrize("switch", ["DOF_TCN_WGRAD_FP32=1", "DOF_TCN_TAIL_FOLD=0", "DOF_TCN_COMBINE_FOLD=0",
-                                    "DOF_TCN_STAT_RECORDS=0", "DOF_TCN_ONEPASS=1"])
+                                    "DOF_TCN_STAT_RECORDS=0", "DOF_TCN_ONEPASS=1", "DOF_TCN_WGRAD_IN=0"])
 def test_tcn_kernel_switches_gpu(switch):
     """The round-3 TCN kernels (bf16-pipe weight gradients, block-tail backward / forward folded into the neighbouring
-    convolutions, batch statistics as mergeable records) and the kernels they replace -- incl. the centred second pass and
+    convolutions, batch statistics as mergeable records, the first block's direct-load weight gradients) and the kernels they replace -- incl. the centred second pass and
     round 2's shifted one-pass sums -- meet the SAME reference check: a B = 64 VaDE-TCN golden with the explicit ReLU-flip
     attribution (the statistics switches on the fixture whose running means equal the batch means, where every channel takes
     the shifted one-pass form), run in a child process per switch (the switches are read once per process)."""
