@@ -132,7 +132,7 @@ def _time_steps(one_step, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def vade_stepper_setup(ids, T, K, B, encoder_type, frames, dev, rank=0, use_graphs=None):
+def vade_stepper_setup(ids, T, K, B, encoder_type, frames, dev, rank=0, use_graphs=None, latent=8):
     """VaDE through deepof_amd.training.VadeStepper in the main phase with distillation, as fit_VADE configures it
     (training.py:1643-1755 of the reference): lr after epoch 0 = 5e-4 / 2e-4, KL weight tf_sigmoid warm-up 5 epochs -> 1,
     lambda 4 held 10 epochs.  Returns (stepper, model, dataset, batch starts, tables)."""
@@ -145,7 +145,7 @@ def vade_stepper_setup(ids, T, K, B, encoder_type, frames, dev, rank=0, use_grap
     from deepof_amd._lib import load_hip_library
     lib = load_hip_library()
     ds, adj, nodes, edges, tn, te = _device_dataset(ids, T, frames, 2, rank, dev, lib)
-    N, E, L = len(nodes), len(edges), 8
+    N, E, L = len(nodes), len(edges), latent
     torch.manual_seed(0)
     model = VaDE((T, N, 3), (T, E, 1), adj, L, K, encoder_type=encoder_type, kmeans_loss=1.0, batch_size=B, device=dev)
     eng = model._base
@@ -177,9 +177,9 @@ def vade_stepper_setup(ids, T, K, B, encoder_type, frames, dev, rank=0, use_grap
     return stepper, model, ds, starts, (tn, te), tau_star
 
 
-def run_vade_product(ids, T, K, B, encoder_type, steps, warmup, frames=100_000, window_storage="fp32"):
+def run_vade_product(ids, T, K, B, encoder_type, steps, warmup, frames=100_000, window_storage="fp32", latent=8):
     dev = torch.device("cuda")
-    stepper, model, ds, starts, _tabs, _tau = vade_stepper_setup(ids, T, K, B, encoder_type, frames, dev)
+    stepper, model, ds, starts, _tabs, _tau = vade_stepper_setup(ids, T, K, B, encoder_type, frames, dev, latent=latent)
     ds.window_storage = window_storage   # "bf16": batches gathered as bf16 and widened for the fp32 step kernels
 
     def one_step(i):
@@ -283,7 +283,9 @@ def secondary_configs(steps=12, warmup=6):
             ("C2 shape, VaDE transformer encoder/decoder (dropout on), batch 1024",
              lambda: run_vade_product([""], 25, 10, 1024, "transformer", steps, warmup), 1024),
             ("C2 with bf16 window storage (BASELINE configs[1]: batches gathered as bf16, fp32 arithmetic), batch 1024",
-             lambda: run_vade_product([""], 25, 10, 1024, "recurrent", 4 * steps, warmup, window_storage="bf16"), 1024)]
+             lambda: run_vade_product([""], 25, 10, 1024, "recurrent", 4 * steps, warmup, window_storage="bf16"), 1024),
+            ("C2 at latent 16 (GRU(32,32) / GRU(64->16) streams on the generic per-sequence kernels), batch 1024",
+             lambda: run_vade_product([""], 25, 10, 1024, "recurrent", steps, warmup, latent=16), 1024)]
     for name, fn, B in plan:
         try:
             sec, loss, path = fn()

@@ -158,7 +158,7 @@ _SIMS = ("cosine", "dot", "euclidean", "edit")
 _LOSSES = ("nce", "dcl", "dlc", "fc", "hard_dcl")  # the reference accepts the "dlc" typo; both spellings work here (Q13)
 
 
-SUPPORTED_LATENT_DIMS = (4, 6, 8)
+SUPPORTED_LATENT_DIMS = (4, 6, 8, 16)
 MAX_CONTRASTIVE_NODES = 64
 TRANSFORMER_KEY_DIMS = (24, 32, 40, 48, 64)
 

@@ -379,16 +379,17 @@ __global__ void __launch_bounds__(256) k_dec_conv_bwd_w(const float* __restrict_
 }
 
 // TCN decoder, block 0: gradient of the 1x1 residual conv (4L -> 64) back to the repeated input,
-// dzrep[t][b][f] += sum_c dsw[c][f] * gres[t][b][c]   (zrep is [T][Bp][32], gres [T][Bp][64])
+// dzrep[t][b][f] += sum_c dsw[c][f] * gres[t][b][c]   (zrep is [T][Bp][ZC], ZC = 32 or 64; gres [T][Bp][64])
 __global__ void __launch_bounds__(256) k_dec_ds_bwd(const float* __restrict__ gres, const float* __restrict__ dsw,
-                                                    float* __restrict__ dzrep, int C4, int T, int64_t B, int64_t Bp) {
+                                                    float* __restrict__ dzrep, int C4, int ZC, int T, int64_t B,
+                                                    int64_t Bp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)T * B) return;
   const int t = (int)(i / B);
   const int64_t b = i - (int64_t)t * B;
   float g[64];
   dof_ld_row<64>(gres + ACT(t, 0, 64, Bp, b), g);
-  float* o = dzrep + ACT(t, 0, 32, Bp, b);
+  float* o = dzrep + ACT(t, 0, ZC, Bp, b);
   for (int f = 0; f < C4; ++f) {
     float acc = o[f];
 #pragma unroll

@@ -936,28 +936,34 @@ __global__ void k_loss_mid(LossMidArgs A) {
     const float den = fmaxf(1e-9f, 2.0f * ls * ls);
     const float norm = (float)(K * K - K > 1 ? K * K - K : 1);
     float ksum = 0.0f;
-    for (int c = lane; c < K; c += 64) {
-      const float pc = mass(c);
-      float acc[8];
+    auto rows = [&](auto lp_c) {  // LP = register width of a latent vector (8 up to latent 8, else 16 / 64)
+      constexpr int LP = decltype(lp_c)::value;
+      for (int c = lane; c < K; c += 64) {
+        const float pc = mass(c);
+        float acc[LP];
 #pragma unroll
-      for (int d = 0; d < 8; ++d) acc[d] = 0.0f;
-      for (int e = 0; e < K; ++e) {
-        if (e == c) continue;
-        float d2 = 0.0f, df[8];
+        for (int d = 0; d < LP; ++d) acc[d] = 0.0f;
+        for (int e = 0; e < K; ++e) {
+          if (e == c) continue;
+          float d2 = 0.0f, df[LP];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          df[d] = d < L ? cen(c, d) - cen(e, d) : 0.0f;
-          d2 += df[d] * df[d];
+          for (int d = 0; d < LP; ++d) {
+            df[d] = d < L ? cen(c, d) - cen(e, d) : 0.0f;
+            d2 += df[d] * df[d];
+          }
+          const float kv = expf(-d2 / den);
+          ksum += kv;
+#pragma unroll
+          for (int d = 0; d < LP; ++d) acc[d] += (rw / norm) * 2.0f * kv * (-2.0f * df[d] / den) / pc;
         }
-        const float kv = expf(-d2 / den);
-        ksum += kv;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) acc[d] += (rw / norm) * 2.0f * kv * (-2.0f * df[d] / den) / pc;
+        for (int d = 0; d < LP; ++d)
+          if (d < L) A.dcen[c * L + d] = acc[d];
       }
-#pragma unroll
-      for (int d = 0; d < 8; ++d)
-        if (d < L) A.dcen[c * L + d] = acc[d];
-    }
+    };
+    if (L <= 8) rows(std::integral_constant<int, 8>{});
+    else if (L <= 16) rows(std::integral_constant<int, 16>{});
+    else rows(std::integral_constant<int, 64>{});
     repel = rw * dof_wave_sum(ksum) / norm;
   } else {
     for (int i = lane; i < K * L; i += 64) A.dcen[i] = 0.0f;

@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
   if (A.res) {
     dof_ld_row<4>(A.res + off, r);
   } else {
-    float xin[32];
+    float xin[64];
     for (int f = 0; f < A.F; ++f) xin[f] = A.xs[ACT(t, f, A.xs_ch, A.Sp, s)];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1148,34 +1148,38 @@ __global__ void __launch_bounds__(256) k_head_rms_bwd(const float* __restrict__ 
 // TCN decoder ends (models_new.py:713-819): repeat the normalised latent features over time; output head
 // ---------------------------------------------------------------------------------------------
 // zrep[t][b][c] = BN2(d2)[c][b] for every t (channels c >= C4 are zero padding up to 32)
+template <int ZC>  // channels per zrep row: 32 (4 L <= 32) or 64 (latent 16)
 __global__ void __launch_bounds__(256) k_dec_repeat(const float* __restrict__ d2, const float* __restrict__ bnp,
                                                     float* __restrict__ zrep, int C4, int T, int64_t B, int64_t Bp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)T * B) return;
   const int t = (int)(i / B);
   const int64_t b = i - (int64_t)t * B;
-  float row[TC];
+  float row[ZC];
 #pragma unroll
-  for (int c = 0; c < TC; ++c)
+  for (int c = 0; c < ZC; ++c)
     row[c] = c < C4 ? BN_APPLY(bnp, C4, c, d2[(int64_t)c * Bp + b]) : 0.0f;
-  dof_st_row<TC>(zrep + ACT(t, 0, TC, Bp, b), row);
+  dof_st_row<ZC>(zrep + ACT(t, 0, ZC, Bp, b), row);
 }
 
 // dzf[c][b] = sum_t dzrep[t][b][c]
+template <int ZC>
 __global__ void __launch_bounds__(256) k_dec_sum_time(const float* __restrict__ dzrep, float* __restrict__ dzf, int C4,
                                                       int T, int64_t B, int64_t Bp) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  float acc[TC];
+  float acc[ZC];
 #pragma unroll
-  for (int c = 0; c < TC; ++c) acc[c] = 0.0f;
+  for (int c = 0; c < ZC; ++c) acc[c] = 0.0f;
   for (int t = 0; t < T; ++t) {
-    float row[TC];
-    dof_ld_row<TC>(dzrep + ACT(t, 0, TC, Bp, b), row);
+    float row[ZC];
+    dof_ld_row<ZC>(dzrep + ACT(t, 0, ZC, Bp, b), row);
 #pragma unroll
-    for (int c = 0; c < TC; ++c) acc[c] += row[c];
+    for (int c = 0; c < ZC; ++c) acc[c] += row[c];
   }
-  for (int c = 0; c < C4; ++c) dzf[(int64_t)c * Bp + b] = acc[c];
+#pragma unroll
+  for (int c = 0; c < ZC; ++c)
+    if (c < C4) dzf[(int64_t)c * Bp + b] = acc[c];
 }
 
 // hidden = ReLU(skip-sum) at every step -> loc = Linear(64 -> 3N) -> unit-variance Normal log-prob on valid
@@ -1932,12 +1936,14 @@ int dof_launch_head_rms_bwd(const float* dhn, const float* hn, const float* rinv
 
 int dof_launch_dec_repeat(const float* d2, const float* bnp, float* zrep, int C4, int T, int64_t B, int64_t Bp,
                           hipStream_t st) {
-  DOF_LAUNCH(k_dec_repeat, (dof_cdiv((int64_t)T * B, 256)), (256), st, d2, bnp, zrep, C4, T, B, Bp);
+  if (C4 > 32) DOF_LAUNCH((k_dec_repeat<64>), (dof_cdiv((int64_t)T * B, 256)), (256), st, d2, bnp, zrep, C4, T, B, Bp);
+  else DOF_LAUNCH((k_dec_repeat<32>), (dof_cdiv((int64_t)T * B, 256)), (256), st, d2, bnp, zrep, C4, T, B, Bp);
   return dof_check_launch("k_dec_repeat");
 }
 
 int dof_launch_dec_sum_time(const float* dzrep, float* dzf, int C4, int T, int64_t B, int64_t Bp, hipStream_t st) {
-  DOF_LAUNCH(k_dec_sum_time, (dof_cdiv(B, 256)), (256), st, dzrep, dzf, C4, T, B, Bp);
+  if (C4 > 32) DOF_LAUNCH((k_dec_sum_time<64>), (dof_cdiv(B, 256)), (256), st, dzrep, dzf, C4, T, B, Bp);
+  else DOF_LAUNCH((k_dec_sum_time<32>), (dof_cdiv(B, 256)), (256), st, dzrep, dzf, C4, T, B, Bp);
   return dof_check_launch("k_dec_sum_time");
 }
 

@@ -72,7 +72,8 @@ struct TcnBlockOff {  // one TemporalBlockPT: conv / BatchNorm (weight, bias, ru
 };
 struct TcnDecWs {  // TCN decoder buffers (sequences = windows; [T][Bp][64] unless noted)
   int64_t hn, rinv, d0, n0, d1, n1, d2, bnp0, bnp1, bnp2;  // front MLP, [c][Bp]
-  int64_t zrep;                                            // [T][Bp][32] BN2 output repeated over time (zero-padded channels)
+  int64_t zrep;                                            // [T][Bp][zc] BN2 output repeated over time (zero-padded channels)
+  int zc;                                                  // channels per zrep row: 32 (4 L <= 32) or 64 (latent 16)
   int64_t y1[4], a1[4], y2[4], out[4], skip, g1[4], g2[4], dout[2], da;
   int64_t bnp[8], partial, partial_rows, sums, coef;
   int64_t hid, dskip, dzrep, dzf, dpre2, dn1, dpre1, dn0, dpre0, dhn;
@@ -599,7 +600,8 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     d.d1 = cv.take(2LL * L * Bp); d.n1 = cv.take(2LL * L * Bp);
     d.d2 = cv.take(4LL * L * Bp);
     d.bnp0 = cv.take(4 * L); d.bnp1 = cv.take(8 * L); d.bnp2 = cv.take(16 * L);
-    d.zrep = cv.take((int64_t)T * Bp * 32);
+    d.zc = 4 * L > 32 ? 64 : 32;
+    d.zrep = cv.take((int64_t)T * Bp * d.zc);
     for (int b = 0; b < 4; ++b) {
       d.y1[b] = cv.take(act); d.a1[b] = cv.take(act); d.y2[b] = cv.take(act); d.out[b] = cv.take(act);
       d.g1[b] = cv.take(act); d.g2[b] = cv.take(act);
@@ -611,7 +613,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     d.partial = cv.take(d.partial_rows * 64);
     d.sums = cv.take(128); d.coef = cv.take(128);
     d.hid = cv.take(act); d.dskip = cv.take(act);
-    d.dzrep = cv.take((int64_t)T * Bp * 32);
+    d.dzrep = cv.take((int64_t)T * Bp * d.zc);
     d.dzf = cv.take(4LL * L * Bp); d.dpre2 = cv.take(4LL * L * Bp);
     d.dn1 = cv.take(2LL * L * Bp); d.dpre1 = cv.take(2LL * L * Bp);
     d.dn0 = cv.take((int64_t)L * Bp); d.dpre0 = cv.take((int64_t)L * Bp);
@@ -809,6 +811,18 @@ struct JobBuilder {
     t.ptr = b.p; t.t_stride = b.ts; t.s_stride = b.ss; t.c_stride = b.cs; t.nc = nc; t.shift = shift; t.pack = pack;
     return j.n_tiles++;
   }
+  // an operand of nc > 16 columns as consecutive full tiles (their columns are contiguous in the partial tile, so one
+  // fin block may span them); returns the first tile
+  int add_tiles_soa(int job, const float* p, int64_t Sp, int nc) {
+    const int first = jobs[job].n_tiles;
+    for (int c0 = 0; c0 < nc; c0 += 16) add_tile(job, soa(p, Sp, c0), nc - c0 < 16 ? nc - c0 : 16, 0);
+    return first;
+  }
+  int add_tiles_aos(int job, const float* p, int C, int64_t Sp, int nc) {
+    const int first = jobs[job].n_tiles;
+    for (int c0 = 0; c0 < nc; c0 += 16) add_tile(job, aos(p, C, Sp, c0), nc - c0 < 16 ? nc - c0 : 16, 0);
+    return first;
+  }
   void add_fin(int job, int col0, int rows, int cols, int r1, int r2, int64_t dst, int64_t rs, int64_t cs,
                int gate_minor = 0) {
     DofFinJob f;
@@ -826,6 +840,41 @@ struct JobBuilder {
 void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int IN, const float* O, int HID, int T,
               int64_t Sp, const GruOff& g, bool gate_minor) {
   const int gm = gate_minor ? HID : 0;
+  if (4 * HID > 64 || (IN + 15) / 16 + 1 > 4) {
+    // wide layers (latent 16: HID = 32 -> 128 gate rows; IN = 64 -> five operand tiles): the product is cut into row
+    // blocks of whole gates (<= 64 rows) and groups of <= 4 operand tiles, one job each; gate-major rows only
+    const int gpb = 64 / HID < 1 ? 1 : (64 / HID > 4 ? 4 : 64 / HID);  // gates per row block
+    struct Tl { View v; int nc, shift, c0; bool hh; };
+    for (int d = 0; d < 2; ++d) {
+      const float* a = dG + (int64_t)d * T * 4 * HID * Sp;
+      std::vector<Tl> tl;
+      for (int c0 = 0; c0 < IN; c0 += 16)
+        tl.push_back(Tl{x_bcast ? soa(X, Sp, c0) : aos(X, IN, Sp, c0), IN - c0 < 16 ? IN - c0 : 16, 0, c0, false});
+      for (int c0 = 0; c0 < HID; c0 += 16)
+        tl.push_back(Tl{aos(O, 2 * HID, Sp, d * HID + c0), HID - c0 < 16 ? HID - c0 : 16, d == 0 ? -1 : +1, c0, true});
+      for (int g0 = 0; g0 < 4; g0 += gpb)
+        for (size_t t0 = 0; t0 < tl.size(); t0 += 4) {
+          const int ng = 4 - g0 < gpb ? 4 - g0 : gpb;
+          const int job = jb.add_job(aos(a, 4 * HID, Sp, g0 * HID), ng * HID, T, Sp);
+          for (size_t ti = t0; ti < tl.size() && ti < t0 + 4; ++ti) {
+            const Tl& q = tl[ti];
+            const int col = jb.add_tile(job, q.v, q.nc, q.shift) * 16;
+            for (int gi = g0; gi < g0 + ng; ++gi) {
+              const int lo = (gi - g0) * HID;  // first source row of the gate inside the block
+              if (!q.hh && gi < 3) jb.add_fin(job, col, HID, q.nc, 0, lo, g.t[d * 4 + 0] + (int64_t)gi * HID * IN + q.c0, IN, 1);
+              if (q.hh && gi != 2) jb.add_fin(job, col, HID, q.nc, 0, lo, g.t[d * 4 + 1] + (int64_t)(gi == 3 ? 2 : gi) * HID * HID + q.c0, HID, 1);
+            }
+          }
+          if (t0 == 0)
+            for (int gi = g0; gi < g0 + ng; ++gi) {
+              const int lo = (gi - g0) * HID;
+              if (gi < 3) jb.add_fin(job, 64, HID, 1, 0, lo, g.t[d * 4 + 2] + (int64_t)gi * HID, 1, 1);
+              if (gi != 2) jb.add_fin(job, 64, HID, 1, 0, lo, g.t[d * 4 + 3] + (int64_t)(gi == 3 ? 2 : gi) * HID, 1, 1);
+            }
+        }
+    }
+    return;
+  }
   for (int d = 0; d < 2; ++d) {
     const float* a = dG + (int64_t)d * T * 4 * HID * Sp;
     const int job = jb.add_job(aos(a, 4 * HID, Sp), 4 * HID, T, Sp);
@@ -869,14 +918,14 @@ void head_jobs(DofVadePlan* p, JobBuilder& jb) {
   for (int r0 = 0; r0 < p->J; r0 += 64) {
     const int rows = p->J - r0 < 64 ? p->J - r0 : 64;
     const int job = jb.add_job(soa(ws + p->hd_hn, Bp, r0), rows, 1, Bp);
-    jb.add_tile(job, soa(ws + p->hd_dpre1, Bp), 2 * L, 0);
+    jb.add_tiles_soa(job, ws + p->hd_dpre1, Bp, 2 * L);
     jb.add_fin(job, 0, rows, 2 * L, rows, rows, p->h0w + r0, 1, p->J);
   }
   int job = jb.add_job(soa(ws + p->hd_dpre1, Bp), 2 * L, 1, Bp);
   jb.add_tile(job, soa(ws + p->hd_dpre1, Bp), 1, 0);
   jb.add_fin(job, 64, 2 * L, 1, 2 * L, 2 * L, p->h0b, 1, 1);
   job = jb.add_job(soa(ws + p->hd_dpre2, Bp), L, 1, Bp);
-  jb.add_tile(job, soa(ws + p->hd_n1, Bp), 2 * L, 0);
+  jb.add_tiles_soa(job, ws + p->hd_n1, Bp, 2 * L);
   jb.add_fin(job, 0, L, 2 * L, L, L, p->h3w, 2 * L, 1);
   jb.add_fin(job, 64, L, 1, L, L, p->h3b, 1, 1);
   job = jb.add_job(soa(dout, Bp), L, 1, Bp);
@@ -1001,7 +1050,7 @@ void build_tcn_jobs(DofVadePlan* p) {
             jd.add_fin(jobc, tl * 16, CD, nc, CD, CD, wOff + (int64_t)c0 * 4 + j, (int64_t)cin * 4, 4);
           }
       };
-      if (b == 0) conv(ws + d.g1[0], ws + d.zrep, 32, C4, o.c1w, o.c1b);
+      if (b == 0) conv(ws + d.g1[0], ws + d.zrep, d.zc, C4, o.c1w, o.c1b);
       else conv(ws + d.g1[b], ws + d.out[b - 1], CD, CD, o.c1w, o.c1b);
       conv(ws + d.g2[b], ws + d.a1[b], CD, CD, o.c2w, o.c2b);
       if (b == 0) {  // 1x1 residual conv (4L -> 64): A = gradient entering block 0's residual branch (dout[1])
@@ -1012,7 +1061,7 @@ void build_tcn_jobs(DofVadePlan* p) {
             jd.add_fin(jobd, 64, CD, 1, CD, CD, o.dsb, 1, 1);
           }
           const int nc = C4 - c0 < 16 ? C4 - c0 : 16;
-          const int tl = jd.add_tile(jobd, aos(ws + d.zrep, 32, Bp, c0), nc, 0);
+          const int tl = jd.add_tile(jobd, aos(ws + d.zrep, d.zc, Bp, c0), nc, 0);
           jd.add_fin(jobd, tl * 16, CD, nc, CD, CD, o.dsw + c0, C4, 1);
         }
       }
@@ -1126,7 +1175,7 @@ void build_jobs(DofVadePlan* p) {
     for (int r0 = 0; r0 < p->C3; r0 += 64) {
       const int rows = p->C3 - r0 < 64 ? p->C3 - r0 : 64;
       job = jb.add_job(aos(ws + p->dloc, p->C3, Bp, r0), rows, T, Bp);
-      jb.add_tile(job, aos(ws + p->n3, CO, Bp), CO, 0);
+      jb.add_tiles_aos(job, ws + p->n3, CO, Bp, CO);
       jb.add_fin(job, 0, rows, CO, rows, rows, p->dpw + (int64_t)r0 * CO, CO, 1);
       jb.add_fin(job, 64, rows, 1, rows, rows, p->dpb + r0, 1, 1);
     }
@@ -1217,7 +1266,8 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     case 4: { constexpr int LL = 4; CALL; } break; \
     case 6: { constexpr int LL = 6; CALL; } break; \
     case 8: { constexpr int LL = 8; CALL; } break; \
-    default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
+    case 16: { constexpr int LL = 16; CALL; } break; \
+    default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
   }
 
 // CensNet kernels are specialised on (latent L, input channels D): D = 2L behind the recurrent blocks, 32 behind the TCNs
@@ -1242,6 +1292,7 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     else if (_l == 4 && _d == 64) DOF_LAUNCH((NAME<4, 64>), GRID, (256), st, __VA_ARGS__);             \
     else if (_l == 6 && _d == 64) DOF_LAUNCH((NAME<6, 64>), GRID, (256), st, __VA_ARGS__);             \
     else if (_l == 8 && _d == 64) DOF_LAUNCH((NAME<8, 64>), GRID, (256), st, __VA_ARGS__);             \
+    else if (_l == 16 && _d == 32) DOF_LAUNCH((NAME<16, 32>), GRID, (256), st, __VA_ARGS__);           \
     else { dof_set_error("CensNet (latent %d, channels %d) not supported by this build", _l, _d); return DOF_ERR_UNSUPPORTED; } \
   } while (0)
 
@@ -1543,7 +1594,7 @@ int tcn_decoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     const TcnBlockOff& o = p->dblk[b];
     const int dl = kTcnDecDil[b];
     if (b == 0) {
-      TRY(dof_launch_tcn_convg(0, 32, CD, ws + d.zrep, params + o.c1w, C4, C4, params + o.c1b, nullptr, nullptr,
+      TRY(dof_launch_tcn_convg(0, d.zc, CD, ws + d.zrep, params + o.c1w, C4, C4, params + o.c1b, nullptr, nullptr,
                                ws + d.y1[0], ws + d.partial, 0, T, dl, B, Bp, st));
     } else {
       TRY(dof_launch_tcn_convg(0, CD, CD, ws + d.out[b - 1], params + o.c1w, CD, CD, params + o.c1b, nullptr, nullptr,
@@ -1559,7 +1610,7 @@ int tcn_decoder_forward(DofVadePlan* p, float* params, const float* x, const flo
                               train, ws + d.bnp[2 * b + 1], CD, st));
     TRY(dof_launch_tcn_combine(ws + d.y2[b], ws + d.bnp[2 * b + 1], b ? ws + d.out[b - 1] : nullptr, ws + d.zrep,
                                b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb, ws + d.out[b], ws + d.skip,
-                               nullptr, b == 0, T, b ? CD : C4, CD, B, Bp, st, 32));
+                               nullptr, b == 0, T, b ? CD : C4, CD, B, Bp, st, d.zc));
   }
   return dof_launch_tcn_dec_out(ws + d.skip, params + p->dpw, params + p->dpb, x, ws + p->valid, ws + d.hid, loc_out,
                                 recon_partial, ws + p->dloc, ws + d.dskip, T, p->C3, keep ? 1 : 0, B, Bp, st);
@@ -1594,10 +1645,10 @@ int tcn_decoder_backward(DofVadePlan* p, const float* params, float* grads, int 
                                nullptr, 1, T, dl, B, Bp, st));
     } else {
       // gradient of the repeated input: conv1^T(dy1) + downsample^T(residual gradient, left in dout[1])
-      TRY(dof_launch_tcn_convg(1, CD, 32, ws + d.g1[0], params + o.c1w, C4, C4, nullptr, nullptr, nullptr, ws + d.dzrep,
+      TRY(dof_launch_tcn_convg(1, CD, d.zc, ws + d.g1[0], params + o.c1w, C4, C4, nullptr, nullptr, nullptr, ws + d.dzrep,
                                nullptr, 0, T, dl, B, Bp, st));
       DOF_LAUNCH(k_dec_ds_bwd, (dof_cdiv((int64_t)T * B, 256)), (256), st, (const float*)(ws + d.dout[1]),
-                 params + o.dsw, ws + d.dzrep, C4, T, B, Bp);
+                 params + o.dsw, ws + d.dzrep, C4, d.zc, T, B, Bp);
       TRY(dof_check_launch("k_dec_ds_bwd"));
     }
   }
@@ -1911,8 +1962,8 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
                   dims->window, dims->n_nodes, dims->n_edges, dims->n_clusters);
     return DOF_ERR_ARG;
   }
-  if (dims->latent != 4 && dims->latent != 6 && dims->latent != 8) {
-    dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", dims->latent);
+  if (dims->latent != 4 && dims->latent != 6 && dims->latent != 8 && dims->latent != 16) {
+    dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16)", dims->latent);
     return DOF_ERR_UNSUPPORTED;
   }
   if (dims->n_nodes > DOF_CL_MAX_NODES && kind == 2) {

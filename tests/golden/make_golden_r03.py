@@ -346,6 +346,12 @@ if __name__ == "__main__":
         MG.gen_vqvae("c5l8", ["B", "W"], 50, 8, 40, 8, 341, kmeans=0.5)
         MG.gen_vqvae("c3k512", [""], 25, 8, 512, 64, 351)
         MG.gen_contrastive("c5l8", ["B", "W"], 50, 8, 8, 361)
+    if "l16" in what:   # latent 16 (internal_dim = min(64, latent_dim) = 16: GRU(32, 32) + GRU(64 -> 16) encoder streams)
+        MG.gen_vade("rec14l16", [""], 25, 16, 10, 12, 431)
+        MG.gen_vqvae("rec14l16", [""], 25, 16, 48, 12, 441, kmeans=0.5)
+        MG.gen_contrastive("rec14l16", [""], 24, 16, 12, 461)
+    if "l16tcn" in what:
+        MG.gen_contrastive("tcn14l16", [""], 24, 16, 6, 481, encoder_type="TCN", cases=[("cosine", "nce")])
     if "vqkinks" in what:   # refresh only the VQ-VAE part of tcn_kinks.npz
         keep = {k: v for k, v in np.load(os.path.join(HERE, "tcn_kinks.npz")).items() if not k.startswith("vqvae_tcn14::")}
         vqvae_tcn_kinks(keep)

@@ -294,12 +294,12 @@ def run_contrastive_check(lib, device, golden_dir, tag):
                 assert float(e1.view(name, e1.grads).abs().max()) == 0.0, name   # incl. the unused distillation head
 
 
-def run_contrastive_tcn_check(lib, device, golden_dir):
+def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn14.npz"):
     """Contrastive step with the TCN encoder (R12): eval-mode embeddings (running statistics), train-mode embeddings,
     BatchNorm buffers after the two passes, loss and all gradients, then the reference's two optimiser steps
     (Adam + weight decay 1e-4, clip 0.75, CensNet tensors outside the optimiser -- quirk Q11)."""
     from deepof_amd.engine import VadeEngine, contrastive_views
-    d = load_golden(golden_dir, "contrastive_tcn14.npz")
+    d = load_golden(golden_dir, fixture)
     pfx = "c0::"
     x_full = torch.from_numpy(d["x_full"]).to(device)
     ei = torch.from_numpy(d["edge_index"]).to(device)
@@ -337,7 +337,12 @@ def run_contrastive_tcn_check(lib, device, golden_dir):
         if k.startswith(pfx + "grad::"):
             name = k[len(pfx) + 6:]
             g = e1.view(name, e1.grads).cpu().numpy()
-            np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=1e-4, rtol=2e-3, err_msg=f"grad {name}")
+            if math_zero_gradient(name):  # a bias in front of a BatchNorm: both sides hold rounding noise, only bounded
+                assert max(float(np.abs(g).max()), float(np.abs(d[k]).max())) < 3e-4, name
+            elif fixture == "contrastive_tcn14.npz":  # the round-1 fixture keeps its elementwise check
+                np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=1e-4, rtol=2e-3, err_msg=f"grad {name}")
+            else:  # latent 16: gradients of O(5); the standard per-tensor bar (5e-5 + 5e-4 max|ref|) of the TCN checks
+                _grad_bar(g, d[k].reshape(g.shape), name)
             n += 1
     assert n == 148
     # optimiser: step 1 on these gradients, step 2 = a full step with the second set of recorded draws
@@ -1563,13 +1568,18 @@ def run_tfm_widths_vs_oracle(lib, device, n_nodes, latent, B=6, T=10, K=5, seed=
         with torch.no_grad():
             ref = OV.vade_forward({k: v.clone() for k, v in P.items()}, x, a, training=False)
         np.testing.assert_allclose(out["z"].cpu().numpy(), ref["z"].numpy(), atol=3e-5, rtol=2e-4)
-        np.testing.assert_allclose(out["loc"].cpu().numpy(), ref["loc"].numpy(), atol=1e-4, rtol=2e-4)
+        ref_l = ref["loc"].numpy()
+        np.testing.assert_allclose(out["loc"].cpu().numpy(), ref_l, atol=max(1e-4, 5e-6 * float(np.abs(ref_l).max())), rtol=2e-4)
     else:
         out = eng.vq_forward(x.to(device), a.to(device))
         with torch.no_grad():
             ref = OQ.vqvae_forward({k: v.clone() for k, v in P.items()}, x, a, training=False)
         np.testing.assert_allclose(out["ze"].cpu().numpy(), ref["ze"].numpy(), atol=3e-5, rtol=2e-4)
-        np.testing.assert_allclose(out["loc_e"].cpu().numpy(), ref["loc_e"].numpy(), atol=1e-4, rtol=2e-4)
+        # (decoder outputs of this random initialisation reach |36| at latent 16: the absolute term follows the tensor
+        # scale -- 5e-6 of it, i.e. about two fp32 ulps of the largest values -- and stays 1e-4 up to a scale of 20)
+        ref_e = ref["loc_e"].numpy()
+        np.testing.assert_allclose(out["loc_e"].cpu().numpy(), ref_e, atol=max(1e-4, 5e-6 * float(np.abs(ref_e).max())),
+                                   rtol=2e-4)
     # train step on random masks (no masked frames: a masked frame makes the reconstruction loss NaN)
     x[1, 2] = torch.randn(N, 3, generator=g)
     a[1, 2] = torch.randn(E, 1, generator=g)

@@ -56,7 +56,7 @@ def test_gather_matches_reference_windows(hip, golden_dir):
             np.testing.assert_array_equal(a.cpu().numpy(), d[f"w{ci}::a"])
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16"])
 def test_vade_eval_forward_gpu(hip, golden_dir, tag):
     from deepof_amd.engine import create_vade_engine
     from parity_common import load_golden, params_from
@@ -76,7 +76,9 @@ def test_vade_eval_forward_gpu(hip, golden_dir, tag):
 @pytest.mark.parametrize("tag,phase", [("rec14", "pre"), ("rec14", "main"), ("rec14", "mainT"), ("rec14", "mainX"),
                                        ("rec28", "pre"), ("rec28", "main"), ("rec28", "mainT"), ("rec28", "mainX"),
                                        # C5 graph at latent 8, window 50, k = 25: the lane-per-unit / MFMA-fused kernels
-                                       ("c5l8", "pre"), ("c5l8", "main"), ("c5l8", "mainT"), ("c5l8", "mainX")])
+                                       ("c5l8", "pre"), ("c5l8", "main"), ("c5l8", "mainT"), ("c5l8", "mainX"),
+                                       # latent 16: GRU(32, 32) / GRU(64 -> 16) streams through the generic kernels
+                                       ("rec14l16", "pre"), ("rec14l16", "main"), ("rec14l16", "mainT"), ("rec14l16", "mainX")])
 def test_vade_loss_grads_gpu(hip, golden_dir, tag, phase):
     from parity_common import run_phase_check
     worst = run_phase_check(hip, "cuda", golden_dir, tag, phase)
@@ -249,7 +251,7 @@ def test_training_api_on_gpu(hip, tmp_path):
     np.testing.assert_allclose(soft.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16"])
 def test_vqvae_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_vqvae_check
     run_vqvae_check(hip, "cuda", golden_dir, tag)
@@ -321,7 +323,7 @@ def test_vqvae_full_size_c3(hip):
     np.testing.assert_allclose(out["soft_counts"].cpu().numpy(), soft.numpy(), rtol=2e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16"])
 def test_contrastive_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_contrastive_check, run_contrastive_loss_check
     run_contrastive_loss_check(hip, "cuda", golden_dir, tag)
@@ -414,9 +416,10 @@ def test_contrastive_training_api_gpu(tmp_path):
     assert (tmp_path / "models" / "contrastive" / "run_0" / "best_model_val.pth").exists()
 
 
-def test_contrastive_tcn_parity_gpu(hip, golden_dir):
+@pytest.mark.parametrize("fixture", ["contrastive_tcn14.npz", "contrastive_tcn14l16.npz"])
+def test_contrastive_tcn_parity_gpu(hip, golden_dir, fixture):
     from parity_common import run_contrastive_tcn_check
-    run_contrastive_tcn_check(hip, "cuda", golden_dir)
+    run_contrastive_tcn_check(hip, "cuda", golden_dir, fixture)
 
 
 def test_contrastive_tcn_full_size_c4(hip):
@@ -571,7 +574,7 @@ def test_distillation_head_gpu(hip, golden_dir):
     run_distill_head_check(hip, "cuda", golden_dir)
 
 
-@pytest.mark.parametrize("L", [4, 6])
+@pytest.mark.parametrize("L", [4, 6, 16])
 def test_vade_tcn_padded_decoder_input_gpu(hip, L):
     from parity_common import run_vade_tcn_vs_oracle
     run_vade_tcn_vs_oracle(hip, "cuda", L=L)
@@ -1096,7 +1099,7 @@ def test_data_parallel_step_rccl(tmp_path, world):
 
 
 @pytest.mark.parametrize("n_nodes,latent,kind", [(8, 4, "vade"), (11, 6, "vqvae"), (16, 8, "vade"), (22, 8, "vqvae"),
-                                                  (28, 8, "vade")])
+                                                  (28, 8, "vade"), (11, 16, "vade"), (11, 16, "vqvae")])
 def test_tfm_other_widths_gpu(hip, n_nodes, latent, kind):
     """key_dim 24 / 32 / 48 / 64, latent 4 / 6 / 8 (decoder widths 16 / 24 / 32) of the transformer family against the
     oracle on injected random keep-masks: eval forward with a masked frame, total loss and every gradient."""
