@@ -316,6 +316,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--frames", type=int, default=600_000, help="frames per synthetic animal (2 animals per rank)")
+    ap.add_argument("--latent", type=int, default=8, help="latent size of the headline model (8 = C2; 16 for profiling that path)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (C3, C4, C5, TCN / transformer)")
@@ -350,12 +351,12 @@ def main():
 
     from deepof_amd import _capi
 
-    B, T, L, K, S = args.batch, 25, 8, 10, 32
+    B, T, L, K, S = args.batch, 25, args.latent, 10, 32
     n_animals, F = 2, args.frames
     # ---- the product objects: model (reference initialisers, identical on every rank = DDP's broadcast), the fit
     # loop's stepper in the main phase with distillation, a device-resident dataset of 2 animals per rank
     stepper, model, ds, starts, (tn, te), tau_star = vade_stepper_setup(
-        [""], T, K, B, "recurrent", F, dev, rank=rank, use_graphs=False if args.no_graph else None)
+        [""], T, K, B, "recurrent", F, dev, rank=rank, use_graphs=False if args.no_graph else None, latent=args.latent)
     eng = model._base
     lib = eng.lib
     N, E = eng.N, eng.E
@@ -426,7 +427,7 @@ def main():
         "metric": "pose-windows/sec (train step) VaDE 14-bp win=25", "value": value, "unit": "windows/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: VaDE GM-VAE recurrent, 14 body parts (N=14,E=14), window=25, k=10, latent=8, "
+        "config": {"workload": f"C2: VaDE GM-VAE recurrent, 14 body parts (N=14,E=14), window=25, k=10, latent={args.latent}, "
                                f"batch={B}/GPU, main phase (MC-KL S=32 + distillation), fp32",
                    "global_batch": world * B, "window": T, "parallelism": f"dp{world}",
                    "hip_graph": stepper.graphs.enabled, "graph_replays": stepper.graphs.replays,

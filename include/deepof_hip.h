@@ -72,7 +72,7 @@ typedef struct DofVadeDims {
   int32_t window;     /* T */
   int32_t n_nodes;    /* N, 3 features per node */
   int32_t n_edges;    /* E, 1 feature per edge */
-  int32_t latent;     /* L (internal GRU width = L; L <= 64 in the reference, this build: 4, 6, 8) */
+  int32_t latent;     /* L (internal GRU width = L; L <= 64 in the reference, this build: 4, 6, 8, 16) */
   int32_t n_clusters; /* K */
   int32_t mc_samples; /* S of the Monte-Carlo KL (reference: 32) */
 } DofVadeDims;
