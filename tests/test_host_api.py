@@ -237,6 +237,22 @@ def test_fit_vade_end_to_end_and_checkpoint_roundtrip(tmp_path):
     assert isinstance(again[0], VaDE) and again[1] is None and again[2] is None
 
 
+def test_fit_latent16_end_to_end(tmp_path):
+    """latent_dim = 16 through the trainer (GRU(32, 32) / GRU(64 -> 16) streams; one video of 16 windows, the emulator
+    runs those layers slowly): finite logs, embeddings of width 16; latent 32 is refused up front."""
+    pre = tiny_preprocessed(n_videos=1, n_win=16, seed=3)
+    kw = dict(preprocessed_object=(pre, pre), adjacency_matrix=chain_adj(4), meta_info={}, encoder_type="recurrent",
+              batch_size=8, epochs=1, output_path=str(tmp_path), n_clusters=3, model_name="VaDE", pretrain_epochs=0,
+              use_turtle_teacher=False, save_weights=False, random_seed=0, _engine_factory=emu_factory)
+    model_val, _score, _teacher, log_summary = TR.train_deepof_model(latent_dim=16, **kw)
+    assert all(np.isfinite(log_summary["train"]["total_loss"])) and len(log_summary["train"]["total_loss"]) == 1
+    x = torch.from_numpy(reorder_and_reshape(pre["vid0"][0])[:8])
+    a = torch.from_numpy(pre["vid0"][1][:8, ..., None])
+    assert tuple(model_val.embed(x, a).shape) == (8, 16)
+    with pytest.raises((NotImplementedError, ValueError, AssertionError), match="32|latent"):
+        TR.train_deepof_model(latent_dim=32, **kw)
+
+
 def test_logged_total_is_sum_of_parts():
     """Reference invariant (tests/test_build_models.py:895-903): total == sum of the parts; main-only terms 0 in pretrain."""
     from parity_common import configure_phase
