@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -82,6 +82,7 @@ PP_MAX_COLS, PP_MAX_ANIMALS = 512, 8
 _P = C.c_void_p
 _I64 = C.c_int64
 _I32 = C.c_int32
+COMM_ID_BYTES = 128
 
 SIGNATURES = {
     "dof_last_error_string": (C.c_char_p, []),
@@ -90,6 +91,11 @@ SIGNATURES = {
     "dof_window_gather_range": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "dof_window_gather_bf16": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "dof_widen_bf16": (C.c_int, [_P, _P, _I64, _P]),
+    "dof_comm_unique_id": (C.c_int, [_P]),
+    "dof_comm_create": (C.c_int, [_P, _I32, _I32, C.POINTER(_P)]),
+    "dof_comm_destroy": (C.c_int, [_P]),
+    "dof_flat_allreduce": (C.c_int, [_P, _P, _I64, _P]),
+    "dof_comm_broadcast": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "dof_vade_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vade_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),
     "dof_vqvae_tcn_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),

@@ -74,18 +74,38 @@ def _dp_step(graphs, key, slot, forward_backward, eng, dist, world: int):
     [clip + Adam with grad_scale 1 / world].  The collective is enqueued by torch.distributed on RCCL's own stream and
     the step's stream waits for it on the device (an event, not the host): the host never blocks inside a step.
     Default: two captured graphs around the eagerly enqueued collective.  DOF_DP_ONE_GRAPH=1 captures the collective
-    too -- the whole step is one hipGraph replay (RCCL kernels are capturable)."""
+    too -- the whole step is one hipGraph replay (RCCL kernels are capturable).  DOF_DP_NATIVE=1: the collective is the
+    C ABI's dof_flat_allreduce on the step's own stream instead of torch.distributed's."""
     scale = 1.0 / world
+    if os.environ.get("DOF_DP_NATIVE", "0") == "1":
+        # the C ABI's own exchange (dof_flat_allreduce): RCCL on the step's stream, stream-ordered with the two graphs
+        comm = _native_comm(eng, dist)
+        reduce = lambda: comm.all_reduce_(eng.grads)
+    else:
+        reduce = lambda: dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
     if os.environ.get("DOF_DP_ONE_GRAPH", "0") == "1":
         def whole():
             forward_backward()
-            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+            reduce()
             eng.optimizer_step(scale)
         graphs.run(key + ("dp",), whole, None if slot is None else slot + ("dp",))
         return
     graphs.run(key + ("grads",), forward_backward, None if slot is None else slot + ("grads",))
-    dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+    reduce()
     graphs.run((eng.B, world, "adam"), lambda: eng.optimizer_step(scale))
+
+
+_NATIVE_COMM = None
+
+
+def _native_comm(eng, dist):
+    """This process's RCCL communicator behind the C ABI (deepof_amd.comm.NativeComm), created on first use: rank 0's
+    unique id travels over the initialised torch.distributed group."""
+    global _NATIVE_COMM
+    if _NATIVE_COMM is None:
+        from .comm import NativeComm
+        _NATIVE_COMM = NativeComm.from_process_group(eng.lib, dist)
+    return _NATIVE_COMM
 
 
 def _dp_active(dist, world: int) -> bool:

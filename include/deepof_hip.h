@@ -24,6 +24,9 @@
  *   dof_contrastive_backward    loss.backward() through one view's encoder pass (training.py:163)
  *   dof_turtle_fit_step/_predict  teacher_model.py:43-350 TurtleTeacher (heads inner fit, task encoder, fit, predict)
  *   dof_optimizer_step          training.py:164-166 clip_grad_value_ + optimizer.step(), losses.py:805-833
+ *   dof_comm_*, dof_flat_allreduce   training.py:1087-1096, 1321-1330, 1567-1576 DistributedDataParallel wrapping
+ *                               (the gradient all-reduce + the initial parameter broadcast; torch.distributed
+ *                               init_process_group("nccl") / destroy_process_group for the communicator)
  *   dof_preprocess_tables, dof_preprocess_video_stats, dof_preprocess_fit_global
  *                               deepof/data.py:3773-3916 TableDict.preprocess (scale="standard") up to window
  *                               extraction: utils.py:2425-2566 scale_table, :2665-2792 _pp_pass1_collect_samples,
@@ -40,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 14
+#define DOF_ABI_VERSION 15
 
 /* ---- error reporting ---------------------------------------------------------------------- */
 const char* dof_last_error_string(void);
@@ -443,6 +446,23 @@ int dof_preprocess_order_stats(const DofPreprocDims* dims, const double* raw, co
  * counts of dims are ignored; workspace as for dof_preprocess_tables. */
 int dof_preprocess_raw_moments(const DofPreprocDims* dims, const double* raw, const int64_t* video_off,
                                const int32_t* col_kind, double* moments_out, void* workspace, void* stream);
+
+/* ---- data-parallel exchange: ONE all-reduce of the flat gradient per step ------------------------
+ * RCCL over xGMI, one process per GPU.  librccl is opened at the first dof_comm_* call (dlopen: the library does not
+ * link it, a process that never trains data-parallel never loads it); without it the calls fail with
+ * DOF_ERR_UNSUPPORTED -- there is no host fallback.  Rank 0 calls dof_comm_unique_id and hands the DOF_COMM_ID_BYTES to
+ * the other ranks over any channel it has (the reference's launcher environment: MASTER_ADDR / a file / MPI); every rank
+ * then calls dof_comm_create on its device.  dof_flat_allreduce sums `n` floats in place over the ranks and
+ * dof_comm_broadcast copies root's buffer to all, both enqueued on `stream` without a host wait: with the step's stream
+ * the data-parallel step is [gather + loss + gradients] -> all-reduce -> [clip + Adam with grad_scale = 1 / world] in
+ * stream order (and capturable into one hipGraph).  The mean of DistributedDataParallel is grad_scale's job. */
+#define DOF_COMM_ID_BYTES 128
+typedef struct DofComm DofComm;
+int dof_comm_unique_id(void* id_out);
+int dof_comm_create(const void* id, int32_t rank, int32_t world, DofComm** out);
+int dof_comm_destroy(DofComm* comm);
+int dof_flat_allreduce(DofComm* comm, float* buf, int64_t n, void* stream);
+int dof_comm_broadcast(DofComm* comm, float* buf, int64_t n, int32_t root, void* stream);
 
 #ifdef __cplusplus
 }

@@ -85,3 +85,13 @@ def test_product_path_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="ROCm GPU"):
         create_vade_engine(8, 25, np.eye(3, dtype=np.float32), 8, 4)
+
+
+def test_native_comm_refuses_without_rccl():
+    """The emulation build has no RCCL: the communicator entry points fail loudly (no host fallback)."""
+    import ctypes
+    from emu_util import emu_lib
+    lib = emu_lib()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.dof_comm_unique_id(buf) != 0
+    assert b"librccl" in lib.dof_last_error_string()

@@ -1040,7 +1040,7 @@ def test_vade_tfm_full_size_c2(hip):
 # ------------------------------------------------------------------------------------------------
 # RCCL ("nccl" backend): the data-parallel step on real devices
 # ------------------------------------------------------------------------------------------------
-def _rccl_worker(rank, world, port, tmp):
+def _rccl_worker(rank, world, port, tmp, native=False):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -1057,7 +1057,13 @@ def _rccl_worker(rank, world, port, tmp):
     eng.params.copy_(torch.randn(eng.params.shape, generator=g) * 0.2)
     if rank != 0:
         eng.params.mul_(0.0)
-    dist.broadcast(eng.params, src=0)
+    comm = None
+    if native:   # the C ABI's own communicator (dof_comm_create / dof_comm_broadcast / dof_flat_allreduce)
+        from deepof_amd.comm import NativeComm
+        comm = NativeComm.from_process_group(eng.lib, dist)
+        comm.broadcast_(eng.params, 0)
+    else:
+        dist.broadcast(eng.params, src=0)
     xs, as_ = torch.randn(4 * world, 8, 4, 3, generator=g), torch.randn(4 * world, 8, 3, 1, generator=g)
     eps = torch.randn(4 * world, 4, generator=g)
     configure_phase(eng, 3, True, 0.2)
@@ -1066,29 +1072,36 @@ def _rccl_worker(rank, world, port, tmp):
     eng.loss_grads(xs[lo:lo + 4].contiguous().to(dev), as_[lo:lo + 4].contiguous().to(dev), eps[lo:lo + 4].contiguous().to(dev),
                    None, None, True)
     local = eng.grads.clone()
-    dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+    if native:
+        comm.all_reduce_(eng.grads)
+    else:
+        dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
     for seg in range(4):
         eng.set_lr(seg, 1e-3)
     eng.push_hyper()
     eng.optimizer_step(1.0 / world)
     torch.cuda.synchronize()
     torch.save({"local": local.cpu(), "sum": eng.grads.cpu(), "params": eng.params.cpu()}, os.path.join(tmp, f"r{rank}.pt"))
+    if comm is not None:
+        comm.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("native", [False, True])
 @pytest.mark.parametrize("world", [1, 2])
-def test_data_parallel_step_rccl(tmp_path, world):
+def test_data_parallel_step_rccl(tmp_path, world, native):
     """The DP contract on the real "nccl" (= RCCL) backend: rank-0 weights broadcast, ONE all-reduce (SUM) of the flat
     gradient, dof_optimizer_step(grad_scale = 1 / world) -> identical parameters on every rank, sum == sum of the
     shards' gradients.  world = 2 runs whenever two devices are visible (skipped on a 1-GPU box); world = 1 runs the
-    same code path through an RCCL process group of one rank."""
+    same code path through an RCCL process group of one rank.  native: the exchange through the C ABI's own
+    communicator (dof_comm_* / dof_flat_allreduce, librccl opened by the library) instead of torch.distributed."""
     import os
     import torch.multiprocessing as mp
     if torch.cuda.device_count() < world:
         pytest.skip(f"{world} devices needed, {torch.cuda.device_count()} visible")
-    port = 29700 + (os.getpid() % 2000)
-    mp.spawn(_rccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 29700 + (os.getpid() % 2000) + (17 if native else 0)
+    mp.spawn(_rccl_worker, args=(world, port, str(tmp_path), native), nprocs=world, join=True)
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
     total = sum(r["local"] for r in res)
     for r in res:
