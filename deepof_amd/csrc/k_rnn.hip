@@ -345,6 +345,266 @@ __global__ void __launch_bounds__(256) k_gru_bwd(const int* __restrict__ len,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Generic GRU with a sequence spread over FOUR adjacent lanes (latent 16: hidden sizes 32 and 16).  The one-thread-per-
+// sequence kernels above run 25,600 sequences of a C2 batch as 800 wavefronts -- less than one per SIMD -- each a serial
+// chain of 3 HID (IN + HID) LDS-fed FMAs per step (6,144 at HID = IN = 32: 735 us forward, 1,141 us backward).  Here
+// lane q of a quad owns units [q HID/4, (q + 1) HID/4) of its sequence: four times the wavefronts, a quarter of the chain,
+// and the quad all-gathers h (forward) or the gate gradients (backward) once per step.  Every sum runs over the same
+// index order as in k_gru_fwd / k_gru_bwd, so the results are bitwise the same; same buffers, gate-major rows.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void dof_quad_allgather(const float (&mine)[N], float (&full)[4 * N]) {
+  const int base = (int)(threadIdx.x & 63) & ~3;
+#pragma unroll
+  for (int src = 0; src < 4; ++src)
+#pragma unroll
+    for (int u = 0; u < N; ++u) full[src * N + u] = __shfl(mine[u], base + src);
+}
+
+template <int IN, int HID, bool BCAST>
+__global__ void __launch_bounds__(256) k_gruq_fwd(const float* __restrict__ X, const int* __restrict__ len,
+                                                  const float* __restrict__ wih0, const float* __restrict__ whh0,
+                                                  const float* __restrict__ bih0, const float* __restrict__ bhh0,
+                                                  const float* __restrict__ wih1, const float* __restrict__ whh1,
+                                                  const float* __restrict__ bih1, const float* __restrict__ bhh1,
+                                                  float* __restrict__ O, float* __restrict__ GS, int T, int64_t S,
+                                                  int64_t Sp) {
+  static_assert(HID % 4 == 0 && IN % 4 == 0, "quad split");
+  constexpr int UQ = HID / 4;
+  const int q = threadIdx.x & 3;
+  const int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const int dir = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) float wih[3 * HID * IN];
+  __shared__ __attribute__((aligned(16))) float whh[3 * HID * HID];
+  __shared__ __attribute__((aligned(16))) float bih[3 * HID];
+  __shared__ __attribute__((aligned(16))) float bhh[3 * HID];
+  {
+    const float* __restrict__ g_wih = dir ? wih1 : wih0;
+    const float* __restrict__ g_whh = dir ? whh1 : whh0;
+    const float* __restrict__ g_bih = dir ? bih1 : bih0;
+    const float* __restrict__ g_bhh = dir ? bhh1 : bhh0;
+    for (int i = threadIdx.x; i < 3 * HID * IN; i += blockDim.x) wih[i] = g_wih[i];
+    for (int i = threadIdx.x; i < 3 * HID * HID; i += blockDim.x) whh[i] = g_whh[i];
+    for (int i = threadIdx.x; i < 3 * HID; i += blockDim.x) {
+      bih[i] = g_bih[i];
+      bhh[i] = g_bhh[i];
+    }
+  }
+  __syncthreads();
+  // (quads of sequences past the end keep running on the last sequence without storing: the all-gathers are wave-wide)
+  const bool live = s < S;
+  const int64_t sr = live ? s : S - 1;
+  float* __restrict__ gs = GS ? GS + (int64_t)dir * T * 4 * HID * Sp : nullptr;
+  const int n = len[sr];
+  int nmax = n;  // the longest sequence of the wavefront bounds the loop
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int o = __shfl_xor(nmax, m);
+    nmax = o > nmax ? o : nmax;
+  }
+  float h[HID];
+#pragma unroll
+  for (int j = 0; j < HID; ++j) h[j] = 0.0f;
+  float x[IN];
+  float gi[3 * UQ];
+  if (BCAST) {
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x[k] = X[(int64_t)k * Sp + sr];
+#pragma unroll
+    for (int u = 0; u < UQ; ++u)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const int j = g * HID + q * UQ + u;
+        float acc = bih[j];
+#pragma unroll
+        for (int k = 0; k < IN; ++k) acc = fmaf(wih[j * IN + k], x[k], acc);
+        gi[g * UQ + u] = acc;
+      }
+  }
+  for (int step = 0; step < nmax; ++step) {
+    const bool act = step < n;
+    const int t = dir ? (n - 1 - step) : step;
+    const int tl = act ? t : 0;
+    if (!BCAST) dof_ld_row<IN>(X + ACT(tl, 0, IN, Sp, sr), x);
+    float hmine[UQ];
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) {
+      DOF_MEM_FENCE();  // one unit's weight reads at a time (hoisted across units they take every register)
+      const int j = q * UQ + u;
+      float ar, az, an, ahn = bhh[2 * HID + j];
+      if (BCAST) {
+        ar = gi[u] + bhh[j];
+        az = gi[UQ + u] + bhh[HID + j];
+        an = gi[2 * UQ + u];
+      } else {
+        ar = bih[j] + bhh[j];
+        az = bih[HID + j] + bhh[HID + j];
+        an = bih[2 * HID + j];
+#pragma unroll
+        for (int k = 0; k < IN; ++k) {
+          ar = fmaf(wih[j * IN + k], x[k], ar);
+          az = fmaf(wih[(HID + j) * IN + k], x[k], az);
+          an = fmaf(wih[(2 * HID + j) * IN + k], x[k], an);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HID; ++k) {
+        ar = fmaf(whh[j * HID + k], h[k], ar);
+        az = fmaf(whh[(HID + j) * HID + k], h[k], az);
+        ahn = fmaf(whh[(2 * HID + j) * HID + k], h[k], ahn);
+      }
+      const float r = dof_sigmoid(ar);
+      const float z = dof_sigmoid(az);
+      const float nn = dof_tanh(fmaf(r, ahn, an));
+      hmine[u] = fmaf(z, h[j] - nn, nn);
+      if (act && live) {
+        O[ACT(t, dir * HID + j, 2 * HID, Sp, s)] = hmine[u];
+        if (gs) {
+          gs[ACT(t, j, 4 * HID, Sp, s)] = r;
+          gs[ACT(t, HID + j, 4 * HID, Sp, s)] = z;
+          gs[ACT(t, 2 * HID + j, 4 * HID, Sp, s)] = nn;
+          gs[ACT(t, 3 * HID + j, 4 * HID, Sp, s)] = ahn;
+        }
+      }
+    }
+    dof_quad_allgather<UQ>(hmine, h);
+  }
+  if (!live) return;
+  for (int t = n; t < T; ++t) {
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) {
+      const int j = q * UQ + u;
+      O[ACT(t, dir * HID + j, 2 * HID, Sp, s)] = 0.0f;
+      if (gs) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gs[ACT(t, g * HID + j, 4 * HID, Sp, s)] = 0.0f;
+      }
+    }
+  }
+}
+
+template <int IN, int HID, bool BCAST>
+__global__ void __launch_bounds__(256) k_gruq_bwd(const int* __restrict__ len, const float* __restrict__ wih0,
+                                                  const float* __restrict__ whh0, const float* __restrict__ wih1,
+                                                  const float* __restrict__ whh1, const float* __restrict__ O,
+                                                  float* __restrict__ GS, const float* __restrict__ dO,
+                                                  const float* __restrict__ dHfin, float* __restrict__ dX, int T,
+                                                  int64_t S, int64_t Sp) {
+  static_assert(HID % 4 == 0 && IN % 4 == 0, "quad split");
+  constexpr int UQ = HID / 4, XQ = IN / 4;
+  const int q = threadIdx.x & 3;
+  const int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const int dir = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) float wih[3 * HID * IN];
+  __shared__ __attribute__((aligned(16))) float whh[3 * HID * HID];
+  {
+    const float* __restrict__ g_wih = dir ? wih1 : wih0;
+    const float* __restrict__ g_whh = dir ? whh1 : whh0;
+    for (int i = threadIdx.x; i < 3 * HID * IN; i += blockDim.x) wih[i] = g_wih[i];
+    for (int i = threadIdx.x; i < 3 * HID * HID; i += blockDim.x) whh[i] = g_whh[i];
+  }
+  __syncthreads();
+  const bool live = s < S;
+  const int64_t sr = live ? s : S - 1;
+  float* __restrict__ gs = GS + (int64_t)dir * T * 4 * HID * Sp;
+  float* __restrict__ dx_out = dX + (int64_t)dir * (BCAST ? 1 : T) * IN * Sp;
+  const int n = len[sr];
+  int nmax = n;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int o = __shfl_xor(nmax, m);
+    nmax = o > nmax ? o : nmax;
+  }
+  float dh[UQ];  // gradient w.r.t. the lane's own units of h
+#pragma unroll
+  for (int u = 0; u < UQ; ++u) dh[u] = (dHfin && n > 0) ? dHfin[(int64_t)(dir * HID + q * UQ + u) * Sp + sr] : 0.0f;
+  float dxacc[XQ];
+#pragma unroll
+  for (int k = 0; k < XQ; ++k) dxacc[k] = 0.0f;
+  for (int step = nmax - 1; step >= 0; --step) {
+    const bool act = step < n;
+    const int t = dir ? (n - 1 - step) : step;
+    const int tp = dir ? t + 1 : t - 1;
+    float dgm[4 * UQ];  // own units: [gate][u]
+    float dhn[UQ];
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) {
+      const int j = q * UQ + u;
+      float r = 0.0f, z = 0.0f, nn = 0.0f, ahn = 0.0f, hp = 0.0f, dht = 0.0f;
+      if (act) {
+        r = gs[ACT(t, j, 4 * HID, Sp, sr)];
+        z = gs[ACT(t, HID + j, 4 * HID, Sp, sr)];
+        nn = gs[ACT(t, 2 * HID + j, 4 * HID, Sp, sr)];
+        ahn = gs[ACT(t, 3 * HID + j, 4 * HID, Sp, sr)];
+        hp = (step > 0) ? O[ACT(tp, dir * HID + j, 2 * HID, Sp, sr)] : 0.0f;
+        dht = dh[u];
+        if (dO) dht += dO[ACT(t, dir * HID + j, 2 * HID, Sp, sr)];
+      }
+      const float dn = dht * (1.0f - z);
+      const float dz = dht * (hp - nn);
+      dhn[u] = dht * z;
+      const float dnp = dn * (1.0f - nn * nn);
+      dgm[u] = dnp * ahn * r * (1.0f - r);
+      dgm[UQ + u] = dz * z * (1.0f - z);
+      dgm[2 * UQ + u] = dnp;
+      dgm[3 * UQ + u] = dnp * r;
+      if (act && live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gs[ACT(t, g * HID + j, 4 * HID, Sp, s)] = dgm[g * UQ + u];
+      }
+    }
+    // the whole gate-gradient vector in every lane of the quad: dg[gate][unit], unit = src * UQ + u
+    float dgf[16 * UQ];
+    dof_quad_allgather<4 * UQ>(dgm, dgf);
+    auto dg = [&](int g, int j) -> float { return dgf[(j / UQ) * 4 * UQ + g * UQ + (j % UQ)]; };
+    // dh_prev of the lane's own units: W_hh^T [dr, dz, d(ahn)], unit order as in k_gru_bwd
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        const int k = q * UQ + u;
+        dhn[u] = fmaf(whh[j * HID + k], dg(0, j), dhn[u]);
+        dhn[u] = fmaf(whh[(HID + j) * HID + k], dg(1, j), dhn[u]);
+        dhn[u] = fmaf(whh[(2 * HID + j) * HID + k], dg(3, j), dhn[u]);
+      }
+    }
+    if (act) {
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) dh[u] = dhn[u];
+    }
+    // dx of the lane's own input channels: W_ih^T [dr, dz, dn]
+    float dx[XQ];
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) dx[k] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int j = 0; j < HID; ++j) {
+#pragma unroll
+        for (int k = 0; k < XQ; ++k) dx[k] = fmaf(wih[(g * HID + j) * IN + q * XQ + k], dg(g, j), dx[k]);
+      }
+    if (act && live) {
+      if (BCAST) {
+#pragma unroll
+        for (int k = 0; k < XQ; ++k) dxacc[k] += dx[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < XQ; ++k) dx_out[ACT(t, q * XQ + k, IN, Sp, s)] = dx[k];
+      }
+    }
+  }
+  if (!live) return;
+  if (BCAST) {
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) dx_out[(int64_t)(q * XQ + k) * Sp + s] = dxacc[k];
+  } else {
+    for (int t = n; t < T; ++t)
+#pragma unroll
+      for (int k = 0; k < XQ; ++k) dx_out[ACT(t, q * XQ + k, IN, Sp, s)] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // GRU, weight-stationary form (latent 8: hidden sizes 16 and 8).  One LANE per hidden unit: the
 // 16 (or 8) lanes of a DPP row own the units of one (sequence, direction), keep their three gate
 // rows of W_ih / W_hh in VGPRs for the whole sequence (no weight traffic inside the time loop) and
@@ -1795,6 +2055,15 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
     else DOF_LAUNCH((k_gru3_fwd<8, 8, true>), (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
     return dof_check_launch("k_gru3_fwd");
   }
+  if (L == 16) {  // a sequence across four lanes
+    const unsigned nq = dof_cdiv(S * 4, 256);
+#define GRUQ_FWD(IN_, HID_, BC_) DOF_LAUNCH((k_gruq_fwd<IN_, HID_, BC_>), (nq, 2), (256), st, X, len, W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1, O, GS, T, S, Sp)
+    if (kind == 0) GRUQ_FWD(32, 32, false);
+    else if (kind == 1) GRUQ_FWD(64, 16, false);
+    else GRUQ_FWD(16, 16, true);
+#undef GRUQ_FWD
+    return dof_check_launch("k_gruq_fwd");
+  }
   const unsigned nb = dof_cdiv(S, 256);
   if (kind == 0) {
     DOF_DISPATCH_L(L, DOF_LAUNCH((k_gru_fwd<2 * LL, 2 * LL, false>), (nb, 2), (256), st, X, len, W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1, O, GS, T, S, Sp));
@@ -1813,6 +2082,15 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
     else if (kind == 1) DOF_LAUNCH((k_gru3_bwd<32, 8, false>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
     else DOF_LAUNCH((k_gru3_bwd<8, 8, true>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
     return dof_check_launch("k_gru3_bwd");
+  }
+  if (L == 16) {
+    const unsigned nq = dof_cdiv(S * 4, 256);
+#define GRUQ_BWD(IN_, HID_, BC_) DOF_LAUNCH((k_gruq_bwd<IN_, HID_, BC_>), (nq, 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp)
+    if (kind == 0) GRUQ_BWD(32, 32, false);
+    else if (kind == 1) GRUQ_BWD(64, 16, false);
+    else GRUQ_BWD(16, 16, true);
+#undef GRUQ_BWD
+    return dof_check_launch("k_gruq_bwd");
   }
   const unsigned nb = dof_cdiv(S, 256);
   if (kind == 0) {
