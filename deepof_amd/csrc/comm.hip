@@ -32,7 +32,7 @@ Rccl g_rccl;
 std::once_flag g_once;
 
 const Rccl* rccl() {
-#ifndef DOF_EMU
+#if DOF_HAS_DEVICE_RUNTIME
   std::call_once(g_once, [] {
     // the soname first: inside a PyTorch process this is the copy torch.distributed already loaded
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {

@@ -53,6 +53,45 @@ __device__ __forceinline__ uint32_t dof_pack_hi16(float lo_half, float hi_half) 
 #endif
 }
 
+// 1: the HIP runtime is underneath (RCCL can be opened); 0: the host-only emulation build
+#ifdef DOF_EMU
+#define DOF_HAS_DEVICE_RUNTIME 0
+#else
+#define DOF_HAS_DEVICE_RUNTIME 1
+#endif
+
+// 16-byte streaming (non-temporal) stores of four words, and the round-to-nearest products / sums the compiler must
+// not contract into FMAs (values compared bit for bit with numpy / torch op-by-op arithmetic).  The kernel sources use
+// these names only: everything that differs between the device build and the pytest-only emulation build lives in
+// this header.
+#ifdef DOF_EMU
+__device__ __forceinline__ void dof_st_stream4(float* out, const float (&v)[4]) {
+  out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
+__device__ __forceinline__ void dof_st_stream4(uint32_t* out, const uint32_t (&w)[4]) {
+  out[0] = w[0]; out[1] = w[1]; out[2] = w[2]; out[3] = w[3];
+}
+__device__ __forceinline__ float dof_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+__device__ __forceinline__ float dof_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+__device__ __forceinline__ double dof_dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+__device__ __forceinline__ double dof_dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+#else
+__device__ __forceinline__ void dof_st_stream4(float* out, const float (&v)[4]) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 pack = {v[0], v[1], v[2], v[3]};
+  __builtin_nontemporal_store(pack, reinterpret_cast<f32x4*>(out));
+}
+__device__ __forceinline__ void dof_st_stream4(uint32_t* out, const uint32_t (&w)[4]) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 pack = {w[0], w[1], w[2], w[3]};
+  __builtin_nontemporal_store(pack, reinterpret_cast<u32x4*>(out));
+}
+__device__ __forceinline__ float dof_fmul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float dof_fadd_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double dof_dmul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double dof_dadd_rn(double a, double b) { return __dadd_rn(a, b); }
+#endif
+
 #ifdef DOF_EMU
 #define DOF_SCHED_FENCE() ((void)0)
 #else

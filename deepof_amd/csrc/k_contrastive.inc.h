@@ -22,13 +22,9 @@ namespace {
 
 #define DOF_CL_MAX_NODES 64
 
-#ifdef DOF_EMU
-__device__ __forceinline__ float cl_mul(float a, float b) { volatile float r = a * b; return r; }
-__device__ __forceinline__ float cl_add(float a, float b) { volatile float r = a + b; return r; }
-#else
-__device__ __forceinline__ float cl_mul(float a, float b) { return __fmul_rn(a, b); }  // no FMA contraction:
-__device__ __forceinline__ float cl_add(float a, float b) { return __fadd_rn(a, b); }  // matches torch's op-by-op rounding
-#endif
+// no FMA contraction: matches torch's op-by-op rounding
+__device__ __forceinline__ float cl_mul(float a, float b) { return dof_fmul_rn(a, b); }
+__device__ __forceinline__ float cl_add(float a, float b) { return dof_fadd_rn(a, b); }
 
 struct ViewArgs {
   const float* x_full;    // (B, Tf, N, 3)

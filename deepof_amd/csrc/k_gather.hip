@@ -40,23 +40,12 @@ __device__ __forceinline__ void store_run(void* __restrict__ out_base, unsigned 
   constexpr int EPV = OUT16 ? 8 : 4;
   if (e0 + EPV - 1 < total) {
     if constexpr (OUT16) {
-      uint16_t* out = reinterpret_cast<uint16_t*>(out_base) + e0;
-#ifdef DOF_EMU
-      for (int j = 0; j < 8; ++j) out[j] = (uint16_t)bf16_rne(v[j]);
-#else
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 pack = {bf16_rne(v[0]) | (bf16_rne(v[1]) << 16), bf16_rne(v[2]) | (bf16_rne(v[3]) << 16),
-                    bf16_rne(v[4]) | (bf16_rne(v[5]) << 16), bf16_rne(v[6]) | (bf16_rne(v[7]) << 16)};
-      __builtin_nontemporal_store(pack, reinterpret_cast<u32x4*>(out));
-#endif
+      const uint32_t w[4] = {bf16_rne(v[0]) | (bf16_rne(v[1]) << 16), bf16_rne(v[2]) | (bf16_rne(v[3]) << 16),
+                             bf16_rne(v[4]) | (bf16_rne(v[5]) << 16), bf16_rne(v[6]) | (bf16_rne(v[7]) << 16)};
+      dof_st_stream4(reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(out_base) + e0), w);
     } else {
-      float* out = reinterpret_cast<float*>(out_base) + e0;
-#ifdef DOF_EMU
-      out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
-#else
-      dof_f32x4 pack = {v[0], v[1], v[2], v[3]};
-      __builtin_nontemporal_store(pack, reinterpret_cast<dof_f32x4*>(out));
-#endif
+      const float f[4] = {v[0], v[1], v[2], v[3]};
+      dof_st_stream4(reinterpret_cast<float*>(out_base) + e0, f);
     }
   } else {
     for (int j = 0; j < EPV; ++j)

@@ -793,13 +793,8 @@ __device__ __forceinline__ double pp_value(double x, double cf0, double cf1, dou
   return (clipk && fabs(z) > clip) ? pp_nanv() : z;
 }
 
-#ifdef DOF_EMU
-#define PP_MUL_RN(a, b) ((a) * (b))
-#define PP_ADD_RN(a, b) ((a) + (b))
-#else
-#define PP_MUL_RN(a, b) __dmul_rn((a), (b))
-#define PP_ADD_RN(a, b) __dadd_rn((a), (b))
-#endif
+#define PP_MUL_RN(a, b) dof_dmul_rn((a), (b))
+#define PP_ADD_RN(a, b) dof_dadd_rn((a), (b))
 // numpy.interp between valid rows p < q (values pv, qv): slope * (x - x0) + y0, multiply and add rounded separately;
 // flat beyond the first / last valid row of the video, 0 for a column without any valid row
 __device__ __forceinline__ double pp_interp(int64_t row, int64_t p, double pv, int64_t q, double qv) {
