@@ -1784,31 +1784,41 @@ __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __re
 // The first block's weight gradients (round 3): conv1 reads the raw input (3 or 1 channels per sequence, dilation 1) and
 // the block's residual branch is a 1 x 1 convolution of the same input.  Through the generic reduction they cost a pass
 // that normalises conv1's gradient in place (k_tcn_bn_bwd2) plus k_outer's operand stream over two 32-channel gradient
-// tensors.  Here thread (channel o, sequence s) walks the T steps of its sequence: its own element of the two gradient
-// rows straight from HBM (a half-wave reads one 128-byte row; pass 2 of BatchNorm1's backward applied on load, like
-// k_tcn_wgrad), the input row as a half-wave broadcast kept in a four-step register window, and the (4 taps + 1) x cin
-// outer products on the vector pipe (a 32 x 15 result does not need the matrix pipe).  No LDS staging, so occupancy is
-// register-bound and the loads of several steps are in flight; the sixteen sequence groups of a workgroup are added in a
-// fixed order into partial tiles of k_outer's layout.
+// tensors.  Here a lane owns four channels of one sequence and walks its T steps: 16-byte loads of the two gradient rows
+// straight from HBM (pass 2 of BatchNorm1's backward applied on load, like k_tcn_wgrad), the input row shared by the
+// eight lanes of the sequence and kept in a four-step register window, and the (4 taps + 1) x cin outer products on the
+// vector pipe (a 32 x 15 result does not need the matrix pipe).  No LDS staging, so occupancy is register-bound and the
+// loads of several steps are in flight; the sequences of a wavefront are added by a fixed butterfly, the wavefronts in
+// order, into partial tiles of k_outer's layout.
 template <int F>
 __device__ __forceinline__ void tcn_wgrad_in_body(const DofTcnWgrad& D, float* __restrict__ partials, float* red) {
   constexpr int NV = 5 * F + 2;  // values per channel: 4 F conv taps, conv bias, F residual weights, its bias
-  constexpr int NG = 16;         // sequence groups (half-waves) per workgroup
+  // lane = (sequence of the wave's eight) * 8 + channel quad: a wavefront reads 1 KB of contiguous gradient rows per
+  // 16-byte load instruction, the eight lanes of a sequence share its input row
   const int T = D.T, tid = threadIdx.x;
   const int64_t Sp = D.Sp;
-  const int o = tid & 31, g = tid >> 5;
-  float ka = 1.0f, kb = 0.0f, kc = 0.0f, bm = 0.0f;
+  const int c4 = (tid & 7) * 4, sl = tid >> 3;
+  float ka[4], kb[4], kc[4], bm[4];
   const bool lazy = D.dy_y != nullptr, two = D.dy2 != nullptr;
   if (lazy) {  // dy = scale (g - c1 - (y - mean) rstd c2) = ka g + kb (y - mean) + kc
-    bm = D.dy_bnp[o];
-    ka = D.dy_bnp[2 * 32 + o];
-    kb = -ka * D.dy_bnp[32 + o] * D.dy_coef[32 + o];
-    kc = -ka * D.dy_coef[o];
-  }
-  float acc[NV];
+    float br[4], c1[4], c2[4];
+    dof_ld_row<4>(D.dy_bnp + c4, bm);
+    dof_ld_row<4>(D.dy_bnp + 32 + c4, br);
+    dof_ld_row<4>(D.dy_bnp + 2 * 32 + c4, ka);
+    dof_ld_row<4>(D.dy_coef + c4, c1);
+    dof_ld_row<4>(D.dy_coef + 32 + c4, c2);
 #pragma unroll
-  for (int v = 0; v < NV; ++v) acc[v] = 0.0f;
-  for (int64_t s = (int64_t)blockIdx.x * NG + g; s < Sp; s += (int64_t)D.nblk * NG) {
+    for (int k = 0; k < 4; ++k) {
+      kb[k] = -ka[k] * br[k] * c2[k];
+      kc[k] = -ka[k] * c1[k];
+    }
+  }
+  float acc[4][NV];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[c][v] = 0.0f;
+  for (int64_t s = (int64_t)blockIdx.x * 64 + sl; s < Sp; s += (int64_t)D.nblk * 64) {
     const bool valid = s < D.S;
     float xw[4][F];
 #pragma unroll
@@ -1818,12 +1828,15 @@ __device__ __forceinline__ void tcn_wgrad_in_body(const DofTcnWgrad& D, float* _
 #pragma unroll 5
     for (int t = 0; t < T; ++t) {
       const int64_t row = (int64_t)t * Sp + s;
-      float a = D.dy[row * 32 + o];
+      float a[4], b2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      dof_ld_row<4>(D.dy + row * 32 + c4, a);
       if (lazy) {
-        const float y = D.dy_y[row * 32 + o];
-        a = valid ? fmaf(ka, a, fmaf(kb, y - bm, kc)) : 0.0f;
+        float y[4];
+        dof_ld_row<4>(D.dy_y + row * 32 + c4, y);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = valid ? fmaf(ka[k], a[k], fmaf(kb[k], y[k] - bm[k], kc[k])) : 0.0f;
       }
-      const float b2 = two ? D.dy2[row * 32 + o] : 0.0f;
+      if (two) dof_ld_row<4>(D.dy2 + row * 32 + c4, b2);
 #pragma unroll
       for (int f = 0; f < F; ++f) {
         xw[0][f] = xw[1][f];
@@ -1832,18 +1845,36 @@ __device__ __forceinline__ void tcn_wgrad_in_body(const DofTcnWgrad& D, float* _
         xw[3][f] = D.in[row * F + f];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) acc[j * F + f] = fmaf(a, xw[j][f], acc[j * F + f]);
-      acc[4 * F] += a;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int f = 0; f < F; ++f) acc[4 * F + 1 + f] = fmaf(b2, xw[3][f], acc[4 * F + 1 + f]);
-      acc[5 * F + 1] += b2;
+          for (int f = 0; f < F; ++f) acc[c][j * F + f] = fmaf(a[c], xw[j][f], acc[c][j * F + f]);
+        acc[c][4 * F] += a[c];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[c][4 * F + 1 + f] = fmaf(b2[c], xw[3][f], acc[c][4 * F + 1 + f]);
+        acc[c][5 * F + 1] += b2[c];
+      }
     }
   }
-  // the sequence groups of the workgroup, added in group order
+  // the eight sequences of a wavefront (fixed butterfly), then the eight wavefronts in order
+  const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-  for (int v = 0; v < NV; ++v) red[(g * 32 + o) * NV + v] = acc[v];
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float x = acc[c][v];
+      x += __shfl_xor(x, 8);
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      acc[c][v] = x;
+    }
+  if (lane < 8) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) red[(wave * 32 + c4 + c) * NV + v] = acc[c][v];
+  }
   __syncthreads();
   float* p0 = partials + D.part0 + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
   float* p1 = partials + D.part1 + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
@@ -1851,7 +1882,7 @@ __device__ __forceinline__ void tcn_wgrad_in_body(const DofTcnWgrad& D, float* _
     const int oo = e / NV, v = e - oo * NV;
     float sum = 0.0f;
 #pragma unroll
-    for (int k = 0; k < NG; ++k) sum += red[(k * 32 + oo) * NV + v];
+    for (int k = 0; k < 8; ++k) sum += red[(k * 32 + oo) * NV + v];
     if (v < 4 * F) p0[oo * 65 + (v / F) * 16 + (v % F)] = sum;
     else if (v == 4 * F) p0[oo * 65 + 64] = sum;
     else if (two) {
@@ -1863,7 +1894,7 @@ __device__ __forceinline__ void tcn_wgrad_in_body(const DofTcnWgrad& D, float* _
 
 // both streams' descriptors in one launch (node: 3 input channels, edge: 1), so that the two fill the chip together
 __global__ void __launch_bounds__(512) k_tcn_wgrad_in(const DofTcnWgrad* __restrict__ descs, float* __restrict__ partials) {
-  __shared__ float red[16 * 32 * 17];
+  __shared__ float red[8 * 32 * 17];
   const DofTcnWgrad D = descs[blockIdx.y];
   if ((int)blockIdx.x >= D.nblk) return;
   if (D.cin == 3) tcn_wgrad_in_body<3>(D, partials, red);

@@ -978,8 +978,8 @@ void build_tcn_jobs(DofVadePlan* p) {
         // 32 -> 32 convolutions: the partial tiles of the two jobs come from k_tcn_wgrad (LDS-staged operands)
         const bool first = cin < C && d == 1 && t.first_staged;  // block 0: one job of four tap tiles, from k_tcn_wgrad_in
         const bool staged = (cin == C && T <= DOF_TCN_WGRAD_MAX_T) || first;
-        // (first: 256 workgroups of 8 waves per stream = the 4 waves per SIMD its registers allow, both streams resident)
-        const int ext = first ? (int)(Sp / 16 < 1 ? 1 : Sp / 16 < 256 ? Sp / 16 : 256) : staged ? (int)(Sp / 8 < 448 ? Sp / 8 : 448) : 0;
+        // (first: 128 workgroups of 8 waves per stream = the 2 waves per SIMD its registers allow, both streams resident)
+        const int ext = first ? (int)(Sp / 64 < 1 ? 1 : Sp / 64 < 128 ? Sp / 64 : 128) : staged ? (int)(Sp / 8 < 448 ? Sp / 8 : 448) : 0;
         if (staged) {
           DofTcnWgrad g;
           memset(&g, 0, sizeof(g));
