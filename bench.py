@@ -309,6 +309,24 @@ def _source_sha(files):
     return h.hexdigest()[:16]
 
 
+def spawn_ranks(n):
+    """Re-run this command line as n ranks under torch.distributed.run on this node (rendezvous on 127.0.0.1, a free
+    port); rank 0's JSON line is the child's stdout, the exit code is the launcher's."""
+    import socket
+    import subprocess
+    if os.environ.get("DOF_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py --gpus {n}: {torch.cuda.device_count()} GPU(s) visible; one rank per GPU is required")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only mode the host driver supports
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,7 +344,14 @@ def main():
     ap.add_argument("--log-every", type=int, default=0, help="debug: print the loss terms every N steps (adds syncs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` run bare: start the N ranks ourselves (one process per GPU, RCCL), exactly as the
+        # driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` would.
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and os.environ.get("DOF_BENCH_FORCE_PG") != "1":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -336,6 +361,9 @@ def main():
     share = os.environ.get("DOF_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {torch.cuda.device_count()} visible "
+                         f"(no oversubscription: RCCL refuses two ranks on one device)")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1 or os.environ.get("DOF_BENCH_FORCE_PG") == "1":  # FORCE_PG: a 1-rank RCCL group (exercises the DP path)
@@ -421,6 +449,16 @@ def main():
             el2 = float(tt.item())
         sustained = {"steps": n_more, "ms_per_step": 1e3 * el2 / n_more, "value": world * B * n_more / el2}
 
+    dp = None
+    if world > 1 or os.environ.get("DOF_BENCH_FORCE_PG") == "1":
+        import torch.distributed as dist
+        from deepof_amd.training import dp_form
+        devs = [None] * dist.get_world_size()
+        dist.all_gather_object(devs, torch.cuda.current_device())
+        dp = {"backend": dist.get_backend(), "rccl_world_size": dist.get_world_size() if dist.get_backend() == "nccl" else None,
+              "world_size": dist.get_world_size(), "form": dp_form(eng, dist),
+              "allreduce_bytes_per_step": int(eng.grads.numel()) * 4, "collectives_per_step": 1,
+              "devices": devs}
     # algorithmic work of one step (7.6 MFLOP forward per window, training = 3 x) against the fp32 vector peak
     flops_per_step = 3.0 * 7.6e6 * B
     out = {
@@ -433,7 +471,7 @@ def main():
                    "hip_graph": stepper.graphs.enabled, "graph_replays": stepper.graphs.replays,
                    "path": "deepof_amd.training.VadeStepper.step (the fit loop's step)",
                    "final_total_loss": logs["total_loss"]},
-        "sustained": sustained,
+        "sustained": sustained, "data_parallel": dp,
         "roofline_step": {"flop_frac": flops_per_step / (ms_per_step * 1e-3) / FP32_PEAK_FLOPS,
                           "achieved_tflops": flops_per_step / (ms_per_step * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_FLOPS / 1e12,
                           "algorithmic_flops_per_step": flops_per_step, "hbm_frac": None, "hbm_bytes_per_step": None},

@@ -5,7 +5,7 @@ The reference wraps its models in ``DistributedDataParallel`` (/root/reference/d
 step's own stream.  ``NativeComm`` is the host side of that: rank 0 draws the RCCL unique id, the 128 bytes travel
 over whatever channel the launcher already has (a ``torch.distributed`` group of any backend, or a callable supplied by
 the caller), every rank creates its communicator on its device.  ``training._dp_step`` uses it when
-``DOF_DP_NATIVE=1``; the default remains ``torch.distributed.all_reduce`` on the same RCCL.
+the process group runs on RCCL (the default; ``DOF_DP_NATIVE=0`` keeps ``torch.distributed.all_reduce``).
 """
 from __future__ import annotations
 

@@ -28,10 +28,12 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, float rcp_l
   return q;
 }
 
-// float -> bf16 bits, round to nearest even (finite inputs)
+// float -> bf16 bits, round to nearest even; +-Inf stay Inf, a NaN keeps its sign and upper payload and is made quiet
+// (the rounding add would turn a NaN with low mantissa bits only into Inf and wrap an all-ones NaN to zero)
 __device__ __forceinline__ uint32_t bf16_rne(float v) {
   const uint32_t u = __builtin_bit_cast(uint32_t, v);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+  const uint32_t r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+  return (u & 0x7FFFFFFFu) > 0x7F800000u ? ((u >> 16) | 0x40u) : r;
 }
 // One 16-byte streaming store of EPV consecutive output elements starting at element e0 (EPV = 4 fp32 or 8 bf16), or the
 // tail elements one by one

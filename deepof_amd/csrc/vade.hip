@@ -1293,6 +1293,10 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     else if (_l == 6 && _d == 64) DOF_LAUNCH((NAME<6, 64>), GRID, (256), st, __VA_ARGS__);             \
     else if (_l == 8 && _d == 64) DOF_LAUNCH((NAME<8, 64>), GRID, (256), st, __VA_ARGS__);             \
     else if (_l == 16 && _d == 32) DOF_LAUNCH((NAME<16, 32>), GRID, (256), st, __VA_ARGS__);           \
+    else if (_l == 16 && _d == 24) DOF_LAUNCH((NAME<16, 24>), GRID, (256), st, __VA_ARGS__);           \
+    else if (_l == 16 && _d == 40) DOF_LAUNCH((NAME<16, 40>), GRID, (256), st, __VA_ARGS__);           \
+    else if (_l == 16 && _d == 48) DOF_LAUNCH((NAME<16, 48>), GRID, (256), st, __VA_ARGS__);           \
+    else if (_l == 16 && _d == 64) DOF_LAUNCH((NAME<16, 64>), GRID, (256), st, __VA_ARGS__);           \
     else { dof_set_error("CensNet (latent %d, channels %d) not supported by this build", _l, _d); return DOF_ERR_UNSUPPORTED; } \
   } while (0)
 

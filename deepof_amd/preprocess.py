@@ -164,9 +164,15 @@ def _scaler_to_dict(per_col: np.ndarray, kinds: np.ndarray, modes: Dict[str, Opt
     return None if all(out[k] is None for k in ("speed", "dist", "dist_inner", "dist_intra", "coord")) else out
 
 
-def _scaler_from_dict(gs: dict, kinds: np.ndarray, modes: Dict[str, Optional[str]]) -> np.ndarray:
+def _scaler_from_dict(gs: dict, kinds: np.ndarray, modes: Dict[str, Optional[str]], scale: str = None,
+                      present: Optional[np.ndarray] = None) -> np.ndarray:
     """Legacy dict (pairs as written by _scaler_to_dict, or fitted sklearn StandardScalers / MinMaxScalers) -> (C,2)
-    (offset, divisor), identity where nothing applies."""
+    (offset, divisor), identity where nothing applies.  ``present`` (C,) marks the columns the low-variance filter kept
+    in at least one video: a per-column section fitted on filtered tables has one entry per PRESENT column (what
+    _scaler_to_dict writes, and what a sklearn scaler fitted on the reference's filtered tables holds), which is mapped
+    back onto those columns; a section with an entry for every column of its kind is accepted as well."""
+    if scale is not None and gs.get("kind") is not None and gs["kind"] != scale:
+        raise ValueError(f"pretrained scaler is of kind {gs['kind']!r}, scale={scale!r} was requested")
     per_col = np.tile(np.array([0.0, 1.0]), (len(kinds), 1))
 
     def pair(v):
@@ -186,7 +192,11 @@ def _scaler_from_dict(gs: dict, kinds: np.ndarray, modes: Dict[str, Optional[str
             return
         m, s = pair(gs[name])
         if mode == "per_column" and len(m) != len(idx):
-            raise ValueError(f"pretrained scaler section {name!r} has {len(m)} columns, the tables have {len(idx)}")
+            kept = [i for i in idx if present is None or present[i]]
+            if len(m) != len(kept):
+                raise ValueError(f"pretrained scaler section {name!r} has {len(m)} columns, the tables have {len(idx)}"
+                                 + (f" ({len(kept)} after the low-variance filter)" if len(kept) != len(idx) else ""))
+            idx = kept
         per_col[idx, 0] = m if mode == "per_column" else m[0]
         per_col[idx, 1] = s if mode == "per_column" else s[0]
 
@@ -359,7 +369,8 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
     n_node, n_edge, n_ang = len(node_columns), len(edge_columns), len(angle_columns)
     fit_global = pretrained_scaler is None
     mask = sample_mask(lengths, samples_max) if fit_global else None
-    scaler_in = None if fit_global else torch.from_numpy(_scaler_from_dict(pretrained_scaler, plan.kinds, modes)).to(device)
+    scaler_in = None if fit_global else torch.from_numpy(_scaler_from_dict(
+        pretrained_scaler, plan.kinds, modes, scale, None if keep is None else keep.any(axis=0))).to(device)
     common = dict(plan=plan, out_cols=out_cols, n_node=n_node, n_edge=n_edge, n_ang=n_ang, modes=modes, log_distances=log_distances,
                   inter_scale=inter_scale, scale=scale,
                   clip=interpolate_normalized if scale == "standard" else 0)   # utils.py:2993: only "standard" clips

@@ -71,19 +71,22 @@ def _dist_state():
 
 def _dp_step(graphs, key, slot, forward_backward, eng, dist, world: int):
     """The data-parallel step: [gather + loss + gradients] -> ONE all-reduce (SUM) of the flat gradient over RCCL ->
-    [clip + Adam with grad_scale 1 / world].  The collective is enqueued by torch.distributed on RCCL's own stream and
-    the step's stream waits for it on the device (an event, not the host): the host never blocks inside a step.
-    Default: two captured graphs around the eagerly enqueued collective.  DOF_DP_ONE_GRAPH=1 captures the collective
-    too -- the whole step is one hipGraph replay (RCCL kernels are capturable).  DOF_DP_NATIVE=1: the collective is the
-    C ABI's dof_flat_allreduce on the step's own stream instead of torch.distributed's."""
+    [clip + Adam with grad_scale 1 / world].
+
+    Default on the RCCL ("nccl") backend: the collective is the C ABI's ``dof_flat_allreduce`` on the step's OWN stream,
+    captured with everything else into ONE hipGraph -- a data-parallel step is a single graph replay, no event hop to
+    a communication stream and no second graph launch.  ``DOF_DP_NATIVE=0`` keeps ``torch.distributed.all_reduce``
+    (enqueued on RCCL's own stream; the step's stream waits for it on the device), ``DOF_DP_ONE_GRAPH=0`` keeps two
+    captured graphs around an eagerly enqueued collective.  Other backends (gloo: the CPU tests) always take the
+    torch.distributed form, two graphs.  The switches are read once per process (``_dp_switches``)."""
     scale = 1.0 / world
-    if os.environ.get("DOF_DP_NATIVE", "0") == "1":
-        # the C ABI's own exchange (dof_flat_allreduce): RCCL on the step's stream, stream-ordered with the two graphs
+    native, one_graph = _dp_switches(eng, dist)
+    if native:
         comm = _native_comm(eng, dist)
         reduce = lambda: comm.all_reduce_(eng.grads)
     else:
         reduce = lambda: dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
-    if os.environ.get("DOF_DP_ONE_GRAPH", "0") == "1":
+    if one_graph:
         def whole():
             forward_backward()
             reduce()
@@ -95,17 +98,58 @@ def _dp_step(graphs, key, slot, forward_backward, eng, dist, world: int):
     graphs.run((eng.B, world, "adam"), lambda: eng.optimizer_step(scale))
 
 
-_NATIVE_COMM = None
+_DP_SWITCHES = {}
+
+
+def _dp_switches(eng, dist):
+    """(native collective, one graph) for this process group, decided once: the RCCL backend on a ROCm device takes the
+    one-graph native form unless DOF_DP_NATIVE=0 / DOF_DP_ONE_GRAPH=0 say otherwise; any other backend cannot."""
+    ident = _pg_identity(eng, dist)
+    sw = _DP_SWITCHES.get(ident)
+    if sw is None:
+        rccl = eng.params.is_cuda and dist.get_backend() == "nccl"
+        native = rccl and os.environ.get("DOF_DP_NATIVE", "1") != "0"
+        one_graph = rccl and os.environ.get("DOF_DP_ONE_GRAPH", "1") != "0"
+        _DP_SWITCHES.clear()
+        sw = _DP_SWITCHES[ident] = (native, one_graph)
+    return sw
+
+
+def dp_form(eng, dist) -> str:
+    """Name of the data-parallel form `_dp_step` takes (bench / log lines)."""
+    native, one_graph = _dp_switches(eng, dist)
+    return ("dof_flat_allreduce" if native else "torch.distributed.all_reduce") + \
+           (" captured in the step graph" if one_graph else " between two graphs")
+
+
+def _pg_identity(eng, dist):
+    """What a cached communicator / switch pair belongs to: the default process group object (a re-initialised group is
+    a new object), its shape, and the device."""
+    pg = dist.distributed_c10d._get_default_group()
+    return (id(pg), dist.get_rank(), dist.get_world_size(), str(eng.params.device))
+
+
+_NATIVE_COMM = {}
 
 
 def _native_comm(eng, dist):
     """This process's RCCL communicator behind the C ABI (deepof_amd.comm.NativeComm), created on first use: rank 0's
-    unique id travels over the initialised torch.distributed group."""
-    global _NATIVE_COMM
-    if _NATIVE_COMM is None:
+    unique id travels over the initialised torch.distributed group.  Cached per (process group, rank, world, device);
+    a communicator of another group is closed when a new one is made, and `close_native_comm` drops it at the end of
+    a fit."""
+    ident = _pg_identity(eng, dist)
+    comm = _NATIVE_COMM.get(ident)
+    if comm is None:
+        close_native_comm()
         from .comm import NativeComm
-        _NATIVE_COMM = NativeComm.from_process_group(eng.lib, dist)
-    return _NATIVE_COMM
+        comm = _NATIVE_COMM[ident] = NativeComm.from_process_group(eng.lib, dist)
+    return comm
+
+
+def close_native_comm():
+    for comm in _NATIVE_COMM.values():
+        comm.close()
+    _NATIVE_COMM.clear()
 
 
 def _dp_active(dist, world: int) -> bool:
@@ -583,9 +627,14 @@ except Exception:   # noqa: BLE001
     pass
 
 
-def _report_trial(trial, score_value: float, epoch: int) -> float:
+def _report_trial(trial, score_value: float, epoch: int, running_max: float = None) -> float:
     """The reference's tuning hook at the end of an epoch (training.py:1224-1228, 1420-1424, 1853-1857): report the
-    epoch's alignment score, stop when the pruner says so.  Returns the reported value (the fit's ``max_score``)."""
+    epoch's alignment score, stop when the pruner says so.  Returns the reported value (the fit's ``max_score``).
+    ``running_max`` (fit_contrastive, training.py:1384, 1420-1422): the reference reports a running maximum that starts
+    at -inf and its score is NaN when the hook runs, so -inf is what Optuna sees (a NaN report would be pruned by
+    MedianPruner at epoch 0, unlike the reference)."""
+    if running_max is not None:
+        score_value = score_value if score_value > running_max else running_max
     if trial is not None:
         trial.report(score_value, step=epoch)
         if trial.should_prune():
@@ -1092,7 +1141,7 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
     _, best_path_val, best_path_score, _ = ckpt_paths("contrastive", common_cfg)
     log_summary = init_log_summary("contrastive")
     selector = CheckpointSelector(common_cfg.epochs, rising_start=False)
-    max_score = 0.0
+    max_score = -float("inf")   # training.py:1384
     keys = ("total_loss", "pos_similarity", "neg_similarity", "distill_loss", "seperability")
 
     log_sum = torch.zeros(_capi.LOG_COUNT, dtype=torch.float64, device=eng.device)
@@ -1140,7 +1189,7 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
                   f"distill={train_logs['distill_loss']:.4f} | val total={v_total:.4f} | "
                   f"align score={float(val_logs['alignment_score']):.3f}")
         improved_val, save_score = selector.update(epoch, v_total, score_value, has_score=tau_star is not None)
-        max_score = _report_trial(trial, score_value, epoch)
+        max_score = _report_trial(trial, score_value, epoch, running_max=max_score)
         if save_score:
             if common_cfg.save_weights and is_main:
                 save_model_info(best_path_score, stage="best_score", epoch=epoch, train_steps=(epoch + 1) * nb,
@@ -1214,6 +1263,9 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
         if TB_WRITER is not None:
             TB_WRITER.close()
             TB_WRITER = None
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        close_native_comm()   # the fit's RCCL communicator behind the C ABI (its step graphs died with the steppers)
 
 
 def train_deepof_model(

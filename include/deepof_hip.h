@@ -61,7 +61,8 @@ int dof_window_gather_range(const float* node_table, const float* edge_table, in
                             int64_t n_windows, int32_t window, int32_t n_nodes, int32_t n_edges, float* x_out,
                             float* a_out, void* stream);
 /* bf16 storage of the window batches (BASELINE.json configs[1] "bf16"; SURVEY 8(d): W*(3N+E)*2 bytes written per
- * window): the same gather writing round-to-nearest-even bf16, eight elements per 16-byte store.  row_start != NULL:
+ * window): the same gather writing round-to-nearest-even bf16 (+-Inf kept, a NaN stays a NaN: sign and upper payload
+ * kept, quiet bit set), eight elements per 16-byte store.  row_start != NULL:
  * the listed start rows (first_row / row_step ignored), NULL: first_row + k * row_step.  W*3N and W*E must be even.
  * dof_widen_bf16 turns a stored batch back into the fp32 tensors the step kernels read (exact). */
 int dof_window_gather_bf16(const float* node_table, const float* edge_table, const int64_t* row_start, int64_t first_row,

@@ -47,6 +47,9 @@ def gather_check(lib, device):
                                   (5, 4, 7, 8400, list(range(1, 1 + 8213)))]:
         nodes = rng.standard_normal((Fr, 3 * N)).astype(np.float32)
         edges = rng.standard_normal((Fr, E)).astype(np.float32)
+        # non-finite table entries travel unchanged (fp32) / as Inf and the canonical NaN (bf16 storage)
+        nodes.view(np.uint32)[5, :5] = [0x7F800001, 0x7FFFFFFF, 0xFFFFFFFF, 0x7F800000, 0xFF800000]
+        edges.view(np.uint32)[4, :3] = [0x7FC00000, 0xFF800001, 0x7F7FFFFF]
         x_ref, a_ref = OW.gather_windows(nodes, edges, np.array(starts), W)
         tn, te = torch.from_numpy(nodes).to(device), torch.from_numpy(edges).to(device)
         st = torch.tensor(starts, dtype=torch.int64, device=device)
@@ -74,17 +77,19 @@ def gather_check(lib, device):
             _capi.check(lib, lib.dof_window_gather_bf16(tn.data_ptr(), te.data_ptr(), st.data_ptr(), 0, 0, len(starts), W, N, E,
                                                         xb.data_ptr(), ab.data_ptr(), stream))
             want_x, want_a = torch.from_numpy(x_ref).to(torch.bfloat16), torch.from_numpy(a_ref).to(torch.bfloat16)
-            assert torch.equal(xb.cpu().view(torch.int16), want_x.view(torch.int16))
-            assert torch.equal(ab.cpu().view(torch.int16), want_a.view(torch.int16))
+
+            def same_bits(got, want):   # bit for bit, a NaN wherever the source holds one (payload bits are not compared)
+                got, nan = got.cpu(), torch.isnan(want)
+                return torch.equal(torch.isnan(got), nan) and torch.equal(got.view(torch.int16)[~nan], want.view(torch.int16)[~nan])
+            assert same_bits(xb, want_x) and same_bits(ab, want_a)
             xb2 = torch.zeros((nw, W, N, 3), dtype=torch.bfloat16, device=device)
             ab2 = torch.zeros((nw, W, E, 1), dtype=torch.bfloat16, device=device)
             _capi.check(lib, lib.dof_window_gather_bf16(tn.data_ptr(), te.data_ptr(), None, 0, 2, nw, W, N, E,
                                                         xb2.data_ptr(), ab2.data_ptr(), stream))
-            assert torch.equal(xb2.cpu().view(torch.int16), torch.from_numpy(xr).to(torch.bfloat16).view(torch.int16))
-            assert torch.equal(ab2.cpu().view(torch.int16), torch.from_numpy(ar).to(torch.bfloat16).view(torch.int16))
+            assert same_bits(xb2, torch.from_numpy(xr).to(torch.bfloat16)) and same_bits(ab2, torch.from_numpy(ar).to(torch.bfloat16))
             wide = torch.full((len(starts), W, N, 3), float("nan"), device=device)
             _capi.check(lib, lib.dof_widen_bf16(xb.data_ptr(), wide.data_ptr(), xb.numel(), stream))
-            assert torch.equal(wide.cpu(), want_x.float())
+            np.testing.assert_array_equal(wide.cpu().numpy(), want_x.float().numpy())
         else:
             xb = torch.zeros((len(starts), W, N, 3), dtype=torch.bfloat16, device=device)
             assert lib.dof_window_gather_bf16(tn.data_ptr(), te.data_ptr(), st.data_ptr(), 0, 0, len(starts), W, N, E,
@@ -1176,6 +1181,14 @@ def run_preprocess_r03_check(lib, device, golden_dir):
         assert res.global_scaler["kind"] == c["scale"]
         if first_mm is None and c["scale"] == "minmax":
             first_mm = (c, res.global_scaler)
+        if c["filter"] and c["dropped"] and "per_column" in (c["dist"], c["speed"], c["coord"]) and c["scale"] != "robust":
+            # a scaler fitted on FILTERED tables (per-column sections hold the kept columns only) is reusable as the
+            # pretrained scaler of tables that drop the same columns, like the reference's sklearn scalers
+            again = preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, pretrained_scaler=res.global_scaler, **kw)
+            _check_tables(again, exp, cols, node_cols, edge_cols, angle_cols, c["case"] + " (own scaler as pretrained)")
+            with pytest.raises(ValueError):   # a scaler of another kind is refused, not silently applied
+                preprocess_tables(tabs, cols, aids, node_cols, edge_cols, angle_cols, pretrained_scaler=res.global_scaler,
+                                  **dict(kw, scale="standard" if c["scale"] != "standard" else "minmax"))
     c, gs = first_mm
     cols, aids, _ = data["pair"]
     node_cols, edge_cols, angle_cols = preprocess_output_columns(cols)

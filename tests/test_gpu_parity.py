@@ -1111,8 +1111,51 @@ def test_data_parallel_step_rccl(tmp_path, world, native):
         assert float((res[0]["local"] - res[1]["local"]).abs().max()) > 0
 
 
+def _dp_default_form_worker(rank, world, port, tmp):
+    import os
+    import sys
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from deepof_amd import training as TR
+    out = {}
+    for tag, force in (("dp", "1"), ("plain", "0")):
+        os.environ["DOF_FORCE_DP"] = force
+        stepper, model, ds, starts, _t, _tau = bench.vade_stepper_setup([""], 25, 10, 64, "recurrent", 1500, torch.device("cuda"))
+        for i in range(6):   # eager, capture, four replays
+            stepper.step(ds, starts[i], starts[i] + 64, True, True)
+        torch.cuda.synchronize()
+        out[tag] = model._base.params.cpu().clone()
+        out[tag + "_replays"] = stepper.graphs.replays
+        out[tag + "_keys"] = [k[-1] for k in stepper.graphs._graphs]
+    out["form"] = TR.dp_form(model._base, dist)
+    torch.save(out, os.path.join(tmp, f"r{rank}.pt"))
+    TR.close_native_comm()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_default_form_is_one_graph_native(tmp_path):
+    """The product steppers' data-parallel step in its DEFAULT form on the RCCL backend: dof_flat_allreduce on the step's
+    stream, captured with gather + loss + backward + clip/Adam into ONE hipGraph.  A 1-rank RCCL group (DOF_FORCE_DP=1
+    takes the DP route at world 1): six steps leave bitwise the same parameters as the non-DP stepper."""
+    import os
+    import torch.multiprocessing as mp
+    port = 30700 + (os.getpid() % 2000)
+    mp.spawn(_dp_default_form_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "r0.pt")
+    assert r["form"] == "dof_flat_allreduce captured in the step graph", r["form"]
+    assert r["dp_keys"] == ["dp"] and r["dp_replays"] == 4, (r["dp_keys"], r["dp_replays"])
+    assert r["plain_keys"] == ["train"]
+    torch.testing.assert_close(r["dp"], r["plain"], rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("n_nodes,latent,kind", [(8, 4, "vade"), (11, 6, "vqvae"), (16, 8, "vade"), (22, 8, "vqvae"),
-                                                  (28, 8, "vade"), (11, 16, "vade"), (11, 16, "vqvae")])
+                                                  (28, 8, "vade"), (11, 16, "vade"), (11, 16, "vqvae"),
+                                                  (14, 16, "vade"), (8, 16, "vqvae"), (16, 16, "vade"), (22, 16, "vqvae")])
 def test_tfm_other_widths_gpu(hip, n_nodes, latent, kind):
     """key_dim 24 / 32 / 48 / 64, latent 4 / 6 / 8 (decoder widths 16 / 24 / 32) of the transformer family against the
     oracle on injected random keep-masks: eval forward with a masked frame, total loss and every gradient."""

@@ -270,7 +270,12 @@ def test_logged_total_is_sum_of_parts():
             assert logs["prior_loss"] == 0.0 and logs["tf_clust_loss"] == 0.0 and logs["temporal_loss"] == 0.0
 
 
-def _dp_worker(rank, world, port, tmp):
+# VadeLoss terms that couple the windows of a batch (Gram k-means, repel between soft centroids, non-empty floor on the
+# batch-mean responsibilities): switched off, what remains is a mean over windows = "batch-separable"
+SEPARABLE = dict(km_latent=0.0, km_loss=0.0, repel_w=0.0, nonempty_w=0.0)
+
+
+def _dp_worker(rank, world, port, tmp, separable=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -284,13 +289,14 @@ def _dp_worker(rank, world, port, tmp):
     dist.broadcast(eng.params, src=0)  # ... fixed by the start-up broadcast
     xs, as_ = torch.randn(8, 8, 4, 3, generator=g), torch.randn(8, 8, 3, 1, generator=g)
     eps = torch.randn(8, 4, generator=g)
-    configure_phase(eng, 3, True, 0.2)
+    configure_phase(eng, 3, True, 0.2, extra=SEPARABLE if separable else None)
     lo = rank * 4
     eng.loss_grads(xs[lo:lo + 4].contiguous(), as_[lo:lo + 4].contiguous(), eps[lo:lo + 4].contiguous(), None, None, True)
     local = eng.grads.clone()
     dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
     eng.grads.mul_(1.0 / world)
-    torch.save({"local": local, "reduced": eng.grads.clone(), "params": eng.params.clone()}, os.path.join(tmp, f"r{rank}.pt"))
+    torch.save({"local": local, "reduced": eng.grads.clone(), "params": eng.params.clone(), "logs": eng.read_logs()},
+               os.path.join(tmp, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -306,6 +312,34 @@ def test_data_parallel_gradient_allreduce_gloo(tmp_path):
     torch.testing.assert_close(r0["reduced"], r1["reduced"], rtol=0, atol=0)
     torch.testing.assert_close(r0["reduced"], 0.5 * (r0["local"] + r1["local"]), rtol=1e-6, atol=1e-8)
     assert float((r0["local"] - r1["local"]).abs().max()) > 0
+
+
+def test_data_parallel_equals_concatenated_batch_gloo(tmp_path):
+    """SURVEY 8(e)'s correctness bar: N ranks x B == 1 rank on the concatenated batch of N*B windows, for the
+    batch-separable terms (reconstruction, KL, activity L1: means over windows; the batch-coupled terms -- Gram k-means,
+    repel, the non-empty floor -- use per-rank statistics, DDP's semantics, and are switched off here).  2 ranks x 4
+    windows (gloo, emulated kernels) against ONE engine on the same 8 windows: reduced gradient == the big batch's
+    gradient, mean of the ranks' loss terms == the big batch's."""
+    import torch.multiprocessing as mp
+    from parity_common import configure_phase
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"r{r}.pt") for r in (0, 1))
+    torch.manual_seed(0)
+    eng = VadeEngine(emu_lib(), "cpu", 8, 8, chain_adj(4), 4, 3)
+    g = torch.Generator().manual_seed(0)
+    eng.params.copy_(torch.randn(eng.params.shape, generator=g) * 0.2)
+    xs, as_ = torch.randn(8, 8, 4, 3, generator=g), torch.randn(8, 8, 3, 1, generator=g)
+    eps = torch.randn(8, 4, generator=g)
+    configure_phase(eng, 3, True, 0.2, extra=SEPARABLE)
+    eng.loss_grads(xs, as_, eps, None, None, True)
+    torch.testing.assert_close(eng.params, r0["params"], rtol=0, atol=0)
+    scale = float(eng.grads.abs().max())
+    assert scale > 1e-3
+    torch.testing.assert_close(r0["reduced"], eng.grads, rtol=2e-5, atol=2e-6 * scale)
+    big = eng.read_logs()
+    for k in ("total_loss", "reconstruct_loss", "kl_div", "activity_l1"):
+        np.testing.assert_allclose(0.5 * (r0["logs"][k] + r1["logs"][k]), big[k], rtol=2e-5, err_msg=k)
 
 
 def test_vqvae_model_and_fit(golden_dir, tmp_path):

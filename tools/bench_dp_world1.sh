@@ -8,8 +8,8 @@ run() {
 }
 for rep in 1 2; do
 echo "no DP route:            $(run X=1)"
-echo "torch, two graphs:      $(run DOF_BENCH_FORCE_PG=1 DOF_FORCE_DP=1)"
-echo "native, two graphs:     $(run DOF_BENCH_FORCE_PG=1 DOF_FORCE_DP=1 DOF_DP_NATIVE=1)"
-echo "torch, one graph:       $(run DOF_BENCH_FORCE_PG=1 DOF_FORCE_DP=1 DOF_DP_ONE_GRAPH=1)"
-echo "native, one graph:      $(run DOF_BENCH_FORCE_PG=1 DOF_FORCE_DP=1 DOF_DP_NATIVE=1 DOF_DP_ONE_GRAPH=1)"
+echo "torch, two graphs:      $(run DOF_BENCH_FORCE_PG=1 DOF_FORCE_DP=1 DOF_DP_NATIVE=0 DOF_DP_ONE_GRAPH=0)"
+echo "native, two graphs:     $(run DOF_BENCH_FORCE_PG=1 DOF_FORCE_DP=1 DOF_DP_ONE_GRAPH=0)"
+echo "torch, one graph:       $(run DOF_BENCH_FORCE_PG=1 DOF_FORCE_DP=1 DOF_DP_NATIVE=0)"
+echo "native, one graph (default): $(run DOF_BENCH_FORCE_PG=1 DOF_FORCE_DP=1)"
 done
