@@ -1148,8 +1148,9 @@ def test_data_parallel_default_form_is_one_graph_native(tmp_path):
     mp.spawn(_dp_default_form_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     r = torch.load(tmp_path / "r0.pt")
     assert r["form"] == "dof_flat_allreduce captured in the step graph", r["form"]
-    assert r["dp_keys"] == ["dp"] and r["dp_replays"] == 4, (r["dp_keys"], r["dp_replays"])
-    assert r["plain_keys"] == ["train"]
+    # six steps = one eager pass + a capture followed by five replays of ONE graph that holds the collective
+    assert r["dp_keys"] == ["dp"] and r["dp_replays"] == 5, (r["dp_keys"], r["dp_replays"])
+    assert r["plain_keys"] == ["train"], r["plain_keys"]
     torch.testing.assert_close(r["dp"], r["plain"], rtol=0, atol=0)
 
 
