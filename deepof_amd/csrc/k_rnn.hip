@@ -1917,6 +1917,102 @@ __global__ void __launch_bounds__(256) k_zero_int(int* __restrict__ p, int64_t n
   if (i < n) p[i] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the encoder convolution (Conv1d k = 5 "same", F = 3 / 1 input channels -> C1 = 2L channels, no
+// bias) straight from the first GRU layer's two input gradients (round 4):
+//   dW[o][f][k] = sum_{t,s} (c[t][s][o] > 0) (dXf + dXb)[t][s][o] * xs[t + k - 2][s][f]
+// Before: k_relu_merge read c, dXf, dXb and wrote the merged gradient (4 x 46 MB per stream at C2), then the generic
+// k_outer job read it back with scalar operand loads.  Here thread (channel quad, sequence) walks its sequence's T
+// steps: three 16-byte loads per step (a wavefront = 1 KB of contiguous rows per load), the five taps' input rows in a
+// sliding register window, 4 x 5F accumulators; nothing is written but the workgroup's partial tile in k_outer's
+// layout (so k_outer_finalize's fixed-order sum applies unchanged).  Both streams in one launch (blockIdx.y).
+// ---------------------------------------------------------------------------------------------
+struct EncConvWgArgs {
+  const float* act; const float* d0; const float* d1; const float* xs;
+  int64_t S, Sp, part_off;
+  int nblk, F;
+};
+template <int C1, int F>
+__device__ __forceinline__ void enc_conv_wgrad_body(const EncConvWgArgs& A, int T, float* __restrict__ partials, float* red) {
+  constexpr int Q = C1 / 4, SL = 256 / Q, NV = 5 * F;   // channel quads, sequence slots per workgroup, values per channel
+  static_assert(256 % Q == 0 && (Q & (Q - 1)) == 0 || Q == 3, "channel quads");
+  const int tid = threadIdx.x;
+  const int c4 = (tid % Q) * 4, sl = tid / Q;
+  float acc[4][NV];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[c][v] = 0.0f;
+  if (sl < SL) {
+    for (int64_t s = (int64_t)blockIdx.x * SL + sl; s < A.S; s += (int64_t)A.nblk * SL) {
+      float xw[5][F];   // xs at t - 2 .. t + 2
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int f = 0; f < F; ++f) xw[k][f] = (k >= 3 && k - 3 < T) ? A.xs[((int64_t)(k - 3) * A.Sp + s) * F + f] : 0.0f;
+#pragma unroll 5
+      for (int t = 0; t < T; ++t) {
+        const int64_t row = (int64_t)t * A.Sp + s;
+        float m[4], a[4], b[4];
+        dof_ld_row<4>(A.act + row * C1 + c4, m);
+        dof_ld_row<4>(A.d0 + row * C1 + c4, a);
+        dof_ld_row<4>(A.d1 + row * C1 + c4, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int f = 0; f < F; ++f) xw[k][f] = xw[k + 1][f];
+#pragma unroll
+        for (int f = 0; f < F; ++f) xw[4][f] = t + 2 < T ? A.xs[((int64_t)(t + 2) * A.Sp + s) * F + f] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float g = m[c] > 0.0f ? a[c] + b[c] : 0.0f;
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[c][k * F + f] = fmaf(g, xw[k][f], acc[c][k * F + f]);
+        }
+      }
+    }
+  }
+  // the sequence slots of a wavefront (fixed butterfly over the lanes that share a channel quad), then the four
+  // wavefronts in order
+  const int wave = tid >> 6, lane = tid & 63;
+  if constexpr ((Q & (Q - 1)) == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float x = acc[c][v];
+#pragma unroll
+        for (int d = Q; d < 64; d <<= 1) x += __shfl_xor(x, d);
+        acc[c][v] = x;
+      }
+    if (lane < Q) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) red[(wave * C1 + c4 + c) * NV + v] = acc[c][v];
+    }
+    __syncthreads();
+    float* p0 = partials + A.part_off + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+    for (int e = tid; e < C1 * NV; e += 256) {
+      const int oo = e / NV, v = e - oo * NV;
+      float sum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sum += red[(k * C1 + oo) * NV + v];
+      p0[oo * 65 + v] = sum;   // tile 0, column k * F + f (the packed five-tap tile of the k_outer job)
+    }
+  }
+}
+template <int C1>
+__global__ void __launch_bounds__(256) k_enc_conv_wgrad(EncConvWgArgs A0, EncConvWgArgs A1, int T, float* __restrict__ partials) {
+  __shared__ float red[4 * C1 * 15];
+  const EncConvWgArgs& A = blockIdx.y ? A1 : A0;
+  if ((int)blockIdx.x >= A.nblk) return;
+  if (A.F == 3) enc_conv_wgrad_body<C1, 3>(A, T, partials, red);
+  else enc_conv_wgrad_body<C1, 1>(A, T, partials, red);
+}
+
 // dc = (dXf + dXb) * (c > 0)   (ReLU mask of the encoder conv; in place into dXf)
 __global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ act, float* __restrict__ d0,
                                                     const float* __restrict__ d1, int64_t n) {
@@ -2248,6 +2344,31 @@ int dof_launch_zero(float* p, int64_t n, hipStream_t st) {
   return dof_check_launch("k_zero_f32");
 }
 
+// both encoder streams' convolution weight gradients (C1 = 8, 16 or 32 channels: latent 4, 8, 16), partial tiles of
+// nblk[s] workgroups each at partials + part_off[s]
+int dof_enc_conv_wgrad_blocks(int C1, int64_t S) {
+  if (C1 != 8 && C1 != 16 && C1 != 32) return 0;   // (latent 6: 12 channels = 3 quads, not a lane-group size)
+  const int SL = 256 / (C1 / 4);
+  const int64_t nb = (S + SL - 1) / SL;
+  return (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
+}
+int dof_launch_enc_conv_wgrad(int C1, const float* const act[2], const float* const dX[2], const float* const xs[2], const int F[2],
+                              int T, const int64_t S[2], const int64_t Sp[2], const int64_t part_off[2], float* partials,
+                              hipStream_t st) {
+  EncConvWgArgs A[2];
+  unsigned nb = 0;
+  for (int k = 0; k < 2; ++k) {
+    A[k].act = act[k]; A[k].d0 = dX[k]; A[k].d1 = dX[k] + (int64_t)T * C1 * Sp[k]; A[k].xs = xs[k];
+    A[k].S = S[k]; A[k].Sp = Sp[k]; A[k].part_off = part_off[k]; A[k].nblk = dof_enc_conv_wgrad_blocks(C1, S[k]); A[k].F = F[k];
+    if (F[k] != 1 && F[k] != 3) { dof_set_error("encoder conv weight gradient: %d input channels", F[k]); return DOF_ERR_UNSUPPORTED; }
+    if ((unsigned)A[k].nblk > nb) nb = (unsigned)A[k].nblk;
+  }
+  if (C1 == 8) DOF_LAUNCH(k_enc_conv_wgrad<8>, (nb, 2), (256), st, A[0], A[1], T, partials);
+  else if (C1 == 16) DOF_LAUNCH(k_enc_conv_wgrad<16>, (nb, 2), (256), st, A[0], A[1], T, partials);
+  else if (C1 == 32) DOF_LAUNCH(k_enc_conv_wgrad<32>, (nb, 2), (256), st, A[0], A[1], T, partials);
+  else { dof_set_error("encoder conv weight gradient: %d channels", C1); return DOF_ERR_UNSUPPORTED; }
+  return dof_check_launch("k_enc_conv_wgrad");
+}
 int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t n, hipStream_t st) {
   unsigned nb = dof_cdiv(n, 256);
   if (nb > 4096) nb = 4096;

@@ -62,6 +62,12 @@ int dof_launch_enc_final_fwd_pair(int L, const float* const O2[2], const int* co
                                   const DofDecValid* dec = nullptr);
 int dof_launch_zero(float* p, int64_t n, hipStream_t st);
 int dof_launch_relu_merge(const float* act, float* d0, const float* d1, int64_t n, hipStream_t st);
+// encoder convolution weight gradient from the first GRU layer's two input gradients (k_enc_conv_wgrad): workgroups per
+// stream (0 = channel count not covered: keep k_relu_merge + the k_outer job) and the launch for both streams
+int dof_enc_conv_wgrad_blocks(int C1, int64_t S);
+int dof_launch_enc_conv_wgrad(int C1, const float* const act[2], const float* const dX[2], const float* const xs[2], const int F[2],
+                              int T, const int64_t S[2], const int64_t Sp[2], const int64_t part_off[2], float* partials,
+                              hipStream_t st);
 
 // ---- k_tcn.hip ---------------------------------------------------------------------------------
 int64_t dof_tcn_row_blocks(int T, int64_t S);   // partial rows written by the row-per-thread kernels

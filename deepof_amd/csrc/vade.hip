@@ -190,6 +190,7 @@ struct DofVadePlan {
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
   int64_t partials, segs_tab, mask_tab, bc_tab;
+  int64_t conv_wg_part[2] = {-1, -1};  // k_enc_conv_wgrad's partial tiles of the two streams (float offsets; -1: generic path)
   double* log_accum = nullptr;  // dof_vade_set_log_accumulator
   int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
@@ -944,6 +945,16 @@ void head_jobs(DofVadePlan* p, JobBuilder& jb) {
 
 const int kTcnDil[8] = {1, 2, 4, 8, 1, 2, 4, 8};
 
+// DOF_CONV_WGRAD_FUSED=0 keeps k_relu_merge + the generic k_outer job for the recurrent encoder's convolution weights
+// (A/B measurements of k_enc_conv_wgrad)
+bool conv_wgrad_fused() {
+  static const bool on = [] {
+    const char* e = getenv("DOF_CONV_WGRAD_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 // DOF_GRU8_FUSED=0 in the environment keeps the second encoder GRU's weight gradients in the generic reduction
 // (A/B measurements of k_gru8_bwd_fused)
 bool gru8_fused() {
@@ -1119,7 +1130,11 @@ void build_jobs(DofVadePlan* p) {
       const int C1 = 2 * L;
       // encoder conv: dW[o][f][k] = sum dc[t][o] * xs[t+k-2][f]
       if (5 * w.F <= 16) {  // all five taps in one packed tile (F = 3: 15 columns, F = 1: 5)
-        const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp);
+        // conv_wgrad_fused(): the partial tiles come from k_enc_conv_wgrad (which also applies the ReLU mask and merges
+        // the two directions' gradients: no k_relu_merge pass, no operand read by k_outer)
+        const int ext = conv_wgrad_fused() ? dof_enc_conv_wgrad_blocks(C1, w.S) : 0;
+        const int job = jb.add_job(aos(ws + w.dc, C1, Sp), C1, T, Sp, ext);
+        p->conv_wg_part[s] = ext > 0 ? jb.jobs[job].partial_off : -1;
         const int tl = jb.add_tile(job, aos(ws + w.xs, w.F, Sp), 5 * w.F, -2, w.F);
         for (int k = 0; k < 5; ++k)
           jb.add_fin(job, tl * 16 + k * w.F, C1, w.F, C1, C1, b.conv + k, (int64_t)w.F * 5, 5);
@@ -1921,7 +1936,16 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     }
     // (fusing this merge into the weight-gradient reduction's operand load was measured: the conv job's loads triple
     // and k_outer, which is latency-bound per wave, loses 19 us per launch against the 19 us this pass costs per stream)
-    TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
+    if (p->conv_wg_part[s] < 0)
+      TRY(dof_launch_relu_merge(ws + w.c, ws + w.dc, ws + w.dc + (int64_t)T * 2 * L * w.Sp, (int64_t)T * 2 * L * w.Sp, st));
+  }
+  if (p->conv_wg_part[0] >= 0 && p->conv_wg_part[1] >= 0) {  // merge + mask + the convolution's weight gradient: one launch
+    const float* act[2] = {ws + p->sw[0].c, ws + p->sw[1].c};
+    const float* dXc[2] = {ws + p->sw[0].dc, ws + p->sw[1].dc};
+    const float* xs[2] = {ws + p->sw[0].xs, ws + p->sw[1].xs};
+    const int F[2] = {p->sw[0].F, p->sw[1].F};
+    const int64_t S[2] = {p->sw[0].S, p->sw[1].S}, Sp[2] = {p->sw[0].Sp, p->sw[1].Sp};
+    TRY(dof_launch_enc_conv_wgrad(2 * L, act, dXc, xs, F, T, S, Sp, p->conv_wg_part, ws + p->partials, st));
   }
   if (L == 8) {  // the first layer's weight gradients of both streams: one finalize launch
     const float* wg[3] = {ws + p->sw[0].wg1, ws + p->sw[1].wg1, p->pend_wg16};
