@@ -2,7 +2,9 @@
 
   python tests/golden/make_golden_ckpt.py            writes the fixtures below + runs both directions once
 
-A. reference -> deepof_amd.  For each model (VaDE, VQ-VAE, contrastive; recurrent encoder, deepof_14 graph) the
+A. reference -> deepof_amd.  For each model (VaDE, VQ-VAE, contrastive with the recurrent encoder; round 4: VaDE and
+   contrastive with the TCN family, VaDE and VQ-VAE with the transformer family -- lazily built CensNet tensors and
+   BatchNorm buffers in the bundle; deepof_14 graph) the
    reference builds the model and writes a bundle with its OWN ``save_model_info`` (model_utils_new.py:263-329):
    ``tests/golden/ckpt/ref_<model>.pth`` + ``_info.txt`` (data: tensors, a plain rebuild_spec dict, the log summary),
    and ``ref_<model>_io.npz`` = inputs and the reference's eval-mode outputs for them.  tests/test_host_api.py loads the
@@ -41,7 +43,16 @@ def _io(model_name, model, x, a):
         return {"z": model(x, a).numpy()}
 
 
-def write_reference_bundles():
+# (model, encoder_type) pairs with a committed reference bundle: ref_<model>.pth (recurrent) / ref_<model>_<enc>.pth
+BUNDLES = [("vade", "recurrent"), ("vqvae", "recurrent"), ("contrastive", "recurrent"),
+           ("vade", "TCN"), ("contrastive", "TCN"), ("vade", "transformer"), ("vqvae", "transformer")]
+
+
+def bundle_stem(name, enc):
+    return f"ref_{name}" if enc == "recurrent" else f"ref_{name}_{ {'TCN': 'tcn', 'transformer': 'tfm'}[enc] }"
+
+
+def write_reference_bundles(only_new=False):
     from deepof_amd.graph import adjacency_from_graph, bodypart_graph
     from make_golden import synth_batch
     R = reference()
@@ -49,26 +60,38 @@ def write_reference_bundles():
     nodes, edges = bodypart_graph([""])
     adj = adjacency_from_graph(nodes, edges)
     N, E, T, L, K, B = len(nodes), len(edges), 25, 8, 10, 6
-    for name in ("vade", "vqvae", "contrastive"):
+    for name, enc in BUNDLES:
+        path = os.path.join(OUT, bundle_stem(name, enc) + ".pth")
+        if only_new and os.path.exists(path):
+            continue
         torch.manual_seed(401)
         Tm = 2 * T if name == "contrastive" else T
         if name == "vade":
-            model = R.M.VaDEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type="recurrent", kmeans_loss=1.0)
+            model = R.M.VaDEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type=enc, kmeans_loss=1.0)
         elif name == "vqvae":
-            model = R.M.VQVAEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type="recurrent", kmeans_loss=0.0)
+            model = R.M.VQVAEPT((T, N, 3), (T, E, 1), adj, L, K, encoder_type=enc, kmeans_loss=0.0)
         else:
-            model = R.M.ContrastivePT((Tm, N, 3), (Tm, E, 1), adj, latent_dim=L, encoder_type="recurrent")
+            model = R.M.ContrastivePT((Tm, N, 3), (Tm, E, 1), adj, latent_dim=L, encoder_type=enc)
         x, a = synth_batch(B, T, N, E, 402)
+        if enc != "recurrent":
+            # the TCN / transformer encoders build their CensNet tensors at the first forward (model_utils_new.py:766-784):
+            # a saved model has run, so its bundle holds them; one train-mode pass also moves the BatchNorm buffers off
+            # their initial values
+            model.eval()
+            R.U._materialize_encoder(model, (T, N, 3), (T, E, 1), torch.device("cpu"))
+            model.train()
+            with torch.no_grad():
+                model.encoder(torch.from_numpy(x), torch.from_numpy(a)) if name == "contrastive" else model(torch.from_numpy(x), torch.from_numpy(a))
+            model.eval()
         spec = {"model_name": name, "x_shape": (Tm, N, 3), "a_shape": (Tm, E, 1),
                 "adjacency_matrix": np.asarray(adj).astype("float32"), "latent_dim": L, "n_components": K,
-                "encoder_type": "recurrent", "use_gnn": True, "interaction_regularization": 0.0}
-        path = os.path.join(OUT, f"ref_{name}.pth")
+                "encoder_type": enc, "use_gnn": True, "interaction_regularization": 0.0}
         R.U.save_model_info(path, stage="best_val", epoch=3, train_steps=12, val_total=1.5, model=model,
                             log_summary={"train": {"total_loss": [2.0, 1.5]}, "val": {"total_loss": [2.1, 1.6]}},
                             rebuild_spec=spec, save_weights=True)
         io = _io(name, model, torch.from_numpy(x), torch.from_numpy(a))
-        np.savez_compressed(os.path.join(OUT, f"ref_{name}_io.npz"), x=x, a=a, **io)
-        print(name, os.path.getsize(path), "bytes;", sorted(io))
+        np.savez_compressed(os.path.join(OUT, bundle_stem(name, enc) + "_io.npz"), x=x, a=a, **io)
+        print(name, enc, os.path.getsize(path), "bytes;", sorted(io))
 
 
 def cross_load_into_reference(path, x, a):
@@ -79,4 +102,4 @@ def cross_load_into_reference(path, x, a):
 
 
 if __name__ == "__main__":
-    write_reference_bundles()
+    write_reference_bundles(only_new="new" in sys.argv[1:])

@@ -337,7 +337,13 @@ def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn1
         np.testing.assert_allclose(logs[k], float(d[pfx + f"log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=k)
     e1.contrastive_backward(dz, accumulate=False)
     e2.contrastive_backward(dza, accumulate=True)
-    n = 0
+    # C4's shape (B = 128, window 50 -> 25, both views): the standard bar + the explicit attribution of ReLU-branch flips
+    # (tcn_kinks.npz, make_golden_r04.py): a tensor no identified flip reaches is held to the plain bar
+    kinks, flips = None, []
+    if fixture == "contrastive_tcn14_b128.npz":
+        kinks = KinkAttribution(golden_dir, "contrastive_tcn14_b128::c0::")
+        flips = kinks.identify(lambda t: e1.view(t, e1.grads).cpu().numpy(), lambda t: d[pfx + "grad::" + t])
+    n, worst = 0, 0.0
     for k in d:
         if k.startswith(pfx + "grad::"):
             name = k[len(pfx) + 6:]
@@ -347,9 +353,11 @@ def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn1
             elif fixture == "contrastive_tcn14.npz":  # the round-1 fixture keeps its elementwise check
                 np.testing.assert_allclose(g, d[k].reshape(g.shape), atol=1e-4, rtol=2e-3, err_msg=f"grad {name}")
             else:  # latent 16: gradients of O(5); the standard per-tensor bar (5e-5 + 5e-4 max|ref|) of the TCN checks
-                _grad_bar(g, d[k].reshape(g.shape), name)
+                worst = max(worst, _grad_bar(g, d[k].reshape(g.shape), name, extra=kinks.extra(name) if kinks else 0.0))
             n += 1
     assert n == 148
+    if kinks is not None:
+        print("contrastive TCN B = 128: worst gradient error / tensor scale", worst, "identified flips", flips)
     # optimiser: step 1 on these gradients, step 2 = a full step with the second set of recorded draws
     for name in e1.names:
         if ".spatial_gnn_block." in name:
@@ -490,7 +498,8 @@ class KinkAttribution:
     every such candidate, the REFERENCE's own gradient change when exactly that element takes the other branch.  Here
     the flipped elements are NAMED: the gradient error at each significant candidate's most affected element ("probe")
     is explained as A c with c_i in {0, 1}; a coefficient that is neither fails the test.  A tensor's bar is then
-    standard bar + (sum of the harmless candidates' changes) + (changes of the identified flips) -- nothing else."""
+    standard bar + (changes of the identified flips [+ the harmless candidates' summed changes]) for the tensors an
+    identified flip reaches, and the plain standard bar for every other tensor -- nothing else."""
 
     def __init__(self, golden_dir, prefix):
         k = load_golden(golden_dir, "tcn_kinks.npz")
@@ -543,11 +552,18 @@ class KinkAttribution:
         return self.first_ordinal[self.flipped].tolist()
 
     def extra(self, name):
-        """Additional bar of tensor ``name``: harmless candidates + 1.25 x the identified flips' measured changes."""
+        """Additional bar of tensor ``name``: 1.25 x the identified flips' measured changes there, plus -- ONLY where a
+        named flip reaches the tensor -- the summed changes of the harmless candidates (each below a quarter of the
+        bar; a branch that flipped upstream moves pre-activations of its block by ~1e-5, enough to take further
+        near-zero elements along).  A tensor no named flip reaches is held to the plain bar: without an identified
+        flip the whole check is the standard one."""
         if name not in self.col:
             return 0.0
         i = self.col[name]
-        return float(self.harmless[i]) + 1.25 * float(self.maxd[self.flipped, i].sum())
+        named = float(self.maxd[self.flipped, i].sum())
+        if named <= 0.0:
+            return 0.0
+        return float(self.harmless[i]) + 1.25 * named
 
 
 def run_vade_tcn_b64_check(lib, device, golden_dir, fixture="vade_tcn14_b64.npz", min_main=20):

@@ -623,21 +623,31 @@ def _check_bundle_outputs(model, name, io, atol=2e-5):
         np.testing.assert_allclose(model(x, a).cpu().numpy(), io["z"], atol=atol, rtol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["vade", "vqvae", "contrastive"])
-def test_reference_checkpoint_loads_here(golden_dir, name):
+CKPT_BUNDLES = [("vade", "recurrent"), ("vqvae", "recurrent"), ("contrastive", "recurrent"),
+                ("vade", "TCN"), ("contrastive", "TCN"), ("vade", "transformer"), ("vqvae", "transformer")]
+
+
+def _bundle_stem(name, enc):
+    return f"ref_{name}" if enc == "recurrent" else f"ref_{name}_{ {'TCN': 'tcn', 'transformer': 'tfm'}[enc] }"
+
+
+@pytest.mark.parametrize("name,enc", CKPT_BUNDLES)
+def test_reference_checkpoint_loads_here(golden_dir, name, enc):
     """A bundle written by the REFERENCE's save_model_info (tests/golden/make_golden_ckpt.py, committed under
     tests/golden/ckpt/) loads with deepof_amd.training.load_model_from_ckpt -- every state_dict entry consumed -- and the
-    rebuilt model reproduces the reference's eval outputs."""
+    rebuilt model reproduces the reference's eval outputs.  TCN / transformer bundles (round 4) carry the lazily built
+    CensNet tensors and BatchNorm running buffers / step counters (model_utils_new.py:766-784)."""
     import os
-    path = os.path.join(golden_dir, "ckpt", f"ref_{name}.pth")
+    stem = _bundle_stem(name, enc)
+    path = os.path.join(golden_dir, "ckpt", f"{stem}.pth")
     model, logs, spec, report = TR.load_model_from_ckpt(path, _engine_factory=emu_factory)
     assert report["missing"] == [] and report["unexpected"] == [], report
-    assert spec["model_name"] == name and logs["train"]["total_loss"] == [2.0, 1.5]
-    _check_bundle_outputs(model, name, dict(np.load(os.path.join(golden_dir, "ckpt", f"ref_{name}_io.npz"))))
+    assert spec["model_name"] == name and spec["encoder_type"] == enc and logs["train"]["total_loss"] == [2.0, 1.5]
+    _check_bundle_outputs(model, name, dict(np.load(os.path.join(golden_dir, "ckpt", f"{stem}_io.npz"))))
 
 
-@pytest.mark.parametrize("name", ["vade", "vqvae", "contrastive"])
-def test_checkpoint_loads_in_the_reference(golden_dir, tmp_path, name):
+@pytest.mark.parametrize("name,enc", CKPT_BUNDLES)
+def test_checkpoint_loads_in_the_reference(golden_dir, tmp_path, name, enc):
     """The other direction, wherever the reference is mounted (the build container; skipped on the GPU box): a bundle
     written by deepof_amd's save_model_info loads with the REFERENCE's load_model_from_ckpt (model_utils_new.py:822-904)
     without missing / unexpected keys, and the reference model computes the same eval outputs as ours."""
@@ -646,19 +656,28 @@ def test_checkpoint_loads_in_the_reference(golden_dir, tmp_path, name):
     if not os.path.isdir("/root/reference/deepof"):
         pytest.skip("the reference is not mounted here")
     from deepof_amd.models import VQVAE, Contrastive
-    d = dict(np.load(os.path.join(golden_dir, "ckpt", f"ref_{name}_io.npz")))
+    d = dict(np.load(os.path.join(golden_dir, "ckpt", f"{_bundle_stem(name, enc)}_io.npz")))
     adj = load_golden(golden_dir, "graph_ops.npz")["single_adj"]
     T, N, E, L, K = 25, 14, 14, 8, 10
     torch.manual_seed(5)
     if name == "vade":
-        model = VaDE((T, N, 3), (T, E, 1), adj, L, K, batch_size=6, _engine_factory=emu_factory)
+        model = VaDE((T, N, 3), (T, E, 1), adj, L, K, encoder_type=enc, batch_size=6, _engine_factory=emu_factory)
     elif name == "vqvae":
-        model = VQVAE((T, N, 3), (T, E, 1), adj, L, K, batch_size=6, _engine_factory=emu_factory)
+        model = VQVAE((T, N, 3), (T, E, 1), adj, L, K, encoder_type=enc, batch_size=6, _engine_factory=emu_factory)
     else:
-        model = Contrastive((2 * T, N, 3), (2 * T, E, 1), adj, L, batch_size=6, _engine_factory=emu_factory)
+        model = Contrastive((2 * T, N, 3), (2 * T, E, 1), adj, L, encoder_type=enc, batch_size=6, _engine_factory=emu_factory)
+    if enc != "recurrent":   # BatchNorm buffers off their initial values, as after training
+        sd = model.state_dict()
+        g = torch.Generator().manual_seed(9)
+        for k, v in sd.items():
+            if k.endswith("running_mean"):
+                sd[k] = 0.1 * torch.randn(v.shape, generator=g)
+            elif k.endswith("running_var"):
+                sd[k] = 0.5 + torch.rand(v.shape, generator=g)
+        model.load_state_dict(sd)
     Tm = 2 * T if name == "contrastive" else T
     spec = {"model_name": name, "x_shape": (Tm, N, 3), "a_shape": (Tm, E, 1), "adjacency_matrix": adj.astype("float32"),
-            "latent_dim": L, "n_components": K, "encoder_type": "recurrent", "use_gnn": True,
+            "latent_dim": L, "n_components": K, "encoder_type": enc, "use_gnn": True,
             "interaction_regularization": 0.0}
     path = str(tmp_path / "models" / f"{name}.pth")
     TR.save_model_info(path, stage="best_val", epoch=1, model=model, log_summary={"train": {}, "val": {}},
