@@ -321,7 +321,7 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
                       filter_low_variance=False, inter_scale: str = "mean", device="cuda", lib=None,
                       raw_device: Optional[torch.Tensor] = None, shard_videos: bool = False) -> PreprocessedTables:
     """``TableDict.preprocess`` on the device, ``scale`` "standard", "minmax" or "robust" (utils.py:2570
-    ``_pp_make_scaler``; "robust" = exact medians / quartiles by radix selection, one process only).  ``filter_low_variance`` (utils.py:2604):
+    ``_pp_make_scaler``; "robust" = exact medians / quartiles by radix selection).  ``filter_low_variance`` (utils.py:2604):
     a column is dropped where its raw variance (pandas ``var``, ddof 1, NaNs skipped) is not above the threshold;
     the device path covers the case in which every video drops the SAME columns (the reference otherwise scales
     tables with differing column sets per video, which its own window extraction cannot stack) and raises otherwise.  ``tables``: {video key: (frames, C) float64
@@ -376,8 +376,6 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
                   clip=interpolate_normalized if scale == "standard" else 0)   # utils.py:2993: only "standard" clips
     import torch.distributed as dist
     world = dist.get_world_size() if (shard_videos and dist.is_available() and dist.is_initialized()) else 1
-    if scale == "robust" and world > 1:
-        raise NotImplementedError("scale='robust' with shard_videos: quantiles of the pooled samples do not merge across ranks")
     if world == 1:
         call = _Call(lib, device, arrays, raw_device=raw_device, keep=keep, **common)
         if scale == "robust":
@@ -386,7 +384,7 @@ def preprocess_tables(tables: Dict[str, np.ndarray], columns: Sequence, animal_i
             node, edge, ang, sizes, vsc, d_scaler = call.tables(mask, scaler_in)
     else:
         node, edge, ang, sizes, vsc, d_scaler = _sharded(lib, device, arrays, video_off, mask, scaler_in, world, dist.get_rank(),
-                                                         len(plan.animal_ids), common, keep)
+                                                         len(plan.animal_ids), common, keep, modes)
     scaler = pretrained_scaler if not fit_global else _scaler_to_dict(d_scaler.cpu().numpy(), plan.kinds, modes, bool(log_distances),
                                                                                scale, None if keep is None else keep.any(axis=0))
     return PreprocessedTables(node, edge, ang, video_off, keys, scaler, sizes, vsc, columns)
@@ -415,13 +413,19 @@ def robust_center_scale(rows: np.ndarray, scaled: np.ndarray) -> np.ndarray:
     return out
 
 
-def _robust_tables(call: "_Call", plan, modes, mask, scaler_in):
-    """scale="robust" on one process: per-video order statistics -> per-video (median, IQR); order statistics of the
-    per-video-scaled sampled rows of all videos -> global (median, IQR); then the common output pass."""
+def _robust_sections(plan, modes):
+    """(C,) masks: columns scaled per video, columns scaled by the global scaler."""
     K = _capi.PP_KINDS
     on = {K["speed"]: modes["speed"], K["dist_inner"]: modes["dist"], K["dist_intra"]: modes["dist"], K["coord"]: modes["coord"]}
     per_video = np.array([k != K["coord"] and on.get(int(k)) is not None for k in plan.kinds])
     globally = np.array([on.get(int(k)) is not None for k in plan.kinds])
+    return per_video, globally
+
+
+def _robust_tables(call: "_Call", plan, modes, mask, scaler_in):
+    """scale="robust" on one process: per-video order statistics -> per-video (median, IQR); order statistics of the
+    per-video-scaled sampled rows of all videos -> global (median, IQR); then the common output pass."""
+    per_video, globally = _robust_sections(plan, modes)
     vs = torch.from_numpy(robust_center_scale(call.order_stats(None, None).cpu().numpy(), per_video)).to(call.device)
     if scaler_in is None:
         scaler_in = torch.from_numpy(robust_center_scale(call.order_stats(vs, mask).cpu().numpy(), globally)).to(call.device)
@@ -489,8 +493,15 @@ def _all_gather_rows(local: torch.Tensor, rows_per_rank: List[int]) -> List[torc
     return [p[:n] for p, n in zip(parts, rows_per_rank)]
 
 
-def _sharded(lib, device, arrays, video_off, mask, scaler_in, world, rank, n_animals, common, keep=None):
-    """Videos i = rank, rank + world, ... on this rank; two collectives (statistics rows, finished tables)."""
+def _sharded(lib, device, arrays, video_off, mask, scaler_in, world, rank, n_animals, common, keep=None, modes=None):
+    """Videos i = rank, rank + world, ... on this rank; two collectives (statistics rows, finished tables).
+
+    scale="robust": medians and quartiles do not merge, so the split is by what each selection ranges over.  The
+    per-video order statistics (every row of every video -- the bulk of the selection work) stay with the video's
+    owner and their (median, IQR) rows are all-gathered; the pooled selection that fits the GLOBAL scaler ranges over
+    the sampled rows of all videos, scaled per video with whole-video size factors: every rank runs it over all
+    tables (one extra upload of tables the rank already holds on the host; the selection is deterministic, so every
+    rank gets the single-process scaler bit for bit and no histogram exchange is needed)."""
     n_videos, n_cols = len(arrays), len(common["plan"].kinds)
     owner = [list(range(r, n_videos, world)) for r in range(world)]
     mine = owner[rank]
@@ -501,7 +512,21 @@ def _sharded(lib, device, arrays, video_off, mask, scaler_in, world, rank, n_ani
         local_mask = np.concatenate([mask[video_off[i]:video_off[i + 1]] for i in mine])
     order = [i for r in range(world) for i in owner[r]]          # global index of the rows as gathered
     back = torch.from_numpy(np.argsort(np.array(order))).to(device)
-    if scaler_in is None:
+    robust = common["scale"] == "robust"
+    if robust:
+        plan = common["plan"]
+        per_video, globally = _robust_sections(plan, modes)
+        vs_local = torch.from_numpy(robust_center_scale(call.order_stats(None, None).cpu().numpy(), per_video)).to(device) if mine \
+            else torch.zeros(0, n_cols, 2, dtype=torch.float64, device=device)
+        if scaler_in is None:
+            vs_all = torch.cat(_all_gather_rows(vs_local, [len(o) for o in owner]))[back]   # global video order
+            full = _Call(lib, device, arrays, keep=keep, **common)
+            scaler_in = torch.from_numpy(robust_center_scale(full.order_stats(vs_all.contiguous(), mask).cpu().numpy(), globally)).to(device)
+            del full
+        if mine:
+            call.video_scaler_in = vs_local   # kept alive for the call
+            call.dims.video_scaler_in = vs_local.data_ptr()
+    elif scaler_in is None:
         ystat = call.video_stats(local_mask) if mine else torch.zeros(0, n_cols, _capi.PP_STAT_DOUBLES, dtype=torch.float64,
                                                                       device=device)
         ystat_all = torch.cat(_all_gather_rows(ystat, [len(o) for o in owner]))[back]      # global video order

@@ -1115,6 +1115,22 @@ def test_data_parallel_step_rccl(tmp_path, world, native):
         assert float((res[0]["local"] - res[1]["local"]).abs().max()) > 0
 
 
+@pytest.mark.parametrize("name,enc", [("vade", "recurrent"), ("vqvae", "recurrent"), ("contrastive", "recurrent"),
+                                      ("vade", "TCN"), ("contrastive", "TCN"), ("vade", "transformer"), ("vqvae", "transformer")])
+def test_reference_checkpoint_loads_gpu(golden_dir, name, enc):
+    """Bundles written by the REFERENCE's save_model_info (tests/golden/ckpt/, make_golden_ckpt.py) load on the device
+    through deepof_amd.training.load_model_from_ckpt and reproduce the reference's eval outputs -- recurrent, TCN and
+    transformer encoders (lazily built CensNet tensors, BatchNorm buffers)."""
+    import os
+    from deepof_amd import training as TR
+    from test_host_api import _bundle_stem, _check_bundle_outputs
+    stem = _bundle_stem(name, enc)
+    model, logs, spec, report = TR.load_model_from_ckpt(os.path.join(golden_dir, "ckpt", f"{stem}.pth"))
+    assert report["missing"] == [] and report["unexpected"] == [], report
+    assert spec["encoder_type"] == enc
+    _check_bundle_outputs(model, name, dict(np.load(os.path.join(golden_dir, "ckpt", f"{stem}_io.npz"))))
+
+
 def _dp_default_form_worker(rank, world, port, tmp):
     import os
     import sys

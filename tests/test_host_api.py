@@ -975,8 +975,10 @@ def _pp_shard_worker(rank, world, port, tmp):
     for name, kw in (("gw", dict(samples_max=50)), ("pc", dict(dist_standardize="per_column", speed_standardize="per_column",
                                                               coord_standardize="per_column")),
                      ("mm", dict(samples_max=60, scale="minmax", speed_standardize="per_column")),
-                     ("flt", dict(samples_max=70, filter_low_variance=0.05))):
-        tabs = filt if name == "flt" else tabs
+                     ("flt", dict(samples_max=70, filter_low_variance=0.05)),
+                     ("rb", dict(samples_max=55, scale="robust", speed_standardize="per_column")),
+                     ("rbf", dict(samples_max=45, scale="robust", filter_low_variance=0.05))):
+        tabs = filt if name in ("flt", "rbf") else tabs
         res = preprocess_tables(tabs, cols, ["B", "W"], node_cols, edge_cols, (), device="cpu", lib=lib, shard_videos=True, **kw)
         out[name] = (res.node_table, res.edge_table, res.size_factors, res.video_scaler, res.global_scaler)
         if rank == 0:
@@ -997,7 +999,7 @@ def test_preprocess_sharded_over_videos_gloo(tmp_path):
     port = 33000 + (os.getpid() % 2000)
     mp.spawn(_pp_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f"pp{r}.pt", weights_only=False) for r in (0, 1))
-    for name in ("gw", "pc", "mm", "flt"):
+    for name in ("gw", "pc", "mm", "flt", "rb", "rbf"):   # rb / rbf: scale="robust" (exact medians / quartiles across the ranks)
         for a, b, c in zip(r0[name][:4], r1[name][:4], r0[name + "_single"][:4]):
             assert torch.equal(a, b) and torch.equal(a, c), name
         for part in ("speed", "dist", "dist_inner", "dist_intra", "coord"):
