@@ -478,13 +478,13 @@ def main():
     }
     # HBM bytes of one step from the round's PMC passes (tools/profile_step_hbm.sh): quoted only while the kernel sources
     # are the ones the passes ran on
-    step_pmc = os.path.join(ROOT, "profiles", "r03_step_pmc.json")
+    step_pmc = os.path.join(ROOT, "profiles", "r04_step_pmc.json")
     if os.path.exists(step_pmc) and B == 1024:
         rec = json.load(open(step_pmc))
         if rec.get("source_sha") == _source_sha(STEP_SOURCES):
             hb = rec["hbm_bytes_per_step"]
             out["roofline_step"].update(hbm_bytes_per_step=hb, hbm_frac=hb / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                                        hbm_bytes_source="profiles/r03_step_pmc.json")
+                                        hbm_bytes_source="profiles/r04_step_pmc.json")
 
     if rank == 0:
         # ---- roofline of the HBM-bound window-gather kernel: full materialisation of this rank's dataset
@@ -517,9 +517,9 @@ def main():
         alg_bytes = win_per_animal * bytes_per_window
         achieved = alg_bytes / sec_per_launch / 1e9
         # HBM bytes/launch from this round's rocprofv3 PMC passes of the same launch (tools/gather_pmc.sh ->
-        # profiles/r03_gather_pmc.json); null when the kernel source has changed since they were taken
+        # profiles/r04_gather_pmc.json); null when the kernel source has changed since they were taken
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r03_gather_pmc.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r04_gather_pmc.json")
         if os.path.exists(pmc_file) and win_per_animal == 599976 and (T, N, E) == (25, 14, 14):
             rec = json.load(open(pmc_file))
             if rec.get("source_sha") == _source_sha(["k_gather.hip"]):

@@ -35,6 +35,18 @@ __device__ __forceinline__ uint32_t bf16_rne(float v) {
   const uint32_t r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
   return (u & 0x7FFFFFFFu) > 0x7F800000u ? ((u >> 16) | 0x40u) : r;
 }
+// two floats -> one word of two bf16 (first argument in the low half), round to nearest even.  Device: one
+// v_cvt_pk_bf16_f32 (gfx950); the emulation build uses the integer form above.
+__device__ __forceinline__ uint32_t bf16_pack2(float a, float b) {
+#ifdef DOF_EMU
+  return bf16_rne(a) | (bf16_rne(b) << 16);
+#else
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+#endif
+}
 // One 16-byte streaming store of EPV consecutive output elements starting at element e0 (EPV = 4 fp32 or 8 bf16), or the
 // tail elements one by one
 template <bool OUT16>
@@ -42,8 +54,7 @@ __device__ __forceinline__ void store_run(void* __restrict__ out_base, unsigned 
   constexpr int EPV = OUT16 ? 8 : 4;
   if (e0 + EPV - 1 < total) {
     if constexpr (OUT16) {
-      const uint32_t w[4] = {bf16_rne(v[0]) | (bf16_rne(v[1]) << 16), bf16_rne(v[2]) | (bf16_rne(v[3]) << 16),
-                             bf16_rne(v[4]) | (bf16_rne(v[5]) << 16), bf16_rne(v[6]) | (bf16_rne(v[7]) << 16)};
+      const uint32_t w[4] = {bf16_pack2(v[0], v[1]), bf16_pack2(v[2], v[3]), bf16_pack2(v[4], v[5]), bf16_pack2(v[6], v[7])};
       dof_st_stream4(reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(out_base) + e0), w);
     } else {
       const float f[4] = {v[0], v[1], v[2], v[3]};
@@ -64,25 +75,28 @@ __device__ __forceinline__ void store_run(void* __restrict__ out_base, unsigned 
 // and reached only 25 % of HBM peak); the 64-bit row offsets of the WB windows sit in LDS.
 //
 // STAGE > 0 (the normal case): the frame rows the workgroup's windows cover -- (WB-1)*step + W rows for
-// regularly spaced windows, 40 rows = 9 KB for BASELINE C2 -- are first copied into LDS with coalesced
-// loads, and a W*3N-entry table holds the (frame, column) source offset of every element of a window, so a
-// 16-byte store costs four table lookups + four LDS reads instead of four strided global gathers (the
-// gathers kept the kernel on the texture-address path: 56 % of HBM peak; a pure fill reaches 6.2 TB/s here).
+// regularly spaced windows, 40 rows = 9 KB for BASELINE C2 -- are first copied into LDS with coalesced loads and
+// TRANSPOSED on the way in: a staged node row holds its values in the OUTPUT order (n, f) instead of the table's column
+// blocks [x.. | y.. | s..], written with an LDS stride of 3 dwords across neighbouring lanes (conflict-free).  A window
+// is then W*3N CONTIGUOUS staged floats, so a 16-byte store is two 8-byte LDS reads of consecutive addresses -- no
+// bank conflicts, no offset table.  (History: strided global gathers, 56 % of the HBM peak; rows staged in table order
+// + a W*3N-entry offset table, 4 lookups + 4 gathered LDS reads per store: 0.66 of peak for fp32 and 0.49 for the bf16
+// output, where PMC showed 62 % / 76 % of all LDS cycles to be bank-conflict cycles and the bf16 kernel LDS-bound --
+// 431 of its 460 us; profiles/r04_gather_pmc.md.)
 // Workgroups whose windows are too far apart for the staging buffer take the direct path (STAGE == 0 code).
 // OUT16: the batch leaves as bf16 (the storage format of BASELINE's bf16 configuration: W*(3N+E)*2 bytes written per
 // window), eight elements per 16-byte store.
-template <bool INDEXED, int STAGE, int TAB, int WB, bool OUT16 = false>
+template <bool INDEXED, int STAGE, int WB, bool OUT16 = false>
 __global__ void __launch_bounds__(256) k_window_gather(
     const float* __restrict__ node_table, const float* __restrict__ edge_table,
     const int64_t* __restrict__ row_start, int64_t first_row, int64_t row_step, int64_t n_windows,
-    int W, int N, int E, float rcp_perwin, float rcp_cols, void* __restrict__ x_out, void* __restrict__ a_out) {
+    int W, int N, int E, float rcp_perwin, float rcp_cols, float rcp_n, void* __restrict__ x_out, void* __restrict__ a_out) {
   constexpr int EPV = OUT16 ? 8 : 4;   // elements per 16-byte store
   constexpr int OSZ = OUT16 ? 2 : 4;   // bytes per output element
   __shared__ int64_t row0[WB];
   __shared__ int lrow[WB];
   __shared__ int64_t span[2];
-  __shared__ float stage[STAGE > 0 ? STAGE : 1];
-  __shared__ int tab[TAB > 0 ? TAB : 1];
+  __shared__ __attribute__((aligned(16))) float stage[STAGE > 0 ? STAGE : 1];
   const int C = 3 * N;
   const unsigned per_x = (unsigned)(W * C), per_a = (unsigned)(W * E);
   const int64_t w0 = (int64_t)blockIdx.x * WB;
@@ -103,73 +117,75 @@ __global__ void __launch_bounds__(256) k_window_gather(
     }
     __syncthreads();
     const int64_t rmin = span[0], rows = span[1];
-    staged = rows * (C + E) <= STAGE && (int)per_x <= TAB;
+    staged = rows * (C + E) <= STAGE;
     if (staged) {
       const int nnode = (int)rows * C, nedge = (int)rows * E;
       const float* __restrict__ srcn = node_table + rmin * C;
       const float* __restrict__ srce = edge_table + rmin * E;
-      for (int i = threadIdx.x; i < nnode; i += 256) stage[i] = srcn[i];
-      for (int i = threadIdx.x; i < nedge; i += 256) stage[nnode + i] = srce[i];
-      // element o = (t, n, f) of a window  <-  frame t, column f*N + n
-      for (unsigned o = threadIdx.x; o < per_x; o += 256) {
-        const unsigned t = fast_div(o, (unsigned)C, rcp_cols);
-        const unsigned r = o - t * C;
-        const unsigned n = (r * 43691u) >> 17;  // r / 3 for r < 2^16
-        tab[o] = (int)(t * C + (r - 3 * n) * N + n);
+      // table element (row r, column f*N + n)  ->  staged position r*C + n*3 + f
+      for (int i = threadIdx.x; i < nnode; i += 256) {
+        const unsigned r = fast_div((unsigned)i, (unsigned)C, rcp_cols);
+        const unsigned c = (unsigned)i - r * C;
+        const unsigned f = fast_div(c, (unsigned)N, rcp_n);
+        stage[r * C + (c - f * N) * 3 + f] = srcn[i];
       }
+      for (int i = threadIdx.x; i < nedge; i += 256) stage[nnode + i] = srce[i];
       if ((int)threadIdx.x < nwin) lrow[threadIdx.x] = (int)(row0[threadIdx.x] - rmin);
       __syncthreads();
-      // ---- nodes: (window, element) of a thread's next store advance incrementally (1024 floats per pass)
-      {
-        char* __restrict__ out = reinterpret_cast<char*>(x_out) + w0 * per_x * OSZ;
-        const unsigned total = (unsigned)nwin * per_x;
+      // one 16-byte store = EPV consecutive elements of window w from element o on; `per` elements per window, rows of
+      // `cols` staged floats.  A run inside one window (all but ~EPV / per of them) is EPV contiguous staged floats.
+      auto copy_windows = [&](const float* __restrict__ st, unsigned per, int cols, char* __restrict__ out, float rcp_per) {
+        const unsigned total = (unsigned)nwin * per;
+        const bool even = ((per | (unsigned)cols) & 1u) == 0;   // then every run starts at an even float: 8-byte LDS reads
         unsigned e0 = EPV * threadIdx.x;
-        unsigned w = fast_div(e0, per_x, rcp_perwin);
-        unsigned o = e0 - w * per_x;
+        unsigned w = fast_div(e0, per, rcp_per);
+        unsigned o = e0 - w * per;
         for (; e0 < total; e0 += EPV * 256) {
           float v[EPV];
-          unsigned wj = w < (unsigned)nwin ? w : (unsigned)nwin - 1, oj = o;
-          int base = lrow[wj] * C;
+          if (o + EPV <= per) {
+            const int at = lrow[w] * cols + (int)o;
+            const float* __restrict__ src = st + at;
+            if ((at & 3) == 0) {   // 16-byte aligned (always, for step-1 windows of an even row width): ds_read_b128,
+                                   // conflict-free for lanes 16 bytes apart
 #pragma unroll
-          for (int j = 0; j < EPV; ++j) {
-            v[j] = stage[base + tab[oj]];
-            if (++oj == per_x) {
-              oj = 0;
-              wj = wj + 1 < (unsigned)nwin ? wj + 1 : wj;
-              base = lrow[wj] * C;
+              for (int j = 0; j < EPV; j += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(src + j);
+                v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
+              }
+            } else if (even) {
+#pragma unroll
+              for (int j = 0; j < EPV; j += 2) {
+                const float2 q = *reinterpret_cast<const float2*>(src + j);
+                v[j] = q.x; v[j + 1] = q.y;
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < EPV; ++j) v[j] = src[j];
+            }
+          } else {   // the run crosses into the next window (or the end of the workgroup's output)
+            unsigned wj = w, oj = o;
+            int base = lrow[wj] * cols;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+              v[j] = st[base + (int)oj];
+              if (++oj == per) {
+                oj = 0;
+                wj = wj + 1 < (unsigned)nwin ? wj + 1 : wj;
+                base = lrow[wj] * cols;
+              }
             }
           }
           store_run<OUT16>(out, e0, total, v);
           o += EPV * 256;
-          while (o >= per_x) {
-            o -= per_x;
+          while (o >= per) {
+            o -= per;
             ++w;
           }
         }
-      }
-      // ---- edges: a window is W*E contiguous staged floats
-      {
-        char* __restrict__ out = reinterpret_cast<char*>(a_out) + w0 * per_a * OSZ;
-        const float* __restrict__ se = stage + nnode;
-        const unsigned total = (unsigned)nwin * per_a;
-        const float rcp_pa = rcp_perwin * ((float)C / (float)E) * 0.999999f;
-        for (unsigned e0 = EPV * threadIdx.x; e0 < total; e0 += EPV * 256) {
-          float v[EPV];
-          unsigned w = fast_div(e0, per_a, rcp_pa);
-          unsigned o = e0 - w * per_a;
-          int base = lrow[w] * E;
-#pragma unroll
-          for (int j = 0; j < EPV; ++j) {
-            v[j] = se[base + o];
-            if (++o == per_a) {
-              o = 0;
-              w = w + 1 < (unsigned)nwin ? w + 1 : w;
-              base = lrow[w] * E;
-            }
-          }
-          store_run<OUT16>(out, e0, total, v);
-        }
-      }
+      };
+      copy_windows(stage, per_x, C, reinterpret_cast<char*>(x_out) + w0 * per_x * OSZ, rcp_perwin);
+      copy_windows(stage + nnode, per_a, E, reinterpret_cast<char*>(a_out) + w0 * per_a * OSZ,
+                   rcp_perwin * ((float)C / (float)E) * 0.999999f);
       return;
     }
   }
@@ -242,28 +258,28 @@ int launch_gather(const float* node_table, const float* edge_table, const int64_
   const bool small = n_windows <= 8192;
   const int wb = small ? WB_SMALL : WB;
   const unsigned blocks = (unsigned)((n_windows + wb - 1) / wb);
-  const float rp = rcp_down((unsigned)(W * 3 * N)), rc = rcp_down((unsigned)(3 * N));
+  const float rp = rcp_down((unsigned)(W * 3 * N)), rc = rcp_down((unsigned)(3 * N)), rn = rcp_down((unsigned)N);
   // staging-buffer class by the footprint of wb stride-1 windows (other spacings decide per workgroup)
-  const int64_t need = (int64_t)(wb - 1 + W) * (3 * N + E), tabn = (int64_t)W * 3 * N;
-#define GATHER1(IDX, ST, TB, WBV)                                                                                        \
-  do {                                                                                                                   \
-    if (out16)                                                                                                           \
-      DOF_LAUNCH((k_window_gather<IDX, ST, TB, WBV, true>), (blocks), (256), stream, node_table, edge_table, row_start,  \
-                 first_row, row_step, n_windows, W, N, E, rp, rc, x_out, a_out);                                         \
-    else                                                                                                                 \
-      DOF_LAUNCH((k_window_gather<IDX, ST, TB, WBV, false>), (blocks), (256), stream, node_table, edge_table, row_start, \
-                 first_row, row_step, n_windows, W, N, E, rp, rc, x_out, a_out);                                         \
+  const int64_t need = (int64_t)(wb - 1 + W) * (3 * N + E);
+#define GATHER1(IDX, ST, WBV)                                                                                        \
+  do {                                                                                                               \
+    if (out16)                                                                                                       \
+      DOF_LAUNCH((k_window_gather<IDX, ST, WBV, true>), (blocks), (256), stream, node_table, edge_table, row_start,  \
+                 first_row, row_step, n_windows, W, N, E, rp, rc, rn, x_out, a_out);                                 \
+    else                                                                                                             \
+      DOF_LAUNCH((k_window_gather<IDX, ST, WBV, false>), (blocks), (256), stream, node_table, edge_table, row_start, \
+                 first_row, row_step, n_windows, W, N, E, rp, rc, rn, x_out, a_out);                                 \
   } while (0)
-#define GATHER(IDX, ST, TB)                                            \
-  do {                                                                 \
-    if (small) GATHER1(IDX, ST, TB, WB_SMALL); else GATHER1(IDX, ST, TB, WB); \
+#define GATHER(IDX, ST)                                        \
+  do {                                                         \
+    if (small) GATHER1(IDX, ST, WB_SMALL); else GATHER1(IDX, ST, WB); \
   } while (0)
-  if (need <= 3072 && tabn <= 1280) {
-    if (row_start) GATHER(true, 3072, 1280); else GATHER(false, 3072, 1280);
-  } else if (need <= 10240 && tabn <= 4608) {
-    if (row_start) GATHER(true, 10240, 4608); else GATHER(false, 10240, 4608);
+  if (need <= 3072) {
+    if (row_start) GATHER(true, 3072); else GATHER(false, 3072);
+  } else if (need <= 10240) {
+    if (row_start) GATHER(true, 10240); else GATHER(false, 10240);
   } else {
-    if (row_start) GATHER(true, 0, 0); else GATHER(false, 0, 0);
+    if (row_start) GATHER(true, 0); else GATHER(false, 0);
   }
 #undef GATHER1
 #undef GATHER

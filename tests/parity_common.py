@@ -337,11 +337,11 @@ def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn1
         np.testing.assert_allclose(logs[k], float(d[pfx + f"log::{k}"]), rtol=1e-4, atol=1e-5, err_msg=k)
     e1.contrastive_backward(dz, accumulate=False)
     e2.contrastive_backward(dza, accumulate=True)
-    # C4's shape (B = 128, window 50 -> 25, both views): the standard bar + the explicit attribution of ReLU-branch flips
+    # C4's shape (B = 64, window 50 -> 25, both views): the standard bar + the explicit attribution of ReLU-branch flips
     # (tcn_kinks.npz, make_golden_r04.py): a tensor no identified flip reaches is held to the plain bar
     kinks, flips = None, []
-    if fixture == "contrastive_tcn14_b128.npz":
-        kinks = KinkAttribution(golden_dir, "contrastive_tcn14_b128::c0::")
+    if fixture == "contrastive_tcn14_b64.npz":
+        kinks = KinkAttribution(golden_dir, "contrastive_tcn14_b64::c0::")
         flips = kinks.identify(lambda t: e1.view(t, e1.grads).cpu().numpy(), lambda t: d[pfx + "grad::" + t])
     n, worst = 0, 0.0
     for k in d:
@@ -357,7 +357,7 @@ def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn1
             n += 1
     assert n == 148
     if kinks is not None:
-        print("contrastive TCN B = 128: worst gradient error / tensor scale", worst, "identified flips", flips)
+        print("contrastive TCN B = 64: worst gradient error / tensor scale", worst, "identified flips", flips)
     # optimiser: step 1 on these gradients, step 2 = a full step with the second set of recorded draws
     for name in e1.names:
         if ".spatial_gnn_block." in name:
@@ -399,7 +399,9 @@ def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn1
             # isolated near-zero-gradient elements elsewhere are tolerated
             if pfx + "grad::" + k in d:
                 bad &= np.abs(d[pfx + "grad::" + k].reshape(got.shape)) > 2e-5
-            assert bad.mean() <= 0.005 and np.abs(got - ref).max() <= 4.2e-3, (k, bad.sum(), np.abs(got - ref).max())
+            # (0.5 % of the elements, at least one: the first block's edge convolution has 128 weights)
+            assert bad.sum() <= max(1, int(0.005 * bad.size)) and np.abs(got - ref).max() <= 4.2e-3, \
+                (k, bad.sum(), np.abs(got - ref).max())
     np.testing.assert_array_equal(sd2["encoder.spatial_gnn_block.node_kernel"].numpy(),
                                   d[pfx + "sd::encoder.spatial_gnn_block.node_kernel"])
 

@@ -416,10 +416,10 @@ def test_contrastive_training_api_gpu(tmp_path):
     assert (tmp_path / "models" / "contrastive" / "run_0" / "best_model_val.pth").exists()
 
 
-@pytest.mark.parametrize("fixture", ["contrastive_tcn14.npz", "contrastive_tcn14l16.npz", "contrastive_tcn14_b128.npz"])
+@pytest.mark.parametrize("fixture", ["contrastive_tcn14.npz", "contrastive_tcn14l16.npz", "contrastive_tcn14_b64.npz"])
 def test_contrastive_tcn_parity_gpu(hip, golden_dir, fixture):
-    """contrastive_tcn14_b128 (round 4, make_golden_r04.py): C4's model at a slice of its batch -- window 50 -> 25, both
-    views with the reference's recorded augmentation draws, B = 128, train mode -- against the REFERENCE's own step at the
+    """contrastive_tcn14_b64 (round 4, make_golden_r04.py): C4's model at a slice of its batch -- window 50 -> 25, both
+    views with the reference's recorded augmentation draws, B = 64, train mode -- against the REFERENCE's own step at the
     standard gradient bar, with the explicit attribution of ReLU-branch flips (replaces round 3's oracle comparison at
     10 x noise + 1 % of scale)."""
     from parity_common import run_contrastive_tcn_check

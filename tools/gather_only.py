@@ -21,5 +21,11 @@ a = torch.empty(nw, T, E, 1, device=dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     _capi.check(lib, lib.dof_window_gather_range(tn.data_ptr(), te.data_ptr(), 0, 1, nw, T, N, E, x.data_ptr(), a.data_ptr(),
                                                  torch.cuda.current_stream().cuda_stream))
+if len(sys.argv) > 2 and sys.argv[2] == "bf16":   # + the bf16-storage variant of the same launch
+    xb = torch.empty(nw, T, N, 3, device=dev, dtype=torch.bfloat16)
+    ab = torch.empty(nw, T, E, 1, device=dev, dtype=torch.bfloat16)
+    for _ in range(int(sys.argv[1])):
+        _capi.check(lib, lib.dof_window_gather_bf16(tn.data_ptr(), te.data_ptr(), None, 0, 1, nw, T, N, E, xb.data_ptr(), ab.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
 print("gathered", nw, "windows x", sys.argv[1] if len(sys.argv) > 1 else 6)
