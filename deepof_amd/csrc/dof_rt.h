@@ -204,6 +204,11 @@ __device__ __forceinline__ void dof_st_row(float* __restrict__ p, const float* v
     reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
 
+// two floats as one 8-byte store (8-byte aligned address)
+__device__ __forceinline__ void dof_st_pair(float* __restrict__ p, float a, float b) {
+  *reinterpret_cast<uint64_t*>(p) = (uint64_t)__builtin_bit_cast(uint32_t, a) | ((uint64_t)__builtin_bit_cast(uint32_t, b) << 32);
+}
+
 #define DOF_OK 0
 #define DOF_ERR_ARG (-1)
 #define DOF_ERR_UNSUPPORTED (-2)

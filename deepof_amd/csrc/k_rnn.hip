@@ -875,6 +875,123 @@ __global__ void __launch_bounds__(64) k_gru16m_fwd(Gru16mStream sa, Gru16mStream
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// GRU forward on the matrix pipe for the second encoder layer of latent 8 (IN = 32, HID = 8; round 4), the twin of
+// k_gru16m_fwd.  Eight units per direction fill half a 16-row tile, so two GATES share a tile and the rows are ordered by
+// OWNER: lane (b, j) of the D layout (rows 4b .. 4b+3, column j) owns units 2b and 2b+1 of sequence j and receives
+//   tile 1 rows 4b + (0, 1, 2, 3) = r_{2b}, r_{2b+1}, z_{2b}, z_{2b+1},   tile 2 = nx_{2b}, nx_{2b+1}, hn_{2b}, hn_{2b+1}
+// (nx = W_in x + b_in, hn = W_hn h + b_hn: the A tile holds zeros where a row does not take that half of [x ; h]) -- all
+// four pre-activations of a unit in ONE lane, no exchange for the gate arithmetic.  K blocks are again the lane's own
+// values: block q of the input half = channels {q, 8+q, 16+q, 24+q} (lane b loads x[8b .. 8b+7]: two 16-byte loads),
+// block q of the hidden half = units {q, 2+q, 4+q, 6+q} (the two units the lane has just computed).  16 + 4 MFMAs per
+// step for 16 (sequence, direction) pairs; the input half runs one step ahead.  Writes the same hidden-state and
+// unit-major gate buffers as k_gru3_fwd<32, 8> (a lane's two units: 32 contiguous bytes), so k_gru8_bwd_fused is
+// unchanged; sums over k in another order than the lane-per-unit kernel (ulp-level differences).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_gru8m_fwd(Gru16mStream sa, Gru16mStream sb, int T) {
+  constexpr int HID = 8, IN = 32;
+  const Gru16mStream& A = blockIdx.z ? sb : sa;
+  const float* __restrict__ X = A.X;
+  const int* __restrict__ len = A.len;
+  float* __restrict__ O = A.O;
+  float* __restrict__ GS = A.GS;
+  const int64_t S = A.S, Sp = A.Sp;
+  if ((int64_t)blockIdx.x * 16 >= S) return;   // (the grid covers the longer stream)
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, b = lane >> 4;
+  const int64_t s = (int64_t)blockIdx.x * 16 + j;
+  const int dir = blockIdx.y;
+  const bool in_range = s < S;
+  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
+  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
+  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
+  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
+  // A tiles: row i = lane & 15 -> owner (i >> 2), slot (i & 3): gate half (slot >> 1), unit 2 (i >> 2) + (slot & 1);
+  // k index = lane >> 4: input channel 8k + q / hidden unit 2k + q of K block q
+  const int arow_unit = 2 * (j >> 2) + (j & 1), arow_hi = (j >> 1) & 1;   // hi: z (tile 1) / hn (tile 2)
+  float a1x[8], a2x[8], a1h[2], a2h[2];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    a1x[q] = wih[((arow_hi ? 1 : 0) * HID + arow_unit) * IN + 8 * b + q];
+    a2x[q] = arow_hi ? 0.0f : wih[(2 * HID + arow_unit) * IN + 8 * b + q];
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    a1h[q] = whh[((arow_hi ? 1 : 0) * HID + arow_unit) * HID + 2 * b + q];
+    a2h[q] = arow_hi ? whh[(2 * HID + arow_unit) * HID + 2 * b + q] : 0.0f;
+  }
+  dof_f32x4 c1, c2;  // biases in the D layout of this lane's two units
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int unit = 2 * b + m;
+    c1[m] = bih[unit] + bhh[unit];
+    c1[2 + m] = bih[HID + unit] + bhh[HID + unit];
+    c2[m] = bih[2 * HID + unit];
+    c2[2 + m] = bhh[2 * HID + unit];
+  }
+  float* __restrict__ gs = GS ? GS + (int64_t)dir * T * 4 * HID * Sp : nullptr;
+  const int n = in_range ? len[s] : 0;
+  float h[2] = {0.0f, 0.0f};
+  constexpr int PF = 4;   // x_t loaded PF steps ahead into static register slots (see k_gru16m_fwd)
+  float xs[PF][8];
+  const int64_t sr = in_range ? s : S - 1;
+  auto load_x = [&](auto slot_c, int step) {
+    constexpr int slot = decltype(slot_c)::value;
+    const int t = step < n ? (dir ? (n - 1 - step) : step) : 0;
+    dof_ld_row<8>(X + ACT(t, 8 * b, IN, Sp, sr), xs[slot]);
+  };
+  dof_f32x4 g1, g2;
+  auto input_half = [&](const float* xq) {
+    g1 = c1; g2 = c2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1x[q], xq[q], g1, 0, 0, 0);
+      g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2x[q], xq[q], g2, 0, 0, 0);
+    }
+  };
+  auto do_step = [&](auto slot_c, int step) {
+    constexpr int slot = decltype(slot_c)::value;
+    constexpr int next = (slot + 1) % PF;
+    dof_f32x4 a1 = g1, a2 = g2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q], h[q], a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2h[q], h[q], a2, 0, 0, 0);
+    }
+    input_half(xs[next]);          // next step's input half (its x arrived PF - 1 steps ago)
+    load_x(slot_c, step + PF);     // this step's slot is free again
+    const bool act = step < n;
+    float gate8[8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float rr = dof_sigmoid(a1[m]);
+      const float zz = dof_sigmoid(a1[2 + m]);
+      const float hn = a2[2 + m];
+      const float nn = dof_tanh(fmaf(rr, hn, a2[m]));
+      const float hnew = fmaf(zz, h[m] - nn, nn);
+      h[m] = act ? hnew : h[m];
+      gate8[4 * m] = rr; gate8[4 * m + 1] = zz; gate8[4 * m + 2] = nn; gate8[4 * m + 3] = hn;
+    }
+    if (act) {
+      const int t = dir ? (n - 1 - step) : step;
+      dof_st_pair(O + ACT(t, dir * HID + 2 * b, 2 * HID, Sp, s), h[0], h[1]);
+      if (gs) dof_st_row<8>(gs + ACT(t, 8 * b, 4 * HID, Sp, s), gate8);
+    }
+  };
+  dof_static_for<PF>([&](auto d) { load_x(d, decltype(d)::value); });
+  input_half(xs[0]);
+  for (int step = 0; step < T; step += PF) {  // wave-uniform trip count: MFMA ignores EXEC, finished sequences idle
+    dof_static_for<PF>([&](auto d) { do_step(d, step + decltype(d)::value); });
+  }
+  if (in_range) {
+    const float zero8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = n; t < T; ++t) {
+      dof_st_pair(O + ACT(t, dir * HID + 2 * b, 2 * HID, Sp, s), 0.0f, 0.0f);
+      if (gs) dof_st_row<8>(gs + ACT(t, 8 * b, 4 * HID, Sp, s), zero8);
+    }
+  }
+}
+
 template <int IN, int HID, bool BCAST>
 __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, const float* __restrict__ wih0,
                                                   const float* __restrict__ whh0, const float* __restrict__ wih1,
@@ -2128,6 +2245,24 @@ static Gru8Args gru3_fwd_args(const float* X, const int* len, const DofGruW& W, 
   A.X = X; A.len = len; A.wih0 = W.wih0; A.whh0 = W.whh0; A.bih0 = W.bih0; A.bhh0 = W.bhh0; A.wih1 = W.wih1; A.whh1 = W.whh1;
   A.bih1 = W.bih1; A.bhh1 = W.bhh1; A.Oout = O; A.GSout = GS; A.S = S; A.Sp = Sp;
   return A;
+}
+// the same layer on the matrix pipe (k_gru8m_fwd; launches of >= DOF_GRU_MFMA_MIN_S sequences per stream): returns 1 when
+// launched, 0 when the caller has to use the lane-per-unit kernels, < 0 on error.  DOF_GRU8_MFMA=0: off (A/B).
+bool dof_gru8m_fwd_selected(int64_t S0, int64_t S1) {
+  static const bool on = [] {
+    const char* e = getenv("DOF_GRU8_MFMA");
+    return !(e && e[0] == '0');
+  }();
+  return on && dof_gru16_mfma(S0) && dof_gru16_mfma(S1);
+}
+int dof_launch_gru8m_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2],
+                              float* const GS[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
+  if (!dof_gru8m_fwd_selected(S[0], S[1])) return 0;
+  const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], O[0], GS[0], nullptr, nullptr, nullptr, S[0], Sp[0]);
+  const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], O[1], GS[1], nullptr, nullptr, nullptr, S[1], Sp[1]);
+  const int64_t smax = S[0] > S[1] ? S[0] : S[1];
+  DOF_LAUNCH(k_gru8m_fwd, (dof_cdiv(smax, 16), 2, 2), (64), st, a, b, T);
+  return dof_check_launch("k_gru8m_fwd (pair)") == DOF_OK ? 1 : DOF_ERR_LAUNCH;
 }
 // the second encoder layer (32 -> 8, latent 8) of both streams in one launch
 int dof_launch_gru8_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2],

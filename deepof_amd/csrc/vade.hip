@@ -1422,15 +1422,17 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
     const char* e = getenv("DOF_GRU8_FWD_PAIR");
     return e && e[0] == '1';
   }();
+  // second layer on the matrix pipe (k_gru8m_fwd, both streams in one launch) where the launch is large enough
+  const bool mfma8 = L == 8 && dof_gru8m_fwd_selected(p->sw[0].S, p->sw[1].S);
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
     const BlockOff& b = p->blk[s];
     int* len = reinterpret_cast<int*>(ws + w.len);
     if (!paired) TRY(dof_launch_gru_fwd(L, 0, ws + w.c, len, gru_w(params, b.g1), ws + w.o1, train ? ws + w.g1 : nullptr, T, w.S, w.Sp, st));
     TRY(dof_launch_ln_fwd(L, 4, ws + w.o1, params + b.n1w, params + b.n1b, ws + w.n1, T, w.S, w.Sp, st));
-    if (L != 8 || !pair_fwd8) TRY(dof_launch_gru_fwd(L, 1, ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, train ? ws + w.g2 : nullptr, T, w.S, w.Sp, st));
+    if (!mfma8 && (L != 8 || !pair_fwd8)) TRY(dof_launch_gru_fwd(L, 1, ws + w.n1, len, gru_w(params, b.g2), ws + w.o2, train ? ws + w.g2 : nullptr, T, w.S, w.Sp, st));
   }
-  if (L == 8 && pair_fwd8) {  // second layer of both streams: one launch
+  if (mfma8 || (L == 8 && pair_fwd8)) {  // second layer of both streams: one launch
     const StreamWs& w0 = p->sw[0];
     const StreamWs& w1 = p->sw[1];
     const float* X[2] = {ws + w0.n1, ws + w1.n1};
@@ -1439,7 +1441,12 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
     float* O[2] = {ws + w0.o2, ws + w1.o2};
     float* GS[2] = {train ? ws + w0.g2 : nullptr, train ? ws + w1.g2 : nullptr};
     const int64_t S[2] = {w0.S, w1.S}, Sp[2] = {w0.Sp, w1.Sp};
-    TRY(dof_launch_gru8_fwd_pair(X, ln, W, O, GS, T, S, Sp, st));
+    if (mfma8) {
+      const int rc = dof_launch_gru8m_fwd_pair(X, ln, W, O, GS, T, S, Sp, st);
+      if (rc < 0) return rc;
+    } else {
+      TRY(dof_launch_gru8_fwd_pair(X, ln, W, O, GS, T, S, Sp, st));
+    }
   }
   {  // both streams' tails in one launch, with the CensNet dot products of the rows they have just normalised
     const StreamWs& wn = p->sw[0];
