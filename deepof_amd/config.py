@@ -160,7 +160,7 @@ _LOSSES = ("nce", "dcl", "dlc", "fc", "hard_dcl")  # the reference accepts the "
 
 SUPPORTED_LATENT_DIMS = (4, 6, 8, 16)
 MAX_CONTRASTIVE_NODES = 64
-TRANSFORMER_KEY_DIMS = (24, 32, 40, 48, 64)
+TRANSFORMER_KEY_DIMS = tuple(range(4, 68, 4))   # every value of min(64, 3 N) // 4 * 4 (models_new.py:1013-1019)
 
 
 def check_model_inputs(preprocessed_object, adjacency_matrix, meta_info, encoder_type, batch_size, latent_dim, epochs,

@@ -43,6 +43,16 @@ __global__ void __launch_bounds__(256) k_cens_dots(const float* __restrict__ X, 
   dots[s] = acc;
 }
 
+// the same with the width as a run-time value (TCN: 32 channels, transformer: key_dim); same summation order
+__global__ void __launch_bounds__(256) k_cens_dots_rt(const float* __restrict__ X, const float* __restrict__ p,
+                                                      float* __restrict__ dots, int D, int64_t S, int64_t Sp) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  float acc = 0.0f;
+  for (int c = 0; c < D; ++c) acc = fmaf(X[(int64_t)c * Sp + s], p[c], acc);
+  dots[s] = acc;
+}
+
 template <int L, int D>
 __global__ void __launch_bounds__(256) k_cens_fwd(CensStream A, CensStream Bs, float* __restrict__ flat, int64_t Bp) {
   const CensStream& P = blockIdx.y ? Bs : A;
@@ -66,7 +76,7 @@ __global__ void __launch_bounds__(256) k_cens_fwd(CensStream A, CensStream Bs, f
     float acc = P.bias[l];
 #pragma unroll
     for (int c = 0; c < D; ++c) acc = fmaf(y[c], P.kern[c * L + l], acc);
-    acc = acc > 0.0f ? acc : 0.0f;
+    acc = acc < 0.0f ? 0.0f : acc;   // torch.relu: a NaN stays a NaN (a sequence with every key masked, transformer cores)
     P.Z[(int64_t)l * P.Sp + s] = acc;
     flat[(int64_t)(P.flat_row0 + r * L + l) * Bp + b] = acc;
   }

@@ -1041,7 +1041,14 @@ __global__ void __launch_bounds__(256) k_head_rms(const float* __restrict__ flat
   const float rms = sqrtf(ss / (float)J);
   const float r = 1.0f / fmaxf(rms, 1.0f);
   rinv[b] = rms > 1.0f ? r : -1.0f;  // sign = "the scale is constant" marker for the backward pass
-  for (int j = 0; j < J; ++j) hn[(int64_t)j * Bp + b] = fminf(fmaxf(flat[(int64_t)j * Bp + b] * r, -1e4f), 1e4f);
+  // clamp(+-1e4), then nan_to_num(nan = 0) (models_new.py:653-655, 1154-1156): a window with a NaN feature -- e.g. a
+  // sequence whose every key is masked in the transformer cores -- has a NaN rms, so its whole row becomes zeros
+  // (fmaxf / fminf alone would turn the NaNs into -1e4)
+  const bool poisoned = rms != rms;   // (fmaxf(NaN, 1) is 1: the reference divides by the NaN and every entry goes to 0)
+  for (int j = 0; j < J; ++j) {
+    const float v = flat[(int64_t)j * Bp + b] * r;
+    hn[(int64_t)j * Bp + b] = (poisoned || v != v) ? 0.0f : fminf(fmaxf(v, -1e4f), 1e4f);
+  }
 }
 
 // out[o][b] = act(bias[o] + sum_i W[o][i] * bn(in[i][b])); thread = (b, o = blockIdx.y); optional channel sums

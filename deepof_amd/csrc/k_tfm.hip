@@ -899,28 +899,46 @@ static int attn_nseq(const DofAttn& a, bool bwd) {
   return n;
 }
 
+// head sizes 1 .. 16: key_dim = min(64, 3 N) rounded down to a multiple of its 4 heads (models_new.py:1013-1019) is any
+// multiple of 4 in 4 .. 64; the decoder's 8 heads of width 4 L / 8 (latent 4, 6, 8, 16: 2, 3, 4, 8)
 #define ATTN_DISPATCH(NAME, A, nb, nt)                                                        \
   do {                                                                                        \
     const int dh = (A).D / (A).H;                                                             \
     if ((A).T <= 32) {                                                                        \
-      if (dh == 4) DOF_LAUNCH((NAME<4, 32>), (nb), (nt), st, A);                              \
-      else if (dh == 2) DOF_LAUNCH((NAME<2, 32>), (nb), (nt), st, A);                         \
-      else if (dh == 3) DOF_LAUNCH((NAME<3, 32>), (nb), (nt), st, A);                         \
-      else if (dh == 6) DOF_LAUNCH((NAME<6, 32>), (nb), (nt), st, A);                         \
-      else if (dh == 8) DOF_LAUNCH((NAME<8, 32>), (nb), (nt), st, A);                         \
-      else if (dh == 10) DOF_LAUNCH((NAME<10, 32>), (nb), (nt), st, A);                       \
-      else if (dh == 12) DOF_LAUNCH((NAME<12, 32>), (nb), (nt), st, A);                       \
-      else if (dh == 16) DOF_LAUNCH((NAME<16, 32>), (nb), (nt), st, A);                       \
+      if (dh == 1) DOF_LAUNCH((NAME<1, 32>), (nb), (nt), st, A);                              \
+      else if (dh == 2) DOF_LAUNCH((NAME<2, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 3) DOF_LAUNCH((NAME<3, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 4) DOF_LAUNCH((NAME<4, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 5) DOF_LAUNCH((NAME<5, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 6) DOF_LAUNCH((NAME<6, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 7) DOF_LAUNCH((NAME<7, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 8) DOF_LAUNCH((NAME<8, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 9) DOF_LAUNCH((NAME<9, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 10) DOF_LAUNCH((NAME<10, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 11) DOF_LAUNCH((NAME<11, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 12) DOF_LAUNCH((NAME<12, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 13) DOF_LAUNCH((NAME<13, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 14) DOF_LAUNCH((NAME<14, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 15) DOF_LAUNCH((NAME<15, 32>), (nb), (nt), st, A);                        \
+      else if (dh == 16) DOF_LAUNCH((NAME<16, 32>), (nb), (nt), st, A);                        \
       else { dof_set_error("attention head size %d not supported", dh); return DOF_ERR_UNSUPPORTED; } \
     } else {                                                                                  \
-      if (dh == 4) DOF_LAUNCH((NAME<4, 64>), (nb), (nt), st, A);                              \
-      else if (dh == 2) DOF_LAUNCH((NAME<2, 64>), (nb), (nt), st, A);                         \
-      else if (dh == 3) DOF_LAUNCH((NAME<3, 64>), (nb), (nt), st, A);                         \
-      else if (dh == 6) DOF_LAUNCH((NAME<6, 64>), (nb), (nt), st, A);                         \
-      else if (dh == 8) DOF_LAUNCH((NAME<8, 64>), (nb), (nt), st, A);                         \
-      else if (dh == 10) DOF_LAUNCH((NAME<10, 64>), (nb), (nt), st, A);                       \
-      else if (dh == 12) DOF_LAUNCH((NAME<12, 64>), (nb), (nt), st, A);                       \
-      else if (dh == 16) DOF_LAUNCH((NAME<16, 64>), (nb), (nt), st, A);                       \
+      if (dh == 1) DOF_LAUNCH((NAME<1, 64>), (nb), (nt), st, A);                              \
+      else if (dh == 2) DOF_LAUNCH((NAME<2, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 3) DOF_LAUNCH((NAME<3, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 4) DOF_LAUNCH((NAME<4, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 5) DOF_LAUNCH((NAME<5, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 6) DOF_LAUNCH((NAME<6, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 7) DOF_LAUNCH((NAME<7, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 8) DOF_LAUNCH((NAME<8, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 9) DOF_LAUNCH((NAME<9, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 10) DOF_LAUNCH((NAME<10, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 11) DOF_LAUNCH((NAME<11, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 12) DOF_LAUNCH((NAME<12, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 13) DOF_LAUNCH((NAME<13, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 14) DOF_LAUNCH((NAME<14, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 15) DOF_LAUNCH((NAME<15, 64>), (nb), (nt), st, A);                        \
+      else if (dh == 16) DOF_LAUNCH((NAME<16, 64>), (nb), (nt), st, A);                        \
       else { dof_set_error("attention head size %d not supported", dh); return DOF_ERR_UNSUPPORTED; } \
     }                                                                                         \
   } while (0)
@@ -951,11 +969,21 @@ int64_t dof_tfm_ln_blocks(int C, int T, int64_t Sp) {
 #define LN_DISPATCH(NAME, C, nb, A)                                          \
   do {                                                                       \
     switch (C) {                                                             \
+      case 4: DOF_LAUNCH((NAME<4>), (nb), (256), st, A); break;            \
+      case 8: DOF_LAUNCH((NAME<8>), (nb), (256), st, A); break;            \
+      case 12: DOF_LAUNCH((NAME<12>), (nb), (256), st, A); break;            \
       case 16: DOF_LAUNCH((NAME<16>), (nb), (256), st, A); break;            \
+      case 20: DOF_LAUNCH((NAME<20>), (nb), (256), st, A); break;            \
       case 24: DOF_LAUNCH((NAME<24>), (nb), (256), st, A); break;            \
+      case 28: DOF_LAUNCH((NAME<28>), (nb), (256), st, A); break;            \
       case 32: DOF_LAUNCH((NAME<32>), (nb), (256), st, A); break;            \
+      case 36: DOF_LAUNCH((NAME<36>), (nb), (256), st, A); break;            \
       case 40: DOF_LAUNCH((NAME<40>), (nb), (256), st, A); break;            \
+      case 44: DOF_LAUNCH((NAME<44>), (nb), (256), st, A); break;            \
       case 48: DOF_LAUNCH((NAME<48>), (nb), (256), st, A); break;            \
+      case 52: DOF_LAUNCH((NAME<52>), (nb), (256), st, A); break;            \
+      case 56: DOF_LAUNCH((NAME<56>), (nb), (256), st, A); break;            \
+      case 60: DOF_LAUNCH((NAME<60>), (nb), (256), st, A); break;            \
       case 64: DOF_LAUNCH((NAME<64>), (nb), (256), st, A); break;            \
       default: dof_set_error("LayerNorm width %d not supported", C); return DOF_ERR_UNSUPPORTED; \
     }                                                                        \

@@ -1285,33 +1285,75 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
   }
 
-// CensNet kernels are specialised on (latent L, input channels D): D = 2L behind the recurrent blocks, 32 behind the TCNs
+// CensNet kernels are specialised on (latent L, input channels D): D = 2L behind the recurrent blocks, 32 behind the TCNs,
+// key_dim (any multiple of 4 up to 64) behind the transformer cores
 #define CENS_DISPATCH(p, NAME, GRID, ...)                                                              \
   do {                                                                                                 \
     const int _l = (p)->L, _d = (p)->D;                                                                \
-    if (_l == 4 && _d == 8) DOF_LAUNCH((NAME<4, 8>), GRID, (256), st, __VA_ARGS__);                    \
-    else if (_l == 6 && _d == 12) DOF_LAUNCH((NAME<6, 12>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 8 && _d == 16) DOF_LAUNCH((NAME<8, 16>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 4 && _d == 32) DOF_LAUNCH((NAME<4, 32>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 6 && _d == 32) DOF_LAUNCH((NAME<6, 32>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 8 && _d == 32) DOF_LAUNCH((NAME<8, 32>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 4 && _d == 24) DOF_LAUNCH((NAME<4, 24>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 6 && _d == 24) DOF_LAUNCH((NAME<6, 24>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 8 && _d == 24) DOF_LAUNCH((NAME<8, 24>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 4 && _d == 40) DOF_LAUNCH((NAME<4, 40>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 6 && _d == 40) DOF_LAUNCH((NAME<6, 40>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 8 && _d == 40) DOF_LAUNCH((NAME<8, 40>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 4 && _d == 48) DOF_LAUNCH((NAME<4, 48>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 6 && _d == 48) DOF_LAUNCH((NAME<6, 48>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 8 && _d == 48) DOF_LAUNCH((NAME<8, 48>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 4 && _d == 64) DOF_LAUNCH((NAME<4, 64>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 6 && _d == 64) DOF_LAUNCH((NAME<6, 64>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 8 && _d == 64) DOF_LAUNCH((NAME<8, 64>), GRID, (256), st, __VA_ARGS__);             \
-    else if (_l == 16 && _d == 32) DOF_LAUNCH((NAME<16, 32>), GRID, (256), st, __VA_ARGS__);           \
-    else if (_l == 16 && _d == 24) DOF_LAUNCH((NAME<16, 24>), GRID, (256), st, __VA_ARGS__);           \
-    else if (_l == 16 && _d == 40) DOF_LAUNCH((NAME<16, 40>), GRID, (256), st, __VA_ARGS__);           \
-    else if (_l == 16 && _d == 48) DOF_LAUNCH((NAME<16, 48>), GRID, (256), st, __VA_ARGS__);           \
-    else if (_l == 16 && _d == 64) DOF_LAUNCH((NAME<16, 64>), GRID, (256), st, __VA_ARGS__);           \
+    if (_l == 4 && _d == 4) DOF_LAUNCH((NAME<4, 4>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 8) DOF_LAUNCH((NAME<4, 8>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 12) DOF_LAUNCH((NAME<4, 12>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 16) DOF_LAUNCH((NAME<4, 16>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 20) DOF_LAUNCH((NAME<4, 20>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 24) DOF_LAUNCH((NAME<4, 24>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 28) DOF_LAUNCH((NAME<4, 28>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 32) DOF_LAUNCH((NAME<4, 32>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 36) DOF_LAUNCH((NAME<4, 36>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 40) DOF_LAUNCH((NAME<4, 40>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 44) DOF_LAUNCH((NAME<4, 44>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 48) DOF_LAUNCH((NAME<4, 48>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 52) DOF_LAUNCH((NAME<4, 52>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 56) DOF_LAUNCH((NAME<4, 56>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 60) DOF_LAUNCH((NAME<4, 60>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 4 && _d == 64) DOF_LAUNCH((NAME<4, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 4) DOF_LAUNCH((NAME<6, 4>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 8) DOF_LAUNCH((NAME<6, 8>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 12) DOF_LAUNCH((NAME<6, 12>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 16) DOF_LAUNCH((NAME<6, 16>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 20) DOF_LAUNCH((NAME<6, 20>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 24) DOF_LAUNCH((NAME<6, 24>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 28) DOF_LAUNCH((NAME<6, 28>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 32) DOF_LAUNCH((NAME<6, 32>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 36) DOF_LAUNCH((NAME<6, 36>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 40) DOF_LAUNCH((NAME<6, 40>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 44) DOF_LAUNCH((NAME<6, 44>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 48) DOF_LAUNCH((NAME<6, 48>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 52) DOF_LAUNCH((NAME<6, 52>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 56) DOF_LAUNCH((NAME<6, 56>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 60) DOF_LAUNCH((NAME<6, 60>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 6 && _d == 64) DOF_LAUNCH((NAME<6, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 4) DOF_LAUNCH((NAME<8, 4>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 8) DOF_LAUNCH((NAME<8, 8>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 12) DOF_LAUNCH((NAME<8, 12>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 16) DOF_LAUNCH((NAME<8, 16>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 20) DOF_LAUNCH((NAME<8, 20>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 24) DOF_LAUNCH((NAME<8, 24>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 28) DOF_LAUNCH((NAME<8, 28>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 32) DOF_LAUNCH((NAME<8, 32>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 36) DOF_LAUNCH((NAME<8, 36>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 40) DOF_LAUNCH((NAME<8, 40>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 44) DOF_LAUNCH((NAME<8, 44>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 48) DOF_LAUNCH((NAME<8, 48>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 52) DOF_LAUNCH((NAME<8, 52>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 56) DOF_LAUNCH((NAME<8, 56>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 60) DOF_LAUNCH((NAME<8, 60>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 8 && _d == 64) DOF_LAUNCH((NAME<8, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 4) DOF_LAUNCH((NAME<16, 4>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 8) DOF_LAUNCH((NAME<16, 8>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 12) DOF_LAUNCH((NAME<16, 12>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 16) DOF_LAUNCH((NAME<16, 16>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 20) DOF_LAUNCH((NAME<16, 20>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 24) DOF_LAUNCH((NAME<16, 24>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 28) DOF_LAUNCH((NAME<16, 28>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 32) DOF_LAUNCH((NAME<16, 32>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 36) DOF_LAUNCH((NAME<16, 36>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 40) DOF_LAUNCH((NAME<16, 40>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 44) DOF_LAUNCH((NAME<16, 44>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 48) DOF_LAUNCH((NAME<16, 48>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 52) DOF_LAUNCH((NAME<16, 52>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 56) DOF_LAUNCH((NAME<16, 56>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 60) DOF_LAUNCH((NAME<16, 60>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 16 && _d == 64) DOF_LAUNCH((NAME<16, 64>), GRID, (256), st, __VA_ARGS__); \
     else { dof_set_error("CensNet (latent %d, channels %d) not supported by this build", _l, _d); return DOF_ERR_UNSUPPORTED; } \
   } while (0)
 
@@ -1321,17 +1363,11 @@ int censnet_forward(DofVadePlan* p, const float* params, hipStream_t st, bool do
   // CensNet: node update is weighted by edge dot products (edge_weights) and vice versa
   const StreamWs& wn = p->sw[0];
   const StreamWs& we = p->sw[1];
-  if (p->D == 32 || p->D == 24 || p->D == 40 || p->D == 48 || p->D == 64) {
+  if (p->tcn || p->tfm) {   // D = 32 (TCN) / key_dim (transformer): the width is a run-time value here
     for (int s = 0; s < 2; ++s) {
       const StreamWs& w = s ? we : wn;
       const float* pw = params + (s ? p->c_ew : p->c_nw);
-      switch (p->D) {
-        case 24: DOF_LAUNCH((k_cens_dots<24>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
-        case 32: DOF_LAUNCH((k_cens_dots<32>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
-        case 40: DOF_LAUNCH((k_cens_dots<40>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
-        case 48: DOF_LAUNCH((k_cens_dots<48>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
-        default: DOF_LAUNCH((k_cens_dots<64>), (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, w.S, w.Sp); break;
-      }
+      DOF_LAUNCH(k_cens_dots_rt, (dof_cdiv(w.S, 256)), (256), st, (const float*)(ws + w.n2), pw, ws + w.dots, p->D, w.S, w.Sp);
     }
   } else if (!dots_done) {  // (the recurrent encoder's tail kernel has already left them)
     LDISPATCH(p->L, DOF_LAUNCH((k_cens_dots<2 * LL>), (dof_cdiv(wn.S, 256)), (256), st, (const float*)(ws + wn.n2),
@@ -2024,8 +2060,8 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
     tf.D4 = 4 * p->L;
     tf.C3p = (p->C3 + 3) / 4 * 4;
     p->D = kd;
-    if (p->T > 64 || (kd != 24 && kd != 32 && kd != 40 && kd != 48 && kd != 64)) {
-      dof_set_error("transformer plan: window %d (max 64) / key_dim %d (24, 32, 40, 48, 64) not supported by this build", p->T, kd);
+    if (p->T > 64 || kd < 4 || kd > 64 || kd % 4 != 0) {
+      dof_set_error("transformer plan: window %d (max 64) / key_dim %d (multiples of 4 up to 64) not supported by this build", p->T, kd);
       delete p;
       return DOF_ERR_UNSUPPORTED;
     }

@@ -193,7 +193,8 @@ def test_contrastive_tfm_emu(golden_dir):
 
 
 @pytest.mark.parametrize("n_nodes,latent,kind", [(8, 4, "vade"), (11, 6, "vqvae"), (16, 8, "vade"), (22, 8, "vqvae"),
-                                                  (11, 16, "vade"), (11, 16, "vqvae"), (14, 16, "vade"), (8, 16, "vqvae")])
+                                                  (11, 16, "vade"), (11, 16, "vqvae"), (14, 16, "vade"), (8, 16, "vqvae"),
+                                                  (10, 8, "vade"), (12, 6, "vqvae"), (19, 8, "vade"), (7, 6, "vqvae")])
 def test_tfm_other_widths_emu(n_nodes, latent, kind):
     """key_dim 24 / 32 / 48 / 64 and decoder widths 16 / 24 / 32 of the transformer family against the oracle."""
     print(PC.run_tfm_widths_vs_oracle(emu_lib(), "cpu", n_nodes, latent, B=4, T=6, kind=kind))

@@ -1176,7 +1176,11 @@ def test_data_parallel_default_form_is_one_graph_native(tmp_path):
 
 @pytest.mark.parametrize("n_nodes,latent,kind", [(8, 4, "vade"), (11, 6, "vqvae"), (16, 8, "vade"), (22, 8, "vqvae"),
                                                   (28, 8, "vade"), (11, 16, "vade"), (11, 16, "vqvae"),
-                                                  (14, 16, "vade"), (8, 16, "vqvae"), (16, 16, "vade"), (22, 16, "vqvae")])
+                                                  (14, 16, "vade"), (8, 16, "vqvae"), (16, 16, "vade"), (22, 16, "vqvae"),
+                                                  # round 4: every key_dim = min(64, 3 N) // 4 * 4 (28, 36, 44, 52, 56, 60, 20, 12, 8, 4);
+                                                  # N = 7, 12, 18, 19 also hold a sequence whose every key is masked (NaN -> zero row)
+                                                  (10, 8, "vade"), (12, 6, "vqvae"), (15, 8, "vade"), (18, 4, "vqvae"), (19, 8, "vade"),
+                                                  (20, 16, "vqvae"), (7, 6, "vqvae"), (5, 8, "vade"), (3, 8, "vade"), (2, 8, "vade")])
 def test_tfm_other_widths_gpu(hip, n_nodes, latent, kind):
     """key_dim 24 / 32 / 48 / 64, latent 4 / 6 / 8 (decoder widths 16 / 24 / 32) of the transformer family against the
     oracle on injected random keep-masks: eval forward with a masked frame, total loss and every gradient."""

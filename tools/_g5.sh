@@ -1,8 +1,9 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r04h
-B="python bench.py --no-cpu-baseline --no-secondary --steps 300 --warmup 30 --gather-iters 2 --sustain-seconds 0"
-for rep in 1 2 3; do
-for cfg in "DOF_GRU8_MFMA=0" "X=1"; do
-  echo "$cfg: $(env $cfg timeout 300 $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['ms_per_step'],4), d['config']['final_total_loss'])")"
-done; done | tee gpurun_out/r04h/ab.txt
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_r03.py -x -q -m gpu -k "not tcn and not tfm and not transformer and not preprocess and not turtle" 2>&1 | tail -4 | tee gpurun_out/r04h/pytest.txt
+mkdir -p gpurun_out/r04i
+export TMPDIR=/tmp
+cd /tmp
+rm -rf /tmp/rp_t
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_t -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary --steps 60 --warmup 10 --gather-iters 3 --sustain-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/r04i/bench_under_rocprof.json 2>/dev/null
+db=$(find /tmp/rp_t -name '*.db' | head -1)
+python $GRAFT_REPO_ROOT/tools/rocpd_stats.py "$db" 60 > $GRAFT_REPO_ROOT/gpurun_out/r04i/kernel_stats_graph.md
+head -45 $GRAFT_REPO_ROOT/gpurun_out/r04i/kernel_stats_graph.md | cut -c1-140
