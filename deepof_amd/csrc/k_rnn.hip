@@ -2149,8 +2149,9 @@ __global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ ac
     case 6: { constexpr int LL = 6; CALL; } break;         \
     case 8: { constexpr int LL = 8; CALL; } break;         \
     case 16: { constexpr int LL = 16; CALL; } break;       \
+    case 32: { constexpr int LL = 32; CALL; } break;       \
     default:                                               \
-      dof_set_error("latent_dim %d not supported by this build (4, 6, 8)", (int)(L)); \
+      dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16, 32)", (int)(L)); \
       return DOF_ERR_UNSUPPORTED;                          \
   }
 

@@ -716,8 +716,8 @@ void take_tables(DofVadePlan* p, Carver& cv) {
     p->dh_partial = cv.take(p->lat_blocks);
   }
   for (JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram, &p->js_all}) {
-    js->jobs_tab = cv.take(96 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
-    js->fin_tab = cv.take(512 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
+    js->jobs_tab = cv.take(256 * (int64_t)(sizeof(DofOuterJob) / 4 + 1));
+    js->fin_tab = cv.take(2048 * (int64_t)(sizeof(DofFinJob) / 4 + 1));
     js->wg_tab = cv.take(48 * (int64_t)(sizeof(DofTcnWgrad) / 4 + 1));
   }
   p->segs_tab = cv.take(DOF_SEG_COUNT * (int64_t)(sizeof(DofAdamSeg) / 4 + 1));
@@ -807,6 +807,15 @@ struct JobBuilder {
     return (int)jobs.size() - 1;
   }
   int add_tile(int job, View b, int nc, int shift, int pack = 0) {
+    if (nc > 16 && pack == 0) {  // a wide operand (latent > 16): consecutive full tiles, contiguous columns in the partial
+      const int first = jobs[job].n_tiles;   // tile, so one fin block may span them (<= 64 columns per job)
+      for (int c0 = 0; c0 < nc; c0 += 16) {
+        View part = b;
+        part.p = b.p + (int64_t)c0 * b.cs;
+        add_tile(job, part, nc - c0 < 16 ? nc - c0 : 16, shift);
+      }
+      return first;
+    }
     DofOuterJob& j = jobs[job];
     DofOuterTile& t = j.tile[j.n_tiles];
     t.ptr = b.p; t.t_stride = b.ts; t.s_stride = b.ss; t.c_stride = b.cs; t.nc = nc; t.shift = shift; t.pack = pack;
@@ -1282,7 +1291,18 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     case 6: { constexpr int LL = 6; CALL; } break; \
     case 8: { constexpr int LL = 8; CALL; } break; \
     case 16: { constexpr int LL = 16; CALL; } break; \
-    default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
+    case 32: { constexpr int LL = 32; CALL; } break; \
+    default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16, 32)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
+  }
+
+// the row-per-window latent kernels (a 16-lane DPP row owns the latent dimensions): latent <= 16 only
+#define LDISPATCH16(L, CALL)                       \
+  switch (L) {                                     \
+    case 4: { constexpr int LL = 4; CALL; } break; \
+    case 6: { constexpr int LL = 6; CALL; } break; \
+    case 8: { constexpr int LL = 8; CALL; } break; \
+    case 16: { constexpr int LL = 16; CALL; } break; \
+    default: dof_set_error("latent_dim %d: the row-per-window latent kernels cover latent <= 16", (int)(L)); return DOF_ERR_UNSUPPORTED; \
   }
 
 // CensNet kernels are specialised on (latent L, input channels D): D = 2L behind the recurrent blocks, 32 behind the TCNs,
@@ -1354,6 +1374,7 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     else if (_l == 16 && _d == 56) DOF_LAUNCH((NAME<16, 56>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 16 && _d == 60) DOF_LAUNCH((NAME<16, 60>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 16 && _d == 64) DOF_LAUNCH((NAME<16, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 32 && _d == 64) DOF_LAUNCH((NAME<32, 64>), GRID, (256), st, __VA_ARGS__); \
     else { dof_set_error("CensNet (latent %d, channels %d) not supported by this build", _l, _d); return DOF_ERR_UNSUPPORTED; } \
   } while (0)
 
@@ -1601,7 +1622,7 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
                    float* q_out, float* mu_out, float* sv_out, float* enc_out, hipStream_t st) {
   float* ws = p->ws;
   LatentFwdArgs A;
-  const bool rows = p->K <= 32;  // components across lanes; encoder.final_dense evaluated in the same launch
+  const bool rows = p->K <= 32 && p->L <= 16;  // components across lanes (a 16-lane row also owns the L latent dimensions); encoder.final_dense evaluated in the same launch
   if (!rows) TRY(final_dense_fwd(p, params, st));
   A.flat = (rows && !p->tcn && !p->tfm) ? ws + p->flat : nullptr; A.J = p->J;
   A.wf = params + p->fd_w; A.bf = params + p->fd_b; A.wm = params + p->mean_w; A.bm = params + p->mean_b;
@@ -1614,9 +1635,9 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
   if (!rows) {
     LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd<LL>), (dof_cdiv(p->B, 256)), (256), st, A));
   } else if (p->K <= 16) {
-    LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd_w<LL, 1>), (dof_cdiv(p->B, kLatRows)), (256), st, A));
+    LDISPATCH16(p->L, DOF_LAUNCH((k_latent_fwd_w<LL, 1>), (dof_cdiv(p->B, kLatRows)), (256), st, A));
   } else {
-    LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd_w<LL, 2>), (dof_cdiv(p->B, kLatRows)), (256), st, A));
+    LDISPATCH16(p->L, DOF_LAUNCH((k_latent_fwd_w<LL, 2>), (dof_cdiv(p->B, kLatRows)), (256), st, A));
   }
   return dof_check_launch("k_latent_fwd");
 }
@@ -2033,8 +2054,8 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
                   dims->window, dims->n_nodes, dims->n_edges, dims->n_clusters);
     return DOF_ERR_ARG;
   }
-  if (dims->latent != 4 && dims->latent != 6 && dims->latent != 8 && dims->latent != 16) {
-    dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16)", dims->latent);
+  if (dims->latent != 4 && dims->latent != 6 && dims->latent != 8 && dims->latent != 16 && !(dims->latent == 32 && !tcn && !tfm)) {
+    dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16; 32 with the recurrent encoder)", dims->latent);
     return DOF_ERR_UNSUPPORTED;
   }
   if (dims->n_nodes > DOF_CL_MAX_NODES && kind == 2) {
@@ -2189,6 +2210,27 @@ extern "C" int dof_vade_set_trainable(DofVadePlan* p, int32_t i, int32_t trainab
   return dof_launch_zero(m, e.numel, (hipStream_t)stream);
 }
 extern "C" int64_t dof_vade_workspace_bytes(const DofVadePlan* p) { return p->ws_floats * 4; }
+#ifdef DOF_EMU
+// (pytest-only emulation build) float offset / padded sequence count of a named workspace tensor, for bisecting a new
+// latent size stage by stage against the oracle: "<stream>.<field>" with stream n / e, or a plan-level field
+extern "C" int64_t dof_emu_ws_offset(const DofVadePlan* p, const char* name, int64_t* sp_out) {
+  const std::string n(name);
+  if (n.size() > 2 && n[1] == '.') {
+    const StreamWs& w = p->sw[n[0] == 'e' ? 1 : 0];
+    if (sp_out) *sp_out = w.Sp;
+    const std::string f = n.substr(2);
+    if (f == "xs") return w.xs; if (f == "c") return w.c; if (f == "o1") return w.o1; if (f == "n1") return w.n1;
+    if (f == "o2") return w.o2; if (f == "hf") return w.hf; if (f == "n2") return w.n2; if (f == "Z") return w.Z;
+    if (f == "len") return w.len;
+    return -1;
+  }
+  if (sp_out) *sp_out = p->Bp;
+  if (n == "flat") return p->flat; if (n == "enc") return p->enc; if (n == "mu") return p->mu; if (n == "z") return p->z;
+  if (n == "o1d") return p->o1d; if (n == "n1d") return p->n1d; if (n == "o2d") return p->o2d; if (n == "n2d") return p->n2d;
+  if (n == "cv") return p->cv; if (n == "n3") return p->n3;
+  return -1;
+}
+#endif
 
 extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
   if (!p || !workspace) {
@@ -2207,7 +2249,7 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
     if (bytes) hipMemcpyAsync(ws + off, src, bytes, hipMemcpyHostToDevice, st);
   };
   for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram, &p->js_all}) {
-    if (js->jobs.size() > 96 || js->fins.size() > 512) {
+    if (js->jobs.size() > 256 || js->fins.size() > 2048) {
       dof_set_error("dof_vade_bind: job table overflow (%zu jobs, %zu fins)", js->jobs.size(), js->fins.size());
       return DOF_ERR_STATE;
     }
@@ -2369,13 +2411,13 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   LB.distill_partial = ws + p->distill_partial; LB.J = p->J; LB.K = K; LB.S = p->S; LB.pretrain = pretrain ? 1 : 0;
   LB.B = B; LB.Bp = Bp;
   int n_lat_partial;
-  if (K <= 32) {  // components across lanes (16 windows per workgroup), final_dense's data gradient included
+  if (K <= 32 && L <= 16) {  // components across lanes (16 windows per workgroup), final_dense's data gradient included
     if (p->tcn || p->tfm) LB.dflat = nullptr;
     n_lat_partial = (int)dof_cdiv(B, kLatRows);
     if (K <= 16) {
-      LDISPATCH(L, DOF_LAUNCH((k_latent_bwd_w<LL, 1>), ((unsigned)n_lat_partial), (256), st, LB));
+      LDISPATCH16(L, DOF_LAUNCH((k_latent_bwd_w<LL, 1>), ((unsigned)n_lat_partial), (256), st, LB));
     } else {
-      LDISPATCH(L, DOF_LAUNCH((k_latent_bwd_w<LL, 2>), ((unsigned)n_lat_partial), (256), st, LB));
+      LDISPATCH16(L, DOF_LAUNCH((k_latent_bwd_w<LL, 2>), ((unsigned)n_lat_partial), (256), st, LB));
     }
     TRY(dof_check_launch("k_latent_bwd_w"));
   } else {

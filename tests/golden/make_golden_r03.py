@@ -350,6 +350,11 @@ if __name__ == "__main__":
         MG.gen_vade("rec14l16", [""], 25, 16, 10, 12, 431)
         MG.gen_vqvae("rec14l16", [""], 25, 16, 48, 12, 441, kmeans=0.5)
         MG.gen_contrastive("rec14l16", [""], 24, 16, 12, 461)
+    if "l32" in what:   # latent 32 (round 4; recurrent family): GRU(64, 64) + GRU(128 -> 32) streams; batch 40 > latent so that the
+        # Gram matrix of the k-means term has full rank (with B < L its value hangs on the clamp of 20 zero eigenvalues)
+        MG.gen_vade("rec14l32", [""], 25, 32, 10, 40, 531)
+        MG.gen_vqvae("rec14l32", [""], 25, 32, 48, 40, 541, kmeans=0.5)
+        MG.gen_contrastive("rec14l32", [""], 24, 32, 12, 561)
     if "l16tcn" in what:
         MG.gen_contrastive("tcn14l16", [""], 24, 16, 6, 481, encoder_type="TCN", cases=[("cosine", "nce")])
     if "vqkinks" in what:   # refresh only the VQ-VAE part of tcn_kinks.npz

@@ -56,7 +56,7 @@ def test_gather_matches_reference_windows(hip, golden_dir):
             np.testing.assert_array_equal(a.cpu().numpy(), d[f"w{ci}::a"])
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32"])
 def test_vade_eval_forward_gpu(hip, golden_dir, tag):
     from deepof_amd.engine import create_vade_engine
     from parity_common import load_golden, params_from
@@ -78,7 +78,8 @@ def test_vade_eval_forward_gpu(hip, golden_dir, tag):
                                        # C5 graph at latent 8, window 50, k = 25: the lane-per-unit / MFMA-fused kernels
                                        ("c5l8", "pre"), ("c5l8", "main"), ("c5l8", "mainT"), ("c5l8", "mainX"),
                                        # latent 16: GRU(32, 32) / GRU(64 -> 16) streams through the generic kernels
-                                       ("rec14l16", "pre"), ("rec14l16", "main"), ("rec14l16", "mainT"), ("rec14l16", "mainX")])
+                                       ("rec14l16", "pre"), ("rec14l16", "main"), ("rec14l16", "mainT"), ("rec14l16", "mainX"),
+                                       ("rec14l32", "pre"), ("rec14l32", "main"), ("rec14l32", "mainT"), ("rec14l32", "mainX")])
 def test_vade_loss_grads_gpu(hip, golden_dir, tag, phase):
     from parity_common import run_phase_check
     worst = run_phase_check(hip, "cuda", golden_dir, tag, phase)
@@ -251,7 +252,7 @@ def test_training_api_on_gpu(hip, tmp_path):
     np.testing.assert_allclose(soft.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32"])
 def test_vqvae_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_vqvae_check
     run_vqvae_check(hip, "cuda", golden_dir, tag)
@@ -323,7 +324,7 @@ def test_vqvae_full_size_c3(hip):
     np.testing.assert_allclose(out["soft_counts"].cpu().numpy(), soft.numpy(), rtol=2e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32"])
 def test_contrastive_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_contrastive_check, run_contrastive_loss_check
     run_contrastive_loss_check(hip, "cuda", golden_dir, tag)
