@@ -2293,6 +2293,13 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
     if (kind == 0) GRUQ_FWD(32, 32, false);
     else if (kind == 1) GRUQ_FWD(64, 16, false);
     else GRUQ_FWD(16, 16, true);
+    return dof_check_launch("k_gruq_fwd");
+  }
+  if (L == 32) {  // the same quad split (thread-per-sequence: 134 ms per C2-shape step, 98 KB of weights per workgroup)
+    const unsigned nq = dof_cdiv(S * 4, 256);
+    if (kind == 0) GRUQ_FWD(64, 64, false);
+    else if (kind == 1) GRUQ_FWD(128, 32, false);
+    else GRUQ_FWD(32, 32, true);
 #undef GRUQ_FWD
     return dof_check_launch("k_gruq_fwd");
   }
@@ -2321,6 +2328,13 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
     if (kind == 0) GRUQ_BWD(32, 32, false);
     else if (kind == 1) GRUQ_BWD(64, 16, false);
     else GRUQ_BWD(16, 16, true);
+    return dof_check_launch("k_gruq_bwd");
+  }
+  if (L == 32) {
+    const unsigned nq = dof_cdiv(S * 4, 256);
+    if (kind == 0) GRUQ_BWD(64, 64, false);
+    else if (kind == 1) GRUQ_BWD(128, 32, false);
+    else GRUQ_BWD(32, 32, true);
 #undef GRUQ_BWD
     return dof_check_launch("k_gruq_bwd");
   }
