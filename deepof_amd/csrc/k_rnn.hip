@@ -2481,7 +2481,9 @@ bool dof_grum_selected(int64_t S) {
     const char* e = getenv("DOF_GRUM");
     return !(e && e[0] == '0');
   }();
-  return on && dof_gru16_mfma(S);
+  // (the alternative here is the quad-split kernel, 290 us for the decoder's 1,024 sequences of a (32, 32) layer: the
+  // matrix-pipe form wins from a few hundred sequences on, unlike the (16, 16) layer whose alternative is lane-per-unit)
+  return on && dof_gru_mfma() && (dof_gru16_mfma(S) || S >= 512);
 }
 
 static Gru16mStream gru16m_stream(const float* X, const int* len, DofGruW W, float* O, float* GS, const float* dO, float* dX,
