@@ -193,8 +193,10 @@ def test_input_validation_errors():
         TR.train_deepof_model(**{**kw, "model_name": "gan"})
     with pytest.raises(ValueError):
         TR.train_deepof_model(**{**kw, "device": "tpu"})
-    with pytest.raises(NotImplementedError, match="key_dim 12"):   # 4 nodes: a transformer width this build has no kernels for
-        TR.train_deepof_model(**{**kw, "model_name": "VQVAE", "encoder_type": "transformer"})
+    with pytest.raises(NotImplementedError, match="latent_dim=64"):   # limits of this build are reported up front
+        TR.train_deepof_model(**{**kw, "latent_dim": 64})
+    with pytest.raises(NotImplementedError, match="recurrent encoder only"):
+        TR.train_deepof_model(**{**kw, "latent_dim": 32, "encoder_type": "TCN"})
     with pytest.raises(RuntimeError):   # product path: no CPU fallback
         TR.train_deepof_model(**{**kw, "device": "cpu", "_engine_factory": None})
 
@@ -239,7 +241,8 @@ def test_fit_vade_end_to_end_and_checkpoint_roundtrip(tmp_path):
 
 def test_fit_latent16_end_to_end(tmp_path):
     """latent_dim = 16 through the trainer (GRU(32, 32) / GRU(64 -> 16) streams; one video of 16 windows, the emulator
-    runs those layers slowly): finite logs, embeddings of width 16; latent 32 is refused up front."""
+    runs those layers slowly): finite logs, embeddings of width 16; latent 64 is refused up front (latent 32: the
+    reference goldens *_rec14l32)."""
     pre = tiny_preprocessed(n_videos=1, n_win=16, seed=3)
     kw = dict(preprocessed_object=(pre, pre), adjacency_matrix=chain_adj(4), meta_info={}, encoder_type="recurrent",
               batch_size=8, epochs=1, output_path=str(tmp_path), n_clusters=3, model_name="VaDE", pretrain_epochs=0,
@@ -249,8 +252,8 @@ def test_fit_latent16_end_to_end(tmp_path):
     x = torch.from_numpy(reorder_and_reshape(pre["vid0"][0])[:8])
     a = torch.from_numpy(pre["vid0"][1][:8, ..., None])
     assert tuple(model_val.embed(x, a).shape) == (8, 16)
-    with pytest.raises((NotImplementedError, ValueError, AssertionError), match="32|latent"):
-        TR.train_deepof_model(latent_dim=32, **kw)
+    with pytest.raises((NotImplementedError, ValueError, AssertionError), match="64|latent"):
+        TR.train_deepof_model(latent_dim=64, **kw)
 
 
 def test_logged_total_is_sum_of_parts():
