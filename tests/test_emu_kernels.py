@@ -32,7 +32,7 @@ def test_vade_eval_forward_emu(golden_dir, tag):
 @pytest.mark.parametrize("tag,phase", [("rec14", "pre"), ("rec14", "main"), ("rec14", "mainT"), ("rec14", "mainX"),
                                        ("rec28", "pre"), ("rec28", "mainT"), ("rec28", "mainX"),
                                        ("c5l8", "pre"), ("c5l8", "mainX"),
-                                       ("rec14l16", "pre"), ("rec14l16", "mainX"), ("rec14l32", "pre"), ("rec14l32", "mainT")])
+                                       ("rec14l16", "pre"), ("rec14l16", "mainX"), ("rec14l32", "pre")])   # (latent 32: the other phases / models on the GPU)
 def test_vade_loss_grads_emu(golden_dir, tag, phase):
     run_phase_check(emu_lib(), "cpu", golden_dir, tag, phase)
 
@@ -52,7 +52,7 @@ def test_vade_train_trace_emu(golden_dir):
     run_trace_check(emu_lib(), "cpu", golden_dir)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "rec14l16", "rec14l32"])   # (c5l8 / c3k512: GPU only, 1-2 minutes each under the emulator)
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "rec14l16"])   # (c5l8 / c3k512 / rec14l32: GPU only, minutes each under the emulator)
 def test_vqvae_emu(golden_dir, tag):
     run_vqvae_check(emu_lib(), "cpu", golden_dir, tag)
 
@@ -63,7 +63,7 @@ def test_contrastive_losses_emu(golden_dir, tag):
     run_contrastive_loss_check(emu_lib(), "cpu", golden_dir, tag)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16"])
 def test_contrastive_step_emu(golden_dir, tag):
     from parity_common import run_contrastive_check
     run_contrastive_check(emu_lib(), "cpu", golden_dir, tag)
