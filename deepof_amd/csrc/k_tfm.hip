@@ -901,6 +901,14 @@ static int attn_nseq(const DofAttn& a, bool bwd) {
 
 // head sizes 1 .. 16: key_dim = min(64, 3 N) rounded down to a multiple of its 4 heads (models_new.py:1013-1019) is any
 // multiple of 4 in 4 .. 64; the decoder's 8 heads of width 4 L / 8 (latent 4, 6, 8, 16: 2, 3, 4, 8)
+// does a (window, width, heads) attention fit the kernels' LDS / thread budget, forward AND backward?  (plan creation
+// asks, so that an unsupported shape fails there and not at the first backward pass)
+bool dof_tfm_attn_fits(int T, int D, int H) {
+  DofAttn a = {};
+  a.T = T; a.D = D; a.H = H;
+  return T <= 64 && D % H == 0 && attn_nseq(a, false) >= 1 && attn_nseq(a, true) >= 1;
+}
+
 #define ATTN_DISPATCH(NAME, A, nb, nt)                                                        \
   do {                                                                                        \
     const int dh = (A).D / (A).H;                                                             \

@@ -220,6 +220,7 @@ int dof_launch_tfm_embed(int F, const float* xin, const float* w, const float* b
 int dof_launch_tfm_embed_bwd(int F, const float* xs, const float* w, const float* bias, const float* dy, float* dpre,
                              const DofDrop& drop, int T, int D, int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_tfm_gemm(const DofGemm& g, hipStream_t st);
+bool dof_tfm_attn_fits(int T, int D, int H);
 int dof_launch_tfm_attn(DofAttn a, int backward, hipStream_t st);
 int64_t dof_tfm_ln_blocks(int C, int T, int64_t Sp);
 int dof_launch_tfm_add_ln(const DofLn& a, int C, hipStream_t st);
