@@ -585,6 +585,56 @@ def test_vade_tcn_padded_decoder_input_gpu(hip, L):
     run_vade_tcn_vs_oracle(hip, "cuda", L=L)
 
 
+def test_full_size_c5_gradients_equal_chunked_small_launches(hip):
+    """The B = 4096 launch geometry of C5 (245,760 sequences per stream: the matrix-pipe GRU kernels, 16 windows per
+    gather workgroup, 256-workgroup reductions) against the SMALL-launch geometry the reference goldens pin
+    (test_gradient_parity_c5_shape: B = 64, lane-per-unit kernels with saved gates): with the batch-separable terms only
+    (reconstruction, KL, activity L1 -- means over windows), the gradient of the 4,096-window batch is the mean of the
+    gradients of its 64 chunks of 64 windows.  Every tensor at the standard gradient bar (5e-5 + 5e-4 of its scale)."""
+    from deepof_amd.engine import create_vade_engine
+    from deepof_amd.graph import adjacency_from_graph, bodypart_graph
+    from parity_common import configure_phase
+    nodes, edges = bodypart_graph(["B", "W"])
+    N, E = len(nodes), len(edges)
+    B, Bc, T, L, K = 4096, 64, 50, 8, 25
+    adj = adjacency_from_graph(nodes, edges)
+    big, small = create_vade_engine(B, T, adj, L, K, 32), create_vade_engine(Bc, T, adj, L, K, 32)
+    g = torch.Generator().manual_seed(3)
+    for n in big.names:
+        shape = big.layout[n][2]
+        v = torch.randn(shape, generator=g) * (0.3 if len(shape) > 1 else 0.1)
+        if "norm" in n and n.endswith("weight"):
+            v = 1.0 + v
+        big.view(n).copy_(v)
+    small.params.copy_(big.params)
+    x = torch.randn(B, T, N, 3, generator=g).cuda()
+    a = torch.randn(B, T, E, 1, generator=g).cuda()
+    x[7, 40:] = 0.0
+    a[7, 40:] = 0.0          # one window with masked frames
+    eps = torch.randn(B, L, generator=g).cuda()
+    sep = dict(km_latent=0.0, km_loss=0.0, repel_w=0.0, nonempty_w=0.0)
+    configure_phase(big, K, True, 0.4, extra=sep)
+    configure_phase(small, K, True, 0.4, extra=sep)
+    big.loss_grads(x, a, eps, None, None, pretrain=True)
+    acc = torch.zeros_like(small.grads, dtype=torch.float64)
+    for c in range(B // Bc):
+        sl = slice(c * Bc, (c + 1) * Bc)
+        small.loss_grads(x[sl].contiguous(), a[sl].contiguous(), eps[sl].contiguous(), None, None, pretrain=True)
+        acc += small.grads.double()
+    mean = (acc / (B // Bc)).float()
+    worst = 0.0
+    for n in big.names:
+        if n not in big.layout:
+            continue
+        gb, gs = big.view(n, big.grads).cpu().numpy(), small.view(n, mean).cpu().numpy()
+        scale = float(np.abs(gs).max())
+        err = float(np.abs(gb - gs).max())
+        assert err <= 5e-5 + 5e-4 * scale, (n, err, scale)
+        worst = max(worst, err / (scale + 1e-12))
+    assert float(big.grads.abs().max()) > 1e-3
+    print("worst gradient difference / tensor scale (B = 4096 launch vs 64 launches of B = 64):", worst)
+
+
 def test_full_size_c5(hip):
     """BASELINE config C5 (VaDE, 2 animals: 28 nodes / 32 edges, window 50, k=25, batch 4096): main-phase step at
     full size -- run-to-run identical gradients, finite, logged total = sum of its parts -- and forward parity
