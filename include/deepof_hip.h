@@ -45,7 +45,10 @@ extern "C" {
 
 #define DOF_ABI_VERSION 15
 
-/* ---- error reporting ---------------------------------------------------------------------- */
+/* ---- error reporting ----------------------------------------------------------------------
+ * Every int entry point returns 0 or a negative code, with the text in dof_last_error_string():
+ * -1 DOF_ERR_ARG (bad argument), -2 DOF_ERR_UNSUPPORTED (shape / feature this build has no kernel for; never a host
+ * fallback), -3 DOF_ERR_LAUNCH (HIP / RCCL runtime error), -4 DOF_ERR_STATE (call order, e.g. a step before parameters). */
 const char* dof_last_error_string(void);
 int dof_abi_version(void);
 
@@ -76,7 +79,7 @@ typedef struct DofVadeDims {
   int32_t window;     /* T */
   int32_t n_nodes;    /* N, 3 features per node */
   int32_t n_edges;    /* E, 1 feature per edge */
-  int32_t latent;     /* L (internal GRU width = L; L <= 64 in the reference, this build: 4, 6, 8, 16) */
+  int32_t latent;     /* L (internal GRU width = min(64, L) in the reference; this build: 4, 6, 8, 16, and 32 with the recurrent encoder) */
   int32_t n_clusters; /* K */
   int32_t mc_samples; /* S of the Monte-Carlo KL (reference: 32) */
 } DofVadeDims;
@@ -121,7 +124,8 @@ int dof_vqvae_tcn_plan_create(const DofVadeDims* dims, const float* laplacian, c
  * same entry points as the other plans, parameters in VaDEPT / VQVAEPT / ContrastivePT(encoder_type="transformer")
  * .state_dict() order.  The BatchNorm running buffers of encoder.head are entries of the flat buffer as for the TCN
  * family; dof_vade_set_batchnorm_training(0) also switches dropout and the batch standardisation off (module.eval()).
- * This build: window <= 64, key_dim in {24, 32, 40, 48, 64}. */
+ * This build: key_dim any multiple of 4 up to 64; window <= 64 with the attention working set (one sequence, forward and
+ * backward) inside the kernel's LDS and 512-thread budget -- checked here, DOF_ERR_UNSUPPORTED otherwise. */
 int dof_vade_tfm_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
                              const float* incidence, DofVadePlan** out);
 int dof_vqvae_tfm_plan_create(const DofVadeDims* dims, const float* laplacian, const float* edge_laplacian,
