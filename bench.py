@@ -280,6 +280,8 @@ def secondary_configs(steps=12, warmup=6):
             ("C4 contrastive TCN encoder, window 50 -> 25, batch 8192",
              lambda: run_contrastive_product(8192, 50, "TCN", max(4, steps // 3), 25), 8192),
             ("C2 shape, VaDE TCN encoder/decoder, batch 1024", lambda: run_vade_product([""], 25, 10, 1024, "TCN", steps, 25), 1024),
+            ("C5 shape, VaDE TCN encoder/decoder: 2 animals (N=28,E=32), window 50 (8-sequence time-resident convolutions), k=25, batch 4096",
+             lambda: run_vade_product(["B", "W"], 50, 25, 4096, "TCN", max(4, steps // 3), 12), 4096),
             ("C2 shape, VaDE transformer encoder/decoder (dropout on), batch 1024",
              lambda: run_vade_product([""], 25, 10, 1024, "transformer", steps, warmup), 1024),
             ("C2 with bf16 window storage (BASELINE configs[1]: batches gathered as bf16, fp32 arithmetic), batch 1024",

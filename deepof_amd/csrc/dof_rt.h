@@ -39,6 +39,13 @@ __device__ __forceinline__ dof_bf16x8 dof_ld_bf16x8(const uint16_t* p) {
   u.h[1] = reinterpret_cast<const uint64_t*>(p)[1];
   return u.v;
 }
+// the same from an address that is 4-byte aligned only
+__device__ __forceinline__ dof_bf16x8 dof_ld_bf16x8_a4(const uint16_t* p) {
+  union { uint32_t w[4]; dof_bf16x8 v; } u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) u.w[k] = reinterpret_cast<const uint32_t*>(p)[k];
+  return u.v;
+}
 // fp32 = hi + mid + lo EXACTLY with three bf16 pieces: each piece is the top 16 bits of what is left (truncation keeps the
 // remainder exactly representable: 8 + 8 + 8 significand bits).  dof_bf16_rest: the value with its top piece removed;
 // dof_pack_hi16: the top pieces of two values as one word (first argument in the low half) -- one v_perm_b32.

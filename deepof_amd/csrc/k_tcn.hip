@@ -349,7 +349,14 @@ __global__ void __launch_bounds__(256) k_bn_bwd_sum_fin(const float* __restrict_
   }
 }
 
-__device__ __forceinline__ int tct_slot(int t, int sq, int chunk) { return (t * 16 + sq) * 8 + (chunk ^ ((sq >> 1) & 7)); }
+// NS = 16: sequences s, s + 1 of a time step share a 256-byte bank row, the chunk swizzle by s >> 1 spreads the 16 lanes of a
+// ds_read_b128 pass over the 16 bank groups.  NS = 8 (two time steps per MFMA column block): the lanes of a pass are 8
+// sequences of row tt and the same 8 of row tt + 1 -- the row parity goes into the swizzle's top bit.
+template <int NS>
+__device__ __forceinline__ int tct_slot(int t, int sq, int chunk) {
+  if (NS == 16) return (t * 16 + sq) * 8 + (chunk ^ ((sq >> 1) & 7));
+  return (t * 8 + sq) * 8 + (chunk ^ (((sq >> 1) & 3) | ((t & 1) << 2)));
+}
 
 // TAIL (with REVERSE, FUSE_BN, BWD2; round 3): the convolution is conv1's data gradient of block b + 1, its result plus
 // tail_src is the complete gradient at block b's output, and the epilogue runs the backward of block b's tail on it --
@@ -359,13 +366,20 @@ __device__ __forceinline__ int tct_slot(int t, int sq, int chunk) { return (t * 
 // COMB (forward, round 3): the input tile is the previous block's OUTPUT, computed while staging from that block's conv2
 // result and residual input -- out = ReLU(ReLU(BN2(y2)) + res) with `in` = res, bwd_y = y2, bnp_in = BatchNorm2's record --
 // and written to a_out for the backward pass: k_tcn_combine's pass over (y2, res, out) becomes one more read here.
-template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL = false, bool COMB = false>
+// NS (round 4): sequences per workgroup.  16 for T <= 25; 8 for T <= 50 -- the same 52 KB tile holds 8 sequences x 50 steps,
+// an MFMA column block is 8 sequences x 2 CONSECUTIVE output rows (lane i: sequence i & 7, row t0 + (i >> 3)), a tap that is
+// outside the window for one of the two rows only is zeroed per lane (the wave-uniform skip needs both outside).
+template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL = false, bool COMB = false, int NS = 16>
 __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
+  static_assert(NS == 16 || NS == 8, "16 sequences x 25 steps or 8 sequences x 50 steps");
+  constexpr int TPC = 16 / NS;         // output rows per MFMA column block
+  constexpr int TS = 256 / (NS * 8);   // time steps per staging pass of the 256 threads
   static_assert(!TAIL || (REVERSE && FUSE_BN && BWD2), "the tail epilogue extends the fused data-gradient variant");
   static_assert(!COMB || (!REVERSE && !BN_IN && !FUSE_BN && !BWD2), "the combine-on-load variant is a plain forward convolution");
   __shared__ float4 tile[(TCT_T + 1) * 16 * 8];  // + one row for the unconditional staging of an odd T
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
+  const int sl = i & (NS - 1), tsub = i / NS;  // the lane's sequence of the group and its row of the column block
   // wavefront -> (output-channel half ct, time parity): 32 of the 128 x 32 weights per lane.
   // A operand: k-step (tap j, q) multiplies input channel (q < 4 ? 0 : 16) + kk*4 + (q & 3) -- the 16-byte chunks
   // kk and kk + 4 of a staged row; lane (kk, i) holds the weight of that channel for output channel ct*16 + i.
@@ -379,7 +393,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
       wr[j][q] = REVERSE ? A.w[(cin * TC + col) * TK + j] : A.w[(col * TC + cin) * TK + j];
     }
   // staging: thread -> (time parity, sequence, 16-byte chunk); its four channels are fixed
-  const int half = threadIdx.x >> 7, sq = (threadIdx.x & 127) >> 3, ch = threadIdx.x & 7;
+  const int half = threadIdx.x / (NS * 8), sq = (threadIdx.x % (NS * 8)) >> 3, ch = threadIdx.x & 7;
   // epilogue constants: output channels ct*16 + kk*4 + r (FUSE_BN: the BatchNorm record waits in LDS)
   __shared__ float4 frec[FUSE_BN ? 4 * TC / 4 : 1];
   if (FUSE_BN) {
@@ -394,9 +408,9 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
   float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float n_rows = 0.0f;  // stat_records: rows this lane has summed; its sums are taken about the first one
   const int T = A.T;
-  const int64_t n_groups = A.Sp / 16;
+  const int64_t n_groups = A.Sp / NS;
   for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const int64_t s0 = grp * 16;
+    const int64_t s0 = grp * NS;
     // per-thread BatchNorm constants of the staging phase, (re)loaded per group: they are dead during the MFMA phase
     // (the fence keeps the compiler from hoisting them out of the loop into registers that phase needs)
     DOF_MEM_FENCE();
@@ -416,7 +430,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     // ---- stage the group's rows: two time steps per pass over the 256 threads, a batch of loads in flight.  The
     // loads are unconditional (steps past T re-read step T - 1 and land in LDS rows nobody reads): a predicate
     // around them would serialise the batch on vmcnt(0).
-    constexpr int NP = (TCT_T + 1) / 2, NBATCH = (BWD2 || COMB) ? 3 : 7;
+    constexpr int NP = (TCT_T * TPC + TS - 1) / TS, NBATCH = (BWD2 || COMB) ? 3 : 7;
     const bool srow = s0 + sq < A.S;
     // 32-bit element offsets (the launcher checks T * Sp * 32 < 2^31): SGPR base + one VGPR per address
     const uint32_t row_stride = (uint32_t)A.Sp * TC;
@@ -427,7 +441,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u) {
         if (n0 + u < NP) {
-          const int t = 2 * (n0 + u) + half;
+          const int t = TS * (n0 + u) + half;
           const uint32_t off = st_base + (uint32_t)(t < T ? t : T - 1) * row_stride;
           v[u] = *reinterpret_cast<const float4*>(A.in + off);
           if (BWD2 || COMB) yv[u] = *reinterpret_cast<const float4*>(A.bwd_y + off);
@@ -436,7 +450,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u) {
         if (n0 + u < NP) {
-          const int t = 2 * (n0 + u) + half;
+          const int t = TS * (n0 + u) + half;
           float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
           if (BN_IN) {
 #pragma unroll
@@ -456,7 +470,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
             }
           }
           const float4 w4 = make_float4(e[0], e[1], e[2], e[3]);
-          tile[tct_slot(t, sq, ch)] = w4;
+          tile[tct_slot<NS>(t, sq, ch)] = w4;
           if (srow && t < T) {
             const uint32_t off = st_base + (uint32_t)t * row_stride;
             if ((BN_IN || COMB) && !REVERSE && A.a_out) *reinterpret_cast<float4*>(A.a_out + off) = w4;
@@ -466,20 +480,21 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
       }
     }
     __syncthreads();
-    // ---- output rows t = tpar, tpar + 2, ... of channel half ct; the epilogue's global operand (the accumulation
-    // target or the BatchNorm input of FUSE_BN) is requested two rows ahead
-    const int64_t s = s0 + i;
-    const bool ok = s < A.S;
+    // ---- output rows t = tpar, tpar + 2, ... (NS = 8: row pairs 2 tpar, 2 tpar + 4, ...) of channel half ct; the
+    // epilogue's global operand (the accumulation target or the BatchNorm input of FUSE_BN) is requested two rows ahead
+    const int64_t s = s0 + sl;
+    const bool ok_s = s < A.S;
     constexpr bool PRE = REVERSE;  // the reverse variants read one epilogue operand (accumulate XOR FUSE_BN)
     const float* pre_src = FUSE_BN ? A.fuse_y : (const float*)A.out;
-    const bool pre_on = PRE && ok && (FUSE_BN || A.accumulate);
+    const bool pre_on = PRE && ok_s && (FUSE_BN || A.accumulate);
     const uint32_t ep_base = (uint32_t)s * TC + ct * 16 + kk * 4;
     const uint32_t pre_base = (uint32_t)(pre_on ? s : s0) * TC + ct * 16 + kk * 4;  // padded lanes read a valid row and ignore it
     float4 p0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), p1 = p0;
     float4 ts0 = p0, to0 = p0;  // TAIL: rows of tail_src / tail_out, requested one output row ahead (register budget)
+    const int tl0 = tpar * TPC + tsub;  // the lane's first output row; its next ones are 2 TPC apart
     if (PRE && (FUSE_BN || A.accumulate)) {
-      const uint32_t o0 = pre_base + (uint32_t)(tpar < T ? tpar : T - 1) * row_stride;
-      const uint32_t o1 = pre_base + (uint32_t)(tpar + 2 < T ? tpar + 2 : T - 1) * row_stride;
+      const uint32_t o0 = pre_base + (uint32_t)(tl0 < T ? tl0 : T - 1) * row_stride;
+      const uint32_t o1 = pre_base + (uint32_t)(tl0 + 2 * TPC < T ? tl0 + 2 * TPC : T - 1) * row_stride;
       p0 = *reinterpret_cast<const float4*>(pre_src + o0);
       p1 = *reinterpret_cast<const float4*>(pre_src + o1);
       if (TAIL) {
@@ -487,36 +502,46 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
         to0 = *reinterpret_cast<const float4*>(A.tail_out + o0);
       }
     }
-    for (int t = tpar; t < T; t += 2) {
+    for (int t0 = tpar * TPC; t0 < T; t0 += 2 * TPC) {
+      const int t = t0 + tsub;
+      const bool ok = ok_s && (TPC == 1 || t < T);
       const uint32_t off = ep_base + (uint32_t)t * row_stride;
       const float4 pc = p0, tsc = ts0, toc = to0;
       if (PRE && (FUSE_BN || A.accumulate)) {
-        const uint32_t o2 = pre_base + (uint32_t)(t + 4 < T ? t + 4 : T - 1) * row_stride;
+        const uint32_t o2 = pre_base + (uint32_t)(t + 4 * TPC < T ? t + 4 * TPC : T - 1) * row_stride;
         p0 = p1;
         p1 = *reinterpret_cast<const float4*>(pre_src + o2);
         if (TAIL) {
-          const uint32_t o1n = pre_base + (uint32_t)(t + 2 < T ? t + 2 : T - 1) * row_stride;
+          const uint32_t o1n = pre_base + (uint32_t)(t + 2 * TPC < T ? t + 2 * TPC : T - 1) * row_stride;
           ts0 = *reinterpret_cast<const float4*>(A.tail_src + o1n);
           to0 = *reinterpret_cast<const float4*>(A.tail_out + o1n);
         }
       }
       dof_f32x4 acc = {bias[0], bias[1], bias[2], bias[3]};
-      // all valid taps' rows are requested from LDS before the first MFMA (validity is wave-uniform)
+      // all valid taps' rows are requested from LDS before the first MFMA (validity is wave-uniform; NS = 8: of either row)
       float4 lo[TK], hi[TK];
-      bool tap[TK];
+      bool tap[TK], mine[TK];
 #pragma unroll
       for (int j = 0; j < TK; ++j) {
-        const int tt = REVERSE ? t + (TK - 1 - j) * A.dil : t - (TK - 1 - j) * A.dil;
-        tap[j] = tt >= 0 && tt < T;
+        const int sh = REVERSE ? (TK - 1 - j) * A.dil : -(TK - 1 - j) * A.dil;
+        const int tu = t0 + sh;  // the tap's row for the column block's first output row
+        tap[j] = (tu >= 0 && tu < T) || (TPC == 2 && tu + 1 >= 0 && tu + 1 < T);
+        const int tt = t + sh;
+        mine[j] = TPC == 1 || (tt >= 0 && tt < T);
         if (tap[j]) {
-          lo[j] = tile[tct_slot(tt, i, kk)];
-          hi[j] = tile[tct_slot(tt, i, kk + 4)];
+          const int tc = TPC == 1 ? tt : (tt < 0 ? 0 : tt < T ? tt : T - 1);
+          lo[j] = tile[tct_slot<NS>(tc, sl, kk)];
+          hi[j] = tile[tct_slot<NS>(tc, sl, kk + 4)];
         }
       }
 #pragma unroll
       for (int j = 0; j < TK; ++j) {
         if (tap[j]) {
-          const float a[8] = {lo[j].x, lo[j].y, lo[j].z, lo[j].w, hi[j].x, hi[j].y, hi[j].z, hi[j].w};
+          float a[8] = {lo[j].x, lo[j].y, lo[j].z, lo[j].w, hi[j].x, hi[j].y, hi[j].z, hi[j].w};
+          if (TPC == 2) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = mine[j] ? a[q] : 0.0f;
+          }
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][q], a[q], acc, 0, 0, 0);
         }
@@ -1280,12 +1305,29 @@ int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float*
   return dof_check_launch("k_tcn_in_conv");
 }
 
-// Workgroups of the time-resident convolution: one per 16 sequences, at most three resident per CU (50 KB of LDS each)
-static bool tct_fits(int T, int64_t Sp) { return T <= TCT_T && (int64_t)T * Sp * TC < ((int64_t)1 << 31); }
-static unsigned tct_blocks(int64_t Sp) {
-  const int64_t groups = Sp / 16;
+// Workgroups of the time-resident convolution: one per 16 sequences (T <= 25) or per 8 sequences (T <= 50, round 4), at most
+// three resident per CU (52 KB of LDS each).  DOF_TCN_RESIDENT_MAX_T=25 restores round 3's limit (A/B measurements: windows
+// of 26 .. 50 steps then take k_tcn_conv's four fetches per input row and none of the folds).
+static int tct_max_t() {
+  static const int v = [] {
+    const char* e = getenv("DOF_TCN_RESIDENT_MAX_T");
+    const int m = e ? atoi(e) : 2 * TCT_T;
+    return m < 2 * TCT_T ? (m < TCT_T ? 0 : TCT_T) : 2 * TCT_T;
+  }();
+  return v;
+}
+static bool tct_fits(int T, int64_t Sp) { return T <= tct_max_t() && (int64_t)T * Sp * TC < ((int64_t)1 << 31); }
+static int tct_ns(int T) { return T <= TCT_T ? 16 : 8; }
+static unsigned tct_blocks(int T, int64_t Sp) {
+  const int64_t groups = Sp / tct_ns(T);
   return (unsigned)(groups < 768 ? groups : 768);
 }
+// k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB> at the group size T asks for
+#define TCT_LAUNCH(R, BN, FUSE, BWD2, TAIL, COMB)                                                         \
+  do {                                                                                                    \
+    if (tct_ns(A.T) == 16) DOF_LAUNCH((k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB, 16>), (nbt), (256), st, A); \
+    else DOF_LAUNCH((k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB, 8>), (nbt), (256), st, A);                \
+  } while (0)
 // One-pass (shifted) BatchNorm statistics (bn_shift_ok) of the time-resident convolutions are OPT-IN since round 3
 // (DOF_TCN_ONEPASS=1): measured elementwise against a reference golden whose running means equal the batch means
 // (tests/golden/vade_tcn14_onepass.npz, every channel on the one-pass form) the gradients of 107 of 200 tensors leave the
@@ -1329,7 +1371,7 @@ int dof_launch_bn_bwd_sum_fin(const float* partial, int64_t nblk, float* sums, f
 }
 int64_t dof_tcn_bn_bwd1_blocks(int T, int64_t S) { return (int64_t)dof_cdiv(S, 256) * T; }
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
-  return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(Sp) : dof_tcn_conv_waves(T, Sp);
+  return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(T, Sp) : dof_tcn_conv_waves(T, Sp);
 }
 
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
@@ -1349,20 +1391,20 @@ int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const floa
   }
   A.T = T; A.dil = dil; A.accumulate = accumulate; A.S = S; A.Sp = Sp;
   if (dof_tcn_conv32_resident(T, Sp)) {
-    const unsigned nbt = tct_blocks(Sp);
+    const unsigned nbt = tct_blocks(T, Sp);
     if (reverse && bwd_y) {
-      DOF_LAUNCH((k_tcn_conv_t<true, false, false, true>), (nbt), (256), st, A);
+      TCT_LAUNCH(true, false, false, true, false, false);
     } else if (reverse) {
-      DOF_LAUNCH((k_tcn_conv_t<true, false, false, false>), (nbt), (256), st, A);
+      TCT_LAUNCH(true, false, false, false, false, false);
     } else if (bnp_in) {
-      DOF_LAUNCH((k_tcn_conv_t<false, true, false, false>), (nbt), (256), st, A);
+      TCT_LAUNCH(false, true, false, false, false, false);
     } else {
-      DOF_LAUNCH((k_tcn_conv_t<false, false, false, false>), (nbt), (256), st, A);
+      TCT_LAUNCH(false, false, false, false, false, false);
     }
     return dof_check_launch("k_tcn_conv_t");
   }
   if (bwd_y) {
-    dof_set_error("k_tcn_conv: the fused BatchNorm-backward pass needs the time-resident kernel (T <= %d)", TCT_T);
+    dof_set_error("k_tcn_conv: the fused BatchNorm-backward pass needs the time-resident kernel (T <= %d)", tct_max_t());
     return DOF_ERR_UNSUPPORTED;
   }
   const unsigned nb = (unsigned)(dof_tcn_conv_waves(T, Sp) / 4);
@@ -1391,17 +1433,17 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
   A.stat_shift = nullptr;
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
   if (dof_tcn_conv32_resident(T, Sp)) {
-    const unsigned nbt = tct_blocks(Sp);
+    const unsigned nbt = tct_blocks(T, Sp);
     if (bwd_y) {
-      DOF_LAUNCH((k_tcn_conv_t<true, false, true, true>), (nbt), (256), st, A);
+      TCT_LAUNCH(true, false, true, true, false, false);
     } else {
-      DOF_LAUNCH((k_tcn_conv_t<true, false, true, false>), (nbt), (256), st, A);
+      TCT_LAUNCH(true, false, true, false, false, false);
     }
     if (int rc = dof_check_launch("k_tcn_conv_t_bwd_bn")) return rc;
     return sums ? dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st) : DOF_OK;
   }
   if (bwd_y) {
-    dof_set_error("k_tcn_conv_bwd_bn: the fused BatchNorm-backward pass needs the time-resident kernel (T <= %d)", TCT_T);
+    dof_set_error("k_tcn_conv_bwd_bn: the fused BatchNorm-backward pass needs the time-resident kernel (T <= %d)", tct_max_t());
     return DOF_ERR_UNSUPPORTED;
   }
   const int64_t waves = dof_tcn_conv_waves(T, Sp);
@@ -1422,7 +1464,7 @@ int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp
                              const float* bias, float* out, float* partial, int T, int dil, int64_t S, int64_t Sp,
                              hipStream_t st, const float* stat_shift, int stat_records) {
   if (!dof_tcn_conv32_resident(T, Sp)) {
-    dof_set_error("k_tcn_conv_comb: needs the time-resident kernel (T <= %d)", TCT_T);
+    dof_set_error("k_tcn_conv_comb: needs the time-resident kernel (T <= %d)", tct_max_t());
     return DOF_ERR_UNSUPPORTED;
   }
   TcnConvArgs A;
@@ -1433,7 +1475,8 @@ int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp
   A.stat_shift = stat_shift;
   A.stat_records = stat_records ? 1 : 0;
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
-  DOF_LAUNCH((k_tcn_conv_t<false, false, false, false, false, true>), (tct_blocks(Sp)), (256), st, A);
+  const unsigned nbt = tct_blocks(T, Sp);
+  TCT_LAUNCH(false, false, false, false, false, true);
   return dof_check_launch("k_tcn_conv_t_comb");
 }
 
@@ -1452,7 +1495,7 @@ int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y
                              const float* tail_skip, const float* tail_dfeat, const float* y2, const float* bnp2, float* g_out,
                              float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st) {
   if (!dof_tcn_conv32_resident(T, Sp) || !bwd_y) {
-    dof_set_error("k_tcn_conv_tail: needs the time-resident kernel (T <= %d) and a lazy BatchNorm1 gradient", TCT_T);
+    dof_set_error("k_tcn_conv_tail: needs the time-resident kernel (T <= %d) and a lazy BatchNorm1 gradient", tct_max_t());
     return DOF_ERR_UNSUPPORTED;
   }
   TcnConvArgs A;
@@ -1463,8 +1506,8 @@ int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y
   A.stat_shift = nullptr;
   A.tail_src = tail_src; A.tail_out = tail_out; A.tail_gres = tail_gres; A.tail_skip = tail_skip; A.tail_dfeat = tail_dfeat;
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
-  const unsigned nbt = tct_blocks(Sp);
-  DOF_LAUNCH((k_tcn_conv_t<true, false, true, true, true>), (nbt), (256), st, A);
+  const unsigned nbt = tct_blocks(T, Sp);
+  TCT_LAUNCH(true, false, true, true, true, false);
   if (int rc = dof_check_launch("k_tcn_conv_t_tail")) return rc;
   return sums ? dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st) : DOF_OK;
 }
@@ -1675,9 +1718,12 @@ __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __re
   // zero once: the K padding of dy (k >= 4 T) and the borders of x are never written again
   for (int i = tid; i < 3 * 32 * WB_DSTR / 2; i += 256) reinterpret_cast<uint32_t*>(&sd16[0][0][0])[i] = 0u;
   for (int i = tid; i < 3 * 32 * WB_XSTR / 2; i += 256) reinterpret_cast<uint32_t*>(&sx16[0][0][0])[i] = 0u;
-  // staging: thread = (time step, 4-channel group); it holds that row piece of the chunk's 4 sequences
+  // staging: thread = (time step, 4-channel group); it holds that row piece of the chunk's 4 sequences.  Windows of 26 .. 50
+  // steps (round 4): chunks of nq = 2 sequences, thread = (PAIR of time steps, channel group) -- its four rows are (t, s) =
+  // (2 st_t + (q >> 1), q & 1), so the K index nq t + s = 4 st_t + q and everything behind the loads is the same code.
   const int st_t = tid >> 3, cg = (tid & 7) * 4;
-  const bool stager = st_t < T;
+  const int nq = T > DOF_TCN_WGRAD_MAX_T ? 2 : 4, tstep = 4 / nq;
+  const bool stager = st_t * tstep < T;
   float xs[4] = {1.0f, 1.0f, 1.0f, 1.0f}, xh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float ka[4], kb[4], kc[4], bm[4];
   if (D.in_bnp) {
@@ -1699,25 +1745,31 @@ __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __re
   }
   const int tap = (wave + (int)blockIdx.x) & 3;  // rotated per workgroup: the taps' K-step counts differ (skipped steps)
   const int shift = -(3 - tap) * D.dil;
-  const int KS = (4 * T + 15) / 16, ks0 = (-shift) / 4;
+  const int KS = (nq * T + 15) / 16, ks0 = (-shift) * nq / 16;
   dof_f32x16 acc;
 #pragma unroll
   for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
   float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  const int64_t chunks = Sp / 4;
+  const int64_t chunks = Sp / nq;
   float4 rx[4], rd[4], ry[4];
+  // row q of the thread: nq = 4: (st_t, sequence q), consecutive rows; nq = 2: (2 st_t + (q >> 1), sequence q & 1) -- a second
+  // time step past an odd T re-reads step T - 1 and is zeroed below
+  const bool t1 = nq == 4 || 2 * st_t + 1 < T;
+  const int64_t tstride = (nq == 2 && t1) ? Sp * 32 : 0;  // q = 2, 3 of a pair: the same two sequences one time step on
   auto fetch = [&](int64_t ch) {  // unconditional loads (clamped chunk): a predicate around them would serialise the batch
     const int64_t chc = ch < chunks ? ch : chunks - 1;
-    const int64_t base = ((int64_t)(stager ? st_t : 0) * Sp + chc * 4) * 32 + cg;
+    const int64_t base = ((int64_t)(stager ? st_t * tstep : 0) * Sp + chc * nq) * 32 + cg;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      rx[q] = *reinterpret_cast<const float4*>(D.in + base + q * 32);
-      rd[q] = *reinterpret_cast<const float4*>(D.dy + base + q * 32);
-      if (D.dy_y) ry[q] = *reinterpret_cast<const float4*>(D.dy_y + base + q * 32);
+      const int64_t o = base + (nq == 4 ? q : (q & 1)) * 32 + (q >= 2 ? tstride : 0);
+      rx[q] = *reinterpret_cast<const float4*>(D.in + o);
+      rd[q] = *reinterpret_cast<const float4*>(D.dy + o);
+      if (D.dy_y) ry[q] = *reinterpret_cast<const float4*>(D.dy_y + o);
     }
   };
   fetch(blockIdx.x);
   const int am = lane & 31, kg = lane >> 5;
+  const bool b4 = ((nq * shift) & 3) != 0;
   for (int64_t ch = blockIdx.x; ch < chunks; ch += D.nblk) {
     __syncthreads();  // the previous chunk's MFMA phase (and the zero fill) is done with the planes
     if (stager) {
@@ -1726,11 +1778,12 @@ __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __re
       for (int q = 0; q < 4; ++q) {
         const float vx[4] = {rx[q].x, rx[q].y, rx[q].z, rx[q].w}, vd[4] = {rd[q].x, rd[q].y, rd[q].z, rd[q].w};
         const float vy[4] = {ry[q].x, ry[q].y, ry[q].z, ry[q].w};
-        const bool valid = ch * 4 + q < D.S;
+        const bool row = q < 2 || t1;  // nq = 2: the pair's second step exists
+        const bool valid = row && ch * nq + (nq == 4 ? q : (q & 1)) < D.S;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          ex[q][k] = D.in_bnp ? fmaxf(fmaf(vx[k], xs[k], xh[k]), 0.0f) : vx[k];
-          ed[q][k] = D.dy_y ? (valid ? fmaf(ka[k], vd[k], fmaf(kb[k], vy[k] - bm[k], kc[k])) : 0.0f) : vd[k];
+          ex[q][k] = !row ? 0.0f : D.in_bnp ? fmaxf(fmaf(vx[k], xs[k], xh[k]), 0.0f) : vx[k];
+          ed[q][k] = D.dy_y ? (valid ? fmaf(ka[k], vd[k], fmaf(kb[k], vy[k] - bm[k], kc[k])) : 0.0f) : (row ? vd[k] : 0.0f);
           rs[k] += ed[q][k];
         }
       }
@@ -1756,11 +1809,15 @@ __global__ void __launch_bounds__(256, 3) k_tcn_wgrad_b3(const DofTcnWgrad* __re
     fetch(ch + D.nblk);  // lands during the MFMA phase
     __syncthreads();
     for (int ks = ks0; ks < KS; ++ks) {
-      const int ka0 = ks * 16 + kg * 8, kb0 = WB_XP + ka0 + 4 * shift;
+      const int ka0 = ks * 16 + kg * 8, kb0 = WB_XP + ka0 + nq * shift;
       const dof_bf16x8 ah = dof_ld_bf16x8(&sd16[0][am][ka0]), amid = dof_ld_bf16x8(&sd16[1][am][ka0]),
                        al = dof_ld_bf16x8(&sd16[2][am][ka0]);
-      const dof_bf16x8 bh = dof_ld_bf16x8(&sx16[0][am][kb0]), bmid = dof_ld_bf16x8(&sx16[1][am][kb0]),
-                       bl = dof_ld_bf16x8(&sx16[2][am][kb0]);
+      dof_bf16x8 bh, bmid, bl;
+      if (b4) {  // 2-sequence chunks at an odd time shift: the B rows start on a 4-byte boundary only
+        bh = dof_ld_bf16x8_a4(&sx16[0][am][kb0]); bmid = dof_ld_bf16x8_a4(&sx16[1][am][kb0]); bl = dof_ld_bf16x8_a4(&sx16[2][am][kb0]);
+      } else {
+        bh = dof_ld_bf16x8(&sx16[0][am][kb0]); bmid = dof_ld_bf16x8(&sx16[1][am][kb0]); bl = dof_ld_bf16x8(&sx16[2][am][kb0]);
+      }
       acc = DOF_MFMA_32x32x16_BF16(ah, bl, acc);
       acc = DOF_MFMA_32x32x16_BF16(al, bh, acc);
       acc = DOF_MFMA_32x32x16_BF16(amid, bmid, acc);
@@ -1919,6 +1976,10 @@ static int dof_tcn_wgrad_fp32() {
   return v;
 }
 
+int dof_tcn_wgrad_max_t(void) {
+  if (dof_tcn_wgrad_fp32()) return DOF_TCN_WGRAD_MAX_T;
+  return tct_max_t() < DOF_TCN_WGRAD_B3_MAX_T ? DOF_TCN_WGRAD_MAX_T : DOF_TCN_WGRAD_B3_MAX_T;
+}
 int dof_launch_tcn_wgrad(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st) {
   if (n <= 0) return DOF_OK;
   if (dof_tcn_wgrad_fp32()) DOF_LAUNCH((k_tcn_wgrad<4>), ((unsigned)max_nblk, (unsigned)n), (256), st, descs_dev, partials);

@@ -143,7 +143,9 @@ struct DofTcnWgrad {
   int cin;
   const float* dy2;
 };
-#define DOF_TCN_WGRAD_MAX_T 25
+#define DOF_TCN_WGRAD_MAX_T 25     // k_tcn_wgrad (fp32 pipe) and the 4-sequence chunks of k_tcn_wgrad_b3
+#define DOF_TCN_WGRAD_B3_MAX_T 50  // k_tcn_wgrad_b3 with 2-sequence chunks
+int dof_tcn_wgrad_max_t(void);     // the longest window the LDS-staged weight-gradient kernel in use takes
 int dof_launch_tcn_wgrad(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st);
 int dof_launch_tcn_wgrad_in(const DofTcnWgrad* descs_dev, int n, int max_nblk, float* partials, hipStream_t st);
 int dof_launch_head_rms(const float* flat, float* hn, float* rinv, int J, int64_t B, int64_t Bp, hipStream_t st);

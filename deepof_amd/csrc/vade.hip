@@ -542,7 +542,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     // lazy weight-gradient operands (time-resident convolutions + the LDS-staged weight-gradient kernel): pass 2 of the
     // BatchNorm backward and conv2's input activation are recomputed where they are read, so neither the normalised
     // gradients nor the activated tensors a1 are ever written (8 x [T][Sp][32] per stream less)
-    t.lazy = (dof_tcn_conv32_resident(T, Sp) && T <= DOF_TCN_WGRAD_MAX_T) ? 1 : 0;
+    t.lazy = (dof_tcn_conv32_resident(T, Sp) && T <= dof_tcn_wgrad_max_t()) ? 1 : 0;
     {  // DOF_TCN_WGRAD_IN=0: block 0 through the generic reduction (A/B measurements)
       const char* e = getenv("DOF_TCN_WGRAD_IN");
       t.first_staged = (t.lazy && (p->sw[s].F == 3 || p->sw[s].F == 1) && !(e && e[0] == '0')) ? 1 : 0;
@@ -997,7 +997,7 @@ void build_tcn_jobs(DofVadePlan* p) {
         bool bias_done = false;
         // 32 -> 32 convolutions: the partial tiles of the two jobs come from k_tcn_wgrad (LDS-staged operands)
         const bool first = cin < C && d == 1 && t.first_staged;  // block 0: one job of four tap tiles, from k_tcn_wgrad_in
-        const bool staged = (cin == C && T <= DOF_TCN_WGRAD_MAX_T) || first;
+        const bool staged = (cin == C && T <= dof_tcn_wgrad_max_t()) || first;
         // (first: 128 workgroups of 8 waves per stream = the 2 waves per SIMD its registers allow, both streams resident)
         const int ext = first ? (int)(Sp / 64 < 1 ? 1 : Sp / 64 < 128 ? Sp / 64 : 128) : staged ? (int)(Sp / 8 < 448 ? Sp / 8 : 448) : 0;
         if (staged) {

@@ -426,10 +426,12 @@ TCN_NOISE_BAR = 10.0
 TCN_B6_RTOL = 5e-3
 
 
-def run_vade_tcn_check(lib, device, golden_dir):
+def run_vade_tcn_check(lib, device, golden_dir, fixture="vade_tcn14.npz"):
     """VaDE with the TCN encoder and decoder (R12) vs the reference golden: eval forward on the running statistics,
-    then (from the same initial state each) train-mode loss terms, all gradients and the refreshed BatchNorm buffers."""
-    d = load_golden(golden_dir, "vade_tcn14.npz")
+    then (from the same initial state each) train-mode loss terms, all gradients and the refreshed BatchNorm buffers.
+    fixture="vade_tcn14w50.npz" (round 4, make_golden_r04.py w50): the same model at window 50 -- the 8-sequence form of
+    the time-resident convolutions and the 2-sequence weight-gradient chunks."""
+    d = load_golden(golden_dir, fixture)
     x, a = torch.from_numpy(d["x"]).to(device), torch.from_numpy(d["a"]).to(device)
     B, T, N, _ = x.shape
     K, L = d["sd::latent_space.gmm_means"].shape

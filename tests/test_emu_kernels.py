@@ -75,9 +75,10 @@ def test_contrastive_tcn_emu(golden_dir, fixture):
     run_contrastive_tcn_check(emu_lib(), "cpu", golden_dir, fixture)
 
 
-def test_vade_tcn_emu(golden_dir):
+@pytest.mark.parametrize("fixture", ["vade_tcn14.npz", "vade_tcn14w50.npz"])
+def test_vade_tcn_emu(golden_dir, fixture):
     from parity_common import run_vade_tcn_check
-    run_vade_tcn_check(emu_lib(), "cpu", golden_dir)
+    run_vade_tcn_check(emu_lib(), "cpu", golden_dir, fixture)
 
 
 def test_vqvae_tcn_emu(golden_dir):

@@ -483,9 +483,11 @@ def test_contrastive_tcn_full_size_c4(hip):
     np.testing.assert_allclose(z_eval[:64].cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-3)
 
 
-def test_vade_tcn_parity_gpu(hip, golden_dir):
+@pytest.mark.parametrize("fixture", ["vade_tcn14.npz", "vade_tcn14w50.npz"])
+def test_vade_tcn_parity_gpu(hip, golden_dir, fixture):
+    """vade_tcn14w50 (round 4): window 50 on the 8-sequence time-resident convolutions / 2-sequence weight-gradient chunks."""
     from parity_common import run_vade_tcn_check
-    run_vade_tcn_check(hip, "cuda", golden_dir)
+    run_vade_tcn_check(hip, "cuda", golden_dir, fixture)
 
 
 def test_vqvae_tcn_parity_gpu(hip, golden_dir):

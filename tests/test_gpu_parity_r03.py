@@ -259,13 +259,16 @@ def test_gru16_matrix_pipe_kernels_gpu():
 
 
 @pytest.mark.parametrize("switch", ["DOF_TCN_WGRAD_FP32=1", "DOF_TCN_TAIL_FOLD=0", "DOF_TCN_COMBINE_FOLD=0",
-                                    "DOF_TCN_STAT_RECORDS=0", "DOF_TCN_ONEPASS=1", "DOF_TCN_WGRAD_IN=0"])
+                                    "DOF_TCN_STAT_RECORDS=0", "DOF_TCN_ONEPASS=1", "DOF_TCN_WGRAD_IN=0",
+                                    "DOF_TCN_RESIDENT_MAX_T=25"])
 def test_tcn_kernel_switches_gpu(switch):
     """The round-3 TCN kernels (bf16-pipe weight gradients, block-tail backward / forward folded into the neighbouring
     convolutions, batch statistics as mergeable records, the first block's direct-load weight gradients) and the kernels they replace -- incl. the centred second pass and
     round 2's shifted one-pass sums -- meet the SAME reference check: a B = 64 VaDE-TCN golden with the explicit ReLU-flip
     attribution (the statistics switches on the fixture whose running means equal the batch means, where every channel takes
-    the shifted one-pass form), run in a child process per switch (the switches are read once per process)."""
+    the shifted one-pass form), run in a child process per switch (the switches are read once per process).
+    DOF_TCN_RESIDENT_MAX_T=25 (round 4): the window-50 golden on round 3's path for windows of 26 .. 50 steps (k_tcn_conv's four
+    fetches per row, k_outer weight gradients) -- the default path's check on it is test_vade_tcn_parity_gpu[vade_tcn14w50]."""
     import json
     import subprocess
     import sys
@@ -275,6 +278,8 @@ def test_tcn_kernel_switches_gpu(switch):
     env[k] = v
     if k in ("DOF_TCN_STAT_RECORDS", "DOF_TCN_ONEPASS"):
         env["DOF_PROBE_FIXTURE"] = "vade_tcn14_onepass.npz"
+    if k == "DOF_TCN_RESIDENT_MAX_T":
+        env["DOF_PROBE_FIXTURE"] = "vade_tcn14w50.npz"
     out = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("PROBE ")][-1]

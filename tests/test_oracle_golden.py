@@ -353,12 +353,13 @@ def test_tcn_contrastive_matches_reference(golden_dir, fixture):
     assert n == 148
 
 
-def test_vade_tcn_matches_reference(golden_dir):
+@pytest.mark.parametrize("fixture", ["vade_tcn14.npz", "vade_tcn14w50.npz"])
+def test_vade_tcn_matches_reference(golden_dir, fixture):
     """VaDE with the TCN encoder AND decoder (R12): eval forward on running statistics (bit-stable), then the
     train-mode step for the pre-training and the main (+teacher) objective.  BatchNorm over 6 windows amplifies
     fp32 rounding to ~1e-4 relative in the gradients, so the golden holds the reference evaluated in float64 plus
     the reference's own fp32 deviation from it per tensor ("noise"); the oracle must sit within a few noise units."""
-    d = _load(golden_dir, "vade_tcn14.npz")
+    d = _load(golden_dir, fixture)
     x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
     K, L = d["sd::latent_space.gmm_means"].shape
     P0 = _params(d)

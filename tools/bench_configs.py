@@ -12,6 +12,7 @@ clip + Adam) on device-resident synthetic data, fp32, eager launches on the curr
   infer  N1: gather + eval-mode encoder forward (embeddings + soft counts) of the C2 model, batch 4096
   c2tcn  the headline C2 workload (VaDE, 14 body parts, window 25, k=10, batch 1024) with the TCN encoder/decoder
   c2tfm  the same workload with the transformer encoder/decoder (dropout from the on-device counter hash)
+  c5tcn  C5's shape (2 animals, window 50, k=25, batch 4096) with the TCN encoder/decoder
 """
 import argparse
 import json
@@ -224,6 +225,10 @@ def main():
             B = 1024
             sec, loss, N, E = run_vade_like("vade_tcn", [""], 25, 10, B, args.steps, args.warmup)
             desc = "C2 with the TCN family: VaDE TCN encoder/decoder, N=14,E=14, window=25, k=10, latent=8, batch=1024, main phase"
+        elif name == "c5tcn":
+            B = 4096
+            sec, loss, N, E = run_vade_like("vade_tcn", ["B", "W"], 50, 25, B, args.steps, args.warmup)
+            desc = "C5 with the TCN family: VaDE TCN encoder/decoder, 2 animals N=28,E=32, window=50, k=25, latent=8, batch=4096, main phase"
         elif name == "c2tfm":
             B = 1024
             sec, loss, N, E = run_vade_like("vade_tfm", [""], 25, 10, B, args.steps, args.warmup)
