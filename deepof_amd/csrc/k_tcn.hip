@@ -1449,7 +1449,7 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
   const int64_t waves = dof_tcn_conv_waves(T, Sp);
   DOF_LAUNCH((k_tcn_conv<true, false, true>), ((unsigned)(waves / 4)), (256), st, A);
   if (int rc = dof_check_launch("k_tcn_conv_bwd_bn")) return rc;
-  return dof_launch_sum_partials(partial, waves, 2 * TC, sums, 0, st);
+  return sums ? dof_launch_sum_partials(partial, waves, 2 * TC, sums, 0, st) : DOF_OK;  // null: the caller's k_bn_bwd_sum_fin reduces them
 }
 
 // forward conv1 of block b + 1 with block b's tail (out = ReLU(ReLU(BN2(y2)) + res), written to out_blk) computed while staging

@@ -1093,7 +1093,9 @@ def run_vade_tcn_vs_oracle(lib, device, L=4, K=3, B=6, T=10, seed=3):
         # the terms that also make up its weight's gradient, so the floor scales with those (2 fp32 ulps), not with |t|
         sib = g64.get(name[:-len("bias")] + "weight") if name.endswith(".bias") else None
         floor = 2.5e-7 * float(sib.abs().max()) if sib is not None else 0.0
-        assert err <= 10.0 * noise + 5e-6 * np.abs(t).max() + 1e-6 + floor, (name, err, noise)
+        # noise is ONE fp32 evaluation's deviation on the host running the test (it moves with the host's BLAS): the bar is
+        # run_vade_tcn_check's -- 10 noise units or TCN_B6_RTOL of the tensor scale, whichever is larger
+        assert err <= max(10.0 * noise, TCN_B6_RTOL * np.abs(t).max()) + 5e-6 * np.abs(t).max() + 1e-6 + floor, (name, err, noise)
         n += 1
     assert n >= 200
 

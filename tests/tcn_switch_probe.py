@@ -11,8 +11,9 @@ from deepof_amd._lib import load_hip_library  # noqa: E402
 import parity_common as PC  # noqa: E402
 
 fixture = os.environ.get("DOF_PROBE_FIXTURE", "vade_tcn14_b64.npz")
-if fixture == "vade_tcn14w50.npz":  # the window-50 golden keeps vade_tcn14.npz's layout and fp64-anchored check
-    PC.run_vade_tcn_check(load_hip_library(), "cuda", os.path.join(HERE, "golden"), fixture)
+if fixture == "oracle_t29_t30":  # windows of 26 .. 50 steps against the oracle on tie-free draws (run_vade_tcn_vs_oracle)
+    for T in (29, 30):
+        PC.run_vade_tcn_vs_oracle(load_hip_library(), "cuda", L=8, T=T)
     print("PROBE " + json.dumps({"ok": True}))
     sys.exit(0)
 res = PC.run_vade_tcn_b64_check(load_hip_library(), "cuda", os.path.join(HERE, "golden"), fixture=fixture,

@@ -91,6 +91,12 @@ def test_turtle_teacher_emu(golden_dir):
     run_turtle_check(emu_lib(), "cpu", golden_dir)
 
 
+def test_vade_tcn_window_29_emu():
+    """An odd window above 25: the 8-sequence time-resident convolutions and the 2-sequence weight-gradient chunks (round 4)."""
+    from parity_common import run_vade_tcn_vs_oracle
+    run_vade_tcn_vs_oracle(emu_lib(), "cpu", L=8, T=29)
+
+
 def test_distillation_head_emu(golden_dir):
     from parity_common import run_distill_head_check
     run_distill_head_check(emu_lib(), "cpu", golden_dir)

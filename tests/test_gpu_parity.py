@@ -587,6 +587,14 @@ def test_vade_tcn_padded_decoder_input_gpu(hip, L):
     run_vade_tcn_vs_oracle(hip, "cuda", L=L)
 
 
+@pytest.mark.parametrize("T", [29, 30])
+def test_vade_tcn_windows_over_25_gpu(hip, T):
+    """Windows of 26 .. 50 steps (round 4: 8 sequences per workgroup in k_tcn_conv_t, 2-sequence chunks in k_tcn_wgrad_b3) against
+    the oracle on a tie-free draw; 29: an odd window (the second row of the last MFMA column block / time-step pair is masked)."""
+    from parity_common import run_vade_tcn_vs_oracle
+    run_vade_tcn_vs_oracle(hip, "cuda", L=8, T=T)
+
+
 def test_full_size_c5_gradients_equal_chunked_small_launches(hip):
     """The B = 4096 launch geometry of C5 (245,760 sequences per stream: the matrix-pipe GRU kernels, 16 windows per
     gather workgroup, 256-workgroup reductions) against the SMALL-launch geometry the reference goldens pin

@@ -267,8 +267,10 @@ def test_tcn_kernel_switches_gpu(switch):
     round 2's shifted one-pass sums -- meet the SAME reference check: a B = 64 VaDE-TCN golden with the explicit ReLU-flip
     attribution (the statistics switches on the fixture whose running means equal the batch means, where every channel takes
     the shifted one-pass form), run in a child process per switch (the switches are read once per process).
-    DOF_TCN_RESIDENT_MAX_T=25 (round 4): the window-50 golden on round 3's path for windows of 26 .. 50 steps (k_tcn_conv's four
-    fetches per row, k_outer weight gradients) -- the default path's check on it is test_vade_tcn_parity_gpu[vade_tcn14w50]."""
+    DOF_TCN_RESIDENT_MAX_T=25 (round 4): windows of 29 and 30 steps on the path windows > 50 take (k_tcn_conv's four fetches per
+    row, k_outer weight gradients) against the oracle on tie-free draws -- the default path's checks at these sizes are
+    test_vade_tcn_windows_over_25_gpu and test_vade_tcn_parity_gpu[vade_tcn14w50].  (Round 3 shipped this path with a null
+    pointer in dof_launch_tcn_conv_bwd_bn: nothing ran a VaDE-TCN window above 25.)"""
     import json
     import subprocess
     import sys
@@ -279,7 +281,7 @@ def test_tcn_kernel_switches_gpu(switch):
     if k in ("DOF_TCN_STAT_RECORDS", "DOF_TCN_ONEPASS"):
         env["DOF_PROBE_FIXTURE"] = "vade_tcn14_onepass.npz"
     if k == "DOF_TCN_RESIDENT_MAX_T":
-        env["DOF_PROBE_FIXTURE"] = "vade_tcn14w50.npz"
+        env["DOF_PROBE_FIXTURE"] = "oracle_t29_t30"
     out = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("PROBE ")][-1]

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/w50
 mkdir -p $OUT
 cd $ROOT
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_r03.py -m gpu -q -x -k "tcn" > $OUT/pytest.txt 2>&1
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_r03.py -m gpu -q -k "tcn" > $OUT/pytest.txt 2>&1
 tail -3 $OUT/pytest.txt
 timeout 600 python tools/bench_configs.py --only c5tcn --steps 6 --warmup 14 > $OUT/c5tcn_new.json 2> $OUT/c5tcn_new.err
 DOF_TCN_RESIDENT_MAX_T=25 timeout 600 python tools/bench_configs.py --only c5tcn --steps 6 --warmup 14 > $OUT/c5tcn_r03path.json 2> $OUT/c5tcn_r03path.err
