@@ -792,12 +792,12 @@ def _oracle_truth(fn, P, *tensors):
     return r32, r64
 
 
-def run_vqvae_tcn_check(lib, device, golden_dir):
+def run_vqvae_tcn_check(lib, device, golden_dir, fixture="vade_tcn14.npz"):
     """VQ-VAE with the TCN encoder/decoder: weights = the VaDE-TCN golden's encoder/decoder + a random codebook.
     Eval forward vs the oracle directly; the train step (encoder once, decoder on the quantised and on the raw
     latents, BatchNorm in train mode) vs the oracle evaluated in fp64, in units of the oracle's own fp32 noise."""
     from oracle import vqvae as OQ
-    d = load_golden(golden_dir, "vade_tcn14.npz")
+    d = load_golden(golden_dir, fixture)
     x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
     B, T, N, _ = x.shape
     L, K = 8, 12
