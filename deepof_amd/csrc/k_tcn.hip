@@ -119,10 +119,13 @@ struct TcnConvArgs {
   const float* stat_shift;  // forward k_tcn_conv_t: per-channel shift K of the channel sums (sum (y - K) | sum (y - K)^2), or null (see k_bn_fwd_fin)
   // TAIL (k_tcn_conv_t, conv1's data gradient of block b + 1): the backward of block b's tail in the epilogue
   const float* tail_src = nullptr;    // gradient already waiting at block b's output (the residual branch of block b + 1)
-  const float* tail_out = nullptr;    // block b's output (ReLU mask)
   float* tail_gres = nullptr;         // masked gradient = what enters block b's residual branch
   const float* tail_skip = nullptr;   // final skip-sum (mask of the last-step feature gradient)
   const float* tail_dfeat = nullptr;  // [32][Sp] gradient of the last-step features
+  // round 4: the ReLU mask of a block output as one word per (t, s) row (bit c = out[t][s][c] > 0), [T][Sp] -- written by the
+  // COMB convolution that computes the output, read by the TAIL convolution instead of the output tensor itself (1 / 32 of it)
+  uint32_t* relu_mask_out = nullptr;
+  const uint32_t* tail_mask = nullptr;
   // forward k_tcn_conv_t: 1 = the workgroup's channel statistics leave as mergeable (n | mean | M2) records,
   // partial[workgroup][3][32] (see k_tcn_stat_merge), instead of plain / shifted sums
   int stat_records = 0;
@@ -349,6 +352,19 @@ __global__ void __launch_bounds__(256) k_bn_bwd_sum_fin(const float* __restrict_
   }
 }
 
+// OR over the eight lanes of a half row (the lanes holding the 16-byte chunks of one [32]-channel row): every lane ends with it
+__device__ __forceinline__ uint32_t tct_or8(uint32_t w) {
+  w |= __builtin_bit_cast(uint32_t, dof_dpp_perm<0xB1>(__builtin_bit_cast(float, w)));
+  w |= __builtin_bit_cast(uint32_t, dof_dpp_perm<0x4E>(__builtin_bit_cast(float, w)));
+  w |= __builtin_bit_cast(uint32_t, dof_dpp_perm<0x141>(__builtin_bit_cast(float, w)));
+  return w;
+}
+// a row's ReLU mask word from the four values of chunk ch held by each of its eight lanes: bit c = value of channel c > 0
+__device__ __forceinline__ uint32_t tct_row_mask(const float* e, int ch) {
+  const uint32_t nib = (e[0] > 0.0f ? 1u : 0u) | (e[1] > 0.0f ? 2u : 0u) | (e[2] > 0.0f ? 4u : 0u) | (e[3] > 0.0f ? 8u : 0u);
+  return tct_or8(nib << (4 * ch));
+}
+
 // NS = 16: sequences s, s + 1 of a time step share a 256-byte bank row, the chunk swizzle by s >> 1 spreads the 16 lanes of a
 // ds_read_b128 pass over the 16 bank groups.  NS = 8 (two time steps per MFMA column block): the lanes of a pass are 8
 // sequences of row tt and the same 8 of row tt + 1 -- the row parity goes into the swizzle's top bit.
@@ -471,6 +487,10 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
           }
           const float4 w4 = make_float4(e[0], e[1], e[2], e[3]);
           tile[tct_slot<NS>(t, sq, ch)] = w4;
+          if (COMB) {  // the row's 32 sign bits for the TAIL convolution of the backward pass
+            const uint32_t wbits = tct_row_mask(e, ch);
+            if (ch == 0 && srow && t < T) A.relu_mask_out[(uint32_t)t * (uint32_t)A.Sp + (uint32_t)(s0 + sq)] = wbits;
+          }
           if (srow && t < T) {
             const uint32_t off = st_base + (uint32_t)t * row_stride;
             if ((BN_IN || COMB) && !REVERSE && A.a_out) *reinterpret_cast<float4*>(A.a_out + off) = w4;
@@ -490,8 +510,10 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     const uint32_t ep_base = (uint32_t)s * TC + ct * 16 + kk * 4;
     const uint32_t pre_base = (uint32_t)(pre_on ? s : s0) * TC + ct * 16 + kk * 4;  // padded lanes read a valid row and ignore it
     float4 p0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), p1 = p0;
-    float4 ts0 = p0, to0 = p0;  // TAIL: rows of tail_src / tail_out, requested one output row ahead (register budget)
+    float4 ts0 = p0;    // TAIL: row of tail_src, requested one output row ahead (register budget) ...
+    uint32_t tm0 = 0u;  // ... and the block output's ReLU mask word of that row (round 4: tail_mask instead of the tensor)
     const int tl0 = tpar * TPC + tsub;  // the lane's first output row; its next ones are 2 TPC apart
+    const uint32_t mk_base = (uint32_t)(pre_on ? s : s0);
     if (PRE && (FUSE_BN || A.accumulate)) {
       const uint32_t o0 = pre_base + (uint32_t)(tl0 < T ? tl0 : T - 1) * row_stride;
       const uint32_t o1 = pre_base + (uint32_t)(tl0 + 2 * TPC < T ? tl0 + 2 * TPC : T - 1) * row_stride;
@@ -499,14 +521,15 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
       p1 = *reinterpret_cast<const float4*>(pre_src + o1);
       if (TAIL) {
         ts0 = *reinterpret_cast<const float4*>(A.tail_src + o0);
-        to0 = *reinterpret_cast<const float4*>(A.tail_out + o0);
+        tm0 = A.tail_mask[mk_base + (uint32_t)(tl0 < T ? tl0 : T - 1) * (uint32_t)A.Sp];
       }
     }
     for (int t0 = tpar * TPC; t0 < T; t0 += 2 * TPC) {
       const int t = t0 + tsub;
       const bool ok = ok_s && (TPC == 1 || t < T);
       const uint32_t off = ep_base + (uint32_t)t * row_stride;
-      const float4 pc = p0, tsc = ts0, toc = to0;
+      const float4 pc = p0, tsc = ts0;
+      const uint32_t tmc = tm0;
       if (PRE && (FUSE_BN || A.accumulate)) {
         const uint32_t o2 = pre_base + (uint32_t)(t + 4 * TPC < T ? t + 4 * TPC : T - 1) * row_stride;
         p0 = p1;
@@ -514,7 +537,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
         if (TAIL) {
           const uint32_t o1n = pre_base + (uint32_t)(t + 2 * TPC < T ? t + 2 * TPC : T - 1) * row_stride;
           ts0 = *reinterpret_cast<const float4*>(A.tail_src + o1n);
-          to0 = *reinterpret_cast<const float4*>(A.tail_out + o1n);
+          tm0 = A.tail_mask[mk_base + (uint32_t)(t + 2 * TPC < T ? t + 2 * TPC : T - 1) * (uint32_t)A.Sp];
         }
       }
       dof_f32x4 acc = {bias[0], bias[1], bias[2], bias[3]};
@@ -552,9 +575,10 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
           v0[0] += pc.x; v0[1] += pc.y; v0[2] += pc.z; v0[3] += pc.w;
         }
         if (TAIL) {
-          const float sv[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, ov[4] = {toc.x, toc.y, toc.z, toc.w};
+          const float sv[4] = {tsc.x, tsc.y, tsc.z, tsc.w};
+          const uint32_t nib = tmc >> (ct * 16 + kk * 4);  // bit r: out[t][s][ct*16 + kk*4 + r] > 0
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v0[r] = ov[r] > 0.0f ? v0[r] + sv[r] : 0.0f;
+          for (int r = 0; r < 4; ++r) v0[r] = ((nib >> r) & 1u) != 0u ? v0[r] + sv[r] : 0.0f;
           *reinterpret_cast<float4*>(A.tail_gres + off) = make_float4(v0[0], v0[1], v0[2], v0[3]);
           if (A.tail_dfeat && t == T - 1) {
             const float4 sk = *reinterpret_cast<const float4*>(A.tail_skip + off);
@@ -897,6 +921,7 @@ struct TcnCombineArgs {
   int first, T, F, CT;
   int skip_last;       // 1: only the last time step of the skip-sum is kept (the encoder reads nothing else of it)
   int t0;              // first time step of the launch (the encoder's last block has no `out`: t0 = T - 1)
+  uint32_t* mask_out = nullptr;  // CT = 32 with `out`: [T][Sp] words, bit c = out[t][s][c] > 0 (what k_tcn_conv_t TAIL reads)
   int64_t S, Sp;
 };
 
@@ -933,6 +958,10 @@ __global__ void __launch_bounds__(256) k_tcn_combine(TcnCombineArgs A) {
   }
   if (do_skip) dof_st_row<4>(A.skip + off, sk);
   if (A.out) dof_st_row<4>(A.out + off, r);
+  if (A.mask_out) {  // CT = 32: the eight lanes of a row
+    const uint32_t wbits = tct_row_mask(r, c0 >> 2);
+    if (c0 == 0) A.mask_out[(int64_t)t * A.Sp + s] = wbits;
+  }
   if (A.feat && t == A.T - 1) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) A.feat[(int64_t)(c0 + c) * A.Sp + s] = fmaxf(sk[c], 0.0f);
@@ -1462,7 +1491,7 @@ int dof_tcn_combine_fold() {
 }
 int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp2, float* out_blk, const float* w,
                              const float* bias, float* out, float* partial, int T, int dil, int64_t S, int64_t Sp,
-                             hipStream_t st, const float* stat_shift, int stat_records) {
+                             hipStream_t st, const float* stat_shift, int stat_records, float* relu_mask_out) {
   if (!dof_tcn_conv32_resident(T, Sp)) {
     dof_set_error("k_tcn_conv_comb: needs the time-resident kernel (T <= %d)", tct_max_t());
     return DOF_ERR_UNSUPPORTED;
@@ -1472,6 +1501,7 @@ int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp
   A.in = res; A.w = w; A.bias = bias; A.bnp_in = bnp2; A.a_out = out_blk; A.out = out; A.partial = partial;
   A.fuse_y = nullptr; A.fuse_bnp = nullptr;
   A.bwd_y = y2; A.bwd_bnp = nullptr; A.bwd_coef = nullptr;
+  A.relu_mask_out = reinterpret_cast<uint32_t*>(relu_mask_out);
   A.stat_shift = stat_shift;
   A.stat_records = stat_records ? 1 : 0;
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
@@ -1491,11 +1521,11 @@ int dof_tcn_tail_fold() {
   return on;
 }
 int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
-                             int bwd_store, const float* tail_src, const float* tail_out, float* tail_gres,
+                             int bwd_store, const float* tail_src, const float* tail_mask, float* tail_gres,
                              const float* tail_skip, const float* tail_dfeat, const float* y2, const float* bnp2, float* g_out,
                              float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st) {
-  if (!dof_tcn_conv32_resident(T, Sp) || !bwd_y) {
-    dof_set_error("k_tcn_conv_tail: needs the time-resident kernel (T <= %d) and a lazy BatchNorm1 gradient", tct_max_t());
+  if (!dof_tcn_conv32_resident(T, Sp) || !bwd_y || !tail_mask) {
+    dof_set_error("k_tcn_conv_tail: needs the time-resident kernel (T <= %d), a lazy BatchNorm1 gradient and the block output's mask words", tct_max_t());
     return DOF_ERR_UNSUPPORTED;
   }
   TcnConvArgs A;
@@ -1504,7 +1534,8 @@ int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y
   A.fuse_y = y2; A.fuse_bnp = bnp2;
   A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
   A.stat_shift = nullptr;
-  A.tail_src = tail_src; A.tail_out = tail_out; A.tail_gres = tail_gres; A.tail_skip = tail_skip; A.tail_dfeat = tail_dfeat;
+  A.tail_src = tail_src; A.tail_gres = tail_gres; A.tail_skip = tail_skip; A.tail_dfeat = tail_dfeat;
+  A.tail_mask = reinterpret_cast<const uint32_t*>(tail_mask);
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
   const unsigned nbt = tct_blocks(T, Sp);
   TCT_LAUNCH(true, false, true, true, true, false);
@@ -1526,8 +1557,9 @@ int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* 
 
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
                            const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
-                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch, int skip_last) {
+                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch, int skip_last, float* mask_out) {
   TcnCombineArgs A;
+  A.mask_out = (out && CT == 32) ? reinterpret_cast<uint32_t*>(mask_out) : nullptr;
   A.skip_last = skip_last;
   A.t0 = (skip_last && !out) ? T - 1 : 0;
   A.xs_ch = xs_ch > 0 ? xs_ch : F;

@@ -101,19 +101,20 @@ int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, i
 int dof_tcn_combine_fold();
 int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp2, float* out_blk, const float* w,
                              const float* bias, float* out, float* partial, int T, int dil, int64_t S, int64_t Sp,
-                             hipStream_t st, const float* stat_shift, int stat_records);
+                             hipStream_t st, const float* stat_shift, int stat_records, float* relu_mask_out);
 int dof_tcn_tail_fold();
 int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
-                             int bwd_store, const float* tail_src, const float* tail_out, float* tail_gres,
+                             int bwd_store, const float* tail_src, const float* tail_mask, float* tail_gres,
                              const float* tail_skip, const float* tail_dfeat, const float* y2, const float* bnp2, float* g_out,
                              float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st);
+// relu_mask_out / tail_mask / mask_out: [T][Sp] words, bit c = out[t][s][c] > 0 (the block output's ReLU mask)
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
                           float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st, int shifted = 0);
 int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,
                           int C, hipStream_t st);
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
                            const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
-                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch = 0, int skip_last = 0);
+                           int64_t S, int64_t Sp, hipStream_t st, int xs_ch = 0, int skip_last = 0, float* mask_out = nullptr);
 int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, float* sums,
                            int blk, const float* out_blk, const float* dfeat, const float* skip, const float* dskip,
                            float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st);

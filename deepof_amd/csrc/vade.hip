@@ -82,6 +82,7 @@ struct TcnDecWs {  // TCN decoder buffers (sequences = windows; [T][Bp][64] unle
 struct TcnWs {  // float offsets of one stream's TCN buffers ([T][Sp][32] unless noted)
   int64_t xs;                           // [T][Sp][F] scrambled raw input
   int64_t y1[8], a1[8], y2[8], out[8];  // pre-BN conv outputs, activated conv2 input, block outputs
+  int64_t omask[8];                     // [T][Sp] words: ReLU mask of out[b], b = 0 .. 6 (bit c = out[t][s][c] > 0; written with out[b], read by the TAIL convolutions), 0 = none
   int64_t skip;                         // running / final skip sum
   int64_t g1[8], g2[8];                 // d loss / d (pre-BN conv output): A operands of the weight-gradient jobs
   int64_t dout[2], da;                  // ping-pong block-output gradients, conv2 input gradient
@@ -551,6 +552,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     for (int b = 0; b < 8; ++b) {
       t.y1[b] = cv.take(act); t.a1[b] = t.lazy ? 0 : cv.take(act); t.y2[b] = cv.take(act);
       t.out[b] = b < 7 ? cv.take(act) : 0;
+      t.omask[b] = (b < 7 && dof_tcn_conv32_resident(T, Sp)) ? cv.take((int64_t)T * Sp) : 0;
       t.g1[b] = cv.take(act); t.g2[b] = cv.take(act);
     }
     t.skip = cv.take(act);
@@ -1562,7 +1564,7 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
         // last step of the skip-sum): out[b-1] = ReLU(ReLU(BN2(y2[b-1])) + out[b-2])
         TRY(dof_launch_tcn_conv_comb(ws + t.out[b - 2], ws + t.y2[b - 1], ws + t.bnp[2 * b - 1], ws + t.out[b - 1], params + o.c1w,
                                      params + o.c1b, ws + t.y1[b], ws + t.partial, T, d, w.S, w.Sp, st,
-                                     sh_on(2 * b) ? params + o.rm1 : nullptr, recs));
+                                     sh_on(2 * b) ? params + o.rm1 : nullptr, recs, ws + t.omask[b - 1]));
         nrows = dof_tcn_conv32_partials(T, w.Sp);
       } else {
         TRY(dof_launch_tcn_conv(0, ws + t.out[b - 1], params + o.c1w, params + o.c1b, nullptr, nullptr, ws + t.y1[b],
@@ -1594,7 +1596,7 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
                                  b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb,
                                  (b < 7 && !(comb && b >= 1)) ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr,
-                                 b == 0, T, w.F, 32, w.S, w.Sp, st, 0, /*skip_last=*/1));
+                                 b == 0, T, w.F, 32, w.S, w.Sp, st, 0, /*skip_last=*/1, t.omask[b] ? ws + t.omask[b] : nullptr));
     }
   }
   TRY(censnet_forward(p, params, st));
@@ -1915,7 +1917,7 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
         // this block's residual-branch gradient, the sum is the gradient at block b - 1's output (never written);
         // its masked form goes to block b - 1's own dprev (this block's din buffer, free by now)
         TRY(dof_launch_tcn_conv_tail(ws + t.g1[b], params + o.c1w, ws + t.y1[b], ws + t.bnp[2 * b], coef1, t.lazy ? 0 : 1, dprev,
-                                     ws + t.out[b - 1], ws + t.dout[b & 1], ws + t.skip, ws + w.dn2, ws + t.y2[b - 1],
+                                     ws + t.omask[b - 1], ws + t.dout[b & 1], ws + t.skip, ws + w.dn2, ws + t.y2[b - 1],
                                      ws + t.bnp[2 * b - 1], ws + t.g2[b - 1], ws + t.partial, nullptr, T, d, w.S, w.Sp, st));
         tail_done = true;
       } else if (fuse2 && b > 0) {  // pass 2 of BN1's backward inside conv1's data gradient

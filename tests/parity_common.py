@@ -829,7 +829,9 @@ def run_vqvae_tcn_check(lib, device, golden_dir, fixture="vade_tcn14.npz"):
         t = t.numpy().reshape(g.shape)
         noise = np.abs(g32[name].numpy().astype(np.float64).reshape(g.shape) - t).max()
         err = np.abs(g - t).max()
-        assert err <= 8.0 * noise + 2e-6 * np.abs(t).max() + 1e-7, (name, err, noise)
+        # (noise: one fp32 evaluation of the oracle on the host running the test -- it moves with the host's BLAS, so the bar
+        # has run_vade_tcn_check's scale term as its floor)
+        assert err <= max(8.0 * noise, TCN_B6_RTOL * np.abs(t).max()) + 2e-6 * np.abs(t).max() + 1e-7, (name, err, noise)
         n += 1
     assert n >= 180
     sd = eng.state_dict()
