@@ -10,3 +10,5 @@ timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 600 $OUT/bench_default.json
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
 timeout 3000 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
+bash tools/prof_c4.sh final/prof_c4 c4
+bash tools/prof_c4.sh final/prof_c5tcn c5tcn
