@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     // ---- stage the group's rows: two time steps per pass over the 256 threads, a batch of loads in flight.  The
     // loads are unconditional (steps past T re-read step T - 1 and land in LDS rows nobody reads): a predicate
     // around them would serialise the batch on vmcnt(0).
-    constexpr int NP = (TCT_T * TPC + TS - 1) / TS, NBATCH = (BWD2 || COMB) ? 3 : 7;
+    constexpr int NP = (TCT_T * TPC + TS - 1) / TS, NBATCH = COMB ? 2 : BWD2 ? 3 : 7;
     const bool srow = s0 + sq < A.S;
     // 32-bit element offsets (the launcher checks T * Sp * 32 < 2^31): SGPR base + one VGPR per address
     const uint32_t row_stride = (uint32_t)A.Sp * TC;

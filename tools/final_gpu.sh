@@ -12,3 +12,4 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 3000 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
 bash tools/prof_c4.sh final/prof_c4 c4
 bash tools/prof_c4.sh final/prof_c5tcn c5tcn
+bash tools/prof_c4_pmc.sh final/c4_pmc
