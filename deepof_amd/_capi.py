@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -94,6 +94,7 @@ SIGNATURES = {
     "dof_comm_unique_id": (C.c_int, [_P]),
     "dof_comm_create": (C.c_int, [_P, _I32, _I32, C.POINTER(_P)]),
     "dof_comm_destroy": (C.c_int, [_P]),
+    "dof_comm_abort": (C.c_int, [_P]),
     "dof_flat_allreduce": (C.c_int, [_P, _P, _I64, _P]),
     "dof_comm_broadcast": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "dof_vade_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),

@@ -68,6 +68,12 @@ class NativeComm:
             self.lib.dof_comm_destroy(self._h)
         self._h = None
 
+    def abort(self):
+        """``ncclCommAbort``: drop the communicator without waiting for collectives in flight."""
+        if self._h is not None and self._h.value:
+            self.lib.dof_comm_abort(self._h)
+        self._h = None
+
     def __del__(self):
         try:
             self.close()

@@ -23,6 +23,7 @@ struct Rccl {
   int (*GetUniqueId)(RcclUniqueId*) = nullptr;
   int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
   int (*CommDestroy)(RcclComm) = nullptr;
+  int (*CommAbort)(RcclComm) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -44,6 +45,7 @@ const Rccl* rccl() {
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
     g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
     g_rccl.Broadcast = reinterpret_cast<decltype(g_rccl.Broadcast)>(dlsym(h, "ncclBroadcast"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
@@ -106,6 +108,15 @@ extern "C" int dof_comm_destroy(DofComm* comm) {
   if (r) rc = r->CommDestroy(comm->comm);
   delete comm;
   return (r && rc != 0) ? rccl_fail(r, rc, "ncclCommDestroy") : DOF_OK;
+}
+
+extern "C" int dof_comm_abort(DofComm* comm) {
+  if (!comm) return DOF_OK;
+  const Rccl* r = rccl();
+  int rc = 0;
+  if (r) rc = r->CommAbort ? r->CommAbort(comm->comm) : r->CommDestroy(comm->comm);
+  delete comm;
+  return (r && rc != 0) ? rccl_fail(r, rc, "ncclCommAbort") : DOF_OK;
 }
 
 extern "C" int dof_flat_allreduce(DofComm* comm, float* buf, int64_t n, void* stream) {

@@ -27,10 +27,15 @@ typedef float dof_f32x4 __attribute__((ext_vector_type(4)));
 typedef emu_bf16x8 dof_bf16x8;
 typedef emu_f32x16 dof_f32x16;
 #define DOF_MFMA_32x32x16_BF16(a, b, c) emu_mfma_32x32x16_bf16((a), (b), (c))
+#define DOF_MFMA_16x16x32_BF16(a, b, c) emu_mfma_16x16x32_bf16((a), (b), (c))
 #else
 typedef __bf16 dof_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float dof_f32x16 __attribute__((ext_vector_type(16)));
 #define DOF_MFMA_32x32x16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_16x16x32_bf16 (gfx950): D (16 x 16 fp32) += A (16 x 32 bf16) B (32 x 16 bf16).  Operand of lane l: row (A) /
+// column (B) l & 15, the eight consecutive k values 8 (l >> 4) .. + 7; D register r of lane l: row 4 (l >> 4) + r, column
+// l & 15 (the layout of v_mfma_f32_16x16x4_f32).
+#define DOF_MFMA_16x16x32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #endif
 // eight bf16 values (16 bytes, 8-byte aligned) from LDS as an MFMA operand
 __device__ __forceinline__ dof_bf16x8 dof_ld_bf16x8(const uint16_t* p) {
@@ -58,6 +63,23 @@ __device__ __forceinline__ uint32_t dof_pack_hi16(float lo_half, float hi_half) 
 #else
   return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi_half), __builtin_bit_cast(uint32_t, lo_half), 0x07060302u);
 #endif
+}
+
+// an MFMA operand of eight bf16 values from four packed words (word w = elements 2w (low half) and 2w + 1)
+__device__ __forceinline__ dof_bf16x8 dof_mk_bf16x8(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  union { uint32_t w[4]; dof_bf16x8 v; } u;
+  u.w[0] = w0; u.w[1] = w1; u.w[2] = w2; u.w[3] = w3;
+  return u.v;
+}
+// The three bf16 pieces of four fp32 values as packed words: out[p][0] = pieces p of v[0], v[1]; out[p][1] = of v[2], v[3].
+// 4 VALU operations per value + 6 packs: v = piece0 + piece1 + piece2 exactly (see dof_bf16_rest).
+__device__ __forceinline__ void dof_split3x4(const float (&v)[4], uint32_t (&out)[3][2]) {
+  float r1[4], r2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r1[i] = dof_bf16_rest(v[i]); r2[i] = dof_bf16_rest(r1[i]); }
+  out[0][0] = dof_pack_hi16(v[0], v[1]);   out[0][1] = dof_pack_hi16(v[2], v[3]);
+  out[1][0] = dof_pack_hi16(r1[0], r1[1]); out[1][1] = dof_pack_hi16(r1[2], r1[3]);
+  out[2][0] = dof_pack_hi16(r2[0], r2[1]); out[2][1] = dof_pack_hi16(r2[2], r2[3]);
 }
 
 // 1: the HIP runtime is underneath (RCCL can be opened); 0: the host-only emulation build
@@ -99,10 +121,22 @@ __device__ __forceinline__ double dof_dmul_rn(double a, double b) { return __dmu
 __device__ __forceinline__ double dof_dadd_rn(double a, double b) { return __dadd_rn(a, b); }
 #endif
 
+// a lambda that must be inlined at every call site (a step body called from the unrolled loop AND from the remainder
+// group is otherwise emitted as a function: its by-reference captures then live in scratch memory)
+#define DOF_INLINE_LAMBDA __attribute__((always_inline))
 #ifdef DOF_EMU
 #define DOF_SCHED_FENCE() ((void)0)
 #else
 #define DOF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+// Orders the LDS accesses of ONE wavefront that owns a region of LDS by itself (write the tile, read it transposed): the
+// hardware executes a wavefront's DS instructions in issue order, so all it takes is that the compiler keeps them in
+// program order (a wavefront-scope fence emits no instruction).  The emulator runs lanes as fibres and needs a real
+// rendezvous (every wavefront of the workgroup must then reach the same calls).
+#ifdef DOF_EMU
+#define DOF_WAVE_LDS_ORDER() __syncthreads()
+#else
+#define DOF_WAVE_LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #endif
 // compiler-only memory fence: loads after it are not merged with / hoisted above earlier ones
 #define DOF_MEM_FENCE() asm volatile("" ::: "memory")

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import math
 import os
+import sys
+import time
 import warnings
 from copy import deepcopy
 from types import SimpleNamespace
@@ -75,10 +77,15 @@ def _dp_step(graphs, key, slot, forward_backward, eng, dist, world: int):
 
     Default on the RCCL ("nccl") backend: the collective is the C ABI's ``dof_flat_allreduce`` on the step's OWN stream,
     captured with everything else into ONE hipGraph -- a data-parallel step is a single graph replay, no event hop to
-    a communication stream and no second graph launch.  ``DOF_DP_NATIVE=0`` keeps ``torch.distributed.all_reduce``
-    (enqueued on RCCL's own stream; the step's stream waits for it on the device), ``DOF_DP_ONE_GRAPH=0`` keeps two
-    captured graphs around an eagerly enqueued collective.  Other backends (gloo: the CPU tests) always take the
-    torch.distributed form, two graphs.  The switches are read once per process (``_dp_switches``)."""
+    a communication stream and no second graph launch.  Before the first step takes that form, `dp_self_check` runs it
+    (eagerly and captured) on a scratch buffer against ``torch.distributed.all_reduce``; on a mismatch, an error or a
+    timeout EVERY rank falls back to the safe form -- ``torch.distributed.all_reduce`` between two captured graphs --
+    with one warning line, and `dp_form` reports the form actually taken.  ``DOF_DP_NATIVE=0`` asks for the safe form
+    directly; ``DOF_DP_ONE_GRAPH=1`` with it captures the torch collective into the step graph (opt-in: never validated
+    multi-rank); ``DOF_DP_ONE_GRAPH=0`` keeps two graphs around an eagerly enqueued native collective.  Other backends
+    (gloo: the CPU tests) always take the torch.distributed form, two graphs.  Decided once per process group
+    (``_dp_switches``).  Reference: DDP's bucketed gradient all-reduce, /root/reference/deepof/clustering/
+    model_utils_new.py:196-226, training.py:1567-1576."""
     scale = 1.0 / world
     native, one_graph = _dp_switches(eng, dist)
     if native:
@@ -99,19 +106,138 @@ def _dp_step(graphs, key, slot, forward_backward, eng, dist, world: int):
 
 
 _DP_SWITCHES = {}
+_DP_CHECK = {}   # process-group identity -> the self-check's verdict string ("" when no check was due)
+
+
+def dp_self_check(candidate, dist, like: torch.Tensor, captured: bool = False, timeout_s: float = None):
+    """Does ``candidate(t)`` -- an in-place SUM over the ranks, enqueued on the current stream -- agree with
+    ``torch.distributed.all_reduce`` on a scratch buffer shaped like ``like`` (the flat gradient)?
+
+    Every rank fills the scratch with its own seeded values, reduces one copy through torch.distributed and one through
+    the candidate on a side stream, polls an event (never a blocking wait: a collective that hangs must not hang the
+    fit) until ``timeout_s`` (DOF_DP_CHECK_TIMEOUT, default 30 s), and compares: bitwise, else 1e-6 of the largest
+    magnitude.  ``captured``: the candidate is then also captured into a hipGraph and replayed once -- the form the
+    one-graph step uses.  The verdict is agreed across ranks (MIN over an all-reduced flag), so either all ranks take
+    the candidate or none does.  Returns (ok, why)."""
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("DOF_DP_CHECK_TIMEOUT", "30"))
+    rank = dist.get_rank()
+    dev = like.device
+    n = int(like.numel())
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(7919 + 104729 * rank)
+    probe = torch.randn(max(n, 1), generator=gen, dtype=torch.float32).to(dev)
+    ref = probe.clone()
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+    ok, why = True, ""
+
+    def agrees(got, what):
+        if torch.equal(got, ref):
+            return True, ""
+        err = float((got - ref).abs().max())
+        bar = 1e-6 * max(float(ref.abs().max()), 1.0)
+        if err <= bar:
+            return True, ""
+        return False, f"{what} differs from torch.distributed.all_reduce by {err:.3e} (bar {bar:.1e})"
+
+    def finished(event):
+        deadline = time.monotonic() + timeout_s
+        while not event.query():
+            if time.monotonic() > deadline:
+                return False
+            time.sleep(0.002)
+        return True
+
+    try:
+        if dev.type == "cuda":
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                got = probe.clone()
+                candidate(got)
+                done = torch.cuda.Event()
+                done.record(side)
+            if not finished(done):
+                ok, why = False, f"the collective did not complete within {timeout_s:.0f} s"
+            else:
+                ok, why = agrees(got, "the eager collective")
+            if ok and captured:
+                with torch.cuda.stream(side):
+                    got2 = probe.clone()
+                    side.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        candidate(got2)
+                    g.replay()
+                    done2 = torch.cuda.Event()
+                    done2.record(side)
+                if not finished(done2):
+                    ok, why = False, f"the captured collective did not complete within {timeout_s:.0f} s"
+                else:
+                    ok, why = agrees(got2, "the captured collective")
+                del g
+        else:
+            got = probe.clone()
+            candidate(got)
+            ok, why = agrees(got, "the collective")
+    except Exception as exc:  # a failing candidate must end in the safe form, not in a dead fit
+        ok, why = False, f"{type(exc).__name__}: {exc}"
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if ok and float(flag.item()) != 1.0:
+        ok, why = False, "another rank's check failed"
+    return ok, why
+
+
+def _decide_dp_form(rccl: bool, dist, grads: torch.Tensor, native_reduce_factory, on_failure=None, env=None):
+    """(native, one_graph, verdict): the form the data-parallel step takes on this process group.  ``rccl``: the group
+    runs on RCCL with the gradient on a ROCm device (any other backend takes the torch.distributed form between two
+    graphs).  ``native_reduce_factory()`` returns the native in-place SUM (it may raise: no librccl, no communicator)."""
+    env = os.environ if env is None else env
+    native = rccl and env.get("DOF_DP_NATIVE", "1") != "0"
+    # the torch.distributed collective is captured into the step graph only on request: that form was never validated
+    # on more than one rank
+    one_graph = rccl and env.get("DOF_DP_ONE_GRAPH", "1" if native else "0") != "0"
+    verdict = ""
+    if native and env.get("DOF_DP_SELF_CHECK", "1") != "0":
+        try:
+            reduce = native_reduce_factory()
+        except Exception as exc:
+            reduce = None
+            why = f"{type(exc).__name__}: {exc}"
+        if reduce is None:
+            def reduce(_t, _why=why):
+                raise RuntimeError(_why)
+        ok, why = dp_self_check(reduce, dist, grads, captured=one_graph)
+        verdict = "passed" if ok else f"failed ({why})"
+        if not ok:
+            native, one_graph = False, False
+            if on_failure is not None:
+                on_failure()
+            if dist.get_rank() == 0:
+                print(f"deepof_amd: WARNING native data-parallel collective self-check {verdict}; "
+                      "falling back to torch.distributed.all_reduce between two graphs", file=sys.stderr, flush=True)
+    return native, one_graph, verdict
 
 
 def _dp_switches(eng, dist):
-    """(native collective, one graph) for this process group, decided once: the RCCL backend on a ROCm device takes the
-    one-graph native form unless DOF_DP_NATIVE=0 / DOF_DP_ONE_GRAPH=0 say otherwise; any other backend cannot."""
+    """(native collective, one graph) for this process group, decided once (`_decide_dp_form`): the RCCL backend on a
+    ROCm device takes the one-graph native form when `dp_self_check` passes, unless DOF_DP_NATIVE=0 /
+    DOF_DP_ONE_GRAPH=0 say otherwise; any other backend takes the torch.distributed form between two graphs."""
     ident = _pg_identity(eng, dist)
     sw = _DP_SWITCHES.get(ident)
     if sw is None:
         rccl = eng.params.is_cuda and dist.get_backend() == "nccl"
-        native = rccl and os.environ.get("DOF_DP_NATIVE", "1") != "0"
-        one_graph = rccl and os.environ.get("DOF_DP_ONE_GRAPH", "1") != "0"
+
+        def factory():
+            comm = _native_comm(eng, dist)
+            return lambda t: comm.all_reduce_(t)
+
+        native, one_graph, verdict = _decide_dp_form(rccl, dist, eng.grads, factory, on_failure=abort_native_comm)
         _DP_SWITCHES.clear()
+        _DP_CHECK.clear()
         sw = _DP_SWITCHES[ident] = (native, one_graph)
+        _DP_CHECK[ident] = verdict
     return sw
 
 
@@ -120,6 +246,12 @@ def dp_form(eng, dist) -> str:
     native, one_graph = _dp_switches(eng, dist)
     return ("dof_flat_allreduce" if native else "torch.distributed.all_reduce") + \
            (" captured in the step graph" if one_graph else " between two graphs")
+
+
+def dp_check_verdict(eng, dist) -> str:
+    """"passed" / "failed (...)" of the native collective's self-check for this process group, "" when none was due."""
+    _dp_switches(eng, dist)
+    return _DP_CHECK.get(_pg_identity(eng, dist), "")
 
 
 def _pg_identity(eng, dist):
@@ -149,6 +281,14 @@ def _native_comm(eng, dist):
 def close_native_comm():
     for comm in _NATIVE_COMM.values():
         comm.close()
+    _NATIVE_COMM.clear()
+
+
+def abort_native_comm():
+    """Drop the communicator without waiting for collectives in flight (``ncclCommAbort``): the self-check's way out of
+    a collective that hung or produced wrong sums."""
+    for comm in _NATIVE_COMM.values():
+        comm.abort()
     _NATIVE_COMM.clear()
 
 

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 15
+#define DOF_ABI_VERSION 16
 
 /* ---- error reporting ----------------------------------------------------------------------
  * Every int entry point returns 0 or a negative code, with the text in dof_last_error_string():
@@ -466,6 +466,9 @@ typedef struct DofComm DofComm;
 int dof_comm_unique_id(void* id_out);
 int dof_comm_create(const void* id, int32_t rank, int32_t world, DofComm** out);
 int dof_comm_destroy(DofComm* comm);
+/* ncclCommAbort: frees the communicator WITHOUT waiting for collectives in flight -- the way out of a collective that
+ * hung or failed its self-check (deepof_amd.training.dp_self_check).  ABI v16. */
+int dof_comm_abort(DofComm* comm);
 int dof_flat_allreduce(DofComm* comm, float* buf, int64_t n, void* stream);
 int dof_comm_broadcast(DofComm* comm, float* buf, int64_t n, int32_t root, void* stream);
 

@@ -186,6 +186,27 @@ emu_f32x16 emu_mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
   return c;
 }
 
+emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
+  // A[m][k]: lane (k / 8) * 16 + m, element k % 8 ; B[k][n]: lane (k / 8) * 16 + n ; D register r: row 4 (lane >> 4) + r
+  int me = g_cur;
+  int lane = me & 63, base = me - lane;
+  for (int e = 0; e < 8; ++e) {
+    g_xchg16[me][e] = a.v[e];
+    g_xchg16[me][8 + e] = b.v[e];
+  }
+  yield_as(WAIT_WAVE);
+  int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (lane >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k)
+      acc = fmaf(bf16f(g_xchg16[base + (k / 8) * 16 + row][k % 8]), bf16f(g_xchg16[base + (k / 8) * 16 + col][8 + k % 8]), acc);
+    c[r] = acc;
+  }
+  yield_as(WAIT_WAVE);
+  return c;
+}
+
 void emu_run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
   g_body = &body;
   gridDim = grid;

@@ -49,6 +49,7 @@ emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c);
 struct emu_bf16x8 { uint16_t v[8]; };
 typedef float emu_f32x16 __attribute__((vector_size(64)));
 emu_f32x16 emu_mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c);
+emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c);
 
 static inline void __syncthreads() { emu_sync_block(); }
 static inline float __shfl_xor(float v, int mask, int width = 64) {

@@ -317,6 +317,67 @@ def test_data_parallel_gradient_allreduce_gloo(tmp_path):
     assert float((r0["local"] - r1["local"]).abs().max()) > 0
 
 
+def _dp_check_worker(rank, world, port, tmp):
+    """The self-check that guards the native data-parallel collective (training.dp_self_check / _decide_dp_form),
+    driven with stand-in candidates over gloo: a correct one, one that forgets to reduce, one that is wrong on ONE rank
+    only, one that raises."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepof_amd import training as TR
+    like = torch.zeros(21_626)
+    good = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    out = {}
+    out["good"] = TR.dp_self_check(good, dist, like)
+    out["identity"] = TR.dp_self_check(lambda t: t, dist, like)
+
+    def wrong_on_rank1(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if rank == 1:
+            t[17] += 1e-3
+    out["one_rank"] = TR.dp_self_check(wrong_on_rank1, dist, like)
+
+    def raising(t):
+        raise RuntimeError("ncclAllReduce failed: unhandled system error")
+    out["raises"] = TR.dp_self_check(raising, dist, like)
+    # the decision: (native, one_graph, verdict) with the RCCL branch forced on
+    aborted = []
+    out["form_good"] = TR._decide_dp_form(True, dist, like, lambda: good, env={})
+    out["form_bad"] = TR._decide_dp_form(True, dist, like, lambda: wrong_on_rank1, on_failure=lambda: aborted.append(1), env={})
+    def no_comm():
+        raise OSError("librccl is not available")
+    out["form_nocomm"] = TR._decide_dp_form(True, dist, like, no_comm, env={})
+    out["form_off"] = TR._decide_dp_form(True, dist, like, lambda: good, env={"DOF_DP_NATIVE": "0"})
+    out["form_off_one"] = TR._decide_dp_form(True, dist, like, lambda: good, env={"DOF_DP_NATIVE": "0", "DOF_DP_ONE_GRAPH": "1"})
+    out["form_gloo"] = TR._decide_dp_form(False, dist, like, lambda: good, env={})
+    out["aborted"] = len(aborted)
+    torch.save(out, os.path.join(tmp, f"check{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_self_check_gloo(tmp_path):
+    """Every rank reaches the same verdict; a failing native collective ends in the safe form (torch.distributed between
+    two graphs), never in a dead fit."""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() * 7 + 3) % 2000
+    mp.spawn(_dp_check_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"check{k}.pt")) for k in range(2)]
+    for k in range(2):
+        assert r[k]["good"] == (True, "")
+        assert r[k]["identity"][0] is False and "differs" in r[k]["identity"][1]
+        assert r[k]["one_rank"][0] is False
+        assert r[k]["raises"][0] is False and "ncclAllReduce failed" in r[k]["raises"][1]
+        assert r[k]["form_good"] == (True, True, "passed")
+        assert r[k]["form_bad"][:2] == (False, False) and r[k]["form_bad"][2].startswith("failed")
+        assert r[k]["form_nocomm"][:2] == (False, False) and "librccl" in r[k]["form_nocomm"][2]
+        assert r[k]["form_off"] == (False, False, "")
+        assert r[k]["form_off_one"] == (False, True, "")
+        assert r[k]["form_gloo"] == (False, False, "")
+        assert r[k]["aborted"] == 1
+    assert "differs" in r[1]["one_rank"][1] and "another rank" in r[0]["one_rank"][1]
+
+
 def test_data_parallel_equals_concatenated_batch_gloo(tmp_path):
     """SURVEY 8(e)'s correctness bar: N ranks x B == 1 rank on the concatenated batch of N*B windows, for the
     batch-separable terms (reconstruction, KL, activity L1: means over windows; the batch-coupled terms -- Gram k-means,
