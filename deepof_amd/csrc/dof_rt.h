@@ -132,9 +132,9 @@ __device__ __forceinline__ double dof_dadd_rn(double a, double b) { return __dad
 // Orders the LDS accesses of ONE wavefront that owns a region of LDS by itself (write the tile, read it transposed): the
 // hardware executes a wavefront's DS instructions in issue order, so all it takes is that the compiler keeps them in
 // program order (a wavefront-scope fence emits no instruction).  The emulator runs lanes as fibres and needs a real
-// rendezvous (every wavefront of the workgroup must then reach the same calls).
+// rendezvous of the wavefront's lanes (a shuffle is one).
 #ifdef DOF_EMU
-#define DOF_WAVE_LDS_ORDER() __syncthreads()
+#define DOF_WAVE_LDS_ORDER() ((void)emu_shfl(0.0f, 0, 64))
 #else
 #define DOF_WAVE_LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #endif

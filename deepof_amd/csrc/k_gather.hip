@@ -117,9 +117,12 @@ __global__ void __launch_bounds__(256) k_window_gather(
     }
     __syncthreads();
     const int64_t rmin = span[0], rows = span[1];
-    staged = rows * (C + E) <= STAGE;
+    // the edge rows are staged behind the node rows at a 4-float boundary, so that `at & 3` / `at & 1` in copy_windows
+    // speak about the real LDS address of BOTH tables (rows * C need not be a multiple of 4)
+    const int64_t nnode_pad = (rows * C + 3) & ~(int64_t)3;
+    staged = nnode_pad + rows * E <= STAGE;
     if (staged) {
-      const int nnode = (int)rows * C, nedge = (int)rows * E;
+      const int nnode = (int)rows * C, nedge = (int)rows * E, edge0 = (int)nnode_pad;
       const float* __restrict__ srcn = node_table + rmin * C;
       const float* __restrict__ srce = edge_table + rmin * E;
       // table element (row r, column f*N + n)  ->  staged position r*C + n*3 + f
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(256) k_window_gather(
         const unsigned f = fast_div(c, (unsigned)N, rcp_n);
         stage[r * C + (c - f * N) * 3 + f] = srcn[i];
       }
-      for (int i = threadIdx.x; i < nedge; i += 256) stage[nnode + i] = srce[i];
+      for (int i = threadIdx.x; i < nedge; i += 256) stage[edge0 + i] = srce[i];
       if ((int)threadIdx.x < nwin) lrow[threadIdx.x] = (int)(row0[threadIdx.x] - rmin);
       __syncthreads();
       // one 16-byte store = EPV consecutive elements of window w from element o on; `per` elements per window, rows of
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(256) k_window_gather(
         }
       };
       copy_windows(stage, per_x, C, reinterpret_cast<char*>(x_out) + w0 * per_x * OSZ, rcp_perwin);
-      copy_windows(stage + nnode, per_a, E, reinterpret_cast<char*>(a_out) + w0 * per_a * OSZ,
+      copy_windows(stage + edge0, per_a, E, reinterpret_cast<char*>(a_out) + w0 * per_a * OSZ,
                    rcp_perwin * ((float)C / (float)E) * 0.999999f);
       return;
     }

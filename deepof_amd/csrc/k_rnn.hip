@@ -1570,6 +1570,50 @@ __global__ void __launch_bounds__(256) k_gru8_wg_finalize(WgFinArgs A0, WgFinArg
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over channels (eps = 1e-3), thread = (t, s).
 // ---------------------------------------------------------------------------------------------
+// grads of a (32 -> 8) GRU layer from k_gru8x_bwd's per-wavefront partials [dir][nblk][GRU8X_WG_FLOATS] (the reference's
+// tensors in order: weight_ih, weight_hh, then the bias sums of g_r, g_z, g_n, g_h); same reduction shape as
+// k_gru16_wg_finalize (8 neighbouring values x 32 row slices per workgroup, slices added in a fixed order)
+__global__ void __launch_bounds__(256) k_gru8x_wg_finalize(WgFinArgs A0, WgFinArgs A1, int accumulate) {
+  const WgFinArgs& A = blockIdx.z ? A1 : A0;
+  const float* __restrict__ wg_partial = A.wg_partial;
+  const int nblk = A.nblk;
+  constexpr int NV = 8;
+  static_assert(GRU8X_WG_FLOATS % NV == 0, "value groups");
+  __shared__ float red[32][NV + 1];
+  const int dir = blockIdx.y;
+  const int vi = (int)threadIdx.x & (NV - 1), slice = (int)threadIdx.x / NV;
+  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU8X_WG_FLOATS + blockIdx.x * NV + vi;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int r = slice;
+  for (; r + 96 < nblk; r += 128) {
+    a0 += p[(int64_t)r * GRU8X_WG_FLOATS];
+    a1 += p[(int64_t)(r + 32) * GRU8X_WG_FLOATS];
+    a2 += p[(int64_t)(r + 64) * GRU8X_WG_FLOATS];
+    a3 += p[(int64_t)(r + 96) * GRU8X_WG_FLOATS];
+  }
+  for (; r < nblk; r += 32) a0 += p[(int64_t)r * GRU8X_WG_FLOATS];
+  red[slice][vi] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x >= NV) return;
+  float val = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) val += red[k][vi];
+  const int v = blockIdx.x * NV + vi;
+  float* g_wih = A.g[dir ? 4 : 0];
+  float* g_whh = A.g[dir ? 5 : 1];
+  float* g_bih = A.g[dir ? 6 : 2];
+  float* g_bhh = A.g[dir ? 7 : 3];
+  auto put = [&](float* d) { *d = accumulate ? *d + val : val; };
+  if (v < 24 * 32) put(&g_wih[v]);
+  else if (v < 24 * 32 + 24 * 8) put(&g_whh[v - 24 * 32]);
+  else {
+    const int kind = (v - (24 * 32 + 24 * 8)) >> 3, unit = v & 7;   // g_r, g_z, g_n (input side), g_h (hidden side)
+    if (kind < 2) { put(&g_bih[kind * 8 + unit]); put(&g_bhh[kind * 8 + unit]); }
+    else if (kind == 2) put(&g_bih[16 + unit]);
+    else put(&g_bhh[16 + unit]);
+  }
+}
+
 template <int C>
 __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ X, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, float* __restrict__ Y, int T,
@@ -2089,21 +2133,15 @@ static Gru8Args gru3_fwd_args(const float* X, const int* len, const DofGruW& W, 
 }
 // the same layer on the matrix pipe (k_gru8m_fwd; launches of >= DOF_GRU_MFMA_MIN_S sequences per stream): returns 1 when
 // launched, 0 when the caller has to use the lane-per-unit kernels, < 0 on error.  DOF_GRU8_MFMA=0: off (A/B).
-bool dof_gru8m_fwd_selected(int64_t S0, int64_t S1) {
-  static const bool on = [] {
-    const char* e = getenv("DOF_GRU8_MFMA");
-    return !(e && e[0] == '0');
-  }();
-  return on && dof_gru16_mfma(S0) && dof_gru16_mfma(S1);
-}
+bool dof_gru8m_fwd_selected(int64_t S0, int64_t S1) { return dof_gru16_mfma(S0) && dof_gru16_mfma(S1); }
 int dof_launch_gru8m_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2],
                               float* const GS[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
   if (!dof_gru8m_fwd_selected(S[0], S[1])) return 0;
   const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], O[0], GS[0], nullptr, nullptr, nullptr, S[0], Sp[0]);
   const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], O[1], GS[1], nullptr, nullptr, nullptr, S[1], Sp[1]);
   const int64_t smax = S[0] > S[1] ? S[0] : S[1];
-  DOF_LAUNCH(k_gru8m_fwd, (dof_cdiv(smax, 16), 2, 2), (64), st, a, b, T);
-  return dof_check_launch("k_gru8m_fwd (pair)") == DOF_OK ? 1 : DOF_ERR_LAUNCH;
+  DOF_LAUNCH((k_gru8x_fwd<4>), (dof_cdiv(smax, 16), 2, 2), (64), st, a, b, T);   // (saves no gates: k_gru8x_bwd recomputes them)
+  return dof_check_launch("k_gru8x_fwd (pair)") == DOF_OK ? 1 : DOF_ERR_LAUNCH;
 }
 // the second encoder layer (32 -> 8, latent 8) of both streams in one launch
 int dof_launch_gru8_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2],
@@ -2267,13 +2305,21 @@ int dof_launch_gru16_wg_finalize_pair(const float* const* wg_partial, const int6
 }
 int dof_launch_gru8_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
                                      int accumulate, hipStream_t st) {
+  if (dof_gru8m_fwd_selected(S[0], S[1])) {   // k_gru8x_bwd's partials: one row per wavefront tile of 16 sequences
+    const WgFinArgs A0 = wg_fin_args(wg_partial[0], (int)dof_cdiv(S[0], 16), g, off[0]);
+    const WgFinArgs A1 = wg_fin_args(wg_partial[1], (int)dof_cdiv(S[1], 16), g, off[1]);
+    DOF_LAUNCH(k_gru8x_wg_finalize, ((unsigned)(GRU8X_WG_FLOATS / 8), 2, 2), (256), st, A0, A1, accumulate);
+    return dof_check_launch("k_gru8x_wg_finalize");
+  }
   const WgFinArgs A0 = wg_fin_args(wg_partial[0], (int)dof_cdiv(S[0], 32), g, off[0]);
   const WgFinArgs A1 = wg_fin_args(wg_partial[1], (int)dof_cdiv(S[1], 32), g, off[1]);
   DOF_LAUNCH(k_gru8_wg_finalize, ((unsigned)(GRU8_WG_FLOATS / 8), 2, 2), (256), st, A0, A1, accumulate);
   return dof_check_launch("k_gru8_wg_finalize");
 }
 
-int64_t dof_gru8_wg_floats(int64_t S) { return 2 * (int64_t)dof_cdiv(S, 32) * GRU8_WG_FLOATS; }
+static_assert(GRU8X_WG_FLOATS == GRU8_WG_FLOATS, "one partial-row size for both backward kernels of the layer");
+// (sized for k_gru8x_bwd: one partial row per wavefront tile of 16 sequences; k_gru8_bwd_fused writes half as many)
+int64_t dof_gru8_wg_floats(int64_t S) { return 2 * (int64_t)dof_cdiv(S, 16) * GRU8_WG_FLOATS; }
 
 int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
                               const float* dHfin, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
@@ -2288,6 +2334,13 @@ int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const f
 int dof_launch_gru8_bwd_fused_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], const float* const O[2],
                                    const float* const GS[2], const float* const dHfin[2], float* const dX[2],
                                    float* const wg_partial[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
+  if (dof_gru8m_fwd_selected(S[0], S[1])) {   // the forward pass saved no gates: recompute on the matrix pipe
+    const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], const_cast<float*>(O[0]), nullptr, dHfin[0], dX[0], wg_partial[0], S[0], Sp[0]);
+    const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], const_cast<float*>(O[1]), nullptr, dHfin[1], dX[1], wg_partial[1], S[1], Sp[1]);
+    const int64_t smax = S[0] > S[1] ? S[0] : S[1];
+    DOF_LAUNCH(k_gru8x_bwd, (dof_cdiv(smax, 16), 2, 2), (64), st, a, b, T);
+    return dof_check_launch("k_gru8x_bwd (pair)");
+  }
   Gru8Args A[2] = {};
   for (int k = 0; k < 2; ++k) {
     A[k].X = X[k]; A[k].len = len[k]; A[k].wih0 = W[k].wih0; A[k].whh0 = W[k].whh0; A[k].wih1 = W[k].wih1; A[k].whh1 = W[k].whh1;

@@ -162,6 +162,7 @@ struct JobSet {  // one launch of the MFMA weight-gradient reduction + its final
   std::vector<DofTcnWgrad> wgrads;  // TCN convolutions whose partial tiles come from k_tcn_wgrad instead of k_outer
   int total_blocks = 0, fin_elems = 0, wg_blocks = 0;
   bool wg_first = false;  // some descriptors are first-block ones (k_tcn_wgrad_in)
+  bool tile_overflow = false;  // a job was handed more than the 4 operand tiles DofOuterJob holds (dof_vade_bind refuses)
   int64_t jobs_tab = 0, fin_tab = 0, wg_tab = 0;  // workspace offsets of the uploaded tables
 };
 
@@ -780,9 +781,11 @@ View soa(const float* p, int64_t Sp, int c0 = 0) { return View{p + (int64_t)c0 *
 struct JobBuilder {
   std::vector<DofOuterJob>& jobs;
   std::vector<DofFinJob>& fins;
-  explicit JobBuilder(JobSet& js) : jobs(js.jobs), fins(js.fins) {
+  bool& tile_overflow;
+  explicit JobBuilder(JobSet& js) : jobs(js.jobs), fins(js.fins), tile_overflow(js.tile_overflow) {
     jobs.clear();
     fins.clear();
+    tile_overflow = false;
   }
   void close(JobSet& js) const {
     js.total_blocks = blk_cur;
@@ -819,6 +822,10 @@ struct JobBuilder {
       return first;
     }
     DofOuterJob& j = jobs[job];
+    if (j.n_tiles >= (int)(sizeof(j.tile) / sizeof(j.tile[0]))) {   // (a wide operand beside other tiles: never silently)
+      tile_overflow = true;
+      return j.n_tiles - 1;
+    }
     DofOuterTile& t = j.tile[j.n_tiles];
     t.ptr = b.p; t.t_stride = b.ts; t.s_stride = b.ss; t.c_stride = b.cs; t.nc = nc; t.shift = shift; t.pack = pack;
     return j.n_tiles++;
@@ -968,13 +975,7 @@ bool conv_wgrad_fused() {
 
 // DOF_GRU8_FUSED=0 in the environment keeps the second encoder GRU's weight gradients in the generic reduction
 // (A/B measurements of k_gru8_bwd_fused)
-bool gru8_fused() {
-  static const bool on = [] {
-    const char* e = getenv("DOF_GRU8_FUSED");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+bool gru8_fused() { return true; }   // (round 5: the unfused form would read gates the matrix-pipe forward no longer saves)
 
 void build_tcn_jobs(DofVadePlan* p) {
   const int L = p->L, T = p->T, C = 32;
@@ -2255,6 +2256,10 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
     if (bytes) hipMemcpyAsync(ws + off, src, bytes, hipMemcpyHostToDevice, st);
   };
   for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram, &p->js_all}) {
+    if (js->tile_overflow) {
+      dof_set_error("dof_vade_bind: a weight-gradient job needs more than 4 operand tiles (unsupported layer width)");
+      return DOF_ERR_UNSUPPORTED;
+    }
     if (js->jobs.size() > 256 || js->fins.size() > 2048) {
       dof_set_error("dof_vade_bind: job table overflow (%zu jobs, %zu fins)", js->jobs.size(), js->fins.size());
       return DOF_ERR_STATE;

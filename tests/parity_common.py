@@ -141,12 +141,17 @@ def run_trace_check(lib, device, golden_dir):
     eng = VadeEngine(lib, device, B, T, nodes_adj, L, K)
     eng.load_state_dict(sd0)
     last = None
+    travel = [0.0, 0.0]   # sum of the steps' learning rates: base segments, GMM segment
+    lr_min = 1.0
     for s in range(6):
         phase = str(d[f"step{s}::phase"])
         if phase != last:
             eng.reset_optimizer()
             last = phase
         lr_b, lr_g = (float(v) for v in d[f"step{s}::lr"])
+        travel[0] += lr_b
+        travel[1] += lr_g
+        lr_min = min(lr_min, lr_b, lr_g)
         for seg in (_capi.SEG_ENCODER, _capi.SEG_DECODER, _capi.SEG_HEADS):
             eng.set_lr(seg, lr_b)
         eng.set_lr(_capi.SEG_GMM, lr_g)
@@ -164,11 +169,21 @@ def run_trace_check(lib, device, golden_dir):
     for k, v in params_from(d, "sd_final::").items():
         if k in eng.layout:
             got, ref = eng.view(k).cpu().numpy(), v.numpy().reshape(eng.layout[k][2])
-            bad = np.abs(got - ref) > 5e-4 + 2e-3 * np.abs(ref)
-            # Adam normalises a gradient element near zero into +-lr steps whose sign is rounding noise: isolated elements
-            # (at most 0.05 % of a tensor, at least one) may sit up to three such steps (3 x 1e-3) from the reference
-            assert bad.sum() <= max(1, int(5e-4 * bad.size)) and np.abs(got - ref).max() <= 3.2e-3, \
-                (k, int(bad.sum()), float(np.abs(got - ref).max()))
+            is_gmm = k.startswith("latent_space.gmm_")
+            assert_trace_params(k, got, ref, sd0[k].numpy().reshape(got.shape), travel[1 if is_gmm else 0], lr_min)
+
+
+def assert_trace_params(name, got, ref, init, full_travel, lr_min=1e-3):
+    """Final parameters of an Adam trace against the reference's.  Strict bar (5e-4 abs + 2e-3 rel) for every element
+    whose reference value travelled (nearly) the full sum of the steps' learning rates: its gradient kept one sign well above rounding
+    noise, so both implementations must have taken the same steps.  An element that travelled less had a gradient near
+    zero at some step -- Adam normalises such an element into +-lr steps whose sign is rounding noise -- and only those
+    may sit off the strict bar: at most max(1, 0.05 %) of a tensor, by at most three steps (3.2e-3)."""
+    err = np.abs(got - ref)
+    bad = err > 5e-4 + 2e-3 * np.abs(ref)
+    steady = np.abs(ref - init) >= full_travel - 0.5 * lr_min
+    assert not (bad & steady).any(), (name, "steady-gradient elements off the strict bar", int((bad & steady).sum()), float(err[steady].max()))
+    assert bad.sum() <= max(1, int(5e-4 * bad.size)) and err.max() <= 3.2e-3, (name, int(bad.sum()), float(err.max()))
 
 
 def run_vqvae_check(lib, device, golden_dir, tag):
@@ -179,7 +194,8 @@ def run_vqvae_check(lib, device, golden_dir, tag):
     L, K = d["sd::vq_layer.codebook"].shape
     km = float(d["kmeans"])
     eng = VadeEngine(lib, device, B, T, d["adj"], L, K, kind="vqvae")
-    eng.load_state_dict(params_from(d))
+    sd_init = params_from(d)
+    eng.load_state_dict(sd_init)
     out = eng.vq_forward(x, a)
     np.testing.assert_array_equal(out["idx"].cpu().numpy(), d["idx"])
     np.testing.assert_allclose(out["ze"].cpu().numpy(), d["ze"], atol=1e-5, rtol=1e-4)
@@ -217,11 +233,7 @@ def run_vqvae_check(lib, device, golden_dir, tag):
     for k, v in params_from(d, "sd_final::").items():
         if k in eng.layout:
             got, ref = eng.view(k).cpu().numpy(), v.numpy().reshape(eng.layout[k][2])
-            bad = np.abs(got - ref) > 5e-4 + 2e-3 * np.abs(ref)
-            # Adam normalises a gradient element near zero into +-lr steps whose sign is rounding noise: isolated elements
-            # (at most 0.05 % of a tensor, at least one) may sit up to three such steps (3 x 1e-3) from the reference
-            assert bad.sum() <= max(1, int(5e-4 * bad.size)) and np.abs(got - ref).max() <= 3.2e-3, \
-                (k, int(bad.sum()), float(np.abs(got - ref).max()))
+            assert_trace_params(k, got, ref, sd_init[k].numpy().reshape(got.shape), 3 * 1e-3)
 
 
 def aug_from_golden(d, pfx, device):

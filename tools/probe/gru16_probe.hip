@@ -131,6 +131,70 @@ int main(int argc, char** argv) {
     printf("  k_gru8m_fwd                  %8.2f us\n", us);
   }
 
+  {
+    std::vector<float> ref8 = fetch(B.O8[0], (size_t)T * Sp * 16);
+    CK(hipMemset(B.O8[0], 0, (size_t)T * Sp * 16 * 4));
+    const float us = time_us([&] { hipLaunchKernelGGL((k_gru8x_fwd<4>), dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, a8, b8, T); });
+    printf("  k_gru8x_fwd<4> (bf16x3)      %8.2f us   max |O - O_m| = %.3g\n", us, max_diff(B.O8[0], ref8, (size_t)T * Sp * 16));
+    const float us3 = time_us([&] { hipLaunchKernelGGL((k_gru8x_fwd<3>), dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, a8, b8, T); });
+    printf("  k_gru8x_fwd<3> (bf16x3)      %8.2f us\n", us3);
+  }
+  // ---- backward 32 -> 8 with recompute, checked against a double-precision host evaluation of tile 0 (16 sequences)
+  {
+    float* dHfin = dalloc((size_t)16 * Sp); fill(dHfin, (size_t)16 * Sp, 0.5f, 77);
+    float* dX8[2]; float* wg8[2];
+    const size_t ndX8 = (size_t)2 * T * 32 * Sp, nwg8 = (size_t)2 * ((S + 15) / 16) * GRU8X_WG_FLOATS;
+    for (int k = 0; k < 2; ++k) { dX8[k] = dalloc(ndX8); wg8[k] = dalloc(nwg8); }
+    Gru16mStream c8 = a8, d8 = b8;
+    c8.dO = dHfin; c8.dX = dX8[0]; c8.wg_partial = wg8[0];
+    d8.dO = dHfin; d8.dX = dX8[1]; d8.wg_partial = wg8[1];
+    hipLaunchKernelGGL((k_gru8x_fwd<4>), dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, a8, b8, T);   // O8 of the x kernel
+    const float us = time_us([&] { hipLaunchKernelGGL(k_gru8x_bwd, dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, c8, d8, T); });
+    // host reference
+    std::vector<float> hX = fetch(B.O[0], nO), hO = fetch(B.O8[0], (size_t)T * Sp * 16), hd = fetch(dHfin, (size_t)16 * Sp);
+    std::vector<float> hw = fetch(B.w8, 2 * W8), gdx = fetch(dX8[0], ndX8), gwg = fetch(wg8[0], nwg8);
+    double worst_dx = 0.0, worst_wg = 0.0, scale_dx = 0.0, scale_wg = 0.0;
+    for (int dir = 0; dir < 2; ++dir) {
+      const float* wih = hw.data() + dir * W8; const float* whh = wih + 768; const float* bih = wih + 960; const float* bhh = wih + 984;
+      std::vector<double> part(GRU8X_WG_FLOATS, 0.0);
+      for (int sq = 0; sq < 16; ++sq) {
+        double dh[8];
+        for (int u = 0; u < 8; ++u) dh[u] = hd[(size_t)(dir * 8 + u) * Sp + sq];
+        for (int step = T - 1; step >= 0; --step) {
+          const int t = dir ? (T - 1 - step) : step, tp = dir ? t + 1 : t - 1;
+          double x[32], hp[8];
+          for (int c = 0; c < 32; ++c) x[c] = hX[((size_t)t * Sp + sq) * 32 + c];
+          for (int u = 0; u < 8; ++u) hp[u] = step > 0 ? hO[((size_t)tp * Sp + sq) * 16 + dir * 8 + u] : 0.0;
+          double gr[8], gz[8], gn[8], gh[8], dhn[8];
+          for (int u = 0; u < 8; ++u) {
+            double ar = bih[u] + bhh[u], az = bih[8 + u] + bhh[8 + u], an = bih[16 + u], ah = bhh[16 + u];
+            for (int c = 0; c < 32; ++c) { ar += wih[u * 32 + c] * x[c]; az += wih[(8 + u) * 32 + c] * x[c]; an += wih[(16 + u) * 32 + c] * x[c]; }
+            for (int v = 0; v < 8; ++v) { ar += whh[u * 8 + v] * hp[v]; az += whh[(8 + u) * 8 + v] * hp[v]; ah += whh[(16 + u) * 8 + v] * hp[v]; }
+            const double r = 1.0 / (1.0 + exp(-ar)), z = 1.0 / (1.0 + exp(-az)), nn = tanh(an + r * ah);
+            const double dht = dh[u], dn = dht * (1.0 - z), dz = dht * (hp[u] - nn), dnp = dn * (1.0 - nn * nn);
+            gr[u] = dnp * ah * r * (1.0 - r); gz[u] = dz * z * (1.0 - z); gn[u] = dnp; gh[u] = dnp * r; dhn[u] = dht * z;
+          }
+          for (int v = 0; v < 8; ++v) for (int u = 0; u < 8; ++u) dhn[v] += whh[u * 8 + v] * gr[u] + whh[(8 + u) * 8 + v] * gz[u] + whh[(16 + u) * 8 + v] * gh[u];
+          for (int c = 0; c < 32; ++c) {
+            double dx = 0.0;
+            for (int u = 0; u < 8; ++u) dx += wih[u * 32 + c] * gr[u] + wih[(8 + u) * 32 + c] * gz[u] + wih[(16 + u) * 32 + c] * gn[u];
+            const double got = gdx[(size_t)dir * T * 32 * Sp + ((size_t)t * Sp + sq) * 32 + c];
+            worst_dx = fmax(worst_dx, fabs(got - dx)); scale_dx = fmax(scale_dx, fabs(dx));
+          }
+          for (int u = 0; u < 8; ++u) {
+            for (int c = 0; c < 32; ++c) { part[u * 32 + c] += gr[u] * x[c]; part[(8 + u) * 32 + c] += gz[u] * x[c]; part[(16 + u) * 32 + c] += gn[u] * x[c]; }
+            for (int v = 0; v < 8; ++v) { part[768 + u * 8 + v] += gr[u] * hp[v]; part[768 + (8 + u) * 8 + v] += gz[u] * hp[v]; part[768 + (16 + u) * 8 + v] += gh[u] * hp[v]; }
+            part[960 + u] += gr[u]; part[968 + u] += gz[u]; part[976 + u] += gn[u]; part[984 + u] += gh[u];
+          }
+          for (int u = 0; u < 8; ++u) dh[u] = dhn[u];
+        }
+      }
+      const float* got = gwg.data() + (size_t)dir * ((S + 15) / 16) * GRU8X_WG_FLOATS;
+      for (int e = 0; e < GRU8X_WG_FLOATS; ++e) { worst_wg = fmax(worst_wg, fabs(got[e] - part[e])); scale_wg = fmax(scale_wg, fabs(part[e])); }
+    }
+    printf("  k_gru8x_bwd (bf16x3, recompute) %8.2f us   tile 0 vs fp64 host: max |dX err| = %.3g (scale %.3g)   max |wg err| = %.3g (scale %.3g)\n",
+           us, worst_dx, scale_dx, worst_wg, scale_wg);
+  }
   // ---- backward 16 -> 16
   std::vector<float> refdX, refwg;
 #define BWD(NAME, KERNEL, GRIDX)                                                                                      \
@@ -151,5 +215,27 @@ int main(int argc, char** argv) {
     const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd2<true>), dim3(dof_cdiv(S, 64), 2, 2), dim3(256), 0, 0, a16, b16, T); });
     printf("  %-28s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", "k_gru16x_bwd2 (pipelined)", us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg));
   }
+  {
+    CK(hipMemset(B.dX[0], 0, ndX * 4)); CK(hipMemset(B.wg[0], 0, nwg * 4));
+    const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd3<true>), dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, a16, b16, T); });
+    printf("  %-28s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", "k_gru16x_bwd3 (regs, 1 wave)", us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg));
+  }
+  {
+    CK(hipMemset(B.dX[0], 0, ndX * 4)); CK(hipMemset(B.wg[0], 0, nwg * 4));
+    const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd4<true>), dim3(dof_cdiv(S, 64), 2, 2), dim3(256), 0, 0, a16, b16, T); });
+    printf("  %-28s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", "k_gru16x_bwd4 (bf16 wgrad)", us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg));
+  }
+#define CUTRUN(C, NAME)                                                                                               \
+  {                                                                                                                   \
+    const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd3<true, C>), dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, a16, b16, T); }); \
+    printf("  bwd3 cut %-40s %8.2f us\n", NAME, us);                                                                  \
+  }
+  CUTRUN(1, "wgrad (LDS tile + 24 fp32 MFMA)")
+  CUTRUN(2, "dx (9 MFMA + split g_n)")
+  CUTRUN(4, "recompute MFMAs (18)")
+  CUTRUN(8, "transcendentals")
+  CUTRUN(16, "dh MFMAs (9)")
+  CUTRUN(31, "all of the above")
+  CUTRUN(23, "all MFMA, keep transcendentals")
   return 0;
 }
