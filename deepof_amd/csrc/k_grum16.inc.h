@@ -1,29 +1,14 @@
-// Matrix-pipe GRU recurrences of the encoder streams at latent 8: GRU(16 -> 16) forward / backward and GRU(32 -> 8)
-// forward (reference: /root/reference/deepof/clustering/models_new.py:184-278, torch.nn.GRU).
-// Included by k_rnn.hip (inside its anonymous namespace) and by the development probe tools/probe/gru16_probe.hip, so that
-// what is timed in isolation is the product kernel text.
+// Matrix-pipe GRU recurrences of the encoder streams at latent 8: GRU(16 -> 16) and GRU(32 -> 8), forward and backward,
+// on v_mfma_f32_16x16x32_bf16 with exact three-piece operands (reference:
+// /root/reference/deepof/clustering/models_new.py:184-278, torch.nn.GRU).  Included by k_rnn.hip (inside its anonymous
+// namespace) and by the development probe tools/probe/gru16_probe.hip, so that what is timed in isolation is the
+// product kernel text.
 #pragma once
 #ifndef GRU16_WG_FLOATS
 #define GRU16_WG_FLOATS (6 * 256 + 4 * 16)
 #endif
-// ---------------------------------------------------------------------------------------------
-// GRU forward on the matrix pipe (IN = HID = 16; round 3).  A wavefront owns 16 (sequence, direction) pairs: lane
-// l = (b = l >> 4, j = l & 15) holds units 4b .. 4b+3 of sequence j -- the C/D layout of v_mfma_f32_16x16x4_f32
-// (D[4b + r][j] in register r).  One time step is G[unit][seq] = W[unit][k] V[k][seq] with V = [x_t ; h_{t-1}]:
-//   * A operand = a 16 x 4 weight tile, resident in one VGPR per (gate, K-block): 24 registers hold W_ih and W_hh
-//     (the lane-per-unit form above keeps 96 weights per lane and pays one DPP broadcast per FMA);
-//   * B operand = four values of the lane's OWN sequence: K-block q is defined as the indices {q, 4+q, 8+q, 12+q}, so
-//     lane (b, j) contributes V[4b + q][j] -- for x the q-th float of the 16-byte piece it loads, for h the q-th of the
-//     four units it has just computed.  The recurrence never moves data between lanes.
-// 24 MFMAs per step and wavefront (768 matrix-pipe cycles for 16 pairs = 48 per pair and step; the VALU form measures
-// 164) beside ~90 VALU instructions of gate arithmetic on four units per lane.  v_mfma_f32_*_f32 multiplies exact
-// fp32 and accumulates like an fmaf chain (MI355X_MICROARCH.md), so the gates differ from the lane-per-unit kernel only
-// by the summation order over k.  Same saved-gate / output layouts as k_gru3_fwd<16,16>: 16-byte output stores, the
-// four units' (r, z, n, W_hn h + b_hn) words are 64 contiguous bytes.
-// ---------------------------------------------------------------------------------------------
-// One launch serves up to two independent layers of this shape (blockIdx.z: the node and the edge stream of the encoder):
-// a stream of 14,336 sequences is only 1.75 wavefronts per SIMD, and a wavefront's MFMA and VALU phases do not overlap,
-// so two streams side by side finish in little more than the time of one (measured at 4 x the sequences: 3.4 x the time).
+// One launch serves up to two independent layers of the same shape (blockIdx.z: the node and the edge stream of the
+// encoder): a stream of 14,336 sequences is only 1.75 wavefronts per SIMD.
 struct Gru16mStream {
   const float* X; const int* len;
   const float *wih0, *whh0, *bih0, *bhh0, *wih1, *whh1, *bih1, *bhh1;
@@ -32,146 +17,9 @@ struct Gru16mStream {
   int64_t S, Sp;
 };
 
-// NT = (sequence, direction) tiles of 16 per wavefront (they share the 24 weight registers; their recurrences are
-// independent, so one tile's MFMAs can issue while the other's gate arithmetic runs), WPE = wavefronts per SIMD the
-// register allocation is held to.  Round 5: the round-4 form (NT = 1, no bound) compiled to 132 registers = 3 wavefronts
-// per SIMD = 3,072 resident wavefronts for the 3,584 of a C2 launch: a second round of 512 wavefronts on an idle chip
-// doubled the kernel's time.
-template <int NT, int WPE>
-__global__ void __launch_bounds__(64, WPE) k_gru16m_fwd(Gru16mStream sa, Gru16mStream sb, int T) {
-  constexpr int HID = 16, IN = 16;
-  const Gru16mStream& A = blockIdx.z ? sb : sa;
-  const float* __restrict__ X = A.X;
-  const int* __restrict__ len = A.len;
-  float* __restrict__ O = A.O;
-  float* __restrict__ GS = A.GS;
-  const int64_t S = A.S, Sp = A.Sp;
-  if ((int64_t)blockIdx.x * (16 * NT) >= S) return;   // (the grid covers the longer stream)
-  const int lane = threadIdx.x & 63;
-  const int j = lane & 15, b = lane >> 4;
-  const int dir = blockIdx.y;
-  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
-  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
-  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
-  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
-  // A tiles: row i = lane & 15 (a unit), k index = lane >> 4; K-block q covers input / hidden indices 4 (lane >> 4) + q
-  float aix[3][4], ahh[3][4];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      aix[g][q] = wih[(g * HID + j) * IN + 4 * b + q];
-      ahh[g][q] = whh[(g * HID + j) * HID + 4 * b + q];
-    }
-  dof_f32x4 c_r, c_z, c_n, c_hn;  // biases in the D layout: register r <-> unit 4b + r
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int unit = 4 * b + r;
-    c_r[r] = bih[unit] + bhh[unit];
-    c_z[r] = bih[HID + unit] + bhh[HID + unit];
-    c_n[r] = bih[2 * HID + unit];
-    c_hn[r] = bhh[2 * HID + unit];
-  }
-  float* __restrict__ gs = GS ? GS + (int64_t)dir * T * 4 * HID * Sp : nullptr;
-  int64_t s[NT], sr[NT];
-  int n[NT];
-  bool in_range[NT];
-  float h[NT][4];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    s[i] = ((int64_t)blockIdx.x * NT + i) * 16 + j;
-    in_range[i] = s[i] < S;
-    n[i] = in_range[i] ? len[s[i]] : 0;
-    sr[i] = in_range[i] ? s[i] : S - 1;  // lanes past the end (and finished sequences) read a valid row: loads stay
-                                         // unconditional (a branch around a load costs a vmcnt(0) at the join)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h[i][r] = 0.0f;
-  }
-  // x_t is loaded PF steps ahead into static register slots (the loop is unrolled by PF): a rotating copy made the
-  // compiler wait `vmcnt(0)` at every loop back-edge -- one exposed HBM round trip (~1.8 us) per time step
-  constexpr int PF = 4;
-  float xs[NT][PF][4];
-  auto load_x = [&](auto tile_c, auto slot_c, int step) {
-    constexpr int i = decltype(tile_c)::value;
-    constexpr int slot = decltype(slot_c)::value;
-    const int t = step < n[i] ? (dir ? (n[i] - 1 - step) : step) : 0;
-    dof_ld_row<4>(X + ACT(t, 4 * b, IN, Sp, sr[i]), xs[i][slot]);
-  };
-  // input halves of the gates: they do not depend on the recurrence and are issued one step ahead, so the matrix pipe
-  // has independent work while the gate arithmetic of the current step runs on the VALU
-  dof_f32x4 g_r[NT], g_z[NT], g_n[NT];
-  auto input_half = [&](auto tile_c, const float* xq) {
-    constexpr int i = decltype(tile_c)::value;
-    g_r[i] = c_r; g_z[i] = c_z; g_n[i] = c_n;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      g_r[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aix[0][q], xq[q], g_r[i], 0, 0, 0);
-      g_z[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aix[1][q], xq[q], g_z[i], 0, 0, 0);
-      g_n[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aix[2][q], xq[q], g_n[i], 0, 0, 0);
-    }
-  };
-  auto do_step = [&](auto slot_c, int step) {   // slot = step % PF holds x of this step
-    constexpr int slot = decltype(slot_c)::value;
-    constexpr int next = (slot + 1) % PF;
-    dof_f32x4 a_r[NT], a_z[NT], a_hn[NT], a_n[NT];
-    dof_static_for<NT>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      a_r[i] = g_r[i]; a_z[i] = g_z[i]; a_hn[i] = c_hn; a_n[i] = g_n[i];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a_r[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][q], h[i][q], a_r[i], 0, 0, 0);
-        a_z[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][q], h[i][q], a_z[i], 0, 0, 0);
-        a_hn[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[2][q], h[i][q], a_hn[i], 0, 0, 0);
-      }
-    });
-    dof_static_for<NT>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      input_half(ic, xs[i][next]);   // next step's input half (its x arrived PF - 1 steps ago)
-      load_x(ic, slot_c, step + PF); // this step's slot is free again
-    });
-    dof_static_for<NT>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const bool act = step < n[i];
-      float gate16[16];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float rr = dof_sigmoid(a_r[i][r]);
-        const float zz = dof_sigmoid(a_z[i][r]);
-        const float nn = dof_tanh(fmaf(rr, a_hn[i][r], a_n[i][r]));
-        const float hnew = fmaf(zz, h[i][r] - nn, nn);
-        h[i][r] = act ? hnew : h[i][r];
-        gate16[4 * r] = rr; gate16[4 * r + 1] = zz; gate16[4 * r + 2] = nn; gate16[4 * r + 3] = a_hn[i][r];
-      }
-      if (act) {
-        const int t = dir ? (n[i] - 1 - step) : step;
-        dof_st_row<4>(O + ACT(t, dir * HID + 4 * b, 2 * HID, Sp, s[i]), h[i]);
-        if (gs) dof_st_row<16>(gs + ACT(t, 16 * b, 4 * HID, Sp, s[i]), gate16);
-      }
-    });
-  };
-  dof_static_for<NT>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    dof_static_for<PF>([&](auto d) { load_x(ic, d, decltype(d)::value); });
-  });
-  dof_static_for<NT>([&](auto ic) { input_half(ic, xs[decltype(ic)::value][0]); });
-  for (int step = 0; step < T; step += PF) {  // wave-uniform trip count: MFMA ignores EXEC, finished sequences idle
-    // (no exit inside the unrolled group: steps >= T are idle steps -- n <= T -- and cost nothing to keep; with exits
-    //  the compiler drained the memory counter at the loop header)
-    dof_static_for<PF>([&](auto d) { do_step(d, step + decltype(d)::value); });
-  }
-  const float zero16[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-    if (in_range[i])
-      for (int t = n[i]; t < T; ++t) {
-        dof_st_row<4>(O + ACT(t, dir * HID + 4 * b, 2 * HID, Sp, s[i]), zero16);
-        if (gs) dof_st_row<16>(gs + ACT(t, 16 * b, 4 * HID, Sp, s[i]), zero16);
-      }
-}
-
 // ---------------------------------------------------------------------------------------------
 // GRU(16 -> 16) forward on the bf16 matrix pipe with EXACT three-piece operands (round 5).  Same lane mapping, loads,
-// stores and gate arithmetic as k_gru16m_fwd; what changes is how G = W [x_t ; h_{t-1}] is multiplied.  Measured on
+// stores and gate arithmetic as k_gru16x_fwd; what changes is how G = W [x_t ; h_{t-1}] is multiplied.  Measured on
 // MI355X (tools/probe/gru16_probe.hip): v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate, costs 40 cycles in these
 // dependent chains and does not overlap the gate arithmetic of any wavefront of its SIMD -- the 24 of a step were 2/3 of
 // the kernel.  Here every fp32 value is cut into three bf16 pieces (v = p0 + p1 + p2 exactly: 8 + 8 + 8 significand
@@ -251,7 +99,11 @@ __global__ void __launch_bounds__(64, WPE) k_gru16x_fwd(Gru16mStream sa, Gru16mS
   const int n = in_range ? len[s] : 0;
   float h[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   uint32_t hw[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};   // pieces of h
-  constexpr int PF = 4;   // x_t loaded PF steps ahead into static register slots (see k_gru16m_fwd)
+  // x_t is loaded PF steps ahead into static register slots (the loop is unrolled by PF): a rotating copy made the
+  // compiler wait `vmcnt(0)` at every loop back-edge -- one exposed HBM round trip (~1.8 us) per time step.  Loads are
+  // unconditional (lanes past the end and finished sequences read a valid row): a branch around a load costs a
+  // vmcnt(0) at the join.
+  constexpr int PF = 4;
   float xs[PF][4];
   const int64_t sr = in_range ? s : S - 1;
   auto load_x = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
@@ -333,319 +185,8 @@ __global__ void __launch_bounds__(64, WPE) k_gru16x_fwd(Gru16mStream sa, Gru16mS
 }
 
 // ---------------------------------------------------------------------------------------------
-// GRU forward on the matrix pipe for the second encoder layer of latent 8 (IN = 32, HID = 8; round 4), the twin of
-// k_gru16m_fwd.  Eight units per direction fill half a 16-row tile, so two GATES share a tile and the rows are ordered by
-// OWNER: lane (b, j) of the D layout (rows 4b .. 4b+3, column j) owns units 2b and 2b+1 of sequence j and receives
-//   tile 1 rows 4b + (0, 1, 2, 3) = r_{2b}, r_{2b+1}, z_{2b}, z_{2b+1},   tile 2 = nx_{2b}, nx_{2b+1}, hn_{2b}, hn_{2b+1}
-// (nx = W_in x + b_in, hn = W_hn h + b_hn: the A tile holds zeros where a row does not take that half of [x ; h]) -- all
-// four pre-activations of a unit in ONE lane, no exchange for the gate arithmetic.  K blocks are again the lane's own
-// values: block q of the input half = channels {q, 8+q, 16+q, 24+q} (lane b loads x[8b .. 8b+7]: two 16-byte loads),
-// block q of the hidden half = units {q, 2+q, 4+q, 6+q} (the two units the lane has just computed).  16 + 4 MFMAs per
-// step for 16 (sequence, direction) pairs; the input half runs one step ahead.  Writes the same hidden-state and
-// unit-major gate buffers as k_gru3_fwd<32, 8> (a lane's two units: 32 contiguous bytes), so k_gru8_bwd_fused is
-// unchanged; sums over k in another order than the lane-per-unit kernel (ulp-level differences).
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_gru8m_fwd(Gru16mStream sa, Gru16mStream sb, int T) {
-  constexpr int HID = 8, IN = 32;
-  const Gru16mStream& A = blockIdx.z ? sb : sa;
-  const float* __restrict__ X = A.X;
-  const int* __restrict__ len = A.len;
-  float* __restrict__ O = A.O;
-  float* __restrict__ GS = A.GS;
-  const int64_t S = A.S, Sp = A.Sp;
-  if ((int64_t)blockIdx.x * 16 >= S) return;   // (the grid covers the longer stream)
-  const int lane = threadIdx.x & 63;
-  const int j = lane & 15, b = lane >> 4;
-  const int64_t s = (int64_t)blockIdx.x * 16 + j;
-  const int dir = blockIdx.y;
-  const bool in_range = s < S;
-  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
-  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
-  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
-  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
-  // A tiles: row i = lane & 15 -> owner (i >> 2), slot (i & 3): gate half (slot >> 1), unit 2 (i >> 2) + (slot & 1);
-  // k index = lane >> 4: input channel 8k + q / hidden unit 2k + q of K block q
-  const int arow_unit = 2 * (j >> 2) + (j & 1), arow_hi = (j >> 1) & 1;   // hi: z (tile 1) / hn (tile 2)
-  float a1x[8], a2x[8], a1h[2], a2h[2];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    a1x[q] = wih[((arow_hi ? 1 : 0) * HID + arow_unit) * IN + 8 * b + q];
-    a2x[q] = arow_hi ? 0.0f : wih[(2 * HID + arow_unit) * IN + 8 * b + q];
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    a1h[q] = whh[((arow_hi ? 1 : 0) * HID + arow_unit) * HID + 2 * b + q];
-    a2h[q] = arow_hi ? whh[(2 * HID + arow_unit) * HID + 2 * b + q] : 0.0f;
-  }
-  dof_f32x4 c1, c2;  // biases in the D layout of this lane's two units
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int unit = 2 * b + m;
-    c1[m] = bih[unit] + bhh[unit];
-    c1[2 + m] = bih[HID + unit] + bhh[HID + unit];
-    c2[m] = bih[2 * HID + unit];
-    c2[2 + m] = bhh[2 * HID + unit];
-  }
-  float* __restrict__ gs = GS ? GS + (int64_t)dir * T * 4 * HID * Sp : nullptr;
-  const int n = in_range ? len[s] : 0;
-  float h[2] = {0.0f, 0.0f};
-  constexpr int PF = 4;   // x_t loaded PF steps ahead into static register slots (see k_gru16m_fwd)
-  float xs[PF][8];
-  const int64_t sr = in_range ? s : S - 1;
-  auto load_x = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    const int t = step < n ? (dir ? (n - 1 - step) : step) : 0;
-    dof_ld_row<8>(X + ACT(t, 8 * b, IN, Sp, sr), xs[slot]);
-  };
-  dof_f32x4 g1, g2;
-  auto input_half = [&](const float* xq) {
-    g1 = c1; g2 = c2;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1x[q], xq[q], g1, 0, 0, 0);
-      g2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2x[q], xq[q], g2, 0, 0, 0);
-    }
-  };
-  auto do_step = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    constexpr int next = (slot + 1) % PF;
-    dof_f32x4 a1 = g1, a2 = g2;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q], h[q], a1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2h[q], h[q], a2, 0, 0, 0);
-    }
-    input_half(xs[next]);          // next step's input half (its x arrived PF - 1 steps ago)
-    load_x(slot_c, step + PF);     // this step's slot is free again
-    const bool act = step < n;
-    float gate8[8];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const float rr = dof_sigmoid(a1[m]);
-      const float zz = dof_sigmoid(a1[2 + m]);
-      const float hn = a2[2 + m];
-      const float nn = dof_tanh(fmaf(rr, hn, a2[m]));
-      const float hnew = fmaf(zz, h[m] - nn, nn);
-      h[m] = act ? hnew : h[m];
-      gate8[4 * m] = rr; gate8[4 * m + 1] = zz; gate8[4 * m + 2] = nn; gate8[4 * m + 3] = hn;
-    }
-    if (act) {
-      const int t = dir ? (n - 1 - step) : step;
-      dof_st_pair(O + ACT(t, dir * HID + 2 * b, 2 * HID, Sp, s), h[0], h[1]);
-      if (gs) dof_st_row<8>(gs + ACT(t, 8 * b, 4 * HID, Sp, s), gate8);
-    }
-  };
-  dof_static_for<PF>([&](auto d) { load_x(d, decltype(d)::value); });
-  input_half(xs[0]);
-  for (int step = 0; step < T; step += PF) {  // wave-uniform trip count: MFMA ignores EXEC, finished sequences idle
-    dof_static_for<PF>([&](auto d) { do_step(d, step + decltype(d)::value); });
-  }
-  if (in_range) {
-    const float zero8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int t = n; t < T; ++t) {
-      dof_st_pair(O + ACT(t, dir * HID + 2 * b, 2 * HID, Sp, s), 0.0f, 0.0f);
-      if (gs) dof_st_row<8>(gs + ACT(t, 8 * b, 4 * HID, Sp, s), zero8);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// GRU backward on the matrix pipe (IN = HID = 16), gates RECOMPUTED (round 3): the twin of k_gru16m_fwd.
-// The forward pass of this layer saves no gates any more -- four floats per unit and step, 229 MB written per encoder
-// stream and read back here, were the largest traffic item of the C2 step and both kernels ran at the per-CU
-// load/store issue limit (~7-10 B/clk/CU), not at any arithmetic limit.  Here a step reads x_t, h_{t-1} and dO_t
-// (3 x 16 B per lane), recomputes the gate pre-activations with the SAME 24 MFMAs in the same order as the forward
-// kernel (bitwise the same r, z, n), and runs the transposed products on the matrix pipe too:
-//   dh_{t-1} = dht * z + W_hh^T [g_r, g_z, g_h],   dx_t = W_ih^T [g_r, g_z, g_n]
-// with A = a transposed weight tile (row = the output index, K-block q = gate units {q, 4+q, 8+q, 12+q}) and B = the
-// lane's own four gate gradients: again no data moves between lanes, and the result lands in the lane that owns those
-// units / input channels (one 16-byte dX store).
-// Weight gradients contract over the SEQUENCE index, which is the lane index here: the step's gate gradients, x_t and
-// h_{t-1} go through a 6 KB LDS tile ([sequence][unit], written as 16-byte words, read back as MFMA operands with the
-// sequence as K) -- 24 more MFMAs into six 16 x 16 accumulator tiles that stay in registers for the whole sequence.
-// 72 MFMAs per step and wavefront = 144 matrix-pipe cycles per (sequence, direction) and step (the VALU form: ~230
-// VALU instructions per four pairs).  Per-wavefront partials in k_gru16_bwd_fused's layout -> k_gru16_wg_finalize.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_gru16m_bwd(Gru16mStream st_a, Gru16mStream st_b, int T) {
-  constexpr int HID = 16, IN = 16;
-  __shared__ __attribute__((aligned(16))) float tile[6][16][16];  // [g_r, g_z, g_n, g_h, x, h_prev][sequence][unit]
-  const Gru16mStream& A = blockIdx.z ? st_b : st_a;
-  const float* __restrict__ X = A.X;
-  const int* __restrict__ len = A.len;
-  const float* __restrict__ O = A.O;
-  const float* __restrict__ dO = A.dO;
-  float* __restrict__ dX = A.dX;
-  float* __restrict__ wg_partial = A.wg_partial;
-  const int64_t S = A.S, Sp = A.Sp;
-  if ((int64_t)blockIdx.x * 16 >= S) return;   // (the grid covers the longer stream; whole workgroups leave)
-  const unsigned nblk_own = (unsigned)((S + 15) / 16);   // partial rows of THIS stream (gridDim.x may be the other stream's)
-  const int lane = threadIdx.x & 63;
-  const int j = lane & 15, b = lane >> 4;
-  const int64_t s = (int64_t)blockIdx.x * 16 + j;
-  const int dir = blockIdx.y;
-  const bool in_range = s < S;
-  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
-  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
-  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
-  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
-  // forward tiles (row = unit lane & 15, K-block q = indices 4 (lane >> 4) + q) and transposed tiles (row = input /
-  // hidden index lane & 15, K-block q = gate units 4 (lane >> 4) + q)
-  float aix[3][4], ahh[3][4], tix[3][4], thh[3][4];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      aix[g][q] = wih[(g * HID + j) * IN + 4 * b + q];
-      ahh[g][q] = whh[(g * HID + j) * HID + 4 * b + q];
-      tix[g][q] = wih[(g * HID + 4 * b + q) * IN + j];
-      thh[g][q] = whh[(g * HID + 4 * b + q) * HID + j];
-    }
-  dof_f32x4 c_r, c_z, c_n, c_hn;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int unit = 4 * b + r;
-    c_r[r] = bih[unit] + bhh[unit];
-    c_z[r] = bih[HID + unit] + bhh[HID + unit];
-    c_n[r] = bih[2 * HID + unit];
-    c_hn[r] = bhh[2 * HID + unit];
-  }
-  float* __restrict__ dx_out = dX + (int64_t)dir * T * IN * Sp;
-  const int n = in_range ? len[s] : 0;
-  float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  dof_f32x4 acc[6];
-#pragma unroll
-  for (int a = 0; a < 6; ++a) acc[a] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  float sb[4][4];  // bias sums [r, z, n, h][unit 4b + r]
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sb[g][r] = 0.0f;
-  // operands of a step: x_t, h_{t-1}, dO_t -- none depends on the recurrence; loaded PF steps ahead into static
-  // register slots (loop unrolled by PF; see k_gru16m_fwd)
-  constexpr int PF = 3;
-  float nx_x[PF][4], nx_h[PF][4], nx_d[PF][4];
-  const int64_t sr = in_range ? s : S - 1;  // loads are unconditional (a branch around a load costs a vmcnt(0) at the
-                                            // join): idle lanes read a valid row and their values are zeroed at use
-  auto issue_loads = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    const bool live = step >= 0 && step < n;
-    const int t = live ? (dir ? (n - 1 - step) : step) : 0;
-    const int tp = (live && step > 0) ? (dir ? t + 1 : t - 1) : 0;
-    dof_ld_row<4>(X + ACT(t, 4 * b, IN, Sp, sr), nx_x[slot]);
-    dof_ld_row<4>(O + ACT(tp, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_h[slot]);
-    if (dO) dof_ld_row<4>(dO + ACT(t, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_d[slot]);   // (wave-uniform condition)
-    else nx_d[slot][0] = nx_d[slot][1] = nx_d[slot][2] = nx_d[slot][3] = 0.0f;
-  };
-  auto do_step = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    const bool act = step < n;
-    float xv[4], hp[4], dov[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      xv[q] = act ? nx_x[slot][q] : 0.0f;
-      hp[q] = (act && step > 0) ? nx_h[slot][q] : 0.0f;
-      dov[q] = act ? nx_d[slot][q] : 0.0f;
-    }
-    issue_loads(slot_c, step - PF);
-    // ---- gates, recomputed exactly as k_gru16m_fwd computes them (input half first, then the hidden half)
-    dof_f32x4 a_r = c_r, a_z = c_z, a_n = c_n, a_hn = c_hn;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      a_r = __builtin_amdgcn_mfma_f32_16x16x4f32(aix[0][q], xv[q], a_r, 0, 0, 0);
-      a_z = __builtin_amdgcn_mfma_f32_16x16x4f32(aix[1][q], xv[q], a_z, 0, 0, 0);
-      a_n = __builtin_amdgcn_mfma_f32_16x16x4f32(aix[2][q], xv[q], a_n, 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      a_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][q], hp[q], a_r, 0, 0, 0);
-      a_z = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][q], hp[q], a_z, 0, 0, 0);
-      a_hn = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[2][q], hp[q], a_hn, 0, 0, 0);
-    }
-    float g_r[4], g_z[4], g_n[4], g_h[4];
-    dof_f32x4 d_h, d_x = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float rr = dof_sigmoid(a_r[r]);
-      const float z = dof_sigmoid(a_z[r]);
-      const float nn = dof_tanh(fmaf(rr, a_hn[r], a_n[r]));
-      const float dht = act ? dh[r] + dov[r] : 0.0f;
-      const float dn = dht * (1.0f - z);
-      const float dz = dht * (hp[r] - nn);
-      const float dnp = dn * (1.0f - nn * nn);
-      g_r[r] = act ? dnp * a_hn[r] * rr * (1.0f - rr) : 0.0f;
-      g_z[r] = act ? dz * z * (1.0f - z) : 0.0f;
-      g_n[r] = act ? dnp : 0.0f;
-      g_h[r] = act ? dnp * rr : 0.0f;
-      d_h[r] = dht * z;
-      sb[0][r] += g_r[r]; sb[1][r] += g_z[r]; sb[2][r] += g_n[r]; sb[3][r] += g_h[r];
-    }
-    // ---- dh_{t-1} and dx_t: transposed tiles x the lane's own gate gradients
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      d_h = __builtin_amdgcn_mfma_f32_16x16x4f32(thh[0][q], g_r[q], d_h, 0, 0, 0);
-      d_h = __builtin_amdgcn_mfma_f32_16x16x4f32(thh[1][q], g_z[q], d_h, 0, 0, 0);
-      d_h = __builtin_amdgcn_mfma_f32_16x16x4f32(thh[2][q], g_h[q], d_h, 0, 0, 0);
-      d_x = __builtin_amdgcn_mfma_f32_16x16x4f32(tix[0][q], g_r[q], d_x, 0, 0, 0);
-      d_x = __builtin_amdgcn_mfma_f32_16x16x4f32(tix[1][q], g_z[q], d_x, 0, 0, 0);
-      d_x = __builtin_amdgcn_mfma_f32_16x16x4f32(tix[2][q], g_n[q], d_x, 0, 0, 0);
-    }
-    // ---- weight gradients: contraction over the 16 sequences of the wavefront through the LDS tile
-    __syncthreads();  // (one wavefront per workgroup: orders this step's writes after the previous step's reads)
-    dof_st_row<4>(&tile[0][j][4 * b], g_r);
-    dof_st_row<4>(&tile[1][j][4 * b], g_z);
-    dof_st_row<4>(&tile[2][j][4 * b], g_n);
-    dof_st_row<4>(&tile[3][j][4 * b], g_h);
-    dof_st_row<4>(&tile[4][j][4 * b], xv);
-    dof_st_row<4>(&tile[5][j][4 * b], hp);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // K-block q = sequences 4q .. 4q+3; A row = unit j, B column = input / hidden index j
-      const float ar_ = tile[0][4 * q + b][j], az_ = tile[1][4 * q + b][j], an_ = tile[2][4 * q + b][j];
-      const float ah_ = tile[3][4 * q + b][j], bx_ = tile[4][4 * q + b][j], bh_ = tile[5][4 * q + b][j];
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar_, bx_, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az_, bx_, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(an_, bx_, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar_, bh_, acc[3], 0, 0, 0);
-      acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(az_, bh_, acc[4], 0, 0, 0);
-      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah_, bh_, acc[5], 0, 0, 0);
-    }
-    if (act) {
-      const int t = dir ? (n - 1 - step) : step;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dh[r] = d_h[r];
-      const float dx4[4] = {d_x[0], d_x[1], d_x[2], d_x[3]};
-      dof_st_row<4>(dx_out + ACT(t, 4 * b, IN, Sp, s), dx4);
-    }
-  };
-  // the loop starts at the first multiple of PF >= T: steps >= T (>= n) are idle, so that the unrolled group needs no
-  // exit (with exits the compiler drained the memory counter at the loop header)
-  const int top = (T + PF - 1) / PF * PF - 1;
-  dof_static_for<PF>([&](auto d) { issue_loads(d, top - decltype(d)::value); });
-  for (int step = top; step >= 0; step -= PF) {  // wave-uniform trip count (MFMA ignores EXEC)
-    dof_static_for<PF>([&](auto d) { do_step(d, step - decltype(d)::value); });
-  }
-  if (in_range) {
-    const float zero4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int t = n; t < T; ++t) dof_st_row<4>(dx_out + ACT(t, 4 * b, IN, Sp, s), zero4);
-  }
-  // ---- partials of this wavefront's 16 sequences: tiles [a][row = unit][col], then the bias sums [gate][unit]
-  float* __restrict__ out = wg_partial + ((int64_t)dir * nblk_own + blockIdx.x) * GRU16_WG_FLOATS;
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[a * 256 + (4 * b + r) * 16 + j] = acc[a][r];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = dof_row16_sum(sb[g][r]);  // over the 16 sequences (lanes of a DPP row share b)
-      if (j == 0) out[6 * 256 + g * 16 + 4 * b + r] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // GRU(32 -> 8) forward on the bf16 matrix pipe with exact three-piece operands (round 5): the second encoder layer of
-// latent 8, the twin of k_gru16x_fwd in k_gru8m_fwd's lane mapping.  Lane (b, j) owns units 2b and 2b+1 of sequence j;
+// latent 8, the twin of k_gru16x_fwd in round 4's lane mapping.  Lane (b, j) owns units 2b and 2b+1 of sequence j;
 // the two 16-row tiles are ordered by owner, D rows 4b + (0, 1, 2, 3) =
 //   tile 1: r_{2b}, r_{2b+1}, z_{2b}, z_{2b+1}       tile 2: nx_{2b}, nx_{2b+1}, hn_{2b}, hn_{2b+1}
 // (nx = W_in x + b_in, hn = W_hn h + b_hn; the A operand holds zeros where a row does not take that half of [x ; h]).
@@ -736,7 +277,7 @@ __global__ void __launch_bounds__(64, WPE) k_gru8x_fwd(Gru16mStream sa, Gru16mSt
   const int n = in_range ? len[s] : 0;
   float h[2] = {0.0f, 0.0f};
   uint32_t hw[3] = {0u, 0u, 0u};
-  constexpr int PF = 4;   // x_t loaded PF steps ahead into static register slots (see k_gru16m_fwd)
+  constexpr int PF = 4;   // x_t loaded PF steps ahead into static register slots (see k_gru16x_fwd)
   float xs[PF][8];
   const int64_t sr = in_range ? s : S - 1;
   auto load_x = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
@@ -1094,545 +635,26 @@ __global__ void __launch_bounds__(64, 2) k_gru8x_bwd(Gru16mStream st_a, Gru16mSt
 
 // ---------------------------------------------------------------------------------------------
 // GRU(16 -> 16) backward on the bf16 matrix pipe with exact three-piece operands (round 5): the twin of k_gru16x_fwd.
-// Same lane mapping and data flow as k_gru16m_bwd (gates recomputed, transposed products for dh_{t-1} and dx_t from the
-// lane's own gate gradients, weight gradients through the LDS tile); the recompute is k_gru16x_fwd's 18 MFMAs in its
-// order (bitwise the same r, z, n), and the transposed products are 18 more:
-//   [dh | dx] parts of gates r, z: K-block b = the lane's own [g_r(4) ; g_z(4)], A = the same K order of the
-//   transposed [W_r | W_z] rows, six piece products each; the n gate's halves (W_hn^T g_h for dh, W_in^T g_n for dx)
-//   pack two piece products into K = 32 like the forward kernel's n halves.
-// Each of dh and dx is collected in three independent accumulators (chains of 3 MFMAs) and summed on the VALU.  The
-// weight-gradient contraction over the sequences stays on v_mfma_f32_16x16x4_f32 through the 6 KB LDS tile (round 4).
-// The time loop has no branch (stores unconditional, see k_gru16x_fwd); HAS_DO: the layer receives dO (compile time).
+// A workgroup = four wavefronts, each an independent tile of 16 (sequence, direction) pairs in k_gru16x_fwd's lane
+// mapping; the 24 MFMA weight operands (4 words per lane: 96 registers if held) live in LDS and are shared by the four.
+// Per step and wavefront:
+//   * recompute: k_gru16x_fwd's 18 MFMAs in its order (bitwise the same r, z, n) from x_t and h_{t-1} -- issued for
+//     step t - 1 in the same scheduling region as the dh chain of step t (nothing in it depends on the recurrence);
+//   * gate gradients on the VALU (inactive steps need no selects: with dO zeroed for them every gate gradient is
+//     exactly zero, dh stays zero and the dX row written is the zero row);
+//   * [dh | dx] parts of gates r, z: K-block b = the lane's own [g_r(4) ; g_z(4)], A = the same K order of the transposed
+//     [W_r | W_z] rows, six piece products each; the n gate's halves (W_hn^T g_h for dh, W_in^T g_n for dx) pack two piece
+//     products into K = 32 like the forward kernel's n halves: 18 MFMAs, each of dh and dx in three independent
+//     accumulators (chains of 3) summed on the VALU;
+//   * weight gradients: contraction over the 16 sequences -- the step's 96 values per sequence go through a 9 KB LDS
+//     image transposed and cut into pieces ([piece][value][sequence] bf16, 2-byte stores of register high halves) and
+//     return as K = 32 = (two piece products) x (16 sequences) operands: 18 MFMAs into six accumulator tiles.
+// 54 v_mfma_f32_16x16x32_bf16 per step against round 4's 72 v_mfma_f32_16x16x4_f32 at 2.5 x the time each.  Measured on
+// MI355X (tools/probe/gru16_probe.hip, both streams of C2): 215 us (round 4) -> 173 us.  The time loop has no branch
+// (stores unconditional, see k_gru16x_fwd); HAS_DO: the layer receives dO (compile time).
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_DO>
 __global__ void __launch_bounds__(256, 2) k_gru16x_bwd(Gru16mStream st_a, Gru16mStream st_b, int T) {
-  constexpr int HID = 16, IN = 16;
-  // The 24 MFMA weight operands (4 words per lane) live in LDS, shared by the four wavefronts of the workgroup (each an
-  // independent tile of 16 sequences): in registers they were 96 of the kernel's ~330 and held it to one wavefront per
-  // SIMD.  [operand][lane]: a wave-wide read is 1 KB contiguous.
-  __shared__ __attribute__((aligned(16))) uint32_t wop[24][64][4];
-  __shared__ __attribute__((aligned(16))) float tiles[4][6][16][16];  // per wavefront: [g_r, g_z, g_n, g_h, x, h_prev][sequence][unit]
-  const Gru16mStream& A = blockIdx.z ? st_b : st_a;
-  const float* __restrict__ X = A.X;
-  const int* __restrict__ len = A.len;
-  const float* __restrict__ O = A.O;
-  const float* __restrict__ dO = A.dO;
-  float* __restrict__ dX = A.dX;
-  float* __restrict__ wg_partial = A.wg_partial;
-  const int64_t S = A.S, Sp = A.Sp;
-  if ((int64_t)blockIdx.x * 64 >= S) return;   // (the grid covers the longer stream; whole workgroups leave)
-  const unsigned nblk_own = (unsigned)((S + 15) / 16);   // partial rows of THIS stream: one per wavefront tile
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, b = lane >> 4;
-  const int64_t tile_idx = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t s = tile_idx * 16 + j;
-  const int dir = blockIdx.y;
-  const bool in_range = s < S;
-  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
-  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
-  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
-  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
-  // operands 0-5: forward [W_ih | W_hh] of gates r, z, three pieces each; 6-8 / 9-11: the n gate's input / hidden halves
-  // (W0|W0), (W1|W0), (W2|W1); 12-14 / 15-17: transposed [W_r | W_z] rows for dh / dx (row = hidden / input index j,
-  // K-block b = gate units 4b .. 4b+3); 18-20 / 21-23: W_hn^T / W_in^T.  Wavefront w prepares operands 6w .. 6w+5.
-  {
-    auto put = [&](int o, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) DOF_INLINE_LAMBDA {
-      wop[o][lane][0] = w0; wop[o][lane][1] = w1; wop[o][lane][2] = w2; wop[o][lane][3] = w3;
-    };
-    const bool transposed = wave >= 2;
-    auto rows = [&](const float* __restrict__ w, int g, uint32_t (&out)[3][2]) DOF_INLINE_LAMBDA {
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = transposed ? w[(g * HID + 4 * b + q) * 16 + j] : w[(g * HID + j) * 16 + 4 * b + q];
-      dof_split3x4(v, out);
-    };
-    if ((wave & 1) == 0) {   // gates r, z: (input | hidden) per piece (forward), (r | z) per piece (transposed)
-      uint32_t i0[3][2], i1[3][2], h0[3][2], h1[3][2];
-      rows(wih, 0, i0); rows(wih, 1, i1); rows(whh, 0, h0); rows(whh, 1, h1);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        if (!transposed) {
-          put(p, i0[p][0], i0[p][1], h0[p][0], h0[p][1]);
-          put(3 + p, i1[p][0], i1[p][1], h1[p][0], h1[p][1]);
-        } else {
-          put(12 + p, h0[p][0], h0[p][1], h1[p][0], h1[p][1]);
-          put(15 + p, i0[p][0], i0[p][1], i1[p][0], i1[p][1]);
-        }
-      }
-    } else {                 // gate n: two piece products per operand
-      uint32_t i2[3][2], h2[3][2];
-      rows(wih, 2, i2); rows(whh, 2, h2);
-      const int oi = transposed ? 21 : 6, oh = transposed ? 18 : 9;
-      put(oi + 0, i2[0][0], i2[0][1], i2[0][0], i2[0][1]);
-      put(oi + 1, i2[1][0], i2[1][1], i2[0][0], i2[0][1]);
-      put(oi + 2, i2[2][0], i2[2][1], i2[1][0], i2[1][1]);
-      put(oh + 0, h2[0][0], h2[0][1], h2[0][0], h2[0][1]);
-      put(oh + 1, h2[1][0], h2[1][1], h2[0][0], h2[0][1]);
-      put(oh + 2, h2[2][0], h2[2][1], h2[1][0], h2[1][1]);
-    }
-  }
-  __syncthreads();
-  if (tile_idx * 16 >= S) return;   // (a wavefront without sequences; no workgroup barrier below)
-  float (*tile)[16][16] = tiles[wave];
-  auto W = [&](int o) DOF_INLINE_LAMBDA { return dof_ld_bf16x8(reinterpret_cast<const uint16_t*>(&wop[o][lane][0])); };
-  dof_f32x4 c_r, c_z, c_n, c_hn;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int unit = 4 * b + r;
-    c_r[r] = bih[unit] + bhh[unit];
-    c_z[r] = bih[HID + unit] + bhh[HID + unit];
-    c_n[r] = bih[2 * HID + unit];
-    c_hn[r] = bhh[2 * HID + unit];
-  }
-  float* __restrict__ dx_out = dX + (int64_t)dir * T * IN * Sp;
-  const int n = in_range ? len[s] : 0;
-  float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  dof_f32x4 acc[6];
-#pragma unroll
-  for (int a = 0; a < 6; ++a) acc[a] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  float sbj[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // bias sums [r, z, n, h] of unit j over the sequences {b, 4 + b, 8 + b, 12 + b}
-  constexpr int PF = 3;   // x_t, h_{t-1}, dO_t loaded PF steps ahead into static register slots (see k_gru16m_fwd)
-  float nx_x[PF][4], nx_h[PF][4], nx_d[PF][4];
-  const int64_t sr = in_range ? s : S - 1;  // idle lanes read a valid row, their values are zeroed at use
-  auto issue_loads = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    const bool live = step >= 0 && step < n;
-    const int t = live ? (dir ? (n - 1 - step) : step) : 0;
-    const int tp = (live && step > 0) ? (dir ? t + 1 : t - 1) : 0;
-    dof_ld_row<4>(X + ACT(t, 4 * b, IN, Sp, sr), nx_x[slot]);
-    dof_ld_row<4>(O + ACT(tp, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_h[slot]);
-    if constexpr (HAS_DO) dof_ld_row<4>(dO + ACT(t, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_d[slot]);
-    else nx_d[slot][0] = nx_d[slot][1] = nx_d[slot][2] = nx_d[slot][3] = 0.0f;
-  };
-  auto do_step = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    const bool act = step < n;
-    float xv[4], hp[4], dov[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      xv[q] = act ? nx_x[slot][q] : 0.0f;
-      hp[q] = (act && step > 0) ? nx_h[slot][q] : 0.0f;
-      dov[q] = act ? nx_d[slot][q] : 0.0f;
-    }
-    issue_loads(slot_c, step - PF);
-    // ---- gates, recomputed exactly as k_gru16x_fwd computes them
-    uint32_t xw[3][2], hw[3][2];
-    dof_split3x4(xv, xw);
-    dof_split3x4(hp, hw);
-    dof_f32x4 a_r = c_r, a_z = c_z, a_n = c_n, a_hn_ = c_hn;
-    {
-      const dof_bf16x8 x01 = dof_mk_bf16x8(xw[0][0], xw[0][1], xw[1][0], xw[1][1]);
-      const dof_bf16x8 x02 = dof_mk_bf16x8(xw[0][0], xw[0][1], xw[2][0], xw[2][1]);
-      a_n = DOF_MFMA_16x16x32_BF16(W(8), x01, a_n);
-      a_n = DOF_MFMA_16x16x32_BF16(W(7), x02, a_n);
-      a_n = DOF_MFMA_16x16x32_BF16(W(6), x01, a_n);
-      const dof_bf16x8 b0 = dof_mk_bf16x8(xw[0][0], xw[0][1], hw[0][0], hw[0][1]);
-      const dof_bf16x8 b1 = dof_mk_bf16x8(xw[1][0], xw[1][1], hw[1][0], hw[1][1]);
-      const dof_bf16x8 b2 = dof_mk_bf16x8(xw[2][0], xw[2][1], hw[2][0], hw[2][1]);
-      const dof_bf16x8 h01 = dof_mk_bf16x8(hw[0][0], hw[0][1], hw[1][0], hw[1][1]);
-      const dof_bf16x8 h02 = dof_mk_bf16x8(hw[0][0], hw[0][1], hw[2][0], hw[2][1]);
-      a_r = DOF_MFMA_16x16x32_BF16(W(0), b2, a_r);
-      a_z = DOF_MFMA_16x16x32_BF16(W(3), b2, a_z);
-      a_hn_ = DOF_MFMA_16x16x32_BF16(W(11), h01, a_hn_);
-      a_r = DOF_MFMA_16x16x32_BF16(W(2), b0, a_r);
-      a_z = DOF_MFMA_16x16x32_BF16(W(5), b0, a_z);
-      a_hn_ = DOF_MFMA_16x16x32_BF16(W(10), h02, a_hn_);
-      a_r = DOF_MFMA_16x16x32_BF16(W(1), b1, a_r);
-      a_z = DOF_MFMA_16x16x32_BF16(W(4), b1, a_z);
-      a_hn_ = DOF_MFMA_16x16x32_BF16(W(9), h01, a_hn_);
-      a_r = DOF_MFMA_16x16x32_BF16(W(0), b1, a_r);
-      a_z = DOF_MFMA_16x16x32_BF16(W(3), b1, a_z);
-      a_r = DOF_MFMA_16x16x32_BF16(W(1), b0, a_r);
-      a_z = DOF_MFMA_16x16x32_BF16(W(4), b0, a_z);
-      a_r = DOF_MFMA_16x16x32_BF16(W(0), b0, a_r);
-      a_z = DOF_MFMA_16x16x32_BF16(W(3), b0, a_z);
-    }
-    float g_r[4], g_z[4], g_n[4], g_h[4];
-    dof_f32x4 dh_a, dh_b = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f}, dh_c = dh_b, dx_a = dh_b, dx_b = dh_b, dx_c = dh_b;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float rr = dof_sigmoid(a_r[r]);
-      const float z = dof_sigmoid(a_z[r]);
-      const float nn = dof_tanh(fmaf(rr, a_hn_[r], a_n[r]));
-      const float dht = act ? dh[r] + dov[r] : 0.0f;
-      const float dn = dht * (1.0f - z);
-      const float dz = dht * (hp[r] - nn);
-      const float dnp = dn * (1.0f - nn * nn);
-      g_r[r] = act ? dnp * a_hn_[r] * rr * (1.0f - rr) : 0.0f;
-      g_z[r] = act ? dz * z * (1.0f - z) : 0.0f;
-      g_n[r] = act ? dnp : 0.0f;
-      g_h[r] = act ? dnp * rr : 0.0f;
-      dh_a[r] = dht * z;
-    }
-    // ---- dh_{t-1} and dx_t: transposed operands x the pieces of the lane's own gate gradients
-    {
-      uint32_t rw[3][2], zw[3][2], nw[3][2], gw[3][2];
-      dof_split3x4(g_r, rw);
-      dof_split3x4(g_z, zw);
-      dof_split3x4(g_h, gw);
-      dof_split3x4(g_n, nw);
-      const dof_bf16x8 b0 = dof_mk_bf16x8(rw[0][0], rw[0][1], zw[0][0], zw[0][1]);
-      const dof_bf16x8 b1 = dof_mk_bf16x8(rw[1][0], rw[1][1], zw[1][0], zw[1][1]);
-      const dof_bf16x8 b2 = dof_mk_bf16x8(rw[2][0], rw[2][1], zw[2][0], zw[2][1]);
-      const dof_bf16x8 h01 = dof_mk_bf16x8(gw[0][0], gw[0][1], gw[1][0], gw[1][1]);
-      const dof_bf16x8 h02 = dof_mk_bf16x8(gw[0][0], gw[0][1], gw[2][0], gw[2][1]);
-      const dof_bf16x8 n01 = dof_mk_bf16x8(nw[0][0], nw[0][1], nw[1][0], nw[1][1]);
-      const dof_bf16x8 n02 = dof_mk_bf16x8(nw[0][0], nw[0][1], nw[2][0], nw[2][1]);
-      // the recurrence waits for dh: its three chains first, round robin with the dx chains
-      dh_b = DOF_MFMA_16x16x32_BF16(W(12), b2, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(20), h01, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(12), b1, dh_a);
-      dh_b = DOF_MFMA_16x16x32_BF16(W(14), b0, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(19), h02, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(13), b0, dh_a);
-      dh_b = DOF_MFMA_16x16x32_BF16(W(13), b1, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(18), h01, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(12), b0, dh_a);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(15), b2, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(23), n01, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(15), b1, dx_a);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(17), b0, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(22), n02, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(16), b0, dx_a);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(16), b1, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(21), n01, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(15), b0, dx_a);
-    }
-    // ---- weight gradients: contraction over the 16 sequences of the wavefront through the LDS tile
-    DOF_WAVE_LDS_ORDER();  // this step's writes after the previous step's reads (one wavefront owns the tile)
-    dof_st_row<4>(&tile[0][j][4 * b], g_r);
-    dof_st_row<4>(&tile[1][j][4 * b], g_z);
-    dof_st_row<4>(&tile[2][j][4 * b], g_n);
-    dof_st_row<4>(&tile[3][j][4 * b], g_h);
-    dof_st_row<4>(&tile[4][j][4 * b], xv);
-    dof_st_row<4>(&tile[5][j][4 * b], hp);
-    DOF_WAVE_LDS_ORDER();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // K-block q = sequences 4q .. 4q+3; A row = unit j, B column = input / hidden index j
-      const float ar_ = tile[0][4 * q + b][j], az_ = tile[1][4 * q + b][j], an_ = tile[2][4 * q + b][j];
-      const float ah_ = tile[3][4 * q + b][j], bx_ = tile[4][4 * q + b][j], bh_ = tile[5][4 * q + b][j];
-      sbj[0] += ar_; sbj[1] += az_; sbj[2] += an_; sbj[3] += ah_;   // bias sums: unit j over sequences 4q + b
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar_, bx_, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az_, bx_, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(an_, bx_, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar_, bh_, acc[3], 0, 0, 0);
-      acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(az_, bh_, acc[4], 0, 0, 0);
-      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah_, bh_, acc[5], 0, 0, 0);
-    }
-    // rows t >= n of dX are zero: a finished lane writes the zero row of time `step`
-    const int t = act ? (dir ? (n - 1 - step) : step) : step;
-    float dx4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dh[r] = act ? dh_a[r] + (dh_b[r] + dh_c[r]) : dh[r];
-      dx4[r] = act ? dx_a[r] + (dx_b[r] + dx_c[r]) : 0.0f;
-    }
-    dof_st_row<4>(dx_out + ACT(t, 4 * b, IN, Sp, s), dx4);
-    DOF_SCHED_FENCE();
-  };
-  // steps run from the last one down; the first group holds the T % PF steps at the top so that the loop needs no exit
-  const int rem = T % PF;
-  dof_static_for<PF>([&](auto d) { issue_loads(d, T - 1 - decltype(d)::value); });
-  // slot of step st = (T - 1 - st) % PF
-  int step = T - 1;
-  for (; step - (PF - 1) >= 0; step -= PF) {   // wave-uniform trip count (MFMA ignores EXEC); no branch inside
-    dof_static_for<PF>([&](auto d) { do_step(d, step - decltype(d)::value); });
-  }
-  dof_static_for<PF - 1>([&](auto d) {   // the last T % PF steps (step = rem - 1 here)
-    if (step - decltype(d)::value >= 0) do_step(d, step - decltype(d)::value);
-  });
-  (void)rem;
-  // ---- partials of this wavefront's 16 sequences: tiles [a][row = unit][col], then the bias sums [gate][unit]
-  float* __restrict__ out = wg_partial + ((int64_t)dir * nblk_own + tile_idx) * GRU16_WG_FLOATS;
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[a * 256 + (4 * b + r) * 16 + j] = acc[a][r];
-  // bias sums: the four lane groups b hold the four quarters of unit j's sum -- through the (now idle) tile
-  DOF_WAVE_LDS_ORDER();
-#pragma unroll
-  for (int g = 0; g < 4; ++g) tile[0][g * 4 + b][j] = sbj[g];
-  DOF_WAVE_LDS_ORDER();
-  if (b == 0) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      out[6 * 256 + g * 16 + j] = (tile[0][g * 4 + 0][j] + tile[0][g * 4 + 1][j]) + (tile[0][g * 4 + 2][j] + tile[0][g * 4 + 3][j]);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_gru16x_bwd, software-pipelined by one step: the recompute of step t - 1 (pieces of x and h, 18 MFMAs, sigmoid / tanh:
-// none of it depends on the recurrence) is issued in the same scheduling region as the dh chain of step t, whose
-// critical path is then gate gradients -> their pieces -> nine MFMAs.  Inactive steps need no selects: with dO zeroed
-// for them every gate gradient is exactly zero, dh stays zero and the dX row written is the zero row.
-// ---------------------------------------------------------------------------------------------
-template <bool HAS_DO>
-__global__ void __launch_bounds__(256, 2) k_gru16x_bwd2(Gru16mStream st_a, Gru16mStream st_b, int T) {
-  constexpr int HID = 16, IN = 16;
-  // The 24 MFMA weight operands (4 words per lane) live in LDS, shared by the four wavefronts of the workgroup (each an
-  // independent tile of 16 sequences): in registers they were 96 of the kernel's ~330 and held it to one wavefront per
-  // SIMD.  [operand][lane]: a wave-wide read is 1 KB contiguous.
-  __shared__ __attribute__((aligned(16))) uint32_t wop[24][64][4];
-  __shared__ __attribute__((aligned(16))) float tiles[4][6][16][16];  // per wavefront: [g_r, g_z, g_n, g_h, x, h_prev][sequence][unit]
-  const Gru16mStream& A = blockIdx.z ? st_b : st_a;
-  const float* __restrict__ X = A.X;
-  const int* __restrict__ len = A.len;
-  const float* __restrict__ O = A.O;
-  const float* __restrict__ dO = A.dO;
-  float* __restrict__ dX = A.dX;
-  float* __restrict__ wg_partial = A.wg_partial;
-  const int64_t S = A.S, Sp = A.Sp;
-  if ((int64_t)blockIdx.x * 64 >= S) return;   // (the grid covers the longer stream; whole workgroups leave)
-  const unsigned nblk_own = (unsigned)((S + 15) / 16);   // partial rows of THIS stream: one per wavefront tile
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, b = lane >> 4;
-  const int64_t tile_idx = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t s = tile_idx * 16 + j;
-  const int dir = blockIdx.y;
-  const bool in_range = s < S;
-  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
-  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
-  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
-  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
-  // operands 0-5: forward [W_ih | W_hh] of gates r, z, three pieces each; 6-8 / 9-11: the n gate's input / hidden halves
-  // (W0|W0), (W1|W0), (W2|W1); 12-14 / 15-17: transposed [W_r | W_z] rows for dh / dx (row = hidden / input index j,
-  // K-block b = gate units 4b .. 4b+3); 18-20 / 21-23: W_hn^T / W_in^T.  Wavefront w prepares operands 6w .. 6w+5.
-  {
-    auto put = [&](int o, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) DOF_INLINE_LAMBDA {
-      wop[o][lane][0] = w0; wop[o][lane][1] = w1; wop[o][lane][2] = w2; wop[o][lane][3] = w3;
-    };
-    const bool transposed = wave >= 2;
-    auto rows = [&](const float* __restrict__ w, int g, uint32_t (&out)[3][2]) DOF_INLINE_LAMBDA {
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = transposed ? w[(g * HID + 4 * b + q) * 16 + j] : w[(g * HID + j) * 16 + 4 * b + q];
-      dof_split3x4(v, out);
-    };
-    if ((wave & 1) == 0) {   // gates r, z: (input | hidden) per piece (forward), (r | z) per piece (transposed)
-      uint32_t i0[3][2], i1[3][2], h0[3][2], h1[3][2];
-      rows(wih, 0, i0); rows(wih, 1, i1); rows(whh, 0, h0); rows(whh, 1, h1);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        if (!transposed) {
-          put(p, i0[p][0], i0[p][1], h0[p][0], h0[p][1]);
-          put(3 + p, i1[p][0], i1[p][1], h1[p][0], h1[p][1]);
-        } else {
-          put(12 + p, h0[p][0], h0[p][1], h1[p][0], h1[p][1]);
-          put(15 + p, i0[p][0], i0[p][1], i1[p][0], i1[p][1]);
-        }
-      }
-    } else {                 // gate n: two piece products per operand
-      uint32_t i2[3][2], h2[3][2];
-      rows(wih, 2, i2); rows(whh, 2, h2);
-      const int oi = transposed ? 21 : 6, oh = transposed ? 18 : 9;
-      put(oi + 0, i2[0][0], i2[0][1], i2[0][0], i2[0][1]);
-      put(oi + 1, i2[1][0], i2[1][1], i2[0][0], i2[0][1]);
-      put(oi + 2, i2[2][0], i2[2][1], i2[1][0], i2[1][1]);
-      put(oh + 0, h2[0][0], h2[0][1], h2[0][0], h2[0][1]);
-      put(oh + 1, h2[1][0], h2[1][1], h2[0][0], h2[0][1]);
-      put(oh + 2, h2[2][0], h2[2][1], h2[1][0], h2[1][1]);
-    }
-  }
-  __syncthreads();
-  if (tile_idx * 16 >= S) return;   // (a wavefront without sequences; no workgroup barrier below)
-  float (*tile)[16][16] = tiles[wave];
-  auto W = [&](int o) DOF_INLINE_LAMBDA { return dof_ld_bf16x8(reinterpret_cast<const uint16_t*>(&wop[o][lane][0])); };
-  dof_f32x4 c_r, c_z, c_n, c_hn;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int unit = 4 * b + r;
-    c_r[r] = bih[unit] + bhh[unit];
-    c_z[r] = bih[HID + unit] + bhh[HID + unit];
-    c_n[r] = bih[2 * HID + unit];
-    c_hn[r] = bhh[2 * HID + unit];
-  }
-  float* __restrict__ dx_out = dX + (int64_t)dir * T * IN * Sp;
-  const int n = in_range ? len[s] : 0;
-  float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  dof_f32x4 acc[6];
-#pragma unroll
-  for (int a = 0; a < 6; ++a) acc[a] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  float sbj[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // bias sums [r, z, n, h] of unit j over the sequences {b, 4 + b, 8 + b, 12 + b}
-  constexpr int PF = 3;   // x_t, h_{t-1}, dO_t loaded PF steps ahead into static register slots (see k_gru16m_fwd)
-  float nx_x[PF][4], nx_h[PF][4], nx_d[PF][4];
-  const int64_t sr = in_range ? s : S - 1;  // idle lanes read a valid row
-  auto issue_loads = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    const bool live = step >= 0 && step < n;
-    const int t = live ? (dir ? (n - 1 - step) : step) : 0;
-    const int tp = (live && step > 0) ? (dir ? t + 1 : t - 1) : 0;
-    dof_ld_row<4>(X + ACT(t, 4 * b, IN, Sp, sr), nx_x[slot]);
-    dof_ld_row<4>(O + ACT(tp, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_h[slot]);
-    if constexpr (HAS_DO) dof_ld_row<4>(dO + ACT(t, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_d[slot]);
-    else nx_d[slot][0] = nx_d[slot][1] = nx_d[slot][2] = nx_d[slot][3] = 0.0f;
-  };
-  // activations of the step the chain works on next: r, z, n, W_hn h + b_hn, and h_{t-1} with the zero of step 0
-  float act_r[4], act_z[4], act_n[4], act_hn[4], act_hp[4];
-  auto recompute = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {   // from slot (step's x, h_{t-1}); k_gru16x_fwd's MFMAs in its order
-    constexpr int slot = decltype(slot_c)::value;
-    float hp[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) hp[q] = step > 0 ? nx_h[slot][q] : 0.0f;   // (wave-uniform condition)
-    uint32_t xw[3][2], hw[3][2];
-    dof_split3x4(nx_x[slot], xw);
-    dof_split3x4(hp, hw);
-    dof_f32x4 a_r = c_r, a_z = c_z, a_n = c_n, a_hn_ = c_hn;
-    const dof_bf16x8 x01 = dof_mk_bf16x8(xw[0][0], xw[0][1], xw[1][0], xw[1][1]);
-    const dof_bf16x8 x02 = dof_mk_bf16x8(xw[0][0], xw[0][1], xw[2][0], xw[2][1]);
-    a_n = DOF_MFMA_16x16x32_BF16(W(8), x01, a_n);
-    a_n = DOF_MFMA_16x16x32_BF16(W(7), x02, a_n);
-    a_n = DOF_MFMA_16x16x32_BF16(W(6), x01, a_n);
-    const dof_bf16x8 b0 = dof_mk_bf16x8(xw[0][0], xw[0][1], hw[0][0], hw[0][1]);
-    const dof_bf16x8 b1 = dof_mk_bf16x8(xw[1][0], xw[1][1], hw[1][0], hw[1][1]);
-    const dof_bf16x8 b2 = dof_mk_bf16x8(xw[2][0], xw[2][1], hw[2][0], hw[2][1]);
-    const dof_bf16x8 h01 = dof_mk_bf16x8(hw[0][0], hw[0][1], hw[1][0], hw[1][1]);
-    const dof_bf16x8 h02 = dof_mk_bf16x8(hw[0][0], hw[0][1], hw[2][0], hw[2][1]);
-    a_r = DOF_MFMA_16x16x32_BF16(W(0), b2, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(3), b2, a_z);
-    a_hn_ = DOF_MFMA_16x16x32_BF16(W(11), h01, a_hn_);
-    a_r = DOF_MFMA_16x16x32_BF16(W(2), b0, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(5), b0, a_z);
-    a_hn_ = DOF_MFMA_16x16x32_BF16(W(10), h02, a_hn_);
-    a_r = DOF_MFMA_16x16x32_BF16(W(1), b1, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(4), b1, a_z);
-    a_hn_ = DOF_MFMA_16x16x32_BF16(W(9), h01, a_hn_);
-    a_r = DOF_MFMA_16x16x32_BF16(W(0), b1, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(3), b1, a_z);
-    a_r = DOF_MFMA_16x16x32_BF16(W(1), b0, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(4), b0, a_z);
-    a_r = DOF_MFMA_16x16x32_BF16(W(0), b0, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(3), b0, a_z);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      act_r[r] = dof_sigmoid(a_r[r]);
-      act_z[r] = dof_sigmoid(a_z[r]);
-      act_hn[r] = a_hn_[r];
-      act_n[r] = dof_tanh(fmaf(act_r[r], a_hn_[r], a_n[r]));
-      act_hp[r] = hp[r];
-    }
-  };
-  auto chain = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {   // the dh recurrence of `step` (its activations are in act_*)
-    constexpr int slot = decltype(slot_c)::value;
-    const bool act = step < n;
-    float g_r[4], g_z[4], g_n[4], g_h[4], xv[4], hp[4];
-    dof_f32x4 dh_a, dh_b = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f}, dh_c = dh_b, dx_a = dh_b, dx_b = dh_b, dx_c = dh_b;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float rr = act_r[r], z = act_z[r], nn = act_n[r], hn = act_hn[r];
-      hp[r] = act_hp[r];
-      xv[r] = nx_x[slot][r];
-      const float dht = dh[r] + (act ? nx_d[slot][r] : 0.0f);   // zero in the idle steps: every product below is then zero
-      const float dn = dht * (1.0f - z);
-      const float dz = dht * (hp[r] - nn);
-      const float dnp = dn * (1.0f - nn * nn);
-      g_r[r] = dnp * hn * rr * (1.0f - rr);
-      g_z[r] = dz * z * (1.0f - z);
-      g_n[r] = dnp;
-      g_h[r] = dnp * rr;
-      dh_a[r] = dht * z;
-    }
-    {
-      uint32_t rw[3][2], zw[3][2], nw[3][2], gw[3][2];
-      dof_split3x4(g_r, rw);
-      dof_split3x4(g_z, zw);
-      dof_split3x4(g_h, gw);
-      const dof_bf16x8 b0 = dof_mk_bf16x8(rw[0][0], rw[0][1], zw[0][0], zw[0][1]);
-      const dof_bf16x8 b1 = dof_mk_bf16x8(rw[1][0], rw[1][1], zw[1][0], zw[1][1]);
-      const dof_bf16x8 b2 = dof_mk_bf16x8(rw[2][0], rw[2][1], zw[2][0], zw[2][1]);
-      const dof_bf16x8 h01 = dof_mk_bf16x8(gw[0][0], gw[0][1], gw[1][0], gw[1][1]);
-      const dof_bf16x8 h02 = dof_mk_bf16x8(gw[0][0], gw[0][1], gw[2][0], gw[2][1]);
-      // the recurrence waits for dh: its three chains first
-      dh_b = DOF_MFMA_16x16x32_BF16(W(12), b2, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(20), h01, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(12), b1, dh_a);
-      dh_b = DOF_MFMA_16x16x32_BF16(W(14), b0, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(19), h02, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(13), b0, dh_a);
-      dh_b = DOF_MFMA_16x16x32_BF16(W(13), b1, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(18), h01, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(12), b0, dh_a);
-      dof_split3x4(g_n, nw);
-      const dof_bf16x8 n01 = dof_mk_bf16x8(nw[0][0], nw[0][1], nw[1][0], nw[1][1]);
-      const dof_bf16x8 n02 = dof_mk_bf16x8(nw[0][0], nw[0][1], nw[2][0], nw[2][1]);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(15), b2, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(23), n01, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(15), b1, dx_a);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(17), b0, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(22), n02, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(16), b0, dx_a);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(16), b1, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(21), n01, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(15), b0, dx_a);
-    }
-    // ---- weight gradients: contraction over the 16 sequences of the wavefront through the LDS tile
-    DOF_WAVE_LDS_ORDER();  // this step's writes after the previous step's reads (one wavefront owns the tile)
-    dof_st_row<4>(&tile[0][j][4 * b], g_r);
-    dof_st_row<4>(&tile[1][j][4 * b], g_z);
-    dof_st_row<4>(&tile[2][j][4 * b], g_n);
-    dof_st_row<4>(&tile[3][j][4 * b], g_h);
-    dof_st_row<4>(&tile[4][j][4 * b], xv);
-    dof_st_row<4>(&tile[5][j][4 * b], hp);
-    DOF_WAVE_LDS_ORDER();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // K-block q = sequences 4q .. 4q+3; A row = unit j, B column = input / hidden index j
-      const float ar_ = tile[0][4 * q + b][j], az_ = tile[1][4 * q + b][j], an_ = tile[2][4 * q + b][j];
-      const float ah_ = tile[3][4 * q + b][j], bx_ = tile[4][4 * q + b][j], bh_ = tile[5][4 * q + b][j];
-      sbj[0] += ar_; sbj[1] += az_; sbj[2] += an_; sbj[3] += ah_;   // bias sums: unit j over sequences 4q + b
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar_, bx_, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az_, bx_, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(an_, bx_, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar_, bh_, acc[3], 0, 0, 0);
-      acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(az_, bh_, acc[4], 0, 0, 0);
-      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah_, bh_, acc[5], 0, 0, 0);
-    }
-    // rows t >= n of dX are zero: an idle lane writes the (zero) row of time `step`
-    const int t = act ? (dir ? (n - 1 - step) : step) : step;
-    float dx4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dh[r] = dh_a[r] + (dh_b[r] + dh_c[r]);
-      dx4[r] = dx_a[r] + (dx_b[r] + dx_c[r]);
-    }
-    dof_st_row<4>(dx_out + ACT(t, 4 * b, IN, Sp, s), dx4);
-  };
-  // slot of step st = (T - 1 - st) % PF
-  dof_static_for<PF>([&](auto d) { issue_loads(d, T - 1 - decltype(d)::value); });
-  recompute(std::integral_constant<int, 0>{}, T - 1);
-  auto do_step = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    constexpr int next = (slot + 1) % PF;
-    chain(slot_c, step);
-    recompute(std::integral_constant<int, next>{}, step - 1);   // (step 0: a discarded recompute of valid rows)
-    issue_loads(slot_c, step - PF);
-    DOF_SCHED_FENCE();
-  };
-  int step = T - 1;
-  for (; step - (PF - 1) >= 0; step -= PF) {   // wave-uniform trip count (MFMA ignores EXEC); no branch inside
-    dof_static_for<PF>([&](auto d) { do_step(d, step - decltype(d)::value); });
-  }
-  dof_static_for<PF - 1>([&](auto d) {   // the last T % PF steps
-    if (step - decltype(d)::value >= 0) do_step(d, step - decltype(d)::value);
-  });
-  // ---- partials of this wavefront's 16 sequences: tiles [a][row = unit][col], then the bias sums [gate][unit]
-  float* __restrict__ out = wg_partial + ((int64_t)dir * nblk_own + tile_idx) * GRU16_WG_FLOATS;
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[a * 256 + (4 * b + r) * 16 + j] = acc[a][r];
-  // bias sums: the four lane groups b hold the four quarters of unit j's sum -- through the (now idle) tile
-  DOF_WAVE_LDS_ORDER();
-#pragma unroll
-  for (int g = 0; g < 4; ++g) tile[0][g * 4 + b][j] = sbj[g];
-  DOF_WAVE_LDS_ORDER();
-  if (b == 0) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      out[6 * 256 + g * 16 + j] = (tile[0][g * 4 + 0][j] + tile[0][g * 4 + 1][j]) + (tile[0][g * 4 + 2][j] + tile[0][g * 4 + 3][j]);
-  }
-}
-
-template <bool HAS_DO>
-__global__ void __launch_bounds__(256, 2) k_gru16x_bwd4(Gru16mStream st_a, Gru16mStream st_b, int T) {
   constexpr int HID = 16, IN = 16;
   // The 24 MFMA weight operands (4 words per lane) live in LDS, shared by the four wavefronts of the workgroup (each an
   // independent tile of 16 sequences): in registers they were 96 of the kernel's ~330 and held it to one wavefront per
@@ -1734,7 +756,7 @@ __global__ void __launch_bounds__(256, 2) k_gru16x_bwd4(Gru16mStream st_a, Gru16
   const uint16_t* __restrict__ pa21 = &tp[b < 2 ? 2 : 1][j][half];
   const uint16_t* __restrict__ pb01 = &tp[b < 2 ? 0 : 1][j][half];
   const uint16_t* __restrict__ pb02 = &tp[b < 2 ? 0 : 2][j][half];
-  constexpr int PF = 2;   // x_t, h_{t-1}, dO_t loaded PF steps ahead into static register slots (see k_gru16m_fwd)
+  constexpr int PF = 2;   // x_t, h_{t-1}, dO_t loaded PF steps ahead into static register slots (see k_gru16x_fwd)
   float nx_x[PF][4], nx_h[PF][4], nx_d[PF][4];
   const int64_t sr = in_range ? s : S - 1;  // idle lanes read a valid row
   auto issue_loads = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
@@ -1936,266 +958,3 @@ __global__ void __launch_bounds__(256, 2) k_gru16x_bwd4(Gru16mStream st_a, Gru16
     }
 }
 
-template <bool HAS_DO, int CUT = 0>
-__global__ void __launch_bounds__(64, 1) k_gru16x_bwd3(Gru16mStream st_a, Gru16mStream st_b, int T) {
-  constexpr int HID = 16, IN = 16;
-  // The 24 MFMA weight operands (4 words per lane) live in LDS, shared by the four wavefronts of the workgroup (each an
-  // independent tile of 16 sequences): in registers they were 96 of the kernel's ~330 and held it to one wavefront per
-  // SIMD.  [operand][lane]: a wave-wide read is 1 KB contiguous.
-  __shared__ __attribute__((aligned(16))) float tiles[1][6][16][16];  // per wavefront: [g_r, g_z, g_n, g_h, x, h_prev][sequence][unit]
-  const Gru16mStream& A = blockIdx.z ? st_b : st_a;
-  const float* __restrict__ X = A.X;
-  const int* __restrict__ len = A.len;
-  const float* __restrict__ O = A.O;
-  const float* __restrict__ dO = A.dO;
-  float* __restrict__ dX = A.dX;
-  float* __restrict__ wg_partial = A.wg_partial;
-  const int64_t S = A.S, Sp = A.Sp;
-  if ((int64_t)blockIdx.x * 16 >= S) return;   // (the grid covers the longer stream; whole workgroups leave)
-  const unsigned nblk_own = (unsigned)((S + 15) / 16);   // partial rows of THIS stream: one per wavefront tile
-  const int lane = threadIdx.x & 63, wave = 0;
-  const int j = lane & 15, b = lane >> 4;
-  const int64_t tile_idx = (int64_t)blockIdx.x;
-  const int64_t s = tile_idx * 16 + j;
-  const int dir = blockIdx.y;
-  const bool in_range = s < S;
-  const float* __restrict__ wih = dir ? A.wih1 : A.wih0;
-  const float* __restrict__ whh = dir ? A.whh1 : A.whh0;
-  const float* __restrict__ bih = dir ? A.bih1 : A.bih0;
-  const float* __restrict__ bhh = dir ? A.bhh1 : A.bhh0;
-  // the 24 operands (see k_gru16x_bwd) in registers: one wavefront per SIMD, no LDS reads in front of the MFMAs
-  dof_bf16x8 wreg[24];
-  {
-    auto rows = [&](const float* __restrict__ w, int g, bool transposed, uint32_t (&out)[3][2]) DOF_INLINE_LAMBDA {
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = transposed ? w[(g * HID + 4 * b + q) * 16 + j] : w[(g * HID + j) * 16 + 4 * b + q];
-      dof_split3x4(v, out);
-    };
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr) {
-      uint32_t i0[3][2], i1[3][2], i2[3][2], h0[3][2], h1[3][2], h2[3][2];
-      rows(wih, 0, tr, i0); rows(wih, 1, tr, i1); rows(wih, 2, tr, i2);
-      rows(whh, 0, tr, h0); rows(whh, 1, tr, h1); rows(whh, 2, tr, h2);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        if (!tr) {
-          wreg[p] = dof_mk_bf16x8(i0[p][0], i0[p][1], h0[p][0], h0[p][1]);
-          wreg[3 + p] = dof_mk_bf16x8(i1[p][0], i1[p][1], h1[p][0], h1[p][1]);
-        } else {
-          wreg[12 + p] = dof_mk_bf16x8(h0[p][0], h0[p][1], h1[p][0], h1[p][1]);
-          wreg[15 + p] = dof_mk_bf16x8(i0[p][0], i0[p][1], i1[p][0], i1[p][1]);
-        }
-      }
-      const int oi = tr ? 21 : 6, oh = tr ? 18 : 9;
-      wreg[oi + 0] = dof_mk_bf16x8(i2[0][0], i2[0][1], i2[0][0], i2[0][1]);
-      wreg[oi + 1] = dof_mk_bf16x8(i2[1][0], i2[1][1], i2[0][0], i2[0][1]);
-      wreg[oi + 2] = dof_mk_bf16x8(i2[2][0], i2[2][1], i2[1][0], i2[1][1]);
-      wreg[oh + 0] = dof_mk_bf16x8(h2[0][0], h2[0][1], h2[0][0], h2[0][1]);
-      wreg[oh + 1] = dof_mk_bf16x8(h2[1][0], h2[1][1], h2[0][0], h2[0][1]);
-      wreg[oh + 2] = dof_mk_bf16x8(h2[2][0], h2[2][1], h2[1][0], h2[1][1]);
-    }
-  }
-  float (*tile)[16][16] = tiles[wave];
-  auto W = [&](int o) DOF_INLINE_LAMBDA { return wreg[o]; };
-  dof_f32x4 c_r, c_z, c_n, c_hn;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int unit = 4 * b + r;
-    c_r[r] = bih[unit] + bhh[unit];
-    c_z[r] = bih[HID + unit] + bhh[HID + unit];
-    c_n[r] = bih[2 * HID + unit];
-    c_hn[r] = bhh[2 * HID + unit];
-  }
-  float* __restrict__ dx_out = dX + (int64_t)dir * T * IN * Sp;
-  const int n = in_range ? len[s] : 0;
-  float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  dof_f32x4 acc[6];
-#pragma unroll
-  for (int a = 0; a < 6; ++a) acc[a] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  float sbj[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // bias sums [r, z, n, h] of unit j over the sequences {b, 4 + b, 8 + b, 12 + b}
-  constexpr int PF = 3;   // x_t, h_{t-1}, dO_t loaded PF steps ahead into static register slots (see k_gru16m_fwd)
-  float nx_x[PF][4], nx_h[PF][4], nx_d[PF][4];
-  const int64_t sr = in_range ? s : S - 1;  // idle lanes read a valid row
-  auto issue_loads = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    const bool live = step >= 0 && step < n;
-    const int t = live ? (dir ? (n - 1 - step) : step) : 0;
-    const int tp = (live && step > 0) ? (dir ? t + 1 : t - 1) : 0;
-    dof_ld_row<4>(X + ACT(t, 4 * b, IN, Sp, sr), nx_x[slot]);
-    dof_ld_row<4>(O + ACT(tp, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_h[slot]);
-    if constexpr (HAS_DO) dof_ld_row<4>(dO + ACT(t, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_d[slot]);
-    else nx_d[slot][0] = nx_d[slot][1] = nx_d[slot][2] = nx_d[slot][3] = 0.0f;
-  };
-  // activations of the step the chain works on next: r, z, n, W_hn h + b_hn, and h_{t-1} with the zero of step 0
-  float act_r[4], act_z[4], act_n[4], act_hn[4], act_hp[4];
-  auto recompute = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {   // from slot (step's x, h_{t-1}); k_gru16x_fwd's MFMAs in its order
-    constexpr int slot = decltype(slot_c)::value;
-    float hp[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) hp[q] = step > 0 ? nx_h[slot][q] : 0.0f;   // (wave-uniform condition)
-    uint32_t xw[3][2], hw[3][2];
-    dof_split3x4(nx_x[slot], xw);
-    dof_split3x4(hp, hw);
-    dof_f32x4 a_r = c_r, a_z = c_z, a_n = c_n, a_hn_ = c_hn;
-    if constexpr (!(CUT & 4)) {
-    const dof_bf16x8 x01 = dof_mk_bf16x8(xw[0][0], xw[0][1], xw[1][0], xw[1][1]);
-    const dof_bf16x8 x02 = dof_mk_bf16x8(xw[0][0], xw[0][1], xw[2][0], xw[2][1]);
-    a_n = DOF_MFMA_16x16x32_BF16(W(8), x01, a_n);
-    a_n = DOF_MFMA_16x16x32_BF16(W(7), x02, a_n);
-    a_n = DOF_MFMA_16x16x32_BF16(W(6), x01, a_n);
-    const dof_bf16x8 b0 = dof_mk_bf16x8(xw[0][0], xw[0][1], hw[0][0], hw[0][1]);
-    const dof_bf16x8 b1 = dof_mk_bf16x8(xw[1][0], xw[1][1], hw[1][0], hw[1][1]);
-    const dof_bf16x8 b2 = dof_mk_bf16x8(xw[2][0], xw[2][1], hw[2][0], hw[2][1]);
-    const dof_bf16x8 h01 = dof_mk_bf16x8(hw[0][0], hw[0][1], hw[1][0], hw[1][1]);
-    const dof_bf16x8 h02 = dof_mk_bf16x8(hw[0][0], hw[0][1], hw[2][0], hw[2][1]);
-    a_r = DOF_MFMA_16x16x32_BF16(W(0), b2, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(3), b2, a_z);
-    a_hn_ = DOF_MFMA_16x16x32_BF16(W(11), h01, a_hn_);
-    a_r = DOF_MFMA_16x16x32_BF16(W(2), b0, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(5), b0, a_z);
-    a_hn_ = DOF_MFMA_16x16x32_BF16(W(10), h02, a_hn_);
-    a_r = DOF_MFMA_16x16x32_BF16(W(1), b1, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(4), b1, a_z);
-    a_hn_ = DOF_MFMA_16x16x32_BF16(W(9), h01, a_hn_);
-    a_r = DOF_MFMA_16x16x32_BF16(W(0), b1, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(3), b1, a_z);
-    a_r = DOF_MFMA_16x16x32_BF16(W(1), b0, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(4), b0, a_z);
-    a_r = DOF_MFMA_16x16x32_BF16(W(0), b0, a_r);
-    a_z = DOF_MFMA_16x16x32_BF16(W(3), b0, a_z);
-    } else { a_r[0] += (float)xw[2][0] + (float)hw[2][1]; a_z[1] += (float)xw[1][1] + (float)hw[1][0]; a_n[2] += (float)xw[0][0]; a_hn_[3] += (float)hw[0][1]; }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      act_r[r] = (CUT & 8) ? a_r[r] * 0.25f : dof_sigmoid(a_r[r]);
-      act_z[r] = (CUT & 8) ? a_z[r] * 0.25f : dof_sigmoid(a_z[r]);
-      act_hn[r] = a_hn_[r];
-      act_n[r] = (CUT & 8) ? fmaf(act_r[r], a_hn_[r], a_n[r]) * 0.125f : dof_tanh(fmaf(act_r[r], a_hn_[r], a_n[r]));
-      act_hp[r] = hp[r];
-    }
-  };
-  auto chain = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {   // the dh recurrence of `step` (its activations are in act_*)
-    constexpr int slot = decltype(slot_c)::value;
-    const bool act = step < n;
-    float g_r[4], g_z[4], g_n[4], g_h[4], xv[4], hp[4];
-    dof_f32x4 dh_a, dh_b = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f}, dh_c = dh_b, dx_a = dh_b, dx_b = dh_b, dx_c = dh_b;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float rr = act_r[r], z = act_z[r], nn = act_n[r], hn = act_hn[r];
-      hp[r] = act_hp[r];
-      xv[r] = nx_x[slot][r];
-      const float dht = dh[r] + (act ? nx_d[slot][r] : 0.0f);   // zero in the idle steps: every product below is then zero
-      const float dn = dht * (1.0f - z);
-      const float dz = dht * (hp[r] - nn);
-      const float dnp = dn * (1.0f - nn * nn);
-      g_r[r] = dnp * hn * rr * (1.0f - rr);
-      g_z[r] = dz * z * (1.0f - z);
-      g_n[r] = dnp;
-      g_h[r] = dnp * rr;
-      dh_a[r] = dht * z;
-    }
-    {
-      uint32_t rw[3][2], zw[3][2], nw[3][2], gw[3][2];
-      dof_split3x4(g_r, rw);
-      dof_split3x4(g_z, zw);
-      dof_split3x4(g_h, gw);
-      const dof_bf16x8 b0 = dof_mk_bf16x8(rw[0][0], rw[0][1], zw[0][0], zw[0][1]);
-      const dof_bf16x8 b1 = dof_mk_bf16x8(rw[1][0], rw[1][1], zw[1][0], zw[1][1]);
-      const dof_bf16x8 b2 = dof_mk_bf16x8(rw[2][0], rw[2][1], zw[2][0], zw[2][1]);
-      const dof_bf16x8 h01 = dof_mk_bf16x8(gw[0][0], gw[0][1], gw[1][0], gw[1][1]);
-      const dof_bf16x8 h02 = dof_mk_bf16x8(gw[0][0], gw[0][1], gw[2][0], gw[2][1]);
-      if constexpr (!(CUT & 16)) {
-      // the recurrence waits for dh: its three chains first
-      dh_b = DOF_MFMA_16x16x32_BF16(W(12), b2, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(20), h01, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(12), b1, dh_a);
-      dh_b = DOF_MFMA_16x16x32_BF16(W(14), b0, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(19), h02, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(13), b0, dh_a);
-      dh_b = DOF_MFMA_16x16x32_BF16(W(13), b1, dh_b);
-      dh_c = DOF_MFMA_16x16x32_BF16(W(18), h01, dh_c);
-      dh_a = DOF_MFMA_16x16x32_BF16(W(12), b0, dh_a);
-      } else { dh_b[0] += (float)rw[2][0] + (float)zw[1][1] + (float)gw[0][0]; }
-      if constexpr (!(CUT & 2)) {
-      dof_split3x4(g_n, nw);
-      const dof_bf16x8 n01 = dof_mk_bf16x8(nw[0][0], nw[0][1], nw[1][0], nw[1][1]);
-      const dof_bf16x8 n02 = dof_mk_bf16x8(nw[0][0], nw[0][1], nw[2][0], nw[2][1]);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(15), b2, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(23), n01, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(15), b1, dx_a);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(17), b0, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(22), n02, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(16), b0, dx_a);
-      dx_b = DOF_MFMA_16x16x32_BF16(W(16), b1, dx_b);
-      dx_c = DOF_MFMA_16x16x32_BF16(W(21), n01, dx_c);
-      dx_a = DOF_MFMA_16x16x32_BF16(W(15), b0, dx_a);
-          } else { dx_a[0] += g_n[0] + g_n[1] + g_n[2] + g_n[3]; }
-    }
-    // ---- weight gradients: contraction over the 16 sequences of the wavefront through the LDS tile
-    if constexpr (!(CUT & 1)) {
-    DOF_WAVE_LDS_ORDER();  // this step's writes after the previous step's reads (one wavefront owns the tile)
-    dof_st_row<4>(&tile[0][j][4 * b], g_r);
-    dof_st_row<4>(&tile[1][j][4 * b], g_z);
-    dof_st_row<4>(&tile[2][j][4 * b], g_n);
-    dof_st_row<4>(&tile[3][j][4 * b], g_h);
-    dof_st_row<4>(&tile[4][j][4 * b], xv);
-    dof_st_row<4>(&tile[5][j][4 * b], hp);
-    DOF_WAVE_LDS_ORDER();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // K-block q = sequences 4q .. 4q+3; A row = unit j, B column = input / hidden index j
-      const float ar_ = tile[0][4 * q + b][j], az_ = tile[1][4 * q + b][j], an_ = tile[2][4 * q + b][j];
-      const float ah_ = tile[3][4 * q + b][j], bx_ = tile[4][4 * q + b][j], bh_ = tile[5][4 * q + b][j];
-      sbj[0] += ar_; sbj[1] += az_; sbj[2] += an_; sbj[3] += ah_;   // bias sums: unit j over sequences 4q + b
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar_, bx_, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(az_, bx_, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(an_, bx_, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar_, bh_, acc[3], 0, 0, 0);
-      acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(az_, bh_, acc[4], 0, 0, 0);
-      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah_, bh_, acc[5], 0, 0, 0);
-    }
-    } else { acc[0][0] += g_r[0] + g_z[1] + g_n[2] + g_h[3] + xv[0] + hp[1]; }
-    // rows t >= n of dX are zero: an idle lane writes the (zero) row of time `step`
-    const int t = act ? (dir ? (n - 1 - step) : step) : step;
-    float dx4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dh[r] = dh_a[r] + (dh_b[r] + dh_c[r]);
-      dx4[r] = dx_a[r] + (dx_b[r] + dx_c[r]);
-    }
-    dof_st_row<4>(dx_out + ACT(t, 4 * b, IN, Sp, s), dx4);
-  };
-  // slot of step st = (T - 1 - st) % PF
-  dof_static_for<PF>([&](auto d) { issue_loads(d, T - 1 - decltype(d)::value); });
-  recompute(std::integral_constant<int, 0>{}, T - 1);
-  auto do_step = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
-    constexpr int slot = decltype(slot_c)::value;
-    constexpr int next = (slot + 1) % PF;
-    chain(slot_c, step);
-    recompute(std::integral_constant<int, next>{}, step - 1);   // (step 0: a discarded recompute of valid rows)
-    issue_loads(slot_c, step - PF);
-    DOF_SCHED_FENCE();
-  };
-  int step = T - 1;
-  for (; step - (PF - 1) >= 0; step -= PF) {   // wave-uniform trip count (MFMA ignores EXEC); no branch inside
-    dof_static_for<PF>([&](auto d) { do_step(d, step - decltype(d)::value); });
-  }
-  dof_static_for<PF - 1>([&](auto d) {   // the last T % PF steps
-    if (step - decltype(d)::value >= 0) do_step(d, step - decltype(d)::value);
-  });
-  // ---- partials of this wavefront's 16 sequences: tiles [a][row = unit][col], then the bias sums [gate][unit]
-  float* __restrict__ out = wg_partial + ((int64_t)dir * nblk_own + tile_idx) * GRU16_WG_FLOATS;
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[a * 256 + (4 * b + r) * 16 + j] = acc[a][r];
-  // bias sums: the four lane groups b hold the four quarters of unit j's sum -- through the (now idle) tile
-  DOF_WAVE_LDS_ORDER();
-#pragma unroll
-  for (int g = 0; g < 4; ++g) tile[0][g * 4 + b][j] = sbj[g];
-  DOF_WAVE_LDS_ORDER();
-  if (b == 0) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      out[6 * 256 + g * 16 + j] = (tile[0][g * 4 + 0][j] + tile[0][g * 4 + 1][j]) + (tile[0][g * 4 + 2][j] + tile[0][g * 4 + 3][j]);
-  }
-}

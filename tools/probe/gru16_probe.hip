@@ -1,7 +1,9 @@
 // Development probe (not product): the matrix-pipe GRU kernels of the C2 step (deepof_amd/csrc/k_grum16.inc.h -- the
 // product kernel text itself) timed in isolation at the C2 launch geometry (two streams of 14,336 sequences, 25 steps,
-// both directions), with variants side by side and each variant's outputs compared with the first one's.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deepof_amd/csrc -I include tools/probe/gru16_probe.hip -o tools/probe/gru16_probe
+// both directions) beside round 4's fp32-MFMA kernels (gru_fp32_mfma.inc.h), outputs compared; the (32 -> 8) backward
+// kernel is checked against a double-precision host evaluation of one tile.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deepof_amd/csrc -I include -I tools/probe tools/probe/gru16_probe.hip -o tools/probe/gru16_probe
+// Run:   tools/probe/gru16_probe [sequences per stream]      (results of round 5: profiles/r05_gru_probe.txt)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +14,7 @@ void dof_set_error(const char*, ...) {}
 int dof_check_launch(const char*) { return 0; }
 namespace {
 #include "k_grum16.inc.h"
+#include "gru_fp32_mfma.inc.h"   // round 4's fp32-MFMA kernels, for the comparison
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -116,14 +119,14 @@ int main(int argc, char** argv) {
     if (refO.empty()) refO = fetch(B.O[0], nO);                                                                       \
     printf("  k_gru16m_fwd<NT=%d, WPE=%d>  %8.2f us   max |O - O_first| = %.3g\n", NT, WPE, us, max_diff(B.O[0], refO, nO)); \
   }
-  FWD(1, 1) FWD(1, 4) FWD(2, 2)
+  FWD(1, 1) FWD(1, 4) FWD(2, 2)   // round 4's kernel: one / two tiles per wavefront, register bounds
 #define FWDX(WPE)                                                                                                     \
   {                                                                                                                   \
     CK(hipMemset(B.O[0], 0, nO * 4));                                                                                 \
     const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_fwd<WPE, false>), dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, a16, b16, T); }); \
     printf("  k_gru16x_fwd<WPE=%d> (bf16x3)  %8.2f us   max |O - O_first| = %.3g\n", WPE, us, max_diff(B.O[0], refO, nO)); \
   }
-  FWDX(1) FWDX(3) FWDX(4)
+  FWDX(3) FWDX(4)
 
   // ---- forward 32 -> 8 (reads the layer above's output)
   {
@@ -202,40 +205,13 @@ int main(int argc, char** argv) {
     CK(hipMemset(B.dX[0], 0, ndX * 4)); CK(hipMemset(B.wg[0], 0, nwg * 4));                                           \
     const float us = time_us([&] { hipLaunchKernelGGL(KERNEL, dim3(GRIDX, 2, 2), dim3(64), 0, 0, a16, b16, T); });   \
     if (refdX.empty()) { refdX = fetch(B.dX[0], ndX); refwg = fetch(B.wg[0], nwg); }                                  \
-    printf("  %-28s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", NAME, us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg)); \
+    printf("  %-36s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", NAME, us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg)); \
   }
-  BWD("k_gru16m_bwd (round 4)", k_gru16m_bwd, dof_cdiv(S, 16))
+  BWD("k_gru16m_bwd (round 4, fp32 MFMA)", k_gru16m_bwd, dof_cdiv(S, 16))
   {
     CK(hipMemset(B.dX[0], 0, ndX * 4)); CK(hipMemset(B.wg[0], 0, nwg * 4));
     const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd<true>), dim3(dof_cdiv(S, 64), 2, 2), dim3(256), 0, 0, a16, b16, T); });
-    printf("  %-28s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", "k_gru16x_bwd (bf16x3, LDS W)", us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg));
+    printf("  %-36s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", "k_gru16x_bwd (bf16 x 3 pieces)", us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg));
   }
-  {
-    CK(hipMemset(B.dX[0], 0, ndX * 4)); CK(hipMemset(B.wg[0], 0, nwg * 4));
-    const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd2<true>), dim3(dof_cdiv(S, 64), 2, 2), dim3(256), 0, 0, a16, b16, T); });
-    printf("  %-28s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", "k_gru16x_bwd2 (pipelined)", us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg));
-  }
-  {
-    CK(hipMemset(B.dX[0], 0, ndX * 4)); CK(hipMemset(B.wg[0], 0, nwg * 4));
-    const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd3<true>), dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, a16, b16, T); });
-    printf("  %-28s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", "k_gru16x_bwd3 (regs, 1 wave)", us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg));
-  }
-  {
-    CK(hipMemset(B.dX[0], 0, ndX * 4)); CK(hipMemset(B.wg[0], 0, nwg * 4));
-    const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd4<true>), dim3(dof_cdiv(S, 64), 2, 2), dim3(256), 0, 0, a16, b16, T); });
-    printf("  %-28s %8.2f us   max |dX - first| = %.3g   max |wg - first| = %.3g\n", "k_gru16x_bwd4 (bf16 wgrad)", us, max_diff(B.dX[0], refdX, ndX), max_diff(B.wg[0], refwg, nwg));
-  }
-#define CUTRUN(C, NAME)                                                                                               \
-  {                                                                                                                   \
-    const float us = time_us([&] { hipLaunchKernelGGL((k_gru16x_bwd3<true, C>), dim3(dof_cdiv(S, 16), 2, 2), dim3(64), 0, 0, a16, b16, T); }); \
-    printf("  bwd3 cut %-40s %8.2f us\n", NAME, us);                                                                  \
-  }
-  CUTRUN(1, "wgrad (LDS tile + 24 fp32 MFMA)")
-  CUTRUN(2, "dx (9 MFMA + split g_n)")
-  CUTRUN(4, "recompute MFMAs (18)")
-  CUTRUN(8, "transcendentals")
-  CUTRUN(16, "dh MFMAs (9)")
-  CUTRUN(31, "all of the above")
-  CUTRUN(23, "all MFMA, keep transcendentals")
   return 0;
 }
