@@ -25,7 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STEP_SOURCES = ["k_gather.hip", "k_rnn.hip", "k_reduce.hip", "vade.hip", "k_decoder.inc.h", "k_graph_latent.inc.h"]
+STEP_SOURCES = ["k_gather.hip", "k_rnn.hip", "k_grum16.inc.h", "k_reduce.hip", "vade.hip", "k_decoder.inc.h", "k_graph_latent.inc.h"]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 FP32_PEAK_FLOPS = 157.3e12  # fp32 vector peak (= the f32-input MFMA rate; MI355X_MICROARCH.md)
 
@@ -313,6 +313,20 @@ def _source_sha(files):
     return h.hexdigest()[:16]
 
 
+def _latest_profile(suffix, sha):
+    """The newest committed profiles/rNN_<suffix> whose `source_sha` equals `sha` -> (record, repo-relative name), else
+    (None, None): counter files are quoted only while the sources they were measured on are unchanged."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except ValueError:
+            continue
+        if rec.get("source_sha") == sha:
+            return rec, os.path.relpath(f, ROOT)
+    return None, None
+
+
 def spawn_ranks(n):
     """Re-run this command line as n ranks under torch.distributed.run on this node (rendezvous on 127.0.0.1, a free
     port); rank 0's JSON line is the child's stdout, the exit code is the launcher's."""
@@ -420,6 +434,7 @@ def main():
         show("step", i)
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed   # this rank's clock (the line carries every rank's, so a slow rank is visible from the line alone)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -456,12 +471,36 @@ def main():
     dp = None
     if world > 1 or os.environ.get("DOF_BENCH_FORCE_PG") == "1":
         import torch.distributed as dist
-        from deepof_amd.training import dp_form
+        from deepof_amd.training import dp_form, dp_check_verdict, _dp_switches, _native_comm
         devs = [None] * dist.get_world_size()
         dist.all_gather_object(devs, torch.cuda.current_device())
+        per_rank_ms = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank_ms, 1e3 * elapsed_own / args.steps)
+        # latency of the gradient all-reduce alone, eagerly enqueued on the current stream (HIP events, 100 calls), in the
+        # form the step uses and through torch.distributed: a bad scaling point can be read off the line
+        scratch = torch.zeros_like(eng.grads)
+
+        def ar_latency_us(fn, calls=100):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(calls):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return 1e3 * e0.elapsed_time(e1) / calls
+
+        native, _one_graph = _dp_switches(eng, dist)
+        lat = {"torch.distributed.all_reduce": ar_latency_us(lambda: dist.all_reduce(scratch, op=dist.ReduceOp.SUM))}
+        if native:
+            comm = _native_comm(eng, dist)
+            lat["dof_flat_allreduce"] = ar_latency_us(lambda: comm.all_reduce_(scratch))
         dp = {"backend": dist.get_backend(), "rccl_world_size": dist.get_world_size() if dist.get_backend() == "nccl" else None,
-              "world_size": dist.get_world_size(), "form": dp_form(eng, dist),
+              "world_size": dist.get_world_size(), "form": dp_form(eng, dist), "self_check": dp_check_verdict(eng, dist),
               "allreduce_bytes_per_step": int(eng.grads.numel()) * 4, "collectives_per_step": 1,
+              "allreduce_eager_latency_us": lat, "ms_per_step_per_rank": per_rank_ms,
               "devices": devs}
     # algorithmic work of one step (7.6 MFLOP forward per window, training = 3 x) against the fp32 vector peak
     flops_per_step = 3.0 * 7.6e6 * B
@@ -482,13 +521,12 @@ def main():
     }
     # HBM bytes of one step from the round's PMC passes (tools/profile_step_hbm.sh): quoted only while the kernel sources
     # are the ones the passes ran on
-    step_pmc = os.path.join(ROOT, "profiles", "r04_step_pmc.json")
-    if os.path.exists(step_pmc) and B == 1024:
-        rec = json.load(open(step_pmc))
-        if rec.get("source_sha") == _source_sha(STEP_SOURCES):
+    if B == 1024:
+        rec, name = _latest_profile("step_pmc.json", _source_sha(STEP_SOURCES))
+        if rec is not None:
             hb = rec["hbm_bytes_per_step"]
             out["roofline_step"].update(hbm_bytes_per_step=hb, hbm_frac=hb / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                                        hbm_bytes_source="profiles/r04_step_pmc.json")
+                                        hbm_bytes_source=name)
 
     if rank == 0:
         # ---- roofline of the HBM-bound window-gather kernel: full materialisation of this rank's dataset
@@ -520,16 +558,15 @@ def main():
         bytes_per_window = T * (3 * N + E) * 4 + (3 * N + E) * 4
         alg_bytes = win_per_animal * bytes_per_window
         achieved = alg_bytes / sec_per_launch / 1e9
-        # HBM bytes/launch from this round's rocprofv3 PMC passes of the same launch (tools/gather_pmc.sh ->
-        # profiles/r04_gather_pmc.json); null when the kernel source has changed since they were taken
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r04_gather_pmc.json")
-        if os.path.exists(pmc_file) and win_per_animal == 599976 and (T, N, E) == (25, 14, 14):
-            rec = json.load(open(pmc_file))
-            if rec.get("source_sha") == _source_sha(["k_gather.hip"]):
+        # HBM bytes/launch from rocprofv3 PMC passes of the same launch (tools/gather_pmc.sh -> profiles/rNN_gather_pmc.json,
+        # the newest one taken on the present kernel source); null when the source has changed since
+        traffic, traffic_src = None, None
+        if win_per_animal == 599976 and (T, N, E) == (25, 14, 14):
+            rec, traffic_src = _latest_profile("gather_pmc.json", _source_sha(["k_gather.hip"]))
+            if rec is not None:
                 traffic = rec["hbm_bytes_per_launch"]
         out["roofline"] = {"kernel": "k_window_gather", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "bytes_per_window": bytes_per_window, "windows_per_launch": win_per_animal,
                            "avg_launch_ms": sec_per_launch * 1e3}

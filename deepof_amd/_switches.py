@@ -1,0 +1,37 @@
+"""Every environment switch the compiled library reads -- the complete list (tests/test_abi.py::test_switch_table_is_complete
+compares it with the ``getenv`` sites of deepof_amd/csrc) -- and what each non-default value selects.  They exist for
+same-box A/B measurements and for the parity tests, which run every non-default value through a reference check
+(``probe``); a fit never needs one.  Each is read once per process.
+
+Round 5 removed the switches whose alternatives no longer exist or no longer matter (DOF_GRU_MFMA, DOF_GRUM,
+DOF_GRU8_MFMA, DOF_GRU8_FUSED, DOF_GRU8_FWD_PAIR, DOF_CONV_WGRAD_FUSED, DOF_TCN_ONEPASS, DOF_TCN_ONEPASS_MASK)."""
+
+# name -> (default, tested non-default value, meaning of the non-default value, where it is exercised)
+LIBRARY_SWITCHES = {
+    "DOF_GRU_MFMA_MIN_S": ("8192", "0",
+                           "sequences per launch from which the encoder GRU layers take the matrix-pipe kernels; 0 sends the small "
+                           "reference goldens through them",
+                           "tests/gru_mfma_probe.py (test_gru_mfma_kernels_on_reference_goldens_*)"),
+    "DOF_TCN_WGRAD_FP32": ("0", "1", "TCN weight gradients on the fp32 k_outer reduction instead of the three-plane bf16 kernel",
+                           "test_tcn_kernel_switches_gpu"),
+    "DOF_TCN_TAIL_FOLD": ("1", "0", "the block tail's backward as its own launches instead of folded into the neighbouring convolution",
+                          "test_tcn_kernel_switches_gpu"),
+    "DOF_TCN_COMBINE_FOLD": ("1", "0", "the block output's forward as its own launch instead of folded into the next convolution",
+                             "test_tcn_kernel_switches_gpu"),
+    "DOF_TCN_STAT_RECORDS": ("1", "0", "BatchNorm batch statistics by a sum pass + a centred second pass instead of mergeable records",
+                             "test_tcn_kernel_switches_gpu, test_tcn_record_statistics_vs_two_pass_gpu"),
+    "DOF_TCN_WGRAD_IN": ("1", "0", "the first block's weight gradients on the staged kernel instead of the direct-load one",
+                         "test_tcn_kernel_switches_gpu"),
+    "DOF_TCN_RESIDENT_MAX_T": ("50", "25", "longest window on the time-resident convolutions (longer windows take the 4-fetch path, "
+                               "as windows > 50 always do)", "test_tcn_kernel_switches_gpu"),
+}
+
+# read by the Python host (deepof_amd.training / stepping), not by the library
+HOST_SWITCHES = {
+    "DOF_NO_GRAPH": "1: launch every step eagerly instead of replaying hipGraphs",
+    "DOF_FORCE_DP": "1: take the data-parallel route with a 1-rank process group (tests / single-GPU measurements)",
+    "DOF_DP_NATIVE": "0: torch.distributed.all_reduce between two graphs (the safe form) instead of dof_flat_allreduce",
+    "DOF_DP_ONE_GRAPH": "0: two graphs around an eagerly enqueued collective; 1 with DOF_DP_NATIVE=0: capture the torch collective",
+    "DOF_DP_SELF_CHECK": "0: skip the native collective's self-check (measurements only)",
+    "DOF_DP_CHECK_TIMEOUT": "seconds the self-check waits for a collective (default 30)",
+}

@@ -2052,18 +2052,8 @@ int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, floa
   return dof_check_launch("k_enc_conv_fwd");
 }
 
-// DOF_GRU_MFMA=0 selects the lane-per-unit VALU recurrences instead of the matrix-pipe ones (A/B measurements)
-bool dof_gru_mfma() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DOF_GRU_MFMA");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
-}
-
 // The (16, 16) layer of a launch with >= 8,192 sequences (the encoder streams) takes the matrix-pipe pair
-// k_gru16m_fwd / k_gru16m_bwd (no saved gates); shorter launches (the decoder: one sequence per window) stay on the
+// k_gru16x_fwd / k_gru16x_bwd (no saved gates); shorter launches (the decoder: one sequence per window) stay on the
 // lane-per-unit pair, whose 16x more wavefronts fill the chip there (measured at 1,024 sequences: 16 + 21 us against
 // 20 + 52 us).  Forward and backward launchers take the same decision from the same S.
 // DOF_GRU_MFMA_MIN_S overrides the threshold (0: always -- how the parity tests run the goldens through these kernels).
@@ -2073,19 +2063,14 @@ bool dof_gru16_mfma(int64_t S) {
     const char* e = getenv("DOF_GRU_MFMA_MIN_S");
     min_s = e ? atoll(e) : 8192;
   }
-  return dof_gru_mfma() && S >= min_s;
+  return S >= min_s;
 }
 
-// the GEMM-shaped recurrence of the wider layers (k_grum_fwd / k_grum_bwd): same size rule; DOF_GRUM=0 keeps the quad-split
-// kernels (A/B measurements)
+// the GEMM-shaped recurrence of the wider layers (k_grum_fwd / k_grum_bwd): same size rule
 bool dof_grum_selected(int64_t S) {
-  static const bool on = [] {
-    const char* e = getenv("DOF_GRUM");
-    return !(e && e[0] == '0');
-  }();
   // (the alternative here is the quad-split kernel, 290 us for the decoder's 1,024 sequences of a (32, 32) layer: the
   // matrix-pipe form wins from a few hundred sequences on, unlike the (16, 16) layer whose alternative is lane-per-unit)
-  return on && dof_gru_mfma() && (dof_gru16_mfma(S) || S >= 512);
+  return dof_gru16_mfma(S) || S >= 512;
 }
 
 static Gru16mStream gru16m_stream(const float* X, const int* len, DofGruW W, float* O, float* GS, const float* dO, float* dX,

@@ -1357,19 +1357,14 @@ static unsigned tct_blocks(int T, int64_t Sp) {
     if (tct_ns(A.T) == 16) DOF_LAUNCH((k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB, 16>), (nbt), (256), st, A); \
     else DOF_LAUNCH((k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB, 8>), (nbt), (256), st, A);                \
   } while (0)
-// One-pass (shifted) BatchNorm statistics (bn_shift_ok) of the time-resident convolutions are OPT-IN since round 3
-// (DOF_TCN_ONEPASS=1): measured elementwise against a reference golden whose running means equal the batch means
+// One-pass (shifted) BatchNorm statistics (bn_shift_ok) of the time-resident convolutions: round 2's default, opt-in in
+// rounds 3 / 4 (DOF_TCN_ONEPASS=1), no longer selectable since round 5 (the mergeable records below are the default and
+// pass the same goldens; the kernels keep the shift argument, always null).  The reason it lost the default: measured elementwise against a reference golden whose running means equal the batch means
 // (tests/golden/vade_tcn14_onepass.npz, every channel on the one-pass form) the gradients of 107 of 200 tensors leave the
 // standard bar, by up to 4.1 x (2e-3 of the tensor scale), while the centred second pass stays within 0.1 x of it on the
 // same fixture -- the refreshed running variances agree with the reference to 1e-7 either way, the loss terms to 1.5e-7.
 // The default path must meet the parity bar; the 4 % of the C4 step the second pass costs is the price.
-int dof_tcn_onepass_stats() {
-  static const int on = [] {
-    const char* e = getenv("DOF_TCN_ONEPASS");
-    return (e && e[0] == '1') ? 1 : 0;
-  }();
-  return on;
-}
+int dof_tcn_onepass_stats() { return 0; }
 int dof_tcn_conv32_resident(int T, int64_t Sp) { return tct_fits(T, Sp) ? 1 : 0; }
 // Mergeable one-pass statistics of the time-resident forward convolutions (default; DOF_TCN_STAT_RECORDS=0: sum pass +
 // centred second pass over the tensor)
@@ -1394,7 +1389,8 @@ int dof_launch_tcn_stat_merge_fin(const float* partial, int64_t nblk, float* sum
   return dof_check_launch("k_tcn_stat_merge_fin");
 }
 int dof_launch_bn_bwd_sum_fin(const float* partial, int64_t nblk, float* sums, float count, float* dgamma, float* dbeta,
-                              int accumulate, float* coef, hipStream_t st) {
+                              int accumulate, float* coef, hipStream_t st, bool frozen) {
+  if (frozen) count = __builtin_inff();   // coefficients = sums / count = 0: eval-mode backward (launchers.h)
   DOF_LAUNCH(k_bn_bwd_sum_fin, (TC), (256), st, partial, nblk, count, dgamma, dbeta, accumulate, coef, sums);
   return dof_check_launch("k_bn_bwd_sum_fin");
 }
@@ -1550,7 +1546,8 @@ int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, co
 }
 
 int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,
-                          int C, hipStream_t st) {
+                          int C, hipStream_t st, bool frozen) {
+  if (frozen) count = __builtin_inff();
   DOF_LAUNCH(k_bn_bwd_fin, (1), (64), st, sums, count, dgamma, dbeta, accumulate, coef, C);
   return dof_check_launch("k_bn_bwd_fin");
 }
@@ -2050,11 +2047,11 @@ int dof_launch_head_dense_bwd(const float* dout, const float* w, float* din, int
 
 int dof_launch_head_bn_bwd(const float* g, const float* h, const float* bnp, float* partial, float* sums, float* coef,
                            float* dgamma, float* dbeta, int accumulate, float* dpre, int C, int64_t B, int64_t Bp,
-                           hipStream_t st, int relu) {
+                           hipStream_t st, int relu, bool frozen) {
   const unsigned nb = dof_cdiv(B, 256);
   DOF_LAUNCH(k_head_bn_bwd1, (nb, (unsigned)C), (256), st, g, h, bnp, partial, C, B, Bp);
   DOF_LAUNCH(k_head_sum, (1), (64), st, (const float*)partial, (int)nb, sums, C);
-  DOF_LAUNCH(k_bn_bwd_fin, (1), (64), st, (const float*)sums, (float)B, dgamma, dbeta, accumulate, coef, C);
+  DOF_LAUNCH(k_bn_bwd_fin, (1), (64), st, (const float*)sums, frozen ? __builtin_inff() : (float)B, dgamma, dbeta, accumulate, coef, C);
   DOF_LAUNCH(k_head_bn_bwd2, (nb, (unsigned)C), (256), st, g, h, bnp, (const float*)coef, dpre, C, relu, B, Bp);
   return dof_check_launch("k_head_bn_bwd");
 }

@@ -77,7 +77,7 @@ int64_t dof_tcn_row_blocks(int T, int64_t S);   // partial rows written by the r
 int64_t dof_tcn_conv_waves(int T, int64_t Sp);  // partial rows written by the MFMA convolution (one per wave)
 int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float* bias, float* xs, float* y,
                            float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st);
-int dof_tcn_onepass_stats();                         // 0 when DOF_TCN_ONEPASS=0 (two-pass BatchNorm statistics instead of the one-pass shifted sums)
+int dof_tcn_onepass_stats();                         // always 0 since round 5 (the shifted one-pass sums are no longer selectable)
 int dof_tcn_conv32_resident(int T, int64_t Sp);               // 1: the 32 -> 32 convolutions run the time-resident kernel (it can fuse pass 2 of a BatchNorm backward)
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp);   // partial rows written by the 32 -> 32 convolution
 int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
@@ -93,8 +93,11 @@ int dof_tcn_stat_records();
 int dof_launch_tcn_stat_merge(const float* partial, int64_t nblk, float* sums, hipStream_t st);
 int dof_launch_tcn_stat_merge_fin(const float* partial, int64_t nblk, float* sums, float count, const float* gamma,
                                   const float* beta, float* rmean, float* rvar, float momentum, float* bnp, hipStream_t st);
+// BatchNorm backward, `frozen`: the layer normalised with its running statistics (dof_vade_set_batchnorm_training(0)), so
+// the batch-mean terms of the train-mode formula vanish -- dx = gamma rstd dy (torch's eval-mode batch_norm backward);
+// the kernels get count = infinity, which makes both coefficients they derive from the sums exactly zero
 int dof_launch_bn_bwd_sum_fin(const float* partial, int64_t nblk, float* sums, float count, float* dgamma, float* dbeta,
-                              int accumulate, float* coef, hipStream_t st);
+                              int accumulate, float* coef, hipStream_t st, bool frozen = false);
 int64_t dof_tcn_bn_bwd1_blocks(int T, int64_t S);
 int dof_launch_tcn_bn_stats(const float* y, float* partial, int64_t n_partial, int stride, float* sums, float count,
                             int T, int CT, int64_t S, int64_t Sp, hipStream_t st, const float* shift = nullptr);
@@ -111,7 +114,7 @@ int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
                           float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st, int shifted = 0);
 int dof_launch_bn_bwd_fin(const float* sums, float count, float* dgamma, float* dbeta, int accumulate, float* coef,
-                          int C, hipStream_t st);
+                          int C, hipStream_t st, bool frozen = false);
 int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res, const float* xs, const float* dsw,
                            const float* dsb, float* out, float* skip, float* feat, int first, int T, int F, int CT,
                            int64_t S, int64_t Sp, hipStream_t st, int xs_ch = 0, int skip_last = 0, float* mask_out = nullptr);
@@ -157,7 +160,7 @@ int dof_launch_head_dense_bwd(const float* dout, const float* w, float* din, int
                               hipStream_t st);
 int dof_launch_head_bn_bwd(const float* g, const float* h, const float* bnp, float* partial, float* sums, float* coef,
                            float* dgamma, float* dbeta, int accumulate, float* dpre, int C, int64_t B, int64_t Bp,
-                           hipStream_t st, int relu = 1);
+                           hipStream_t st, int relu = 1, bool frozen = false);
 int dof_launch_dec_repeat(const float* d2, const float* bnp, float* zrep, int C4, int T, int64_t B, int64_t Bp,
                           hipStream_t st);
 int dof_launch_dec_sum_time(const float* dzrep, float* dzf, int C4, int T, int64_t B, int64_t Bp, hipStream_t st);

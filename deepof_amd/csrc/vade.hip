@@ -963,19 +963,11 @@ void head_jobs(DofVadePlan* p, JobBuilder& jb) {
 
 const int kTcnDil[8] = {1, 2, 4, 8, 1, 2, 4, 8};
 
-// DOF_CONV_WGRAD_FUSED=0 keeps k_relu_merge + the generic k_outer job for the recurrent encoder's convolution weights
-// (A/B measurements of k_enc_conv_wgrad)
-bool conv_wgrad_fused() {
-  static const bool on = [] {
-    const char* e = getenv("DOF_CONV_WGRAD_FUSED");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
-// DOF_GRU8_FUSED=0 in the environment keeps the second encoder GRU's weight gradients in the generic reduction
-// (A/B measurements of k_gru8_bwd_fused)
-bool gru8_fused() { return true; }   // (round 5: the unfused form would read gates the matrix-pipe forward no longer saves)
+// (rounds 3 / 4 kept A/B switches here -- DOF_CONV_WGRAD_FUSED, DOF_GRU8_FUSED -- for the measurements in DESIGN.md; the
+//  fused forms are the only ones since round 5: the matrix-pipe forward of the second layer saves no gates an unfused
+//  backward could read)
+bool conv_wgrad_fused() { return true; }
+bool gru8_fused() { return true; }
 
 void build_tcn_jobs(DofVadePlan* p) {
   const int L = p->L, T = p->T, C = 32;
@@ -1442,10 +1434,10 @@ int head_backward(DofVadePlan* p, const float* params, float* grads, int accumul
   const int64_t B = p->B, Bp = p->Bp;
   TRY(dof_launch_head_dense_bwd(dout, params + p->h6w, ws + p->hd_dn2, L, L, B, Bp, st));
   TRY(dof_launch_head_bn_bwd(ws + p->hd_dn2, ws + p->hd_h2, ws + p->hd_bnp2, ws + p->hd_partial, ws + p->hd_sums,
-                             ws + p->hd_coef, grads + p->h5g, grads + p->h5b, accumulate, ws + p->hd_dpre2, L, B, Bp, st));
+                             ws + p->hd_coef, grads + p->h5g, grads + p->h5b, accumulate, ws + p->hd_dpre2, L, B, Bp, st, 1, !p->bn_training));
   TRY(dof_launch_head_dense_bwd(ws + p->hd_dpre2, params + p->h3w, ws + p->hd_dn1, 2 * L, L, B, Bp, st));
   TRY(dof_launch_head_bn_bwd(ws + p->hd_dn1, ws + p->hd_h1, ws + p->hd_bnp1, ws + p->hd_partial, ws + p->hd_sums,
-                             ws + p->hd_coef, grads + p->h2g, grads + p->h2b, accumulate, ws + p->hd_dpre1, 2 * L, B, Bp, st));
+                             ws + p->hd_coef, grads + p->h2g, grads + p->h2b, accumulate, ws + p->hd_dpre1, 2 * L, B, Bp, st, 1, !p->bn_training));
   TRY(dof_launch_head_dense_bwd(ws + p->hd_dpre1, params + p->h0w, ws + p->hd_dhn, p->J, 2 * L, B, Bp, st));
   return dof_launch_head_rms_bwd(ws + p->hd_dhn, ws + p->hd_hn, ws + p->hd_rinv, ws + p->dflat, p->J, B, Bp, st);
 }
@@ -1476,13 +1468,10 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
     paired = dof_launch_gru16_fwd_pair(X, ln, W, O, T, S, Sp, st);
     if (paired < 0) return paired;
   }
-  // (the second layer's forward of both streams in one launch measured 5 - 8 us SLOWER than two launches on the same box,
-  //  unlike its backward: off unless DOF_GRU8_FWD_PAIR=1)
-  static const bool pair_fwd8 = [] {
-    const char* e = getenv("DOF_GRU8_FWD_PAIR");
-    return e && e[0] == '1';
-  }();
-  // second layer on the matrix pipe (k_gru8m_fwd, both streams in one launch) where the launch is large enough
+  // (the lane-per-unit forward of the second layer stays one launch per stream: both streams in one launch measured
+  //  5 - 8 us slower on the same box, round 3)
+  constexpr bool pair_fwd8 = false;
+  // second layer on the matrix pipe (k_gru8x_fwd, both streams in one launch) where the launch is large enough
   const bool mfma8 = L == 8 && dof_gru8m_fwd_selected(p->sw[0].S, p->sw[1].S);
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
@@ -1543,12 +1532,8 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     const TcnWs& t = p->tw[s];
     const float count = (float)((int64_t)T * w.S);
     // batch statistics in one pass: the time-resident convolutions sum (y - K), (y - K)^2 with K = the layer's running mean
-    const bool sh = train && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_onepass_stats();
-    static const unsigned long long sh_mask = [] {  // development aid: DOF_TCN_ONEPASS_MASK = hex mask over layers (stream * 16 + 2 block + conv)
-      const char* e = getenv("DOF_TCN_ONEPASS_MASK");
-      return e ? strtoull(e, nullptr, 16) : ~0ull;
-    }();
-    auto sh_on = [&](int layer) { return sh && ((sh_mask >> (s * 16 + layer)) & 1ull); };
+    const bool sh = train && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_onepass_stats();   // (always false: see dof_tcn_onepass_stats)
+    auto sh_on = [&](int) { return sh; };
     const bool comb = dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_combine_fold() != 0;
     // batch statistics of the time-resident convolutions as mergeable (n, mean, M2) records: no pass over the tensor
     const bool recs = train && !sh && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_stat_records() != 0;
@@ -1718,13 +1703,13 @@ int tcn_decoder_backward(DofVadePlan* p, const float* params, float* grads, int 
     TRY(dof_launch_tcn_bn_bwd1(b == 3 ? nullptr : ws + d.dout[b & 1], ws + d.y2[b], ws + d.bnp[2 * b + 1], ws + d.g2[b],
                                ws + d.partial, ws + d.sums, 1, b == 3 ? nullptr : ws + d.out[b], nullptr, nullptr,
                                ws + d.dskip, dprev, T, CD, B, Bp, st));
-    TRY(dof_launch_bn_bwd_fin(ws + d.sums, count, grads + o.g2, grads + o.b2, accumulate, ws + d.coef, CD, st));
+    TRY(dof_launch_bn_bwd_fin(ws + d.sums, count, grads + o.g2, grads + o.b2, accumulate, ws + d.coef, CD, st, !p->bn_training));
     TRY(dof_launch_tcn_bn_bwd2(ws + d.g2[b], ws + d.y2[b], ws + d.bnp[2 * b + 1], ws + d.coef, T, CD, B, Bp, st));
     TRY(dof_launch_tcn_convg(1, CD, CD, ws + d.g2[b], params + o.c2w, CD, CD, nullptr, nullptr, nullptr, ws + d.da,
                              nullptr, 0, T, dl, B, Bp, st));
     TRY(dof_launch_tcn_bn_bwd1(ws + d.da, ws + d.y1[b], ws + d.bnp[2 * b], ws + d.g1[b], ws + d.partial, ws + d.sums, 0,
                                nullptr, nullptr, nullptr, nullptr, nullptr, T, CD, B, Bp, st));
-    TRY(dof_launch_bn_bwd_fin(ws + d.sums, count, grads + o.g1, grads + o.b1, accumulate, ws + d.coef, CD, st));
+    TRY(dof_launch_bn_bwd_fin(ws + d.sums, count, grads + o.g1, grads + o.b1, accumulate, ws + d.coef, CD, st, !p->bn_training));
     TRY(dof_launch_tcn_bn_bwd2(ws + d.g1[b], ws + d.y1[b], ws + d.bnp[2 * b], ws + d.coef, T, CD, B, Bp, st));
     if (b > 0) {
       TRY(dof_launch_tcn_convg(1, CD, CD, ws + d.g1[b], params + o.c1w, CD, CD, nullptr, nullptr, nullptr, dprev,
@@ -1741,13 +1726,13 @@ int tcn_decoder_backward(DofVadePlan* p, const float* params, float* grads, int 
   TRY(dof_launch_dec_sum_time(ws + d.dzrep, ws + d.dzf, C4, T, B, Bp, st));
   // front MLP backward: BN2 <- ReLU <- fc2 <- BN1 <- ReLU <- fc1 <- BN0 <- fc0 <- RMS guard
   TRY(dof_launch_head_bn_bwd(ws + d.dzf, ws + d.d2, ws + d.bnp2, ws + d.hpartial, ws + d.hsums, ws + d.hcoef,
-                             grads + p->dbn2[0], grads + p->dbn2[1], accumulate, ws + d.dpre2, C4, B, Bp, st, 1));
+                             grads + p->dbn2[0], grads + p->dbn2[1], accumulate, ws + d.dpre2, C4, B, Bp, st, 1, !p->bn_training));
   TRY(dof_launch_head_dense_bwd(ws + d.dpre2, params + p->dfc2w, ws + d.dn1, 2 * L, C4, B, Bp, st));
   TRY(dof_launch_head_bn_bwd(ws + d.dn1, ws + d.d1, ws + d.bnp1, ws + d.hpartial, ws + d.hsums, ws + d.hcoef,
-                             grads + p->dbn1[0], grads + p->dbn1[1], accumulate, ws + d.dpre1, 2 * L, B, Bp, st, 1));
+                             grads + p->dbn1[0], grads + p->dbn1[1], accumulate, ws + d.dpre1, 2 * L, B, Bp, st, 1, !p->bn_training));
   TRY(dof_launch_head_dense_bwd(ws + d.dpre1, params + p->dfc1w, ws + d.dn0, L, 2 * L, B, Bp, st));
   TRY(dof_launch_head_bn_bwd(ws + d.dn0, ws + d.d0, ws + d.bnp0, ws + d.hpartial, ws + d.hsums, ws + d.hcoef,
-                             grads + p->dbn0[0], grads + p->dbn0[1], accumulate, ws + d.dpre0, L, B, Bp, st, 0));
+                             grads + p->dbn0[0], grads + p->dbn0[1], accumulate, ws + d.dpre0, L, B, Bp, st, 0, !p->bn_training));
   TRY(dof_launch_head_dense_bwd(ws + d.dpre0, params + p->dfc0w, ws + d.dhn, L, L, B, Bp, st));
   TRY(dof_launch_head_rms_bwd(ws + d.dhn, ws + d.hn, ws + d.rinv, ws + p->dzdec, L, B, Bp, st));
   return run_jobset(p, p->js_dec[0], grads, accumulate, st);
@@ -1898,7 +1883,7 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
       tail_done = false;
       float* coef2 = ws + (t.lazy ? t.coefs[2 * b + 1] : t.coef);
       float* coef1 = ws + (t.lazy ? t.coefs[2 * b] : t.coef);
-      TRY(dof_launch_bn_bwd_sum_fin(ws + t.partial, nb2, ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, coef2, st));
+      TRY(dof_launch_bn_bwd_sum_fin(ws + t.partial, nb2, ws + t.sums, count, grads + o.g2, grads + o.b2, accumulate, coef2, st, !p->bn_training));
       // conv2's data gradient with BN1 + ReLU's first backward pass in its epilogue; the time-resident kernel also
       // applies pass 2 of BN2's backward while it stages g2 (lazy: the weight-gradient kernel does the same on load;
       // otherwise written back in place for it)
@@ -1912,7 +1897,7 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
                                        ws + t.partial, nullptr, T, d, w.S, w.Sp, st));
       }
       TRY(dof_launch_bn_bwd_sum_fin(ws + t.partial, dof_tcn_conv32_partials(T, w.Sp), ws + t.sums, count, grads + o.g1, grads + o.b1,
-                                    accumulate, coef1, st));
+                                    accumulate, coef1, st, !p->bn_training));
       if (fuse2 && b > 0 && dof_tcn_tail_fold()) {
         // ... and the backward of block b - 1's tail + the first pass of its BatchNorm2 in the epilogue: dprev holds
         // this block's residual-branch gradient, the sum is the gradient at block b - 1's output (never written);

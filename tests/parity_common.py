@@ -525,6 +525,8 @@ class KinkAttribution:
     standard bar + (changes of the identified flips [+ the harmless candidates' summed changes]) for the tensors an
     identified flip reaches, and the plain standard bar for every other tensor -- nothing else."""
 
+    MAX_NAMED = 8
+
     def __init__(self, golden_dir, prefix):
         k = load_golden(golden_dir, "tcn_kinks.npz")
         self.prefix = prefix
@@ -573,7 +575,12 @@ class KinkAttribution:
             for t, i, v in zip(self.probe_tensor[best], self.probe_index[best], V[best]):
                 err[(int(t), int(i))] -= v
             R = np.array([[err[(int(t), int(i))] for t, i in zip(self.probe_tensor[c], self.probe_index[c])] for c in range(n)])
-        return self.first_ordinal[self.flipped].tolist()
+        named = self.first_ordinal[self.flipped].tolist()
+        # a ceiling on the attribution: MI355X names 0 - 4 flips on these fixtures; matching pursuit over ~1,700 candidates
+        # must not be able to explain an arbitrary error away by naming many
+        print(f"KinkAttribution[{self.prefix}]: {len(named)} named flip(s) of {n} candidates: {named}")
+        assert len(named) <= self.MAX_NAMED, (self.prefix, len(named), named)
+        return named
 
     def extra(self, name):
         """Additional bar of tensor ``name``: 1.25 x the identified flips' measured changes there, plus -- ONLY where a

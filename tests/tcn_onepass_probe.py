@@ -1,6 +1,7 @@
-"""Helper of test_tcn_onepass_statistics_gpu: one VaDE-TCN train step whose BatchNorm running means equal the batch means,
-so that the one-pass (shifted) statistics are used for every channel -- or, with DOF_TCN_ONEPASS=0 in the environment,
-the centred second pass.  Prints one JSON line (loss terms, gradient checksums, refreshed running variances)."""
+"""Helper of test_tcn_record_statistics_vs_two_pass_gpu: one VaDE-TCN train step whose BatchNorm running means equal the
+batch means (the hardest case for a one-pass variance); the parent runs it with the default record statistics and with
+DOF_TCN_STAT_RECORDS=0 (sum pass + centred second pass).  Prints one JSON line (loss terms, gradient checksums, refreshed
+running variances)."""
 import json
 import os
 import sys

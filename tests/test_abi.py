@@ -95,3 +95,23 @@ def test_native_comm_refuses_without_rccl():
     buf = ctypes.create_string_buffer(128)
     assert lib.dof_comm_unique_id(buf) != 0
     assert b"librccl" in lib.dof_last_error_string()
+
+
+def test_switch_table_is_complete():
+    """deepof_amd/_switches.py lists EVERY environment variable the compiled library reads: the table against the getenv
+    sites of the kernel sources (a switch cannot be added without documenting it and naming the test that runs it)."""
+    import glob
+    import re
+    from deepof_amd._switches import HOST_SWITCHES, LIBRARY_SWITCHES
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepof_amd")
+    found = set()
+    for f in glob.glob(os.path.join(root, "csrc", "*.hip")) + glob.glob(os.path.join(root, "csrc", "*.h")):
+        found |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(f).read()))
+    assert found == set(LIBRARY_SWITCHES), (sorted(found - set(LIBRARY_SWITCHES)), sorted(set(LIBRARY_SWITCHES) - found))
+    for name, (default, other, meaning, probe) in LIBRARY_SWITCHES.items():
+        assert default != other and meaning and probe, name
+    host = set()
+    for f in glob.glob(os.path.join(root, "*.py")):
+        if not f.endswith("_switches.py"):
+            host |= set(re.findall(r'"(DOF_[A-Z0-9_]+)"', open(f).read()))
+    assert host <= set(HOST_SWITCHES) | set(LIBRARY_SWITCHES), sorted(host - set(HOST_SWITCHES) - set(LIBRARY_SWITCHES))

@@ -483,6 +483,91 @@ def test_contrastive_tcn_full_size_c4(hip):
     np.testing.assert_allclose(z_eval[:64].cpu().numpy(), ref.numpy(), atol=2e-4, rtol=2e-3)
 
 
+def test_full_size_c4_tcn_frozen_batchnorm_gradients_equal_chunked_launches(hip):
+    """The B = 8192 launch geometry of C4's TCN encoder (time-resident convolutions over 114,688 sequences per stream,
+    three-plane weight-gradient chunks, mask-word tails) against the SMALL-launch geometry the reference golden pins
+    (contrastive_tcn14_b64: B = 64).  BatchNorm couples the windows of a batch, so the statistics are FROZEN
+    (dof_vade_set_batchnorm_training(0): the train-mode entries normalise with the running buffers, set to non-trivial
+    values here); the encoder is then separable over windows and, for a given output gradient dz, the parameter
+    gradient of the 8,192-window launch is the SUM of the gradients of its 128 chunks of 64 windows.  Every tensor at
+    the TCN family's gradient bar (1e-4 + 2e-3 of its scale).  The twin of the C5 test above."""
+    from deepof_amd import graph as G
+    from deepof_amd.engine import contrastive_views, create_vade_engine
+    nodes, edges = G.bodypart_graph([""])
+    adj = G.adjacency_from_graph(nodes, edges)
+    ei, _ = G.edge_index_from_graph(nodes, edges)
+    B, Bc, Tf, L, N = 8192, 64, 50, 8, len(nodes)
+    g = torch.Generator().manual_seed(11)
+    x_full = (torch.randn(B, Tf, N, 3, generator=g).cumsum(1) * 0.1).contiguous().cuda()
+    eid = torch.from_numpy(ei).cuda()
+    big = create_vade_engine(B, Tf // 2, adj, L, 1, kind="contrastive_tcn")
+    small = create_vade_engine(Bc, Tf // 2, adj, L, 1, kind="contrastive_tcn")
+    for n in big.names:
+        shape = big.layout[n][2]
+        if n.endswith("running_var"):
+            v = 0.5 + torch.rand(shape, generator=g)
+        elif n.endswith("running_mean"):
+            v = torch.randn(shape, generator=g) * 0.2
+        elif (".bn" in n and n.endswith("weight")) or n in ("encoder.head.2.weight", "encoder.head.5.weight"):
+            v = 1.0 + torch.randn(shape, generator=g) * 0.1
+        elif n.endswith("bias"):
+            v = torch.randn(shape, generator=g) * 0.05
+        elif ".head." in n or "spatial_gnn_block" in n:
+            v = torch.randn(shape, generator=g) * 0.3
+        else:
+            v = torch.randn(shape, generator=g) * 0.05
+        big.view(n).copy_(v)
+    small.params.copy_(big.params)
+    big.set_bn_training(False)
+    small.set_bn_training(False)
+    x, a = contrastive_views(hip, x_full, eid, None)
+    dz = (torch.randn(B, L, generator=g) * 0.1).cuda()
+    p0 = big.params.clone()
+    z_big = big.contrastive_encode(x, a, train=True, count=False)
+    big.contrastive_backward(dz, accumulate=False)
+    assert torch.equal(big.params, p0)   # frozen statistics: the running buffers did not move
+    acc = torch.zeros_like(small.grads, dtype=torch.float64)
+    for c in range(B // Bc):
+        sl = slice(c * Bc, (c + 1) * Bc)
+        z_c = small.contrastive_encode(x[sl].contiguous(), a[sl].contiguous(), train=True, count=False)
+        if c in (0, 77, 127):
+            np.testing.assert_allclose(z_c.cpu().numpy(), z_big[sl].cpu().numpy(), atol=2e-5, rtol=2e-4)
+        small.contrastive_backward(dz[sl].contiguous(), accumulate=False)
+        acc += small.grads.double()
+    total = acc.float()
+    worst, checked = 0.0, 0
+    for n in big.names:
+        if n not in big.layout or "running" in n or n.startswith("distill_head."):
+            continue
+        gb, gs = big.view(n, big.grads).cpu().numpy(), small.view(n, total).cpu().numpy()
+        scale = float(np.abs(gs).max())
+        err = float(np.abs(gb - gs).max())
+        assert err <= 1e-4 + 2e-3 * scale, (n, err, scale)
+        worst = max(worst, err / (scale + 1e-12))
+        checked += 1
+    assert checked >= 100 and float(big.grads.abs().max()) > 1e-3
+    print("worst gradient difference / tensor scale (B = 8192 launch vs 128 launches of B = 64, frozen BatchNorm):", worst)
+    # ... and the small launch itself against torch autograd through the CPU oracle in eval mode (BatchNorm's eval-mode
+    # backward is dx = gamma rstd dy: no batch-mean terms -- what makes the encoder separable in the first place)
+    from oracle import tcn as OT
+    P = {k: v.clone().cpu() for k, v in small.state_dict().items()}
+    leaves = {k: v.requires_grad_(True) for k, v in P.items() if v.dtype.is_floating_point and "running" not in k
+              and k.split(".")[-1] not in ("laplacian", "edge_laplacian", "incidence")}
+    z_ref = OT.tcn_encoder(x[:Bc].cpu(), a[:Bc].cpu(), P, False)
+    (z_ref * dz[:Bc].cpu()).sum().backward()
+    small.contrastive_encode(x[:Bc].contiguous(), a[:Bc].contiguous(), train=True, count=False)
+    small.contrastive_backward(dz[:Bc].contiguous(), accumulate=False)
+    n_ref = 0
+    for n, leaf in leaves.items():
+        if n not in small.layout or leaf.grad is None:
+            continue
+        got, ref = small.view(n, small.grads).cpu().numpy(), leaf.grad.numpy().reshape(small.layout[n][2])
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(got - ref).max()) <= 1e-4 + 2e-3 * scale, (n, float(np.abs(got - ref).max()), scale)
+        n_ref += 1
+    assert n_ref >= 100, n_ref
+
+
 @pytest.mark.parametrize("fixture", ["vade_tcn14.npz", "vade_tcn14w50.npz"])
 def test_vade_tcn_parity_gpu(hip, golden_dir, fixture):
     """vade_tcn14w50 (round 4): window 50 on the 8-sequence time-resident convolutions / 2-sequence weight-gradient chunks."""
@@ -1211,6 +1296,11 @@ def _dp_default_form_worker(rank, world, port, tmp):
         out[tag + "_replays"] = stepper.graphs.replays
         out[tag + "_keys"] = [k[-1] for k in stepper.graphs._graphs]
     out["form"] = TR.dp_form(model._base, dist)
+    out["self_check"] = TR.dp_check_verdict(model._base, dist)
+    # the self-check's fallback on the real backend: a native collective that returns wrong sums must end in the safe form
+    like = model._base.grads
+    out["fallback"] = TR._decide_dp_form(True, dist, like, lambda: (lambda t: t.mul_(1.5)), env={})
+    out["fallback_torch"] = TR.dp_self_check(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), dist, like, captured=False)
     torch.save(out, os.path.join(tmp, f"r{rank}.pt"))
     TR.close_native_comm()
     dist.barrier()
@@ -1227,6 +1317,10 @@ def test_data_parallel_default_form_is_one_graph_native(tmp_path):
     mp.spawn(_dp_default_form_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     r = torch.load(tmp_path / "r0.pt")
     assert r["form"] == "dof_flat_allreduce captured in the step graph", r["form"]
+    # the form was taken only after the self-check (eager AND captured collective against torch.distributed) passed
+    assert r["self_check"] == "passed", r["self_check"]
+    assert r["fallback"][:2] == (False, False) and r["fallback"][2].startswith("failed"), r["fallback"]
+    assert r["fallback_torch"] == (True, ""), r["fallback_torch"]
     # six steps = one eager pass + a capture followed by five replays of ONE graph that holds the collective
     assert r["dp_keys"] == ["dp"] and r["dp_replays"] == 5, (r["dp_keys"], r["dp_replays"])
     assert r["plain_keys"] == ["train"], r["plain_keys"]
@@ -1280,11 +1374,11 @@ def test_step_begin_noise_gpu(hip):
     assert abs(float(x.mean())) < 0.01 and abs(float(x.var()) - 1.0) < 0.01
 
 
-def test_tcn_onepass_statistics_gpu():
-    """The one-pass (shifted) BatchNorm statistics of the time-resident TCN convolutions against the centred second pass:
-    the same train step (running means set to the batch means, so the one-pass form is taken for every channel) in two
-    processes, DOF_TCN_ONEPASS = 1 / DOF_TCN_STAT_RECORDS = 0 (the switches are read once per process).  Summaries only: the
-    elementwise comparison with the REFERENCE is test_tcn_kernel_switches_gpu (test_gpu_parity_r03.py)."""
+def test_tcn_record_statistics_vs_two_pass_gpu():
+    """The mergeable (n, mean, M2) record statistics of the time-resident TCN convolutions (default) against the sum pass +
+    centred second pass they replaced: the same train step in two processes, default / DOF_TCN_STAT_RECORDS = 0 (the
+    switch is read once per process).  Summaries only: the elementwise comparison with the REFERENCE is
+    test_tcn_kernel_switches_gpu (test_gpu_parity_r03.py)."""
     import json
     import subprocess
     import sys
@@ -1292,14 +1386,14 @@ def test_tcn_onepass_statistics_gpu():
 
     def run(env_extra):
         env = dict(os.environ)
-        env.pop("DOF_TCN_ONEPASS", None)
+        env.pop("DOF_TCN_STAT_RECORDS", None)
         env.update(env_extra)
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("PROBE ")][-1]
         return json.loads(line[len("PROBE "):])
 
-    one, two = run({"DOF_TCN_ONEPASS": "1"}), run({"DOF_TCN_STAT_RECORDS": "0"})   # shifted one-pass sums vs centred second pass
+    one, two = run({}), run({"DOF_TCN_STAT_RECORDS": "0"})   # records vs centred second pass
     for k, v in two["logs"].items():
         np.testing.assert_allclose(one["logs"][k], v, rtol=2e-5, atol=1e-6, err_msg=k)
     for n, v in two["rvar"].items():

@@ -224,13 +224,12 @@ def test_contrastive_tcn_gradient_parity_c4_slice(hip):
 def test_vade_tcn_onepass_reference_gpu(hip, golden_dir):
     """A reference golden whose BatchNorm running means equal the batch means of the recorded step (make_golden_r03.py):
     |mean - K| <= 0.1 sigma then holds for every channel of every time-resident convolution layer, i.e. every channel
-    takes the shifted one-pass statistics of round 2 when DOF_TCN_ONEPASS=1 (test_tcn_kernel_switches_gpu runs that).  The
+    took the shifted one-pass statistics of round 2 (selectable until round 4).  The
     product default (mergeable (n, mean, M2) records from the convolution epilogue) meets the same bars as the B = 64 fixture
     here: eval forward, both objectives' loss terms, all 200 gradients (standard bar + identified ReLU-branch flips),
     refreshed BatchNorm buffers."""
     import os
     from parity_common import load_golden, run_vade_tcn_b64_check
-    assert os.environ.get("DOF_TCN_ONEPASS", "0") != "1"
     d = load_golden(golden_dir, "vade_tcn14_onepass.npz")
     # the fixture's premise, checked on the fixture itself: refreshed running mean = 0.9 K + 0.1 batch mean = K
     n = 0
@@ -258,15 +257,19 @@ def test_gru16_matrix_pipe_kernels_gpu():
     assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("switch", ["DOF_TCN_WGRAD_FP32=1", "DOF_TCN_TAIL_FOLD=0", "DOF_TCN_COMBINE_FOLD=0",
-                                    "DOF_TCN_STAT_RECORDS=0", "DOF_TCN_ONEPASS=1", "DOF_TCN_WGRAD_IN=0",
-                                    "DOF_TCN_RESIDENT_MAX_T=25"])
+def _tcn_switches():
+    from deepof_amd._switches import LIBRARY_SWITCHES
+    return [f"{k}={v[1]}" for k, v in LIBRARY_SWITCHES.items() if k.startswith("DOF_TCN_")]
+
+
+@pytest.mark.parametrize("switch", _tcn_switches())
 def test_tcn_kernel_switches_gpu(switch):
     """The round-3 TCN kernels (bf16-pipe weight gradients, block-tail backward / forward folded into the neighbouring
-    convolutions, batch statistics as mergeable records, the first block's direct-load weight gradients) and the kernels they replace -- incl. the centred second pass and
-    round 2's shifted one-pass sums -- meet the SAME reference check: a B = 64 VaDE-TCN golden with the explicit ReLU-flip
-    attribution (the statistics switches on the fixture whose running means equal the batch means, where every channel takes
-    the shifted one-pass form), run in a child process per switch (the switches are read once per process).
+    convolutions, batch statistics as mergeable records, the first block's direct-load weight gradients) and the kernels they replace -- incl. the centred second
+    pass -- meet the SAME reference check: a B = 64 VaDE-TCN golden with the explicit ReLU-flip attribution (the statistics
+    switch on the fixture whose running means equal the batch means), run in a child process per switch (the switches are
+    read once per process).  The list is the library's whole TCN switch table (deepof_amd/_switches.py): every switch the
+    compiled library reads is run through a reference check here or in the test the table names.
     DOF_TCN_RESIDENT_MAX_T=25 (round 4): windows of 29 and 30 steps on the path windows > 50 take (k_tcn_conv's four fetches per
     row, k_outer weight gradients) against the oracle on tie-free draws -- the default path's checks at these sizes are
     test_vade_tcn_windows_over_25_gpu and test_vade_tcn_parity_gpu[vade_tcn14w50].  (Round 3 shipped this path with a null
@@ -278,7 +281,7 @@ def test_tcn_kernel_switches_gpu(switch):
     env = dict(os.environ)
     k, v = switch.split("=")
     env[k] = v
-    if k in ("DOF_TCN_STAT_RECORDS", "DOF_TCN_ONEPASS"):
+    if k == "DOF_TCN_STAT_RECORDS":
         env["DOF_PROBE_FIXTURE"] = "vade_tcn14_onepass.npz"
     if k == "DOF_TCN_RESIDENT_MAX_T":
         env["DOF_PROBE_FIXTURE"] = "oracle_t29_t30"
