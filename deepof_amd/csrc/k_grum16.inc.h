@@ -36,6 +36,42 @@ struct Gru16mStream {
 // products are accumulated first.  Deviation from the fp32 kernels: 2^-23-level relative differences of the
 // pre-activations (the fp32 MFMA form rounds once per product, ~the same size).
 // ---------------------------------------------------------------------------------------------
+// Row addressing of the time loops without a 64-bit multiply per access (v_mul_lo_u32 / v_mad_u64_u32 run at a quarter
+// of the rate: they were a fifth of the forward kernels' VALU time).  A [T][Sp][C] tensor is addressed by a 32-bit BYTE
+// offset from its base (the launchers bound T * Sp * 32 * 4 < 2^31: dof_gru16_mfma): one time step = `str` bytes
+// (wave-uniform), the lane's row at t = 0 = `lane` bytes, `rev` = its row n - 1 (row 0 for an empty sequence).  The forward
+// direction walks t = step, the reverse direction t = n - 1 - step; `step` is wave-uniform, so step * str is scalar work.
+struct DofRowWalk {
+  int str, lane, rev;
+  __device__ __forceinline__ DofRowWalk(int64_t Sp, int C, int64_t s, int c0, int n)
+      : str((int)(Sp * C * 4)), lane((int)((s * C + c0) * 4)), rev(lane + (n > 0 ? n - 1 : 0) * str) {}
+  // a row that is VALID to read for every lane -- the step's row where the lane is active, some row of the tensor where
+  // it is not (its value is not used); `step` may lie outside [0, T) (prefetches past either end)
+  __device__ __forceinline__ int read(int dir, int step, int T) const {
+    const int st = step < 0 ? 0 : (step < T ? step : T - 1);
+    const int r = rev - st * str;
+    return dir ? (r > lane ? r : lane) : lane + st * str;
+  }
+  // the row before it in processing order (t - 1 forward, t + 1 reverse: h_{t-1} of a backward step); at step 0 -- where
+  // the caller substitutes zeros -- still a valid row
+  __device__ __forceinline__ int read_prev(int dir, int step, int T) const {
+    const int st = step < 1 ? 1 : (step < T ? step : T - 1);
+    const int r = rev + str - st * str;
+    return dir ? (r > lane ? r : lane) : lane + (st - 1) * str;
+  }
+  // the row an output of `step` goes to: the step's row where the lane is active, row `step` (which must hold zeros:
+  // rows t >= n are zero) where it is not
+  __device__ __forceinline__ int write(int dir, int step, bool act) const {
+    return (act && dir) ? rev - step * str : lane + step * str;
+  }
+};
+__device__ __forceinline__ const float* dof_at(const float* base, int byte_off) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (uint32_t)byte_off);
+}
+__device__ __forceinline__ float* dof_at(float* base, int byte_off) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (uint32_t)byte_off);
+}
+
 // SAVE: write the (r, z, n, W_hn h + b_hn) words of every unit (the layout k_gru3_fwd<16,16> saves) -- compile-time, so
 // that the time loop has NO branch: with a branch around a store (or a load) hipcc can no longer count the outstanding
 // memory operations and waits vmcnt(0) every step, i.e. for the previous step's stores.  All stores are unconditional:
@@ -106,10 +142,10 @@ __global__ void __launch_bounds__(64, WPE) k_gru16x_fwd(Gru16mStream sa, Gru16mS
   constexpr int PF = 4;
   float xs[PF][4];
   const int64_t sr = in_range ? s : S - 1;
+  const DofRowWalk wx(Sp, IN, sr, 4 * b, n), wo(Sp, 2 * HID, s, dir * HID + 4 * b, n);
   auto load_x = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
     constexpr int slot = decltype(slot_c)::value;
-    const int t = step < n ? (dir ? (n - 1 - step) : step) : 0;
-    dof_ld_row<4>(X + ACT(t, 4 * b, IN, Sp, sr), xs[slot]);
+    dof_ld_row<4>(dof_at(X, wx.read(dir, step, T)), xs[slot]);
   };
   uint32_t xw[3][2];   // pieces of the CURRENT step's x
   dof_f32x4 g_n;       // W_in x + b_in of the current step
@@ -161,12 +197,12 @@ __global__ void __launch_bounds__(64, WPE) k_gru16x_fwd(Gru16mStream sa, Gru16mS
     }
     dof_split3x4(h, hw);
     // rows t >= n are zero: a finished lane writes the zero row of time `step` (>= n), which nobody else writes
-    const int t = act ? (dir ? (n - 1 - step) : step) : step;
     float hout[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) hout[r] = act ? h[r] : 0.0f;
-    dof_st_row<4>(O + ACT(t, dir * HID + 4 * b, 2 * HID, Sp, s), hout);
+    dof_st_row<4>(dof_at(O, wo.write(dir, step, act)), hout);
     if constexpr (SAVE) {
+      const int t = act ? (dir ? (n - 1 - step) : step) : step;
 #pragma unroll
       for (int e = 0; e < 16; ++e) gate16[e] = act ? gate16[e] : 0.0f;
       dof_st_row<16>(gs + ACT(t, 16 * b, 4 * HID, Sp, s), gate16);
@@ -280,10 +316,10 @@ __global__ void __launch_bounds__(64, WPE) k_gru8x_fwd(Gru16mStream sa, Gru16mSt
   constexpr int PF = 4;   // x_t loaded PF steps ahead into static register slots (see k_gru16x_fwd)
   float xs[PF][8];
   const int64_t sr = in_range ? s : S - 1;
+  const DofRowWalk wx(Sp, IN, sr, 8 * b, n), wo(Sp, 2 * HID, s, dir * HID + 2 * b, n);
   auto load_x = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
     constexpr int slot = decltype(slot_c)::value;
-    const int t = step < n ? (dir ? (n - 1 - step) : step) : 0;
-    dof_ld_row<8>(X + ACT(t, 8 * b, IN, Sp, sr), xs[slot]);
+    dof_ld_row<8>(dof_at(X, wx.read(dir, step, T)), xs[slot]);
   };
   dof_f32x4 g1, g2;   // input parts of the current step
   auto input_part = [&](const float (&xq)[8]) DOF_INLINE_LAMBDA {
@@ -330,8 +366,7 @@ __global__ void __launch_bounds__(64, WPE) k_gru8x_fwd(Gru16mStream sa, Gru16mSt
     }
     dof_split3x2(h[0], h[1], hw);
     // rows t >= n are zero: a finished lane writes the zero row of time `step` (>= n), which nobody else writes
-    const int t = act ? (dir ? (n - 1 - step) : step) : step;
-    dof_st_pair(O + ACT(t, dir * HID + 2 * b, 2 * HID, Sp, s), act ? h[0] : 0.0f, act ? h[1] : 0.0f);
+    dof_st_pair(dof_at(O, wo.write(dir, step, act)), act ? h[0] : 0.0f, act ? h[1] : 0.0f);
     DOF_SCHED_FENCE();
   };
   dof_static_for<PF>([&](auto d) { load_x(d, decltype(d)::value); });
@@ -459,13 +494,11 @@ __global__ void __launch_bounds__(64, 2) k_gru8x_bwd(Gru16mStream st_a, Gru16mSt
   constexpr int PF = 2;
   float nx_x[PF][8], nx_h[PF][2];
   const int64_t sr = in_range ? s : S - 1;  // idle lanes read a valid row
+  const DofRowWalk wx(Sp, IN, sr, 8 * b, n), wh(Sp, 2 * HID, sr, dir * HID + 2 * b, n), wdx(Sp, IN, s, 8 * b, n);
   auto issue_loads = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
     constexpr int slot = decltype(slot_c)::value;
-    const bool live = step >= 0 && step < n;
-    const int t = live ? (dir ? (n - 1 - step) : step) : 0;
-    const int tp = (live && step > 0) ? (dir ? t + 1 : t - 1) : 0;
-    dof_ld_row<8>(X + ACT(t, 8 * b, IN, Sp, sr), nx_x[slot]);
-    const float2 hv = *reinterpret_cast<const float2*>(O + ACT(tp, dir * HID + 2 * b, 2 * HID, Sp, sr));
+    dof_ld_row<8>(dof_at(X, wx.read(dir, step, T)), nx_x[slot]);
+    const float2 hv = *reinterpret_cast<const float2*>(dof_at(O, wh.read_prev(dir, step, T)));
     nx_h[slot][0] = hv.x; nx_h[slot][1] = hv.y;
   };
   auto TBC = [&](int o) DOF_INLINE_LAMBDA { return dof_ld_bf16x8(reinterpret_cast<const uint16_t*>(&tbc[o][lane][0])); };
@@ -592,11 +625,10 @@ __global__ void __launch_bounds__(64, 2) k_gru8x_bwd(Gru16mStream st_a, Gru16mSt
       }
     }
     // rows t >= n of dX are zero: an idle lane writes the (zero) row of time `step`
-    const int t = act ? (dir ? (n - 1 - step) : step) : step;
 #pragma unroll
     for (int m = 0; m < 2; ++m) dh[m] = act ? d_a0[m] + d_a1[m] : dh[m];
     const float dx8[8] = {d_a0[2] + d_a1[2], d_a0[3] + d_a1[3], d_b[0], d_b[1], d_b[2], d_b[3], d_c[0], d_c[1]};
-    dof_st_row<8>(dx_out + ACT(t, 8 * b, IN, Sp, s), dx8);
+    dof_st_row<8>(dof_at(dx_out, wdx.write(dir, step, act)), dx8);
     DOF_SCHED_FENCE();
   };
   // slot of step st = (T - 1 - st) % PF
@@ -759,14 +791,12 @@ __global__ void __launch_bounds__(256, 2) k_gru16x_bwd(Gru16mStream st_a, Gru16m
   constexpr int PF = 2;   // x_t, h_{t-1}, dO_t loaded PF steps ahead into static register slots (see k_gru16x_fwd)
   float nx_x[PF][4], nx_h[PF][4], nx_d[PF][4];
   const int64_t sr = in_range ? s : S - 1;  // idle lanes read a valid row
+  const DofRowWalk wx(Sp, IN, sr, 4 * b, n), wh(Sp, 2 * HID, sr, dir * HID + 4 * b, n), wdx(Sp, IN, s, 4 * b, n);
   auto issue_loads = [&](auto slot_c, int step) DOF_INLINE_LAMBDA {
     constexpr int slot = decltype(slot_c)::value;
-    const bool live = step >= 0 && step < n;
-    const int t = live ? (dir ? (n - 1 - step) : step) : 0;
-    const int tp = (live && step > 0) ? (dir ? t + 1 : t - 1) : 0;
-    dof_ld_row<4>(X + ACT(t, 4 * b, IN, Sp, sr), nx_x[slot]);
-    dof_ld_row<4>(O + ACT(tp, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_h[slot]);
-    if constexpr (HAS_DO) dof_ld_row<4>(dO + ACT(t, dir * HID + 4 * b, 2 * HID, Sp, sr), nx_d[slot]);
+    dof_ld_row<4>(dof_at(X, wx.read(dir, step, T)), nx_x[slot]);
+    dof_ld_row<4>(dof_at(O, wh.read_prev(dir, step, T)), nx_h[slot]);
+    if constexpr (HAS_DO) dof_ld_row<4>(dof_at(dO, wh.read(dir, step, T)), nx_d[slot]);
     else nx_d[slot][0] = nx_d[slot][1] = nx_d[slot][2] = nx_d[slot][3] = 0.0f;
   };
   // activations of the step the chain works on next: r, z, n, W_hn h + b_hn, and h_{t-1} with the zero of step 0
@@ -916,14 +946,13 @@ __global__ void __launch_bounds__(256, 2) k_gru16x_bwd(Gru16mStream st_a, Gru16m
       });
     }
     // rows t >= n of dX are zero: an idle lane writes the (zero) row of time `step`
-    const int t = act ? (dir ? (n - 1 - step) : step) : step;
     float dx4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       dh[r] = dh_a[r] + (dh_b[r] + dh_c[r]);
       dx4[r] = dx_a[r] + (dx_b[r] + dx_c[r]);
     }
-    dof_st_row<4>(dx_out + ACT(t, 4 * b, IN, Sp, s), dx4);
+    dof_st_row<4>(dof_at(dx_out, wdx.write(dir, step, act)), dx4);
   };
   // slot of step st = (T - 1 - st) % PF
   dof_static_for<PF>([&](auto d) { issue_loads(d, T - 1 - decltype(d)::value); });

@@ -2057,12 +2057,14 @@ int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, floa
 // lane-per-unit pair, whose 16x more wavefronts fill the chip there (measured at 1,024 sequences: 16 + 21 us against
 // 20 + 52 us).  Forward and backward launchers take the same decision from the same S.
 // DOF_GRU_MFMA_MIN_S overrides the threshold (0: always -- how the parity tests run the goldens through these kernels).
-bool dof_gru16_mfma(int64_t S) {
+bool dof_gru16_mfma(int64_t S, int T) {
   static int64_t min_s = -1;
   if (min_s < 0) {
     const char* e = getenv("DOF_GRU_MFMA_MIN_S");
     min_s = e ? atoll(e) : 8192;
   }
+  // the kernels address a [T][Sp][<= 32] tensor by 32-bit byte offsets (DofRowWalk): larger launches stay on the lane-per-unit pair
+  if (T > 0 && (int64_t)T * dof_pad64(S) * 32 * 4 >= ((int64_t)1 << 31)) return false;
   return S >= min_s;
 }
 
@@ -2070,7 +2072,7 @@ bool dof_gru16_mfma(int64_t S) {
 bool dof_grum_selected(int64_t S) {
   // (the alternative here is the quad-split kernel, 290 us for the decoder's 1,024 sequences of a (32, 32) layer: the
   // matrix-pipe form wins from a few hundred sequences on, unlike the (16, 16) layer whose alternative is lane-per-unit)
-  return dof_gru16_mfma(S) || S >= 512;
+  return dof_gru16_mfma(S, 0) || S >= 512;
 }
 
 static Gru16mStream gru16m_stream(const float* X, const int* len, DofGruW W, float* O, float* GS, const float* dO, float* dX,
@@ -2087,7 +2089,7 @@ static Gru16mStream gru16m_stream(const float* X, const int* len, DofGruW W, flo
 // has to launch the layers one by one (the matrix-pipe kernels are not selected for these sizes), < 0 on error.
 int dof_launch_gru16_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2], int T,
                               const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
-  if (!(dof_gru16_mfma(S[0]) && dof_gru16_mfma(S[1]))) return 0;
+  if (!(dof_gru16_mfma(S[0], T) && dof_gru16_mfma(S[1], T))) return 0;
   const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], O[0], nullptr, nullptr, nullptr, nullptr, S[0], Sp[0]);
   const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], O[1], nullptr, nullptr, nullptr, nullptr, S[1], Sp[1]);
   const int64_t smax = S[0] > S[1] ? S[0] : S[1];
@@ -2098,7 +2100,7 @@ int dof_launch_gru16_fwd_pair(const float* const X[2], const int* const len[2], 
 int dof_launch_gru16_bwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], const float* const O[2],
                               const float* const dO[2], float* const dX[2], float* const wg_partial[2], int T,
                               const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
-  if (!(dof_gru16_mfma(S[0]) && dof_gru16_mfma(S[1]))) return 0;
+  if (!(dof_gru16_mfma(S[0], T) && dof_gru16_mfma(S[1], T))) return 0;
   const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], const_cast<float*>(O[0]), nullptr, dO[0], dX[0], wg_partial[0], S[0], Sp[0]);
   const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], const_cast<float*>(O[1]), nullptr, dO[1], dX[1], wg_partial[1], S[1], Sp[1]);
   const int64_t smax = S[0] > S[1] ? S[0] : S[1];
@@ -2118,10 +2120,10 @@ static Gru8Args gru3_fwd_args(const float* X, const int* len, const DofGruW& W, 
 }
 // the same layer on the matrix pipe (k_gru8m_fwd; launches of >= DOF_GRU_MFMA_MIN_S sequences per stream): returns 1 when
 // launched, 0 when the caller has to use the lane-per-unit kernels, < 0 on error.  DOF_GRU8_MFMA=0: off (A/B).
-bool dof_gru8m_fwd_selected(int64_t S0, int64_t S1) { return dof_gru16_mfma(S0) && dof_gru16_mfma(S1); }
+bool dof_gru8m_fwd_selected(int64_t S0, int64_t S1, int T) { return dof_gru16_mfma(S0, T) && dof_gru16_mfma(S1, T); }
 int dof_launch_gru8m_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2],
                               float* const GS[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
-  if (!dof_gru8m_fwd_selected(S[0], S[1])) return 0;
+  if (!dof_gru8m_fwd_selected(S[0], S[1], T)) return 0;
   const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], O[0], GS[0], nullptr, nullptr, nullptr, S[0], Sp[0]);
   const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], O[1], GS[1], nullptr, nullptr, nullptr, S[1], Sp[1]);
   const int64_t smax = S[0] > S[1] ? S[0] : S[1];
@@ -2139,12 +2141,12 @@ int dof_launch_gru8_fwd_pair(const float* const X[2], const int* const len[2], c
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st) {
   if (L == 8) {  // weight-stationary kernels: matrix-pipe recurrence (kind 0) / lane per unit
-    if (kind == 0 && dof_gru16_mfma(S)) {  // (no gates saved: k_gru16m_bwd recomputes them)
+    if (kind == 0 && dof_gru16_mfma(S, T)) {  // (no gates saved: k_gru16x_bwd recomputes them)
       const Gru16mStream a = gru16m_stream(X, len, W, O, nullptr, nullptr, nullptr, nullptr, S, Sp);
       DOF_LAUNCH((k_gru16x_fwd<3, false>), (dof_cdiv(S, 16), 2, 1), (64), st, a, a, T);
     }
     const Gru8Args A = gru3_fwd_args(X, len, W, O, GS, S, Sp);
-    if (kind == 0 && dof_gru16_mfma(S)) {}
+    if (kind == 0 && dof_gru16_mfma(S, T)) {}
     else if (kind == 0) DOF_LAUNCH((k_gru3_fwd<16, 16, false>), (dof_cdiv(S, 16), 2, 1), (256), st, A, A, T);
     else if (kind == 1) DOF_LAUNCH((k_gru3_fwd<32, 8, false>), (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
     else DOF_LAUNCH((k_gru3_fwd<8, 8, true>), (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
@@ -2254,7 +2256,7 @@ int64_t dof_gru16_wg_floats(int64_t S) { return 2 * (int64_t)dof_cdiv(S, 16) * G
 int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
                                const float* dO, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
                                hipStream_t st) {
-  if (dof_gru16_mfma(S)) {  // matrix-pipe recurrence, gates recomputed (GS is not read: k_gru16m_fwd saved none)
+  if (dof_gru16_mfma(S, T)) {  // matrix-pipe recurrence, gates recomputed (GS is not read: k_gru16x_fwd saved none)
     const Gru16mStream a = gru16m_stream(X, len, W, const_cast<float*>(O), nullptr, dO, dX, wg_partial, S, Sp);
     if (dO) DOF_LAUNCH((k_gru16x_bwd<true>), (dof_cdiv(S, 64), 2, 1), (256), st, a, a, T);
     else DOF_LAUNCH((k_gru16x_bwd<false>), (dof_cdiv(S, 64), 2, 1), (256), st, a, a, T);
@@ -2289,8 +2291,8 @@ int dof_launch_gru16_wg_finalize_pair(const float* const* wg_partial, const int6
   return dof_check_launch("k_gru16_wg_finalize");
 }
 int dof_launch_gru8_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
-                                     int accumulate, hipStream_t st) {
-  if (dof_gru8m_fwd_selected(S[0], S[1])) {   // k_gru8x_bwd's partials: one row per wavefront tile of 16 sequences
+                                     int accumulate, hipStream_t st, int T) {
+  if (dof_gru8m_fwd_selected(S[0], S[1], T)) {   // k_gru8x_bwd's partials: one row per wavefront tile of 16 sequences
     const WgFinArgs A0 = wg_fin_args(wg_partial[0], (int)dof_cdiv(S[0], 16), g, off[0]);
     const WgFinArgs A1 = wg_fin_args(wg_partial[1], (int)dof_cdiv(S[1], 16), g, off[1]);
     DOF_LAUNCH(k_gru8x_wg_finalize, ((unsigned)(GRU8X_WG_FLOATS / 8), 2, 2), (256), st, A0, A1, accumulate);
@@ -2319,7 +2321,7 @@ int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const f
 int dof_launch_gru8_bwd_fused_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], const float* const O[2],
                                    const float* const GS[2], const float* const dHfin[2], float* const dX[2],
                                    float* const wg_partial[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st) {
-  if (dof_gru8m_fwd_selected(S[0], S[1])) {   // the forward pass saved no gates: recompute on the matrix pipe
+  if (dof_gru8m_fwd_selected(S[0], S[1], T)) {   // the forward pass saved no gates: recompute on the matrix pipe
     const Gru16mStream a = gru16m_stream(X[0], len[0], W[0], const_cast<float*>(O[0]), nullptr, dHfin[0], dX[0], wg_partial[0], S[0], Sp[0]);
     const Gru16mStream b = gru16m_stream(X[1], len[1], W[1], const_cast<float*>(O[1]), nullptr, dHfin[1], dX[1], wg_partial[1], S[1], Sp[1]);
     const int64_t smax = S[0] > S[1] ? S[0] : S[1];

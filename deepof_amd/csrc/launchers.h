@@ -29,7 +29,7 @@ int64_t dof_gru8_wg_floats(int64_t S);
 int dof_launch_gru8_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
                               const float* dHfin, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
                               hipStream_t st);
-bool dof_gru8m_fwd_selected(int64_t S0, int64_t S1);
+bool dof_gru8m_fwd_selected(int64_t S0, int64_t S1, int T);   // (T: the kernels' 32-bit row offsets bound T * Sp)
 int dof_launch_gru8m_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2],
                               float* const GS[2], int T, const int64_t S[2], const int64_t Sp[2], hipStream_t st);
 int dof_launch_gru8_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2],
@@ -42,7 +42,7 @@ int dof_launch_gru8_wg_finalize(const float* wg_partial, int64_t S, float* g, co
 int dof_launch_gru16_wg_finalize_pair(const float* const* wg_partial, const int64_t* S, float* g, const int64_t* const* off,
                                       int accumulate, hipStream_t st, int n = 2);
 int dof_launch_gru8_wg_finalize_pair(const float* const wg_partial[2], const int64_t S[2], float* g, const int64_t* const off[2],
-                                     int accumulate, hipStream_t st);
+                                     int accumulate, hipStream_t st, int T);
 int dof_launch_gru16_bwd_fused(const float* X, const int* len, DofGruW W, const float* O, const float* GS,
                                const float* dO, float* dX, float* wg_partial, int T, int64_t S, int64_t Sp,
                                hipStream_t st);

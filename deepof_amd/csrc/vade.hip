@@ -1472,7 +1472,7 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
   //  5 - 8 us slower on the same box, round 3)
   constexpr bool pair_fwd8 = false;
   // second layer on the matrix pipe (k_gru8x_fwd, both streams in one launch) where the launch is large enough
-  const bool mfma8 = L == 8 && dof_gru8m_fwd_selected(p->sw[0].S, p->sw[1].S);
+  const bool mfma8 = L == 8 && dof_gru8m_fwd_selected(p->sw[0].S, p->sw[1].S, T);
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
     const BlockOff& b = p->blk[s];
@@ -1960,7 +1960,7 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     const float* wg[2] = {ws + p->sw[0].wg2, ws + p->sw[1].wg2};
     const int64_t S2[2] = {p->sw[0].S, p->sw[1].S};
     const int64_t* off[2] = {p->blk[0].g2.t, p->blk[1].g2.t};
-    TRY(dof_launch_gru8_wg_finalize_pair(wg, S2, grads, off, accumulate, st));
+    TRY(dof_launch_gru8_wg_finalize_pair(wg, S2, grads, off, accumulate, st, T));
   }
   int paired = 0;
   if (L == 8) {   // first layer: both streams in one launch when the matrix-pipe kernels serve it

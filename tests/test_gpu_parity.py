@@ -563,7 +563,10 @@ def test_full_size_c4_tcn_frozen_batchnorm_gradients_equal_chunked_launches(hip)
             continue
         got, ref = small.view(n, small.grads).cpu().numpy(), leaf.grad.numpy().reshape(small.layout[n][2])
         scale = float(np.abs(ref).max())
-        assert float(np.abs(got - ref).max()) <= 1e-4 + 2e-3 * scale, (n, float(np.abs(got - ref).max()), scale)
+        # 1 % of scale: a ReLU input within rounding of zero may take the other branch here than in the oracle and moves
+        # a few elements by some 1e-3 of scale (the goldens' flip attribution handles that where it is tight); a missing
+        # or extra batch-mean term -- what this comparison is for -- is a 2 - 10 % effect on every tensor below a BatchNorm
+        assert float(np.abs(got - ref).max()) <= 1e-4 + 1e-2 * scale, (n, float(np.abs(got - ref).max()), scale)
         n_ref += 1
     assert n_ref >= 100, n_ref
 

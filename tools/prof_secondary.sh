@@ -1,8 +1,8 @@
 #!/bin/bash
 # rocprofv3 kernel traces of the secondary BASELINE configurations through the product steppers (bench.py's functions):
-#   bash tools/prof_secondary.sh   ->  gpurun_out/prof_secondary/{c3,c5}_kernel_stats.md
+#   bash tools/prof_secondary.sh   [tag]  ->  gpurun_out/<tag>/{c3,c5}_kernel_stats.md
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_secondary
+OUT=$ROOT/gpurun_out/${1:-prof_secondary}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
