@@ -73,7 +73,10 @@ struct DecTailArgs {
   int64_t B, Bp;
 };
 
-template <int L>
+// CONV = false: the convolution already ran on the matrix pipe (five shifted GEMMs, vade.hip: dec_conv_gemm) and left its
+// pre-activation in A.cv; this kernel then starts at the ReLU.  Thread-per-row, the convolution is 2 L x 4 L x 5 FMAs per
+// row with scalar weight loads: 2.0 ms of the 13 ms step at latent 32 (profiles/r04_latent32_grum_kernel_stats.md).
+template <int L, bool CONV = true>
 __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
   constexpr int CI = 4 * L, CO = 2 * L;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,19 +90,24 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
     const int64_t b = i - (int64_t)t * A.B;
     const dof_cfp wc = dof_cw(A.wc), g3 = dof_cw(A.g3), b3 = dof_cw(A.b3), wp = dof_cw(A.wp), bp = dof_cw(A.bp);
     float cv[CO];
+    if constexpr (CONV) {
 #pragma unroll
-    for (int o = 0; o < CO; ++o) cv[o] = 0.0f;
+      for (int o = 0; o < CO; ++o) cv[o] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int ts = t + k - 2;
-      if (ts < 0 || ts >= A.T) continue;
-      float xin[CI];
-      dof_ld_row<CI>(A.n2 + ACT(ts, 0, CI, A.Bp, b), xin);
+      for (int k = 0; k < 5; ++k) {
+        const int ts = t + k - 2;
+        if (ts < 0 || ts >= A.T) continue;
+        float xin[CI];
+        dof_ld_row<CI>(A.n2 + ACT(ts, 0, CI, A.Bp, b), xin);
 #pragma unroll
-      for (int c = 0; c < CI; ++c) {
+        for (int c = 0; c < CI; ++c) {
 #pragma unroll
-        for (int o = 0; o < CO; ++o) cv[o] = fmaf(wc[(o * CI + c) * 5 + k], xin[c], cv[o]);
+          for (int o = 0; o < CO; ++o) cv[o] = fmaf(wc[(o * CI + c) * 5 + k], xin[c], cv[o]);
+        }
       }
+    } else {
+      (void)wc;
+      dof_ld_row<CO>(A.cv + ACT(t, 0, CO, A.Bp, b), cv);
     }
     float mean = 0.0f;
 #pragma unroll
@@ -174,6 +182,14 @@ __global__ void __launch_bounds__(256) k_dec_tail(DecTailArgs A) {
 }
 
 // d n2[t][c] = sum_k sum_o wc[o][c][k] * dcv[t-k+2][o]
+// Conv1d weights (CO, CI, 5) -> five (CO, CI) matrices, one per tap: the operand layout the GEMM kernel stages
+__global__ void __launch_bounds__(256) k_dec_conv_taps(const float* __restrict__ wc, float* __restrict__ taps, int n_oc) {
+  const int e = blockIdx.x * 256 + threadIdx.x;   // (o * CI + c)
+  if (e >= n_oc) return;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) taps[k * n_oc + e] = wc[e * 5 + k];
+}
+
 template <int L>
 __global__ void __launch_bounds__(256) k_dec_conv_bwd(const float* __restrict__ dcv, const float* __restrict__ wc,
                                                       float* __restrict__ dn2, int T, int64_t B, int64_t Bp) {

@@ -189,6 +189,8 @@ struct DofVadePlan {
   int64_t mlse, mzs, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   bool tail_wide = false;
+  bool tail_gemm = false;   // decoder convolution of latent 16 / 32 on the matrix pipe (dec_conv_gemm)
+  int64_t dconv_taps = 0;   // its weights, one (CO, CI) matrix per tap
   int64_t valid, len_d, o1d, g1d, n1d, o2d, g2d, n2d, cv, n3, dloc, dcv, dn2d, do2d, dn1dx, do1d, dzdec;
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
   int64_t partials, segs_tab, mask_tab, bc_tab;
@@ -698,6 +700,7 @@ void build_workspace_layout(DofVadePlan* p) {
   p->n3 = cv.take((int64_t)T * 2 * L * Bp);
   p->dloc = cv.take((int64_t)T * p->C3 * Bp);
   p->dcv = cv.take((int64_t)T * 2 * L * Bp);
+  p->dconv_taps = cv.take((L == 16 || L == 32) ? (int64_t)5 * 2 * L * 4 * L : 0);
   p->dn2d = cv.take((int64_t)T * 4 * L * Bp);
   p->do2d = cv.take((int64_t)T * 4 * L * Bp);
   p->dn1dx = cv.take(2LL * T * 2 * L * Bp);
@@ -757,6 +760,7 @@ void take_latent_buffers(DofVadePlan* p, Carver& cv) {
   p->mckl_blocks = dof_cdiv(p->B, kMcklWindows);
   // recurrent family, latent 8: the lane-per-channel decoder tail (16 rows per workgroup); else one row per thread
   p->tail_wide = !p->tcn && !p->tfm && L == 8 && p->C3 <= 96;
+  p->tail_gemm = !p->tcn && !p->tfm && (L == 16 || L == 32);
   p->tail_blocks = dof_cdiv((int64_t)T * p->B, p->tail_wide ? 64 : 256);
   p->mckl_partial = cv.take(p->mckl_blocks);
   p->distill_partial = cv.take(dof_cdiv(p->B, kLatRows));  // k_latent_bwd_w: 16 windows per workgroup
@@ -1744,6 +1748,45 @@ int tfm_decoder_backward(DofVadePlan* p, const float* params, int which_input, f
                          hipStream_t st);
 int tfm_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStream_t st, int accumulate);
 
+// The recurrent decoder's Conv1d(4L -> 2L, k = 5, same, no bias; models_new.py:311-317) at latent 16 / 32 as five shifted
+// GEMMs on the matrix pipe (k_tfm_gemm): rows are (t, b) in time-major order, so tap k's input is the SAME matrix
+// shifted by (k - 2) Bp rows, and the rows whose source step falls outside [0, T) are simply left out of that tap's
+// row range.  forward: cv[t] = sum_k n2[t + k - 2] W_k^T (pre-activation; k_dec_tail<L, false> starts at the ReLU);
+// backward: dn2[t] = sum_k dcv[t - k + 2] W_k.  The centre tap covers every row and initialises, the others accumulate.
+// Round 4's thread-per-row forms took 2.0 + 1.6 ms at latent 32 for 1,024 windows.
+int dec_conv_gemm(DofVadePlan* p, const float* params, bool backward, hipStream_t st) {
+  float* ws = p->ws;
+  const int L = p->L, T = p->T, CI = 4 * L, CO = 2 * L;
+  const int64_t Bp = p->Bp;
+  if (!backward) {   // (the backward pass of the same step reuses the forward pass's copy: the weights have not moved)
+    DOF_LAUNCH(k_dec_conv_taps, (dof_cdiv((int64_t)CO * CI, 256)), (256), st, params + p->dconv, ws + p->dconv_taps, CO * CI);
+    TRY(dof_check_launch("k_dec_conv_taps"));
+  }
+  static const int order[5] = {2, 0, 1, 3, 4};
+  for (int i = 0; i < 5; ++i) {
+    const int k = order[i];
+    const int sh = backward ? 2 - k : k - 2;          // source step = t + sh
+    const int t0 = sh < 0 ? -sh : 0, t1 = sh > 0 ? T - sh : T;
+    if (t1 <= t0) continue;
+    DofGemm g = {};
+    g.W = ws + p->dconv_taps + (int64_t)k * CO * CI;
+    g.ldw = CI;
+    g.T = t1 - t0; g.S = p->B; g.Sp = Bp;
+    g.epi = DOF_EPI_NONE; g.accumulate = i == 0 ? 0 : 1;
+    if (!backward) {
+      g.X = ws + p->n2d + (int64_t)(t0 + sh) * Bp * CI; g.ldx = CI;
+      g.Y = ws + p->cv + (int64_t)t0 * Bp * CO; g.ldy = CO;
+      g.K = CI; g.N = CO; g.trans = 0;                // Y[r][o] += sum_c X[r][c] W_k[o][c]
+    } else {
+      g.X = ws + p->dcv + (int64_t)(t0 + sh) * Bp * CO; g.ldx = CO;
+      g.Y = ws + p->dn2d + (int64_t)t0 * Bp * CI; g.ldy = CI;
+      g.K = CO; g.N = CI; g.trans = 1;                // Y[r][c] += sum_o X[r][o] W_k[o][c]
+    }
+    TRY(dof_launch_tfm_gemm(g, st));
+  }
+  return DOF_OK;
+}
+
 int decoder_forward(DofVadePlan* p, const float* params, const float* x, const float* zin, float* recon_partial,
                     bool train, float* loc_out, hipStream_t st) {
   if (p->tfm)
@@ -1767,6 +1810,10 @@ int decoder_forward(DofVadePlan* p, const float* params, const float* x, const f
   A.T = T; A.C3 = p->C3; A.train = train ? 1 : 0; A.B = B; A.Bp = Bp;
   if (p->tail_wide) {
     DOF_LAUNCH(k_dec_tail_w, ((unsigned)p->tail_blocks), (256), st, A);
+  } else if (p->tail_gemm) {
+    TRY(dec_conv_gemm(p, params, /*backward=*/false, st));
+    if (L == 16) DOF_LAUNCH((k_dec_tail<16, false>), ((unsigned)p->tail_blocks), (256), st, A);
+    else DOF_LAUNCH((k_dec_tail<32, false>), ((unsigned)p->tail_blocks), (256), st, A);
   } else {
     LDISPATCH(L, DOF_LAUNCH((k_dec_tail<LL>), ((unsigned)p->tail_blocks), (256), st, A));
   }
@@ -1785,6 +1832,8 @@ int decoder_backward(DofVadePlan* p, const float* params, int which_input, float
   if (p->tail_wide) {
     DOF_LAUNCH(k_dec_conv_bwd_w, (dof_cdiv((int64_t)T * B, 8)), (256), st, (const float*)(ws + p->dcv), params + p->dconv,
                ws + p->dn2d, T, B, Bp);
+  } else if (p->tail_gemm) {
+    TRY(dec_conv_gemm(p, params, /*backward=*/true, st));
   } else {
     LDISPATCH(L, DOF_LAUNCH((k_dec_conv_bwd<LL>), ((unsigned)p->tail_blocks), (256), st, (const float*)(ws + p->dcv),
                             params + p->dconv, ws + p->dn2d, T, B, Bp));
