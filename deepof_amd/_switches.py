@@ -11,7 +11,7 @@ LIBRARY_SWITCHES = {
     "DOF_GRU_MFMA_MIN_S": ("8192", "0",
                            "sequences per launch from which the encoder GRU layers take the matrix-pipe kernels; 0 sends the small "
                            "reference goldens through them",
-                           "tests/gru_mfma_probe.py (test_gru_mfma_kernels_on_reference_goldens_*)"),
+                           "tests/gru_mfma_probe.py (test_gru16_matrix_pipe_kernels_emu / _gpu)"),
     "DOF_TCN_WGRAD_FP32": ("0", "1", "TCN weight gradients on the fp32 k_outer reduction instead of the three-plane bf16 kernel",
                            "test_tcn_kernel_switches_gpu"),
     "DOF_TCN_TAIL_FOLD": ("1", "0", "the block tail's backward as its own launches instead of folded into the neighbouring convolution",

@@ -605,146 +605,14 @@ __global__ void __launch_bounds__(256) k_gruq_bwd(const int* __restrict__ len, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// GEMM-shaped GRU for the wider layers (round 4; latent 16: (32,32), (64 -> 16); latent 32: (64,64), (128 -> 32)): the
-// recurrence of k_gru16m_fwd with HID / 16 row tiles per gate and the weights in LDS.  A workgroup = four wavefronts =
-// 4 x 16 (sequence, direction) pairs of ONE direction; lane (b, j) of a wavefront owns units 16 m + 4 b + r (m < HID / 16,
-// r < 4) of sequence j -- the D layout of v_mfma_f32_16x16x4_f32 for row tile m.  One step is
-//   G[unit][seq] = W[unit][k] V[k][seq],  V = [x_t ; h_{t-1}],
-// with the K blocks again made of the lane's OWN values (input block q = channels {q, IN/4 + q, 2 IN/4 + q, 3 IN/4 + q}:
-// lane b loads x[b IN/4 .. (b+1) IN/4); hidden block (m, r) = the units 16 m + 4 k + r: what lane k has just computed), so
-// nothing moves between lanes, and the A operand of every MFMA is one conflict-free ds_read_b32 of a weight table staged
-// once per workgroup in operand order ([gate tile][K block][lane]; 98 KB for (64, 64)).  3 (HID / 16) (IN + HID) / 4 MFMAs
-// per step.  Gates are saved gate-major ([t][s][4 HID], the generic layout of k_gru_fwd / k_gruq_fwd), so the generic
-// weight-gradient jobs apply; k_grum_bwd is the matching backward.  Launches of fewer than DOF_GRU_MFMA_MIN_S sequences (the
-// decoder) stay on the quad-split kernels.
+// GEMM-shaped GRU for the wider layers (latent 16: (32,32), (64 -> 16); latent 32: (64,64), (128 -> 32)).  The forward
+// recurrence is k_grumx_fwd (k_grumx.inc.h: bf16 matrix pipe, three-piece operands; round 4's fp32-MFMA k_grum_fwd took
+// 650 us per encoder stream at (64, 64), 351 us now).  Gates are saved gate-major ([t][s][4 HID], the generic layout of
+// k_gru_fwd / k_gruq_fwd), so the generic weight-gradient jobs apply; k_grum_bwd below is the matching backward, still on
+// v_mfma_f32_16x16x4_f32.  What bounds these layers now is the traffic of the saved gates and gate gradients (734 MB per
+// stream and pass at latent 32), not arithmetic: the latent-8 treatment -- recompute in the backward kernel, weight
+// gradients fused -- is what is left to do here.
 // ---------------------------------------------------------------------------------------------
-template <int IN, int HID>
-__global__ void __launch_bounds__(256) k_grum_fwd(const float* __restrict__ X, const int* __restrict__ len,
-                                                  const float* __restrict__ wih0, const float* __restrict__ whh0,
-                                                  const float* __restrict__ bih0, const float* __restrict__ bhh0,
-                                                  const float* __restrict__ wih1, const float* __restrict__ whh1,
-                                                  const float* __restrict__ bih1, const float* __restrict__ bhh1,
-                                                  float* __restrict__ O, float* __restrict__ GS, int T, int64_t S,
-                                                  int64_t Sp) {
-  static_assert(HID % 16 == 0 && IN % 16 == 0, "row tiles of 16 units, 16-byte input pieces per lane");
-  constexpr int MT = HID / 16, XL = IN / 4, KX = IN / 4, KH = HID / 4, KB = KX + KH;
-  __shared__ float wl[3 * MT * KB * 64];                      // [gate][m][K block][lane]
-  __shared__ __attribute__((aligned(16))) float bl[4 * HID];  // r: b_ih + b_hh | z: b_ih + b_hh | n: b_ih | hn: b_hh
-  const int dir = blockIdx.y;
-  {
-    const float* __restrict__ g_wih = dir ? wih1 : wih0;
-    const float* __restrict__ g_whh = dir ? whh1 : whh0;
-    const float* __restrict__ g_bih = dir ? bih1 : bih0;
-    const float* __restrict__ g_bhh = dir ? bhh1 : bhh0;
-    for (int e = threadIdx.x; e < 3 * MT * KB * 64; e += 256) {
-      const int ln = e & 63, kb = (e >> 6) % KB, tm = (e >> 6) / KB;
-      const int row = (tm / MT) * HID + 16 * (tm % MT) + (ln & 15), k = ln >> 4;
-      wl[e] = kb < KX ? g_wih[row * IN + k * XL + kb]
-                      : g_whh[row * HID + 16 * ((kb - KX) >> 2) + 4 * k + ((kb - KX) & 3)];
-    }
-    for (int u = threadIdx.x; u < HID; u += 256) {
-      bl[u] = g_bih[u] + g_bhh[u];
-      bl[HID + u] = g_bih[HID + u] + g_bhh[HID + u];
-      bl[2 * HID + u] = g_bih[2 * HID + u];
-      bl[3 * HID + u] = g_bhh[2 * HID + u];
-    }
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, b = lane >> 4;
-  const int64_t s = ((int64_t)blockIdx.x * 4 + wave) * 16 + j;
-  if (((int64_t)blockIdx.x * 4 + wave) * 16 >= S) return;   // whole wavefronts leave (no barrier below)
-  const bool live = s < S;
-  const int64_t sr = live ? s : S - 1;
-  float* __restrict__ gs = GS ? GS + (int64_t)dir * T * 4 * HID * Sp : nullptr;
-  const int n = live ? len[sr] : 0;
-  int nmax = n;  // the longest sequence of the wavefront bounds the loop (MFMA ignores EXEC: wave-uniform trip count)
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const int o = __shfl_xor(nmax, m);
-    nmax = o > nmax ? o : nmax;
-  }
-  float h[KH];
-#pragma unroll
-  for (int q = 0; q < KH; ++q) h[q] = 0.0f;
-  float xa[XL], xb[XL];   // x of the current / the next step (loads unconditional: idle lanes read a valid row)
-  auto load_x = [&](int step, float* dst) {
-    const int t = step < n ? (dir ? (n - 1 - step) : step) : 0;
-    dof_ld_row<XL>(X + ACT(t, b * XL, IN, Sp, sr), dst);
-  };
-  load_x(0, xa);
-  const float* __restrict__ wlane = wl + lane;
-  for (int step = 0; step < nmax; ++step) {
-    load_x(step + 1, xb);
-    dof_f32x4 a_r[MT], a_z[MT], a_n[MT], a_h[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      float c[4];
-      dof_ld_row<4>(&bl[16 * m + 4 * b], c);             a_r[m] = dof_f32x4{c[0], c[1], c[2], c[3]};
-      dof_ld_row<4>(&bl[HID + 16 * m + 4 * b], c);       a_z[m] = dof_f32x4{c[0], c[1], c[2], c[3]};
-      dof_ld_row<4>(&bl[2 * HID + 16 * m + 4 * b], c);   a_n[m] = dof_f32x4{c[0], c[1], c[2], c[3]};
-      dof_ld_row<4>(&bl[3 * HID + 16 * m + 4 * b], c);   a_h[m] = dof_f32x4{c[0], c[1], c[2], c[3]};
-    }
-#pragma unroll
-    for (int kb = 0; kb < KX; ++kb) {
-      const float xv = xa[kb];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        a_r[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlane[((0 * MT + m) * KB + kb) * 64], xv, a_r[m], 0, 0, 0);
-        a_z[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlane[((1 * MT + m) * KB + kb) * 64], xv, a_z[m], 0, 0, 0);
-        a_n[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlane[((2 * MT + m) * KB + kb) * 64], xv, a_n[m], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < KH; ++q) {
-      const float hv = h[q];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        a_r[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlane[((0 * MT + m) * KB + KX + q) * 64], hv, a_r[m], 0, 0, 0);
-        a_z[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlane[((1 * MT + m) * KB + KX + q) * 64], hv, a_z[m], 0, 0, 0);
-        a_h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlane[((2 * MT + m) * KB + KX + q) * 64], hv, a_h[m], 0, 0, 0);
-      }
-    }
-    const bool act = step < n;
-    const int t = dir ? (n - 1 - step) : step;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      float hn4[4], r4[4], z4[4], n4[4], a4[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float rr = dof_sigmoid(a_r[m][r]);
-        const float zz = dof_sigmoid(a_z[m][r]);
-        const float nn = dof_tanh(fmaf(rr, a_h[m][r], a_n[m][r]));
-        const float hnew = fmaf(zz, h[4 * m + r] - nn, nn);
-        h[4 * m + r] = act ? hnew : h[4 * m + r];
-        hn4[r] = hnew; r4[r] = rr; z4[r] = zz; n4[r] = nn; a4[r] = a_h[m][r];
-      }
-      if (act) {
-        dof_st_row<4>(O + ACT(t, dir * HID + 16 * m + 4 * b, 2 * HID, Sp, s), hn4);
-        if (gs) {
-          dof_st_row<4>(gs + ACT(t, 16 * m + 4 * b, 4 * HID, Sp, s), r4);
-          dof_st_row<4>(gs + ACT(t, HID + 16 * m + 4 * b, 4 * HID, Sp, s), z4);
-          dof_st_row<4>(gs + ACT(t, 2 * HID + 16 * m + 4 * b, 4 * HID, Sp, s), n4);
-          dof_st_row<4>(gs + ACT(t, 3 * HID + 16 * m + 4 * b, 4 * HID, Sp, s), a4);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < XL; ++k) xa[k] = xb[k];
-  }
-  if (!live) return;
-  const float zero4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (int t = n; t < T; ++t)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      dof_st_row<4>(O + ACT(t, dir * HID + 16 * m + 4 * b, 2 * HID, Sp, s), zero4);
-      if (gs) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dof_st_row<4>(gs + ACT(t, g * HID + 16 * m + 4 * b, 4 * HID, Sp, s), zero4);
-      }
-    }
-}
-
 // Backward of that layer from the saved gates: per step the gate gradients of the lane's own units (VALU), then
 //   dh_{t-1} = dht * z + W_hh^T [g_r, g_z, g_h],   dx_t = W_ih^T [g_r, g_z, g_n]
 // on the matrix pipe with the TRANSPOSED weights staged in operand order (row tile = 16 output indices, K block (gate, m, r) =
@@ -1006,7 +874,8 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(Gru8Args A0, Gru8Args A1, int 
   }
 }
 
-#include "k_grum16.inc.h"   // Gru16mStream, k_gru16m_fwd, k_gru8m_fwd, k_gru16m_bwd
+#include "k_grum16.inc.h"   // Gru16mStream, k_gru16x_fwd / _bwd, k_gru8x_fwd / _bwd (latent 8)
+#include "k_grumx.inc.h"    // k_grumx_fwd / _bwd (latent 16 / 32)
 
 
 template <int IN, int HID, bool BCAST>
@@ -2068,7 +1937,7 @@ bool dof_gru16_mfma(int64_t S, int T) {
   return S >= min_s;
 }
 
-// the GEMM-shaped recurrence of the wider layers (k_grum_fwd / k_grum_bwd): same size rule
+// the GEMM-shaped recurrence of the wider layers (k_grumx_fwd / k_grum_bwd): same size rule
 bool dof_grum_selected(int64_t S) {
   // (the alternative here is the quad-split kernel, 290 us for the decoder's 1,024 sequences of a (32, 32) layer: the
   // matrix-pipe form wins from a few hundred sequences on, unlike the (16, 16) layer whose alternative is lane-per-unit)
@@ -2153,14 +2022,14 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
     return dof_check_launch("k_gru3_fwd");
   }
   if ((L == 16 || L == 32) && kind != 2 && dof_grum_selected(S)) {  // encoder-sized launches: the GEMM-shaped recurrence
-    const unsigned nbm = dof_cdiv(S, 64);
-#define GRUM_FWD(IN_, HID_) DOF_LAUNCH((k_grum_fwd<IN_, HID_>), (nbm, 2), (256), st, X, len, W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1, O, GS, T, S, Sp)
+    const unsigned nbm = dof_cdiv(S, 128);   // four wavefronts x two tiles of 16 sequences
+#define GRUM_FWD(IN_, HID_) DOF_LAUNCH((k_grumx_fwd<IN_, HID_>), (nbm, 2), (256), st, X, len, W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1, O, GS, T, S, Sp)
     if (L == 16 && kind == 0) GRUM_FWD(32, 32);
     else if (L == 16) GRUM_FWD(64, 16);
     else if (kind == 0) GRUM_FWD(64, 64);
     else GRUM_FWD(128, 32);
 #undef GRUM_FWD
-    return dof_check_launch("k_grum_fwd");
+    return dof_check_launch("k_grumx_fwd");
   }
   if (L == 16) {  // a sequence across four lanes
     const unsigned nq = dof_cdiv(S * 4, 256);

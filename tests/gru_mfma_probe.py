@@ -1,6 +1,6 @@
 """Child process of test_gru16_matrix_pipe_* : runs the recurrent reference goldens with DOF_GRU_MFMA_MIN_S=0 (set by the
-parent), i.e. through k_gru16m_fwd / k_gru16m_bwd (matrix-pipe recurrence, recomputed gates), k_gru8m_fwd and -- latent 16 / 32 --
-k_grum_fwd / k_grum_bwd at the goldens' small batch sizes, where the product would pick the lane-per-unit kernels.  argv[1] = "emu" | "gpu"."""
+parent), i.e. through k_gru16x_fwd / _bwd and k_gru8x_fwd / _bwd (matrix-pipe recurrences, recomputed gates) and -- latent 16 / 32 --
+k_grumx_fwd / k_grum_bwd at the goldens' small batch sizes, where the product would pick the lane-per-unit kernels.  argv[1] = "emu" | "gpu"."""
 import os
 import sys
 
@@ -23,7 +23,7 @@ for tag, phase in cases:
     print(tag, phase, PC.run_phase_check(lib, dev, G, tag, phase))
 PC.run_trace_check(lib, dev, G)                      # 6 optimiser steps
 PC.run_vqvae_check(lib, dev, G, "rec14")             # VQ-VAE: two decoder passes share the encoder's kernels
-if sys.argv[1] == "gpu":   # the GEMM-shaped recurrence of the wider layers (k_grum_fwd / k_grum_bwd; latent 16 / 32)
+if sys.argv[1] == "gpu":   # the GEMM-shaped recurrence of the wider layers (k_grumx_fwd / k_grum_bwd; latent 16 / 32)
     for tag in ("rec14l16", "rec14l32"):
         PC.run_vqvae_check(lib, dev, G, tag)
         PC.run_contrastive_check(lib, dev, G, tag)
