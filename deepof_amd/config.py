@@ -158,8 +158,8 @@ _SIMS = ("cosine", "dot", "euclidean", "edit")
 _LOSSES = ("nce", "dcl", "dlc", "fc", "hard_dcl")  # the reference accepts the "dlc" typo; both spellings work here (Q13)
 
 
-SUPPORTED_LATENT_DIMS = (4, 6, 8, 16, 32)
-RECURRENT_ONLY_LATENT_DIMS = (32,)   # GRU(64, 64) / GRU(128 -> 32) streams; the TCN / transformer families stop at 16
+SUPPORTED_LATENT_DIMS = (4, 5, 6, 8, 10, 12, 16, 20, 24, 32)
+RECURRENT_ONLY_LATENT_DIMS = (20, 24, 32)   # the TCN / transformer families stop at 16 (row-per-window latent kernels)
 MAX_CONTRASTIVE_NODES = 64
 TRANSFORMER_KEY_DIMS = tuple(range(4, 68, 4))   # every value of min(64, 3 N) // 4 * 4 (models_new.py:1013-1019)
 
@@ -189,6 +189,9 @@ def check_model_inputs(preprocessed_object, adjacency_matrix, meta_info, encoder
         if int(latent_dim) in RECURRENT_ONLY_LATENT_DIMS and str(encoder_type).lower() != "recurrent":
             raise NotImplementedError(f"latent_dim={latent_dim} with encoder_type={encoder_type!r}: this size is built for "
                                       f"the recurrent encoder only")
+        if str(encoder_type).lower() == "transformer" and str(model_name).lower() != "contrastive":
+            # the reference's transformer decoder: 8 heads over d_model = 4 * latent_dim (models_new.py:1272-1277, 1494)
+            assert (4 * int(latent_dim)) % 8 == 0, "d_model must be divisible by num_heads"
         if str(encoder_type).lower() == "transformer":
             # TFMEncoderPT's key_dim = min(64, 3 N) rounded down to a multiple of its 4 heads (models_new.py:1013-1019)
             kd = max(4, min(64, 3 * int(adjacency_matrix.shape[0])) // 4 * 4)

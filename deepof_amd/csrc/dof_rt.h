@@ -226,23 +226,41 @@ __device__ __forceinline__ float dof_row16_max(float v) {
   return v;
 }
 
-// One sequence's C channels at one time step are 4C contiguous, 16-byte aligned bytes: move them
-// as dwordx4 (scalar dword accesses at a 4C-byte lane stride touch 64 cache lines per instruction).
+// One sequence's C channels at one time step are 4C contiguous bytes, aligned to 16 (C % 4 == 0), 8 (C even) or 4: move
+// them as the widest words that alignment allows (scalar dword accesses at a 4C-byte lane stride touch 64 cache lines
+// per instruction).
 template <int C>
 __device__ __forceinline__ void dof_ld_row(const float* __restrict__ p, float* v) {
-  static_assert(C % 4 == 0, "row width must be a multiple of 4 floats");
+  if constexpr (C % 4 == 0) {
 #pragma unroll
-  for (int i = 0; i < C / 4; ++i) {
-    const float4 q = reinterpret_cast<const float4*>(p)[i];
-    v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    for (int i = 0; i < C / 4; ++i) {
+      const float4 q = reinterpret_cast<const float4*>(p)[i];
+      v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+  } else if constexpr (C % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < C / 2; ++i) {
+      const float2 q = reinterpret_cast<const float2*>(p)[i];
+      v[2 * i] = q.x; v[2 * i + 1] = q.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) v[i] = p[i];
   }
 }
 template <int C>
 __device__ __forceinline__ void dof_st_row(float* __restrict__ p, const float* v) {
-  static_assert(C % 4 == 0, "row width must be a multiple of 4 floats");
+  if constexpr (C % 4 == 0) {
 #pragma unroll
-  for (int i = 0; i < C / 4; ++i)
-    reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    for (int i = 0; i < C / 4; ++i)
+      reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else if constexpr (C % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < C / 2; ++i) reinterpret_cast<float2*>(p)[i] = make_float2(v[2 * i], v[2 * i + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) p[i] = v[i];
+  }
 }
 
 // two floats as one 8-byte store (8-byte aligned address)

@@ -1885,12 +1885,17 @@ __global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ ac
 #define DOF_DISPATCH_L(L, CALL)                            \
   switch (L) {                                             \
     case 4: { constexpr int LL = 4; CALL; } break;         \
+    case 5: { constexpr int LL = 5; CALL; } break;         \
     case 6: { constexpr int LL = 6; CALL; } break;         \
     case 8: { constexpr int LL = 8; CALL; } break;         \
+    case 10: { constexpr int LL = 10; CALL; } break;       \
+    case 12: { constexpr int LL = 12; CALL; } break;       \
     case 16: { constexpr int LL = 16; CALL; } break;       \
+    case 20: { constexpr int LL = 20; CALL; } break;       \
+    case 24: { constexpr int LL = 24; CALL; } break;       \
     case 32: { constexpr int LL = 32; CALL; } break;       \
     default:                                               \
-      dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16, 32)", (int)(L)); \
+      dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 10, 12, 16, 20, 24, 32)", (int)(L)); \
       return DOF_ERR_UNSUPPORTED;                          \
   }
 
@@ -2031,19 +2036,20 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
 #undef GRUM_FWD
     return dof_check_launch("k_grumx_fwd");
   }
-  if (L == 16) {  // a sequence across four lanes
+  if (L >= 12 && L % 4 == 0) {  // a sequence across four lanes (at latent 32 thread-per-sequence took 134 ms per C2-shape step)
     const unsigned nq = dof_cdiv(S * 4, 256);
 #define GRUQ_FWD(IN_, HID_, BC_) DOF_LAUNCH((k_gruq_fwd<IN_, HID_, BC_>), (nq, 2), (256), st, X, len, W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1, O, GS, T, S, Sp)
-    if (kind == 0) GRUQ_FWD(32, 32, false);
-    else if (kind == 1) GRUQ_FWD(64, 16, false);
-    else GRUQ_FWD(16, 16, true);
-    return dof_check_launch("k_gruq_fwd");
-  }
-  if (L == 32) {  // the same quad split (thread-per-sequence: 134 ms per C2-shape step, 98 KB of weights per workgroup)
-    const unsigned nq = dof_cdiv(S * 4, 256);
-    if (kind == 0) GRUQ_FWD(64, 64, false);
-    else if (kind == 1) GRUQ_FWD(128, 32, false);
-    else GRUQ_FWD(32, 32, true);
+#define GRUQ_FWD_L(LL_) \
+  case LL_: \
+    if (kind == 0) GRUQ_FWD(2 * LL_, 2 * LL_, false); \
+    else if (kind == 1) GRUQ_FWD(4 * LL_, LL_, false); \
+    else GRUQ_FWD(LL_, LL_, true); \
+    break
+    switch (L) {
+      GRUQ_FWD_L(12); GRUQ_FWD_L(16); GRUQ_FWD_L(20); GRUQ_FWD_L(24); GRUQ_FWD_L(32);
+      default: dof_set_error("GRU: latent_dim %d has no quad-split kernel", L); return DOF_ERR_UNSUPPORTED;
+    }
+#undef GRUQ_FWD_L
 #undef GRUQ_FWD
     return dof_check_launch("k_gruq_fwd");
   }
@@ -2076,19 +2082,20 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
 #undef GRUM_BWD
     return dof_check_launch("k_grum_bwd");
   }
-  if (L == 16) {
+  if (L >= 12 && L % 4 == 0) {
     const unsigned nq = dof_cdiv(S * 4, 256);
 #define GRUQ_BWD(IN_, HID_, BC_) DOF_LAUNCH((k_gruq_bwd<IN_, HID_, BC_>), (nq, 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp)
-    if (kind == 0) GRUQ_BWD(32, 32, false);
-    else if (kind == 1) GRUQ_BWD(64, 16, false);
-    else GRUQ_BWD(16, 16, true);
-    return dof_check_launch("k_gruq_bwd");
-  }
-  if (L == 32) {
-    const unsigned nq = dof_cdiv(S * 4, 256);
-    if (kind == 0) GRUQ_BWD(64, 64, false);
-    else if (kind == 1) GRUQ_BWD(128, 32, false);
-    else GRUQ_BWD(32, 32, true);
+#define GRUQ_BWD_L(LL_) \
+  case LL_: \
+    if (kind == 0) GRUQ_BWD(2 * LL_, 2 * LL_, false); \
+    else if (kind == 1) GRUQ_BWD(4 * LL_, LL_, false); \
+    else GRUQ_BWD(LL_, LL_, true); \
+    break
+    switch (L) {
+      GRUQ_BWD_L(12); GRUQ_BWD_L(16); GRUQ_BWD_L(20); GRUQ_BWD_L(24); GRUQ_BWD_L(32);
+      default: dof_set_error("GRU: latent_dim %d has no quad-split kernel", L); return DOF_ERR_UNSUPPORTED;
+    }
+#undef GRUQ_BWD_L
 #undef GRUQ_BWD
     return dof_check_launch("k_gruq_bwd");
   }

@@ -1030,8 +1030,11 @@ int dof_launch_tfm_dec_expand(int L, const DofDecExp& a, hipStream_t st) {
   const unsigned nb = dof_cdiv(a.B, 256);
   switch (L) {
     case 4: DOF_LAUNCH((k_tfm_dec_expand_fwd<4>), (nb), (256), st, a); break;
+    case 5: DOF_LAUNCH((k_tfm_dec_expand_fwd<5>), (nb), (256), st, a); break;
     case 6: DOF_LAUNCH((k_tfm_dec_expand_fwd<6>), (nb), (256), st, a); break;
     case 8: DOF_LAUNCH((k_tfm_dec_expand_fwd<8>), (nb), (256), st, a); break;
+    case 10: DOF_LAUNCH((k_tfm_dec_expand_fwd<10>), (nb), (256), st, a); break;
+    case 12: DOF_LAUNCH((k_tfm_dec_expand_fwd<12>), (nb), (256), st, a); break;
     case 16: DOF_LAUNCH((k_tfm_dec_expand_fwd<16>), (nb), (256), st, a); break;
     default: dof_set_error("latent_dim %d not supported", L); return DOF_ERR_UNSUPPORTED;
   }
@@ -1042,8 +1045,11 @@ int dof_launch_tfm_dec_expand_bwd(int L, const DofDecExp& a, const float* dg3, f
   const unsigned nb = dof_cdiv(a.B, 256);
   switch (L) {
     case 4: DOF_LAUNCH((k_tfm_dec_expand_bwd<4>), (nb), (256), st, a, dg3, da3, da2, da1, dz); break;
+    case 5: DOF_LAUNCH((k_tfm_dec_expand_bwd<5>), (nb), (256), st, a, dg3, da3, da2, da1, dz); break;
     case 6: DOF_LAUNCH((k_tfm_dec_expand_bwd<6>), (nb), (256), st, a, dg3, da3, da2, da1, dz); break;
     case 8: DOF_LAUNCH((k_tfm_dec_expand_bwd<8>), (nb), (256), st, a, dg3, da3, da2, da1, dz); break;
+    case 10: DOF_LAUNCH((k_tfm_dec_expand_bwd<10>), (nb), (256), st, a, dg3, da3, da2, da1, dz); break;
+    case 12: DOF_LAUNCH((k_tfm_dec_expand_bwd<12>), (nb), (256), st, a, dg3, da3, da2, da1, dz); break;
     case 16: DOF_LAUNCH((k_tfm_dec_expand_bwd<16>), (nb), (256), st, a, dg3, da3, da2, da1, dz); break;
     default: dof_set_error("latent_dim %d not supported", L); return DOF_ERR_UNSUPPORTED;
   }

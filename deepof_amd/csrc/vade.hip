@@ -1287,19 +1287,27 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
 #define LDISPATCH(L, CALL)                         \
   switch (L) {                                     \
     case 4: { constexpr int LL = 4; CALL; } break; \
+    case 5: { constexpr int LL = 5; CALL; } break; \
     case 6: { constexpr int LL = 6; CALL; } break; \
     case 8: { constexpr int LL = 8; CALL; } break; \
+    case 10: { constexpr int LL = 10; CALL; } break; \
+    case 12: { constexpr int LL = 12; CALL; } break; \
     case 16: { constexpr int LL = 16; CALL; } break; \
+    case 20: { constexpr int LL = 20; CALL; } break; \
+    case 24: { constexpr int LL = 24; CALL; } break; \
     case 32: { constexpr int LL = 32; CALL; } break; \
-    default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16, 32)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
+    default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 10, 12, 16, 20, 24, 32)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
   }
 
 // the row-per-window latent kernels (a 16-lane DPP row owns the latent dimensions): latent <= 16 only
 #define LDISPATCH16(L, CALL)                       \
   switch (L) {                                     \
     case 4: { constexpr int LL = 4; CALL; } break; \
+    case 5: { constexpr int LL = 5; CALL; } break; \
     case 6: { constexpr int LL = 6; CALL; } break; \
     case 8: { constexpr int LL = 8; CALL; } break; \
+    case 10: { constexpr int LL = 10; CALL; } break; \
+    case 12: { constexpr int LL = 12; CALL; } break; \
     case 16: { constexpr int LL = 16; CALL; } break; \
     default: dof_set_error("latent_dim %d: the row-per-window latent kernels cover latent <= 16", (int)(L)); return DOF_ERR_UNSUPPORTED; \
   }
@@ -1325,6 +1333,23 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     else if (_l == 4 && _d == 56) DOF_LAUNCH((NAME<4, 56>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 4 && _d == 60) DOF_LAUNCH((NAME<4, 60>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 4 && _d == 64) DOF_LAUNCH((NAME<4, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 10) DOF_LAUNCH((NAME<5, 10>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 4) DOF_LAUNCH((NAME<5, 4>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 8) DOF_LAUNCH((NAME<5, 8>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 12) DOF_LAUNCH((NAME<5, 12>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 16) DOF_LAUNCH((NAME<5, 16>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 20) DOF_LAUNCH((NAME<5, 20>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 24) DOF_LAUNCH((NAME<5, 24>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 28) DOF_LAUNCH((NAME<5, 28>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 32) DOF_LAUNCH((NAME<5, 32>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 36) DOF_LAUNCH((NAME<5, 36>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 40) DOF_LAUNCH((NAME<5, 40>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 44) DOF_LAUNCH((NAME<5, 44>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 48) DOF_LAUNCH((NAME<5, 48>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 52) DOF_LAUNCH((NAME<5, 52>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 56) DOF_LAUNCH((NAME<5, 56>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 60) DOF_LAUNCH((NAME<5, 60>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 5 && _d == 64) DOF_LAUNCH((NAME<5, 64>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 6 && _d == 4) DOF_LAUNCH((NAME<6, 4>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 6 && _d == 8) DOF_LAUNCH((NAME<6, 8>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 6 && _d == 12) DOF_LAUNCH((NAME<6, 12>), GRID, (256), st, __VA_ARGS__); \
@@ -1374,6 +1399,40 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     else if (_l == 16 && _d == 60) DOF_LAUNCH((NAME<16, 60>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 16 && _d == 64) DOF_LAUNCH((NAME<16, 64>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 32 && _d == 64) DOF_LAUNCH((NAME<32, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 4) DOF_LAUNCH((NAME<10, 4>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 8) DOF_LAUNCH((NAME<10, 8>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 12) DOF_LAUNCH((NAME<10, 12>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 16) DOF_LAUNCH((NAME<10, 16>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 20) DOF_LAUNCH((NAME<10, 20>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 24) DOF_LAUNCH((NAME<10, 24>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 28) DOF_LAUNCH((NAME<10, 28>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 32) DOF_LAUNCH((NAME<10, 32>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 36) DOF_LAUNCH((NAME<10, 36>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 40) DOF_LAUNCH((NAME<10, 40>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 44) DOF_LAUNCH((NAME<10, 44>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 48) DOF_LAUNCH((NAME<10, 48>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 52) DOF_LAUNCH((NAME<10, 52>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 56) DOF_LAUNCH((NAME<10, 56>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 60) DOF_LAUNCH((NAME<10, 60>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 10 && _d == 64) DOF_LAUNCH((NAME<10, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 4) DOF_LAUNCH((NAME<12, 4>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 8) DOF_LAUNCH((NAME<12, 8>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 12) DOF_LAUNCH((NAME<12, 12>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 16) DOF_LAUNCH((NAME<12, 16>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 20) DOF_LAUNCH((NAME<12, 20>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 24) DOF_LAUNCH((NAME<12, 24>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 28) DOF_LAUNCH((NAME<12, 28>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 32) DOF_LAUNCH((NAME<12, 32>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 36) DOF_LAUNCH((NAME<12, 36>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 40) DOF_LAUNCH((NAME<12, 40>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 44) DOF_LAUNCH((NAME<12, 44>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 48) DOF_LAUNCH((NAME<12, 48>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 52) DOF_LAUNCH((NAME<12, 52>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 56) DOF_LAUNCH((NAME<12, 56>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 60) DOF_LAUNCH((NAME<12, 60>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 12 && _d == 64) DOF_LAUNCH((NAME<12, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 20 && _d == 40) DOF_LAUNCH((NAME<20, 40>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 24 && _d == 48) DOF_LAUNCH((NAME<24, 48>), GRID, (256), st, __VA_ARGS__); \
     else { dof_set_error("CensNet (latent %d, channels %d) not supported by this build", _l, _d); return DOF_ERR_UNSUPPORTED; } \
   } while (0)
 
@@ -2091,8 +2150,11 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
                   dims->window, dims->n_nodes, dims->n_edges, dims->n_clusters);
     return DOF_ERR_ARG;
   }
-  if (dims->latent != 4 && dims->latent != 6 && dims->latent != 8 && dims->latent != 16 && !(dims->latent == 32 && !tcn && !tfm)) {
-    dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 16; 32 with the recurrent encoder)", dims->latent);
+  const int lat = dims->latent;   // the sizes DOF_DISPATCH_L / LDISPATCH instantiate; above 16 only the recurrent family has a latent head
+  const bool lat_small = lat == 4 || lat == 5 || lat == 6 || lat == 8 || lat == 10 || lat == 12 || lat == 16;
+  const bool lat_large = lat == 20 || lat == 24 || lat == 32;
+  if (!lat_small && !(lat_large && !tcn && !tfm)) {
+    dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 10, 12, 16; 20, 24, 32 with the recurrent encoder)", lat);
     return DOF_ERR_UNSUPPORTED;
   }
   if (dims->n_nodes > DOF_CL_MAX_NODES && kind == 2) {

@@ -6,7 +6,7 @@ tuple ``(model_val, model_score, model_teacher_init_or_None, log_summary)`` and 
 unchanged.  The epoch loop, the step and the optimiser run in libdeepof_hip on a
 ROCm device; data parallelism = one process per GPU, one RCCL all-reduce of the flat gradient per
 step (torch.distributed "nccl").  Model families: VaDE, VQ-VAE and contrastive, each with the recurrent, TCN or
-transformer encoder (``encoder_type``); latent_dim in {4, 6, 8, 16} (check_model_inputs rejects other values up front).
+transformer encoder (``encoder_type``); latent_dim in config.SUPPORTED_LATENT_DIMS (check_model_inputs rejects other values up front).
 """
 from __future__ import annotations
 

@@ -355,6 +355,20 @@ if __name__ == "__main__":
         MG.gen_vade("rec14l32", [""], 25, 32, 10, 40, 531)
         MG.gen_vqvae("rec14l32", [""], 25, 32, 48, 40, 541, kmeans=0.5)
         MG.gen_contrastive("rec14l32", [""], 24, 32, 12, 561)
+    if "lgen" in what:   # round 5: the sizes the generic kernels take (even latent sizes up to 32); batch > latent as above
+        MG.gen_vade("rec14l12", [""], 25, 12, 10, 16, 631)
+        MG.gen_vqvae("rec14l12", [""], 25, 12, 48, 16, 641, kmeans=0.5)
+        MG.gen_contrastive("rec14l12", [""], 24, 12, 12, 661)
+        MG.gen_vade("rec14l24", [""], 25, 24, 10, 28, 731)
+        MG.gen_vqvae("rec14l24", [""], 25, 24, 48, 28, 741, kmeans=0.5)
+        # (seed 761 puts one CensNet ReLU input of case 0 at 1.4e-7, below the fp32 noise of that sum (2.5e-6): its sign is
+        # not a property of the algorithm; 762 keeps every one above 4e-5)
+        MG.gen_contrastive("rec14l24", [""], 24, 24, 12, 762)
+        MG.gen_vade("rec14l10", [""], 25, 10, 10, 12, 831)
+        MG.gen_vade("rec14l20", [""], 25, 20, 10, 24, 931)
+        MG.gen_vade("rec14l5", [""], 25, 5, 10, 12, 1031)     # an odd size: 10- and 20-channel rows (8-byte aligned)
+        MG.gen_vqvae("rec14l5", [""], 25, 5, 48, 12, 1041, kmeans=0.5)
+        MG.gen_contrastive("rec14l5", [""], 24, 5, 12, 1061)
     if "l16tcn" in what:
         MG.gen_contrastive("tcn14l16", [""], 24, 16, 6, 481, encoder_type="TCN", cases=[("cosine", "nce")])
     if "vqkinks" in what:   # refresh only the VQ-VAE part of tcn_kinks.npz

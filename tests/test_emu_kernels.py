@@ -14,7 +14,7 @@ def test_gather_emu():
     gather_check(emu_lib(), "cpu")
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l5", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
 def test_vade_eval_forward_emu(golden_dir, tag):
     d = load_golden(golden_dir, f"vade_{tag}.npz")
     x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
@@ -32,7 +32,8 @@ def test_vade_eval_forward_emu(golden_dir, tag):
 @pytest.mark.parametrize("tag,phase", [("rec14", "pre"), ("rec14", "main"), ("rec14", "mainT"), ("rec14", "mainX"),
                                        ("rec28", "pre"), ("rec28", "mainT"), ("rec28", "mainX"),
                                        ("c5l8", "pre"), ("c5l8", "mainX"),
-                                       ("rec14l16", "pre"), ("rec14l16", "mainX"), ("rec14l32", "pre")])   # (latent 32: the other phases / models on the GPU)
+                                       ("rec14l16", "pre"), ("rec14l16", "mainX"), ("rec14l32", "pre"),
+                                       ("rec14l12", "mainX"), ("rec14l10", "pre"), ("rec14l5", "main"), ("rec14l5", "mainX")])   # (latent 32: the other phases / models on the GPU)
 def test_vade_loss_grads_emu(golden_dir, tag, phase):
     run_phase_check(emu_lib(), "cpu", golden_dir, tag, phase)
 
@@ -52,7 +53,7 @@ def test_vade_train_trace_emu(golden_dir):
     run_trace_check(emu_lib(), "cpu", golden_dir)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "rec14l16"])   # (c5l8 / c3k512 / rec14l32: GPU only, minutes each under the emulator)
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "rec14l16", "rec14l12", "rec14l5"])   # (c5l8 / c3k512 / rec14l32: GPU only, minutes each under the emulator)
 def test_vqvae_emu(golden_dir, tag):
     run_vqvae_check(emu_lib(), "cpu", golden_dir, tag)
 
@@ -63,7 +64,7 @@ def test_contrastive_losses_emu(golden_dir, tag):
     run_contrastive_loss_check(emu_lib(), "cpu", golden_dir, tag)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l12", "rec14l5"])
 def test_contrastive_step_emu(golden_dir, tag):
     from parity_common import run_contrastive_check
     run_contrastive_check(emu_lib(), "cpu", golden_dir, tag)
@@ -102,7 +103,7 @@ def test_distillation_head_emu(golden_dir):
     run_distill_head_check(emu_lib(), "cpu", golden_dir)
 
 
-@pytest.mark.parametrize("L", [4, 6, 16])   # 16: the decoder's repeated input takes 64-channel rows
+@pytest.mark.parametrize("L", [4, 5, 6, 12, 16])   # 16: the decoder's repeated input takes 64-channel rows
 def test_vade_tcn_padded_decoder_input_emu(L):
     from parity_common import run_vade_tcn_vs_oracle
     run_vade_tcn_vs_oracle(emu_lib(), "cpu", L=L)
@@ -201,7 +202,8 @@ def test_contrastive_tfm_emu(golden_dir):
 
 @pytest.mark.parametrize("n_nodes,latent,kind", [(8, 4, "vade"), (11, 6, "vqvae"), (16, 8, "vade"), (22, 8, "vqvae"),
                                                   (11, 16, "vade"), (11, 16, "vqvae"), (14, 16, "vade"), (8, 16, "vqvae"),
-                                                  (10, 8, "vade"), (12, 6, "vqvae"), (19, 8, "vade"), (7, 6, "vqvae")])
+                                                  (10, 8, "vade"), (12, 6, "vqvae"), (19, 8, "vade"), (7, 6, "vqvae"),
+                                                  (11, 10, "vade"), (11, 12, "vqvae")])
 def test_tfm_other_widths_emu(n_nodes, latent, kind):
     """key_dim 24 / 32 / 48 / 64 and decoder widths 16 / 24 / 32 of the transformer family against the oracle."""
     print(PC.run_tfm_widths_vs_oracle(emu_lib(), "cpu", n_nodes, latent, B=4, T=6, kind=kind))

@@ -56,7 +56,7 @@ def test_gather_matches_reference_windows(hip, golden_dir):
             np.testing.assert_array_equal(a.cpu().numpy(), d[f"w{ci}::a"])
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l5", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
 def test_vade_eval_forward_gpu(hip, golden_dir, tag):
     from deepof_amd.engine import create_vade_engine
     from parity_common import load_golden, params_from
@@ -79,7 +79,11 @@ def test_vade_eval_forward_gpu(hip, golden_dir, tag):
                                        ("c5l8", "pre"), ("c5l8", "main"), ("c5l8", "mainT"), ("c5l8", "mainX"),
                                        # latent 16: GRU(32, 32) / GRU(64 -> 16) streams through the generic kernels
                                        ("rec14l16", "pre"), ("rec14l16", "main"), ("rec14l16", "mainT"), ("rec14l16", "mainX"),
-                                       ("rec14l32", "pre"), ("rec14l32", "main"), ("rec14l32", "mainT"), ("rec14l32", "mainX")])
+                                       ("rec14l32", "pre"), ("rec14l32", "main"), ("rec14l32", "mainT"), ("rec14l32", "mainX"),
+                                       ("rec14l5", "pre"), ("rec14l5", "main"), ("rec14l5", "mainT"), ("rec14l5", "mainX"),
+                                       ("rec14l10", "pre"), ("rec14l10", "mainX"), ("rec14l12", "pre"), ("rec14l12", "main"),
+                                       ("rec14l12", "mainT"), ("rec14l12", "mainX"), ("rec14l20", "pre"), ("rec14l20", "mainX"),
+                                       ("rec14l24", "pre"), ("rec14l24", "main"), ("rec14l24", "mainT"), ("rec14l24", "mainX")])
 def test_vade_loss_grads_gpu(hip, golden_dir, tag, phase):
     from parity_common import run_phase_check
     worst = run_phase_check(hip, "cuda", golden_dir, tag, phase)
@@ -252,7 +256,7 @@ def test_training_api_on_gpu(hip, tmp_path):
     np.testing.assert_allclose(soft.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32", "rec14l5", "rec14l12", "rec14l24"])
 def test_vqvae_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_vqvae_check
     run_vqvae_check(hip, "cuda", golden_dir, tag)
@@ -324,7 +328,7 @@ def test_vqvae_full_size_c3(hip):
     np.testing.assert_allclose(out["soft_counts"].cpu().numpy(), soft.numpy(), rtol=2e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l5", "rec14l12", "rec14l24"])
 def test_contrastive_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_contrastive_check, run_contrastive_loss_check
     run_contrastive_loss_check(hip, "cuda", golden_dir, tag)
@@ -669,7 +673,7 @@ def test_distillation_head_gpu(hip, golden_dir):
     run_distill_head_check(hip, "cuda", golden_dir)
 
 
-@pytest.mark.parametrize("L", [4, 6, 16])
+@pytest.mark.parametrize("L", [4, 5, 6, 10, 12, 16])
 def test_vade_tcn_padded_decoder_input_gpu(hip, L):
     from parity_common import run_vade_tcn_vs_oracle
     run_vade_tcn_vs_oracle(hip, "cuda", L=L)
@@ -1336,7 +1340,9 @@ def test_data_parallel_default_form_is_one_graph_native(tmp_path):
                                                   # round 4: every key_dim = min(64, 3 N) // 4 * 4 (28, 36, 44, 52, 56, 60, 20, 12, 8, 4);
                                                   # N = 7, 12, 18, 19 also hold a sequence whose every key is masked (NaN -> zero row)
                                                   (10, 8, "vade"), (12, 6, "vqvae"), (15, 8, "vade"), (18, 4, "vqvae"), (19, 8, "vade"),
-                                                  (20, 16, "vqvae"), (7, 6, "vqvae"), (5, 8, "vade"), (3, 8, "vade"), (2, 8, "vade")])
+                                                  (20, 16, "vqvae"), (7, 6, "vqvae"), (5, 8, "vade"), (3, 8, "vade"), (2, 8, "vade"),
+                                                  # round 5: latent 10 / 12 (decoder widths 40 / 48)
+                                                  (14, 10, "vade"), (11, 10, "vqvae"), (14, 12, "vqvae"), (11, 12, "vade")])
 def test_tfm_other_widths_gpu(hip, n_nodes, latent, kind):
     """key_dim 24 / 32 / 48 / 64, latent 4 / 6 / 8 (decoder widths 16 / 24 / 32) of the transformer family against the
     oracle on injected random keep-masks: eval forward with a masked frame, total loss and every gradient."""
