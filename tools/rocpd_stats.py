@@ -31,7 +31,7 @@ def timeline(path, marker, which=-2):
     rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
     a, b = marks[which], marks[which + 1]
-    print(f"| # | kernel | dur_us | gap_us |\n|---|---|---|---|")
+    print(f"| # | kernel | dur_us | gap_us | start_us |\n|---|---|---|---|---|")
     busy = gaps = 0.0
     for i in range(a, b):
         n, s, e = rows[i]
@@ -40,7 +40,7 @@ def timeline(path, marker, which=-2):
         gap = (s - rows[i - 1][2]) / 1e3
         busy += (e - s) / 1e3
         gaps += max(gap, 0.0)
-        print(f"| {i - a} | {n} | {(e - s) / 1e3:.2f} | {gap:.2f} |")
+        print(f"| {i - a} | {n} | {(e - s) / 1e3:.2f} | {gap:.2f} | {(s - rows[a][1]) / 1e3:.1f} |")
     print(f"\nstep span {(rows[b][1] - rows[a][1]) / 1e3:.1f} us: {b - a} dispatches, busy {busy:.1f} us, idle {gaps:.1f} us")
 
 
