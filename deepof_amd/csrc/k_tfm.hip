@@ -13,9 +13,9 @@
 // rows with s >= S are never written and stay zero from the bind, which the weight-gradient reductions rely on).
 // All dense layers are one kernel: rows x K times K x N on v_mfma_f32_16x16x4_f32 (exact fp32), the weight matrix
 // staged once per workgroup in LDS in B-operand order, A operands as 16-byte row loads (the k index is permuted
-// consistently on both operands so that a lane's float4 feeds four consecutive MFMAs).  Attention works on T <= 64
-// steps and head sizes 4..16: one thread per (sequence, head, query), q/k/v of a few sequences staged in LDS, the
-// backward pass recomputes the probabilities (nothing but q, k, v and the output is stored).
+// consistently on both operands so that a lane's float4 feeds four consecutive MFMAs).  Attention on windows <= 64
+// and head sizes 1..16: one thread per (sequence, head, query), q/k/v of a few sequences staged in LDS, the backward pass
+// recomputes the probabilities (nothing but q, k, v and the output is stored); longer windows: k_tfm_attn_*_long.
 // Dropout keep-masks are a counter-based hash of (site seed, device step counter, element index in the reference's
 // tensor order) evaluated where needed in forward and backward -- or read from an injected byte mask (parity tests).
 #include <cmath>
@@ -29,6 +29,7 @@ namespace {
 
 constexpr int kGemmLds = 12288;  // floats: KC * NT * 256 <= kGemmLds
 constexpr int kAttLds = 16384;   // floats
+constexpr int kAttLongStats = 12288;   // floats: 3 per (head, row) of one sequence in k_tfm_attn_bwd_long (heads x window <= 4096)
 
 __device__ __forceinline__ float drop_scale(const DofDrop& d, uint32_t ctr, int64_t idx) {
   if (d.scale == 0.0f) return 1.0f;
@@ -440,6 +441,178 @@ __global__ void __launch_bounds__(512) k_tfm_attn_bwd(DofAttn A) {
       }
     }
     float* __restrict__ dst = A.dqkv + ((int64_t)tx * A.Sp + s0 + seq) * W + h * DH;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      dst[D + d] = dk[d];
+      dst[2 * D + d] = dv[d];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention for windows the LDS-resident kernels above do not take (T > 64, or a window x width product beyond their
+// 64 KB; round 5).  One sequence per workgroup; a thread owns (row, head) pairs and walks the other rows straight from
+// global memory (a sequence's q | k | v rows are T * 3 D floats -- 98 KB at T = 128, D = 64 -- read by the workgroup's own
+// threads only, i.e. from its L1 / L2), with a running maximum instead of a row of probabilities in registers.  Same
+// arithmetic per element as the resident kernels (scaled q, fmaf chains over the head width, __expf, 1 / sum, the
+// dropout factor on the normalised probability), the sums over keys in key order.  No window limit; the model's default
+// windows never come here.
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ void __launch_bounds__(256) k_tfm_attn_fwd_long(DofAttn A) {
+  const int T = A.T, D = A.D, H = A.H, W = 3 * D;
+  const int64_t s = blockIdx.x;
+  if (s >= A.S) return;
+  const float scale = A.scale;
+  const uint32_t ctr = drop_ctr(A.drop);
+  auto row = [&](int t) { return A.qkv + ((int64_t)t * A.Sp + s) * W; };
+  auto masked = [&](int tq, int tk) { return (A.causal && tk > tq) || (A.pad && A.pad[(int64_t)tk * A.Sp + s] != 0.0f); };
+  for (int item = threadIdx.x; item < T * H; item += blockDim.x) {
+    const int tq = item % T, h = item / T;
+    if (A.q_last && tq != T - 1) continue;
+    float q[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) q[d] = row(tq)[h * DH + d] * scale;
+    float mx = -INFINITY;
+    for (int tk = 0; tk < T; ++tk) {
+      if (masked(tq, tk)) continue;
+      const float* __restrict__ kr = row(tk) + D + h * DH;
+      float sc = 0.0f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) sc = fmaf(q[d], kr[d], sc);
+      mx = fmaxf(mx, sc);
+    }
+    float l = 0.0f;
+    for (int tk = 0; tk < T; ++tk) {
+      float sc = -INFINITY;
+      if (!masked(tq, tk)) {
+        const float* __restrict__ kr = row(tk) + D + h * DH;
+        sc = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) sc = fmaf(q[d], kr[d], sc);
+      }
+      l += __expf(sc - mx);   // all keys masked: exp(-inf + inf) = NaN, as the reference's softmax
+    }
+    const float inv = 1.0f / l;
+    const int64_t dbase = ((s * H + h) * T + tq) * (int64_t)T;
+    float o[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = 0.0f;
+    for (int tk = 0; tk < T; ++tk) {
+      float sc = -INFINITY;
+      const float* __restrict__ kr = row(tk) + D + h * DH;
+      if (!masked(tq, tk)) {
+        sc = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) sc = fmaf(q[d], kr[d], sc);
+      }
+      const float pw = __expf(sc - mx) * inv * drop_scale(A.drop, ctr, dbase + tk);
+      const float* __restrict__ vr = kr + D;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) o[d] = fmaf(pw, vr[d], o[d]);
+    }
+    float* __restrict__ dst = A.ao + ((int64_t)tq * A.Sp + s) * D + h * DH;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dst[d] = o[d];
+  }
+}
+
+// backward: phase A (thread = query row): row maximum, 1 / row sum, sum_k P dP, then dQ; the three row statistics go to
+// LDS ([h][t][3], 12 B per row and head).  Phase B (thread = key / value row): dK, dV over the query rows.
+template <int DH>
+__global__ void __launch_bounds__(256) k_tfm_attn_bwd_long(DofAttn A) {
+  __shared__ float sst[kAttLongStats];
+  const int T = A.T, D = A.D, H = A.H, W = 3 * D;
+  const int64_t s = blockIdx.x;
+  if (s >= A.S) return;
+  const float scale = A.scale;
+  const uint32_t ctr = drop_ctr(A.drop);
+  auto row = [&](int t) { return A.qkv + ((int64_t)t * A.Sp + s) * W; };
+  auto grow = [&](int t) { return A.dao + ((int64_t)t * A.Sp + s) * D; };
+  auto padded = [&](int tk) { return A.pad && A.pad[(int64_t)tk * A.Sp + s] != 0.0f; };
+  for (int item = threadIdx.x; item < T * H; item += blockDim.x) {
+    const int tx = item % T, h = item / T;
+    if (A.q_last && tx != T - 1) continue;
+    float q[DH], go[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      q[d] = row(tx)[h * DH + d] * scale;
+      go[d] = grow(tx)[h * DH + d];
+    }
+    auto score = [&](int tk) {
+      float sc = -INFINITY;
+      if (!(A.causal && tk > tx) && !padded(tk)) {
+        const float* __restrict__ kr = row(tk) + D + h * DH;
+        sc = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) sc = fmaf(q[d], kr[d], sc);
+      }
+      return sc;
+    };
+    float mx = -INFINITY;
+    for (int tk = 0; tk < T; ++tk) mx = fmaxf(mx, score(tk));
+    float l = 0.0f;
+    for (int tk = 0; tk < T; ++tk) l += __expf(score(tk) - mx);
+    const float inv = 1.0f / l;
+    const int64_t dbase = ((s * H + h) * T + tx) * (int64_t)T;
+    auto dprob = [&](int tk) {
+      const float* __restrict__ vr = row(tk) + 2 * D + h * DH;
+      float a = 0.0f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) a = fmaf(go[d], vr[d], a);
+      return a * drop_scale(A.drop, ctr, dbase + tk);
+    };
+    float drow = 0.0f;
+    for (int tk = 0; tk < T; ++tk) drow = fmaf(__expf(score(tk) - mx) * inv, dprob(tk), drow);
+    float dq[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = 0.0f;
+    for (int tk = 0; tk < T; ++tk) {
+      const float ds = __expf(score(tk) - mx) * inv * (dprob(tk) - drow);
+      const float* __restrict__ kr = row(tk) + D + h * DH;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kr[d], dq[d]);
+    }
+    float* __restrict__ dst = A.dqkv + ((int64_t)tx * A.Sp + s) * W + h * DH;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dst[d] = dq[d] * scale;
+    float* __restrict__ st = sst + (h * T + tx) * 3;
+    st[0] = mx; st[1] = inv; st[2] = drow;
+  }
+  __syncthreads();
+  for (int item = threadIdx.x; item < T * H; item += blockDim.x) {
+    const int tx = item % T, h = item / T;
+    float kk[DH], vv[DH], dk[DH], dv[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      kk[d] = row(tx)[D + h * DH + d];
+      vv[d] = row(tx)[2 * D + h * DH + d];
+      dk[d] = 0.0f;
+      dv[d] = 0.0f;
+    }
+    const bool key_masked = padded(tx);
+    for (int tq = (A.q_last ? T - 1 : (A.causal ? tx : 0)); tq < T; ++tq) {
+      const float* __restrict__ st = sst + (h * T + tq) * 3;
+      const float* __restrict__ qr = row(tq) + h * DH;
+      const float* __restrict__ gr = grow(tq) + h * DH;
+      float sc = 0.0f, a = 0.0f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        sc = fmaf(qr[d], kk[d], sc);
+        a = fmaf(gr[d], vv[d], a);
+      }
+      float pw = key_masked ? 0.0f : __expf(sc * scale - st[0]) * st[1];
+      if (key_masked && !(st[0] > -INFINITY)) pw = NAN;  // a row with every key masked is NaN in the reference
+      const float ks = drop_scale(A.drop, ctr, ((s * H + h) * T + tq) * (int64_t)T + tx);
+      const float ds = pw * (a * ks - st[2]) * scale;
+      const float pd = pw * ks;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        dk[d] = fmaf(ds, qr[d], dk[d]);
+        dv[d] = fmaf(pd, gr[d], dv[d]);
+      }
+    }
+    float* __restrict__ dst = A.dqkv + ((int64_t)tx * A.Sp + s) * W + h * DH;
 #pragma unroll
     for (int d = 0; d < DH; ++d) {
       dst[D + d] = dk[d];
@@ -903,10 +1076,14 @@ static int attn_nseq(const DofAttn& a, bool bwd) {
 // multiple of 4 in 4 .. 64; the decoder's 8 heads of width 4 L / 8 (latent 4, 6, 8, 16: 2, 3, 4, 8)
 // does a (window, width, heads) attention fit the kernels' LDS / thread budget, forward AND backward?  (plan creation
 // asks, so that an unsupported shape fails there and not at the first backward pass)
+// (resident kernels: windows <= 64 that fit their LDS; otherwise the long-window pair, whose only bound is its LDS table of
+// three row statistics per head and row)
+static bool attn_resident(const DofAttn& a, bool bwd) { return a.T <= 64 && attn_nseq(a, bwd) >= 1; }
 bool dof_tfm_attn_fits(int T, int D, int H) {
   DofAttn a = {};
   a.T = T; a.D = D; a.H = H;
-  return T <= 64 && D % H == 0 && attn_nseq(a, false) >= 1 && attn_nseq(a, true) >= 1;
+  if (D % H != 0 || D / H > 16) return false;
+  return (attn_resident(a, false) && attn_resident(a, true)) || 3 * H * T <= kAttLongStats;
 }
 
 #define ATTN_DISPATCH(NAME, A, nb, nt)                                                        \
@@ -951,17 +1128,34 @@ bool dof_tfm_attn_fits(int T, int D, int H) {
     }                                                                                         \
   } while (0)
 
-int dof_launch_tfm_attn(DofAttn a, int backward, hipStream_t st) {
-  if (a.T > 64 || a.D % a.H) {
-    dof_set_error("attention: window %d > 64 or width %d not divisible by %d heads", a.T, a.D, a.H);
-    return DOF_ERR_UNSUPPORTED;
+#define ATTN_LONG_CASE(NAME, DHV) case DHV: DOF_LAUNCH((NAME<DHV>), ((unsigned)a.S), (256), st, a); break
+#define ATTN_LONG_DISPATCH(NAME)                                                                                  \
+  switch (a.D / a.H) {                                                                                            \
+    ATTN_LONG_CASE(NAME, 1); ATTN_LONG_CASE(NAME, 2); ATTN_LONG_CASE(NAME, 3); ATTN_LONG_CASE(NAME, 4);           \
+    ATTN_LONG_CASE(NAME, 5); ATTN_LONG_CASE(NAME, 6); ATTN_LONG_CASE(NAME, 7); ATTN_LONG_CASE(NAME, 8);           \
+    ATTN_LONG_CASE(NAME, 9); ATTN_LONG_CASE(NAME, 10); ATTN_LONG_CASE(NAME, 11); ATTN_LONG_CASE(NAME, 12);        \
+    ATTN_LONG_CASE(NAME, 13); ATTN_LONG_CASE(NAME, 14); ATTN_LONG_CASE(NAME, 15); ATTN_LONG_CASE(NAME, 16);       \
+    default: dof_set_error("attention head size %d not supported", a.D / a.H); return DOF_ERR_UNSUPPORTED;        \
   }
-  a.nseq = attn_nseq(a, backward != 0);
-  if (a.nseq < 1) {
-    dof_set_error("attention: window %d x width %d does not fit the LDS budget", a.T, a.D);
+
+int dof_launch_tfm_attn(DofAttn a, int backward, hipStream_t st) {
+  if (a.D % a.H) {
+    dof_set_error("attention: width %d not divisible by %d heads", a.D, a.H);
     return DOF_ERR_UNSUPPORTED;
   }
   a.scale = 1.0f / std::sqrt((float)(a.D / a.H));
+  // one choice for the pair: the backward kernel recomputes what the forward kernel computed, in the same order
+  if (!(attn_resident(a, false) && attn_resident(a, true))) {
+    if (3 * a.H * a.T > kAttLongStats) {
+      dof_set_error("attention: %d heads x window %d exceed the long-window kernel's statistics table (%d rows)", a.H, a.T,
+                    kAttLongStats / 3);
+      return DOF_ERR_UNSUPPORTED;
+    }
+    a.nseq = 1;
+    if (backward) { ATTN_LONG_DISPATCH(k_tfm_attn_bwd_long) } else { ATTN_LONG_DISPATCH(k_tfm_attn_fwd_long) }
+    return dof_check_launch("k_tfm_attn_long");
+  }
+  a.nseq = attn_nseq(a, backward != 0);
   const unsigned nb = dof_cdiv(a.S, a.nseq);
   const unsigned nt = (unsigned)((a.nseq * a.H * a.T + 63) / 64 * 64);
   if (backward) ATTN_DISPATCH(k_tfm_attn_bwd, a, nb, nt);

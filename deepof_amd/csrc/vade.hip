@@ -2180,12 +2180,13 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
     tf.D4 = 4 * p->L;
     tf.C3p = (p->C3 + 3) / 4 * 4;
     p->D = kd;
-    // (the attention kernels keep a sequence's q | k | v [+ dO] rows and statistics in 64 KB of LDS: window x width is bounded)
+    // (windows <= 64 whose q | k | v [+ dO] rows fit 64 KB of LDS take the resident attention kernels, longer ones the
+    // long-window pair: heads x window <= 4096)
     const bool fits = dof_tfm_attn_fits(p->T, kd, tf.H) && (kind == 2 || dof_tfm_attn_fits(p->T, tf.D4, 8));
-    if (p->T > 64 || kd < 4 || kd > 64 || kd % 4 != 0 || !fits) {
-      dof_set_error("transformer plan: window %d (max 64; window x width must fit the attention kernels' 64 KB of LDS: "
-                    "window * (4 * width + 13) <= 16384 for the encoder width %d and the decoder width %d) / key_dim %d "
-                    "(multiples of 4 up to 64) not supported by this build", p->T, kd, tf.D4, kd);
+    if (kd < 4 || kd > 64 || kd % 4 != 0 || !fits) {
+      dof_set_error("transformer plan: window %d (heads x window <= 4096: 512 steps with the decoder's 8 heads) / key_dim %d "
+                    "(multiples of 4 up to 64) / decoder width %d (a multiple of its 8 heads, <= 128) not supported by this build",
+                    p->T, kd, tf.D4);
       delete p;
       return DOF_ERR_UNSUPPORTED;
     }

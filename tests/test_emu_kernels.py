@@ -209,6 +209,12 @@ def test_tfm_other_widths_emu(n_nodes, latent, kind):
     print(PC.run_tfm_widths_vs_oracle(emu_lib(), "cpu", n_nodes, latent, B=4, T=6, kind=kind))
 
 
+@pytest.mark.parametrize("n_nodes,latent,kind,T", [(8, 8, "vade", 66), (11, 6, "vqvae", 70)])
+def test_tfm_long_windows_emu(n_nodes, latent, kind, T):
+    """Windows beyond the LDS-resident attention kernels (T > 64): k_tfm_attn_fwd_long / _bwd_long against the oracle."""
+    print(PC.run_tfm_widths_vs_oracle(emu_lib(), "cpu", n_nodes, latent, B=2, T=T, kind=kind))
+
+
 def test_gru16_matrix_pipe_kernels_emu():
     """k_gru16m_fwd / k_gru16m_bwd (the encoder streams' (16, 16) GRU on the matrix pipe, gates recomputed in the
     backward pass) against the reference goldens: a child process with DOF_GRU_MFMA_MIN_S=0, because at the goldens'

@@ -687,6 +687,16 @@ def test_vade_tcn_windows_over_25_gpu(hip, T):
     run_vade_tcn_vs_oracle(hip, "cuda", L=8, T=T)
 
 
+@pytest.mark.parametrize("T,B,seed", [(60, 3, 389003), (75, 2, 162003)])
+def test_vade_tcn_windows_over_50_gpu(hip, T, B, seed):
+    """Windows beyond the time-resident TCN kernels (T > 50: k_tcn_conv's four fetches per row, k_outer weight gradients)
+    against the oracle on a tie-free draw.  The chance of a draw without a ReLU input inside the tie margin falls with the
+    number of pre-activations: small batches, and the seeds are the first tie-free ones of run_vade_tcn_vs_oracle's own
+    search from seed 3 (attempts 390 and 163 -- found once on the host, a minute each; the function re-checks the margin)."""
+    from parity_common import run_vade_tcn_vs_oracle
+    run_vade_tcn_vs_oracle(hip, "cuda", L=8, T=T, B=B, seed=seed)
+
+
 def test_full_size_c5_gradients_equal_chunked_small_launches(hip):
     """The B = 4096 launch geometry of C5 (245,760 sequences per stream: the matrix-pipe GRU kernels, 16 windows per
     gather workgroup, 256-workgroup reductions) against the SMALL-launch geometry the reference goldens pin
@@ -1348,6 +1358,17 @@ def test_tfm_other_widths_gpu(hip, n_nodes, latent, kind):
     oracle on injected random keep-masks: eval forward with a masked frame, total loss and every gradient."""
     from parity_common import run_tfm_widths_vs_oracle
     print("worst gradient error / tensor scale:", run_tfm_widths_vs_oracle(hip, "cuda", n_nodes, latent, B=24, T=25, kind=kind))
+
+
+@pytest.mark.parametrize("n_nodes,latent,kind,T", [(14, 8, "vade", 65), (11, 6, "vqvae", 100), (14, 8, "vade", 128), (8, 4, "vqvae", 200),
+                                                   (22, 8, "vade", 64)])   # (64 steps x key_dim 64: beyond the resident kernels' LDS)
+def test_tfm_long_windows_gpu(hip, n_nodes, latent, kind, T):
+    """Transformer windows the LDS-resident attention kernels do not take (T > 64, or window x width beyond 64 KB) run the
+    long-window pair (k_tfm_attn_fwd_long / _bwd_long: one sequence per workgroup, rows from global memory, running
+    maximum): eval forward with a masked frame, total loss and every gradient against the oracle, as
+    test_tfm_other_widths_gpu does for the resident kernels."""
+    from parity_common import run_tfm_widths_vs_oracle
+    print("worst gradient error / tensor scale:", run_tfm_widths_vs_oracle(hip, "cuda", n_nodes, latent, B=6, T=T, kind=kind))
 
 
 def test_step_begin_noise_gpu(hip):
