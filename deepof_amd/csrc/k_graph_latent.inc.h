@@ -218,6 +218,8 @@ struct LatentFwdArgs {
   float *enc, *mu, *pre, *sv, *z;  // [L][Bp]
   float *q, *qn;      // [K][Bp] posterior, clamp+renormalised posterior
   float *z_out, *q_out, *mu_out, *sv_out, *enc_out;  // reference-layout exports (B,L)/(B,K) or null
+  // k_latent_fwd_w: the Gram Z^T Z of the workgroup's 16 windows, [workgroup][L][L] (what k_kmeans_eig sums), or null
+  float* gram_partial = nullptr;
   int K;
   int64_t B, Bp;
 };
@@ -371,6 +373,7 @@ template <int L, int NC>
 __global__ void __launch_bounds__(256) k_latent_fwd_w(LatentFwdArgs A) {
   constexpr int KMAX = 16 * NC;
   __shared__ float s_inv[KMAX * L], s_gm[KMAX * L], s_const[KMAX];
+  __shared__ float s_zz[kLatRows][L * L];   // z z^T of each window (gram_partial)
   __shared__ float s_wm[L * L], s_ws[L * L], s_bm[L], s_bs[L];
   __shared__ float s_wf[kWfMax];  // [input][l]
   const int K = A.K;
@@ -444,6 +447,20 @@ __global__ void __launch_bounds__(256) k_latent_fwd_w(LatentFwdArgs A) {
     constexpr int d = decltype(dc)::value;
     z[d] = dof_gbcast<d, 16>(zl);
   });
+  if (A.gram_partial) {  // (round 5) the k-means term's Gram, 16 windows here, the workgroups' tiles summed by k_kmeans_eig:
+    // the separate reduction launch over z (k_outer, ~17 us at C2) is gone.  Row sums in window order.
+    if (j < L) {
+#pragma unroll
+      for (int d = 0; d < L; ++d) s_zz[row][l * L + d] = live ? zl * z[d] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < L * L; e += 256) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int r = 0; r < kLatRows; ++r) acc += s_zz[r][e];
+      A.gram_partial[(int64_t)blockIdx.x * (L * L) + e] = acc;
+    }
+  }
   // posterior: softmax_c(log(prior+1e-9) + sum_d log N(z_d; m_cd, max(exp(l_cd/2),1e-3)))
   float lg[NC], mx = -INFINITY;
 #pragma unroll
@@ -493,20 +510,21 @@ __global__ void __launch_bounds__(256) k_latent_fwd_w(LatentFwdArgs A) {
 //   loss = w * mean_i sqrt(max(lambda_i(Z^T Z / B), 1e-9)) ;  dLoss/dZ = w/(L*B) * Z * G^{-1/2}
 // One thread, cyclic Jacobi in fp64 on the L x L Gram (formed in fp32 like the reference).
 // ---------------------------------------------------------------------------------------------
-// partial != null: the Gram's partial tiles ([nblk][64][65] of the weight-gradient reduction, one job) are reduced here
+// partial != null: the Gram's partial tiles ([nblk][64][65] of the weight-gradient reduction, one job: row_stride 65,
+// tile_stride DOF_OUTER_PARTIAL_FLOATS; or k_latent_fwd_w's [nblk][L][L]: row_stride L, tile_stride L L) are reduced here
 // first -- k_outer_finalize's arithmetic per element (64 lanes stride over the tiles, fixed butterfly), 16 wavefronts x
 // 4 elements -- and also written to gram_sum: the finalize launch in front of this kernel is gone.
 template <int L>
 __global__ void __launch_bounds__(1024) k_kmeans_eig(float* __restrict__ gram_sum, const float* __restrict__ partial, int nblk,
                                                     const float* __restrict__ hyper, int64_t B,
                                                     float* __restrict__ km_out /*[0]=weighted loss*/,
-                                                    float* __restrict__ Pm /*[L][L]*/) {
+                                                    float* __restrict__ Pm /*[L][L]*/, int row_stride, int tile_stride) {
   if (partial) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int e = wv; e < L * L; e += nw) {
-      const float* __restrict__ p = partial + (int64_t)(e / L) * 65 + (e % L);
+      const float* __restrict__ p = partial + (int64_t)(e / L) * row_stride + (e % L);
       float acc = 0.0f;
-      for (int b = lane; b < nblk; b += 64) acc += p[(int64_t)b * DOF_OUTER_PARTIAL_FLOATS];
+      for (int b = lane; b < nblk; b += 64) acc += p[(int64_t)b * tile_stride];
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
       if (lane == 0) gram_sum[e] = acc;

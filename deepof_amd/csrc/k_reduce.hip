@@ -13,6 +13,7 @@
 //    (/root/reference/deepof/clustering/training.py:162-166, losses.py:817-833).
 #include "dof_rt.h"
 #include "launchers.h"
+#include "k_sum_partials.inc.h"
 
 namespace {
 
@@ -186,23 +187,7 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_sum_partials_multi(DofSumJobs J, int accumulate) {
   __shared__ float red[256];
-  int v = blockIdx.x, j = 0;
-  while (j + 1 < J.n && v >= J.nv[j]) {
-    v -= J.nv[j];
-    ++j;
-  }
-  const float* __restrict__ partial = J.partial[j];
-  const int64_t nblk = J.nblk[j];
-  const int nv = J.nv[j];
-  float acc = 0.0f;
-  for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += partial[b * nv + v];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) J.out[j][v] = accumulate ? J.out[j][v] + red[0] : red[0];
+  dof_sum_partials_multi_body(J, (int)blockIdx.x, accumulate, red);
 }
 
 // clip_grad_value_ + Adam on the flat buffer.  The Adam step count t of every optimiser segment lives on the device

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include "dof_rt.h"
 #include "launchers.h"
+#include "k_sum_partials.inc.h"
 
 namespace {
 
@@ -1160,16 +1161,13 @@ struct WgFinArgs {
   int nblk;
   float* g[8];  // wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1
 };
-__global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinArgs A1, WgFinArgs A2, int accumulate) {
-  const WgFinArgs& A = blockIdx.z == 0 ? A0 : blockIdx.z == 1 ? A1 : A2;
+__device__ __forceinline__ void gru16_wg_finalize_body(const WgFinArgs& A, int bx, int dir, int accumulate, float (*red)[kWgVals + 1]) {
   const float* __restrict__ wg_partial = A.wg_partial;
   const int nblk = A.nblk;
   float *g_wih0 = A.g[0], *g_whh0 = A.g[1], *g_bih0 = A.g[2], *g_bhh0 = A.g[3], *g_wih1 = A.g[4], *g_whh1 = A.g[5],
         *g_bih1 = A.g[6], *g_bhh1 = A.g[7];
-  __shared__ float red[32][kWgVals + 1];
-  const int dir = blockIdx.y;
   const int vi = (int)threadIdx.x & (kWgVals - 1), slice = (int)threadIdx.x / kWgVals;
-  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU16_WG_FLOATS + blockIdx.x * kWgVals + vi;
+  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU16_WG_FLOATS + bx * kWgVals + vi;
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
   int r = slice;
   for (; r + 96 < nblk; r += 128) {
@@ -1185,7 +1183,7 @@ __global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinAr
   float val = 0.0f;
 #pragma unroll
   for (int k = 0; k < 32; ++k) val += red[k][vi];
-  const int v = blockIdx.x * kWgVals + vi;
+  const int v = bx * kWgVals + vi;
   float* g_wih = dir ? g_wih1 : g_wih0;
   float* g_whh = dir ? g_whh1 : g_whh0;
   float* g_bih = dir ? g_bih1 : g_bih0;
@@ -1203,6 +1201,10 @@ __global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinAr
       *d1 = accumulate ? *d1 + val : val;
     }
   }
+}
+__global__ void __launch_bounds__(256) k_gru16_wg_finalize(WgFinArgs A0, WgFinArgs A1, WgFinArgs A2, int accumulate) {
+  __shared__ float red[32][kWgVals + 1];
+  gru16_wg_finalize_body(blockIdx.z == 0 ? A0 : blockIdx.z == 1 ? A1 : A2, (int)blockIdx.x, (int)blockIdx.y, accumulate, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1442,16 +1444,13 @@ __global__ void __launch_bounds__(256) k_gru8_wg_finalize(WgFinArgs A0, WgFinArg
 // grads of a (32 -> 8) GRU layer from k_gru8x_bwd's per-wavefront partials [dir][nblk][GRU8X_WG_FLOATS] (the reference's
 // tensors in order: weight_ih, weight_hh, then the bias sums of g_r, g_z, g_n, g_h); same reduction shape as
 // k_gru16_wg_finalize (8 neighbouring values x 32 row slices per workgroup, slices added in a fixed order)
-__global__ void __launch_bounds__(256) k_gru8x_wg_finalize(WgFinArgs A0, WgFinArgs A1, int accumulate) {
-  const WgFinArgs& A = blockIdx.z ? A1 : A0;
+__device__ __forceinline__ void gru8x_wg_finalize_body(const WgFinArgs& A, int bx, int dir, int accumulate, float (*red)[kWgVals + 1]) {
   const float* __restrict__ wg_partial = A.wg_partial;
   const int nblk = A.nblk;
   constexpr int NV = 8;
-  static_assert(GRU8X_WG_FLOATS % NV == 0, "value groups");
-  __shared__ float red[32][NV + 1];
-  const int dir = blockIdx.y;
+  static_assert(GRU8X_WG_FLOATS % NV == 0 && NV == kWgVals, "value groups");
   const int vi = (int)threadIdx.x & (NV - 1), slice = (int)threadIdx.x / NV;
-  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU8X_WG_FLOATS + blockIdx.x * NV + vi;
+  const float* __restrict__ p = wg_partial + (int64_t)dir * nblk * GRU8X_WG_FLOATS + bx * NV + vi;
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
   int r = slice;
   for (; r + 96 < nblk; r += 128) {
@@ -1467,7 +1466,7 @@ __global__ void __launch_bounds__(256) k_gru8x_wg_finalize(WgFinArgs A0, WgFinAr
   float val = 0.0f;
 #pragma unroll
   for (int k = 0; k < 32; ++k) val += red[k][vi];
-  const int v = blockIdx.x * NV + vi;
+  const int v = bx * NV + vi;
   float* g_wih = A.g[dir ? 4 : 0];
   float* g_whh = A.g[dir ? 5 : 1];
   float* g_bih = A.g[dir ? 6 : 2];
@@ -1481,6 +1480,39 @@ __global__ void __launch_bounds__(256) k_gru8x_wg_finalize(WgFinArgs A0, WgFinAr
     else if (kind == 2) put(&g_bih[16 + unit]);
     else put(&g_bhh[16 + unit]);
   }
+}
+__global__ void __launch_bounds__(256) k_gru8x_wg_finalize(WgFinArgs A0, WgFinArgs A1, int accumulate) {
+  __shared__ float red[32][kWgVals + 1];
+  gru8x_wg_finalize_body(blockIdx.z ? A1 : A0, (int)blockIdx.x, (int)blockIdx.y, accumulate, red);
+}
+
+// The end-of-step reductions of the latent-8 recurrent step in ONE launch (round 5): the first layer's weight-gradient tiles
+// (two encoder streams + the decoder's second layer), the second layer's (two streams) and the plain partial sums
+// (LayerNorm weights / biases, mixture parameters) were three launches of 7 - 16 us one after another, each a few hundred
+// workgroups of latency-bound strided sums; side by side they take what the longest takes.  Block ranges:
+// [0, n16) k_gru16_wg_finalize's blocks (x fastest, then direction, then layer), [n16, n16 + n8) k_gru8x_wg_finalize's,
+// the rest k_sum_partials_multi's (one output value each).  Same arithmetic and summation order as the three kernels.
+struct StepFinArgs {
+  WgFinArgs a16[3];
+  WgFinArgs a8[2];
+  DofSumJobs sums;
+  int n16, n8;   // block counts of the first two ranges
+};
+__global__ void __launch_bounds__(256) k_step_finalize(StepFinArgs A, int accumulate) {
+  __shared__ float red[32][kWgVals + 1];
+  __shared__ float red1[256];
+  constexpr int NX16 = GRU16_WG_FLOATS / kWgVals, NX8 = GRU8X_WG_FLOATS / kWgVals;
+  int b = (int)blockIdx.x;
+  if (b < A.n16) {
+    gru16_wg_finalize_body(A.a16[b / (2 * NX16)], b % NX16, (b / NX16) & 1, accumulate, red);
+    return;
+  }
+  b -= A.n16;
+  if (b < A.n8) {
+    gru8x_wg_finalize_body(A.a8[b / (2 * NX8)], b % NX8, (b / NX8) & 1, accumulate, red);
+    return;
+  }
+  dof_sum_partials_multi_body(A.sums, b - A.n8, accumulate, red1);
 }
 
 template <int C>
@@ -2178,6 +2210,23 @@ int dof_launch_gru8_wg_finalize_pair(const float* const wg_partial[2], const int
   const WgFinArgs A1 = wg_fin_args(wg_partial[1], (int)dof_cdiv(S[1], 32), g, off[1]);
   DOF_LAUNCH(k_gru8_wg_finalize, ((unsigned)(GRU8_WG_FLOATS / 8), 2, 2), (256), st, A0, A1, accumulate);
   return dof_check_launch("k_gru8_wg_finalize");
+}
+
+// k_step_finalize: n16 = 2 or 3 first-layer partial sets, the two second-layer sets of k_gru8x_bwd, the plain sums
+bool dof_step_finalize_selected(const int64_t S8[2], int T) { return dof_gru8m_fwd_selected(S8[0], S8[1], T); }
+int dof_launch_step_finalize(const float* const* wg16, const int64_t* S16, const int64_t* const* off16, int n16,
+                             const float* const wg8[2], const int64_t S8[2], const int64_t* const off8[2],
+                             const DofSumJobs& sums, float* g, int accumulate, hipStream_t st) {
+  StepFinArgs A;
+  for (int k = 0; k < 3; ++k) A.a16[k] = wg_fin_args(wg16[k < n16 ? k : 0], (int)dof_cdiv(S16[k < n16 ? k : 0], 16), g, off16[k < n16 ? k : 0]);
+  for (int k = 0; k < 2; ++k) A.a8[k] = wg_fin_args(wg8[k], (int)dof_cdiv(S8[k], 16), g, off8[k]);
+  A.sums = sums;
+  A.n16 = n16 * 2 * (GRU16_WG_FLOATS / kWgVals);
+  A.n8 = 2 * 2 * (GRU8X_WG_FLOATS / kWgVals);
+  int total = 0;
+  for (int j = 0; j < sums.n; ++j) total += sums.nv[j];
+  DOF_LAUNCH(k_step_finalize, ((unsigned)(A.n16 + A.n8 + total)), (256), st, A, accumulate);
+  return dof_check_launch("k_step_finalize");
 }
 
 static_assert(GRU8X_WG_FLOATS == GRU8_WG_FLOATS, "one partial-row size for both backward kernels of the layer");

@@ -298,6 +298,12 @@ struct DofSumJobs {
   float* out[8];
 };
 int dof_launch_sum_partials_multi(const DofSumJobs& jobs, int accumulate, hipStream_t st);
+// the latent-8 recurrent step's three end-of-step reductions in one launch (k_step_finalize): n16 (2 or 3) first-layer
+// weight-gradient partial sets, k_gru8x_bwd's two second-layer sets, the plain partial sums
+bool dof_step_finalize_selected(const int64_t S8[2], int T);
+int dof_launch_step_finalize(const float* const* wg16, const int64_t* S16, const int64_t* const* off16, int n16,
+                             const float* const wg8[2], const int64_t S8[2], const int64_t* const off8[2],
+                             const DofSumJobs& sums, float* g, int accumulate, hipStream_t st);
 
 struct DofAdamSeg {  // one contiguous parameter range with its own lr / step count / freeze flag
   int64_t lo, hi;

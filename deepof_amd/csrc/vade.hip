@@ -186,6 +186,8 @@ struct DofVadePlan {
   StreamWs sw[2];
   int64_t flat, enc, mu, pre, sv, z, q, qn, dlogit, dmu_dpre, denc, dflat;
   int64_t gram, Pm, km, stats, dqbar, dcen, dscat, dlogp2, tf_partial, scal;
+  int64_t gram_part = 0;       // Gram tiles written by k_latent_fwd_w (VaDE, row-per-window latent kernels)
+  bool gram_in_latent = false; // ... by the latent_forward call in front of gram_spectrum
   int64_t mlse, mzs, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   bool tail_wide = false;
@@ -745,6 +747,7 @@ void take_latent_buffers(DofVadePlan* p, Carver& cv) {
   p->dlogit = cv.take((int64_t)K * Bp);
   p->dmu_dpre = cv.take(2LL * L * Bp);
   p->gram = cv.take(L * L);
+  p->gram_part = cv.take(dof_cdiv(p->B, 16) * (int64_t)L * L);   // k_latent_fwd_w's Gram tiles (kLatRows = 16 windows each)
   p->Pm = cv.take(L * L);
   p->km = cv.take(1);
   p->stats = cv.take((int64_t)K * (3 * L + 1) + 4);
@@ -1683,6 +1686,8 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
   A.q = ws + p->q; A.qn = ws + p->qn;
   A.z_out = z_out; A.q_out = q_out; A.mu_out = mu_out; A.sv_out = sv_out; A.enc_out = enc_out;
   A.K = p->K; A.B = p->B; A.Bp = p->Bp;
+  p->gram_in_latent = rows && p->kind == 0;   // the Gram of ws.z for the k-means term, 16 windows per tile
+  A.gram_partial = p->gram_in_latent ? ws + p->gram_part : nullptr;
   if (!rows) {
     LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd<LL>), (dof_cdiv(p->B, 256)), (256), st, A));
   } else if (p->K <= 16) {
@@ -2064,11 +2069,14 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
                           ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
   }
-  if (L == 8 && gru8_fused()) {  // the second layer's weight gradients of both streams: one finalize launch
+  // latent 8 on the matrix-pipe kernels: the second layer's finalize, the first layer's and the plain partial sums are ONE
+  // launch at the end of this function (k_step_finalize)
+  const int64_t S2f[2] = {p->sw[0].S, p->sw[1].S};
+  const bool one_fin = L == 8 && gru8_fused() && dof_step_finalize_selected(S2f, T);
+  if (L == 8 && gru8_fused() && !one_fin) {  // the second layer's weight gradients of both streams: one finalize launch
     const float* wg[2] = {ws + p->sw[0].wg2, ws + p->sw[1].wg2};
-    const int64_t S2[2] = {p->sw[0].S, p->sw[1].S};
     const int64_t* off[2] = {p->blk[0].g2.t, p->blk[1].g2.t};
-    TRY(dof_launch_gru8_wg_finalize_pair(wg, S2, grads, off, accumulate, st, T));
+    TRY(dof_launch_gru8_wg_finalize_pair(wg, S2f, grads, off, accumulate, st, T));
   }
   int paired = 0;
   if (L == 8) {   // first layer: both streams in one launch when the matrix-pipe kernels serve it
@@ -2107,13 +2115,14 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     const int64_t S[2] = {p->sw[0].S, p->sw[1].S}, Sp[2] = {p->sw[0].Sp, p->sw[1].Sp};
     TRY(dof_launch_enc_conv_wgrad(2 * L, act, dXc, xs, F, T, S, Sp, p->conv_wg_part, ws + p->partials, st));
   }
-  if (L == 8) {  // the first layer's weight gradients of both streams: one finalize launch
-    const float* wg[3] = {ws + p->sw[0].wg1, ws + p->sw[1].wg1, p->pend_wg16};
-    const int64_t S1[3] = {p->sw[0].S, p->sw[1].S, p->pend_wg16_S};
-    const int64_t* off[3] = {p->blk[0].g1.t, p->blk[1].g1.t, p->pend_wg16_off};
-    TRY(dof_launch_gru16_wg_finalize_pair(wg, S1, grads, off, accumulate, st, (p->pend_wg16 && !accumulate) ? 3 : 2));
-    p->pend_wg16 = nullptr;
+  const float* wg16[3] = {ws + p->sw[0].wg1, ws + p->sw[1].wg1, p->pend_wg16};
+  const int64_t S16[3] = {p->sw[0].S, p->sw[1].S, p->pend_wg16_S};
+  const int64_t* off16[3] = {p->blk[0].g1.t, p->blk[1].g1.t, p->pend_wg16_off};
+  const int n16 = (p->pend_wg16 && !accumulate) ? 3 : 2;
+  if (L == 8 && !one_fin) {  // the first layer's weight gradients of both streams: one finalize launch
+    TRY(dof_launch_gru16_wg_finalize_pair(wg16, S16, grads, off16, accumulate, st, n16));
   }
+  if (L == 8) p->pend_wg16 = nullptr;
   {  // LayerNorm weight / bias gradients of both streams: one launch
     DofSumJobs sj;
     sj.n = 4;
@@ -2130,7 +2139,13 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
       ++sj.n;
     }
     p->pend.n = 0;
-    TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
+    if (one_fin) {
+      const float* wg8[2] = {ws + p->sw[0].wg2, ws + p->sw[1].wg2};
+      const int64_t* off8[2] = {p->blk[0].g2.t, p->blk[1].g2.t};
+      TRY(dof_launch_step_finalize(wg16, S16, off16, n16, wg8, S2f, off8, sj, grads, accumulate, st));
+    } else {
+      TRY(dof_launch_sum_partials_multi(sj, accumulate, st));
+    }
   }
   return run_jobset(p, p->use_js_all ? p->js_all : p->js_enc, grads, accumulate, st);
 }
@@ -2419,13 +2434,19 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
 
 static int gram_spectrum(DofVadePlan* p, const float* hyper, hipStream_t st) {
   float* ws = p->ws;
+  if (p->gram_in_latent) {   // VaDE: k_latent_fwd_w left the Gram of its 16-window groups
+    const int L = p->L;
+    LDISPATCH(p->L, DOF_LAUNCH((k_kmeans_eig<LL>), (1), (1024), st, ws + p->gram, (const float*)(ws + p->gram_part),
+                               (int)dof_cdiv(p->B, 16), hyper, p->B, ws + p->km, ws + p->Pm, L, L * L));
+    return dof_check_launch("k_kmeans_eig");
+  }
   // the Gram's reduction (one job of the weight-gradient kernel); its partial tiles are summed inside the eigen-solver's launch
   const JobSet& js = p->js_gram;
   const DofOuterJob* jobs = reinterpret_cast<const DofOuterJob*>(ws + js.jobs_tab);
   TRY(dof_launch_outer(jobs, (int)js.jobs.size(), js.total_blocks, ws + p->partials, st));
   const float* part = ws + p->partials + js.jobs[0].partial_off;
   LDISPATCH(p->L, DOF_LAUNCH((k_kmeans_eig<LL>), (1), (1024), st, ws + p->gram, part, js.jobs[0].nblk, hyper, p->B, ws + p->km,
-                             ws + p->Pm));
+                             ws + p->Pm, 65, (int)DOF_OUTER_PARTIAL_FLOATS));
   return dof_check_launch("k_kmeans_eig");
 }
 
