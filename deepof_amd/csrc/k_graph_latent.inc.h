@@ -514,11 +514,15 @@ __global__ void __launch_bounds__(256) k_latent_fwd_w(LatentFwdArgs A) {
 // tile_stride DOF_OUTER_PARTIAL_FLOATS; or k_latent_fwd_w's [nblk][L][L]: row_stride L, tile_stride L L) are reduced here
 // first -- k_outer_finalize's arithmetic per element (64 lanes stride over the tiles, fixed butterfly), 16 wavefronts x
 // 4 elements -- and also written to gram_sum: the finalize launch in front of this kernel is gone.
+struct KmeansEigArgs {   // (an argument set with partial == null and gram_sum == null: "not in this launch")
+  float* gram_sum; const float* partial; int nblk; const float* hyper; int64_t B; float* km_out; float* Pm;
+  int row_stride, tile_stride;
+};
 template <int L>
-__global__ void __launch_bounds__(1024) k_kmeans_eig(float* __restrict__ gram_sum, const float* __restrict__ partial, int nblk,
-                                                    const float* __restrict__ hyper, int64_t B,
-                                                    float* __restrict__ km_out /*[0]=weighted loss*/,
-                                                    float* __restrict__ Pm /*[L][L]*/, int row_stride, int tile_stride) {
+__device__ __forceinline__ void kmeans_eig_body(float* __restrict__ gram_sum, const float* __restrict__ partial, int nblk,
+                                                const float* __restrict__ hyper, int64_t B,
+                                                float* __restrict__ km_out /*[0]=weighted loss*/,
+                                                float* __restrict__ Pm /*[L][L]*/, int row_stride, int tile_stride) {
   if (partial) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int e = wv; e < L * L; e += nw) {
@@ -531,7 +535,7 @@ __global__ void __launch_bounds__(1024) k_kmeans_eig(float* __restrict__ gram_su
     }
     __syncthreads();  // (the same workgroup reads gram_sum below: global writes of a workgroup are visible to it after the barrier)
   }
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (threadIdx.x != 0) return;
   const float w_lat = hyper[DOF_H_KM_LATENT];
   const float w_loss = hyper[DOF_H_KM_LOSS];
   if (!(w_lat > 0.0f) || w_loss == 0.0f) {  // value and gradient are multiplied by both weights
@@ -539,7 +543,9 @@ __global__ void __launch_bounds__(1024) k_kmeans_eig(float* __restrict__ gram_su
     for (int i = 0; i < L * L; ++i) Pm[i] = 0.0f;
     return;
   }
-  double a[L][L], v[L][L];
+  // (LDS, not per-thread arrays: dynamically indexed private arrays are scratch memory, which every wavefront of the launches
+  // this body is merged into would be sized for)
+  __shared__ double a[L][L], v[L][L], inv[L];
   for (int i = 0; i < L; ++i)
     for (int j = 0; j < L; ++j) {
       a[i][j] = (double)(gram_sum[i * L + j] / (float)B);
@@ -577,7 +583,7 @@ __global__ void __launch_bounds__(1024) k_kmeans_eig(float* __restrict__ gram_su
         }
       }
   }
-  double val = 0.0, inv[L];
+  double val = 0.0;
   for (int i = 0; i < L; ++i) {
     const double lam = fabs(a[i][i]);  // singular values of a symmetric matrix = |eigenvalues|
     val += sqrt(lam > 1e-9 ? lam : 1e-9);
@@ -592,6 +598,13 @@ __global__ void __launch_bounds__(1024) k_kmeans_eig(float* __restrict__ gram_su
       for (int k = 0; k < L; ++k) acc += v[i][k] * inv[k] * v[j][k];
       Pm[i * L + j] = (float)(scale * acc);
     }
+}
+template <int L>
+__global__ void __launch_bounds__(1024) k_kmeans_eig(float* __restrict__ gram_sum, const float* __restrict__ partial, int nblk,
+                                                    const float* __restrict__ hyper, int64_t B, float* __restrict__ km_out,
+                                                    float* __restrict__ Pm, int row_stride, int tile_stride) {
+  if (blockIdx.x != 0) return;
+  kmeans_eig_body<L>(gram_sum, partial, nblk, hyper, B, km_out, Pm, row_stride, tile_stride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -838,9 +851,12 @@ __device__ __forceinline__ void mckl_body(const McklArgs& A, const int blk) {
     A.partial[blk] = t;
   }
 }
+// (E.gram_sum != null: one more workgroup, the last, is the k-means term's eigen-solver -- independent of the statistics, a
+// single-thread fp64 Jacobi of ~5 us that used to be a launch of its own)
 template <int L>
-__global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A) {
-  batch_stats_body<L>(A, (int)blockIdx.x);
+__global__ void __launch_bounds__(256) k_batch_stats(StatsArgs A, KmeansEigArgs E, int n_stats) {
+  if ((int)blockIdx.x < n_stats) batch_stats_body<L>(A, (int)blockIdx.x);
+  else if (E.gram_sum) kmeans_eig_body<L>(E.gram_sum, E.partial, E.nblk, E.hyper, E.B, E.km_out, E.Pm, E.row_stride, E.tile_stride);
 }
 template <int L>
 __global__ void __launch_bounds__(256) k_mckl(McklArgs A) {
@@ -849,9 +865,10 @@ __global__ void __launch_bounds__(256) k_mckl(McklArgs A) {
 // Both in one launch (they are independent and each is a few dozen workgroups of latency): workgroups [0, n_stats) take the
 // batch statistics, the rest the Monte-Carlo KL term.
 template <int L>
-__global__ void __launch_bounds__(256) k_stats_mckl(StatsArgs SA, McklArgs MA, int n_stats) {
+__global__ void __launch_bounds__(256) k_stats_mckl(StatsArgs SA, McklArgs MA, int n_stats, KmeansEigArgs E, int n_mckl) {
   if ((int)blockIdx.x < n_stats) batch_stats_body<L>(SA, (int)blockIdx.x);
-  else mckl_body<L>(MA, (int)blockIdx.x - n_stats);
+  else if ((int)blockIdx.x < n_stats + n_mckl) mckl_body<L>(MA, (int)blockIdx.x - n_stats);
+  else if (E.gram_sum) kmeans_eig_body<L>(E.gram_sum, E.partial, E.nblk, E.hyper, E.B, E.km_out, E.Pm, E.row_stride, E.tile_stride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1060,14 +1077,18 @@ __global__ void k_loss_mid(LossMidArgs A) {
   lg[DOF_LOG_TOTAL] = recon + kl + nonempty + prior_loss + A.km[0] + activity + repel + cat + temporal + scatter;
 }
 
-__global__ void k_loss_total(const float* __restrict__ distill_partial, const float* __restrict__ tf_partial, int n,
-                             const float* __restrict__ hyper, int64_t B, int pretrain, float* __restrict__ logs,
-                             double* __restrict__ accum) {
-  // launched as one wavefront; lane i owns logs[i] (and its running fp64 sum when the caller keeps one)
+struct LossTotalArgs {   // (logs == null: "not in this launch")
+  const float* distill_partial; const float* tf_partial; int n; const float* hyper; int64_t B; int pretrain; float* logs;
+  double* accum;
+};
+// one wavefront (threads 0 .. 63 of the calling workgroup); lane i owns logs[i] (and its running fp64 sum when the caller keeps one)
+__device__ __forceinline__ void loss_total_body(const float* __restrict__ distill_partial, const float* __restrict__ tf_partial, int n,
+                                                const float* __restrict__ hyper, int64_t B, int pretrain, float* __restrict__ logs,
+                                                double* __restrict__ accum) {
   const float s = dof_wave_sum_array(distill_partial, n);
   const float t = dof_wave_sum_array(tf_partial, n);
   const int i = (int)threadIdx.x;
-  if (i >= DOF_LOG_COUNT || blockIdx.x != 0) return;
+  if (i >= DOF_LOG_COUNT) return;
   const float d = hyper[DOF_H_LAMBDA_DISTILL] * s / (float)B;
   const float tf = pretrain ? 0.0f : -hyper[DOF_H_TF_W] * t / (float)B;
   float v = logs[i];
@@ -1076,6 +1097,12 @@ __global__ void k_loss_total(const float* __restrict__ distill_partial, const fl
   if (i == DOF_LOG_TOTAL) v += d + tf;
   if (i == DOF_LOG_DISTILL || i == DOF_LOG_TFCLUST || i == DOF_LOG_TOTAL) logs[i] = v;
   if (accum) accum[i] += (double)v;
+}
+__global__ void k_loss_total(const float* __restrict__ distill_partial, const float* __restrict__ tf_partial, int n,
+                             const float* __restrict__ hyper, int64_t B, int pretrain, float* __restrict__ logs,
+                             double* __restrict__ accum) {
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  loss_total_body(distill_partial, tf_partial, n, hyper, B, pretrain, logs, accum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1645,8 +1672,15 @@ struct GmmGradArgs {
   int64_t B, Bp;
 };
 
+// (LT.logs != null: workgroup (K, 0) -- one past the components -- finishes the step's logged totals, k_loss_total's
+// one-wavefront job: both wait for k_latent_bwd only)
 template <int L>
-__global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A) {
+__global__ void __launch_bounds__(256) k_gmm_grads(GmmGradArgs A, LossTotalArgs LT) {
+  if ((int)blockIdx.x >= A.K) {
+    if (LT.logs && blockIdx.y == 0 && threadIdx.x < 64)
+      loss_total_body(LT.distill_partial, LT.tf_partial, LT.n, LT.hyper, LT.B, LT.pretrain, LT.logs, LT.accum);
+    return;
+  }
   const int c = blockIdx.x;
   float vals[2 * L];
 #pragma unroll

@@ -81,11 +81,9 @@ __global__ void __launch_bounds__(256) k_enc_conv_fwd(const float* __restrict__ 
 // counted in LDS and stored once (no global atomics).
 constexpr int ENC_CONV_LDS = 12288;  // floats: largest window (T*G*F) staged; larger ones take the direct kernel
 template <int C1, int F>
-__global__ void __launch_bounds__(256) k_enc_conv_fwd_lds(const float* __restrict__ xin, const float* __restrict__ w,
-                                                          float* __restrict__ xs, float* __restrict__ c,
-                                                          int* __restrict__ len, int T, int G, int64_t S, int64_t Sp) {
-  __shared__ float sy[ENC_CONV_LDS];
-  __shared__ int cnt[256];
+__device__ __forceinline__ void enc_conv_fwd_lds_body(const float* __restrict__ xin, const float* __restrict__ w,
+                                                      float* __restrict__ xs, float* __restrict__ c, int* __restrict__ len,
+                                                      int T, int G, int64_t S, int64_t Sp, float* sy, int* cnt) {
   const int64_t b = blockIdx.x;
   const int GF = G * F, n = T * GF;
   const float* __restrict__ win = xin + b * (int64_t)n;
@@ -126,6 +124,30 @@ __global__ void __launch_bounds__(256) k_enc_conv_fwd_lds(const float* __restric
   }
   __syncthreads();
   if ((int)threadIdx.x < G) len[b * G + threadIdx.x] = cnt[threadIdx.x];
+}
+template <int C1, int F>
+__global__ void __launch_bounds__(256) k_enc_conv_fwd_lds(const float* __restrict__ xin, const float* __restrict__ w,
+                                                          float* __restrict__ xs, float* __restrict__ c,
+                                                          int* __restrict__ len, int T, int G, int64_t S, int64_t Sp) {
+  __shared__ float sy[ENC_CONV_LDS];
+  __shared__ int cnt[256];
+  enc_conv_fwd_lds_body<C1, F>(xin, w, xs, c, len, T, G, S, Sp, sy, cnt);
+}
+// both encoder streams (node: 3 features per group, edge: 1) in one launch, blockIdx.y = stream: the two launches were
+// 21 + 15 us of one-pass-and-a-tail workgroups at C2; side by side the tails overlap
+struct EncConvFwdArgs {
+  const float* xin; const float* w; float* xs; float* c; int* len;
+  int G; int64_t S, Sp;
+};
+template <int C1>
+__global__ void __launch_bounds__(256) k_enc_conv_fwd_lds_pair(EncConvFwdArgs A0, EncConvFwdArgs A1, int T) {
+  __shared__ float sy[ENC_CONV_LDS];
+  __shared__ int cnt[256];
+  if (blockIdx.y == 0) {
+    if ((int64_t)blockIdx.x * A0.G < A0.S) enc_conv_fwd_lds_body<C1, 3>(A0.xin, A0.w, A0.xs, A0.c, A0.len, T, A0.G, A0.S, A0.Sp, sy, cnt);
+  } else {
+    if ((int64_t)blockIdx.x * A1.G < A1.S) enc_conv_fwd_lds_body<C1, 1>(A1.xin, A1.w, A1.xs, A1.c, A1.len, T, A1.G, A1.S, A1.Sp, sy, cnt);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1931,6 +1953,22 @@ __global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ ac
       return DOF_ERR_UNSUPPORTED;                          \
   }
 
+// the node (F = 3) and the edge (F = 1) stream's encoder convolution in one launch; returns 1 when launched, 0 when the
+// shapes ask for the per-stream launcher (a window that does not fit the LDS staging), < 0 on error
+int dof_launch_enc_conv_fwd_pair(int L, const int F[2], const float* const xin[2], const float* const w[2], float* const xs[2],
+                                 float* const c[2], int* const len[2], int T, const int G[2], const int64_t S[2],
+                                 const int64_t Sp[2], hipStream_t st) {
+  if (F[0] != 3 || F[1] != 1) return 0;
+  EncConvFwdArgs A[2];
+  unsigned nwin = 0;
+  for (int k = 0; k < 2; ++k) {
+    if (!((int64_t)T * G[k] * F[k] <= ENC_CONV_LDS && G[k] <= 256 && S[k] % G[k] == 0)) return 0;
+    A[k].xin = xin[k]; A[k].w = w[k]; A[k].xs = xs[k]; A[k].c = c[k]; A[k].len = len[k]; A[k].G = G[k]; A[k].S = S[k]; A[k].Sp = Sp[k];
+    if ((unsigned)(S[k] / G[k]) > nwin) nwin = (unsigned)(S[k] / G[k]);
+  }
+  DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd_lds_pair<2 * LL>), (nwin, 2), (256), st, A[0], A[1], T));
+  return dof_check_launch("k_enc_conv_fwd_lds_pair") == DOF_OK ? 1 : DOF_ERR_LAUNCH;
+}
 int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, float* xs, float* c, int* len, int T,
                             int G, int64_t S, int64_t Sp, hipStream_t st) {
   const unsigned nb = dof_cdiv((int64_t)T * S, 256);

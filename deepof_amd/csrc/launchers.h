@@ -10,6 +10,9 @@ struct DofGruW {  // both directions of one torch.nn.GRU layer (weight_ih_l0[_re
 };
 
 // ---- k_rnn.hip ------------------------------------------------------------------------------
+int dof_launch_enc_conv_fwd_pair(int L, const int F[2], const float* const xin[2], const float* const w[2], float* const xs[2],
+                                 float* const c[2], int* const len[2], int T, const int G[2], const int64_t S[2],
+                                 const int64_t Sp[2], hipStream_t st);   // 1: launched, 0: use the per-stream launcher
 int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, float* xs, float* c, int* len, int T,
                             int G, int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_gru16_fwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], float* const O[2], int T,

@@ -1519,7 +1519,19 @@ int encoder_forward(DofVadePlan* p, const float* params, const float* x, const f
   const int L = p->L, T = p->T;
   // stage by stage over both streams (they are independent): the first GRU layer of the two streams shares one launch
   // when the matrix-pipe kernels serve it (dof_launch_gru16_fwd_pair)
-  for (int s = 0; s < 2; ++s) {
+  int conv_paired;
+  {  // encoder convolutions: both streams in one launch when both windows fit the LDS staging
+    const int F2[2] = {p->sw[0].F, p->sw[1].F}, G2[2] = {p->sw[0].G, p->sw[1].G};
+    const float* xin[2] = {x, a};
+    const float* wc[2] = {params + p->blk[0].conv, params + p->blk[1].conv};
+    float* xs2[2] = {ws + p->sw[0].xs, ws + p->sw[1].xs};
+    float* c2[2] = {ws + p->sw[0].c, ws + p->sw[1].c};
+    int* len2[2] = {reinterpret_cast<int*>(ws + p->sw[0].len), reinterpret_cast<int*>(ws + p->sw[1].len)};
+    const int64_t S2[2] = {p->sw[0].S, p->sw[1].S}, Sp2[2] = {p->sw[0].Sp, p->sw[1].Sp};
+    conv_paired = dof_launch_enc_conv_fwd_pair(L, F2, xin, wc, xs2, c2, len2, T, G2, S2, Sp2, st);
+    if (conv_paired < 0) return conv_paired;
+  }
+  for (int s = 0; s < 2 && !conv_paired; ++s) {
     const StreamWs& w = p->sw[s];
     TRY(dof_launch_enc_conv_fwd(L, w.F, s == 0 ? x : a, params + p->blk[s].conv, ws + w.xs, ws + w.c,
                                 reinterpret_cast<int*>(ws + w.len), T, w.G, w.S, w.Sp, st));
@@ -2492,7 +2504,9 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   // ---------------- forward
   TRY(encoder_forward(p, params, x, a, true, st));
   TRY(latent_forward(p, params, prior, eps, nullptr, nullptr, nullptr, nullptr, nullptr, st));
-  TRY(gram_spectrum(p, hyper, st));
+  // the k-means term's eigen-solver: with the Gram tiles of k_latent_fwd_w it is one more workgroup of the statistics launch below
+  const bool eig_here = p->gram_in_latent;
+  if (!eig_here) TRY(gram_spectrum(p, hyper, st));
   TRY(decoder_forward(p, params, x, ws + p->z, ws + p->recon_partial, true, nullptr, st));
 
   // ---------------- decoder backward (needed first: it yields d loss / d z)
@@ -2505,6 +2519,11 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
   TRY(rc_dec);
 
   // ---------------- batch-level loss terms
+  KmeansEigArgs EA = {};
+  if (eig_here) {
+    EA.gram_sum = ws + p->gram; EA.partial = ws + p->gram_part; EA.nblk = (int)dof_cdiv(p->B, 16); EA.hyper = hyper; EA.B = p->B;
+    EA.km_out = ws + p->km; EA.Pm = ws + p->Pm; EA.row_stride = L; EA.tile_stride = L * L;
+  }
   StatsArgs SA;
   SA.qn = ws + p->qn; SA.z = ws + p->z; SA.mu = ws + p->mu; SA.sv = ws + p->sv; SA.tau = tau;
   SA.class_weight = teacher; SA.hyper = hyper; SA.stats = ws + p->stats; SA.K = K; SA.B = B; SA.Bp = Bp;
@@ -2513,10 +2532,11 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
     MA.mu = ws + p->mu; MA.sv = ws + p->sv; MA.eps_mc = eps_mc; MA.gmm_means = params + p->gmm_m;
     MA.gmm_log_vars = params + p->gmm_lv; MA.prior = prior; MA.hyper = hyper; MA.partial = ws + p->mckl_partial;
     MA.lse = ws + p->mlse; MA.zs = ws + p->mzs; MA.gsum = ws + p->mgsum; MA.K = K; MA.S = p->S; MA.B = B; MA.Bp = Bp;
-    LDISPATCH(L, DOF_LAUNCH((k_stats_mckl<LL>), ((unsigned)(K + 3 + p->mckl_blocks)), (256), st, SA, MA, K + 3));
+    LDISPATCH(L, DOF_LAUNCH((k_stats_mckl<LL>), ((unsigned)(K + 3 + p->mckl_blocks + (eig_here ? 1 : 0))), (256), st, SA, MA, K + 3, EA,
+                            (int)p->mckl_blocks));
     TRY(dof_check_launch("k_stats_mckl"));
   } else {
-    LDISPATCH(L, DOF_LAUNCH((k_batch_stats<LL>), ((unsigned)(K + 3)), (256), st, SA));
+    LDISPATCH(L, DOF_LAUNCH((k_batch_stats<LL>), ((unsigned)(K + 3 + (eig_here ? 1 : 0))), (256), st, SA, EA, K + 3));
     TRY(dof_check_launch("k_batch_stats"));
   }
   LossMidArgs LM;
@@ -2555,15 +2575,15 @@ extern "C" int dof_vade_loss_grads(DofVadePlan* p, const float* params, const fl
     TRY(dof_check_launch("k_latent_bwd"));
     TRY(final_dense_bwd(p, params, st));
   }
-  DOF_LAUNCH(k_loss_total, (1), (64), st, (const float*)(ws + p->distill_partial), (const float*)(ws + p->tf_partial),
-             n_lat_partial, hyper, B, pretrain ? 1 : 0, logs, p->log_accum);
-  TRY(dof_check_launch("k_loss_total"));
+  LossTotalArgs LT;   // the logged totals: one more workgroup of the mixture-gradient launch
+  LT.distill_partial = ws + p->distill_partial; LT.tf_partial = ws + p->tf_partial; LT.n = n_lat_partial; LT.hyper = hyper;
+  LT.B = B; LT.pretrain = pretrain ? 1 : 0; LT.logs = logs; LT.accum = p->log_accum;
   GmmGradArgs GG;
   GG.z = ws + p->z; GG.dlogit = ws + p->dlogit; GG.dlogp2 = ws + p->dlogp2; GG.zs = ws + p->mzs;
   GG.lse = ws + p->mlse; GG.gmm_means = params + p->gmm_m; GG.gmm_log_vars = params + p->gmm_lv; GG.prior = prior;
   GG.scal = ws + p->scal; GG.hyper = hyper; GG.partial = ws + p->gmmp;
   GG.K = K; GG.S = p->S; GG.pretrain = pretrain ? 1 : 0; GG.B = B; GG.Bp = Bp;
-  LDISPATCH(L, DOF_LAUNCH((k_gmm_grads<LL>), ((unsigned)K, 16), (256), st, GG));
+  LDISPATCH(L, DOF_LAUNCH((k_gmm_grads<LL>), ((unsigned)K + 1, 16), (256), st, GG, LT));
   TRY(dof_check_launch("k_gmm_grads"));
   if (p->tcn || p->tfm) {
     TRY(dof_launch_sum_partials(ws + p->gmmp, 16, 2 * K * L, grads + p->gmm_m, 0, st));  // gmm_means | gmm_log_vars
