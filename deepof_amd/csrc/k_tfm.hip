@@ -28,7 +28,11 @@
 namespace {
 
 constexpr int kGemmLds = 12288;  // floats: KC * NT * 256 <= kGemmLds
-constexpr int kAttLds = 16384;   // floats
+constexpr int kAttLds = 16384;   // floats: the attention kernels' LDS image of nseq sequences (large class, 64 KB)
+// small classes (round 5): the kernels are latency-bound at one or two workgroups per CU; at C2's shape a 24 KB (forward, two
+// sequences) / 36 KB (backward, two sequences) image runs 4 - 6 workgroups per CU: the transformer step 6.80 -> 6.37 ms.  A launch
+// takes the small class when at least one sequence fits it.
+constexpr int kAttLdsFwdSmall = 6144, kAttLdsBwdSmall = 9216;
 constexpr int kAttLongStats = 12288;   // floats: 3 per (head, row) of one sequence in k_tfm_attn_bwd_long (heads x window <= 4096)
 
 __device__ __forceinline__ float drop_scale(const DofDrop& d, uint32_t ctr, int64_t idx) {
@@ -266,9 +270,9 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
   }
 }
 
-template <int DH, int TMAX>
+template <int DH, int TMAX, int LDSF>
 __global__ void __launch_bounds__(512) k_tfm_attn_fwd(DofAttn A) {
-  __shared__ float sm[kAttLds];
+  __shared__ float sm[LDSF];
   const int T = A.T, D = A.D, H = A.H, nseq = A.nseq, W = 3 * D;
   const int64_t s0 = (int64_t)blockIdx.x * nseq;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -326,9 +330,9 @@ __global__ void __launch_bounds__(512) k_tfm_attn_fwd(DofAttn A) {
   for (int d = 0; d < DH; ++d) dst[d] = o[d];
 }
 
-template <int DH, int TMAX>
+template <int DH, int TMAX, int LDSF>
 __global__ void __launch_bounds__(512) k_tfm_attn_bwd(DofAttn A) {
-  __shared__ float sm[kAttLds];
+  __shared__ float sm[LDSF];
   const int T = A.T, D = A.D, H = A.H, nseq = A.nseq, W = 3 * D;
   const int64_t s0 = (int64_t)blockIdx.x * nseq;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1063,9 +1067,9 @@ int dof_launch_tfm_gemm(const DofGemm& gin, hipStream_t st) {
 }
 
 // sequences per workgroup of the attention kernels (LDS and thread budget)
-static int attn_nseq(const DofAttn& a, bool bwd) {
+static int attn_nseq(const DofAttn& a, bool bwd, int budget = kAttLds) {
   const int per_seq = a.T * (bwd ? 4 : 3) * a.D + a.T + (bwd ? 3 * a.H * a.T : 0);
-  int n = kAttLds / per_seq;
+  int n = budget / per_seq;
   const int by_threads = 512 / (a.H * a.T);
   if (n > by_threads) n = by_threads;
   if (!bwd && n > 4) n = 4;
@@ -1086,44 +1090,44 @@ bool dof_tfm_attn_fits(int T, int D, int H) {
   return (attn_resident(a, false) && attn_resident(a, true)) || 3 * H * T <= kAttLongStats;
 }
 
-#define ATTN_DISPATCH(NAME, A, nb, nt)                                                        \
+#define ATTN_DISPATCH(NAME, A, nb, nt, LDSF)                                                       \
   do {                                                                                        \
     const int dh = (A).D / (A).H;                                                             \
     if ((A).T <= 32) {                                                                        \
-      if (dh == 1) DOF_LAUNCH((NAME<1, 32>), (nb), (nt), st, A);                              \
-      else if (dh == 2) DOF_LAUNCH((NAME<2, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 3) DOF_LAUNCH((NAME<3, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 4) DOF_LAUNCH((NAME<4, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 5) DOF_LAUNCH((NAME<5, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 6) DOF_LAUNCH((NAME<6, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 7) DOF_LAUNCH((NAME<7, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 8) DOF_LAUNCH((NAME<8, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 9) DOF_LAUNCH((NAME<9, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 10) DOF_LAUNCH((NAME<10, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 11) DOF_LAUNCH((NAME<11, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 12) DOF_LAUNCH((NAME<12, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 13) DOF_LAUNCH((NAME<13, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 14) DOF_LAUNCH((NAME<14, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 15) DOF_LAUNCH((NAME<15, 32>), (nb), (nt), st, A);                        \
-      else if (dh == 16) DOF_LAUNCH((NAME<16, 32>), (nb), (nt), st, A);                        \
+      if (dh == 1) DOF_LAUNCH((NAME<1, 32, LDSF>), (nb), (nt), st, A);                              \
+      else if (dh == 2) DOF_LAUNCH((NAME<2, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 3) DOF_LAUNCH((NAME<3, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 4) DOF_LAUNCH((NAME<4, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 5) DOF_LAUNCH((NAME<5, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 6) DOF_LAUNCH((NAME<6, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 7) DOF_LAUNCH((NAME<7, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 8) DOF_LAUNCH((NAME<8, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 9) DOF_LAUNCH((NAME<9, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 10) DOF_LAUNCH((NAME<10, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 11) DOF_LAUNCH((NAME<11, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 12) DOF_LAUNCH((NAME<12, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 13) DOF_LAUNCH((NAME<13, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 14) DOF_LAUNCH((NAME<14, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 15) DOF_LAUNCH((NAME<15, 32, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 16) DOF_LAUNCH((NAME<16, 32, LDSF>), (nb), (nt), st, A);                        \
       else { dof_set_error("attention head size %d not supported", dh); return DOF_ERR_UNSUPPORTED; } \
     } else {                                                                                  \
-      if (dh == 1) DOF_LAUNCH((NAME<1, 64>), (nb), (nt), st, A);                              \
-      else if (dh == 2) DOF_LAUNCH((NAME<2, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 3) DOF_LAUNCH((NAME<3, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 4) DOF_LAUNCH((NAME<4, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 5) DOF_LAUNCH((NAME<5, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 6) DOF_LAUNCH((NAME<6, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 7) DOF_LAUNCH((NAME<7, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 8) DOF_LAUNCH((NAME<8, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 9) DOF_LAUNCH((NAME<9, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 10) DOF_LAUNCH((NAME<10, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 11) DOF_LAUNCH((NAME<11, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 12) DOF_LAUNCH((NAME<12, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 13) DOF_LAUNCH((NAME<13, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 14) DOF_LAUNCH((NAME<14, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 15) DOF_LAUNCH((NAME<15, 64>), (nb), (nt), st, A);                        \
-      else if (dh == 16) DOF_LAUNCH((NAME<16, 64>), (nb), (nt), st, A);                        \
+      if (dh == 1) DOF_LAUNCH((NAME<1, 64, LDSF>), (nb), (nt), st, A);                              \
+      else if (dh == 2) DOF_LAUNCH((NAME<2, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 3) DOF_LAUNCH((NAME<3, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 4) DOF_LAUNCH((NAME<4, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 5) DOF_LAUNCH((NAME<5, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 6) DOF_LAUNCH((NAME<6, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 7) DOF_LAUNCH((NAME<7, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 8) DOF_LAUNCH((NAME<8, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 9) DOF_LAUNCH((NAME<9, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 10) DOF_LAUNCH((NAME<10, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 11) DOF_LAUNCH((NAME<11, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 12) DOF_LAUNCH((NAME<12, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 13) DOF_LAUNCH((NAME<13, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 14) DOF_LAUNCH((NAME<14, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 15) DOF_LAUNCH((NAME<15, 64, LDSF>), (nb), (nt), st, A);                        \
+      else if (dh == 16) DOF_LAUNCH((NAME<16, 64, LDSF>), (nb), (nt), st, A);                        \
       else { dof_set_error("attention head size %d not supported", dh); return DOF_ERR_UNSUPPORTED; } \
     }                                                                                         \
   } while (0)
@@ -1155,11 +1159,17 @@ int dof_launch_tfm_attn(DofAttn a, int backward, hipStream_t st) {
     if (backward) { ATTN_LONG_DISPATCH(k_tfm_attn_bwd_long) } else { ATTN_LONG_DISPATCH(k_tfm_attn_fwd_long) }
     return dof_check_launch("k_tfm_attn_long");
   }
-  a.nseq = attn_nseq(a, backward != 0);
+  const int n_small = attn_nseq(a, backward != 0, backward ? kAttLdsBwdSmall : kAttLdsFwdSmall);
+  a.nseq = n_small >= 1 ? n_small : attn_nseq(a, backward != 0);
   const unsigned nb = dof_cdiv(a.S, a.nseq);
   const unsigned nt = (unsigned)((a.nseq * a.H * a.T + 63) / 64 * 64);
-  if (backward) ATTN_DISPATCH(k_tfm_attn_bwd, a, nb, nt);
-  else ATTN_DISPATCH(k_tfm_attn_fwd, a, nb, nt);
+  if (backward) {
+    if (n_small >= 1) ATTN_DISPATCH(k_tfm_attn_bwd, a, nb, nt, kAttLdsBwdSmall);
+    else ATTN_DISPATCH(k_tfm_attn_bwd, a, nb, nt, kAttLds);
+  } else {
+    if (n_small >= 1) ATTN_DISPATCH(k_tfm_attn_fwd, a, nb, nt, kAttLdsFwdSmall);
+    else ATTN_DISPATCH(k_tfm_attn_fwd, a, nb, nt, kAttLds);
+  }
   return dof_check_launch("k_tfm_attn");
 }
 
