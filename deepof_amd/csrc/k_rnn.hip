@@ -139,9 +139,11 @@ struct EncConvFwdArgs {
   const float* xin; const float* w; float* xs; float* c; int* len;
   int G; int64_t S, Sp;
 };
-template <int C1>
+// LDSF: floats of the staged window (classes 2048 / 6144 / ENC_CONV_LDS): the kernel is latency-bound and a C2 window is 1,050
+// floats -- with the 48 KB array it ran three workgroups per CU
+template <int C1, int LDSF>
 __global__ void __launch_bounds__(256) k_enc_conv_fwd_lds_pair(EncConvFwdArgs A0, EncConvFwdArgs A1, int T) {
-  __shared__ float sy[ENC_CONV_LDS];
+  __shared__ float sy[LDSF];
   __shared__ int cnt[256];
   if (blockIdx.y == 0) {
     if ((int64_t)blockIdx.x * A0.G < A0.S) enc_conv_fwd_lds_body<C1, 3>(A0.xin, A0.w, A0.xs, A0.c, A0.len, T, A0.G, A0.S, A0.Sp, sy, cnt);
@@ -1966,7 +1968,15 @@ int dof_launch_enc_conv_fwd_pair(int L, const int F[2], const float* const xin[2
     A[k].xin = xin[k]; A[k].w = w[k]; A[k].xs = xs[k]; A[k].c = c[k]; A[k].len = len[k]; A[k].G = G[k]; A[k].S = S[k]; A[k].Sp = Sp[k];
     if ((unsigned)(S[k] / G[k]) > nwin) nwin = (unsigned)(S[k] / G[k]);
   }
-  DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd_lds_pair<2 * LL>), (nwin, 2), (256), st, A[0], A[1], T));
+  int64_t need = 0;
+  for (int k = 0; k < 2; ++k) need = (int64_t)T * G[k] * F[k] > need ? (int64_t)T * G[k] * F[k] : need;
+  if (need <= 2048) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd_lds_pair<2 * LL, 2048>), (nwin, 2), (256), st, A[0], A[1], T));
+  } else if (need <= 6144) {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd_lds_pair<2 * LL, 6144>), (nwin, 2), (256), st, A[0], A[1], T));
+  } else {
+    DOF_DISPATCH_L(L, DOF_LAUNCH((k_enc_conv_fwd_lds_pair<2 * LL, ENC_CONV_LDS>), (nwin, 2), (256), st, A[0], A[1], T));
+  }
   return dof_check_launch("k_enc_conv_fwd_lds_pair") == DOF_OK ? 1 : DOF_ERR_LAUNCH;
 }
 int dof_launch_enc_conv_fwd(int L, int F, const float* xin, const float* w, float* xs, float* c, int* len, int T,
