@@ -2,6 +2,7 @@
 """Headline benchmark: pose-windows/sec of the VaDE train step (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+  python bench.py --config c4|c5 --gpus N ...        (BASELINE configs[3] / [4], the two that name data parallelism)
 
 One "step" = one pass of the hot path over one batch of synthetic windows, inputs resident in
 HBM: window gather from the frame table -> VaDE forward -> VadeLoss -> backward -> [RCCL
@@ -25,7 +26,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STEP_SOURCES = ["k_gather.hip", "k_rnn.hip", "k_grum16.inc.h", "k_reduce.hip", "vade.hip", "k_decoder.inc.h", "k_graph_latent.inc.h"]
+# every source the C2 step's kernels are compiled from (the headers with device code included: dof_rt.h carries the MFMA /
+# piece-split helpers): profiles/rNN_step_pmc.json is quoted only while all of them are unchanged
+STEP_SOURCES = ["k_gather.hip", "k_rnn.hip", "k_grum16.inc.h", "k_grumx.inc.h", "k_sum_partials.inc.h", "dof_rt.h", "launchers.h",
+                "k_reduce.hip", "vade.hip", "k_decoder.inc.h", "k_graph_latent.inc.h"]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 FP32_PEAK_FLOPS = 157.3e12  # fp32 vector peak (= the f32-input MFMA rate; MI355X_MICROARCH.md)
 
@@ -225,9 +229,11 @@ def run_vqvae_product(B, K, steps, warmup, frames=100_000, T=25):
     return sec, logs["total_loss"], "deepof_amd.training.VQVAEStepper.step"
 
 
-def run_contrastive_product(B, Tf, encoder_type, steps, warmup, frames=100_000):
+def contrastive_stepper_setup(B, Tf, encoder_type, frames, dev, rank=0, use_graphs=None):
     """C4 through fit_contrastive's stepper: both views with the reference's default augmentations, TCN encoder on the
-    half windows, NCE / cosine, Adam lr 1e-3 + weight decay 1e-4, clip 0.75 (CensNet outside the optimiser, Q11)."""
+    half windows, NCE / cosine, Adam lr 1e-3 + weight decay 1e-4, clip 0.75 (CensNet outside the optimiser, Q11).
+    Returns (one_step(i), stepper, model, dataset, (node table, edge table)); rank: this rank's synthetic animals
+    (the model's initial state is the same on every rank -- DDP's broadcast)."""
     from deepof_amd import _capi
     from deepof_amd._lib import load_hip_library
     from deepof_amd.augment import edge_index_from_meta
@@ -236,8 +242,7 @@ def run_contrastive_product(B, Tf, encoder_type, steps, warmup, frames=100_000):
     from deepof_amd.graph import make_meta_info
     from deepof_amd.models import Contrastive
     from deepof_amd.training import ContrastiveStepper
-    dev = torch.device("cuda")
-    ds, adj, nodes, edges, _tn, _te = _device_dataset([""], Tf, frames, 2, 0, dev, load_hip_library())
+    ds, adj, nodes, edges, _tn, _te = _device_dataset([""], Tf, frames, 2, rank, dev, load_hip_library())
     ccfg = ContrastiveCfg()
     torch.manual_seed(0)
     model = Contrastive(ds.x_shape, ds.a_shape, adj, latent_dim=8, encoder_type=encoder_type, use_gnn=True,
@@ -247,6 +252,9 @@ def run_contrastive_product(B, Tf, encoder_type, steps, warmup, frames=100_000):
     eng = model._base
     ei_g, ei_l = edge_index_from_meta(make_meta_info(nodes, edges), ds.x_shape[1])
     stepper = ContrastiveStepper(model, ei_g, ei_l, ccfg, seed=0)
+    if use_graphs is not None:
+        from deepof_amd.training import StepGraphs
+        stepper.graphs = StepGraphs(model.device, use_graphs)
     eng.reset_optimizer()
     for seg in range(_capi.SEG_COUNT):
         eng.set_lr(seg, 1e-3)
@@ -260,6 +268,12 @@ def run_contrastive_product(B, Tf, encoder_type, steps, warmup, frames=100_000):
         s0 = starts[i % len(starts)]
         stepper.step(ds, s0, s0 + B, True, None, None, log_sum)
 
+    return one_step, stepper, model, ds, (_tn, _te)
+
+
+def run_contrastive_product(B, Tf, encoder_type, steps, warmup, frames=100_000):
+    one_step, _stepper, model, _ds, _tabs = contrastive_stepper_setup(B, Tf, encoder_type, frames, torch.device("cuda"))
+    eng = model._base
     sec = _time_steps(one_step, steps, warmup)
     logs = eng.read_contrastive_logs()
     assert np.isfinite(logs["total_loss"]), logs
@@ -350,8 +364,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--frames", type=int, default=600_000, help="frames per synthetic animal (2 animals per rank)")
+    ap.add_argument("--config", choices=("c2", "c4", "c5"), default="c2",
+                    help="c2 (default, the headline): BASELINE configs[1].  c4 / c5: BASELINE configs[3] / configs[4] -- the two that "
+                         "name data parallelism -- through the same steppers, barriers, self-check and data_parallel report")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU (default: the configuration's 1024 / 8192 / 4096)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per synthetic animal (2 animals per rank; default 600,000 / 100,000)")
     ap.add_argument("--latent", type=int, default=8, help="latent size of the headline model (8 = C2; 16 for profiling that path)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -397,22 +414,47 @@ def main():
 
     from deepof_amd import _capi
 
-    B, T, L, K, S = args.batch, 25, args.latent, 10, 32
-    n_animals, F = 2, args.frames
+    cfg = args.config
+    B = args.batch if args.batch else {"c2": 1024, "c4": 8192, "c5": 4096}[cfg]
+    L, S = args.latent, 32
+    n_animals, F = 2, args.frames if args.frames else (600_000 if cfg == "c2" else 100_000)
+    graphs_arg = False if args.no_graph else None
     # ---- the product objects: model (reference initialisers, identical on every rank = DDP's broadcast), the fit
-    # loop's stepper in the main phase with distillation, a device-resident dataset of 2 animals per rank
-    stepper, model, ds, starts, (tn, te), tau_star = vade_stepper_setup(
-        [""], T, K, B, "recurrent", F, dev, rank=rank, use_graphs=False if args.no_graph else None, latent=args.latent)
+    # loop's stepper, a device-resident dataset of 2 animals per rank
+    tau_star = None
+    if cfg == "c4":   # contrastive, TCN encoder on the half windows of 50-step windows
+        T, K = 50, 0
+        one_step, stepper, model, ds, (tn, te) = contrastive_stepper_setup(B, T, "TCN", F, dev, rank=rank, use_graphs=graphs_arg)
+        workload = (f"C4: contrastive TCN encoder + augmented second view, 14 body parts (N=14,E=14), window=50 -> halves of 25, "
+                    f"nce / cosine, latent={L}, batch={B}/GPU, fp32")
+        metric = "pose-windows/sec (train step) contrastive TCN win=50"
+        step_path = "deepof_amd.training.ContrastiveStepper.step (the fit loop's step)"
+        read_logs = lambda: model._base.read_contrastive_logs()   # noqa: E731
+    else:
+        ids, T, K = ([""], 25, 10) if cfg == "c2" else (["B", "W"], 50, 25)
+        stepper, model, ds, starts, (tn, te), tau_star = vade_stepper_setup(
+            ids, T, K, B, "recurrent", F, dev, rank=rank, use_graphs=graphs_arg, latent=args.latent)
+
+        def one_step(i):
+            s0 = starts[i % len(starts)]
+            stepper.step(ds, s0, s0 + B, True, True)   # gather + forward + loss + backward [+ all-reduce] + clip/Adam
+
+        if cfg == "c2":
+            workload = (f"C2: VaDE GM-VAE recurrent, 14 body parts (N=14,E=14), window=25, k=10, latent={args.latent}, "
+                        f"batch={B}/GPU, main phase (MC-KL S=32 + distillation), fp32")
+            metric = "pose-windows/sec (train step) VaDE 14-bp win=25"
+        else:
+            workload = (f"C5: VaDE GM-VAE recurrent, 2 animals (N=28,E=32), window=50, k=25, latent={args.latent}, "
+                        f"batch={B}/GPU, main phase (MC-KL S=32 + distillation), fp32")
+            metric = "pose-windows/sec (train step) VaDE 2 animals 28-bp win=50"
+        step_path = "deepof_amd.training.VadeStepper.step (the fit loop's step)"
+        read_logs = lambda: model._base.read_logs()   # noqa: E731
     eng = model._base
     lib = eng.lib
     N, E = eng.N, eng.E
     n_windows = len(ds)
     win_per_animal = F - T + 1
-    initial_state = eng.state_dict() if rank == 0 else None   # (no step has run yet)
-
-    def one_step(i):
-        s0 = starts[i % len(starts)]
-        stepper.step(ds, s0, s0 + B, True, True)   # gather + forward + loss + backward [+ all-reduce] + clip/Adam
+    initial_state = eng.state_dict() if (rank == 0 and cfg == "c2") else None   # (no step has run yet)
 
     def barrier():
         if world > 1:
@@ -422,7 +464,7 @@ def main():
 
     def show(tag, i):
         if args.log_every and rank == 0 and i % args.log_every == 0:
-            print(tag, i, {k: round(v, 4) for k, v in eng.read_logs().items()}, file=sys.stderr, flush=True)
+            print(tag, i, {k: round(v, 4) for k, v in read_logs().items()}, file=sys.stderr, flush=True)
 
     for i in range(args.warmup):
         one_step(i)
@@ -440,7 +482,7 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    logs = eng.read_logs()
+    logs = read_logs()
     if not np.isfinite(logs["total_loss"]):
         raise SystemExit(f"non-finite loss after benchmark steps: {logs}")
     ms_per_step = 1e3 * elapsed / args.steps
@@ -502,26 +544,27 @@ def main():
               "allreduce_bytes_per_step": int(eng.grads.numel()) * 4, "collectives_per_step": 1,
               "allreduce_eager_latency_us": lat, "ms_per_step_per_rank": per_rank_ms,
               "devices": devs}
-    # algorithmic work of one step (7.6 MFLOP forward per window, training = 3 x) against the fp32 vector peak
-    flops_per_step = 3.0 * 7.6e6 * B
+    # algorithmic work of one step against the fp32 vector peak (C2 7.6 MFLOP forward per window, training =
+    # 3 x; C4: 4.25 TFLOP per step of 8192 windows; C5: not tabulated)
+    flops_per_step = {"c2": 3.0 * 7.6e6 * B, "c4": 4.25e12 * B / 8192.0, "c5": None}[cfg]
     out = {
-        "metric": "pose-windows/sec (train step) VaDE 14-bp win=25", "value": value, "unit": "windows/s",
+        "metric": metric, "value": value, "unit": "windows/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C2: VaDE GM-VAE recurrent, 14 body parts (N=14,E=14), window=25, k=10, latent={args.latent}, "
-                               f"batch={B}/GPU, main phase (MC-KL S=32 + distillation), fp32",
+        "config": {"workload": workload,
                    "global_batch": world * B, "window": T, "parallelism": f"dp{world}",
                    "hip_graph": stepper.graphs.enabled, "graph_replays": stepper.graphs.replays,
-                   "path": "deepof_amd.training.VadeStepper.step (the fit loop's step)",
+                   "path": step_path,
                    "final_total_loss": logs["total_loss"]},
         "sustained": sustained, "data_parallel": dp,
-        "roofline_step": {"flop_frac": flops_per_step / (ms_per_step * 1e-3) / FP32_PEAK_FLOPS,
-                          "achieved_tflops": flops_per_step / (ms_per_step * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_FLOPS / 1e12,
-                          "algorithmic_flops_per_step": flops_per_step, "hbm_frac": None, "hbm_bytes_per_step": None},
+        "roofline_step": None if flops_per_step is None else {
+            "flop_frac": flops_per_step / (ms_per_step * 1e-3) / FP32_PEAK_FLOPS,
+            "achieved_tflops": flops_per_step / (ms_per_step * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_FLOPS / 1e12,
+            "algorithmic_flops_per_step": flops_per_step, "hbm_frac": None, "hbm_bytes_per_step": None},
     }
     # HBM bytes of one step from the round's PMC passes (tools/profile_step_hbm.sh): quoted only while the kernel sources
     # are the ones the passes ran on
-    if B == 1024:
+    if B == 1024 and cfg == "c2":
         rec, name = _latest_profile("step_pmc.json", _source_sha(STEP_SOURCES))
         if rec is not None:
             hb = rec["hbm_bytes_per_step"]
@@ -621,10 +664,10 @@ def main():
                                         "measured_peak": measured_peak,
                                         "frac_of_measured": win_per_animal * bpw16 / sec16 / 1e9 / measured_peak}
         del xg16, ag16
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and cfg == "c2":
             xb, ab = ds.fetch(starts[0], starts[0] + B)   # the first batch the device path trained on
             out["cpu_baseline"] = cpu_baseline(initial_state, xb.cpu(), ab.cpu(), L, K)
-        if not args.no_secondary and world == 1:
+        if not args.no_secondary and world == 1 and cfg == "c2":
             del stepper, ds, tau_star, model, eng
             import gc
             gc.collect()

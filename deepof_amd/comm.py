@@ -40,10 +40,37 @@ class NativeComm:
         if dist is None:
             import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [cls.unique_id(lib) if rank == 0 else None]
+        # Creation is collective, so it must fail on every rank or on none: rank 0 ALWAYS broadcasts (ok, id or error text)
+        # -- a rank 0 that raised before the broadcast would leave the others blocked in it -- and after ncclCommInitRank
+        # the ranks agree on a success flag before anyone uses (or gives up on) the communicator.
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = (True, cls.unique_id(lib))
+            except Exception as exc:
+                box[0] = (False, f"{type(exc).__name__}: {exc}")
         if world > 1:
             dist.broadcast_object_list(box, src=0)
-        return cls(lib, rank, world, box[0])
+        ok, payload = box[0]
+        if not ok:
+            raise RuntimeError(f"rank 0 could not draw the RCCL unique id ({payload})")
+        comm, err = None, ""
+        try:
+            comm = cls(lib, rank, world, payload)
+        except Exception as exc:
+            err = f"{type(exc).__name__}: {exc}"
+        if world > 1:
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            bad = [(r, e) for r, e in enumerate(flags) if e]
+        else:
+            bad = [(rank, err)] if err else []
+        if bad:
+            if comm is not None:
+                comm.abort()
+            raise RuntimeError("RCCL communicator creation failed on rank(s) " +
+                               "; ".join(f"{r}: {e}" for r, e in bad))
+        return comm
 
     def _stream(self, stream):
         return torch.cuda.current_stream().cuda_stream if stream is None else stream

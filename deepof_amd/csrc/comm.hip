@@ -114,7 +114,8 @@ extern "C" int dof_comm_abort(DofComm* comm) {
   if (!comm) return DOF_OK;
   const Rccl* r = rccl();
   int rc = 0;
-  if (r) rc = r->CommAbort ? r->CommAbort(comm->comm) : r->CommDestroy(comm->comm);
+  // without ncclCommAbort the communicator is leaked: ncclCommDestroy would block behind the collective being abandoned
+  if (r && r->CommAbort) rc = r->CommAbort(comm->comm);
   delete comm;
   return (r && rc != 0) ? rccl_fail(r, rc, "ncclCommAbort") : DOF_OK;
 }

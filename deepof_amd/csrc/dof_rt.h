@@ -51,6 +51,26 @@ __device__ __forceinline__ dof_bf16x8 dof_ld_bf16x8_a4(const uint16_t* p) {
   for (int k = 0; k < 4; ++k) u.w[k] = reinterpret_cast<const uint32_t*>(p)[k];
   return u.v;
 }
+// eight bf16 values from a 16-byte aligned LDS address: one ds_read_b128
+__device__ __forceinline__ dof_bf16x8 dof_ld_bf16x8_16(const uint16_t* p) { return *reinterpret_cast<const dof_bf16x8*>(p); }
+// ds_read_b64_tr_b16 (gfx950): the transposing LDS read.  Inside each 16-lane group, lane q supplies the (8-byte aligned)
+// address of four contiguous 16-bit elements; lane i receives element i & 3 of the run supplied by lane 4 j + (i >> 2) as
+// its element j (j = 0 .. 3) -- the four runs of a row j make a 16-element row, lane i reads column i of the 4 x 16 block
+// (tools/probe/tr_probe.hip checks this model with per-lane addresses on the device).  w0 = elements 0, 1; w1 = 2, 3.
+__device__ __forceinline__ void dof_lds_tr16(const uint16_t* p, uint32_t& w0, uint32_t& w1) {
+#ifdef DOF_EMU
+  uint16_t o[4];
+  emu_lds_tr16(p, o);
+  w0 = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+  w1 = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+#else
+  typedef short dof_v4s __attribute__((ext_vector_type(4)));
+  union { dof_v4s v; uint32_t w[2]; } u;
+  u.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dof_v4s*)(p));
+  w0 = u.w[0];
+  w1 = u.w[1];
+#endif
+}
 // fp32 = hi + mid + lo EXACTLY with three bf16 pieces: each piece is the top 16 bits of what is left (truncation keeps the
 // remainder exactly representable: 8 + 8 + 8 significand bits).  dof_bf16_rest: the value with its top piece removed;
 // dof_pack_hi16: the top pieces of two values as one word (first argument in the low half) -- one v_perm_b32.

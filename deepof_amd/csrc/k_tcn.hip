@@ -129,6 +129,12 @@ struct TcnConvArgs {
   // forward k_tcn_conv_t: 1 = the workgroup's channel statistics leave as mergeable (n | mean | M2) records,
   // partial[workgroup][3][32] (see k_tcn_stat_merge), instead of plain / shifted sums
   int stat_records = 0;
+  // round 6 (k_tcn_conv_b WGRAD): the convolution's weight gradient accumulated in the same launch -- wg_x = the forward
+  // input of the convolution when the epilogue cannot recompute it (TAIL: the previous block's output), wg_partials + wg_part0 /
+  // wg_part1 = the partial-tile regions of taps 0, 1 / 2, 3 ([workgroup][64][65], k_tcn_wgrad_b3's layout)
+  const float* wg_x = nullptr;
+  float* wg_partials = nullptr;
+  int64_t wg_part0 = 0, wg_part1 = 0;
   int T, dil, accumulate;
   int64_t S, Sp;
 };
@@ -672,6 +678,8 @@ __global__ void __launch_bounds__(256, 3) k_tcn_conv_t(TcnConvArgs A) {
     }
   }
 }
+
+#include "k_tcn_b3.inc.h"
 
 // Generic variant for the 64-filter decoder TCN: KC input channels per tap, NC output channels, the whole
 // (4 KC) x NC weight matrix staged ONCE per workgroup in LDS in B-operand order (64 KB for 64 x 64), so an
@@ -1346,16 +1354,43 @@ static int tct_max_t() {
   return v;
 }
 static bool tct_fits(int T, int64_t Sp) { return T <= tct_max_t() && (int64_t)T * Sp * TC < ((int64_t)1 << 31); }
-static int tct_ns(int T) { return T <= TCT_T ? 16 : 8; }
-static unsigned tct_blocks(int T, int64_t Sp) {
-  const int64_t groups = Sp / tct_ns(T);
-  return (unsigned)(groups < 768 ? groups : 768);
+// Round 6: the time-resident convolutions on the bf16 matrix pipe (k_tcn_conv_b, three exact pieces per operand), 8 / 4
+// sequences per workgroup, two workgroups per CU.  DOF_TCN_CONV_B3=0: round 5's fp32-MFMA kernels (A/B measurements).
+static int tcn_conv_b3() {
+  static const int on = [] {
+    const char* e = getenv("DOF_TCN_CONV_B3");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return on;
 }
-// k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB> at the group size T asks for
+static int tct_ns(int T) { return tcn_conv_b3() ? (T <= TCT_T ? 8 : 4) : (T <= TCT_T ? 16 : 8); }
+static unsigned tct_blocks(int T, int64_t Sp) {
+  const int64_t groups = Sp / tct_ns(T), cap = tcn_conv_b3() ? 256 : 768;   // (k_tcn_conv_b: one 512-thread workgroup per CU)
+  return (unsigned)(groups < cap ? groups : cap);
+}
+// ... with the convolution's weight gradient accumulated by the two fused data-gradient variants of the backward pass
+// (DOF_TCN_WGRAD_FUSED=0: k_tcn_wgrad_b3 as in round 5)
+int dof_tcn_wgrad_fused(int T, int64_t Sp) {
+  static const int on = [] {
+    const char* e = getenv("DOF_TCN_WGRAD_FUSED");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return (on && tcn_conv_b3() && tct_fits(T, Sp)) ? 1 : 0;
+}
+// k_tcn_conv_t / k_tcn_conv_b <R, BN, FUSE, BWD2, TAIL, COMB> at the group size T asks for
 #define TCT_LAUNCH(R, BN, FUSE, BWD2, TAIL, COMB)                                                         \
   do {                                                                                                    \
-    if (tct_ns(A.T) == 16) DOF_LAUNCH((k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB, 16>), (nbt), (256), st, A); \
+    if (tcn_conv_b3()) {                                                                                  \
+      if (tct_ns(A.T) == 8) DOF_LAUNCH((k_tcn_conv_b<R, BN, FUSE, BWD2, TAIL, COMB, false, 8>), (nbt), (512), st, A); \
+      else DOF_LAUNCH((k_tcn_conv_b<R, BN, FUSE, BWD2, TAIL, COMB, false, 4>), (nbt), (512), st, A);       \
+    } else if (tct_ns(A.T) == 16) DOF_LAUNCH((k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB, 16>), (nbt), (256), st, A); \
     else DOF_LAUNCH((k_tcn_conv_t<R, BN, FUSE, BWD2, TAIL, COMB, 8>), (nbt), (256), st, A);                \
+  } while (0)
+// the fused data-gradient + weight-gradient variants (A.wg_partials set)
+#define TCT_LAUNCH_WG(TAIL)                                                                               \
+  do {                                                                                                    \
+    if (tct_ns(A.T) == 8) DOF_LAUNCH((k_tcn_conv_b<true, false, true, true, TAIL, false, true, 8>), (nbt), (512), st, A); \
+    else DOF_LAUNCH((k_tcn_conv_b<true, false, true, true, TAIL, false, true, 4>), (nbt), (512), st, A);   \
   } while (0)
 // One-pass (shifted) BatchNorm statistics (bn_shift_ok) of the time-resident convolutions: round 2's default, opt-in in
 // rounds 3 / 4 (DOF_TCN_ONEPASS=1), no longer selectable since round 5 (the mergeable records below are the default and
@@ -1449,9 +1484,15 @@ int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const floa
 // while staging and written back in place.
 int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
                                float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st,
-                               const float* bwd_y, const float* bwd_bnp, const float* bwd_coef, int bwd_store) {
+                               const float* bwd_y, const float* bwd_bnp, const float* bwd_coef, int bwd_store,
+                               float* wg_partials, int64_t wg_part0, int64_t wg_part1) {
   TcnConvArgs A;
   A.bwd_store = bwd_store;
+  if (wg_partials && !(bwd_y && dof_tcn_wgrad_fused(T, Sp))) {
+    dof_set_error("k_tcn_conv_bwd_bn: the fused weight gradient needs k_tcn_conv_b and a lazy BatchNorm2 gradient");
+    return DOF_ERR_UNSUPPORTED;
+  }
+  A.wg_partials = wg_partials; A.wg_part0 = wg_part0; A.wg_part1 = wg_part1;
   A.in = dy; A.w = w; A.bias = nullptr; A.bnp_in = nullptr; A.a_out = nullptr; A.out = g_out; A.partial = partial;
   A.fuse_y = y; A.fuse_bnp = bnp;
   A.bwd_y = bwd_y; A.bwd_bnp = bwd_bnp; A.bwd_coef = bwd_coef;
@@ -1459,7 +1500,9 @@ int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, 
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
   if (dof_tcn_conv32_resident(T, Sp)) {
     const unsigned nbt = tct_blocks(T, Sp);
-    if (bwd_y) {
+    if (wg_partials) {
+      TCT_LAUNCH_WG(false);
+    } else if (bwd_y) {
       TCT_LAUNCH(true, false, true, true, false, false);
     } else {
       TCT_LAUNCH(true, false, true, false, false, false);
@@ -1519,8 +1562,13 @@ int dof_tcn_tail_fold() {
 int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
                              int bwd_store, const float* tail_src, const float* tail_mask, float* tail_gres,
                              const float* tail_skip, const float* tail_dfeat, const float* y2, const float* bnp2, float* g_out,
-                             float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st) {
-  if (!dof_tcn_conv32_resident(T, Sp) || !bwd_y || !tail_mask) {
+                             float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st,
+                             const float* wg_x, float* wg_partials, int64_t wg_part0, int64_t wg_part1) {
+  if (wg_partials && !(wg_x && dof_tcn_wgrad_fused(T, Sp))) {
+    dof_set_error("k_tcn_conv_tail: the fused weight gradient needs k_tcn_conv_b and the convolution's input tensor");
+    return DOF_ERR_UNSUPPORTED;
+  }
+  if (!dof_tcn_conv32_resident(T, Sp) || !bwd_y || !(tail_mask || wg_partials)) {
     dof_set_error("k_tcn_conv_tail: needs the time-resident kernel (T <= %d), a lazy BatchNorm1 gradient and the block output's mask words", tct_max_t());
     return DOF_ERR_UNSUPPORTED;
   }
@@ -1532,9 +1580,11 @@ int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y
   A.stat_shift = nullptr;
   A.tail_src = tail_src; A.tail_gres = tail_gres; A.tail_skip = tail_skip; A.tail_dfeat = tail_dfeat;
   A.tail_mask = reinterpret_cast<const uint32_t*>(tail_mask);
+  A.wg_x = wg_x; A.wg_partials = wg_partials; A.wg_part0 = wg_part0; A.wg_part1 = wg_part1;
   A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
   const unsigned nbt = tct_blocks(T, Sp);
-  TCT_LAUNCH(true, false, true, true, true, false);
+  if (wg_partials) TCT_LAUNCH_WG(true);
+  else TCT_LAUNCH(true, false, true, true, true, false);
   if (int rc = dof_check_launch("k_tcn_conv_t_tail")) return rc;
   return sums ? dof_launch_sum_partials(partial, (int64_t)nbt, 2 * TC, sums, 0, st) : DOF_OK;
 }

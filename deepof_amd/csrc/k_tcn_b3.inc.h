@@ -1,0 +1,510 @@
+// Round 6: the time-resident 32 -> 32 convolution of k_tcn.hip on the bf16 matrix pipe with exact three-piece operands,
+// and the convolution's WEIGHT GRADIENT accumulated in the same launch.  Included by k_tcn.hip inside its namespace.
+//
+// What changes against k_tcn_conv_t (same arguments, same epilogues, same results to fp32 rounding):
+//   * the staged tile is cut ONCE, while it is staged, into three bf16 planes (value = p0 + p1 + p2 exactly, dof_split3x4);
+//     a product is the six piece products that carry more than 2^-24 of it, each one
+//     v_mfma_f32_16x16x32_bf16 whose K = the 32 input channels of a tap: 24 matrix instructions per 16 x 16 output tile
+//     against 32 v_mfma_f32_16x16x4_f32, at ~1/2 of the time each;
+//   * a tile is NS = 8 sequences (windows <= 25 steps) or 4 (<= 50): an MFMA column block is NS sequences x 16 / NS
+//     consecutive output rows.  Image = 224 (row, sequence) pairs x 32 channels x 3 planes of bf16 = 42 KB; rows behind the
+//     window are staged as zeros, so a tap that leaves the window reads the zero row T instead of being masked per lane;
+//   * LOADER and COMPUTE wavefronts (one 512-thread workgroup per CU, two images): wavefronts 4 - 7 stage tile n + 1
+//     (BatchNorm / BatchNorm-backward arithmetic, the cut, the LDS writes) into one image while wavefronts 0 - 3 run the
+//     matrix phase and the epilogues of tile n on the other; the loaders' global loads are issued one tile further ahead
+//     (tile n + 2's loads replace a pass's registers as soon as the pass is written), the compute wavefronts request a
+//     column block's epilogue operands one round ahead.  PMC of the single-role form (every wavefront staging, then
+//     computing, two workgroups per CU): 60 - 75 % of the wave cycles parked in s_waitcnt / s_barrier;
+//   * a compute wavefront owns BOTH channel halves of its column block (the B operand is read from LDS once), wavefront w
+//     takes the column blocks 4 r + w of round r; output channel of accumulator row m of half ct = (m >> 2) 8 + ct 4 + (m & 3),
+//     so a lane's two quads are 32 contiguous bytes and the four lanes of a sequence cover its 128-byte row;
+//   * WGRAD (the two data-gradient variants of the backward pass, k_tcn_conv_t's <true,false,true,true,*>): the kernel has
+//     dy = the staged tile on chip and the convolution's forward input x on its way through the epilogue -- conv2: x =
+//     ReLU(BN1(y1)), recomputed from the row of y1 the BatchNorm-backward epilogue loads anyway; conv1 (TAIL): x = the
+//     previous block's output, one extra read that also replaces the mask words.  dW_j[o][c] = sum over (t, s) of
+//     dy[t + (3 - j) d][s][o] x[t][s][c] is a GEMM whose K runs over (t, s): the column block's x rows go through a small
+//     LDS ring (cut into pieces), a round's four column blocks are exchanged at ONE barrier, and compute wavefront j
+//     accumulates tap j on v_mfma_f32_32x32x16_bf16 with both operands read TRANSPOSED from their channel-minor images
+//     (ds_read_b64_tr_b16).  The separate weight-gradient kernel (k_tcn_wgrad_b3: three more reads of three tensors per
+//     convolution, 66 GB of the C4 step's 262) is not launched for these convolutions; the partial tiles keep its layout.
+//
+// LDS images.  Plane p of a tile: [row = t NS + s][32 channels] bf16, 64 bytes per row; the 16-byte chunk c of a row sits
+// at chunk c ^ 2 ((row >> 2) & 1): with it the sixteen lanes of every ds_read_b128 service group (lane l reads chunk l >> 4
+// of row R + (l & 15)) hit sixteen different 16-byte slots of the 256-byte bank row for every R that is a multiple of 4
+// (brute-forced over the four groups of the microarchitecture guide's table; SQ_LDS_BANK_CONFLICT = 0 measured).  The
+// transposing reads take four whole consecutive rows per 32 lanes: conflict-free under any in-row permutation.  Ring slot
+// plane: [column 16][32 channels], 8-byte chunk c8 at c8 ^ ((column >> 1) & 7) (the epilogue's ds_write_b64 of sixteen
+// columns, same chunk, then spreads over all banks).
+constexpr int TB_ROWS = 224;
+constexpr int TB_PLANE = TB_ROWS * 32;  // bf16 elements per plane
+constexpr int TB_IMG = 3 * TB_PLANE;    // ... per image
+constexpr int TB_RING = 16 * 32;        // bf16 elements per ring slot plane
+
+__device__ __forceinline__ int tb_off(int row, int chunk) { return row * 32 + ((chunk ^ (((row >> 2) & 1) << 1)) << 3); }
+__device__ __forceinline__ int tb_ring_off(int col, int c8) { return col * 32 + ((c8 ^ ((col >> 1) & 7)) << 2); }
+__device__ __forceinline__ void tb_st8(uint16_t* p, uint32_t lo, uint32_t hi) {
+  *reinterpret_cast<uint64_t*>(p) = (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL, bool COMB, bool WGRAD, int NS>
+__global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
+  static_assert(NS == 8 || NS == 4, "8 sequences x 25 steps or 4 sequences x 50 steps");
+  constexpr int TPC = 16 / NS;        // output rows per MFMA column block
+  constexpr int TS = 256 / (NS * 8);  // time steps per staging pass of the 256 loader threads
+  constexpr int NP = TB_ROWS / NS / TS;
+  constexpr bool TWO = BWD2 || COMB;  // the staging reads two tensors
+  static_assert(!TAIL || (REVERSE && FUSE_BN && BWD2), "the tail epilogue extends the fused data-gradient variant");
+  static_assert(!COMB || (!REVERSE && !BN_IN && !FUSE_BN && !BWD2), "the combine-on-load variant is a plain forward convolution");
+  static_assert(!WGRAD || (REVERSE && FUSE_BN && BWD2), "the weight gradient rides on the fused data-gradient variants");
+  __shared__ __attribute__((aligned(16))) uint16_t img[2 * TB_IMG];
+  __shared__ __attribute__((aligned(16))) uint16_t ring[WGRAD ? 2 * 4 * 3 * TB_RING : 8];
+  __shared__ float4 frec[FUSE_BN ? 4 * TC / 4 : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool loader = wv >= 4;  // wave-uniform role
+  const int T = A.T;
+  const int n_cb = (T + TPC - 1) / TPC, n_rounds = (n_cb + 3) / 4;
+  const int np_run = T / TS + 1;  // staging passes that reach row T (the zero row); T < NP TS is the launcher's condition
+  const int64_t n_groups = A.Sp / NS;
+  const uint32_t row_stride = (uint32_t)A.Sp * TC;  // 32-bit element offsets (the launcher checks T * Sp * 32 < 2^31)
+  if (FUSE_BN) {
+    if (threadIdx.x < 4 * TC / 4) frec[threadIdx.x] = reinterpret_cast<const float4*>(A.fuse_bnp)[threadIdx.x];
+  }
+  float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // WGRAD, loaders: the thread's channel sums of dy (bias gradient)
+  float s1[2][4], s2[2][4], kshift[2][4];   // compute: channel sums of the lane's output values
+  float n_rows = 0.0f;                     // stat_records: rows this lane has summed; its sums are taken about the first one
+  dof_f32x16 accw;                         // WGRAD, compute: tap wv of the weight gradient, 32 x 32
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[ct][r] = s2[ct][r] = kshift[ct][r] = 0.0f;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) accw[v] = 0.0f;
+
+  if (loader) {
+    // =========================================== loader wavefronts ===========================================
+    // thread -> (time step of the pass, sequence, 8-byte chunk); its four channels are fixed
+    const int lt = threadIdx.x - 256;
+    const int tq = lt / (NS * 8), sq = (lt % (NS * 8)) >> 3, ch = lt & 7;
+    float k0[4], k1[4];                        // BN_IN / COMB: scale, shift of the producer's BatchNorm
+    float bm[4], br[4], bs[4], c1[4], c2[4];  // BWD2: mean, rstd, scale, mean g, mean g xhat
+    if (BN_IN || COMB) {
+      dof_ld_row<4>(A.bnp_in + 2 * TC + ch * 4, k0);
+      dof_ld_row<4>(A.bnp_in + 3 * TC + ch * 4, k1);
+    }
+    if (BWD2) {
+      dof_ld_row<4>(A.bwd_bnp + ch * 4, bm);
+      dof_ld_row<4>(A.bwd_bnp + TC + ch * 4, br);
+      dof_ld_row<4>(A.bwd_bnp + 2 * TC + ch * 4, bs);
+      dof_ld_row<4>(A.bwd_coef + ch * 4, c1);
+      dof_ld_row<4>(A.bwd_coef + TC + ch * 4, c2);
+    }
+    float4 v[NP], yv[TWO ? NP : 1];
+    // the loads of pass u of tile g (unconditional: steps past T re-read step T - 1 and are staged as zeros; a tile past
+    // the end re-reads the last one and is never staged)
+    auto issue = [&](int u, int64_t g) DOF_INLINE_LAMBDA {
+      const int64_t gc = g < n_groups ? g : n_groups - 1;
+      const int t = TS * u + tq;
+      const uint32_t off = (uint32_t)(gc * NS + sq) * TC + ch * 4 + (uint32_t)(t < T ? t : T - 1) * row_stride;
+      v[u] = *reinterpret_cast<const float4*>(A.in + off);
+      if (TWO) yv[TWO ? u : 0] = *reinterpret_cast<const float4*>(A.bwd_y + off);
+    };
+    // pass u of tile g from its registers into image `buf`
+    auto stage = [&](int u, int64_t g, int buf) DOF_INLINE_LAMBDA {
+      const int64_t s0 = g * NS;
+      const int t = TS * u + tq;
+      const bool live = s0 + sq < A.S && t < T;
+      float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      if (BN_IN) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) e[c] = fmaxf(fmaf(e[c], k0[c], k1[c]), 0.0f);
+      }
+      if (COMB) {
+        const float4 yq = yv[TWO ? u : 0];
+        const float y4[4] = {yq.x, yq.y, yq.z, yq.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) e[c] = fmaxf(fmaxf(fmaf(y4[c], k0[c], k1[c]), 0.0f) + e[c], 0.0f);
+      }
+      if (BWD2) {
+        const float4 yq = yv[TWO ? u : 0];
+        const float y4[4] = {yq.x, yq.y, yq.z, yq.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float xh = (y4[c] - bm[c]) * br[c];
+          e[c] = bs[c] * (e[c] - c1[c] - xh * c2[c]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) e[c] = live ? e[c] : 0.0f;
+      if (WGRAD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rs[c] += e[c];
+      }
+      uint32_t pw[3][2];
+      dof_split3x4(e, pw);
+      const int row = t * NS + sq, eo = buf * TB_IMG + tb_off(row, ch >> 1) + (ch & 1) * 4;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) tb_st8(&img[p * TB_PLANE + eo], pw[p][0], pw[p][1]);
+      if (COMB) {  // the row's 32 sign bits for the TAIL convolution of the backward pass
+        const uint32_t wbits = tct_row_mask(e, ch);
+        if (ch == 0 && live && A.relu_mask_out) A.relu_mask_out[(uint32_t)t * (uint32_t)A.Sp + (uint32_t)(s0 + sq)] = wbits;
+      }
+      if (live) {
+        const uint32_t off = (uint32_t)(s0 + sq) * TC + ch * 4 + (uint32_t)t * row_stride;
+        const float4 w4 = make_float4(e[0], e[1], e[2], e[3]);
+        if ((BN_IN || COMB) && !REVERSE && A.a_out) *reinterpret_cast<float4*>(A.a_out + off) = w4;
+        if (BWD2 && A.bwd_store) *reinterpret_cast<float4*>(const_cast<float*>(A.in) + off) = w4;
+      }
+    };
+    // Iteration k of the workgroup (k = 0 .. tiles): the loaders stage tile k from their registers into image k & 1 and
+    // then issue tile k + 1's loads (one vmcnt(0) per tile: a whole iteration has passed since they were issued; loads and
+    // the staging's stores share the counter, so a wait between them would drain both); the compute wavefronts work on
+    // tile k - 1.  Both roles pass the same barriers: the compute rounds' (WGRAD, k >= 1), then the end of the iteration.
+    const int64_t g0 = blockIdx.x, gs = gridDim.x;
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (u < np_run) issue(u, g0);
+    int k = 0;
+    for (int64_t grp = g0;; grp += gs, ++k) {
+      const bool have = grp < n_groups;  // tile k exists (the last iteration only lets the compute wavefronts finish)
+      int bar = (WGRAD && k >= 1) ? 0 : n_rounds;
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        if (u < np_run && have) stage(u, grp, k & 1);
+        if (WGRAD) {
+          while (bar < n_rounds && (u + 1) * n_rounds >= (bar + 1) * np_run) {
+            __syncthreads();
+            ++bar;
+          }
+        }
+      }
+      if (have && grp + gs < n_groups) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+          if (u < np_run) issue(u, grp + gs);
+      }
+      if (WGRAD) {
+        for (; bar < n_rounds; ++bar) __syncthreads();
+      }
+      __syncthreads();  // tile k - 1 is consumed, tile k is staged
+      if (!have) break;
+    }
+  } else {
+    // =========================================== compute wavefronts ===========================================
+    const int i = lane & 15, kk = lane >> 4;
+    const int sl = i % NS, tsub = i / NS;  // the lane's sequence of the tile and its row of the column block
+    // A operands: for tap j, piece p, channel half ct the 16 x 32 weight block of output channels (m >> 2) 8 + ct 4 + (m & 3),
+    // m = lane & 15, input channels kk 8 .. + 7
+    dof_bf16x8 wq[TK][3][2];
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float v0[4], v1[4];
+        const int col = (i >> 2) * 8 + ct * 4 + (i & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c0 = kk * 8 + e, c1 = kk * 8 + 4 + e;
+          v0[e] = REVERSE ? A.w[(c0 * TC + col) * TK + j] : A.w[(col * TC + c0) * TK + j];
+          v1[e] = REVERSE ? A.w[(c1 * TC + col) * TK + j] : A.w[(col * TC + c1) * TK + j];
+        }
+        uint32_t s0w[3][2], s1w[3][2];
+        dof_split3x4(v0, s0w);
+        dof_split3x4(v1, s1w);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wq[j][p][ct] = dof_mk_bf16x8(s0w[p][0], s0w[p][1], s1w[p][0], s1w[p][1]);
+      }
+    // the lane's output channels: kk 8 + ct 4 + q
+    float bias[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bias[ct][q] = (!REVERSE && A.bias) ? A.bias[kk * 8 + ct * 4 + q] : 0.0f;
+        kshift[ct][q] = (!REVERSE && A.stat_shift) ? A.stat_shift[kk * 8 + ct * 4 + q] : 0.0f;
+      }
+    const float* pre_src = FUSE_BN ? A.fuse_y : (const float*)A.out;
+    const bool pre_on = REVERSE && (FUSE_BN || A.accumulate);
+    const int64_t g0 = blockIdx.x, gs = gridDim.x;
+    __syncthreads();  // iteration 0: image 0 is being staged (and frec is loaded)
+    int k = 1;
+    for (int64_t grp = g0; grp < n_groups; grp += gs, ++k) {
+      const int64_t s0 = grp * NS;
+      const uint16_t* im = &img[((k - 1) & 1) * TB_IMG];
+      const int64_t s = s0 + sl;
+      const bool ok_s = s < A.S;
+      // epilogue operands of the lane's column block: two quads = 32 contiguous bytes per tensor.  Requested one round ahead
+      // (round 0's at the top of the tile): the registers of a round are dead once its epilogue has run, and every request is
+      // straight-line code between its round and the next -- a value carried around a loop edge costs the compiler a copy,
+      // i.e. a wait right behind the load.  Unconditional loads from clamped addresses (a predicate would merge old and new
+      // values: the same copies).
+      float4 pre[2], tsv[2], xo[2];
+      uint32_t tmw = 0u;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) pre[ct] = tsv[ct] = xo[ct] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      auto prefetch = [&](int r) DOF_INLINE_LAMBDA {
+        const int cb = 4 * r + wv;
+        const int t = (cb < n_cb ? cb : n_cb - 1) * TPC + tsub;
+        const uint32_t sv = (uint32_t)(ok_s ? s : s0);  // padded lanes read a valid row and ignore it
+        const uint32_t tv = (uint32_t)(t < T ? t : T - 1);
+        const uint32_t off = sv * TC + kk * 8 + tv * row_stride;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          if (pre_on) pre[ct] = *reinterpret_cast<const float4*>(pre_src + off + ct * 4);
+          if (TAIL) tsv[ct] = *reinterpret_cast<const float4*>(A.tail_src + off + ct * 4);
+          if (TAIL && WGRAD) xo[ct] = *reinterpret_cast<const float4*>(A.wg_x + off + ct * 4);
+        }
+        if (TAIL && !WGRAD) tmw = A.tail_mask[sv + tv * (uint32_t)A.Sp];
+      };
+      auto round = [&](int r) DOF_INLINE_LAMBDA {
+        const int cb = 4 * r + wv;
+        if (cb < n_cb) {
+          const int t0 = cb * TPC, t = t0 + tsub;
+          const bool ok = ok_s && t < T;
+          dof_f32x4 acc[2];
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) acc[ct] = dof_f32x4{bias[ct][0], bias[ct][1], bias[ct][2], bias[ct][3]};
+#pragma unroll
+          for (int j = 0; j < TK; ++j) {
+            const int sh = REVERSE ? (TK - 1 - j) * A.dil : -(TK - 1 - j) * A.dil;
+            const int tlo = t0 + sh;
+            if (tlo + TPC - 1 >= 0 && tlo < T) {  // wave-uniform: some row of the block has this tap inside the window
+              const int tt = t + sh;
+              const int row = ((tt >= 0 && tt < T) ? tt : T) * NS + sl;
+              const int eo = tb_off(row, kk);
+              const dof_bf16x8 b0 = dof_ld_bf16x8_16(&im[eo]), b1 = dof_ld_bf16x8_16(&im[TB_PLANE + eo]),
+                               b2 = dof_ld_bf16x8_16(&im[2 * TB_PLANE + eo]);
+              // small terms first; the two channel halves are independent accumulator chains
+              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][0][0], b2, acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][0][1], b2, acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][2][0], b0, acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][2][1], b0, acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][1][0], b1, acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][1][1], b1, acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][0][0], b1, acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][0][1], b1, acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][1][0], b0, acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][1][1], b0, acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][0][0], b0, acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][0][1], b0, acc[1]);
+            }
+          }
+          // ---- epilogue: lane = sequence sl at row t, output channels kk 8 + ct 4 + q
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const uint32_t off = (uint32_t)s * TC + kk * 8 + ct * 4 + (uint32_t)t * row_stride;
+            float xw[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // WGRAD: the convolution's forward input at (t, s), this lane's channels
+            if (ok) {
+              float v0[4] = {acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]};
+              const float pc[4] = {pre[ct].x, pre[ct].y, pre[ct].z, pre[ct].w};
+              if (REVERSE && !FUSE_BN && A.accumulate) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v0[q] += pc[q];
+              }
+              if (TAIL) {
+                const float sv[4] = {tsv[ct].x, tsv[ct].y, tsv[ct].z, tsv[ct].w};
+                if (WGRAD) {
+                  xw[0] = xo[ct].x; xw[1] = xo[ct].y; xw[2] = xo[ct].z; xw[3] = xo[ct].w;
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v0[q] = xw[q] > 0.0f ? v0[q] + sv[q] : 0.0f;
+                } else {
+                  const uint32_t nib = tmw >> (kk * 8 + ct * 4);  // bit q: out[t][s][kk*8 + ct*4 + q] > 0
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v0[q] = ((nib >> q) & 1u) != 0u ? v0[q] + sv[q] : 0.0f;
+                }
+                *reinterpret_cast<float4*>(A.tail_gres + off) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+                if (A.tail_dfeat && t == T - 1) {
+                  const float4 sk = *reinterpret_cast<const float4*>(A.tail_skip + off);
+                  const float sk4[4] = {sk.x, sk.y, sk.z, sk.w};
+#pragma unroll
+                  for (int q = 0; q < 4; ++q)
+                    v0[q] += sk4[q] > 0.0f ? A.tail_dfeat[(int64_t)(kk * 8 + ct * 4 + q) * A.Sp + s] : 0.0f;
+                }
+              }
+              if (FUSE_BN) {
+                const int cw = kk * 2 + ct;
+                const float4 m4 = frec[cw], r4 = frec[TC / 4 + cw], sc4 = frec[2 * TC / 4 + cw], sh4 = frec[3 * TC / 4 + cw];
+                const float fm[4] = {m4.x, m4.y, m4.z, m4.w}, fr[4] = {r4.x, r4.y, r4.z, r4.w};
+                const float fsc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, fsh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float act = fmaf(pc[q], fsc[q], fsh[q]);
+                  if (WGRAD && !TAIL) xw[q] = fmaxf(act, 0.0f);  // conv2's input a1 = ReLU(BN1(y1)), the forward's expression
+                  v0[q] = act > 0.0f ? v0[q] : 0.0f;
+                  s1[ct][q] += v0[q];
+                  s2[ct][q] = fmaf(v0[q], (pc[q] - fm[q]) * fr[q], s2[ct][q]);
+                }
+              }
+              *reinterpret_cast<float4*>(A.out + off) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+              if (!REVERSE) {
+                if (A.stat_records && n_rows == 0.0f) {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) kshift[ct][q] = v0[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float dv = v0[q] - kshift[ct][q];
+                  s1[ct][q] += dv;
+                  s2[ct][q] = fmaf(dv, dv, s2[ct][q]);
+                }
+              }
+            }
+            if (WGRAD) {  // every lane writes its four channels (zeros for padded sequences / rows behind the window)
+              uint32_t pw[3][2];
+              dof_split3x4(xw, pw);
+              uint16_t* slot = &ring[((r & 1) * 4 + wv) * 3 * TB_RING];
+              const int eo = tb_ring_off(i, kk * 2 + ct);
+#pragma unroll
+              for (int p = 0; p < 3; ++p) tb_st8(&slot[p * TB_RING + eo], pw[p][0], pw[p][1]);
+            }
+          }
+          if (!REVERSE && ok) n_rows += 1.0f;
+        }
+        // the next round's epilogue operands: they fly during the weight-gradient phase and the next matrix phase
+        if (r + 1 < 4) prefetch(r + 1);
+        if (WGRAD) {
+          __syncthreads();  // the round's four ring slots are complete (double-buffered: the next round writes the other set)
+          const int shw = (TK - 1 - wv) * A.dil;  // wavefront wv = tap wv
+          const int g = lane >> 4, q = lane & 15, kh = g >> 1, mh = g & 1;
+#pragma unroll 1
+          for (int w2 = 0; w2 < 4; ++w2) {
+            const int cb2 = 4 * r + w2;
+            if (cb2 >= n_cb) break;
+            const int t02 = cb2 * TPC;
+            if (t02 + shw >= T) continue;  // every dy row of this tap lies behind the window
+            const uint16_t* slot = &ring[((r & 1) * 4 + w2) * 3 * TB_RING];
+            uint32_t aw[3][4], bw[3][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int kcol = 8 * kh + 4 * h + (q >> 2);  // the K index (column of the block) whose run this lane supplies
+              const int tt = t02 + kcol / NS + shw;
+              const int row = (tt < T ? tt : T) * NS + kcol % NS;
+              // A row m of half mh = output channel (m >> 2) 8 + mh 4 + (m & 3): the run of lane q covers rows 4 (q & 3) .. + 3,
+              // i.e. the four channels (q & 3) 8 + mh 4 .. + 3 = 16-byte chunk q & 3, its half mh
+              const int ea = tb_off(row, q & 3) + mh * 4;
+              const int eb = tb_ring_off(kcol, mh * 4 + (q & 3));
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                dof_lds_tr16(&im[p * TB_PLANE + ea], aw[p][2 * h], aw[p][2 * h + 1]);
+                dof_lds_tr16(&slot[p * TB_RING + eb], bw[p][2 * h], bw[p][2 * h + 1]);
+              }
+            }
+            dof_bf16x8 a[3], b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              a[p] = dof_mk_bf16x8(aw[p][0], aw[p][1], aw[p][2], aw[p][3]);
+              b[p] = dof_mk_bf16x8(bw[p][0], bw[p][1], bw[p][2], bw[p][3]);
+            }
+            accw = DOF_MFMA_32x32x16_BF16(a[0], b[2], accw);
+            accw = DOF_MFMA_32x32x16_BF16(a[2], b[0], accw);
+            accw = DOF_MFMA_32x32x16_BF16(a[1], b[1], accw);
+            accw = DOF_MFMA_32x32x16_BF16(a[0], b[1], accw);
+            accw = DOF_MFMA_32x32x16_BF16(a[1], b[0], accw);
+            accw = DOF_MFMA_32x32x16_BF16(a[0], b[0], accw);
+          }
+        }
+      };
+      prefetch(0);
+      // at most four rounds (13 column blocks), nested so that every request dominates its use
+      static_assert((TB_ROWS / NS / TPC + 3) / 4 <= 4 || true, "");
+      if (n_rounds > 0) {
+        round(0);
+        if (n_rounds > 1) {
+          round(1);
+          if (n_rounds > 2) {
+            round(2);
+            if (n_rounds > 3) round(3);
+          }
+        }
+      }
+      __syncthreads();  // tile k - 1 is consumed, tile k is staged
+    }
+  }
+  // ---- the workgroup's sums (every wavefront is past its last tile barrier: both images are free)
+  float* scratch = reinterpret_cast<float*>(img);
+  const int i = lane & 15, kk = lane >> 4;
+  if (WGRAD) {
+    if (!loader) {
+      // tap wv's 32 x 32 tile.  D register v of lane l = row 8 (v / 4) + 4 (l >> 5) + v % 4, column l & 31; row m of the A
+      // operand was output channel 16 (m >> 4) ... in the image's order: m = 16 mh + i <-> channel (i >> 2) 8 + mh 4 + (i & 3);
+      // the columns (B operand, the ring's channel order kk 8 + ct 4 + q at 8-byte chunk kk 2 + ct) are channels in natural order
+      float* outp = A.wg_partials + (wv < 2 ? A.wg_part0 : A.wg_part1) + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int m = 8 * (v / 4) + 4 * (lane >> 5) + v % 4;
+        const int oc = ((m & 15) >> 2) * 8 + (m >> 4) * 4 + (m & 3);
+        outp[oc * 65 + (wv & 1) * 32 + (lane & 31)] = accw[v];
+      }
+    } else {
+      // bias gradient: channel sums of dy over the staging threads of a channel quad, fixed order
+      const int lt = threadIdx.x - 256;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) scratch[(lt >> 3) * 32 + (lt & 7) * 4 + c] = rs[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float b = 0.0f;
+      for (int k = 0; k < 32; ++k) b += scratch[k * 32 + threadIdx.x];
+      A.wg_partials[A.wg_part0 + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS + threadIdx.x * 65 + 64] = b;
+    }
+    __syncthreads();
+  }
+  if (!REVERSE && A.partial && A.stat_records) {
+    // one-pass statistics without a reference value (see k_tcn_conv_t): every lane's sums are about ITS first output
+    // value, turned into (n, mean, M2) and merged with Chan's update -- the 16 lanes of a row, the four compute wavefronts
+    // in order, then the workgroups (k_tcn_stat_merge)
+    float* rec = scratch;  // [wavefront][3][32]
+    if (!loader) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float n = n_rows, mean = 0.0f, m2 = 0.0f;
+          if (n > 0.0f) {
+            const float d = s1[ct][q] / n;
+            mean = kshift[ct][q] + d;
+            m2 = fmaxf(s2[ct][q] - s1[ct][q] * d, 0.0f);
+          }
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) {
+            const float nb = __shfl_xor(n, m), mb = __shfl_xor(mean, m), qb = __shfl_xor(m2, m);
+            dof_stat_merge(n, mean, m2, nb, mb, qb);
+          }
+          if (i == 0) {
+            const int c = kk * 8 + ct * 4 + q;
+            rec[(wv * 3 + 0) * 32 + c] = n;
+            rec[(wv * 3 + 1) * 32 + c] = mean;
+            rec[(wv * 3 + 2) * 32 + c] = m2;
+          }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TC) {
+      const int c = threadIdx.x;
+      float n = rec[c], mean = rec[32 + c], m2 = rec[64 + c];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) dof_stat_merge(n, mean, m2, rec[(w * 3 + 0) * 32 + c], rec[(w * 3 + 1) * 32 + c], rec[(w * 3 + 2) * 32 + c]);
+      float* out = A.partial + (int64_t)blockIdx.x * 3 * TC;
+      out[c] = n;
+      out[TC + c] = mean;
+      out[2 * TC + c] = m2;
+    }
+  } else if ((!REVERSE || FUSE_BN) && A.partial) {
+    float* wsum = scratch;  // [wavefront][64]: (sum 32 | second sum 32)
+    if (!loader) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float a1 = dof_row16_sum(s1[ct][q]), a2 = dof_row16_sum(s2[ct][q]);
+          if (i == 0) {
+            wsum[wv * 64 + kk * 8 + ct * 4 + q] = a1;
+            wsum[wv * 64 + 32 + kk * 8 + ct * 4 + q] = a2;
+          }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * TC)
+      A.partial[(int64_t)blockIdx.x * 2 * TC + threadIdx.x] =
+          ((wsum[threadIdx.x] + wsum[64 + threadIdx.x]) + wsum[128 + threadIdx.x]) + wsum[192 + threadIdx.x];
+  }
+}

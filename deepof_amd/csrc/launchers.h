@@ -86,7 +86,11 @@ int64_t dof_tcn_conv32_partials(int T, int64_t Sp);   // partial rows written by
 int dof_launch_tcn_conv_bwd_bn(const float* dy, const float* w, const float* y, const float* bnp, float* g_out,
                                float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st,
                                const float* bwd_y = nullptr, const float* bwd_bnp = nullptr,
-                               const float* bwd_coef = nullptr, int bwd_store = 1);
+                               const float* bwd_coef = nullptr, int bwd_store = 1,
+                               float* wg_partials = nullptr, int64_t wg_part0 = 0, int64_t wg_part1 = 0);
+// 1: the fused data-gradient variants of the time-resident convolution also accumulate the convolution's weight gradient
+// (k_tcn_conv_b WGRAD; partial tiles [dof_tcn_conv32_partials][64][65] per tap pair, k_tcn_wgrad_b3's layout)
+int dof_tcn_wgrad_fused(int T, int64_t Sp);
 int dof_launch_tcn_conv(int reverse, const float* in, const float* w, const float* bias, const float* bnp_in,
                         float* a_out, float* out, float* partial, int accumulate, int T, int dil, int64_t S, int64_t Sp,
                         hipStream_t st, const float* bwd_y = nullptr, const float* bwd_bnp = nullptr,
@@ -112,7 +116,8 @@ int dof_tcn_tail_fold();
 int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
                              int bwd_store, const float* tail_src, const float* tail_mask, float* tail_gres,
                              const float* tail_skip, const float* tail_dfeat, const float* y2, const float* bnp2, float* g_out,
-                             float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st);
+                             float* partial, float* sums, int T, int dil, int64_t S, int64_t Sp, hipStream_t st,
+                             const float* wg_x = nullptr, float* wg_partials = nullptr, int64_t wg_part0 = 0, int64_t wg_part1 = 0);
 // relu_mask_out / tail_mask / mask_out: [T][Sp] words, bit c = out[t][s][c] > 0 (the block output's ReLU mask)
 int dof_launch_bn_fwd_fin(const float* sums, float count, const float* gamma, const float* beta, float* rmean,
                           float* rvar, float momentum, int train, float* bnp, int C, hipStream_t st, int shifted = 0);

@@ -90,6 +90,9 @@ struct TcnWs {  // float offsets of one stream's TCN buffers ([T][Sp][32] unless
   int64_t partial, sums, coef;
   int64_t coefs[16];                    // per-layer (mean g | mean g xhat): read again by the lazy weight-gradient operands
   int lazy;                             // 1: BatchNorm-backward pass 2 and the conv2 input activation are applied on load
+  int wg_fused;                         // 1 (round 6): the weight gradients of conv2 (every block) and conv1 (blocks 1 .. 7, with the tail fold) are
+                                        // accumulated by the data-gradient launches themselves (k_tcn_conv_b WGRAD), not by k_tcn_wgrad_b3
+  int64_t wgp[16][2];                   // ... partial-tile regions of layer 2 b (conv1) / 2 b + 1 (conv2): taps 0, 1 | taps 2, 3
   int first_staged;                     // 1: block 0's weight gradients come from k_tcn_wgrad_in (lazy conv1 gradient)
   int64_t partial_rows;
 };
@@ -549,6 +552,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     // BatchNorm backward and conv2's input activation are recomputed where they are read, so neither the normalised
     // gradients nor the activated tensors a1 are ever written (8 x [T][Sp][32] per stream less)
     t.lazy = (dof_tcn_conv32_resident(T, Sp) && T <= dof_tcn_wgrad_max_t()) ? 1 : 0;
+    t.wg_fused = (t.lazy && dof_tcn_wgrad_fused(T, Sp)) ? 1 : 0;
     {  // DOF_TCN_WGRAD_IN=0: block 0 through the generic reduction (A/B measurements)
       const char* e = getenv("DOF_TCN_WGRAD_IN");
       t.first_staged = (t.lazy && (p->sw[s].F == 3 || p->sw[s].F == 1) && !(e && e[0] == '0')) ? 1 : 0;
@@ -986,7 +990,7 @@ void build_tcn_jobs(DofVadePlan* p) {
   p->js_enc.wg_first = p->tw[0].first_staged || p->tw[1].first_staged;
   for (int s = 0; s < 2; ++s) {
     const StreamWs& w = p->sw[s];
-    const TcnWs& t = p->tw[s];
+    TcnWs& t = p->tw[s];
     const int64_t Sp = w.Sp;
     for (int b = 0; b < 8; ++b) {
       const TcnBlockOff& o = p->tblk[s][b];
@@ -999,10 +1003,13 @@ void build_tcn_jobs(DofVadePlan* p) {
         bool bias_done = false;
         // 32 -> 32 convolutions: the partial tiles of the two jobs come from k_tcn_wgrad (LDS-staged operands)
         const bool first = cin < C && d == 1 && t.first_staged;  // block 0: one job of four tap tiles, from k_tcn_wgrad_in
+        // round 6: ... or from the convolution's own data-gradient launch (conv2 of every block; conv1 behind the tail fold)
+        const bool fusedk = cin == C && t.wg_fused && ((layer & 1) || dof_tcn_tail_fold());
         const bool staged = (cin == C && T <= dof_tcn_wgrad_max_t()) || first;
         // (first: 128 workgroups of 8 waves per stream = the 2 waves per SIMD its registers allow, both streams resident)
-        const int ext = first ? (int)(Sp / 64 < 1 ? 1 : Sp / 64 < 128 ? Sp / 64 : 128) : staged ? (int)(Sp / 8 < 448 ? Sp / 8 : 448) : 0;
-        if (staged) {
+        const int ext = first ? (int)(Sp / 64 < 1 ? 1 : Sp / 64 < 128 ? Sp / 64 : 128)
+                      : fusedk ? (int)dof_tcn_conv32_partials(T, Sp) : staged ? (int)(Sp / 8 < 448 ? Sp / 8 : 448) : 0;
+        if (staged && !fusedk) {
           DofTcnWgrad g;
           memset(&g, 0, sizeof(g));
           g.dy = dy; g.in = in; g.dil = d; g.nblk = ext; g.T = T; g.Sp = Sp; g.S = w.S;
@@ -1020,7 +1027,8 @@ void build_tcn_jobs(DofVadePlan* p) {
           for (int c0 = 0; c0 < cin; c0 += 16) {
             if (job < 0 || jb.jobs[job].n_tiles == 4) {
               job = jb.add_job(aos(dy, C, Sp), C, T, Sp, ext);
-              if (staged) (j < 2 ? p->js_enc.wgrads.back().part0 : p->js_enc.wgrads.back().part1) = jb.jobs[job].partial_off;
+              if (fusedk) t.wgp[layer][j < 2 ? 0 : 1] = jb.jobs[job].partial_off;
+              else if (staged) (j < 2 ? p->js_enc.wgrads.back().part0 : p->js_enc.wgrads.back().part1) = jb.jobs[job].partial_off;
               if (!bias_done) jb.add_fin(job, 64, C, 1, C, C, bOff, 1, 1);
               bias_done = true;
             }
@@ -1030,10 +1038,10 @@ void build_tcn_jobs(DofVadePlan* p) {
           }
       };
       conv(ws + t.g1[b], b == 0 ? ws + t.xs : ws + t.out[b - 1], b == 0 ? w.F : C, o.c1w, o.c1b, 2 * b, -1);
+      const size_t first_desc = p->js_enc.wgrads.size() - 1;  // (first_staged: block 0's conv1 descriptor was pushed last)
       conv(ws + t.g2[b], t.lazy ? ws + t.y1[b] : ws + t.a1[b], C, o.c2w, o.c2b, 2 * b + 1, 2 * b);
       if (b == 0) {  // 1x1 residual conv: A = gradient entering the residual branch of block 0 (left in dout[1])
-        // (first_staged: block 0's conv1 descriptor is the one before conv2's)
-        DofTcnWgrad* g0 = t.first_staged ? &p->js_enc.wgrads[p->js_enc.wgrads.size() - 2] : nullptr;
+        DofTcnWgrad* g0 = t.first_staged ? &p->js_enc.wgrads[first_desc] : nullptr;
         const int job = jb.add_job(aos(ws + t.dout[1], C, Sp), C, T, Sp, g0 ? g0->nblk : 0);
         if (g0) {
           g0->dy2 = ws + t.dout[1];
@@ -1262,8 +1270,11 @@ int run_jobset(DofVadePlan* p, const JobSet& js, float* dst, int accumulate, hip
   const DofOuterJob* jobs = reinterpret_cast<const DofOuterJob*>(p->ws + js.jobs_tab);
   const DofFinJob* fins = reinterpret_cast<const DofFinJob*>(p->ws + js.fin_tab);
   TRY(dof_launch_outer(jobs, (int)js.jobs.size(), js.total_blocks, p->ws + p->partials, st));
-  TRY(dof_launch_tcn_wgrad(reinterpret_cast<const DofTcnWgrad*>(p->ws + js.wg_tab), (int)js.wgrads.size(), js.wg_blocks,
-                           p->ws + p->partials, st));
+  bool any32 = false;  // (round 6: the 32-channel convolutions may all have their weight gradients from k_tcn_conv_b)
+  for (const DofTcnWgrad& g : js.wgrads) any32 = any32 || g.cin == 0;
+  if (any32)
+    TRY(dof_launch_tcn_wgrad(reinterpret_cast<const DofTcnWgrad*>(p->ws + js.wg_tab), (int)js.wgrads.size(), js.wg_blocks,
+                             p->ws + p->partials, st));
   if (js.wg_first)
     TRY(dof_launch_tcn_wgrad_in(reinterpret_cast<const DofTcnWgrad*>(p->ws + js.wg_tab), (int)js.wgrads.size(), js.wg_blocks,
                                 p->ws + p->partials, st));
@@ -2015,7 +2026,8 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
       if (fuse2) {
         TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
                                        ws + t.partial, nullptr, T, d, w.S, w.Sp, st, ws + t.y2[b],
-                                       ws + t.bnp[2 * b + 1], coef2, t.lazy ? 0 : 1));
+                                       ws + t.bnp[2 * b + 1], coef2, t.lazy ? 0 : 1,
+                                       t.wg_fused ? ws + p->partials : nullptr, t.wgp[2 * b + 1][0], t.wgp[2 * b + 1][1]));
       } else {
         TRY(dof_launch_tcn_bn_bwd2(ws + t.g2[b], ws + t.y2[b], ws + t.bnp[2 * b + 1], coef2, T, 32, w.S, w.Sp, st));
         TRY(dof_launch_tcn_conv_bwd_bn(ws + t.g2[b], params + o.c2w, ws + t.y1[b], ws + t.bnp[2 * b], ws + t.g1[b],
@@ -2029,7 +2041,9 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
         // its masked form goes to block b - 1's own dprev (this block's din buffer, free by now)
         TRY(dof_launch_tcn_conv_tail(ws + t.g1[b], params + o.c1w, ws + t.y1[b], ws + t.bnp[2 * b], coef1, t.lazy ? 0 : 1, dprev,
                                      ws + t.omask[b - 1], ws + t.dout[b & 1], ws + t.skip, ws + w.dn2, ws + t.y2[b - 1],
-                                     ws + t.bnp[2 * b - 1], ws + t.g2[b - 1], ws + t.partial, nullptr, T, d, w.S, w.Sp, st));
+                                     ws + t.bnp[2 * b - 1], ws + t.g2[b - 1], ws + t.partial, nullptr, T, d, w.S, w.Sp, st,
+                                     t.wg_fused ? ws + t.out[b - 1] : nullptr, t.wg_fused ? ws + p->partials : nullptr,
+                                     t.wgp[2 * b][0], t.wgp[2 * b][1]));
         tail_done = true;
       } else if (fuse2 && b > 0) {  // pass 2 of BN1's backward inside conv1's data gradient
         TRY(dof_launch_tcn_conv(1, ws + t.g1[b], params + o.c1w, nullptr, nullptr, nullptr, dprev, nullptr, 1, T, d, w.S,

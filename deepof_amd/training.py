@@ -109,7 +109,10 @@ _DP_SWITCHES = {}
 _DP_CHECK = {}   # process-group identity -> the self-check's verdict string ("" when no check was due)
 
 
-def dp_self_check(candidate, dist, like: torch.Tensor, captured: bool = False, timeout_s: float = None):
+_DP_CHECK_LEAKED = []   # buffers / graphs of a timed-out self-check (deliberately never freed)
+
+
+def dp_self_check(candidate, dist, like: torch.Tensor, captured: bool = False, timeout_s: float = None, on_timeout=None):
     """Does ``candidate(t)`` -- an in-place SUM over the ranks, enqueued on the current stream -- agree with
     ``torch.distributed.all_reduce`` on a scratch buffer shaped like ``like`` (the flat gradient)?
 
@@ -130,6 +133,7 @@ def dp_self_check(candidate, dist, like: torch.Tensor, captured: bool = False, t
     ref = probe.clone()
     dist.all_reduce(ref, op=dist.ReduceOp.SUM)
     ok, why = True, ""
+    hung = []
 
     def agrees(got, what):
         if torch.equal(got, ref):
@@ -159,6 +163,7 @@ def dp_self_check(candidate, dist, like: torch.Tensor, captured: bool = False, t
                 done.record(side)
             if not finished(done):
                 ok, why = False, f"the collective did not complete within {timeout_s:.0f} s"
+                hung += [got, side]
             else:
                 ok, why = agrees(got, "the eager collective")
             if ok and captured:
@@ -173,15 +178,22 @@ def dp_self_check(candidate, dist, like: torch.Tensor, captured: bool = False, t
                     done2.record(side)
                 if not finished(done2):
                     ok, why = False, f"the captured collective did not complete within {timeout_s:.0f} s"
+                    hung += [got2, g, side]
                 else:
                     ok, why = agrees(got2, "the captured collective")
-                del g
+                    del g
         else:
             got = probe.clone()
             candidate(got)
             ok, why = agrees(got, "the collective")
     except Exception as exc:  # a failing candidate must end in the safe form, not in a dead fit
         ok, why = False, f"{type(exc).__name__}: {exc}"
+    if hung:
+        # a collective that never finished may still be reading its buffers / replaying its graph: keep them alive for the
+        # rest of the process, and drop the communicator BEFORE the verdict's all-reduce has to share the device with it
+        _DP_CHECK_LEAKED.extend(hung)
+        if on_timeout is not None:
+            on_timeout()
     flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if ok and float(flag.item()) != 1.0:
@@ -208,7 +220,7 @@ def _decide_dp_form(rccl: bool, dist, grads: torch.Tensor, native_reduce_factory
         if reduce is None:
             def reduce(_t, _why=why):
                 raise RuntimeError(_why)
-        ok, why = dp_self_check(reduce, dist, grads, captured=one_graph)
+        ok, why = dp_self_check(reduce, dist, grads, captured=one_graph, on_timeout=on_failure)
         verdict = "passed" if ok else f"failed ({why})"
         if not ok:
             native, one_graph = False, False

@@ -207,6 +207,18 @@ emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
   return c;
 }
 
+namespace {
+const uint16_t* g_trp[1024];  // per-thread run addresses of a transposing read
+}
+void emu_lds_tr16(const uint16_t* p, uint16_t out[4]) {
+  int me = g_cur;
+  int lane = me & 63, base = me - lane, grp = lane & ~15, i = lane & 15;
+  g_trp[me] = p;
+  yield_as(WAIT_WAVE);
+  for (int j = 0; j < 4; ++j) out[j] = g_trp[base + grp + 4 * j + (i >> 2)][i & 3];
+  yield_as(WAIT_WAVE);
+}
+
 void emu_run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
   g_body = &body;
   gridDim = grid;

@@ -50,6 +50,7 @@ struct emu_bf16x8 { uint16_t v[8]; };
 typedef float emu_f32x16 __attribute__((vector_size(64)));
 emu_f32x16 emu_mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c);
 emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c);
+void emu_lds_tr16(const uint16_t* p, uint16_t out[4]);  // ds_read_b64_tr_b16 (see dof_lds_tr16)
 
 static inline void __syncthreads() { emu_sync_block(); }
 static inline float __shfl_xor(float v, int mask, int width = 64) {

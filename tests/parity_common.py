@@ -359,9 +359,11 @@ def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn1
     e2.contrastive_backward(dza, accumulate=True)
     # C4's shape (B = 64, window 50 -> 25, both views): the standard bar + the explicit attribution of ReLU-branch flips
     # (tcn_kinks.npz, make_golden_r04.py): a tensor no identified flip reaches is held to the plain bar
+    # (round 6: the latent-16 fixture too -- tests/golden/make_golden_r06.py -- since the bf16-piece convolutions sum in another
+    #  order than the fp32-MFMA ones did and one of its 69 near-zero pre-activations changes branch on the MI355X)
     kinks, flips = None, []
-    if fixture == "contrastive_tcn14_b64.npz":
-        kinks = KinkAttribution(golden_dir, "contrastive_tcn14_b64::c0::")
+    if fixture in ("contrastive_tcn14_b64.npz", "contrastive_tcn14l16.npz"):
+        kinks = KinkAttribution(golden_dir, fixture[:-4] + "::c0::")
         flips = kinks.identify(lambda t: e1.view(t, e1.grads).cpu().numpy(), lambda t: d[pfx + "grad::" + t])
     n, worst = 0, 0.0
     for k in d:

@@ -56,7 +56,7 @@ def test_gather_matches_reference_windows(hip, golden_dir):
             np.testing.assert_array_equal(a.cpu().numpy(), d[f"w{ci}::a"])
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l5", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
 def test_vade_eval_forward_gpu(hip, golden_dir, tag):
     from deepof_amd.engine import create_vade_engine
     from parity_common import load_golden, params_from
@@ -81,6 +81,7 @@ def test_vade_eval_forward_gpu(hip, golden_dir, tag):
                                        ("rec14l16", "pre"), ("rec14l16", "main"), ("rec14l16", "mainT"), ("rec14l16", "mainX"),
                                        ("rec14l32", "pre"), ("rec14l32", "main"), ("rec14l32", "mainT"), ("rec14l32", "mainX"),
                                        ("rec14l5", "pre"), ("rec14l5", "main"), ("rec14l5", "mainT"), ("rec14l5", "mainX"),
+                                       ("rec14l4", "pre"), ("rec14l4", "main"), ("rec14l4", "mainT"), ("rec14l4", "mainX"),
                                        ("rec14l10", "pre"), ("rec14l10", "mainX"), ("rec14l12", "pre"), ("rec14l12", "main"),
                                        ("rec14l12", "mainT"), ("rec14l12", "mainX"), ("rec14l20", "pre"), ("rec14l20", "mainX"),
                                        ("rec14l24", "pre"), ("rec14l24", "main"), ("rec14l24", "mainT"), ("rec14l24", "mainX")])
@@ -256,7 +257,7 @@ def test_training_api_on_gpu(hip, tmp_path):
     np.testing.assert_allclose(soft.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32", "rec14l5", "rec14l12", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l12", "rec14l24"])
 def test_vqvae_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_vqvae_check
     run_vqvae_check(hip, "cuda", golden_dir, tag)
@@ -328,7 +329,7 @@ def test_vqvae_full_size_c3(hip):
     np.testing.assert_allclose(out["soft_counts"].cpu().numpy(), soft.numpy(), rtol=2e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l5", "rec14l12", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l12", "rec14l24"])
 def test_contrastive_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_contrastive_check, run_contrastive_loss_check
     run_contrastive_loss_check(hip, "cuda", golden_dir, tag)
@@ -1342,6 +1343,42 @@ def test_data_parallel_default_form_is_one_graph_native(tmp_path):
     assert r["dp_keys"] == ["dp"] and r["dp_replays"] == 5, (r["dp_keys"], r["dp_replays"])
     assert r["plain_keys"] == ["train"], r["plain_keys"]
     torch.testing.assert_close(r["dp"], r["plain"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("config,extra", [("c2", ["--batch", "256", "--frames", "20000"]),
+                                          ("c4", ["--batch", "256", "--frames", "4000"]),
+                                          ("c5", ["--batch", "128", "--frames", "4000"])])
+def test_bench_two_ranks_share_the_gpu(config, extra):
+    """`python bench.py --gpus 2` end to end on the one device of this box (DOF_BENCH_SHARE_GPU=1: both ranks on cuda:0, gloo --
+    RCCL refuses two ranks on one device): the launcher's own code path -- spawn_ranks -> torch.distributed.run -> process group ->
+    the product steppers' data-parallel step -> barriers -> max-over-ranks -> rank 0's ONE JSON line with the `data_parallel`
+    object -- runs on a GPU box every round, for the headline configuration AND for the two BASELINE configurations that
+    name data parallelism (round-5 review, item 4).  Never a result: two ranks share one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DOF_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--config", config,
+           "--no-cpu-baseline", "--no-secondary", "--sustain-seconds", "0", "--gather-iters", "1"] + extra
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    B = int(extra[1])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak" and out["unit"] == "windows/s"
+    assert out["config"]["global_batch"] == 2 * B and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["workload"].startswith(config.upper() + ":"), out["config"]["workload"]
+    np.testing.assert_allclose(out["value"], 2 * B * 5 / (out["ms_per_step"] * 5e-3), rtol=1e-9)
+    dp = out["data_parallel"]
+    assert dp["world_size"] == 2 and dp["backend"] == "gloo" and dp["collectives_per_step"] == 1
+    assert dp["form"] == "torch.distributed.all_reduce between two graphs", dp["form"]
+    assert len(dp["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in dp["ms_per_step_per_rank"])
+    assert out["ms_per_step"] >= max(dp["ms_per_step_per_rank"]) * (1 - 1e-6)   # the line's time is the slowest rank's
+    assert dp["allreduce_bytes_per_step"] > 20_000 and np.isfinite(out["config"]["final_total_loss"])
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
 
 
 @pytest.mark.parametrize("n_nodes,latent,kind", [(8, 4, "vade"), (11, 6, "vqvae"), (16, 8, "vade"), (22, 8, "vqvae"),

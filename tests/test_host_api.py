@@ -362,6 +362,145 @@ def _dp_check_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _dp8_worker(rank, world, port, tmp):
+    """One rank of the 8-rank check: its shard of the epoch's batch starts (dataset.batch_starts, the reference's
+    `starts[rank::world]` arithmetic), one batch of 2 windows, loss + gradients on the emulated kernels, mean all-reduce."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from parity_common import configure_phase
+    bs, n, seed, epoch = 2, 37, 11, 1           # 19 batch starts (the last one short): 16 survive the truncation to 2 per rank
+    mine = batch_starts(n, bs, epoch, seed, True, world, rank)
+    g = torch.Generator().manual_seed(0)
+    eng = VadeEngine(emu_lib(), "cpu", bs, 8, chain_adj(4), 4, 3)
+    eng.params.copy_(torch.randn(eng.params.shape, generator=g) * 0.2)
+    xs, as_ = torch.randn(n + bs, 8, 4, 3, generator=g), torch.randn(n + bs, 8, 3, 1, generator=g)
+    eps = torch.randn(n + bs, 4, generator=g)
+    configure_phase(eng, 3, True, 0.2, extra=SEPARABLE)
+    s0 = int(mine[0])                            # this rank's first step of the epoch
+    eng.loss_grads(xs[s0:s0 + bs].contiguous(), as_[s0:s0 + bs].contiguous(), eps[s0:s0 + bs].contiguous(), None, None, True)
+    dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+    eng.grads.mul_(1.0 / world)
+    torch.save({"starts": mine, "reduced": eng.grads.clone(), "logs": eng.read_logs()}, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_eight_ranks_gloo(tmp_path):
+    """8 ranks (the node size BASELINE names): the shard arithmetic gives every rank the same number of batches, disjoint,
+    in the reference's order (dataset.py:592-618); the first step's 8 x 2 windows reduced over the ranks == ONE engine on the
+    concatenated 16 windows (batch-separable terms), gradient and loss terms."""
+    import torch.multiprocessing as mp
+    from parity_common import configure_phase
+    world, bs, n, seed, epoch = 8, 2, 37, 11, 1
+    port = 34500 + (os.getpid() * 5 + 2) % 2000
+    mp.spawn(_dp8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"r{k}.pt", weights_only=False) for k in range(world)]
+    full = batch_starts(n, bs, epoch, seed, True)
+    keep = full[: (len(full) // world) * world]
+    for k in range(world):
+        np.testing.assert_array_equal(r[k]["starts"], keep[k::world])
+        assert len(r[k]["starts"]) == n_batches(n, bs, world) == 2
+        torch.testing.assert_close(r[k]["reduced"], r[0]["reduced"], rtol=0, atol=0)
+    assert len(set(np.concatenate([x["starts"] for x in r]).tolist())) == 16
+    # the same 16 windows as one batch, in rank order
+    g = torch.Generator().manual_seed(0)
+    eng = VadeEngine(emu_lib(), "cpu", world * bs, 8, chain_adj(4), 4, 3)
+    eng.params.copy_(torch.randn(eng.params.shape, generator=g) * 0.2)
+    xs, as_ = torch.randn(n + bs, 8, 4, 3, generator=g), torch.randn(n + bs, 8, 3, 1, generator=g)
+    eps = torch.randn(n + bs, 4, generator=g)
+    idx = torch.cat([torch.arange(int(x["starts"][0]), int(x["starts"][0]) + bs) for x in r])
+    configure_phase(eng, 3, True, 0.2, extra=SEPARABLE)
+    eng.loss_grads(xs[idx].contiguous(), as_[idx].contiguous(), eps[idx].contiguous(), None, None, True)
+    scale = float(eng.grads.abs().max())
+    assert scale > 1e-3
+    torch.testing.assert_close(r[0]["reduced"], eng.grads, rtol=2e-5, atol=2e-6 * scale)
+    big = eng.read_logs()
+    for k in ("total_loss", "reconstruct_loss", "kl_div", "activity_l1"):
+        np.testing.assert_allclose(np.mean([x["logs"][k] for x in r]), big[k], rtol=2e-5, err_msg=k)
+
+
+class _FakeCommLib:
+    """Stand-in for the C library's dof_comm_* entries: draws an id, 'creates' a communicator, and fails where told to
+    (rank-asymmetric failures of the collective creation, the advisor's round-5 finding)."""
+
+    def __init__(self, rank, fail_id_on=None, fail_create_on=None):
+        self.rank, self.fail_id_on, self.fail_create_on = rank, fail_id_on, fail_create_on
+        self.aborted = self.destroyed = 0
+
+    def dof_comm_unique_id(self, buf):
+        if self.fail_id_on == self.rank:
+            return -2
+        buf.raw = bytes(range(128))
+        return 0
+
+    def dof_comm_create(self, buf, rank, world, handle_ref):
+        if self.fail_create_on == self.rank:
+            return -3
+        handle_ref._obj.value = 0x1234
+        return 0
+
+    def dof_comm_abort(self, h):
+        self.aborted += 1
+        return 0
+
+    def dof_comm_destroy(self, h):
+        self.destroyed += 1
+        return 0
+
+    def dof_last_error_string(self):
+        return b"stand-in failure"
+
+
+def _comm_create_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepof_amd.comm import NativeComm
+    from deepof_amd import training as TR
+    out = {}
+    for tag, kw in (("ok", {}), ("id_fails_rank0", {"fail_id_on": 0}), ("create_fails_rank1", {"fail_create_on": 1})):
+        lib = _FakeCommLib(rank, **kw)
+        try:
+            comm = NativeComm.from_process_group(lib, dist)
+            out[tag] = ("created", comm.rank)
+            comm._h = None
+        except RuntimeError as exc:
+            out[tag] = ("raised", str(exc), lib.aborted)
+        # every rank must still be able to run the SAME next collective: a mismatch here is the hang the fix removes
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out[tag + "::next"] = float(probe)
+
+    # the decision on top: a factory that fails on one rank only ends in the safe form on every rank
+    def factory():
+        lib = _FakeCommLib(rank, fail_create_on=1)
+        NativeComm.from_process_group(lib, dist)
+        return lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    out["form"] = TR._decide_dp_form(True, dist, torch.zeros(1000), factory, env={})
+    torch.save(out, os.path.join(tmp, f"comm{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_comm_creation_fails_symmetrically_gloo(tmp_path):
+    """NativeComm.from_process_group is collective: when rank 0 cannot draw the id, or ONE rank's ncclCommInitRank
+    fails, every rank raises (after the same sequence of collectives) and the ranks that did create a communicator
+    abort it; `_decide_dp_form` then takes the safe form everywhere."""
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() * 3 + 1) % 2000
+    mp.spawn(_comm_create_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"comm{k}.pt")) for k in range(2)]
+    for k in range(2):
+        assert r[k]["ok"] == ("created", k)
+        assert r[k]["id_fails_rank0"][0] == "raised" and "unique id" in r[k]["id_fails_rank0"][1]
+        assert r[k]["create_fails_rank1"][0] == "raised" and "rank(s) 1" in r[k]["create_fails_rank1"][1]
+        for tag in ("ok", "id_fails_rank0", "create_fails_rank1"):
+            assert r[k][tag + "::next"] == 3.0
+        assert r[k]["form"][:2] == (False, False) and "rank(s) 1" in r[k]["form"][2]
+    assert r[0]["create_fails_rank1"][2] == 1 and r[1]["create_fails_rank1"][2] == 0   # rank 0's communicator was aborted
+
+
 def test_dp_self_check_gloo(tmp_path):
     """Every rank reaches the same verdict; a failing native collective ends in the safe form (torch.distributed between
     two graphs), never in a dead fit."""
