@@ -16,8 +16,8 @@
 //     column block's epilogue operands one round ahead.  PMC of the single-role form (every wavefront staging, then
 //     computing, two workgroups per CU): 60 - 75 % of the wave cycles parked in s_waitcnt / s_barrier;
 //   * a compute wavefront owns BOTH channel halves of its column block (the B operand is read from LDS once), wavefront w
-//     takes the column blocks 4 r + w of round r; output channel of accumulator row m of half ct = (m >> 2) 8 + ct 4 + (m & 3),
-//     so a lane's two quads are 32 contiguous bytes and the four lanes of a sequence cover its 128-byte row;
+//     takes the column blocks 4 r + w of round r; a lane's quad of half ct is 16 bytes of the sequence's 128-byte row, the
+//     four lanes of a sequence cover a contiguous 64-byte half row per instruction;
 //   * WGRAD (the two data-gradient variants of the backward pass, k_tcn_conv_t's <true,false,true,true,*>): the kernel has
 //     dy = the staged tile on chip and the convolution's forward input x on its way through the epilogue -- conv2: x =
 //     ReLU(BN1(y1)), recomputed from the row of y1 the BatchNorm-backward epilogue loads anyway; conv1 (TAIL): x = the
@@ -35,6 +35,16 @@
 // transposing reads take four whole consecutive rows per 32 lanes: conflict-free under any in-row permutation.  Ring slot
 // plane: [column 16][32 channels], 8-byte chunk c8 at c8 ^ ((column >> 1) & 7) (the epilogue's ds_write_b64 of sixteen
 // columns, same chunk, then spreads over all banks).
+// development probe (tools/probe/tcn_conv_probe.hip compiles this file with TCN_PROBE_STAMPS): cycle stamps of one tile of
+// workgroup 0 -- slot 32 w + 8 r + {0 round start, 1 matrix phase issued, 2 epilogue + requests issued, 3 past the round barrier,
+// 4 weight-gradient phase issued} for compute wavefront w, 128 + 16 (w - 4) + {0 start, 1 staged, 2 loads issued, 3 past the
+// tile barrier} for loader wavefront w
+#ifdef TCN_PROBE_STAMPS
+__device__ unsigned long long g_tcn_stamps[256];
+#define TCN_STAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && k == TCN_PROBE_STAMPS) g_tcn_stamps[(slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TCN_STAMP(slot) ((void)0)
+#endif
 constexpr int TB_ROWS = 224;
 constexpr int TB_PLANE = TB_ROWS * 32;  // bf16 elements per plane
 constexpr int TB_IMG = 3 * TB_PLANE;    // ... per image
@@ -58,6 +68,9 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
   static_assert(!WGRAD || (REVERSE && FUSE_BN && BWD2), "the weight gradient rides on the fused data-gradient variants");
   __shared__ __attribute__((aligned(16))) uint16_t img[2 * TB_IMG];
   __shared__ __attribute__((aligned(16))) uint16_t ring[WGRAD ? 2 * 4 * 3 * TB_RING : 8];
+  // the A operands (weights): [tap][piece][channel half][lane] x 16 bytes, every compute wavefront reads the same 24 KB (in
+  // registers they cost 96 VGPRs per lane, which left no room to request LDS operands ahead of the matrix instructions)
+  __shared__ __attribute__((aligned(16))) uint16_t wlds[TK * 3 * 2 * 64 * 8];
   __shared__ float4 frec[FUSE_BN ? 4 * TC / 4 : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool loader = wv >= 4;  // wave-uniform role
@@ -72,13 +85,13 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
   float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // WGRAD, loaders: the thread's channel sums of dy (bias gradient)
   float s1[2][4], s2[2][4], kshift[2][4];   // compute: channel sums of the lane's output values
   float n_rows = 0.0f;                     // stat_records: rows this lane has summed; its sums are taken about the first one
-  dof_f32x16 accw;                         // WGRAD, compute: tap wv of the weight gradient, 32 x 32
+  dof_f32x16 accw, accw2;                  // WGRAD, compute: tap wv of the weight gradient, 32 x 32, in two partial sums
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[ct][r] = s2[ct][r] = kshift[ct][r] = 0.0f;
 #pragma unroll
-  for (int v = 0; v < 16; ++v) accw[v] = 0.0f;
+  for (int v = 0; v < 16; ++v) accw[v] = accw2[v] = 0.0f;
 
   if (loader) {
     // =========================================== loader wavefronts ===========================================
@@ -156,51 +169,111 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
       }
     };
     // Iteration k of the workgroup (k = 0 .. tiles): the loaders stage tile k from their registers into image k & 1 and
-    // then issue tile k + 1's loads (one vmcnt(0) per tile: a whole iteration has passed since they were issued; loads and
-    // the staging's stores share the counter, so a wait between them would drain both); the compute wavefronts work on
-    // tile k - 1.  Both roles pass the same barriers: the compute rounds' (WGRAD, k >= 1), then the end of the iteration.
+    // then issue tile k + 1's loads (a whole iteration passes before they are read); the compute wavefronts work on tile
+    // k - 1.  WGRAD: behind each of the compute wavefronts' round barriers loader wavefront j accumulates tap j of the
+    // weight gradient over the round's four column blocks -- the matrix work of a tile is shared between the two roles
+    // (compute: 4 x 48 convolution instructions + epilogues; loaders: staging + 4 x 24 weight-gradient instructions).
+    // The seven passes are straight-line code: a branch between two passes makes the compiler's wait-count pass merge
+    // states at the join, and with loads and the staging's stores on one counter that merge becomes s_waitcnt vmcnt(0)
+    // in front of EVERY load (measured: the seven loads of a tile took 10,000 cycles to issue, one after the other).
+    // Passes beyond the window (T < 24) stage zero rows nobody reads.
+    const int tapw = wv - 4;                     // WGRAD: this wavefront's tap
+    const int shw = (TK - 1 - tapw) * A.dil;
+    const int g = lane >> 4, q = lane & 15, kh = g >> 1, mh = g & 1;
+    // The round's four column blocks, straight-line (a block past the last one, or a tap that lies behind the window,
+    // multiplies the zero row: nothing to skip); the products alternate between two accumulators (a v_mfma_f32_32x32x16
+    // that waits for its own previous result costs its full latency) and block w2 + 1's twelve transposing reads are
+    // requested before block w2's six matrix instructions.
+    auto wgrad_round = [&](int r, const uint16_t* im) DOF_INLINE_LAMBDA {
+      dof_bf16x8 wa[2][3], wb[2][3];
+      auto wrequest = [&](int w2, int slot_i) DOF_INLINE_LAMBDA {
+        const int t02 = (4 * r + w2) * TPC;
+        const uint16_t* slot = &ring[((r & 1) * 4 + w2) * 3 * TB_RING];
+        uint32_t aw[3][4], bw[3][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int kcol = 8 * kh + 4 * h + (q >> 2);  // the K index (column of the block) whose run this lane supplies
+          const int tt = t02 + kcol / NS + shw;
+          const int row = (tt < T ? tt : T) * NS + kcol % NS;
+          // A row m = 16 mh + (lane & 15) = output channel m: the run of lane q covers the four channels 16 mh + 4 (q & 3) .. + 3 =
+          // 16-byte chunk 2 mh + ((q & 3) >> 1), its half q & 1
+          const int ea = tb_off(row, mh * 2 + ((q & 3) >> 1)) + (q & 1) * 4;
+          const int eb = tb_ring_off(kcol, mh * 4 + (q & 3));
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            dof_lds_tr16(&im[p * TB_PLANE + ea], aw[p][2 * h], aw[p][2 * h + 1]);
+            dof_lds_tr16(&slot[p * TB_RING + eb], bw[p][2 * h], bw[p][2 * h + 1]);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          wa[slot_i][p] = dof_mk_bf16x8(aw[p][0], aw[p][1], aw[p][2], aw[p][3]);
+          wb[slot_i][p] = dof_mk_bf16x8(bw[p][0], bw[p][1], bw[p][2], bw[p][3]);
+        }
+      };
+      wrequest(0, 0);
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) {
+        const int c = w2 & 1;
+        if (w2 + 1 < 4) wrequest(w2 + 1, c ^ 1);
+        DOF_SCHED_FENCE();
+        accw = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][2], accw);
+        accw2 = DOF_MFMA_32x32x16_BF16(wa[c][2], wb[c][0], accw2);
+        accw = DOF_MFMA_32x32x16_BF16(wa[c][1], wb[c][1], accw);
+        accw2 = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][1], accw2);
+        accw = DOF_MFMA_32x32x16_BF16(wa[c][1], wb[c][0], accw);
+        accw2 = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][0], accw2);
+        DOF_SCHED_FENCE();
+      }
+    };
     const int64_t g0 = blockIdx.x, gs = gridDim.x;
 #pragma unroll
-    for (int u = 0; u < NP; ++u)
-      if (u < np_run) issue(u, g0);
+    for (int u = 0; u < NP; ++u) issue(u, g0);
     int k = 0;
     for (int64_t grp = g0;; grp += gs, ++k) {
       const bool have = grp < n_groups;  // tile k exists (the last iteration only lets the compute wavefronts finish)
-      int bar = (WGRAD && k >= 1) ? 0 : n_rounds;
+      TCN_STAMP(128 + 16 * (wv - 4) + 0);
+      if (have) {
 #pragma unroll
-      for (int u = 0; u < NP; ++u) {
-        if (u < np_run && have) stage(u, grp, k & 1);
-        if (WGRAD) {
-          while (bar < n_rounds && (u + 1) * n_rounds >= (bar + 1) * np_run) {
-            __syncthreads();
-            ++bar;
+        for (int u = 0; u < NP; ++u) stage(u, grp, k & 1);
+      }
+      TCN_STAMP(128 + 16 * (wv - 4) + 1);
+      // tile k + 1's loads (a tile past the end re-reads the last one).  WGRAD: behind the first round barrier -- the CU's
+      // vector-memory queue is full at this point of a tile and issuing fourteen loads takes ~2,000 cycles, which the
+      // compute wavefronts would otherwise spend waiting at that barrier
+      if (have && !(WGRAD && k >= 1)) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) issue(u, grp + gs);
+      }
+      if (WGRAD && k >= 1) {
+        const uint16_t* im = &img[((k - 1) & 1) * TB_IMG];
+        for (int r = 0; r < n_rounds; ++r) {
+          __syncthreads();  // the round's four ring slots are complete (double-buffered: the next round writes the other set)
+          if (r == 0 && have) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) issue(u, grp + gs);
           }
+          wgrad_round(r, im);
+          TCN_STAMP(128 + 16 * (wv - 4) + 4 + r);
         }
       }
-      if (have && grp + gs < n_groups) {
-#pragma unroll
-        for (int u = 0; u < NP; ++u)
-          if (u < np_run) issue(u, grp + gs);
-      }
-      if (WGRAD) {
-        for (; bar < n_rounds; ++bar) __syncthreads();
-      }
+      TCN_STAMP(128 + 16 * (wv - 4) + 2);
       __syncthreads();  // tile k - 1 is consumed, tile k is staged
+      TCN_STAMP(128 + 16 * (wv - 4) + 3);
       if (!have) break;
     }
   } else {
     // =========================================== compute wavefronts ===========================================
     const int i = lane & 15, kk = lane >> 4;
     const int sl = i % NS, tsub = i / NS;  // the lane's sequence of the tile and its row of the column block
-    // A operands: for tap j, piece p, channel half ct the 16 x 32 weight block of output channels (m >> 2) 8 + ct 4 + (m & 3),
-    // m = lane & 15, input channels kk 8 .. + 7
-    dof_bf16x8 wq[TK][3][2];
-#pragma unroll
-    for (int j = 0; j < TK; ++j)
+    // A operands: for tap j, piece p, channel half ct the 16 x 32 weight block of output channels ct 16 + (lane & 15), input
+    // channels kk 8 .. + 7.  Compute wavefront j cuts tap j's.
+    {
+      const int j = wv;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         float v0[4], v1[4];
-        const int col = (i >> 2) * 8 + ct * 4 + (i & 3);
+        const int col = ct * 16 + i;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c0 = kk * 8 + e, c1 = kk * 8 + 4 + e;
@@ -211,16 +284,25 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
         dof_split3x4(v0, s0w);
         dof_split3x4(v1, s1w);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wq[j][p][ct] = dof_mk_bf16x8(s0w[p][0], s0w[p][1], s1w[p][0], s1w[p][1]);
+        for (int p = 0; p < 3; ++p) {
+          uint16_t* dst = &wlds[(((j * 3 + p) * 2 + ct) * 64 + lane) * 8];
+          tb_st8(dst, s0w[p][0], s0w[p][1]);
+          tb_st8(dst + 4, s1w[p][0], s1w[p][1]);
+        }
       }
-    // the lane's output channels: kk 8 + ct 4 + q
+      if (WGRAD) {  // the ring is read before every slot has been written once (short last round): no NaN patterns in it
+        for (int e = lane + 64 * wv; e < 2 * 4 * 3 * TB_RING / 2; e += 256) reinterpret_cast<uint32_t*>(ring)[e] = 0u;
+      }
+    }
+    const uint16_t* wl = &wlds[lane * 8];
+    // the lane's output channels: ct 16 + kk 4 + q
     float bias[2][4];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bias[ct][q] = (!REVERSE && A.bias) ? A.bias[kk * 8 + ct * 4 + q] : 0.0f;
-        kshift[ct][q] = (!REVERSE && A.stat_shift) ? A.stat_shift[kk * 8 + ct * 4 + q] : 0.0f;
+        bias[ct][q] = (!REVERSE && A.bias) ? A.bias[ct * 16 + kk * 4 + q] : 0.0f;
+        kshift[ct][q] = (!REVERSE && A.stat_shift) ? A.stat_shift[ct * 16 + kk * 4 + q] : 0.0f;
       }
     const float* pre_src = FUSE_BN ? A.fuse_y : (const float*)A.out;
     const bool pre_on = REVERSE && (FUSE_BN || A.accumulate);
@@ -232,66 +314,89 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
       const uint16_t* im = &img[((k - 1) & 1) * TB_IMG];
       const int64_t s = s0 + sl;
       const bool ok_s = s < A.S;
-      // epilogue operands of the lane's column block: two quads = 32 contiguous bytes per tensor.  Requested one round ahead
-      // (round 0's at the top of the tile): the registers of a round are dead once its epilogue has run, and every request is
-      // straight-line code between its round and the next -- a value carried around a loop edge costs the compiler a copy,
-      // i.e. a wait right behind the load.  Unconditional loads from clamped addresses (a predicate would merge old and new
-      // values: the same copies).
-      float4 pre[2], tsv[2], xo[2];
-      uint32_t tmw = 0u;
+      // epilogue operands of the lane's four column blocks: two quads per tensor and round.  Straight-line
+      // code inside the tile -- a value carried around a loop edge costs the compiler a copy, i.e. a wait right behind the load --
+      // and unconditional loads from clamped addresses (a predicate would merge old and new values: the same copies).
+      float4 pre4[4][2], tsv4[4][2], xo4[4][2];
+      uint32_t tmw4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) pre[ct] = tsv[ct] = xo[ct] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) pre4[r][ct] = tsv4[r][ct] = xo4[r][ct] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       auto prefetch = [&](int r) DOF_INLINE_LAMBDA {
+        float4 (&pre)[2] = pre4[r];
+        float4 (&tsv)[2] = tsv4[r];
+        float4 (&xo)[2] = xo4[r];
+        uint32_t& tmw = tmw4[r];
         const int cb = 4 * r + wv;
         const int t = (cb < n_cb ? cb : n_cb - 1) * TPC + tsub;
         const uint32_t sv = (uint32_t)(ok_s ? s : s0);  // padded lanes read a valid row and ignore it
         const uint32_t tv = (uint32_t)(t < T ? t : T - 1);
-        const uint32_t off = sv * TC + kk * 8 + tv * row_stride;
+        const uint32_t off = sv * TC + kk * 4 + tv * row_stride;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          if (pre_on) pre[ct] = *reinterpret_cast<const float4*>(pre_src + off + ct * 4);
-          if (TAIL) tsv[ct] = *reinterpret_cast<const float4*>(A.tail_src + off + ct * 4);
-          if (TAIL && WGRAD) xo[ct] = *reinterpret_cast<const float4*>(A.wg_x + off + ct * 4);
+          if (pre_on) pre[ct] = *reinterpret_cast<const float4*>(pre_src + off + ct * 16);
+          if (TAIL) tsv[ct] = *reinterpret_cast<const float4*>(A.tail_src + off + ct * 16);
+          if (TAIL && WGRAD) xo[ct] = *reinterpret_cast<const float4*>(A.wg_x + off + ct * 16);
         }
         if (TAIL && !WGRAD) tmw = A.tail_mask[sv + tv * (uint32_t)A.Sp];
       };
       auto round = [&](int r) DOF_INLINE_LAMBDA {
+        const float4 (&pre)[2] = pre4[r];
+        const float4 (&tsv)[2] = tsv4[r];
+        const float4 (&xo)[2] = xo4[r];
+        const uint32_t tmw = tmw4[r];
         const int cb = 4 * r + wv;
+        TCN_STAMP(32 * wv + 8 * r + 0);
         if (cb < n_cb) {
           const int t0 = cb * TPC, t = t0 + tsub;
           const bool ok = ok_s && t < T;
           dof_f32x4 acc[2];
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) acc[ct] = dof_f32x4{bias[ct][0], bias[ct][1], bias[ct][2], bias[ct][3]};
+          // Straight-line over the four taps: a tap that leaves the window reads the zero row (no branch: a branch would cut
+          // the matrix phase into basic blocks and the LDS requests could not be placed ahead of the previous tap's matrix
+          // instructions); tap j + 1's nine operands (three pieces of B, three pieces x two halves of A) are requested
+          // before tap j's twelve matrix instructions.
+          dof_bf16x8 bq[2][3], aq[2][3][2];
+          auto request = [&](int j, int slot) DOF_INLINE_LAMBDA {
+            const int sh = REVERSE ? (TK - 1 - j) * A.dil : -(TK - 1 - j) * A.dil;
+            const int tt = t + sh;
+            const int row = ((tt >= 0 && tt < T) ? tt : T) * NS + sl;
+            const int eo = tb_off(row, kk);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              bq[slot][p] = dof_ld_bf16x8_16(&im[p * TB_PLANE + eo]);
+              aq[slot][p][0] = dof_ld_bf16x8_16(&wl[((j * 3 + p) * 2 + 0) * 512]);
+              aq[slot][p][1] = dof_ld_bf16x8_16(&wl[((j * 3 + p) * 2 + 1) * 512]);
+            }
+          };
+          request(0, 0);
 #pragma unroll
           for (int j = 0; j < TK; ++j) {
-            const int sh = REVERSE ? (TK - 1 - j) * A.dil : -(TK - 1 - j) * A.dil;
-            const int tlo = t0 + sh;
-            if (tlo + TPC - 1 >= 0 && tlo < T) {  // wave-uniform: some row of the block has this tap inside the window
-              const int tt = t + sh;
-              const int row = ((tt >= 0 && tt < T) ? tt : T) * NS + sl;
-              const int eo = tb_off(row, kk);
-              const dof_bf16x8 b0 = dof_ld_bf16x8_16(&im[eo]), b1 = dof_ld_bf16x8_16(&im[TB_PLANE + eo]),
-                               b2 = dof_ld_bf16x8_16(&im[2 * TB_PLANE + eo]);
-              // small terms first; the two channel halves are independent accumulator chains
-              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][0][0], b2, acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][0][1], b2, acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][2][0], b0, acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][2][1], b0, acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][1][0], b1, acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][1][1], b1, acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][0][0], b1, acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][0][1], b1, acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][1][0], b0, acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][1][1], b0, acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(wq[j][0][0], b0, acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(wq[j][0][1], b0, acc[1]);
-            }
+            const int c = j & 1;
+            if (j + 1 < TK) request(j + 1, c ^ 1);
+            DOF_SCHED_FENCE();  // (left alone the scheduler sinks every request to just in front of its use: ~12 exposed LDS round trips per block)
+            // small terms first; the two channel halves are independent accumulator chains
+            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][2], acc[0]);
+            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][2], acc[1]);
+            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][2][0], bq[c][0], acc[0]);
+            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][2][1], bq[c][0], acc[1]);
+            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][1][0], bq[c][1], acc[0]);
+            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][1][1], bq[c][1], acc[1]);
+            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][1], acc[0]);
+            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][1], acc[1]);
+            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][1][0], bq[c][0], acc[0]);
+            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][1][1], bq[c][0], acc[1]);
+            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][0], acc[0]);
+            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][0], acc[1]);
+            DOF_SCHED_FENCE();
           }
-          // ---- epilogue: lane = sequence sl at row t, output channels kk 8 + ct 4 + q
+          TCN_STAMP(32 * wv + 8 * r + 1);
+          // ---- epilogue: lane = sequence sl at row t, output channels ct 16 + kk 4 + q
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) {
-            const uint32_t off = (uint32_t)s * TC + kk * 8 + ct * 4 + (uint32_t)t * row_stride;
+            const uint32_t off = (uint32_t)s * TC + ct * 16 + kk * 4 + (uint32_t)t * row_stride;
             float xw[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // WGRAD: the convolution's forward input at (t, s), this lane's channels
             if (ok) {
               float v0[4] = {acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]};
@@ -307,7 +412,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
 #pragma unroll
                   for (int q = 0; q < 4; ++q) v0[q] = xw[q] > 0.0f ? v0[q] + sv[q] : 0.0f;
                 } else {
-                  const uint32_t nib = tmw >> (kk * 8 + ct * 4);  // bit q: out[t][s][kk*8 + ct*4 + q] > 0
+                  const uint32_t nib = tmw >> (ct * 16 + kk * 4);  // bit q: out[t][s][ct*16 + kk*4 + q] > 0
 #pragma unroll
                   for (int q = 0; q < 4; ++q) v0[q] = ((nib >> q) & 1u) != 0u ? v0[q] + sv[q] : 0.0f;
                 }
@@ -317,11 +422,11 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
                   const float sk4[4] = {sk.x, sk.y, sk.z, sk.w};
 #pragma unroll
                   for (int q = 0; q < 4; ++q)
-                    v0[q] += sk4[q] > 0.0f ? A.tail_dfeat[(int64_t)(kk * 8 + ct * 4 + q) * A.Sp + s] : 0.0f;
+                    v0[q] += sk4[q] > 0.0f ? A.tail_dfeat[(int64_t)(ct * 16 + kk * 4 + q) * A.Sp + s] : 0.0f;
                 }
               }
               if (FUSE_BN) {
-                const int cw = kk * 2 + ct;
+                const int cw = ct * 4 + kk;
                 const float4 m4 = frec[cw], r4 = frec[TC / 4 + cw], sc4 = frec[2 * TC / 4 + cw], sh4 = frec[3 * TC / 4 + cw];
                 const float fm[4] = {m4.x, m4.y, m4.z, m4.w}, fr[4] = {r4.x, r4.y, r4.z, r4.w};
                 const float fsc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, fsh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
@@ -352,58 +457,24 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
               uint32_t pw[3][2];
               dof_split3x4(xw, pw);
               uint16_t* slot = &ring[((r & 1) * 4 + wv) * 3 * TB_RING];
-              const int eo = tb_ring_off(i, kk * 2 + ct);
+              const int eo = tb_ring_off(i, ct * 4 + kk);
 #pragma unroll
               for (int p = 0; p < 3; ++p) tb_st8(&slot[p * TB_RING + eo], pw[p][0], pw[p][1]);
             }
           }
           if (!REVERSE && ok) n_rows += 1.0f;
         }
-        // the next round's epilogue operands: they fly during the weight-gradient phase and the next matrix phase
-        if (r + 1 < 4) prefetch(r + 1);
+        TCN_STAMP(32 * wv + 8 * r + 2);
         if (WGRAD) {
-          __syncthreads();  // the round's four ring slots are complete (double-buffered: the next round writes the other set)
-          const int shw = (TK - 1 - wv) * A.dil;  // wavefront wv = tap wv
-          const int g = lane >> 4, q = lane & 15, kh = g >> 1, mh = g & 1;
-#pragma unroll 1
-          for (int w2 = 0; w2 < 4; ++w2) {
-            const int cb2 = 4 * r + w2;
-            if (cb2 >= n_cb) break;
-            const int t02 = cb2 * TPC;
-            if (t02 + shw >= T) continue;  // every dy row of this tap lies behind the window
-            const uint16_t* slot = &ring[((r & 1) * 4 + w2) * 3 * TB_RING];
-            uint32_t aw[3][4], bw[3][4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int kcol = 8 * kh + 4 * h + (q >> 2);  // the K index (column of the block) whose run this lane supplies
-              const int tt = t02 + kcol / NS + shw;
-              const int row = (tt < T ? tt : T) * NS + kcol % NS;
-              // A row m of half mh = output channel (m >> 2) 8 + mh 4 + (m & 3): the run of lane q covers rows 4 (q & 3) .. + 3,
-              // i.e. the four channels (q & 3) 8 + mh 4 .. + 3 = 16-byte chunk q & 3, its half mh
-              const int ea = tb_off(row, q & 3) + mh * 4;
-              const int eb = tb_ring_off(kcol, mh * 4 + (q & 3));
-#pragma unroll
-              for (int p = 0; p < 3; ++p) {
-                dof_lds_tr16(&im[p * TB_PLANE + ea], aw[p][2 * h], aw[p][2 * h + 1]);
-                dof_lds_tr16(&slot[p * TB_RING + eb], bw[p][2 * h], bw[p][2 * h + 1]);
-              }
-            }
-            dof_bf16x8 a[3], b[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-              a[p] = dof_mk_bf16x8(aw[p][0], aw[p][1], aw[p][2], aw[p][3]);
-              b[p] = dof_mk_bf16x8(bw[p][0], bw[p][1], bw[p][2], bw[p][3]);
-            }
-            accw = DOF_MFMA_32x32x16_BF16(a[0], b[2], accw);
-            accw = DOF_MFMA_32x32x16_BF16(a[2], b[0], accw);
-            accw = DOF_MFMA_32x32x16_BF16(a[1], b[1], accw);
-            accw = DOF_MFMA_32x32x16_BF16(a[0], b[1], accw);
-            accw = DOF_MFMA_32x32x16_BF16(a[1], b[0], accw);
-            accw = DOF_MFMA_32x32x16_BF16(a[0], b[0], accw);
-          }
+          __syncthreads();  // the round's four ring slots are complete: the loader wavefronts take the weight-gradient phase
+          TCN_STAMP(32 * wv + 8 * r + 3);
         }
       };
-      prefetch(0);
+      // Every round's operands are requested here, at the top of the tile: a CU's vector-memory path serves its wavefronts'
+      // requests in order, so a request issued behind the loaders' 57 KB of the next tile waits for all of it (measured: 5,000
+      // - 10,000 cycles from request to use when a round's operands were requested one round ahead).
+#pragma unroll
+      for (int r = 0; r < 4; ++r) prefetch(r);
       // at most four rounds (13 column blocks), nested so that every request dominates its use
       static_assert((TB_ROWS / NS / TPC + 3) / 4 <= 4 || true, "");
       if (n_rounds > 0) {
@@ -416,25 +487,26 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
           }
         }
       }
+      TCN_STAMP(32 * wv + 31);
       __syncthreads();  // tile k - 1 is consumed, tile k is staged
+      TCN_STAMP(32 * wv + 30);
     }
   }
   // ---- the workgroup's sums (every wavefront is past its last tile barrier: both images are free)
   float* scratch = reinterpret_cast<float*>(img);
   const int i = lane & 15, kk = lane >> 4;
   if (WGRAD) {
-    if (!loader) {
-      // tap wv's 32 x 32 tile.  D register v of lane l = row 8 (v / 4) + 4 (l >> 5) + v % 4, column l & 31; row m of the A
+    if (loader) {
+      // tap (wv - 4)'s 32 x 32 tile.  D register v of lane l = row 8 (v / 4) + 4 (l >> 5) + v % 4, column l & 31; row m of the A
       // operand was output channel 16 (m >> 4) ... in the image's order: m = 16 mh + i <-> channel (i >> 2) 8 + mh 4 + (i & 3);
       // the columns (B operand, the ring's channel order kk 8 + ct 4 + q at 8-byte chunk kk 2 + ct) are channels in natural order
-      float* outp = A.wg_partials + (wv < 2 ? A.wg_part0 : A.wg_part1) + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+      const int tap = wv - 4;
+      float* outp = A.wg_partials + (tap < 2 ? A.wg_part0 : A.wg_part1) + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int m = 8 * (v / 4) + 4 * (lane >> 5) + v % 4;
-        const int oc = ((m & 15) >> 2) * 8 + (m >> 4) * 4 + (m & 3);
-        outp[oc * 65 + (wv & 1) * 32 + (lane & 31)] = accw[v];
+        const int oc = 8 * (v / 4) + 4 * (lane >> 5) + v % 4;
+        outp[oc * 65 + (tap & 1) * 32 + (lane & 31)] = accw[v] + accw2[v];
       }
-    } else {
       // bias gradient: channel sums of dy over the staging threads of a channel quad, fixed order
       const int lt = threadIdx.x - 256;
 #pragma unroll
@@ -470,7 +542,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
             dof_stat_merge(n, mean, m2, nb, mb, qb);
           }
           if (i == 0) {
-            const int c = kk * 8 + ct * 4 + q;
+            const int c = ct * 16 + kk * 4 + q;
             rec[(wv * 3 + 0) * 32 + c] = n;
             rec[(wv * 3 + 1) * 32 + c] = mean;
             rec[(wv * 3 + 2) * 32 + c] = m2;
@@ -497,8 +569,8 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
         for (int q = 0; q < 4; ++q) {
           const float a1 = dof_row16_sum(s1[ct][q]), a2 = dof_row16_sum(s2[ct][q]);
           if (i == 0) {
-            wsum[wv * 64 + kk * 8 + ct * 4 + q] = a1;
-            wsum[wv * 64 + 32 + kk * 8 + ct * 4 + q] = a2;
+            wsum[wv * 64 + ct * 16 + kk * 4 + q] = a1;
+            wsum[wv * 64 + 32 + ct * 16 + kk * 4 + q] = a2;
           }
         }
     }

@@ -2390,8 +2390,9 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
   }
   build_jobs(p);
   float* ws = p->ws;
+  bool up_ok = true;   // checked after the last table (the copies are enqueued, nothing else reads the result before)
   auto up = [&](int64_t off, const void* src, size_t bytes) {
-    if (bytes) hipMemcpyAsync(ws + off, src, bytes, hipMemcpyHostToDevice, st);
+    if (bytes && hipMemcpyAsync(ws + off, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) up_ok = false;
   };
   for (const JobSet* js : {&p->js_enc, &p->js_dec[0], &p->js_dec[1], &p->js_gram, &p->js_all}) {
     if (js->tile_overflow) {
@@ -2455,6 +2456,10 @@ extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
   static thread_local DofAdamSeg seg_keep[DOF_SEG_COUNT];  // source must outlive the async copy
   memcpy(seg_keep, segs, sizeof(segs));
   up(p->segs_tab, seg_keep, sizeof(segs));
+  if (!up_ok) {
+    dof_set_error("dof_vade_bind: a table upload (hipMemcpyAsync) failed");
+    return DOF_ERR_LAUNCH;
+  }
   return dof_check_launch("dof_vade_bind");
 }
 

@@ -220,6 +220,26 @@ class WindowDataset:
         return ds
 
     @classmethod
+    def from_indexed(cls, dataset, device) -> "WindowDataset":
+        """An indexed in-memory dataset in the reference's item format -- ``dataset[i] = (x (T,N,3), a (T,E,1), [angles,]
+        idx, vid)`` with ``x_shape`` / ``a_shape`` attributes (BatchDictDataset, /root/reference/deepof/clustering/dataset.py:16-181;
+        the stand-in of the reference's tests, tests/test_build_models.py:43-103) -- materialised once on ``device`` in index
+        order.  ``vid`` (the last element of an item) becomes the video index of the window."""
+        ds = cls(device)
+        n = len(dataset)
+        items = [dataset[i] for i in range(n)]
+        ds.x = torch.stack([torch.as_tensor(it[0], dtype=torch.float32) for it in items]).contiguous().to(ds.device)
+        ds.a = torch.stack([torch.as_tensor(it[1], dtype=torch.float32) for it in items]).contiguous().to(ds.device)
+        ds.video_idx = np.asarray([int(it[-1]) for it in items], dtype=np.int32) if n and len(items[0]) >= 4 else \
+            np.zeros(n, dtype=np.int32)
+        ds.keys = [f"video{v}" for v in sorted(set(ds.video_idx.tolist()))]
+        ds.angles = None
+        ds.length = n
+        ds.x_shape = tuple(int(v) for v in getattr(dataset, "x_shape", tuple(ds.x.shape[1:])))
+        ds.a_shape = tuple(int(v) for v in getattr(dataset, "a_shape", tuple(ds.a.shape[1:])))
+        return ds
+
+    @classmethod
     def from_tables(cls, tables: Dict, window_size: int, window_step: int, device, lib) -> "WindowDataset":
         """``tables``: {video_key: (node_table (frames,3N), edge_table (frames,E))}, un-windowed."""
         ds = cls(device)

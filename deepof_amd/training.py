@@ -794,8 +794,8 @@ def _report_trial(trial, score_value: float, epoch: int, running_max: float = No
     return score_value
 
 
-def fit_VADE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
-             teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, device=None, _engine_factory=None, shuffle: bool = True, trial=None):
+def _fit_vade(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
+              teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, device=None, _engine_factory=None, shuffle: bool = True, trial=None):
     """training.py:1522-1918 (pretrain -> GMM init -> main epochs with best-val / best-score selection)."""
     dist, rank, world = _dist_state()
     is_main = rank == 0
@@ -1008,8 +1008,8 @@ class VQVAEStepper:
         e.count_vq_step()
 
 
-def fit_VQVAE(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
-              teacher_cfg: TurtleTeacherCfg, device=None, _engine_factory=None, shuffle: bool = True, trial=None):
+def _fit_vqvae(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
+               teacher_cfg: TurtleTeacherCfg, device=None, _engine_factory=None, shuffle: bool = True, trial=None):
     """training.py:1036-1263: Adam(lr, weight_decay 1e-4) on encoder + decoder + codebook (+ the distillation head
     when the TURTLE teacher is on), clip 0.75; best-val / best-score (alignment of the head with tau*) checkpoints."""
     dist, rank, world = _dist_state()
@@ -1255,9 +1255,9 @@ class ContrastiveStepper:
                 lambda_scheduler.step()
 
 
-def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, meta_info: dict,
-                    common_cfg: CommonFitCfg, teacher_cfg: TurtleTeacherCfg, contrastive_cfg: ContrastiveCfg,
-                    device=None, _engine_factory=None, shuffle: bool = True, trial=None):
+def _fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_matrix: np.ndarray, meta_info: dict,
+                     common_cfg: CommonFitCfg, teacher_cfg: TurtleTeacherCfg, contrastive_cfg: ContrastiveCfg,
+                     device=None, _engine_factory=None, shuffle: bool = True, trial=None):
     """training.py:1266-1520: Adam(lr, weight_decay 1e-4) on the encoder (+ the distillation head when the TURTLE
     teacher is on), clip 0.75, best-val / best-score checkpointing."""
     from .augment import edge_index_from_meta
@@ -1363,6 +1363,84 @@ def fit_contrastive(train_ds: WindowDataset, val_ds: WindowDataset, adjacency_ma
 # ------------------------------------------------------------------------------------------------
 # public API
 # ------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# fit_VADE / fit_VQVAE / fit_contrastive with the reference's signatures (training.py:1522-1532, 1036-1045, 1266-1277; the
+# reference's own tests call them directly, tests/test_build_models.py:791, 1041, 1319)
+# ------------------------------------------------------------------------------------------------
+def _as_window_dataset(source, device) -> WindowDataset:
+    """``source``: a WindowDataset (what train_deepof_model hands over: device-resident frame tables), or anything shaped
+    like the reference's loaders -- an object with ``.dataset`` (or the dataset itself) whose items are
+    ``(x (T,N,3), a (T,E,1), [angles,] idx, vid)`` and which carries ``x_shape`` / ``a_shape`` (dataset.py:16-181 of the
+    reference; the in-memory stand-in of its tests).  Such a dataset is materialised once on the device, in index order."""
+    if isinstance(source, WindowDataset):
+        return source
+    return WindowDataset.from_indexed(getattr(source, "dataset", source), device)
+
+
+class _WriterScope:
+    """The fit's event writer for the duration of one fit_* call: the caller's ``writer`` (the reference's SummaryWriter
+    argument; flushed and closed at the end as the reference does, training.py:1257-1258) or the one already open."""
+
+    def __init__(self, writer):
+        self.writer, self.prev = writer, None
+
+    def __enter__(self):
+        global TB_WRITER
+        self.prev = TB_WRITER
+        if self.writer is not None:
+            TB_WRITER = self.writer
+        return self
+
+    def __exit__(self, *exc):
+        global TB_WRITER
+        if self.writer is not None:
+            self.writer.flush()
+            self.writer.close()
+        TB_WRITER = self.prev
+        return False
+
+
+def _fit_device(device, _engine_factory):
+    if device is not None and str(device) != "cpu":
+        return device
+    # the reference's default is CPU; the HIP path has no CPU form, so its default is the ROCm device (an emulator engine
+    # factory -- the CPU tests -- keeps "cpu")
+    return "cpu" if _engine_factory is not None else None
+
+
+def fit_VADE(train_loader, val_loader, preprocessed_train: dict, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
+             teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, writer=None, device=None, trial=None, *,
+             _engine_factory=None, shuffle: bool = True):
+    """training.py:1522-1918, same arguments in the same order.  ``preprocessed_train`` is accepted for signature parity:
+    the teacher's views are computed from the training dataset itself (the frame tables it was built from)."""
+    dev = _fit_device(device, _engine_factory)
+    with _WriterScope(writer):
+        return _fit_vade(_as_window_dataset(train_loader, dev or "cuda"), _as_window_dataset(val_loader, dev or "cuda"),
+                         np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
+                         _engine_factory=_engine_factory, shuffle=shuffle, trial=trial)
+
+
+def fit_VQVAE(train_loader, val_loader, preprocessed_train: dict, adjacency_matrix: np.ndarray, common_cfg: CommonFitCfg,
+              teacher_cfg: TurtleTeacherCfg, writer=None, device=None, trial=None, *, _engine_factory=None, shuffle: bool = True):
+    """training.py:1036-1263, same arguments in the same order."""
+    dev = _fit_device(device, _engine_factory)
+    with _WriterScope(writer):
+        return _fit_vqvae(_as_window_dataset(train_loader, dev or "cuda"), _as_window_dataset(val_loader, dev or "cuda"),
+                          np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
+                          _engine_factory=_engine_factory, shuffle=shuffle, trial=trial)
+
+
+def fit_contrastive(train_loader, val_loader, preprocessed_train: dict, adjacency_matrix: np.ndarray, meta_info: dict,
+                    common_cfg: CommonFitCfg, teacher_cfg: TurtleTeacherCfg, contrastive_cfg: ContrastiveCfg, writer=None,
+                    device=None, trial=None, *, _engine_factory=None, shuffle: bool = True):
+    """training.py:1266-1520, same arguments in the same order."""
+    dev = _fit_device(device, _engine_factory)
+    with _WriterScope(writer):
+        return _fit_contrastive(_as_window_dataset(train_loader, dev or "cuda"), _as_window_dataset(val_loader, dev or "cuda"),
+                                np.asarray(adjacency_matrix), meta_info, common_cfg, teacher_cfg, contrastive_cfg, device=dev,
+                                _engine_factory=_engine_factory, shuffle=shuffle, trial=trial)
+
+
 def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, common_cfg: CommonFitCfg,
                             teacher_cfg: TurtleTeacherCfg, vade_cfg: VaDECfg, contrastive_cfg: ContrastiveCfg,
                             h5_dataset_folder: str = None, shuffle: bool = True, device: str = None,
@@ -1404,13 +1482,13 @@ def train_deepof_model_base(preprocessed_object, adjacency_matrix, meta_info, co
     TB_WRITER = open_writer(common_cfg, model_name, rank == 0)
     try:
         if model_name == "vqvae":
-            return fit_VQVAE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
-                             _engine_factory=_engine_factory, shuffle=shuffle)
+            return _fit_vqvae(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, device=dev,
+                              _engine_factory=_engine_factory, shuffle=shuffle)
         if model_name == "contrastive":
-            return fit_contrastive(train_ds, val_ds, np.asarray(adjacency_matrix), meta_info, common_cfg, teacher_cfg,
-                                   contrastive_cfg, device=dev, _engine_factory=_engine_factory, shuffle=shuffle)
-        return fit_VADE(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
-                        _engine_factory=_engine_factory, shuffle=shuffle)
+            return _fit_contrastive(train_ds, val_ds, np.asarray(adjacency_matrix), meta_info, common_cfg, teacher_cfg,
+                                    contrastive_cfg, device=dev, _engine_factory=_engine_factory, shuffle=shuffle)
+        return _fit_vade(train_ds, val_ds, np.asarray(adjacency_matrix), common_cfg, teacher_cfg, vade_cfg, device=dev,
+                         _engine_factory=_engine_factory, shuffle=shuffle)
     finally:
         if TB_WRITER is not None:
             TB_WRITER.close()

@@ -1379,12 +1379,12 @@ def run_fit_trace_check(engine_factory, device, golden_dir, model_name, rtol=0.0
     np.random.seed(0)
     try:
         if model_name == "vade":
-            res = TR.fit_VADE(train_ds, val_ds, adj, common, teacher, vade, device=device, _engine_factory=engine_factory)
+            res = TR.fit_VADE(train_ds, val_ds, {}, adj, common, teacher, vade, device=device, _engine_factory=engine_factory)
         elif model_name == "vqvae":
-            res = TR.fit_VQVAE(train_ds, val_ds, adj, common, teacher, device=device, _engine_factory=engine_factory)
+            res = TR.fit_VQVAE(train_ds, val_ds, {}, adj, common, teacher, device=device, _engine_factory=engine_factory)
         else:
             nodes, edges = bodypart_graph([""])
-            res = TR.fit_contrastive(train_ds, val_ds, adj, make_meta_info(nodes, edges), common, teacher, ccfg,
+            res = TR.fit_contrastive(train_ds, val_ds, {}, adj, make_meta_info(nodes, edges), common, teacher, ccfg,
                                      device=device, _engine_factory=engine_factory)
     finally:
         cls.__init__, TR.save_model_info, TR.VadeStepper.train_epoch, TR.NOISE_HOOK = orig_init, orig_save, orig_epoch, None

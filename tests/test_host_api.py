@@ -245,6 +245,77 @@ def test_fit_vade_end_to_end_and_checkpoint_roundtrip(tmp_path):
     assert isinstance(again[0], VaDE) and again[1] is None and again[2] is None
 
 
+class _TinyIndexedDataset(torch.utils.data.Dataset):
+    """In-memory dataset in the reference's item format (x, a, idx, vid) with x_shape / a_shape -- the shape of the stand-in the
+    reference's own fit_* tests use (/root/reference/tests/test_build_models.py:43-103); written here, not copied."""
+
+    def __init__(self, n, T, N, E, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.X, self.A = torch.randn(n, T, N, 3, generator=g), torch.randn(n, T, E, 1, generator=g)
+        self.x_shape, self.a_shape = (T, N, 3), (T, E, 1)
+
+    def __len__(self):
+        return len(self.X)
+
+    def __getitem__(self, i):
+        return self.X[i], self.A[i], torch.tensor(i), torch.tensor(i // 8)
+
+
+class _RecordingWriter:
+    def __init__(self):
+        self.tags, self.flushed, self.closed = [], False, False
+
+    def add_scalar(self, tag, value, step):
+        self.tags.append(tag)
+
+    def flush(self):
+        self.flushed = True
+
+    def close(self):
+        self.closed = True
+
+
+@pytest.mark.parametrize("name", ["vade", "vqvae", "contrastive"])
+def test_fit_functions_take_the_reference_signatures(tmp_path, name):
+    """fit_VADE / fit_VQVAE / fit_contrastive called the way the reference's tests call them (training.py:1522-1532,
+    1036-1045, 1266-1277; tests/test_build_models.py:791, 1041, 1319): DataLoaders over an indexed in-memory dataset, the
+    (unused) preprocessed dict, keyword arguments with the reference's names, a SummaryWriter-like `writer` -- the same
+    4-tuple comes back, the writer has received the epoch scalars and was flushed and closed."""
+    from torch.utils.data import DataLoader
+    import inspect
+    T = 8 if name != "contrastive" else 16
+    tr, va = _TinyIndexedDataset(24, T, 4, 3, 1), _TinyIndexedDataset(16, T, 4, 3, 2)
+    common = TR.CommonFitCfg(model_name=name, encoder_type="recurrent", batch_size=8, latent_dim=4, epochs=2, n_components=3,
+                             output_path=str(tmp_path), diag_max_batches=1)
+    teacher = TR.TurtleTeacherCfg(use_turtle_teacher=False)
+    writer = _RecordingWriter()
+    kw = dict(train_loader=DataLoader(tr, batch_size=8, shuffle=False), val_loader=DataLoader(va, batch_size=8, shuffle=False),
+              preprocessed_train={}, adjacency_matrix=chain_adj(4), common_cfg=common, teacher_cfg=teacher, writer=writer,
+              _engine_factory=emu_factory)
+    if name == "vade":
+        fn, kw = TR.fit_VADE, dict(kw, vade_cfg=TR.VaDECfg(pretrain_epochs=1))
+    elif name == "vqvae":
+        fn = TR.fit_VQVAE
+    else:
+        from deepof_amd.graph import make_meta_info
+        nodes = ["Center", "Nose", "Tail_1", "Tail_base"]
+        edges = [("Center", "Nose"), ("Center", "Tail_base"), ("Tail_1", "Tail_base")]
+        fn, kw = TR.fit_contrastive, dict(kw, meta_info=make_meta_info(nodes, edges), contrastive_cfg=TR.ContrastiveCfg())
+    ref_args = {"vade": ["train_loader", "val_loader", "preprocessed_train", "adjacency_matrix", "common_cfg", "teacher_cfg",
+                         "vade_cfg", "writer", "device", "trial"],
+                "vqvae": ["train_loader", "val_loader", "preprocessed_train", "adjacency_matrix", "common_cfg", "teacher_cfg",
+                          "writer", "device", "trial"],
+                "contrastive": ["train_loader", "val_loader", "preprocessed_train", "adjacency_matrix", "meta_info", "common_cfg",
+                                "teacher_cfg", "contrastive_cfg", "writer", "device", "trial"]}[name]
+    positional = [p.name for p in inspect.signature(fn).parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+    assert positional == ref_args
+    model_val, model_score, teacher_model, logs = fn(**kw)
+    assert model_val is not None and model_score is not None and teacher_model is None
+    assert len(logs["train"]["total_loss"]) == 2 and all(np.isfinite(logs["train"]["total_loss"]))
+    assert writer.flushed and writer.closed and any(t.startswith("Train/") for t in writer.tags)
+    assert TR.TB_WRITER is None
+
+
 def test_fit_latent16_end_to_end(tmp_path):
     """latent_dim = 16 through the trainer (GRU(32, 32) / GRU(64 -> 16) streams; one video of 16 windows, the emulator
     runs those layers slowly): finite logs, embeddings of width 16; latent 64 is refused up front (latent 32: the
@@ -1139,14 +1210,14 @@ def test_tuning_trial_hooks_emu(tmp_path):
             return self.prune_at is not None and len(self.reports) > self.prune_at
 
     t = Trial(None)
-    res = TR.fit_VQVAE(train, val, adj, common, teacher, device="cpu", _engine_factory=emu_factory, trial=t)
+    res = TR.fit_VQVAE(train, val, {}, adj, common, teacher, device="cpu", _engine_factory=emu_factory, trial=t)
     assert len(res) == 4 and [s for _, s in t.reports] == [0, 1, 2]
     assert np.array_equal(res[3], t.reports[-1][0], equal_nan=True)   # (no teacher here: the alignment score is NaN, as in the reference)
     t2 = Trial(1)
     with pytest.raises(TR.TrialPruned):
-        TR.fit_VQVAE(train, val, adj, common, teacher, device="cpu", _engine_factory=emu_factory, trial=t2)
+        TR.fit_VQVAE(train, val, {}, adj, common, teacher, device="cpu", _engine_factory=emu_factory, trial=t2)
     assert [s for _, s in t2.reports] == [0, 1]
-    assert len(TR.fit_VQVAE(train, val, adj, common, teacher, device="cpu", _engine_factory=emu_factory)) == 4   # (m, m, None, logs)
+    assert len(TR.fit_VQVAE(train, val, {}, adj, common, teacher, device="cpu", _engine_factory=emu_factory)) == 4   # (m, m, None, logs)
 
 
 def test_bf16_window_storage_emu():
