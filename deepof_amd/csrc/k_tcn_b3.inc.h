@@ -317,17 +317,31 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
       // epilogue operands of the lane's four column blocks: two quads per tensor and round.  Straight-line
       // code inside the tile -- a value carried around a loop edge costs the compiler a copy, i.e. a wait right behind the load --
       // and unconditional loads from clamped addresses (a predicate would merge old and new values: the same copies).
-      float4 pre4[4][2], tsv4[4][2], xo4[4][2];
-      uint32_t tmw4[4] = {0u, 0u, 0u, 0u};
+      // TAIL: the wavefront whose column block holds the last time step also needs that row of the skip sum and the feature
+      // gradient of its sequences
+      float4 skl[2];
+      float dfe[2][4];
+      const bool own_last = TAIL && A.tail_dfeat != nullptr && wv == ((n_cb - 1) & 3);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int ct = 0; ct < 2; ++ct) {
+        skl[ct] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dfe[ct][q] = 0.0f;
+      }
+      constexpr int PD = (TAIL && WGRAD) ? 3 : 4;   // rounds requested ahead (three tensors x four rounds do not fit the registers)
+      float4 pre4[PD][2], tsv4[PD][2], xo4[PD][2];
+      uint32_t tmw4[PD];
+#pragma unroll
+      for (int r = 0; r < PD; ++r) {
+        tmw4[r] = 0u;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) pre4[r][ct] = tsv4[r][ct] = xo4[r][ct] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
       auto prefetch = [&](int r) DOF_INLINE_LAMBDA {
-        float4 (&pre)[2] = pre4[r];
-        float4 (&tsv)[2] = tsv4[r];
-        float4 (&xo)[2] = xo4[r];
-        uint32_t& tmw = tmw4[r];
+        float4 (&pre)[2] = pre4[r % PD];
+        float4 (&tsv)[2] = tsv4[r % PD];
+        float4 (&xo)[2] = xo4[r % PD];
+        uint32_t& tmw = tmw4[r % PD];
         const int cb = 4 * r + wv;
         const int t = (cb < n_cb ? cb : n_cb - 1) * TPC + tsub;
         const uint32_t sv = (uint32_t)(ok_s ? s : s0);  // padded lanes read a valid row and ignore it
@@ -342,10 +356,10 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
         if (TAIL && !WGRAD) tmw = A.tail_mask[sv + tv * (uint32_t)A.Sp];
       };
       auto round = [&](int r) DOF_INLINE_LAMBDA {
-        const float4 (&pre)[2] = pre4[r];
-        const float4 (&tsv)[2] = tsv4[r];
-        const float4 (&xo)[2] = xo4[r];
-        const uint32_t tmw = tmw4[r];
+        const float4 (&pre)[2] = pre4[r % PD];
+        const float4 (&tsv)[2] = tsv4[r % PD];
+        const float4 (&xo)[2] = xo4[r % PD];
+        const uint32_t tmw = tmw4[r % PD];
         const int cb = 4 * r + wv;
         TCN_STAMP(32 * wv + 8 * r + 0);
         if (cb < n_cb) {
@@ -354,10 +368,10 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
           dof_f32x4 acc[2];
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) acc[ct] = dof_f32x4{bias[ct][0], bias[ct][1], bias[ct][2], bias[ct][3]};
-          // Straight-line over the four taps: a tap that leaves the window reads the zero row (no branch: a branch would cut
-          // the matrix phase into basic blocks and the LDS requests could not be placed ahead of the previous tap's matrix
-          // instructions); tap j + 1's nine operands (three pieces of B, three pieces x two halves of A) are requested
-          // before tap j's twelve matrix instructions.
+          // Straight-line over the taps: a lane whose row leaves the window under a tap reads the zero row (no branch inside:
+          // a branch would cut the matrix phase into basic blocks and the LDS requests could not be placed ahead of the
+          // previous tap's matrix instructions); tap j + 1's nine operands (three pieces of B, three pieces x two halves of A)
+          // are requested before tap j's twelve matrix instructions.
           dof_bf16x8 bq[2][3], aq[2][3][2];
           auto request = [&](int j, int slot) DOF_INLINE_LAMBDA {
             const int sh = REVERSE ? (TK - 1 - j) * A.dil : -(TK - 1 - j) * A.dil;
@@ -371,26 +385,40 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
               aq[slot][p][1] = dof_ld_bf16x8_16(&wl[((j * 3 + p) * 2 + 1) * 512]);
             }
           };
-          request(0, 0);
+          // the taps that reach into the window for some row of the block are the last NT ones (wave-uniform); one
+          // straight-line instance per count (a dilation-8 block of a 25-step window has 2.1 of 4 on average)
+          auto taps = [&](auto ntc) DOF_INLINE_LAMBDA {
+            constexpr int NT = decltype(ntc)::value;
+            request(TK - NT, 0);
 #pragma unroll
-          for (int j = 0; j < TK; ++j) {
-            const int c = j & 1;
-            if (j + 1 < TK) request(j + 1, c ^ 1);
-            DOF_SCHED_FENCE();  // (left alone the scheduler sinks every request to just in front of its use: ~12 exposed LDS round trips per block)
-            // small terms first; the two channel halves are independent accumulator chains
-            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][2], acc[0]);
-            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][2], acc[1]);
-            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][2][0], bq[c][0], acc[0]);
-            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][2][1], bq[c][0], acc[1]);
-            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][1][0], bq[c][1], acc[0]);
-            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][1][1], bq[c][1], acc[1]);
-            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][1], acc[0]);
-            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][1], acc[1]);
-            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][1][0], bq[c][0], acc[0]);
-            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][1][1], bq[c][0], acc[1]);
-            acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][0], acc[0]);
-            acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][0], acc[1]);
-            DOF_SCHED_FENCE();
+            for (int jj = 0; jj < NT; ++jj) {
+              const int c = jj & 1;
+              if (jj + 1 < NT) request(TK - NT + jj + 1, c ^ 1);
+              DOF_SCHED_FENCE();  // (left alone the scheduler sinks every request to just in front of its use: ~12 exposed LDS round trips per block)
+              // small terms first; the two channel halves are independent accumulator chains
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][2], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][2], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][2][0], bq[c][0], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][2][1], bq[c][0], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][1][0], bq[c][1], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][1][1], bq[c][1], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][1], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][1], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][1][0], bq[c][0], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][1][1], bq[c][0], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][0], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][0], acc[1]);
+              DOF_SCHED_FENCE();
+            }
+          };
+          // REVERSE: tap j reads row t + (3 - j) d: inside for the block's first row iff (3 - j) d < T - t0;
+          // forward: row t - (3 - j) d: inside for the block's last row iff (3 - j) d <= t0 + TPC - 1
+          const int reach = REVERSE ? (T - t0 + A.dil - 1) / A.dil : (t0 + TPC - 1) / A.dil + 1;
+          switch (reach < TK ? reach : TK) {
+            case 1: taps(std::integral_constant<int, 1>{}); break;
+            case 2: taps(std::integral_constant<int, 2>{}); break;
+            case 3: taps(std::integral_constant<int, 3>{}); break;
+            default: taps(std::integral_constant<int, 4>{}); break;
           }
           TCN_STAMP(32 * wv + 8 * r + 1);
           // ---- epilogue: lane = sequence sl at row t, output channels ct 16 + kk 4 + q
@@ -417,12 +445,10 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
                   for (int q = 0; q < 4; ++q) v0[q] = ((nib >> q) & 1u) != 0u ? v0[q] + sv[q] : 0.0f;
                 }
                 *reinterpret_cast<float4*>(A.tail_gres + off) = make_float4(v0[0], v0[1], v0[2], v0[3]);
-                if (A.tail_dfeat && t == T - 1) {
-                  const float4 sk = *reinterpret_cast<const float4*>(A.tail_skip + off);
-                  const float sk4[4] = {sk.x, sk.y, sk.z, sk.w};
+                if (own_last && t == T - 1) {   // (requested at the top of the tile: a load here would be waited for on the spot)
+                  const float sk4[4] = {skl[ct].x, skl[ct].y, skl[ct].z, skl[ct].w};
 #pragma unroll
-                  for (int q = 0; q < 4; ++q)
-                    v0[q] += sk4[q] > 0.0f ? A.tail_dfeat[(int64_t)(ct * 16 + kk * 4 + q) * A.Sp + s] : 0.0f;
+                  for (int q = 0; q < 4; ++q) v0[q] += sk4[q] > 0.0f ? dfe[ct][q] : 0.0f;
                 }
               }
               if (FUSE_BN) {
@@ -465,6 +491,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
           if (!REVERSE && ok) n_rows += 1.0f;
         }
         TCN_STAMP(32 * wv + 8 * r + 2);
+        if (r + PD < 4) prefetch(r + PD);   // (this round's registers are free)
         if (WGRAD) {
           __syncthreads();  // the round's four ring slots are complete: the loader wavefronts take the weight-gradient phase
           TCN_STAMP(32 * wv + 8 * r + 3);
@@ -474,7 +501,17 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
       // requests in order, so a request issued behind the loaders' 57 KB of the next tile waits for all of it (measured: 5,000
       // - 10,000 cycles from request to use when a round's operands were requested one round ahead).
 #pragma unroll
-      for (int r = 0; r < 4; ++r) prefetch(r);
+      for (int r = 0; r < PD; ++r) prefetch(r);
+      if (TAIL && own_last) {
+        const uint32_t sv = (uint32_t)(ok_s ? s : s0);
+        const uint32_t off = sv * TC + kk * 4 + (uint32_t)(T - 1) * row_stride;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          skl[ct] = *reinterpret_cast<const float4*>(A.tail_skip + off + ct * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dfe[ct][q] = A.tail_dfeat[(int64_t)(ct * 16 + kk * 4 + q) * A.Sp + sv];
+        }
+      }
       // at most four rounds (13 column blocks), nested so that every request dominates its use
       static_assert((TB_ROWS / NS / TPC + 3) / 4 <= 4 || true, "");
       if (n_rounds > 0) {

@@ -35,8 +35,9 @@ static void stamps(const char* tag, bool wgrad) {
            (long long)(h[128 + 16 * w + 1] - t0), (long long)(h[128 + 16 * w + 2] - t0), (long long)(h[128 + 16 * w + 3] - t0));
 }
 
-int main() {
-  const int T = 25, dil = 2;
+int main(int argc, char** argv) {
+  const int T = 25, dil = argc > 1 ? atoi(argv[1]) : 2;
+  printf("dilation %d\n", dil);
   const int64_t S = 8192 * 14, Sp = S;
   const size_t n = (size_t)T * Sp * 32;
   float *in, *y, *out, *out2, *src, *xprev, *w, *bias, *bnp, *coef, *partial, *wgp;
