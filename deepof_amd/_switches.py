@@ -22,6 +22,11 @@ LIBRARY_SWITCHES = {
                              "test_tcn_kernel_switches_gpu, test_tcn_record_statistics_vs_two_pass_gpu"),
     "DOF_TCN_WGRAD_IN": ("1", "0", "the first block's weight gradients on the staged kernel instead of the direct-load one",
                          "test_tcn_kernel_switches_gpu"),
+    "DOF_TCN_CONV_B3": ("1", "0", "the time-resident TCN convolutions on round 5's fp32-MFMA kernels (k_tcn_conv_t, three workgroups per CU) "
+                        "instead of the bf16-piece loader / compute kernel k_tcn_conv_b; also switches the fused weight gradient off",
+                        "test_tcn_kernel_switches_gpu"),
+    "DOF_TCN_WGRAD_FUSED": ("1", "0", "the 32-channel convolutions' weight gradients from k_tcn_wgrad_b3 (its own passes over dy, y and the "
+                            "convolution input) instead of k_tcn_conv_b's data-gradient launches", "test_tcn_kernel_switches_gpu"),
     "DOF_TCN_RESIDENT_MAX_T": ("50", "25", "longest window on the time-resident convolutions (longer windows take the 4-fetch path, "
                                "as windows > 50 always do)", "test_tcn_kernel_switches_gpu"),
 }
