@@ -300,6 +300,10 @@ def secondary_configs(steps=12, warmup=6):
              lambda: run_vade_product([""], 25, 10, 1024, "transformer", steps, warmup), 1024),
             ("C2 with bf16 window storage (BASELINE configs[1]: batches gathered as bf16, fp32 arithmetic), batch 1024",
              lambda: run_vade_product([""], 25, 10, 1024, "recurrent", 4 * steps, warmup, window_storage="bf16"), 1024),
+            ("C2 at latent 4 (the API's default latent_dim; GRU(8,8) / GRU(16->4) layers on the lane-per-unit kernels k_gru3_*), batch 1024",
+             lambda: run_vade_product([""], 25, 10, 1024, "recurrent", steps, warmup, latent=4), 1024),
+            ("C2 at latent 6 (the tutorial's latent_dim; GRU(12,12) / GRU(24->6) layers, k_gru3_* on padded lane groups), batch 1024",
+             lambda: run_vade_product([""], 25, 10, 1024, "recurrent", steps, warmup, latent=6), 1024),
             ("C2 at latent 16 (GRU(32,32) / GRU(64->16) layers on the GEMM-shaped matrix-pipe kernels k_grum_*), batch 1024",
              lambda: run_vade_product([""], 25, 10, 1024, "recurrent", steps, warmup, latent=16), 1024),
             ("C2 at latent 32 (GRU(64,64) / GRU(128->32) layers, k_grum_*), batch 1024",

@@ -794,8 +794,15 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(Gru8Args A0, Gru8Args A1, int 
               *__restrict__ bih1 = AA.bih1, *__restrict__ bhh1 = AA.bhh1;
   float *__restrict__ O = AA.Oout, *__restrict__ GS = AA.GSout;
   const int64_t S = AA.S, Sp = AA.Sp;
-  constexpr int G = HID;
-  const int u = threadIdx.x % G;
+  // Round 6: hidden sizes that are not a DPP group width (4, 5, 6, 10, 12: latent 4 / 5 / 6) take the next one -- 8 or 16
+  // lanes per (sequence, direction), the lanes u >= HID idle: zero weights, a hidden value that stays zero, no stores.
+  // (The thread-per-sequence kernels these sizes ran before are pure latency at C2's 28,672 sequences: 155 / 199 us for a
+  // GRU(8 -> 8) forward / backward launch, profiles/r06_latent4_kernel_stats_before.md.)
+  constexpr int G = HID <= 8 ? 8 : 16;
+  static_assert(HID <= 16, "lane-per-unit recurrence: at most 16 hidden units");
+  const int ul = threadIdx.x % G;
+  const bool unit = ul < HID;
+  const int u = unit ? ul : 0;   // idle lanes address unit 0 and multiply by zero
   const int64_t s = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
   const int dir = blockIdx.y;
   if (s >= S) return;  // whole groups leave together
@@ -803,21 +810,22 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(Gru8Args A0, Gru8Args A1, int 
   const float* __restrict__ whh = dir ? whh1 : whh0;
   const float* __restrict__ bih = dir ? bih1 : bih0;
   const float* __restrict__ bhh = dir ? bhh1 : bhh0;
+  const float live_w = unit ? 1.0f : 0.0f;
   float wr[IN], wz[IN], wn[IN], hr[HID], hz[HID], hnw[HID];
 #pragma unroll
   for (int k = 0; k < IN; ++k) {
-    wr[k] = wih[u * IN + k];
-    wz[k] = wih[(HID + u) * IN + k];
-    wn[k] = wih[(2 * HID + u) * IN + k];
+    wr[k] = wih[u * IN + k] * live_w;
+    wz[k] = wih[(HID + u) * IN + k] * live_w;
+    wn[k] = wih[(2 * HID + u) * IN + k] * live_w;
   }
 #pragma unroll
   for (int k = 0; k < HID; ++k) {
-    hr[k] = whh[u * HID + k];
-    hz[k] = whh[(HID + u) * HID + k];
-    hnw[k] = whh[(2 * HID + u) * HID + k];
+    hr[k] = whh[u * HID + k] * live_w;
+    hz[k] = whh[(HID + u) * HID + k] * live_w;
+    hnw[k] = whh[(2 * HID + u) * HID + k] * live_w;
   }
-  float br = bih[u] + bhh[u], bz = bih[HID + u] + bhh[HID + u], bin = bih[2 * HID + u];
-  const float bhn = bhh[2 * HID + u];
+  float br = (bih[u] + bhh[u]) * live_w, bz = (bih[HID + u] + bhh[HID + u]) * live_w, bin = bih[2 * HID + u] * live_w;
+  const float bhn = bhh[2 * HID + u] * live_w;
   if (BCAST) {  // input constant over time: fold W_ih x into the biases once
 #pragma unroll
     for (int k = 0; k < IN; ++k) {
@@ -842,7 +850,7 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(Gru8Args A0, Gru8Args A1, int 
     if (!BCAST && step < n) {
       const int t = dir ? (n - 1 - step) : step;
       if constexpr (WIDE) dof_ld_row<IN>(X + ACT(t, 0, IN, Sp, s), xrow_next);
-      else xu_next = X[ACT(t, u, IN, Sp, s)];
+      else xu_next = X[ACT(t, u, IN, Sp, s)];   // (IN == G here: every lane is a unit)
     }
   };
   auto input_half = [&]() {  // gates' input half from the x held in xu_next / xrow_next
@@ -883,13 +891,16 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(Gru8Args A0, Gru8Args A1, int 
     const float r = dof_sigmoid(ar);
     const float z = dof_sigmoid(az);
     const float nn = dof_tanh(fmaf(r, ahn, an));
-    h = fmaf(z, h - nn, nn);
-    O[ACT(t, dir * HID + u, 2 * HID, Sp, s)] = h;
-    if (gs) {  // unit-major gate buffer: (r, z, n, W_hn h + b_hn) of unit u are one 16-byte word
-      const float gate4[4] = {r, z, nn, ahn};
-      dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), gate4);
+    h = unit ? fmaf(z, h - nn, nn) : 0.0f;   // (an idle lane: sigmoid(0) h = h / 2 would stay 0 anyway; made explicit)
+    if (unit) {
+      O[ACT(t, dir * HID + u, 2 * HID, Sp, s)] = h;
+      if (gs) {  // unit-major gate buffer: (r, z, n, W_hn h + b_hn) of unit u are one 16-byte word
+        const float gate4[4] = {r, z, nn, ahn};
+        dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), gate4);
+      }
     }
   }
+  if (!unit) return;
   for (int t = n; t < T; ++t) {
     O[ACT(t, dir * HID + u, 2 * HID, Sp, s)] = 0.0f;
     if (gs) {
@@ -910,34 +921,42 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
                                                   float* __restrict__ GS, const float* __restrict__ dO,
                                                   const float* __restrict__ dHfin, float* __restrict__ dX, int T,
                                                   int64_t S, int64_t Sp) {
-  constexpr int G = HID;
-  constexpr int M = IN / G;  // input columns handled by this lane: u, u+G, ...
-  static_assert(IN % G == 0, "input width must be a multiple of the group width");
-  const int u = threadIdx.x % G;
+  // (round 6: padded lane groups, see k_gru3_fwd -- lanes u >= HID hold zero gate gradients; a lane owns the input columns
+  //  M u .. M u + M - 1 that exist)
+  constexpr int G = HID <= 8 ? 8 : 16;
+  constexpr int M = (IN + G - 1) / G;
+  static_assert(HID <= 16, "lane-per-unit recurrence: at most 16 hidden units");
+  const int ul = threadIdx.x % G;
+  const bool unit = ul < HID;
+  const int u = unit ? ul : 0;
   const int64_t s = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
   const int dir = blockIdx.y;
   if (s >= S) return;
   const float* __restrict__ wih = dir ? wih1 : wih0;
   const float* __restrict__ whh = dir ? whh1 : whh0;
-  // transposed views: column u of W_hh, columns u + m*G of W_ih
+  // transposed views: column u of W_hh, columns M ul + m of W_ih
   float tr[HID], tz[HID], tn[HID];
   float xr[M][HID], xz[M][HID], xn[M][HID];
+  bool col[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) col[m] = M * ul + m < IN;
 #pragma unroll
   for (int j = 0; j < HID; ++j) {
-    tr[j] = whh[j * HID + u];
-    tz[j] = whh[(HID + j) * HID + u];
-    tn[j] = whh[(2 * HID + j) * HID + u];
+    tr[j] = unit ? whh[j * HID + u] : 0.0f;
+    tz[j] = unit ? whh[(HID + j) * HID + u] : 0.0f;
+    tn[j] = unit ? whh[(2 * HID + j) * HID + u] : 0.0f;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      xr[m][j] = wih[j * IN + M * u + m];
-      xz[m][j] = wih[(HID + j) * IN + M * u + m];
-      xn[m][j] = wih[(2 * HID + j) * IN + M * u + m];
+      const int c = col[m] ? M * ul + m : 0;
+      xr[m][j] = col[m] ? wih[j * IN + c] : 0.0f;
+      xz[m][j] = col[m] ? wih[(HID + j) * IN + c] : 0.0f;
+      xn[m][j] = col[m] ? wih[(2 * HID + j) * IN + c] : 0.0f;
     }
   }
   float* __restrict__ gs = GS + (int64_t)dir * T * 4 * HID * Sp;
   float* __restrict__ dx_out = dX + (int64_t)dir * (BCAST ? 1 : T) * IN * Sp;
   const int n = len[s];
-  float dh = (dHfin && n > 0) ? dHfin[(int64_t)(dir * HID + u) * Sp + s] : 0.0f;
+  float dh = (dHfin && n > 0 && unit) ? dHfin[(int64_t)(dir * HID + u) * Sp + s] : 0.0f;
   float dxacc[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) dxacc[m] = 0.0f;
@@ -956,7 +975,7 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
       const int tp = dir ? t + 1 : t - 1;
       dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), nx_gate[slot]);
       nx_hp[slot] = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
-      nx_do[slot] = dO ? dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
+      nx_do[slot] = (dO && unit) ? dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;   // (idle lane: dht = 0, every gate gradient 0)
     }
   };
   auto do_step = [&](auto slot_c, int step) {
@@ -974,7 +993,7 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
     const float g_n = dnp;
     const float g_h = dnp * r;
     const float dg4[4] = {g_r, g_z, g_n, g_h};
-    dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), dg4);
+    if (unit) dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), dg4);
     float dhp = dht * z;
     float dx[M];
 #pragma unroll
@@ -995,15 +1014,16 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
         dx[m] = fmaf(xn[m][j], b_n, dx[m]);
       }
     });
-    dh = dhp;
+    dh = unit ? dhp : 0.0f;
     if (BCAST) {
 #pragma unroll
       for (int m = 0; m < M; ++m) dxacc[m] += dx[m];
-    } else if (M == 4) {  // lane u owns input columns 4u .. 4u+3: one 16-byte store
-      dof_st_row<4>(dx_out + ACT(t, 4 * u, IN, Sp, s), dx);
+    } else if (M == 4 && IN == 4 * G) {  // lane u owns input columns 4u .. 4u+3: one 16-byte store
+      dof_st_row<4>(dx_out + ACT(t, 4 * ul, IN, Sp, s), dx);
     } else {
 #pragma unroll
-      for (int m = 0; m < M; ++m) dx_out[ACT(t, M * u + m, IN, Sp, s)] = dx[m];
+      for (int m = 0; m < M; ++m)
+        if (col[m]) dx_out[ACT(t, M * ul + m, IN, Sp, s)] = dx[m];
     }
   };
   dof_static_for<PF>([&](auto d) { issue_loads(d, n - 1 - decltype(d)::value); });
@@ -1015,10 +1035,11 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
   }
 #pragma unroll
   for (int m = 0; m < M; ++m) {
+    if (!col[m]) continue;
     if (BCAST) {
-      dx_out[(int64_t)(M * u + m) * Sp + s] = dxacc[m];
+      dx_out[(int64_t)(M * ul + m) * Sp + s] = dxacc[m];
     } else {
-      for (int t = n; t < T; ++t) dx_out[ACT(t, M * u + m, IN, Sp, s)] = 0.0f;
+      for (int t = n; t < T; ++t) dx_out[ACT(t, M * ul + m, IN, Sp, s)] = 0.0f;
     }
   }
 }
@@ -2092,6 +2113,9 @@ int dof_launch_gru8_fwd_pair(const float* const X[2], const int* const len[2], c
   DOF_LAUNCH((k_gru3_fwd<32, 8, false>), (dof_cdiv(S[0] > S[1] ? S[0] : S[1], 32), 2, 2), (256), st, A0, A1, T);
   return dof_check_launch("k_gru3_fwd");
 }
+// latent sizes whose GRU layers (hidden 2 L and L <= 16, not 8 / 16 themselves) run the lane-per-unit kernels on padded lane
+// groups; their saved gates / gate gradients are unit-major like latent 8's (the weight-gradient jobs' `gate_minor`)
+bool dof_gru_lane_per_unit(int L) { return L == 4 || L == 5 || L == 6; }
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st) {
   if (L == 8) {  // weight-stationary kernels: matrix-pipe recurrence (kind 0) / lane per unit
@@ -2104,6 +2128,23 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
     else if (kind == 0) DOF_LAUNCH((k_gru3_fwd<16, 16, false>), (dof_cdiv(S, 16), 2, 1), (256), st, A, A, T);
     else if (kind == 1) DOF_LAUNCH((k_gru3_fwd<32, 8, false>), (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
     else DOF_LAUNCH((k_gru3_fwd<8, 8, true>), (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
+    return dof_check_launch("k_gru3_fwd");
+  }
+  if (dof_gru_lane_per_unit(L)) {  // latent 4 / 5 / 6 (round 6): the lane-per-unit kernels on padded lane groups
+    const Gru8Args A = gru3_fwd_args(X, len, W, O, GS, S, Sp);
+#define GRU3_FWD(IN_, HID_, BC_) DOF_LAUNCH((k_gru3_fwd<IN_, HID_, BC_>), (dof_cdiv(S, 256 / ((HID_) <= 8 ? 8 : 16)), 2, 1), (256), st, A, A, T)
+#define GRU3_FWD_L(LL_) \
+  case LL_: \
+    if (kind == 0) GRU3_FWD(2 * LL_, 2 * LL_, false); \
+    else if (kind == 1) GRU3_FWD(4 * LL_, LL_, false); \
+    else GRU3_FWD(LL_, LL_, true); \
+    break
+    switch (L) {
+      GRU3_FWD_L(4); GRU3_FWD_L(5); GRU3_FWD_L(6);
+      default: return DOF_ERR_UNSUPPORTED;
+    }
+#undef GRU3_FWD_L
+#undef GRU3_FWD
     return dof_check_launch("k_gru3_fwd");
   }
   if ((L == 16 || L == 32) && kind != 2 && dof_grum_selected(S)) {  // encoder-sized launches: the GEMM-shaped recurrence
@@ -2150,6 +2191,22 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
     if (kind == 0) DOF_LAUNCH((k_gru3_bwd<16, 16, false>), (dof_cdiv(S, 16), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
     else if (kind == 1) DOF_LAUNCH((k_gru3_bwd<32, 8, false>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
     else DOF_LAUNCH((k_gru3_bwd<8, 8, true>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
+    return dof_check_launch("k_gru3_bwd");
+  }
+  if (dof_gru_lane_per_unit(L)) {
+#define GRU3_BWD(IN_, HID_, BC_) DOF_LAUNCH((k_gru3_bwd<IN_, HID_, BC_>), (dof_cdiv(S, 256 / ((HID_) <= 8 ? 8 : 16)), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp)
+#define GRU3_BWD_L(LL_) \
+  case LL_: \
+    if (kind == 0) GRU3_BWD(2 * LL_, 2 * LL_, false); \
+    else if (kind == 1) GRU3_BWD(4 * LL_, LL_, false); \
+    else GRU3_BWD(LL_, LL_, true); \
+    break
+    switch (L) {
+      GRU3_BWD_L(4); GRU3_BWD_L(5); GRU3_BWD_L(6);
+      default: return DOF_ERR_UNSUPPORTED;
+    }
+#undef GRU3_BWD_L
+#undef GRU3_BWD
     return dof_check_launch("k_gru3_bwd");
   }
   if ((L == 16 || L == 32) && kind != 2 && dof_grum_selected(S)) {

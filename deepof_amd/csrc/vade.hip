@@ -1166,8 +1166,8 @@ void build_jobs(DofVadePlan* p) {
           }
         }
       }
-      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1, L == 8);  // L == 8: fused in k_gru16_bwd_fused
-      if (L != 8 || !gru8_fused()) gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8);  // else: fused in k_gru8_bwd_fused
+      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1, L == 8 || dof_gru_lane_per_unit(L));  // L == 8: fused in k_gru16_bwd_fused
+      if (L != 8 || !gru8_fused()) gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8 || dof_gru_lane_per_unit(L));  // else: fused in k_gru8_bwd_fused
       cens_jobs(p, jb, s);
     }
     // final dense (L,J): A = flat rows (<=64 per job), B = denc
@@ -1195,8 +1195,8 @@ void build_jobs(DofVadePlan* p) {
   for (int v = 0; v < 2; ++v) {
     JobBuilder jb(p->js_dec[v]);
     const float* zin = ws + (v == 0 ? p->z : p->enc);
-    gru_jobs(jb, ws + p->g1d, zin, true, L, ws + p->o1d, L, T, Bp, p->dg1, L == 8);
-    if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2, L == 8);
+    gru_jobs(jb, ws + p->g1d, zin, true, L, ws + p->o1d, L, T, Bp, p->dg1, L == 8 || dof_gru_lane_per_unit(L));
+    if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2, L == 8 || dof_gru_lane_per_unit(L));
     const int CI = 4 * L, CO = 2 * L;
     int job = -1;
     for (int k = 0; k < 5; ++k)

@@ -1,6 +1,6 @@
 """Round-6 reference fixtures (run in the build container, where /root/reference is importable):
 
-    python tests/golden/make_golden_r06.py l4          # recurrent family at latent 4 (the API's default latent_dim)
+    python tests/golden/make_golden_r06.py l4 l6       # recurrent family at latent 4 (the API's default latent_dim) and 6 (the tutorial's)
     python tests/golden/make_golden_r06.py tcnkinks    # ReLU-kink attribution for the two small contrastive TCN fixtures
 
 * vade_rec14l4.npz / vqvae_rec14l4.npz / contrastive_rec14l4.npz
@@ -103,13 +103,23 @@ def gen_latent4():
     MG.gen_contrastive("rec14l4", [""], 24, 4, 12, 1161)
 
 
+def gen_latent6():
+    """latent_dim = 6, the size the reference's tutorial trains: GRU(12 -> 12) / GRU(24 -> 6) streams"""
+    MG.gen_vade("rec14l6", [""], 25, 6, 10, 12, 1231)
+    MG.gen_vqvae("rec14l6", [""], 25, 6, 48, 12, 1241, kmeans=0.5)
+    MG.gen_contrastive("rec14l6", [""], 24, 6, 12, 1261)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["l4", "tcnkinks"]
+    what = sys.argv[1:] or ["l4", "l6", "tcnkinks"]
     if "l4" in what:
         gen_latent4()
+    if "l6" in what:
+        gen_latent6()
     if "tcnkinks" in what:
         gen_small_tcn_kinks()
-    for f in ("vade_rec14l4.npz", "vqvae_rec14l4.npz", "contrastive_rec14l4.npz", "tcn_kinks.npz"):
+    for f in ("vade_rec14l4.npz", "vqvae_rec14l4.npz", "contrastive_rec14l4.npz", "vade_rec14l6.npz", "vqvae_rec14l6.npz",
+              "contrastive_rec14l6.npz", "tcn_kinks.npz"):
         p = os.path.join(HERE, f)
         if os.path.exists(p):
             print(f, os.path.getsize(p))
