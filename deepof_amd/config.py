@@ -158,8 +158,10 @@ _SIMS = ("cosine", "dot", "euclidean", "edit")
 _LOSSES = ("nce", "dcl", "dlc", "fc", "hard_dcl")  # the reference accepts the "dlc" typo; both spellings work here (Q13)
 
 
-SUPPORTED_LATENT_DIMS = (4, 5, 6, 8, 10, 12, 16, 20, 24, 32)
-RECURRENT_ONLY_LATENT_DIMS = (20, 24, 32)   # the TCN / transformer families stop at 16 (row-per-window latent kernels)
+SUPPORTED_LATENT_DIMS = (4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24, 32)
+# the TCN / transformer families stop at 16 (row-per-window latent kernels); 7, 9, 14 (round 6) are built behind the recurrent
+# blocks only
+RECURRENT_ONLY_LATENT_DIMS = (7, 9, 14, 20, 24, 32)
 MAX_CONTRASTIVE_NODES = 64
 TRANSFORMER_KEY_DIMS = tuple(range(4, 68, 4))   # every value of min(64, 3 N) // 4 * 4 (models_new.py:1013-1019)
 
@@ -191,7 +193,8 @@ def check_model_inputs(preprocessed_object, adjacency_matrix, meta_info, encoder
                                       f"the recurrent encoder only")
         if str(encoder_type).lower() == "transformer" and str(model_name).lower() != "contrastive":
             # the reference's transformer decoder: 8 heads over d_model = 4 * latent_dim (models_new.py:1272-1277, 1494)
-            assert (4 * int(latent_dim)) % 8 == 0, "d_model must be divisible by num_heads"
+            if (4 * int(latent_dim)) % 8 != 0:   # (an explicit raise: a bare assert disappears under python -O)
+                raise AssertionError("d_model must be divisible by num_heads")
         if str(encoder_type).lower() == "transformer":
             # TFMEncoderPT's key_dim = min(64, 3 N) rounded down to a multiple of its 4 heads (models_new.py:1013-1019)
             kd = max(4, min(64, 3 * int(adjacency_matrix.shape[0])) // 4 * 4)

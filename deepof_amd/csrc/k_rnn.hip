@@ -1964,15 +1964,18 @@ __global__ void __launch_bounds__(256) k_relu_merge(const float* __restrict__ ac
     case 4: { constexpr int LL = 4; CALL; } break;         \
     case 5: { constexpr int LL = 5; CALL; } break;         \
     case 6: { constexpr int LL = 6; CALL; } break;         \
+    case 7: { constexpr int LL = 7; CALL; } break;         \
     case 8: { constexpr int LL = 8; CALL; } break;         \
+    case 9: { constexpr int LL = 9; CALL; } break;         \
     case 10: { constexpr int LL = 10; CALL; } break;       \
     case 12: { constexpr int LL = 12; CALL; } break;       \
+    case 14: { constexpr int LL = 14; CALL; } break;       \
     case 16: { constexpr int LL = 16; CALL; } break;       \
     case 20: { constexpr int LL = 20; CALL; } break;       \
     case 24: { constexpr int LL = 24; CALL; } break;       \
     case 32: { constexpr int LL = 32; CALL; } break;       \
     default:                                               \
-      dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 10, 12, 16, 20, 24, 32)", (int)(L)); \
+      dof_set_error("latent_dim %d not supported by this build (4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24, 32)", (int)(L)); \
       return DOF_ERR_UNSUPPORTED;                          \
   }
 
@@ -2115,7 +2118,17 @@ int dof_launch_gru8_fwd_pair(const float* const X[2], const int* const len[2], c
 }
 // latent sizes whose GRU layers (hidden 2 L and L <= 16, not 8 / 16 themselves) run the lane-per-unit kernels on padded lane
 // groups; their saved gates / gate gradients are unit-major like latent 8's (the weight-gradient jobs' `gate_minor`)
-bool dof_gru_lane_per_unit(int L) { return L == 4 || L == 5 || L == 6; }
+// (kind: 0 = GRU(2L -> 2L), 1 = GRU(4L -> L), 2 = GRU(L -> L) with a time-constant input.)  Latent 10: the two layers of
+// hidden size 10; its GRU(20 -> 20) layers take the quad-split kernels (gate-major buffers).
+bool dof_gru_lane_per_unit(int L, int kind) {
+  const int hid = kind == 0 ? 2 * L : L, in = kind == 0 ? 2 * L : kind == 1 ? 4 * L : L;
+  // (input widths above 48 take the weight-gradient jobs' row-block form, which reads gate-major buffers only: 14's
+  //  GRU(56 -> 14) layers stay on the thread-per-sequence kernels)
+  return (L == 4 || L == 5 || L == 6 || L == 7 || L == 9 || L == 10 || L == 14) && hid <= 16 && in <= 48;
+}
+// ... and the GRU(2L -> 2L) layers of 10 and 14 the quad-split kernels (hidden 20 / 28: a multiple of 4); 9's (hidden 18) stay on
+// the thread-per-sequence kernels
+static bool gru_quad_layer(int L, int kind) { return (L >= 12 && L % 4 == 0) || ((L == 10 || L == 14) && kind == 0); }
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st) {
   if (L == 8) {  // weight-stationary kernels: matrix-pipe recurrence (kind 0) / lane per unit
@@ -2130,7 +2143,7 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
     else DOF_LAUNCH((k_gru3_fwd<8, 8, true>), (dof_cdiv(S, 32), 2, 1), (256), st, A, A, T);
     return dof_check_launch("k_gru3_fwd");
   }
-  if (dof_gru_lane_per_unit(L)) {  // latent 4 / 5 / 6 (round 6): the lane-per-unit kernels on padded lane groups
+  if (dof_gru_lane_per_unit(L, kind)) {  // latent 4 / 5 / 6 / 10 (round 6): the lane-per-unit kernels on padded lane groups
     const Gru8Args A = gru3_fwd_args(X, len, W, O, GS, S, Sp);
 #define GRU3_FWD(IN_, HID_, BC_) DOF_LAUNCH((k_gru3_fwd<IN_, HID_, BC_>), (dof_cdiv(S, 256 / ((HID_) <= 8 ? 8 : 16)), 2, 1), (256), st, A, A, T)
 #define GRU3_FWD_L(LL_) \
@@ -2140,7 +2153,11 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
     else GRU3_FWD(LL_, LL_, true); \
     break
     switch (L) {
-      GRU3_FWD_L(4); GRU3_FWD_L(5); GRU3_FWD_L(6);
+      GRU3_FWD_L(4); GRU3_FWD_L(5); GRU3_FWD_L(6); GRU3_FWD_L(7);
+#define GRU3_FWD_H(LL_) case LL_: if (kind == 1) GRU3_FWD(4 * LL_, LL_, false); else GRU3_FWD(LL_, LL_, true); break
+      GRU3_FWD_H(9); GRU3_FWD_H(10);
+      case 14: GRU3_FWD(14, 14, true); break;
+#undef GRU3_FWD_H
       default: return DOF_ERR_UNSUPPORTED;
     }
 #undef GRU3_FWD_L
@@ -2157,7 +2174,7 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
 #undef GRUM_FWD
     return dof_check_launch("k_grumx_fwd");
   }
-  if (L >= 12 && L % 4 == 0) {  // a sequence across four lanes (at latent 32 thread-per-sequence took 134 ms per C2-shape step)
+  if (gru_quad_layer(L, kind)) {  // a sequence across four lanes (at latent 32 thread-per-sequence took 134 ms per C2-shape step)
     const unsigned nq = dof_cdiv(S * 4, 256);
 #define GRUQ_FWD(IN_, HID_, BC_) DOF_LAUNCH((k_gruq_fwd<IN_, HID_, BC_>), (nq, 2), (256), st, X, len, W.wih0, W.whh0, W.bih0, W.bhh0, W.wih1, W.whh1, W.bih1, W.bhh1, O, GS, T, S, Sp)
 #define GRUQ_FWD_L(LL_) \
@@ -2168,6 +2185,8 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
     break
     switch (L) {
       GRUQ_FWD_L(12); GRUQ_FWD_L(16); GRUQ_FWD_L(20); GRUQ_FWD_L(24); GRUQ_FWD_L(32);
+      case 10: GRUQ_FWD(20, 20, false); break;
+      case 14: GRUQ_FWD(28, 28, false); break;
       default: dof_set_error("GRU: latent_dim %d has no quad-split kernel", L); return DOF_ERR_UNSUPPORTED;
     }
 #undef GRUQ_FWD_L
@@ -2193,7 +2212,7 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
     else DOF_LAUNCH((k_gru3_bwd<8, 8, true>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
     return dof_check_launch("k_gru3_bwd");
   }
-  if (dof_gru_lane_per_unit(L)) {
+  if (dof_gru_lane_per_unit(L, kind)) {
 #define GRU3_BWD(IN_, HID_, BC_) DOF_LAUNCH((k_gru3_bwd<IN_, HID_, BC_>), (dof_cdiv(S, 256 / ((HID_) <= 8 ? 8 : 16)), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp)
 #define GRU3_BWD_L(LL_) \
   case LL_: \
@@ -2202,7 +2221,11 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
     else GRU3_BWD(LL_, LL_, true); \
     break
     switch (L) {
-      GRU3_BWD_L(4); GRU3_BWD_L(5); GRU3_BWD_L(6);
+      GRU3_BWD_L(4); GRU3_BWD_L(5); GRU3_BWD_L(6); GRU3_BWD_L(7);
+#define GRU3_BWD_H(LL_) case LL_: if (kind == 1) GRU3_BWD(4 * LL_, LL_, false); else GRU3_BWD(LL_, LL_, true); break
+      GRU3_BWD_H(9); GRU3_BWD_H(10);
+      case 14: GRU3_BWD(14, 14, true); break;
+#undef GRU3_BWD_H
       default: return DOF_ERR_UNSUPPORTED;
     }
 #undef GRU3_BWD_L
@@ -2219,7 +2242,7 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
 #undef GRUM_BWD
     return dof_check_launch("k_grum_bwd");
   }
-  if (L >= 12 && L % 4 == 0) {
+  if (gru_quad_layer(L, kind)) {
     const unsigned nq = dof_cdiv(S * 4, 256);
 #define GRUQ_BWD(IN_, HID_, BC_) DOF_LAUNCH((k_gruq_bwd<IN_, HID_, BC_>), (nq, 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp)
 #define GRUQ_BWD_L(LL_) \
@@ -2230,6 +2253,8 @@ int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* 
     break
     switch (L) {
       GRUQ_BWD_L(12); GRUQ_BWD_L(16); GRUQ_BWD_L(20); GRUQ_BWD_L(24); GRUQ_BWD_L(32);
+      case 10: GRUQ_BWD(20, 20, false); break;
+      case 14: GRUQ_BWD(28, 28, false); break;
       default: dof_set_error("GRU: latent_dim %d has no quad-split kernel", L); return DOF_ERR_UNSUPPORTED;
     }
 #undef GRUQ_BWD_L

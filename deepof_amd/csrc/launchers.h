@@ -20,7 +20,7 @@ int dof_launch_gru16_fwd_pair(const float* const X[2], const int* const len[2], 
 int dof_launch_gru16_bwd_pair(const float* const X[2], const int* const len[2], const DofGruW W[2], const float* const O[2],
                               const float* const dO[2], float* const dX[2], float* const wg_partial[2], int T,
                               const int64_t S[2], const int64_t Sp[2], hipStream_t st);
-bool dof_gru_lane_per_unit(int L);   // latent 4 / 5 / 6: lane-per-unit GRU kernels, unit-major gate buffers (as latent 8)
+bool dof_gru_lane_per_unit(int L, int kind);   // latent 4 / 5 / 6 (and 10's hidden-10 layers): lane-per-unit GRU kernels, unit-major gate buffers (as latent 8)
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* O, float* GS, const float* dO,

@@ -190,7 +190,7 @@ struct DofVadePlan {
   int64_t flat, enc, mu, pre, sv, z, q, qn, dlogit, dmu_dpre, denc, dflat;
   int64_t gram, Pm, km, stats, dqbar, dcen, dscat, dlogp2, tf_partial, scal;
   int64_t gram_part = 0;       // Gram tiles written by k_latent_fwd_w (VaDE, row-per-window latent kernels)
-  bool gram_in_latent = false; // ... by the latent_forward call in front of gram_spectrum
+  bool gram_in_latent = false; // ... by k_latent_fwd_w (K <= 32, L <= 16, VaDE): immutable, set once when the plan's sizes are known
   int64_t mlse, mzs, mgsum, gmmp, mckl_partial, distill_partial, recon_partial;
   int64_t mckl_blocks, lat_blocks, tail_blocks;
   bool tail_wide = false;
@@ -1166,8 +1166,8 @@ void build_jobs(DofVadePlan* p) {
           }
         }
       }
-      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1, L == 8 || dof_gru_lane_per_unit(L));  // L == 8: fused in k_gru16_bwd_fused
-      if (L != 8 || !gru8_fused()) gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8 || dof_gru_lane_per_unit(L));  // else: fused in k_gru8_bwd_fused
+      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1, L == 8 || dof_gru_lane_per_unit(L, 0));  // L == 8: fused in k_gru16_bwd_fused
+      if (L != 8 || !gru8_fused()) gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8 || dof_gru_lane_per_unit(L, 1));  // else: fused in k_gru8_bwd_fused
       cens_jobs(p, jb, s);
     }
     // final dense (L,J): A = flat rows (<=64 per job), B = denc
@@ -1195,8 +1195,8 @@ void build_jobs(DofVadePlan* p) {
   for (int v = 0; v < 2; ++v) {
     JobBuilder jb(p->js_dec[v]);
     const float* zin = ws + (v == 0 ? p->z : p->enc);
-    gru_jobs(jb, ws + p->g1d, zin, true, L, ws + p->o1d, L, T, Bp, p->dg1, L == 8 || dof_gru_lane_per_unit(L));
-    if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2, L == 8 || dof_gru_lane_per_unit(L));
+    gru_jobs(jb, ws + p->g1d, zin, true, L, ws + p->o1d, L, T, Bp, p->dg1, L == 8 || dof_gru_lane_per_unit(L, 2));
+    if (L != 8) gru_jobs(jb, ws + p->g2d, ws + p->n1d, false, 2 * L, ws + p->o2d, 2 * L, T, Bp, p->dg2, L == 8 || dof_gru_lane_per_unit(L, 0));
     const int CI = 4 * L, CO = 2 * L;
     int job = -1;
     for (int k = 0; k < 5; ++k)
@@ -1303,14 +1303,17 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     case 4: { constexpr int LL = 4; CALL; } break; \
     case 5: { constexpr int LL = 5; CALL; } break; \
     case 6: { constexpr int LL = 6; CALL; } break; \
+    case 7: { constexpr int LL = 7; CALL; } break; \
     case 8: { constexpr int LL = 8; CALL; } break; \
+    case 9: { constexpr int LL = 9; CALL; } break; \
     case 10: { constexpr int LL = 10; CALL; } break; \
     case 12: { constexpr int LL = 12; CALL; } break; \
+    case 14: { constexpr int LL = 14; CALL; } break; \
     case 16: { constexpr int LL = 16; CALL; } break; \
     case 20: { constexpr int LL = 20; CALL; } break; \
     case 24: { constexpr int LL = 24; CALL; } break; \
     case 32: { constexpr int LL = 32; CALL; } break; \
-    default: dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 10, 12, 16, 20, 24, 32)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
+    default: dof_set_error("latent_dim %d not supported by this build (4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24, 32)", (int)(L)); return DOF_ERR_UNSUPPORTED; \
   }
 
 // the row-per-window latent kernels (a 16-lane DPP row owns the latent dimensions): latent <= 16 only
@@ -1319,9 +1322,12 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     case 4: { constexpr int LL = 4; CALL; } break; \
     case 5: { constexpr int LL = 5; CALL; } break; \
     case 6: { constexpr int LL = 6; CALL; } break; \
+    case 7: { constexpr int LL = 7; CALL; } break; \
     case 8: { constexpr int LL = 8; CALL; } break; \
+    case 9: { constexpr int LL = 9; CALL; } break; \
     case 10: { constexpr int LL = 10; CALL; } break; \
     case 12: { constexpr int LL = 12; CALL; } break; \
+    case 14: { constexpr int LL = 14; CALL; } break; \
     case 16: { constexpr int LL = 16; CALL; } break; \
     default: dof_set_error("latent_dim %d: the row-per-window latent kernels cover latent <= 16", (int)(L)); return DOF_ERR_UNSUPPORTED; \
   }
@@ -1413,6 +1419,9 @@ DofTriplets trip_dev(const float* ws, const int64_t* t) {
     else if (_l == 16 && _d == 60) DOF_LAUNCH((NAME<16, 60>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 16 && _d == 64) DOF_LAUNCH((NAME<16, 64>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 32 && _d == 64) DOF_LAUNCH((NAME<32, 64>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 7 && _d == 14) DOF_LAUNCH((NAME<7, 14>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 9 && _d == 18) DOF_LAUNCH((NAME<9, 18>), GRID, (256), st, __VA_ARGS__); \
+    else if (_l == 14 && _d == 28) DOF_LAUNCH((NAME<14, 28>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 10 && _d == 4) DOF_LAUNCH((NAME<10, 4>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 10 && _d == 8) DOF_LAUNCH((NAME<10, 8>), GRID, (256), st, __VA_ARGS__); \
     else if (_l == 10 && _d == 12) DOF_LAUNCH((NAME<10, 12>), GRID, (256), st, __VA_ARGS__); \
@@ -1709,7 +1718,8 @@ int latent_forward(DofVadePlan* p, const float* params, const float* prior, cons
   A.q = ws + p->q; A.qn = ws + p->qn;
   A.z_out = z_out; A.q_out = q_out; A.mu_out = mu_out; A.sv_out = sv_out; A.enc_out = enc_out;
   A.K = p->K; A.B = p->B; A.Bp = p->Bp;
-  p->gram_in_latent = rows && p->kind == 0;   // the Gram of ws.z for the k-means term, 16 windows per tile
+  // (p->gram_in_latent -- the Gram of ws.z for the k-means term, 16 windows per tile -- is fixed at plan creation:
+  //  dof_plan_gram_in_latent)
   A.gram_partial = p->gram_in_latent ? ws + p->gram_part : nullptr;
   if (!rows) {
     LDISPATCH(p->L, DOF_LAUNCH((k_latent_fwd<LL>), (dof_cdiv(p->B, 256)), (256), st, A));
@@ -2193,9 +2203,9 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
   }
   const int lat = dims->latent;   // the sizes DOF_DISPATCH_L / LDISPATCH instantiate; above 16 only the recurrent family has a latent head
   const bool lat_small = lat == 4 || lat == 5 || lat == 6 || lat == 8 || lat == 10 || lat == 12 || lat == 16;
-  const bool lat_large = lat == 20 || lat == 24 || lat == 32;
+  const bool lat_large = lat == 7 || lat == 9 || lat == 14 || lat == 20 || lat == 24 || lat == 32;   // recurrent family only
   if (!lat_small && !(lat_large && !tcn && !tfm)) {
-    dof_set_error("latent_dim %d not supported by this build (4, 6, 8, 10, 12, 16; 20, 24, 32 with the recurrent encoder)", lat);
+    dof_set_error("latent_dim %d not supported by this build (4, 5, 6, 8, 10, 12, 16; 7, 9, 14, 20, 24, 32 with the recurrent encoder)", lat);
     return DOF_ERR_UNSUPPORTED;
   }
   if (dims->n_nodes > DOF_CL_MAX_NODES && kind == 2) {
@@ -2212,6 +2222,10 @@ static int plan_create(const DofVadeDims* dims, const float* laplacian, const fl
   p->J = (p->N + p->E) * p->L;
   p->C3 = 3 * p->N;
   p->D = tcn ? 32 : 2 * p->L;
+  // k_latent_fwd_w (components across lanes) also leaves the Gram of z for the k-means term (VaDE plans): the choice of the
+  // tile layout / the eigen-solver's host kernel downstream depends on this flag alone (advisor, round 5: it used to be
+  // written as a side effect of latent_forward)
+  p->gram_in_latent = p->K <= 32 && p->L <= 16 && kind == 0;
   if (tfm) {  // TFMEncoderPT.__init__ (models_new.py:1013-1019): key_dim from the NODE feature count for both streams
     TfmPlan& tf = p->tf;
     int kd = 3 * p->N < 64 ? 3 * p->N : 64;

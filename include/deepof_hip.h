@@ -79,7 +79,7 @@ typedef struct DofVadeDims {
   int32_t window;     /* T */
   int32_t n_nodes;    /* N, 3 features per node */
   int32_t n_edges;    /* E, 1 feature per edge */
-  int32_t latent;     /* L (internal GRU width = min(64, L) in the reference; this build: 4, 5, 6, 8, 10, 12, 16; 20, 24, 32 with the recurrent encoder) */
+  int32_t latent;     /* L (internal GRU width = min(64, L) in the reference; this build: 4, 5, 6, 8, 10, 12, 16; 7, 9, 14, 20, 24, 32 with the recurrent encoder) */
   int32_t n_clusters; /* K */
   int32_t mc_samples; /* S of the Monte-Carlo KL (reference: 32) */
 } DofVadeDims;

@@ -1,6 +1,7 @@
 """Round-6 reference fixtures (run in the build container, where /root/reference is importable):
 
     python tests/golden/make_golden_r06.py l4 l6       # recurrent family at latent 4 (the API's default latent_dim) and 6 (the tutorial's)
+    python tests/golden/make_golden_r06.py lodd        # latent 7, 9, 14 (recurrent family)
     python tests/golden/make_golden_r06.py tcnkinks    # ReLU-kink attribution for the two small contrastive TCN fixtures
 
 * vade_rec14l4.npz / vqvae_rec14l4.npz / contrastive_rec14l4.npz
@@ -110,12 +111,23 @@ def gen_latent6():
     MG.gen_contrastive("rec14l6", [""], 24, 6, 12, 1261)
 
 
+def gen_latent_odd():
+    """latent 7, 9, 14 (round 6: sizes between the built ones; recurrent family) -- VaDE only, batch > latent as for the other sizes"""
+    MG.gen_vade("rec14l7", [""], 25, 7, 10, 12, 1331)
+    MG.gen_vade("rec14l9", [""], 25, 9, 10, 12, 1431)
+    MG.gen_vade("rec14l14", [""], 25, 14, 10, 16, 1531)
+    MG.gen_contrastive("rec14l7", [""], 24, 7, 12, 1361)
+    MG.gen_vqvae("rec14l14", [""], 25, 14, 48, 16, 1541, kmeans=0.5)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["l4", "l6", "tcnkinks"]
     if "l4" in what:
         gen_latent4()
     if "l6" in what:
         gen_latent6()
+    if "lodd" in what:
+        gen_latent_odd()
     if "tcnkinks" in what:
         gen_small_tcn_kinks()
     for f in ("vade_rec14l4.npz", "vqvae_rec14l4.npz", "contrastive_rec14l4.npz", "vade_rec14l6.npz", "vqvae_rec14l6.npz",

@@ -71,10 +71,16 @@ def test_plan_layout_without_gpu(lib):
     assert lib.dof_tfm_dropout_site_name(plan, 1) == b"enc.node.l0.attn"
     assert lib.dof_tfm_dropout_site_numel(plan, 1) == 1024 * 14 * 4 * 25 * 25
     lib.dof_vade_plan_destroy(plan)
-    bad = _capi.VadeDims(8, 25, 14, 14, 7, 10, 32)
+    bad = _capi.VadeDims(8, 25, 14, 14, 11, 10, 32)
     assert lib.dof_vade_plan_create(ctypes.byref(bad), lap.ctypes.data, elap.ctypes.data, inc.ctypes.data,
                                     ctypes.byref(plan)) == -2
-    assert b"latent_dim 7" in lib.dof_last_error_string()
+    assert b"latent_dim 11" in lib.dof_last_error_string()
+    odd = _capi.VadeDims(8, 25, 14, 14, 7, 10, 32)   # 7, 9, 14 (round 6): the recurrent family only
+    assert lib.dof_vade_plan_create(ctypes.byref(odd), lap.ctypes.data, elap.ctypes.data, inc.ctypes.data,
+                                    ctypes.byref(plan)) == 0
+    lib.dof_vade_plan_destroy(plan)
+    assert lib.dof_vade_tcn_plan_create(ctypes.byref(odd), lap.ctypes.data, elap.ctypes.data, inc.ctypes.data,
+                                        ctypes.byref(plan)) == -2
 
 
 def test_product_path_fails_loudly_without_gpu():

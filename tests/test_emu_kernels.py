@@ -14,7 +14,7 @@ def test_gather_emu():
     gather_check(emu_lib(), "cpu")
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l7", "rec14l9", "rec14l14", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
 def test_vade_eval_forward_emu(golden_dir, tag):
     d = load_golden(golden_dir, f"vade_{tag}.npz")
     x, a = torch.from_numpy(d["x"]), torch.from_numpy(d["a"])
@@ -33,7 +33,7 @@ def test_vade_eval_forward_emu(golden_dir, tag):
                                        ("rec28", "pre"), ("rec28", "mainT"), ("rec28", "mainX"),
                                        ("c5l8", "pre"), ("c5l8", "mainX"),
                                        ("rec14l16", "pre"), ("rec14l16", "mainX"), ("rec14l32", "pre"),
-                                       ("rec14l12", "mainX"), ("rec14l10", "pre"), ("rec14l5", "main"), ("rec14l5", "mainX"), ("rec14l4", "pre"), ("rec14l4", "mainT"), ("rec14l6", "pre"), ("rec14l6", "mainX")])   # (latent 32: the other phases / models on the GPU)
+                                       ("rec14l12", "mainX"), ("rec14l10", "pre"), ("rec14l5", "main"), ("rec14l5", "mainX"), ("rec14l4", "pre"), ("rec14l4", "mainT"), ("rec14l6", "pre"), ("rec14l6", "mainX"), ("rec14l7", "mainX"), ("rec14l9", "pre"), ("rec14l14", "mainX")])   # (latent 32: the other phases / models on the GPU)
 def test_vade_loss_grads_emu(golden_dir, tag, phase):
     run_phase_check(emu_lib(), "cpu", golden_dir, tag, phase)
 

@@ -56,7 +56,7 @@ def test_gather_matches_reference_windows(hip, golden_dir):
             np.testing.assert_array_equal(a.cpu().numpy(), d[f"w{ci}::a"])
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l7", "rec14l9", "rec14l14", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
 def test_vade_eval_forward_gpu(hip, golden_dir, tag):
     from deepof_amd.engine import create_vade_engine
     from parity_common import load_golden, params_from
@@ -83,6 +83,8 @@ def test_vade_eval_forward_gpu(hip, golden_dir, tag):
                                        ("rec14l5", "pre"), ("rec14l5", "main"), ("rec14l5", "mainT"), ("rec14l5", "mainX"),
                                        ("rec14l4", "pre"), ("rec14l4", "main"), ("rec14l4", "mainT"), ("rec14l4", "mainX"),
                                        ("rec14l6", "pre"), ("rec14l6", "main"), ("rec14l6", "mainT"), ("rec14l6", "mainX"),
+                                       ("rec14l7", "pre"), ("rec14l7", "mainX"), ("rec14l9", "pre"), ("rec14l9", "mainX"),
+                                       ("rec14l14", "pre"), ("rec14l14", "mainT"), ("rec14l14", "mainX"),
                                        ("rec14l10", "pre"), ("rec14l10", "mainX"), ("rec14l12", "pre"), ("rec14l12", "main"),
                                        ("rec14l12", "mainT"), ("rec14l12", "mainX"), ("rec14l20", "pre"), ("rec14l20", "mainX"),
                                        ("rec14l24", "pre"), ("rec14l24", "main"), ("rec14l24", "mainT"), ("rec14l24", "mainX")])
@@ -258,7 +260,7 @@ def test_training_api_on_gpu(hip, tmp_path):
     np.testing.assert_allclose(soft.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l12", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l12", "rec14l24", "rec14l14"])
 def test_vqvae_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_vqvae_check
     run_vqvae_check(hip, "cuda", golden_dir, tag)
@@ -330,7 +332,7 @@ def test_vqvae_full_size_c3(hip):
     np.testing.assert_allclose(out["soft_counts"].cpu().numpy(), soft.numpy(), rtol=2e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l12", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l12", "rec14l24", "rec14l7"])
 def test_contrastive_parity_gpu(hip, golden_dir, tag):
     from parity_common import run_contrastive_check, run_contrastive_loss_check
     run_contrastive_loss_check(hip, "cuda", golden_dir, tag)

@@ -199,8 +199,10 @@ def test_input_validation_errors():
         TR.train_deepof_model(**{**kw, "latent_dim": 32, "encoder_type": "TCN"})
     with pytest.raises(NotImplementedError, match="recurrent encoder only"):
         TR.train_deepof_model(**{**kw, "latent_dim": 24, "encoder_type": "transformer"})
-    with pytest.raises(NotImplementedError, match="latent_dim=7"):
-        TR.train_deepof_model(**{**kw, "latent_dim": 7})
+    with pytest.raises(NotImplementedError, match="latent_dim=11"):
+        TR.train_deepof_model(**{**kw, "latent_dim": 11})
+    with pytest.raises(NotImplementedError, match="recurrent encoder only"):   # 7, 9, 14 (round 6): behind the recurrent blocks only
+        TR.train_deepof_model(**{**kw, "latent_dim": 7, "encoder_type": "TCN"})
     with pytest.raises(AssertionError, match="divisible by num_heads"):   # the reference's own assertion (models_new.py:1277)
         TR.train_deepof_model(**{**kw, "latent_dim": 5, "encoder_type": "transformer"})
     with pytest.raises(RuntimeError):   # product path: no CPU fallback

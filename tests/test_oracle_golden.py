@@ -107,7 +107,7 @@ def test_recurrent_block(golden_dir, tag):
             np.testing.assert_allclose(leaf[name].grad.numpy(), v, atol=5e-5, rtol=1e-4, err_msg=name)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l7", "rec14l9", "rec14l14", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
 def test_vade_eval_forward(golden_dir, tag):
     d = _load(golden_dir, f"vade_{tag}.npz")
     P = _params(d)
@@ -143,7 +143,7 @@ def make_cfg(K, phase, tau):
     return OV.VadeLossCfg(K, spec["pretrain"], **kw), spec["klw"]
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l7", "rec14l9", "rec14l14", "rec14l10", "rec14l12", "rec14l20", "rec14l24"])
 @pytest.mark.parametrize("phase", list(PHASES))
 def test_vade_train_loss_and_grads(golden_dir, tag, phase):
     d = _load(golden_dir, f"vade_{tag}.npz")
@@ -207,7 +207,7 @@ def test_kmeans_value_and_grad(golden_dir):
     np.testing.assert_allclose(z.grad.numpy(), d["km_grad"], atol=1e-7, rtol=1e-5)
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l12", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "c3k512", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l12", "rec14l24", "rec14l14"])
 def test_vqvae_forward_loss_grads_trace(golden_dir, tag):
     from oracle import vqvae as OQ
     d = _load(golden_dir, f"vqvae_{tag}.npz")
@@ -256,7 +256,7 @@ def _aug_draws(d, pfx):
                        noise=torch.from_numpy(d[pfx + "aug::noise"]))
 
 
-@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l12", "rec14l24"])
+@pytest.mark.parametrize("tag", ["rec14", "rec28", "c5l8", "rec14l16", "rec14l32", "rec14l4", "rec14l5", "rec14l6", "rec14l12", "rec14l24", "rec14l7"])
 def test_contrastive_losses_match_reference(golden_dir, tag):
     from oracle import contrastive as OC
     d = _load(golden_dir, f"contrastive_{tag}.npz")
@@ -272,7 +272,7 @@ def test_contrastive_losses_match_reference(golden_dir, tag):
                                        rtol=1e-4, atol=1e-6, err_msg=f"{sim}/{lf}")
 
 
-@pytest.mark.parametrize("tag,ids", [("rec14", [""]), ("rec28", ["B", "W"]), ("c5l8", ["B", "W"]), ("rec14l16", [""]), ("rec14l32", [""]), ("rec14l4", [""]), ("rec14l5", [""]), ("rec14l6", [""]), ("rec14l12", [""]), ("rec14l24", [""])])
+@pytest.mark.parametrize("tag,ids", [("rec14", [""]), ("rec28", ["B", "W"]), ("c5l8", ["B", "W"]), ("rec14l16", [""]), ("rec14l32", [""]), ("rec14l4", [""]), ("rec14l5", [""]), ("rec14l6", [""]), ("rec14l7", [""]), ("rec14l12", [""]), ("rec14l24", [""])])
 def test_contrastive_views_and_step_match_reference(golden_dir, tag, ids):
     from oracle import contrastive as OC
     d = _load(golden_dir, f"contrastive_{tag}.npz")
