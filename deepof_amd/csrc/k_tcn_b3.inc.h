@@ -41,7 +41,7 @@
 // tile barrier} for loader wavefront w
 #ifdef TCN_PROBE_STAMPS
 __device__ unsigned long long g_tcn_stamps[256];
-#define TCN_STAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && k == TCN_PROBE_STAMPS) g_tcn_stamps[(slot)] = __builtin_readcyclecounter(); } while (0)
+#define TCN_STAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && k == TCN_PROBE_STAMPS && (slot) < 256 && ((slot) >= 128 || (threadIdx.x >> 6) < 4)) g_tcn_stamps[(slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TCN_STAMP(slot) ((void)0)
 #endif
@@ -56,9 +56,13 @@ __device__ __forceinline__ void tb_st8(uint16_t* p, uint32_t lo, uint32_t hi) {
   *reinterpret_cast<uint64_t*>(p) = (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL, bool COMB, bool WGRAD, int NS>
-__global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
+// NCW = compute wavefronts: 4 (512 threads, <= 256 registers) or 8 (768 threads, <= 168 registers: two compute wavefronts
+// per SIMD share its matrix pipe and hide each other's epilogue)
+template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL, bool COMB, bool WGRAD, int NS, int NCW = 4>
+__global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b(TcnConvArgs A) {
   static_assert(NS == 8 || NS == 4, "8 sequences x 25 steps or 4 sequences x 50 steps");
+  static_assert(NCW == 4 || NCW == 8, "four or eight compute wavefronts");
+  constexpr int MAXR = 16 / NCW;      // rounds of a tile (at most 13 column blocks)
   constexpr int TPC = 16 / NS;        // output rows per MFMA column block
   constexpr int TS = 256 / (NS * 8);  // time steps per staging pass of the 256 loader threads
   constexpr int NP = TB_ROWS / NS / TS;
@@ -67,15 +71,15 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
   static_assert(!COMB || (!REVERSE && !BN_IN && !FUSE_BN && !BWD2), "the combine-on-load variant is a plain forward convolution");
   static_assert(!WGRAD || (REVERSE && FUSE_BN && BWD2), "the weight gradient rides on the fused data-gradient variants");
   __shared__ __attribute__((aligned(16))) uint16_t img[2 * TB_IMG];
-  __shared__ __attribute__((aligned(16))) uint16_t ring[WGRAD ? 2 * 4 * 3 * TB_RING : 8];
+  __shared__ __attribute__((aligned(16))) uint16_t ring[WGRAD ? 2 * NCW * 3 * TB_RING : 8];
   // the A operands (weights): [tap][piece][channel half][lane] x 16 bytes, every compute wavefront reads the same 24 KB (in
   // registers they cost 96 VGPRs per lane, which left no room to request LDS operands ahead of the matrix instructions)
   __shared__ __attribute__((aligned(16))) uint16_t wlds[TK * 3 * 2 * 64 * 8];
   __shared__ float4 frec[FUSE_BN ? 4 * TC / 4 : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const bool loader = wv >= 4;  // wave-uniform role
+  const bool loader = wv >= NCW;  // wave-uniform role
   const int T = A.T;
-  const int n_cb = (T + TPC - 1) / TPC, n_rounds = (n_cb + 3) / 4;
+  const int n_cb = (T + TPC - 1) / TPC, n_rounds = (n_cb + NCW - 1) / NCW;
   const int np_run = T / TS + 1;  // staging passes that reach row T (the zero row); T < NP TS is the launcher's condition
   const int64_t n_groups = A.Sp / NS;
   const uint32_t row_stride = (uint32_t)A.Sp * TC;  // 32-bit element offsets (the launcher checks T * Sp * 32 < 2^31)
@@ -96,7 +100,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
   if (loader) {
     // =========================================== loader wavefronts ===========================================
     // thread -> (time step of the pass, sequence, 8-byte chunk); its four channels are fixed
-    const int lt = threadIdx.x - 256;
+    const int lt = threadIdx.x - 64 * NCW;
     const int tq = lt / (NS * 8), sq = (lt % (NS * 8)) >> 3, ch = lt & 7;
     float k0[4], k1[4];                        // BN_IN / COMB: scale, shift of the producer's BatchNorm
     float bm[4], br[4], bs[4], c1[4], c2[4];  // BWD2: mean, rstd, scale, mean g, mean g xhat
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
     // states at the join, and with loads and the staging's stores on one counter that merge becomes s_waitcnt vmcnt(0)
     // in front of EVERY load (measured: the seven loads of a tile took 10,000 cycles to issue, one after the other).
     // Passes beyond the window (T < 24) stage zero rows nobody reads.
-    const int tapw = wv - 4;                     // WGRAD: this wavefront's tap
+    const int tapw = wv - NCW;                   // WGRAD: this wavefront's tap
     const int shw = (TK - 1 - tapw) * A.dil;
     const int g = lane >> 4, q = lane & 15, kh = g >> 1, mh = g & 1;
     // The round's four column blocks, straight-line (a block past the last one, or a tap that lies behind the window,
@@ -187,8 +191,8 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
     auto wgrad_round = [&](int r, const uint16_t* im) DOF_INLINE_LAMBDA {
       dof_bf16x8 wa[2][3], wb[2][3];
       auto wrequest = [&](int w2, int slot_i) DOF_INLINE_LAMBDA {
-        const int t02 = (4 * r + w2) * TPC;
-        const uint16_t* slot = &ring[((r & 1) * 4 + w2) * 3 * TB_RING];
+        const int t02 = (NCW * r + w2) * TPC;
+        const uint16_t* slot = &ring[((r & 1) * NCW + w2) * 3 * TB_RING];
         uint32_t aw[3][4], bw[3][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -213,9 +217,9 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
       };
       wrequest(0, 0);
 #pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) {
+      for (int w2 = 0; w2 < NCW; ++w2) {
         const int c = w2 & 1;
-        if (w2 + 1 < 4) wrequest(w2 + 1, c ^ 1);
+        if (w2 + 1 < NCW) wrequest(w2 + 1, c ^ 1);
         DOF_SCHED_FENCE();
         accw = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][2], accw);
         accw2 = DOF_MFMA_32x32x16_BF16(wa[c][2], wb[c][0], accw2);
@@ -232,12 +236,12 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
     int k = 0;
     for (int64_t grp = g0;; grp += gs, ++k) {
       const bool have = grp < n_groups;  // tile k exists (the last iteration only lets the compute wavefronts finish)
-      TCN_STAMP(128 + 16 * (wv - 4) + 0);
+      TCN_STAMP(128 + 16 * (wv - NCW) + 0);
       if (have) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) stage(u, grp, k & 1);
       }
-      TCN_STAMP(128 + 16 * (wv - 4) + 1);
+      TCN_STAMP(128 + 16 * (wv - NCW) + 1);
       // tile k + 1's loads (a tile past the end re-reads the last one).  WGRAD: behind the first round barrier -- the CU's
       // vector-memory queue is full at this point of a tile and issuing fourteen loads takes ~2,000 cycles, which the
       // compute wavefronts would otherwise spend waiting at that barrier
@@ -254,12 +258,12 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
             for (int u = 0; u < NP; ++u) issue(u, grp + gs);
           }
           wgrad_round(r, im);
-          TCN_STAMP(128 + 16 * (wv - 4) + 4 + r);
+          TCN_STAMP(128 + 16 * (wv - NCW) + 4 + r);
         }
       }
-      TCN_STAMP(128 + 16 * (wv - 4) + 2);
+      TCN_STAMP(128 + 16 * (wv - NCW) + 2);
       __syncthreads();  // tile k - 1 is consumed, tile k is staged
-      TCN_STAMP(128 + 16 * (wv - 4) + 3);
+      TCN_STAMP(128 + 16 * (wv - NCW) + 3);
       if (!have) break;
     }
   } else {
@@ -268,7 +272,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
     const int sl = i % NS, tsub = i / NS;  // the lane's sequence of the tile and its row of the column block
     // A operands: for tap j, piece p, channel half ct the 16 x 32 weight block of output channels ct 16 + (lane & 15), input
     // channels kk 8 .. + 7.  Compute wavefront j cuts tap j's.
-    {
+    if (wv < TK) {
       const int j = wv;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
@@ -290,9 +294,9 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
           tb_st8(dst + 4, s1w[p][0], s1w[p][1]);
         }
       }
-      if (WGRAD) {  // the ring is read before every slot has been written once (short last round): no NaN patterns in it
-        for (int e = lane + 64 * wv; e < 2 * 4 * 3 * TB_RING / 2; e += 256) reinterpret_cast<uint32_t*>(ring)[e] = 0u;
-      }
+    }
+    if (WGRAD) {  // the ring is read before every slot has been written once (short last round): no NaN patterns in it
+      for (int e = lane + 64 * wv; e < 2 * NCW * 3 * TB_RING / 2; e += 64 * NCW) reinterpret_cast<uint32_t*>(ring)[e] = 0u;
     }
     const uint16_t* wl = &wlds[lane * 8];
     // the lane's output channels: ct 16 + kk 4 + q
@@ -321,14 +325,14 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
       // gradient of its sequences
       float4 skl[2];
       float dfe[2][4];
-      const bool own_last = TAIL && A.tail_dfeat != nullptr && wv == ((n_cb - 1) & 3);
+      const bool own_last = TAIL && A.tail_dfeat != nullptr && wv == ((n_cb - 1) % NCW);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         skl[ct] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dfe[ct][q] = 0.0f;
       }
-      constexpr int PD = (TAIL && WGRAD) ? 3 : 4;   // rounds requested ahead (three tensors x four rounds do not fit the registers)
+      constexpr int PD = (TAIL && WGRAD && MAXR > 3) ? 3 : MAXR;   // rounds requested ahead (three tensors x four rounds do not fit the registers)
       float4 pre4[PD][2], tsv4[PD][2], xo4[PD][2];
       uint32_t tmw4[PD];
 #pragma unroll
@@ -342,7 +346,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
         float4 (&tsv)[2] = tsv4[r % PD];
         float4 (&xo)[2] = xo4[r % PD];
         uint32_t& tmw = tmw4[r % PD];
-        const int cb = 4 * r + wv;
+        const int cb = NCW * r + wv;
         const int t = (cb < n_cb ? cb : n_cb - 1) * TPC + tsub;
         const uint32_t sv = (uint32_t)(ok_s ? s : s0);  // padded lanes read a valid row and ignore it
         const uint32_t tv = (uint32_t)(t < T ? t : T - 1);
@@ -360,7 +364,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
         const float4 (&tsv)[2] = tsv4[r % PD];
         const float4 (&xo)[2] = xo4[r % PD];
         const uint32_t tmw = tmw4[r % PD];
-        const int cb = 4 * r + wv;
+        const int cb = NCW * r + wv;
         TCN_STAMP(32 * wv + 8 * r + 0);
         if (cb < n_cb) {
           const int t0 = cb * TPC, t = t0 + tsub;
@@ -482,7 +486,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
             if (WGRAD) {  // every lane writes its four channels (zeros for padded sequences / rows behind the window)
               uint32_t pw[3][2];
               dof_split3x4(xw, pw);
-              uint16_t* slot = &ring[((r & 1) * 4 + wv) * 3 * TB_RING];
+              uint16_t* slot = &ring[((r & 1) * NCW + wv) * 3 * TB_RING];
               const int eo = tb_ring_off(i, ct * 4 + kk);
 #pragma unroll
               for (int p = 0; p < 3; ++p) tb_st8(&slot[p * TB_RING + eo], pw[p][0], pw[p][1]);
@@ -491,7 +495,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
           if (!REVERSE && ok) n_rows += 1.0f;
         }
         TCN_STAMP(32 * wv + 8 * r + 2);
-        if (r + PD < 4) prefetch(r + PD);   // (this round's registers are free)
+        if (r + PD < MAXR) prefetch(r + PD);   // (this round's registers are free)
         if (WGRAD) {
           __syncthreads();  // the round's four ring slots are complete: the loader wavefronts take the weight-gradient phase
           TCN_STAMP(32 * wv + 8 * r + 3);
@@ -512,15 +516,16 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
           for (int q = 0; q < 4; ++q) dfe[ct][q] = A.tail_dfeat[(int64_t)(ct * 16 + kk * 4 + q) * A.Sp + sv];
         }
       }
-      // at most four rounds (13 column blocks), nested so that every request dominates its use
-      static_assert((TB_ROWS / NS / TPC + 3) / 4 <= 4 || true, "");
+      // at most MAXR rounds (13 column blocks), nested so that every request dominates its use
       if (n_rounds > 0) {
         round(0);
         if (n_rounds > 1) {
           round(1);
-          if (n_rounds > 2) {
-            round(2);
-            if (n_rounds > 3) round(3);
+          if constexpr (MAXR > 2) {
+            if (n_rounds > 2) {
+              round(2);
+              if (n_rounds > 3) round(3);
+            }
           }
         }
       }
@@ -537,7 +542,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
       // tap (wv - 4)'s 32 x 32 tile.  D register v of lane l = row 8 (v / 4) + 4 (l >> 5) + v % 4, column l & 31; row m of the A
       // operand was output channel 16 (m >> 4) ... in the image's order: m = 16 mh + i <-> channel (i >> 2) 8 + mh 4 + (i & 3);
       // the columns (B operand, the ring's channel order kk 8 + ct 4 + q at 8-byte chunk kk 2 + ct) are channels in natural order
-      const int tap = wv - 4;
+      const int tap = wv - NCW;
       float* outp = A.wg_partials + (tap < 2 ? A.wg_part0 : A.wg_part1) + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
@@ -545,7 +550,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
         outp[oc * 65 + (tap & 1) * 32 + (lane & 31)] = accw[v] + accw2[v];
       }
       // bias gradient: channel sums of dy over the staging threads of a channel quad, fixed order
-      const int lt = threadIdx.x - 256;
+      const int lt = threadIdx.x - 64 * NCW;
 #pragma unroll
       for (int c = 0; c < 4; ++c) scratch[(lt >> 3) * 32 + (lt & 7) * 4 + c] = rs[c];
     }
@@ -591,7 +596,7 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
       const int c = threadIdx.x;
       float n = rec[c], mean = rec[32 + c], m2 = rec[64 + c];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) dof_stat_merge(n, mean, m2, rec[(w * 3 + 0) * 32 + c], rec[(w * 3 + 1) * 32 + c], rec[(w * 3 + 2) * 32 + c]);
+      for (int w = 1; w < NCW; ++w) dof_stat_merge(n, mean, m2, rec[(w * 3 + 0) * 32 + c], rec[(w * 3 + 1) * 32 + c], rec[(w * 3 + 2) * 32 + c]);
       float* out = A.partial + (int64_t)blockIdx.x * 3 * TC;
       out[c] = n;
       out[TC + c] = mean;
@@ -612,8 +617,11 @@ __global__ void __launch_bounds__(512, 2) k_tcn_conv_b(TcnConvArgs A) {
         }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * TC)
-      A.partial[(int64_t)blockIdx.x * 2 * TC + threadIdx.x] =
-          ((wsum[threadIdx.x] + wsum[64 + threadIdx.x]) + wsum[128 + threadIdx.x]) + wsum[192 + threadIdx.x];
+    if (threadIdx.x < 2 * TC) {
+      float acc = wsum[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < NCW; ++w) acc += wsum[64 * w + threadIdx.x];
+      A.partial[(int64_t)blockIdx.x * 2 * TC + threadIdx.x] = acc;
+    }
   }
 }
