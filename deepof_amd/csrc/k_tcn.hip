@@ -1389,7 +1389,8 @@ int dof_tcn_wgrad_fused(int T, int64_t Sp) {
 // the fused data-gradient + weight-gradient variants (A.wg_partials set)
 // (NCW = 4 compute wavefronts everywhere.  Eight -- 768 threads, two compute wavefronts per SIMD -- were built and measured:
 //  the variants without the weight gradient gained 7 - 11 % in isolation (forward BN_IN 204 -> 181 us) and nothing in the C4 step
-//  (50.8 against 50.2 ms); the fused variants spill 67 - 158 registers under the 168-register cap.  EXPERIMENTS.md, round 6.)
+//  (50.8 against 50.2 ms); the fused variants spill 67 - 158 registers under the 168-register cap -- conv2's, put on a register
+//  diet (one operand set, one accumulator: still 20 spilled), ran 524 us against 387.  EXPERIMENTS.md, round 6.)
 #define TCT_LAUNCH_WG(TAIL)                                                                               \
   do {                                                                                                    \
     if (tct_ns(A.T) == 8) DOF_LAUNCH((k_tcn_conv_b<true, false, true, true, TAIL, false, true, 8>), (nbt), (512), st, A); \

@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b
     // that waits for its own previous result costs its full latency) and block w2 + 1's twelve transposing reads are
     // requested before block w2's six matrix instructions.
     auto wgrad_round = [&](int r, const uint16_t* im) DOF_INLINE_LAMBDA {
-      dof_bf16x8 wa[2][3], wb[2][3];
+      constexpr bool WDB = NCW == 4;   // operands one block ahead (NCW = 8: the 168-register cap leaves room for one set only)
+      dof_bf16x8 wa[WDB ? 2 : 1][3], wb[WDB ? 2 : 1][3];
       auto wrequest = [&](int w2, int slot_i) DOF_INLINE_LAMBDA {
         const int t02 = (NCW * r + w2) * TPC;
         const uint16_t* slot = &ring[((r & 1) * NCW + w2) * 3 * TB_RING];
@@ -215,18 +216,31 @@ __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b
           wb[slot_i][p] = dof_mk_bf16x8(bw[p][0], bw[p][1], bw[p][2], bw[p][3]);
         }
       };
-      wrequest(0, 0);
+      if (WDB) wrequest(0, 0);
 #pragma unroll
       for (int w2 = 0; w2 < NCW; ++w2) {
-        const int c = w2 & 1;
-        if (w2 + 1 < NCW) wrequest(w2 + 1, c ^ 1);
+        const int c = WDB ? (w2 & 1) : 0;
+        if (WDB) {
+          if (w2 + 1 < NCW) wrequest(w2 + 1, c ^ 1);
+        } else {
+          wrequest(w2, 0);
+        }
         DOF_SCHED_FENCE();
-        accw = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][2], accw);
-        accw2 = DOF_MFMA_32x32x16_BF16(wa[c][2], wb[c][0], accw2);
-        accw = DOF_MFMA_32x32x16_BF16(wa[c][1], wb[c][1], accw);
-        accw2 = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][1], accw2);
-        accw = DOF_MFMA_32x32x16_BF16(wa[c][1], wb[c][0], accw);
-        accw2 = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][0], accw2);
+        if (WDB) {
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][2], accw);
+          accw2 = DOF_MFMA_32x32x16_BF16(wa[c][2], wb[c][0], accw2);
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][1], wb[c][1], accw);
+          accw2 = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][1], accw2);
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][1], wb[c][0], accw);
+          accw2 = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][0], accw2);
+        } else {   // one accumulator: the SIMD's two compute wavefronts fill the matrix pipe between these
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][2], accw);
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][2], wb[c][0], accw);
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][1], wb[c][1], accw);
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][1], accw);
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][1], wb[c][0], accw);
+          accw = DOF_MFMA_32x32x16_BF16(wa[c][0], wb[c][0], accw);
+        }
         DOF_SCHED_FENCE();
       }
     };
@@ -376,18 +390,23 @@ __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b
           // a branch would cut the matrix phase into basic blocks and the LDS requests could not be placed ahead of the
           // previous tap's matrix instructions); tap j + 1's nine operands (three pieces of B, three pieces x two halves of A)
           // are requested before tap j's twelve matrix instructions.
-          dof_bf16x8 bq[2][3], aq[2][3][2];
+          constexpr bool ADB = NCW == 4;   // NCW = 8: the weights of a tap are requested with the tap (one register set)
+          dof_bf16x8 bq[2][3], aq[ADB ? 2 : 1][3][2];
+          auto request_a = [&](int j, int slot) DOF_INLINE_LAMBDA {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              aq[slot][p][0] = dof_ld_bf16x8_16(&wl[((j * 3 + p) * 2 + 0) * 512]);
+              aq[slot][p][1] = dof_ld_bf16x8_16(&wl[((j * 3 + p) * 2 + 1) * 512]);
+            }
+          };
           auto request = [&](int j, int slot) DOF_INLINE_LAMBDA {
             const int sh = REVERSE ? (TK - 1 - j) * A.dil : -(TK - 1 - j) * A.dil;
             const int tt = t + sh;
             const int row = ((tt >= 0 && tt < T) ? tt : T) * NS + sl;
             const int eo = tb_off(row, kk);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-              bq[slot][p] = dof_ld_bf16x8_16(&im[p * TB_PLANE + eo]);
-              aq[slot][p][0] = dof_ld_bf16x8_16(&wl[((j * 3 + p) * 2 + 0) * 512]);
-              aq[slot][p][1] = dof_ld_bf16x8_16(&wl[((j * 3 + p) * 2 + 1) * 512]);
-            }
+            for (int p = 0; p < 3; ++p) bq[slot][p] = dof_ld_bf16x8_16(&im[p * TB_PLANE + eo]);
+            if (ADB) request_a(j, slot);
           };
           // the taps that reach into the window for some row of the block are the last NT ones (wave-uniform); one
           // straight-line instance per count (a dilation-8 block of a 25-step window has 2.1 of 4 on average)
@@ -397,21 +416,22 @@ __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
               const int c = jj & 1;
+              if (!ADB) request_a(TK - NT + jj, 0);
               if (jj + 1 < NT) request(TK - NT + jj + 1, c ^ 1);
               DOF_SCHED_FENCE();  // (left alone the scheduler sinks every request to just in front of its use: ~12 exposed LDS round trips per block)
               // small terms first; the two channel halves are independent accumulator chains
-              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][2], acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][2], acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][2][0], bq[c][0], acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][2][1], bq[c][0], acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][1][0], bq[c][1], acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][1][1], bq[c][1], acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][1], acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][1], acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][1][0], bq[c][0], acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][1][1], bq[c][0], acc[1]);
-              acc[0] = DOF_MFMA_16x16x32_BF16(aq[c][0][0], bq[c][0], acc[0]);
-              acc[1] = DOF_MFMA_16x16x32_BF16(aq[c][0][1], bq[c][0], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][0][0], bq[c][2], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][0][1], bq[c][2], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][2][0], bq[c][0], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][2][1], bq[c][0], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][1][0], bq[c][1], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][1][1], bq[c][1], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][0][0], bq[c][1], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][0][1], bq[c][1], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][1][0], bq[c][0], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][1][1], bq[c][0], acc[1]);
+              acc[0] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][0][0], bq[c][0], acc[0]);
+              acc[1] = DOF_MFMA_16x16x32_BF16(aq[ADB ? c : 0][0][1], bq[c][0], acc[1]);
               DOF_SCHED_FENCE();
             }
           };
