@@ -914,24 +914,42 @@ __global__ void __launch_bounds__(256) k_gru3_fwd(Gru8Args A0, Gru8Args A1, int 
 #include "k_grumx.inc.h"    // k_grumx_fwd / _bwd (latent 16 / 32)
 
 
-template <int IN, int HID, bool BCAST>
+// WG (round 6, the padded lane groups' layers): the layer's weight gradients in the same launch, the way k_gru16_bwd_fused
+// does it for latent 8.  A wavefront's lanes are (unit, sequence) pairs -- the operand layout of v_mfma_f32_16x16x4_f32 --
+// so dW_ih[g] += dG_g x_t^T and dW_hh[g] += dG_g h_{t-1}^T are 3 (M + 1) matrix instructions per step straight from the
+// registers that hold dG, x_t and h_{t-1} (the matrix pipe idles beside the VALU recurrence; the generic k_outer job spent
+// the same instructions in a pass of its own: 239 us of the 1.16 ms latent-6 step).  Groups of 8 lanes put two sequences
+// into a tile's sixteen rows: the two diagonal 8 x 8 blocks of the result are the sums, the off-diagonal ones (products
+// across sequences) are dropped.  dG is not written.  The workgroup's sums go out as ONE partial tile in k_outer's layout
+// (rows 4 u + gate, columns = the job's operand tiles, column 64 = row sums), so k_outer_finalize's fixed-order sum
+// applies unchanged.  The time loop runs over the whole window for every lane (the matrix instructions ignore EXEC): a
+// finished or absent sequence holds zero operands.  Cost: 24 - 48 accumulator registers take the kernel from 3 to 2
+// wavefronts per SIMD and the matrix instructions' issue slots sit inside the dependent chain of a step (measured at
+// latent 6: GRU(12 -> 12) 93 -> 106 us, GRU(24 -> 6) 52 -> 93 us per launch, against k_outer 239 -> 36 us; the step 1.145 ->
+// 1.088 ms, latent 4 0.830 -> 0.751 ms).  __launch_bounds__(256, 3) spills 50 - 155 registers: not used.
+template <int IN, int HID, bool BCAST, bool WG = false>
 __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, const float* __restrict__ wih0,
                                                   const float* __restrict__ whh0, const float* __restrict__ wih1,
                                                   const float* __restrict__ whh1, const float* __restrict__ O,
                                                   float* __restrict__ GS, const float* __restrict__ dO,
                                                   const float* __restrict__ dHfin, float* __restrict__ dX, int T,
-                                                  int64_t S, int64_t Sp) {
+                                                  int64_t S, int64_t Sp, const float* __restrict__ X,
+                                                  float* __restrict__ wg_part0, float* __restrict__ wg_part1) {
   // (round 6: padded lane groups, see k_gru3_fwd -- lanes u >= HID hold zero gate gradients; a lane owns the input columns
   //  M u .. M u + M - 1 that exist)
   constexpr int G = HID <= 8 ? 8 : 16;
   constexpr int M = (IN + G - 1) / G;
+  constexpr int NXT = (IN + 15) / 16;   // WG: operand tiles of x in the k_outer job (the h tile follows them)
   static_assert(HID <= 16, "lane-per-unit recurrence: at most 16 hidden units");
+  static_assert(!WG || (!BCAST && NXT + 1 <= 4), "fused weight gradient: a time-varying input of at most 48 columns");
+  __shared__ float red[WG ? 64 * 65 : 1];
   const int ul = threadIdx.x % G;
   const bool unit = ul < HID;
   const int u = unit ? ul : 0;
   const int64_t s = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
   const int dir = blockIdx.y;
-  if (s >= S) return;
+  const bool valid = s < S;
+  if (!WG && !valid) return;
   const float* __restrict__ wih = dir ? wih1 : wih0;
   const float* __restrict__ whh = dir ? whh1 : whh0;
   // transposed views: column u of W_hh, columns M ul + m of W_ih
@@ -955,35 +973,58 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
   }
   float* __restrict__ gs = GS + (int64_t)dir * T * 4 * HID * Sp;
   float* __restrict__ dx_out = dX + (int64_t)dir * (BCAST ? 1 : T) * IN * Sp;
-  const int n = len[s];
-  float dh = (dHfin && n > 0 && unit) ? dHfin[(int64_t)(dir * HID + u) * Sp + s] : 0.0f;
+  const int n = valid ? len[s] : 0;
+  const float dhfin = (dHfin && n > 0 && unit) ? dHfin[(int64_t)(dir * HID + u) * Sp + s] : 0.0f;
+  float dh = WG ? 0.0f : dhfin;   // WG: added at the lane's own last step (the loop starts at the window's)
   float dxacc[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) dxacc[m] = 0.0f;
+  dof_f32x4 accx[WG ? M : 1][3], acch[3];
+  float rsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    acch[g] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int m = 0; m < (WG ? M : 1); ++m) accx[m][g] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
   // loads of step - PF are issued before the arithmetic of step (see k_gru16_bwd_fused)
   constexpr int PF = 3;
-  float nx_gate[PF][4], nx_hp[PF], nx_do[PF];
+  float nx_gate[PF][4], nx_hp[PF], nx_do[PF], nx_x[PF][WG ? M : 1];
 #pragma unroll
   for (int d = 0; d < PF; ++d) {
     nx_gate[d][0] = nx_gate[d][1] = nx_gate[d][2] = nx_gate[d][3] = 0.0f;
     nx_hp[d] = nx_do[d] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < (WG ? M : 1); ++m) nx_x[d][m] = 0.0f;
   }
   auto issue_loads = [&](auto slot_c, int step) {
     constexpr int slot = decltype(slot_c)::value;
-    if (step >= 0) {
+    if (step >= 0 && step < n) {
       const int t = dir ? (n - 1 - step) : step;
       const int tp = dir ? t + 1 : t - 1;
       dof_ld_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), nx_gate[slot]);
       nx_hp[slot] = (step > 0) ? O[ACT(tp, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;
       nx_do[slot] = (dO && unit) ? dO[ACT(t, dir * HID + u, 2 * HID, Sp, s)] : 0.0f;   // (idle lane: dht = 0, every gate gradient 0)
+      if constexpr (WG) {
+        if constexpr (M == 4 && IN == 4 * G) {
+          dof_ld_row<4>(X + ACT(t, 4 * ul, IN, Sp, s), nx_x[slot]);
+        } else {
+#pragma unroll
+          for (int m = 0; m < M; ++m) nx_x[slot][m] = col[m] ? X[ACT(t, M * ul + m, IN, Sp, s)] : 0.0f;
+        }
+      }
     }
   };
   auto do_step = [&](auto slot_c, int step) {
     constexpr int slot = decltype(slot_c)::value;
+    const bool active = !WG || step < n;
     const int t = dir ? (n - 1 - step) : step;
     const float r = nx_gate[slot][0], z = nx_gate[slot][1], nn = nx_gate[slot][2], ahn = nx_gate[slot][3];
     const float hp = nx_hp[slot];
-    const float dht = dh + nx_do[slot];
+    const float dht = dh + nx_do[slot] + ((WG && step == n - 1) ? dhfin : 0.0f);
+    float xv[WG ? M : 1];
+#pragma unroll
+    for (int m = 0; m < (WG ? M : 1); ++m) xv[m] = nx_x[slot][m];
     issue_loads(slot_c, step - PF);
     const float dn = dht * (1.0f - z);
     const float dz = dht * (hp - nn);
@@ -992,8 +1033,26 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
     const float g_z = dz * z * (1.0f - z);
     const float g_n = dnp;
     const float g_h = dnp * r;
-    const float dg4[4] = {g_r, g_z, g_n, g_h};
-    if (unit) dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), dg4);
+    if constexpr (WG) {
+      // an inactive step's slot holds the zeros it was created with or an already consumed step: dht = 0 makes every gate
+      // gradient 0 for a lane that has not reached its sequence yet; the operands are cleared explicitly all the same
+      const float a_r = active ? g_r : 0.0f, a_z = active ? g_z : 0.0f, a_n = active ? g_n : 0.0f, a_h = active ? g_h : 0.0f;
+      const float bh = (active && unit) ? hp : 0.0f;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const float bx = (active && col[m]) ? xv[m] : 0.0f;
+        accx[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r, bx, accx[m][0], 0, 0, 0);
+        accx[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_z, bx, accx[m][1], 0, 0, 0);
+        accx[m][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_n, bx, accx[m][2], 0, 0, 0);
+      }
+      acch[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r, bh, acch[0], 0, 0, 0);
+      acch[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_z, bh, acch[1], 0, 0, 0);
+      acch[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, bh, acch[2], 0, 0, 0);
+      rsum[0] += a_r; rsum[1] += a_z; rsum[2] += a_n; rsum[3] += a_h;
+    } else {
+      const float dg4[4] = {g_r, g_z, g_n, g_h};
+      if (unit) dof_st_row<4>(gs + ACT(t, 4 * u, 4 * HID, Sp, s), dg4);
+    }
     float dhp = dht * z;
     float dx[M];
 #pragma unroll
@@ -1014,10 +1073,12 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
         dx[m] = fmaf(xn[m][j], b_n, dx[m]);
       }
     });
-    dh = unit ? dhp : 0.0f;
+    dh = (unit && active) ? dhp : 0.0f;
     if (BCAST) {
 #pragma unroll
       for (int m = 0; m < M; ++m) dxacc[m] += dx[m];
+    } else if (!active) {
+      // (WG: a step in front of the lane's sequence -- nothing to store)
     } else if (M == 4 && IN == 4 * G) {  // lane u owns input columns 4u .. 4u+3: one 16-byte store
       dof_st_row<4>(dx_out + ACT(t, 4 * ul, IN, Sp, s), dx);
     } else {
@@ -1026,20 +1087,77 @@ __global__ void __launch_bounds__(256) k_gru3_bwd(const int* __restrict__ len, c
         if (col[m]) dx_out[ACT(t, M * ul + m, IN, Sp, s)] = dx[m];
     }
   };
-  dof_static_for<PF>([&](auto d) { issue_loads(d, n - 1 - decltype(d)::value); });
-  for (int step = n - 1; step >= 0; step -= PF) {
+  const int nloop = WG ? T : n;
+  dof_static_for<PF>([&](auto d) { issue_loads(d, nloop - 1 - decltype(d)::value); });
+  for (int step = nloop - 1; step >= 0; step -= PF) {
     dof_static_for<PF>([&](auto d) {
       const int st = step - decltype(d)::value;
       if (st >= 0) do_step(d, st);
     });
   }
+  if (valid) {
 #pragma unroll
-  for (int m = 0; m < M; ++m) {
-    if (!col[m]) continue;
-    if (BCAST) {
-      dx_out[(int64_t)(M * ul + m) * Sp + s] = dxacc[m];
-    } else {
-      for (int t = n; t < T; ++t) dx_out[ACT(t, M * ul + m, IN, Sp, s)] = 0.0f;
+    for (int m = 0; m < M; ++m) {
+      if (!col[m]) continue;
+      if (BCAST) {
+        dx_out[(int64_t)(M * ul + m) * Sp + s] = dxacc[m];
+      } else {
+        for (int t = n; t < T; ++t) dx_out[ACT(t, M * ul + m, IN, Sp, s)] = 0.0f;
+      }
+    }
+  }
+  if constexpr (WG) {
+    // the workgroup's partial tile: the four wavefronts in order through one LDS tile (deterministic)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < 64 * 65; e += 256) red[e] = 0.0f;
+    // row sums over the wavefront's sequences (lanes that share a unit)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = rsum[g];
+#pragma unroll
+      for (int d = G; d < 64; d <<= 1) v += __shfl_xor(v, d);
+      rsum[g] = v;
+    }
+    __syncthreads();
+    // D of v_mfma_f32_16x16x4: the lane holds rows (lane >> 4) 4 + r, column lane & 15
+    const int dj = lane & 15;
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+        if (lane < G && unit) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) red[(4 * ul + g) * 65 + 64] += rsum[g];
+        }
+#pragma unroll
+        for (int half = 0; half < (G == 8 ? 2 : 1); ++half) {   // groups of 8: the two diagonal blocks, one after the other
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int di = (lane >> 4) * 4 + r4;
+            const bool mine = G == 16 || ((di >> 3) == half && (dj >> 3) == half);
+            const int ui = G == 16 ? di : (di & 7), uj = G == 16 ? dj : (dj & 7);
+            if (mine && ui < HID) {
+#pragma unroll
+              for (int m = 0; m < M; ++m) {
+                const int c = M * uj + m;
+                if (c < IN) {
+#pragma unroll
+                  for (int g = 0; g < 3; ++g) red[(4 * ui + g) * 65 + c] += accx[m][g][r4];
+                }
+              }
+              if (uj < HID) {
+                red[(4 * ui + 0) * 65 + 16 * NXT + uj] += acch[0][r4];
+                red[(4 * ui + 1) * 65 + 16 * NXT + uj] += acch[1][r4];
+                red[(4 * ui + 3) * 65 + 16 * NXT + uj] += acch[2][r4];
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float* __restrict__ outp = (dir ? wg_part1 : wg_part0) + (int64_t)blockIdx.x * DOF_OUTER_PARTIAL_FLOATS;
+    for (int e = threadIdx.x; e < 4 * HID * 65; e += 256) {
+      const int col_e = e % 65;
+      if (col_e < 16 * NXT + HID || col_e == 64) outp[e] = red[e];
     }
   }
 }
@@ -1867,10 +1985,12 @@ struct EncConvWgArgs {
 };
 template <int C1, int F>
 __device__ __forceinline__ void enc_conv_wgrad_body(const EncConvWgArgs& A, int T, float* __restrict__ partials, float* red) {
-  constexpr int Q = C1 / 4, SL = 256 / Q, NV = 5 * F;   // channel quads, sequence slots per workgroup, values per channel
-  static_assert(256 % Q == 0 && (Q & (Q - 1)) == 0 || Q == 3, "channel quads");
+  // channel quads (padded to a lane-group size QP: latent 6 = 3 quads in groups of 4, the fourth lane idles), sequence
+  // slots per workgroup, values per channel
+  constexpr int Q = C1 / 4, QP = Q <= 2 ? Q : Q <= 4 ? 4 : 8, SL = 256 / QP, NV = 5 * F;
+  static_assert(C1 % 4 == 0 && Q <= 8, "channel quads");
   const int tid = threadIdx.x;
-  const int c4 = (tid % Q) * 4, sl = tid / Q;
+  const int c4 = (tid % QP) * 4, sl = (tid % QP) < Q ? tid / QP : SL;
   float acc[4][NV];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -1910,14 +2030,14 @@ __device__ __forceinline__ void enc_conv_wgrad_body(const EncConvWgArgs& A, int 
   // the sequence slots of a wavefront (fixed butterfly over the lanes that share a channel quad), then the four
   // wavefronts in order
   const int wave = tid >> 6, lane = tid & 63;
-  if constexpr ((Q & (Q - 1)) == 0) {
+  {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         float x = acc[c][v];
 #pragma unroll
-        for (int d = Q; d < 64; d <<= 1) x += __shfl_xor(x, d);
+        for (int d = QP; d < 64; d <<= 1) x += __shfl_xor(x, d);
         acc[c][v] = x;
       }
     if (lane < Q) {
@@ -2204,31 +2324,54 @@ int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW 
   return dof_check_launch("k_gru_fwd");
 }
 
+// Workgroups per direction of the lane-per-unit backward kernel when it also produces the layer's weight gradients (one
+// partial tile each; 0: the layer's gradients are a k_outer job).  DOF_GRU_WGRAD_FUSED=0 keeps the job.
+int dof_gru3_wg_blocks(int L, int kind, int64_t S) {
+  static const int on = [] {
+    const char* e = getenv("DOF_GRU_WGRAD_FUSED");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  if (!on || L == 8 || kind == 2 || !dof_gru_lane_per_unit(L, kind)) return 0;
+  const int hid = kind == 0 ? 2 * L : L;
+  return (int)dof_cdiv(S, 256 / (hid <= 8 ? 8 : 16));
+}
 int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* O, float* GS, const float* dO,
-                       const float* dHfin, float* dX, int T, int64_t S, int64_t Sp, hipStream_t st) {
+                       const float* dHfin, float* dX, int T, int64_t S, int64_t Sp, hipStream_t st, const float* X,
+                       float* wg_part0, float* wg_part1) {
   if (L == 8) {
-    if (kind == 0) DOF_LAUNCH((k_gru3_bwd<16, 16, false>), (dof_cdiv(S, 16), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
-    else if (kind == 1) DOF_LAUNCH((k_gru3_bwd<32, 8, false>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
-    else DOF_LAUNCH((k_gru3_bwd<8, 8, true>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp);
+    if (kind == 0) DOF_LAUNCH((k_gru3_bwd<16, 16, false>), (dof_cdiv(S, 16), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    else if (kind == 1) DOF_LAUNCH((k_gru3_bwd<32, 8, false>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    else DOF_LAUNCH((k_gru3_bwd<8, 8, true>), (dof_cdiv(S, 32), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     return dof_check_launch("k_gru3_bwd");
   }
   if (dof_gru_lane_per_unit(L, kind)) {
-#define GRU3_BWD(IN_, HID_, BC_) DOF_LAUNCH((k_gru3_bwd<IN_, HID_, BC_>), (dof_cdiv(S, 256 / ((HID_) <= 8 ? 8 : 16)), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp)
+    const bool wg = wg_part0 != nullptr;
+    if (wg && (!X || !wg_part1 || dof_gru3_wg_blocks(L, kind, S) == 0)) {
+      dof_set_error("GRU backward: fused weight gradient asked for a layer that has none (latent %d, kind %d)", L, kind);
+      return DOF_ERR_ARG;
+    }
+#define GRU3_BWD(IN_, HID_, BC_) DOF_LAUNCH((k_gru3_bwd<IN_, HID_, BC_>), (dof_cdiv(S, 256 / ((HID_) <= 8 ? 8 : 16)), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp, (const float*)nullptr, (float*)nullptr, (float*)nullptr)
+#define GRU3_BWD_W(IN_, HID_) \
+  do { \
+    if (wg) DOF_LAUNCH((k_gru3_bwd<IN_, HID_, false, true>), (dof_cdiv(S, 256 / ((HID_) <= 8 ? 8 : 16)), 2), (256), st, len, W.wih0, W.whh0, W.wih1, W.whh1, O, GS, dO, dHfin, dX, T, S, Sp, X, wg_part0, wg_part1); \
+    else GRU3_BWD(IN_, HID_, false); \
+  } while (0)
 #define GRU3_BWD_L(LL_) \
   case LL_: \
-    if (kind == 0) GRU3_BWD(2 * LL_, 2 * LL_, false); \
-    else if (kind == 1) GRU3_BWD(4 * LL_, LL_, false); \
+    if (kind == 0) GRU3_BWD_W(2 * LL_, 2 * LL_); \
+    else if (kind == 1) GRU3_BWD_W(4 * LL_, LL_); \
     else GRU3_BWD(LL_, LL_, true); \
     break
     switch (L) {
       GRU3_BWD_L(4); GRU3_BWD_L(5); GRU3_BWD_L(6); GRU3_BWD_L(7);
-#define GRU3_BWD_H(LL_) case LL_: if (kind == 1) GRU3_BWD(4 * LL_, LL_, false); else GRU3_BWD(LL_, LL_, true); break
+#define GRU3_BWD_H(LL_) case LL_: if (kind == 1) GRU3_BWD_W(4 * LL_, LL_); else GRU3_BWD(LL_, LL_, true); break
       GRU3_BWD_H(9); GRU3_BWD_H(10);
       case 14: GRU3_BWD(14, 14, true); break;
 #undef GRU3_BWD_H
       default: return DOF_ERR_UNSUPPORTED;
     }
 #undef GRU3_BWD_L
+#undef GRU3_BWD_W
 #undef GRU3_BWD
     return dof_check_launch("k_gru3_bwd");
   }
@@ -2453,8 +2596,8 @@ int dof_launch_zero(float* p, int64_t n, hipStream_t st) {
 // both encoder streams' convolution weight gradients (C1 = 8, 16 or 32 channels: latent 4, 8, 16), partial tiles of
 // nblk[s] workgroups each at partials + part_off[s]
 int dof_enc_conv_wgrad_blocks(int C1, int64_t S) {
-  if (C1 != 8 && C1 != 16 && C1 != 32) return 0;   // (latent 6: 12 channels = 3 quads, not a lane-group size)
-  const int SL = 256 / (C1 / 4);
+  if (C1 != 8 && C1 != 12 && C1 != 16 && C1 != 32) return 0;
+  const int SL = C1 == 12 ? 64 : 256 / (C1 / 4);   // (latent 6: 12 channels = 3 quads in lane groups of 4)
   const int64_t nb = (S + SL - 1) / SL;
   return (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
 }
@@ -2470,6 +2613,7 @@ int dof_launch_enc_conv_wgrad(int C1, const float* const act[2], const float* co
     if ((unsigned)A[k].nblk > nb) nb = (unsigned)A[k].nblk;
   }
   if (C1 == 8) DOF_LAUNCH(k_enc_conv_wgrad<8>, (nb, 2), (256), st, A[0], A[1], T, partials);
+  else if (C1 == 12) DOF_LAUNCH(k_enc_conv_wgrad<12>, (nb, 2), (256), st, A[0], A[1], T, partials);
   else if (C1 == 16) DOF_LAUNCH(k_enc_conv_wgrad<16>, (nb, 2), (256), st, A[0], A[1], T, partials);
   else if (C1 == 32) DOF_LAUNCH(k_enc_conv_wgrad<32>, (nb, 2), (256), st, A[0], A[1], T, partials);
   else { dof_set_error("encoder conv weight gradient: %d channels", C1); return DOF_ERR_UNSUPPORTED; }

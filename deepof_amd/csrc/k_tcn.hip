@@ -48,8 +48,11 @@ __global__ void __launch_bounds__(256) k_tcn_in_conv(const float* __restrict__ x
                                                      const float* __restrict__ w,    // (32,F,4)
                                                      const float* __restrict__ bias, float* __restrict__ xs,  // [T][Sp][F]
                                                      float* __restrict__ y,          // [T][Sp][32]
-                                                     float* __restrict__ partial,    // [nblk][64]
-                                                     int T, int G, int64_t S, int64_t Sp, int dil) {
+                                                     float* __restrict__ partial,    // [nblk][64] sums, or [nblk][3][32] records
+                                                     int T, int G, int64_t S, int64_t Sp, int dil, int rec) {
+  // rec: the block's channel statistics as one mergeable (n, mean, M2) record per channel (k_tcn_stat_merge), from sums
+  // shifted by the block's first row -- the layer then needs no second pass over y (k_tcn_var)
+  __shared__ float kshift[TC], bsum[2 * TC];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float st[2 * TC];
 #pragma unroll
@@ -92,7 +95,34 @@ __global__ void __launch_bounds__(256) k_tcn_in_conv(const float* __restrict__ x
     }
     dof_st_row<TC>(y + ACT(to, 0, TC, Sp, s), out);
   }
-  dof_block_colsum<2 * TC>(st, partial + (int64_t)blockIdx.x * 2 * TC);
+  if (!rec) {
+    dof_block_colsum<2 * TC>(st, partial + (int64_t)blockIdx.x * 2 * TC);
+    return;
+  }
+  if (threadIdx.x == 0) {   // row 0 of a launched block always exists
+#pragma unroll
+    for (int o = 0; o < TC; ++o) kshift[o] = st[o];
+  }
+  __syncthreads();
+  const bool live = i < (int64_t)T * S;
+#pragma unroll
+  for (int o = 0; o < TC; ++o) {
+    const float dv = live ? st[o] - kshift[o] : 0.0f;
+    st[o] = dv;
+    st[TC + o] = dv * dv;
+  }
+  dof_block_colsum<2 * TC>(st, bsum);
+  __syncthreads();
+  if (threadIdx.x < TC) {
+    const int c = threadIdx.x;
+    const int64_t left = (int64_t)T * S - (int64_t)blockIdx.x * blockDim.x;
+    const float n = (float)(left < (int64_t)blockDim.x ? left : (int64_t)blockDim.x);
+    const float dm = bsum[c] / n;
+    float* r = partial + (int64_t)blockIdx.x * 3 * TC;
+    r[c] = n;
+    r[TC + c] = kshift[c] + dm;
+    r[2 * TC + c] = fmaxf(bsum[TC + c] - bsum[c] * dm, 0.0f);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1329,12 +1359,12 @@ int64_t dof_tcn_conv_waves(int T, int64_t Sp) {
 }
 
 int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float* bias, float* xs, float* y,
-                           float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st) {
+                           float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st, int records) {
   const unsigned nb = (unsigned)dof_tcn_row_blocks(T, S);
   if (F == 3) {
-    DOF_LAUNCH((k_tcn_in_conv<3>), (nb), (256), st, xin, w, bias, xs, y, partial, T, G, S, Sp, dil);
+    DOF_LAUNCH((k_tcn_in_conv<3>), (nb), (256), st, xin, w, bias, xs, y, partial, T, G, S, Sp, dil, records);
   } else if (F == 1) {
-    DOF_LAUNCH((k_tcn_in_conv<1>), (nb), (256), st, xin, w, bias, xs, y, partial, T, G, S, Sp, dil);
+    DOF_LAUNCH((k_tcn_in_conv<1>), (nb), (256), st, xin, w, bias, xs, y, partial, T, G, S, Sp, dil, records);
   } else {
     dof_set_error("features per group %d not supported (3 or 1)", F);
     return DOF_ERR_UNSUPPORTED;

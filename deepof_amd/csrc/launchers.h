@@ -24,7 +24,9 @@ bool dof_gru_lane_per_unit(int L, int kind);   // latent 4 / 5 / 6 (and 10's hid
 int dof_launch_gru_fwd(int L, int kind, const float* X, const int* len, DofGruW W, float* O, float* GS, int T,
                        int64_t S, int64_t Sp, hipStream_t st);
 int dof_launch_gru_bwd(int L, int kind, const int* len, DofGruW W, const float* O, float* GS, const float* dO,
-                       const float* dHfin, float* dX, int T, int64_t S, int64_t Sp, hipStream_t st);
+                       const float* dHfin, float* dX, int T, int64_t S, int64_t Sp, hipStream_t st, const float* X = nullptr,
+                       float* wg_part0 = nullptr, float* wg_part1 = nullptr);
+int dof_gru3_wg_blocks(int L, int kind, int64_t S);
 int dof_launch_ln_fwd(int L, int mult, const float* X, const float* gamma, const float* beta, float* Y, int T,
                       int64_t S, int64_t Sp, hipStream_t st);
 // fused GRU(16,16) backward + MFMA weight-gradient accumulation (latent 8)
@@ -80,7 +82,7 @@ int dof_launch_enc_conv_wgrad(int C1, const float* const act[2], const float* co
 int64_t dof_tcn_row_blocks(int T, int64_t S);   // partial rows written by the row-per-thread kernels
 int64_t dof_tcn_conv_waves(int T, int64_t Sp);  // partial rows written by the MFMA convolution (one per wave)
 int dof_launch_tcn_in_conv(int F, const float* xin, const float* w, const float* bias, float* xs, float* y,
-                           float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st);
+                           float* partial, int T, int G, int64_t S, int64_t Sp, int dil, hipStream_t st, int records = 0);
 int dof_tcn_onepass_stats();                         // always 0 since round 5 (the shifted one-pass sums are no longer selectable)
 int dof_tcn_conv32_resident(int T, int64_t Sp);               // 1: the 32 -> 32 convolutions run the time-resident kernel (it can fuse pass 2 of a BatchNorm backward)
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp);   // partial rows written by the 32 -> 32 convolution

@@ -200,6 +200,7 @@ struct DofVadePlan {
   int64_t ln3p, lnd2p, lnd1p, lnd_blocks, wgd2;
   int64_t partials, segs_tab, mask_tab, bc_tab;
   int64_t conv_wg_part[2] = {-1, -1};  // k_enc_conv_wgrad's partial tiles of the two streams (float offsets; -1: generic path)
+  int64_t gru_wg_part[2][2][2] = {{{-1, -1}, {-1, -1}}, {{-1, -1}, {-1, -1}}};  // [stream][layer][direction]: k_gru3_bwd<.., WG>'s partial tiles
   double* log_accum = nullptr;  // dof_vade_set_log_accumulator
   int64_t recon_partial2, vq_idx, vq_partial, vq_pop;   // VQ-VAE extras
   int64_t cl_zn, cl_inv, cl_rn, cl_rowstat, cl_partial, cl_blocks, cl_theta;  // contrastive loss scratch
@@ -569,7 +570,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     for (int k = 0; k < 16; ++k) t.bnp[k] = cv.take(4 * 32);
     const int64_t rows = dof_tcn_row_blocks(T, w.S), waves = dof_tcn_conv_waves(T, Sp);
     t.partial_rows = rows > waves ? rows : waves;
-    t.partial = cv.take(t.partial_rows * 64);
+    t.partial = cv.take(t.partial_rows * 96);   // [rows][64] sums or [rows][3][32] records
     t.sums = cv.take(128);  // (S1 | S2 | M2 of the fallback pass)
     t.coef = cv.take(64);
     for (int k = 0; k < 16; ++k) t.coefs[k] = cv.take(64);
@@ -867,8 +868,10 @@ struct JobBuilder {
 // One bidirectional GRU layer: per direction A = dG (4*HID rows), tiles = input channels + h_prev.
 // X_bcast: the layer input is a per-window vector [IN][Sp] repeated over time (decoder GRU1).
 // gate_minor: dG rows are unit-major (the lane-per-unit kernels of latent 8), see DofFinJob
+// ext_blocks > 0: the partial tiles of the two directions' jobs come from the layer's backward kernel (k_gru3_bwd<.., WG>,
+// ext_blocks workgroups per direction); their float offsets are returned in part_off[2]
 void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int IN, const float* O, int HID, int T,
-              int64_t Sp, const GruOff& g, bool gate_minor) {
+              int64_t Sp, const GruOff& g, bool gate_minor, int ext_blocks = 0, int64_t* part_off = nullptr) {
   const int gm = gate_minor ? HID : 0;
   if (4 * HID > 64 || (IN + 15) / 16 + 1 > 4) {
     // wide layers (latent 16: HID = 32 -> 128 gate rows; IN = 64 -> five operand tiles): the product is cut into row
@@ -907,7 +910,8 @@ void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int
   }
   for (int d = 0; d < 2; ++d) {
     const float* a = dG + (int64_t)d * T * 4 * HID * Sp;
-    const int job = jb.add_job(aos(a, 4 * HID, Sp), 4 * HID, T, Sp);
+    const int job = jb.add_job(aos(a, 4 * HID, Sp), 4 * HID, T, Sp, ext_blocks);
+    if (part_off) part_off[d] = ext_blocks > 0 ? jb.jobs[job].partial_off : -1;
     for (int c0 = 0; c0 < IN; c0 += 16)
       jb.add_tile(job, x_bcast ? soa(X, Sp, c0) : aos(X, IN, Sp, c0), IN - c0 < 16 ? IN - c0 : 16, 0);
     const int hh = jb.add_tile(job, aos(O, 2 * HID, Sp, d * HID), HID, d == 0 ? -1 : +1);
@@ -1166,8 +1170,12 @@ void build_jobs(DofVadePlan* p) {
           }
         }
       }
-      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1, L == 8 || dof_gru_lane_per_unit(L, 0));  // L == 8: fused in k_gru16_bwd_fused
-      if (L != 8 || !gru8_fused()) gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8 || dof_gru_lane_per_unit(L, 1));  // else: fused in k_gru8_bwd_fused
+      // (the padded-lane-group sizes: the layer's backward kernel writes the partial tiles itself, dof_gru3_wg_blocks)
+      p->gru_wg_part[s][0][0] = p->gru_wg_part[s][0][1] = p->gru_wg_part[s][1][0] = p->gru_wg_part[s][1][1] = -1;
+      if (L != 8) gru_jobs(jb, ws + w.g1, ws + w.c, false, C1, ws + w.o1, C1, T, Sp, b.g1, L == 8 || dof_gru_lane_per_unit(L, 0),
+                           dof_gru3_wg_blocks(L, 0, w.S), p->gru_wg_part[s][0]);  // L == 8: fused in k_gru16_bwd_fused
+      if (L != 8 || !gru8_fused()) gru_jobs(jb, ws + w.g2, ws + w.n1, false, 4 * L, ws + w.o2, L, T, Sp, b.g2, L == 8 || dof_gru_lane_per_unit(L, 1),
+                                            L != 8 ? dof_gru3_wg_blocks(L, 1, w.S) : 0, p->gru_wg_part[s][1]);  // else: fused in k_gru8_bwd_fused
       cens_jobs(p, jb, s);
     }
     // final dense (L,J): A = flat rows (<=64 per job), B = denc
@@ -1635,13 +1643,14 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     const bool comb = dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_combine_fold() != 0;
     // batch statistics of the time-resident convolutions as mergeable (n, mean, M2) records: no pass over the tensor
     const bool recs = train && !sh && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_stat_records() != 0;
+    const bool rec0 = train && !sh && dof_tcn_stat_records() != 0;   // block 0's input convolution: one record per 256 rows
     for (int b = 0; b < 8; ++b) {
       const TcnBlockOff& o = p->tblk[s][b];
       const int d = kTcnDil[b];
       int64_t nrows;
       if (b == 0) {
         TRY(dof_launch_tcn_in_conv(w.F, s == 0 ? x : a, params + o.c1w, params + o.c1b, ws + t.xs, ws + t.y1[0],
-                                   ws + t.partial, T, w.G, w.S, w.Sp, d, st));
+                                   ws + t.partial, T, w.G, w.S, w.Sp, d, st, rec0 ? 1 : 0));
         nrows = dof_tcn_row_blocks(T, w.S);
       } else if (comb && b >= 2) {
         // the previous block's output is computed here, while the tile is staged (its own combine launch only kept the
@@ -1657,7 +1666,7 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
         nrows = dof_tcn_conv32_partials(T, w.Sp);
       }
       const float* sh1 = (sh_on(2 * b) && b > 0) ? params + o.rm1 : nullptr;
-      if (train && recs && b > 0) {  // records -> statistics -> BatchNorm record + running buffers: one launch
+      if (train && (b > 0 ? recs : rec0)) {  // records -> statistics -> BatchNorm record + running buffers: one launch
         TRY(dof_launch_tcn_stat_merge_fin(ws + t.partial, nrows, ws + t.sums, count, params + o.g1, params + o.b1, params + o.rm1,
                                           params + o.rv1, 0.1f, ws + t.bnp[2 * b], st));
       } else {
@@ -2101,7 +2110,9 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
     const BlockOff& b = p->blk[s];
     const int* len = reinterpret_cast<const int*>(ws + w.len);
     if (!pair8)
-      TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st));
+      TRY(dof_launch_gru_bwd(L, 1, len, gru_w(params, b.g2), ws + w.o2, ws + w.g2, nullptr, ws + w.dhf, ws + w.dn1x, T, w.S, w.Sp, st,
+                             ws + w.n1, p->gru_wg_part[s][1][0] >= 0 ? ws + p->partials + p->gru_wg_part[s][1][0] : nullptr,
+                             p->gru_wg_part[s][1][1] >= 0 ? ws + p->partials + p->gru_wg_part[s][1][1] : nullptr));
     TRY(dof_launch_ln_bwd(L, 4, ws + w.o1, ws + w.dn1x, ws + w.dn1x + (int64_t)T * 4 * L * w.Sp, params + b.n1w,
                           ws + w.do1, ws + w.ln1p, T, w.S, w.Sp, st));
   }
@@ -2136,7 +2147,9 @@ int encoder_backward(DofVadePlan* p, const float* params, float* grads, hipStrea
       if (!paired) TRY(dof_launch_gru16_bwd_fused(ws + w.c, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, ws + w.dc,
                                                   ws + w.wg1, T, w.S, w.Sp, st));
     } else {
-      TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st));
+      TRY(dof_launch_gru_bwd(L, 0, len, gru_w(params, b.g1), ws + w.o1, ws + w.g1, ws + w.do1, nullptr, ws + w.dc, T, w.S, w.Sp, st,
+                             ws + w.c, p->gru_wg_part[s][0][0] >= 0 ? ws + p->partials + p->gru_wg_part[s][0][0] : nullptr,
+                             p->gru_wg_part[s][0][1] >= 0 ? ws + p->partials + p->gru_wg_part[s][0][1] : nullptr));
     }
     // (fusing this merge into the weight-gradient reduction's operand load was measured: the conv job's loads triple
     // and k_outer, which is latency-bound per wave, loses 19 us per launch against the 19 us this pass costs per stream)
