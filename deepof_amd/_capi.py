@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # hyper[] indices (enum in deepof_hip.h)
 H_KLW, H_LAMBDA_DISTILL, H_KM_LATENT, H_KM_LOSS, H_REPEL_W, H_REPEL_LS = 0, 1, 2, 3, 4, 5
@@ -121,6 +121,7 @@ SIGNATURES = {
     "dof_vade_set_batchnorm_training": (C.c_int, [_P, _I32]),
     "dof_vade_workspace_bytes": (_I64, [_P]),
     "dof_vade_bind": (C.c_int, [_P, _P, _P]),
+    "dof_vade_ws_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dof_vade_forward": (C.c_int, [_P] * 13),
     "dof_vade_loss_grads": (C.c_int, [_P] * 10 + [_I32, _P, _P, _P]),
     "dof_vqvae_plan_create": (C.c_int, [C.POINTER(VadeDims), _P, _P, _P, C.POINTER(_P)]),

@@ -12,6 +12,9 @@ LIBRARY_SWITCHES = {
                            "sequences per launch from which the encoder GRU layers take the matrix-pipe kernels; 0 sends the small "
                            "reference goldens through them",
                            "tests/gru_mfma_probe.py (test_gru16_matrix_pipe_kernels_emu / _gpu)"),
+    "DOF_GRU_WGRAD_FUSED": ("1", "0", "the lane-per-unit GRU layers (latent 4 - 7, 9, 10) write dG and the generic k_outer jobs reduce it, "
+                            "instead of k_gru3_bwd accumulating the weight gradients on the matrix pipe",
+                            "tests/gru_wgrad_probe.py (test_gru_unfused_weight_gradient_emu / _gpu)"),
     "DOF_TCN_WGRAD_FP32": ("0", "1", "TCN weight gradients on the fp32 k_outer reduction instead of the three-plane bf16 kernel",
                            "test_tcn_kernel_switches_gpu"),
     "DOF_TCN_TAIL_FOLD": ("1", "0", "the block tail's backward as its own launches instead of folded into the neighbouring convolution",

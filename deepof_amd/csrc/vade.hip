@@ -2404,6 +2404,43 @@ extern "C" int64_t dof_emu_ws_offset(const DofVadePlan* p, const char* name, int
 }
 #endif
 
+extern "C" int dof_vade_ws_tensor(const DofVadePlan* p, const char* name, int64_t* offset_floats, int64_t* padded_sequences) {
+  if (!p || !name || !offset_floats) {
+    dof_set_error("dof_vade_ws_tensor: null argument");
+    return DOF_ERR_ARG;
+  }
+  const std::string n(name);
+  if (!p->tcn || n.size() < 6 || n[1] != '.' || (n[0] != 'n' && n[0] != 'e')) {
+    dof_set_error("dof_vade_ws_tensor: '%s' (a TCN plan's \"<n|e>.<y1|y2|out|bnp1|bnp2>.<block>\" or \"<n|e>.skip\")", name);
+    return DOF_ERR_ARG;
+  }
+  const int s = n[0] == 'e' ? 1 : 0;
+  const TcnWs& t = p->tw[s];
+  if (padded_sequences) *padded_sequences = p->sw[s].Sp;
+  const std::string f = n.substr(2);
+  int64_t off = -1;
+  if (f == "skip") {
+    off = t.skip;
+  } else {
+    const size_t dot = f.find('.');
+    const int b = dot == std::string::npos ? -1 : atoi(f.c_str() + dot + 1);
+    const std::string k = dot == std::string::npos ? f : f.substr(0, dot);
+    if (b >= 0 && b < 8) {
+      if (k == "y1") off = t.y1[b];
+      else if (k == "y2") off = t.y2[b];
+      else if (k == "out") off = b < 7 ? t.out[b] : -1;
+      else if (k == "bnp1") off = t.bnp[2 * b];
+      else if (k == "bnp2") off = t.bnp[2 * b + 1];
+    }
+  }
+  if (off < 0) {
+    dof_set_error("dof_vade_ws_tensor: no tensor '%s'", name);
+    return DOF_ERR_ARG;
+  }
+  *offset_floats = off;
+  return DOF_OK;
+}
+
 extern "C" int dof_vade_bind(DofVadePlan* p, void* workspace, void* stream) {
   if (!p || !workspace) {
     dof_set_error("dof_vade_bind: null argument");

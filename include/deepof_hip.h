@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DOF_ABI_VERSION 16
+#define DOF_ABI_VERSION 17
 
 /* ---- error reporting ----------------------------------------------------------------------
  * Every int entry point returns 0 or a negative code, with the text in dof_last_error_string():
@@ -106,6 +106,14 @@ int64_t dof_vade_workspace_bytes(const DofVadePlan* plan);
 /* Zero the workspace and upload the plan's tables into it (enqueued on stream).  Call once per
  * workspace before the first forward / step, outside any graph capture. */
 int dof_vade_bind(DofVadePlan* plan, void* workspace, void* stream);
+
+/* Diagnostics (ABI v17): where a named intermediate tensor of a TCN plan sits in the caller-owned workspace -- float
+ * offset into the bound workspace, and the padded sequence count Sp of its [time][Sp][32] layout.  The parity tests use it
+ * to look at the device's own BatchNorm+ReLU pre-activations where a reference fixture names a ReLU-branch candidate
+ * (tests/parity_common.py::confirm_flips_on_device).  Names: "<n|e>.<y1|y2|out|bnp1|bnp2>.<block 0..7>" for the node / edge
+ * stream's encoder blocks (bnp = the BatchNorm record mean | rstd | scale | shift, 4 x 32 floats), "<n|e>.skip".
+ * Returns DOF_ERR_ARG for another name or a plan without a TCN encoder.  The layout is not part of the contract. */
+int dof_vade_ws_tensor(const DofVadePlan* plan, const char* name, int64_t* offset_floats, int64_t* padded_sequences);
 
 /* TCN family (models_new.py:376-819: TCNEncoderPT + TCNDecoderPT): same entry points as the recurrent plans,
  * parameters in VaDEPT / VQVAEPT(encoder_type="TCN").state_dict() order with the BatchNorm running_mean /

@@ -3,6 +3,7 @@
     python tests/golden/make_golden_r06.py l4 l6       # recurrent family at latent 4 (the API's default latent_dim) and 6 (the tutorial's)
     python tests/golden/make_golden_r06.py lodd        # latent 7, 9, 14 (recurrent family)
     python tests/golden/make_golden_r06.py tcnkinks    # ReLU-kink attribution for the two small contrastive TCN fixtures
+    python tests/golden/make_golden_r06.py kinkloc     # where each ReLU-kink candidate of the contrastive TCN fixtures sits
 
 * vade_rec14l4.npz / vqvae_rec14l4.npz / contrastive_rec14l4.npz
       the recurrent encoder / decoder at latent_dim = 4 -- /root/reference/deepof/data.py:3260 (`latent_dim: int = 4`) and the
@@ -98,6 +99,74 @@ def gen_small_tcn_kinks():
     np.savez_compressed(os.path.join(HERE, "tcn_kinks.npz"), **keep)
 
 
+class KinkLocator(MG3.KinkFlipper):
+    """The dry pass of KinkFlipper that also records WHERE each candidate sits: the index of the ReLU call within the step and
+    the call's tensor shape (the ordinals KinkAttribution names are positions in this sequence)."""
+
+    def __init__(self, delta):
+        super().__init__(delta=delta, dry=True)
+        self.calls, self.where = [], []
+
+    def relu(self, x, inplace=False):
+        k = len(self.calls)
+        self.calls.append(tuple(x.shape))
+        before = len(self.ident)
+        y = super().relu(x, inplace)
+        self.where += [k] * (len(self.ident) - before)
+        return y
+
+
+def gen_kink_locations():
+    """tcn_kinks.npz += <prefix>loc_call / loc_flat / loc_value (per candidate ORDINAL: ReLU call index, flat index in that
+    call's (S, C, T) input, the reference's pre-activation value) and <prefix>loc_shapes (per call, padded to 3 dims) for the
+    contrastive TCN fixtures -- what tests/parity_common.py::confirm_flips_on_device needs to look a named flip up in the
+    device's own tensors."""
+    import make_golden_r04 as MG4
+    keep = dict(np.load(os.path.join(HERE, "tcn_kinks.npz")).items())
+    jobs = []
+    d, model, base, rerun = MG4._c4_replay_setup()
+    jobs.append((f"contrastive_{MG4.C4_TAG}::c0::", MG4.C4_DELTA, rerun))
+    for tag, seed, B, t_full, L in (("tcn14l16", 481, 6, 24, 16), ("tcn14", 81, 6, 24, 8)):
+        model, base, rerun = _replay_setup(tag, seed, B, t_full, L)
+        jobs.append((f"contrastive_{tag}::c0::", KINK_DELTA, rerun))
+    # VaDE with the TCN encoder / decoder (make_golden_r03.vade_tcn_kinks' replays): the encoder's calls come first
+    for fname, tagp in (("vade_tcn14_b64.npz", "vade_tcn14_b64"), ("vade_tcn14_onepass.npz", "vade_tcn14_onepass")):
+        d = dict(np.load(os.path.join(HERE, fname)))
+        x, a = d["x"], d["a"]
+        B, T, N, _ = x.shape
+        E = a.shape[2]
+        K, L = d["sd::latent_space.gmm_means"].shape
+        vmodel, sd0 = MG3._tcn_vade_model(d, T, N, E, L, K)
+        xt, at = torch.from_numpy(x), torch.from_numpy(a)
+        eps, eps_mc, tau = (torch.from_numpy(d[k]) for k in ("eps", "eps_mc", "tau"))
+        for phase, klw, teacher in (("pre", 0.13, False), ("mainT", 0.7, True)):
+            if f"{tagp}::{phase}::first_ordinal" not in keep:
+                continue
+
+            def vrerun(phase=phase, klw=klw, teacher=teacher, vmodel=vmodel, sd0=sd0, xt=xt, at=at, eps=eps, eps_mc=eps_mc, tau=tau, K=K, L=L):
+                vmodel.load_state_dict(sd0)
+                MG3._vade_run(vmodel, xt, at, eps, eps_mc, tau, phase, klw, teacher, K, L)
+            jobs.append((f"{tagp}::{phase}::", float(keep.get(f"{tagp}::delta", MG3.KINK_DELTA)), vrerun))
+    for pfx, delta, rerun in jobs:
+        with KinkLocator(delta) as loc:
+            rerun()
+        n = len(loc.ident)
+        assert n == loc.count == len(loc.where)
+        assert n == int(keep[pfx + "count"]), ("another candidate sequence than the attribution's", pfx, n, int(keep[pfx + "count"]))
+        first = keep[pfx + "first_ordinal"]
+        assert first.size == 0 or int(first.max()) < n, (pfx, n, first.max() if first.size else None)
+        keep[pfx + "loc_call"] = np.asarray(loc.where, dtype=np.int32)
+        keep[pfx + "loc_flat"] = np.asarray([j for j, _ in loc.ident], dtype=np.int64)
+        keep[pfx + "loc_value"] = np.asarray([v for _, v in loc.ident], dtype=np.float32)
+        shp = np.ones((len(loc.calls), 3), dtype=np.int64)
+        for k, sh in enumerate(loc.calls):
+            assert len(sh) <= 3
+            shp[k, :len(sh)] = sh
+        keep[pfx + "loc_shapes"] = shp
+        print(pfx, n, "candidates in", len(loc.calls), "ReLU calls")
+    np.savez_compressed(os.path.join(HERE, "tcn_kinks.npz"), **keep)
+
+
 def gen_latent4():
     MG.gen_vade("rec14l4", [""], 25, 4, 10, 12, 1131)
     MG.gen_vqvae("rec14l4", [""], 25, 4, 48, 12, 1141, kmeans=0.5)
@@ -130,6 +199,8 @@ if __name__ == "__main__":
         gen_latent_odd()
     if "tcnkinks" in what:
         gen_small_tcn_kinks()
+    if "kinkloc" in what:
+        gen_kink_locations()
     for f in ("vade_rec14l4.npz", "vqvae_rec14l4.npz", "contrastive_rec14l4.npz", "vade_rec14l6.npz", "vqvae_rec14l6.npz",
               "contrastive_rec14l6.npz", "tcn_kinks.npz"):
         p = os.path.join(HERE, f)

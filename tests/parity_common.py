@@ -365,6 +365,10 @@ def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn1
     if fixture in ("contrastive_tcn14_b64.npz", "contrastive_tcn14l16.npz"):
         kinks = KinkAttribution(golden_dir, fixture[:-4] + "::c0::")
         flips = kinks.identify(lambda t: e1.view(t, e1.grads).cpu().numpy(), lambda t: d[pfx + "grad::" + t])
+        # ... which is an inference from the residual; the device's own tensors say which candidates DID change branch, and
+        # those set the bars (round 6: the pursuit had named three that did not and missed one below a bar)
+        observed, _ = confirm_flips_on_device(kinks, [e1, e2], flips)
+        kinks.use_observed(observed)
     n, worst = 0, 0.0
     for k in d:
         if k.startswith(pfx + "grad::"):
@@ -379,7 +383,8 @@ def run_contrastive_tcn_check(lib, device, golden_dir, fixture="contrastive_tcn1
             n += 1
     assert n == 148
     if kinks is not None:
-        print("contrastive TCN B = 64: worst gradient error / tensor scale", worst, "identified flips", flips)
+        print("contrastive TCN B = 64: worst gradient error / tensor scale", worst, "flips observed on the device",
+              [int(o) for o in kinks.first_ordinal[kinks.flipped]])
     # optimiser: step 1 on these gradients, step 2 = a full step with the second set of recorded draws
     for name in e1.names:
         if ".spatial_gnn_block." in name:
@@ -538,7 +543,7 @@ class KinkAttribution:
 
     def __init__(self, golden_dir, prefix):
         k = load_golden(golden_dir, "tcn_kinks.npz")
-        self.prefix = prefix
+        self.prefix, self.golden_dir = prefix, golden_dir
         self.tensors = [str(t) for t in k[prefix + "tensors"]]
         self.col = {t: i for i, t in enumerate(self.tensors)}
         self.harmless = k[prefix + "harmless"]
@@ -549,6 +554,10 @@ class KinkAttribution:
         self.maxd = k[prefix + "maxd"]
         self.rtol, self.atol = float(k[prefix + "rtol"]), float(k[prefix + "atol"])
         self.flipped = np.zeros(len(self.first_ordinal), dtype=bool)
+        self._has_loc = (prefix + "loc_call") in k
+
+    def has_locations(self):
+        return self._has_loc
 
     def identify(self, got_of, ref_of):
         """got_of / ref_of: name -> gradient array.  Matching pursuit over the significant candidates: the one whose
@@ -591,6 +600,17 @@ class KinkAttribution:
         assert len(named) <= self.MAX_NAMED, (self.prefix, len(named), named)
         return named
 
+    def use_observed(self, candidate_indices, unlocated=()):
+        """Replace the inferred flips by the ones observed on the device (confirm_flips_on_device); same ceiling.  A flip the
+        pursuit inferred on a ReLU the device lookup cannot reach (``unlocated`` ordinals: the decoder's, CensNet's and the
+        head's) stays inferred."""
+        unloc = set(int(o) for o in unlocated)
+        inferred = [ci for ci in np.nonzero(self.flipped)[0].tolist() if int(self.first_ordinal[ci]) in unloc]
+        self.flipped[:] = False
+        self.flipped[list(candidate_indices) + inferred] = True
+        assert int(self.flipped.sum()) <= self.MAX_NAMED, (self.prefix, int(self.flipped.sum()))
+        return [int(self.first_ordinal[ci]) for ci in inferred]
+
     def extra(self, name):
         """Additional bar of tensor ``name``: 1.25 x the identified flips' measured changes there, plus -- ONLY where a
         named flip reaches the tensor -- the summed changes of the harmless candidates (each below a quarter of the
@@ -604,6 +624,86 @@ class KinkAttribution:
         if named <= 0.0:
             return 0.0
         return float(self.harmless[i]) + 1.25 * named
+
+
+def confirm_flips_on_device(kinks, engines, named):
+    """The attribution's other half: KinkAttribution NAMES flips from the gradient residual; here the device's own tensors say
+    which branch each candidate took.  ``engines`` = the plans of the step in the reference's forward order (contrastive:
+    central view, augmented view).  tcn_kinks.npz holds, per candidate ordinal, the ReLU call it belongs to, its flat index
+    in that call's (S, 32, T) input and the reference's pre-activation value (tests/golden/make_golden_r06.py kinkloc); the
+    reference runs 25 ReLU calls per TCN stream -- block b: ReLU(BN1(conv1)), ReLU(BN2(conv2)), ReLU(y + res); then the
+    skip-sum's (models_new.py:431-446, 492-505) -- node stream first (models_new.py:617-632).  The device branch of a
+    candidate is the sign of the same quantity recomputed from the plan's workspace (dof_vade_ws_tensor): fma(y, scale,
+    shift) of the stored convolution output and BatchNorm record, or the stored block output.
+    Returns (observed, unlocated): the indices (into kinks.first_ordinal) of the significant candidates whose branch on the
+    device differs from the reference's -- OBSERVED flips, which the caller uses for the bars instead of the ones the
+    matching pursuit inferred from the gradient residual -- and the ordinals it cannot look up (the CensNet / head ReLUs,
+    the skip-sum's ReLU, the last block's unused output).  Asserts that the looked-up quantities ARE the reference's (every
+    candidate's device value within 2e-5 of the recorded one)."""
+    import ctypes as C
+    k = load_golden(kinks.golden_dir, "tcn_kinks.npz")
+    pfx = kinks.prefix
+    call, flat, val, shapes = (k[pfx + n] for n in ("loc_call", "loc_flat", "loc_value", "loc_shapes"))
+    per_fwd = len(shapes) // len(engines)
+    assert per_fwd * len(engines) == len(shapes)
+    cache = {}
+
+    def tensor(eng, name):
+        key = (id(eng), name)
+        if key not in cache:
+            off, sp = C.c_int64(), C.c_int64()
+            _capi.check(eng.lib, eng.lib.dof_vade_ws_tensor(eng.plan, name.encode(), C.byref(off), C.byref(sp)), "dof_vade_ws_tensor")
+            cache[key] = (off.value, sp.value)
+        return cache[key]
+
+    last, dev = [None], [0.0]
+
+    def device_positive(o):
+        """None = a ReLU whose input the workspace does not keep (last block's output, the skip-sum before its last step)"""
+        c = int(call[o])
+        eng = engines[c // per_fwd]
+        kk = c % per_fwd
+        if kk >= 50:
+            return None
+        stream, kk = ("n" if kk < 25 else "e"), kk % 25
+        S, Cc, T = (int(v) for v in shapes[c])
+        j = int(flat[o])
+        s_i, c_i, t_i = j // (Cc * T), (j // T) % Cc, j % T
+        ws = eng.workspace
+        if kk == 24:
+            return None
+        b, which = kk // 3, kk % 3
+        if which == 2:
+            if b == 7:
+                return None
+            off, sp = tensor(eng, f"{stream}.out.{b}")
+            last[0] = (c, stream, b, which, s_i, c_i, t_i, float(ws[off + (t_i * sp + s_i) * 32 + c_i]))
+            return float(ws[off + (t_i * sp + s_i) * 32 + c_i]) > 0.0
+        off, sp = tensor(eng, f"{stream}.{'y1' if which == 0 else 'y2'}.{b}")
+        boff, _ = tensor(eng, f"{stream}.{'bnp1' if which == 0 else 'bnp2'}.{b}")
+        y = np.float64(float(ws[off + (t_i * sp + s_i) * 32 + c_i]))
+        scale, shift = np.float64(float(ws[boff + 64 + c_i])), np.float64(float(ws[boff + 96 + c_i]))
+        last[0] = (c, stream, b, which, s_i, c_i, t_i, float(y), float(scale), float(shift), float(y * scale + shift))
+        dev[0] = max(dev[0], abs(float(y * scale + shift) - float(val[o])))   # the lookup itself: same quantity as the reference's
+        return float(y * scale + shift) > 0.0   # (exact sign of the device's fmaf: the product of two floats is exact in double)
+
+    named = set(int(o) for o in named)
+    observed, unlocated = [], []
+    # first_ordinal lists the SIGNIFICANT candidates (a flip moves some gradient by >= a quarter of its bar); probe_value = the
+    # candidate's largest changes in bar units
+    for ci, o in enumerate(kinks.first_ordinal.tolist()):
+        pos = device_positive(o)
+        if pos is None:
+            unlocated.append(o)
+        elif pos != (float(val[o]) > 0.0):
+            observed.append(ci)
+    assert dev[0] < 2e-5, ("the device's pre-activations at the candidates are not the reference's quantities", dev[0])
+    obs_ord = [int(kinks.first_ordinal[ci]) for ci in observed]
+    print(f"confirm_flips_on_device[{pfx}]: {len(kinks.first_ordinal) - len(unlocated)} significant candidates looked up in the "
+          f"device's workspace (largest |device - reference| pre-activation {dev[0]:.2e}); {len(obs_ord)} took the other branch: "
+          f"{[(o, round(float(np.abs(kinks.probe_value[ci]).max()), 2)) for o, ci in zip(obs_ord, observed)]} (ordinal, largest "
+          f"change in bars); the gradient residual had named {sorted(named)}; not kept in the workspace: {len(unlocated)}")
+    return observed, unlocated
 
 
 def run_vade_tcn_b64_check(lib, device, golden_dir, fixture="vade_tcn14_b64.npz", min_main=20):
@@ -647,6 +747,11 @@ def run_vade_tcn_b64_check(lib, device, golden_dir, fixture="vade_tcn14_b64.npz"
         assert n_terms >= 12
         kinks = KinkAttribution(golden_dir, f"{fixture[:-4]}::{phase}::")
         flips = kinks.identify(lambda t: eng.view(t, eng.grads).cpu().numpy(), lambda t: d[f"{phase}::grad::{t}"])
+        if kinks.has_locations():   # the encoder's candidates: observed in the device's workspace instead of inferred
+            observed, unlocated = confirm_flips_on_device(kinks, [eng], flips)
+            still_inferred = kinks.use_observed(observed, unlocated)
+            flips = [int(o) for o in kinks.first_ordinal[kinks.flipped]]
+            print(f"VaDE TCN {phase}: flips used for the bars {flips} (inferred, on ReLUs outside the encoder blocks: {still_inferred})")
         n, w = 0, 0.0
         for k in d:
             if k.startswith(f"{phase}::grad::"):

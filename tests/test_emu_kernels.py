@@ -226,3 +226,15 @@ def test_gru16_matrix_pipe_kernels_emu():
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gru_mfma_probe.py")
     r = subprocess.run([sys.executable, probe, "emu"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_gru_unfused_weight_gradient_emu():
+    """DOF_GRU_WGRAD_FUSED=0: the lane-per-unit GRU layers' weight gradients through dG + the generic k_outer jobs (the
+    default fuses them into k_gru3_bwd) against the reference goldens, in a child process (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DOF_GRU_WGRAD_FUSED="0")
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gru_wgrad_probe.py")
+    r = subprocess.run([sys.executable, probe, "emu"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -257,6 +257,18 @@ def test_gru16_matrix_pipe_kernels_gpu():
     assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_gru_unfused_weight_gradient_gpu():
+    """DOF_GRU_WGRAD_FUSED=0 (tests/gru_wgrad_probe.py): latent 4 / 5 / 6 / 7 / 9 / 10 with the GRU weight gradients on the
+    generic reduction, all four phases against the reference goldens."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DOF_GRU_WGRAD_FUSED="0")
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gru_wgrad_probe.py")
+    r = subprocess.run([sys.executable, probe, "gpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def _tcn_switches():
     from deepof_amd._switches import LIBRARY_SWITCHES
     return [f"{k}={v[1]}" for k, v in LIBRARY_SWITCHES.items() if k.startswith("DOF_TCN_")]
