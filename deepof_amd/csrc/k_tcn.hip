@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_tcn_in_conv(const float* __restrict__ x
                                                      float* __restrict__ partial,    // [nblk][64] sums, or [nblk][3][32] records
                                                      int T, int G, int64_t S, int64_t Sp, int dil, int rec) {
   // rec: the block's channel statistics as one mergeable (n, mean, M2) record per channel (k_tcn_stat_merge), from sums
-  // shifted by the block's first row -- the layer then needs no second pass over y (k_tcn_var)
+  // about the block's own mean -- the layer then needs no second pass over y (k_tcn_var)
   __shared__ float kshift[TC], bsum[2 * TC];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float st[2 * TC];
@@ -99,10 +99,14 @@ __global__ void __launch_bounds__(256) k_tcn_in_conv(const float* __restrict__ x
     dof_block_colsum<2 * TC>(st, partial + (int64_t)blockIdx.x * 2 * TC);
     return;
   }
-  if (threadIdx.x == 0) {   // row 0 of a launched block always exists
-#pragma unroll
-    for (int o = 0; o < TC; ++o) kshift[o] = st[o];
-  }
+  // shift = the block's own mean (a first 32-value block sum; the values stay in registers): with the block's first row as
+  // the shift the ill-conditioned 6-window fixture lost a factor 6 against the centred second pass
+  // (encoder.node_tcn.blocks.0.conv1.weight 0.81 against 0.13 on a scale of 162, tests/parity_common.py::run_vqvae_tcn_check)
+  const int64_t left = (int64_t)T * S - (int64_t)blockIdx.x * blockDim.x;
+  const float nrows = (float)(left < (int64_t)blockDim.x ? left : (int64_t)blockDim.x);
+  dof_block_colsum<TC>(st, bsum);
+  __syncthreads();
+  if (threadIdx.x < TC) kshift[threadIdx.x] = bsum[threadIdx.x] / nrows;
   __syncthreads();
   const bool live = i < (int64_t)T * S;
 #pragma unroll
@@ -115,8 +119,7 @@ __global__ void __launch_bounds__(256) k_tcn_in_conv(const float* __restrict__ x
   __syncthreads();
   if (threadIdx.x < TC) {
     const int c = threadIdx.x;
-    const int64_t left = (int64_t)T * S - (int64_t)blockIdx.x * blockDim.x;
-    const float n = (float)(left < (int64_t)blockDim.x ? left : (int64_t)blockDim.x);
+    const float n = nrows;
     const float dm = bsum[c] / n;
     float* r = partial + (int64_t)blockIdx.x * 3 * TC;
     r[c] = n;

@@ -21,7 +21,7 @@ def test_library_is_the_hip_build(hip):
     import deepof_amd._lib as L
     from deepof_amd import _capi
     assert L.LIB_PATH.endswith("libdeepof_hip.so")
-    assert hip.dof_abi_version() == _capi.ABI_VERSION == 16
+    assert hip.dof_abi_version() == _capi.ABI_VERSION == 17
 
 
 def test_gather_gpu(hip):
