@@ -15,6 +15,9 @@ LIBRARY_SWITCHES = {
     "DOF_GRU_WGRAD_FUSED": ("1", "0", "the lane-per-unit GRU layers (latent 4 - 7, 9, 10) write dG and the generic k_outer jobs reduce it, "
                             "instead of k_gru3_bwd accumulating the weight gradients on the matrix pipe",
                             "tests/gru_wgrad_probe.py (test_gru_unfused_weight_gradient_emu / _gpu)"),
+    "DOF_OUTER_B3": ("1", "0", "the weight-gradient jobs on k_outer (v_mfma_f32_16x16x4_f32 on fp32 operands) instead of k_outer_b3 "
+                     "(three-piece bf16 operands, v_mfma_f32_16x16x32_bf16)",
+                     "tests/gru_wgrad_probe.py (test_outer_fp32_kernel_emu / _gpu)"),
     "DOF_TCN_WGRAD_FP32": ("0", "1", "TCN weight gradients on the fp32 k_outer reduction instead of the three-plane bf16 kernel",
                            "test_tcn_kernel_switches_gpu"),
     "DOF_TCN_TAIL_FOLD": ("1", "0", "the block tail's backward as its own launches instead of folded into the neighbouring convolution",

@@ -138,6 +138,148 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
   }
 }
 
+// Round 6: the same reduction on the bf16 matrix pipe.  k_outer is bound by the fp32 matrix instructions themselves
+// (v_mfma_f32_16x16x4_f32: 256 FLOP per cycle and CU -- 16 jobs x 14 us at latent 6, 2 x 1.2 ms at latent 32).  Here a unit is 32
+// sequences of one time step: the lane (row i, k group g) loads its row's values of the sequences 8 g .. 8 g + 7, cuts them
+// into three bf16 pieces (value = p0 + p1 + p2 exactly) and a product is the six piece products that carry more than 2^-24
+// of it, each one v_mfma_f32_16x16x32_bf16 (K = the 32 sequences): 6 x 16 cycles per 16 x 16 tile and 32 sequences against
+// 8 x 32.  Same jobs, same partial tiles, same finalize; the sums differ from k_outer's in their order only.
+__global__ void __launch_bounds__(256, 2) k_outer_b3(const DofOuterJob* __restrict__ jobs, int njobs,
+                                                  float* __restrict__ partials) {
+  __shared__ float red[64][65];
+  int jid = 0;
+  for (int j = 0; j < njobs; ++j)
+    if ((int)blockIdx.x >= jobs[j].blk0) jid = j;
+  const DofOuterJob& J = jobs[jid];
+  const int blk = blockIdx.x - J.blk0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kg = lane >> 4;
+  const int T = J.T;
+  const int64_t Sp = J.Sp;
+  const int64_t chunks = (Sp + 31) >> 5;  // 32 sequences per unit
+  const int64_t n_units = (int64_t)T * chunks;
+  const int MT = (J.a_rows + 15) >> 4;
+  const int NT = J.n_tiles;
+  const int64_t stride = (int64_t)J.nblk * 4;
+
+  dof_f32x4 acc[4][4];
+  float rs[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    rs[a] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = dof_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  float av[4][8], bv[4][8];   // the unit in flight: [tile][sequence of the lane's k group]
+  auto load_a_row = [&](int64_t u, int mt) {
+    const int t = (int)(u / chunks);
+    const int64_t s0 = ((u - (int64_t)t * chunks) << 5) + 8 * kg;
+    const bool in = s0 < Sp;   // (Sp is a multiple of 8: a k group is inside or outside as a whole)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) av[mt][j] = 0.0f;
+    const int row = mt * 16 + i;
+    if (row < J.a_rows && in) {
+      const float* __restrict__ ap = J.a_ptr + (int64_t)t * J.a_tstride + (int64_t)row * J.a_cstride + s0 * J.a_sstride;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[mt][j] = ap[(int64_t)j * J.a_sstride];
+    }
+  };
+  auto load_a = [&](int64_t u) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      if (mt < MT) load_a_row(u, mt);
+  };
+  auto load_b = [&](int64_t u) {
+    const int t = (int)(u / chunks);
+    const int64_t s0 = ((u - (int64_t)t * chunks) << 5) + 8 * kg;
+    const bool in = s0 < Sp;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[nt][j] = 0.0f;
+      if (nt < NT) {
+        const DofOuterTile& Bt = J.tile[nt];
+        const int tap = Bt.pack > 0 ? i / Bt.pack : 0;
+        const int ch = Bt.pack > 0 ? i - tap * Bt.pack : i;
+        const int tb = t + Bt.shift + tap;
+        if (tb >= 0 && tb < T && i < Bt.nc && in) {
+          const float* __restrict__ bp = Bt.ptr + (int64_t)tb * Bt.t_stride + (int64_t)ch * Bt.c_stride + s0 * Bt.s_stride;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bv[nt][j] = bp[(int64_t)j * Bt.s_stride];
+        }
+      }
+    }
+  };
+  auto cut = [&](const float (&v)[8], dof_bf16x8 (&p)[3]) {
+    const float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+    uint32_t wl[3][2], wh[3][2];
+    dof_split3x4(lo, wl);
+    dof_split3x4(hi, wh);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[q] = dof_mk_bf16x8(wl[q][0], wl[q][1], wh[q][0], wh[q][1]);
+  };
+
+  int64_t u = (int64_t)blk * 4 + wave;
+  if (u < n_units) {
+    load_b(u);
+    load_a(u);
+  }
+  for (; u < n_units; u += stride) {
+    // B pieces for the whole unit, then one row block of A at a time (its pieces live for 24 instructions): 2 wavefronts per SIMD
+    const bool more = u + stride < n_units;
+    dof_bf16x8 pb[4][3];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      if (nt < NT) cut(bv[nt], pb[nt]);
+    if (more) load_b(u + stride);   // in flight while the matrix instructions run
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      if (mt < MT) {
+        dof_bf16x8 pa[3];
+        rs[mt] += ((av[mt][0] + av[mt][1]) + (av[mt][2] + av[mt][3])) + ((av[mt][4] + av[mt][5]) + (av[mt][6] + av[mt][7]));
+        cut(av[mt], pa);
+        if (more) load_a_row(u + stride, mt);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (nt < NT) {
+            dof_f32x4 c = acc[mt][nt];
+            c = DOF_MFMA_16x16x32_BF16(pa[0], pb[nt][2], c);
+            c = DOF_MFMA_16x16x32_BF16(pa[2], pb[nt][0], c);
+            c = DOF_MFMA_16x16x32_BF16(pa[1], pb[nt][1], c);
+            c = DOF_MFMA_16x16x32_BF16(pa[0], pb[nt][1], c);
+            c = DOF_MFMA_16x16x32_BF16(pa[1], pb[nt][0], c);
+            c = DOF_MFMA_16x16x32_BF16(pa[0], pb[nt][0], c);
+            acc[mt][nt] = c;
+          }
+      }
+  }
+  // the four waves' tiles through one LDS tile, in wave order (k_outer's epilogue: same D layout)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float r = rs[mt];
+        r += __shfl_xor(r, 16);
+        r += __shfl_xor(r, 32);
+        if (kg == 0) red[mt * 16 + i][64] = (w == 0 ? 0.0f : red[mt * 16 + i][64]) + r;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            float* cell = &red[mt * 16 + kg * 4 + r4][nt * 16 + i];
+            *cell = (w == 0 ? 0.0f : *cell) + acc[mt][nt][r4];
+          }
+      }
+    }
+    __syncthreads();
+  }
+  float* __restrict__ out = partials + J.partial_off + (int64_t)blk * DOF_OUTER_PARTIAL_FLOATS;
+  for (int e = threadIdx.x; e < 64 * 65; e += 256) {
+    const int row = e / 65, col = e - row * 65;
+    if (row < J.a_rows && (col < NT * 16 || col == 64)) out[e] = red[row][col];
+  }
+}
+
 // One 64-lane wavefront per output element: lanes stride over the job's per-workgroup partial
 // tiles, then a fixed-shape butterfly adds the 64 lane sums (deterministic).
 __global__ void __launch_bounds__(256) k_outer_finalize(const DofOuterJob* __restrict__ jobs,
@@ -341,7 +483,13 @@ __global__ void k_schedule_apply(float* __restrict__ hyper, DofSchedItems items)
 
 int dof_launch_outer(const DofOuterJob* jobs_dev, int njobs, int total_blocks, float* partials, hipStream_t st) {
   if (total_blocks <= 0) return DOF_OK;
-  DOF_LAUNCH(k_outer, ((unsigned)total_blocks), (256), st, jobs_dev, njobs, partials);
+  // DOF_OUTER_B3=0: the fp32 matrix instructions (k_outer) instead of the bf16-piece kernel
+  static const int b3 = [] {
+    const char* e = getenv("DOF_OUTER_B3");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  if (b3) DOF_LAUNCH(k_outer_b3, ((unsigned)total_blocks), (256), st, jobs_dev, njobs, partials);
+  else DOF_LAUNCH(k_outer, ((unsigned)total_blocks), (256), st, jobs_dev, njobs, partials);
   return dof_check_launch("k_outer");
 }
 

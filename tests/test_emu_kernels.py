@@ -238,3 +238,15 @@ def test_gru_unfused_weight_gradient_emu():
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gru_wgrad_probe.py")
     r = subprocess.run([sys.executable, probe, "emu"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_outer_fp32_kernel_emu():
+    """DOF_OUTER_B3=0: the weight-gradient jobs on k_outer (fp32 matrix instructions; the default is the bf16-piece kernel
+    k_outer_b3) against the reference goldens, in a child process (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DOF_OUTER_B3="0")
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gru_wgrad_probe.py")
+    r = subprocess.run([sys.executable, probe, "emu", "DOF_OUTER_B3"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -269,6 +269,18 @@ def test_gru_unfused_weight_gradient_gpu():
     assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_outer_fp32_kernel_gpu():
+    """DOF_OUTER_B3=0 (tests/gru_wgrad_probe.py): the weight-gradient jobs on the fp32 k_outer instead of k_outer_b3, recurrent
+    goldens of latent 4 .. 10, 8, 16 and 32."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DOF_OUTER_B3="0")
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gru_wgrad_probe.py")
+    r = subprocess.run([sys.executable, probe, "gpu", "DOF_OUTER_B3"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PROBE ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def _tcn_switches():
     from deepof_amd._switches import LIBRARY_SWITCHES
     return [f"{k}={v[1]}" for k, v in LIBRARY_SWITCHES.items() if k.startswith("DOF_TCN_")]
