@@ -150,6 +150,11 @@ struct TcnConvArgs {
   const float* bwd_coef;  // BWD2: (mean g | mean g * xhat) of that BatchNorm
   int bwd_store;          // BWD2: 1 = write dy back over `in` (0: the weight-gradient kernel applies pass 2 itself)
   const float* stat_shift;  // forward k_tcn_conv_t: per-channel shift K of the channel sums (sum (y - K) | sum (y - K)^2), or null (see k_bn_fwd_fin)
+  // COMB of block 1 (k_tcn_conv_b<.., DS0>): `in` = the raw input rows xs [T][Sp][ds_F] and the residual of block 0 is its
+  // 1 x 1 downsample convolution ds_w (32, ds_F) / ds_b (32), computed while the tile is staged
+  const float* ds_w = nullptr;
+  const float* ds_b = nullptr;
+  int ds_F = 0;
   // TAIL (k_tcn_conv_t, conv1's data gradient of block b + 1): the backward of block b's tail in the epilogue
   const float* tail_src = nullptr;    // gradient already waiting at block b's output (the residual branch of block b + 1)
   float* tail_gres = nullptr;         // masked gradient = what enters block b's residual branch
@@ -1584,6 +1589,32 @@ int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp
   const unsigned nbt = tct_blocks(T, Sp);
   TCT_LAUNCH(false, false, false, false, false, true);
   return dof_check_launch("k_tcn_conv_t_comb");
+}
+
+// ... of block 1: block 0's residual is the 1 x 1 convolution of the raw input, computed from xs while staging (k_tcn_conv_b
+// only; k_tcn_combine's own arithmetic: bias, then one fmaf per input channel in order)
+int dof_tcn_combine_fold0() { return (dof_tcn_combine_fold() && tcn_conv_b3()) ? 1 : 0; }
+int dof_launch_tcn_conv_comb0(const float* xs, int F, const float* dsw, const float* dsb, const float* y2, const float* bnp2,
+                              float* out_blk, const float* w, const float* bias, float* out, float* partial, int T, int dil,
+                              int64_t S, int64_t Sp, hipStream_t st, int stat_records, float* relu_mask_out) {
+  if (!dof_tcn_conv32_resident(T, Sp) || !tcn_conv_b3() || F < 1 || F > 3) {
+    dof_set_error("k_tcn_conv_comb0: needs the time-resident bf16-piece kernel and 1 .. 3 input channels (T %d, F %d)", T, F);
+    return DOF_ERR_UNSUPPORTED;
+  }
+  TcnConvArgs A;
+  A.bwd_store = 0;
+  A.in = xs; A.w = w; A.bias = bias; A.bnp_in = bnp2; A.a_out = out_blk; A.out = out; A.partial = partial;
+  A.fuse_y = nullptr; A.fuse_bnp = nullptr;
+  A.bwd_y = y2; A.bwd_bnp = nullptr; A.bwd_coef = nullptr;
+  A.relu_mask_out = reinterpret_cast<uint32_t*>(relu_mask_out);
+  A.stat_shift = nullptr;
+  A.stat_records = stat_records ? 1 : 0;
+  A.ds_w = dsw; A.ds_b = dsb; A.ds_F = F;
+  A.T = T; A.dil = dil; A.accumulate = 0; A.S = S; A.Sp = Sp;
+  const unsigned nbt = tct_blocks(T, Sp);
+  if (tct_ns(A.T) == 8) DOF_LAUNCH((k_tcn_conv_b<false, false, false, false, false, true, false, 8, 4, true>), (nbt), (512), st, A);
+  else DOF_LAUNCH((k_tcn_conv_b<false, false, false, false, false, true, false, 4, 4, true>), (nbt), (512), st, A);
+  return dof_check_launch("k_tcn_conv_b_comb0");
 }
 
 // conv1's data gradient of block b + 1 with the backward of block b's tail and the first pass of block b's BatchNorm2

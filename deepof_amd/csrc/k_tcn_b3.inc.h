@@ -58,7 +58,10 @@ __device__ __forceinline__ void tb_st8(uint16_t* p, uint32_t lo, uint32_t hi) {
 
 // NCW = compute wavefronts: 4 (512 threads, <= 256 registers) or 8 (768 threads, <= 168 registers: two compute wavefronts
 // per SIMD share its matrix pipe and hide each other's epilogue)
-template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL, bool COMB, bool WGRAD, int NS, int NCW = 4>
+// DS0 (COMB of block 1): the residual of block 0 is not a stored tensor but the 1 x 1 convolution of the raw input -- the
+// loaders read the row's ds_F input values instead of 32 channels and evaluate it (k_tcn_combine's arithmetic); block 0's
+// full-size combine launch (409 us at C4) is then a last-step-only one like the other blocks'
+template <bool REVERSE, bool BN_IN, bool FUSE_BN, bool BWD2, bool TAIL, bool COMB, bool WGRAD, int NS, int NCW = 4, bool DS0 = false>
 __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b(TcnConvArgs A) {
   static_assert(NS == 8 || NS == 4, "8 sequences x 25 steps or 4 sequences x 50 steps");
   static_assert(NCW == 4 || NCW == 8, "four or eight compute wavefronts");
@@ -70,6 +73,7 @@ __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b
   static_assert(!TAIL || (REVERSE && FUSE_BN && BWD2), "the tail epilogue extends the fused data-gradient variant");
   static_assert(!COMB || (!REVERSE && !BN_IN && !FUSE_BN && !BWD2), "the combine-on-load variant is a plain forward convolution");
   static_assert(!WGRAD || (REVERSE && FUSE_BN && BWD2), "the weight gradient rides on the fused data-gradient variants");
+  static_assert(!DS0 || COMB, "the downsample residual belongs to the combine-on-load variant");
   __shared__ __attribute__((aligned(16))) uint16_t img[2 * TB_IMG];
   __shared__ __attribute__((aligned(16))) uint16_t ring[WGRAD ? 2 * NCW * 3 * TB_RING : 8];
   // the A operands (weights): [tap][piece][channel half][lane] x 16 bytes, every compute wavefront reads the same 24 KB (in
@@ -108,6 +112,14 @@ __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b
       dof_ld_row<4>(A.bnp_in + 2 * TC + ch * 4, k0);
       dof_ld_row<4>(A.bnp_in + 3 * TC + ch * 4, k1);
     }
+    float dw[4][3], db[4];   // DS0: the thread's four rows of the downsample convolution (absent input channels: weight 0)
+    const int dsF = DS0 ? A.ds_F : 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      db[c] = DS0 ? A.ds_b[ch * 4 + c] : 0.0f;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) dw[c][f] = (DS0 && f < dsF) ? A.ds_w[(ch * 4 + c) * dsF + f] : 0.0f;
+    }
     if (BWD2) {
       dof_ld_row<4>(A.bwd_bnp + ch * 4, bm);
       dof_ld_row<4>(A.bwd_bnp + TC + ch * 4, br);
@@ -122,7 +134,12 @@ __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b
       const int64_t gc = g < n_groups ? g : n_groups - 1;
       const int t = TS * u + tq;
       const uint32_t off = (uint32_t)(gc * NS + sq) * TC + ch * 4 + (uint32_t)(t < T ? t : T - 1) * row_stride;
-      v[u] = *reinterpret_cast<const float4*>(A.in + off);
+      if (DS0) {   // the row's ds_F raw input values (an absent channel re-reads channel 0 and meets a zero weight)
+        const uint32_t xo = ((uint32_t)(gc * NS + sq) + (uint32_t)(t < T ? t : T - 1) * (uint32_t)A.Sp) * (uint32_t)dsF;
+        v[u] = make_float4(A.in[xo], A.in[xo + (dsF > 1 ? 1 : 0)], A.in[xo + (dsF > 2 ? 2 : 0)], 0.0f);
+      } else {
+        v[u] = *reinterpret_cast<const float4*>(A.in + off);
+      }
       if (TWO) yv[TWO ? u : 0] = *reinterpret_cast<const float4*>(A.bwd_y + off);
     };
     // pass u of tile g from its registers into image `buf`
@@ -131,6 +148,16 @@ __global__ void __launch_bounds__(64 * (NCW + 4), NCW == 8 ? 3 : 2) k_tcn_conv_b
       const int t = TS * u + tq;
       const bool live = s0 + sq < A.S && t < T;
       float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      if (DS0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float acc = db[c];
+          acc = fmaf(dw[c][0], v[u].x, acc);
+          acc = fmaf(dw[c][1], v[u].y, acc);
+          acc = fmaf(dw[c][2], v[u].z, acc);
+          e[c] = acc;
+        }
+      }
       if (BN_IN) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) e[c] = fmaxf(fmaf(e[c], k0[c], k1[c]), 0.0f);

@@ -115,6 +115,10 @@ int dof_tcn_combine_fold();
 int dof_launch_tcn_conv_comb(const float* res, const float* y2, const float* bnp2, float* out_blk, const float* w,
                              const float* bias, float* out, float* partial, int T, int dil, int64_t S, int64_t Sp,
                              hipStream_t st, const float* stat_shift, int stat_records, float* relu_mask_out);
+int dof_tcn_combine_fold0();
+int dof_launch_tcn_conv_comb0(const float* xs, int F, const float* dsw, const float* dsb, const float* y2, const float* bnp2,
+                              float* out_blk, const float* w, const float* bias, float* out, float* partial, int T, int dil,
+                              int64_t S, int64_t Sp, hipStream_t st, int stat_records, float* relu_mask_out);
 int dof_tcn_tail_fold();
 int dof_launch_tcn_conv_tail(const float* dy, const float* w, const float* bwd_y, const float* bwd_bnp, const float* bwd_coef,
                              int bwd_store, const float* tail_src, const float* tail_mask, float* tail_gres,

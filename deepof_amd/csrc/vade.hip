@@ -1641,6 +1641,7 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
     const bool sh = train && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_onepass_stats();   // (always false: see dof_tcn_onepass_stats)
     auto sh_on = [&](int) { return sh; };
     const bool comb = dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_combine_fold() != 0;
+    const bool comb0 = comb && dof_tcn_combine_fold0() != 0;   // block 0's output too (the bf16-piece kernel only)
     // batch statistics of the time-resident convolutions as mergeable (n, mean, M2) records: no pass over the tensor
     const bool recs = train && !sh && dof_tcn_conv32_resident(T, w.Sp) != 0 && dof_tcn_stat_records() != 0;
     const bool rec0 = train && !sh && dof_tcn_stat_records() != 0;   // block 0's input convolution: one record per 256 rows
@@ -1652,6 +1653,12 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
         TRY(dof_launch_tcn_in_conv(w.F, s == 0 ? x : a, params + o.c1w, params + o.c1b, ws + t.xs, ws + t.y1[0],
                                    ws + t.partial, T, w.G, w.S, w.Sp, d, st, rec0 ? 1 : 0));
         nrows = dof_tcn_row_blocks(T, w.S);
+      } else if (comb0 && b == 1) {
+        // ... block 0's output: its residual is the 1 x 1 convolution of the raw input rows (ws.xs), evaluated while staging
+        TRY(dof_launch_tcn_conv_comb0(ws + t.xs, w.F, params + p->tblk[s][0].dsw, params + p->tblk[s][0].dsb, ws + t.y2[0],
+                                      ws + t.bnp[1], ws + t.out[0], params + o.c1w, params + o.c1b, ws + t.y1[1], ws + t.partial, T, d,
+                                      w.S, w.Sp, st, recs, ws + t.omask[0]));
+        nrows = dof_tcn_conv32_partials(T, w.Sp);
       } else if (comb && b >= 2) {
         // the previous block's output is computed here, while the tile is staged (its own combine launch only kept the
         // last step of the skip-sum): out[b-1] = ReLU(ReLU(BN2(y2[b-1])) + out[b-2])
@@ -1688,7 +1695,7 @@ int tcn_encoder_forward(DofVadePlan* p, float* params, const float* x, const flo
       }
       TRY(dof_launch_tcn_combine(ws + t.y2[b], ws + t.bnp[2 * b + 1], b ? ws + t.out[b - 1] : nullptr, ws + t.xs,
                                  b ? nullptr : params + o.dsw, b ? nullptr : params + o.dsb,
-                                 (b < 7 && !(comb && b >= 1)) ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr,
+                                 (b < 7 && !(comb && b >= 1) && !(comb0 && b == 0)) ? ws + t.out[b] : nullptr, ws + t.skip, b == 7 ? ws + w.n2 : nullptr,
                                  b == 0, T, w.F, 32, w.S, w.Sp, st, 0, /*skip_last=*/1, t.omask[b] ? ws + t.omask[b] : nullptr));
     }
   }
