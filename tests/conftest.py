@@ -26,7 +26,7 @@ def pytest_cmdline_main(config):
         # build the emulator library once, before the workers race to do it
         subprocess.run(["make", "-C", os.path.join(ROOT, "deepof_amd", "csrc"), "emu", "-j4"], check=False,
                        stdout=subprocess.DEVNULL)
-        config.option.numprocesses = min(4, os.cpu_count() or 1)
+        config.option.numprocesses = min(6, os.cpu_count() or 1)
     return None
 
 
