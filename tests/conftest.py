@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+if not os.path.exists("/dev/kfd"):
+    # CPU container: one worker process per core (below), so one BLAS / OpenMP thread each -- eight workers with a thread pool
+    # per core each only fight for the cores, and the oracle's own fp32 rounding then does not move with the thread count
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+
 
 def _gpu_present() -> bool:
     return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
@@ -26,7 +32,7 @@ def pytest_cmdline_main(config):
         # build the emulator library once, before the workers race to do it
         subprocess.run(["make", "-C", os.path.join(ROOT, "deepof_amd", "csrc"), "emu", "-j4"], check=False,
                        stdout=subprocess.DEVNULL)
-        config.option.numprocesses = min(6, os.cpu_count() or 1)
+        config.option.numprocesses = min(8, os.cpu_count() or 1)
     return None
 
 
