@@ -23,8 +23,14 @@ __global__ void __launch_bounds__(256) k_outer(const DofOuterJob* __restrict__ j
   int jid = 0;
   for (int j = 0; j < njobs; ++j)
     if ((int)blockIdx.x >= jobs[j].blk0) jid = j;
+  int blk = blockIdx.x - jobs[jid].blk0;
+  if (jobs[jid].grp_jobs > 1) {   // operand-sharing group: see DofOuterJob
+    const DofOuterJob& G0 = jobs[jid];
+    const int v = blockIdx.x - G0.grp_blk0, x = v & 7, q = v >> 3;
+    jid = G0.grp_job0 + q % G0.grp_jobs;
+    blk = (q / G0.grp_jobs) * 8 + x;
+  }
   const DofOuterJob& J = jobs[jid];
-  const int blk = blockIdx.x - J.blk0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int T = J.T;
@@ -150,8 +156,14 @@ __global__ void __launch_bounds__(256, 2) k_outer_b3(const DofOuterJob* __restri
   int jid = 0;
   for (int j = 0; j < njobs; ++j)
     if ((int)blockIdx.x >= jobs[j].blk0) jid = j;
+  int blk = blockIdx.x - jobs[jid].blk0;
+  if (jobs[jid].grp_jobs > 1) {   // operand-sharing group: see DofOuterJob
+    const DofOuterJob& G0 = jobs[jid];
+    const int v = blockIdx.x - G0.grp_blk0, x = v & 7, q = v >> 3;
+    jid = G0.grp_job0 + q % G0.grp_jobs;
+    blk = (q / G0.grp_jobs) * 8 + x;
+  }
   const DofOuterJob& J = jobs[jid];
-  const int blk = blockIdx.x - J.blk0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kg = lane >> 4;
   const int T = J.T;

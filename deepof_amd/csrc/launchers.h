@@ -285,6 +285,12 @@ struct DofOuterJob {
   DofOuterTile tile[4];
   int blk0, nblk;        // block range of this job inside the launch
   int64_t partial_off;   // float offset of this job's partials: [nblk][64][65]  (col 64 = row sums of A)
+  // Jobs that read the same operand rows (the row blocks x tile groups of one wide layer) form a group of grp_jobs consecutive
+  // jobs with equal nblk (a multiple of 8), first job grp_job0, first block grp_blk0: inside the group's block range the
+  // workgroups are dealt out so that the ones an XCD receives back to back (block indices b, b + 8, b + 16, ...) are the
+  // group's jobs on the SAME K slice -- they stream the same rows at the same time and share them in that XCD's L2
+  // (workgroup v of the group: XCD x = v % 8, q = v / 8 -> job q % grp_jobs, slice (q / grp_jobs) * 8 + x).  0 / 1: no group.
+  int grp_job0, grp_jobs, grp_blk0;
 };
 struct DofFinJob {  // scatter-add of one reduced (rows x cols) block into a gradient tensor
   int job;              // source DofOuterJob index

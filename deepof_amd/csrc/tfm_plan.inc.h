@@ -220,6 +220,7 @@ void build_tfm_workspace_layout(DofVadePlan* p) {
 // activations.  Bias gradient (row sums of dY) when b_off >= 0.
 void tfm_dense_jobs(JobBuilder& jb, const float* dY, int ldy, int CO, const float* X, int ldx, int CI, int64_t w_off,
                     int64_t b_off, int T, int64_t Sp) {
+  const int first_job = (int)jb.jobs.size();
   for (int r0 = 0; r0 < CO; r0 += 64) {
     const int rows = CO - r0 < 64 ? CO - r0 : 64;
     int job = -1;
@@ -234,6 +235,7 @@ void tfm_dense_jobs(JobBuilder& jb, const float* dY, int ldy, int CO, const floa
       jb.add_fin(job, tl * 16, rows, nc, rows, rows, w_off + (int64_t)r0 * CI + c0, CI, 1);
     }
   }
+  jb.group(first_job, (int)jb.jobs.size() - first_job);   // the layer's row blocks x tile groups share dY and X rows
 }
 
 // per-window dense layer ([c][Bp] operands): dW[o][i] = sum_b dpre[o][b] * in[i][b]

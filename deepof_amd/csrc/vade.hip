@@ -823,6 +823,16 @@ struct JobBuilder {
     jobs.push_back(j);
     return (int)jobs.size() - 1;
   }
+  // jobs [first, first + count) read the same operand rows: deal their workgroups out per XCD (DofOuterJob::grp_*)
+  void group(int first, int count) {
+    if (count < 2 || first < 0) return;
+    const int nb = jobs[first].nblk;
+    for (int j = first; j < first + count; ++j)
+      if (jobs[j].nblk != nb || (nb & 7) != 0 || jobs[j].blk0 == 0x7fffffff || jobs[j].T != jobs[first].T || jobs[j].Sp != jobs[first].Sp) return;
+    for (int j = first; j < first + count; ++j) {
+      jobs[j].grp_job0 = first; jobs[j].grp_jobs = count; jobs[j].grp_blk0 = jobs[first].blk0;
+    }
+  }
   int add_tile(int job, View b, int nc, int shift, int pack = 0) {
     if (nc > 16 && pack == 0) {  // a wide operand (latent > 16): consecutive full tiles, contiguous columns in the partial
       const int first = jobs[job].n_tiles;   // tile, so one fin block may span them (<= 64 columns per job)
@@ -885,6 +895,7 @@ void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int
         tl.push_back(Tl{x_bcast ? soa(X, Sp, c0) : aos(X, IN, Sp, c0), IN - c0 < 16 ? IN - c0 : 16, 0, c0, false});
       for (int c0 = 0; c0 < HID; c0 += 16)
         tl.push_back(Tl{aos(O, 2 * HID, Sp, d * HID + c0), HID - c0 < 16 ? HID - c0 : 16, d == 0 ? -1 : +1, c0, true});
+      const int first_job = (int)jb.jobs.size();
       for (int g0 = 0; g0 < 4; g0 += gpb)
         for (size_t t0 = 0; t0 < tl.size(); t0 += 4) {
           const int ng = 4 - g0 < gpb ? 4 - g0 : gpb;
@@ -905,6 +916,7 @@ void gru_jobs(JobBuilder& jb, const float* dG, const float* X, bool x_bcast, int
               if (gi != 2) jb.add_fin(job, 64, HID, 1, 0, lo, g.t[d * 4 + 3] + (int64_t)(gi == 3 ? 2 : gi) * HID, 1, 1);
             }
         }
+      jb.group(first_job, (int)jb.jobs.size() - first_job);   // the direction's row blocks x tile groups share dG, x and h rows
     }
     return;
   }
@@ -1245,6 +1257,8 @@ void build_jobs(DofVadePlan* p) {
       for (DofOuterJob j : js->jobs) {
         own += (int64_t)j.nblk * DOF_OUTER_PARTIAL_FLOATS;
         j.blk0 += all.total_blocks;
+        j.grp_blk0 += all.total_blocks;
+        j.grp_job0 += job0;
         j.partial_off += part;
         all.jobs.push_back(j);
       }
