@@ -33,6 +33,9 @@ LIBRARY_SWITCHES = {
                         "test_tcn_kernel_switches_gpu"),
     "DOF_TCN_WGRAD_FUSED": ("1", "0", "the 32-channel convolutions' weight gradients from k_tcn_wgrad_b3 (its own passes over dy, y and the "
                             "convolution input) instead of k_tcn_conv_b's data-gradient launches", "test_tcn_kernel_switches_gpu"),
+    "DOF_TCN_LAST_BLOCK_SPARSE": ("1", "0", "the encoder's last block runs BatchNorm2's backward pass 1 over the whole window and writes its (zero) "
+                                  "residual-branch gradient, instead of the last step alone + a never-written zero tensor",
+                                  "test_tcn_kernel_switches_gpu"),
     "DOF_TCN_RESIDENT_MAX_T": ("50", "25", "longest window on the time-resident convolutions (longer windows take the 4-fetch path, "
                                "as windows > 50 always do)", "test_tcn_kernel_switches_gpu"),
 }

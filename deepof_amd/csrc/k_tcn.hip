@@ -1031,6 +1031,7 @@ struct TcnBnBwd1Args {
   const float* skip;    // final skip-sum (mask of dfeat)
   const float* dskip;   // [T][Sp][CT] gradient of the skip-sum at every step, already masked (decoder) or null
   float* gres;          // [T][Sp][CT] masked din (gradient entering the residual branch) or null
+  int t0;               // first time step of the launch (the encoder's last block: T - 1, grid.y = 1)
   int blk, T, CT;
   int64_t S, Sp;
 };
@@ -1041,7 +1042,7 @@ __global__ void __launch_bounds__(256) k_tcn_bn_bwd1_w(TcnBnBwd1Args A) {
   __shared__ float red[256][8];
   const int CT = A.CT, q = CT >> 2, rpp = 256 / q;
   const int sub = threadIdx.x / q, c0 = (threadIdx.x % q) * 4;
-  const int t = blockIdx.y;
+  const int t = blockIdx.y + A.t0;
   float acc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
@@ -1472,6 +1473,15 @@ int dof_launch_bn_bwd_sum_fin(const float* partial, int64_t nblk, float* sums, f
   return dof_check_launch("k_bn_bwd_sum_fin");
 }
 int64_t dof_tcn_bn_bwd1_blocks(int T, int64_t S) { return (int64_t)dof_cdiv(S, 256) * T; }
+// The encoder's last block: BatchNorm2's backward pass 1 on the last time step only, residual-branch gradient = a zero tensor
+// (tcn_encoder_backward).  DOF_TCN_LAST_BLOCK_SPARSE=0: the full-size pass of rounds 2 - 5.
+int dof_tcn_last_block_sparse() {
+  static const int on = [] {
+    const char* e = getenv("DOF_TCN_LAST_BLOCK_SPARSE");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return on;
+}
 int64_t dof_tcn_conv32_partials(int T, int64_t Sp) {
   return dof_tcn_conv32_resident(T, Sp) ? (int64_t)tct_blocks(T, Sp) : dof_tcn_conv_waves(T, Sp);
 }
@@ -1687,14 +1697,15 @@ int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res,
 // pass 1 of a layer's BatchNorm backward + the reduction of its channel sums into sums[2][CT]
 int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, float* sums,
                            int blk, const float* out_blk, const float* dfeat, const float* skip, const float* dskip,
-                           float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st) {
+                           float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st, int last_step_only) {
   TcnBnBwd1Args A;
   A.din = din; A.y = y; A.bnp = bnp; A.g = g; A.partial = partial; A.blk = blk; A.out_blk = out_blk; A.dfeat = dfeat;
   A.skip = skip; A.dskip = dskip; A.gres = gres; A.T = T; A.CT = CT; A.S = S; A.Sp = Sp;
-  const unsigned nbx = dof_cdiv(S, 256);
-  DOF_LAUNCH(k_tcn_bn_bwd1_w, (nbx, (unsigned)T), (256), st, A);
+  A.t0 = last_step_only ? T - 1 : 0;
+  const unsigned nbx = dof_cdiv(S, 256), nby = last_step_only ? 1u : (unsigned)T;
+  DOF_LAUNCH(k_tcn_bn_bwd1_w, (nbx, nby), (256), st, A);
   if (int rc = dof_check_launch("k_tcn_bn_bwd1_w")) return rc;
-  return sums ? dof_launch_sum_partials(partial, (int64_t)nbx * T, 2 * CT, sums, 0, st) : DOF_OK;
+  return sums ? dof_launch_sum_partials(partial, (int64_t)nbx * nby, 2 * CT, sums, 0, st) : DOF_OK;
 }
 
 int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int CT, int64_t S,

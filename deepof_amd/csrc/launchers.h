@@ -135,7 +135,8 @@ int dof_launch_tcn_combine(const float* y2, const float* bnp2, const float* res,
                            int64_t S, int64_t Sp, hipStream_t st, int xs_ch = 0, int skip_last = 0, float* mask_out = nullptr);
 int dof_launch_tcn_bn_bwd1(const float* din, const float* y, const float* bnp, float* g, float* partial, float* sums,
                            int blk, const float* out_blk, const float* dfeat, const float* skip, const float* dskip,
-                           float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st);
+                           float* gres, int T, int CT, int64_t S, int64_t Sp, hipStream_t st, int last_step_only = 0);
+int dof_tcn_last_block_sparse();
 int dof_launch_tcn_bn_bwd2(float* g, const float* y, const float* bnp, const float* coef, int T, int CT, int64_t S,
                            int64_t Sp, hipStream_t st);
 int dof_launch_tcn_convg(int reverse, int KC, int NC, const float* in, const float* w, int w_ci, int cin_real,

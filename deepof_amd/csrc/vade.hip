@@ -86,6 +86,8 @@ struct TcnWs {  // float offsets of one stream's TCN buffers ([T][Sp][32] unless
   int64_t skip;                         // running / final skip sum
   int64_t g1[8], g2[8];                 // d loss / d (pre-BN conv output): A operands of the weight-gradient jobs
   int64_t dout[2], da;                  // ping-pong block-output gradients, conv2 input gradient
+  int64_t zero_act;                     // a [T][Sp][32] tensor nobody writes (zero since dof_vade_bind), or 0: the residual-branch gradient of the
+                                        // LAST block, whose output the encoder does not use (tcn_encoder_backward: last-step-only pass 1)
   int64_t bnp[16];                      // per-layer BatchNorm records [4][32]
   int64_t partial, sums, coef;
   int64_t coefs[16];                    // per-layer (mean g | mean g xhat): read again by the lazy weight-gradient operands
@@ -567,6 +569,7 @@ void build_tcn_workspace_layout(DofVadePlan* p) {
     }
     t.skip = cv.take(act);
     t.dout[0] = cv.take(act); t.dout[1] = cv.take(act); t.da = cv.take(act);
+    t.zero_act = (t.lazy && dof_tcn_tail_fold() && dof_tcn_last_block_sparse()) ? cv.take(act) : 0;
     for (int k = 0; k < 16; ++k) t.bnp[k] = cv.take(4 * 32);
     const int64_t rows = dof_tcn_row_blocks(T, w.S), waves = dof_tcn_conv_waves(T, Sp);
     t.partial_rows = rows > waves ? rows : waves;
@@ -2050,11 +2053,17 @@ int tcn_encoder_backward(DofVadePlan* p, const float* params, float* grads, hipS
       // BN2 + ReLU + block tail
       // (the producers leave per-workgroup partials; their reduction and the BatchNorm gradient step share one launch)
       int64_t nb2 = dof_tcn_conv32_partials(T, w.Sp);  // partial rows of BN2's sums: the previous block's TAIL convolution ...
+      // The last block's output is not used by the encoder: the only gradient that reaches its BatchNorm2 is the last step's
+      // (through the skip-sum), and its residual-branch gradient is zero.  Pass 1 then runs on the last step alone -- g2[7]'s
+      // other rows are zero since dof_vade_bind and nobody writes them (lazy: the convolution does not store dy back) -- and
+      // the TAIL convolution reads the never-written zero tensor as the residual-branch gradient: three tensor passes less
+      const bool last7 = b == 7 && t.zero_act != 0 && fuse2 && t.lazy && dof_tcn_tail_fold();
+      if (last7) dprev = ws + t.zero_act;
       if (!tail_done) {
         TRY(dof_launch_tcn_bn_bwd1(b == 7 ? nullptr : ws + t.dout[b & 1], ws + t.y2[b], ws + t.bnp[2 * b + 1], ws + t.g2[b],
                                    ws + t.partial, nullptr, 1, b == 7 ? nullptr : ws + t.out[b], ws + w.dn2, ws + t.skip,
-                                   nullptr, dprev, T, 32, w.S, w.Sp, st));
-        nb2 = dof_tcn_bn_bwd1_blocks(T, w.S);  // ... or k_tcn_bn_bwd1_w's
+                                   nullptr, last7 ? nullptr : dprev, T, 32, w.S, w.Sp, st, last7 ? 1 : 0));
+        nb2 = dof_tcn_bn_bwd1_blocks(last7 ? 1 : T, w.S);  // ... or k_tcn_bn_bwd1_w's
       }
       tail_done = false;
       float* coef2 = ws + (t.lazy ? t.coefs[2 * b + 1] : t.coef);
